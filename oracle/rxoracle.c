@@ -1,0 +1,669 @@
+/*
+ * rxoracle.c — CPU restatement of the ReactiveMP Gaussian sum-product rules, message product,
+ * marginals and Bethe free energy that RxInfer fires on a linear Gaussian state-space model.
+ *
+ * TEST INFRASTRUCTURE ONLY (see rxoracle.h).  fp64, plain C, written for clarity: every
+ * function below names the reference rule / call site it restates.  The message schedule is
+ * the reference's: per time step 6 rule calls, 4 pairwise products,
+ * 1 marginal; parametrisations change exactly where ExponentialFamily changes them
+ * (mean/covariance <-> weighted-mean/precision through `cholinv`).
+ */
+#include "rxoracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define LOG2PI 1.8378770664093454835606594728112
+
+const char* rxo_version(void) { return "rxoracle 0.1 (restates ReactiveMP ~6.0 / ExponentialFamily 2.1 rules)"; }
+
+/* ------------------------------------------------------------------------------------------
+ * FastCholesky.jl restatement: cholinv / chollogdet (FastCholesky.jl 1.3.0, `cholinv(x) =
+ * inv(fastcholesky(x))`).  Non-SPD input is an error, as in the reference CI
+ * (.github/workflows/CI.yml:72, JULIA_FASTCHOLESKY_THROW_ERROR_NON_SYMMETRIC=1).
+ * ------------------------------------------------------------------------------------------ */
+static int chol_lower(int n, const double* A, double* L) {
+    memset(L, 0, sizeof(double) * (size_t)n * n);
+    for (int j = 0; j < n; ++j) {
+        double s = A[j * n + j];
+        for (int k = 0; k < j; ++k) s -= L[j * n + k] * L[j * n + k];
+        if (!(s > 0.0)) return RXO_ERR_NOT_POSDEF;
+        double ljj = sqrt(s);
+        L[j * n + j] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            double t = A[i * n + j];
+            for (int k = 0; k < j; ++k) t -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = t / ljj;
+        }
+    }
+    return RXO_OK;
+}
+
+/* out = inv(A) for SPD A, logdet (nullable) = log det A.  work: 2*n*n doubles. */
+static int cholinv(int n, const double* A, double* out, double* logdet, double* work) {
+    double* L = work;
+    double* Li = work + (size_t)n * n;
+    int rc = chol_lower(n, A, L);
+    if (rc) return rc;
+    if (logdet) {
+        double ld = 0.0;
+        for (int i = 0; i < n; ++i) ld += log(L[i * n + i]);
+        *logdet = 2.0 * ld;
+    }
+    /* Li = inv(L) (lower) */
+    memset(Li, 0, sizeof(double) * (size_t)n * n);
+    for (int j = 0; j < n; ++j) {
+        Li[j * n + j] = 1.0 / L[j * n + j];
+        for (int i = j + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s -= L[i * n + k] * Li[k * n + j];
+            Li[i * n + j] = s / L[i * n + i];
+        }
+    }
+    /* out = Li' * Li */
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+            for (int k = i; k < n; ++k) s += Li[k * n + i] * Li[k * n + j];
+            out[i * n + j] = s;
+            out[j * n + i] = s;
+        }
+    return RXO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* small dense helpers (row-major)                                                            */
+static void matvec(int n, int m, const double* A, const double* x, double* y) { /* y = A x, A n×m */
+    for (int i = 0; i < n; ++i) {
+        double s = 0.0;
+        for (int k = 0; k < m; ++k) s += A[i * m + k] * x[k];
+        y[i] = s;
+    }
+}
+static void matTvec(int n, int m, const double* A, const double* x, double* y) { /* y = A' x, A n×m */
+    for (int k = 0; k < m; ++k) y[k] = 0.0;
+    for (int i = 0; i < n; ++i)
+        for (int k = 0; k < m; ++k) y[k] += A[i * m + k] * x[i];
+}
+/* C = A S A'  with A n×m, S m×m ; tmp n*m */
+static void congruence(int n, int m, const double* A, const double* S, double* C, double* tmp) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < m; ++k) s += A[i * m + k] * S[k * m + j];
+            tmp[i * m + j] = s;
+        }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < m; ++k) s += tmp[i * m + k] * A[j * m + k];
+            C[i * n + j] = s;
+        }
+}
+/* C = A' S A with A n×m, S n×n -> C m×m ; tmp n*m */
+static void congruenceT(int n, int m, const double* A, const double* S, double* C, double* tmp) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += S[i * n + k] * A[k * m + j];
+            tmp[i * m + j] = s;
+        }
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < m; ++j) {
+            double s = 0.0;
+            for (int k = 0; k < n; ++k) s += A[k * m + i] * tmp[k * m + j];
+            C[i * m + j] = s;
+        }
+}
+
+/* ------------------------------------------------------------------------------------------
+ * ExponentialFamily.jl restatement: the two Gaussian parametrisations on the path and their
+ * conversions:
+ *   MvNormalMeanCovariance(μ,Σ)            <->   MvNormalWeightedMeanPrecision(ξ,Λ), ξ = Λμ
+ *   mean_cov(ξ,Λ): Σ = cholinv(Λ), μ = Σξ       weightedmean_precision(μ,Σ): Λ = cholinv(Σ), ξ = Λμ
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int n;
+    double* mean; /* or ξ */
+    double* mat;  /* Σ or Λ */
+} gauss;
+
+typedef struct {
+    rxo_counters c;
+    double* work; /* scratch */
+    int count;
+} ctx;
+
+static int to_other_param(int n, const double* v, const double* M, double* v2, double* M2, double* logdetM,
+                          double* work) {
+    int rc = cholinv(n, M, M2, logdetM, work);
+    if (rc) return rc;
+    matvec(n, n, M2, v, v2);
+    return RXO_OK;
+}
+
+/* BayesBase.prod(GenericProd, Gaussian, Gaussian) -> MvNormalWeightedMeanPrecision(ξ1+ξ2, Λ1+Λ2)
+ * (prod constraint GenericProd from src/constraints/form/form_ensure_supported.jl:13) */
+static void prod_wmp(int n, const double* x1, const double* L1, const double* x2, const double* L2, double* x,
+                     double* L, ctx* c) {
+    for (int i = 0; i < n; ++i) x[i] = x1[i] + x2[i];
+    for (int i = 0; i < n * n; ++i) L[i] = L1[i] + L2[i];
+    if (c->count) c->c.products++;
+}
+
+/* @rule MvNormalMeanCovariance(:out, Marginalisation) (m_μ, q_Σ::PointMass) = N(mean(m_μ), cov(m_μ)+Σ)
+ * @rule MvNormalMeanCovariance(:μ,   Marginalisation) (m_out, q_Σ::PointMass): same arithmetic      */
+static void rule_mvn_additive(int n, const double* mean_in, const double* cov_in, const double* Sigma,
+                              double* mean_out, double* cov_out, ctx* c) {
+    for (int i = 0; i < n; ++i) mean_out[i] = mean_in[i];
+    for (int i = 0; i < n * n; ++i) cov_out[i] = (cov_in ? cov_in[i] : 0.0) + Sigma[i];
+    if (c->count) c->c.rule_calls++;
+}
+/* @rule typeof(*)(:out, Marginalisation) (m_A::PointMass, m_in) = N(Aμ, AΣA')   A: n×m */
+static void rule_mul_out(int n, int m, const double* A, const double* mean_in, const double* cov_in,
+                         double* mean_out, double* cov_out, ctx* c) {
+    matvec(n, m, A, mean_in, mean_out);
+    congruence(n, m, A, cov_in, cov_out, c->work);
+    if (c->count) c->c.rule_calls++;
+}
+/* @rule typeof(*)(:in, Marginalisation) (m_out, m_A::PointMass) = WMP(A'ξ, A'ΛA)   A: n×m */
+static void rule_mul_in(int n, int m, const double* A, const double* xi_out, const double* L_out,
+                        double* xi_in, double* L_in, ctx* c) {
+    matTvec(n, m, A, xi_out, xi_in);
+    congruenceT(n, m, A, L_out, L_in, c->work);
+    if (c->count) c->c.rule_calls++;
+}
+
+/* entropy(MvNormal) = ½(n·log(2πe) + logdet Σ) */
+static double gauss_entropy_from_logdetcov(int n, double logdetcov) {
+    return 0.5 * (n * (LOG2PI + 1.0) + logdetcov);
+}
+
+/* BayesBase.CountingReal: finite part + number of infinities */
+typedef struct {
+    double v;
+    long ninf;
+} creal;
+
+/* ------------------------------------------------------------------------------------------ */
+int rxo_lgssm_bp(int d, int dy, int T, const double* A, const double* B, const double* P, const double* Q,
+                 const double* m0, const double* V0, int ptt, const double* y, double* post_mean,
+                 double* post_cov, double* free_energy, rxo_counters* counters) {
+    if (d <= 0 || dy <= 0 || T <= 0) return RXO_ERR_BADARG;
+    const int n = T + (ptt ? 1 : 0); /* number of state variables; state k observes y[k-ptt] */
+    const int want_fe = free_energy != NULL;
+    const int dm = d > dy ? d : dy;
+    const size_t vs = (size_t)d, ms = (size_t)d * d;
+    int rc = RXO_OK;
+
+    ctx c;
+    memset(&c, 0, sizeof c);
+    c.count = 1;
+    c.work = (double*)malloc(sizeof(double) * (size_t)(16 * dm * dm + 64));
+    double* big = (double*)malloc(sizeof(double) * (size_t)(40 * dm * dm + 64));
+
+    /* stored messages */
+    double* fwdp_x = (double*)malloc(sizeof(double) * n * (vs + ms)); /* (fwd ⊗ obs) as WMP */
+    double* fwdp_L = fwdp_x + n * vs;
+    double *fwdx_m = NULL, *fwdx_V = NULL, *amsg_m = NULL, *amsg_V = NULL, *tox_x = NULL, *tox_L = NULL,
+           *mum_m = NULL, *mum_V = NULL, *bwd_x = NULL, *bwd_L = NULL, *q_m = NULL, *q_V = NULL, *q_ld = NULL;
+    if (want_fe) {
+        fwdx_m = (double*)malloc(sizeof(double) * n * (vs + ms) * 6 + sizeof(double) * n);
+        fwdx_V = fwdx_m + n * vs;
+        amsg_m = fwdx_V + n * ms;
+        amsg_V = amsg_m + n * vs;
+        tox_x = amsg_V + n * ms;
+        tox_L = tox_x + n * vs;
+        mum_m = tox_L + n * ms;
+        mum_V = mum_m + n * vs;
+        bwd_x = mum_V + n * ms;
+        bwd_L = bwd_x + n * vs;
+        q_m = bwd_L + n * ms;
+        q_V = q_m + n * vs;
+        q_ld = q_V + n * ms;
+    }
+    if (!c.work || !big || !fwdp_x || (want_fe && !fwdx_m)) {
+        rc = RXO_ERR_BADARG;
+        goto done;
+    }
+
+    /* scratch vectors / matrices (sized for max(d,dy)) */
+    double* t_m = big;                  /* mean-like */
+    double* t_V = t_m + dm;             /* cov-like  */
+    double* t_x = t_V + dm * dm;        /* ξ-like    */
+    double* t_L = t_x + dm;             /* Λ-like    */
+    double* f_m = t_L + dm * dm;        /* current fwd_x mean */
+    double* f_V = f_m + dm;             /* current fwd_x cov  */
+    double* o_x = f_V + dm * dm;        /* obs ξ */
+    double* o_L = o_x + dm;             /* obs Λ */
+    double* a_m = o_L + dm * dm;
+    double* a_V = a_m + dm;
+    double* ny_m = a_V + dm * dm;       /* N(y,Q) mean (dy) */
+    double* ny_V = ny_m + dm;           /* N(y,Q) cov (dy×dy) */
+    double* ny_x = ny_V + dm * dm;
+    double* ny_L = ny_x + dm;
+    double* b_x = ny_L + dm * dm;       /* backward ξ */
+    double* b_L = b_x + dm;
+    double* u_x = b_L + dm * dm;
+    double* u_L = u_x + dm;
+    double* chw = u_L + dm * dm;        /* cholinv work, 2*(2dm)^2 = 8 dm^2 */
+
+    /* ---------------- forward pass ---------------- */
+    for (int k = 0; k < n; ++k) {
+        if (k == 0) {
+            /* prior node: @rule MvNormalMeanCovariance(:out)(q_μ::PointMass, q_Σ::PointMass) */
+            rule_mvn_additive(d, m0, NULL, V0, f_m, f_V, &c);
+        } else {
+            /* x[k-1] -> `*`_A : message already formed as fwdp[k-1] (WMP). `*`(:out) needs mean/cov */
+            rc = to_other_param(d, fwdp_x + (k - 1) * vs, fwdp_L + (k - 1) * ms, t_m, t_V, NULL, chw);
+            if (rc) goto done;
+            rule_mul_out(d, d, A, t_m, t_V, a_m, a_V, &c);
+            rule_mvn_additive(d, a_m, a_V, P, f_m, f_V, &c);
+            if (want_fe) {
+                memcpy(amsg_m + k * vs, a_m, sizeof(double) * vs);
+                memcpy(amsg_V + k * ms, a_V, sizeof(double) * ms);
+            }
+        }
+        if (want_fe) {
+            memcpy(fwdx_m + k * vs, f_m, sizeof(double) * vs);
+            memcpy(fwdx_V + k * ms, f_V, sizeof(double) * ms);
+        }
+        /* fwd_x as WMP (prod converts a mean/cov operand with weightedmean_precision) */
+        rc = to_other_param(d, f_m, f_V, t_x, t_L, NULL, chw);
+        if (rc) goto done;
+        if (k >= ptt) {
+            const double* yk = y + (size_t)(k - ptt) * dy;
+            /* MvN_y(:μ) with observed out: N(y, Q); then `*`_B(:in) */
+            rule_mvn_additive(dy, yk, NULL, Q, ny_m, ny_V, &c);
+            rc = to_other_param(dy, ny_m, ny_V, ny_x, ny_L, NULL, chw);
+            if (rc) goto done;
+            rule_mul_in(dy, d, B, ny_x, ny_L, o_x, o_L, &c);
+            /* outbound toward next `*`_A: product (fwd_x ⊗ obs_x), left to right */
+            prod_wmp(d, t_x, t_L, o_x, o_L, fwdp_x + k * vs, fwdp_L + k * ms, &c);
+        } else {
+            memcpy(fwdp_x + k * vs, t_x, sizeof(double) * vs);
+            memcpy(fwdp_L + k * ms, t_L, sizeof(double) * ms);
+        }
+    }
+    /* the last variable has no outgoing `*`_A, so its (fwd ⊗ obs) product toward it is never
+       requested by a subscriber; it is formed for the marginal instead (counted there) */
+    if (c.count && n - 1 >= ptt) c.c.products--;
+
+    /* ---------------- backward pass + marginals ---------------- */
+    int have_bwd = 0;
+    for (int k = n - 1; k >= 0; --k) {
+        const int has_obs = k >= ptt;
+        /* marginal q(x_k) = ((fwd ⊗ obs) ⊗ bwd), left-to-right fold (reactivemp_inference.jl:365-374) */
+        if (has_obs && c.count) c.c.products++; /* (fwd ⊗ obs) inside the marginal fold */
+        if (have_bwd)
+            prod_wmp(d, fwdp_x + k * vs, fwdp_L + k * ms, b_x, b_L, u_x, u_L, &c);
+        else {
+            memcpy(u_x, fwdp_x + k * vs, sizeof(double) * vs);
+            memcpy(u_L, fwdp_L + k * ms, sizeof(double) * ms);
+        }
+        double ldL;
+        rc = to_other_param(d, u_x, u_L, t_m, t_V, &ldL, chw);
+        if (rc) goto done;
+        if (c.count) c.c.marginals++;
+        if (k >= ptt) {
+            memcpy(post_mean + (size_t)(k - ptt) * vs, t_m, sizeof(double) * vs);
+            memcpy(post_cov + (size_t)(k - ptt) * ms, t_V, sizeof(double) * ms);
+        }
+        if (want_fe) {
+            memcpy(q_m + k * vs, t_m, sizeof(double) * vs);
+            memcpy(q_V + k * ms, t_V, sizeof(double) * ms);
+            q_ld[k] = -ldL; /* logdet cov */
+            if (have_bwd) {
+                memcpy(bwd_x + k * vs, b_x, sizeof(double) * vs);
+                memcpy(bwd_L + k * ms, b_L, sizeof(double) * ms);
+            }
+        }
+        /* message x_k -> MvN_x(k) (out interface): product of the other inbound messages (obs, bwd) */
+        if (has_obs) {
+            const double* yk = y + (size_t)(k - ptt) * dy;
+            /* obs message is memoised in the reference; recomputed here without counting */
+            c.count = 0;
+            rule_mvn_additive(dy, yk, NULL, Q, ny_m, ny_V, &c);
+            rc = to_other_param(dy, ny_m, ny_V, ny_x, ny_L, NULL, chw);
+            if (rc) goto done;
+            rule_mul_in(dy, d, B, ny_x, ny_L, o_x, o_L, &c);
+            c.count = 1;
+        }
+        /* (only MvN_x(k), k >= 1, subscribes to this message: the prior node's other interfaces
+           are constants, and messages toward constants are never computed) */
+        if (k >= 1) {
+            if (has_obs && have_bwd)
+                prod_wmp(d, o_x, o_L, b_x, b_L, u_x, u_L, &c);
+            else if (has_obs) {
+                memcpy(u_x, o_x, sizeof(double) * vs);
+                memcpy(u_L, o_L, sizeof(double) * ms);
+            } else {
+                memcpy(u_x, b_x, sizeof(double) * vs);
+                memcpy(u_L, b_L, sizeof(double) * ms);
+            }
+            if (want_fe) {
+                memcpy(tox_x + k * vs, u_x, sizeof(double) * vs);
+                memcpy(tox_L + k * ms, u_L, sizeof(double) * ms);
+            }
+        }
+        if (k >= 1) {
+            /* MvN_x(k)(:μ)(m_out, q_Σ) = N(mean(m_out), cov(m_out) + P) */
+            rc = to_other_param(d, u_x, u_L, t_m, t_V, NULL, chw);
+            if (rc) goto done;
+            rule_mvn_additive(d, t_m, t_V, P, a_m, a_V, &c);
+            if (want_fe) {
+                memcpy(mum_m + k * vs, a_m, sizeof(double) * vs);
+                memcpy(mum_V + k * ms, a_V, sizeof(double) * ms);
+            }
+            /* `*`_A(k)(:in)(m_out, m_A) = WMP(A'ξ, A'ΛA) */
+            rc = to_other_param(d, a_m, a_V, t_x, t_L, NULL, chw);
+            if (rc) goto done;
+            rule_mul_in(d, d, A, t_x, t_L, b_x, b_L, &c);
+            have_bwd = 1;
+        }
+    }
+    if (counters) *counters = c.c;
+
+    /* ---------------- Bethe free energy (reactivemp_free_energy.jl:51-126) ---------------- */
+    if (want_fe) {
+        c.count = 0;
+        creal nodes = {0.0, 0}, vars = {0.0, 0};
+        long point_entropies = 0;
+        const int d2 = 2 * d;
+        double* Lj = (double*)malloc(sizeof(double) * (size_t)(3 * d2 * d2 + 4 * d2) + sizeof(double) * 8 * d2 * d2);
+        double* Vj = Lj + d2 * d2;
+        double* xj = Vj + d2 * d2;
+        double* mj = xj + d2;
+        double* jw = mj + d2; /* cholinv work 2*(2d)^2 = 8 d^2 */
+        double* Wp = jw + 8 * d * d + d2 * d2; /* cholinv(P) */
+        double ldP, ldV0, ldQ;
+        double* Wq = (double*)malloc(sizeof(double) * (size_t)(dy * dy + d * d));
+        double* W0 = Wq + dy * dy;
+        rc = cholinv(d, P, Wp, &ldP, chw);
+        if (!rc) rc = cholinv(dy, Q, Wq, &ldQ, chw);
+        if (!rc) rc = cholinv(d, V0, W0, &ldV0, chw);
+        for (int k = 0; k < n && !rc; ++k) {
+            const int has_obs = k >= ptt;
+            const double* qm = q_m + k * vs;
+            const double* qV = q_V + k * ms;
+            const double Hx = gauss_entropy_from_logdetcov(d, q_ld[k]);
+            if (k == 0) {
+                /* prior node MvNormalMeanCovariance(out = x, μ = const, Σ = const):
+                   U = ½[d log2π + logdet V0 + tr(V0⁻¹ (V + (m-m0)(m-m0)'))], clusters: (out), (μ), (Σ) */
+                double tr = 0.0;
+                for (int i = 0; i < d; ++i)
+                    for (int j = 0; j < d; ++j)
+                        tr += W0[i * d + j] * (qV[j * d + i] + (qm[j] - m0[j]) * (qm[i] - m0[i]));
+                nodes.v += 0.5 * (d * LOG2PI + ldV0 + tr) - Hx;
+                nodes.ninf += 2; /* -H[PointMass μ] - H[PointMass Σ] */
+                point_entropies += 2;
+            } else {
+                /* `*`_A(k): deterministic node, contribution −H[q(in)] (+∞ counted for const A) */
+                nodes.v += -gauss_entropy_from_logdetcov(d, q_ld[k - 1]);
+                nodes.ninf += 1;
+                point_entropies += 1;
+                /* MvN_x(k): joint q(out, μ) from @marginalrule MvNormalMeanCovariance(:out_μ)
+                   (SURVEY Appendix A.3): Λj = [[Λo+W, −W],[−W, Λμ+W]], ξj = [ξo; ξμ] */
+                rc = to_other_param(d, amsg_m + k * vs, amsg_V + k * ms, t_x, t_L, NULL, chw); /* m_μ as WMP */
+                if (rc) break;
+                const double* xo = tox_x + k * vs;
+                const double* Lo = tox_L + k * ms;
+                for (int i = 0; i < d; ++i) {
+                    xj[i] = xo[i];
+                    xj[d + i] = t_x[i];
+                    for (int j = 0; j < d; ++j) {
+                        Lj[i * d2 + j] = Lo[i * d + j] + Wp[i * d + j];
+                        Lj[i * d2 + d + j] = -Wp[i * d + j];
+                        Lj[(d + i) * d2 + j] = -Wp[i * d + j];
+                        Lj[(d + i) * d2 + d + j] = t_L[i * d + j] + Wp[i * d + j];
+                    }
+                }
+                double ldLj;
+                rc = cholinv(d2, Lj, Vj, &ldLj, jw);
+                if (rc) break;
+                matvec(d2, d2, Vj, xj, mj);
+                double tr = 0.0;
+                for (int i = 0; i < d; ++i)
+                    for (int j = 0; j < d; ++j) {
+                        double e = Vj[j * d2 + i] - Vj[j * d2 + d + i] - Vj[(d + j) * d2 + i] +
+                                   Vj[(d + j) * d2 + d + i] + (mj[j] - mj[d + j]) * (mj[i] - mj[d + i]);
+                        tr += Wp[i * d + j] * e;
+                    }
+                double U = 0.5 * (d * LOG2PI + ldP + tr);
+                nodes.v += U - gauss_entropy_from_logdetcov(d2, -ldLj);
+                nodes.ninf += 1; /* Σ = const P */
+                point_entropies += 1;
+                /* variable a_k (anonymous, degree 2): + H[q(a_k)], q(a_k) = prod(`*`_A(:out), MvN_x(:μ)) */
+                rc = to_other_param(d, mum_m + k * vs, mum_V + k * ms, u_x, u_L, NULL, chw);
+                if (rc) break;
+                for (int i = 0; i < d * d; ++i) u_L[i] += t_L[i];
+                double lda;
+                rc = cholinv(d, u_L, t_V, &lda, chw);
+                if (rc) break;
+                vars.v += gauss_entropy_from_logdetcov(d, -lda);
+            }
+            int deg = 1 + (has_obs ? 1 : 0) + (k < n - 1 ? 1 : 0);
+            vars.v += (deg - 1) * Hx;
+            if (has_obs) {
+                const double* yk = y + (size_t)(k - ptt) * dy;
+                /* `*`_B(k): −H[q(x_k)] */
+                nodes.v += -Hx;
+                nodes.ninf += 1;
+                point_entropies += 1;
+                /* message x_k -> `*`_B = prod(fwd_x, bwd_x); `*`_B(:out) = N(Bm, BVB') */
+                rc = to_other_param(d, fwdx_m + k * vs, fwdx_V + k * ms, t_x, t_L, NULL, chw);
+                if (rc) break;
+                if (k < n - 1) {
+                    for (int i = 0; i < d; ++i) t_x[i] += bwd_x[k * vs + i];
+                    for (int i = 0; i < d * d; ++i) t_L[i] += bwd_L[k * ms + i];
+                }
+                rc = to_other_param(d, t_x, t_L, t_m, t_V, NULL, chw);
+                if (rc) break;
+                rule_mul_out(dy, d, B, t_m, t_V, a_m, a_V, &c); /* dy-dim */
+                /* q(b_k) = prod(N(Bm,BVB'), N(y,Q)) */
+                rc = to_other_param(dy, a_m, a_V, u_x, u_L, NULL, chw);
+                if (rc) break;
+                matvec(dy, dy, Wq, yk, ny_x);
+                for (int i = 0; i < dy; ++i) u_x[i] += ny_x[i];
+                for (int i = 0; i < dy * dy; ++i) u_L[i] += Wq[i];
+                double ldb;
+                rc = to_other_param(dy, u_x, u_L, t_m, t_V, &ldb, chw);
+                if (rc) break;
+                double Hb = gauss_entropy_from_logdetcov(dy, -ldb);
+                /* MvN_y(k): out = PointMass(y): U = ½[dy log2π + logdet Q + tr(Q⁻¹(Vb + (y−mb)(y−mb)'))] */
+                double tr = 0.0;
+                for (int i = 0; i < dy; ++i)
+                    for (int j = 0; j < dy; ++j)
+                        tr += Wq[i * dy + j] * (t_V[j * dy + i] + (yk[j] - t_m[j]) * (yk[i] - t_m[i]));
+                nodes.v += 0.5 * (dy * LOG2PI + ldQ + tr) - Hb;
+                nodes.ninf += 2; /* −H[PointMass y] − H[PointMass Q] */
+                point_entropies += 2;
+                vars.v += Hb; /* variable b_k, degree 2 */
+            }
+        }
+        if (!rc) {
+            /* float(nodes + vars − point_entropies): infinities must cancel exactly */
+            long ninf = nodes.ninf + vars.ninf - point_entropies;
+            double fe = nodes.v + vars.v;
+            if (ninf != 0) fe = ninf > 0 ? INFINITY : -INFINITY;
+            *free_energy = fe;
+            if (!isfinite(fe)) rc = RXO_ERR_NONFINITE_FE;
+        }
+        free(Lj);
+        free(Wq);
+    }
+
+done:
+    free(c.work);
+    free(big);
+    free(fwdp_x);
+    free(fwdx_m);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+int rxo_lgssm_bp_batch(int d, int dy, int T, int n_chains, const double* A, const double* B, const double* P,
+                       const double* Q, const double* m0, const double* V0, int ptt, const double* y,
+                       double* post_mean, double* post_cov, double* fe, int nthreads, rxo_counters* counters) {
+    if (n_chains <= 0) return RXO_ERR_BADARG;
+    int rc_all = RXO_OK;
+    uint64_t rc_rules = 0, rc_prods = 0, rc_margs = 0;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1) reduction(+ : rc_rules, rc_prods, rc_margs)
+#endif
+    for (int ch = 0; ch < n_chains; ++ch) {
+        double* yc = (double*)malloc(sizeof(double) * (size_t)T * dy);
+        double* pm = (double*)malloc(sizeof(double) * (size_t)T * d);
+        double* pc = (double*)malloc(sizeof(double) * (size_t)T * d * d);
+        for (int t = 0; t < T; ++t)
+            memcpy(yc + (size_t)t * dy, y + ((size_t)t * n_chains + ch) * dy, sizeof(double) * dy);
+        rxo_counters cc;
+        double f = 0.0;
+        int rc = rxo_lgssm_bp(d, dy, T, A, B, P, Q, m0, V0, ptt, yc, pm, pc, fe ? &f : NULL, &cc);
+        if (rc) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            rc_all = rc;
+        }
+        for (int t = 0; t < T; ++t) {
+            memcpy(post_mean + ((size_t)t * n_chains + ch) * d, pm + (size_t)t * d, sizeof(double) * d);
+            memcpy(post_cov + ((size_t)t * n_chains + ch) * d * d, pc + (size_t)t * d * d, sizeof(double) * d * d);
+        }
+        if (fe) fe[ch] = f;
+        rc_rules += cc.rule_calls;
+        rc_prods += cc.products;
+        rc_margs += cc.marginals;
+        free(yc);
+        free(pm);
+        free(pc);
+    }
+    if (counters) {
+        counters->rule_calls = rc_rules;
+        counters->products = rc_prods;
+        counters->marginals = rc_margs;
+    }
+    (void)nthreads;
+    return rc_all;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Independent textbook implementation, used ONLY to validate the restatement above
+ * (identity: BP on a tree == Kalman filter + RTS smoother; Bethe FE == −log p(y)).
+ * ------------------------------------------------------------------------------------------ */
+int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B, const double* P,
+                         const double* Q, const double* m0, const double* V0, int ptt, const double* y,
+                         double* post_mean, double* post_cov, double* neg_loglik) {
+    const int dm = d > dy ? d : dy;
+    const size_t vs = d, ms = (size_t)d * d;
+    double* mf = (double*)malloc(sizeof(double) * T * (vs + ms));
+    double* Vf = mf + T * vs;
+    double* w = (double*)malloc(sizeof(double) * (size_t)(20 * dm * dm + 8 * dm));
+    double *mp = w, *Vp = mp + dm, *S = Vp + dm * dm, *Si = S + dm * dm, *K = Si + dm * dm, *tmp = K + dm * dm,
+           *e = tmp + dm * dm, *BV = e + dm, *chw = BV + dm * dm, *G = chw + 2 * dm * dm, *D = G + dm * dm,
+           *t2 = D + dm * dm;
+    int rc = RXO_OK;
+    double nll = 0.0;
+    double *pm0 = (double*)malloc(sizeof(double) * (vs + ms)), *pV0 = pm0 + vs;
+    if (ptt) {
+        matvec(d, d, A, m0, pm0);
+        congruence(d, d, A, V0, pV0, tmp);
+        for (size_t i = 0; i < ms; ++i) pV0[i] += P[i];
+    } else {
+        memcpy(pm0, m0, sizeof(double) * vs);
+        memcpy(pV0, V0, sizeof(double) * ms);
+    }
+    for (int t = 0; t < T && !rc; ++t) {
+        if (t == 0) {
+            memcpy(mp, pm0, sizeof(double) * vs);
+            memcpy(Vp, pV0, sizeof(double) * ms);
+        } else {
+            matvec(d, d, A, mf + (t - 1) * vs, mp);
+            congruence(d, d, A, Vf + (t - 1) * ms, Vp, tmp);
+            for (size_t i = 0; i < ms; ++i) Vp[i] += P[i];
+        }
+        congruence(dy, d, B, Vp, S, tmp);
+        for (int i = 0; i < dy * dy; ++i) S[i] += Q[i];
+        double ldS;
+        rc = cholinv(dy, S, Si, &ldS, chw);
+        if (rc) break;
+        matvec(dy, d, B, mp, e);
+        for (int i = 0; i < dy; ++i) e[i] = y[(size_t)t * dy + i] - e[i];
+        double q = 0.0;
+        for (int i = 0; i < dy; ++i)
+            for (int j = 0; j < dy; ++j) q += e[i] * Si[i * dy + j] * e[j];
+        nll += 0.5 * (dy * LOG2PI + ldS + q);
+        /* BV = B Vp (dy×d); K = BV' Si (d×dy) */
+        for (int i = 0; i < dy; ++i)
+            for (int j = 0; j < d; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < d; ++k) s += B[i * d + k] * Vp[k * d + j];
+                BV[i * d + j] = s;
+            }
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < dy; ++j) {
+                double s = 0.0;
+                for (int k = 0; k < dy; ++k) s += BV[k * d + i] * Si[k * dy + j];
+                K[i * dy + j] = s;
+            }
+        for (int i = 0; i < d; ++i) {
+            double s = mp[i];
+            for (int j = 0; j < dy; ++j) s += K[i * dy + j] * e[j];
+            mf[t * vs + i] = s;
+        }
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                double s = Vp[i * d + j];
+                for (int k = 0; k < dy; ++k) s -= K[i * dy + k] * BV[k * d + j];
+                Vf[t * ms + i * d + j] = s;
+            }
+        for (int i = 0; i < d; ++i) /* symmetrise */
+            for (int j = 0; j < i; ++j) {
+                double s = 0.5 * (Vf[t * ms + i * d + j] + Vf[t * ms + j * d + i]);
+                Vf[t * ms + i * d + j] = Vf[t * ms + j * d + i] = s;
+            }
+    }
+    if (!rc) {
+        memcpy(post_mean + (size_t)(T - 1) * vs, mf + (T - 1) * vs, sizeof(double) * vs);
+        memcpy(post_cov + (size_t)(T - 1) * ms, Vf + (T - 1) * ms, sizeof(double) * ms);
+        for (int t = T - 2; t >= 0 && !rc; --t) {
+            matvec(d, d, A, mf + t * vs, mp);
+            congruence(d, d, A, Vf + t * ms, Vp, tmp);
+            for (size_t i = 0; i < ms; ++i) Vp[i] += P[i];
+            rc = cholinv(d, Vp, Si, NULL, chw);
+            if (rc) break;
+            /* G = Vf A' Vp^-1 */
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j < d; ++j) {
+                    double s = 0.0;
+                    for (int k = 0; k < d; ++k) s += Vf[t * ms + i * d + k] * A[j * d + k];
+                    tmp[i * d + j] = s;
+                }
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j < d; ++j) {
+                    double s = 0.0;
+                    for (int k = 0; k < d; ++k) s += tmp[i * d + k] * Si[k * d + j];
+                    G[i * d + j] = s;
+                }
+            for (int i = 0; i < d; ++i) e[i] = post_mean[(size_t)(t + 1) * vs + i] - mp[i];
+            for (int i = 0; i < d; ++i) {
+                double s = mf[t * vs + i];
+                for (int j = 0; j < d; ++j) s += G[i * d + j] * e[j];
+                post_mean[(size_t)t * vs + i] = s;
+            }
+            for (size_t i = 0; i < ms; ++i) D[i] = post_cov[(size_t)(t + 1) * ms + i] - Vp[i];
+            congruence(d, d, G, D, t2, tmp);
+            for (size_t i = 0; i < ms; ++i) post_cov[(size_t)t * ms + i] = Vf[t * ms + i] + t2[i];
+        }
+    }
+    if (neg_loglik) *neg_loglik = nll;
+    free(mf);
+    free(w);
+    free(pm0);
+    return rc;
+}

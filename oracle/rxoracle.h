@@ -1,0 +1,92 @@
+/*
+ * rxoracle.h — CPU restatement ("oracle") of the RxInfer / ReactiveMP hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under oracle/ is part of the product: only tests/,
+ * __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library, and only as the
+ * checker / the reported CPU baseline.  The shipped engine is librxhip (rxinfer.jl_amd/csrc).
+ *
+ * Provenance / pinning status
+ * ---------------------------
+ * The arithmetic of the reference hot path does not live in /root/reference: it lives in the
+ * un-vendored Julia packages ReactiveMP.jl (~6.0.0), ExponentialFamily.jl (2.1.0),
+ * BayesBase.jl (1.5.0) and FastCholesky.jl (1.3.0) (reference Project.toml:43-73).  There is no
+ * Julia toolchain in this image, so the reference itself cannot be executed.  This file restates
+ * the published algorithm of those rules and follows the reference's own call sites:
+ *   - which node each `MvNormal(μ, Σ)` / `A * x` spelling selects  src/model/graphppl.jl:372-376,
+ *     docs/src/manuals/model-specification.md:217-240
+ *   - message product order (left-to-right over a variable's neighbours)
+ *     src/model/plugins/reactivemp_inference.jl:365-374
+ *   - iteration semantics (same data re-pushed each iteration)      src/inference/batch.jl:391-430
+ *   - Bethe free energy: which terms, how summed, point-mass bookkeeping
+ *     src/model/plugins/reactivemp_free_energy.jl:51-126, src/helpers.jl:21
+ * It is pinned against (a) the RNG-free known answers of the reference tests
+ * (test/models/models_tests.jl:255,286,308,335: FE 3.51551 / 2.26551, means 1.5 / 1.0) and
+ * (b) the identities BP == Kalman/RTS smoother and Bethe FE == -log p(y) on trees
+ * (docs/src/manuals/variational/bethe-free-energy.md:70).  The RNG-dependent golden values of
+ * the reference tests (StableRNG data) cannot be regenerated without Julia:
+ * for those "parity unpinned" (see DESIGN.md §oracle).
+ */
+#ifndef RXORACLE_H
+#define RXORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* status codes */
+#define RXO_OK 0
+#define RXO_ERR_NOT_POSDEF 3 /* mirrors FastCholesky / PosDefException */
+#define RXO_ERR_BADARG 1
+#define RXO_ERR_NONFINITE_FE 4 /* mirrors src/score/diagnostics.jl:19-51 */
+
+/* Operation counters, the oracle's equivalent of the reference's callback events
+ * (src/callbacks/events.jl; counted in test/callbacks/trace_tests.jl:93-104). */
+typedef struct {
+    uint64_t rule_calls;   /* after_message_rule_call */
+    uint64_t products;     /* after_product_of_two_messages */
+    uint64_t marginals;    /* after_marginal_computation */
+} rxo_counters;
+
+/*
+ * Linear Gaussian state-space model, one chain, one BP sweep in the reference's message
+ * schedule.  Model (benchmarks notebook cell 4):
+ *     x[1] ~ MvNormal(μ = m0, Σ = V0)                      (prior_through_transition = 0)
+ *     x[t] ~ MvNormal(μ = A * x[t-1], Σ = P)    t = 2..T    (P: state noise)
+ *     y[t] ~ MvNormal(μ = B * x[t],   Σ = Q)    t = 1..T    (Q: observation noise)
+ * With prior_through_transition = 1 (test/models/statespace/mlgssm_test.jl:9-17):
+ *     x0 ~ MvNormal(m0, V0);  x[1] ~ MvNormal(A * x0, P);  ...
+ * All matrices row-major.  A: d×d, B: dy×d, P: d×d, Q: dy×dy, y: [T][dy].
+ * Outputs: post_mean [T][d], post_cov [T][d][d] (posteriors of x[1..T]);
+ * free_energy (nullable): Bethe free energy, full node/variable sum with CountingReal
+ * bookkeeping; counters (nullable) counts the posterior-only sweep (6 rule calls per step).
+ */
+int rxo_lgssm_bp(int d, int dy, int T, const double* A, const double* B, const double* P,
+                 const double* Q, const double* m0, const double* V0,
+                 int prior_through_transition, const double* y, double* post_mean,
+                 double* post_cov, double* free_energy, rxo_counters* counters);
+
+/*
+ * Batch driver used for the CPU baseline: n_chains independent chains sharing one model,
+ * y laid out [T][chain][dy], outputs [T][chain][d] and [T][chain][d][d], fe[chain] (nullable).
+ * nthreads > 1 uses OpenMP over chains (the reference itself is single-threaded).
+ */
+int rxo_lgssm_bp_batch(int d, int dy, int T, int n_chains, const double* A, const double* B,
+                       const double* P, const double* Q, const double* m0, const double* V0,
+                       int prior_through_transition, const double* y, double* post_mean,
+                       double* post_cov, double* fe, int nthreads, rxo_counters* counters);
+
+/* Independent cross-check used only to validate the oracle itself: textbook Kalman filter +
+ * RTS smoother and -log p(y) via innovations.  Same argument layout as rxo_lgssm_bp. */
+int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B, const double* P,
+                         const double* Q, const double* m0, const double* V0,
+                         int prior_through_transition, const double* y, double* post_mean,
+                         double* post_cov, double* neg_loglik);
+
+const char* rxo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,97 @@
+"""ctypes binding of the CPU oracle (oracle/librxoracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product (rxinfer.jl_amd) never imports this module.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Counters(ctypes.Structure):
+    _fields_ = [("rule_calls", ctypes.c_uint64), ("products", ctypes.c_uint64), ("marginals", ctypes.c_uint64)]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "librxoracle.so")
+    src = [os.path.join(_HERE, f) for f in ("rxoracle.c", "rxoracle.h", "Makefile")]
+    if force or not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in src):
+        subprocess.check_call(["make", "-C", _HERE, "-B", "librxoracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "librxoracle.so")
+        if not os.path.exists(so):
+            build()
+        _LIB = ctypes.CDLL(so)
+        dp = ctypes.POINTER(ctypes.c_double)
+        _LIB.rxo_lgssm_bp.restype = ctypes.c_int
+        _LIB.rxo_lgssm_bp.argtypes = [ctypes.c_int] * 3 + [dp] * 6 + [ctypes.c_int, dp, dp, dp, dp,
+                                                                    ctypes.POINTER(Counters)]
+        _LIB.rxo_lgssm_kalman_rts.restype = ctypes.c_int
+        _LIB.rxo_lgssm_kalman_rts.argtypes = [ctypes.c_int] * 3 + [dp] * 6 + [ctypes.c_int, dp, dp, dp, dp]
+        _LIB.rxo_lgssm_bp_batch.restype = ctypes.c_int
+        _LIB.rxo_lgssm_bp_batch.argtypes = [ctypes.c_int] * 4 + [dp] * 6 + [ctypes.c_int, dp, dp, dp, dp,
+                                                                          ctypes.c_int, ctypes.POINTER(Counters)]
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def lgssm_bp(A, B, P, Q, m0, V0, y, prior_through_transition=False, free_energy=True):
+    """One chain, reference schedule.  y: [T][dy].  Returns (mean [T,d], cov [T,d,d], fe|None, Counters)."""
+    A, B, P, Q, m0, V0, y = map(_c, (A, B, P, Q, m0, V0, y))
+    d, dy, T = A.shape[0], B.shape[0], y.shape[0]
+    mean = np.empty((T, d))
+    cov = np.empty((T, d, d))
+    fe = ctypes.c_double(0.0)
+    cnt = Counters()
+    rc = lib().rxo_lgssm_bp(d, dy, T, _p(A), _p(B), _p(P), _p(Q), _p(m0), _p(V0), int(prior_through_transition),
+                            _p(y), _p(mean), _p(cov), ctypes.byref(fe) if free_energy else None, ctypes.byref(cnt))
+    if rc:
+        raise RuntimeError(f"rxo_lgssm_bp failed with status {rc}")
+    return mean, cov, (fe.value if free_energy else None), cnt
+
+
+def lgssm_kalman_rts(A, B, P, Q, m0, V0, y, prior_through_transition=False):
+    A, B, P, Q, m0, V0, y = map(_c, (A, B, P, Q, m0, V0, y))
+    d, dy, T = A.shape[0], B.shape[0], y.shape[0]
+    mean = np.empty((T, d))
+    cov = np.empty((T, d, d))
+    nll = ctypes.c_double(0.0)
+    rc = lib().rxo_lgssm_kalman_rts(d, dy, T, _p(A), _p(B), _p(P), _p(Q), _p(m0), _p(V0),
+                                    int(prior_through_transition), _p(y), _p(mean), _p(cov), ctypes.byref(nll))
+    if rc:
+        raise RuntimeError(f"rxo_lgssm_kalman_rts failed with status {rc}")
+    return mean, cov, nll.value
+
+
+def lgssm_bp_batch(A, B, P, Q, m0, V0, y, prior_through_transition=False, free_energy=True, nthreads=1):
+    """Batch of chains sharing one model.  y: [T][chain][dy].  Returns mean [T,C,d], cov [T,C,d,d], fe[C]|None."""
+    A, B, P, Q, m0, V0, y = map(_c, (A, B, P, Q, m0, V0, y))
+    d, dy = A.shape[0], B.shape[0]
+    T, C = y.shape[0], y.shape[1]
+    mean = np.empty((T, C, d))
+    cov = np.empty((T, C, d, d))
+    fe = np.empty(C) if free_energy else None
+    cnt = Counters()
+    rc = lib().rxo_lgssm_bp_batch(d, dy, T, C, _p(A), _p(B), _p(P), _p(Q), _p(m0), _p(V0),
+                                  int(prior_through_transition), _p(y), _p(mean), _p(cov),
+                                  _p(fe) if free_energy else None, int(nthreads), ctypes.byref(cnt))
+    if rc:
+        raise RuntimeError(f"rxo_lgssm_bp_batch failed with status {rc}")
+    return mean, cov, fe, cnt
