@@ -1,0 +1,175 @@
+/*
+ * rxhip.h — C ABI of librxhip, the MI355X-native message-passing engine that replaces the
+ * ReactiveMP hot path behind RxInfer's `infer(...)`.
+ *
+ * The reference has no FFI for this path (it is pure Julia): the boundary it
+ * sits behind is a GraphPPL plugin.  Each entry point below names the reference interface it
+ * stands in for (paths relative to the RxInfer.jl checkout).  A Julia `ccall` shim binding
+ * exactly these symbols is in rxinfer.jl_amd/julia/RxHip.jl; see INTEGRATION.md.
+ *
+ * Conventions: plain C, no exceptions cross the ABI, every function returns an rxhip_status
+ * (0 = ok).  All matrices are dense row-major IEEE fp64.  The caller owns every host buffer it
+ * passes; the engine copies what it needs and owns its device memory until rxhip_destroy.
+ * One host thread per handle; handles are independent; no global state.
+ */
+#ifndef RXHIP_H
+#define RXHIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rxhip_engine rxhip_engine;
+typedef int32_t rxhip_status;
+
+enum {
+    RXHIP_OK = 0,
+    RXHIP_ERR_BADARG = 1,           /* malformed descriptor / argument */
+    RXHIP_ERR_UNSUPPORTED = 2,      /* node type / graph shape without a device schedule
+                                       (reference: RuleMethodError, docs/src/manuals/inference/undefinedrules.md) */
+    RXHIP_ERR_NOT_POSDEF = 3,       /* mirrors FastCholesky PosDefException (.github/workflows/CI.yml:72) */
+    RXHIP_ERR_NONFINITE_FE = 4,     /* mirrors ObjectiveDiagnosticCheckNaNs/Infs, src/score/diagnostics.jl:19-51 */
+    RXHIP_ERR_HIP = 5,              /* HIP runtime failure (see rxhip_last_error) */
+    RXHIP_ERR_NO_DEVICE = 6,        /* no MI355X visible: the product path never falls back to the CPU */
+    RXHIP_ERR_STATE = 7,            /* call order violated (e.g. run before set_data) */
+    RXHIP_ERR_RCCL = 8
+};
+
+/* host/device layouts of per-(time, chain) arrays */
+enum {
+    RXHIP_LAYOUT_TIME_CHAIN = 0, /* [T][chain][k]  (device-native) */
+    RXHIP_LAYOUT_CHAIN_TIME = 1  /* [chain][T][k]  (one Vector{Vector{Float64}} per chain, as `data = (y = ...,)`) */
+};
+
+/* variable ids of the LGSSM schedule */
+enum {
+    RXHIP_VAR_Y = 0, /* data variable y[t]   (src/inference/batch.jl:405-407 new_observation!) */
+    RXHIP_VAR_X = 1  /* random variable x[t] (posteriors[:x], src/inference/batch.jl:325-332) */
+};
+
+/* ------------------------------------------------------------------------------------------
+ * Structured descriptor of a batch of linear Gaussian state-space factor graphs — what the
+ * lowering of the materialised graph produces (replaces the per-node objects built by
+ * GraphPPL.postprocess_plugin(::ReactiveMPInferencePlugin, model),
+ * src/model/plugins/reactivemp_inference.jl:272-326, for this model family):
+ *     x[1] ~ MvNormal(μ = m0, Σ = V0)                   (prior_through_transition = 0;
+ *                                                        benchmarks notebook cell 4)
+ *     x0 ~ MvNormal(m0, V0); x[1] ~ MvNormal(A*x0, P)   (prior_through_transition = 1;
+ *                                                        test/models/statespace/mlgssm_test.jl:9-17)
+ *     x[t] ~ MvNormal(μ = A * x[t-1], Σ = P)     P: state noise        d×d
+ *     y[t] ~ MvNormal(μ = B * x[t],   Σ = Q)     Q: observation noise  dy×dy, B: dy×d
+ * `n_models` distinct constant sets; chain c uses model chain_model[c] (NULL: all chains use
+ * model 0).  The schedule is compiled per (d, dy); supported: see rxhip_lgssm_supported().
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t d;
+    int32_t dy;
+    int64_t T;
+    int64_t n_chains;
+    int32_t n_models;
+    int32_t prior_through_transition;
+    const double* A;  /* [n_models][d][d]   */
+    const double* B;  /* [n_models][dy][d]  */
+    const double* P;  /* [n_models][d][d]   */
+    const double* Q;  /* [n_models][dy][dy] */
+    const double* m0; /* [n_models][d]      */
+    const double* V0; /* [n_models][d][d]   */
+    const int32_t* chain_model; /* [n_chains] or NULL */
+    int32_t segments; /* time segments per chain for the parallel-in-time schedule; 0 = auto */
+    int32_t device;   /* HIP device ordinal; -1 = current device */
+    void* stream;     /* hipStream_t to run on; NULL = engine-owned stream */
+} rxhip_lgssm_desc;
+
+/* replaces: create_model(...) + postprocess_plugin (src/inference/batch.jl:252,
+ * src/model/plugins/reactivemp_inference.jl:272-326) for the LGSSM family */
+rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* desc, rxhip_engine** out);
+
+/* 1 if a device schedule is compiled for state dimension d and observation dimension dy */
+int32_t rxhip_lgssm_supported(int32_t d, int32_t dy);
+
+/* replaces: new_observation!(datavar, value) (src/inference/batch.jl:405-407).  Copies n doubles
+ * from the host; n must equal T*n_chains*dy.  layout: RXHIP_LAYOUT_*. */
+rxhip_status rxhip_set_data(rxhip_engine* e, int32_t var_id, const double* host, size_t n, int32_t layout);
+
+/* same, but the observations already live in device memory (layout RXHIP_LAYOUT_TIME_CHAIN is
+ * used in place, zero-copy: the buffer must stay valid until the next set_data / destroy). */
+rxhip_status rxhip_set_data_device(rxhip_engine* e, int32_t var_id, const double* dev, size_t n, int32_t layout);
+
+/* replaces: the iteration loop `for iteration in 1:iterations` with its synchronous reactive
+ * cascade (src/inference/batch.jl:391-430).  Every iteration re-pushes the data and recomputes
+ * every message, marginal and (if want_free_energy) the Bethe free energy, as the reference
+ * does.  Synchronous: returns after the stream has drained (drivers read results immediately,
+ * batch.jl:415).  Non-SPD matrices / non-finite free energy are reported as status codes. */
+rxhip_status rxhip_run(rxhip_engine* e, int32_t iterations, int32_t want_free_energy);
+
+/* asynchronous variant used for measurement: enqueues the same work, does not wait. */
+rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_free_energy);
+/* waits for the engine's stream and collects device-side diagnostics (status as rxhip_run) */
+rxhip_status rxhip_sync(rxhip_engine* e);
+
+/* replaces: obtain_marginal(var) |> subscribe! + KeepLast actor (reactivemp_inference.jl:626-629,
+ * batch.jl:325-340) followed by mean_cov of the posterior (src/inference/postprocess.jl:32-38).
+ * mean: T*n_chains*d doubles, cov: T*n_chains*d*d doubles (either may be NULL), in `layout`. */
+rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout);
+
+/* device views of the same results, layout [T][chain][d] and [T][chain][d][d]; valid until the
+ * next run / destroy */
+rxhip_status rxhip_get_marginals_device(rxhip_engine* e, int32_t var_id, const double** mean_dev,
+                                        const double** cov_dev);
+
+/* replaces: score(model, BetheFreeEnergy{Float64}, checks) |> ScoreActor
+ * (src/model/plugins/reactivemp_free_energy.jl:84-126, src/score/actor.jl:38-63).
+ * per_iteration[i] = Bethe free energy of the whole batch (sum over chains) at iteration i of
+ * the last rxhip_run; length = iterations of that run. */
+rxhip_status rxhip_get_free_energy(rxhip_engine* e, double* per_iteration);
+/* free energy of each chain (= what `infer` returns for that chain alone), last iteration; n_chains doubles */
+rxhip_status rxhip_get_free_energy_per_chain(rxhip_engine* e, double* per_chain);
+/* device address of the batch free energy of the last iteration (1 double) — the buffer the
+ * multi-GPU host all-reduces over RCCL */
+rxhip_status rxhip_get_free_energy_device(rxhip_engine* e, double** fe_dev);
+/* enqueue (on the engine's stream, asynchronously) a device-to-device copy of the batch free
+ * energy of the last enqueued iteration into dst_dev[0] — lets the multi-GPU host hand the
+ * scalar to RCCL without a host round trip */
+rxhip_status rxhip_copy_free_energy_to_device(rxhip_engine* e, double* dst_dev);
+
+/* replaces: the after_message_rule_call / after_product_of_two_messages event counts
+ * (src/callbacks/events.jl, counted in test/callbacks/trace_tests.jl:93-104): the number of
+ * reference rule calls / pairwise products the work done by the last rxhip_run is equivalent to. */
+rxhip_status rxhip_counters(rxhip_engine* e, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals);
+
+/* ------------------------------------------------------------------------------------------
+ * measurement hooks (no reference counterpart; RxInferBenchmarkCallbacks is the closest,
+ * src/callbacks/benchmark.jl:99-155)
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    RXHIP_K_SEG_AGGREGATE = 0, /* phase 1: per-segment Kalman "elements" (reads y)            */
+    RXHIP_K_BOUNDARY_SCAN = 1, /* phase 2: prefix/suffix scan over segment boundaries          */
+    RXHIP_K_FORWARD = 2,       /* phase 3: forward messages + evidence terms (reads y, writes fwd) */
+    RXHIP_K_BACKWARD = 3,      /* phase 4: backward messages + marginals (reads fwd, writes posteriors) */
+    RXHIP_K_FE_REDUCE = 4,     /* Bethe free-energy reduction                                  */
+    RXHIP_K_COUNT = 5
+};
+/* enable (1) / disable (0) per-kernel HIP-event timing on the engine's stream */
+rxhip_status rxhip_set_profiling(rxhip_engine* e, int32_t enabled);
+/* average duration in milliseconds of each kernel (index RXHIP_K_*) over all launches since
+ * profiling was enabled / last reset, and the number of launches averaged */
+rxhip_status rxhip_get_kernel_times(rxhip_engine* e, double* ms_avg, uint64_t* launches);
+rxhip_status rxhip_reset_kernel_times(rxhip_engine* e);
+/* the hipStream_t the engine launches on */
+rxhip_status rxhip_get_stream(rxhip_engine* e, void** stream);
+/* the number of time segments the schedule uses and their length */
+rxhip_status rxhip_get_schedule(rxhip_engine* e, int32_t* segments, int64_t* segment_len);
+
+const char* rxhip_last_error(const rxhip_engine* e); /* never NULL; valid until the next call on e */
+const char* rxhip_status_string(rxhip_status s);
+const char* rxhip_version(void);
+int32_t rxhip_device_count(void); /* number of visible HIP devices (0 if none) */
+rxhip_status rxhip_destroy(rxhip_engine* e);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RXHIP_H */

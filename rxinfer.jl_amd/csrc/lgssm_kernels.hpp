@@ -1,0 +1,775 @@
+// lgssm_kernels.hpp — hand-written HIP kernels (gfx950 / CDNA4, fp64) for the Gaussian
+// sum-product hot path of RxInfer on linear Gaussian state-space factor graphs.
+//
+// What these kernels replace (reference = RxInfer.jl checkout; the rule bodies themselves live
+// in the un-vendored ReactiveMP.jl / ExponentialFamily.jl):
+//   a3  @rule MvNormalMeanCovariance(:out|:μ)      selected at src/model/graphppl.jl:372-376
+//   a4  @rule typeof(*)(:out|:in) with constant A   created for `A * x[t-1]` (benchmarks notebook cell 4)
+//   a5  message product at a variable               src/model/plugins/reactivemp_inference.jl:365-374,432-447
+//   a6  marginal computation + mean_cov             reactivemp_inference.jl:440-447,626-629
+//   a7  Bethe free energy                           src/model/plugins/reactivemp_free_energy.jl:51-126
+//
+// Design: one lane owns one (chain, time-segment).  All d×d algebra of a
+// factor node lives in that lane's registers as fully unrolled fp64 FMAs (packed-symmetric
+// where the matrix is symmetric); adjacent lanes are adjacent chains so every global access of a
+// wave is a contiguous run.  Time is cut into S segments per chain so that 1024 chains × S
+// segments fill 256 CUs; segment boundaries are made exact (not approximate) with Kalman
+// "elements" (Särkkä & García-Fernández 2021, temporal parallelisation of Bayesian smoothers):
+//   phase 1  k_seg_aggregate : per (chain, segment) the data-dependent part (b, η) of the
+//                              segment's element, using per-model gain tables (reads y)
+//   phase 2  k_boundary_scan : prefix scan -> filtered belief at every segment start,
+//                              suffix scan -> backward message at every segment end
+//   phase 3  k_forward       : forward messages inside each segment (`*`(:out), MvN(:out), product
+//                              with the observation message) + evidence terms of the Bethe free
+//                              energy; stores the filtered message packed-symmetric
+//   phase 4  k_backward      : backward messages + marginals inside each segment (MvN(:μ),
+//                              `*`(:in), 3-way product, mean_cov) in Rauch–Tung–Striebel form
+//   k_fe_reduce              : deterministic reduction of the free-energy partials
+// The result equals the reference's sequential schedule up to fp64 rounding (tests: 1e-6
+// relative on posteriors, 1e-8 relative on free energy — the north_star tolerances).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rxhip {
+
+// ------------------------------------------------------------------------------------------
+// device status bits (OR-ed into Params::status)
+constexpr int ST_NOT_POSDEF = 1;
+constexpr int ST_NONFINITE = 2;
+
+template <int D>
+struct Dim {
+    static constexpr int NS = D * (D + 1) / 2;  // packed symmetric size
+    static constexpr int NP = D + NS;           // Gaussian record: vector + packed matrix
+    static constexpr int NP2 = (NP + 1) / 2;    // record size in 16-byte pairs
+};
+
+__host__ __device__ constexpr int sidx(int i, int j) { return i >= j ? i * (i + 1) / 2 + j : j * (j + 1) / 2 + i; }
+
+template <int D>
+struct Sym {
+    double v[D * (D + 1) / 2];
+    __device__ __forceinline__ double& operator()(int i, int j) { return v[sidx(i, j)]; }
+    __device__ __forceinline__ const double& operator()(int i, int j) const { return v[sidx(i, j)]; }
+};
+
+// Per-model constant block (doubles), built on the host at create time.
+template <int D, int DY>
+struct CstLayout {
+    static constexpr int NS = D * (D + 1) / 2;
+    static constexpr int NSY = DY * (DY + 1) / 2;
+    static constexpr int A = 0;               // [D][D]      transition matrix
+    static constexpr int P = A + D * D;       // [NS]        state-noise covariance (packed)
+    static constexpr int LOBS = P + NS;       // [NS]        B' Q^-1 B  (precision of the `*`_B(:in) message)
+    static constexpr int G = LOBS + NS;       // [D][DY]     B' Q^-1    (its weighted mean is G y)
+    static constexpr int QI = G + D * DY;     // [NSY]       Q^-1 (packed)
+    static constexpr int C0 = QI + NSY;       // [1]         dy log 2π + logdet Q
+    static constexpr int M1 = C0 + 1;         // [D]         mean of the message toward x[1]
+    static constexpr int V1 = M1 + D;         // [NS]        its covariance
+    static constexpr int HF = V1 + NS;        // [DY][D]     B A
+    static constexpr int SIZE = ((HF + DY * D + 7) / 8) * 8;
+};
+// Per-model, per-offset gain table entry (phase 1): K_i [D][DY], U_i [D][DY]
+template <int D, int DY>
+struct TabLayout {
+    static constexpr int K = 0;
+    static constexpr int U = D * DY;
+    static constexpr int SIZE = 2 * D * DY;
+};
+// Per-model, per-length matrix part of a segment element (phase 2)
+template <int D>
+struct AggLayout {
+    static constexpr int NS = D * (D + 1) / 2;
+    static constexpr int PI = 0;          // [D][D]  Π  (product of closed-loop matrices)
+    static constexpr int C = PI + D * D;  // [NS]    C  (covariance of x_end | x_start, y_seg)
+    static constexpr int J = C + NS;      // [NS]    J  (information about x_start in y_seg)
+    static constexpr int CI = J + NS;     // [NS]    C^-1
+    static constexpr int X = CI + NS;     // [D][D]  C^-1 Π
+    static constexpr int JJ = X + D * D;  // [NS]    J + Π' C^-1 Π
+    static constexpr int SIZE = ((JJ + NS + 7) / 8) * 8;
+};
+
+struct Params {
+    // problem
+    long long T;
+    long long n_chains;
+    int S;           // segments
+    long long L;     // segment length (last one may be shorter)
+    int n_models;
+    // device buffers
+    const double* y;        // [T][chain][DY]
+    double* filt;           // [T][NP2][chain][2]   filtered message (m_f, V_f packed)
+    double* mean;           // [T][chain][D]
+    double* cov;            // [T][chain][D][D]
+    const double* cst;      // [n_models][CstLayout::SIZE]
+    const double* tab;      // [n_models][L][TabLayout::SIZE]
+    const double* agg;      // [n_models][2][AggLayout::SIZE]   (0: length L, 1: length of the last segment)
+    const int* chain_model; // [chain] or nullptr
+    double* elem;           // [S][2D][chain]       (b, η) of every segment element
+    double* fstart;         // [S][NP][chain]       filtered belief at every segment start
+    double* beta;           // [S+1][NP][chain]     backward message (ξ, Λ packed) at every boundary
+    double* fe_part;        // [S+1][chain]         Σ log p(y_t | y_<t) partials
+    double* fe_chain;       // [chain]
+    double* fe_total;       // [iterations]
+    int iteration;
+    int* status;
+};
+
+// ------------------------------------------------------------------------------------------
+// small dense algebra, everything unrolled so that all indices are compile-time constants and
+// the operands stay in VGPRs (checked with -Rpass-analysis=kernel-resource-usage: no scratch).
+
+// SPD inverse through LDL' (no square roots).  `det` receives det(a) (product of pivots).
+// Restates FastCholesky.cholinv for the small blocks on the path; a non-positive pivot
+// reports ST_NOT_POSDEF (the reference throws PosDefException).
+template <int D>
+__device__ __forceinline__ bool spd_inv(const Sym<D>& a, Sym<D>& out, double& det) {
+    double L[D][D], W[D][D], r[D];
+    bool ok = true;
+    det = 1.0;
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        double s = a(j, j);
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= W[j][k] * L[j][k];
+        ok = ok && (s > 0.0);
+        det *= s;
+        r[j] = 1.0 / s;
+#pragma unroll
+        for (int i = j + 1; i < D; ++i) {
+            double t = a(i, j);
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= W[i][k] * L[j][k];
+            W[i][j] = t;
+            L[i][j] = t * r[j];
+        }
+    }
+    // M = L^-1 (unit lower)
+    double M[D][D];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+#pragma unroll
+        for (int i = j + 1; i < D; ++i) {
+            double s = -L[i][j];
+#pragma unroll
+            for (int k = j + 1; k < i; ++k) s -= L[i][k] * M[k][j];
+            M[i][j] = s;
+        }
+    }
+    // out = M' D^-1 M
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            // k = i term: M(i,i) = 1
+            double s = (i == j) ? r[i] : r[i] * M[i][j];
+#pragma unroll
+            for (int k = i + 1; k < D; ++k) s += (M[k][i] * r[k]) * M[k][j];
+            out(i, j) = s;
+        }
+    }
+    return ok;
+}
+
+// y = S x  (S symmetric packed)
+template <int D>
+__device__ __forceinline__ void symv(const Sym<D>& S, const double (&x)[D], double (&y)[D]) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s += S(i, k) * x[k];
+        y[i] = s;
+    }
+}
+
+// constant access: uniform (scalar loads) or per-lane pointer — same code
+struct CPtr {
+    const double* p;
+    __device__ __forceinline__ double operator[](int i) const { return p[i]; }
+};
+
+// Vp = A V A' + P ; also returns T = A V (needed by the smoother gain)
+template <int D>
+__device__ __forceinline__ void predict_cov(const CPtr A, const CPtr P, const Sym<D>& V, double (&T)[D][D],
+                                            Sym<D>& Vp) {
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += A[i * D + k] * V(k, j);
+            T[i][j] = s;
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double s = P[sidx(i, j)];
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += T[i][k] * A[j * D + k];
+            Vp(i, j) = s;
+        }
+}
+
+template <int D>
+__device__ __forceinline__ void matvec_c(const CPtr A, const double (&x)[D], double (&y)[D]) {
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) s += A[i * D + k] * x[k];
+        y[i] = s;
+    }
+}
+
+// Observation update in information form (product of the forward message with the `*`_B(:in)
+// message) and the evidence term.  In: predicted (mp, Vp), y.  Out: filtered (m, V).
+// Returns log p(y_t | y_<t) when FE.
+template <int D, int DY, bool FE>
+__device__ __forceinline__ double obs_update(const CPtr c, const double (&mp)[D], const Sym<D>& Vp,
+                                             const double (&y)[DY], double (&m)[D], Sym<D>& V, bool& ok) {
+    using CL = CstLayout<D, DY>;
+    Sym<D> Lp, Lf;
+    double detp, detl;
+    ok = spd_inv<D>(Vp, Lp, detp) && ok;  // weightedmean_precision of the forward message
+    double xp[D], xf[D];
+    symv<D>(Lp, mp, xp);
+#pragma unroll
+    for (int i = 0; i < D * (D + 1) / 2; ++i) Lf.v[i] = Lp.v[i] + c[CL::LOBS + i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double s = xp[i];
+#pragma unroll
+        for (int k = 0; k < DY; ++k) s += c[CL::G + i * DY + k] * y[k];
+        xf[i] = s;
+    }
+    ok = spd_inv<D>(Lf, V, detl) && ok;  // mean_cov of the product
+    symv<D>(V, xf, m);
+    if (!FE) return 0.0;
+    // log p(y|past) = -½[c0 + y'Q⁻¹y + log(det Λf · det Vp) − ξf'm_f + m_p'Λ_p m_p]
+    double q = 0.0;
+#pragma unroll
+    for (int i = 0; i < DY; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < DY; ++k) s += c[CL::QI + sidx(i, k)] * y[k];
+        q += s * y[i];
+    }
+    double a1 = 0.0, a2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        a1 += xf[i] * m[i];
+        a2 += xp[i] * mp[i];
+    }
+    return -0.5 * (c[CL::C0] + q + log(detl * detp) - a1 + a2);
+}
+
+// record I/O.  A Gaussian record is NP = D + NS doubles: vector, then packed lower triangle.
+// filt layout [T][NP2][chain][2]: lane = chain, every 16-byte access of a wave is contiguous.
+template <int D>
+__device__ __forceinline__ void store_filt(double* filt, long long t, long long n_chains, long long chain,
+                                           const double (&m)[D], const Sym<D>& V) {
+    constexpr int NP = Dim<D>::NP, NP2 = Dim<D>::NP2;
+    double r[2 * NP2];
+#pragma unroll
+    for (int i = 0; i < D; ++i) r[i] = m[i];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::NS; ++i) r[D + i] = V.v[i];
+    if (NP < 2 * NP2) r[2 * NP2 - 1] = 0.0;
+    double2* base = reinterpret_cast<double2*>(filt) + (t * NP2) * n_chains + chain;
+#pragma unroll
+    for (int k = 0; k < NP2; ++k) base[k * n_chains] = make_double2(r[2 * k], r[2 * k + 1]);
+}
+template <int D>
+__device__ __forceinline__ void load_filt_raw(const double* filt, long long t, long long n_chains,
+                                              long long chain, double2 (&r)[Dim<D>::NP2]) {
+    constexpr int NP2 = Dim<D>::NP2;
+    const double2* base = reinterpret_cast<const double2*>(filt) + (t * NP2) * n_chains + chain;
+#pragma unroll
+    for (int k = 0; k < NP2; ++k) r[k] = base[k * n_chains];
+}
+template <int D>
+__device__ __forceinline__ void unpack_rec(const double2 (&r)[Dim<D>::NP2], double (&m)[D], Sym<D>& V) {
+    constexpr int NP = Dim<D>::NP;
+    double f[2 * Dim<D>::NP2];
+#pragma unroll
+    for (int k = 0; k < Dim<D>::NP2; ++k) {
+        f[2 * k] = r[k].x;
+        f[2 * k + 1] = r[k].y;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) m[i] = f[i];
+#pragma unroll
+    for (int i = 0; i < NP - D; ++i) V.v[i] = f[D + i];
+}
+// SoA boundary records [slot][NP][chain]
+template <int D>
+__device__ __forceinline__ void store_soa(double* buf, long long slot, long long n_chains, long long chain,
+                                          const double (&m)[D], const Sym<D>& V) {
+    double* b = buf + (slot * Dim<D>::NP) * n_chains + chain;
+#pragma unroll
+    for (int i = 0; i < D; ++i) b[i * n_chains] = m[i];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::NS; ++i) b[(D + i) * n_chains] = V.v[i];
+}
+template <int D>
+__device__ __forceinline__ void load_soa(const double* buf, long long slot, long long n_chains, long long chain,
+                                         double (&m)[D], Sym<D>& V) {
+    const double* b = buf + (slot * Dim<D>::NP) * n_chains + chain;
+#pragma unroll
+    for (int i = 0; i < D; ++i) m[i] = b[i * n_chains];
+#pragma unroll
+    for (int i = 0; i < Dim<D>::NS; ++i) V.v[i] = b[(D + i) * n_chains];
+}
+template <int DY>
+__device__ __forceinline__ void load_y(const double* y, long long t, long long n_chains, long long chain,
+                                       double (&v)[DY]) {
+    const double* p = y + (t * n_chains + chain) * DY;
+    if constexpr (DY % 2 == 0) {
+        const double2* p2 = reinterpret_cast<const double2*>(p);
+#pragma unroll
+        for (int k = 0; k < DY / 2; ++k) {
+            double2 q = p2[k];
+            v[2 * k] = q.x;
+            v[2 * k + 1] = q.y;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < DY; ++k) v[k] = p[k];
+    }
+}
+
+template <bool UNI>
+__device__ __forceinline__ int model_of(const Params& p, long long chain) {
+    if (UNI) return 0;
+    return p.chain_model ? p.chain_model[chain] : 0;
+}
+
+// segment s covers times (1-based) b_s+1 .. b_{s+1}, b_s = 1 + s·L, b_S = T
+__device__ __forceinline__ long long seg_len(const Params& p, long long s) {
+    long long b0 = 1 + s * p.L;
+    long long b1 = b0 + p.L;
+    if (b1 > p.T) b1 = p.T;
+    return b1 - b0;
+}
+
+// ------------------------------------------------------------------------------------------
+// phase 1: data-dependent part (b, η) of each segment element.
+//   e_i = y_i − (BA) m_{i−1};  η += U_i e_i;  m_i = A m_{i−1} + K_i e_i       (m_0 = 0)
+// K_i, U_i: per-model gain tables (Kalman gain of the filter started from an exactly known
+// state, and the sensitivity of the innovations to that state).  64 FMAs / step at d = dy = 4.
+template <int D, int DY, bool UNI>
+__global__ void __launch_bounds__(64) k_seg_aggregate(Params p) {
+    using CL = CstLayout<D, DY>;
+    using TL = TabLayout<D, DY>;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = p.n_chains * (long long)p.S;
+    const bool live = g < total;
+    const long long seg = live ? g / p.n_chains : 0;
+    const long long chain = live ? g - seg * p.n_chains : 0;
+    const long long len = live ? seg_len(p, seg) : 0;
+    const int mdl = model_of<UNI>(p, chain);
+    const CPtr c{p.cst + (long long)mdl * CL::SIZE};
+    const double* tab = p.tab + (long long)mdl * p.L * TL::SIZE;
+    const long long t0 = seg * p.L + 1;  // zero-based index of the first observation of the segment
+
+    double m[D], eta[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) m[i] = eta[i] = 0.0;
+    double yv[DY], yn[DY];
+    if (len > 0) load_y<DY>(p.y, t0, p.n_chains, chain, yn);
+    for (long long i = 0; i < p.L; ++i) {  // uniform trip count: table addresses stay scalar
+        if (i < len) {
+#pragma unroll
+            for (int k = 0; k < DY; ++k) yv[k] = yn[k];
+            if (i + 1 < len) load_y<DY>(p.y, t0 + i + 1, p.n_chains, chain, yn);
+            const CPtr tb{tab + i * TL::SIZE};
+            double e[DY];
+#pragma unroll
+            for (int a = 0; a < DY; ++a) {
+                double s = yv[a];
+#pragma unroll
+                for (int k = 0; k < D; ++k) s -= c[CL::HF + a * D + k] * m[k];
+                e[a] = s;
+            }
+            double mn[D];
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                double s = 0.0, u = eta[a];
+#pragma unroll
+                for (int k = 0; k < D; ++k) s += c[CL::A + a * D + k] * m[k];
+#pragma unroll
+                for (int k = 0; k < DY; ++k) {
+                    s += tb[TL::K + a * DY + k] * e[k];
+                    u += tb[TL::U + a * DY + k] * e[k];
+                }
+                mn[a] = s;
+                eta[a] = u;
+            }
+#pragma unroll
+            for (int a = 0; a < D; ++a) m[a] = mn[a];
+        }
+    }
+    if (live) {
+        double* o = p.elem + (seg * 2 * D) * p.n_chains + chain;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            o[a * p.n_chains] = m[a];
+            o[(D + a) * p.n_chains] = eta[a];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// phase 2: scans over segment boundaries, one lane per (chain, role).
+//   role 0 (prefix): filtered belief at x[1] (prior ⊗ observation), then
+//        f(b_{s+1}) = element_s applied to f(b_s):  W = (V⁻¹ + J)⁻¹,
+//        m' = Π W (V⁻¹ m + η) + b,  V' = Π W Π' + C
+//   role 1 (suffix): backward message β(b_S) = (0, 0), then
+//        β(b_s): W = (C⁻¹ + Λ)⁻¹,  ξ' = η + X' W (ξ − Λ b),  Λ' = JJ − X' W X
+template <int D, int DY, bool UNI, bool FE>
+__global__ void __launch_bounds__(64) k_boundary_scan(Params p) {
+    using CL = CstLayout<D, DY>;
+    using AL = AggLayout<D>;
+    constexpr int NS = Dim<D>::NS;
+    const long long chain = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (chain >= p.n_chains) return;
+    const int role = blockIdx.y;
+    const int mdl = model_of<UNI>(p, chain);
+    const CPtr c{p.cst + (long long)mdl * CL::SIZE};
+    const double* aggm = p.agg + (long long)mdl * 2 * AL::SIZE;
+    const int S = p.S;
+    bool ok = true;
+    if (role == 0) {
+        double mp[D], m[D], yv[DY];
+        Sym<D> Vp, V;
+#pragma unroll
+        for (int i = 0; i < D; ++i) mp[i] = c[CL::M1 + i];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) Vp.v[i] = c[CL::V1 + i];
+        load_y<DY>(p.y, 0, p.n_chains, chain, yv);
+        double l = obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok);
+        store_filt<D>(p.filt, 0, p.n_chains, chain, m, V);
+        if (FE) p.fe_part[chain] = l;
+        if (p.T == 1) {  // single observation: the filtered belief is the posterior
+            double* om = p.mean + chain * D;
+            double* oc = p.cov + chain * D * D;
+#pragma unroll
+            for (int i = 0; i < D; ++i) om[i] = m[i];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) oc[i * D + j] = V(i, j);
+        }
+        for (int s = 0; s < S; ++s) {
+            store_soa<D>(p.fstart, s, p.n_chains, chain, m, V);
+            if (s == S - 1) break;
+            const CPtr a{aggm};  // interior segments always have the full length L
+            const double* el = p.elem + ((long long)s * 2 * D) * p.n_chains + chain;
+            Sym<D> Vi, W, T1;
+            double det;
+            ok = spd_inv<D>(V, Vi, det) && ok;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) T1.v[i] = Vi.v[i] + a[AL::J + i];
+            ok = spd_inv<D>(T1, W, det) && ok;
+            double u[D], w[D];
+            symv<D>(Vi, m, u);
+#pragma unroll
+            for (int i = 0; i < D; ++i) u[i] += el[(D + i) * p.n_chains];
+            symv<D>(W, u, w);
+            // PW = Π W
+            double PW[D][D];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sacc += a[AL::PI + i * D + k] * W(k, j);
+                    PW[i][j] = sacc;
+                }
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double sacc = el[i * p.n_chains];
+#pragma unroll
+                for (int k = 0; k < D; ++k) sacc += a[AL::PI + i * D + k] * w[k];
+                m[i] = sacc;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double sacc = a[AL::C + sidx(i, j)];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sacc += PW[i][k] * a[AL::PI + j * D + k];
+                    V(i, j) = sacc;
+                }
+        }
+    } else {
+        double xi[D];
+        Sym<D> Lm;
+#pragma unroll
+        for (int i = 0; i < D; ++i) xi[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) Lm.v[i] = 0.0;
+        store_soa<D>(p.beta, S, p.n_chains, chain, xi, Lm);
+        for (int s = S - 1; s >= 1; --s) {
+            const CPtr a{aggm + ((s == S - 1) ? AL::SIZE : 0)};
+            const double* el = p.elem + ((long long)s * 2 * D) * p.n_chains + chain;
+            double b[D], eta[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                b[i] = el[i * p.n_chains];
+                eta[i] = el[(D + i) * p.n_chains];
+            }
+            Sym<D> T1, W;
+            double det;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) T1.v[i] = a[AL::CI + i] + Lm.v[i];
+            ok = spd_inv<D>(T1, W, det) && ok;
+            double v[D], w[D];
+            symv<D>(Lm, b, v);
+#pragma unroll
+            for (int i = 0; i < D; ++i) v[i] = xi[i] - v[i];
+            symv<D>(W, v, w);
+            // WX = W X
+            double WX[D][D];
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sacc += W(i, k) * a[AL::X + k * D + j];
+                    WX[i][j] = sacc;
+                }
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double sacc = eta[i];
+#pragma unroll
+                for (int k = 0; k < D; ++k) sacc += a[AL::X + k * D + i] * w[k];
+                xi[i] = sacc;
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j <= i; ++j) {
+                    double sacc = a[AL::JJ + sidx(i, j)];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sacc -= a[AL::X + k * D + i] * WX[k][j];
+                    Lm(i, j) = sacc;
+                }
+            store_soa<D>(p.beta, s, p.n_chains, chain, xi, Lm);
+        }
+    }
+    if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// ------------------------------------------------------------------------------------------
+// phase 3: forward sweep inside each segment.  Per step (reference rule names):
+//   `*`_A(:out)           N(A m, A V A')                       predict_cov / matvec_c
+//   MvN_x(:out)           + P
+//   MvN_y(:μ), `*`_B(:in) observation message (G y, B'Q⁻¹B)     constants LOBS, G
+//   product at x[t]       information-form sum, then mean_cov   obs_update
+//   Bethe FE terms        telescoped to log p(y_t | y_<t)       obs_update<FE>
+template <int D, int DY, bool UNI, bool FE>
+__global__ void __launch_bounds__(64) k_forward(Params p) {
+    using CL = CstLayout<D, DY>;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = p.n_chains * (long long)p.S;
+    const bool live = g < total;
+    const long long seg = live ? g / p.n_chains : 0;
+    const long long chain = live ? g - seg * p.n_chains : 0;
+    const long long len = live ? seg_len(p, seg) : 0;
+    const int mdl = model_of<UNI>(p, chain);
+    const CPtr c{p.cst + (long long)mdl * CL::SIZE};
+    const long long t0 = seg * p.L + 1;  // zero-based time index of the segment's first step
+
+    double m[D];
+    Sym<D> V;
+    if (live) load_soa<D>(p.fstart, seg, p.n_chains, chain, m, V);
+    else {
+#pragma unroll
+        for (int i = 0; i < D; ++i) m[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < Dim<D>::NS; ++i) V.v[i] = (sidx(0, 0) == i || sidx(D - 1, D - 1) == i) ? 1.0 : 0.0;
+    }
+    bool ok = true;
+    double acc = 0.0;
+    double yv[DY], yn[DY];
+    if (len > 0) load_y<DY>(p.y, t0, p.n_chains, chain, yn);
+    for (long long i = 0; i < len; ++i) {
+#pragma unroll
+        for (int k = 0; k < DY; ++k) yv[k] = yn[k];
+        if (i + 1 < len) load_y<DY>(p.y, t0 + i + 1, p.n_chains, chain, yn);
+        double mp[D], T[D][D];
+        Sym<D> Vp;
+        matvec_c<D>(CPtr{c.p + CL::A}, m, mp);
+        predict_cov<D>(CPtr{c.p + CL::A}, CPtr{c.p + CL::P}, V, T, Vp);
+        double l = obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok);
+        if (FE) acc += l;
+        store_filt<D>(p.filt, t0 + i, p.n_chains, chain, m, V);
+    }
+    if (FE && live) p.fe_part[(seg + 1) * p.n_chains + chain] = acc;
+    if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// ------------------------------------------------------------------------------------------
+// phase 4: backward sweep + marginals inside each segment, Rauch–Tung–Striebel form of the
+// reference's backward schedule (MvN_x(:μ) -> `*`_A(:in) -> 3-way product -> mean_cov):
+//   Vp = A V_f A' + P,  G = V_f A' Vp⁻¹,
+//   m_s(t) = m_f + G (m_s(t+1) − A m_f),  V_s(t) = V_f + G (V_s(t+1) − Vp) G'
+// The smoothed belief at the segment's end is (filtered ⊗ β) with β from phase 2.
+template <int D, bool UNI>
+__device__ __forceinline__ void write_marginal(const Params& p, long long t, long long chain, const double (&m)[D],
+                                               const Sym<D>& V) {
+    double* om = p.mean + (t * p.n_chains + chain) * D;
+    double* oc = p.cov + (t * p.n_chains + chain) * D * D;
+    if constexpr (D % 2 == 0) {
+        double2* om2 = reinterpret_cast<double2*>(om);
+#pragma unroll
+        for (int i = 0; i < D / 2; ++i) om2[i] = make_double2(m[2 * i], m[2 * i + 1]);
+        double2* oc2 = reinterpret_cast<double2*>(oc);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D / 2; ++j) oc2[i * (D / 2) + j] = make_double2(V(i, 2 * j), V(i, 2 * j + 1));
+    } else {
+#pragma unroll
+        for (int i = 0; i < D; ++i) om[i] = m[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) oc[i * D + j] = V(i, j);
+    }
+}
+
+template <int D, int DY, bool UNI>
+__global__ void __launch_bounds__(64) k_backward(Params p) {
+    using CL = CstLayout<D, DY>;
+    constexpr int NS = Dim<D>::NS;
+    constexpr int NP2 = Dim<D>::NP2;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = p.n_chains * (long long)p.S;
+    if (g >= total) return;
+    const long long seg = g / p.n_chains;
+    const long long chain = g - seg * p.n_chains;
+    const long long len = seg_len(p, seg);
+    const int mdl = model_of<UNI>(p, chain);
+    const CPtr c{p.cst + (long long)mdl * CL::SIZE};
+    const long long tb = seg * p.L;   // zero-based time index of boundary b_seg
+    const long long te = tb + len;    // zero-based time index of boundary b_{seg+1}
+    bool ok = true;
+
+    // smoothed belief at the end boundary: filtered(te) ⊗ β(b_{seg+1})
+    double ms[D], mf[D];
+    Sym<D> Vs, Vf;
+    {
+        double2 r[NP2];
+        load_filt_raw<D>(p.filt, te, p.n_chains, chain, r);
+        unpack_rec<D>(r, mf, Vf);
+        double xb[D];
+        Sym<D> Lb, Vi, Ls;
+        load_soa<D>(p.beta, seg + 1, p.n_chains, chain, xb, Lb);
+        double det;
+        ok = spd_inv<D>(Vf, Vi, det) && ok;
+        double u[D];
+        symv<D>(Vi, mf, u);
+#pragma unroll
+        for (int i = 0; i < D; ++i) u[i] += xb[i];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) Ls.v[i] = Vi.v[i] + Lb.v[i];
+        ok = spd_inv<D>(Ls, Vs, det) && ok;
+        symv<D>(Vs, u, ms);
+        if (seg == p.S - 1) write_marginal<D, UNI>(p, te, chain, ms, Vs);
+    }
+    double2 rn[NP2];
+    if (len > 0) load_filt_raw<D>(p.filt, te - 1, p.n_chains, chain, rn);
+    for (long long t = te - 1; t >= tb; --t) {
+        unpack_rec<D>(rn, mf, Vf);
+        if (t > tb) load_filt_raw<D>(p.filt, t - 1, p.n_chains, chain, rn);
+        double mp[D], T[D][D];
+        Sym<D> Vp, Lp;
+        matvec_c<D>(CPtr{c.p + CL::A}, mf, mp);
+        predict_cov<D>(CPtr{c.p + CL::A}, CPtr{c.p + CL::P}, Vf, T, Vp);
+        double det;
+        ok = spd_inv<D>(Vp, Lp, det) && ok;
+        // G = T' Lp   (T = A V_f)
+        double G[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) s += T[k][i] * Lp(k, j);
+                G[i][j] = s;
+            }
+        double dm[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) dm[i] = ms[i] - mp[i];
+        Sym<D> Dm;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) Dm.v[i] = Vs.v[i] - Vp.v[i];
+        double H[D][D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double s = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) s += G[i][k] * Dm(k, j);
+                H[i][j] = s;
+            }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double s = mf[i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += G[i][k] * dm[k];
+            ms[i] = s;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                double s = Vf(i, j);
+#pragma unroll
+                for (int k = 0; k < D; ++k) s += H[i][k] * G[j][k];
+                Vs(i, j) = s;
+            }
+        write_marginal<D, UNI>(p, t, chain, ms, Vs);
+    }
+    if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// ------------------------------------------------------------------------------------------
+// Bethe free energy reduction: fe_chain[c] = −Σ_s fe_part[s][c] (fixed order), and the batch
+// total Σ_c fe_chain[c] by a fixed-shape tree (deterministic run to run: needed for 1e-8).
+// Restates the global sum of src/model/plugins/reactivemp_free_energy.jl:101-123
+// (`sumreduce`, src/helpers.jl:21); NaN/Inf check mirrors src/score/diagnostics.jl:19-51.
+__global__ void __launch_bounds__(256) k_fe_reduce(Params p) {
+    __shared__ double sh[256];
+    double local = 0.0;
+    bool bad = false;
+    for (long long ch = threadIdx.x; ch < p.n_chains; ch += 256) {
+        double s = 0.0;
+        for (int k = 0; k <= p.S; ++k) s += p.fe_part[(long long)k * p.n_chains + ch];
+        s = -s;
+        p.fe_chain[ch] = s;
+        bad = bad || !(s - s == 0.0);
+        local += s;
+    }
+    sh[threadIdx.x] = local;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.fe_total[p.iteration] = sh[0];
+    if (bad) atomicOr(p.status, ST_NONFINITE);
+}
+
+}  // namespace rxhip

@@ -1,0 +1,796 @@
+// rxhip.hip — host runtime and C ABI of librxhip (see include/rxhip.h).
+//
+// One engine handle = one batch of factor graphs lowered to a static device schedule:
+// device buffers, per-model constant tables, one HIP stream, optional HIP-event profiling.
+// No CPU fallback: if no HIP device is visible rxhip_lgssm_create fails with
+// RXHIP_ERR_NO_DEVICE (the parity tests must exercise the kernels, never a host path).
+#include "../../include/rxhip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "lgssm_kernels.hpp"
+
+using namespace rxhip;
+
+// ------------------------------------------------------------------------------------------
+// per-(d,dy) dispatch table
+struct LgssmVtbl {
+    int d, dy;
+    int cst_size, tab_size, agg_size;
+    // layout offsets (host table builder writes through these)
+    int oA, oP, oLOBS, oG, oQI, oC0, oM1, oV1, oHF;
+    int tK, tU;
+    int aPI, aC, aJ, aCI, aX, aJJ;
+    void (*seg_aggregate)(const Params&, bool, hipStream_t);
+    void (*boundary_scan)(const Params&, bool, bool, hipStream_t);
+    void (*forward)(const Params&, bool, bool, hipStream_t);
+    void (*backward)(const Params&, bool, hipStream_t);
+};
+
+static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
+
+template <int D, int DY>
+struct Launch {
+    static void seg_aggregate(const Params& p, bool uni, hipStream_t s) {
+        const long long total = p.n_chains * (long long)p.S;
+        if (uni)
+            hipLaunchKernelGGL((k_seg_aggregate<D, DY, true>), dim3(nblk(total, 64)), dim3(64), 0, s, p);
+        else
+            hipLaunchKernelGGL((k_seg_aggregate<D, DY, false>), dim3(nblk(total, 64)), dim3(64), 0, s, p);
+    }
+    static void boundary_scan(const Params& p, bool uni, bool fe, hipStream_t s) {
+        dim3 grid(nblk(p.n_chains, 64), 2);
+        if (uni) {
+            if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, true, true>), grid, dim3(64), 0, s, p);
+            else hipLaunchKernelGGL((k_boundary_scan<D, DY, true, false>), grid, dim3(64), 0, s, p);
+        } else {
+            if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, false, true>), grid, dim3(64), 0, s, p);
+            else hipLaunchKernelGGL((k_boundary_scan<D, DY, false, false>), grid, dim3(64), 0, s, p);
+        }
+    }
+    static void forward(const Params& p, bool uni, bool fe, hipStream_t s) {
+        const long long total = p.n_chains * (long long)p.S;
+        dim3 grid(nblk(total, 64));
+        if (uni) {
+            if (fe) hipLaunchKernelGGL((k_forward<D, DY, true, true>), grid, dim3(64), 0, s, p);
+            else hipLaunchKernelGGL((k_forward<D, DY, true, false>), grid, dim3(64), 0, s, p);
+        } else {
+            if (fe) hipLaunchKernelGGL((k_forward<D, DY, false, true>), grid, dim3(64), 0, s, p);
+            else hipLaunchKernelGGL((k_forward<D, DY, false, false>), grid, dim3(64), 0, s, p);
+        }
+    }
+    static void backward(const Params& p, bool uni, hipStream_t s) {
+        const long long total = p.n_chains * (long long)p.S;
+        dim3 grid(nblk(total, 64));
+        if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((k_backward<D, DY, false>), grid, dim3(64), 0, s, p);
+    }
+    static LgssmVtbl vtbl() {
+        using CL = CstLayout<D, DY>;
+        using TL = TabLayout<D, DY>;
+        using AL = AggLayout<D>;
+        LgssmVtbl v;
+        v.d = D; v.dy = DY;
+        v.cst_size = CL::SIZE; v.tab_size = TL::SIZE; v.agg_size = AL::SIZE;
+        v.oA = CL::A; v.oP = CL::P; v.oLOBS = CL::LOBS; v.oG = CL::G; v.oQI = CL::QI; v.oC0 = CL::C0;
+        v.oM1 = CL::M1; v.oV1 = CL::V1; v.oHF = CL::HF;
+        v.tK = TL::K; v.tU = TL::U;
+        v.aPI = AL::PI; v.aC = AL::C; v.aJ = AL::J; v.aCI = AL::CI; v.aX = AL::X; v.aJJ = AL::JJ;
+        v.seg_aggregate = &Launch::seg_aggregate;
+        v.boundary_scan = &Launch::boundary_scan;
+        v.forward = &Launch::forward;
+        v.backward = &Launch::backward;
+        return v;
+    }
+};
+
+static const std::vector<LgssmVtbl>& vtbls() {
+    static const std::vector<LgssmVtbl> t = {
+        Launch<1, 1>::vtbl(), Launch<2, 1>::vtbl(), Launch<2, 2>::vtbl(), Launch<3, 3>::vtbl(),
+        Launch<4, 2>::vtbl(), Launch<4, 4>::vtbl(),
+    };
+    return t;
+}
+static const LgssmVtbl* find_vtbl(int d, int dy) {
+    for (const auto& v : vtbls())
+        if (v.d == d && v.dy == dy) return &v;
+    return nullptr;
+}
+
+// ------------------------------------------------------------------------------------------
+// layout helpers on device
+__global__ void k_transpose_rows(const double* __restrict__ in, double* __restrict__ out, long long n_outer_in,
+                                 long long n_inner_in, int k) {
+    // in: [n_outer_in][n_inner_in][k]  ->  out: [n_inner_in][n_outer_in][k]
+    const long long total = n_outer_in * n_inner_in * k;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total;
+         g += (long long)gridDim.x * blockDim.x) {
+        const long long e = g % k;
+        const long long r = g / k;
+        const long long o = r % n_outer_in;  // output is contiguous in (inner, outer, k): index by output
+        const long long i = r / n_outer_in;
+        out[g] = in[(o * n_inner_in + i) * k + e];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+struct rxhip_engine {
+    // description
+    int d = 0, dy = 0;
+    long long T = 0, n_chains = 0;
+    int n_models = 1;
+    int ptt = 0;
+    int S = 0;
+    long long L = 0, Llast = 0;
+    bool uniform = true;
+    const LgssmVtbl* vt = nullptr;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    // device memory
+    double* d_y = nullptr;
+    bool own_y = false;
+    bool have_data = false;
+    double *d_filt = nullptr, *d_mean = nullptr, *d_cov = nullptr, *d_cst = nullptr, *d_tab = nullptr,
+           *d_agg = nullptr, *d_elem = nullptr, *d_fstart = nullptr, *d_beta = nullptr, *d_fe_part = nullptr,
+           *d_fe_chain = nullptr, *d_fe_total = nullptr;
+    int* d_chain_model = nullptr;
+    int* d_status = nullptr;
+    int fe_total_cap = 0;
+    // results bookkeeping
+    int last_iterations = 0;
+    bool last_want_fe = false;
+    bool ran = false;
+    uint64_t rule_calls = 0, products = 0, marginals = 0;
+    // profiling
+    bool profiling = false;
+    struct Pending { int k; hipEvent_t a, b; };
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> pool;
+    double k_ms[RXHIP_K_COUNT] = {0, 0, 0, 0, 0};
+    uint64_t k_n[RXHIP_K_COUNT] = {0, 0, 0, 0, 0};
+    std::string err = "";
+};
+
+static rxhip_status fail(rxhip_engine* e, rxhip_status s, const char* fmt, ...) {
+    if (e) {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof buf, fmt, ap);
+        va_end(ap);
+        e->err = buf;
+    }
+    return s;
+}
+#define HIPCHK(e, call)                                                                              \
+    do {                                                                                             \
+        hipError_t _err = (call);                                                                    \
+        if (_err != hipSuccess)                                                                      \
+            return fail((e), RXHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_err), \
+                        __FILE__, __LINE__);                                                         \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// host dense helpers for the per-model tables (generic n; off the hot path)
+namespace host {
+static bool chol_inv(int n, const double* A, double* out, double* logdet) {
+    std::vector<double> L((size_t)n * n, 0.0), Li((size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double s = A[j * n + j];
+        for (int k = 0; k < j; ++k) s -= L[j * n + k] * L[j * n + k];
+        if (!(s > 0.0)) return false;
+        double ljj = std::sqrt(s);
+        L[j * n + j] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            double t = 0.5 * (A[i * n + j] + A[j * n + i]);
+            for (int k = 0; k < j; ++k) t -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = t / ljj;
+        }
+    }
+    if (logdet) {
+        double ld = 0.0;
+        for (int i = 0; i < n; ++i) ld += std::log(L[i * n + i]);
+        *logdet = 2.0 * ld;
+    }
+    for (int j = 0; j < n; ++j) {
+        Li[j * n + j] = 1.0 / L[j * n + j];
+        for (int i = j + 1; i < n; ++i) {
+            double s = 0.0;
+            for (int k = j; k < i; ++k) s -= L[i * n + k] * Li[k * n + j];
+            Li[i * n + j] = s / L[i * n + i];
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double s = 0.0;
+            for (int k = i; k < n; ++k) s += Li[k * n + i] * Li[k * n + j];
+            out[i * n + j] = out[j * n + i] = s;
+        }
+    return true;
+}
+// C[n×k] = A[n×m] B[m×k]
+static void mm(int n, int m, int k, const double* A, const double* B, double* C) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) {
+            double s = 0.0;
+            for (int q = 0; q < m; ++q) s += A[i * m + q] * B[q * k + j];
+            C[i * k + j] = s;
+        }
+}
+// C[n×k] = A[n×m] B'[k×m]
+static void mmT(int n, int m, int k, const double* A, const double* B, double* C) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < k; ++j) {
+            double s = 0.0;
+            for (int q = 0; q < m; ++q) s += A[i * m + q] * B[j * m + q];
+            C[i * k + j] = s;
+        }
+}
+// C[m×k] = A'[n×m] B[n×k]
+static void mTm(int n, int m, int k, const double* A, const double* B, double* C) {
+    for (int i = 0; i < m; ++i)
+        for (int j = 0; j < k; ++j) {
+            double s = 0.0;
+            for (int q = 0; q < n; ++q) s += A[q * m + i] * B[q * k + j];
+            C[i * k + j] = s;
+        }
+}
+static void pack_sym(int n, const double* A, double* out) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) out[sidx(i, j)] = 0.5 * (A[i * n + j] + A[j * n + i]);
+}
+}  // namespace host
+
+// Build constant block, gain tables and element matrices of one model.
+static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgssm_desc* ds, double* cst,
+                                       double* tab, double* agg) {
+    const LgssmVtbl& v = *e->vt;
+    const int d = e->d, dy = e->dy;
+    const double* A = ds->A + (size_t)mdl * d * d;
+    const double* B = ds->B + (size_t)mdl * dy * d;
+    const double* P = ds->P + (size_t)mdl * d * d;
+    const double* Q = ds->Q + (size_t)mdl * dy * dy;
+    const double* m0 = ds->m0 + (size_t)mdl * d;
+    const double* V0 = ds->V0 + (size_t)mdl * d * d;
+    std::vector<double> Qi(dy * dy), tmp(4 * (d + dy) * (d + dy)), G(d * dy), Lobs(d * d), HF(dy * d), V1(d * d),
+        m1(d), scratch(d * d);
+    double ldQ = 0.0;
+    if (!host::chol_inv(dy, Q, Qi.data(), &ldQ))
+        return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: observation noise Q is not positive definite", mdl);
+    if (!host::chol_inv(d, P, scratch.data(), nullptr))
+        return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: state noise P is not positive definite", mdl);
+    host::mTm(dy, d, dy, B, Qi.data(), G.data());    // G = B' Qi  (d×dy)
+    host::mm(d, dy, d, G.data(), B, Lobs.data());    // Lobs = B' Qi B
+    host::mm(dy, d, d, B, A, HF.data());             // HF = B A
+    if (e->ptt) {
+        for (int i = 0; i < d; ++i) {
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += A[i * d + k] * m0[k];
+            m1[i] = s;
+        }
+        host::mm(d, d, d, A, V0, tmp.data());
+        host::mmT(d, d, d, tmp.data(), A, V1.data());
+        for (int i = 0; i < d * d; ++i) V1[i] += P[i];
+    } else {
+        for (int i = 0; i < d; ++i) m1[i] = m0[i];
+        for (int i = 0; i < d * d; ++i) V1[i] = V0[i];
+    }
+    if (!host::chol_inv(d, V1.data(), scratch.data(), nullptr))
+        return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: prior covariance is not positive definite", mdl);
+
+    std::memset(cst, 0, sizeof(double) * v.cst_size);
+    for (int i = 0; i < d * d; ++i) cst[v.oA + i] = A[i];
+    host::pack_sym(d, P, cst + v.oP);
+    host::pack_sym(d, Lobs.data(), cst + v.oLOBS);
+    for (int i = 0; i < d * dy; ++i) cst[v.oG + i] = G[i];
+    host::pack_sym(dy, Qi.data(), cst + v.oQI);
+    cst[v.oC0] = dy * 1.8378770664093454835606594728112 + ldQ;
+    for (int i = 0; i < d; ++i) cst[v.oM1 + i] = m1[i];
+    host::pack_sym(d, V1.data(), cst + v.oV1);
+    for (int i = 0; i < dy * d; ++i) cst[v.oHF + i] = HF[i];
+
+    // gain tables: Kalman filter started from an exactly known state (V = 0)
+    const long long L = e->L;
+    std::vector<double> V(d * d, 0.0), Pi(d * d, 0.0), J(d * d, 0.0), Vp(d * d), S(dy * dy), Si(dy * dy), K(d * dy),
+        HFPi(dy * d), U(d * dy), t1(d * d + dy * d + d * dy), t2(d * d + dy * d + d * dy), Phi(d * d), Ci(d * d),
+        X(d * d), JJ(d * d);
+    for (int i = 0; i < d; ++i) Pi[i * d + i] = 1.0;
+    std::memset(agg, 0, sizeof(double) * 2 * v.agg_size);
+    for (long long i = 1; i <= L; ++i) {
+        host::mm(d, d, d, A, V.data(), t1.data());
+        host::mmT(d, d, d, t1.data(), A, Vp.data());
+        for (int q = 0; q < d * d; ++q) Vp[q] += P[q];
+        host::mm(dy, d, d, B, Vp.data(), t1.data());   // B Vp (dy×d)
+        host::mmT(dy, d, dy, t1.data(), B, S.data());  // B Vp B'
+        for (int q = 0; q < dy * dy; ++q) S[q] += Q[q];
+        if (!host::chol_inv(dy, S.data(), Si.data(), nullptr))
+            return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: innovation covariance not positive definite", mdl);
+        host::mTm(dy, d, dy, t1.data(), Si.data(), K.data());       // K = (B Vp)' Si  (d×dy)
+        host::mm(dy, d, d, HF.data(), Pi.data(), HFPi.data());      // HF Π_{i-1}
+        host::mTm(dy, d, dy, HFPi.data(), Si.data(), U.data());     // U = (HF Π)' Si  (d×dy)
+        host::mm(d, dy, d, U.data(), HFPi.data(), t2.data());       // (HFΠ)' Si (HFΠ)
+        for (int q = 0; q < d * d; ++q) J[q] += t2[q];
+        // V = Vp − K (B Vp)
+        host::mm(d, dy, d, K.data(), t1.data(), t2.data());
+        for (int a = 0; a < d; ++a)
+            for (int b = 0; b <= a; ++b) {
+                double s = 0.5 * ((Vp[a * d + b] - t2[a * d + b]) + (Vp[b * d + a] - t2[b * d + a]));
+                V[a * d + b] = V[b * d + a] = s;
+            }
+        // Π = (A − K HF) Π
+        host::mm(d, dy, d, K.data(), HF.data(), t2.data());
+        for (int q = 0; q < d * d; ++q) Phi[q] = A[q] - t2[q];
+        host::mm(d, d, d, Phi.data(), Pi.data(), t2.data());
+        for (int q = 0; q < d * d; ++q) Pi[q] = t2[q];
+        double* te = tab + (size_t)(i - 1) * v.tab_size;
+        for (int q = 0; q < d * dy; ++q) {
+            te[v.tK + q] = K[q];
+            te[v.tU + q] = U[q];
+        }
+        for (int which = 0; which < 2; ++which) {
+            const long long want = which == 0 ? L : e->Llast;
+            if (i != want) continue;
+            double* ag = agg + (size_t)which * v.agg_size;
+            if (!host::chol_inv(d, V.data(), Ci.data(), nullptr))
+                return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: segment covariance not positive definite", mdl);
+            host::mm(d, d, d, Ci.data(), Pi.data(), X.data());
+            host::mTm(d, d, d, Pi.data(), X.data(), JJ.data());
+            for (int q = 0; q < d * d; ++q) JJ[q] += J[q];
+            for (int q = 0; q < d * d; ++q) {
+                ag[v.aPI + q] = Pi[q];
+                ag[v.aX + q] = X[q];
+            }
+            host::pack_sym(d, V.data(), ag + v.aC);
+            host::pack_sym(d, J.data(), ag + v.aJ);
+            host::pack_sym(d, Ci.data(), ag + v.aCI);
+            host::pack_sym(d, JJ.data(), ag + v.aJJ);
+        }
+    }
+    return RXHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* rxhip_version(void) { return "rxhip 0.1 (gfx950, fp64)"; }
+
+const char* rxhip_status_string(rxhip_status s) {
+    switch (s) {
+        case RXHIP_OK: return "ok";
+        case RXHIP_ERR_BADARG: return "bad argument";
+        case RXHIP_ERR_UNSUPPORTED: return "unsupported node type / graph shape";
+        case RXHIP_ERR_NOT_POSDEF: return "matrix is not positive definite";
+        case RXHIP_ERR_NONFINITE_FE: return "free energy is NaN or Inf";
+        case RXHIP_ERR_HIP: return "HIP runtime error";
+        case RXHIP_ERR_NO_DEVICE: return "no HIP device";
+        case RXHIP_ERR_STATE: return "invalid call order";
+        case RXHIP_ERR_RCCL: return "RCCL error";
+        default: return "unknown status";
+    }
+}
+
+int32_t rxhip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int32_t rxhip_lgssm_supported(int32_t d, int32_t dy) { return find_vtbl(d, dy) ? 1 : 0; }
+
+const char* rxhip_last_error(const rxhip_engine* e) { return e ? e->err.c_str() : "null engine"; }
+
+static void free_all(rxhip_engine* e) {
+    if (e->device >= 0) (void)hipSetDevice(e->device);
+    double** bufs[] = {&e->d_filt, &e->d_mean, &e->d_cov, &e->d_cst, &e->d_tab, &e->d_agg, &e->d_elem,
+                       &e->d_fstart, &e->d_beta, &e->d_fe_part, &e->d_fe_chain, &e->d_fe_total};
+    for (auto b : bufs)
+        if (*b) { (void)hipFree(*b); *b = nullptr; }
+    if (e->own_y && e->d_y) (void)hipFree(e->d_y);
+    e->d_y = nullptr;
+    if (e->d_chain_model) (void)hipFree(e->d_chain_model);
+    if (e->d_status) (void)hipFree(e->d_status);
+    for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
+    for (auto ev : e->pool) (void)hipEventDestroy(ev);
+    e->pending.clear();
+    e->pool.clear();
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+}
+
+rxhip_status rxhip_destroy(rxhip_engine* e) {
+    if (!e) return RXHIP_OK;
+    free_all(e);
+    delete e;
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    *out = nullptr;
+    if (!ds || ds->d <= 0 || ds->dy <= 0 || ds->T <= 0 || ds->n_chains <= 0 || ds->n_models <= 0 || !ds->A ||
+        !ds->B || !ds->P || !ds->Q || !ds->m0 || !ds->V0)
+        return RXHIP_ERR_BADARG;
+    const LgssmVtbl* vt = find_vtbl(ds->d, ds->dy);
+    if (!vt) return RXHIP_ERR_UNSUPPORTED;
+    if (ds->chain_model)
+        for (long long c = 0; c < ds->n_chains; ++c)
+            if (ds->chain_model[c] < 0 || ds->chain_model[c] >= ds->n_models) return RXHIP_ERR_BADARG;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RXHIP_ERR_NO_DEVICE;
+
+    rxhip_engine* e = new rxhip_engine();
+    *out = e;  // returned even on failure so that rxhip_last_error is readable; caller destroys
+    e->vt = vt;
+    e->d = ds->d;
+    e->dy = ds->dy;
+    e->T = ds->T;
+    e->n_chains = ds->n_chains;
+    e->n_models = ds->n_models;
+    e->ptt = ds->prior_through_transition ? 1 : 0;
+    e->uniform = (ds->n_models == 1);
+    if (ds->device >= 0) {
+        if (ds->device >= ndev) return fail(e, RXHIP_ERR_BADARG, "device %d out of range (%d visible)", ds->device, ndev);
+        e->device = ds->device;
+    } else
+        HIPCHK(e, hipGetDevice(&e->device));
+    HIPCHK(e, hipSetDevice(e->device));
+    if (ds->stream) {
+        e->stream = (hipStream_t)ds->stream;
+    } else {
+        HIPCHK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+
+    // time segmentation: enough (chain, segment) lanes to fill 256 CUs × 8 waves × 64 lanes
+    const long long steps = e->T - 1;  // transitions
+    if (steps <= 0) {
+        e->S = 0;
+        e->L = 1;
+        e->Llast = 1;
+    } else {
+        long long S_target = ds->segments > 0 ? ds->segments : (131072 + e->n_chains - 1) / e->n_chains;
+        if (S_target < 1) S_target = 1;
+        long long L = (steps + S_target - 1) / S_target;
+        const long long Lmin = ds->segments > 0 ? 1 : 16;
+        if (L < Lmin) L = Lmin;
+        if (L > steps) L = steps;
+        e->L = L;
+        e->S = (int)((steps + L - 1) / L);
+        e->Llast = steps - (long long)(e->S - 1) * L;
+    }
+
+    // per-model tables
+    const size_t NP = (size_t)e->d + (size_t)e->d * (e->d + 1) / 2;
+    const size_t NP2 = (NP + 1) / 2;
+    std::vector<double> cst((size_t)e->n_models * vt->cst_size), tab((size_t)e->n_models * e->L * vt->tab_size),
+        agg((size_t)e->n_models * 2 * vt->agg_size);
+    for (int m = 0; m < e->n_models; ++m) {
+        rxhip_status st = build_model_tables(e, m, ds, cst.data() + (size_t)m * vt->cst_size,
+                                             tab.data() + (size_t)m * e->L * vt->tab_size,
+                                             agg.data() + (size_t)m * 2 * vt->agg_size);
+        if (st) return st;
+    }
+    const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1);
+    HIPCHK(e, hipMalloc(&e->d_cst, sizeof(double) * cst.size()));
+    HIPCHK(e, hipMalloc(&e->d_tab, sizeof(double) * tab.size()));
+    HIPCHK(e, hipMalloc(&e->d_agg, sizeof(double) * agg.size()));
+    HIPCHK(e, hipMemcpy(e->d_cst, cst.data(), sizeof(double) * cst.size(), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->d_agg, agg.data(), sizeof(double) * agg.size(), hipMemcpyHostToDevice));
+    if (ds->chain_model && !e->uniform) {
+        HIPCHK(e, hipMalloc(&e->d_chain_model, sizeof(int) * C));
+        HIPCHK(e, hipMemcpy(e->d_chain_model, ds->chain_model, sizeof(int) * C, hipMemcpyHostToDevice));
+    }
+    HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * T * NP2 * 2 * C));
+    HIPCHK(e, hipMalloc(&e->d_mean, sizeof(double) * T * C * e->d));
+    HIPCHK(e, hipMalloc(&e->d_cov, sizeof(double) * T * C * e->d * e->d));
+    HIPCHK(e, hipMalloc(&e->d_elem, sizeof(double) * Sg * 2 * e->d * C));
+    HIPCHK(e, hipMalloc(&e->d_fstart, sizeof(double) * Sg * NP * C));
+    HIPCHK(e, hipMalloc(&e->d_beta, sizeof(double) * (Sg + 1) * NP * C));
+    HIPCHK(e, hipMalloc(&e->d_fe_part, sizeof(double) * (Sg + 1) * C));
+    HIPCHK(e, hipMalloc(&e->d_fe_chain, sizeof(double) * C));
+    e->fe_total_cap = 16;
+    HIPCHK(e, hipMalloc(&e->d_fe_total, sizeof(double) * e->fe_total_cap));
+    HIPCHK(e, hipMalloc(&e->d_status, sizeof(int)));
+    HIPCHK(e, hipMemset(e->d_status, 0, sizeof(int)));
+    HIPCHK(e, hipMemset(e->d_fe_part, 0, sizeof(double) * (Sg + 1) * C));
+    HIPCHK(e, hipMemset(e->d_fe_total, 0, sizeof(double) * e->fe_total_cap));
+    return RXHIP_OK;
+}
+
+static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t layout, bool src_on_device) {
+    if (!e) return RXHIP_ERR_BADARG;
+    const size_t need = (size_t)e->T * e->n_chains * e->dy;
+    if (!src || n != need) return fail(e, RXHIP_ERR_BADARG, "set_data: expected %zu doubles, got %zu", need, n);
+    if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
+        return fail(e, RXHIP_ERR_BADARG, "set_data: unknown layout %d", layout);
+    HIPCHK(e, hipSetDevice(e->device));
+    if (src_on_device && layout == RXHIP_LAYOUT_TIME_CHAIN) {  // zero-copy
+        if (e->own_y && e->d_y) HIPCHK(e, hipFree(e->d_y));
+        e->d_y = const_cast<double*>(src);
+        e->own_y = false;
+        e->have_data = true;
+        return RXHIP_OK;
+    }
+    if (!e->own_y || !e->d_y) {
+        e->d_y = nullptr;
+        HIPCHK(e, hipMalloc(&e->d_y, sizeof(double) * need));
+        e->own_y = true;
+    }
+    if (layout == RXHIP_LAYOUT_TIME_CHAIN) {
+        HIPCHK(e, hipMemcpyAsync(e->d_y, src, sizeof(double) * need, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+    } else {
+        double* tmp = nullptr;
+        const double* dsrc = src;
+        if (!src_on_device) {
+            HIPCHK(e, hipMalloc(&tmp, sizeof(double) * need));
+            HIPCHK(e, hipMemcpyAsync(tmp, src, sizeof(double) * need, hipMemcpyHostToDevice, e->stream));
+            dsrc = tmp;
+        }
+        // [chain][T][dy] -> [T][chain][dy]
+        hipLaunchKernelGGL(k_transpose_rows, dim3(2048), dim3(256), 0, e->stream, dsrc, e->d_y, e->n_chains, e->T,
+                           e->dy);
+        HIPCHK(e, hipGetLastError());
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (tmp) HIPCHK(e, hipFree(tmp));
+    }
+    e->have_data = true;
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_set_data(rxhip_engine* e, int32_t var_id, const double* host, size_t n, int32_t layout) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (var_id != RXHIP_VAR_Y) return fail(e, RXHIP_ERR_BADARG, "set_data: variable %d is not a data variable", var_id);
+    return ingest(e, host, n, layout, false);
+}
+rxhip_status rxhip_set_data_device(rxhip_engine* e, int32_t var_id, const double* dev, size_t n, int32_t layout) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (var_id != RXHIP_VAR_Y) return fail(e, RXHIP_ERR_BADARG, "set_data: variable %d is not a data variable", var_id);
+    return ingest(e, dev, n, layout, true);
+}
+
+static rxhip_status prof_begin(rxhip_engine* e, int k) {
+    if (!e->profiling) return RXHIP_OK;
+    rxhip_engine::Pending p;
+    p.k = k;
+    for (hipEvent_t* ev : {&p.a, &p.b}) {
+        if (!e->pool.empty()) {
+            *ev = e->pool.back();
+            e->pool.pop_back();
+        } else
+            HIPCHK(e, hipEventCreate(ev));
+    }
+    HIPCHK(e, hipEventRecord(p.a, e->stream));
+    e->pending.push_back(p);
+    return RXHIP_OK;
+}
+static rxhip_status prof_end(rxhip_engine* e) {
+    if (!e->profiling) return RXHIP_OK;
+    HIPCHK(e, hipEventRecord(e->pending.back().b, e->stream));
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
+    if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (iterations > e->fe_total_cap) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        HIPCHK(e, hipFree(e->d_fe_total));
+        e->d_fe_total = nullptr;
+        e->fe_total_cap = iterations;
+        HIPCHK(e, hipMalloc(&e->d_fe_total, sizeof(double) * e->fe_total_cap));
+    }
+    Params p;
+    p.T = e->T;
+    p.n_chains = e->n_chains;
+    p.S = e->S;
+    p.L = e->L;
+    p.n_models = e->n_models;
+    p.y = e->d_y;
+    p.filt = e->d_filt;
+    p.mean = e->d_mean;
+    p.cov = e->d_cov;
+    p.cst = e->d_cst;
+    p.tab = e->d_tab;
+    p.agg = e->d_agg;
+    p.chain_model = e->d_chain_model;
+    p.elem = e->d_elem;
+    p.fstart = e->d_fstart;
+    p.beta = e->d_beta;
+    p.fe_part = e->d_fe_part;
+    p.fe_chain = e->d_fe_chain;
+    p.fe_total = e->d_fe_total;
+    p.status = e->d_status;
+    const bool fe = want_fe != 0;
+    rxhip_status st;
+    for (int it = 0; it < iterations; ++it) {
+        p.iteration = it;
+        if (e->S > 0) {
+            if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
+            e->vt->seg_aggregate(p, e->uniform, e->stream);
+            if ((st = prof_end(e))) return st;
+        }
+        if ((st = prof_begin(e, RXHIP_K_BOUNDARY_SCAN))) return st;
+        e->vt->boundary_scan(p, e->uniform, fe, e->stream);
+        if ((st = prof_end(e))) return st;
+        if (e->S > 0) {
+            if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
+            e->vt->forward(p, e->uniform, fe, e->stream);
+            if ((st = prof_end(e))) return st;
+            if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
+            e->vt->backward(p, e->uniform, e->stream);
+            if ((st = prof_end(e))) return st;
+        }
+        if (fe) {
+            if ((st = prof_begin(e, RXHIP_K_FE_REDUCE))) return st;
+            hipLaunchKernelGGL(k_fe_reduce, dim3(1), dim3(256), 0, e->stream, p);
+            if ((st = prof_end(e))) return st;
+        }
+    }
+    HIPCHK(e, hipGetLastError());
+    e->last_iterations = iterations;
+    e->last_want_fe = fe;
+    e->ran = true;
+    // reference-equivalent operation counts (6 rule calls, 4 products per step)
+    const uint64_t C = (uint64_t)e->n_chains, T = (uint64_t)e->T, I = (uint64_t)iterations;
+    e->rule_calls = I * C * (e->ptt ? 6 * T + 1 : 6 * T - 3);
+    e->products = I * C * (e->ptt ? 4 * T - 2 : (T == 1 ? 1 : 4 * T - 4));
+    e->marginals = I * C * (e->ptt ? T + 1 : T);
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_sync(rxhip_engine* e) {
+    if (!e) return RXHIP_ERR_BADARG;
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    for (auto& pe : e->pending) {
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, pe.a, pe.b));
+        e->k_ms[pe.k] += ms;
+        e->k_n[pe.k] += 1;
+        e->pool.push_back(pe.a);
+        e->pool.push_back(pe.b);
+    }
+    e->pending.clear();
+    int st = 0;
+    HIPCHK(e, hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    if (st) {
+        HIPCHK(e, hipMemset(e->d_status, 0, sizeof(int)));
+        if (st & ST_NOT_POSDEF)
+            return fail(e, RXHIP_ERR_NOT_POSDEF, "a covariance / precision block lost positive definiteness on device");
+        return fail(e, RXHIP_ERR_NONFINITE_FE, "free energy is NaN or Inf");
+    }
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_run(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
+    rxhip_status st = rxhip_run_async(e, iterations, want_fe);
+    if (st) return st;
+    return rxhip_sync(e);
+}
+
+rxhip_status rxhip_get_marginals_device(rxhip_engine* e, int32_t var_id, const double** mean_dev,
+                                        const double** cov_dev) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (var_id != RXHIP_VAR_X) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
+    if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals: no run yet");
+    if (mean_dev) *mean_dev = e->d_mean;
+    if (cov_dev) *cov_dev = e->d_cov;
+    return RXHIP_OK;
+}
+
+static rxhip_status copy_out(rxhip_engine* e, const double* dsrc, double* host, int k, int32_t layout) {
+    const size_t n = (size_t)e->T * e->n_chains * k;
+    if (layout == RXHIP_LAYOUT_TIME_CHAIN) {
+        HIPCHK(e, hipMemcpy(host, dsrc, sizeof(double) * n, hipMemcpyDeviceToHost));
+        return RXHIP_OK;
+    }
+    double* tmp = nullptr;
+    HIPCHK(e, hipMalloc(&tmp, sizeof(double) * n));
+    // [T][chain][k] -> [chain][T][k]
+    hipLaunchKernelGGL(k_transpose_rows, dim3(2048), dim3(256), 0, e->stream, dsrc, tmp, e->T, e->n_chains, k);
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(host, tmp, sizeof(double) * n, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipFree(tmp));
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (var_id != RXHIP_VAR_X) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
+    if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals: no run yet");
+    if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
+        return fail(e, RXHIP_ERR_BADARG, "get_marginals: unknown layout %d", layout);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    rxhip_status st;
+    if (mean && (st = copy_out(e, e->d_mean, mean, e->d, layout))) return st;
+    if (cov && (st = copy_out(e, e->d_cov, cov, e->d * e->d, layout))) return st;
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_get_free_energy(rxhip_engine* e, double* per_iteration) {
+    if (!e || !per_iteration) return RXHIP_ERR_BADARG;
+    if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(per_iteration, e->d_fe_total, sizeof(double) * e->last_iterations, hipMemcpyDeviceToHost));
+    return RXHIP_OK;
+}
+rxhip_status rxhip_get_free_energy_per_chain(rxhip_engine* e, double* per_chain) {
+    if (!e || !per_chain) return RXHIP_ERR_BADARG;
+    if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(per_chain, e->d_fe_chain, sizeof(double) * e->n_chains, hipMemcpyDeviceToHost));
+    return RXHIP_OK;
+}
+rxhip_status rxhip_get_free_energy_device(rxhip_engine* e, double** fe_dev) {
+    if (!e || !fe_dev) return RXHIP_ERR_BADARG;
+    if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
+    *fe_dev = e->d_fe_total + (e->last_iterations - 1);
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_copy_free_energy_to_device(rxhip_engine* e, double* dst_dev) {
+    if (!e || !dst_dev) return RXHIP_ERR_BADARG;
+    if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipMemcpyAsync(dst_dev, e->d_fe_total + (e->last_iterations - 1), sizeof(double),
+                             hipMemcpyDeviceToDevice, e->stream));
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_counters(rxhip_engine* e, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (rule_calls) *rule_calls = e->rule_calls;
+    if (products) *products = e->products;
+    if (marginals) *marginals = e->marginals;
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_set_profiling(rxhip_engine* e, int32_t enabled) {
+    if (!e) return RXHIP_ERR_BADARG;
+    e->profiling = enabled != 0;
+    return RXHIP_OK;
+}
+rxhip_status rxhip_get_kernel_times(rxhip_engine* e, double* ms_avg, uint64_t* launches) {
+    if (!e) return RXHIP_ERR_BADARG;
+    for (int k = 0; k < RXHIP_K_COUNT; ++k) {
+        if (ms_avg) ms_avg[k] = e->k_n[k] ? e->k_ms[k] / (double)e->k_n[k] : 0.0;
+        if (launches) launches[k] = e->k_n[k];
+    }
+    return RXHIP_OK;
+}
+rxhip_status rxhip_reset_kernel_times(rxhip_engine* e) {
+    if (!e) return RXHIP_ERR_BADARG;
+    for (int k = 0; k < RXHIP_K_COUNT; ++k) {
+        e->k_ms[k] = 0.0;
+        e->k_n[k] = 0;
+    }
+    return RXHIP_OK;
+}
+rxhip_status rxhip_get_stream(rxhip_engine* e, void** stream) {
+    if (!e || !stream) return RXHIP_ERR_BADARG;
+    *stream = (void*)e->stream;
+    return RXHIP_OK;
+}
+rxhip_status rxhip_get_schedule(rxhip_engine* e, int32_t* segments, int64_t* segment_len) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (segments) *segments = e->S;
+    if (segment_len) *segment_len = e->L;
+    return RXHIP_OK;
+}
+
+}  // extern "C"

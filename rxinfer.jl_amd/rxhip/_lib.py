@@ -1,0 +1,83 @@
+"""ctypes binding of librxhip.so (include/rxhip.h).  The library is the product; this module is
+plumbing.  It fails loudly when the HIP extension is missing: there is no CPU fallback."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "librxhip.so"))
+
+c_double_p = ctypes.POINTER(ctypes.c_double)
+c_int32_p = ctypes.POINTER(ctypes.c_int32)
+c_u64_p = ctypes.POINTER(ctypes.c_uint64)
+
+OK, ERR_BADARG, ERR_UNSUPPORTED, ERR_NOT_POSDEF, ERR_NONFINITE_FE, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_RCCL = range(9)
+LAYOUT_TIME_CHAIN, LAYOUT_CHAIN_TIME = 0, 1
+VAR_Y, VAR_X = 0, 1
+K_SEG_AGGREGATE, K_BOUNDARY_SCAN, K_FORWARD, K_BACKWARD, K_FE_REDUCE, K_COUNT = range(6)
+KERNEL_NAMES = ["k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce"]
+
+
+class LgssmDesc(ctypes.Structure):
+    _fields_ = [
+        ("d", ctypes.c_int32), ("dy", ctypes.c_int32), ("T", ctypes.c_int64), ("n_chains", ctypes.c_int64),
+        ("n_models", ctypes.c_int32), ("prior_through_transition", ctypes.c_int32),
+        ("A", c_double_p), ("B", c_double_p), ("P", c_double_p), ("Q", c_double_p), ("m0", c_double_p),
+        ("V0", c_double_p), ("chain_model", c_int32_p), ("segments", ctypes.c_int32), ("device", ctypes.c_int32),
+        ("stream", ctypes.c_void_p),
+    ]
+
+
+# every symbol include/rxhip.h declares: (name, restype, argtypes)
+_H = ctypes.c_void_p
+SYMBOLS = [
+    ("rxhip_lgssm_create", ctypes.c_int32, [ctypes.POINTER(LgssmDesc), ctypes.POINTER(_H)]),
+    ("rxhip_lgssm_supported", ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
+    ("rxhip_set_data", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, ctypes.c_size_t, ctypes.c_int32]),
+    ("rxhip_set_data_device", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32]),
+    ("rxhip_run", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.c_int32]),
+    ("rxhip_run_async", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.c_int32]),
+    ("rxhip_sync", ctypes.c_int32, [_H]),
+    ("rxhip_get_marginals", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_int32]),
+    ("rxhip_get_marginals_device", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p),
+                                                    ctypes.POINTER(ctypes.c_void_p)]),
+    ("rxhip_get_free_energy", ctypes.c_int32, [_H, c_double_p]),
+    ("rxhip_get_free_energy_per_chain", ctypes.c_int32, [_H, c_double_p]),
+    ("rxhip_get_free_energy_device", ctypes.c_int32, [_H, ctypes.POINTER(ctypes.c_void_p)]),
+    ("rxhip_copy_free_energy_to_device", ctypes.c_int32, [_H, ctypes.c_void_p]),
+    ("rxhip_counters", ctypes.c_int32, [_H, c_u64_p, c_u64_p, c_u64_p]),
+    ("rxhip_set_profiling", ctypes.c_int32, [_H, ctypes.c_int32]),
+    ("rxhip_get_kernel_times", ctypes.c_int32, [_H, c_double_p, c_u64_p]),
+    ("rxhip_reset_kernel_times", ctypes.c_int32, [_H]),
+    ("rxhip_get_stream", ctypes.c_int32, [_H, ctypes.POINTER(ctypes.c_void_p)]),
+    ("rxhip_get_schedule", ctypes.c_int32, [_H, c_int32_p, ctypes.POINTER(ctypes.c_int64)]),
+    ("rxhip_last_error", ctypes.c_char_p, [_H]),
+    ("rxhip_status_string", ctypes.c_char_p, [ctypes.c_int32]),
+    ("rxhip_version", ctypes.c_char_p, []),
+    ("rxhip_device_count", ctypes.c_int32, []),
+    ("rxhip_destroy", ctypes.c_int32, [_H]),
+]
+
+_LIB = None
+
+
+class RxHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(f"rxhip status {status}: {message}")
+        self.status = status
+
+
+def lib():
+    """Load librxhip.so.  Raises if the HIP extension has not been built (no fallback)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build the HIP extension first "
+                "(python -c 'import __graft_entry__ as g; g.build()' or make -C rxinfer.jl_amd/csrc)")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, res, args in SYMBOLS:
+            fn = getattr(L, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB

@@ -1,0 +1,172 @@
+"""LGSSMEngine — thin object wrapper over the rxhip C ABI (one handle = one batch of chains)."""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import RxHipError, c_double_p
+
+
+def _c(a, shape=None):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def _p(a):
+    return a.ctypes.data_as(c_double_p)
+
+
+class LGSSMEngine:
+    """Batch of linear Gaussian state-space factor graphs on one MI355X.
+
+    A, B, P, Q, m0, V0 may carry a leading model axis ([n_models, ...]); chain_model maps chains
+    to models.  P is the state-noise covariance, Q the observation-noise covariance (the
+    benchmark notebook's naming; test/models/statespace/mlgssm_test.jl swaps the two names).
+    """
+
+    def __init__(self, A, B, P, Q, m0, V0, T, n_chains=1, chain_model=None, prior_through_transition=False,
+                 segments=0, device=-1, stream=None):
+        L = _lib.lib()
+        A = _c(A)
+        B = _c(B)
+        if A.ndim == 2:
+            A, B, P, Q, m0, V0 = (np.asarray(x, dtype=np.float64)[None] for x in (A, B, P, Q, m0, V0))
+        self.n_models = A.shape[0]
+        self.d = A.shape[-1]
+        self.dy = _c(B).shape[-2]
+        self.T = int(T)
+        self.n_chains = int(n_chains)
+        d, dy, M = self.d, self.dy, self.n_models
+        self._keep = [_c(A, (M, d, d)), _c(B, (M, dy, d)), _c(P, (M, d, d)), _c(Q, (M, dy, dy)), _c(m0, (M, d)),
+                      _c(V0, (M, d, d))]
+        desc = _lib.LgssmDesc()
+        desc.d, desc.dy, desc.T, desc.n_chains, desc.n_models = d, dy, self.T, self.n_chains, M
+        desc.prior_through_transition = int(bool(prior_through_transition))
+        desc.A, desc.B, desc.P, desc.Q, desc.m0, desc.V0 = (_p(x) for x in self._keep)
+        if chain_model is not None:
+            cm = np.ascontiguousarray(chain_model, dtype=np.int32)
+            if cm.shape != (self.n_chains,):
+                raise ValueError("chain_model must have one entry per chain")
+            self._keep.append(cm)
+            desc.chain_model = cm.ctypes.data_as(_lib.c_int32_p)
+        desc.segments = int(segments)
+        desc.device = int(device)
+        desc.stream = ctypes.c_void_p(stream) if stream else None
+        self._h = ctypes.c_void_p()
+        st = L.rxhip_lgssm_create(ctypes.byref(desc), ctypes.byref(self._h))
+        if st != _lib.OK:
+            msg = L.rxhip_last_error(self._h).decode() if self._h else L.rxhip_status_string(st).decode()
+            if self._h:
+                L.rxhip_destroy(self._h)
+                self._h = None
+            raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
+        self._data_ref = None
+
+    # -- plumbing ---------------------------------------------------------------------------
+    def _chk(self, st):
+        if st != _lib.OK:
+            raise RxHipError(st, _lib.lib().rxhip_last_error(self._h).decode())
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _lib.lib().rxhip_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    # -- data -------------------------------------------------------------------------------
+    def set_data(self, y, layout="time_chain"):
+        """y: [T][chain][dy] (layout='time_chain') or [chain][T][dy] ('chain_time'), host array."""
+        y = _c(y)
+        lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
+        self._chk(_lib.lib().rxhip_set_data(self._h, _lib.VAR_Y, _p(y), y.size, lay))
+
+    def set_data_device(self, ptr, n, layout="time_chain", keepalive=None):
+        """Observations already in device memory (e.g. a torch tensor's data_ptr())."""
+        lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
+        self._data_ref = keepalive
+        self._chk(_lib.lib().rxhip_set_data_device(self._h, _lib.VAR_Y, ctypes.c_void_p(ptr), n, lay))
+
+    # -- inference --------------------------------------------------------------------------
+    def run(self, iterations=1, free_energy=True):
+        self._chk(_lib.lib().rxhip_run(self._h, int(iterations), int(bool(free_energy))))
+        self._iters = int(iterations)
+
+    def run_async(self, iterations=1, free_energy=True):
+        self._chk(_lib.lib().rxhip_run_async(self._h, int(iterations), int(bool(free_energy))))
+        self._iters = int(iterations)
+
+    def sync(self):
+        self._chk(_lib.lib().rxhip_sync(self._h))
+
+    def marginals(self, layout="time_chain", want_cov=True):
+        d, T, C = self.d, self.T, self.n_chains
+        lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
+        shp = (T, C) if layout == "time_chain" else (C, T)
+        mean = np.empty(shp + (d,))
+        cov = np.empty(shp + (d, d)) if want_cov else None
+        self._chk(_lib.lib().rxhip_get_marginals(self._h, _lib.VAR_X, _p(mean), _p(cov) if want_cov else None, lay))
+        return mean, cov
+
+    def marginals_device(self):
+        m, c = ctypes.c_void_p(), ctypes.c_void_p()
+        self._chk(_lib.lib().rxhip_get_marginals_device(self._h, _lib.VAR_X, ctypes.byref(m), ctypes.byref(c)))
+        return m.value, c.value
+
+    def free_energy(self):
+        out = np.empty(self._iters)
+        self._chk(_lib.lib().rxhip_get_free_energy(self._h, _p(out)))
+        return out
+
+    def free_energy_per_chain(self):
+        out = np.empty(self.n_chains)
+        self._chk(_lib.lib().rxhip_get_free_energy_per_chain(self._h, _p(out)))
+        return out
+
+    def free_energy_device(self):
+        p = ctypes.c_void_p()
+        self._chk(_lib.lib().rxhip_get_free_energy_device(self._h, ctypes.byref(p)))
+        return p.value
+
+    def copy_free_energy_to_device(self, dst_ptr):
+        self._chk(_lib.lib().rxhip_copy_free_energy_to_device(self._h, ctypes.c_void_p(dst_ptr)))
+
+    def counters(self):
+        r, p, m = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+        self._chk(_lib.lib().rxhip_counters(self._h, ctypes.byref(r), ctypes.byref(p), ctypes.byref(m)))
+        return {"rule_calls": r.value, "products": p.value, "marginals": m.value}
+
+    # -- measurement ------------------------------------------------------------------------
+    def set_profiling(self, on=True):
+        self._chk(_lib.lib().rxhip_set_profiling(self._h, int(bool(on))))
+
+    def reset_kernel_times(self):
+        self._chk(_lib.lib().rxhip_reset_kernel_times(self._h))
+
+    def kernel_times(self):
+        ms = (ctypes.c_double * _lib.K_COUNT)()
+        n = (ctypes.c_uint64 * _lib.K_COUNT)()
+        self._chk(_lib.lib().rxhip_get_kernel_times(self._h, ms, n))
+        return {name: {"ms_avg": ms[i], "launches": n[i]} for i, name in enumerate(_lib.KERNEL_NAMES)}
+
+    def schedule(self):
+        s, l = ctypes.c_int32(), ctypes.c_int64()
+        self._chk(_lib.lib().rxhip_get_schedule(self._h, ctypes.byref(s), ctypes.byref(l)))
+        return {"segments": s.value, "segment_len": l.value}
+
+    def stream(self):
+        p = ctypes.c_void_p()
+        self._chk(_lib.lib().rxhip_get_stream(self._h, ctypes.byref(p)))
+        return p.value

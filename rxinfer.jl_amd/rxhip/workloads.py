@@ -1,0 +1,68 @@
+"""Synthetic workloads of BASELINE.json / SURVEY.md §8(d) (shared by tests and bench.py)."""
+import numpy as np
+
+
+def rot(theta):
+    return np.array([[np.cos(theta), -np.sin(theta)], [np.sin(theta), np.cos(theta)]])
+
+
+def c1_model():
+    """C1/C2 model: d = dy = 4.  A = blockdiag(R(π/15), R(π/35)) (benchmarks notebook cell 6,
+    test/models/statespace/mlgssm_test.jl:90-91), B = diag(1.3,0.7,1.3,0.7), state noise 0.05·I,
+    observation noise 10·I, prior N(0, 100·I)."""
+    A = np.zeros((4, 4))
+    A[:2, :2] = rot(np.pi / 15)
+    A[2:, 2:] = rot(np.pi / 35)
+    B = np.diag([1.3, 0.7, 1.3, 0.7])
+    P = 0.05 * np.eye(4)
+    Q = 10.0 * np.eye(4)
+    return dict(A=A, B=B, P=P, Q=Q, m0=np.zeros(4), V0=100.0 * np.eye(4))
+
+
+def notebook_model():
+    """d = 2 model of the benchmark notebook (cell 6)."""
+    return dict(A=rot(np.pi / 15), B=np.diag([1.3, 0.7]), P=0.05 * np.eye(2), Q=10.0 * np.eye(2), m0=np.zeros(2),
+                V0=100.0 * np.eye(2))
+
+
+def generate_chain(model, T, seed):
+    """Generative loop of the notebook (cell 5) with numpy's default_rng(seed): returns x [T][d], y [T][dy]."""
+    A, B, P, Q = model["A"], model["B"], model["P"], model["Q"]
+    d, dy = A.shape[0], B.shape[0]
+    rng = np.random.default_rng(seed)
+    Lp = np.linalg.cholesky(P)
+    Lq = np.linalg.cholesky(Q)
+    wx = rng.standard_normal((T, d)) @ Lp.T
+    wy = rng.standard_normal((T, dy)) @ Lq.T
+    x = np.zeros((T, d))
+    xp = np.zeros(d)
+    for t in range(T):
+        xp = A @ xp + wx[t]
+        x[t] = xp
+    y = x @ B.T + wy
+    return x, y
+
+
+def generate_batch(model, T, n_chains, seed0=42):
+    """y [T][chain][dy]; chain c uses default_rng(seed0 + c)."""
+    dy = model["B"].shape[0]
+    y = np.empty((T, n_chains, dy))
+    for c in range(n_chains):
+        y[:, c, :] = generate_chain(model, T, seed0 + c)[1]
+    return y
+
+
+def random_model(d, dy, seed, stable=0.95):
+    """Random dense, well-conditioned model for parity tests."""
+    rng = np.random.default_rng(seed)
+    Qm, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    A = stable * Qm
+    B = rng.standard_normal((dy, d)) / np.sqrt(d) + (np.eye(dy, d) if dy <= d else 0.0)
+    Wp = rng.standard_normal((d, d)) * 0.3
+    P = Wp @ Wp.T + 0.1 * np.eye(d)
+    Wq = rng.standard_normal((dy, dy)) * 0.5
+    Q = Wq @ Wq.T + 0.5 * np.eye(dy)
+    Wv = rng.standard_normal((d, d))
+    V0 = Wv @ Wv.T + np.eye(d)
+    m0 = rng.standard_normal(d)
+    return dict(A=A, B=B, P=P, Q=Q, m0=m0, V0=V0)

@@ -1,0 +1,86 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol that
+include/rxhip.h declares; argument validation that needs no GPU; host-side API mirror."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import rxhip
+from rxhip import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_symbols():
+    src = open(os.path.join(ROOT, "include", "rxhip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rxhip_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    declared = _header_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(L, name), f"{name} declared in include/rxhip.h but not exported"
+    # and the python binding knows all of them
+    bound = {s[0] for s in _lib.SYMBOLS}
+    assert set(declared) == bound
+
+
+def test_version_and_status_strings():
+    L = rxhip.lib()
+    assert b"rxhip" in L.rxhip_version()
+    assert L.rxhip_status_string(0) == b"ok"
+    assert L.rxhip_status_string(_lib.ERR_NOT_POSDEF) != L.rxhip_status_string(_lib.ERR_HIP)
+
+
+def test_supported_dimensions():
+    L = rxhip.lib()
+    for d, dy in [(1, 1), (2, 2), (4, 4), (4, 2), (2, 1), (3, 3)]:
+        assert L.rxhip_lgssm_supported(d, dy) == 1
+    assert L.rxhip_lgssm_supported(5, 7) == 0
+
+
+def test_bad_descriptor_rejected_without_gpu():
+    L = rxhip.lib()
+    h = ctypes.c_void_p()
+    assert L.rxhip_lgssm_create(None, ctypes.byref(h)) == _lib.ERR_BADARG
+    desc = _lib.LgssmDesc()  # zeroed
+    assert L.rxhip_lgssm_create(ctypes.byref(desc), ctypes.byref(h)) == _lib.ERR_BADARG
+    assert not h.value
+
+
+def test_unsupported_dimension_is_reported():
+    I = np.eye(5)
+    with pytest.raises(rxhip.RxHipError) as ei:
+        rxhip.LGSSMEngine(I, I, I, I, np.zeros(5), I, T=10)
+    assert ei.value.status == _lib.ERR_UNSUPPORTED
+
+
+@pytest.mark.skipif(rxhip.lib().rxhip_device_count() > 0, reason="checks the no-device error path")
+def test_no_cpu_fallback():
+    """Without a GPU the product refuses to run (it must never silently compute on the host)."""
+    I = np.eye(4)
+    with pytest.raises(rxhip.RxHipError) as ei:
+        rxhip.LGSSMEngine(I, I, I, I, np.zeros(4), I, T=10)
+    assert ei.value.status == _lib.ERR_NO_DEVICE
+
+
+def test_infer_rejects_unknown_options():
+    # closed option key set, as src/model/plugins/reactivemp_inference.jl:129-143
+    mdl = rxhip.linear_gaussian_ssm(np.eye(2), np.eye(2), np.eye(2), np.eye(2), np.zeros(2), np.eye(2))
+    with pytest.raises(ValueError):
+        rxhip.infer(model=mdl, data={"y": np.zeros((3, 2))}, options={"no_such_option": 1})
+
+
+def test_product_does_not_import_oracle():
+    """The shipped package must not reference anything under oracle/."""
+    pkg = os.path.join(ROOT, "rxinfer.jl_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".jl")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "rxoracle" not in txt and "oracle/" not in txt, os.path.join(dp, f)
