@@ -99,7 +99,8 @@ struct Params {
     int n_models;
     // device buffers
     const double* y;        // [T][chain][DY]
-    double* filt;           // [T][NP2][chain][2]   filtered message (m_f, V_f packed)
+    double* filt;           // [T][chain/64][NP2][64][2]   filtered message (m_f, V_f packed), wave-blocked
+    long long nb64;         // ceil(n_chains / 64)
     double* mean;           // [T][chain][D]
     double* cov;            // [T][chain][D][D]
     const double* cst;      // [n_models][CstLayout::SIZE]
@@ -189,6 +190,18 @@ struct CPtr {
     const double* p;
     __device__ __forceinline__ double operator[](int i) const { return p[i]; }
 };
+// When every chain uses the same model the constant block travels BY VALUE in the kernel
+// argument segment: kernarg reads are scalar loads (s_load_*) that in-loop global stores can
+// never alias, and the values feed v_fma_f64 straight from SGPRs.  (Read through the global
+// pointer instead, the compiler must assume the stores clobber them and re-fetches all ~60
+// constants with vector loads every step — measured: 58 % of k_forward's wave cycles in
+// s_waitcnt.)  With per-chain models the kernels fall back to per-lane global loads.
+template <int N>
+struct CstArg {
+    double v[N];
+};
+template <bool UNI, int N>
+using CstArgFor = CstArg<UNI ? N : 1>;
 
 // Vp = A V A' + P ; also returns T = A V (needed by the smoother gain)
 template <int D>
@@ -268,7 +281,8 @@ __device__ __forceinline__ double obs_update(const CPtr c, const double (&mp)[D]
 }
 
 // record I/O.  A Gaussian record is NP = D + NS doubles: vector, then packed lower triangle.
-// filt layout [T][NP2][chain][2]: lane = chain, every 16-byte access of a wave is contiguous.
+// filt layout [T][chain/64][NP2][64][2]: lane = chain % 64; every 16-byte access of a wave is one
+// contiguous 1 KiB run and the NP2 accesses of a wave-step cover one contiguous NP2 KiB block.
 template <int D>
 __device__ __forceinline__ void store_filt(double* filt, long long t, long long n_chains, long long chain,
                                            const double (&m)[D], const Sym<D>& V) {
@@ -279,17 +293,19 @@ __device__ __forceinline__ void store_filt(double* filt, long long t, long long 
 #pragma unroll
     for (int i = 0; i < Dim<D>::NS; ++i) r[D + i] = V.v[i];
     if (NP < 2 * NP2) r[2 * NP2 - 1] = 0.0;
-    double2* base = reinterpret_cast<double2*>(filt) + (t * NP2) * n_chains + chain;
+    const long long nb64 = (n_chains + 63) >> 6;
+    double2* base = reinterpret_cast<double2*>(filt) + ((t * nb64 + (chain >> 6)) * NP2) * 64 + (chain & 63);
 #pragma unroll
-    for (int k = 0; k < NP2; ++k) base[k * n_chains] = make_double2(r[2 * k], r[2 * k + 1]);
+    for (int k = 0; k < NP2; ++k) base[k * 64] = make_double2(r[2 * k], r[2 * k + 1]);
 }
 template <int D>
 __device__ __forceinline__ void load_filt_raw(const double* filt, long long t, long long n_chains,
                                               long long chain, double2 (&r)[Dim<D>::NP2]) {
     constexpr int NP2 = Dim<D>::NP2;
-    const double2* base = reinterpret_cast<const double2*>(filt) + (t * NP2) * n_chains + chain;
+    const long long nb64 = (n_chains + 63) >> 6;
+    const double2* base = reinterpret_cast<const double2*>(filt) + ((t * nb64 + (chain >> 6)) * NP2) * 64 + (chain & 63);
 #pragma unroll
-    for (int k = 0; k < NP2; ++k) r[k] = base[k * n_chains];
+    for (int k = 0; k < NP2; ++k) r[k] = base[k * 64];
 }
 template <int D>
 __device__ __forceinline__ void unpack_rec(const double2 (&r)[Dim<D>::NP2], double (&m)[D], Sym<D>& V) {
@@ -362,9 +378,18 @@ __device__ __forceinline__ long long seg_len(const Params& p, long long s) {
 // K_i, U_i: per-model gain tables (Kalman gain of the filter started from an exactly known
 // state, and the sensitivity of the innovations to that state).  64 FMAs / step at d = dy = 4.
 template <int D, int DY, bool UNI>
-__global__ void __launch_bounds__(64) k_seg_aggregate(Params p) {
+__global__ void __launch_bounds__(64) k_seg_aggregate(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
     using CL = CstLayout<D, DY>;
     using TL = TabLayout<D, DY>;
+    constexpr int U = 4;                  // steps per chunk
+    constexpr int NPC = U * TL::SIZE / 2; // 16-byte pieces of gain table per chunk
+    constexpr int PPL = (NPC + 63) / 64;  // pieces per lane
+    // The per-offset gains are the same for every lane of the wave (one model): the wave streams
+    // them cooperatively global -> registers -> LDS one chunk ahead (double buffered) and reads
+    // them back with broadcast ds_reads.  (Scalar loads of the table stall the wave on every
+    // step: SMEM returns out of order, so each s_load needs lgkmcnt(0) before first use.)
+    __shared__ double2 tbuf[2][UNI ? NPC : 1];
+    const int lane = threadIdx.x;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = p.n_chains * (long long)p.S;
     const bool live = g < total;
@@ -372,45 +397,89 @@ __global__ void __launch_bounds__(64) k_seg_aggregate(Params p) {
     const long long chain = live ? g - seg * p.n_chains : 0;
     const long long len = live ? seg_len(p, seg) : 0;
     const int mdl = model_of<UNI>(p, chain);
-    const CPtr c{p.cst + (long long)mdl * CL::SIZE};
+    const CPtr c{UNI ? cb.v : p.cst + (long long)mdl * CL::SIZE};
     const double* tab = p.tab + (long long)mdl * p.L * TL::SIZE;
     const long long t0 = seg * p.L + 1;  // zero-based index of the first observation of the segment
+    const long long tab_pieces = p.L * TL::SIZE / 2;
+
+    double2 tr[PPL];
+    auto fetch = [&](long long i0) {
+        const double2* t2 = reinterpret_cast<const double2*>(p.tab);
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            const int idx = k * 64 + lane;
+            const long long gi = i0 * (TL::SIZE / 2) + idx;
+            tr[k] = (idx < NPC && gi < tab_pieces) ? t2[gi] : make_double2(0.0, 0.0);
+        }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            const int idx = k * 64 + lane;
+            if (idx < NPC) tbuf[b][idx] = tr[k];
+        }
+    };
+    if (UNI) {
+        fetch(0);
+        stash(0);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
 
     double m[D], eta[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) m[i] = eta[i] = 0.0;
-    double yv[DY], yn[DY];
-    if (len > 0) load_y<DY>(p.y, t0, p.n_chains, chain, yn);
-    for (long long i = 0; i < p.L; ++i) {  // uniform trip count: table addresses stay scalar
-        if (i < len) {
+    // observations are prefetched one chunk (U steps) ahead: they do not depend on the recursion
+    double yb[U][DY], yn[U][DY];
 #pragma unroll
-            for (int k = 0; k < DY; ++k) yv[k] = yn[k];
-            if (i + 1 < len) load_y<DY>(p.y, t0 + i + 1, p.n_chains, chain, yn);
-            const CPtr tb{tab + i * TL::SIZE};
-            double e[DY];
+    for (int u = 0; u < U; ++u)
+        if (u < len) load_y<DY>(p.y, t0 + u, p.n_chains, chain, yn[u]);
+    int b = 0;
+    for (long long i0 = 0; i0 < p.L; i0 += U, b ^= 1) {  // uniform trip count
+        if (UNI && i0 + U < p.L) fetch(i0 + U);
 #pragma unroll
-            for (int a = 0; a < DY; ++a) {
-                double s = yv[a];
+        for (int u = 0; u < U; ++u) {
 #pragma unroll
-                for (int k = 0; k < D; ++k) s -= c[CL::HF + a * D + k] * m[k];
-                e[a] = s;
-            }
-            double mn[D];
+            for (int k = 0; k < DY; ++k) yb[u][k] = yn[u][k];
+            if (i0 + U + u < len) load_y<DY>(p.y, t0 + i0 + U + u, p.n_chains, chain, yn[u]);
+        }
 #pragma unroll
-            for (int a = 0; a < D; ++a) {
-                double s = 0.0, u = eta[a];
+        for (int u = 0; u < U; ++u) {
+            const long long i = i0 + u;
+            if (i < len) {
+                const CPtr tb{UNI ? reinterpret_cast<const double*>(&tbuf[b][0]) + u * TL::SIZE : tab + i * TL::SIZE};
+                double e[DY];
 #pragma unroll
-                for (int k = 0; k < D; ++k) s += c[CL::A + a * D + k] * m[k];
+                for (int a = 0; a < DY; ++a) {
+                    double s = yb[u][a];
 #pragma unroll
-                for (int k = 0; k < DY; ++k) {
-                    s += tb[TL::K + a * DY + k] * e[k];
-                    u += tb[TL::U + a * DY + k] * e[k];
+                    for (int k = 0; k < D; ++k) s -= c[CL::HF + a * D + k] * m[k];
+                    e[a] = s;
                 }
-                mn[a] = s;
-                eta[a] = u;
-            }
+                double mn[D];
 #pragma unroll
-            for (int a = 0; a < D; ++a) m[a] = mn[a];
+                for (int a = 0; a < D; ++a) {
+                    double s = 0.0, uu = eta[a];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) s += c[CL::A + a * D + k] * m[k];
+#pragma unroll
+                    for (int k = 0; k < DY; ++k) {
+                        s += tb[TL::K + a * DY + k] * e[k];
+                        uu += tb[TL::U + a * DY + k] * e[k];
+                    }
+                    mn[a] = s;
+                    eta[a] = uu;
+                }
+#pragma unroll
+                for (int a = 0; a < D; ++a) m[a] = mn[a];
+            }
+        }
+        if (UNI) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            if (i0 + U < p.L) stash(b ^ 1);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
     if (live) {
@@ -431,7 +500,7 @@ __global__ void __launch_bounds__(64) k_seg_aggregate(Params p) {
 //   role 1 (suffix): backward message β(b_S) = (0, 0), then
 //        β(b_s): W = (C⁻¹ + Λ)⁻¹,  ξ' = η + X' W (ξ − Λ b),  Λ' = JJ − X' W X
 template <int D, int DY, bool UNI, bool FE>
-__global__ void __launch_bounds__(64) k_boundary_scan(Params p) {
+__global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
     using CL = CstLayout<D, DY>;
     using AL = AggLayout<D>;
     constexpr int NS = Dim<D>::NS;
@@ -439,7 +508,7 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p) {
     if (chain >= p.n_chains) return;
     const int role = blockIdx.y;
     const int mdl = model_of<UNI>(p, chain);
-    const CPtr c{p.cst + (long long)mdl * CL::SIZE};
+    const CPtr c{UNI ? cb.v : p.cst + (long long)mdl * CL::SIZE};
     const double* aggm = p.agg + (long long)mdl * 2 * AL::SIZE;
     const int S = p.S;
     bool ok = true;
@@ -576,7 +645,7 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p) {
 //   product at x[t]       information-form sum, then mean_cov   obs_update
 //   Bethe FE terms        telescoped to log p(y_t | y_<t)       obs_update<FE>
 template <int D, int DY, bool UNI, bool FE>
-__global__ void __launch_bounds__(64) k_forward(Params p) {
+__global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
     using CL = CstLayout<D, DY>;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = p.n_chains * (long long)p.S;
@@ -585,7 +654,7 @@ __global__ void __launch_bounds__(64) k_forward(Params p) {
     const long long chain = live ? g - seg * p.n_chains : 0;
     const long long len = live ? seg_len(p, seg) : 0;
     const int mdl = model_of<UNI>(p, chain);
-    const CPtr c{p.cst + (long long)mdl * CL::SIZE};
+    const CPtr c{UNI ? cb.v : p.cst + (long long)mdl * CL::SIZE};
     const long long t0 = seg * p.L + 1;  // zero-based time index of the segment's first step
 
     double m[D];
@@ -623,7 +692,7 @@ __global__ void __launch_bounds__(64) k_forward(Params p) {
 //   Vp = A V_f A' + P,  G = V_f A' Vp⁻¹,
 //   m_s(t) = m_f + G (m_s(t+1) − A m_f),  V_s(t) = V_f + G (V_s(t+1) − Vp) G'
 // The smoothed belief at the segment's end is (filtered ⊗ β) with β from phase 2.
-template <int D, bool UNI>
+template <int D>
 __device__ __forceinline__ void write_marginal(const Params& p, long long t, long long chain, const double (&m)[D],
                                                const Sym<D>& V) {
     double* om = p.mean + (t * p.n_chains + chain) * D;
@@ -647,19 +716,67 @@ __device__ __forceinline__ void write_marginal(const Params& p, long long t, lon
     }
 }
 
+// Posterior stores, coalesced.  A lane owns one chain, so written directly each 16-byte store
+// of a wave lands in 64 different 128-byte lines (lane stride d²·8 B): the stores become
+// request-rate bound (measured: SQ_WAIT_INST_ANY = 74 % of k_backward's wave cycles).  Instead
+// the wave transposes its 64 × (d + d²) doubles through LDS so that every global_store_dwordx4
+// writes one contiguous 1 KiB run of the [T][chain][d] / [T][chain][d][d] arrays.
+// Row stride is an odd number of 16-byte chunks -> conflict-free ds_write_b128 / ds_read_b128.
+// One wave per workgroup and LDS executes a wave's accesses in order, so no s_barrier is needed.
+template <int D>
+struct OutTile {
+    static constexpr int NOUT = D + D * D;           // doubles per chain
+    static constexpr int CH = NOUT / 2;              // 16-byte chunks per chain
+    static constexpr int STRIDE = CH | 1;            // odd
+    static constexpr int CH_MEAN = D / 2, CH_COV = D * D / 2;
+};
+template <int D>
+__device__ __forceinline__ void write_marginal_wave(const Params& p, double2* tile, int lane, long long t,
+                                                    long long chain0, const double (&m)[D], const Sym<D>& V) {
+    using OT = OutTile<D>;
+    double2* row = tile + lane * OT::STRIDE;
+#pragma unroll
+    for (int i = 0; i < D / 2; ++i) row[i] = make_double2(m[2 * i], m[2 * i + 1]);
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D / 2; ++j) row[OT::CH_MEAN + i * (D / 2) + j] = make_double2(V(i, 2 * j), V(i, 2 * j + 1));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double2* om = reinterpret_cast<double2*>(p.mean + (t * p.n_chains + chain0) * D);
+    double2* oc = reinterpret_cast<double2*>(p.cov + (t * p.n_chains + chain0) * D * D);
+#pragma unroll
+    for (int k = 0; k < OT::CH_MEAN; ++k) {
+        const int q = k * 64 + lane;
+        om[q] = tile[(q / OT::CH_MEAN) * OT::STRIDE + (q % OT::CH_MEAN)];
+    }
+#pragma unroll
+    for (int k = 0; k < OT::CH_COV; ++k) {
+        const int q = k * 64 + lane;
+        oc[q] = tile[(q / OT::CH_COV) * OT::STRIDE + OT::CH_MEAN + (q % OT::CH_COV)];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
 template <int D, int DY, bool UNI>
-__global__ void __launch_bounds__(64) k_backward(Params p) {
+__global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
     using CL = CstLayout<D, DY>;
     constexpr int NS = Dim<D>::NS;
     constexpr int NP2 = Dim<D>::NP2;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = p.n_chains * (long long)p.S;
+    // coalesced-store path: every wave holds 64 consecutive chains of ONE segment
+    constexpr bool CAN_TILE = (D % 2 == 0);
+    __shared__ double2 tile[CAN_TILE ? 64 * OutTile<CAN_TILE ? D : 2>::STRIDE : 1];
+    const bool tiled = CAN_TILE && (p.n_chains % 64 == 0);
+    const int lane = threadIdx.x;
     if (g >= total) return;
     const long long seg = g / p.n_chains;
     const long long chain = g - seg * p.n_chains;
     const long long len = seg_len(p, seg);
     const int mdl = model_of<UNI>(p, chain);
-    const CPtr c{p.cst + (long long)mdl * CL::SIZE};
+    const CPtr c{UNI ? cb.v : p.cst + (long long)mdl * CL::SIZE};
     const long long tb = seg * p.L;   // zero-based time index of boundary b_seg
     const long long te = tb + len;    // zero-based time index of boundary b_{seg+1}
     bool ok = true;
@@ -684,7 +801,7 @@ __global__ void __launch_bounds__(64) k_backward(Params p) {
         for (int i = 0; i < NS; ++i) Ls.v[i] = Vi.v[i] + Lb.v[i];
         ok = spd_inv<D>(Ls, Vs, det) && ok;
         symv<D>(Vs, u, ms);
-        if (seg == p.S - 1) write_marginal<D, UNI>(p, te, chain, ms, Vs);
+        if (seg == p.S - 1) write_marginal<D>(p, te, chain, ms, Vs);
     }
     double2 rn[NP2];
     if (len > 0) load_filt_raw<D>(p.filt, te - 1, p.n_chains, chain, rn);
@@ -740,28 +857,60 @@ __global__ void __launch_bounds__(64) k_backward(Params p) {
                 for (int k = 0; k < D; ++k) s += H[i][k] * G[j][k];
                 Vs(i, j) = s;
             }
-        write_marginal<D, UNI>(p, t, chain, ms, Vs);
+        if constexpr (CAN_TILE) {
+            if (tiled) write_marginal_wave<D>(p, tile, lane, t, chain - lane, ms, Vs);
+            else write_marginal<D>(p, t, chain, ms, Vs);
+        } else
+            write_marginal<D>(p, t, chain, ms, Vs);
     }
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
 }
 
 // ------------------------------------------------------------------------------------------
-// Bethe free energy reduction: fe_chain[c] = −Σ_s fe_part[s][c] (fixed order), and the batch
-// total Σ_c fe_chain[c] by a fixed-shape tree (deterministic run to run: needed for 1e-8).
+// Bethe free energy reduction: fe_chain[c] = −Σ_s fe_part[s][c] and the batch total Σ_c fe_chain[c],
+// both with a fixed summation shape (deterministic run to run: needed for the 1e-8 tolerance).
 // Restates the global sum of src/model/plugins/reactivemp_free_energy.jl:101-123
 // (`sumreduce`, src/helpers.jl:21); NaN/Inf check mirrors src/score/diagnostics.jl:19-51.
-__global__ void __launch_bounds__(256) k_fe_reduce(Params p) {
+__global__ void __launch_bounds__(256) k_fe_chain(Params p, double* block_part) {
+    // 64 chains per block; the 4 waves each sum a contiguous quarter of the S+1 partials of
+    // their chain (independent loads in flight), combined in fixed order.
+    __shared__ double sh[4][64];
+    const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long long ch = (long long)blockIdx.x * 64 + lane;
+    const int n = p.S + 1;
+    const int per = (n + 3) / 4;
+    const int k0 = q * per, k1 = (k0 + per < n) ? k0 + per : n;
+    double s = 0.0;
+    if (ch < p.n_chains) {
+#pragma unroll 8
+        for (int k = k0; k < k1; ++k) s += p.fe_part[(long long)k * p.n_chains + ch];
+    }
+    sh[q][lane] = s;
+    __syncthreads();
+    if (q == 0) {
+        double f = -(((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]);
+        bool bad = false;
+        if (ch < p.n_chains) {
+            p.fe_chain[ch] = f;
+            bad = !(f - f == 0.0);
+        } else
+            f = 0.0;
+        if (bad) atomicOr(p.status, ST_NONFINITE);
+        sh[0][lane] = f;
+    }
+    __syncthreads();
+    if (threadIdx.x < 32) sh[0][threadIdx.x] += sh[0][threadIdx.x + 32];
+    __syncthreads();
+    for (int w = 16; w > 0; w >>= 1) {
+        if ((int)threadIdx.x < w) sh[0][threadIdx.x] += sh[0][threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_part[blockIdx.x] = sh[0][0];
+}
+__global__ void __launch_bounds__(256) k_fe_total(Params p, const double* block_part, int nblocks) {
     __shared__ double sh[256];
     double local = 0.0;
-    bool bad = false;
-    for (long long ch = threadIdx.x; ch < p.n_chains; ch += 256) {
-        double s = 0.0;
-        for (int k = 0; k <= p.S; ++k) s += p.fe_part[(long long)k * p.n_chains + ch];
-        s = -s;
-        p.fe_chain[ch] = s;
-        bad = bad || !(s - s == 0.0);
-        local += s;
-    }
+    for (int b = threadIdx.x; b < nblocks; b += 256) local += block_part[b];
     sh[threadIdx.x] = local;
     __syncthreads();
     for (int w = 128; w > 0; w >>= 1) {
@@ -769,7 +918,6 @@ __global__ void __launch_bounds__(256) k_fe_reduce(Params p) {
         __syncthreads();
     }
     if (threadIdx.x == 0) p.fe_total[p.iteration] = sh[0];
-    if (bad) atomicOr(p.status, ST_NONFINITE);
 }
 
 }  // namespace rxhip

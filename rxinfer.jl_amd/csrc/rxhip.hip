@@ -28,52 +28,58 @@ struct LgssmVtbl {
     int oA, oP, oLOBS, oG, oQI, oC0, oM1, oV1, oHF;
     int tK, tU;
     int aPI, aC, aJ, aCI, aX, aJJ;
-    void (*seg_aggregate)(const Params&, bool, hipStream_t);
-    void (*boundary_scan)(const Params&, bool, bool, hipStream_t);
-    void (*forward)(const Params&, bool, bool, hipStream_t);
-    void (*backward)(const Params&, bool, hipStream_t);
+    void (*seg_aggregate)(const Params&, const double*, bool, hipStream_t);
+    void (*boundary_scan)(const Params&, const double*, bool, bool, hipStream_t);
+    void (*forward)(const Params&, const double*, bool, bool, hipStream_t);
+    void (*backward)(const Params&, const double*, bool, hipStream_t);
 };
 
 static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
 
 template <int D, int DY>
 struct Launch {
-    static void seg_aggregate(const Params& p, bool uni, hipStream_t s) {
+    using CL = CstLayout<D, DY>;
+    // `hc`: host copy of model 0's constant block, passed by value when all chains share it
+    static CstArg<CL::SIZE> carg(const double* hc) {
+        CstArg<CL::SIZE> a;
+        std::memcpy(a.v, hc, sizeof(double) * CL::SIZE);
+        return a;
+    }
+    static void seg_aggregate(const Params& p, const double* hc, bool uni, hipStream_t s) {
         const long long total = p.n_chains * (long long)p.S;
         if (uni)
-            hipLaunchKernelGGL((k_seg_aggregate<D, DY, true>), dim3(nblk(total, 64)), dim3(64), 0, s, p);
+            hipLaunchKernelGGL((k_seg_aggregate<D, DY, true>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
         else
-            hipLaunchKernelGGL((k_seg_aggregate<D, DY, false>), dim3(nblk(total, 64)), dim3(64), 0, s, p);
+            hipLaunchKernelGGL((k_seg_aggregate<D, DY, false>), dim3(nblk(total, 64)), dim3(64), 0, s, p, CstArg<1>{});
     }
-    static void boundary_scan(const Params& p, bool uni, bool fe, hipStream_t s) {
+    static void boundary_scan(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
         dim3 grid(nblk(p.n_chains, 64), 2);
         if (uni) {
-            if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, true, true>), grid, dim3(64), 0, s, p);
-            else hipLaunchKernelGGL((k_boundary_scan<D, DY, true, false>), grid, dim3(64), 0, s, p);
+            if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));
+            else hipLaunchKernelGGL((k_boundary_scan<D, DY, true, false>), grid, dim3(64), 0, s, p, carg(hc));
         } else {
-            if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, false, true>), grid, dim3(64), 0, s, p);
-            else hipLaunchKernelGGL((k_boundary_scan<D, DY, false, false>), grid, dim3(64), 0, s, p);
+            if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, false, true>), grid, dim3(64), 0, s, p, CstArg<1>{});
+            else hipLaunchKernelGGL((k_boundary_scan<D, DY, false, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
         }
     }
-    static void forward(const Params& p, bool uni, bool fe, hipStream_t s) {
+    static void forward(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
         const long long total = p.n_chains * (long long)p.S;
         dim3 grid(nblk(total, 64));
         if (uni) {
-            if (fe) hipLaunchKernelGGL((k_forward<D, DY, true, true>), grid, dim3(64), 0, s, p);
-            else hipLaunchKernelGGL((k_forward<D, DY, true, false>), grid, dim3(64), 0, s, p);
+            if (fe) hipLaunchKernelGGL((k_forward<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));
+            else hipLaunchKernelGGL((k_forward<D, DY, true, false>), grid, dim3(64), 0, s, p, carg(hc));
         } else {
-            if (fe) hipLaunchKernelGGL((k_forward<D, DY, false, true>), grid, dim3(64), 0, s, p);
-            else hipLaunchKernelGGL((k_forward<D, DY, false, false>), grid, dim3(64), 0, s, p);
+            if (fe) hipLaunchKernelGGL((k_forward<D, DY, false, true>), grid, dim3(64), 0, s, p, CstArg<1>{});
+            else hipLaunchKernelGGL((k_forward<D, DY, false, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
         }
     }
-    static void backward(const Params& p, bool uni, hipStream_t s) {
+    static void backward(const Params& p, const double* hc, bool uni, hipStream_t s) {
         const long long total = p.n_chains * (long long)p.S;
         dim3 grid(nblk(total, 64));
-        if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p);
-        else hipLaunchKernelGGL((k_backward<D, DY, false>), grid, dim3(64), 0, s, p);
+        if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
+        else hipLaunchKernelGGL((k_backward<D, DY, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
     }
     static LgssmVtbl vtbl() {
-        using CL = CstLayout<D, DY>;
         using TL = TabLayout<D, DY>;
         using AL = AggLayout<D>;
         LgssmVtbl v;
@@ -143,6 +149,8 @@ struct rxhip_engine {
            *d_fe_chain = nullptr, *d_fe_total = nullptr;
     int* d_chain_model = nullptr;
     int* d_status = nullptr;
+    double* d_fe_blocks = nullptr;
+    std::vector<double> h_cst0;  // model 0's constant block (kernel argument when all chains share it)
     int fe_total_cap = 0;
     // results bookkeeping
     int last_iterations = 0;
@@ -397,6 +405,7 @@ static void free_all(rxhip_engine* e) {
     e->d_y = nullptr;
     if (e->d_chain_model) (void)hipFree(e->d_chain_model);
     if (e->d_status) (void)hipFree(e->d_status);
+    if (e->d_fe_blocks) (void)hipFree(e->d_fe_blocks);
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     e->pending.clear();
@@ -477,7 +486,9 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
                                              agg.data() + (size_t)m * 2 * vt->agg_size);
         if (st) return st;
     }
+    e->h_cst0.assign(cst.begin(), cst.begin() + vt->cst_size);
     const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1);
+    HIPCHK(e, hipMalloc(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64)));
     HIPCHK(e, hipMalloc(&e->d_cst, sizeof(double) * cst.size()));
     HIPCHK(e, hipMalloc(&e->d_tab, sizeof(double) * tab.size()));
     HIPCHK(e, hipMalloc(&e->d_agg, sizeof(double) * agg.size()));
@@ -488,7 +499,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         HIPCHK(e, hipMalloc(&e->d_chain_model, sizeof(int) * C));
         HIPCHK(e, hipMemcpy(e->d_chain_model, ds->chain_model, sizeof(int) * C, hipMemcpyHostToDevice));
     }
-    HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * T * NP2 * 2 * C));
+    HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * T * NP2 * 2 * (((C + 63) / 64) * 64)));
     HIPCHK(e, hipMalloc(&e->d_mean, sizeof(double) * T * C * e->d));
     HIPCHK(e, hipMalloc(&e->d_cov, sizeof(double) * T * C * e->d * e->d));
     HIPCHK(e, hipMalloc(&e->d_elem, sizeof(double) * Sg * 2 * e->d * C));
@@ -598,6 +609,7 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.n_models = e->n_models;
     p.y = e->d_y;
     p.filt = e->d_filt;
+    p.nb64 = (e->n_chains + 63) / 64;
     p.mean = e->d_mean;
     p.cov = e->d_cov;
     p.cst = e->d_cst;
@@ -617,23 +629,25 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
         p.iteration = it;
         if (e->S > 0) {
             if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
-            e->vt->seg_aggregate(p, e->uniform, e->stream);
+            e->vt->seg_aggregate(p, e->h_cst0.data(), e->uniform, e->stream);
             if ((st = prof_end(e))) return st;
         }
         if ((st = prof_begin(e, RXHIP_K_BOUNDARY_SCAN))) return st;
-        e->vt->boundary_scan(p, e->uniform, fe, e->stream);
+        e->vt->boundary_scan(p, e->h_cst0.data(), e->uniform, fe, e->stream);
         if ((st = prof_end(e))) return st;
         if (e->S > 0) {
             if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
-            e->vt->forward(p, e->uniform, fe, e->stream);
+            e->vt->forward(p, e->h_cst0.data(), e->uniform, fe, e->stream);
             if ((st = prof_end(e))) return st;
             if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
-            e->vt->backward(p, e->uniform, e->stream);
+            e->vt->backward(p, e->h_cst0.data(), e->uniform, e->stream);
             if ((st = prof_end(e))) return st;
         }
         if (fe) {
             if ((st = prof_begin(e, RXHIP_K_FE_REDUCE))) return st;
-            hipLaunchKernelGGL(k_fe_reduce, dim3(1), dim3(256), 0, e->stream, p);
+            const int nb = (int)((e->n_chains + 63) / 64);
+            hipLaunchKernelGGL(k_fe_chain, dim3(nb), dim3(256), 0, e->stream, p, e->d_fe_blocks);
+            hipLaunchKernelGGL(k_fe_total, dim3(1), dim3(256), 0, e->stream, p, (const double*)e->d_fe_blocks, nb);
             if ((st = prof_end(e))) return st;
         }
     }

@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Summarise rocprofv3 outputs (kernel stats + PMC counters per kernel) into a small text table."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def find(pattern):
+    return sorted(glob.glob(os.path.join(out, "**", pattern), recursive=True))
+
+
+def short(name):
+    name = name.split("(")[0]
+    for k in ("k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce", "k_fe_chain", "k_fe_total",
+              "k_transpose_rows"):
+        if k in name:
+            return k
+    return name[:60]
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in find("*kernel_stats.csv"):
+    for row in csv.DictReader(open(f)):
+        n = short(row.get("Name", ""))
+        if n.startswith("k_"):
+            print(f"{n:18s} calls={row.get('Calls'):>5s} total_ns={row.get('TotalDurationNs'):>14s} "
+                  f"avg_ns={row.get('AverageNs'):>14s} pct={row.get('Percentage')}")
+
+print("== PMC counters, average per dispatch (last 5 dispatches of each kernel = timed steps) ==")
+agg = defaultdict(lambda: defaultdict(list))
+for f in find("*counter_collection.csv"):
+    for row in csv.DictReader(open(f)):
+        n = short(row.get("Kernel_Name", ""))
+        if not n.startswith("k_"):
+            continue
+        agg[n][row["Counter_Name"]].append(float(row["Counter_Value"]))
+for n in sorted(agg):
+    parts = []
+    for c in sorted(agg[n]):
+        v = agg[n][c][-5:]
+        parts.append(f"{c}={sum(v) / len(v):.6g}")
+    print(f"{n:18s} " + " ".join(parts))
+print("note: FETCH_SIZE/WRITE_SIZE are in KiB-units as reported by rocprofv3 (x1024 = bytes); on gfx950 "
+      "FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md §HBM).")
