@@ -121,6 +121,18 @@ struct Params {
 // small dense algebra, everything unrolled so that all indices are compile-time constants and
 // the operands stay in VGPRs (checked with -Rpass-analysis=kernel-resource-usage: no scratch).
 
+// 1/x for a positive, normal x: v_rcp_f64 seed + two Newton steps (5 instructions instead of the
+// ~11 of the IEEE-exact division expansion; result within 1–2 ulp, far inside the 1e-6 / 1e-8
+// parity budget — the pivots it is applied to are already rounded results).
+__device__ __forceinline__ double rcp_pos(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    return r;
+}
+
 // SPD inverse through LDL' (no square roots).  `det` receives det(a) (product of pivots).
 // Restates FastCholesky.cholinv for the small blocks on the path; a non-positive pivot
 // reports ST_NOT_POSDEF (the reference throws PosDefException).
@@ -136,7 +148,7 @@ __device__ __forceinline__ bool spd_inv(const Sym<D>& a, Sym<D>& out, double& de
         for (int k = 0; k < j; ++k) s -= W[j][k] * L[j][k];
         ok = ok && (s > 0.0);
         det *= s;
-        r[j] = 1.0 / s;
+        r[j] = rcp_pos(s);
 #pragma unroll
         for (int i = j + 1; i < D; ++i) {
             double t = a(i, j);
@@ -240,10 +252,13 @@ __device__ __forceinline__ void matvec_c(const CPtr A, const double (&x)[D], dou
 
 // Observation update in information form (product of the forward message with the `*`_B(:in)
 // message) and the evidence term.  In: predicted (mp, Vp), y.  Out: filtered (m, V).
-// Returns log p(y_t | y_<t) when FE.
+// When FE: log p(y_t | y_<t) = −½[quad + log(detprod)], returned in two parts so that the caller
+// can take ONE logarithm per segment (running product with exponent extraction) instead of one
+// per step:  quad = c0 + y'Q⁻¹y − ξf'm_f + m_p'Λ_p m_p,   detprod = det Λf · det Vp.
 template <int D, int DY, bool FE>
-__device__ __forceinline__ double obs_update(const CPtr c, const double (&mp)[D], const Sym<D>& Vp,
-                                             const double (&y)[DY], double (&m)[D], Sym<D>& V, bool& ok) {
+__device__ __forceinline__ void obs_update(const CPtr c, const double (&mp)[D], const Sym<D>& Vp,
+                                           const double (&y)[DY], double (&m)[D], Sym<D>& V, bool& ok,
+                                           double& quad, double& detprod) {
     using CL = CstLayout<D, DY>;
     Sym<D> Lp, Lf;
     double detp, detl;
@@ -261,8 +276,7 @@ __device__ __forceinline__ double obs_update(const CPtr c, const double (&mp)[D]
     }
     ok = spd_inv<D>(Lf, V, detl) && ok;  // mean_cov of the product
     symv<D>(V, xf, m);
-    if (!FE) return 0.0;
-    // log p(y|past) = -½[c0 + y'Q⁻¹y + log(det Λf · det Vp) − ξf'm_f + m_p'Λ_p m_p]
+    if (!FE) return;
     double q = 0.0;
 #pragma unroll
     for (int i = 0; i < DY; ++i) {
@@ -277,8 +291,23 @@ __device__ __forceinline__ double obs_update(const CPtr c, const double (&mp)[D]
         a1 += xf[i] * m[i];
         a2 += xp[i] * mp[i];
     }
-    return -0.5 * (c[CL::C0] + q + log(detl * detp) - a1 + a2);
+    quad = c[CL::C0] + q - a1 + a2;
+    detprod = detl * detp;
 }
+
+// running Σ log(x_t) as log(Π x_t): mantissa product renormalised every step (v_frexp_*), exponents
+// summed exactly; one log at the end.
+struct LogProd {
+    double mant = 1.0;
+    long long expo = 0;
+    __device__ __forceinline__ void mul(double x) {
+        double t = mant * x;
+        int e = __builtin_amdgcn_frexp_exp(t);
+        mant = __builtin_amdgcn_frexp_mant(t);
+        expo += e;
+    }
+    __device__ __forceinline__ double value() const { return log(mant) + 0.6931471805599453094 * (double)expo; }
+};
 
 // record I/O.  A Gaussian record is NP = D + NS doubles: vector, then packed lower triangle.
 // filt layout [T][chain/64][NP2][64][2]: lane = chain % 64; every 16-byte access of a wave is one
@@ -520,9 +549,10 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
 #pragma unroll
         for (int i = 0; i < NS; ++i) Vp.v[i] = c[CL::V1 + i];
         load_y<DY>(p.y, 0, p.n_chains, chain, yv);
-        double l = obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok);
+        double quad = 0.0, detprod = 1.0;
+        obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok, quad, detprod);
         store_filt<D>(p.filt, 0, p.n_chains, chain, m, V);
-        if (FE) p.fe_part[chain] = l;
+        if (FE) p.fe_part[chain] = -0.5 * (quad + log(detprod));
         if (p.T == 1) {  // single observation: the filtered belief is the posterior
             double* om = p.mean + chain * D;
             double* oc = p.cov + chain * D * D;
@@ -668,6 +698,7 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
     }
     bool ok = true;
     double acc = 0.0;
+    LogProd lp;
     double yv[DY], yn[DY];
     if (len > 0) load_y<DY>(p.y, t0, p.n_chains, chain, yn);
     for (long long i = 0; i < len; ++i) {
@@ -678,11 +709,15 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
         Sym<D> Vp;
         matvec_c<D>(CPtr{c.p + CL::A}, m, mp);
         predict_cov<D>(CPtr{c.p + CL::A}, CPtr{c.p + CL::P}, V, T, Vp);
-        double l = obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok);
-        if (FE) acc += l;
+        double quad = 0.0, detprod = 1.0;
+        obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok, quad, detprod);
+        if (FE) {
+            acc += quad;
+            lp.mul(detprod);
+        }
         store_filt<D>(p.filt, t0 + i, p.n_chains, chain, m, V);
     }
-    if (FE && live) p.fe_part[(seg + 1) * p.n_chains + chain] = acc;
+    if (FE && live) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc + lp.value());
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
 }
 

@@ -457,14 +457,16 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->own_stream = true;
     }
 
-    // time segmentation: enough (chain, segment) lanes to fill 256 CUs × 8 waves × 64 lanes
+    // time segmentation: one (chain, segment) lane per SIMD lane slot — 256 CUs × 4 SIMDs × 64 lanes.
+    // The big kernels are HBM-bound at one wave per SIMD (measured: 48…128 segments within 2 %),
+    // and the boundary scan grows linearly with the number of segments.
     const long long steps = e->T - 1;  // transitions
     if (steps <= 0) {
         e->S = 0;
         e->L = 1;
         e->Llast = 1;
     } else {
-        long long S_target = ds->segments > 0 ? ds->segments : (131072 + e->n_chains - 1) / e->n_chains;
+        long long S_target = ds->segments > 0 ? ds->segments : (65536 + e->n_chains - 1) / e->n_chains;
         if (S_target < 1) S_target = 1;
         long long L = (steps + S_target - 1) / S_target;
         const long long Lmin = ds->segments > 0 ? 1 : 16;
