@@ -1,0 +1,68 @@
+"""Multi-GPU host logic: one process per GPU, chains sharded, no data-path collective.
+
+The path partitions by independent factor graphs (chains): rank r owns a contiguous block of chains
+and runs the unmodified single-GPU engine on it.  The ONLY exchange is the global Bethe free energy
+(reference: one scalar per iteration out of `score(model, BetheFreeEnergy, …)`,
+src/model/plugins/reactivemp_free_energy.jl:119-123) — an all-reduce(sum) of one double per sweep
+(`torch.distributed`, backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests)."""
+import numpy as np
+
+
+def shard_bounds(n_chains, rank, world):
+    """Contiguous, balanced partition: the first n_chains % world ranks get one extra chain."""
+    if not (0 <= rank < world):
+        raise ValueError("rank out of range")
+    base, extra = divmod(int(n_chains), int(world))
+    lo = rank * base + min(rank, extra)
+    hi = lo + base + (1 if rank < extra else 0)
+    return lo, hi
+
+
+def shard_observations(y_chain_major, rank, world):
+    """y: [chain][T][dy] (host).  Returns this rank's block."""
+    lo, hi = shard_bounds(y_chain_major.shape[0], rank, world)
+    return y_chain_major[lo:hi]
+
+
+def allreduce_free_energy(fe_local, dist=None, device=None):
+    """Sum the per-rank batch free energies (per iteration).  fe_local: array-like [iterations] or a
+    torch tensor already on the right device.  Deterministic for a fixed world size (ring/tree order is
+    fixed by the backend); the result is identical on every rank."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return fe_local
+    import torch
+
+    if isinstance(fe_local, torch.Tensor):
+        dist.all_reduce(fe_local, op=dist.ReduceOp.SUM)
+        return fe_local
+    t = torch.as_tensor(np.asarray(fe_local, dtype=np.float64))
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy()
+
+
+def gather_per_chain(values_local, n_chains, dist=None):
+    """All-gather a per-chain array ([local_chains, ...]) into chain order (used by tests / result
+    assembly; not on the timed path)."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return values_local
+    import torch
+
+    world = dist.get_world_size()
+    parts = [None] * world
+    dist.all_gather_object(parts, np.asarray(values_local))
+    out = np.concatenate(parts, axis=0)
+    assert out.shape[0] == n_chains
+    return out
+
+
+def sharded_infer(run_shard, y_chain_major, dist=None):
+    """Drive one sharded inference: `run_shard(y_block) -> (mean, cov, fe_per_chain)` is the single-GPU
+    engine on this rank's chains.  Returns (mean_block, cov_block, fe_per_chain_block, fe_total_global)."""
+    rank = dist.get_rank() if dist is not None and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist is not None and dist.is_initialized() else 1
+    yb = shard_observations(y_chain_major, rank, world)
+    mean, cov, fe = run_shard(yb)
+    fe_total = allreduce_free_energy(np.array([np.sum(fe)]), dist)[0]
+    return mean, cov, fe, float(fe_total)

@@ -1,0 +1,83 @@
+"""World-size-2 `gloo` test of the multi-GPU host logic (chains shard, free energy all-reduced).
+No GPU here, so the per-shard compute is the CPU oracle standing in for the engine — allowed in
+tests only; the sharding / all-reduce code under test is the product's (rxhip/distributed.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "rxinfer.jl_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import rxoracle
+    from rxhip import distributed as rd
+    from rxhip import workloads
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    mdl = workloads.c1_model()
+    C, T = 7, 60  # odd chain count: uneven shards
+    y = np.transpose(workloads.generate_batch(mdl, T, C), (1, 0, 2))  # [chain][T][dy]
+
+    def run_shard(yb):
+        m, V, fe, _ = rxoracle.lgssm_bp_batch(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"],
+                                              np.ascontiguousarray(np.transpose(yb, (1, 0, 2))))
+        return np.transpose(m, (1, 0, 2)), np.transpose(V, (1, 0, 2, 3)), fe
+
+    mean, cov, fe, fe_total = rd.sharded_infer(run_shard, y, dist)
+    fe_all = rd.gather_per_chain(fe, C, dist)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), fe_total=fe_total, fe_all=fe_all, lo_hi=rd.shard_bounds(C, rank, world),
+             mean=mean)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds_cover_and_balance():
+    from rxhip.distributed import shard_bounds
+
+    for n in (1, 7, 8, 1024, 4096):
+        for w in (1, 2, 3, 8):
+            spans = [shard_bounds(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_rank_sharded_free_energy(tmp_path):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "rank0.npz")
+    r1 = np.load(tmp_path / "rank1.npz")
+    # every rank sees the same global free energy and the same gathered per-chain values
+    assert r0["fe_total"] == r1["fe_total"]
+    assert np.array_equal(r0["fe_all"], r1["fe_all"])
+    assert tuple(r0["lo_hi"]) == (0, 4) and tuple(r1["lo_hi"]) == (4, 7)
+    # and it equals the unsharded result
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rxoracle
+    from rxhip import workloads
+
+    mdl = workloads.c1_model()
+    y = workloads.generate_batch(mdl, 60, 7)
+    _, _, fe, _ = rxoracle.lgssm_bp_batch(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y)
+    assert np.allclose(r0["fe_all"], fe, rtol=0, atol=0)
+    assert abs(float(r0["fe_total"]) - fe.sum()) <= 1e-12 * abs(fe.sum())
