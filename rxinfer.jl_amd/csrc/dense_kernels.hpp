@@ -1,0 +1,726 @@
+// dense_kernels.hpp — LGSSM message passing for LARGE state dimension (d = 16·NT ≤ 64,
+// BASELINE config 3: d = dy = 64) on the fp64 matrix cores of gfx950.
+//
+// Same reference rules as lgssm_kernels.hpp (a3 MvNormalMeanCovariance, a4 typeof(*), a5 product,
+// a6 marginal, a7 Bethe free energy) and the same exact parallel-in-time schedule, but the unit of
+// execution is different: a d×d covariance no longer fits one lane, so ONE WORKGROUP (NT waves) owns one
+// (chain, time-segment) and every d×d object is distributed over its threads in the accumulator layout
+// of v_mfma_f64_16x16x4_f64:
+//     wave w owns tile-row w (rows 16w..16w+15), all NT tile-columns;
+//     lane l, tile t, register r  <->  element (row 16w + (l>>4) + 4r, col 16t + (l&15))
+// (the f64 C/D map differs from the f32 one: cdna_hip_programming.md §3).
+//   * dense contractions (A V A', V_f A' Λ_p, G D G', …) are MFMA: operands are read from LDS (or from
+//     L2 for the constant matrices) in the A/B operand layout, 16 k-steps of 4, NT MFMAs per k-step;
+//   * SPD inverses (cholinv in the reference) are an in-place Gauss–Jordan sweep directly on the
+//     accumulator registers: per pivot the owners publish the pivot row and column through LDS, one
+//     barrier, and every thread does a rank-1 update of its 4×NT elements; the pivots give logdet;
+//   * vectors live in LDS; matvecs are row-per-thread dot products.
+// Segment boundaries: the data-independent matrix parts of the boundary scan (covariance at every
+// segment start, precision of the backward message at every segment end, and the d×d maps that carry
+// the means) are per-model tables built at create time; the kernels carry only the data-dependent
+// vectors across boundaries.  Inside a segment every step recomputes the full matrix algebra.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "lgssm_kernels.hpp"
+
+namespace rxhip {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// per-model constant block for the dense path (doubles; all matrices dense row-major)
+struct DenseCst {
+    int d, dy;
+    long long oA, oP, oLOBS, oG, oQI, oHF, oC0, oX1, oS1, oLD1, oC1, oK1, oVF1, oAT, oGT, oHFT, oK1T, size;
+    __host__ __device__ static DenseCst make(int d, int dy) {
+        DenseCst c;
+        c.d = d;
+        c.dy = dy;
+        long long o = 0;
+        c.oA = o; o += (long long)d * d;
+        c.oP = o; o += (long long)d * d;
+        c.oLOBS = o; o += (long long)d * d;
+        c.oG = o; o += (long long)d * dy;
+        c.oQI = o; o += (long long)dy * dy;
+        c.oHF = o; o += (long long)dy * d;
+        c.oC0 = o; o += 1;   // dy log 2π + logdet Q
+        c.oX1 = o; o += d;   // V1⁻¹ m1
+        c.oS1 = o; o += 1;   // m1' V1⁻¹ m1
+        c.oLD1 = o; o += 1;  // log(det Λf(1) · det V1)
+        c.oC1 = o; o += d;   // Vf(1) V1⁻¹ m1
+        c.oK1 = o; o += (long long)d * dy;  // Vf(1) G
+        c.oVF1 = o; o += (long long)d * d;  // Vf(1)
+        // transposed copies: out[i] = Σ_k M'[k][i] x[k] is coalesced over threads i
+        c.oAT = o; o += (long long)d * d;    // A'   [d][d]
+        c.oGT = o; o += (long long)dy * d;   // G'   [dy][d]
+        c.oHFT = o; o += (long long)d * dy;  // (BA)' [d][dy]
+        c.oK1T = o; o += (long long)dy * d;  // K1'  [dy][d]
+        c.size = (o + 7) / 8 * 8;
+        return c;
+    }
+};
+
+struct DenseParams {
+    long long T, n_chains;
+    int S;
+    long long L;
+    int d, dy;
+    const double* y;      // [T][chain][dy]
+    double* filt;         // [chain][T][d + NTRI*256]   filtered (m_f | V_f lower tiles in register order)
+    double* mean;         // [T][chain][d]
+    double* cov;          // [T][chain][d][d]
+    const double* cst;    // DenseCst block (model 0; the dense path takes one model)
+    const double* tab;    // [L][2][d][dy]  K_i, U_i
+    const double* scanm;  // [S][6][d][d]   0:M1' 1:M2' 2:V(b_s)  3:N1' 4:N2' 5:Λβ(b_{s+1})  (maps stored transposed)
+    double* elem;         // [chain][S][2][d]   b, η
+    double* fstart_m;     // [chain][S][d]      filtered mean at b_s
+    double* beta_xi;      // [chain][S+1][d]    ξβ at b_s
+    double* fe_part;      // [S+1][chain]
+    int* status;
+    int ablate;           // diagnostics only (RXHIP_ABLATE): bit0 skip inverses, bit1 skip contractions, bit2 skip matvecs, bit3 skip stores, bit4 skip FE dots
+};
+
+template <int NT>
+struct DenseCfg {
+    static constexpr int D = 16 * NT;
+    static constexpr int LD = D + 2;           // LDS leading dimension (doubles): A-operand reads conflict-free
+    static constexpr int THREADS = 64 * NT;
+    static constexpr int NTRI = NT * (NT + 1) / 2;
+    static constexpr int REC = D + NTRI * 256;  // doubles per filtered record
+    static constexpr int MAT = D * LD;          // doubles per LDS matrix
+};
+
+// ---- accumulator-layout helpers ------------------------------------------------------------------
+template <int NT>
+struct Acc {
+    double v[NT][4];  // v[tile-col][reg]   (plain scalars: every index below is a compile-time constant)
+};
+template <int NT>
+__device__ __forceinline__ int acc_row(int w, int lane, int r) { return 16 * w + (lane >> 4) + 4 * r; }
+template <int NT>
+__device__ __forceinline__ int acc_col(int lane, int t) { return 16 * t + (lane & 15); }
+
+template <int NT>
+__device__ __forceinline__ void acc_zero(Acc<NT>& a) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.v[t][r] = 0.0;
+}
+// row-major matrix (leading dimension ld) <-> accumulator layout
+template <int NT>
+__device__ __forceinline__ void acc_load(Acc<NT>& a, const double* M, int ld, int w, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.v[t][r] = M[acc_row<NT>(w, lane, r) * ld + acc_col<NT>(lane, t)];
+}
+template <int NT>
+__device__ __forceinline__ void acc_store(const Acc<NT>& a, double* M, int ld, int w, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[acc_row<NT>(w, lane, r) * ld + acc_col<NT>(lane, t)] = a.v[t][r];
+}
+template <int NT>
+__device__ __forceinline__ void acc_add_mat(Acc<NT>& a, const double* M, int ld, int w, int lane, double sgn) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.v[t][r] += sgn * M[acc_row<NT>(w, lane, r) * ld + acc_col<NT>(lane, t)];
+}
+// lower-triangle tiles of a symmetric matrix in register order: [tile idx][r][lane] — every access of a
+// wave is 512 contiguous bytes.  Tiles above the diagonal are reconstructed by symmetry through LDS.
+template <int NT>
+__device__ __forceinline__ void acc_store_tri(const Acc<NT>& a, double* rec, int w, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t <= w) {
+            double* p = rec + (w * (w + 1) / 2 + t) * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) p[r * 64 + lane] = a.v[t][r];
+        }
+}
+// load the lower tiles from a record into an LDS matrix (full symmetric, row-major ld)
+template <int NT>
+__device__ __forceinline__ void tri_to_lds(const double* rec, double* M, int ld, int w, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t <= w) {
+            const double* p = rec + (w * (w + 1) / 2 + t) * 256;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double v = p[r * 64 + lane];
+                const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
+                M[i * ld + j] = v;
+                if (t != w) M[j * ld + i] = v;  // diagonal tiles are stored in full (deterministic: no double writer)
+            }
+        }
+}
+
+// ---- MFMA contraction: acc += X·Y, X and Y addressed as X[i][k], Y[k][j] through element functors ----
+// A operand of v_mfma_f64_16x16x4_f64: lane l holds X[i = l&15][k = l>>4]; B operand: Y[k = l>>4][j = l&15].
+template <int NT, bool TX, bool TY>
+__device__ __forceinline__ void mm_acc(Acc<NT>& c, const double* X, int ldx, const double* Y, int ldy, int w, int lane) {
+    constexpr int D = 16 * NT;
+    const int i = 16 * w + (lane & 15), kq = lane >> 4, jl = lane & 15;
+    d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4){c.v[t][0], c.v[t][1], c.v[t][2], c.v[t][3]};
+#pragma unroll 4
+    for (int kk = 0; kk < D / 4; ++kk) {
+        const int k = 4 * kk + kq;
+        const double a = TX ? X[k * ldx + i] : X[i * ldx + k];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = 16 * t + jl;
+            const double b = TY ? Y[j * ldy + k] : Y[k * ldy + j];
+            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        c.v[t][0] = acc[t][0];
+        c.v[t][1] = acc[t][1];
+        c.v[t][2] = acc[t][2];
+        c.v[t][3] = acc[t][3];
+    }
+}
+
+// ---- SPD inverse, in place on the accumulator registers (restates FastCholesky.cholinv for large blocks) ----
+// Symmetric sweep operator, one pivot per barrier:  with r = row p of the current matrix, d = 1/r_p,
+//     a_ij <- a_ij − (r_i r_j) d   (i,j ≠ p);   a_pj = a_jp <- r_j d;   a_pp <- −d
+// keeps the array exactly symmetric (the product r_i r_j commutes bitwise), so only the pivot ROW is
+// published through LDS and every thread reads it at its 4 row and NT column positions.  After all D
+// sweeps the array holds −A⁻¹.  The 16 pivots of a tile block are unrolled at compile time (template
+// recursion): the owner register / lane group of the pivot row are constants, no dynamic register selection.
+// rowbuf: 2·D doubles (double buffered, one barrier per pivot).  lp accumulates log det A.
+template <int NT, int Q>
+struct Sweep {
+    // pivot p = 16·pb + Q: the register (Q>>2) and lane group (Q&3) of row p are compile-time constants,
+    // the tile block pb is a (wave-uniform) run-time value
+    static __device__ __forceinline__ void run(Acc<NT>& a, double* rowbuf, int pb, int w, int lane, bool& ok, LogProd& lp) {
+        constexpr int D = 16 * NT, PR = Q >> 2, PQ = Q & 3;
+        const int p = 16 * pb + Q;
+        double* rb = rowbuf + (Q & 1) * D;
+        const bool rowp = (w == pb) && ((lane >> 4) == PQ);
+        if (rowp) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) rb[16 * t + (lane & 15)] = a.v[t][PR];
+        }
+        __syncthreads();
+        const double piv = rb[p];
+        ok = ok && (piv > 0.0);
+        if (w == 0 && lane == 0) lp.mul(piv);
+        const double d = rcp_pos(piv);
+        double rc[NT], rr[4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) rc[t] = rb[16 * t + (lane & 15)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rr[r] = rb[16 * w + (lane >> 4) + 4 * r];
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.v[t][r] = __builtin_fma(-(rr[r] * rc[t]), d, a.v[t][r]);
+        // row p (this wave, register PR) and column p (tile pb, lanes with lane&15 == Q)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) a.v[t][PR] = rowp ? rc[t] * d : a.v[t][PR];
+        const bool colq = (lane & 15) == Q;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const bool colp = colq && (t == pb);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.v[t][r] = colp ? rr[r] * d : a.v[t][r];
+            a.v[t][PR] = (rowp && colp) ? -d : a.v[t][PR];
+        }
+        Sweep<NT, Q + 1>::run(a, rowbuf, pb, w, lane, ok, lp);
+    }
+};
+template <int NT>
+struct Sweep<NT, 16> {
+    static __device__ __forceinline__ void run(Acc<NT>&, double*, int, int, int, bool&, LogProd&) {}
+};
+template <int NT>
+__device__ __forceinline__ bool gj_inverse(Acc<NT>& a, double* rowbuf, double* /*colbuf*/, int w, int lane, LogProd& lp) {
+    bool ok = true;
+#pragma unroll 1
+    for (int pb = 0; pb < NT; ++pb) Sweep<NT, 0>::run(a, rowbuf, pb, w, lane, ok, lp);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.v[t][r] = -a.v[t][r];
+    __syncthreads();
+    return ok;
+}
+
+// ---- vectors in LDS ------------------------------------------------------------------------------
+// out[i] = s0·add[i] + Σ_k M[i][k] x[k]   (M: n×m row-major ld; thread i < n does row i)
+__device__ __forceinline__ void matvec_lds(double* out, const double* M, int ld, int n, int m, const double* x,
+                                           const double* add, double sadd, int tid) {
+    if (tid < n) {
+        double s = add ? sadd * add[tid] : 0.0;
+#pragma unroll 8
+        for (int k = 0; k < m; ++k) s += M[tid * ld + k] * x[k];
+        out[tid] = s;
+    }
+}
+// out[k] = Σ_i M[i][k] x[i]  (transposed)
+__device__ __forceinline__ void matTvec_lds(double* out, const double* M, int ld, int n, int m, const double* x,
+                                            const double* add, double sadd, int tid) {
+    if (tid < m) {
+        double s = add ? sadd * add[tid] : 0.0;
+        for (int i = 0; i < n; ++i) s += M[i * ld + tid] * x[i];
+        out[tid] = s;
+    }
+}
+// out[i] = sadd·add[i] + Σ_k MT[k][i] x[k]  with MT = M' stored row-major [m][n] in global memory:
+// consecutive threads read consecutive addresses (coalesced), the m loads of a thread are independent.
+__device__ __forceinline__ void matvec_gT(double* out, const double* MT, int n, int m, const double* x, const double* add,
+                                          double sadd, int tid) {
+    if (tid < n) {
+        double s0 = add ? sadd * add[tid] : 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = 0;
+        for (; k + 15 < m; k += 16) {  // 16 independent (coalesced) loads in flight per thread
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = MT[(size_t)(k + u) * n + tid];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                s0 += v[u] * x[k + u];
+                s1 += v[u + 1] * x[k + u + 1];
+                s2 += v[u + 2] * x[k + u + 2];
+                s3 += v[u + 3] * x[k + u + 3];
+            }
+        }
+        for (; k < m; ++k) s0 += MT[(size_t)k * n + tid] * x[k];
+        out[tid] = (s0 + s1) + (s2 + s3);
+    }
+}
+// out[i] = base[i] + Σ_k M1T[k][i] x1[k] + sgn2 · Σ_k M2T[k][i] x2[k]   (both maps stored transposed, n×n).
+// All threads work: thread (part, i) sums a quarter/…/ of the k range with 8 coalesced loads in flight per
+// map, partial sums are combined through LDS in fixed order.  part count = nthreads / n (n = 16·NT ⇒ 4).
+__device__ __forceinline__ void matvec2_gT_all(double* out, const double* M1T, const double* M2T, int n, const double* x1,
+                                               const double* x2, double sgn2, const double* base, double* red, int tid,
+                                               int nthreads) {
+    const int parts = nthreads / n, part = tid / n, i = tid - part * n;
+    const int kper = (n + parts - 1) / parts, k0 = part * kper, k1 = (k0 + kper < n) ? k0 + kper : n;
+    double s0 = 0.0, s1 = 0.0;
+    int k = k0;
+    for (; k + 7 < k1; k += 8) {
+        double a[8], b[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            a[u] = M1T[(size_t)(k + u) * n + i];
+            b[u] = M2T[(size_t)(k + u) * n + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            s0 += a[u] * x1[k + u];
+            s1 += b[u] * x2[k + u];
+        }
+    }
+    for (; k < k1; ++k) {
+        s0 += M1T[(size_t)k * n + i] * x1[k];
+        s1 += M2T[(size_t)k * n + i] * x2[k];
+    }
+    red[tid] = s0 + sgn2 * s1;
+    __syncthreads();
+    if (tid < n) {
+        double s = base[tid];
+        for (int q = 0; q < parts; ++q) s += red[q * n + tid];
+        out[tid] = s;
+    }
+    __syncthreads();
+}
+
+// three block-wide dot products in one reduction (result valid in every thread); red: 3·nthreads doubles.
+// Works for any thread count (192 threads at d = 48).
+__device__ __forceinline__ void block_dot3(const double* a0, const double* b0, int n0, const double* a1, const double* b1,
+                                           int n1, const double* a2, const double* b2, int n2, double* red, int tid,
+                                           int nthreads, double (&out)[3]) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int i = tid; i < n0; i += nthreads) s0 += a0[i] * b0[i];
+    for (int i = tid; i < n1; i += nthreads) s1 += a1[i] * b1[i];
+    for (int i = tid; i < n2; i += nthreads) s2 += a2[i] * b2[i];
+    red[tid] = s0;
+    red[nthreads + tid] = s1;
+    red[2 * nthreads + tid] = s2;
+    __syncthreads();
+    for (int n = nthreads; n > 1;) {
+        const int h = (n + 1) / 2;
+        if (tid < n - h) {
+            red[tid] += red[tid + h];
+            red[nthreads + tid] += red[nthreads + tid + h];
+            red[2 * nthreads + tid] += red[2 * nthreads + tid + h];
+        }
+        __syncthreads();
+        n = h;
+    }
+    out[0] = red[0];
+    out[1] = red[nthreads];
+    out[2] = red[2 * nthreads];
+    __syncthreads();
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS carve (dynamic): 4 matrices + vectors
+template <int NT>
+struct DenseLds {
+    using C = DenseCfg<NT>;
+    static constexpr int NVEC = 12;
+    static constexpr size_t bytes(int dmax) {
+        return sizeof(double) * ((size_t)4 * C::MAT + (size_t)NVEC * dmax + 4 * C::D + 3 * C::THREADS);
+    }
+};
+
+// phase 1 (dense): b, η of one segment.  One workgroup per (segment, chain).
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
+    constexpr int D = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int dy = p.dy, tid = threadIdx.x;
+    const int dm = D > dy ? D : dy;
+    double* m = smem;
+    double* mn = m + dm;
+    double* eta = mn + dm;
+    double* e = eta + dm;
+    double* yv = e + dm;
+    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const DenseCst c = DenseCst::make(D, dy);
+    const double* cst = p.cst;
+    const long long b0 = 1 + seg * p.L;
+    long long b1 = b0 + p.L;
+    if (b1 > p.T) b1 = p.T;
+    const long long len = b1 - b0;
+    const long long t0 = seg * p.L + 1;
+    if (tid < D) {
+        m[tid] = 0.0;
+        eta[tid] = 0.0;
+    }
+    __syncthreads();
+    for (long long i = 0; i < len; ++i) {
+        if (tid < dy) yv[tid] = p.y[((t0 + i) * p.n_chains + chain) * dy + tid];
+        __syncthreads();
+        // e = y − HF m
+        matvec_gT(e, cst + c.oHFT, dy, D, m, nullptr, 0.0, tid);
+        __syncthreads();
+        if (tid < dy) e[tid] = yv[tid] - e[tid];             // e = y − (BA) m
+        __syncthreads();
+        const double* tb = p.tab + i * 2 * D * dy;           // [2][dy][D]: K_i', U_i' (transposed, coalesced)
+        if (tid < D) {
+            double s = 0.0, u = eta[tid];
+            for (int k = 0; k < D; ++k) s += cst[c.oAT + (long long)k * D + tid] * m[k];
+            for (int k = 0; k < dy; ++k) {
+                s += tb[(long long)k * D + tid] * e[k];
+                u += tb[(long long)dy * D + (long long)k * D + tid] * e[k];
+            }
+            mn[tid] = s;
+            eta[tid] = u;
+        }
+        __syncthreads();
+        if (tid < D) m[tid] = mn[tid];
+        __syncthreads();
+    }
+    if (tid < D) {
+        double* o = p.elem + ((chain * p.S + seg) * 2) * D;
+        o[tid] = m[tid];
+        o[D + tid] = eta[tid];
+    }
+}
+
+// phase 2 (dense): carries the data-dependent vectors across segment boundaries with the per-model maps.
+//   blockIdx.x = 0: prefix   m(b_{s+1}) = M1_s m(b_s) + M2_s η_s + b_s ;  also the t = 1 update
+//   blockIdx.x = 1: suffix   ξβ(b_s) = η_s + N1_s ξβ(b_{s+1}) − N2_s b_s
+template <int NT, bool FE>
+__global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
+    constexpr int D = 16 * NT;
+    using C = DenseCfg<NT>;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int dm = D > dy ? D : dy;
+    double* v0 = smem;
+    double* v1 = v0 + dm;
+    double* v2 = v1 + dm;
+    double* yv = v2 + dm;
+    double* red = yv + dm;
+    const long long chain = blockIdx.y;
+    const DenseCst c = DenseCst::make(D, dy);
+    const double* cst = p.cst;
+    const int S = p.S;
+    const size_t MM = (size_t)D * D;
+    if (blockIdx.x == 0) {
+        // filtered belief at t = 1: ξf = V1⁻¹m1 + G y;  mf = c1 + K1 y
+        if (tid < dy) yv[tid] = p.y[(0 * p.n_chains + chain) * dy + tid];
+        __syncthreads();
+        if (tid < D) {
+            double xs = cst[c.oX1 + tid], ms = cst[c.oC1 + tid];
+            for (int k = 0; k < dy; ++k) {
+                xs += cst[c.oGT + (long long)k * D + tid] * yv[k];
+                ms += cst[c.oK1T + (long long)k * D + tid] * yv[k];
+            }
+            v1[tid] = xs;  // ξf
+            v0[tid] = ms;  // mf
+        }
+        if (tid < dy) {
+            double s = 0.0;
+            for (int k = 0; k < dy; ++k) s += cst[c.oQI + (long long)tid * dy + k] * yv[k];
+            v2[tid] = s;  // Q⁻¹ y
+        }
+        __syncthreads();
+        double* rec = p.filt + (chain * p.T + 0) * C::REC;
+        if (tid < D) rec[tid] = v0[tid];
+        {
+            Acc<NT> a;
+            acc_load<NT>(a, cst + c.oVF1, D, w, lane);
+            acc_store_tri<NT>(a, rec + D, w, lane);
+            if (p.T == 1) {
+                if (tid < D) p.mean[(0 * p.n_chains + chain) * D + tid] = v0[tid];
+                acc_store<NT>(a, p.cov + (0 * p.n_chains + chain) * MM, D, w, lane);
+            }
+        }
+        if (FE) {
+            double dots[3];
+            block_dot3(v2, yv, dy, v1, v0, D, v1, v0, 0, red, tid, 64 * NT, dots);
+            if (tid == 0) p.fe_part[chain] = -0.5 * (cst[c.oC0] + dots[0] - dots[1] + cst[c.oS1] + cst[c.oLD1]);
+        }
+        for (int s = 0; s < S; ++s) {
+            if (tid < D) p.fstart_m[(chain * S + s) * D + tid] = v0[tid];
+            if (s == S - 1) break;
+            const double* el = p.elem + ((chain * S + s) * 2) * D;
+            const double* M1 = p.scanm + ((size_t)s * 6 + 0) * MM;
+            const double* M2 = p.scanm + ((size_t)s * 6 + 1) * MM;
+            __syncthreads();
+            if (tid < D) {
+                v2[tid] = el[D + tid];  // η_s
+                yv[tid] = el[tid];      // b_s
+            }
+            __syncthreads();
+            matvec2_gT_all(v1, M1, M2, D, v0, v2, 1.0, yv, red, tid, 64 * NT);
+            if (tid < D) v0[tid] = v1[tid];
+            __syncthreads();
+        }
+    } else {
+        if (tid < D) {
+            v0[tid] = 0.0;
+            p.beta_xi[(chain * (S + 1) + S) * D + tid] = 0.0;
+        }
+        __syncthreads();
+        for (int s = S - 1; s >= 1; --s) {
+            const double* el = p.elem + ((chain * S + s) * 2) * D;
+            const double* N1 = p.scanm + ((size_t)s * 6 + 3) * MM;
+            const double* N2 = p.scanm + ((size_t)s * 6 + 4) * MM;
+            if (tid < D) {
+                v2[tid] = el[tid];      // b_s
+                yv[tid] = el[D + tid];  // η_s
+            }
+            __syncthreads();
+            matvec2_gT_all(v1, N1, N2, D, v0, v2, -1.0, yv, red, tid, 64 * NT);
+            if (tid < D) {
+                v0[tid] = v1[tid];
+                p.beta_xi[(chain * (S + 1) + s) * D + tid] = v1[tid];
+            }
+            __syncthreads();
+        }
+    }
+}
+
+// phase 3 (dense): forward sweep of one segment.
+template <int NT, bool FE>
+__global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
+    constexpr int D = 16 * NT;
+    using C = DenseCfg<NT>;
+    constexpr int LD = C::LD;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int dm = D > dy ? D : dy;
+    double* M0 = smem;               // V (state covariance), then Vf
+    double* M1 = M0 + C::MAT;        // T = A V, then Λp
+    double* vec = M1 + 2 * C::MAT + C::MAT;  // after 4 matrix slots (M2, M3 unused here)
+    double* m = vec;
+    double* mp = m + dm;
+    double* xp = mp + dm;
+    double* xf = xp + dm;
+    double* yv = xf + dm;
+    double* qy = yv + dm;
+    double* rowbuf = qy + dm;
+    double* colbuf = rowbuf + 2 * D;
+    double* red = colbuf + 2 * D;
+    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const DenseCst c = DenseCst::make(D, dy);
+    const double* cst = p.cst;
+    const double* A = cst + c.oA;
+    const size_t MM = (size_t)D * D;
+    const long long b0 = 1 + seg * p.L;
+    long long b1 = b0 + p.L;
+    if (b1 > p.T) b1 = p.T;
+    const long long len = b1 - b0, t0 = seg * p.L + 1;
+    bool ok = true;
+    double acc_quad = 0.0;
+    LogProd lp;
+    // state at the segment start: mean from the scan, covariance from the per-model table
+    if (tid < D) m[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
+    {
+        Acc<NT> a;
+        acc_load<NT>(a, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
+        acc_store<NT>(a, M0, LD, w, lane);
+    }
+    __syncthreads();
+    for (long long i = 0; i < len; ++i) {
+        const long long t = t0 + i;
+        if (tid < dy) yv[tid] = p.y[(t * p.n_chains + chain) * dy + tid];
+        // `*`_A(:out): T = A V ; Vp = T A' + P ;  mp = A m
+        Acc<NT> a;
+        acc_zero<NT>(a);
+        if (!(p.ablate & 2)) mm_acc<NT, false, false>(a, A, D, M0, LD, w, lane);
+        acc_store<NT>(a, M1, LD, w, lane);
+        if (!(p.ablate & 4)) matvec_gT(mp, cst + c.oAT, D, D, m, nullptr, 0.0, tid);
+        __syncthreads();
+        acc_load<NT>(a, cst + c.oP, D, w, lane);
+        if (!(p.ablate & 2)) mm_acc<NT, false, true>(a, M1, LD, A, D, w, lane);
+        // weightedmean_precision of the forward message: Λp = Vp⁻¹
+        if (!(p.ablate & 1)) ok = gj_inverse<NT>(a, rowbuf, colbuf, w, lane, lp) && ok;
+        acc_store<NT>(a, M1, LD, w, lane);
+        __syncthreads();
+        // product with the `*`_B(:in) message: Λf = Λp + B'Q⁻¹B, ξf = Λp mp + G y
+        if (!(p.ablate & 4)) {
+            matvec_lds(xp, M1, LD, D, D, mp, nullptr, 0.0, tid);
+            matvec_gT(qy, cst + c.oQI, dy, dy, yv, nullptr, 0.0, tid);  // Q⁻¹ symmetric
+        }
+        __syncthreads();
+        if (!(p.ablate & 4)) matvec_gT(xf, cst + c.oGT, D, dy, yv, xp, 1.0, tid);
+        acc_add_mat<NT>(a, cst + c.oLOBS, D, w, lane, 1.0);
+        // mean_cov of the product: Vf = Λf⁻¹, mf = Vf ξf
+        if (!(p.ablate & 1)) ok = gj_inverse<NT>(a, rowbuf, colbuf, w, lane, lp) && ok;
+        acc_store<NT>(a, M0, LD, w, lane);
+        __syncthreads();
+        if (!(p.ablate & 4)) matvec_lds(m, M0, LD, D, D, xf, nullptr, 0.0, tid);
+        __syncthreads();
+        double* rec = p.filt + (chain * p.T + t) * C::REC;
+        if (!(p.ablate & 8)) {
+            if (tid < D) rec[tid] = m[tid];
+            acc_store_tri<NT>(a, rec + D, w, lane);
+        }
+        if (FE && !(p.ablate & 16)) {
+            double dots[3];
+            block_dot3(qy, yv, dy, xf, m, D, xp, mp, D, red, tid, 64 * NT, dots);
+            acc_quad += cst[c.oC0] + dots[0] - dots[1] + dots[2];
+        }
+    }
+    if (FE && tid == 0) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc_quad + lp.value());
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// phase 4 (dense): backward sweep + marginals of one segment (RTS form, see lgssm_kernels.hpp).
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
+    constexpr int D = 16 * NT;
+    using C = DenseCfg<NT>;
+    constexpr int LD = C::LD;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int dm = D > dy ? D : dy;
+    double* M0 = smem;
+    double* M1 = M0 + C::MAT;
+    double* M2 = M1 + C::MAT;
+    double* M3 = M2 + C::MAT;
+    double* vec = M3 + C::MAT;
+    double* ms = vec;
+    double* mf = ms + dm;
+    double* mp = mf + dm;
+    double* dv = mp + dm;
+    double* u = dv + dm;
+    double* tmp = u + dm;
+    double* rowbuf = tmp + dm;
+    double* colbuf = rowbuf + 2 * D;
+    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const DenseCst c = DenseCst::make(D, dy);
+    const double* cst = p.cst;
+    const double* A = cst + c.oA;
+    const size_t MM = (size_t)D * D;
+    const long long b0 = 1 + seg * p.L;
+    long long b1 = b0 + p.L;
+    if (b1 > p.T) b1 = p.T;
+    const long long len = b1 - b0, tb = seg * p.L, te = tb + len;
+    bool ok = true;
+    LogProd lpd;  // determinants are not needed in this pass
+    // smoothed belief at the end boundary: (Vf⁻¹ + Λβ)⁻¹, Vs (Vf⁻¹ mf + ξβ)
+    {
+        const double* rec = p.filt + (chain * p.T + te) * C::REC;
+        if (tid < D) mf[tid] = rec[tid];
+        tri_to_lds<NT>(rec + D, M0, LD, w, lane);
+        __syncthreads();
+        Acc<NT> a;
+        acc_load<NT>(a, M0, LD, w, lane);
+        ok = gj_inverse<NT>(a, rowbuf, colbuf, w, lane, lpd) && ok;  // Vf⁻¹
+        acc_store<NT>(a, M1, LD, w, lane);
+        __syncthreads();
+        if (tid < D) {
+            double s = p.beta_xi[(chain * (p.S + 1) + seg + 1) * D + tid];
+            for (int k = 0; k < D; ++k) s += M1[tid * LD + k] * mf[k];
+            u[tid] = s;
+        }
+        acc_add_mat<NT>(a, p.scanm + ((size_t)seg * 6 + 5) * MM, D, w, lane, 1.0);
+        ok = gj_inverse<NT>(a, rowbuf, colbuf, w, lane, lpd) && ok;  // Vs
+        acc_store<NT>(a, M2, LD, w, lane);
+        __syncthreads();
+        matvec_lds(ms, M2, LD, D, D, u, nullptr, 0.0, tid);
+        __syncthreads();
+        if (seg == p.S - 1) {
+            if (tid < D) p.mean[(te * p.n_chains + chain) * D + tid] = ms[tid];
+            acc_store<NT>(a, p.cov + (te * p.n_chains + chain) * MM, D, w, lane);
+        }
+    }
+    for (long long t = te - 1; t >= tb; --t) {
+        const double* rec = p.filt + (chain * p.T + t) * C::REC;
+        if (tid < D) mf[tid] = rec[tid];
+        tri_to_lds<NT>(rec + D, M0, LD, w, lane);  // Vf
+        __syncthreads();
+        // T = A Vf ; Vp = T A' + P ; mp = A mf
+        Acc<NT> a, vp;
+        acc_zero<NT>(a);
+        mm_acc<NT, false, false>(a, A, D, M0, LD, w, lane);
+        acc_store<NT>(a, M1, LD, w, lane);
+        matvec_gT(mp, cst + c.oAT, D, D, mf, nullptr, 0.0, tid);
+        __syncthreads();
+        acc_load<NT>(a, cst + c.oP, D, w, lane);
+        mm_acc<NT, false, true>(a, M1, LD, A, D, w, lane);
+        vp = a;
+        ok = gj_inverse<NT>(a, rowbuf, colbuf, w, lane, lpd) && ok;  // Λp
+        acc_store<NT>(a, M3, LD, w, lane);
+        // D = Vs − Vp  (into M2, overwriting Vs after it has been read into registers)
+        Acc<NT> dd;
+        acc_load<NT>(dd, M2, LD, w, lane);
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dd.v[q][r] -= vp.v[q][r];
+        if (tid < D) dv[tid] = ms[tid] - mp[tid];
+        __syncthreads();
+        acc_store<NT>(dd, M2, LD, w, lane);
+        // G = T' Λp
+        acc_zero<NT>(a);
+        mm_acc<NT, true, false>(a, M1, LD, M3, LD, w, lane);
+        __syncthreads();
+        acc_store<NT>(a, M3, LD, w, lane);  // G (Λp no longer needed)
+        __syncthreads();
+        // H = G D
+        acc_zero<NT>(a);
+        mm_acc<NT, false, false>(a, M3, LD, M2, LD, w, lane);
+        acc_store<NT>(a, M1, LD, w, lane);  // H (T no longer needed)
+        // ms = mf + G dv
+        matvec_lds(tmp, M3, LD, D, D, dv, mf, 1.0, tid);
+        __syncthreads();
+        // Vs = Vf + H G'
+        acc_load<NT>(a, M0, LD, w, lane);
+        mm_acc<NT, false, true>(a, M1, LD, M3, LD, w, lane);
+        if (tid < D) ms[tid] = tmp[tid];
+        __syncthreads();
+        acc_store<NT>(a, M2, LD, w, lane);
+        if (tid < D) p.mean[(t * p.n_chains + chain) * D + tid] = ms[tid];
+        acc_store<NT>(a, p.cov + (t * p.n_chains + chain) * MM, D, w, lane);
+        __syncthreads();
+    }
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+}  // namespace rxhip

@@ -12,10 +12,12 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
 #include "lgssm_kernels.hpp"
+#include "dense_kernels.hpp"
 
 using namespace rxhip;
 
@@ -150,6 +152,10 @@ struct rxhip_engine {
     int* d_chain_model = nullptr;
     int* d_status = nullptr;
     double* d_fe_blocks = nullptr;
+    // dense (d = 16·NT) path
+    bool dense = false;
+    int nt = 0;
+    double *d_scanm = nullptr, *d_fstart_m = nullptr, *d_beta_xi = nullptr;
     std::vector<double> h_cst0;  // model 0's constant block (kernel argument when all chains share it)
     int fe_total_cap = 0;
     // results bookkeeping
@@ -365,6 +371,206 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
     return RXHIP_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// dense path (d multiple of 16, ≤ 64): host-side per-model tables and launches
+static bool dense_supported(int d, int dy) { return d >= 16 && d <= 64 && d % 16 == 0 && dy >= 1 && dy <= 64; }
+
+template <int NT>
+struct DenseLaunch {
+    static size_t lds_bytes(int d, int dy) { return DenseLds<NT>::bytes(d > dy ? d : dy); }
+    static hipError_t prepare(int d, int dy) {
+        const int bytes = (int)lds_bytes(d, dy);
+        hipError_t e;
+        if ((e = hipFuncSetAttribute((const void*)kd_seg_aggregate<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_boundary_scan<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_boundary_scan<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_forward<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_forward<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_backward<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        return hipSuccess;
+    }
+    static void seg_aggregate(const DenseParams& p, hipStream_t s) {
+        hipLaunchKernelGGL((kd_seg_aggregate<NT>), dim3(p.S, (unsigned)p.n_chains), dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+    }
+    static void boundary_scan(const DenseParams& p, bool fe, hipStream_t s) {
+        dim3 g(2, (unsigned)p.n_chains);
+        if (fe) hipLaunchKernelGGL((kd_boundary_scan<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        else hipLaunchKernelGGL((kd_boundary_scan<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+    }
+    static void forward(const DenseParams& p, bool fe, hipStream_t s) {
+        dim3 g(p.S, (unsigned)p.n_chains);
+        if (fe) hipLaunchKernelGGL((kd_forward<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        else hipLaunchKernelGGL((kd_forward<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+    }
+    static void backward(const DenseParams& p, hipStream_t s) {
+        hipLaunchKernelGGL((kd_backward<NT>), dim3(p.S, (unsigned)p.n_chains), dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+    }
+};
+#define DENSE_DISPATCH(nt, CALL)                    \
+    switch (nt) {                                   \
+        case 1: DenseLaunch<1>::CALL; break;        \
+        case 2: DenseLaunch<2>::CALL; break;        \
+        case 3: DenseLaunch<3>::CALL; break;        \
+        default: DenseLaunch<4>::CALL; break;       \
+    }
+static int dense_rec(int nt) { return 16 * nt + nt * (nt + 1) / 2 * 256; }
+
+// Per-model tables of the dense path: constants, per-offset gains (K_i, U_i), and the data-independent
+// matrix part of the boundary scan for every segment (see dense_kernels.hpp DenseParams::scanm).
+static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* ds, std::vector<double>& cst,
+                                       std::vector<double>& tab, std::vector<double>& scanm) {
+    const int d = e->d, dy = e->dy;
+    const size_t MM = (size_t)d * d;
+    const double *A = ds->A, *B = ds->B, *P = ds->P, *Q = ds->Q, *m0 = ds->m0, *V0 = ds->V0;
+    const DenseCst c = DenseCst::make(d, dy);
+    cst.assign((size_t)c.size, 0.0);
+    std::vector<double> Qi(dy * dy), G(d * dy), Lobs(MM), HF(dy * d), V1(MM), V1i(MM), m1(d), t1(MM + dy * d + d * dy),
+        t2(MM + dy * d + d * dy), Lf(MM), Vf1(MM);
+    double ldQ = 0, ldV1 = 0, ldLf = 0;
+    if (!host::chol_inv(dy, Q, Qi.data(), &ldQ)) return fail(e, RXHIP_ERR_NOT_POSDEF, "observation noise Q is not positive definite");
+    if (!host::chol_inv(d, P, t1.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "state noise P is not positive definite");
+    host::mTm(dy, d, dy, B, Qi.data(), G.data());
+    host::mm(d, dy, d, G.data(), B, Lobs.data());
+    host::mm(dy, d, d, B, A, HF.data());
+    if (e->ptt) {
+        for (int i = 0; i < d; ++i) {
+            double s = 0;
+            for (int k = 0; k < d; ++k) s += A[i * d + k] * m0[k];
+            m1[i] = s;
+        }
+        host::mm(d, d, d, A, V0, t1.data());
+        host::mmT(d, d, d, t1.data(), A, V1.data());
+        for (size_t i = 0; i < MM; ++i) V1[i] += P[i];
+    } else {
+        for (int i = 0; i < d; ++i) m1[i] = m0[i];
+        for (size_t i = 0; i < MM; ++i) V1[i] = V0[i];
+    }
+    if (!host::chol_inv(d, V1.data(), V1i.data(), &ldV1)) return fail(e, RXHIP_ERR_NOT_POSDEF, "prior covariance is not positive definite");
+    for (size_t i = 0; i < MM; ++i) Lf[i] = V1i[i] + Lobs[i];
+    if (!host::chol_inv(d, Lf.data(), Vf1.data(), &ldLf)) return fail(e, RXHIP_ERR_NOT_POSDEF, "first filtered precision not positive definite");
+    for (size_t i = 0; i < MM; ++i) { cst[c.oA + i] = A[i]; cst[c.oP + i] = 0.5 * (P[i] + P[(i % d) * d + i / d]); cst[c.oLOBS + i] = Lobs[i]; cst[c.oVF1 + i] = Vf1[i]; }
+    for (int i = 0; i < d * dy; ++i) cst[c.oG + i] = G[i];
+    for (int i = 0; i < dy * dy; ++i) cst[c.oQI + i] = Qi[i];
+    for (int i = 0; i < dy * d; ++i) cst[c.oHF + i] = HF[i];
+    cst[c.oC0] = dy * 1.8378770664093454835606594728112 + ldQ;
+    double s1 = 0;
+    for (int i = 0; i < d; ++i) {
+        double s = 0;
+        for (int k = 0; k < d; ++k) s += V1i[i * d + k] * m1[k];
+        cst[c.oX1 + i] = s;
+        s1 += s * m1[i];
+    }
+    cst[c.oS1] = s1;
+    cst[c.oLD1] = ldLf + ldV1;
+    for (int i = 0; i < d; ++i) {
+        double s = 0;
+        for (int k = 0; k < d; ++k) s += Vf1[i * d + k] * cst[c.oX1 + k];
+        cst[c.oC1 + i] = s;
+    }
+    host::mm(d, d, dy, Vf1.data(), G.data(), &cst[c.oK1]);
+    for (int i = 0; i < d; ++i) {
+        for (int k = 0; k < d; ++k) cst[c.oAT + (size_t)k * d + i] = A[i * d + k];
+        for (int k = 0; k < dy; ++k) {
+            cst[c.oGT + (size_t)k * d + i] = G[i * dy + k];
+            cst[c.oK1T + (size_t)k * d + i] = cst[c.oK1 + (size_t)i * dy + k];
+            cst[c.oHFT + (size_t)i * dy + k] = HF[k * d + i];
+        }
+    }
+
+    // gains and element matrices (Kalman filter from an exactly known state)
+    const long long L = e->L;
+    tab.assign((size_t)L * 2 * d * dy, 0.0);
+    std::vector<double> V(MM, 0.0), Pi(MM, 0.0), J(MM, 0.0), Vp(MM), S(dy * dy), Si(dy * dy), K(d * dy), HFPi(dy * d),
+        U(d * dy), Phi(MM);
+    struct Agg { std::vector<double> Pi, C, J, Ci, X, JJ; };
+    Agg ag[2];
+    for (int i = 0; i < d; ++i) Pi[i * d + i] = 1.0;
+    for (long long i = 1; i <= L; ++i) {
+        host::mm(d, d, d, A, V.data(), t1.data());
+        host::mmT(d, d, d, t1.data(), A, Vp.data());
+        for (size_t q = 0; q < MM; ++q) Vp[q] += P[q];
+        host::mm(dy, d, d, B, Vp.data(), t1.data());
+        host::mmT(dy, d, dy, t1.data(), B, S.data());
+        for (int q = 0; q < dy * dy; ++q) S[q] += Q[q];
+        if (!host::chol_inv(dy, S.data(), Si.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "innovation covariance not positive definite");
+        host::mTm(dy, d, dy, t1.data(), Si.data(), K.data());
+        host::mm(dy, d, d, HF.data(), Pi.data(), HFPi.data());
+        host::mTm(dy, d, dy, HFPi.data(), Si.data(), U.data());
+        host::mm(d, dy, d, U.data(), HFPi.data(), t2.data());
+        for (size_t q = 0; q < MM; ++q) J[q] += t2[q];
+        host::mm(d, dy, d, K.data(), t1.data(), t2.data());
+        for (int a = 0; a < d; ++a)
+            for (int b = 0; b <= a; ++b) {
+                double s = 0.5 * ((Vp[a * d + b] - t2[a * d + b]) + (Vp[b * d + a] - t2[b * d + a]));
+                V[a * d + b] = V[b * d + a] = s;
+            }
+        host::mm(d, dy, d, K.data(), HF.data(), t2.data());
+        for (size_t q = 0; q < MM; ++q) Phi[q] = A[q] - t2[q];
+        host::mm(d, d, d, Phi.data(), Pi.data(), t2.data());
+        for (size_t q = 0; q < MM; ++q) Pi[q] = t2[q];
+        double* te = tab.data() + (size_t)(i - 1) * 2 * d * dy;
+        for (int a = 0; a < d; ++a)
+            for (int b = 0; b < dy; ++b) { te[(size_t)b * d + a] = K[a * dy + b]; te[(size_t)d * dy + (size_t)b * d + a] = U[a * dy + b]; }
+        for (int which = 0; which < 2; ++which) {
+            if (i != (which == 0 ? L : e->Llast)) continue;
+            Agg& g = ag[which];
+            g.Pi = Pi; g.C = V; g.J = J;
+            for (int a = 0; a < d; ++a) for (int b = 0; b < a; ++b) { double s = 0.5 * (g.J[a * d + b] + g.J[b * d + a]); g.J[a * d + b] = g.J[b * d + a] = s; }
+            g.Ci.resize(MM); g.X.resize(MM); g.JJ.resize(MM);
+            if (!host::chol_inv(d, V.data(), g.Ci.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "segment covariance not positive definite");
+            host::mm(d, d, d, g.Ci.data(), Pi.data(), g.X.data());
+            host::mTm(d, d, d, Pi.data(), g.X.data(), g.JJ.data());
+            for (size_t q = 0; q < MM; ++q) g.JJ[q] += g.J[q];
+        }
+    }
+    // boundary-scan matrices
+    const int S_ = e->S;
+    scanm.assign((size_t)(S_ > 0 ? S_ : 1) * 6 * MM, 0.0);
+    if (S_ > 0) {
+        std::vector<double> Vc = Vf1, Vi(MM), W(MM), M1(MM), M2(MM), tt(MM);
+        for (int s = 0; s < S_; ++s) {
+            double* sm = scanm.data() + (size_t)s * 6 * MM;
+            for (size_t q = 0; q < MM; ++q) sm[2 * MM + q] = Vc[q];
+            if (s == S_ - 1) break;
+            const Agg& g = ag[0];
+            if (!host::chol_inv(d, Vc.data(), Vi.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "boundary covariance not positive definite");
+            for (size_t q = 0; q < MM; ++q) tt[q] = Vi[q] + g.J[q];
+            if (!host::chol_inv(d, tt.data(), W.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "boundary precision not positive definite");
+            host::mm(d, d, d, g.Pi.data(), W.data(), M2.data());
+            host::mm(d, d, d, M2.data(), Vi.data(), M1.data());
+            host::mmT(d, d, d, M2.data(), g.Pi.data(), tt.data());
+            for (int a = 0; a < d; ++a)
+                for (int b = 0; b < d; ++b) { sm[(size_t)b * d + a] = M1[a * d + b]; sm[MM + (size_t)b * d + a] = M2[a * d + b]; }
+            for (int a = 0; a < d; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    double v = 0.5 * (tt[a * d + b] + tt[b * d + a]) + g.C[a * d + b];
+                    Vc[a * d + b] = Vc[b * d + a] = v;
+                }
+        }
+        std::vector<double> Lm(MM, 0.0), N1(MM), N2(MM);
+        // scanm[s][5] = Λβ(b_{s+1}); Λβ(b_S) = 0
+        for (int s = S_ - 1; s >= 1; --s) {
+            const Agg& g = ag[s == S_ - 1 ? 1 : 0];
+            double* sm = scanm.data() + (size_t)s * 6 * MM;
+            for (size_t q = 0; q < MM; ++q) { sm[5 * MM + q] = Lm[q]; tt[q] = g.Ci[q] + Lm[q]; }
+            if (!host::chol_inv(d, tt.data(), W.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "backward boundary precision not positive definite");
+            host::mTm(d, d, d, g.X.data(), W.data(), N1.data());   // X' W
+            host::mm(d, d, d, N1.data(), Lm.data(), N2.data());    // X' W Λ
+            host::mm(d, d, d, N1.data(), g.X.data(), tt.data());   // X' W X
+            for (int a = 0; a < d; ++a)
+                for (int b = 0; b < d; ++b) { sm[3 * MM + (size_t)b * d + a] = N1[a * d + b]; sm[4 * MM + (size_t)b * d + a] = N2[a * d + b]; }
+            for (int a = 0; a < d; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    double v = g.JJ[a * d + b] - 0.5 * (tt[a * d + b] + tt[b * d + a]);
+                    Lm[a * d + b] = Lm[b * d + a] = v;
+                }
+        }
+        for (size_t q = 0; q < MM; ++q) scanm[5 * MM + q] = Lm[q];  // segment 0: Λβ(b_1)
+    }
+    return RXHIP_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -391,7 +597,7 @@ int32_t rxhip_device_count(void) {
     return n;
 }
 
-int32_t rxhip_lgssm_supported(int32_t d, int32_t dy) { return find_vtbl(d, dy) ? 1 : 0; }
+int32_t rxhip_lgssm_supported(int32_t d, int32_t dy) { return (find_vtbl(d, dy) || dense_supported(d, dy)) ? 1 : 0; }
 
 const char* rxhip_last_error(const rxhip_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
@@ -406,6 +612,8 @@ static void free_all(rxhip_engine* e) {
     if (e->d_chain_model) (void)hipFree(e->d_chain_model);
     if (e->d_status) (void)hipFree(e->d_status);
     if (e->d_fe_blocks) (void)hipFree(e->d_fe_blocks);
+    for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi})
+        if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     e->pending.clear();
@@ -427,7 +635,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         !ds->B || !ds->P || !ds->Q || !ds->m0 || !ds->V0)
         return RXHIP_ERR_BADARG;
     const LgssmVtbl* vt = find_vtbl(ds->d, ds->dy);
-    if (!vt) return RXHIP_ERR_UNSUPPORTED;
+    const bool dense = !vt && dense_supported(ds->d, ds->dy) && ds->n_models == 1;
+    if (!vt && !dense) return RXHIP_ERR_UNSUPPORTED;
     if (ds->chain_model)
         for (long long c = 0; c < ds->n_chains; ++c)
             if (ds->chain_model[c] < 0 || ds->chain_model[c] >= ds->n_models) return RXHIP_ERR_BADARG;
@@ -437,6 +646,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     rxhip_engine* e = new rxhip_engine();
     *out = e;  // returned even on failure so that rxhip_last_error is readable; caller destroys
     e->vt = vt;
+    e->dense = dense;
+    e->nt = ds->d / 16;
     e->d = ds->d;
     e->dy = ds->dy;
     e->T = ds->T;
@@ -466,10 +677,12 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->L = 1;
         e->Llast = 1;
     } else {
-        long long S_target = ds->segments > 0 ? ds->segments : (65536 + e->n_chains - 1) / e->n_chains;
+        long long S_target = ds->segments > 0 ? ds->segments
+                             : dense ? (256 + e->n_chains - 1) / e->n_chains   // one workgroup per CU
+                                     : (65536 + e->n_chains - 1) / e->n_chains;
         if (S_target < 1) S_target = 1;
         long long L = (steps + S_target - 1) / S_target;
-        const long long Lmin = ds->segments > 0 ? 1 : 16;
+        const long long Lmin = ds->segments > 0 ? 1 : (dense ? 8 : 16);
         if (L < Lmin) L = Lmin;
         if (L > steps) L = steps;
         e->L = L;
@@ -477,6 +690,37 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->Llast = steps - (long long)(e->S - 1) * L;
     }
 
+    if (dense) {
+        std::vector<double> cst, tab, scanm;
+        rxhip_status st = build_dense_tables(e, ds, cst, tab, scanm);
+        if (st) return st;
+        hipError_t herr = hipSuccess;
+        DENSE_DISPATCH(e->nt, prepare(e->d, e->dy) == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
+        if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+        const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1), D = (size_t)e->d;
+        HIPCHK(e, hipMalloc(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64)));
+        HIPCHK(e, hipMalloc(&e->d_cst, sizeof(double) * cst.size()));
+        HIPCHK(e, hipMalloc(&e->d_tab, sizeof(double) * tab.size()));
+        HIPCHK(e, hipMalloc(&e->d_scanm, sizeof(double) * scanm.size()));
+        HIPCHK(e, hipMemcpy(e->d_cst, cst.data(), sizeof(double) * cst.size(), hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
+        HIPCHK(e, hipMemcpy(e->d_scanm, scanm.data(), sizeof(double) * scanm.size(), hipMemcpyHostToDevice));
+        HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * C * T * dense_rec(e->nt)));
+        HIPCHK(e, hipMalloc(&e->d_mean, sizeof(double) * T * C * D));
+        HIPCHK(e, hipMalloc(&e->d_cov, sizeof(double) * T * C * D * D));
+        HIPCHK(e, hipMalloc(&e->d_elem, sizeof(double) * C * Sg * 2 * D));
+        HIPCHK(e, hipMalloc(&e->d_fstart_m, sizeof(double) * C * Sg * D));
+        HIPCHK(e, hipMalloc(&e->d_beta_xi, sizeof(double) * C * (Sg + 1) * D));
+        HIPCHK(e, hipMalloc(&e->d_fe_part, sizeof(double) * (Sg + 1) * C));
+        HIPCHK(e, hipMalloc(&e->d_fe_chain, sizeof(double) * C));
+        e->fe_total_cap = 16;
+        HIPCHK(e, hipMalloc(&e->d_fe_total, sizeof(double) * e->fe_total_cap));
+        HIPCHK(e, hipMalloc(&e->d_status, sizeof(int)));
+        HIPCHK(e, hipMemset(e->d_status, 0, sizeof(int)));
+        HIPCHK(e, hipMemset(e->d_fe_part, 0, sizeof(double) * (Sg + 1) * C));
+        HIPCHK(e, hipMemset(e->d_fe_total, 0, sizeof(double) * e->fe_total_cap));
+        return RXHIP_OK;
+    }
     // per-model tables
     const size_t NP = (size_t)e->d + (size_t)e->d * (e->d + 1) / 2;
     const size_t NP2 = (NP + 1) / 2;
@@ -627,17 +871,44 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.status = e->d_status;
     const bool fe = want_fe != 0;
     rxhip_status st;
+    DenseParams dp;
+    if (e->dense) {
+        dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->S; dp.L = e->L; dp.d = e->d; dp.dy = e->dy;
+        dp.y = e->d_y; dp.filt = e->d_filt; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
+        dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
+        dp.fe_part = e->d_fe_part; dp.status = e->d_status;
+        { const char* ab = getenv("RXHIP_ABLATE"); dp.ablate = ab ? atoi(ab) : 0; }
+    }
     for (int it = 0; it < iterations; ++it) {
         p.iteration = it;
-        if (e->S > 0) {
+        if (e->dense) {
+            if (e->S > 0) {
+                if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
+                DENSE_DISPATCH(e->nt, seg_aggregate(dp, e->stream));
+                if ((st = prof_end(e))) return st;
+            }
+            if ((st = prof_begin(e, RXHIP_K_BOUNDARY_SCAN))) return st;
+            DENSE_DISPATCH(e->nt, boundary_scan(dp, fe, e->stream));
+            if ((st = prof_end(e))) return st;
+            if (e->S > 0) {
+                if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
+                DENSE_DISPATCH(e->nt, forward(dp, fe, e->stream));
+                if ((st = prof_end(e))) return st;
+                if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
+                DENSE_DISPATCH(e->nt, backward(dp, e->stream));
+                if ((st = prof_end(e))) return st;
+            }
+        } else if (e->S > 0) {
             if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
             e->vt->seg_aggregate(p, e->h_cst0.data(), e->uniform, e->stream);
             if ((st = prof_end(e))) return st;
         }
-        if ((st = prof_begin(e, RXHIP_K_BOUNDARY_SCAN))) return st;
-        e->vt->boundary_scan(p, e->h_cst0.data(), e->uniform, fe, e->stream);
-        if ((st = prof_end(e))) return st;
-        if (e->S > 0) {
+        if (!e->dense) {
+            if ((st = prof_begin(e, RXHIP_K_BOUNDARY_SCAN))) return st;
+            e->vt->boundary_scan(p, e->h_cst0.data(), e->uniform, fe, e->stream);
+            if ((st = prof_end(e))) return st;
+        }
+        if (!e->dense && e->S > 0) {
             if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
             e->vt->forward(p, e->h_cst0.data(), e->uniform, fe, e->stream);
             if ((st = prof_end(e))) return st;

@@ -66,3 +66,14 @@ def random_model(d, dy, seed, stable=0.95):
     V0 = Wv @ Wv.T + np.eye(d)
     m0 = rng.standard_normal(d)
     return dict(A=A, B=B, P=P, Q=Q, m0=m0, V0=V0)
+
+
+def c3_model(d=64):
+    """BASELINE config 3: d = dy = 64, dense A = 0.98·Q-factor of default_rng(64) normals,
+    dense full-rank B = I + 0.1·G/8 (G from the same generator), state noise 0.05·I, obs noise 10·I,
+    prior N(0, 100·I)."""
+    rng = np.random.default_rng(64)
+    Qm, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    G = rng.standard_normal((d, d))
+    return dict(A=0.98 * Qm, B=np.eye(d) + 0.1 * G / 8.0, P=0.05 * np.eye(d), Q=10.0 * np.eye(d), m0=np.zeros(d),
+                V0=100.0 * np.eye(d))

@@ -20,10 +20,16 @@ ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--T", type=int, default=100000)
 ap.add_argument("--chains", type=int, default=1024)
 ap.add_argument("--segments", type=int, default=0)
+ap.add_argument("--config", default="c2")
 a = ap.parse_args()
-mdl = workloads.c1_model()
+if a.config == "c3":
+    mdl = workloads.c3_model()
+    if a.T == 100000:
+        a.T, a.chains = 10000, 1
+else:
+    mdl = workloads.c1_model()
 rng = np.random.default_rng(0)
-y = rng.standard_normal((a.T, a.chains, 4)) * 3.0
+y = rng.standard_normal((a.T, a.chains, mdl["B"].shape[0])) * 3.0
 eng = rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=a.T, n_chains=a.chains,
                         segments=a.segments)
 eng.set_data(y)
@@ -34,4 +40,6 @@ eng.run(a.steps, True)
 dt = time.perf_counter() - t0
 print({"ms_per_step": dt / a.steps * 1e3, "kernels": {k: round(v["ms_avg"], 4) for k, v in eng.kernel_times().items()},
        "schedule": eng.schedule()})
+import os
+if os.environ.get("RXHIP_ABLATE"): print("fe(debug)", eng.free_energy()[-1], "segments", eng.schedule())
 eng.close()

@@ -15,7 +15,7 @@ def find(pattern):
 
 def short(name):
     name = name.split("(")[0]
-    for k in ("k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce", "k_fe_chain", "k_fe_total",
+    for k in ("kd_seg_aggregate", "kd_boundary_scan", "kd_forward", "kd_backward", "k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce", "k_fe_chain", "k_fe_total",
               "k_transpose_rows"):
         if k in name:
             return k
@@ -26,7 +26,7 @@ print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
 for f in find("*kernel_stats.csv"):
     for row in csv.DictReader(open(f)):
         n = short(row.get("Name", ""))
-        if n.startswith("k_"):
+        if n.startswith("k"):
             print(f"{n:18s} calls={row.get('Calls'):>5s} total_ns={row.get('TotalDurationNs'):>14s} "
                   f"avg_ns={row.get('AverageNs'):>14s} pct={row.get('Percentage')}")
 
@@ -35,7 +35,7 @@ agg = defaultdict(lambda: defaultdict(list))
 for f in find("*counter_collection.csv"):
     for row in csv.DictReader(open(f)):
         n = short(row.get("Kernel_Name", ""))
-        if not n.startswith("k_"):
+        if not n.startswith("k"):
             continue
         agg[n][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for n in sorted(agg):

@@ -80,6 +80,24 @@ def test_dimensions_dense_models(d, dy):
     check_against_oracle(mdl, y, segments=5)
 
 
+@pytest.mark.parametrize("d,dy,T,C,segments", [(16, 16, 90, 3, 4), (32, 32, 70, 2, 0), (48, 48, 40, 1, 3), (64, 64, 61, 2, 5),
+                                                 (32, 8, 50, 2, 3), (64, 64, 1, 1, 0), (16, 16, 2, 2, 0)])
+def test_dense_state_dimensions(d, dy, T, C, segments):
+    """d = 16·NT path (BASELINE config 3 is d = dy = 64): one workgroup per (chain, segment), MFMA f64
+    contractions, Gauss–Jordan SPD inverses."""
+    mdl = workloads.random_model(d, dy, seed=7 + d + dy, stable=0.9)
+    y = workloads.generate_batch(mdl, T, C, seed0=11)
+    check_against_oracle(mdl, y, segments=segments)
+
+
+def test_c3_model_short():
+    """BASELINE config 3's model (dense A, dense full-rank B, d = 64) on a short chain."""
+    mdl = workloads.c3_model()
+    y = workloads.generate_batch(mdl, 200, 1, seed0=6400)
+    mean, cov, fe, sched = check_against_oracle(mdl, y)
+    assert sched["segments"] > 1
+
+
 def test_prior_through_transition_variant():
     """test/models/statespace/mlgssm_test.jl:9-17 spelling: x0 ~ prior; x[1] ~ MvNormal(A*x0, .)"""
     mdl = workloads.random_model(2, 2, seed=5)
