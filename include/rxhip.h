@@ -141,6 +141,41 @@ rxhip_status rxhip_copy_free_energy_to_device(rxhip_engine* e, double* dst_dev);
 rxhip_status rxhip_counters(rxhip_engine* e, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals);
 
 /* ------------------------------------------------------------------------------------------
+ * Univariate Gaussian mixture, mean-field VMP (BASELINE config 5; reference model
+ * test/models/mixtures/gmm_univariate_tests.jl:7-26, K-component form as gmm_multivariate_tests.jl:22-31):
+ *     s ~ Dirichlet(alpha0);  m[k] ~ Normal(mean = mu0[k], variance = v0[k]);  p[k] ~ Gamma(shape = a0[k], rate = b0[k]);
+ *     z[i] ~ Categorical(s);  y[i] ~ NormalMixture(switch = z[i], m = m, p = p);   q = q(z)q(s)Πq(m[k])Πq(p[k])
+ * K = 1 is the iid Gaussian with unknown mean and precision (test/models/models_tests.jl:114-128).
+ * init_*: the `@initialization` marginals q(m[k]) = N(mean, var), q(p[k]) = Gamma(shape, rate), q(s) = Dirichlet.
+ * Replaces create_model + postprocess_plugin for this family; then rxhip_set_data(RXHIP_VAR_Y, y, N, 0),
+ * rxhip_run(iterations, want_free_energy), rxhip_get_free_energy (one value per VMP iteration).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t N;      /* observations held by THIS engine (one shard when several GPUs split the data) */
+    int32_t K;      /* components, 1..16 */
+    const double* mu0; const double* v0; const double* a0; const double* b0; const double* alpha0;        /* [K] priors */
+    const double* init_m_mean; const double* init_m_var; const double* init_p_shape; const double* init_p_rate;
+    const double* init_s_alpha;                                                                          /* [K] q init */
+    int32_t materialize_responsibilities; /* 0: never, 1: q(z) of the last iteration is written to HBM ([N][K]) */
+    int32_t device;
+    void* stream;
+} rxhip_gmm_desc;
+rxhip_status rxhip_gmm_create(const rxhip_gmm_desc* desc, rxhip_engine** out);
+/* posteriors after every iteration of the last run (KeepEach): hist[iterations][5][K] =
+ * (mean m, var m, shape p, rate p, alpha s)   — replaces the marginal actors of src/inference/batch.jl:325-340 */
+rxhip_status rxhip_gmm_get_history(rxhip_engine* e, double* hist);
+/* q(z[i]) of the last iteration, [N][K]; requires materialize_responsibilities = 1 */
+rxhip_status rxhip_gmm_get_responsibilities(rxhip_engine* e, double* resp);
+/* split-phase iteration for several GPUs: accumulate() streams this shard and leaves the 3K'+1
+ * responsibility-weighted statistics (K' = padded K, see n) in a device buffer; the host all-reduces that
+ * buffer over RCCL; update() forms the new marginals / free energy from the (global) statistics.
+ * rxhip_run == begin_run + iterations × (accumulate, update). */
+rxhip_status rxhip_gmm_begin_run(rxhip_engine* e, int32_t iterations);
+rxhip_status rxhip_gmm_accumulate(rxhip_engine* e);
+rxhip_status rxhip_gmm_statistics_device(rxhip_engine* e, double** stats_dev, int32_t* n);
+rxhip_status rxhip_gmm_update(rxhip_engine* e, int32_t want_free_energy);
+
+/* ------------------------------------------------------------------------------------------
  * measurement hooks (no reference counterpart; RxInferBenchmarkCallbacks is the closest,
  * src/callbacks/benchmark.jl:99-155)
  * ------------------------------------------------------------------------------------------ */
@@ -150,7 +185,10 @@ enum {
     RXHIP_K_FORWARD = 2,       /* phase 3: forward messages + evidence terms (reads y, writes fwd) */
     RXHIP_K_BACKWARD = 3,      /* phase 4: backward messages + marginals (reads fwd, writes posteriors) */
     RXHIP_K_FE_REDUCE = 4,     /* Bethe free-energy reduction                                  */
-    RXHIP_K_COUNT = 5
+    RXHIP_K_GMM_PASS = 5,      /* mixture: responsibilities + weighted statistics (streams y)  */
+    RXHIP_K_GMM_REDUCE = 6,    /* mixture: block partials -> totals                            */
+    RXHIP_K_GMM_UPDATE = 7,    /* mixture: new marginals of m[k], p[k], s + free energy        */
+    RXHIP_K_COUNT = 8
 };
 /* enable (1) / disable (0) per-kernel HIP-event timing on the engine's stream */
 rxhip_status rxhip_set_profiling(rxhip_engine* e, int32_t enabled);

@@ -84,6 +84,27 @@ int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B,
                          int prior_through_transition, const double* y, double* post_mean,
                          double* post_cov, double* neg_loglik);
 
+/*
+ * Univariate Gaussian mixture, mean-field VMP (test/models/mixtures/gmm_univariate_tests.jl:7-26,
+ * generalised to K components: Beta(1,1)/Bernoulli -> Dirichlet/Categorical as in
+ * gmm_multivariate_tests.jl:22-31):
+ *     s ~ Dirichlet(alpha0);  m[k] ~ Normal(mean = mu0[k], variance = v0[k]);
+ *     p[k] ~ Gamma(shape = a0[k], rate = b0[k]);
+ *     z[i] ~ Categorical(s);  y[i] ~ NormalMixture(switch = z[i], m = m, p = p)
+ * with q(z, s, m, p) = q(z)q(s)Πq(m[k])Πq(p[k]).  K = 1 is the iid Gaussian with unknown mean and
+ * precision (test/models/models_tests.jl:114-128, `iid_gaussians_params`).
+ * Rules restated from SURVEY.md Appendix A.4/A.5.  Schedule (ASSUMED — the reactive update order is
+ * not documented in the reference tree): per iteration, q(z[i]) from the marginals of the
+ * previous iteration; then q(s), q(m[k]), q(p[k]) from the new q(z), q(m) using E[p] and q(p) using
+ * q(m) of the previous iteration.  Converged posteriors are schedule-independent.
+ * init_*: the `@initialization` marginals.  hist: [iterations][5][K] = (mean m, var m, shape p, rate p,
+ * alpha s) after each iteration; fe: [iterations] Bethe free energy; resp (nullable): [N][K] final q(z).
+ */
+int rxo_gmm_vmp(long long N, int K, const double* y, const double* mu0, const double* v0, const double* a0,
+                const double* b0, const double* alpha0, const double* init_m_mean, const double* init_m_var,
+                const double* init_p_shape, const double* init_p_rate, const double* init_s_alpha, int iterations,
+                double* hist, double* fe, double* resp, rxo_counters* counters);
+
 const char* rxo_version(void);
 
 #ifdef __cplusplus

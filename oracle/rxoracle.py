@@ -41,6 +41,9 @@ def lib():
         _LIB.rxo_lgssm_bp_batch.restype = ctypes.c_int
         _LIB.rxo_lgssm_bp_batch.argtypes = [ctypes.c_int] * 4 + [dp] * 6 + [ctypes.c_int, dp, dp, dp, dp,
                                                                           ctypes.c_int, ctypes.POINTER(Counters)]
+        _LIB.rxo_gmm_vmp.restype = ctypes.c_int
+        _LIB.rxo_gmm_vmp.argtypes = [ctypes.c_longlong, ctypes.c_int] + [dp] * 11 + [ctypes.c_int, dp, dp, dp,
+                                                                                        ctypes.POINTER(Counters)]
     return _LIB
 
 
@@ -95,3 +98,20 @@ def lgssm_bp_batch(A, B, P, Q, m0, V0, y, prior_through_transition=False, free_e
     if rc:
         raise RuntimeError(f"rxo_lgssm_bp_batch failed with status {rc}")
     return mean, cov, fe, cnt
+
+
+def gmm_vmp(y, mu0, v0, a0, b0, alpha0, init_m_mean, init_m_var, init_p_shape, init_p_rate, init_s_alpha, iterations,
+            want_resp=False):
+    """Univariate GMM mean-field VMP (see rxoracle.h).  Returns hist [it,5,K], fe [it], resp [N,K]|None, Counters."""
+    y = _c(y)
+    args = [_c(a) for a in (mu0, v0, a0, b0, alpha0, init_m_mean, init_m_var, init_p_shape, init_p_rate, init_s_alpha)]
+    K, N = args[0].size, y.size
+    hist = np.empty((iterations, 5, K))
+    fe = np.empty(iterations)
+    resp = np.empty((N, K)) if want_resp else None
+    cnt = Counters()
+    rc = lib().rxo_gmm_vmp(N, K, _p(y), *[_p(a) for a in args], int(iterations), _p(hist), _p(fe),
+                           _p(resp) if want_resp else None, ctypes.byref(cnt))
+    if rc:
+        raise RuntimeError(f"rxo_gmm_vmp failed with status {rc}")
+    return hist, fe, resp, cnt

@@ -18,6 +18,7 @@
 
 #include "lgssm_kernels.hpp"
 #include "dense_kernels.hpp"
+#include "gmm_kernels.hpp"
 
 using namespace rxhip;
 
@@ -152,6 +153,14 @@ struct rxhip_engine {
     int* d_chain_model = nullptr;
     int* d_status = nullptr;
     double* d_fe_blocks = nullptr;
+    // Gaussian-mixture VMP engine (kind == 1)
+    int kind = 0;  // 0: LGSSM, 1: GMM
+    struct Gmm {
+        long long N = 0;
+        int K = 0, KT = 0, materialize = 0, nblocks = 0, it = 0, iterations = 0, hist_cap = 0;
+        double *d_resp = nullptr, *d_par = nullptr, *d_drv = nullptr, *d_prior = nullptr, *d_init = nullptr,
+               *d_partial = nullptr, *d_totals = nullptr, *d_hist = nullptr, *d_fe = nullptr;
+    } g;
     // dense (d = 16·NT) path
     bool dense = false;
     int nt = 0;
@@ -168,8 +177,8 @@ struct rxhip_engine {
     struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
-    double k_ms[RXHIP_K_COUNT] = {0, 0, 0, 0, 0};
-    uint64_t k_n[RXHIP_K_COUNT] = {0, 0, 0, 0, 0};
+    double k_ms[RXHIP_K_COUNT] = {};
+    uint64_t k_n[RXHIP_K_COUNT] = {};
     std::string err = "";
 };
 
@@ -571,6 +580,39 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
     return RXHIP_OK;
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Gaussian-mixture VMP engine
+static int gmm_kt(int K) { return K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : 16; }
+static GmmParams gmm_params(rxhip_engine* e) {
+    GmmParams p;
+    p.N = e->g.N; p.K = e->g.K; p.y = e->d_y; p.resp = e->g.d_resp; p.par = e->g.d_par; p.drv = e->g.d_drv;
+    p.prior = e->g.d_prior; p.partial = e->g.d_partial; p.totals = e->g.d_totals; p.hist = e->g.d_hist; p.fe = e->g.d_fe;
+    p.iteration = e->g.it; p.nblocks = e->g.nblocks; p.write_resp = 0; p.status = e->d_status;
+    return p;
+}
+template <int KT>
+struct GmmLaunch {
+    static void init(const GmmParams& p, hipStream_t s) { hipLaunchKernelGGL((k_gmm_init<KT>), dim3(1), dim3(256), 0, s, p); }
+    static void pass(const GmmParams& p, bool resp, hipStream_t s) {
+        if (resp) hipLaunchKernelGGL((k_gmm_pass<KT, true>), dim3(p.nblocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_gmm_pass<KT, false>), dim3(p.nblocks), dim3(256), 0, s, p);
+    }
+    static void reduce(const GmmParams& p, hipStream_t s) { hipLaunchKernelGGL((k_gmm_reduce<KT>), dim3(1), dim3(256), 0, s, p); }
+    static void update(const GmmParams& p, bool fe, hipStream_t s) {
+        if (fe) hipLaunchKernelGGL((k_gmm_update<KT, true>), dim3(1), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((k_gmm_update<KT, false>), dim3(1), dim3(64), 0, s, p);
+    }
+};
+#define GMM_DISPATCH(kt, CALL)                   \
+    switch (kt) {                                \
+        case 1: GmmLaunch<1>::CALL; break;       \
+        case 2: GmmLaunch<2>::CALL; break;       \
+        case 4: GmmLaunch<4>::CALL; break;       \
+        case 8: GmmLaunch<8>::CALL; break;       \
+        default: GmmLaunch<16>::CALL; break;     \
+    }
+
 // ------------------------------------------------------------------------------------------
 extern "C" {
 
@@ -612,6 +654,9 @@ static void free_all(rxhip_engine* e) {
     if (e->d_chain_model) (void)hipFree(e->d_chain_model);
     if (e->d_status) (void)hipFree(e->d_status);
     if (e->d_fe_blocks) (void)hipFree(e->d_fe_blocks);
+    for (double** b : {&e->g.d_resp, &e->g.d_par, &e->g.d_drv, &e->g.d_prior, &e->g.d_init, &e->g.d_partial, &e->g.d_totals,
+                       &e->g.d_hist, &e->g.d_fe})
+        if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi})
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
@@ -762,6 +807,155 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     return RXHIP_OK;
 }
 
+
+static rxhip_status prof_begin(rxhip_engine* e, int k);
+static rxhip_status prof_end(rxhip_engine* e);
+
+rxhip_status rxhip_gmm_create(const rxhip_gmm_desc* ds, rxhip_engine** out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    *out = nullptr;
+    if (!ds || ds->N <= 0 || ds->K <= 0 || !ds->mu0 || !ds->v0 || !ds->a0 || !ds->b0 || !ds->alpha0 || !ds->init_m_mean ||
+        !ds->init_m_var || !ds->init_p_shape || !ds->init_p_rate || !ds->init_s_alpha)
+        return RXHIP_ERR_BADARG;
+    if (ds->K > 16) return RXHIP_ERR_UNSUPPORTED;
+    for (int k = 0; k < ds->K; ++k)
+        if (!(ds->v0[k] > 0) || !(ds->a0[k] > 0) || !(ds->b0[k] > 0) || !(ds->alpha0[k] > 0) || !(ds->init_m_var[k] > 0) ||
+            !(ds->init_p_shape[k] > 0) || !(ds->init_p_rate[k] > 0) || !(ds->init_s_alpha[k] > 0))
+            return RXHIP_ERR_NOT_POSDEF;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RXHIP_ERR_NO_DEVICE;
+    rxhip_engine* e = new rxhip_engine();
+    *out = e;
+    e->kind = 1;
+    e->g.N = ds->N;
+    e->g.K = ds->K;
+    e->g.KT = gmm_kt(ds->K);
+    e->g.materialize = ds->materialize_responsibilities ? 1 : 0;
+    e->n_chains = 1;
+    e->T = ds->N;
+    e->dy = 1;
+    if (ds->device >= 0) {
+        if (ds->device >= ndev) return fail(e, RXHIP_ERR_BADARG, "device %d out of range (%d visible)", ds->device, ndev);
+        e->device = ds->device;
+    } else
+        HIPCHK(e, hipGetDevice(&e->device));
+    HIPCHK(e, hipSetDevice(e->device));
+    if (ds->stream) e->stream = (hipStream_t)ds->stream;
+    else {
+        HIPCHK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    const int KT = e->g.KT, K = e->g.K;
+    long long nb = (e->g.N + 255) / 256;
+    if (nb > 1024) nb = 1024;  // 4 workgroups per CU, grid-stride over the observations
+    e->g.nblocks = (int)nb;
+    std::vector<double> prior(5 * KT, 1.0), init(5 * KT, 1.0);
+    const double* pr[5] = {ds->mu0, ds->v0, ds->a0, ds->b0, ds->alpha0};
+    const double* in[5] = {ds->init_m_mean, ds->init_m_var, ds->init_p_shape, ds->init_p_rate, ds->init_s_alpha};
+    for (int f = 0; f < 5; ++f)
+        for (int k = 0; k < K; ++k) {
+            prior[f * KT + k] = pr[f][k];
+            init[f * KT + k] = in[f][k];
+        }
+    HIPCHK(e, hipMalloc(&e->g.d_prior, sizeof(double) * 5 * KT));
+    HIPCHK(e, hipMalloc(&e->g.d_init, sizeof(double) * 5 * KT));
+    HIPCHK(e, hipMalloc(&e->g.d_par, sizeof(double) * 5 * KT));
+    HIPCHK(e, hipMalloc(&e->g.d_drv, sizeof(double) * 3 * KT));
+    HIPCHK(e, hipMalloc(&e->g.d_partial, sizeof(double) * (size_t)nb * (3 * KT + 1)));
+    HIPCHK(e, hipMalloc(&e->g.d_totals, sizeof(double) * (3 * KT + 1)));
+    HIPCHK(e, hipMemcpy(e->g.d_prior, prior.data(), sizeof(double) * 5 * KT, hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->g.d_init, init.data(), sizeof(double) * 5 * KT, hipMemcpyHostToDevice));
+    if (e->g.materialize) HIPCHK(e, hipMalloc(&e->g.d_resp, sizeof(double) * (size_t)e->g.N * K));
+    HIPCHK(e, hipMalloc(&e->d_status, sizeof(int)));
+    HIPCHK(e, hipMemset(e->d_status, 0, sizeof(int)));
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_gmm_begin_run(rxhip_engine* e, int32_t iterations) {
+    if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
+    if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
+    if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
+    HIPCHK(e, hipSetDevice(e->device));
+    if (iterations > e->g.hist_cap) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->g.d_hist) HIPCHK(e, hipFree(e->g.d_hist));
+        if (e->g.d_fe) HIPCHK(e, hipFree(e->g.d_fe));
+        e->g.d_hist = e->g.d_fe = nullptr;
+        HIPCHK(e, hipMalloc(&e->g.d_hist, sizeof(double) * (size_t)iterations * 5 * e->g.K));
+        HIPCHK(e, hipMalloc(&e->g.d_fe, sizeof(double) * iterations));
+        e->g.hist_cap = iterations;
+    }
+    HIPCHK(e, hipMemsetAsync(e->g.d_fe, 0, sizeof(double) * iterations, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->g.d_par, e->g.d_init, sizeof(double) * 5 * e->g.KT, hipMemcpyDeviceToDevice, e->stream));
+    e->g.it = 0;
+    e->g.iterations = iterations;
+    GmmParams p = gmm_params(e);
+    GMM_DISPATCH(e->g.KT, init(p, e->stream));
+    HIPCHK(e, hipGetLastError());
+    e->rule_calls = e->products = e->marginals = 0;
+    return RXHIP_OK;
+}
+rxhip_status rxhip_gmm_accumulate(rxhip_engine* e) {
+    if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
+    if (e->g.it >= e->g.iterations) return fail(e, RXHIP_ERR_STATE, "accumulate: no iteration left (call rxhip_gmm_begin_run)");
+    HIPCHK(e, hipSetDevice(e->device));
+    GmmParams p = gmm_params(e);
+    const bool resp = e->g.materialize && e->g.it == e->g.iterations - 1;
+    rxhip_status st;
+    if ((st = prof_begin(e, RXHIP_K_GMM_PASS))) return st;
+    GMM_DISPATCH(e->g.KT, pass(p, resp, e->stream));
+    if ((st = prof_end(e))) return st;
+    if ((st = prof_begin(e, RXHIP_K_GMM_REDUCE))) return st;
+    GMM_DISPATCH(e->g.KT, reduce(p, e->stream));
+    if ((st = prof_end(e))) return st;
+    HIPCHK(e, hipGetLastError());
+    return RXHIP_OK;
+}
+rxhip_status rxhip_gmm_statistics_device(rxhip_engine* e, double** stats_dev, int32_t* n) {
+    if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
+    if (stats_dev) *stats_dev = e->g.d_totals;
+    if (n) *n = 3 * e->g.KT + 1;
+    return RXHIP_OK;
+}
+rxhip_status rxhip_gmm_update(rxhip_engine* e, int32_t want_fe) {
+    if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
+    if (e->g.it >= e->g.iterations) return fail(e, RXHIP_ERR_STATE, "update: no iteration left");
+    HIPCHK(e, hipSetDevice(e->device));
+    GmmParams p = gmm_params(e);
+    rxhip_status st;
+    if ((st = prof_begin(e, RXHIP_K_GMM_UPDATE))) return st;
+    GMM_DISPATCH(e->g.KT, update(p, want_fe != 0, e->stream));
+    if ((st = prof_end(e))) return st;
+    HIPCHK(e, hipGetLastError());
+    e->g.it++;
+    e->last_iterations = e->g.it;
+    e->last_want_fe = want_fe != 0;
+    e->ran = true;
+    // reference-equivalent event counts per iteration (the oracle counts its own invocations the same way)
+    const uint64_t N = (uint64_t)e->g.N, K = (uint64_t)e->g.K;
+    e->rule_calls += N * (2 + 3 * K);
+    e->products += N * (1 + 3 * K);
+    e->marginals += N + 3 * K;
+    return RXHIP_OK;
+}
+rxhip_status rxhip_gmm_get_history(rxhip_engine* e, double* hist) {
+    if (!e || e->kind != 1 || !hist) return RXHIP_ERR_BADARG;
+    if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_history: no run yet");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(hist, e->g.d_hist, sizeof(double) * (size_t)e->g.it * 5 * e->g.K, hipMemcpyDeviceToHost));
+    return RXHIP_OK;
+}
+rxhip_status rxhip_gmm_get_responsibilities(rxhip_engine* e, double* resp) {
+    if (!e || e->kind != 1 || !resp) return RXHIP_ERR_BADARG;
+    if (!e->g.materialize) return fail(e, RXHIP_ERR_STATE, "responsibilities were not materialised (desc.materialize_responsibilities)");
+    if (!e->ran || e->g.it < e->g.iterations) return fail(e, RXHIP_ERR_STATE, "get_responsibilities: run not finished");
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(resp, e->g.d_resp, sizeof(double) * (size_t)e->g.N * e->g.K, hipMemcpyDeviceToHost));
+    return RXHIP_OK;
+}
+
 static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t layout, bool src_on_device) {
     if (!e) return RXHIP_ERR_BADARG;
     const size_t need = (size_t)e->T * e->n_chains * e->dy;
@@ -837,6 +1031,14 @@ static rxhip_status prof_end(rxhip_engine* e) {
 
 rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
     if (!e) return RXHIP_ERR_BADARG;
+    if (e->kind == 1) {
+        rxhip_status st = rxhip_gmm_begin_run(e, iterations);
+        for (int it = 0; !st && it < iterations; ++it) {
+            st = rxhip_gmm_accumulate(e);
+            if (!st) st = rxhip_gmm_update(e, want_fe);
+        }
+        return st;
+    }
     if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
     if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
     HIPCHK(e, hipSetDevice(e->device));
@@ -969,7 +1171,7 @@ rxhip_status rxhip_run(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
 rxhip_status rxhip_get_marginals_device(rxhip_engine* e, int32_t var_id, const double** mean_dev,
                                         const double** cov_dev) {
     if (!e) return RXHIP_ERR_BADARG;
-    if (var_id != RXHIP_VAR_X) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
+    if (var_id != RXHIP_VAR_X || e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals: no run yet");
     if (mean_dev) *mean_dev = e->d_mean;
     if (cov_dev) *cov_dev = e->d_cov;
@@ -995,7 +1197,7 @@ static rxhip_status copy_out(rxhip_engine* e, const double* dsrc, double* host, 
 
 rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout) {
     if (!e) return RXHIP_ERR_BADARG;
-    if (var_id != RXHIP_VAR_X) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
+    if (var_id != RXHIP_VAR_X || e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals: no run yet");
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
         return fail(e, RXHIP_ERR_BADARG, "get_marginals: unknown layout %d", layout);
@@ -1012,11 +1214,13 @@ rxhip_status rxhip_get_free_energy(rxhip_engine* e, double* per_iteration) {
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(per_iteration, e->d_fe_total, sizeof(double) * e->last_iterations, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(per_iteration, e->kind == 1 ? e->g.d_fe : e->d_fe_total, sizeof(double) * e->last_iterations,
+                        hipMemcpyDeviceToHost));
     return RXHIP_OK;
 }
 rxhip_status rxhip_get_free_energy_per_chain(rxhip_engine* e, double* per_chain) {
     if (!e || !per_chain) return RXHIP_ERR_BADARG;
+    if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "per-chain free energy is an LGSSM result");
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1026,7 +1230,7 @@ rxhip_status rxhip_get_free_energy_per_chain(rxhip_engine* e, double* per_chain)
 rxhip_status rxhip_get_free_energy_device(rxhip_engine* e, double** fe_dev) {
     if (!e || !fe_dev) return RXHIP_ERR_BADARG;
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
-    *fe_dev = e->d_fe_total + (e->last_iterations - 1);
+    *fe_dev = (e->kind == 1 ? e->g.d_fe : e->d_fe_total) + (e->last_iterations - 1);
     return RXHIP_OK;
 }
 
@@ -1034,7 +1238,7 @@ rxhip_status rxhip_copy_free_energy_to_device(rxhip_engine* e, double* dst_dev) 
     if (!e || !dst_dev) return RXHIP_ERR_BADARG;
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipMemcpyAsync(dst_dev, e->d_fe_total + (e->last_iterations - 1), sizeof(double),
+    HIPCHK(e, hipMemcpyAsync(dst_dev, (e->kind == 1 ? e->g.d_fe : e->d_fe_total) + (e->last_iterations - 1), sizeof(double),
                              hipMemcpyDeviceToDevice, e->stream));
     return RXHIP_OK;
 }
@@ -1075,6 +1279,11 @@ rxhip_status rxhip_get_stream(rxhip_engine* e, void** stream) {
 }
 rxhip_status rxhip_get_schedule(rxhip_engine* e, int32_t* segments, int64_t* segment_len) {
     if (!e) return RXHIP_ERR_BADARG;
+    if (e->kind == 1) {
+        if (segments) *segments = e->g.nblocks;
+        if (segment_len) *segment_len = 256;
+        return RXHIP_OK;
+    }
     if (segments) *segments = e->S;
     if (segment_len) *segment_len = e->L;
     return RXHIP_OK;

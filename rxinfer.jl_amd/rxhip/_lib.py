@@ -13,8 +13,9 @@ c_u64_p = ctypes.POINTER(ctypes.c_uint64)
 OK, ERR_BADARG, ERR_UNSUPPORTED, ERR_NOT_POSDEF, ERR_NONFINITE_FE, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_RCCL = range(9)
 LAYOUT_TIME_CHAIN, LAYOUT_CHAIN_TIME = 0, 1
 VAR_Y, VAR_X = 0, 1
-K_SEG_AGGREGATE, K_BOUNDARY_SCAN, K_FORWARD, K_BACKWARD, K_FE_REDUCE, K_COUNT = range(6)
-KERNEL_NAMES = ["k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce"]
+K_SEG_AGGREGATE, K_BOUNDARY_SCAN, K_FORWARD, K_BACKWARD, K_FE_REDUCE, K_GMM_PASS, K_GMM_REDUCE, K_GMM_UPDATE, K_COUNT = range(9)
+KERNEL_NAMES = ["k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce", "k_gmm_pass", "k_gmm_reduce",
+                "k_gmm_update"]
 
 
 class LgssmDesc(ctypes.Structure):
@@ -25,6 +26,12 @@ class LgssmDesc(ctypes.Structure):
         ("V0", c_double_p), ("chain_model", c_int32_p), ("segments", ctypes.c_int32), ("device", ctypes.c_int32),
         ("stream", ctypes.c_void_p),
     ]
+
+
+class GmmDesc(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int64), ("K", ctypes.c_int32)] + [(n, c_double_p) for n in (
+        "mu0", "v0", "a0", "b0", "alpha0", "init_m_mean", "init_m_var", "init_p_shape", "init_p_rate", "init_s_alpha")] + [
+        ("materialize_responsibilities", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p)]
 
 
 # every symbol include/rxhip.h declares: (name, restype, argtypes)
@@ -45,6 +52,13 @@ SYMBOLS = [
     ("rxhip_get_free_energy_device", ctypes.c_int32, [_H, ctypes.POINTER(ctypes.c_void_p)]),
     ("rxhip_copy_free_energy_to_device", ctypes.c_int32, [_H, ctypes.c_void_p]),
     ("rxhip_counters", ctypes.c_int32, [_H, c_u64_p, c_u64_p, c_u64_p]),
+    ("rxhip_gmm_create", ctypes.c_int32, [ctypes.POINTER(GmmDesc), ctypes.POINTER(_H)]),
+    ("rxhip_gmm_get_history", ctypes.c_int32, [_H, c_double_p]),
+    ("rxhip_gmm_get_responsibilities", ctypes.c_int32, [_H, c_double_p]),
+    ("rxhip_gmm_begin_run", ctypes.c_int32, [_H, ctypes.c_int32]),
+    ("rxhip_gmm_accumulate", ctypes.c_int32, [_H]),
+    ("rxhip_gmm_statistics_device", ctypes.c_int32, [_H, ctypes.POINTER(ctypes.c_void_p), c_int32_p]),
+    ("rxhip_gmm_update", ctypes.c_int32, [_H, ctypes.c_int32]),
     ("rxhip_set_profiling", ctypes.c_int32, [_H, ctypes.c_int32]),
     ("rxhip_get_kernel_times", ctypes.c_int32, [_H, c_double_p, c_u64_p]),
     ("rxhip_reset_kernel_times", ctypes.c_int32, [_H]),

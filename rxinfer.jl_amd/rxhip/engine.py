@@ -170,3 +170,94 @@ class LGSSMEngine:
         p = ctypes.c_void_p()
         self._chk(_lib.lib().rxhip_get_stream(self._h, ctypes.byref(p)))
         return p.value
+
+
+class GMMEngine:
+    """Mean-field VMP for the univariate Gaussian mixture on one MI355X (see include/rxhip.h rxhip_gmm_desc).
+    K = 1 is the iid Gaussian with unknown mean and precision."""
+
+    def __init__(self, N, mu0, v0, a0, b0, alpha0, init_m_mean, init_m_var, init_p_shape, init_p_rate, init_s_alpha,
+                 materialize_responsibilities=False, device=-1, stream=None):
+        L = _lib.lib()
+        arrs = [_c(a).ravel() for a in (mu0, v0, a0, b0, alpha0, init_m_mean, init_m_var, init_p_shape, init_p_rate,
+                                        init_s_alpha)]
+        self.K = arrs[0].size
+        if any(a.size != self.K for a in arrs):
+            raise ValueError("all prior / initialisation arrays must have K entries")
+        self.N = int(N)
+        self._keep = arrs
+        desc = _lib.GmmDesc()
+        desc.N, desc.K = self.N, self.K
+        for name, a in zip(("mu0", "v0", "a0", "b0", "alpha0", "init_m_mean", "init_m_var", "init_p_shape", "init_p_rate",
+                            "init_s_alpha"), arrs):
+            setattr(desc, name, _p(a))
+        desc.materialize_responsibilities = int(bool(materialize_responsibilities))
+        desc.device = int(device)
+        desc.stream = ctypes.c_void_p(stream) if stream else None
+        self._h = ctypes.c_void_p()
+        st = L.rxhip_gmm_create(ctypes.byref(desc), ctypes.byref(self._h))
+        if st != _lib.OK:
+            msg = L.rxhip_last_error(self._h).decode() if self._h else L.rxhip_status_string(st).decode()
+            if self._h:
+                L.rxhip_destroy(self._h)
+                self._h = None
+            raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
+        self._iters = 0
+        self._data_ref = None
+
+    _chk = LGSSMEngine._chk
+    close = LGSSMEngine.close
+    __del__ = LGSSMEngine.__del__
+    __enter__ = LGSSMEngine.__enter__
+    __exit__ = LGSSMEngine.__exit__
+    sync = LGSSMEngine.sync
+    free_energy = LGSSMEngine.free_energy
+    free_energy_device = LGSSMEngine.free_energy_device
+    counters = LGSSMEngine.counters
+    set_profiling = LGSSMEngine.set_profiling
+    reset_kernel_times = LGSSMEngine.reset_kernel_times
+    kernel_times = LGSSMEngine.kernel_times
+    stream = LGSSMEngine.stream
+
+    def set_data(self, y):
+        y = _c(y).ravel()
+        self._chk(_lib.lib().rxhip_set_data(self._h, _lib.VAR_Y, _p(y), y.size, _lib.LAYOUT_TIME_CHAIN))
+
+    def set_data_device(self, ptr, n, keepalive=None):
+        self._data_ref = keepalive
+        self._chk(_lib.lib().rxhip_set_data_device(self._h, _lib.VAR_Y, ctypes.c_void_p(ptr), n, _lib.LAYOUT_TIME_CHAIN))
+
+    def run(self, iterations=1, free_energy=True):
+        self._chk(_lib.lib().rxhip_run(self._h, int(iterations), int(bool(free_energy))))
+        self._iters = int(iterations)
+
+    def run_async(self, iterations=1, free_energy=True):
+        self._chk(_lib.lib().rxhip_run_async(self._h, int(iterations), int(bool(free_energy))))
+        self._iters = int(iterations)
+
+    # split-phase iteration (several GPUs: all-reduce the statistics between accumulate and update)
+    def begin_run(self, iterations):
+        self._chk(_lib.lib().rxhip_gmm_begin_run(self._h, int(iterations)))
+        self._iters = int(iterations)
+
+    def accumulate(self):
+        self._chk(_lib.lib().rxhip_gmm_accumulate(self._h))
+
+    def statistics_device(self):
+        p, n = ctypes.c_void_p(), ctypes.c_int32()
+        self._chk(_lib.lib().rxhip_gmm_statistics_device(self._h, ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
+    def update(self, free_energy=True):
+        self._chk(_lib.lib().rxhip_gmm_update(self._h, int(bool(free_energy))))
+
+    def history(self):
+        """[iterations][5][K]: mean m, var m, shape p, rate p, alpha s after every iteration (KeepEach)."""
+        h = np.empty((self._iters, 5, self.K))
+        self._chk(_lib.lib().rxhip_gmm_get_history(self._h, _p(h)))
+        return h
+
+    def responsibilities(self):
+        r = np.empty((self.N, self.K))
+        self._chk(_lib.lib().rxhip_gmm_get_responsibilities(self._h, _p(r)))
+        return r

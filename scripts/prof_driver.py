@@ -22,6 +22,29 @@ ap.add_argument("--chains", type=int, default=1024)
 ap.add_argument("--segments", type=int, default=0)
 ap.add_argument("--config", default="c2")
 a = ap.parse_args()
+if a.config == "c5":
+    # BASELINE config 5: univariate GMM, K = 16, N = 1e7, 20 VMP iterations, component means k·10 − 80
+    K, N = 16, (a.T if a.T != 100000 else 10_000_000)
+    mus = np.arange(1, K + 1) * 10.0 - 80.0
+    rng = np.random.default_rng(12345)
+    z = rng.integers(0, K, size=N)
+    y = mus[z] + rng.standard_normal(N)
+    for mat in (False, True):
+        eng = rxhip.GMMEngine(N, mus + 1.5, np.full(K, 1e3), np.full(K, 0.01), np.full(K, 0.01), np.ones(K), mus + 1.5,
+                              np.full(K, 10.0), np.ones(K), np.ones(K), np.ones(K), materialize_responsibilities=mat)
+        eng.set_data(y)
+        eng.run(2, True)
+        eng.set_profiling(True)
+        t0 = time.perf_counter()
+        eng.run(20, True)
+        dt = time.perf_counter() - t0
+        fe = eng.free_energy()
+        kt = {k: round(v["ms_avg"], 4) for k, v in eng.kernel_times().items() if v["launches"]}
+        print({"config": "c5", "materialize_last_q_z": mat, "ms_per_iteration": dt / 20 * 1e3, "kernels": kt,
+               "point_iterations_per_s": N * 20 / dt, "GBps_read_y": N * 8 * 20 / dt / 1e9, "fe_last": fe[-1],
+               "fe_monotone": bool(np.all(np.diff(fe) <= 1e-6 * abs(fe[-1]))), "means": np.round(eng.history()[-1, 0], 3).tolist()})
+        eng.close()
+    sys.exit(0)
 if a.config == "c3":
     mdl = workloads.c3_model()
     if a.T == 100000:
