@@ -17,7 +17,8 @@
 //                  host all-reduces these 3K+1 doubles over RCCL — the path's one exchange step
 //   k_gmm_update : products of the messages toward m[k], p[k], s in closed form from the statistics,
 //                  Bethe free energy, and the per-component constants of the next pass
-// Schedule: see oracle/rxoracle.h (assumed; the reference's reactive order is undocumented).
+// Schedule (assumed; the reference's reactive order is undocumented): per iteration
+// q(z_i) from the marginals of the previous iteration, then q(s), q(m[k]), q(p[k]) from the new q(z).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -159,18 +160,16 @@ template <int KT>
 __global__ void __launch_bounds__(256) k_gmm_reduce(GmmParams p) {
     __shared__ double sh[256];
     constexpr int NQ = 3 * KT + 1;
-    for (int q = 0; q < NQ; ++q) {
-        double s = 0.0;
-        for (int b = threadIdx.x; b < p.nblocks; b += 256) s += p.partial[(size_t)b * NQ + q];
-        sh[threadIdx.x] = s;
-        __syncthreads();
-        for (int wd = 128; wd > 0; wd >>= 1) {
-            if ((int)threadIdx.x < wd) sh[threadIdx.x] += sh[threadIdx.x + wd];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) p.totals[q] = sh[0];
+    const int q = blockIdx.x;  // one workgroup per statistic
+    double s = 0.0;
+    for (int b = threadIdx.x; b < p.nblocks; b += 256) s += p.partial[(size_t)b * NQ + q];
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int wd = 128; wd > 0; wd >>= 1) {
+        if ((int)threadIdx.x < wd) sh[threadIdx.x] += sh[threadIdx.x + wd];
         __syncthreads();
     }
+    if (threadIdx.x == 0) p.totals[q] = sh[0];
 }
 
 template <int KT, bool FE>

@@ -598,7 +598,7 @@ struct GmmLaunch {
         if (resp) hipLaunchKernelGGL((k_gmm_pass<KT, true>), dim3(p.nblocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((k_gmm_pass<KT, false>), dim3(p.nblocks), dim3(256), 0, s, p);
     }
-    static void reduce(const GmmParams& p, hipStream_t s) { hipLaunchKernelGGL((k_gmm_reduce<KT>), dim3(1), dim3(256), 0, s, p); }
+    static void reduce(const GmmParams& p, hipStream_t s) { hipLaunchKernelGGL((k_gmm_reduce<KT>), dim3(3 * KT + 1), dim3(256), 0, s, p); }
     static void update(const GmmParams& p, bool fe, hipStream_t s) {
         if (fe) hipLaunchKernelGGL((k_gmm_update<KT, true>), dim3(1), dim3(64), 0, s, p);
         else hipLaunchKernelGGL((k_gmm_update<KT, false>), dim3(1), dim3(64), 0, s, p);
