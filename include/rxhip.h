@@ -176,6 +176,32 @@ rxhip_status rxhip_gmm_statistics_device(rxhip_engine* e, double** stats_dev, in
 rxhip_status rxhip_gmm_update(rxhip_engine* e, int32_t want_free_energy);
 
 /* ------------------------------------------------------------------------------------------
+ * Hierarchical Gaussian filter, online (BASELINE config 4; reference model + driver
+ * test/models/statespace/hgf_tests.jl:9-70): per observation the one-step graph
+ *     zt_min ~ Normal(zm, zv); xt_min ~ Normal(xm, xv); zt ~ Normal(mean = zt_min, var = z_variance);
+ *     xt ~ GCV(xt_min, zt, kappa, omega); y ~ Normal(mean = xt, var = y_variance);  q = q(xt, xt_min) q(zt)
+ * is iterated `iterations` times (rxhip_run's argument = `iterations = vmp_iters` of infer) and the posteriors
+ * of zt, xt feed the next observation's priors (@autoupdates).  n_series independent series run side by side.
+ * Data: rxhip_set_data(RXHIP_VAR_Y, y, T*n_series, layout) with k = 1.  Replaces streaming_inference's
+ * per-event loop (src/inference/streaming.jl:349-407) for this model.
+ * rxhip_get_free_energy: per iteration, Σ_series of the mean-over-observations free energy
+ * (free_energy_history, src/score/actor.jl:98-104); rxhip_get_free_energy_per_chain: per series, last iteration.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t T;
+    int64_t n_series;
+    double kappa, omega, z_variance, y_variance;
+    double z0_mean, z0_var, x0_mean, x0_var; /* @initialization q(zt), q(xt) */
+    int32_t n_gh;                            /* Gauss–Hermite points (GaussHermiteCubature(n)), 1..32 */
+    int32_t device;
+    void* stream;
+} rxhip_hgf_desc;
+rxhip_status rxhip_hgf_create(const rxhip_hgf_desc* desc, rxhip_engine** out);
+/* history[:zt], history[:xt] (KeepLast per observation): means and variances, each T*n_series doubles in `layout` */
+rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_var, double* x_mean, double* x_var,
+                                   int32_t layout);
+
+/* ------------------------------------------------------------------------------------------
  * measurement hooks (no reference counterpart; RxInferBenchmarkCallbacks is the closest,
  * src/callbacks/benchmark.jl:99-155)
  * ------------------------------------------------------------------------------------------ */
@@ -188,7 +214,8 @@ enum {
     RXHIP_K_GMM_PASS = 5,      /* mixture: responsibilities + weighted statistics (streams y)  */
     RXHIP_K_GMM_REDUCE = 6,    /* mixture: block partials -> totals                            */
     RXHIP_K_GMM_UPDATE = 7,    /* mixture: new marginals of m[k], p[k], s + free energy        */
-    RXHIP_K_COUNT = 8
+    RXHIP_K_HGF_FILTER = 8,    /* hierarchical Gaussian filter: all observations × VMP iterations */
+    RXHIP_K_COUNT = 9
 };
 /* enable (1) / disable (0) per-kernel HIP-event timing on the engine's stream */
 rxhip_status rxhip_set_profiling(rxhip_engine* e, int32_t enabled);

@@ -802,3 +802,115 @@ int rxo_gmm_vmp(long long N, int K, const double* y, const double* mu0, const do
     free(w);
     return rc;
 }
+
+
+/* ==========================================================================================
+ * Hierarchical Gaussian filter (GCV node) — see rxoracle.h for the model, provenance and assumptions.
+ * ========================================================================================== */
+int rxo_gauss_hermite(int n, double* x, double* w) {
+    /* Newton iteration on the orthonormal Hermite recurrence (Numerical Recipes gauher, fp64) */
+    if (n < 1 || n > 64) return RXO_ERR_BADARG;
+    const double PIM4 = 0.7511255444649425; /* π^{-1/4} */
+    int m = (n + 1) / 2;
+    double z = 0.0, pp = 0.0;
+    for (int i = 0; i < m; ++i) {
+        if (i == 0) z = sqrt((double)(2 * n + 1)) - 1.85575 * pow((double)(2 * n + 1), -0.16667);
+        else if (i == 1) z -= 1.14 * pow((double)n, 0.426) / z;
+        else if (i == 2) z = 1.86 * z - 0.86 * x[0];
+        else if (i == 3) z = 1.91 * z - 0.91 * x[1];
+        else z = 2.0 * z - x[i - 2];
+        for (int its = 0; its < 100; ++its) {
+            double p1 = PIM4, p2 = 0.0;
+            for (int j = 0; j < n; ++j) {
+                double p3 = p2;
+                p2 = p1;
+                p1 = z * sqrt(2.0 / (j + 1)) * p2 - sqrt((double)j / (j + 1)) * p3;
+            }
+            pp = sqrt(2.0 * n) * p2;
+            double z1 = z;
+            z = z1 - p1 / pp;
+            if (fabs(z - z1) <= 1e-15 * (1.0 + fabs(z))) break;
+        }
+        x[i] = z;
+        x[n - 1 - i] = -z;
+        w[i] = 2.0 / (pp * pp);
+        w[n - 1 - i] = w[i];
+    }
+    return RXO_OK;
+}
+
+int rxo_hgf_filter(long long T, const double* y, double kappa, double omega, double z_variance, double y_variance,
+                   double z0m, double z0v, double x0m, double x0v, int vmp_iters, int n_gh, double* zm_o, double* zv_o,
+                   double* xm_o, double* xv_o, double* fe, rxo_counters* counters) {
+    if (T <= 0 || vmp_iters <= 0 || n_gh < 1 || n_gh > 64) return RXO_ERR_BADARG;
+    double gx[64], gw[64];
+    int rc = rxo_gauss_hermite(n_gh, gx, gw);
+    if (rc) return rc;
+    const double SQRTPI = 1.7724538509055160273;
+    double qzm = z0m, qzv = z0v, qxm = x0m, qxv = x0v; /* current marginals q(zt), q(xt) */
+    uint64_t rules = 0, prods = 0, margs = 0;
+    if (fe) for (int n = 0; n < vmp_iters; ++n) fe[n] = 0.0;
+    for (long long t = 0; t < T; ++t) {
+        /* @autoupdates: priors of this step from the previous posteriors */
+        const double zm = qzm, zv = qzv, xm = qxm, xv = qxv;
+        const double fzv = zv + z_variance; /* NormalMeanVariance(:out)(m_μ, q_v): forward message to zt */
+        rules += 3;                         /* two prior nodes + transition node; the obs message: */
+        rules += 1;
+        for (int n = 0; n < vmp_iters; ++n) {
+            /* expected precision of the GCV node under q(zt):  A·B,  A = exp(−ω), B = exp(−κ z̄ + κ² v_z / 2) */
+            const double A = exp(-omega);
+            const double B = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
+            const double g = A * B;
+            /* @marginalrule GCV(:y_x)(m_y = N(y_t, y_variance), m_x = N(xm, xv), q_z): joint precision / weighted mean */
+            const double l11 = 1.0 / y_variance + g, l22 = 1.0 / xv + g, l12 = -g;
+            const double det = l11 * l22 - l12 * l12;
+            if (!(det > 0.0)) { rc = RXO_ERR_NOT_POSDEF; goto out; }
+            const double v11 = l22 / det, v22 = l11 / det, v12 = -l12 / det;
+            const double x1 = y[t] / y_variance, x2 = xm / xv;
+            const double m1 = v11 * x1 + v12 * x2, m2 = v12 * x1 + v22 * x2;
+            const double psi = (m1 - m2) * (m1 - m2) + v11 + v22 - 2.0 * v12;
+            /* @rule GCV(:z)(q_y_x, q_κ, q_ω): ExponentialLinearQuadratic(a = κ, b = ψA, c = −κ, d = 0);
+               product with the forward message N(zm, fzv) moment-matched by approximate_meancov (Gauss–Hermite) */
+            const double a = kappa, b = psi * A, c = -kappa;
+            double norm = 0.0, mean = 0.0, cs[64], pts[64];
+            const double sc = sqrt(2.0 * fzv);
+            for (int i = 0; i < n_gh; ++i) {
+                const double pt = zm + sc * gx[i];
+                const double gv = exp(-0.5 * (a * pt + b * exp(c * pt)));
+                const double cv = gw[i] / SQRTPI * gv;
+                pts[i] = pt;
+                cs[i] = cv;
+                mean += pt * cv;
+                norm += cv;
+            }
+            mean /= norm;
+            double var = 0.0;
+            for (int i = 0; i < n_gh; ++i) var += cs[i] * (pts[i] - mean) * (pts[i] - mean);
+            var /= norm;
+            if (!(var > 0.0) || !isfinite(mean)) { rc = RXO_ERR_NONFINITE_FE; goto out; }
+            qzm = mean; qzv = var; qxm = m1; qxv = v11;
+            rules += 2; prods += 2; margs += 3;
+            if (fe) {
+                const double Bn = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
+                const double cc = 1.0 / (1.0 / zv + 1.0 / z_variance); /* var(zt_min | zt) */
+                const double r = 1.0 - cc / z_variance;
+                const double mu_m = cc * (zm / zv + qzm / z_variance), var_m = cc + (cc / z_variance) * (cc / z_variance) * qzv;
+                const double e2 = cc + r * r * qzv + (r * qzm - cc * zm / zv) * (r * qzm - cc * zm / zv);
+                double F = 0.0;
+                F += 0.5 * (LOG2PI + log(zv) + ((mu_m - zm) * (mu_m - zm) + var_m) / zv);           /* prior zt_min */
+                F += 0.5 * (LOG2PI + log(xv) + ((m2 - xm) * (m2 - xm) + v22) / xv);                  /* prior xt_min */
+                F += 0.5 * (LOG2PI + log(z_variance) + e2 / z_variance);                             /* transition   */
+                F -= 0.5 * (LOG2PI + 1.0 + log(qzv)) + 0.5 * (LOG2PI + 1.0 + log(cc));               /* −H[zt,zt_min] */
+                F += 0.5 * (LOG2PI + (qzm * kappa + omega) + psi * A * Bn);                          /* GCV average energy */
+                F -= 0.5 * (2.0 * (LOG2PI + 1.0) + log(v11 * v22 - v12 * v12));                      /* −H[xt,xt_min] */
+                F += 0.5 * (LOG2PI + log(y_variance) + ((y[t] - m1) * (y[t] - m1) + v11) / y_variance); /* observation */
+                fe[n] += F;
+            }
+        }
+        zm_o[t] = qzm; zv_o[t] = qzv; xm_o[t] = qxm; xv_o[t] = qxv;
+    }
+    if (fe) for (int n = 0; n < vmp_iters; ++n) fe[n] /= (double)T;
+out:
+    if (counters) { counters->rule_calls = rules; counters->products = prods; counters->marginals = margs; }
+    return rc;
+}

@@ -105,6 +105,28 @@ int rxo_gmm_vmp(long long N, int K, const double* y, const double* mu0, const do
                 const double* init_p_shape, const double* init_p_rate, const double* init_s_alpha, int iterations,
                 double* hist, double* fe, double* resp, rxo_counters* counters);
 
+/*
+ * Hierarchical Gaussian filter, one series, online (test/models/statespace/hgf_tests.jl:9-70):
+ *     zt_min ~ Normal(zm, zv); xt_min ~ Normal(xm, xv); zt ~ Normal(mean = zt_min, var = z_variance);
+ *     xt ~ GCV(xt_min, zt, kappa, omega);  y ~ Normal(mean = xt, var = y_variance)
+ *     q(xt, zt, xt_min) = q(xt, xt_min) q(zt);  GCVMetadata(GaussHermiteCubature(n_gh))
+ * streamed over the observations with `@autoupdates` zt_min ← mean_var(q(zt)), xt_min ← mean_var(q(xt)) and
+ * `vmp_iters` iterations per observation; initial q(zt) = N(z0m, z0v), q(xt) = N(x0m, x0v).
+ * GCV rules restated from ReactiveMP (average energy verbatim from
+ * test/inference/inference_tests.jl:594-606); the z-message is the ExponentialLinearQuadratic
+ * exp(−½(κz + ψA·exp(−κz))) and its product with the Gaussian forward message is moment-matched with the
+ * Gauss–Hermite rule (approximate_meancov).  Order inside an iteration (ASSUMED): joint q(xt, xt_min)
+ * from the previous q(zt), then q(zt).  The joint q(zt, zt_min) entering the Bethe free energy is taken as
+ * q(zt)·p(zt_min | zt) (ASSUMED; the reference's treatment of the non-Gaussian message there is not in-tree).
+ * Outputs: zm/zv/xm/xv [T] final marginals per observation (historyvars KeepLast), fe [vmp_iters] = mean over
+ * observations of the per-iteration free energy (free_energy_history, src/score/actor.jl:98-104).
+ */
+int rxo_hgf_filter(long long T, const double* y, double kappa, double omega, double z_variance, double y_variance,
+                   double z0m, double z0v, double x0m, double x0v, int vmp_iters, int n_gh, double* zm, double* zv,
+                   double* xm, double* xv, double* fe, rxo_counters* counters);
+/* Gauss–Hermite nodes / weights (physicists' convention, Σ w f(x) ≈ ∫ e^{−x²} f), n ≤ 64 */
+int rxo_gauss_hermite(int n, double* x, double* w);
+
 const char* rxo_version(void);
 
 #ifdef __cplusplus

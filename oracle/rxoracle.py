@@ -44,6 +44,11 @@ def lib():
         _LIB.rxo_gmm_vmp.restype = ctypes.c_int
         _LIB.rxo_gmm_vmp.argtypes = [ctypes.c_longlong, ctypes.c_int] + [dp] * 11 + [ctypes.c_int, dp, dp, dp,
                                                                                         ctypes.POINTER(Counters)]
+        _LIB.rxo_hgf_filter.restype = ctypes.c_int
+        _LIB.rxo_hgf_filter.argtypes = [ctypes.c_longlong, dp] + [ctypes.c_double] * 8 + [ctypes.c_int, ctypes.c_int] + \
+            [dp] * 5 + [ctypes.POINTER(Counters)]
+        _LIB.rxo_gauss_hermite.restype = ctypes.c_int
+        _LIB.rxo_gauss_hermite.argtypes = [ctypes.c_int, dp, dp]
     return _LIB
 
 
@@ -115,3 +120,25 @@ def gmm_vmp(y, mu0, v0, a0, b0, alpha0, init_m_mean, init_m_var, init_p_shape, i
     if rc:
         raise RuntimeError(f"rxo_gmm_vmp failed with status {rc}")
     return hist, fe, resp, cnt
+
+
+def gauss_hermite(n):
+    x, w = np.empty(n), np.empty(n)
+    rc = lib().rxo_gauss_hermite(n, _p(x), _p(w))
+    if rc:
+        raise RuntimeError(f"rxo_gauss_hermite failed with status {rc}")
+    return x, w
+
+
+def hgf_filter(y, kappa, omega, z_variance, y_variance, z0=(0.0, 5.0), x0=(0.0, 5.0), vmp_iters=10, n_gh=31):
+    """HGF online filtering of one series (see rxoracle.h).  Returns zm, zv, xm, xv [T], fe [vmp_iters], Counters."""
+    y = _c(y)
+    T = y.size
+    zm, zv, xm, xv, fe = (np.empty(T) for _ in range(4)) + (np.empty(vmp_iters),) if False else \
+        (np.empty(T), np.empty(T), np.empty(T), np.empty(T), np.empty(vmp_iters))
+    cnt = Counters()
+    rc = lib().rxo_hgf_filter(T, _p(y), kappa, omega, z_variance, y_variance, z0[0], z0[1], x0[0], x0[1], vmp_iters, n_gh,
+                              _p(zm), _p(zv), _p(xm), _p(xv), _p(fe), ctypes.byref(cnt))
+    if rc:
+        raise RuntimeError(f"rxo_hgf_filter failed with status {rc}")
+    return zm, zv, xm, xv, fe, cnt

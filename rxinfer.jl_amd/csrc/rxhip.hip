@@ -19,6 +19,7 @@
 #include "lgssm_kernels.hpp"
 #include "dense_kernels.hpp"
 #include "gmm_kernels.hpp"
+#include "hgf_kernels.hpp"
 
 using namespace rxhip;
 
@@ -154,7 +155,12 @@ struct rxhip_engine {
     int* d_status = nullptr;
     double* d_fe_blocks = nullptr;
     // Gaussian-mixture VMP engine (kind == 1)
-    int kind = 0;  // 0: LGSSM, 1: GMM
+    int kind = 0;  // 0: LGSSM, 1: GMM, 2: HGF
+    struct Hgf {
+        rxhip_hgf_desc ds;
+        double *d_out = nullptr, *d_fe_series = nullptr, *d_gh = nullptr, *d_fe_total = nullptr;
+        int fe_cap = 0;
+    } h;
     struct Gmm {
         long long N = 0;
         int K = 0, KT = 0, materialize = 0, nblocks = 0, it = 0, iterations = 0, hist_cap = 0;
@@ -657,6 +663,8 @@ static void free_all(rxhip_engine* e) {
     for (double** b : {&e->g.d_resp, &e->g.d_par, &e->g.d_drv, &e->g.d_prior, &e->g.d_init, &e->g.d_partial, &e->g.d_totals,
                        &e->g.d_hist, &e->g.d_fe})
         if (*b) { (void)hipFree(*b); *b = nullptr; }
+    for (double** b : {&e->h.d_out, &e->h.d_fe_series, &e->h.d_gh, &e->h.d_fe_total})
+        if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi})
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
@@ -956,6 +964,126 @@ rxhip_status rxhip_gmm_get_responsibilities(rxhip_engine* e, double* resp) {
     return RXHIP_OK;
 }
 
+
+// Gauss–Hermite nodes / weights (Newton iteration on the orthonormal recurrence)
+static void gauss_hermite_host(int n, double* x, double* w) {
+    const double PIM4 = 0.7511255444649425;
+    const int m = (n + 1) / 2;
+    double z = 0.0, pp = 0.0;
+    for (int i = 0; i < m; ++i) {
+        if (i == 0) z = std::sqrt((double)(2 * n + 1)) - 1.85575 * std::pow((double)(2 * n + 1), -0.16667);
+        else if (i == 1) z -= 1.14 * std::pow((double)n, 0.426) / z;
+        else if (i == 2) z = 1.86 * z - 0.86 * x[0];
+        else if (i == 3) z = 1.91 * z - 0.91 * x[1];
+        else z = 2.0 * z - x[i - 2];
+        for (int its = 0; its < 100; ++its) {
+            double p1 = PIM4, p2 = 0.0;
+            for (int j = 0; j < n; ++j) {
+                const double p3 = p2;
+                p2 = p1;
+                p1 = z * std::sqrt(2.0 / (j + 1)) * p2 - std::sqrt((double)j / (j + 1)) * p3;
+            }
+            pp = std::sqrt(2.0 * n) * p2;
+            const double z1 = z;
+            z = z1 - p1 / pp;
+            if (std::fabs(z - z1) <= 1e-15 * (1.0 + std::fabs(z))) break;
+        }
+        x[i] = z;
+        x[n - 1 - i] = -z;
+        w[i] = 2.0 / (pp * pp);
+        w[n - 1 - i] = w[i];
+    }
+}
+
+rxhip_status rxhip_hgf_create(const rxhip_hgf_desc* ds, rxhip_engine** out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    *out = nullptr;
+    if (!ds || ds->T <= 0 || ds->n_series <= 0 || ds->n_gh < 1) return RXHIP_ERR_BADARG;
+    if (ds->n_gh > 32) return RXHIP_ERR_UNSUPPORTED;
+    if (!(ds->z_variance > 0) || !(ds->y_variance > 0) || !(ds->z0_var > 0) || !(ds->x0_var > 0)) return RXHIP_ERR_NOT_POSDEF;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RXHIP_ERR_NO_DEVICE;
+    rxhip_engine* e = new rxhip_engine();
+    *out = e;
+    e->kind = 2;
+    e->h.ds = *ds;
+    e->T = ds->T;
+    e->n_chains = ds->n_series;
+    e->dy = 1;
+    e->d = 1;
+    if (ds->device >= 0) {
+        if (ds->device >= ndev) return fail(e, RXHIP_ERR_BADARG, "device %d out of range (%d visible)", ds->device, ndev);
+        e->device = ds->device;
+    } else
+        HIPCHK(e, hipGetDevice(&e->device));
+    HIPCHK(e, hipSetDevice(e->device));
+    if (ds->stream) e->stream = (hipStream_t)ds->stream;
+    else {
+        HIPCHK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        e->own_stream = true;
+    }
+    double gh[64] = {0}, gx[32], gw[32];
+    gauss_hermite_host(ds->n_gh, gx, gw);
+    for (int i = 0; i < ds->n_gh; ++i) {
+        gh[i] = gx[i];
+        gh[32 + i] = gw[i] / 1.7724538509055160273;
+    }
+    HIPCHK(e, hipMalloc(&e->h.d_gh, sizeof(gh)));
+    HIPCHK(e, hipMemcpy(e->h.d_gh, gh, sizeof(gh), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMalloc(&e->h.d_out, sizeof(double) * 4 * (size_t)ds->T * ds->n_series));
+    HIPCHK(e, hipMalloc(&e->d_fe_chain, sizeof(double) * (size_t)ds->n_series));
+    HIPCHK(e, hipMalloc(&e->d_status, sizeof(int)));
+    HIPCHK(e, hipMemset(e->d_status, 0, sizeof(int)));
+    return RXHIP_OK;
+}
+
+static rxhip_status hgf_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
+    if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
+    if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
+    HIPCHK(e, hipSetDevice(e->device));
+    const size_t C = (size_t)e->n_chains, T = (size_t)e->T;
+    if (iterations > e->h.fe_cap) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->h.d_fe_series) HIPCHK(e, hipFree(e->h.d_fe_series));
+        if (e->h.d_fe_total) HIPCHK(e, hipFree(e->h.d_fe_total));
+        e->h.d_fe_series = e->h.d_fe_total = nullptr;
+        HIPCHK(e, hipMalloc(&e->h.d_fe_series, sizeof(double) * (size_t)iterations * C));
+        HIPCHK(e, hipMalloc(&e->h.d_fe_total, sizeof(double) * iterations));
+        e->h.fe_cap = iterations;
+    }
+    HIPCHK(e, hipMemsetAsync(e->h.d_fe_series, 0, sizeof(double) * (size_t)iterations * C, e->stream));
+    HgfParams p;
+    p.T = e->T; p.n_series = e->n_chains; p.y = e->d_y;
+    p.zm = e->h.d_out; p.zv = e->h.d_out + T * C; p.xm = e->h.d_out + 2 * T * C; p.xv = e->h.d_out + 3 * T * C;
+    p.fe_series = e->h.d_fe_series; p.gh = e->h.d_gh;
+    const rxhip_hgf_desc& d = e->h.ds;
+    p.kappa = d.kappa; p.omega = d.omega; p.z_variance = d.z_variance; p.y_variance = d.y_variance;
+    p.z0m = d.z0_mean; p.z0v = d.z0_var; p.x0m = d.x0_mean; p.x0v = d.x0_var;
+    p.iters = iterations; p.n_gh = d.n_gh; p.status = e->d_status;
+    rxhip_status st;
+    if ((st = prof_begin(e, RXHIP_K_HGF_FILTER))) return st;
+    const unsigned nb = (unsigned)((C + 1) / 2);
+    if (want_fe) hipLaunchKernelGGL((k_hgf_filter<true>), dim3(nb), dim3(64), 0, e->stream, p);
+    else hipLaunchKernelGGL((k_hgf_filter<false>), dim3(nb), dim3(64), 0, e->stream, p);
+    if ((st = prof_end(e))) return st;
+    if (want_fe) {
+        hipLaunchKernelGGL(k_hgf_fe, dim3(iterations), dim3(256), 0, e->stream, p, e->h.d_fe_total);
+        HIPCHK(e, hipMemcpyAsync(e->d_fe_chain, e->h.d_fe_series + (size_t)(iterations - 1) * C, sizeof(double) * C,
+                                 hipMemcpyDeviceToDevice, e->stream));
+    }
+    HIPCHK(e, hipGetLastError());
+    e->last_iterations = iterations;
+    e->last_want_fe = want_fe != 0;
+    e->ran = true;
+    e->rule_calls = (uint64_t)C * T * (4 + 2 * (uint64_t)iterations);
+    e->products = (uint64_t)C * T * 2 * (uint64_t)iterations;
+    e->marginals = (uint64_t)C * T * 3 * (uint64_t)iterations;
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_var, double* x_mean, double* x_var,
+                                   int32_t layout);
+
 static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t layout, bool src_on_device) {
     if (!e) return RXHIP_ERR_BADARG;
     const size_t need = (size_t)e->T * e->n_chains * e->dy;
@@ -1031,6 +1159,7 @@ static rxhip_status prof_end(rxhip_engine* e) {
 
 rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
     if (!e) return RXHIP_ERR_BADARG;
+    if (e->kind == 2) return hgf_run_async(e, iterations, want_fe);
     if (e->kind == 1) {
         rxhip_status st = rxhip_gmm_begin_run(e, iterations);
         for (int it = 0; !st && it < iterations; ++it) {
@@ -1195,6 +1324,23 @@ static rxhip_status copy_out(rxhip_engine* e, const double* dsrc, double* host, 
     return RXHIP_OK;
 }
 
+rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_var, double* x_mean, double* x_var,
+                                   int32_t layout) {
+    if (!e || e->kind != 2) return RXHIP_ERR_BADARG;
+    if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_history: no run yet");
+    if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
+        return fail(e, RXHIP_ERR_BADARG, "get_history: unknown layout %d", layout);
+    HIPCHK(e, hipSetDevice(e->device));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    const size_t n = (size_t)e->T * e->n_chains;
+    double* outs[4] = {z_mean, z_var, x_mean, x_var};
+    for (int q = 0; q < 4; ++q) {
+        rxhip_status st;
+        if (outs[q] && (st = copy_out(e, e->h.d_out + q * n, outs[q], 1, layout))) return st;
+    }
+    return RXHIP_OK;
+}
+
 rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout) {
     if (!e) return RXHIP_ERR_BADARG;
     if (var_id != RXHIP_VAR_X || e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
@@ -1214,13 +1360,13 @@ rxhip_status rxhip_get_free_energy(rxhip_engine* e, double* per_iteration) {
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(per_iteration, e->kind == 1 ? e->g.d_fe : e->d_fe_total, sizeof(double) * e->last_iterations,
+    HIPCHK(e, hipMemcpy(per_iteration, e->kind == 1 ? e->g.d_fe : e->kind == 2 ? e->h.d_fe_total : e->d_fe_total, sizeof(double) * e->last_iterations,
                         hipMemcpyDeviceToHost));
     return RXHIP_OK;
 }
 rxhip_status rxhip_get_free_energy_per_chain(rxhip_engine* e, double* per_chain) {
     if (!e || !per_chain) return RXHIP_ERR_BADARG;
-    if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "per-chain free energy is an LGSSM result");
+    if (e->kind == 1) return fail(e, RXHIP_ERR_BADARG, "per-chain free energy is not defined for the mixture engine");
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1230,7 +1376,7 @@ rxhip_status rxhip_get_free_energy_per_chain(rxhip_engine* e, double* per_chain)
 rxhip_status rxhip_get_free_energy_device(rxhip_engine* e, double** fe_dev) {
     if (!e || !fe_dev) return RXHIP_ERR_BADARG;
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
-    *fe_dev = (e->kind == 1 ? e->g.d_fe : e->d_fe_total) + (e->last_iterations - 1);
+    *fe_dev = (e->kind == 1 ? e->g.d_fe : e->kind == 2 ? e->h.d_fe_total : e->d_fe_total) + (e->last_iterations - 1);
     return RXHIP_OK;
 }
 
@@ -1238,7 +1384,7 @@ rxhip_status rxhip_copy_free_energy_to_device(rxhip_engine* e, double* dst_dev) 
     if (!e || !dst_dev) return RXHIP_ERR_BADARG;
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     HIPCHK(e, hipSetDevice(e->device));
-    HIPCHK(e, hipMemcpyAsync(dst_dev, (e->kind == 1 ? e->g.d_fe : e->d_fe_total) + (e->last_iterations - 1), sizeof(double),
+    HIPCHK(e, hipMemcpyAsync(dst_dev, (e->kind == 1 ? e->g.d_fe : e->kind == 2 ? e->h.d_fe_total : e->d_fe_total) + (e->last_iterations - 1), sizeof(double),
                              hipMemcpyDeviceToDevice, e->stream));
     return RXHIP_OK;
 }

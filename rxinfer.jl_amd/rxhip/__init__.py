@@ -4,5 +4,5 @@ The arithmetic lives in csrc/ (hand-written HIP for gfx950, exported through the
 include/rxhip.h); this package only marshals arguments.  Importing it does not require a GPU;
 constructing an engine does (no CPU fallback)."""
 from ._lib import RxHipError, lib, LIB_PATH  # noqa: F401
-from .engine import LGSSMEngine, GMMEngine  # noqa: F401
+from .engine import LGSSMEngine, GMMEngine, HGFEngine  # noqa: F401
 from .api import InferenceResult, infer, linear_gaussian_ssm, MvNormalMeanCovariance  # noqa: F401

@@ -13,9 +13,9 @@ c_u64_p = ctypes.POINTER(ctypes.c_uint64)
 OK, ERR_BADARG, ERR_UNSUPPORTED, ERR_NOT_POSDEF, ERR_NONFINITE_FE, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_RCCL = range(9)
 LAYOUT_TIME_CHAIN, LAYOUT_CHAIN_TIME = 0, 1
 VAR_Y, VAR_X = 0, 1
-K_SEG_AGGREGATE, K_BOUNDARY_SCAN, K_FORWARD, K_BACKWARD, K_FE_REDUCE, K_GMM_PASS, K_GMM_REDUCE, K_GMM_UPDATE, K_COUNT = range(9)
+K_SEG_AGGREGATE, K_BOUNDARY_SCAN, K_FORWARD, K_BACKWARD, K_FE_REDUCE, K_GMM_PASS, K_GMM_REDUCE, K_GMM_UPDATE, K_HGF_FILTER, K_COUNT = range(10)
 KERNEL_NAMES = ["k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce", "k_gmm_pass", "k_gmm_reduce",
-                "k_gmm_update"]
+                "k_gmm_update", "k_hgf_filter"]
 
 
 class LgssmDesc(ctypes.Structure):
@@ -32,6 +32,12 @@ class GmmDesc(ctypes.Structure):
     _fields_ = [("N", ctypes.c_int64), ("K", ctypes.c_int32)] + [(n, c_double_p) for n in (
         "mu0", "v0", "a0", "b0", "alpha0", "init_m_mean", "init_m_var", "init_p_shape", "init_p_rate", "init_s_alpha")] + [
         ("materialize_responsibilities", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p)]
+
+
+class HgfDesc(ctypes.Structure):
+    _fields_ = [("T", ctypes.c_int64), ("n_series", ctypes.c_int64)] + [(n, ctypes.c_double) for n in (
+        "kappa", "omega", "z_variance", "y_variance", "z0_mean", "z0_var", "x0_mean", "x0_var")] + [
+        ("n_gh", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p)]
 
 
 # every symbol include/rxhip.h declares: (name, restype, argtypes)
@@ -59,6 +65,8 @@ SYMBOLS = [
     ("rxhip_gmm_accumulate", ctypes.c_int32, [_H]),
     ("rxhip_gmm_statistics_device", ctypes.c_int32, [_H, ctypes.POINTER(ctypes.c_void_p), c_int32_p]),
     ("rxhip_gmm_update", ctypes.c_int32, [_H, ctypes.c_int32]),
+    ("rxhip_hgf_create", ctypes.c_int32, [ctypes.POINTER(HgfDesc), ctypes.POINTER(_H)]),
+    ("rxhip_hgf_get_history", ctypes.c_int32, [_H, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_int32]),
     ("rxhip_set_profiling", ctypes.c_int32, [_H, ctypes.c_int32]),
     ("rxhip_get_kernel_times", ctypes.c_int32, [_H, c_double_p, c_u64_p]),
     ("rxhip_reset_kernel_times", ctypes.c_int32, [_H]),

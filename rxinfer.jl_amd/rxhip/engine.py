@@ -261,3 +261,65 @@ class GMMEngine:
         r = np.empty((self.N, self.K))
         self._chk(_lib.lib().rxhip_gmm_get_responsibilities(self._h, _p(r)))
         return r
+
+
+class HGFEngine:
+    """Online hierarchical Gaussian filter (GCV node) for n_series independent series (include/rxhip.h rxhip_hgf_desc)."""
+
+    def __init__(self, T, n_series, kappa, omega, z_variance, y_variance, z0=(0.0, 5.0), x0=(0.0, 5.0), n_gh=31,
+                 device=-1, stream=None):
+        L = _lib.lib()
+        desc = _lib.HgfDesc()
+        desc.T, desc.n_series = int(T), int(n_series)
+        desc.kappa, desc.omega, desc.z_variance, desc.y_variance = float(kappa), float(omega), float(z_variance), float(y_variance)
+        desc.z0_mean, desc.z0_var, desc.x0_mean, desc.x0_var = float(z0[0]), float(z0[1]), float(x0[0]), float(x0[1])
+        desc.n_gh, desc.device = int(n_gh), int(device)
+        desc.stream = ctypes.c_void_p(stream) if stream else None
+        self.T, self.n_series, self.n_chains = int(T), int(n_series), int(n_series)
+        self._h = ctypes.c_void_p()
+        st = L.rxhip_hgf_create(ctypes.byref(desc), ctypes.byref(self._h))
+        if st != _lib.OK:
+            msg = L.rxhip_last_error(self._h).decode() if self._h else L.rxhip_status_string(st).decode()
+            if self._h:
+                L.rxhip_destroy(self._h)
+                self._h = None
+            raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
+        self._iters = 0
+        self._data_ref = None
+
+    _chk = LGSSMEngine._chk
+    close = LGSSMEngine.close
+    __del__ = LGSSMEngine.__del__
+    __enter__ = LGSSMEngine.__enter__
+    __exit__ = LGSSMEngine.__exit__
+    sync = LGSSMEngine.sync
+    run = LGSSMEngine.run
+    run_async = LGSSMEngine.run_async
+    free_energy = LGSSMEngine.free_energy
+    free_energy_per_chain = LGSSMEngine.free_energy_per_chain
+    free_energy_device = LGSSMEngine.free_energy_device
+    copy_free_energy_to_device = LGSSMEngine.copy_free_energy_to_device
+    counters = LGSSMEngine.counters
+    set_profiling = LGSSMEngine.set_profiling
+    reset_kernel_times = LGSSMEngine.reset_kernel_times
+    kernel_times = LGSSMEngine.kernel_times
+    stream = LGSSMEngine.stream
+
+    def set_data(self, y, layout="time_chain"):
+        """y: [T][series] ('time_chain') or [series][T] ('chain_time')."""
+        y = _c(y)
+        lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
+        self._chk(_lib.lib().rxhip_set_data(self._h, _lib.VAR_Y, _p(y), y.size, lay))
+
+    def set_data_device(self, ptr, n, layout="time_chain", keepalive=None):
+        lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
+        self._data_ref = keepalive
+        self._chk(_lib.lib().rxhip_set_data_device(self._h, _lib.VAR_Y, ctypes.c_void_p(ptr), n, lay))
+
+    def history(self, layout="time_chain"):
+        """(z_mean, z_var, x_mean, x_var), each [T][series] (or [series][T])."""
+        lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
+        shp = (self.T, self.n_series) if layout == "time_chain" else (self.n_series, self.T)
+        outs = [np.empty(shp) for _ in range(4)]
+        self._chk(_lib.lib().rxhip_hgf_get_history(self._h, *[_p(o) for o in outs], lay))
+        return tuple(outs)

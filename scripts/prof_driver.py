@@ -22,6 +22,27 @@ ap.add_argument("--chains", type=int, default=1024)
 ap.add_argument("--segments", type=int, default=0)
 ap.add_argument("--config", default="c2")
 a = ap.parse_args()
+if a.config == "c4":
+    # BASELINE config 4: 4096 independent HGF series, T = 2000, 10 VMP iterations / observation, GH-31
+    S, T = (a.chains if a.chains != 1024 else 4096), (a.T if a.T != 100000 else 2000)
+    rng = np.random.default_rng(42)
+    z = np.cumsum(0.2 * rng.standard_normal((T, S)), axis=0)
+    x = np.cumsum(np.exp(0.5 * z) * rng.standard_normal((T, S)), axis=0)
+    y = x + 0.1 * rng.standard_normal((T, S))
+    eng = rxhip.HGFEngine(T, S, 1.0, 0.0, 0.04, 0.01)
+    eng.set_data(y)
+    eng.run(10, True)
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.run(10, True)
+    dt = (time.perf_counter() - t0) / a.steps
+    fe = eng.free_energy()
+    print({"config": "c4", "series": S, "T": T, "ms_per_run": dt * 1e3, "kernels": {k: round(v["ms_avg"], 4) for k, v in eng.kernel_times().items() if v["launches"]},
+           "gh_evaluations_per_s": 31 * 10 * T * S / dt, "series_observations_per_s": T * S / dt, "rule_calls_per_s": eng.counters()["rule_calls"] / dt,
+           "fe_mean_per_series": (fe / S).tolist()})
+    eng.close()
+    sys.exit(0)
 if a.config == "c5":
     # BASELINE config 5: univariate GMM, K = 16, N = 1e7, 20 VMP iterations, component means k·10 − 80
     K, N = 16, (a.T if a.T != 100000 else 10_000_000)
