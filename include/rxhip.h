@@ -87,6 +87,66 @@ typedef struct {
  * src/model/plugins/reactivemp_inference.jl:272-326) for the LGSSM family */
 rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* desc, rxhip_engine** out);
 
+/* ------------------------------------------------------------------------------------------
+ * Generic factor-graph descriptor — the struct-of-arrays dump of a materialised GraphPPL model, i.e. what
+ * GraphPPL.postprocess_plugin(::ReactiveMPInferencePlugin, model) iterates over
+ * (src/model/plugins/reactivemp_inference.jl:272-326: variable_nodes / factor_nodes, GraphPPL.fform,
+ * GraphPPL.neighbors + getname(edge), is_random / is_data / is_constant, GraphPPL.value).
+ * One descriptor holds ONE graph; `n_replicas` independent copies (different data, same constants) form the
+ * chain batch.  The lowering pass (host C++) recognises the graph shapes that have a device schedule and
+ * produces the structured descriptor above; anything else is RXHIP_ERR_UNSUPPORTED (the caller falls back to
+ * the stock ReactiveMP plugin, cf. options.rulefallback, docs/src/manuals/inference/undefinedrules.md:101-108).
+ * ------------------------------------------------------------------------------------------ */
+enum {
+    RXHIP_VARKIND_RANDOM = 0, /* randomvar  (reactivemp_inference.jl:337-341) */
+    RXHIP_VARKIND_DATA = 1,   /* datavar    (:349-353) */
+    RXHIP_VARKIND_CONST = 2   /* constvar   (:343-348) */
+};
+enum {
+    /* ExponentialFamily.MvNormalMeanCovariance, interfaces (out, μ, Σ) — `MvNormal(μ = …, Σ = …)`, src/model/graphppl.jl:372-376 */
+    RXHIP_NODE_MVNORMAL_MEAN_COV = 1,
+    /* typeof(*), interfaces (out, A, in) — `A * x`, docs/src/manuals/model-specification.md:217-240 */
+    RXHIP_NODE_MULTIPLY = 2
+};
+typedef struct {
+    int64_t n_variables;
+    const int32_t* var_kind;     /* [n_variables] RXHIP_VARKIND_* */
+    const int32_t* var_rows;     /* [n_variables] rows of the value (vector length; matrix rows) */
+    const int32_t* var_cols;     /* [n_variables] 1 for vectors, columns for matrix-valued constants */
+    const int64_t* var_const;    /* [n_variables] offset of a constant's value (row-major) in const_pool, −1 otherwise */
+    int64_t n_factors;
+    const int32_t* factor_type;  /* [n_factors] RXHIP_NODE_* */
+    const int64_t* factor_iface; /* [n_factors][3] variable id per interface, in the node's interface order */
+    const double* const_pool;
+    int64_t n_const;
+    int64_t n_replicas;
+} rxhip_graph_desc;
+
+/* result of the lowering pass for the LGSSM family; matrices are written into caller buffers of the sizes below */
+typedef struct {
+    int32_t d, dy;
+    int64_t T;
+    int32_t prior_through_transition;
+    double* A;  /* [d][d]   */
+    double* B;  /* [dy][d]  */
+    double* P;  /* [d][d]   */
+    double* Q;  /* [dy][dy] */
+    double* m0; /* [d]      */
+    double* V0; /* [d][d]   */
+    int64_t* state_var; /* [T] variable id of x[t] in time order (nullable) */
+    int64_t* data_var;  /* [T] variable id of y[t] in time order (nullable) */
+} rxhip_lgssm_lowered;
+
+/* Host-only (no device needed): recognise a linear Gaussian state-space chain in `g`.  First call with all
+ * pointer members of `out` NULL to learn d, dy, T; then with buffers to receive the constants.
+ * RXHIP_ERR_UNSUPPORTED if the graph is not such a chain (message via rxhip_lowering_error()). */
+rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowered* out);
+const char* rxhip_lowering_error(void); /* thread-local text of the last lowering failure */
+
+/* replaces: create_model + postprocess_plugin for ANY supported graph (src/inference/batch.jl:252): lowers `g`,
+ * then builds the engine exactly as rxhip_lgssm_create would.  segments/device/stream as in rxhip_lgssm_desc. */
+rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out);
+
 /* 1 if a device schedule is compiled for state dimension d and observation dimension dy */
 int32_t rxhip_lgssm_supported(int32_t d, int32_t dy);
 

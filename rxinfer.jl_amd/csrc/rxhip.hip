@@ -20,6 +20,7 @@
 #include "dense_kernels.hpp"
 #include "gmm_kernels.hpp"
 #include "hgf_kernels.hpp"
+#include "graph_lowering.hpp"
 
 using namespace rxhip;
 
@@ -1083,6 +1084,35 @@ static rxhip_status hgf_run_async(rxhip_engine* e, int32_t iterations, int32_t w
 
 rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_var, double* x_mean, double* x_var,
                                    int32_t layout);
+
+rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowered* out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    rxhip_lower::Lgssm L;
+    rxhip_status st = rxhip_lower::lower_lgssm(g, L);
+    if (st) return st;
+    out->d = L.d; out->dy = L.dy; out->T = L.T; out->prior_through_transition = L.ptt;
+    auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
+    cp(out->A, L.A); cp(out->B, L.B); cp(out->P, L.P); cp(out->Q, L.Q); cp(out->m0, L.m0); cp(out->V0, L.V0);
+    if (out->state_var) for (long long t = 0; t < L.T; ++t) out->state_var[t] = L.state_var[t];
+    if (out->data_var) for (long long t = 0; t < L.T; ++t) out->data_var[t] = L.data_var[t];
+    return RXHIP_OK;
+}
+const char* rxhip_lowering_error(void) { return rxhip_lower::last_error().c_str(); }
+
+rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    *out = nullptr;
+    rxhip_lower::Lgssm L;
+    rxhip_status st = rxhip_lower::lower_lgssm(g, L);
+    if (st) return st;
+    rxhip_lgssm_desc d;
+    std::memset(&d, 0, sizeof d);
+    d.d = L.d; d.dy = L.dy; d.T = L.T; d.n_chains = g->n_replicas > 0 ? g->n_replicas : 1; d.n_models = 1;
+    d.prior_through_transition = L.ptt;
+    d.A = L.A.data(); d.B = L.B.data(); d.P = L.P.data(); d.Q = L.Q.data(); d.m0 = L.m0.data(); d.V0 = L.V0.data();
+    d.segments = segments; d.device = device; d.stream = stream;
+    return rxhip_lgssm_create(&d, out);
+}
 
 static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t layout, bool src_on_device) {
     if (!e) return RXHIP_ERR_BADARG;

@@ -28,6 +28,24 @@ class LgssmDesc(ctypes.Structure):
     ]
 
 
+c_int64_p = ctypes.POINTER(ctypes.c_int64)
+VARKIND_RANDOM, VARKIND_DATA, VARKIND_CONST = 0, 1, 2
+NODE_MVNORMAL_MEAN_COV, NODE_MULTIPLY = 1, 2
+
+
+class GraphDesc(ctypes.Structure):
+    _fields_ = [("n_variables", ctypes.c_int64), ("var_kind", c_int32_p), ("var_rows", c_int32_p), ("var_cols", c_int32_p),
+                ("var_const", c_int64_p), ("n_factors", ctypes.c_int64), ("factor_type", c_int32_p),
+                ("factor_iface", c_int64_p), ("const_pool", c_double_p), ("n_const", ctypes.c_int64),
+                ("n_replicas", ctypes.c_int64)]
+
+
+class LgssmLowered(ctypes.Structure):
+    _fields_ = [("d", ctypes.c_int32), ("dy", ctypes.c_int32), ("T", ctypes.c_int64),
+                ("prior_through_transition", ctypes.c_int32), ("A", c_double_p), ("B", c_double_p), ("P", c_double_p),
+                ("Q", c_double_p), ("m0", c_double_p), ("V0", c_double_p), ("state_var", c_int64_p), ("data_var", c_int64_p)]
+
+
 class GmmDesc(ctypes.Structure):
     _fields_ = [("N", ctypes.c_int64), ("K", ctypes.c_int32)] + [(n, c_double_p) for n in (
         "mu0", "v0", "a0", "b0", "alpha0", "init_m_mean", "init_m_var", "init_p_shape", "init_p_rate", "init_s_alpha")] + [
@@ -44,6 +62,10 @@ class HgfDesc(ctypes.Structure):
 _H = ctypes.c_void_p
 SYMBOLS = [
     ("rxhip_lgssm_create", ctypes.c_int32, [ctypes.POINTER(LgssmDesc), ctypes.POINTER(_H)]),
+    ("rxhip_graph_lower_lgssm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(LgssmLowered)]),
+    ("rxhip_lowering_error", ctypes.c_char_p, []),
+    ("rxhip_create", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
+                                      ctypes.POINTER(_H)]),
     ("rxhip_lgssm_supported", ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),
     ("rxhip_set_data", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, ctypes.c_size_t, ctypes.c_int32]),
     ("rxhip_set_data_device", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32]),
