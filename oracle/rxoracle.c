@@ -720,6 +720,7 @@ int rxo_gmm_vmp(long long N, int K, const double* y, const double* mu0, const do
         double S0[64], S1[64], S2[64];
         if (K > 64) { rc = RXO_ERR_BADARG; break; }
         for (int k = 0; k < K; ++k) S0[k] = S1[k] = S2[k] = 0.0;
+        /* pass 1: q(z_i) from the marginals of the previous iteration; messages toward m[k] and s */
         for (long long i = 0; i < N; ++i) {
             /* @rule NormalMixture(:switch): ∝ exp(−U_k), U_k = NormalMeanPrecision average energy;
                @rule Categorical(:out)(q_p::Dirichlet): ∝ exp(E log s_k); q(z_i) = normalised product */
@@ -743,10 +744,6 @@ int rxo_gmm_vmp(long long N, int K, const double* y, const double* mu0, const do
                 /* @rule NormalMixture(m[k]): N(mean = y_i, precision = π_ik E[p_k]) — product in (ξ, Λ) */
                 nm[k] += pi[k] * Ep[k] * y[i];
                 nv[k] += pi[k] * Ep[k];
-                /* @rule NormalMixture(p[k]): GammaShapeRate(1 + π/2, π ½[(y−m̄)² + v]); Gamma×Gamma = (a1+a2−1, b1+b2) */
-                double d = y[i] - mm[k];
-                na[k] += 0.5 * pi[k];
-                nb[k] += 0.5 * pi[k] * (d * d + mv[k]);
                 /* @rule Categorical(:p)(q_out): Dirichlet(1 + π) ; Dirichlet×Dirichlet = α1 + α2 − 1 */
                 nal[k] += pi[k];
                 S0[k] += pi[k];
@@ -758,9 +755,15 @@ int rxo_gmm_vmp(long long N, int K, const double* y, const double* mu0, const do
         for (int k = 0; k < K; ++k) {
             mv[k] = 1.0 / nv[k];
             mm[k] = nm[k] * mv[k];
+            al[k] = nal[k];
+        }
+        /* pass 2: @rule NormalMixture(p[k]): GammaShapeRate(1 + π/2, π ½[(y−m̄)² + v]) with the NEW q(m[k]);
+           Gamma×Gamma = (a1+a2−1, b1+b2).  Σ_i π_ik[(y_i−m̄)² + v] = S2 − 2m̄S1 + m̄²S0 + vS0 */
+        for (int k = 0; k < K; ++k) {
+            na[k] += 0.5 * S0[k];
+            nb[k] += 0.5 * (S2[k] - 2.0 * mm[k] * S1[k] + mm[k] * mm[k] * S0[k] + mv[k] * S0[k]);
             pa[k] = na[k];
             pb[k] = nb[k];
-            al[k] = nal[k];
             margs += 3;
             if (!(mv[k] > 0.0) || !(pb[k] > 0.0)) rc = RXO_ERR_NOT_POSDEF;
         }

@@ -95,8 +95,10 @@ int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B,
  * precision (test/models/models_tests.jl:114-128, `iid_gaussians_params`).
  * Rules restated from SURVEY.md Appendix A.4/A.5.  Schedule (ASSUMED — the reactive update order is
  * not documented in the reference tree): per iteration, q(z[i]) from the marginals of the
- * previous iteration; then q(s), q(m[k]), q(p[k]) from the new q(z), q(m) using E[p] and q(p) using
- * q(m) of the previous iteration.  Converged posteriors are schedule-independent.
+ * previous iteration; then q(s) and q(m[k]) from the new q(z) (q(m) with E[p] of the previous iteration); then
+ * q(p[k]) from the new q(z) AND the new q(m[k]).  (With q(p) computed from the previous q(m) the reference
+ * test's own initialisation — vague Gamma, E[p] = 1e12 — drives the iteration into a poor optimum, FE ≈ 571 on
+ * the reference's data, whereas the reference reaches 284.76; the sequential order converges at once.)
  * init_*: the `@initialization` marginals.  hist: [iterations][5][K] = (mean m, var m, shape p, rate p,
  * alpha s) after each iteration; fe: [iterations] Bethe free energy; resp (nullable): [N][K] final q(z).
  */

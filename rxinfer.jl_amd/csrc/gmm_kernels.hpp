@@ -18,7 +18,8 @@
 //   k_gmm_update : products of the messages toward m[k], p[k], s in closed form from the statistics,
 //                  Bethe free energy, and the per-component constants of the next pass
 // Schedule (assumed; the reference's reactive order is undocumented): per iteration
-// q(z_i) from the marginals of the previous iteration, then q(s), q(m[k]), q(p[k]) from the new q(z).
+// q(z_i) from the marginals of the previous iteration, then q(s), q(m[k]) from the new q(z), then q(p[k]) from
+// the new q(z) and the new q(m[k]) (the order under which the reference test's own initialisation converges).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(64) k_gmm_update(GmmParams p) {
         S0 = p.totals[k];
         S1 = p.totals[KT + k];
         S2 = p.totals[2 * KT + k];
-        const double m_old = p.par[k], v_old = p.par[KT + k], Ep_old = p.par[2 * KT + k] / p.par[3 * KT + k];
+        const double Ep_old = p.par[2 * KT + k] / p.par[3 * KT + k];
         // q(m[k]) = N(μ0, v0) × Π_i N(y_i, (π_ik E p_k)⁻¹)            (ξ, Λ) sums
         const double L = 1.0 / pr[KT + k] + Ep_old * S0;
         const double xi = pr[k] / pr[KT + k] + Ep_old * S1;
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(64) k_gmm_update(GmmParams p) {
         nm = xi * nv;
         // q(p[k]) = Gamma(a0, b0) × Π_i Gamma(1 + π/2, π ½[(y_i − m̄)² + v])
         na = pr[2 * KT + k] + 0.5 * S0;
-        nb = pr[3 * KT + k] + 0.5 * (S2 - 2.0 * m_old * S1 + m_old * m_old * S0 + v_old * S0);
+        nb = pr[3 * KT + k] + 0.5 * (S2 - 2.0 * nm * S1 + nm * nm * S0 + nv * S0);  // with the NEW q(m[k])
         // q(s) = Dirichlet(α0) × Π_i Dirichlet(1 + π_i)
         nal = pr[4 * KT + k] + S0;
         bad = !(nv > 0.0) || !(nb > 0.0);

@@ -41,6 +41,7 @@ def test_gmm_univariate_reference_test_shape():
     assert_parity(hist, fe, ohist, ofe)
     assert np.max(np.abs(resp - oresp)) < 1e-9
     assert np.all(np.diff(fe) <= 1e-10)  # FE non-increasing, gmm_univariate_tests.jl:96
+    assert np.all(np.abs(np.sort(hist[-1, 0]) - np.array([-10.0, 10.0])) < 1.0)  # clusters found from the vague initialisation
     assert cnt["rule_calls"] == ocnt.rule_calls and cnt["products"] == ocnt.products
 
 
