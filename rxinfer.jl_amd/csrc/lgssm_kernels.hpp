@@ -90,6 +90,22 @@ struct AggLayout {
     static constexpr int SIZE = ((JJ + NS + 7) / 8) * 8;
 };
 
+// Per-model, per-segment matrices of the boundary scan (shared-model batches): the covariance at every
+// segment start, the precision of the backward message at every segment end and the d×d maps that carry the
+// data-dependent vectors across a segment do not depend on the observations; they are built on the host.
+//   m(b_{s+1}) = b_s + M1_s m(b_s) + M2_s η_s          ξβ(b_s) = η_s + N1_s ξβ(b_{s+1}) − N2_s b_s
+template <int D>
+struct ScanLayout {
+    static constexpr int NS = D * (D + 1) / 2;
+    static constexpr int M1 = 0;             // [D][D]
+    static constexpr int M2 = M1 + D * D;    // [D][D]
+    static constexpr int VB = M2 + D * D;    // [NS]  V(b_s)
+    static constexpr int N1 = VB + NS;       // [D][D]
+    static constexpr int N2 = N1 + D * D;    // [D][D]
+    static constexpr int LB = N2 + D * D;    // [NS]  Λβ(b_{s+1})
+    static constexpr int SIZE = ((LB + NS + 7) / 8) * 8;
+};
+
 struct Params {
     // problem
     long long T;
@@ -101,6 +117,8 @@ struct Params {
     const double* y;        // [T][chain][DY]
     double* filt;           // [T][chain/64][NP2][64][2]   filtered message (m_f, V_f packed), wave-blocked
     long long nb64;         // ceil(n_chains / 64)
+    double* vtab;           // [T][NS]  forward-message covariance V_f(t), ONE copy per model (shared-model batches)
+    const double* scan;     // [S][ScanLayout::SIZE]  data-independent part of the boundary scan (shared-model batches)
     double* mean;           // [T][chain][D]
     double* cov;            // [T][chain][D][D]
     const double* cst;      // [n_models][CstLayout::SIZE]
@@ -312,6 +330,56 @@ struct LogProd {
 // record I/O.  A Gaussian record is NP = D + NS doubles: vector, then packed lower triangle.
 // filt layout [T][chain/64][NP2][64][2]: lane = chain % 64; every 16-byte access of a wave is one
 // contiguous 1 KiB run and the NP2 accesses of a wave-step cover one contiguous NP2 KiB block.
+// Shared-model batches: V_f(t) does not depend on the data, so it is bitwise identical in every chain of a
+// model (same instruction sequence, same inputs).  Every chain still COMPUTES it, but only the mean part of
+// the forward message is stored per chain ([T][chain/64][MP2][64][2]); the covariance is stored once per model
+// (written by chain 0) and read back as a broadcast — 32 instead of 112 B per (chain, step) each way at d = 4.
+template <int D>
+struct DimM {
+    static constexpr int MP2 = (D + 1) / 2;  // mean part in 16-byte pairs
+};
+template <int D>
+__device__ __forceinline__ void store_filt_sh(const Params& p, long long t, long long chain, const double (&m)[D],
+                                              const Sym<D>& V) {
+    constexpr int MP2 = DimM<D>::MP2;
+    double r[2 * MP2];
+#pragma unroll
+    for (int i = 0; i < D; ++i) r[i] = m[i];
+    if (D < 2 * MP2) r[2 * MP2 - 1] = 0.0;
+    double2* base = reinterpret_cast<double2*>(p.filt) + ((t * p.nb64 + (chain >> 6)) * MP2) * 64 + (chain & 63);
+#pragma unroll
+    for (int k = 0; k < MP2; ++k) base[k * 64] = make_double2(r[2 * k], r[2 * k + 1]);
+    if (chain == 0) {
+        double* v = p.vtab + t * Dim<D>::NS;
+#pragma unroll
+        for (int i = 0; i < Dim<D>::NS; ++i) v[i] = V.v[i];
+    }
+}
+template <int D>
+__device__ __forceinline__ void load_filt_m_sh(const Params& p, long long t, long long chain, double2 (&r)[DimM<D>::MP2]) {
+    constexpr int MP2 = DimM<D>::MP2;
+    const double2* base = reinterpret_cast<const double2*>(p.filt) + ((t * p.nb64 + (chain >> 6)) * MP2) * 64 + (chain & 63);
+#pragma unroll
+    for (int k = 0; k < MP2; ++k) r[k] = base[k * 64];
+}
+template <int D>
+__device__ __forceinline__ void unpack_m_sh(const double2 (&r)[DimM<D>::MP2], double (&m)[D]) {
+    double f[2 * DimM<D>::MP2];
+#pragma unroll
+    for (int k = 0; k < DimM<D>::MP2; ++k) {
+        f[2 * k] = r[k].x;
+        f[2 * k + 1] = r[k].y;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) m[i] = f[i];
+}
+template <int D>
+__device__ __forceinline__ void load_v_sh(const Params& p, long long t, Sym<D>& V) {
+    const double* v = p.vtab + t * Dim<D>::NS;  // wave-uniform address
+#pragma unroll
+    for (int i = 0; i < Dim<D>::NS; ++i) V.v[i] = v[i];
+}
+
 template <int D>
 __device__ __forceinline__ void store_filt(double* filt, long long t, long long n_chains, long long chain,
                                            const double (&m)[D], const Sym<D>& V) {
@@ -551,7 +619,8 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
         load_y<DY>(p.y, 0, p.n_chains, chain, yv);
         double quad = 0.0, detprod = 1.0;
         obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok, quad, detprod);
-        store_filt<D>(p.filt, 0, p.n_chains, chain, m, V);
+        if (UNI) store_filt_sh<D>(p, 0, chain, m, V);
+        else store_filt<D>(p.filt, 0, p.n_chains, chain, m, V);
         if (FE) p.fe_part[chain] = -0.5 * (quad + log(detprod));
         if (p.T == 1) {  // single observation: the filtered belief is the posterior
             double* om = p.mean + chain * D;
@@ -667,6 +736,141 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
 }
 
+// phase 2 for shared-model batches: only the data-dependent vectors are scanned on the device
+// (two 4×4 matvecs per segment and role); matrices come from the per-model ScanLayout table, staged through
+// LDS in chunks of 64 segments (the recursion is latency-bound: a scalar or global load per step would
+// cost more than the arithmetic), and the per-chain element vectors are prefetched one segment ahead.
+template <int D, int DY, bool FE>
+__global__ void __launch_bounds__(64) k_boundary_scan_tab(Params p, const CstArg<CstLayout<D, DY>::SIZE> cb) {
+    using CL = CstLayout<D, DY>;
+    using SL = ScanLayout<D>;
+    constexpr int NS = Dim<D>::NS;
+    constexpr int CH = 64;  // segments per LDS chunk
+    __shared__ double2 tbl[CH * SL::SIZE / 2];
+    const int lane = threadIdx.x;
+    const long long chain_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = chain_raw < p.n_chains;
+    const long long chain = live ? chain_raw : 0;
+    const int role = blockIdx.y;
+    const CPtr c{cb.v};
+    const int S = p.S;
+    bool ok = true;
+    auto stage = [&](int s0, int n) {  // segments [s0, s0+n) -> LDS
+        __syncthreads();
+        const double2* src = reinterpret_cast<const double2*>(p.scan + (long long)s0 * SL::SIZE);
+        for (int q = lane; q < n * SL::SIZE / 2; q += 64) tbl[q] = src[q];
+        __syncthreads();
+    };
+    auto load_el = [&](int s, double (&b)[D], double (&eta)[D]) {
+        const double* el = p.elem + ((long long)s * 2 * D) * p.n_chains + chain;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            b[i] = el[i * p.n_chains];
+            eta[i] = el[(D + i) * p.n_chains];
+        }
+    };
+    if (role == 0) {
+        double mp[D], m[D], yv[DY];
+        Sym<D> Vp, V;
+#pragma unroll
+        for (int i = 0; i < D; ++i) mp[i] = c[CL::M1 + i];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) Vp.v[i] = c[CL::V1 + i];
+        load_y<DY>(p.y, 0, p.n_chains, chain, yv);
+        double quad = 0.0, detprod = 1.0;
+        obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok, quad, detprod);
+        if (live) {
+            store_filt_sh<D>(p, 0, chain, m, V);
+            if (FE) p.fe_part[chain] = -0.5 * (quad + log(detprod));
+            if (p.T == 1) {
+                double* om = p.mean + chain * D;
+                double* oc = p.cov + chain * D * D;
+#pragma unroll
+                for (int i = 0; i < D; ++i) om[i] = m[i];
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) oc[i * D + j] = V(i, j);
+            }
+        }
+        double bn[D], en[D];
+        if (S > 1) load_el(0, bn, en);
+        for (int s0 = 0; s0 < S; s0 += CH) {
+            const int n = (S - s0 < CH) ? S - s0 : CH;
+            stage(s0, n);
+            for (int q = 0; q < n; ++q) {
+                const int s = s0 + q;
+                const double* t = reinterpret_cast<const double*>(tbl) + q * SL::SIZE;
+                Sym<D> Vb;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) Vb.v[i] = t[SL::VB + i];
+                if (live) store_soa<D>(p.fstart, s, p.n_chains, chain, m, Vb);
+                if (s == S - 1) break;
+                double b[D], eta[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    b[i] = bn[i];
+                    eta[i] = en[i];
+                }
+                if (s + 1 < S - 1) load_el(s + 1, bn, en);
+                double mn[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double acc = b[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc += t[SL::M1 + i * D + k] * m[k] + t[SL::M2 + i * D + k] * eta[k];
+                    mn[i] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i) m[i] = mn[i];
+            }
+        }
+    } else {
+        double xi[D];
+        Sym<D> Lm;
+#pragma unroll
+        for (int i = 0; i < D; ++i) xi[i] = 0.0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) Lm.v[i] = 0.0;
+        if (live) store_soa<D>(p.beta, S, p.n_chains, chain, xi, Lm);
+        double bn[D], en[D];
+        if (S > 1) load_el(S - 1, bn, en);
+        // segments S−1 … 1 from the top; step s needs table[s] (N1, N2) and table[s−1].LB = Λβ(b_s), so
+        // consecutive chunks overlap by one entry
+        int hi = S;
+        while (hi > 1) {
+            const int s0 = (hi - CH > 0) ? hi - CH : 0;
+            stage(s0, hi - s0);
+            for (int s = hi - 1; s >= s0 + 1; --s) {
+                const double* t = reinterpret_cast<const double*>(tbl) + (s - s0) * SL::SIZE;
+                const double* tp = reinterpret_cast<const double*>(tbl) + (s - 1 - s0) * SL::SIZE;
+                double b[D], eta[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    b[i] = bn[i];
+                    eta[i] = en[i];
+                }
+                if (s - 1 >= 1) load_el(s - 1, bn, en);
+                double xn[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double acc = eta[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc += t[SL::N1 + i * D + k] * xi[k] - t[SL::N2 + i * D + k] * b[k];
+                    xn[i] = acc;
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i) xi[i] = xn[i];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) Lm.v[i] = tp[SL::LB + i];
+                if (live) store_soa<D>(p.beta, s, p.n_chains, chain, xi, Lm);
+            }
+            hi = s0 + 1;
+        }
+    }
+    if (!ok && live) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
 // ------------------------------------------------------------------------------------------
 // phase 3: forward sweep inside each segment.  Per step (reference rule names):
 //   `*`_A(:out)           N(A m, A V A')                       predict_cov / matvec_c
@@ -715,7 +919,8 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
             acc += quad;
             lp.mul(detprod);
         }
-        store_filt<D>(p.filt, t0 + i, p.n_chains, chain, m, V);
+        if (UNI) store_filt_sh<D>(p, t0 + i, chain, m, V);
+        else store_filt<D>(p.filt, t0 + i, p.n_chains, chain, m, V);
     }
     if (FE && live) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc + lp.value());
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
@@ -820,9 +1025,16 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
     double ms[D], mf[D];
     Sym<D> Vs, Vf;
     {
-        double2 r[NP2];
-        load_filt_raw<D>(p.filt, te, p.n_chains, chain, r);
-        unpack_rec<D>(r, mf, Vf);
+        if (UNI) {
+            double2 r[DimM<D>::MP2];
+            load_filt_m_sh<D>(p, te, chain, r);
+            unpack_m_sh<D>(r, mf);
+            load_v_sh<D>(p, te, Vf);
+        } else {
+            double2 r[NP2];
+            load_filt_raw<D>(p.filt, te, p.n_chains, chain, r);
+            unpack_rec<D>(r, mf, Vf);
+        }
         double xb[D];
         Sym<D> Lb, Vi, Ls;
         load_soa<D>(p.beta, seg + 1, p.n_chains, chain, xb, Lb);
@@ -838,11 +1050,19 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
         symv<D>(Vs, u, ms);
         if (seg == p.S - 1) write_marginal<D>(p, te, chain, ms, Vs);
     }
-    double2 rn[NP2];
-    if (len > 0) load_filt_raw<D>(p.filt, te - 1, p.n_chains, chain, rn);
+    double2 rn[UNI ? DimM<D>::MP2 : NP2];
+    auto prefetch = [&](long long tt) {
+        if constexpr (UNI) load_filt_m_sh<D>(p, tt, chain, rn);
+        else load_filt_raw<D>(p.filt, tt, p.n_chains, chain, rn);
+    };
+    if (len > 0) prefetch(te - 1);
     for (long long t = te - 1; t >= tb; --t) {
-        unpack_rec<D>(rn, mf, Vf);
-        if (t > tb) load_filt_raw<D>(p.filt, t - 1, p.n_chains, chain, rn);
+        if constexpr (UNI) {
+            unpack_m_sh<D>(rn, mf);
+            load_v_sh<D>(p, t, Vf);
+        } else
+            unpack_rec<D>(rn, mf, Vf);
+        if (t > tb) prefetch(t - 1);
         double mp[D], T[D][D];
         Sym<D> Vp, Lp;
         matvec_c<D>(CPtr{c.p + CL::A}, mf, mp);

@@ -33,6 +33,8 @@ struct LgssmVtbl {
     int oA, oP, oLOBS, oG, oQI, oC0, oM1, oV1, oHF;
     int tK, tU;
     int aPI, aC, aJ, aCI, aX, aJJ;
+    int scan_size, sM1, sM2, sVB, sN1, sN2, sLB;
+    void (*boundary_scan_tab)(const Params&, const double*, bool, hipStream_t);
     void (*seg_aggregate)(const Params&, const double*, bool, hipStream_t);
     void (*boundary_scan)(const Params&, const double*, bool, bool, hipStream_t);
     void (*forward)(const Params&, const double*, bool, bool, hipStream_t);
@@ -67,6 +69,11 @@ struct Launch {
             else hipLaunchKernelGGL((k_boundary_scan<D, DY, false, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
         }
     }
+    static void boundary_scan_tab(const Params& p, const double* hc, bool fe, hipStream_t s) {
+        dim3 grid(nblk(p.n_chains, 64), 2);
+        if (fe) hipLaunchKernelGGL((k_boundary_scan_tab<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
+        else hipLaunchKernelGGL((k_boundary_scan_tab<D, DY, false>), grid, dim3(64), 0, s, p, carg(hc));
+    }
     static void forward(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
         const long long total = p.n_chains * (long long)p.S;
         dim3 grid(nblk(total, 64));
@@ -94,6 +101,9 @@ struct Launch {
         v.oM1 = CL::M1; v.oV1 = CL::V1; v.oHF = CL::HF;
         v.tK = TL::K; v.tU = TL::U;
         v.aPI = AL::PI; v.aC = AL::C; v.aJ = AL::J; v.aCI = AL::CI; v.aX = AL::X; v.aJJ = AL::JJ;
+        using SL = ScanLayout<D>;
+        v.scan_size = SL::SIZE; v.sM1 = SL::M1; v.sM2 = SL::M2; v.sVB = SL::VB; v.sN1 = SL::N1; v.sN2 = SL::N2; v.sLB = SL::LB;
+        v.boundary_scan_tab = &Launch::boundary_scan_tab;
         v.seg_aggregate = &Launch::seg_aggregate;
         v.boundary_scan = &Launch::boundary_scan;
         v.forward = &Launch::forward;
@@ -150,7 +160,7 @@ struct rxhip_engine {
     bool own_y = false;
     bool have_data = false;
     double *d_filt = nullptr, *d_mean = nullptr, *d_cov = nullptr, *d_cst = nullptr, *d_tab = nullptr,
-           *d_agg = nullptr, *d_elem = nullptr, *d_fstart = nullptr, *d_beta = nullptr, *d_fe_part = nullptr,
+           *d_vtab = nullptr, *d_scan = nullptr, *d_agg = nullptr, *d_elem = nullptr, *d_fstart = nullptr, *d_beta = nullptr, *d_fe_part = nullptr,
            *d_fe_chain = nullptr, *d_fe_total = nullptr;
     int* d_chain_model = nullptr;
     int* d_status = nullptr;
@@ -280,8 +290,56 @@ static void pack_sym(int n, const double* A, double* out) {
 }  // namespace host
 
 // Build constant block, gain tables and element matrices of one model.
+struct HostAgg { std::vector<double> Pi, C, J, Ci, X, JJ; };
+
+// data-independent part of the boundary scan (see ScanLayout / DenseParams::scanm): per segment the maps that
+// carry the means / weighted means across it, the covariance at its start and the backward precision at its end
+static bool build_scan_matrices(int d, int S, const HostAgg& a0, const HostAgg& aLast, const double* Vf1,
+                                std::vector<std::vector<double>>& M1, std::vector<std::vector<double>>& M2,
+                                std::vector<std::vector<double>>& Vb, std::vector<std::vector<double>>& N1,
+                                std::vector<std::vector<double>>& N2, std::vector<std::vector<double>>& Lb) {
+    const size_t MM = (size_t)d * d;
+    auto z = std::vector<double>(MM, 0.0);
+    M1.assign(S, z); M2.assign(S, z); Vb.assign(S, z); N1.assign(S, z); N2.assign(S, z); Lb.assign(S, z);
+    std::vector<double> Vc(Vf1, Vf1 + MM), Vi(MM), W(MM), tt(MM), m1(MM), m2(MM);
+    for (int s = 0; s < S; ++s) {
+        Vb[s] = Vc;
+        if (s == S - 1) break;
+        if (!host::chol_inv(d, Vc.data(), Vi.data(), nullptr)) return false;
+        for (size_t q = 0; q < MM; ++q) tt[q] = Vi[q] + a0.J[q];
+        if (!host::chol_inv(d, tt.data(), W.data(), nullptr)) return false;
+        host::mm(d, d, d, a0.Pi.data(), W.data(), m2.data());
+        host::mm(d, d, d, m2.data(), Vi.data(), m1.data());
+        host::mmT(d, d, d, m2.data(), a0.Pi.data(), tt.data());
+        M1[s] = m1; M2[s] = m2;
+        for (int a = 0; a < d; ++a)
+            for (int b = 0; b <= a; ++b) {
+                const double v = 0.5 * (tt[a * d + b] + tt[b * d + a]) + a0.C[a * d + b];
+                Vc[a * d + b] = Vc[b * d + a] = v;
+            }
+    }
+    std::vector<double> Lm(MM, 0.0), n1(MM), n2(MM);
+    for (int s = S - 1; s >= 1; --s) {  // Lb[s] = Λβ(b_{s+1})
+        const HostAgg& g = (s == S - 1) ? aLast : a0;
+        Lb[s] = Lm;
+        for (size_t q = 0; q < MM; ++q) tt[q] = g.Ci[q] + Lm[q];
+        if (!host::chol_inv(d, tt.data(), W.data(), nullptr)) return false;
+        host::mTm(d, d, d, g.X.data(), W.data(), n1.data());
+        host::mm(d, d, d, n1.data(), Lm.data(), n2.data());
+        host::mm(d, d, d, n1.data(), g.X.data(), tt.data());
+        N1[s] = n1; N2[s] = n2;
+        for (int a = 0; a < d; ++a)
+            for (int b = 0; b <= a; ++b) {
+                const double v = g.JJ[a * d + b] - 0.5 * (tt[a * d + b] + tt[b * d + a]);
+                Lm[a * d + b] = Lm[b * d + a] = v;
+            }
+    }
+    if (S > 0) Lb[0] = Lm;
+    return true;
+}
+
 static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgssm_desc* ds, double* cst,
-                                       double* tab, double* agg) {
+                                       double* tab, double* agg, std::vector<double>* scan_out) {
     const LgssmVtbl& v = *e->vt;
     const int d = e->d, dy = e->dy;
     const double* A = ds->A + (size_t)mdl * d * d;
@@ -334,6 +392,7 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
         X(d * d), JJ(d * d);
     for (int i = 0; i < d; ++i) Pi[i * d + i] = 1.0;
     std::memset(agg, 0, sizeof(double) * 2 * v.agg_size);
+    HostAgg hagg[2];
     for (long long i = 1; i <= L; ++i) {
         host::mm(d, d, d, A, V.data(), t1.data());
         host::mmT(d, d, d, t1.data(), A, Vp.data());
@@ -382,6 +441,30 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
             host::pack_sym(d, J.data(), ag + v.aJ);
             host::pack_sym(d, Ci.data(), ag + v.aCI);
             host::pack_sym(d, JJ.data(), ag + v.aJJ);
+            HostAgg& h = hagg[which];
+            h.Pi = Pi; h.C = V; h.J = J; h.Ci = Ci; h.X = X; h.JJ = JJ;
+            for (int a = 0; a < d; ++a)
+                for (int b = 0; b < a; ++b) {
+                    double sj = 0.5 * (h.J[a * d + b] + h.J[b * d + a]); h.J[a * d + b] = h.J[b * d + a] = sj;
+                    double sq = 0.5 * (h.JJ[a * d + b] + h.JJ[b * d + a]); h.JJ[a * d + b] = h.JJ[b * d + a] = sq;
+                }
+        }
+    }
+    if (scan_out && e->S > 0) {
+        // filtered covariance at t = 1: (V1⁻¹ + B'Q⁻¹B)⁻¹
+        std::vector<double> V1i(d * d), Lf(d * d), Vf1(d * d);
+        if (!host::chol_inv(d, V1.data(), V1i.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "prior covariance is not positive definite");
+        for (int q = 0; q < d * d; ++q) Lf[q] = V1i[q] + Lobs[q];
+        if (!host::chol_inv(d, Lf.data(), Vf1.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "first filtered precision not positive definite");
+        std::vector<std::vector<double>> M1, M2, Vb, N1, N2, Lb;
+        if (!build_scan_matrices(d, e->S, hagg[0], hagg[1], Vf1.data(), M1, M2, Vb, N1, N2, Lb))
+            return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: boundary scan matrix not positive definite", mdl);
+        scan_out->assign((size_t)e->S * v.scan_size, 0.0);
+        for (int s = 0; s < e->S; ++s) {
+            double* t = scan_out->data() + (size_t)s * v.scan_size;
+            for (int q = 0; q < d * d; ++q) { t[v.sM1 + q] = M1[s][q]; t[v.sM2 + q] = M2[s][q]; t[v.sN1 + q] = N1[s][q]; t[v.sN2 + q] = N2[s][q]; }
+            host::pack_sym(d, Vb[s].data(), t + v.sVB);
+            host::pack_sym(d, Lb[s].data(), t + v.sLB);
         }
     }
     return RXHIP_OK;
@@ -652,7 +735,7 @@ const char* rxhip_last_error(const rxhip_engine* e) { return e ? e->err.c_str() 
 
 static void free_all(rxhip_engine* e) {
     if (e->device >= 0) (void)hipSetDevice(e->device);
-    double** bufs[] = {&e->d_filt, &e->d_mean, &e->d_cov, &e->d_cst, &e->d_tab, &e->d_agg, &e->d_elem,
+    double** bufs[] = {&e->d_vtab, &e->d_scan, &e->d_filt, &e->d_mean, &e->d_cov, &e->d_cst, &e->d_tab, &e->d_agg, &e->d_elem,
                        &e->d_fstart, &e->d_beta, &e->d_fe_part, &e->d_fe_chain, &e->d_fe_total};
     for (auto b : bufs)
         if (*b) { (void)hipFree(*b); *b = nullptr; }
@@ -722,9 +805,9 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->own_stream = true;
     }
 
-    // time segmentation: one (chain, segment) lane per SIMD lane slot — 256 CUs × 4 SIMDs × 64 lanes.
-    // The big kernels are HBM-bound at one wave per SIMD (measured: 48…128 segments within 2 %),
-    // and the boundary scan grows linearly with the number of segments.
+    // time segmentation: two (chain, segment) lanes per SIMD lane slot — 256 CUs × 4 SIMDs × 2 waves × 64 lanes.
+    // Once the forward message is stored compactly the backward kernel is issue-bound at one wave per SIMD
+    // (measured at C2: 4.7 ms with 64 segments, 3.9–4.0 ms with 128…512); the boundary scan is cheap.
     const long long steps = e->T - 1;  // transitions
     if (steps <= 0) {
         e->S = 0;
@@ -733,7 +816,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     } else {
         long long S_target = ds->segments > 0 ? ds->segments
                              : dense ? (256 + e->n_chains - 1) / e->n_chains   // one workgroup per CU
-                                     : (65536 + e->n_chains - 1) / e->n_chains;
+                                     : (131072 + e->n_chains - 1) / e->n_chains;
         if (S_target < 1) S_target = 1;
         long long L = (steps + S_target - 1) / S_target;
         const long long Lmin = ds->segments > 0 ? 1 : (dense ? 8 : 16);
@@ -779,11 +862,11 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     const size_t NP = (size_t)e->d + (size_t)e->d * (e->d + 1) / 2;
     const size_t NP2 = (NP + 1) / 2;
     std::vector<double> cst((size_t)e->n_models * vt->cst_size), tab((size_t)e->n_models * e->L * vt->tab_size),
-        agg((size_t)e->n_models * 2 * vt->agg_size);
+        agg((size_t)e->n_models * 2 * vt->agg_size), scan;
     for (int m = 0; m < e->n_models; ++m) {
         rxhip_status st = build_model_tables(e, m, ds, cst.data() + (size_t)m * vt->cst_size,
                                              tab.data() + (size_t)m * e->L * vt->tab_size,
-                                             agg.data() + (size_t)m * 2 * vt->agg_size);
+                                             agg.data() + (size_t)m * 2 * vt->agg_size, e->uniform ? &scan : nullptr);
         if (st) return st;
     }
     e->h_cst0.assign(cst.begin(), cst.begin() + vt->cst_size);
@@ -799,7 +882,16 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         HIPCHK(e, hipMalloc(&e->d_chain_model, sizeof(int) * C));
         HIPCHK(e, hipMemcpy(e->d_chain_model, ds->chain_model, sizeof(int) * C, hipMemcpyHostToDevice));
     }
-    HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * T * NP2 * 2 * (((C + 63) / 64) * 64)));
+    if (e->uniform && !scan.empty()) {
+        HIPCHK(e, hipMalloc(&e->d_scan, sizeof(double) * scan.size()));
+        HIPCHK(e, hipMemcpy(e->d_scan, scan.data(), sizeof(double) * scan.size(), hipMemcpyHostToDevice));
+    }
+    if (e->uniform) {  // mean part per chain + one covariance copy per model (see lgssm_kernels.hpp store_filt_sh)
+        const size_t MP2 = ((size_t)e->d + 1) / 2;
+        HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * T * MP2 * 2 * (((C + 63) / 64) * 64)));
+        HIPCHK(e, hipMalloc(&e->d_vtab, sizeof(double) * T * ((size_t)e->d * (e->d + 1) / 2)));
+    } else
+        HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * T * NP2 * 2 * (((C + 63) / 64) * 64)));
     HIPCHK(e, hipMalloc(&e->d_mean, sizeof(double) * T * C * e->d));
     HIPCHK(e, hipMalloc(&e->d_cov, sizeof(double) * T * C * e->d * e->d));
     HIPCHK(e, hipMalloc(&e->d_elem, sizeof(double) * Sg * 2 * e->d * C));
@@ -1217,6 +1309,8 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.y = e->d_y;
     p.filt = e->d_filt;
     p.nb64 = (e->n_chains + 63) / 64;
+    p.vtab = e->d_vtab;
+    p.scan = e->d_scan;
     p.mean = e->d_mean;
     p.cov = e->d_cov;
     p.cst = e->d_cst;
@@ -1266,7 +1360,8 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
         }
         if (!e->dense) {
             if ((st = prof_begin(e, RXHIP_K_BOUNDARY_SCAN))) return st;
-            e->vt->boundary_scan(p, e->h_cst0.data(), e->uniform, fe, e->stream);
+            if (e->uniform && (e->d_scan || e->S == 0)) e->vt->boundary_scan_tab(p, e->h_cst0.data(), fe, e->stream);
+            else e->vt->boundary_scan(p, e->h_cst0.data(), e->uniform, fe, e->stream);
             if ((st = prof_end(e))) return st;
         }
         if (!e->dense && e->S > 0) {
