@@ -5,4 +5,5 @@ include/rxhip.h); this package only marshals arguments.  Importing it does not r
 constructing an engine does (no CPU fallback)."""
 from ._lib import RxHipError, lib, LIB_PATH  # noqa: F401
 from .engine import LGSSMEngine, GMMEngine, HGFEngine  # noqa: F401
-from .api import InferenceResult, infer, linear_gaussian_ssm, MvNormalMeanCovariance  # noqa: F401
+from .api import (InferenceResult, infer, linear_gaussian_ssm, MvNormalMeanCovariance, NormalMeanVariance,  # noqa: F401
+                  GammaShapeRate, Dirichlet, gaussian_mixture, iid_normal_gamma, hierarchical_gaussian_filter)

@@ -11,7 +11,7 @@ from typing import Any, Optional
 
 import numpy as np
 
-from .engine import LGSSMEngine
+from .engine import GMMEngine, HGFEngine, LGSSMEngine
 
 
 @dataclass
@@ -41,6 +41,63 @@ def linear_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transit
 
 
 @dataclass
+class NormalMeanVariance:
+    mean: np.ndarray
+    var: np.ndarray
+
+
+@dataclass
+class GammaShapeRate:
+    shape: np.ndarray
+    rate: np.ndarray
+
+
+@dataclass
+class Dirichlet:
+    alpha: np.ndarray
+
+
+@dataclass
+class UnivariateGaussianMixture:
+    """`s ~ Dirichlet(alpha0); m[k] ~ Normal(mean, variance); p[k] ~ Gamma(shape, rate); z[i] ~ Categorical(s);
+    y[i] ~ NormalMixture(switch = z[i], m = m, p = p)` with MeanField() constraints
+    (test/models/mixtures/gmm_univariate_tests.jl:7-26).  K = 1: the iid Gaussian with unknown mean and precision
+    (test/models/models_tests.jl:114-128)."""
+    prior_mean: np.ndarray
+    prior_var: np.ndarray
+    prior_shape: np.ndarray
+    prior_rate: np.ndarray
+    prior_alpha: np.ndarray
+
+
+def gaussian_mixture(prior_mean, prior_var, prior_shape, prior_rate, prior_alpha=None):
+    f = lambda a: np.atleast_1d(np.asarray(a, dtype=np.float64))
+    pm = f(prior_mean)
+    return UnivariateGaussianMixture(pm, f(prior_var), f(prior_shape), f(prior_rate),
+                                     np.ones_like(pm) if prior_alpha is None else f(prior_alpha))
+
+
+def iid_normal_gamma(mean, variance, shape, rate):
+    """`μ ~ Normal(mean, variance); τ ~ Gamma(shape, rate); y[i] ~ Normal(mean = μ, precision = τ)`"""
+    return gaussian_mixture([mean], [variance], [shape], [rate], [1.0])
+
+
+@dataclass
+class HierarchicalGaussianFilter:
+    """One-step HGF graph streamed over the observations with posterior→prior autoupdates
+    (test/models/statespace/hgf_tests.jl:9-70)."""
+    kappa: float
+    omega: float
+    z_variance: float
+    y_variance: float
+    n_gh: int = 31
+
+
+def hierarchical_gaussian_filter(kappa, omega, z_variance, y_variance, n_gh=31):
+    return HierarchicalGaussianFilter(float(kappa), float(omega), float(z_variance), float(y_variance), int(n_gh))
+
+
+@dataclass
 class InferenceResult:
     """src/inference/batch.jl:18-24"""
     posteriors: dict
@@ -50,16 +107,97 @@ class InferenceResult:
     error: Optional[BaseException] = None
 
 
-_OPTION_KEYS = {"limit_stack_depth", "warn", "device", "segments", "backend"}
+_OPTION_KEYS = {"limit_stack_depth", "warn", "device", "segments", "backend", "materialize_z"}
+
+
+def _check_options(options):
+    options = dict(options or {})
+    unknown = set(options) - _OPTION_KEYS
+    if unknown:
+        raise ValueError(f"Unknown option keys {sorted(unknown)}; available: {sorted(_OPTION_KEYS)}")
+    return options
+
+
+def _infer_mixture(model, data, iterations, free_energy, options, initialization, catch_exception):
+    """posteriors (KeepEach, one entry per iteration as `returnvars = KeepEach()`): m -> NormalMeanVariance [it][K],
+    p -> GammaShapeRate [it][K], s -> Dirichlet [it][K]; z (last iteration) if options['materialize_z']."""
+    options = _check_options(options)
+    if initialization is None:
+        raise ValueError("mean-field VMP needs `initialization` (q(m), q(p), q(s)); cf. test/inference/inference_tests.jl:361-363")
+    y = np.asarray(data["y"], dtype=np.float64).ravel()
+    iters = 1 if iterations is None else int(iterations)
+    K = model.prior_mean.size
+    qm, qp = initialization["m"], initialization["p"]
+    qs = initialization.get("s", Dirichlet(np.ones(K)))
+    eng = None
+    try:
+        eng = GMMEngine(y.size, model.prior_mean, model.prior_var, model.prior_shape, model.prior_rate, model.prior_alpha,
+                        qm.mean, qm.var, qp.shape, qp.rate, qs.alpha,
+                        materialize_responsibilities=bool(options.get("materialize_z", False)), device=int(options.get("device", -1)))
+        eng.set_data(y)
+        eng.run(iters, free_energy)
+        h = eng.history()
+        post = {"m": NormalMeanVariance(h[:, 0], h[:, 1]), "p": GammaShapeRate(h[:, 2], h[:, 3]), "s": Dirichlet(h[:, 4])}
+        if options.get("materialize_z", False):
+            post["z"] = eng.responsibilities()
+        return InferenceResult(post, None, eng.free_energy() if free_energy else None, model, None)
+    except Exception as err:
+        if not catch_exception:
+            raise
+        return InferenceResult({}, None, None, model, err)
+    finally:
+        if eng is not None:
+            eng.close()
+
+
+def _infer_hgf(model, data, iterations, free_energy, options, initialization, catch_exception):
+    """history[:zt], history[:xt] (KeepLast per observation) as NormalMeanVariance [T] (or [series][T]);
+    free_energy = free_energy_history: mean over observations per VMP iteration (per series)."""
+    options = _check_options(options)
+    y = np.asarray(data["y"], dtype=np.float64)
+    single = y.ndim == 1
+    if single:
+        y = y[None]
+    S, T = y.shape
+    iters = 1 if iterations is None else int(iterations)
+    init = initialization or {}
+    z0 = init.get("zt", NormalMeanVariance(0.0, 5.0))
+    x0 = init.get("xt", NormalMeanVariance(0.0, 5.0))
+    eng = None
+    try:
+        eng = HGFEngine(T, S, model.kappa, model.omega, model.z_variance, model.y_variance, (float(z0.mean), float(z0.var)),
+                        (float(x0.mean), float(x0.var)), n_gh=model.n_gh, device=int(options.get("device", -1)))
+        eng.set_data(y, layout="chain_time")
+        eng.run(iters, free_energy)
+        zm, zv, xm, xv = eng.history("chain_time")
+        fe = None
+        if free_energy:
+            fe = eng.free_energy() / S if single else None
+            if not single:
+                fe = eng.free_energy_per_chain()
+        if single:
+            zm, zv, xm, xv = zm[0], zv[0], xm[0], xv[0]
+        return InferenceResult({"zt": NormalMeanVariance(zm, zv), "xt": NormalMeanVariance(xm, xv)}, None, fe, model, None)
+    except Exception as err:
+        if not catch_exception:
+            raise
+        return InferenceResult({}, None, None, model, err)
+    finally:
+        if eng is not None:
+            eng.close()
 
 
 def infer(*, model, data, iterations=None, free_energy=False, options=None, returnvars=None,
-          catch_exception=False):
+          catch_exception=False, initialization=None):
     """Static (batch) inference on the device engine.
 
     data = {"y": array}: [T][dy] for one chain (as `data = (y = observations,)`), or
     [chain][T][dy] for a batch of independent chains sharing the model.
     Returns posteriors["x"] as MvNormalMeanCovariance with mean [T][d] / [chain][T][d]."""
+    if isinstance(model, UnivariateGaussianMixture):
+        return _infer_mixture(model, data, iterations, free_energy, options, initialization, catch_exception)
+    if isinstance(model, HierarchicalGaussianFilter):
+        return _infer_hgf(model, data, iterations, free_energy, options, initialization, catch_exception)
     if not isinstance(model, LinearGaussianSSM):
         raise TypeError("infer: no device schedule for this model type")
     options = dict(options or {})

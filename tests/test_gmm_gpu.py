@@ -89,3 +89,21 @@ def test_split_phase_equals_run():
             eng.update(True)
         eng.sync()
         assert np.array_equal(eng.history(), h1) and np.array_equal(eng.free_energy(), f1)  # deterministic
+
+
+def test_infer_mirror_for_vmp_models():
+    """`infer(model = …, data = (y = …,), constraints = MeanField(), initialization = …, iterations = 10, free_energy = true)`
+    mirror for the mixture / iid Gaussian×Gamma / HGF models."""
+    y = 0.75 + 10.0 * np.random.default_rng(123).standard_normal(100)
+    res = rxhip.infer(model=rxhip.iid_normal_gamma(4.0, 8.0, 4.0, 1.0 / 8.0), data={"y": y}, iterations=10, free_energy=True,
+                      initialization={"m": rxhip.NormalMeanVariance(0.0, 1.0), "p": rxhip.GammaShapeRate(1.0, 1.0)})
+    ohist, ofe, _, _ = rxoracle.gmm_vmp(y, [4.0], [8.0], [4.0], [1 / 8.0], [1.0], [0.0], [1.0], [1.0], [1.0], [1.0], 10)
+    assert res.posteriors["m"].mean.shape == (10, 1) and np.allclose(res.posteriors["m"].mean[:, 0], ohist[:, 0, 0], rtol=1e-9)
+    assert np.allclose(res.posteriors["p"].rate[:, 0], ohist[:, 3, 0], rtol=1e-9) and np.allclose(res.free_energy, ofe, rtol=1e-9)
+    with pytest.raises(ValueError):
+        rxhip.infer(model=rxhip.iid_normal_gamma(4.0, 8.0, 4.0, 0.125), data={"y": y}, iterations=3)  # no initialization
+    rng = np.random.default_rng(1)
+    yh = np.cumsum(rng.standard_normal(300))
+    r2 = rxhip.infer(model=rxhip.hierarchical_gaussian_filter(1.0, 0.0, 0.04, 0.01), data={"y": yh}, iterations=5, free_energy=True)
+    o = rxoracle.hgf_filter(yh, 1.0, 0.0, 0.04, 0.01, vmp_iters=5)
+    assert np.allclose(r2.posteriors["zt"].mean, o[0], rtol=1e-8, atol=1e-10) and np.allclose(r2.free_energy, o[4], rtol=1e-8)
