@@ -66,7 +66,8 @@ struct DenseParams {
     long long L;
     int d, dy;
     const double* y;      // [T][chain][dy]
-    double* filt;         // [chain][T][d + NTRI*256]   filtered (m_f | V_f lower tiles in register order)
+    double* filt;         // [chain][T][REC]   m_f(t) | C_t = V_f − G_t A V_f (lower tiles) | G_t = V_f A' V_p(t+1)⁻¹ (smoother gain)
+    double* vend;         // [chain][S][TRI]   V_f at the last step of every segment (lower tiles)
     double* mean;         // [T][chain][d]
     double* cov;          // [T][chain][d][d]
     const double* cst;    // DenseCst block (model 0; the dense path takes one model)
@@ -86,7 +87,8 @@ struct DenseCfg {
     static constexpr int LD = D + 2;           // LDS leading dimension (doubles): A-operand reads conflict-free
     static constexpr int THREADS = 64 * NT;
     static constexpr int NTRI = NT * (NT + 1) / 2;
-    static constexpr int REC = D + NTRI * 256;  // doubles per filtered record
+    static constexpr int TRI = NTRI * 256;           // a symmetric matrix as lower tiles in register order
+    static constexpr int REC = D + TRI + D * D;      // record: m_f(t) | C_t (lower tiles) | G_t (accumulator order)
     static constexpr int MAT = D * LD;          // doubles per LDS matrix
 };
 
@@ -158,6 +160,22 @@ __device__ __forceinline__ void tri_to_lds(const double* rec, double* M, int ld,
         }
 }
 
+// a full matrix in accumulator register order: [wave][tile][r][lane] — every access of a wave is 512 contiguous bytes
+template <int NT>
+__device__ __forceinline__ void acc_store_full(const Acc<NT>& a, double* g, int w, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) g[((w * NT + t) * 4 + r) * 64 + lane] = a.v[t][r];
+}
+template <int NT>
+__device__ __forceinline__ void acc_load_full(Acc<NT>& a, const double* g, int w, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.v[t][r] = g[((w * NT + t) * 4 + r) * 64 + lane];
+}
+
 // ---- MFMA contraction: acc += X·Y, X and Y addressed as X[i][k], Y[k][j] through element functors ----
 // A operand of v_mfma_f64_16x16x4_f64: lane l holds X[i = l&15][k = l>>4]; B operand: Y[k = l>>4][j = l&15].
 template <int NT, bool TX, bool TY>
@@ -188,63 +206,119 @@ __device__ __forceinline__ void mm_acc(Acc<NT>& c, const double* X, int ldx, con
 }
 
 // ---- SPD inverse, in place on the accumulator registers (restates FastCholesky.cholinv for large blocks) ----
-// Symmetric sweep operator, one pivot per barrier:  with r = row p of the current matrix, d = 1/r_p,
-//     a_ij <- a_ij − (r_i r_j) d   (i,j ≠ p);   a_pj = a_jp <- r_j d;   a_pp <- −d
-// keeps the array exactly symmetric (the product r_i r_j commutes bitwise), so only the pivot ROW is
-// published through LDS and every thread reads it at its 4 row and NT column positions.  After all D
-// sweeps the array holds −A⁻¹.  The 16 pivots of a tile block are unrolled at compile time (template
-// recursion): the owner register / lane group of the pivot row are constants, no dynamic register selection.
-// rowbuf: 2·D doubles (double buffered, one barrier per pivot).  lp accumulates log det A.
+// Block sweep operator, FOUR pivots per barrier.  The rows K = {16·pb + q + 4i, i = 0..3} of tile-row pb live in
+// the same 16 lanes of wave pb (lane>>4 == q, registers i = 0..3), so one LDS publish delivers four pivot rows
+// R (4 × D).  With D4 = R[:, K] (the 4×4 pivot block) every thread applies
+//     A_JJ <- A_JJ − R_J' D4⁻¹ R_J,     A_KJ <- D4⁻¹ R_J,     A_KK <- −D4⁻¹
+// to its 4 × NT elements; D4⁻¹ (SPD, via the LDL' inverse of lgssm_kernels.hpp) is recomputed redundantly by
+// every thread, which is cheaper than a second barrier.  After the D/4 blocks the array holds −A⁻¹ (any pivot
+// order is valid for SPD matrices).  det A = Π det D4.  16 barriers per 64×64 inverse instead of 64.
+// rowbuf: 2 buffers × D columns × 4 rows (layout [col][4]: a thread fetches the four pivot-row values of a
+// column with two ds_read_b128).
 template <int NT, int Q>
-struct Sweep {
-    // pivot p = 16·pb + Q: the register (Q>>2) and lane group (Q&3) of row p are compile-time constants,
-    // the tile block pb is a (wave-uniform) run-time value
+struct Sweep4 {
     static __device__ __forceinline__ void run(Acc<NT>& a, double* rowbuf, int pb, int w, int lane, bool& ok, LogProd& lp) {
-        constexpr int D = 16 * NT, PR = Q >> 2, PQ = Q & 3;
-        const int p = 16 * pb + Q;
-        double* rb = rowbuf + (Q & 1) * D;
-        const bool rowp = (w == pb) && ((lane >> 4) == PQ);
-        if (rowp) {
+        constexpr int D = 16 * NT;
+        double* rb = rowbuf + ((pb * 4 + Q) & 1) * 4 * D;
+        const bool rowown = (w == pb) && ((lane >> 4) == Q);
+        if (rowown) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) rb[16 * t + (lane & 15)] = a.v[t][PR];
+            for (int t = 0; t < NT; ++t) {
+                double* dst = rb + (16 * t + (lane & 15)) * 4;
+                reinterpret_cast<double2*>(dst)[0] = make_double2(a.v[t][0], a.v[t][1]);
+                reinterpret_cast<double2*>(dst)[1] = make_double2(a.v[t][2], a.v[t][3]);
+            }
         }
         __syncthreads();
-        const double piv = rb[p];
-        ok = ok && (piv > 0.0);
-        if (w == 0 && lane == 0) lp.mul(piv);
-        const double d = rcp_pos(piv);
-        double rc[NT], rr[4];
+        // the four pivot rows at this thread's columns (rc[u][t]) and rows (rr[u][r])
+        double rc[4][NT], rr[4][4];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) rc[t] = rb[16 * t + (lane & 15)];
+        for (int t = 0; t < NT; ++t) {
+            const double2* src = reinterpret_cast<const double2*>(rb + (16 * t + (lane & 15)) * 4);
+            const double2 x0 = src[0], x1 = src[1];
+            rc[0][t] = x0.x; rc[1][t] = x0.y; rc[2][t] = x1.x; rc[3][t] = x1.y;
+        }
 #pragma unroll
-        for (int r = 0; r < 4; ++r) rr[r] = rb[16 * w + (lane >> 4) + 4 * r];
+        for (int r = 0; r < 4; ++r) {
+            const double2* src = reinterpret_cast<const double2*>(rb + (16 * w + (lane >> 4) + 4 * r) * 4);
+            const double2 x0 = src[0], x1 = src[1];
+            rr[0][r] = x0.x; rr[1][r] = x0.y; rr[2][r] = x1.x; rr[3][r] = x1.y;
+        }
+        // pivot block D4[u][v] = R[u][K_v]  (lower triangle), inverse
+        Sym<4> d4, di;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const double2* src = reinterpret_cast<const double2*>(rb + (16 * pb + Q + 4 * v) * 4);
+            const double2 x0 = src[0], x1 = src[1];
+            const double col[4] = {x0.x, x0.y, x1.x, x1.y};
+#pragma unroll
+            for (int u = v; u < 4; ++u) d4(u, v) = col[u];
+        }
+        double det;
+        ok = spd_inv<4>(d4, di, det) && ok;
+        if (w == 0 && lane == 0) lp.mul(det);
+        // wm[v][t] = Σ_u D4⁻¹[v][u] R[u][col t]
+        double wm[4][NT];
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) sacc += di(v, u) * rc[u][t];
+                wm[v][t] = sacc;
+            }
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.v[t][r] = __builtin_fma(-(rr[r] * rc[t]), d, a.v[t][r]);
-        // row p (this wave, register PR) and column p (tile pb, lanes with lane&15 == Q)
+            for (int r = 0; r < 4; ++r) {
+                double sacc = a.v[t][r];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) a.v[t][PR] = rowp ? rc[t] * d : a.v[t][PR];
-        const bool colq = (lane & 15) == Q;
+                for (int v = 0; v < 4; ++v) sacc -= rr[v][r] * wm[v][t];
+                a.v[t][r] = sacc;
+            }
+        // pivot rows: this thread's row K_i is register i (all four registers are pivot rows for the owner lanes)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a.v[t][i] = rowown ? wm[i][t] : a.v[t][i];
+        // pivot columns: tile pb, lanes whose column index (lane&15) = Q + 4j
+        const bool colown = ((lane & 15) & 3) == Q;
+        const int jsel = (lane & 15) >> 2;
+        double dsel[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double x = di(0, u);
+            x = jsel == 1 ? di(1, u) : x;
+            x = jsel == 2 ? di(2, u) : x;
+            x = jsel == 3 ? di(3, u) : x;
+            dsel[u] = x;
+        }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const bool colp = colq && (t == pb);
+            const bool cp = colown && (t == pb);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) a.v[t][r] = colp ? rr[r] * d : a.v[t][r];
-            a.v[t][PR] = (rowp && colp) ? -d : a.v[t][PR];
+            for (int r = 0; r < 4; ++r) {
+                double wr = 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) wr += dsel[u] * rr[u][r];
+                double x = cp ? wr : a.v[t][r];
+                x = (cp && rowown) ? -dsel[r] : x;  // block element (K_r, K_jsel) = −D4⁻¹[r][jsel]
+                a.v[t][r] = x;
+            }
         }
-        Sweep<NT, Q + 1>::run(a, rowbuf, pb, w, lane, ok, lp);
+        Sweep4<NT, Q + 1>::run(a, rowbuf, pb, w, lane, ok, lp);
     }
 };
 template <int NT>
-struct Sweep<NT, 16> {
+struct Sweep4<NT, 4> {
     static __device__ __forceinline__ void run(Acc<NT>&, double*, int, int, int, bool&, LogProd&) {}
 };
 template <int NT>
-__device__ __forceinline__ bool gj_inverse(Acc<NT>& a, double* rowbuf, double* /*colbuf*/, int w, int lane, LogProd& lp) {
+__device__ __forceinline__ bool gj_inverse(Acc<NT>& a, double* rowbuf, double* /*unused*/, int w, int lane, LogProd& lp) {
     bool ok = true;
 #pragma unroll 1
-    for (int pb = 0; pb < NT; ++pb) Sweep<NT, 0>::run(a, rowbuf, pb, w, lane, ok, lp);
+    for (int pb = 0; pb < NT; ++pb) Sweep4<NT, 0>::run(a, rowbuf, pb, w, lane, ok, lp);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -369,7 +443,7 @@ struct DenseLds {
     using C = DenseCfg<NT>;
     static constexpr int NVEC = 12;
     static constexpr size_t bytes(int dmax) {
-        return sizeof(double) * ((size_t)4 * C::MAT + (size_t)NVEC * dmax + 4 * C::D + 3 * C::THREADS);
+        return sizeof(double) * ((size_t)4 * C::MAT + (size_t)NVEC * dmax + 8 * C::D + 3 * C::THREADS);
     }
 };
 
@@ -379,7 +453,7 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
     constexpr int D = 16 * NT;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int dy = p.dy, tid = threadIdx.x;
-    const int dm = D > dy ? D : dy;
+    const int dm = ((D > dy ? D : dy) + 1) & ~1;  // even: keeps every LDS carve 16-byte aligned
     double* m = smem;
     double* mn = m + dm;
     double* eta = mn + dm;
@@ -437,7 +511,7 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
     using C = DenseCfg<NT>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int dm = D > dy ? D : dy;
+    const int dm = ((D > dy ? D : dy) + 1) & ~1;  // even: keeps every LDS carve 16-byte aligned
     double* v0 = smem;
     double* v1 = v0 + dm;
     double* v2 = v1 + dm;
@@ -472,7 +546,6 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
         {
             Acc<NT> a;
             acc_load<NT>(a, cst + c.oVF1, D, w, lane);
-            acc_store_tri<NT>(a, rec + D, w, lane);
             if (p.T == 1) {
                 if (tid < D) p.mean[(0 * p.n_chains + chain) * D + tid] = v0[tid];
                 acc_store<NT>(a, p.cov + (0 * p.n_chains + chain) * MM, D, w, lane);
@@ -524,7 +597,10 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
     }
 }
 
-// phase 3 (dense): forward sweep of one segment.
+// phase 3 (dense): forward sweep of one segment.  Besides the forward message it forms, for the PREVIOUS time
+// index, the Rauch–Tung–Striebel gain G = V_f A' V_p⁻¹ and C = V_f − G A V_f from the T = A V_f and Λp = V_p⁻¹
+// this step has anyway — the arithmetic of the reference's backward rules MvN_x(:μ) -> `*`_A(:in) — so that the
+// backward sweep needs no inverse.
 template <int NT, bool FE>
 __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     constexpr int D = 16 * NT;
@@ -532,19 +608,20 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     constexpr int LD = C::LD;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int dm = D > dy ? D : dy;
-    double* M0 = smem;               // V (state covariance), then Vf
-    double* M1 = M0 + C::MAT;        // T = A V, then Λp
-    double* vec = M1 + 2 * C::MAT + C::MAT;  // after 4 matrix slots (M2, M3 unused here)
+    const int dm = ((D > dy ? D : dy) + 1) & ~1;  // even: keeps every LDS carve 16-byte aligned
+    double* M0 = smem;          // V_f of the previous step, then of this step
+    double* M1 = M0 + C::MAT;   // T = A V_f
+    double* M2 = M1 + C::MAT;   // Λp
+    double* M3 = M2 + C::MAT;   // G
+    double* vec = M3 + C::MAT;
     double* m = vec;
     double* mp = m + dm;
     double* xp = mp + dm;
     double* xf = xp + dm;
     double* yv = xf + dm;
     double* qy = yv + dm;
-    double* rowbuf = qy + dm;
-    double* colbuf = rowbuf + 2 * D;
-    double* red = colbuf + 2 * D;
+    double* rowbuf = qy + dm;  // 8·D doubles (two buffers of four pivot rows)
+    double* red = rowbuf + 8 * D;
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
@@ -557,60 +634,74 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     bool ok = true;
     double acc_quad = 0.0;
     LogProd lp;
-    // state at the segment start: mean from the scan, covariance from the per-model table
     if (tid < D) m[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
-    {
-        Acc<NT> a;
-        acc_load<NT>(a, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
-        acc_store<NT>(a, M0, LD, w, lane);
-    }
+    Acc<NT> a;
+    acc_load<NT>(a, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
+    acc_store<NT>(a, M0, LD, w, lane);
     __syncthreads();
     for (long long i = 0; i < len; ++i) {
         const long long t = t0 + i;
         if (tid < dy) yv[tid] = p.y[(t * p.n_chains + chain) * dy + tid];
         // `*`_A(:out): T = A V ; Vp = T A' + P ;  mp = A m
-        Acc<NT> a;
         acc_zero<NT>(a);
         if (!(p.ablate & 2)) mm_acc<NT, false, false>(a, A, D, M0, LD, w, lane);
         acc_store<NT>(a, M1, LD, w, lane);
         if (!(p.ablate & 4)) matvec_gT(mp, cst + c.oAT, D, D, m, nullptr, 0.0, tid);
         __syncthreads();
-        acc_load<NT>(a, cst + c.oP, D, w, lane);
-        if (!(p.ablate & 2)) mm_acc<NT, false, true>(a, M1, LD, A, D, w, lane);
+        Acc<NT> lam;
+        acc_load<NT>(lam, cst + c.oP, D, w, lane);
+        if (!(p.ablate & 2)) mm_acc<NT, false, true>(lam, M1, LD, A, D, w, lane);
         // weightedmean_precision of the forward message: Λp = Vp⁻¹
-        if (!(p.ablate & 1)) ok = gj_inverse<NT>(a, rowbuf, colbuf, w, lane, lp) && ok;
-        acc_store<NT>(a, M1, LD, w, lane);
+        if (!(p.ablate & 1)) ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
+        acc_store<NT>(lam, M2, LD, w, lane);
         __syncthreads();
+        // smoother gain and residual of the previous time index (t − 1): G = T' Λp,  C = V_f − G T
+        {
+            double* rec = p.filt + (chain * p.T + (t - 1)) * C::REC;
+            acc_zero<NT>(a);
+            mm_acc<NT, true, false>(a, M1, LD, M2, LD, w, lane);
+            acc_store_full<NT>(a, rec + D + C::TRI, w, lane);
+            acc_store<NT>(a, M3, LD, w, lane);
+            __syncthreads();
+            Acc<NT> cc;
+            acc_zero<NT>(cc);
+            mm_acc<NT, false, false>(cc, M3, LD, M1, LD, w, lane);
+            acc_load<NT>(a, M0, LD, w, lane);
+#pragma unroll
+            for (int q = 0; q < NT; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) a.v[q][r] -= cc.v[q][r];
+            acc_store_tri<NT>(a, rec + D, w, lane);
+        }
         // product with the `*`_B(:in) message: Λf = Λp + B'Q⁻¹B, ξf = Λp mp + G y
         if (!(p.ablate & 4)) {
-            matvec_lds(xp, M1, LD, D, D, mp, nullptr, 0.0, tid);
+            matvec_lds(xp, M2, LD, D, D, mp, nullptr, 0.0, tid);
             matvec_gT(qy, cst + c.oQI, dy, dy, yv, nullptr, 0.0, tid);  // Q⁻¹ symmetric
         }
         __syncthreads();
         if (!(p.ablate & 4)) matvec_gT(xf, cst + c.oGT, D, dy, yv, xp, 1.0, tid);
-        acc_add_mat<NT>(a, cst + c.oLOBS, D, w, lane, 1.0);
+        acc_add_mat<NT>(lam, cst + c.oLOBS, D, w, lane, 1.0);
         // mean_cov of the product: Vf = Λf⁻¹, mf = Vf ξf
-        if (!(p.ablate & 1)) ok = gj_inverse<NT>(a, rowbuf, colbuf, w, lane, lp) && ok;
-        acc_store<NT>(a, M0, LD, w, lane);
+        if (!(p.ablate & 1)) ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
+        acc_store<NT>(lam, M0, LD, w, lane);
         __syncthreads();
         if (!(p.ablate & 4)) matvec_lds(m, M0, LD, D, D, xf, nullptr, 0.0, tid);
         __syncthreads();
-        double* rec = p.filt + (chain * p.T + t) * C::REC;
-        if (!(p.ablate & 8)) {
-            if (tid < D) rec[tid] = m[tid];
-            acc_store_tri<NT>(a, rec + D, w, lane);
-        }
+        if (tid < D) p.filt[(chain * p.T + t) * C::REC + tid] = m[tid];
         if (FE && !(p.ablate & 16)) {
             double dots[3];
             block_dot3(qy, yv, dy, xf, m, D, xp, mp, D, red, tid, 64 * NT, dots);
             acc_quad += cst[c.oC0] + dots[0] - dots[1] + dots[2];
         }
+        if (i == len - 1) acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);
     }
     if (FE && tid == 0) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc_quad + lp.value());
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
 
-// phase 4 (dense): backward sweep + marginals of one segment (RTS form, see lgssm_kernels.hpp).
+// phase 4 (dense): backward sweep + marginals of one segment with the gains of phase 3:
+//     m_s(t) = m_f + G_t (m_s(t+1) − A m_f),     V_s(t) = C_t + G_t V_s(t+1) G_t'
+// (two MFMA contractions per step, no inverse).  The smoothed belief at the segment's end is (filtered ⊗ β).
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
     constexpr int D = 16 * NT;
@@ -618,11 +709,11 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
     constexpr int LD = C::LD;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int dm = D > dy ? D : dy;
-    double* M0 = smem;
-    double* M1 = M0 + C::MAT;
-    double* M2 = M1 + C::MAT;
-    double* M3 = M2 + C::MAT;
+    const int dm = ((D > dy ? D : dy) + 1) & ~1;  // even: keeps every LDS carve 16-byte aligned
+    double* M0 = smem;          // C_t
+    double* M1 = M0 + C::MAT;   // H = G V_s
+    double* M2 = M1 + C::MAT;   // V_s
+    double* M3 = M2 + C::MAT;   // G_t
     double* vec = M3 + C::MAT;
     double* ms = vec;
     double* mf = ms + dm;
@@ -630,12 +721,10 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
     double* dv = mp + dm;
     double* u = dv + dm;
     double* tmp = u + dm;
-    double* rowbuf = tmp + dm;
-    double* colbuf = rowbuf + 2 * D;
+    double* rowbuf = tmp + dm;  // 8·D doubles
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
-    const double* A = cst + c.oA;
     const size_t MM = (size_t)D * D;
     const long long b0 = 1 + seg * p.L;
     long long b1 = b0 + p.L;
@@ -643,24 +732,23 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
     const long long len = b1 - b0, tb = seg * p.L, te = tb + len;
     bool ok = true;
     LogProd lpd;  // determinants are not needed in this pass
+    Acc<NT> a;
     // smoothed belief at the end boundary: (Vf⁻¹ + Λβ)⁻¹, Vs (Vf⁻¹ mf + ξβ)
     {
-        const double* rec = p.filt + (chain * p.T + te) * C::REC;
-        if (tid < D) mf[tid] = rec[tid];
-        tri_to_lds<NT>(rec + D, M0, LD, w, lane);
+        if (tid < D) mf[tid] = p.filt[(chain * p.T + te) * C::REC + tid];
+        tri_to_lds<NT>(p.vend + (chain * p.S + seg) * C::TRI, M0, LD, w, lane);
         __syncthreads();
-        Acc<NT> a;
         acc_load<NT>(a, M0, LD, w, lane);
-        ok = gj_inverse<NT>(a, rowbuf, colbuf, w, lane, lpd) && ok;  // Vf⁻¹
+        ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;  // Vf⁻¹
         acc_store<NT>(a, M1, LD, w, lane);
         __syncthreads();
         if (tid < D) {
-            double s = p.beta_xi[(chain * (p.S + 1) + seg + 1) * D + tid];
-            for (int k = 0; k < D; ++k) s += M1[tid * LD + k] * mf[k];
-            u[tid] = s;
+            double sacc = p.beta_xi[(chain * (p.S + 1) + seg + 1) * D + tid];
+            for (int k = 0; k < D; ++k) sacc += M1[tid * LD + k] * mf[k];
+            u[tid] = sacc;
         }
         acc_add_mat<NT>(a, p.scanm + ((size_t)seg * 6 + 5) * MM, D, w, lane, 1.0);
-        ok = gj_inverse<NT>(a, rowbuf, colbuf, w, lane, lpd) && ok;  // Vs
+        ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;  // Vs
         acc_store<NT>(a, M2, LD, w, lane);
         __syncthreads();
         matvec_lds(ms, M2, LD, D, D, u, nullptr, 0.0, tid);
@@ -673,48 +761,24 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
     for (long long t = te - 1; t >= tb; --t) {
         const double* rec = p.filt + (chain * p.T + t) * C::REC;
         if (tid < D) mf[tid] = rec[tid];
-        tri_to_lds<NT>(rec + D, M0, LD, w, lane);  // Vf
+        tri_to_lds<NT>(rec + D, M0, LD, w, lane);  // C_t
+        acc_load_full<NT>(a, rec + D + C::TRI, w, lane);
+        acc_store<NT>(a, M3, LD, w, lane);  // G_t
         __syncthreads();
-        // T = A Vf ; Vp = T A' + P ; mp = A mf
-        Acc<NT> a, vp;
-        acc_zero<NT>(a);
-        mm_acc<NT, false, false>(a, A, D, M0, LD, w, lane);
-        acc_store<NT>(a, M1, LD, w, lane);
         matvec_gT(mp, cst + c.oAT, D, D, mf, nullptr, 0.0, tid);
-        __syncthreads();
-        acc_load<NT>(a, cst + c.oP, D, w, lane);
-        mm_acc<NT, false, true>(a, M1, LD, A, D, w, lane);
-        vp = a;
-        ok = gj_inverse<NT>(a, rowbuf, colbuf, w, lane, lpd) && ok;  // Λp
-        acc_store<NT>(a, M3, LD, w, lane);
-        // D = Vs − Vp  (into M2, overwriting Vs after it has been read into registers)
-        Acc<NT> dd;
-        acc_load<NT>(dd, M2, LD, w, lane);
-#pragma unroll
-        for (int q = 0; q < NT; ++q)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) dd.v[q][r] -= vp.v[q][r];
-        if (tid < D) dv[tid] = ms[tid] - mp[tid];
-        __syncthreads();
-        acc_store<NT>(dd, M2, LD, w, lane);
-        // G = T' Λp
-        acc_zero<NT>(a);
-        mm_acc<NT, true, false>(a, M1, LD, M3, LD, w, lane);
-        __syncthreads();
-        acc_store<NT>(a, M3, LD, w, lane);  // G (Λp no longer needed)
-        __syncthreads();
-        // H = G D
+        // H = G V_s
         acc_zero<NT>(a);
         mm_acc<NT, false, false>(a, M3, LD, M2, LD, w, lane);
-        acc_store<NT>(a, M1, LD, w, lane);  // H (T no longer needed)
-        // ms = mf + G dv
-        matvec_lds(tmp, M3, LD, D, D, dv, mf, 1.0, tid);
+        acc_store<NT>(a, M1, LD, w, lane);
         __syncthreads();
-        // Vs = Vf + H G'
+        if (tid < D) dv[tid] = ms[tid] - mp[tid];
+        __syncthreads();
+        matvec_lds(tmp, M3, LD, D, D, dv, mf, 1.0, tid);  // m_s = m_f + G (m_s⁺ − A m_f)
+        // V_s = C + H G'
         acc_load<NT>(a, M0, LD, w, lane);
         mm_acc<NT, false, true>(a, M1, LD, M3, LD, w, lane);
-        if (tid < D) ms[tid] = tmp[tid];
         __syncthreads();
+        if (tid < D) ms[tid] = tmp[tid];
         acc_store<NT>(a, M2, LD, w, lane);
         if (tid < D) p.mean[(t * p.n_chains + chain) * D + tid] = ms[tid];
         acc_store<NT>(a, p.cov + (t * p.n_chains + chain) * MM, D, w, lane);

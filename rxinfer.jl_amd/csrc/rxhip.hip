@@ -181,7 +181,7 @@ struct rxhip_engine {
     // dense (d = 16·NT) path
     bool dense = false;
     int nt = 0;
-    double *d_scanm = nullptr, *d_fstart_m = nullptr, *d_beta_xi = nullptr;
+    double *d_scanm = nullptr, *d_fstart_m = nullptr, *d_beta_xi = nullptr, *d_vend = nullptr;
     std::vector<double> h_cst0;  // model 0's constant block (kernel argument when all chains share it)
     int fe_total_cap = 0;
     // results bookkeeping
@@ -477,7 +477,7 @@ static bool dense_supported(int d, int dy) { return d >= 16 && d <= 64 && d % 16
 
 template <int NT>
 struct DenseLaunch {
-    static size_t lds_bytes(int d, int dy) { return DenseLds<NT>::bytes(d > dy ? d : dy); }
+    static size_t lds_bytes(int d, int dy) { return DenseLds<NT>::bytes(((d > dy ? d : dy) + 1) & ~1); }
     static hipError_t prepare(int d, int dy) {
         const int bytes = (int)lds_bytes(d, dy);
         hipError_t e;
@@ -513,7 +513,8 @@ struct DenseLaunch {
         case 3: DenseLaunch<3>::CALL; break;        \
         default: DenseLaunch<4>::CALL; break;       \
     }
-static int dense_rec(int nt) { return 16 * nt + nt * (nt + 1) / 2 * 256; }
+static int dense_tri(int nt) { return nt * (nt + 1) / 2 * 256; }
+static int dense_rec(int nt) { return 16 * nt + dense_tri(nt) + 256 * nt * nt; }
 
 // Per-model tables of the dense path: constants, per-offset gains (K_i, U_i), and the data-independent
 // matrix part of the boundary scan for every segment (see dense_kernels.hpp DenseParams::scanm).
@@ -749,7 +750,7 @@ static void free_all(rxhip_engine* e) {
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&e->h.d_out, &e->h.d_fe_series, &e->h.d_gh, &e->h.d_fe_total})
         if (*b) { (void)hipFree(*b); *b = nullptr; }
-    for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi})
+    for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend})
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
@@ -843,6 +844,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         HIPCHK(e, hipMemcpy(e->d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
         HIPCHK(e, hipMemcpy(e->d_scanm, scanm.data(), sizeof(double) * scanm.size(), hipMemcpyHostToDevice));
         HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * C * T * dense_rec(e->nt)));
+        HIPCHK(e, hipMalloc(&e->d_vend, sizeof(double) * C * Sg * dense_tri(e->nt)));
         HIPCHK(e, hipMalloc(&e->d_mean, sizeof(double) * T * C * D));
         HIPCHK(e, hipMalloc(&e->d_cov, sizeof(double) * T * C * D * D));
         HIPCHK(e, hipMalloc(&e->d_elem, sizeof(double) * C * Sg * 2 * D));
@@ -1329,7 +1331,7 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
     DenseParams dp;
     if (e->dense) {
         dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->S; dp.L = e->L; dp.d = e->d; dp.dy = e->dy;
-        dp.y = e->d_y; dp.filt = e->d_filt; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
+        dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
         dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;
         { const char* ab = getenv("RXHIP_ABLATE"); dp.ablate = ab ? atoi(ab) : 0; }
