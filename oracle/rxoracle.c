@@ -895,15 +895,32 @@ int rxo_hgf_filter(long long T, const double* y, double kappa, double omega, dou
             rules += 2; prods += 2; margs += 3;
             if (fe) {
                 const double Bn = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
-                const double cc = 1.0 / (1.0 / zv + 1.0 / z_variance); /* var(zt_min | zt) */
-                const double r = 1.0 - cc / z_variance;
-                const double mu_m = cc * (zm / zv + qzm / z_variance), var_m = cc + (cc / z_variance) * (cc / z_variance) * qzv;
-                const double e2 = cc + r * r * qzv + (r * qzm - cc * zm / zv) * (r * qzm - cc * zm / zv);
+                /* The transition node's joint q(zt, zt_min) (@marginalrule NormalMeanVariance(:out_μ)) and the message
+                   toward zt_min see the GCV z-message through its Gaussian moments: mean_var(ExponentialLinearQuadratic)
+                   = approximate_meancov of pdf(z)·exp(z²/2) against N(0, 1).  (With this treatment the reference's golden
+                   value test/models/statespace/hgf_tests.jl:113 is reproduced to 1e-5; see tests/golden.) */
+                double en = 0.0, em = 0.0, ecs[64], epts[64];
+                for (int i = 0; i < n_gh; ++i) {
+                    const double pt = 1.4142135623730951 * gx[i];
+                    const double cv = gw[i] / SQRTPI * exp(-0.5 * (a * pt + b * exp(c * pt)) + 0.5 * pt * pt);
+                    epts[i] = pt; ecs[i] = cv; em += pt * cv; en += cv;
+                }
+                em /= en;
+                double ev = 0.0;
+                for (int i = 0; i < n_gh; ++i) ev += ecs[i] * (epts[i] - em) * (epts[i] - em);
+                ev /= en;
+                if (!(ev > 0.0) || !isfinite(em)) { rc = RXO_ERR_NONFINITE_FE; goto out; }
+                const double wb = 1.0 / z_variance, w00 = 1.0 / ev + wb, w11 = 1.0 / zv + wb;
+                const double dW = w00 * w11 - wb * wb;
+                const double s00 = w11 / dW, s11 = w00 / dW, s01 = wb / dW;
+                const double j0 = s00 * (em / ev) + s01 * (zm / zv), j1 = s01 * (em / ev) + s11 * (zm / zv);
+                const double mu_m = j1, var_m = s11;
+                const double e2 = (j0 - j1) * (j0 - j1) + s00 + s11 - 2.0 * s01;
                 double F = 0.0;
                 F += 0.5 * (LOG2PI + log(zv) + ((mu_m - zm) * (mu_m - zm) + var_m) / zv);           /* prior zt_min */
                 F += 0.5 * (LOG2PI + log(xv) + ((m2 - xm) * (m2 - xm) + v22) / xv);                  /* prior xt_min */
                 F += 0.5 * (LOG2PI + log(z_variance) + e2 / z_variance);                             /* transition   */
-                F -= 0.5 * (LOG2PI + 1.0 + log(qzv)) + 0.5 * (LOG2PI + 1.0 + log(cc));               /* −H[zt,zt_min] */
+                F -= 0.5 * (2.0 * (LOG2PI + 1.0) - log(dW));                                         /* −H[zt,zt_min] */
                 F += 0.5 * (LOG2PI + (qzm * kappa + omega) + psi * A * Bn);                          /* GCV average energy */
                 F -= 0.5 * (2.0 * (LOG2PI + 1.0) + log(v11 * v22 - v12 * v12));                      /* −H[xt,xt_min] */
                 F += 0.5 * (LOG2PI + log(y_variance) + ((y[t] - m1) * (y[t] - m1) + v11) / y_variance); /* observation */

@@ -22,9 +22,11 @@
  * It is pinned against (a) the RNG-free known answers of the reference tests
  * (test/models/models_tests.jl:255,286,308,335: FE 3.51551 / 2.26551, means 1.5 / 1.0) and
  * (b) the identities BP == Kalman/RTS smoother and Bethe FE == -log p(y) on trees
- * (docs/src/manuals/variational/bethe-free-energy.md:70).  The RNG-dependent golden values of
- * the reference tests (StableRNG data) cannot be regenerated without Julia:
- * for those "parity unpinned" (see DESIGN.md §oracle).
+ * (docs/src/manuals/variational/bethe-free-energy.md:70), and (c) the RNG-dependent golden values of the
+ * reference tests, on data regenerated bit-exactly by oracle/stable_rng.py (StableRNGs + Julia's randn restated):
+ * mlgssm_test.jl:128 FE 6275.9015944677 (13 digits), ulgssm_tests.jl:48 FE 1854.297647, hgf_tests.jl:113 FE
+ * 1.009879989585 (to 1e-5); fixtures under tests/golden/.  "Parity unpinned" remains only for the mixture
+ * goldens (their data need Distributions' alias-table sampler) — see DESIGN.md §5.
  */
 #ifndef RXORACLE_H
 #define RXORACLE_H
@@ -118,8 +120,9 @@ int rxo_gmm_vmp(long long N, int K, const double* y, const double* mu0, const do
  * test/inference/inference_tests.jl:594-606); the z-message is the ExponentialLinearQuadratic
  * exp(−½(κz + ψA·exp(−κz))) and its product with the Gaussian forward message is moment-matched with the
  * Gauss–Hermite rule (approximate_meancov).  Order inside an iteration (ASSUMED): joint q(xt, xt_min)
- * from the previous q(zt), then q(zt).  The joint q(zt, zt_min) entering the Bethe free energy is taken as
- * q(zt)·p(zt_min | zt) (ASSUMED; the reference's treatment of the non-Gaussian message there is not in-tree).
+ * from the previous q(zt), then q(zt).  The joint q(zt, zt_min) entering the Bethe free energy is the Gaussian
+ * marginalrule of the transition node fed with mean_var(z-message), i.e. the Gauss–Hermite moments of
+ * pdf(z)·exp(z²/2) against N(0,1) — the reading that reproduces the golden free energy of hgf_tests.jl:113 to 1e-5.
  * Outputs: zm/zv/xm/xv [T] final marginals per observation (historyvars KeepLast), fe [vmp_iters] = mean over
  * observations of the per-iteration free energy (free_energy_history, src/score/actor.jl:98-104).
  */

@@ -130,7 +130,7 @@ def gauss_hermite(n):
     return x, w
 
 
-def hgf_filter(y, kappa, omega, z_variance, y_variance, z0=(0.0, 5.0), x0=(0.0, 5.0), vmp_iters=10, n_gh=31):
+def hgf_filter(y, kappa, omega, z_variance, y_variance, z0=(0.0, 5.0), x0=(0.0, 5.0), vmp_iters=10, n_gh=31, want_fe=True):
     """HGF online filtering of one series (see rxoracle.h).  Returns zm, zv, xm, xv [T], fe [vmp_iters], Counters."""
     y = _c(y)
     T = y.size
@@ -138,7 +138,7 @@ def hgf_filter(y, kappa, omega, z_variance, y_variance, z0=(0.0, 5.0), x0=(0.0, 
         (np.empty(T), np.empty(T), np.empty(T), np.empty(T), np.empty(vmp_iters))
     cnt = Counters()
     rc = lib().rxo_hgf_filter(T, _p(y), kappa, omega, z_variance, y_variance, z0[0], z0[1], x0[0], x0[1], vmp_iters, n_gh,
-                              _p(zm), _p(zv), _p(xm), _p(xv), _p(fe), ctypes.byref(cnt))
+                              _p(zm), _p(zv), _p(xm), _p(xv), _p(fe) if want_fe else None, ctypes.byref(cnt))
     if rc:
         raise RuntimeError(f"rxo_hgf_filter failed with status {rc}")
     return zm, zv, xm, xv, fe, cnt

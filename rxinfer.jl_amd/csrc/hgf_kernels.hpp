@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
     const double gw = j < p.n_gh ? p.gh[32 + j] : 0.0;
     const double kappa = p.kappa, omega = p.omega, zvar = p.z_variance, yvar = p.y_variance;
     const double A = exp(-omega);
+    const double pe = 1.4142135623730951 * gx;  // cubature points against N(0, 1)
     double qzm = p.z0m, qzv = p.z0v, qxm = p.x0m, qxv = p.x0v;
     bool bad = false;
     double yn = p.y[sc_];
@@ -76,16 +77,26 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
             qzm = mean; qzv = var; qxm = m1; qxv = v11;
             if (FE) {
                 const double Bn = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
-                const double cc = 1.0 / (1.0 / zv + 1.0 / zvar);
-                const double r = 1.0 - cc / zvar;
-                const double mu_m = cc * (zm / zv + qzm / zvar), var_m = cc + (cc / zvar) * (cc / zvar) * qzv;
-                const double q1 = r * qzm - cc * zm / zv;
-                const double e2 = cc + r * r * qzv + q1 * q1;
+                // the transition node's joint q(zt, zt_min) and the message toward zt_min see the z-message through its
+                // Gaussian moments: mean_var(ExponentialLinearQuadratic) = cubature of pdf(z)·exp(z²/2) against N(0, 1)
+                const double ecv = gw * exp(-0.5 * (kappa * pe + b * exp(-kappa * pe)) + 0.5 * pe * pe);
+                const double en = half_sum(ecv);
+                const double em = half_sum(pe * ecv) / en;
+                const double ed = pe - em;
+                const double ev = half_sum(ecv * ed * ed) / en;
+                bad = bad || !(ev > 0.0) || !(em - em == 0.0);
+                const double wb = 1.0 / zvar, w00 = 1.0 / ev + wb, w11 = 1.0 / zv + wb;
+                const double dW = w00 * w11 - wb * wb;
+                const double idw = 1.0 / dW;
+                const double s00 = w11 * idw, s11 = w00 * idw, s01 = wb * idw;
+                const double j0 = s00 * (em / ev) + s01 * (zm / zv), j1 = s01 * (em / ev) + s11 * (zm / zv);
+                const double mu_m = j1, var_m = s11;
+                const double e2 = (j0 - j1) * (j0 - j1) + s00 + s11 - 2.0 * s01;
                 double F = 0.0;
                 F += 0.5 * (kLog2Pi + log(zv) + ((mu_m - zm) * (mu_m - zm) + var_m) / zv);
                 F += 0.5 * (kLog2Pi + log(xv) + ((m2 - xm) * (m2 - xm) + v22) / xv);
                 F += 0.5 * (kLog2Pi + log(zvar) + e2 / zvar);
-                F -= 0.5 * (kLog2Pi + 1.0 + log(qzv)) + 0.5 * (kLog2Pi + 1.0 + log(cc));
+                F -= 0.5 * (2.0 * (kLog2Pi + 1.0) - log(dW));
                 F += 0.5 * (kLog2Pi + (qzm * kappa + omega) + psi * A * Bn);
                 F -= 0.5 * (2.0 * (kLog2Pi + 1.0) + log(v11 * v22 - v12 * v12));
                 F += 0.5 * (kLog2Pi + log(yvar) + ((yt - m1) * (yt - m1) + v11) / yvar);

@@ -1,4 +1,6 @@
 """Synthetic workloads of BASELINE.json / SURVEY.md §8(d) (shared by tests and bench.py)."""
+import math
+
 import numpy as np
 
 
@@ -77,3 +79,33 @@ def c3_model(d=64):
     G = rng.standard_normal((d, d))
     return dict(A=0.98 * Qm, B=np.eye(d) + 0.1 * G / 8.0, P=0.05 * np.eye(d), Q=10.0 * np.eye(d), m0=np.zeros(d),
                 V0=100.0 * np.eye(d))
+
+
+def generate_hgf_batch(T=2000, n_series=4096, seed=42, kappa=1.0, omega=0.0, z_variance=0.04, y_variance=0.01,
+                       z_bound=5.0):
+    """BASELINE config 4 data: the generative loop of test/models/statespace/hgf_tests.jl:72-92 for `n_series`
+    independent series (numpy default_rng), returned as (z, x, y) arrays [T][series].
+
+    The log-volatility random walk is reflected at ±z_bound.  The reference test has ONE series of 2000 steps; over
+    thousands of series an unbounded walk (σ = 0.2·√2000 ≈ 9) takes some of them beyond the range the reference's
+    31-point Gauss–Hermite rule can represent (nodes up to ±9.9 for the N(0,1)-based `mean_var` of the z-message),
+    where the reference's free energy is NaN — and so is ours, by the same arithmetic (status
+    RXHIP_ERR_NONFINITE_FE).  z_bound=None gives the unbounded walk.
+    """
+    rng = np.random.default_rng(seed)
+    dz = math.sqrt(z_variance) * rng.standard_normal((T, n_series))
+    ex = rng.standard_normal((T, n_series))
+    ey = math.sqrt(y_variance) * rng.standard_normal((T, n_series))
+    z = np.empty((T, n_series))
+    x = np.empty((T, n_series))
+    zp = np.zeros(n_series)
+    xp = np.zeros(n_series)
+    for t in range(T):
+        zt = zp + dz[t]
+        if z_bound is not None:
+            zt = np.where(zt > z_bound, 2 * z_bound - zt, zt)
+            zt = np.where(zt < -z_bound, -2 * z_bound - zt, zt)
+        xt = xp + np.exp(0.5 * (kappa * zt + omega)) * ex[t]
+        z[t], x[t] = zt, xt
+        zp, xp = zt, xt
+    return z, x, x + ey

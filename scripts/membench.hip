@@ -9,6 +9,22 @@ __global__ void k_fill(double2* __restrict__ o, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
     for (; i < n; i += st) o[i] = make_double2(1.0, 2.0);
 }
+typedef double d2v __attribute__((ext_vector_type(2)));
+__global__ void k_fill_nt(d2v* __restrict__ o, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
+    d2v v = {1.0, 2.0};
+    for (; i < n; i += st) __builtin_nontemporal_store(v, o + i);
+}
+__global__ void k_mix_streams_nt(const d2v* __restrict__ a, d2v* __restrict__ o, size_t per_wave) {
+    size_t w = blockIdx.x;
+    const d2v* ap = a + w * per_wave * 7 * 64;
+    d2v* op = o + w * per_wave * 10 * 64;
+    for (size_t u = 0; u < per_wave; ++u) {
+        d2v acc = {0, 0};
+        for (int k = 0; k < 7; ++k) { d2v v = __builtin_nontemporal_load(ap + (u * 7 + k) * 64 + threadIdx.x); acc += v; }
+        for (int k = 0; k < 10; ++k) __builtin_nontemporal_store(acc, op + (u * 10 + k) * 64 + threadIdx.x);
+    }
+}
 __global__ void k_read(const double2* __restrict__ a, size_t n, double* out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x, st = (size_t)gridDim.x * blockDim.x;
     double s = 0;
@@ -54,6 +70,7 @@ int main() {
     for (int blocks : {2048, 8192}) {
         printf("grid %d x 256\n", blocks);
         t("fill", (double)nbytes, [&] { hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, 0, a, n); });
+        t("fill nontemporal", (double)nbytes, [&] { hipLaunchKernelGGL(k_fill_nt, dim3(blocks), dim3(256), 0, 0, (d2v*)a, n); });
         t("read", (double)nbytes, [&] { hipLaunchKernelGGL(k_read, dim3(blocks), dim3(256), 0, 0, a, n, out); });
         t("copy (r+w)", 2.0 * nbytes, [&] { hipLaunchKernelGGL(k_copy, dim3(blocks), dim3(256), 0, 0, a, b, n); });
     }
@@ -66,6 +83,11 @@ int main() {
         size_t per = nunits / waves;
         char nm[64]; snprintf(nm, 64, "mix 7r:10w %d streams", waves);
         t(nm, (double)per * waves * 17 * 1024, [&] { hipLaunchKernelGGL(k_mix_streams, dim3(waves), dim3(64), 0, 0, a, b, per); });
+    }
+    for (int waves : {2048, 4096}) {
+        size_t per = nunits / waves;
+        char nm[64]; snprintf(nm, 64, "mix 7r:10w %d streams nt", waves);
+        t(nm, (double)per * waves * 17 * 1024, [&] { hipLaunchKernelGGL(k_mix_streams_nt, dim3(waves), dim3(64), 0, 0, (const d2v*)a, (d2v*)b, per); });
     }
     return 0;
 }

@@ -25,10 +25,8 @@ a = ap.parse_args()
 if a.config == "c4":
     # BASELINE config 4: 4096 independent HGF series, T = 2000, 10 VMP iterations / observation, GH-31
     S, T = (a.chains if a.chains != 1024 else 4096), (a.T if a.T != 100000 else 2000)
-    rng = np.random.default_rng(42)
-    z = np.cumsum(0.2 * rng.standard_normal((T, S)), axis=0)
-    x = np.cumsum(np.exp(0.5 * z) * rng.standard_normal((T, S)), axis=0)
-    y = x + 0.1 * rng.standard_normal((T, S))
+    from rxhip.workloads import generate_hgf_batch
+    _, _, y = generate_hgf_batch(T, S, 42)
     eng = rxhip.HGFEngine(T, S, 1.0, 0.0, 0.04, 0.01)
     eng.set_data(y)
     eng.run(10, True)

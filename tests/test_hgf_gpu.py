@@ -72,3 +72,25 @@ def test_hgf_shapes(S, T, iters, n_gh, layout):
         assert np.max(np.abs(xv[:, s] - o[3])) <= 1e-6 * np.max(np.abs(o[3]))
         fe_sum += o[4]
     assert np.max(np.abs(fe - fe_sum) / np.abs(fe_sum)) < 1e-8
+
+
+def test_hgf_free_energy_outside_cubature_range_fails_like_the_reference():
+    """A log-volatility far outside the ±9.9 range of the 31-point rule: `mean_var` of the z-message collapses to zero
+    variance, the reference's free energy is NaN (src/score/diagnostics.jl:19-51 raises) — the engine reports
+    RXHIP_ERR_NONFINITE_FE, the oracle RXO_ERR_NONFINITE_FE; the posteriors (free energy off) are unaffected."""
+    rng = np.random.default_rng(3)
+    T = 60
+    y = np.cumsum(np.exp(0.5 * 17.0) * rng.standard_normal(T)) + 0.1 * rng.standard_normal(T)
+    with pytest.raises(RuntimeError):
+        rxoracle.hgf_filter(y, 1.0, 0.0, 0.04, 0.01)
+    with rxhip.HGFEngine(T, 1, 1.0, 0.0, 0.04, 0.01) as eng:
+        eng.set_data(y[:, None])
+        with pytest.raises(rxhip.RxHipError) as ei:
+            eng.run(10, True)
+        assert ei.value.status == 4
+    with rxhip.HGFEngine(T, 1, 1.0, 0.0, 0.04, 0.01) as eng:
+        eng.set_data(y[:, None])
+        eng.run(10, False)
+        zm, zv, xm, xv = eng.history()
+    o = rxoracle.hgf_filter(y, 1.0, 0.0, 0.04, 0.01, want_fe=False)
+    assert np.max(np.abs(zm[:, 0] - o[0])) <= 1e-6 * np.max(np.abs(o[0]))
