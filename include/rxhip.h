@@ -167,6 +167,21 @@ rxhip_status rxhip_run(rxhip_engine* e, int32_t iterations, int32_t want_free_en
 
 /* asynchronous variant used for measurement: enqueues the same work, does not wait. */
 rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_free_energy);
+/* replaces: the streaming driver with `@autoupdates` posterior -> prior feedback kept on the device
+ * (src/inference/streaming.jl:349-407, src/inference/autoupdates.jl:640-659) for the one-step state-space graph of
+ * the benchmark notebook (`linear_gaussian_ssm_filtering`, cell 4; driver `rxinfer_inference_filtering`, cell 7):
+ *     x_min_t ~ MvNormal(μ = x_min_t_mean, Σ = x_min_t_cov);  x_t ~ MvNormal(μ = A * x_min_t, Σ = P);
+ *     y_t ~ MvNormal(μ = B * x_t, Σ = Q);   x_min_t_mean, x_min_t_cov = mean_cov(q(x_t))
+ * with `initialization q(x_t) = MvNormalMeanCovariance(m0, V0)` (engine created with prior_through_transition = 1;
+ * with 0 the first observation sees the prior on x_1 directly).  One observation per chain and time index is
+ * pushed through the one-step graph; the history of q(x_t) (`historyvars = (x_t = KeepLast(),)`, `keephistory = T`)
+ * is what rxhip_get_marginals returns afterwards.  The time loop is evaluated parallel-in-time (segment aggregation
+ * + prefix scan + forward kernel), exact to rounding.  Free energy (if requested): rxhip_get_free_energy returns ONE
+ * value, Σ_chains mean_t F_t — the mean over observations of the per-observation Bethe free energy that the
+ * reference's `free_energy_history` holds for a streaming run (src/score/actor.jl:98-104);
+ * rxhip_get_free_energy_per_chain the per-chain means.  LGSSM engines only. */
+rxhip_status rxhip_run_filter(rxhip_engine* e, int32_t want_free_energy);
+rxhip_status rxhip_run_filter_async(rxhip_engine* e, int32_t want_free_energy);
 /* waits for the engine's stream and collects device-side diagnostics (status as rxhip_run) */
 rxhip_status rxhip_sync(rxhip_engine* e);
 

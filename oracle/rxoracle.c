@@ -553,6 +553,76 @@ int rxo_lgssm_bp_batch(int d, int dy, int T, int n_chains, const double* A, cons
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Streaming / filtering driver (see rxoracle.h): one-step graph per observation, reference rule order.
+ * The per-observation Bethe free energy of the one-step TREE equals −log p(y_t | y_<t)
+ * (docs/src/manuals/variational/bethe-free-energy.md:70; the identity is checked for the full sweep in
+ * tests/test_oracle.py) and is evaluated in that innovation form.
+ * ------------------------------------------------------------------------------------------ */
+int rxo_lgssm_filter(int d, int dy, int T, const double* A, const double* B, const double* P, const double* Q,
+                     const double* m0, const double* V0, int prior_through_transition, const double* y,
+                     double* hist_mean, double* hist_cov, double* fe, rxo_counters* counters) {
+    if (d <= 0 || dy <= 0 || T <= 0) return RXO_ERR_BADARG;
+    const int n = d > dy ? d : dy;
+    const size_t nn = (size_t)n * n;
+    double* buf = (double*)malloc(sizeof(double) * (14 * nn + 8 * (size_t)n));
+    if (!buf) return RXO_ERR_BADARG;
+    double *work = buf, *chw = work + nn, *Vp = chw + 2 * nn, *Lp = Vp + nn, *Lq = Lp + nn, *Lb = Lq + nn, *Lf = Lb + nn,
+           *Vf = Lf + nn, *Sm = Vf + nn, *Si = Sm + nn, *tmpm = Si + nn, *V = tmpm + nn, *vecs = V + 2 * nn;
+    double *m = vecs, *mp = m + n, *xp = mp + n, *xq = xp + n, *xb = xq + n, *xf = xb + n, *r = xf + n, *sr = r + n;
+    ctx c;
+    memset(&c, 0, sizeof c);
+    c.work = work;
+    c.count = 1;
+    int rc = RXO_OK;
+    double fsum = 0.0;
+    memcpy(m, m0, sizeof(double) * d);
+    memcpy(V, V0, sizeof(double) * d * d);
+    /* MvN_y(:μ) with the clamped observation gives N(y, Q); its precision is constant */
+    if ((rc = cholinv(dy, Q, Lq, NULL, chw))) goto done;
+    for (int t = 0; t < T; ++t) {
+        const double* yt = y + (size_t)t * dy;
+        c.c.rule_calls++; /* prior node MvN(:out) with the data mean / covariance of @autoupdates */
+        if (t > 0 || prior_through_transition) {
+            rule_mul_out(d, d, A, m, V, mp, tmpm, &c);            /* `*`_A(:out)  */
+            rule_mvn_additive(d, mp, tmpm, P, mp, Vp, &c);        /* MvN_x(:out)  */
+        } else {
+            memcpy(mp, m, sizeof(double) * d);
+            memcpy(Vp, V, sizeof(double) * d * d);
+        }
+        c.c.rule_calls++;                                         /* MvN_y(:μ)    */
+        matvec(dy, dy, Lq, yt, xq);
+        rule_mul_in(dy, d, B, xq, Lq, xb, Lb, &c);                /* `*`_B(:in)   */
+        if ((rc = to_other_param(d, mp, Vp, xp, Lp, NULL, chw))) goto done; /* weightedmean_precision(forward msg) */
+        prod_wmp(d, xp, Lp, xb, Lb, xf, Lf, &c);                  /* q(x_t)       */
+        if ((rc = to_other_param(d, xf, Lf, m, Vf, NULL, chw))) goto done;  /* mean_cov(q(x_t)) */
+        memcpy(V, Vf, sizeof(double) * d * d);
+        c.c.marginals++;
+        memcpy(hist_mean + (size_t)t * d, m, sizeof(double) * d);
+        memcpy(hist_cov + (size_t)t * d * d, V, sizeof(double) * d * d);
+        if (fe) {
+            double ld;
+            congruence(dy, d, B, Vp, Sm, work);
+            for (int i = 0; i < dy * dy; ++i) Sm[i] += Q[i];
+            if ((rc = cholinv(dy, Sm, Si, &ld, chw))) goto done;
+            matvec(dy, d, B, mp, r);
+            for (int i = 0; i < dy; ++i) r[i] = yt[i] - r[i];
+            matvec(dy, dy, Si, r, sr);
+            double q = 0.0;
+            for (int i = 0; i < dy; ++i) q += r[i] * sr[i];
+            fsum += 0.5 * (dy * LOG2PI + ld + q);
+        }
+    }
+    if (fe) {
+        *fe = fsum / (double)T;
+        if (!isfinite(*fe)) rc = RXO_ERR_NONFINITE_FE;
+    }
+done:
+    if (counters) *counters = c.c;
+    free(buf);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Independent textbook implementation, used ONLY to validate the restatement above
  * (identity: BP on a tree == Kalman filter + RTS smoother; Bethe FE == −log p(y)).
  * ------------------------------------------------------------------------------------------ */

@@ -79,6 +79,20 @@ int rxo_lgssm_bp_batch(int d, int dy, int T, int n_chains, const double* A, cons
                        int prior_through_transition, const double* y, double* post_mean,
                        double* post_cov, double* fe, int nthreads, rxo_counters* counters);
 
+/*
+ * Streaming / filtering twin (src/inference/streaming.jl:349-407 with `@autoupdates`, benchmark notebook cells 4 and 7,
+ * `linear_gaussian_ssm_filtering`): for every observation the one-step graph
+ *     x_min_t ~ MvNormal(μ = m, Σ = V);  x_t ~ MvNormal(μ = A * x_min_t, Σ = P);  y_t ~ MvNormal(μ = B * x_t, Σ = Q)
+ * is evaluated in the reference's rule order (`*`_A(:out), MvN_x(:out), MvN_y(:μ), `*`_B(:in), product, mean_cov) and
+ * (m, V) <- mean_cov(q(x_t)).  prior_through_transition = 0: the first observation sees the prior on x_1 directly.
+ * hist_mean [T][d], hist_cov [T][d][d]: q(x_t) after each observation; fe (nullable): mean over observations of the
+ * per-observation Bethe free energy (= −log p(y_t | y_<t) on the one-step tree), the value the reference's
+ * free_energy_history holds for a streaming run (src/score/actor.jl:98-104).
+ */
+int rxo_lgssm_filter(int d, int dy, int T, const double* A, const double* B, const double* P, const double* Q,
+                     const double* m0, const double* V0, int prior_through_transition, const double* y,
+                     double* hist_mean, double* hist_cov, double* fe, rxo_counters* counters);
+
 /* Independent cross-check used only to validate the oracle itself: textbook Kalman filter +
  * RTS smoother and -log p(y) via innovations.  Same argument layout as rxo_lgssm_bp. */
 int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B, const double* P,

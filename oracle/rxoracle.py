@@ -47,6 +47,8 @@ def lib():
         _LIB.rxo_hgf_filter.restype = ctypes.c_int
         _LIB.rxo_hgf_filter.argtypes = [ctypes.c_longlong, dp] + [ctypes.c_double] * 8 + [ctypes.c_int, ctypes.c_int] + \
             [dp] * 5 + [ctypes.POINTER(Counters)]
+        _LIB.rxo_lgssm_filter.restype = ctypes.c_int
+        _LIB.rxo_lgssm_filter.argtypes = [ctypes.c_int] * 3 + [dp] * 6 + [ctypes.c_int] + [dp] * 4 + [ctypes.POINTER(Counters)]
         _LIB.rxo_gauss_hermite.restype = ctypes.c_int
         _LIB.rxo_gauss_hermite.argtypes = [ctypes.c_int, dp, dp]
     return _LIB
@@ -86,6 +88,22 @@ def lgssm_kalman_rts(A, B, P, Q, m0, V0, y, prior_through_transition=False):
     if rc:
         raise RuntimeError(f"rxo_lgssm_kalman_rts failed with status {rc}")
     return mean, cov, nll.value
+
+
+def lgssm_filter(A, B, P, Q, m0, V0, y, prior_through_transition=True, free_energy=True):
+    """Streaming / filtering run of one chain (rxo_lgssm_filter).  Returns history mean [T,d], cov [T,d,d],
+    fe (mean over observations) | None, Counters."""
+    A, B, P, Q, m0, V0, y = map(_c, (A, B, P, Q, m0, V0, y))
+    d, dy, T = A.shape[0], B.shape[0], y.shape[0]
+    mean = np.empty((T, d))
+    cov = np.empty((T, d, d))
+    fe = np.zeros(1)
+    cnt = Counters()
+    rc = lib().rxo_lgssm_filter(d, dy, T, _p(A), _p(B), _p(P), _p(Q), _p(m0), _p(V0), int(prior_through_transition),
+                                _p(y), _p(mean), _p(cov), _p(fe) if free_energy else None, ctypes.byref(cnt))
+    if rc:
+        raise RuntimeError(f"rxo_lgssm_filter failed with status {rc}")
+    return mean, cov, (float(fe[0]) if free_energy else None), cnt
 
 
 def lgssm_bp_batch(A, B, P, Q, m0, V0, y, prior_through_transition=False, free_energy=True, nthreads=1):

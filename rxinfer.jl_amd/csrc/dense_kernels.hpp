@@ -67,6 +67,7 @@ struct DenseParams {
     int d, dy;
     const double* y;      // [T][chain][dy]
     double* filt;         // [chain][T][REC]   m_f(t) | C_t = V_f − G_t A V_f (lower tiles) | G_t = V_f A' V_p(t+1)⁻¹ (smoother gain)
+    int filter;           // 1: filtering run (forward pass only; the filtered belief is written as the marginal)
     double* vend;         // [chain][S][TRI]   V_f at the last step of every segment (lower tiles)
     double* mean;         // [T][chain][d]
     double* cov;          // [T][chain][d][d]
@@ -546,7 +547,7 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
         {
             Acc<NT> a;
             acc_load<NT>(a, cst + c.oVF1, D, w, lane);
-            if (p.T == 1) {
+            if (p.T == 1 || p.filter) {
                 if (tid < D) p.mean[(0 * p.n_chains + chain) * D + tid] = v0[tid];
                 acc_store<NT>(a, p.cov + (0 * p.n_chains + chain) * MM, D, w, lane);
             }
@@ -656,7 +657,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
         acc_store<NT>(lam, M2, LD, w, lane);
         __syncthreads();
         // smoother gain and residual of the previous time index (t − 1): G = T' Λp,  C = V_f − G T
-        {
+        if (!p.filter) {
             double* rec = p.filt + (chain * p.T + (t - 1)) * C::REC;
             acc_zero<NT>(a);
             mm_acc<NT, true, false>(a, M1, LD, M2, LD, w, lane);
@@ -687,13 +688,17 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
         __syncthreads();
         if (!(p.ablate & 4)) matvec_lds(m, M0, LD, D, D, xf, nullptr, 0.0, tid);
         __syncthreads();
-        if (tid < D) p.filt[(chain * p.T + t) * C::REC + tid] = m[tid];
+        if (p.filter) {  // q(x_t | y_1..t) is the marginal of the one-step graph
+            if (tid < D) p.mean[(t * p.n_chains + chain) * D + tid] = m[tid];
+            acc_store<NT>(lam, p.cov + (t * p.n_chains + chain) * MM, D, w, lane);
+        } else if (tid < D)
+            p.filt[(chain * p.T + t) * C::REC + tid] = m[tid];
         if (FE && !(p.ablate & 16)) {
             double dots[3];
             block_dot3(qy, yv, dy, xf, m, D, xp, mp, D, red, tid, 64 * NT, dots);
             acc_quad += cst[c.oC0] + dots[0] - dots[1] + dots[2];
         }
-        if (i == len - 1) acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);
+        if (i == len - 1 && !p.filter) acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);
     }
     if (FE && tid == 0) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc_quad + lp.value());
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);

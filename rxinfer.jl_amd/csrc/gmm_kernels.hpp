@@ -238,7 +238,7 @@ __global__ void __launch_bounds__(64) k_gmm_update(GmmParams p) {
             for (int j = 0; j < K; ++j) F += fsh[j];
             if (K > 1) F += -lgamma(a0sum) - (-lgamma(asum) + (asum - K) * digamma_dev(asum));
             p.fe[p.iteration] = F;
-            if (!(F - F == 0.0)) atomicOr(p.status, ST_NONFINITE);
+            if (!is_finite(F)) atomicOr(p.status, ST_NONFINITE);
         }
     }
     if (bad) atomicOr(p.status, ST_NOT_POSDEF);

@@ -73,7 +73,7 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
             const double mean = half_sum(pt * cv) / norm;
             const double dv = pt - mean;
             const double var = half_sum(cv * dv * dv) / norm;
-            bad = bad || !(det > 0.0) || !(var > 0.0) || !(mean - mean == 0.0);
+            bad = bad || !(det > 0.0) || !(var > 0.0) || !is_finite(mean);
             qzm = mean; qzv = var; qxm = m1; qxv = v11;
             if (FE) {
                 const double Bn = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
                 const double em = half_sum(pe * ecv) / en;
                 const double ed = pe - em;
                 const double ev = half_sum(ecv * ed * ed) / en;
-                bad = bad || !(ev > 0.0) || !(em - em == 0.0);
+                bad = bad || !(ev > 0.0) || !is_finite(em);
                 const double wb = 1.0 / zvar, w00 = 1.0 / ev + wb, w11 = 1.0 / zv + wb;
                 const double dW = w00 * w11 - wb * wb;
                 const double idw = 1.0 / dW;
@@ -129,7 +129,7 @@ __global__ void __launch_bounds__(256) k_hgf_fe(HgfParams p, double* fe_total) {
     }
     if (threadIdx.x == 0) {
         fe_total[n] = sh[0];
-        if (!(sh[0] - sh[0] == 0.0)) atomicOr(p.status, ST_NONFINITE);
+        if (!is_finite(sh[0])) atomicOr(p.status, ST_NONFINITE);
     }
 }
 

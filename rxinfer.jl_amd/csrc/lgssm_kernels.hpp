@@ -37,6 +37,8 @@ namespace rxhip {
 // device status bits (OR-ed into Params::status)
 constexpr int ST_NOT_POSDEF = 1;
 constexpr int ST_NONFINITE = 2;
+// finiteness from the bit pattern (x − x == 0 is not safe under -ffp-contract=fast when x is a product)
+__device__ __forceinline__ bool is_finite(double x) { return (__double2hiint(x) & 0x7ff00000) != 0x7ff00000; }
 
 template <int D>
 struct Dim {
@@ -132,6 +134,8 @@ struct Params {
     double* fe_chain;       // [chain]
     double* fe_total;       // [iterations]
     int iteration;
+    int filter;        // 1: filtering run — forward pass only, q(x_t | y_1..t) written as the marginals
+    double fe_scale;   // 1 (smoothing: Bethe free energy of the chain) or 1/T (filtering: mean over observations)
     int* status;
 };
 
@@ -622,7 +626,7 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
         if (UNI) store_filt_sh<D>(p, 0, chain, m, V);
         else store_filt<D>(p.filt, 0, p.n_chains, chain, m, V);
         if (FE) p.fe_part[chain] = -0.5 * (quad + log(detprod));
-        if (p.T == 1) {  // single observation: the filtered belief is the posterior
+        if (p.T == 1 || p.filter) {  // single observation: the filtered belief is the posterior
             double* om = p.mean + chain * D;
             double* oc = p.cov + chain * D * D;
 #pragma unroll
@@ -782,7 +786,7 @@ __global__ void __launch_bounds__(64) k_boundary_scan_tab(Params p, const CstArg
         if (live) {
             store_filt_sh<D>(p, 0, chain, m, V);
             if (FE) p.fe_part[chain] = -0.5 * (quad + log(detprod));
-            if (p.T == 1) {
+            if (p.T == 1 || p.filter) {
                 double* om = p.mean + chain * D;
                 double* oc = p.cov + chain * D * D;
 #pragma unroll
@@ -878,9 +882,23 @@ __global__ void __launch_bounds__(64) k_boundary_scan_tab(Params p, const CstArg
 //   MvN_y(:μ), `*`_B(:in) observation message (G y, B'Q⁻¹B)     constants LOBS, G
 //   product at x[t]       information-form sum, then mean_cov   obs_update
 //   Bethe FE terms        telescoped to log p(y_t | y_<t)       obs_update<FE>
-template <int D, int DY, bool UNI, bool FE>
+// FILT: filtering run (the streaming driver of src/inference/streaming.jl:349-407 with `@autoupdates` posterior ->
+// prior feedback, notebook model `linear_gaussian_ssm_filtering`): the filtered belief IS the marginal of x_t and is
+// written to the output arrays instead of the forward-message store.
+template <int D>
+__device__ __forceinline__ void write_marginal(const Params& p, long long t, long long chain, const double (&m)[D],
+                                               const Sym<D>& V);
+template <int D>
+struct OutTile;
+template <int D>
+__device__ __forceinline__ void write_marginal_wave(const Params& p, double2* tile, int lane, long long t,
+                                                    long long chain0, const double (&m)[D], const Sym<D>& V);
+template <int D, int DY, bool UNI, bool FE, bool FILT = false>
 __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
     using CL = CstLayout<D, DY>;
+    constexpr bool CAN_TILE = FILT && (D % 2 == 0);
+    __shared__ double2 tile[CAN_TILE ? 64 * (((D + D * D) / 2) | 1) : 1];
+    const bool tiled = CAN_TILE && (p.n_chains % 64 == 0);
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = p.n_chains * (long long)p.S;
     const bool live = g < total;
@@ -919,8 +937,16 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
             acc += quad;
             lp.mul(detprod);
         }
-        if (UNI) store_filt_sh<D>(p, t0 + i, chain, m, V);
-        else store_filt<D>(p.filt, t0 + i, p.n_chains, chain, m, V);
+        if constexpr (FILT) {
+            if constexpr (CAN_TILE) {
+                if (tiled) write_marginal_wave<D>(p, tile, (int)threadIdx.x, t0 + i, chain - threadIdx.x, m, V);
+                else if (live) write_marginal<D>(p, t0 + i, chain, m, V);
+            } else if (live)
+                write_marginal<D>(p, t0 + i, chain, m, V);
+        } else {
+            if (UNI) store_filt_sh<D>(p, t0 + i, chain, m, V);
+            else store_filt<D>(p.filt, t0 + i, p.n_chains, chain, m, V);
+        }
     }
     if (FE && live) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc + lp.value());
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
@@ -1143,11 +1169,11 @@ __global__ void __launch_bounds__(256) k_fe_chain(Params p, double* block_part) 
     sh[q][lane] = s;
     __syncthreads();
     if (q == 0) {
-        double f = -(((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]);
+        double f = -(((sh[0][lane] + sh[1][lane]) + sh[2][lane]) + sh[3][lane]) * p.fe_scale;
         bool bad = false;
         if (ch < p.n_chains) {
             p.fe_chain[ch] = f;
-            bad = !(f - f == 0.0);
+            bad = !is_finite(f);
         } else
             f = 0.0;
         if (bad) atomicOr(p.status, ST_NONFINITE);

@@ -37,7 +37,7 @@ struct LgssmVtbl {
     void (*boundary_scan_tab)(const Params&, const double*, bool, hipStream_t);
     void (*seg_aggregate)(const Params&, const double*, bool, hipStream_t);
     void (*boundary_scan)(const Params&, const double*, bool, bool, hipStream_t);
-    void (*forward)(const Params&, const double*, bool, bool, hipStream_t);
+    void (*forward)(const Params&, const double*, bool, bool, hipStream_t);  // p.filter selects the filtering variant
     void (*backward)(const Params&, const double*, bool, hipStream_t);
 };
 
@@ -60,7 +60,7 @@ struct Launch {
             hipLaunchKernelGGL((k_seg_aggregate<D, DY, false>), dim3(nblk(total, 64)), dim3(64), 0, s, p, CstArg<1>{});
     }
     static void boundary_scan(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
-        dim3 grid(nblk(p.n_chains, 64), 2);
+        dim3 grid(nblk(p.n_chains, 64), p.filter ? 1 : 2);  // a filtering run needs the prefix role only
         if (uni) {
             if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));
             else hipLaunchKernelGGL((k_boundary_scan<D, DY, true, false>), grid, dim3(64), 0, s, p, carg(hc));
@@ -70,20 +70,25 @@ struct Launch {
         }
     }
     static void boundary_scan_tab(const Params& p, const double* hc, bool fe, hipStream_t s) {
-        dim3 grid(nblk(p.n_chains, 64), 2);
+        dim3 grid(nblk(p.n_chains, 64), p.filter ? 1 : 2);
         if (fe) hipLaunchKernelGGL((k_boundary_scan_tab<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
         else hipLaunchKernelGGL((k_boundary_scan_tab<D, DY, false>), grid, dim3(64), 0, s, p, carg(hc));
     }
-    static void forward(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
+    template <bool FILT>
+    static void forward_t(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
         const long long total = p.n_chains * (long long)p.S;
         dim3 grid(nblk(total, 64));
         if (uni) {
-            if (fe) hipLaunchKernelGGL((k_forward<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));
-            else hipLaunchKernelGGL((k_forward<D, DY, true, false>), grid, dim3(64), 0, s, p, carg(hc));
+            if (fe) hipLaunchKernelGGL((k_forward<D, DY, true, true, FILT>), grid, dim3(64), 0, s, p, carg(hc));
+            else hipLaunchKernelGGL((k_forward<D, DY, true, false, FILT>), grid, dim3(64), 0, s, p, carg(hc));
         } else {
-            if (fe) hipLaunchKernelGGL((k_forward<D, DY, false, true>), grid, dim3(64), 0, s, p, CstArg<1>{});
-            else hipLaunchKernelGGL((k_forward<D, DY, false, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
+            if (fe) hipLaunchKernelGGL((k_forward<D, DY, false, true, FILT>), grid, dim3(64), 0, s, p, CstArg<1>{});
+            else hipLaunchKernelGGL((k_forward<D, DY, false, false, FILT>), grid, dim3(64), 0, s, p, CstArg<1>{});
         }
+    }
+    static void forward(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
+        if (p.filter) forward_t<true>(p, hc, uni, fe, s);
+        else forward_t<false>(p, hc, uni, fe, s);
     }
     static void backward(const Params& p, const double* hc, bool uni, hipStream_t s) {
         const long long total = p.n_chains * (long long)p.S;
@@ -187,7 +192,7 @@ struct rxhip_engine {
     // results bookkeeping
     int last_iterations = 0;
     bool last_want_fe = false;
-    bool ran = false;
+    bool ran = false, last_filter = false;
     uint64_t rule_calls = 0, products = 0, marginals = 0;
     // profiling
     bool profiling = false;
@@ -493,7 +498,7 @@ struct DenseLaunch {
         hipLaunchKernelGGL((kd_seg_aggregate<NT>), dim3(p.S, (unsigned)p.n_chains), dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
     }
     static void boundary_scan(const DenseParams& p, bool fe, hipStream_t s) {
-        dim3 g(2, (unsigned)p.n_chains);
+        dim3 g(p.filter ? 1 : 2, (unsigned)p.n_chains);
         if (fe) hipLaunchKernelGGL((kd_boundary_scan<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
         else hipLaunchKernelGGL((kd_boundary_scan<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
     }
@@ -1281,7 +1286,19 @@ static rxhip_status prof_end(rxhip_engine* e) {
     return RXHIP_OK;
 }
 
-rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
+static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_fe, bool filter);
+rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) { return run_impl(e, iterations, want_fe, false); }
+rxhip_status rxhip_run_filter_async(rxhip_engine* e, int32_t want_fe) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "run_filter: not a state-space engine (the HGF engine is a filter already)");
+    return run_impl(e, 1, want_fe, true);
+}
+rxhip_status rxhip_run_filter(rxhip_engine* e, int32_t want_fe) {
+    rxhip_status st = rxhip_run_filter_async(e, want_fe);
+    if (st) return st;
+    return rxhip_sync(e);
+}
+static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_fe, bool filter) {
     if (!e) return RXHIP_ERR_BADARG;
     if (e->kind == 2) return hgf_run_async(e, iterations, want_fe);
     if (e->kind == 1) {
@@ -1326,6 +1343,8 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.fe_chain = e->d_fe_chain;
     p.fe_total = e->d_fe_total;
     p.status = e->d_status;
+    p.filter = filter ? 1 : 0;
+    p.fe_scale = filter ? 1.0 / (double)e->T : 1.0;
     const bool fe = want_fe != 0;
     rxhip_status st;
     DenseParams dp;
@@ -1335,6 +1354,7 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
         dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;
         { const char* ab = getenv("RXHIP_ABLATE"); dp.ablate = ab ? atoi(ab) : 0; }
+        dp.filter = p.filter;
     }
     for (int it = 0; it < iterations; ++it) {
         p.iteration = it;
@@ -1351,9 +1371,11 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
                 if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
                 DENSE_DISPATCH(e->nt, forward(dp, fe, e->stream));
                 if ((st = prof_end(e))) return st;
-                if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
-                DENSE_DISPATCH(e->nt, backward(dp, e->stream));
-                if ((st = prof_end(e))) return st;
+                if (!filter) {
+                    if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
+                    DENSE_DISPATCH(e->nt, backward(dp, e->stream));
+                    if ((st = prof_end(e))) return st;
+                }
             }
         } else if (e->S > 0) {
             if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
@@ -1370,9 +1392,11 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
             if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
             e->vt->forward(p, e->h_cst0.data(), e->uniform, fe, e->stream);
             if ((st = prof_end(e))) return st;
-            if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
-            e->vt->backward(p, e->h_cst0.data(), e->uniform, e->stream);
-            if ((st = prof_end(e))) return st;
+            if (!filter) {
+                if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
+                e->vt->backward(p, e->h_cst0.data(), e->uniform, e->stream);
+                if ((st = prof_end(e))) return st;
+            }
         }
         if (fe) {
             if ((st = prof_begin(e, RXHIP_K_FE_REDUCE))) return st;
@@ -1388,6 +1412,15 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
     e->ran = true;
     // reference-equivalent operation counts (6 rule calls, 4 products per step)
     const uint64_t C = (uint64_t)e->n_chains, T = (uint64_t)e->T, I = (uint64_t)iterations;
+    e->last_filter = filter;
+    if (filter) {
+        // one-step graph per observation: prior MvN(:out), `*`_A(:out), MvN_x(:out), MvN_y(:μ), `*`_B(:in) -> 5 rule
+        // calls, 1 product for q(x_t) (without the transition at t = 1 when the prior sits on x[1]: 3 rule calls)
+        e->rule_calls = C * (e->ptt ? 5 * T : 5 * T - 2);
+        e->products = C * T;
+        e->marginals = C * T;
+        return RXHIP_OK;
+    }
     e->rule_calls = I * C * (e->ptt ? 6 * T + 1 : 6 * T - 3);
     e->products = I * C * (e->ptt ? 4 * T - 2 : (T == 1 ? 1 : 4 * T - 4));
     e->marginals = I * C * (e->ptt ? T + 1 : T);
@@ -1413,7 +1446,7 @@ rxhip_status rxhip_sync(rxhip_engine* e) {
         HIPCHK(e, hipMemset(e->d_status, 0, sizeof(int)));
         if (st & ST_NOT_POSDEF)
             return fail(e, RXHIP_ERR_NOT_POSDEF, "a covariance / precision block lost positive definiteness on device");
-        return fail(e, RXHIP_ERR_NONFINITE_FE, "free energy is NaN or Inf");
+        return fail(e, RXHIP_ERR_NONFINITE_FE, "free energy is NaN or Inf (device flags 0x%x)", st);
     }
     return RXHIP_OK;
 }

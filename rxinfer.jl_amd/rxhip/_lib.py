@@ -71,6 +71,8 @@ SYMBOLS = [
     ("rxhip_set_data_device", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int32]),
     ("rxhip_run", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.c_int32]),
     ("rxhip_run_async", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.c_int32]),
+    ("rxhip_run_filter", ctypes.c_int32, [_H, ctypes.c_int32]),
+    ("rxhip_run_filter_async", ctypes.c_int32, [_H, ctypes.c_int32]),
     ("rxhip_sync", ctypes.c_int32, [_H]),
     ("rxhip_get_marginals", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_int32]),
     ("rxhip_get_marginals_device", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p),

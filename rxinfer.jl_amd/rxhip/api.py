@@ -105,6 +105,9 @@ class InferenceResult:
     free_energy: Optional[np.ndarray]
     model: Any
     error: Optional[BaseException] = None
+    # streaming runs (src/inference/streaming.jl:18-30): history of the `historyvars`, free_energy_history
+    history: Optional[dict] = None
+    free_energy_history: Optional[np.ndarray] = None
 
 
 _OPTION_KEYS = {"limit_stack_depth", "warn", "device", "segments", "backend", "materialize_z"}
@@ -187,9 +190,48 @@ def _infer_hgf(model, data, iterations, free_energy, options, initialization, ca
             eng.close()
 
 
+def _infer_lgssm_filtering(model, data, free_energy, options, initialization, catch_exception):
+    """Streaming inference with posterior -> prior feedback (`autoupdates`), the notebook's
+    `rxinfer_inference_filtering` (benchmarks notebook cell 7): history["x"] = q(x_t) after every observation
+    (`historyvars = (x_t = KeepLast(),)`, `keephistory = T`); free_energy_history = mean over observations of the
+    per-observation free energy, one value (iterations = 1) per chain.  `initialization = {"x": MvNormalMeanCovariance}`
+    overrides the model's prior as the initial q(x_t)."""
+    options = _check_options(options)
+    y = np.asarray(data["y"], dtype=np.float64)
+    single = y.ndim == 2
+    if single:
+        y = y[None]
+    C, T, dy = y.shape
+    m0, V0 = model.prior_mean, model.prior_cov
+    if initialization and "x" in initialization:
+        m0, V0 = initialization["x"].mean, initialization["x"].cov
+    eng = None
+    try:
+        eng = LGSSMEngine(model.A, model.B, model.P, model.Q, m0, V0, T=T, n_chains=C,
+                          prior_through_transition=model.prior_through_transition,
+                          segments=int(options.get("segments", 0)), device=int(options.get("device", -1)))
+        eng.set_data(y, layout="chain_time")
+        eng.run_filter(free_energy=free_energy)
+        mean, cov = eng.marginals(layout="chain_time")
+        fe = eng.free_energy_per_chain()[:, None] if free_energy else None
+        if single:
+            mean, cov = mean[0], cov[0]
+            fe = fe[0] if fe is not None else None
+        return InferenceResult({}, None, None, model, None, history={"x": MvNormalMeanCovariance(mean, cov)},
+                               free_energy_history=fe)
+    except Exception as err:
+        if not catch_exception:
+            raise
+        return InferenceResult({}, None, None, model, err)
+    finally:
+        if eng is not None:
+            eng.close()
+
+
 def infer(*, model, data, iterations=None, free_energy=False, options=None, returnvars=None,
-          catch_exception=False, initialization=None):
-    """Static (batch) inference on the device engine.
+          catch_exception=False, initialization=None, autoupdates=None, keephistory=None, historyvars=None):
+    """Static (batch) inference on the device engine; with `autoupdates` (any truthy value: the state-space spec has
+    exactly one feedback, `mean_cov(q(x_t))` -> prior of the next step) the streaming / filtering twin.
 
     data = {"y": array}: [T][dy] for one chain (as `data = (y = observations,)`), or
     [chain][T][dy] for a batch of independent chains sharing the model.
@@ -200,6 +242,10 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
         return _infer_hgf(model, data, iterations, free_energy, options, initialization, catch_exception)
     if not isinstance(model, LinearGaussianSSM):
         raise TypeError("infer: no device schedule for this model type")
+    if autoupdates:
+        if iterations not in (None, 1):
+            raise ValueError("filtering: the one-step graph is a tree, iterations must be 1")
+        return _infer_lgssm_filtering(model, data, free_energy, options, initialization, catch_exception)
     options = dict(options or {})
     unknown = set(options) - _OPTION_KEYS
     if unknown:  # closed key set, as reactivemp_inference.jl:129-143

@@ -108,6 +108,16 @@ class LGSSMEngine:
         self._chk(_lib.lib().rxhip_run_async(self._h, int(iterations), int(bool(free_energy))))
         self._iters = int(iterations)
 
+    def run_filter(self, free_energy=True):
+        """Streaming / filtering run (rxhip_run_filter): afterwards `marginals()` holds q(x_t | y_1..t) and
+        `free_energy()` ONE value — Σ_chains of the mean-over-observations free energy."""
+        self._chk(_lib.lib().rxhip_run_filter(self._h, int(bool(free_energy))))
+        self._iters = 1
+
+    def run_filter_async(self, free_energy=True):
+        self._chk(_lib.lib().rxhip_run_filter_async(self._h, int(bool(free_energy))))
+        self._iters = 1
+
     def sync(self):
         self._chk(_lib.lib().rxhip_sync(self._h))
 

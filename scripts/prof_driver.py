@@ -21,6 +21,7 @@ ap.add_argument("--T", type=int, default=100000)
 ap.add_argument("--chains", type=int, default=1024)
 ap.add_argument("--segments", type=int, default=0)
 ap.add_argument("--config", default="c2")
+ap.add_argument("--filter", action="store_true", help="time the streaming / filtering driver (rxhip_run_filter) instead of the smoother")
 a = ap.parse_args()
 if a.config == "c4":
     # BASELINE config 4: 4096 independent HGF series, T = 2000, 10 VMP iterations / observation, GH-31
@@ -75,12 +76,21 @@ y = rng.standard_normal((a.T, a.chains, mdl["B"].shape[0])) * 3.0
 eng = rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=a.T, n_chains=a.chains,
                         segments=a.segments)
 eng.set_data(y)
-eng.run(a.warmup, True)
-eng.set_profiling(True)
-t0 = time.perf_counter()
-eng.run(a.steps, True)
+if a.filter:
+    for _ in range(a.warmup):
+        eng.run_filter(True)
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        eng.run_filter_async(True)
+    eng.sync()
+else:
+    eng.run(a.warmup, True)
+    eng.set_profiling(True)
+    t0 = time.perf_counter()
+    eng.run(a.steps, True)
 dt = time.perf_counter() - t0
-print({"ms_per_step": dt / a.steps * 1e3, "kernels": {k: round(v["ms_avg"], 4) for k, v in eng.kernel_times().items()},
+print({"mode": "filter" if a.filter else "smooth", "ms_per_step": dt / a.steps * 1e3, "kernels": {k: round(v["ms_avg"], 4) for k, v in eng.kernel_times().items()},
        "schedule": eng.schedule()})
 import os
 if os.environ.get("RXHIP_ABLATE"): print("fe(debug)", eng.free_energy()[-1], "segments", eng.schedule())
