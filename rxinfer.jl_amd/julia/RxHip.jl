@@ -134,6 +134,93 @@ function free_energy(e::Engine)
     return fe
 end
 
+"""Streaming twin: `infer(model = linear_gaussian_ssm_filtering(...), data = (y_t = observations,), autoupdates = ...,
+historyvars = (x_t = KeepLast(),), keephistory = n)` of the benchmark notebook (cell 7; driver
+src/inference/streaming.jl:349-407).  Afterwards `marginals(e)` is `result.history[:x_t]` and `free_energy(e)[1]` the
+mean-over-observations free energy (`free_energy_history`)."""
+function run_filter!(e::Engine; free_energy::Bool = false)
+    check(e, ccall((:rxhip_run_filter, librxhip), Int32, (Ptr{Cvoid}, Int32), e.handle, free_energy ? 1 : 0))
+    e.iterations = 1
+end
+
+# ---- mean-field families (same handle type; the generic entry points run!/free_energy/counters apply) -----
+
+# mirrors rxhip_gmm_desc
+struct GmmDesc
+    N::Int64
+    K::Int32
+    mu0::Ptr{Float64}; v0::Ptr{Float64}; a0::Ptr{Float64}; b0::Ptr{Float64}; alpha0::Ptr{Float64}
+    init_m_mean::Ptr{Float64}; init_m_var::Ptr{Float64}; init_p_shape::Ptr{Float64}; init_p_rate::Ptr{Float64}
+    init_s_alpha::Ptr{Float64}
+    materialize_responsibilities::Int32
+    device::Int32
+    stream::Ptr{Cvoid}
+end
+
+"""
+    MixtureEngine(y; mu0, v0, a0, b0, alpha0, q_m_mean, q_m_var, q_p_shape, q_p_rate, q_s_alpha)
+
+`univariate_gaussian_mixture_model` (test/models/mixtures/gmm_univariate_tests.jl:7-26, K components) with the
+`@initialization` marginals; K = 1 is `iid_gaussians_params` (test/models/models_tests.jl:114-128)."""
+function MixtureEngine(y::Vector{Float64}; mu0, v0, a0, b0, alpha0, q_m_mean, q_m_var, q_p_shape, q_p_rate, q_s_alpha,
+                       materialize_z::Bool = false, device::Integer = -1)
+    K = length(mu0)
+    vs = map(x -> Vector{Float64}(x), (mu0, v0, a0, b0, alpha0, q_m_mean, q_m_var, q_p_shape, q_p_rate, q_s_alpha))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    st = GC.@preserve vs begin
+        desc = GmmDesc(length(y), K, map(pointer, vs)..., materialize_z ? 1 : 0, device, C_NULL)
+        ccall((:rxhip_gmm_create, librxhip), Int32, (Ref{GmmDesc}, Ref{Ptr{Cvoid}}), desc, h)
+    end
+    e = Engine(h[], 1, 1, length(y), 1, 0)
+    st == RXHIP_OK || throw(RxHipError(st, unsafe_string(ccall((:rxhip_status_string, librxhip), Cstring, (Int32,), st))))
+    finalizer(destroy!, e)
+    GC.@preserve y check(e, ccall((:rxhip_set_data, librxhip), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Csize_t, Int32),
+                                  e.handle, RXHIP_VAR_Y, y, length(y), RXHIP_LAYOUT_TIME_CHAIN))
+    return e
+end
+
+"""posteriors of m, p, s after every iteration (`returnvars = KeepEach()`): hist[k, j, it], j = (mean m, var m, shape p, rate p, α s)."""
+function mixture_history(e::Engine, K::Integer)
+    hist = Array{Float64}(undef, K, 5, e.iterations)      # column-major view of [iterations][5][K]
+    GC.@preserve hist check(e, ccall((:rxhip_gmm_get_history, librxhip), Int32, (Ptr{Cvoid}, Ptr{Float64}), e.handle, hist))
+    return hist
+end
+
+# mirrors rxhip_hgf_desc
+struct HgfDesc
+    T::Int64
+    n_series::Int64
+    kappa::Float64; omega::Float64; z_variance::Float64; y_variance::Float64
+    z0_mean::Float64; z0_var::Float64; x0_mean::Float64; x0_var::Float64
+    n_gh::Int32
+    device::Int32
+    stream::Ptr{Cvoid}
+end
+
+"""`hgf_online_inference` of test/models/statespace/hgf_tests.jl:43-70 for `size(y, 2)` independent series (y: T × series)."""
+function HgfEngine(y::Matrix{Float64}; kappa, omega, z_variance, y_variance, q_zt = (0.0, 5.0), q_xt = (0.0, 5.0),
+                   n_gh::Integer = 31, device::Integer = -1)
+    T, S = size(y)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    desc = HgfDesc(T, S, kappa, omega, z_variance, y_variance, q_zt[1], q_zt[2], q_xt[1], q_xt[2], n_gh, device, C_NULL)
+    st = ccall((:rxhip_hgf_create, librxhip), Int32, (Ref{HgfDesc}, Ref{Ptr{Cvoid}}), desc, h)
+    e = Engine(h[], 1, 1, T, S, 0)
+    st == RXHIP_OK || throw(RxHipError(st, unsafe_string(ccall((:rxhip_status_string, librxhip), Cstring, (Int32,), st))))
+    finalizer(destroy!, e)
+    # Julia's T × series matrix is series-major in memory = [chain][time]
+    GC.@preserve y check(e, ccall((:rxhip_set_data, librxhip), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Csize_t, Int32),
+                                  e.handle, RXHIP_VAR_Y, y, length(y), RXHIP_LAYOUT_CHAIN_TIME))
+    return e
+end
+
+"""result.history[:zt], result.history[:xt] as (mean, var) matrices T × series."""
+function hgf_history(e::Engine)
+    zm, zv, xm, xv = (Matrix{Float64}(undef, e.T, e.n_chains) for _ in 1:4)
+    GC.@preserve zm zv xm xv check(e, ccall((:rxhip_hgf_get_history, librxhip), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Int32), e.handle, zm, zv, xm, xv, RXHIP_LAYOUT_CHAIN_TIME))
+    return (zt = (zm, zv), xt = (xm, xv))
+end
+
 function counters(e::Engine)
     r, p, m = Ref{UInt64}(0), Ref{UInt64}(0), Ref{UInt64}(0)
     check(e, ccall((:rxhip_counters, librxhip), Int32, (Ptr{Cvoid}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}), e.handle, r, p, m))
