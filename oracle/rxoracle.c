@@ -755,127 +755,136 @@ static double digamma_(double x) {
            f * (1.0 / 12 - f * (1.0 / 120 - f * (1.0 / 252 - f * (1.0 / 240 - f * (1.0 / 132 - f * (691.0 / 32760 - f / 12))))));
 }
 
+/* split-phase form (what several GPUs do: every rank accumulates its shard, the 3K+1 statistics are summed over
+ * ranks, every rank applies the same update).  state = (mean m, var m, shape p, rate p, alpha s), 5K doubles. */
+int rxo_gmm_accumulate(long long N, int K, const double* y, const double* state, double* stats, double* resp,
+                       rxo_counters* counters) {
+    if (N < 0 || K <= 0 || K > 64) return RXO_ERR_BADARG;
+    const double *mm = state, *mv = state + K, *pa = state + 2 * K, *pb = state + 3 * K, *al = state + 4 * K;
+    double Ep[64], Elp[64], Els[64], lg[64], pi[64];
+    double *S0 = stats, *S1 = stats + K, *S2 = stats + 2 * K;
+    uint64_t rules = 0, prods = 0, margs = 0;
+    double asum = 0.0, Hz = 0.0;
+    for (int k = 0; k < K; ++k) asum += al[k];
+    for (int k = 0; k < K; ++k) {
+        Ep[k] = pa[k] / pb[k];                     /* E[p] of GammaShapeRate */
+        Elp[k] = digamma_(pa[k]) - log(pb[k]);     /* E[log p] */
+        Els[k] = digamma_(al[k]) - digamma_(asum); /* E[log s_k] of Dirichlet */
+        S0[k] = S1[k] = S2[k] = 0.0;
+    }
+    /* q(z_i) from the marginals of the previous iteration; responsibility-weighted statistics */
+    for (long long i = 0; i < N; ++i) {
+        /* @rule NormalMixture(:switch): ∝ exp(−U_k), U_k = NormalMeanPrecision average energy;
+           @rule Categorical(:out)(q_p::Dirichlet): ∝ exp(E log s_k); q(z_i) = normalised product */
+        double mx = -INFINITY;
+        for (int k = 0; k < K; ++k) {
+            double d = y[i] - mm[k];
+            double U = 0.5 * (LOG2PI - Elp[k] + Ep[k] * (mv[k] + d * d));
+            lg[k] = Els[k] - U;
+            if (lg[k] > mx) mx = lg[k];
+        }
+        double Z = 0.0;
+        for (int k = 0; k < K; ++k) {
+            pi[k] = exp(lg[k] - mx);
+            Z += pi[k];
+        }
+        rules += 2; prods += 1; margs += 1;
+        for (int k = 0; k < K; ++k) {
+            pi[k] /= Z;
+            if (pi[k] > 0.0) Hz -= pi[k] * log(pi[k]);
+            if (resp) resp[i * K + k] = pi[k];
+            /* the messages toward m[k] (N(y_i, precision π_ik E[p_k])), s (Dirichlet(1 + π)) and p[k] are functions of
+               these sums: Σπ, Σπy, Σπy² */
+            S0[k] += pi[k];
+            S1[k] += pi[k] * y[i];
+            S2[k] += pi[k] * y[i] * y[i];
+            rules += 3; prods += 3;
+        }
+    }
+    stats[3 * K] = Hz;
+    if (counters) { counters->rule_calls += rules; counters->products += prods; counters->marginals += margs; }
+    return RXO_OK;
+}
+
+int rxo_gmm_update(int K, const double* mu0, const double* v0, const double* a0, const double* b0, const double* alpha0,
+                   const double* stats, double* state, double* fe, rxo_counters* counters) {
+    if (K <= 0 || K > 64) return RXO_ERR_BADARG;
+    double *mm = state, *mv = state + K, *pa = state + 2 * K, *pb = state + 3 * K, *al = state + 4 * K;
+    const double *S0 = stats, *S1 = stats + K, *S2 = stats + 2 * K;
+    const double Hz = stats[3 * K];
+    int rc = RXO_OK;
+    for (int k = 0; k < K; ++k) {
+        /* product of the prior message and the N messages NormalMixture(m[k]) in (ξ, Λ) form, E[p] of the previous q(p) */
+        const double Ep = pa[k] / pb[k];
+        const double xi = mu0[k] / v0[k] + Ep * S1[k], lam = 1.0 / v0[k] + Ep * S0[k];
+        mv[k] = 1.0 / lam;
+        mm[k] = xi * mv[k];
+        /* Dirichlet×Dirichlet = α1 + α2 − 1 over the N messages Dirichlet(1 + π) */
+        al[k] = alpha0[k] + S0[k];
+    }
+    /* @rule NormalMixture(p[k]): GammaShapeRate(1 + π/2, π ½[(y−m̄)² + v]) with the NEW q(m[k]);
+       Gamma×Gamma = (a1+a2−1, b1+b2).  Σ_i π_ik[(y_i−m̄)² + v] = S2 − 2m̄S1 + m̄²S0 + vS0 */
+    for (int k = 0; k < K; ++k) {
+        pa[k] = a0[k] + 0.5 * S0[k];
+        pb[k] = b0[k] + 0.5 * (S2[k] - 2.0 * mm[k] * S1[k] + mm[k] * mm[k] * S0[k] + mv[k] * S0[k]);
+        if (counters) counters->marginals += 3;
+        if (!(mv[k] > 0.0) || !(pb[k] > 0.0)) rc = RXO_ERR_NOT_POSDEF;
+    }
+    if (fe) {
+        /* Bethe free energy at the marginals of this iteration:
+           Σ_i U_mix,i + Σ_i U_cat,i − Σ_i H[z_i] + Σ_k (U_m − H[m_k]) + Σ_k (U_p − H[p_k]) + (U_s − H[s]) */
+        double F = -Hz, as2 = 0.0, a0s = 0.0;
+        for (int k = 0; k < K; ++k) { as2 += al[k]; a0s += alpha0[k]; }
+        double lB = -lgamma(as2), lB0 = -lgamma(a0s), Hs_t = 0.0, Us_t = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double Epk = pa[k] / pb[k], Elpk = digamma_(pa[k]) - log(pb[k]), Elsk = digamma_(al[k]) - digamma_(as2);
+            /* NormalMixture average energy Σ_i π_ik U_k(i) through the responsibility-weighted statistics */
+            F += 0.5 * ((LOG2PI - Elpk) * S0[k] + Epk * (mv[k] * S0[k] + S2[k] - 2.0 * mm[k] * S1[k] + mm[k] * mm[k] * S0[k]));
+            F += -S0[k] * Elsk; /* Categorical average energy */
+            /* prior nodes minus entropies */
+            double dm = mm[k] - mu0[k];
+            F += 0.5 * (LOG2PI + log(v0[k]) + (dm * dm + mv[k]) / v0[k]) - 0.5 * (LOG2PI + 1.0 + log(mv[k]));
+            F += (-a0[k] * log(b0[k]) + lgamma(a0[k]) - (a0[k] - 1.0) * Elpk + b0[k] * Epk) -
+                 (pa[k] - log(pb[k]) + lgamma(pa[k]) + (1.0 - pa[k]) * digamma_(pa[k]));
+            lB += lgamma(al[k]);
+            lB0 += lgamma(alpha0[k]);
+            Us_t += (alpha0[k] - 1.0) * Elsk;
+            Hs_t += (al[k] - 1.0) * digamma_(al[k]);
+        }
+        double Us = lB0 - Us_t;
+        double Hs = lB + (as2 - K) * digamma_(as2) - Hs_t;
+        if (K > 1) F += Us - Hs; /* K = 1: no switch variable in the iid model (Dirichlet(1) terms vanish identically) */
+        *fe = F;
+        if (!isfinite(F)) rc = RXO_ERR_NONFINITE_FE;
+    }
+    return rc;
+}
+
 int rxo_gmm_vmp(long long N, int K, const double* y, const double* mu0, const double* v0, const double* a0,
                 const double* b0, const double* alpha0, const double* init_m_mean, const double* init_m_var,
                 const double* init_p_shape, const double* init_p_rate, const double* init_s_alpha, int iterations,
                 double* hist, double* fe, double* resp, rxo_counters* counters) {
-    if (N <= 0 || K <= 0 || iterations <= 0) return RXO_ERR_BADARG;
-    double* w = (double*)malloc(sizeof(double) * (size_t)(16 * K));
-    double *mm = w, *mv = mm + K, *pa = mv + K, *pb = pa + K, *al = pb + K, *nm = al + K, *nv = nm + K, *na = nv + K,
-           *nb = na + K, *nal = nb + K, *lg = nal + K, *pi = lg + K, *Ep = pi + K, *Elp = Ep + K, *Els = Elp + K;
-    uint64_t rules = 0, prods = 0, margs = 0;
+    if (N <= 0 || K <= 0 || K > 64 || iterations <= 0) return RXO_ERR_BADARG;
+    double state[5 * 64], stats[3 * 64 + 1];
+    rxo_counters c = {0, 0, 0};
     for (int k = 0; k < K; ++k) {
-        mm[k] = init_m_mean[k];
-        mv[k] = init_m_var[k];
-        pa[k] = init_p_shape[k];
-        pb[k] = init_p_rate[k];
-        al[k] = init_s_alpha[k];
+        state[k] = init_m_mean[k];
+        state[K + k] = init_m_var[k];
+        state[2 * K + k] = init_p_shape[k];
+        state[3 * K + k] = init_p_rate[k];
+        state[4 * K + k] = init_s_alpha[k];
     }
     int rc = RXO_OK;
     for (int it = 0; it < iterations; ++it) {
-        double asum = 0.0;
-        for (int k = 0; k < K; ++k) asum += al[k];
-        for (int k = 0; k < K; ++k) {
-            Ep[k] = pa[k] / pb[k];                   /* E[p] of GammaShapeRate */
-            Elp[k] = digamma_(pa[k]) - log(pb[k]);   /* E[log p] */
-            Els[k] = digamma_(al[k]) - digamma_(asum); /* E[log s_k] of Dirichlet */
-            /* accumulators of the products of messages toward m[k], p[k], s */
-            nm[k] = mu0[k] / v0[k]; /* ξ */
-            nv[k] = 1.0 / v0[k];    /* Λ */
-            na[k] = a0[k];
-            nb[k] = b0[k];
-            nal[k] = alpha0[k];
-        }
-        double Hz = 0.0;
-        double S0[64], S1[64], S2[64];
-        if (K > 64) { rc = RXO_ERR_BADARG; break; }
-        for (int k = 0; k < K; ++k) S0[k] = S1[k] = S2[k] = 0.0;
-        /* pass 1: q(z_i) from the marginals of the previous iteration; messages toward m[k] and s */
-        for (long long i = 0; i < N; ++i) {
-            /* @rule NormalMixture(:switch): ∝ exp(−U_k), U_k = NormalMeanPrecision average energy;
-               @rule Categorical(:out)(q_p::Dirichlet): ∝ exp(E log s_k); q(z_i) = normalised product */
-            double mx = -INFINITY;
-            for (int k = 0; k < K; ++k) {
-                double d = y[i] - mm[k];
-                double U = 0.5 * (LOG2PI - Elp[k] + Ep[k] * (mv[k] + d * d));
-                lg[k] = Els[k] - U;
-                if (lg[k] > mx) mx = lg[k];
-            }
-            double Z = 0.0;
-            for (int k = 0; k < K; ++k) {
-                pi[k] = exp(lg[k] - mx);
-                Z += pi[k];
-            }
-            rules += 2; prods += 1; margs += 1;
-            for (int k = 0; k < K; ++k) {
-                pi[k] /= Z;
-                if (pi[k] > 0.0) Hz -= pi[k] * log(pi[k]);
-                if (resp && it == iterations - 1) resp[i * K + k] = pi[k];
-                /* @rule NormalMixture(m[k]): N(mean = y_i, precision = π_ik E[p_k]) — product in (ξ, Λ) */
-                nm[k] += pi[k] * Ep[k] * y[i];
-                nv[k] += pi[k] * Ep[k];
-                /* @rule Categorical(:p)(q_out): Dirichlet(1 + π) ; Dirichlet×Dirichlet = α1 + α2 − 1 */
-                nal[k] += pi[k];
-                S0[k] += pi[k];
-                S1[k] += pi[k] * y[i];
-                S2[k] += pi[k] * y[i] * y[i];
-                rules += 3; prods += 3;
-            }
-        }
-        for (int k = 0; k < K; ++k) {
-            mv[k] = 1.0 / nv[k];
-            mm[k] = nm[k] * mv[k];
-            al[k] = nal[k];
-        }
-        /* pass 2: @rule NormalMixture(p[k]): GammaShapeRate(1 + π/2, π ½[(y−m̄)² + v]) with the NEW q(m[k]);
-           Gamma×Gamma = (a1+a2−1, b1+b2).  Σ_i π_ik[(y_i−m̄)² + v] = S2 − 2m̄S1 + m̄²S0 + vS0 */
-        for (int k = 0; k < K; ++k) {
-            na[k] += 0.5 * S0[k];
-            nb[k] += 0.5 * (S2[k] - 2.0 * mm[k] * S1[k] + mm[k] * mm[k] * S0[k] + mv[k] * S0[k]);
-            pa[k] = na[k];
-            pb[k] = nb[k];
-            margs += 3;
-            if (!(mv[k] > 0.0) || !(pb[k] > 0.0)) rc = RXO_ERR_NOT_POSDEF;
-        }
-        if (hist)
-            for (int k = 0; k < K; ++k) {
-                double* h = hist + (size_t)it * 5 * K;
-                h[k] = mm[k]; h[K + k] = mv[k]; h[2 * K + k] = pa[k]; h[3 * K + k] = pb[k]; h[4 * K + k] = al[k];
-            }
-        if (fe) {
-            /* Bethe free energy at the marginals of this iteration:
-               Σ_i U_mix,i + Σ_i U_cat,i − Σ_i H[z_i] + Σ_k (U_m − H[m_k]) + Σ_k (U_p − H[p_k]) + (U_s − H[s]) */
-            double F = -Hz, as2 = 0.0, a0s = 0.0;
-            for (int k = 0; k < K; ++k) { as2 += al[k]; a0s += alpha0[k]; }
-            double lB = -lgamma(as2), lB0 = -lgamma(a0s), Hs_t = 0.0, Us_t = 0.0;
-            for (int k = 0; k < K; ++k) {
-                double Epk = pa[k] / pb[k], Elpk = digamma_(pa[k]) - log(pb[k]), Elsk = digamma_(al[k]) - digamma_(as2);
-                /* NormalMixture average energy Σ_i π_ik U_k(i) through the responsibility-weighted statistics */
-                F += 0.5 * ((LOG2PI - Elpk) * S0[k] + Epk * (mv[k] * S0[k] + S2[k] - 2.0 * mm[k] * S1[k] + mm[k] * mm[k] * S0[k]));
-                F += -S0[k] * Elsk; /* Categorical average energy */
-                /* prior nodes minus entropies */
-                double dm = mm[k] - mu0[k];
-                F += 0.5 * (LOG2PI + log(v0[k]) + (dm * dm + mv[k]) / v0[k]) - 0.5 * (LOG2PI + 1.0 + log(mv[k]));
-                F += (-a0[k] * log(b0[k]) + lgamma(a0[k]) - (a0[k] - 1.0) * Elpk + b0[k] * Epk) -
-                     (pa[k] - log(pb[k]) + lgamma(pa[k]) + (1.0 - pa[k]) * digamma_(pa[k]));
-                lB += lgamma(al[k]);
-                lB0 += lgamma(alpha0[k]);
-                Us_t += (alpha0[k] - 1.0) * Elsk;
-                Hs_t += (al[k] - 1.0) * digamma_(al[k]);
-            }
-            double Us = lB0 - Us_t;
-            double Hs = lB + (as2 - K) * digamma_(as2) - Hs_t;
-            if (K > 1) F += Us - Hs;
-            else F += 0.0; /* K = 1: no switch variable in the iid model (Dirichlet(1) terms vanish identically) */
-            fe[it] = F;
-            if (!isfinite(F)) rc = RXO_ERR_NONFINITE_FE;
-        }
+        int r = rxo_gmm_accumulate(N, K, y, state, stats, (resp && it == iterations - 1) ? resp : NULL, &c);
+        if (!r) r = rxo_gmm_update(K, mu0, v0, a0, b0, alpha0, stats, state, fe ? fe + it : NULL, &c);
+        if (r) rc = r;
+        if (r == RXO_ERR_BADARG) break;
+        if (hist) memcpy(hist + (size_t)it * 5 * K, state, sizeof(double) * 5 * K);
     }
-    if (counters) { counters->rule_calls = rules; counters->products = prods; counters->marginals = margs; }
-    free(w);
+    if (counters) *counters = c;
     return rc;
 }
-
 
 /* ==========================================================================================
  * Hierarchical Gaussian filter (GCV node) — see rxoracle.h for the model, provenance and assumptions.

@@ -123,6 +123,15 @@ int rxo_gmm_vmp(long long N, int K, const double* y, const double* mu0, const do
                 const double* init_p_shape, const double* init_p_rate, const double* init_s_alpha, int iterations,
                 double* hist, double* fe, double* resp, rxo_counters* counters);
 
+/* Split-phase form of one iteration (rxo_gmm_vmp is the loop over these): what several GPUs do — every rank
+ * accumulates its shard of the points, the 3K+1 statistics (Σπ, Σπy, Σπy² per component, Σ_i H[q(z_i)]) are summed
+ * over ranks, every rank applies the same update.  state: 5K doubles (mean m, var m, shape p, rate p, alpha s),
+ * stats: 3K+1 doubles.  resp (nullable): [N][K] q(z) of this call. */
+int rxo_gmm_accumulate(long long N, int K, const double* y, const double* state, double* stats, double* resp,
+                       rxo_counters* counters);
+int rxo_gmm_update(int K, const double* mu0, const double* v0, const double* a0, const double* b0, const double* alpha0,
+                   const double* stats, double* state, double* fe, rxo_counters* counters);
+
 /*
  * Hierarchical Gaussian filter, one series, online (test/models/statespace/hgf_tests.jl:9-70):
  *     zt_min ~ Normal(zm, zv); xt_min ~ Normal(xm, xv); zt ~ Normal(mean = zt_min, var = z_variance);

@@ -47,6 +47,10 @@ def lib():
         _LIB.rxo_hgf_filter.restype = ctypes.c_int
         _LIB.rxo_hgf_filter.argtypes = [ctypes.c_longlong, dp] + [ctypes.c_double] * 8 + [ctypes.c_int, ctypes.c_int] + \
             [dp] * 5 + [ctypes.POINTER(Counters)]
+        _LIB.rxo_gmm_accumulate.restype = ctypes.c_int
+        _LIB.rxo_gmm_accumulate.argtypes = [ctypes.c_longlong, ctypes.c_int, dp, dp, dp, dp, ctypes.POINTER(Counters)]
+        _LIB.rxo_gmm_update.restype = ctypes.c_int
+        _LIB.rxo_gmm_update.argtypes = [ctypes.c_int] + [dp] * 8 + [ctypes.POINTER(Counters)]
         _LIB.rxo_lgssm_filter.restype = ctypes.c_int
         _LIB.rxo_lgssm_filter.argtypes = [ctypes.c_int] * 3 + [dp] * 6 + [ctypes.c_int] + [dp] * 4 + [ctypes.POINTER(Counters)]
         _LIB.rxo_gauss_hermite.restype = ctypes.c_int
@@ -146,6 +150,31 @@ def gauss_hermite(n):
     if rc:
         raise RuntimeError(f"rxo_gauss_hermite failed with status {rc}")
     return x, w
+
+
+def gmm_accumulate(y, state, stats=None):
+    """One shard's pass of one VMP iteration: state [5][K] (mean m, var m, shape p, rate p, alpha s) -> stats [3K+1]."""
+    y = _c(y).ravel()
+    state = _c(state)
+    K = state.size // 5
+    if stats is None:
+        stats = np.empty(3 * K + 1)
+    rc = lib().rxo_gmm_accumulate(y.size, K, _p(y), _p(state), _p(stats), None, None)
+    if rc:
+        raise RuntimeError(f"rxo_gmm_accumulate failed with status {rc}")
+    return stats
+
+
+def gmm_update(mu0, v0, a0, b0, alpha0, stats, state, want_fe=True):
+    """Update from the (global) statistics; `state` [5][K] is modified in place.  Returns the free energy or None."""
+    pri = [_c(a) for a in (mu0, v0, a0, b0, alpha0)]
+    K = pri[0].size
+    fe = np.zeros(1)
+    assert state.flags.c_contiguous and state.dtype == np.float64 and state.size == 5 * K
+    rc = lib().rxo_gmm_update(K, *[_p(a) for a in pri], _p(_c(stats)), _p(state), _p(fe) if want_fe else None, None)
+    if rc:
+        raise RuntimeError(f"rxo_gmm_update failed with status {rc}")
+    return float(fe[0]) if want_fe else None
 
 
 def hgf_filter(y, kappa, omega, z_variance, y_variance, z0=(0.0, 5.0), x0=(0.0, 5.0), vmp_iters=10, n_gh=31, want_fe=True):

@@ -66,3 +66,46 @@ def sharded_infer(run_shard, y_chain_major, dist=None):
     mean, cov, fe = run_shard(yb)
     fe_total = allreduce_free_energy(np.array([np.sum(fe)]), dist)[0]
     return mean, cov, fe, float(fe_total)
+
+
+# ---- mean-field mixture: the path's one real exchange step ------------------------------------------------
+class DeviceMixtureShard:
+    """Adapter of a `GMMEngine` holding this rank's points to the split-phase protocol of `sharded_mixture_vmp`."""
+
+    def __init__(self, engine):
+        self.engine = engine
+
+    def begin(self, iterations):
+        self.engine.begin_run(iterations)
+
+    def accumulate(self):
+        """Streams the shard; returns a tensor ALIASING the 3K'+1 statistics (all-reduced in place)."""
+        import torch
+
+        self.engine.accumulate()
+        # the statistics are produced on the engine's stream; the collective must be ordered after them
+        self.engine.sync()
+        return self.engine.statistics_tensor()
+
+    def update(self, want_fe):
+        import torch
+
+        torch.cuda.current_stream().synchronize()  # the in-place all-reduce (torch's stream) before the update kernel
+        self.engine.update(want_fe)
+
+
+def sharded_mixture_vmp(shard, iterations, want_fe=True, dist=None):
+    """VMP for a mixture whose points are sharded over ranks (C5): per iteration every rank accumulates the
+    responsibility-weighted statistics of its points (3K+1 numbers: Σπ, Σπy, Σπy² per component and Σ H[q(z_i)]),
+    ONE all-reduce(sum) makes them global, and every rank applies the identical update — so all ranks hold the same
+    q(m), q(p), q(s) and the same (global) free energy without any further exchange.
+    Reference semantics: the messages toward m[k], p[k], s are products over ALL points
+    (src/model/plugins/reactivemp_inference.jl:365-374); the sum over shards is that product in the natural
+    parameters.  `shard`: begin(iterations) / accumulate() -> tensor aliasing the statistics / update(want_fe)."""
+    shard.begin(iterations)
+    multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    for _ in range(iterations):
+        stats = shard.accumulate()
+        if multi:
+            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+        shard.update(want_fe)

@@ -258,6 +258,19 @@ class GMMEngine:
         self._chk(_lib.lib().rxhip_gmm_statistics_device(self._h, ctypes.byref(p), ctypes.byref(n)))
         return p.value, n.value
 
+    def statistics_tensor(self):
+        """torch tensor ALIASING the device statistics buffer (3K'+1 doubles) — what the multi-GPU host hands to
+        `torch.distributed.all_reduce` in place (RCCL) between accumulate() and update()."""
+        import torch
+
+        ptr, n = self.statistics_device()
+
+        class _View:  # zero-copy: torch adopts foreign device memory through the array interface
+            __cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 2}
+
+        self._stats_view = _View()  # keep the descriptor object alive as long as the engine
+        return torch.as_tensor(self._stats_view, device=f"cuda:{torch.cuda.current_device()}")
+
     def update(self, free_energy=True):
         self._chk(_lib.lib().rxhip_gmm_update(self._h, int(bool(free_energy))))
 

@@ -81,3 +81,78 @@ def test_two_rank_sharded_free_energy(tmp_path):
     _, _, fe, _ = rxoracle.lgssm_bp_batch(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y)
     assert np.allclose(r0["fe_all"], fe, rtol=0, atol=0)
     assert abs(float(r0["fe_total"]) - fe.sum()) <= 1e-12 * abs(fe.sum())
+
+
+# ---- mixture: sharded points, statistics all-reduced every iteration (C5's exchange step) -----------------
+_GMM = dict(N=1001, mus=[-6.0, 0.0, 7.0], seed=4,
+            priors=([-4.0, 1.0, 5.0], [1e2] * 3, [0.1] * 3, [0.1] * 3, [1.0] * 3),
+            init=([-4.0, 1.0, 5.0], [1.0] * 3, [1.0] * 3, [1.0] * 3, [1.0] * 3), iters=6)
+
+
+def _gmm_data():
+    rng = np.random.default_rng(_GMM["seed"])
+    z = rng.integers(0, 3, size=_GMM["N"])
+    return np.asarray(_GMM["mus"])[z] + rng.standard_normal(_GMM["N"])
+
+
+class _OracleMixtureShard:
+    """CPU stand-in for DeviceMixtureShard (tests only): the oracle's split-phase functions on this rank's points."""
+
+    def __init__(self, rxoracle, y):
+        import torch
+
+        self.o, self.y = rxoracle, y
+        self.state = np.ascontiguousarray(np.array(_GMM["init"], dtype=np.float64))  # [5][K]
+        self.stats = np.zeros(3 * 3 + 1)
+        self.t = torch.from_numpy(self.stats)  # aliases the buffer: all_reduce happens in place
+        self.fe, self.hist = [], []
+
+    def begin(self, iterations):
+        self.fe, self.hist = [], []
+
+    def accumulate(self):
+        self.o.gmm_accumulate(self.y, self.state, self.stats)
+        return self.t
+
+    def update(self, want_fe):
+        self.fe.append(self.o.gmm_update(*_GMM["priors"], self.stats, self.state, want_fe))
+        self.hist.append(self.state.copy())
+
+
+def _gmm_worker(rank, world, port, out_dir):
+    for p in (os.path.join(ROOT, "rxinfer.jl_amd"), os.path.join(ROOT, "oracle")):
+        sys.path.insert(0, p)
+    import torch.distributed as dist
+
+    import rxoracle
+    from rxhip import distributed as rd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    y = _gmm_data()
+    lo, hi = rd.shard_bounds(y.size, rank, world)
+    shard = _OracleMixtureShard(rxoracle, y[lo:hi])
+    rd.sharded_mixture_vmp(shard, _GMM["iters"], True, dist)
+    np.savez(os.path.join(out_dir, f"gmm{rank}.npz"), fe=np.array(shard.fe), hist=np.array(shard.hist), lo_hi=(lo, hi))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_mixture(tmp_path):
+    import torch.multiprocessing as mp
+
+    mp.spawn(_gmm_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "gmm0.npz"), np.load(tmp_path / "gmm1.npz")
+    assert tuple(r0["lo_hi"]) == (0, 501) and tuple(r1["lo_hi"]) == (501, 1001)
+    # every rank holds the same global posteriors and the same global free energy, bit for bit
+    assert np.array_equal(r0["fe"], r1["fe"]) and np.array_equal(r0["hist"], r1["hist"])
+    # and they are the unsharded run's (summation order differs: rounding only)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import rxoracle
+
+    hist, fe, _, _ = rxoracle.gmm_vmp(_gmm_data(), *_GMM["priors"], *_GMM["init"], _GMM["iters"])
+    assert np.max(np.abs(r0["fe"] - fe) / np.abs(fe)) < 1e-12
+    # (the Gamma rate is a difference of sums, S2 − 2 m S1 + m² S0: its rounding is amplified ≈ 10³×)
+    assert np.max(np.abs(r0["hist"].reshape(hist.shape) - hist) / np.abs(hist)) < 1e-9
+    assert np.all(np.diff(fe) < 1e-9)

@@ -107,3 +107,60 @@ def test_infer_mirror_for_vmp_models():
     r2 = rxhip.infer(model=rxhip.hierarchical_gaussian_filter(1.0, 0.0, 0.04, 0.01), data={"y": yh}, iterations=5, free_energy=True)
     o = rxoracle.hgf_filter(yh, 1.0, 0.0, 0.04, 0.01, vmp_iters=5)
     assert np.allclose(r2.posteriors["zt"].mean, o[0], rtol=1e-8, atol=1e-10) and np.allclose(r2.free_energy, o[4], rtol=1e-8)
+
+
+def _mp_worker(rank, world, port, out_dir):
+    """One process per shard on the SAME GPU (the box has one); gloo moves the device statistics — on the 8-GPU
+    node the identical code runs with backend nccl (= RCCL)."""
+    import os
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "rxinfer.jl_amd"))
+    import torch
+    import torch.distributed as dist
+
+    import rxhip as rx
+    from rxhip import distributed as rd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    y = gmm_data(20001, [-5.0, 0.0, 5.0], [1, 1, 1], [0.3, 0.3, 0.4], 9)
+    lo, hi = rd.shard_bounds(y.size, rank, world)
+    priors = ([-4.0, 1.0, 4.0], [1e2] * 3, [0.1] * 3, [0.1] * 3, [1.0] * 3)
+    init = ([-4.0, 1.0, 4.0], [1.0] * 3, [1.0] * 3, [1.0] * 3, [1.0] * 3)
+    with rx.GMMEngine(hi - lo, *priors, *init, device=0) as eng:
+        eng.set_data(y[lo:hi])
+        rd.sharded_mixture_vmp(rd.DeviceMixtureShard(eng), 6, True, dist)
+        eng.sync()
+        np.savez(os.path.join(out_dir, f"gmm{rank}.npz"), hist=eng.history(), fe=eng.free_energy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_sharded_mixture(tmp_path):
+    """C5's exchange step end to end: two processes, each with half of the points on its engine, the 3K'+1 device
+    statistics all-reduced in place every iteration — equals the single-engine run."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_mp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "gmm0.npz"), np.load(tmp_path / "gmm1.npz")
+    assert np.array_equal(r0["hist"], r1["hist"]) and np.array_equal(r0["fe"], r1["fe"])
+    y = gmm_data(20001, [-5.0, 0.0, 5.0], [1, 1, 1], [0.3, 0.3, 0.4], 9)
+    priors = ([-4.0, 1.0, 4.0], [1e2] * 3, [0.1] * 3, [0.1] * 3, [1.0] * 3)
+    init = ([-4.0, 1.0, 4.0], [1.0] * 3, [1.0] * 3, [1.0] * 3, [1.0] * 3)
+    with rxhip.GMMEngine(y.size, *priors, *init) as eng:
+        eng.set_data(y)
+        eng.run(6, True)
+        h, f = eng.history(), eng.free_energy()
+    assert np.max(np.abs(r0["fe"] - f) / np.abs(f)) < 1e-10 and np.max(np.abs(r0["hist"] - h) / np.abs(h)) < 1e-8
+    ohist, ofe, _, _ = rxoracle.gmm_vmp(y, *priors, *init, 6)
+    assert np.max(np.abs(r0["fe"] - ofe) / np.abs(ofe)) < 1e-8
