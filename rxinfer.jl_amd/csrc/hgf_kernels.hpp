@@ -29,15 +29,40 @@ struct HgfParams {
     int* status;
 };
 
-__device__ __forceinline__ double half_sum(double v) {
+// ---- 32-lane sums without the LDS crossbar: four DPP stages inside a 16-lane row, then v_permlane16_swap for the
+// neighbouring row (gfx950).  The cubature sums are the latency chain of an iteration; ds_bpermute shuffles cost
+// ≈100 cycles per stage, DPP moves a few.  Fixed order -> deterministic; every lane of the half-wave gets the sum.
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row_swap16(double v, bool odd_row) {  // the value held 16 lanes away
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // a[0]: rows (r0,r0,r2,r2), a[1]: (r1,r1,r3,r3)
+    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    return __hiloint2double((int)(odd_row ? b[0] : b[1]), (int)(odd_row ? a[0] : a[1]));
+}
+template <int N>
+__device__ __forceinline__ void half_sums(double (&v)[N], bool odd_row) {
 #pragma unroll
-    for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 32);
-    return v;  // identical in all 32 lanes (xor butterfly: fixed order)
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<0xB1>(v[i]);   // quad_perm [1,0,3,2]
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x4E>(v[i]);   // quad_perm [2,3,0,1]
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x141>(v[i]);  // row_half_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x140>(v[i]);  // row_mirror
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] += row_swap16(v[i], odd_row);
 }
 
 template <bool FE>
 __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
     const int j = threadIdx.x & 31;
+    const bool odd_row = (threadIdx.x >> 4) & 1;
     const long long s = (long long)blockIdx.x * 2 + (threadIdx.x >> 5);
     const bool live = s < p.n_series;
     const long long sc_ = live ? s : 0;
@@ -46,61 +71,88 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
     const double kappa = p.kappa, omega = p.omega, zvar = p.z_variance, yvar = p.y_variance;
     const double A = exp(-omega);
     const double pe = 1.4142135623730951 * gx;  // cubature points against N(0, 1)
+    const double hpe2 = 0.5 * pe * pe, iyvar = 1.0 / yvar, wb = 1.0 / zvar, lzvar = log(zvar), lyvar = log(yvar);
     double qzm = p.z0m, qzv = p.z0v, qxm = p.x0m, qxv = p.x0v;
     bool bad = false;
     double yn = p.y[sc_];
+    double fe_acc = 0.0;  // lane n of the half-wave accumulates the free energy of VMP iteration n (n < 32; beyond: global)
     for (long long t = 0; t < p.T; ++t) {
         const double yt = yn;
         if (t + 1 < p.T) yn = p.y[(t + 1) * p.n_series + sc_];
         const double zm = qzm, zv = qzv, xm = qxm, xv = qxv;  // @autoupdates
         const double fzv = zv + zvar, sc = sqrt(2.0 * fzv);
-        const double pt = zm + sc * gx;
+        const double dx = sc * gx, pt = zm + dx;  // cubature points against the forward message N(zm, fzv)
+        const double ixv = rcp_pos(xv), izv = rcp_pos(zv);
+        const double x1 = yt * iyvar, x2 = xm * ixv, zx = zm * izv;
+        // point-wise constants of the two cubatures: exp(−½κ·point) factors out of the iteration loop
+        const double ept = exp(-kappa * pt), epe = exp(-kappa * pe);
+        const double lpt = -0.5 * kappa * pt, lpe = -0.5 * kappa * pe + hpe2;
+        double fe_t_const = 0.0;
+        if (FE) fe_t_const = 0.5 * (kLog2Pi + log(zv)) + 0.5 * (kLog2Pi + log(xv)) + 0.5 * (kLog2Pi + lzvar) + 0.5 * (kLog2Pi + lyvar);
         for (int n = 0; n < p.iters; ++n) {
             const double B = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
             const double g = A * B;
-            const double l11 = 1.0 / yvar + g, l22 = 1.0 / xv + g, l12 = -g;
-            const double det = l11 * l22 - l12 * l12;
-            const double id = 1.0 / det;
-            const double v11 = l22 * id, v22 = l11 * id, v12 = -l12 * id;
-            const double x1 = yt / yvar, x2 = xm / xv;
+            const double l11 = iyvar + g, l22 = ixv + g;
+            const double det = l11 * l22 - g * g;
+            const double id = rcp_pos(det);
+            const double v11 = l22 * id, v22 = l11 * id, v12 = g * id;
             const double m1 = v11 * x1 + v12 * x2, m2 = v12 * x1 + v22 * x2;
             const double psi = (m1 - m2) * (m1 - m2) + v11 + v22 - 2.0 * v12;
             const double b = psi * A;
-            // one cubature point per lane
-            const double gv = exp(-0.5 * (kappa * pt + b * exp(-kappa * pt)));
-            const double cv = gw * gv;
-            const double norm = half_sum(cv);
-            const double mean = half_sum(pt * cv) / norm;
-            const double dv = pt - mean;
-            const double var = half_sum(cv * dv * dv) / norm;
+            // one cubature point per lane: z-message pdf exp(−½(κz + b·exp(−κz))) at the forward-message points and (for
+            // the free energy) times exp(z²/2) at the N(0,1) points; first moments taken about zm / 0
+            // Two reduction rounds, exactly the reference's approximate_meancov: (norm, first moment), then the second
+            // moment about the mean — when a message's mode leaves the cubature range the variance is pure rounding
+            // residue and only the same formula reproduces the reference there.
+            double r[FE ? 4 : 2];
+            const double cv = gw * exp(lpt - 0.5 * b * ept);
+            r[0] = cv; r[1] = cv * dx;
+            double ecv = 0.0;
+            if (FE) {
+                ecv = gw * exp(lpe - 0.5 * b * epe);
+                r[2] = ecv; r[3] = ecv * pe;
+            }
+            half_sums(r, odd_row);
+            const double in0 = rcp_pos(r[0]);
+            const double dmean = r[1] * in0;
+            const double mean = zm + dmean;
+            double em = 0.0;
+            double ie0 = 0.0;
+            if (FE) {
+                ie0 = rcp_pos(r[2]);
+                em = r[3] * ie0;
+            }
+            double q[FE ? 2 : 1];
+            q[0] = cv * (dx - dmean) * (dx - dmean);
+            if (FE) q[1] = ecv * (pe - em) * (pe - em);
+            half_sums(q, odd_row);
+            const double var = q[0] * in0;
             bad = bad || !(det > 0.0) || !(var > 0.0) || !is_finite(mean);
             qzm = mean; qzv = var; qxm = m1; qxv = v11;
             if (FE) {
                 const double Bn = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
                 // the transition node's joint q(zt, zt_min) and the message toward zt_min see the z-message through its
                 // Gaussian moments: mean_var(ExponentialLinearQuadratic) = cubature of pdf(z)·exp(z²/2) against N(0, 1)
-                const double ecv = gw * exp(-0.5 * (kappa * pe + b * exp(-kappa * pe)) + 0.5 * pe * pe);
-                const double en = half_sum(ecv);
-                const double em = half_sum(pe * ecv) / en;
-                const double ed = pe - em;
-                const double ev = half_sum(ecv * ed * ed) / en;
+                const double ev = q[1] * ie0;
                 bad = bad || !(ev > 0.0) || !is_finite(em);
-                const double wb = 1.0 / zvar, w00 = 1.0 / ev + wb, w11 = 1.0 / zv + wb;
+                const double iev = rcp_pos(ev);
+                const double w00 = iev + wb, w11 = izv + wb;
                 const double dW = w00 * w11 - wb * wb;
-                const double idw = 1.0 / dW;
+                const double idw = rcp_pos(dW);
                 const double s00 = w11 * idw, s11 = w00 * idw, s01 = wb * idw;
-                const double j0 = s00 * (em / ev) + s01 * (zm / zv), j1 = s01 * (em / ev) + s11 * (zm / zv);
-                const double mu_m = j1, var_m = s11;
+                const double xo = em * iev;
+                const double j0 = s00 * xo + s01 * zx, j1 = s01 * xo + s11 * zx;
                 const double e2 = (j0 - j1) * (j0 - j1) + s00 + s11 - 2.0 * s01;
-                double F = 0.0;
-                F += 0.5 * (kLog2Pi + log(zv) + ((mu_m - zm) * (mu_m - zm) + var_m) / zv);
-                F += 0.5 * (kLog2Pi + log(xv) + ((m2 - xm) * (m2 - xm) + v22) / xv);
-                F += 0.5 * (kLog2Pi + log(zvar) + e2 / zvar);
-                F -= 0.5 * (2.0 * (kLog2Pi + 1.0) - log(dW));
-                F += 0.5 * (kLog2Pi + (qzm * kappa + omega) + psi * A * Bn);
-                F -= 0.5 * (2.0 * (kLog2Pi + 1.0) + log(v11 * v22 - v12 * v12));
-                F += 0.5 * (kLog2Pi + log(yvar) + ((yt - m1) * (yt - m1) + v11) / yvar);
-                if (live && j == 0) p.fe_series[(long long)n * p.n_series + s] += F;
+                double F = fe_t_const;
+                F += 0.5 * ((j1 - zm) * (j1 - zm) + s11) * izv;                  // prior zt_min
+                F += 0.5 * ((m2 - xm) * (m2 - xm) + v22) * ixv;                  // prior xt_min
+                F += 0.5 * e2 * wb;                                              // transition
+                F += 0.5 * (kLog2Pi + (qzm * kappa + omega) + psi * A * Bn);     // GCV average energy
+                // −H[zt, zt_min] − H[xt, xt_min] = −2(log 2π + 1) + ½ log(dW / det Σ_x),  det Σ_x = 1 / det
+                F += -2.0 * (kLog2Pi + 1.0) + 0.5 * log(dW * det);
+                F += 0.5 * ((yt - m1) * (yt - m1) + v11) * iyvar;                // observation
+                if (n < 32) fe_acc += (j == n) ? F : 0.0;
+                else if (live && j == 0) p.fe_series[(long long)n * p.n_series + s] += F;
             }
         }
         if (live && j == 0) {
@@ -108,6 +160,7 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
             p.zm[o] = qzm; p.zv[o] = qzv; p.xm[o] = qxm; p.xv[o] = qxv;
         }
     }
+    if (FE && live && j < p.iters) p.fe_series[(long long)j * p.n_series + s] += fe_acc;
     if (bad && live) atomicOr(p.status, ST_NONFINITE);
 }
 
