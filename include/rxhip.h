@@ -106,7 +106,24 @@ enum {
     /* ExponentialFamily.MvNormalMeanCovariance, interfaces (out, μ, Σ) — `MvNormal(μ = …, Σ = …)`, src/model/graphppl.jl:372-376 */
     RXHIP_NODE_MVNORMAL_MEAN_COV = 1,
     /* typeof(*), interfaces (out, A, in) — `A * x`, docs/src/manuals/model-specification.md:217-240 */
-    RXHIP_NODE_MULTIPLY = 2
+    RXHIP_NODE_MULTIPLY = 2,
+    /* the mean-field families (aliases src/model/graphppl.jl:340-370 Normal, :399-423 Gamma; interface orders as in
+     * ReactiveMP's @node declarations) */
+    RXHIP_NODE_NORMAL_MEAN_VARIANCE = 3,  /* (out, μ, v)  `Normal(mean = …, var = …)` */
+    RXHIP_NODE_NORMAL_MEAN_PRECISION = 4, /* (out, μ, τ)  `Normal(mean = …, precision = …)` */
+    RXHIP_NODE_GAMMA_SHAPE_RATE = 5,      /* (out, α, β)  `Gamma(shape = …, rate = …)` */
+    RXHIP_NODE_DIRICHLET = 6,             /* (out, a) */
+    RXHIP_NODE_BETA = 7,                  /* (out, a, b) */
+    RXHIP_NODE_CATEGORICAL = 8,           /* (out, p) */
+    RXHIP_NODE_BERNOULLI = 9,             /* (out, p) */
+    RXHIP_NODE_NORMAL_MIXTURE = 10,       /* (out, switch, m[1..K], p[1..K])  test/models/mixtures/gmm_univariate_tests.jl:16-19 */
+    RXHIP_NODE_GCV = 11                   /* (y, x, z, κ, ω)  test/models/statespace/hgf_tests.jl:28 */
+};
+enum { /* family of an `@initialization` marginal (InitMarExtraKey, src/model/plugins/initialization_plugin.jl:201-202) */
+    RXHIP_INIT_NONE = 0,
+    RXHIP_INIT_NORMAL = 1,   /* (mean, variance) */
+    RXHIP_INIT_GAMMA = 2,    /* (shape, rate) */
+    RXHIP_INIT_DIRICHLET = 3 /* alpha[rows]; Beta(a, b) = (a, b) */
 };
 typedef struct {
     int64_t n_variables;
@@ -120,6 +137,12 @@ typedef struct {
     const double* const_pool;
     int64_t n_const;
     int64_t n_replicas;
+    /* ---- optional extensions (all-zero = the 3-interface Gaussian graphs above) ---- */
+    const int64_t* factor_iface_ptr; /* NULL: factor_iface is [n_factors][3]; else CSR offsets [n_factors+1] into factor_iface */
+    const int32_t* var_init_family;  /* NULL or [n_variables] RXHIP_INIT_*: the `@initialization` marginal of a random variable */
+    const int64_t* var_init;         /* [n_variables] offset of its parameters in const_pool (−1: none) */
+    int32_t gh_points;               /* GCVMetadata(GaussHermiteCubature(n)) of the GCV nodes; 0 = 31 */
+    int64_t n_observations;          /* streaming (one-step) graphs: observations that will be pushed per replica */
 } rxhip_graph_desc;
 
 /* result of the lowering pass for the LGSSM family; matrices are written into caller buffers of the sizes below */
@@ -143,8 +166,34 @@ typedef struct {
 rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowered* out);
 const char* rxhip_lowering_error(void); /* thread-local text of the last lowering failure */
 
+/* Mean-field mixture (a9/a10): recognises  s ~ Dirichlet|Beta(const); m[k] ~ Normal(mean, var const); p[k] ~ Gamma(shape,
+ * rate const); z[i] ~ Categorical|Bernoulli(s); y[i] (data) ~ NormalMixture(switch = z[i], m, p)  in any node order, and
+ * the K = 1 form  y[i] ~ Normal(mean = m, precision = p)  (test/models/models_tests.jl:114-128).  Two-call protocol as
+ * above (N, K first; then the [K] arrays and data_var [N]).  init_*: the `@initialization` marginals of m[k], p[k]
+ * (required) and s (default Dirichlet(1)). */
+typedef struct {
+    int64_t N;
+    int32_t K;
+    double *mu0, *v0, *a0, *b0, *alpha0;                                             /* [K] priors  */
+    double *init_m_mean, *init_m_var, *init_p_shape, *init_p_rate, *init_s_alpha;    /* [K] q init  */
+    int64_t* data_var;                                                               /* [N] variable id of y[i] (nullable) */
+} rxhip_gmm_lowered;
+rxhip_status rxhip_graph_lower_gmm(const rxhip_graph_desc* g, rxhip_gmm_lowered* out);
+
+/* Hierarchical Gaussian filter one-step graph (a11; test/models/statespace/hgf_tests.jl:9-31):
+ *     zt_min ~ Normal(data, data); xt_min ~ Normal(data, data); zt ~ Normal(mean = zt_min, var = const);
+ *     xt ~ GCV(xt_min, zt, κ const, ω const); y (data) ~ Normal(mean = xt, var = const)
+ * with `@initialization` q(zt), q(xt) and the cubature order of the GCV meta. */
+typedef struct {
+    double kappa, omega, z_variance, y_variance, z0_mean, z0_var, x0_mean, x0_var;
+    int32_t n_gh;
+    int64_t zt_var, xt_var, y_var; /* variable ids of zt, xt, y */
+} rxhip_hgf_lowered;
+rxhip_status rxhip_graph_lower_hgf(const rxhip_graph_desc* g, rxhip_hgf_lowered* out);
+
 /* replaces: create_model + postprocess_plugin for ANY supported graph (src/inference/batch.jl:252): lowers `g`,
- * then builds the engine exactly as rxhip_lgssm_create would.  segments/device/stream as in rxhip_lgssm_desc. */
+ * then builds the engine exactly as rxhip_lgssm_create / rxhip_gmm_create / rxhip_hgf_create would (family chosen by
+ * the node types present; HGF: T = n_observations, series = n_replicas).  segments/device/stream as in rxhip_lgssm_desc. */
 rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out);
 
 /* 1 if a device schedule is compiled for state dimension d and observation dimension dy */

@@ -34,6 +34,45 @@ struct Lgssm {
     std::vector<long long> state_var, data_var;
 };
 
+// interface k of factor f / number of interfaces (3-wide table or CSR)
+inline long long iface(const rxhip_graph_desc* g, long long f, int k) {
+    return g->factor_iface_ptr ? g->factor_iface[g->factor_iface_ptr[f] + k] : g->factor_iface[f * 3 + k];
+}
+inline int n_iface(const rxhip_graph_desc* g, long long f) {
+    return g->factor_iface_ptr ? (int)(g->factor_iface_ptr[f + 1] - g->factor_iface_ptr[f]) : 3;
+}
+inline rxhip_status check_tables(const rxhip_graph_desc* g) {
+    if (!g || g->n_variables <= 0 || g->n_factors <= 0 || !g->var_kind || !g->var_rows || !g->var_cols || !g->var_const ||
+        !g->factor_type || !g->factor_iface || (g->n_const > 0 && !g->const_pool))
+        return badarg("graph descriptor has null tables");
+    for (long long f = 0; f < g->n_factors; ++f) {
+        const int n = n_iface(g, f);
+        if (n <= 0) return badarg("factor without interfaces");
+        for (int k = 0; k < n; ++k)
+            if (iface(g, f, k) < 0 || iface(g, f, k) >= g->n_variables) return badarg("factor interface refers to an unknown variable");
+    }
+    return RXHIP_OK;
+}
+inline bool has_node(const rxhip_graph_desc* g, int type) {
+    for (long long f = 0; f < g->n_factors; ++f)
+        if (g->factor_type[f] == type) return true;
+    return false;
+}
+// scalar constant
+inline bool const_scalar(const rxhip_graph_desc* g, long long v, double* out) {
+    if (g->var_kind[v] != RXHIP_VARKIND_CONST || g->var_const[v] < 0 || g->var_rows[v] != 1 || g->var_cols[v] != 1) return false;
+    if (g->var_const[v] + 1 > g->n_const) return false;
+    *out = g->const_pool[g->var_const[v]];
+    return true;
+}
+// `@initialization` marginal of a random variable: n parameters of the given family
+inline bool init_params(const rxhip_graph_desc* g, long long v, int family, int n, const double** out) {
+    if (!g->var_init_family || !g->var_init) return false;
+    if (g->var_init_family[v] != family || g->var_init[v] < 0 || g->var_init[v] + n > g->n_const) return false;
+    *out = g->const_pool + g->var_init[v];
+    return true;
+}
+
 // value of a constant variable, with shape check
 inline bool const_value(const rxhip_graph_desc* g, long long v, int rows, int cols, const double** out) {
     if (g->var_kind[v] != RXHIP_VARKIND_CONST || g->var_const[v] < 0) return false;
@@ -54,19 +93,16 @@ inline bool same_const(const rxhip_graph_desc* g, long long a, long long b) {
 //                           [`*`(out = a, A = A, in = x);  MvN(out = x_next (random), μ = a, Σ = P)] (transition)
 // with time-invariant constants.  Node order in the tables is irrelevant.
 inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
-    if (!g || g->n_variables <= 0 || g->n_factors <= 0 || !g->var_kind || !g->var_rows || !g->var_cols || !g->var_const ||
-        !g->factor_type || !g->factor_iface || (g->n_const > 0 && !g->const_pool))
-        return badarg("graph descriptor has null tables");
+    if (rxhip_status st = check_tables(g)) return st;
     const long long NV = g->n_variables, NF = g->n_factors;
     for (long long f = 0; f < NF; ++f)
-        for (int k = 0; k < 3; ++k)
-            if (g->factor_iface[f * 3 + k] < 0 || g->factor_iface[f * 3 + k] >= NV) return badarg("factor interface refers to an unknown variable");
+        if (n_iface(g, f) != 3) return unsupported("node with " + std::to_string(n_iface(g, f)) + " interfaces in a state-space chain");
     // `*` node producing each (anonymous) variable, and MvN nodes by their μ variable
     std::vector<long long> mul_of_out(NV, -1), mvn_of_mu(NV, -1);
     std::vector<std::vector<long long>> mul_of_in(NV);
     long long prior = -1;
     for (long long f = 0; f < NF; ++f) {
-        const int64_t* io = g->factor_iface + f * 3;
+        const long long io[3] = {iface(g, f, 0), iface(g, f, 1), iface(g, f, 2)};
         if (g->factor_type[f] == RXHIP_NODE_MULTIPLY) {
             if (g->var_kind[io[1]] != RXHIP_VARKIND_CONST) return unsupported("`*` node with a non-constant matrix (no device schedule)");
             if (g->var_kind[io[2]] != RXHIP_VARKIND_RANDOM || g->var_kind[io[0]] != RXHIP_VARKIND_RANDOM)
@@ -87,11 +123,11 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
             return unsupported("node type " + std::to_string(g->factor_type[f]) + " has no device schedule");
     }
     if (prior < 0) return unsupported("no prior node (MvNormalMeanCovariance with constant mean)");
-    long long x = g->factor_iface[prior * 3 + 0];
+    long long x = iface(g, prior, 0);
     if (g->var_kind[x] != RXHIP_VARKIND_RANDOM) return unsupported("prior node on a non-random variable");
     const int d = g->var_rows[x];
     const double *m0, *V0;
-    if (!const_value(g, g->factor_iface[prior * 3 + 1], d, 1, &m0) || !const_value(g, g->factor_iface[prior * 3 + 2], d, d, &V0))
+    if (!const_value(g, iface(g, prior, 1), d, 1, &m0) || !const_value(g, iface(g, prior, 2), d, d, &V0))
         return badarg("prior constants have the wrong shape");
     long long vA = -1, vP = -1, vB = -1, vQ = -1;
     long long used_factors = 1;
@@ -100,10 +136,10 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
     while (true) {
         long long obs_mul = -1, tr_mul = -1;
         for (long long f : mul_of_in[x]) {
-            const long long outv = g->factor_iface[f * 3 + 0];
+            const long long outv = iface(g, f, 0);
             const long long mv = mvn_of_mu[outv];
             if (mv < 0) return unsupported("`*` node whose output feeds no MvNormal mean");
-            const long long target = g->factor_iface[mv * 3 + 0];
+            const long long target = iface(g, mv, 0);
             if (g->var_kind[target] == RXHIP_VARKIND_DATA) {
                 if (obs_mul >= 0) return unsupported("state with two observation branches");
                 obs_mul = f;
@@ -114,12 +150,12 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
                 return unsupported("MvNormal with a constant output");
         }
         if (obs_mul >= 0) {
-            const long long mv = mvn_of_mu[g->factor_iface[obs_mul * 3 + 0]];
-            const long long b = g->factor_iface[obs_mul * 3 + 1], q = g->factor_iface[mv * 3 + 2];
+            const long long mv = mvn_of_mu[iface(g, obs_mul, 0)];
+            const long long b = iface(g, obs_mul, 1), q = iface(g, mv, 2);
             if (vB < 0) { vB = b; vQ = q; }
             else if (!same_const(g, vB, b) || !same_const(g, vQ, q)) return unsupported("time-varying observation model");
             L.state_var.push_back(x);
-            L.data_var.push_back(g->factor_iface[mv * 3 + 0]);
+            L.data_var.push_back(iface(g, mv, 0));
             used_factors += 2;
         } else if (first && tr_mul >= 0) {
             L.ptt = 1;  // x0 ~ prior without an observation: test/models/statespace/mlgssm_test.jl:9-17
@@ -127,12 +163,12 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
             return unsupported("state variable without an observation");
         first = false;
         if (tr_mul < 0) break;
-        const long long mv = mvn_of_mu[g->factor_iface[tr_mul * 3 + 0]];
-        const long long a = g->factor_iface[tr_mul * 3 + 1], pv = g->factor_iface[mv * 3 + 2];
+        const long long mv = mvn_of_mu[iface(g, tr_mul, 0)];
+        const long long a = iface(g, tr_mul, 1), pv = iface(g, mv, 2);
         if (vA < 0) { vA = a; vP = pv; }
         else if (!same_const(g, vA, a) || !same_const(g, vP, pv)) return unsupported("time-varying transition model");
         used_factors += 2;
-        x = g->factor_iface[mv * 3 + 0];
+        x = iface(g, mv, 0);
         if (g->var_rows[x] != d) return unsupported("state dimension changes along the chain");
     }
     if (used_factors != NF) return unsupported("graph has factors outside the state-space chain");
@@ -155,6 +191,184 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         L.P.assign((size_t)d * d, 0.0);
         for (int i = 0; i < d; ++i) L.A[i * d + i] = L.P[i * d + i] = 1.0;
     }
+    last_error().clear();
+    return RXHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Mean-field mixture (NormalMixture, K ≤ 16) and its K = 1 form (iid Gaussian with unknown mean and precision)
+struct Gmm {
+    long long N = 0;
+    int K = 0;
+    std::vector<double> mu0, v0, a0, b0, alpha0, qm_mean, qm_var, qp_shape, qp_rate, qs_alpha;
+    std::vector<long long> data_var;
+};
+inline rxhip_status lower_gmm(const rxhip_graph_desc* g, Gmm& M) {
+    if (rxhip_status st = check_tables(g)) return st;
+    const long long NV = g->n_variables, NF = g->n_factors;
+    M = Gmm();
+    std::vector<long long> prior_of(NV, -1), cat_of(NV, -1);
+    std::vector<long long> mix;
+    long long s_var = -1, s_prior = -1;
+    for (long long f = 0; f < NF; ++f) {
+        const int t = g->factor_type[f], n = n_iface(g, f);
+        const long long out = iface(g, f, 0);
+        switch (t) {
+        case RXHIP_NODE_NORMAL_MEAN_VARIANCE:
+        case RXHIP_NODE_GAMMA_SHAPE_RATE:
+            if (n != 3) return badarg("prior node must have 3 interfaces");
+            if (g->var_kind[out] != RXHIP_VARKIND_RANDOM) return unsupported("Normal / Gamma node on a non-random variable in a mixture graph");
+            if (prior_of[out] >= 0) return unsupported("variable with two prior nodes");
+            prior_of[out] = f;
+            break;
+        case RXHIP_NODE_DIRICHLET:
+        case RXHIP_NODE_BETA:
+            if (n != (t == RXHIP_NODE_DIRICHLET ? 2 : 3)) return badarg("Dirichlet / Beta node with the wrong number of interfaces");
+            if (s_prior >= 0) return unsupported("more than one switch prior");
+            s_prior = f;
+            s_var = out;
+            break;
+        case RXHIP_NODE_CATEGORICAL:
+        case RXHIP_NODE_BERNOULLI:
+            if (n != 2) return badarg("Categorical / Bernoulli node must have 2 interfaces");
+            if (cat_of[out] >= 0) return unsupported("switch variable with two Categorical nodes");
+            cat_of[out] = f;
+            break;
+        case RXHIP_NODE_NORMAL_MIXTURE:
+        case RXHIP_NODE_NORMAL_MEAN_PRECISION:
+            mix.push_back(f);
+            break;
+        default:
+            return unsupported("node type " + std::to_string(t) + " has no place in a mixture graph");
+        }
+    }
+    if (mix.empty()) return unsupported("no NormalMixture / Normal(mean, precision) observation nodes");
+    const bool iid = g->factor_type[mix[0]] == RXHIP_NODE_NORMAL_MEAN_PRECISION;
+    const int K = iid ? 1 : (n_iface(g, mix[0]) - 2) / 2;
+    if (K < 1 || K > 16 || (!iid && n_iface(g, mix[0]) != 2 + 2 * K)) return unsupported("mixture with an unsupported number of components");
+    std::vector<long long> mv(K), pv(K);
+    for (int k = 0; k < K; ++k) {
+        mv[k] = iface(g, mix[0], iid ? 1 : 2 + k);
+        pv[k] = iface(g, mix[0], iid ? 2 : 2 + K + k);
+    }
+    long long used = 0;
+    for (long long f : mix) {
+        if (g->factor_type[f] != g->factor_type[mix[0]] || n_iface(g, f) != n_iface(g, mix[0])) return unsupported("observation nodes of different shapes");
+        const long long y = iface(g, f, 0);
+        if (g->var_kind[y] != RXHIP_VARKIND_DATA || g->var_rows[y] != 1) return unsupported("mixture observation must be a scalar data variable");
+        for (int k = 0; k < K; ++k)
+            if (iface(g, f, iid ? 1 : 2 + k) != mv[k] || iface(g, f, iid ? 2 : 2 + K + k) != pv[k])
+                return unsupported("observation nodes do not share the component variables");
+        if (!iid) {
+            const long long z = iface(g, f, 1);
+            if (g->var_kind[z] != RXHIP_VARKIND_RANDOM || cat_of[z] < 0) return unsupported("switch variable without a Categorical / Bernoulli node");
+            if (iface(g, cat_of[z], 1) != s_var) return unsupported("switch variables do not share one probability vector");
+            cat_of[z] = -2;  // consumed
+            used += 1;
+        }
+        M.data_var.push_back(y);
+        used += 1;
+    }
+    for (long long v = 0; v < NV; ++v)
+        if (cat_of[v] >= 0) return unsupported("Categorical node outside the mixture");
+    M.N = (long long)mix.size();
+    M.K = K;
+    auto grab = [&](std::vector<double>& a, std::vector<double>& b, const std::vector<long long>& vars, int node, int fam,
+                    std::vector<double>& qa, std::vector<double>& qb, const char* what) -> rxhip_status {
+        for (int k = 0; k < K; ++k) {
+            const long long f = prior_of[vars[k]];
+            if (f < 0 || g->factor_type[f] != node) return unsupported(std::string("component ") + what + " without its prior node");
+            double x, y;
+            if (!const_scalar(g, iface(g, f, 1), &x) || !const_scalar(g, iface(g, f, 2), &y)) return unsupported(std::string("prior of ") + what + " with non-constant parameters");
+            a.push_back(x);
+            b.push_back(y);
+            const double* q;
+            if (!init_params(g, vars[k], fam, 2, &q)) return badarg(std::string("mean-field VMP needs an @initialization marginal for every ") + what);
+            qa.push_back(q[0]);
+            qb.push_back(q[1]);
+            used += 1;
+        }
+        return RXHIP_OK;
+    };
+    if (rxhip_status st = grab(M.mu0, M.v0, mv, RXHIP_NODE_NORMAL_MEAN_VARIANCE, RXHIP_INIT_NORMAL, M.qm_mean, M.qm_var, "m[k]")) return st;
+    if (rxhip_status st = grab(M.a0, M.b0, pv, RXHIP_NODE_GAMMA_SHAPE_RATE, RXHIP_INIT_GAMMA, M.qp_shape, M.qp_rate, "p[k]")) return st;
+    if (iid) {
+        if (s_prior >= 0) return unsupported("switch prior in a graph without a mixture node");
+        M.alpha0.assign(1, 1.0);
+        M.qs_alpha.assign(1, 1.0);
+    } else {
+        if (s_prior < 0) return unsupported("mixture without a Dirichlet / Beta prior on the switch probabilities");
+        if (g->factor_type[s_prior] == RXHIP_NODE_BETA) {
+            double a, b;
+            if (K != 2 || !const_scalar(g, iface(g, s_prior, 1), &a) || !const_scalar(g, iface(g, s_prior, 2), &b)) return unsupported("Beta switch prior needs K = 2 and constant parameters");
+            M.alpha0 = {a, b};
+        } else {
+            const double* al;
+            if (!const_value(g, iface(g, s_prior, 1), K, 1, &al)) return unsupported("Dirichlet prior with non-constant or mis-sized parameters");
+            M.alpha0.assign(al, al + K);
+        }
+        const double* q;
+        if (init_params(g, s_var, RXHIP_INIT_DIRICHLET, K, &q)) M.qs_alpha.assign(q, q + K);
+        else M.qs_alpha.assign(K, 1.0);
+        used += 1;
+    }
+    if (used != NF) return unsupported("graph has factors outside the mixture");
+    last_error().clear();
+    return RXHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Hierarchical Gaussian filter, one-step graph
+struct Hgf {
+    double kappa = 0, omega = 0, z_variance = 0, y_variance = 0, z0m = 0, z0v = 0, x0m = 0, x0v = 0;
+    int n_gh = 31;
+    long long zt = -1, xt = -1, y = -1;
+};
+inline rxhip_status lower_hgf(const rxhip_graph_desc* g, Hgf& H) {
+    if (rxhip_status st = check_tables(g)) return st;
+    H = Hgf();
+    long long gcv = -1;
+    for (long long f = 0; f < g->n_factors; ++f) {
+        if (g->factor_type[f] == RXHIP_NODE_GCV) {
+            if (gcv >= 0) return unsupported("more than one GCV node: not the one-step filter graph");
+            gcv = f;
+        } else if (g->factor_type[f] != RXHIP_NODE_NORMAL_MEAN_VARIANCE)
+            return unsupported("node type " + std::to_string(g->factor_type[f]) + " has no place in the HGF step graph");
+    }
+    if (gcv < 0 || n_iface(g, gcv) != 5 || g->n_factors != 5) return unsupported("HGF step graph = 4 Normal nodes + 1 GCV node");
+    const long long xt = iface(g, gcv, 0), xt_min = iface(g, gcv, 1), zt = iface(g, gcv, 2);
+    if (!const_scalar(g, iface(g, gcv, 3), &H.kappa) || !const_scalar(g, iface(g, gcv, 4), &H.omega)) return unsupported("GCV with non-constant κ / ω");
+    int seen = 0;
+    long long zt_min = -1, zprior_out = -1;
+    for (long long f = 0; f < g->n_factors; ++f) {
+        if (f == gcv) continue;
+        if (n_iface(g, f) != 3) return badarg("Normal node must have 3 interfaces");
+        const long long out = iface(g, f, 0), mu = iface(g, f, 1), v = iface(g, f, 2);
+        if (out == zt) {  // zt ~ Normal(mean = zt_min, var = const)
+            if (g->var_kind[mu] != RXHIP_VARKIND_RANDOM || !const_scalar(g, v, &H.z_variance)) return unsupported("upper layer must be a random walk with constant variance");
+            zt_min = mu;
+            seen |= 1;
+        } else if (g->var_kind[out] == RXHIP_VARKIND_DATA) {  // y ~ Normal(mean = xt, var = const)
+            if (mu != xt || !const_scalar(g, v, &H.y_variance)) return unsupported("observation must read xt with constant variance");
+            H.y = out;
+            seen |= 2;
+        } else if (out == xt_min) {  // xt_min ~ Normal(data, data)
+            if (g->var_kind[mu] != RXHIP_VARKIND_DATA || g->var_kind[v] != RXHIP_VARKIND_DATA) return unsupported("xt_min prior must be fed by @autoupdates data variables");
+            seen |= 4;
+        } else {  // zt_min ~ Normal(data, data)
+            if (g->var_kind[mu] != RXHIP_VARKIND_DATA || g->var_kind[v] != RXHIP_VARKIND_DATA) return unsupported("zt_min prior must be fed by @autoupdates data variables");
+            if (zprior_out >= 0) return unsupported("unexpected Normal node");
+            zprior_out = out;
+            seen |= 8;
+        }
+    }
+    if (seen != 15 || zprior_out != zt_min) return unsupported("HGF step graph is incomplete");
+    const double *qz, *qx;
+    if (!init_params(g, zt, RXHIP_INIT_NORMAL, 2, &qz) || !init_params(g, xt, RXHIP_INIT_NORMAL, 2, &qx))
+        return badarg("the HGF filter needs @initialization marginals q(zt), q(xt)");
+    H.z0m = qz[0]; H.z0v = qz[1]; H.x0m = qx[0]; H.x0v = qx[1];
+    H.n_gh = g->gh_points > 0 ? g->gh_points : 31;
+    H.zt = zt; H.xt = xt;
     last_error().clear();
     return RXHIP_OK;
 }

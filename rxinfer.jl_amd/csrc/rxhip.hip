@@ -1198,9 +1198,61 @@ rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowe
 }
 const char* rxhip_lowering_error(void) { return rxhip_lower::last_error().c_str(); }
 
+rxhip_status rxhip_graph_lower_gmm(const rxhip_graph_desc* g, rxhip_gmm_lowered* out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    rxhip_lower::Gmm M;
+    rxhip_status st = rxhip_lower::lower_gmm(g, M);
+    if (st) return st;
+    out->N = M.N; out->K = M.K;
+    auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
+    cp(out->mu0, M.mu0); cp(out->v0, M.v0); cp(out->a0, M.a0); cp(out->b0, M.b0); cp(out->alpha0, M.alpha0);
+    cp(out->init_m_mean, M.qm_mean); cp(out->init_m_var, M.qm_var); cp(out->init_p_shape, M.qp_shape);
+    cp(out->init_p_rate, M.qp_rate); cp(out->init_s_alpha, M.qs_alpha);
+    if (out->data_var) for (long long i = 0; i < M.N; ++i) out->data_var[i] = M.data_var[i];
+    return RXHIP_OK;
+}
+rxhip_status rxhip_graph_lower_hgf(const rxhip_graph_desc* g, rxhip_hgf_lowered* out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    rxhip_lower::Hgf H;
+    rxhip_status st = rxhip_lower::lower_hgf(g, H);
+    if (st) return st;
+    out->kappa = H.kappa; out->omega = H.omega; out->z_variance = H.z_variance; out->y_variance = H.y_variance;
+    out->z0_mean = H.z0m; out->z0_var = H.z0v; out->x0_mean = H.x0m; out->x0_var = H.x0v;
+    out->n_gh = H.n_gh; out->zt_var = H.zt; out->xt_var = H.xt; out->y_var = H.y;
+    return RXHIP_OK;
+}
+
 rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out) {
     if (!out) return RXHIP_ERR_BADARG;
     *out = nullptr;
+    if (rxhip_status st0 = rxhip_lower::check_tables(g)) return st0;
+    // family by the node types present (the lowering passes reject everything that is not exactly their graph)
+    if (rxhip_lower::has_node(g, RXHIP_NODE_GCV)) {
+        rxhip_lower::Hgf H;
+        rxhip_status st = rxhip_lower::lower_hgf(g, H);
+        if (st) return st;
+        if (g->n_observations <= 0) { rxhip_lower::last_error() = "streaming graph: n_observations must be positive"; return RXHIP_ERR_BADARG; }
+        rxhip_hgf_desc d;
+        std::memset(&d, 0, sizeof d);
+        d.T = g->n_observations; d.n_series = g->n_replicas > 0 ? g->n_replicas : 1;
+        d.kappa = H.kappa; d.omega = H.omega; d.z_variance = H.z_variance; d.y_variance = H.y_variance;
+        d.z0_mean = H.z0m; d.z0_var = H.z0v; d.x0_mean = H.x0m; d.x0_var = H.x0v;
+        d.n_gh = H.n_gh; d.device = device; d.stream = stream;
+        return rxhip_hgf_create(&d, out);
+    }
+    if (rxhip_lower::has_node(g, RXHIP_NODE_NORMAL_MIXTURE) || rxhip_lower::has_node(g, RXHIP_NODE_NORMAL_MEAN_PRECISION)) {
+        rxhip_lower::Gmm M;
+        rxhip_status st = rxhip_lower::lower_gmm(g, M);
+        if (st) return st;
+        rxhip_gmm_desc d;
+        std::memset(&d, 0, sizeof d);
+        d.N = M.N; d.K = M.K;
+        d.mu0 = M.mu0.data(); d.v0 = M.v0.data(); d.a0 = M.a0.data(); d.b0 = M.b0.data(); d.alpha0 = M.alpha0.data();
+        d.init_m_mean = M.qm_mean.data(); d.init_m_var = M.qm_var.data(); d.init_p_shape = M.qp_shape.data();
+        d.init_p_rate = M.qp_rate.data(); d.init_s_alpha = M.qs_alpha.data();
+        d.device = device; d.stream = stream;
+        return rxhip_gmm_create(&d, out);
+    }
     rxhip_lower::Lgssm L;
     rxhip_status st = rxhip_lower::lower_lgssm(g, L);
     if (st) return st;

@@ -31,19 +31,36 @@ class LgssmDesc(ctypes.Structure):
 c_int64_p = ctypes.POINTER(ctypes.c_int64)
 VARKIND_RANDOM, VARKIND_DATA, VARKIND_CONST = 0, 1, 2
 NODE_MVNORMAL_MEAN_COV, NODE_MULTIPLY = 1, 2
+(NODE_NORMAL_MEAN_VARIANCE, NODE_NORMAL_MEAN_PRECISION, NODE_GAMMA_SHAPE_RATE, NODE_DIRICHLET, NODE_BETA, NODE_CATEGORICAL,
+ NODE_BERNOULLI, NODE_NORMAL_MIXTURE, NODE_GCV) = range(3, 12)
+INIT_NONE, INIT_NORMAL, INIT_GAMMA, INIT_DIRICHLET = 0, 1, 2, 3
 
 
 class GraphDesc(ctypes.Structure):
     _fields_ = [("n_variables", ctypes.c_int64), ("var_kind", c_int32_p), ("var_rows", c_int32_p), ("var_cols", c_int32_p),
                 ("var_const", c_int64_p), ("n_factors", ctypes.c_int64), ("factor_type", c_int32_p),
                 ("factor_iface", c_int64_p), ("const_pool", c_double_p), ("n_const", ctypes.c_int64),
-                ("n_replicas", ctypes.c_int64)]
+                ("n_replicas", ctypes.c_int64),
+                # optional extensions (zero = 3-interface Gaussian graphs)
+                ("factor_iface_ptr", c_int64_p), ("var_init_family", c_int32_p), ("var_init", c_int64_p),
+                ("gh_points", ctypes.c_int32), ("n_observations", ctypes.c_int64)]
 
 
 class LgssmLowered(ctypes.Structure):
     _fields_ = [("d", ctypes.c_int32), ("dy", ctypes.c_int32), ("T", ctypes.c_int64),
                 ("prior_through_transition", ctypes.c_int32), ("A", c_double_p), ("B", c_double_p), ("P", c_double_p),
                 ("Q", c_double_p), ("m0", c_double_p), ("V0", c_double_p), ("state_var", c_int64_p), ("data_var", c_int64_p)]
+
+
+class GmmLowered(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int64), ("K", ctypes.c_int32)] + [(n, c_double_p) for n in (
+        "mu0", "v0", "a0", "b0", "alpha0", "init_m_mean", "init_m_var", "init_p_shape", "init_p_rate", "init_s_alpha")] + [
+        ("data_var", c_int64_p)]
+
+
+class HgfLowered(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_double) for n in ("kappa", "omega", "z_variance", "y_variance", "z0_mean", "z0_var", "x0_mean", "x0_var")] + [
+        ("n_gh", ctypes.c_int32), ("zt_var", ctypes.c_int64), ("xt_var", ctypes.c_int64), ("y_var", ctypes.c_int64)]
 
 
 class GmmDesc(ctypes.Structure):
@@ -63,6 +80,8 @@ _H = ctypes.c_void_p
 SYMBOLS = [
     ("rxhip_lgssm_create", ctypes.c_int32, [ctypes.POINTER(LgssmDesc), ctypes.POINTER(_H)]),
     ("rxhip_graph_lower_lgssm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(LgssmLowered)]),
+    ("rxhip_graph_lower_gmm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(GmmLowered)]),
+    ("rxhip_graph_lower_hgf", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(HgfLowered)]),
     ("rxhip_lowering_error", ctypes.c_char_p, []),
     ("rxhip_create", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.POINTER(_H)]),

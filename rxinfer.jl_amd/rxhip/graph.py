@@ -19,6 +19,8 @@ class GraphBuilder:
         self.ftype, self.fiface = [], []
         self.pool = []
         self._n = 0
+        self.init_family, self.init_off = {}, {}
+        self.gh_points = 0
 
     def _var(self, kind, rows, cols=1, coff=-1):
         self.kind.append(kind); self.rows.append(rows); self.cols.append(cols); self.coff.append(coff)
@@ -42,20 +44,39 @@ class GraphBuilder:
         """out ~ MvNormal(μ = mu, Σ = sigma)  ->  MvNormalMeanCovariance (src/model/graphppl.jl:372-376)"""
         self.ftype.append(_lib.NODE_MVNORMAL_MEAN_COV); self.fiface.append((out, mu, sigma))
 
+    def node(self, ntype, *ifaces):
+        """generic factor node: interfaces in the node's declared order"""
+        self.ftype.append(ntype); self.fiface.append(tuple(ifaces))
+
+    def initialize(self, var, family, params):
+        """`@initialization q(var) = …` (InitMarExtraKey, src/model/plugins/initialization_plugin.jl:201-202)"""
+        v = np.atleast_1d(np.asarray(params, dtype=np.float64)).ravel()
+        self.init_family[var], self.init_off[var] = family, self._n
+        self.pool.append(v)
+        self._n += v.size
+
     def multiply(self, out, A, x):
         """out := A * x  ->  typeof(*) node with an anonymous output variable"""
         self.ftype.append(_lib.NODE_MULTIPLY); self.fiface.append((out, A, x))
 
-    def tables(self, n_replicas=1, permute=None):
+    def tables(self, n_replicas=1, permute=None, n_observations=0):
         ft = np.asarray(self.ftype, dtype=np.int32)
-        fi = np.asarray(self.fiface, dtype=np.int64).reshape(-1, 3)
-        if permute is not None:  # node order must not matter to the lowering
-            ft, fi = ft[permute], fi[permute]
+        order = np.arange(len(ft)) if permute is None else np.asarray(permute)  # node order must not matter to the lowering
+        ft = ft[order]
+        ifaces = [self.fiface[i] for i in order]
+        wide = any(len(t) != 3 for t in ifaces)
+        fi = np.asarray([v for t in ifaces for v in t], dtype=np.int64)
+        ptr = np.concatenate([[0], np.cumsum([len(t) for t in ifaces])]).astype(np.int64)
+        nv = len(self.kind)
+        fam = np.zeros(nv, dtype=np.int32)
+        ioff = np.full(nv, -1, dtype=np.int64)
+        for v, f in self.init_family.items():
+            fam[v], ioff[v] = f, self.init_off[v]
         arrs = dict(kind=np.asarray(self.kind, dtype=np.int32), rows=np.asarray(self.rows, dtype=np.int32),
                     cols=np.asarray(self.cols, dtype=np.int32), coff=np.asarray(self.coff, dtype=np.int64), ft=np.ascontiguousarray(ft),
-                    fi=np.ascontiguousarray(fi), pool=np.concatenate(self.pool) if self.pool else np.zeros(1))
+                    fi=np.ascontiguousarray(fi), ptr=ptr, fam=fam, ioff=ioff, pool=np.concatenate(self.pool) if self.pool else np.zeros(1))
         g = _lib.GraphDesc()
-        g.n_variables = len(self.kind)
+        g.n_variables = nv
         g.var_kind = arrs["kind"].ctypes.data_as(_lib.c_int32_p)
         g.var_rows = arrs["rows"].ctypes.data_as(_lib.c_int32_p)
         g.var_cols = arrs["cols"].ctypes.data_as(_lib.c_int32_p)
@@ -66,7 +87,15 @@ class GraphBuilder:
         g.const_pool = arrs["pool"].ctypes.data_as(_lib.c_double_p)
         g.n_const = int(arrs["pool"].size if self.pool else 0)
         g.n_replicas = int(n_replicas)
-        return g, arrs  # keep `arrs` alive while `g` is in use
+        if wide:  # CSR interface table; 3-wide graphs keep the plain [n_factors][3] form
+            g.factor_iface_ptr = arrs["ptr"].ctypes.data_as(_lib.c_int64_p)
+        if self.init_family:
+            g.var_init_family = arrs["fam"].ctypes.data_as(_lib.c_int32_p)
+            g.var_init = arrs["ioff"].ctypes.data_as(_lib.c_int64_p)
+        g.gh_points = int(self.gh_points)
+        g.n_observations = int(n_observations)
+        g._keep = arrs  # the descriptor points into these arrays
+        return g, arrs
 
 
 def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=None):
@@ -127,5 +156,124 @@ def create_engine_from_graph(g, segments=0, device=-1, stream=None):
     low = lower_lgssm(g)
     eng = LGSSMEngine.__new__(LGSSMEngine)
     eng._h, eng.d, eng.dy, eng.T, eng.n_chains, eng.n_models = h, low["d"], low["dy"], low["T"], int(g.n_replicas or 1), 1
+    eng._keep, eng._data_ref = [], None
+    return eng
+
+
+def mixture_graph(N, prior_mean, prior_var, prior_shape, prior_rate, prior_alpha, init=None, bernoulli=False):
+    """The graph of `univariate_gaussian_mixture_model` (test/models/mixtures/gmm_univariate_tests.jl:7-20) with K
+    components (`Beta` / `Bernoulli` for the reference's K = 2 spelling, else `Dirichlet` / `Categorical`).
+    init = dict(m=(means, vars), p=(shapes, rates), s=alphas) are the `@initialization` marginals."""
+    K = len(prior_mean)
+    gb = GraphBuilder()
+    s = gb.randomvar(K)
+    if bernoulli:
+        assert K == 2
+        gb.node(_lib.NODE_BETA, s, gb.constvar(prior_alpha[0]), gb.constvar(prior_alpha[1]))
+    else:
+        gb.node(_lib.NODE_DIRICHLET, s, gb.constvar(np.asarray(prior_alpha, float)))
+    m, p = [], []
+    for k in range(K):
+        mk, pk = gb.randomvar(1), gb.randomvar(1)
+        gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, mk, gb.constvar(prior_mean[k]), gb.constvar(prior_var[k]))
+        gb.node(_lib.NODE_GAMMA_SHAPE_RATE, pk, gb.constvar(prior_shape[k]), gb.constvar(prior_rate[k]))
+        m.append(mk); p.append(pk)
+    ys = []
+    for _ in range(N):
+        z, y = gb.randomvar(1), gb.datavar(1)
+        gb.node(_lib.NODE_BERNOULLI if bernoulli else _lib.NODE_CATEGORICAL, z, s)
+        gb.node(_lib.NODE_NORMAL_MIXTURE, y, z, *m, *p)
+        ys.append(y)
+    if init is not None:
+        for k in range(K):
+            gb.initialize(m[k], _lib.INIT_NORMAL, (init["m"][0][k], init["m"][1][k]))
+            gb.initialize(p[k], _lib.INIT_GAMMA, (init["p"][0][k], init["p"][1][k]))
+        if "s" in init:
+            gb.initialize(s, _lib.INIT_DIRICHLET, init["s"])
+    return gb, ys
+
+
+def iid_normal_graph(N, mean, variance, shape, rate, init=None):
+    """`iid_gaussians_params` (test/models/models_tests.jl:114-128): m ~ Normal, p ~ Gamma, y[i] ~ Normal(mean = m, precision = p)."""
+    gb = GraphBuilder()
+    m, p = gb.randomvar(1), gb.randomvar(1)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, m, gb.constvar(mean), gb.constvar(variance))
+    gb.node(_lib.NODE_GAMMA_SHAPE_RATE, p, gb.constvar(shape), gb.constvar(rate))
+    ys = []
+    for _ in range(N):
+        y = gb.datavar(1)
+        gb.node(_lib.NODE_NORMAL_MEAN_PRECISION, y, m, p)
+        ys.append(y)
+    if init is not None:
+        gb.initialize(m, _lib.INIT_NORMAL, init["m"])
+        gb.initialize(p, _lib.INIT_GAMMA, init["p"])
+    return gb, ys
+
+
+def hgf_step_graph(kappa, omega, z_variance, y_variance, q_zt=(0.0, 5.0), q_xt=(0.0, 5.0), n_gh=31):
+    """The one-step graph of test/models/statespace/hgf_tests.jl:9-31 with its `@initialization` and GCV meta."""
+    gb = GraphBuilder()
+    zt_min, xt_min, zt, xt = gb.randomvar(1), gb.randomvar(1), gb.randomvar(1), gb.randomvar(1)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, zt_min, gb.datavar(1), gb.datavar(1))
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, xt_min, gb.datavar(1), gb.datavar(1))
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, zt, zt_min, gb.constvar(z_variance))
+    gb.node(_lib.NODE_GCV, xt, xt_min, zt, gb.constvar(kappa), gb.constvar(omega))
+    y = gb.datavar(1)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y, xt, gb.constvar(y_variance))
+    gb.initialize(zt, _lib.INIT_NORMAL, q_zt)
+    gb.initialize(xt, _lib.INIT_NORMAL, q_xt)
+    gb.gh_points = n_gh
+    return gb, dict(zt=zt, xt=xt, y=y)
+
+
+def lower_gmm(g):
+    """Host-only lowering of a mixture graph: dict(N, K, mu0, v0, a0, b0, alpha0, init_*, data_var)."""
+    L = _lib.lib()
+    out = _lib.GmmLowered()
+    st = L.rxhip_graph_lower_gmm(ctypes.byref(g), ctypes.byref(out))
+    if st != _lib.OK:
+        raise RxHipError(st, L.rxhip_lowering_error().decode())
+    N, K = out.N, out.K
+    names = ("mu0", "v0", "a0", "b0", "alpha0", "init_m_mean", "init_m_var", "init_p_shape", "init_p_rate", "init_s_alpha")
+    bufs = {n: np.empty(K) for n in names}
+    dv = np.empty(N, dtype=np.int64)
+    for n, v in bufs.items():
+        setattr(out, n, v.ctypes.data_as(_lib.c_double_p))
+    out.data_var = dv.ctypes.data_as(_lib.c_int64_p)
+    st = L.rxhip_graph_lower_gmm(ctypes.byref(g), ctypes.byref(out))
+    if st != _lib.OK:
+        raise RxHipError(st, L.rxhip_lowering_error().decode())
+    return dict(N=N, K=K, data_var=dv, **bufs)
+
+
+def lower_hgf(g):
+    L = _lib.lib()
+    out = _lib.HgfLowered()
+    st = L.rxhip_graph_lower_hgf(ctypes.byref(g), ctypes.byref(out))
+    if st != _lib.OK:
+        raise RxHipError(st, L.rxhip_lowering_error().decode())
+    return {n: getattr(out, n) for n, _ in _lib.HgfLowered._fields_}
+
+
+def create_vmp_engine_from_graph(g, device=-1, stream=None):
+    """rxhip_create for the mean-field families: returns a GMMEngine / HGFEngine around the new handle."""
+    from .engine import GMMEngine, HGFEngine
+
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    st = L.rxhip_create(ctypes.byref(g), 0, int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
+    if st != _lib.OK:
+        msg = L.rxhip_lowering_error().decode() or (L.rxhip_last_error(h).decode() if h else "")
+        if h:
+            L.rxhip_destroy(h)
+        raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
+    if any(t == _lib.NODE_GCV for t in np.ctypeslib.as_array(g.factor_type, (g.n_factors,))):
+        eng = HGFEngine.__new__(HGFEngine)
+        eng._h, eng.T, eng.n_series, eng._iters = h, int(g.n_observations), int(g.n_replicas or 1), 0
+        eng.n_chains = eng.n_series
+    else:
+        low = lower_gmm(g)
+        eng = GMMEngine.__new__(GMMEngine)
+        eng._h, eng.N, eng.K, eng._iters = h, low["N"], low["K"], 0
     eng._keep, eng._data_ref = [], None
     return eng

@@ -81,3 +81,104 @@ def test_engine_from_graph_matches_structured_descriptor():
         e2.set_data(y); e2.run(1, True)
         m2, V2 = e2.marginals(); f2 = e2.free_energy_per_chain()
     assert np.array_equal(m1, m2) and np.array_equal(V1, V2) and np.array_equal(f1, f2)
+
+
+# ---- mean-field families (a9 / a10 / a11) ---------------------------------------------------------------------
+_PRI = dict(mean=[-2.0, 2.0, 7.0], var=[1e3, 1e3, 5e2], shape=[0.01, 0.02, 0.03], rate=[0.01, 0.01, 0.04], alpha=[1.0, 2.0, 3.0])
+_INIT = dict(m=([-2.0, 2.0, 6.0], [1e3, 1e2, 1e1]), p=([1.0, 1.5, 2.0], [1e-12, 1.0, 2.0]), s=[1.0, 1.0, 4.0])
+
+
+def test_mixture_graph_is_recognised_whatever_the_node_order():
+    N = 40
+    gb, ys = graph.mixture_graph(N, _PRI["mean"], _PRI["var"], _PRI["shape"], _PRI["rate"], _PRI["alpha"], init=_INIT)
+    assert len(gb.ftype) == 1 + 2 * 3 + 2 * N
+    for perm in (None, np.random.default_rng(1).permutation(len(gb.ftype))):
+        low = graph.lower_gmm(gb.tables(permute=perm)[0])
+        assert (low["N"], low["K"]) == (N, 3)
+        assert np.array_equal(low["mu0"], _PRI["mean"]) and np.array_equal(low["v0"], _PRI["var"])
+        assert np.array_equal(low["a0"], _PRI["shape"]) and np.array_equal(low["b0"], _PRI["rate"]) and np.array_equal(low["alpha0"], _PRI["alpha"])
+        assert np.array_equal(low["init_m_mean"], _INIT["m"][0]) and np.array_equal(low["init_m_var"], _INIT["m"][1])
+        assert np.array_equal(low["init_p_shape"], _INIT["p"][0]) and np.array_equal(low["init_p_rate"], _INIT["p"][1])
+        assert np.array_equal(low["init_s_alpha"], _INIT["s"])
+        if perm is None:
+            assert list(low["data_var"]) == ys
+
+
+def test_reference_spelling_beta_bernoulli_and_iid_gaussian():
+    """test/models/mixtures/gmm_univariate_tests.jl:7-26 (Beta / Bernoulli, K = 2) and models_tests.jl:114-128 (K = 1)."""
+    init = dict(m=([-2.0, 2.0], [1e3, 1e3]), p=([1.0, 1.0], [1e-12, 1e-12]), s=[1.0, 1.0])
+    gb, _ = graph.mixture_graph(15, [-2.0, 2.0], [1e3, 1e3], [0.01, 0.01], [0.01, 0.01], [1.0, 1.0], init=init, bernoulli=True)
+    low = graph.lower_gmm(gb.tables()[0])
+    assert (low["N"], low["K"]) == (15, 2) and np.array_equal(low["alpha0"], [1.0, 1.0]) and np.array_equal(low["init_p_rate"], [1e-12, 1e-12])
+    gb, ys = graph.iid_normal_graph(9, 4.0, 8.0, 4.0, 0.125, init=dict(m=(0.0, 1.0), p=(1.0, 1.0)))
+    low = graph.lower_gmm(gb.tables()[0])
+    assert (low["N"], low["K"]) == (9, 1) and low["mu0"][0] == 4.0 and low["b0"][0] == 0.125 and low["alpha0"][0] == 1.0
+
+
+def test_mixture_graphs_outside_the_family_are_rejected():
+    # no @initialization: mean-field VMP cannot start (cf. test/inference/inference_tests.jl:361-363)
+    gb, _ = graph.mixture_graph(5, _PRI["mean"], _PRI["var"], _PRI["shape"], _PRI["rate"], _PRI["alpha"])
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_gmm(gb.tables()[0])
+    assert ei.value.status == _lib.ERR_BADARG and "initialization" in str(ei.value)
+    # observation nodes that do not share the component variables
+    gb, _ = graph.mixture_graph(5, _PRI["mean"], _PRI["var"], _PRI["shape"], _PRI["rate"], _PRI["alpha"], init=_INIT)
+    it = list(gb.fiface[-1]); it[2], it[3] = it[3], it[2]; gb.fiface[-1] = tuple(it)
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_gmm(gb.tables()[0])
+    assert ei.value.status == _lib.ERR_UNSUPPORTED and "share" in str(ei.value)
+    # a stray node
+    gb, _ = graph.mixture_graph(5, _PRI["mean"], _PRI["var"], _PRI["shape"], _PRI["rate"], _PRI["alpha"], init=_INIT)
+    gb.node(_lib.NODE_GCV, 0, 1, 2, 3, 4)
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_gmm(gb.tables()[0])
+    assert ei.value.status == _lib.ERR_UNSUPPORTED
+    # an LGSSM graph is not a mixture and vice versa
+    mdl = workloads.c1_model()
+    gl, _, _ = graph.lgssm_graph(4, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    with pytest.raises(rxhip.RxHipError):
+        graph.lower_gmm(gl.tables()[0])
+    gb, _ = graph.mixture_graph(5, _PRI["mean"], _PRI["var"], _PRI["shape"], _PRI["rate"], _PRI["alpha"], init=_INIT)
+    with pytest.raises(rxhip.RxHipError):
+        graph.lower_lgssm(gb.tables()[0])
+
+
+def test_hgf_step_graph_is_recognised():
+    gb, ids = graph.hgf_step_graph(1.0, 0.0, 0.04, 0.01, q_zt=(0.1, 5.0), q_xt=(-0.2, 3.0), n_gh=21)
+    for perm in (None, [4, 2, 0, 3, 1]):
+        low = graph.lower_hgf(gb.tables(permute=perm, n_observations=100)[0])
+        assert (low["kappa"], low["omega"], low["z_variance"], low["y_variance"]) == (1.0, 0.0, 0.04, 0.01)
+        assert (low["z0_mean"], low["z0_var"], low["x0_mean"], low["x0_var"], low["n_gh"]) == (0.1, 5.0, -0.2, 3.0, 21)
+        assert (low["zt_var"], low["xt_var"], low["y_var"]) == (ids["zt"], ids["xt"], ids["y"])
+    # a constant instead of the @autoupdates data variables on a prior: not the streaming filter graph
+    gb, _ = graph.hgf_step_graph(1.0, 0.0, 0.04, 0.01)
+    it = list(gb.fiface[0]); it[1] = gb.constvar(0.0); gb.fiface[0] = tuple(it)
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_hgf(gb.tables()[0])
+    assert ei.value.status == _lib.ERR_UNSUPPORTED
+
+
+@pytest.mark.gpu
+def test_vmp_engines_from_graphs_match_structured_descriptors():
+    """rxhip_create(graph) == rxhip_gmm_create / rxhip_hgf_create (structured) on the device."""
+    rng = np.random.default_rng(2)
+    y = np.asarray(_PRI["mean"])[rng.integers(0, 3, 3000)] + rng.standard_normal(3000)
+    init = dict(m=([-3.0, 1.0, 6.0], [1.0] * 3), p=([1.0] * 3, [1.0] * 3), s=[1.0] * 3)
+    gb, _ = graph.mixture_graph(y.size, _PRI["mean"], [1e2] * 3, [0.1] * 3, [0.1] * 3, [1.0] * 3, init=init)
+    g, keep = gb.tables()
+    e1 = graph.create_vmp_engine_from_graph(g)
+    e1.set_data(y); e1.run(5, True)
+    h1, f1 = e1.history(), e1.free_energy(); e1.close()
+    with rxhip.GMMEngine(y.size, _PRI["mean"], [1e2] * 3, [0.1] * 3, [0.1] * 3, [1.0] * 3, *init["m"], *init["p"], init["s"]) as e2:
+        e2.set_data(y); e2.run(5, True)
+        assert np.array_equal(h1, e2.history()) and np.array_equal(f1, e2.free_energy())
+    T, S = 200, 3
+    _, _, ys = workloads.generate_hgf_batch(T, S, seed=8)
+    gb, _ = graph.hgf_step_graph(1.0, 0.0, 0.04, 0.01)
+    g, keep = gb.tables(n_replicas=S, n_observations=T)
+    e1 = graph.create_vmp_engine_from_graph(g)
+    e1.set_data(ys); e1.run(10, True)
+    z1, f1 = e1.history(), e1.free_energy(); e1.close()
+    with rxhip.HGFEngine(T, S, 1.0, 0.0, 0.04, 0.01) as e2:
+        e2.set_data(ys); e2.run(10, True)
+        assert all(np.array_equal(a, b) for a, b in zip(z1, e2.history())) and np.array_equal(f1, e2.free_energy())
