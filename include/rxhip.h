@@ -10,7 +10,10 @@
  * Conventions: plain C, no exceptions cross the ABI, every function returns an rxhip_status
  * (0 = ok).  All matrices are dense row-major IEEE fp64.  The caller owns every host buffer it
  * passes; the engine copies what it needs and owns its device memory until rxhip_destroy.
- * One host thread per handle; handles are independent; no global state.
+ * One host thread per handle; handles are independent.  The only process-wide state is a mutex-protected pool of idle
+ * engine-owned HIP streams and of up to 128 MB of small device blocks per device (stream creation / destruction costs
+ * milliseconds and hipFree ≈0.15 ms on this runtime — more than a whole sweep of the reference's own benchmark sizes);
+ * rxhip_release_cached_memory() returns the parked blocks to the driver.
  */
 #ifndef RXHIP_H
 #define RXHIP_H
@@ -357,6 +360,8 @@ const char* rxhip_status_string(rxhip_status s);
 const char* rxhip_version(void);
 int32_t rxhip_device_count(void); /* number of visible HIP devices (0 if none) */
 rxhip_status rxhip_destroy(rxhip_engine* e);
+/* frees the device blocks parked by destroyed engines (see the note on process-wide state at the top) */
+rxhip_status rxhip_release_cached_memory(void);
 
 #ifdef __cplusplus
 }

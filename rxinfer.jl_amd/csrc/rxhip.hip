@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -148,6 +149,11 @@ __global__ void k_transpose_rows(const double* __restrict__ in, double* __restri
 
 // ------------------------------------------------------------------------------------------
 struct rxhip_engine {
+    // one device allocation holds every buffer of a state-space engine (creation / destruction cost two driver calls
+    // instead of ≈40: 2.9 ms -> see DESIGN §6c); pointers inside it are never freed individually
+    char* arena = nullptr;
+    size_t arena_bytes = 0;
+    bool in_arena(const void* q) const { return arena && (const char*)q >= arena && (const char*)q < arena + arena_bytes; }
     // description
     int d = 0, dy = 0;
     long long T = 0, n_chains = 0;
@@ -203,6 +209,122 @@ struct rxhip_engine {
     uint64_t k_n[RXHIP_K_COUNT] = {};
     std::string err = "";
 };
+
+
+// ---- idle-stream pool: on this runtime hipStreamCreate costs 1.5–9 ms and hipStreamDestroy ≈1.1 ms, which made
+// engine construction + destruction ≈2.9 ms whatever the problem size.  Engine-owned streams are therefore recycled
+// per device (drained before they are parked).  This is the library's only process-wide state; it is mutex-protected.
+struct StreamPool {
+    std::mutex m;
+    std::vector<std::pair<int, hipStream_t>> idle;
+};
+static StreamPool& stream_pool() {
+    static StreamPool* p = new StreamPool;  // intentionally leaked: no destruction-order hazards at process exit
+    return *p;
+}
+static hipError_t stream_acquire(int device, hipStream_t* out) {
+    {
+        StreamPool& sp = stream_pool();
+        std::lock_guard<std::mutex> g(sp.m);
+        for (size_t i = 0; i < sp.idle.size(); ++i)
+            if (sp.idle[i].first == device) {
+                *out = sp.idle[i].second;
+                sp.idle.erase(sp.idle.begin() + (long)i);
+                return hipSuccess;
+            }
+    }
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+// Small arenas (≤ 64 MB) are parked the same way — hipFree of a multi-megabyte block costs ≈120–170 µs, more than a whole
+// sweep of the reference's own benchmark sizes.  At most 4 blocks / 128 MB are kept; rxhip_release_cached_memory() frees them.
+struct ArenaPool {
+    struct Blk { int device; char* p; size_t bytes; };
+    std::mutex m;
+    std::vector<Blk> idle;
+    size_t total = 0;
+};
+static ArenaPool& arena_pool() {
+    static ArenaPool* p = new ArenaPool;
+    return *p;
+}
+static char* arena_acquire(int device, size_t need, size_t* got) {
+    ArenaPool& ap = arena_pool();
+    std::lock_guard<std::mutex> g(ap.m);
+    for (size_t i = 0; i < ap.idle.size(); ++i)
+        if (ap.idle[i].device == device && ap.idle[i].bytes >= need && ap.idle[i].bytes <= 2 * need + (1 << 20)) {
+            char* p = ap.idle[i].p;
+            *got = ap.idle[i].bytes;
+            ap.total -= ap.idle[i].bytes;
+            ap.idle.erase(ap.idle.begin() + (long)i);
+            return p;
+        }
+    return nullptr;
+}
+static void arena_release(int device, char* p, size_t bytes) {
+    if (bytes > ((size_t)64 << 20)) {
+        (void)hipFree(p);
+        return;
+    }
+    std::vector<char*> evict;
+    {
+        ArenaPool& ap = arena_pool();
+        std::lock_guard<std::mutex> g(ap.m);
+        while (!ap.idle.empty() && (ap.idle.size() >= 4 || ap.total + bytes > ((size_t)128 << 20))) {  // least recently parked first
+            evict.push_back(ap.idle.front().p);
+            ap.total -= ap.idle.front().bytes;
+            ap.idle.erase(ap.idle.begin());
+        }
+        ap.idle.push_back({device, p, bytes});
+        ap.total += bytes;
+    }
+    for (char* q : evict) (void)hipFree(q);
+}
+static void stream_release(int device, hipStream_t s) {
+    (void)hipStreamSynchronize(s);
+    StreamPool& sp = stream_pool();
+    {
+        std::lock_guard<std::mutex> g(sp.m);
+        if (sp.idle.size() < 32) {
+            sp.idle.emplace_back(device, s);
+            return;
+        }
+    }
+    (void)hipStreamDestroy(s);
+}
+
+// ---- arena planning: register every buffer, then one hipMalloc, one upload of the table block, one memset ----
+struct ArenaPlan {
+    struct Item { void** pp; size_t bytes, off; const void* src; bool zero; };
+    std::vector<Item> up, zr, pl;  // uploaded tables | zero-initialised | plain
+    template <class T> void upload(T** pp, const void* src, size_t bytes) { up.push_back({(void**)pp, bytes, 0, src, false}); }
+    template <class T> void zeroed(T** pp, size_t bytes) { zr.push_back({(void**)pp, bytes, 0, nullptr, true}); }
+    template <class T> void plain(T** pp, size_t bytes) { pl.push_back({(void**)pp, bytes, 0, nullptr, false}); }
+    static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
+};
+static rxhip_status fail(rxhip_engine* e, rxhip_status s, const char* fmt, ...);
+static rxhip_status arena_commit(rxhip_engine* e, ArenaPlan& ap) {
+    size_t off = 0;
+    for (auto* grp : {&ap.up, &ap.zr, &ap.pl})
+        for (auto& it : *grp) { it.off = off; off += ArenaPlan::al(it.bytes ? it.bytes : 1); }
+    const size_t up_end = ap.zr.empty() ? (ap.pl.empty() ? off : ap.pl.front().off) : ap.zr.front().off;
+    const size_t zr_end = ap.pl.empty() ? off : ap.pl.front().off;
+    size_t got = off;
+    e->arena = arena_acquire(e->device, off, &got);
+    if (!e->arena && hipMalloc(&e->arena, off) != hipSuccess) { e->arena = nullptr; return fail(e, RXHIP_ERR_HIP, "hipMalloc of %zu bytes failed", off); }
+    e->arena_bytes = got;
+    for (auto* grp : {&ap.up, &ap.zr, &ap.pl})
+        for (auto& it : *grp) *it.pp = e->arena + it.off;
+    if (up_end) {
+        std::vector<char> stage(up_end, 0);
+        for (auto& it : ap.up) std::memcpy(stage.data() + it.off, it.src, it.bytes);
+        if (hipMemcpyAsync(e->arena, stage.data(), up_end, hipMemcpyHostToDevice, e->stream) != hipSuccess) return fail(e, RXHIP_ERR_HIP, "table upload failed");
+        if (zr_end > up_end && hipMemsetAsync(e->arena + up_end, 0, zr_end - up_end, e->stream) != hipSuccess) return fail(e, RXHIP_ERR_HIP, "memset failed");
+        if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, RXHIP_ERR_HIP, "table upload failed");  // `stage` dies here
+    } else if (zr_end > up_end) {
+        if (hipMemsetAsync(e->arena + up_end, 0, zr_end - up_end, e->stream) != hipSuccess) return fail(e, RXHIP_ERR_HIP, "memset failed");
+    }
+    return RXHIP_OK;
+}
 
 static rxhip_status fail(rxhip_engine* e, rxhip_status s, const char* fmt, ...) {
     if (e) {
@@ -744,24 +866,40 @@ static void free_all(rxhip_engine* e) {
     double** bufs[] = {&e->d_vtab, &e->d_scan, &e->d_filt, &e->d_mean, &e->d_cov, &e->d_cst, &e->d_tab, &e->d_agg, &e->d_elem,
                        &e->d_fstart, &e->d_beta, &e->d_fe_part, &e->d_fe_chain, &e->d_fe_total};
     for (auto b : bufs)
-        if (*b) { (void)hipFree(*b); *b = nullptr; }
-    if (e->own_y && e->d_y) (void)hipFree(e->d_y);
+        if (*b) { if (!e->in_arena(*b)) (void)hipFree(*b); *b = nullptr; }
+    if (e->own_y && e->d_y && !e->in_arena(e->d_y)) (void)hipFree(e->d_y);
     e->d_y = nullptr;
-    if (e->d_chain_model) (void)hipFree(e->d_chain_model);
-    if (e->d_status) (void)hipFree(e->d_status);
-    if (e->d_fe_blocks) (void)hipFree(e->d_fe_blocks);
+    if (e->d_chain_model && !e->in_arena(e->d_chain_model)) (void)hipFree(e->d_chain_model);
+    if (e->d_status && !e->in_arena(e->d_status)) (void)hipFree(e->d_status);
+    if (e->d_fe_blocks && !e->in_arena(e->d_fe_blocks)) (void)hipFree(e->d_fe_blocks);
     for (double** b : {&e->g.d_resp, &e->g.d_par, &e->g.d_drv, &e->g.d_prior, &e->g.d_init, &e->g.d_partial, &e->g.d_totals,
                        &e->g.d_hist, &e->g.d_fe})
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&e->h.d_out, &e->h.d_fe_series, &e->h.d_gh, &e->h.d_fe_total})
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend})
-        if (*b) { (void)hipFree(*b); *b = nullptr; }
+        if (*b) { if (!e->in_arena(*b)) (void)hipFree(*b); *b = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     e->pending.clear();
     e->pool.clear();
-    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);  // nothing of this engine may still be running on its buffers
+    if (e->own_stream && e->stream) stream_release(e->device, e->stream);
+    e->stream = nullptr;
+    if (e->arena) arena_release(e->device, e->arena, e->arena_bytes);
+    e->arena = nullptr;
+}
+
+rxhip_status rxhip_release_cached_memory(void) {
+    ArenaPool& ap = arena_pool();
+    std::lock_guard<std::mutex> g(ap.m);
+    for (auto& b : ap.idle) {
+        (void)hipSetDevice(b.device);
+        (void)hipFree(b.p);
+    }
+    ap.idle.clear();
+    ap.total = 0;
+    return RXHIP_OK;
 }
 
 rxhip_status rxhip_destroy(rxhip_engine* e) {
@@ -807,7 +945,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     if (ds->stream) {
         e->stream = (hipStream_t)ds->stream;
     } else {
-        HIPCHK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIPCHK(e, stream_acquire(e->device, &e->stream));
         e->own_stream = true;
     }
 
@@ -823,9 +961,16 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         long long S_target = ds->segments > 0 ? ds->segments
                              : dense ? (256 + e->n_chains - 1) / e->n_chains   // one workgroup per CU
                                      : (131072 + e->n_chains - 1) / e->n_chains;
+        if (ds->segments <= 0 && !dense) {
+            // few chains: the lanes do not fill the machine and the sweep is a latency chain of L steps through three
+            // kernels (≈0.86 µs per step, fitted at d = 2) plus S sequential boundary steps (≈0.26 µs each):
+            // S* = sqrt(steps · 0.86 / 0.26).  (measured, one chain, d = 2, T = 50 000: 1.18 ms with L = 16, S = 3125.)
+            const long long s_lat = (long long)std::ceil(std::sqrt(3.3 * (double)steps));
+            if (S_target > s_lat) S_target = s_lat;
+        }
         if (S_target < 1) S_target = 1;
         long long L = (steps + S_target - 1) / S_target;
-        const long long Lmin = ds->segments > 0 ? 1 : (dense ? 8 : 16);
+        const long long Lmin = ds->segments > 0 ? 1 : 8;
         if (L < Lmin) L = Lmin;
         if (L > steps) L = steps;
         e->L = L;
@@ -841,29 +986,24 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         DENSE_DISPATCH(e->nt, prepare(e->d, e->dy) == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
         if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1), D = (size_t)e->d;
-        HIPCHK(e, hipMalloc(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64)));
-        HIPCHK(e, hipMalloc(&e->d_cst, sizeof(double) * cst.size()));
-        HIPCHK(e, hipMalloc(&e->d_tab, sizeof(double) * tab.size()));
-        HIPCHK(e, hipMalloc(&e->d_scanm, sizeof(double) * scanm.size()));
-        HIPCHK(e, hipMemcpy(e->d_cst, cst.data(), sizeof(double) * cst.size(), hipMemcpyHostToDevice));
-        HIPCHK(e, hipMemcpy(e->d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
-        HIPCHK(e, hipMemcpy(e->d_scanm, scanm.data(), sizeof(double) * scanm.size(), hipMemcpyHostToDevice));
-        HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * C * T * dense_rec(e->nt)));
-        HIPCHK(e, hipMalloc(&e->d_vend, sizeof(double) * C * Sg * dense_tri(e->nt)));
-        HIPCHK(e, hipMalloc(&e->d_mean, sizeof(double) * T * C * D));
-        HIPCHK(e, hipMalloc(&e->d_cov, sizeof(double) * T * C * D * D));
-        HIPCHK(e, hipMalloc(&e->d_elem, sizeof(double) * C * Sg * 2 * D));
-        HIPCHK(e, hipMalloc(&e->d_fstart_m, sizeof(double) * C * Sg * D));
-        HIPCHK(e, hipMalloc(&e->d_beta_xi, sizeof(double) * C * (Sg + 1) * D));
-        HIPCHK(e, hipMalloc(&e->d_fe_part, sizeof(double) * (Sg + 1) * C));
-        HIPCHK(e, hipMalloc(&e->d_fe_chain, sizeof(double) * C));
+        ArenaPlan ap;
+        ap.upload(&e->d_cst, cst.data(), sizeof(double) * cst.size());
+        ap.upload(&e->d_tab, tab.data(), sizeof(double) * tab.size());
+        ap.upload(&e->d_scanm, scanm.data(), sizeof(double) * scanm.size());
+        ap.zeroed(&e->d_status, sizeof(int));
+        ap.zeroed(&e->d_fe_part, sizeof(double) * (Sg + 1) * C);
         e->fe_total_cap = 16;
-        HIPCHK(e, hipMalloc(&e->d_fe_total, sizeof(double) * e->fe_total_cap));
-        HIPCHK(e, hipMalloc(&e->d_status, sizeof(int)));
-        HIPCHK(e, hipMemset(e->d_status, 0, sizeof(int)));
-        HIPCHK(e, hipMemset(e->d_fe_part, 0, sizeof(double) * (Sg + 1) * C));
-        HIPCHK(e, hipMemset(e->d_fe_total, 0, sizeof(double) * e->fe_total_cap));
-        return RXHIP_OK;
+        ap.zeroed(&e->d_fe_total, sizeof(double) * e->fe_total_cap);
+        ap.plain(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64));
+        ap.plain(&e->d_filt, sizeof(double) * C * T * dense_rec(e->nt));
+        ap.plain(&e->d_vend, sizeof(double) * C * Sg * dense_tri(e->nt));
+        ap.plain(&e->d_mean, sizeof(double) * T * C * D);
+        ap.plain(&e->d_cov, sizeof(double) * T * C * D * D);
+        ap.plain(&e->d_elem, sizeof(double) * C * Sg * 2 * D);
+        ap.plain(&e->d_fstart_m, sizeof(double) * C * Sg * D);
+        ap.plain(&e->d_beta_xi, sizeof(double) * C * (Sg + 1) * D);
+        ap.plain(&e->d_fe_chain, sizeof(double) * C);
+        return arena_commit(e, ap);
     }
     // per-model tables
     const size_t NP = (size_t)e->d + (size_t)e->d * (e->d + 1) / 2;
@@ -878,41 +1018,36 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     }
     e->h_cst0.assign(cst.begin(), cst.begin() + vt->cst_size);
     const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1);
-    HIPCHK(e, hipMalloc(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64)));
-    HIPCHK(e, hipMalloc(&e->d_cst, sizeof(double) * cst.size()));
-    HIPCHK(e, hipMalloc(&e->d_tab, sizeof(double) * tab.size()));
-    HIPCHK(e, hipMalloc(&e->d_agg, sizeof(double) * agg.size()));
-    HIPCHK(e, hipMemcpy(e->d_cst, cst.data(), sizeof(double) * cst.size(), hipMemcpyHostToDevice));
-    HIPCHK(e, hipMemcpy(e->d_tab, tab.data(), sizeof(double) * tab.size(), hipMemcpyHostToDevice));
-    HIPCHK(e, hipMemcpy(e->d_agg, agg.data(), sizeof(double) * agg.size(), hipMemcpyHostToDevice));
-    if (ds->chain_model && !e->uniform) {
-        HIPCHK(e, hipMalloc(&e->d_chain_model, sizeof(int) * C));
-        HIPCHK(e, hipMemcpy(e->d_chain_model, ds->chain_model, sizeof(int) * C, hipMemcpyHostToDevice));
-    }
-    if (e->uniform && !scan.empty()) {
-        HIPCHK(e, hipMalloc(&e->d_scan, sizeof(double) * scan.size()));
-        HIPCHK(e, hipMemcpy(e->d_scan, scan.data(), sizeof(double) * scan.size(), hipMemcpyHostToDevice));
-    }
+    ArenaPlan ap;
+    ap.upload(&e->d_cst, cst.data(), sizeof(double) * cst.size());
+    ap.upload(&e->d_tab, tab.data(), sizeof(double) * tab.size());
+    ap.upload(&e->d_agg, agg.data(), sizeof(double) * agg.size());
+    if (ds->chain_model && !e->uniform) ap.upload(&e->d_chain_model, ds->chain_model, sizeof(int) * C);
+    if (e->uniform && !scan.empty()) ap.upload(&e->d_scan, scan.data(), sizeof(double) * scan.size());
+    ap.zeroed(&e->d_status, sizeof(int));
+    ap.zeroed(&e->d_fe_part, sizeof(double) * (Sg + 1) * C);
+    e->fe_total_cap = 16;
+    ap.zeroed(&e->d_fe_total, sizeof(double) * e->fe_total_cap);
+    ap.plain(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64));
     if (e->uniform) {  // mean part per chain + one covariance copy per model (see lgssm_kernels.hpp store_filt_sh)
         const size_t MP2 = ((size_t)e->d + 1) / 2;
-        HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * T * MP2 * 2 * (((C + 63) / 64) * 64)));
-        HIPCHK(e, hipMalloc(&e->d_vtab, sizeof(double) * T * ((size_t)e->d * (e->d + 1) / 2)));
+        ap.plain(&e->d_filt, sizeof(double) * T * MP2 * 2 * (((C + 63) / 64) * 64));
+        ap.plain(&e->d_vtab, sizeof(double) * T * ((size_t)e->d * (e->d + 1) / 2));
     } else
-        HIPCHK(e, hipMalloc(&e->d_filt, sizeof(double) * T * NP2 * 2 * (((C + 63) / 64) * 64)));
-    HIPCHK(e, hipMalloc(&e->d_mean, sizeof(double) * T * C * e->d));
-    HIPCHK(e, hipMalloc(&e->d_cov, sizeof(double) * T * C * e->d * e->d));
-    HIPCHK(e, hipMalloc(&e->d_elem, sizeof(double) * Sg * 2 * e->d * C));
-    HIPCHK(e, hipMalloc(&e->d_fstart, sizeof(double) * Sg * NP * C));
-    HIPCHK(e, hipMalloc(&e->d_beta, sizeof(double) * (Sg + 1) * NP * C));
-    HIPCHK(e, hipMalloc(&e->d_fe_part, sizeof(double) * (Sg + 1) * C));
-    HIPCHK(e, hipMalloc(&e->d_fe_chain, sizeof(double) * C));
-    e->fe_total_cap = 16;
-    HIPCHK(e, hipMalloc(&e->d_fe_total, sizeof(double) * e->fe_total_cap));
-    HIPCHK(e, hipMalloc(&e->d_status, sizeof(int)));
-    HIPCHK(e, hipMemset(e->d_status, 0, sizeof(int)));
-    HIPCHK(e, hipMemset(e->d_fe_part, 0, sizeof(double) * (Sg + 1) * C));
-    HIPCHK(e, hipMemset(e->d_fe_total, 0, sizeof(double) * e->fe_total_cap));
-    return RXHIP_OK;
+        ap.plain(&e->d_filt, sizeof(double) * T * NP2 * 2 * (((C + 63) / 64) * 64));
+    ap.plain(&e->d_mean, sizeof(double) * T * C * e->d);
+    ap.plain(&e->d_cov, sizeof(double) * T * C * e->d * e->d);
+    ap.plain(&e->d_elem, sizeof(double) * Sg * 2 * e->d * C);
+    ap.plain(&e->d_fstart, sizeof(double) * Sg * NP * C);
+    ap.plain(&e->d_beta, sizeof(double) * (Sg + 1) * NP * C);
+    ap.plain(&e->d_fe_chain, sizeof(double) * C);
+    // observations of small problems live in the arena too (large ones are allocated on first set_data, or never when
+    // the caller hands over a device buffer)
+    if (sizeof(double) * T * C * e->dy <= ((size_t)64 << 20)) {
+        ap.plain(&e->d_y, sizeof(double) * T * C * e->dy);
+        e->own_y = true;
+    }
+    return arena_commit(e, ap);
 }
 
 
@@ -950,7 +1085,7 @@ rxhip_status rxhip_gmm_create(const rxhip_gmm_desc* ds, rxhip_engine** out) {
     HIPCHK(e, hipSetDevice(e->device));
     if (ds->stream) e->stream = (hipStream_t)ds->stream;
     else {
-        HIPCHK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIPCHK(e, stream_acquire(e->device, &e->stream));
         e->own_stream = true;
     }
     const int KT = e->g.KT, K = e->g.K;
@@ -1119,7 +1254,7 @@ rxhip_status rxhip_hgf_create(const rxhip_hgf_desc* ds, rxhip_engine** out) {
     HIPCHK(e, hipSetDevice(e->device));
     if (ds->stream) e->stream = (hipStream_t)ds->stream;
     else {
-        HIPCHK(e, hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+        HIPCHK(e, stream_acquire(e->device, &e->stream));
         e->own_stream = true;
     }
     double gh[64] = {0}, gx[32], gw[32];
@@ -1272,8 +1407,9 @@ static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
         return fail(e, RXHIP_ERR_BADARG, "set_data: unknown layout %d", layout);
     HIPCHK(e, hipSetDevice(e->device));
+    if (e->n_chains == 1) layout = RXHIP_LAYOUT_TIME_CHAIN;  // one chain: the two layouts coincide
     if (src_on_device && layout == RXHIP_LAYOUT_TIME_CHAIN) {  // zero-copy
-        if (e->own_y && e->d_y) HIPCHK(e, hipFree(e->d_y));
+        if (e->own_y && e->d_y && !e->in_arena(e->d_y)) HIPCHK(e, hipFree(e->d_y));
         e->d_y = const_cast<double*>(src);
         e->own_y = false;
         e->have_data = true;
@@ -1366,7 +1502,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     HIPCHK(e, hipSetDevice(e->device));
     if (iterations > e->fe_total_cap) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
-        HIPCHK(e, hipFree(e->d_fe_total));
+        if (!e->in_arena(e->d_fe_total)) HIPCHK(e, hipFree(e->d_fe_total));
         e->d_fe_total = nullptr;
         e->fe_total_cap = iterations;
         HIPCHK(e, hipMalloc(&e->d_fe_total, sizeof(double) * e->fe_total_cap));
@@ -1521,7 +1657,7 @@ rxhip_status rxhip_get_marginals_device(rxhip_engine* e, int32_t var_id, const d
 
 static rxhip_status copy_out(rxhip_engine* e, const double* dsrc, double* host, int k, int32_t layout) {
     const size_t n = (size_t)e->T * e->n_chains * k;
-    if (layout == RXHIP_LAYOUT_TIME_CHAIN) {
+    if (layout == RXHIP_LAYOUT_TIME_CHAIN || e->n_chains == 1) {
         HIPCHK(e, hipMemcpy(host, dsrc, sizeof(double) * n, hipMemcpyDeviceToHost));
         return RXHIP_OK;
     }

@@ -93,6 +93,7 @@ SYMBOLS = [
     ("rxhip_run_filter", ctypes.c_int32, [_H, ctypes.c_int32]),
     ("rxhip_run_filter_async", ctypes.c_int32, [_H, ctypes.c_int32]),
     ("rxhip_sync", ctypes.c_int32, [_H]),
+    ("rxhip_release_cached_memory", ctypes.c_int32, []),
     ("rxhip_get_marginals", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_int32]),
     ("rxhip_get_marginals_device", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p),
                                                     ctypes.POINTER(ctypes.c_void_p)]),
