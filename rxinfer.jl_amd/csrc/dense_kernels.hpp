@@ -79,7 +79,6 @@ struct DenseParams {
     double* beta_xi;      // [chain][S+1][d]    ξβ at b_s
     double* fe_part;      // [S+1][chain]
     int* status;
-    int ablate;           // diagnostics only (RXHIP_ABLATE): bit0 skip inverses, bit1 skip contractions, bit2 skip matvecs, bit3 skip stores, bit4 skip FE dots
 };
 
 template <int NT>
@@ -645,15 +644,15 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
         if (tid < dy) yv[tid] = p.y[(t * p.n_chains + chain) * dy + tid];
         // `*`_A(:out): T = A V ; Vp = T A' + P ;  mp = A m
         acc_zero<NT>(a);
-        if (!(p.ablate & 2)) mm_acc<NT, false, false>(a, A, D, M0, LD, w, lane);
+        mm_acc<NT, false, false>(a, A, D, M0, LD, w, lane);
         acc_store<NT>(a, M1, LD, w, lane);
-        if (!(p.ablate & 4)) matvec_gT(mp, cst + c.oAT, D, D, m, nullptr, 0.0, tid);
+        matvec_gT(mp, cst + c.oAT, D, D, m, nullptr, 0.0, tid);
         __syncthreads();
         Acc<NT> lam;
         acc_load<NT>(lam, cst + c.oP, D, w, lane);
-        if (!(p.ablate & 2)) mm_acc<NT, false, true>(lam, M1, LD, A, D, w, lane);
+        mm_acc<NT, false, true>(lam, M1, LD, A, D, w, lane);
         // weightedmean_precision of the forward message: Λp = Vp⁻¹
-        if (!(p.ablate & 1)) ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
+        ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
         acc_store<NT>(lam, M2, LD, w, lane);
         __syncthreads();
         // smoother gain and residual of the previous time index (t − 1): G = T' Λp,  C = V_f − G T
@@ -675,25 +674,25 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
             acc_store_tri<NT>(a, rec + D, w, lane);
         }
         // product with the `*`_B(:in) message: Λf = Λp + B'Q⁻¹B, ξf = Λp mp + G y
-        if (!(p.ablate & 4)) {
+        {
             matvec_lds(xp, M2, LD, D, D, mp, nullptr, 0.0, tid);
             matvec_gT(qy, cst + c.oQI, dy, dy, yv, nullptr, 0.0, tid);  // Q⁻¹ symmetric
         }
         __syncthreads();
-        if (!(p.ablate & 4)) matvec_gT(xf, cst + c.oGT, D, dy, yv, xp, 1.0, tid);
+        matvec_gT(xf, cst + c.oGT, D, dy, yv, xp, 1.0, tid);
         acc_add_mat<NT>(lam, cst + c.oLOBS, D, w, lane, 1.0);
         // mean_cov of the product: Vf = Λf⁻¹, mf = Vf ξf
-        if (!(p.ablate & 1)) ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
+        ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
         acc_store<NT>(lam, M0, LD, w, lane);
         __syncthreads();
-        if (!(p.ablate & 4)) matvec_lds(m, M0, LD, D, D, xf, nullptr, 0.0, tid);
+        matvec_lds(m, M0, LD, D, D, xf, nullptr, 0.0, tid);
         __syncthreads();
         if (p.filter) {  // q(x_t | y_1..t) is the marginal of the one-step graph
             if (tid < D) p.mean[(t * p.n_chains + chain) * D + tid] = m[tid];
             acc_store<NT>(lam, p.cov + (t * p.n_chains + chain) * MM, D, w, lane);
         } else if (tid < D)
             p.filt[(chain * p.T + t) * C::REC + tid] = m[tid];
-        if (FE && !(p.ablate & 16)) {
+        if (FE) {
             double dots[3];
             block_dot3(qy, yv, dy, xf, m, D, xp, mp, D, red, tid, 64 * NT, dots);
             acc_quad += cst[c.oC0] + dots[0] - dots[1] + dots[2];

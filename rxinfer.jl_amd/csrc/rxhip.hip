@@ -1541,7 +1541,6 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
         dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;
-        { const char* ab = getenv("RXHIP_ABLATE"); dp.ablate = ab ? atoi(ab) : 0; }
         dp.filter = p.filter;
     }
     for (int it = 0; it < iterations; ++it) {

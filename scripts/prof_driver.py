@@ -92,6 +92,4 @@ else:
 dt = time.perf_counter() - t0
 print({"mode": "filter" if a.filter else "smooth", "ms_per_step": dt / a.steps * 1e3, "kernels": {k: round(v["ms_avg"], 4) for k, v in eng.kernel_times().items()},
        "schedule": eng.schedule()})
-import os
-if os.environ.get("RXHIP_ABLATE"): print("fe(debug)", eng.free_energy()[-1], "segments", eng.schedule())
 eng.close()
