@@ -70,27 +70,37 @@ def sharded_infer(run_shard, y_chain_major, dist=None):
 
 # ---- mean-field mixture: the path's one real exchange step ------------------------------------------------
 class DeviceMixtureShard:
-    """Adapter of a `GMMEngine` holding this rank's points to the split-phase protocol of `sharded_mixture_vmp`."""
+    """Adapter of a `GMMEngine` holding this rank's points to the split-phase protocol of `sharded_mixture_vmp`.
+
+    If the engine was created on torch's CURRENT stream (`GMMEngine(..., stream=torch.cuda.current_stream().cuda_stream)`)
+    the three steps of an iteration — accumulate kernel, RCCL all-reduce, update kernel — are simply enqueued in order on
+    that one stream and the host never waits.  Otherwise the host synchronises around the collective."""
 
     def __init__(self, engine):
         self.engine = engine
+        self._stats = None
+
+    def _same_stream(self):
+        import torch
+
+        return int(self.engine.stream() or 0) == int(torch.cuda.current_stream().cuda_stream or 0)
 
     def begin(self, iterations):
         self.engine.begin_run(iterations)
+        self._stats = self.engine.statistics_tensor()  # aliases the device buffer (fixed for the engine's lifetime)
 
     def accumulate(self):
         """Streams the shard; returns a tensor ALIASING the 3K'+1 statistics (all-reduced in place)."""
-        import torch
-
         self.engine.accumulate()
-        # the statistics are produced on the engine's stream; the collective must be ordered after them
-        self.engine.sync()
-        return self.engine.statistics_tensor()
+        if not self._same_stream():
+            self.engine.sync()  # the statistics are produced on the engine's stream; the collective must come after them
+        return self._stats
 
     def update(self, want_fe):
         import torch
 
-        torch.cuda.current_stream().synchronize()  # the in-place all-reduce (torch's stream) before the update kernel
+        if not self._same_stream():
+            torch.cuda.current_stream().synchronize()  # the in-place all-reduce (torch's stream) before the update kernel
         self.engine.update(want_fe)
 
 

@@ -101,17 +101,20 @@ def main():
         mus = np.arange(1, K + 1) * 10.0 - 80.0
         rng = np.random.default_rng(12345 + rank)
         y = mus[rng.integers(0, K, size=N)] + rng.standard_normal(N)
+        stream = torch.cuda.Stream(device=device)  # engine kernels and the RCCL all-reduce share one stream: no host waits
         eng = rxhip.GMMEngine(N, mus + 1.5, np.full(K, 1e3), np.full(K, 0.01), np.full(K, 0.01), np.ones(K), mus + 1.5,
-                              np.full(K, 10.0), np.ones(K), np.ones(K), np.ones(K), device=local_rank)
+                              np.full(K, 10.0), np.ones(K), np.ones(K), np.ones(K), device=local_rank, stream=stream.cuda_stream)
         eng.set_data(y)
         shard = rd.DeviceMixtureShard(eng)
-        eng.begin_run(a.warmup + steps)
+        with torch.cuda.stream(stream):
+            shard.begin(a.warmup + steps)
 
         def step():
-            stats = shard.accumulate()
-            if dist is not None:
-                dist.all_reduce(stats)
-            shard.update(True)
+            with torch.cuda.stream(stream):
+                stats = shard.accumulate()
+                if dist is not None:
+                    dist.all_reduce(stats)
+                shard.update(True)
 
         dt = timed(step, steps, eng.sync)
         fe = eng.free_energy()
