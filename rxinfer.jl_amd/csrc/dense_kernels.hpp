@@ -208,43 +208,67 @@ __device__ __forceinline__ void mm_acc(Acc<NT>& c, const double* X, int ldx, con
 // ---- SPD inverse, in place on the accumulator registers (restates FastCholesky.cholinv for large blocks) ----
 // Block sweep operator, FOUR pivots per barrier.  The rows K = {16·pb + q + 4i, i = 0..3} of tile-row pb live in
 // the same 16 lanes of wave pb (lane>>4 == q, registers i = 0..3), so one LDS publish delivers four pivot rows
-// R (4 × D).  With D4 = R[:, K] (the 4×4 pivot block) every thread applies
+// R (4 × D).  With D4 = R[:, K] (the 4×4 pivot block) the step
 //     A_JJ <- A_JJ − R_J' D4⁻¹ R_J,     A_KJ <- D4⁻¹ R_J,     A_KK <- −D4⁻¹
-// to its 4 × NT elements; D4⁻¹ (SPD, via the LDL' inverse of lgssm_kernels.hpp) is recomputed redundantly by
-// every thread, which is cheaper than a second barrier.  After the D/4 blocks the array holds −A⁻¹ (any pivot
+// is a rank-4 update of every 16×16 tile: one v_mfma_f64_16x16x4_f64 per tile with suitably modified operands (see
+// below) instead of ≈190 vector FMAs per thread; D4⁻¹ (SPD, via the LDL' inverse of lgssm_kernels.hpp) is recomputed
+// redundantly by every thread, which is cheaper than a second barrier.  After the D/4 blocks the array holds −A⁻¹ (any pivot
 // order is valid for SPD matrices).  det A = Π det D4.  16 barriers per 64×64 inverse instead of 64.
 // rowbuf: 2 buffers × D columns × 4 rows (layout [col][4]: a thread fetches the four pivot-row values of a
 // column with two ds_read_b128).
+// 4×4 SPD inverse by cofactors (2×2 minors, Laplace expansion): every product is independent, so the dependent chain
+// is ≈8 fp64 operations + one reciprocal instead of the four sequential pivots of an LDL' — this inverse sits on the
+// critical path of every sweep round.  Positive definiteness = positivity of the four leading minors.
+__device__ __forceinline__ bool spd_inv4_cof(const Sym<4>& A, Sym<4>& B, double& det) {
+    const double a00 = A(0, 0), a10 = A(1, 0), a11 = A(1, 1), a20 = A(2, 0), a21 = A(2, 1), a22 = A(2, 2), a30 = A(3, 0),
+                 a31 = A(3, 1), a32 = A(3, 2), a33 = A(3, 3);
+    const double s0 = a00 * a11 - a10 * a10, s1 = a00 * a21 - a10 * a20, s2 = a00 * a31 - a10 * a30;
+    const double s3 = a10 * a21 - a11 * a20, s4 = a10 * a31 - a11 * a30, s5 = a20 * a31 - a21 * a30;
+    const double c5 = a22 * a33 - a32 * a32, c4 = a21 * a33 - a31 * a32, c3 = a21 * a32 - a31 * a22;
+    const double c2 = a20 * a33 - a30 * a32, c1 = a20 * a32 - a30 * a22, c0 = a20 * a31 - a30 * a21;
+    det = (s0 * c5 - s1 * c4 + s2 * c3) + (s3 * c2 - s4 * c1 + s5 * c0);
+    const double m3 = a20 * s3 - a21 * s1 + a22 * s0;  // leading 3×3 minor
+    const bool ok = (a00 > 0.0) && (s0 > 0.0) && (m3 > 0.0) && (det > 0.0);
+    const double id = rcp_pos(det);
+    B(0, 0) = (a11 * c5 - a21 * c4 + a31 * c3) * id;
+    B(1, 0) = (-a10 * c5 + a21 * c2 - a31 * c1) * id;
+    B(1, 1) = (a00 * c5 - a20 * c2 + a30 * c1) * id;
+    B(2, 0) = (a10 * c4 - a11 * c2 + a31 * c0) * id;
+    B(2, 1) = (-a00 * c4 + a10 * c2 - a30 * c0) * id;
+    B(2, 2) = (a30 * s4 - a31 * s2 + a33 * s0) * id;
+    B(3, 0) = (-a10 * c3 + a11 * c1 - a21 * c0) * id;
+    B(3, 1) = (a00 * c3 - a10 * c1 + a20 * c0) * id;
+    B(3, 2) = (-a30 * s3 + a31 * s1 - a32 * s0) * id;
+    B(3, 3) = m3 * id;
+    return ok;
+}
+
 template <int NT, int Q>
 struct Sweep4 {
     static __device__ __forceinline__ void run(Acc<NT>& a, double* rowbuf, int pb, int w, int lane, bool& ok, LogProd& lp) {
+        typedef double v4d __attribute__((ext_vector_type(4)));
         constexpr int D = 16 * NT;
         double* rb = rowbuf + ((pb * 4 + Q) & 1) * 4 * D;
-        const bool rowown = (w == pb) && ((lane >> 4) == Q);
+        const int jl = lane & 15, vl = lane >> 4;
+        const bool rowown = (w == pb) && (vl == Q);
         if (rowown) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                double* dst = rb + (16 * t + (lane & 15)) * 4;
+                double* dst = rb + (16 * t + jl) * 4;
                 reinterpret_cast<double2*>(dst)[0] = make_double2(a.v[t][0], a.v[t][1]);
                 reinterpret_cast<double2*>(dst)[1] = make_double2(a.v[t][2], a.v[t][3]);
             }
         }
         __syncthreads();
-        // the four pivot rows at this thread's columns (rc[u][t]) and rows (rr[u][r])
-        double rc[4][NT], rr[4][4];
+        // the four pivot rows at this thread's columns, rc[u][t] = R[u][16t + jl]
+        double rc[4][NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const double2* src = reinterpret_cast<const double2*>(rb + (16 * t + (lane & 15)) * 4);
+            const double2* src = reinterpret_cast<const double2*>(rb + (16 * t + jl) * 4);
             const double2 x0 = src[0], x1 = src[1];
             rc[0][t] = x0.x; rc[1][t] = x0.y; rc[2][t] = x1.x; rc[3][t] = x1.y;
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const double2* src = reinterpret_cast<const double2*>(rb + (16 * w + (lane >> 4) + 4 * r) * 4);
-            const double2 x0 = src[0], x1 = src[1];
-            rr[0][r] = x0.x; rr[1][r] = x0.y; rr[2][r] = x1.x; rr[3][r] = x1.y;
-        }
-        // pivot block D4[u][v] = R[u][K_v]  (lower triangle), inverse
+        // pivot block D4[u][v] = R[u][K_v]  (lower triangle), inverse — redundantly in every thread (cheaper than a barrier)
         Sym<4> d4, di;
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
@@ -255,57 +279,45 @@ struct Sweep4 {
             for (int u = v; u < 4; ++u) d4(u, v) = col[u];
         }
         double det;
-        ok = spd_inv<4>(d4, di, det) && ok;
+        ok = spd_inv4_cof(d4, di, det) && ok;
         if (w == 0 && lane == 0) lp.mul(det);
-        // wm[v][t] = Σ_u D4⁻¹[v][u] R[u][col t]
-        double wm[4][NT];
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                double sacc = 0.0;
-#pragma unroll
-                for (int u = 0; u < 4; ++u) sacc += di(v, u) * rc[u][t];
-                wm[v][t] = sacc;
-            }
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double sacc = a.v[t][r];
-#pragma unroll
-                for (int v = 0; v < 4; ++v) sacc -= rr[v][r] * wm[v][t];
-                a.v[t][r] = sacc;
-            }
-        // pivot rows: this thread's row K_i is register i (all four registers are pivot rows for the owner lanes)
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) a.v[t][i] = rowown ? wm[i][t] : a.v[t][i];
-        // pivot columns: tile pb, lanes whose column index (lane&15) = Q + 4j
-        const bool colown = ((lane & 15) & 3) == Q;
-        const int jsel = (lane & 15) >> 2;
-        double dsel[4];
+        // The whole sweep step as ONE rank-4 MFMA per 16×16 tile, A ← A + X·Y with
+        //   X[i][v] = −R[v][i] + [i = K_v]        (16 rows of this wave × 4)
+        //   Y[v][j] = (D4⁻¹R)[v][j] − [j = K_c]·D4⁻¹[v][c]      (4 × 16 columns of tile t)
+        // which yields  A_JJ − R_J'D4⁻¹R_J,  A_KJ = D4⁻¹R_J,  A_JK = (D4⁻¹R_J)'  and  A_KK = 2I − D4⁻¹  (the 2I is removed
+        // below): −D4⁻¹ on the pivot block, as the sweep operator requires.
+        // row vl of D4⁻¹ (this lane's k index in the MFMA operand layout)
+        double dv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             double x = di(0, u);
-            x = jsel == 1 ? di(1, u) : x;
-            x = jsel == 2 ? di(2, u) : x;
-            x = jsel == 3 ? di(3, u) : x;
-            dsel[u] = x;
+            x = vl == 1 ? di(1, u) : x;
+            x = vl == 2 ? di(2, u) : x;
+            x = vl == 3 ? di(3, u) : x;
+            dv[u] = x;
         }
+        const double xa = -rb[(16 * w + jl) * 4 + vl] + ((w == pb && jl == Q + 4 * vl) ? 1.0 : 0.0);
+        const bool pcol = (jl & 3) == Q;  // this lane's column of tile pb is the pivot column K_c, c = jl >> 2
+        const int c = jl >> 2;
+        double dvc = dv[0];
+        dvc = c == 1 ? dv[1] : dvc;
+        dvc = c == 2 ? dv[2] : dvc;
+        dvc = c == 3 ? dv[3] : dvc;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const bool cp = colown && (t == pb);
+            double yb = dv[0] * rc[0][t] + dv[1] * rc[1][t] + dv[2] * rc[2][t] + dv[3] * rc[3][t];
+            yb -= (pcol && t == pb) ? dvc : 0.0;
+            v4d acc = {a.v[t][0], a.v[t][1], a.v[t][2], a.v[t][3]};
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb, acc, 0, 0, 0);
+            a.v[t][0] = acc[0]; a.v[t][1] = acc[1]; a.v[t][2] = acc[2]; a.v[t][3] = acc[3];
+        }
+        // pivot-block diagonal (K_r, K_r): this thread's element (row vl + 4r of wave pb, column jl of tile pb) with
+        // vl = Q and jl = Q + 4r
+        if (rowown && pcol) {  // four lanes of one wave; every other wave branches over this
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                double wr = 0.0;
+            for (int t = 0; t < NT; ++t)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) wr += dsel[u] * rr[u][r];
-                double x = cp ? wr : a.v[t][r];
-                x = (cp && rowown) ? -dsel[r] : x;  // block element (K_r, K_jsel) = −D4⁻¹[r][jsel]
-                a.v[t][r] = x;
-            }
+                for (int r = 0; r < 4; ++r) a.v[t][r] -= (t == pb && c == r) ? 2.0 : 0.0;
         }
         Sweep4<NT, Q + 1>::run(a, rowbuf, pb, w, lane, ok, lp);
     }
