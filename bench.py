@@ -90,16 +90,16 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device visible (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)  # before the process group: every collective (and barrier) runs on THIS rank's GPU
+    device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")  # RCCL on ROCm
-    if not torch.cuda.is_available():
-        sys.exit("bench.py needs an MI355X: no HIP device visible (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=device)  # RCCL on ROCm
 
     mdl = workloads.c1_model()
     T, C = args.T, args.chains

@@ -40,16 +40,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world and world == 1 and a.gpus > 1:
         sys.exit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("needs an MI355X: no HIP device visible (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl")
-    if not torch.cuda.is_available():
-        sys.exit("needs an MI355X: no HIP device visible (the product has no CPU path)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+        dist.init_process_group("nccl", device_id=device)
 
     def timed(step, steps, finish):
         for _ in range(a.warmup):
