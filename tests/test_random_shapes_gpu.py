@@ -1,0 +1,61 @@
+"""Randomised parity sweep: shapes, segmentations, prior conventions, shared / per-chain models, smoothing and filtering,
+drawn from a fixed seed — every case against the oracle at the BASELINE tolerances.  Complements the hand-picked edge
+cases of test_lgssm_gpu.py / test_lgssm_filter_gpu.py (the reference's own tests use one shape per model)."""
+import numpy as np
+import pytest
+
+import rxhip
+import rxoracle
+from rxhip import workloads
+
+pytestmark = pytest.mark.gpu
+
+SHAPES = [(1, 1), (2, 1), (2, 2), (3, 3), (4, 2), (4, 4)]
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / max(np.max(np.abs(b)), 1e-300))
+
+
+def _cases(n, seed):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        d, dy = SHAPES[rng.integers(len(SHAPES))]
+        T = int(rng.choice([1, 2, 3, 17, 64, 65, 130, 257, 400]))
+        C = int(rng.choice([1, 2, 63, 64, 65, 128, 130]))
+        seg = int(rng.choice([0, 0, 1, 2, 5, 31, 1000]))
+        yield dict(i=i, d=d, dy=dy, T=T, C=C, segments=seg, ptt=bool(rng.integers(2)), per_chain=bool(rng.integers(3) == 0),
+                   seed=int(rng.integers(1 << 30)))
+
+
+@pytest.mark.parametrize("case", list(_cases(36, 2024)), ids=lambda c: f"{c['i']}-d{c['d']}x{c['dy']}-T{c['T']}-C{c['C']}-s{c['segments']}-{'ptt' if c['ptt'] else 'x1'}-{'pc' if c['per_chain'] else 'uni'}")
+def test_random_case(case):
+    d, dy, T, C = case["d"], case["dy"], case["T"], case["C"]
+    nm = 3 if case["per_chain"] else 1
+    mdls = [workloads.random_model(d, dy, seed=case["seed"] + k) for k in range(nm)]
+    cm = (np.arange(C) * 7 + 1) % nm
+    y = np.empty((T, C, dy))
+    for c in range(C):
+        y[:, c] = workloads.generate_chain(mdls[cm[c]], T, case["seed"] + 100 + c)[1]
+    stack = lambda k: np.stack([m[k] for m in mdls]) if nm > 1 else mdls[0][k]
+    kw = dict(chain_model=cm) if nm > 1 else {}
+    with rxhip.LGSSMEngine(stack("A"), stack("B"), stack("P"), stack("Q"), stack("m0"), stack("V0"), T=T, n_chains=C,
+                           segments=case["segments"], prior_through_transition=case["ptt"], **kw) as eng:
+        eng.set_data(y)
+        eng.run(1, True)
+        sm, sc = eng.marginals()
+        sfe = eng.free_energy_per_chain()
+        eng.run_filter(True)
+        fm, fc = eng.marginals()
+        ffe = eng.free_energy_per_chain()
+    # check a subset of chains against the oracle (all of them when the batch is small)
+    for c in (range(C) if C <= 4 else [0, 1, C // 2, C - 2, C - 1]):
+        m = mdls[cm[c]]
+        args = (m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], y[:, c])
+        if dy >= d:
+            om, oc, ofe, _ = rxoracle.lgssm_bp(*args, prior_through_transition=case["ptt"])
+        else:  # the reference schedule inverts the singular B'Q⁻¹B: textbook smoother as the checker (see test_oracle.py)
+            om, oc, ofe = rxoracle.lgssm_kalman_rts(*args, prior_through_transition=case["ptt"])
+        assert rel(sm[:, c], om) < 1e-6 and rel(sc[:, c], oc) < 1e-6 and abs(sfe[c] - ofe) < 1e-8 * abs(ofe)
+        hm, hc, hfe, _ = rxoracle.lgssm_filter(*args, case["ptt"])
+        assert rel(fm[:, c], hm) < 1e-6 and rel(fc[:, c], hc) < 1e-6 and abs(ffe[c] - hfe) < 1e-8 * abs(hfe)
