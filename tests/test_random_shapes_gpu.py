@@ -59,3 +59,35 @@ def test_random_case(case):
         assert rel(sm[:, c], om) < 1e-6 and rel(sc[:, c], oc) < 1e-6 and abs(sfe[c] - ofe) < 1e-8 * abs(ofe)
         hm, hc, hfe, _ = rxoracle.lgssm_filter(*args, case["ptt"])
         assert rel(fm[:, c], hm) < 1e-6 and rel(fc[:, c], hc) < 1e-6 and abs(ffe[c] - hfe) < 1e-8 * abs(hfe)
+
+
+def _dense_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        d = int(rng.choice([16, 32, 48, 64]))
+        dy = int(rng.choice([1, 3, d // 2, d - 1, d, 64]))
+        yield dict(i=i, d=d, dy=min(dy, 64), T=int(rng.choice([1, 2, 9, 33, 70])), C=int(rng.choice([1, 2, 3])),
+                   segments=int(rng.choice([0, 1, 4, 100])), ptt=bool(rng.integers(2)), seed=int(rng.integers(1 << 30)))
+
+
+@pytest.mark.parametrize("case", list(_dense_cases(14, 77)), ids=lambda c: f"{c['i']}-d{c['d']}x{c['dy']}-T{c['T']}-C{c['C']}-s{c['segments']}-{'ptt' if c['ptt'] else 'x1'}")
+def test_random_dense_case(case):
+    """d = 16 … 64 (MFMA path) with any observation dimension 1 … 64."""
+    d, dy, T, C = case["d"], case["dy"], case["T"], case["C"]
+    m = workloads.random_model(d, dy, seed=case["seed"])
+    y = workloads.generate_batch(m, T, C, seed0=case["seed"] % 1000)
+    with rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=T, n_chains=C, segments=case["segments"],
+                           prior_through_transition=case["ptt"]) as eng:
+        eng.set_data(y)
+        eng.run(1, True)
+        sm, sc = eng.marginals()
+        sfe = eng.free_energy_per_chain()
+        eng.run_filter(True)
+        fm, fc = eng.marginals()
+        ffe = eng.free_energy_per_chain()
+    for c in range(C):
+        args = (m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], y[:, c])
+        om, oc, ofe = rxoracle.lgssm_kalman_rts(*args, prior_through_transition=case["ptt"])
+        assert rel(sm[:, c], om) < 1e-6 and rel(sc[:, c], oc) < 1e-6 and abs(sfe[c] - ofe) < 1e-8 * abs(ofe)
+        hm, hc, hfe, _ = rxoracle.lgssm_filter(*args, case["ptt"])
+        assert rel(fm[:, c], hm) < 1e-6 and rel(fc[:, c], hc) < 1e-6 and abs(ffe[c] - hfe) < 1e-8 * abs(hfe)
