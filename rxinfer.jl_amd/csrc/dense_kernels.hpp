@@ -67,6 +67,8 @@ struct DenseParams {
     int d, dy;
     const double* y;      // [T][chain][dy]
     double* filt;         // [chain][T][REC]   m_f(t) | C_t = V_f − G_t A V_f (lower tiles) | G_t = V_f A' V_p(t+1)⁻¹ (smoother gain)
+    int d_out;            // state dimension of the MODEL (≤ d): the kernels run on d = 16·NT with decoupled padding dimensions
+                          // (A = 0, P = V0 = I, B = 0 there), only the leading d_out block of every posterior is written
     int filter;           // 1: filtering run (forward pass only; the filtered belief is written as the marginal)
     double* vend;         // [chain][S][TRI]   V_f at the last step of every segment (lower tiles)
     double* mean;         // [T][chain][d]
@@ -123,6 +125,17 @@ __device__ __forceinline__ void acc_store(const Acc<NT>& a, double* M, int ld, i
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) M[acc_row<NT>(w, lane, r) * ld + acc_col<NT>(lane, t)] = a.v[t][r];
+}
+// posterior store: the leading n×n block, row-major with leading dimension n (n = D unless the model was padded)
+template <int NT>
+__device__ __forceinline__ void acc_store_out(const Acc<NT>& a, double* M, int n, int w, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
+            if (i < n && j < n) M[i * n + j] = a.v[t][r];
+        }
 }
 template <int NT>
 __device__ __forceinline__ void acc_add_mat(Acc<NT>& a, const double* M, int ld, int w, int lane, double sgn) {
@@ -559,8 +572,8 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
             Acc<NT> a;
             acc_load<NT>(a, cst + c.oVF1, D, w, lane);
             if (p.T == 1 || p.filter) {
-                if (tid < D) p.mean[(0 * p.n_chains + chain) * D + tid] = v0[tid];
-                acc_store<NT>(a, p.cov + (0 * p.n_chains + chain) * MM, D, w, lane);
+                if (tid < p.d_out) p.mean[(0 * p.n_chains + chain) * p.d_out + tid] = v0[tid];
+                acc_store_out<NT>(a, p.cov + (0 * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
             }
         }
         if (FE) {
@@ -700,8 +713,8 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
         matvec_lds(m, M0, LD, D, D, xf, nullptr, 0.0, tid);
         __syncthreads();
         if (p.filter) {  // q(x_t | y_1..t) is the marginal of the one-step graph
-            if (tid < D) p.mean[(t * p.n_chains + chain) * D + tid] = m[tid];
-            acc_store<NT>(lam, p.cov + (t * p.n_chains + chain) * MM, D, w, lane);
+            if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = m[tid];
+            acc_store_out<NT>(lam, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
         } else if (tid < D)
             p.filt[(chain * p.T + t) * C::REC + tid] = m[tid];
         if (FE) {
@@ -770,8 +783,8 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
         matvec_lds(ms, M2, LD, D, D, u, nullptr, 0.0, tid);
         __syncthreads();
         if (seg == p.S - 1) {
-            if (tid < D) p.mean[(te * p.n_chains + chain) * D + tid] = ms[tid];
-            acc_store<NT>(a, p.cov + (te * p.n_chains + chain) * MM, D, w, lane);
+            if (tid < p.d_out) p.mean[(te * p.n_chains + chain) * p.d_out + tid] = ms[tid];
+            acc_store_out<NT>(a, p.cov + (te * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
         }
     }
     for (long long t = te - 1; t >= tb; --t) {
@@ -796,8 +809,8 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
         __syncthreads();
         if (tid < D) ms[tid] = tmp[tid];
         acc_store<NT>(a, M2, LD, w, lane);
-        if (tid < D) p.mean[(t * p.n_chains + chain) * D + tid] = ms[tid];
-        acc_store<NT>(a, p.cov + (t * p.n_chains + chain) * MM, D, w, lane);
+        if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = ms[tid];
+        acc_store_out<NT>(a, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
         __syncthreads();
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);

@@ -120,8 +120,12 @@ struct Launch {
 
 static const std::vector<LgssmVtbl>& vtbls() {
     static const std::vector<LgssmVtbl> t = {
-        Launch<1, 1>::vtbl(), Launch<2, 1>::vtbl(), Launch<2, 2>::vtbl(), Launch<3, 3>::vtbl(),
-        Launch<4, 2>::vtbl(), Launch<4, 4>::vtbl(),
+        // every state dimension 1..4 with every observation dimension 1..4 (the reference is dimension-generic; d = 5..15
+        // has no schedule yet, d = 16..64 in steps of 16 takes the MFMA path with any dy ≤ 64)
+        Launch<1, 1>::vtbl(), Launch<1, 2>::vtbl(), Launch<1, 3>::vtbl(), Launch<1, 4>::vtbl(),
+        Launch<2, 1>::vtbl(), Launch<2, 2>::vtbl(), Launch<2, 3>::vtbl(), Launch<2, 4>::vtbl(),
+        Launch<3, 1>::vtbl(), Launch<3, 2>::vtbl(), Launch<3, 3>::vtbl(), Launch<3, 4>::vtbl(),
+        Launch<4, 1>::vtbl(), Launch<4, 2>::vtbl(), Launch<4, 3>::vtbl(), Launch<4, 4>::vtbl(),
     };
     return t;
 }
@@ -156,6 +160,7 @@ struct rxhip_engine {
     bool in_arena(const void* q) const { return arena && (const char*)q >= arena && (const char*)q < arena + arena_bytes; }
     // description
     int d = 0, dy = 0;
+    int dpad = 0;  // dense path: d rounded up to a multiple of 16 (kernel dimension); == d otherwise
     long long T = 0, n_chains = 0;
     int n_models = 1;
     int ptt = 0;
@@ -600,7 +605,10 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
 
 // ------------------------------------------------------------------------------------------
 // dense path (d multiple of 16, ≤ 64): host-side per-model tables and launches
-static bool dense_supported(int d, int dy) { return d >= 16 && d <= 64 && d % 16 == 0 && dy >= 1 && dy <= 64; }
+// any state dimension up to 64: the MFMA path runs on d rounded up to a multiple of 16, the extra dimensions are
+// decoupled padding (A = 0, P = V0 = I, m0 = 0, B = 0: posterior N(0, I), no contribution to the free energy)
+static bool dense_supported(int d, int dy) { return d >= 1 && d <= 64 && dy >= 1 && dy <= 64; }
+static int dense_pad(int d) { return (d + 15) / 16 * 16; }
 
 template <int NT>
 struct DenseLaunch {
@@ -647,9 +655,21 @@ static int dense_rec(int nt) { return 16 * nt + dense_tri(nt) + 256 * nt * nt; }
 // matrix part of the boundary scan for every segment (see dense_kernels.hpp DenseParams::scanm).
 static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* ds, std::vector<double>& cst,
                                        std::vector<double>& tab, std::vector<double>& scanm) {
-    const int d = e->d, dy = e->dy;
+    const int d = e->dpad, dy = e->dy, du = e->d;
     const size_t MM = (size_t)d * d;
-    const double *A = ds->A, *B = ds->B, *P = ds->P, *Q = ds->Q, *m0 = ds->m0, *V0 = ds->V0;
+    // padded copies of the model (identity blocks on the padding dimensions)
+    std::vector<double> Ap(MM, 0.0), Pp(MM, 0.0), V0p(MM, 0.0), Bp((size_t)dy * d, 0.0), m0p(d, 0.0);
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            const bool in = i < du && j < du;
+            Ap[(size_t)i * d + j] = in ? ds->A[(size_t)i * du + j] : 0.0;
+            Pp[(size_t)i * d + j] = in ? ds->P[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
+            V0p[(size_t)i * d + j] = in ? ds->V0[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
+        }
+    for (int i = 0; i < dy; ++i)
+        for (int j = 0; j < du; ++j) Bp[(size_t)i * d + j] = ds->B[(size_t)i * du + j];
+    for (int i = 0; i < du; ++i) m0p[i] = ds->m0[i];
+    const double *A = Ap.data(), *B = Bp.data(), *P = Pp.data(), *Q = ds->Q, *m0 = m0p.data(), *V0 = V0p.data();
     const DenseCst c = DenseCst::make(d, dy);
     cst.assign((size_t)c.size, 0.0);
     std::vector<double> Qi(dy * dy), G(d * dy), Lobs(MM), HF(dy * d), V1(MM), V1i(MM), m1(d), t1(MM + dy * d + d * dy),
@@ -928,7 +948,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     *out = e;  // returned even on failure so that rxhip_last_error is readable; caller destroys
     e->vt = vt;
     e->dense = dense;
-    e->nt = ds->d / 16;
+    e->dpad = dense ? dense_pad(ds->d) : ds->d;
+    e->nt = e->dpad / 16;
     e->d = ds->d;
     e->dy = ds->dy;
     e->T = ds->T;
@@ -983,9 +1004,10 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         rxhip_status st = build_dense_tables(e, ds, cst, tab, scanm);
         if (st) return st;
         hipError_t herr = hipSuccess;
-        DENSE_DISPATCH(e->nt, prepare(e->d, e->dy) == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
+        DENSE_DISPATCH(e->nt, prepare(e->dpad, e->dy) == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
         if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-        const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1), D = (size_t)e->d;
+        const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1), D = (size_t)e->dpad,
+                     Du = (size_t)e->d;
         ArenaPlan ap;
         ap.upload(&e->d_cst, cst.data(), sizeof(double) * cst.size());
         ap.upload(&e->d_tab, tab.data(), sizeof(double) * tab.size());
@@ -997,8 +1019,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64));
         ap.plain(&e->d_filt, sizeof(double) * C * T * dense_rec(e->nt));
         ap.plain(&e->d_vend, sizeof(double) * C * Sg * dense_tri(e->nt));
-        ap.plain(&e->d_mean, sizeof(double) * T * C * D);
-        ap.plain(&e->d_cov, sizeof(double) * T * C * D * D);
+        ap.plain(&e->d_mean, sizeof(double) * T * C * Du);
+        ap.plain(&e->d_cov, sizeof(double) * T * C * Du * Du);
         ap.plain(&e->d_elem, sizeof(double) * C * Sg * 2 * D);
         ap.plain(&e->d_fstart_m, sizeof(double) * C * Sg * D);
         ap.plain(&e->d_beta_xi, sizeof(double) * C * (Sg + 1) * D);
@@ -1537,7 +1559,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     rxhip_status st;
     DenseParams dp;
     if (e->dense) {
-        dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->S; dp.L = e->L; dp.d = e->d; dp.dy = e->dy;
+        dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->S; dp.L = e->L; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy;
         dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
         dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;

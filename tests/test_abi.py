@@ -39,9 +39,10 @@ def test_version_and_status_strings():
 
 def test_supported_dimensions():
     L = rxhip.lib()
-    for d, dy in [(1, 1), (2, 2), (4, 4), (4, 2), (2, 1), (3, 3)]:
+    for d, dy in [(1, 1), (2, 2), (4, 4), (4, 2), (2, 1), (3, 3), (2, 4), (5, 7), (17, 3), (64, 64)]:
         assert L.rxhip_lgssm_supported(d, dy) == 1
-    assert L.rxhip_lgssm_supported(5, 7) == 0
+    for d, dy in [(65, 1), (4, 65), (0, 1)]:
+        assert L.rxhip_lgssm_supported(d, dy) == 0
 
 
 def test_bad_descriptor_rejected_without_gpu():
@@ -54,9 +55,9 @@ def test_bad_descriptor_rejected_without_gpu():
 
 
 def test_unsupported_dimension_is_reported():
-    I = np.eye(5)
+    I = np.eye(65)  # state dimensions above 64 have no device schedule
     with pytest.raises(rxhip.RxHipError) as ei:
-        rxhip.LGSSMEngine(I, I, I, I, np.zeros(5), I, T=10)
+        rxhip.LGSSMEngine(I, I, I, I, np.zeros(65), I, T=10)
     assert ei.value.status == _lib.ERR_UNSUPPORTED
 
 
