@@ -305,6 +305,36 @@ rxhip_status rxhip_gmm_statistics_device(rxhip_engine* e, double** stats_dev, in
 rxhip_status rxhip_gmm_update(rxhip_engine* e, int32_t want_free_energy);
 
 /* ------------------------------------------------------------------------------------------
+ * Multivariate Gaussian mixture, mean-field VMP (reference model test/models/mixtures/gmm_multivariate_tests.jl:6-32):
+ *     m[k] ~ MvNormal(mean = mu0[k], cov = S0[k]);  w[k] ~ Wishart(nu0[k], V0[k]);  s ~ Dirichlet(alpha0);
+ *     z[i] ~ Categorical(s);  y[i] ~ NormalMixture(switch = z[i], m = m, p = w)           (w: precision matrices)
+ * d = 1…4; K ≤ 16 (d ≤ 2) or K ≤ 8 (d = 3, 4).  init_*: the `@initialization` marginals q(m[k]) = N(mean, cov),
+ * q(w[k]) = Wishart(nu, V), q(s) = Dirichlet.  Same handle protocol as the univariate engine: rxhip_set_data(RXHIP_VAR_Y,
+ * y [N][d], N*d, 0), rxhip_run / the split-phase rxhip_gmm_begin_run, _accumulate, _statistics_device, _update (statistics:
+ * K'(1 + d + d(d+1)/2) + 1 doubles), rxhip_get_free_energy, rxhip_gmm_get_responsibilities.
+ * rxhip_gmm_get_history: hist[iterations][K][2 + d + 2d²] = per component  mean[d] | cov[d][d] | nu | V[d][d] | alpha.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t N;
+    int32_t K;
+    int32_t d;
+    const double* mu0;   /* [K][d]    */
+    const double* S0;    /* [K][d][d] prior covariance of m[k] */
+    const double* nu0;   /* [K]       Wishart degrees of freedom (> d − 1) */
+    const double* V0;    /* [K][d][d] Wishart scale */
+    const double* alpha0;       /* [K] */
+    const double* init_m_mean;  /* [K][d]    */
+    const double* init_m_cov;   /* [K][d][d] */
+    const double* init_w_nu;    /* [K]       */
+    const double* init_w_V;     /* [K][d][d] */
+    const double* init_s_alpha; /* [K]       */
+    int32_t materialize_responsibilities;
+    int32_t device;
+    void* stream;
+} rxhip_mvgmm_desc;
+rxhip_status rxhip_mvgmm_create(const rxhip_mvgmm_desc* desc, rxhip_engine** out);
+
+/* ------------------------------------------------------------------------------------------
  * Hierarchical Gaussian filter, online (BASELINE config 4; reference model + driver
  * test/models/statespace/hgf_tests.jl:9-70): per observation the one-step graph
  *     zt_min ~ Normal(zm, zv); xt_min ~ Normal(xm, xv); zt ~ Normal(mean = zt_min, var = z_variance);

@@ -886,6 +886,160 @@ int rxo_gmm_vmp(long long N, int K, const double* y, const double* mu0, const do
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * Multivariate Gaussian mixture, mean-field VMP (test/models/mixtures/gmm_multivariate_tests.jl:6-32):
+ *     m[k] ~ MvNormal(mean = mu0[k], cov = S0[k]);  w[k] ~ Wishart(nu0[k], V0[k]);  s ~ Dirichlet(alpha0);
+ *     z[i] ~ Categorical(s);  y[i] ~ NormalMixture(switch = z[i], m = m, p = w)      (p: precision matrices)
+ * Rules as in the univariate case with NormalMeanPrecision -> MvNormalMeanPrecision and Gamma -> Wishart
+ * (ExponentialFamily: E[W] = νV, E log|W| = ψ_d(ν/2) + d log 2 + log|V|):
+ *   NormalMixture(:switch)  ∝ exp(−U_k),  U_k = ½[d log 2π − E log|W_k| + tr(E[W_k] E[(y−m_k)(y−m_k)'])]
+ *   NormalMixture(m[k])     MvNormalMeanPrecision(y_i, π_ik E[W_k]); product with the prior in (ξ, Λ)
+ *   NormalMixture(w[k])     natural parameters of the Wishart product: ν += π_ik, V⁻¹ += π_ik E[(y_i−m_k)(y_i−m_k)']
+ * Same schedule as rxo_gmm_vmp: q(z) from the previous marginals, then q(s), q(m) with the previous E[W], then q(w)
+ * with the new q(m); the sum over points of the w-message is evaluated through Σπ, Σπy, Σπyy' (exact algebra).
+ * For d = 1 the model IS the univariate one (Wishart(ν, V) = Gamma(shape ν/2, rate 1/(2V))): tests/test_oracle.py
+ * checks that the two restatements agree to rounding, free energy included.
+ * state / init / hist layout per component: mean[d] | cov[d][d] | nu | V[d][d] | alpha   (SZ = 2 + d + 2d² doubles)
+ * ------------------------------------------------------------------------------------------ */
+static double mvdigamma_(double a, int d) {
+    double s = 0.0;
+    for (int i = 0; i < d; ++i) s += digamma_(a - 0.5 * i);
+    return s;
+}
+static double mvlgamma_(double a, int d) {
+    double s = 0.25 * d * (d - 1) * 1.1447298858494001741434273513531; /* log π */
+    for (int i = 0; i < d; ++i) s += lgamma(a - 0.5 * i);
+    return s;
+}
+int rxo_mvgmm_vmp(long long N, int K, int d, const double* y, const double* mu0, const double* S0, const double* nu0,
+                  const double* V0, const double* alpha0, const double* init, int iterations, double* hist, double* fe,
+                  double* resp) {
+    if (N <= 0 || K <= 0 || K > 64 || d <= 0 || d > 8 || iterations <= 0) return RXO_ERR_BADARG;
+    const int dd = d * d, SZ = 2 + d + 2 * dd;
+    const double LOG2 = 0.69314718055994530942;
+    double* st = (double*)malloc(sizeof(double) * (size_t)K * SZ);
+    double* w = (double*)calloc((size_t)(K * (6 * dd + 2 * d + 8) + 8 * dd + 4 * d + 64), sizeof(double));
+    if (!st || !w) { free(st); free(w); return RXO_ERR_BADARG; }
+    memcpy(st, init, sizeof(double) * (size_t)K * SZ);
+    double *EW = w, *S0i = EW + K * dd, *V0i = S0i + K * dd, *Lam = V0i + K * dd, *S2 = Lam + K * dd, *Sc = S2 + K * dd,
+           *xi = Sc + K * dd, *S1 = xi + K * d, *Elw = S1 + K * d, *Els = Elw + K, *lg = Els + K, *pi = lg + K, *S0k = pi + K,
+           *tmp = S0k + K, *chw = tmp + 2 * dd, *dv = chw + 4 * dd;
+    int rc = RXO_OK;
+    double ldS0[64], ldV0[64];
+    for (int k = 0; k < K; ++k) {
+        if ((rc = cholinv(d, S0 + k * dd, S0i + k * dd, &ldS0[k], chw))) goto done;
+        if ((rc = cholinv(d, V0 + k * dd, V0i + k * dd, &ldV0[k], chw))) goto done;
+    }
+    for (int it = 0; it < iterations; ++it) {
+        double asum = 0.0, Hz = 0.0;
+        for (int k = 0; k < K; ++k) asum += st[k * SZ + SZ - 1];
+        for (int k = 0; k < K; ++k) {
+            const double* sk = st + k * SZ;
+            const double nu = sk[d + dd];
+            const double* V = sk + d + dd + 1;
+            double ldV;
+            if ((rc = cholinv(d, V, tmp, &ldV, chw))) goto done; /* log|V| */
+            for (int i = 0; i < dd; ++i) EW[k * dd + i] = nu * V[i];
+            Elw[k] = mvdigamma_(0.5 * nu, d) + d * LOG2 + ldV;
+            Els[k] = digamma_(sk[SZ - 1]) - digamma_(asum);
+            for (int i = 0; i < dd; ++i) { Lam[k * dd + i] = S0i[k * dd + i]; S2[k * dd + i] = 0.0; }
+            matvec(d, d, S0i + k * dd, mu0 + k * d, xi + k * d);
+            for (int a = 0; a < d; ++a) S1[k * d + a] = 0.0;
+            S0k[k] = 0.0;
+        }
+        for (long long i = 0; i < N; ++i) {
+            const double* yi = y + i * d;
+            double mx = -INFINITY;
+            for (int k = 0; k < K; ++k) {
+                const double* sk = st + k * SZ;
+                double q = 0.0;
+                for (int a = 0; a < d; ++a) dv[a] = yi[a] - sk[a];
+                for (int a = 0; a < d; ++a)
+                    for (int b = 0; b < d; ++b) q += EW[k * dd + a * d + b] * (dv[a] * dv[b] + sk[d + a * d + b]);
+                lg[k] = Els[k] - 0.5 * (d * LOG2PI - Elw[k] + q);
+                if (lg[k] > mx) mx = lg[k];
+            }
+            double Z = 0.0;
+            for (int k = 0; k < K; ++k) { pi[k] = exp(lg[k] - mx); Z += pi[k]; }
+            for (int k = 0; k < K; ++k) {
+                pi[k] /= Z;
+                if (pi[k] > 0.0) Hz -= pi[k] * log(pi[k]);
+                if (resp && it == iterations - 1) resp[i * K + k] = pi[k];
+                for (int a = 0; a < d; ++a) {
+                    double s1 = 0.0;
+                    for (int b = 0; b < d; ++b) {
+                        Lam[k * dd + a * d + b] += pi[k] * EW[k * dd + a * d + b]; /* message toward m[k]: precision */
+                        s1 += EW[k * dd + a * d + b] * yi[b];
+                        S2[k * dd + a * d + b] += pi[k] * yi[a] * yi[b];
+                    }
+                    xi[k * d + a] += pi[k] * s1;                                   /* … and weighted mean */
+                    S1[k * d + a] += pi[k] * yi[a];
+                }
+                S0k[k] += pi[k];
+            }
+        }
+        double F = -Hz, as2 = 0.0, a0s = 0.0;
+        for (int k = 0; k < K; ++k) {
+            double* sk = st + k * SZ;
+            double ldC;
+            if ((rc = cholinv(d, Lam + k * dd, sk + d, NULL, chw))) goto done; /* cov of q(m[k]) */
+            matvec(d, d, sk + d, xi + k * d, sk);
+            if ((rc = cholinv(d, sk + d, tmp, &ldC, chw))) goto done;          /* log|cov| for the entropy */
+            sk[SZ - 1] = alpha0[k] + S0k[k];
+            /* Sc = Σ_i π_ik E[(y_i − m)(y_i − m)'] with the new q(m[k]) */
+            for (int a = 0; a < d; ++a)
+                for (int b = 0; b < d; ++b)
+                    Sc[k * dd + a * d + b] = S2[k * dd + a * d + b] - sk[a] * S1[k * d + b] - S1[k * d + a] * sk[b] +
+                                             S0k[k] * (sk[a] * sk[b] + sk[d + a * d + b]);
+            for (int i = 0; i < dd; ++i) tmp[i] = V0i[k * dd + i] + Sc[k * dd + i];
+            double ldVn;
+            if ((rc = cholinv(d, tmp, sk + d + dd + 1, &ldVn, chw))) goto done; /* new V = (V0⁻¹ + Sc)⁻¹, ldVn = log|V⁻¹| */
+            sk[d + dd] = nu0[k] + S0k[k];
+            as2 += sk[SZ - 1];
+            a0s += alpha0[k];
+        }
+        if (hist) memcpy(hist + (size_t)it * K * SZ, st, sizeof(double) * (size_t)K * SZ);
+        if (fe) {
+            double lB = -lgamma(as2), lB0 = -lgamma(a0s), Hs_t = 0.0, Us_t = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const double* sk = st + k * SZ;
+                const double nu = sk[d + dd], *V = sk + d + dd + 1, al = sk[SZ - 1];
+                double ldV, ldC;
+                if ((rc = cholinv(d, V, tmp, &ldV, chw))) goto done;
+                if ((rc = cholinv(d, sk + d, tmp, &ldC, chw))) goto done;
+                const double Elwk = mvdigamma_(0.5 * nu, d) + d * LOG2 + ldV, Elsk = digamma_(al) - digamma_(as2);
+                double trWS = 0.0, trV0W = 0.0, trS0 = 0.0;
+                for (int a = 0; a < d; ++a)
+                    for (int b = 0; b < d; ++b) {
+                        trWS += nu * V[a * d + b] * Sc[k * dd + b * d + a];
+                        trV0W += V0i[k * dd + a * d + b] * nu * V[b * d + a];
+                        trS0 += S0i[k * dd + a * d + b] * (sk[d + b * d + a] + (sk[b] - mu0[k * d + b]) * (sk[a] - mu0[k * d + a]));
+                    }
+                /* NormalMixture and Categorical average energies */
+                F += 0.5 * (S0k[k] * (d * LOG2PI - Elwk) + trWS) - S0k[k] * Elsk;
+                /* MvNormal prior node of m[k] minus H[q(m[k])] */
+                F += 0.5 * (d * LOG2PI + ldS0[k] + trS0) - 0.5 * (d * (LOG2PI + 1.0) + ldC);
+                /* Wishart prior node of w[k] minus H[q(w[k])] */
+                const double n0 = nu0[k];
+                F += -(0.5 * (n0 - d - 1.0) * Elwk - 0.5 * trV0W - 0.5 * n0 * d * LOG2 - 0.5 * n0 * ldV0[k] - mvlgamma_(0.5 * n0, d));
+                F -= 0.5 * (d + 1.0) * ldV + 0.5 * d * (d + 1.0) * LOG2 + mvlgamma_(0.5 * nu, d) -
+                     0.5 * (nu - d - 1.0) * mvdigamma_(0.5 * nu, d) + 0.5 * nu * d;
+                lB += lgamma(al);
+                lB0 += lgamma(alpha0[k]);
+                Us_t += (alpha0[k] - 1.0) * Elsk;
+                Hs_t += (al - 1.0) * digamma_(al);
+            }
+            if (K > 1) F += (lB0 - Us_t) - (lB + (as2 - K) * digamma_(as2) - Hs_t);
+            fe[it] = F;
+            if (!isfinite(F)) { rc = RXO_ERR_NONFINITE_FE; goto done; }
+        }
+    }
+done:
+    free(st);
+    free(w);
+    return rc;
+}
+
 /* ==========================================================================================
  * Hierarchical Gaussian filter (GCV node) — see rxoracle.h for the model, provenance and assumptions.
  * ========================================================================================== */

@@ -133,6 +133,18 @@ int rxo_gmm_update(int K, const double* mu0, const double* v0, const double* a0,
                    const double* stats, double* state, double* fe, rxo_counters* counters);
 
 /*
+ * Multivariate Gaussian mixture, mean-field VMP (test/models/mixtures/gmm_multivariate_tests.jl:6-32):
+ *     m[k] ~ MvNormal(mean = mu0[k], cov = S0[k]);  w[k] ~ Wishart(nu0[k], V0[k]);  s ~ Dirichlet(alpha0);
+ *     z[i] ~ Categorical(s);  y[i] ~ NormalMixture(switch = z[i], m = m, p = w)
+ * y: [N][d].  init / hist layout per component: mean[d] | cov[d][d] | nu | V[d][d] | alpha  (SZ = 2 + d + 2d² doubles);
+ * init: [K][SZ] (`@initialization`), hist: [iterations][K][SZ], fe: [iterations], resp (nullable): [N][K] final q(z).
+ * Schedule as rxo_gmm_vmp.  d = 1 reproduces rxo_gmm_vmp (Wishart(ν, V) = Gamma(ν/2, 1/(2V))).
+ */
+int rxo_mvgmm_vmp(long long N, int K, int d, const double* y, const double* mu0, const double* S0, const double* nu0,
+                  const double* V0, const double* alpha0, const double* init, int iterations, double* hist, double* fe,
+                  double* resp);
+
+/*
  * Hierarchical Gaussian filter, one series, online (test/models/statespace/hgf_tests.jl:9-70):
  *     zt_min ~ Normal(zm, zv); xt_min ~ Normal(xm, xv); zt ~ Normal(mean = zt_min, var = z_variance);
  *     xt ~ GCV(xt_min, zt, kappa, omega);  y ~ Normal(mean = xt, var = y_variance)

@@ -51,6 +51,8 @@ def lib():
         _LIB.rxo_gmm_accumulate.argtypes = [ctypes.c_longlong, ctypes.c_int, dp, dp, dp, dp, ctypes.POINTER(Counters)]
         _LIB.rxo_gmm_update.restype = ctypes.c_int
         _LIB.rxo_gmm_update.argtypes = [ctypes.c_int] + [dp] * 8 + [ctypes.POINTER(Counters)]
+        _LIB.rxo_mvgmm_vmp.restype = ctypes.c_int
+        _LIB.rxo_mvgmm_vmp.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_int] + [dp] * 7 + [ctypes.c_int, dp, dp, dp]
         _LIB.rxo_lgssm_filter.restype = ctypes.c_int
         _LIB.rxo_lgssm_filter.argtypes = [ctypes.c_int] * 3 + [dp] * 6 + [ctypes.c_int] + [dp] * 4 + [ctypes.POINTER(Counters)]
         _LIB.rxo_gauss_hermite.restype = ctypes.c_int
@@ -175,6 +177,44 @@ def gmm_update(mu0, v0, a0, b0, alpha0, stats, state, want_fe=True):
     if rc:
         raise RuntimeError(f"rxo_gmm_update failed with status {rc}")
     return float(fe[0]) if want_fe else None
+
+
+def mvgmm_pack(mean, cov, nu, V, alpha):
+    """[K][SZ] state block (mean[d] | cov[d][d] | nu | V[d][d] | alpha) from per-component arrays."""
+    mean, cov, V = (np.asarray(a, dtype=np.float64) for a in (mean, cov, V))
+    K, d = mean.shape
+    out = np.empty((K, 2 + d + 2 * d * d))
+    out[:, :d] = mean
+    out[:, d:d + d * d] = cov.reshape(K, -1)
+    out[:, d + d * d] = nu
+    out[:, d + d * d + 1:d + 2 * d * d + 1] = V.reshape(K, -1)
+    out[:, -1] = alpha
+    return out
+
+
+def mvgmm_unpack(state, d):
+    """inverse of mvgmm_pack for an array [..., K, SZ]: dict(mean, cov, nu, V, alpha)"""
+    s = np.asarray(state)
+    dd = d * d
+    return dict(mean=s[..., :d], cov=s[..., d:d + dd].reshape(s.shape[:-1] + (d, d)), nu=s[..., d + dd],
+                V=s[..., d + dd + 1:d + 2 * dd + 1].reshape(s.shape[:-1] + (d, d)), alpha=s[..., -1])
+
+
+def mvgmm_vmp(y, mu0, S0, nu0, V0, alpha0, init, iterations, want_resp=False):
+    """Multivariate mixture VMP (see rxoracle.h).  y: [N][d]; init: [K][SZ] (mvgmm_pack).  Returns hist [it][K][SZ], fe [it], resp|None."""
+    y = _c(y)
+    N, d = y.shape
+    mu0, S0, nu0, V0, alpha0, init = (_c(a) for a in (mu0, S0, nu0, V0, alpha0, init))
+    K = mu0.shape[0]
+    SZ = 2 + d + 2 * d * d
+    hist = np.empty((iterations, K, SZ))
+    fe = np.empty(iterations)
+    resp = np.empty((N, K)) if want_resp else None
+    rc = lib().rxo_mvgmm_vmp(N, K, d, _p(y), _p(mu0), _p(S0), _p(nu0), _p(V0), _p(alpha0), _p(init), int(iterations),
+                             _p(hist), _p(fe), _p(resp) if want_resp else None)
+    if rc:
+        raise RuntimeError(f"rxo_mvgmm_vmp failed with status {rc}")
+    return hist, fe, resp
 
 
 def hgf_filter(y, kappa, omega, z_variance, y_variance, z0=(0.0, 5.0), x0=(0.0, 5.0), vmp_iters=10, n_gh=31, want_fe=True):

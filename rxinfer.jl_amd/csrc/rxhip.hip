@@ -21,6 +21,7 @@
 #include "dense_kernels.hpp"
 #include "gmm_kernels.hpp"
 #include "hgf_kernels.hpp"
+#include "mvgmm_kernels.hpp"
 #include "graph_lowering.hpp"
 
 using namespace rxhip;
@@ -191,6 +192,10 @@ struct rxhip_engine {
     struct Gmm {
         long long N = 0;
         int K = 0, KT = 0, materialize = 0, nblocks = 0, it = 0, iterations = 0, hist_cap = 0;
+        int mvd = 0;          // 0: univariate engine; d ≥ 1: multivariate engine (mvgmm_kernels.hpp) of that dimension
+        int nq = 0;           // statistics per iteration (the multi-GPU all-reduce payload)
+        int hist_stride = 0;  // doubles of history per iteration
+        int state_size = 0;   // doubles of the marginal block (d_par / d_init)
         double *d_resp = nullptr, *d_par = nullptr, *d_drv = nullptr, *d_prior = nullptr, *d_init = nullptr,
                *d_partial = nullptr, *d_totals = nullptr, *d_hist = nullptr, *d_fe = nullptr;
     } g;
@@ -822,6 +827,43 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
 // ------------------------------------------------------------------------------------------
 // Gaussian-mixture VMP engine
 static int gmm_kt(int K) { return K <= 1 ? 1 : K <= 2 ? 2 : K <= 4 ? 4 : K <= 8 ? 8 : 16; }
+static MvgParams mvg_params(rxhip_engine* e) {
+    MvgParams p;
+    p.N = e->g.N; p.K = e->g.K; p.y = e->d_y; p.resp = e->g.d_resp; p.state = e->g.d_par; p.drv = e->g.d_drv;
+    p.prior = e->g.d_prior; p.partial = e->g.d_partial; p.totals = e->g.d_totals; p.hist = e->g.d_hist; p.fe = e->g.d_fe;
+    p.iteration = e->g.it; p.nblocks = e->g.nblocks; p.write_resp = 0; p.status = e->d_status;
+    return p;
+}
+template <int D, int KT>
+struct MvgLaunch {
+    static void init(const MvgParams& p, hipStream_t s) { hipLaunchKernelGGL((k_mvg_init<D, KT>), dim3(1), dim3(64), 0, s, p); }
+    static void pass(const MvgParams& p, bool resp, hipStream_t s) {
+        if (resp) hipLaunchKernelGGL((k_mvg_pass<D, KT, true>), dim3(p.nblocks), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((k_mvg_pass<D, KT, false>), dim3(p.nblocks), dim3(256), 0, s, p);
+    }
+    static void reduce(const MvgParams& p, hipStream_t s) {
+        hipLaunchKernelGGL(k_mvg_reduce, dim3(KT * MvgDim<D>::STAT + 1), dim3(256), 0, s, p, KT * MvgDim<D>::STAT + 1);
+    }
+    static void update(const MvgParams& p, bool fe, hipStream_t s) {
+        if (fe) hipLaunchKernelGGL((k_mvg_update<D, KT, true>), dim3(1), dim3(64), 0, s, p);
+        else hipLaunchKernelGGL((k_mvg_update<D, KT, false>), dim3(1), dim3(64), 0, s, p);
+    }
+};
+// component tile: the statistics of a lane live in registers, KT·(1 + d + d(d+1)/2) ≤ 128 doubles
+static int mvg_kt(int d, int K) {
+    const int cap = d <= 2 ? 16 : 8;
+    const int kt = K <= 4 ? 4 : K <= 8 ? 8 : 16;
+    return kt <= cap ? kt : 0;
+}
+#define MVG_DISPATCH(d, kt, CALL)                                                    \
+    switch ((d) * 100 + (kt)) {                                                      \
+        case 104: MvgLaunch<1, 4>::CALL; break;  case 108: MvgLaunch<1, 8>::CALL; break;  case 116: MvgLaunch<1, 16>::CALL; break; \
+        case 204: MvgLaunch<2, 4>::CALL; break;  case 208: MvgLaunch<2, 8>::CALL; break;  case 216: MvgLaunch<2, 16>::CALL; break; \
+        case 304: MvgLaunch<3, 4>::CALL; break;  case 308: MvgLaunch<3, 8>::CALL; break;                                          \
+        case 404: MvgLaunch<4, 4>::CALL; break;  default: MvgLaunch<4, 8>::CALL; break;                                           \
+    }
+
+
 static GmmParams gmm_params(rxhip_engine* e) {
     GmmParams p;
     p.N = e->g.N; p.K = e->g.K; p.y = e->d_y; p.resp = e->g.d_resp; p.par = e->g.d_par; p.drv = e->g.d_drv;
@@ -1073,6 +1115,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
 }
 
 
+
 static rxhip_status prof_begin(rxhip_engine* e, int k);
 static rxhip_status prof_end(rxhip_engine* e);
 
@@ -1111,6 +1154,9 @@ rxhip_status rxhip_gmm_create(const rxhip_gmm_desc* ds, rxhip_engine** out) {
         e->own_stream = true;
     }
     const int KT = e->g.KT, K = e->g.K;
+    e->g.nq = 3 * KT + 1;
+    e->g.hist_stride = 5 * K;
+    e->g.state_size = 5 * KT;
     long long nb = (e->g.N + 255) / 256;
     if (nb > 1024) nb = 1024;  // 4 workgroups per CU, grid-stride over the observations
     e->g.nblocks = (int)nb;
@@ -1136,6 +1182,76 @@ rxhip_status rxhip_gmm_create(const rxhip_gmm_desc* ds, rxhip_engine** out) {
     return RXHIP_OK;
 }
 
+rxhip_status rxhip_mvgmm_create(const rxhip_mvgmm_desc* ds, rxhip_engine** out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    *out = nullptr;
+    if (!ds || ds->N <= 0 || ds->K <= 0 || ds->d <= 0 || !ds->mu0 || !ds->S0 || !ds->nu0 || !ds->V0 || !ds->alpha0 ||
+        !ds->init_m_mean || !ds->init_m_cov || !ds->init_w_nu || !ds->init_w_V || !ds->init_s_alpha)
+        return RXHIP_ERR_BADARG;
+    if (ds->d > 4 || mvg_kt(ds->d, ds->K) == 0) return RXHIP_ERR_UNSUPPORTED;
+    const int d = ds->d, dd = d * d, K = ds->K, KT = mvg_kt(d, K);
+    const int SZ = 2 + d + 2 * dd, PRI = d + 2 * dd + 4, STAT = 1 + d + d * (d + 1) / 2, DRV = 1 + d * (d + 1) / 2 + d;
+    for (int k = 0; k < K; ++k)
+        if (!(ds->nu0[k] > d - 1) || !(ds->init_w_nu[k] > d - 1) || !(ds->alpha0[k] > 0) || !(ds->init_s_alpha[k] > 0)) return RXHIP_ERR_NOT_POSDEF;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RXHIP_ERR_NO_DEVICE;
+    rxhip_engine* e = new rxhip_engine();
+    *out = e;
+    e->kind = 1;
+    e->g.mvd = d;
+    e->g.N = ds->N; e->g.K = K; e->g.KT = KT;
+    e->g.materialize = ds->materialize_responsibilities ? 1 : 0;
+    e->g.nq = KT * STAT + 1; e->g.hist_stride = K * SZ; e->g.state_size = K * SZ;
+    e->n_chains = 1; e->T = ds->N; e->dy = d; e->d = d;
+    if (ds->device >= 0) {
+        if (ds->device >= ndev) return fail(e, RXHIP_ERR_BADARG, "device %d out of range (%d visible)", ds->device, ndev);
+        e->device = ds->device;
+    } else
+        HIPCHK(e, hipGetDevice(&e->device));
+    HIPCHK(e, hipSetDevice(e->device));
+    if (ds->stream) e->stream = (hipStream_t)ds->stream;
+    else {
+        HIPCHK(e, stream_acquire(e->device, &e->stream));
+        e->own_stream = true;
+    }
+    long long nb = (e->g.N + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    e->g.nblocks = (int)nb;
+    // prior block per component: mu0 | S0⁻¹ | nu0 | V0⁻¹ | alpha0 | log|S0| | log|V0|   (inverses / log-determinants once, here)
+    std::vector<double> prior((size_t)K * PRI), init((size_t)K * SZ), tmp(dd);
+    for (int k = 0; k < K; ++k) {
+        double* pr = prior.data() + (size_t)k * PRI;
+        double ldS = 0, ldV = 0;
+        for (int a = 0; a < d; ++a) pr[a] = ds->mu0[k * d + a];
+        if (!host::chol_inv(d, ds->S0 + (size_t)k * dd, pr + d, &ldS)) return fail(e, RXHIP_ERR_NOT_POSDEF, "prior covariance of m[%d] is not positive definite", k);
+        pr[d + dd] = ds->nu0[k];
+        if (!host::chol_inv(d, ds->V0 + (size_t)k * dd, pr + d + dd + 1, &ldV)) return fail(e, RXHIP_ERR_NOT_POSDEF, "Wishart scale of w[%d] is not positive definite", k);
+        pr[d + 2 * dd + 1] = ds->alpha0[k];
+        pr[d + 2 * dd + 2] = ldS;
+        pr[d + 2 * dd + 3] = ldV;
+        double* in = init.data() + (size_t)k * SZ;
+        for (int a = 0; a < d; ++a) in[a] = ds->init_m_mean[k * d + a];
+        for (int q = 0; q < dd; ++q) in[d + q] = ds->init_m_cov[(size_t)k * dd + q];
+        in[d + dd] = ds->init_w_nu[k];
+        for (int q = 0; q < dd; ++q) in[d + dd + 1 + q] = ds->init_w_V[(size_t)k * dd + q];
+        in[SZ - 1] = ds->init_s_alpha[k];
+        if (!host::chol_inv(d, in + d, tmp.data(), nullptr) || !host::chol_inv(d, in + d + dd + 1, tmp.data(), nullptr))
+            return fail(e, RXHIP_ERR_NOT_POSDEF, "initial marginal of component %d is not positive definite", k);
+    }
+    HIPCHK(e, hipMalloc(&e->g.d_prior, sizeof(double) * prior.size()));
+    HIPCHK(e, hipMalloc(&e->g.d_init, sizeof(double) * init.size()));
+    HIPCHK(e, hipMalloc(&e->g.d_par, sizeof(double) * init.size()));
+    HIPCHK(e, hipMalloc(&e->g.d_drv, sizeof(double) * (size_t)KT * DRV));
+    HIPCHK(e, hipMalloc(&e->g.d_partial, sizeof(double) * (size_t)nb * e->g.nq));
+    HIPCHK(e, hipMalloc(&e->g.d_totals, sizeof(double) * e->g.nq));
+    HIPCHK(e, hipMemcpy(e->g.d_prior, prior.data(), sizeof(double) * prior.size(), hipMemcpyHostToDevice));
+    HIPCHK(e, hipMemcpy(e->g.d_init, init.data(), sizeof(double) * init.size(), hipMemcpyHostToDevice));
+    if (e->g.materialize) HIPCHK(e, hipMalloc(&e->g.d_resp, sizeof(double) * (size_t)e->g.N * K));
+    HIPCHK(e, hipMalloc(&e->d_status, sizeof(int)));
+    HIPCHK(e, hipMemset(e->d_status, 0, sizeof(int)));
+    return RXHIP_OK;
+}
+
 rxhip_status rxhip_gmm_begin_run(rxhip_engine* e, int32_t iterations) {
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
@@ -1146,16 +1262,21 @@ rxhip_status rxhip_gmm_begin_run(rxhip_engine* e, int32_t iterations) {
         if (e->g.d_hist) HIPCHK(e, hipFree(e->g.d_hist));
         if (e->g.d_fe) HIPCHK(e, hipFree(e->g.d_fe));
         e->g.d_hist = e->g.d_fe = nullptr;
-        HIPCHK(e, hipMalloc(&e->g.d_hist, sizeof(double) * (size_t)iterations * 5 * e->g.K));
+        HIPCHK(e, hipMalloc(&e->g.d_hist, sizeof(double) * (size_t)iterations * e->g.hist_stride));
         HIPCHK(e, hipMalloc(&e->g.d_fe, sizeof(double) * iterations));
         e->g.hist_cap = iterations;
     }
     HIPCHK(e, hipMemsetAsync(e->g.d_fe, 0, sizeof(double) * iterations, e->stream));
-    HIPCHK(e, hipMemcpyAsync(e->g.d_par, e->g.d_init, sizeof(double) * 5 * e->g.KT, hipMemcpyDeviceToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->g.d_par, e->g.d_init, sizeof(double) * e->g.state_size, hipMemcpyDeviceToDevice, e->stream));
     e->g.it = 0;
     e->g.iterations = iterations;
-    GmmParams p = gmm_params(e);
-    GMM_DISPATCH(e->g.KT, init(p, e->stream));
+    if (e->g.mvd) {
+        MvgParams p = mvg_params(e);
+        MVG_DISPATCH(e->g.mvd, e->g.KT, init(p, e->stream));
+    } else {
+        GmmParams p = gmm_params(e);
+        GMM_DISPATCH(e->g.KT, init(p, e->stream));
+    }
     HIPCHK(e, hipGetLastError());
     e->rule_calls = e->products = e->marginals = 0;
     return RXHIP_OK;
@@ -1164,14 +1285,25 @@ rxhip_status rxhip_gmm_accumulate(rxhip_engine* e) {
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (e->g.it >= e->g.iterations) return fail(e, RXHIP_ERR_STATE, "accumulate: no iteration left (call rxhip_gmm_begin_run)");
     HIPCHK(e, hipSetDevice(e->device));
-    GmmParams p = gmm_params(e);
     const bool resp = e->g.materialize && e->g.it == e->g.iterations - 1;
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_GMM_PASS))) return st;
-    GMM_DISPATCH(e->g.KT, pass(p, resp, e->stream));
+    if (e->g.mvd) {
+        MvgParams p = mvg_params(e);
+        MVG_DISPATCH(e->g.mvd, e->g.KT, pass(p, resp, e->stream));
+    } else {
+        GmmParams p = gmm_params(e);
+        GMM_DISPATCH(e->g.KT, pass(p, resp, e->stream));
+    }
     if ((st = prof_end(e))) return st;
     if ((st = prof_begin(e, RXHIP_K_GMM_REDUCE))) return st;
-    GMM_DISPATCH(e->g.KT, reduce(p, e->stream));
+    if (e->g.mvd) {
+        MvgParams p = mvg_params(e);
+        MVG_DISPATCH(e->g.mvd, e->g.KT, reduce(p, e->stream));
+    } else {
+        GmmParams p = gmm_params(e);
+        GMM_DISPATCH(e->g.KT, reduce(p, e->stream));
+    }
     if ((st = prof_end(e))) return st;
     HIPCHK(e, hipGetLastError());
     return RXHIP_OK;
@@ -1179,17 +1311,22 @@ rxhip_status rxhip_gmm_accumulate(rxhip_engine* e) {
 rxhip_status rxhip_gmm_statistics_device(rxhip_engine* e, double** stats_dev, int32_t* n) {
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (stats_dev) *stats_dev = e->g.d_totals;
-    if (n) *n = 3 * e->g.KT + 1;
+    if (n) *n = e->g.nq;
     return RXHIP_OK;
 }
 rxhip_status rxhip_gmm_update(rxhip_engine* e, int32_t want_fe) {
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (e->g.it >= e->g.iterations) return fail(e, RXHIP_ERR_STATE, "update: no iteration left");
     HIPCHK(e, hipSetDevice(e->device));
-    GmmParams p = gmm_params(e);
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_GMM_UPDATE))) return st;
-    GMM_DISPATCH(e->g.KT, update(p, want_fe != 0, e->stream));
+    if (e->g.mvd) {
+        MvgParams p = mvg_params(e);
+        MVG_DISPATCH(e->g.mvd, e->g.KT, update(p, want_fe != 0, e->stream));
+    } else {
+        GmmParams p = gmm_params(e);
+        GMM_DISPATCH(e->g.KT, update(p, want_fe != 0, e->stream));
+    }
     if ((st = prof_end(e))) return st;
     HIPCHK(e, hipGetLastError());
     e->g.it++;
@@ -1208,7 +1345,7 @@ rxhip_status rxhip_gmm_get_history(rxhip_engine* e, double* hist) {
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_history: no run yet");
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    HIPCHK(e, hipMemcpy(hist, e->g.d_hist, sizeof(double) * (size_t)e->g.it * 5 * e->g.K, hipMemcpyDeviceToHost));
+    HIPCHK(e, hipMemcpy(hist, e->g.d_hist, sizeof(double) * (size_t)e->g.it * e->g.hist_stride, hipMemcpyDeviceToHost));
     return RXHIP_OK;
 }
 rxhip_status rxhip_gmm_get_responsibilities(rxhip_engine* e, double* resp) {

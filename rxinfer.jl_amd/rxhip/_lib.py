@@ -69,6 +69,12 @@ class GmmDesc(ctypes.Structure):
         ("materialize_responsibilities", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p)]
 
 
+class MvGmmDesc(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int64), ("K", ctypes.c_int32), ("d", ctypes.c_int32)] + [(n, c_double_p) for n in (
+        "mu0", "S0", "nu0", "V0", "alpha0", "init_m_mean", "init_m_cov", "init_w_nu", "init_w_V", "init_s_alpha")] + [
+        ("materialize_responsibilities", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p)]
+
+
 class HgfDesc(ctypes.Structure):
     _fields_ = [("T", ctypes.c_int64), ("n_series", ctypes.c_int64)] + [(n, ctypes.c_double) for n in (
         "kappa", "omega", "z_variance", "y_variance", "z0_mean", "z0_var", "x0_mean", "x0_var")] + [
@@ -103,6 +109,7 @@ SYMBOLS = [
     ("rxhip_copy_free_energy_to_device", ctypes.c_int32, [_H, ctypes.c_void_p]),
     ("rxhip_counters", ctypes.c_int32, [_H, c_u64_p, c_u64_p, c_u64_p]),
     ("rxhip_gmm_create", ctypes.c_int32, [ctypes.POINTER(GmmDesc), ctypes.POINTER(_H)]),
+    ("rxhip_mvgmm_create", ctypes.c_int32, [ctypes.POINTER(MvGmmDesc), ctypes.POINTER(_H)]),
     ("rxhip_gmm_get_history", ctypes.c_int32, [_H, c_double_p]),
     ("rxhip_gmm_get_responsibilities", ctypes.c_int32, [_H, c_double_p]),
     ("rxhip_gmm_begin_run", ctypes.c_int32, [_H, ctypes.c_int32]),

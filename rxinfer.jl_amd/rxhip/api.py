@@ -11,7 +11,7 @@ from typing import Any, Optional
 
 import numpy as np
 
-from .engine import GMMEngine, HGFEngine, LGSSMEngine
+from .engine import GMMEngine, HGFEngine, LGSSMEngine, MvGMMEngine
 
 
 @dataclass
@@ -83,6 +83,31 @@ def iid_normal_gamma(mean, variance, shape, rate):
 
 
 @dataclass
+class Wishart:
+    """ExponentialFamily.Wishart(ν, S): degrees of freedom and scale matrix (arrays over components allowed)"""
+    nu: Any
+    S: Any
+
+
+@dataclass
+class MultivariateGaussianMixture:
+    """test/models/mixtures/gmm_multivariate_tests.jl:6-32: m[k] ~ MvNormal(mean, cov), w[k] ~ Wishart(ν, V), s ~ Dirichlet"""
+    prior_mean: np.ndarray   # [K][d]
+    prior_cov: np.ndarray    # [K][d][d]
+    prior_nu: np.ndarray     # [K]
+    prior_scale: np.ndarray  # [K][d][d]
+    prior_alpha: np.ndarray  # [K]
+
+
+def multivariate_gaussian_mixture(prior_mean, prior_cov, prior_nu, prior_scale, prior_alpha=None):
+    m = np.asarray(prior_mean, dtype=np.float64)
+    K = m.shape[0]
+    return MultivariateGaussianMixture(m, np.asarray(prior_cov, dtype=np.float64), np.asarray(prior_nu, dtype=np.float64),
+                                       np.asarray(prior_scale, dtype=np.float64),
+                                       np.ones(K) if prior_alpha is None else np.asarray(prior_alpha, dtype=np.float64))
+
+
+@dataclass
 class HierarchicalGaussianFilter:
     """One-step HGF graph streamed over the observations with posterior→prior autoupdates
     (test/models/statespace/hgf_tests.jl:9-70)."""
@@ -141,6 +166,38 @@ def _infer_mixture(model, data, iterations, free_energy, options, initialization
         eng.run(iters, free_energy)
         h = eng.history()
         post = {"m": NormalMeanVariance(h[:, 0], h[:, 1]), "p": GammaShapeRate(h[:, 2], h[:, 3]), "s": Dirichlet(h[:, 4])}
+        if options.get("materialize_z", False):
+            post["z"] = eng.responsibilities()
+        return InferenceResult(post, None, eng.free_energy() if free_energy else None, model, None)
+    except Exception as err:
+        if not catch_exception:
+            raise
+        return InferenceResult({}, None, None, model, err)
+    finally:
+        if eng is not None:
+            eng.close()
+
+
+def _infer_mv_mixture(model, data, iterations, free_energy, options, initialization, catch_exception):
+    """posteriors (KeepEach): m -> MvNormalMeanCovariance [it][K], w -> Wishart [it][K], s -> Dirichlet [it][K];
+    z (last iteration) if options['materialize_z'].  initialization = {"m": MvNormalMeanCovariance, "w": Wishart, "s": Dirichlet}."""
+    options = _check_options(options)
+    if initialization is None or "m" not in initialization or "w" not in initialization:
+        raise ValueError("mean-field VMP needs `initialization` (q(m), q(w)[, q(s)]); cf. test/models/mixtures/gmm_multivariate_tests.jl:66-70")
+    y = np.asarray(data["y"], dtype=np.float64)
+    iters = 1 if iterations is None else int(iterations)
+    K = model.prior_mean.shape[0]
+    qm, qw = initialization["m"], initialization["w"]
+    qs = initialization.get("s", Dirichlet(np.ones(K)))
+    eng = None
+    try:
+        eng = MvGMMEngine(y.shape[0], model.prior_mean, model.prior_cov, model.prior_nu, model.prior_scale, model.prior_alpha,
+                          qm.mean, qm.cov, np.broadcast_to(np.asarray(qw.nu, dtype=np.float64), (K,)).copy(), qw.S, qs.alpha,
+                          materialize_responsibilities=bool(options.get("materialize_z", False)), device=int(options.get("device", -1)))
+        eng.set_data(y)
+        eng.run(iters, free_energy)
+        h = eng.history()
+        post = {"m": MvNormalMeanCovariance(h["mean"], h["cov"]), "w": Wishart(h["nu"], h["V"]), "s": Dirichlet(h["alpha"])}
         if options.get("materialize_z", False):
             post["z"] = eng.responsibilities()
         return InferenceResult(post, None, eng.free_energy() if free_energy else None, model, None)
@@ -238,6 +295,8 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
     Returns posteriors["x"] as MvNormalMeanCovariance with mean [T][d] / [chain][T][d]."""
     if isinstance(model, UnivariateGaussianMixture):
         return _infer_mixture(model, data, iterations, free_energy, options, initialization, catch_exception)
+    if isinstance(model, MultivariateGaussianMixture):
+        return _infer_mv_mixture(model, data, iterations, free_energy, options, initialization, catch_exception)
     if isinstance(model, HierarchicalGaussianFilter):
         return _infer_hgf(model, data, iterations, free_energy, options, initialization, catch_exception)
     if not isinstance(model, LinearGaussianSSM):

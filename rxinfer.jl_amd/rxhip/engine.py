@@ -286,6 +286,54 @@ class GMMEngine:
         return r
 
 
+class MvGMMEngine(GMMEngine):
+    """Mean-field VMP for the multivariate Gaussian mixture, d = 1…4 (include/rxhip.h rxhip_mvgmm_desc).
+    priors: mu0 [K][d], S0 [K][d][d], nu0 [K], V0 [K][d][d], alpha0 [K]; init: the same five blocks of the initial marginals."""
+
+    def __init__(self, N, mu0, S0, nu0, V0, alpha0, init_m_mean, init_m_cov, init_w_nu, init_w_V, init_s_alpha,
+                 materialize_responsibilities=False, device=-1, stream=None):
+        L = _lib.lib()
+        arrs = [_c(a) for a in (mu0, S0, nu0, V0, alpha0, init_m_mean, init_m_cov, init_w_nu, init_w_V, init_s_alpha)]
+        self.K, self.d = arrs[0].shape
+        K, d = self.K, self.d
+        shapes = [(K, d), (K, d, d), (K,), (K, d, d), (K,)] * 2
+        if any(a.shape != sh for a, sh in zip(arrs, shapes)):
+            raise ValueError("prior / initialisation arrays have inconsistent shapes")
+        self.N = int(N)
+        self._keep = arrs
+        desc = _lib.MvGmmDesc()
+        desc.N, desc.K, desc.d = self.N, K, d
+        for name, a in zip(("mu0", "S0", "nu0", "V0", "alpha0", "init_m_mean", "init_m_cov", "init_w_nu", "init_w_V", "init_s_alpha"), arrs):
+            setattr(desc, name, _p(a))
+        desc.materialize_responsibilities = int(bool(materialize_responsibilities))
+        desc.device = int(device)
+        desc.stream = ctypes.c_void_p(stream) if stream else None
+        self._h = ctypes.c_void_p()
+        st = L.rxhip_mvgmm_create(ctypes.byref(desc), ctypes.byref(self._h))
+        if st != _lib.OK:
+            msg = L.rxhip_last_error(self._h).decode() if self._h else L.rxhip_status_string(st).decode()
+            if self._h:
+                L.rxhip_destroy(self._h)
+                self._h = None
+            raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
+        self._iters = 0
+        self._data_ref = None
+
+    def set_data(self, y):
+        y = _c(y)
+        if y.shape != (self.N, self.d):
+            raise ValueError(f"observations must be [N][d] = {(self.N, self.d)}")
+        self._chk(_lib.lib().rxhip_set_data(self._h, _lib.VAR_Y, _p(y), y.size, _lib.LAYOUT_TIME_CHAIN))
+
+    def history(self):
+        """dict of arrays over (iteration, component): mean [.., d], cov [.., d, d], nu, V [.., d, d], alpha (KeepEach)."""
+        d, dd = self.d, self.d * self.d
+        h = np.empty((self._iters, self.K, 2 + d + 2 * dd))
+        self._chk(_lib.lib().rxhip_gmm_get_history(self._h, _p(h)))
+        return dict(mean=h[..., :d], cov=h[..., d:d + dd].reshape(h.shape[:-1] + (d, d)), nu=h[..., d + dd],
+                    V=h[..., d + dd + 1:d + 2 * dd + 1].reshape(h.shape[:-1] + (d, d)), alpha=h[..., -1], raw=h)
+
+
 class HGFEngine:
     """Online hierarchical Gaussian filter (GCV node) for n_series independent series (include/rxhip.h rxhip_hgf_desc)."""
 

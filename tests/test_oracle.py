@@ -93,3 +93,45 @@ def test_batch_driver_matches_single_chain():
         m, V, fe, _ = rxoracle.lgssm_bp(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y[:, c])
         assert np.array_equal(m, bm[:, c]) and np.array_equal(V, bV[:, c]) and fe == bfe[c]
     assert cnt.rule_calls == 5 * (6 * 50 - 3)
+
+
+# ---- multivariate mixture oracle --------------------------------------------------------------------------------
+def test_multivariate_mixture_oracle_reduces_to_the_univariate_one():
+    """d = 1: Wishart(ν, V) = Gamma(shape ν/2, rate 1/(2V)) — the two independent restatements agree to rounding,
+    marginals and free energy, at every iteration."""
+    rng = np.random.default_rng(5)
+    K, N = 3, 400
+    mus = np.array([-5.0, 0.0, 6.0])
+    z = rng.integers(0, K, N)
+    y = mus[z] + rng.standard_normal(N) * np.array([0.5, 1.0, 2.0])[z]
+    mu0, v0, a0, b0, al0 = np.array([-4.0, 1.0, 5.0]), np.array([1e2, 50.0, 1e3]), np.array([0.1, 0.5, 1.5]), np.array([0.2, 0.1, 0.7]), np.array([1.0, 2.0, 0.5])
+    im, iv, ia, ib, isa = np.array([-4.0, 1.0, 5.0]), np.array([1.0, 2.0, 3.0]), np.array([1.0, 2.0, 1.5]), np.array([1.0, 0.5, 2.0]), np.array([1.0, 1.0, 2.0])
+    h1, f1, _, _ = rxoracle.gmm_vmp(y, mu0, v0, a0, b0, al0, im, iv, ia, ib, isa, 8)
+    init = rxoracle.mvgmm_pack(im[:, None], iv[:, None, None], 2 * ia, (1 / (2 * ib))[:, None, None], isa)
+    h2, f2, _ = rxoracle.mvgmm_vmp(y[:, None], mu0[:, None], v0[:, None, None], 2 * a0, (1 / (2 * b0))[:, None, None], al0, init, 8)
+    u = rxoracle.mvgmm_unpack(h2, 1)
+    assert np.max(np.abs(f1 - f2) / np.abs(f1)) < 1e-12
+    assert np.max(np.abs(u["mean"][..., 0] - h1[:, 0])) < 1e-12 and np.max(np.abs(u["cov"][..., 0, 0] - h1[:, 1]) / h1[:, 1]) < 1e-12
+    assert np.max(np.abs(u["nu"] / 2 - h1[:, 2])) < 1e-12 and np.max(np.abs(1 / (2 * u["V"][..., 0, 0]) - h1[:, 3]) / h1[:, 3]) < 1e-12
+    assert np.max(np.abs(u["alpha"] - h1[:, 4])) < 1e-12
+
+
+def test_multivariate_mixture_oracle_on_the_reference_layout():
+    """K = 3 clusters on a ring of radius 50, covariances diag(10, 20) rotated (gmm_multivariate_tests.jl:86-103), vague
+    priors: the free energy decreases monotonically, the means are found, E[W]⁻¹ is close to the true covariances."""
+    rng = np.random.default_rng(11)
+    K, N = 3, 600
+    ang = 2 * np.pi / K * np.arange(K)
+    means = 50.0 * np.stack([np.cos(ang), np.sin(ang)], axis=1)
+    covs = [np.array([[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]) @ np.diag([10.0, 20.0]) @ np.array([[np.cos(a), np.sin(a)], [-np.sin(a), np.cos(a)]]) for a in ang]
+    zs = rng.integers(0, K, N)
+    y = np.stack([rng.multivariate_normal(means[k], covs[k]) for k in zs])
+    mu0 = 0.5 * means + rng.uniform(0, 10, (K, 2))
+    S0, nu0, V0 = np.tile(1e6 * np.eye(2), (K, 1, 1)), np.full(K, 3.0), np.tile(1e2 * np.eye(2), (K, 1, 1))
+    h, fe, resp = rxoracle.mvgmm_vmp(y, mu0, S0, nu0, V0, np.ones(K), rxoracle.mvgmm_pack(mu0, S0, nu0, V0, np.ones(K)), 25, want_resp=True)
+    u = rxoracle.mvgmm_unpack(h[-1], 2)
+    assert np.all(np.diff(fe) < 1e-9 * abs(fe[-1]))
+    assert np.max(np.abs(u["mean"] - means)) < 1.5
+    for k in range(K):
+        assert np.max(np.abs(np.linalg.inv(u["nu"][k] * u["V"][k]) - covs[k])) < 6.0
+    assert np.mean(np.argmax(resp, axis=1) == zs) > 0.99 and abs(u["alpha"].sum() - (N + K)) < 1e-9
