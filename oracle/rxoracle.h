@@ -25,8 +25,8 @@
  * (docs/src/manuals/variational/bethe-free-energy.md:70), and (c) the RNG-dependent golden values of the
  * reference tests, on data regenerated bit-exactly by oracle/stable_rng.py (StableRNGs + Julia's randn restated):
  * mlgssm_test.jl:128 FE 6275.9015944677 (13 digits), ulgssm_tests.jl:48 FE 1854.297647, hgf_tests.jl:113 FE
- * 1.009879989585 (to 1e-5); fixtures under tests/golden/.  "Parity unpinned" remains only for the mixture
- * goldens (their data need Distributions' alias-table sampler) — see DESIGN.md §5.
+ * 1.009879989585 (to 1e-5), gmm_multivariate_tests.jl:141 FE 3436.7 (3436.721; the label sampler's alias-table layout
+ * is inferred — DESIGN.md §5); fixtures under tests/golden/.  Not reproduced: gmm_univariate_tests.jl:97.
  */
 #ifndef RXORACLE_H
 #define RXORACLE_H
