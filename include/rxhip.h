@@ -120,13 +120,16 @@ enum {
     RXHIP_NODE_CATEGORICAL = 8,           /* (out, p) */
     RXHIP_NODE_BERNOULLI = 9,             /* (out, p) */
     RXHIP_NODE_NORMAL_MIXTURE = 10,       /* (out, switch, m[1..K], p[1..K])  test/models/mixtures/gmm_univariate_tests.jl:16-19 */
-    RXHIP_NODE_GCV = 11                   /* (y, x, z, κ, ω)  test/models/statespace/hgf_tests.jl:28 */
+    RXHIP_NODE_GCV = 11,                  /* (y, x, z, κ, ω)  test/models/statespace/hgf_tests.jl:28 */
+    RXHIP_NODE_WISHART = 12               /* (out, ν, S)  `Wishart(ν, S)`, test/models/mixtures/gmm_multivariate_tests.jl:23 */
 };
 enum { /* family of an `@initialization` marginal (InitMarExtraKey, src/model/plugins/initialization_plugin.jl:201-202) */
     RXHIP_INIT_NONE = 0,
     RXHIP_INIT_NORMAL = 1,   /* (mean, variance) */
     RXHIP_INIT_GAMMA = 2,    /* (shape, rate) */
-    RXHIP_INIT_DIRICHLET = 3 /* alpha[rows]; Beta(a, b) = (a, b) */
+    RXHIP_INIT_DIRICHLET = 3, /* alpha[rows]; Beta(a, b) = (a, b) */
+    RXHIP_INIT_MVNORMAL = 4,  /* mean[d], cov[d][d] */
+    RXHIP_INIT_WISHART = 5    /* nu, S[d][d] */
 };
 typedef struct {
     int64_t n_variables;
@@ -182,6 +185,18 @@ typedef struct {
     int64_t* data_var;                                                               /* [N] variable id of y[i] (nullable) */
 } rxhip_gmm_lowered;
 rxhip_status rxhip_graph_lower_gmm(const rxhip_graph_desc* g, rxhip_gmm_lowered* out);
+
+/* Multivariate mixture (test/models/mixtures/gmm_multivariate_tests.jl:6-32): m[k] ~ MvNormal(mean, cov const);
+ * w[k] ~ Wishart(ν, S const); s ~ Dirichlet; z[i] ~ Categorical(s); y[i] (data, d-vector) ~ NormalMixture(z[i], m, w).
+ * Two-call protocol (N, K, d first).  Arrays as in rxhip_mvgmm_desc. */
+typedef struct {
+    int64_t N;
+    int32_t K, d;
+    double *mu0, *S0, *nu0, *V0, *alpha0;
+    double *init_m_mean, *init_m_cov, *init_w_nu, *init_w_V, *init_s_alpha;
+    int64_t* data_var; /* [N] (nullable) */
+} rxhip_mvgmm_lowered;
+rxhip_status rxhip_graph_lower_mvgmm(const rxhip_graph_desc* g, rxhip_mvgmm_lowered* out);
 
 /* Hierarchical Gaussian filter one-step graph (a11; test/models/statespace/hgf_tests.jl:9-31):
  *     zt_min ~ Normal(data, data); xt_min ~ Normal(data, data); zt ~ Normal(mean = zt_min, var = const);

@@ -373,4 +373,90 @@ inline rxhip_status lower_hgf(const rxhip_graph_desc* g, Hgf& H) {
     return RXHIP_OK;
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Multivariate mixture: MvNormalMeanCovariance priors on m[k] (constant mean / covariance), Wishart priors on w[k],
+// Dirichlet + Categorical switch, NormalMixture observation nodes over d-vector data
+struct MvGmm {
+    long long N = 0;
+    int K = 0, d = 0;
+    std::vector<double> mu0, S0, nu0, V0, alpha0, qm_mean, qm_cov, qw_nu, qw_V, qs_alpha;
+    std::vector<long long> data_var;
+};
+inline rxhip_status lower_mvgmm(const rxhip_graph_desc* g, MvGmm& M) {
+    if (rxhip_status st = check_tables(g)) return st;
+    const long long NV = g->n_variables, NF = g->n_factors;
+    M = MvGmm();
+    std::vector<long long> prior_of(NV, -1), cat_of(NV, -1), mix;
+    long long s_var = -1, s_prior = -1;
+    for (long long f = 0; f < NF; ++f) {
+        const int t = g->factor_type[f], n = n_iface(g, f);
+        const long long out = iface(g, f, 0);
+        if (t == RXHIP_NODE_MVNORMAL_MEAN_COV || t == RXHIP_NODE_WISHART) {
+            if (n != 3) return badarg("prior node must have 3 interfaces");
+            if (g->var_kind[out] != RXHIP_VARKIND_RANDOM || prior_of[out] >= 0) return unsupported("MvNormal / Wishart node is not a component prior");
+            prior_of[out] = f;
+        } else if (t == RXHIP_NODE_DIRICHLET) {
+            if (n != 2 || s_prior >= 0) return unsupported("more than one switch prior");
+            s_prior = f;
+            s_var = out;
+        } else if (t == RXHIP_NODE_CATEGORICAL) {
+            if (n != 2 || cat_of[out] >= 0) return unsupported("switch variable with two Categorical nodes");
+            cat_of[out] = f;
+        } else if (t == RXHIP_NODE_NORMAL_MIXTURE)
+            mix.push_back(f);
+        else
+            return unsupported("node type " + std::to_string(t) + " has no place in a multivariate mixture graph");
+    }
+    if (mix.empty() || s_prior < 0) return unsupported("no NormalMixture nodes / no switch prior");
+    const int K = (n_iface(g, mix[0]) - 2) / 2;
+    const int d = g->var_rows[iface(g, mix[0], 0)];
+    if (K < 1 || K > 16 || n_iface(g, mix[0]) != 2 + 2 * K || d < 1 || d > 4) return unsupported("mixture with an unsupported number of components / dimension");
+    std::vector<long long> mv(K), wv(K);
+    for (int k = 0; k < K; ++k) { mv[k] = iface(g, mix[0], 2 + k); wv[k] = iface(g, mix[0], 2 + K + k); }
+    long long used = 1;
+    for (long long f : mix) {
+        if (n_iface(g, f) != 2 + 2 * K) return unsupported("observation nodes of different shapes");
+        const long long y = iface(g, f, 0), z = iface(g, f, 1);
+        if (g->var_kind[y] != RXHIP_VARKIND_DATA || g->var_rows[y] != d) return unsupported("mixture observation must be a d-vector data variable");
+        for (int k = 0; k < K; ++k)
+            if (iface(g, f, 2 + k) != mv[k] || iface(g, f, 2 + K + k) != wv[k]) return unsupported("observation nodes do not share the component variables");
+        if (g->var_kind[z] != RXHIP_VARKIND_RANDOM || cat_of[z] < 0 || iface(g, cat_of[z], 1) != s_var) return unsupported("switch variable without its Categorical node");
+        cat_of[z] = -2;
+        M.data_var.push_back(y);
+        used += 2;
+    }
+    for (int k = 0; k < K; ++k) {
+        const long long fm = prior_of[mv[k]], fw = prior_of[wv[k]];
+        if (fm < 0 || g->factor_type[fm] != RXHIP_NODE_MVNORMAL_MEAN_COV || fw < 0 || g->factor_type[fw] != RXHIP_NODE_WISHART)
+            return unsupported("component without its MvNormal / Wishart prior node");
+        const double *mu, *S, *V, *q;
+        double nu;
+        if (!const_value(g, iface(g, fm, 1), d, 1, &mu) || !const_value(g, iface(g, fm, 2), d, d, &S)) return unsupported("MvNormal prior with non-constant parameters");
+        if (!const_scalar(g, iface(g, fw, 1), &nu) || !const_value(g, iface(g, fw, 2), d, d, &V)) return unsupported("Wishart prior with non-constant parameters");
+        M.mu0.insert(M.mu0.end(), mu, mu + d);
+        M.S0.insert(M.S0.end(), S, S + d * d);
+        M.nu0.push_back(nu);
+        M.V0.insert(M.V0.end(), V, V + d * d);
+        if (!init_params(g, mv[k], RXHIP_INIT_MVNORMAL, d + d * d, &q)) return badarg("mean-field VMP needs an @initialization marginal for every m[k]");
+        M.qm_mean.insert(M.qm_mean.end(), q, q + d);
+        M.qm_cov.insert(M.qm_cov.end(), q + d, q + d + d * d);
+        if (!init_params(g, wv[k], RXHIP_INIT_WISHART, 1 + d * d, &q)) return badarg("mean-field VMP needs an @initialization marginal for every w[k]");
+        M.qw_nu.push_back(q[0]);
+        M.qw_V.insert(M.qw_V.end(), q + 1, q + 1 + d * d);
+        used += 2;
+    }
+    const double* al;
+    if (!const_value(g, iface(g, s_prior, 1), K, 1, &al)) return unsupported("Dirichlet prior with non-constant or mis-sized parameters");
+    M.alpha0.assign(al, al + K);
+    const double* q;
+    if (init_params(g, s_var, RXHIP_INIT_DIRICHLET, K, &q)) M.qs_alpha.assign(q, q + K);
+    else M.qs_alpha.assign(K, 1.0);
+    if (used != NF) return unsupported("graph has factors outside the mixture");
+    M.N = (long long)mix.size();
+    M.K = K;
+    M.d = d;
+    last_error().clear();
+    return RXHIP_OK;
+}
+
 }  // namespace rxhip_lower

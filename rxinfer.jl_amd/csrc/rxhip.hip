@@ -1505,6 +1505,19 @@ rxhip_status rxhip_graph_lower_gmm(const rxhip_graph_desc* g, rxhip_gmm_lowered*
     if (out->data_var) for (long long i = 0; i < M.N; ++i) out->data_var[i] = M.data_var[i];
     return RXHIP_OK;
 }
+rxhip_status rxhip_graph_lower_mvgmm(const rxhip_graph_desc* g, rxhip_mvgmm_lowered* out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    rxhip_lower::MvGmm M;
+    rxhip_status st = rxhip_lower::lower_mvgmm(g, M);
+    if (st) return st;
+    out->N = M.N; out->K = M.K; out->d = M.d;
+    auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
+    cp(out->mu0, M.mu0); cp(out->S0, M.S0); cp(out->nu0, M.nu0); cp(out->V0, M.V0); cp(out->alpha0, M.alpha0);
+    cp(out->init_m_mean, M.qm_mean); cp(out->init_m_cov, M.qm_cov); cp(out->init_w_nu, M.qw_nu); cp(out->init_w_V, M.qw_V);
+    cp(out->init_s_alpha, M.qs_alpha);
+    if (out->data_var) for (long long i = 0; i < M.N; ++i) out->data_var[i] = M.data_var[i];
+    return RXHIP_OK;
+}
 rxhip_status rxhip_graph_lower_hgf(const rxhip_graph_desc* g, rxhip_hgf_lowered* out) {
     if (!out) return RXHIP_ERR_BADARG;
     rxhip_lower::Hgf H;
@@ -1533,6 +1546,19 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
         d.z0_mean = H.z0m; d.z0_var = H.z0v; d.x0_mean = H.x0m; d.x0_var = H.x0v;
         d.n_gh = H.n_gh; d.device = device; d.stream = stream;
         return rxhip_hgf_create(&d, out);
+    }
+    if (rxhip_lower::has_node(g, RXHIP_NODE_WISHART)) {
+        rxhip_lower::MvGmm M;
+        rxhip_status st = rxhip_lower::lower_mvgmm(g, M);
+        if (st) return st;
+        rxhip_mvgmm_desc d;
+        std::memset(&d, 0, sizeof d);
+        d.N = M.N; d.K = M.K; d.d = M.d;
+        d.mu0 = M.mu0.data(); d.S0 = M.S0.data(); d.nu0 = M.nu0.data(); d.V0 = M.V0.data(); d.alpha0 = M.alpha0.data();
+        d.init_m_mean = M.qm_mean.data(); d.init_m_cov = M.qm_cov.data(); d.init_w_nu = M.qw_nu.data(); d.init_w_V = M.qw_V.data();
+        d.init_s_alpha = M.qs_alpha.data();
+        d.device = device; d.stream = stream;
+        return rxhip_mvgmm_create(&d, out);
     }
     if (rxhip_lower::has_node(g, RXHIP_NODE_NORMAL_MIXTURE) || rxhip_lower::has_node(g, RXHIP_NODE_NORMAL_MEAN_PRECISION)) {
         rxhip_lower::Gmm M;

@@ -32,8 +32,8 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 VARKIND_RANDOM, VARKIND_DATA, VARKIND_CONST = 0, 1, 2
 NODE_MVNORMAL_MEAN_COV, NODE_MULTIPLY = 1, 2
 (NODE_NORMAL_MEAN_VARIANCE, NODE_NORMAL_MEAN_PRECISION, NODE_GAMMA_SHAPE_RATE, NODE_DIRICHLET, NODE_BETA, NODE_CATEGORICAL,
- NODE_BERNOULLI, NODE_NORMAL_MIXTURE, NODE_GCV) = range(3, 12)
-INIT_NONE, INIT_NORMAL, INIT_GAMMA, INIT_DIRICHLET = 0, 1, 2, 3
+ NODE_BERNOULLI, NODE_NORMAL_MIXTURE, NODE_GCV, NODE_WISHART) = range(3, 13)
+INIT_NONE, INIT_NORMAL, INIT_GAMMA, INIT_DIRICHLET, INIT_MVNORMAL, INIT_WISHART = 0, 1, 2, 3, 4, 5
 
 
 class GraphDesc(ctypes.Structure):
@@ -55,6 +55,12 @@ class LgssmLowered(ctypes.Structure):
 class GmmLowered(ctypes.Structure):
     _fields_ = [("N", ctypes.c_int64), ("K", ctypes.c_int32)] + [(n, c_double_p) for n in (
         "mu0", "v0", "a0", "b0", "alpha0", "init_m_mean", "init_m_var", "init_p_shape", "init_p_rate", "init_s_alpha")] + [
+        ("data_var", c_int64_p)]
+
+
+class MvGmmLowered(ctypes.Structure):
+    _fields_ = [("N", ctypes.c_int64), ("K", ctypes.c_int32), ("d", ctypes.c_int32)] + [(n, c_double_p) for n in (
+        "mu0", "S0", "nu0", "V0", "alpha0", "init_m_mean", "init_m_cov", "init_w_nu", "init_w_V", "init_s_alpha")] + [
         ("data_var", c_int64_p)]
 
 
@@ -87,6 +93,7 @@ SYMBOLS = [
     ("rxhip_lgssm_create", ctypes.c_int32, [ctypes.POINTER(LgssmDesc), ctypes.POINTER(_H)]),
     ("rxhip_graph_lower_lgssm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(LgssmLowered)]),
     ("rxhip_graph_lower_gmm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(GmmLowered)]),
+    ("rxhip_graph_lower_mvgmm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(MvGmmLowered)]),
     ("rxhip_graph_lower_hgf", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(HgfLowered)]),
     ("rxhip_lowering_error", ctypes.c_char_p, []),
     ("rxhip_create", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,

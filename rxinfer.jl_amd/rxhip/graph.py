@@ -193,6 +193,56 @@ def mixture_graph(N, prior_mean, prior_var, prior_shape, prior_rate, prior_alpha
     return gb, ys
 
 
+def mv_mixture_graph(N, prior_mean, prior_cov, prior_nu, prior_scale, prior_alpha, init=None):
+    """The graph of `multivariate_gaussian_mixture_model` (test/models/mixtures/gmm_multivariate_tests.jl:6-32).
+    init = dict(m=(means [K][d], covs [K][d][d]), w=(nus [K], scales [K][d][d]), s=alphas)."""
+    prior_mean = np.asarray(prior_mean, float)
+    K, d = prior_mean.shape
+    gb = GraphBuilder()
+    s = gb.randomvar(K)
+    gb.node(_lib.NODE_DIRICHLET, s, gb.constvar(np.asarray(prior_alpha, float)))
+    m, w = [], []
+    for k in range(K):
+        mk, wk = gb.randomvar(d), gb.randomvar(d)
+        gb.node(_lib.NODE_MVNORMAL_MEAN_COV, mk, gb.constvar(prior_mean[k]), gb.constvar(np.asarray(prior_cov[k], float)))
+        gb.node(_lib.NODE_WISHART, wk, gb.constvar(float(prior_nu[k])), gb.constvar(np.asarray(prior_scale[k], float)))
+        m.append(mk); w.append(wk)
+    ys = []
+    for _ in range(N):
+        z, y = gb.randomvar(1), gb.datavar(d)
+        gb.node(_lib.NODE_CATEGORICAL, z, s)
+        gb.node(_lib.NODE_NORMAL_MIXTURE, y, z, *m, *w)
+        ys.append(y)
+    if init is not None:
+        for k in range(K):
+            gb.initialize(m[k], _lib.INIT_MVNORMAL, np.concatenate([np.ravel(init["m"][0][k]), np.ravel(init["m"][1][k])]))
+            gb.initialize(w[k], _lib.INIT_WISHART, np.concatenate([[init["w"][0][k]], np.ravel(init["w"][1][k])]))
+        if "s" in init:
+            gb.initialize(s, _lib.INIT_DIRICHLET, init["s"])
+    return gb, ys
+
+
+def lower_mvgmm(g):
+    """Host-only lowering of a multivariate mixture graph."""
+    L = _lib.lib()
+    out = _lib.MvGmmLowered()
+    st = L.rxhip_graph_lower_mvgmm(ctypes.byref(g), ctypes.byref(out))
+    if st != _lib.OK:
+        raise RxHipError(st, L.rxhip_lowering_error().decode())
+    N, K, d = out.N, out.K, out.d
+    shapes = dict(mu0=(K, d), S0=(K, d, d), nu0=(K,), V0=(K, d, d), alpha0=(K,), init_m_mean=(K, d), init_m_cov=(K, d, d),
+                  init_w_nu=(K,), init_w_V=(K, d, d), init_s_alpha=(K,))
+    bufs = {n: np.empty(sh) for n, sh in shapes.items()}
+    dv = np.empty(N, dtype=np.int64)
+    for n, v in bufs.items():
+        setattr(out, n, v.ctypes.data_as(_lib.c_double_p))
+    out.data_var = dv.ctypes.data_as(_lib.c_int64_p)
+    st = L.rxhip_graph_lower_mvgmm(ctypes.byref(g), ctypes.byref(out))
+    if st != _lib.OK:
+        raise RxHipError(st, L.rxhip_lowering_error().decode())
+    return dict(N=N, K=K, d=d, data_var=dv, **bufs)
+
+
 def iid_normal_graph(N, mean, variance, shape, rate, init=None):
     """`iid_gaussians_params` (test/models/models_tests.jl:114-128): m ~ Normal, p ~ Gamma, y[i] ~ Normal(mean = m, precision = p)."""
     gb = GraphBuilder()
@@ -271,6 +321,12 @@ def create_vmp_engine_from_graph(g, device=-1, stream=None):
         eng = HGFEngine.__new__(HGFEngine)
         eng._h, eng.T, eng.n_series, eng._iters = h, int(g.n_observations), int(g.n_replicas or 1), 0
         eng.n_chains = eng.n_series
+    elif any(t == _lib.NODE_WISHART for t in np.ctypeslib.as_array(g.factor_type, (g.n_factors,))):
+        from .engine import MvGMMEngine
+
+        low = lower_mvgmm(g)
+        eng = MvGMMEngine.__new__(MvGMMEngine)
+        eng._h, eng.N, eng.K, eng.d, eng._iters = h, low["N"], low["K"], low["d"], 0
     else:
         low = lower_gmm(g)
         eng = GMMEngine.__new__(GMMEngine)

@@ -182,3 +182,46 @@ def test_vmp_engines_from_graphs_match_structured_descriptors():
     with rxhip.HGFEngine(T, S, 1.0, 0.0, 0.04, 0.01) as e2:
         e2.set_data(ys); e2.run(10, True)
         assert all(np.array_equal(a, b) for a, b in zip(z1, e2.history())) and np.array_equal(f1, e2.free_energy())
+
+
+def _mv_graph(N=30, with_init=True):
+    rng = np.random.default_rng(3)
+    K, d = 3, 2
+    pm = rng.standard_normal((K, d))
+    pc = np.tile(1e6 * np.eye(d), (K, 1, 1))
+    nu = np.array([3.0, 4.0, 5.0])
+    sc = np.stack([(k + 1.0) * np.eye(d) + 0.1 for k in range(K)])
+    init = dict(m=(pm + 1.0, pc * 0.5), w=(nu + 1.0, sc * 2.0), s=[1.0, 2.0, 3.0]) if with_init else None
+    gb, ys = graph.mv_mixture_graph(N, pm, pc, nu, sc, [1.0, 1.0, 2.0], init=init)
+    return gb, ys, pm, pc, nu, sc, init
+
+
+def test_multivariate_mixture_graph_is_recognised():
+    gb, ys, pm, pc, nu, sc, init = _mv_graph()
+    for perm in (None, np.random.default_rng(5).permutation(len(gb.ftype))):
+        low = graph.lower_mvgmm(gb.tables(permute=perm)[0])
+        assert (low["N"], low["K"], low["d"]) == (30, 3, 2)
+        assert np.array_equal(low["mu0"], pm) and np.array_equal(low["S0"], pc) and np.array_equal(low["nu0"], nu) and np.array_equal(low["V0"], sc)
+        assert np.array_equal(low["alpha0"], [1.0, 1.0, 2.0]) and np.array_equal(low["init_s_alpha"], init["s"])
+        assert np.array_equal(low["init_m_mean"], init["m"][0]) and np.array_equal(low["init_m_cov"], init["m"][1])
+        assert np.array_equal(low["init_w_nu"], init["w"][0]) and np.array_equal(low["init_w_V"], init["w"][1])
+    assert list(graph.lower_mvgmm(gb.tables()[0])["data_var"]) == ys
+    with pytest.raises(rxhip.RxHipError) as ei:  # no @initialization
+        graph.lower_mvgmm(_mv_graph(with_init=False)[0].tables()[0])
+    assert ei.value.status == _lib.ERR_BADARG
+    with pytest.raises(rxhip.RxHipError):  # a univariate mixture graph is not a multivariate one
+        gu, _ = graph.mixture_graph(5, _PRI["mean"], _PRI["var"], _PRI["shape"], _PRI["rate"], _PRI["alpha"], init=_INIT)
+        graph.lower_mvgmm(gu.tables()[0])
+
+
+@pytest.mark.gpu
+def test_multivariate_engine_from_graph_matches_structured_descriptor():
+    gb, ys, pm, pc, nu, sc, init = _mv_graph(N=400)
+    rng = np.random.default_rng(9)
+    y = rng.standard_normal((400, 2)) * 3.0 + np.array([[4.0, -2.0]]) * rng.integers(-1, 2, (400, 1))
+    e1 = graph.create_vmp_engine_from_graph(gb.tables()[0])
+    e1.set_data(y); e1.run(4, True)
+    h1, f1 = e1.history()["raw"], e1.free_energy(); e1.close()
+    with rxhip.MvGMMEngine(400, pm, pc, nu, sc, [1.0, 1.0, 2.0], init["m"][0], init["m"][1], init["w"][0], init["w"][1], init["s"]) as e2:
+        e2.set_data(y); e2.run(4, True)
+        assert np.array_equal(h1, e2.history()["raw"]) and np.array_equal(f1, e2.free_energy())
