@@ -186,6 +186,41 @@ function mixture_history(e::Engine, K::Integer)
     return hist
 end
 
+# mirrors rxhip_mvgmm_desc
+struct MvGmmDesc
+    N::Int64
+    K::Int32
+    d::Int32
+    mu0::Ptr{Float64}; S0::Ptr{Float64}; nu0::Ptr{Float64}; V0::Ptr{Float64}; alpha0::Ptr{Float64}
+    init_m_mean::Ptr{Float64}; init_m_cov::Ptr{Float64}; init_w_nu::Ptr{Float64}; init_w_V::Ptr{Float64}; init_s_alpha::Ptr{Float64}
+    materialize_responsibilities::Int32
+    device::Int32
+    stream::Ptr{Cvoid}
+end
+
+"""
+    MvMixtureEngine(y; mu0, S0, nu0, V0, alpha0, q_m_mean, q_m_cov, q_w_nu, q_w_V, q_s_alpha)
+
+`multivariate_gaussian_mixture_model` (test/models/mixtures/gmm_multivariate_tests.jl:6-32); y is d × N (one observation per
+column = the C layout [N][d]); matrices per component are symmetric, so Julia's column-major blocks are passed as they are."""
+function MvMixtureEngine(y::Matrix{Float64}; mu0, S0, nu0, V0, alpha0, q_m_mean, q_m_cov, q_w_nu, q_w_V, q_s_alpha, device::Integer = -1)
+    d, N = size(y)
+    K = length(nu0)
+    flat(x) = x isa AbstractVector{<:AbstractArray} ? reduce(vcat, vec.(x)) : Vector{Float64}(vec(x))
+    vs = map(x -> Vector{Float64}(flat(x)), (mu0, S0, nu0, V0, alpha0, q_m_mean, q_m_cov, q_w_nu, q_w_V, q_s_alpha))
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    st = GC.@preserve vs begin
+        desc = MvGmmDesc(N, K, d, map(pointer, vs)..., 0, device, C_NULL)
+        ccall((:rxhip_mvgmm_create, librxhip), Int32, (Ref{MvGmmDesc}, Ref{Ptr{Cvoid}}), desc, h)
+    end
+    e = Engine(h[], d, d, N, 1, 0)
+    st == RXHIP_OK || throw(RxHipError(st, unsafe_string(ccall((:rxhip_status_string, librxhip), Cstring, (Int32,), st))))
+    finalizer(destroy!, e)
+    GC.@preserve y check(e, ccall((:rxhip_set_data, librxhip), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Csize_t, Int32),
+                                  e.handle, RXHIP_VAR_Y, y, length(y), RXHIP_LAYOUT_TIME_CHAIN))
+    return e
+end
+
 # mirrors rxhip_hgf_desc
 struct HgfDesc
     T::Int64
