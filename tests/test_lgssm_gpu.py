@@ -215,3 +215,36 @@ def test_properties_at_scale():
         om, oc, ofe, _ = rxoracle.lgssm_bp(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y1[:, c])
         assert rel(m1[:, c], om) < RTOL_POST and rel(V[:, c], oc) < RTOL_POST
         assert abs(out[0][2][c] - ofe) < RTOL_FE * abs(ofe)
+
+
+def test_independent_handles_from_several_host_threads():
+    """One host thread per handle, handles independent (include/rxhip.h): four threads create / run / destroy engines
+    concurrently (the stream and block pools are the only shared state) and every result matches the oracle."""
+    import threading
+
+    mdl = workloads.notebook_model()
+    errs, lock = [], threading.Lock()
+
+    def worker(seed):
+        try:
+            rng = np.random.default_rng(seed)
+            for _ in range(25):
+                T, C = int(rng.choice([3, 40, 300])), int(rng.choice([1, 2, 64]))
+                y = workloads.generate_batch(mdl, T, C, seed0=int(rng.integers(1000)))
+                with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C) as eng:
+                    eng.set_data(y)
+                    eng.run(1, True)
+                    mean, _ = eng.marginals()
+                    fe = eng.free_energy_per_chain()
+                om, _, ofe, _ = rxoracle.lgssm_bp(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y[:, 0])
+                assert rel(mean[:, 0], om) < RTOL_POST and abs(fe[0] - ofe) < RTOL_FE * abs(ofe)
+        except Exception as e:  # noqa: BLE001
+            with lock:
+                errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(s,)) for s in range(4)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errs, errs
