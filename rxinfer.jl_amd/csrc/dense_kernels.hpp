@@ -476,6 +476,7 @@ struct DenseLds {
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
     constexpr int D = 16 * NT;
+    constexpr int NTH = 64 * NT;  // = 4·D: four thread groups of D, each sums half of the k range of one of two maps
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int dy = p.dy, tid = threadIdx.x;
     const int dm = ((D > dy ? D : dy) + 1) & ~1;  // even: keeps every LDS carve 16-byte aligned
@@ -484,6 +485,9 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
     double* eta = mn + dm;
     double* e = eta + dm;
     double* yv = e + dm;
+    double* red = yv + dm;          // [4][dm] partial sums
+    double* HFs = red + 4 * dm;     // (BA)' [D][dy]   constant maps staged in LDS once
+    double* As = HFs + D * dy;      // A'    [D][D]
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
@@ -492,32 +496,68 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
     if (b1 > p.T) b1 = p.T;
     const long long len = b1 - b0;
     const long long t0 = seg * p.L + 1;
+    for (int q = tid; q < D * dy; q += NTH) HFs[q] = cst[c.oHFT + q];
+    for (int q = tid; q < D * D; q += NTH) As[q] = cst[c.oAT + q];
     if (tid < D) {
         m[tid] = 0.0;
         eta[tid] = 0.0;
     }
+    const int part = tid / D, i = tid - part * D;
+    const int half = part & 1;
     __syncthreads();
-    for (long long i = 0; i < len; ++i) {
-        if (tid < dy) yv[tid] = p.y[((t0 + i) * p.n_chains + chain) * dy + tid];
-        __syncthreads();
-        // e = y − HF m
-        matvec_gT(e, cst + c.oHFT, dy, D, m, nullptr, 0.0, tid);
-        __syncthreads();
-        if (tid < dy) e[tid] = yv[tid] - e[tid];             // e = y − (BA) m
-        __syncthreads();
-        const double* tb = p.tab + i * 2 * D * dy;           // [2][dy][D]: K_i', U_i' (transposed, coalesced)
-        if (tid < D) {
-            double s = 0.0, u = eta[tid];
-            for (int k = 0; k < D; ++k) s += cst[c.oAT + (long long)k * D + tid] * m[k];
-            for (int k = 0; k < dy; ++k) {
-                s += tb[(long long)k * D + tid] * e[k];
-                u += tb[(long long)dy * D + (long long)k * D + tid] * e[k];
+    for (long long it = 0; it < len; ++it) {
+        if (tid < dy) yv[tid] = p.y[((t0 + it) * p.n_chains + chain) * dy + tid];
+        // phase 1: groups 0,1 -> halves of (BA) m ; groups 2,3 -> halves of A m        (both maps from LDS)
+        {
+            const int k0 = half * (D / 2), k1 = k0 + D / 2;
+            double s0 = 0.0, s1 = 0.0;
+            if (part < 2) {
+                for (int r = i; r < dy; r += D) {  // dy may exceed D (padded small state, wide observation)
+                    s0 = s1 = 0.0;
+#pragma unroll 8
+                    for (int k = k0; k < k1; k += 2) {
+                        s0 += HFs[k * dy + r] * m[k];
+                        s1 += HFs[(k + 1) * dy + r] * m[k + 1];
+                    }
+                    red[part * dm + r] = s0 + s1;
+                }
+            } else {
+#pragma unroll 8
+                for (int k = k0; k < k1; k += 2) {
+                    s0 += As[k * D + i] * m[k];
+                    s1 += As[(k + 1) * D + i] * m[k + 1];
+                }
+                red[part * dm + i] = s0 + s1;
             }
-            mn[tid] = s;
-            eta[tid] = u;
         }
         __syncthreads();
-        if (tid < D) m[tid] = mn[tid];
+        if (tid < dy) e[tid] = yv[tid] - (red[tid] + red[dm + tid]);  // e = y − (BA) m
+        if (tid < D) mn[tid] = red[2 * dm + tid] + red[3 * dm + tid]; // A m
+        __syncthreads();
+        // phase 2: groups 0,1 -> halves of K_i e ; groups 2,3 -> halves of U_i e        (per-offset tables from L2, coalesced)
+        {
+            const double* tb = p.tab + it * 2 * D * dy + (part < 2 ? 0 : (long long)dy * D);  // [2][dy][D]: K_i', U_i'
+            const int kh = (dy + 1) / 2, k0 = half * kh, k1 = (k0 + kh < dy) ? k0 + kh : dy;
+            double s0 = 0.0, s1 = 0.0;
+            int k = k0;
+            for (; k + 15 < k1; k += 16) {  // 16 independent loads in flight
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = tb[(long long)(k + u) * D + i];
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) {
+                    s0 += v[u] * e[k + u];
+                    s1 += v[u + 1] * e[k + u + 1];
+                }
+            }
+            for (; k < k1; ++k) s0 += tb[(long long)k * D + i] * e[k];
+            red[part * dm + i] = s0 + s1;
+        }
+        __syncthreads();
+        if (tid < D) {
+            m[tid] = mn[tid] + (red[tid] + red[dm + tid]);
+            eta[tid] += red[2 * dm + tid] + red[3 * dm + tid];
+        }
         __syncthreads();
     }
     if (tid < D) {
