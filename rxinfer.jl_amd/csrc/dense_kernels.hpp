@@ -272,7 +272,7 @@ struct Sweep4 {
                 reinterpret_cast<double2*>(dst)[1] = make_double2(a.v[t][2], a.v[t][3]);
             }
         }
-        __syncthreads();
+        lds_barrier();
         // the four pivot rows at this thread's columns, rc[u][t] = R[u][16t + jl]
         double rc[4][NT];
 #pragma unroll
@@ -348,7 +348,7 @@ __device__ __forceinline__ bool gj_inverse(Acc<NT>& a, double* rowbuf, double* /
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.v[t][r] = -a.v[t][r];
-    __syncthreads();
+    lds_barrier();
     return ok;
 }
 
@@ -395,43 +395,6 @@ __device__ __forceinline__ void matvec_gT(double* out, const double* MT, int n, 
         out[tid] = (s0 + s1) + (s2 + s3);
     }
 }
-// out[i] = base[i] + Σ_k M1T[k][i] x1[k] + sgn2 · Σ_k M2T[k][i] x2[k]   (both maps stored transposed, n×n).
-// All threads work: thread (part, i) sums a quarter/…/ of the k range with 8 coalesced loads in flight per
-// map, partial sums are combined through LDS in fixed order.  part count = nthreads / n (n = 16·NT ⇒ 4).
-__device__ __forceinline__ void matvec2_gT_all(double* out, const double* M1T, const double* M2T, int n, const double* x1,
-                                               const double* x2, double sgn2, const double* base, double* red, int tid,
-                                               int nthreads) {
-    const int parts = nthreads / n, part = tid / n, i = tid - part * n;
-    const int kper = (n + parts - 1) / parts, k0 = part * kper, k1 = (k0 + kper < n) ? k0 + kper : n;
-    double s0 = 0.0, s1 = 0.0;
-    int k = k0;
-    for (; k + 7 < k1; k += 8) {
-        double a[8], b[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            a[u] = M1T[(size_t)(k + u) * n + i];
-            b[u] = M2T[(size_t)(k + u) * n + i];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            s0 += a[u] * x1[k + u];
-            s1 += b[u] * x2[k + u];
-        }
-    }
-    for (; k < k1; ++k) {
-        s0 += M1T[(size_t)k * n + i] * x1[k];
-        s1 += M2T[(size_t)k * n + i] * x2[k];
-    }
-    red[tid] = s0 + sgn2 * s1;
-    __syncthreads();
-    if (tid < n) {
-        double s = base[tid];
-        for (int q = 0; q < parts; ++q) s += red[q * n + tid];
-        out[tid] = s;
-    }
-    __syncthreads();
-}
-
 // three block-wide dot products in one reduction (result valid in every thread); red: 3·nthreads doubles.
 // Works for any thread count (192 threads at d = 48).
 __device__ __forceinline__ void block_dot3(const double* a0, const double* b0, int n0, const double* a1, const double* b1,
@@ -444,7 +407,7 @@ __device__ __forceinline__ void block_dot3(const double* a0, const double* b0, i
     red[tid] = s0;
     red[nthreads + tid] = s1;
     red[2 * nthreads + tid] = s2;
-    __syncthreads();
+    lds_barrier();
     for (int n = nthreads; n > 1;) {
         const int h = (n + 1) / 2;
         if (tid < n - h) {
@@ -452,13 +415,13 @@ __device__ __forceinline__ void block_dot3(const double* a0, const double* b0, i
             red[nthreads + tid] += red[nthreads + tid + h];
             red[2 * nthreads + tid] += red[2 * nthreads + tid + h];
         }
-        __syncthreads();
+        lds_barrier();
         n = h;
     }
     out[0] = red[0];
     out[1] = red[nthreads];
     out[2] = red[2 * nthreads];
-    __syncthreads();
+    lds_barrier();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -504,7 +467,7 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
     }
     const int part = tid / D, i = tid - part * D;
     const int half = part & 1;
-    __syncthreads();
+    lds_barrier();
     for (long long it = 0; it < len; ++it) {
         if (tid < dy) yv[tid] = p.y[((t0 + it) * p.n_chains + chain) * dy + tid];
         // phase 1: groups 0,1 -> halves of (BA) m ; groups 2,3 -> halves of A m        (both maps from LDS)
@@ -530,10 +493,10 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
                 red[part * dm + i] = s0 + s1;
             }
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < dy) e[tid] = yv[tid] - (red[tid] + red[dm + tid]);  // e = y − (BA) m
         if (tid < D) mn[tid] = red[2 * dm + tid] + red[3 * dm + tid]; // A m
-        __syncthreads();
+        lds_barrier();
         // phase 2: groups 0,1 -> halves of K_i e ; groups 2,3 -> halves of U_i e        (per-offset tables from L2, coalesced)
         {
             const double* tb = p.tab + it * 2 * D * dy + (part < 2 ? 0 : (long long)dy * D);  // [2][dy][D]: K_i', U_i'
@@ -553,17 +516,88 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
             for (; k < k1; ++k) s0 += tb[(long long)k * D + i] * e[k];
             red[part * dm + i] = s0 + s1;
         }
-        __syncthreads();
+        lds_barrier();
         if (tid < D) {
             m[tid] = mn[tid] + (red[tid] + red[dm + tid]);
             eta[tid] += red[2 * dm + tid] + red[3 * dm + tid];
         }
-        __syncthreads();
+        lds_barrier();
     }
-    if (tid < D) {
-        double* o = p.elem + ((chain * p.S + seg) * 2) * D;
-        o[tid] = m[tid];
-        o[D + tid] = eta[tid];
+    // The boundary scan carries v <- w_s + M1_s v (prefix) and ξ <- w_s' + N1_s ξ (suffix); the parts that do not depend on
+    // the carried vector are formed here, in parallel over segments:  w_s = b_s + M2_s η_s,  w_s' = η_s − N2_s b_s.
+    {
+        const size_t MM = (size_t)D * D;
+        const double* Mt = p.scanm + ((size_t)seg * 6 + (part < 2 ? 1 : 4)) * MM;  // transposed maps: [k][i]
+        const double* x = part < 2 ? eta : m;
+        const int k0 = half * (D / 2);
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < D / 2; k += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (k + u < D / 2) ? Mt[(size_t)(k0 + k + u) * D + i] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 16; u += 2)
+                if (k + u < D / 2) {  // D/2 is even: pairs never straddle the bound
+                    s0 += v[u] * x[k0 + k + u];
+                    s1 += v[u + 1] * x[k0 + k + u + 1];
+                }
+        }
+        red[part * dm + i] = s0 + s1;
+        lds_barrier();
+        if (tid < D) {
+            double* o = p.elem + ((chain * p.S + seg) * 2) * D;
+            o[tid] = m[tid] + (red[tid] + red[dm + tid]);                     // w_s
+            o[D + tid] = eta[tid] - (red[2 * dm + tid] + red[3 * dm + tid]);  // w_s'
+        }
+    }
+}
+
+// The carried-vector recursion of the boundary scan (prefix: segments 0 … S−2 ascending, map 0 and w_s; suffix: segments
+// S−1 … 1 descending, map 3 and w_s').  v lives in LDS (v0); thread group `part` sums a quarter of the k range.
+template <int NT, bool SUFFIX>
+__device__ __forceinline__ void dense_scan_chain(const DenseParams& p, long long chain, double* v0, double* red, int tid) {
+    constexpr int D = 16 * NT, KP = D / 4, PD = 4;
+    const int S = p.S, nsteps = S - 1;
+    const size_t MM = (size_t)D * D;
+    const int part = tid / D, i = tid - part * D, k0 = part * KP;
+    double buf[PD][KP], wb[PD];
+    auto seg_of = [&](int st) { return SUFFIX ? S - 1 - st : st; };
+    auto fetch = [&](double (&dst)[KP], double& w, int st) {
+        const int sg = seg_of(st);
+        const double* Mt = p.scanm + ((size_t)sg * 6 + (SUFFIX ? 3 : 0)) * MM;
+#pragma unroll
+        for (int u = 0; u < KP; ++u) dst[u] = Mt[(size_t)(k0 + u) * D + i];
+        w = tid < D ? p.elem[((chain * S + sg) * 2 + (SUFFIX ? 1 : 0)) * D + tid] : 0.0;
+    };
+#pragma unroll
+    for (int q = 0; q < PD; ++q)
+        if (q < nsteps) fetch(buf[q], wb[q], q);
+    lds_barrier();
+    for (int st0 = 0; st0 <= nsteps; st0 += PD) {
+#pragma unroll
+        for (int q = 0; q < PD; ++q) {
+            const int st = st0 + q;
+            if (st > nsteps) break;
+            if (!SUFFIX && tid < D) p.fstart_m[(chain * S + st) * D + tid] = v0[tid];
+            if (st == nsteps) break;
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int u = 0; u < KP; u += 2) {
+                s0 += buf[q][u] * v0[k0 + u];
+                s1 += buf[q][u + 1] * v0[k0 + u + 1];
+            }
+            const double wv = wb[q];
+            if (st + PD < nsteps) fetch(buf[q], wb[q], st + PD);
+            red[tid] = s0 + s1;
+            lds_barrier();
+            if (tid < D) {
+                const double x = wv + ((red[tid] + red[D + tid]) + (red[2 * D + tid] + red[3 * D + tid]));
+                v0[tid] = x;
+                if (SUFFIX) p.beta_xi[(chain * (S + 1) + seg_of(st)) * D + tid] = x;
+            }
+            lds_barrier();
+        }
     }
 }
 
@@ -590,7 +624,7 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
     if (blockIdx.x == 0) {
         // filtered belief at t = 1: ξf = V1⁻¹m1 + G y;  mf = c1 + K1 y
         if (tid < dy) yv[tid] = p.y[(0 * p.n_chains + chain) * dy + tid];
-        __syncthreads();
+        lds_barrier();
         if (tid < D) {
             double xs = cst[c.oX1 + tid], ms = cst[c.oC1 + tid];
             for (int k = 0; k < dy; ++k) {
@@ -605,7 +639,7 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
             for (int k = 0; k < dy; ++k) s += cst[c.oQI + (long long)tid * dy + k] * yv[k];
             v2[tid] = s;  // Q⁻¹ y
         }
-        __syncthreads();
+        lds_barrier();
         double* rec = p.filt + (chain * p.T + 0) * C::REC;
         if (tid < D) rec[tid] = v0[tid];
         {
@@ -621,44 +655,16 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
             block_dot3(v2, yv, dy, v1, v0, D, v1, v0, 0, red, tid, 64 * NT, dots);
             if (tid == 0) p.fe_part[chain] = -0.5 * (cst[c.oC0] + dots[0] - dots[1] + cst[c.oS1] + cst[c.oLD1]);
         }
-        for (int s = 0; s < S; ++s) {
-            if (tid < D) p.fstart_m[(chain * S + s) * D + tid] = v0[tid];
-            if (s == S - 1) break;
-            const double* el = p.elem + ((chain * S + s) * 2) * D;
-            const double* M1 = p.scanm + ((size_t)s * 6 + 0) * MM;
-            const double* M2 = p.scanm + ((size_t)s * 6 + 1) * MM;
-            __syncthreads();
-            if (tid < D) {
-                v2[tid] = el[D + tid];  // η_s
-                yv[tid] = el[tid];      // b_s
-            }
-            __syncthreads();
-            matvec2_gT_all(v1, M1, M2, D, v0, v2, 1.0, yv, red, tid, 64 * NT);
-            if (tid < D) v0[tid] = v1[tid];
-            __syncthreads();
-        }
+        // sequential part: v <- w_s + M1_s v.  A cold 32 KB map read costs ≈2.6 µs of latency; the maps of the next PD segments
+        // are therefore kept in flight in registers (the loads do not depend on v) and a step costs one LDS partial-sum round.
+        dense_scan_chain<NT, false>(p, chain, v0, red, tid);
     } else {
         if (tid < D) {
             v0[tid] = 0.0;
             p.beta_xi[(chain * (S + 1) + S) * D + tid] = 0.0;
         }
-        __syncthreads();
-        for (int s = S - 1; s >= 1; --s) {
-            const double* el = p.elem + ((chain * S + s) * 2) * D;
-            const double* N1 = p.scanm + ((size_t)s * 6 + 3) * MM;
-            const double* N2 = p.scanm + ((size_t)s * 6 + 4) * MM;
-            if (tid < D) {
-                v2[tid] = el[tid];      // b_s
-                yv[tid] = el[D + tid];  // η_s
-            }
-            __syncthreads();
-            matvec2_gT_all(v1, N1, N2, D, v0, v2, -1.0, yv, red, tid, 64 * NT);
-            if (tid < D) {
-                v0[tid] = v1[tid];
-                p.beta_xi[(chain * (S + 1) + s) * D + tid] = v1[tid];
-            }
-            __syncthreads();
-        }
+        lds_barrier();
+        dense_scan_chain<NT, true>(p, chain, v0, red, tid);
     }
 }
 
@@ -703,7 +709,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     Acc<NT> a;
     acc_load<NT>(a, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
     acc_store<NT>(a, M0, LD, w, lane);
-    __syncthreads();
+    lds_barrier();
     for (long long i = 0; i < len; ++i) {
         const long long t = t0 + i;
         if (tid < dy) yv[tid] = p.y[(t * p.n_chains + chain) * dy + tid];
@@ -712,14 +718,14 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
         mm_acc<NT, false, false>(a, A, D, M0, LD, w, lane);
         acc_store<NT>(a, M1, LD, w, lane);
         matvec_gT(mp, cst + c.oAT, D, D, m, nullptr, 0.0, tid);
-        __syncthreads();
+        lds_barrier();
         Acc<NT> lam;
         acc_load<NT>(lam, cst + c.oP, D, w, lane);
         mm_acc<NT, false, true>(lam, M1, LD, A, D, w, lane);
         // weightedmean_precision of the forward message: Λp = Vp⁻¹
         ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
         acc_store<NT>(lam, M2, LD, w, lane);
-        __syncthreads();
+        lds_barrier();
         // smoother gain and residual of the previous time index (t − 1): G = T' Λp,  C = V_f − G T
         if (!p.filter) {
             double* rec = p.filt + (chain * p.T + (t - 1)) * C::REC;
@@ -727,7 +733,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
             mm_acc<NT, true, false>(a, M1, LD, M2, LD, w, lane);
             acc_store_full<NT>(a, rec + D + C::TRI, w, lane);
             acc_store<NT>(a, M3, LD, w, lane);
-            __syncthreads();
+            lds_barrier();
             Acc<NT> cc;
             acc_zero<NT>(cc);
             mm_acc<NT, false, false>(cc, M3, LD, M1, LD, w, lane);
@@ -743,15 +749,15 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
             matvec_lds(xp, M2, LD, D, D, mp, nullptr, 0.0, tid);
             matvec_gT(qy, cst + c.oQI, dy, dy, yv, nullptr, 0.0, tid);  // Q⁻¹ symmetric
         }
-        __syncthreads();
+        lds_barrier();
         matvec_gT(xf, cst + c.oGT, D, dy, yv, xp, 1.0, tid);
         acc_add_mat<NT>(lam, cst + c.oLOBS, D, w, lane, 1.0);
         // mean_cov of the product: Vf = Λf⁻¹, mf = Vf ξf
         ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
         acc_store<NT>(lam, M0, LD, w, lane);
-        __syncthreads();
+        lds_barrier();
         matvec_lds(m, M0, LD, D, D, xf, nullptr, 0.0, tid);
-        __syncthreads();
+        lds_barrier();
         if (p.filter) {  // q(x_t | y_1..t) is the marginal of the one-step graph
             if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = m[tid];
             acc_store_out<NT>(lam, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
@@ -806,11 +812,11 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
     {
         if (tid < D) mf[tid] = p.filt[(chain * p.T + te) * C::REC + tid];
         tri_to_lds<NT>(p.vend + (chain * p.S + seg) * C::TRI, M0, LD, w, lane);
-        __syncthreads();
+        lds_barrier();
         acc_load<NT>(a, M0, LD, w, lane);
         ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;  // Vf⁻¹
         acc_store<NT>(a, M1, LD, w, lane);
-        __syncthreads();
+        lds_barrier();
         if (tid < D) {
             double sacc = p.beta_xi[(chain * (p.S + 1) + seg + 1) * D + tid];
             for (int k = 0; k < D; ++k) sacc += M1[tid * LD + k] * mf[k];
@@ -819,9 +825,9 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
         acc_add_mat<NT>(a, p.scanm + ((size_t)seg * 6 + 5) * MM, D, w, lane, 1.0);
         ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;  // Vs
         acc_store<NT>(a, M2, LD, w, lane);
-        __syncthreads();
+        lds_barrier();
         matvec_lds(ms, M2, LD, D, D, u, nullptr, 0.0, tid);
-        __syncthreads();
+        lds_barrier();
         if (seg == p.S - 1) {
             if (tid < p.d_out) p.mean[(te * p.n_chains + chain) * p.d_out + tid] = ms[tid];
             acc_store_out<NT>(a, p.cov + (te * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
@@ -833,25 +839,25 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
         tri_to_lds<NT>(rec + D, M0, LD, w, lane);  // C_t
         acc_load_full<NT>(a, rec + D + C::TRI, w, lane);
         acc_store<NT>(a, M3, LD, w, lane);  // G_t
-        __syncthreads();
+        lds_barrier();
         matvec_gT(mp, cst + c.oAT, D, D, mf, nullptr, 0.0, tid);
         // H = G V_s
         acc_zero<NT>(a);
         mm_acc<NT, false, false>(a, M3, LD, M2, LD, w, lane);
         acc_store<NT>(a, M1, LD, w, lane);
-        __syncthreads();
+        lds_barrier();
         if (tid < D) dv[tid] = ms[tid] - mp[tid];
-        __syncthreads();
+        lds_barrier();
         matvec_lds(tmp, M3, LD, D, D, dv, mf, 1.0, tid);  // m_s = m_f + G (m_s⁺ − A m_f)
         // V_s = C + H G'
         acc_load<NT>(a, M0, LD, w, lane);
         mm_acc<NT, false, true>(a, M1, LD, M3, LD, w, lane);
-        __syncthreads();
+        lds_barrier();
         if (tid < D) ms[tid] = tmp[tid];
         acc_store<NT>(a, M2, LD, w, lane);
         if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = ms[tid];
         acc_store_out<NT>(a, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
-        __syncthreads();
+        lds_barrier();
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }

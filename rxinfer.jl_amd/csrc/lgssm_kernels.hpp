@@ -37,6 +37,14 @@ namespace rxhip {
 // device status bits (OR-ed into Params::status)
 constexpr int ST_NOT_POSDEF = 1;
 constexpr int ST_NONFINITE = 2;
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also fences global memory, i.e. it drains every global
+// load / store in flight (s_waitcnt vmcnt(0)) — fatal for kernels that keep prefetches or large posterior / record stores in
+// flight across their LDS exchange points.  Use where threads communicate through LDS alone.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
 // finiteness from the bit pattern (x − x == 0 is not safe under -ffp-contract=fast when x is a product)
 __device__ __forceinline__ bool is_finite(double x) { return (__double2hiint(x) & 0x7ff00000) != 0x7ff00000; }
 
