@@ -395,6 +395,29 @@ __device__ __forceinline__ void matvec_gT(double* out, const double* MT, int n, 
         out[tid] = (s0 + s1) + (s2 + s3);
     }
 }
+// out[r] = Σ_k MT[k][r] x[k] for r = i, i + width, … < n   (MT = M' row-major [m][n] in global memory; one thread group of
+// `width` threads, local index i) — lets different thread groups of a workgroup run different matvecs at the same time
+__device__ __forceinline__ void matvec_gT_group(double* out, const double* MT, int n, int m, const double* x, int i, int width) {
+    for (int r = i; r < n; r += width) {
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+        int k = 0;
+        for (; k + 15 < m; k += 16) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = MT[(size_t)(k + u) * n + r];
+#pragma unroll
+            for (int u = 0; u < 16; u += 4) {
+                s0 += v[u] * x[k + u];
+                s1 += v[u + 1] * x[k + u + 1];
+                s2 += v[u + 2] * x[k + u + 2];
+                s3 += v[u + 3] * x[k + u + 3];
+            }
+        }
+        for (; k < m; ++k) s0 += MT[(size_t)k * n + r] * x[k];
+        out[r] = (s0 + s1) + (s2 + s3);
+    }
+}
+
 // three block-wide dot products in one reduction (result valid in every thread); red: 3·nthreads doubles.
 // Works for any thread count (192 threads at d = 48).
 __device__ __forceinline__ void block_dot3(const double* a0, const double* b0, int n0, const double* a1, const double* b1,
@@ -691,12 +714,14 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     double* xf = xp + dm;
     double* yv = xf + dm;
     double* qy = yv + dm;
-    double* rowbuf = qy + dm;  // 8·D doubles (two buffers of four pivot rows)
+    double* gy = qy + dm;      // B'Q⁻¹ y_t
+    double* rowbuf = gy + dm;  // 8·D doubles (two buffers of four pivot rows)
     double* red = rowbuf + 8 * D;
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
     const double* A = cst + c.oA;
+    const int grp = tid / D, gi = tid - grp * D;  // four thread groups of D
     const size_t MM = (size_t)D * D;
     const long long b0 = 1 + seg * p.L;
     long long b1 = b0 + p.L;
@@ -713,11 +738,16 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     for (long long i = 0; i < len; ++i) {
         const long long t = t0 + i;
         if (tid < dy) yv[tid] = p.y[(t * p.n_chains + chain) * dy + tid];
-        // `*`_A(:out): T = A V ; Vp = T A' + P ;  mp = A m
+        lds_barrier();
+        // the three matvecs with constant maps from L2 run side by side in different thread groups:
+        //   mp = A m (`*`_A(:out) mean),   Q⁻¹ y and B'Q⁻¹ y (the `*`_B(:in) message of the observation)
+        if (grp == 0) matvec_gT_group(mp, cst + c.oAT, D, D, m, gi, D);
+        else if (grp == 1) matvec_gT_group(qy, cst + c.oQI, dy, dy, yv, gi, D);  // Q⁻¹ symmetric
+        else if (grp == 2) matvec_gT_group(gy, cst + c.oGT, D, dy, yv, gi, D);
+        // `*`_A(:out): T = A V ; Vp = T A' + P
         acc_zero<NT>(a);
         mm_acc<NT, false, false>(a, A, D, M0, LD, w, lane);
         acc_store<NT>(a, M1, LD, w, lane);
-        matvec_gT(mp, cst + c.oAT, D, D, m, nullptr, 0.0, tid);
         lds_barrier();
         Acc<NT> lam;
         acc_load<NT>(lam, cst + c.oP, D, w, lane);
@@ -745,12 +775,13 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
             acc_store_tri<NT>(a, rec + D, w, lane);
         }
         // product with the `*`_B(:in) message: Λf = Λp + B'Q⁻¹B, ξf = Λp mp + G y
-        {
-            matvec_lds(xp, M2, LD, D, D, mp, nullptr, 0.0, tid);
-            matvec_gT(qy, cst + c.oQI, dy, dy, yv, nullptr, 0.0, tid);  // Q⁻¹ symmetric
+        if (tid < D) {
+            double sx = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < D; ++k) sx += M2[tid * LD + k] * mp[k];
+            xp[tid] = sx;            // Λp mp
+            xf[tid] = sx + gy[tid];  // ξf = Λp mp + B'Q⁻¹ y
         }
-        lds_barrier();
-        matvec_gT(xf, cst + c.oGT, D, dy, yv, xp, 1.0, tid);
         acc_add_mat<NT>(lam, cst + c.oLOBS, D, w, lane, 1.0);
         // mean_cov of the product: Vf = Λf⁻¹, mf = Vf ξf
         ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
