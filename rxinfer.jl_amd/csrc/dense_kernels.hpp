@@ -593,9 +593,10 @@ __device__ __forceinline__ void dense_scan_chain(const DenseParams& p, long long
         for (int u = 0; u < KP; ++u) dst[u] = Mt[(size_t)(k0 + u) * D + i];
         w = tid < D ? p.elem[((chain * S + sg) * 2 + (SUFFIX ? 1 : 0)) * D + tid] : 0.0;
     };
+    if (nsteps > 0) {
 #pragma unroll
-    for (int q = 0; q < PD; ++q)
-        if (q < nsteps) fetch(buf[q], wb[q], q);
+        for (int q = 0; q < PD; ++q) fetch(buf[q], wb[q], q < nsteps ? q : nsteps - 1);
+    }
     lds_barrier();
     for (int st0 = 0; st0 <= nsteps; st0 += PD) {
 #pragma unroll
@@ -611,7 +612,7 @@ __device__ __forceinline__ void dense_scan_chain(const DenseParams& p, long long
                 s1 += buf[q][u + 1] * v0[k0 + u + 1];
             }
             const double wv = wb[q];
-            if (st + PD < nsteps) fetch(buf[q], wb[q], st + PD);
+            fetch(buf[q], wb[q], st + PD < nsteps ? st + PD : nsteps - 1);  // unconditional (clamped): keeps the waitcnt bookkeeping exact
             red[tid] = s0 + s1;
             lds_barrier();
             if (tid < D) {
