@@ -66,7 +66,7 @@ struct DenseParams {
     long long L;
     int d, dy;
     const double* y;      // [T][chain][dy]
-    double* filt;         // [chain][T][REC]   m_f(t) | C_t = V_f − G_t A V_f (lower tiles) | G_t = V_f A' V_p(t+1)⁻¹ (smoother gain)
+    double* filt;         // [chain][T][REC]   m_f(t) | A m_f(t) | C_t = V_f − G_t A V_f (lower tiles) | G_t = V_f A' V_p(t+1)⁻¹ (smoother gain)
     int d_out;            // state dimension of the MODEL (≤ d): the kernels run on d = 16·NT with decoupled padding dimensions
                           // (A = 0, P = V0 = I, B = 0 there), only the leading d_out block of every posterior is written
     int filter;           // 1: filtering run (forward pass only; the filtered belief is written as the marginal)
@@ -90,7 +90,8 @@ struct DenseCfg {
     static constexpr int THREADS = 64 * NT;
     static constexpr int NTRI = NT * (NT + 1) / 2;
     static constexpr int TRI = NTRI * 256;           // a symmetric matrix as lower tiles in register order
-    static constexpr int REC = D + TRI + D * D;      // record: m_f(t) | C_t (lower tiles) | G_t (accumulator order)
+    static constexpr int HDR = 2 * D;                // m_f(t) | A m_f(t)
+    static constexpr int REC = HDR + TRI + D * D;    // record: m_f(t) | A m_f(t) | C_t (lower tiles) | G_t (accumulator order)
     static constexpr int MAT = D * LD;          // doubles per LDS matrix
 };
 
@@ -146,6 +147,26 @@ __device__ __forceinline__ void acc_add_mat(Acc<NT>& a, const double* M, int ld,
 }
 // lower-triangle tiles of a symmetric matrix in register order: [tile idx][r][lane] — every access of a
 // wave is 512 contiguous bytes.  Tiles above the diagonal are reconstructed by symmetry through LDS.
+template <int NT>
+__device__ __forceinline__ void tri_load(Acc<NT>& a, const double* rec, int w, int lane) {  // tiles t ≤ w of this wave's tile row
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.v[t][r] = (t <= w) ? rec[(w * (w + 1) / 2 + t) * 256 + r * 64 + lane] : 0.0;
+}
+template <int NT>
+__device__ __forceinline__ void tri_regs_to_lds(const Acc<NT>& a, double* M, int ld, int w, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+        if (t <= w) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
+                M[i * ld + j] = a.v[t][r];
+                if (t != w) M[j * ld + i] = a.v[t][r];
+            }
+        }
+}
 template <int NT>
 __device__ __forceinline__ void acc_store_tri(const Acc<NT>& a, double* rec, int w, int lane) {
 #pragma unroll
@@ -762,7 +783,8 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
             double* rec = p.filt + (chain * p.T + (t - 1)) * C::REC;
             acc_zero<NT>(a);
             mm_acc<NT, true, false>(a, M1, LD, M2, LD, w, lane);
-            acc_store_full<NT>(a, rec + D + C::TRI, w, lane);
+            if (tid < D) rec[D + tid] = mp[tid];  // A m_f(t − 1): the backward sweep needs it, this step has it
+            acc_store_full<NT>(a, rec + C::HDR + C::TRI, w, lane);
             acc_store<NT>(a, M3, LD, w, lane);
             lds_barrier();
             Acc<NT> cc;
@@ -773,7 +795,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
             for (int q = 0; q < NT; ++q)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) a.v[q][r] -= cc.v[q][r];
-            acc_store_tri<NT>(a, rec + D, w, lane);
+            acc_store_tri<NT>(a, rec + C::HDR, w, lane);
         }
         // product with the `*`_B(:in) message: Λf = Λp + B'Q⁻¹B, ξf = Λp mp + G y
         if (tid < D) {
@@ -865,19 +887,38 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
             acc_store_out<NT>(a, p.cov + (te * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
         }
     }
+    // The record of step t − 1 (48 KB: m_f, A m_f, C, G) is fetched into registers while step t is computed and committed to
+    // LDS after the last use of this step's C and G — the cold read no longer sits on the critical path of every step.
+    Acc<NT> gN, cN;
+    double mfN = 0.0, mpN = 0.0;
+    auto prefetch = [&](long long tt) {
+        const double* rec = p.filt + (chain * p.T + tt) * C::REC;
+        acc_load_full<NT>(gN, rec + C::HDR + C::TRI, w, lane);
+        tri_load<NT>(cN, rec + C::HDR, w, lane);
+        if (tid < D) {
+            mfN = rec[tid];
+            mpN = rec[D + tid];
+        }
+    };
+    auto commit = [&]() {
+        acc_store<NT>(gN, M3, LD, w, lane);          // G_t
+        tri_regs_to_lds<NT>(cN, M0, LD, w, lane);    // C_t
+        if (tid < D) {
+            mf[tid] = mfN;
+            mp[tid] = mpN;  // A m_f(t), stored by the forward sweep
+        }
+    };
+    if (te - 1 >= tb) {
+        prefetch(te - 1);
+        commit();
+    }
+    lds_barrier();
     for (long long t = te - 1; t >= tb; --t) {
-        const double* rec = p.filt + (chain * p.T + t) * C::REC;
-        if (tid < D) mf[tid] = rec[tid];
-        tri_to_lds<NT>(rec + D, M0, LD, w, lane);  // C_t
-        acc_load_full<NT>(a, rec + D + C::TRI, w, lane);
-        acc_store<NT>(a, M3, LD, w, lane);  // G_t
-        lds_barrier();
-        matvec_gT(mp, cst + c.oAT, D, D, mf, nullptr, 0.0, tid);
+        prefetch(t - 1 >= tb ? t - 1 : tb);  // unconditional (clamped): the waitcnt bookkeeping stays exact
         // H = G V_s
         acc_zero<NT>(a);
         mm_acc<NT, false, false>(a, M3, LD, M2, LD, w, lane);
         acc_store<NT>(a, M1, LD, w, lane);
-        lds_barrier();
         if (tid < D) dv[tid] = ms[tid] - mp[tid];
         lds_barrier();
         matvec_lds(tmp, M3, LD, D, D, dv, mf, 1.0, tid);  // m_s = m_f + G (m_s⁺ − A m_f)
@@ -889,6 +930,7 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
         acc_store<NT>(a, M2, LD, w, lane);
         if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = ms[tid];
         acc_store_out<NT>(a, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
+        commit();
         lds_barrier();
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);

@@ -654,7 +654,7 @@ struct DenseLaunch {
         default: DenseLaunch<4>::CALL; break;       \
     }
 static int dense_tri(int nt) { return nt * (nt + 1) / 2 * 256; }
-static int dense_rec(int nt) { return 16 * nt + dense_tri(nt) + 256 * nt * nt; }
+static int dense_rec(int nt) { return 2 * 16 * nt + dense_tri(nt) + 256 * nt * nt; }
 
 // Per-model tables of the dense path: constants, per-offset gains (K_i, U_i), and the data-independent
 // matrix part of the boundary scan for every segment (see dense_kernels.hpp DenseParams::scanm).
