@@ -31,7 +31,8 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 // per-model constant block for the dense path (doubles; all matrices dense row-major)
 struct DenseCst {
     int d, dy;
-    long long oA, oP, oLOBS, oG, oQI, oHF, oC0, oX1, oS1, oLD1, oC1, oK1, oVF1, oAT, oGT, oHFT, oK1T, size;
+    long long oA, oP, oLOBS, oG, oQI, oHF, oC0, oX1, oS1, oLD1, oC1, oK1, oVF1, oAT, oGT, oHFT, oK1T, oPI, oK, oKT, oW, oV1I, oM1,
+        oBT, oFEC, size;
     __host__ __device__ static DenseCst make(int d, int dy) {
         DenseCst c;
         c.d = d;
@@ -55,6 +56,15 @@ struct DenseCst {
         c.oGT = o; o += (long long)dy * d;   // G'   [dy][d]
         c.oHFT = o; o += (long long)d * dy;  // (BA)' [d][dy]
         c.oK1T = o; o += (long long)dy * d;  // K1'  [dy][d]
+        // information-form smoother (kd_forward_info / kd_backward_info)
+        c.oPI = o; o += (long long)d * d;    // P⁻¹
+        c.oK = o; o += (long long)d * d;     // K = P⁻¹A
+        c.oKT = o; o += (long long)d * d;    // K'
+        c.oW = o; o += (long long)d * d;     // W = A'P⁻¹A
+        c.oV1I = o; o += (long long)d * d;   // V1⁻¹ (prior of the first state, through the transition if so modelled)
+        c.oM1 = o; o += d;                   // m1
+        c.oBT = o; o += (long long)d * dy;   // B'   [d][dy]
+        c.oFEC = o; o += 1;                  // ½[log|V1| + (T−1) log|P| + T(dy log 2π + log|Q|)]
         c.size = (o + 7) / 8 * 8;
         return c;
     }
@@ -126,6 +136,23 @@ __device__ __forceinline__ void acc_store(const Acc<NT>& a, double* M, int ld, i
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) M[acc_row<NT>(w, lane, r) * ld + acc_col<NT>(lane, t)] = a.v[t][r];
+}
+// a <- ½(a + M') with M = a copy of a in LDS: restores exact symmetry (the sweep inverse reads one triangle's worth of every
+// pivot row; in a long recursion rounding-level asymmetry would otherwise be fed back and grow)
+template <int NT>
+__device__ __forceinline__ void acc_symmetrise(Acc<NT>& a, const double* M, int ld, int w, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.v[t][r] = 0.5 * (a.v[t][r] + M[acc_col<NT>(lane, t) * ld + acc_row<NT>(w, lane, r)]);
+}
+// transposed store: M[col][row] = a(row, col)
+template <int NT>
+__device__ __forceinline__ void acc_store_T(const Acc<NT>& a, double* M, int ld, int w, int lane) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) M[acc_col<NT>(lane, t) * ld + acc_row<NT>(w, lane, r)] = a.v[t][r];
 }
 // posterior store: the leading n×n block, row-major with leading dimension n (n = D unless the model was padded)
 template <int NT>
@@ -932,6 +959,257 @@ __global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
         acc_store_out<NT>(a, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
         commit();
         lds_barrier();
+    }
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// =====================================================================================================================
+// Information-form smoother (smoothing runs).  The covariance-form forward step above needs two d×d inverses
+// (V_p⁻¹ and Λ_f⁻¹); carrying the filtered belief as (ξ_f, Λ_f) needs ONE:
+//     M_t = Λ_f(t) + A'P⁻¹A,   C_t = M_t⁻¹,   G_t = C_t (P⁻¹A)',   Λ_p(t+1) = P⁻¹ − (P⁻¹A) G_t,   ξ_p(t+1) = (P⁻¹A) C_t ξ_f(t)
+// and C_t, G_t are exactly the residual V_f − G A V_f and the smoother gain V_f A'V_p⁻¹ the backward sweep wants
+// (matrix inversion lemma), with  m_s(t) = C_t ξ_f(t) + G_t m_s(t+1),  V_s(t) = C_t + G_t V_s(t+1) G_t'.
+// The Bethe free energy of the tree, −log p(y), is evaluated at the smoothed means x̂ (for a Gaussian posterior
+// log p(y) = log p(x̂, y) − log q(x̂)):
+//     F = ½[log|V1| + (T−1) log|P| + T(d_y log 2π + log|Q|)]                     (constant, host)
+//       + ½[Σ_{t<T} log|M_t| + log|Λ_f(T)|]                                       (pivots of the inverses, forward / last init)
+//       + ½[(x̂_1−m1)'V1⁻¹(x̂_1−m1) + Σ r_x'P⁻¹r_x + Σ r_y'Q⁻¹r_y]                  (residuals at the smoothed means, backward)
+// Record of time index t: ξ_f(t) | (spare) | C_t (lower tiles) | G_t' (accumulator order).  vend: Λ_f at the segment end.
+// fe_part slots (negated contributions): 0 and S+s: backward of segment 0 / s ≥ 1;  1+s: forward of segment s.
+template <int NT, bool FE>
+__global__ void __launch_bounds__(64 * NT) kd_forward_info(DenseParams p) {
+    constexpr int D = 16 * NT;
+    using C = DenseCfg<NT>;
+    constexpr int LD = C::LD;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int dm = ((D > dy ? D : dy) + 1) & ~1;
+    double* S0 = smem;          // C_t
+    double* S1 = S0 + C::MAT;   // G_t
+    double* vec = S1 + C::MAT;
+    double* xi = vec;           // ξ_f
+    double* u = xi + dm;
+    double* xp = u + dm;
+    double* yv = xp + dm;
+    double* gy = yv + dm;
+    double* rowbuf = gy + dm;   // 8·D doubles
+    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const DenseCst c = DenseCst::make(D, dy);
+    const double* cst = p.cst;
+    const double* K = cst + c.oK;
+    const size_t MM = (size_t)D * D;
+    const int grp = tid / D, gi = tid - grp * D;
+    const long long b0 = 1 + seg * p.L;
+    long long b1 = b0 + p.L;
+    if (b1 > p.T) b1 = p.T;
+    const long long len = b1 - b0, t0 = seg * p.L + 1;
+    bool ok = true;
+    LogProd lp, lpd;
+    Acc<NT> lam, a;
+    // belief at the segment start in information form: Λ_f = V(b_s)⁻¹, ξ_f = Λ_f m(b_s)
+    acc_load<NT>(lam, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
+    ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lpd) && ok;
+    acc_store<NT>(lam, S0, LD, w, lane);
+    if (tid < D) u[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
+    lds_barrier();
+    matvec_lds(xi, S0, LD, D, D, u, nullptr, 0.0, tid);
+    lds_barrier();
+    for (long long i = 0; i < len; ++i) {
+        const long long t = t0 + i;
+        double* rec = p.filt + (chain * p.T + (t - 1)) * C::REC;
+        if (tid < dy) yv[tid] = p.y[(t * p.n_chains + chain) * dy + tid];
+        if (tid < D) rec[tid] = xi[tid];  // ξ_f(t − 1)
+        lds_barrier();
+        if (grp == 2) matvec_gT_group(gy, cst + c.oGT, D, dy, yv, gi, D);  // B'Q⁻¹ y_t
+        // C = (Λ_f + A'P⁻¹A)⁻¹
+        acc_add_mat<NT>(lam, cst + c.oW, D, w, lane, 1.0);
+        ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
+        acc_store_tri<NT>(lam, rec + C::HDR, w, lane);
+        acc_store<NT>(lam, S0, LD, w, lane);
+        lds_barrier();
+        // u = C ξ_f ;  G' = K C
+        matvec_lds(u, S0, LD, D, D, xi, nullptr, 0.0, tid);
+        acc_zero<NT>(a);
+        mm_acc<NT, false, false>(a, K, D, S0, LD, w, lane);
+        acc_store_full<NT>(a, rec + C::HDR + C::TRI, w, lane);
+        acc_store_T<NT>(a, S1, LD, w, lane);
+        lds_barrier();
+        // ξ_p = K u ;  Λ_f(t) = P⁻¹ − K G + B'Q⁻¹B
+        if (grp == 0) matvec_gT_group(xp, cst + c.oKT, D, D, u, gi, D);
+        acc_zero<NT>(a);
+        mm_acc<NT, false, false>(a, K, D, S1, LD, w, lane);
+        acc_load<NT>(lam, cst + c.oPI, D, w, lane);
+#pragma unroll
+        for (int q = 0; q < NT; ++q)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lam.v[q][r] -= a.v[q][r];
+        acc_add_mat<NT>(lam, cst + c.oLOBS, D, w, lane, 1.0);
+        lds_barrier();
+        if (tid < D) xi[tid] = xp[tid] + gy[tid];  // ξ_f(t)
+        acc_store<NT>(lam, S1, LD, w, lane);       // G is no longer needed: S1 carries Λ_f for the symmetrisation
+        lds_barrier();
+        acc_symmetrise<NT>(lam, S1, LD, w, lane);
+    }
+    acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);  // Λ_f at the segment end
+    if (seg == p.S - 1 && tid < D) p.filt[(chain * p.T + (t0 + len - 1)) * C::REC + tid] = xi[tid];  // ξ_f(T): no successor writes it
+    if (FE && tid == 0) p.fe_part[(1 + seg) * p.n_chains + chain] = -0.5 * lp.value();
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// sum over the first n ≤ 64 lanes of wave 0 (valid in lane 0)
+__device__ __forceinline__ double wave0_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
+template <int NT, bool FE>
+__global__ void __launch_bounds__(64 * NT) kd_backward_info(DenseParams p) {
+    constexpr int D = 16 * NT;
+    using C = DenseCfg<NT>;
+    constexpr int LD = C::LD;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int dm = ((D > dy ? D : dy) + 1) & ~1;
+    double* M0 = smem;          // C_t
+    double* M1 = M0 + C::MAT;   // H = G V_s
+    double* M2 = M1 + C::MAT;   // V_s
+    double* M3 = M2 + C::MAT;   // G_t
+    double* vec = M3 + C::MAT;
+    double* ms = vec;           // m_s(t+1), then m_s(t)
+    double* xf = ms + dm;       // ξ_f(t)
+    double* tmp = xf + dm;
+    double* r1 = tmp + dm;      // A m_s(t)   -> r_x -> …
+    double* r2 = r1 + dm;       // B m_s(t)   -> r_y
+    double* p1 = r2 + dm;       // P⁻¹ r_x
+    double* p2 = p1 + dm;       // Q⁻¹ r_y
+    double* yv = p2 + dm;
+    double* rowbuf = yv + dm;   // 8·D doubles
+    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const DenseCst c = DenseCst::make(D, dy);
+    const double* cst = p.cst;
+    const size_t MM = (size_t)D * D;
+    const int grp = tid / D, gi = tid - grp * D;
+    const long long b0 = 1 + seg * p.L;
+    long long b1 = b0 + p.L;
+    if (b1 > p.T) b1 = p.T;
+    const long long len = b1 - b0, tb = seg * p.L, te = tb + len;
+    bool ok = true;
+    double quad = 0.0;  // lane 0 of wave 0
+    LogProd lpe;
+    Acc<NT> a;
+    // r_y'Q⁻¹r_y at time index tt for the smoothed mean in `mv`: groups in parallel, dots in wave 0
+    auto obs_quad = [&](long long tt, const double* mv) {
+        if (tid < dy) yv[tid] = p.y[(tt * p.n_chains + chain) * dy + tid];
+        if (grp == 1) matvec_gT_group(r2, cst + c.oBT, dy, D, mv, gi, D);
+        lds_barrier();
+        if (tid < dy) r2[tid] = yv[tid] - r2[tid];
+        lds_barrier();
+        if (grp == 1) matvec_gT_group(p2, cst + c.oQI, dy, dy, r2, gi, D);
+        lds_barrier();
+        if (w == 0) {
+            const double s = wave0_sum(lane < dy ? r2[lane] * p2[lane] : 0.0);
+            if (lane == 0) quad += s;
+        }
+    };
+    // smoothed belief at the end boundary: V_s = (Λ_f + Λβ)⁻¹, m_s = V_s (ξ_f + ξβ)
+    {
+        tri_to_lds<NT>(p.vend + (chain * p.S + seg) * C::TRI, M0, LD, w, lane);
+        if (tid < D) xf[tid] = p.filt[(chain * p.T + te) * C::REC + tid] + p.beta_xi[(chain * (p.S + 1) + seg + 1) * D + tid];
+        lds_barrier();
+        acc_load<NT>(a, M0, LD, w, lane);
+        acc_add_mat<NT>(a, p.scanm + ((size_t)seg * 6 + 5) * MM, D, w, lane, 1.0);
+        ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpe) && ok;  // last segment: Λβ = 0, the pivots give |Λ_f(T)|
+        acc_store<NT>(a, M2, LD, w, lane);
+        lds_barrier();
+        matvec_lds(ms, M2, LD, D, D, xf, nullptr, 0.0, tid);
+        lds_barrier();
+        if (seg == p.S - 1) {
+            if (tid < p.d_out) p.mean[(te * p.n_chains + chain) * p.d_out + tid] = ms[tid];
+            acc_store_out<NT>(a, p.cov + (te * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
+            if (FE) obs_quad(te, ms);
+        }
+    }
+    Acc<NT> gN, cN;
+    double xfN = 0.0;
+    auto prefetch = [&](long long tt) {
+        const double* rec = p.filt + (chain * p.T + tt) * C::REC;
+        acc_load_full<NT>(gN, rec + C::HDR + C::TRI, w, lane);
+        tri_load<NT>(cN, rec + C::HDR, w, lane);
+        if (tid < D) xfN = rec[tid];
+    };
+    auto commit = [&]() {
+        acc_store_T<NT>(gN, M3, LD, w, lane);        // the record holds G'
+        tri_regs_to_lds<NT>(cN, M0, LD, w, lane);    // C_t
+        if (tid < D) xf[tid] = xfN;
+    };
+    if (te - 1 >= tb) {
+        prefetch(te - 1);
+        commit();
+    }
+    lds_barrier();
+    for (long long t = te - 1; t >= tb; --t) {
+        prefetch(t - 1 >= tb ? t - 1 : tb);
+        // m_s(t) = C ξ_f + G m_s(t+1)
+        if (tid < D) {
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < D; ++k) {
+                s0 += M0[tid * LD + k] * xf[k];
+                s1 += M3[tid * LD + k] * ms[k];
+            }
+            tmp[tid] = s0 + s1;
+        }
+        // H = G V_s
+        acc_zero<NT>(a);
+        mm_acc<NT, false, false>(a, M3, LD, M2, LD, w, lane);
+        acc_store<NT>(a, M1, LD, w, lane);
+        lds_barrier();
+        if (FE) {  // residuals of the transition (t -> t+1) and of the observation at t, at the smoothed means
+            if (tid < dy) yv[tid] = p.y[(t * p.n_chains + chain) * dy + tid];
+            if (grp == 0) matvec_gT_group(r1, cst + c.oAT, D, D, tmp, gi, D);
+            else if (grp == 1) matvec_gT_group(r2, cst + c.oBT, dy, D, tmp, gi, D);
+        }
+        // V_s = C + H G'
+        acc_load<NT>(a, M0, LD, w, lane);
+        mm_acc<NT, false, true>(a, M1, LD, M3, LD, w, lane);
+        lds_barrier();
+        if (FE) {
+            if (tid < D) r1[tid] = ms[tid] - r1[tid];   // r_x = m_s(t+1) − A m_s(t)
+            if (tid < dy) r2[tid] = yv[tid] - r2[tid];  // r_y = y_t − B m_s(t)
+            if (t == 0 && tid < D) p1[tid] = tmp[tid] - cst[c.oM1 + tid];  // x̂_1 − m1 (first state of the chain)
+        }
+        if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = tmp[tid];
+        acc_store_out<NT>(a, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
+        acc_store<NT>(a, M2, LD, w, lane);
+        lds_barrier();
+        if (FE) {
+            if (t == 0) {  // prior quadratic form: reuse yv as V1⁻¹(x̂_1 − m1)
+                if (grp == 2) matvec_gT_group(yv, cst + c.oV1I, D, D, p1, gi, D);
+                lds_barrier();
+                if (w == 0) {
+                    const double s = wave0_sum(lane < D ? p1[lane] * yv[lane] : 0.0);
+                    if (lane == 0) quad += s;
+                }
+                lds_barrier();
+            }
+            if (grp == 0) matvec_gT_group(p1, cst + c.oPI, D, D, r1, gi, D);
+            else if (grp == 1) matvec_gT_group(p2, cst + c.oQI, dy, dy, r2, gi, D);
+            lds_barrier();
+            if (w == 0) {
+                const double s = wave0_sum((lane < D ? r1[lane] * p1[lane] : 0.0) + (lane < dy ? r2[lane] * p2[lane] : 0.0));
+                if (lane == 0) quad += s;
+            }
+        }
+        if (tid < D) ms[tid] = tmp[tid];
+        commit();
+        lds_barrier();
+    }
+    if (FE && tid == 0) {
+        double f = 0.5 * quad;
+        if (seg == p.S - 1) f += 0.5 * lpe.value();   // ½ log|Λ_f(T)|
+        if (seg == 0) f += cst[c.oFEC];
+        p.fe_part[(seg == 0 ? 0 : p.S + seg) * p.n_chains + chain] = -f;
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }

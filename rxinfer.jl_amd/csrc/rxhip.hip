@@ -627,6 +627,10 @@ struct DenseLaunch {
         if ((e = hipFuncSetAttribute((const void*)kd_forward<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_forward<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_backward<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_forward_info<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_forward_info<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_backward_info<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_backward_info<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         return hipSuccess;
     }
     static void seg_aggregate(const DenseParams& p, hipStream_t s) {
@@ -644,6 +648,17 @@ struct DenseLaunch {
     }
     static void backward(const DenseParams& p, hipStream_t s) {
         hipLaunchKernelGGL((kd_backward<NT>), dim3(p.S, (unsigned)p.n_chains), dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+    }
+    // information-form smoother (one inverse per step; free energy at the smoothed means)
+    static void forward_info(const DenseParams& p, bool fe, hipStream_t s) {
+        dim3 g(p.S, (unsigned)p.n_chains);
+        if (fe) hipLaunchKernelGGL((kd_forward_info<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        else hipLaunchKernelGGL((kd_forward_info<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+    }
+    static void backward_info(const DenseParams& p, bool fe, hipStream_t s) {
+        dim3 g(p.S, (unsigned)p.n_chains);
+        if (fe) hipLaunchKernelGGL((kd_backward_info<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        else hipLaunchKernelGGL((kd_backward_info<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
     }
 };
 #define DENSE_DISPATCH(nt, CALL)                    \
@@ -721,6 +736,25 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
         cst[c.oC1 + i] = s;
     }
     host::mm(d, d, dy, Vf1.data(), G.data(), &cst[c.oK1]);
+    {   // constants of the information-form smoother
+        std::vector<double> Pinv(MM), Kc(MM), Wc(MM);
+        double ldP = 0;
+        if (!host::chol_inv(d, P, Pinv.data(), &ldP)) return fail(e, RXHIP_ERR_NOT_POSDEF, "state noise P is not positive definite");
+        host::mm(d, d, d, Pinv.data(), A, Kc.data());   // K = P⁻¹A
+        host::mTm(d, d, d, A, Kc.data(), Wc.data());    // W = A'(P⁻¹A)
+        for (int i = 0; i < d; ++i)
+            for (int k = 0; k < d; ++k) {
+                cst[c.oPI + (size_t)i * d + k] = 0.5 * (Pinv[(size_t)i * d + k] + Pinv[(size_t)k * d + i]);
+                cst[c.oK + (size_t)i * d + k] = Kc[(size_t)i * d + k];
+                cst[c.oKT + (size_t)k * d + i] = Kc[(size_t)i * d + k];
+                cst[c.oW + (size_t)i * d + k] = 0.5 * (Wc[(size_t)i * d + k] + Wc[(size_t)k * d + i]);
+                cst[c.oV1I + (size_t)i * d + k] = V1i[(size_t)i * d + k];
+            }
+        for (int i = 0; i < d; ++i) cst[c.oM1 + i] = m1[i];
+        for (int r = 0; r < dy; ++r)
+            for (int k = 0; k < d; ++k) cst[c.oBT + (size_t)k * dy + r] = B[(size_t)r * d + k];
+        cst[c.oFEC] = 0.5 * (ldV1 + (double)(e->T - 1) * ldP + (double)e->T * (dy * 1.8378770664093454835606594728112 + ldQ));
+    }
     for (int i = 0; i < d; ++i) {
         for (int k = 0; k < d; ++k) cst[c.oAT + (size_t)k * d + i] = A[i * d + k];
         for (int k = 0; k < dy; ++k) {
@@ -1055,7 +1089,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.upload(&e->d_tab, tab.data(), sizeof(double) * tab.size());
         ap.upload(&e->d_scanm, scanm.data(), sizeof(double) * scanm.size());
         ap.zeroed(&e->d_status, sizeof(int));
-        ap.zeroed(&e->d_fe_part, sizeof(double) * (Sg + 1) * C);
+        ap.zeroed(&e->d_fe_part, sizeof(double) * (2 * Sg + 2) * C);  // smoothing runs use 2S slots (forward + backward parts)
         e->fe_total_cap = 16;
         ap.zeroed(&e->d_fe_total, sizeof(double) * e->fe_total_cap);
         ap.plain(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64));
@@ -1736,16 +1770,20 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 DENSE_DISPATCH(e->nt, seg_aggregate(dp, e->stream));
                 if ((st = prof_end(e))) return st;
             }
+            // smoothing runs with S > 0 evaluate the free energy in the forward / backward kernels (information form);
+            // filtering runs and single-observation chains keep the evidence terms of the scan + covariance-form forward kernel
+            const bool info = !filter && e->S > 0;
             if ((st = prof_begin(e, RXHIP_K_BOUNDARY_SCAN))) return st;
-            DENSE_DISPATCH(e->nt, boundary_scan(dp, fe, e->stream));
+            DENSE_DISPATCH(e->nt, boundary_scan(dp, fe && !info, e->stream));
             if ((st = prof_end(e))) return st;
             if (e->S > 0) {
                 if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
-                DENSE_DISPATCH(e->nt, forward(dp, fe, e->stream));
+                if (info) { DENSE_DISPATCH(e->nt, forward_info(dp, fe, e->stream)); }
+                else { DENSE_DISPATCH(e->nt, forward(dp, fe, e->stream)); }
                 if ((st = prof_end(e))) return st;
-                if (!filter) {
+                if (info) {
                     if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
-                    DENSE_DISPATCH(e->nt, backward(dp, e->stream));
+                    DENSE_DISPATCH(e->nt, backward_info(dp, fe, e->stream));
                     if ((st = prof_end(e))) return st;
                 }
             }
@@ -1773,7 +1811,9 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         if (fe) {
             if ((st = prof_begin(e, RXHIP_K_FE_REDUCE))) return st;
             const int nb = (int)((e->n_chains + 63) / 64);
-            hipLaunchKernelGGL(k_fe_chain, dim3(nb), dim3(256), 0, e->stream, p, e->d_fe_blocks);
+            Params pr = p;
+            if (e->dense && !filter && e->S > 0) pr.S = 2 * e->S - 1;  // 2S partial slots (see kd_forward_info / kd_backward_info)
+            hipLaunchKernelGGL(k_fe_chain, dim3(nb), dim3(256), 0, e->stream, pr, e->d_fe_blocks);
             hipLaunchKernelGGL(k_fe_total, dim3(1), dim3(256), 0, e->stream, p, (const double*)e->d_fe_blocks, nb);
             if ((st = prof_end(e))) return st;
         }
