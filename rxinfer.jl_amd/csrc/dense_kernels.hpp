@@ -692,7 +692,6 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
     const int S = p.S;
-    const size_t MM = (size_t)D * D;
     if (blockIdx.x == 0) {
         // filtered belief at t = 1: ξf = V1⁻¹m1 + G y;  mf = c1 + K1 y
         if (tid < dy) yv[tid] = p.y[(0 * p.n_chains + chain) * dy + tid];
@@ -740,10 +739,9 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
     }
 }
 
-// phase 3 (dense): forward sweep of one segment.  Besides the forward message it forms, for the PREVIOUS time
-// index, the Rauch–Tung–Striebel gain G = V_f A' V_p⁻¹ and C = V_f − G A V_f from the T = A V_f and Λp = V_p⁻¹
-// this step has anyway — the arithmetic of the reference's backward rules MvN_x(:μ) -> `*`_A(:in) — so that the
-// backward sweep needs no inverse.
+// phase 3 (dense, FILTERING runs): covariance-form forward sweep of one segment — the filtered belief (m_f, V_f) of every
+// time index is the marginal of the streaming one-step graph and is written out.  Smoothing runs use the information-form
+// kernels at the end of this file.
 template <int NT, bool FE>
 __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     constexpr int D = 16 * NT;
@@ -755,8 +753,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     double* M0 = smem;          // V_f of the previous step, then of this step
     double* M1 = M0 + C::MAT;   // T = A V_f
     double* M2 = M1 + C::MAT;   // Λp
-    double* M3 = M2 + C::MAT;   // G
-    double* vec = M3 + C::MAT;
+    double* vec = M2 + C::MAT;
     double* m = vec;
     double* mp = m + dm;
     double* xp = mp + dm;
@@ -805,25 +802,6 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
         ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
         acc_store<NT>(lam, M2, LD, w, lane);
         lds_barrier();
-        // smoother gain and residual of the previous time index (t − 1): G = T' Λp,  C = V_f − G T
-        if (!p.filter) {
-            double* rec = p.filt + (chain * p.T + (t - 1)) * C::REC;
-            acc_zero<NT>(a);
-            mm_acc<NT, true, false>(a, M1, LD, M2, LD, w, lane);
-            if (tid < D) rec[D + tid] = mp[tid];  // A m_f(t − 1): the backward sweep needs it, this step has it
-            acc_store_full<NT>(a, rec + C::HDR + C::TRI, w, lane);
-            acc_store<NT>(a, M3, LD, w, lane);
-            lds_barrier();
-            Acc<NT> cc;
-            acc_zero<NT>(cc);
-            mm_acc<NT, false, false>(cc, M3, LD, M1, LD, w, lane);
-            acc_load<NT>(a, M0, LD, w, lane);
-#pragma unroll
-            for (int q = 0; q < NT; ++q)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a.v[q][r] -= cc.v[q][r];
-            acc_store_tri<NT>(a, rec + C::HDR, w, lane);
-        }
         // product with the `*`_B(:in) message: Λf = Λp + B'Q⁻¹B, ξf = Λp mp + G y
         if (tid < D) {
             double sx = 0.0;
@@ -839,127 +817,16 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
         lds_barrier();
         matvec_lds(m, M0, LD, D, D, xf, nullptr, 0.0, tid);
         lds_barrier();
-        if (p.filter) {  // q(x_t | y_1..t) is the marginal of the one-step graph
-            if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = m[tid];
-            acc_store_out<NT>(lam, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
-        } else if (tid < D)
-            p.filt[(chain * p.T + t) * C::REC + tid] = m[tid];
+        // q(x_t | y_1..t) is the marginal of the one-step graph
+        if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = m[tid];
+        acc_store_out<NT>(lam, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
         if (FE) {
             double dots[3];
             block_dot3(qy, yv, dy, xf, m, D, xp, mp, D, red, tid, 64 * NT, dots);
             acc_quad += cst[c.oC0] + dots[0] - dots[1] + dots[2];
         }
-        if (i == len - 1 && !p.filter) acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);
     }
     if (FE && tid == 0) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc_quad + lp.value());
-    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
-}
-
-// phase 4 (dense): backward sweep + marginals of one segment with the gains of phase 3:
-//     m_s(t) = m_f + G_t (m_s(t+1) − A m_f),     V_s(t) = C_t + G_t V_s(t+1) G_t'
-// (two MFMA contractions per step, no inverse).  The smoothed belief at the segment's end is (filtered ⊗ β).
-template <int NT>
-__global__ void __launch_bounds__(64 * NT) kd_backward(DenseParams p) {
-    constexpr int D = 16 * NT;
-    using C = DenseCfg<NT>;
-    constexpr int LD = C::LD;
-    extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const int dm = ((D > dy ? D : dy) + 1) & ~1;  // even: keeps every LDS carve 16-byte aligned
-    double* M0 = smem;          // C_t
-    double* M1 = M0 + C::MAT;   // H = G V_s
-    double* M2 = M1 + C::MAT;   // V_s
-    double* M3 = M2 + C::MAT;   // G_t
-    double* vec = M3 + C::MAT;
-    double* ms = vec;
-    double* mf = ms + dm;
-    double* mp = mf + dm;
-    double* dv = mp + dm;
-    double* u = dv + dm;
-    double* tmp = u + dm;
-    double* rowbuf = tmp + dm;  // 8·D doubles
-    const long long seg = blockIdx.x, chain = blockIdx.y;
-    const DenseCst c = DenseCst::make(D, dy);
-    const double* cst = p.cst;
-    const size_t MM = (size_t)D * D;
-    const long long b0 = 1 + seg * p.L;
-    long long b1 = b0 + p.L;
-    if (b1 > p.T) b1 = p.T;
-    const long long len = b1 - b0, tb = seg * p.L, te = tb + len;
-    bool ok = true;
-    LogProd lpd;  // determinants are not needed in this pass
-    Acc<NT> a;
-    // smoothed belief at the end boundary: (Vf⁻¹ + Λβ)⁻¹, Vs (Vf⁻¹ mf + ξβ)
-    {
-        if (tid < D) mf[tid] = p.filt[(chain * p.T + te) * C::REC + tid];
-        tri_to_lds<NT>(p.vend + (chain * p.S + seg) * C::TRI, M0, LD, w, lane);
-        lds_barrier();
-        acc_load<NT>(a, M0, LD, w, lane);
-        ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;  // Vf⁻¹
-        acc_store<NT>(a, M1, LD, w, lane);
-        lds_barrier();
-        if (tid < D) {
-            double sacc = p.beta_xi[(chain * (p.S + 1) + seg + 1) * D + tid];
-            for (int k = 0; k < D; ++k) sacc += M1[tid * LD + k] * mf[k];
-            u[tid] = sacc;
-        }
-        acc_add_mat<NT>(a, p.scanm + ((size_t)seg * 6 + 5) * MM, D, w, lane, 1.0);
-        ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;  // Vs
-        acc_store<NT>(a, M2, LD, w, lane);
-        lds_barrier();
-        matvec_lds(ms, M2, LD, D, D, u, nullptr, 0.0, tid);
-        lds_barrier();
-        if (seg == p.S - 1) {
-            if (tid < p.d_out) p.mean[(te * p.n_chains + chain) * p.d_out + tid] = ms[tid];
-            acc_store_out<NT>(a, p.cov + (te * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
-        }
-    }
-    // The record of step t − 1 (48 KB: m_f, A m_f, C, G) is fetched into registers while step t is computed and committed to
-    // LDS after the last use of this step's C and G — the cold read no longer sits on the critical path of every step.
-    Acc<NT> gN, cN;
-    double mfN = 0.0, mpN = 0.0;
-    auto prefetch = [&](long long tt) {
-        const double* rec = p.filt + (chain * p.T + tt) * C::REC;
-        acc_load_full<NT>(gN, rec + C::HDR + C::TRI, w, lane);
-        tri_load<NT>(cN, rec + C::HDR, w, lane);
-        if (tid < D) {
-            mfN = rec[tid];
-            mpN = rec[D + tid];
-        }
-    };
-    auto commit = [&]() {
-        acc_store<NT>(gN, M3, LD, w, lane);          // G_t
-        tri_regs_to_lds<NT>(cN, M0, LD, w, lane);    // C_t
-        if (tid < D) {
-            mf[tid] = mfN;
-            mp[tid] = mpN;  // A m_f(t), stored by the forward sweep
-        }
-    };
-    if (te - 1 >= tb) {
-        prefetch(te - 1);
-        commit();
-    }
-    lds_barrier();
-    for (long long t = te - 1; t >= tb; --t) {
-        prefetch(t - 1 >= tb ? t - 1 : tb);  // unconditional (clamped): the waitcnt bookkeeping stays exact
-        // H = G V_s
-        acc_zero<NT>(a);
-        mm_acc<NT, false, false>(a, M3, LD, M2, LD, w, lane);
-        acc_store<NT>(a, M1, LD, w, lane);
-        if (tid < D) dv[tid] = ms[tid] - mp[tid];
-        lds_barrier();
-        matvec_lds(tmp, M3, LD, D, D, dv, mf, 1.0, tid);  // m_s = m_f + G (m_s⁺ − A m_f)
-        // V_s = C + H G'
-        acc_load<NT>(a, M0, LD, w, lane);
-        mm_acc<NT, false, true>(a, M1, LD, M3, LD, w, lane);
-        lds_barrier();
-        if (tid < D) ms[tid] = tmp[tid];
-        acc_store<NT>(a, M2, LD, w, lane);
-        if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = ms[tid];
-        acc_store_out<NT>(a, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
-        commit();
-        lds_barrier();
-    }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
 

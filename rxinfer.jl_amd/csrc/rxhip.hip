@@ -626,7 +626,6 @@ struct DenseLaunch {
         if ((e = hipFuncSetAttribute((const void*)kd_boundary_scan<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_forward<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_forward<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_backward<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_forward_info<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_forward_info<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_backward_info<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
@@ -645,9 +644,6 @@ struct DenseLaunch {
         dim3 g(p.S, (unsigned)p.n_chains);
         if (fe) hipLaunchKernelGGL((kd_forward<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
         else hipLaunchKernelGGL((kd_forward<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
-    }
-    static void backward(const DenseParams& p, hipStream_t s) {
-        hipLaunchKernelGGL((kd_backward<NT>), dim3(p.S, (unsigned)p.n_chains), dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
     }
     // information-form smoother (one inverse per step; free energy at the smoothed means)
     static void forward_info(const DenseParams& p, bool fe, hipStream_t s) {
