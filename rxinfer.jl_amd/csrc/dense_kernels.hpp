@@ -946,39 +946,19 @@ __global__ void __launch_bounds__(64 * NT) kd_backward_info(DenseParams p) {
     double* ms = vec;           // m_s(t+1), then m_s(t)
     double* xf = ms + dm;       // ξ_f(t)
     double* tmp = xf + dm;
-    double* r1 = tmp + dm;      // A m_s(t)   -> r_x -> …
-    double* r2 = r1 + dm;       // B m_s(t)   -> r_y
-    double* p1 = r2 + dm;       // P⁻¹ r_x
-    double* p2 = p1 + dm;       // Q⁻¹ r_y
-    double* yv = p2 + dm;
-    double* rowbuf = yv + dm;   // 8·D doubles
+    double* rowbuf = tmp + dm;  // 8·D doubles
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
     const size_t MM = (size_t)D * D;
-    const int grp = tid / D, gi = tid - grp * D;
+    
     const long long b0 = 1 + seg * p.L;
     long long b1 = b0 + p.L;
     if (b1 > p.T) b1 = p.T;
     const long long len = b1 - b0, tb = seg * p.L, te = tb + len;
     bool ok = true;
-    double quad = 0.0;  // lane 0 of wave 0
     LogProd lpe;
     Acc<NT> a;
-    // r_y'Q⁻¹r_y at time index tt for the smoothed mean in `mv`: groups in parallel, dots in wave 0
-    auto obs_quad = [&](long long tt, const double* mv) {
-        if (tid < dy) yv[tid] = p.y[(tt * p.n_chains + chain) * dy + tid];
-        if (grp == 1) matvec_gT_group(r2, cst + c.oBT, dy, D, mv, gi, D);
-        lds_barrier();
-        if (tid < dy) r2[tid] = yv[tid] - r2[tid];
-        lds_barrier();
-        if (grp == 1) matvec_gT_group(p2, cst + c.oQI, dy, dy, r2, gi, D);
-        lds_barrier();
-        if (w == 0) {
-            const double s = wave0_sum(lane < dy ? r2[lane] * p2[lane] : 0.0);
-            if (lane == 0) quad += s;
-        }
-    };
     // smoothed belief at the end boundary: V_s = (Λ_f + Λβ)⁻¹, m_s = V_s (ξ_f + ξβ)
     {
         tri_to_lds<NT>(p.vend + (chain * p.S + seg) * C::TRI, M0, LD, w, lane);
@@ -994,7 +974,6 @@ __global__ void __launch_bounds__(64 * NT) kd_backward_info(DenseParams p) {
         if (seg == p.S - 1) {
             if (tid < p.d_out) p.mean[(te * p.n_chains + chain) * p.d_out + tid] = ms[tid];
             acc_store_out<NT>(a, p.cov + (te * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
-            if (FE) obs_quad(te, ms);
         }
     }
     Acc<NT> gN, cN;
@@ -1032,53 +1011,154 @@ __global__ void __launch_bounds__(64 * NT) kd_backward_info(DenseParams p) {
         mm_acc<NT, false, false>(a, M3, LD, M2, LD, w, lane);
         acc_store<NT>(a, M1, LD, w, lane);
         lds_barrier();
-        if (FE) {  // residuals of the transition (t -> t+1) and of the observation at t, at the smoothed means
-            if (tid < dy) yv[tid] = p.y[(t * p.n_chains + chain) * dy + tid];
-            if (grp == 0) matvec_gT_group(r1, cst + c.oAT, D, D, tmp, gi, D);
-            else if (grp == 1) matvec_gT_group(r2, cst + c.oBT, dy, D, tmp, gi, D);
-        }
         // V_s = C + H G'
         acc_load<NT>(a, M0, LD, w, lane);
         mm_acc<NT, false, true>(a, M1, LD, M3, LD, w, lane);
         lds_barrier();
-        if (FE) {
-            if (tid < D) r1[tid] = ms[tid] - r1[tid];   // r_x = m_s(t+1) − A m_s(t)
-            if (tid < dy) r2[tid] = yv[tid] - r2[tid];  // r_y = y_t − B m_s(t)
-            if (t == 0 && tid < D) p1[tid] = tmp[tid] - cst[c.oM1 + tid];  // x̂_1 − m1 (first state of the chain)
-        }
         if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = tmp[tid];
         acc_store_out<NT>(a, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
         acc_store<NT>(a, M2, LD, w, lane);
         lds_barrier();
-        if (FE) {
-            if (t == 0) {  // prior quadratic form: reuse yv as V1⁻¹(x̂_1 − m1)
-                if (grp == 2) matvec_gT_group(yv, cst + c.oV1I, D, D, p1, gi, D);
-                lds_barrier();
-                if (w == 0) {
-                    const double s = wave0_sum(lane < D ? p1[lane] * yv[lane] : 0.0);
-                    if (lane == 0) quad += s;
-                }
-                lds_barrier();
-            }
-            if (grp == 0) matvec_gT_group(p1, cst + c.oPI, D, D, r1, gi, D);
-            else if (grp == 1) matvec_gT_group(p2, cst + c.oQI, dy, dy, r2, gi, D);
-            lds_barrier();
-            if (w == 0) {
-                const double s = wave0_sum((lane < D ? r1[lane] * p1[lane] : 0.0) + (lane < dy ? r2[lane] * p2[lane] : 0.0));
-                if (lane == 0) quad += s;
-            }
-        }
         if (tid < D) ms[tid] = tmp[tid];
         commit();
         lds_barrier();
     }
-    if (FE && tid == 0) {
-        double f = 0.5 * quad;
+    if (FE && tid == 0) {  // the residual quadratic forms are kd_fe_resid's
+        double f = 0.0;
         if (seg == p.S - 1) f += 0.5 * lpe.value();   // ½ log|Λ_f(T)|
         if (seg == 0) f += cst[c.oFEC];
         p.fe_part[(seg == 0 ? 0 : p.S + seg) * p.n_chains + chain] = -f;
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// Residual quadratic forms of the Bethe free energy at the smoothed means x̂ (information-form smoothing runs):
+//   (x̂_1 − m1)'V1⁻¹(x̂_1 − m1) + Σ_{t<T} r_x(t)'P⁻¹r_x(t) + Σ_t r_y(t)'Q⁻¹r_y(t),   r_x = x̂_{t+1} − A x̂_t,  r_y = y_t − B x̂_t
+// — the average energies of the MvNormalMeanCovariance nodes minus the part the entropies cancel (a7/a8).  Every term
+// depends on the smoothed means of at most two neighbouring steps, so it is NOT part of the sequential backward sweep:
+// it runs over all steps in parallel after it, reading the means the sweep stored (inside the sweep the four matvecs and
+// their exchange points cost 0.3 ms of 0.67 ms at d = 64 and spilled registers).  One workgroup per FR_STEPS consecutive
+// steps of one chain; the four constant maps are staged in LDS once per workgroup (≤ 128 KB), thread (i, wave g) forms row
+// i of the matvecs for four steps at a time (one matrix element read feeds four FMAs; the means are LDS broadcasts).
+// Fixed summation order -> deterministic.  Partial written (negated, as every fe_part slot) to slot `slot0 + blockIdx.x`.
+constexpr int FR_STEPS = 48, FR_PASS = 16;
+inline size_t fe_resid_lds_bytes(int D, int dy) {
+    return sizeof(double) * ((size_t)2 * D * D + (size_t)D * dy + (size_t)dy * dy + (size_t)(2 * FR_PASS + 1) * D + (size_t)FR_PASS * dy + 8);
+}
+__global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int D = p.d, dy = p.dy, du = p.d_out, tid = threadIdx.x, i = tid & 63, g = tid >> 6;
+    const long long chain = blockIdx.y, t00 = (long long)blockIdx.x * FR_STEPS;
+    const DenseCst c = DenseCst::make(D, dy);
+    double* AT = smem;                     // [D][D]   A'
+    double* PI = AT + (size_t)D * D;       // [D][D]   P⁻¹
+    double* BT = PI + (size_t)D * D;       // [D][dy]  B'
+    double* QI = BT + (size_t)D * dy;      // [dy][dy] Q⁻¹
+    double* mb = QI + (((size_t)dy * dy + 1) & ~(size_t)1);  // [FR_PASS + 1][D], 16-byte aligned  x̂_t of the pass (+ the step after it)
+    double* rx = mb + (size_t)(FR_PASS + 1) * D;  // [FR_PASS][D]
+    double* ry = rx + (size_t)FR_PASS * D;        // [FR_PASS][dy]
+    double* red = ry + (size_t)FR_PASS * dy;      // [4]
+    auto stage = [&](double* dst, const double* src, int n) {  // eight loads in flight per thread
+        int k = tid;
+        for (; k + 7 * 256 < n; k += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = src[k + u * 256];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) dst[k + u * 256] = v[u];
+        }
+        for (; k < n; k += 256) dst[k] = src[k];
+    };
+    stage(AT, p.cst + c.oAT, D * D);
+    stage(PI, p.cst + c.oPI, D * D);
+    stage(BT, p.cst + c.oBT, D * dy);
+    stage(QI, p.cst + c.oQI, dy * dy);
+    double acc = 0.0;
+    for (int ps = 0; ps < FR_STEPS / FR_PASS; ++ps) {
+        const long long t0 = t00 + (long long)ps * FR_PASS;
+        if (t0 >= p.T) break;  // uniform over the workgroup
+        for (int k = tid; k < (FR_PASS + 1) * D; k += 256) {
+            const int s = k / D, j = k - s * D;
+            const long long t = t0 + s;
+            mb[k] = (t < p.T && j < du) ? p.mean[(t * p.n_chains + chain) * du + j] : 0.0;
+        }
+        for (int k = tid; k < FR_PASS * dy; k += 256) {
+            const int s = k / dy, j = k - s * dy;
+            const long long t = t0 + s;
+            ry[k] = t < p.T ? p.y[(t * p.n_chains + chain) * dy + j] : 0.0;
+        }
+        __syncthreads();
+        if (t0 == 0 && g == 0) {  // prior of the first state (constant map read from L2 once per chain)
+            if (i < D) {
+                const double* V1I = p.cst + c.oV1I;
+                const double* m1 = p.cst + c.oM1;
+                double u = 0.0;
+                for (int k = 0; k < D; k += 16) {  // D is a multiple of 16; sixteen loads in flight
+                    double v[16];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) v[q] = V1I[(size_t)(k + q) * D + i];
+#pragma unroll
+                    for (int q = 0; q < 16; ++q) u += v[q] * (mb[k + q] - m1[k + q]);
+                }
+                acc += (mb[i] - m1[i]) * u;
+            }
+        }
+        const int s0 = g * 4;
+        {
+            double ax[4] = {0.0, 0.0, 0.0, 0.0}, bx[4] = {0.0, 0.0, 0.0, 0.0};
+            const bool ix = i < D, iy = i < dy;
+#pragma unroll 4
+            for (int k = 0; k < D; k += 2) {  // D is even (a multiple of 16)
+                const double a0 = ix ? AT[(size_t)k * D + i] : 0.0, a1 = ix ? AT[(size_t)(k + 1) * D + i] : 0.0;
+                const double b0 = iy ? BT[(size_t)k * dy + i] : 0.0, b1 = iy ? BT[(size_t)(k + 1) * dy + i] : 0.0;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const double2 m2 = *reinterpret_cast<const double2*>(mb + (size_t)(s0 + u) * D + k);
+                    ax[u] += a0 * m2.x + a1 * m2.y;
+                    bx[u] += b0 * m2.x + b1 * m2.y;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long long t = t0 + s0 + u;
+                if (ix) rx[(size_t)(s0 + u) * D + i] = (t + 1 < p.T) ? mb[(size_t)(s0 + u + 1) * D + i] - ax[u] : 0.0;
+                if (iy) ry[(size_t)(s0 + u) * dy + i] = (t < p.T) ? ry[(size_t)(s0 + u) * dy + i] - bx[u] : 0.0;
+            }
+        }
+        __syncthreads();
+        {
+            double ux[4] = {0.0, 0.0, 0.0, 0.0}, uy[4] = {0.0, 0.0, 0.0, 0.0};
+            if (i < D) {
+#pragma unroll 4
+                for (int k = 0; k < D; k += 2) {
+                    const double a0 = PI[(size_t)k * D + i], a1 = PI[(size_t)(k + 1) * D + i];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const double2 r2 = *reinterpret_cast<const double2*>(rx + (size_t)(s0 + u) * D + k);
+                        ux[u] += a0 * r2.x + a1 * r2.y;
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += rx[(size_t)(s0 + u) * D + i] * ux[u];
+            }
+            if (i < dy) {
+#pragma unroll 4
+                for (int k = 0; k < dy; ++k) {
+                    const double a0 = QI[(size_t)k * dy + i];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) uy[u] += a0 * ry[(size_t)(s0 + u) * dy + k];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc += ry[(size_t)(s0 + u) * dy + i] * uy[u];
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (i == 0) red[g] = acc;
+    __syncthreads();
+    if (tid == 0) p.fe_part[(size_t)(slot0 + blockIdx.x) * p.n_chains + chain] = -0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
 }
 
 }  // namespace rxhip

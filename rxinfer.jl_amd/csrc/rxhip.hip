@@ -630,6 +630,7 @@ struct DenseLaunch {
         if ((e = hipFuncSetAttribute((const void*)kd_forward_info<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_backward_info<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_backward_info<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_fe_resid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fe_resid_lds_bytes(d, dy)))) return e;
         return hipSuccess;
     }
     static void seg_aggregate(const DenseParams& p, hipStream_t s) {
@@ -657,6 +658,11 @@ struct DenseLaunch {
         else hipLaunchKernelGGL((kd_backward_info<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
     }
 };
+// free-energy residual terms of an information-form smoothing run: one workgroup per FR_STEPS steps, partial slots 2S…
+static int fe_resid_blocks(long long T) { return (int)((T + FR_STEPS - 1) / FR_STEPS); }
+static void launch_fe_resid(const DenseParams& p, hipStream_t s) {
+    hipLaunchKernelGGL(kd_fe_resid, dim3(fe_resid_blocks(p.T), (unsigned)p.n_chains), dim3(256), fe_resid_lds_bytes(p.d, p.dy), s, p, 2 * p.S);
+}
 #define DENSE_DISPATCH(nt, CALL)                    \
     switch (nt) {                                   \
         case 1: DenseLaunch<1>::CALL; break;        \
@@ -1085,7 +1091,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.upload(&e->d_tab, tab.data(), sizeof(double) * tab.size());
         ap.upload(&e->d_scanm, scanm.data(), sizeof(double) * scanm.size());
         ap.zeroed(&e->d_status, sizeof(int));
-        ap.zeroed(&e->d_fe_part, sizeof(double) * (2 * Sg + 2) * C);  // smoothing runs use 2S slots (forward + backward parts)
+        // smoothing runs use 2S slots (forward + backward parts) + one per workgroup of kd_fe_resid
+        ap.zeroed(&e->d_fe_part, sizeof(double) * (2 * Sg + 2 + (size_t)fe_resid_blocks(e->T)) * C);
         e->fe_total_cap = 16;
         ap.zeroed(&e->d_fe_total, sizeof(double) * e->fe_total_cap);
         ap.plain(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64));
@@ -1808,7 +1815,12 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             if ((st = prof_begin(e, RXHIP_K_FE_REDUCE))) return st;
             const int nb = (int)((e->n_chains + 63) / 64);
             Params pr = p;
-            if (e->dense && !filter && e->S > 0) pr.S = 2 * e->S - 1;  // 2S partial slots (see kd_forward_info / kd_backward_info)
+            if (e->dense && !filter && e->S > 0) {
+                // residual quadratic forms at the smoothed means (parallel over all steps), then 2S partial slots of
+                // kd_forward_info / kd_backward_info + kd_fe_resid's
+                launch_fe_resid(dp, e->stream);
+                pr.S = 2 * e->S - 1 + fe_resid_blocks(e->T);
+            }
             hipLaunchKernelGGL(k_fe_chain, dim3(nb), dim3(256), 0, e->stream, pr, e->d_fe_blocks);
             hipLaunchKernelGGL(k_fe_total, dim3(1), dim3(256), 0, e->stream, p, (const double*)e->d_fe_blocks, nb);
             if ((st = prof_end(e))) return st;
