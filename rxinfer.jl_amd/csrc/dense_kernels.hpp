@@ -32,7 +32,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct DenseCst {
     int d, dy;
     long long oA, oP, oLOBS, oG, oQI, oHF, oC0, oX1, oS1, oLD1, oC1, oK1, oVF1, oAT, oGT, oHFT, oK1T, oPI, oK, oKT, oW, oV1I, oM1,
-        oBT, oFEC, size;
+        oBT, oFEC, oPLW, size;
     __host__ __device__ static DenseCst make(int d, int dy) {
         DenseCst c;
         c.d = d;
@@ -65,6 +65,7 @@ struct DenseCst {
         c.oM1 = o; o += d;                   // m1
         c.oBT = o; o += (long long)d * dy;   // B'   [d][dy]
         c.oFEC = o; o += 1;                  // ½[log|V1| + (T−1) log|P| + T(dy log 2π + log|Q|)]
+        c.oPLW = o; o += (long long)d * d;   // P⁻¹ + B'Q⁻¹B + A'P⁻¹A (symmetric): M_{t+1} = PLW − K G_t
         c.size = (o + 7) / 8 * 8;
         return c;
     }
@@ -522,6 +523,7 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
     double* red = yv + dm;          // [4][dm] partial sums
     double* HFs = red + 4 * dm;     // (BA)' [D][dy]   constant maps staged in LDS once
     double* As = HFs + D * dy;      // A'    [D][D]
+    double* gpart = As + D * D;     // [4][D] partial sums of B'Q⁻¹ y_t (smoothing runs: handed to kd_forward_info in the record)
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
@@ -587,10 +589,30 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
             for (; k < k1; ++k) s0 += tb[(long long)k * D + i] * e[k];
             red[part * dm + i] = s0 + s1;
         }
+        if (!p.filter) {  // B'Q⁻¹ y_t: group `part` sums a quarter of the k range (map from L2, coalesced)
+            const double* GT = cst + c.oGT;
+            const int kq = (dy + 3) / 4, k0 = part * kq, k1 = (k0 + kq < dy) ? k0 + kq : dy;
+            double s0 = 0.0, s1 = 0.0;
+            int k = k0;
+            for (; k + 15 < k1; k += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = GT[(long long)(k + u) * D + i];
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) {
+                    s0 += v[u] * yv[k + u];
+                    s1 += v[u + 1] * yv[k + u + 1];
+                }
+            }
+            for (; k < k1; ++k) s0 += GT[(long long)k * D + i] * yv[k];
+            gpart[part * D + i] = s0 + s1;
+        }
         lds_barrier();
         if (tid < D) {
             m[tid] = mn[tid] + (red[tid] + red[dm + tid]);
             eta[tid] += red[2 * dm + tid] + red[3 * dm + tid];
+            if (!p.filter)
+                p.filt[(chain * p.T + (t0 + it)) * DenseCfg<NT>::REC + D + tid] = (gpart[tid] + gpart[D + tid]) + (gpart[2 * D + tid] + gpart[3 * D + tid]);
         }
         lds_barrier();
     }
@@ -852,18 +874,16 @@ __global__ void __launch_bounds__(64 * NT) kd_forward_info(DenseParams p) {
     const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int dm = ((D > dy ? D : dy) + 1) & ~1;
     double* S0 = smem;          // C_t
-    double* S1 = S0 + C::MAT;   // G_t
-    double* vec = S1 + C::MAT;
+    double* S1 = S0 + C::MAT;   // −G_t, then M_{t+1} for the symmetrisation
+    double* S2 = S1 + C::MAT;   // PLW = P⁻¹ + B'Q⁻¹B + A'P⁻¹A (constant)
+    double* vec = S2 + C::MAT;
     double* xi = vec;           // ξ_f
     double* u = xi + dm;
-    double* xp = u + dm;
-    double* yv = xp + dm;
-    double* gy = yv + dm;
-    double* rowbuf = gy + dm;   // 8·D doubles
+    double* xpp = u + dm;       // [4][D] partial sums of ξ_p
+    double* rowbuf = xpp + 4 * dm;  // 8·D doubles
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
-    const double* K = cst + c.oK;
     const size_t MM = (size_t)D * D;
     const int grp = tid / D, gi = tid - grp * D;
     const long long b0 = 1 + seg * p.L;
@@ -873,50 +893,90 @@ __global__ void __launch_bounds__(64 * NT) kd_forward_info(DenseParams p) {
     bool ok = true;
     LogProd lp, lpd;
     Acc<NT> lam, a;
+    // K = P⁻¹A is the A operand of both contractions of a step: its fragments stay in registers for the whole segment
+    double kf[D / 4];
+    {
+        const double* K = cst + c.oK;
+        const int i = 16 * w + (lane & 15), kq = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < D / 4; ++kk) kf[kk] = K[i * D + 4 * kk + kq];
+    }
+    auto mm_k = [&](Acc<NT>& cacc, const double* Y) {  // cacc += K Y   (Y in LDS, leading dimension LD)
+        const int jl = lane & 15, kq = lane >> 4;
+        d4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (d4){cacc.v[t][0], cacc.v[t][1], cacc.v[t][2], cacc.v[t][3]};
+#pragma unroll
+        for (int kk = 0; kk < D / 4; ++kk) {
+            const int k = 4 * kk + kq;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(kf[kk], Y[k * LD + 16 * t + jl], acc[t], 0, 0, 0);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            cacc.v[t][0] = acc[t][0];
+            cacc.v[t][1] = acc[t][1];
+            cacc.v[t][2] = acc[t][2];
+            cacc.v[t][3] = acc[t][3];
+        }
+    };
     // belief at the segment start in information form: Λ_f = V(b_s)⁻¹, ξ_f = Λ_f m(b_s)
     acc_load<NT>(lam, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
     ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lpd) && ok;
     acc_store<NT>(lam, S0, LD, w, lane);
+    acc_load<NT>(a, cst + c.oPLW, D, w, lane);
+    acc_store<NT>(a, S2, LD, w, lane);
     if (tid < D) u[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
     lds_barrier();
     matvec_lds(xi, S0, LD, D, D, u, nullptr, 0.0, tid);
+    acc_add_mat<NT>(lam, cst + c.oW, D, w, lane, 1.0);  // lam carries M_t = Λ_f(t−1) + A'P⁻¹A from here on
+    // B'Q⁻¹ y_t comes from the aggregation kernel (record of t, second header slot), fetched one step ahead
+    double gyn = (tid < D && len > 0) ? p.filt[(chain * p.T + t0) * C::REC + D + tid] : 0.0;
     lds_barrier();
     for (long long i = 0; i < len; ++i) {
         const long long t = t0 + i;
         double* rec = p.filt + (chain * p.T + (t - 1)) * C::REC;
-        if (tid < dy) yv[tid] = p.y[(t * p.n_chains + chain) * dy + tid];
-        if (tid < D) rec[tid] = xi[tid];  // ξ_f(t − 1)
-        lds_barrier();
-        if (grp == 2) matvec_gT_group(gy, cst + c.oGT, D, dy, yv, gi, D);  // B'Q⁻¹ y_t
+        const double gyc = gyn;
+        if (tid < D) {
+            rec[tid] = xi[tid];  // ξ_f(t − 1)
+            gyn = p.filt[(chain * p.T + (i + 1 < len ? t + 1 : t)) * C::REC + D + tid];
+        }
         // C = (Λ_f + A'P⁻¹A)⁻¹
-        acc_add_mat<NT>(lam, cst + c.oW, D, w, lane, 1.0);
         ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
         acc_store_tri<NT>(lam, rec + C::HDR, w, lane);
         acc_store<NT>(lam, S0, LD, w, lane);
         lds_barrier();
-        // u = C ξ_f ;  G' = K C
-        matvec_lds(u, S0, LD, D, D, xi, nullptr, 0.0, tid);
+        // G' = K C
         acc_zero<NT>(a);
-        mm_acc<NT, false, false>(a, K, D, S0, LD, w, lane);
+        mm_k(a, S0);
         acc_store_full<NT>(a, rec + C::HDR + C::TRI, w, lane);
-        acc_store_T<NT>(a, S1, LD, w, lane);
-        lds_barrier();
-        // ξ_p = K u ;  Λ_f(t) = P⁻¹ − K G + B'Q⁻¹B
-        if (grp == 0) matvec_gT_group(xp, cst + c.oKT, D, D, u, gi, D);
-        acc_zero<NT>(a);
-        mm_acc<NT, false, false>(a, K, D, S1, LD, w, lane);
-        acc_load<NT>(lam, cst + c.oPI, D, w, lane);
 #pragma unroll
         for (int q = 0; q < NT; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) lam.v[q][r] -= a.v[q][r];
-        acc_add_mat<NT>(lam, cst + c.oLOBS, D, w, lane, 1.0);
+            for (int r = 0; r < 4; ++r) a.v[q][r] = -a.v[q][r];
+        acc_store_T<NT>(a, S1, LD, w, lane);  // S1 = −G
         lds_barrier();
-        if (tid < D) xi[tid] = xp[tid] + gy[tid];  // ξ_f(t)
-        acc_store<NT>(lam, S1, LD, w, lane);       // G is no longer needed: S1 carries Λ_f for the symmetrisation
+        // ξ_p = K C ξ_f = G' ξ_f: column sums of S1, a quarter of the range per thread group;
+        // M_{t+1} = Λ_f(t) + A'P⁻¹A = PLW − K G
+        {
+            double s0 = 0.0, s1 = 0.0;
+            const int k0 = grp * (D / 4);
+#pragma unroll
+            for (int k = 0; k < D / 4; k += 2) {
+                s0 += S1[(k0 + k) * LD + gi] * xi[k0 + k];
+                s1 += S1[(k0 + k + 1) * LD + gi] * xi[k0 + k + 1];
+            }
+            xpp[grp * D + gi] = s0 + s1;
+        }
+        acc_load<NT>(lam, S2, LD, w, lane);
+        mm_k(lam, S1);
+        lds_barrier();
+        if (tid < D) xi[tid] = gyc - ((xpp[tid] + xpp[D + tid]) + (xpp[2 * D + tid] + xpp[3 * D + tid]));  // ξ_f(t)
+        acc_store<NT>(lam, S1, LD, w, lane);       // G is no longer needed: S1 carries M for the symmetrisation
         lds_barrier();
         acc_symmetrise<NT>(lam, S1, LD, w, lane);
     }
+    acc_add_mat<NT>(lam, cst + c.oW, D, w, lane, -1.0);
     acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);  // Λ_f at the segment end
     if (seg == p.S - 1 && tid < D) p.filt[(chain * p.T + (t0 + len - 1)) * C::REC + tid] = xi[tid];  // ξ_f(T): no successor writes it
     if (FE && tid == 0) p.fe_part[(1 + seg) * p.n_chains + chain] = -0.5 * lp.value();

@@ -751,6 +751,9 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
                 cst[c.oKT + (size_t)k * d + i] = Kc[(size_t)i * d + k];
                 cst[c.oW + (size_t)i * d + k] = 0.5 * (Wc[(size_t)i * d + k] + Wc[(size_t)k * d + i]);
                 cst[c.oV1I + (size_t)i * d + k] = V1i[(size_t)i * d + k];
+                cst[c.oPLW + (size_t)i * d + k] = 0.5 * (Pinv[(size_t)i * d + k] + Pinv[(size_t)k * d + i]) +
+                                                  0.5 * (Lobs[(size_t)i * d + k] + Lobs[(size_t)k * d + i]) +
+                                                  0.5 * (Wc[(size_t)i * d + k] + Wc[(size_t)k * d + i]);
             }
         for (int i = 0; i < d; ++i) cst[c.oM1 + i] = m1[i];
         for (int r = 0; r < dy; ++r)
