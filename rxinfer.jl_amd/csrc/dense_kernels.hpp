@@ -90,6 +90,10 @@ struct DenseParams {
     double* elem;         // [chain][S][2][d]   b, η
     double* fstart_m;     // [chain][S][d]      filtered mean at b_s
     double* beta_xi;      // [chain][S+1][d]    ξβ at b_s
+    // two-level boundary scan (see kd_scan_local / kd_scan_fix): scan steps st = 0 … S−2 in groups of `sg`
+    const double* qtab;   // [2][S][d][d]  index q = st + 1: product of the step maps from the start of q's group through st (transposed)
+    double* loc;          // [chain][2][S][d]  index q: state after step q − 1 of a scan that starts every group from zero
+    int sg, ng;           // group size, number of groups
     double* fe_part;      // [S+1][chain]
     int* status;
 };
@@ -505,6 +509,10 @@ struct DenseLds {
     static constexpr size_t bytes(int dmax) {
         return sizeof(double) * ((size_t)4 * C::MAT + (size_t)NVEC * dmax + 8 * C::D + 3 * C::THREADS);
     }
+    // kd_seg_aggregate: 9 vectors, three constant maps ((BA)', A', (B'Q⁻¹)') and the partial sums of B'Q⁻¹y
+    static constexpr size_t agg_bytes(int dy) {
+        return sizeof(double) * ((size_t)9 * ((((C::D > dy ? C::D : dy) + 1) & ~1)) + (size_t)2 * C::D * dy + (size_t)C::D * C::D + 4 * C::D);
+    }
 };
 
 // phase 1 (dense): b, η of one segment.  One workgroup per (segment, chain).
@@ -524,6 +532,7 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
     double* HFs = red + 4 * dm;     // (BA)' [D][dy]   constant maps staged in LDS once
     double* As = HFs + D * dy;      // A'    [D][D]
     double* gpart = As + D * D;     // [4][D] partial sums of B'Q⁻¹ y_t (smoothing runs: handed to kd_forward_info in the record)
+    double* GTs = gpart + 4 * D;    // (B'Q⁻¹)' [dy][D], staged for smoothing runs
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
@@ -534,6 +543,8 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
     const long long t0 = seg * p.L + 1;
     for (int q = tid; q < D * dy; q += NTH) HFs[q] = cst[c.oHFT + q];
     for (int q = tid; q < D * D; q += NTH) As[q] = cst[c.oAT + q];
+    if (!p.filter)
+        for (int q = tid; q < D * dy; q += NTH) GTs[q] = cst[c.oGT + q];
     if (tid < D) {
         m[tid] = 0.0;
         eta[tid] = 0.0;
@@ -589,22 +600,16 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
             for (; k < k1; ++k) s0 += tb[(long long)k * D + i] * e[k];
             red[part * dm + i] = s0 + s1;
         }
-        if (!p.filter) {  // B'Q⁻¹ y_t: group `part` sums a quarter of the k range (map from L2, coalesced)
-            const double* GT = cst + c.oGT;
+        if (!p.filter) {  // B'Q⁻¹ y_t: group `part` sums a quarter of the k range
             const int kq = (dy + 3) / 4, k0 = part * kq, k1 = (k0 + kq < dy) ? k0 + kq : dy;
             double s0 = 0.0, s1 = 0.0;
             int k = k0;
-            for (; k + 15 < k1; k += 16) {
-                double v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = GT[(long long)(k + u) * D + i];
-#pragma unroll
-                for (int u = 0; u < 16; u += 2) {
-                    s0 += v[u] * yv[k + u];
-                    s1 += v[u + 1] * yv[k + u + 1];
-                }
+#pragma unroll 4
+            for (; k + 1 < k1; k += 2) {
+                s0 += GTs[k * D + i] * yv[k];
+                s1 += GTs[(k + 1) * D + i] * yv[k + 1];
             }
-            for (; k < k1; ++k) s0 += GT[(long long)k * D + i] * yv[k];
+            if (k < k1) s0 += GTs[k * D + i] * yv[k];
             gpart[part * D + i] = s0 + s1;
         }
         lds_barrier();
@@ -646,35 +651,37 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
     }
 }
 
-// The carried-vector recursion of the boundary scan (prefix: segments 0 … S−2 ascending, map 0 and w_s; suffix: segments
-// S−1 … 1 descending, map 3 and w_s').  v lives in LDS (v0); thread group `part` sums a quarter of the k range.
-template <int NT, bool SUFFIX>
-__device__ __forceinline__ void dense_scan_chain(const DenseParams& p, long long chain, double* v0, double* red, int tid) {
+// ---- boundary scan, two levels --------------------------------------------------------------------------------------
+// The scan carries a d-vector across segment boundaries: x_{st+1} = w_st + Map_st x_st, st = 0 … S−2 (prefix: segments
+// ascending, map 0 and w_s of the aggregation kernel, x = filtered mean at the segment start; suffix: segments descending,
+// map 3 and w_s', x = ξβ at the segment end).  The maps are per-model constants, so products of maps are too: the host
+// composes, for every q = st + 1, Q_q = Map_st ⋯ Map_{first step of q's group} (groups of sg ≈ √S steps).  Then
+//   level 1 (kd_scan_local, one workgroup per group): the recursion from x = 0 at every group start -> l_q
+//   level 2 (kd_scan_fix, every workgroup redundantly): X_{j+1} = l_{(j+1)sg} + Q_{(j+1)sg} X_j over the groups before its own
+//   level 3 (kd_scan_fix):                              x_q = l_q + Q_q X_j   for the q of its group
+// — a sequential depth of ≈ 3√S matvec rounds instead of S (250 rounds of ≈1.1 µs were 16 % of a d = 64 sweep).
+// One round: y = w + Mt'x with thread group `part` summing a quarter of the k range; the maps of the next PD rounds are kept
+// in flight in registers (a cold 32 KB map read costs ≈2.6 µs; the loads do not depend on x).
+//   CARRY: x <- y after every round (recursion), else x stays (independent applications).
+template <int NT, bool CARRY, class MapF, class WF, class OutF>
+__device__ __forceinline__ void dense_affine_rounds(int nrounds, MapF map_of, WF w_of, OutF out, double* v0, double* red, int tid) {
     constexpr int D = 16 * NT, KP = D / 4, PD = 4;
-    const int S = p.S, nsteps = S - 1;
-    const size_t MM = (size_t)D * D;
     const int part = tid / D, i = tid - part * D, k0 = part * KP;
+    if (nrounds <= 0) return;
     double buf[PD][KP], wb[PD];
-    auto seg_of = [&](int st) { return SUFFIX ? S - 1 - st : st; };
-    auto fetch = [&](double (&dst)[KP], double& w, int st) {
-        const int sg = seg_of(st);
-        const double* Mt = p.scanm + ((size_t)sg * 6 + (SUFFIX ? 3 : 0)) * MM;
+    auto fetch = [&](double (&dst)[KP], double& w, int r) {
+        const double* Mt = map_of(r);
 #pragma unroll
         for (int u = 0; u < KP; ++u) dst[u] = Mt[(size_t)(k0 + u) * D + i];
-        w = tid < D ? p.elem[((chain * S + sg) * 2 + (SUFFIX ? 1 : 0)) * D + tid] : 0.0;
+        w = tid < D ? w_of(r)[tid] : 0.0;
     };
-    if (nsteps > 0) {
 #pragma unroll
-        for (int q = 0; q < PD; ++q) fetch(buf[q], wb[q], q < nsteps ? q : nsteps - 1);
-    }
-    lds_barrier();
-    for (int st0 = 0; st0 <= nsteps; st0 += PD) {
+    for (int q = 0; q < PD; ++q) fetch(buf[q], wb[q], q < nrounds ? q : nrounds - 1);
+    for (int r0 = 0; r0 < nrounds; r0 += PD) {
 #pragma unroll
         for (int q = 0; q < PD; ++q) {
-            const int st = st0 + q;
-            if (st > nsteps) break;
-            if (!SUFFIX && tid < D) p.fstart_m[(chain * S + st) * D + tid] = v0[tid];
-            if (st == nsteps) break;
+            const int r = r0 + q;
+            if (r >= nrounds) break;
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
             for (int u = 0; u < KP; u += 2) {
@@ -682,24 +689,23 @@ __device__ __forceinline__ void dense_scan_chain(const DenseParams& p, long long
                 s1 += buf[q][u + 1] * v0[k0 + u + 1];
             }
             const double wv = wb[q];
-            fetch(buf[q], wb[q], st + PD < nsteps ? st + PD : nsteps - 1);  // unconditional (clamped): keeps the waitcnt bookkeeping exact
+            fetch(buf[q], wb[q], r + PD < nrounds ? r + PD : nrounds - 1);  // unconditional (clamped): keeps the waitcnt bookkeeping exact
             red[tid] = s0 + s1;
             lds_barrier();
             if (tid < D) {
                 const double x = wv + ((red[tid] + red[D + tid]) + (red[2 * D + tid] + red[3 * D + tid]));
-                v0[tid] = x;
-                if (SUFFIX) p.beta_xi[(chain * (S + 1) + seg_of(st)) * D + tid] = x;
+                if (CARRY) v0[tid] = x;
+                out(r, x);
             }
             lds_barrier();
         }
     }
 }
 
-// phase 2 (dense): carries the data-dependent vectors across segment boundaries with the per-model maps.
-//   blockIdx.x = 0: prefix   m(b_{s+1}) = M1_s m(b_s) + M2_s η_s + b_s ;  also the t = 1 update
-//   blockIdx.x = 1: suffix   ξβ(b_s) = η_s + N1_s ξβ(b_{s+1}) − N2_s b_s
+// level 1.  grid (2·ng, chains): blockIdx.x = dir·ng + group;  dir 0 = prefix, 1 = suffix.  Workgroup (0, 0) also performs the
+// t = 1 update (filtered belief of the first observation, evidence term of filtering runs).
 template <int NT, bool FE>
-__global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
+__global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
     constexpr int D = 16 * NT;
     using C = DenseCfg<NT>;
     extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -713,8 +719,10 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
     const long long chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
-    const int S = p.S;
-    if (blockIdx.x == 0) {
+    const int S = p.S, n = S - 1;
+    const int dir = blockIdx.x / p.ng, grpj = blockIdx.x - dir * p.ng;
+    const size_t MM = (size_t)D * D;
+    if (dir == 0 && grpj == 0) {
         // filtered belief at t = 1: ξf = V1⁻¹m1 + G y;  mf = c1 + K1 y
         if (tid < dy) yv[tid] = p.y[(0 * p.n_chains + chain) * dy + tid];
         lds_barrier();
@@ -734,7 +742,10 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
         }
         lds_barrier();
         double* rec = p.filt + (chain * p.T + 0) * C::REC;
-        if (tid < D) rec[tid] = v0[tid];
+        if (tid < D) {
+            rec[tid] = v0[tid];
+            if (S > 0) p.fstart_m[(chain * S + 0) * D + tid] = v0[tid];  // x_0 of the prefix scan
+        }
         {
             Acc<NT> a;
             acc_load<NT>(a, cst + c.oVF1, D, w, lane);
@@ -748,17 +759,60 @@ __global__ void __launch_bounds__(64 * NT) kd_boundary_scan(DenseParams p) {
             block_dot3(v2, yv, dy, v1, v0, D, v1, v0, 0, red, tid, 64 * NT, dots);
             if (tid == 0) p.fe_part[chain] = -0.5 * (cst[c.oC0] + dots[0] - dots[1] + cst[c.oS1] + cst[c.oLD1]);
         }
-        // sequential part: v <- w_s + M1_s v.  A cold 32 KB map read costs ≈2.6 µs of latency; the maps of the next PD segments
-        // are therefore kept in flight in registers (the loads do not depend on v) and a step costs one LDS partial-sum round.
-        dense_scan_chain<NT, false>(p, chain, v0, red, tid);
-    } else {
-        if (tid < D) {
-            v0[tid] = 0.0;
-            p.beta_xi[(chain * (S + 1) + S) * D + tid] = 0.0;
-        }
         lds_barrier();
-        dense_scan_chain<NT, true>(p, chain, v0, red, tid);
     }
+    if (dir == 1 && grpj == 0 && tid < D && S > 0) p.beta_xi[(chain * (S + 1) + S) * D + tid] = 0.0;  // x_0 of the suffix scan
+    if (n <= 0) return;
+    const int st0 = grpj * p.sg;
+    int st1 = st0 + p.sg;
+    if (st1 > n) st1 = n;
+    if (tid < D) v0[tid] = 0.0;
+    lds_barrier();
+    double* loc = p.loc + ((chain * 2 + dir) * (size_t)S) * D;
+    auto seg_of = [&](int st) { return dir ? S - 1 - st : st; };
+    dense_affine_rounds<NT, true>(
+        st1 - st0,
+        [&](int r) { return p.scanm + ((size_t)seg_of(st0 + r) * 6 + (dir ? 3 : 0)) * MM; },
+        [&](int r) { return p.elem + ((chain * S + seg_of(st0 + r)) * 2 + dir) * D; },
+        [&](int r, double x) { loc[(size_t)(st0 + r + 1) * D + tid] = x; }, v0, red, tid);
+}
+
+// levels 2 and 3.  Same grid.  Output: prefix x_q -> fstart_m[q] (filtered mean at the start of segment q);
+// suffix x_q -> beta_xi[S − q] (ξβ at the start boundary of segment S − q).
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) kd_scan_fix(DenseParams p) {
+    constexpr int D = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int dy = p.dy, tid = threadIdx.x;
+    const int dm = ((D > dy ? D : dy) + 1) & ~1;
+    double* v0 = smem;
+    double* red = v0 + 4 * dm;
+    const long long chain = blockIdx.y;
+    const int S = p.S, n = S - 1;
+    const int dir = blockIdx.x / p.ng, grpj = blockIdx.x - dir * p.ng;
+    const size_t MM = (size_t)D * D;
+    if (n <= 0) return;
+    const double* loc = p.loc + ((chain * 2 + dir) * (size_t)S) * D;
+    const double* qt = p.qtab + (size_t)dir * S * MM;
+    if (tid < D) v0[tid] = dir ? 0.0 : p.fstart_m[(chain * S + 0) * D + tid];
+    lds_barrier();
+    const int sg = p.sg;
+    // level 2: state at the start of this group
+    dense_affine_rounds<NT, true>(
+        grpj, [&](int r) { return qt + (size_t)((r + 1) * sg) * MM; }, [&](int r) { return loc + (size_t)((r + 1) * sg) * D; },
+        [&](int, double) {}, v0, red, tid);
+    // level 3: the states inside the group
+    const int q0 = grpj * sg + 1;
+    int q1 = q0 + sg;
+    if (q1 > n + 1) q1 = n + 1;
+    dense_affine_rounds<NT, false>(
+        q1 - q0, [&](int r) { return qt + (size_t)(q0 + r) * MM; }, [&](int r) { return loc + (size_t)(q0 + r) * D; },
+        [&](int r, double x) {
+            const int q = q0 + r;
+            if (dir) p.beta_xi[(chain * (S + 1) + (S - q)) * D + tid] = x;
+            else p.fstart_m[(chain * S + q) * D + tid] = x;
+        },
+        v0, red, tid);
 }
 
 // phase 3 (dense, FILTERING runs): covariance-form forward sweep of one segment — the filtered belief (m_f, V_f) of every

@@ -202,7 +202,8 @@ struct rxhip_engine {
     // dense (d = 16·NT) path
     bool dense = false;
     int nt = 0;
-    double *d_scanm = nullptr, *d_fstart_m = nullptr, *d_beta_xi = nullptr, *d_vend = nullptr;
+    double *d_scanm = nullptr, *d_fstart_m = nullptr, *d_beta_xi = nullptr, *d_vend = nullptr, *d_qtab = nullptr, *d_loc = nullptr;
+    int scan_sg = 1, scan_ng = 1;  // two-level boundary scan of the dense path: group size, groups
     std::vector<double> h_cst0;  // model 0's constant block (kernel argument when all chains share it)
     int fe_total_cap = 0;
     // results bookkeeping
@@ -621,9 +622,10 @@ struct DenseLaunch {
     static hipError_t prepare(int d, int dy) {
         const int bytes = (int)lds_bytes(d, dy);
         hipError_t e;
-        if ((e = hipFuncSetAttribute((const void*)kd_seg_aggregate<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_boundary_scan<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_boundary_scan<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_seg_aggregate<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DenseLds<NT>::agg_bytes(dy)))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_scan_local<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_scan_local<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_scan_fix<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_forward<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_forward<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_forward_info<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
@@ -634,12 +636,13 @@ struct DenseLaunch {
         return hipSuccess;
     }
     static void seg_aggregate(const DenseParams& p, hipStream_t s) {
-        hipLaunchKernelGGL((kd_seg_aggregate<NT>), dim3(p.S, (unsigned)p.n_chains), dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        hipLaunchKernelGGL((kd_seg_aggregate<NT>), dim3(p.S, (unsigned)p.n_chains), dim3(64 * NT), DenseLds<NT>::agg_bytes(p.dy), s, p);
     }
     static void boundary_scan(const DenseParams& p, bool fe, hipStream_t s) {
-        dim3 g(p.filter ? 1 : 2, (unsigned)p.n_chains);
-        if (fe) hipLaunchKernelGGL((kd_boundary_scan<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
-        else hipLaunchKernelGGL((kd_boundary_scan<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        dim3 g((p.filter ? 1 : 2) * p.ng, (unsigned)p.n_chains);  // filtering runs need the prefix direction only
+        if (fe) hipLaunchKernelGGL((kd_scan_local<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        else hipLaunchKernelGGL((kd_scan_local<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        if (p.S > 1) hipLaunchKernelGGL((kd_scan_fix<NT>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
     }
     static void forward(const DenseParams& p, bool fe, hipStream_t s) {
         dim3 g(p.S, (unsigned)p.n_chains);
@@ -676,7 +679,7 @@ static int dense_rec(int nt) { return 2 * 16 * nt + dense_tri(nt) + 256 * nt * n
 // Per-model tables of the dense path: constants, per-offset gains (K_i, U_i), and the data-independent
 // matrix part of the boundary scan for every segment (see dense_kernels.hpp DenseParams::scanm).
 static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* ds, std::vector<double>& cst,
-                                       std::vector<double>& tab, std::vector<double>& scanm) {
+                                       std::vector<double>& tab, std::vector<double>& scanm, std::vector<double>& qtab) {
     const int d = e->dpad, dy = e->dy, du = e->d;
     const size_t MM = (size_t)d * d;
     // padded copies of the model (identity blocks on the padding dimensions)
@@ -859,6 +862,29 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
         }
         for (size_t q = 0; q < MM; ++q) scanm[5 * MM + q] = Lm[q];  // segment 0: Λβ(b_1)
     }
+    // two-level scan (kd_scan_local / kd_scan_fix): groups of sg ≈ √(S−1) scan steps, composed maps Q_q (transposed)
+    {
+        const int n = S_ - 1;
+        int sg = 1;
+        while (sg * sg < n) ++sg;
+        e->scan_sg = sg;
+        e->scan_ng = n > 0 ? (n + sg - 1) / sg : 1;
+        qtab.assign((size_t)2 * (S_ > 0 ? S_ : 1) * MM, 0.0);
+        std::vector<double> Mp(MM), Qc(MM), Qn(MM);
+        for (int dir = 0; dir < 2 && n > 0; ++dir)
+            for (int st = 0; st < n; ++st) {
+                const int seg = dir ? S_ - 1 - st : st;
+                const double* mt = scanm.data() + ((size_t)seg * 6 + (dir ? 3 : 0)) * MM;  // stored transposed
+                for (int a = 0; a < d; ++a)
+                    for (int b = 0; b < d; ++b) Mp[(size_t)a * d + b] = mt[(size_t)b * d + a];
+                if (st % sg == 0) Qn = Mp;
+                else host::mm(d, d, d, Mp.data(), Qc.data(), Qn.data());
+                Qc = Qn;
+                double* qt = qtab.data() + ((size_t)dir * S_ + (st + 1)) * MM;
+                for (int a = 0; a < d; ++a)
+                    for (int b = 0; b < d; ++b) qt[(size_t)b * d + a] = Qc[(size_t)a * d + b];
+            }
+    }
     return RXHIP_OK;
 }
 
@@ -978,7 +1004,7 @@ static void free_all(rxhip_engine* e) {
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&e->h.d_out, &e->h.d_fe_series, &e->h.d_gh, &e->h.d_fe_total})
         if (*b) { (void)hipFree(*b); *b = nullptr; }
-    for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend})
+    for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend, &e->d_qtab, &e->d_loc})
         if (*b) { if (!e->in_arena(*b)) (void)hipFree(*b); *b = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
@@ -1081,8 +1107,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     }
 
     if (dense) {
-        std::vector<double> cst, tab, scanm;
-        rxhip_status st = build_dense_tables(e, ds, cst, tab, scanm);
+        std::vector<double> cst, tab, scanm, qtab;
+        rxhip_status st = build_dense_tables(e, ds, cst, tab, scanm, qtab);
         if (st) return st;
         hipError_t herr = hipSuccess;
         DENSE_DISPATCH(e->nt, prepare(e->dpad, e->dy) == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
@@ -1093,6 +1119,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.upload(&e->d_cst, cst.data(), sizeof(double) * cst.size());
         ap.upload(&e->d_tab, tab.data(), sizeof(double) * tab.size());
         ap.upload(&e->d_scanm, scanm.data(), sizeof(double) * scanm.size());
+        ap.upload(&e->d_qtab, qtab.data(), sizeof(double) * qtab.size());
+        ap.plain(&e->d_loc, sizeof(double) * C * 2 * Sg * D);
         ap.zeroed(&e->d_status, sizeof(int));
         // smoothing runs use 2S slots (forward + backward parts) + one per workgroup of kd_fe_resid
         ap.zeroed(&e->d_fe_part, sizeof(double) * (2 * Sg + 2 + (size_t)fe_resid_blocks(e->T)) * C);
@@ -1764,6 +1792,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     if (e->dense) {
         dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->S; dp.L = e->L; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy;
         dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
+        dp.qtab = e->d_qtab; dp.loc = e->d_loc; dp.sg = e->scan_sg; dp.ng = e->scan_ng;
         dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;
         dp.filter = p.filter;
