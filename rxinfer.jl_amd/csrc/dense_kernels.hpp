@@ -85,7 +85,10 @@ struct DenseParams {
     double* mean;         // [T][chain][d]
     double* cov;          // [T][chain][d][d]
     const double* cst;    // DenseCst block (model 0; the dense path takes one model)
-    const double* tab;    // [L][2][d][dy]  K_i, U_i
+    const double* tab;    // [2][L·dyp][2d]  aggregation tables Ψ_i | Θ_i (set 0: full segments, set 1: the last segment), dyp = dy padded to 4
+    double* aggpart;      // [chain][agg_kc][S][2d]  partial sums of kd_agg_gemm
+    int agg_oc, agg_kc;   // offsets per K-chunk, K-chunks
+    long long Llast;      // length of the last segment
     const double* scanm;  // [S][6][d][d]   0:M1' 1:M2' 2:V(b_s)  3:N1' 4:N2' 5:Λβ(b_{s+1})  (maps stored transposed)
     double* elem;         // [chain][S][2][d]   b, η
     double* fstart_m;     // [chain][S][d]      filtered mean at b_s
@@ -509,30 +512,86 @@ struct DenseLds {
     static constexpr size_t bytes(int dmax) {
         return sizeof(double) * ((size_t)4 * C::MAT + (size_t)NVEC * dmax + 8 * C::D + 3 * C::THREADS);
     }
-    // kd_seg_aggregate: 9 vectors, three constant maps ((BA)', A', (B'Q⁻¹)') and the partial sums of B'Q⁻¹y
+    // kd_agg_finish: 6 vectors, the map (B'Q⁻¹)' and a tile of 16 observations
     static constexpr size_t agg_bytes(int dy) {
-        return sizeof(double) * ((size_t)9 * ((((C::D > dy ? C::D : dy) + 1) & ~1)) + (size_t)2 * C::D * dy + (size_t)C::D * C::D + 4 * C::D);
+        return sizeof(double) * ((size_t)6 * ((((C::D > dy ? C::D : dy) + 1) & ~1)) + (size_t)C::D * dy + (size_t)16 * dy + 16);
     }
 };
 
-// phase 1 (dense): b, η of one segment.  One workgroup per (segment, chain).
+// phase 1 (dense): the element (b_s, η_s) of every segment.  It is linear in the segment's observations with per-offset
+// constant maps (host tables Ψ_i, Θ_i: see build_dense_tables), so instead of a sequential recursion per segment it is ONE
+// product  [2d × L·dy] · [L·dy × S]  on the matrix cores, split over K-chunks of agg_oc offsets for parallelism:
+//   kd_agg_gemm   grid (segment blocks of 16, K-chunks, chains): partial sums, v_mfma_f64_16x16x4_f64, operands straight from
+//                 L2 (the table is shared by all segments; y is read once)
+//   kd_agg_finish grid (S, chains): fixed-order sum of the partials, the data-dependent halves of the boundary scan
+//                 (w_s = b_s + M2_s η_s, w_s' = η_s − N2_s b_s) and, for smoothing runs, B'Q⁻¹y_t of every step of the segment
+//                 (handed to kd_forward_info in the record).
+// The full segments 0 … S−2 share table set 0; the last segment (length Llast ≤ L) has its own set and its own block.
 template <int NT>
-__global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
+__global__ void __launch_bounds__(64 * NT) kd_agg_gemm(DenseParams p) {
     constexpr int D = 16 * NT;
-    constexpr int NTH = 64 * NT;  // = 4·D: four thread groups of D, each sums half of the k range of one of two maps
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    const int dy = p.dy, dyp = (dy + 3) & ~3, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int jl = lane & 15, kq = lane >> 4;
+    const int nblk = gridDim.x, sb = blockIdx.x, kc = blockIdx.y;
+    const long long chain = blockIdx.z;
+    const bool lastblk = sb == nblk - 1;
+    const int seg = lastblk ? p.S - 1 : 16 * sb + jl;                      // this lane's B-operand column
+    const bool segok = lastblk ? jl == 0 : seg < p.S - 1;
+    const long long len = lastblk ? p.Llast : p.L;
+    const double* tab = p.tab + (lastblk ? (size_t)p.L * dyp * 2 * D : 0);
+    long long o0 = (long long)kc * p.agg_oc, o1 = o0 + p.agg_oc;
+    if (o1 > len) o1 = len;
+    v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    const int r0 = 16 * w + jl, r1 = 16 * (w + NT) + jl;                   // A-operand rows of this wave's two tiles
+    // flattened (offset, k-step) loop, four steps per trip with all twelve loads issued first
+    const int kpo = dyp / 4;
+    const long long nq = (o1 > o0 ? o1 - o0 : 0) * kpo;
+    const double* ybase = p.y + ((1 + (long long)seg * p.L) * p.n_chains + chain) * dy;
+    const long long ystride = p.n_chains * (long long)dy;
+    long long o = o0;
+    int kk = 0;
+    for (long long q = 0; q < nq; q += 4) {
+        double a0[4], a1[4], b[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool in = q + u < nq;
+            const int k = 4 * kk + kq;
+            const double* tb = tab + ((size_t)o * dyp + k) * 2 * D;
+            a0[u] = in ? tb[r0] : 0.0;
+            a1[u] = in ? tb[r1] : 0.0;
+            b[u] = (in && segok && k < dy) ? ybase[o * ystride + k] : 0.0;
+            if (++kk == kpo) { kk = 0; ++o; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b[u], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b[u], acc1, 0, 0, 0);
+        }
+    }
+    // accumulator element (row = 16·tile + kq + 4r, column = segment jl)
+    if (segok) {
+        double* out = p.aggpart + (((size_t)chain * p.agg_kc + kc) * p.S + seg) * 2 * D;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            out[16 * w + kq + 4 * r] = acc0[r];
+            out[16 * (w + NT) + kq + 4 * r] = acc1[r];
+        }
+    }
+}
+
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) kd_agg_finish(DenseParams p) {
+    constexpr int D = 16 * NT;
+    constexpr int TS = 16;  // steps per tile of the B'Q⁻¹y pass
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int dy = p.dy, tid = threadIdx.x;
     const int dm = ((D > dy ? D : dy) + 1) & ~1;  // even: keeps every LDS carve 16-byte aligned
-    double* m = smem;
-    double* mn = m + dm;
-    double* eta = mn + dm;
-    double* e = eta + dm;
-    double* yv = e + dm;
-    double* red = yv + dm;          // [4][dm] partial sums
-    double* HFs = red + 4 * dm;     // (BA)' [D][dy]   constant maps staged in LDS once
-    double* As = HFs + D * dy;      // A'    [D][D]
-    double* gpart = As + D * D;     // [4][D] partial sums of B'Q⁻¹ y_t (smoothing runs: handed to kd_forward_info in the record)
-    double* GTs = gpart + 4 * D;    // (B'Q⁻¹)' [dy][D], staged for smoothing runs
+    double* m = smem;               // b_s
+    double* eta = m + dm;           // η_s
+    double* red = eta + dm;         // [4][dm] partial sums
+    double* GTs = red + 4 * dm;     // (B'Q⁻¹)' [dy][D]
+    double* Ys = GTs + D * dy;      // [TS][dy]
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
@@ -540,87 +599,17 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
     long long b1 = b0 + p.L;
     if (b1 > p.T) b1 = p.T;
     const long long len = b1 - b0;
-    const long long t0 = seg * p.L + 1;
-    for (int q = tid; q < D * dy; q += NTH) HFs[q] = cst[c.oHFT + q];
-    for (int q = tid; q < D * D; q += NTH) As[q] = cst[c.oAT + q];
-    if (!p.filter)
-        for (int q = tid; q < D * dy; q += NTH) GTs[q] = cst[c.oGT + q];
-    if (tid < D) {
-        m[tid] = 0.0;
-        eta[tid] = 0.0;
-    }
     const int part = tid / D, i = tid - part * D;
     const int half = part & 1;
-    lds_barrier();
-    for (long long it = 0; it < len; ++it) {
-        if (tid < dy) yv[tid] = p.y[((t0 + it) * p.n_chains + chain) * dy + tid];
-        // phase 1: groups 0,1 -> halves of (BA) m ; groups 2,3 -> halves of A m        (both maps from LDS)
-        {
-            const int k0 = half * (D / 2), k1 = k0 + D / 2;
-            double s0 = 0.0, s1 = 0.0;
-            if (part < 2) {
-                for (int r = i; r < dy; r += D) {  // dy may exceed D (padded small state, wide observation)
-                    s0 = s1 = 0.0;
-#pragma unroll 8
-                    for (int k = k0; k < k1; k += 2) {
-                        s0 += HFs[k * dy + r] * m[k];
-                        s1 += HFs[(k + 1) * dy + r] * m[k + 1];
-                    }
-                    red[part * dm + r] = s0 + s1;
-                }
-            } else {
-#pragma unroll 8
-                for (int k = k0; k < k1; k += 2) {
-                    s0 += As[k * D + i] * m[k];
-                    s1 += As[(k + 1) * D + i] * m[k + 1];
-                }
-                red[part * dm + i] = s0 + s1;
-            }
-        }
-        lds_barrier();
-        if (tid < dy) e[tid] = yv[tid] - (red[tid] + red[dm + tid]);  // e = y − (BA) m
-        if (tid < D) mn[tid] = red[2 * dm + tid] + red[3 * dm + tid]; // A m
-        lds_barrier();
-        // phase 2: groups 0,1 -> halves of K_i e ; groups 2,3 -> halves of U_i e        (per-offset tables from L2, coalesced)
-        {
-            const double* tb = p.tab + it * 2 * D * dy + (part < 2 ? 0 : (long long)dy * D);  // [2][dy][D]: K_i', U_i'
-            const int kh = (dy + 1) / 2, k0 = half * kh, k1 = (k0 + kh < dy) ? k0 + kh : dy;
-            double s0 = 0.0, s1 = 0.0;
-            int k = k0;
-            for (; k + 15 < k1; k += 16) {  // 16 independent loads in flight
-                double v[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) v[u] = tb[(long long)(k + u) * D + i];
-#pragma unroll
-                for (int u = 0; u < 16; u += 2) {
-                    s0 += v[u] * e[k + u];
-                    s1 += v[u + 1] * e[k + u + 1];
-                }
-            }
-            for (; k < k1; ++k) s0 += tb[(long long)k * D + i] * e[k];
-            red[part * dm + i] = s0 + s1;
-        }
-        if (!p.filter) {  // B'Q⁻¹ y_t: group `part` sums a quarter of the k range
-            const int kq = (dy + 3) / 4, k0 = part * kq, k1 = (k0 + kq < dy) ? k0 + kq : dy;
-            double s0 = 0.0, s1 = 0.0;
-            int k = k0;
-#pragma unroll 4
-            for (; k + 1 < k1; k += 2) {
-                s0 += GTs[k * D + i] * yv[k];
-                s1 += GTs[(k + 1) * D + i] * yv[k + 1];
-            }
-            if (k < k1) s0 += GTs[k * D + i] * yv[k];
-            gpart[part * D + i] = s0 + s1;
-        }
-        lds_barrier();
-        if (tid < D) {
-            m[tid] = mn[tid] + (red[tid] + red[dm + tid]);
-            eta[tid] += red[2 * dm + tid] + red[3 * dm + tid];
-            if (!p.filter)
-                p.filt[(chain * p.T + (t0 + it)) * DenseCfg<NT>::REC + D + tid] = (gpart[tid] + gpart[D + tid]) + (gpart[2 * D + tid] + gpart[3 * D + tid]);
-        }
-        lds_barrier();
+    if (tid < 2 * D) {
+        double s = 0.0;
+        for (int kc = 0; kc < p.agg_kc; ++kc) s += p.aggpart[(((size_t)chain * p.agg_kc + kc) * p.S + seg) * 2 * D + tid];
+        if (tid < D) m[tid] = s;
+        else eta[tid - D] = s;
     }
+    if (!p.filter)
+        for (int q = tid; q < D * dy; q += 64 * NT) GTs[q] = cst[c.oGT + q];
+    lds_barrier();
     // The boundary scan carries v <- w_s + M1_s v (prefix) and ξ <- w_s' + N1_s ξ (suffix); the parts that do not depend on
     // the carried vector are formed here, in parallel over segments:  w_s = b_s + M2_s η_s,  w_s' = η_s − N2_s b_s.
     {
@@ -647,6 +636,30 @@ __global__ void __launch_bounds__(64 * NT) kd_seg_aggregate(DenseParams p) {
             double* o = p.elem + ((chain * p.S + seg) * 2) * D;
             o[tid] = m[tid] + (red[tid] + red[dm + tid]);                     // w_s
             o[D + tid] = eta[tid] - (red[2 * dm + tid] + red[3 * dm + tid]);  // w_s'
+        }
+    }
+    if (p.filter) return;
+    // B'Q⁻¹ y_t for every step of the segment, TS steps per pass: thread (i, part) forms row i for steps part, part + 4, …
+    for (long long s0 = 0; s0 < len; s0 += TS) {
+        lds_barrier();
+        for (int q = tid; q < TS * dy; q += 64 * NT) {
+            const int st = q / dy, j = q - st * dy;
+            Ys[q] = (s0 + st < len) ? p.y[((b0 + s0 + st) * p.n_chains + chain) * dy + j] : 0.0;
+        }
+        lds_barrier();
+        double g[TS / 4];
+#pragma unroll
+        for (int u = 0; u < TS / 4; ++u) g[u] = 0.0;
+#pragma unroll 4
+        for (int k = 0; k < dy; ++k) {
+            const double gt = GTs[k * D + i];
+#pragma unroll
+            for (int u = 0; u < TS / 4; ++u) g[u] += gt * Ys[(part + 4 * u) * dy + k];
+        }
+#pragma unroll
+        for (int u = 0; u < TS / 4; ++u) {
+            const long long st = s0 + part + 4 * u;
+            if (st < len) p.filt[(chain * p.T + (b0 + st)) * DenseCfg<NT>::REC + D + i] = g[u];
         }
     }
 }

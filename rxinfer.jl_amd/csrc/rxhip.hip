@@ -204,6 +204,8 @@ struct rxhip_engine {
     int nt = 0;
     double *d_scanm = nullptr, *d_fstart_m = nullptr, *d_beta_xi = nullptr, *d_vend = nullptr, *d_qtab = nullptr, *d_loc = nullptr;
     int scan_sg = 1, scan_ng = 1;  // two-level boundary scan of the dense path: group size, groups
+    int agg_oc = 1, agg_kc = 1;    // dense aggregation product: offsets per K-chunk, K-chunks
+    double* d_aggpart = nullptr;   // [chain][agg_kc][S][2·dpad] partial sums of kd_agg_gemm
     std::vector<double> h_cst0;  // model 0's constant block (kernel argument when all chains share it)
     int fe_total_cap = 0;
     // results bookkeeping
@@ -622,7 +624,7 @@ struct DenseLaunch {
     static hipError_t prepare(int d, int dy) {
         const int bytes = (int)lds_bytes(d, dy);
         hipError_t e;
-        if ((e = hipFuncSetAttribute((const void*)kd_seg_aggregate<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DenseLds<NT>::agg_bytes(dy)))) return e;
+        if ((e = hipFuncSetAttribute((const void*)kd_agg_finish<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DenseLds<NT>::agg_bytes(dy)))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_scan_local<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_scan_local<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         if ((e = hipFuncSetAttribute((const void*)kd_scan_fix<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
@@ -636,7 +638,9 @@ struct DenseLaunch {
         return hipSuccess;
     }
     static void seg_aggregate(const DenseParams& p, hipStream_t s) {
-        hipLaunchKernelGGL((kd_seg_aggregate<NT>), dim3(p.S, (unsigned)p.n_chains), dim3(64 * NT), DenseLds<NT>::agg_bytes(p.dy), s, p);
+        const unsigned sb = (unsigned)((p.S - 1 + 15) / 16 + 1);  // blocks of 16 full segments + the last segment on its own
+        hipLaunchKernelGGL((kd_agg_gemm<NT>), dim3(sb, (unsigned)p.agg_kc, (unsigned)p.n_chains), dim3(64 * NT), 0, s, p);
+        hipLaunchKernelGGL((kd_agg_finish<NT>), dim3(p.S, (unsigned)p.n_chains), dim3(64 * NT), DenseLds<NT>::agg_bytes(p.dy), s, p);
     }
     static void boundary_scan(const DenseParams& p, bool fe, hipStream_t s) {
         dim3 g((p.filter ? 1 : 2) * p.ng, (unsigned)p.n_chains);  // filtering runs need the prefix direction only
@@ -774,7 +778,8 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
 
     // gains and element matrices (Kalman filter from an exactly known state)
     const long long L = e->L;
-    tab.assign((size_t)L * 2 * d * dy, 0.0);
+    // per-offset gains and closed-loop maps, kept for the aggregation tables built after the loop
+    std::vector<double> Kall((size_t)L * d * dy), Uall((size_t)L * d * dy), Phiall((size_t)L * MM);
     std::vector<double> V(MM, 0.0), Pi(MM, 0.0), J(MM, 0.0), Vp(MM), S(dy * dy), Si(dy * dy), K(d * dy), HFPi(dy * d),
         U(d * dy), Phi(MM);
     struct Agg { std::vector<double> Pi, C, J, Ci, X, JJ; };
@@ -803,9 +808,9 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
         for (size_t q = 0; q < MM; ++q) Phi[q] = A[q] - t2[q];
         host::mm(d, d, d, Phi.data(), Pi.data(), t2.data());
         for (size_t q = 0; q < MM; ++q) Pi[q] = t2[q];
-        double* te = tab.data() + (size_t)(i - 1) * 2 * d * dy;
-        for (int a = 0; a < d; ++a)
-            for (int b = 0; b < dy; ++b) { te[(size_t)b * d + a] = K[a * dy + b]; te[(size_t)d * dy + (size_t)b * d + a] = U[a * dy + b]; }
+        std::copy(K.begin(), K.end(), Kall.begin() + (size_t)(i - 1) * d * dy);
+        std::copy(U.begin(), U.end(), Uall.begin() + (size_t)(i - 1) * d * dy);
+        std::copy(Phi.begin(), Phi.end(), Phiall.begin() + (size_t)(i - 1) * MM);
         for (int which = 0; which < 2; ++which) {
             if (i != (which == 0 ? L : e->Llast)) continue;
             Agg& g = ag[which];
@@ -817,6 +822,44 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
             host::mTm(d, d, d, Pi.data(), g.X.data(), g.JJ.data());
             for (size_t q = 0; q < MM; ++q) g.JJ[q] += g.J[q];
         }
+    }
+    // Aggregation tables (kd_agg_gemm).  A segment's element (b_s, η_s) — the filtered mean from a zero start and the
+    // accumulated information vector — is LINEAR in the segment's observations: with Φ_i = A − K_i (BA),
+    //   b_s = Σ_i Ψ_i y_i,  Ψ_i = Φ_L ⋯ Φ_{i+1} K_i ;     η_s = Σ_i Θ_i y_i,  Θ_i = U_i − Z_i K_i,  Z_{i−1} = U_i (BA) + Z_i Φ_i, Z_L = 0
+    // so the sequential per-step recursion becomes one [2d × L·dy]·[L·dy × S] product.  Two sets: full segments (length L) and the
+    // last one (length Llast).  Layout [set][k = (i−1)·dyp + j][row]: rows 0..d−1 = Ψ_i[:, j], d..2d−1 = Θ_i[:, j]; dyp = dy padded to 4.
+    {
+        const int dyp = (dy + 3) & ~3;
+        tab.assign((size_t)2 * L * dyp * 2 * d, 0.0);
+        std::vector<double> Pc(MM), Pn(MM), Z(MM), Zn(MM), Psi(d * dy), ZK(d * dy), UH(MM);
+        for (int which = 0; which < 2; ++which) {
+            const long long Lx = which == 0 ? L : e->Llast;
+            std::fill(Pc.begin(), Pc.end(), 0.0);
+            for (int a = 0; a < d; ++a) Pc[(size_t)a * d + a] = 1.0;
+            std::fill(Z.begin(), Z.end(), 0.0);
+            for (long long i = Lx; i >= 1; --i) {
+                const double* Ki = Kall.data() + (size_t)(i - 1) * d * dy;
+                const double* Ui = Uall.data() + (size_t)(i - 1) * d * dy;
+                const double* Phii = Phiall.data() + (size_t)(i - 1) * MM;
+                host::mm(d, d, dy, Pc.data(), Ki, Psi.data());
+                host::mm(d, d, dy, Z.data(), Ki, ZK.data());
+                double* te = tab.data() + ((size_t)which * L + (size_t)(i - 1)) * dyp * 2 * d;
+                for (int j = 0; j < dy; ++j)
+                    for (int a = 0; a < d; ++a) {
+                        te[(size_t)j * 2 * d + a] = Psi[(size_t)a * dy + j];
+                        te[(size_t)j * 2 * d + d + a] = Ui[(size_t)a * dy + j] - ZK[(size_t)a * dy + j];
+                    }
+                host::mm(d, d, d, Pc.data(), Phii, Pn.data());
+                Pc = Pn;
+                host::mm(d, dy, d, Ui, HF.data(), UH.data());
+                host::mm(d, d, d, Z.data(), Phii, Zn.data());
+                for (size_t q = 0; q < MM; ++q) Z[q] = UH[q] + Zn[q];
+            }
+        }
+        long long oc = (L + 11) / 12;
+        if (oc < 1) oc = 1;
+        e->agg_oc = (int)oc;
+        e->agg_kc = (int)((L + oc - 1) / oc);
     }
     // boundary-scan matrices
     const int S_ = e->S;
@@ -1004,7 +1047,7 @@ static void free_all(rxhip_engine* e) {
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&e->h.d_out, &e->h.d_fe_series, &e->h.d_gh, &e->h.d_fe_total})
         if (*b) { (void)hipFree(*b); *b = nullptr; }
-    for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend, &e->d_qtab, &e->d_loc})
+    for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend, &e->d_qtab, &e->d_loc, &e->d_aggpart})
         if (*b) { if (!e->in_arena(*b)) (void)hipFree(*b); *b = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
@@ -1121,6 +1164,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.upload(&e->d_scanm, scanm.data(), sizeof(double) * scanm.size());
         ap.upload(&e->d_qtab, qtab.data(), sizeof(double) * qtab.size());
         ap.plain(&e->d_loc, sizeof(double) * C * 2 * Sg * D);
+        ap.plain(&e->d_aggpart, sizeof(double) * C * (size_t)e->agg_kc * Sg * 2 * D);
         ap.zeroed(&e->d_status, sizeof(int));
         // smoothing runs use 2S slots (forward + backward parts) + one per workgroup of kd_fe_resid
         ap.zeroed(&e->d_fe_part, sizeof(double) * (2 * Sg + 2 + (size_t)fe_resid_blocks(e->T)) * C);
@@ -1793,6 +1837,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->S; dp.L = e->L; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy;
         dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
         dp.qtab = e->d_qtab; dp.loc = e->d_loc; dp.sg = e->scan_sg; dp.ng = e->scan_ng;
+        dp.aggpart = e->d_aggpart; dp.agg_oc = e->agg_oc; dp.agg_kc = e->agg_kc; dp.Llast = e->Llast;
         dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;
         dp.filter = p.filter;

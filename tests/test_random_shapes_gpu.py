@@ -95,3 +95,28 @@ def test_random_dense_case(case):
         assert rel(sm[:, c], om) < 1e-6 and rel(sc[:, c], oc) < 1e-6 and abs(sfe[c] - ofe) < 1e-8 * abs(ofe)
         hm, hc, hfe, _ = rxoracle.lgssm_filter(*args, case["ptt"])
         assert rel(fm[:, c], hm) < 1e-6 and rel(fc[:, c], hc) < 1e-6 and abs(ffe[c] - hfe) < 1e-8 * abs(hfe)
+
+
+@pytest.mark.parametrize("T,segments", [(600, 60), (171, 17), (400, 26), (33, 3), (17, 2)])
+def test_dense_two_level_scan(T, segments):
+    """Many segments on the MFMA path: the boundary scan runs in groups of ≈√S steps with host-composed maps
+    (kd_scan_local / kd_scan_fix) — full groups, a partial last group, a single group and S = 2 must all reproduce
+    the sequential smoother, for smoothing and for filtering runs."""
+    d, dy, C = 16, 7, 2
+    m = workloads.random_model(d, dy, seed=4242 + T)
+    y = workloads.generate_batch(m, T, C, seed0=T)
+    with rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=T, n_chains=C, segments=segments) as eng:
+        assert abs(eng.schedule()["segments"] - segments) <= 1
+        eng.set_data(y)
+        eng.run(1, True)
+        sm, sc = eng.marginals()
+        sfe = eng.free_energy_per_chain()
+        eng.run_filter(True)
+        fm, fc = eng.marginals()
+        ffe = eng.free_energy_per_chain()
+    for c in range(C):
+        args = (m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], y[:, c])
+        om, oc, ofe = rxoracle.lgssm_kalman_rts(*args, prior_through_transition=False)
+        assert rel(sm[:, c], om) < 1e-6 and rel(sc[:, c], oc) < 1e-6 and abs(sfe[c] - ofe) < 1e-8 * abs(ofe)
+        hm, hc, hfe, _ = rxoracle.lgssm_filter(*args, False)
+        assert rel(fm[:, c], hm) < 1e-6 and rel(fc[:, c], hc) < 1e-6 and abs(ffe[c] - hfe) < 1e-8 * abs(hfe)
