@@ -1078,7 +1078,7 @@ __global__ void __launch_bounds__(64 * NT) kd_backward_info(DenseParams p) {
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
     const size_t MM = (size_t)D * D;
-    
+    const int grp = tid / D, gi = tid - grp * D;
     const long long b0 = 1 + seg * p.L;
     long long b1 = b0 + p.L;
     if (b1 > p.T) b1 = p.T;
@@ -1123,30 +1123,32 @@ __global__ void __launch_bounds__(64 * NT) kd_backward_info(DenseParams p) {
     lds_barrier();
     for (long long t = te - 1; t >= tb; --t) {
         prefetch(t - 1 >= tb ? t - 1 : tb);
-        // m_s(t) = C ξ_f + G m_s(t+1)
-        if (tid < D) {
+        // m_s(t) = C ξ_f + G m_s(t+1): thread group `grp` sums a quarter of the k range (partials in rowbuf, free after the prologue)
+        {
+            const int k0 = grp * (D / 4);
             double s0 = 0.0, s1 = 0.0;
-#pragma unroll 8
-            for (int k = 0; k < D; ++k) {
-                s0 += M0[tid * LD + k] * xf[k];
-                s1 += M3[tid * LD + k] * ms[k];
+#pragma unroll
+            for (int k = 0; k < D / 4; ++k) {
+                s0 += M0[gi * LD + k0 + k] * xf[k0 + k];
+                s1 += M3[gi * LD + k0 + k] * ms[k0 + k];
             }
-            tmp[tid] = s0 + s1;
+            rowbuf[grp * D + gi] = s0 + s1;
         }
         // H = G V_s
         acc_zero<NT>(a);
         mm_acc<NT, false, false>(a, M3, LD, M2, LD, w, lane);
         acc_store<NT>(a, M1, LD, w, lane);
         lds_barrier();
+        double mnew = 0.0;
+        if (tid < D) mnew = (rowbuf[tid] + rowbuf[D + tid]) + (rowbuf[2 * D + tid] + rowbuf[3 * D + tid]);
         // V_s = C + H G'
         acc_load<NT>(a, M0, LD, w, lane);
         mm_acc<NT, false, true>(a, M1, LD, M3, LD, w, lane);
-        lds_barrier();
-        if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = tmp[tid];
+        if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = mnew;
         acc_store_out<NT>(a, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
-        acc_store<NT>(a, M2, LD, w, lane);
+        acc_store<NT>(a, M2, LD, w, lane);  // mm1 (the only reader of M2) finished before the barrier above
         lds_barrier();
-        if (tid < D) ms[tid] = tmp[tid];
+        if (tid < D) ms[tid] = mnew;
         commit();
         lds_barrier();
     }
