@@ -7,10 +7,10 @@
 //   a9  NormalMeanVariance prior / transition / observation nodes of the one-step graph (hgf_tests.jl:9-31)
 //   the streaming driver's per-observation VMP loop with @autoupdates posterior -> prior feedback
 //       (src/inference/streaming.jl:349-407, src/inference/autoupdates.jl:640-659), kept on the device
-// One series is sequential in time; series are independent.  A series is owned by a 32-lane half-wave: the
-// scalar algebra of an iteration is done redundantly by all lanes, the n_gh ≤ 32 cubature points of the
-// z-message are evaluated one per lane (2 exp each) and reduced with half-wave xor shuffles.  4096 series
-// fill 2048 wavefronts.  Compute-bound (transcendentals), ≈48 B of HBM traffic per (series, observation).
+// One series is sequential in time; series are independent.  A series is owned by a 16-lane DPP row: the
+// scalar algebra of an iteration is done redundantly by its lanes, the n_gh ≤ 32 cubature points of the
+// z-message are evaluated two per lane (2 exp each) and reduced with row-local DPP adds.  4096 series
+// fill 1024 wavefronts (one per SIMD).  Compute-bound (transcendentals), ≈48 B of HBM traffic per (series, observation).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -29,9 +29,9 @@ struct HgfParams {
     int* status;
 };
 
-// ---- 32-lane sums without the LDS crossbar: four DPP stages inside a 16-lane row, then v_permlane16_swap for the
-// neighbouring row (gfx950).  The cubature sums are the latency chain of an iteration; ds_bpermute shuffles cost
-// ≈100 cycles per stage, DPP moves a few.  Fixed order -> deterministic; every lane of the half-wave gets the sum.
+// ---- 16-lane sums without the LDS crossbar: four DPP stages inside a 16-lane row.  The cubature sums are the latency
+// chain of an iteration; ds_bpermute shuffles cost ≈100 cycles per stage, DPP moves a few.  Fixed order -> deterministic;
+// every lane of the row gets the sum.
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -39,14 +39,8 @@ __device__ __forceinline__ double dpp_mov(double v) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-__device__ __forceinline__ double row_swap16(double v, bool odd_row) {  // the value held 16 lanes away
-    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
-    const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);  // a[0]: rows (r0,r0,r2,r2), a[1]: (r1,r1,r3,r3)
-    const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-    return __hiloint2double((int)(odd_row ? b[0] : b[1]), (int)(odd_row ? a[0] : a[1]));
-}
 template <int N>
-__device__ __forceinline__ void half_sums(double (&v)[N], bool odd_row) {
+__device__ __forceinline__ void row_sums(double (&v)[N]) {
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] += dpp_mov<0xB1>(v[i]);   // quad_perm [1,0,3,2]
 #pragma unroll
@@ -55,38 +49,52 @@ __device__ __forceinline__ void half_sums(double (&v)[N], bool odd_row) {
     for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x141>(v[i]);  // row_half_mirror
 #pragma unroll
     for (int i = 0; i < N; ++i) v[i] += dpp_mov<0x140>(v[i]);  // row_mirror
-#pragma unroll
-    for (int i = 0; i < N; ++i) v[i] += row_swap16(v[i], odd_row);
 }
 
+// One series per 16-lane DPP row (four series per wavefront): the scalar algebra of an iteration is shared by 16 lanes
+// instead of 32, every lane carries two of the n_gh ≤ 32 cubature points, and the reductions stay inside a row (no
+// cross-row permute).  Measured against the 32-lane form: ≈half the VALU instructions per (series, iteration).
+constexpr int HGF_LANES = 16, HGF_SERIES_PER_WAVE = 64 / HGF_LANES;
 template <bool FE>
 __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
-    const int j = threadIdx.x & 31;
-    const bool odd_row = (threadIdx.x >> 4) & 1;
-    const long long s = (long long)blockIdx.x * 2 + (threadIdx.x >> 5);
+    const int j = threadIdx.x & (HGF_LANES - 1);
+    const long long s = (long long)blockIdx.x * HGF_SERIES_PER_WAVE + (threadIdx.x / HGF_LANES);
     const bool live = s < p.n_series;
     const long long sc_ = live ? s : 0;
-    const double gx = j < p.n_gh ? p.gh[j] : 0.0;
-    const double gw = j < p.n_gh ? p.gh[32 + j] : 0.0;
+    double gx[2], gw[2], pe[2], hpe2[2], epe[2], lpe[2];
     const double kappa = p.kappa, omega = p.omega, zvar = p.z_variance, yvar = p.y_variance;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int q = j + HGF_LANES * u;
+        gx[u] = q < p.n_gh ? p.gh[q] : 0.0;
+        gw[u] = q < p.n_gh ? p.gh[32 + q] : 0.0;
+        pe[u] = 1.4142135623730951 * gx[u];  // cubature points against N(0, 1)
+        hpe2[u] = 0.5 * pe[u] * pe[u];
+        epe[u] = exp(-kappa * pe[u]);
+        lpe[u] = -0.5 * kappa * pe[u] + hpe2[u];
+    }
     const double A = exp(-omega);
-    const double pe = 1.4142135623730951 * gx;  // cubature points against N(0, 1)
-    const double hpe2 = 0.5 * pe * pe, iyvar = 1.0 / yvar, wb = 1.0 / zvar, lzvar = log(zvar), lyvar = log(yvar);
+    const double iyvar = 1.0 / yvar, wb = 1.0 / zvar, lzvar = log(zvar), lyvar = log(yvar);
     double qzm = p.z0m, qzv = p.z0v, qxm = p.x0m, qxv = p.x0v;
     bool bad = false;
     double yn = p.y[sc_];
-    double fe_acc = 0.0;  // lane n of the half-wave accumulates the free energy of VMP iteration n (n < 32; beyond: global)
+    double fe_acc = 0.0;  // lane n of the row accumulates the free energy of VMP iteration n (n < 16; beyond: global)
     for (long long t = 0; t < p.T; ++t) {
         const double yt = yn;
         if (t + 1 < p.T) yn = p.y[(t + 1) * p.n_series + sc_];
         const double zm = qzm, zv = qzv, xm = qxm, xv = qxv;  // @autoupdates
         const double fzv = zv + zvar, sc = sqrt(2.0 * fzv);
-        const double dx = sc * gx, pt = zm + dx;  // cubature points against the forward message N(zm, fzv)
         const double ixv = rcp_pos(xv), izv = rcp_pos(zv);
         const double x1 = yt * iyvar, x2 = xm * ixv, zx = zm * izv;
         // point-wise constants of the two cubatures: exp(−½κ·point) factors out of the iteration loop
-        const double ept = exp(-kappa * pt), epe = exp(-kappa * pe);
-        const double lpt = -0.5 * kappa * pt, lpe = -0.5 * kappa * pe + hpe2;
+        double dx[2], ept[2], lpt[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            dx[u] = sc * gx[u];  // cubature points against the forward message N(zm, fzv)
+            const double pt = zm + dx[u];
+            ept[u] = exp(-kappa * pt);
+            lpt[u] = -0.5 * kappa * pt;
+        }
         double fe_t_const = 0.0;
         if (FE) fe_t_const = 0.5 * (kLog2Pi + log(zv)) + 0.5 * (kLog2Pi + log(xv)) + 0.5 * (kLog2Pi + lzvar) + 0.5 * (kLog2Pi + lyvar);
         for (int n = 0; n < p.iters; ++n) {
@@ -99,20 +107,24 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
             const double m1 = v11 * x1 + v12 * x2, m2 = v12 * x1 + v22 * x2;
             const double psi = (m1 - m2) * (m1 - m2) + v11 + v22 - 2.0 * v12;
             const double b = psi * A;
-            // one cubature point per lane: z-message pdf exp(−½(κz + b·exp(−κz))) at the forward-message points and (for
+            // two cubature points per lane: z-message pdf exp(−½(κz + b·exp(−κz))) at the forward-message points and (for
             // the free energy) times exp(z²/2) at the N(0,1) points; first moments taken about zm / 0
             // Two reduction rounds, exactly the reference's approximate_meancov: (norm, first moment), then the second
             // moment about the mean — when a message's mode leaves the cubature range the variance is pure rounding
             // residue and only the same formula reproduces the reference there.
             double r[FE ? 4 : 2];
-            const double cv = gw * exp(lpt - 0.5 * b * ept);
-            r[0] = cv; r[1] = cv * dx;
-            double ecv = 0.0;
+            double cv[2], ecv[2] = {0.0, 0.0};
+#pragma unroll
+            for (int u = 0; u < 2; ++u) cv[u] = gw[u] * exp(lpt[u] - 0.5 * b * ept[u]);
+            r[0] = cv[0] + cv[1];
+            r[1] = cv[0] * dx[0] + cv[1] * dx[1];
             if (FE) {
-                ecv = gw * exp(lpe - 0.5 * b * epe);
-                r[2] = ecv; r[3] = ecv * pe;
+#pragma unroll
+                for (int u = 0; u < 2; ++u) ecv[u] = gw[u] * exp(lpe[u] - 0.5 * b * epe[u]);
+                r[2] = ecv[0] + ecv[1];
+                r[3] = ecv[0] * pe[0] + ecv[1] * pe[1];
             }
-            half_sums(r, odd_row);
+            row_sums(r);
             const double in0 = rcp_pos(r[0]);
             const double dmean = r[1] * in0;
             const double mean = zm + dmean;
@@ -123,9 +135,9 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
                 em = r[3] * ie0;
             }
             double q[FE ? 2 : 1];
-            q[0] = cv * (dx - dmean) * (dx - dmean);
-            if (FE) q[1] = ecv * (pe - em) * (pe - em);
-            half_sums(q, odd_row);
+            q[0] = cv[0] * (dx[0] - dmean) * (dx[0] - dmean) + cv[1] * (dx[1] - dmean) * (dx[1] - dmean);
+            if (FE) q[1] = ecv[0] * (pe[0] - em) * (pe[0] - em) + ecv[1] * (pe[1] - em) * (pe[1] - em);
+            row_sums(q);
             const double var = q[0] * in0;
             bad = bad || !(det > 0.0) || !(var > 0.0) || !is_finite(mean);
             qzm = mean; qzv = var; qxm = m1; qxv = v11;
@@ -151,7 +163,7 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
                 // −H[zt, zt_min] − H[xt, xt_min] = −2(log 2π + 1) + ½ log(dW / det Σ_x),  det Σ_x = 1 / det
                 F += -2.0 * (kLog2Pi + 1.0) + 0.5 * log(dW * det);
                 F += 0.5 * ((yt - m1) * (yt - m1) + v11) * iyvar;                // observation
-                if (n < 32) fe_acc += (j == n) ? F : 0.0;
+                if (n < HGF_LANES) fe_acc += (j == n) ? F : 0.0;
                 else if (live && j == 0) p.fe_series[(long long)n * p.n_series + s] += F;
             }
         }

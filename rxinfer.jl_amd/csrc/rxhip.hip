@@ -1568,7 +1568,7 @@ static rxhip_status hgf_run_async(rxhip_engine* e, int32_t iterations, int32_t w
     p.iters = iterations; p.n_gh = d.n_gh; p.status = e->d_status;
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_HGF_FILTER))) return st;
-    const unsigned nb = (unsigned)((C + 1) / 2);
+    const unsigned nb = (unsigned)((C + HGF_SERIES_PER_WAVE - 1) / HGF_SERIES_PER_WAVE);
     if (want_fe) hipLaunchKernelGGL((k_hgf_filter<true>), dim3(nb), dim3(64), 0, e->stream, p);
     else hipLaunchKernelGGL((k_hgf_filter<false>), dim3(nb), dim3(64), 0, e->stream, p);
     if ((st = prof_end(e))) return st;
