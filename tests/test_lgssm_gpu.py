@@ -98,6 +98,15 @@ def test_c3_model_short():
     assert sched["segments"] > 1
 
 
+def test_c3_full_size():
+    """BASELINE config 3 at its full size (d = dy = 64, T = 10⁴, one chain): 250 segments, two-level boundary scan,
+    aggregation as a matrix product — against the oracle's reference schedule over the whole chain (≈30 s of CPU)."""
+    mdl = workloads.c3_model()
+    y = workloads.generate_batch(mdl, 10000, 1, seed0=6401)
+    mean, cov, fe, sched = check_against_oracle(mdl, y)
+    assert sched["segments"] >= 200
+
+
 def test_prior_through_transition_variant():
     """test/models/statespace/mlgssm_test.jl:9-17 spelling: x0 ~ prior; x[1] ~ MvNormal(A*x0, .)"""
     mdl = workloads.random_model(2, 2, seed=5)
