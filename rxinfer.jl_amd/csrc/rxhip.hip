@@ -380,48 +380,73 @@ static bool chol_inv(int n, const double* A, double* out, double* logdet) {
         for (int i = 0; i < n; ++i) ld += std::log(L[i * n + i]);
         *logdet = 2.0 * ld;
     }
-    for (int j = 0; j < n; ++j) {
-        Li[j * n + j] = 1.0 / L[j * n + j];
-        for (int i = j + 1; i < n; ++i) {
-            double s = 0.0;
-            for (int k = j; k < i; ++k) s -= L[i * n + k] * Li[k * n + j];
-            Li[i * n + j] = s / L[i * n + i];
+    // Li = L⁻¹ row by row (row i of Li is e_i minus a combination of the rows above it), then A⁻¹ = Li'Li as a sum of
+    // outer products of the rows of Li: every inner loop runs over contiguous memory (the tables of a d = 64, S = 250
+    // engine need ≈750 of these inverses)
+    for (int i = 0; i < n; ++i) {
+        double* ri = &Li[(size_t)i * n];
+        ri[i] = 1.0;
+        for (int k = 0; k < i; ++k) {
+            const double l = L[i * n + k];
+            const double* rk = &Li[(size_t)k * n];
+            for (int j = 0; j <= k; ++j) ri[j] -= l * rk[j];
+        }
+        const double inv = 1.0 / L[i * n + i];
+        for (int j = 0; j <= i; ++j) ri[j] *= inv;
+    }
+    std::fill(out, out + (size_t)n * n, 0.0);
+    for (int k = 0; k < n; ++k) {
+        const double* rk = &Li[(size_t)k * n];
+        for (int i = 0; i <= k; ++i) {
+            const double a = rk[i];
+            double* oi = out + (size_t)i * n;
+            for (int j = 0; j <= i; ++j) oi[j] += a * rk[j];
         }
     }
     for (int i = 0; i < n; ++i)
-        for (int j = 0; j <= i; ++j) {
-            double s = 0.0;
-            for (int k = i; k < n; ++k) s += Li[k * n + i] * Li[k * n + j];
-            out[i * n + j] = out[j * n + i] = s;
-        }
+        for (int j = 0; j < i; ++j) out[(size_t)j * n + i] = out[(size_t)i * n + j];
     return true;
 }
-// C[n×k] = A[n×m] B[m×k]
+// C[n×k] = A[n×m] B[m×k]   (row of C accumulated from rows of B: contiguous inner loops)
 static void mm(int n, int m, int k, const double* A, const double* B, double* C) {
-    for (int i = 0; i < n; ++i)
-        for (int j = 0; j < k; ++j) {
-            double s = 0.0;
-            for (int q = 0; q < m; ++q) s += A[i * m + q] * B[q * k + j];
-            C[i * k + j] = s;
+    for (int i = 0; i < n; ++i) {
+        double* ci = C + (size_t)i * k;
+        for (int j = 0; j < k; ++j) ci[j] = 0.0;
+        for (int q = 0; q < m; ++q) {
+            const double a = A[(size_t)i * m + q];
+            const double* bq = B + (size_t)q * k;
+            for (int j = 0; j < k; ++j) ci[j] += a * bq[j];
         }
+    }
 }
-// C[n×k] = A[n×m] B'[k×m]
+// C[n×k] = A[n×m] B'[k×m]   (dot products of rows, four partial sums)
 static void mmT(int n, int m, int k, const double* A, const double* B, double* C) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < k; ++j) {
-            double s = 0.0;
-            for (int q = 0; q < m; ++q) s += A[i * m + q] * B[j * m + q];
-            C[i * k + j] = s;
+            const double *a = A + (size_t)i * m, *b = B + (size_t)j * m;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+            int q = 0;
+            for (; q + 3 < m; q += 4) {
+                s0 += a[q] * b[q];
+                s1 += a[q + 1] * b[q + 1];
+                s2 += a[q + 2] * b[q + 2];
+                s3 += a[q + 3] * b[q + 3];
+            }
+            for (; q < m; ++q) s0 += a[q] * b[q];
+            C[(size_t)i * k + j] = (s0 + s1) + (s2 + s3);
         }
 }
 // C[m×k] = A'[n×m] B[n×k]
 static void mTm(int n, int m, int k, const double* A, const double* B, double* C) {
-    for (int i = 0; i < m; ++i)
-        for (int j = 0; j < k; ++j) {
-            double s = 0.0;
-            for (int q = 0; q < n; ++q) s += A[q * m + i] * B[q * k + j];
-            C[i * k + j] = s;
+    std::fill(C, C + (size_t)m * k, 0.0);
+    for (int q = 0; q < n; ++q) {
+        const double* bq = B + (size_t)q * k;
+        for (int i = 0; i < m; ++i) {
+            const double a = A[(size_t)q * m + i];
+            double* ci = C + (size_t)i * k;
+            for (int j = 0; j < k; ++j) ci[j] += a * bq[j];
         }
+    }
 }
 static void pack_sym(int n, const double* A, double* out) {
     for (int i = 0; i < n; ++i)
@@ -865,9 +890,26 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
     const int S_ = e->S;
     scanm.assign((size_t)(S_ > 0 ? S_ : 1) * 6 * MM, 0.0);
     if (S_ > 0) {
-        std::vector<double> Vc = Vf1, Vi(MM), W(MM), M1(MM), M2(MM), tt(MM);
+        // Both recursions below are Riccati iterations with constant coefficients: after a transient of a few segments the
+        // boundary covariance (precision) stops changing, and with it the maps.  Once two consecutive boundaries agree to
+        // 1e-14 (relative, max norm) the remaining segments reuse the converged maps — the tables of a d = 64, S = 250
+        // engine otherwise cost ≈1.5 GFLOP of host arithmetic per create.
+        auto same = [&](const std::vector<double>& a, const std::vector<double>& b) {
+            double dmax = 0.0, amax = 0.0;
+            for (size_t q = 0; q < MM; ++q) {
+                dmax = std::max(dmax, std::fabs(a[q] - b[q]));
+                amax = std::max(amax, std::fabs(a[q]));
+            }
+            return dmax <= 1e-14 * amax;
+        };
+        std::vector<double> Vc = Vf1, Vi(MM), W(MM), M1(MM), M2(MM), tt(MM), Vprev(MM);
+        bool conv = false;
         for (int s = 0; s < S_; ++s) {
             double* sm = scanm.data() + (size_t)s * 6 * MM;
+            if (conv) {  // maps 0, 1 and V(b_s) of the previous segment
+                std::copy(sm - 6 * MM, sm - 3 * MM, sm);
+                continue;
+            }
             for (size_t q = 0; q < MM; ++q) sm[2 * MM + q] = Vc[q];
             if (s == S_ - 1) break;
             const Agg& g = ag[0];
@@ -879,17 +921,24 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
             host::mmT(d, d, d, M2.data(), g.Pi.data(), tt.data());
             for (int a = 0; a < d; ++a)
                 for (int b = 0; b < d; ++b) { sm[(size_t)b * d + a] = M1[a * d + b]; sm[MM + (size_t)b * d + a] = M2[a * d + b]; }
+            Vprev = Vc;
             for (int a = 0; a < d; ++a)
                 for (int b = 0; b <= a; ++b) {
                     double v = 0.5 * (tt[a * d + b] + tt[b * d + a]) + g.C[a * d + b];
                     Vc[a * d + b] = Vc[b * d + a] = v;
                 }
+            conv = same(Vc, Vprev);
         }
-        std::vector<double> Lm(MM, 0.0), N1(MM), N2(MM);
+        std::vector<double> Lm(MM, 0.0), N1(MM), N2(MM), Lprev(MM);
         // scanm[s][5] = Λβ(b_{s+1}); Λβ(b_S) = 0
+        conv = false;
         for (int s = S_ - 1; s >= 1; --s) {
             const Agg& g = ag[s == S_ - 1 ? 1 : 0];
             double* sm = scanm.data() + (size_t)s * 6 * MM;
+            if (conv) {  // maps 3, 4 and Λβ of the following segment (both full-length segments)
+                std::copy(sm + 9 * MM, sm + 12 * MM, sm + 3 * MM);
+                continue;
+            }
             for (size_t q = 0; q < MM; ++q) { sm[5 * MM + q] = Lm[q]; tt[q] = g.Ci[q] + Lm[q]; }
             if (!host::chol_inv(d, tt.data(), W.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "backward boundary precision not positive definite");
             host::mTm(d, d, d, g.X.data(), W.data(), N1.data());   // X' W
@@ -897,11 +946,13 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
             host::mm(d, d, d, N1.data(), g.X.data(), tt.data());   // X' W X
             for (int a = 0; a < d; ++a)
                 for (int b = 0; b < d; ++b) { sm[3 * MM + (size_t)b * d + a] = N1[a * d + b]; sm[4 * MM + (size_t)b * d + a] = N2[a * d + b]; }
+            Lprev = Lm;
             for (int a = 0; a < d; ++a)
                 for (int b = 0; b <= a; ++b) {
                     double v = g.JJ[a * d + b] - 0.5 * (tt[a * d + b] + tt[b * d + a]);
                     Lm[a * d + b] = Lm[b * d + a] = v;
                 }
+            conv = s < S_ - 1 && same(Lm, Lprev);  // the last segment has its own length: compare full-length steps only
         }
         for (size_t q = 0; q < MM; ++q) scanm[5 * MM + q] = Lm[q];  // segment 0: Λβ(b_1)
     }
@@ -914,19 +965,40 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
         e->scan_ng = n > 0 ? (n + sg - 1) / sg : 1;
         qtab.assign((size_t)2 * (S_ > 0 ? S_ : 1) * MM, 0.0);
         std::vector<double> Mp(MM), Qc(MM), Qn(MM);
-        for (int dir = 0; dir < 2 && n > 0; ++dir)
+        for (int dir = 0; dir < 2 && n > 0; ++dir) {
+            bool grp_same = false, qc_stale = false;
             for (int st = 0; st < n; ++st) {
                 const int seg = dir ? S_ - 1 - st : st;
                 const double* mt = scanm.data() + ((size_t)seg * 6 + (dir ? 3 : 0)) * MM;  // stored transposed
+                // converged region of the Riccati recursions: a group whose step maps equal (bit for bit — they are copies)
+                // those of the previous group has the same products
+                if (st % sg == 0) grp_same = st >= sg;
+                if (grp_same) {
+                    const int pseg = dir ? S_ - 1 - (st - sg) : st - sg;
+                    const double* pt = scanm.data() + ((size_t)pseg * 6 + (dir ? 3 : 0)) * MM;
+                    grp_same = std::memcmp(pt, mt, sizeof(double) * MM) == 0;
+                }
+                double* qt = qtab.data() + ((size_t)dir * S_ + (st + 1)) * MM;
+                if (grp_same) {
+                    std::copy(qt - (size_t)sg * MM, qt - (size_t)sg * MM + MM, qt);
+                    qc_stale = true;
+                    continue;
+                }
                 for (int a = 0; a < d; ++a)
                     for (int b = 0; b < d; ++b) Mp[(size_t)a * d + b] = mt[(size_t)b * d + a];
                 if (st % sg == 0) Qn = Mp;
-                else host::mm(d, d, d, Mp.data(), Qc.data(), Qn.data());
+                else {
+                    if (qc_stale)  // the product through the previous step was copied, not computed: read it back
+                        for (int a = 0; a < d; ++a)
+                            for (int b = 0; b < d; ++b) Qc[(size_t)a * d + b] = (qt - MM)[(size_t)b * d + a];
+                    host::mm(d, d, d, Mp.data(), Qc.data(), Qn.data());
+                }
+                qc_stale = false;
                 Qc = Qn;
-                double* qt = qtab.data() + ((size_t)dir * S_ + (st + 1)) * MM;
                 for (int a = 0; a < d; ++a)
                     for (int b = 0; b < d; ++b) qt[(size_t)b * d + a] = Qc[(size_t)a * d + b];
             }
+        }
     }
     return RXHIP_OK;
 }
