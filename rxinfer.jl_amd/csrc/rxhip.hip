@@ -646,20 +646,16 @@ static int dense_pad(int d) { return (d + 15) / 16 * 16; }
 template <int NT>
 struct DenseLaunch {
     static size_t lds_bytes(int d, int dy) { return DenseLds<NT>::bytes(((d > dy ? d : dy) + 1) & ~1); }
-    static hipError_t prepare(int d, int dy) {
-        const int bytes = (int)lds_bytes(d, dy);
+    // The dynamic-LDS ceiling is a per-FUNCTION attribute shared by every engine of the process: it is raised to the
+    // hardware limit once, never to one engine's need (a later, smaller engine would otherwise lower it under a live one).
+    static hipError_t prepare() {
+        const int bytes = 160 * 1024;
         hipError_t e;
-        if ((e = hipFuncSetAttribute((const void*)kd_agg_finish<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DenseLds<NT>::agg_bytes(dy)))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_scan_local<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_scan_local<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_scan_fix<NT>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_forward<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_forward<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_forward_info<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_forward_info<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_backward_info<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_backward_info<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        if ((e = hipFuncSetAttribute((const void*)kd_fe_resid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fe_resid_lds_bytes(d, dy)))) return e;
+        for (const void* f : {(const void*)kd_agg_finish<NT>, (const void*)kd_scan_local<NT, true>, (const void*)kd_scan_local<NT, false>,
+                              (const void*)kd_scan_fix<NT>, (const void*)kd_forward<NT, true>, (const void*)kd_forward<NT, false>,
+                              (const void*)kd_forward_info<NT, true>, (const void*)kd_forward_info<NT, false>,
+                              (const void*)kd_backward_info<NT, true>, (const void*)kd_backward_info<NT, false>, (const void*)kd_fe_resid})
+            if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         return hipSuccess;
     }
     static void seg_aggregate(const DenseParams& p, hipStream_t s) {
@@ -1226,7 +1222,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         rxhip_status st = build_dense_tables(e, ds, cst, tab, scanm, qtab);
         if (st) return st;
         hipError_t herr = hipSuccess;
-        DENSE_DISPATCH(e->nt, prepare(e->dpad, e->dy) == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
+        DENSE_DISPATCH(e->nt, prepare() == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
         if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1), D = (size_t)e->dpad,
                      Du = (size_t)e->d;

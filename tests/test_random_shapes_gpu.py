@@ -120,3 +120,26 @@ def test_dense_two_level_scan(T, segments):
         assert rel(sm[:, c], om) < 1e-6 and rel(sc[:, c], oc) < 1e-6 and abs(sfe[c] - ofe) < 1e-8 * abs(ofe)
         hm, hc, hfe, _ = rxoracle.lgssm_filter(*args, False)
         assert rel(fm[:, c], hm) < 1e-6 and rel(fc[:, c], hc) < 1e-6 and abs(ffe[c] - hfe) < 1e-8 * abs(hfe)
+
+
+def test_dense_engines_of_different_sizes_coexist():
+    """The dynamic-LDS ceiling of a kernel is process-wide state: creating a small engine must not lower it under a
+    live larger one (d = 64 / dy = 64 needs 156 KB in kd_fe_resid, d = 16 / dy = 2 a few KB)."""
+    big = workloads.random_model(64, 64, seed=5)
+    small = workloads.random_model(16, 2, seed=6)
+    T = 40
+    yb = workloads.generate_batch(big, T, 1, seed0=1)
+    ys = workloads.generate_batch(small, T, 1, seed0=2)
+    with rxhip.LGSSMEngine(big["A"], big["B"], big["P"], big["Q"], big["m0"], big["V0"], T=T, n_chains=1, segments=4) as eb:
+        with rxhip.LGSSMEngine(small["A"], small["B"], small["P"], small["Q"], small["m0"], small["V0"], T=T, n_chains=1, segments=4) as es:
+            es.set_data(ys)
+            es.run(1, True)
+            eb.set_data(yb)
+            eb.run(1, True)
+            mb, cb = eb.marginals()
+            fb = eb.free_energy_per_chain()
+            ms, cs = es.marginals()
+            fs = es.free_energy_per_chain()
+    for m, y, mm, cc, ff in ((big, yb, mb, cb, fb), (small, ys, ms, cs, fs)):
+        om, oc, ofe = rxoracle.lgssm_kalman_rts(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], y[:, 0], prior_through_transition=False)
+        assert rel(mm[:, 0], om) < 1e-6 and rel(cc[:, 0], oc) < 1e-6 and abs(ff[0] - ofe) < 1e-8 * abs(ofe)
