@@ -1191,6 +1191,11 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     // time segmentation: two (chain, segment) lanes per SIMD lane slot — 256 CUs × 4 SIMDs × 2 waves × 64 lanes.
     // Once the forward message is stored compactly the backward kernel is issue-bound at one wave per SIMD
     // (measured at C2: 4.7 ms with 64 segments, 3.9–4.0 ms with 128…512); the boundary scan is cheap.
+    // Dense (MFMA) path: one workgroup of NT wavefronts per (chain, segment).  At d = 49…64 a workgroup fills a CU (one
+    // wavefront per SIMD, 256 + registers); the smaller tiles leave room for more, and the kernels are latency-bound, so
+    // more resident workgroups pay until the per-segment prologue dominates (measured, scripts/time_mid_dims.py:
+    // d = 16, 512 chains, T = 1000: 4.27 ms with 2 workgroups per CU, 2.22 ms with 48; d = 32, 128 chains: 4.86 -> 3.02 ms).
+    const int dense_wg_per_cu = !dense ? 0 : e->nt == 1 ? 48 : e->nt == 2 ? 8 : e->nt == 3 ? 2 : 1;
     const long long steps = e->T - 1;  // transitions
     if (steps <= 0) {
         e->S = 0;
@@ -1198,7 +1203,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->Llast = 1;
     } else {
         long long S_target = ds->segments > 0 ? ds->segments
-                             : dense ? (256 + e->n_chains - 1) / e->n_chains   // one workgroup per CU
+                             : dense ? (256 * dense_wg_per_cu + e->n_chains - 1) / e->n_chains
                                      : (131072 + e->n_chains - 1) / e->n_chains;
         if (ds->segments <= 0 && !dense) {
             // few chains: the lanes do not fill the machine and the sweep is a latency chain of L steps through three
