@@ -524,8 +524,8 @@ struct DenseLds {
 //   kd_agg_gemm   grid (segment blocks of 16, K-chunks, chains): partial sums, v_mfma_f64_16x16x4_f64, operands straight from
 //                 L2 (the table is shared by all segments; y is read once)
 //   kd_agg_finish grid (S, chains): fixed-order sum of the partials, the data-dependent halves of the boundary scan
-//                 (w_s = b_s + M2_s η_s, w_s' = η_s − N2_s b_s) and, for smoothing runs, B'Q⁻¹y_t of every step of the segment
-//                 (handed to kd_forward_info in the record).
+//                 (w_s = b_s + M2_s η_s, w_s' = η_s − N2_s b_s) and B'Q⁻¹y_t of every step of the segment
+//                 (handed to the forward kernels in the record).
 // The full segments 0 … S−2 share table set 0; the last segment (length Llast ≤ L) has its own set and its own block.
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) kd_agg_gemm(DenseParams p) {
@@ -607,8 +607,7 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_finish(DenseParams p) {
         if (tid < D) m[tid] = s;
         else eta[tid - D] = s;
     }
-    if (!p.filter)
-        for (int q = tid; q < D * dy; q += 64 * NT) GTs[q] = cst[c.oGT + q];
+    for (int q = tid; q < D * dy; q += 64 * NT) GTs[q] = cst[c.oGT + q];
     lds_barrier();
     // The boundary scan carries v <- w_s + M1_s v (prefix) and ξ <- w_s' + N1_s ξ (suffix); the parts that do not depend on
     // the carried vector are formed here, in parallel over segments:  w_s = b_s + M2_s η_s,  w_s' = η_s − N2_s b_s.
@@ -638,7 +637,6 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_finish(DenseParams p) {
             o[D + tid] = eta[tid] - (red[2 * dm + tid] + red[3 * dm + tid]);  // w_s'
         }
     }
-    if (p.filter) return;
     // B'Q⁻¹ y_t for every step of the segment, TS steps per pass: thread (i, part) forms row i for steps part, part + 4, …
     for (long long s0 = 0; s0 < len; s0 += TS) {
         lds_barrier();
@@ -828,9 +826,19 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_fix(DenseParams p) {
         v0, red, tid);
 }
 
+// sum over the first n ≤ 64 lanes of wave 0 (valid in lane 0)
+__device__ __forceinline__ double wave0_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    return v;
+}
+
 // phase 3 (dense, FILTERING runs): covariance-form forward sweep of one segment — the filtered belief (m_f, V_f) of every
-// time index is the marginal of the streaming one-step graph and is written out.  Smoothing runs use the information-form
-// kernels at the end of this file.
+// time index is the marginal of the streaming one-step graph and is written out (two inverses per step: V_p⁻¹ and Λ_f⁻¹).
+// Smoothing runs use the information-form kernels at the end of this file.  As there, everything that does not depend on the
+// carried belief stays out of the chain: A is the A operand of both contractions (V_p = A (A V)' + P) and lives in registers,
+// B'Q⁻¹y_t comes from the aggregation kernel, the matvecs are spread over the four thread groups and combined after barriers
+// the step has anyway, the three dot products of the evidence term are wave-0 shuffles.
 template <int NT, bool FE>
 __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     constexpr int D = 16 * NT;
@@ -845,17 +853,15 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     double* vec = M2 + C::MAT;
     double* m = vec;
     double* mp = m + dm;
-    double* xp = mp + dm;
-    double* xf = xp + dm;
+    double* xf = mp + dm;
     double* yv = xf + dm;
     double* qy = yv + dm;
-    double* gy = qy + dm;      // B'Q⁻¹ y_t
-    double* rowbuf = gy + dm;  // 8·D doubles (two buffers of four pivot rows)
-    double* red = rowbuf + 8 * D;
+    double* rowbuf = qy + dm;   // 8·D doubles (two buffers of four pivot rows)
+    double* red = rowbuf + 8 * D;  // [4][dm] partial sums
+    double* red2 = red + 4 * dm;   // [4][dm]
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
-    const double* A = cst + c.oA;
     const int grp = tid / D, gi = tid - grp * D;  // four thread groups of D
     const size_t MM = (size_t)D * D;
     const long long b0 = 1 + seg * p.L;
@@ -865,55 +871,133 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     bool ok = true;
     double acc_quad = 0.0;
     LogProd lp;
+    double af[D / 4];  // A-operand fragments of the transition matrix
+    {
+        const double* A = cst + c.oA;
+        const int i = 16 * w + (lane & 15), kq = lane >> 4;
+#pragma unroll
+        for (int kk = 0; kk < D / 4; ++kk) af[kk] = A[i * D + 4 * kk + kq];
+    }
+    // cacc += A Y (TY = false) or A Y' (TY = true), Y in LDS
+    auto mm_a = [&](Acc<NT>& cacc, const double* Y, auto ty) {
+        constexpr bool TY = decltype(ty)::value;
+        const int jl = lane & 15, kq = lane >> 4;
+        d4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = (d4){cacc.v[t][0], cacc.v[t][1], cacc.v[t][2], cacc.v[t][3]};
+#pragma unroll
+        for (int kk = 0; kk < D / 4; ++kk) {
+            const int k = 4 * kk + kq;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int j = 16 * t + jl;
+                acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[kk], TY ? Y[j * LD + k] : Y[k * LD + j], acc[t], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            cacc.v[t][0] = acc[t][0];
+            cacc.v[t][1] = acc[t][1];
+            cacc.v[t][2] = acc[t][2];
+            cacc.v[t][3] = acc[t][3];
+        }
+    };
+    // out-partial of a matvec with a row-major LDS matrix: group grp sums a quarter of the k range for row gi
+    auto part_lds = [&](double* dst, const double* M, const double* x) {
+        const int k0 = grp * (D / 4);
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int k = 0; k < D / 4; k += 2) {
+            s0 += M[gi * LD + k0 + k] * x[k0 + k];
+            s1 += M[gi * LD + k0 + k + 1] * x[k0 + k + 1];
+        }
+        dst[grp * dm + gi] = s0 + s1;
+    };
     if (tid < D) m[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
-    Acc<NT> a;
+    Acc<NT> a, lam;
     acc_load<NT>(a, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
     acc_store<NT>(a, M0, LD, w, lane);
+    // y_t and B'Q⁻¹y_t (record of t, second header slot: kd_agg_finish), fetched one step ahead
+    double yn = (tid < dy && len > 0) ? p.y[(t0 * p.n_chains + chain) * dy + tid] : 0.0;
+    double gyn = (tid < D && len > 0) ? p.filt[(chain * p.T + t0) * C::REC + D + tid] : 0.0;
+    if (tid < dy) yv[tid] = yn;
     lds_barrier();
     for (long long i = 0; i < len; ++i) {
-        const long long t = t0 + i;
-        if (tid < dy) yv[tid] = p.y[(t * p.n_chains + chain) * dy + tid];
-        lds_barrier();
-        // the three matvecs with constant maps from L2 run side by side in different thread groups:
-        //   mp = A m (`*`_A(:out) mean),   Q⁻¹ y and B'Q⁻¹ y (the `*`_B(:in) message of the observation)
-        if (grp == 0) matvec_gT_group(mp, cst + c.oAT, D, D, m, gi, D);
-        else if (grp == 1) matvec_gT_group(qy, cst + c.oQI, dy, dy, yv, gi, D);  // Q⁻¹ symmetric
-        else if (grp == 2) matvec_gT_group(gy, cst + c.oGT, D, dy, yv, gi, D);
-        // `*`_A(:out): T = A V ; Vp = T A' + P
+        const long long t = t0 + i, tn = i + 1 < len ? t + 1 : t;
+        const double gyc = gyn;
+        if (tid < dy) yn = p.y[(tn * p.n_chains + chain) * dy + tid];
+        if (tid < D) gyn = p.filt[(chain * p.T + tn) * C::REC + D + tid];
+        // partial sums of  mp = A m  (`*`_A(:out) mean) and, for the evidence term, Q⁻¹y  — constant maps from L2, coalesced
+        {
+            const double* AT = cst + c.oAT;
+            const int k0 = grp * (D / 4);
+            double v[D / 4];
+#pragma unroll
+            for (int u = 0; u < D / 4; ++u) v[u] = AT[(size_t)(k0 + u) * D + gi];
+            double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+            for (int u = 0; u < D / 4; u += 2) {
+                s0 += v[u] * m[k0 + u];
+                s1 += v[u + 1] * m[k0 + u + 1];
+            }
+            red[grp * dm + gi] = s0 + s1;
+            if (FE) {
+                const double* QI = cst + c.oQI;
+                const int kq4 = (dy + 3) / 4, q0 = grp * kq4, q1 = (q0 + kq4 < dy) ? q0 + kq4 : dy;
+                for (int r = gi; r < dy; r += D) {
+                    double sq = 0.0;
+#pragma unroll 4
+                    for (int k = q0; k < q1; ++k) sq += QI[(size_t)k * dy + r] * yv[k];  // Q⁻¹ symmetric
+                    red2[grp * dm + r] = sq;
+                }
+            }
+        }
+        // `*`_A(:out): T = A V ; Vp = A T' + P
+        acc_load<NT>(lam, cst + c.oP, D, w, lane);
         acc_zero<NT>(a);
-        mm_acc<NT, false, false>(a, A, D, M0, LD, w, lane);
+        mm_a(a, M0, std::false_type{});
         acc_store<NT>(a, M1, LD, w, lane);
         lds_barrier();
-        Acc<NT> lam;
-        acc_load<NT>(lam, cst + c.oP, D, w, lane);
-        mm_acc<NT, false, true>(lam, M1, LD, A, D, w, lane);
+        if (tid < D) mp[tid] = (red[tid] + red[dm + tid]) + (red[2 * dm + tid] + red[3 * dm + tid]);
+        if (FE && tid < dy) qy[tid] = (red2[tid] + red2[dm + tid]) + (red2[2 * dm + tid] + red2[3 * dm + tid]);
+        mm_a(lam, M1, std::true_type{});
         // weightedmean_precision of the forward message: Λp = Vp⁻¹
         ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
         acc_store<NT>(lam, M2, LD, w, lane);
         lds_barrier();
-        // product with the `*`_B(:in) message: Λf = Λp + B'Q⁻¹B, ξf = Λp mp + G y
-        if (tid < D) {
-            double sx = 0.0;
-#pragma unroll 8
-            for (int k = 0; k < D; ++k) sx += M2[tid * LD + k] * mp[k];
-            xp[tid] = sx;            // Λp mp
-            xf[tid] = sx + gy[tid];  // ξf = Λp mp + B'Q⁻¹ y
-        }
+        // product with the `*`_B(:in) message: Λf = Λp + B'Q⁻¹B, ξf = Λp mp + G y   (partials; combined after the inverse)
+        part_lds(red, M2, mp);
         acc_add_mat<NT>(lam, cst + c.oLOBS, D, w, lane, 1.0);
         // mean_cov of the product: Vf = Λf⁻¹, mf = Vf ξf
         ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
+        double sx = 0.0, xfr = 0.0;
+        if (tid < D) {
+            sx = (red[tid] + red[dm + tid]) + (red[2 * dm + tid] + red[3 * dm + tid]);  // Λp mp
+            xfr = sx + gyc;                                                               // ξf = Λp mp + B'Q⁻¹ y
+            xf[tid] = xfr;
+        }
         acc_store<NT>(lam, M0, LD, w, lane);
         lds_barrier();
-        matvec_lds(m, M0, LD, D, D, xf, nullptr, 0.0, tid);
-        lds_barrier();
+        part_lds(red, M0, xf);
         // q(x_t | y_1..t) is the marginal of the one-step graph
-        if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = m[tid];
         acc_store_out<NT>(lam, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
-        if (FE) {
-            double dots[3];
-            block_dot3(qy, yv, dy, xf, m, D, xp, mp, D, red, tid, 64 * NT, dots);
-            acc_quad += cst[c.oC0] + dots[0] - dots[1] + dots[2];
+        lds_barrier();
+        double mnew = 0.0;
+        if (tid < D) {
+            mnew = (red[tid] + red[dm + tid]) + (red[2 * dm + tid] + red[3 * dm + tid]);
+            if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = mnew;
         }
+        if (FE && w == 0) {  // −2 log p(y_t | y_<t) − log-dets = y'Q⁻¹y − ξf'mf + (Λp mp)'mp + const   (D, dy ≤ 64: one lane per element)
+            double d0 = lane < dy ? qy[lane] * yv[lane] : 0.0;
+            double d1 = lane < D ? xfr * mnew : 0.0;
+            double d2 = lane < D ? sx * mp[lane] : 0.0;
+            d0 = wave0_sum(d0); d1 = wave0_sum(d1); d2 = wave0_sum(d2);
+            if (lane == 0) acc_quad += cst[c.oC0] + d0 - d1 + d2;
+        }
+        lds_barrier();  // every reader of m, yv, mp of this step is done
+        if (tid < D) m[tid] = mnew;
+        if (tid < dy) yv[tid] = yn;
+        lds_barrier();
     }
     if (FE && tid == 0) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc_quad + lp.value());
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
@@ -1048,13 +1132,6 @@ __global__ void __launch_bounds__(64 * NT) kd_forward_info(DenseParams p) {
     if (seg == p.S - 1 && tid < D) p.filt[(chain * p.T + (t0 + len - 1)) * C::REC + tid] = xi[tid];  // ξ_f(T): no successor writes it
     if (FE && tid == 0) p.fe_part[(1 + seg) * p.n_chains + chain] = -0.5 * lp.value();
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
-}
-
-// sum over the first n ≤ 64 lanes of wave 0 (valid in lane 0)
-__device__ __forceinline__ double wave0_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
-    return v;
 }
 
 template <int NT, bool FE>
