@@ -1,6 +1,8 @@
 """Randomised parity sweep: shapes, segmentations, prior conventions, shared / per-chain models, smoothing and filtering,
 drawn from a fixed seed — every case against the oracle at the BASELINE tolerances.  Complements the hand-picked edge
 cases of test_lgssm_gpu.py / test_lgssm_filter_gpu.py (the reference's own tests use one shape per model)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -73,7 +75,20 @@ def _dense_cases(n, seed):
                    segments=int(rng.choice([0, 1, 4, 100])), ptt=bool(rng.integers(2)), seed=int(rng.integers(1 << 30)))
 
 
-@pytest.mark.parametrize("case", list(_dense_cases(20, 77)), ids=lambda c: f"{c['i']}-d{c['d']}x{c['dy']}-T{c['T']}-C{c['C']}-s{c['segments']}-{'ptt' if c['ptt'] else 'x1'}")
+# RXHIP_STRESS=n widens the sweep (n extra cases from another seed, longer chains / more segments): run by hand on a GPU box
+_STRESS = int(os.environ.get("RXHIP_STRESS", "0"))
+
+
+def _dense_stress(n, seed):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        d = int(rng.integers(5, 65))
+        dy = int(rng.integers(1, 65))
+        yield dict(i=1000 + i, d=d, dy=dy, T=int(rng.choice([5, 40, 97, 160, 333])), C=int(rng.choice([1, 2, 5])),
+                   segments=int(rng.choice([0, 2, 3, 7, 16, 37])), ptt=bool(rng.integers(2)), seed=int(rng.integers(1 << 30)))
+
+
+@pytest.mark.parametrize("case", list(_dense_cases(20, 77)) + list(_dense_stress(_STRESS, 4321)), ids=lambda c: f"{c['i']}-d{c['d']}x{c['dy']}-T{c['T']}-C{c['C']}-s{c['segments']}-{'ptt' if c['ptt'] else 'x1'}")
 def test_random_dense_case(case):
     """d = 5 … 64 (MFMA path; dimensions that are not multiples of 16 run padded) with any observation dimension 1 … 64,
     and d ≤ 4 with dy > 4."""
