@@ -54,7 +54,8 @@ def test_hgf_reference_test_shape():
 
 
 @pytest.mark.parametrize("S,T,iters,n_gh,layout", [(1, 50, 3, 31, "time_chain"), (3, 200, 5, 21, "chain_time"), (130, 64, 2, 32, "time_chain"),
-                                                   (2, 1, 10, 31, "time_chain")])
+                                                   (2, 1, 10, 31, "time_chain"), (5, 30, 20, 17, "time_chain"), (7, 20, 18, 3, "chain_time"),
+                                                   (4, 25, 16, 16, "time_chain")])
 def test_hgf_shapes(S, T, iters, n_gh, layout):
     k, w, zv, yv = 0.8, -0.5, 0.05, 0.02
     ys = np.stack([hgf_series(T, k, w, zv, yv, 7 + s)[2] for s in range(S)], axis=1)
