@@ -1175,6 +1175,9 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     e->n_models = ds->n_models;
     e->ptt = ds->prior_through_transition ? 1 : 0;
     e->uniform = (ds->n_models == 1);
+    if (dense && ds->n_chains > 65535)  // the chain index is a grid y/z coordinate of the MFMA-path kernels
+        return fail(e, RXHIP_ERR_UNSUPPORTED, "d = %d runs on the MFMA path, which takes at most 65535 chains per engine (%lld given)", ds->d,
+                    (long long)ds->n_chains);
     if (ds->device >= 0) {
         if (ds->device >= ndev) return fail(e, RXHIP_ERR_BADARG, "device %d out of range (%d visible)", ds->device, ndev);
         e->device = ds->device;
