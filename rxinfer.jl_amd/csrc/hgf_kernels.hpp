@@ -79,6 +79,7 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
     bool bad = false;
     double yn = p.y[sc_];
     double fe_acc = 0.0;  // lane n of the row accumulates the free energy of VMP iteration n (n < 16; beyond: global)
+    double Bcur = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);  // exp(−κ E z + ½κ² var z) of the current q(z)
     for (long long t = 0; t < p.T; ++t) {
         const double yt = yn;
         if (t + 1 < p.T) yn = p.y[(t + 1) * p.n_series + sc_];
@@ -97,8 +98,14 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
         }
         double fe_t_const = 0.0;
         if (FE) fe_t_const = 0.5 * (kLog2Pi + log(zv)) + 0.5 * (kLog2Pi + log(xv)) + 0.5 * (kLog2Pi + lzvar) + 0.5 * (kLog2Pi + lyvar);
-        for (int n = 0; n < p.iters; ++n) {
-            const double B = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
+        // One VMP iteration = a dependent chain (B → joint (x, x_min) → b → cubature → reductions → new q(z)) followed by the
+        // free-energy terms of the iteration, which nothing downstream waits for.  The loop is software-pipelined by hand:
+        // the free energy of iteration n − 1 is evaluated inside iteration n, so its ≈250 instructions fill the latency gaps
+        // of the chain instead of extending it.  exp(−κ E z + ½κ² var z) of the new q(z) is both the GCV energy's factor of
+        // this iteration and B of the next one: computed once (Bcur is carried across iterations and observations).
+        struct FeIn { double Bn, ev, em, m1, m2, v11, v22, psi, det, qzm; };
+        auto chain = [&](FeIn& f) {
+            const double B = Bcur;
             const double g = A * B;
             const double l11 = iyvar + g, l22 = ixv + g;
             const double det = l11 * l22 - g * g;
@@ -141,32 +148,43 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
             const double var = q[0] * in0;
             bad = bad || !(det > 0.0) || !(var > 0.0) || !is_finite(mean);
             qzm = mean; qzv = var; qxm = m1; qxv = v11;
+            Bcur = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
             if (FE) {
-                const double Bn = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
-                // the transition node's joint q(zt, zt_min) and the message toward zt_min see the z-message through its
-                // Gaussian moments: mean_var(ExponentialLinearQuadratic) = cubature of pdf(z)·exp(z²/2) against N(0, 1)
-                const double ev = q[1] * ie0;
-                bad = bad || !(ev > 0.0) || !is_finite(em);
-                const double iev = rcp_pos(ev);
-                const double w00 = iev + wb, w11 = izv + wb;
-                const double dW = w00 * w11 - wb * wb;
-                const double idw = rcp_pos(dW);
-                const double s00 = w11 * idw, s11 = w00 * idw, s01 = wb * idw;
-                const double xo = em * iev;
-                const double j0 = s00 * xo + s01 * zx, j1 = s01 * xo + s11 * zx;
-                const double e2 = (j0 - j1) * (j0 - j1) + s00 + s11 - 2.0 * s01;
-                double F = fe_t_const;
-                F += 0.5 * ((j1 - zm) * (j1 - zm) + s11) * izv;                  // prior zt_min
-                F += 0.5 * ((m2 - xm) * (m2 - xm) + v22) * ixv;                  // prior xt_min
-                F += 0.5 * e2 * wb;                                              // transition
-                F += 0.5 * (kLog2Pi + (qzm * kappa + omega) + psi * A * Bn);     // GCV average energy
-                // −H[zt, zt_min] − H[xt, xt_min] = −2(log 2π + 1) + ½ log(dW / det Σ_x),  det Σ_x = 1 / det
-                F += -2.0 * (kLog2Pi + 1.0) + 0.5 * log(dW * det);
-                F += 0.5 * ((yt - m1) * (yt - m1) + v11) * iyvar;                // observation
-                if (n < HGF_LANES) fe_acc += (j == n) ? F : 0.0;
-                else if (live && j == 0) p.fe_series[(long long)n * p.n_series + s] += F;
+                f.Bn = Bcur; f.ev = q[1] * ie0; f.em = em; f.m1 = m1; f.m2 = m2; f.v11 = v11; f.v22 = v22; f.psi = psi; f.det = det;
+                f.qzm = mean;
             }
+        };
+        auto fe_eval = [&](const FeIn& f, int n) {
+            // the transition node's joint q(zt, zt_min) and the message toward zt_min see the z-message through its
+            // Gaussian moments: mean_var(ExponentialLinearQuadratic) = cubature of pdf(z)·exp(z²/2) against N(0, 1)
+            bad = bad || !(f.ev > 0.0) || !is_finite(f.em);
+            const double iev = rcp_pos(f.ev);
+            const double w00 = iev + wb, w11 = izv + wb;
+            const double dW = w00 * w11 - wb * wb;
+            const double idw = rcp_pos(dW);
+            const double s00 = w11 * idw, s11 = w00 * idw, s01 = wb * idw;
+            const double xo = f.em * iev;
+            const double j0 = s00 * xo + s01 * zx, j1 = s01 * xo + s11 * zx;
+            const double e2 = (j0 - j1) * (j0 - j1) + s00 + s11 - 2.0 * s01;
+            double F = fe_t_const;
+            F += 0.5 * ((j1 - zm) * (j1 - zm) + s11) * izv;                      // prior zt_min
+            F += 0.5 * ((f.m2 - xm) * (f.m2 - xm) + f.v22) * ixv;                // prior xt_min
+            F += 0.5 * e2 * wb;                                                  // transition
+            F += 0.5 * (kLog2Pi + (f.qzm * kappa + omega) + f.psi * A * f.Bn);   // GCV average energy
+            // −H[zt, zt_min] − H[xt, xt_min] = −2(log 2π + 1) + ½ log(dW / det Σ_x),  det Σ_x = 1 / det
+            F += -2.0 * (kLog2Pi + 1.0) + 0.5 * log(dW * f.det);
+            F += 0.5 * ((yt - f.m1) * (yt - f.m1) + f.v11) * iyvar;              // observation
+            if (n < HGF_LANES) fe_acc += (j == n) ? F : 0.0;
+            else if (live && j == 0) p.fe_series[(long long)n * p.n_series + s] += F;
+        };
+        FeIn pend, cur;
+        chain(pend);
+        for (int n = 1; n < p.iters; ++n) {
+            chain(cur);
+            if (FE) fe_eval(pend, n - 1);
+            pend = cur;
         }
+        if (FE) fe_eval(pend, p.iters - 1);
         if (live && j == 0) {
             const long long o = t * p.n_series + s;
             p.zm[o] = qzm; p.zv[o] = qzv; p.xm[o] = qxm; p.xv[o] = qxv;
