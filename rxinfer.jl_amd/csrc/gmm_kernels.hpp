@@ -65,6 +65,30 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;  // valid in lane 0; fixed tree shape
 }
 
+// exp(x) for x ≤ 0 (softmax numerators): the argument is clamped to −745 (below it the result is a denormal no sum can
+// see), so none of the library routine's range checks are needed — k = rint(x log2 e), r = x − k ln 2 in two pieces,
+// degree-12 Taylor polynomial on |r| ≤ ½ ln 2, scaling by 2^k with v_ldexp_f64.  ≈1 ulp.
+__device__ __forceinline__ double exp_nonpos(double x) {
+    x = fmax(x, -745.0);  // swallows a NaN argument: the caller poisons its sums when the observation is not finite
+    const double k = __builtin_rint(x * 1.4426950408889634074);
+    double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
+    r = __builtin_fma(k, -1.90821492927058770002e-10, r);
+    double p = 2.08767569878680989792e-09;   // 1/12!
+    p = __builtin_fma(p, r, 2.50521083854417187751e-08);   // 1/11!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-07);   // 1/10!
+    p = __builtin_fma(p, r, 2.75573192239858906526e-06);   // 1/9!
+    p = __builtin_fma(p, r, 2.48015873015873015873e-05);   // 1/8!
+    p = __builtin_fma(p, r, 1.98412698412698412698e-04);   // 1/7!
+    p = __builtin_fma(p, r, 1.38888888888888888889e-03);   // 1/6!
+    p = __builtin_fma(p, r, 8.33333333333333333333e-03);   // 1/5!
+    p = __builtin_fma(p, r, 4.16666666666666666667e-02);   // 1/4!
+    p = __builtin_fma(p, r, 1.66666666666666666667e-01);   // 1/3!
+    p = __builtin_fma(p, r, 0.5);
+    p = __builtin_fma(p, r, 1.0);
+    p = __builtin_fma(p, r, 1.0);
+    return __builtin_amdgcn_ldexp(p, (int)k);
+}
+
 // per-component constants of the responsibility rule from the current marginals:
 //   logit_k(y) = E log s_k − ½[log2π − E log p_k + E p_k (v_k + (y − m̄_k)²)]  = c_k − h_k (y − m̄_k)²  (+ const)
 template <int KT>
@@ -113,12 +137,12 @@ __global__ void __launch_bounds__(256) k_gmm_pass(GmmParams p) {
         for (int k = 0; k < KT; ++k) {
             const double d = y - m[k];
             lg[k] = c[k] - h[k] * d * d;
-            mx = lg[k] > mx ? lg[k] : mx;
+            mx = fmax(mx, lg[k]);
         }
         double Z = 0.0, e[KT], sl = 0.0;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            e[k] = exp(lg[k] - mx);
+            e[k] = exp_nonpos(lg[k] - mx);
             Z += e[k];
         }
         const double zi = 1.0 / Z, y2 = y * y;
@@ -131,7 +155,7 @@ __global__ void __launch_bounds__(256) k_gmm_pass(GmmParams p) {
             S2[k] += pi * y2;
             e[k] = pi;
         }
-        Hz += log(Z) - sl;  // H[q(z_i)] = −Σ π log π
+        Hz += (log(Z) - sl) + (y - y);  // H[q(z_i)] = −Σ π log π;  y − y: NaN for a non-finite observation (exp_nonpos hides it)
         if (RESP) {
             double* r = p.resp + i * p.K;
             for (int k = 0; k < p.K && k < KT; ++k) r[k] = e[k];

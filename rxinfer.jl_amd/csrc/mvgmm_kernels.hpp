@@ -144,12 +144,12 @@ __global__ void __launch_bounds__(256) k_mvg_pass(MvgParams p) {
 #pragma unroll
                 for (int b = 0; b <= a; ++b) qf += dr[q++] * dv[a] * dv[b];
             lg[k] = dr[0] - qf;
-            mx = lg[k] > mx ? lg[k] : mx;
+            mx = fmax(mx, lg[k]);
         }
         double Z = 0.0, e[KT], sl = 0.0;
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            e[k] = exp(lg[k] - mx);
+            e[k] = exp_nonpos(lg[k] - mx);
             Z += e[k];
         }
         const double zi = 1.0 / Z;
@@ -168,7 +168,10 @@ __global__ void __launch_bounds__(256) k_mvg_pass(MvgParams p) {
             }
             e[k] = pi;
         }
-        Hz += log(Z) - sl;  // H[q(z_i)] = −Σ π log π
+        double ysum = 0.0;
+#pragma unroll
+        for (int a = 0; a < D; ++a) ysum += y[a];
+        Hz += (log(Z) - sl) + (ysum - ysum);  // H[q(z_i)] = −Σ π log π;  NaN for a non-finite observation (exp_nonpos hides it)
         if (RESP) {
             double* r = p.resp + i * p.K;
             for (int k = 0; k < p.K && k < KT; ++k) r[k] = e[k];
