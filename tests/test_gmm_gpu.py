@@ -164,3 +164,17 @@ def test_two_process_sharded_mixture(tmp_path):
     assert np.max(np.abs(r0["fe"] - f) / np.abs(f)) < 1e-10 and np.max(np.abs(r0["hist"] - h) / np.abs(h)) < 1e-8
     ohist, ofe, _, _ = rxoracle.gmm_vmp(y, *priors, *init, 6)
     assert np.max(np.abs(r0["fe"] - ofe) / np.abs(ofe)) < 1e-8
+
+
+def test_non_finite_observation_is_reported():
+    """A NaN among the observations must not disappear in the softmax (the pass kernel's exp clamps its argument): the run
+    fails with a non-finite free energy, as the reference's NaN check (src/score/diagnostics.jl:19-51) would."""
+    y = gmm_data(500, [-10.0, 10.0], [3.777, 0.333], [1 / 3, 2 / 3], 7)
+    y[123] = np.nan
+    priors = ([-2.0, 2.0], [1e3, 1e3], [0.01, 0.01], [0.01, 0.01], [1.0, 1.0])
+    init = ([-2.0, 2.0], [1e3, 1e3], [1.0, 1.0], [1e-12, 1e-12], [1.0, 1.0])
+    with rxhip.GMMEngine(y.size, *priors, *init) as eng:
+        eng.set_data(y)
+        with pytest.raises(rxhip.RxHipError):
+            eng.run(3, True)
+            eng.free_energy()
