@@ -65,11 +65,11 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;  // valid in lane 0; fixed tree shape
 }
 
-// exp(x) for x ≤ 0 (softmax numerators): the argument is clamped to −745 (below it the result is a denormal no sum can
-// see), so none of the library routine's range checks are needed — k = rint(x log2 e), r = x − k ln 2 in two pieces,
-// degree-12 Taylor polynomial on |r| ≤ ½ ln 2, scaling by 2^k with v_ldexp_f64.  ≈1 ulp.
-__device__ __forceinline__ double exp_nonpos(double x) {
-    x = fmax(x, -745.0);  // swallows a NaN argument: the caller poisons its sums when the observation is not finite
+// exp without the library routine's range checks: k = rint(x log2 e), r = x − k ln 2 in two pieces, degree-12 Taylor
+// polynomial on |r| ≤ ½ ln 2, scaling by 2^k with v_ldexp_f64 (≈1 ulp).  The argument is clamped instead: below −745 the
+// result is a denormal no sum can see, above 709.7 it saturates near DBL_MAX.  The clamps swallow a NaN argument — callers
+// detect non-finite inputs themselves (the mixture passes poison their entropy sum, the HGF kernel checks its moments).
+__device__ __forceinline__ double exp_core(double x) {
     const double k = __builtin_rint(x * 1.4426950408889634074);
     double r = __builtin_fma(k, -6.93147180369123816490e-01, x);
     r = __builtin_fma(k, -1.90821492927058770002e-10, r);
@@ -88,6 +88,8 @@ __device__ __forceinline__ double exp_nonpos(double x) {
     p = __builtin_fma(p, r, 1.0);
     return __builtin_amdgcn_ldexp(p, (int)k);
 }
+__device__ __forceinline__ double exp_nonpos(double x) { return exp_core(fmax(x, -745.0)); }                 // x ≤ 0
+__device__ __forceinline__ double exp_bounded(double x) { return exp_core(fmin(fmax(x, -745.0), 709.7)); }  // any x
 
 // per-component constants of the responsibility rule from the current marginals:
 //   logit_k(y) = E log s_k − ½[log2π − E log p_k + E p_k (v_k + (y − m̄_k)²)]  = c_k − h_k (y − m̄_k)²  (+ const)

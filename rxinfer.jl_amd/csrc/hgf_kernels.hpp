@@ -35,8 +35,10 @@ struct HgfParams {
 template <int CTRL>
 __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    // every lane of these permutations has a source lane inside its row: no `old` value is needed (bound_ctrl form, one
+    // v_mov_b32_dpp per half instead of a copy + a DPP move)
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
     return __hiloint2double(hi, lo);
 }
 template <int N>
@@ -70,16 +72,16 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
         gw[u] = q < p.n_gh ? p.gh[32 + q] : 0.0;
         pe[u] = 1.4142135623730951 * gx[u];  // cubature points against N(0, 1)
         hpe2[u] = 0.5 * pe[u] * pe[u];
-        epe[u] = exp(-kappa * pe[u]);
+        epe[u] = exp_bounded(-kappa * pe[u]);
         lpe[u] = -0.5 * kappa * pe[u] + hpe2[u];
     }
-    const double A = exp(-omega);
+    const double A = exp_bounded(-omega);
     const double iyvar = 1.0 / yvar, wb = 1.0 / zvar, lzvar = log(zvar), lyvar = log(yvar);
     double qzm = p.z0m, qzv = p.z0v, qxm = p.x0m, qxv = p.x0v;
     bool bad = false;
     double yn = p.y[sc_];
     double fe_acc = 0.0;  // lane n of the row accumulates the free energy of VMP iteration n (n < 16; beyond: global)
-    double Bcur = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);  // exp(−κ E z + ½κ² var z) of the current q(z)
+    double Bcur = exp_bounded(-kappa * qzm + 0.5 * kappa * kappa * qzv);  // exp_bounded(−κ E z + ½κ² var z) of the current q(z)
     for (long long t = 0; t < p.T; ++t) {
         const double yt = yn;
         if (t + 1 < p.T) yn = p.y[(t + 1) * p.n_series + sc_];
@@ -87,13 +89,13 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
         const double fzv = zv + zvar, sc = sqrt(2.0 * fzv);
         const double ixv = rcp_pos(xv), izv = rcp_pos(zv);
         const double x1 = yt * iyvar, x2 = xm * ixv, zx = zm * izv;
-        // point-wise constants of the two cubatures: exp(−½κ·point) factors out of the iteration loop
+        // point-wise constants of the two cubatures: exp_bounded(−½κ·point) factors out of the iteration loop
         double dx[2], ept[2], lpt[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             dx[u] = sc * gx[u];  // cubature points against the forward message N(zm, fzv)
             const double pt = zm + dx[u];
-            ept[u] = exp(-kappa * pt);
+            ept[u] = exp_bounded(-kappa * pt);
             lpt[u] = -0.5 * kappa * pt;
         }
         double fe_t_const = 0.0;
@@ -101,7 +103,7 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
         // One VMP iteration = a dependent chain (B → joint (x, x_min) → b → cubature → reductions → new q(z)) followed by the
         // free-energy terms of the iteration, which nothing downstream waits for.  The loop is software-pipelined by hand:
         // the free energy of iteration n − 1 is evaluated inside iteration n, so its ≈250 instructions fill the latency gaps
-        // of the chain instead of extending it.  exp(−κ E z + ½κ² var z) of the new q(z) is both the GCV energy's factor of
+        // of the chain instead of extending it.  exp_bounded(−κ E z + ½κ² var z) of the new q(z) is both the GCV energy's factor of
         // this iteration and B of the next one: computed once (Bcur is carried across iterations and observations).
         struct FeIn { double Bn, ev, em, m1, m2, v11, v22, psi, det, qzm; };
         auto chain = [&](FeIn& f) {
@@ -114,20 +116,20 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
             const double m1 = v11 * x1 + v12 * x2, m2 = v12 * x1 + v22 * x2;
             const double psi = (m1 - m2) * (m1 - m2) + v11 + v22 - 2.0 * v12;
             const double b = psi * A;
-            // two cubature points per lane: z-message pdf exp(−½(κz + b·exp(−κz))) at the forward-message points and (for
-            // the free energy) times exp(z²/2) at the N(0,1) points; first moments taken about zm / 0
+            // two cubature points per lane: z-message pdf exp_bounded(−½(κz + b·exp(−κz))) at the forward-message points and (for
+            // the free energy) times exp_bounded(z²/2) at the N(0,1) points; first moments taken about zm / 0
             // Two reduction rounds, exactly the reference's approximate_meancov: (norm, first moment), then the second
             // moment about the mean — when a message's mode leaves the cubature range the variance is pure rounding
             // residue and only the same formula reproduces the reference there.
             double r[FE ? 4 : 2];
             double cv[2], ecv[2] = {0.0, 0.0};
 #pragma unroll
-            for (int u = 0; u < 2; ++u) cv[u] = gw[u] * exp(lpt[u] - 0.5 * b * ept[u]);
+            for (int u = 0; u < 2; ++u) cv[u] = gw[u] * exp_bounded(lpt[u] - 0.5 * b * ept[u]);
             r[0] = cv[0] + cv[1];
             r[1] = cv[0] * dx[0] + cv[1] * dx[1];
             if (FE) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u) ecv[u] = gw[u] * exp(lpe[u] - 0.5 * b * epe[u]);
+                for (int u = 0; u < 2; ++u) ecv[u] = gw[u] * exp_bounded(lpe[u] - 0.5 * b * epe[u]);
                 r[2] = ecv[0] + ecv[1];
                 r[3] = ecv[0] * pe[0] + ecv[1] * pe[1];
             }
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(64) k_hgf_filter(HgfParams p) {
             const double var = q[0] * in0;
             bad = bad || !(det > 0.0) || !(var > 0.0) || !is_finite(mean);
             qzm = mean; qzv = var; qxm = m1; qxv = v11;
-            Bcur = exp(-kappa * qzm + 0.5 * kappa * kappa * qzv);
+            Bcur = exp_bounded(-kappa * qzm + 0.5 * kappa * kappa * qzv);
             if (FE) {
                 f.Bn = Bcur; f.ev = q[1] * ie0; f.em = em; f.m1 = m1; f.m2 = m2; f.v11 = v11; f.v22 = v22; f.psi = psi; f.det = det;
                 f.qzm = mean;
