@@ -285,23 +285,38 @@ __device__ __forceinline__ void matvec_c(const CPtr A, const double (&x)[D], dou
 // When FE: log p(y_t | y_<t) = −½[quad + log(detprod)], returned in two parts so that the caller
 // can take ONE logarithm per segment (running product with exponent extraction) instead of one
 // per step:  quad = c0 + y'Q⁻¹y − ξf'm_f + m_p'Λ_p m_p,   detprod = det Λf · det Vp.
+// The constants of the observation side (B'Q⁻¹B packed, B'Q⁻¹, Q⁻¹ packed, c0) as plain arrays: k_forward keeps them in
+// VECTOR registers for shared-model batches (see there), every other caller reads them through the constant pointer.
+template <int D, int DY>
+struct ObsCst {
+    double lobs[D * (D + 1) / 2], g[D * DY], qi[DY * (DY + 1) / 2], c0;
+    __device__ __forceinline__ void load(const double* p) {
+        using CL = CstLayout<D, DY>;
+#pragma unroll
+        for (int i = 0; i < D * (D + 1) / 2; ++i) lobs[i] = p[CL::LOBS + i];
+#pragma unroll
+        for (int i = 0; i < D * DY; ++i) g[i] = p[CL::G + i];
+#pragma unroll
+        for (int i = 0; i < DY * (DY + 1) / 2; ++i) qi[i] = p[CL::QI + i];
+        c0 = p[CL::C0];
+    }
+};
 template <int D, int DY, bool FE>
-__device__ __forceinline__ void obs_update(const CPtr c, const double (&mp)[D], const Sym<D>& Vp,
+__device__ __forceinline__ void obs_update(const ObsCst<D, DY>& oc, const double (&mp)[D], const Sym<D>& Vp,
                                            const double (&y)[DY], double (&m)[D], Sym<D>& V, bool& ok,
                                            double& quad, double& detprod) {
-    using CL = CstLayout<D, DY>;
     Sym<D> Lp, Lf;
     double detp, detl;
     ok = spd_inv<D>(Vp, Lp, detp) && ok;  // weightedmean_precision of the forward message
     double xp[D], xf[D];
     symv<D>(Lp, mp, xp);
 #pragma unroll
-    for (int i = 0; i < D * (D + 1) / 2; ++i) Lf.v[i] = Lp.v[i] + c[CL::LOBS + i];
+    for (int i = 0; i < D * (D + 1) / 2; ++i) Lf.v[i] = Lp.v[i] + oc.lobs[i];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         double s = xp[i];
 #pragma unroll
-        for (int k = 0; k < DY; ++k) s += c[CL::G + i * DY + k] * y[k];
+        for (int k = 0; k < DY; ++k) s += oc.g[i * DY + k] * y[k];
         xf[i] = s;
     }
     ok = spd_inv<D>(Lf, V, detl) && ok;  // mean_cov of the product
@@ -312,7 +327,7 @@ __device__ __forceinline__ void obs_update(const CPtr c, const double (&mp)[D], 
     for (int i = 0; i < DY; ++i) {
         double s = 0.0;
 #pragma unroll
-        for (int k = 0; k < DY; ++k) s += c[CL::QI + sidx(i, k)] * y[k];
+        for (int k = 0; k < DY; ++k) s += oc.qi[sidx(i, k)] * y[k];
         q += s * y[i];
     }
     double a1 = 0.0, a2 = 0.0;
@@ -321,8 +336,16 @@ __device__ __forceinline__ void obs_update(const CPtr c, const double (&mp)[D], 
         a1 += xf[i] * m[i];
         a2 += xp[i] * mp[i];
     }
-    quad = c[CL::C0] + q - a1 + a2;
+    quad = oc.c0 + q - a1 + a2;
     detprod = detl * detp;
+}
+template <int D, int DY, bool FE>
+__device__ __forceinline__ void obs_update(const CPtr c, const double (&mp)[D], const Sym<D>& Vp,
+                                           const double (&y)[DY], double (&m)[D], Sym<D>& V, bool& ok,
+                                           double& quad, double& detprod) {
+    ObsCst<D, DY> oc;
+    oc.load(c.p);
+    obs_update<D, DY, FE>(oc, mp, Vp, y, m, V, ok, quad, detprod);
 }
 
 // running Σ log(x_t) as log(Π x_t): mantissa product renormalised every step (v_frexp_*), exponents
@@ -929,6 +952,17 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
     bool ok = true;
     double acc = 0.0;
     LogProd lp;
+    // The ≈60 constants of a step do not fit the scalar register file (measured: 70 SGPRs spilled to VGPR lanes and 50
+    // v_readlane restores per step, 14 % of the issue slots of this VALU-bound kernel).  The observation-side constants are
+    // therefore loaded once through an address the compiler cannot prove uniform, which keeps them in VECTOR registers —
+    // free here: the batch occupies two wavefronts per SIMD whatever the register count.
+    ObsCst<D, DY> oc;
+    if constexpr (UNI) {
+        int z;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+        oc.load(p.cst + z);
+    } else
+        oc.load(c.p);
     double yv[DY], yn[DY];
     if (len > 0) load_y<DY>(p.y, t0, p.n_chains, chain, yn);
     for (long long i = 0; i < len; ++i) {
@@ -940,7 +974,7 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
         matvec_c<D>(CPtr{c.p + CL::A}, m, mp);
         predict_cov<D>(CPtr{c.p + CL::A}, CPtr{c.p + CL::P}, V, T, Vp);
         double quad = 0.0, detprod = 1.0;
-        obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok, quad, detprod);
+        obs_update<D, DY, FE>(oc, mp, Vp, yv, m, V, ok, quad, detprod);
         if (FE) {
             acc += quad;
             lp.mul(detprod);
