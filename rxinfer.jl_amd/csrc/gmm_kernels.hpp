@@ -121,12 +121,23 @@ __global__ void __launch_bounds__(256) k_gmm_init(GmmParams p) {
 template <int KT, bool RESP>
 __global__ void __launch_bounds__(256) k_gmm_pass(GmmParams p) {
     __shared__ double sh[4][3 * KT + 1];
-    double c[KT], h[KT], m[KT];
+    // The 3·KT per-component constants do not fit the scalar register file at KT = 16 (72 SGPRs were spilled to VGPR lanes and
+    // restored with 54 v_readlane per point — VALU issue slots of a VALU-bound kernel).  They are read from LDS inside the
+    // loop instead (wave-uniform broadcast reads on the otherwise idle LDS pipe); the per-iteration opaque zero keeps the
+    // reads in the loop (hoisted, they would occupy 96 vector registers).  Small KT keeps them in scalar registers.
+    constexpr bool CST_LDS = KT >= 16;
+    __shared__ __attribute__((aligned(16))) double sc[CST_LDS ? 4 * KT : 4];  // [k][c, h, m, pad]
+    double c[CST_LDS ? 1 : KT], h[CST_LDS ? 1 : KT], m[CST_LDS ? 1 : KT];
+    if constexpr (CST_LDS) {
+        for (int q = threadIdx.x; q < 3 * KT; q += 256) sc[4 * (q % KT) + q / KT] = p.drv[q];
+        __syncthreads();
+    } else {
 #pragma unroll
-    for (int k = 0; k < KT; ++k) {
-        c[k] = p.drv[k];
-        h[k] = p.drv[KT + k];
-        m[k] = p.drv[2 * KT + k];
+        for (int k = 0; k < KT; ++k) {
+            c[k] = p.drv[k];
+            h[k] = p.drv[KT + k];
+            m[k] = p.drv[2 * KT + k];
+        }
     }
     double S0[KT], S1[KT], S2[KT], Hz = 0.0;
 #pragma unroll
@@ -135,10 +146,19 @@ __global__ void __launch_bounds__(256) k_gmm_pass(GmmParams p) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < p.N; i += stride) {
         const double y = p.y[i];
         double lg[KT], mx = -1e308;
+        int z = 0;
+        if constexpr (CST_LDS) asm volatile("v_mov_b32 %0, 0" : "=v"(z));
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            const double d = y - m[k];
-            lg[k] = c[k] - h[k] * d * d;
+            double ck, hk, mk;
+            if constexpr (CST_LDS) {
+                const double2 ch = *reinterpret_cast<const double2*>(sc + 4 * k + z);
+                ck = ch.x; hk = ch.y; mk = sc[4 * k + 2 + z];
+            } else {
+                ck = c[k]; hk = h[k]; mk = m[k];
+            }
+            const double d = y - mk;
+            lg[k] = ck - hk * d * d;
             mx = fmax(mx, lg[k]);
         }
         double Z = 0.0, e[KT], sl = 0.0;
