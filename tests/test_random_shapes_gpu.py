@@ -30,7 +30,7 @@ def _cases(n, seed):
                    seed=int(rng.integers(1 << 30)))
 
 
-@pytest.mark.parametrize("case", list(_cases(48, 2024)), ids=lambda c: f"{c['i']}-d{c['d']}x{c['dy']}-T{c['T']}-C{c['C']}-s{c['segments']}-{'ptt' if c['ptt'] else 'x1'}-{'pc' if c['per_chain'] else 'uni'}")
+@pytest.mark.parametrize("case", list(_cases(48, 2024)) + list(_cases(int(os.environ.get("RXHIP_STRESS", "0")), 90210)), ids=lambda c: f"{c['i']}-d{c['d']}x{c['dy']}-T{c['T']}-C{c['C']}-s{c['segments']}-{'ptt' if c['ptt'] else 'x1'}-{'pc' if c['per_chain'] else 'uni'}")
 def test_random_case(case):
     d, dy, T, C = case["d"], case["dy"], case["T"], case["C"]
     nm = 3 if case["per_chain"] else 1
