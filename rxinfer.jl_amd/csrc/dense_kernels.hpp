@@ -96,6 +96,7 @@ struct DenseParams {
     // two-level boundary scan (see kd_scan_local / kd_scan_fix): scan steps st = 0 … S−2 in groups of `sg`
     const double* qtab;   // [2][S][d][d]  index q = st + 1: product of the step maps from the start of q's group through st (transposed)
     double* loc;          // [chain][2][S][d]  index q: state after step q − 1 of a scan that starts every group from zero
+    double* bnd;          // [S][2][d][d]  data-independent boundary inverses (kd_prepare_bnd, once per engine): 0: Λ_f(b_s) = V(b_s)⁻¹;  1: V_s(b_{s+1}) = (Λ_f + Λβ)⁻¹ (s < S − 1)
     int sg, ng;           // group size, number of groups
     double* fe_part;      // [S+1][chain]
     int* status;
@@ -826,6 +827,33 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_fix(DenseParams p) {
         v0, red, tid);
 }
 
+// Once per engine: the inverses at the segment boundaries that do not depend on the data —
+//   bnd[s][0] = Λ_f(b_s) = V(b_s)⁻¹  (start of kd_forward_info),   bnd[s][1] = V_s(b_{s+1}) = (Λ_f(b_{s+1}) + Λβ(b_{s+1}))⁻¹  (start of
+//   kd_backward_info, s < S − 1) — so that no sweep pays for them.  One workgroup per segment.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) kd_prepare_bnd(DenseParams p) {
+    constexpr int D = 16 * NT;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* rowbuf = smem;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const int seg = blockIdx.x;
+    const size_t MM = (size_t)D * D;
+    bool ok = true;
+    LogProd lpd;
+    Acc<NT> a;
+    acc_load<NT>(a, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
+    ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;
+    acc_store<NT>(a, p.bnd + ((size_t)seg * 2 + 0) * MM, D, w, lane);
+    if (seg + 1 < p.S) {
+        acc_load<NT>(a, p.scanm + ((size_t)(seg + 1) * 6 + 2) * MM, D, w, lane);
+        ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;
+        acc_add_mat<NT>(a, p.scanm + ((size_t)seg * 6 + 5) * MM, D, w, lane, 1.0);
+        ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;
+        acc_store<NT>(a, p.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);
+    }
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
 // sum over the first n ≤ 64 lanes of wave 0 (valid in lane 0)
 __device__ __forceinline__ double wave0_sum(double v) {
 #pragma unroll
@@ -1042,7 +1070,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward_info(DenseParams p) {
     if (b1 > p.T) b1 = p.T;
     const long long len = b1 - b0, t0 = seg * p.L + 1;
     bool ok = true;
-    LogProd lp, lpd;
+    LogProd lp;
     Acc<NT> lam, a;
     // K = P⁻¹A is the A operand of both contractions of a step: its fragments stay in registers for the whole segment
     double kf[D / 4];
@@ -1071,9 +1099,8 @@ __global__ void __launch_bounds__(64 * NT) kd_forward_info(DenseParams p) {
             cacc.v[t][3] = acc[t][3];
         }
     };
-    // belief at the segment start in information form: Λ_f = V(b_s)⁻¹, ξ_f = Λ_f m(b_s)
-    acc_load<NT>(lam, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
-    ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lpd) && ok;
+    // belief at the segment start in information form: Λ_f = V(b_s)⁻¹ (data-independent: host table), ξ_f = Λ_f m(b_s)
+    acc_load<NT>(lam, p.bnd + ((size_t)seg * 2 + 0) * MM, D, w, lane);
     acc_store<NT>(lam, S0, LD, w, lane);
     acc_load<NT>(a, cst + c.oPLW, D, w, lane);
     acc_store<NT>(a, S2, LD, w, lane);
@@ -1163,14 +1190,17 @@ __global__ void __launch_bounds__(64 * NT) kd_backward_info(DenseParams p) {
     bool ok = true;
     LogProd lpe;
     Acc<NT> a;
-    // smoothed belief at the end boundary: V_s = (Λ_f + Λβ)⁻¹, m_s = V_s (ξ_f + ξβ)
+    // smoothed belief at the end boundary: V_s = (Λ_f + Λβ)⁻¹, m_s = V_s (ξ_f + ξβ).  Inner boundaries: V_s does not depend
+    // on the data (host table).  Last segment: Λβ = 0, V_s = Λ_f(T)⁻¹ from the forward sweep; its pivots give |Λ_f(T)|.
     {
-        tri_to_lds<NT>(p.vend + (chain * p.S + seg) * C::TRI, M0, LD, w, lane);
         if (tid < D) xf[tid] = p.filt[(chain * p.T + te) * C::REC + tid] + p.beta_xi[(chain * (p.S + 1) + seg + 1) * D + tid];
-        lds_barrier();
-        acc_load<NT>(a, M0, LD, w, lane);
-        acc_add_mat<NT>(a, p.scanm + ((size_t)seg * 6 + 5) * MM, D, w, lane, 1.0);
-        ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpe) && ok;  // last segment: Λβ = 0, the pivots give |Λ_f(T)|
+        if (seg == p.S - 1) {  // uniform over the workgroup
+            tri_to_lds<NT>(p.vend + (chain * p.S + seg) * C::TRI, M0, LD, w, lane);
+            lds_barrier();
+            acc_load<NT>(a, M0, LD, w, lane);
+            ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpe) && ok;
+        } else
+            acc_load<NT>(a, p.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);
         acc_store<NT>(a, M2, LD, w, lane);
         lds_barrier();
         matvec_lds(ms, M2, LD, D, D, xf, nullptr, 0.0, tid);

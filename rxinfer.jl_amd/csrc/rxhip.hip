@@ -202,7 +202,7 @@ struct rxhip_engine {
     // dense (d = 16·NT) path
     bool dense = false;
     int nt = 0;
-    double *d_scanm = nullptr, *d_fstart_m = nullptr, *d_beta_xi = nullptr, *d_vend = nullptr, *d_qtab = nullptr, *d_loc = nullptr;
+    double *d_scanm = nullptr, *d_fstart_m = nullptr, *d_beta_xi = nullptr, *d_vend = nullptr, *d_qtab = nullptr, *d_loc = nullptr, *d_bnd = nullptr;
     int scan_sg = 1, scan_ng = 1;  // two-level boundary scan of the dense path: group size, groups
     int agg_oc = 1, agg_kc = 1;    // dense aggregation product: offsets per K-chunk, K-chunks
     double* d_aggpart = nullptr;   // [chain][agg_kc][S][2·dpad] partial sums of kd_agg_gemm
@@ -652,11 +652,14 @@ struct DenseLaunch {
         const int bytes = 160 * 1024;
         hipError_t e;
         for (const void* f : {(const void*)kd_agg_finish<NT>, (const void*)kd_scan_local<NT, true>, (const void*)kd_scan_local<NT, false>,
-                              (const void*)kd_scan_fix<NT>, (const void*)kd_forward<NT, true>, (const void*)kd_forward<NT, false>,
+                              (const void*)kd_scan_fix<NT>, (const void*)kd_prepare_bnd<NT>, (const void*)kd_forward<NT, true>, (const void*)kd_forward<NT, false>,
                               (const void*)kd_forward_info<NT, true>, (const void*)kd_forward_info<NT, false>,
                               (const void*)kd_backward_info<NT, true>, (const void*)kd_backward_info<NT, false>, (const void*)kd_fe_resid})
             if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         return hipSuccess;
+    }
+    static void prepare_bnd(const DenseParams& p, hipStream_t s) {
+        hipLaunchKernelGGL((kd_prepare_bnd<NT>), dim3(p.S), dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
     }
     static void seg_aggregate(const DenseParams& p, hipStream_t s) {
         const unsigned sb = (unsigned)((p.S - 1 + 15) / 16 + 1);  // blocks of 16 full segments + the last segment on its own
@@ -1115,7 +1118,7 @@ static void free_all(rxhip_engine* e) {
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&e->h.d_out, &e->h.d_fe_series, &e->h.d_gh, &e->h.d_fe_total})
         if (*b) { (void)hipFree(*b); *b = nullptr; }
-    for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend, &e->d_qtab, &e->d_loc, &e->d_aggpart})
+    for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend, &e->d_qtab, &e->d_loc, &e->d_aggpart, &e->d_bnd})
         if (*b) { if (!e->in_arena(*b)) (void)hipFree(*b); *b = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
@@ -1239,6 +1242,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.upload(&e->d_tab, tab.data(), sizeof(double) * tab.size());
         ap.upload(&e->d_scanm, scanm.data(), sizeof(double) * scanm.size());
         ap.upload(&e->d_qtab, qtab.data(), sizeof(double) * qtab.size());
+        ap.plain(&e->d_bnd, sizeof(double) * Sg * 2 * D * D);
         ap.plain(&e->d_loc, sizeof(double) * C * 2 * Sg * D);
         ap.plain(&e->d_aggpart, sizeof(double) * C * (size_t)e->agg_kc * Sg * 2 * D);
         ap.zeroed(&e->d_status, sizeof(int));
@@ -1255,7 +1259,14 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_fstart_m, sizeof(double) * C * Sg * D);
         ap.plain(&e->d_beta_xi, sizeof(double) * C * (Sg + 1) * D);
         ap.plain(&e->d_fe_chain, sizeof(double) * C);
-        return arena_commit(e, ap);
+        if ((st = arena_commit(e, ap))) return st;
+        if (e->S > 0) {  // data-independent inverses at the segment boundaries: once per engine, on the device
+            DenseParams dp{};
+            dp.S = e->S; dp.d = e->dpad; dp.dy = e->dy; dp.scanm = e->d_scanm; dp.bnd = e->d_bnd; dp.status = e->d_status;
+            DENSE_DISPATCH(e->nt, prepare_bnd(dp, e->stream));
+            HIPCHK(e, hipGetLastError());
+        }
+        return RXHIP_OK;
     }
     // per-model tables
     const size_t NP = (size_t)e->d + (size_t)e->d * (e->d + 1) / 2;
@@ -1912,7 +1923,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     if (e->dense) {
         dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->S; dp.L = e->L; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy;
         dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
-        dp.qtab = e->d_qtab; dp.loc = e->d_loc; dp.sg = e->scan_sg; dp.ng = e->scan_ng;
+        dp.bnd = e->d_bnd; dp.qtab = e->d_qtab; dp.loc = e->d_loc; dp.sg = e->scan_sg; dp.ng = e->scan_ng;
         dp.aggpart = e->d_aggpart; dp.agg_oc = e->agg_oc; dp.agg_kc = e->agg_kc; dp.Llast = e->Llast;
         dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;
