@@ -1230,6 +1230,34 @@ __global__ void __launch_bounds__(256) k_fe_chain(Params p, double* block_part) 
     }
     if (threadIdx.x == 0) block_part[blockIdx.x] = sh[0][0];
 }
+// Few chains (≤ 16): k_fe_chain leaves all but one lane of each wave idle and walks the partials one by one.  Here one
+// workgroup sums the p.S + 1 partials of every chain with all 256 threads (fixed stride and tree shape: deterministic) and
+// finishes with the total — chain and total reduction in a single launch.
+__global__ void __launch_bounds__(256) k_fe_few(Params p) {
+    __shared__ double sh[256];
+    const int n = p.S + 1;
+    double total = 0.0;
+    bool bad = false;
+    for (long long ch = 0; ch < p.n_chains; ++ch) {
+        double s = 0.0;
+        for (int k = threadIdx.x; k < n; k += 256) s += p.fe_part[(long long)k * p.n_chains + ch];
+        sh[threadIdx.x] = s;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+            __syncthreads();
+        }
+        const double f = -sh[0] * p.fe_scale;
+        __syncthreads();
+        if (threadIdx.x == 0) p.fe_chain[ch] = f;
+        bad = bad || !is_finite(f);
+        total += f;
+    }
+    if (threadIdx.x == 0) {
+        p.fe_total[p.iteration] = total;
+        if (bad) atomicOr(p.status, ST_NONFINITE);
+    }
+}
 __global__ void __launch_bounds__(256) k_fe_total(Params p, const double* block_part, int nblocks) {
     __shared__ double sh[256];
     double local = 0.0;

@@ -1985,8 +1985,12 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 launch_fe_resid(dp, e->stream);
                 pr.S = 2 * e->S - 1 + fe_resid_blocks(e->T);
             }
-            hipLaunchKernelGGL(k_fe_chain, dim3(nb), dim3(256), 0, e->stream, pr, e->d_fe_blocks);
-            hipLaunchKernelGGL(k_fe_total, dim3(1), dim3(256), 0, e->stream, p, (const double*)e->d_fe_blocks, nb);
+            if (e->n_chains <= 16) {
+                hipLaunchKernelGGL(k_fe_few, dim3(1), dim3(256), 0, e->stream, pr);
+            } else {
+                hipLaunchKernelGGL(k_fe_chain, dim3(nb), dim3(256), 0, e->stream, pr, e->d_fe_blocks);
+                hipLaunchKernelGGL(k_fe_total, dim3(1), dim3(256), 0, e->stream, p, (const double*)e->d_fe_blocks, nb);
+            }
             if ((st = prof_end(e))) return st;
         }
     }
