@@ -255,7 +255,7 @@ __device__ __forceinline__ void mm_acc(Acc<NT>& c, const double* X, int ldx, con
     d4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = (d4){c.v[t][0], c.v[t][1], c.v[t][2], c.v[t][3]};
-#pragma unroll 4
+#pragma unroll
     for (int kk = 0; kk < D / 4; ++kk) {
         const int k = 4 * kk + kq;
         const double a = TX ? X[k * ldx + i] : X[i * ldx + k];
