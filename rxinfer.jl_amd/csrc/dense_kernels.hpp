@@ -545,17 +545,18 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_gemm(DenseParams p) {
     if (o1 > len) o1 = len;
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     const int r0 = 16 * w + jl, r1 = 16 * (w + NT) + jl;                   // A-operand rows of this wave's two tiles
-    // flattened (offset, k-step) loop, four steps per trip with all twelve loads issued first
+    // flattened (offset, k-step) loop, AG steps per trip with all their loads issued first
     const int kpo = dyp / 4;
     const long long nq = (o1 > o0 ? o1 - o0 : 0) * kpo;
     const double* ybase = p.y + ((1 + (long long)seg * p.L) * p.n_chains + chain) * dy;
     const long long ystride = p.n_chains * (long long)dy;
     long long o = o0;
     int kk = 0;
-    for (long long q = 0; q < nq; q += 4) {
-        double a0[4], a1[4], b[4];
+    constexpr int AG = 16;  // k-steps per trip: 3·AG loads in flight (the operands come straight from L2)
+    for (long long q = 0; q < nq; q += AG) {
+        double a0[AG], a1[AG], b[AG];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < AG; ++u) {
             const bool in = q + u < nq;
             const int k = 4 * kk + kq;
             const double* tb = tab + ((size_t)o * dyp + k) * 2 * D;
@@ -565,7 +566,7 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_gemm(DenseParams p) {
             if (++kk == kpo) { kk = 0; ++o; }
         }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < AG; ++u) {
             acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b[u], acc0, 0, 0, 0);
             acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b[u], acc1, 0, 0, 0);
         }
