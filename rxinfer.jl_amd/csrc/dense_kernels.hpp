@@ -330,13 +330,20 @@ struct Sweep4 {
             }
         }
         lds_barrier();
-        // the four pivot rows at this thread's columns, rc[u][t] = R[u][16t + jl]
-        double rc[4][NT];
+        // The whole sweep step as ONE rank-4 MFMA per 16×16 tile, A ← A + X·Y with D4⁻¹ on the X side:
+        //   X[i][v] = −(R'D4⁻¹)[i][v] + [i = K_u]·D4⁻¹[u][v]      (16 rows of this wave × 4)
+        //   Y[v][j] = R[v][j] − [j = K_v]                           (4 × 16 columns of tile t)
+        // which yields  A_JJ − R_J'D4⁻¹R_J,  A_KJ = D4⁻¹R_J,  A_JK = (D4⁻¹R_J)'  and  A_KK = 2I − D4⁻¹  (the 2I is removed
+        // below): −D4⁻¹ on the pivot block, as the sweep operator requires.  The Y operands are plain LDS values that do
+        // not wait for D4⁻¹; a thread applies D4⁻¹ to ONE column of R (its row's X entry: four FMAs) instead of one per tile.
+        double yb[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const double2* src = reinterpret_cast<const double2*>(rb + (16 * t + jl) * 4);
+        for (int t = 0; t < NT; ++t) yb[t] = rb[(16 * t + jl) * 4 + vl];   // R[vl][16t + jl]
+        double ri[4];                                                       // R[0..3][row i of this lane's X entry]
+        {
+            const double2* src = reinterpret_cast<const double2*>(rb + (16 * w + jl) * 4);
             const double2 x0 = src[0], x1 = src[1];
-            rc[0][t] = x0.x; rc[1][t] = x0.y; rc[2][t] = x1.x; rc[3][t] = x1.y;
+            ri[0] = x0.x; ri[1] = x0.y; ri[2] = x1.x; ri[3] = x1.y;
         }
         // pivot block D4[u][v] = R[u][K_v]  (lower triangle), inverse — redundantly in every thread (cheaper than a barrier)
         Sym<4> d4, di;
@@ -351,12 +358,7 @@ struct Sweep4 {
         double det;
         ok = spd_inv4_cof(d4, di, det) && ok;
         if (w == 0 && lane == 0) lp.mul(det);
-        // The whole sweep step as ONE rank-4 MFMA per 16×16 tile, A ← A + X·Y with
-        //   X[i][v] = −R[v][i] + [i = K_v]        (16 rows of this wave × 4)
-        //   Y[v][j] = (D4⁻¹R)[v][j] − [j = K_c]·D4⁻¹[v][c]      (4 × 16 columns of tile t)
-        // which yields  A_JJ − R_J'D4⁻¹R_J,  A_KJ = D4⁻¹R_J,  A_JK = (D4⁻¹R_J)'  and  A_KK = 2I − D4⁻¹  (the 2I is removed
-        // below): −D4⁻¹ on the pivot block, as the sweep operator requires.
-        // row vl of D4⁻¹ (this lane's k index in the MFMA operand layout)
+        // column vl of D4⁻¹ (= row vl: symmetric) — this lane's k index in the MFMA operand layout
         double dv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -366,19 +368,19 @@ struct Sweep4 {
             x = vl == 3 ? di(3, u) : x;
             dv[u] = x;
         }
-        const double xa = -rb[(16 * w + jl) * 4 + vl] + ((w == pb && jl == Q + 4 * vl) ? 1.0 : 0.0);
-        const bool pcol = (jl & 3) == Q;  // this lane's column of tile pb is the pivot column K_c, c = jl >> 2
+        const bool pcol = (jl & 3) == Q;  // position jl of tile pb is a pivot index K_c, c = jl >> 2
         const int c = jl >> 2;
         double dvc = dv[0];
         dvc = c == 1 ? dv[1] : dvc;
         dvc = c == 2 ? dv[2] : dvc;
         dvc = c == 3 ? dv[3] : dvc;
+        double xa = -(ri[0] * dv[0] + ri[1] * dv[1] + ri[2] * dv[2] + ri[3] * dv[3]);
+        xa += (w == pb && pcol) ? dvc : 0.0;                 // row 16w + jl is the pivot row K_c
+        const bool ycol = jl == Q + 4 * vl;                  // column jl of tile pb is K_vl
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            double yb = dv[0] * rc[0][t] + dv[1] * rc[1][t] + dv[2] * rc[2][t] + dv[3] * rc[3][t];
-            yb -= (pcol && t == pb) ? dvc : 0.0;
             v4d acc = {a.v[t][0], a.v[t][1], a.v[t][2], a.v[t][3]};
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb[t] - ((ycol && t == pb) ? 1.0 : 0.0), acc, 0, 0, 0);
             a.v[t][0] = acc[0]; a.v[t][1] = acc[1]; a.v[t][2] = acc[2]; a.v[t][3] = acc[3];
         }
         // pivot-block diagonal (K_r, K_r): this thread's element (row vl + 4r of wave pb, column jl of tile pb) with
