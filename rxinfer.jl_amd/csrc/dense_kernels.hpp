@@ -312,6 +312,30 @@ __device__ __forceinline__ bool spd_inv4_cof(const Sym<4>& A, Sym<4>& B, double&
     B(3, 3) = m3 * id;
     return ok;
 }
+// the same, but B = adj(A) = det·A⁻¹ (unscaled cofactors) and id = 1/det: a caller that needs one column scales four numbers
+__device__ __forceinline__ bool spd_adj4_cof(const Sym<4>& A, Sym<4>& B, double& det, double& id) {
+    const double a00 = A(0, 0), a10 = A(1, 0), a11 = A(1, 1), a20 = A(2, 0), a21 = A(2, 1), a22 = A(2, 2), a30 = A(3, 0),
+                 a31 = A(3, 1), a32 = A(3, 2), a33 = A(3, 3);
+    const double s0 = a00 * a11 - a10 * a10, s1 = a00 * a21 - a10 * a20, s2 = a00 * a31 - a10 * a30;
+    const double s3 = a10 * a21 - a11 * a20, s4 = a10 * a31 - a11 * a30, s5 = a20 * a31 - a21 * a30;
+    const double c5 = a22 * a33 - a32 * a32, c4 = a21 * a33 - a31 * a32, c3 = a21 * a32 - a31 * a22;
+    const double c2 = a20 * a33 - a30 * a32, c1 = a20 * a32 - a30 * a22, c0 = a20 * a31 - a30 * a21;
+    det = (s0 * c5 - s1 * c4 + s2 * c3) + (s3 * c2 - s4 * c1 + s5 * c0);
+    const double m3 = a20 * s3 - a21 * s1 + a22 * s0;  // leading 3×3 minor
+    const bool ok = (a00 > 0.0) && (s0 > 0.0) && (m3 > 0.0) && (det > 0.0);
+    id = rcp_pos(det);
+    B(0, 0) = (a11 * c5 - a21 * c4 + a31 * c3);
+    B(1, 0) = (-a10 * c5 + a21 * c2 - a31 * c1);
+    B(1, 1) = (a00 * c5 - a20 * c2 + a30 * c1);
+    B(2, 0) = (a10 * c4 - a11 * c2 + a31 * c0);
+    B(2, 1) = (-a00 * c4 + a10 * c2 - a30 * c0);
+    B(2, 2) = (a30 * s4 - a31 * s2 + a33 * s0);
+    B(3, 0) = (-a10 * c3 + a11 * c1 - a21 * c0);
+    B(3, 1) = (a00 * c3 - a10 * c1 + a20 * c0);
+    B(3, 2) = (-a30 * s3 + a31 * s1 - a32 * s0);
+    B(3, 3) = m3;
+    return ok;
+}
 
 template <int NT, int Q>
 struct Sweep4 {
@@ -355,19 +379,15 @@ struct Sweep4 {
 #pragma unroll
             for (int u = v; u < 4; ++u) d4(u, v) = col[u];
         }
-        double det;
-        ok = spd_inv4_cof(d4, di, det) && ok;
+        double det, idet;
+        ok = spd_adj4_cof(d4, di, det, idet) && ok;  // di = adj(D4)
         if (w == 0 && lane == 0) lp.mul(det);
-        // column vl of D4⁻¹ (= row vl: symmetric) — this lane's k index in the MFMA operand layout
+        // column vl of D4⁻¹ (= row vl: symmetric) — this lane's k index in the MFMA operand layout — as adj(D4)·e_vl / det with
+        // the unit vector as DATA (loop-invariant registers): FMAs instead of a select tree per entry
+        const double e0 = vl == 0 ? 1.0 : 0.0, e1 = vl == 1 ? 1.0 : 0.0, e2 = vl == 2 ? 1.0 : 0.0, e3 = vl == 3 ? 1.0 : 0.0;
         double dv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            double x = di(0, u);
-            x = vl == 1 ? di(1, u) : x;
-            x = vl == 2 ? di(2, u) : x;
-            x = vl == 3 ? di(3, u) : x;
-            dv[u] = x;
-        }
+        for (int u = 0; u < 4; ++u) dv[u] = (di(u, 0) * e0 + di(u, 1) * e1 + di(u, 2) * e2 + di(u, 3) * e3) * idet;
         const bool pcol = (jl & 3) == Q;  // position jl of tile pb is a pivot index K_c, c = jl >> 2
         const int c = jl >> 2;
         double dvc = dv[0];
