@@ -2098,6 +2098,19 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
     HIPCHK(e, hipSetDevice(e->device));
     HIPCHK(e, hipStreamSynchronize(e->stream));
     rxhip_status st;
+    // small results (the reference's own benchmark sizes): mean and covariance sit next to each other in the arena, so ONE
+    // device-to-host copy of the span serves both — a synchronous hipMemcpy costs ≈12 µs whatever its size
+    const size_t nm = (size_t)e->T * e->n_chains * e->d, nc = nm * e->d;
+    const bool same_layout = layout == RXHIP_LAYOUT_TIME_CHAIN || e->n_chains == 1;
+    if (mean && cov && same_layout && e->in_arena(e->d_mean) && e->in_arena(e->d_cov) && e->d_cov > e->d_mean &&
+        (size_t)((e->d_cov + nc) - e->d_mean) <= ((size_t)1 << 17)) {
+        const size_t span = (size_t)((e->d_cov + nc) - e->d_mean);
+        std::vector<double> stage(span);
+        HIPCHK(e, hipMemcpy(stage.data(), e->d_mean, sizeof(double) * span, hipMemcpyDeviceToHost));
+        std::memcpy(mean, stage.data(), sizeof(double) * nm);
+        std::memcpy(cov, stage.data() + (e->d_cov - e->d_mean), sizeof(double) * nc);
+        return RXHIP_OK;
+    }
     if (mean && (st = copy_out(e, e->d_mean, mean, e->d, layout))) return st;
     if (cov && (st = copy_out(e, e->d_cov, cov, e->d * e->d, layout))) return st;
     return RXHIP_OK;
