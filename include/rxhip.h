@@ -265,6 +265,12 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
 rxhip_status rxhip_get_marginals_device(rxhip_engine* e, int32_t var_id, const double** mean_dev,
                                         const double** cov_dev);
 
+/* posteriors of SELECTED chains, chain-major: mean [n][T][d], cov [n][T][d][d] (either may be NULL) — what `infer` returns
+ * for each of those chains alone (`result.posteriors[:x]`, src/inference/batch.jl:325-340); a strided device gather + one
+ * copy, so that a host can inspect a few chains of a 20 GB batch result without moving the batch. */
+rxhip_status rxhip_get_marginals_chains(rxhip_engine* e, int32_t var_id, const int64_t* chains, int64_t n, double* mean,
+                                        double* cov);
+
 /* replaces: score(model, BetheFreeEnergy{Float64}, checks) |> ScoreActor
  * (src/model/plugins/reactivemp_free_energy.jl:84-126, src/score/actor.jl:38-63).
  * per_iteration[i] = Bethe free energy of the whole batch (sum over chains) at iteration i of
@@ -375,6 +381,27 @@ rxhip_status rxhip_hgf_create(const rxhip_hgf_desc* desc, rxhip_engine** out);
 /* history[:zt], history[:xt] (KeepLast per observation): means and variances, each T*n_series doubles in `layout` */
 rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_var, double* x_mean, double* x_var,
                                    int32_t layout);
+
+/* ------------------------------------------------------------------------------------------
+ * Several GPUs (one process per GPU; chains / series / points shard).  The path's only exchange is the sum
+ * over shards of the Bethe free energy (reference: the single `sumreduce` of src/model/plugins/reactivemp_free_energy.jl:99-123
+ * over ALL nodes and variables of the model) and, for the mixture, of the responsibility-weighted statistics that
+ * form the messages toward m[k], p[k], s (products over all points, reactivemp_inference.jl:365-374).  Both run over
+ * RCCL (xGMI) on the engine's stream, in place on the engine's device buffers, as all-gather + a sum in ascending rank
+ * order: every rank obtains bit-identical totals, and the same totals on every run.  librccl is opened on first use.
+ * The communicator is a plain ncclComm_t: either the host's own (e.g. from AMDGPU.jl / torch) or one made with the three
+ * helpers below — rank 0 creates the 128-byte id, the host moves it to the other ranks by any means (file, socket, MPI.jl),
+ * every rank calls rxhip_comm_init_rank (collective).  Errors of the helpers: rxhip_comm_last_error() (thread-local).
+ * ------------------------------------------------------------------------------------------ */
+rxhip_status rxhip_comm_unique_id(char* id128);
+rxhip_status rxhip_comm_init_rank(void** comm, int32_t nranks, const char* id128, int32_t rank, int32_t device /* −1: current */);
+rxhip_status rxhip_comm_destroy(void* comm);
+const char* rxhip_comm_last_error(void);
+/* after rxhip_run[_async](…, want_free_energy = 1): per_iteration free energies of the last run become the sums over all
+ * ranks (asynchronous on the engine's stream; rxhip_get_free_energy afterwards returns the global values on every rank) */
+rxhip_status rxhip_allreduce_free_energy(rxhip_engine* e, void* rccl_comm);
+/* between rxhip_gmm_accumulate and rxhip_gmm_update: the statistics buffer becomes the sum over all ranks */
+rxhip_status rxhip_gmm_allreduce_statistics(rxhip_engine* e, void* rccl_comm);
 
 /* ------------------------------------------------------------------------------------------
  * measurement hooks (no reference counterpart; RxInferBenchmarkCallbacks is the closest,

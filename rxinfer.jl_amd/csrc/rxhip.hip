@@ -152,6 +152,26 @@ __global__ void k_transpose_rows(const double* __restrict__ in, double* __restri
     }
 }
 
+
+// out[i][t][k] = in[t][chains[i]][k]: posteriors of a few chains, chain-major (what `infer` returns for ONE chain)
+__global__ void k_gather_chains(const double* __restrict__ in, double* __restrict__ out, const long long* __restrict__ chains,
+                                long long n_sel, long long T, long long n_chains, int k) {
+    const long long total = n_sel * T * k;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const long long e = g % k, r = g / k, t = r % T, i = r / T;
+        out[g] = in[(t * n_chains + chains[i]) * k + e];
+    }
+}
+// out[j] = Σ_r buf[r][j], ranks in ascending order: the cross-GPU sums are bit-identical on every rank and from run to run
+// whatever algorithm the collective library picked for moving the bytes
+__global__ void k_rank_sum(const double* __restrict__ buf, double* __restrict__ out, int nranks, int n) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    double s = 0.0;
+    for (int r = 0; r < nranks; ++r) s += buf[(size_t)r * n + j];
+    out[j] = s;
+}
+
 // ------------------------------------------------------------------------------------------
 struct rxhip_engine {
     // one device allocation holds every buffer of a state-space engine (creation / destruction cost two driver calls
@@ -221,6 +241,9 @@ struct rxhip_engine {
     double k_ms[RXHIP_K_COUNT] = {};
     uint64_t k_n[RXHIP_K_COUNT] = {};
     std::string err = "";
+    // scratch of the cross-GPU sums (rxhip_allreduce_free_energy / rxhip_gmm_allreduce_statistics): [nranks][n]
+    double* d_coll = nullptr;
+    size_t coll_cap = 0;
 };
 
 
@@ -357,6 +380,23 @@ static rxhip_status fail(rxhip_engine* e, rxhip_status s, const char* fmt, ...) 
             return fail((e), RXHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_err), \
                         __FILE__, __LINE__);                                                         \
     } while (0)
+
+
+// Every entry point runs on the engine's device and leaves the CALLER's current device as it found it (a host that drives
+// several GPUs from one thread — torch, the Julia shim — must not be left on another device after a destroy / getter).
+struct DevGuard {
+    int prev = -1;
+    bool changed = false;
+    hipError_t set(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev == dev) return hipSuccess;
+        hipError_t err = hipSetDevice(dev);
+        changed = err == hipSuccess;
+        return err;
+    }
+    ~DevGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+};
+#define SET_DEVICE(e) DevGuard _dev_guard; HIPCHK((e), _dev_guard.set((e)->device))
 
 // ------------------------------------------------------------------------------------------
 // host dense helpers for the per-model tables (generic n; off the hot path)
@@ -1103,7 +1143,8 @@ int32_t rxhip_lgssm_supported(int32_t d, int32_t dy) { return (find_vtbl(d, dy) 
 const char* rxhip_last_error(const rxhip_engine* e) { return e ? e->err.c_str() : "null engine"; }
 
 static void free_all(rxhip_engine* e) {
-    if (e->device >= 0) (void)hipSetDevice(e->device);
+    DevGuard dg;
+    if (e->device >= 0) (void)dg.set(e->device);
     double** bufs[] = {&e->d_vtab, &e->d_scan, &e->d_filt, &e->d_mean, &e->d_cov, &e->d_cst, &e->d_tab, &e->d_agg, &e->d_elem,
                        &e->d_fstart, &e->d_beta, &e->d_fe_part, &e->d_fe_chain, &e->d_fe_total};
     for (auto b : bufs)
@@ -1120,6 +1161,7 @@ static void free_all(rxhip_engine* e) {
         if (*b) { (void)hipFree(*b); *b = nullptr; }
     for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend, &e->d_qtab, &e->d_loc, &e->d_aggpart, &e->d_bnd})
         if (*b) { if (!e->in_arena(*b)) (void)hipFree(*b); *b = nullptr; }
+    if (e->d_coll) { (void)hipFree(e->d_coll); e->d_coll = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     e->pending.clear();
@@ -1135,7 +1177,8 @@ rxhip_status rxhip_release_cached_memory(void) {
     ArenaPool& ap = arena_pool();
     std::lock_guard<std::mutex> g(ap.m);
     for (auto& b : ap.idle) {
-        (void)hipSetDevice(b.device);
+        DevGuard dg;
+        (void)dg.set(b.device);
         (void)hipFree(b.p);
     }
     ap.idle.clear();
@@ -1186,7 +1229,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->device = ds->device;
     } else
         HIPCHK(e, hipGetDevice(&e->device));
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     if (ds->stream) {
         e->stream = (hipStream_t)ds->stream;
     } else {
@@ -1346,7 +1389,7 @@ rxhip_status rxhip_gmm_create(const rxhip_gmm_desc* ds, rxhip_engine** out) {
         e->device = ds->device;
     } else
         HIPCHK(e, hipGetDevice(&e->device));
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     if (ds->stream) e->stream = (hipStream_t)ds->stream;
     else {
         HIPCHK(e, stream_acquire(e->device, &e->stream));
@@ -1407,7 +1450,7 @@ rxhip_status rxhip_mvgmm_create(const rxhip_mvgmm_desc* ds, rxhip_engine** out) 
         e->device = ds->device;
     } else
         HIPCHK(e, hipGetDevice(&e->device));
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     if (ds->stream) e->stream = (hipStream_t)ds->stream;
     else {
         HIPCHK(e, stream_acquire(e->device, &e->stream));
@@ -1455,7 +1498,7 @@ rxhip_status rxhip_gmm_begin_run(rxhip_engine* e, int32_t iterations) {
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
     if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     if (iterations > e->g.hist_cap) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         if (e->g.d_hist) HIPCHK(e, hipFree(e->g.d_hist));
@@ -1483,7 +1526,7 @@ rxhip_status rxhip_gmm_begin_run(rxhip_engine* e, int32_t iterations) {
 rxhip_status rxhip_gmm_accumulate(rxhip_engine* e) {
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (e->g.it >= e->g.iterations) return fail(e, RXHIP_ERR_STATE, "accumulate: no iteration left (call rxhip_gmm_begin_run)");
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     const bool resp = e->g.materialize && e->g.it == e->g.iterations - 1;
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_GMM_PASS))) return st;
@@ -1516,7 +1559,7 @@ rxhip_status rxhip_gmm_statistics_device(rxhip_engine* e, double** stats_dev, in
 rxhip_status rxhip_gmm_update(rxhip_engine* e, int32_t want_fe) {
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (e->g.it >= e->g.iterations) return fail(e, RXHIP_ERR_STATE, "update: no iteration left");
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_GMM_UPDATE))) return st;
     if (e->g.mvd) {
@@ -1542,7 +1585,7 @@ rxhip_status rxhip_gmm_update(rxhip_engine* e, int32_t want_fe) {
 rxhip_status rxhip_gmm_get_history(rxhip_engine* e, double* hist) {
     if (!e || e->kind != 1 || !hist) return RXHIP_ERR_BADARG;
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_history: no run yet");
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(hist, e->g.d_hist, sizeof(double) * (size_t)e->g.it * e->g.hist_stride, hipMemcpyDeviceToHost));
     return RXHIP_OK;
@@ -1551,7 +1594,7 @@ rxhip_status rxhip_gmm_get_responsibilities(rxhip_engine* e, double* resp) {
     if (!e || e->kind != 1 || !resp) return RXHIP_ERR_BADARG;
     if (!e->g.materialize) return fail(e, RXHIP_ERR_STATE, "responsibilities were not materialised (desc.materialize_responsibilities)");
     if (!e->ran || e->g.it < e->g.iterations) return fail(e, RXHIP_ERR_STATE, "get_responsibilities: run not finished");
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(resp, e->g.d_resp, sizeof(double) * (size_t)e->g.N * e->g.K, hipMemcpyDeviceToHost));
     return RXHIP_OK;
@@ -1609,7 +1652,7 @@ rxhip_status rxhip_hgf_create(const rxhip_hgf_desc* ds, rxhip_engine** out) {
         e->device = ds->device;
     } else
         HIPCHK(e, hipGetDevice(&e->device));
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     if (ds->stream) e->stream = (hipStream_t)ds->stream;
     else {
         HIPCHK(e, stream_acquire(e->device, &e->stream));
@@ -1633,7 +1676,7 @@ rxhip_status rxhip_hgf_create(const rxhip_hgf_desc* ds, rxhip_engine** out) {
 static rxhip_status hgf_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
     if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
     if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     const size_t C = (size_t)e->n_chains, T = (size_t)e->T;
     if (iterations > e->h.fe_cap) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -1790,7 +1833,7 @@ static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t
     if (!src || n != need) return fail(e, RXHIP_ERR_BADARG, "set_data: expected %zu doubles, got %zu", need, n);
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
         return fail(e, RXHIP_ERR_BADARG, "set_data: unknown layout %d", layout);
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     if (e->n_chains == 1) layout = RXHIP_LAYOUT_TIME_CHAIN;  // one chain: the two layouts coincide
     if (src_on_device && layout == RXHIP_LAYOUT_TIME_CHAIN) {  // zero-copy
         if (e->own_y && e->d_y && !e->in_arena(e->d_y)) HIPCHK(e, hipFree(e->d_y));
@@ -1837,8 +1880,29 @@ rxhip_status rxhip_set_data_device(rxhip_engine* e, int32_t var_id, const double
     return ingest(e, dev, n, layout, true);
 }
 
+// fold finished (kernel start, kernel end) event pairs into the per-kernel sums; with `wait` the stream has been drained and
+// every pair is finished.  Called from rxhip_sync and — so that long run_async loops stay bounded — from prof_begin.
+static rxhip_status prof_drain(rxhip_engine* e, bool wait) {
+    size_t done = 0;
+    for (auto& pe : e->pending) {
+        if (!wait && hipEventQuery(pe.b) != hipSuccess) break;  // events complete in stream order
+        float ms = 0.f;
+        HIPCHK(e, hipEventElapsedTime(&ms, pe.a, pe.b));
+        e->k_ms[pe.k] += ms;
+        e->k_n[pe.k] += 1;
+        e->pool.push_back(pe.a);
+        e->pool.push_back(pe.b);
+        ++done;
+    }
+    e->pending.erase(e->pending.begin(), e->pending.begin() + (long)done);
+    return RXHIP_OK;
+}
 static rxhip_status prof_begin(rxhip_engine* e, int k) {
     if (!e->profiling) return RXHIP_OK;
+    if (e->pending.size() >= 64) {
+        rxhip_status st = prof_drain(e, false);
+        if (st) return st;
+    }
     rxhip_engine::Pending p;
     p.k = k;
     for (hipEvent_t* ev : {&p.a, &p.b}) {
@@ -1883,7 +1947,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     }
     if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
     if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     if (iterations > e->fe_total_cap) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
         if (!e->in_arena(e->d_fe_total)) HIPCHK(e, hipFree(e->d_fe_total));
@@ -2017,17 +2081,9 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
 
 rxhip_status rxhip_sync(rxhip_engine* e) {
     if (!e) return RXHIP_ERR_BADARG;
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
-    for (auto& pe : e->pending) {
-        float ms = 0.f;
-        HIPCHK(e, hipEventElapsedTime(&ms, pe.a, pe.b));
-        e->k_ms[pe.k] += ms;
-        e->k_n[pe.k] += 1;
-        e->pool.push_back(pe.a);
-        e->pool.push_back(pe.b);
-    }
-    e->pending.clear();
+    if (rxhip_status pst = prof_drain(e, true)) return pst;
     int st = 0;
     HIPCHK(e, hipMemcpy(&st, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
     if (st) {
@@ -2078,7 +2134,7 @@ rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_va
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_history: no run yet");
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
         return fail(e, RXHIP_ERR_BADARG, "get_history: unknown layout %d", layout);
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     const size_t n = (size_t)e->T * e->n_chains;
     double* outs[4] = {z_mean, z_var, x_mean, x_var};
@@ -2095,7 +2151,7 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals: no run yet");
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
         return fail(e, RXHIP_ERR_BADARG, "get_marginals: unknown layout %d", layout);
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     rxhip_status st;
     // small results (the reference's own benchmark sizes): mean and covariance sit next to each other in the arena, so ONE
@@ -2119,7 +2175,7 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
 rxhip_status rxhip_get_free_energy(rxhip_engine* e, double* per_iteration) {
     if (!e || !per_iteration) return RXHIP_ERR_BADARG;
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(per_iteration, e->kind == 1 ? e->g.d_fe : e->kind == 2 ? e->h.d_fe_total : e->d_fe_total, sizeof(double) * e->last_iterations,
                         hipMemcpyDeviceToHost));
@@ -2129,7 +2185,7 @@ rxhip_status rxhip_get_free_energy_per_chain(rxhip_engine* e, double* per_chain)
     if (!e || !per_chain) return RXHIP_ERR_BADARG;
     if (e->kind == 1) return fail(e, RXHIP_ERR_BADARG, "per-chain free energy is not defined for the mixture engine");
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(per_chain, e->d_fe_chain, sizeof(double) * e->n_chains, hipMemcpyDeviceToHost));
     return RXHIP_OK;
@@ -2144,7 +2200,7 @@ rxhip_status rxhip_get_free_energy_device(rxhip_engine* e, double** fe_dev) {
 rxhip_status rxhip_copy_free_energy_to_device(rxhip_engine* e, double* dst_dev) {
     if (!e || !dst_dev) return RXHIP_ERR_BADARG;
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
-    HIPCHK(e, hipSetDevice(e->device));
+    SET_DEVICE(e);
     HIPCHK(e, hipMemcpyAsync(dst_dev, (e->kind == 1 ? e->g.d_fe : e->kind == 2 ? e->h.d_fe_total : e->d_fe_total) + (e->last_iterations - 1), sizeof(double),
                              hipMemcpyDeviceToDevice, e->stream));
     return RXHIP_OK;
@@ -2194,6 +2250,159 @@ rxhip_status rxhip_get_schedule(rxhip_engine* e, int32_t* segments, int64_t* seg
     if (segments) *segments = e->S;
     if (segment_len) *segment_len = e->L;
     return RXHIP_OK;
+}
+
+
+rxhip_status rxhip_get_marginals_chains(rxhip_engine* e, int32_t var_id, const int64_t* chains, int64_t n, double* mean,
+                                        double* cov) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (var_id != RXHIP_VAR_X || e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "get_marginals_chains: variable %d is not random", var_id);
+    if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals_chains: no run yet");
+    if (!chains || n <= 0) return fail(e, RXHIP_ERR_BADARG, "get_marginals_chains: empty chain list");
+    for (int64_t i = 0; i < n; ++i)
+        if (chains[i] < 0 || chains[i] >= e->n_chains) return fail(e, RXHIP_ERR_BADARG, "get_marginals_chains: chain %lld out of range", (long long)chains[i]);
+    SET_DEVICE(e);
+    const size_t nm = (size_t)n * e->T * e->d, nc = nm * e->d;
+    char* tmp = nullptr;
+    HIPCHK(e, hipMalloc(&tmp, sizeof(long long) * (size_t)n + sizeof(double) * (nm + nc)));
+    double* g_mean = (double*)tmp;
+    double* g_cov = g_mean + nm;
+    long long* d_ch = (long long*)(g_cov + nc);
+    rxhip_status st = RXHIP_OK;
+    auto chk = [&](hipError_t err, const char* what) {
+        if (err != hipSuccess && !st) st = fail(e, RXHIP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(err));
+    };
+    static_assert(sizeof(long long) == sizeof(int64_t), "chain ids are 64-bit");
+    chk(hipMemcpyAsync(d_ch, chains, sizeof(long long) * (size_t)n, hipMemcpyHostToDevice, e->stream), "chain list upload");
+    if (!st && mean) hipLaunchKernelGGL(k_gather_chains, dim3(1024), dim3(256), 0, e->stream, (const double*)e->d_mean, g_mean, (const long long*)d_ch, (long long)n, e->T, e->n_chains, e->d);
+    if (!st && cov) hipLaunchKernelGGL(k_gather_chains, dim3(1024), dim3(256), 0, e->stream, (const double*)e->d_cov, g_cov, (const long long*)d_ch, (long long)n, e->T, e->n_chains, e->d * e->d);
+    chk(hipGetLastError(), "gather launch");
+    chk(hipStreamSynchronize(e->stream), "gather");
+    if (!st && mean) chk(hipMemcpy(mean, g_mean, sizeof(double) * nm, hipMemcpyDeviceToHost), "copy of means");
+    if (!st && cov) chk(hipMemcpy(cov, g_cov, sizeof(double) * nc, hipMemcpyDeviceToHost), "copy of covariances");
+    (void)hipFree(tmp);
+    return st;
+}
+
+// ------------------------------------------------------------------------------------------
+// Cross-GPU exchange over RCCL (xGMI).  librccl is opened on first use, not linked: single-GPU hosts never need it, and
+// a process that already carries an RCCL (torch) keeps exactly that one.
+}  // extern "C"
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+namespace {
+struct Rccl {
+    void* h = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string err;
+    bool ok = false;
+};
+Rccl& rccl() {
+    static Rccl* r = [] {
+        Rccl* q = new Rccl;
+        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        q->h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);  // the copy the host process already uses, if any
+        for (int i = 0; !q->h && i < 3; ++i) q->h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        if (!q->h) { q->err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return q; }
+        bool all = true;
+        auto sym = [&](const char* n) { void* p = dlsym(q->h, n); if (!p) { all = false; q->err = std::string("librccl lacks ") + n; } return p; };
+        q->GetUniqueId = (decltype(q->GetUniqueId))sym("ncclGetUniqueId");
+        q->CommInitRank = (decltype(q->CommInitRank))sym("ncclCommInitRank");
+        q->CommDestroy = (decltype(q->CommDestroy))sym("ncclCommDestroy");
+        q->CommCount = (decltype(q->CommCount))sym("ncclCommCount");
+        q->AllGather = (decltype(q->AllGather))sym("ncclAllGather");
+        q->GetErrorString = (decltype(q->GetErrorString))sym("ncclGetErrorString");
+        q->ok = all;
+        return q;
+    }();
+    return *r;
+}
+thread_local std::string g_comm_err;
+// all-gather `n` doubles of every rank into the engine's scratch, then sum in rank order into `inout` (in place)
+rxhip_status ordered_allreduce(rxhip_engine* e, void* comm, double* inout, int n, const char* what) {
+    Rccl& r = rccl();
+    if (!r.ok) return fail(e, RXHIP_ERR_RCCL, "%s: %s", what, r.err.c_str());
+    if (!comm) return fail(e, RXHIP_ERR_BADARG, "%s: null communicator", what);
+    int nranks = 0;
+    ncclResult_t rc = r.CommCount((ncclComm_t)comm, &nranks);
+    if (rc != ncclSuccess) return fail(e, RXHIP_ERR_RCCL, "%s: ncclCommCount: %s", what, r.GetErrorString(rc));
+    if (nranks <= 1) return RXHIP_OK;  // one rank: the local value is the global one, bit for bit
+    SET_DEVICE(e);
+    const size_t need = (size_t)nranks * (size_t)n;
+    if (need > e->coll_cap) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (e->d_coll) HIPCHK(e, hipFree(e->d_coll));
+        e->d_coll = nullptr;
+        HIPCHK(e, hipMalloc(&e->d_coll, sizeof(double) * need));
+        e->coll_cap = need;
+    }
+    rc = r.AllGather(inout, e->d_coll, (size_t)n, ncclDouble, (ncclComm_t)comm, e->stream);
+    if (rc != ncclSuccess) return fail(e, RXHIP_ERR_RCCL, "%s: ncclAllGather: %s", what, r.GetErrorString(rc));
+    hipLaunchKernelGGL(k_rank_sum, dim3((n + 63) / 64), dim3(64), 0, e->stream, (const double*)e->d_coll, inout, nranks, n);
+    HIPCHK(e, hipGetLastError());
+    return RXHIP_OK;
+}
+}  // namespace
+extern "C" {
+
+const char* rxhip_comm_last_error(void) { return g_comm_err.c_str(); }
+
+rxhip_status rxhip_comm_unique_id(char* id128) {
+    if (!id128) return RXHIP_ERR_BADARG;
+    Rccl& r = rccl();
+    if (!r.ok) { g_comm_err = r.err; return RXHIP_ERR_RCCL; }
+    ncclUniqueId id;
+    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
+    ncclResult_t rc = r.GetUniqueId(&id);
+    if (rc != ncclSuccess) { g_comm_err = std::string("ncclGetUniqueId: ") + r.GetErrorString(rc); return RXHIP_ERR_RCCL; }
+    std::memcpy(id128, &id, sizeof id);
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_comm_init_rank(void** comm, int32_t nranks, const char* id128, int32_t rank, int32_t device) {
+    if (!comm || !id128 || nranks <= 0 || rank < 0 || rank >= nranks) return RXHIP_ERR_BADARG;
+    *comm = nullptr;
+    Rccl& r = rccl();
+    if (!r.ok) { g_comm_err = r.err; return RXHIP_ERR_RCCL; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_comm_err = "no HIP device"; return RXHIP_ERR_NO_DEVICE; }
+    DevGuard dg;
+    if (device >= 0) {
+        if (device >= ndev || dg.set(device) != hipSuccess) { g_comm_err = "device out of range"; return RXHIP_ERR_BADARG; }
+    }
+    ncclUniqueId id;
+    std::memcpy(&id, id128, sizeof id);
+    ncclComm_t c = nullptr;
+    ncclResult_t rc = r.CommInitRank(&c, nranks, id, rank);
+    if (rc != ncclSuccess) { g_comm_err = std::string("ncclCommInitRank: ") + r.GetErrorString(rc); return RXHIP_ERR_RCCL; }
+    *comm = (void*)c;
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_comm_destroy(void* comm) {
+    if (!comm) return RXHIP_OK;
+    Rccl& r = rccl();
+    if (!r.ok) { g_comm_err = r.err; return RXHIP_ERR_RCCL; }
+    ncclResult_t rc = r.CommDestroy((ncclComm_t)comm);
+    if (rc != ncclSuccess) { g_comm_err = std::string("ncclCommDestroy: ") + r.GetErrorString(rc); return RXHIP_ERR_RCCL; }
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_allreduce_free_energy(rxhip_engine* e, void* rccl_comm) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
+    double* fe = e->kind == 1 ? e->g.d_fe : e->kind == 2 ? e->h.d_fe_total : e->d_fe_total;
+    return ordered_allreduce(e, rccl_comm, fe, e->last_iterations, "allreduce_free_energy");
+}
+
+rxhip_status rxhip_gmm_allreduce_statistics(rxhip_engine* e, void* rccl_comm) {
+    if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
+    return ordered_allreduce(e, rccl_comm, e->g.d_totals, e->g.nq, "gmm_allreduce_statistics");
 }
 
 }  // extern "C"

@@ -110,6 +110,14 @@ SYMBOLS = [
     ("rxhip_get_marginals", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_int32]),
     ("rxhip_get_marginals_device", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p),
                                                     ctypes.POINTER(ctypes.c_void_p)]),
+    ("rxhip_get_marginals_chains", ctypes.c_int32, [_H, ctypes.c_int32, c_int64_p, ctypes.c_int64, c_double_p, c_double_p]),
+    ("rxhip_comm_unique_id", ctypes.c_int32, [ctypes.c_char_p]),
+    ("rxhip_comm_init_rank", ctypes.c_int32, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_int32, ctypes.c_char_p, ctypes.c_int32,
+                                              ctypes.c_int32]),
+    ("rxhip_comm_destroy", ctypes.c_int32, [ctypes.c_void_p]),
+    ("rxhip_comm_last_error", ctypes.c_char_p, []),
+    ("rxhip_allreduce_free_energy", ctypes.c_int32, [_H, ctypes.c_void_p]),
+    ("rxhip_gmm_allreduce_statistics", ctypes.c_int32, [_H, ctypes.c_void_p]),
     ("rxhip_get_free_energy", ctypes.c_int32, [_H, c_double_p]),
     ("rxhip_get_free_energy_per_chain", ctypes.c_int32, [_H, c_double_p]),
     ("rxhip_get_free_energy_device", ctypes.c_int32, [_H, ctypes.POINTER(ctypes.c_void_p)]),

@@ -63,6 +63,7 @@ class LGSSMEngine:
                 self._h = None
             raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
         self._data_ref = None
+        self._iters = 0
 
     # -- plumbing ---------------------------------------------------------------------------
     def _chk(self, st):
@@ -130,6 +131,16 @@ class LGSSMEngine:
         self._chk(_lib.lib().rxhip_get_marginals(self._h, _lib.VAR_X, _p(mean), _p(cov) if want_cov else None, lay))
         return mean, cov
 
+    def marginals_of_chains(self, chains, want_cov=True):
+        """Posteriors of the selected chains only, chain-major: mean [n][T][d], cov [n][T][d][d] (strided gather on the
+        device + one copy; rxhip_get_marginals_chains)."""
+        ch = np.ascontiguousarray(chains, dtype=np.int64).ravel()
+        mean = np.empty((ch.size, self.T, self.d))
+        cov = np.empty((ch.size, self.T, self.d, self.d)) if want_cov else None
+        self._chk(_lib.lib().rxhip_get_marginals_chains(self._h, _lib.VAR_X, ch.ctypes.data_as(_lib.c_int64_p), ch.size,
+                                                         _p(mean), _p(cov) if want_cov else None))
+        return mean, cov
+
     def marginals_device(self):
         m, c = ctypes.c_void_p(), ctypes.c_void_p()
         self._chk(_lib.lib().rxhip_get_marginals_device(self._h, _lib.VAR_X, ctypes.byref(m), ctypes.byref(c)))
@@ -152,6 +163,11 @@ class LGSSMEngine:
 
     def copy_free_energy_to_device(self, dst_ptr):
         self._chk(_lib.lib().rxhip_copy_free_energy_to_device(self._h, ctypes.c_void_p(dst_ptr)))
+
+    def allreduce_free_energy(self, comm):
+        """Sum the free energies of the last run over all ranks of the RCCL communicator `comm` (a `Communicator` or a raw
+        ncclComm_t address), in place on the device, on the engine's stream."""
+        self._chk(_lib.lib().rxhip_allreduce_free_energy(self._h, ctypes.c_void_p(int(getattr(comm, "handle", comm) or 0))))
 
     def counters(self):
         r, p, m = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
@@ -271,6 +287,12 @@ class GMMEngine:
         self._stats_view = _View()  # keep the descriptor object alive as long as the engine
         return torch.as_tensor(self._stats_view, device=f"cuda:{torch.cuda.current_device()}")
 
+    def allreduce_statistics(self, comm):
+        """Sum the statistics of this iteration over all ranks of the RCCL communicator (between accumulate and update)."""
+        self._chk(_lib.lib().rxhip_gmm_allreduce_statistics(self._h, ctypes.c_void_p(int(getattr(comm, "handle", comm) or 0))))
+
+    allreduce_free_energy = LGSSMEngine.allreduce_free_energy
+
     def update(self, free_energy=True):
         self._chk(_lib.lib().rxhip_gmm_update(self._h, int(bool(free_energy))))
 
@@ -370,6 +392,7 @@ class HGFEngine:
     free_energy_per_chain = LGSSMEngine.free_energy_per_chain
     free_energy_device = LGSSMEngine.free_energy_device
     copy_free_energy_to_device = LGSSMEngine.copy_free_energy_to_device
+    allreduce_free_energy = LGSSMEngine.allreduce_free_energy
     counters = LGSSMEngine.counters
     set_profiling = LGSSMEngine.set_profiling
     reset_kernel_times = LGSSMEngine.reset_kernel_times
@@ -394,3 +417,37 @@ class HGFEngine:
         outs = [np.empty(shp) for _ in range(4)]
         self._chk(_lib.lib().rxhip_hgf_get_history(self._h, *[_p(o) for o in outs], lay))
         return tuple(outs)
+
+
+class Communicator:
+    """RCCL communicator made through the C ABI (rxhip_comm_*): rank 0 calls `Communicator.unique_id()`, the 128 bytes
+    travel to the other ranks by any host-side means, every rank constructs `Communicator(nranks, id, rank)`."""
+
+    @staticmethod
+    def unique_id():
+        buf = ctypes.create_string_buffer(128)
+        st = _lib.lib().rxhip_comm_unique_id(buf)
+        if st != _lib.OK:
+            raise RxHipError(st, _lib.lib().rxhip_comm_last_error().decode())
+        return buf.raw
+
+    def __init__(self, nranks, unique_id, rank, device=-1):
+        if len(unique_id) != 128:
+            raise ValueError("unique_id must be the 128 bytes of Communicator.unique_id()")
+        self.nranks, self.rank = int(nranks), int(rank)
+        h = ctypes.c_void_p()
+        st = _lib.lib().rxhip_comm_init_rank(ctypes.byref(h), self.nranks, unique_id, self.rank, int(device))
+        if st != _lib.OK:
+            raise RxHipError(st, _lib.lib().rxhip_comm_last_error().decode())
+        self.handle = h.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            _lib.lib().rxhip_comm_destroy(ctypes.c_void_p(self.handle))
+            self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()

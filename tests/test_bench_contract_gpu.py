@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 @pytest.mark.gpu
 def test_bench_prints_the_contract_line():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--T", "3000",
-                          "--chains", "128", "--cpu-sample-chains", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--chains", "128", "--cpu-sample-chains", "2", "--no-extras"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1
@@ -30,3 +30,19 @@ def test_bench_prints_the_contract_line():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+    assert c["all_cores"]["cores"] == os.cpu_count() and c["all_cores"]["value"] > 0
+    assert c["free_energy_rel_vs_gpu"] < 1e-8  # both legs ran on the same observations
+    ps = d["parity_spot"]
+    assert ps["ok"] and ps["mean_rel"] < 1e-6 and ps["cov_rel"] < 1e-6 and ps["fe_rel"] < 1e-8
+
+
+@pytest.mark.gpu
+def test_bench_multi_gpu_request_on_a_single_gpu_box_fails_clearly():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run; with fewer than N
+    devices it must say so instead of hanging in a rendezvous."""
+    import torch
+
+    n = torch.cuda.device_count() + 1
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert out.returncode != 0 and "HIP device" in (out.stderr + out.stdout)
