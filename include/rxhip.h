@@ -121,7 +121,8 @@ enum {
     RXHIP_NODE_BERNOULLI = 9,             /* (out, p) */
     RXHIP_NODE_NORMAL_MIXTURE = 10,       /* (out, switch, m[1..K], p[1..K])  test/models/mixtures/gmm_univariate_tests.jl:16-19 */
     RXHIP_NODE_GCV = 11,                  /* (y, x, z, κ, ω)  test/models/statespace/hgf_tests.jl:28 */
-    RXHIP_NODE_WISHART = 12               /* (out, ν, S)  `Wishart(ν, S)`, test/models/mixtures/gmm_multivariate_tests.jl:23 */
+    RXHIP_NODE_WISHART = 12,              /* (out, ν, S)  `Wishart(ν, S)`, test/models/mixtures/gmm_multivariate_tests.jl:23 */
+    RXHIP_NODE_ADD = 13                   /* typeof(+), interfaces (out, in1, in2) — `x_prev + c`, test/models/statespace/ulgssm_tests.jl:12 */
 };
 enum { /* family of an `@initialization` marginal (InitMarExtraKey, src/model/plugins/initialization_plugin.jl:201-202) */
     RXHIP_INIT_NONE = 0,
@@ -164,9 +165,13 @@ typedef struct {
     double* V0; /* [d][d]   */
     int64_t* state_var; /* [T] variable id of x[t] in time order (nullable) */
     int64_t* data_var;  /* [T] variable id of y[t] in time order (nullable) */
+    int32_t deterministic; /* 1: noise-free drift chain `x[t] ~ x[t-1] + c` (P is zero, A the identity) */
+    double* c;             /* [d] drift (nullable); zero unless deterministic */
 } rxhip_lgssm_lowered;
 
-/* Host-only (no device needed): recognise a linear Gaussian state-space chain in `g`.  First call with all
+/* Host-only (no device needed): recognise a linear Gaussian state-space chain in `g` — MvNormalMeanCovariance or (scalar
+ * chains) NormalMeanVariance nodes, each mean either `A * x` through a `*` node or the state itself (identity map), in any
+ * mixture of the spellings of mlgssm_test.jl:9-66 — or the noise-free drift chain of ulgssm_tests.jl:8-15.  First call with all
  * pointer members of `out` NULL to learn d, dy, T; then with buffers to receive the constants.
  * RXHIP_ERR_UNSUPPORTED if the graph is not such a chain (message via rxhip_lowering_error()). */
 rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowered* out);
@@ -383,6 +388,25 @@ rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_va
                                    int32_t layout);
 
 /* ------------------------------------------------------------------------------------------
+ * Noise-free drift chain (reference model test/models/statespace/ulgssm_tests.jl:8-15):
+ *     x_prior ~ Normal(μ = m0, v = v0);  x[t] ~ x[t-1] + c;  y[t] ~ Normal(μ = x[t], v = obs_var)     t = 1…T
+ * (prior_through_transition = 1: the spelling above, x[1] = x_prior + c; 0: the prior sits on x[1] itself).  Every
+ * transition is a deterministic typeof(+) node, so the sweep through the `+`(:out) / `+`(:in1) rules and the message
+ * products is a reduction over time (csrc/drift_kernels.hpp).  Same handle protocol as the state-space engine:
+ * rxhip_set_data(RXHIP_VAR_Y, y, T*n_chains, layout), rxhip_run, rxhip_get_marginals (d = 1: mean, variance of x[1…T]),
+ * rxhip_get_free_energy[_per_chain].  rxhip_create builds it from the graph (RXHIP_NODE_ADD).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t T;
+    int64_t n_chains;
+    double m0, v0, c, obs_var;
+    int32_t prior_through_transition;
+    int32_t device;
+    void* stream;
+} rxhip_drift_chain_desc;
+rxhip_status rxhip_drift_chain_create(const rxhip_drift_chain_desc* desc, rxhip_engine** out);
+
+/* ------------------------------------------------------------------------------------------
  * Several GPUs (one process per GPU; chains / series / points shard).  The path's only exchange is the sum
  * over shards of the Bethe free energy (reference: the single `sumreduce` of src/model/plugins/reactivemp_free_energy.jl:99-123
  * over ALL nodes and variables of the model) and, for the mixture, of the responsibility-weighted statistics that
@@ -417,7 +441,8 @@ enum {
     RXHIP_K_GMM_REDUCE = 6,    /* mixture: block partials -> totals                            */
     RXHIP_K_GMM_UPDATE = 7,    /* mixture: new marginals of m[k], p[k], s + free energy        */
     RXHIP_K_HGF_FILTER = 8,    /* hierarchical Gaussian filter: all observations × VMP iterations */
-    RXHIP_K_COUNT = 9
+    RXHIP_K_DRIFT_CHAIN = 9,   /* noise-free drift chain: time reduction + marginals + free energy */
+    RXHIP_K_COUNT = 10
 };
 /* enable (1) / disable (0) per-kernel HIP-event timing on the engine's stream */
 rxhip_status rxhip_set_profiling(rxhip_engine* e, int32_t enabled);

@@ -623,6 +623,107 @@ done:
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Noise-free drift chain (test/models/statespace/ulgssm_tests.jl:8-15), reference schedule, scalars:
+ *     x_prior ~ Normal(μ = m0, v = v0);  x[t] ~ x[t-1] + c;  y[t] ~ Normal(μ = x[t], v = obs_var)
+ * Rules restated (ReactiveMP, univariate Normal family; messages in mean–variance form, products in weighted-mean–
+ * precision form):
+ *   NormalMeanVariance(:out)(m_μ::PointMass, q_v::PointMass) = N(m0, v0)             (prior node)
+ *   NormalMeanVariance(:μ)(m_out::PointMass(y), q_v::PointMass) = N(y, v)            (observation node)
+ *   typeof(+)(:out)(m_in1, m_in2::PointMass(c)) = N(mean + c, var);  typeof(+)(:in1)(m_out, m_in2) = N(mean − c, var)
+ * Bethe free energy: prior node U − H[q(x_prior)]; every `+` node −H[q(in1)] (deterministic node; its constant input
+ * is a counted −∞, reactivemp_force_marginal_computation_plugin.jl:52-98); observation nodes U over q(x[t]) − H[q(x[t])];
+ * variables (degree − 1)·H; point entropies cancelled as reactivemp_free_energy.jl:108-123.
+ * ------------------------------------------------------------------------------------------ */
+int rxo_drift_chain_bp(long long T, const double* y, double m0, double v0, double c, double obs_var,
+                       int prior_through_transition, double* post_mean, double* post_var, double* free_energy,
+                       rxo_counters* counters) {
+    if (T <= 0 || !y || !post_mean || !post_var) return RXO_ERR_BADARG;
+    if (!(v0 > 0.0) || !(obs_var > 0.0)) return RXO_ERR_NOT_POSDEF;
+    const int ptt = prior_through_transition ? 1 : 0;
+    const long long n = T + ptt; /* states x_prior (if ptt), x[1..T] */
+    rxo_counters cn = {0, 0, 0};
+    /* inbound messages at every state, (ξ, w) form; have_* flags */
+    double* fx = (double*)malloc(sizeof(double) * (size_t)n * 8);
+    if (!fx) return RXO_ERR_BADARG;
+    double *fw = fx + n, *bx = fw + n, *bw = bx + n, *ox = bw + n, *ow = ox + n, *qm = ow + n, *qv = qm + n;
+    /* forward */
+    double m = m0, v = v0;
+    cn.rule_calls++; /* prior node (:out) */
+    for (long long k = 0; k < n; ++k) {
+        if (k > 0) { /* `+`(:out)(message from x[k-1] toward the node = prod of its other inbound messages) */
+            double xi = fx[k - 1], w = fw[k - 1];
+            if (k - 1 >= ptt) { xi += ox[k - 1]; w += ow[k - 1]; cn.products++; }
+            m = xi / w + c;
+            v = 1.0 / w;
+            cn.rule_calls++;
+        }
+        fx[k] = m / v;
+        fw[k] = 1.0 / v;
+        if (k >= ptt) { /* observation node (:μ): N(y, obs_var) */
+            ox[k] = y[k - ptt] / obs_var;
+            ow[k] = 1.0 / obs_var;
+            cn.rule_calls++;
+        } else
+            ox[k] = ow[k] = 0.0;
+    }
+    /* backward: toward x[k-1] through `+`(:in1) */
+    bx[n - 1] = bw[n - 1] = 0.0;
+    for (long long k = n - 1; k >= 1; --k) {
+        double xi = ox[k], w = ow[k];
+        if (k < n - 1) { xi += bx[k]; w += bw[k]; cn.products++; }
+        const double mm = xi / w - c, vv = 1.0 / w;
+        bx[k - 1] = mm / vv;
+        bw[k - 1] = 1.0 / vv;
+        cn.rule_calls++;
+    }
+    /* marginals */
+    for (long long k = 0; k < n; ++k) {
+        double xi = fx[k], w = fw[k];
+        int parts = 1;
+        if (k >= ptt) { xi += ox[k]; w += ow[k]; ++parts; }
+        if (k < n - 1) { xi += bx[k]; w += bw[k]; ++parts; }
+        cn.products += (uint64_t)(parts - 1);
+        cn.marginals++;
+        qm[k] = xi / w;
+        qv[k] = 1.0 / w;
+        if (k >= ptt) { post_mean[k - ptt] = qm[k]; post_var[k - ptt] = qv[k]; }
+    }
+    if (counters) *counters = cn;
+    int rc = RXO_OK;
+    if (free_energy) {
+        creal nodes = {0.0, 0}, vars = {0.0, 0};
+        long point_entropies = 0;
+        for (long long k = 0; k < n; ++k) {
+            const double H = 0.5 * (LOG2PI + 1.0 + log(qv[k]));
+            if (k == 0) { /* prior node: clusters (out), (μ const), (v const) */
+                nodes.v += 0.5 * (LOG2PI + log(v0) + ((qm[0] - m0) * (qm[0] - m0) + qv[0]) / v0) - H;
+                nodes.ninf += 2;
+                point_entropies += 2;
+            } else { /* `+` node k: −H[q(in1)] and the counted point mass of c */
+                nodes.v += -0.5 * (LOG2PI + 1.0 + log(qv[k - 1]));
+                nodes.ninf += 1;
+                point_entropies += 1;
+            }
+            if (k >= ptt) { /* observation node: out = PointMass(y), v const */
+                const double e = y[k - ptt] - qm[k];
+                nodes.v += 0.5 * (LOG2PI + log(obs_var) + (e * e + qv[k]) / obs_var) - H;
+                nodes.ninf += 2;
+                point_entropies += 2;
+            }
+            const int deg = 1 + (k >= ptt ? 1 : 0) + (k < n - 1 ? 1 : 0);
+            vars.v += (deg - 1) * H;
+        }
+        const long ninf = nodes.ninf + vars.ninf - point_entropies;
+        double fe = nodes.v + vars.v;
+        if (ninf != 0) fe = ninf > 0 ? INFINITY : -INFINITY;
+        *free_energy = fe;
+        if (!isfinite(fe)) rc = RXO_ERR_NONFINITE_FE;
+    }
+    free(fx);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Independent textbook implementation, used ONLY to validate the restatement above
  * (identity: BP on a tree == Kalman filter + RTS smoother; Bethe FE == −log p(y)).
  * ------------------------------------------------------------------------------------------ */

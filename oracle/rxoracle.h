@@ -93,6 +93,15 @@ int rxo_lgssm_filter(int d, int dy, int T, const double* A, const double* B, con
                      const double* m0, const double* V0, int prior_through_transition, const double* y,
                      double* hist_mean, double* hist_cov, double* fe, rxo_counters* counters);
 
+/* Noise-free drift chain (test/models/statespace/ulgssm_tests.jl:8-15) in the reference's message schedule:
+ *     x_prior ~ Normal(μ = m0, v = v0);  x[t] ~ x[t-1] + c;  y[t] ~ Normal(μ = x[t], v = obs_var),  t = 1..T
+ * (prior_through_transition = 0: the prior sits on x[1]).  post_mean / post_var [T]: q(x[t]); free_energy (nullable):
+ * full Bethe sum with CountingReal bookkeeping — reproduces the reference's golden 1854.297647 (ulgssm_tests.jl:48)
+ * on the regenerated data (tests/golden/ulgssm_stablerng123.npz). */
+int rxo_drift_chain_bp(long long T, const double* y, double m0, double v0, double c, double obs_var,
+                       int prior_through_transition, double* post_mean, double* post_var, double* free_energy,
+                       rxo_counters* counters);
+
 /* Independent cross-check used only to validate the oracle itself: textbook Kalman filter +
  * RTS smoother and -log p(y) via innovations.  Same argument layout as rxo_lgssm_bp. */
 int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B, const double* P,

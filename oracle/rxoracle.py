@@ -55,6 +55,9 @@ def lib():
         _LIB.rxo_mvgmm_vmp.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_int] + [dp] * 7 + [ctypes.c_int, dp, dp, dp]
         _LIB.rxo_lgssm_filter.restype = ctypes.c_int
         _LIB.rxo_lgssm_filter.argtypes = [ctypes.c_int] * 3 + [dp] * 6 + [ctypes.c_int] + [dp] * 4 + [ctypes.POINTER(Counters)]
+        _LIB.rxo_drift_chain_bp.restype = ctypes.c_int
+        _LIB.rxo_drift_chain_bp.argtypes = [ctypes.c_longlong, dp] + [ctypes.c_double] * 4 + [ctypes.c_int, dp, dp, dp,
+                                                                                                 ctypes.POINTER(Counters)]
         _LIB.rxo_gauss_hermite.restype = ctypes.c_int
         _LIB.rxo_gauss_hermite.argtypes = [ctypes.c_int, dp, dp]
     return _LIB
@@ -81,6 +84,19 @@ def lgssm_bp(A, B, P, Q, m0, V0, y, prior_through_transition=False, free_energy=
     if rc:
         raise RuntimeError(f"rxo_lgssm_bp failed with status {rc}")
     return mean, cov, (fe.value if free_energy else None), cnt
+
+
+def drift_chain_bp(y, m0, v0, c, obs_var, prior_through_transition=True, free_energy=True):
+    """Noise-free drift chain, one chain (rxo_drift_chain_bp).  Returns mean [T], var [T], fe | None, Counters."""
+    y = _c(y).ravel()
+    mean, var = np.empty(y.size), np.empty(y.size)
+    fe = np.zeros(1)
+    cnt = Counters()
+    rc = lib().rxo_drift_chain_bp(y.size, _p(y), float(m0), float(v0), float(c), float(obs_var), int(prior_through_transition),
+                                  _p(mean), _p(var), _p(fe) if free_energy else None, ctypes.byref(cnt))
+    if rc:
+        raise RuntimeError(f"rxo_drift_chain_bp failed with status {rc}")
+    return mean, var, (float(fe[0]) if free_energy else None), cnt
 
 
 def lgssm_kalman_rts(A, B, P, Q, m0, V0, y, prior_through_transition=False):

@@ -30,7 +30,8 @@ struct Lgssm {
     int d = 0, dy = 0;
     long long T = 0;
     int ptt = 0;
-    std::vector<double> A, B, P, Q, m0, V0;
+    int deterministic = 0;  // 1: every transition is `x[t] ~ x[t-1] + c` (typeof(+) with a constant, no state noise)
+    std::vector<double> A, B, P, Q, m0, V0, c;
     std::vector<long long> state_var, data_var;
 };
 
@@ -45,11 +46,22 @@ inline rxhip_status check_tables(const rxhip_graph_desc* g) {
     if (!g || g->n_variables <= 0 || g->n_factors <= 0 || !g->var_kind || !g->var_rows || !g->var_cols || !g->var_const ||
         !g->factor_type || !g->factor_iface || (g->n_const > 0 && !g->const_pool))
         return badarg("graph descriptor has null tables");
+    if (g->factor_iface_ptr) {
+        if (g->factor_iface_ptr[0] < 0) return badarg("factor_iface_ptr must start at a non-negative offset");
+        for (long long f = 0; f < g->n_factors; ++f)
+            if (g->factor_iface_ptr[f + 1] < g->factor_iface_ptr[f]) return badarg("factor_iface_ptr is not non-decreasing");
+    }
     for (long long f = 0; f < g->n_factors; ++f) {
         const int n = n_iface(g, f);
         if (n <= 0) return badarg("factor without interfaces");
         for (int k = 0; k < n; ++k)
             if (iface(g, f, k) < 0 || iface(g, f, k) >= g->n_variables) return badarg("factor interface refers to an unknown variable");
+    }
+    for (long long v = 0; v < g->n_variables; ++v) {
+        if (g->var_rows[v] <= 0 || g->var_cols[v] <= 0) return badarg("variable with a non-positive shape");
+        if (g->var_kind[v] == RXHIP_VARKIND_CONST && g->var_const[v] >= 0 &&
+            g->var_const[v] + (long long)g->var_rows[v] * g->var_cols[v] > g->n_const)
+            return badarg("constant value lies outside the constant pool");
     }
     return RXHIP_OK;
 }
@@ -81,115 +93,171 @@ inline bool const_value(const rxhip_graph_desc* g, long long v, int rows, int co
     *out = g->const_pool + g->var_const[v];
     return true;
 }
+// two constant variables with equal values (both must carry a value inside the pool)
 inline bool same_const(const rxhip_graph_desc* g, long long a, long long b) {
     if (a == b) return true;
+    if (g->var_kind[a] != RXHIP_VARKIND_CONST || g->var_kind[b] != RXHIP_VARKIND_CONST) return false;
     if (g->var_rows[a] != g->var_rows[b] || g->var_cols[a] != g->var_cols[b]) return false;
-    const size_t n = (size_t)g->var_rows[a] * g->var_cols[a];
-    return std::memcmp(g->const_pool + g->var_const[a], g->const_pool + g->var_const[b], n * sizeof(double)) == 0;
+    const long long n = (long long)g->var_rows[a] * g->var_cols[a];
+    if (g->var_const[a] < 0 || g->var_const[b] < 0 || g->var_const[a] + n > g->n_const || g->var_const[b] + n > g->n_const) return false;
+    return std::memcmp(g->const_pool + g->var_const[a], g->const_pool + g->var_const[b], (size_t)n * sizeof(double)) == 0;
 }
 
-// Recognise   prior:  MvN(out = x_first, μ = const, Σ = const)
-//             per state x:  [`*`(out = b, A = B, in = x);  MvN(out = y (data), μ = b, Σ = Q)]      (observation)
-//                           [`*`(out = a, A = A, in = x);  MvN(out = x_next (random), μ = a, Σ = P)] (transition)
-// with time-invariant constants.  Node order in the tables is irrelevant.
+// Recognise a linear Gaussian state-space chain.  A "Gaussian node" is MvNormalMeanCovariance(out, μ, Σ) or — for scalar
+// chains — NormalMeanVariance(out, μ, v), Σ / v constant:
+//     prior:        Gaussian(out = x_first, μ = const)
+//     per state x:  Gaussian(out = y (data), μ = B·x)                 observation; B·x is either the output of a
+//                   Gaussian(out = x_next (random), μ = A·x)          `*`(out, A const, in = x) node or x itself (B, A = I)
+// (`y ~ MvNormal(μ = B * x, Σ = Q)`, `x ~ Normal(μ = x_prev, v = …)` and their mixtures) with time-invariant constants, and
+// the noise-free drift chain of test/models/statespace/ulgssm_tests.jl:8-15,
+//     x[t] ~ x[t-1] + c        `+`(out = x_next, in1 = x, in2 = c const)  (or in1 const)
+// whose every transition is such a node.  Node order in the tables is irrelevant.
 inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
     if (rxhip_status st = check_tables(g)) return st;
     const long long NV = g->n_variables, NF = g->n_factors;
     for (long long f = 0; f < NF; ++f)
         if (n_iface(g, f) != 3) return unsupported("node with " + std::to_string(n_iface(g, f)) + " interfaces in a state-space chain");
-    // `*` node producing each (anonymous) variable, and MvN nodes by their μ variable
-    std::vector<long long> mul_of_out(NV, -1), mvn_of_mu(NV, -1);
-    std::vector<std::vector<long long>> mul_of_in(NV);
+    // `*` node producing each (anonymous) variable; Gaussian node by its μ variable; `+` nodes by their random input
+    std::vector<long long> mul_of_out(NV, -1), add_of_in(NV, -1), writer(NV, -1);
+    std::vector<std::vector<long long>> mul_of_in(NV), gauss_by_mu(NV);
     long long prior = -1;
+    bool scalar_nodes = false;
+    auto writes = [&](long long v, long long f) -> bool {  // one factor "produces" a variable: rejects merges and cycles early
+        if (writer[v] >= 0) return false;
+        writer[v] = f;
+        return true;
+    };
     for (long long f = 0; f < NF; ++f) {
         const long long io[3] = {iface(g, f, 0), iface(g, f, 1), iface(g, f, 2)};
-        if (g->factor_type[f] == RXHIP_NODE_MULTIPLY) {
+        const int t = g->factor_type[f];
+        if (t == RXHIP_NODE_MULTIPLY) {
             if (g->var_kind[io[1]] != RXHIP_VARKIND_CONST) return unsupported("`*` node with a non-constant matrix (no device schedule)");
             if (g->var_kind[io[2]] != RXHIP_VARKIND_RANDOM || g->var_kind[io[0]] != RXHIP_VARKIND_RANDOM)
                 return unsupported("`*` node must connect two random variables");
-            if (mul_of_out[io[0]] >= 0) return unsupported("variable produced by two `*` nodes");
+            if (mul_of_out[io[0]] >= 0 || !writes(io[0], f)) return unsupported("variable produced by two nodes");
             mul_of_out[io[0]] = f;
             mul_of_in[io[2]].push_back(f);
-        } else if (g->factor_type[f] == RXHIP_NODE_MVNORMAL_MEAN_COV) {
-            if (g->var_kind[io[2]] != RXHIP_VARKIND_CONST) return unsupported("MvNormalMeanCovariance with a non-constant covariance");
+        } else if (t == RXHIP_NODE_MVNORMAL_MEAN_COV || t == RXHIP_NODE_NORMAL_MEAN_VARIANCE) {
+            if (t == RXHIP_NODE_NORMAL_MEAN_VARIANCE) scalar_nodes = true;
+            if (g->var_kind[io[2]] != RXHIP_VARKIND_CONST) return unsupported("Gaussian node with a non-constant covariance");
+            if (g->var_kind[io[0]] == RXHIP_VARKIND_CONST) return unsupported("Gaussian node with a constant output");
+            if (g->var_kind[io[0]] == RXHIP_VARKIND_RANDOM && !writes(io[0], f)) return unsupported("random variable that is the output of two nodes: not a chain");
             if (g->var_kind[io[1]] == RXHIP_VARKIND_CONST) {
                 if (prior >= 0) return unsupported("more than one prior node: not a single chain");
                 prior = f;
-            } else {
-                if (mvn_of_mu[io[1]] >= 0) return unsupported("mean variable shared by two MvNormal nodes");
-                mvn_of_mu[io[1]] = f;
-            }
+            } else if (g->var_kind[io[1]] == RXHIP_VARKIND_RANDOM) {
+                gauss_by_mu[io[1]].push_back(f);  // an anonymous `A * x` feeds exactly one; a state may feed its observation and its transition
+            } else
+                return unsupported("Gaussian node whose mean is a data variable");
+        } else if (t == RXHIP_NODE_ADD) {
+            const bool c1 = g->var_kind[io[1]] == RXHIP_VARKIND_CONST, c2 = g->var_kind[io[2]] == RXHIP_VARKIND_CONST;
+            if (c1 == c2) return unsupported("`+` node needs exactly one constant input");
+            const long long xin = c1 ? io[2] : io[1];
+            if (g->var_kind[xin] != RXHIP_VARKIND_RANDOM || g->var_kind[io[0]] != RXHIP_VARKIND_RANDOM) return unsupported("`+` node must connect two random variables");
+            if (add_of_in[xin] >= 0) return unsupported("state with two `+` transitions: not a chain");
+            if (!writes(io[0], f)) return unsupported("random variable that is the output of two nodes: not a chain");
+            add_of_in[xin] = f;
         } else
-            return unsupported("node type " + std::to_string(g->factor_type[f]) + " has no device schedule");
+            return unsupported("node type " + std::to_string(t) + " has no device schedule");
     }
-    if (prior < 0) return unsupported("no prior node (MvNormalMeanCovariance with constant mean)");
+    if (prior < 0) return unsupported("no prior node (Gaussian node with constant mean)");
+    for (long long v = 0; v < NV; ++v)
+        if (mul_of_out[v] >= 0 && gauss_by_mu[v].size() != 1)
+            return unsupported(gauss_by_mu[v].empty() ? "`*` node whose output feeds no Gaussian mean" : "mean variable shared by two Gaussian nodes");
     long long x = iface(g, prior, 0);
     if (g->var_kind[x] != RXHIP_VARKIND_RANDOM) return unsupported("prior node on a non-random variable");
     const int d = g->var_rows[x];
+    if (scalar_nodes && d != 1) return unsupported("NormalMeanVariance node in a vector-valued chain");
     const double *m0, *V0;
     if (!const_value(g, iface(g, prior, 1), d, 1, &m0) || !const_value(g, iface(g, prior, 2), d, d, &V0))
         return badarg("prior constants have the wrong shape");
-    long long vA = -1, vP = -1, vB = -1, vQ = -1;
+    // a branch out of state x: the Gaussian node it feeds and the constant matrix in between (-1: identity)
+    struct Branch { long long gauss, matrix; };
+    long long vA = -2, vP = -1, vB = -2, vQ = -1, vC = -1;  // -2: not seen yet, -1: identity
+    int n_noisy = 0, n_det = 0;
     long long used_factors = 1;
     bool first = true;
+    std::vector<char> visited(NV, 0);
     L = Lgssm();
-    while (true) {
-        long long obs_mul = -1, tr_mul = -1;
-        for (long long f : mul_of_in[x]) {
-            const long long outv = iface(g, f, 0);
-            const long long mv = mvn_of_mu[outv];
-            if (mv < 0) return unsupported("`*` node whose output feeds no MvNormal mean");
-            const long long target = iface(g, mv, 0);
+    for (long long guard = 0; guard <= NV; ++guard) {
+        if (visited[x]) return unsupported("state visited twice: the graph has a cycle, not a chain");
+        visited[x] = 1;
+        std::vector<Branch> br;
+        if (mul_of_out[x] >= 0) return unsupported("the output of a `*` node used as a state");
+        for (long long f : mul_of_in[x]) br.push_back({gauss_by_mu[iface(g, f, 0)][0], iface(g, f, 1)});
+        for (long long gn : gauss_by_mu[x]) br.push_back({gn, -1});  // Gaussian nodes reading the state directly (A, B = I)
+        long long obs = -1, obs_m = -1, tr = -1, tr_m = -1;
+        for (const Branch& b : br) {
+            const long long target = iface(g, b.gauss, 0);
             if (g->var_kind[target] == RXHIP_VARKIND_DATA) {
-                if (obs_mul >= 0) return unsupported("state with two observation branches");
-                obs_mul = f;
-            } else if (g->var_kind[target] == RXHIP_VARKIND_RANDOM) {
-                if (tr_mul >= 0) return unsupported("state with two transitions: not a chain");
-                tr_mul = f;
-            } else
-                return unsupported("MvNormal with a constant output");
+                if (obs >= 0) return unsupported("state with two observation branches");
+                obs = b.gauss; obs_m = b.matrix;
+            } else {
+                if (tr >= 0) return unsupported("state with two transitions: not a chain");
+                tr = b.gauss; tr_m = b.matrix;
+            }
+            used_factors += b.matrix >= 0 ? 2 : 1;
         }
-        if (obs_mul >= 0) {
-            const long long mv = mvn_of_mu[iface(g, obs_mul, 0)];
-            const long long b = iface(g, obs_mul, 1), q = iface(g, mv, 2);
-            if (vB < 0) { vB = b; vQ = q; }
-            else if (!same_const(g, vB, b) || !same_const(g, vQ, q)) return unsupported("time-varying observation model");
+        const long long add = add_of_in[x];
+        if (add >= 0 && tr >= 0) return unsupported("state with two transitions: not a chain");
+        if (obs >= 0) {
+            const long long q = iface(g, obs, 2);
+            if (vB == -2) { vB = obs_m; vQ = q; }
+            else if ((vB < 0) != (obs_m < 0) || (vB >= 0 && !same_const(g, vB, obs_m)) || !same_const(g, vQ, q)) return unsupported("time-varying observation model");
             L.state_var.push_back(x);
-            L.data_var.push_back(iface(g, mv, 0));
-            used_factors += 2;
-        } else if (first && tr_mul >= 0) {
+            L.data_var.push_back(iface(g, obs, 0));
+        } else if (first && (tr >= 0 || add >= 0)) {
             L.ptt = 1;  // x0 ~ prior without an observation: test/models/statespace/mlgssm_test.jl:9-17
         } else
             return unsupported("state variable without an observation");
         first = false;
-        if (tr_mul < 0) break;
-        const long long mv = mvn_of_mu[iface(g, tr_mul, 0)];
-        const long long a = iface(g, tr_mul, 1), pv = iface(g, mv, 2);
-        if (vA < 0) { vA = a; vP = pv; }
-        else if (!same_const(g, vA, a) || !same_const(g, vP, pv)) return unsupported("time-varying transition model");
-        used_factors += 2;
-        x = iface(g, mv, 0);
+        if (tr >= 0) {
+            const long long pv = iface(g, tr, 2);
+            if (vA == -2) { vA = tr_m; vP = pv; }
+            else if ((vA < 0) != (tr_m < 0) || (vA >= 0 && !same_const(g, vA, tr_m)) || !same_const(g, vP, pv)) return unsupported("time-varying transition model");
+            ++n_noisy;
+            x = iface(g, tr, 0);
+        } else if (add >= 0) {
+            const long long cv = g->var_kind[iface(g, add, 1)] == RXHIP_VARKIND_CONST ? iface(g, add, 1) : iface(g, add, 2);
+            if (vC < 0) vC = cv;
+            else if (!same_const(g, vC, cv)) return unsupported("time-varying drift");
+            ++n_det;
+            used_factors += 1;
+            x = iface(g, add, 0);
+        } else
+            break;
         if (g->var_rows[x] != d) return unsupported("state dimension changes along the chain");
     }
     if (used_factors != NF) return unsupported("graph has factors outside the state-space chain");
+    if (n_det > 0 && n_noisy > 0) return unsupported("chain mixing noisy and noise-free (`+`) transitions");
     L.T = (long long)L.state_var.size();
-    if (L.T <= 0 || vB < 0) return unsupported("chain without observations");
+    if (L.T <= 0 || vB == -2) return unsupported("chain without observations");
     L.d = d;
-    L.dy = g->var_rows[vB];
-    const double *pA = nullptr, *pP = nullptr, *pB, *pQ;
-    if (!const_value(g, vB, L.dy, d, &pB) || !const_value(g, vQ, L.dy, L.dy, &pQ)) return badarg("observation constants have the wrong shape");
-    if (vA >= 0 && (!const_value(g, vA, d, d, &pA) || !const_value(g, vP, d, d, &pP))) return badarg("transition constants have the wrong shape");
+    L.dy = g->var_rows[L.data_var[0]];
+    const double *pA = nullptr, *pP = nullptr, *pB = nullptr, *pQ;
+    if (vB >= 0 && !const_value(g, vB, L.dy, d, &pB)) return badarg("observation matrix has the wrong shape");
+    if (vB < 0 && L.dy != d) return unsupported("observation without a `*` node must have the state's dimension");
+    if (!const_value(g, vQ, L.dy, L.dy, &pQ)) return badarg("observation noise has the wrong shape");
+    if (n_noisy > 0) {
+        if (vA >= 0 && !const_value(g, vA, d, d, &pA)) return badarg("transition matrix has the wrong shape");
+        if (!const_value(g, vP, d, d, &pP)) return badarg("state noise has the wrong shape");
+    }
+    auto eye = [](std::vector<double>& M, int r, int c) { M.assign((size_t)r * c, 0.0); for (int i = 0; i < (r < c ? r : c); ++i) M[(size_t)i * c + i] = 1.0; };
     L.m0.assign(m0, m0 + d);
     L.V0.assign(V0, V0 + (size_t)d * d);
-    L.B.assign(pB, pB + (size_t)L.dy * d);
+    if (pB) L.B.assign(pB, pB + (size_t)L.dy * d); else eye(L.B, L.dy, d);
     L.Q.assign(pQ, pQ + (size_t)L.dy * L.dy);
-    if (pA) {
-        L.A.assign(pA, pA + (size_t)d * d);
-        L.P.assign(pP, pP + (size_t)d * d);
-    } else {  // single time step: no transition in the graph
-        L.A.assign((size_t)d * d, 0.0);
-        L.P.assign((size_t)d * d, 0.0);
-        for (int i = 0; i < d; ++i) L.A[i * d + i] = L.P[i * d + i] = 1.0;
+    if (pA) L.A.assign(pA, pA + (size_t)d * d); else eye(L.A, d, d);
+    if (pP) L.P.assign(pP, pP + (size_t)d * d);
+    else if (n_det > 0) L.P.assign((size_t)d * d, 0.0);  // noise-free transitions
+    else eye(L.P, d, d);                                 // single time step: no transition in the graph
+    L.c.assign(d, 0.0);
+    if (n_det > 0) {
+        const double* pc;
+        if (!const_value(g, vC, d, 1, &pc)) return badarg("drift constant has the wrong shape");
+        L.c.assign(pc, pc + d);
+        L.deterministic = 1;
+        if (d != 1 || vB >= 0) return unsupported("noise-free `+` chains have a device schedule for scalar states observed directly");
     }
     last_error().clear();
     return RXHIP_OK;

@@ -22,6 +22,7 @@
 #include "gmm_kernels.hpp"
 #include "hgf_kernels.hpp"
 #include "mvgmm_kernels.hpp"
+#include "drift_kernels.hpp"
 #include "graph_lowering.hpp"
 
 using namespace rxhip;
@@ -203,7 +204,8 @@ struct rxhip_engine {
     int* d_status = nullptr;
     double* d_fe_blocks = nullptr;
     // Gaussian-mixture VMP engine (kind == 1)
-    int kind = 0;  // 0: LGSSM, 1: GMM, 2: HGF
+    int kind = 0;  // 0: LGSSM, 1: GMM, 2: HGF, 3: noise-free drift chain
+    struct Drift { double m0 = 0, v0 = 1, c = 0, obs_var = 1; } dr;
     struct Hgf {
         rxhip_hgf_desc ds;
         double *d_out = nullptr, *d_fe_series = nullptr, *d_gh = nullptr, *d_fe_total = nullptr;
@@ -1673,6 +1675,82 @@ rxhip_status rxhip_hgf_create(const rxhip_hgf_desc* ds, rxhip_engine** out) {
     return RXHIP_OK;
 }
 
+
+rxhip_status rxhip_drift_chain_create(const rxhip_drift_chain_desc* ds, rxhip_engine** out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    *out = nullptr;
+    if (!ds || ds->T <= 0 || ds->n_chains <= 0) return RXHIP_ERR_BADARG;
+    if (!(ds->v0 > 0) || !(ds->obs_var > 0)) return RXHIP_ERR_NOT_POSDEF;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RXHIP_ERR_NO_DEVICE;
+    rxhip_engine* e = new rxhip_engine();
+    *out = e;
+    e->kind = 3;
+    e->T = ds->T; e->n_chains = ds->n_chains; e->d = 1; e->dy = 1; e->dpad = 1;
+    e->ptt = ds->prior_through_transition ? 1 : 0;
+    e->dr.m0 = ds->m0; e->dr.v0 = ds->v0; e->dr.c = ds->c; e->dr.obs_var = ds->obs_var;
+    if (ds->device >= 0) {
+        if (ds->device >= ndev) return fail(e, RXHIP_ERR_BADARG, "device %d out of range (%d visible)", ds->device, ndev);
+        e->device = ds->device;
+    } else
+        HIPCHK(e, hipGetDevice(&e->device));
+    SET_DEVICE(e);
+    if (ds->stream) e->stream = (hipStream_t)ds->stream;
+    else {
+        HIPCHK(e, stream_acquire(e->device, &e->stream));
+        e->own_stream = true;
+    }
+    const size_t C = (size_t)e->n_chains, T = (size_t)e->T;
+    ArenaPlan ap;
+    ap.zeroed(&e->d_status, sizeof(int));
+    e->fe_total_cap = 16;
+    ap.zeroed(&e->d_fe_total, sizeof(double) * e->fe_total_cap);
+    ap.plain(&e->d_mean, sizeof(double) * T * C);
+    ap.plain(&e->d_cov, sizeof(double) * T * C);
+    ap.plain(&e->d_fe_chain, sizeof(double) * C);
+    if (sizeof(double) * T * C <= ((size_t)64 << 20)) {
+        ap.plain(&e->d_y, sizeof(double) * T * C);
+        e->own_y = true;
+    }
+    return arena_commit(e, ap);
+}
+
+static rxhip_status drift_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
+    if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
+    if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
+    SET_DEVICE(e);
+    if (iterations > e->fe_total_cap) {
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (!e->in_arena(e->d_fe_total)) HIPCHK(e, hipFree(e->d_fe_total));
+        e->d_fe_total = nullptr;
+        e->fe_total_cap = iterations;
+        HIPCHK(e, hipMalloc(&e->d_fe_total, sizeof(double) * e->fe_total_cap));
+    }
+    DriftParams p;
+    p.T = e->T; p.n_chains = e->n_chains; p.y = e->d_y; p.mean = e->d_mean; p.var = e->d_cov; p.fe_chain = e->d_fe_chain;
+    p.m0 = e->dr.m0; p.v0 = e->dr.v0; p.c = e->dr.c; p.obs_var = e->dr.obs_var; p.ptt = e->ptt; p.status = e->d_status;
+    rxhip_status st;
+    for (int it = 0; it < iterations; ++it) {  // a tree: every iteration re-pushes the data and recomputes the same fixed point
+        if ((st = prof_begin(e, RXHIP_K_DRIFT_CHAIN))) return st;
+        if (want_fe) hipLaunchKernelGGL((k_drift_chain<true>), dim3((unsigned)e->n_chains), dim3(256), 0, e->stream, p);
+        else hipLaunchKernelGGL((k_drift_chain<false>), dim3((unsigned)e->n_chains), dim3(256), 0, e->stream, p);
+        if ((st = prof_end(e))) return st;
+        if (want_fe) hipLaunchKernelGGL(k_sum_fixed, dim3(1), dim3(256), 0, e->stream, (const double*)e->d_fe_chain, e->n_chains, e->d_fe_total + it);
+    }
+    HIPCHK(e, hipGetLastError());
+    e->last_iterations = iterations;
+    e->last_want_fe = want_fe != 0;
+    e->ran = true;
+    e->last_filter = false;
+    // reference-equivalent events per chain and iteration: `+`(:out), Normal(:μ), `+`(:in1) per step + the prior's message;
+    // products: forward (fwd ⊗ obs) and backward (obs ⊗ bwd) at every interior state, the marginals (2 / 1 pairwise), q(x_prior)
+    const uint64_t C = (uint64_t)e->n_chains, T = (uint64_t)e->T, I = (uint64_t)iterations;
+    e->rule_calls = I * C * (3 * T + 1 - (e->ptt ? 0 : 2));
+    e->products = I * C * (4 * (T - 1) + (e->ptt ? 2 : 0));
+    e->marginals = I * C * (T + (e->ptt ? 1 : 0));
+    return RXHIP_OK;
+}
+
 static rxhip_status hgf_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
     if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
     if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
@@ -1726,6 +1804,8 @@ rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowe
     rxhip_status st = rxhip_lower::lower_lgssm(g, L);
     if (st) return st;
     out->d = L.d; out->dy = L.dy; out->T = L.T; out->prior_through_transition = L.ptt;
+    out->deterministic = L.deterministic;
+    if (out->c) std::memcpy(out->c, L.c.data(), L.c.size() * sizeof(double));
     auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
     cp(out->A, L.A); cp(out->B, L.B); cp(out->P, L.P); cp(out->Q, L.Q); cp(out->m0, L.m0); cp(out->V0, L.V0);
     if (out->state_var) for (long long t = 0; t < L.T; ++t) out->state_var[t] = L.state_var[t];
@@ -1818,6 +1898,14 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
     rxhip_lower::Lgssm L;
     rxhip_status st = rxhip_lower::lower_lgssm(g, L);
     if (st) return st;
+    if (L.deterministic) {
+        rxhip_drift_chain_desc dd;
+        std::memset(&dd, 0, sizeof dd);
+        dd.T = L.T; dd.n_chains = g->n_replicas > 0 ? g->n_replicas : 1;
+        dd.m0 = L.m0[0]; dd.v0 = L.V0[0]; dd.c = L.c[0]; dd.obs_var = L.Q[0];
+        dd.prior_through_transition = L.ptt; dd.device = device; dd.stream = stream;
+        return rxhip_drift_chain_create(&dd, out);
+    }
     rxhip_lgssm_desc d;
     std::memset(&d, 0, sizeof d);
     d.d = L.d; d.dy = L.dy; d.T = L.T; d.n_chains = g->n_replicas > 0 ? g->n_replicas : 1; d.n_models = 1;
@@ -1926,7 +2014,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
 rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) { return run_impl(e, iterations, want_fe, false); }
 rxhip_status rxhip_run_filter_async(rxhip_engine* e, int32_t want_fe) {
     if (!e) return RXHIP_ERR_BADARG;
-    if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "run_filter: not a state-space engine (the HGF engine is a filter already)");
+    if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "run_filter: not a state-space engine with a streaming twin (the HGF engine is a filter already)");
     return run_impl(e, 1, want_fe, true);
 }
 rxhip_status rxhip_run_filter(rxhip_engine* e, int32_t want_fe) {
@@ -1937,6 +2025,10 @@ rxhip_status rxhip_run_filter(rxhip_engine* e, int32_t want_fe) {
 static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_fe, bool filter) {
     if (!e) return RXHIP_ERR_BADARG;
     if (e->kind == 2) return hgf_run_async(e, iterations, want_fe);
+    if (e->kind == 3) {
+        if (filter) return fail(e, RXHIP_ERR_BADARG, "run_filter: not a state-space engine with a streaming twin");
+        return drift_run_async(e, iterations, want_fe);
+    }
     if (e->kind == 1) {
         rxhip_status st = rxhip_gmm_begin_run(e, iterations);
         for (int it = 0; !st && it < iterations; ++it) {
@@ -2104,7 +2196,7 @@ rxhip_status rxhip_run(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
 rxhip_status rxhip_get_marginals_device(rxhip_engine* e, int32_t var_id, const double** mean_dev,
                                         const double** cov_dev) {
     if (!e) return RXHIP_ERR_BADARG;
-    if (var_id != RXHIP_VAR_X || e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
+    if (var_id != RXHIP_VAR_X || (e->kind != 0 && e->kind != 3)) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals: no run yet");
     if (mean_dev) *mean_dev = e->d_mean;
     if (cov_dev) *cov_dev = e->d_cov;
@@ -2147,7 +2239,7 @@ rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_va
 
 rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout) {
     if (!e) return RXHIP_ERR_BADARG;
-    if (var_id != RXHIP_VAR_X || e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
+    if (var_id != RXHIP_VAR_X || (e->kind != 0 && e->kind != 3)) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals: no run yet");
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
         return fail(e, RXHIP_ERR_BADARG, "get_marginals: unknown layout %d", layout);
@@ -2256,7 +2348,7 @@ rxhip_status rxhip_get_schedule(rxhip_engine* e, int32_t* segments, int64_t* seg
 rxhip_status rxhip_get_marginals_chains(rxhip_engine* e, int32_t var_id, const int64_t* chains, int64_t n, double* mean,
                                         double* cov) {
     if (!e) return RXHIP_ERR_BADARG;
-    if (var_id != RXHIP_VAR_X || e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "get_marginals_chains: variable %d is not random", var_id);
+    if (var_id != RXHIP_VAR_X || (e->kind != 0 && e->kind != 3)) return fail(e, RXHIP_ERR_BADARG, "get_marginals_chains: variable %d is not random", var_id);
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals_chains: no run yet");
     if (!chains || n <= 0) return fail(e, RXHIP_ERR_BADARG, "get_marginals_chains: empty chain list");
     for (int64_t i = 0; i < n; ++i)
@@ -2341,6 +2433,7 @@ rxhip_status ordered_allreduce(rxhip_engine* e, void* comm, double* inout, int n
         HIPCHK(e, hipMalloc(&e->d_coll, sizeof(double) * need));
         e->coll_cap = need;
     }
+    (void)hipGetLastError();
     rc = r.AllGather(inout, e->d_coll, (size_t)n, ncclDouble, (ncclComm_t)comm, e->stream);
     if (rc != ncclSuccess) return fail(e, RXHIP_ERR_RCCL, "%s: ncclAllGather: %s", what, r.GetErrorString(rc));
     hipLaunchKernelGGL(k_rank_sum, dim3((n + 63) / 64), dim3(64), 0, e->stream, (const double*)e->d_coll, inout, nranks, n);
@@ -2378,6 +2471,7 @@ rxhip_status rxhip_comm_init_rank(void** comm, int32_t nranks, const char* id128
     ncclUniqueId id;
     std::memcpy(&id, id128, sizeof id);
     ncclComm_t c = nullptr;
+    (void)hipGetLastError();  // RCCL checks hipGetLastError() after its launches: a stale non-sticky error of the host process must not fail it
     ncclResult_t rc = r.CommInitRank(&c, nranks, id, rank);
     if (rc != ncclSuccess) { g_comm_err = std::string("ncclCommInitRank: ") + r.GetErrorString(rc); return RXHIP_ERR_RCCL; }
     *comm = (void*)c;

@@ -13,9 +13,10 @@ c_u64_p = ctypes.POINTER(ctypes.c_uint64)
 OK, ERR_BADARG, ERR_UNSUPPORTED, ERR_NOT_POSDEF, ERR_NONFINITE_FE, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_RCCL = range(9)
 LAYOUT_TIME_CHAIN, LAYOUT_CHAIN_TIME = 0, 1
 VAR_Y, VAR_X = 0, 1
-K_SEG_AGGREGATE, K_BOUNDARY_SCAN, K_FORWARD, K_BACKWARD, K_FE_REDUCE, K_GMM_PASS, K_GMM_REDUCE, K_GMM_UPDATE, K_HGF_FILTER, K_COUNT = range(10)
+(K_SEG_AGGREGATE, K_BOUNDARY_SCAN, K_FORWARD, K_BACKWARD, K_FE_REDUCE, K_GMM_PASS, K_GMM_REDUCE, K_GMM_UPDATE, K_HGF_FILTER,
+ K_DRIFT_CHAIN, K_COUNT) = range(11)
 KERNEL_NAMES = ["k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce", "k_gmm_pass", "k_gmm_reduce",
-                "k_gmm_update", "k_hgf_filter"]
+                "k_gmm_update", "k_hgf_filter", "k_drift_chain"]
 
 
 class LgssmDesc(ctypes.Structure):
@@ -32,7 +33,7 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 VARKIND_RANDOM, VARKIND_DATA, VARKIND_CONST = 0, 1, 2
 NODE_MVNORMAL_MEAN_COV, NODE_MULTIPLY = 1, 2
 (NODE_NORMAL_MEAN_VARIANCE, NODE_NORMAL_MEAN_PRECISION, NODE_GAMMA_SHAPE_RATE, NODE_DIRICHLET, NODE_BETA, NODE_CATEGORICAL,
- NODE_BERNOULLI, NODE_NORMAL_MIXTURE, NODE_GCV, NODE_WISHART) = range(3, 13)
+ NODE_BERNOULLI, NODE_NORMAL_MIXTURE, NODE_GCV, NODE_WISHART, NODE_ADD) = range(3, 14)
 INIT_NONE, INIT_NORMAL, INIT_GAMMA, INIT_DIRICHLET, INIT_MVNORMAL, INIT_WISHART = 0, 1, 2, 3, 4, 5
 
 
@@ -49,7 +50,8 @@ class GraphDesc(ctypes.Structure):
 class LgssmLowered(ctypes.Structure):
     _fields_ = [("d", ctypes.c_int32), ("dy", ctypes.c_int32), ("T", ctypes.c_int64),
                 ("prior_through_transition", ctypes.c_int32), ("A", c_double_p), ("B", c_double_p), ("P", c_double_p),
-                ("Q", c_double_p), ("m0", c_double_p), ("V0", c_double_p), ("state_var", c_int64_p), ("data_var", c_int64_p)]
+                ("Q", c_double_p), ("m0", c_double_p), ("V0", c_double_p), ("state_var", c_int64_p), ("data_var", c_int64_p),
+                ("deterministic", ctypes.c_int32), ("c", c_double_p)]
 
 
 class GmmLowered(ctypes.Structure):
@@ -79,6 +81,12 @@ class MvGmmDesc(ctypes.Structure):
     _fields_ = [("N", ctypes.c_int64), ("K", ctypes.c_int32), ("d", ctypes.c_int32)] + [(n, c_double_p) for n in (
         "mu0", "S0", "nu0", "V0", "alpha0", "init_m_mean", "init_m_cov", "init_w_nu", "init_w_V", "init_s_alpha")] + [
         ("materialize_responsibilities", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p)]
+
+
+class DriftChainDesc(ctypes.Structure):
+    _fields_ = [("T", ctypes.c_int64), ("n_chains", ctypes.c_int64), ("m0", ctypes.c_double), ("v0", ctypes.c_double),
+                ("c", ctypes.c_double), ("obs_var", ctypes.c_double), ("prior_through_transition", ctypes.c_int32),
+                ("device", ctypes.c_int32), ("stream", ctypes.c_void_p)]
 
 
 class HgfDesc(ctypes.Structure):
@@ -132,6 +140,7 @@ SYMBOLS = [
     ("rxhip_gmm_statistics_device", ctypes.c_int32, [_H, ctypes.POINTER(ctypes.c_void_p), c_int32_p]),
     ("rxhip_gmm_update", ctypes.c_int32, [_H, ctypes.c_int32]),
     ("rxhip_hgf_create", ctypes.c_int32, [ctypes.POINTER(HgfDesc), ctypes.POINTER(_H)]),
+    ("rxhip_drift_chain_create", ctypes.c_int32, [ctypes.POINTER(DriftChainDesc), ctypes.POINTER(_H)]),
     ("rxhip_hgf_get_history", ctypes.c_int32, [_H, c_double_p, c_double_p, c_double_p, c_double_p, ctypes.c_int32]),
     ("rxhip_set_profiling", ctypes.c_int32, [_H, ctypes.c_int32]),
     ("rxhip_get_kernel_times", ctypes.c_int32, [_H, c_double_p, c_u64_p]),

@@ -11,7 +11,7 @@ from typing import Any, Optional
 
 import numpy as np
 
-from .engine import GMMEngine, HGFEngine, LGSSMEngine, MvGMMEngine
+from .engine import DriftChainEngine, GMMEngine, HGFEngine, LGSSMEngine, MvGMMEngine
 
 
 @dataclass
@@ -120,6 +120,52 @@ class HierarchicalGaussianFilter:
 
 def hierarchical_gaussian_filter(kappa, omega, z_variance, y_variance, n_gh=31):
     return HierarchicalGaussianFilter(float(kappa), float(omega), float(z_variance), float(y_variance), int(n_gh))
+
+
+@dataclass
+class UnivariateDriftChain:
+    """`x_prior ~ Normal(μ = mean(x0), v = var(x0)); x[i] ~ x_prev + c; y[i] ~ Normal(μ = x[i], v = P)`
+    (test/models/statespace/ulgssm_tests.jl:8-15): noise-free transitions through `typeof(+)` nodes."""
+    prior_mean: float
+    prior_var: float
+    c: float
+    obs_var: float
+    prior_through_transition: bool = True
+
+
+def univariate_drift_chain(prior_mean, prior_var, c, obs_var, prior_through_transition=True):
+    return UnivariateDriftChain(float(prior_mean), float(prior_var), float(c), float(obs_var), bool(prior_through_transition))
+
+
+def _infer_drift_chain(model, data, iterations, free_energy, options, catch_exception):
+    """posteriors["x"] = NormalMeanVariance with mean / var [T] (or [chain][T]); free_energy one value per iteration."""
+    options = _check_options(options)
+    y = np.asarray(data["y"], dtype=np.float64)
+    single = y.ndim == 1
+    if single:
+        y = y[None]
+    C, T = y.shape
+    iters = 1 if iterations is None else int(iterations)
+    eng = None
+    try:
+        eng = DriftChainEngine(T, model.prior_mean, model.prior_var, model.c, model.obs_var, n_chains=C,
+                               prior_through_transition=model.prior_through_transition, device=int(options.get("device", -1)))
+        eng.set_data(y[..., None], layout="chain_time")
+        eng.run(iterations=iters, free_energy=free_energy)
+        mean, var = eng.marginals(layout="chain_time")
+        mean, var = mean[..., 0], var[..., 0, 0]
+        fe = np.repeat(eng.free_energy_per_chain()[:, None], iters, axis=1) if free_energy else None
+        if single:
+            mean, var = mean[0], var[0]
+            fe = fe[0] if fe is not None else None
+        return InferenceResult({"x": NormalMeanVariance(mean, var)}, None, fe, model, None)
+    except Exception as err:
+        if not catch_exception:
+            raise
+        return InferenceResult({}, None, None, model, err)
+    finally:
+        if eng is not None:
+            eng.close()
 
 
 @dataclass
@@ -299,6 +345,8 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
         return _infer_mv_mixture(model, data, iterations, free_energy, options, initialization, catch_exception)
     if isinstance(model, HierarchicalGaussianFilter):
         return _infer_hgf(model, data, iterations, free_energy, options, initialization, catch_exception)
+    if isinstance(model, UnivariateDriftChain):
+        return _infer_drift_chain(model, data, iterations, free_energy, options, catch_exception)
     if not isinstance(model, LinearGaussianSSM):
         raise TypeError("infer: no device schedule for this model type")
     if autoupdates:

@@ -419,6 +419,53 @@ class HGFEngine:
         return tuple(outs)
 
 
+class DriftChainEngine:
+    """Noise-free drift chain `x_prior ~ Normal(m0, v0); x[t] ~ x[t-1] + c; y[t] ~ Normal(x[t], obs_var)`
+    (test/models/statespace/ulgssm_tests.jl:8-15) for n_chains independent chains (include/rxhip.h rxhip_drift_chain_desc)."""
+
+    def __init__(self, T, m0, v0, c, obs_var, n_chains=1, prior_through_transition=True, device=-1, stream=None):
+        L = _lib.lib()
+        desc = _lib.DriftChainDesc()
+        desc.T, desc.n_chains = int(T), int(n_chains)
+        desc.m0, desc.v0, desc.c, desc.obs_var = float(m0), float(v0), float(c), float(obs_var)
+        desc.prior_through_transition = int(bool(prior_through_transition))
+        desc.device = int(device)
+        desc.stream = ctypes.c_void_p(stream) if stream else None
+        self.T, self.n_chains, self.d, self.dy, self.n_models = int(T), int(n_chains), 1, 1, 1
+        self._h = ctypes.c_void_p()
+        st = L.rxhip_drift_chain_create(ctypes.byref(desc), ctypes.byref(self._h))
+        if st != _lib.OK:
+            msg = L.rxhip_last_error(self._h).decode() if self._h else L.rxhip_status_string(st).decode()
+            if self._h:
+                L.rxhip_destroy(self._h)
+                self._h = None
+            raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
+        self._iters = 0
+        self._data_ref = None
+        self._keep = []
+
+    _chk = LGSSMEngine._chk
+    close = LGSSMEngine.close
+    __del__ = LGSSMEngine.__del__
+    __enter__ = LGSSMEngine.__enter__
+    __exit__ = LGSSMEngine.__exit__
+    sync = LGSSMEngine.sync
+    run = LGSSMEngine.run
+    run_async = LGSSMEngine.run_async
+    set_data = LGSSMEngine.set_data
+    set_data_device = LGSSMEngine.set_data_device
+    marginals = LGSSMEngine.marginals
+    marginals_of_chains = LGSSMEngine.marginals_of_chains
+    free_energy = LGSSMEngine.free_energy
+    free_energy_per_chain = LGSSMEngine.free_energy_per_chain
+    allreduce_free_energy = LGSSMEngine.allreduce_free_energy
+    counters = LGSSMEngine.counters
+    set_profiling = LGSSMEngine.set_profiling
+    reset_kernel_times = LGSSMEngine.reset_kernel_times
+    kernel_times = LGSSMEngine.kernel_times
+    stream = LGSSMEngine.stream
+
+
 class Communicator:
     """RCCL communicator made through the C ABI (rxhip_comm_*): rank 0 calls `Communicator.unique_id()`, the 128 bytes
     travel to the other ranks by any host-side means, every rank constructs `Communicator(nranks, id, rank)`."""

@@ -121,6 +121,53 @@ def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=No
     return gb, xs, ys
 
 
+def scalar_chain_graph(T, a, b, p, q, m0, v0, prior_through_transition=False, spell="normal"):
+    """Scalar random-walk / AR(1) chains in the spellings RxInfer users write them:
+    spell = "normal":  x[t] ~ Normal(mean = x[t-1], var = p), y[t] ~ Normal(mean = x[t], var = q)   (a = b = 1, no `*` nodes)
+    spell = "scaled":  x[t] ~ Normal(mean = a * x[t-1], var = p), y[t] ~ Normal(mean = b * x[t], var = q)
+    spell = "mixed":   `*` on the transition only."""
+    gb = GraphBuilder()
+    x = gb.randomvar(1)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, x, gb.constvar(m0), gb.constvar(v0))
+    xs, ys = [], []
+    for t in range(T):
+        if t > 0 or prior_through_transition:
+            mu = x
+            if spell in ("scaled", "mixed"):
+                mu = gb.randomvar(1)
+                gb.multiply(mu, gb.constvar(a), x)
+            xn = gb.randomvar(1)
+            gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, xn, mu, gb.constvar(p))
+            x = xn
+        mu = x
+        if spell == "scaled":
+            mu = gb.randomvar(1)
+            gb.multiply(mu, gb.constvar(b), x)
+        y = gb.datavar(1)
+        gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y, mu, gb.constvar(q))
+        xs.append(x); ys.append(y)
+    return gb, xs, ys
+
+
+def drift_chain_graph(T, m0, v0, c, obs_var, const_first=False):
+    """test/models/statespace/ulgssm_tests.jl:8-15: x_prior ~ Normal(μ, v); x[i] ~ x_prev + c; y[i] ~ Normal(μ = x[i], v = P)."""
+    gb = GraphBuilder()
+    x = gb.randomvar(1)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, x, gb.constvar(m0), gb.constvar(v0))
+    xs, ys = [], []
+    for _ in range(T):
+        xn = gb.randomvar(1)
+        if const_first:
+            gb.node(_lib.NODE_ADD, xn, gb.constvar(c), x)
+        else:
+            gb.node(_lib.NODE_ADD, xn, x, gb.constvar(c))
+        x = xn
+        y = gb.datavar(1)
+        gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y, x, gb.constvar(obs_var))
+        xs.append(x); ys.append(y)
+    return gb, xs, ys
+
+
 def lower_lgssm(g):
     """Host-only lowering (no GPU): returns dict(d, dy, T, prior_through_transition, A, B, P, Q, m0, V0, state_var, data_var)."""
     L = _lib.lib()
@@ -129,7 +176,8 @@ def lower_lgssm(g):
     if st != _lib.OK:
         raise RxHipError(st, L.rxhip_lowering_error().decode())
     d, dy, T = out.d, out.dy, out.T
-    bufs = dict(A=np.empty((d, d)), B=np.empty((dy, d)), P=np.empty((d, d)), Q=np.empty((dy, dy)), m0=np.empty(d), V0=np.empty((d, d)))
+    bufs = dict(A=np.empty((d, d)), B=np.empty((dy, d)), P=np.empty((d, d)), Q=np.empty((dy, dy)), m0=np.empty(d), V0=np.empty((d, d)),
+                c=np.empty(d))
     sv, dv = np.empty(T, dtype=np.int64), np.empty(T, dtype=np.int64)
     for k, v in bufs.items():
         setattr(out, k, v.ctypes.data_as(_lib.c_double_p))
@@ -138,7 +186,8 @@ def lower_lgssm(g):
     st = L.rxhip_graph_lower_lgssm(ctypes.byref(g), ctypes.byref(out))
     if st != _lib.OK:
         raise RxHipError(st, L.rxhip_lowering_error().decode())
-    return dict(d=d, dy=dy, T=T, prior_through_transition=bool(out.prior_through_transition), state_var=sv, data_var=dv, **bufs)
+    return dict(d=d, dy=dy, T=T, prior_through_transition=bool(out.prior_through_transition), deterministic=bool(out.deterministic),
+                state_var=sv, data_var=dv, **bufs)
 
 
 def create_engine_from_graph(g, segments=0, device=-1, stream=None):
@@ -154,9 +203,14 @@ def create_engine_from_graph(g, segments=0, device=-1, stream=None):
             L.rxhip_destroy(h)
         raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
     low = lower_lgssm(g)
-    eng = LGSSMEngine.__new__(LGSSMEngine)
+    if low["deterministic"]:
+        from .engine import DriftChainEngine
+
+        eng = DriftChainEngine.__new__(DriftChainEngine)
+    else:
+        eng = LGSSMEngine.__new__(LGSSMEngine)
     eng._h, eng.d, eng.dy, eng.T, eng.n_chains, eng.n_models = h, low["d"], low["dy"], low["T"], int(g.n_replicas or 1), 1
-    eng._keep, eng._data_ref = [], None
+    eng._keep, eng._data_ref, eng._iters = [], None, 0
     return eng
 
 

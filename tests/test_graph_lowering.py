@@ -225,3 +225,93 @@ def test_multivariate_engine_from_graph_matches_structured_descriptor():
     with rxhip.MvGMMEngine(400, pm, pc, nu, sc, [1.0, 1.0, 2.0], init["m"][0], init["m"][1], init["w"][0], init["w"][1], init["s"]) as e2:
         e2.set_data(y); e2.run(4, True)
         assert np.array_equal(h1, e2.history()["raw"]) and np.array_equal(f1, e2.free_energy())
+
+
+# ---- generalised chain spellings, the `+` drift chain, malformed graphs (round 2) ------------------------------
+def test_scalar_chain_spellings_are_recognised():
+    """`x[t] ~ Normal(mean = x[t-1], var = p)`, `y[t] ~ Normal(mean = x[t], var = q)` and the `a * x` variants lower to the
+    same structured descriptor (identity maps where no `*` node stands)."""
+    for spell, a, b in (("normal", 1.0, 1.0), ("scaled", 0.9, 1.7), ("mixed", 0.8, 1.0)):
+        for ptt in (False, True):
+            gb, xs, ys = graph.scalar_chain_graph(9, a, b, 0.3, 2.0, -1.0, 25.0, prior_through_transition=ptt, spell=spell)
+            perm = np.random.default_rng(3).permutation(len(gb.ftype))
+            low = graph.lower_lgssm(gb.tables(permute=perm)[0])
+            assert (low["d"], low["dy"], low["T"], low["prior_through_transition"], low["deterministic"]) == (1, 1, 9, ptt, False)
+            assert low["A"][0, 0] == a and low["B"][0, 0] == b and low["P"][0, 0] == 0.3 and low["Q"][0, 0] == 2.0
+            assert low["m0"][0] == -1.0 and low["V0"][0, 0] == 25.0 and list(low["data_var"]) == ys and list(low["state_var"]) == xs
+
+
+def test_identity_observation_in_a_vector_chain():
+    """`y[t] ~ MvNormal(μ = x[t], Σ = Q)` without a `*` node: B = I."""
+    mdl = workloads.random_model(3, 3, seed=2)
+    gb = graph.GraphBuilder()
+    x = gb.randomvar(3)
+    gb.mvnormal_mean_cov(x, gb.constvar(mdl["m0"]), gb.constvar(mdl["V0"]))
+    ys = []
+    for t in range(6):
+        if t:
+            a = gb.randomvar(3); gb.multiply(a, gb.constvar(mdl["A"]), x)
+            xn = gb.randomvar(3); gb.mvnormal_mean_cov(xn, a, gb.constvar(mdl["P"])); x = xn
+        y = gb.datavar(3); gb.mvnormal_mean_cov(y, x, gb.constvar(mdl["Q"])); ys.append(y)
+    low = graph.lower_lgssm(gb.tables()[0])
+    assert np.array_equal(low["B"], np.eye(3)) and np.array_equal(low["A"], mdl["A"]) and low["T"] == 6
+
+
+def test_drift_chain_of_the_reference_test_is_recognised():
+    """test/models/statespace/ulgssm_tests.jl:8-15: `x[i] ~ x_prev + c` (typeof(+) with a constant), either argument order."""
+    for const_first in (False, True):
+        gb, xs, ys = graph.drift_chain_graph(12, 0.0, 1e4, 1.0, 100.0, const_first=const_first)
+        assert len(gb.ftype) == 1 + 2 * 12
+        low = graph.lower_lgssm(gb.tables(permute=np.random.default_rng(5).permutation(len(gb.ftype)))[0])
+        assert low["deterministic"] and low["prior_through_transition"] and low["T"] == 12
+        assert low["c"][0] == 1.0 and low["Q"][0, 0] == 100.0 and low["V0"][0, 0] == 1e4 and low["P"][0, 0] == 0.0
+        assert list(low["data_var"]) == ys
+    # mixing noisy and noise-free transitions has no schedule
+    gb, xs, ys = graph.drift_chain_graph(4, 0.0, 1.0, 1.0, 1.0)
+    xn = gb.randomvar(1); gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, xn, xs[-1], gb.constvar(0.5))
+    y = gb.datavar(1); gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y, xn, gb.constvar(1.0))
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_lgssm(gb.tables()[0])
+    assert ei.value.status == _lib.ERR_UNSUPPORTED
+
+
+def test_cyclic_and_merging_graphs_are_rejected_not_followed():
+    """a chain whose last transition writes back into x[1] used to be walked forever."""
+    mdl = workloads.notebook_model()
+    gb, xs, ys = graph.lgssm_graph(4, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    a = gb.randomvar(2); gb.multiply(a, gb.constvar(mdl["A"]), xs[-1])
+    gb.mvnormal_mean_cov(xs[0], a, gb.constvar(mdl["P"]))  # x[1] now has two writers: the prior and this transition
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_lgssm(gb.tables()[0])
+    assert ei.value.status == _lib.ERR_UNSUPPORTED and "two nodes" in str(ei.value)
+    # pure cycle without a second writer on the prior's variable: x[2] written by the last transition
+    gb, xs, ys = graph.lgssm_graph(4, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    a = gb.randomvar(2); gb.multiply(a, gb.constvar(mdl["A"]), xs[-1])
+    gb.mvnormal_mean_cov(xs[1], a, gb.constvar(mdl["P"]))
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_lgssm(gb.tables()[0])
+    assert ei.value.status == _lib.ERR_UNSUPPORTED
+
+
+def test_malformed_constant_tables_are_bad_arguments():
+    """constants without a value (offset −1), offsets past the pool, CSR offsets that go backwards."""
+    mdl = workloads.notebook_model()
+    gb, xs, ys = graph.lgssm_graph(3, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    g, keep = gb.tables()
+    consts = [i for i, k in enumerate(gb.kind) if k == _lib.VARKIND_CONST]
+    keep["coff"][consts[-1]] = -1  # a constant that carries no value
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_lgssm(g)
+    assert ei.value.status in (_lib.ERR_UNSUPPORTED, _lib.ERR_BADARG)
+    g, keep = gb.tables()
+    keep["coff"][consts[-1]] = keep["pool"].size - 1  # 2×2 matrix starting at the last pool entry
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_lgssm(g)
+    assert ei.value.status == _lib.ERR_BADARG
+    gbm, _ = graph.mixture_graph(4, [0.0, 1.0], [1.0, 1.0], [1.0, 1.0], [1.0, 1.0], [1.0, 1.0],
+                                 init=dict(m=([0.0, 1.0], [1.0, 1.0]), p=([1.0, 1.0], [1.0, 1.0])))
+    g, keep = gbm.tables()
+    keep["ptr"][2] = keep["ptr"][1] - 1
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_gmm(g)
+    assert ei.value.status == _lib.ERR_BADARG
