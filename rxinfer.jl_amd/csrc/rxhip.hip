@@ -2398,7 +2398,9 @@ Rccl& rccl() {
     static Rccl* r = [] {
         Rccl* q = new Rccl;
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        q->h = dlopen(names[0], RTLD_NOW | RTLD_NOLOAD);  // the copy the host process already uses, if any
+        // the copy the host process already uses, if any: two RCCL builds in one process do not coexist (torch ships its own
+        // as "librccl.so" with SONAME librccl.so.1; glibc matches the name a library was loaded under, so both are tried)
+        for (int i = 0; !q->h && i < 2; ++i) q->h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
         for (int i = 0; !q->h && i < 3; ++i) q->h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
         if (!q->h) { q->err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return q; }
         bool all = true;
