@@ -535,6 +535,10 @@ struct DenseLds {
     static constexpr size_t bytes(int dmax) {
         return sizeof(double) * ((size_t)4 * C::MAT + (size_t)NVEC * dmax + 8 * C::D + 3 * C::THREADS);
     }
+    // kd_forward_info: 2 matrices, ξ_f | u | 4 partial-sum rows, the pivot-row buffers
+    static constexpr size_t fwd_info_bytes(int dmax) {
+        return sizeof(double) * ((size_t)2 * C::MAT + (size_t)6 * dmax + 8 * C::D);
+    }
     // kd_agg_finish: 6 vectors, the map (B'Q⁻¹)' and a tile of 16 observations
     static constexpr size_t agg_bytes(int dy) {
         return sizeof(double) * ((size_t)6 * ((((C::D > dy ? C::D : dy) + 1) & ~1)) + (size_t)C::D * dy + (size_t)16 * dy + 16);
@@ -1068,17 +1072,19 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
 // Record of time index t: ξ_f(t) | (spare) | C_t (lower tiles) | G_t' (accumulator order).  vend: Λ_f at the segment end.
 // fe_part slots (negated contributions): 0 and S+s: backward of segment 0 / s ≥ 1;  1+s: forward of segment s.
 template <int NT, bool FE>
-__global__ void __launch_bounds__(64 * NT) kd_forward_info(DenseParams p) {
+__global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  // ≥ 2 waves per SIMD: ≤ 256 registers
     constexpr int D = 16 * NT;
     using C = DenseCfg<NT>;
     constexpr int LD = C::LD;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int dm = ((D > dy ? D : dy) + 1) & ~1;
+    // Two LDS matrices only (75 KB at d = 64): TWO workgroups share a CU, so that one's publish → barrier → cofactor → MFMA
+    // latency chain runs under the other's (the kernel holds 255 registers: two waves per SIMD fit).  The constant
+    // PLW = P⁻¹ + B'Q⁻¹B + A'P⁻¹A is re-read from L2 into dead registers a whole contraction before its use.
     double* S0 = smem;          // C_t
     double* S1 = S0 + C::MAT;   // −G_t, then M_{t+1} for the symmetrisation
-    double* S2 = S1 + C::MAT;   // PLW = P⁻¹ + B'Q⁻¹B + A'P⁻¹A (constant)
-    double* vec = S2 + C::MAT;
+    double* vec = S1 + C::MAT;
     double* xi = vec;           // ξ_f
     double* u = xi + dm;
     double* xpp = u + dm;       // [4][D] partial sums of ξ_p
@@ -1125,8 +1131,6 @@ __global__ void __launch_bounds__(64 * NT) kd_forward_info(DenseParams p) {
     // belief at the segment start in information form: Λ_f = V(b_s)⁻¹ (data-independent: host table), ξ_f = Λ_f m(b_s)
     acc_load<NT>(lam, p.bnd + ((size_t)seg * 2 + 0) * MM, D, w, lane);
     acc_store<NT>(lam, S0, LD, w, lane);
-    acc_load<NT>(a, cst + c.oPLW, D, w, lane);
-    acc_store<NT>(a, S2, LD, w, lane);
     if (tid < D) u[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
     lds_barrier();
     matvec_lds(xi, S0, LD, D, D, u, nullptr, 0.0, tid);
@@ -1146,6 +1150,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward_info(DenseParams p) {
         ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
         acc_store_tri<NT>(lam, rec + C::HDR, w, lane);
         acc_store<NT>(lam, S0, LD, w, lane);
+        acc_load<NT>(lam, cst + c.oPLW, D, w, lane);  // lam is dead until M_{t+1} below: the L2 latency hides under G' = K C
         lds_barrier();
         // G' = K C
         acc_zero<NT>(a);
@@ -1169,7 +1174,6 @@ __global__ void __launch_bounds__(64 * NT) kd_forward_info(DenseParams p) {
             }
             xpp[grp * D + gi] = s0 + s1;
         }
-        acc_load<NT>(lam, S2, LD, w, lane);
         mm_k(lam, S1);
         lds_barrier();
         if (tid < D) xi[tid] = gyc - ((xpp[tid] + xpp[D + tid]) + (xpp[2 * D + tid] + xpp[3 * D + tid]));  // ξ_f(t)

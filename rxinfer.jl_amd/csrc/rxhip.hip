@@ -722,8 +722,9 @@ struct DenseLaunch {
     // information-form smoother (one inverse per step; free energy at the smoothed means)
     static void forward_info(const DenseParams& p, bool fe, hipStream_t s) {
         dim3 g(p.S, (unsigned)p.n_chains);
-        if (fe) hipLaunchKernelGGL((kd_forward_info<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
-        else hipLaunchKernelGGL((kd_forward_info<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        const size_t lds = DenseLds<NT>::fwd_info_bytes(((p.d > p.dy ? p.d : p.dy) + 1) & ~1);
+        if (fe) hipLaunchKernelGGL((kd_forward_info<NT, true>), g, dim3(64 * NT), lds, s, p);
+        else hipLaunchKernelGGL((kd_forward_info<NT, false>), g, dim3(64 * NT), lds, s, p);
     }
     static void backward_info(const DenseParams& p, bool fe, hipStream_t s) {
         dim3 g(p.S, (unsigned)p.n_chains);
@@ -1242,11 +1243,13 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     // time segmentation: two (chain, segment) lanes per SIMD lane slot — 256 CUs × 4 SIMDs × 2 waves × 64 lanes.
     // Once the forward message is stored compactly the backward kernel is issue-bound at one wave per SIMD
     // (measured at C2: 4.7 ms with 64 segments, 3.9–4.0 ms with 128…512); the boundary scan is cheap.
-    // Dense (MFMA) path: one workgroup of NT wavefronts per (chain, segment).  At d = 49…64 a workgroup fills a CU (one
-    // wavefront per SIMD, 256 + registers); the smaller tiles leave room for more, and the kernels are latency-bound, so
+    // Dense (MFMA) path: one workgroup of NT wavefronts per (chain, segment).  At d = 49…64 the forward kernel keeps two
+    // matrices in LDS and 254 registers, so TWO workgroups share a CU (one wavefront of each per SIMD): measured at C3,
+    // forward 0.72 -> 0.58 ms with 500 instead of 250 segments (750: 0.62).  The smaller tiles leave room for more, and the
+    // kernels are latency-bound, so
     // more resident workgroups pay until the per-segment prologue dominates (measured, scripts/time_mid_dims.py:
     // d = 16, 512 chains, T = 1000: 4.27 ms with 2 workgroups per CU, 2.22 ms with 48; d = 32, 128 chains: 4.86 -> 3.02 ms).
-    const int dense_wg_per_cu = !dense ? 0 : e->nt == 1 ? 48 : e->nt == 2 ? 8 : e->nt == 3 ? 2 : 1;
+    const int dense_wg_per_cu = !dense ? 0 : e->nt == 1 ? 48 : e->nt == 2 ? 8 : 2;
     const long long steps = e->T - 1;  // transitions
     if (steps <= 0) {
         e->S = 0;
