@@ -63,7 +63,7 @@ function check(e::Engine, st::Int32)
     throw(RxHipError(st, msg))
 end
 
-rowmajor(M::AbstractMatrix) = collect(transpose(Matrix{Float64}(M)))   # Julia is column-major
+rowmajor(M::AbstractMatrix) = vec(collect(transpose(Matrix{Float64}(M))))   # Julia is column-major
 rowmajor(v::AbstractVector) = Vector{Float64}(v)
 
 """
@@ -74,13 +74,21 @@ state-space family (src/inference/batch.jl:252, src/model/plugins/reactivemp_inf
 `P` is the state-noise covariance, `Q` the observation-noise covariance.
 """
 function Engine(A, B, P, Q, m0, V0; T::Integer, n_chains::Integer = 1, prior_through_transition::Bool = false,
-                segments::Integer = 0, device::Integer = -1)
-    d, dy = size(A, 1), size(B, 1)
-    a, b, p, q, m, v = rowmajor(A), rowmajor(B), rowmajor(P), rowmajor(Q), rowmajor(m0), rowmajor(V0)
+                segments::Integer = 0, device::Integer = -1, chain_model::Union{Nothing, AbstractVector{<:Integer}} = nothing,
+                stream = nothing)
+    # one model: plain matrices; several: vectors of matrices (A[m], B[m], …) with chain_model[c] ∈ 0:n_models-1
+    multi = A isa AbstractVector{<:AbstractMatrix}
+    n_models = multi ? length(A) : 1
+    cat(xs) = multi ? reduce(vcat, rowmajor.(xs)) : rowmajor(xs)
+    d, dy = multi ? (size(A[1], 1), size(B[1], 1)) : (size(A, 1), size(B, 1))
+    a, b, p, q, m, v = cat(A), cat(B), cat(P), cat(Q), cat(m0), cat(V0)
+    cm = chain_model === nothing ? Int32[] : Vector{Int32}(chain_model)
+    (chain_model === nothing || length(cm) == n_chains) || throw(ArgumentError("chain_model needs one entry per chain"))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    st = GC.@preserve a b p q m v begin
-        desc = LgssmDesc(d, dy, T, n_chains, 1, prior_through_transition ? 1 : 0, pointer(a), pointer(b), pointer(p),
-                         pointer(q), pointer(m), pointer(v), Ptr{Int32}(C_NULL), segments, device, C_NULL)
+    st = GC.@preserve a b p q m v cm begin
+        desc = LgssmDesc(d, dy, T, n_chains, n_models, prior_through_transition ? 1 : 0, pointer(a), pointer(b), pointer(p),
+                         pointer(q), pointer(m), pointer(v), isempty(cm) ? Ptr{Int32}(C_NULL) : pointer(cm), segments, device,
+                         stream_handle(stream))
         ccall((:rxhip_lgssm_create, librxhip), Int32, (Ref{LgssmDesc}, Ref{Ptr{Cvoid}}), desc, h)
     end
     e = Engine(h[], d, dy, T, n_chains, 0)
@@ -262,14 +270,184 @@ function counters(e::Engine)
     return (rule_calls = r[], products = p[], marginals = m[])
 end
 
-# ---- plugin sketch -----------------------------------------------------------------------------------
-# A sibling of ReactiveMPInferencePlugin (src/model/plugins/reactivemp_inference.jl:207-326), selected with
-# `options = (backend = :hip,)` (the closed option key set at :129-143 must learn `:backend`, `:device`,
-# `:segments`).  `postprocess_plugin` walks the finished GraphPPL graph exactly as :272-326 does, recognises
-# the chain  MvNormalMeanCovariance ← typeof(*) ← x[t-1]  /  MvNormalMeanCovariance(y[t]) ← typeof(*) ← x[t]
-# (node types from GraphPPL.fform, interface names from GraphPPL.getname(edge), constants from
-# GraphPPL.value), and fills an `Engine`; `new_observation!` maps to `set_data!`, `obtain_marginal` to a
-# Rocket `of(...)` observable over `marginals(e)`, `score(…, BetheFreeEnergy, …)` to `of(free_energy(e)...)`.
-# Anything it does not recognise falls through to the stock ReactiveMP plugin.
+# ---- generic graph entry: rxhip_graph_desc / rxhip_create (used by HIPInferencePlugin.jl) ----------------------------
+const RXHIP_ERR_UNSUPPORTED = Int32(2)
+
+# mirrors rxhip_graph_desc (include/rxhip.h) field for field
+struct GraphDesc
+    n_variables::Int64
+    var_kind::Ptr{Int32}
+    var_rows::Ptr{Int32}
+    var_cols::Ptr{Int32}
+    var_const::Ptr{Int64}
+    n_factors::Int64
+    factor_type::Ptr{Int32}
+    factor_iface::Ptr{Int64}
+    const_pool::Ptr{Float64}
+    n_const::Int64
+    n_replicas::Int64
+    factor_iface_ptr::Ptr{Int64}
+    var_init_family::Ptr{Int32}
+    var_init::Ptr{Int64}
+    gh_points::Int32
+    n_observations::Int64
+end
+
+# mirrors rxhip_lgssm_lowered
+mutable struct LgssmLowered
+    d::Int32
+    dy::Int32
+    T::Int64
+    prior_through_transition::Int32
+    A::Ptr{Float64}; B::Ptr{Float64}; P::Ptr{Float64}; Q::Ptr{Float64}; m0::Ptr{Float64}; V0::Ptr{Float64}
+    state_var::Ptr{Int64}
+    data_var::Ptr{Int64}
+    deterministic::Int32
+    c::Ptr{Float64}
+    LgssmLowered() = new(0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL)
+end
+
+"""The engine's stream: `nothing` (engine-owned) or an AMDGPU.jl stream, whose raw `hipStream_t` is handed over so that the
+host's own kernels / copies and the engine's launches are ordered on one queue (AMDGPU.jl only for handles)."""
+stream_handle(::Nothing) = Ptr{Cvoid}(C_NULL)
+stream_handle(s) = Base.unsafe_convert(Ptr{Cvoid}, s)     # AMDGPU.HIPStream -> hipStream_t
+
+with_desc(f, t, n_replicas::Integer, n_observations::Integer) = GC.@preserve t begin
+    f(GraphDesc(length(t.var_kind), pointer(t.var_kind), pointer(t.var_rows), pointer(t.var_cols), pointer(t.var_const),
+                length(t.factor_type), pointer(t.factor_type), pointer(t.factor_iface), pointer(t.const_pool), length(t.const_pool),
+                n_replicas, pointer(t.factor_iface_ptr), pointer(t.var_init_family), pointer(t.var_init), t.gh_points, n_observations))
+end
+
+lowering_error() = unsafe_string(ccall((:rxhip_lowering_error, librxhip), Cstring, ()))
+
+"""
+    create_from_tables(tables; n_replicas = 1, n_observations = 0, segments = 0, device = -1, stream = nothing)
+
+`rxhip_create`: lowers the graph tables and builds the engine of the family the node types select.  Throws
+`RxHipError(RXHIP_ERR_UNSUPPORTED, why)` for graphs without a device schedule (the plugin then uses ReactiveMP)."""
+function create_from_tables(t; n_replicas::Integer = 1, n_observations::Integer = 0, segments::Integer = 0, device::Integer = -1, stream = nothing)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    st = with_desc(t, n_replicas, n_observations) do desc
+        ccall((:rxhip_create, librxhip), Int32, (Ref{GraphDesc}, Int32, Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), desc, segments, device,
+              stream_handle(stream), h)
+    end
+    if st != RXHIP_OK
+        msg = lowering_error()
+        if h[] != C_NULL
+            isempty(msg) && (msg = unsafe_string(ccall((:rxhip_last_error, librxhip), Cstring, (Ptr{Cvoid},), h[])))
+            ccall((:rxhip_destroy, librxhip), Int32, (Ptr{Cvoid},), h[])
+        end
+        st == RXHIP_ERR_NOT_POSDEF && throw(PosDefException(0))
+        throw(RxHipError(st, msg))
+    end
+    lay = lowered_layout(t)
+    e = Engine(h[], lay.d, lay.width, length(lay.data_ids), n_replicas, 0)
+    finalizer(destroy!, e)
+    return e
+end
+
+"""Family of the graph and the variable ids (0-based, time order) of its observations / states, from the host-only lowering
+entry points (`rxhip_graph_lower_*`, two-call protocol)."""
+function lowered_layout(t)
+    has(code) = any(==(Int32(code)), t.factor_type)
+    if has(11)
+        return (family = :hgf, d = 1, width = 1, data_ids = Int64[findfirst(==(Int32(1)), t.var_kind) - 1], state_ids = Int64[])
+    elseif has(10) || has(4)
+        ids = Int64[]
+        for f in eachindex(t.factor_type)   # the observation nodes' `out` interface, in node order = data order
+            t.factor_type[f] in (Int32(10), Int32(4)) && push!(ids, t.factor_iface[t.factor_iface_ptr[f] + 1])
+        end
+        d = Int(t.var_rows[ids[1] + 1])
+        return (family = has(12) ? :mvmixture : :mixture, d = d, width = d, data_ids = ids, state_ids = Int64[])
+    end
+    low = LgssmLowered()
+    st = with_desc(t, 1, 0) do desc
+        ccall((:rxhip_graph_lower_lgssm, librxhip), Int32, (Ref{GraphDesc}, Ref{LgssmLowered}), desc, low)
+    end
+    st == RXHIP_OK || throw(RxHipError(st, lowering_error()))
+    sv, dv = Vector{Int64}(undef, low.T), Vector{Int64}(undef, low.T)
+    GC.@preserve sv dv begin
+        low.state_var, low.data_var = pointer(sv), pointer(dv)
+        st = with_desc(t, 1, 0) do desc
+            ccall((:rxhip_graph_lower_lgssm, librxhip), Int32, (Ref{GraphDesc}, Ref{LgssmLowered}), desc, low)
+        end
+    end
+    st == RXHIP_OK || throw(RxHipError(st, lowering_error()))
+    return (family = low.deterministic != 0 ? :drift : :lgssm, d = Int(low.d), width = Int(low.dy), data_ids = dv, state_ids = sv)
+end
+
+"""Split-phase VMP iteration of the mixture engines (`rxhip_gmm_begin_run` once, then accumulate + update per iteration):
+what the plugin's `fire!` runs for a mixture graph, because `rxhip_run` restarts from the `@initialization` marginals."""
+function vmp_iteration!(e::Engine; free_energy::Bool, max_iterations::Integer = 1000)
+    if e.iterations == 0
+        check(e, ccall((:rxhip_gmm_begin_run, librxhip), Int32, (Ptr{Cvoid}, Int32), e.handle, max_iterations))
+    end
+    e.iterations < max_iterations || throw(RxHipError(Int32(7), "more than max_iterations = $(max_iterations) VMP iterations"))
+    check(e, ccall((:rxhip_gmm_accumulate, librxhip), Int32, (Ptr{Cvoid},), e.handle))
+    check(e, ccall((:rxhip_gmm_update, librxhip), Int32, (Ptr{Cvoid}, Int32), e.handle, free_energy ? 1 : 0))
+    check(e, ccall((:rxhip_sync, librxhip), Int32, (Ptr{Cvoid},), e.handle))
+    e.iterations += 1
+end
+
+"""Univariate mixture: the marginals of the iteration just run as `(mean m, var m, shape p, rate p, α s)[k]`; multivariate:
+per component `mean[d] | cov[d][d] | ν | V[d][d] | α` — the last block of `rxhip_gmm_get_history`."""
+function last_mixture_state(e::Engine, K::Integer; d::Integer = 0)
+    stride = d == 0 ? 5 * K : K * (2 + d + 2 * d * d)
+    hist = Vector{Float64}(undef, stride * e.iterations)
+    GC.@preserve hist check(e, ccall((:rxhip_gmm_get_history, librxhip), Int32, (Ptr{Cvoid}, Ptr{Float64}), e.handle, hist))
+    return hist[(end - stride + 1):end]
+end
+
+"""posteriors of selected chains only (`rxhip_get_marginals_chains`): chains are 0-based ids."""
+function marginals_of_chains(e::Engine, chains::Vector{Int64})
+    mean = Array{Float64}(undef, e.d, e.T, length(chains))
+    cov = Array{Float64}(undef, e.d, e.d, e.T, length(chains))
+    GC.@preserve chains mean cov check(e, ccall((:rxhip_get_marginals_chains, librxhip), Int32,
+        (Ptr{Cvoid}, Int32, Ptr{Int64}, Int64, Ptr{Float64}, Ptr{Float64}), e.handle, RXHIP_VAR_X, chains, length(chains), mean, cov))
+    return mean, cov
+end
+
+# mirrors rxhip_drift_chain_desc
+struct DriftChainDesc
+    T::Int64
+    n_chains::Int64
+    m0::Float64; v0::Float64; c::Float64; obs_var::Float64
+    prior_through_transition::Int32
+    device::Int32
+    stream::Ptr{Cvoid}
+end
+"""`univariate_lgssm_model` of test/models/statespace/ulgssm_tests.jl:8-15 (noise-free `x[i] ~ x_prev + c` transitions)."""
+function DriftChainEngine(; T::Integer, m0, v0, c, obs_var, n_chains::Integer = 1, prior_through_transition::Bool = true,
+                          device::Integer = -1, stream = nothing)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    desc = DriftChainDesc(T, n_chains, m0, v0, c, obs_var, prior_through_transition ? 1 : 0, device, stream_handle(stream))
+    st = ccall((:rxhip_drift_chain_create, librxhip), Int32, (Ref{DriftChainDesc}, Ref{Ptr{Cvoid}}), desc, h)
+    e = Engine(h[], 1, 1, T, n_chains, 0)
+    st == RXHIP_OK || throw(RxHipError(st, unsafe_string(ccall((:rxhip_status_string, librxhip), Cstring, (Int32,), st))))
+    finalizer(destroy!, e)
+    return e
+end
+
+# ---- several GPUs: the free-energy / statistics exchange over RCCL (no torch, no MPI dependency in this file) ----------
+"""128-byte RCCL id, created by rank 0 and moved to the other ranks by the host (file, socket, MPI.jl, Distributed)."""
+function comm_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    st = ccall((:rxhip_comm_unique_id, librxhip), Int32, (Ptr{UInt8},), id)
+    st == RXHIP_OK || throw(RxHipError(st, unsafe_string(ccall((:rxhip_comm_last_error, librxhip), Cstring, ()))))
+    return id
+end
+function comm_init_rank(nranks::Integer, id::Vector{UInt8}, rank::Integer; device::Integer = -1)
+    c = Ref{Ptr{Cvoid}}(C_NULL)
+    st = ccall((:rxhip_comm_init_rank, librxhip), Int32, (Ref{Ptr{Cvoid}}, Int32, Ptr{UInt8}, Int32, Int32), c, nranks, id, rank, device)
+    st == RXHIP_OK || throw(RxHipError(st, unsafe_string(ccall((:rxhip_comm_last_error, librxhip), Cstring, ()))))
+    return c[]
+end
+comm_destroy(comm::Ptr{Cvoid}) = ccall((:rxhip_comm_destroy, librxhip), Int32, (Ptr{Cvoid},), comm)
+"""after `run!(…, free_energy = true)`: the free energies become the sums over all ranks (bit-identical on every rank)."""
+allreduce_free_energy!(e::Engine, comm::Ptr{Cvoid}) =
+    check(e, ccall((:rxhip_allreduce_free_energy, librxhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), e.handle, comm))
+"""between `rxhip_gmm_accumulate` and `rxhip_gmm_update` of a sharded mixture"""
+allreduce_statistics!(e::Engine, comm::Ptr{Cvoid}) =
+    check(e, ccall((:rxhip_gmm_allreduce_statistics, librxhip), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), e.handle, comm))
 
 end # module

@@ -13,6 +13,26 @@ from . import _lib
 from ._lib import RxHipError
 
 
+# node vocabulary of include/rxhip.h: code -> (GraphPPL.fform name, interface order); the Julia plugin carries the same table
+NODE_VOCABULARY = {
+    _lib.NODE_MVNORMAL_MEAN_COV: ("MvNormalMeanCovariance", ("out", "μ", "Σ")),
+    _lib.NODE_MULTIPLY: ("*", ("out", "A", "in")),
+    _lib.NODE_NORMAL_MEAN_VARIANCE: ("NormalMeanVariance", ("out", "μ", "v")),
+    _lib.NODE_NORMAL_MEAN_PRECISION: ("NormalMeanPrecision", ("out", "μ", "τ")),
+    _lib.NODE_GAMMA_SHAPE_RATE: ("GammaShapeRate", ("out", "α", "β")),
+    _lib.NODE_DIRICHLET: ("Dirichlet", ("out", "a")),
+    _lib.NODE_BETA: ("Beta", ("out", "a", "b")),
+    _lib.NODE_CATEGORICAL: ("Categorical", ("out", "p")),
+    _lib.NODE_BERNOULLI: ("Bernoulli", ("out", "p")),
+    _lib.NODE_NORMAL_MIXTURE: ("NormalMixture", ("out", "switch", "m", "p")),
+    _lib.NODE_GCV: ("GCV", ("y", "x", "z", "κ", "ω")),
+    _lib.NODE_WISHART: ("Wishart", ("out", "ν", "S")),
+    _lib.NODE_ADD: ("+", ("out", "in1", "in2")),
+}
+INIT_FAMILIES = {"normal": _lib.INIT_NORMAL, "gamma": _lib.INIT_GAMMA, "dirichlet": _lib.INIT_DIRICHLET, "mvnormal": _lib.INIT_MVNORMAL,
+                 "wishart": _lib.INIT_WISHART}
+
+
 class GraphBuilder:
     def __init__(self):
         self.kind, self.rows, self.cols, self.coff = [], [], [], []
@@ -21,24 +41,80 @@ class GraphBuilder:
         self._n = 0
         self.init_family, self.init_off = {}, {}
         self.gh_points = 0
+        self.names = []
+        self.n_replicas, self.n_observations = 1, 0
 
-    def _var(self, kind, rows, cols=1, coff=-1):
+    def _var(self, kind, rows, cols=1, coff=-1, name=""):
         self.kind.append(kind); self.rows.append(rows); self.cols.append(cols); self.coff.append(coff)
+        self.names.append(name)
         return len(self.kind) - 1
 
-    def randomvar(self, dim):
-        return self._var(_lib.VARKIND_RANDOM, dim)
+    def randomvar(self, dim, name=""):
+        return self._var(_lib.VARKIND_RANDOM, dim, name=name)
 
-    def datavar(self, dim):
-        return self._var(_lib.VARKIND_DATA, dim)
+    def datavar(self, dim, name=""):
+        return self._var(_lib.VARKIND_DATA, dim, name=name)
 
-    def constvar(self, value):
+    def constvar(self, value, name=""):
         v = np.atleast_1d(np.asarray(value, dtype=np.float64))
         rows, cols = (v.shape[0], 1) if v.ndim == 1 else v.shape
         off = self._n
         self.pool.append(v.ravel())
         self._n += v.size
-        return self._var(_lib.VARKIND_CONST, rows, cols, off)
+        return self._var(_lib.VARKIND_CONST, rows, cols, off, name=name)
+
+    # ---- exchange format "rxhip-graph-1": what HIPInferencePlugin.jl's `dump_graph` writes after walking a GraphPPL model ----
+    def to_dump(self, n_replicas=1, n_observations=0):
+        pool = np.concatenate(self.pool) if self.pool else np.zeros(0)
+        kinds = ("random", "data", "constant")
+        fams = {v: k for k, v in INIT_FAMILIES.items()}
+        ends = sorted([o for o in self.coff if o >= 0] + list(self.init_off.values()) + [pool.size])
+        variables = []
+        for i in range(len(self.kind)):
+            v = {"name": self.names[i], "kind": kinds[self.kind[i]], "rows": int(self.rows[i]), "cols": int(self.cols[i])}
+            if self.coff[i] >= 0:
+                v["value"] = pool[self.coff[i]:self.coff[i] + self.rows[i] * self.cols[i]].tolist()
+            if i in self.init_family:
+                o = self.init_off[i]
+                v["init"] = {"family": fams[self.init_family[i]], "params": pool[o:min(e for e in ends if e > o)].tolist()}
+            variables.append(v)
+        factors = []
+        for t, ifs in zip(self.ftype, self.fiface):
+            name, order = NODE_VOCABULARY[t]
+            labels = list(order[:2]) + [f"{order[2]}[{k + 1}]" for k in range((len(ifs) - 2) // 2)] + \
+                [f"{order[3]}[{k + 1}]" for k in range((len(ifs) - 2) // 2)] if name == "NormalMixture" else list(order)
+            factors.append({"type": name, "interfaces": [[l, int(v)] for l, v in zip(labels, ifs)]})
+        return {"format": "rxhip-graph-1", "n_replicas": int(n_replicas), "n_observations": int(n_observations),
+                "gh_points": int(self.gh_points), "variables": variables, "factors": factors}
+
+    @classmethod
+    def from_dump(cls, dump):
+        """Rebuild the tables from a dump (a dict, or the path of a .json / .json.gz file)."""
+        if not isinstance(dump, dict):
+            import gzip
+            import json
+
+            with (gzip.open(dump, "rt") if str(dump).endswith(".gz") else open(dump)) as f:
+                dump = json.load(f)
+        if dump.get("format") != "rxhip-graph-1":
+            raise ValueError("not an rxhip-graph-1 dump")
+        codes = {name: code for code, (name, _) in NODE_VOCABULARY.items()}
+        gb = cls()
+        for v in dump["variables"]:
+            if v["kind"] == "constant":
+                val = np.asarray(v["value"], dtype=np.float64)
+                i = gb.constvar(val.reshape(v["rows"], v["cols"]) if v["cols"] > 1 else val, name=v.get("name", ""))
+            else:
+                i = (gb.randomvar if v["kind"] == "random" else gb.datavar)(v["rows"], name=v.get("name", ""))
+            if "init" in v:
+                gb.initialize(i, INIT_FAMILIES[v["init"]["family"]], v["init"]["params"])
+        for f in dump["factors"]:
+            if f["type"] not in codes:
+                raise RxHipError(_lib.ERR_UNSUPPORTED, f"node {f['type']} has no device schedule")
+            gb.node(codes[f["type"]], *[int(i) for _, i in f["interfaces"]])
+        gb.gh_points = int(dump.get("gh_points", 0))
+        gb.n_replicas, gb.n_observations = int(dump.get("n_replicas", 1)), int(dump.get("n_observations", 0))
+        return gb
 
     def mvnormal_mean_cov(self, out, mu, sigma):
         """out ~ MvNormal(μ = mu, Σ = sigma)  ->  MvNormalMeanCovariance (src/model/graphppl.jl:372-376)"""
