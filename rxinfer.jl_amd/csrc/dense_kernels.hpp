@@ -109,8 +109,8 @@ struct DenseCfg {
     static constexpr int THREADS = 64 * NT;
     static constexpr int NTRI = NT * (NT + 1) / 2;
     static constexpr int TRI = NTRI * 256;           // a symmetric matrix as lower tiles in register order
-    static constexpr int HDR = 2 * D;                // m_f(t) | A m_f(t)
-    static constexpr int REC = HDR + TRI + D * D;    // record: m_f(t) | A m_f(t) | C_t (lower tiles) | G_t (accumulator order)
+    static constexpr int HDR = 3 * D;                // ξ_f(t) | B'Q⁻¹y_t (aggregation kernel) | C_t ξ_f(t) (forward kernel)
+    static constexpr int REC = HDR + 2 * D * D;      // record of a time index: header | C_t | G_t'  (both in accumulator order)
     static constexpr int MAT = D * LD;          // doubles per LDS matrix
 };
 
@@ -537,7 +537,11 @@ struct DenseLds {
     }
     // kd_forward_info: 2 matrices, ξ_f | u | 4 partial-sum rows, the pivot-row buffers
     static constexpr size_t fwd_info_bytes(int dmax) {
-        return sizeof(double) * ((size_t)2 * C::MAT + (size_t)6 * dmax + 8 * C::D);
+        return sizeof(double) * ((size_t)2 * C::MAT + (size_t)10 * dmax + 8 * C::D);
+    }
+    // kd_backward_info: 2 matrices, m_s | C ξ_f, the pivot-row buffers / matvec partials
+    static constexpr size_t bwd_info_bytes(int dmax) {
+        return sizeof(double) * ((size_t)2 * C::MAT + (size_t)2 * dmax + 8 * C::D);
     }
     // kd_agg_finish: 6 vectors, the map (B'Q⁻¹)' and a tile of 16 observations
     static constexpr size_t agg_bytes(int dy) {
@@ -1088,7 +1092,8 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     double* xi = vec;           // ξ_f
     double* u = xi + dm;
     double* xpp = u + dm;       // [4][D] partial sums of ξ_p
-    double* rowbuf = xpp + 4 * dm;  // 8·D doubles
+    double* cpp = xpp + 4 * dm; // [4][D] partial sums of C_t ξ_f(t) (handed to the backward kernel in the record)
+    double* rowbuf = cpp + 4 * dm;  // 8·D doubles
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
@@ -1148,14 +1153,14 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
         }
         // C = (Λ_f + A'P⁻¹A)⁻¹
         ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
-        acc_store_tri<NT>(lam, rec + C::HDR, w, lane);
+        acc_store_full<NT>(lam, rec + C::HDR, w, lane);
         acc_store<NT>(lam, S0, LD, w, lane);
         acc_load<NT>(lam, cst + c.oPLW, D, w, lane);  // lam is dead until M_{t+1} below: the L2 latency hides under G' = K C
         lds_barrier();
         // G' = K C
         acc_zero<NT>(a);
         mm_k(a, S0);
-        acc_store_full<NT>(a, rec + C::HDR + C::TRI, w, lane);
+        acc_store_full<NT>(a, rec + C::HDR + D * D, w, lane);
 #pragma unroll
         for (int q = 0; q < NT; ++q)
 #pragma unroll
@@ -1165,18 +1170,24 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
         // ξ_p = K C ξ_f = G' ξ_f: column sums of S1, a quarter of the range per thread group;
         // M_{t+1} = Λ_f(t) + A'P⁻¹A = PLW − K G
         {
-            double s0 = 0.0, s1 = 0.0;
+            double s0 = 0.0, s1 = 0.0, c0 = 0.0, c1 = 0.0;
             const int k0 = grp * (D / 4);
 #pragma unroll
             for (int k = 0; k < D / 4; k += 2) {
                 s0 += S1[(k0 + k) * LD + gi] * xi[k0 + k];
                 s1 += S1[(k0 + k + 1) * LD + gi] * xi[k0 + k + 1];
+                c0 += S0[(k0 + k) * LD + gi] * xi[k0 + k];          // C is symmetric: column sums are conflict-free
+                c1 += S0[(k0 + k + 1) * LD + gi] * xi[k0 + k + 1];
             }
             xpp[grp * D + gi] = s0 + s1;
+            cpp[grp * D + gi] = c0 + c1;
         }
         mm_k(lam, S1);
         lds_barrier();
-        if (tid < D) xi[tid] = gyc - ((xpp[tid] + xpp[D + tid]) + (xpp[2 * D + tid] + xpp[3 * D + tid]));  // ξ_f(t)
+        if (tid < D) {
+            rec[2 * D + tid] = (cpp[tid] + cpp[D + tid]) + (cpp[2 * D + tid] + cpp[3 * D + tid]);      // C_{t−1} ξ_f(t−1)
+            xi[tid] = gyc - ((xpp[tid] + xpp[D + tid]) + (xpp[2 * D + tid] + xpp[3 * D + tid]));       // ξ_f(t)
+        }
         acc_store<NT>(lam, S1, LD, w, lane);       // G is no longer needed: S1 carries M for the symmetrisation
         lds_barrier();
         acc_symmetrise<NT>(lam, S1, LD, w, lane);
@@ -1189,22 +1200,26 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
 }
 
 template <int NT, bool FE>
-__global__ void __launch_bounds__(64 * NT) kd_backward_info(DenseParams p) {
+__global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) {  // ≥ 2 waves per SIMD: ≤ 256 registers
     constexpr int D = 16 * NT;
     using C = DenseCfg<NT>;
     constexpr int LD = C::LD;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int dy = p.dy, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int dm = ((D > dy ? D : dy) + 1) & ~1;
-    double* M0 = smem;          // C_t
-    double* M1 = M0 + C::MAT;   // H = G V_s
-    double* M2 = M1 + C::MAT;   // V_s
-    double* M3 = M2 + C::MAT;   // G_t
-    double* vec = M3 + C::MAT;
+    // Two LDS matrices (73 KB at d = 64), so that two workgroups share a CU as in the forward kernel:
+    //   MV  V_s(t+1) as the B operand of H = G V_s; then every wave parks ITS OWN 16 rows of H there to re-read them as the A
+    //       operand of V_s(t) = C + H G' (accumulator layout -> operand layout is a wave-local exchange);
+    //   MG  G_t' exactly as the record holds it (MG[k][j] = G[j][k]): the B operand of the second contraction, the A operand
+    //       of the first one (read transposed), and — by columns, conflict-free — the matvec G m_s.
+    // C_t never touches LDS: the record carries it in accumulator order (it is the accumulator's initial value) together
+    // with C_t ξ_f(t), formed in the forward kernel where both operands sit in LDS anyway.
+    double* MV = smem;
+    double* MG = MV + C::MAT;
+    double* vec = MG + C::MAT;
     double* ms = vec;           // m_s(t+1), then m_s(t)
-    double* xf = ms + dm;       // ξ_f(t)
-    double* tmp = xf + dm;
-    double* rowbuf = tmp + dm;  // 8·D doubles
+    double* xf = ms + dm;       // boundary: ξ_f + ξβ; in the loop: C_t ξ_f(t)
+    double* rowbuf = xf + dm;   // 8·D doubles: pivot rows of the last segment's inverse, then the matvec partials
     const long long seg = blockIdx.x, chain = blockIdx.y;
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = p.cst;
@@ -1222,33 +1237,32 @@ __global__ void __launch_bounds__(64 * NT) kd_backward_info(DenseParams p) {
     {
         if (tid < D) xf[tid] = p.filt[(chain * p.T + te) * C::REC + tid] + p.beta_xi[(chain * (p.S + 1) + seg + 1) * D + tid];
         if (seg == p.S - 1) {  // uniform over the workgroup
-            tri_to_lds<NT>(p.vend + (chain * p.S + seg) * C::TRI, M0, LD, w, lane);
+            tri_to_lds<NT>(p.vend + (chain * p.S + seg) * C::TRI, MV, LD, w, lane);
             lds_barrier();
-            acc_load<NT>(a, M0, LD, w, lane);
+            acc_load<NT>(a, MV, LD, w, lane);
+            lds_barrier();  // every wave has its rows in registers before MV is overwritten below
             ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpe) && ok;
         } else
             acc_load<NT>(a, p.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);
-        acc_store<NT>(a, M2, LD, w, lane);
+        acc_store<NT>(a, MV, LD, w, lane);
         lds_barrier();
-        matvec_lds(ms, M2, LD, D, D, xf, nullptr, 0.0, tid);
+        matvec_lds(ms, MV, LD, D, D, xf, nullptr, 0.0, tid);
         lds_barrier();
         if (seg == p.S - 1) {
             if (tid < p.d_out) p.mean[(te * p.n_chains + chain) * p.d_out + tid] = ms[tid];
             acc_store_out<NT>(a, p.cov + (te * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
         }
     }
-    Acc<NT> gN, cN;
-    double xfN = 0.0;
-    auto prefetch = [&](long long tt) {
+    Acc<NT> gN, cc;
+    double cxN = 0.0;
+    auto prefetch = [&](long long tt) {   // G_tt' and C_tt ξ_f(tt) of the NEXT step travel under the current one
         const double* rec = p.filt + (chain * p.T + tt) * C::REC;
-        acc_load_full<NT>(gN, rec + C::HDR + C::TRI, w, lane);
-        tri_load<NT>(cN, rec + C::HDR, w, lane);
-        if (tid < D) xfN = rec[tid];
+        acc_load_full<NT>(gN, rec + C::HDR + D * D, w, lane);
+        if (tid < D) cxN = rec[2 * D + tid];
     };
     auto commit = [&]() {
-        acc_store_T<NT>(gN, M3, LD, w, lane);        // the record holds G'
-        tri_regs_to_lds<NT>(cN, M0, LD, w, lane);    // C_t
-        if (tid < D) xf[tid] = xfN;
+        acc_store<NT>(gN, MG, LD, w, lane);
+        if (tid < D) xf[tid] = cxN;
     };
     if (te - 1 >= tb) {
         prefetch(te - 1);
@@ -1257,31 +1271,33 @@ __global__ void __launch_bounds__(64 * NT) kd_backward_info(DenseParams p) {
     lds_barrier();
     for (long long t = te - 1; t >= tb; --t) {
         prefetch(t - 1 >= tb ? t - 1 : tb);
-        // m_s(t) = C ξ_f + G m_s(t+1): thread group `grp` sums a quarter of the k range (partials in rowbuf, free after the prologue)
+        // C_t: the accumulator of the second contraction; its L2 / HBM latency hides under the first one
+        acc_load_full<NT>(cc, p.filt + (chain * p.T + t) * C::REC + C::HDR, w, lane);
+        // G m_s(t+1): thread group `grp` sums a quarter of the k range down the columns of MG (consecutive threads read
+        // consecutive addresses)
         {
             const int k0 = grp * (D / 4);
             double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-            for (int k = 0; k < D / 4; ++k) {
-                s0 += M0[gi * LD + k0 + k] * xf[k0 + k];
-                s1 += M3[gi * LD + k0 + k] * ms[k0 + k];
+            for (int k = 0; k < D / 4; k += 2) {
+                s0 += MG[(k0 + k) * LD + gi] * ms[k0 + k];
+                s1 += MG[(k0 + k + 1) * LD + gi] * ms[k0 + k + 1];
             }
             rowbuf[grp * D + gi] = s0 + s1;
         }
         // H = G V_s
         acc_zero<NT>(a);
-        mm_acc<NT, false, false>(a, M3, LD, M2, LD, w, lane);
-        acc_store<NT>(a, M1, LD, w, lane);
-        lds_barrier();
+        mm_acc<NT, true, false>(a, MG, LD, MV, LD, w, lane);
+        lds_barrier();  // every wave is through with V_s; the matvec partials are complete
         double mnew = 0.0;
-        if (tid < D) mnew = (rowbuf[tid] + rowbuf[D + tid]) + (rowbuf[2 * D + tid] + rowbuf[3 * D + tid]);
-        // V_s = C + H G'
-        acc_load<NT>(a, M0, LD, w, lane);
-        mm_acc<NT, false, true>(a, M1, LD, M3, LD, w, lane);
+        if (tid < D) mnew = xf[tid] + ((rowbuf[tid] + rowbuf[D + tid]) + (rowbuf[2 * D + tid] + rowbuf[3 * D + tid]));
+        acc_store<NT>(a, MV, LD, w, lane);  // this wave's rows of H; only this wave reads them back (LDS is in order per wave)
+        // V_s(t) = C + H G'
+        mm_acc<NT, false, false>(cc, MV, LD, MG, LD, w, lane);
         if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = mnew;
-        acc_store_out<NT>(a, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
-        acc_store<NT>(a, M2, LD, w, lane);  // mm1 (the only reader of M2) finished before the barrier above
-        lds_barrier();
+        acc_store_out<NT>(cc, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
+        lds_barrier();  // every wave is through with G' (and with its rows of H)
+        acc_store<NT>(cc, MV, LD, w, lane);
         if (tid < D) ms[tid] = mnew;
         commit();
         lds_barrier();

@@ -728,8 +728,9 @@ struct DenseLaunch {
     }
     static void backward_info(const DenseParams& p, bool fe, hipStream_t s) {
         dim3 g(p.S, (unsigned)p.n_chains);
-        if (fe) hipLaunchKernelGGL((kd_backward_info<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
-        else hipLaunchKernelGGL((kd_backward_info<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        const size_t lds = DenseLds<NT>::bwd_info_bytes(((p.d > p.dy ? p.d : p.dy) + 1) & ~1);
+        if (fe) hipLaunchKernelGGL((kd_backward_info<NT, true>), g, dim3(64 * NT), lds, s, p);
+        else hipLaunchKernelGGL((kd_backward_info<NT, false>), g, dim3(64 * NT), lds, s, p);
     }
 };
 // free-energy residual terms of an information-form smoothing run: one workgroup per FR_STEPS steps, partial slots 2S…
@@ -745,7 +746,7 @@ static void launch_fe_resid(const DenseParams& p, hipStream_t s) {
         default: DenseLaunch<4>::CALL; break;       \
     }
 static int dense_tri(int nt) { return nt * (nt + 1) / 2 * 256; }
-static int dense_rec(int nt) { return 2 * 16 * nt + dense_tri(nt) + 256 * nt * nt; }
+static int dense_rec(int nt) { return 3 * 16 * nt + 2 * 256 * nt * nt; }  // DenseCfg<NT>::REC
 
 // Per-model tables of the dense path: constants, per-offset gains (K_i, U_i), and the data-independent
 // matrix part of the boundary scan for every segment (see dense_kernels.hpp DenseParams::scanm).
@@ -2400,11 +2401,26 @@ struct Rccl {
 Rccl& rccl() {
     static Rccl* r = [] {
         Rccl* q = new Rccl;
-        const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        // the copy the host process already uses, if any: two RCCL builds in one process do not coexist (torch ships its own
-        // as "librccl.so" with SONAME librccl.so.1; glibc matches the name a library was loaded under, so both are tried)
-        for (int i = 0; !q->h && i < 2; ++i) q->h = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD);
-        for (int i = 0; !q->h && i < 3; ++i) q->h = dlopen(names[i], RTLD_NOW | RTLD_LOCAL);
+        // The RCCL to use is the one that belongs to the HIP runtime THIS library runs on: streams and device pointers of
+        // one ROCm installation mean nothing to the libraries of another, and a process may carry two (a pip-installed
+        // torch bundles its own librccl / libhsa-runtime64 next to its libamdhip64).  So: the directory of the loaded
+        // libamdhip64 (dladdr of a HIP entry point) first, then the usual names.  RTLD_DEEPBIND keeps a second RCCL copy in
+        // the process from interposing this one's internal symbols.
+        std::vector<std::string> names;
+        Dl_info di;
+        if (dladdr((const void*)&hipGetDeviceCount, &di) && di.dli_fname) {
+            std::string dir(di.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                names.push_back(dir + "librccl.so.1");
+                names.push_back(dir + "librccl.so");
+            }
+        }
+        names.push_back("librccl.so.1");
+        names.push_back("librccl.so");
+        names.push_back("/opt/rocm/lib/librccl.so.1");
+        for (size_t i = 0; !q->h && i < names.size(); ++i) q->h = dlopen(names[i].c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
         if (!q->h) { q->err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return q; }
         bool all = true;
         auto sym = [&](const char* n) { void* p = dlsym(q->h, n); if (!p) { all = false; q->err = std::string("librccl lacks ") + n; } return p; };
