@@ -10,10 +10,12 @@
  * Conventions: plain C, no exceptions cross the ABI, every function returns an rxhip_status
  * (0 = ok).  All matrices are dense row-major IEEE fp64.  The caller owns every host buffer it
  * passes; the engine copies what it needs and owns its device memory until rxhip_destroy.
- * One host thread per handle; handles are independent.  The only process-wide state is a mutex-protected pool of idle
- * engine-owned HIP streams and of up to 128 MB of small device blocks per device (stream creation / destruction costs
- * milliseconds and hipFree ≈0.15 ms on this runtime — more than a whole sweep of the reference's own benchmark sizes);
- * rxhip_release_cached_memory() returns the parked blocks to the driver.
+ * One host thread per handle; handles are independent.  The only process-wide state is mutex-protected and exists because
+ * `infer(...)` builds an engine per call while driver calls cost more than a sweep of the reference's own benchmark sizes:
+ * a pool of idle engine-owned HIP streams (creation / destruction costs milliseconds on this runtime), up to 4 parked device
+ * blocks / 4 GB per process (hipFree ≈0.15 ms for megabytes, tens of ms for a gigabyte), and the read-only per-model tables of
+ * the MFMA path, shared by reference count between engines of the same model (≈50 ms of host recursions + a 100 MB upload at
+ * d = 64 otherwise).  rxhip_release_cached_memory() returns everything idle to the driver.
  */
 #ifndef RXHIP_H
 #define RXHIP_H

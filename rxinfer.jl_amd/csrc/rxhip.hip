@@ -46,6 +46,20 @@ struct LgssmVtbl {
 
 static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
 
+// RXHIP_TRACE=1: stage timings of engine creation on stderr (measurement aid, off by default)
+#include <chrono>
+struct StageTrace {
+    bool on;
+    std::chrono::steady_clock::time_point t0;
+    StageTrace() : on(std::getenv("RXHIP_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what) {
+        if (!on) return;
+        const auto t1 = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[rxhip] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+};
+
 template <int D, int DY>
 struct Launch {
     using CL = CstLayout<D, DY>;
@@ -228,6 +242,7 @@ struct rxhip_engine {
     int scan_sg = 1, scan_ng = 1;  // two-level boundary scan of the dense path: group size, groups
     int agg_oc = 1, agg_kc = 1;    // dense aggregation product: offsets per K-chunk, K-chunks
     double* d_aggpart = nullptr;   // [chain][agg_kc][S][2·dpad] partial sums of kd_agg_gemm
+    struct DenseTables* dt = nullptr;  // shared per-model device tables of the MFMA path (d_cst, d_tab, d_scanm, d_qtab, d_bnd point into it)
     std::vector<double> h_cst0;  // model 0's constant block (kernel argument when all chains share it)
     int fe_total_cap = 0;
     // results bookkeeping
@@ -273,8 +288,9 @@ static hipError_t stream_acquire(int device, hipStream_t* out) {
     }
     return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
 }
-// Small arenas (≤ 64 MB) are parked the same way — hipFree of a multi-megabyte block costs ≈120–170 µs, more than a whole
-// sweep of the reference's own benchmark sizes.  At most 4 blocks / 128 MB are kept; rxhip_release_cached_memory() frees them.
+// Arenas up to 2 GB are parked the same way — hipFree of a multi-megabyte block costs ≈120–170 µs (more than a whole sweep of
+// the reference's own benchmark sizes), hipMalloc + hipFree of the 1 GB of a d = 64, T = 10⁴ engine ≈40 ms.  At most 4 blocks /
+// 4 GB are kept; rxhip_release_cached_memory() frees them.
 struct ArenaPool {
     struct Blk { int device; char* p; size_t bytes; };
     std::mutex m;
@@ -299,7 +315,7 @@ static char* arena_acquire(int device, size_t need, size_t* got) {
     return nullptr;
 }
 static void arena_release(int device, char* p, size_t bytes) {
-    if (bytes > ((size_t)64 << 20)) {
+    if (bytes > ((size_t)2 << 30)) {
         (void)hipFree(p);
         return;
     }
@@ -307,7 +323,7 @@ static void arena_release(int device, char* p, size_t bytes) {
     {
         ArenaPool& ap = arena_pool();
         std::lock_guard<std::mutex> g(ap.m);
-        while (!ap.idle.empty() && (ap.idle.size() >= 4 || ap.total + bytes > ((size_t)128 << 20))) {  // least recently parked first
+        while (!ap.idle.empty() && (ap.idle.size() >= 4 || ap.total + bytes > ((size_t)4 << 30))) {  // least recently parked first
             evict.push_back(ap.idle.front().p);
             ap.total -= ap.idle.front().bytes;
             ap.idle.erase(ap.idle.begin());
@@ -328,6 +344,97 @@ static void stream_release(int device, hipStream_t s) {
         }
     }
     (void)hipStreamDestroy(s);
+}
+
+
+// minimal "run this scope on device d, then go back" (the HIPCHK-aware DevGuard below needs an engine for its message)
+struct DevGuardLite {
+    int prev = -1;
+    bool changed = false;
+    explicit DevGuardLite(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevGuardLite() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+};
+
+// ---- per-model device tables of the MFMA path, shared between engines ---------------------------------------------
+// Constants, per-offset aggregation maps, boundary-scan maps and the boundary inverses depend on the model and the
+// schedule only.  Building them costs ≈50 ms of host Riccati recursions + a 100 MB upload at d = 64 — two orders of
+// magnitude more than a sweep — and `infer(...)` builds an engine per call, so engines of the same model (same bytes) share
+// ONE read-only device copy: reference counted, a few idle copies kept (least recently used first out),
+// rxhip_release_cached_memory() drops the idle ones.  Part of the library's mutex-protected process-wide state.
+struct DenseTables {
+    std::vector<unsigned char> key;
+    int device = 0;
+    char* block = nullptr;
+    size_t bytes = 0;
+    double *d_cst = nullptr, *d_tab = nullptr, *d_scanm = nullptr, *d_qtab = nullptr, *d_bnd = nullptr;
+    int agg_oc = 1, agg_kc = 1, scan_sg = 1, scan_ng = 1;
+    int refs = 0;
+    unsigned long long last_use = 0;
+};
+struct DenseTablesPool {
+    std::mutex m;
+    std::vector<DenseTables*> all;
+    unsigned long long clock = 0;
+};
+static DenseTablesPool& dense_tables_pool() {
+    static DenseTablesPool* p = new DenseTablesPool;
+    return *p;
+}
+static DenseTables* dense_tables_acquire(const std::vector<unsigned char>& key, int device) {
+    DenseTablesPool& tp = dense_tables_pool();
+    std::lock_guard<std::mutex> g(tp.m);
+    for (DenseTables* t : tp.all)
+        if (t->device == device && t->key == key) {
+            t->refs++;
+            t->last_use = ++tp.clock;
+            return t;
+        }
+    return nullptr;
+}
+static void dense_tables_insert(DenseTables* t) {
+    DenseTablesPool& tp = dense_tables_pool();
+    std::lock_guard<std::mutex> g(tp.m);
+    t->refs = 1;
+    t->last_use = ++tp.clock;
+    tp.all.push_back(t);
+}
+// drop idle entries beyond `keep_idle` copies / `keep_bytes` bytes (least recently used first)
+static void dense_tables_trim(size_t keep_idle, size_t keep_bytes) {
+    std::vector<DenseTables*> victims;
+    {
+        DenseTablesPool& tp = dense_tables_pool();
+        std::lock_guard<std::mutex> g(tp.m);
+        for (;;) {
+            size_t idle = 0, bytes = 0;
+            DenseTables* lru = nullptr;
+            for (DenseTables* t : tp.all)
+                if (t->refs == 0) {
+                    ++idle;
+                    bytes += t->bytes;
+                    if (!lru || t->last_use < lru->last_use) lru = t;
+                }
+            if (!lru || (idle <= keep_idle && bytes <= keep_bytes)) break;
+            for (size_t i = 0; i < tp.all.size(); ++i)
+                if (tp.all[i] == lru) { tp.all.erase(tp.all.begin() + (long)i); break; }
+            victims.push_back(lru);
+        }
+    }
+    for (DenseTables* t : victims) {
+        DevGuardLite dg(t->device);
+        (void)hipFree(t->block);
+        delete t;
+    }
+}
+static void dense_tables_release(DenseTables* t) {
+    {
+        DenseTablesPool& tp = dense_tables_pool();
+        std::lock_guard<std::mutex> g(tp.m);
+        t->refs--;
+    }
+    dense_tables_trim(4, (size_t)1 << 30);
 }
 
 // ---- arena planning: register every buffer, then one hipMalloc, one upload of the table block, one memset ----
@@ -1149,6 +1256,12 @@ const char* rxhip_last_error(const rxhip_engine* e) { return e ? e->err.c_str() 
 static void free_all(rxhip_engine* e) {
     DevGuard dg;
     if (e->device >= 0) (void)dg.set(e->device);
+    if (e->dt) {  // shared tables: not this engine's to free; nothing may still read them
+        if (e->stream) (void)hipStreamSynchronize(e->stream);
+        e->d_cst = e->d_tab = e->d_scanm = e->d_qtab = e->d_bnd = nullptr;
+        dense_tables_release(e->dt);
+        e->dt = nullptr;
+    }
     double** bufs[] = {&e->d_vtab, &e->d_scan, &e->d_filt, &e->d_mean, &e->d_cov, &e->d_cst, &e->d_tab, &e->d_agg, &e->d_elem,
                        &e->d_fstart, &e->d_beta, &e->d_fe_part, &e->d_fe_chain, &e->d_fe_total};
     for (auto b : bufs)
@@ -1178,6 +1291,7 @@ static void free_all(rxhip_engine* e) {
 }
 
 rxhip_status rxhip_release_cached_memory(void) {
+    dense_tables_trim(0, 0);
     ArenaPool& ap = arena_pool();
     std::lock_guard<std::mutex> g(ap.m);
     for (auto& b : ap.idle) {
@@ -1278,20 +1392,79 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     }
 
     if (dense) {
-        std::vector<double> cst, tab, scanm, qtab;
-        rxhip_status st = build_dense_tables(e, ds, cst, tab, scanm, qtab);
-        if (st) return st;
+        StageTrace tr;
         hipError_t herr = hipSuccess;
         DENSE_DISPATCH(e->nt, prepare() == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
         if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1), D = (size_t)e->dpad,
                      Du = (size_t)e->d;
+        // the model's tables: shared with every other engine of the same model and schedule on this device
+        std::vector<unsigned char> key;
+        {
+            const long long hdr[8] = {e->d, e->dy, e->T, e->S, e->L, e->Llast, e->ptt, e->dpad};
+            auto put = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; key.insert(key.end(), b, b + n); };
+            put(hdr, sizeof hdr);
+            put(ds->A, sizeof(double) * Du * Du); put(ds->B, sizeof(double) * e->dy * Du); put(ds->P, sizeof(double) * Du * Du);
+            put(ds->Q, sizeof(double) * e->dy * e->dy); put(ds->m0, sizeof(double) * Du); put(ds->V0, sizeof(double) * Du * Du);
+        }
+        rxhip_status st = RXHIP_OK;
+        DenseTables* dt = dense_tables_acquire(key, e->device);
+        if (!dt) {
+            std::vector<double> cst, tab, scanm, qtab;
+            st = build_dense_tables(e, ds, cst, tab, scanm, qtab);
+            if (st) return st;
+            tr.mark("dense: host tables");
+            dt = new DenseTables;
+            dt->key.swap(key);
+            dt->device = e->device;
+            dt->agg_oc = e->agg_oc; dt->agg_kc = e->agg_kc; dt->scan_sg = e->scan_sg; dt->scan_ng = e->scan_ng;
+            const size_t nb[5] = {cst.size(), tab.size(), scanm.size(), qtab.size(), Sg * 2 * D * D};
+            size_t off[6] = {0};
+            for (int q = 0; q < 5; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * (nb[q] ? nb[q] : 1));
+            dt->bytes = off[5];
+            if (hipMalloc(&dt->block, dt->bytes) != hipSuccess) { delete dt; return fail(e, RXHIP_ERR_HIP, "hipMalloc of %zu bytes (model tables) failed", off[5]); }
+            double** dst[5] = {&dt->d_cst, &dt->d_tab, &dt->d_scanm, &dt->d_qtab, &dt->d_bnd};
+            const std::vector<double>* src[4] = {&cst, &tab, &scanm, &qtab};
+            hipError_t up = hipSuccess;
+            for (int q = 0; q < 5; ++q) *dst[q] = (double*)(dt->block + off[q]);
+            for (int q = 0; q < 4 && up == hipSuccess; ++q)
+                up = hipMemcpyAsync(*dst[q], src[q]->data(), sizeof(double) * src[q]->size(), hipMemcpyHostToDevice, e->stream);
+            if (up == hipSuccess && e->S > 0) {  // data-independent inverses at the segment boundaries: once per model, on the device
+                DenseParams dp{};
+                dp.S = e->S; dp.d = e->dpad; dp.dy = e->dy; dp.scanm = dt->d_scanm; dp.bnd = dt->d_bnd; dp.status = nullptr;
+                int* d_st = nullptr;
+                up = hipMalloc(&d_st, sizeof(int));
+                if (up == hipSuccess) up = hipMemsetAsync(d_st, 0, sizeof(int), e->stream);
+                dp.status = d_st;
+                if (up == hipSuccess) {
+                    DENSE_DISPATCH(e->nt, prepare_bnd(dp, e->stream));
+                    up = hipGetLastError();
+                }
+                int hst = 0;
+                if (up == hipSuccess) up = hipMemcpyAsync(&hst, d_st, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+                if (up == hipSuccess) up = hipStreamSynchronize(e->stream);
+                if (d_st) (void)hipFree(d_st);
+                if (up == hipSuccess && hst) {
+                    (void)hipFree(dt->block);
+                    delete dt;
+                    return fail(e, RXHIP_ERR_NOT_POSDEF, "a boundary covariance / precision of the model is not positive definite");
+                }
+            } else if (up == hipSuccess)
+                up = hipStreamSynchronize(e->stream);  // the host vectors die at the end of this scope
+            if (up != hipSuccess) {
+                (void)hipFree(dt->block);
+                delete dt;
+                return fail(e, RXHIP_ERR_HIP, "upload of the model tables failed: %s", hipGetErrorString(up));
+            }
+            dense_tables_insert(dt);
+            tr.mark("dense: table upload + bnd");
+        } else {
+            e->agg_oc = dt->agg_oc; e->agg_kc = dt->agg_kc; e->scan_sg = dt->scan_sg; e->scan_ng = dt->scan_ng;
+            tr.mark("dense: tables from cache");
+        }
+        e->dt = dt;
+        e->d_cst = dt->d_cst; e->d_tab = dt->d_tab; e->d_scanm = dt->d_scanm; e->d_qtab = dt->d_qtab; e->d_bnd = dt->d_bnd;
         ArenaPlan ap;
-        ap.upload(&e->d_cst, cst.data(), sizeof(double) * cst.size());
-        ap.upload(&e->d_tab, tab.data(), sizeof(double) * tab.size());
-        ap.upload(&e->d_scanm, scanm.data(), sizeof(double) * scanm.size());
-        ap.upload(&e->d_qtab, qtab.data(), sizeof(double) * qtab.size());
-        ap.plain(&e->d_bnd, sizeof(double) * Sg * 2 * D * D);
         ap.plain(&e->d_loc, sizeof(double) * C * 2 * Sg * D);
         ap.plain(&e->d_aggpart, sizeof(double) * C * (size_t)e->agg_kc * Sg * 2 * D);
         ap.zeroed(&e->d_status, sizeof(int));
@@ -1309,12 +1482,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_beta_xi, sizeof(double) * C * (Sg + 1) * D);
         ap.plain(&e->d_fe_chain, sizeof(double) * C);
         if ((st = arena_commit(e, ap))) return st;
-        if (e->S > 0) {  // data-independent inverses at the segment boundaries: once per engine, on the device
-            DenseParams dp{};
-            dp.S = e->S; dp.d = e->dpad; dp.dy = e->dy; dp.scanm = e->d_scanm; dp.bnd = e->d_bnd; dp.status = e->d_status;
-            DENSE_DISPATCH(e->nt, prepare_bnd(dp, e->stream));
-            HIPCHK(e, hipGetLastError());
-        }
+        tr.mark("dense: work buffers");
         return RXHIP_OK;
     }
     // per-model tables
