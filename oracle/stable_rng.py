@@ -87,6 +87,84 @@ class StableRNG:
         """rand(rng, Normal(mu, sigma))"""
         return mu + sigma * self.randn()
 
+    def rand_range(self, n):
+        """rand(rng, 1:n) for a StableRNG: StableRNGs pins `SamplerRangeFast` for its generator — the low
+        bits of one UInt64 under the mask of n − 1, rejection above n − 1.  Returns a 0-based index."""
+        m = n - 1
+        mask = (1 << m.bit_length()) - 1
+        while True:
+            x = self.rand_u64() & mask
+            if x <= m:
+                return x
+
+    def categorical_alias_table(self, probs):
+        """`rand(rng, Categorical(p))` through AliasTables.jl 1.1 (Distributions ≥ 0.25.109; benchmarks/Manifest.toml:158-162):
+        one UInt64 per draw, the top bits select a cell of the power-of-two table, the remaining bits, left-aligned, are
+        compared with the cell's redirect threshold (values below it go to the cell's alias).  A deficient cell draws from the
+        first element that still has surplus; a donor that falls short in its own cell joins the queue.  Layout restated from the package's
+        documentation, not from its source (absent here) — see tests/test_golden_reference.py for what pins it.  0-based."""
+        table = getattr(self, "_alias_cache", {}).get(tuple(probs))
+        if table is None:
+            K = len(probs)
+            n = 1 << max(K - 1, 0).bit_length() if K > 1 else 1
+            cap = 1.0 / n
+            rem = [float(p) / sum(probs) for p in probs] + [0.0] * (n - K)   # mass of element i still to be placed
+            table = [(0.0, i) for i in range(n)]                              # (fraction of the cell that redirects, where to)
+            queue = [i for i in range(n) if rem[i] < cap - 1e-18]             # deficient cells, in index order
+            while queue:
+                i = queue.pop(0)
+                need = cap - rem[i]
+                donor = next((j for j in range(n) if rem[j] > cap + 1e-18), None)
+                if donor is None:
+                    break                                                      # rounding residue only
+                table[i] = (need / cap, donor)
+                rem[donor] -= need
+                if rem[donor] < cap - 1e-18:
+                    queue.append(donor)                                        # the donor's own cell is now short
+            self._alias_cache = getattr(self, "_alias_cache", {})
+            self._alias_cache[tuple(probs)] = table
+        n = len(table)
+        shift = (n - 1).bit_length()
+        x = self.rand_u64()
+        cell = x >> (64 - shift) if shift else 0
+        val = (x << shift) & ((1 << 64) - 1)
+        frac, alias = table[cell]
+        return alias if val < int(frac * 2.0 ** 64) else cell
+
+    def categorical_legacy_alias(self, probs):
+        """The sampler Distributions used before AliasTables.jl (StatsBase.make_alias_table! + two draws per sample:
+        `i = rand(rng, 1:K)`, `u = rand(rng)`, `u < accept[i] ? i : alias[i]`).  0-based."""
+        K = len(probs)
+        key = ("legacy",) + tuple(probs)
+        tab = getattr(self, "_alias_cache", {}).get(key)
+        if tab is None:
+            a = [p * K / sum(probs) for p in probs]
+            alias = list(range(K))
+            larges = [i for i in range(K) if a[i] > 1.0]
+            smalls = [i for i in range(K) if a[i] < 1.0]
+            while larges and smalls:
+                sm, lg = smalls.pop(), larges.pop()
+                alias[sm] = lg
+                a[lg] = (a[lg] - 1.0) + a[sm]
+                (larges if a[lg] > 1.0 else smalls).append(lg)
+            for i in smalls:
+                a[i] = 1.0
+            tab = (a, alias)
+            self._alias_cache = getattr(self, "_alias_cache", {})
+            self._alias_cache[key] = tab
+        a, alias = tab
+        i = self.rand_range(K)
+        return i if self.rand() < a[i] else alias[i]
+
+    def categorical_inverse_cdf(self, probs):
+        """`rand(rng, d::DiscreteNonParametric)` for a SINGLE draw: inverse CDF on one `rand(rng)`.  0-based."""
+        u, c = self.rand(), 0.0
+        for i, p in enumerate(probs):
+            c += p
+            if u < c:
+                return i
+        return len(probs) - 1
+
     def mvnormal(self, mu, cov):
         """rand(rng, MvNormal(mu, cov))"""
         L = np.linalg.cholesky(np.asarray(cov, dtype=np.float64))

