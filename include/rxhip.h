@@ -86,6 +86,9 @@ typedef struct {
     int32_t segments; /* time segments per chain for the parallel-in-time schedule; 0 = auto */
     int32_t device;   /* HIP device ordinal; -1 = current device */
     void* stream;     /* hipStream_t to run on; NULL = engine-owned stream */
+    int64_t horizon;  /* further time indices T+1 … T+horizon WITHOUT an observation (`missing` at the end of the data,
+                         test/inference/inference_tests.jl `predictvars`): their posteriors are forward predictions; the
+                         posterior arrays then hold T + horizon rows.  d, dy ≤ 4 only; 0 = none */
 } rxhip_lgssm_desc;
 
 /* replaces: create_model(...) + postprocess_plugin (src/inference/batch.jl:252,
@@ -266,6 +269,13 @@ rxhip_status rxhip_sync(rxhip_engine* e);
  * batch.jl:325-340) followed by mean_cov of the posterior (src/inference/postprocess.jl:32-38).
  * mean: T*n_chains*d doubles, cov: T*n_chains*d*d doubles (either may be NULL), in `layout`. */
 rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout);
+
+/* replaces: obtain_prediction(var) |> subscribe! (reactivemp_inference.jl:619-624; `predictvars = (y = KeepLast(),)`):
+ * the message toward every data variable y[t], N(B m, B V B' + Q) with (m, V) the product of the forward and backward
+ * messages into x[t] — its own observation excluded — and, for the `horizon` unobserved steps, of the forward prediction.
+ * mean: (T+horizon)*n_chains*dy doubles, cov: …*dy*dy (either may be NULL), in `layout`.  After rxhip_run; d, dy ≤ 4.
+ * (The reference refuses free_energy together with predictions, src/inference/batch.jl:337-341; here both are available.) */
+rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout);
 
 /* device views of the same results, layout [T][chain][d] and [T][chain][d][d]; valid until the
  * next run / destroy */

@@ -724,6 +724,120 @@ int rxo_drift_chain_bp(long long T, const double* y, double m0, double v0, doubl
 }
 
 /* ------------------------------------------------------------------------------------------
+ * Predictions (`predictvars = (y = KeepLast(),)`, src/model/plugins/reactivemp_inference.jl:619-624: the stream of the
+ * message toward a data variable).  For y[t] that is MvN_y(:out)(m_μ, q_Σ) = N(B m, B V B' + Q) with (m, V) the
+ * message x[t] -> `*`_B, i.e. the product of the OTHER messages into x[t] — the forward message and the backward message,
+ * NOT its own observation.  The last H time indices have no observation (`missing`): their posteriors are the forward
+ * predictions and nothing flows back from them.  Reference rule order: forward `*`_A(:out), MvN_x(:out); observation
+ * MvN_y(:μ), `*`_B(:in); backward MvN_x(:μ), `*`_A(:in); products left to right.
+ * y: [T][dy] observed part.  pred_mean [T+H][dy], pred_cov [T+H][dy][dy]; post_mean / post_cov (nullable): posteriors of
+ * x for the H unobserved steps ([H][d], [H][d][d]).  prior_through_transition as rxo_lgssm_bp.
+ * ------------------------------------------------------------------------------------------ */
+int rxo_lgssm_predict(int d, int dy, int T, int H, const double* A, const double* B, const double* P, const double* Q,
+                      const double* m0, const double* V0, int ptt, const double* y, double* pred_mean, double* pred_cov,
+                      double* post_mean, double* post_cov) {
+    if (d <= 0 || dy <= 0 || T <= 0 || H < 0 || !pred_mean || !pred_cov) return RXO_ERR_BADARG;
+    const int dm = d > dy ? d : dy;
+    const size_t vs = (size_t)d, ms = (size_t)d * d;
+    int rc = RXO_OK;
+    ctx c;
+    memset(&c, 0, sizeof c);
+    c.work = (double*)malloc(sizeof(double) * (size_t)(16 * dm * dm + 64));
+    double* st = (double*)malloc(sizeof(double) * ((size_t)T * 2 * (vs + ms) + (size_t)(24 * dm * dm + 64)));
+    if (!c.work || !st) { free(c.work); free(st); return RXO_ERR_BADARG; }
+    double* fw_x = st;                 /* forward message into x[t] as WMP: ξ [T][d] */
+    double* fw_L = fw_x + T * vs;      /* Λ [T][d][d] */
+    double* bw_x = fw_L + T * ms;      /* backward message into x[t] (WMP); zero at t = T−1 */
+    double* bw_L = bw_x + T * vs;
+    double* f_m = bw_L + T * ms;       /* scratch */
+    double* f_V = f_m + dm;
+    double* t_m = f_V + dm * dm;
+    double* t_V = t_m + dm;
+    double* t_x = t_V + dm * dm;
+    double* t_L = t_x + dm;
+    double* o_x = t_L + dm * dm;
+    double* o_L = o_x + dm;
+    double* ny_x = o_L + dm * dm;
+    double* ny_L = ny_x + dm;
+    double* a_m = ny_L + dm * dm;
+    double* a_V = a_m + dm;
+    double* chw = a_V + dm * dm;       /* 8 dm² */
+    double* Qi = chw + 8 * dm * dm;
+    rc = cholinv(dy, Q, Qi, NULL, chw);
+    /* ---- forward: the message MvN_x(:out) -> x[t], then x[t] -> next `*`_A = prod(fwd, obs) ---- */
+    for (int t = 0; t < T && !rc; ++t) {
+        if (t == 0) {
+            if (ptt) {  /* x0 ~ prior; x[1] ~ MvN(A x0, P) */
+                rule_mul_out(d, d, A, m0, V0, a_m, a_V, &c);
+                rule_mvn_additive(d, a_m, a_V, P, f_m, f_V, &c);
+            } else
+                rule_mvn_additive(d, m0, NULL, V0, f_m, f_V, &c);
+        } else {
+            /* x[t-1] -> `*`_A: prod(fwd(t-1), obs(t-1)) in WMP, then mean_cov */
+            rc = to_other_param(d, t_x, t_L, t_m, t_V, NULL, chw);
+            if (rc) break;
+            rule_mul_out(d, d, A, t_m, t_V, a_m, a_V, &c);
+            rule_mvn_additive(d, a_m, a_V, P, f_m, f_V, &c);
+        }
+        rc = to_other_param(d, f_m, f_V, fw_x + t * vs, fw_L + t * ms, NULL, chw);
+        if (rc) break;
+        /* observation branch: MvN_y(:μ)(y, Q) = N(y, Q); `*`_B(:in) = WMP(B'Q⁻¹y, B'Q⁻¹B) */
+        matvec(dy, dy, Qi, y + (size_t)t * dy, ny_x);
+        rule_mul_in(dy, d, B, ny_x, Qi, o_x, o_L, &c);
+        prod_wmp(d, fw_x + t * vs, fw_L + t * ms, o_x, o_L, t_x, t_L, &c);
+    }
+    /* (t_x, t_L) = filtered belief of the last observed step: the forecast start */
+    double* fc_x = (double*)malloc(sizeof(double) * (vs + ms));
+    double* fc_L = fc_x + vs;
+    if (!fc_x) rc = RXO_ERR_BADARG;
+    if (!rc) { memcpy(fc_x, t_x, sizeof(double) * vs); memcpy(fc_L, t_L, sizeof(double) * ms); }
+    /* ---- backward messages into x[t]: `*`_A(:in)(MvN_x(:μ)(prod(obs(t+1), bwd(t+1)))) ---- */
+    if (!rc) {
+        memset(bw_x + (size_t)(T - 1) * vs, 0, sizeof(double) * vs);
+        memset(bw_L + (size_t)(T - 1) * ms, 0, sizeof(double) * ms);
+    }
+    for (int t = T - 2; t >= 0 && !rc; --t) {
+        matvec(dy, dy, Qi, y + (size_t)(t + 1) * dy, ny_x);
+        rule_mul_in(dy, d, B, ny_x, Qi, o_x, o_L, &c);
+        if (t + 1 < T - 1) prod_wmp(d, o_x, o_L, bw_x + (size_t)(t + 1) * vs, bw_L + (size_t)(t + 1) * ms, t_x, t_L, &c);
+        else { memcpy(t_x, o_x, sizeof(double) * vs); memcpy(t_L, o_L, sizeof(double) * ms); }
+        rc = to_other_param(d, t_x, t_L, t_m, t_V, NULL, chw);  /* toward MvN_x(:out side) as mean / covariance */
+        if (rc) break;
+        rule_mvn_additive(d, t_m, t_V, P, a_m, a_V, &c);          /* MvN_x(:μ) */
+        rc = to_other_param(d, a_m, a_V, t_x, t_L, NULL, chw);
+        if (rc) break;
+        rule_mul_in(d, d, A, t_x, t_L, bw_x + (size_t)t * vs, bw_L + (size_t)t * ms, &c);
+    }
+    /* ---- predictions of the observed y[t]: x[t] -> `*`_B = prod(fwd, bwd) ---- */
+    for (int t = 0; t < T && !rc; ++t) {
+        if (t < T - 1) prod_wmp(d, fw_x + t * vs, fw_L + t * ms, bw_x + t * vs, bw_L + t * ms, t_x, t_L, &c);
+        else { memcpy(t_x, fw_x + t * vs, sizeof(double) * vs); memcpy(t_L, fw_L + t * ms, sizeof(double) * ms); }
+        rc = to_other_param(d, t_x, t_L, t_m, t_V, NULL, chw);
+        if (rc) break;
+        rule_mul_out(dy, d, B, t_m, t_V, a_m, a_V, &c);
+        rule_mvn_additive(dy, a_m, a_V, Q, pred_mean + (size_t)t * dy, pred_cov + (size_t)t * dy * dy, &c);
+    }
+    /* ---- the unobserved tail: forward messages only ---- */
+    if (!rc && H > 0) {
+        rc = to_other_param(d, fc_x, fc_L, t_m, t_V, NULL, chw);
+        for (int h = 0; h < H && !rc; ++h) {
+            rule_mul_out(d, d, A, t_m, t_V, a_m, a_V, &c);
+            rule_mvn_additive(d, a_m, a_V, P, f_m, f_V, &c);   /* q(x[T+h]) = the forward message (nothing else arrives) */
+            if (post_mean) memcpy(post_mean + (size_t)h * vs, f_m, sizeof(double) * vs);
+            if (post_cov) memcpy(post_cov + (size_t)h * ms, f_V, sizeof(double) * ms);
+            rule_mul_out(dy, d, B, f_m, f_V, a_m, a_V, &c);
+            rule_mvn_additive(dy, a_m, a_V, Q, pred_mean + (size_t)(T + h) * dy, pred_cov + (size_t)(T + h) * dy * dy, &c);
+            memcpy(t_m, f_m, sizeof(double) * vs);
+            memcpy(t_V, f_V, sizeof(double) * ms);
+        }
+    }
+    free(fc_x);
+    free(st);
+    free(c.work);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------
  * Independent textbook implementation, used ONLY to validate the restatement above
  * (identity: BP on a tree == Kalman filter + RTS smoother; Bethe FE == −log p(y)).
  * ------------------------------------------------------------------------------------------ */

@@ -93,6 +93,15 @@ int rxo_lgssm_filter(int d, int dy, int T, const double* A, const double* B, con
                      const double* m0, const double* V0, int prior_through_transition, const double* y,
                      double* hist_mean, double* hist_cov, double* fe, rxo_counters* counters);
 
+/* Predictions of the data variables (`predictvars`, src/model/plugins/reactivemp_inference.jl:619-624): the message
+ * MvN_y(:out) toward y[t] = N(B m, B V B' + Q) with (m, V) = product of the forward and backward messages into x[t]
+ * (its own observation excluded).  H ≥ 0 further time steps carry no observation (`missing`): their x-posteriors
+ * (post_mean / post_cov, [H][d] / [H][d][d], nullable) are the forward predictions.  pred_mean [T+H][dy], pred_cov
+ * [T+H][dy][dy]. */
+int rxo_lgssm_predict(int d, int dy, int T, int H, const double* A, const double* B, const double* P, const double* Q,
+                      const double* m0, const double* V0, int prior_through_transition, const double* y,
+                      double* pred_mean, double* pred_cov, double* post_mean, double* post_cov);
+
 /* Noise-free drift chain (test/models/statespace/ulgssm_tests.jl:8-15) in the reference's message schedule:
  *     x_prior ~ Normal(μ = m0, v = v0);  x[t] ~ x[t-1] + c;  y[t] ~ Normal(μ = x[t], v = obs_var),  t = 1..T
  * (prior_through_transition = 0: the prior sits on x[1]).  post_mean / post_var [T]: q(x[t]); free_energy (nullable):

@@ -55,6 +55,8 @@ def lib():
         _LIB.rxo_mvgmm_vmp.argtypes = [ctypes.c_longlong, ctypes.c_int, ctypes.c_int] + [dp] * 7 + [ctypes.c_int, dp, dp, dp]
         _LIB.rxo_lgssm_filter.restype = ctypes.c_int
         _LIB.rxo_lgssm_filter.argtypes = [ctypes.c_int] * 3 + [dp] * 6 + [ctypes.c_int] + [dp] * 4 + [ctypes.POINTER(Counters)]
+        _LIB.rxo_lgssm_predict.restype = ctypes.c_int
+        _LIB.rxo_lgssm_predict.argtypes = [ctypes.c_int] * 4 + [dp] * 6 + [ctypes.c_int] + [dp] * 5
         _LIB.rxo_drift_chain_bp.restype = ctypes.c_int
         _LIB.rxo_drift_chain_bp.argtypes = [ctypes.c_longlong, dp] + [ctypes.c_double] * 4 + [ctypes.c_int, dp, dp, dp,
                                                                                                  ctypes.POINTER(Counters)]
@@ -84,6 +86,20 @@ def lgssm_bp(A, B, P, Q, m0, V0, y, prior_through_transition=False, free_energy=
     if rc:
         raise RuntimeError(f"rxo_lgssm_bp failed with status {rc}")
     return mean, cov, (fe.value if free_energy else None), cnt
+
+
+def lgssm_predict(A, B, P, Q, m0, V0, y, horizon=0, prior_through_transition=False):
+    """Predictions of y[1..T+H] (leave-one-out for the observed part, forecasts for the H unobserved steps) and the
+    x-posteriors of the unobserved steps.  Returns pred_mean [T+H,dy], pred_cov [T+H,dy,dy], post_mean [H,d], post_cov [H,d,d]."""
+    A, B, P, Q, m0, V0, y = map(_c, (A, B, P, Q, m0, V0, y))
+    d, dy, T, H = A.shape[0], B.shape[0], y.shape[0], int(horizon)
+    pm, pc = np.empty((T + H, dy)), np.empty((T + H, dy, dy))
+    xm, xc = np.empty((H, d)), np.empty((H, d, d))
+    rc = lib().rxo_lgssm_predict(d, dy, T, H, _p(A), _p(B), _p(P), _p(Q), _p(m0), _p(V0), int(prior_through_transition), _p(y),
+                                 _p(pm), _p(pc), _p(xm), _p(xc))
+    if rc:
+        raise RuntimeError(f"rxo_lgssm_predict failed with status {rc}")
+    return pm, pc, xm, xc
 
 
 def drift_chain_bp(y, m0, v0, c, obs_var, prior_through_transition=True, free_energy=True):

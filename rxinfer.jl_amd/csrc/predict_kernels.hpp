@@ -1,0 +1,134 @@
+// predict_kernels.hpp — predictions of the data variables and the unobserved tail of a state-space chain (d, dy ≤ 4).
+//
+// Replaces `obtain_prediction(ref)` (src/model/plugins/reactivemp_inference.jl:619-624): the stream of the message toward a
+// data variable.  For y[t] that message is MvN_y(:out)(m_μ, q_Σ) = N(B m, B V B' + Q), where (m, V) is the message
+// x[t] -> `*`_B: the product of the OTHER messages into x[t] (forward ⊗ backward), its own observation excluded.  The
+// sweep has already formed the full product q(x[t]) = fwd ⊗ obs ⊗ bwd, so the leave-one-out belief is that posterior with
+// the observation's information taken out again:
+//     Λ = V_s⁻¹ − B'Q⁻¹B,    ξ = V_s⁻¹ m_s − B'Q⁻¹ y_t,    (m, V) = mean_cov(ξ, Λ)
+// — independent for every (chain, t): one thread each, no recursion.  Time indices beyond the last observation
+// (`missing` observations, rxhip_lgssm_desc.horizon) carry forward messages only: k_forecast runs
+// `*`_A(:out) -> MvN_x(:out) from the last filtered belief, one thread per chain, and their predictions are N(B m, B V B' + Q)
+// of those posteriors directly.
+#pragma once
+#include "lgssm_kernels.hpp"
+
+namespace rxhip {
+
+struct PredictParams {
+    long long T, H, n_chains;
+    const double* y;      // [T][chain][DY]
+    double* mean;         // [T+H][chain][D]      posteriors (rows ≥ T written by k_forecast)
+    double* cov;          // [T+H][chain][D][D]
+    const double* cst;    // [n_models][CstLayout::SIZE]
+    const double* bq;     // [n_models][DY·D + DY·DY]   B | Q (row-major)
+    const int* chain_model;
+    double* pmean;        // [T+H][chain][DY]
+    double* pcov;         // [T+H][chain][DY][DY]
+    int* status;
+};
+
+template <int D, int DY>
+__global__ __launch_bounds__(64) void k_forecast(PredictParams p) {
+    using CL = CstLayout<D, DY>;
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.n_chains) return;
+    const double* cst = p.cst + (size_t)(p.chain_model ? p.chain_model[c] : 0) * CL::SIZE;
+    const CPtr A{cst + CL::A}, P{cst + CL::P};
+    double m[D];
+    Sym<D> V;
+    const long long r0 = (p.T - 1) * p.n_chains + c;
+#pragma unroll
+    for (int i = 0; i < D; ++i) m[i] = p.mean[r0 * D + i];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) V(i, j) = p.cov[r0 * D * D + i * D + j];
+    for (long long h = 0; h < p.H; ++h) {
+        double mn[D], Tm[D][D];
+        Sym<D> Vn;
+        matvec_c<D>(A, m, mn);             // `*`_A(:out): N(A m, A V A')
+        predict_cov<D>(A, P, V, Tm, Vn);   // MvN_x(:out): + P
+        const long long r = (p.T + h) * p.n_chains + c;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            m[i] = mn[i];
+            p.mean[r * D + i] = mn[i];
+        }
+        V = Vn;
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) p.cov[r * D * D + i * D + j] = Vn(i, j);
+    }
+}
+
+template <int D, int DY>
+__global__ __launch_bounds__(256) void k_predict(PredictParams p) {
+    using CL = CstLayout<D, DY>;
+    const long long total = (p.T + p.H) * p.n_chains;
+    bool ok = true;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const long long t = g / p.n_chains, c = g - t * p.n_chains;
+        const int mdl = p.chain_model ? p.chain_model[c] : 0;
+        const double* cst = p.cst + (size_t)mdl * CL::SIZE;
+        const double* B = p.bq + (size_t)mdl * (DY * D + DY * DY);
+        const double* Q = B + DY * D;
+        double m[D];
+        Sym<D> V;
+#pragma unroll
+        for (int i = 0; i < D; ++i) m[i] = p.mean[g * D + i];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j <= i; ++j) V(i, j) = p.cov[g * D * D + i * D + j];
+        if (t < p.T) {  // take this step's observation message out of the posterior again
+            Sym<D> Ls, L;
+            double det, xi[D], yv[DY];
+            ok = spd_inv<D>(V, Ls, det) && ok;
+            symv<D>(Ls, m, xi);
+#pragma unroll
+            for (int k = 0; k < DY; ++k) yv[k] = p.y[g * DY + k];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double s = xi[i];
+#pragma unroll
+                for (int k = 0; k < DY; ++k) s -= cst[CL::G + i * DY + k] * yv[k];
+                xi[i] = s;
+            }
+#pragma unroll
+            for (int q = 0; q < D * (D + 1) / 2; ++q) L.v[q] = Ls.v[q] - cst[CL::LOBS + q];
+            ok = spd_inv<D>(L, V, det) && ok;
+            symv<D>(V, xi, m);
+        }
+        // `*`_B(:out) = N(B m, B V B'), MvN_y(:out) = + Q
+        double BV[DY][D];
+#pragma unroll
+        for (int a = 0; a < DY; ++a) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += B[a * D + k] * m[k];
+            p.pmean[g * DY + a] = s;
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                double v = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) v += B[a * D + k] * V(k, j);
+                BV[a][j] = v;
+            }
+        }
+#pragma unroll
+        for (int a = 0; a < DY; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+                double s = 0.5 * (Q[a * DY + b] + Q[b * DY + a]);
+#pragma unroll
+                for (int k = 0; k < D; ++k) s += BV[a][k] * B[b * D + k];
+                p.pcov[g * DY * DY + a * DY + b] = s;
+                p.pcov[g * DY * DY + b * DY + a] = s;
+            }
+    }
+    if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+}  // namespace rxhip

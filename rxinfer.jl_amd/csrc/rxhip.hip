@@ -23,6 +23,7 @@
 #include "hgf_kernels.hpp"
 #include "mvgmm_kernels.hpp"
 #include "drift_kernels.hpp"
+#include "predict_kernels.hpp"
 #include "graph_lowering.hpp"
 
 using namespace rxhip;
@@ -42,6 +43,8 @@ struct LgssmVtbl {
     void (*boundary_scan)(const Params&, const double*, bool, bool, hipStream_t);
     void (*forward)(const Params&, const double*, bool, bool, hipStream_t);  // p.filter selects the filtering variant
     void (*backward)(const Params&, const double*, bool, hipStream_t);
+    void (*forecast)(const PredictParams&, hipStream_t);
+    void (*predict)(const PredictParams&, hipStream_t);
 };
 
 static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -113,6 +116,14 @@ struct Launch {
         if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
         else hipLaunchKernelGGL((k_backward<D, DY, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
     }
+    static void forecast(const PredictParams& p, hipStream_t s) {
+        hipLaunchKernelGGL((k_forecast<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
+    }
+    static void predict(const PredictParams& p, hipStream_t s) {
+        const long long total = (p.T + p.H) * p.n_chains;
+        const long long nb = (total + 255) / 256;
+        hipLaunchKernelGGL((k_predict<D, DY>), dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, p);
+    }
     static LgssmVtbl vtbl() {
         using TL = TabLayout<D, DY>;
         using AL = AggLayout<D>;
@@ -130,6 +141,8 @@ struct Launch {
         v.boundary_scan = &Launch::boundary_scan;
         v.forward = &Launch::forward;
         v.backward = &Launch::backward;
+        v.forecast = &Launch::forecast;
+        v.predict = &Launch::predict;
         return v;
     }
 };
@@ -198,6 +211,10 @@ struct rxhip_engine {
     int d = 0, dy = 0;
     int dpad = 0;  // dense path: d rounded up to a multiple of 16 (kernel dimension); == d otherwise
     long long T = 0, n_chains = 0;
+    long long H = 0;     // time indices without an observation after the T observed ones (rxhip_lgssm_desc.horizon)
+    long long Tout() const { return T + H; }  // rows of the posterior / prediction arrays
+    std::vector<double> h_bq;  // per model B | Q (row-major): the prediction kernel needs them, the sweep does not
+    double* d_bq = nullptr;
     int n_models = 1;
     int ptt = 0;
     int S = 0;
@@ -1279,6 +1296,7 @@ static void free_all(rxhip_engine* e) {
     for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend, &e->d_qtab, &e->d_loc, &e->d_aggpart, &e->d_bnd})
         if (*b) { if (!e->in_arena(*b)) (void)hipFree(*b); *b = nullptr; }
     if (e->d_coll) { (void)hipFree(e->d_coll); e->d_coll = nullptr; }
+    if (e->d_bq) { (void)hipFree(e->d_bq); e->d_bq = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     e->pending.clear();
@@ -1339,6 +1357,18 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     e->n_models = ds->n_models;
     e->ptt = ds->prior_through_transition ? 1 : 0;
     e->uniform = (ds->n_models == 1);
+    if (ds->horizon < 0) return fail(e, RXHIP_ERR_BADARG, "horizon must be non-negative");
+    if (ds->horizon > 0 && dense)
+        return fail(e, RXHIP_ERR_UNSUPPORTED, "unobserved time steps (horizon) have a device schedule for d, dy ≤ 4 only");
+    e->H = ds->horizon;
+    if (!dense) {
+        const size_t nb = (size_t)ds->dy * ds->d, nq = (size_t)ds->dy * ds->dy;
+        e->h_bq.resize((size_t)ds->n_models * (nb + nq));
+        for (int m = 0; m < ds->n_models; ++m) {
+            std::memcpy(&e->h_bq[(size_t)m * (nb + nq)], ds->B + (size_t)m * nb, sizeof(double) * nb);
+            std::memcpy(&e->h_bq[(size_t)m * (nb + nq) + nb], ds->Q + (size_t)m * nq, sizeof(double) * nq);
+        }
+    }
     if (dense && ds->n_chains > 65535)  // the chain index is a grid y/z coordinate of the MFMA-path kernels
         return fail(e, RXHIP_ERR_UNSUPPORTED, "d = %d runs on the MFMA path, which takes at most 65535 chains per engine (%lld given)", ds->d,
                     (long long)ds->n_chains);
@@ -1515,8 +1545,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_vtab, sizeof(double) * T * ((size_t)e->d * (e->d + 1) / 2));
     } else
         ap.plain(&e->d_filt, sizeof(double) * T * NP2 * 2 * (((C + 63) / 64) * 64));
-    ap.plain(&e->d_mean, sizeof(double) * T * C * e->d);
-    ap.plain(&e->d_cov, sizeof(double) * T * C * e->d * e->d);
+    ap.plain(&e->d_mean, sizeof(double) * (size_t)e->Tout() * C * e->d);
+    ap.plain(&e->d_cov, sizeof(double) * (size_t)e->Tout() * C * e->d * e->d);
     ap.plain(&e->d_elem, sizeof(double) * Sg * 2 * e->d * C);
     ap.plain(&e->d_fstart, sizeof(double) * Sg * NP * C);
     ap.plain(&e->d_beta, sizeof(double) * (Sg + 1) * NP * C);
@@ -2303,6 +2333,12 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 if ((st = prof_end(e))) return st;
             }
         }
+        if (e->H > 0 && !e->dense) {  // the unobserved tail: forward messages from the last filtered (= smoothed) belief
+            PredictParams pp{};
+            pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
+            pp.chain_model = e->d_chain_model; pp.status = e->d_status;
+            e->vt->forecast(pp, e->stream);
+        }
         if (fe) {
             if ((st = prof_begin(e, RXHIP_K_FE_REDUCE))) return st;
             const int nb = (int)((e->n_chains + 63) / 64);
@@ -2375,8 +2411,9 @@ rxhip_status rxhip_get_marginals_device(rxhip_engine* e, int32_t var_id, const d
     return RXHIP_OK;
 }
 
-static rxhip_status copy_out(rxhip_engine* e, const double* dsrc, double* host, int k, int32_t layout) {
-    const size_t n = (size_t)e->T * e->n_chains * k;
+static rxhip_status copy_out(rxhip_engine* e, const double* dsrc, double* host, int k, int32_t layout, long long rows = -1) {
+    if (rows < 0) rows = e->T;
+    const size_t n = (size_t)rows * e->n_chains * k;
     if (layout == RXHIP_LAYOUT_TIME_CHAIN || e->n_chains == 1) {
         HIPCHK(e, hipMemcpy(host, dsrc, sizeof(double) * n, hipMemcpyDeviceToHost));
         return RXHIP_OK;
@@ -2384,7 +2421,7 @@ static rxhip_status copy_out(rxhip_engine* e, const double* dsrc, double* host, 
     double* tmp = nullptr;
     HIPCHK(e, hipMalloc(&tmp, sizeof(double) * n));
     // [T][chain][k] -> [chain][T][k]
-    hipLaunchKernelGGL(k_transpose_rows, dim3(2048), dim3(256), 0, e->stream, dsrc, tmp, e->T, e->n_chains, k);
+    hipLaunchKernelGGL(k_transpose_rows, dim3(2048), dim3(256), 0, e->stream, dsrc, tmp, rows, e->n_chains, k);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(host, tmp, sizeof(double) * n, hipMemcpyDeviceToHost));
@@ -2420,7 +2457,7 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
     rxhip_status st;
     // small results (the reference's own benchmark sizes): mean and covariance sit next to each other in the arena, so ONE
     // device-to-host copy of the span serves both — a synchronous hipMemcpy costs ≈12 µs whatever its size
-    const size_t nm = (size_t)e->T * e->n_chains * e->d, nc = nm * e->d;
+    const size_t nm = (size_t)e->Tout() * e->n_chains * e->d, nc = nm * e->d;
     const bool same_layout = layout == RXHIP_LAYOUT_TIME_CHAIN || e->n_chains == 1;
     if (mean && cov && same_layout && e->in_arena(e->d_mean) && e->in_arena(e->d_cov) && e->d_cov > e->d_mean &&
         (size_t)((e->d_cov + nc) - e->d_mean) <= ((size_t)1 << 17)) {
@@ -2431,9 +2468,36 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
         std::memcpy(cov, stage.data() + (e->d_cov - e->d_mean), sizeof(double) * nc);
         return RXHIP_OK;
     }
-    if (mean && (st = copy_out(e, e->d_mean, mean, e->d, layout))) return st;
-    if (cov && (st = copy_out(e, e->d_cov, cov, e->d * e->d, layout))) return st;
+    if (mean && (st = copy_out(e, e->d_mean, mean, e->d, layout, e->Tout()))) return st;
+    if (cov && (st = copy_out(e, e->d_cov, cov, e->d * e->d, layout, e->Tout()))) return st;
     return RXHIP_OK;
+}
+
+rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (var_id != RXHIP_VAR_Y || e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "get_predictions: variable %d is not a data variable of a state-space engine", var_id);
+    if (!e->ran || e->last_filter) return fail(e, RXHIP_ERR_STATE, "get_predictions: needs a smoothing run (rxhip_run) first");
+    if (e->dense || !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "predictions have a device schedule for d, dy ≤ 4 only");
+    if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME) return fail(e, RXHIP_ERR_BADARG, "get_predictions: unknown layout %d", layout);
+    SET_DEVICE(e);
+    const size_t rows = (size_t)e->Tout() * e->n_chains, dy = (size_t)e->dy;
+    if (!e->d_bq) {
+        HIPCHK(e, hipMalloc(&e->d_bq, sizeof(double) * e->h_bq.size()));
+        HIPCHK(e, hipMemcpy(e->d_bq, e->h_bq.data(), sizeof(double) * e->h_bq.size(), hipMemcpyHostToDevice));
+    }
+    double* tmp = nullptr;
+    HIPCHK(e, hipMalloc(&tmp, sizeof(double) * rows * (dy + dy * dy)));
+    PredictParams pp{};
+    pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.y = e->d_y; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
+    pp.bq = e->d_bq; pp.chain_model = e->d_chain_model; pp.pmean = tmp; pp.pcov = tmp + rows * dy; pp.status = e->d_status;
+    e->vt->predict(pp, e->stream);
+    rxhip_status st = RXHIP_OK;
+    if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "prediction kernel launch failed");
+    if (!st) st = rxhip_sync(e);  // also reports a leave-one-out precision that is not positive definite
+    if (!st && mean) st = copy_out(e, pp.pmean, mean, e->dy, layout, e->Tout());
+    if (!st && cov) st = copy_out(e, pp.pcov, cov, e->dy * e->dy, layout, e->Tout());
+    (void)hipFree(tmp);
+    return st;
 }
 
 rxhip_status rxhip_get_free_energy(rxhip_engine* e, double* per_iteration) {
@@ -2526,7 +2590,7 @@ rxhip_status rxhip_get_marginals_chains(rxhip_engine* e, int32_t var_id, const i
     for (int64_t i = 0; i < n; ++i)
         if (chains[i] < 0 || chains[i] >= e->n_chains) return fail(e, RXHIP_ERR_BADARG, "get_marginals_chains: chain %lld out of range", (long long)chains[i]);
     SET_DEVICE(e);
-    const size_t nm = (size_t)n * e->T * e->d, nc = nm * e->d;
+    const size_t nm = (size_t)n * e->Tout() * e->d, nc = nm * e->d;
     char* tmp = nullptr;
     HIPCHK(e, hipMalloc(&tmp, sizeof(long long) * (size_t)n + sizeof(double) * (nm + nc)));
     double* g_mean = (double*)tmp;
@@ -2538,8 +2602,8 @@ rxhip_status rxhip_get_marginals_chains(rxhip_engine* e, int32_t var_id, const i
     };
     static_assert(sizeof(long long) == sizeof(int64_t), "chain ids are 64-bit");
     chk(hipMemcpyAsync(d_ch, chains, sizeof(long long) * (size_t)n, hipMemcpyHostToDevice, e->stream), "chain list upload");
-    if (!st && mean) hipLaunchKernelGGL(k_gather_chains, dim3(1024), dim3(256), 0, e->stream, (const double*)e->d_mean, g_mean, (const long long*)d_ch, (long long)n, e->T, e->n_chains, e->d);
-    if (!st && cov) hipLaunchKernelGGL(k_gather_chains, dim3(1024), dim3(256), 0, e->stream, (const double*)e->d_cov, g_cov, (const long long*)d_ch, (long long)n, e->T, e->n_chains, e->d * e->d);
+    if (!st && mean) hipLaunchKernelGGL(k_gather_chains, dim3(1024), dim3(256), 0, e->stream, (const double*)e->d_mean, g_mean, (const long long*)d_ch, (long long)n, e->Tout(), e->n_chains, e->d);
+    if (!st && cov) hipLaunchKernelGGL(k_gather_chains, dim3(1024), dim3(256), 0, e->stream, (const double*)e->d_cov, g_cov, (const long long*)d_ch, (long long)n, e->Tout(), e->n_chains, e->d * e->d);
     chk(hipGetLastError(), "gather launch");
     chk(hipStreamSynchronize(e->stream), "gather");
     if (!st && mean) chk(hipMemcpy(mean, g_mean, sizeof(double) * nm, hipMemcpyDeviceToHost), "copy of means");

@@ -43,6 +43,7 @@ struct LgssmDesc
     segments::Int32
     device::Int32
     stream::Ptr{Cvoid}
+    horizon::Int64
 end
 
 mutable struct Engine
@@ -75,7 +76,7 @@ state-space family (src/inference/batch.jl:252, src/model/plugins/reactivemp_inf
 """
 function Engine(A, B, P, Q, m0, V0; T::Integer, n_chains::Integer = 1, prior_through_transition::Bool = false,
                 segments::Integer = 0, device::Integer = -1, chain_model::Union{Nothing, AbstractVector{<:Integer}} = nothing,
-                stream = nothing)
+                stream = nothing, horizon::Integer = 0)
     # one model: plain matrices; several: vectors of matrices (A[m], B[m], …) with chain_model[c] ∈ 0:n_models-1
     multi = A isa AbstractVector{<:AbstractMatrix}
     n_models = multi ? length(A) : 1
@@ -88,10 +89,10 @@ function Engine(A, B, P, Q, m0, V0; T::Integer, n_chains::Integer = 1, prior_thr
     st = GC.@preserve a b p q m v cm begin
         desc = LgssmDesc(d, dy, T, n_chains, n_models, prior_through_transition ? 1 : 0, pointer(a), pointer(b), pointer(p),
                          pointer(q), pointer(m), pointer(v), isempty(cm) ? Ptr{Int32}(C_NULL) : pointer(cm), segments, device,
-                         stream_handle(stream))
+                         stream_handle(stream), horizon)
         ccall((:rxhip_lgssm_create, librxhip), Int32, (Ref{LgssmDesc}, Ref{Ptr{Cvoid}}), desc, h)
     end
-    e = Engine(h[], d, dy, T, n_chains, 0)
+    e = Engine(h[], d, dy, T + horizon, n_chains, 0)   # T counts the rows of the result arrays (observed + horizon)
     if st != RXHIP_OK
         h[] != C_NULL && (try check(e, st) finally ccall((:rxhip_destroy, librxhip), Int32, (Ptr{Cvoid},), h[]) end)
         throw(RxHipError(st, unsafe_string(ccall((:rxhip_status_string, librxhip), Cstring, (Int32,), st))))
@@ -109,9 +110,9 @@ end
 
 """`new_observation!(datavar, value)` (src/inference/batch.jl:405-407): y is a Vector (chains) of Vector (time) of Vector{Float64}."""
 function set_data!(e::Engine, y::AbstractVector)
-    flat = Vector{Float64}(undef, e.n_chains * e.T * e.dy)
-    k = 1
     chains = e.n_chains == 1 && eltype(y) <: AbstractVector{<:Real} ? (y,) : y
+    flat = Vector{Float64}(undef, e.n_chains * length(first(chains)) * e.dy)   # the observed rows only (without the horizon)
+    k = 1
     for yc in chains, yt in yc, v in yt
         flat[k] = v; k += 1
     end
@@ -133,6 +134,17 @@ function marginals(e::Engine)
                                          (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Int32),
                                          e.handle, RXHIP_VAR_X, mean, cov, RXHIP_LAYOUT_CHAIN_TIME))
     return mean, cov   # covariances are symmetric, so the row-/column-major distinction is immaterial
+end
+
+"""`result.predictions[:y]` (`predictvars = (y = KeepLast(),)`, reactivemp_inference.jl:619-624): mean dy × T × chains,
+cov dy × dy × T × chains — leave-one-out predictive for observed steps, forecasts for the `horizon` missing ones."""
+function predictions(e::Engine)
+    mean = Array{Float64}(undef, e.dy, e.T, e.n_chains)
+    cov = Array{Float64}(undef, e.dy, e.dy, e.T, e.n_chains)
+    GC.@preserve mean cov check(e, ccall((:rxhip_get_predictions, librxhip), Int32,
+                                         (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Int32),
+                                         e.handle, RXHIP_VAR_Y, mean, cov, RXHIP_LAYOUT_CHAIN_TIME))
+    return mean, cov
 end
 
 """score(model, BetheFreeEnergy, checks) |> ScoreActor (reactivemp_free_energy.jl:84-126, score/actor.jl:38-63)."""

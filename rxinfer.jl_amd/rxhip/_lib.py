@@ -25,7 +25,7 @@ class LgssmDesc(ctypes.Structure):
         ("n_models", ctypes.c_int32), ("prior_through_transition", ctypes.c_int32),
         ("A", c_double_p), ("B", c_double_p), ("P", c_double_p), ("Q", c_double_p), ("m0", c_double_p),
         ("V0", c_double_p), ("chain_model", c_int32_p), ("segments", ctypes.c_int32), ("device", ctypes.c_int32),
-        ("stream", ctypes.c_void_p),
+        ("stream", ctypes.c_void_p), ("horizon", ctypes.c_int64),
     ]
 
 
@@ -116,6 +116,7 @@ SYMBOLS = [
     ("rxhip_sync", ctypes.c_int32, [_H]),
     ("rxhip_release_cached_memory", ctypes.c_int32, []),
     ("rxhip_get_marginals", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_int32]),
+    ("rxhip_get_predictions", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_int32]),
     ("rxhip_get_marginals_device", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p),
                                                     ctypes.POINTER(ctypes.c_void_p)]),
     ("rxhip_get_marginals_chains", ctypes.c_int32, [_H, ctypes.c_int32, c_int64_p, ctypes.c_int64, c_double_p, c_double_p]),

@@ -331,14 +331,17 @@ def _infer_lgssm_filtering(model, data, free_energy, options, initialization, ca
             eng.close()
 
 
-def infer(*, model, data, iterations=None, free_energy=False, options=None, returnvars=None,
+def infer(*, model, data, iterations=None, free_energy=False, options=None, returnvars=None, predictvars=None,
           catch_exception=False, initialization=None, autoupdates=None, keephistory=None, historyvars=None):
     """Static (batch) inference on the device engine; with `autoupdates` (any truthy value: the state-space spec has
     exactly one feedback, `mean_cov(q(x_t))` -> prior of the next step) the streaming / filtering twin.
 
     data = {"y": array}: [T][dy] for one chain (as `data = (y = observations,)`), or
     [chain][T][dy] for a batch of independent chains sharing the model.
-    Returns posteriors["x"] as MvNormalMeanCovariance with mean [T][d] / [chain][T][d]."""
+    Returns posteriors["x"] as MvNormalMeanCovariance with mean [T][d] / [chain][T][d].
+    `predictvars = ("y",)` (reference: `predictvars = (y = KeepLast(),)`): result.predictions["y"] holds the message toward
+    every y[t] — leave-one-out predictive for observed steps; trailing all-NaN rows of `y` are `missing` observations
+    (a forecast horizon) whose posteriors and predictions are forward predictions."""
     if isinstance(model, UnivariateGaussianMixture):
         return _infer_mixture(model, data, iterations, free_energy, options, initialization, catch_exception)
     if isinstance(model, MultivariateGaussianMixture):
@@ -365,14 +368,26 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
         y = y[None]
     C, T, dy = y.shape
     iters = 1 if iterations is None else int(iterations)
+    horizon = 0
+    if predictvars:
+        missing = np.all(np.isnan(y), axis=(0, 2))      # a time index is `missing` when no chain observed it
+        while horizon < T - 1 and missing[T - 1 - horizon]:
+            horizon += 1
+        if np.any(np.isnan(y[:, :T - horizon])):
+            raise ValueError("missing observations are supported at the END of the data only (forecast horizon)")
+        y, T = y[:, :T - horizon], T - horizon
     eng = None
     try:
         eng = LGSSMEngine(model.A, model.B, model.P, model.Q, model.prior_mean, model.prior_cov, T=T, n_chains=C,
-                          prior_through_transition=model.prior_through_transition,
+                          prior_through_transition=model.prior_through_transition, horizon=horizon,
                           segments=int(options.get("segments", 0)), device=int(options.get("device", -1)))
         eng.set_data(y, layout="chain_time")
         eng.run(iterations=iters, free_energy=free_energy)
         mean, cov = eng.marginals(layout="chain_time")
+        pred = None
+        if predictvars:
+            pm, pc = eng.predictions(layout="chain_time")
+            pred = {"y": MvNormalMeanCovariance(pm[0], pc[0]) if single else MvNormalMeanCovariance(pm, pc)}
         if free_energy:
             # one value per iteration, per chain-graph: what `infer` returns for each chain
             fe = eng.free_energy_per_chain()
@@ -385,7 +400,7 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
         post = {"x": MvNormalMeanCovariance(mean, cov)}
         if returnvars is not None:
             post = {k: v for k, v in post.items() if k in returnvars}
-        return InferenceResult(post, None, fe, model, None)
+        return InferenceResult(post, pred, fe, model, None)
     except Exception as err:  # catch_exception semantics of batch.jl:440-446
         if not catch_exception:
             raise

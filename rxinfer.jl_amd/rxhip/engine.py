@@ -27,7 +27,7 @@ class LGSSMEngine:
     """
 
     def __init__(self, A, B, P, Q, m0, V0, T, n_chains=1, chain_model=None, prior_through_transition=False,
-                 segments=0, device=-1, stream=None):
+                 segments=0, device=-1, stream=None, horizon=0):
         L = _lib.lib()
         A = _c(A)
         B = _c(B)
@@ -37,6 +37,7 @@ class LGSSMEngine:
         self.d = A.shape[-1]
         self.dy = _c(B).shape[-2]
         self.T = int(T)
+        self.horizon = int(horizon)
         self.n_chains = int(n_chains)
         d, dy, M = self.d, self.dy, self.n_models
         self._keep = [_c(A, (M, d, d)), _c(B, (M, dy, d)), _c(P, (M, d, d)), _c(Q, (M, dy, dy)), _c(m0, (M, d)),
@@ -54,6 +55,7 @@ class LGSSMEngine:
         desc.segments = int(segments)
         desc.device = int(device)
         desc.stream = ctypes.c_void_p(stream) if stream else None
+        desc.horizon = self.horizon
         self._h = ctypes.c_void_p()
         st = L.rxhip_lgssm_create(ctypes.byref(desc), ctypes.byref(self._h))
         if st != _lib.OK:
@@ -122,8 +124,18 @@ class LGSSMEngine:
     def sync(self):
         self._chk(_lib.lib().rxhip_sync(self._h))
 
+    def predictions(self, layout="time_chain", want_cov=True):
+        """Messages toward y[1..T+horizon] (`predictvars`): mean [T+H][chain][dy], cov [...][dy][dy] (rxhip_get_predictions)."""
+        dy, T, C = self.dy, self.T + getattr(self, "horizon", 0), self.n_chains
+        lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
+        shp = (T, C) if layout == "time_chain" else (C, T)
+        mean = np.empty(shp + (dy,))
+        cov = np.empty(shp + (dy, dy)) if want_cov else None
+        self._chk(_lib.lib().rxhip_get_predictions(self._h, _lib.VAR_Y, _p(mean), _p(cov) if want_cov else None, lay))
+        return mean, cov
+
     def marginals(self, layout="time_chain", want_cov=True):
-        d, T, C = self.d, self.T, self.n_chains
+        d, T, C = self.d, self.T + getattr(self, "horizon", 0), self.n_chains
         lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
         shp = (T, C) if layout == "time_chain" else (C, T)
         mean = np.empty(shp + (d,))
@@ -135,8 +147,9 @@ class LGSSMEngine:
         """Posteriors of the selected chains only, chain-major: mean [n][T][d], cov [n][T][d][d] (strided gather on the
         device + one copy; rxhip_get_marginals_chains)."""
         ch = np.ascontiguousarray(chains, dtype=np.int64).ravel()
-        mean = np.empty((ch.size, self.T, self.d))
-        cov = np.empty((ch.size, self.T, self.d, self.d)) if want_cov else None
+        T = self.T + getattr(self, "horizon", 0)
+        mean = np.empty((ch.size, T, self.d))
+        cov = np.empty((ch.size, T, self.d, self.d)) if want_cov else None
         self._chk(_lib.lib().rxhip_get_marginals_chains(self._h, _lib.VAR_X, ch.ctypes.data_as(_lib.c_int64_p), ch.size,
                                                          _p(mean), _p(cov) if want_cov else None))
         return mean, cov

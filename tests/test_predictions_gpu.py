@@ -1,0 +1,77 @@
+"""Predictions of the data variables and unobserved (`missing`) trailing time steps (`obtain_prediction`,
+src/model/plugins/reactivemp_inference.jl:619-624): the HIP path against the oracle's restatement of the reference's
+message schedule (forward ⊗ backward into `*`_B(:out), MvN_y(:out)), for every d, dy ≤ 4 with dy ≥ d (for dy < d the
+reference's own backward conversion fails)."""
+import numpy as np
+import pytest
+
+import rxhip
+import rxoracle
+from rxhip import workloads
+
+pytestmark = pytest.mark.gpu
+
+
+def rel(a, b):
+    return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
+
+
+@pytest.mark.parametrize("d,dy,T,H,C,ptt", [(1, 1, 50, 7, 3, False), (2, 2, 400, 0, 5, True), (2, 4, 333, 12, 2, False),
+                                          (3, 3, 1200, 30, 66, False), (4, 4, 5000, 100, 130, True)])
+def test_predictions_and_forecast_match_oracle(d, dy, T, H, C, ptt):
+    mdl = workloads.random_model(d, dy, seed=10 * d + dy)
+    y = workloads.generate_batch(mdl, T, C, seed0=T)
+    with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C, horizon=H,
+                           prior_through_transition=ptt) as eng:
+        eng.set_data(y)
+        eng.run(1, True)
+        mean, cov = eng.marginals()
+        pm, pc = eng.predictions()
+        fe = eng.free_energy_per_chain()
+        sub_m, _ = eng.marginals_of_chains([C - 1])
+    assert mean.shape == (T + H, C, d) and pm.shape == (T + H, C, dy) and pc.shape == (T + H, C, dy, dy)
+    assert np.array_equal(sub_m[0], mean[:, C - 1])
+    for c in sorted({0, C // 2, C - 1}):
+        # dy > d: the reference's Bethe sum needs the (singular) marginal of b = B x — posteriors only, evidence from the textbook filter
+        om, oc, ofe, _ = rxoracle.lgssm_bp(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y[:, c], prior_through_transition=ptt,
+                                           free_energy=dy <= d)
+        if ofe is None:
+            ofe = rxoracle.lgssm_kalman_rts(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y[:, c], prior_through_transition=ptt)[2]
+        opm, opc, oxm, oxc = rxoracle.lgssm_predict(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y[:, c], horizon=H,
+                                                    prior_through_transition=ptt)
+        assert rel(mean[:T, c], om) < 1e-6 and rel(cov[:T, c], oc) < 1e-6 and abs(fe[c] - ofe) < 1e-8 * abs(ofe)  # the horizon changes nothing observed
+        assert rel(pm[:, c], opm) < 1e-6 and rel(pc[:, c], opc) < 1e-6
+        if H:
+            assert rel(mean[T:, c], oxm) < 1e-6 and rel(cov[T:, c], oxc) < 1e-6
+
+
+def test_infer_mirror_with_predictvars_and_missing_tail():
+    """`infer(model = …, data = (y = [obs…, missing, missing],), predictvars = (y = KeepLast(),))`"""
+    mdl = workloads.notebook_model()
+    _, y = workloads.generate_chain(mdl, 120, 4)
+    ym = np.vstack([y, np.full((5, 2), np.nan)])
+    spec = rxhip.linear_gaussian_ssm(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    res = rxhip.infer(model=spec, data={"y": ym}, predictvars=("y",), free_energy=True)
+    opm, opc, oxm, oxc = rxoracle.lgssm_predict(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y, horizon=5)
+    assert res.predictions["y"].mean.shape == (125, 2) and rel(res.predictions["y"].mean, opm) < 1e-6 and rel(res.predictions["y"].cov, opc) < 1e-6
+    assert res.posteriors["x"].mean.shape == (125, 2) and rel(res.posteriors["x"].mean[120:], oxm) < 1e-6
+    with pytest.raises(ValueError):
+        bad = ym.copy(); bad[10] = np.nan
+        rxhip.infer(model=spec, data={"y": bad}, predictvars=("y",))
+
+
+def test_predictions_call_order_and_unsupported_shapes():
+    mdl = workloads.notebook_model()
+    with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=20) as eng:
+        with pytest.raises(rxhip.RxHipError) as ei:
+            eng.predictions()
+        assert ei.value.status == 7
+        eng.set_data(np.zeros((20, 1, 2)))
+        eng.run_filter(True)
+        with pytest.raises(rxhip.RxHipError) as ei:   # a filtering run has no backward messages
+            eng.predictions()
+        assert ei.value.status == 7
+    big = workloads.random_model(8, 8, seed=1)
+    with pytest.raises(rxhip.RxHipError) as ei:
+        rxhip.LGSSMEngine(big["A"], big["B"], big["P"], big["Q"], big["m0"], big["V0"], T=20, horizon=3)
+    assert ei.value.status == 2
