@@ -98,9 +98,41 @@ struct DenseParams {
     double* loc;          // [chain][2][S][d]  index q: state after step q − 1 of a scan that starts every group from zero
     double* bnd;          // [S][2][d][d]  data-independent boundary inverses (kd_prepare_bnd, once per engine): 0: Λ_f(b_s) = V(b_s)⁻¹;  1: V_s(b_{s+1}) = (Λ_f + Λβ)⁻¹ (s < S − 1)
     int sg, ng;           // group size, number of groups
-    double* fe_part;      // [S+1][chain]
+    double* fe_part;      // [slot][user chain]
     int* status;
+    // Packed layout (d ≤ 8, NT = 1): TWO chains of the batch share one 16×16 tile as a block-diagonal model — chain 2c in the
+    // leading d_sub = 8 dimensions, chain 2c + 1 in the trailing ones (each padded to 8 with decoupled dimensions).  Block-
+    // diagonal matrices stay block-diagonal under every operation of the sweep, the tile's zeros cost nothing extra, and the
+    // observations / posteriors of the pair are adjacent in memory already.  pack = 1: one chain per tile row set (default).
+    int pack, d_sub, dy_sub;
 };
+
+// ---- posterior / free-energy output addressing (one chain per workgroup, or the packed pair) -------------------------
+// p.n_chains counts what a workgroup owns (a chain, or a pair); the result arrays are indexed by USER chains.
+__device__ __forceinline__ void dense_store_mean(const DenseParams& p, long long t, long long chain, int tid, double v) {
+    if (p.pack == 2) {
+        const int sub = tid >> 3, i = tid & 7;
+        if (tid < 16 && i < p.d_out) p.mean[((t * p.n_chains + chain) * 2 + sub) * p.d_out + i] = v;
+    } else if (tid < p.d_out)
+        p.mean[(t * p.n_chains + chain) * p.d_out + tid] = v;
+}
+__device__ __forceinline__ double dense_load_mean(const DenseParams& p, long long t, long long chain, int j) {
+    if (p.pack == 2) {
+        const int sub = j >> 3, i = j & 7;
+        return (j < 16 && i < p.d_out) ? p.mean[((t * p.n_chains + chain) * 2 + sub) * p.d_out + i] : 0.0;
+    }
+    return j < p.d_out ? p.mean[(t * p.n_chains + chain) * p.d_out + j] : 0.0;
+}
+// one free-energy partial of workgroup-chain `chain`: `indep` does not depend on the data (log-determinants, constants: both
+// chains of a pair share the model, so each owns half of the pair's value), dep0 / dep1 are the data-dependent parts of the
+// first / second chain of a pair (dep1 = 0 and dep0 = the whole when unpacked).  Stored negated, as every slot.
+__device__ __forceinline__ void dense_fe_write(const DenseParams& p, long long slot, long long chain, double indep, double dep0, double dep1) {
+    if (p.pack == 2) {
+        p.fe_part[slot * (2 * p.n_chains) + 2 * chain] = -0.5 * (0.5 * indep + dep0);
+        p.fe_part[slot * (2 * p.n_chains) + 2 * chain + 1] = -0.5 * (0.5 * indep + dep1);
+    } else
+        p.fe_part[slot * p.n_chains + chain] = -0.5 * (indep + dep0 + dep1);
+}
 
 template <int NT>
 struct DenseCfg {
@@ -173,6 +205,21 @@ __device__ __forceinline__ void acc_store_out(const Acc<NT>& a, double* M, int n
             const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
             if (i < n && j < n) M[i * n + j] = a.v[t][r];
         }
+}
+// posterior covariance of (t, chain): the leading d_out × d_out block, or — packed pairs — the two diagonal 8×8 blocks of the
+// tile, each to its own chain
+template <int NT>
+__device__ __forceinline__ void dense_store_cov(const DenseParams& p, const Acc<NT>& a, long long t, long long chain, int w, int lane) {
+    const size_t dd = (size_t)p.d_out * p.d_out;
+    if (NT == 1 && p.pack == 2) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, 0);
+            const int si = i >> 3, ii = i & 7, jj = j & 7;
+            if (si == (j >> 3) && ii < p.d_out && jj < p.d_out) p.cov[((t * p.n_chains + chain) * 2 + si) * dd + (size_t)ii * p.d_out + jj] = a.v[0][r];
+        }
+    } else
+        acc_store_out<NT>(a, p.cov + (t * p.n_chains + chain) * dd, p.d_out, w, lane);
 }
 template <int NT>
 __device__ __forceinline__ void acc_add_mat(Acc<NT>& a, const double* M, int ld, int w, int lane, double sgn) {
@@ -793,14 +840,19 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
             Acc<NT> a;
             acc_load<NT>(a, cst + c.oVF1, D, w, lane);
             if (p.T == 1 || p.filter) {
-                if (tid < p.d_out) p.mean[(0 * p.n_chains + chain) * p.d_out + tid] = v0[tid];
-                acc_store_out<NT>(a, p.cov + (0 * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
+                if (tid < D) dense_store_mean(p, 0, chain, tid, v0[tid]);
+                dense_store_cov<NT>(p, a, 0, chain, w, lane);
             }
         }
         if (FE) {
-            double dots[3];
+            double dots[3], dot1[3] = {0.0, 0.0, 0.0};
             block_dot3(v2, yv, dy, v1, v0, D, v1, v0, 0, red, tid, 64 * NT, dots);
-            if (tid == 0) p.fe_part[chain] = -0.5 * (cst[c.oC0] + dots[0] - dots[1] + cst[c.oS1] + cst[c.oLD1]);
+            if (NT == 1 && p.pack == 2)   // the second chain's share of the two data-dependent dot products
+                block_dot3(v2 + p.dy_sub, yv + p.dy_sub, dy - p.dy_sub, v1 + p.d_sub, v0 + p.d_sub, D - p.d_sub, v1, v0, 0, red, tid, 64 * NT, dot1);
+            if (tid == 0) {
+                const double dep1 = dot1[0] - dot1[1];
+                dense_fe_write(p, 0, chain, cst[c.oC0] + cst[c.oS1] + cst[c.oLD1], (dots[0] - dots[1]) - dep1, dep1);
+            }
         }
         lds_barrier();
     }
@@ -928,7 +980,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     if (b1 > p.T) b1 = p.T;
     const long long len = b1 - b0, t0 = seg * p.L + 1;
     bool ok = true;
-    double acc_quad = 0.0;
+    double acc_quad = 0.0, acc_const = 0.0, acc_dep1 = 0.0;  // data-dependent sum | constants | second chain of a packed pair
     LogProd lp;
     double af[D / 4];  // A-operand fragments of the transition matrix
     {
@@ -1039,26 +1091,31 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
         lds_barrier();
         part_lds(red, M0, xf);
         // q(x_t | y_1..t) is the marginal of the one-step graph
-        acc_store_out<NT>(lam, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
+        dense_store_cov<NT>(p, lam, t, chain, w, lane);
         lds_barrier();
         double mnew = 0.0;
         if (tid < D) {
             mnew = (red[tid] + red[dm + tid]) + (red[2 * dm + tid] + red[3 * dm + tid]);
-            if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = mnew;
+            dense_store_mean(p, t, chain, tid, mnew);
         }
         if (FE && w == 0) {  // −2 log p(y_t | y_<t) − log-dets = y'Q⁻¹y − ξf'mf + (Λp mp)'mp + const   (D, dy ≤ 64: one lane per element)
             double d0 = lane < dy ? qy[lane] * yv[lane] : 0.0;
             double d1 = lane < D ? xfr * mnew : 0.0;
             double d2 = lane < D ? sx * mp[lane] : 0.0;
+            if (NT == 1 && p.pack == 2) {  // the second chain's share: its elements of the same three dot products
+                double e0 = (lane >= p.dy_sub && lane < dy) ? d0 : 0.0, e12 = (lane >= p.d_sub && lane < D) ? d2 - d1 : 0.0;
+                e0 = wave0_sum(e0 + e12);
+                if (lane == 0) acc_dep1 += e0;
+            }
             d0 = wave0_sum(d0); d1 = wave0_sum(d1); d2 = wave0_sum(d2);
-            if (lane == 0) acc_quad += cst[c.oC0] + d0 - d1 + d2;
+            if (lane == 0) { acc_quad += d0 - d1 + d2; acc_const += cst[c.oC0]; }
         }
         lds_barrier();  // every reader of m, yv, mp of this step is done
         if (tid < D) m[tid] = mnew;
         if (tid < dy) yv[tid] = yn;
         lds_barrier();
     }
-    if (FE && tid == 0) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc_quad + lp.value());
+    if (FE && tid == 0) dense_fe_write(p, seg + 1, chain, acc_const + lp.value(), acc_quad - acc_dep1, acc_dep1);
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
 
@@ -1195,7 +1252,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     acc_add_mat<NT>(lam, cst + c.oW, D, w, lane, -1.0);
     acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);  // Λ_f at the segment end
     if (seg == p.S - 1 && tid < D) p.filt[(chain * p.T + (t0 + len - 1)) * C::REC + tid] = xi[tid];  // ξ_f(T): no successor writes it
-    if (FE && tid == 0) p.fe_part[(1 + seg) * p.n_chains + chain] = -0.5 * lp.value();
+    if (FE && tid == 0) dense_fe_write(p, 1 + seg, chain, lp.value(), 0.0, 0.0);
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
 
@@ -1249,8 +1306,8 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
         matvec_lds(ms, MV, LD, D, D, xf, nullptr, 0.0, tid);
         lds_barrier();
         if (seg == p.S - 1) {
-            if (tid < p.d_out) p.mean[(te * p.n_chains + chain) * p.d_out + tid] = ms[tid];
-            acc_store_out<NT>(a, p.cov + (te * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
+            if (tid < D) dense_store_mean(p, te, chain, tid, ms[tid]);
+            dense_store_cov<NT>(p, a, te, chain, w, lane);
         }
     }
     Acc<NT> gN, cc;
@@ -1294,8 +1351,8 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
         acc_store<NT>(a, MV, LD, w, lane);  // this wave's rows of H; only this wave reads them back (LDS is in order per wave)
         // V_s(t) = C + H G'
         mm_acc<NT, false, false>(cc, MV, LD, MG, LD, w, lane);
-        if (tid < p.d_out) p.mean[(t * p.n_chains + chain) * p.d_out + tid] = mnew;
-        acc_store_out<NT>(cc, p.cov + (t * p.n_chains + chain) * (size_t)p.d_out * p.d_out, p.d_out, w, lane);
+        if (tid < D) dense_store_mean(p, t, chain, tid, mnew);
+        dense_store_cov<NT>(p, cc, t, chain, w, lane);
         lds_barrier();  // every wave is through with G' (and with its rows of H)
         acc_store<NT>(cc, MV, LD, w, lane);
         if (tid < D) ms[tid] = mnew;
@@ -1304,9 +1361,9 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
     }
     if (FE && tid == 0) {  // the residual quadratic forms are kd_fe_resid's
         double f = 0.0;
-        if (seg == p.S - 1) f += 0.5 * lpe.value();   // ½ log|Λ_f(T)|
-        if (seg == 0) f += cst[c.oFEC];
-        p.fe_part[(seg == 0 ? 0 : p.S + seg) * p.n_chains + chain] = -f;
+        if (seg == p.S - 1) f += lpe.value();        // log|Λ_f(T)|
+        if (seg == 0) f += 2.0 * cst[c.oFEC];
+        dense_fe_write(p, seg == 0 ? 0 : p.S + seg, chain, f, 0.0, 0.0);
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
@@ -1320,23 +1377,32 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
 // steps of one chain; the four constant maps are staged in LDS once per workgroup (≤ 128 KB), thread (i, wave g) forms row
 // i of the matvecs for four steps at a time (one matrix element read feeds four FMAs; the means are LDS broadcasts).
 // Fixed summation order -> deterministic.  Partial written (negated, as every fe_part slot) to slot `slot0 + blockIdx.x`.
-constexpr int FR_STEPS = 48, FR_PASS = 16;
+// Small tiles (d, dy ≤ 16 / ≤ 32) would leave three quarters / half of every wavefront idle with one row per lane, so the 64
+// lanes of a wavefront split into G = 4 / 2 lane groups that work on different steps: a pass covers 16·G steps.
+__host__ __device__ inline int fe_resid_groups(int D, int dy) { const int m = D > dy ? D : dy; return m <= 16 ? 4 : m <= 32 ? 2 : 1; }
+__host__ __device__ inline int fe_resid_steps(int D, int dy) { return 48 * fe_resid_groups(D, dy); }  // steps per workgroup (3 passes)
 inline size_t fe_resid_lds_bytes(int D, int dy) {
-    return sizeof(double) * ((size_t)2 * D * D + (size_t)D * dy + (size_t)dy * dy + (size_t)(2 * FR_PASS + 1) * D + (size_t)FR_PASS * dy + 8);
+    const size_t pass = 16 * (size_t)fe_resid_groups(D, dy);
+    return sizeof(double) * ((size_t)2 * D * D + (size_t)D * dy + (size_t)dy * dy + (2 * pass + 1) * D + pass * dy + 16);
 }
 __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int D = p.d, dy = p.dy, du = p.d_out, tid = threadIdx.x, i = tid & 63, g = tid >> 6;
-    const long long chain = blockIdx.y, t00 = (long long)blockIdx.x * FR_STEPS;
+    const int D = p.d, dy = p.dy, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    const int G = fe_resid_groups(D, dy), DL = 64 / G, q = lane / DL, i = lane - q * DL;  // lane group q, row i
+    const int PASS = 16 * G, STEPS = 3 * PASS;
+    const bool pk = p.pack == 2;
+    const bool x1 = pk && i >= p.d_sub, y1 = pk && i >= p.dy_sub;  // row i of the state / observation terms belongs to the pair's second chain
+    double acc1 = 0.0;
+    const long long chain = blockIdx.y, t00 = (long long)blockIdx.x * STEPS;
     const DenseCst c = DenseCst::make(D, dy);
     double* AT = smem;                     // [D][D]   A'
     double* PI = AT + (size_t)D * D;       // [D][D]   P⁻¹
     double* BT = PI + (size_t)D * D;       // [D][dy]  B'
     double* QI = BT + (size_t)D * dy;      // [dy][dy] Q⁻¹
-    double* mb = QI + (((size_t)dy * dy + 1) & ~(size_t)1);  // [FR_PASS + 1][D], 16-byte aligned  x̂_t of the pass (+ the step after it)
-    double* rx = mb + (size_t)(FR_PASS + 1) * D;  // [FR_PASS][D]
-    double* ry = rx + (size_t)FR_PASS * D;        // [FR_PASS][dy]
-    double* red = ry + (size_t)FR_PASS * dy;      // [4]
+    double* mb = QI + (((size_t)dy * dy + 1) & ~(size_t)1);  // [PASS + 1][D], 16-byte aligned  x̂_t of the pass (+ the step after it)
+    double* rx = mb + (size_t)(PASS + 1) * D;  // [PASS][D]
+    double* ry = rx + (size_t)PASS * D;        // [PASS][dy]
+    double* red = ry + (((size_t)PASS * dy + 1) & ~(size_t)1);  // [8]
     auto stage = [&](double* dst, const double* src, int n) {  // eight loads in flight per thread
         int k = tid;
         for (; k + 7 * 256 < n; k += 8 * 256) {
@@ -1353,21 +1419,21 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
     stage(BT, p.cst + c.oBT, D * dy);
     stage(QI, p.cst + c.oQI, dy * dy);
     double acc = 0.0;
-    for (int ps = 0; ps < FR_STEPS / FR_PASS; ++ps) {
-        const long long t0 = t00 + (long long)ps * FR_PASS;
+    for (int ps = 0; ps < 3; ++ps) {
+        const long long t0 = t00 + (long long)ps * PASS;
         if (t0 >= p.T) break;  // uniform over the workgroup
-        for (int k = tid; k < (FR_PASS + 1) * D; k += 256) {
+        for (int k = tid; k < (PASS + 1) * D; k += 256) {
             const int s = k / D, j = k - s * D;
             const long long t = t0 + s;
-            mb[k] = (t < p.T && j < du) ? p.mean[(t * p.n_chains + chain) * du + j] : 0.0;
+            mb[k] = t < p.T ? dense_load_mean(p, t, chain, j) : 0.0;
         }
-        for (int k = tid; k < FR_PASS * dy; k += 256) {
+        for (int k = tid; k < PASS * dy; k += 256) {
             const int s = k / dy, j = k - s * dy;
             const long long t = t0 + s;
             ry[k] = t < p.T ? p.y[(t * p.n_chains + chain) * dy + j] : 0.0;
         }
         __syncthreads();
-        if (t0 == 0 && g == 0) {  // prior of the first state (constant map read from L2 once per chain)
+        if (t0 == 0 && g == 0 && q == 0) {  // prior of the first state (constant map read from L2 once per chain)
             if (i < D) {
                 const double* V1I = p.cst + c.oV1I;
                 const double* m1 = p.cst + c.oM1;
@@ -1375,14 +1441,15 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
                 for (int k = 0; k < D; k += 16) {  // D is a multiple of 16; sixteen loads in flight
                     double v[16];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) v[q] = V1I[(size_t)(k + q) * D + i];
+                    for (int r = 0; r < 16; ++r) v[r] = V1I[(size_t)(k + r) * D + i];
 #pragma unroll
-                    for (int q = 0; q < 16; ++q) u += v[q] * (mb[k + q] - m1[k + q]);
+                    for (int r = 0; r < 16; ++r) u += v[r] * (mb[k + r] - m1[k + r]);
                 }
                 acc += (mb[i] - m1[i]) * u;
+                if (x1) acc1 += (mb[i] - m1[i]) * u;
             }
         }
-        const int s0 = g * 4;
+        const int s0 = (g * G + q) * 4;  // this thread's four steps of the pass
         {
             double ax[4] = {0.0, 0.0, 0.0, 0.0}, bx[4] = {0.0, 0.0, 0.0, 0.0};
             const bool ix = i < D, iy = i < dy;
@@ -1418,7 +1485,10 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
                     }
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc += rx[(size_t)(s0 + u) * D + i] * ux[u];
+                for (int u = 0; u < 4; ++u) {
+                    acc += rx[(size_t)(s0 + u) * D + i] * ux[u];
+                    if (x1) acc1 += rx[(size_t)(s0 + u) * D + i] * ux[u];
+                }
             }
             if (i < dy) {
 #pragma unroll 4
@@ -1428,16 +1498,25 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
                     for (int u = 0; u < 4; ++u) uy[u] += a0 * ry[(size_t)(s0 + u) * dy + k];
                 }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) acc += ry[(size_t)(s0 + u) * dy + i] * uy[u];
+                for (int u = 0; u < 4; ++u) {
+                    acc += ry[(size_t)(s0 + u) * dy + i] * uy[u];
+                    if (y1) acc1 += ry[(size_t)(s0 + u) * dy + i] * uy[u];
+                }
             }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
-    if (i == 0) red[g] = acc;
+    for (int off = 32; off > 0; off >>= 1) {
+        acc += __shfl_down(acc, off);
+        acc1 += __shfl_down(acc1, off);
+    }
+    if (lane == 0) { red[g] = acc; red[4 + g] = acc1; }
     __syncthreads();
-    if (tid == 0) p.fe_part[(size_t)(slot0 + blockIdx.x) * p.n_chains + chain] = -0.5 * (((red[0] + red[1]) + red[2]) + red[3]);
+    if (tid == 0) {
+        const double tot = ((red[0] + red[1]) + red[2]) + red[3], sec = ((red[4] + red[5]) + red[6]) + red[7];
+        dense_fe_write(p, slot0 + blockIdx.x, chain, 0.0, tot - sec, sec);
+    }
 }
 
 }  // namespace rxhip

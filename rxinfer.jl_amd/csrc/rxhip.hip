@@ -259,6 +259,9 @@ struct rxhip_engine {
     int scan_sg = 1, scan_ng = 1;  // two-level boundary scan of the dense path: group size, groups
     int agg_oc = 1, agg_kc = 1;    // dense aggregation product: offsets per K-chunk, K-chunks
     double* d_aggpart = nullptr;   // [chain][agg_kc][S][2·dpad] partial sums of kd_agg_gemm
+    int pack = 1;             // 2: pairs of chains share a 16×16 tile as a block-diagonal model (d ≤ 8), see dense_kernels.hpp
+    long long wg_chains = 0;  // chains (or pairs) the kernels' grids run over
+    int dyk = 0;              // observation dimension at kernel level (2·dy when packed)
     struct DenseTables* dt = nullptr;  // shared per-model device tables of the MFMA path (d_cst, d_tab, d_scanm, d_qtab, d_bnd point into it)
     std::vector<double> h_cst0;  // model 0's constant block (kernel argument when all chains share it)
     int fe_total_cap = 0;
@@ -858,9 +861,9 @@ struct DenseLaunch {
     }
 };
 // free-energy residual terms of an information-form smoothing run: one workgroup per FR_STEPS steps, partial slots 2S…
-static int fe_resid_blocks(long long T) { return (int)((T + FR_STEPS - 1) / FR_STEPS); }
+static int fe_resid_blocks(long long T, int d, int dy) { const int st = fe_resid_steps(d, dy); return (int)((T + st - 1) / st); }
 static void launch_fe_resid(const DenseParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(kd_fe_resid, dim3(fe_resid_blocks(p.T), (unsigned)p.n_chains), dim3(256), fe_resid_lds_bytes(p.d, p.dy), s, p, 2 * p.S);
+    hipLaunchKernelGGL(kd_fe_resid, dim3(fe_resid_blocks(p.T, p.d, p.dy), (unsigned)p.n_chains), dim3(256), fe_resid_lds_bytes(p.d, p.dy), s, p, 2 * p.S);
 }
 #define DENSE_DISPATCH(nt, CALL)                    \
     switch (nt) {                                   \
@@ -876,7 +879,8 @@ static int dense_rec(int nt) { return 3 * 16 * nt + 2 * 256 * nt * nt; }  // Den
 // matrix part of the boundary scan for every segment (see dense_kernels.hpp DenseParams::scanm).
 static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* ds, std::vector<double>& cst,
                                        std::vector<double>& tab, std::vector<double>& scanm, std::vector<double>& qtab) {
-    const int d = e->dpad, dy = e->dy, du = e->d;
+    // ds: the model at KERNEL level (a packed pair is one block-diagonal model of dimension 16, see rxhip_lgssm_create)
+    const int d = e->dpad, dy = ds->dy, du = ds->d;
     const size_t MM = (size_t)d * d;
     // padded copies of the model (identity blocks on the padding dimensions)
     std::vector<double> Ap(MM, 0.0), Pp(MM, 0.0), V0p(MM, 0.0), Bp((size_t)dy * d, 0.0), m0p(d, 0.0);
@@ -1369,9 +1373,14 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             std::memcpy(&e->h_bq[(size_t)m * (nb + nq) + nb], ds->Q + (size_t)m * nq, sizeof(double) * nq);
         }
     }
-    if (dense && ds->n_chains > 65535)  // the chain index is a grid y/z coordinate of the MFMA-path kernels
-        return fail(e, RXHIP_ERR_UNSUPPORTED, "d = %d runs on the MFMA path, which takes at most 65535 chains per engine (%lld given)", ds->d,
-                    (long long)ds->n_chains);
+    // d ≤ 8: two chains per 16×16 tile (block-diagonal pair) instead of one chain padded to 16 — twice the chains per
+    // workgroup for the same MFMA work.  Needs an even batch (the pair is formed from neighbours in memory).
+    e->pack = (dense && ds->d <= 8 && ds->dy <= 32 && ds->n_chains % 2 == 0 && !std::getenv("RXHIP_NO_PACK")) ? 2 : 1;
+    e->wg_chains = ds->n_chains / e->pack;
+    e->dyk = ds->dy * e->pack;
+    if (dense && e->wg_chains > 65535)  // the chain index is a grid y/z coordinate of the MFMA-path kernels
+        return fail(e, RXHIP_ERR_UNSUPPORTED, "d = %d runs on the MFMA path, which takes at most %d chains per engine (%lld given)", ds->d,
+                    65535 * e->pack, (long long)ds->n_chains);
     if (ds->device >= 0) {
         if (ds->device >= ndev) return fail(e, RXHIP_ERR_BADARG, "device %d out of range (%d visible)", ds->device, ndev);
         e->device = ds->device;
@@ -1402,7 +1411,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->Llast = 1;
     } else {
         long long S_target = ds->segments > 0 ? ds->segments
-                             : dense ? (256 * dense_wg_per_cu + e->n_chains - 1) / e->n_chains
+                             : dense ? (256 * dense_wg_per_cu + e->wg_chains - 1) / e->wg_chains
                                      : (131072 + e->n_chains - 1) / e->n_chains;
         if (ds->segments <= 0 && !dense) {
             // few chains: the lanes do not fill the machine and the sweep is a latency chain of L steps through three
@@ -1426,12 +1435,38 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         hipError_t herr = hipSuccess;
         DENSE_DISPATCH(e->nt, prepare() == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
         if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
-        const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1), D = (size_t)e->dpad,
-                     Du = (size_t)e->d;
+        const size_t C = (size_t)e->wg_chains, CU = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1),
+                     D = (size_t)e->dpad, Du = (size_t)e->d;
+        // kernel-level model: the user's, or — packed — blockdiag(M8, M8) with M8 the model padded to 8 decoupled dimensions
+        // (A = 0, P = V0 = I, m0 = 0, B = 0 there: posterior N(0, I), no contribution to the free energy)
+        rxhip_lgssm_desc dk = *ds;
+        std::vector<double> pA, pB, pP, pQ, pm, pV;
+        if (e->pack == 2) {
+            const int du = ds->d, dyu = ds->dy, dyk = e->dyk;
+            pA.assign(256, 0.0); pP.assign(256, 0.0); pV.assign(256, 0.0); pm.assign(16, 0.0);
+            pB.assign((size_t)dyk * 16, 0.0); pQ.assign((size_t)dyk * dyk, 0.0);
+            for (int b = 0; b < 2; ++b) {
+                for (int i = 0; i < 8; ++i)
+                    for (int j = 0; j < 8; ++j) {
+                        const bool in = i < du && j < du;
+                        const size_t o = (size_t)(8 * b + i) * 16 + 8 * b + j;
+                        pA[o] = in ? ds->A[(size_t)i * du + j] : 0.0;
+                        pP[o] = in ? ds->P[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
+                        pV[o] = in ? ds->V0[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
+                    }
+                for (int i = 0; i < du; ++i) pm[8 * b + i] = ds->m0[i];
+                for (int r = 0; r < dyu; ++r) {
+                    for (int j = 0; j < du; ++j) pB[(size_t)(dyu * b + r) * 16 + 8 * b + j] = ds->B[(size_t)r * du + j];
+                    for (int q = 0; q < dyu; ++q) pQ[(size_t)(dyu * b + r) * dyk + dyu * b + q] = ds->Q[(size_t)r * dyu + q];
+                }
+            }
+            dk.d = 16; dk.dy = dyk; dk.n_chains = e->wg_chains;
+            dk.A = pA.data(); dk.B = pB.data(); dk.P = pP.data(); dk.Q = pQ.data(); dk.m0 = pm.data(); dk.V0 = pV.data();
+        }
         // the model's tables: shared with every other engine of the same model and schedule on this device
         std::vector<unsigned char> key;
         {
-            const long long hdr[8] = {e->d, e->dy, e->T, e->S, e->L, e->Llast, e->ptt, e->dpad};
+            const long long hdr[9] = {e->d, e->dy, e->T, e->S, e->L, e->Llast, e->ptt, e->dpad, e->pack};
             auto put = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; key.insert(key.end(), b, b + n); };
             put(hdr, sizeof hdr);
             put(ds->A, sizeof(double) * Du * Du); put(ds->B, sizeof(double) * e->dy * Du); put(ds->P, sizeof(double) * Du * Du);
@@ -1441,7 +1476,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         DenseTables* dt = dense_tables_acquire(key, e->device);
         if (!dt) {
             std::vector<double> cst, tab, scanm, qtab;
-            st = build_dense_tables(e, ds, cst, tab, scanm, qtab);
+            st = build_dense_tables(e, &dk, cst, tab, scanm, qtab);
             if (st) return st;
             tr.mark("dense: host tables");
             dt = new DenseTables;
@@ -1461,7 +1496,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
                 up = hipMemcpyAsync(*dst[q], src[q]->data(), sizeof(double) * src[q]->size(), hipMemcpyHostToDevice, e->stream);
             if (up == hipSuccess && e->S > 0) {  // data-independent inverses at the segment boundaries: once per model, on the device
                 DenseParams dp{};
-                dp.S = e->S; dp.d = e->dpad; dp.dy = e->dy; dp.scanm = dt->d_scanm; dp.bnd = dt->d_bnd; dp.status = nullptr;
+                dp.S = e->S; dp.d = e->dpad; dp.dy = e->dyk; dp.scanm = dt->d_scanm; dp.bnd = dt->d_bnd; dp.status = nullptr;
                 int* d_st = nullptr;
                 up = hipMalloc(&d_st, sizeof(int));
                 if (up == hipSuccess) up = hipMemsetAsync(d_st, 0, sizeof(int), e->stream);
@@ -1499,18 +1534,18 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_aggpart, sizeof(double) * C * (size_t)e->agg_kc * Sg * 2 * D);
         ap.zeroed(&e->d_status, sizeof(int));
         // smoothing runs use 2S slots (forward + backward parts) + one per workgroup of kd_fe_resid
-        ap.zeroed(&e->d_fe_part, sizeof(double) * (2 * Sg + 2 + (size_t)fe_resid_blocks(e->T)) * C);
+        ap.zeroed(&e->d_fe_part, sizeof(double) * (2 * Sg + 2 + (size_t)fe_resid_blocks(e->T, e->dpad, e->dyk)) * CU);
         e->fe_total_cap = 16;
         ap.zeroed(&e->d_fe_total, sizeof(double) * e->fe_total_cap);
-        ap.plain(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64));
+        ap.plain(&e->d_fe_blocks, sizeof(double) * ((CU + 63) / 64));
         ap.plain(&e->d_filt, sizeof(double) * C * T * dense_rec(e->nt));
         ap.plain(&e->d_vend, sizeof(double) * C * Sg * dense_tri(e->nt));
-        ap.plain(&e->d_mean, sizeof(double) * T * C * Du);
-        ap.plain(&e->d_cov, sizeof(double) * T * C * Du * Du);
+        ap.plain(&e->d_mean, sizeof(double) * T * CU * Du);
+        ap.plain(&e->d_cov, sizeof(double) * T * CU * Du * Du);
         ap.plain(&e->d_elem, sizeof(double) * C * Sg * 2 * D);
         ap.plain(&e->d_fstart_m, sizeof(double) * C * Sg * D);
         ap.plain(&e->d_beta_xi, sizeof(double) * C * (Sg + 1) * D);
-        ap.plain(&e->d_fe_chain, sizeof(double) * C);
+        ap.plain(&e->d_fe_chain, sizeof(double) * CU);
         if ((st = arena_commit(e, ap))) return st;
         tr.mark("dense: work buffers");
         return RXHIP_OK;
@@ -2279,7 +2314,8 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     rxhip_status st;
     DenseParams dp;
     if (e->dense) {
-        dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->S; dp.L = e->L; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy;
+        dp.T = e->T; dp.n_chains = e->wg_chains; dp.S = e->S; dp.L = e->L; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dyk;
+        dp.pack = e->pack; dp.d_sub = 8; dp.dy_sub = e->dy;
         dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
         dp.bnd = e->d_bnd; dp.qtab = e->d_qtab; dp.loc = e->d_loc; dp.sg = e->scan_sg; dp.ng = e->scan_ng;
         dp.aggpart = e->d_aggpart; dp.agg_oc = e->agg_oc; dp.agg_kc = e->agg_kc; dp.Llast = e->Llast;
@@ -2347,7 +2383,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 // residual quadratic forms at the smoothed means (parallel over all steps), then 2S partial slots of
                 // kd_forward_info / kd_backward_info + kd_fe_resid's
                 launch_fe_resid(dp, e->stream);
-                pr.S = 2 * e->S - 1 + fe_resid_blocks(e->T);
+                pr.S = 2 * e->S - 1 + fe_resid_blocks(e->T, e->dpad, e->dyk);
             }
             if (e->n_chains <= 16) {
                 hipLaunchKernelGGL(k_fe_few, dim3(1), dim3(256), 0, e->stream, pr);

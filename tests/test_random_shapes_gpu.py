@@ -158,3 +158,41 @@ def test_dense_engines_of_different_sizes_coexist():
     for m, y, mm, cc, ff in ((big, yb, mb, cb, fb), (small, ys, ms, cs, fs)):
         om, oc, ofe = rxoracle.lgssm_kalman_rts(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], y[:, 0], prior_through_transition=False)
         assert rel(mm[:, 0], om) < 1e-6 and rel(cc[:, 0], oc) < 1e-6 and abs(ff[0] - ofe) < 1e-8 * abs(ofe)
+
+
+@pytest.mark.parametrize("d,dy,T,C,segments,ptt", [(8, 8, 300, 64, 0, False), (5, 3, 97, 10, 4, True), (6, 12, 33, 2, 1, False),
+                                                     (7, 1, 160, 130, 7, True), (8, 4, 1000, 256, 0, False), (2, 9, 50, 4, 3, False),
+                                                     (8, 32, 40, 6, 2, True), (5, 5, 1, 8, 0, False)])
+def test_packed_pairs_of_chains(d, dy, T, C, segments, ptt):
+    """d ≤ 8 with an even batch: two chains share one 16×16 tile as a block-diagonal pair (dense_kernels.hpp `pack`).
+    Every chain of the pair must come out as if it ran alone — posteriors, per-chain free energy, smoothing and filtering —
+    and bit-identical to the unpacked schedule's result up to the documented tolerances; an odd batch takes the
+    one-chain-per-tile path."""
+    m = workloads.random_model(d, dy, seed=100 * d + dy)
+    y = workloads.generate_batch(m, T, C, seed0=T + C)
+    with rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=T, n_chains=C, segments=segments,
+                           prior_through_transition=ptt) as eng:
+        eng.set_data(y)
+        eng.run(2, True)
+        sm, sc = eng.marginals()
+        sfe, sfe_it = eng.free_energy_per_chain(), eng.free_energy()
+        sub_m, sub_c = eng.marginals_of_chains([1, C - 2])
+        eng.run_filter(True)
+        fm, fc = eng.marginals()
+        ffe = eng.free_energy_per_chain()
+    assert abs(sfe_it[0] - sfe.sum()) < 1e-11 * abs(sfe_it[0]) and sfe_it[0] == sfe_it[1]
+    assert np.array_equal(sub_m[0], sm[:, 1]) and np.array_equal(sub_c[1], sc[:, C - 2])
+    for c in sorted({0, 1, C // 2, C - 1}):
+        args = (m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], y[:, c])
+        om, oc, ofe = rxoracle.lgssm_kalman_rts(*args, prior_through_transition=ptt)
+        assert rel(sm[:, c], om) < 1e-6 and rel(sc[:, c], oc) < 1e-6 and abs(sfe[c] - ofe) < 1e-8 * abs(ofe), c
+        hm, hc, hfe, _ = rxoracle.lgssm_filter(*args, ptt)
+        assert rel(fm[:, c], hm) < 1e-6 and rel(fc[:, c], hc) < 1e-6 and abs(ffe[c] - hfe) < 1e-8 * abs(hfe), c
+    if C > 2:  # the same chains in an odd batch (unpacked path): same numbers to rounding
+        with rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=T, n_chains=C - 1, segments=segments,
+                               prior_through_transition=ptt) as eng:
+            eng.set_data(y[:, :C - 1])
+            eng.run(1, True)
+            um, uc = eng.marginals()
+            ufe = eng.free_energy_per_chain()
+        assert rel(um, sm[:, :C - 1]) < 1e-9 and rel(uc, sc[:, :C - 1]) < 1e-9 and np.max(np.abs(ufe - sfe[:C - 1]) / np.abs(ufe)) < 1e-10
