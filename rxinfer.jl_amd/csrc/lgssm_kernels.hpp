@@ -1029,7 +1029,10 @@ __device__ __forceinline__ void write_marginal(const Params& p, long long t, lon
 // request-rate bound (measured: SQ_WAIT_INST_ANY = 74 % of k_backward's wave cycles).  Instead
 // the wave transposes its 64 × (d + d²) doubles through LDS so that every global_store_dwordx4
 // writes one contiguous 1 KiB run of the [T][chain][d] / [T][chain][d][d] arrays.
-// Row stride is an odd number of 16-byte chunks -> conflict-free ds_write_b128 / ds_read_b128.
+// Row stride is an odd number of 16-byte chunks: the per-lane row writes (ds_write_b128) are conflict-free; the transposed
+// reads walk rows of 2 (mean) / 8 (covariance) chunks at that stride and collide two-way on part of the banks (PMC:
+// SQ_LDS_BANK_CONFLICT ≈ 1.2·10⁸ cycles per C2 launch, profiles/r01/rocprof_summary_v2.txt) — hidden: the kernel is bound by
+// the HBM writes these reads feed.
 // One wave per workgroup and LDS executes a wave's accesses in order, so no s_barrier is needed.
 template <int D>
 struct OutTile {
