@@ -317,6 +317,11 @@ rxhip_status rxhip_counters(rxhip_engine* e, uint64_t* rule_calls, uint64_t* pro
  * init_*: the `@initialization` marginals q(m[k]) = N(mean, var), q(p[k]) = Gamma(shape, rate), q(s) = Dirichlet.
  * Replaces create_model + postprocess_plugin for this family; then rxhip_set_data(RXHIP_VAR_Y, y, N, 0),
  * rxhip_run(iterations, want_free_energy), rxhip_get_free_energy (one value per VMP iteration).
+ * PINNING: the order of the mean-field updates inside an iteration (q(z) from the previous marginals; q(s), q(m); q(p) with
+ * the new q(m)) is an assumption — the reference's reactive order is not documented and no Julia run is available.  What
+ * is pinned to the reference is the FIXED POINT (the multivariate golden free energy); intermediate iterates
+ * (rxhip_gmm_get_history rows, free energies of early iterations) match the oracle's restatement, not yet RxInfer itself
+ * (gate: tests/golden/dump_rxinfer_reference.jl).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
     int64_t N;      /* observations held by THIS engine (one shard when several GPUs split the data) */

@@ -194,7 +194,9 @@ def _check_options(options):
 
 def _infer_mixture(model, data, iterations, free_energy, options, initialization, catch_exception):
     """posteriors (KeepEach, one entry per iteration as `returnvars = KeepEach()`): m -> NormalMeanVariance [it][K],
-    p -> GammaShapeRate [it][K], s -> Dirichlet [it][K]; z (last iteration) if options['materialize_z']."""
+    p -> GammaShapeRate [it][K], s -> Dirichlet [it][K]; z (last iteration) if options['materialize_z'].
+    Only the fixed point is pinned to the reference: the update order inside an iteration is an assumption, so per-iteration
+    entries are drop-in for RxInfer's `KeepEach` results up to that order (include/rxhip.h)."""
     options = _check_options(options)
     if initialization is None:
         raise ValueError("mean-field VMP needs `initialization` (q(m), q(p), q(s)); cf. test/inference/inference_tests.jl:361-363")

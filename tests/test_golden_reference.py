@@ -191,3 +191,29 @@ def test_univariate_mixture_reference_data_gpu_matches_oracle():
     assert min(abs(ms[0] - 1 / 3), abs(ms[0] - 2 / 3)) < 0.1
     m, v = res.posteriors["m"].mean[-1], res.posteriors["m"].var[-1]
     assert np.all(np.abs(np.sort(m) - np.array([-10.0, 10.0])) < 3 * np.sqrt(v[np.argsort(m)]))
+
+
+_REF_DUMP = os.path.join(GOLD, "rxinfer_reference.json")
+
+
+@pytest.mark.skipif(not os.path.exists(_REF_DUMP), reason="needs tests/golden/rxinfer_reference.json from a real RxInfer run "
+                    "(tests/golden/dump_rxinfer_reference.jl; no Julia toolchain in the build image)")
+def test_against_a_real_rxinfer_dump():
+    """Hard versions of what DESIGN §5 can only bound or assume, for whoever has Julia: the RNG restatement draw by draw,
+    the label vector of the univariate mixture test, and the per-iteration posteriors / free energies (the VMP update order)."""
+    import json
+
+    import stable_rng
+
+    ref = json.load(open(_REF_DUMP))
+    r = stable_rng.StableRNG(12345)
+    assert [r.rand_u64() for _ in range(4)] == ref["draws"]["u64"]
+    assert [r.rand() for _ in range(4)] == ref["draws"]["rand"] and [r.randn() for _ in range(4)] == ref["draws"]["randn"]
+    r7 = stable_rng.StableRNG(7)
+    assert [r7.categorical_alias_table([0.1, 0.2, 0.3, 0.25, 0.15]) + 1 for _ in range(32)] == ref["draws"]["categorical"]
+    y = np.asarray(ref["y"])
+    hist, fe, _, _ = rxoracle.gmm_vmp(y, [-2.0, 2.0], [1e3, 1e3], [0.01, 0.01], [0.01, 0.01], [1.0, 1.0], [-2.0, 2.0], [1e3, 1e3],
+                                      [1.0, 1.0], [1e-12, 1e-12], [1.0, 1.0], 10)
+    assert abs(fe[-1] - ref["free_energy"][-1]) < 1e-6 * abs(fe[-1])            # the fixed point
+    assert np.allclose(fe, ref["free_energy"], rtol=1e-8)                        # … and the path to it: the update order
+    assert np.allclose(hist[:, 0], ref["m_mean"], rtol=1e-6) and np.allclose(hist[:, 3], ref["p_rate"], rtol=1e-6)
