@@ -105,7 +105,18 @@ struct DenseParams {
     // diagonal matrices stay block-diagonal under every operation of the sweep, the tile's zeros cost nothing extra, and the
     // observations / posteriors of the pair are adjacent in memory already.  pack = 1: one chain per tile row set (default).
     int pack, d_sub, dy_sub;
+    // several models in one engine (chain c runs model chain_model[c]): per-model table pointers; NULL = the single model above
+    const struct DenseModel* models;
+    const int* chain_model;
 };
+struct DenseModel {
+    const double *cst, *tab, *scanm, *qtab;
+    double* bnd;
+};
+__device__ __forceinline__ DenseModel dense_model(const DenseParams& p, long long chain) {
+    if (p.models) return p.models[p.chain_model[chain]];
+    return DenseModel{p.cst, p.tab, p.scanm, p.qtab, p.bnd};
+}
 
 // ---- posterior / free-energy output addressing (one chain per workgroup, or the packed pair) -------------------------
 // p.n_chains counts what a workgroup owns (a chain, or a pair); the result arrays are indexed by USER chains.
@@ -613,11 +624,12 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_gemm(DenseParams p) {
     const int jl = lane & 15, kq = lane >> 4;
     const int nblk = gridDim.x, sb = blockIdx.x, kc = blockIdx.y;
     const long long chain = blockIdx.z;
+    const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const bool lastblk = sb == nblk - 1;
     const int seg = lastblk ? p.S - 1 : 16 * sb + jl;                      // this lane's B-operand column
     const bool segok = lastblk ? jl == 0 : seg < p.S - 1;
     const long long len = lastblk ? p.Llast : p.L;
-    const double* tab = p.tab + (lastblk ? (size_t)p.L * dyp * 2 * D : 0);
+    const double* tab = M.tab + (lastblk ? (size_t)p.L * dyp * 2 * D : 0);
     long long o0 = (long long)kc * p.agg_oc, o1 = o0 + p.agg_oc;
     if (o1 > len) o1 = len;
     v4d acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
@@ -672,8 +684,9 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_finish(DenseParams p) {
     double* GTs = red + 4 * dm;     // (B'Q⁻¹)' [dy][D]
     double* Ys = GTs + D * dy;      // [TS][dy]
     const long long seg = blockIdx.x, chain = blockIdx.y;
+    const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
-    const double* cst = p.cst;
+    const double* cst = M.cst;
     const long long b0 = 1 + seg * p.L;
     long long b1 = b0 + p.L;
     if (b1 > p.T) b1 = p.T;
@@ -692,7 +705,7 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_finish(DenseParams p) {
     // the carried vector are formed here, in parallel over segments:  w_s = b_s + M2_s η_s,  w_s' = η_s − N2_s b_s.
     {
         const size_t MM = (size_t)D * D;
-        const double* Mt = p.scanm + ((size_t)seg * 6 + (part < 2 ? 1 : 4)) * MM;  // transposed maps: [k][i]
+        const double* Mt = M.scanm + ((size_t)seg * 6 + (part < 2 ? 1 : 4)) * MM;  // transposed maps: [k][i]
         const double* x = part < 2 ? eta : m;
         const int k0 = half * (D / 2);
         double s0 = 0.0, s1 = 0.0;
@@ -807,8 +820,9 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
     double* yv = v2 + dm;
     double* red = yv + dm;
     const long long chain = blockIdx.y;
+    const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
-    const double* cst = p.cst;
+    const double* cst = M.cst;
     const int S = p.S, n = S - 1;
     const int dir = blockIdx.x / p.ng, grpj = blockIdx.x - dir * p.ng;
     const size_t MM = (size_t)D * D;
@@ -867,7 +881,7 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
     auto seg_of = [&](int st) { return dir ? S - 1 - st : st; };
     dense_affine_rounds<NT, true>(
         st1 - st0,
-        [&](int r) { return p.scanm + ((size_t)seg_of(st0 + r) * 6 + (dir ? 3 : 0)) * MM; },
+        [&](int r) { return M.scanm + ((size_t)seg_of(st0 + r) * 6 + (dir ? 3 : 0)) * MM; },
         [&](int r) { return p.elem + ((chain * S + seg_of(st0 + r)) * 2 + dir) * D; },
         [&](int r, double x) { loc[(size_t)(st0 + r + 1) * D + tid] = x; }, v0, red, tid);
 }
@@ -883,12 +897,13 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_fix(DenseParams p) {
     double* v0 = smem;
     double* red = v0 + 4 * dm;
     const long long chain = blockIdx.y;
+    const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const int S = p.S, n = S - 1;
     const int dir = blockIdx.x / p.ng, grpj = blockIdx.x - dir * p.ng;
     const size_t MM = (size_t)D * D;
     if (n <= 0) return;
     const double* loc = p.loc + ((chain * 2 + dir) * (size_t)S) * D;
-    const double* qt = p.qtab + (size_t)dir * S * MM;
+    const double* qt = M.qtab + (size_t)dir * S * MM;
     if (tid < D) v0[tid] = dir ? 0.0 : p.fstart_m[(chain * S + 0) * D + tid];
     lds_barrier();
     const int sg = p.sg;
@@ -971,8 +986,9 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     double* red = rowbuf + 8 * D;  // [4][dm] partial sums
     double* red2 = red + 4 * dm;   // [4][dm]
     const long long seg = blockIdx.x, chain = blockIdx.y;
+    const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
-    const double* cst = p.cst;
+    const double* cst = M.cst;
     const int grp = tid / D, gi = tid - grp * D;  // four thread groups of D
     const size_t MM = (size_t)D * D;
     const long long b0 = 1 + seg * p.L;
@@ -1026,7 +1042,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     };
     if (tid < D) m[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
     Acc<NT> a, lam;
-    acc_load<NT>(a, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
+    acc_load<NT>(a, M.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
     acc_store<NT>(a, M0, LD, w, lane);
     // y_t and B'Q⁻¹y_t (record of t, second header slot: kd_agg_finish), fetched one step ahead
     double yn = (tid < dy && len > 0) ? p.y[(t0 * p.n_chains + chain) * dy + tid] : 0.0;
@@ -1152,8 +1168,9 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     double* cpp = xpp + 4 * dm; // [4][D] partial sums of C_t ξ_f(t) (handed to the backward kernel in the record)
     double* rowbuf = cpp + 4 * dm;  // 8·D doubles
     const long long seg = blockIdx.x, chain = blockIdx.y;
+    const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
-    const double* cst = p.cst;
+    const double* cst = M.cst;
     const size_t MM = (size_t)D * D;
     const int grp = tid / D, gi = tid - grp * D;
     const long long b0 = 1 + seg * p.L;
@@ -1191,7 +1208,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
         }
     };
     // belief at the segment start in information form: Λ_f = V(b_s)⁻¹ (data-independent: host table), ξ_f = Λ_f m(b_s)
-    acc_load<NT>(lam, p.bnd + ((size_t)seg * 2 + 0) * MM, D, w, lane);
+    acc_load<NT>(lam, M.bnd + ((size_t)seg * 2 + 0) * MM, D, w, lane);
     acc_store<NT>(lam, S0, LD, w, lane);
     if (tid < D) u[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
     lds_barrier();
@@ -1278,8 +1295,9 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
     double* xf = ms + dm;       // boundary: ξ_f + ξβ; in the loop: C_t ξ_f(t)
     double* rowbuf = xf + dm;   // 8·D doubles: pivot rows of the last segment's inverse, then the matvec partials
     const long long seg = blockIdx.x, chain = blockIdx.y;
+    const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
-    const double* cst = p.cst;
+    const double* cst = M.cst;
     const size_t MM = (size_t)D * D;
     const int grp = tid / D, gi = tid - grp * D;
     const long long b0 = 1 + seg * p.L;
@@ -1300,7 +1318,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
             lds_barrier();  // every wave has its rows in registers before MV is overwritten below
             ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpe) && ok;
         } else
-            acc_load<NT>(a, p.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);
+            acc_load<NT>(a, M.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);
         acc_store<NT>(a, MV, LD, w, lane);
         lds_barrier();
         matvec_lds(ms, MV, LD, D, D, xf, nullptr, 0.0, tid);
@@ -1394,6 +1412,7 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
     const bool x1 = pk && i >= p.d_sub, y1 = pk && i >= p.dy_sub;  // row i of the state / observation terms belongs to the pair's second chain
     double acc1 = 0.0;
     const long long chain = blockIdx.y, t00 = (long long)blockIdx.x * STEPS;
+    const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
     double* AT = smem;                     // [D][D]   A'
     double* PI = AT + (size_t)D * D;       // [D][D]   P⁻¹
@@ -1414,10 +1433,10 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
         }
         for (; k < n; k += 256) dst[k] = src[k];
     };
-    stage(AT, p.cst + c.oAT, D * D);
-    stage(PI, p.cst + c.oPI, D * D);
-    stage(BT, p.cst + c.oBT, D * dy);
-    stage(QI, p.cst + c.oQI, dy * dy);
+    stage(AT, M.cst + c.oAT, D * D);
+    stage(PI, M.cst + c.oPI, D * D);
+    stage(BT, M.cst + c.oBT, D * dy);
+    stage(QI, M.cst + c.oQI, dy * dy);
     double acc = 0.0;
     for (int ps = 0; ps < 3; ++ps) {
         const long long t0 = t00 + (long long)ps * PASS;
@@ -1435,8 +1454,8 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
         __syncthreads();
         if (t0 == 0 && g == 0 && q == 0) {  // prior of the first state (constant map read from L2 once per chain)
             if (i < D) {
-                const double* V1I = p.cst + c.oV1I;
-                const double* m1 = p.cst + c.oM1;
+                const double* V1I = M.cst + c.oV1I;
+                const double* m1 = M.cst + c.oM1;
                 double u = 0.0;
                 for (int k = 0; k < D; k += 16) {  // D is a multiple of 16; sixteen loads in flight
                     double v[16];

@@ -262,7 +262,8 @@ struct rxhip_engine {
     int pack = 1;             // 2: pairs of chains share a 16×16 tile as a block-diagonal model (d ≤ 8), see dense_kernels.hpp
     long long wg_chains = 0;  // chains (or pairs) the kernels' grids run over
     int dyk = 0;              // observation dimension at kernel level (2·dy when packed)
-    struct DenseTables* dt = nullptr;  // shared per-model device tables of the MFMA path (d_cst, d_tab, d_scanm, d_qtab, d_bnd point into it)
+    std::vector<struct DenseTables*> dts;  // shared per-model device tables of the MFMA path (d_cst, d_tab, … point into model 0's)
+    struct DenseModel* d_models = nullptr;  // [n_models] table pointers on the device (several models per engine)
     std::vector<double> h_cst0;  // model 0's constant block (kernel argument when all chains share it)
     int fe_total_cap = 0;
     // results bookkeeping
@@ -1277,12 +1278,13 @@ const char* rxhip_last_error(const rxhip_engine* e) { return e ? e->err.c_str() 
 static void free_all(rxhip_engine* e) {
     DevGuard dg;
     if (e->device >= 0) (void)dg.set(e->device);
-    if (e->dt) {  // shared tables: not this engine's to free; nothing may still read them
+    if (!e->dts.empty()) {  // shared tables: not this engine's to free; nothing may still read them
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         e->d_cst = e->d_tab = e->d_scanm = e->d_qtab = e->d_bnd = nullptr;
-        dense_tables_release(e->dt);
-        e->dt = nullptr;
+        for (DenseTables* dt : e->dts) dense_tables_release(dt);
+        e->dts.clear();
     }
+    e->d_models = nullptr;  // lives in the arena
     double** bufs[] = {&e->d_vtab, &e->d_scan, &e->d_filt, &e->d_mean, &e->d_cov, &e->d_cst, &e->d_tab, &e->d_agg, &e->d_elem,
                        &e->d_fstart, &e->d_beta, &e->d_fe_part, &e->d_fe_chain, &e->d_fe_total};
     for (auto b : bufs)
@@ -1340,7 +1342,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         !ds->B || !ds->P || !ds->Q || !ds->m0 || !ds->V0)
         return RXHIP_ERR_BADARG;
     const LgssmVtbl* vt = find_vtbl(ds->d, ds->dy);
-    const bool dense = !vt && dense_supported(ds->d, ds->dy) && ds->n_models == 1;
+    const bool dense = !vt && dense_supported(ds->d, ds->dy);
+    if (dense && ds->n_models > 1 && !ds->chain_model) return RXHIP_ERR_BADARG;
     if (!vt && !dense) return RXHIP_ERR_UNSUPPORTED;
     if (ds->chain_model)
         for (long long c = 0; c < ds->n_chains; ++c)
@@ -1375,7 +1378,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     }
     // d ≤ 8: two chains per 16×16 tile (block-diagonal pair) instead of one chain padded to 16 — twice the chains per
     // workgroup for the same MFMA work.  Needs an even batch (the pair is formed from neighbours in memory).
-    e->pack = (dense && ds->d <= 8 && ds->dy <= 32 && ds->n_chains % 2 == 0 && !std::getenv("RXHIP_NO_PACK")) ? 2 : 1;
+    e->pack = (dense && ds->d <= 8 && ds->dy <= 32 && ds->n_chains % 2 == 0 && ds->n_models == 1 && !std::getenv("RXHIP_NO_PACK")) ? 2 : 1;
     e->wg_chains = ds->n_chains / e->pack;
     e->dyk = ds->dy * e->pack;
     if (dense && e->wg_chains > 65535)  // the chain index is a grid y/z coordinate of the MFMA-path kernels
@@ -1463,73 +1466,92 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             dk.d = 16; dk.dy = dyk; dk.n_chains = e->wg_chains;
             dk.A = pA.data(); dk.B = pB.data(); dk.P = pP.data(); dk.Q = pQ.data(); dk.m0 = pm.data(); dk.V0 = pV.data();
         }
-        // the model's tables: shared with every other engine of the same model and schedule on this device
-        std::vector<unsigned char> key;
-        {
-            const long long hdr[9] = {e->d, e->dy, e->T, e->S, e->L, e->Llast, e->ptt, e->dpad, e->pack};
-            auto put = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; key.insert(key.end(), b, b + n); };
-            put(hdr, sizeof hdr);
-            put(ds->A, sizeof(double) * Du * Du); put(ds->B, sizeof(double) * e->dy * Du); put(ds->P, sizeof(double) * Du * Du);
-            put(ds->Q, sizeof(double) * e->dy * e->dy); put(ds->m0, sizeof(double) * Du); put(ds->V0, sizeof(double) * Du * Du);
-        }
+        // the tables of every model: shared with every other engine of the same model and schedule on this device
         rxhip_status st = RXHIP_OK;
-        DenseTables* dt = dense_tables_acquire(key, e->device);
-        if (!dt) {
-            std::vector<double> cst, tab, scanm, qtab;
-            st = build_dense_tables(e, &dk, cst, tab, scanm, qtab);
-            if (st) return st;
-            tr.mark("dense: host tables");
-            dt = new DenseTables;
-            dt->key.swap(key);
-            dt->device = e->device;
-            dt->agg_oc = e->agg_oc; dt->agg_kc = e->agg_kc; dt->scan_sg = e->scan_sg; dt->scan_ng = e->scan_ng;
-            const size_t nb[5] = {cst.size(), tab.size(), scanm.size(), qtab.size(), Sg * 2 * D * D};
-            size_t off[6] = {0};
-            for (int q = 0; q < 5; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * (nb[q] ? nb[q] : 1));
-            dt->bytes = off[5];
-            if (hipMalloc(&dt->block, dt->bytes) != hipSuccess) { delete dt; return fail(e, RXHIP_ERR_HIP, "hipMalloc of %zu bytes (model tables) failed", off[5]); }
-            double** dst[5] = {&dt->d_cst, &dt->d_tab, &dt->d_scanm, &dt->d_qtab, &dt->d_bnd};
-            const std::vector<double>* src[4] = {&cst, &tab, &scanm, &qtab};
-            hipError_t up = hipSuccess;
-            for (int q = 0; q < 5; ++q) *dst[q] = (double*)(dt->block + off[q]);
-            for (int q = 0; q < 4 && up == hipSuccess; ++q)
-                up = hipMemcpyAsync(*dst[q], src[q]->data(), sizeof(double) * src[q]->size(), hipMemcpyHostToDevice, e->stream);
-            if (up == hipSuccess && e->S > 0) {  // data-independent inverses at the segment boundaries: once per model, on the device
-                DenseParams dp{};
-                dp.S = e->S; dp.d = e->dpad; dp.dy = e->dyk; dp.scanm = dt->d_scanm; dp.bnd = dt->d_bnd; dp.status = nullptr;
-                int* d_st = nullptr;
-                up = hipMalloc(&d_st, sizeof(int));
-                if (up == hipSuccess) up = hipMemsetAsync(d_st, 0, sizeof(int), e->stream);
-                dp.status = d_st;
-                if (up == hipSuccess) {
-                    DENSE_DISPATCH(e->nt, prepare_bnd(dp, e->stream));
-                    up = hipGetLastError();
-                }
-                int hst = 0;
-                if (up == hipSuccess) up = hipMemcpyAsync(&hst, d_st, sizeof(int), hipMemcpyDeviceToHost, e->stream);
-                if (up == hipSuccess) up = hipStreamSynchronize(e->stream);
-                if (d_st) (void)hipFree(d_st);
-                if (up == hipSuccess && hst) {
+        for (int mdl = 0; mdl < e->n_models; ++mdl) {
+            rxhip_lgssm_desc dm = dk;  // model `mdl` at kernel level (a packed pair has one model by construction)
+            if (e->pack == 1) {
+                dm.A = ds->A + (size_t)mdl * Du * Du; dm.B = ds->B + (size_t)mdl * e->dy * Du; dm.P = ds->P + (size_t)mdl * Du * Du;
+                dm.Q = ds->Q + (size_t)mdl * e->dy * e->dy; dm.m0 = ds->m0 + (size_t)mdl * Du; dm.V0 = ds->V0 + (size_t)mdl * Du * Du;
+            }
+            std::vector<unsigned char> key;
+            {
+                const long long hdr[9] = {e->d, e->dy, e->T, e->S, e->L, e->Llast, e->ptt, e->dpad, e->pack};
+                auto put = [&](const void* q, size_t n) { const unsigned char* b = (const unsigned char*)q; key.insert(key.end(), b, b + n); };
+                put(hdr, sizeof hdr);
+                const size_t o = (size_t)mdl;  // the USER's model bytes identify the tables
+                put(ds->A + o * Du * Du, sizeof(double) * Du * Du); put(ds->B + o * e->dy * Du, sizeof(double) * e->dy * Du);
+                put(ds->P + o * Du * Du, sizeof(double) * Du * Du); put(ds->Q + o * e->dy * e->dy, sizeof(double) * e->dy * e->dy);
+                put(ds->m0 + o * Du, sizeof(double) * Du); put(ds->V0 + o * Du * Du, sizeof(double) * Du * Du);
+            }
+            DenseTables* dt = dense_tables_acquire(key, e->device);
+            if (!dt) {
+                std::vector<double> cst, tab, scanm, qtab;
+                st = build_dense_tables(e, &dm, cst, tab, scanm, qtab);
+                if (st) return st;
+                tr.mark("dense: host tables");
+                dt = new DenseTables;
+                dt->key.swap(key);
+                dt->device = e->device;
+                dt->agg_oc = e->agg_oc; dt->agg_kc = e->agg_kc; dt->scan_sg = e->scan_sg; dt->scan_ng = e->scan_ng;
+                const size_t nb[5] = {cst.size(), tab.size(), scanm.size(), qtab.size(), Sg * 2 * D * D};
+                size_t off[6] = {0};
+                for (int q = 0; q < 5; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * (nb[q] ? nb[q] : 1));
+                dt->bytes = off[5];
+                if (hipMalloc(&dt->block, dt->bytes) != hipSuccess) { delete dt; return fail(e, RXHIP_ERR_HIP, "hipMalloc of %zu bytes (model tables) failed", off[5]); }
+                double** dst[5] = {&dt->d_cst, &dt->d_tab, &dt->d_scanm, &dt->d_qtab, &dt->d_bnd};
+                const std::vector<double>* src[4] = {&cst, &tab, &scanm, &qtab};
+                hipError_t up = hipSuccess;
+                for (int q = 0; q < 5; ++q) *dst[q] = (double*)(dt->block + off[q]);
+                for (int q = 0; q < 4 && up == hipSuccess; ++q)
+                    up = hipMemcpyAsync(*dst[q], src[q]->data(), sizeof(double) * src[q]->size(), hipMemcpyHostToDevice, e->stream);
+                if (up == hipSuccess && e->S > 0) {  // data-independent inverses at the segment boundaries: once per model, on the device
+                    DenseParams dp{};
+                    dp.S = e->S; dp.d = e->dpad; dp.dy = e->dyk; dp.scanm = dt->d_scanm; dp.bnd = dt->d_bnd; dp.status = nullptr;
+                    int* d_st = nullptr;
+                    up = hipMalloc(&d_st, sizeof(int));
+                    if (up == hipSuccess) up = hipMemsetAsync(d_st, 0, sizeof(int), e->stream);
+                    dp.status = d_st;
+                    if (up == hipSuccess) {
+                        DENSE_DISPATCH(e->nt, prepare_bnd(dp, e->stream));
+                        up = hipGetLastError();
+                    }
+                    int hst = 0;
+                    if (up == hipSuccess) up = hipMemcpyAsync(&hst, d_st, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+                    if (up == hipSuccess) up = hipStreamSynchronize(e->stream);
+                    if (d_st) (void)hipFree(d_st);
+                    if (up == hipSuccess && hst) {
+                        (void)hipFree(dt->block);
+                        delete dt;
+                        return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: a boundary covariance / precision is not positive definite", mdl);
+                    }
+                } else if (up == hipSuccess)
+                    up = hipStreamSynchronize(e->stream);  // the host vectors die at the end of this scope
+                if (up != hipSuccess) {
                     (void)hipFree(dt->block);
                     delete dt;
-                    return fail(e, RXHIP_ERR_NOT_POSDEF, "a boundary covariance / precision of the model is not positive definite");
+                    return fail(e, RXHIP_ERR_HIP, "upload of the model tables failed: %s", hipGetErrorString(up));
                 }
-            } else if (up == hipSuccess)
-                up = hipStreamSynchronize(e->stream);  // the host vectors die at the end of this scope
-            if (up != hipSuccess) {
-                (void)hipFree(dt->block);
-                delete dt;
-                return fail(e, RXHIP_ERR_HIP, "upload of the model tables failed: %s", hipGetErrorString(up));
+                dense_tables_insert(dt);
+                tr.mark("dense: table upload + bnd");
+            } else {
+                e->agg_oc = dt->agg_oc; e->agg_kc = dt->agg_kc; e->scan_sg = dt->scan_sg; e->scan_ng = dt->scan_ng;
+                tr.mark("dense: tables from cache");
             }
-            dense_tables_insert(dt);
-            tr.mark("dense: table upload + bnd");
-        } else {
-            e->agg_oc = dt->agg_oc; e->agg_kc = dt->agg_kc; e->scan_sg = dt->scan_sg; e->scan_ng = dt->scan_ng;
-            tr.mark("dense: tables from cache");
+            e->dts.push_back(dt);  // released in free_all, whatever happens below
         }
-        e->dt = dt;
-        e->d_cst = dt->d_cst; e->d_tab = dt->d_tab; e->d_scanm = dt->d_scanm; e->d_qtab = dt->d_qtab; e->d_bnd = dt->d_bnd;
+        {
+            DenseTables* dt = e->dts[0];
+            e->d_cst = dt->d_cst; e->d_tab = dt->d_tab; e->d_scanm = dt->d_scanm; e->d_qtab = dt->d_qtab; e->d_bnd = dt->d_bnd;
+        }
+        std::vector<DenseModel> hmodels;
+        if (e->n_models > 1)
+            for (DenseTables* dt : e->dts) hmodels.push_back(DenseModel{dt->d_cst, dt->d_tab, dt->d_scanm, dt->d_qtab, dt->d_bnd});
         ArenaPlan ap;
+        if (e->n_models > 1) {
+            ap.upload(&e->d_models, hmodels.data(), sizeof(DenseModel) * hmodels.size());
+            ap.upload(&e->d_chain_model, ds->chain_model, sizeof(int) * CU);
+        }
         ap.plain(&e->d_loc, sizeof(double) * C * 2 * Sg * D);
         ap.plain(&e->d_aggpart, sizeof(double) * C * (size_t)e->agg_kc * Sg * 2 * D);
         ap.zeroed(&e->d_status, sizeof(int));
@@ -2316,6 +2338,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     if (e->dense) {
         dp.T = e->T; dp.n_chains = e->wg_chains; dp.S = e->S; dp.L = e->L; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dyk;
         dp.pack = e->pack; dp.d_sub = 8; dp.dy_sub = e->dy;
+        dp.models = e->n_models > 1 ? e->d_models : nullptr; dp.chain_model = e->d_chain_model;
         dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
         dp.bnd = e->d_bnd; dp.qtab = e->d_qtab; dp.loc = e->d_loc; dp.sg = e->scan_sg; dp.ng = e->scan_ng;
         dp.aggpart = e->d_aggpart; dp.agg_oc = e->agg_oc; dp.agg_kc = e->agg_kc; dp.Llast = e->Llast;

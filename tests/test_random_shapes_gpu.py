@@ -196,3 +196,31 @@ def test_packed_pairs_of_chains(d, dy, T, C, segments, ptt):
             um, uc = eng.marginals()
             ufe = eng.free_energy_per_chain()
         assert rel(um, sm[:, :C - 1]) < 1e-9 and rel(uc, sc[:, :C - 1]) < 1e-9 and np.max(np.abs(ufe - sfe[:C - 1]) / np.abs(ufe)) < 1e-10
+
+
+@pytest.mark.parametrize("d,dy,T,C,M,segments", [(16, 16, 120, 7, 3, 0), (20, 5, 61, 4, 2, 3), (8, 8, 90, 6, 2, 0), (64, 64, 33, 3, 3, 2)])
+def test_several_models_on_the_mfma_path(d, dy, T, C, M, segments):
+    """`n_models` constant sets with `chain_model[c]` on the MFMA path (round 1: one model per engine): every chain reads
+    ITS model's tables (constants, aggregation maps, scan maps, boundary inverses) — smoothing and filtering vs the oracle."""
+    mdls = [workloads.random_model(d, dy, seed=7 * d + m) for m in range(M)]
+    cm = np.arange(C, dtype=np.int32) % M
+    y = np.empty((T, C, dy))
+    for c in range(C):
+        y[:, c] = workloads.generate_chain(mdls[cm[c]], T, 900 + c)[1]
+    stack = lambda k: np.stack([m[k] for m in mdls])
+    with rxhip.LGSSMEngine(stack("A"), stack("B"), stack("P"), stack("Q"), stack("m0"), stack("V0"), T=T, n_chains=C,
+                           chain_model=cm, segments=segments) as eng:
+        eng.set_data(y)
+        eng.run(1, True)
+        sm, sc = eng.marginals()
+        sfe = eng.free_energy_per_chain()
+        eng.run_filter(True)
+        fm, fc = eng.marginals()
+        ffe = eng.free_energy_per_chain()
+    for c in range(C):
+        m = mdls[cm[c]]
+        args = (m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], y[:, c])
+        om, oc, ofe = rxoracle.lgssm_kalman_rts(*args)
+        assert rel(sm[:, c], om) < 1e-6 and rel(sc[:, c], oc) < 1e-6 and abs(sfe[c] - ofe) < 1e-8 * abs(ofe), c
+        hm, hc, hfe, _ = rxoracle.lgssm_filter(*args, False)
+        assert rel(fm[:, c], hm) < 1e-6 and rel(fc[:, c], hc) < 1e-6 and abs(ffe[c] - hfe) < 1e-8 * abs(hfe), c
