@@ -242,6 +242,9 @@ def main():
     fe_all = torch.zeros(world, dtype=torch.float64, device=device)
     fe_buf = torch.zeros(1, dtype=torch.float64, device=device)
     fe_sum = torch.zeros(1, dtype=torch.float64, device=device)
+    if dist is not None:  # RCCL builds its communicator on the first collective: do that here, never inside the timed region
+        with torch.cuda.stream(stream):
+            dist.all_gather_into_tensor(fe_all, fe_buf)
     torch.cuda.synchronize()
 
     eng = rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C,
