@@ -89,6 +89,11 @@ typedef struct {
     int64_t horizon;  /* further time indices T+1 … T+horizon WITHOUT an observation (`missing` at the end of the data,
                          test/inference/inference_tests.jl `predictvars`): their posteriors are forward predictions; the
                          posterior arrays then hold T + horizon rows.  d, dy ≤ 4 only; 0 = none */
+    int32_t allow_missing; /* 1: an observation y[t] of a chain whose entries are NaN is `missing` ANYWHERE in the data
+                         (docs/src/manuals/inference/static.md:98-123): no message from its observation branch, no evidence
+                         term; its prediction (rxhip_get_predictions) is the plain predictive.  The covariances then differ
+                         per chain and time index, so the engine runs each chain as one segment (sequential in time,
+                         parallel over chains) on per-chain records.  d, dy ≤ 4 only */
 } rxhip_lgssm_desc;
 
 /* replaces: create_model(...) + postprocess_plugin (src/inference/batch.jl:252,

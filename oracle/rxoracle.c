@@ -872,6 +872,16 @@ int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B,
             congruence(d, d, A, Vf + (t - 1) * ms, Vp, tmp);
             for (size_t i = 0; i < ms; ++i) Vp[i] += P[i];
         }
+        {   /* a `missing` observation (any NaN entry; docs/src/manuals/inference/static.md:98-123): the observation
+               branch sends no message, the filtered belief is the prediction and the step has no evidence term */
+            int miss = 0;
+            for (int i = 0; i < dy; ++i) miss |= (y[(size_t)t * dy + i] != y[(size_t)t * dy + i]);
+            if (miss) {
+                memcpy(mf + t * vs, mp, sizeof(double) * vs);
+                memcpy(Vf + t * ms, Vp, sizeof(double) * ms);
+                continue;
+            }
+        }
         congruence(dy, d, B, Vp, S, tmp);
         for (int i = 0; i < dy * dy; ++i) S[i] += Q[i];
         double ldS;

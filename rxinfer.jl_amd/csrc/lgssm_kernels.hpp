@@ -145,6 +145,7 @@ struct Params {
     int filter;        // 1: filtering run — forward pass only, q(x_t | y_1..t) written as the marginals
     double fe_scale;   // 1 (smoothing: Bethe free energy of the chain) or 1/T (filtering: mean over observations)
     int* status;
+    int masked;        // 1: NaN observations are `missing` (per-chain records, one segment: rxhip_lgssm_desc.allow_missing)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -301,17 +302,29 @@ struct ObsCst {
         c0 = p[CL::C0];
     }
 };
-template <int D, int DY, bool FE>
+// A `missing` observation (docs/src/manuals/inference/static.md:98-123; the host marks it with NaNs): no message arrives from
+// the observation branch, the product is the forward message itself and the step contributes no evidence term.
+template <int DY>
+__device__ __forceinline__ bool obs_missing(const double (&y)[DY]) {
+    bool miss = false;
+#pragma unroll
+    for (int k = 0; k < DY; ++k) miss = miss || (y[k] != y[k]);
+    return miss;
+}
+template <int D, int DY, bool FE, bool MASKED = false>
 __device__ __forceinline__ void obs_update(const ObsCst<D, DY>& oc, const double (&mp)[D], const Sym<D>& Vp,
-                                           const double (&y)[DY], double (&m)[D], Sym<D>& V, bool& ok,
-                                           double& quad, double& detprod) {
+                                           const double (&yin)[DY], double (&m)[D], Sym<D>& V, bool& ok,
+                                           double& quad, double& detprod, bool miss = false) {
     Sym<D> Lp, Lf;
     double detp, detl;
     ok = spd_inv<D>(Vp, Lp, detp) && ok;  // weightedmean_precision of the forward message
-    double xp[D], xf[D];
+    double xp[D], xf[D], y[DY];
+    const double wgt = (MASKED && miss) ? 0.0 : 1.0;
+#pragma unroll
+    for (int k = 0; k < DY; ++k) y[k] = (MASKED && miss) ? 0.0 : yin[k];
     symv<D>(Lp, mp, xp);
 #pragma unroll
-    for (int i = 0; i < D * (D + 1) / 2; ++i) Lf.v[i] = Lp.v[i] + oc.lobs[i];
+    for (int i = 0; i < D * (D + 1) / 2; ++i) Lf.v[i] = MASKED ? Lp.v[i] + wgt * oc.lobs[i] : Lp.v[i] + oc.lobs[i];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         double s = xp[i];
@@ -336,16 +349,16 @@ __device__ __forceinline__ void obs_update(const ObsCst<D, DY>& oc, const double
         a1 += xf[i] * m[i];
         a2 += xp[i] * mp[i];
     }
-    quad = oc.c0 + q - a1 + a2;
+    quad = (MASKED ? wgt * oc.c0 : oc.c0) + q - a1 + a2;
     detprod = detl * detp;
 }
-template <int D, int DY, bool FE>
+template <int D, int DY, bool FE, bool MASKED = false>
 __device__ __forceinline__ void obs_update(const CPtr c, const double (&mp)[D], const Sym<D>& Vp,
                                            const double (&y)[DY], double (&m)[D], Sym<D>& V, bool& ok,
-                                           double& quad, double& detprod) {
+                                           double& quad, double& detprod, bool miss = false) {
     ObsCst<D, DY> oc;
     oc.load(c.p);
-    obs_update<D, DY, FE>(oc, mp, Vp, y, m, V, ok, quad, detprod);
+    obs_update<D, DY, FE, MASKED>(oc, mp, Vp, y, m, V, ok, quad, detprod, miss);
 }
 
 // running Σ log(x_t) as log(Π x_t): mantissa product renormalised every step (v_frexp_*), exponents
@@ -653,7 +666,7 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
         for (int i = 0; i < NS; ++i) Vp.v[i] = c[CL::V1 + i];
         load_y<DY>(p.y, 0, p.n_chains, chain, yv);
         double quad = 0.0, detprod = 1.0;
-        obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok, quad, detprod);
+        obs_update<D, DY, FE, !UNI>(c, mp, Vp, yv, m, V, ok, quad, detprod, !UNI && p.masked && obs_missing<DY>(yv));
         if (UNI) store_filt_sh<D>(p, 0, chain, m, V);
         else store_filt<D>(p.filt, 0, p.n_chains, chain, m, V);
         if (FE) p.fe_part[chain] = -0.5 * (quad + log(detprod));
@@ -974,7 +987,7 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
         matvec_c<D>(CPtr{c.p + CL::A}, m, mp);
         predict_cov<D>(CPtr{c.p + CL::A}, CPtr{c.p + CL::P}, V, T, Vp);
         double quad = 0.0, detprod = 1.0;
-        obs_update<D, DY, FE>(oc, mp, Vp, yv, m, V, ok, quad, detprod);
+        obs_update<D, DY, FE, !UNI>(oc, mp, Vp, yv, m, V, ok, quad, detprod, !UNI && p.masked && obs_missing<DY>(yv));
         if (FE) {
             acc += quad;
             lp.mul(detprod);

@@ -82,13 +82,18 @@ __global__ __launch_bounds__(256) void k_predict(PredictParams p) {
         for (int i = 0; i < D; ++i)
 #pragma unroll
             for (int j = 0; j <= i; ++j) V(i, j) = p.cov[g * D * D + i * D + j];
-        if (t < p.T) {  // take this step's observation message out of the posterior again
-            Sym<D> Ls, L;
-            double det, xi[D], yv[DY];
-            ok = spd_inv<D>(V, Ls, det) && ok;
-            symv<D>(Ls, m, xi);
+        double yv[DY];
+        bool observed = t < p.T;
+        if (observed) {
 #pragma unroll
             for (int k = 0; k < DY; ++k) yv[k] = p.y[g * DY + k];
+            observed = !obs_missing<DY>(yv);  // a `missing` y[t] sent no message: the posterior IS the leave-one-out belief
+        }
+        if (observed) {  // take this step's observation message out of the posterior again
+            Sym<D> Ls, L;
+            double det, xi[D];
+            ok = spd_inv<D>(V, Ls, det) && ok;
+            symv<D>(Ls, m, xi);
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 double s = xi[i];

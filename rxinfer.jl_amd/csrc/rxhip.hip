@@ -259,6 +259,7 @@ struct rxhip_engine {
     int scan_sg = 1, scan_ng = 1;  // two-level boundary scan of the dense path: group size, groups
     int agg_oc = 1, agg_kc = 1;    // dense aggregation product: offsets per K-chunk, K-chunks
     double* d_aggpart = nullptr;   // [chain][agg_kc][S][2·dpad] partial sums of kd_agg_gemm
+    bool masked = false;      // NaN observations are `missing` (rxhip_lgssm_desc.allow_missing): per-chain records, one segment
     int pack = 1;             // 2: pairs of chains share a 16×16 tile as a block-diagonal model (d ≤ 8), see dense_kernels.hpp
     long long wg_chains = 0;  // chains (or pairs) the kernels' grids run over
     int dyk = 0;              // observation dimension at kernel level (2·dy when packed)
@@ -1364,6 +1365,13 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     e->n_models = ds->n_models;
     e->ptt = ds->prior_through_transition ? 1 : 0;
     e->uniform = (ds->n_models == 1);
+    if (ds->allow_missing) {
+        // `missing` observations change the covariances per chain and per time index: no table of the time-parallel schedule
+        // survives.  The chain runs as ONE segment (sequential in time, parallel over chains) on the per-chain-record kernels.
+        if (dense) return fail(e, RXHIP_ERR_UNSUPPORTED, "missing observations inside the data have a device schedule for d, dy ≤ 4 only");
+        e->masked = true;
+        e->uniform = false;
+    }
     if (ds->horizon < 0) return fail(e, RXHIP_ERR_BADARG, "horizon must be non-negative");
     if (ds->horizon > 0 && dense)
         return fail(e, RXHIP_ERR_UNSUPPORTED, "unobserved time steps (horizon) have a device schedule for d, dy ≤ 4 only");
@@ -1413,7 +1421,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->L = 1;
         e->Llast = 1;
     } else {
-        long long S_target = ds->segments > 0 ? ds->segments
+        long long S_target = e->masked ? 1 : ds->segments > 0 ? ds->segments
                              : dense ? (256 * dense_wg_per_cu + e->wg_chains - 1) / e->wg_chains
                                      : (131072 + e->n_chains - 1) / e->n_chains;
         if (ds->segments <= 0 && !dense) {
@@ -1425,7 +1433,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         }
         if (S_target < 1) S_target = 1;
         long long L = (steps + S_target - 1) / S_target;
-        const long long Lmin = ds->segments > 0 ? 1 : 8;
+        const long long Lmin = (ds->segments > 0 || e->masked) ? 1 : 8;
         if (L < Lmin) L = Lmin;
         if (L > steps) L = steps;
         e->L = L;
@@ -2331,6 +2339,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.fe_total = e->d_fe_total;
     p.status = e->d_status;
     p.filter = filter ? 1 : 0;
+    p.masked = e->masked ? 1 : 0;
     p.fe_scale = filter ? 1.0 / (double)e->T : 1.0;
     const bool fe = want_fe != 0;
     rxhip_status st;

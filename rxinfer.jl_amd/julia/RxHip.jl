@@ -44,6 +44,7 @@ struct LgssmDesc
     device::Int32
     stream::Ptr{Cvoid}
     horizon::Int64
+    allow_missing::Int32
 end
 
 mutable struct Engine
@@ -76,7 +77,7 @@ state-space family (src/inference/batch.jl:252, src/model/plugins/reactivemp_inf
 """
 function Engine(A, B, P, Q, m0, V0; T::Integer, n_chains::Integer = 1, prior_through_transition::Bool = false,
                 segments::Integer = 0, device::Integer = -1, chain_model::Union{Nothing, AbstractVector{<:Integer}} = nothing,
-                stream = nothing, horizon::Integer = 0)
+                stream = nothing, horizon::Integer = 0, allow_missing::Bool = false)
     # one model: plain matrices; several: vectors of matrices (A[m], B[m], …) with chain_model[c] ∈ 0:n_models-1
     multi = A isa AbstractVector{<:AbstractMatrix}
     n_models = multi ? length(A) : 1
@@ -89,7 +90,7 @@ function Engine(A, B, P, Q, m0, V0; T::Integer, n_chains::Integer = 1, prior_thr
     st = GC.@preserve a b p q m v cm begin
         desc = LgssmDesc(d, dy, T, n_chains, n_models, prior_through_transition ? 1 : 0, pointer(a), pointer(b), pointer(p),
                          pointer(q), pointer(m), pointer(v), isempty(cm) ? Ptr{Int32}(C_NULL) : pointer(cm), segments, device,
-                         stream_handle(stream), horizon)
+                         stream_handle(stream), horizon, allow_missing ? 1 : 0)
         ccall((:rxhip_lgssm_create, librxhip), Int32, (Ref{LgssmDesc}, Ref{Ptr{Cvoid}}), desc, h)
     end
     e = Engine(h[], d, dy, T + horizon, n_chains, 0)   # T counts the rows of the result arrays (observed + horizon)

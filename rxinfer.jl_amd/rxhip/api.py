@@ -342,8 +342,10 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
     [chain][T][dy] for a batch of independent chains sharing the model.
     Returns posteriors["x"] as MvNormalMeanCovariance with mean [T][d] / [chain][T][d].
     `predictvars = ("y",)` (reference: `predictvars = (y = KeepLast(),)`): result.predictions["y"] holds the message toward
-    every y[t] — leave-one-out predictive for observed steps; trailing all-NaN rows of `y` are `missing` observations
-    (a forecast horizon) whose posteriors and predictions are forward predictions."""
+    every y[t] — leave-one-out predictive for observed steps.  NaN rows of `y` are `missing` observations: a tail that no
+    chain observed is a forecast horizon (posteriors and predictions there are forward predictions, the sweep stays
+    time-parallel); `missing` values anywhere else select the masked schedule (d, dy ≤ 4), where a missing y[t] sends no
+    message and its prediction is the smoothed predictive."""
     if isinstance(model, UnivariateGaussianMixture):
         return _infer_mixture(model, data, iterations, free_energy, options, initialization, catch_exception)
     if isinstance(model, MultivariateGaussianMixture):
@@ -370,18 +372,23 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
         y = y[None]
     C, T, dy = y.shape
     iters = 1 if iterations is None else int(iterations)
-    horizon = 0
-    if predictvars:
-        missing = np.all(np.isnan(y), axis=(0, 2))      # a time index is `missing` when no chain observed it
+    horizon, allow_missing = 0, False
+    nans = np.isnan(y)
+    if nans.any():
+        # `missing` observations (docs/src/manuals/inference/static.md:98-123).  A tail that no chain observed is a forecast
+        # horizon and keeps the time-parallel schedule; anything else runs the per-chain masked schedule.
+        missing = np.all(nans, axis=(0, 2))
         while horizon < T - 1 and missing[T - 1 - horizon]:
             horizon += 1
-        if np.any(np.isnan(y[:, :T - horizon])):
-            raise ValueError("missing observations are supported at the END of the data only (forecast horizon)")
-        y, T = y[:, :T - horizon], T - horizon
+        if nans[:, :T - horizon].any():
+            horizon, allow_missing = 0, True
+        else:
+            y, T = y[:, :T - horizon], T - horizon
     eng = None
     try:
         eng = LGSSMEngine(model.A, model.B, model.P, model.Q, model.prior_mean, model.prior_cov, T=T, n_chains=C,
                           prior_through_transition=model.prior_through_transition, horizon=horizon,
+                          allow_missing=allow_missing,
                           segments=int(options.get("segments", 0)), device=int(options.get("device", -1)))
         eng.set_data(y, layout="chain_time")
         eng.run(iterations=iters, free_energy=free_energy)

@@ -27,7 +27,7 @@ class LGSSMEngine:
     """
 
     def __init__(self, A, B, P, Q, m0, V0, T, n_chains=1, chain_model=None, prior_through_transition=False,
-                 segments=0, device=-1, stream=None, horizon=0):
+                 segments=0, device=-1, stream=None, horizon=0, allow_missing=False):
         L = _lib.lib()
         A = _c(A)
         B = _c(B)
@@ -56,6 +56,7 @@ class LGSSMEngine:
         desc.device = int(device)
         desc.stream = ctypes.c_void_p(stream) if stream else None
         desc.horizon = self.horizon
+        desc.allow_missing = int(bool(allow_missing))
         self._h = ctypes.c_void_p()
         st = L.rxhip_lgssm_create(ctypes.byref(desc), ctypes.byref(self._h))
         if st != _lib.OK:

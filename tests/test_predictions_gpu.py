@@ -55,9 +55,13 @@ def test_infer_mirror_with_predictvars_and_missing_tail():
     opm, opc, oxm, oxc = rxoracle.lgssm_predict(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y, horizon=5)
     assert res.predictions["y"].mean.shape == (125, 2) and rel(res.predictions["y"].mean, opm) < 1e-6 and rel(res.predictions["y"].cov, opc) < 1e-6
     assert res.posteriors["x"].mean.shape == (125, 2) and rel(res.posteriors["x"].mean[120:], oxm) < 1e-6
-    with pytest.raises(ValueError):
-        bad = ym.copy(); bad[10] = np.nan
-        rxhip.infer(model=spec, data={"y": bad}, predictvars=("y",))
+    # a `missing` value inside the data selects the masked schedule; the tail is then five more missing observations
+    holes = ym.copy(); holes[10] = np.nan
+    res2 = rxhip.infer(model=spec, data={"y": holes}, predictvars=("y",))
+    om, oc, _ = rxoracle.lgssm_kalman_rts(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], holes,
+                                          prior_through_transition=spec.prior_through_transition)
+    assert res2.posteriors["x"].mean.shape == (125, 2) and rel(res2.posteriors["x"].mean, om) < 1e-6 and rel(res2.posteriors["x"].cov, oc) < 1e-6
+    assert rel(res2.predictions["y"].mean[120:], opm[120:]) < 1e-3   # one hole 110 steps earlier: the forecasts barely move
 
 
 def test_predictions_call_order_and_unsupported_shapes():
