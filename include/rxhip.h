@@ -93,7 +93,13 @@ typedef struct {
                          (docs/src/manuals/inference/static.md:98-123): no message from its observation branch, no evidence
                          term; its prediction (rxhip_get_predictions) is the plain predictive.  The covariances then differ
                          per chain and time index, so the engine runs each chain as one segment (sequential in time,
-                         parallel over chains) on per-chain records.  d, dy ≤ 4 only */
+                         parallel over chains) on per-chain records.  d, dy ≤ 4 only.  rxhip_counters keeps reporting the
+                         all-observed schedule */
+    const int32_t* step_model; /* NULL, or [T + horizon]: time-varying constants.  step_model[t] names the model (of n_models)
+                         whose A, P make the transition INTO x[t] and whose B, Q observe y[t] (`A[t] * x[t-1]`,
+                         `MvNormal(μ = …, Σ = P[t])` with per-step constants in the @model loop); the prior (m0, V0) is that of
+                         model step_model[0].  All chains share the schedule (chain_model must be NULL); the engine runs
+                         each chain as one segment, as for allow_missing.  d, dy ≤ 4 only */
 } rxhip_lgssm_desc;
 
 /* replaces: create_model(...) + postprocess_plugin (src/inference/batch.jl:252,
@@ -160,23 +166,28 @@ typedef struct {
     const int64_t* var_init;         /* [n_variables] offset of its parameters in const_pool (−1: none) */
     int32_t gh_points;               /* GCVMetadata(GaussHermiteCubature(n)) of the GCV nodes; 0 = 31 */
     int64_t n_observations;          /* streaming (one-step) graphs: observations that will be pushed per replica */
+    int32_t allow_missing;           /* state-space graphs: some data variable holds `missing` (the data is known when the model
+                                        is created, src/inference/batch.jl:252) — as rxhip_lgssm_desc.allow_missing */
 } rxhip_graph_desc;
 
-/* result of the lowering pass for the LGSSM family; matrices are written into caller buffers of the sizes below */
+/* result of the lowering pass for the LGSSM family; matrices are written into caller buffers of the sizes below
+ * (n_models = 1 unless the constants differ from step to step) */
 typedef struct {
     int32_t d, dy;
     int64_t T;
     int32_t prior_through_transition;
-    double* A;  /* [d][d]   */
-    double* B;  /* [dy][d]  */
-    double* P;  /* [d][d]   */
-    double* Q;  /* [dy][dy] */
+    double* A;  /* [n_models][d][d]   */
+    double* B;  /* [n_models][dy][d]  */
+    double* P;  /* [n_models][d][d]   */
+    double* Q;  /* [n_models][dy][dy] */
     double* m0; /* [d]      */
     double* V0; /* [d][d]   */
     int64_t* state_var; /* [T] variable id of x[t] in time order (nullable) */
     int64_t* data_var;  /* [T] variable id of y[t] in time order (nullable) */
     int32_t deterministic; /* 1: noise-free drift chain `x[t] ~ x[t-1] + c` (P is zero, A the identity) */
     double* c;             /* [d] drift (nullable); zero unless deterministic */
+    int32_t n_models;      /* distinct (A, P, B, Q) along the chain: per-step constants `A[t] * x[t-1]`, `Σ = P[t]`, … */
+    int32_t* step_model;   /* [T] model of time index t (nullable; all zero when n_models = 1) */
 } rxhip_lgssm_lowered;
 
 /* Host-only (no device needed): recognise a linear Gaussian state-space chain in `g` — MvNormalMeanCovariance or (scalar

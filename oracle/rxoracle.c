@@ -841,9 +841,13 @@ int rxo_lgssm_predict(int d, int dy, int T, int H, const double* A, const double
  * Independent textbook implementation, used ONLY to validate the restatement above
  * (identity: BP on a tree == Kalman filter + RTS smoother; Bethe FE == −log p(y)).
  * ------------------------------------------------------------------------------------------ */
-int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B, const double* P,
-                         const double* Q, const double* m0, const double* V0, int ptt, const double* y,
-                         double* post_mean, double* post_cov, double* neg_loglik) {
+static int kalman_rts_impl(int d, int dy, int T, const double* A0, const double* B0, const double* P0,
+                           const double* Q0, const double* m00, const double* V00, const int* sm, int ptt, const double* y,
+                           double* post_mean, double* post_cov, double* neg_loglik) {
+    /* time-varying constants: time index t uses model sm[t] (transition INTO x[t], observation of y[t]) */
+#define MDL(t) (sm ? (size_t)sm[t] : (size_t)0)
+    const double *A = A0 + MDL(0) * d * d, *B = B0 + MDL(0) * dy * d, *P = P0 + MDL(0) * d * d, *Q = Q0 + MDL(0) * dy * dy;
+    const double *m0 = m00 + MDL(0) * d, *V0 = V00 + MDL(0) * d * d;
     const int dm = d > dy ? d : dy;
     const size_t vs = d, ms = (size_t)d * d;
     double* mf = (double*)malloc(sizeof(double) * T * (vs + ms));
@@ -864,6 +868,7 @@ int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B,
         memcpy(pV0, V0, sizeof(double) * ms);
     }
     for (int t = 0; t < T && !rc; ++t) {
+        A = A0 + MDL(t) * d * d; B = B0 + MDL(t) * dy * d; P = P0 + MDL(t) * d * d; Q = Q0 + MDL(t) * dy * dy;
         if (t == 0) {
             memcpy(mp, pm0, sizeof(double) * vs);
             memcpy(Vp, pV0, sizeof(double) * ms);
@@ -927,6 +932,7 @@ int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B,
         memcpy(post_mean + (size_t)(T - 1) * vs, mf + (T - 1) * vs, sizeof(double) * vs);
         memcpy(post_cov + (size_t)(T - 1) * ms, Vf + (T - 1) * ms, sizeof(double) * ms);
         for (int t = T - 2; t >= 0 && !rc; --t) {
+            A = A0 + MDL(t + 1) * d * d; P = P0 + MDL(t + 1) * d * d; /* the transition into x[t+1] */
             matvec(d, d, A, mf + t * vs, mp);
             congruence(d, d, A, Vf + t * ms, Vp, tmp);
             for (size_t i = 0; i < ms; ++i) Vp[i] += P[i];
@@ -961,6 +967,22 @@ int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B,
     free(w);
     free(pm0);
     return rc;
+}
+#undef MDL
+int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B, const double* P,
+                         const double* Q, const double* m0, const double* V0, int ptt, const double* y,
+                         double* post_mean, double* post_cov, double* neg_loglik) {
+    return kalman_rts_impl(d, dy, T, A, B, P, Q, m0, V0, NULL, ptt, y, post_mean, post_cov, neg_loglik);
+}
+/* Time-varying constants (`A[t] * x[t-1]`, `Σ = P[t]` … in the @model loop): A, B, P, Q, m0, V0 hold n_models models,
+   step_model[t] names the model of time index t.  Test infrastructure: checks rxhip_lgssm_desc.step_model. */
+int rxo_lgssm_kalman_rts_tv(int d, int dy, int T, int n_models, const double* A, const double* B, const double* P,
+                            const double* Q, const double* m0, const double* V0, const int* step_model, int ptt,
+                            const double* y, double* post_mean, double* post_cov, double* neg_loglik) {
+    if (!step_model || n_models <= 0) return RXO_ERR_BADARG;
+    for (int t = 0; t < T; ++t)
+        if (step_model[t] < 0 || step_model[t] >= n_models) return RXO_ERR_BADARG;
+    return kalman_rts_impl(d, dy, T, A, B, P, Q, m0, V0, step_model, ptt, y, post_mean, post_cov, neg_loglik);
 }
 
 

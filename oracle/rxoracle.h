@@ -117,6 +117,10 @@ int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B,
                          const double* Q, const double* m0, const double* V0,
                          int prior_through_transition, const double* y, double* post_mean,
                          double* post_cov, double* neg_loglik);
+/* the same with time-varying constants: n_models models, step_model[t] = model of time index t */
+int rxo_lgssm_kalman_rts_tv(int d, int dy, int T, int n_models, const double* A, const double* B, const double* P,
+                            const double* Q, const double* m0, const double* V0, const int* step_model, int ptt,
+                            const double* y, double* post_mean, double* post_cov, double* neg_loglik);
 
 /*
  * Univariate Gaussian mixture, mean-field VMP (test/models/mixtures/gmm_univariate_tests.jl:7-26,

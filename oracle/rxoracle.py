@@ -38,6 +38,9 @@ def lib():
                                                                     ctypes.POINTER(Counters)]
         _LIB.rxo_lgssm_kalman_rts.restype = ctypes.c_int
         _LIB.rxo_lgssm_kalman_rts.argtypes = [ctypes.c_int] * 3 + [dp] * 6 + [ctypes.c_int, dp, dp, dp, dp]
+        _LIB.rxo_lgssm_kalman_rts_tv.restype = ctypes.c_int
+        _LIB.rxo_lgssm_kalman_rts_tv.argtypes = ([ctypes.c_int] * 4 + [dp] * 6 +
+                                                 [ctypes.POINTER(ctypes.c_int), ctypes.c_int, dp, dp, dp, dp])
         _LIB.rxo_lgssm_bp_batch.restype = ctypes.c_int
         _LIB.rxo_lgssm_bp_batch.argtypes = [ctypes.c_int] * 4 + [dp] * 6 + [ctypes.c_int, dp, dp, dp, dp,
                                                                           ctypes.c_int, ctypes.POINTER(Counters)]
@@ -125,6 +128,22 @@ def lgssm_kalman_rts(A, B, P, Q, m0, V0, y, prior_through_transition=False):
                                     int(prior_through_transition), _p(y), _p(mean), _p(cov), ctypes.byref(nll))
     if rc:
         raise RuntimeError(f"rxo_lgssm_kalman_rts failed with status {rc}")
+    return mean, cov, nll.value
+
+
+def lgssm_kalman_rts_tv(A, B, P, Q, m0, V0, step_model, y, prior_through_transition=False):
+    """Textbook smoother with time-varying constants: A … V0 carry a leading model axis, step_model[t] names the model of t."""
+    A, B, P, Q, m0, V0, y = map(_c, (A, B, P, Q, m0, V0, y))
+    sm = np.ascontiguousarray(step_model, dtype=np.int32)
+    M, d, dy, T = A.shape[0], A.shape[-1], B.shape[-2], y.shape[0]
+    mean = np.empty((T, d))
+    cov = np.empty((T, d, d))
+    nll = ctypes.c_double(0.0)
+    rc = lib().rxo_lgssm_kalman_rts_tv(d, dy, T, M, _p(A), _p(B), _p(P), _p(Q), _p(m0), _p(V0),
+                                       sm.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), int(prior_through_transition),
+                                       _p(y), _p(mean), _p(cov), ctypes.byref(nll))
+    if rc:
+        raise RuntimeError(f"rxo_lgssm_kalman_rts_tv failed with status {rc}")
     return mean, cov, nll.value
 
 

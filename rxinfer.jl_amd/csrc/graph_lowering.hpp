@@ -4,6 +4,9 @@
 // GraphPPL.postprocess_plugin(::ReactiveMPInferencePlugin, model) (src/model/plugins/reactivemp_inference.jl:272-326):
 // instead of one ReactiveMP object per variable / factor, one pass over the SoA tables.
 #pragma once
+#include <array>
+#include <map>
+#include <unordered_map>
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -31,8 +34,10 @@ struct Lgssm {
     long long T = 0;
     int ptt = 0;
     int deterministic = 0;  // 1: every transition is `x[t] ~ x[t-1] + c` (typeof(+) with a constant, no state noise)
-    std::vector<double> A, B, P, Q, m0, V0, c;
+    std::vector<double> A, B, P, Q, m0, V0, c;  // A, B, P, Q: [n_models] matrices
     std::vector<long long> state_var, data_var;
+    int n_models = 1;
+    std::vector<int> step_model;  // [T] when n_models > 1: the constants of time index t (per-step A[t], P[t], B[t], Q[t])
 };
 
 // interface k of factor f / number of interfaces (3-wide table or CSR)
@@ -108,8 +113,8 @@ inline bool same_const(const rxhip_graph_desc* g, long long a, long long b) {
 //     prior:        Gaussian(out = x_first, μ = const)
 //     per state x:  Gaussian(out = y (data), μ = B·x)                 observation; B·x is either the output of a
 //                   Gaussian(out = x_next (random), μ = A·x)          `*`(out, A const, in = x) node or x itself (B, A = I)
-// (`y ~ MvNormal(μ = B * x, Σ = Q)`, `x ~ Normal(μ = x_prev, v = …)` and their mixtures) with time-invariant constants, and
-// the noise-free drift chain of test/models/statespace/ulgssm_tests.jl:8-15,
+// (`y ~ MvNormal(μ = B * x, Σ = Q)`, `x ~ Normal(μ = x_prev, v = …)` and their mixtures); constants that differ from step to
+// step (`A[t] * x[t-1]`, `Σ = P[t]`) are grouped into models by value (Lgssm::step_model).  Also the noise-free drift chain of test/models/statespace/ulgssm_tests.jl:8-15,
 //     x[t] ~ x[t-1] + c        `+`(out = x_next, in1 = x, in2 = c const)  (or in1 const)
 // whose every transition is such a node.  Node order in the tables is irrelevant.
 inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
@@ -174,6 +179,8 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
     // a branch out of state x: the Gaussian node it feeds and the constant matrix in between (-1: identity)
     struct Branch { long long gauss, matrix; };
     long long vA = -2, vP = -1, vB = -2, vQ = -1, vC = -1;  // -2: not seen yet, -1: identity
+    constexpr long long NONE = -3;                           // no transition into this time index (t = 1 of a chain whose prior sits on x[1])
+    std::vector<long long> sA, sP, sB, sQ;                   // per time index: the constant variables of its transition / observation
     int n_noisy = 0, n_det = 0;
     long long used_factors = 1;
     bool first = true;
@@ -203,7 +210,8 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         if (obs >= 0) {
             const long long q = iface(g, obs, 2);
             if (vB == -2) { vB = obs_m; vQ = q; }
-            else if ((vB < 0) != (obs_m < 0) || (vB >= 0 && !same_const(g, vB, obs_m)) || !same_const(g, vQ, q)) return unsupported("time-varying observation model");
+            sB.push_back(obs_m);
+            sQ.push_back(q);
             L.state_var.push_back(x);
             L.data_var.push_back(iface(g, obs, 0));
         } else if (first && (tr >= 0 || add >= 0)) {
@@ -214,7 +222,10 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         if (tr >= 0) {
             const long long pv = iface(g, tr, 2);
             if (vA == -2) { vA = tr_m; vP = pv; }
-            else if ((vA < 0) != (tr_m < 0) || (vA >= 0 && !same_const(g, vA, tr_m)) || !same_const(g, vP, pv)) return unsupported("time-varying transition model");
+            sA.resize(L.state_var.size() + 1, NONE);  // the transition INTO the next observed state
+            sP.resize(L.state_var.size() + 1, NONE);
+            sA.back() = tr_m;
+            sP.back() = pv;
             ++n_noisy;
             x = iface(g, tr, 0);
         } else if (add >= 0) {
@@ -234,23 +245,72 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
     if (L.T <= 0 || vB == -2) return unsupported("chain without observations");
     L.d = d;
     L.dy = g->var_rows[L.data_var[0]];
-    const double *pA = nullptr, *pP = nullptr, *pB = nullptr, *pQ;
-    if (vB >= 0 && !const_value(g, vB, L.dy, d, &pB)) return badarg("observation matrix has the wrong shape");
-    if (vB < 0 && L.dy != d) return unsupported("observation without a `*` node must have the state's dimension");
-    if (!const_value(g, vQ, L.dy, L.dy, &pQ)) return badarg("observation noise has the wrong shape");
-    if (n_noisy > 0) {
-        if (vA >= 0 && !const_value(g, vA, d, d, &pA)) return badarg("transition matrix has the wrong shape");
-        if (!const_value(g, vP, d, d, &pP)) return badarg("state noise has the wrong shape");
-    }
-    auto eye = [](std::vector<double>& M, int r, int c) { M.assign((size_t)r * c, 0.0); for (int i = 0; i < (r < c ? r : c); ++i) M[(size_t)i * c + i] = 1.0; };
+    const int dy = L.dy;
     L.m0.assign(m0, m0 + d);
     L.V0.assign(V0, V0 + (size_t)d * d);
-    if (pB) L.B.assign(pB, pB + (size_t)L.dy * d); else eye(L.B, L.dy, d);
-    L.Q.assign(pQ, pQ + (size_t)L.dy * L.dy);
-    if (pA) L.A.assign(pA, pA + (size_t)d * d); else eye(L.A, d, d);
-    if (pP) L.P.assign(pP, pP + (size_t)d * d);
-    else if (n_det > 0) L.P.assign((size_t)d * d, 0.0);  // noise-free transitions
-    else eye(L.P, d, d);                                 // single time step: no transition in the graph
+    // the constants of every time index, grouped into models: first by variable id, then by value
+    const long long T = L.T;
+    sA.resize((size_t)T, NONE);
+    sP.resize((size_t)T, NONE);
+    for (long long t = 0; t < T; ++t)
+        if (g->var_rows[L.data_var[t]] != dy) return unsupported("observation dimension changes along the chain");
+    if (n_noisy > 0 && sA[0] == NONE) {  // no transition into the first state: its A, P are never used — take the next step's
+        sA[0] = T > 1 ? sA[1] : -1;
+        sP[0] = T > 1 ? sP[1] : NONE;
+    }
+    auto append = [&](std::vector<double>& dst, long long v, int r, int c, int fill) -> bool {  // fill: 1 identity, 0 zero
+        if (v >= 0) {
+            const double* q;
+            if (!const_value(g, v, r, c, &q)) return false;
+            dst.insert(dst.end(), q, q + (size_t)r * c);
+        } else {
+            const size_t o = dst.size();
+            dst.resize(o + (size_t)r * c, 0.0);
+            if (fill) for (int i = 0; i < (r < c ? r : c); ++i) dst[o + (size_t)i * c + i] = 1.0;
+        }
+        return true;
+    };
+    std::map<std::array<long long, 4>, int> by_id;
+    std::unordered_map<std::string, int> by_value;
+    std::vector<int> step((size_t)T);
+    for (long long t = 0; t < T; ++t) {
+        const std::array<long long, 4> ids = {sA[t], sP[t], sB[t], sQ[t]};
+        if (t > 0) {  // the common case — GraphPPL makes a new constant variable per use, with equal values: compare with the last step
+            const std::array<long long, 4> pv = {sA[t - 1], sP[t - 1], sB[t - 1], sQ[t - 1]};
+            bool same = true;
+            for (int k = 0; k < 4 && same; ++k) same = ids[k] == pv[k] || (ids[k] >= 0 && pv[k] >= 0 && same_const(g, ids[k], pv[k]));
+            if (same) { step[t] = step[t - 1]; continue; }
+        }
+        auto it = by_id.find(ids);
+        if (it != by_id.end()) { step[t] = it->second; continue; }
+        if (sB[t] < 0 && dy != d) return unsupported("observation without a `*` node must have the state's dimension");
+        std::vector<double> a, pm, b, q;
+        // a chain of `+` nodes has A = I, P = 0; a single time step has no transition in the graph (A = P = I, never used)
+        if (!append(a, sA[t] == NONE ? -1 : sA[t], d, d, 1)) return badarg("transition matrix has the wrong shape");
+        if (!append(pm, sP[t] == NONE ? -1 : sP[t], d, d, n_det > 0 ? 0 : 1)) return badarg("state noise has the wrong shape");
+        if (!append(b, sB[t], dy, d, 1)) return badarg("observation matrix has the wrong shape");
+        if (sQ[t] < 0 || !append(q, sQ[t], dy, dy, 1)) return badarg("observation noise has the wrong shape");
+        std::string key;
+        for (const std::vector<double>* m : {&a, &pm, &b, &q}) key.append((const char*)m->data(), m->size() * sizeof(double));
+        auto iv = by_value.find(key);
+        int mdl;
+        if (iv != by_value.end()) mdl = iv->second;
+        else {
+            mdl = (int)by_value.size();
+            by_value.emplace(std::move(key), mdl);
+            L.A.insert(L.A.end(), a.begin(), a.end());
+            L.P.insert(L.P.end(), pm.begin(), pm.end());
+            L.B.insert(L.B.end(), b.begin(), b.end());
+            L.Q.insert(L.Q.end(), q.begin(), q.end());
+        }
+        by_id.emplace(ids, mdl);
+        step[t] = mdl;
+    }
+    L.n_models = (int)by_value.size();
+    if (L.n_models > 1) {
+        if (n_det > 0) return unsupported("noise-free `+` chain with time-varying observation noise");
+        L.step_model.swap(step);
+    }
     L.c.assign(d, 0.0);
     if (n_det > 0) {
         const double* pc;

@@ -146,6 +146,8 @@ struct Params {
     double fe_scale;   // 1 (smoothing: Bethe free energy of the chain) or 1/T (filtering: mean over observations)
     int* status;
     int masked;        // 1: NaN observations are `missing` (per-chain records, one segment: rxhip_lgssm_desc.allow_missing)
+    const int* step_model;  // [T] or null: the model of time index t (transition INTO x[t] and observation of y[t]);
+                            // one segment, per-chain records (rxhip_lgssm_desc.step_model)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -508,6 +510,12 @@ __device__ __forceinline__ int model_of(const Params& p, long long chain) {
     if (UNI) return 0;
     return p.chain_model ? p.chain_model[chain] : 0;
 }
+// time-varying constants A_t, P_t, B_t, Q_t: the model of time index t
+template <bool UNI>
+__device__ __forceinline__ int model_at(const Params& p, int chain_mdl, long long t) {
+    if constexpr (UNI) return 0;
+    else return p.step_model ? p.step_model[t] : chain_mdl;
+}
 
 // segment s covers times (1-based) b_s+1 .. b_{s+1}, b_s = 1 + s·L, b_S = T
 __device__ __forceinline__ long long seg_len(const Params& p, long long s) {
@@ -652,7 +660,7 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
     const long long chain = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (chain >= p.n_chains) return;
     const int role = blockIdx.y;
-    const int mdl = model_of<UNI>(p, chain);
+    const int mdl = model_at<UNI>(p, model_of<UNI>(p, chain), 0);  // role 0 takes the step at t = 0; the scans below run all-observed, time-invariant segments
     const CPtr c{UNI ? cb.v : p.cst + (long long)mdl * CL::SIZE};
     const double* aggm = p.agg + (long long)mdl * 2 * AL::SIZE;
     const int S = p.S;
@@ -984,8 +992,15 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
         if (i + 1 < len) load_y<DY>(p.y, t0 + i + 1, p.n_chains, chain, yn);
         double mp[D], T[D][D];
         Sym<D> Vp;
-        matvec_c<D>(CPtr{c.p + CL::A}, m, mp);
-        predict_cov<D>(CPtr{c.p + CL::A}, CPtr{c.p + CL::P}, V, T, Vp);
+        const double* ct = c.p;
+        if constexpr (!UNI) {
+            if (p.step_model) {  // A_t, P_t and the observation constants of this time index
+                ct = p.cst + (long long)p.step_model[t0 + i] * CL::SIZE;
+                oc.load(ct);
+            }
+        }
+        matvec_c<D>(CPtr{ct + CL::A}, m, mp);
+        predict_cov<D>(CPtr{ct + CL::A}, CPtr{ct + CL::P}, V, T, Vp);
         double quad = 0.0, detprod = 1.0;
         obs_update<D, DY, FE, !UNI>(oc, mp, Vp, yv, m, V, ok, quad, detprod, !UNI && p.masked && obs_missing<DY>(yv));
         if (FE) {
@@ -1149,8 +1164,12 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
         if (t > tb) prefetch(t - 1);
         double mp[D], T[D][D];
         Sym<D> Vp, Lp;
-        matvec_c<D>(CPtr{c.p + CL::A}, mf, mp);
-        predict_cov<D>(CPtr{c.p + CL::A}, CPtr{c.p + CL::P}, Vf, T, Vp);
+        const double* ct = c.p;
+        if constexpr (!UNI) {
+            if (p.step_model) ct = p.cst + (long long)p.step_model[t + 1] * CL::SIZE;  // the transition into x[t+1]
+        }
+        matvec_c<D>(CPtr{ct + CL::A}, mf, mp);
+        predict_cov<D>(CPtr{ct + CL::A}, CPtr{ct + CL::P}, Vf, T, Vp);
         double det;
         ok = spd_inv<D>(Vp, Lp, det) && ok;
         // G = T' Lp   (T = A V_f)

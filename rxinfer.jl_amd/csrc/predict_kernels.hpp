@@ -23,6 +23,7 @@ struct PredictParams {
     const double* cst;    // [n_models][CstLayout::SIZE]
     const double* bq;     // [n_models][DY·D + DY·DY]   B | Q (row-major)
     const int* chain_model;
+    const int* step_model; // [T+H] or null: time-varying constants (Params::step_model)
     double* pmean;        // [T+H][chain][DY]
     double* pcov;         // [T+H][chain][DY][DY]
     int* status;
@@ -34,7 +35,6 @@ __global__ __launch_bounds__(64) void k_forecast(PredictParams p) {
     const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= p.n_chains) return;
     const double* cst = p.cst + (size_t)(p.chain_model ? p.chain_model[c] : 0) * CL::SIZE;
-    const CPtr A{cst + CL::A}, P{cst + CL::P};
     double m[D];
     Sym<D> V;
     const long long r0 = (p.T - 1) * p.n_chains + c;
@@ -47,6 +47,8 @@ __global__ __launch_bounds__(64) void k_forecast(PredictParams p) {
     for (long long h = 0; h < p.H; ++h) {
         double mn[D], Tm[D][D];
         Sym<D> Vn;
+        if (p.step_model) cst = p.cst + (size_t)p.step_model[p.T + h] * CL::SIZE;
+        const CPtr A{cst + CL::A}, P{cst + CL::P};
         matvec_c<D>(A, m, mn);             // `*`_A(:out): N(A m, A V A')
         predict_cov<D>(A, P, V, Tm, Vn);   // MvN_x(:out): + P
         const long long r = (p.T + h) * p.n_chains + c;
@@ -70,7 +72,7 @@ __global__ __launch_bounds__(256) void k_predict(PredictParams p) {
     bool ok = true;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const long long t = g / p.n_chains, c = g - t * p.n_chains;
-        const int mdl = p.chain_model ? p.chain_model[c] : 0;
+        const int mdl = p.step_model ? p.step_model[t] : p.chain_model ? p.chain_model[c] : 0;
         const double* cst = p.cst + (size_t)mdl * CL::SIZE;
         const double* B = p.bq + (size_t)mdl * (DY * D + DY * DY);
         const double* Q = B + DY * D;

@@ -259,6 +259,8 @@ struct rxhip_engine {
     int scan_sg = 1, scan_ng = 1;  // two-level boundary scan of the dense path: group size, groups
     int agg_oc = 1, agg_kc = 1;    // dense aggregation product: offsets per K-chunk, K-chunks
     double* d_aggpart = nullptr;   // [chain][agg_kc][S][2·dpad] partial sums of kd_agg_gemm
+    bool sequential = false;  // one segment per chain on per-chain records (missing observations, time-varying constants)
+    int* d_step_model = nullptr;
     bool masked = false;      // NaN observations are `missing` (rxhip_lgssm_desc.allow_missing): per-chain records, one segment
     int pack = 1;             // 2: pairs of chains share a 16×16 tile as a block-diagonal model (d ≤ 8), see dense_kernels.hpp
     long long wg_chains = 0;  // chains (or pairs) the kernels' grids run over
@@ -722,7 +724,7 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
     for (int i = 0; i < dy * d; ++i) cst[v.oHF + i] = HF[i];
 
     // gain tables: Kalman filter started from an exactly known state (V = 0)
-    const long long L = e->L;
+    const long long L = e->sequential ? 0 : e->L;
     std::vector<double> V(d * d, 0.0), Pi(d * d, 0.0), J(d * d, 0.0), Vp(d * d), S(dy * dy), Si(dy * dy), K(d * dy),
         HFPi(dy * d), U(d * dy), t1(d * d + dy * d + d * dy), t2(d * d + dy * d + d * dy), Phi(d * d), Ci(d * d),
         X(d * d), JJ(d * d);
@@ -1344,11 +1346,16 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         return RXHIP_ERR_BADARG;
     const LgssmVtbl* vt = find_vtbl(ds->d, ds->dy);
     const bool dense = !vt && dense_supported(ds->d, ds->dy);
-    if (dense && ds->n_models > 1 && !ds->chain_model) return RXHIP_ERR_BADARG;
+    if (dense && ds->n_models > 1 && !ds->chain_model && !ds->step_model) return RXHIP_ERR_BADARG;
     if (!vt && !dense) return RXHIP_ERR_UNSUPPORTED;
     if (ds->chain_model)
         for (long long c = 0; c < ds->n_chains; ++c)
             if (ds->chain_model[c] < 0 || ds->chain_model[c] >= ds->n_models) return RXHIP_ERR_BADARG;
+    if (ds->step_model) {
+        if (ds->chain_model || ds->horizon < 0) return RXHIP_ERR_BADARG;
+        for (long long t = 0; t < ds->T + ds->horizon; ++t)
+            if (ds->step_model[t] < 0 || ds->step_model[t] >= ds->n_models) return RXHIP_ERR_BADARG;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RXHIP_ERR_NO_DEVICE;
 
@@ -1370,6 +1377,13 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         // survives.  The chain runs as ONE segment (sequential in time, parallel over chains) on the per-chain-record kernels.
         if (dense) return fail(e, RXHIP_ERR_UNSUPPORTED, "missing observations inside the data have a device schedule for d, dy ≤ 4 only");
         e->masked = true;
+        e->sequential = true;
+        e->uniform = false;
+    }
+    if (ds->step_model) {
+        // time-varying A_t, P_t, B_t, Q_t: the tables of the time-parallel schedule assume one model along the chain
+        if (dense) return fail(e, RXHIP_ERR_UNSUPPORTED, "time-varying constants have a device schedule for d, dy ≤ 4 only");
+        e->sequential = true;
         e->uniform = false;
     }
     if (ds->horizon < 0) return fail(e, RXHIP_ERR_BADARG, "horizon must be non-negative");
@@ -1421,7 +1435,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->L = 1;
         e->Llast = 1;
     } else {
-        long long S_target = e->masked ? 1 : ds->segments > 0 ? ds->segments
+        long long S_target = e->sequential ? 1 : ds->segments > 0 ? ds->segments
                              : dense ? (256 * dense_wg_per_cu + e->wg_chains - 1) / e->wg_chains
                                      : (131072 + e->n_chains - 1) / e->n_chains;
         if (ds->segments <= 0 && !dense) {
@@ -1433,7 +1447,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         }
         if (S_target < 1) S_target = 1;
         long long L = (steps + S_target - 1) / S_target;
-        const long long Lmin = (ds->segments > 0 || e->masked) ? 1 : 8;
+        const long long Lmin = (ds->segments > 0 || e->sequential) ? 1 : 8;
         if (L < Lmin) L = Lmin;
         if (L > steps) L = steps;
         e->L = L;
@@ -1583,11 +1597,12 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     // per-model tables
     const size_t NP = (size_t)e->d + (size_t)e->d * (e->d + 1) / 2;
     const size_t NP2 = (NP + 1) / 2;
-    std::vector<double> cst((size_t)e->n_models * vt->cst_size), tab((size_t)e->n_models * e->L * vt->tab_size),
+    const size_t Ltab = e->sequential ? 0 : (size_t)e->L;  // one segment: no gain tables, no segment aggregates
+    std::vector<double> cst((size_t)e->n_models * vt->cst_size), tab((size_t)e->n_models * Ltab * vt->tab_size + 1),
         agg((size_t)e->n_models * 2 * vt->agg_size), scan;
     for (int m = 0; m < e->n_models; ++m) {
         rxhip_status st = build_model_tables(e, m, ds, cst.data() + (size_t)m * vt->cst_size,
-                                             tab.data() + (size_t)m * e->L * vt->tab_size,
+                                             tab.data() + (size_t)m * Ltab * vt->tab_size,
                                              agg.data() + (size_t)m * 2 * vt->agg_size, e->uniform ? &scan : nullptr);
         if (st) return st;
     }
@@ -1598,6 +1613,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     ap.upload(&e->d_tab, tab.data(), sizeof(double) * tab.size());
     ap.upload(&e->d_agg, agg.data(), sizeof(double) * agg.size());
     if (ds->chain_model && !e->uniform) ap.upload(&e->d_chain_model, ds->chain_model, sizeof(int) * C);
+    if (ds->step_model) ap.upload(&e->d_step_model, ds->step_model, sizeof(int) * (size_t)(e->T + e->H));
     if (e->uniform && !scan.empty()) ap.upload(&e->d_scan, scan.data(), sizeof(double) * scan.size());
     ap.zeroed(&e->d_status, sizeof(int));
     ap.zeroed(&e->d_fe_part, sizeof(double) * (Sg + 1) * C);
@@ -2072,6 +2088,8 @@ rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowe
     if (st) return st;
     out->d = L.d; out->dy = L.dy; out->T = L.T; out->prior_through_transition = L.ptt;
     out->deterministic = L.deterministic;
+    out->n_models = L.n_models;
+    if (out->step_model) for (long long t = 0; t < L.T; ++t) out->step_model[t] = L.n_models > 1 ? L.step_model[t] : 0;
     if (out->c) std::memcpy(out->c, L.c.data(), L.c.size() * sizeof(double));
     auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
     cp(out->A, L.A); cp(out->B, L.B); cp(out->P, L.P); cp(out->Q, L.Q); cp(out->m0, L.m0); cp(out->V0, L.V0);
@@ -2175,9 +2193,19 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
     }
     rxhip_lgssm_desc d;
     std::memset(&d, 0, sizeof d);
-    d.d = L.d; d.dy = L.dy; d.T = L.T; d.n_chains = g->n_replicas > 0 ? g->n_replicas : 1; d.n_models = 1;
+    d.d = L.d; d.dy = L.dy; d.T = L.T; d.n_chains = g->n_replicas > 0 ? g->n_replicas : 1; d.n_models = L.n_models;
     d.prior_through_transition = L.ptt;
-    d.A = L.A.data(); d.B = L.B.data(); d.P = L.P.data(); d.Q = L.Q.data(); d.m0 = L.m0.data(); d.V0 = L.V0.data();
+    std::vector<double> m0s, V0s;
+    if (L.n_models > 1) {  // per-step constants: every model carries the (one) prior of the chain
+        for (int m = 0; m < L.n_models; ++m) {
+            m0s.insert(m0s.end(), L.m0.begin(), L.m0.end());
+            V0s.insert(V0s.end(), L.V0.begin(), L.V0.end());
+        }
+        d.step_model = L.step_model.data();
+    }
+    d.A = L.A.data(); d.B = L.B.data(); d.P = L.P.data(); d.Q = L.Q.data();
+    d.m0 = L.n_models > 1 ? m0s.data() : L.m0.data(); d.V0 = L.n_models > 1 ? V0s.data() : L.V0.data();
+    d.allow_missing = g->allow_missing;
     d.segments = segments; d.device = device; d.stream = stream;
     return rxhip_lgssm_create(&d, out);
 }
@@ -2340,6 +2368,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.status = e->d_status;
     p.filter = filter ? 1 : 0;
     p.masked = e->masked ? 1 : 0;
+    p.step_model = e->d_step_model;
     p.fe_scale = filter ? 1.0 / (double)e->T : 1.0;
     const bool fe = want_fe != 0;
     rxhip_status st;
@@ -2380,7 +2409,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                     if ((st = prof_end(e))) return st;
                 }
             }
-        } else if (e->S > 0) {
+        } else if (e->S > 0 && !e->sequential) {
             if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
             e->vt->seg_aggregate(p, e->h_cst0.data(), e->uniform, e->stream);
             if ((st = prof_end(e))) return st;
@@ -2404,7 +2433,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         if (e->H > 0 && !e->dense) {  // the unobserved tail: forward messages from the last filtered (= smoothed) belief
             PredictParams pp{};
             pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
-            pp.chain_model = e->d_chain_model; pp.status = e->d_status;
+            pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.status = e->d_status;
             e->vt->forecast(pp, e->stream);
         }
         if (fe) {
@@ -2557,7 +2586,7 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
     HIPCHK(e, hipMalloc(&tmp, sizeof(double) * rows * (dy + dy * dy)));
     PredictParams pp{};
     pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.y = e->d_y; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
-    pp.bq = e->d_bq; pp.chain_model = e->d_chain_model; pp.pmean = tmp; pp.pcov = tmp + rows * dy; pp.status = e->d_status;
+    pp.bq = e->d_bq; pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.pmean = tmp; pp.pcov = tmp + rows * dy; pp.status = e->d_status;
     e->vt->predict(pp, e->stream);
     rxhip_status st = RXHIP_OK;
     if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "prediction kernel launch failed");

@@ -298,6 +298,9 @@ mutable struct HIPGraphEngine
     state_ids::Vector{Int64}             # x[t] in time order (state-space families)
     width::Int                           # doubles per observation
     component_ids::Any                   # mixtures: (m = ids, p = ids, s = id, beta = Bool)
+    predictions::Dict{Int64, Any}        # data variable id -> RecentSubject of its prediction, created on first request
+    masked::Bool                         # the engine takes `missing` observations (rebuilt on the first one, see `fire!`)
+    options::Any                         # HIPInferenceOptions (segments, device) for that rebuild
 end
 
 """`randomvar` stand-in: a marginal stream the engine pushes into after every sweep."""
@@ -326,16 +329,27 @@ ReactiveMP.isdata(::HIPConstVariable) = false
 ReactiveMP.isconst(::HIPConstVariable) = true
 
 ReactiveMP.get_stream_of_marginals(v::HIPRandomVariable) = v.stream
-# predictions need the `*`_B(:out) / MvN_y(:out) messages the device schedule does not form (reactivemp_inference.jl:619-624)
-ReactiveMP.get_stream_of_predictions(v::Union{HIPRandomVariable, HIPDataVariable}) =
-    error("the HIP backend does not provide predictions; use options = (backend = :reactivemp,) for `predictvars`")
+# `obtain_prediction` (reactivemp_inference.jl:619-624): the message toward a data variable, MvN_y(:out) — formed on the device
+# by rxhip_get_predictions after the sweep, for the state-space families with d, dy ≤ 4
+function ReactiveMP.get_stream_of_predictions(v::HIPDataVariable)
+    g = v.graph[]
+    g === nothing && error("HIP data variable is not attached to an engine")
+    g.family === :lgssm || error("the HIP backend predicts the data variables of state-space graphs only; use options = (backend = :reactivemp,)")
+    return get!(() -> Rocket.RecentSubject(ReactiveMP.Marginal), g.predictions, v.id)
+end
+ReactiveMP.get_stream_of_predictions(v::HIPRandomVariable) = v.stream   # a random variable's prediction is its marginal
 
 function ReactiveMP.new_observation!(v::HIPDataVariable, value)
     g = v.graph[]
     g === nothing && error("HIP data variable is not attached to an engine")
-    ismissing(value) && error("the HIP backend has no schedule for missing observations")
     slot = g.data_slot[v.id]
-    vals = value isa Real ? (Float64(value),) : value
+    if ismissing(value)   # `missing` = NaN on the device: no message from this observation branch (static.md:98-123)
+        g.family === :lgssm || error("the HIP backend takes missing observations in state-space graphs only")
+        vals = ntuple(_ -> NaN, g.width)
+    else
+        vals = value isa Real ? (Float64(value),) : value
+        any(ismissing, vals) && (vals = ntuple(_ -> NaN, g.width))   # a partly missing vector is missing
+    end
     length(vals) == g.width || error("observation of length $(length(vals)), expected $(g.width)")
     @inbounds for (k, x) in enumerate(vals)
         g.staging[(slot - 1) * g.width + k] = x
@@ -348,6 +362,13 @@ end
 """One iteration of the loop at batch.jl:391-430: push the staged data, run ONE sweep / VMP iteration, publish."""
 function fire!(g::HIPGraphEngine)
     g.received = 0
+    if !g.masked && g.family === :lgssm && any(isnan, g.staging)
+        # the first `missing` observation: the time-parallel tables assume every step observed — rebuild the engine with the
+        # masked schedule (rxhip_lgssm_desc.allow_missing).  RXHIP_ERR_UNSUPPORTED (d or dy > 4) surfaces as the error it is.
+        RxHip.destroy!(g.engine)
+        g.engine = RxHip.create_from_tables(g.tables; segments = g.options.segments, device = g.options.device, allow_missing = true)
+        g.masked = true
+    end
     e = g.engine
     GC.@preserve g begin
         RxHip.check(e, ccall((:rxhip_set_data, RxHip.librxhip), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Csize_t, Int32),
@@ -359,6 +380,13 @@ function fire!(g::HIPGraphEngine)
         RxHip.run!(e; iterations = 1, free_energy = g.want_free_energy)   # trees: one sweep is the fixed point
     end
     publish_marginals!(g)
+    if !isempty(g.predictions)
+        mean, cov = RxHip.predictions(e)                         # dy × T, dy × dy × T
+        for (t, id) in enumerate(g.data_ids)
+            haskey(g.predictions, id) || continue
+            Rocket.next!(g.predictions[id], as_marginal(ReactiveMP.MvNormalMeanCovariance(mean[:, t, 1], Symmetric(cov[:, :, t, 1]))))
+        end
+    end
     if g.want_free_energy && g.free_energy !== nothing
         Rocket.next!(g.free_energy, RxHip.free_energy(e)[end])
     end
@@ -474,7 +502,7 @@ function GraphPPL.postprocess_plugin(plugin::HIPInferencePlugin, model::GraphPPL
     width = Int(tables.var_rows[lowered.data_ids[1] + 1])
     g = HIPGraphEngine(engine, tables, lowered.family, lowered.data_ids, Dict(id => k for (k, id) in enumerate(lowered.data_ids)),
                        zeros(Float64, width * length(lowered.data_ids)), 0, false, marginals, nothing, lowered.state_ids, width,
-                       component_ids(tables))
+                       component_ids(tables), Dict{Int64, Any}(), false, getoptions(plugin))
     gref[] = g
     GraphPPL.setextra!(GraphPPL.getcontext(model), HIPEngineKey, g)   # one handle per model; found again by `score`
     return nothing

@@ -45,6 +45,7 @@ struct LgssmDesc
     stream::Ptr{Cvoid}
     horizon::Int64
     allow_missing::Int32
+    step_model::Ptr{Int32}
 end
 
 mutable struct Engine
@@ -77,8 +78,10 @@ state-space family (src/inference/batch.jl:252, src/model/plugins/reactivemp_inf
 """
 function Engine(A, B, P, Q, m0, V0; T::Integer, n_chains::Integer = 1, prior_through_transition::Bool = false,
                 segments::Integer = 0, device::Integer = -1, chain_model::Union{Nothing, AbstractVector{<:Integer}} = nothing,
-                stream = nothing, horizon::Integer = 0, allow_missing::Bool = false)
-    # one model: plain matrices; several: vectors of matrices (A[m], B[m], …) with chain_model[c] ∈ 0:n_models-1
+                stream = nothing, horizon::Integer = 0, allow_missing::Bool = false,
+                step_model::Union{Nothing, AbstractVector{<:Integer}} = nothing)
+    # one model: plain matrices; several: vectors of matrices (A[m], B[m], …) with chain_model[c] ∈ 0:n_models-1 (a model per
+    # chain) or step_model[t] ∈ 0:n_models-1 (per-step constants `A[t] * x[t-1]`, shared by the chains; T + horizon entries)
     multi = A isa AbstractVector{<:AbstractMatrix}
     n_models = multi ? length(A) : 1
     cat(xs) = multi ? reduce(vcat, rowmajor.(xs)) : rowmajor(xs)
@@ -86,11 +89,13 @@ function Engine(A, B, P, Q, m0, V0; T::Integer, n_chains::Integer = 1, prior_thr
     a, b, p, q, m, v = cat(A), cat(B), cat(P), cat(Q), cat(m0), cat(V0)
     cm = chain_model === nothing ? Int32[] : Vector{Int32}(chain_model)
     (chain_model === nothing || length(cm) == n_chains) || throw(ArgumentError("chain_model needs one entry per chain"))
+    sm = step_model === nothing ? Int32[] : Vector{Int32}(step_model)
+    (step_model === nothing || length(sm) == T + horizon) || throw(ArgumentError("step_model needs one entry per time index"))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    st = GC.@preserve a b p q m v cm begin
+    st = GC.@preserve a b p q m v cm sm begin
         desc = LgssmDesc(d, dy, T, n_chains, n_models, prior_through_transition ? 1 : 0, pointer(a), pointer(b), pointer(p),
                          pointer(q), pointer(m), pointer(v), isempty(cm) ? Ptr{Int32}(C_NULL) : pointer(cm), segments, device,
-                         stream_handle(stream), horizon, allow_missing ? 1 : 0)
+                         stream_handle(stream), horizon, allow_missing ? 1 : 0, isempty(sm) ? Ptr{Int32}(C_NULL) : pointer(sm))
         ccall((:rxhip_lgssm_create, librxhip), Int32, (Ref{LgssmDesc}, Ref{Ptr{Cvoid}}), desc, h)
     end
     e = Engine(h[], d, dy, T + horizon, n_chains, 0)   # T counts the rows of the result arrays (observed + horizon)
@@ -304,6 +309,7 @@ struct GraphDesc
     var_init::Ptr{Int64}
     gh_points::Int32
     n_observations::Int64
+    allow_missing::Int32
 end
 
 # mirrors rxhip_lgssm_lowered
@@ -317,7 +323,9 @@ mutable struct LgssmLowered
     data_var::Ptr{Int64}
     deterministic::Int32
     c::Ptr{Float64}
-    LgssmLowered() = new(0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL)
+    n_models::Int32
+    step_model::Ptr{Int32}
+    LgssmLowered() = new(0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, 0, C_NULL)
 end
 
 """The engine's stream: `nothing` (engine-owned) or an AMDGPU.jl stream, whose raw `hipStream_t` is handed over so that the
@@ -325,22 +333,25 @@ host's own kernels / copies and the engine's launches are ordered on one queue (
 stream_handle(::Nothing) = Ptr{Cvoid}(C_NULL)
 stream_handle(s) = Base.unsafe_convert(Ptr{Cvoid}, s)     # AMDGPU.HIPStream -> hipStream_t
 
-with_desc(f, t, n_replicas::Integer, n_observations::Integer) = GC.@preserve t begin
+with_desc(f, t, n_replicas::Integer, n_observations::Integer; allow_missing::Bool = false) = GC.@preserve t begin
     f(GraphDesc(length(t.var_kind), pointer(t.var_kind), pointer(t.var_rows), pointer(t.var_cols), pointer(t.var_const),
                 length(t.factor_type), pointer(t.factor_type), pointer(t.factor_iface), pointer(t.const_pool), length(t.const_pool),
-                n_replicas, pointer(t.factor_iface_ptr), pointer(t.var_init_family), pointer(t.var_init), t.gh_points, n_observations))
+                n_replicas, pointer(t.factor_iface_ptr), pointer(t.var_init_family), pointer(t.var_init), t.gh_points, n_observations,
+                allow_missing ? 1 : 0))
 end
 
 lowering_error() = unsafe_string(ccall((:rxhip_lowering_error, librxhip), Cstring, ()))
 
 """
-    create_from_tables(tables; n_replicas = 1, n_observations = 0, segments = 0, device = -1, stream = nothing)
+    create_from_tables(tables; n_replicas = 1, n_observations = 0, segments = 0, device = -1, stream = nothing, allow_missing = false)
 
-`rxhip_create`: lowers the graph tables and builds the engine of the family the node types select.  Throws
+`rxhip_create`: lowers the graph tables and builds the engine of the family the node types select (`allow_missing`: a
+state-space engine that takes `missing` = NaN observations anywhere in the data, rxhip_lgssm_desc.allow_missing).  Throws
 `RxHipError(RXHIP_ERR_UNSUPPORTED, why)` for graphs without a device schedule (the plugin then uses ReactiveMP)."""
-function create_from_tables(t; n_replicas::Integer = 1, n_observations::Integer = 0, segments::Integer = 0, device::Integer = -1, stream = nothing)
+function create_from_tables(t; n_replicas::Integer = 1, n_observations::Integer = 0, segments::Integer = 0, device::Integer = -1, stream = nothing,
+                            allow_missing::Bool = false)
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    st = with_desc(t, n_replicas, n_observations) do desc
+    st = with_desc(t, n_replicas, n_observations; allow_missing = allow_missing) do desc
         ccall((:rxhip_create, librxhip), Int32, (Ref{GraphDesc}, Int32, Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), desc, segments, device,
               stream_handle(stream), h)
     end

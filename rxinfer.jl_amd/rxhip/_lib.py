@@ -26,6 +26,7 @@ class LgssmDesc(ctypes.Structure):
         ("A", c_double_p), ("B", c_double_p), ("P", c_double_p), ("Q", c_double_p), ("m0", c_double_p),
         ("V0", c_double_p), ("chain_model", c_int32_p), ("segments", ctypes.c_int32), ("device", ctypes.c_int32),
         ("stream", ctypes.c_void_p), ("horizon", ctypes.c_int64), ("allow_missing", ctypes.c_int32),
+        ("step_model", c_int32_p),
     ]
 
 
@@ -44,14 +45,14 @@ class GraphDesc(ctypes.Structure):
                 ("n_replicas", ctypes.c_int64),
                 # optional extensions (zero = 3-interface Gaussian graphs)
                 ("factor_iface_ptr", c_int64_p), ("var_init_family", c_int32_p), ("var_init", c_int64_p),
-                ("gh_points", ctypes.c_int32), ("n_observations", ctypes.c_int64)]
+                ("gh_points", ctypes.c_int32), ("n_observations", ctypes.c_int64), ("allow_missing", ctypes.c_int32)]
 
 
 class LgssmLowered(ctypes.Structure):
     _fields_ = [("d", ctypes.c_int32), ("dy", ctypes.c_int32), ("T", ctypes.c_int64),
                 ("prior_through_transition", ctypes.c_int32), ("A", c_double_p), ("B", c_double_p), ("P", c_double_p),
                 ("Q", c_double_p), ("m0", c_double_p), ("V0", c_double_p), ("state_var", c_int64_p), ("data_var", c_int64_p),
-                ("deterministic", ctypes.c_int32), ("c", c_double_p)]
+                ("deterministic", ctypes.c_int32), ("c", c_double_p), ("n_models", ctypes.c_int32), ("step_model", c_int32_p)]
 
 
 class GmmLowered(ctypes.Structure):

@@ -33,11 +33,30 @@ class LinearGaussianSSM:
     prior_mean: np.ndarray
     prior_cov: np.ndarray
     prior_through_transition: bool = False
+    step_model: Optional[np.ndarray] = None   # time-varying constants: A, B, P, Q are [n_models, …], step_model[t] picks
 
 
 def linear_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transition=False):
     f = lambda a: np.asarray(a, dtype=np.float64)
     return LinearGaussianSSM(f(A), f(B), f(P), f(Q), f(prior_mean), f(prior_cov), bool(prior_through_transition))
+
+
+def time_varying_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transition=False):
+    """The state-space model with per-step constants, as written in a @model loop over arrays of matrices:
+        x[t] ~ MvNormal(μ = A[t] * x[t-1], Σ = P[t]);  y[t] ~ MvNormal(μ = B[t] * x[t], Σ = Q[t]).
+    Any of A, B, P, Q may carry a leading time axis [T, …] (the others are held constant); equal steps share one model."""
+    f = lambda a: np.asarray(a, dtype=np.float64)
+    A, B, P, Q = f(A), f(B), f(P), f(Q)
+    lens = {a.shape[0] for a in (A, B, P, Q) if a.ndim == 3}
+    if len(lens) != 1:
+        raise ValueError("time-varying constants: give at least one of A, B, P, Q as [T, …], all with the same T")
+    T = lens.pop()
+    full = [a if a.ndim == 3 else np.broadcast_to(a, (T,) + a.shape) for a in (A, B, P, Q)]
+    keys = np.concatenate([a.reshape(T, -1) for a in full], axis=1)
+    _, first, step_model = np.unique(keys, axis=0, return_index=True, return_inverse=True)
+    A, B, P, Q = (np.ascontiguousarray(a[first]) for a in full)
+    return LinearGaussianSSM(A, B, P, Q, f(prior_mean), f(prior_cov), bool(prior_through_transition),
+                             np.ascontiguousarray(step_model.ravel(), dtype=np.int32))
 
 
 @dataclass
@@ -375,6 +394,8 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
     horizon, allow_missing = 0, False
     nans = np.isnan(y)
     if nans.any():
+        if not predictvars:   # data with `missing` values is predicted without being asked (src/inference/batch.jl:221-227)
+            predictvars = ("y",)
         # `missing` observations (docs/src/manuals/inference/static.md:98-123).  A tail that no chain observed is a forecast
         # horizon and keeps the time-parallel schedule; anything else runs the per-chain masked schedule.
         missing = np.all(nans, axis=(0, 2))
@@ -386,9 +407,15 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
             y, T = y[:, :T - horizon], T - horizon
     eng = None
     try:
-        eng = LGSSMEngine(model.A, model.B, model.P, model.Q, model.prior_mean, model.prior_cov, T=T, n_chains=C,
+        m0, V0, step_model = model.prior_mean, model.prior_cov, model.step_model
+        if step_model is not None:
+            if step_model.shape[0] != T + horizon:
+                raise ValueError(f"time-varying model has {step_model.shape[0]} steps, the data {T + horizon}")
+            M = model.A.shape[0]
+            m0, V0 = np.broadcast_to(m0, (M,) + m0.shape[-1:]), np.broadcast_to(V0, (M,) + V0.shape[-2:])
+        eng = LGSSMEngine(model.A, model.B, model.P, model.Q, m0, V0, T=T, n_chains=C,
                           prior_through_transition=model.prior_through_transition, horizon=horizon,
-                          allow_missing=allow_missing,
+                          allow_missing=allow_missing, step_model=step_model,
                           segments=int(options.get("segments", 0)), device=int(options.get("device", -1)))
         eng.set_data(y, layout="chain_time")
         eng.run(iterations=iters, free_energy=free_energy)

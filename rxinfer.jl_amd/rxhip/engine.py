@@ -27,7 +27,7 @@ class LGSSMEngine:
     """
 
     def __init__(self, A, B, P, Q, m0, V0, T, n_chains=1, chain_model=None, prior_through_transition=False,
-                 segments=0, device=-1, stream=None, horizon=0, allow_missing=False):
+                 segments=0, device=-1, stream=None, horizon=0, allow_missing=False, step_model=None):
         L = _lib.lib()
         A = _c(A)
         B = _c(B)
@@ -57,6 +57,12 @@ class LGSSMEngine:
         desc.stream = ctypes.c_void_p(stream) if stream else None
         desc.horizon = self.horizon
         desc.allow_missing = int(bool(allow_missing))
+        if step_model is not None:  # time-varying constants: the model of every time index
+            sm = np.ascontiguousarray(step_model, dtype=np.int32)
+            if sm.shape != (self.T + self.horizon,):
+                raise ValueError("step_model must have one entry per time index (T + horizon)")
+            self._keep.append(sm)
+            desc.step_model = sm.ctypes.data_as(_lib.c_int32_p)
         self._h = ctypes.c_void_p()
         st = L.rxhip_lgssm_create(ctypes.byref(desc), ctypes.byref(self._h))
         if st != _lib.OK:

@@ -135,7 +135,7 @@ class GraphBuilder:
         """out := A * x  ->  typeof(*) node with an anonymous output variable"""
         self.ftype.append(_lib.NODE_MULTIPLY); self.fiface.append((out, A, x))
 
-    def tables(self, n_replicas=1, permute=None, n_observations=0):
+    def tables(self, n_replicas=1, permute=None, n_observations=0, allow_missing=False):
         ft = np.asarray(self.ftype, dtype=np.int32)
         order = np.arange(len(ft)) if permute is None else np.asarray(permute)  # node order must not matter to the lowering
         ft = ft[order]
@@ -170,12 +170,14 @@ class GraphBuilder:
             g.var_init = arrs["ioff"].ctypes.data_as(_lib.c_int64_p)
         g.gh_points = int(self.gh_points)
         g.n_observations = int(n_observations)
+        g.allow_missing = int(bool(allow_missing))
         g._keep = arrs  # the descriptor points into these arrays
         return g, arrs
 
 
-def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=None):
-    """The graph GraphPPL builds for the benchmark notebook's model (cell 4) / mlgssm_test.jl:9-17."""
+def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=None, P_of_t=None, B_of_t=None, Q_of_t=None):
+    """The graph GraphPPL builds for the benchmark notebook's model (cell 4) / mlgssm_test.jl:9-17.  X_of_t(t): the constant
+    of time index t when the @model loop indexes an array of matrices (`A[t] * x[t-1]`, `Σ = P[t]`, …)."""
     A, B = np.asarray(A, float), np.asarray(B, float)
     d, dy = A.shape[0], B.shape[0]
     gb = GraphBuilder()
@@ -187,12 +189,12 @@ def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=No
             a = gb.randomvar(d)
             gb.multiply(a, gb.constvar(A if A_of_t is None else A_of_t(t)), x)
             xn = gb.randomvar(d)
-            gb.mvnormal_mean_cov(xn, a, gb.constvar(P))
+            gb.mvnormal_mean_cov(xn, a, gb.constvar(P if P_of_t is None else P_of_t(t)))
             x = xn
         b = gb.randomvar(dy)
-        gb.multiply(b, gb.constvar(B), x)
+        gb.multiply(b, gb.constvar(B if B_of_t is None else B_of_t(t)), x)
         y = gb.datavar(dy)
-        gb.mvnormal_mean_cov(y, b, gb.constvar(Q))
+        gb.mvnormal_mean_cov(y, b, gb.constvar(Q if Q_of_t is None else Q_of_t(t)))
         xs.append(x); ys.append(y)
     return gb, xs, ys
 
@@ -251,19 +253,23 @@ def lower_lgssm(g):
     st = L.rxhip_graph_lower_lgssm(ctypes.byref(g), ctypes.byref(out))
     if st != _lib.OK:
         raise RxHipError(st, L.rxhip_lowering_error().decode())
-    d, dy, T = out.d, out.dy, out.T
-    bufs = dict(A=np.empty((d, d)), B=np.empty((dy, d)), P=np.empty((d, d)), Q=np.empty((dy, dy)), m0=np.empty(d), V0=np.empty((d, d)),
-                c=np.empty(d))
-    sv, dv = np.empty(T, dtype=np.int64), np.empty(T, dtype=np.int64)
+    d, dy, T, M = out.d, out.dy, out.T, out.n_models
+    bufs = dict(A=np.empty((M, d, d)), B=np.empty((M, dy, d)), P=np.empty((M, d, d)), Q=np.empty((M, dy, dy)), m0=np.empty(d),
+                V0=np.empty((d, d)), c=np.empty(d))
+    sv, dv, sm = np.empty(T, dtype=np.int64), np.empty(T, dtype=np.int64), np.empty(T, dtype=np.int32)
     for k, v in bufs.items():
         setattr(out, k, v.ctypes.data_as(_lib.c_double_p))
     out.state_var = sv.ctypes.data_as(_lib.c_int64_p)
     out.data_var = dv.ctypes.data_as(_lib.c_int64_p)
+    out.step_model = sm.ctypes.data_as(_lib.c_int32_p)
     st = L.rxhip_graph_lower_lgssm(ctypes.byref(g), ctypes.byref(out))
     if st != _lib.OK:
         raise RxHipError(st, L.rxhip_lowering_error().decode())
+    if M == 1:  # time-invariant: plain matrices, as before
+        for k in "ABPQ":
+            bufs[k] = bufs[k][0]
     return dict(d=d, dy=dy, T=T, prior_through_transition=bool(out.prior_through_transition), deterministic=bool(out.deterministic),
-                state_var=sv, data_var=dv, **bufs)
+                state_var=sv, data_var=dv, n_models=M, step_model=sm if M > 1 else None, **bufs)
 
 
 def create_engine_from_graph(g, segments=0, device=-1, stream=None):
@@ -285,7 +291,8 @@ def create_engine_from_graph(g, segments=0, device=-1, stream=None):
         eng = DriftChainEngine.__new__(DriftChainEngine)
     else:
         eng = LGSSMEngine.__new__(LGSSMEngine)
-    eng._h, eng.d, eng.dy, eng.T, eng.n_chains, eng.n_models = h, low["d"], low["dy"], low["T"], int(g.n_replicas or 1), 1
+    eng._h, eng.d, eng.dy, eng.T, eng.n_chains, eng.n_models = h, low["d"], low["dy"], low["T"], int(g.n_replicas or 1), low["n_models"]
+    eng.horizon = 0
     eng._keep, eng._data_ref, eng._iters = [], None, 0
     return eng
 

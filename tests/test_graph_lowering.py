@@ -41,12 +41,6 @@ def test_single_observation_graph():
 
 def test_unsupported_graphs_are_rejected():
     mdl = workloads.c1_model()
-    # time-varying transition matrix
-    gb, xs, ys = graph.lgssm_graph(5, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"],
-                                   A_of_t=lambda t: mdl["A"] * (1.0 + 0.01 * (t == 3)))
-    with pytest.raises(rxhip.RxHipError) as ei:
-        graph.lower_lgssm(gb.tables()[0])
-    assert ei.value.status == _lib.ERR_UNSUPPORTED
     # a branching graph: two transitions out of one state
     gb, xs, ys = graph.lgssm_graph(3, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
     a = gb.randomvar(4); gb.multiply(a, gb.constvar(mdl["A"]), xs[0]); xn = gb.randomvar(4); gb.mvnormal_mean_cov(xn, a, gb.constvar(mdl["P"]))
@@ -315,3 +309,27 @@ def test_malformed_constant_tables_are_bad_arguments():
     with pytest.raises(rxhip.RxHipError) as ei:
         graph.lower_gmm(g)
     assert ei.value.status == _lib.ERR_BADARG
+
+
+def test_per_step_constants_are_grouped_into_models():
+    """`A[t] * x[t-1]`, `Σ = Q[t]` in the @model loop: equal constants share a model, whatever variable carries them."""
+    mdl = workloads.c1_model()
+    T = 9
+    A_of_t = lambda t: mdl["A"] * (1.0 + 0.01 * (t % 3 == 0))          # two transition regimes
+    Q_of_t = lambda t: mdl["Q"] * (2.0 if t >= 6 else 1.0)             # the noise doubles at t = 6
+    for ptt in (False, True):
+        gb, xs, ys = graph.lgssm_graph(T, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], prior_through_transition=ptt,
+                                       A_of_t=A_of_t, Q_of_t=Q_of_t)
+        perm = np.random.default_rng(0).permutation(len(gb.ftype))
+        low = graph.lower_lgssm(gb.tables(permute=perm)[0])
+        sm = low["step_model"]
+        assert low["T"] == T and low["n_models"] == len(set(sm)) and low["A"].shape == (low["n_models"], 4, 4)
+        for t in range(T):
+            if t > 0 or ptt:   # without a transition into the first state its A is never used (the next step's is stored)
+                assert np.array_equal(low["A"][sm[t]], A_of_t(t))
+            assert np.array_equal(low["Q"][sm[t]], Q_of_t(t)) and np.array_equal(low["B"][sm[t]], mdl["B"])
+        assert low["n_models"] == (4 if ptt else 4)
+    # time-invariant graphs keep plain matrices
+    gb, xs, ys = graph.lgssm_graph(T, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    low = graph.lower_lgssm(gb.tables()[0])
+    assert low["n_models"] == 1 and low["step_model"] is None and low["A"].shape == (4, 4)
