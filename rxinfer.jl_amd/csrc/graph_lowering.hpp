@@ -178,7 +178,7 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         return badarg("prior constants have the wrong shape");
     // a branch out of state x: the Gaussian node it feeds and the constant matrix in between (-1: identity)
     struct Branch { long long gauss, matrix; };
-    long long vA = -2, vP = -1, vB = -2, vQ = -1, vC = -1;  // -2: not seen yet, -1: identity
+    long long vA = -2, vB = -2, vC = -1;  // -2: not seen yet, -1: identity
     constexpr long long NONE = -3;                           // no transition into this time index (t = 1 of a chain whose prior sits on x[1])
     std::vector<long long> sA, sP, sB, sQ;                   // per time index: the constant variables of its transition / observation
     int n_noisy = 0, n_det = 0;
@@ -209,7 +209,7 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         if (add >= 0 && tr >= 0) return unsupported("state with two transitions: not a chain");
         if (obs >= 0) {
             const long long q = iface(g, obs, 2);
-            if (vB == -2) { vB = obs_m; vQ = q; }
+            if (vB == -2) vB = obs_m;
             sB.push_back(obs_m);
             sQ.push_back(q);
             L.state_var.push_back(x);
@@ -221,7 +221,7 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         first = false;
         if (tr >= 0) {
             const long long pv = iface(g, tr, 2);
-            if (vA == -2) { vA = tr_m; vP = pv; }
+            if (vA == -2) vA = tr_m;
             sA.resize(L.state_var.size() + 1, NONE);  // the transition INTO the next observed state
             sP.resize(L.state_var.size() + 1, NONE);
             sA.back() = tr_m;

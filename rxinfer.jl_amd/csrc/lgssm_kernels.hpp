@@ -87,6 +87,38 @@ struct TabLayout {
     static constexpr int U = D * DY;
     static constexpr int SIZE = 2 * D * DY;
 };
+// Shared-model smoothing runs make ONE pass over the observations (k_forward0): per position in a segment the gains of
+// TabLayout plus the inverse innovation covariance of the known-start filter (evidence), and per TIME INDEX the map M_t that
+// turns the known-start quantities into the true filtered mean up to the term in the segment's start mean (see k_forward0).
+template <int D, int DY>
+struct F0Layout {
+    static constexpr int K = 0;                   // [D][DY]
+    static constexpr int U = D * DY;              // [D][DY]
+    static constexpr int SI = 2 * D * DY;         // [NSY]  (S⁰_i)⁻¹ packed
+    static constexpr int SIZE = ((SI + DY * (DY + 1) / 2 + 1) / 2) * 2;
+};
+template <int D>
+struct TimeTab {
+    static constexpr int MT = ((D * D + 1) / 2) * 2;  // a row of mtab / ntab: [D][D], padded to whole 16-byte pieces
+};
+// per position in a segment, data-independent (input of k_time_tables): Π_i, J_i, C_i
+template <int D>
+struct PosLayout {
+    static constexpr int NS = D * (D + 1) / 2;
+    static constexpr int PI = 0;
+    static constexpr int J = D * D;
+    static constexpr int C = J + NS;
+    static constexpr int SIZE = C + NS;
+};
+// per segment, data-independent: the quadratic form of the segment's evidence in (m_s, η_s)  (k_fe_seg)
+template <int D>
+struct FeSegLayout {
+    static constexpr int NS = D * (D + 1) / 2;
+    static constexpr int A1 = 0;          // [NS]   J W V_s⁻¹ = (V_s + J⁻¹)⁻¹
+    static constexpr int A2 = NS;         // [D][D] W V_s⁻¹
+    static constexpr int W = A2 + D * D;  // [NS]   (V_s⁻¹ + J)⁻¹
+    static constexpr int SIZE = W + NS;
+};
 // Per-model, per-length matrix part of a segment element (phase 2)
 template <int D>
 struct AggLayout {
@@ -146,6 +178,12 @@ struct Params {
     double fe_scale;   // 1 (smoothing: Bethe free energy of the chain) or 1/T (filtering: mean over observations)
     int* status;
     int masked;        // 1: NaN observations are `missing` (per-chain records, one segment: rxhip_lgssm_desc.allow_missing)
+    // shared-model smoothing, one pass over the observations (null / 0: the two-pass schedule of a filtering run)
+    const double* ftab;     // [L][F0Layout::SIZE]
+    const double* mtab;     // [T][TimeTab::MT]   M_t
+    const double* ntab;     // [T][TimeTab::MT]   N_t = M_t V_s⁻¹
+    const double* fseg;     // [S][FeSegLayout::SIZE]
+    double fe_const;        // Σ_segments of the data-independent evidence terms
     const int* step_model;  // [T] or null: the model of time index t (transition INTO x[t] and observation of y[t]);
                             // one segment, per-chain records (rxhip_lgssm_desc.step_model)
 };

@@ -38,6 +38,10 @@ struct LgssmVtbl {
     int tK, tU;
     int aPI, aC, aJ, aCI, aX, aJJ;
     int scan_size, sM1, sM2, sVB, sN1, sN2, sLB;
+    int f0_size, fK, fU, fSI, pos_size, pPI, pJ, pC, fs_size, fsA1, fsA2, fsW, mt_row;  // one-pass schedule (k_forward0)
+    void (*forward0)(const Params&, const double*, bool, hipStream_t);
+    void (*time_tables)(const TimeTabParams&, hipStream_t);
+    void (*fe_seg)(const Params&, hipStream_t);
     void (*boundary_scan_tab)(const Params&, const double*, bool, hipStream_t);
     void (*seg_aggregate)(const Params&, const double*, bool, hipStream_t);
     void (*boundary_scan)(const Params&, const double*, bool, bool, hipStream_t);
@@ -116,6 +120,17 @@ struct Launch {
         if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
         else hipLaunchKernelGGL((k_backward<D, DY, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
     }
+    static void forward0(const Params& p, const double* hc, bool fe, hipStream_t s) {
+        const long long total = p.n_chains * (long long)p.S;
+        if (fe) hipLaunchKernelGGL((k_forward0<D, DY, true>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
+        else hipLaunchKernelGGL((k_forward0<D, DY, false>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
+    }
+    static void time_tables(const TimeTabParams& q, hipStream_t s) {
+        if (q.T > 1) hipLaunchKernelGGL((k_time_tables<D>), dim3(nblk(q.T - 1, 64)), dim3(64), 0, s, q);
+    }
+    static void fe_seg(const Params& p, hipStream_t s) {
+        hipLaunchKernelGGL((k_fe_seg<D>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
+    }
     static void forecast(const PredictParams& p, hipStream_t s) {
         hipLaunchKernelGGL((k_forecast<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
     }
@@ -136,6 +151,15 @@ struct Launch {
         v.aPI = AL::PI; v.aC = AL::C; v.aJ = AL::J; v.aCI = AL::CI; v.aX = AL::X; v.aJJ = AL::JJ;
         using SL = ScanLayout<D>;
         v.scan_size = SL::SIZE; v.sM1 = SL::M1; v.sM2 = SL::M2; v.sVB = SL::VB; v.sN1 = SL::N1; v.sN2 = SL::N2; v.sLB = SL::LB;
+        using FL = F0Layout<D, DY>;
+        using PL = PosLayout<D>;
+        using FS = FeSegLayout<D>;
+        v.f0_size = FL::SIZE; v.fK = FL::K; v.fU = FL::U; v.fSI = FL::SI;
+        v.pos_size = PL::SIZE; v.pPI = PL::PI; v.pJ = PL::J; v.pC = PL::C;
+        v.fs_size = FS::SIZE; v.fsA1 = FS::A1; v.fsA2 = FS::A2; v.fsW = FS::W; v.mt_row = TimeTab<D>::MT;
+        v.forward0 = &Launch::forward0;
+        v.time_tables = &Launch::time_tables;
+        v.fe_seg = &Launch::fe_seg;
         v.boundary_scan_tab = &Launch::boundary_scan_tab;
         v.seg_aggregate = &Launch::seg_aggregate;
         v.boundary_scan = &Launch::boundary_scan;
@@ -259,6 +283,10 @@ struct rxhip_engine {
     int scan_sg = 1, scan_ng = 1;  // two-level boundary scan of the dense path: group size, groups
     int agg_oc = 1, agg_kc = 1;    // dense aggregation product: offsets per K-chunk, K-chunks
     double* d_aggpart = nullptr;   // [chain][agg_kc][S][2·dpad] partial sums of kd_agg_gemm
+    // shared-model smoothing in one pass over the observations (k_forward0): tables, see lgssm_kernels.hpp
+    bool fused = false;
+    double *d_ftab = nullptr, *d_mtab = nullptr, *d_ntab = nullptr, *d_pos = nullptr, *d_fseg = nullptr;
+    double fe_const = 0.0;
     bool sequential = false;  // one segment per chain on per-chain records (missing observations, time-varying constants)
     int* d_step_model = nullptr;
     bool masked = false;      // NaN observations are `missing` (rxhip_lgssm_desc.allow_missing): per-chain records, one segment
@@ -629,6 +657,8 @@ static void pack_sym(int n, const double* A, double* out) {
 
 // Build constant block, gain tables and element matrices of one model.
 struct HostAgg { std::vector<double> Pi, C, J, Ci, X, JJ; };
+// host part of the one-pass schedule's tables (F0Layout, PosLayout, FeSegLayout) and the data-independent evidence terms
+struct FusedTables { std::vector<double> ftab, pos, fseg; double fe_const = 0.0; };
 
 // data-independent part of the boundary scan (see ScanLayout / DenseParams::scanm): per segment the maps that
 // carry the means / weighted means across it, the covariance at its start and the backward precision at its end
@@ -677,7 +707,7 @@ static bool build_scan_matrices(int d, int S, const HostAgg& a0, const HostAgg& 
 }
 
 static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgssm_desc* ds, double* cst,
-                                       double* tab, double* agg, std::vector<double>* scan_out) {
+                                       double* tab, double* agg, std::vector<double>* scan_out, FusedTables* fused = nullptr) {
     const LgssmVtbl& v = *e->vt;
     const int d = e->d, dy = e->dy;
     const double* A = ds->A + (size_t)mdl * d * d;
@@ -731,6 +761,12 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
     for (int i = 0; i < d; ++i) Pi[i * d + i] = 1.0;
     std::memset(agg, 0, sizeof(double) * 2 * v.agg_size);
     HostAgg hagg[2];
+    std::vector<double> ld_prefix;  // Σ_{k ≤ i} logdet S⁰_k
+    if (fused) {
+        fused->ftab.assign((size_t)L * v.f0_size, 0.0);
+        fused->pos.assign((size_t)L * v.pos_size, 0.0);
+        ld_prefix.assign((size_t)L + 1, 0.0);
+    }
     for (long long i = 1; i <= L; ++i) {
         host::mm(d, d, d, A, V.data(), t1.data());
         host::mmT(d, d, d, t1.data(), A, Vp.data());
@@ -738,7 +774,8 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
         host::mm(dy, d, d, B, Vp.data(), t1.data());   // B Vp (dy×d)
         host::mmT(dy, d, dy, t1.data(), B, S.data());  // B Vp B'
         for (int q = 0; q < dy * dy; ++q) S[q] += Q[q];
-        if (!host::chol_inv(dy, S.data(), Si.data(), nullptr))
+        double ldS = 0.0;
+        if (!host::chol_inv(dy, S.data(), Si.data(), &ldS))
             return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: innovation covariance not positive definite", mdl);
         host::mTm(dy, d, dy, t1.data(), Si.data(), K.data());       // K = (B Vp)' Si  (d×dy)
         host::mm(dy, d, d, HF.data(), Pi.data(), HFPi.data());      // HF Π_{i-1}
@@ -761,6 +798,19 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
         for (int q = 0; q < d * dy; ++q) {
             te[v.tK + q] = K[q];
             te[v.tU + q] = U[q];
+        }
+        if (fused) {
+            double* fe = fused->ftab.data() + (size_t)(i - 1) * v.f0_size;
+            for (int q = 0; q < d * dy; ++q) {
+                fe[v.fK + q] = K[q];
+                fe[v.fU + q] = U[q];
+            }
+            host::pack_sym(dy, Si.data(), fe + v.fSI);
+            double* pe = fused->pos.data() + (size_t)(i - 1) * v.pos_size;
+            for (int q = 0; q < d * d; ++q) pe[v.pPI + q] = Pi[q];
+            host::pack_sym(d, J.data(), pe + v.pJ);
+            host::pack_sym(d, V.data(), pe + v.pC);
+            ld_prefix[(size_t)i] = ld_prefix[(size_t)i - 1] + ldS;
         }
         for (int which = 0; which < 2; ++which) {
             const long long want = which == 0 ? L : e->Llast;
@@ -803,6 +853,28 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
             for (int q = 0; q < d * d; ++q) { t[v.sM1 + q] = M1[s][q]; t[v.sM2 + q] = M2[s][q]; t[v.sN1 + q] = N1[s][q]; t[v.sN2 + q] = N2[s][q]; }
             host::pack_sym(d, Vb[s].data(), t + v.sVB);
             host::pack_sym(d, Lb[s].data(), t + v.sLB);
+        }
+        if (fused) {
+            // per segment: −2 log p(y_seg | y_before) = [len·dy·log 2π + Σ logdet S⁰_i + logdet(I + V_s J)] + q0
+            //                                           + m_s'A1 m_s − 2 η'A2 m_s − η'W η
+            fused->fseg.assign((size_t)e->S * v.fs_size, 0.0);
+            fused->fe_const = 0.0;
+            std::vector<double> Vi(d * d), W(d * d), A2(d * d), A1(d * d), tt(d * d);
+            for (int s = 0; s < e->S; ++s) {
+                const HostAgg& g = (s == e->S - 1) ? hagg[1] : hagg[0];
+                const long long len = (s == e->S - 1) ? e->Llast : L;
+                double ldV = 0.0, ldT = 0.0;
+                if (!host::chol_inv(d, Vb[s].data(), Vi.data(), &ldV)) return fail(e, RXHIP_ERR_NOT_POSDEF, "segment start covariance not positive definite");
+                for (int q = 0; q < d * d; ++q) tt[q] = Vi[q] + g.J[q];
+                if (!host::chol_inv(d, tt.data(), W.data(), &ldT)) return fail(e, RXHIP_ERR_NOT_POSDEF, "segment precision not positive definite");
+                host::mm(d, d, d, W.data(), Vi.data(), A2.data());
+                host::mm(d, d, d, g.J.data(), A2.data(), A1.data());
+                double* f = fused->fseg.data() + (size_t)s * v.fs_size;
+                host::pack_sym(d, A1.data(), f + v.fsA1);
+                for (int q = 0; q < d * d; ++q) f[v.fsA2 + q] = A2[q];
+                host::pack_sym(d, W.data(), f + v.fsW);
+                fused->fe_const += (double)len * dy * 1.8378770664093454835606594728112 + ld_prefix[(size_t)len] + ldV + ldT;
+            }
         }
     }
     return RXHIP_OK;
@@ -1600,12 +1672,17 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     const size_t Ltab = e->sequential ? 0 : (size_t)e->L;  // one segment: no gain tables, no segment aggregates
     std::vector<double> cst((size_t)e->n_models * vt->cst_size), tab((size_t)e->n_models * Ltab * vt->tab_size + 1),
         agg((size_t)e->n_models * 2 * vt->agg_size), scan;
+    FusedTables ft;
+    const bool want_fused = e->uniform && e->S > 0;
     for (int m = 0; m < e->n_models; ++m) {
         rxhip_status st = build_model_tables(e, m, ds, cst.data() + (size_t)m * vt->cst_size,
                                              tab.data() + (size_t)m * Ltab * vt->tab_size,
-                                             agg.data() + (size_t)m * 2 * vt->agg_size, e->uniform ? &scan : nullptr);
+                                             agg.data() + (size_t)m * 2 * vt->agg_size, e->uniform ? &scan : nullptr,
+                                             want_fused ? &ft : nullptr);
         if (st) return st;
     }
+    e->fused = want_fused && !scan.empty();
+    e->fe_const = ft.fe_const;
     e->h_cst0.assign(cst.begin(), cst.begin() + vt->cst_size);
     const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1);
     ArenaPlan ap;
@@ -1615,6 +1692,13 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     if (ds->chain_model && !e->uniform) ap.upload(&e->d_chain_model, ds->chain_model, sizeof(int) * C);
     if (ds->step_model) ap.upload(&e->d_step_model, ds->step_model, sizeof(int) * (size_t)(e->T + e->H));
     if (e->uniform && !scan.empty()) ap.upload(&e->d_scan, scan.data(), sizeof(double) * scan.size());
+    if (e->fused) {
+        ap.upload(&e->d_ftab, ft.ftab.data(), sizeof(double) * ft.ftab.size());
+        ap.upload(&e->d_pos, ft.pos.data(), sizeof(double) * ft.pos.size());
+        ap.upload(&e->d_fseg, ft.fseg.data(), sizeof(double) * ft.fseg.size());
+        ap.plain(&e->d_mtab, sizeof(double) * T * vt->mt_row);
+        ap.plain(&e->d_ntab, sizeof(double) * T * vt->mt_row);
+    }
     ap.zeroed(&e->d_status, sizeof(int));
     ap.zeroed(&e->d_fe_part, sizeof(double) * (Sg + 1) * C);
     e->fe_total_cap = 16;
@@ -1638,7 +1722,21 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_y, sizeof(double) * T * C * e->dy);
         e->own_y = true;
     }
-    return arena_commit(e, ap);
+    if (rxhip_status st = arena_commit(e, ap)) return st;
+    if (e->fused) {  // the per-time-index maps of the one-pass schedule: data-independent, once per engine
+        TimeTabParams q{};
+        q.T = e->T; q.L = e->L; q.pos = e->d_pos; q.scan = e->d_scan; q.mtab = e->d_mtab; q.ntab = e->d_ntab; q.vtab = e->d_vtab;
+        q.status = e->d_status;
+        HIPCHK(e, hipMemsetAsync(e->d_mtab, 0, sizeof(double) * vt->mt_row, e->stream));  // row 0 is never used
+        HIPCHK(e, hipMemsetAsync(e->d_ntab, 0, sizeof(double) * vt->mt_row, e->stream));
+        vt->time_tables(q, e->stream);
+        HIPCHK(e, hipGetLastError());
+        int hst = 0;
+        HIPCHK(e, hipMemcpyAsync(&hst, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        if (hst) return fail(e, RXHIP_ERR_NOT_POSDEF, "a filtered covariance of the model is not positive definite");
+    }
+    return RXHIP_OK;
 }
 
 
@@ -2369,6 +2467,9 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.filter = filter ? 1 : 0;
     p.masked = e->masked ? 1 : 0;
     p.step_model = e->d_step_model;
+    const bool fused = e->fused && !filter;
+    p.ftab = fused ? e->d_ftab : nullptr; p.mtab = fused ? e->d_mtab : nullptr; p.ntab = fused ? e->d_ntab : nullptr;
+    p.fseg = fused ? e->d_fseg : nullptr; p.fe_const = e->fe_const;
     p.fe_scale = filter ? 1.0 / (double)e->T : 1.0;
     const bool fe = want_fe != 0;
     rxhip_status st;
@@ -2409,6 +2510,10 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                     if ((st = prof_end(e))) return st;
                 }
             }
+        } else if (fused) {  // one pass over the observations: known-start recursion + z_t records + evidence parts
+            if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
+            e->vt->forward0(p, e->h_cst0.data(), fe, e->stream);
+            if ((st = prof_end(e))) return st;
         } else if (e->S > 0 && !e->sequential) {
             if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
             e->vt->seg_aggregate(p, e->h_cst0.data(), e->uniform, e->stream);
@@ -2421,9 +2526,12 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             if ((st = prof_end(e))) return st;
         }
         if (!e->dense && e->S > 0) {
-            if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
-            e->vt->forward(p, e->h_cst0.data(), e->uniform, fe, e->stream);
-            if ((st = prof_end(e))) return st;
+            if (!fused) {
+                if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
+                e->vt->forward(p, e->h_cst0.data(), e->uniform, fe, e->stream);
+                if ((st = prof_end(e))) return st;
+            } else if (fe)
+                e->vt->fe_seg(p, e->stream);
             if (!filter) {
                 if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
                 e->vt->backward(p, e->h_cst0.data(), e->uniform, e->stream);
