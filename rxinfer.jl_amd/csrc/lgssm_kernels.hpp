@@ -684,6 +684,286 @@ __global__ void __launch_bounds__(64) k_seg_aggregate(Params p, const CstArgFor<
 }
 
 // ------------------------------------------------------------------------------------------
+// Shared-model smoothing runs: phases 1 and 3 in ONE pass over the observations.
+//
+// With one model for every chain all covariances are data-independent, and the true filtered mean inside segment s
+// (start belief N(m_s, V_s) at boundary b_s) is an affine function of the known-start quantities this phase already tracks:
+//     m_f(b_s + i) = b_i + Π_i W_{s,i} (V_s⁻¹ m_s + η_i),      W_{s,i} = (V_s⁻¹ + J_i)⁻¹
+// (the element formula of the boundary scan, applied to the prefix of length i).  With the data-independent, per-time-index
+// matrices  M_t = Π_i W_{s,i}  and  N_t = M_t V_s⁻¹  (k_time_tables, once per engine)
+//     m_f(t) = z_t + N_t m_s,        z_t = b_i + M_t η_i.
+// z_t is stored as the forward-message mean record; the backward kernels add N_t m_s, with m_s from the boundary scan that
+// runs in between.  The observations are read once and the data-independent inverses of k_forward are not recomputed in
+// every lane.  The segment's evidence comes from the same quantities:
+//     −2 log p(y_seg | y_before) = const_s + q0 + [m_s'A1 m_s − 2 η'A2 m_s − η'W η],   q0 = Σ_i e_i'(S⁰_i)⁻¹e_i
+// with e_i the known-start innovations (k_fe_seg evaluates the bracket, const_s is summed on the host).
+template <int D, int DY, bool FE>
+__global__ void __launch_bounds__(64) k_forward0(Params p, const CstArg<CstLayout<D, DY>::SIZE> cb) {
+    using CL = CstLayout<D, DY>;
+    using FL = F0Layout<D, DY>;
+    constexpr int MT = TimeTab<D>::MT;
+    constexpr int MP2 = DimM<D>::MP2;
+    constexpr int U = 4;                    // steps per chunk
+    constexpr int NPF = U * FL::SIZE / 2;   // 16-byte pieces of the position table per chunk
+    constexpr int NPM = U * MT / 2;         // … of the time table
+    constexpr int NPC = NPF + NPM;
+    constexpr int PPL = (NPC + 63) / 64;    // pieces per lane
+    __shared__ double2 tbuf[2][NPC];
+    const int lane = threadIdx.x;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = p.n_chains * (long long)p.S;
+    const bool live = g < total;
+    // every wave holds 64 consecutive (segment, chain) lanes; when the batch is not a multiple of 64 a wave may straddle two
+    // segments — the time-table stream follows lane 0's segment, so such waves read their own M_t rows from memory
+    const long long seg = live ? g / p.n_chains : 0;
+    const long long chain = live ? g - seg * p.n_chains : 0;
+    const long long len = live ? seg_len(p, seg) : 0;
+    const CPtr c{cb.v};
+    const long long t0 = seg * p.L + 1;
+    const long long seg0 = __builtin_amdgcn_readfirstlane((int)seg);
+    const bool straddle = __builtin_amdgcn_ballot_w64(live && seg != seg0) != 0;
+    const long long tw0 = seg0 * p.L + 1;   // first time index of the wave's table stream
+    const long long f_pieces = p.L * (FL::SIZE / 2);
+    const long long m_pieces = p.T * (MT / 2);
+    const double2* f2 = reinterpret_cast<const double2*>(p.ftab);
+    const double2* m2 = reinterpret_cast<const double2*>(p.mtab);
+
+    double2 tr[PPL];
+    auto fetch = [&](long long i0) {
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            const int idx = k * 64 + lane;
+            double2 v = make_double2(0.0, 0.0);
+            if (idx < NPF) {
+                const long long gi = i0 * (FL::SIZE / 2) + idx;
+                if (gi < f_pieces) v = f2[gi];
+            } else if (idx < NPC) {
+                const long long gi = (tw0 + i0) * (MT / 2) + (idx - NPF);
+                if (gi < m_pieces) v = m2[gi];
+            }
+            tr[k] = v;
+        }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            const int idx = k * 64 + lane;
+            if (idx < NPC) tbuf[b][idx] = tr[k];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+
+    double m[D], eta[D], q0 = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) m[i] = eta[i] = 0.0;
+    double yb[U][DY], yn[U][DY];
+#pragma unroll
+    for (int u = 0; u < U; ++u)
+        if (u < len) load_y<DY>(p.y, t0 + u, p.n_chains, chain, yn[u]);
+    int b = 0;
+    for (long long i0 = 0; i0 < p.L; i0 += U, b ^= 1) {  // uniform trip count
+        if (i0 + U < p.L) fetch(i0 + U);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#pragma unroll
+            for (int k = 0; k < DY; ++k) yb[u][k] = yn[u][k];
+            if (i0 + U + u < len) load_y<DY>(p.y, t0 + i0 + U + u, p.n_chains, chain, yn[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = i0 + u;
+            if (i < len) {
+                const double* tb = reinterpret_cast<const double*>(&tbuf[b][0]) + u * FL::SIZE;
+                const double* mt = reinterpret_cast<const double*>(&tbuf[b][NPF]) + u * MT;
+                double e[DY];
+#pragma unroll
+                for (int a = 0; a < DY; ++a) {
+                    double s = yb[u][a];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) s -= c[CL::HF + a * D + k] * m[k];
+                    e[a] = s;
+                }
+                if (FE) {
+#pragma unroll
+                    for (int a = 0; a < DY; ++a) {
+                        double s = 0.0;
+#pragma unroll
+                        for (int k = 0; k < DY; ++k) s += tb[FL::SI + sidx(a, k)] * e[k];
+                        q0 += s * e[a];
+                    }
+                }
+                double mn[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    double s = 0.0, uu = eta[a];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) s += c[CL::A + a * D + k] * m[k];
+#pragma unroll
+                    for (int k = 0; k < DY; ++k) {
+                        s += tb[FL::K + a * DY + k] * e[k];
+                        uu += tb[FL::U + a * DY + k] * e[k];
+                    }
+                    mn[a] = s;
+                    eta[a] = uu;
+                }
+#pragma unroll
+                for (int a = 0; a < D; ++a) m[a] = mn[a];
+                // z_t = b_i + M_t η_i  (values, not pointers, select between LDS and memory: a pointer that may be either
+                // becomes a generic pointer, which this compiler cannot lower here)
+                double z[2 * MP2], mrow[D * D];
+                if (straddle) {
+                    const double* gm = p.mtab + (t0 + i) * MT;
+#pragma unroll
+                    for (int k = 0; k < D * D; ++k) mrow[k] = gm[k];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < D * D; ++k) mrow[k] = mt[k];
+                }
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    double s = m[a];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) s += mrow[a * D + k] * eta[k];
+                    z[a] = s;
+                }
+                if (D < 2 * MP2) z[2 * MP2 - 1] = 0.0;
+                double2* base = reinterpret_cast<double2*>(p.filt) + (((t0 + i) * p.nb64 + (chain >> 6)) * MP2) * 64 + (chain & 63);
+#pragma unroll
+                for (int k = 0; k < MP2; ++k) base[k * 64] = make_double2(z[2 * k], z[2 * k + 1]);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (i0 + U < p.L) stash(b ^ 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (live) {
+        double* o = p.elem + (seg * 2 * D) * p.n_chains + chain;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            o[a * p.n_chains] = m[a];
+            o[(D + a) * p.n_chains] = eta[a];
+        }
+        if (FE) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * q0;
+    }
+}
+
+// Data-independent per-time-index tables of the one-pass schedule, once per engine: one lane per time index.
+struct TimeTabParams {
+    long long T, L;
+    const double* pos;   // [L][PosLayout::SIZE]
+    const double* scan;  // [S][ScanLayout::SIZE]  (VB = V(b_s))
+    double* mtab;        // [T][MT]
+    double* ntab;        // [T][MT]
+    double* vtab;        // [T][NS]   V_f(t)
+    int* status;
+};
+template <int D>
+__global__ void __launch_bounds__(64) k_time_tables(TimeTabParams q) {
+    using PL = PosLayout<D>;
+    using SL = ScanLayout<D>;
+    constexpr int NS = Dim<D>::NS;
+    constexpr int MT = TimeTab<D>::MT;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= q.T) return;
+    if (t == 0) {  // the filtered covariance at x[1] is the start covariance of segment 0; rows 0 of M, N are never used
+#pragma unroll
+        for (int k = 0; k < NS; ++k) q.vtab[k] = q.scan[SL::VB + k];
+#pragma unroll
+        for (int k = 0; k < MT; ++k) q.mtab[k] = q.ntab[k] = 0.0;
+        return;
+    }
+    const long long s = (t - 1) / q.L, i = t - s * q.L;  // position 1..L inside segment s
+    const double* ps = q.pos + (i - 1) * PL::SIZE;
+    const double* sc = q.scan + s * SL::SIZE;
+    Sym<D> Vs, Vi, T1, W;
+    double det;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Vs.v[k] = sc[SL::VB + k];
+    ok = spd_inv<D>(Vs, Vi, det) && ok;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) T1.v[k] = Vi.v[k] + ps[PL::J + k];
+    ok = spd_inv<D>(T1, W, det) && ok;
+    double M[D][D], N[D][D];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += ps[PL::PI + a * D + k] * W(k, b);
+            M[a][b] = acc;
+        }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += M[a][k] * Vi(k, b);
+            N[a][b] = acc;
+        }
+    double* mo = q.mtab + t * MT;
+    double* no = q.ntab + t * MT;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            mo[a * D + b] = M[a][b];
+            no[a * D + b] = N[a][b];
+        }
+    if (D * D < MT) mo[MT - 1] = no[MT - 1] = 0.0;
+    double* vo = q.vtab + t * NS;  // V_f(t) = C_i + Π_i W Π_i'
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            double acc = ps[PL::C + sidx(a, b)];
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += M[a][k] * ps[PL::PI + b * D + k];
+            vo[sidx(a, b)] = acc;
+        }
+    if (!ok) atomicOr(q.status, ST_NOT_POSDEF);
+}
+
+// The data-dependent quadratic form of every segment's evidence, after the boundary scan: one lane per (chain, segment).
+template <int D>
+__global__ void __launch_bounds__(64) k_fe_seg(Params p) {
+    using FS = FeSegLayout<D>;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.n_chains * (long long)p.S) return;
+    const long long seg = g / p.n_chains, chain = g - seg * p.n_chains;
+    const double* f = p.fseg + seg * FS::SIZE;
+    const double* ms = p.fstart + (seg * Dim<D>::NP) * p.n_chains + chain;
+    const double* el = p.elem + (seg * 2 * D) * p.n_chains + chain;
+    double m[D], eta[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        m[i] = ms[i * p.n_chains];
+        eta[i] = el[(D + i) * p.n_chains];
+    }
+    double v = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        double a1 = 0.0, a2 = 0.0, w = 0.0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            a1 += f[FS::A1 + sidx(i, k)] * m[k];
+            a2 += f[FS::A2 + i * D + k] * m[k];
+            w += f[FS::W + sidx(i, k)] * eta[k];
+        }
+        v += m[i] * a1 - eta[i] * (2.0 * a2 + w);
+    }
+    double* slot = p.fe_part + (seg + 1) * p.n_chains + chain;
+    *slot += -0.5 * (v + (seg == 0 ? p.fe_const : 0.0));
+}
+
+// ------------------------------------------------------------------------------------------
 // phase 2: scans over segment boundaries, one lane per (chain, role).
 //   role 0 (prefix): filtered belief at x[1] (prior ⊗ observation), then
 //        f(b_{s+1}) = element_s applied to f(b_s):  W = (V⁻¹ + J)⁻¹,
@@ -1158,6 +1438,33 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
     const long long te = tb + len;    // zero-based time index of boundary b_{seg+1}
     bool ok = true;
 
+    // shared-model runs are one-pass runs (k_forward0): the mean records hold z_t, the filtered mean is z_t + N_t m_seg
+    constexpr bool fused = UNI;
+    double mseg[D];
+    if (fused) {
+        const double* q = p.fstart + (seg * Dim<D>::NP) * p.n_chains + chain;
+#pragma unroll
+        for (int i = 0; i < D; ++i) mseg[i] = q[i * p.n_chains];
+    }
+    double Nn[UNI ? D * D : 1];  // N_t of the NEXT step to process, loaded one step ahead (wave-uniform address)
+    auto load_N = [&](long long t) {
+        if constexpr (UNI) {
+            const double* N = p.ntab + t * TimeTab<D>::MT;
+#pragma unroll
+            for (int k = 0; k < D * D; ++k) Nn[k] = N[k];
+        }
+    };
+    auto add_start = [&](double (&mfv)[D]) {
+        if constexpr (UNI) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double s = mfv[i];
+#pragma unroll
+                for (int k = 0; k < D; ++k) s += Nn[i * D + k] * mseg[k];
+                mfv[i] = s;
+            }
+        }
+    };
     // smoothed belief at the end boundary: filtered(te) ⊗ β(b_{seg+1})
     double ms[D], mf[D];
     Sym<D> Vs, Vf;
@@ -1167,6 +1474,13 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
             load_filt_m_sh<D>(p, te, chain, r);
             unpack_m_sh<D>(r, mf);
             load_v_sh<D>(p, te, Vf);
+            if (len > 0) {
+                load_N(te);
+                add_start(mf);
+            } else {
+#pragma unroll
+                for (int i = 0; i < D; ++i) mf[i] = mseg[i];
+            }
         } else {
             double2 r[NP2];
             load_filt_raw<D>(p.filt, te, p.n_chains, chain, r);
@@ -1193,10 +1507,19 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
         else load_filt_raw<D>(p.filt, tt, p.n_chains, chain, rn);
     };
     if (len > 0) prefetch(te - 1);
+    if (fused && len > 0) load_N(te - 1);
     for (long long t = te - 1; t >= tb; --t) {
         if constexpr (UNI) {
             unpack_m_sh<D>(rn, mf);
             load_v_sh<D>(p, t, Vf);
+            double zf[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) zf[i] = mf[i];
+            add_start(zf);
+            // at the segment's start boundary the filtered mean is the scan's own result
+#pragma unroll
+            for (int i = 0; i < D; ++i) mf[i] = (t > tb) ? zf[i] : mseg[i];
+            load_N(t > 0 ? t - 1 : 0);  // unconditional: behind a branch the compiler copies the 16 values every step and waits
         } else
             unpack_rec<D>(rn, mf, Vf);
         if (t > tb) prefetch(t - 1);

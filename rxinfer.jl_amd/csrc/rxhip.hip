@@ -126,7 +126,7 @@ struct Launch {
         else hipLaunchKernelGGL((k_forward0<D, DY, false>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
     }
     static void time_tables(const TimeTabParams& q, hipStream_t s) {
-        if (q.T > 1) hipLaunchKernelGGL((k_time_tables<D>), dim3(nblk(q.T - 1, 64)), dim3(64), 0, s, q);
+        hipLaunchKernelGGL((k_time_tables<D>), dim3(nblk(q.T, 64)), dim3(64), 0, s, q);
     }
     static void fe_seg(const Params& p, hipStream_t s) {
         hipLaunchKernelGGL((k_fe_seg<D>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
@@ -1727,8 +1727,6 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         TimeTabParams q{};
         q.T = e->T; q.L = e->L; q.pos = e->d_pos; q.scan = e->d_scan; q.mtab = e->d_mtab; q.ntab = e->d_ntab; q.vtab = e->d_vtab;
         q.status = e->d_status;
-        HIPCHK(e, hipMemsetAsync(e->d_mtab, 0, sizeof(double) * vt->mt_row, e->stream));  // row 0 is never used
-        HIPCHK(e, hipMemsetAsync(e->d_ntab, 0, sizeof(double) * vt->mt_row, e->stream));
         vt->time_tables(q, e->stream);
         HIPCHK(e, hipGetLastError());
         int hst = 0;
