@@ -1667,4 +1667,288 @@ __global__ void __launch_bounds__(256) k_fe_total(Params p, const double* block_
     if (threadIdx.x == 0) p.fe_total[p.iteration] = sh[0];
 }
 
+
+// ------------------------------------------------------------------------------------------
+// phase 4 for shared-model batches whose size is a multiple of 64: table-driven backward sweep.
+//
+// With one model for every chain the smoother gain G_t and the smoothed covariance V_s(t) do not depend on the data either.
+// k_smooth_tables builds them once per engine (one lane per segment, the recursion of k_backward on covariances only) together
+// with  E_t = I − G_t A  and  F_t = E_t N_t,  so that the per-chain work of a step is three small matrix–vector products,
+//     m_s(t) = E_t z_t + F_t m_seg + G_t m_s(t+1)
+// (m_s(t) = m_f + G (m_s(t+1) − A m_f) with m_f = z_t + N_t m_seg), and the posterior covariance is written from the table:
+// the 64·d² doubles a wavefront owes for one time index are contiguous in memory and periodic with period d², so every lane
+// keeps writing the same one or two table entries and every store instruction covers a contiguous 1 KiB run — no transposition
+// through LDS, no inverse, ≈50 instead of ≈600 VALU instructions per step.  The means go through a 2 KiB LDS tile.
+template <int D>
+struct SmoothTab {  // one row per time index
+    static constexpr int E = 0, F = D * D, G = 2 * D * D, VS = 3 * D * D;  // VS: V_s(t), full row-major [D][D]
+    static constexpr int SIZE = 4 * D * D;
+};
+template <int D>
+struct SegEndTab {  // per segment: m_s(te) = H1 m_f(te) + H2 ξβ
+    static constexpr int H1 = 0, H2 = D * D;  // V_s(te) V_f(te)⁻¹, V_s(te)
+    static constexpr int SIZE = 2 * D * D;
+};
+struct SmoothTabParams {
+    long long T, L;
+    int S;
+    const double* vtab;  // [T][NS]
+    const double* ntab;  // [T][MT]
+    const double* scan;  // [S][ScanLayout::SIZE]  (LB = Λβ(b_{s+1}))
+    double* gtab;        // [T][SmoothTab::SIZE]
+    double* segend;      // [S][SegEndTab::SIZE]
+    int* status;
+};
+template <int D, int DY>
+__global__ void __launch_bounds__(64) k_smooth_tables(SmoothTabParams q, const CstArg<CstLayout<D, DY>::SIZE> cb) {
+    using CL = CstLayout<D, DY>;
+    using SL = ScanLayout<D>;
+    using ST = SmoothTab<D>;
+    constexpr int NS = Dim<D>::NS;
+    constexpr int MT = TimeTab<D>::MT;
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= q.S) return;
+    const CPtr c{cb.v};
+    const long long tb = s * q.L;
+    long long te = tb + q.L;
+    if (te > q.T - 1) te = q.T - 1;
+    bool ok = true;
+    Sym<D> Vf, Vi, Ls, Vs;
+    double det;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Vf.v[k] = q.vtab[te * NS + k];
+    ok = spd_inv<D>(Vf, Vi, det) && ok;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Ls.v[k] = Vi.v[k] + q.scan[s * SL::SIZE + SL::LB + k];
+    ok = spd_inv<D>(Ls, Vs, det) && ok;
+    double* se = q.segend + s * SegEndTab<D>::SIZE;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += Vs(a, k) * Vi(k, b);
+            se[SegEndTab<D>::H1 + a * D + b] = acc;
+            se[SegEndTab<D>::H2 + a * D + b] = Vs(a, b);
+        }
+    if (s == q.S - 1) {  // the last time index is written by the last segment only
+        double* row = q.gtab + te * ST::SIZE;
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                row[ST::E + a * D + b] = row[ST::F + a * D + b] = row[ST::G + a * D + b] = 0.0;
+                row[ST::VS + a * D + b] = Vs(a, b);
+            }
+    }
+    for (long long t = te - 1; t >= tb; --t) {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) Vf.v[k] = q.vtab[t * NS + k];
+        double T[D][D], G[D][D], H[D][D], E[D][D];
+        Sym<D> Vp, Lp, Dm;
+        predict_cov<D>(CPtr{c.p + CL::A}, CPtr{c.p + CL::P}, Vf, T, Vp);
+        ok = spd_inv<D>(Vp, Lp, det) && ok;
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += T[k][a] * Lp(k, b);
+                G[a][b] = acc;
+            }
+#pragma unroll
+        for (int k = 0; k < NS; ++k) Dm.v[k] = Vs.v[k] - Vp.v[k];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += G[a][k] * Dm(k, b);
+                H[a][b] = acc;
+            }
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b <= a; ++b) {
+                double acc = Vf(a, b);
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += H[a][k] * G[b][k];
+                Vs(a, b) = acc;
+            }
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                double acc = (a == b) ? 1.0 : 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc -= G[a][k] * c[CL::A + k * D + b];
+                E[a][b] = acc;
+            }
+        double* row = q.gtab + t * ST::SIZE;
+        const double* N = q.ntab + t * MT;
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                double f = 0.0;
+                if (t > tb) {  // at the segment's own start boundary the filtered mean is m_seg itself: no N term
+#pragma unroll
+                    for (int k = 0; k < D; ++k) f += E[a][k] * N[k * D + b];
+                }
+                row[ST::E + a * D + b] = E[a][b];
+                row[ST::F + a * D + b] = f;
+                row[ST::G + a * D + b] = G[a][b];
+                row[ST::VS + a * D + b] = Vs(a, b);
+            }
+    }
+    if (!ok) atomicOr(q.status, ST_NOT_POSDEF);
+}
+
+template <int D>
+__global__ void __launch_bounds__(64) k_backward_sh(Params p, const double* __restrict__ gtab, const double* __restrict__ segend) {
+    using ST = SmoothTab<D>;
+    constexpr int MP2 = DimM<D>::MP2;
+    constexpr int MT = TimeTab<D>::MT;
+    constexpr int U = 4;                     // steps per table chunk
+    constexpr int RP = ST::SIZE / 2;         // 16-byte pieces per row
+    constexpr int NPC = U * RP;
+    constexpr int PPL = (NPC + 63) / 64;
+    constexpr int NMP = 32 * D;              // 16-byte pieces of the 64 means of a time index
+    constexpr int NCP = 32 * D * D;          // … of the 64 covariances
+    __shared__ double2 tbuf[2][NPC];
+    __shared__ double mtile[64 * D];
+    const int lane = threadIdx.x;
+    const long long g0 = (long long)blockIdx.x * 64;  // n_chains % 64 == 0: the wave holds 64 chains of ONE segment
+    const long long seg = g0 / p.n_chains;
+    const long long chain0 = g0 - seg * p.n_chains;
+    const long long chain = chain0 + lane;
+    const long long len = seg_len(p, seg);
+    const long long tb = seg * p.L, te = tb + len;
+
+    double mseg[D], ms[D];
+    {
+        const double* q = p.fstart + (seg * Dim<D>::NP) * p.n_chains + chain;
+        const double* bq = p.beta + ((seg + 1) * Dim<D>::NP) * p.n_chains + chain;
+        double mf[D], xb[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            mseg[i] = q[i * p.n_chains];
+            xb[i] = bq[i * p.n_chains];
+        }
+        if (len > 0) {
+            double2 r[MP2];
+            load_filt_m_sh<D>(p, te, chain, r);
+            unpack_m_sh<D>(r, mf);
+            const double* N = p.ntab + te * MT;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double s = mf[i];
+#pragma unroll
+                for (int k = 0; k < D; ++k) s += N[i * D + k] * mseg[k];
+                mf[i] = s;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) mf[i] = mseg[i];
+        }
+        const double* se = segend + seg * SegEndTab<D>::SIZE;
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += se[SegEndTab<D>::H1 + i * D + k] * mf[k] + se[SegEndTab<D>::H2 + i * D + k] * xb[k];
+            ms[i] = s;
+        }
+    }
+    // one time index of output: means through the LDS tile, covariances straight from table row `vs`
+    auto write_out = [&](long long t, const double* vs) {
+#pragma unroll
+        for (int i = 0; i < D; ++i) mtile[lane * D + i] = ms[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double2* om = reinterpret_cast<double2*>(p.mean + (t * p.n_chains + chain0) * D);
+        double2* oc = reinterpret_cast<double2*>(p.cov + (t * p.n_chains + chain0) * D * D);
+#pragma unroll
+        for (int k = 0; k < (NMP + 63) / 64; ++k) {
+            const int q = k * 64 + lane;
+            if (q < NMP) om[q] = make_double2(mtile[2 * q], mtile[2 * q + 1]);
+        }
+#pragma unroll
+        for (int k = 0; k < (NCP + 63) / 64; ++k) {
+            const int q = k * 64 + lane;
+            if (q < NCP) oc[q] = make_double2(vs[(2 * q) % (D * D)], vs[(2 * q + 1) % (D * D)]);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    };
+    if (seg == p.S - 1) write_out(te, gtab + te * ST::SIZE + ST::VS);
+
+    // table rows te−1, te−2, … stream through LDS one chunk ahead (the gains are the same for every lane of the wave)
+    const double2* g2 = reinterpret_cast<const double2*>(gtab);
+    double2 tr[PPL];
+    auto fetch = [&](long long i0) {
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            const int idx = k * 64 + lane;
+            const long long r = i0 + idx / RP;  // step index
+            tr[k] = (idx < NPC && r < len) ? g2[(te - 1 - r) * RP + idx % RP] : make_double2(0.0, 0.0);
+        }
+    };
+    auto stash = [&](int b) {
+#pragma unroll
+        for (int k = 0; k < PPL; ++k) {
+            const int idx = k * 64 + lane;
+            if (idx < NPC) tbuf[b][idx] = tr[k];
+        }
+    };
+    fetch(0);
+    stash(0);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    double2 rn[MP2];
+    if (len > 0) load_filt_m_sh<D>(p, te - 1, chain, rn);
+    int b = 0;
+    for (long long i0 = 0; i0 < len; i0 += U, b ^= 1) {  // `len` is uniform across the wave
+        if (i0 + U < len) fetch(i0 + U);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long i = i0 + u;
+            if (i < len) {
+                const long long t = te - 1 - i;
+                const double* row = reinterpret_cast<const double*>(&tbuf[b][0]) + u * ST::SIZE;
+                double z[D];
+                unpack_m_sh<D>(rn, z);
+                if (t > tb) load_filt_m_sh<D>(p, t - 1, chain, rn);
+                else {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) z[k] = mseg[k];  // the start boundary: the scan's own filtered mean (F row is zero)
+                }
+                double mn[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) {
+                        s0 += row[ST::E + a * D + k] * z[k] + row[ST::F + a * D + k] * mseg[k];
+                        s1 += row[ST::G + a * D + k] * ms[k];
+                    }
+                    mn[a] = s0 + s1;
+                }
+#pragma unroll
+                for (int a = 0; a < D; ++a) ms[a] = mn[a];
+                write_out(t, row + ST::VS);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        if (i0 + U < len) stash(b ^ 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 }  // namespace rxhip

@@ -42,6 +42,9 @@ struct LgssmVtbl {
     void (*forward0)(const Params&, const double*, bool, hipStream_t);
     void (*time_tables)(const TimeTabParams&, hipStream_t);
     void (*fe_seg)(const Params&, hipStream_t);
+    int gt_row, se_size;  // SmoothTab / SegEndTab
+    void (*smooth_tables)(const SmoothTabParams&, const double*, hipStream_t);
+    void (*backward_sh)(const Params&, const double*, const double*, hipStream_t);
     void (*boundary_scan_tab)(const Params&, const double*, bool, hipStream_t);
     void (*seg_aggregate)(const Params&, const double*, bool, hipStream_t);
     void (*boundary_scan)(const Params&, const double*, bool, bool, hipStream_t);
@@ -131,6 +134,12 @@ struct Launch {
     static void fe_seg(const Params& p, hipStream_t s) {
         hipLaunchKernelGGL((k_fe_seg<D>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
     }
+    static void smooth_tables(const SmoothTabParams& q, const double* hc, hipStream_t s) {
+        hipLaunchKernelGGL((k_smooth_tables<D, DY>), dim3(nblk(q.S, 64)), dim3(64), 0, s, q, carg(hc));
+    }
+    static void backward_sh(const Params& p, const double* gtab, const double* segend, hipStream_t s) {
+        hipLaunchKernelGGL((k_backward_sh<D>), dim3((unsigned)(p.n_chains / 64 * p.S)), dim3(64), 0, s, p, gtab, segend);
+    }
     static void forecast(const PredictParams& p, hipStream_t s) {
         hipLaunchKernelGGL((k_forecast<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
     }
@@ -160,6 +169,9 @@ struct Launch {
         v.forward0 = &Launch::forward0;
         v.time_tables = &Launch::time_tables;
         v.fe_seg = &Launch::fe_seg;
+        v.gt_row = SmoothTab<D>::SIZE; v.se_size = SegEndTab<D>::SIZE;
+        v.smooth_tables = &Launch::smooth_tables;
+        v.backward_sh = &Launch::backward_sh;
         v.boundary_scan_tab = &Launch::boundary_scan_tab;
         v.seg_aggregate = &Launch::seg_aggregate;
         v.boundary_scan = &Launch::boundary_scan;
@@ -287,6 +299,7 @@ struct rxhip_engine {
     bool fused = false;
     double *d_ftab = nullptr, *d_mtab = nullptr, *d_ntab = nullptr, *d_pos = nullptr, *d_fseg = nullptr;
     double fe_const = 0.0;
+    double *d_gtab = nullptr, *d_segend = nullptr;  // table-driven backward sweep (k_backward_sh): batches of a multiple of 64 chains
     bool sequential = false;  // one segment per chain on per-chain records (missing observations, time-varying constants)
     int* d_step_model = nullptr;
     bool masked = false;      // NaN observations are `missing` (rxhip_lgssm_desc.allow_missing): per-chain records, one segment
@@ -1698,6 +1711,10 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.upload(&e->d_fseg, ft.fseg.data(), sizeof(double) * ft.fseg.size());
         ap.plain(&e->d_mtab, sizeof(double) * T * vt->mt_row);
         ap.plain(&e->d_ntab, sizeof(double) * T * vt->mt_row);
+        if (C % 64 == 0 && !std::getenv("RXHIP_BACKWARD_LANES")) {
+            ap.plain(&e->d_gtab, sizeof(double) * T * vt->gt_row);
+            ap.plain(&e->d_segend, sizeof(double) * Sg * vt->se_size);
+        }
     }
     ap.zeroed(&e->d_status, sizeof(int));
     ap.zeroed(&e->d_fe_part, sizeof(double) * (Sg + 1) * C);
@@ -1728,6 +1745,12 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         q.T = e->T; q.L = e->L; q.pos = e->d_pos; q.scan = e->d_scan; q.mtab = e->d_mtab; q.ntab = e->d_ntab; q.vtab = e->d_vtab;
         q.status = e->d_status;
         vt->time_tables(q, e->stream);
+        if (e->d_gtab) {
+            SmoothTabParams sq{};
+            sq.T = e->T; sq.L = e->L; sq.S = e->S; sq.vtab = e->d_vtab; sq.ntab = e->d_ntab; sq.scan = e->d_scan;
+            sq.gtab = e->d_gtab; sq.segend = e->d_segend; sq.status = e->d_status;
+            vt->smooth_tables(sq, e->h_cst0.data(), e->stream);
+        }
         HIPCHK(e, hipGetLastError());
         int hst = 0;
         HIPCHK(e, hipMemcpyAsync(&hst, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -2532,7 +2555,8 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 e->vt->fe_seg(p, e->stream);
             if (!filter) {
                 if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
-                e->vt->backward(p, e->h_cst0.data(), e->uniform, e->stream);
+                if (fused && e->d_gtab) e->vt->backward_sh(p, e->d_gtab, e->d_segend, e->stream);
+                else e->vt->backward(p, e->h_cst0.data(), e->uniform, e->stream);
                 if ((st = prof_end(e))) return st;
             }
         }
