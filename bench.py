@@ -247,8 +247,11 @@ def main():
             dist.all_gather_into_tensor(fe_all, fe_buf)
     torch.cuda.synchronize()
 
+    t_create = time.perf_counter()
     eng = rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C,
                             segments=args.segments, device=local_rank, stream=stream.cuda_stream)
+    torch.cuda.synchronize()
+    create_ms = (time.perf_counter() - t_create) * 1e3  # device allocation + every data-independent table of the model
     eng.set_data_device(y.data_ptr(), y.numel(), keepalive=y)
 
     def step():
@@ -293,12 +296,11 @@ def main():
     value = rule_calls_per_step * args.steps / dt
     units = T * C  # (chain, time-step) units per launch on this rank
     d, dy = 4, 4
-    ns = d * (d + 1) // 2
     # Algorithmic bytes per (chain, step).  SURVEY §8d's model (416 B/U) lets every chain write and re-read its own packed
     # forward message (d + d(d+1)/2 doubles).  In a batch that shares one model the covariance half of that message does not
     # depend on the data — it is ONE table per model, not a per-chain stream — so the floor for THIS workload is
-    # y (32) + forward mean out/in (32 + 32) + dense posterior (160) = 256 B/U, of which k_backward owns 32 + 160 = 192.
-    survey_bwd, survey_sweep = 8 * ((d + ns) + (d + d * d)), 8 * (dy + 2 * (d + ns) + (d + d * d))  # 272, 416
+    # y (32) + forward mean record out/in (32 + 32) + dense posterior (160) = 256 B/U, of which k_backward owns 32 + 160 = 192.
+    # Since round 2 the sweep moves exactly these bytes: the observations are read once (k_forward0).
     floor_bwd, floor_sweep = 8 * (d + (d + d * d)), 8 * (dy + 2 * d + (d + d * d))                   # 192, 256
     dom_ms = kt["k_backward"]["ms_avg"]
     sweep_ms = dt / args.steps * 1e3
@@ -332,18 +334,19 @@ def main():
         "vmp_iters_per_sec": args.steps / dt,
         # `achieved` = algorithmic bytes of THIS workload (shared-model batch: 192 B/U for this kernel, see above) ÷ the kernel's
         # HIP-event time measured in the timed region; it coincides with what the HBM physically moves (`traffic`, PMC passes of
-        # the same command under profiles/).  `survey_model_*` prices the same time with SURVEY's per-chain-message byte model —
-        # bytes this kernel does not move; kept for reference only.
+        # the same command under profiles/, which also counts the per-time-index tables the kernel streams: +3 %).
         "roofline": {"bound": "hbm", "kernel": "k_backward", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": tsrc,
                      "traffic_achieved": gbs(traffic, dom_ms) if traffic else None,
                      "traffic_frac": gbs(traffic, dom_ms) / HBM_PEAK_GBS if traffic else None,
                      "algorithmic_bytes_per_launch": floor_bwd * units, "algorithmic_bytes_per_U": floor_bwd,
                      "algorithmic_floor_bytes_per_U_sweep": floor_sweep, "kernel_ms_avg": dom_ms,
-                     "sweep_achieved": gbs(floor_sweep * units, sweep_ms), "sweep_frac": gbs(floor_sweep * units, sweep_ms) / HBM_PEAK_GBS,
-                     "survey_model_bytes_per_U": survey_bwd, "survey_model_frac": gbs(survey_bwd * units, dom_ms) / HBM_PEAK_GBS,
-                     "survey_model_sweep_frac": gbs(survey_sweep * units, sweep_ms) / HBM_PEAK_GBS},
+                     "sweep_achieved": gbs(floor_sweep * units, sweep_ms), "sweep_frac": gbs(floor_sweep * units, sweep_ms) / HBM_PEAK_GBS},
         "kernels_ms_avg": {k: round(v["ms_avg"], 4) for k, v in kt.items() if v["launches"]},
+        # Not in the timed sweep: what depends on the model only (gains, covariances, smoother gains of a batch that shares one
+        # model) is built once per engine — `engine_create_ms` is that cost plus the device allocation.  Every sweep reads all
+        # observations, recomputes every mean and the free energy, and writes the full posterior (mean + covariance per chain).
+        "engine_create_ms": create_ms,
         "free_energy_rank0": fe_local,
         "free_energy_global": float(fe_sum.item()) if dist is not None else fe_local,
     }
