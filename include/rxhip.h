@@ -294,6 +294,15 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
  * (The reference refuses free_energy together with predictions, src/inference/batch.jl:337-341; here both are available.) */
 rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout);
 
+/* replaces: ReactiveMP.get_node_local_marginals / `@marginalrule MvNormalMeanCovariance(:out_μ)` (the joint the
+ * node's Bethe energy is taken over, reactivemp_free_energy.jl:57-66; deterministic neighbours:
+ * reactivemp_force_marginal_computation_plugin.jl:52-98): the node-local joint marginal q(out, μ) of every transition node
+ * MvNormalMeanCovariance(out = x[t], μ = A x[t-1], Σ = P) between observed states, t = 2 … T, in (out, μ) order:
+ * mean (T-1)*n_chains*2d doubles = [m(x[t]); A m(x[t-1])], cov …*2d*2d = [[V(x[t]), (A X)′], [A X, A V(x[t-1]) A′]] with
+ * X = Cov(x[t-1], x[t] | y) (either may be NULL), in `layout` ([T-1][chain][·] or [chain][T-1][·]).
+ * node_type: RXHIP_NODE_MVNORMAL_MEAN_COV.  After rxhip_run of a state-space engine; d, dy ≤ 4. */
+rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double* mean, double* cov, int32_t layout);
+
 /* device views of the same results, layout [T][chain][d] and [T][chain][d][d]; valid until the
  * next run / destroy */
 rxhip_status rxhip_get_marginals_device(rxhip_engine* e, int32_t var_id, const double** mean_dev,

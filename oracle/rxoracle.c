@@ -190,6 +190,10 @@ typedef struct {
 } creal;
 
 /* ------------------------------------------------------------------------------------------ */
+/* optional tap on the node-local joints q(out, μ) of the transition nodes (set by rxo_lgssm_bp_joints) */
+static __thread double* g_joint_mean = NULL; /* [T-1][2d]     */
+static __thread double* g_joint_cov = NULL;  /* [T-1][2d][2d] */
+
 int rxo_lgssm_bp(int d, int dy, int T, const double* A, const double* B, const double* P, const double* Q,
                  const double* m0, const double* V0, int ptt, const double* y, double* post_mean,
                  double* post_cov, double* free_energy, rxo_counters* counters) {
@@ -426,6 +430,10 @@ int rxo_lgssm_bp(int d, int dy, int T, const double* A, const double* B, const d
                 rc = cholinv(d2, Lj, Vj, &ldLj, jw);
                 if (rc) break;
                 matvec(d2, d2, Vj, xj, mj);
+                if (g_joint_mean && k - 1 - ptt >= 0) { /* node between the observed states k-1 and k */
+                    memcpy(g_joint_mean + (size_t)(k - 1 - ptt) * d2, mj, sizeof(double) * d2);
+                    memcpy(g_joint_cov + (size_t)(k - 1 - ptt) * d2 * d2, Vj, sizeof(double) * d2 * d2);
+                }
                 double tr = 0.0;
                 for (int i = 0; i < d; ++i)
                     for (int j = 0; j < d; ++j) {
@@ -502,6 +510,22 @@ done:
     free(big);
     free(fwdp_x);
     free(fwdx_m);
+    return rc;
+}
+
+/* Node-local joint marginals q(out = x[t], μ = A x[t-1]) of the transition nodes between observed states, t = 2..T, exactly as
+   the @marginalrule MvNormalMeanCovariance(:out_μ) of the Bethe sum above forms them: mean [T-1][2d],
+   cov [T-1][2d][2d], (out, μ) order.  Test infrastructure: checks rxhip_get_node_marginals. */
+int rxo_lgssm_bp_joints(int d, int dy, int T, const double* A, const double* B, const double* P, const double* Q,
+                        const double* m0, const double* V0, int ptt, const double* y, double* joint_mean, double* joint_cov) {
+    if (!joint_mean || !joint_cov) return RXO_ERR_BADARG;
+    double* pm = (double*)malloc(sizeof(double) * (size_t)T * (d + (size_t)d * d));
+    double fe = 0.0;
+    g_joint_mean = joint_mean;
+    g_joint_cov = joint_cov;
+    int rc = rxo_lgssm_bp(d, dy, T, A, B, P, Q, m0, V0, ptt, y, pm, pm + (size_t)T * d, &fe, NULL);
+    g_joint_mean = g_joint_cov = NULL;
+    free(pm);
     return rc;
 }
 

@@ -74,6 +74,9 @@ int rxo_lgssm_bp(int d, int dy, int T, const double* A, const double* B, const d
  * y laid out [T][chain][dy], outputs [T][chain][d] and [T][chain][d][d], fe[chain] (nullable).
  * nthreads > 1 uses OpenMP over chains (the reference itself is single-threaded).
  */
+/* node-local joints q(out = x[t], μ = A x[t-1]) of the transition nodes between observed states (mean [T-1][2d], cov [T-1][2d][2d]) */
+int rxo_lgssm_bp_joints(int d, int dy, int T, const double* A, const double* B, const double* P, const double* Q,
+                        const double* m0, const double* V0, int ptt, const double* y, double* joint_mean, double* joint_cov);
 int rxo_lgssm_bp_batch(int d, int dy, int T, int n_chains, const double* A, const double* B,
                        const double* P, const double* Q, const double* m0, const double* V0,
                        int prior_through_transition, const double* y, double* post_mean,

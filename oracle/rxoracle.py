@@ -91,6 +91,20 @@ def lgssm_bp(A, B, P, Q, m0, V0, y, prior_through_transition=False, free_energy=
     return mean, cov, (fe.value if free_energy else None), cnt
 
 
+def lgssm_joints(A, B, P, Q, m0, V0, y, prior_through_transition=False):
+    """Node-local joints q(x[t], A x[t-1]) of the transition nodes, reference schedule: mean [T-1, 2d], cov [T-1, 2d, 2d]."""
+    A, B, P, Q, m0, V0, y = map(_c, (A, B, P, Q, m0, V0, y))
+    d, dy, T = A.shape[0], B.shape[0], y.shape[0]
+    jm, jc = np.empty((max(T - 1, 0), 2 * d)), np.empty((max(T - 1, 0), 2 * d, 2 * d))
+    L = lib()
+    L.rxo_lgssm_bp_joints.restype = ctypes.c_int
+    rc = L.rxo_lgssm_bp_joints(ctypes.c_int(d), ctypes.c_int(dy), ctypes.c_int(T), _p(A), _p(B), _p(P), _p(Q), _p(m0), _p(V0),
+                               ctypes.c_int(int(prior_through_transition)), _p(y), _p(jm), _p(jc))
+    if rc:
+        raise RuntimeError(f"rxo_lgssm_bp_joints failed with status {rc}")
+    return jm, jc
+
+
 def lgssm_predict(A, B, P, Q, m0, V0, y, horizon=0, prior_through_transition=False):
     """Predictions of y[1..T+H] (leave-one-out for the observed part, forecasts for the H unobserved steps) and the
     x-posteriors of the unobserved steps.  Returns pred_mean [T+H,dy], pred_cov [T+H,dy,dy], post_mean [H,d], post_cov [H,d,d]."""

@@ -24,6 +24,11 @@ struct PredictParams {
     const double* bq;     // [n_models][DY·D + DY·DY]   B | Q (row-major)
     const int* chain_model;
     const int* step_model; // [T+H] or null: time-varying constants (Params::step_model)
+    // node-local joints (k_joint): the forward message's covariance of every step, as the sweep left it
+    const double* filt;   // per-chain records [T][chain/64][NP2][64][2] (per-chain models, masked / per-step schedules) …
+    const double* vtab;   // … or [T][NS], one copy for a shared-model batch (then `filt` is null)
+    double* jmean;        // [T-1][chain][2D]
+    double* jcov;         // [T-1][chain][2D][2D]
     double* pmean;        // [T+H][chain][DY]
     double* pcov;         // [T+H][chain][DY][DY]
     int* status;
@@ -133,6 +138,97 @@ __global__ __launch_bounds__(256) void k_predict(PredictParams p) {
                 for (int k = 0; k < D; ++k) s += BV[a][k] * B[b * D + k];
                 p.pcov[g * DY * DY + a * DY + b] = s;
                 p.pcov[g * DY * DY + b * DY + a] = s;
+            }
+    }
+    if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+
+// Node-local joint marginal of every transition node MvNormalMeanCovariance(out = x[t], μ = A x[t-1], Σ = P), t = 2 … T:
+// what `@marginalrule MvNormalMeanCovariance(:out_μ)` forms in the reference (the joint the Bethe energy of the node
+// is taken over, src/model/plugins/reactivemp_force_marginal_computation_plugin.jl:52-98 for the deterministic neighbours).
+// On a chain it follows from the sweep's own results:  Cov(x[t-1], x[t] | y) = G V_s(t),  G = V_f(t-1) A′ (A V_f(t-1) A′ + P)⁻¹,
+// so  q(out, μ) = N([m_s(t); A m_s(t-1)], [[V_s(t), (A X)′], [A X, A V_s(t-1) A′]])  with X = G V_s(t).  One thread per (chain, node).
+template <int D, int DY>
+__global__ __launch_bounds__(256) void k_joint(PredictParams p) {
+    using CL = CstLayout<D, DY>;
+    constexpr int NS = Dim<D>::NS, NP2 = Dim<D>::NP2;
+    const long long total = (p.T - 1) * p.n_chains;
+    bool ok = true;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const long long k = g / p.n_chains, c = g - k * p.n_chains;  // node k joins x[k] (μ side) and x[k+1] (out), zero-based
+        const int mdl = p.step_model ? p.step_model[k + 1] : p.chain_model ? p.chain_model[c] : 0;
+        const double* cst = p.cst + (size_t)mdl * CL::SIZE;
+        Sym<D> Vf, Vp, Lp;
+        if (p.filt) {
+            double2 r[NP2];
+            double mf[D];
+            load_filt_raw<D>(p.filt, k, p.n_chains, c, r);
+            unpack_rec<D>(r, mf, Vf);
+        } else {
+#pragma unroll
+            for (int q = 0; q < NS; ++q) Vf.v[q] = p.vtab[k * NS + q];
+        }
+        double T[D][D], G[D][D], X[D][D], AX[D][D], det;
+        predict_cov<D>(CPtr{cst + CL::A}, CPtr{cst + CL::P}, Vf, T, Vp);
+        ok = spd_inv<D>(Vp, Lp, det) && ok;
+        const double* v0 = p.cov + (k * p.n_chains + c) * D * D;        // V_s(k)
+        const double* v1 = p.cov + ((k + 1) * p.n_chains + c) * D * D;  // V_s(k+1)
+        const double* m0 = p.mean + (k * p.n_chains + c) * D;
+        const double* m1 = p.mean + ((k + 1) * p.n_chains + c) * D;
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < D; ++q) s += T[q][a] * Lp(q, b);  // G = (A V_f)′ V_p⁻¹
+                G[a][b] = s;
+            }
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < D; ++q) s += G[a][q] * v1[q * D + b];
+                X[a][b] = s;
+            }
+        double AV[D][D];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                double s = 0.0, w = 0.0;
+#pragma unroll
+                for (int q = 0; q < D; ++q) {
+                    s += cst[CL::A + a * D + q] * X[q][b];
+                    w += cst[CL::A + a * D + q] * v0[q * D + b];
+                }
+                AX[a][b] = s;
+                AV[a][b] = w;
+            }
+        double* jm = p.jmean + g * 2 * D;
+        double* jc = p.jcov + g * 4 * D * D;
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            double s = 0.0;
+#pragma unroll
+            for (int q = 0; q < D; ++q) s += cst[CL::A + a * D + q] * m0[q];
+            jm[a] = m1[a];
+            jm[D + a] = s;
+        }
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                double s = 0.0;
+#pragma unroll
+                for (int q = 0; q < D; ++q) s += AV[a][q] * cst[CL::A + b * D + q];  // A V_s(k) A′
+                jc[a * 2 * D + b] = v1[a * D + b];
+                jc[a * 2 * D + D + b] = AX[b][a];
+                jc[(D + a) * 2 * D + b] = AX[a][b];
+                jc[(D + a) * 2 * D + D + b] = s;
             }
     }
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);

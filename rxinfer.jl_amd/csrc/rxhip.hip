@@ -52,6 +52,7 @@ struct LgssmVtbl {
     void (*backward)(const Params&, const double*, bool, hipStream_t);
     void (*forecast)(const PredictParams&, hipStream_t);
     void (*predict)(const PredictParams&, hipStream_t);
+    void (*joint)(const PredictParams&, hipStream_t);
 };
 
 static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -149,6 +150,10 @@ struct Launch {
         const long long nb = (total + 255) / 256;
         hipLaunchKernelGGL((k_predict<D, DY>), dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, p);
     }
+    static void joint(const PredictParams& p, hipStream_t s) {
+        const long long nb = ((p.T - 1) * p.n_chains + 255) / 256;
+        hipLaunchKernelGGL((k_joint<D, DY>), dim3((unsigned)(nb < 8192 ? (nb > 0 ? nb : 1) : 8192)), dim3(256), 0, s, p);
+    }
     static LgssmVtbl vtbl() {
         using TL = TabLayout<D, DY>;
         using AL = AggLayout<D>;
@@ -180,6 +185,7 @@ struct Launch {
         v.backward = &Launch::backward;
         v.forecast = &Launch::forecast;
         v.predict = &Launch::predict;
+        v.joint = &Launch::joint;
         return v;
     }
 };
@@ -2727,6 +2733,33 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
     if (!st) st = rxhip_sync(e);  // also reports a leave-one-out precision that is not positive definite
     if (!st && mean) st = copy_out(e, pp.pmean, mean, e->dy, layout, e->Tout());
     if (!st && cov) st = copy_out(e, pp.pcov, cov, e->dy * e->dy, layout, e->Tout());
+    (void)hipFree(tmp);
+    return st;
+}
+
+rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double* mean, double* cov, int32_t layout) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (node_type != RXHIP_NODE_MVNORMAL_MEAN_COV || e->kind != 0)
+        return fail(e, RXHIP_ERR_BADARG, "get_node_marginals: node-local joints exist for the transition nodes of a state-space engine");
+    if (!e->ran || e->last_filter) return fail(e, RXHIP_ERR_STATE, "get_node_marginals: needs a smoothing run (rxhip_run) first");
+    if (e->dense || !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "node-local joints have a device schedule for d, dy ≤ 4 only");
+    if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME) return fail(e, RXHIP_ERR_BADARG, "get_node_marginals: unknown layout %d", layout);
+    if (e->T < 2) return RXHIP_OK;  // a single time step has no transition node between observed states
+    SET_DEVICE(e);
+    const size_t rows = (size_t)(e->T - 1) * e->n_chains, d2 = 2 * (size_t)e->d;
+    double* tmp = nullptr;
+    HIPCHK(e, hipMalloc(&tmp, sizeof(double) * rows * (d2 + d2 * d2)));
+    PredictParams pp{};
+    pp.T = e->T; pp.H = 0; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
+    pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.status = e->d_status;
+    pp.filt = e->uniform ? nullptr : e->d_filt; pp.vtab = e->d_vtab;
+    pp.jmean = tmp; pp.jcov = tmp + rows * d2;
+    e->vt->joint(pp, e->stream);
+    rxhip_status st = RXHIP_OK;
+    if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "joint-marginal kernel launch failed");
+    if (!st) st = rxhip_sync(e);
+    if (!st && mean) st = copy_out(e, pp.jmean, mean, (int)d2, layout, e->T - 1);
+    if (!st && cov) st = copy_out(e, pp.jcov, cov, (int)(d2 * d2), layout, e->T - 1);
     (void)hipFree(tmp);
     return st;
 }

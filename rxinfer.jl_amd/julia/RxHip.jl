@@ -153,6 +153,18 @@ function predictions(e::Engine)
     return mean, cov
 end
 
+"""`get_node_local_marginals` of the transition nodes `x[t] ~ MvNormal(μ = A * x[t-1], Σ = P)`, t = 2 … T: the joint q(out, μ) in
+(out, μ) order — mean 2d × (T-1) × chains, cov 2d × 2d × (T-1) × chains (`rxhip_get_node_marginals`; d, dy ≤ 4)."""
+function node_marginals(e::Engine)
+    d2, n = 2 * e.d, e.T - 1
+    mean = Array{Float64}(undef, d2, n, e.n_chains)
+    cov = Array{Float64}(undef, d2, d2, n, e.n_chains)
+    GC.@preserve mean cov check(e, ccall((:rxhip_get_node_marginals, librxhip), Int32,
+                                         (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Int32),
+                                         e.handle, Int32(1), mean, cov, RXHIP_LAYOUT_CHAIN_TIME))
+    return mean, permutedims(cov, (2, 1, 3, 4))   # row-major blocks -> Julia's column-major
+end
+
 """score(model, BetheFreeEnergy, checks) |> ScoreActor (reactivemp_free_energy.jl:84-126, score/actor.jl:38-63)."""
 function free_energy(e::Engine)
     fe = Vector{Float64}(undef, e.iterations)

@@ -141,6 +141,16 @@ class LGSSMEngine:
         self._chk(_lib.lib().rxhip_get_predictions(self._h, _lib.VAR_Y, _p(mean), _p(cov) if want_cov else None, lay))
         return mean, cov
 
+    def node_marginals(self, layout="time_chain"):
+        """Node-local joints q(x[t], A x[t-1]) of the transition nodes (rxhip_get_node_marginals): mean [T-1][chain][2d],
+        cov [T-1][chain][2d][2d] in (out, μ) order."""
+        d2, T, C = 2 * self.d, self.T - 1, self.n_chains
+        lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
+        shp = (T, C) if layout == "time_chain" else (C, T)
+        mean, cov = np.empty(shp + (d2,)), np.empty(shp + (d2, d2))
+        self._chk(_lib.lib().rxhip_get_node_marginals(self._h, _lib.NODE_MVNORMAL_MEAN_COV, _p(mean), _p(cov), lay))
+        return mean, cov
+
     def marginals(self, layout="time_chain", want_cov=True):
         d, T, C = self.d, self.T + getattr(self, "horizon", 0), self.n_chains
         lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
