@@ -184,6 +184,9 @@ struct Params {
     const double* ntab;     // [T][TimeTab::MT]   N_t = M_t V_s⁻¹
     const double* fseg;     // [S][FeSegLayout::SIZE]
     double fe_const;        // Σ_segments of the data-independent evidence terms
+    double* elemx;          // [S][D² + 2·NS][chain] or null: matrix part (Π, J, C) of every segment element, per chain — the
+                            // masked / per-step-constant schedules, where it depends on the chain's data pattern and the
+                            // time index (k_seg_elements); null: per-model tables `agg`
     const int* step_model;  // [T] or null: the model of time index t (transition INTO x[t] and observation of y[t]);
                             // one segment, per-chain records (rxhip_lgssm_desc.step_model)
 };
@@ -684,6 +687,197 @@ __global__ void __launch_bounds__(64) k_seg_aggregate(Params p, const CstArgFor<
 }
 
 // ------------------------------------------------------------------------------------------
+// phase 1 without tables: the WHOLE segment element (Π, b, C, η, J), computed in the lane.
+//
+// With `missing` observations the gains of the known-start filter depend on the chain's own pattern of observed steps, with
+// per-step constants on the time index: no per-position table exists.  The lane then runs the known-start filter itself —
+// the information-form update of k_forward from (m, V) = (0, 0) — and carries the dependence on the unknown start state
+// along:  m_i(x_s) = Π_i x_s + b_i.  With Z = A_i Π_{i−1}, Λp = V_p⁻¹, Y = Λp Z and the filtered covariance V_i:
+//     Π_i = V_i Y,    b_i = V_i (Λp A b_{i−1} + B′Q⁻¹ y_i),    C = V_L,
+//     η += Y′ (b_i − A b_{i−1}),          J += Z′ (Y − Λp Π_i)
+// (the innovation form  η += (B Z)′S⁻¹e,  J += (B Z)′S⁻¹(B Z)  with S⁻¹ = Q⁻¹ − Q⁻¹B V B′Q⁻¹ pushed through B: neither B nor Q
+// is needed, only the constants k_forward uses).  A missing step has V_i = V_p, b_i = A b_{i−1}: both increments vanish.
+template <int D>
+struct ElemX {
+    static constexpr int NS = D * (D + 1) / 2;
+    static constexpr int PI = 0, J = D * D, C = D * D + NS, SIZE = D * D + 2 * NS;
+};
+template <int D, int DY>
+__global__ void __launch_bounds__(64) k_seg_elements(Params p) {
+    using CL = CstLayout<D, DY>;
+    using EX = ElemX<D>;
+    constexpr int NS = Dim<D>::NS;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.n_chains * (long long)p.S) return;
+    const long long seg = g / p.n_chains, chain = g - seg * p.n_chains;
+    const long long len = seg_len(p, seg);
+    const long long t0 = seg * p.L + 1;
+    const int cmdl = model_of<false>(p, chain);
+    bool ok = true;
+    double b[D], eta[D], Pi[D][D];
+    Sym<D> V, J;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        b[i] = eta[i] = 0.0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) Pi[i][j] = i == j ? 1.0 : 0.0;
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) V.v[i] = J.v[i] = 0.0;
+    for (long long i = 0; i < len; ++i) {
+        const long long t = t0 + i;
+        const double* ct = p.cst + (long long)model_at<false>(p, cmdl, t) * CL::SIZE;
+        double yv[DY];
+        load_y<DY>(p.y, t, p.n_chains, chain, yv);
+        const bool miss = p.masked && obs_missing<DY>(yv);
+        double mp[D], T[D][D], Z[D][D];
+        Sym<D> Vp, Lp, Lf, Vn;
+        matvec_c<D>(CPtr{ct + CL::A}, b, mp);
+        predict_cov<D>(CPtr{ct + CL::A}, CPtr{ct + CL::P}, V, T, Vp);
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += ct[CL::A + a * D + k] * Pi[k][c];
+                Z[a][c] = acc;
+            }
+        double det;
+        ok = spd_inv<D>(Vp, Lp, det) && ok;
+        const double wgt = miss ? 0.0 : 1.0;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) Lf.v[q] = Lp.v[q] + wgt * ct[CL::LOBS + q];
+        ok = spd_inv<D>(Lf, Vn, det) && ok;
+        double xf[D], bn[D];
+        symv<D>(Lp, mp, xf);
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            double acc = xf[a];
+#pragma unroll
+            for (int k = 0; k < DY; ++k) acc += ct[CL::G + a * DY + k] * (miss ? 0.0 : yv[k]);
+            xf[a] = acc;
+        }
+        symv<D>(Vn, xf, bn);
+        double Y[D][D], Pn[D][D];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += Lp(a, k) * Z[k][c];
+                Y[a][c] = acc;
+            }
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += Vn(a, k) * Y[k][c];
+                Pn[a][c] = acc;
+            }
+        double db[D];
+#pragma unroll
+        for (int a = 0; a < D; ++a) db[a] = bn[a] - mp[a];
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            double acc = eta[a];
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += Y[k][a] * db[k];
+            eta[a] = acc;
+        }
+        // J += Z′ (Y − Λp Π_i)   (symmetric: lower triangle)
+        double R[D][D];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double acc = Y[a][c];
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc -= Lp(a, k) * Pn[k][c];
+                R[a][c] = acc;
+            }
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int c = 0; c <= a; ++c) {
+                double acc = J(a, c);
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += Z[k][a] * R[k][c];
+                J(a, c) = acc;
+            }
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+            b[a] = bn[a];
+#pragma unroll
+            for (int c = 0; c < D; ++c) Pi[a][c] = Pn[a][c];
+        }
+        V = Vn;
+    }
+    double* o = p.elem + (seg * 2 * D) * p.n_chains + chain;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        o[a * p.n_chains] = b[a];
+        o[(D + a) * p.n_chains] = eta[a];
+    }
+    double* x = p.elemx + (seg * EX::SIZE) * p.n_chains + chain;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = 0; c < D; ++c) x[(EX::PI + a * D + c) * p.n_chains] = Pi[a][c];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        x[(EX::J + q) * p.n_chains] = J.v[q];
+        x[(EX::C + q) * p.n_chains] = V.v[q];
+    }
+    if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+}
+// the element matrices of (chain, segment) in AggLayout order; `derived`: also C⁻¹, C⁻¹Π, J + Π′C⁻¹Π (suffix scan)
+template <int D>
+__device__ __forceinline__ bool load_elemx(const Params& p, long long s, long long chain, bool derived, double (&al)[AggLayout<D>::SIZE]) {
+    using AL = AggLayout<D>;
+    using EX = ElemX<D>;
+    constexpr int NS = Dim<D>::NS;
+    const double* x = p.elemx + (s * EX::SIZE) * p.n_chains + chain;
+#pragma unroll
+    for (int q = 0; q < D * D; ++q) al[AL::PI + q] = x[(EX::PI + q) * p.n_chains];
+#pragma unroll
+    for (int q = 0; q < NS; ++q) {
+        al[AL::J + q] = x[(EX::J + q) * p.n_chains];
+        al[AL::C + q] = x[(EX::C + q) * p.n_chains];
+    }
+    if (!derived) return true;
+    Sym<D> C, Ci;
+    double det;
+#pragma unroll
+    for (int q = 0; q < NS; ++q) C.v[q] = al[AL::C + q];
+    const bool ok = spd_inv<D>(C, Ci, det);
+#pragma unroll
+    for (int q = 0; q < NS; ++q) al[AL::CI + q] = Ci.v[q];
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = 0; c < D; ++c) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += Ci(a, k) * al[AL::PI + k * D + c];
+            al[AL::X + a * D + c] = acc;
+        }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int c = 0; c <= a; ++c) {
+            double acc = al[AL::J + sidx(a, c)];
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += al[AL::PI + k * D + a] * al[AL::X + k * D + c];
+            al[AL::JJ + sidx(a, c)] = acc;
+        }
+    return ok;
+}
+
+// ------------------------------------------------------------------------------------------
 // Shared-model smoothing runs: phases 1 and 3 in ONE pass over the observations.
 //
 // With one model for every chain all covariances are data-independent, and the true filtered mean inside segment s
@@ -1009,7 +1203,17 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
         for (int s = 0; s < S; ++s) {
             store_soa<D>(p.fstart, s, p.n_chains, chain, m, V);
             if (s == S - 1) break;
-            const CPtr a{aggm};  // interior segments always have the full length L
+            // per-chain models: the element matrices go through registers — the model's table (interior segments always
+            // have the full length L) or, on the masked / per-step schedules, this (chain, segment)'s own
+            double al[(!UNI) ? AL::SIZE : 1];
+            if constexpr (!UNI) {
+                if (p.elemx) load_elemx<D>(p, s, chain, false, al);
+                else {
+#pragma unroll
+                    for (int q = 0; q < AL::SIZE; ++q) al[q] = aggm[q];
+                }
+            }
+            const CPtr a{UNI ? aggm : al};
             const double* el = p.elem + ((long long)s * 2 * D) * p.n_chains + chain;
             Sym<D> Vi, W, T1;
             double det;
@@ -1059,7 +1263,16 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
         for (int i = 0; i < NS; ++i) Lm.v[i] = 0.0;
         store_soa<D>(p.beta, S, p.n_chains, chain, xi, Lm);
         for (int s = S - 1; s >= 1; --s) {
-            const CPtr a{aggm + ((s == S - 1) ? AL::SIZE : 0)};
+            const double* am = aggm + ((s == S - 1) ? AL::SIZE : 0);
+            double al[(!UNI) ? AL::SIZE : 1];
+            if constexpr (!UNI) {
+                if (p.elemx) ok = load_elemx<D>(p, s, chain, true, al) && ok;
+                else {
+#pragma unroll
+                    for (int q = 0; q < AL::SIZE; ++q) al[q] = am[q];
+                }
+            }
+            const CPtr a{UNI ? am : al};
             const double* el = p.elem + ((long long)s * 2 * D) * p.n_chains + chain;
             double b[D], eta[D];
 #pragma unroll

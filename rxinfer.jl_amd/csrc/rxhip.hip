@@ -47,6 +47,8 @@ struct LgssmVtbl {
     void (*backward_sh)(const Params&, const double*, const double*, hipStream_t);
     void (*boundary_scan_tab)(const Params&, const double*, bool, hipStream_t);
     void (*seg_aggregate)(const Params&, const double*, bool, hipStream_t);
+    int ex_size;  // ElemX
+    void (*seg_elements)(const Params&, hipStream_t);
     void (*boundary_scan)(const Params&, const double*, bool, bool, hipStream_t);
     void (*forward)(const Params&, const double*, bool, bool, hipStream_t);  // p.filter selects the filtering variant
     void (*backward)(const Params&, const double*, bool, hipStream_t);
@@ -86,6 +88,9 @@ struct Launch {
             hipLaunchKernelGGL((k_seg_aggregate<D, DY, true>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
         else
             hipLaunchKernelGGL((k_seg_aggregate<D, DY, false>), dim3(nblk(total, 64)), dim3(64), 0, s, p, CstArg<1>{});
+    }
+    static void seg_elements(const Params& p, hipStream_t s) {
+        hipLaunchKernelGGL((k_seg_elements<D, DY>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
     }
     static void boundary_scan(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
         dim3 grid(nblk(p.n_chains, 64), p.filter ? 1 : 2);  // a filtering run needs the prefix role only
@@ -180,6 +185,8 @@ struct Launch {
         v.backward_sh = &Launch::backward_sh;
         v.boundary_scan_tab = &Launch::boundary_scan_tab;
         v.seg_aggregate = &Launch::seg_aggregate;
+        v.ex_size = ElemX<D>::SIZE;
+        v.seg_elements = &Launch::seg_elements;
         v.boundary_scan = &Launch::boundary_scan;
         v.forward = &Launch::forward;
         v.backward = &Launch::backward;
@@ -307,7 +314,9 @@ struct rxhip_engine {
     double *d_ftab = nullptr, *d_mtab = nullptr, *d_ntab = nullptr, *d_pos = nullptr, *d_fseg = nullptr;
     double fe_const = 0.0;
     double *d_gtab = nullptr, *d_segend = nullptr;  // table-driven backward sweep (k_backward_sh): batches of a multiple of 64 chains
-    bool sequential = false;  // one segment per chain on per-chain records (missing observations, time-varying constants)
+    bool sequential = false;  // no per-position tables: missing observations / per-step constants (per-chain records; the segment
+                              // elements are computed in the lane, k_seg_elements, or the chain is ONE segment)
+    double* d_elemx = nullptr;
     int* d_step_model = nullptr;
     bool masked = false;      // NaN observations are `missing` (rxhip_lgssm_desc.allow_missing): per-chain records, one segment
     int pack = 1;             // 2: pairs of chains share a 16×16 tile as a block-diagonal model (d ≤ 8), see dense_kernels.hpp
@@ -1478,6 +1487,10 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->sequential = true;
         e->uniform = false;
     }
+    // Per-chain models take the same table-free route: per-position gain tables PER MODEL were 256 B per lane and step of
+    // streamed traffic (26 GB per sweep at C2 with n_models = n_chains — more than the observations and posteriors together);
+    // computing the element in the lane costs less than reading it (measured: k_seg_aggregate 5.97 ms -> k_seg_elements)
+    if (!dense && !e->uniform) e->sequential = true;
     if (ds->horizon < 0) return fail(e, RXHIP_ERR_BADARG, "horizon must be non-negative");
     if (ds->horizon > 0 && dense)
         return fail(e, RXHIP_ERR_UNSUPPORTED, "unobserved time steps (horizon) have a device schedule for d, dy ≤ 4 only");
@@ -1527,7 +1540,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->L = 1;
         e->Llast = 1;
     } else {
-        long long S_target = e->sequential ? 1 : ds->segments > 0 ? ds->segments
+        long long S_target = (e->sequential && std::getenv("RXHIP_ONE_SEGMENT")) ? 1 : ds->segments > 0 ? ds->segments
                              : dense ? (256 * dense_wg_per_cu + e->wg_chains - 1) / e->wg_chains
                                      : (131072 + e->n_chains - 1) / e->n_chains;
         if (ds->segments <= 0 && !dense) {
@@ -1539,7 +1552,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         }
         if (S_target < 1) S_target = 1;
         long long L = (steps + S_target - 1) / S_target;
-        const long long Lmin = (ds->segments > 0 || e->sequential) ? 1 : 8;
+        const long long Lmin = ds->segments > 0 ? 1 : 8;
         if (L < Lmin) L = Lmin;
         if (L > steps) L = steps;
         e->L = L;
@@ -1742,6 +1755,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     ap.plain(&e->d_mean, sizeof(double) * (size_t)e->Tout() * C * e->d);
     ap.plain(&e->d_cov, sizeof(double) * (size_t)e->Tout() * C * e->d * e->d);
     ap.plain(&e->d_elem, sizeof(double) * Sg * 2 * e->d * C);
+    if (e->sequential && e->S > 1) ap.plain(&e->d_elemx, sizeof(double) * Sg * vt->ex_size * C);
     ap.plain(&e->d_fstart, sizeof(double) * Sg * NP * C);
     ap.plain(&e->d_beta, sizeof(double) * (Sg + 1) * NP * C);
     ap.plain(&e->d_fe_chain, sizeof(double) * C);
@@ -2498,6 +2512,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.filter = filter ? 1 : 0;
     p.masked = e->masked ? 1 : 0;
     p.step_model = e->d_step_model;
+    p.elemx = e->d_elemx;
     const bool fused = e->fused && !filter;
     p.ftab = fused ? e->d_ftab : nullptr; p.mtab = fused ? e->d_mtab : nullptr; p.ntab = fused ? e->d_ntab : nullptr;
     p.fseg = fused ? e->d_fseg : nullptr; p.fe_const = e->fe_const;
@@ -2548,6 +2563,10 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         } else if (e->S > 0 && !e->sequential) {
             if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
             e->vt->seg_aggregate(p, e->h_cst0.data(), e->uniform, e->stream);
+            if ((st = prof_end(e))) return st;
+        } else if (e->d_elemx) {  // masked / per-step schedules with several segments: the elements are computed in the lane
+            if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
+            e->vt->seg_elements(p, e->stream);
             if ((st = prof_end(e))) return st;
         }
         if (!e->dense) {

@@ -97,15 +97,21 @@ def _holes(rng, y, frac):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("segments", [0, 1, 7, 59], ids=lambda s: f"seg{s}")
 @pytest.mark.parametrize("d,dy,ptt", [(1, 1, True), (2, 1, False), (2, 2, True), (3, 2, False), (4, 1, True), (4, 4, False),
                                       (2, 3, True)])
-def test_masked_schedule_matches_the_oracle(d, dy, ptt):
+def test_masked_schedule_matches_the_oracle(d, dy, ptt, segments):
+    """segments = 0: the engine's own choice (several segments: elements computed in the lane); 1: one segment, sequential."""
     import rxhip
     rng = np.random.default_rng(100 * d + dy)
     A, B, P, Q, m0, V0 = _model(rng, d, dy)
     C, T = 37, 60
     y, mask = _holes(rng, _simulate(rng, A, B, P, Q, m0, V0, T, C), 0.25)
-    with rxhip.LGSSMEngine(A, B, P, Q, m0, V0, T=T, n_chains=C, prior_through_transition=ptt, allow_missing=True) as eng:
+    y[3, 16:40] = np.nan       # whole segments without a single observation
+    mask[3, 16:40] = True
+    with rxhip.LGSSMEngine(A, B, P, Q, m0, V0, T=T, n_chains=C, prior_through_transition=ptt, allow_missing=True,
+                           segments=segments) as eng:
+        assert segments == 0 or eng.schedule()["segments"] == segments
         eng.set_data(y, layout="chain_time")
         eng.run(free_energy=True)
         mean, cov = eng.marginals(layout="chain_time")

@@ -92,14 +92,15 @@ def test_one_model_schedule_is_the_time_invariant_oracle():
 @pytest.mark.gpu
 @pytest.mark.parametrize("d,dy,ptt,M", [(1, 1, True, 3), (2, 1, False, 2), (2, 2, True, 40), (3, 2, False, 5), (4, 4, True, 40),
                                         (4, 1, False, 7)])
-def test_per_step_constants_match_the_oracle(d, dy, ptt, M):
+@pytest.mark.parametrize("segments", [0, 1, 6], ids=lambda s: f"seg{s}")
+def test_per_step_constants_match_the_oracle(d, dy, ptt, M, segments):
     import rxhip
     rng = np.random.default_rng(31 * d + dy + M)
     C, T = 21, 40
     mdl = _models(rng, d, dy, M)
     sm = (rng.permutation(T) % M).astype(np.int32)
     y = _simulate(rng, mdl, sm, C, ptt)
-    with rxhip.LGSSMEngine(*mdl, T=T, n_chains=C, prior_through_transition=ptt, step_model=sm) as eng:
+    with rxhip.LGSSMEngine(*mdl, T=T, n_chains=C, prior_through_transition=ptt, step_model=sm, segments=segments) as eng:
         eng.set_data(y, layout="chain_time")
         eng.run(free_energy=True)
         mean, cov = eng.marginals(layout="chain_time")
