@@ -92,14 +92,14 @@ typedef struct {
     int32_t allow_missing; /* 1: an observation y[t] of a chain whose entries are NaN is `missing` ANYWHERE in the data
                          (docs/src/manuals/inference/static.md:98-123): no message from its observation branch, no evidence
                          term; its prediction (rxhip_get_predictions) is the plain predictive.  The covariances then differ
-                         per chain and time index, so the engine runs each chain as one segment (sequential in time,
-                         parallel over chains) on per-chain records.  d, dy ≤ 4 only.  rxhip_counters keeps reporting the
-                         all-observed schedule */
+                         per chain and time index: the engine keeps per-chain records and computes the segment elements of
+                         the time-parallel schedule in the lane (no per-model tables).  d, dy ≤ 4 only.  rxhip_counters keeps
+                         reporting the all-observed schedule */
     const int32_t* step_model; /* NULL, or [T + horizon]: time-varying constants.  step_model[t] names the model (of n_models)
                          whose A, P make the transition INTO x[t] and whose B, Q observe y[t] (`A[t] * x[t-1]`,
                          `MvNormal(μ = …, Σ = P[t])` with per-step constants in the @model loop); the prior (m0, V0) is that of
-                         model step_model[0].  All chains share the schedule (chain_model must be NULL); the engine runs
-                         each chain as one segment, as for allow_missing.  d, dy ≤ 4 only */
+                         model step_model[0].  All chains share the schedule (chain_model must be NULL); runs on the
+                         table-free schedule of allow_missing.  d, dy ≤ 4 only */
 } rxhip_lgssm_desc;
 
 /* replaces: create_model(...) + postprocess_plugin (src/inference/batch.jl:252,

@@ -84,10 +84,8 @@ struct Launch {
     }
     static void seg_aggregate(const Params& p, const double* hc, bool uni, hipStream_t s) {
         const long long total = p.n_chains * (long long)p.S;
-        if (uni)
-            hipLaunchKernelGGL((k_seg_aggregate<D, DY, true>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
-        else
-            hipLaunchKernelGGL((k_seg_aggregate<D, DY, false>), dim3(nblk(total, 64)), dim3(64), 0, s, p, CstArg<1>{});
+        // shared-model batches only (filtering runs, small smoothing runs); per-chain models compute their elements in the lane
+        if (uni) hipLaunchKernelGGL((k_seg_aggregate<D, DY, true>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
     }
     static void seg_elements(const Params& p, hipStream_t s) {
         hipLaunchKernelGGL((k_seg_elements<D, DY>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
