@@ -88,7 +88,7 @@ typedef struct {
     void* stream;     /* hipStream_t to run on; NULL = engine-owned stream */
     int64_t horizon;  /* further time indices T+1 … T+horizon WITHOUT an observation (`missing` at the end of the data,
                          test/inference/inference_tests.jl `predictvars`): their posteriors are forward predictions; the
-                         posterior arrays then hold T + horizon rows.  d, dy ≤ 4 only; 0 = none */
+                         posterior arrays then hold T + horizon rows.  Any d, dy ≤ 64; 0 = none */
     int32_t allow_missing; /* 1: an observation y[t] of a chain whose entries are NaN is `missing` ANYWHERE in the data
                          (docs/src/manuals/inference/static.md:98-123): no message from its observation branch, no evidence
                          term; its prediction (rxhip_get_predictions) is the plain predictive.  The covariances then differ
@@ -290,7 +290,9 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
 /* replaces: obtain_prediction(var) |> subscribe! (reactivemp_inference.jl:619-624; `predictvars = (y = KeepLast(),)`):
  * the message toward every data variable y[t], N(B m, B V B' + Q) with (m, V) the product of the forward and backward
  * messages into x[t] — its own observation excluded — and, for the `horizon` unobserved steps, of the forward prediction.
- * mean: (T+horizon)*n_chains*dy doubles, cov: …*dy*dy (either may be NULL), in `layout`.  After rxhip_run; d, dy ≤ 4.
+ * mean: (T+horizon)*n_chains*dy doubles, cov: …*dy*dy (either may be NULL), in `layout`.  After rxhip_run; any d, dy ≤ 64
+ * (d, dy ≤ 4: state-space form, predict_kernels.hpp; the MFMA path: observation-space form with one dy×dy inverse per step,
+ * generic_kernels.hpp).
  * (The reference refuses free_energy together with predictions, src/inference/batch.jl:337-341; here both are available.) */
 rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout);
 

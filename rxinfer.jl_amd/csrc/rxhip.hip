@@ -24,6 +24,7 @@
 #include "mvgmm_kernels.hpp"
 #include "drift_kernels.hpp"
 #include "predict_kernels.hpp"
+#include "generic_kernels.hpp"
 #include "graph_lowering.hpp"
 
 using namespace rxhip;
@@ -315,6 +316,8 @@ struct rxhip_engine {
     bool sequential = false;  // no per-position tables: missing observations / per-step constants (per-chain records; the segment
                               // elements are computed in the lane, k_seg_elements, or the chain is ONE segment)
     double* d_elemx = nullptr;
+    std::vector<double> h_user;  // MFMA path: user-level A | P | B | Q | Q⁻¹ of every model (generic_kernels.hpp)
+    double* d_user = nullptr;
     int* d_step_model = nullptr;
     bool masked = false;      // NaN observations are `missing` (rxhip_lgssm_desc.allow_missing): per-chain records, one segment
     int pack = 1;             // 2: pairs of chains share a 16×16 tile as a block-diagonal model (d ≤ 8), see dense_kernels.hpp
@@ -1490,9 +1493,20 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     // computing the element in the lane costs less than reading it (measured: k_seg_aggregate 5.97 ms -> k_seg_elements)
     if (!dense && !e->uniform) e->sequential = true;
     if (ds->horizon < 0) return fail(e, RXHIP_ERR_BADARG, "horizon must be non-negative");
-    if (ds->horizon > 0 && dense)
-        return fail(e, RXHIP_ERR_UNSUPPORTED, "unobserved time steps (horizon) have a device schedule for d, dy ≤ 4 only");
     e->H = ds->horizon;
+    if (dense) {  // predictions / forecasts of the MFMA path run on the user-level constants
+        const size_t dd = (size_t)ds->d * ds->d, bd = (size_t)ds->dy * ds->d, qq = (size_t)ds->dy * ds->dy, sz = 2 * dd + bd + 2 * qq;
+        e->h_user.assign((size_t)ds->n_models * sz, 0.0);
+        for (int m = 0; m < ds->n_models; ++m) {
+            double* u = &e->h_user[(size_t)m * sz];
+            std::memcpy(u, ds->A + m * dd, sizeof(double) * dd);
+            std::memcpy(u + dd, ds->P + m * dd, sizeof(double) * dd);
+            std::memcpy(u + 2 * dd, ds->B + m * bd, sizeof(double) * bd);
+            std::memcpy(u + 2 * dd + bd, ds->Q + m * qq, sizeof(double) * qq);
+            if (!host::chol_inv(ds->dy, ds->Q + m * qq, u + 2 * dd + bd + qq, nullptr))
+                return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: observation noise Q is not positive definite", m);
+        }
+    }
     if (!dense) {
         const size_t nb = (size_t)ds->dy * ds->d, nq = (size_t)ds->dy * ds->dy;
         e->h_bq.resize((size_t)ds->n_models * (nb + nq));
@@ -1687,8 +1701,9 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_fe_blocks, sizeof(double) * ((CU + 63) / 64));
         ap.plain(&e->d_filt, sizeof(double) * C * T * dense_rec(e->nt));
         ap.plain(&e->d_vend, sizeof(double) * C * Sg * dense_tri(e->nt));
-        ap.plain(&e->d_mean, sizeof(double) * T * CU * Du);
-        ap.plain(&e->d_cov, sizeof(double) * T * CU * Du * Du);
+        ap.upload(&e->d_user, e->h_user.data(), sizeof(double) * e->h_user.size());
+        ap.plain(&e->d_mean, sizeof(double) * (size_t)e->Tout() * CU * Du);
+        ap.plain(&e->d_cov, sizeof(double) * (size_t)e->Tout() * CU * Du * Du);
         ap.plain(&e->d_elem, sizeof(double) * C * Sg * 2 * D);
         ap.plain(&e->d_fstart_m, sizeof(double) * C * Sg * D);
         ap.plain(&e->d_beta_xi, sizeof(double) * C * (Sg + 1) * D);
@@ -2587,6 +2602,12 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 if ((st = prof_end(e))) return st;
             }
         }
+        if (e->H > 0 && e->dense) {  // the unobserved tail on the MFMA path: generic-dimension forecast, one workgroup per chain
+            GenericParams gp{};
+            gp.T = e->T; gp.H = e->H; gp.n_chains = e->n_chains; gp.d = e->d; gp.dy = e->dy; gp.mean = e->d_mean; gp.cov = e->d_cov;
+            gp.user = e->d_user; gp.chain_model = e->d_chain_model; gp.status = e->d_status;
+            hipLaunchKernelGGL(k_forecast_generic, dim3((unsigned)e->n_chains), dim3(256), generic_forecast_lds(e->d), e->stream, gp);
+        }
         if (e->H > 0 && !e->dense) {  // the unobserved tail: forward messages from the last filtered (= smoothed) belief
             PredictParams pp{};
             pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
@@ -2731,10 +2752,29 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
     if (!e) return RXHIP_ERR_BADARG;
     if (var_id != RXHIP_VAR_Y || e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "get_predictions: variable %d is not a data variable of a state-space engine", var_id);
     if (!e->ran || e->last_filter) return fail(e, RXHIP_ERR_STATE, "get_predictions: needs a smoothing run (rxhip_run) first");
-    if (e->dense || !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "predictions have a device schedule for d, dy ≤ 4 only");
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME) return fail(e, RXHIP_ERR_BADARG, "get_predictions: unknown layout %d", layout);
     SET_DEVICE(e);
     const size_t rows = (size_t)e->Tout() * e->n_chains, dy = (size_t)e->dy;
+    if (e->dense) {  // any d, dy ≤ 64: observation-space form, one workgroup per (chain, time index)
+        static std::once_flag lds_once;
+        // 133 KB of dynamic LDS at d = dy = 64 (the kernel also holds a few bytes of static LDS: not the full 160 KB)
+        std::call_once(lds_once, [] { (void)hipFuncSetAttribute((const void*)k_predict_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
+        (void)hipGetLastError();
+        double* tmp = nullptr;
+        HIPCHK(e, hipMalloc(&tmp, sizeof(double) * rows * (dy + dy * dy)));
+        GenericParams gp{};
+        gp.T = e->T; gp.H = e->H; gp.n_chains = e->n_chains; gp.d = e->d; gp.dy = e->dy; gp.y = e->d_y; gp.mean = e->d_mean; gp.cov = e->d_cov;
+        gp.user = e->d_user; gp.chain_model = e->d_chain_model; gp.pmean = tmp; gp.pcov = tmp + rows * dy; gp.status = e->d_status;
+        hipLaunchKernelGGL(k_predict_generic, dim3((unsigned)rows), dim3(256), generic_predict_lds(e->d, e->dy), e->stream, gp);
+        rxhip_status st = RXHIP_OK;
+        if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "prediction kernel launch failed");
+        if (!st) st = rxhip_sync(e);
+        if (!st && mean) st = copy_out(e, gp.pmean, mean, e->dy, layout, e->Tout());
+        if (!st && cov) st = copy_out(e, gp.pcov, cov, e->dy * e->dy, layout, e->Tout());
+        (void)hipFree(tmp);
+        return st;
+    }
+    if (!e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "predictions: no schedule for this shape");
     if (!e->d_bq) {
         HIPCHK(e, hipMalloc(&e->d_bq, sizeof(double) * e->h_bq.size()));
         HIPCHK(e, hipMemcpy(e->d_bq, e->h_bq.data(), sizeof(double) * e->h_bq.size(), hipMemcpyHostToDevice));

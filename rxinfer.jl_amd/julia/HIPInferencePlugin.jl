@@ -330,7 +330,7 @@ ReactiveMP.isconst(::HIPConstVariable) = true
 
 ReactiveMP.get_stream_of_marginals(v::HIPRandomVariable) = v.stream
 # `obtain_prediction` (reactivemp_inference.jl:619-624): the message toward a data variable, MvN_y(:out) — formed on the device
-# by rxhip_get_predictions after the sweep, for the state-space families with d, dy ≤ 4
+# by rxhip_get_predictions after the sweep, for the state-space families (any d, dy ≤ 64)
 function ReactiveMP.get_stream_of_predictions(v::HIPDataVariable)
     g = v.graph[]
     g === nothing && error("HIP data variable is not attached to an engine")

@@ -1,7 +1,8 @@
 """Predictions of the data variables and unobserved (`missing`) trailing time steps (`obtain_prediction`,
 src/model/plugins/reactivemp_inference.jl:619-624): the HIP path against the oracle's restatement of the reference's
-message schedule (forward ⊗ backward into `*`_B(:out), MvN_y(:out)), for every d, dy ≤ 4 with dy ≥ d (for dy < d the
-reference's own backward conversion fails)."""
+message schedule (forward ⊗ backward into `*`_B(:out), MvN_y(:out)), for d, dy ≤ 4 (state-space form, predict_kernels.hpp) and
+on the MFMA path up to d = dy = 64 (observation-space form, generic_kernels.hpp), with dy ≥ d (for dy < d the reference's own
+backward conversion fails)."""
 import numpy as np
 import pytest
 
@@ -17,7 +18,10 @@ def rel(a, b):
 
 
 @pytest.mark.parametrize("d,dy,T,H,C,ptt", [(1, 1, 50, 7, 3, False), (2, 2, 400, 0, 5, True), (2, 4, 333, 12, 2, False),
-                                          (3, 3, 1200, 30, 66, False), (4, 4, 5000, 100, 130, True)])
+                                          (3, 3, 1200, 30, 66, False), (4, 4, 5000, 100, 130, True),
+                                          # the MFMA path (generic_kernels.hpp): packed pairs, padded and full tiles
+                                          (6, 6, 120, 9, 4, False), (8, 8, 90, 0, 6, True), (5, 7, 77, 3, 3, False),
+                                          (16, 16, 64, 5, 3, False), (20, 24, 50, 4, 2, True), (64, 64, 40, 6, 1, False)])
 def test_predictions_and_forecast_match_oracle(d, dy, T, H, C, ptt):
     mdl = workloads.random_model(d, dy, seed=10 * d + dy)
     y = workloads.generate_batch(mdl, T, C, seed0=T)
@@ -76,6 +80,6 @@ def test_predictions_call_order_and_unsupported_shapes():
             eng.predictions()
         assert ei.value.status == 7
     big = workloads.random_model(8, 8, seed=1)
-    with pytest.raises(rxhip.RxHipError) as ei:
-        rxhip.LGSSMEngine(big["A"], big["B"], big["P"], big["Q"], big["m0"], big["V0"], T=20, horizon=3)
+    with pytest.raises(rxhip.RxHipError) as ei:   # `missing` inside the data has no schedule on the MFMA path
+        rxhip.LGSSMEngine(big["A"], big["B"], big["P"], big["Q"], big["m0"], big["V0"], T=20, allow_missing=True)
     assert ei.value.status == 2
