@@ -703,7 +703,7 @@ struct ElemX {
     static constexpr int PI = 0, J = D * D, C = D * D + NS, SIZE = D * D + 2 * NS;
 };
 template <int D, int DY>
-__global__ void __launch_bounds__(64) k_seg_elements(Params p) {
+__global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wavefronts per SIMD: the batch is sized for that
     using CL = CstLayout<D, DY>;
     using EX = ElemX<D>;
     constexpr int NS = Dim<D>::NS;
@@ -724,9 +724,17 @@ __global__ void __launch_bounds__(64) k_seg_elements(Params p) {
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i) V.v[i] = J.v[i] = 0.0;
+    // the ≈50 constants of a step in registers for the whole segment; per-step constants reload them every step
+    double cr[CL::M1];  // A | P | LOBS | G | QI | C0 (the prefix of the block this kernel reads)
+    auto load_c = [&](const double* src) {
+#pragma unroll
+        for (int k = 0; k < CL::M1; ++k) cr[k] = src[k];
+    };
+    load_c(p.cst + (long long)cmdl * CL::SIZE);
     for (long long i = 0; i < len; ++i) {
         const long long t = t0 + i;
-        const double* ct = p.cst + (long long)model_at<false>(p, cmdl, t) * CL::SIZE;
+        if (p.step_model) load_c(p.cst + (long long)p.step_model[t] * CL::SIZE);
+        const double* ct = cr;
         double yv[DY];
         load_y<DY>(p.y, t, p.n_chains, chain, yv);
         const bool miss = p.masked && obs_missing<DY>(yv);
@@ -1515,6 +1523,18 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
         oc.load(p.cst + z);
     } else
         oc.load(c.p);
+    // per-chain models: the transition constants live in registers for the whole segment (read through the global pointer
+    // the compiler must assume the record stores alias them and re-fetches all 26 every step)
+    double Ar[UNI ? 1 : D * D], Pr[UNI ? 1 : Dim<D>::NS];
+    auto load_AP = [&](const double* ct) {
+        if constexpr (!UNI) {
+#pragma unroll
+            for (int k = 0; k < D * D; ++k) Ar[k] = ct[CL::A + k];
+#pragma unroll
+            for (int k = 0; k < Dim<D>::NS; ++k) Pr[k] = ct[CL::P + k];
+        }
+    };
+    load_AP(c.p);
     double yv[DY], yn[DY];
     if (len > 0) load_y<DY>(p.y, t0, p.n_chains, chain, yn);
     for (long long i = 0; i < len; ++i) {
@@ -1523,15 +1543,16 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
         if (i + 1 < len) load_y<DY>(p.y, t0 + i + 1, p.n_chains, chain, yn);
         double mp[D], T[D][D];
         Sym<D> Vp;
-        const double* ct = c.p;
         if constexpr (!UNI) {
             if (p.step_model) {  // A_t, P_t and the observation constants of this time index
-                ct = p.cst + (long long)p.step_model[t0 + i] * CL::SIZE;
+                const double* ct = p.cst + (long long)p.step_model[t0 + i] * CL::SIZE;
                 oc.load(ct);
+                load_AP(ct);
             }
         }
-        matvec_c<D>(CPtr{ct + CL::A}, m, mp);
-        predict_cov<D>(CPtr{ct + CL::A}, CPtr{ct + CL::P}, V, T, Vp);
+        const CPtr Ac{UNI ? c.p + CL::A : Ar}, Pc{UNI ? c.p + CL::P : Pr};
+        matvec_c<D>(Ac, m, mp);
+        predict_cov<D>(Ac, Pc, V, T, Vp);
         double quad = 0.0, detprod = 1.0;
         obs_update<D, DY, FE, !UNI>(oc, mp, Vp, yv, m, V, ok, quad, detprod, !UNI && p.masked && obs_missing<DY>(yv));
         if (FE) {
@@ -1722,6 +1743,17 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
         if constexpr (UNI) load_filt_m_sh<D>(p, tt, chain, rn);
         else load_filt_raw<D>(p.filt, tt, p.n_chains, chain, rn);
     };
+    // per-chain models: transition constants in registers for the whole segment (see k_forward)
+    double Ar[UNI ? 1 : D * D], Pr[UNI ? 1 : NS];
+    auto load_AP = [&](const double* ct) {
+        if constexpr (!UNI) {
+#pragma unroll
+            for (int k = 0; k < D * D; ++k) Ar[k] = ct[CL::A + k];
+#pragma unroll
+            for (int k = 0; k < NS; ++k) Pr[k] = ct[CL::P + k];
+        }
+    };
+    load_AP(c.p);
     if (len > 0) prefetch(te - 1);
     if (fused && len > 0) load_N(te - 1);
     for (long long t = te - 1; t >= tb; --t) {
@@ -1743,12 +1775,12 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
         if (t > tb) prefetch(t - 1);
         double mp[D], T[D][D];
         Sym<D> Vp, Lp;
-        const double* ct = c.p;
         if constexpr (!UNI) {
-            if (p.step_model) ct = p.cst + (long long)p.step_model[t + 1] * CL::SIZE;  // the transition into x[t+1]
+            if (p.step_model) load_AP(p.cst + (long long)p.step_model[t + 1] * CL::SIZE);  // the transition into x[t+1]
         }
-        matvec_c<D>(CPtr{ct + CL::A}, mf, mp);
-        predict_cov<D>(CPtr{ct + CL::A}, CPtr{ct + CL::P}, Vf, T, Vp);
+        const CPtr Ac{UNI ? c.p + CL::A : Ar}, Pc{UNI ? c.p + CL::P : Pr};
+        matvec_c<D>(Ac, mf, mp);
+        predict_cov<D>(Ac, Pc, Vf, T, Vp);
         double det;
         ok = spd_inv<D>(Vp, Lp, det) && ok;
         // G = T' Lp   (T = A V_f)

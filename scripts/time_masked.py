@@ -39,4 +39,8 @@ for T in (10000, 100000):
             for _ in range(n):
                 eng.run(1, True)
             dt = (time.perf_counter() - t0) / n
-            print(f"T={T} {mode}: {dt * 1e3:.2f} ms per sweep, schedule {eng.schedule()}", flush=True)
+            eng.set_profiling(True)
+            eng.reset_kernel_times()
+            eng.run(1, True)
+            kt = {k: round(v["ms_avg"], 3) for k, v in eng.kernel_times().items() if v["launches"]}
+            print(f"T={T} {mode}: {dt * 1e3:.2f} ms per sweep, schedule {eng.schedule()}, kernels {kt}", flush=True)
