@@ -83,3 +83,30 @@ def test_predictions_call_order_and_unsupported_shapes():
     with pytest.raises(rxhip.RxHipError) as ei:   # `missing` inside the data has no schedule on the MFMA path
         rxhip.LGSSMEngine(big["A"], big["B"], big["P"], big["Q"], big["m0"], big["V0"], T=20, allow_missing=True)
     assert ei.value.status == 2
+
+
+@pytest.mark.parametrize("C", [64, 70])
+def test_one_pass_schedule_with_horizon_predictions_and_joints(C, monkeypatch):
+    """The one-pass / table-driven schedule under everything that reads its results afterwards: forecast tail,
+    predictions, node-local joints, chain gather — for a multiple of 64 chains (k_backward_sh) and not (k_backward<FUSED>)."""
+    monkeypatch.setenv("RXHIP_ONE_PASS", "1")
+    d, dy, T, H = 3, 3, 257, 11
+    mdl = workloads.random_model(d, dy, seed=5)
+    y = workloads.generate_batch(mdl, T, C, seed0=9)
+    with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C, horizon=H,
+                           prior_through_transition=True) as eng:
+        eng.set_data(y)
+        eng.run(2, True)
+        mean, cov = eng.marginals()
+        pm, pc = eng.predictions()
+        jm, jc = eng.node_marginals()
+        fe = eng.free_energy_per_chain()
+    for c in (0, 63, C - 1):
+        args = (mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y[:, c])
+        om, oc, ofe, _ = rxoracle.lgssm_bp(*args, prior_through_transition=True)
+        opm, opc, oxm, oxc = rxoracle.lgssm_predict(*args, horizon=H, prior_through_transition=True)
+        ojm, ojc = rxoracle.lgssm_joints(*args, prior_through_transition=True)
+        assert rel(mean[:T, c], om) < 1e-6 and rel(cov[:T, c], oc) < 1e-6 and abs(fe[c] - ofe) < 1e-8 * abs(ofe)
+        assert rel(mean[T:, c], oxm) < 1e-6 and rel(cov[T:, c], oxc) < 1e-6
+        assert rel(pm[:, c], opm) < 1e-6 and rel(pc[:, c], opc) < 1e-6
+        assert rel(jm[:, c], ojm) < 1e-6 and rel(jc[:, c], ojc) < 1e-6
