@@ -100,6 +100,13 @@ typedef struct {
                          `MvNormal(μ = …, Σ = P[t])` with per-step constants in the @model loop); the prior (m0, V0) is that of
                          model step_model[0].  All chains share the schedule (chain_model must be NULL); runs on the
                          table-free schedule of allow_missing.  d, dy ≤ 4 only */
+    const double* state_offset; /* NULL, or [T + horizon][d]: known inputs.  x[t] ~ MvNormal(μ = A * x[t-1] + c[t], Σ = P) — the
+                         `+` node with a constant (or a `*` of a constant with data, e.g. B_u * u[t]) behind the transition's `*`
+                         node; row 0 enters only through the prior's transition (prior_through_transition) */
+    const double* obs_offset;   /* NULL, or [T + horizon][dy]: y[t] ~ MvNormal(μ = B * x[t] + d[t], Σ = Q).
+                         Offsets are shared by all chains and need one model per time index (chain_model must be NULL).  They cost
+                         no kernel anything: with μ[t] = A μ[t-1] + c[t] the chain x − μ is the homogeneous model observed through
+                         y − B μ − d, so the data are shifted on the way in and the means on the way out (any d, dy) */
 } rxhip_lgssm_desc;
 
 /* replaces: create_model(...) + postprocess_plugin (src/inference/batch.jl:252,

@@ -865,9 +865,14 @@ int rxo_lgssm_predict(int d, int dy, int T, int H, const double* A, const double
  * Independent textbook implementation, used ONLY to validate the restatement above
  * (identity: BP on a tree == Kalman filter + RTS smoother; Bethe FE == −log p(y)).
  * ------------------------------------------------------------------------------------------ */
+/* offsets (known inputs): x[t] ~ N(A x[t-1] + cx[t], P), y[t] ~ N(B x[t] + cy[t], Q); NULL = none.  cx[0] enters only
+   through the prior's transition (ptt). */
+static const double* g_cx = NULL; /* [T][d]  */
+static const double* g_cy = NULL; /* [T][dy] */
 static int kalman_rts_impl(int d, int dy, int T, const double* A0, const double* B0, const double* P0,
                            const double* Q0, const double* m00, const double* V00, const int* sm, int ptt, const double* y,
                            double* post_mean, double* post_cov, double* neg_loglik) {
+    const double *cx = g_cx, *cy = g_cy;
     /* time-varying constants: time index t uses model sm[t] (transition INTO x[t], observation of y[t]) */
 #define MDL(t) (sm ? (size_t)sm[t] : (size_t)0)
     const double *A = A0 + MDL(0) * d * d, *B = B0 + MDL(0) * dy * d, *P = P0 + MDL(0) * d * d, *Q = Q0 + MDL(0) * dy * dy;
@@ -885,6 +890,7 @@ static int kalman_rts_impl(int d, int dy, int T, const double* A0, const double*
     double *pm0 = (double*)malloc(sizeof(double) * (vs + ms)), *pV0 = pm0 + vs;
     if (ptt) {
         matvec(d, d, A, m0, pm0);
+        if (cx) for (size_t i = 0; i < vs; ++i) pm0[i] += cx[i];
         congruence(d, d, A, V0, pV0, tmp);
         for (size_t i = 0; i < ms; ++i) pV0[i] += P[i];
     } else {
@@ -898,6 +904,7 @@ static int kalman_rts_impl(int d, int dy, int T, const double* A0, const double*
             memcpy(Vp, pV0, sizeof(double) * ms);
         } else {
             matvec(d, d, A, mf + (t - 1) * vs, mp);
+            if (cx) for (size_t i = 0; i < vs; ++i) mp[i] += cx[(size_t)t * vs + i];
             congruence(d, d, A, Vf + (t - 1) * ms, Vp, tmp);
             for (size_t i = 0; i < ms; ++i) Vp[i] += P[i];
         }
@@ -917,7 +924,7 @@ static int kalman_rts_impl(int d, int dy, int T, const double* A0, const double*
         rc = cholinv(dy, S, Si, &ldS, chw);
         if (rc) break;
         matvec(dy, d, B, mp, e);
-        for (int i = 0; i < dy; ++i) e[i] = y[(size_t)t * dy + i] - e[i];
+        for (int i = 0; i < dy; ++i) e[i] = y[(size_t)t * dy + i] - e[i] - (cy ? cy[(size_t)t * dy + i] : 0.0);
         double q = 0.0;
         for (int i = 0; i < dy; ++i)
             for (int j = 0; j < dy; ++j) q += e[i] * Si[i * dy + j] * e[j];
@@ -958,6 +965,7 @@ static int kalman_rts_impl(int d, int dy, int T, const double* A0, const double*
         for (int t = T - 2; t >= 0 && !rc; --t) {
             A = A0 + MDL(t + 1) * d * d; P = P0 + MDL(t + 1) * d * d; /* the transition into x[t+1] */
             matvec(d, d, A, mf + t * vs, mp);
+            if (cx) for (size_t i = 0; i < vs; ++i) mp[i] += cx[(size_t)(t + 1) * vs + i];
             congruence(d, d, A, Vf + t * ms, Vp, tmp);
             for (size_t i = 0; i < ms; ++i) Vp[i] += P[i];
             rc = cholinv(d, Vp, Si, NULL, chw);
@@ -997,6 +1005,22 @@ int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B,
                          const double* Q, const double* m0, const double* V0, int ptt, const double* y,
                          double* post_mean, double* post_cov, double* neg_loglik) {
     return kalman_rts_impl(d, dy, T, A, B, P, Q, m0, V0, NULL, ptt, y, post_mean, post_cov, neg_loglik);
+}
+/* Known inputs / offsets: x[t] ~ N(A x[t-1] + cx[t], P), y[t] ~ N(B x[t] + cy[t], Q) (either array may be NULL), optionally with
+   per-step constants (step_model NULL: one model).  Test infrastructure: checks rxhip_lgssm_desc.state_offset / obs_offset. */
+int rxo_lgssm_kalman_rts_affine(int d, int dy, int T, int n_models, const double* A, const double* B, const double* P,
+                                const double* Q, const double* m0, const double* V0, const int* step_model, int ptt,
+                                const double* cx, const double* cy, const double* y, double* post_mean, double* post_cov,
+                                double* neg_loglik) {
+    if (n_models <= 0) return RXO_ERR_BADARG;
+    if (step_model)
+        for (int t = 0; t < T; ++t)
+            if (step_model[t] < 0 || step_model[t] >= n_models) return RXO_ERR_BADARG;
+    g_cx = cx;
+    g_cy = cy;
+    const int rc = kalman_rts_impl(d, dy, T, A, B, P, Q, m0, V0, step_model, ptt, y, post_mean, post_cov, neg_loglik);
+    g_cx = g_cy = NULL;
+    return rc;
 }
 /* Time-varying constants (`A[t] * x[t-1]`, `Σ = P[t]` … in the @model loop): A, B, P, Q, m0, V0 hold n_models models,
    step_model[t] names the model of time index t.  Test infrastructure: checks rxhip_lgssm_desc.step_model. */

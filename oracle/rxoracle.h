@@ -120,6 +120,11 @@ int rxo_lgssm_kalman_rts(int d, int dy, int T, const double* A, const double* B,
                          const double* Q, const double* m0, const double* V0,
                          int prior_through_transition, const double* y, double* post_mean,
                          double* post_cov, double* neg_loglik);
+/* the same with known inputs: x[t] ~ N(A x[t-1] + cx[t], P), y[t] ~ N(B x[t] + cy[t], Q); cx [T][d], cy [T][dy], either may be NULL */
+int rxo_lgssm_kalman_rts_affine(int d, int dy, int T, int n_models, const double* A, const double* B, const double* P,
+                                const double* Q, const double* m0, const double* V0, const int* step_model, int ptt,
+                                const double* cx, const double* cy, const double* y, double* post_mean, double* post_cov,
+                                double* neg_loglik);
 /* the same with time-varying constants: n_models models, step_model[t] = model of time index t */
 int rxo_lgssm_kalman_rts_tv(int d, int dy, int T, int n_models, const double* A, const double* B, const double* P,
                             const double* Q, const double* m0, const double* V0, const int* step_model, int ptt,

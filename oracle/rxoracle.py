@@ -161,6 +161,28 @@ def lgssm_kalman_rts_tv(A, B, P, Q, m0, V0, step_model, y, prior_through_transit
     return mean, cov, nll.value
 
 
+def lgssm_kalman_rts_affine(A, B, P, Q, m0, V0, y, state_offset=None, obs_offset=None, step_model=None, prior_through_transition=False):
+    """Textbook smoother with known inputs: x[t] ~ N(A x[t-1] + cx[t], P), y[t] ~ N(B x[t] + cy[t], Q).  With `step_model`
+    A … V0 carry a leading model axis."""
+    A, B, P, Q, m0, V0, y = map(_c, (A, B, P, Q, m0, V0, y))
+    M = A.shape[0] if step_model is not None else 1
+    d, dy, T = A.shape[-1], B.shape[-2], y.shape[0]
+    cx = None if state_offset is None else _c(np.broadcast_to(state_offset, (T, d)))
+    cy = None if obs_offset is None else _c(np.broadcast_to(obs_offset, (T, dy)))
+    sm = None if step_model is None else np.ascontiguousarray(step_model, dtype=np.int32)
+    mean, cov, nll = np.empty((T, d)), np.empty((T, d, d)), ctypes.c_double(0.0)
+    L = lib()
+    L.rxo_lgssm_kalman_rts_affine.restype = ctypes.c_int
+    ip = ctypes.POINTER(ctypes.c_int)
+    rc = L.rxo_lgssm_kalman_rts_affine(ctypes.c_int(d), ctypes.c_int(dy), ctypes.c_int(T), ctypes.c_int(M), _p(A), _p(B), _p(P), _p(Q),
+                                       _p(m0), _p(V0), sm.ctypes.data_as(ip) if sm is not None else None,
+                                       ctypes.c_int(int(prior_through_transition)), _p(cx) if cx is not None else None,
+                                       _p(cy) if cy is not None else None, _p(y), _p(mean), _p(cov), ctypes.byref(nll))
+    if rc:
+        raise RuntimeError(f"rxo_lgssm_kalman_rts_affine failed with status {rc}")
+    return mean, cov, nll.value
+
+
 def lgssm_filter(A, B, P, Q, m0, V0, y, prior_through_transition=True, free_energy=True):
     """Streaming / filtering run of one chain (rxo_lgssm_filter).  Returns history mean [T,d], cov [T,d,d],
     fe (mean over observations) | None, Counters."""

@@ -26,6 +26,7 @@ struct GenericParams {
     double* cov;         // [T+H][chain][d][d]
     const double* user;  // [n_models][2d² + dy·d + 2dy²]  A | P | B | Q | Q⁻¹
     const int* chain_model;
+    const double *mu, *nu, *cx;  // known inputs (PredictParams): μ[t] [T+H][d], ν[t] [T+H][dy], c[t] [T+H][d]; null: none
     double* pmean;       // [T+H][chain][dy]
     double* pcov;        // [T+H][chain][dy][dy]
     int* status;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) k_predict_generic(GenericParams p) {
     const long long t = g / p.n_chains, c = g - t * p.n_chains;
     const GenericModel M = generic_model(p, c);
     const double* Vs = p.cov + g * d * d;  // read straight from memory (L2): used once, in B V_s
-    for (int e = tid; e < d; e += nt) ms[e] = p.mean[g * d + e];
+    for (int e = tid; e < d; e += nt) ms[e] = p.mean[g * d + e] - (p.mu ? p.mu[(g / p.n_chains) * d + e] : 0.0);
     __shared__ int s_obs;
     if (tid == 0) {
         int obs = t < p.T;
@@ -120,7 +121,7 @@ __global__ void __launch_bounds__(256) k_predict_generic(GenericParams p) {
     }
     __syncthreads();
     if (!observed) {
-        for (int a = tid; a < dy; a += nt) p.pmean[g * dy + a] = u[a];
+        for (int a = tid; a < dy; a += nt) p.pmean[g * dy + a] = u[a] + (p.nu ? p.nu[t * dy + a] : 0.0);
         for (int e = tid; e < dy * dy; e += nt) {
             const int a = e / dy, b = e - a * dy;
             p.pcov[g * dy * dy + e] = 0.5 * (Sg[a * dy + b] + Sg[b * dy + a]) + 0.5 * (M.Q[a * dy + b] + M.Q[b * dy + a]);
@@ -153,7 +154,7 @@ __global__ void __launch_bounds__(256) k_predict_generic(GenericParams p) {
     for (int a = tid; a < dy; a += nt) {  // mean = Q R u
         double s = 0.0;
         for (int k = 0; k < dy; ++k) s += M.Q[a * dy + k] * u[k];
-        p.pmean[g * dy + a] = s;
+        p.pmean[g * dy + a] = s + (p.nu ? p.nu[t * dy + a] : 0.0);
     }
     for (int e = tid; e < dy * dy; e += nt) {  // cov = Q + Σ (R Q): symmetric in exact arithmetic, stored symmetrised
         const int a = e / dy, b = e - a * dy;
@@ -193,7 +194,7 @@ __global__ void __launch_bounds__(256) k_forecast_generic(GenericParams p) {
         for (int i = tid; i < d; i += nt) {
             double s = 0.0;
             for (int k = 0; k < d; ++k) s += M.A[i * d + k] * m[k];
-            mn[i] = s;
+            mn[i] = s + (p.cx ? p.cx[(p.T + h) * d + i] : 0.0);
         }
         __syncthreads();
         for (int e = tid; e < d * d; e += nt) {

@@ -29,6 +29,9 @@ struct PredictParams {
     const double* vtab;   // … or [T][NS], one copy for a shared-model batch (then `filt` is null)
     double* jmean;        // [T-1][chain][2D]
     double* jcov;         // [T-1][chain][2D][2D]
+    const double* mu;     // known inputs (null: none): μ[t] [T+H][D] — the sweep ran on x − μ, y − ν; posteriors are back in x
+    const double* nu;     // ν[t] = B μ[t] + d[t] [T+H][DY]
+    const double* cx;     // c[t] [T+H][D]
     double* pmean;        // [T+H][chain][DY]
     double* pcov;         // [T+H][chain][DY][DY]
     int* status;
@@ -55,6 +58,10 @@ __global__ __launch_bounds__(64) void k_forecast(PredictParams p) {
         if (p.step_model) cst = p.cst + (size_t)p.step_model[p.T + h] * CL::SIZE;
         const CPtr A{cst + CL::A}, P{cst + CL::P};
         matvec_c<D>(A, m, mn);             // `*`_A(:out): N(A m, A V A')
+        if (p.cx) {                        // `+` with the known input of this time index
+#pragma unroll
+            for (int i = 0; i < D; ++i) mn[i] += p.cx[(p.T + h) * D + i];
+        }
         predict_cov<D>(A, P, V, Tm, Vn);   // MvN_x(:out): + P
         const long long r = (p.T + h) * p.n_chains + c;
 #pragma unroll
@@ -84,7 +91,7 @@ __global__ __launch_bounds__(256) void k_predict(PredictParams p) {
         double m[D];
         Sym<D> V;
 #pragma unroll
-        for (int i = 0; i < D; ++i) m[i] = p.mean[g * D + i];
+        for (int i = 0; i < D; ++i) m[i] = p.mean[g * D + i] - (p.mu ? p.mu[t * D + i] : 0.0);
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -120,7 +127,7 @@ __global__ __launch_bounds__(256) void k_predict(PredictParams p) {
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) s += B[a * D + k] * m[k];
-            p.pmean[g * DY + a] = s;
+            p.pmean[g * DY + a] = s + (p.nu ? p.nu[t * DY + a] : 0.0);
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 double v = 0.0;
@@ -216,7 +223,7 @@ __global__ __launch_bounds__(256) void k_joint(PredictParams p) {
 #pragma unroll
             for (int q = 0; q < D; ++q) s += cst[CL::A + a * D + q] * m0[q];
             jm[a] = m1[a];
-            jm[D + a] = s;
+            jm[D + a] = s + (p.cx ? p.cx[(k + 1) * D + a] : 0.0);
         }
 #pragma unroll
         for (int a = 0; a < D; ++a)

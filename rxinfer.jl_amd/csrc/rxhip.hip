@@ -230,6 +230,14 @@ __global__ void k_transpose_rows(const double* __restrict__ in, double* __restri
 }
 
 
+// x[t][c][k] += sign · off[t][k]: known inputs (rxhip_lgssm_desc.state_offset / obs_offset) enter and leave the sweep as shifts
+__global__ void k_shift_rows(double* __restrict__ x, const double* __restrict__ off, long long rows, long long n_chains, int k, double sign) {
+    const long long total = rows * n_chains * k;
+    for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
+        const long long t = g / (n_chains * k);
+        x[g] += sign * off[t * k + g % k];
+    }
+}
 // out[i][t][k] = in[t][chains[i]][k]: posteriors of a few chains, chain-major (what `infer` returns for ONE chain)
 __global__ void k_gather_chains(const double* __restrict__ in, double* __restrict__ out, const long long* __restrict__ chains,
                                 long long n_sel, long long T, long long n_chains, int k) {
@@ -316,6 +324,8 @@ struct rxhip_engine {
     bool sequential = false;  // no per-position tables: missing observations / per-step constants (per-chain records; the segment
                               // elements are computed in the lane, k_seg_elements, or the chain is ONE segment)
     double* d_elemx = nullptr;
+    double *d_mu = nullptr, *d_nu = nullptr, *d_cx = nullptr;  // known inputs: μ[t] [Tout][d], ν[t] = B μ[t] + d[t] [Tout][dy], c[t]
+    std::vector<double> h_mu, h_nu, h_cx;
     std::vector<double> h_user;  // MFMA path: user-level A | P | B | Q | Q⁻¹ of every model (generic_kernels.hpp)
     double* d_user = nullptr;
     int* d_step_model = nullptr;
@@ -1494,6 +1504,33 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     if (!dense && !e->uniform) e->sequential = true;
     if (ds->horizon < 0) return fail(e, RXHIP_ERR_BADARG, "horizon must be non-negative");
     e->H = ds->horizon;
+    if (ds->state_offset || ds->obs_offset) {
+        // known inputs: μ[t] = A μ[t-1] + c[t] (μ before the first state = 0), ν[t] = B μ[t] + d[t]; the sweep runs on x − μ, y − ν
+        if (ds->chain_model) return fail(e, RXHIP_ERR_UNSUPPORTED, "offsets need one model per time index (no chain_model)");
+        const size_t d = (size_t)ds->d, dy = (size_t)ds->dy, To = (size_t)(ds->T + ds->horizon);
+        e->h_mu.assign(To * d, 0.0);
+        e->h_nu.assign(To * dy, 0.0);
+        e->h_cx.assign(To * d, 0.0);
+        if (ds->state_offset) std::memcpy(e->h_cx.data(), ds->state_offset, sizeof(double) * To * d);
+        for (size_t t = 0; t < To; ++t) {
+            const size_t mdl = ds->step_model ? (size_t)ds->step_model[t] : 0;
+            const double *A = ds->A + mdl * d * d, *B = ds->B + mdl * dy * d;
+            double* mu = &e->h_mu[t * d];
+            if (t > 0 || ds->prior_through_transition) {
+                for (size_t i = 0; i < d; ++i) {
+                    double s = e->h_cx[t * d + i];
+                    if (t > 0)
+                        for (size_t k = 0; k < d; ++k) s += A[i * d + k] * e->h_mu[(t - 1) * d + k];
+                    mu[i] = s;
+                }
+            }
+            for (size_t a = 0; a < dy; ++a) {
+                double s = ds->obs_offset ? ds->obs_offset[t * dy + a] : 0.0;
+                for (size_t k = 0; k < d; ++k) s += B[a * d + k] * mu[k];
+                e->h_nu[t * dy + a] = s;
+            }
+        }
+    }
     if (dense) {  // predictions / forecasts of the MFMA path run on the user-level constants
         const size_t dd = (size_t)ds->d * ds->d, bd = (size_t)ds->dy * ds->d, qq = (size_t)ds->dy * ds->dy, sz = 2 * dd + bd + 2 * qq;
         e->h_user.assign((size_t)ds->n_models * sz, 0.0);
@@ -1702,6 +1739,11 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_filt, sizeof(double) * C * T * dense_rec(e->nt));
         ap.plain(&e->d_vend, sizeof(double) * C * Sg * dense_tri(e->nt));
         ap.upload(&e->d_user, e->h_user.data(), sizeof(double) * e->h_user.size());
+        if (!e->h_mu.empty()) {
+            ap.upload(&e->d_mu, e->h_mu.data(), sizeof(double) * e->h_mu.size());
+            ap.upload(&e->d_nu, e->h_nu.data(), sizeof(double) * e->h_nu.size());
+            ap.upload(&e->d_cx, e->h_cx.data(), sizeof(double) * e->h_cx.size());
+        }
         ap.plain(&e->d_mean, sizeof(double) * (size_t)e->Tout() * CU * Du);
         ap.plain(&e->d_cov, sizeof(double) * (size_t)e->Tout() * CU * Du * Du);
         ap.plain(&e->d_elem, sizeof(double) * C * Sg * 2 * D);
@@ -1742,6 +1784,11 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     ap.upload(&e->d_agg, agg.data(), sizeof(double) * agg.size());
     if (ds->chain_model && !e->uniform) ap.upload(&e->d_chain_model, ds->chain_model, sizeof(int) * C);
     if (ds->step_model) ap.upload(&e->d_step_model, ds->step_model, sizeof(int) * (size_t)(e->T + e->H));
+    if (!e->h_mu.empty()) {
+        ap.upload(&e->d_mu, e->h_mu.data(), sizeof(double) * e->h_mu.size());
+        ap.upload(&e->d_nu, e->h_nu.data(), sizeof(double) * e->h_nu.size());
+        ap.upload(&e->d_cx, e->h_cx.data(), sizeof(double) * e->h_cx.size());
+    }
     if (e->uniform && !scan.empty()) ap.upload(&e->d_scan, scan.data(), sizeof(double) * scan.size());
     if (e->fused) {
         ap.upload(&e->d_ftab, ft.ftab.data(), sizeof(double) * ft.ftab.size());
@@ -2374,7 +2421,7 @@ static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t
         return fail(e, RXHIP_ERR_BADARG, "set_data: unknown layout %d", layout);
     SET_DEVICE(e);
     if (e->n_chains == 1) layout = RXHIP_LAYOUT_TIME_CHAIN;  // one chain: the two layouts coincide
-    if (src_on_device && layout == RXHIP_LAYOUT_TIME_CHAIN) {  // zero-copy
+    if (src_on_device && layout == RXHIP_LAYOUT_TIME_CHAIN && !e->d_nu) {  // zero-copy (not with offsets: the engine shifts its own copy)
         if (e->own_y && e->d_y && !e->in_arena(e->d_y)) HIPCHK(e, hipFree(e->d_y));
         e->d_y = const_cast<double*>(src);
         e->own_y = false;
@@ -2387,7 +2434,7 @@ static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t
         e->own_y = true;
     }
     if (layout == RXHIP_LAYOUT_TIME_CHAIN) {
-        HIPCHK(e, hipMemcpyAsync(e->d_y, src, sizeof(double) * need, hipMemcpyHostToDevice, e->stream));
+        HIPCHK(e, hipMemcpyAsync(e->d_y, src, sizeof(double) * need, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
         HIPCHK(e, hipStreamSynchronize(e->stream));
     } else {
         double* tmp = nullptr;
@@ -2403,6 +2450,10 @@ static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipStreamSynchronize(e->stream));
         if (tmp) HIPCHK(e, hipFree(tmp));
+    }
+    if (e->d_nu) {  // known inputs: the sweep sees y − B μ − d
+        hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, -1.0);
+        HIPCHK(e, hipGetLastError());
     }
     e->have_data = true;
     return RXHIP_OK;
@@ -2602,18 +2653,6 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 if ((st = prof_end(e))) return st;
             }
         }
-        if (e->H > 0 && e->dense) {  // the unobserved tail on the MFMA path: generic-dimension forecast, one workgroup per chain
-            GenericParams gp{};
-            gp.T = e->T; gp.H = e->H; gp.n_chains = e->n_chains; gp.d = e->d; gp.dy = e->dy; gp.mean = e->d_mean; gp.cov = e->d_cov;
-            gp.user = e->d_user; gp.chain_model = e->d_chain_model; gp.status = e->d_status;
-            hipLaunchKernelGGL(k_forecast_generic, dim3((unsigned)e->n_chains), dim3(256), generic_forecast_lds(e->d), e->stream, gp);
-        }
-        if (e->H > 0 && !e->dense) {  // the unobserved tail: forward messages from the last filtered (= smoothed) belief
-            PredictParams pp{};
-            pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
-            pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.status = e->d_status;
-            e->vt->forecast(pp, e->stream);
-        }
         if (fe) {
             if ((st = prof_begin(e, RXHIP_K_FE_REDUCE))) return st;
             const int nb = (int)((e->n_chains + 63) / 64);
@@ -2631,6 +2670,21 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 hipLaunchKernelGGL(k_fe_total, dim3(1), dim3(256), 0, e->stream, p, (const double*)e->d_fe_blocks, nb);
             }
             if ((st = prof_end(e))) return st;
+        }
+        if (e->d_mu) {  // known inputs: back from x − μ to x (the free-energy terms above are invariant under the shift)
+            hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_mean, (const double*)e->d_mu, e->T, e->n_chains, e->d, 1.0);
+        }
+        if (e->H > 0 && e->dense) {  // the unobserved tail on the MFMA path: generic-dimension forecast, one workgroup per chain
+            GenericParams gp{};
+            gp.T = e->T; gp.H = e->H; gp.n_chains = e->n_chains; gp.d = e->d; gp.dy = e->dy; gp.mean = e->d_mean; gp.cov = e->d_cov;
+            gp.user = e->d_user; gp.cx = e->d_cx; gp.chain_model = e->d_chain_model; gp.status = e->d_status;
+            hipLaunchKernelGGL(k_forecast_generic, dim3((unsigned)e->n_chains), dim3(256), generic_forecast_lds(e->d), e->stream, gp);
+        }
+        if (e->H > 0 && !e->dense) {  // the unobserved tail: forward messages from the last filtered (= smoothed) belief
+            PredictParams pp{};
+            pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
+            pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.status = e->d_status; pp.cx = e->d_cx;
+            e->vt->forecast(pp, e->stream);
         }
     }
     HIPCHK(e, hipGetLastError());
@@ -2765,6 +2819,7 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
         GenericParams gp{};
         gp.T = e->T; gp.H = e->H; gp.n_chains = e->n_chains; gp.d = e->d; gp.dy = e->dy; gp.y = e->d_y; gp.mean = e->d_mean; gp.cov = e->d_cov;
         gp.user = e->d_user; gp.chain_model = e->d_chain_model; gp.pmean = tmp; gp.pcov = tmp + rows * dy; gp.status = e->d_status;
+        gp.mu = e->d_mu; gp.nu = e->d_nu;
         hipLaunchKernelGGL(k_predict_generic, dim3((unsigned)rows), dim3(256), generic_predict_lds(e->d, e->dy), e->stream, gp);
         rxhip_status st = RXHIP_OK;
         if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "prediction kernel launch failed");
@@ -2784,6 +2839,7 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
     PredictParams pp{};
     pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.y = e->d_y; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
     pp.bq = e->d_bq; pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.pmean = tmp; pp.pcov = tmp + rows * dy; pp.status = e->d_status;
+    pp.mu = e->d_mu; pp.nu = e->d_nu;
     e->vt->predict(pp, e->stream);
     rxhip_status st = RXHIP_OK;
     if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "prediction kernel launch failed");
@@ -2810,7 +2866,7 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
     pp.T = e->T; pp.H = 0; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
     pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.status = e->d_status;
     pp.filt = e->uniform ? nullptr : e->d_filt; pp.vtab = e->d_vtab;
-    pp.jmean = tmp; pp.jcov = tmp + rows * d2;
+    pp.jmean = tmp; pp.jcov = tmp + rows * d2; pp.cx = e->d_cx;
     e->vt->joint(pp, e->stream);
     rxhip_status st = RXHIP_OK;
     if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "joint-marginal kernel launch failed");

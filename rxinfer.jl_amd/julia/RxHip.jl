@@ -46,6 +46,8 @@ struct LgssmDesc
     horizon::Int64
     allow_missing::Int32
     step_model::Ptr{Int32}
+    state_offset::Ptr{Float64}
+    obs_offset::Ptr{Float64}
 end
 
 mutable struct Engine
@@ -79,7 +81,8 @@ state-space family (src/inference/batch.jl:252, src/model/plugins/reactivemp_inf
 function Engine(A, B, P, Q, m0, V0; T::Integer, n_chains::Integer = 1, prior_through_transition::Bool = false,
                 segments::Integer = 0, device::Integer = -1, chain_model::Union{Nothing, AbstractVector{<:Integer}} = nothing,
                 stream = nothing, horizon::Integer = 0, allow_missing::Bool = false,
-                step_model::Union{Nothing, AbstractVector{<:Integer}} = nothing)
+                step_model::Union{Nothing, AbstractVector{<:Integer}} = nothing,
+                state_offset::Union{Nothing, AbstractMatrix} = nothing, obs_offset::Union{Nothing, AbstractMatrix} = nothing)
     # one model: plain matrices; several: vectors of matrices (A[m], B[m], …) with chain_model[c] ∈ 0:n_models-1 (a model per
     # chain) or step_model[t] ∈ 0:n_models-1 (per-step constants `A[t] * x[t-1]`, shared by the chains; T + horizon entries)
     multi = A isa AbstractVector{<:AbstractMatrix}
@@ -91,11 +94,15 @@ function Engine(A, B, P, Q, m0, V0; T::Integer, n_chains::Integer = 1, prior_thr
     (chain_model === nothing || length(cm) == n_chains) || throw(ArgumentError("chain_model needs one entry per chain"))
     sm = step_model === nothing ? Int32[] : Vector{Int32}(step_model)
     (step_model === nothing || length(sm) == T + horizon) || throw(ArgumentError("step_model needs one entry per time index"))
+    # known inputs, d × (T + horizon) / dy × (T + horizon) (one column per time index: row-major [t][·] on the C side)
+    cx = state_offset === nothing ? Float64[] : vec(Matrix{Float64}(state_offset))
+    cy = obs_offset === nothing ? Float64[] : vec(Matrix{Float64}(obs_offset))
     h = Ref{Ptr{Cvoid}}(C_NULL)
-    st = GC.@preserve a b p q m v cm sm begin
+    st = GC.@preserve a b p q m v cm sm cx cy begin
         desc = LgssmDesc(d, dy, T, n_chains, n_models, prior_through_transition ? 1 : 0, pointer(a), pointer(b), pointer(p),
                          pointer(q), pointer(m), pointer(v), isempty(cm) ? Ptr{Int32}(C_NULL) : pointer(cm), segments, device,
-                         stream_handle(stream), horizon, allow_missing ? 1 : 0, isempty(sm) ? Ptr{Int32}(C_NULL) : pointer(sm))
+                         stream_handle(stream), horizon, allow_missing ? 1 : 0, isempty(sm) ? Ptr{Int32}(C_NULL) : pointer(sm),
+                         isempty(cx) ? Ptr{Float64}(C_NULL) : pointer(cx), isempty(cy) ? Ptr{Float64}(C_NULL) : pointer(cy))
         ccall((:rxhip_lgssm_create, librxhip), Int32, (Ref{LgssmDesc}, Ref{Ptr{Cvoid}}), desc, h)
     end
     e = Engine(h[], d, dy, T + horizon, n_chains, 0)   # T counts the rows of the result arrays (observed + horizon)

@@ -26,7 +26,7 @@ class LgssmDesc(ctypes.Structure):
         ("A", c_double_p), ("B", c_double_p), ("P", c_double_p), ("Q", c_double_p), ("m0", c_double_p),
         ("V0", c_double_p), ("chain_model", c_int32_p), ("segments", ctypes.c_int32), ("device", ctypes.c_int32),
         ("stream", ctypes.c_void_p), ("horizon", ctypes.c_int64), ("allow_missing", ctypes.c_int32),
-        ("step_model", c_int32_p),
+        ("step_model", c_int32_p), ("state_offset", c_double_p), ("obs_offset", c_double_p),
     ]
 
 

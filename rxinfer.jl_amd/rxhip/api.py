@@ -34,11 +34,17 @@ class LinearGaussianSSM:
     prior_cov: np.ndarray
     prior_through_transition: bool = False
     step_model: Optional[np.ndarray] = None   # time-varying constants: A, B, P, Q are [n_models, …], step_model[t] picks
+    state_offset: Optional[np.ndarray] = None  # known inputs: x[t] ~ MvNormal(μ = A*x[t-1] + c[t], Σ = P); [d] or [T, d]
+    obs_offset: Optional[np.ndarray] = None    # y[t] ~ MvNormal(μ = B*x[t] + d[t], Σ = Q); [dy] or [T, dy]
 
 
-def linear_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transition=False):
+def linear_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transition=False, state_offset=None, obs_offset=None):
+    """`state_offset` / `obs_offset`: known inputs added to the means (`A * x[t-1] + c`, `B * x[t] + d`), one vector or one
+    per time index."""
     f = lambda a: np.asarray(a, dtype=np.float64)
-    return LinearGaussianSSM(f(A), f(B), f(P), f(Q), f(prior_mean), f(prior_cov), bool(prior_through_transition))
+    g = lambda a: None if a is None else f(a)
+    return LinearGaussianSSM(f(A), f(B), f(P), f(Q), f(prior_mean), f(prior_cov), bool(prior_through_transition),
+                             state_offset=g(state_offset), obs_offset=g(obs_offset))
 
 
 def time_varying_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transition=False):
@@ -333,6 +339,7 @@ def _infer_lgssm_filtering(model, data, free_energy, options, initialization, ca
     try:
         eng = LGSSMEngine(model.A, model.B, model.P, model.Q, m0, V0, T=T, n_chains=C,
                           prior_through_transition=model.prior_through_transition,
+                          state_offset=model.state_offset, obs_offset=model.obs_offset,
                           segments=int(options.get("segments", 0)), device=int(options.get("device", -1)))
         eng.set_data(y, layout="chain_time")
         eng.run_filter(free_energy=free_energy)
@@ -416,6 +423,7 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
         eng = LGSSMEngine(model.A, model.B, model.P, model.Q, m0, V0, T=T, n_chains=C,
                           prior_through_transition=model.prior_through_transition, horizon=horizon,
                           allow_missing=allow_missing, step_model=step_model,
+                          state_offset=model.state_offset, obs_offset=model.obs_offset,
                           segments=int(options.get("segments", 0)), device=int(options.get("device", -1)))
         eng.set_data(y, layout="chain_time")
         eng.run(iterations=iters, free_energy=free_energy)

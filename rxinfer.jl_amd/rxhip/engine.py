@@ -27,7 +27,7 @@ class LGSSMEngine:
     """
 
     def __init__(self, A, B, P, Q, m0, V0, T, n_chains=1, chain_model=None, prior_through_transition=False,
-                 segments=0, device=-1, stream=None, horizon=0, allow_missing=False, step_model=None):
+                 segments=0, device=-1, stream=None, horizon=0, allow_missing=False, step_model=None, state_offset=None, obs_offset=None):
         L = _lib.lib()
         A = _c(A)
         B = _c(B)
@@ -63,6 +63,12 @@ class LGSSMEngine:
                 raise ValueError("step_model must have one entry per time index (T + horizon)")
             self._keep.append(sm)
             desc.step_model = sm.ctypes.data_as(_lib.c_int32_p)
+        # known inputs: x[t] ~ N(A x[t-1] + c[t], P), y[t] ~ N(B x[t] + d[t], Q); a single vector is the same offset at every step
+        for name, off, k in (("state_offset", state_offset, d), ("obs_offset", obs_offset, dy)):
+            if off is not None:
+                a = _c(np.broadcast_to(np.asarray(off, dtype=np.float64), (self.T + self.horizon, k)))
+                self._keep.append(a)
+                setattr(desc, name, _p(a))
         self._h = ctypes.c_void_p()
         st = L.rxhip_lgssm_create(ctypes.byref(desc), ctypes.byref(self._h))
         if st != _lib.OK:

@@ -1,0 +1,143 @@
+"""Known inputs / offsets: x[t] ~ MvNormal(μ = A*x[t-1] + c[t], Σ = P), y[t] ~ MvNormal(μ = B*x[t] + d[t], Σ = Q) — a `+` node with
+a constant behind the `*` node (control inputs B_u*u[t], drifts, biases).  The oracle's affine smoother against brute-force
+conditioning of the joint Gaussian (CPU); the device — which runs the homogeneous sweep on shifted data — against the oracle."""
+import numpy as np
+import pytest
+
+from oracle import rxoracle as rxo
+from test_time_varying import _models
+
+
+def _simulate(rng, mdl, cx, cy, C, ptt):
+    A, B, P, Q, m0, V0 = (x[0] for x in mdl)
+    d, dy, T = A.shape[0], B.shape[0], cx.shape[0]
+    y = np.empty((C, T, dy))
+    for c in range(C):
+        x = rng.multivariate_normal(m0, V0)
+        for t in range(T):
+            if t or ptt:
+                x = A @ x + cx[t] + rng.multivariate_normal(np.zeros(d), P)
+            y[c, t] = B @ x + cy[t] + rng.multivariate_normal(np.zeros(dy), Q)
+    return y
+
+
+def _brute(mdl, cx, cy, y, ptt):
+    A, B, P, Q, m0, V0 = (x[0] for x in mdl)
+    d, dy, T = A.shape[0], B.shape[0], y.shape[0]
+    mx, Vx = np.zeros((T, d)), np.zeros((T, d, T, d))
+    if ptt:
+        mx[0], Vx[0, :, 0, :] = A @ m0 + cx[0], A @ V0 @ A.T + P
+    else:
+        mx[0], Vx[0, :, 0, :] = m0, V0
+    for t in range(1, T):
+        mx[t] = A @ mx[t - 1] + cx[t]
+        Vx[t, :, t, :] = A @ Vx[t - 1, :, t - 1, :] @ A.T + P
+        for s in range(t):
+            Vx[t, :, s, :] = A @ Vx[t - 1, :, s, :]
+            Vx[s, :, t, :] = Vx[t, :, s, :].T
+    Vx = Vx.reshape(T * d, T * d)
+    Bb, Qb = np.kron(np.eye(T), B), np.kron(np.eye(T), Q)
+    my = Bb @ mx.ravel() + cy.ravel()
+    Syy = Bb @ Vx @ Bb.T + Qb
+    K = np.linalg.solve(Syy, Bb @ Vx).T
+    r = y.ravel() - my
+    pm = (mx.ravel() + K @ r).reshape(T, d)
+    pV = Vx - K @ Bb @ Vx
+    nll = 0.5 * (T * dy * np.log(2 * np.pi) + np.linalg.slogdet(Syy)[1] + r @ np.linalg.solve(Syy, r))
+    return pm, np.stack([pV[t * d:(t + 1) * d, t * d:(t + 1) * d] for t in range(T)]), nll
+
+
+@pytest.mark.parametrize("d,dy,ptt", [(1, 1, False), (2, 2, True), (3, 2, False), (4, 3, True)])
+def test_affine_oracle_is_the_conditional_of_the_joint(d, dy, ptt):
+    rng = np.random.default_rng(3 * d + dy)
+    mdl, T = _models(rng, d, dy, 1), 9
+    cx, cy = rng.standard_normal((T, d)), rng.standard_normal((T, dy))
+    y = _simulate(rng, mdl, cx, cy, 1, ptt)[0]
+    m, V, nll = rxo.lgssm_kalman_rts_affine(*(x[0] for x in mdl), y, cx, cy, prior_through_transition=ptt)
+    pm, pV, ref = _brute(mdl, cx, cy, y, ptt)
+    assert np.allclose(m, pm, rtol=1e-9, atol=1e-11) and np.allclose(V, pV, rtol=1e-9, atol=1e-11)
+    assert nll == pytest.approx(ref, rel=1e-10)
+
+
+# ---------------------------------------------------------------------------------------------------------------- device
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,dy,ptt,C,T,H", [(1, 1, True, 3, 50, 0), (2, 2, False, 64, 300, 5), (4, 4, True, 70, 120, 0), (3, 1, False, 5, 40, 3),
+                                            (6, 6, False, 4, 60, 4), (16, 12, True, 2, 40, 0), (64, 64, False, 1, 30, 2)])
+def test_device_with_known_inputs_matches_the_oracle(d, dy, ptt, C, T, H, monkeypatch):
+    import rxhip
+    rng = np.random.default_rng(17 * d + T)
+    mdl = _models(rng, d, dy, 1)
+    one = tuple(x[0] for x in mdl)
+    cx, cy = rng.standard_normal((T + H, d)), rng.standard_normal((T + H, dy))
+    y = _simulate(rng, mdl, cx[:T], cy[:T], C, ptt)
+    if C % 64 == 0:
+        monkeypatch.setenv("RXHIP_ONE_PASS", "1")
+    with rxhip.LGSSMEngine(*one, T=T, n_chains=C, prior_through_transition=ptt, horizon=H, state_offset=cx, obs_offset=cy) as eng:
+        eng.set_data(y, layout="chain_time")
+        eng.run(2, True)
+        mean, cov = eng.marginals(layout="chain_time")
+        fe = eng.free_energy_per_chain()
+        pm, pc = eng.predictions(layout="chain_time")
+        jm = eng.node_marginals(layout="chain_time")[0] if d <= 4 else None
+        eng.run_filter(False)
+        fm, _ = eng.marginals(layout="chain_time")
+    A, B, P, Q = one[:4]
+    for c in sorted({0, C - 1}):
+        yy = np.vstack([y[c], np.full((H, dy), np.nan)])
+        om, oc, nll = rxo.lgssm_kalman_rts_affine(*one, yy, cx, cy, prior_through_transition=ptt)
+        assert np.allclose(mean[c], om, rtol=1e-6, atol=1e-8) and np.allclose(cov[c], oc, rtol=1e-6, atol=1e-8)
+        assert fe[c] == pytest.approx(nll, rel=1e-8)
+        for t in (0, T // 2, T - 1):   # leave-one-out prediction of y[t]
+            yl = yy.copy()
+            yl[t] = np.nan
+            lm, lc, _ = rxo.lgssm_kalman_rts_affine(*one, yl, cx, cy, prior_through_transition=ptt)
+            assert np.allclose(pm[c, t], B @ lm[t] + cy[t], rtol=1e-6, atol=1e-7)
+            assert np.allclose(pc[c, t], B @ lc[t] @ B.T + Q, rtol=1e-6, atol=1e-7)
+        for t in range(T, T + H):      # forecasts carry the inputs of their time index
+            assert np.allclose(pm[c, t], B @ om[t] + cy[t], rtol=1e-6, atol=1e-8)
+        if jm is not None:
+            for k in (0, T - 2):       # node-local joint of the transition into x[k+1]: mean [m(x[k+1]); A m(x[k]) + c[k+1]]
+                assert np.allclose(jm[c, k], np.concatenate([om[k + 1], A @ om[k] + cx[k + 1]]), rtol=1e-6, atol=1e-8)
+        qm, _, _ = rxo.lgssm_kalman_rts_affine(*one, y[c, :T // 2 + 1], cx[:T // 2 + 1], cy[:T // 2 + 1], prior_through_transition=ptt)
+        assert np.allclose(fm[c, T // 2], qm[-1], rtol=1e-6, atol=1e-8)   # filtering: the smoother of the first half ends there
+
+
+@pytest.mark.gpu
+def test_known_inputs_with_missing_values_per_step_constants_and_device_data():
+    import ctypes
+
+    import rxhip
+    rng = np.random.default_rng(4)
+    d, dy, T, C = 2, 2, 30, 3
+    mdl = _models(rng, d, dy, T)
+    sm = np.arange(T, dtype=np.int32)
+    cx, cy = rng.standard_normal((T, d)), rng.standard_normal((T, dy))
+    y = rng.standard_normal((T, C, dy))
+    y[[4, 9], 1] = np.nan
+    hip = ctypes.CDLL("libamdhip64.so")   # a device buffer of the caller's, without torch
+    yd, back = ctypes.c_void_p(), np.empty_like(y)
+    assert hip.hipMalloc(ctypes.byref(yd), ctypes.c_size_t(y.nbytes)) == 0
+    assert hip.hipMemcpy(yd, y.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(y.nbytes), 1) == 0
+    with rxhip.LGSSMEngine(*mdl, T=T, n_chains=C, step_model=sm, allow_missing=True, state_offset=cx, obs_offset=cy) as eng:
+        eng.set_data_device(yd.value, y.size)   # the engine shifts its own copy: the caller's buffer stays as it is
+        eng.run(1, True)
+        mean, cov = eng.marginals(layout="chain_time")
+        fe = eng.free_energy_per_chain()
+    assert hip.hipMemcpy(back.ctypes.data_as(ctypes.c_void_p), yd, ctypes.c_size_t(y.nbytes), 2) == 0 and hip.hipFree(yd) == 0
+    assert np.array_equal(back, y, equal_nan=True)
+    for c in range(C):
+        om, oc, nll = rxo.lgssm_kalman_rts_affine(*mdl, y[:, c], cx, cy, step_model=sm)
+        assert np.allclose(mean[c], om, rtol=1e-6, atol=1e-8) and np.allclose(cov[c], oc, rtol=1e-6, atol=1e-8)
+        assert fe[c] == pytest.approx(nll, rel=1e-8)
+
+
+@pytest.mark.gpu
+def test_infer_mirror_with_a_constant_drift():
+    import rxhip
+    rng = np.random.default_rng(6)
+    A, B, P, Q = np.eye(2), np.eye(2), np.eye(2) * 0.1, np.eye(2)
+    spec = rxhip.linear_gaussian_ssm(A, B, P, Q, np.zeros(2), np.eye(2) * 10, state_offset=[0.5, -0.25])
+    y = np.cumsum(np.tile([0.5, -0.25], (80, 1)), axis=0) + rng.standard_normal((80, 2))
+    res = rxhip.infer(model=spec, data={"y": y}, free_energy=True)
+    om, oc, nll = rxo.lgssm_kalman_rts_affine(A, B, P, Q, np.zeros(2), np.eye(2) * 10, y, np.tile([0.5, -0.25], (80, 1)), None)
+    assert np.allclose(res.posteriors["x"].mean, om, rtol=1e-6, atol=1e-8) and res.free_energy[-1] == pytest.approx(nll, rel=1e-8)
