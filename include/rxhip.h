@@ -195,6 +195,9 @@ typedef struct {
     double* c;             /* [d] drift (nullable); zero unless deterministic */
     int32_t n_models;      /* distinct (A, P, B, Q) along the chain: per-step constants `A[t] * x[t-1]`, `Σ = P[t]`, … */
     int32_t* step_model;   /* [T] model of time index t (nullable; all zero when n_models = 1) */
+    int32_t has_offsets;   /* 1: some mean carries a `+` with a constant (known inputs) */
+    double* state_offset;  /* [T][d]  c[t] of `A * x[t-1] + c[t]` (nullable; zeros where a step has none) */
+    double* obs_offset;    /* [T][dy] d[t] of `B * x[t] + d[t]` (nullable) */
 } rxhip_lgssm_lowered;
 
 /* Host-only (no device needed): recognise a linear Gaussian state-space chain in `g` — MvNormalMeanCovariance or (scalar

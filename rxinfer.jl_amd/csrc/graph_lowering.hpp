@@ -38,6 +38,7 @@ struct Lgssm {
     std::vector<long long> state_var, data_var;
     int n_models = 1;
     std::vector<int> step_model;  // [T] when n_models > 1: the constants of time index t (per-step A[t], P[t], B[t], Q[t])
+    std::vector<double> cx, cy;   // known inputs [T][d] / [T][dy] (`A * x[t-1] + c`, `B * x[t] + d`); empty: none
 };
 
 // interface k of factor f / number of interfaces (3-wide table or CSR)
@@ -116,15 +117,16 @@ inline bool same_const(const rxhip_graph_desc* g, long long a, long long b) {
 // (`y ~ MvNormal(μ = B * x, Σ = Q)`, `x ~ Normal(μ = x_prev, v = …)` and their mixtures); constants that differ from step to
 // step (`A[t] * x[t-1]`, `Σ = P[t]`) are grouped into models by value (Lgssm::step_model).  Also the noise-free drift chain of test/models/statespace/ulgssm_tests.jl:8-15,
 //     x[t] ~ x[t-1] + c        `+`(out = x_next, in1 = x, in2 = c const)  (or in1 const)
-// whose every transition is such a node.  Node order in the tables is irrelevant.
+// whose every transition is such a node.  A `+` with a constant IN FRONT of a Gaussian mean (`A * x[t-1] + c`, `B * x[t] + d`,
+// `x[t-1] + c` with state noise) is a known input of that time index (Lgssm::cx / cy).  Node order in the tables is irrelevant.
 inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
     if (rxhip_status st = check_tables(g)) return st;
     const long long NV = g->n_variables, NF = g->n_factors;
     for (long long f = 0; f < NF; ++f)
         if (n_iface(g, f) != 3) return unsupported("node with " + std::to_string(n_iface(g, f)) + " interfaces in a state-space chain");
     // `*` node producing each (anonymous) variable; Gaussian node by its μ variable; `+` nodes by their random input
-    std::vector<long long> mul_of_out(NV, -1), add_of_in(NV, -1), writer(NV, -1);
-    std::vector<std::vector<long long>> mul_of_in(NV), gauss_by_mu(NV);
+    std::vector<long long> mul_of_out(NV, -1), add_of_out(NV, -1), writer(NV, -1);
+    std::vector<std::vector<long long>> mul_of_in(NV), gauss_by_mu(NV), add_of_in(NV);
     long long prior = -1;
     bool scalar_nodes = false;
     auto writes = [&](long long v, long long f) -> bool {  // one factor "produces" a variable: rejects merges and cycles early
@@ -159,16 +161,19 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
             if (c1 == c2) return unsupported("`+` node needs exactly one constant input");
             const long long xin = c1 ? io[2] : io[1];
             if (g->var_kind[xin] != RXHIP_VARKIND_RANDOM || g->var_kind[io[0]] != RXHIP_VARKIND_RANDOM) return unsupported("`+` node must connect two random variables");
-            if (add_of_in[xin] >= 0) return unsupported("state with two `+` transitions: not a chain");
             if (!writes(io[0], f)) return unsupported("random variable that is the output of two nodes: not a chain");
-            add_of_in[xin] = f;
+            add_of_in[xin].push_back(f);
+            add_of_out[io[0]] = f;
         } else
             return unsupported("node type " + std::to_string(t) + " has no device schedule");
     }
     if (prior < 0) return unsupported("no prior node (Gaussian node with constant mean)");
-    for (long long v = 0; v < NV; ++v)
-        if (mul_of_out[v] >= 0 && gauss_by_mu[v].size() != 1)
-            return unsupported(gauss_by_mu[v].empty() ? "`*` node whose output feeds no Gaussian mean" : "mean variable shared by two Gaussian nodes");
+    // an anonymous `A * x` feeds exactly one consumer: a Gaussian mean, or a `+` with a constant (known input) in front of one
+    for (long long v = 0; v < NV; ++v) {
+        if (mul_of_out[v] >= 0 && gauss_by_mu[v].size() + add_of_in[v].size() != 1)
+            return unsupported(gauss_by_mu[v].empty() && add_of_in[v].empty() ? "`*` node whose output feeds no Gaussian mean" : "mean variable shared by two nodes");
+        if (add_of_out[v] >= 0 && gauss_by_mu[v].size() > 1) return unsupported("mean variable shared by two Gaussian nodes");
+    }
     long long x = iface(g, prior, 0);
     if (g->var_kind[x] != RXHIP_VARKIND_RANDOM) return unsupported("prior node on a non-random variable");
     const int d = g->var_rows[x];
@@ -177,10 +182,10 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
     if (!const_value(g, iface(g, prior, 1), d, 1, &m0) || !const_value(g, iface(g, prior, 2), d, d, &V0))
         return badarg("prior constants have the wrong shape");
     // a branch out of state x: the Gaussian node it feeds and the constant matrix in between (-1: identity)
-    struct Branch { long long gauss, matrix; };
+    struct Branch { long long gauss, matrix, offset; };  // offset: the constant of a `+` node in front of the Gaussian mean (-1: none)
     long long vA = -2, vB = -2, vC = -1;  // -2: not seen yet, -1: identity
     constexpr long long NONE = -3;                           // no transition into this time index (t = 1 of a chain whose prior sits on x[1])
-    std::vector<long long> sA, sP, sB, sQ;                   // per time index: the constant variables of its transition / observation
+    std::vector<long long> sA, sP, sB, sQ, sCx, sCy;         // per time index: the constant variables of its transition / observation
     int n_noisy = 0, n_det = 0;
     long long used_factors = 1;
     bool first = true;
@@ -191,27 +196,57 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         visited[x] = 1;
         std::vector<Branch> br;
         if (mul_of_out[x] >= 0) return unsupported("the output of a `*` node used as a state");
-        for (long long f : mul_of_in[x]) br.push_back({gauss_by_mu[iface(g, f, 0)][0], iface(g, f, 1)});
-        for (long long gn : gauss_by_mu[x]) br.push_back({gn, -1});  // Gaussian nodes reading the state directly (A, B = I)
-        long long obs = -1, obs_m = -1, tr = -1, tr_m = -1;
+        auto add_const = [&](long long f) { return g->var_kind[iface(g, f, 1)] == RXHIP_VARKIND_CONST ? iface(g, f, 1) : iface(g, f, 2); };
+        long long add = -1;  // a `+` whose output is the next STATE: the noise-free drift transition
+        for (long long f : mul_of_in[x]) {
+            const long long v = iface(g, f, 0);
+            if (!add_of_in[v].empty()) {  // A * x + c
+                const long long a = add_of_in[v][0], w = iface(g, a, 0);
+                if (gauss_by_mu[w].empty()) return unsupported("`A * x + c` that feeds no Gaussian mean");
+                br.push_back({gauss_by_mu[w][0], iface(g, f, 1), add_const(a)});
+                used_factors += 1;
+            } else
+                br.push_back({gauss_by_mu[v][0], iface(g, f, 1), -1});
+        }
+        for (long long gn : gauss_by_mu[x]) br.push_back({gn, -1, -1});  // Gaussian nodes reading the state directly (A, B = I)
+        bool onward = false;  // a transition out of x other than through a `+`
+        for (const Branch& b : br) onward = onward || g->var_kind[iface(g, b.gauss, 0)] == RXHIP_VARKIND_RANDOM;
+        for (long long a : add_of_in[x]) {
+            // x + c is either an anonymous mean (a known input of a transition / an observation with A or B = I) or the NEXT
+            // STATE of a noise-free drift chain, which is observed through a Gaussian node of its own
+            const long long w = iface(g, a, 0);
+            const bool continues = !mul_of_in[w].empty() || !add_of_in[w].empty();
+            const bool one_gauss = gauss_by_mu[w].size() == 1;
+            const bool to_random = one_gauss && g->var_kind[iface(g, gauss_by_mu[w][0], 0)] == RXHIP_VARKIND_RANDOM;
+            const bool to_data = one_gauss && g->var_kind[iface(g, gauss_by_mu[w][0], 0)] == RXHIP_VARKIND_DATA;
+            if (!continues && (to_random || (to_data && (onward || n_noisy > 0)))) {
+                br.push_back({gauss_by_mu[w][0], -1, add_const(a)});
+                used_factors += 1;
+                onward = onward || to_random;
+            } else {
+                if (add >= 0) return unsupported("state with two `+` transitions: not a chain");
+                add = a;
+            }
+        }
+        long long obs = -1, obs_m = -1, obs_c = -1, tr = -1, tr_m = -1, tr_c = -1;
         for (const Branch& b : br) {
             const long long target = iface(g, b.gauss, 0);
             if (g->var_kind[target] == RXHIP_VARKIND_DATA) {
                 if (obs >= 0) return unsupported("state with two observation branches");
-                obs = b.gauss; obs_m = b.matrix;
+                obs = b.gauss; obs_m = b.matrix; obs_c = b.offset;
             } else {
                 if (tr >= 0) return unsupported("state with two transitions: not a chain");
-                tr = b.gauss; tr_m = b.matrix;
+                tr = b.gauss; tr_m = b.matrix; tr_c = b.offset;
             }
             used_factors += b.matrix >= 0 ? 2 : 1;
         }
-        const long long add = add_of_in[x];
         if (add >= 0 && tr >= 0) return unsupported("state with two transitions: not a chain");
         if (obs >= 0) {
             const long long q = iface(g, obs, 2);
             if (vB == -2) vB = obs_m;
             sB.push_back(obs_m);
             sQ.push_back(q);
+            sCy.push_back(obs_c);
             L.state_var.push_back(x);
             L.data_var.push_back(iface(g, obs, 0));
         } else if (first && (tr >= 0 || add >= 0)) {
@@ -226,10 +261,12 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
             sP.resize(L.state_var.size() + 1, NONE);
             sA.back() = tr_m;
             sP.back() = pv;
+            sCx.resize(L.state_var.size() + 1, -1);
+            sCx.back() = tr_c;
             ++n_noisy;
             x = iface(g, tr, 0);
         } else if (add >= 0) {
-            const long long cv = g->var_kind[iface(g, add, 1)] == RXHIP_VARKIND_CONST ? iface(g, add, 1) : iface(g, add, 2);
+            const long long cv = add_const(add);
             if (vC < 0) vC = cv;
             else if (!same_const(g, vC, cv)) return unsupported("time-varying drift");
             ++n_det;
@@ -305,6 +342,29 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         }
         by_id.emplace(ids, mdl);
         step[t] = mdl;
+    }
+    // known inputs of every time index
+    sCx.resize((size_t)T, -1);
+    bool any_cx = false, any_cy = false;
+    for (long long t = 0; t < T; ++t) {
+        any_cx = any_cx || sCx[t] >= 0;
+        any_cy = any_cy || sCy[t] >= 0;
+    }
+    if (any_cx || any_cy) {
+        if (n_det > 0) return unsupported("noise-free `+` chain with further offsets");
+        L.cx.assign((size_t)T * d, 0.0);
+        L.cy.assign((size_t)T * dy, 0.0);
+        for (long long t = 0; t < T; ++t) {
+            const double* q;
+            if (sCx[t] >= 0) {
+                if (!const_value(g, sCx[t], d, 1, &q)) return badarg("state offset has the wrong shape");
+                std::memcpy(&L.cx[(size_t)t * d], q, sizeof(double) * d);
+            }
+            if (sCy[t] >= 0) {
+                if (!const_value(g, sCy[t], dy, 1, &q)) return badarg("observation offset has the wrong shape");
+                std::memcpy(&L.cy[(size_t)t * dy], q, sizeof(double) * dy);
+            }
+        }
     }
     L.n_models = (int)by_value.size();
     if (L.n_models > 1) {

@@ -2292,6 +2292,9 @@ rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowe
     out->d = L.d; out->dy = L.dy; out->T = L.T; out->prior_through_transition = L.ptt;
     out->deterministic = L.deterministic;
     out->n_models = L.n_models;
+    out->has_offsets = L.cx.empty() ? 0 : 1;
+    if (out->state_offset) for (size_t q = 0; q < (size_t)L.T * L.d; ++q) out->state_offset[q] = L.cx.empty() ? 0.0 : L.cx[q];
+    if (out->obs_offset) for (size_t q = 0; q < (size_t)L.T * L.dy; ++q) out->obs_offset[q] = L.cy.empty() ? 0.0 : L.cy[q];
     if (out->step_model) for (long long t = 0; t < L.T; ++t) out->step_model[t] = L.n_models > 1 ? L.step_model[t] : 0;
     if (out->c) std::memcpy(out->c, L.c.data(), L.c.size() * sizeof(double));
     auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
@@ -2409,6 +2412,7 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
     d.A = L.A.data(); d.B = L.B.data(); d.P = L.P.data(); d.Q = L.Q.data();
     d.m0 = L.n_models > 1 ? m0s.data() : L.m0.data(); d.V0 = L.n_models > 1 ? V0s.data() : L.V0.data();
     d.allow_missing = g->allow_missing;
+    if (!L.cx.empty()) { d.state_offset = L.cx.data(); d.obs_offset = L.cy.data(); }
     d.segments = segments; d.device = device; d.stream = stream;
     return rxhip_lgssm_create(&d, out);
 }

@@ -52,7 +52,8 @@ class LgssmLowered(ctypes.Structure):
     _fields_ = [("d", ctypes.c_int32), ("dy", ctypes.c_int32), ("T", ctypes.c_int64),
                 ("prior_through_transition", ctypes.c_int32), ("A", c_double_p), ("B", c_double_p), ("P", c_double_p),
                 ("Q", c_double_p), ("m0", c_double_p), ("V0", c_double_p), ("state_var", c_int64_p), ("data_var", c_int64_p),
-                ("deterministic", ctypes.c_int32), ("c", c_double_p), ("n_models", ctypes.c_int32), ("step_model", c_int32_p)]
+                ("deterministic", ctypes.c_int32), ("c", c_double_p), ("n_models", ctypes.c_int32), ("step_model", c_int32_p),
+                ("has_offsets", ctypes.c_int32), ("state_offset", c_double_p), ("obs_offset", c_double_p)]
 
 
 class GmmLowered(ctypes.Structure):

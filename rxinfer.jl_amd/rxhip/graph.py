@@ -175,7 +175,8 @@ class GraphBuilder:
         return g, arrs
 
 
-def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=None, P_of_t=None, B_of_t=None, Q_of_t=None):
+def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=None, P_of_t=None, B_of_t=None, Q_of_t=None,
+                c_of_t=None, d_of_t=None, const_first=False):
     """The graph GraphPPL builds for the benchmark notebook's model (cell 4) / mlgssm_test.jl:9-17.  X_of_t(t): the constant
     of time index t when the @model loop indexes an array of matrices (`A[t] * x[t-1]`, `Σ = P[t]`, …)."""
     A, B = np.asarray(A, float), np.asarray(B, float)
@@ -188,11 +189,19 @@ def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=No
         if t > 0 or prior_through_transition:
             a = gb.randomvar(d)
             gb.multiply(a, gb.constvar(A if A_of_t is None else A_of_t(t)), x)
+            if c_of_t is not None and c_of_t(t) is not None:   # `A * x[t-1] + c[t]`: a known input
+                w = gb.randomvar(d)
+                gb.node(_lib.NODE_ADD, w, *((gb.constvar(c_of_t(t)), a) if const_first else (a, gb.constvar(c_of_t(t)))))
+                a = w
             xn = gb.randomvar(d)
             gb.mvnormal_mean_cov(xn, a, gb.constvar(P if P_of_t is None else P_of_t(t)))
             x = xn
         b = gb.randomvar(dy)
         gb.multiply(b, gb.constvar(B if B_of_t is None else B_of_t(t)), x)
+        if d_of_t is not None and d_of_t(t) is not None:       # `B * x[t] + d[t]`
+            w = gb.randomvar(dy)
+            gb.node(_lib.NODE_ADD, w, b, gb.constvar(d_of_t(t)))
+            b = w
         y = gb.datavar(dy)
         gb.mvnormal_mean_cov(y, b, gb.constvar(Q if Q_of_t is None else Q_of_t(t)))
         xs.append(x); ys.append(y)
@@ -257,6 +266,7 @@ def lower_lgssm(g):
     bufs = dict(A=np.empty((M, d, d)), B=np.empty((M, dy, d)), P=np.empty((M, d, d)), Q=np.empty((M, dy, dy)), m0=np.empty(d),
                 V0=np.empty((d, d)), c=np.empty(d))
     sv, dv, sm = np.empty(T, dtype=np.int64), np.empty(T, dtype=np.int64), np.empty(T, dtype=np.int32)
+    bufs["state_offset"], bufs["obs_offset"] = np.empty((T, d)), np.empty((T, dy))
     for k, v in bufs.items():
         setattr(out, k, v.ctypes.data_as(_lib.c_double_p))
     out.state_var = sv.ctypes.data_as(_lib.c_int64_p)
@@ -269,7 +279,7 @@ def lower_lgssm(g):
         for k in "ABPQ":
             bufs[k] = bufs[k][0]
     return dict(d=d, dy=dy, T=T, prior_through_transition=bool(out.prior_through_transition), deterministic=bool(out.deterministic),
-                state_var=sv, data_var=dv, n_models=M, step_model=sm if M > 1 else None, **bufs)
+                state_var=sv, data_var=dv, n_models=M, step_model=sm if M > 1 else None, has_offsets=bool(out.has_offsets), **bufs)
 
 
 def create_engine_from_graph(g, segments=0, device=-1, stream=None):

@@ -114,7 +114,7 @@ def test_known_inputs_with_missing_values_per_step_constants_and_device_data():
     cx, cy = rng.standard_normal((T, d)), rng.standard_normal((T, dy))
     y = rng.standard_normal((T, C, dy))
     y[[4, 9], 1] = np.nan
-    hip = ctypes.CDLL("libamdhip64.so")   # a device buffer of the caller's, without torch
+    hip = ctypes.CDLL("/opt/rocm/lib/libamdhip64.so")   # the runtime librxhip uses (torch, if loaded, carries its own copy)
     yd, back = ctypes.c_void_p(), np.empty_like(y)
     assert hip.hipMalloc(ctypes.byref(yd), ctypes.c_size_t(y.nbytes)) == 0
     assert hip.hipMemcpy(yd, y.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(y.nbytes), 1) == 0
@@ -141,3 +141,66 @@ def test_infer_mirror_with_a_constant_drift():
     res = rxhip.infer(model=spec, data={"y": y}, free_energy=True)
     om, oc, nll = rxo.lgssm_kalman_rts_affine(A, B, P, Q, np.zeros(2), np.eye(2) * 10, y, np.tile([0.5, -0.25], (80, 1)), None)
     assert np.allclose(res.posteriors["x"].mean, om, rtol=1e-6, atol=1e-8) and res.free_energy[-1] == pytest.approx(nll, rel=1e-8)
+
+
+# ---------------------------------------------------------------------------------------------------------------- graphs
+def test_plus_nodes_in_front_of_gaussian_means_lower_to_known_inputs():
+    import rxhip  # noqa: F401
+    from rxhip import _lib, graph
+    rng = np.random.default_rng(2)
+    d, dy, T = 3, 2, 7
+    mdl = _models(rng, d, dy, 1)
+    A, B, P, Q, m0, V0 = (x[0] for x in mdl)
+    cx, cy = rng.standard_normal((T, d)), rng.standard_normal((T, dy))
+    for ptt, const_first in ((False, False), (True, True)):
+        gb, xs, ys = graph.lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=ptt, const_first=const_first,
+                                       c_of_t=lambda t: cx[t] if t % 2 == 0 else None,   # every other transition has an input
+                                       d_of_t=lambda t: cy[t])
+        low = graph.lower_lgssm(gb.tables(permute=rng.permutation(len(gb.ftype)))[0])
+        assert low["has_offsets"] and low["n_models"] == 1 and low["T"] == T
+        for t in range(T):
+            want = cx[t] if (t % 2 == 0 and (t > 0 or ptt)) else np.zeros(d)
+            assert np.array_equal(low["state_offset"][t], want) and np.array_equal(low["obs_offset"][t], cy[t])
+        assert np.array_equal(low["A"], A) and list(low["data_var"]) == ys
+    # the scalar random walk with drift and state noise, no `*` node: x[t] ~ Normal(mean = x[t-1] + c, var = p)
+    gb = graph.GraphBuilder()
+    x = gb.randomvar(1)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, x, gb.constvar(0.0), gb.constvar(4.0))
+    for t in range(5):
+        if t:
+            w, xn = gb.randomvar(1), gb.randomvar(1)
+            gb.node(_lib.NODE_ADD, w, x, gb.constvar(0.3))
+            gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, xn, w, gb.constvar(0.1))
+            x = xn
+        gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, gb.datavar(1), x, gb.constvar(1.0))
+    low = graph.lower_lgssm(gb.tables()[0])
+    assert not low["deterministic"] and low["has_offsets"] and np.allclose(low["state_offset"][1:, 0], 0.3) and low["state_offset"][0, 0] == 0.0
+    assert low["A"][0, 0] == 1.0 and low["P"][0, 0] == 0.1
+    # …and the noise-free drift chain of ulgssm_tests.jl stays what it was
+    gb, xs, ys = graph.drift_chain_graph(6, 0.0, 100.0, 1.0, 1.0)
+    low = graph.lower_lgssm(gb.tables()[0])
+    assert low["deterministic"] and not low["has_offsets"]
+
+
+@pytest.mark.gpu
+def test_graph_with_known_inputs_runs_on_the_device():
+    import rxhip  # noqa: F401
+    from rxhip import graph
+    rng = np.random.default_rng(11)
+    d, dy, T, C = 2, 2, 40, 3
+    mdl = _models(rng, d, dy, 1)
+    A, B, P, Q, m0, V0 = (x[0] for x in mdl)
+    cx, cy = rng.standard_normal((T, d)), rng.standard_normal((T, dy))
+    y = _simulate(rng, mdl, cx, cy, C, True)
+    gb, xs, ys = graph.lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=True, c_of_t=lambda t: cx[t], d_of_t=lambda t: cy[t])
+    g, keep = gb.tables(n_replicas=C, permute=rng.permutation(len(gb.ftype)))
+    eng = graph.create_engine_from_graph(g)
+    eng.set_data(y, layout="chain_time")
+    eng.run(1, True)
+    mean, cov = eng.marginals(layout="chain_time")
+    fe = eng.free_energy_per_chain()
+    eng.close()
+    for c in range(C):
+        om, oc, nll = rxo.lgssm_kalman_rts_affine(A, B, P, Q, m0, V0, y[c], cx, cy, prior_through_transition=True)
+        assert np.allclose(mean[c], om, rtol=1e-6, atol=1e-8) and np.allclose(cov[c], oc, rtol=1e-6, atol=1e-8)
+        assert fe[c] == pytest.approx(nll, rel=1e-8)
