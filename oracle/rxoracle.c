@@ -867,8 +867,8 @@ int rxo_lgssm_predict(int d, int dy, int T, int H, const double* A, const double
  * ------------------------------------------------------------------------------------------ */
 /* offsets (known inputs): x[t] ~ N(A x[t-1] + cx[t], P), y[t] ~ N(B x[t] + cy[t], Q); NULL = none.  cx[0] enters only
    through the prior's transition (ptt). */
-static const double* g_cx = NULL; /* [T][d]  */
-static const double* g_cy = NULL; /* [T][dy] */
+static __thread const double* g_cx = NULL; /* [T][d]  */
+static __thread const double* g_cy = NULL; /* [T][dy] */
 static int kalman_rts_impl(int d, int dy, int T, const double* A0, const double* B0, const double* P0,
                            const double* Q0, const double* m00, const double* V00, const int* sm, int ptt, const double* y,
                            double* post_mean, double* post_cov, double* neg_loglik) {
