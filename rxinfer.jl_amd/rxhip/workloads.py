@@ -60,10 +60,10 @@ def generate_batch(model, T, n_chains, seed0=42, threads=None):
     x = np.empty((T, n_chains, d))
     wy = np.empty((T, n_chains, dy))
 
-    def draw(c):
-        rng = np.random.default_rng(seed0 + c)
-        x[:, c, :] = rng.standard_normal((T, d)) @ Lp.T
-        wy[:, c, :] = rng.standard_normal((T, dy)) @ Lq.T
+    def draw(c):  # standard normals only: no BLAS call inside the pool (concurrent matmuls from Python threads returned
+        rng = np.random.default_rng(seed0 + c)  # different data from run to run with this numpy build)
+        x[:, c, :] = rng.standard_normal((T, d))
+        wy[:, c, :] = rng.standard_normal((T, dy))
 
     nthr = threads or min(32, os.cpu_count() or 1, n_chains)
     if nthr > 1:
@@ -72,6 +72,8 @@ def generate_batch(model, T, n_chains, seed0=42, threads=None):
     else:
         for c in range(n_chains):
             draw(c)
+    x = (x.reshape(-1, d) @ Lp.T).reshape(T, n_chains, d)      # w_t = L_P ε,  v_t = L_Q ε'
+    wy = (wy.reshape(-1, dy) @ Lq.T).reshape(T, n_chains, dy)
     At = np.ascontiguousarray(A.T)
     for t in range(1, T):  # x_t = A x_{t-1} + w_t for every chain (x_0 = 0, as the notebook's generate_data)
         x[t] += x[t - 1] @ At

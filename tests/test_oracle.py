@@ -135,3 +135,14 @@ def test_multivariate_mixture_oracle_on_the_reference_layout():
     for k in range(K):
         assert np.max(np.abs(np.linalg.inv(u["nu"][k] * u["V"][k]) - covs[k])) < 6.0
     assert np.mean(np.argmax(resp, axis=1) == zs) > 0.99 and abs(u["alpha"].sum() - (N + K)) < 1e-9
+
+
+def test_batch_generator_is_the_per_chain_generator_and_reproducible():
+    """chain c of the C2 batch is the notebook's generative loop on default_rng(42 + c) — whatever the thread pool does."""
+    from rxhip import workloads
+    mdl = workloads.c1_model()
+    a = workloads.generate_batch(mdl, 3000, 96, seed0=42)
+    b = workloads.generate_batch(mdl, 3000, 96, seed0=42)
+    assert np.array_equal(a, b)
+    for c in (0, 17, 95):
+        assert np.allclose(a[:, c], workloads.generate_chain(mdl, 3000, 42 + c)[1], rtol=0, atol=1e-11)
