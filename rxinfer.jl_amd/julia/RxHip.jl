@@ -344,7 +344,10 @@ mutable struct LgssmLowered
     c::Ptr{Float64}
     n_models::Int32
     step_model::Ptr{Int32}
-    LgssmLowered() = new(0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, 0, C_NULL)
+    has_offsets::Int32
+    state_offset::Ptr{Float64}
+    obs_offset::Ptr{Float64}
+    LgssmLowered() = new(0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, 0, C_NULL, 0, C_NULL, C_NULL)
 end
 
 """The engine's stream: `nothing` (engine-owned) or an AMDGPU.jl stream, whose raw `hipStream_t` is handed over so that the
