@@ -288,6 +288,16 @@ rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_f
  * reference's `free_energy_history` holds for a streaming run (src/score/actor.jl:98-104);
  * rxhip_get_free_energy_per_chain the per-chain means.  LGSSM engines only. */
 rxhip_status rxhip_run_filter(rxhip_engine* e, int32_t want_free_energy);
+
+/* The same driver ONE OBSERVATION AT A TIME — what `RxInferenceEngine` does with an unbounded datastream
+ * (src/inference/streaming.jl:349-407: `on_next!` pushes the datum, the one-step graph fires, `@autoupdates` turns the posterior
+ * into the next prior): y holds the new observation of every chain, [chains][dy] on the host (NaN = `missing`: the belief is
+ * propagated only); mean [chains][d], cov [chains][d][d] and free_energy [chains] (−log p(y_k | y_<k); any of the three may be
+ * NULL) receive the posterior after this observation.  The belief stays on the device between calls; the first call after
+ * creation or rxhip_filter_reset starts from the prior.  Per-step constants (step_model) and known inputs are indexed by the
+ * number of observations seen (streams longer than the engine's T + horizon need a time-invariant model).  d, dy ≤ 4. */
+rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, double* cov, double* free_energy);
+rxhip_status rxhip_filter_reset(rxhip_engine* e);
 rxhip_status rxhip_run_filter_async(rxhip_engine* e, int32_t want_free_energy);
 /* waits for the engine's stream and collects device-side diagnostics (status as rxhip_run) */
 rxhip_status rxhip_sync(rxhip_engine* e);

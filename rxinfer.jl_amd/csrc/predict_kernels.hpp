@@ -241,4 +241,77 @@ __global__ __launch_bounds__(256) void k_joint(PredictParams p) {
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
 }
 
+
+// One step of the streaming driver (src/inference/streaming.jl:349-407 with `@autoupdates`: every new observation fires the
+// one-step graph and the posterior becomes the next prior): the belief of every chain lives in `state`, one thread per chain.
+//   prior (first step) or `*`_A(:out) -> [+ c_k] -> MvN_x(:out), then the product with the observation message of y (missing: none)
+// `k` counts the observations of the stream; per-step constants and known inputs are indexed by it.
+struct StreamParams {
+    long long n_chains, k;
+    int ptt, first;          // first: the belief is the prior (through its transition when ptt)
+    const double* y;         // [chain][DY]  (device)
+    double* state;           // [chain][D + NS]  belief q(x) after the last step
+    const double* cst;
+    const int* chain_model;
+    const int* step_model;   // null, or model of observation k (k < its length)
+    const double *cx, *cy;   // null, or known inputs [·][D], [·][DY] of observation k
+    double* mean;            // [chain][D]
+    double* cov;             // [chain][D][D]
+    double* fe;              // [chain]  −log p(y_k | y_<k), or null
+    int* status;
+};
+template <int D, int DY>
+__global__ __launch_bounds__(64) void k_stream_step(StreamParams p) {
+    using CL = CstLayout<D, DY>;
+    constexpr int NS = Dim<D>::NS;
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.n_chains) return;
+    const int mdl = p.step_model ? p.step_model[p.k] : p.chain_model ? p.chain_model[c] : 0;
+    const double* cst = p.cst + (size_t)mdl * CL::SIZE;
+    double m[D], mp[D], yv[DY];
+    Sym<D> V, Vp;
+    double* st = p.state + c * (D + NS);
+    if (p.first) {  // CL::M1 / V1 hold the prior already pushed through its transition when ptt
+#pragma unroll
+        for (int i = 0; i < D; ++i) mp[i] = cst[CL::M1 + i] + ((p.ptt && p.cx) ? p.cx[p.k * D + i] : 0.0);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) Vp.v[i] = cst[CL::V1 + i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < D; ++i) m[i] = st[i];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) V.v[i] = st[D + i];
+        double T[D][D];
+        matvec_c<D>(CPtr{cst + CL::A}, m, mp);
+        if (p.cx) {
+#pragma unroll
+            for (int i = 0; i < D; ++i) mp[i] += p.cx[p.k * D + i];
+        }
+        predict_cov<D>(CPtr{cst + CL::A}, CPtr{cst + CL::P}, V, T, Vp);
+    }
+    bool miss = false;
+#pragma unroll
+    for (int a = 0; a < DY; ++a) {
+        yv[a] = p.y[c * DY + a];
+        miss = miss || (yv[a] != yv[a]);
+        if (p.cy) yv[a] -= p.cy[p.k * DY + a];
+    }
+    bool ok = true;
+    double quad = 0.0, detprod = 1.0;
+    obs_update<D, DY, true, true>(CPtr{cst}, mp, Vp, yv, m, V, ok, quad, detprod, miss);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        st[i] = m[i];
+        p.mean[c * D + i] = m[i];
+    }
+#pragma unroll
+    for (int i = 0; i < NS; ++i) st[D + i] = V.v[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) p.cov[(c * D + i) * D + j] = V(i, j);
+    if (p.fe) p.fe[c] = miss ? 0.0 : 0.5 * (quad + log(detprod));
+    if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
 }  // namespace rxhip

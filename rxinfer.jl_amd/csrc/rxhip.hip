@@ -56,6 +56,7 @@ struct LgssmVtbl {
     void (*forecast)(const PredictParams&, hipStream_t);
     void (*predict)(const PredictParams&, hipStream_t);
     void (*joint)(const PredictParams&, hipStream_t);
+    void (*stream_step)(const StreamParams&, hipStream_t);
 };
 
 static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
@@ -158,6 +159,9 @@ struct Launch {
         const long long nb = ((p.T - 1) * p.n_chains + 255) / 256;
         hipLaunchKernelGGL((k_joint<D, DY>), dim3((unsigned)(nb < 8192 ? (nb > 0 ? nb : 1) : 8192)), dim3(256), 0, s, p);
     }
+    static void stream_step(const StreamParams& p, hipStream_t s) {
+        hipLaunchKernelGGL((k_stream_step<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
+    }
     static LgssmVtbl vtbl() {
         using TL = TabLayout<D, DY>;
         using AL = AggLayout<D>;
@@ -192,6 +196,7 @@ struct Launch {
         v.forecast = &Launch::forecast;
         v.predict = &Launch::predict;
         v.joint = &Launch::joint;
+        v.stream_step = &Launch::stream_step;
         return v;
     }
 };
@@ -324,8 +329,11 @@ struct rxhip_engine {
     bool sequential = false;  // no per-position tables: missing observations / per-step constants (per-chain records; the segment
                               // elements are computed in the lane, k_seg_elements, or the chain is ONE segment)
     double* d_elemx = nullptr;
-    double *d_mu = nullptr, *d_nu = nullptr, *d_cx = nullptr;  // known inputs: μ[t] [Tout][d], ν[t] = B μ[t] + d[t] [Tout][dy], c[t]
-    std::vector<double> h_mu, h_nu, h_cx;
+    double* h_stream = nullptr;   // its pinned host staging block
+    double* d_stream = nullptr;   // rxhip_filter_step: belief per chain | staging of y, mean, cov, fe (allocated on first use)
+    long long stream_k = 0;
+    double *d_mu = nullptr, *d_nu = nullptr, *d_cx = nullptr, *d_cy_raw = nullptr;  // known inputs: μ[t] [Tout][d], ν[t] = B μ[t] + d[t] [Tout][dy], c[t], d[t]
+    std::vector<double> h_mu, h_nu, h_cx, h_cy;
     std::vector<double> h_user;  // MFMA path: user-level A | P | B | Q | Q⁻¹ of every model (generic_kernels.hpp)
     double* d_user = nullptr;
     int* d_step_model = nullptr;
@@ -1418,6 +1426,8 @@ static void free_all(rxhip_engine* e) {
         if (*b) { if (!e->in_arena(*b)) (void)hipFree(*b); *b = nullptr; }
     if (e->d_coll) { (void)hipFree(e->d_coll); e->d_coll = nullptr; }
     if (e->d_bq) { (void)hipFree(e->d_bq); e->d_bq = nullptr; }
+    if (e->d_stream) { (void)hipFree(e->d_stream); e->d_stream = nullptr; }
+    if (e->h_stream) { (void)hipHostFree(e->h_stream); e->h_stream = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     e->pending.clear();
@@ -1512,6 +1522,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->h_nu.assign(To * dy, 0.0);
         e->h_cx.assign(To * d, 0.0);
         if (ds->state_offset) std::memcpy(e->h_cx.data(), ds->state_offset, sizeof(double) * To * d);
+        e->h_cy.assign(To * dy, 0.0);
+        if (ds->obs_offset) std::memcpy(e->h_cy.data(), ds->obs_offset, sizeof(double) * To * dy);
         for (size_t t = 0; t < To; ++t) {
             const size_t mdl = ds->step_model ? (size_t)ds->step_model[t] : 0;
             const double *A = ds->A + mdl * d * d, *B = ds->B + mdl * dy * d;
@@ -1743,6 +1755,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             ap.upload(&e->d_mu, e->h_mu.data(), sizeof(double) * e->h_mu.size());
             ap.upload(&e->d_nu, e->h_nu.data(), sizeof(double) * e->h_nu.size());
             ap.upload(&e->d_cx, e->h_cx.data(), sizeof(double) * e->h_cx.size());
+            ap.upload(&e->d_cy_raw, e->h_cy.data(), sizeof(double) * e->h_cy.size());
         }
         ap.plain(&e->d_mean, sizeof(double) * (size_t)e->Tout() * CU * Du);
         ap.plain(&e->d_cov, sizeof(double) * (size_t)e->Tout() * CU * Du * Du);
@@ -1788,6 +1801,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.upload(&e->d_mu, e->h_mu.data(), sizeof(double) * e->h_mu.size());
         ap.upload(&e->d_nu, e->h_nu.data(), sizeof(double) * e->h_nu.size());
         ap.upload(&e->d_cx, e->h_cx.data(), sizeof(double) * e->h_cx.size());
+        ap.upload(&e->d_cy_raw, e->h_cy.data(), sizeof(double) * e->h_cy.size());
     }
     if (e->uniform && !scan.empty()) ap.upload(&e->d_scan, scan.data(), sizeof(double) * scan.size());
     if (e->fused) {
@@ -2522,6 +2536,44 @@ rxhip_status rxhip_run_filter_async(rxhip_engine* e, int32_t want_fe) {
     if (!e) return RXHIP_ERR_BADARG;
     if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "run_filter: not a state-space engine with a streaming twin (the HGF engine is a filter already)");
     return run_impl(e, 1, want_fe, true);
+}
+rxhip_status rxhip_filter_reset(rxhip_engine* e) {
+    if (!e || e->kind != 0) return RXHIP_ERR_BADARG;
+    e->stream_k = 0;
+    return RXHIP_OK;
+}
+rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, double* cov, double* free_energy) {
+    if (!e || !y) return RXHIP_ERR_BADARG;
+    if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "filter_step: not a state-space engine");
+    if (e->dense || !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "filter_step has a device schedule for d, dy ≤ 4 only");
+    if ((e->d_step_model || e->d_cx) && e->stream_k >= e->Tout())
+        return fail(e, RXHIP_ERR_STATE, "filter_step: the per-step constants / known inputs of this engine end after %lld observations", (long long)e->Tout());
+    SET_DEVICE(e);
+    const size_t C = (size_t)e->n_chains, d = (size_t)e->d, dy = (size_t)e->dy, ns = d * (d + 1) / 2;
+    const size_t o_y = C * (d + ns), o_m = o_y + C * dy, o_c = o_m + C * d, o_f = o_c + C * d * d, total = o_f + C;
+    if (!e->d_stream) {
+        HIPCHK(e, hipMalloc(&e->d_stream, sizeof(double) * total));
+        HIPCHK(e, hipHostMalloc((void**)&e->h_stream, sizeof(double) * (total - o_y), hipHostMallocDefault));  // pinned: y | mean | cov | fe
+    }
+    // one pinned staging block each way: a step is H2D + kernel + D2H + one synchronisation
+    std::memcpy(e->h_stream, y, sizeof(double) * C * dy);
+    HIPCHK(e, hipMemcpyAsync(e->d_stream + o_y, e->h_stream, sizeof(double) * C * dy, hipMemcpyHostToDevice, e->stream));
+    StreamParams sp{};
+    sp.n_chains = e->n_chains; sp.k = e->stream_k; sp.ptt = e->ptt; sp.first = e->stream_k == 0;
+    sp.y = e->d_stream + o_y; sp.state = e->d_stream; sp.cst = e->d_cst; sp.chain_model = e->d_chain_model;
+    sp.step_model = e->d_step_model; sp.cx = e->d_cx; sp.cy = e->d_mu ? e->d_cy_raw : nullptr;
+    sp.mean = e->d_stream + o_m; sp.cov = e->d_stream + o_c; sp.fe = e->d_stream + o_f; sp.status = e->d_status;
+    e->vt->stream_step(sp, e->stream);
+    HIPCHK(e, hipGetLastError());
+    const size_t n_out = (cov || free_energy) ? total - o_m : C * d;  // mean | cov | fe are contiguous
+    if (mean || cov || free_energy)
+        HIPCHK(e, hipMemcpyAsync(e->h_stream + (o_m - o_y), sp.mean, sizeof(double) * n_out, hipMemcpyDeviceToHost, e->stream));
+    e->stream_k += 1;
+    if (rxhip_status st = rxhip_sync(e)) return st;
+    if (mean) std::memcpy(mean, e->h_stream + (o_m - o_y), sizeof(double) * C * d);
+    if (cov) std::memcpy(cov, e->h_stream + (o_c - o_y), sizeof(double) * C * d * d);
+    if (free_energy) std::memcpy(free_energy, e->h_stream + (o_f - o_y), sizeof(double) * C);
+    return RXHIP_OK;
 }
 rxhip_status rxhip_run_filter(rxhip_engine* e, int32_t want_fe) {
     rxhip_status st = rxhip_run_filter_async(e, want_fe);

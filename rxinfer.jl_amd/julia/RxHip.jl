@@ -179,6 +179,21 @@ function free_energy(e::Engine)
     return fe
 end
 
+"""One observation at a time, as `RxInferenceEngine` consumes a datastream (src/inference/streaming.jl:349-407): `y` holds the new
+observation of every chain (dy × chains; `NaN` = missing); returns q(x) after it (mean d × chains, cov d × d × chains) and
+−log p(y_k | y_<k) per chain.  The belief stays on the device between calls (`filter_reset!` starts over from the prior)."""
+function filter_step!(e::Engine, y::AbstractMatrix)
+    flat = vec(Matrix{Float64}(y))                       # column-major dy × chains = row-major [chain][dy]
+    mean = Array{Float64}(undef, e.d, e.n_chains)
+    cov = Array{Float64}(undef, e.d, e.d, e.n_chains)
+    fe = Vector{Float64}(undef, e.n_chains)
+    GC.@preserve flat mean cov fe check(e, ccall((:rxhip_filter_step, librxhip), Int32,
+                                                  (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+                                                  e.handle, flat, mean, cov, fe))
+    return mean, cov, fe                                  # covariances are symmetric: no transposition needed
+end
+filter_reset!(e::Engine) = check(e, ccall((:rxhip_filter_reset, librxhip), Int32, (Ptr{Cvoid},), e.handle))
+
 """Streaming twin: `infer(model = linear_gaussian_ssm_filtering(...), data = (y_t = observations,), autoupdates = ...,
 historyvars = (x_t = KeepLast(),), keephistory = n)` of the benchmark notebook (cell 7; driver
 src/inference/streaming.jl:349-407).  Afterwards `marginals(e)` is `result.history[:x_t]` and `free_energy(e)[1]` the

@@ -134,6 +134,19 @@ class LGSSMEngine:
         self._chk(_lib.lib().rxhip_run_filter_async(self._h, int(bool(free_energy))))
         self._iters = 1
 
+    def filter_step(self, y, want_cov=True, free_energy=True):
+        """One observation of every chain (y: [chain][dy]; NaN = missing) through the streaming driver (rxhip_filter_step):
+        returns the posterior mean [chain][d], covariance [chain][d][d] | None, −log p(y_k | y_<k) [chain] | None."""
+        y = _c(y, (self.n_chains, self.dy))
+        mean = np.empty((self.n_chains, self.d))
+        cov = np.empty((self.n_chains, self.d, self.d)) if want_cov else None
+        fe = np.empty(self.n_chains) if free_energy else None
+        self._chk(_lib.lib().rxhip_filter_step(self._h, _p(y), _p(mean), _p(cov) if want_cov else None, _p(fe) if free_energy else None))
+        return mean, cov, fe
+
+    def filter_reset(self):
+        self._chk(_lib.lib().rxhip_filter_reset(self._h))
+
     def sync(self):
         self._chk(_lib.lib().rxhip_sync(self._h))
 
