@@ -109,6 +109,11 @@ typedef struct {
                          y − B μ − d, so the data are shifted on the way in and the means on the way out (any d, dy) */
 } rxhip_lgssm_desc;
 
+/* New known inputs for an engine created WITH offsets (pass zero arrays at creation to reserve them): same shapes as
+ * rxhip_lgssm_desc.state_offset / obs_offset, either may be NULL (= zeros).  A control loop that re-plans its inputs keeps the
+ * engine, its tables and its observations; the next run / filter step uses the new inputs. */
+rxhip_status rxhip_lgssm_set_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset);
+
 /* replaces: create_model(...) + postprocess_plugin (src/inference/batch.jl:252,
  * src/model/plugins/reactivemp_inference.jl:272-326) for the LGSSM family */
 rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* desc, rxhip_engine** out);

@@ -333,7 +333,8 @@ struct rxhip_engine {
     double* d_stream = nullptr;   // rxhip_filter_step: belief per chain | staging of y, mean, cov, fe (allocated on first use)
     long long stream_k = 0;
     double *d_mu = nullptr, *d_nu = nullptr, *d_cx = nullptr, *d_cy_raw = nullptr;  // known inputs: μ[t] [Tout][d], ν[t] = B μ[t] + d[t] [Tout][dy], c[t], d[t]
-    std::vector<double> h_mu, h_nu, h_cx, h_cy;
+    std::vector<double> h_mu, h_nu, h_cx, h_cy, h_offA, h_offB;
+    std::vector<int> h_offsm;
     std::vector<double> h_user;  // MFMA path: user-level A | P | B | Q | Q⁻¹ of every model (generic_kernels.hpp)
     double* d_user = nullptr;
     int* d_step_model = nullptr;
@@ -1460,6 +1461,52 @@ rxhip_status rxhip_destroy(rxhip_engine* e) {
     return RXHIP_OK;
 }
 
+// known inputs: μ[t] = A μ[t-1] + c[t] (μ before the first state = 0), ν[t] = B μ[t] + d[t]; the sweep runs on x − μ, y − ν
+static void offsets_to_shifts(rxhip_engine* e, const double* cx, const double* cy) {
+    const size_t d = (size_t)e->d, dy = (size_t)e->dy, To = (size_t)e->Tout();
+    e->h_mu.assign(To * d, 0.0);
+    e->h_nu.assign(To * dy, 0.0);
+    e->h_cx.assign(To * d, 0.0);
+    e->h_cy.assign(To * dy, 0.0);
+    if (cx) std::memcpy(e->h_cx.data(), cx, sizeof(double) * To * d);
+    if (cy) std::memcpy(e->h_cy.data(), cy, sizeof(double) * To * dy);
+    for (size_t t = 0; t < To; ++t) {
+        const size_t mdl = e->h_offsm.empty() ? 0 : (size_t)e->h_offsm[t];
+        const double *A = e->h_offA.data() + mdl * d * d, *B = e->h_offB.data() + mdl * dy * d;
+        double* mu = &e->h_mu[t * d];
+        if (t > 0 || e->ptt) {
+            for (size_t i = 0; i < d; ++i) {
+                double s = e->h_cx[t * d + i];
+                if (t > 0)
+                    for (size_t k = 0; k < d; ++k) s += A[i * d + k] * e->h_mu[(t - 1) * d + k];
+                mu[i] = s;
+            }
+        }
+        for (size_t a = 0; a < dy; ++a) {
+            double s = e->h_cy[t * dy + a];
+            for (size_t k = 0; k < d; ++k) s += B[a * d + k] * mu[k];
+            e->h_nu[t * dy + a] = s;
+        }
+    }
+}
+
+rxhip_status rxhip_lgssm_set_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset) {
+    if (!e || e->kind != 0) return RXHIP_ERR_BADARG;
+    if (!e->d_mu) return fail(e, RXHIP_ERR_STATE, "set_offsets: the engine was created without offsets (pass zero arrays at creation to reserve them)");
+    SET_DEVICE(e);
+    // the engine's copy of the observations carries the old shift: take it out, put the new one in
+    if (e->have_data) hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, 1.0);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    offsets_to_shifts(e, state_offset, obs_offset);
+    HIPCHK(e, hipMemcpyAsync(e->d_mu, e->h_mu.data(), sizeof(double) * e->h_mu.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_nu, e->h_nu.data(), sizeof(double) * e->h_nu.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_cx, e->h_cx.data(), sizeof(double) * e->h_cx.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->d_cy_raw, e->h_cy.data(), sizeof(double) * e->h_cy.size(), hipMemcpyHostToDevice, e->stream));
+    if (e->have_data) hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, -1.0);
+    HIPCHK(e, hipGetLastError());
+    return rxhip_sync(e);  // the host vectors are the copy sources
+}
+
 rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) {
     if (!out) return RXHIP_ERR_BADARG;
     *out = nullptr;
@@ -1515,33 +1562,12 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     if (ds->horizon < 0) return fail(e, RXHIP_ERR_BADARG, "horizon must be non-negative");
     e->H = ds->horizon;
     if (ds->state_offset || ds->obs_offset) {
-        // known inputs: μ[t] = A μ[t-1] + c[t] (μ before the first state = 0), ν[t] = B μ[t] + d[t]; the sweep runs on x − μ, y − ν
         if (ds->chain_model) return fail(e, RXHIP_ERR_UNSUPPORTED, "offsets need one model per time index (no chain_model)");
         const size_t d = (size_t)ds->d, dy = (size_t)ds->dy, To = (size_t)(ds->T + ds->horizon);
-        e->h_mu.assign(To * d, 0.0);
-        e->h_nu.assign(To * dy, 0.0);
-        e->h_cx.assign(To * d, 0.0);
-        if (ds->state_offset) std::memcpy(e->h_cx.data(), ds->state_offset, sizeof(double) * To * d);
-        e->h_cy.assign(To * dy, 0.0);
-        if (ds->obs_offset) std::memcpy(e->h_cy.data(), ds->obs_offset, sizeof(double) * To * dy);
-        for (size_t t = 0; t < To; ++t) {
-            const size_t mdl = ds->step_model ? (size_t)ds->step_model[t] : 0;
-            const double *A = ds->A + mdl * d * d, *B = ds->B + mdl * dy * d;
-            double* mu = &e->h_mu[t * d];
-            if (t > 0 || ds->prior_through_transition) {
-                for (size_t i = 0; i < d; ++i) {
-                    double s = e->h_cx[t * d + i];
-                    if (t > 0)
-                        for (size_t k = 0; k < d; ++k) s += A[i * d + k] * e->h_mu[(t - 1) * d + k];
-                    mu[i] = s;
-                }
-            }
-            for (size_t a = 0; a < dy; ++a) {
-                double s = ds->obs_offset ? ds->obs_offset[t * dy + a] : 0.0;
-                for (size_t k = 0; k < d; ++k) s += B[a * d + k] * mu[k];
-                e->h_nu[t * dy + a] = s;
-            }
-        }
+        e->h_offA.assign(ds->A, ds->A + (size_t)ds->n_models * d * d);   // kept for rxhip_lgssm_set_offsets
+        e->h_offB.assign(ds->B, ds->B + (size_t)ds->n_models * dy * d);
+        if (ds->step_model) e->h_offsm.assign(ds->step_model, ds->step_model + To);
+        offsets_to_shifts(e, ds->state_offset, ds->obs_offset);
     }
     if (dense) {  // predictions / forecasts of the MFMA path run on the user-level constants
         const size_t dd = (size_t)ds->d * ds->d, bd = (size_t)ds->dy * ds->d, qq = (size_t)ds->dy * ds->dy, sz = 2 * dd + bd + 2 * qq;

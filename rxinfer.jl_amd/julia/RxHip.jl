@@ -192,6 +192,13 @@ function filter_step!(e::Engine, y::AbstractMatrix)
                                                   e.handle, flat, mean, cov, fe))
     return mean, cov, fe                                  # covariances are symmetric: no transposition needed
 end
+"""New known inputs (d × T / dy × T matrices or `nothing` = zeros) for an engine created with offsets (`rxhip_lgssm_set_offsets`)."""
+function set_offsets!(e::Engine; state_offset = nothing, obs_offset = nothing)
+    cx = state_offset === nothing ? Float64[] : vec(Matrix{Float64}(state_offset))
+    cy = obs_offset === nothing ? Float64[] : vec(Matrix{Float64}(obs_offset))
+    GC.@preserve cx cy check(e, ccall((:rxhip_lgssm_set_offsets, librxhip), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle,
+                                      isempty(cx) ? Ptr{Float64}(C_NULL) : pointer(cx), isempty(cy) ? Ptr{Float64}(C_NULL) : pointer(cy)))
+end
 filter_reset!(e::Engine) = check(e, ccall((:rxhip_filter_reset, librxhip), Int32, (Ptr{Cvoid},), e.handle))
 
 """Streaming twin: `infer(model = linear_gaussian_ssm_filtering(...), data = (y_t = observations,), autoupdates = ...,

@@ -144,6 +144,13 @@ class LGSSMEngine:
         self._chk(_lib.lib().rxhip_filter_step(self._h, _p(y), _p(mean), _p(cov) if want_cov else None, _p(fe) if free_energy else None))
         return mean, cov, fe
 
+    def set_offsets(self, state_offset=None, obs_offset=None):
+        """New known inputs (rxhip_lgssm_set_offsets); the engine must have been created with offsets."""
+        To = self.T + self.horizon
+        cx = None if state_offset is None else _c(np.broadcast_to(np.asarray(state_offset, dtype=np.float64), (To, self.d)))
+        cy = None if obs_offset is None else _c(np.broadcast_to(np.asarray(obs_offset, dtype=np.float64), (To, self.dy)))
+        self._chk(_lib.lib().rxhip_lgssm_set_offsets(self._h, _p(cx) if cx is not None else None, _p(cy) if cy is not None else None))
+
     def filter_reset(self):
         self._chk(_lib.lib().rxhip_filter_reset(self._h))
 

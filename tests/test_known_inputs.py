@@ -204,3 +204,27 @@ def test_graph_with_known_inputs_runs_on_the_device():
         om, oc, nll = rxo.lgssm_kalman_rts_affine(A, B, P, Q, m0, V0, y[c], cx, cy, prior_through_transition=True)
         assert np.allclose(mean[c], om, rtol=1e-6, atol=1e-8) and np.allclose(cov[c], oc, rtol=1e-6, atol=1e-8)
         assert fe[c] == pytest.approx(nll, rel=1e-8)
+
+
+@pytest.mark.gpu
+def test_new_inputs_for_a_live_engine():
+    """A control loop re-plans its inputs: same engine, same tables, same observations, new c[t] / d[t] (rxhip_lgssm_set_offsets)."""
+    import rxhip
+    rng = np.random.default_rng(21)
+    d, dy, T, C = 3, 2, 60, 5
+    mdl = _models(rng, d, dy, 1)
+    one = tuple(x[0] for x in mdl)
+    y = rng.standard_normal((C, T, dy))
+    with rxhip.LGSSMEngine(*one, T=T, n_chains=C, state_offset=np.zeros(d), obs_offset=np.zeros(dy)) as eng:
+        eng.set_data(y, layout="chain_time")
+        for trial in range(3):
+            cx, cy = rng.standard_normal((T, d)), (rng.standard_normal((T, dy)) if trial != 1 else None)
+            eng.set_offsets(cx, cy)
+            eng.run(1, True)
+            mean, cov = eng.marginals(layout="chain_time")
+            fe = eng.free_energy_per_chain()
+            for c in (0, C - 1):
+                om, oc, nll = rxo.lgssm_kalman_rts_affine(*one, y[c], cx, cy)
+                assert np.allclose(mean[c], om, rtol=1e-6, atol=1e-8) and fe[c] == pytest.approx(nll, rel=1e-8)
+    with rxhip.LGSSMEngine(*one, T=T, n_chains=C) as eng, pytest.raises(rxhip.RxHipError):
+        eng.set_offsets(np.zeros(d))
