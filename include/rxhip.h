@@ -113,6 +113,11 @@ typedef struct {
  * rxhip_lgssm_desc.state_offset / obs_offset, either may be NULL (= zeros).  A control loop that re-plans its inputs keeps the
  * engine, its tables and its observations; the next run / filter step uses the new inputs. */
 rxhip_status rxhip_lgssm_set_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset);
+/* Known inputs that are DATA of every chain — `x[t] ~ MvNormal(μ = A * x[t-1] + B_u * u[t], Σ = P)` with `u` a data variable: the
+ * host passes c = B_u u per chain, (T + horizon)·n_chains·d doubles in `layout` ([t][chain][d] or [chain][t][d]); obs_offset
+ * likewise with dy; either may be NULL (= zeros).  The engine runs μ[t] = A μ[t-1] + c[t] per chain on the device and shifts data
+ * and means per chain from then on.  Same precondition as rxhip_lgssm_set_offsets. */
+rxhip_status rxhip_lgssm_set_chain_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset, int32_t layout);
 
 /* replaces: create_model(...) + postprocess_plugin (src/inference/batch.jl:252,
  * src/model/plugins/reactivemp_inference.jl:272-326) for the LGSSM family */

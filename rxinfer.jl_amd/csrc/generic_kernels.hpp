@@ -27,6 +27,7 @@ struct GenericParams {
     const double* user;  // [n_models][2d² + dy·d + 2dy²]  A | P | B | Q | Q⁻¹
     const int* chain_model;
     const double *mu, *nu, *cx;  // known inputs (PredictParams): μ[t] [T+H][d], ν[t] [T+H][dy], c[t] [T+H][d]; null: none
+    int off_chain;               // 1: with a chain axis, [T+H][chain][·]
     double* pmean;       // [T+H][chain][dy]
     double* pcov;        // [T+H][chain][dy][dy]
     int* status;
@@ -88,7 +89,7 @@ __global__ void __launch_bounds__(256) k_predict_generic(GenericParams p) {
     const long long t = g / p.n_chains, c = g - t * p.n_chains;
     const GenericModel M = generic_model(p, c);
     const double* Vs = p.cov + g * d * d;  // read straight from memory (L2): used once, in B V_s
-    for (int e = tid; e < d; e += nt) ms[e] = p.mean[g * d + e] - (p.mu ? p.mu[(g / p.n_chains) * d + e] : 0.0);
+    for (int e = tid; e < d; e += nt) ms[e] = p.mean[g * d + e] - (p.mu ? p.mu[(p.off_chain ? g : g / p.n_chains) * d + e] : 0.0);
     __shared__ int s_obs;
     if (tid == 0) {
         int obs = t < p.T;
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(256) k_predict_generic(GenericParams p) {
     }
     __syncthreads();
     if (!observed) {
-        for (int a = tid; a < dy; a += nt) p.pmean[g * dy + a] = u[a] + (p.nu ? p.nu[t * dy + a] : 0.0);
+        for (int a = tid; a < dy; a += nt) p.pmean[g * dy + a] = u[a] + (p.nu ? p.nu[(p.off_chain ? g : t) * dy + a] : 0.0);
         for (int e = tid; e < dy * dy; e += nt) {
             const int a = e / dy, b = e - a * dy;
             p.pcov[g * dy * dy + e] = 0.5 * (Sg[a * dy + b] + Sg[b * dy + a]) + 0.5 * (M.Q[a * dy + b] + M.Q[b * dy + a]);
@@ -154,7 +155,7 @@ __global__ void __launch_bounds__(256) k_predict_generic(GenericParams p) {
     for (int a = tid; a < dy; a += nt) {  // mean = Q R u
         double s = 0.0;
         for (int k = 0; k < dy; ++k) s += M.Q[a * dy + k] * u[k];
-        p.pmean[g * dy + a] = s + (p.nu ? p.nu[t * dy + a] : 0.0);
+        p.pmean[g * dy + a] = s + (p.nu ? p.nu[(p.off_chain ? g : t) * dy + a] : 0.0);
     }
     for (int e = tid; e < dy * dy; e += nt) {  // cov = Q + Σ (R Q): symmetric in exact arithmetic, stored symmetrised
         const int a = e / dy, b = e - a * dy;
@@ -194,7 +195,7 @@ __global__ void __launch_bounds__(256) k_forecast_generic(GenericParams p) {
         for (int i = tid; i < d; i += nt) {
             double s = 0.0;
             for (int k = 0; k < d; ++k) s += M.A[i * d + k] * m[k];
-            mn[i] = s + (p.cx ? p.cx[(p.T + h) * d + i] : 0.0);
+            mn[i] = s + (p.cx ? p.cx[((p.T + h) * (p.off_chain ? p.n_chains : 1) + (p.off_chain ? c : 0)) * d + i] : 0.0);
         }
         __syncthreads();
         for (int e = tid; e < d * d; e += nt) {
@@ -213,6 +214,45 @@ __global__ void __launch_bounds__(256) k_forecast_generic(GenericParams p) {
             p.mean[r * d + i] = mn[i];
         }
         __syncthreads();
+    }
+}
+
+
+// Known inputs that are DATA of every chain (`B_u * u[t]` with u a datavar): μ[t] = A μ[t-1] + c[t], ν[t] = B μ[t] + d[t] per
+// chain, one thread each (sequential in t, four steps of inputs in flight).  cx, cy: [T+H][chain][·]; ab: A | B of every model.
+struct MuParams {
+    long long To, n_chains;
+    int d, dy, ptt, n_models;
+    const double *cx, *cy, *ab;
+    const int* step_model;
+    double *mu, *nu;
+};
+__global__ void __launch_bounds__(64) k_mu_recursion(MuParams p) {
+    const long long c = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= p.n_chains) return;
+    const int d = p.d, dy = p.dy;
+    double m[64], mn[64];
+    for (int i = 0; i < d; ++i) m[i] = 0.0;
+    for (long long t = 0; t < p.To; ++t) {
+        const size_t mdl = p.step_model ? (size_t)p.step_model[t] : 0;
+        const double* A = p.ab + mdl * ((size_t)d * d + (size_t)dy * d);
+        const double* B = A + (size_t)d * d;
+        const long long r = t * p.n_chains + c;
+        if (t > 0 || p.ptt) {
+            for (int i = 0; i < d; ++i) {
+                double s = p.cx ? p.cx[r * d + i] : 0.0;
+                if (t > 0)
+                    for (int k = 0; k < d; ++k) s += A[i * d + k] * m[k];
+                mn[i] = s;
+            }
+            for (int i = 0; i < d; ++i) m[i] = mn[i];
+        }
+        for (int i = 0; i < d; ++i) p.mu[r * d + i] = m[i];
+        for (int a = 0; a < dy; ++a) {
+            double s = p.cy ? p.cy[r * dy + a] : 0.0;
+            for (int k = 0; k < d; ++k) s += B[a * d + k] * m[k];
+            p.nu[r * dy + a] = s;
+        }
     }
 }
 

@@ -32,6 +32,7 @@ struct PredictParams {
     const double* mu;     // known inputs (null: none): μ[t] [T+H][D] — the sweep ran on x − μ, y − ν; posteriors are back in x
     const double* nu;     // ν[t] = B μ[t] + d[t] [T+H][DY]
     const double* cx;     // c[t] [T+H][D]
+    int off_chain;        // 1: the three arrays carry a chain axis, [T+H][chain][·] (inputs that are data of every chain)
     double* pmean;        // [T+H][chain][DY]
     double* pcov;         // [T+H][chain][DY][DY]
     int* status;
@@ -60,7 +61,7 @@ __global__ __launch_bounds__(64) void k_forecast(PredictParams p) {
         matvec_c<D>(A, m, mn);             // `*`_A(:out): N(A m, A V A')
         if (p.cx) {                        // `+` with the known input of this time index
 #pragma unroll
-            for (int i = 0; i < D; ++i) mn[i] += p.cx[(p.T + h) * D + i];
+            for (int i = 0; i < D; ++i) mn[i] += p.cx[((p.T + h) * (p.off_chain ? p.n_chains : 1) + (p.off_chain ? c : 0)) * D + i];
         }
         predict_cov<D>(A, P, V, Tm, Vn);   // MvN_x(:out): + P
         const long long r = (p.T + h) * p.n_chains + c;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void k_predict(PredictParams p) {
         double m[D];
         Sym<D> V;
 #pragma unroll
-        for (int i = 0; i < D; ++i) m[i] = p.mean[g * D + i] - (p.mu ? p.mu[t * D + i] : 0.0);
+        for (int i = 0; i < D; ++i) m[i] = p.mean[g * D + i] - (p.mu ? p.mu[(p.off_chain ? g : t) * D + i] : 0.0);
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(256) void k_predict(PredictParams p) {
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < D; ++k) s += B[a * D + k] * m[k];
-            p.pmean[g * DY + a] = s + (p.nu ? p.nu[t * DY + a] : 0.0);
+            p.pmean[g * DY + a] = s + (p.nu ? p.nu[(p.off_chain ? g : t) * DY + a] : 0.0);
 #pragma unroll
             for (int j = 0; j < D; ++j) {
                 double v = 0.0;
@@ -223,7 +224,7 @@ __global__ __launch_bounds__(256) void k_joint(PredictParams p) {
 #pragma unroll
             for (int q = 0; q < D; ++q) s += cst[CL::A + a * D + q] * m0[q];
             jm[a] = m1[a];
-            jm[D + a] = s + (p.cx ? p.cx[(k + 1) * D + a] : 0.0);
+            jm[D + a] = s + (p.cx ? p.cx[((k + 1) * (p.off_chain ? p.n_chains : 1) + (p.off_chain ? c : 0)) * D + a] : 0.0);
         }
 #pragma unroll
         for (int a = 0; a < D; ++a)
@@ -254,7 +255,8 @@ struct StreamParams {
     const double* cst;
     const int* chain_model;
     const int* step_model;   // null, or model of observation k (k < its length)
-    const double *cx, *cy;   // null, or known inputs [·][D], [·][DY] of observation k
+    const double *cx, *cy;   // null, or known inputs [·][D], [·][DY] of observation k ([·][chain][·] when off_chain)
+    int off_chain;
     double* mean;            // [chain][D]
     double* cov;             // [chain][D][D]
     double* fe;              // [chain]  −log p(y_k | y_<k), or null
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(64) void k_stream_step(StreamParams p) {
     double* st = p.state + c * (D + NS);
     if (p.first) {  // CL::M1 / V1 hold the prior already pushed through its transition when ptt
 #pragma unroll
-        for (int i = 0; i < D; ++i) mp[i] = cst[CL::M1 + i] + ((p.ptt && p.cx) ? p.cx[p.k * D + i] : 0.0);
+        for (int i = 0; i < D; ++i) mp[i] = cst[CL::M1 + i] + ((p.ptt && p.cx) ? p.cx[(p.k * (p.off_chain ? p.n_chains : 1) + (p.off_chain ? c : 0)) * D + i] : 0.0);
 #pragma unroll
         for (int i = 0; i < NS; ++i) Vp.v[i] = cst[CL::V1 + i];
     } else {
@@ -285,7 +287,7 @@ __global__ __launch_bounds__(64) void k_stream_step(StreamParams p) {
         matvec_c<D>(CPtr{cst + CL::A}, m, mp);
         if (p.cx) {
 #pragma unroll
-            for (int i = 0; i < D; ++i) mp[i] += p.cx[p.k * D + i];
+            for (int i = 0; i < D; ++i) mp[i] += p.cx[(p.k * (p.off_chain ? p.n_chains : 1) + (p.off_chain ? c : 0)) * D + i];
         }
         predict_cov<D>(CPtr{cst + CL::A}, CPtr{cst + CL::P}, V, T, Vp);
     }
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(64) void k_stream_step(StreamParams p) {
     for (int a = 0; a < DY; ++a) {
         yv[a] = p.y[c * DY + a];
         miss = miss || (yv[a] != yv[a]);
-        if (p.cy) yv[a] -= p.cy[p.k * DY + a];
+        if (p.cy) yv[a] -= p.cy[(p.k * (p.off_chain ? p.n_chains : 1) + (p.off_chain ? c : 0)) * DY + a];
     }
     bool ok = true;
     double quad = 0.0, detprod = 1.0;

@@ -236,11 +236,12 @@ __global__ void k_transpose_rows(const double* __restrict__ in, double* __restri
 
 
 // x[t][c][k] += sign · off[t][k]: known inputs (rxhip_lgssm_desc.state_offset / obs_offset) enter and leave the sweep as shifts
-__global__ void k_shift_rows(double* __restrict__ x, const double* __restrict__ off, long long rows, long long n_chains, int k, double sign) {
+__global__ void k_shift_rows(double* __restrict__ x, const double* __restrict__ off, long long rows, long long n_chains, int k, double sign,
+                             int per_chain = 0) {  // per_chain: `off` has the shape of x
     const long long total = rows * n_chains * k;
     for (long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x; g < total; g += (long long)gridDim.x * blockDim.x) {
         const long long t = g / (n_chains * k);
-        x[g] += sign * off[t * k + g % k];
+        x[g] += sign * (per_chain ? off[g] : off[t * k + g % k]);
     }
 }
 // out[i][t][k] = in[t][chains[i]][k]: posteriors of a few chains, chain-major (what `infer` returns for ONE chain)
@@ -335,6 +336,8 @@ struct rxhip_engine {
     double *d_mu = nullptr, *d_nu = nullptr, *d_cx = nullptr, *d_cy_raw = nullptr;  // known inputs: μ[t] [Tout][d], ν[t] = B μ[t] + d[t] [Tout][dy], c[t], d[t]
     std::vector<double> h_mu, h_nu, h_cx, h_cy, h_offA, h_offB;
     std::vector<int> h_offsm;
+    bool off_chain = false;        // the device offset arrays carry a chain axis (rxhip_lgssm_set_chain_offsets)
+    double* d_off_chain = nullptr; // their block: μ | ν | c | d with a chain axis, and A | B of every model
     std::vector<double> h_user;  // MFMA path: user-level A | P | B | Q | Q⁻¹ of every model (generic_kernels.hpp)
     double* d_user = nullptr;
     int* d_step_model = nullptr;
@@ -1429,6 +1432,7 @@ static void free_all(rxhip_engine* e) {
     if (e->d_bq) { (void)hipFree(e->d_bq); e->d_bq = nullptr; }
     if (e->d_stream) { (void)hipFree(e->d_stream); e->d_stream = nullptr; }
     if (e->h_stream) { (void)hipHostFree(e->h_stream); e->h_stream = nullptr; }
+    if (e->d_off_chain) { (void)hipFree(e->d_off_chain); e->d_off_chain = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
     e->pending.clear();
@@ -1493,18 +1497,66 @@ static void offsets_to_shifts(rxhip_engine* e, const double* cx, const double* c
 rxhip_status rxhip_lgssm_set_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset) {
     if (!e || e->kind != 0) return RXHIP_ERR_BADARG;
     if (!e->d_mu) return fail(e, RXHIP_ERR_STATE, "set_offsets: the engine was created without offsets (pass zero arrays at creation to reserve them)");
+    if (e->off_chain) return fail(e, RXHIP_ERR_STATE, "set_offsets: this engine carries per-chain inputs (rxhip_lgssm_set_chain_offsets)");
     SET_DEVICE(e);
     // the engine's copy of the observations carries the old shift: take it out, put the new one in
-    if (e->have_data) hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, 1.0);
+    if (e->have_data) hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, 1.0, e->off_chain ? 1 : 0);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     offsets_to_shifts(e, state_offset, obs_offset);
     HIPCHK(e, hipMemcpyAsync(e->d_mu, e->h_mu.data(), sizeof(double) * e->h_mu.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->d_nu, e->h_nu.data(), sizeof(double) * e->h_nu.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->d_cx, e->h_cx.data(), sizeof(double) * e->h_cx.size(), hipMemcpyHostToDevice, e->stream));
     HIPCHK(e, hipMemcpyAsync(e->d_cy_raw, e->h_cy.data(), sizeof(double) * e->h_cy.size(), hipMemcpyHostToDevice, e->stream));
-    if (e->have_data) hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, -1.0);
+    if (e->have_data) hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, -1.0, e->off_chain ? 1 : 0);
     HIPCHK(e, hipGetLastError());
     return rxhip_sync(e);  // the host vectors are the copy sources
+}
+
+rxhip_status rxhip_lgssm_set_chain_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset, int32_t layout) {
+    if (!e || e->kind != 0) return RXHIP_ERR_BADARG;
+    if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME) return fail(e, RXHIP_ERR_BADARG, "set_chain_offsets: unknown layout %d", layout);
+    if (!e->d_mu) return fail(e, RXHIP_ERR_STATE, "set_chain_offsets: the engine was created without offsets (pass zero arrays at creation to reserve them)");
+    SET_DEVICE(e);
+    const size_t C = (size_t)e->n_chains, To = (size_t)e->Tout(), d = (size_t)e->d, dy = (size_t)e->dy;
+    const size_t n_mu = To * C * d, n_nu = To * C * dy, n_ab = e->h_offA.size() + e->h_offB.size();
+    // take the old shift out of the engine's copy of the observations (shared or per chain, whatever it was)
+    if (e->have_data) hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, 1.0, e->off_chain ? 1 : 0);
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    if (!e->d_off_chain) HIPCHK(e, hipMalloc(&e->d_off_chain, sizeof(double) * (2 * n_mu + 2 * n_nu + n_ab)));
+    double *mu = e->d_off_chain, *nu = mu + n_mu, *cx = nu + n_nu, *cy = cx + n_mu, *ab = cy + n_nu;
+    {   // A | B per model, interleaved per model as the kernel reads them
+        std::vector<double> hab;
+        const size_t M = e->h_offA.size() / (d * d);
+        for (size_t m = 0; m < M; ++m) {
+            hab.insert(hab.end(), e->h_offA.begin() + m * d * d, e->h_offA.begin() + (m + 1) * d * d);
+            hab.insert(hab.end(), e->h_offB.begin() + m * dy * d, e->h_offB.begin() + (m + 1) * dy * d);
+        }
+        HIPCHK(e, hipMemcpy(ab, hab.data(), sizeof(double) * hab.size(), hipMemcpyHostToDevice));
+    }
+    auto put = [&](double* dst, const double* src, size_t k) -> rxhip_status {  // host [To][C][k] or [C][To][k] -> device [To][C][k]
+        const size_t n = To * C * k;
+        if (!src) { HIPCHK(e, hipMemsetAsync(dst, 0, sizeof(double) * n, e->stream)); return RXHIP_OK; }
+        if (layout == RXHIP_LAYOUT_TIME_CHAIN || C == 1) { HIPCHK(e, hipMemcpy(dst, src, sizeof(double) * n, hipMemcpyHostToDevice)); return RXHIP_OK; }
+        double* tmp = nullptr;
+        HIPCHK(e, hipMalloc(&tmp, sizeof(double) * n));
+        HIPCHK(e, hipMemcpy(tmp, src, sizeof(double) * n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_transpose_rows, dim3(2048), dim3(256), 0, e->stream, (const double*)tmp, dst, (long long)C, (long long)To, (int)k);
+        HIPCHK(e, hipStreamSynchronize(e->stream));
+        HIPCHK(e, hipFree(tmp));
+        return RXHIP_OK;
+    };
+    if (rxhip_status st = put(cx, state_offset, d)) return st;
+    if (rxhip_status st = put(cy, obs_offset, dy)) return st;
+    MuParams mp{};
+    mp.To = (long long)To; mp.n_chains = e->n_chains; mp.d = e->d; mp.dy = e->dy; mp.ptt = e->ptt; mp.cx = cx; mp.cy = cy; mp.ab = ab;
+    mp.step_model = e->d_step_model; mp.mu = mu; mp.nu = nu;
+    hipLaunchKernelGGL(k_mu_recursion, dim3(nblk(e->n_chains, 64)), dim3(64), 0, e->stream, mp);
+    HIPCHK(e, hipGetLastError());
+    e->d_mu = mu; e->d_nu = nu; e->d_cx = cx; e->d_cy_raw = cy;  // the shared arrays stay where they are (arena); these take over
+    e->off_chain = true;
+    if (e->have_data) hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, -1.0, 1);
+    HIPCHK(e, hipGetLastError());
+    return rxhip_sync(e);
 }
 
 rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) {
@@ -2496,7 +2548,7 @@ static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t
         if (tmp) HIPCHK(e, hipFree(tmp));
     }
     if (e->d_nu) {  // known inputs: the sweep sees y − B μ − d
-        hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, -1.0);
+        hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, -1.0, e->off_chain ? 1 : 0);
         HIPCHK(e, hipGetLastError());
     }
     e->have_data = true;
@@ -2587,7 +2639,7 @@ rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, d
     StreamParams sp{};
     sp.n_chains = e->n_chains; sp.k = e->stream_k; sp.ptt = e->ptt; sp.first = e->stream_k == 0;
     sp.y = e->d_stream + o_y; sp.state = e->d_stream; sp.cst = e->d_cst; sp.chain_model = e->d_chain_model;
-    sp.step_model = e->d_step_model; sp.cx = e->d_cx; sp.cy = e->d_mu ? e->d_cy_raw : nullptr;
+    sp.step_model = e->d_step_model; sp.cx = e->d_cx; sp.cy = e->d_mu ? e->d_cy_raw : nullptr; sp.off_chain = e->off_chain ? 1 : 0;
     sp.mean = e->d_stream + o_m; sp.cov = e->d_stream + o_c; sp.fe = e->d_stream + o_f; sp.status = e->d_status;
     e->vt->stream_step(sp, e->stream);
     HIPCHK(e, hipGetLastError());
@@ -2754,18 +2806,18 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             if ((st = prof_end(e))) return st;
         }
         if (e->d_mu) {  // known inputs: back from x − μ to x (the free-energy terms above are invariant under the shift)
-            hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_mean, (const double*)e->d_mu, e->T, e->n_chains, e->d, 1.0);
+            hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_mean, (const double*)e->d_mu, e->T, e->n_chains, e->d, 1.0, e->off_chain ? 1 : 0);
         }
         if (e->H > 0 && e->dense) {  // the unobserved tail on the MFMA path: generic-dimension forecast, one workgroup per chain
             GenericParams gp{};
             gp.T = e->T; gp.H = e->H; gp.n_chains = e->n_chains; gp.d = e->d; gp.dy = e->dy; gp.mean = e->d_mean; gp.cov = e->d_cov;
-            gp.user = e->d_user; gp.cx = e->d_cx; gp.chain_model = e->d_chain_model; gp.status = e->d_status;
+            gp.user = e->d_user; gp.cx = e->d_cx; gp.off_chain = e->off_chain ? 1 : 0; gp.chain_model = e->d_chain_model; gp.status = e->d_status;
             hipLaunchKernelGGL(k_forecast_generic, dim3((unsigned)e->n_chains), dim3(256), generic_forecast_lds(e->d), e->stream, gp);
         }
         if (e->H > 0 && !e->dense) {  // the unobserved tail: forward messages from the last filtered (= smoothed) belief
             PredictParams pp{};
             pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
-            pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.status = e->d_status; pp.cx = e->d_cx;
+            pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.status = e->d_status; pp.cx = e->d_cx; pp.off_chain = e->off_chain ? 1 : 0;
             e->vt->forecast(pp, e->stream);
         }
     }
@@ -2901,7 +2953,7 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
         GenericParams gp{};
         gp.T = e->T; gp.H = e->H; gp.n_chains = e->n_chains; gp.d = e->d; gp.dy = e->dy; gp.y = e->d_y; gp.mean = e->d_mean; gp.cov = e->d_cov;
         gp.user = e->d_user; gp.chain_model = e->d_chain_model; gp.pmean = tmp; gp.pcov = tmp + rows * dy; gp.status = e->d_status;
-        gp.mu = e->d_mu; gp.nu = e->d_nu;
+        gp.mu = e->d_mu; gp.nu = e->d_nu; gp.off_chain = e->off_chain ? 1 : 0;
         hipLaunchKernelGGL(k_predict_generic, dim3((unsigned)rows), dim3(256), generic_predict_lds(e->d, e->dy), e->stream, gp);
         rxhip_status st = RXHIP_OK;
         if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "prediction kernel launch failed");
@@ -2921,7 +2973,7 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
     PredictParams pp{};
     pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.y = e->d_y; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
     pp.bq = e->d_bq; pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.pmean = tmp; pp.pcov = tmp + rows * dy; pp.status = e->d_status;
-    pp.mu = e->d_mu; pp.nu = e->d_nu;
+    pp.mu = e->d_mu; pp.nu = e->d_nu; pp.off_chain = e->off_chain ? 1 : 0;
     e->vt->predict(pp, e->stream);
     rxhip_status st = RXHIP_OK;
     if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "prediction kernel launch failed");
@@ -2948,7 +3000,7 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
     pp.T = e->T; pp.H = 0; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
     pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.status = e->d_status;
     pp.filt = e->uniform ? nullptr : e->d_filt; pp.vtab = e->d_vtab;
-    pp.jmean = tmp; pp.jcov = tmp + rows * d2; pp.cx = e->d_cx;
+    pp.jmean = tmp; pp.jcov = tmp + rows * d2; pp.cx = e->d_cx; pp.off_chain = e->off_chain ? 1 : 0;
     e->vt->joint(pp, e->stream);
     rxhip_status st = RXHIP_OK;
     if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "joint-marginal kernel launch failed");

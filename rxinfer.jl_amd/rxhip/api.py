@@ -36,15 +36,17 @@ class LinearGaussianSSM:
     step_model: Optional[np.ndarray] = None   # time-varying constants: A, B, P, Q are [n_models, …], step_model[t] picks
     state_offset: Optional[np.ndarray] = None  # known inputs: x[t] ~ MvNormal(μ = A*x[t-1] + c[t], Σ = P); [d] or [T, d]
     obs_offset: Optional[np.ndarray] = None    # y[t] ~ MvNormal(μ = B*x[t] + d[t], Σ = Q); [dy] or [T, dy]
+    input_matrix: Optional[np.ndarray] = None  # B_u of x[t] ~ MvNormal(μ = A*x[t-1] + B_u*u[t], Σ = P), u a data variable
 
 
-def linear_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transition=False, state_offset=None, obs_offset=None):
+def linear_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transition=False, state_offset=None, obs_offset=None,
+                        input_matrix=None):
     """`state_offset` / `obs_offset`: known inputs added to the means (`A * x[t-1] + c`, `B * x[t] + d`), one vector or one
-    per time index."""
+    per time index.  `input_matrix` = B_u: the inputs are DATA, `infer(..., data = {"y": …, "u": …})` with u [T][du] per chain."""
     f = lambda a: np.asarray(a, dtype=np.float64)
     g = lambda a: None if a is None else f(a)
     return LinearGaussianSSM(f(A), f(B), f(P), f(Q), f(prior_mean), f(prior_cov), bool(prior_through_transition),
-                             state_offset=g(state_offset), obs_offset=g(obs_offset))
+                             state_offset=g(state_offset), obs_offset=g(obs_offset), input_matrix=g(input_matrix))
 
 
 def time_varying_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transition=False):
@@ -423,8 +425,20 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
         eng = LGSSMEngine(model.A, model.B, model.P, model.Q, m0, V0, T=T, n_chains=C,
                           prior_through_transition=model.prior_through_transition, horizon=horizon,
                           allow_missing=allow_missing, step_model=step_model,
-                          state_offset=model.state_offset, obs_offset=model.obs_offset,
+                          state_offset=(model.state_offset if model.input_matrix is None else np.zeros(model.A.shape[-1])),
+                          obs_offset=model.obs_offset,
                           segments=int(options.get("segments", 0)), device=int(options.get("device", -1)))
+        if model.input_matrix is not None:   # control inputs as data: c[t] = B_u u[t] (+ the constant part) for every chain
+            if "u" not in data:
+                raise ValueError("this model has data inputs: data must provide `u`")
+            u = np.asarray(data["u"], dtype=np.float64)
+            u = u[None] if single else u
+            c = u @ model.input_matrix.T
+            if model.state_offset is not None:
+                c = c + model.state_offset
+            if c.shape[1] != T + horizon:
+                raise ValueError(f"`u` has {c.shape[1]} steps, the data {T + horizon}")
+            eng.set_chain_offsets(c, None, layout="chain_time")
         eng.set_data(y, layout="chain_time")
         eng.run(iterations=iters, free_energy=free_energy)
         mean, cov = eng.marginals(layout="chain_time")

@@ -151,6 +151,17 @@ class LGSSMEngine:
         cy = None if obs_offset is None else _c(np.broadcast_to(np.asarray(obs_offset, dtype=np.float64), (To, self.dy)))
         self._chk(_lib.lib().rxhip_lgssm_set_offsets(self._h, _p(cx) if cx is not None else None, _p(cy) if cy is not None else None))
 
+    def set_chain_offsets(self, state_offset=None, obs_offset=None, layout="time_chain"):
+        """Known inputs per chain (rxhip_lgssm_set_chain_offsets): [T+horizon][chain][d] / [..][dy] ('time_chain') or
+        [chain][T+horizon][·] ('chain_time')."""
+        To, C = self.T + self.horizon, self.n_chains
+        shp = (lambda k: (To, C, k)) if layout == "time_chain" else (lambda k: (C, To, k))
+        cx = None if state_offset is None else _c(state_offset, shp(self.d))
+        cy = None if obs_offset is None else _c(obs_offset, shp(self.dy))
+        lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
+        self._chk(_lib.lib().rxhip_lgssm_set_chain_offsets(self._h, _p(cx) if cx is not None else None,
+                                                           _p(cy) if cy is not None else None, lay))
+
     def filter_reset(self):
         self._chk(_lib.lib().rxhip_filter_reset(self._h))
 

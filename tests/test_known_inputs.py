@@ -228,3 +228,59 @@ def test_new_inputs_for_a_live_engine():
                 assert np.allclose(mean[c], om, rtol=1e-6, atol=1e-8) and fe[c] == pytest.approx(nll, rel=1e-8)
     with rxhip.LGSSMEngine(*one, T=T, n_chains=C) as eng, pytest.raises(rxhip.RxHipError):
         eng.set_offsets(np.zeros(d))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,dy,C,T,H,ptt,lay", [(2, 2, 5, 60, 0, False, "chain_time"), (4, 3, 64, 130, 4, True, "time_chain"), (8, 6, 4, 50, 3, False, "chain_time")])
+def test_inputs_that_are_data_of_every_chain(d, dy, C, T, H, ptt, lay, monkeypatch):
+    """`x[t] ~ MvNormal(μ = A*x[t-1] + B_u*u[t], Σ = P)` with u a datavar: every chain has its own inputs (rxhip_lgssm_set_chain_offsets)."""
+    import rxhip
+    if C % 64 == 0:
+        monkeypatch.setenv("RXHIP_ONE_PASS", "1")
+    rng = np.random.default_rng(d + T)
+    mdl = _models(rng, d, dy, 1)
+    one = tuple(x[0] for x in mdl)
+    A, B, P, Q = one[:4]
+    cx, cy = rng.standard_normal((C, T + H, d)), rng.standard_normal((C, T + H, dy))
+    y = rng.standard_normal((C, T, dy))
+    put = (lambda a: np.ascontiguousarray(np.transpose(a, (1, 0, 2)))) if lay == "time_chain" else (lambda a: a)
+    with rxhip.LGSSMEngine(*one, T=T, n_chains=C, horizon=H, prior_through_transition=ptt, state_offset=np.zeros(d)) as eng:
+        eng.set_data(y, layout="chain_time")
+        eng.set_chain_offsets(put(cx), put(cy), layout=lay)
+        eng.run(1, True)
+        mean, cov = eng.marginals(layout="chain_time")
+        fe = eng.free_energy_per_chain()
+        pm, _ = eng.predictions(layout="chain_time")
+        with pytest.raises(rxhip.RxHipError):
+            eng.set_offsets(np.zeros(d))
+        eng.set_chain_offsets(put(2 * cx), None, layout=lay)      # re-planned inputs: same engine, same observations
+        eng.run(1, True)
+        mean2, _ = eng.marginals(layout="chain_time")
+        fe2 = eng.free_energy_per_chain()
+    for c in sorted({0, C // 2, C - 1}):
+        yy = np.vstack([y[c], np.full((H, dy), np.nan)])
+        om, oc, nll = rxo.lgssm_kalman_rts_affine(*one, yy, cx[c], cy[c], prior_through_transition=ptt)
+        assert np.allclose(mean[c], om, rtol=1e-6, atol=1e-8) and np.allclose(cov[c], oc, rtol=1e-6, atol=1e-8)
+        assert fe[c] == pytest.approx(nll, rel=1e-8)
+        for t in range(T, T + H):
+            assert np.allclose(pm[c, t], B @ om[t] + cy[c, t], rtol=1e-6, atol=1e-8)
+        yl = yy.copy(); yl[3] = np.nan
+        lm, _, _ = rxo.lgssm_kalman_rts_affine(*one, yl, cx[c], cy[c], prior_through_transition=ptt)
+        assert np.allclose(pm[c, 3], B @ lm[3] + cy[c, 3], rtol=1e-6, atol=1e-7)
+        om2, _, nll2 = rxo.lgssm_kalman_rts_affine(*one, yy, 2 * cx[c], None, prior_through_transition=ptt)
+        assert np.allclose(mean2[c], om2, rtol=1e-6, atol=1e-8) and fe2[c] == pytest.approx(nll2, rel=1e-8)
+
+
+@pytest.mark.gpu
+def test_infer_mirror_with_control_inputs_as_data():
+    import rxhip
+    rng = np.random.default_rng(33)
+    A, B, P, Q = np.array([[1.0, 0.1], [0.0, 1.0]]), np.array([[1.0, 0.0]]), np.eye(2) * 0.01, np.eye(1) * 0.25
+    Bu = np.array([[0.005], [0.1]])
+    spec = rxhip.linear_gaussian_ssm(A, B, P, Q, np.zeros(2), np.eye(2), input_matrix=Bu)
+    T = 70
+    u = rng.standard_normal((T, 1))
+    y = rng.standard_normal((T, 1))
+    res = rxhip.infer(model=spec, data={"y": y, "u": u}, free_energy=True)
+    om, oc, nll = rxo.lgssm_kalman_rts_affine(A, B, P, Q, np.zeros(2), np.eye(2), y, u @ Bu.T, None)
+    assert np.allclose(res.posteriors["x"].mean, om, rtol=1e-6, atol=1e-8) and res.free_energy[-1] == pytest.approx(nll, rel=1e-8)
