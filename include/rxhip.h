@@ -52,7 +52,9 @@ enum {
 /* variable ids of the LGSSM schedule */
 enum {
     RXHIP_VAR_Y = 0, /* data variable y[t]   (src/inference/batch.jl:405-407 new_observation!) */
-    RXHIP_VAR_X = 1  /* random variable x[t] (posteriors[:x], src/inference/batch.jl:325-332) */
+    RXHIP_VAR_X = 1, /* random variable x[t] (posteriors[:x], src/inference/batch.jl:325-332) */
+    RXHIP_VAR_U = 2  /* data variable u[t] of `A * x[t-1] + B_u * u[t]`: engines built by rxhip_create from a graph with such
+                        inputs take them through rxhip_set_data, (T·n_chains·du doubles, same layouts as y) */
 };
 
 /* ------------------------------------------------------------------------------------------
@@ -208,6 +210,9 @@ typedef struct {
     int32_t has_offsets;   /* 1: some mean carries a `+` with a constant (known inputs) */
     double* state_offset;  /* [T][d]  c[t] of `A * x[t-1] + c[t]` (nullable; zeros where a step has none) */
     double* obs_offset;    /* [T][dy] d[t] of `B * x[t] + d[t]` (nullable) */
+    int32_t du;            /* > 0: the transitions carry DATA inputs `+ B_u * u[t]` of this dimension */
+    double* input_matrix;  /* [d][du] B_u (nullable) */
+    int64_t* input_var;    /* [T] variable id of u[t], −1 where a transition has none (nullable) */
 } rxhip_lgssm_lowered;
 
 /* Host-only (no device needed): recognise a linear Gaussian state-space chain in `g` — MvNormalMeanCovariance or (scalar

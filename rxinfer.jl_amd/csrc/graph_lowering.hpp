@@ -39,6 +39,10 @@ struct Lgssm {
     int n_models = 1;
     std::vector<int> step_model;  // [T] when n_models > 1: the constants of time index t (per-step A[t], P[t], B[t], Q[t])
     std::vector<double> cx, cy;   // known inputs [T][d] / [T][dy] (`A * x[t-1] + c`, `B * x[t] + d`); empty: none
+    // inputs that are data: `A * x[t-1] + B_u * u[t]` with u[t] a data variable
+    int du = 0;                       // dimension of u (0: none)
+    std::vector<double> Bu;           // [d][du] (identity when u is added without a `*` node)
+    std::vector<long long> input_var; // [T] variable id of u[t] (-1: this transition has no input)
 };
 
 // interface k of factor f / number of interfaces (3-wide table or CSR)
@@ -125,10 +129,12 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
     for (long long f = 0; f < NF; ++f)
         if (n_iface(g, f) != 3) return unsupported("node with " + std::to_string(n_iface(g, f)) + " interfaces in a state-space chain");
     // `*` node producing each (anonymous) variable; Gaussian node by its μ variable; `+` nodes by their random input
-    std::vector<long long> mul_of_out(NV, -1), add_of_out(NV, -1), writer(NV, -1);
+    std::vector<long long> mul_of_out(NV, -1), add_of_out(NV, -1), writer(NV, -1), mul_data(NV, -1);
+    std::vector<long long> add_input(NF, -1);  // `+` node -> its data-side input variable (u[t] itself or the output of B_u * u[t])
     std::vector<std::vector<long long>> mul_of_in(NV), gauss_by_mu(NV), add_of_in(NV);
     long long prior = -1;
     bool scalar_nodes = false;
+    std::vector<long long> pending_adds;
     auto writes = [&](long long v, long long f) -> bool {  // one factor "produces" a variable: rejects merges and cycles early
         if (writer[v] >= 0) return false;
         writer[v] = f;
@@ -139,6 +145,11 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         const int t = g->factor_type[f];
         if (t == RXHIP_NODE_MULTIPLY) {
             if (g->var_kind[io[1]] != RXHIP_VARKIND_CONST) return unsupported("`*` node with a non-constant matrix (no device schedule)");
+            if (g->var_kind[io[2]] == RXHIP_VARKIND_DATA && g->var_kind[io[0]] == RXHIP_VARKIND_RANDOM) {
+                if (!writes(io[0], f)) return unsupported("variable produced by two nodes");
+                mul_data[io[0]] = f;  // `B_u * u[t]`: a deterministic function of data, consumed by a `+` below
+                continue;
+            }
             if (g->var_kind[io[2]] != RXHIP_VARKIND_RANDOM || g->var_kind[io[0]] != RXHIP_VARKIND_RANDOM)
                 return unsupported("`*` node must connect two random variables");
             if (mul_of_out[io[0]] >= 0 || !writes(io[0], f)) return unsupported("variable produced by two nodes");
@@ -157,8 +168,15 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
             } else
                 return unsupported("Gaussian node whose mean is a data variable");
         } else if (t == RXHIP_NODE_ADD) {
-            const bool c1 = g->var_kind[io[1]] == RXHIP_VARKIND_CONST, c2 = g->var_kind[io[2]] == RXHIP_VARKIND_CONST;
-            if (c1 == c2) return unsupported("`+` node needs exactly one constant input");
+            bool c1 = g->var_kind[io[1]] == RXHIP_VARKIND_CONST, c2 = g->var_kind[io[2]] == RXHIP_VARKIND_CONST;
+            if (c1 && c2) return unsupported("`+` node with two constant inputs");
+            if (!c1 && !c2) {
+                // no constant: one side must be data — u[t] itself or (later resolved) the output of `B_u * u[t]`
+                const bool d1 = g->var_kind[io[1]] == RXHIP_VARKIND_DATA, d2 = g->var_kind[io[2]] == RXHIP_VARKIND_DATA;
+                if (d1 == d2) { pending_adds.push_back(f); continue; }  // decided once every `*` node has been seen
+                add_input[f] = d1 ? io[1] : io[2];
+                c1 = d1; c2 = d2;
+            }
             const long long xin = c1 ? io[2] : io[1];
             if (g->var_kind[xin] != RXHIP_VARKIND_RANDOM || g->var_kind[io[0]] != RXHIP_VARKIND_RANDOM) return unsupported("`+` node must connect two random variables");
             if (!writes(io[0], f)) return unsupported("random variable that is the output of two nodes: not a chain");
@@ -166,6 +184,17 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
             add_of_out[io[0]] = f;
         } else
             return unsupported("node type " + std::to_string(t) + " has no device schedule");
+    }
+    for (long long f : pending_adds) {  // `+` of two random variables: one of them is `B_u * u[t]`
+        const long long io[3] = {iface(g, f, 0), iface(g, f, 1), iface(g, f, 2)};
+        const bool m1 = mul_data[io[1]] >= 0, m2 = mul_data[io[2]] >= 0;
+        if (m1 == m2) return unsupported("`+` node needs a constant or a data-driven input");
+        add_input[f] = m1 ? io[1] : io[2];
+        const long long xin = m1 ? io[2] : io[1];
+        if (g->var_kind[io[0]] != RXHIP_VARKIND_RANDOM) return unsupported("`+` node must connect two random variables");
+        if (!writes(io[0], f)) return unsupported("random variable that is the output of two nodes: not a chain");
+        add_of_in[xin].push_back(f);
+        add_of_out[io[0]] = f;
     }
     if (prior < 0) return unsupported("no prior node (Gaussian node with constant mean)");
     // an anonymous `A * x` feeds exactly one consumer: a Gaussian mean, or a `+` with a constant (known input) in front of one
@@ -196,7 +225,11 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         visited[x] = 1;
         std::vector<Branch> br;
         if (mul_of_out[x] >= 0) return unsupported("the output of a `*` node used as a state");
-        auto add_const = [&](long long f) { return g->var_kind[iface(g, f, 1)] == RXHIP_VARKIND_CONST ? iface(g, f, 1) : iface(g, f, 2); };
+        // the `+` node's constant — or, for a data-driven input, the node itself encoded as −(10 + f)
+        auto add_const = [&](long long f) -> long long {
+            if (add_input[f] >= 0) return -(10 + f);
+            return g->var_kind[iface(g, f, 1)] == RXHIP_VARKIND_CONST ? iface(g, f, 1) : iface(g, f, 2);
+        };
         long long add = -1;  // a `+` whose output is the next STATE: the noise-free drift transition
         for (long long f : mul_of_in[x]) {
             const long long v = iface(g, f, 0);
@@ -204,7 +237,7 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
                 const long long a = add_of_in[v][0], w = iface(g, a, 0);
                 if (gauss_by_mu[w].empty()) return unsupported("`A * x + c` that feeds no Gaussian mean");
                 br.push_back({gauss_by_mu[w][0], iface(g, f, 1), add_const(a)});
-                used_factors += 1;
+                used_factors += 1 + ((add_input[a] >= 0 && g->var_kind[add_input[a]] != RXHIP_VARKIND_DATA) ? 1 : 0);  // `+` (and `B_u * u`)
             } else
                 br.push_back({gauss_by_mu[v][0], iface(g, f, 1), -1});
         }
@@ -221,7 +254,7 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
             const bool to_data = one_gauss && g->var_kind[iface(g, gauss_by_mu[w][0], 0)] == RXHIP_VARKIND_DATA;
             if (!continues && (to_random || (to_data && (onward || n_noisy > 0)))) {
                 br.push_back({gauss_by_mu[w][0], -1, add_const(a)});
-                used_factors += 1;
+                used_factors += 1 + ((add_input[a] >= 0 && g->var_kind[add_input[a]] != RXHIP_VARKIND_DATA) ? 1 : 0);
                 onward = onward || to_random;
             } else {
                 if (add >= 0) return unsupported("state with two `+` transitions: not a chain");
@@ -266,6 +299,7 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
             ++n_noisy;
             x = iface(g, tr, 0);
         } else if (add >= 0) {
+            if (add_input[add] >= 0) return unsupported("noise-free transition with a data input");
             const long long cv = add_const(add);
             if (vC < 0) vC = cv;
             else if (!same_const(g, vC, cv)) return unsupported("time-varying drift");
@@ -350,10 +384,46 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
         any_cx = any_cx || sCx[t] >= 0;
         any_cy = any_cy || sCy[t] >= 0;
     }
+    // data-driven inputs of the transitions: u[t] and B_u (one matrix for the whole chain)
+    long long vBu = -2;  // -2: none seen, -1: identity (u added directly)
+    for (long long t = 0; t < T; ++t) {
+        if (sCy[t] <= -10) return unsupported("data-driven offset of an observation");
+        if (sCx[t] > -10) continue;
+        const long long f = -(sCx[t] + 10), v = add_input[f];
+        long long uvar = v, bu = -1;
+        if (g->var_kind[v] != RXHIP_VARKIND_DATA) {
+            const long long mf = mul_data[v];
+            uvar = iface(g, mf, 2);
+            bu = iface(g, mf, 1);
+        }
+        if (vBu == -2) { vBu = bu; L.du = g->var_rows[uvar]; L.input_var.assign((size_t)T, -1); }
+        else if ((vBu < 0) != (bu < 0) || (bu >= 0 && !same_const(g, vBu, bu))) return unsupported("input matrix B_u changes along the chain");
+        if (g->var_rows[uvar] != L.du) return unsupported("input dimension changes along the chain");
+        L.input_var[(size_t)t] = uvar;
+        sCx[t] = -1;  // no constant part at this step
+    }
+    if (L.du > 0) {
+        if (n_det > 0) return unsupported("noise-free `+` chain with data inputs");
+        if (vBu >= 0) {
+            const double* q;
+            if (!const_value(g, vBu, d, L.du, &q)) return badarg("input matrix B_u has the wrong shape");
+            L.Bu.assign(q, q + (size_t)d * L.du);
+        } else {
+            if (L.du != d) return unsupported("an input added without a `*` node must have the state's dimension");
+            L.Bu.assign((size_t)d * d, 0.0);
+            for (int i = 0; i < d; ++i) L.Bu[(size_t)i * d + i] = 1.0;
+        }
+        any_cx = false;
+        for (long long t = 0; t < T; ++t) any_cx = any_cx || sCx[t] >= 0;
+        L.cx.assign((size_t)T * d, 0.0);  // offsets are reserved whenever inputs exist
+        L.cy.assign((size_t)T * dy, 0.0);
+    }
     if (any_cx || any_cy) {
         if (n_det > 0) return unsupported("noise-free `+` chain with further offsets");
+        if (L.cx.empty()) {
         L.cx.assign((size_t)T * d, 0.0);
         L.cy.assign((size_t)T * dy, 0.0);
+        }
         for (long long t = 0; t < T; ++t) {
             const double* q;
             if (sCx[t] >= 0) {

@@ -335,7 +335,11 @@ struct rxhip_engine {
     long long stream_k = 0;
     double *d_mu = nullptr, *d_nu = nullptr, *d_cx = nullptr, *d_cy_raw = nullptr;  // known inputs: μ[t] [Tout][d], ν[t] = B μ[t] + d[t] [Tout][dy], c[t], d[t]
     std::vector<double> h_mu, h_nu, h_cx, h_cy, h_offA, h_offB;
+    std::vector<double> h_cx_const, h_cy_const;  // the offsets the engine was created with (graph constants), for RXHIP_VAR_U
     std::vector<int> h_offsm;
+    int du = 0;                    // graph engines with data inputs `+ B_u * u[t]`: dimension of u, B_u [d][du], which steps have one
+    std::vector<double> h_Bu;
+    std::vector<char> h_umask;
     bool off_chain = false;        // the device offset arrays carry a chain axis (rxhip_lgssm_set_chain_offsets)
     double* d_off_chain = nullptr; // their block: μ | ν | c | d with a chain axis, and A | B of every model
     std::vector<double> h_user;  // MFMA path: user-level A | P | B | Q | Q⁻¹ of every model (generic_kernels.hpp)
@@ -1620,6 +1624,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->h_offB.assign(ds->B, ds->B + (size_t)ds->n_models * dy * d);
         if (ds->step_model) e->h_offsm.assign(ds->step_model, ds->step_model + To);
         offsets_to_shifts(e, ds->state_offset, ds->obs_offset);
+        e->h_cx_const = e->h_cx;
+        e->h_cy_const = e->h_cy;
     }
     if (dense) {  // predictions / forecasts of the MFMA path run on the user-level constants
         const size_t dd = (size_t)ds->d * ds->d, bd = (size_t)ds->dy * ds->d, qq = (size_t)ds->dy * ds->dy, sz = 2 * dd + bd + 2 * qq;
@@ -2385,6 +2391,9 @@ rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowe
     out->deterministic = L.deterministic;
     out->n_models = L.n_models;
     out->has_offsets = L.cx.empty() ? 0 : 1;
+    out->du = L.du;
+    if (out->input_matrix && L.du > 0) std::memcpy(out->input_matrix, L.Bu.data(), sizeof(double) * L.Bu.size());
+    if (out->input_var) for (long long t = 0; t < L.T; ++t) out->input_var[t] = L.du > 0 ? L.input_var[t] : -1;
     if (out->state_offset) for (size_t q = 0; q < (size_t)L.T * L.d; ++q) out->state_offset[q] = L.cx.empty() ? 0.0 : L.cx[q];
     if (out->obs_offset) for (size_t q = 0; q < (size_t)L.T * L.dy; ++q) out->obs_offset[q] = L.cy.empty() ? 0.0 : L.cy[q];
     if (out->step_model) for (long long t = 0; t < L.T; ++t) out->step_model[t] = L.n_models > 1 ? L.step_model[t] : 0;
@@ -2506,7 +2515,14 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
     d.allow_missing = g->allow_missing;
     if (!L.cx.empty()) { d.state_offset = L.cx.data(); d.obs_offset = L.cy.data(); }
     d.segments = segments; d.device = device; d.stream = stream;
-    return rxhip_lgssm_create(&d, out);
+    st = rxhip_lgssm_create(&d, out);
+    if (!st && L.du > 0) {  // data inputs: u arrives through rxhip_set_data(RXHIP_VAR_U); its constant part (if any) stays in c
+        (*out)->du = L.du;
+        (*out)->h_Bu = L.Bu;
+        (*out)->h_umask.assign((size_t)L.T, 0);
+        for (long long t = 0; t < L.T; ++t) (*out)->h_umask[(size_t)t] = L.input_var[(size_t)t] >= 0 ? 1 : 0;
+    }
+    return st;
 }
 
 static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t layout, bool src_on_device) {
@@ -2555,8 +2571,37 @@ static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t
     return RXHIP_OK;
 }
 
+// u[t] of every chain -> c[t] = B_u u[t] (+ the constant part of the same step) -> per-chain offsets
+static rxhip_status ingest_inputs(rxhip_engine* e, const double* u, size_t n, int32_t layout) {
+    if (e->kind != 0 || e->du <= 0) return fail(e, RXHIP_ERR_BADARG, "set_data: this engine has no data inputs u[t]");
+    const size_t C = (size_t)e->n_chains, T = (size_t)e->T, To = (size_t)e->Tout(), d = (size_t)e->d, du = (size_t)e->du;
+    if (!u || n != T * C * du) return fail(e, RXHIP_ERR_BADARG, "set_data(u): expected %zu doubles, got %zu", T * C * du, n);
+    if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME) return fail(e, RXHIP_ERR_BADARG, "set_data: unknown layout %d", layout);
+    std::vector<double> c(To * C * d, 0.0);  // [t][chain][d]
+    for (size_t t = 0; t < T; ++t)
+        for (size_t ch = 0; ch < C; ++ch) {
+            const double* ut = u + (layout == RXHIP_LAYOUT_TIME_CHAIN ? (t * C + ch) : (ch * T + t)) * du;
+            double* ct = &c[(t * C + ch) * d];
+            for (size_t i = 0; i < d; ++i) {
+                double s = e->h_cx.empty() ? 0.0 : e->h_cx_const[t * d + i];
+                if (e->h_umask[t])
+                    for (size_t k = 0; k < du; ++k) s += e->h_Bu[i * du + k] * ut[k];
+                ct[i] = s;
+            }
+        }
+    // the observation offsets of the graph (constants) stay what they were: replicate them per chain
+    std::vector<double> cy;
+    if (!e->h_cy_const.empty()) {
+        cy.resize(To * C * (size_t)e->dy);
+        for (size_t t = 0; t < To; ++t)
+            for (size_t ch = 0; ch < C; ++ch) std::memcpy(&cy[(t * C + ch) * e->dy], &e->h_cy_const[t * e->dy], sizeof(double) * e->dy);
+    }
+    return rxhip_lgssm_set_chain_offsets(e, c.data(), cy.empty() ? nullptr : cy.data(), RXHIP_LAYOUT_TIME_CHAIN);
+}
+
 rxhip_status rxhip_set_data(rxhip_engine* e, int32_t var_id, const double* host, size_t n, int32_t layout) {
     if (!e) return RXHIP_ERR_BADARG;
+    if (var_id == RXHIP_VAR_U) return ingest_inputs(e, host, n, layout);
     if (var_id != RXHIP_VAR_Y) return fail(e, RXHIP_ERR_BADARG, "set_data: variable %d is not a data variable", var_id);
     return ingest(e, host, n, layout, false);
 }

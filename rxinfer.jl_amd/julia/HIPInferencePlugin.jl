@@ -298,6 +298,9 @@ mutable struct HIPGraphEngine
     state_ids::Vector{Int64}             # x[t] in time order (state-space families)
     width::Int                           # doubles per observation
     component_ids::Any                   # mixtures: (m = ids, p = ids, s = id, beta = Bool)
+    input_slot::Dict{Int64, Int}         # data inputs u[t] (`A * x[t-1] + B_u * u[t]`): variable id -> time index (1-based)
+    input_staging::Vector{Float64}       # [t][du], zero where a transition has no input
+    du::Int
     predictions::Dict{Int64, Any}        # data variable id -> RecentSubject of its prediction, created on first request
     masked::Bool                         # the engine takes `missing` observations (rebuilt on the first one, see `fire!`)
     options::Any                         # HIPInferenceOptions (segments, device) for that rebuild
@@ -342,6 +345,18 @@ ReactiveMP.get_stream_of_predictions(v::HIPRandomVariable) = v.stream   # a rand
 function ReactiveMP.new_observation!(v::HIPDataVariable, value)
     g = v.graph[]
     g === nothing && error("HIP data variable is not attached to an engine")
+    if haskey(g.input_slot, v.id)   # a control input u[t]: staged like an observation, never missing
+        ismissing(value) && error("a data input of the transition cannot be missing")
+        vals = value isa Real ? (Float64(value),) : value
+        length(vals) == g.du || error("input of length $(length(vals)), expected $(g.du)")
+        t = g.input_slot[v.id]
+        @inbounds for (k, x) in enumerate(vals)
+            g.input_staging[(t - 1) * g.du + k] = x
+        end
+        g.received += 1
+        g.received == length(g.data_ids) + length(g.input_slot) && fire!(g)
+        return nothing
+    end
     slot = g.data_slot[v.id]
     if ismissing(value)   # `missing` = NaN on the device: no message from this observation branch (static.md:98-123)
         g.family === :lgssm || error("the HIP backend takes missing observations in state-space graphs only")
@@ -355,7 +370,7 @@ function ReactiveMP.new_observation!(v::HIPDataVariable, value)
         g.staging[(slot - 1) * g.width + k] = x
     end
     g.received += 1
-    g.received == length(g.data_ids) && fire!(g)
+    g.received == length(g.data_ids) + length(g.input_slot) && fire!(g)
     return nothing
 end
 
@@ -370,6 +385,7 @@ function fire!(g::HIPGraphEngine)
         g.masked = true
     end
     e = g.engine
+    isempty(g.input_slot) || RxHip.set_inputs!(e, g.input_staging)
     GC.@preserve g begin
         RxHip.check(e, ccall((:rxhip_set_data, RxHip.librxhip), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Csize_t, Int32),
                              e.handle, RxHip.RXHIP_VAR_Y, g.staging, length(g.staging), RxHip.RXHIP_LAYOUT_CHAIN_TIME))
@@ -502,7 +518,10 @@ function GraphPPL.postprocess_plugin(plugin::HIPInferencePlugin, model::GraphPPL
     width = Int(tables.var_rows[lowered.data_ids[1] + 1])
     g = HIPGraphEngine(engine, tables, lowered.family, lowered.data_ids, Dict(id => k for (k, id) in enumerate(lowered.data_ids)),
                        zeros(Float64, width * length(lowered.data_ids)), 0, false, marginals, nothing, lowered.state_ids, width,
-                       component_ids(tables), Dict{Int64, Any}(), false, getoptions(plugin))
+                       component_ids(tables),
+                       Dict{Int64, Int}(id => t for (t, id) in enumerate(get(lowered, :input_ids, Int64[])) if id >= 0),
+                       zeros(Float64, get(lowered, :du, 0) * length(lowered.data_ids)), get(lowered, :du, 0),
+                       Dict{Int64, Any}(), false, getoptions(plugin))
     gref[] = g
     GraphPPL.setextra!(GraphPPL.getcontext(model), HIPEngineKey, g)   # one handle per model; found again by `score`
     return nothing

@@ -18,6 +18,7 @@ const RXHIP_LAYOUT_TIME_CHAIN = Int32(0)
 const RXHIP_LAYOUT_CHAIN_TIME = Int32(1)
 const RXHIP_VAR_Y = Int32(0)
 const RXHIP_VAR_X = Int32(1)
+const RXHIP_VAR_U = Int32(2)
 
 struct RxHipError <: Exception
     status::Int32
@@ -158,6 +159,12 @@ function predictions(e::Engine)
                                          (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Int32),
                                          e.handle, RXHIP_VAR_Y, mean, cov, RXHIP_LAYOUT_CHAIN_TIME))
     return mean, cov
+end
+
+"""Data inputs u[t] of `A * x[t-1] + B_u * u[t]` (graph engines, `rxhip_set_data(RXHIP_VAR_U)`): `flat` is [chain][t][du] row-major."""
+function set_inputs!(e::Engine, flat::Vector{Float64})
+    GC.@preserve flat check(e, ccall((:rxhip_set_data, librxhip), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Csize_t, Int32),
+                                     e.handle, RXHIP_VAR_U, flat, length(flat), RXHIP_LAYOUT_CHAIN_TIME))
 end
 
 """`get_node_local_marginals` of the transition nodes `x[t] ~ MvNormal(μ = A * x[t-1], Σ = P)`, t = 2 … T: the joint q(out, μ) in
@@ -369,7 +376,11 @@ mutable struct LgssmLowered
     has_offsets::Int32
     state_offset::Ptr{Float64}
     obs_offset::Ptr{Float64}
-    LgssmLowered() = new(0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, 0, C_NULL, 0, C_NULL, C_NULL)
+    du::Int32
+    input_matrix::Ptr{Float64}
+    input_var::Ptr{Int64}
+    LgssmLowered() = new(0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, 0, C_NULL, 0, C_NULL, 0, C_NULL, C_NULL,
+                         0, C_NULL, C_NULL)
 end
 
 """The engine's stream: `nothing` (engine-owned) or an AMDGPU.jl stream, whose raw `hipStream_t` is handed over so that the
@@ -433,15 +444,17 @@ function lowered_layout(t)
         ccall((:rxhip_graph_lower_lgssm, librxhip), Int32, (Ref{GraphDesc}, Ref{LgssmLowered}), desc, low)
     end
     st == RXHIP_OK || throw(RxHipError(st, lowering_error()))
-    sv, dv = Vector{Int64}(undef, low.T), Vector{Int64}(undef, low.T)
-    GC.@preserve sv dv begin
-        low.state_var, low.data_var = pointer(sv), pointer(dv)
+    sv, dv, uv = Vector{Int64}(undef, low.T), Vector{Int64}(undef, low.T), Vector{Int64}(undef, low.T)
+    GC.@preserve sv dv uv begin
+        low.state_var, low.data_var, low.input_var = pointer(sv), pointer(dv), pointer(uv)
         st = with_desc(t, 1, 0) do desc
             ccall((:rxhip_graph_lower_lgssm, librxhip), Int32, (Ref{GraphDesc}, Ref{LgssmLowered}), desc, low)
         end
     end
     st == RXHIP_OK || throw(RxHipError(st, lowering_error()))
-    return (family = low.deterministic != 0 ? :drift : :lgssm, d = Int(low.d), width = Int(low.dy), data_ids = dv, state_ids = sv)
+    # data inputs `A * x[t-1] + B_u * u[t]`: variable id of u[t] per time index (−1: that transition has none), dimension du
+    return (family = low.deterministic != 0 ? :drift : :lgssm, d = Int(low.d), width = Int(low.dy), data_ids = dv, state_ids = sv,
+            du = Int(low.du), input_ids = low.du > 0 ? uv : Int64[])
 end
 
 """Split-phase VMP iteration of the mixture engines (`rxhip_gmm_begin_run` once, then accumulate + update per iteration):

@@ -12,7 +12,7 @@ c_u64_p = ctypes.POINTER(ctypes.c_uint64)
 
 OK, ERR_BADARG, ERR_UNSUPPORTED, ERR_NOT_POSDEF, ERR_NONFINITE_FE, ERR_HIP, ERR_NO_DEVICE, ERR_STATE, ERR_RCCL = range(9)
 LAYOUT_TIME_CHAIN, LAYOUT_CHAIN_TIME = 0, 1
-VAR_Y, VAR_X = 0, 1
+VAR_Y, VAR_X, VAR_U = 0, 1, 2
 (K_SEG_AGGREGATE, K_BOUNDARY_SCAN, K_FORWARD, K_BACKWARD, K_FE_REDUCE, K_GMM_PASS, K_GMM_REDUCE, K_GMM_UPDATE, K_HGF_FILTER,
  K_DRIFT_CHAIN, K_COUNT) = range(11)
 KERNEL_NAMES = ["k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce", "k_gmm_pass", "k_gmm_reduce",
@@ -53,7 +53,8 @@ class LgssmLowered(ctypes.Structure):
                 ("prior_through_transition", ctypes.c_int32), ("A", c_double_p), ("B", c_double_p), ("P", c_double_p),
                 ("Q", c_double_p), ("m0", c_double_p), ("V0", c_double_p), ("state_var", c_int64_p), ("data_var", c_int64_p),
                 ("deterministic", ctypes.c_int32), ("c", c_double_p), ("n_models", ctypes.c_int32), ("step_model", c_int32_p),
-                ("has_offsets", ctypes.c_int32), ("state_offset", c_double_p), ("obs_offset", c_double_p)]
+                ("has_offsets", ctypes.c_int32), ("state_offset", c_double_p), ("obs_offset", c_double_p),
+                ("du", ctypes.c_int32), ("input_matrix", c_double_p), ("input_var", c_int64_p)]
 
 
 class GmmLowered(ctypes.Structure):

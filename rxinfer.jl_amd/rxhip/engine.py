@@ -109,6 +109,12 @@ class LGSSMEngine:
         lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
         self._chk(_lib.lib().rxhip_set_data(self._h, _lib.VAR_Y, _p(y), y.size, lay))
 
+    def set_inputs(self, u, layout="time_chain"):
+        """Data inputs u[t] of `A * x[t-1] + B_u * u[t]` (engines built from a graph with such inputs): [T][chain][du] / [chain][T][du]."""
+        u = _c(u)
+        lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME
+        self._chk(_lib.lib().rxhip_set_data(self._h, _lib.VAR_U, _p(u), u.size, lay))
+
     def set_data_device(self, ptr, n, layout="time_chain", keepalive=None):
         """Observations already in device memory (e.g. a torch tensor's data_ptr())."""
         lay = _lib.LAYOUT_TIME_CHAIN if layout == "time_chain" else _lib.LAYOUT_CHAIN_TIME

@@ -176,7 +176,8 @@ class GraphBuilder:
 
 
 def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=None, P_of_t=None, B_of_t=None, Q_of_t=None,
-                c_of_t=None, d_of_t=None, const_first=False):
+                c_of_t=None, d_of_t=None, const_first=False, Bu=None, du=0):
+    # Bu / du: data inputs `A * x[t-1] + B_u * u[t]` (Bu = None with du > 0: u[t] added directly, du = d); returned as a 4th list
     """The graph GraphPPL builds for the benchmark notebook's model (cell 4) / mlgssm_test.jl:9-17.  X_of_t(t): the constant
     of time index t when the @model loop indexes an array of matrices (`A[t] * x[t-1]`, `Σ = P[t]`, …)."""
     A, B = np.asarray(A, float), np.asarray(B, float)
@@ -184,7 +185,7 @@ def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=No
     gb = GraphBuilder()
     x = gb.randomvar(d)
     gb.mvnormal_mean_cov(x, gb.constvar(m0), gb.constvar(V0))
-    xs, ys = [], []
+    xs, ys, us = [], [], []
     for t in range(T):
         if t > 0 or prior_through_transition:
             a = gb.randomvar(d)
@@ -192,6 +193,16 @@ def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=No
             if c_of_t is not None and c_of_t(t) is not None:   # `A * x[t-1] + c[t]`: a known input
                 w = gb.randomvar(d)
                 gb.node(_lib.NODE_ADD, w, *((gb.constvar(c_of_t(t)), a) if const_first else (a, gb.constvar(c_of_t(t)))))
+                a = w
+            if du:                                             # `… + B_u * u[t]` with u[t] a data variable
+                u = gb.datavar(du)
+                us.append(u)
+                if Bu is not None:
+                    bu = gb.randomvar(d)
+                    gb.multiply(bu, gb.constvar(Bu), u)
+                    u = bu
+                w = gb.randomvar(d)
+                gb.node(_lib.NODE_ADD, w, a, u)
                 a = w
             xn = gb.randomvar(d)
             gb.mvnormal_mean_cov(xn, a, gb.constvar(P if P_of_t is None else P_of_t(t)))
@@ -205,6 +216,8 @@ def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=No
         y = gb.datavar(dy)
         gb.mvnormal_mean_cov(y, b, gb.constvar(Q if Q_of_t is None else Q_of_t(t)))
         xs.append(x); ys.append(y)
+    if du:
+        return gb, xs, ys, us
     return gb, xs, ys
 
 
@@ -272,9 +285,14 @@ def lower_lgssm(g):
     out.state_var = sv.ctypes.data_as(_lib.c_int64_p)
     out.data_var = dv.ctypes.data_as(_lib.c_int64_p)
     out.step_model = sm.ctypes.data_as(_lib.c_int32_p)
+    du = int(out.du)
+    Bu, uv = np.empty((d, max(du, 1))), np.empty(T, dtype=np.int64)
+    out.input_matrix = Bu.ctypes.data_as(_lib.c_double_p)
+    out.input_var = uv.ctypes.data_as(_lib.c_int64_p)
     st = L.rxhip_graph_lower_lgssm(ctypes.byref(g), ctypes.byref(out))
     if st != _lib.OK:
         raise RxHipError(st, L.rxhip_lowering_error().decode())
+    bufs["input_matrix"], bufs["input_var"], bufs["du"] = (Bu if du else None), (uv if du else None), du
     if M == 1:  # time-invariant: plain matrices, as before
         for k in "ABPQ":
             bufs[k] = bufs[k][0]
@@ -303,6 +321,7 @@ def create_engine_from_graph(g, segments=0, device=-1, stream=None):
         eng = LGSSMEngine.__new__(LGSSMEngine)
     eng._h, eng.d, eng.dy, eng.T, eng.n_chains, eng.n_models = h, low["d"], low["dy"], low["T"], int(g.n_replicas or 1), low["n_models"]
     eng.horizon = 0
+    eng.du = int(low["du"])
     eng._keep, eng._data_ref, eng._iters = [], None, 0
     return eng
 

@@ -284,3 +284,48 @@ def test_infer_mirror_with_control_inputs_as_data():
     res = rxhip.infer(model=spec, data={"y": y, "u": u}, free_energy=True)
     om, oc, nll = rxo.lgssm_kalman_rts_affine(A, B, P, Q, np.zeros(2), np.eye(2), y, u @ Bu.T, None)
     assert np.allclose(res.posteriors["x"].mean, om, rtol=1e-6, atol=1e-8) and res.free_energy[-1] == pytest.approx(nll, rel=1e-8)
+
+
+def test_data_inputs_in_a_graph_are_recognised():
+    """`x[t] ~ MvNormal(μ = A * x[t-1] + B_u * u[t], Σ = P)` with u[t] a data variable: `*`(B_u, u) feeding a `+` without a constant."""
+    import rxhip  # noqa: F401
+    from rxhip import graph
+    rng = np.random.default_rng(8)
+    d, dy, T, du = 3, 2, 6, 2
+    mdl = _models(rng, d, dy, 1)
+    A, B, P, Q, m0, V0 = (x[0] for x in mdl)
+    Bu = rng.standard_normal((d, du))
+    for ptt in (False, True):
+        gb, xs, ys, us = graph.lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=ptt, Bu=Bu, du=du)
+        low = graph.lower_lgssm(gb.tables(permute=rng.permutation(len(gb.ftype)))[0])
+        assert low["du"] == du and np.array_equal(low["input_matrix"], Bu) and low["has_offsets"] and low["T"] == T
+        want = [-1] * (0 if ptt else 1) + us   # no transition into the first state when the prior sits on x[1]
+        assert list(low["input_var"]) == want and list(low["data_var"]) == ys
+    gb, xs, ys, us = graph.lgssm_graph(T, A, B, P, Q, m0, V0, du=d)       # u[t] added directly: B_u = I
+    low = graph.lower_lgssm(gb.tables()[0])
+    assert low["du"] == d and np.array_equal(low["input_matrix"], np.eye(d))
+
+
+@pytest.mark.gpu
+def test_graph_engine_with_data_inputs():
+    import rxhip  # noqa: F401
+    from rxhip import graph
+    rng = np.random.default_rng(13)
+    d, dy, T, du, C = 2, 2, 45, 1, 3
+    mdl = _models(rng, d, dy, 1)
+    A, B, P, Q, m0, V0 = (x[0] for x in mdl)
+    Bu = rng.standard_normal((d, du))
+    cy = rng.standard_normal((T, dy))
+    gb, xs, ys, us = graph.lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=True, Bu=Bu, du=du, d_of_t=lambda t: cy[t])
+    eng = graph.create_engine_from_graph(gb.tables(n_replicas=C)[0])
+    y, u = rng.standard_normal((C, T, dy)), rng.standard_normal((C, T, du))
+    eng.set_data(y, layout="chain_time")
+    eng.set_inputs(u, layout="chain_time")
+    eng.run(1, True)
+    mean, cov = eng.marginals(layout="chain_time")
+    fe = eng.free_energy_per_chain()
+    eng.close()
+    for c in range(C):
+        om, oc, nll = rxo.lgssm_kalman_rts_affine(A, B, P, Q, m0, V0, y[c], u[c] @ Bu.T, cy, prior_through_transition=True)
+        assert np.allclose(mean[c], om, rtol=1e-6, atol=1e-8) and np.allclose(cov[c], oc, rtol=1e-6, atol=1e-8)
+        assert fe[c] == pytest.approx(nll, rel=1e-8)
