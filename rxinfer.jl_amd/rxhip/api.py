@@ -439,16 +439,21 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
             if c.shape[1] != T + horizon:
                 raise ValueError(f"`u` has {c.shape[1]} steps, the data {T + horizon}")
             eng.set_chain_offsets(c, None, layout="chain_time")
-        eng.set_data(y, layout="chain_time")
-        eng.run(iterations=iters, free_energy=free_energy)
-        mean, cov = eng.marginals(layout="chain_time")
+        fe1 = None
+        if single:   # one chain: the whole call in one round trip (rxhip_lgssm_infer)
+            m1, c1, fe1 = eng.infer(y[0][:, None, :], iterations=iters, free_energy=free_energy)
+            mean, cov = np.transpose(m1, (1, 0, 2)), np.transpose(c1, (1, 0, 2, 3))
+        else:
+            eng.set_data(y, layout="chain_time")
+            eng.run(iterations=iters, free_energy=free_energy)
+            mean, cov = eng.marginals(layout="chain_time")
         pred = None
         if predictvars:
             pm, pc = eng.predictions(layout="chain_time")
             pred = {"y": MvNormalMeanCovariance(pm[0], pc[0]) if single else MvNormalMeanCovariance(pm, pc)}
         if free_energy:
             # one value per iteration, per chain-graph: what `infer` returns for each chain
-            fe = eng.free_energy_per_chain()
+            fe = fe1 if fe1 is not None else eng.free_energy_per_chain()
             fe = np.repeat(fe[:, None], iters, axis=1)
         else:
             fe = None

@@ -257,3 +257,19 @@ def test_independent_handles_from_several_host_threads():
     for t in ts:
         t.join()
     assert not errs, errs
+
+
+def test_one_round_trip_inference_equals_the_plain_sequence():
+    """rxhip_lgssm_infer (set_data + run + marginals + free energy, one synchronisation) against the four separate calls, incl. a
+    problem large enough to take the plain sequence internally and an engine with a forecast horizon."""
+    for T, C, H in ((50, 1, 0), (300, 7, 3), (40000, 16, 0)):
+        mdl = workloads.c1_model()
+        y = workloads.generate_batch(mdl, T, C, seed0=T)
+        with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C, horizon=H) as eng:
+            m1, c1, f1 = eng.infer(y, iterations=2, free_energy=True)
+            eng.set_data(y)
+            eng.run(2, True)
+            m2, c2 = eng.marginals()
+            f2 = eng.free_energy_per_chain()
+            m3, _, _ = eng.infer(y, free_energy=False, want_cov=False)
+        assert np.array_equal(m1, m2) and np.array_equal(c1, c2) and np.array_equal(f1, f2) and np.array_equal(m3, m2)
