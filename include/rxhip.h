@@ -327,8 +327,9 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
  * […][d][d] and the per-chain free energy out (any of the three may be NULL), one pinned copy each way and a single
  * synchronisation.  At the reference's own benchmark sizes the four blocking calls of the plain sequence (≈12 µs each) are most
  * of the run time; problems above 512 KB of traffic take the plain sequence internally.  Layout: RXHIP_LAYOUT_TIME_CHAIN. */
-rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32_t iterations, int32_t want_free_energy, double* mean,
-                               double* cov, double* free_energy_per_chain);
+rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32_t iterations, int32_t want_free_energy,
+                               int32_t filtering /* 1: the streaming twin, rxhip_run_filter */, double* mean, double* cov,
+                               double* free_energy_per_chain);
 
 /* replaces: obtain_prediction(var) |> subscribe! (reactivemp_inference.jl:619-624; `predictvars = (y = KeepLast(),)`):
  * the message toward every data variable y[t], N(B m, B V B' + Q) with (m, V) the product of the forward and backward

@@ -2956,8 +2956,8 @@ rxhip_status rxhip_run(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
     return rxhip_sync(e);
 }
 
-rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32_t iterations, int32_t want_fe, double* mean, double* cov,
-                               double* fe_per_chain) {
+rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32_t iterations, int32_t want_fe, int32_t filtering,
+                               double* mean, double* cov, double* fe_per_chain) {
     if (!e || !y) return RXHIP_ERR_BADARG;
     if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "infer: not a state-space engine");
     const size_t C = (size_t)e->n_chains, ny = (size_t)e->T * C * e->dy, nm = (size_t)e->Tout() * C * e->d, nc = nm * e->d;
@@ -2967,7 +2967,7 @@ rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32
     // T = 10⁴, 0.65 MB: 0.345 against 0.362 ms; T = 2.5·10⁴, 1.6 MB: 0.93 against 0.53): they take the plain sequence.
     if (sizeof(double) * total > ((size_t)512 << 10) || !e->d_y || !e->own_y) {
         rxhip_status st = rxhip_set_data(e, RXHIP_VAR_Y, y, n, RXHIP_LAYOUT_TIME_CHAIN);
-        if (!st) st = rxhip_run(e, iterations, want_fe);
+        if (!st) st = filtering ? rxhip_run_filter(e, want_fe) : rxhip_run(e, iterations, want_fe);
         if (!st && (mean || cov)) st = rxhip_get_marginals(e, RXHIP_VAR_X, mean, cov, RXHIP_LAYOUT_TIME_CHAIN);
         if (!st && fe_per_chain && want_fe) st = rxhip_get_free_energy_per_chain(e, fe_per_chain);
         return st;
@@ -2983,7 +2983,7 @@ rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32
     HIPCHK(e, hipMemcpyAsync(e->d_y, hy, sizeof(double) * ny, hipMemcpyHostToDevice, e->stream));
     if (e->d_nu) hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, -1.0, e->off_chain ? 1 : 0);
     e->have_data = true;
-    if (rxhip_status st = run_impl(e, iterations, want_fe, false)) return st;
+    if (rxhip_status st = run_impl(e, filtering ? 1 : iterations, want_fe, filtering != 0)) return st;
     if (mean) HIPCHK(e, hipMemcpyAsync(hm, e->d_mean, sizeof(double) * nm, hipMemcpyDeviceToHost, e->stream));
     if (cov) HIPCHK(e, hipMemcpyAsync(hc, e->d_cov, sizeof(double) * nc, hipMemcpyDeviceToHost, e->stream));
     if (fe_per_chain && want_fe) HIPCHK(e, hipMemcpyAsync(hf, e->d_fe_chain, sizeof(double) * C, hipMemcpyDeviceToHost, e->stream));

@@ -186,6 +186,21 @@ function free_energy(e::Engine)
     return fe
 end
 
+"""The body of a static `infer(...)` in one round trip (`rxhip_lgssm_infer`): observations `y` (vector of dy-vectors, one chain) in;
+posterior mean d × T, covariance d × d × T and the free energy out.  `filtering = true`: the streaming twin."""
+function infer!(e::Engine, y::AbstractVector; iterations::Integer = 1, free_energy::Bool = false, filtering::Bool = false)
+    flat = reduce(vcat, Vector{Float64}.(y))
+    mean = Array{Float64}(undef, e.d, e.T, e.n_chains)
+    cov = Array{Float64}(undef, e.d, e.d, e.T, e.n_chains)
+    fe = Vector{Float64}(undef, e.n_chains)
+    e.n_chains == 1 || throw(ArgumentError("infer!: one chain (batches: set_data! / run! / marginals)"))
+    GC.@preserve flat mean cov fe check(e, ccall((:rxhip_lgssm_infer, librxhip), Int32,
+        (Ptr{Cvoid}, Ptr{Float64}, Csize_t, Int32, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ptr{Float64}),
+        e.handle, flat, length(flat), iterations, free_energy ? 1 : 0, filtering ? 1 : 0, mean, cov, fe))
+    e.iterations = iterations
+    return mean, cov, (free_energy ? fe[1] : nothing)
+end
+
 """One observation at a time, as `RxInferenceEngine` consumes a datastream (src/inference/streaming.jl:349-407): `y` holds the new
 observation of every chain (dy × chains; `NaN` = missing); returns q(x) after it (mean d × chains, cov d × d × chains) and
 −log p(y_k | y_<k) per chain.  The belief stays on the device between calls (`filter_reset!` starts over from the prior)."""

@@ -125,7 +125,7 @@ SYMBOLS = [
     ("rxhip_filter_reset", ctypes.c_int32, [_H]),
     ("rxhip_lgssm_set_offsets", ctypes.c_int32, [_H, c_double_p, c_double_p]),
     ("rxhip_lgssm_set_chain_offsets", ctypes.c_int32, [_H, c_double_p, c_double_p, ctypes.c_int32]),
-    ("rxhip_lgssm_infer", ctypes.c_int32, [_H, c_double_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, c_double_p, c_double_p, c_double_p]),
+    ("rxhip_lgssm_infer", ctypes.c_int32, [_H, c_double_p, ctypes.c_size_t, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, c_double_p, c_double_p, c_double_p]),
     ("rxhip_get_marginals_device", ctypes.c_int32, [_H, ctypes.c_int32, ctypes.POINTER(ctypes.c_void_p),
                                                     ctypes.POINTER(ctypes.c_void_p)]),
     ("rxhip_get_marginals_chains", ctypes.c_int32, [_H, ctypes.c_int32, c_int64_p, ctypes.c_int64, c_double_p, c_double_p]),

@@ -343,10 +343,15 @@ def _infer_lgssm_filtering(model, data, free_energy, options, initialization, ca
                           prior_through_transition=model.prior_through_transition,
                           state_offset=model.state_offset, obs_offset=model.obs_offset,
                           segments=int(options.get("segments", 0)), device=int(options.get("device", -1)))
-        eng.set_data(y, layout="chain_time")
-        eng.run_filter(free_energy=free_energy)
-        mean, cov = eng.marginals(layout="chain_time")
-        fe = eng.free_energy_per_chain()[:, None] if free_energy else None
+        if single:   # one series: the whole call in one round trip
+            m1, c1, f1 = eng.infer(y[0][:, None, :], free_energy=free_energy, filtering=True)
+            mean, cov = np.transpose(m1, (1, 0, 2)), np.transpose(c1, (1, 0, 2, 3))
+            fe = f1[:, None] if free_energy else None
+        else:
+            eng.set_data(y, layout="chain_time")
+            eng.run_filter(free_energy=free_energy)
+            mean, cov = eng.marginals(layout="chain_time")
+            fe = eng.free_energy_per_chain()[:, None] if free_energy else None
         if single:
             mean, cov = mean[0], cov[0]
             fe = fe[0] if fe is not None else None

@@ -126,7 +126,7 @@ class LGSSMEngine:
         self._chk(_lib.lib().rxhip_run(self._h, int(iterations), int(bool(free_energy))))
         self._iters = int(iterations)
 
-    def infer(self, y, iterations=1, free_energy=True, want_cov=True):
+    def infer(self, y, iterations=1, free_energy=True, want_cov=True, filtering=False):
         """set_data + run + marginals (+ per-chain free energy) in one round trip (rxhip_lgssm_infer); y: [T][chain][dy].
         Returns mean [T+H][chain][d], cov | None, fe [chain] | None."""
         y = _c(y)
@@ -134,7 +134,7 @@ class LGSSMEngine:
         mean = np.empty((To, C, d))
         cov = np.empty((To, C, d, d)) if want_cov else None
         fe = np.empty(C) if free_energy else None
-        self._chk(_lib.lib().rxhip_lgssm_infer(self._h, _p(y), y.size, int(iterations), int(bool(free_energy)), _p(mean),
+        self._chk(_lib.lib().rxhip_lgssm_infer(self._h, _p(y), y.size, int(iterations), int(bool(free_energy)), int(bool(filtering)), _p(mean),
                                                _p(cov) if want_cov else None, _p(fe) if free_energy else None))
         self._iters = int(iterations)
         return mean, cov, fe

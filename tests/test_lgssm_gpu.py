@@ -272,4 +272,9 @@ def test_one_round_trip_inference_equals_the_plain_sequence():
             m2, c2 = eng.marginals()
             f2 = eng.free_energy_per_chain()
             m3, _, _ = eng.infer(y, free_energy=False, want_cov=False)
+            eng.run_filter(True)
+            fm, fc = eng.marginals()
+            ff = eng.free_energy_per_chain()
+            m4, c4, f4 = eng.infer(y, free_energy=True, filtering=True)
+        assert np.array_equal(m4, fm) and np.array_equal(c4, fc) and np.array_equal(f4, ff)
         assert np.array_equal(m1, m2) and np.array_equal(c1, c2) and np.array_equal(f1, f2) and np.array_equal(m3, m2)
