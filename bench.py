@@ -120,6 +120,45 @@ def extra_per_chain_models(mdl, T, C, y_dev, device, steps=3):
             "sweep_frac": b_sweep * units / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
 
 
+def extra_c1(device, with_cpu=True):
+    """BASELINE config 1 (the reference's own CPU-runnable case): d = 4, T = 1000, one chain — `infer(...)` END TO END per call
+    (engine construction, host → device, sweep + free energy, device → host), next to the CPU restatement on the same data
+    (the cpu_baseline leg of this config: checker and baseline, never the product path)."""
+    mdl = workloads.c1_model()
+    _, y = workloads.generate_chain(mdl, 1000, 42)
+    spec = rxhip.linear_gaussian_ssm(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    rxhip.infer(model=spec, data={"y": y}, free_energy=True, options={"device": device})
+    best = 1e9
+    for _ in range(10):
+        t0 = time.perf_counter()
+        res = rxhip.infer(model=spec, data={"y": y}, free_energy=True, options={"device": device})
+        best = min(best, time.perf_counter() - t0)
+    out = {"workload": "LGSSM d=4 T=1000, 1 chain: infer(...) end to end (create + H2D + sweep + free energy + D2H), minimum of 10",
+           "infer_ms": best * 1e3, "rule_calls_per_s": (6 * 1000 - 3) / best}
+    if with_cpu:
+        rxo = _oracle()
+        t0 = time.perf_counter()
+        om, oc, ofe, cnt = rxo.lgssm_bp(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y)
+        cpu = time.perf_counter() - t0
+        out["cpu_baseline"] = {"ms": cpu * 1e3, "kind": "port", "cores": 1,
+                               "mean_rel_vs_gpu": float(np.max(np.abs(res.posteriors["x"].mean - om)) / np.max(np.abs(om))),
+                               "free_energy_rel_vs_gpu": float(abs(res.free_energy[-1] - ofe) / abs(ofe))}
+    return out
+
+
+def extra_missing(mdl, T, C, y, device):
+    """The C2 batch with 10 % of the observations `missing` (masked, table-free schedule)."""
+    yy = y.clone()
+    mask = torch.rand((T, C), device=yy.device, generator=torch.Generator(device=yy.device).manual_seed(0)) < 0.1
+    yy[mask] = float("nan")
+    eng = rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C, device=device, allow_missing=True)
+    eng.set_data_device(yy.data_ptr(), yy.numel(), keepalive=yy)
+    ms, kt = timed_sweeps(eng, 5, 2)
+    eng.close()
+    return {"workload": f"the headline batch with 10 % of the observations missing (T={T}, {C} chains), 1 BP sweep + free energy",
+            "ms_per_step": ms, "kernels_ms_avg": kt, "steps_per_s": T * C / (ms * 1e-3)}
+
+
 def extra_c3(device):
     """BASELINE config 3: d = dy = 64, T = 10^4, one chain — the MFMA path."""
     mdl = workloads.c3_model()
@@ -362,7 +401,8 @@ def main():
     eng.close()
     if rank == 0 and world == 1 and not args.no_extras:
         extra = {}
-        for name, fn in (("per_chain_models", lambda: extra_per_chain_models(mdl, T, C, y, local_rank)), ("c3", lambda: extra_c3(local_rank)),
+        for name, fn in (("per_chain_models", lambda: extra_per_chain_models(mdl, T, C, y, local_rank)), ("c1", lambda: extra_c1(local_rank, not args.no_cpu_baseline)),
+                         ("c2_missing", lambda: extra_missing(mdl, T, C, y, local_rank)), ("c3", lambda: extra_c3(local_rank)),
                          ("c4", lambda: extra_c4(local_rank)), ("c5", lambda: extra_c5(local_rank))):
             try:
                 extra[name] = fn()
