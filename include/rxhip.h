@@ -157,7 +157,8 @@ enum {
     RXHIP_NODE_NORMAL_MIXTURE = 10,       /* (out, switch, m[1..K], p[1..K])  test/models/mixtures/gmm_univariate_tests.jl:16-19 */
     RXHIP_NODE_GCV = 11,                  /* (y, x, z, κ, ω)  test/models/statespace/hgf_tests.jl:28 */
     RXHIP_NODE_WISHART = 12,              /* (out, ν, S)  `Wishart(ν, S)`, test/models/mixtures/gmm_multivariate_tests.jl:23 */
-    RXHIP_NODE_ADD = 13                   /* typeof(+), interfaces (out, in1, in2) — `x_prev + c`, test/models/statespace/ulgssm_tests.jl:12 */
+    RXHIP_NODE_ADD = 13,                  /* typeof(+), interfaces (out, in1, in2) — `x_prev + c`, test/models/statespace/ulgssm_tests.jl:12 */
+    RXHIP_NODE_MVNORMAL_MEAN_PRECISION = 14 /* (out, μ, Λ)  `MvNormal(μ = …, Λ = …)`, test/models/iid/mv_iid_precision_tests.jl:11-15 */
 };
 enum { /* family of an `@initialization` marginal (InitMarExtraKey, src/model/plugins/initialization_plugin.jl:201-202) */
     RXHIP_INIT_NONE = 0,
@@ -240,6 +241,9 @@ rxhip_status rxhip_graph_lower_gmm(const rxhip_graph_desc* g, rxhip_gmm_lowered*
 /* Multivariate mixture (test/models/mixtures/gmm_multivariate_tests.jl:6-32): m[k] ~ MvNormal(mean, cov const);
  * w[k] ~ Wishart(ν, S const); s ~ Dirichlet; z[i] ~ Categorical(s); y[i] (data, d-vector) ~ NormalMixture(z[i], m, w).
  * Two-call protocol (N, K, d first).  Arrays as in rxhip_mvgmm_desc. */
+/* Also the K = 1 form without a switch (test/models/iid/mv_iid_precision_tests.jl:11-15):  m ~ MvNormal(μ, Λ | Σ const);
+ * P ~ Wishart(ν, S const); y[i] (data) ~ MvNormal(μ = m, Λ = P)  with q(m, P) = q(m)q(P) — a precision-parametrised prior is
+ * returned as its covariance. */
 typedef struct {
     int64_t N;
     int32_t K, d;

@@ -644,12 +644,14 @@ inline rxhip_status lower_mvgmm(const rxhip_graph_desc* g, MvGmm& M) {
     if (rxhip_status st = check_tables(g)) return st;
     const long long NV = g->n_variables, NF = g->n_factors;
     M = MvGmm();
-    std::vector<long long> prior_of(NV, -1), cat_of(NV, -1), mix;
+    std::vector<long long> prior_of(NV, -1), cat_of(NV, -1), mix, iid;
     long long s_var = -1, s_prior = -1;
     for (long long f = 0; f < NF; ++f) {
         const int t = g->factor_type[f], n = n_iface(g, f);
         const long long out = iface(g, f, 0);
-        if (t == RXHIP_NODE_MVNORMAL_MEAN_COV || t == RXHIP_NODE_WISHART) {
+        if (t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION && n == 3 && g->var_kind[out] == RXHIP_VARKIND_DATA) {
+            iid.push_back(f);  // y[i] ~ MvNormal(μ = m, Λ = P): the K = 1 form, no switch
+        } else if (t == RXHIP_NODE_MVNORMAL_MEAN_COV || t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_WISHART) {
             if (n != 3) return badarg("prior node must have 3 interfaces");
             if (g->var_kind[out] != RXHIP_VARKIND_RANDOM || prior_of[out] >= 0) return unsupported("MvNormal / Wishart node is not a component prior");
             prior_of[out] = f;
@@ -664,6 +666,59 @@ inline rxhip_status lower_mvgmm(const rxhip_graph_desc* g, MvGmm& M) {
             mix.push_back(f);
         else
             return unsupported("node type " + std::to_string(t) + " has no place in a multivariate mixture graph");
+    }
+    if (!iid.empty()) {
+        // iid multivariate Gaussian with unknown mean and precision (test/models/iid/mv_iid_precision_tests.jl:11-15)
+        if (!mix.empty() || s_prior >= 0) return unsupported("iid observation nodes next to a mixture");
+        const long long mvar = iface(g, iid[0], 1), pvar = iface(g, iid[0], 2);
+        const int d = g->var_rows[iface(g, iid[0], 0)];
+        if (d < 1 || d > 4) return unsupported("iid multivariate Gaussian with an unsupported dimension");
+        if (g->var_kind[mvar] != RXHIP_VARKIND_RANDOM || g->var_kind[pvar] != RXHIP_VARKIND_RANDOM) return unsupported("iid Gaussian with a known mean or precision");
+        for (long long f : iid) {
+            if (iface(g, f, 1) != mvar || iface(g, f, 2) != pvar || g->var_rows[iface(g, f, 0)] != d) return unsupported("observation nodes do not share mean and precision");
+            M.data_var.push_back(iface(g, f, 0));
+        }
+        const long long fm = prior_of[mvar], fw = prior_of[pvar];
+        if (fm < 0 || g->factor_type[fm] == RXHIP_NODE_WISHART || fw < 0 || g->factor_type[fw] != RXHIP_NODE_WISHART)
+            return unsupported("iid Gaussian without its MvNormal / Wishart priors");
+        const double *mu, *S, *V, *q;
+        double nu;
+        if (!const_value(g, iface(g, fm, 1), d, 1, &mu) || !const_value(g, iface(g, fm, 2), d, d, &S)) return unsupported("MvNormal prior with non-constant parameters");
+        if (!const_scalar(g, iface(g, fw, 1), &nu) || !const_value(g, iface(g, fw, 2), d, d, &V)) return unsupported("Wishart prior with non-constant parameters");
+        M.mu0.assign(mu, mu + d);
+        M.S0.assign(S, S + d * d);
+        if (g->factor_type[fm] == RXHIP_NODE_MVNORMAL_MEAN_PRECISION) {  // Λ given: the descriptor carries the covariance
+            // Gauss–Jordan on a d ≤ 4 SPD block
+            double a[16], inv[16];
+            for (int i = 0; i < d * d; ++i) { a[i] = S[i]; inv[i] = (i / d == i % d) ? 1.0 : 0.0; }
+            for (int k = 0; k < d; ++k) {
+                const double pv = a[k * d + k];
+                if (!(pv > 0.0)) return badarg("prior precision of the mean is not positive definite");
+                for (int j = 0; j < d; ++j) { a[k * d + j] /= pv; inv[k * d + j] /= pv; }
+                for (int i = 0; i < d; ++i) {
+                    if (i == k) continue;
+                    const double f2 = a[i * d + k];
+                    for (int j = 0; j < d; ++j) { a[i * d + j] -= f2 * a[k * d + j]; inv[i * d + j] -= f2 * inv[k * d + j]; }
+                }
+            }
+            M.S0.assign(inv, inv + d * d);
+        }
+        M.nu0.assign(1, nu);
+        M.V0.assign(V, V + d * d);
+        if (!init_params(g, mvar, RXHIP_INIT_MVNORMAL, d + d * d, &q)) return badarg("mean-field VMP needs an @initialization marginal for the mean");
+        M.qm_mean.assign(q, q + d);
+        M.qm_cov.assign(q + d, q + d + d * d);
+        if (!init_params(g, pvar, RXHIP_INIT_WISHART, 1 + d * d, &q)) return badarg("mean-field VMP needs an @initialization marginal for the precision");
+        M.qw_nu.assign(1, q[0]);
+        M.qw_V.assign(q + 1, q + 1 + d * d);
+        M.alpha0.assign(1, 1.0);
+        M.qs_alpha.assign(1, 1.0);
+        if ((long long)iid.size() + 2 != NF) return unsupported("graph has factors outside the iid model");
+        M.N = (long long)iid.size();
+        M.K = 1;
+        M.d = d;
+        last_error().clear();
+        return RXHIP_OK;
     }
     if (mix.empty() || s_prior < 0) return unsupported("no NormalMixture nodes / no switch prior");
     const int K = (n_iface(g, mix[0]) - 2) / 2;

@@ -73,6 +73,7 @@ hip_node(::Type{<:ReactiveMP.NormalMixture}) = (Int32(10), "NormalMixture", (:ou
 hip_node(::Type{<:ReactiveMP.GCV}) = (Int32(11), "GCV", (:y, :x, :z, :κ, :ω))
 hip_node(::Type{<:ReactiveMP.Wishart}) = (Int32(12), "Wishart", (:out, :ν, :S))
 hip_node(::typeof(+)) = (Int32(13), "+", (:out, :in1, :in2))
+hip_node(::Type{<:ReactiveMP.MvNormalMeanPrecision}) = (Int32(14), "MvNormalMeanPrecision", (:out, :μ, :Λ))
 hip_node(f::Function) = nothing
 
 # row-major flattening of a constant's value (Julia arrays are column-major)
@@ -460,10 +461,12 @@ end
 """variable ids of m[k], p[k] (or w[k]) and s of a mixture graph, from the first observation node's interfaces
 (out, switch, m[1..K], p[1..K]) and the switch's Categorical / Bernoulli node; iid Normal(mean, precision): (out, μ, τ)."""
 function component_ids(t::GraphTables)
-    f = findfirst(c -> c == Int32(10) || c == Int32(4), t.factor_type)
+    isobs(c) = t.factor_type[c] == Int32(10) || t.factor_type[c] == Int32(4) ||
+               (t.factor_type[c] == Int32(14) && t.var_kind[t.factor_iface[t.factor_iface_ptr[c] + 1] + 1] == Int32(1))   # MvNormal(μ = m, Λ = P) on data
+    f = findfirst(isobs, eachindex(t.factor_type))
     f === nothing && return (m = Int64[], p = Int64[], s = Int64(-1), beta = false)
     ids = t.factor_iface[(t.factor_iface_ptr[f] + 1):t.factor_iface_ptr[f + 1]]
-    t.factor_type[f] == Int32(4) && return (m = [ids[2]], p = [ids[3]], s = Int64(-1), beta = false)
+    t.factor_type[f] != Int32(10) && return (m = [ids[2]], p = [ids[3]], s = Int64(-1), beta = false)
     K = (length(ids) - 2) ÷ 2
     s, beta = Int64(-1), false
     for c in eachindex(t.factor_type)

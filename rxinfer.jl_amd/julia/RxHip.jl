@@ -446,10 +446,12 @@ function lowered_layout(t)
     has(code) = any(==(Int32(code)), t.factor_type)
     if has(11)
         return (family = :hgf, d = 1, width = 1, data_ids = Int64[findfirst(==(Int32(1)), t.var_kind) - 1], state_ids = Int64[])
-    elseif has(10) || has(4)
+    elseif has(10) || has(4) || (has(14) && has(12))
         ids = Int64[]
         for f in eachindex(t.factor_type)   # the observation nodes' `out` interface, in node order = data order
-            t.factor_type[f] in (Int32(10), Int32(4)) && push!(ids, t.factor_iface[t.factor_iface_ptr[f] + 1])
+            out = t.factor_iface[t.factor_iface_ptr[f] + 1]
+            # NormalMixture / Normal(mean, precision) observation nodes; MvNormal(μ, Λ) counts when its `out` is data (iid family)
+            (t.factor_type[f] in (Int32(10), Int32(4)) || (t.factor_type[f] == Int32(14) && t.var_kind[out + 1] == Int32(1))) && push!(ids, out)
         end
         d = Int(t.var_rows[ids[1] + 1])
         return (family = has(12) ? :mvmixture : :mixture, d = d, width = d, data_ids = ids, state_ids = Int64[])

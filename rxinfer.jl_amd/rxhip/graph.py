@@ -28,6 +28,7 @@ NODE_VOCABULARY = {
     _lib.NODE_GCV: ("GCV", ("y", "x", "z", "κ", "ω")),
     _lib.NODE_WISHART: ("Wishart", ("out", "ν", "S")),
     _lib.NODE_ADD: ("+", ("out", "in1", "in2")),
+    _lib.NODE_MVNORMAL_MEAN_PRECISION: ("MvNormalMeanPrecision", ("out", "μ", "Λ")),
 }
 INIT_FAMILIES = {"normal": _lib.INIT_NORMAL, "gamma": _lib.INIT_GAMMA, "dirichlet": _lib.INIT_DIRICHLET, "mvnormal": _lib.INIT_MVNORMAL,
                  "wishart": _lib.INIT_WISHART}
@@ -385,6 +386,26 @@ def mv_mixture_graph(N, prior_mean, prior_cov, prior_nu, prior_scale, prior_alph
             gb.initialize(w[k], _lib.INIT_WISHART, np.concatenate([[init["w"][0][k]], np.ravel(init["w"][1][k])]))
         if "s" in init:
             gb.initialize(s, _lib.INIT_DIRICHLET, init["s"])
+    return gb, ys
+
+
+def mv_iid_graph(N, prior_mean, prior_precision, prior_nu, prior_scale, init=None):
+    """The graph of `mv_iid_wishart` (test/models/iid/mv_iid_precision_tests.jl:11-15): m ~ MvNormal(μ, Λ); P ~ Wishart(ν, S);
+    y[i] ~ MvNormal(μ = m, Λ = P).  init = dict(m=(mean [d], cov [d][d]), w=(nu, scale [d][d])): the `@initialization` marginals."""
+    prior_mean = np.asarray(prior_mean, float)
+    d = prior_mean.shape[0]
+    gb = GraphBuilder()
+    m, P = gb.randomvar(d), gb.randomvar(d)
+    gb.node(_lib.NODE_MVNORMAL_MEAN_PRECISION, m, gb.constvar(prior_mean), gb.constvar(np.asarray(prior_precision, float)))
+    gb.node(_lib.NODE_WISHART, P, gb.constvar(float(prior_nu)), gb.constvar(np.asarray(prior_scale, float)))
+    ys = []
+    for _ in range(N):
+        y = gb.datavar(d)
+        gb.node(_lib.NODE_MVNORMAL_MEAN_PRECISION, y, m, P)
+        ys.append(y)
+    if init is not None:
+        gb.initialize(m, _lib.INIT_MVNORMAL, np.concatenate([np.ravel(init["m"][0]), np.ravel(init["m"][1])]))
+        gb.initialize(P, _lib.INIT_WISHART, np.concatenate([[init["w"][0]], np.ravel(init["w"][1])]))
     return gb, ys
 
 
