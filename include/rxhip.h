@@ -158,7 +158,9 @@ enum {
     RXHIP_NODE_GCV = 11,                  /* (y, x, z, κ, ω)  test/models/statespace/hgf_tests.jl:28 */
     RXHIP_NODE_WISHART = 12,              /* (out, ν, S)  `Wishart(ν, S)`, test/models/mixtures/gmm_multivariate_tests.jl:23 */
     RXHIP_NODE_ADD = 13,                  /* typeof(+), interfaces (out, in1, in2) — `x_prev + c`, test/models/statespace/ulgssm_tests.jl:12 */
-    RXHIP_NODE_MVNORMAL_MEAN_PRECISION = 14 /* (out, μ, Λ)  `MvNormal(μ = …, Λ = …)`, test/models/iid/mv_iid_precision_tests.jl:11-15 */
+    RXHIP_NODE_MVNORMAL_MEAN_PRECISION = 14, /* (out, μ, Λ)  `MvNormal(μ = …, Λ = …)`, test/models/iid/mv_iid_precision_tests.jl:11-15 */
+    RXHIP_NODE_GAMMA_SHAPE_SCALE = 15     /* (out, α, θ)  `Gamma(shape = …, scale = …)` and Distributions' `Gamma(α, θ)` (src/model/graphppl.jl:399-423,
+                                             test/models/models_tests.jl:121-127): lowered as the rate form with β = 1/θ */
 };
 enum { /* family of an `@initialization` marginal (InitMarExtraKey, src/model/plugins/initialization_plugin.jl:201-202) */
     RXHIP_INIT_NONE = 0,

@@ -474,6 +474,7 @@ inline rxhip_status lower_gmm(const rxhip_graph_desc* g, Gmm& M) {
         switch (t) {
         case RXHIP_NODE_NORMAL_MEAN_VARIANCE:
         case RXHIP_NODE_GAMMA_SHAPE_RATE:
+        case RXHIP_NODE_GAMMA_SHAPE_SCALE:
             if (n != 3) return badarg("prior node must have 3 interfaces");
             if (g->var_kind[out] != RXHIP_VARKIND_RANDOM) return unsupported("Normal / Gamma node on a non-random variable in a mixture graph");
             if (prior_of[out] >= 0) return unsupported("variable with two prior nodes");
@@ -535,9 +536,15 @@ inline rxhip_status lower_gmm(const rxhip_graph_desc* g, Gmm& M) {
                     std::vector<double>& qa, std::vector<double>& qb, const char* what) -> rxhip_status {
         for (int k = 0; k < K; ++k) {
             const long long f = prior_of[vars[k]];
-            if (f < 0 || g->factor_type[f] != node) return unsupported(std::string("component ") + what + " without its prior node");
+            // `Gamma(shape = …, scale = …)` (and the positional `Gamma(α, θ)` of Distributions) is the rate form with β = 1/θ
+            const bool scale_form = f >= 0 && node == RXHIP_NODE_GAMMA_SHAPE_RATE && g->factor_type[f] == RXHIP_NODE_GAMMA_SHAPE_SCALE;
+            if (f < 0 || (g->factor_type[f] != node && !scale_form)) return unsupported(std::string("component ") + what + " without its prior node");
             double x, y;
             if (!const_scalar(g, iface(g, f, 1), &x) || !const_scalar(g, iface(g, f, 2), &y)) return unsupported(std::string("prior of ") + what + " with non-constant parameters");
+            if (scale_form) {
+                if (!(y > 0.0)) return badarg("Gamma prior with a non-positive scale");
+                y = 1.0 / y;
+            }
             a.push_back(x);
             b.push_back(y);
             const double* q;

@@ -74,6 +74,7 @@ hip_node(::Type{<:ReactiveMP.GCV}) = (Int32(11), "GCV", (:y, :x, :z, :κ, :ω))
 hip_node(::Type{<:ReactiveMP.Wishart}) = (Int32(12), "Wishart", (:out, :ν, :S))
 hip_node(::typeof(+)) = (Int32(13), "+", (:out, :in1, :in2))
 hip_node(::Type{<:ReactiveMP.MvNormalMeanPrecision}) = (Int32(14), "MvNormalMeanPrecision", (:out, :μ, :Λ))
+hip_node(::Type{<:ReactiveMP.GammaShapeScale}) = (Int32(15), "GammaShapeScale", (:out, :α, :θ))
 hip_node(f::Function) = nothing
 
 # row-major flattening of a constant's value (Julia arrays are column-major)

@@ -6,5 +6,5 @@ constructing an engine does (no CPU fallback)."""
 from ._lib import RxHipError, lib, LIB_PATH  # noqa: F401
 from .engine import LGSSMEngine, GMMEngine, MvGMMEngine, HGFEngine, DriftChainEngine, Communicator  # noqa: F401
 from .api import (InferenceResult, infer, linear_gaussian_ssm, MvNormalMeanCovariance, NormalMeanVariance,  # noqa: F401
-                  GammaShapeRate, Dirichlet, Wishart, gaussian_mixture, multivariate_gaussian_mixture, iid_normal_gamma,
+                  GammaShapeRate, GammaShapeScale, Dirichlet, Wishart, gaussian_mixture, multivariate_gaussian_mixture, iid_normal_gamma,
                   hierarchical_gaussian_filter, univariate_drift_chain, time_varying_gaussian_ssm)

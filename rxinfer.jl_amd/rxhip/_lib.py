@@ -34,7 +34,7 @@ c_int64_p = ctypes.POINTER(ctypes.c_int64)
 VARKIND_RANDOM, VARKIND_DATA, VARKIND_CONST = 0, 1, 2
 NODE_MVNORMAL_MEAN_COV, NODE_MULTIPLY = 1, 2
 (NODE_NORMAL_MEAN_VARIANCE, NODE_NORMAL_MEAN_PRECISION, NODE_GAMMA_SHAPE_RATE, NODE_DIRICHLET, NODE_BETA, NODE_CATEGORICAL,
- NODE_BERNOULLI, NODE_NORMAL_MIXTURE, NODE_GCV, NODE_WISHART, NODE_ADD, NODE_MVNORMAL_MEAN_PRECISION) = range(3, 15)
+ NODE_BERNOULLI, NODE_NORMAL_MIXTURE, NODE_GCV, NODE_WISHART, NODE_ADD, NODE_MVNORMAL_MEAN_PRECISION, NODE_GAMMA_SHAPE_SCALE) = range(3, 16)
 INIT_NONE, INIT_NORMAL, INIT_GAMMA, INIT_DIRICHLET, INIT_MVNORMAL, INIT_WISHART = 0, 1, 2, 3, 4, 5
 
 

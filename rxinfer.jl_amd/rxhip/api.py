@@ -80,6 +80,17 @@ class GammaShapeRate:
 
 
 @dataclass
+class GammaShapeScale:
+    """ExponentialFamily.GammaShapeScale (= Distributions.Gamma(α, θ)); `.rate` is 1/θ"""
+    shape: np.ndarray
+    scale: np.ndarray
+
+    @property
+    def rate(self):
+        return 1.0 / np.asarray(self.scale, dtype=np.float64)
+
+
+@dataclass
 class Dirichlet:
     alpha: np.ndarray
 
@@ -104,9 +115,12 @@ def gaussian_mixture(prior_mean, prior_var, prior_shape, prior_rate, prior_alpha
                                      np.ones_like(pm) if prior_alpha is None else f(prior_alpha))
 
 
-def iid_normal_gamma(mean, variance, shape, rate):
-    """`μ ~ Normal(mean, variance); τ ~ Gamma(shape, rate); y[i] ~ Normal(mean = μ, precision = τ)`"""
-    return gaussian_mixture([mean], [variance], [shape], [rate], [1.0])
+def iid_normal_gamma(mean, variance, shape, rate=None, *, scale=None):
+    """`μ ~ Normal(mean, variance); τ ~ Gamma(shape, rate); y[i] ~ Normal(mean = μ, precision = τ)`; `scale = θ` is the
+    `Gamma(shape = …, scale = …)` spelling of test/models/models_tests.jl:121-127 (rate = 1/θ)."""
+    if (rate is None) == (scale is None):
+        raise ValueError("give exactly one of rate and scale")
+    return gaussian_mixture([mean], [variance], [shape], [rate if scale is None else 1.0 / scale], [1.0])
 
 
 @dataclass

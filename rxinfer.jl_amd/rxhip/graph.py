@@ -29,6 +29,7 @@ NODE_VOCABULARY = {
     _lib.NODE_WISHART: ("Wishart", ("out", "ν", "S")),
     _lib.NODE_ADD: ("+", ("out", "in1", "in2")),
     _lib.NODE_MVNORMAL_MEAN_PRECISION: ("MvNormalMeanPrecision", ("out", "μ", "Λ")),
+    _lib.NODE_GAMMA_SHAPE_SCALE: ("GammaShapeScale", ("out", "α", "θ")),
 }
 INIT_FAMILIES = {"normal": _lib.INIT_NORMAL, "gamma": _lib.INIT_GAMMA, "dirichlet": _lib.INIT_DIRICHLET, "mvnormal": _lib.INIT_MVNORMAL,
                  "wishart": _lib.INIT_WISHART}
@@ -430,12 +431,16 @@ def lower_mvgmm(g):
     return dict(N=N, K=K, d=d, data_var=dv, **bufs)
 
 
-def iid_normal_graph(N, mean, variance, shape, rate, init=None):
-    """`iid_gaussians_params` (test/models/models_tests.jl:114-128): m ~ Normal, p ~ Gamma, y[i] ~ Normal(mean = m, precision = p)."""
+def iid_normal_graph(N, mean, variance, shape, rate=None, init=None, scale=None):
+    """`iid_gaussians_params` (test/models/models_tests.jl:114-128): m ~ Normal, p ~ Gamma, y[i] ~ Normal(mean = m, precision = p).
+    `scale = θ` emits the reference's own node for that model, `Gamma(shape = …, scale = …)` -> GammaShapeScale."""
     gb = GraphBuilder()
     m, p = gb.randomvar(1), gb.randomvar(1)
     gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, m, gb.constvar(mean), gb.constvar(variance))
-    gb.node(_lib.NODE_GAMMA_SHAPE_RATE, p, gb.constvar(shape), gb.constvar(rate))
+    if scale is None:
+        gb.node(_lib.NODE_GAMMA_SHAPE_RATE, p, gb.constvar(shape), gb.constvar(rate))
+    else:
+        gb.node(_lib.NODE_GAMMA_SHAPE_SCALE, p, gb.constvar(shape), gb.constvar(scale))
     ys = []
     for _ in range(N):
         y = gb.datavar(1)

@@ -72,6 +72,29 @@ def test_iid_gaussian_unknown_mean_and_precision():
     assert abs(a - (4.0 + 50.0)) < 1e-12
 
 
+def test_iid_gaussian_gamma_scale_spelling_equals_rate_spelling():
+    """test/models/models_tests.jl:114-199: `iid_gaussians_priors` (τ ~ Gamma(4, 8), Distributions' shape/scale) and
+    `iid_gaussians_params` (τ ~ Gamma(shape = 4, scale = 8)) give `mean.(posteriors[:μ]) ≈`, `mean.(posteriors[:τ]) ≈`,
+    `free_energy ≈` of one another (models_tests.jl:183-195).  Both build a GammaShapeScale node; on the device that node and
+    the rate spelling with β = 1/8 run the same engine, bit for bit, and match the oracle."""
+    from rxhip import graph
+    y = 0.75 + 10.0 * np.random.default_rng(123).standard_normal(100)
+    init = dict(m=(0.0, 1.0), p=(1.0, 1.0))
+    out = []
+    for kw in (dict(scale=8.0), dict(rate=0.125)):
+        gb, _ = graph.iid_normal_graph(100, 4.0, 8.0, 4.0, init=init, **kw)
+        with graph.create_vmp_engine_from_graph(gb.tables()[0]) as eng:
+            eng.set_data(y)
+            eng.run(10, True)
+            out.append((eng.history().copy(), eng.free_energy().copy()))
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    ohist, ofe, _, _ = rxoracle.gmm_vmp(y, [4.0], [8.0], [4.0], [1 / 8.0], [1.0], [0.0], [1.0], [1.0], [1.0], [1.0], 10)
+    assert_parity(out[0][0], out[0][1], ohist, ofe)
+    res = rxhip.infer(model=rxhip.iid_normal_gamma(4.0, 8.0, 4.0, scale=8.0), data={"y": y}, iterations=10, free_energy=True,
+                      initialization={"m": rxhip.NormalMeanVariance(0.0, 1.0), "p": rxhip.GammaShapeScale(1.0, 1.0)})
+    assert np.allclose(res.free_energy, out[0][1], rtol=0, atol=0)
+
+
 def test_split_phase_equals_run():
     """accumulate / update (the multi-GPU split with the statistics exposed for the RCCL all-reduce)."""
     y = gmm_data(4096, [-5.0, 0.0, 5.0], [1, 1, 1], [0.3, 0.3, 0.4], 9)

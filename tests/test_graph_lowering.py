@@ -107,6 +107,14 @@ def test_reference_spelling_beta_bernoulli_and_iid_gaussian():
     gb, ys = graph.iid_normal_graph(9, 4.0, 8.0, 4.0, 0.125, init=dict(m=(0.0, 1.0), p=(1.0, 1.0)))
     low = graph.lower_gmm(gb.tables()[0])
     assert (low["N"], low["K"]) == (9, 1) and low["mu0"][0] == 4.0 and low["b0"][0] == 0.125 and low["alpha0"][0] == 1.0
+    # the reference's own spelling of that prior: `τ ~ Gamma(shape = 4, scale = 8)` (models_tests.jl:121-127) is the same model
+    gb, _ = graph.iid_normal_graph(9, 4.0, 8.0, 4.0, scale=8.0, init=dict(m=(0.0, 1.0), p=(1.0, 1.0)))
+    low2 = graph.lower_gmm(gb.tables()[0])
+    assert all(np.array_equal(low[k], low2[k]) for k in ("mu0", "v0", "a0", "b0", "alpha0", "init_p_shape", "init_p_rate"))
+    gb, _ = graph.iid_normal_graph(9, 4.0, 8.0, 4.0, scale=-1.0, init=dict(m=(0.0, 1.0), p=(1.0, 1.0)))
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_gmm(gb.tables()[0])
+    assert ei.value.status == _lib.ERR_BADARG and "scale" in str(ei.value)
 
 
 def test_mixture_graphs_outside_the_family_are_rejected():
