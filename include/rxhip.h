@@ -545,6 +545,11 @@ rxhip_status rxhip_set_profiling(rxhip_engine* e, int32_t enabled);
  * profiling was enabled / last reset, and the number of launches averaged */
 rxhip_status rxhip_get_kernel_times(rxhip_engine* e, double* ms_avg, uint64_t* launches);
 rxhip_status rxhip_reset_kernel_times(rxhip_engine* e);
+/* device time in milliseconds of the kernels that ran ONCE at creation because their results depend on the model only
+ * (gain, covariance and smoother-gain tables of a batch that shares one model); 0 for engines without
+ * such tables.  Waits for those kernels.  The reference has no counterpart: it recomputes these messages for every chain
+ * and every call (src/inference/batch.jl:391-430). */
+rxhip_status rxhip_get_model_tables_ms(rxhip_engine* e, double* ms);
 /* the hipStream_t the engine launches on */
 rxhip_status rxhip_get_stream(rxhip_engine* e, void** stream);
 /* the number of time segments the schedule uses and their length */

@@ -1922,7 +1922,7 @@ __global__ void __launch_bounds__(256) k_fe_total(Params p, const double* block_
 // phase 4 for shared-model batches whose size is a multiple of 64: table-driven backward sweep.
 //
 // With one model for every chain the smoother gain G_t and the smoothed covariance V_s(t) do not depend on the data either.
-// k_smooth_tables builds them once per engine (one lane per segment, the recursion of k_backward on covariances only) together
+// The k_smooth_tab_* kernels build them once per engine (the recursion of k_backward on covariances only) together
 // with  E_t = I − G_t A  and  F_t = E_t N_t,  so that the per-chain work of a step is three small matrix–vector products,
 //     m_s(t) = E_t z_t + F_t m_seg + G_t m_s(t+1)
 // (m_s(t) = m_f + G (m_s(t+1) − A m_f) with m_f = z_t + N_t m_seg), and the posterior covariance is written from the table:
@@ -1939,6 +1939,19 @@ struct SegEndTab {  // per segment: m_s(te) = H1 m_f(te) + H2 ξβ
     static constexpr int H1 = 0, H2 = D * D;  // V_s(te) V_f(te)⁻¹, V_s(te)
     static constexpr int SIZE = 2 * D * D;
 };
+// The tables are built in four data-parallel stages (the first version walked a whole segment in one lane: 5.6 ms at
+// T = 10⁵ — longer than the sweep it serves):
+//   steps      one lane per time index: G_t, E_t, F_t and  C_t = V_f − G_t V_p G_t'  — everything that needs V_f(t) only;
+//   compose    one lane per block of SMOOTH_LB steps: the map  V_s(u0) = Ĝ V_s(u1) Ĝ' + Ĉ  over the block
+//              ((G1, C1)∘(G2, C2) = (G1 G2, C1 + G1 C2 G1'): V ↦ G V G' + C is closed under composition);
+//   chain      one lane per segment: V_s at the segment end from the boundary scan, then over the segment's blocks;
+//   apply      one lane per block: V_s(t) = C_t + G_t V_s(t+1) G_t' from the block's end value.
+constexpr int SMOOTH_LB = 32;
+template <int D>
+struct SmoothBlk {  // per block of SMOOTH_LB steps
+    static constexpr int GA = 0, CA = D * D, VE = 2 * D * D;  // Ĝ, Ĉ, V_s at the block's end (all full row-major)
+    static constexpr int SIZE = 3 * D * D;
+};
 struct SmoothTabParams {
     long long T, L;
     int S;
@@ -1947,18 +1960,166 @@ struct SmoothTabParams {
     const double* scan;  // [S][ScanLayout::SIZE]  (LB = Λβ(b_{s+1}))
     double* gtab;        // [T][SmoothTab::SIZE]
     double* segend;      // [S][SegEndTab::SIZE]
+    double* blk;         // [S][ceil(L / SMOOTH_LB)][SmoothBlk::SIZE]
     int* status;
 };
+__host__ __device__ inline long long smooth_blocks_per_segment(long long L) { return (L + SMOOTH_LB - 1) / SMOOTH_LB; }
+
+template <int D>
+__device__ __forceinline__ void congruence(const double (&G)[D][D], const double (&V)[D][D], const double* C, double (&out)[D][D]) {
+    double H[D][D];  // out = C + G V G'  (V, C, out symmetric)
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += G[a][k] * V[k][b];
+            H[a][b] = acc;
+        }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b <= a; ++b) {
+            double acc = C[a * D + b];
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += H[a][k] * G[b][k];
+            out[a][b] = acc;
+            out[b][a] = acc;
+        }
+}
+
 template <int D, int DY>
-__global__ void __launch_bounds__(64) k_smooth_tables(SmoothTabParams q, const CstArg<CstLayout<D, DY>::SIZE> cb) {
+__global__ void __launch_bounds__(64) k_smooth_tab_steps(SmoothTabParams q, const CstArg<CstLayout<D, DY>::SIZE> cb) {
     using CL = CstLayout<D, DY>;
-    using SL = ScanLayout<D>;
     using ST = SmoothTab<D>;
     constexpr int NS = Dim<D>::NS;
     constexpr int MT = TimeTab<D>::MT;
+    const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= q.T - 1) return;
+    const CPtr c{cb.v};
+    Sym<D> Vf, Vp, Lp;
+    double det;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Vf.v[k] = q.vtab[t * NS + k];
+    double AV[D][D], G[D][D], E[D][D];
+    predict_cov<D>(CPtr{c.p + CL::A}, CPtr{c.p + CL::P}, Vf, AV, Vp);   // AV = A V_f
+    if (!spd_inv<D>(Vp, Lp, det)) atomicOr(q.status, ST_NOT_POSDEF);
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            double acc = 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc += AV[k][a] * Lp(k, b);
+            G[a][b] = acc;
+        }
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            double acc = (a == b) ? 1.0 : 0.0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) acc -= G[a][k] * c[CL::A + k * D + b];
+            E[a][b] = acc;
+        }
+    double* row = q.gtab + t * ST::SIZE;
+    const double* N = q.ntab + t * MT;
+    const bool at_start = t % q.L == 0;  // at the segment's own start boundary the filtered mean is m_seg itself: no N term
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            double f = 0.0;
+            if (!at_start) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) f += E[a][k] * N[k * D + b];
+            }
+            double cc = Vf(a, b);  // C_t = V_f − G V_p G',  G V_p = (A V_f)'
+#pragma unroll
+            for (int k = 0; k < D; ++k) cc -= AV[k][a] * G[b][k];
+            row[ST::E + a * D + b] = E[a][b];
+            row[ST::F + a * D + b] = f;
+            row[ST::G + a * D + b] = G[a][b];
+            row[ST::VS + a * D + b] = cc;   // replaced by V_s(t) in the apply stage
+        }
+}
+
+// block (s, j) covers the time indices [u0, u1) of segment s; false when it is empty
+__device__ __forceinline__ bool smooth_block_range(const SmoothTabParams& q, long long id, long long& u0, long long& u1) {
+    const long long nb = smooth_blocks_per_segment(q.L);
+    const long long s = id / nb, j = id - s * nb;
+    if (s >= q.S) return false;
+    const long long tb = s * q.L;
+    long long te = tb + q.L;
+    if (te > q.T - 1) te = q.T - 1;
+    u0 = tb + j * SMOOTH_LB;
+    u1 = u0 + SMOOTH_LB;
+    if (u1 > te) u1 = te;
+    return u0 < u1;
+}
+
+template <int D>
+__global__ void __launch_bounds__(64) k_smooth_tab_compose(SmoothTabParams q) {
+    using ST = SmoothTab<D>;
+    using SB = SmoothBlk<D>;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long u0, u1;
+    if (!smooth_block_range(q, id, u0, u1)) return;
+    double Ga[D][D], Ca[D][D];
+    {
+        const double* row = q.gtab + (u1 - 1) * ST::SIZE;
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                Ga[a][b] = row[ST::G + a * D + b];
+                Ca[a][b] = row[ST::VS + a * D + b];
+            }
+    }
+    for (long long t = u1 - 2; t >= u0; --t) {  // prepend the map of step t
+        const double* row = q.gtab + t * ST::SIZE;
+        double G[D][D], Gn[D][D], Cn[D][D];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) G[a][b] = row[ST::G + a * D + b];
+        congruence<D>(G, Ca, row + ST::VS, Cn);
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += G[a][k] * Ga[k][b];
+                Gn[a][b] = acc;
+            }
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                Ga[a][b] = Gn[a][b];
+                Ca[a][b] = Cn[a][b];
+            }
+    }
+    double* o = q.blk + id * SB::SIZE;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) {
+            o[SB::GA + a * D + b] = Ga[a][b];
+            o[SB::CA + a * D + b] = Ca[a][b];
+        }
+}
+
+template <int D>
+__global__ void __launch_bounds__(64) k_smooth_tab_chain(SmoothTabParams q) {
+    using SL = ScanLayout<D>;
+    using ST = SmoothTab<D>;
+    using SB = SmoothBlk<D>;
+    constexpr int NS = Dim<D>::NS;
     const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= q.S) return;
-    const CPtr c{cb.v};
     const long long tb = s * q.L;
     long long te = tb + q.L;
     if (te > q.T - 1) te = q.T - 1;
@@ -1972,6 +2133,7 @@ __global__ void __launch_bounds__(64) k_smooth_tables(SmoothTabParams q, const C
     for (int k = 0; k < NS; ++k) Ls.v[k] = Vi.v[k] + q.scan[s * SL::SIZE + SL::LB + k];
     ok = spd_inv<D>(Ls, Vs, det) && ok;
     double* se = q.segend + s * SegEndTab<D>::SIZE;
+    double V[D][D];
 #pragma unroll
     for (int a = 0; a < D; ++a)
 #pragma unroll
@@ -1981,6 +2143,7 @@ __global__ void __launch_bounds__(64) k_smooth_tables(SmoothTabParams q, const C
             for (int k = 0; k < D; ++k) acc += Vs(a, k) * Vi(k, b);
             se[SegEndTab<D>::H1 + a * D + b] = acc;
             se[SegEndTab<D>::H2 + a * D + b] = Vs(a, b);
+            V[a][b] = Vs(a, b);
         }
     if (s == q.S - 1) {  // the last time index is written by the last segment only
         double* row = q.gtab + te * ST::SIZE;
@@ -1992,69 +2155,56 @@ __global__ void __launch_bounds__(64) k_smooth_tables(SmoothTabParams q, const C
                 row[ST::VS + a * D + b] = Vs(a, b);
             }
     }
-    for (long long t = te - 1; t >= tb; --t) {
-#pragma unroll
-        for (int k = 0; k < NS; ++k) Vf.v[k] = q.vtab[t * NS + k];
-        double T[D][D], G[D][D], H[D][D], E[D][D];
-        Sym<D> Vp, Lp, Dm;
-        predict_cov<D>(CPtr{c.p + CL::A}, CPtr{c.p + CL::P}, Vf, T, Vp);
-        ok = spd_inv<D>(Vp, Lp, det) && ok;
+    const long long nb = smooth_blocks_per_segment(q.L);
+    const long long used = te > tb ? (te - tb + SMOOTH_LB - 1) / SMOOTH_LB : 0;
+    for (long long j = used - 1; j >= 0; --j) {
+        double* o = q.blk + (s * nb + j) * SB::SIZE;
+        double G[D][D], Vn[D][D];
 #pragma unroll
         for (int a = 0; a < D; ++a)
 #pragma unroll
             for (int b = 0; b < D; ++b) {
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k < D; ++k) acc += T[k][a] * Lp(k, b);
-                G[a][b] = acc;
+                o[SB::VE + a * D + b] = V[a][b];
+                G[a][b] = o[SB::GA + a * D + b];
             }
-#pragma unroll
-        for (int k = 0; k < NS; ++k) Dm.v[k] = Vs.v[k] - Vp.v[k];
+        congruence<D>(G, V, o + SB::CA, Vn);
 #pragma unroll
         for (int a = 0; a < D; ++a)
 #pragma unroll
-            for (int b = 0; b < D; ++b) {
-                double acc = 0.0;
-#pragma unroll
-                for (int k = 0; k < D; ++k) acc += G[a][k] * Dm(k, b);
-                H[a][b] = acc;
-            }
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-            for (int b = 0; b <= a; ++b) {
-                double acc = Vf(a, b);
-#pragma unroll
-                for (int k = 0; k < D; ++k) acc += H[a][k] * G[b][k];
-                Vs(a, b) = acc;
-            }
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-            for (int b = 0; b < D; ++b) {
-                double acc = (a == b) ? 1.0 : 0.0;
-#pragma unroll
-                for (int k = 0; k < D; ++k) acc -= G[a][k] * c[CL::A + k * D + b];
-                E[a][b] = acc;
-            }
-        double* row = q.gtab + t * ST::SIZE;
-        const double* N = q.ntab + t * MT;
-#pragma unroll
-        for (int a = 0; a < D; ++a)
-#pragma unroll
-            for (int b = 0; b < D; ++b) {
-                double f = 0.0;
-                if (t > tb) {  // at the segment's own start boundary the filtered mean is m_seg itself: no N term
-#pragma unroll
-                    for (int k = 0; k < D; ++k) f += E[a][k] * N[k * D + b];
-                }
-                row[ST::E + a * D + b] = E[a][b];
-                row[ST::F + a * D + b] = f;
-                row[ST::G + a * D + b] = G[a][b];
-                row[ST::VS + a * D + b] = Vs(a, b);
-            }
+            for (int b = 0; b < D; ++b) V[a][b] = Vn[a][b];
     }
     if (!ok) atomicOr(q.status, ST_NOT_POSDEF);
+}
+
+template <int D>
+__global__ void __launch_bounds__(64) k_smooth_tab_apply(SmoothTabParams q) {
+    using ST = SmoothTab<D>;
+    using SB = SmoothBlk<D>;
+    const long long id = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long u0, u1;
+    if (!smooth_block_range(q, id, u0, u1)) return;
+    double V[D][D];
+    const double* o = q.blk + id * SB::SIZE;
+#pragma unroll
+    for (int a = 0; a < D; ++a)
+#pragma unroll
+        for (int b = 0; b < D; ++b) V[a][b] = o[SB::VE + a * D + b];
+    for (long long t = u1 - 1; t >= u0; --t) {
+        double* row = q.gtab + t * ST::SIZE;
+        double G[D][D], Vn[D][D];
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) G[a][b] = row[ST::G + a * D + b];
+        congruence<D>(G, V, row + ST::VS, Vn);
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int b = 0; b < D; ++b) {
+                V[a][b] = Vn[a][b];
+                row[ST::VS + a * D + b] = Vn[a][b];
+            }
+    }
 }
 
 template <int D>

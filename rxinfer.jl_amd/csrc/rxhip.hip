@@ -142,7 +142,11 @@ struct Launch {
         hipLaunchKernelGGL((k_fe_seg<D>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
     }
     static void smooth_tables(const SmoothTabParams& q, const double* hc, hipStream_t s) {
-        hipLaunchKernelGGL((k_smooth_tables<D, DY>), dim3(nblk(q.S, 64)), dim3(64), 0, s, q, carg(hc));
+        const long long nblocks = (long long)q.S * smooth_blocks_per_segment(q.L);
+        if (q.T > 1) hipLaunchKernelGGL((k_smooth_tab_steps<D, DY>), dim3(nblk(q.T - 1, 64)), dim3(64), 0, s, q, carg(hc));
+        hipLaunchKernelGGL((k_smooth_tab_compose<D>), dim3(nblk(nblocks, 64)), dim3(64), 0, s, q);
+        hipLaunchKernelGGL((k_smooth_tab_chain<D>), dim3(nblk(q.S, 64)), dim3(64), 0, s, q);
+        hipLaunchKernelGGL((k_smooth_tab_apply<D>), dim3(nblk(nblocks, 64)), dim3(64), 0, s, q);
     }
     static void backward_sh(const Params& p, const double* gtab, const double* segend, hipStream_t s) {
         hipLaunchKernelGGL((k_backward_sh<D>), dim3((unsigned)(p.n_chains / 64 * p.S)), dim3(64), 0, s, p, gtab, segend);
@@ -326,7 +330,8 @@ struct rxhip_engine {
     bool fused = false;
     double *d_ftab = nullptr, *d_mtab = nullptr, *d_ntab = nullptr, *d_pos = nullptr, *d_fseg = nullptr;
     double fe_const = 0.0;
-    double *d_gtab = nullptr, *d_segend = nullptr;  // table-driven backward sweep (k_backward_sh): batches of a multiple of 64 chains
+    double *d_gtab = nullptr, *d_segend = nullptr, *d_sblk = nullptr;
+    hipEvent_t ev_tab0 = nullptr, ev_tab1 = nullptr;  // around the once-per-engine table kernels (rxhip_get_model_tables_ms)  // table-driven backward sweep (k_backward_sh): batches of a multiple of 64 chains
     bool sequential = false;  // no per-position tables: missing observations / per-step constants (per-chain records; the segment
                               // elements are computed in the lane, k_seg_elements, or the chain is ONE segment)
     double* d_elemx = nullptr;
@@ -1482,6 +1487,8 @@ static void free_all(rxhip_engine* e) {
     if (e->d_off_chain) { (void)hipFree(e->d_off_chain); e->d_off_chain = nullptr; }
     for (auto& pe : e->pending) { (void)hipEventDestroy(pe.a); (void)hipEventDestroy(pe.b); }
     for (auto ev : e->pool) (void)hipEventDestroy(ev);
+    if (e->ev_tab0) { (void)hipEventDestroy(e->ev_tab0); e->ev_tab0 = nullptr; }
+    if (e->ev_tab1) { (void)hipEventDestroy(e->ev_tab1); e->ev_tab1 = nullptr; }
     e->pending.clear();
     e->pool.clear();
     if (e->stream) (void)hipStreamSynchronize(e->stream);  // nothing of this engine may still be running on its buffers
@@ -1944,6 +1951,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         if (C % 64 == 0 && !std::getenv("RXHIP_BACKWARD_LANES")) {
             ap.plain(&e->d_gtab, sizeof(double) * T * vt->gt_row);
             ap.plain(&e->d_segend, sizeof(double) * Sg * vt->se_size);
+            ap.plain(&e->d_sblk, sizeof(double) * Sg * (size_t)smooth_blocks_per_segment(e->L) * 3 * e->d * e->d);
         }
     }
     ap.zeroed(&e->d_status, sizeof(int));
@@ -1975,13 +1983,17 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         TimeTabParams q{};
         q.T = e->T; q.L = e->L; q.pos = e->d_pos; q.scan = e->d_scan; q.mtab = e->d_mtab; q.ntab = e->d_ntab; q.vtab = e->d_vtab;
         q.status = e->d_status;
+        HIPCHK(e, hipEventCreate(&e->ev_tab0));
+        HIPCHK(e, hipEventCreate(&e->ev_tab1));
+        HIPCHK(e, hipEventRecord(e->ev_tab0, e->stream));
         vt->time_tables(q, e->stream);
         if (e->d_gtab) {
             SmoothTabParams sq{};
             sq.T = e->T; sq.L = e->L; sq.S = e->S; sq.vtab = e->d_vtab; sq.ntab = e->d_ntab; sq.scan = e->d_scan;
-            sq.gtab = e->d_gtab; sq.segend = e->d_segend; sq.status = e->d_status;
+            sq.gtab = e->d_gtab; sq.segend = e->d_segend; sq.blk = e->d_sblk; sq.status = e->d_status;
             vt->smooth_tables(sq, e->h_cst0.data(), e->stream);
         }
+        HIPCHK(e, hipEventRecord(e->ev_tab1, e->stream));
         // no synchronisation here: the table kernels are ordered before every sweep on the engine's stream, and a covariance
         // that is not positive definite raises the status flag the first run reports (RXHIP_ERR_NOT_POSDEF)
         HIPCHK(e, hipGetLastError());
@@ -3201,6 +3213,17 @@ rxhip_status rxhip_get_kernel_times(rxhip_engine* e, double* ms_avg, uint64_t* l
         if (ms_avg) ms_avg[k] = e->k_n[k] ? e->k_ms[k] / (double)e->k_n[k] : 0.0;
         if (launches) launches[k] = e->k_n[k];
     }
+    return RXHIP_OK;
+}
+rxhip_status rxhip_get_model_tables_ms(rxhip_engine* e, double* ms) {
+    if (!e || !ms) return RXHIP_ERR_BADARG;
+    *ms = 0.0;
+    if (!e->ev_tab1) return RXHIP_OK;
+    SET_DEVICE(e);
+    HIPCHK(e, hipEventSynchronize(e->ev_tab1));
+    float f = 0.0f;
+    HIPCHK(e, hipEventElapsedTime(&f, e->ev_tab0, e->ev_tab1));
+    *ms = (double)f;
     return RXHIP_OK;
 }
 rxhip_status rxhip_reset_kernel_times(rxhip_engine* e) {

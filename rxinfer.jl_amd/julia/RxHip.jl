@@ -351,6 +351,13 @@ function counters(e::Engine)
     return (rule_calls = r[], products = p[], marginals = m[])
 end
 
+"device time (ms) of the kernels that ran once at creation because their results depend on the model only"
+function model_tables_ms(e::Engine)
+    ms = Ref{Float64}(0.0)
+    check(e, ccall((:rxhip_get_model_tables_ms, librxhip), Int32, (Ptr{Cvoid}, Ref{Float64}), e.handle, ms))
+    return ms[]
+end
+
 # ---- generic graph entry: rxhip_graph_desc / rxhip_create (used by HIPInferencePlugin.jl) ----------------------------
 const RXHIP_ERR_UNSUPPORTED = Int32(2)
 

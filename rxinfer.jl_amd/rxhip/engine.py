@@ -273,6 +273,12 @@ class LGSSMEngine:
         self._chk(_lib.lib().rxhip_get_kernel_times(self._h, ms, n))
         return {name: {"ms_avg": ms[i], "launches": n[i]} for i, name in enumerate(_lib.KERNEL_NAMES)}
 
+    def model_tables_ms(self):
+        """device time of the once-per-engine kernels (tables that depend on the model only); 0 without such tables"""
+        ms = ctypes.c_double()
+        self._chk(_lib.lib().rxhip_get_model_tables_ms(self._h, ctypes.byref(ms)))
+        return ms.value
+
     def schedule(self):
         s, l = ctypes.c_int32(), ctypes.c_int64()
         self._chk(_lib.lib().rxhip_get_schedule(self._h, ctypes.byref(s), ctypes.byref(l)))
