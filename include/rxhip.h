@@ -95,13 +95,14 @@ typedef struct {
                          (docs/src/manuals/inference/static.md:98-123): no message from its observation branch, no evidence
                          term; its prediction (rxhip_get_predictions) is the plain predictive.  The covariances then differ
                          per chain and time index: the engine keeps per-chain records and computes the segment elements of
-                         the time-parallel schedule in the lane (no per-model tables).  d, dy ≤ 4 only.  rxhip_counters keeps
-                         reporting the all-observed schedule */
+                         the time-parallel schedule in the lane (no per-model tables) at d, dy ≤ 4; larger states (any d, dy ≤ 64)
+                         run the reference's own message order, sequential in time, one workgroup per chain
+                         (csrc/gseq_kernels.hpp).  rxhip_counters keeps reporting the all-observed schedule */
     const int32_t* step_model; /* NULL, or [T + horizon]: time-varying constants.  step_model[t] names the model (of n_models)
                          whose A, P make the transition INTO x[t] and whose B, Q observe y[t] (`A[t] * x[t-1]`,
                          `MvNormal(μ = …, Σ = P[t])` with per-step constants in the @model loop); the prior (m0, V0) is that of
                          model step_model[0].  All chains share the schedule (chain_model must be NULL); runs on the
-                         table-free schedule of allow_missing.  d, dy ≤ 4 only */
+                         table-free schedules of allow_missing (any d, dy ≤ 64) */
     const double* state_offset; /* NULL, or [T + horizon][d]: known inputs.  x[t] ~ MvNormal(μ = A * x[t-1] + c[t], Σ = P) — the
                          `+` node with a constant (or a `*` of a constant with data, e.g. B_u * u[t]) behind the transition's `*`
                          node; row 0 enters only through the prior's transition (prior_through_transition) */

@@ -26,15 +26,16 @@ struct GenericParams {
     double* cov;         // [T+H][chain][d][d]
     const double* user;  // [n_models][2d² + dy·d + 2dy²]  A | P | B | Q | Q⁻¹
     const int* chain_model;
+    const int* step_model;       // [T+H] model of a time index (per-step constants), or null
     const double *mu, *nu, *cx;  // known inputs (PredictParams): μ[t] [T+H][d], ν[t] [T+H][dy], c[t] [T+H][d]; null: none
     int off_chain;               // 1: with a chain axis, [T+H][chain][·]
     double* pmean;       // [T+H][chain][dy]
     double* pcov;        // [T+H][chain][dy][dy]
     int* status;
 };
-__device__ __forceinline__ GenericModel generic_model(const GenericParams& p, long long chain) {
+__device__ __forceinline__ GenericModel generic_model(const GenericParams& p, long long chain, long long t) {
     const size_t sz = 2 * (size_t)p.d * p.d + (size_t)p.dy * p.d + 2 * (size_t)p.dy * p.dy;
-    const double* u = p.user + (p.chain_model ? p.chain_model[chain] : 0) * sz;
+    const double* u = p.user + (p.step_model ? p.step_model[t] : p.chain_model ? p.chain_model[chain] : 0) * sz;
     GenericModel m;
     m.A = u;
     m.P = m.A + (size_t)p.d * p.d;
@@ -87,7 +88,7 @@ __global__ void __launch_bounds__(256) k_predict_generic(GenericParams p) {
     double* ms = qy + dy;                // d
     const long long g = blockIdx.x;      // row (t, chain)
     const long long t = g / p.n_chains, c = g - t * p.n_chains;
-    const GenericModel M = generic_model(p, c);
+    const GenericModel M = generic_model(p, c, t);
     const double* Vs = p.cov + g * d * d;  // read straight from memory (L2): used once, in B V_s
     for (int e = tid; e < d; e += nt) ms[e] = p.mean[g * d + e] - (p.mu ? p.mu[(p.off_chain ? g : g / p.n_chains) * d + e] : 0.0);
     __shared__ int s_obs;
@@ -179,13 +180,13 @@ __global__ void __launch_bounds__(256) k_forecast_generic(GenericParams p) {
     double* m = AV + d * d;
     double* mn = m + d;
     const long long c = blockIdx.x;
-    const GenericModel M = generic_model(p, c);
     const long long r0 = (p.T - 1) * p.n_chains + c;
     for (int e = tid; e < d * d; e += nt) V[e] = p.cov[r0 * d * d + e];
     for (int e = tid; e < d; e += nt) m[e] = p.mean[r0 * d + e];
     __syncthreads();
     for (long long h = 0; h < p.H; ++h) {
         const long long r = (p.T + h) * p.n_chains + c;
+        const GenericModel M = generic_model(p, c, p.T + h);  // the transition into x[T+h]
         for (int e = tid; e < d * d; e += nt) {
             const int i = e / d, j = e - i * d;
             double s = 0.0;

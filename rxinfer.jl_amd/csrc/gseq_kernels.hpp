@@ -1,0 +1,320 @@
+// gseq_kernels.hpp — `missing` observations anywhere in the data and per-step constants A[t], P[t], B[t], Q[t] for ANY state
+// dimension (d, dy ≤ 64).
+//
+// Both features make the covariances of a chain depend on the time index in a way no table of the time-parallel MFMA schedule
+// survives (dense_kernels.hpp builds its segment boundaries from ONE model and a fully observed chain).  What remains is the
+// message schedule of the reference itself (src/inference/batch.jl:391-430 on the chain of test/models/statespace/
+// mlgssm_test.jl:9-26): forward messages in time order, backward messages in reverse, one product per variable — sequential
+// in t, parallel over chains.  One workgroup per chain, all matrices in LDS, runtime dimensions:
+//
+//   k_gseq_forward    `*`_A(:out) -> MvN_x(:out) -> product with MvN_y(:μ)∘`*`_B(:in) when y[t] is not `missing`
+//                     (covariance form; a missing y[t] sends no message, docs/src/manuals/inference/static.md:98-123);
+//                     writes the filtered belief to the output arrays and −log p(y_t | y_<t) terms to the free energy
+//   k_gseq_backward   MvN_x(:μ) -> `*`_A(:in) backward messages folded into the marginal (RTS form), in place on the output
+//                     arrays:  G = V_f A′ V_p⁻¹,  m_s = m_f + G (m_s⁺ − A m_f),  V_s = V_f − G (A V_f) + (G V_s⁺) G′
+//
+// Matrix products run on 4×4 register tiles over LDS (leading dimension n | 1: the four rows of a tile fall into different
+// banks), the d_y×d_y and d×d inverses are in-place Gauss–Jordan sweeps (two barriers per pivot).  This is the coverage path
+// for these model classes at d > 4 — the d, dy ≤ 4 kernels (lgssm_kernels.hpp) stay the fast path for small states.
+#pragma once
+#ifndef RXHIP_GSEQ_HOST_EMULATION  // tests/emu/gseq_emu.cpp compiles this file as plain C++ (one-thread workgroup) for the CPU tests
+#include "generic_kernels.hpp"
+#define RXHIP_GSEQ_EXTERN_SHARED(name) extern __shared__ double name[];
+#endif
+
+namespace rxhip {
+
+struct GseqParams {
+    long long T, n_chains;
+    int d, dy, ptt, fe;
+    const double* y;         // [T][chain][dy]; a NaN entry: y[t] is missing
+    double* mean;            // [T(+H)][chain][d]     filtered beliefs after the forward kernel, marginals after the backward kernel
+    double* cov;             // [T(+H)][chain][d][d]
+    const double* user;      // [n_models][A | P | B | Q | Q⁻¹]  (generic_kernels.hpp)
+    const double* prior;     // [n_models][m0 | V0]
+    const int* chain_model;  // model of a chain, or null
+    const int* step_model;   // model of a time index (transition INTO x[t], observation of y[t]), or null
+    double* fe_part;         // [chain]  log p(y) of the chain (the reduction kernels negate and scale)
+    int* status;
+};
+__device__ __forceinline__ size_t gseq_model_index(const GseqParams& p, long long chain, long long t) {
+    return p.step_model ? (size_t)p.step_model[t] : p.chain_model ? (size_t)p.chain_model[chain] : 0;
+}
+__device__ __forceinline__ GenericModel gseq_model(const GseqParams& p, size_t idx) {
+    const size_t sz = 2 * (size_t)p.d * p.d + (size_t)p.dy * p.d + 2 * (size_t)p.dy * p.dy;
+    const double* u = p.user + idx * sz;
+    GenericModel m;
+    m.A = u;
+    m.P = m.A + (size_t)p.d * p.d;
+    m.B = m.P + (size_t)p.d * p.d;
+    m.Q = m.B + (size_t)p.dy * p.d;
+    m.Qi = m.Q + (size_t)p.dy * p.dy;
+    return m;
+}
+
+__host__ __device__ inline int gseq_ld(int d, int dy) { return (d > dy ? d : dy) | 1; }
+__host__ __device__ inline size_t gseq_lds_bytes(int d, int dy) {
+    const size_t n = (size_t)(d > dy ? d : dy), ld = (size_t)gseq_ld(d, dy);
+    return sizeof(double) * (4 * n * ld + 8 * n + 8);
+}
+
+// out(i, j) = [out(i, j) +] alpha · Σ_k X(i, k) Y(k, j),   i < ni, j < nj, k < nk
+// with X(i, k) = X[i·sxi + k·sxk], Y(k, j) = Y[k·syk + j·syj], out(i, j) = out[i·ldo + j]; one 4×4 tile per thread and pass
+__device__ __forceinline__ void tile_gemm(double* out, int ldo, int ni, int nj, int nk, const double* X, int sxi, int sxk,
+                                          const double* Y, int syk, int syj, double alpha, bool accumulate, int tid, int nthreads) {
+    const int ti_n = (ni + 3) >> 2, tj_n = (nj + 3) >> 2;
+    for (int tile = tid; tile < ti_n * tj_n; tile += nthreads) {
+        const int ti = tile / tj_n, tj = tile - ti * tj_n;
+        const int i0 = 4 * ti, j0 = 4 * tj;
+        int xi[4], yj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // rows / columns past the edge repeat the last valid one (never stored)
+            xi[u] = (i0 + u < ni ? i0 + u : ni - 1) * sxi;
+            yj[u] = (j0 + u < nj ? j0 + u : nj - 1) * syj;
+        }
+        double acc[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+        for (int k = 0; k < nk; ++k) {
+            double xv[4], yv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                xv[u] = X[xi[u] + k * sxk];
+                yv[u] = Y[k * syk + yj[u]];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += xv[u] * yv[v];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int v = 0; v < 4; ++v)
+                if (i0 + u < ni && j0 + v < nj) {
+                    double* o = out + (i0 + u) * ldo + j0 + v;
+                    *o = accumulate ? *o + alpha * acc[u][v] : alpha * acc[u][v];
+                }
+    }
+}
+
+// M <- ½(M + M′) + ½(C + C′) in place (M: n×n in LDS, leading dimension ld; C: n×n row-major, may be null): every thread owns
+// whole (i, j) / (j, i) pairs
+__device__ __forceinline__ void sym_add(double* M, int ld, int n, const double* C, int tid, int nthreads) {
+    for (int e = tid; e < n * n; e += nthreads) {
+        const int i = e / n, j = e - i * n;
+        if (j > i) continue;
+        double v = 0.5 * (M[i * ld + j] + M[j * ld + i]);
+        if (C) v += 0.5 * (C[i * n + j] + C[j * n + i]);
+        M[i * ld + j] = v;
+        M[j * ld + i] = v;
+    }
+}
+
+// in-place inverse of a symmetric positive definite n×n matrix in LDS (Gauss–Jordan without pivoting: the pivots are those of
+// the LDL′ factorisation, their product is the determinant); buf: 2n doubles.  Returns false when a pivot is not positive;
+// *logdet (thread 0 only is meaningful) = log|M|.  Ends with a barrier.
+__device__ __forceinline__ bool lds_gj_inverse(double* M, int ld, int n, double* buf, double* logdet, int tid, int nthreads) {
+    bool ok = true;
+    double ld_acc = 0.0;
+    double* rowk = buf;
+    double* colk = buf + n;
+    for (int k = 0; k < n; ++k) {
+        for (int i = tid; i < n; i += nthreads) {
+            rowk[i] = M[k * ld + i];
+            colk[i] = M[i * ld + k];
+        }
+        __syncthreads();
+        const double piv = rowk[k];
+        ok = ok && piv > 0.0;
+        const double r = 1.0 / piv;
+        if (logdet && tid == 0) ld_acc += log(piv);
+        for (int e = tid; e < n * n; e += nthreads) {
+            const int i = e / n, j = e - i * n;
+            double v;
+            if (i == k) v = (j == k) ? r : rowk[j] * r;
+            else if (j == k) v = -colk[i] * r;
+            else v = M[i * ld + j] - colk[i] * rowk[j] * r;
+            M[i * ld + j] = v;
+        }
+        __syncthreads();
+    }
+    if (logdet) *logdet = ld_acc;
+    return ok;
+}
+
+__global__ void __launch_bounds__(256) k_gseq_forward(GseqParams p) {
+    RXHIP_GSEQ_EXTERN_SHARED(sm)
+    const int d = p.d, dy = p.dy, tid = threadIdx.x, nt = blockDim.x;
+    const int n = d > dy ? d : dy, ld = gseq_ld(d, dy);
+    double* X0 = sm;                 // V_f(t−1) -> V_p(t) -> V_f(t)
+    double* X1 = X0 + n * ld;        // A V, then B V_p (dy×d)
+    double* X2 = X1 + n * ld;        // products before symmetrisation; S = B V_p B′ + Q and its inverse
+    double* X3 = X2 + n * ld;        // S⁻¹ B V_p (dy×d)
+    double* m = X3 + n * ld;         // filtered mean
+    double* mp = m + n;              // predicted mean
+    double* r = mp + n;              // innovation y − B m_p
+    double* sr = r + n;              // S⁻¹ r
+    double* buf = sr + n;            // 2n: pivot row / column
+    double* yv = buf + 2 * n;        // n: y[t]
+    __shared__ int s_obs;
+    const long long c = blockIdx.x;
+    bool ok = true;
+    double logev = 0.0;              // thread 0: Σ log p(y_t | y_<t)
+    {
+        const size_t idx = gseq_model_index(p, c, 0);
+        const double* pr = p.prior + idx * ((size_t)d + (size_t)d * d);
+        for (int i = tid; i < d; i += nt) m[i] = pr[i];
+        for (int e = tid; e < d * d; e += nt) X0[(e / d) * ld + (e % d)] = pr[d + e];
+    }
+    __syncthreads();
+    for (long long t = 0; t < p.T; ++t) {
+        const GenericModel M = gseq_model(p, gseq_model_index(p, c, t));
+        const long long row = t * p.n_chains + c;
+        for (int a = tid; a < dy; a += nt) yv[a] = p.y[row * dy + a];
+        if (t > 0 || p.ptt) {  // `*`_A(:out) -> MvN_x(:out)
+            tile_gemm(X1, ld, d, d, d, M.A, d, 1, X0, ld, 1, 1.0, false, tid, nt);       // A V
+            for (int i = tid; i < d; i += nt) {
+                double s = 0.0;
+                for (int k = 0; k < d; ++k) s += M.A[i * d + k] * m[k];
+                mp[i] = s;
+            }
+            __syncthreads();
+            tile_gemm(X2, ld, d, d, d, X1, ld, 1, M.A, 1, d, 1.0, false, tid, nt);       // (A V) A′
+            __syncthreads();
+            for (int e = tid; e < d * d; e += nt) {
+                const int i = e / d, j = e - i * d;
+                X0[i * ld + j] = 0.5 * (X2[i * ld + j] + X2[j * ld + i]) + 0.5 * (M.P[i * d + j] + M.P[j * d + i]);
+            }
+        } else
+            for (int i = tid; i < d; i += nt) mp[i] = m[i];
+        __syncthreads();
+        if (tid == 0) {
+            int obs = 1;
+            for (int k = 0; k < dy; ++k) obs = obs && (yv[k] == yv[k]);
+            s_obs = obs;
+        }
+        __syncthreads();
+        if (s_obs) {  // uniform over the workgroup
+            tile_gemm(X1, ld, dy, d, d, M.B, d, 1, X0, ld, 1, 1.0, false, tid, nt);      // B V_p
+            for (int a = tid; a < dy; a += nt) {
+                double s = yv[a];
+                for (int k = 0; k < d; ++k) s -= M.B[a * d + k] * mp[k];
+                r[a] = s;
+            }
+            __syncthreads();
+            tile_gemm(X2, ld, dy, dy, d, X1, ld, 1, M.B, 1, d, 1.0, false, tid, nt);     // (B V_p) B′
+            __syncthreads();
+            sym_add(X2, ld, dy, M.Q, tid, nt);                                            // S
+            __syncthreads();
+            double logdet = 0.0;
+            ok = lds_gj_inverse(X2, ld, dy, buf, &logdet, tid, nt) && ok;
+            tile_gemm(X3, ld, dy, d, dy, X2, ld, 1, X1, ld, 1, 1.0, false, tid, nt);     // S⁻¹ B V_p
+            for (int a = tid; a < dy; a += nt) {
+                double s = 0.0;
+                for (int k = 0; k < dy; ++k) s += X2[a * ld + k] * r[k];
+                sr[a] = s;
+            }
+            __syncthreads();
+            tile_gemm(X2, ld, d, d, dy, X1, 1, ld, X3, ld, 1, 1.0, false, tid, nt);      // (B V_p)′ S⁻¹ (B V_p)
+            for (int i = tid; i < d; i += nt) {
+                double s = mp[i];
+                for (int a = 0; a < dy; ++a) s += X1[a * ld + i] * sr[a];
+                m[i] = s;
+            }
+            if (p.fe && tid == 0) {
+                double q = 0.0;
+                for (int a = 0; a < dy; ++a) q += r[a] * sr[a];
+                logev -= 0.5 * ((double)dy * 1.8378770664093453 + logdet + q);
+            }
+            __syncthreads();
+            for (int e = tid; e < d * d; e += nt) {
+                const int i = e / d, j = e - i * d;
+                if (j > i) continue;
+                const double v = 0.5 * (X0[i * ld + j] + X0[j * ld + i]) - 0.5 * (X2[i * ld + j] + X2[j * ld + i]);
+                X0[i * ld + j] = v;
+                X0[j * ld + i] = v;
+            }
+        } else
+            for (int i = tid; i < d; i += nt) m[i] = mp[i];
+        __syncthreads();
+        for (int i = tid; i < d; i += nt) p.mean[row * d + i] = m[i];
+        for (int e = tid; e < d * d; e += nt) p.cov[row * d * d + e] = X0[(e / d) * ld + (e % d)];
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (p.fe) p.fe_part[c] = logev;
+        if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+    }
+}
+
+__global__ void __launch_bounds__(256) k_gseq_backward(GseqParams p) {
+    RXHIP_GSEQ_EXTERN_SHARED(sm)
+    const int d = p.d, dy = p.dy, tid = threadIdx.x, nt = blockDim.x;
+    const int n = d > dy ? d : dy, ld = gseq_ld(d, dy);
+    double* X0 = sm;                 // V_f(t), then G
+    double* X1 = X0 + n * ld;        // V_s(t+1), then V_s(t)
+    double* X2 = X1 + n * ld;        // A V_f
+    double* X3 = X2 + n * ld;        // V_p(t+1) and its inverse, then G V_s(t+1)
+    double* ms = X3 + n * ld;        // m_s(t+1), then m_s(t)
+    double* mf = ms + n;             // m_f(t)
+    double* dm = mf + n;             // m_s(t+1) − A m_f
+    double* buf = dm + n;            // 2n
+    const long long c = blockIdx.x;
+    bool ok = true;
+    {
+        const long long row = (p.T - 1) * p.n_chains + c;
+        for (int i = tid; i < d; i += nt) ms[i] = p.mean[row * d + i];
+        for (int e = tid; e < d * d; e += nt) X1[(e / d) * ld + (e % d)] = p.cov[row * d * d + e];
+    }
+    __syncthreads();
+    for (long long t = p.T - 2; t >= 0; --t) {
+        const GenericModel M = gseq_model(p, gseq_model_index(p, c, t + 1));  // the transition into x[t+1]
+        const long long row = t * p.n_chains + c;
+        const double* Vf = p.cov + row * d * d;
+        for (int i = tid; i < d; i += nt) mf[i] = p.mean[row * d + i];
+        for (int e = tid; e < d * d; e += nt) X0[(e / d) * ld + (e % d)] = Vf[e];
+        __syncthreads();
+        tile_gemm(X2, ld, d, d, d, M.A, d, 1, X0, ld, 1, 1.0, false, tid, nt);           // A V_f
+        for (int i = tid; i < d; i += nt) {
+            double s = 0.0;
+            for (int k = 0; k < d; ++k) s += M.A[i * d + k] * mf[k];
+            dm[i] = ms[i] - s;
+        }
+        __syncthreads();
+        tile_gemm(X3, ld, d, d, d, X2, ld, 1, M.A, 1, d, 1.0, false, tid, nt);           // (A V_f) A′
+        __syncthreads();
+        sym_add(X3, ld, d, M.P, tid, nt);                                                 // V_p(t+1)
+        __syncthreads();
+        ok = lds_gj_inverse(X3, ld, d, buf, nullptr, tid, nt) && ok;
+        tile_gemm(X0, ld, d, d, d, X2, 1, ld, X3, ld, 1, 1.0, false, tid, nt);           // G = (A V_f)′ V_p⁻¹
+        __syncthreads();
+        tile_gemm(X3, ld, d, d, d, X0, ld, 1, X1, ld, 1, 1.0, false, tid, nt);           // G V_s(t+1)
+        for (int i = tid; i < d; i += nt) {
+            double s = mf[i];
+            for (int k = 0; k < d; ++k) s += X0[i * ld + k] * dm[k];
+            mf[i] = s;                                                                    // m_s(t): thread i owns entry i
+        }
+        __syncthreads();
+        tile_gemm(X1, ld, d, d, d, X3, ld, 1, X0, 1, ld, 1.0, false, tid, nt);           // (G V_s⁺) G′
+        tile_gemm(X1, ld, d, d, d, X0, ld, 1, X2, ld, 1, -1.0, true, tid, nt);           // − G (A V_f): same tile owner, no barrier
+        __syncthreads();
+        for (int e = tid; e < d * d; e += nt) {
+            const int i = e / d, j = e - i * d;
+            if (j > i) continue;
+            const double v = 0.5 * (X1[i * ld + j] + X1[j * ld + i]) + 0.5 * (Vf[i * d + j] + Vf[j * d + i]);
+            X1[i * ld + j] = v;
+            X1[j * ld + i] = v;
+        }
+        for (int i = tid; i < d; i += nt) ms[i] = mf[i];
+        __syncthreads();  // every read of the filtered row is done before it is overwritten
+        for (int i = tid; i < d; i += nt) p.mean[row * d + i] = ms[i];
+        for (int e = tid; e < d * d; e += nt) p.cov[row * d * d + e] = X1[(e / d) * ld + (e % d)];
+        __syncthreads();
+    }
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+}  // namespace rxhip

@@ -19,6 +19,7 @@
 
 #include "lgssm_kernels.hpp"
 #include "dense_kernels.hpp"
+#include "gseq_kernels.hpp"
 #include "gmm_kernels.hpp"
 #include "hgf_kernels.hpp"
 #include "mvgmm_kernels.hpp"
@@ -352,6 +353,8 @@ struct rxhip_engine {
     std::vector<double> h_user;  // MFMA path: user-level A | P | B | Q | Q⁻¹ of every model (generic_kernels.hpp)
     double* d_user = nullptr;
     int* d_step_model = nullptr;
+    bool gseq = false;        // d > 4 with `missing` observations or per-step constants: sequential schedule (gseq_kernels.hpp)
+    double* d_prior = nullptr;  // gseq: [n_models][m0 | V0]
     bool masked = false;      // NaN observations are `missing` (rxhip_lgssm_desc.allow_missing): per-chain records, one segment
     int pack = 1;             // 2: pairs of chains share a 16×16 tile as a block-diagonal model (d ≤ 8), see dense_kernels.hpp
     long long wg_chains = 0;  // chains (or pairs) the kernels' grids run over
@@ -1654,14 +1657,14 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     if (ds->allow_missing) {
         // `missing` observations change the covariances per chain and per time index: no table of the time-parallel schedule
         // survives.  The chain runs as ONE segment (sequential in time, parallel over chains) on the per-chain-record kernels.
-        if (dense) return fail(e, RXHIP_ERR_UNSUPPORTED, "missing observations inside the data have a device schedule for d, dy ≤ 4 only");
+        if (dense) e->gseq = true;  // any d, dy ≤ 64: one workgroup per chain, sequential in time (gseq_kernels.hpp)
         e->masked = true;
         e->sequential = true;
         e->uniform = false;
     }
     if (ds->step_model) {
         // time-varying A_t, P_t, B_t, Q_t: the tables of the time-parallel schedule assume one model along the chain
-        if (dense) return fail(e, RXHIP_ERR_UNSUPPORTED, "time-varying constants have a device schedule for d, dy ≤ 4 only");
+        if (dense) e->gseq = true;
         e->sequential = true;
         e->uniform = false;
     }
@@ -1704,10 +1707,10 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     }
     // d ≤ 8: two chains per 16×16 tile (block-diagonal pair) instead of one chain padded to 16 — twice the chains per
     // workgroup for the same MFMA work.  Needs an even batch (the pair is formed from neighbours in memory).
-    e->pack = (dense && ds->d <= 8 && ds->dy <= 32 && ds->n_chains % 2 == 0 && ds->n_models == 1 && !std::getenv("RXHIP_NO_PACK")) ? 2 : 1;
+    e->pack = (dense && !e->gseq && ds->d <= 8 && ds->dy <= 32 && ds->n_chains % 2 == 0 && ds->n_models == 1 && !std::getenv("RXHIP_NO_PACK")) ? 2 : 1;
     e->wg_chains = ds->n_chains / e->pack;
     e->dyk = ds->dy * e->pack;
-    if (dense && e->wg_chains > 65535)  // the chain index is a grid y/z coordinate of the MFMA-path kernels
+    if (dense && !e->gseq && e->wg_chains > 65535)  // the chain index is a grid y/z coordinate of the MFMA-path kernels
         return fail(e, RXHIP_ERR_UNSUPPORTED, "d = %d runs on the MFMA path, which takes at most %d chains per engine (%lld given)", ds->d,
                     65535 * e->pack, (long long)ds->n_chains);
     if (ds->device >= 0) {
@@ -1759,6 +1762,42 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->Llast = steps - (long long)(e->S - 1) * L;
     }
 
+    if (e->gseq) {  // no tables: the user-level constants, the priors, the outputs
+        e->S = 0; e->L = 1; e->Llast = 1;
+        static std::once_flag lds_once;
+        std::call_once(lds_once, [] {
+            (void)hipFuncSetAttribute((const void*)k_gseq_forward, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_gseq_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        });
+        (void)hipGetLastError();
+        const size_t CU = (size_t)e->n_chains, Du = (size_t)e->d, np = Du + Du * Du;
+        std::vector<double> prior((size_t)e->n_models * np);
+        for (int m = 0; m < e->n_models; ++m) {
+            std::memcpy(&prior[(size_t)m * np], ds->m0 + (size_t)m * Du, sizeof(double) * Du);
+            std::memcpy(&prior[(size_t)m * np + Du], ds->V0 + (size_t)m * Du * Du, sizeof(double) * Du * Du);
+        }
+        ArenaPlan ap;
+        ap.upload(&e->d_user, e->h_user.data(), sizeof(double) * e->h_user.size());
+        ap.upload(&e->d_prior, prior.data(), sizeof(double) * prior.size());
+        if (ds->chain_model) ap.upload(&e->d_chain_model, ds->chain_model, sizeof(int) * CU);
+        if (ds->step_model) ap.upload(&e->d_step_model, ds->step_model, sizeof(int) * (size_t)(e->T + e->H));
+        if (!e->h_mu.empty()) {
+            ap.upload(&e->d_mu, e->h_mu.data(), sizeof(double) * e->h_mu.size());
+            ap.upload(&e->d_nu, e->h_nu.data(), sizeof(double) * e->h_nu.size());
+            ap.upload(&e->d_cx, e->h_cx.data(), sizeof(double) * e->h_cx.size());
+            ap.upload(&e->d_cy_raw, e->h_cy.data(), sizeof(double) * e->h_cy.size());
+        }
+        ap.zeroed(&e->d_status, sizeof(int));
+        ap.zeroed(&e->d_fe_part, sizeof(double) * CU);
+        e->fe_total_cap = 16;
+        ap.zeroed(&e->d_fe_total, sizeof(double) * e->fe_total_cap);
+        ap.plain(&e->d_fe_blocks, sizeof(double) * ((CU + 63) / 64));
+        ap.plain(&e->d_fe_chain, sizeof(double) * CU);
+        ap.plain(&e->d_mean, sizeof(double) * (size_t)e->Tout() * CU * Du);
+        ap.plain(&e->d_cov, sizeof(double) * (size_t)e->Tout() * CU * Du * Du);
+        if (rxhip_status st = arena_commit(e, ap)) return st;
+        return RXHIP_OK;
+    }
     if (dense) {
         StageTrace tr;
         hipError_t herr = hipSuccess;
@@ -2822,7 +2861,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     const bool fe = want_fe != 0;
     rxhip_status st;
     DenseParams dp;
-    if (e->dense) {
+    if (e->dense && !e->gseq) {
         dp.T = e->T; dp.n_chains = e->wg_chains; dp.S = e->S; dp.L = e->L; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dyk;
         dp.pack = e->pack; dp.d_sub = 8; dp.dy_sub = e->dy;
         dp.models = e->n_models > 1 ? e->d_models : nullptr; dp.chain_model = e->d_chain_model;
@@ -2835,7 +2874,21 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     }
     for (int it = 0; it < iterations; ++it) {
         p.iteration = it;
-        if (e->dense) {
+        if (e->gseq) {
+            GseqParams gq{};
+            gq.T = e->T; gq.n_chains = e->n_chains; gq.d = e->d; gq.dy = e->dy; gq.ptt = e->ptt; gq.fe = fe ? 1 : 0; gq.y = e->d_y;
+            gq.mean = e->d_mean; gq.cov = e->d_cov; gq.user = e->d_user; gq.prior = e->d_prior; gq.chain_model = e->d_chain_model;
+            gq.step_model = e->d_step_model; gq.fe_part = e->d_fe_part; gq.status = e->d_status;
+            const size_t lds = gseq_lds_bytes(e->d, e->dy);
+            if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
+            hipLaunchKernelGGL(k_gseq_forward, dim3((unsigned)e->n_chains), dim3(256), lds, e->stream, gq);
+            if ((st = prof_end(e))) return st;
+            if (!filter && e->T > 1) {
+                if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
+                hipLaunchKernelGGL(k_gseq_backward, dim3((unsigned)e->n_chains), dim3(256), lds, e->stream, gq);
+                if ((st = prof_end(e))) return st;
+            }
+        } else if (e->dense) {
             if (e->S > 0) {
                 if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
                 DENSE_DISPATCH(e->nt, seg_aggregate(dp, e->stream));
@@ -2915,7 +2968,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         if (e->H > 0 && e->dense) {  // the unobserved tail on the MFMA path: generic-dimension forecast, one workgroup per chain
             GenericParams gp{};
             gp.T = e->T; gp.H = e->H; gp.n_chains = e->n_chains; gp.d = e->d; gp.dy = e->dy; gp.mean = e->d_mean; gp.cov = e->d_cov;
-            gp.user = e->d_user; gp.cx = e->d_cx; gp.off_chain = e->off_chain ? 1 : 0; gp.chain_model = e->d_chain_model; gp.status = e->d_status;
+            gp.user = e->d_user; gp.cx = e->d_cx; gp.off_chain = e->off_chain ? 1 : 0; gp.chain_model = e->d_chain_model; gp.step_model = e->d_step_model; gp.status = e->d_status;
             hipLaunchKernelGGL(k_forecast_generic, dim3((unsigned)e->n_chains), dim3(256), generic_forecast_lds(e->d), e->stream, gp);
         }
         if (e->H > 0 && !e->dense) {  // the unobserved tail: forward messages from the last filtered (= smoothed) belief
@@ -3101,7 +3154,7 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
         HIPCHK(e, hipMalloc(&tmp, sizeof(double) * rows * (dy + dy * dy)));
         GenericParams gp{};
         gp.T = e->T; gp.H = e->H; gp.n_chains = e->n_chains; gp.d = e->d; gp.dy = e->dy; gp.y = e->d_y; gp.mean = e->d_mean; gp.cov = e->d_cov;
-        gp.user = e->d_user; gp.chain_model = e->d_chain_model; gp.pmean = tmp; gp.pcov = tmp + rows * dy; gp.status = e->d_status;
+        gp.user = e->d_user; gp.chain_model = e->d_chain_model; gp.step_model = e->d_step_model; gp.pmean = tmp; gp.pcov = tmp + rows * dy; gp.status = e->d_status;
         gp.mu = e->d_mu; gp.nu = e->d_nu; gp.off_chain = e->off_chain ? 1 : 0;
         hipLaunchKernelGGL(k_predict_generic, dim3((unsigned)rows), dim3(256), generic_predict_lds(e->d, e->dy), e->stream, gp);
         rxhip_status st = RXHIP_OK;

@@ -391,7 +391,7 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
     `predictvars = ("y",)` (reference: `predictvars = (y = KeepLast(),)`): result.predictions["y"] holds the message toward
     every y[t] — leave-one-out predictive for observed steps.  NaN rows of `y` are `missing` observations: a tail that no
     chain observed is a forecast horizon (posteriors and predictions there are forward predictions, the sweep stays
-    time-parallel); `missing` values anywhere else select the masked schedule (d, dy ≤ 4), where a missing y[t] sends no
+    time-parallel); `missing` values anywhere else select the masked schedule (any d, dy ≤ 64), where a missing y[t] sends no
     message and its prediction is the smoothed predictive."""
     if isinstance(model, UnivariateGaussianMixture):
         return _infer_mixture(model, data, iterations, free_energy, options, initialization, catch_exception)

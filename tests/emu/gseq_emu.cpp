@@ -1,0 +1,51 @@
+// Host emulation of rxinfer.jl_amd/csrc/gseq_kernels.hpp for the CPU test suite: the kernel SOURCE compiled as plain C++ with
+// a workgroup of ONE thread (every `for (e = tid; e < n; e += nthreads)` loop becomes a full loop, barriers are no-ops).
+// Checks the index arithmetic, the LDS layout and the formulas of the kernels against the oracle without a GPU; the
+// synchronisation of the real 256-thread workgroup is what the `-m gpu` tests check.  Test infrastructure only.
+#include <cmath>
+#include <cstddef>
+#include <cstring>
+#include <vector>
+
+#define RXHIP_GSEQ_HOST_EMULATION 1
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define __shared__ static
+#define __syncthreads() ((void)0)
+
+namespace rxhip {
+struct GenericModel {
+    const double *A, *P, *B, *Q, *Qi;
+};
+constexpr int ST_NOT_POSDEF = 1;
+static inline void atomicOr(int* p, int v) { *p |= v; }
+struct Idx { unsigned x; };
+static Idx threadIdx{0}, blockDim{1}, blockIdx{0};
+static double* sm = nullptr;   // the dynamic LDS block
+}  // namespace rxhip
+#define RXHIP_GSEQ_EXTERN_SHARED(name)   /* `extern __shared__ double sm[]` of the kernels: the namespace-level pointer above */
+
+#include "../../rxinfer.jl_amd/csrc/gseq_kernels.hpp"
+
+extern "C" int gseq_emu_run(long long T, long long n_chains, int d, int dy, int ptt, int n_models, const double* user, const double* prior,
+                            const int* chain_model, const int* step_model, const double* y, int smooth, double* mean, double* cov,
+                            double* logev) {
+    using namespace rxhip;
+    GseqParams p{};
+    p.T = T; p.n_chains = n_chains; p.d = d; p.dy = dy; p.ptt = ptt; p.fe = 1; p.y = y; p.mean = mean; p.cov = cov; p.user = user;
+    p.prior = prior; p.chain_model = chain_model; p.step_model = step_model; p.fe_part = logev;
+    int status = 0;
+    p.status = &status;
+    std::vector<double> lds(gseq_lds_bytes(d, dy) / sizeof(double));
+    sm = lds.data();
+    for (long long c = 0; c < n_chains; ++c) {
+        blockIdx.x = (unsigned)c;
+        k_gseq_forward(p);
+        if (smooth) k_gseq_backward(p);
+    }
+    (void)n_models;
+    return status;
+}
