@@ -77,6 +77,7 @@ __device__ __forceinline__ void tile_gemm(double* out, int ldo, int ni, int nj, 
         for (int u = 0; u < 4; ++u)
 #pragma unroll
             for (int v = 0; v < 4; ++v) acc[u][v] = 0.0;
+#pragma unroll 2
         for (int k = 0; k < nk; ++k) {
             double xv[4], yv[4];
 #pragma unroll
@@ -100,11 +101,26 @@ __device__ __forceinline__ void tile_gemm(double* out, int ldo, int ni, int nj, 
     }
 }
 
+// thread -> (column j0, row group i0) for element-wise passes over an n-column matrix: `lanes` (a power of two ≥ n, at most a
+// wavefront) consecutive threads walk one row, so that no index needs a division by the runtime dimension
+struct Map2 {
+    int lanes, groups, j0, i0;
+    __device__ __forceinline__ Map2(int n, int tid, int nthreads) {
+        int sh = 0;
+        while ((1 << sh) < n && (1 << sh) < 64 && (2 << sh) <= nthreads) ++sh;
+        lanes = 1 << sh;
+        groups = nthreads >> sh;
+        j0 = tid & (lanes - 1);
+        i0 = tid >> sh;
+    }
+};
+#define RXHIP_FOR_2D(mp, ni, nj, i, j) for (int i = (mp).i0; i < (ni); i += (mp).groups) for (int j = (mp).j0; j < (nj); j += (mp).lanes)
+
 // M <- ½(M + M′) + ½(C + C′) in place (M: n×n in LDS, leading dimension ld; C: n×n row-major, may be null): every thread owns
 // whole (i, j) / (j, i) pairs
 __device__ __forceinline__ void sym_add(double* M, int ld, int n, const double* C, int tid, int nthreads) {
-    for (int e = tid; e < n * n; e += nthreads) {
-        const int i = e / n, j = e - i * n;
+    const Map2 mp(n, tid, nthreads);
+    RXHIP_FOR_2D(mp, n, n, i, j) {
         if (j > i) continue;
         double v = 0.5 * (M[i * ld + j] + M[j * ld + i]);
         if (C) v += 0.5 * (C[i * n + j] + C[j * n + i]);
@@ -121,6 +137,7 @@ __device__ __forceinline__ bool lds_gj_inverse(double* M, int ld, int n, double*
     double ld_acc = 0.0;
     double* rowk = buf;
     double* colk = buf + n;
+    const Map2 mp(n, tid, nthreads);
     for (int k = 0; k < n; ++k) {
         for (int i = tid; i < n; i += nthreads) {
             rowk[i] = M[k * ld + i];
@@ -131,13 +148,16 @@ __device__ __forceinline__ bool lds_gj_inverse(double* M, int ld, int n, double*
         ok = ok && piv > 0.0;
         const double r = 1.0 / piv;
         if (logdet && tid == 0) ld_acc += log(piv);
-        for (int e = tid; e < n * n; e += nthreads) {
-            const int i = e / n, j = e - i * n;
-            double v;
-            if (i == k) v = (j == k) ? r : rowk[j] * r;
-            else if (j == k) v = -colk[i] * r;
-            else v = M[i * ld + j] - colk[i] * rowk[j] * r;
-            M[i * ld + j] = v;
+        for (int j = mp.j0; j < n; j += mp.lanes) {
+            const double rj = rowk[j] * r;
+#pragma unroll 4
+            for (int i = mp.i0; i < n; i += mp.groups) {  // independent elements: their LDS reads overlap
+                const double ci = colk[i], mij = M[i * ld + j];
+                double v = mij - ci * rj;
+                v = (j == k) ? -ci * r : v;
+                v = (i == k) ? ((j == k) ? r : rj) : v;
+                M[i * ld + j] = v;
+            }
         }
         __syncthreads();
     }
@@ -145,10 +165,11 @@ __device__ __forceinline__ bool lds_gj_inverse(double* M, int ld, int n, double*
     return ok;
 }
 
-__global__ void __launch_bounds__(256) k_gseq_forward(GseqParams p) {
+__global__ void __launch_bounds__(256, 4) k_gseq_forward(GseqParams p) {
     RXHIP_GSEQ_EXTERN_SHARED(sm)
     const int d = p.d, dy = p.dy, tid = threadIdx.x, nt = blockDim.x;
     const int n = d > dy ? d : dy, ld = gseq_ld(d, dy);
+    const Map2 md(d, tid, nt);
     double* X0 = sm;                 // V_f(t−1) -> V_p(t) -> V_f(t)
     double* X1 = X0 + n * ld;        // A V, then B V_p (dy×d)
     double* X2 = X1 + n * ld;        // products before symmetrisation; S = B V_p B′ + Q and its inverse
@@ -167,29 +188,29 @@ __global__ void __launch_bounds__(256) k_gseq_forward(GseqParams p) {
         const size_t idx = gseq_model_index(p, c, 0);
         const double* pr = p.prior + idx * ((size_t)d + (size_t)d * d);
         for (int i = tid; i < d; i += nt) m[i] = pr[i];
-        for (int e = tid; e < d * d; e += nt) X0[(e / d) * ld + (e % d)] = pr[d + e];
+        RXHIP_FOR_2D(md, d, d, i, j) X0[i * ld + j] = pr[d + i * d + j];
     }
     __syncthreads();
     for (long long t = 0; t < p.T; ++t) {
         const GenericModel M = gseq_model(p, gseq_model_index(p, c, t));
         const long long row = t * p.n_chains + c;
         for (int a = tid; a < dy; a += nt) yv[a] = p.y[row * dy + a];
-        if (t > 0 || p.ptt) {  // `*`_A(:out) -> MvN_x(:out)
-            tile_gemm(X1, ld, d, d, d, M.A, d, 1, X0, ld, 1, 1.0, false, tid, nt);       // A V
+        if (t > 0 || p.ptt) {  // `*`_A(:out) -> MvN_x(:out); A is staged in X3 (free until the observation update): an operand
+            RXHIP_FOR_2D(md, d, d, i, j) X3[i * ld + j] = M.A[i * d + j];  // read from global memory costs an L2 round trip per k step
+            __syncthreads();
+            tile_gemm(X1, ld, d, d, d, X3, ld, 1, X0, ld, 1, 1.0, false, tid, nt);       // A V
             for (int i = tid; i < d; i += nt) {
                 double s = 0.0;
-                for (int k = 0; k < d; ++k) s += M.A[i * d + k] * m[k];
+                for (int k = 0; k < d; ++k) s += X3[i * ld + k] * m[k];
                 mp[i] = s;
             }
             __syncthreads();
-            tile_gemm(X2, ld, d, d, d, X1, ld, 1, M.A, 1, d, 1.0, false, tid, nt);       // (A V) A′
+            tile_gemm(X2, ld, d, d, d, X1, ld, 1, X3, 1, ld, 1.0, false, tid, nt);       // (A V) A′
             __syncthreads();
-            for (int e = tid; e < d * d; e += nt) {
-                const int i = e / d, j = e - i * d;
-                X0[i * ld + j] = 0.5 * (X2[i * ld + j] + X2[j * ld + i]) + 0.5 * (M.P[i * d + j] + M.P[j * d + i]);
-            }
+            RXHIP_FOR_2D(md, d, d, i, j) X0[i * ld + j] = 0.5 * (X2[i * ld + j] + X2[j * ld + i]) + 0.5 * (M.P[i * d + j] + M.P[j * d + i]);
         } else
             for (int i = tid; i < d; i += nt) mp[i] = m[i];
+        RXHIP_FOR_2D(md, dy, d, a, k) X3[a * ld + k] = M.B[a * d + k];   // B, until S⁻¹ B V_p takes the buffer
         __syncthreads();
         if (tid == 0) {
             int obs = 1;
@@ -198,14 +219,14 @@ __global__ void __launch_bounds__(256) k_gseq_forward(GseqParams p) {
         }
         __syncthreads();
         if (s_obs) {  // uniform over the workgroup
-            tile_gemm(X1, ld, dy, d, d, M.B, d, 1, X0, ld, 1, 1.0, false, tid, nt);      // B V_p
+            tile_gemm(X1, ld, dy, d, d, X3, ld, 1, X0, ld, 1, 1.0, false, tid, nt);      // B V_p
             for (int a = tid; a < dy; a += nt) {
                 double s = yv[a];
-                for (int k = 0; k < d; ++k) s -= M.B[a * d + k] * mp[k];
+                for (int k = 0; k < d; ++k) s -= X3[a * ld + k] * mp[k];
                 r[a] = s;
             }
             __syncthreads();
-            tile_gemm(X2, ld, dy, dy, d, X1, ld, 1, M.B, 1, d, 1.0, false, tid, nt);     // (B V_p) B′
+            tile_gemm(X2, ld, dy, dy, d, X1, ld, 1, X3, 1, ld, 1.0, false, tid, nt);     // (B V_p) B′
             __syncthreads();
             sym_add(X2, ld, dy, M.Q, tid, nt);                                            // S
             __syncthreads();
@@ -230,8 +251,7 @@ __global__ void __launch_bounds__(256) k_gseq_forward(GseqParams p) {
                 logev -= 0.5 * ((double)dy * 1.8378770664093453 + logdet + q);
             }
             __syncthreads();
-            for (int e = tid; e < d * d; e += nt) {
-                const int i = e / d, j = e - i * d;
+            RXHIP_FOR_2D(md, d, d, i, j) {
                 if (j > i) continue;
                 const double v = 0.5 * (X0[i * ld + j] + X0[j * ld + i]) - 0.5 * (X2[i * ld + j] + X2[j * ld + i]);
                 X0[i * ld + j] = v;
@@ -241,7 +261,7 @@ __global__ void __launch_bounds__(256) k_gseq_forward(GseqParams p) {
             for (int i = tid; i < d; i += nt) m[i] = mp[i];
         __syncthreads();
         for (int i = tid; i < d; i += nt) p.mean[row * d + i] = m[i];
-        for (int e = tid; e < d * d; e += nt) p.cov[row * d * d + e] = X0[(e / d) * ld + (e % d)];
+        RXHIP_FOR_2D(md, d, d, i, j) p.cov[row * d * d + i * d + j] = X0[i * ld + j];
         __syncthreads();
     }
     if (tid == 0) {
@@ -250,14 +270,15 @@ __global__ void __launch_bounds__(256) k_gseq_forward(GseqParams p) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_gseq_backward(GseqParams p) {
+__global__ void __launch_bounds__(256, 4) k_gseq_backward(GseqParams p) {
     RXHIP_GSEQ_EXTERN_SHARED(sm)
     const int d = p.d, dy = p.dy, tid = threadIdx.x, nt = blockDim.x;
     const int n = d > dy ? d : dy, ld = gseq_ld(d, dy);
-    double* X0 = sm;                 // V_f(t), then G
+    const Map2 md(d, tid, nt);
+    double* X0 = sm;                 // V_f(t), then V_p(t+1) and its inverse, then G V_s(t+1)
     double* X1 = X0 + n * ld;        // V_s(t+1), then V_s(t)
     double* X2 = X1 + n * ld;        // A V_f
-    double* X3 = X2 + n * ld;        // V_p(t+1) and its inverse, then G V_s(t+1)
+    double* X3 = X2 + n * ld;        // A, then G
     double* ms = X3 + n * ld;        // m_s(t+1), then m_s(t)
     double* mf = ms + n;             // m_f(t)
     double* dm = mf + n;             // m_s(t+1) − A m_f
@@ -267,7 +288,7 @@ __global__ void __launch_bounds__(256) k_gseq_backward(GseqParams p) {
     {
         const long long row = (p.T - 1) * p.n_chains + c;
         for (int i = tid; i < d; i += nt) ms[i] = p.mean[row * d + i];
-        for (int e = tid; e < d * d; e += nt) X1[(e / d) * ld + (e % d)] = p.cov[row * d * d + e];
+        RXHIP_FOR_2D(md, d, d, i, j) X1[i * ld + j] = p.cov[row * d * d + i * d + j];
     }
     __syncthreads();
     for (long long t = p.T - 2; t >= 0; --t) {
@@ -275,34 +296,36 @@ __global__ void __launch_bounds__(256) k_gseq_backward(GseqParams p) {
         const long long row = t * p.n_chains + c;
         const double* Vf = p.cov + row * d * d;
         for (int i = tid; i < d; i += nt) mf[i] = p.mean[row * d + i];
-        for (int e = tid; e < d * d; e += nt) X0[(e / d) * ld + (e % d)] = Vf[e];
+        RXHIP_FOR_2D(md, d, d, i, j) {
+            X0[i * ld + j] = Vf[i * d + j];
+            X3[i * ld + j] = M.A[i * d + j];   // A staged in LDS for the two products that use it
+        }
         __syncthreads();
-        tile_gemm(X2, ld, d, d, d, M.A, d, 1, X0, ld, 1, 1.0, false, tid, nt);           // A V_f
+        tile_gemm(X2, ld, d, d, d, X3, ld, 1, X0, ld, 1, 1.0, false, tid, nt);           // A V_f
         for (int i = tid; i < d; i += nt) {
             double s = 0.0;
-            for (int k = 0; k < d; ++k) s += M.A[i * d + k] * mf[k];
+            for (int k = 0; k < d; ++k) s += X3[i * ld + k] * mf[k];
             dm[i] = ms[i] - s;
         }
         __syncthreads();
-        tile_gemm(X3, ld, d, d, d, X2, ld, 1, M.A, 1, d, 1.0, false, tid, nt);           // (A V_f) A′
+        tile_gemm(X0, ld, d, d, d, X2, ld, 1, X3, 1, ld, 1.0, false, tid, nt);           // (A V_f) A′   (V_f is re-read from memory below)
         __syncthreads();
-        sym_add(X3, ld, d, M.P, tid, nt);                                                 // V_p(t+1)
+        sym_add(X0, ld, d, M.P, tid, nt);                                                 // V_p(t+1)
         __syncthreads();
-        ok = lds_gj_inverse(X3, ld, d, buf, nullptr, tid, nt) && ok;
-        tile_gemm(X0, ld, d, d, d, X2, 1, ld, X3, ld, 1, 1.0, false, tid, nt);           // G = (A V_f)′ V_p⁻¹
+        ok = lds_gj_inverse(X0, ld, d, buf, nullptr, tid, nt) && ok;
+        tile_gemm(X3, ld, d, d, d, X2, 1, ld, X0, ld, 1, 1.0, false, tid, nt);           // G = (A V_f)′ V_p⁻¹
         __syncthreads();
-        tile_gemm(X3, ld, d, d, d, X0, ld, 1, X1, ld, 1, 1.0, false, tid, nt);           // G V_s(t+1)
+        tile_gemm(X0, ld, d, d, d, X3, ld, 1, X1, ld, 1, 1.0, false, tid, nt);           // G V_s(t+1)
         for (int i = tid; i < d; i += nt) {
             double s = mf[i];
-            for (int k = 0; k < d; ++k) s += X0[i * ld + k] * dm[k];
+            for (int k = 0; k < d; ++k) s += X3[i * ld + k] * dm[k];
             mf[i] = s;                                                                    // m_s(t): thread i owns entry i
         }
         __syncthreads();
-        tile_gemm(X1, ld, d, d, d, X3, ld, 1, X0, 1, ld, 1.0, false, tid, nt);           // (G V_s⁺) G′
-        tile_gemm(X1, ld, d, d, d, X0, ld, 1, X2, ld, 1, -1.0, true, tid, nt);           // − G (A V_f): same tile owner, no barrier
+        tile_gemm(X1, ld, d, d, d, X0, ld, 1, X3, 1, ld, 1.0, false, tid, nt);           // (G V_s⁺) G′
+        tile_gemm(X1, ld, d, d, d, X3, ld, 1, X2, ld, 1, -1.0, true, tid, nt);           // − G (A V_f): same tile owner, no barrier
         __syncthreads();
-        for (int e = tid; e < d * d; e += nt) {
-            const int i = e / d, j = e - i * d;
+        RXHIP_FOR_2D(md, d, d, i, j) {
             if (j > i) continue;
             const double v = 0.5 * (X1[i * ld + j] + X1[j * ld + i]) + 0.5 * (Vf[i * d + j] + Vf[j * d + i]);
             X1[i * ld + j] = v;
@@ -311,7 +334,7 @@ __global__ void __launch_bounds__(256) k_gseq_backward(GseqParams p) {
         for (int i = tid; i < d; i += nt) ms[i] = mf[i];
         __syncthreads();  // every read of the filtered row is done before it is overwritten
         for (int i = tid; i < d; i += nt) p.mean[row * d + i] = ms[i];
-        for (int e = tid; e < d * d; e += nt) p.cov[row * d * d + e] = X1[(e / d) * ld + (e % d)];
+        RXHIP_FOR_2D(md, d, d, i, j) p.cov[row * d * d + i * d + j] = X1[i * ld + j];
         __syncthreads();
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);

@@ -1,0 +1,31 @@
+"""Sweep time of the sequential schedule (csrc/gseq_kernels.hpp: `missing` observations / per-step constants at d > 4)
+next to the time-parallel MFMA schedule on the same fully observed batch."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rxinfer.jl_amd"))
+import numpy as np
+import rxhip
+from rxhip import workloads
+
+
+def timed(eng, n=3):
+    eng.run(free_energy=True)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        eng.run(free_energy=True)
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for d, C, T in ((8, 1024, 1000), (16, 512, 1000), (32, 256, 500), (64, 256, 200), (64, 1, 2000)):
+    mdl = workloads.random_model(d, d, seed=d)
+    y = workloads.generate_batch(mdl, T, C, seed0=1)
+    args = (mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    with rxhip.LGSSMEngine(*args, T=T, n_chains=C) as eng:
+        eng.set_data(y)
+        ms_par = timed(eng)
+    ym = y.copy()
+    ym[np.random.default_rng(0).random((T, C)) < 0.1] = np.nan
+    with rxhip.LGSSMEngine(*args, T=T, n_chains=C, allow_missing=True) as eng:
+        eng.set_data(ym)
+        ms_seq = timed(eng)
+    print(f"d=dy={d} chains={C} T={T}: time-parallel MFMA schedule {ms_par:.2f} ms | sequential schedule, 10 % missing {ms_seq:.2f} ms "
+          f"= {T * C / ms_seq * 1e3:.3g} steps/s", flush=True)

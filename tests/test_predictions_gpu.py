@@ -80,9 +80,13 @@ def test_predictions_call_order_and_unsupported_shapes():
             eng.predictions()
         assert ei.value.status == 7
     big = workloads.random_model(8, 8, seed=1)
-    with pytest.raises(rxhip.RxHipError) as ei:   # `missing` inside the data has no schedule on the MFMA path
-        rxhip.LGSSMEngine(big["A"], big["B"], big["P"], big["Q"], big["m0"], big["V0"], T=20, allow_missing=True)
-    assert ei.value.status == 2
+    # `missing` inside the data at d > 4: the sequential schedule (tests/test_dense_sequential.py); node-local joints stay d ≤ 4
+    with rxhip.LGSSMEngine(big["A"], big["B"], big["P"], big["Q"], big["m0"], big["V0"], T=20, allow_missing=True) as eng:
+        eng.set_data(np.zeros((20, 1, 8)))
+        eng.run()
+        with pytest.raises(rxhip.RxHipError) as ei:
+            eng.node_marginals()
+        assert ei.value.status == 2
 
 
 @pytest.mark.parametrize("C", [64, 70])
