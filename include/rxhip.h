@@ -317,7 +317,8 @@ rxhip_status rxhip_run_filter(rxhip_engine* e, int32_t want_free_energy);
  * propagated only); mean [chains][d], cov [chains][d][d] and free_energy [chains] (−log p(y_k | y_<k); any of the three may be
  * NULL) receive the posterior after this observation.  The belief stays on the device between calls; the first call after
  * creation or rxhip_filter_reset starts from the prior.  Per-step constants (step_model) and known inputs are indexed by the
- * number of observations seen (streams longer than the engine's T + horizon need a time-invariant model).  d, dy ≤ 4. */
+ * number of observations seen (streams longer than the engine's T + horizon need a time-invariant model).  Any d, dy ≤ 64
+ * (one thread per chain at d, dy ≤ 4, one workgroup per chain above). */
 rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, double* cov, double* free_energy);
 rxhip_status rxhip_filter_reset(rxhip_engine* e);
 rxhip_status rxhip_run_filter_async(rxhip_engine* e, int32_t want_free_energy);

@@ -165,21 +165,111 @@ __device__ __forceinline__ bool lds_gj_inverse(double* M, int ld, int n, double*
     return ok;
 }
 
+struct GseqLds {  // the dynamic LDS block of the forward kernels
+    double *X0, *X1, *X2, *X3;   // X0: V_f(t−1) -> V_p(t) -> V_f(t);  X1: A V, then B V_p;  X2: products / S and S⁻¹;  X3: A, B, S⁻¹ B V_p
+    double *m, *mp, *r, *sr;     // filtered mean, predicted mean, innovation, S⁻¹ r
+    double *buf, *yv;            // 2n: pivot row / column;  n: y[t] (known observation offsets already taken out)
+    int ld;
+};
+__device__ __forceinline__ GseqLds gseq_lds(double* sm, int d, int dy) {
+    const int n = d > dy ? d : dy;
+    GseqLds l;
+    l.ld = gseq_ld(d, dy);
+    l.X0 = sm;
+    l.X1 = l.X0 + n * l.ld;
+    l.X2 = l.X1 + n * l.ld;
+    l.X3 = l.X2 + n * l.ld;
+    l.m = l.X3 + n * l.ld;
+    l.mp = l.m + n;
+    l.r = l.mp + n;
+    l.sr = l.r + n;
+    l.buf = l.sr + n;
+    l.yv = l.buf + 2 * n;
+    return l;
+}
+
+// One time index of the forward pass on the belief (l.m, l.X0): `*`_A(:out) -> MvN_x(:out) when `predict` (cx: known input c[t]
+// of this step or null), then the product with the observation branch unless l.yv holds a NaN.  Every thread of the workgroup
+// calls it; starts and ends with the belief consistent across the workgroup (barrier at the end).  *logev -= the step's
+// −log p(y_t | y_<t) on thread 0 when `fe`.  Returns false when S lost positive definiteness.
+__device__ __forceinline__ bool gseq_forward_step(const GseqLds& l, const GenericModel& M, int d, int dy, bool predict, const double* cx,
+                                                  const Map2& md, int* s_obs, bool fe, double* logev, int tid, int nt) {
+    double *X0 = l.X0, *X1 = l.X1, *X2 = l.X2, *X3 = l.X3, *m = l.m, *mp = l.mp, *r = l.r, *sr = l.sr, *yv = l.yv;
+    const int ld = l.ld;
+    bool ok = true;
+    if (predict) {  // A is staged in X3 (free until the observation update): an operand read from global memory costs an L2
+        RXHIP_FOR_2D(md, d, d, i, j) X3[i * ld + j] = M.A[i * d + j];  // round trip per k step
+        __syncthreads();
+        tile_gemm(X1, ld, d, d, d, X3, ld, 1, X0, ld, 1, 1.0, false, tid, nt);       // A V
+        for (int i = tid; i < d; i += nt) {
+            double s = cx ? cx[i] : 0.0;
+            for (int k = 0; k < d; ++k) s += X3[i * ld + k] * m[k];
+            mp[i] = s;
+        }
+        __syncthreads();
+        tile_gemm(X2, ld, d, d, d, X1, ld, 1, X3, 1, ld, 1.0, false, tid, nt);       // (A V) A′
+        __syncthreads();
+        RXHIP_FOR_2D(md, d, d, i, j) X0[i * ld + j] = 0.5 * (X2[i * ld + j] + X2[j * ld + i]) + 0.5 * (M.P[i * d + j] + M.P[j * d + i]);
+    } else
+        for (int i = tid; i < d; i += nt) mp[i] = m[i];
+    RXHIP_FOR_2D(md, dy, d, a, k) X3[a * ld + k] = M.B[a * d + k];   // B, until S⁻¹ B V_p takes the buffer
+    __syncthreads();
+    if (tid == 0) {
+        int obs = 1;
+        for (int k = 0; k < dy; ++k) obs = obs && (yv[k] == yv[k]);
+        *s_obs = obs;
+    }
+    __syncthreads();
+    if (*s_obs) {  // uniform over the workgroup
+        tile_gemm(X1, ld, dy, d, d, X3, ld, 1, X0, ld, 1, 1.0, false, tid, nt);      // B V_p
+        for (int a = tid; a < dy; a += nt) {
+            double s = yv[a];
+            for (int k = 0; k < d; ++k) s -= X3[a * ld + k] * mp[k];
+            r[a] = s;
+        }
+        __syncthreads();
+        tile_gemm(X2, ld, dy, dy, d, X1, ld, 1, X3, 1, ld, 1.0, false, tid, nt);     // (B V_p) B′
+        __syncthreads();
+        sym_add(X2, ld, dy, M.Q, tid, nt);                                            // S
+        __syncthreads();
+        double logdet = 0.0;
+        ok = lds_gj_inverse(X2, ld, dy, l.buf, &logdet, tid, nt);
+        tile_gemm(X3, ld, dy, d, dy, X2, ld, 1, X1, ld, 1, 1.0, false, tid, nt);     // S⁻¹ B V_p
+        for (int a = tid; a < dy; a += nt) {
+            double s = 0.0;
+            for (int k = 0; k < dy; ++k) s += X2[a * ld + k] * r[k];
+            sr[a] = s;
+        }
+        __syncthreads();
+        tile_gemm(X2, ld, d, d, dy, X1, 1, ld, X3, ld, 1, 1.0, false, tid, nt);      // (B V_p)′ S⁻¹ (B V_p)
+        for (int i = tid; i < d; i += nt) {
+            double s = mp[i];
+            for (int a = 0; a < dy; ++a) s += X1[a * ld + i] * sr[a];
+            m[i] = s;
+        }
+        if (fe && tid == 0) {
+            double q = 0.0;
+            for (int a = 0; a < dy; ++a) q += r[a] * sr[a];
+            *logev -= 0.5 * ((double)dy * 1.8378770664093453 + logdet + q);
+        }
+        __syncthreads();
+        RXHIP_FOR_2D(md, d, d, i, j) {
+            if (j > i) continue;
+            const double v = 0.5 * (X0[i * ld + j] + X0[j * ld + i]) - 0.5 * (X2[i * ld + j] + X2[j * ld + i]);
+            X0[i * ld + j] = v;
+            X0[j * ld + i] = v;
+        }
+    } else
+        for (int i = tid; i < d; i += nt) m[i] = mp[i];
+    __syncthreads();
+    return ok;
+}
+
 __global__ void __launch_bounds__(256, 4) k_gseq_forward(GseqParams p) {
     RXHIP_GSEQ_EXTERN_SHARED(sm)
     const int d = p.d, dy = p.dy, tid = threadIdx.x, nt = blockDim.x;
-    const int n = d > dy ? d : dy, ld = gseq_ld(d, dy);
+    const GseqLds l = gseq_lds(sm, d, dy);
     const Map2 md(d, tid, nt);
-    double* X0 = sm;                 // V_f(t−1) -> V_p(t) -> V_f(t)
-    double* X1 = X0 + n * ld;        // A V, then B V_p (dy×d)
-    double* X2 = X1 + n * ld;        // products before symmetrisation; S = B V_p B′ + Q and its inverse
-    double* X3 = X2 + n * ld;        // S⁻¹ B V_p (dy×d)
-    double* m = X3 + n * ld;         // filtered mean
-    double* mp = m + n;              // predicted mean
-    double* r = mp + n;              // innovation y − B m_p
-    double* sr = r + n;              // S⁻¹ r
-    double* buf = sr + n;            // 2n: pivot row / column
-    double* yv = buf + 2 * n;        // n: y[t]
     __shared__ int s_obs;
     const long long c = blockIdx.x;
     bool ok = true;
@@ -187,85 +277,73 @@ __global__ void __launch_bounds__(256, 4) k_gseq_forward(GseqParams p) {
     {
         const size_t idx = gseq_model_index(p, c, 0);
         const double* pr = p.prior + idx * ((size_t)d + (size_t)d * d);
-        for (int i = tid; i < d; i += nt) m[i] = pr[i];
-        RXHIP_FOR_2D(md, d, d, i, j) X0[i * ld + j] = pr[d + i * d + j];
+        for (int i = tid; i < d; i += nt) l.m[i] = pr[i];
+        RXHIP_FOR_2D(md, d, d, i, j) l.X0[i * l.ld + j] = pr[d + i * d + j];
     }
     __syncthreads();
     for (long long t = 0; t < p.T; ++t) {
         const GenericModel M = gseq_model(p, gseq_model_index(p, c, t));
         const long long row = t * p.n_chains + c;
-        for (int a = tid; a < dy; a += nt) yv[a] = p.y[row * dy + a];
-        if (t > 0 || p.ptt) {  // `*`_A(:out) -> MvN_x(:out); A is staged in X3 (free until the observation update): an operand
-            RXHIP_FOR_2D(md, d, d, i, j) X3[i * ld + j] = M.A[i * d + j];  // read from global memory costs an L2 round trip per k step
-            __syncthreads();
-            tile_gemm(X1, ld, d, d, d, X3, ld, 1, X0, ld, 1, 1.0, false, tid, nt);       // A V
-            for (int i = tid; i < d; i += nt) {
-                double s = 0.0;
-                for (int k = 0; k < d; ++k) s += X3[i * ld + k] * m[k];
-                mp[i] = s;
-            }
-            __syncthreads();
-            tile_gemm(X2, ld, d, d, d, X1, ld, 1, X3, 1, ld, 1.0, false, tid, nt);       // (A V) A′
-            __syncthreads();
-            RXHIP_FOR_2D(md, d, d, i, j) X0[i * ld + j] = 0.5 * (X2[i * ld + j] + X2[j * ld + i]) + 0.5 * (M.P[i * d + j] + M.P[j * d + i]);
-        } else
-            for (int i = tid; i < d; i += nt) mp[i] = m[i];
-        RXHIP_FOR_2D(md, dy, d, a, k) X3[a * ld + k] = M.B[a * d + k];   // B, until S⁻¹ B V_p takes the buffer
-        __syncthreads();
-        if (tid == 0) {
-            int obs = 1;
-            for (int k = 0; k < dy; ++k) obs = obs && (yv[k] == yv[k]);
-            s_obs = obs;
-        }
-        __syncthreads();
-        if (s_obs) {  // uniform over the workgroup
-            tile_gemm(X1, ld, dy, d, d, X3, ld, 1, X0, ld, 1, 1.0, false, tid, nt);      // B V_p
-            for (int a = tid; a < dy; a += nt) {
-                double s = yv[a];
-                for (int k = 0; k < d; ++k) s -= X3[a * ld + k] * mp[k];
-                r[a] = s;
-            }
-            __syncthreads();
-            tile_gemm(X2, ld, dy, dy, d, X1, ld, 1, X3, 1, ld, 1.0, false, tid, nt);     // (B V_p) B′
-            __syncthreads();
-            sym_add(X2, ld, dy, M.Q, tid, nt);                                            // S
-            __syncthreads();
-            double logdet = 0.0;
-            ok = lds_gj_inverse(X2, ld, dy, buf, &logdet, tid, nt) && ok;
-            tile_gemm(X3, ld, dy, d, dy, X2, ld, 1, X1, ld, 1, 1.0, false, tid, nt);     // S⁻¹ B V_p
-            for (int a = tid; a < dy; a += nt) {
-                double s = 0.0;
-                for (int k = 0; k < dy; ++k) s += X2[a * ld + k] * r[k];
-                sr[a] = s;
-            }
-            __syncthreads();
-            tile_gemm(X2, ld, d, d, dy, X1, 1, ld, X3, ld, 1, 1.0, false, tid, nt);      // (B V_p)′ S⁻¹ (B V_p)
-            for (int i = tid; i < d; i += nt) {
-                double s = mp[i];
-                for (int a = 0; a < dy; ++a) s += X1[a * ld + i] * sr[a];
-                m[i] = s;
-            }
-            if (p.fe && tid == 0) {
-                double q = 0.0;
-                for (int a = 0; a < dy; ++a) q += r[a] * sr[a];
-                logev -= 0.5 * ((double)dy * 1.8378770664093453 + logdet + q);
-            }
-            __syncthreads();
-            RXHIP_FOR_2D(md, d, d, i, j) {
-                if (j > i) continue;
-                const double v = 0.5 * (X0[i * ld + j] + X0[j * ld + i]) - 0.5 * (X2[i * ld + j] + X2[j * ld + i]);
-                X0[i * ld + j] = v;
-                X0[j * ld + i] = v;
-            }
-        } else
-            for (int i = tid; i < d; i += nt) m[i] = mp[i];
-        __syncthreads();
-        for (int i = tid; i < d; i += nt) p.mean[row * d + i] = m[i];
-        RXHIP_FOR_2D(md, d, d, i, j) p.cov[row * d * d + i * d + j] = X0[i * ld + j];
+        for (int a = tid; a < dy; a += nt) l.yv[a] = p.y[row * dy + a];
+        ok = gseq_forward_step(l, M, d, dy, t > 0 || p.ptt, nullptr, md, &s_obs, p.fe != 0, &logev, tid, nt) && ok;
+        for (int i = tid; i < d; i += nt) p.mean[row * d + i] = l.m[i];
+        RXHIP_FOR_2D(md, d, d, i, j) p.cov[row * d * d + i * d + j] = l.X0[i * l.ld + j];
         __syncthreads();
     }
     if (tid == 0) {
         if (p.fe) p.fe_part[c] = logev;
+        if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+    }
+}
+
+// The streaming driver one observation at a time at any d, dy ≤ 64 (rxhip_filter_step; src/inference/streaming.jl:349-407):
+// the belief of every chain stays in `state`, one call pushes one observation through the one-step graph.
+struct GseqStreamParams {
+    long long n_chains, k;   // k: number of observations seen so far (indexes step_model and the known inputs)
+    int d, dy, ptt, first;   // first: the belief is the prior (through its transition when ptt)
+    const double* y;         // [chain][dy]
+    double* state;           // [chain][d + d²]  belief q(x) after the last step
+    const double* user;
+    const double* prior;
+    const int* chain_model;
+    const int* step_model;
+    const double *cx, *cy;   // null, or known inputs [·][d], [·][dy] of observation k ([·][chain][·] when off_chain)
+    int off_chain;
+    double* mean;            // [chain][d]
+    double* cov;             // [chain][d][d]
+    double* fe;              // [chain]  −log p(y_k | y_<k)
+    int* status;
+};
+__global__ void __launch_bounds__(256, 4) k_gseq_stream_step(GseqStreamParams p) {
+    RXHIP_GSEQ_EXTERN_SHARED(sm)
+    const int d = p.d, dy = p.dy, tid = threadIdx.x, nt = blockDim.x;
+    const GseqLds l = gseq_lds(sm, d, dy);
+    const Map2 md(d, tid, nt);
+    __shared__ int s_obs;
+    const long long c = blockIdx.x;
+    const size_t idx = p.step_model ? (size_t)p.step_model[p.k] : p.chain_model ? (size_t)p.chain_model[c] : 0;
+    GseqParams q{};
+    q.d = d; q.dy = dy; q.user = p.user;
+    const GenericModel M = gseq_model(q, idx);
+    double* st = p.state + c * ((size_t)d + (size_t)d * d);
+    const double* src = p.first ? p.prior + idx * ((size_t)d + (size_t)d * d) : st;
+    for (int i = tid; i < d; i += nt) l.m[i] = src[i];
+    RXHIP_FOR_2D(md, d, d, i, j) l.X0[i * l.ld + j] = src[d + i * d + j];
+    const long long orow = p.k * (p.off_chain ? p.n_chains : 1) + (p.off_chain ? c : 0);
+    for (int a = tid; a < dy; a += nt) l.yv[a] = p.y[c * dy + a] - (p.cy ? p.cy[orow * dy + a] : 0.0);
+    __syncthreads();
+    double logev = 0.0;
+    const bool ok = gseq_forward_step(l, M, d, dy, !p.first || p.ptt, p.cx ? p.cx + orow * d : nullptr, md, &s_obs, true, &logev, tid, nt);
+    for (int i = tid; i < d; i += nt) {
+        st[i] = l.m[i];
+        p.mean[c * d + i] = l.m[i];
+    }
+    RXHIP_FOR_2D(md, d, d, i, j) {
+        st[d + i * d + j] = l.X0[i * l.ld + j];
+        p.cov[(c * d + i) * d + j] = l.X0[i * l.ld + j];
+    }
+    if (tid == 0) {
+        if (p.fe) p.fe[c] = -logev;
         if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
     }
 }

@@ -1762,6 +1762,15 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->Llast = steps - (long long)(e->S - 1) * L;
     }
 
+    std::vector<double> prior;  // dense engines: [n_models][m0 | V0] at user level (sequential schedule, rxhip_filter_step)
+    if (dense) {
+        const size_t Du = (size_t)e->d, np = Du + Du * Du;
+        prior.resize((size_t)e->n_models * np);
+        for (int m = 0; m < e->n_models; ++m) {
+            std::memcpy(&prior[(size_t)m * np], ds->m0 + (size_t)m * Du, sizeof(double) * Du);
+            std::memcpy(&prior[(size_t)m * np + Du], ds->V0 + (size_t)m * Du * Du, sizeof(double) * Du * Du);
+        }
+    }
     if (e->gseq) {  // no tables: the user-level constants, the priors, the outputs
         e->S = 0; e->L = 1; e->Llast = 1;
         static std::once_flag lds_once;
@@ -1770,12 +1779,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             (void)hipFuncSetAttribute((const void*)k_gseq_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         });
         (void)hipGetLastError();
-        const size_t CU = (size_t)e->n_chains, Du = (size_t)e->d, np = Du + Du * Du;
-        std::vector<double> prior((size_t)e->n_models * np);
-        for (int m = 0; m < e->n_models; ++m) {
-            std::memcpy(&prior[(size_t)m * np], ds->m0 + (size_t)m * Du, sizeof(double) * Du);
-            std::memcpy(&prior[(size_t)m * np + Du], ds->V0 + (size_t)m * Du * Du, sizeof(double) * Du * Du);
-        }
+        const size_t CU = (size_t)e->n_chains, Du = (size_t)e->d;
         ArenaPlan ap;
         ap.upload(&e->d_user, e->h_user.data(), sizeof(double) * e->h_user.size());
         ap.upload(&e->d_prior, prior.data(), sizeof(double) * prior.size());
@@ -1928,6 +1932,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_filt, sizeof(double) * C * T * dense_rec(e->nt));
         ap.plain(&e->d_vend, sizeof(double) * C * Sg * dense_tri(e->nt));
         ap.upload(&e->d_user, e->h_user.data(), sizeof(double) * e->h_user.size());
+        ap.upload(&e->d_prior, prior.data(), sizeof(double) * prior.size());
         if (!e->h_mu.empty()) {
             ap.upload(&e->d_mu, e->h_mu.data(), sizeof(double) * e->h_mu.size());
             ap.upload(&e->d_nu, e->h_nu.data(), sizeof(double) * e->h_nu.size());
@@ -2766,11 +2771,11 @@ rxhip_status rxhip_filter_reset(rxhip_engine* e) {
 rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, double* cov, double* free_energy) {
     if (!e || !y) return RXHIP_ERR_BADARG;
     if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "filter_step: not a state-space engine");
-    if (e->dense || !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "filter_step has a device schedule for d, dy ≤ 4 only");
+    if (!e->dense && !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "filter_step: no device schedule for this shape");
     if ((e->d_step_model || e->d_cx) && e->stream_k >= e->Tout())
         return fail(e, RXHIP_ERR_STATE, "filter_step: the per-step constants / known inputs of this engine end after %lld observations", (long long)e->Tout());
     SET_DEVICE(e);
-    const size_t C = (size_t)e->n_chains, d = (size_t)e->d, dy = (size_t)e->dy, ns = d * (d + 1) / 2;
+    const size_t C = (size_t)e->n_chains, d = (size_t)e->d, dy = (size_t)e->dy, ns = e->dense ? d * d : d * (d + 1) / 2;
     const size_t o_y = C * (d + ns), o_m = o_y + C * dy, o_c = o_m + C * d, o_f = o_c + C * d * d, total = o_f + C;
     if (!e->d_stream) {
         HIPCHK(e, hipMalloc(&e->d_stream, sizeof(double) * total));
@@ -2784,7 +2789,17 @@ rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, d
     sp.y = e->d_stream + o_y; sp.state = e->d_stream; sp.cst = e->d_cst; sp.chain_model = e->d_chain_model;
     sp.step_model = e->d_step_model; sp.cx = e->d_cx; sp.cy = e->d_mu ? e->d_cy_raw : nullptr; sp.off_chain = e->off_chain ? 1 : 0;
     sp.mean = e->d_stream + o_m; sp.cov = e->d_stream + o_c; sp.fe = e->d_stream + o_f; sp.status = e->d_status;
-    e->vt->stream_step(sp, e->stream);
+    if (e->dense) {  // any d, dy ≤ 64: one workgroup per chain on the user-level constants (gseq_kernels.hpp)
+        static std::once_flag lds_once;
+        std::call_once(lds_once, [] { (void)hipFuncSetAttribute((const void*)k_gseq_stream_step, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
+        (void)hipGetLastError();
+        GseqStreamParams gs{};
+        gs.n_chains = sp.n_chains; gs.k = sp.k; gs.d = e->d; gs.dy = e->dy; gs.ptt = sp.ptt; gs.first = sp.first; gs.y = sp.y; gs.state = sp.state;
+        gs.user = e->d_user; gs.prior = e->d_prior; gs.chain_model = sp.chain_model; gs.step_model = sp.step_model; gs.cx = sp.cx; gs.cy = sp.cy;
+        gs.off_chain = sp.off_chain; gs.mean = sp.mean; gs.cov = sp.cov; gs.fe = sp.fe; gs.status = sp.status;
+        hipLaunchKernelGGL(k_gseq_stream_step, dim3((unsigned)e->n_chains), dim3(256), gseq_lds_bytes(e->d, e->dy), e->stream, gs);
+    } else
+        e->vt->stream_step(sp, e->stream);
     HIPCHK(e, hipGetLastError());
     const size_t n_out = (cov || free_energy) ? total - o_m : C * d;  // mean | cov | fe are contiguous
     if (mean || cov || free_energy)

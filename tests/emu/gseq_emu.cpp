@@ -49,3 +49,26 @@ extern "C" int gseq_emu_run(long long T, long long n_chains, int d, int dy, int 
     (void)n_models;
     return status;
 }
+
+// rxhip_filter_step on the host: T calls of k_gseq_stream_step; y [T][chain][dy], outputs [T][chain][·]
+extern "C" int gseq_emu_stream(long long T, long long n_chains, int d, int dy, int ptt, const double* user, const double* prior,
+                               const int* chain_model, const int* step_model, const double* cx, const double* cy, const double* y,
+                               double* mean, double* cov, double* fe) {
+    using namespace rxhip;
+    std::vector<double> state((size_t)n_chains * ((size_t)d + (size_t)d * d));
+    std::vector<double> lds(gseq_lds_bytes(d, dy) / sizeof(double));
+    sm = lds.data();
+    int status = 0;
+    for (long long k = 0; k < T; ++k) {
+        GseqStreamParams p{};
+        p.n_chains = n_chains; p.k = k; p.d = d; p.dy = dy; p.ptt = ptt; p.first = k == 0; p.y = y + (size_t)k * n_chains * dy;
+        p.state = state.data(); p.user = user; p.prior = prior; p.chain_model = chain_model; p.step_model = step_model; p.cx = cx; p.cy = cy;
+        p.off_chain = 0; p.mean = mean + (size_t)k * n_chains * d; p.cov = cov + (size_t)k * n_chains * d * d; p.fe = fe + (size_t)k * n_chains;
+        p.status = &status;
+        for (long long c = 0; c < n_chains; ++c) {
+            blockIdx.x = (unsigned)c;
+            k_gseq_stream_step(p);
+        }
+    }
+    return status;
+}

@@ -111,6 +111,34 @@ def test_kernel_source_on_the_host_with_one_model_per_chain(emu):
         assert nll[c] == pytest.approx(onll, rel=1e-11)
 
 
+def test_stream_step_source_on_the_host_matches_the_filtering_oracle(emu):
+    """k_gseq_stream_step (rxhip_filter_step at d > 4) one observation at a time, with per-step constants, known inputs and
+    missing observations, against the oracle's smoother of the observations seen so far (its last belief is the filtered one)."""
+    rng = np.random.default_rng(19)
+    d, dy, T, C, M = 6, 3, 12, 2, 4
+    mdl = _models(rng, d, dy, M)
+    sm = (rng.permutation(T) % M).astype(np.int32)
+    cx, cy = rng.standard_normal((T, d)), rng.standard_normal((T, dy))
+    y = _punch(rng, _simulate(rng, mdl, sm, C, True) + cy[None])
+    A, B, P, Q, m0, V0 = (np.ascontiguousarray(x, dtype=np.float64) for x in mdl)
+    user = np.concatenate([np.concatenate([A[m].ravel(), P[m].ravel(), B[m].ravel(), Q[m].ravel(), np.linalg.inv(Q[m]).ravel()]) for m in range(M)])
+    prior = np.concatenate([np.concatenate([m0[m].ravel(), V0[m].ravel()]) for m in range(M)])
+    yt = np.ascontiguousarray(np.transpose(y, (1, 0, 2)))
+    mean, cov, fe = np.empty((T, C, d)), np.empty((T, C, d, d)), np.empty((T, C))
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    st = emu.gseq_emu_stream(ctypes.c_longlong(T), ctypes.c_longlong(C), d, dy, 1, dp(user), dp(prior), None,
+                             sm.ctypes.data_as(ctypes.POINTER(ctypes.c_int)), dp(cx), dp(cy), dp(yt), dp(mean), dp(cov), dp(fe))
+    assert st == 0
+    for c in range(C):
+        prev = 0.0
+        for t in range(T):
+            qm, qc, nll = rxo.lgssm_kalman_rts_affine(*mdl, y[c, :t + 1], state_offset=cx[:t + 1], obs_offset=cy[:t + 1], step_model=sm[:t + 1],
+                                                      prior_through_transition=True)
+            assert np.allclose(mean[t, c], qm[-1], rtol=1e-9, atol=1e-11) and np.allclose(cov[t, c], qc[-1], rtol=1e-9, atol=1e-11)
+            assert fe[t, c] == pytest.approx(nll - prev, rel=1e-9, abs=1e-11)
+            prev = nll
+
+
 # ---------------------------------------------------------------------------------------------------------------- device
 @pytest.mark.gpu
 @pytest.mark.parametrize("d,dy,ptt,C", [(5, 3, False, 3), (8, 8, True, 20), (16, 4, False, 5), (33, 7, True, 2), (64, 64, False, 2), (6, 40, True, 3)])
@@ -228,3 +256,32 @@ def test_infer_mirror_routes_interior_missing_values_at_d_10():
     om, oc, nll = rxo.lgssm_kalman_rts(*one, y)
     assert np.allclose(res.posteriors["x"].mean, om, rtol=1e-6, atol=1e-9) and np.allclose(res.posteriors["x"].cov, oc, rtol=1e-6, atol=1e-9)
     assert res.free_energy[-1] == pytest.approx(nll, rel=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,dy,C,masked", [(6, 3, 4, False), (16, 16, 3, True), (64, 8, 2, False)])
+def test_filter_step_at_any_dimension(d, dy, C, masked):
+    """rxhip_filter_step on the MFMA-path engines (time-parallel or sequential schedule): one observation at a time ≡ the
+    filtering run of the whole series ≡ the oracle."""
+    import rxhip
+    rng = np.random.default_rng(d + dy)
+    T = 15
+    mdl = _models(rng, d, dy, 1)
+    one = tuple(x[0] for x in mdl)
+    y = _simulate(rng, mdl, np.zeros(T, dtype=np.int32), C, True)
+    if masked:
+        y = _punch(rng, y)
+    with rxhip.LGSSMEngine(*one, T=T, n_chains=C, prior_through_transition=True, allow_missing=masked) as eng:
+        eng.set_data(y, layout="chain_time")
+        eng.run_filter(free_energy=False)
+        fm, fc = eng.marginals(layout="chain_time")
+        for rep in range(2):
+            eng.filter_reset()
+            nll = np.zeros(C)
+            for t in range(T):
+                m, v, f = eng.filter_step(y[:, t])
+                assert np.allclose(m, fm[:, t], rtol=1e-8, atol=1e-10) and np.allclose(v, fc[:, t], rtol=1e-8, atol=1e-10)
+                nll += f
+    for c in range(C):
+        _, _, onll = rxo.lgssm_kalman_rts(*one, y[c], prior_through_transition=True)
+        assert nll[c] == pytest.approx(onll, rel=1e-8)
