@@ -192,12 +192,3 @@ def test_masked_filtering_skips_the_update():
                 m, V = m + K @ (y[c, t] - B @ m), V - K @ B @ V
             assert np.allclose(mean[c, t], m, rtol=1e-6, atol=1e-9)
             assert np.allclose(cov[c, t], V, rtol=1e-6, atol=1e-9)
-
-
-@pytest.mark.gpu
-def test_masked_schedule_is_refused_on_the_mfma_path():
-    import rxhip
-    rng = np.random.default_rng(1)
-    A, B, P, Q, m0, V0 = _model(rng, 6, 2)
-    with pytest.raises(Exception, match="missing"):
-        rxhip.LGSSMEngine(A, B, P, Q, m0, V0, T=10, n_chains=2, allow_missing=True)
