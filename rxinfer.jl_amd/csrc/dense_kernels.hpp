@@ -416,7 +416,7 @@ struct Sweep4 {
         //   X[i][v] = −(R'D4⁻¹)[i][v] + [i = K_u]·D4⁻¹[u][v]      (16 rows of this wave × 4)
         //   Y[v][j] = R[v][j] − [j = K_v]                           (4 × 16 columns of tile t)
         // which yields  A_JJ − R_J'D4⁻¹R_J,  A_KJ = D4⁻¹R_J,  A_JK = (D4⁻¹R_J)'  and  A_KK = 2I − D4⁻¹  (the 2I is removed
-        // below): −D4⁻¹ on the pivot block, as the sweep operator requires.  The Y operands are plain LDS values that do
+        // once, at the end of gj_inverse): −D4⁻¹ on the pivot block, as the sweep operator requires.  The Y operands are plain LDS values that do
         // not wait for D4⁻¹; a thread applies D4⁻¹ to ONE column of R (its row's X entry: four FMAs) instead of one per tile.
         double yb[NT];
 #pragma unroll
@@ -461,14 +461,6 @@ struct Sweep4 {
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb[t] - ((ycol && t == pb) ? 1.0 : 0.0), acc, 0, 0, 0);
             a.v[t][0] = acc[0]; a.v[t][1] = acc[1]; a.v[t][2] = acc[2]; a.v[t][3] = acc[3];
         }
-        // pivot-block diagonal (K_r, K_r): this thread's element (row vl + 4r of wave pb, column jl of tile pb) with
-        // vl = Q and jl = Q + 4r
-        if (rowown && pcol) {  // four lanes of one wave; every other wave branches over this
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) a.v[t][r] -= (t == pb && c == r) ? 2.0 : 0.0;
-        }
         Sweep4<NT, Q + 1>::run(a, rowbuf, pb, w, lane, ok, lp);
     }
 };
@@ -481,10 +473,14 @@ __device__ __forceinline__ bool gj_inverse(Acc<NT>& a, double* rowbuf, double* /
     bool ok = true;
 #pragma unroll 1
     for (int pb = 0; pb < NT; ++pb) Sweep4<NT, 0>::run(a, rowbuf, pb, w, lane, ok, lp);
+    // The 2I of the pivot blocks (see Sweep4) comes off here, once: a pivot block's diagonal is never read again after its own
+    // round (later rounds publish OTHER rows and only add to it), so the correction commutes with every later update — inside
+    // the round it sat in the owner wave's publish path, behind the matrix pipe's result latency (11.3 instead of 16.7 µs per
+    // 64×64 inverse, scripts/dense_micro.hip).  Diagonal element of this lane: tile t = w, register r with (lane & 15) = (lane >> 4) + 4r.
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) a.v[t][r] = -a.v[t][r];
+        for (int r = 0; r < 4; ++r) a.v[t][r] = ((t == w && (lane & 15) == (lane >> 4) + 4 * r) ? 2.0 : 0.0) - a.v[t][r];
     lds_barrier();
     return ok;
 }
