@@ -108,6 +108,7 @@ struct DenseParams {
     // several models in one engine (chain c runs model chain_model[c]): per-model table pointers; NULL = the single model above
     const struct DenseModel* models;
     const int* chain_model;
+    double* vlast;        // null, or [d][d]: V_s(T−1) of this run (the model pass of dense_split_kernels.hpp keeps it)
 };
 struct DenseModel {
     const double *cst, *tab, *scanm, *qtab;
@@ -1313,6 +1314,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
             acc_load<NT>(a, MV, LD, w, lane);
             lds_barrier();  // every wave has its rows in registers before MV is overwritten below
             ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpe) && ok;
+            if (p.vlast && chain == 0) acc_store<NT>(a, p.vlast, D, w, lane);
         } else
             acc_load<NT>(a, M.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);
         acc_store<NT>(a, MV, LD, w, lane);

@@ -1,0 +1,166 @@
+// dense_split_kernels.hpp — batches that SHARE one model on the MFMA path (4 < d ≤ 64): model pass once, data pass per sweep.
+//
+// In the information-form smoother of dense_kernels.hpp everything that is a matrix — C_t = (Λ_f(t) + A′P⁻¹A)⁻¹, the smoother
+// gain G_t = C_t (P⁻¹A)′, the posterior covariance V_s(t), the log-determinants of the free energy — depends on the model and
+// the time index only.  A batch of chains with one model used to recompute all of it in every chain's workgroup (one d×d
+// inverse and four d×d×d contractions per step and chain).  Here kd_forward_info / kd_backward_info run ONCE per engine on a
+// single chain (the model pass: their records are turned into plain row-major tables by kd_split_tables), and a sweep is
+//     ξ_f(t) = B′Q⁻¹y_t + G′_{t−1} ξ_f(t−1),      c_t = C_t ξ_f(t)                    (kd_split_forward)
+//     m_s(t) = c_t + G_t m_s(t+1)                                                      (kd_split_backward)
+// per chain — three matrix–vector products per step against tables every chain of the batch reads from L2 — plus a broadcast
+// of V_s(t) into the posterior arrays and the residual quadratic forms of the free energy (kd_fe_resid, unchanged).  The
+// segment boundaries (start belief, backward message at the segment end) come from the same aggregation and scan kernels as
+// before: they were vector-only already.  Same idea as lgssm_kernels.hpp's one-pass schedule for d ≤ 4.
+//
+// One wavefront serves 64 / D (chain, segment) units: lane i of a unit owns component i of every vector; a matrix–vector
+// product reads the matrix TRANSPOSED row by row (consecutive lanes, consecutive addresses; the units of a wavefront belong to
+// the same segment and read the same rows) and gets x[k] by a cross-lane read.
+#pragma once
+#include "dense_kernels.hpp"
+
+namespace rxhip {
+
+struct SplitTab {  // per time index: three D×D row-major matrices
+    // CT: C_t (symmetric);  AT: (G_t′)′ = G_t, i.e. [k][i] = G′[i][k] — the operand of  out_i = Σ_k G′[i][k] x_k;
+    // A: G_t′ itself, [k][i] = G′[k][i] — the operand of  out_i = Σ_k G[i][k] x_k
+    __host__ __device__ static size_t size(int D) { return 3 * (size_t)D * D; }
+};
+struct SplitParams {
+    DenseParams p;         // as the sweep's (n_chains = workgroup chains: a chain, or a packed pair)
+    int D;                 // kernel dimension 16·NT
+    int rec;               // doubles per record (DenseCfg<NT>::REC)
+    double* dtab;          // [T][3][D][D]
+    double* vlast;         // [D][D]  V_s(T−1) of the model pass (row-major)
+    double* vstab;         // [T][d_out][d_out]  posterior covariance of a (user) chain
+    double* fe_const;      // [2S]  data-independent free-energy slots of one user chain
+};
+
+// records of workgroup chain 0 (accumulator order) -> row-major tables; one workgroup per time index
+__global__ void __launch_bounds__(256) kd_split_tables(SplitParams q) {
+    const int D = q.D, NT = D / 16, tid = threadIdx.x;
+    const long long t = blockIdx.x;
+    const double* rec = q.p.filt + t * q.rec + 3 * D;   // chain 0: C_t | G_t′, both in accumulator order
+    double* tab = q.dtab + (size_t)t * SplitTab::size(D);
+    for (int e = tid; e < D * D; e += blockDim.x) {
+        // accumulator order: index ((w·NT + tile)·4 + r)·64 + lane  <->  (row 16w + (lane >> 4) + 4r, col 16·tile + (lane & 15))
+        const int lane = e & 63, r = (e >> 6) & 3, wt = e >> 8, w = wt / NT, tile = wt - w * NT;
+        const int row = 16 * w + (lane >> 4) + 4 * r, col = 16 * tile + (lane & 15);
+        const double c = rec[e], a = rec[D * D + e];
+        tab[row * D + col] = c;
+        tab[D * D + col * D + row] = a;       // AT[k = col][i = row] = G′[row][col]
+        tab[2 * D * D + row * D + col] = a;   // A[k = row][i = col]  = G′[row][col]
+    }
+}
+
+// after the model pass: the posterior covariances and the constant free-energy slots of user chain 0
+__global__ void __launch_bounds__(256) kd_split_save(SplitParams q, long long user_chains) {
+    const long long dd = (long long)q.p.d_out * q.p.d_out, total = q.p.T * dd;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long t = e / dd, k = e - t * dd;
+        q.vstab[e] = q.p.cov[(t * user_chains) * dd + k];
+    }
+    if (blockIdx.x == 0)
+        for (int s = threadIdx.x; s < 2 * q.p.S; s += blockDim.x) q.fe_const[s] = q.p.fe_part[(long long)s * user_chains];
+}
+
+// every sweep: V_s(t) into the posterior array of every chain, the constant free-energy slots into every chain's column
+__global__ void __launch_bounds__(256) kd_split_broadcast(SplitParams q, long long user_chains, int want_fe) {
+    const long long dd = (long long)q.p.d_out * q.p.d_out, row = user_chains * dd, total = q.p.T * row;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
+        const long long t = e / row, k = (e - t * row) % dd;
+        q.p.cov[e] = q.vstab[t * dd + k];
+    }
+    if (want_fe) {
+        const long long n = 2LL * q.p.S * user_chains;
+        for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x)
+            q.p.fe_part[e] = q.fe_const[e / user_chains];
+    }
+}
+
+// out_i = Σ_k Mt[k·D + i] · x_k  for the unit of this lane (x_k lives in lane base + k)
+__device__ __forceinline__ double split_matvec(const double* __restrict__ Mt, int D, int i, int base, double x) {
+    double s0 = 0.0, s1 = 0.0;
+    for (int k = 0; k < D; k += 2) {
+        s0 += Mt[k * D + i] * __shfl(x, base + k);
+        s1 += Mt[(k + 1) * D + i] * __shfl(x, base + k + 1);
+    }
+    return s0 + s1;
+}
+
+struct SplitUnit {
+    long long seg, chain;
+    int i, base;
+    bool live;
+};
+__device__ __forceinline__ SplitUnit split_unit(const SplitParams& q) {
+    const int D = q.D, gpw = 64 / D, lane = threadIdx.x;
+    SplitUnit u;
+    const int g = lane / D;
+    u.i = lane - g * D;
+    u.base = g * D;
+    const long long unit = (long long)blockIdx.x * gpw + (g < gpw ? g : 0);
+    u.seg = unit / q.p.n_chains;        // the units of a wavefront share the segment: they read the same table rows
+    u.chain = unit - u.seg * q.p.n_chains;
+    u.live = g < gpw && u.seg < q.p.S;
+    if (!u.live) { u.seg = 0; u.chain = 0; }  // idle lanes follow unit 0 (uniform control flow, no stores)
+    return u;
+}
+
+__global__ void __launch_bounds__(64) kd_split_forward(SplitParams q) {
+    const DenseParams& p = q.p;
+    const int D = q.D;
+    const SplitUnit u = split_unit(q);
+    const int i = u.i;
+    const size_t DD = (size_t)D * D;
+    const long long b0 = 1 + u.seg * p.L;
+    long long b1 = b0 + p.L;
+    if (b1 > p.T) b1 = p.T;
+    const long long len = b1 - b0, t0 = u.seg * p.L + 1;
+    double* filt = p.filt + u.chain * p.T * q.rec;
+    // belief at the segment start in information form: ξ_f = Λ_f(b_s) m(b_s)
+    double xi = split_matvec(p.bnd + ((size_t)u.seg * 2 + 0) * DD, D, i, u.base, p.fstart_m[(u.chain * p.S + u.seg) * D + i]);
+    double gyn = len > 0 ? filt[t0 * q.rec + D + i] : 0.0;
+    for (long long s = 0; s < len; ++s) {
+        const long long t = t0 + s;
+        double* rec = filt + (t - 1) * q.rec;
+        const double* tab = q.dtab + (size_t)(t - 1) * SplitTab::size(D);
+        const double gyc = gyn;
+        gyn = filt[(s + 1 < len ? t + 1 : t) * q.rec + D + i];
+        const double cxi = split_matvec(tab, D, i, u.base, xi);            // C_{t−1} ξ_f(t−1)
+        const double axi = split_matvec(tab + DD, D, i, u.base, xi);       // G′_{t−1} ξ_f(t−1)
+        if (u.live) {
+            rec[i] = xi;
+            rec[2 * D + i] = cxi;
+        }
+        xi = gyc + axi;                                                    // ξ_f(t)
+    }
+    if (u.live && u.seg == p.S - 1) filt[(t0 + len - 1) * q.rec + i] = xi;  // ξ_f(T−1): no successor writes it
+}
+
+__global__ void __launch_bounds__(64) kd_split_backward(SplitParams q) {
+    const DenseParams& p = q.p;
+    const int D = q.D;
+    const SplitUnit u = split_unit(q);
+    const int i = u.i;
+    const size_t DD = (size_t)D * D;
+    const long long b0 = 1 + u.seg * p.L;
+    long long b1 = b0 + p.L;
+    if (b1 > p.T) b1 = p.T;
+    const long long len = b1 - b0, tb = u.seg * p.L, te = tb + len;
+    const double* filt = p.filt + u.chain * p.T * q.rec;
+    // smoothed mean at the end boundary: m_s = V_s (ξ_f + ξβ); V_s of an inner boundary from the table, of the last index from
+    // the model pass
+    const double xf = filt[te * q.rec + i] + p.beta_xi[(u.chain * (p.S + 1) + u.seg + 1) * D + i];
+    const bool last = u.seg == p.S - 1;
+    double ms = split_matvec(last ? q.vlast : p.bnd + ((size_t)u.seg * 2 + 1) * DD, D, i, u.base, xf);
+    if (u.live && last) dense_store_mean(p, te, u.chain, i, ms);
+    double cxn = len > 0 ? filt[(te - 1) * q.rec + 2 * D + i] : 0.0;
+    for (long long t = te - 1; t >= tb; --t) {
+        const double cx = cxn;
+        cxn = filt[(t - 1 >= tb ? t - 1 : tb) * q.rec + 2 * D + i];
+        ms = cx + split_matvec(q.dtab + (size_t)t * SplitTab::size(D) + 2 * DD, D, i, u.base, ms);   // C_t ξ_f(t) + G_t m_s(t+1)
+        if (u.live) dense_store_mean(p, t, u.chain, i, ms);
+    }
+}
+
+}  // namespace rxhip

@@ -20,6 +20,7 @@
 #include "lgssm_kernels.hpp"
 #include "dense_kernels.hpp"
 #include "gseq_kernels.hpp"
+#include "dense_split_kernels.hpp"
 #include "gmm_kernels.hpp"
 #include "hgf_kernels.hpp"
 #include "mvgmm_kernels.hpp"
@@ -353,6 +354,9 @@ struct rxhip_engine {
     std::vector<double> h_user;  // MFMA path: user-level A | P | B | Q | Q⁻¹ of every model (generic_kernels.hpp)
     double* d_user = nullptr;
     int* d_step_model = nullptr;
+    // MFMA path, a batch that shares one model: matrices once per engine, vectors per sweep (dense_split_kernels.hpp)
+    bool split = false, split_ready = false;
+    double *d_dtab = nullptr, *d_vlast = nullptr, *d_vstab = nullptr, *d_fe_const = nullptr;
     bool gseq = false;        // d > 4 with `missing` observations or per-step constants: sequential schedule (gseq_kernels.hpp)
     double* d_prior = nullptr;  // gseq: [n_models][m0 | V0]
     bool masked = false;      // NaN observations are `missing` (rxhip_lgssm_desc.allow_missing): per-chain records, one segment
@@ -1029,14 +1033,14 @@ struct DenseLaunch {
         else hipLaunchKernelGGL((kd_forward<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
     }
     // information-form smoother (one inverse per step; free energy at the smoothed means)
-    static void forward_info(const DenseParams& p, bool fe, hipStream_t s) {
-        dim3 g(p.S, (unsigned)p.n_chains);
+    static void forward_info(const DenseParams& p, bool fe, hipStream_t s, long long chains = -1) {
+        dim3 g(p.S, (unsigned)(chains < 0 ? p.n_chains : chains));
         const size_t lds = DenseLds<NT>::fwd_info_bytes(((p.d > p.dy ? p.d : p.dy) + 1) & ~1);
         if (fe) hipLaunchKernelGGL((kd_forward_info<NT, true>), g, dim3(64 * NT), lds, s, p);
         else hipLaunchKernelGGL((kd_forward_info<NT, false>), g, dim3(64 * NT), lds, s, p);
     }
-    static void backward_info(const DenseParams& p, bool fe, hipStream_t s) {
-        dim3 g(p.S, (unsigned)p.n_chains);
+    static void backward_info(const DenseParams& p, bool fe, hipStream_t s, long long chains = -1) {
+        dim3 g(p.S, (unsigned)(chains < 0 ? p.n_chains : chains));
         const size_t lds = DenseLds<NT>::bwd_info_bytes(((p.d > p.dy ? p.d : p.dy) + 1) & ~1);
         if (fe) hipLaunchKernelGGL((kd_backward_info<NT, true>), g, dim3(64 * NT), lds, s, p);
         else hipLaunchKernelGGL((kd_backward_info<NT, false>), g, dim3(64 * NT), lds, s, p);
@@ -1945,6 +1949,18 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_fstart_m, sizeof(double) * C * Sg * D);
         ap.plain(&e->d_beta_xi, sizeof(double) * C * (Sg + 1) * D);
         ap.plain(&e->d_fe_chain, sizeof(double) * CU);
+        // One model for at least four workgroups' worth of chains: the matrices of the information-form smoother are computed
+        // once (model pass on one chain), every sweep is vectors only.  RXHIP_DENSE_SPLIT=0/1 overrides (tests).
+        {
+            const char* sp_env = std::getenv("RXHIP_DENSE_SPLIT");
+            e->split = e->n_models == 1 && e->S > 0 && (sp_env ? std::atoi(sp_env) != 0 : e->wg_chains >= 4);
+        }
+        if (e->split) {
+            ap.plain(&e->d_dtab, sizeof(double) * T * 3 * D * D);
+            ap.plain(&e->d_vlast, sizeof(double) * D * D);
+            ap.plain(&e->d_vstab, sizeof(double) * T * Du * Du);
+            ap.plain(&e->d_fe_const, sizeof(double) * 2 * Sg);
+        }
         if ((st = arena_commit(e, ap))) return st;
         tr.mark("dense: work buffers");
         return RXHIP_OK;
@@ -2875,7 +2891,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.fe_scale = filter ? 1.0 / (double)e->T : 1.0;
     const bool fe = want_fe != 0;
     rxhip_status st;
-    DenseParams dp;
+    DenseParams dp{};
     if (e->dense && !e->gseq) {
         dp.T = e->T; dp.n_chains = e->wg_chains; dp.S = e->S; dp.L = e->L; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dyk;
         dp.pack = e->pack; dp.d_sub = 8; dp.dy_sub = e->dy;
@@ -2915,7 +2931,29 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             if ((st = prof_begin(e, RXHIP_K_BOUNDARY_SCAN))) return st;
             DENSE_DISPATCH(e->nt, boundary_scan(dp, fe && !info, e->stream));
             if ((st = prof_end(e))) return st;
-            if (e->S > 0) {
+            if (e->S > 0 && info && e->split) {
+                SplitParams sq{};
+                sq.p = dp; sq.D = e->dpad; sq.rec = dense_rec(e->nt); sq.dtab = e->d_dtab; sq.vlast = e->d_vlast; sq.vstab = e->d_vstab;
+                sq.fe_const = e->d_fe_const;
+                if (!e->split_ready) {  // the model pass: the full kernels on ONE workgroup chain, their records -> tables
+                    DenseParams mp = dp;
+                    mp.vlast = e->d_vlast;
+                    DENSE_DISPATCH(e->nt, forward_info(mp, true, e->stream, 1));
+                    DENSE_DISPATCH(e->nt, backward_info(mp, true, e->stream, 1));
+                    hipLaunchKernelGGL(kd_split_tables, dim3((unsigned)e->T), dim3(256), 0, e->stream, sq);
+                    hipLaunchKernelGGL(kd_split_save, dim3(256), dim3(256), 0, e->stream, sq, (long long)e->n_chains);
+                    e->split_ready = true;
+                }
+                const int gpw = 64 / e->dpad;
+                const unsigned nblk_units = (unsigned)(((long long)e->wg_chains * e->S + gpw - 1) / gpw);
+                if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
+                hipLaunchKernelGGL(kd_split_forward, dim3(nblk_units), dim3(64), 0, e->stream, sq);
+                if ((st = prof_end(e))) return st;
+                if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
+                hipLaunchKernelGGL(kd_split_backward, dim3(nblk_units), dim3(64), 0, e->stream, sq);
+                hipLaunchKernelGGL(kd_split_broadcast, dim3(2048), dim3(256), 0, e->stream, sq, (long long)e->n_chains, fe ? 1 : 0);
+                if ((st = prof_end(e))) return st;
+            } else if (e->S > 0) {
                 if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
                 if (info) { DENSE_DISPATCH(e->nt, forward_info(dp, fe, e->stream)); }
                 else { DENSE_DISPATCH(e->nt, forward(dp, fe, e->stream)); }

@@ -229,3 +229,43 @@ def test_several_models_on_the_mfma_path(d, dy, T, C, M, segments):
         assert rel(sm[:, c], om) < 1e-6 and rel(sc[:, c], oc) < 1e-6 and abs(sfe[c] - ofe) < 1e-8 * abs(ofe), c
         hm, hc, hfe, _ = rxoracle.lgssm_filter(*args, False)
         assert rel(fm[:, c], hm) < 1e-6 and rel(fc[:, c], hc) < 1e-6 and abs(ffe[c] - hfe) < 1e-8 * abs(hfe), c
+
+
+@pytest.mark.parametrize("d,dy,T,C,segments,ptt", [(8, 8, 200, 16, 0, False), (12, 5, 150, 9, 5, True), (16, 16, 101, 4, 3, False),
+                                                     (24, 30, 77, 6, 0, True), (40, 12, 64, 5, 4, False), (64, 64, 48, 4, 2, True),
+                                                     (7, 3, 60, 11, 1, False)])
+def test_shared_model_batches_on_the_mfma_path_split_model_and_data_pass(d, dy, T, C, segments, ptt, monkeypatch):
+    """A batch that shares one model on the MFMA path: the matrices of the information-form smoother are computed once per
+    engine on one chain, every sweep is three matrix–vector products per step and chain (dense_split_kernels.hpp).  Same
+    posteriors and free energies as the all-matrix schedule (RXHIP_DENSE_SPLIT=0) and as the oracle; the tables survive a
+    filtering run in between and new data."""
+    m = workloads.random_model(d, dy, seed=3 * d + dy)
+    y = workloads.generate_batch(m, T, C, seed0=5 * T + C)
+    y2 = workloads.generate_batch(m, T, C, seed0=77)
+    args = (m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"])
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("RXHIP_DENSE_SPLIT", mode)
+        with rxhip.LGSSMEngine(*args, T=T, n_chains=C, segments=segments, prior_through_transition=ptt) as eng:
+            eng.set_data(y)
+            eng.run(2, True)
+            first = (eng.marginals(), eng.free_energy_per_chain().copy(), eng.free_energy().copy())
+            eng.run_filter(True)          # writes the records and the posterior arrays in another format
+            eng.set_data(y2)
+            eng.run(1, True)
+            second = (eng.marginals(), eng.free_energy_per_chain().copy())
+            pm, pc = eng.predictions()
+            out[mode] = (first, second, (pm, pc))
+    (m1, c1), fe1, it1 = out["1"][0]
+    (m0_, c0_), fe0, _ = out["0"][0]
+    assert it1[0] == it1[1] and abs(it1[0] - fe1.sum()) < 1e-11 * abs(it1[0])
+    assert rel(m1, m0_) < 1e-9 and rel(c1, c0_) < 1e-9 and np.max(np.abs(fe1 - fe0) / np.abs(fe0)) < 1e-10
+    (m2, c2), fe2 = out["1"][1]
+    (n2, k2), ge2 = out["0"][1]
+    assert rel(m2, n2) < 1e-9 and rel(c2, k2) < 1e-9 and np.max(np.abs(fe2 - ge2) / np.abs(ge2)) < 1e-10
+    assert rel(out["1"][2][0], out["0"][2][0]) < 1e-8 and rel(out["1"][2][1], out["0"][2][1]) < 1e-8
+    for c in sorted({0, C // 2, C - 1}):
+        om, oc, ofe = rxoracle.lgssm_kalman_rts(*args, y[:, c], prior_through_transition=ptt)
+        assert rel(m1[:, c], om) < 1e-6 and rel(c1[:, c], oc) < 1e-6 and abs(fe1[c] - ofe) < 1e-8 * abs(ofe), c
+        om, oc, ofe = rxoracle.lgssm_kalman_rts(*args, y2[:, c], prior_through_transition=ptt)
+        assert rel(m2[:, c], om) < 1e-6 and rel(c2[:, c], oc) < 1e-6 and abs(fe2[c] - ofe) < 1e-8 * abs(ofe), c
