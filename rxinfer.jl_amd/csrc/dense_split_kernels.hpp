@@ -77,57 +77,100 @@ __global__ void __launch_bounds__(256) kd_split_broadcast(SplitParams q, long lo
     }
 }
 
-// out_i = Σ_k Mt[k·D + i] · x_k  for the unit of this lane (x_k lives in lane base + k)
-__device__ __forceinline__ double split_matvec(const double* __restrict__ Mt, int D, int i, int base, double x) {
-    double s0 = 0.0, s1 = 0.0;
-    for (int k = 0; k < D; k += 2) {
-        s0 += Mt[k * D + i] * __shfl(x, base + k);
-        s1 += Mt[(k + 1) * D + i] * __shfl(x, base + k + 1);
-    }
-    return s0 + s1;
-}
-
 struct SplitUnit {
     long long seg, chain;
     int i, base;
     bool live;
 };
+template <int D>
 __device__ __forceinline__ SplitUnit split_unit(const SplitParams& q) {
-    const int D = q.D, gpw = 64 / D, lane = threadIdx.x;
+    constexpr int gpw = 64 / D;
+    const int lane = threadIdx.x;
     SplitUnit u;
     const int g = lane / D;
     u.i = lane - g * D;
     u.base = g * D;
     const long long unit = (long long)blockIdx.x * gpw + (g < gpw ? g : 0);
-    u.seg = unit / q.p.n_chains;        // the units of a wavefront share the segment: they read the same table rows
+    u.seg = unit / q.p.n_chains;        // neighbouring units are neighbouring chains of one segment: they read the same table rows
     u.chain = unit - u.seg * q.p.n_chains;
     u.live = g < gpw && u.seg < q.p.S;
     if (!u.live) { u.seg = 0; u.chain = 0; }  // idle lanes follow unit 0 (uniform control flow, no stores)
     return u;
 }
 
+// column i of a D×D row-major table matrix (the lane's operand of out_i = Σ_k Mt[k][i] x_k): D independent loads in flight
+template <int D>
+__device__ __forceinline__ void split_load_col(double (&c)[D], const double* __restrict__ Mt, int i) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) c[k] = Mt[k * D + i];
+}
+// Σ_k c[k] · x_k, x_k from lane base + k (four partial sums)
+template <int D>
+__device__ __forceinline__ double split_dot(const double (&c)[D], int base, double x) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < D; ++k) s[k & 3] += c[k] * __shfl(x, base + k);
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+// without registers for a whole column (D = 48, 64): sixteen rows of the table at a time
+template <int D>
+__device__ __forceinline__ double split_matvec(const double* __restrict__ Mt, int i, int base, double x) {
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k0 = 0; k0 < D; k0 += 16) {
+        double c[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) c[k] = Mt[(k0 + k) * D + i];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s[k & 3] += c[k] * __shfl(x, base + k0 + k);
+    }
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+// PF: the table columns of the NEXT step travel in registers under the current step's cross-lane reads (D ≤ 32: 4·D doubles)
+template <int D>
 __global__ void __launch_bounds__(64) kd_split_forward(SplitParams q) {
+    constexpr bool PF = D <= 32;
     const DenseParams& p = q.p;
-    const int D = q.D;
-    const SplitUnit u = split_unit(q);
+    const SplitUnit u = split_unit<D>(q);
     const int i = u.i;
-    const size_t DD = (size_t)D * D;
+    constexpr size_t DD = (size_t)D * D, TS = 3 * DD;
     const long long b0 = 1 + u.seg * p.L;
     long long b1 = b0 + p.L;
     if (b1 > p.T) b1 = p.T;
     const long long len = b1 - b0, t0 = u.seg * p.L + 1;
     double* filt = p.filt + u.chain * p.T * q.rec;
     // belief at the segment start in information form: ξ_f = Λ_f(b_s) m(b_s)
-    double xi = split_matvec(p.bnd + ((size_t)u.seg * 2 + 0) * DD, D, i, u.base, p.fstart_m[(u.chain * p.S + u.seg) * D + i]);
+    double xi = split_matvec<D>(p.bnd + ((size_t)u.seg * 2 + 0) * DD, i, u.base, p.fstart_m[(u.chain * p.S + u.seg) * D + i]);
     double gyn = len > 0 ? filt[t0 * q.rec + D + i] : 0.0;
+    double c[PF ? D : 1], a[PF ? D : 1];
+    if (PF && len > 0) {
+        split_load_col<PF ? D : 1>(c, q.dtab + (size_t)(t0 - 1) * TS, i);
+        split_load_col<PF ? D : 1>(a, q.dtab + (size_t)(t0 - 1) * TS + DD, i);
+    }
     for (long long s = 0; s < len; ++s) {
         const long long t = t0 + s;
         double* rec = filt + (t - 1) * q.rec;
-        const double* tab = q.dtab + (size_t)(t - 1) * SplitTab::size(D);
         const double gyc = gyn;
-        gyn = filt[(s + 1 < len ? t + 1 : t) * q.rec + D + i];
-        const double cxi = split_matvec(tab, D, i, u.base, xi);            // C_{t−1} ξ_f(t−1)
-        const double axi = split_matvec(tab + DD, D, i, u.base, xi);       // G′_{t−1} ξ_f(t−1)
+        const long long tn = s + 1 < len ? t + 1 : t;   // unconditional prefetch (the last one re-reads this step's rows)
+        gyn = filt[tn * q.rec + D + i];
+        double cxi, axi;
+        if (PF) {
+            double cn[PF ? D : 1], an[PF ? D : 1];
+            split_load_col<PF ? D : 1>(cn, q.dtab + (size_t)(tn - 1) * TS, i);
+            split_load_col<PF ? D : 1>(an, q.dtab + (size_t)(tn - 1) * TS + DD, i);
+            cxi = split_dot<PF ? D : 1>(c, u.base, xi);                     // C_{t−1} ξ_f(t−1)
+            axi = split_dot<PF ? D : 1>(a, u.base, xi);                     // G′_{t−1} ξ_f(t−1)
+#pragma unroll
+            for (int k = 0; k < (PF ? D : 1); ++k) {
+                c[k] = cn[k];
+                a[k] = an[k];
+            }
+        } else {
+            const double* tab = q.dtab + (size_t)(t - 1) * TS;
+            cxi = split_matvec<D>(tab, i, u.base, xi);
+            axi = split_matvec<D>(tab + DD, i, u.base, xi);
+        }
         if (u.live) {
             rec[i] = xi;
             rec[2 * D + i] = cxi;
@@ -137,12 +180,13 @@ __global__ void __launch_bounds__(64) kd_split_forward(SplitParams q) {
     if (u.live && u.seg == p.S - 1) filt[(t0 + len - 1) * q.rec + i] = xi;  // ξ_f(T−1): no successor writes it
 }
 
+template <int D>
 __global__ void __launch_bounds__(64) kd_split_backward(SplitParams q) {
+    constexpr bool PF = D <= 32;
     const DenseParams& p = q.p;
-    const int D = q.D;
-    const SplitUnit u = split_unit(q);
+    const SplitUnit u = split_unit<D>(q);
     const int i = u.i;
-    const size_t DD = (size_t)D * D;
+    constexpr size_t DD = (size_t)D * D, TS = 3 * DD;
     const long long b0 = 1 + u.seg * p.L;
     long long b1 = b0 + p.L;
     if (b1 > p.T) b1 = p.T;
@@ -152,13 +196,25 @@ __global__ void __launch_bounds__(64) kd_split_backward(SplitParams q) {
     // the model pass
     const double xf = filt[te * q.rec + i] + p.beta_xi[(u.chain * (p.S + 1) + u.seg + 1) * D + i];
     const bool last = u.seg == p.S - 1;
-    double ms = split_matvec(last ? q.vlast : p.bnd + ((size_t)u.seg * 2 + 1) * DD, D, i, u.base, xf);
+    double ms = split_matvec<D>(last ? q.vlast : p.bnd + ((size_t)u.seg * 2 + 1) * DD, i, u.base, xf);
     if (u.live && last) dense_store_mean(p, te, u.chain, i, ms);
     double cxn = len > 0 ? filt[(te - 1) * q.rec + 2 * D + i] : 0.0;
+    double g[PF ? D : 1];
+    if (PF && len > 0) split_load_col<PF ? D : 1>(g, q.dtab + (size_t)(te - 1) * TS + 2 * DD, i);
     for (long long t = te - 1; t >= tb; --t) {
         const double cx = cxn;
-        cxn = filt[(t - 1 >= tb ? t - 1 : tb) * q.rec + 2 * D + i];
-        ms = cx + split_matvec(q.dtab + (size_t)t * SplitTab::size(D) + 2 * DD, D, i, u.base, ms);   // C_t ξ_f(t) + G_t m_s(t+1)
+        const long long tn = t - 1 >= tb ? t - 1 : tb;
+        cxn = filt[tn * q.rec + 2 * D + i];
+        double gm;
+        if (PF) {
+            double gn[PF ? D : 1];
+            split_load_col<PF ? D : 1>(gn, q.dtab + (size_t)tn * TS + 2 * DD, i);
+            gm = split_dot<PF ? D : 1>(g, u.base, ms);
+#pragma unroll
+            for (int k = 0; k < (PF ? D : 1); ++k) g[k] = gn[k];
+        } else
+            gm = split_matvec<D>(q.dtab + (size_t)t * TS + 2 * DD, i, u.base, ms);
+        ms = cx + gm;                                                      // C_t ξ_f(t) + G_t m_s(t+1)
         if (u.live) dense_store_mean(p, t, u.chain, i, ms);
     }
 }
