@@ -104,12 +104,43 @@ __device__ __forceinline__ void split_load_col(double (&c)[D], const double* __r
 #pragma unroll
     for (int k = 0; k < D; ++k) c[k] = Mt[k * D + i];
 }
-// Σ_k c[k] · x_k, x_k from lane base + k (four partial sums)
+// lane k of this lane's 16-lane row, without the LDS crossbar: v_mov_b32_dpp row_newbcast:k per half (a ds_bpermute pair costs
+// ≈100 cycles of latency and two LDS-pipe issues per element; the data pass is exactly this chain, D times per product)
+template <int K>
+__device__ __forceinline__ double row_bcast(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, 0x150 + K, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, 0x150 + K, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+template <int K0, int D>
+struct RowDot {  // s[k & 3] += c[KOFF + k] · (lane k of the row), k = K0 … 15
+    template <int KOFF>
+    static __device__ __forceinline__ void run(const double (&c)[D], double x, double (&s)[4]) {
+        s[K0 & 3] += c[KOFF + K0] * row_bcast<K0>(x);
+        RowDot<K0 + 1, D>::template run<KOFF>(c, x, s);
+    }
+};
+template <int D>
+struct RowDot<16, D> {
+    template <int KOFF>
+    static __device__ __forceinline__ void run(const double (&)[D], double, double (&)[4]) {}
+};
+// Σ_k c[k] · x_k for a unit of D = 16 or 32 lanes (x_k lives in lane base + k; four partial sums)
 template <int D>
 __device__ __forceinline__ double split_dot(const double (&c)[D], int base, double x) {
+    static_assert(D == 16 || D == 32, "one or two DPP rows");
     double s[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int k = 0; k < D; ++k) s[k & 3] += c[k] * __shfl(x, base + k);
+    if (D == 16) {
+        RowDot<0, D>::template run<0>(c, x, s);
+    } else {
+        const double xo = __shfl_xor(x, 16);          // the unit's other row
+        const bool hi = (threadIdx.x & 16) != 0;       // this lane sits in the unit's second row: its own row holds x_16 … x_31
+        const double x0 = hi ? xo : x, x1 = hi ? x : xo;
+        RowDot<0, D>::template run<0>(c, x0, s);
+        RowDot<0, D>::template run<(D == 32 ? 16 : 0)>(c, x1, s);
+    }
+    (void)base;
     return (s[0] + s[1]) + (s[2] + s[3]);
 }
 // without registers for a whole column (D = 48, 64): sixteen rows of the table at a time
@@ -143,39 +174,50 @@ __global__ void __launch_bounds__(64) kd_split_forward(SplitParams q) {
     // belief at the segment start in information form: ξ_f = Λ_f(b_s) m(b_s)
     double xi = split_matvec<D>(p.bnd + ((size_t)u.seg * 2 + 0) * DD, i, u.base, p.fstart_m[(u.chain * p.S + u.seg) * D + i]);
     double gyn = len > 0 ? filt[t0 * q.rec + D + i] : 0.0;
-    double c[PF ? D : 1], a[PF ? D : 1];
-    if (PF && len > 0) {
-        split_load_col<PF ? D : 1>(c, q.dtab + (size_t)(t0 - 1) * TS, i);
-        split_load_col<PF ? D : 1>(a, q.dtab + (size_t)(t0 - 1) * TS + DD, i);
-    }
-    for (long long s = 0; s < len; ++s) {
-        const long long t = t0 + s;
-        double* rec = filt + (t - 1) * q.rec;
-        const double gyc = gyn;
-        const long long tn = s + 1 < len ? t + 1 : t;   // unconditional prefetch (the last one re-reads this step's rows)
-        gyn = filt[tn * q.rec + D + i];
-        double cxi, axi;
-        if (PF) {
-            double cn[PF ? D : 1], an[PF ? D : 1];
-            split_load_col<PF ? D : 1>(cn, q.dtab + (size_t)(tn - 1) * TS, i);
-            split_load_col<PF ? D : 1>(an, q.dtab + (size_t)(tn - 1) * TS + DD, i);
-            cxi = split_dot<PF ? D : 1>(c, u.base, xi);                     // C_{t−1} ξ_f(t−1)
-            axi = split_dot<PF ? D : 1>(a, u.base, xi);                     // G′_{t−1} ξ_f(t−1)
-#pragma unroll
-            for (int k = 0; k < (PF ? D : 1); ++k) {
-                c[k] = cn[k];
-                a[k] = an[k];
+    if constexpr (PF) {
+        // two column sets in registers, used alternately: the step that works on one set loads the other for the next step
+        double c0[D], a0[D], c1[D], a1[D];
+        if (len > 0) {
+            split_load_col<D>(c0, q.dtab + (size_t)(t0 - 1) * TS, i);
+            split_load_col<D>(a0, q.dtab + (size_t)(t0 - 1) * TS + DD, i);
+        }
+        auto step = [&](long long s, const double (&cc)[D], const double (&ca)[D], double (&nc)[D], double (&na)[D]) {
+            const long long t = t0 + s;
+            double* rec = filt + (t - 1) * q.rec;
+            const double gyc = gyn;
+            const long long tn = s + 1 < len ? t + 1 : t;   // unconditional prefetch (the last one re-reads this step's rows)
+            gyn = filt[tn * q.rec + D + i];
+            split_load_col<D>(nc, q.dtab + (size_t)(tn - 1) * TS, i);
+            split_load_col<D>(na, q.dtab + (size_t)(tn - 1) * TS + DD, i);
+            const double cxi = split_dot<D>(cc, u.base, xi);                // C_{t−1} ξ_f(t−1)
+            const double axi = split_dot<D>(ca, u.base, xi);                // G′_{t−1} ξ_f(t−1)
+            if (u.live) {
+                rec[i] = xi;
+                rec[2 * D + i] = cxi;
             }
-        } else {
+            xi = gyc + axi;                                                 // ξ_f(t)
+        };
+        long long s = 0;
+        for (; s + 1 < len; s += 2) {
+            step(s, c0, a0, c1, a1);
+            step(s + 1, c1, a1, c0, a0);
+        }
+        if (s < len) step(s, c0, a0, c1, a1);
+    } else {
+        for (long long s = 0; s < len; ++s) {
+            const long long t = t0 + s;
+            double* rec = filt + (t - 1) * q.rec;
+            const double gyc = gyn;
+            gyn = filt[(s + 1 < len ? t + 1 : t) * q.rec + D + i];
             const double* tab = q.dtab + (size_t)(t - 1) * TS;
-            cxi = split_matvec<D>(tab, i, u.base, xi);
-            axi = split_matvec<D>(tab + DD, i, u.base, xi);
+            const double cxi = split_matvec<D>(tab, i, u.base, xi);
+            const double axi = split_matvec<D>(tab + DD, i, u.base, xi);
+            if (u.live) {
+                rec[i] = xi;
+                rec[2 * D + i] = cxi;
+            }
+            xi = gyc + axi;
         }
-        if (u.live) {
-            rec[i] = xi;
-            rec[2 * D + i] = cxi;
-        }
-        xi = gyc + axi;                                                    // ξ_f(t)
     }
     if (u.live && u.seg == p.S - 1) filt[(t0 + len - 1) * q.rec + i] = xi;  // ξ_f(T−1): no successor writes it
 }
@@ -199,23 +241,30 @@ __global__ void __launch_bounds__(64) kd_split_backward(SplitParams q) {
     double ms = split_matvec<D>(last ? q.vlast : p.bnd + ((size_t)u.seg * 2 + 1) * DD, i, u.base, xf);
     if (u.live && last) dense_store_mean(p, te, u.chain, i, ms);
     double cxn = len > 0 ? filt[(te - 1) * q.rec + 2 * D + i] : 0.0;
-    double g[PF ? D : 1];
-    if (PF && len > 0) split_load_col<PF ? D : 1>(g, q.dtab + (size_t)(te - 1) * TS + 2 * DD, i);
-    for (long long t = te - 1; t >= tb; --t) {
-        const double cx = cxn;
-        const long long tn = t - 1 >= tb ? t - 1 : tb;
-        cxn = filt[tn * q.rec + 2 * D + i];
-        double gm;
-        if (PF) {
-            double gn[PF ? D : 1];
-            split_load_col<PF ? D : 1>(gn, q.dtab + (size_t)tn * TS + 2 * DD, i);
-            gm = split_dot<PF ? D : 1>(g, u.base, ms);
-#pragma unroll
-            for (int k = 0; k < (PF ? D : 1); ++k) g[k] = gn[k];
-        } else
-            gm = split_matvec<D>(q.dtab + (size_t)t * TS + 2 * DD, i, u.base, ms);
-        ms = cx + gm;                                                      // C_t ξ_f(t) + G_t m_s(t+1)
-        if (u.live) dense_store_mean(p, t, u.chain, i, ms);
+    if constexpr (PF) {
+        double g0[D], g1[D];
+        if (len > 0) split_load_col<D>(g0, q.dtab + (size_t)(te - 1) * TS + 2 * DD, i);
+        auto step = [&](long long t, const double (&cg)[D], double (&ng)[D]) {
+            const double cx = cxn;
+            const long long tn = t - 1 >= tb ? t - 1 : tb;
+            cxn = filt[tn * q.rec + 2 * D + i];
+            split_load_col<D>(ng, q.dtab + (size_t)tn * TS + 2 * DD, i);
+            ms = cx + split_dot<D>(cg, u.base, ms);                         // C_t ξ_f(t) + G_t m_s(t+1)
+            if (u.live) dense_store_mean(p, t, u.chain, i, ms);
+        };
+        long long t = te - 1;
+        for (; t - 1 >= tb; t -= 2) {
+            step(t, g0, g1);
+            step(t - 1, g1, g0);
+        }
+        if (t >= tb) step(t, g0, g1);
+    } else {
+        for (long long t = te - 1; t >= tb; --t) {
+            const double cx = cxn;
+            cxn = filt[(t - 1 >= tb ? t - 1 : tb) * q.rec + 2 * D + i];
+            ms = cx + split_matvec<D>(q.dtab + (size_t)t * TS + 2 * DD, i, u.base, ms);
+            if (u.live) dense_store_mean(p, t, u.chain, i, ms);
+        }
     }
 }
 
