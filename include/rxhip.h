@@ -275,8 +275,8 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
 /* 1 if a device schedule exists for state dimension d and observation dimension dy: every d, dy ≤ 4 has a dedicated
  * one-lane-per-chain schedule; any other d ≤ 64 with dy ≤ 64 runs on the MFMA path (state dimension rounded up to a
  * multiple of 16 with decoupled padding dimensions — exact, but priced as the padded size; d ≤ 8 with an even batch of one
- * model: two chains per 16×16 tile; several models per engine allowed; at most 65535 chains — 131070 when paired — per
- * engine) */
+ * model: two chains per 16×16 tile, and a batch of one model computes the matrices of the sweep once per engine; several
+ * models per engine allowed; any number of chains — batches beyond a grid dimension are launched in slices) */
 int32_t rxhip_lgssm_supported(int32_t d, int32_t dy);
 
 /* replaces: new_observation!(datavar, value) (src/inference/batch.jl:405-407).  Copies n doubles

@@ -109,6 +109,7 @@ struct DenseParams {
     const struct DenseModel* models;
     const int* chain_model;
     double* vlast;        // null, or [d][d]: V_s(T−1) of this run (the model pass of dense_split_kernels.hpp keeps it)
+    long long chain0;     // first workgroup chain of this launch: a grid dimension holds 65 535 blocks, larger batches are launched in slices
 };
 struct DenseModel {
     const double *cst, *tab, *scanm, *qtab;
@@ -620,7 +621,7 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_gemm(DenseParams p) {
     const int dy = p.dy, dyp = (dy + 3) & ~3, tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     const int jl = lane & 15, kq = lane >> 4;
     const int nblk = gridDim.x, sb = blockIdx.x, kc = blockIdx.y;
-    const long long chain = blockIdx.z;
+    const long long chain = blockIdx.z + p.chain0;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const bool lastblk = sb == nblk - 1;
     const int seg = lastblk ? p.S - 1 : 16 * sb + jl;                      // this lane's B-operand column
@@ -680,7 +681,7 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_finish(DenseParams p) {
     double* red = eta + dm;         // [4][dm] partial sums
     double* GTs = red + 4 * dm;     // (B'Q⁻¹)' [dy][D]
     double* Ys = GTs + D * dy;      // [TS][dy]
-    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const long long seg = blockIdx.x, chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = M.cst;
@@ -816,7 +817,7 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
     double* v2 = v1 + dm;
     double* yv = v2 + dm;
     double* red = yv + dm;
-    const long long chain = blockIdx.y;
+    const long long chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = M.cst;
@@ -893,7 +894,7 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_fix(DenseParams p) {
     const int dm = ((D > dy ? D : dy) + 1) & ~1;
     double* v0 = smem;
     double* red = v0 + 4 * dm;
-    const long long chain = blockIdx.y;
+    const long long chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const int S = p.S, n = S - 1;
     const int dir = blockIdx.x / p.ng, grpj = blockIdx.x - dir * p.ng;
@@ -982,7 +983,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     double* rowbuf = qy + dm;   // 8·D doubles (two buffers of four pivot rows)
     double* red = rowbuf + 8 * D;  // [4][dm] partial sums
     double* red2 = red + 4 * dm;   // [4][dm]
-    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const long long seg = blockIdx.x, chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = M.cst;
@@ -1164,7 +1165,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     double* xpp = u + dm;       // [4][D] partial sums of ξ_p
     double* cpp = xpp + 4 * dm; // [4][D] partial sums of C_t ξ_f(t) (handed to the backward kernel in the record)
     double* rowbuf = cpp + 4 * dm;  // 8·D doubles
-    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const long long seg = blockIdx.x, chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = M.cst;
@@ -1291,7 +1292,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
     double* ms = vec;           // m_s(t+1), then m_s(t)
     double* xf = ms + dm;       // boundary: ξ_f + ξβ; in the loop: C_t ξ_f(t)
     double* rowbuf = xf + dm;   // 8·D doubles: pivot rows of the last segment's inverse, then the matvec partials
-    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const long long seg = blockIdx.x, chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = M.cst;
@@ -1409,7 +1410,7 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
     const bool pk = p.pack == 2;
     const bool x1 = pk && i >= p.d_sub, y1 = pk && i >= p.dy_sub;  // row i of the state / observation terms belongs to the pair's second chain
     double acc1 = 0.0;
-    const long long chain = blockIdx.y, t00 = (long long)blockIdx.x * STEPS;
+    const long long chain = blockIdx.y + p.chain0, t00 = (long long)blockIdx.x * STEPS;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
     double* AT = smem;                     // [D][D]   A'

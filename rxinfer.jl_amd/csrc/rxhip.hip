@@ -1013,43 +1013,67 @@ struct DenseLaunch {
             if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         return hipSuccess;
     }
+    // one launch per slice of at most 32 768 workgroup chains (grid.y / grid.z hold 65 535 blocks)
+    template <class F>
+    static void slices(const DenseParams& p, long long chains, F launch) {
+        for (long long c0 = 0; c0 < chains; c0 += 32768) {
+            DenseParams q = p;
+            q.chain0 = p.chain0 + c0;
+            launch(q, (unsigned)(chains - c0 < 32768 ? chains - c0 : 32768));
+        }
+    }
     static void prepare_bnd(const DenseParams& p, hipStream_t s) {
         hipLaunchKernelGGL((kd_prepare_bnd<NT>), dim3(p.S), dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
     }
     static void seg_aggregate(const DenseParams& p, hipStream_t s) {
         const unsigned sb = (unsigned)((p.S - 1 + 15) / 16 + 1);  // blocks of 16 full segments + the last segment on its own
-        hipLaunchKernelGGL((kd_agg_gemm<NT>), dim3(sb, (unsigned)p.agg_kc, (unsigned)p.n_chains), dim3(64 * NT), 0, s, p);
-        hipLaunchKernelGGL((kd_agg_finish<NT>), dim3(p.S, (unsigned)p.n_chains), dim3(64 * NT), DenseLds<NT>::agg_bytes(p.dy), s, p);
+        slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
+            hipLaunchKernelGGL((kd_agg_gemm<NT>), dim3(sb, (unsigned)q.agg_kc, nc), dim3(64 * NT), 0, s, q);
+            hipLaunchKernelGGL((kd_agg_finish<NT>), dim3(q.S, nc), dim3(64 * NT), DenseLds<NT>::agg_bytes(q.dy), s, q);
+        });
     }
     static void boundary_scan(const DenseParams& p, bool fe, hipStream_t s) {
-        dim3 g((p.filter ? 1 : 2) * p.ng, (unsigned)p.n_chains);  // filtering runs need the prefix direction only
-        if (fe) hipLaunchKernelGGL((kd_scan_local<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
-        else hipLaunchKernelGGL((kd_scan_local<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
-        if (p.S > 1) hipLaunchKernelGGL((kd_scan_fix<NT>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
+            dim3 g((q.filter ? 1 : 2) * q.ng, nc);  // filtering runs need the prefix direction only
+            if (fe) hipLaunchKernelGGL((kd_scan_local<NT, true>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
+            else hipLaunchKernelGGL((kd_scan_local<NT, false>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
+            if (q.S > 1) hipLaunchKernelGGL((kd_scan_fix<NT>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
+        });
     }
     static void forward(const DenseParams& p, bool fe, hipStream_t s) {
-        dim3 g(p.S, (unsigned)p.n_chains);
-        if (fe) hipLaunchKernelGGL((kd_forward<NT, true>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
-        else hipLaunchKernelGGL((kd_forward<NT, false>), g, dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
+        slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
+            dim3 g(q.S, nc);
+            if (fe) hipLaunchKernelGGL((kd_forward<NT, true>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
+            else hipLaunchKernelGGL((kd_forward<NT, false>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
+        });
     }
     // information-form smoother (one inverse per step; free energy at the smoothed means)
     static void forward_info(const DenseParams& p, bool fe, hipStream_t s, long long chains = -1) {
-        dim3 g(p.S, (unsigned)(chains < 0 ? p.n_chains : chains));
         const size_t lds = DenseLds<NT>::fwd_info_bytes(((p.d > p.dy ? p.d : p.dy) + 1) & ~1);
-        if (fe) hipLaunchKernelGGL((kd_forward_info<NT, true>), g, dim3(64 * NT), lds, s, p);
-        else hipLaunchKernelGGL((kd_forward_info<NT, false>), g, dim3(64 * NT), lds, s, p);
+        slices(p, chains < 0 ? p.n_chains : chains, [&](const DenseParams& q, unsigned nc) {
+            dim3 g(q.S, nc);
+            if (fe) hipLaunchKernelGGL((kd_forward_info<NT, true>), g, dim3(64 * NT), lds, s, q);
+            else hipLaunchKernelGGL((kd_forward_info<NT, false>), g, dim3(64 * NT), lds, s, q);
+        });
     }
     static void backward_info(const DenseParams& p, bool fe, hipStream_t s, long long chains = -1) {
-        dim3 g(p.S, (unsigned)(chains < 0 ? p.n_chains : chains));
         const size_t lds = DenseLds<NT>::bwd_info_bytes(((p.d > p.dy ? p.d : p.dy) + 1) & ~1);
-        if (fe) hipLaunchKernelGGL((kd_backward_info<NT, true>), g, dim3(64 * NT), lds, s, p);
-        else hipLaunchKernelGGL((kd_backward_info<NT, false>), g, dim3(64 * NT), lds, s, p);
+        slices(p, chains < 0 ? p.n_chains : chains, [&](const DenseParams& q, unsigned nc) {
+            dim3 g(q.S, nc);
+            if (fe) hipLaunchKernelGGL((kd_backward_info<NT, true>), g, dim3(64 * NT), lds, s, q);
+            else hipLaunchKernelGGL((kd_backward_info<NT, false>), g, dim3(64 * NT), lds, s, q);
+        });
     }
 };
 // free-energy residual terms of an information-form smoothing run: one workgroup per FR_STEPS steps, partial slots 2S…
 static int fe_resid_blocks(long long T, int d, int dy) { const int st = fe_resid_steps(d, dy); return (int)((T + st - 1) / st); }
 static void launch_fe_resid(const DenseParams& p, hipStream_t s) {
-    hipLaunchKernelGGL(kd_fe_resid, dim3(fe_resid_blocks(p.T, p.d, p.dy), (unsigned)p.n_chains), dim3(256), fe_resid_lds_bytes(p.d, p.dy), s, p, 2 * p.S);
+    for (long long c0 = 0; c0 < p.n_chains; c0 += 32768) {  // grid.y holds 65 535 blocks
+        DenseParams q = p;
+        q.chain0 = c0;
+        const unsigned nc = (unsigned)(p.n_chains - c0 < 32768 ? p.n_chains - c0 : 32768);
+        hipLaunchKernelGGL(kd_fe_resid, dim3(fe_resid_blocks(p.T, p.d, p.dy), nc), dim3(256), fe_resid_lds_bytes(p.d, p.dy), s, q, 2 * p.S);
+    }
 }
 #define DENSE_DISPATCH(nt, CALL)                    \
     switch (nt) {                                   \
@@ -1714,9 +1738,6 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     e->pack = (dense && !e->gseq && ds->d <= 8 && ds->dy <= 32 && ds->n_chains % 2 == 0 && ds->n_models == 1 && !std::getenv("RXHIP_NO_PACK")) ? 2 : 1;
     e->wg_chains = ds->n_chains / e->pack;
     e->dyk = ds->dy * e->pack;
-    if (dense && !e->gseq && e->wg_chains > 65535)  // the chain index is a grid y/z coordinate of the MFMA-path kernels
-        return fail(e, RXHIP_ERR_UNSUPPORTED, "d = %d runs on the MFMA path, which takes at most %d chains per engine (%lld given)", ds->d,
-                    65535 * e->pack, (long long)ds->n_chains);
     if (ds->device >= 0) {
         if (ds->device >= ndev) return fail(e, RXHIP_ERR_BADARG, "device %d out of range (%d visible)", ds->device, ndev);
         e->device = ds->device;

@@ -269,3 +269,28 @@ def test_shared_model_batches_on_the_mfma_path_split_model_and_data_pass(d, dy, 
         assert rel(m1[:, c], om) < 1e-6 and rel(c1[:, c], oc) < 1e-6 and abs(fe1[c] - ofe) < 1e-8 * abs(ofe), c
         om, oc, ofe = rxoracle.lgssm_kalman_rts(*args, y2[:, c], prior_through_transition=ptt)
         assert rel(m2[:, c], om) < 1e-6 and rel(c2[:, c], oc) < 1e-6 and abs(fe2[c] - ofe) < 1e-8 * abs(ofe), c
+
+
+def test_more_chains_than_a_grid_dimension_on_the_mfma_path():
+    """grid.y / grid.z hold 65 535 blocks: a batch of more workgroup chains than that is launched in slices (round 1 refused it).
+    140 002 chains of d = 5 (70 001 packed pairs), T = 6: chains from both slices against the oracle, smoothing and filtering."""
+    d, dy, T, C = 5, 2, 6, 140002
+    m = workloads.random_model(d, dy, seed=11)
+    rng = np.random.default_rng(4)
+    y = rng.standard_normal((T, C, dy))
+    args = (m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"])
+    with rxhip.LGSSMEngine(*args, T=T, n_chains=C, segments=2) as eng:
+        eng.set_data(y)
+        eng.run(1, True)
+        sel = [0, 1, 65535, 65536, 131071, 131072, C - 2, C - 1]
+        sm, sc = eng.marginals_of_chains(sel)
+        fe = eng.free_energy_per_chain()
+        total = eng.free_energy()[-1]
+        eng.run_filter(False)
+        fm, fc = eng.marginals_of_chains(sel)
+    assert abs(total - fe.sum()) < 1e-10 * abs(total)
+    for k, c in enumerate(sel):
+        om, oc, ofe = rxoracle.lgssm_kalman_rts(*args, y[:, c])
+        assert rel(sm[k], om) < 1e-6 and rel(sc[k], oc) < 1e-6 and abs(fe[c] - ofe) < 1e-8 * abs(ofe), c
+        hm, hc, _, _ = rxoracle.lgssm_filter(*args, y[:, c], False)
+        assert rel(fm[k], hm) < 1e-6 and rel(fc[k], hc) < 1e-6, c
