@@ -149,7 +149,8 @@ enum {
     /* the mean-field families (aliases src/model/graphppl.jl:340-370 Normal, :399-423 Gamma; interface orders as in
      * ReactiveMP's @node declarations) */
     RXHIP_NODE_NORMAL_MEAN_VARIANCE = 3,  /* (out, μ, v)  `Normal(mean = …, var = …)` */
-    RXHIP_NODE_NORMAL_MEAN_PRECISION = 4, /* (out, μ, τ)  `Normal(mean = …, precision = …)` */
+    RXHIP_NODE_NORMAL_MEAN_PRECISION = 4, /* (out, μ, τ)  `Normal(mean = …, precision = …)`: random τ -> the iid Gaussian×Gamma family; constant τ
+                                             -> a Gaussian chain in precision form (test/inference/prediction_tests.jl:197-213), lowered as 1/τ */
     RXHIP_NODE_GAMMA_SHAPE_RATE = 5,      /* (out, α, β)  `Gamma(shape = …, rate = …)` */
     RXHIP_NODE_DIRICHLET = 6,             /* (out, a) */
     RXHIP_NODE_BETA = 7,                  /* (out, a, b) */

@@ -123,8 +123,88 @@ inline bool same_const(const rxhip_graph_desc* g, long long a, long long b) {
 //     x[t] ~ x[t-1] + c        `+`(out = x_next, in1 = x, in2 = c const)  (or in1 const)
 // whose every transition is such a node.  A `+` with a constant IN FRONT of a Gaussian mean (`A * x[t-1] + c`, `B * x[t] + d`,
 // `x[t-1] + c` with state noise) is a known input of that time index (Lgssm::cx / cy).  Node order in the tables is irrelevant.
+// `NormalMeanPrecision(μ, τ)` / `MvNormalMeanPrecision(μ, Λ)` nodes with a CONSTANT precision are the same factors as their
+// covariance-parametrised forms (test/inference/prediction_tests.jl:197-213 spells a whole random-walk chain this way): a
+// private copy of the tables gets a new constant variable W⁻¹ per such node and the node type of the covariance form, and the
+// chain lowering below never sees a precision.  Nodes with a random precision (the iid Gaussian×Gamma family) are left alone.
+struct NormalisedGraph {
+    rxhip_graph_desc g;
+    std::vector<int32_t> var_kind, var_rows, var_cols, factor_type, var_init_family;
+    std::vector<int64_t> var_const, factor_iface, var_init;
+    std::vector<double> pool;
+};
+inline rxhip_status normalise_precision_nodes(const rxhip_graph_desc* g0, NormalisedGraph& N, bool& changed) {
+    changed = false;
+    for (long long f = 0; f < g0->n_factors && !changed; ++f) {
+        const int t = g0->factor_type[f];
+        if ((t == RXHIP_NODE_NORMAL_MEAN_PRECISION || t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION) && n_iface(g0, f) == 3 &&
+            g0->var_kind[iface(g0, f, 2)] == RXHIP_VARKIND_CONST)
+            changed = true;
+    }
+    if (!changed) return RXHIP_OK;
+    if (g0->factor_iface_ptr) { changed = false; return RXHIP_OK; }  // CSR tables: not a 3-interface Gaussian graph
+    const long long NV = g0->n_variables, NF = g0->n_factors;
+    N.var_kind.assign(g0->var_kind, g0->var_kind + NV);
+    N.var_rows.assign(g0->var_rows, g0->var_rows + NV);
+    N.var_cols.assign(g0->var_cols, g0->var_cols + NV);
+    N.var_const.assign(g0->var_const, g0->var_const + NV);
+    N.factor_type.assign(g0->factor_type, g0->factor_type + NF);
+    N.factor_iface.assign(g0->factor_iface, g0->factor_iface + 3 * NF);
+    N.pool.assign(g0->const_pool, g0->const_pool + g0->n_const);
+    if (g0->var_init_family) N.var_init_family.assign(g0->var_init_family, g0->var_init_family + NV);
+    if (g0->var_init) N.var_init.assign(g0->var_init, g0->var_init + NV);
+    for (long long f = 0; f < NF; ++f) {
+        const int t = g0->factor_type[f];
+        if (t != RXHIP_NODE_NORMAL_MEAN_PRECISION && t != RXHIP_NODE_MVNORMAL_MEAN_PRECISION) continue;
+        const long long w = iface(g0, f, 2);
+        if (g0->var_kind[w] != RXHIP_VARKIND_CONST) continue;
+        const int d = g0->var_rows[w];
+        const double* W;
+        if (g0->var_cols[w] != d || !const_value(g0, w, d, d, &W)) return badarg("precision of a Gaussian node is not a square constant");
+        std::vector<double> a(W, W + (size_t)d * d), inv((size_t)d * d, 0.0);
+        for (int i = 0; i < d; ++i) inv[(size_t)i * d + i] = 1.0;
+        for (int k = 0; k < d; ++k) {  // Gauss–Jordan on an SPD block
+            const double pv = a[(size_t)k * d + k];
+            if (!(pv > 0.0)) return badarg("precision of a Gaussian node is not positive definite");
+            for (int j = 0; j < d; ++j) { a[(size_t)k * d + j] /= pv; inv[(size_t)k * d + j] /= pv; }
+            for (int i = 0; i < d; ++i) {
+                if (i == k) continue;
+                const double f2 = a[(size_t)i * d + k];
+                if (f2 == 0.0) continue;
+                for (int j = 0; j < d; ++j) { a[(size_t)i * d + j] -= f2 * a[(size_t)k * d + j]; inv[(size_t)i * d + j] -= f2 * inv[(size_t)k * d + j]; }
+            }
+        }
+        for (int i = 0; i < d; ++i)  // exact symmetry of the covariance the kernels will read
+            for (int j = 0; j < i; ++j) inv[(size_t)i * d + j] = inv[(size_t)j * d + i] = 0.5 * (inv[(size_t)i * d + j] + inv[(size_t)j * d + i]);
+        const long long nv = (long long)N.var_kind.size();
+        N.var_kind.push_back(RXHIP_VARKIND_CONST);
+        N.var_rows.push_back(d);
+        N.var_cols.push_back(d);
+        N.var_const.push_back((long long)N.pool.size());
+        if (!N.var_init_family.empty()) N.var_init_family.push_back(RXHIP_INIT_NONE);
+        if (!N.var_init.empty()) N.var_init.push_back(-1);
+        N.pool.insert(N.pool.end(), inv.begin(), inv.end());
+        N.factor_iface[(size_t)3 * f + 2] = nv;
+        N.factor_type[f] = t == RXHIP_NODE_NORMAL_MEAN_PRECISION ? RXHIP_NODE_NORMAL_MEAN_VARIANCE : RXHIP_NODE_MVNORMAL_MEAN_COV;
+    }
+    N.g = *g0;
+    N.g.n_variables = (long long)N.var_kind.size();
+    N.g.var_kind = N.var_kind.data(); N.g.var_rows = N.var_rows.data(); N.g.var_cols = N.var_cols.data(); N.g.var_const = N.var_const.data();
+    N.g.factor_type = N.factor_type.data(); N.g.factor_iface = N.factor_iface.data();
+    N.g.const_pool = N.pool.data(); N.g.n_const = (long long)N.pool.size();
+    N.g.var_init_family = N.var_init_family.empty() ? nullptr : N.var_init_family.data();
+    N.g.var_init = N.var_init.empty() ? nullptr : N.var_init.data();
+    return RXHIP_OK;
+}
+
 inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
     if (rxhip_status st = check_tables(g)) return st;
+    NormalisedGraph norm;
+    {
+        bool changed = false;
+        if (rxhip_status st = normalise_precision_nodes(g, norm, changed)) return st;
+        if (changed) g = &norm.g;
+    }
     const long long NV = g->n_variables, NF = g->n_factors;
     for (long long f = 0; f < NF; ++f)
         if (n_iface(g, f) != 3) return unsupported("node with " + std::to_string(n_iface(g, f)) + " interfaces in a state-space chain");

@@ -2617,7 +2617,13 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
         d.device = device; d.stream = stream;
         return rxhip_mvgmm_create(&d, out);
     }
-    if (rxhip_lower::has_node(g, RXHIP_NODE_NORMAL_MIXTURE) || rxhip_lower::has_node(g, RXHIP_NODE_NORMAL_MEAN_PRECISION)) {
+    // `NormalMeanPrecision` with a RANDOM precision is the iid Gaussian×Gamma model; with constant precisions it is a Gaussian
+    // chain written in precision form (test/inference/prediction_tests.jl:197-213) and belongs to the state-space lowering
+    bool random_precision = false;
+    for (long long f = 0; f < g->n_factors && !random_precision; ++f)
+        random_precision = g->factor_type[f] == RXHIP_NODE_NORMAL_MEAN_PRECISION && rxhip_lower::n_iface(g, f) == 3 &&
+                           g->var_kind[rxhip_lower::iface(g, f, 2)] == RXHIP_VARKIND_RANDOM;
+    if (rxhip_lower::has_node(g, RXHIP_NODE_NORMAL_MIXTURE) || random_precision) {
         rxhip_lower::Gmm M;
         rxhip_status st = rxhip_lower::lower_gmm(g, M);
         if (st) return st;

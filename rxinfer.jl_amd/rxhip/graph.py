@@ -65,6 +65,12 @@ class GraphBuilder:
         self._n += v.size
         return self._var(_lib.VARKIND_CONST, rows, cols, off, name=name)
 
+    def const_value(self, var):
+        """value of a constant variable (vector, or matrix for cols > 1)"""
+        pool = np.concatenate(self.pool)
+        v = pool[self.coff[var]:self.coff[var] + self.rows[var] * self.cols[var]]
+        return v.reshape(self.rows[var], self.cols[var]) if self.cols[var] > 1 else v.copy()
+
     # ---- exchange format "rxhip-graph-1": what HIPInferencePlugin.jl's `dump_graph` writes after walking a GraphPPL model ----
     def to_dump(self, n_replicas=1, n_observations=0):
         pool = np.concatenate(self.pool) if self.pool else np.zeros(0)
@@ -223,14 +229,19 @@ def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=No
     return gb, xs, ys
 
 
-def scalar_chain_graph(T, a, b, p, q, m0, v0, prior_through_transition=False, spell="normal"):
+def scalar_chain_graph(T, a, b, p, q, m0, v0, prior_through_transition=False, spell="normal", precision=False):
     """Scalar random-walk / AR(1) chains in the spellings RxInfer users write them:
     spell = "normal":  x[t] ~ Normal(mean = x[t-1], var = p), y[t] ~ Normal(mean = x[t], var = q)   (a = b = 1, no `*` nodes)
     spell = "scaled":  x[t] ~ Normal(mean = a * x[t-1], var = p), y[t] ~ Normal(mean = b * x[t], var = q)
-    spell = "mixed":   `*` on the transition only."""
+    spell = "mixed":   `*` on the transition only.
+    precision = True: every Gaussian node is `NormalMeanPrecision(μ, 1/var)` (test/inference/prediction_tests.jl:197-213)."""
     gb = GraphBuilder()
     x = gb.randomvar(1)
-    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, x, gb.constvar(m0), gb.constvar(v0))
+    if precision:
+        normal = lambda out, mu, var: gb.node(_lib.NODE_NORMAL_MEAN_PRECISION, out, mu, gb.constvar(1.0 / var))
+    else:
+        normal = lambda out, mu, var: gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, out, mu, gb.constvar(var))
+    normal(x, gb.constvar(m0), v0)
     xs, ys = [], []
     for t in range(T):
         if t > 0 or prior_through_transition:
@@ -239,14 +250,14 @@ def scalar_chain_graph(T, a, b, p, q, m0, v0, prior_through_transition=False, sp
                 mu = gb.randomvar(1)
                 gb.multiply(mu, gb.constvar(a), x)
             xn = gb.randomvar(1)
-            gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, xn, mu, gb.constvar(p))
+            normal(xn, mu, p)
             x = xn
         mu = x
         if spell == "scaled":
             mu = gb.randomvar(1)
             gb.multiply(mu, gb.constvar(b), x)
         y = gb.datavar(1)
-        gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y, mu, gb.constvar(q))
+        normal(y, mu, q)
         xs.append(x); ys.append(y)
     return gb, xs, ys
 

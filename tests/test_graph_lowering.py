@@ -243,6 +243,36 @@ def test_scalar_chain_spellings_are_recognised():
             assert low["m0"][0] == -1.0 and low["V0"][0, 0] == 25.0 and list(low["data_var"]) == ys and list(low["state_var"]) == xs
 
 
+def test_precision_parametrised_chains_are_the_covariance_form():
+    """`x[i] ~ NormalMeanPrecision(z, 1.0)`, `y[i] ~ NormalMeanPrecision(x[i], 1.0)` (test/inference/prediction_tests.jl:197-213)
+    and `MvNormal(μ = …, Λ = …)` transitions: constant precisions are inverted once, the chain lowers as before."""
+    for ptt in (False, True):
+        gb, xs, ys = graph.scalar_chain_graph(7, 1.0, 1.0, 0.25, 4.0, -1.0, 0.5, prior_through_transition=ptt, precision=True)
+        low = graph.lower_lgssm(gb.tables(permute=np.random.default_rng(2).permutation(len(gb.ftype)))[0])
+        ref = graph.lower_lgssm(graph.scalar_chain_graph(7, 1.0, 1.0, 0.25, 4.0, -1.0, 0.5, prior_through_transition=ptt)[0].tables()[0])
+        for k in ("A", "B", "P", "Q", "m0", "V0"):
+            assert np.allclose(low[k], ref[k], rtol=1e-15, atol=0), k
+        assert (low["T"], low["prior_through_transition"]) == (7, ptt) and list(low["data_var"]) == ys and list(low["state_var"]) == xs
+    # vector chain: Λ-parametrised transition and observation nodes
+    mdl = workloads.random_model(3, 2, seed=4)
+    gb, xs, ys = graph.lgssm_graph(6, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    for f, t in enumerate(gb.ftype):
+        if t == _lib.NODE_MVNORMAL_MEAN_COV:
+            it = list(gb.fiface[f])
+            it[2] = gb.constvar(np.linalg.inv(np.asarray(gb.const_value(it[2]))))
+            gb.fiface[f] = tuple(it)
+            gb.ftype[f] = _lib.NODE_MVNORMAL_MEAN_PRECISION
+    low = graph.lower_lgssm(gb.tables()[0])
+    P, Q = np.reshape(low["P"], (-1, 3, 3))[0], np.reshape(low["Q"], (-1, 2, 2))[0]
+    assert np.allclose(P, mdl["P"], rtol=1e-12) and np.allclose(Q, mdl["Q"], rtol=1e-12) and np.allclose(low["V0"], mdl["V0"], rtol=1e-12)
+    assert np.array_equal(P, P.T)
+    # a precision that is not positive definite is a malformed model, not an unsupported one
+    gb, _, _ = graph.scalar_chain_graph(3, 1.0, 1.0, -0.25, 4.0, 0.0, 1.0, precision=True)
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_lgssm(gb.tables()[0])
+    assert ei.value.status == _lib.ERR_BADARG and "positive definite" in str(ei.value)
+
+
 def test_identity_observation_in_a_vector_chain():
     """`y[t] ~ MvNormal(μ = x[t], Σ = Q)` without a `*` node: B = I."""
     mdl = workloads.random_model(3, 3, seed=2)

@@ -192,3 +192,36 @@ def test_masked_filtering_skips_the_update():
                 m, V = m + K @ (y[c, t] - B @ m), V - K @ B @ V
             assert np.allclose(mean[c, t], m, rtol=1e-6, atol=1e-9)
             assert np.allclose(cov[c, t], V, rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("data", [[1.0, -500.0, np.nan, 100.0], [1.0, -500.0, np.nan, 100.0, np.nan, np.nan]], ids=["one_missing", "missing_tail"])
+@pytest.mark.parametrize("iterations", [10, 20])
+def test_reference_prediction_test_with_missing_values_in_an_array(data, iterations):
+    """test/inference/prediction_tests.jl:197-250 ("test #1: array with missing + KeepLast predictvars"): the random walk
+    x_0 ~ NormalMeanPrecision(0, 1); x[i] ~ NormalMeanPrecision(x[i-1], 1); y[i] ~ NormalMeanPrecision(x[i], 1) with two further
+    states observed by o[1], o[2], for which no data is given.  The graph the plugin would emit (precision-parametrised nodes,
+    `missing` entries inside y, o never observed) runs on the device: a prediction for every y[i] and both o, posteriors and
+    predictions equal to the oracle's smoother that skips the missing rows — in every iteration (a tree: the iterations agree)."""
+    import rxhip
+    from rxhip import graph
+    n = len(data)
+    gb, xs, ys = graph.scalar_chain_graph(n + 2, 1.0, 1.0, 1.0, 1.0, 0.0, 1.0, prior_through_transition=True, precision=True)
+    yfull = np.array(data + [np.nan, np.nan])          # o[1], o[2]: predictvars without data
+    with graph.create_engine_from_graph(gb.tables(allow_missing=True)[0]) as eng:
+        eng.set_data(yfull.reshape(n + 2, 1, 1))
+        eng.run(iterations, True)
+        mean, cov = eng.marginals()
+        pm, pc = eng.predictions()
+        fe = eng.free_energy()
+    assert pm.shape == (n + 2, 1, 1) and np.all(np.isfinite(pm)) and np.all(pc > 0)   # length(predictions[:y]) == length(data), 2 for o
+    assert fe.shape == (iterations,) and np.all(fe == fe[0])
+    one = (np.eye(1), np.eye(1), np.eye(1), np.eye(1), np.zeros(1), np.eye(1))
+    om, oc, nll = rxo.lgssm_kalman_rts(*one, yfull.reshape(-1, 1), prior_through_transition=True)
+    assert np.allclose(mean[:, 0], om, rtol=1e-6, atol=1e-9) and np.allclose(cov[:, 0], oc, rtol=1e-6, atol=1e-9)
+    assert fe[-1] == pytest.approx(nll, rel=1e-8)
+    for t in range(n + 2):
+        yl = yfull.copy()
+        yl[t] = np.nan                                   # the message toward y[t] never contains y[t]
+        lm, lc, _ = rxo.lgssm_kalman_rts(*one, yl.reshape(-1, 1), prior_through_transition=True)
+        assert pm[t, 0, 0] == pytest.approx(lm[t, 0], rel=1e-6, abs=1e-8) and pc[t, 0, 0, 0] == pytest.approx(lc[t, 0, 0] + 1.0, rel=1e-6)
