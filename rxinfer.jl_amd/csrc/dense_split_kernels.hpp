@@ -268,4 +268,123 @@ __global__ void __launch_bounds__(64) kd_split_backward(SplitParams q) {
     }
 }
 
+// ---- D = 48, 64: the table rows of a step go through LDS ------------------------------------------------------------------
+// At these sizes a lane cannot hold the columns of the next step in registers, and reading them when they are needed made every
+// step a chain of L2 round trips (26 µs per step at D = 64).  Here a workgroup of four wavefronts serves four chains of ONE
+// segment: the 2·D² (forward) or D² (backward) table doubles of the next step are fetched by all 256 threads (coalesced, in
+// flight under the current step) and parked in the other half of a double buffer; the products read LDS rows (consecutive
+// lanes, consecutive addresses) and get x_k by v_readlane.  One barrier per step.
+__device__ __forceinline__ double wave_bcast(double v, int k) {  // lane k of the wavefront (k uniform)
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), k), hi = __builtin_amdgcn_readlane(__double2hiint(v), k);
+    return __hiloint2double(hi, lo);
+}
+template <int D>
+__device__ __forceinline__ double lds_matvec(const double* Mt, int i, double x) {  // Σ_k Mt[k·D + i] x_k, Mt in LDS
+    double s[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 16
+    for (int k = 0; k < D; ++k) s[k & 3] += Mt[k * D + i] * wave_bcast(x, k);
+    return (s[0] + s[1]) + (s[2] + s[3]);
+}
+template <int N>   // N doubles per thread of a contiguous block of 256·N doubles (a wavefront instruction covers 512 contiguous bytes)
+struct StageRegs {
+    double v[N];
+    __device__ __forceinline__ void load(const double* __restrict__ src, int tid) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = src[j * 256 + tid];
+    }
+    __device__ __forceinline__ void store(double* dst, int tid) const {
+#pragma unroll
+        for (int j = 0; j < N; ++j) dst[j * 256 + tid] = v[j];
+    }
+};
+__host__ __device__ inline size_t split_lds_bytes(int D, int matrices) { return sizeof(double) * 2 * (size_t)matrices * D * D; }
+
+template <int D>
+__global__ void __launch_bounds__(256) kd_split_forward_lds(SplitParams q) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr size_t DD = (size_t)D * D, TS = 3 * DD;
+    constexpr int NPT = (int)(2 * DD / 256);   // doubles per thread and step: C_t | G_t (contiguous in the table row)
+    static_assert((2 * DD) % 256 == 0, "whole doubles over 256 threads");
+    const DenseParams& p = q.p;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane < D ? lane : D - 1;
+    const long long seg = blockIdx.y;
+    long long chain = (long long)blockIdx.x * 4 + w;
+    const bool live = chain < p.n_chains && lane < D;
+    if (chain >= p.n_chains) chain = p.n_chains - 1;   // idle wavefronts follow the last chain (uniform control flow, no stores)
+    const long long b0 = 1 + seg * p.L;
+    long long b1 = b0 + p.L;
+    if (b1 > p.T) b1 = p.T;
+    const long long len = b1 - b0, t0 = seg * p.L + 1;
+    double* filt = p.filt + chain * p.T * q.rec;
+    double xi = split_matvec<D>(p.bnd + ((size_t)seg * 2 + 0) * DD, i, 0, p.fstart_m[(chain * p.S + seg) * D + i]);
+    double gyn = len > 0 ? filt[t0 * q.rec + D + i] : 0.0;
+    StageRegs<NPT> st;
+    if (len > 0) {
+        st.load(q.dtab + (size_t)(t0 - 1) * TS, tid);
+        st.store(smem, tid);
+    }
+    __syncthreads();
+    for (long long s = 0; s < len; ++s) {
+        const long long t = t0 + s;
+        const double* buf = smem + (s & 1) * 2 * DD;
+        const long long tn = s + 1 < len ? t + 1 : t;            // unconditional prefetch (the last one re-reads this step's rows)
+        st.load(q.dtab + (size_t)(tn - 1) * TS, tid);
+        double* rec = filt + (t - 1) * q.rec;
+        const double gyc = gyn;
+        gyn = filt[tn * q.rec + D + i];
+        const double cxi = lds_matvec<D>(buf, i, xi);             // C_{t−1} ξ_f(t−1)
+        const double axi = lds_matvec<D>(buf + DD, i, xi);        // G′_{t−1} ξ_f(t−1)
+        if (live) {
+            rec[i] = xi;
+            rec[2 * D + i] = cxi;
+        }
+        xi = gyc + axi;                                           // ξ_f(t)
+        st.store(smem + ((s + 1) & 1) * 2 * DD, tid);             // nobody reads that half before the barrier below
+        __syncthreads();
+    }
+    if (live && seg == p.S - 1) filt[(t0 + len - 1) * q.rec + i] = xi;
+}
+
+template <int D>
+__global__ void __launch_bounds__(256) kd_split_backward_lds(SplitParams q) {
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    constexpr size_t DD = (size_t)D * D, TS = 3 * DD;
+    constexpr int NPT = (int)(DD / 256);
+    static_assert(DD % 256 == 0, "whole doubles over 256 threads");
+    const DenseParams& p = q.p;
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, i = lane < D ? lane : D - 1;
+    const long long seg = blockIdx.y;
+    long long chain = (long long)blockIdx.x * 4 + w;
+    const bool live = chain < p.n_chains && lane < D;
+    if (chain >= p.n_chains) chain = p.n_chains - 1;
+    const long long b0 = 1 + seg * p.L;
+    long long b1 = b0 + p.L;
+    if (b1 > p.T) b1 = p.T;
+    const long long len = b1 - b0, tb = seg * p.L, te = tb + len;
+    const double* filt = p.filt + chain * p.T * q.rec;
+    const double xf = filt[te * q.rec + i] + p.beta_xi[(chain * (p.S + 1) + seg + 1) * D + i];
+    const bool last = seg == p.S - 1;
+    double ms = split_matvec<D>(last ? q.vlast : p.bnd + ((size_t)seg * 2 + 1) * DD, i, 0, xf);
+    if (live && last) dense_store_mean(p, te, chain, i, ms);
+    double cxn = len > 0 ? filt[(te - 1) * q.rec + 2 * D + i] : 0.0;
+    StageRegs<NPT> st;
+    if (len > 0) {
+        st.load(q.dtab + (size_t)(te - 1) * TS + 2 * DD, tid);
+        st.store(smem, tid);
+    }
+    __syncthreads();
+    long long n = 0;
+    for (long long t = te - 1; t >= tb; --t, ++n) {
+        const double* buf = smem + (n & 1) * DD;
+        const long long tn = t - 1 >= tb ? t - 1 : tb;
+        st.load(q.dtab + (size_t)tn * TS + 2 * DD, tid);
+        const double cx = cxn;
+        cxn = filt[tn * q.rec + 2 * D + i];
+        ms = cx + lds_matvec<D>(buf, i, ms);                      // C_t ξ_f(t) + G_t m_s(t+1)
+        if (live) dense_store_mean(p, t, chain, i, ms);
+        st.store(smem + ((n + 1) & 1) * DD, tid);
+        __syncthreads();
+    }
+}
+
 }  // namespace rxhip

@@ -1971,15 +1971,20 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_beta_xi, sizeof(double) * C * (Sg + 1) * D);
         ap.plain(&e->d_fe_chain, sizeof(double) * CU);
         // One model for at least four workgroups' worth of chains: the matrices of the information-form smoother are computed
-        // once (model pass on one chain), every sweep is vectors only.  Kernel dimensions 16 and 32 (d ≤ 32): there the
-        // lane-per-component data pass wins 2–2.6× (d = 8 × 1024 chains × T = 1000: 1.86 -> 0.77 ms); at 48 / 64 its table
-        // reads are a latency chain per step (5.3 against 5.7 ms at d = 64 × 64 chains) — a chains-as-columns MFMA data
-        // pass is the form that fits there.  RXHIP_DENSE_SPLIT=0/1 overrides (tests).
+        // once (model pass on one chain), every sweep is vectors only (d = 8 × 1024 chains × T = 1000: 1.86 -> 0.77 ms;
+        // d = 64 × 64 chains: 5.70 -> 1.92 ms).  RXHIP_DENSE_SPLIT=0/1 overrides (tests).
         {
             const char* sp_env = std::getenv("RXHIP_DENSE_SPLIT");
-            e->split = e->n_models == 1 && e->S > 0 && (sp_env ? std::atoi(sp_env) != 0 : (e->wg_chains >= 4 && e->nt <= 2));
+            e->split = e->n_models == 1 && e->S > 0 && (sp_env ? std::atoi(sp_env) != 0 : e->wg_chains >= 4);
         }
         if (e->split) {
+            static std::once_flag split_once;
+            std::call_once(split_once, [] {
+                for (const void* f : {(const void*)kd_split_forward_lds<48>, (const void*)kd_split_forward_lds<64>, (const void*)kd_split_backward_lds<48>,
+                                      (const void*)kd_split_backward_lds<64>})
+                    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            });
+            (void)hipGetLastError();
             ap.plain(&e->d_dtab, sizeof(double) * T * 3 * D * D);
             ap.plain(&e->d_vlast, sizeof(double) * D * D);
             ap.plain(&e->d_vstab, sizeof(double) * T * Du * Du);
@@ -2977,19 +2982,20 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 const int gpw = 64 / e->dpad;
                 const unsigned nblk_units = (unsigned)(((long long)e->wg_chains * e->S + gpw - 1) / gpw);
                 if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
+                const dim3 lds_grid((unsigned)((e->wg_chains + 3) / 4), (unsigned)e->S);  // four chains of one segment per workgroup
                 switch (e->nt) {
                     case 1: hipLaunchKernelGGL(kd_split_forward<16>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
                     case 2: hipLaunchKernelGGL(kd_split_forward<32>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
-                    case 3: hipLaunchKernelGGL(kd_split_forward<48>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
-                    default: hipLaunchKernelGGL(kd_split_forward<64>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
+                    case 3: hipLaunchKernelGGL(kd_split_forward_lds<48>, lds_grid, dim3(256), split_lds_bytes(48, 2), e->stream, sq); break;
+                    default: hipLaunchKernelGGL(kd_split_forward_lds<64>, lds_grid, dim3(256), split_lds_bytes(64, 2), e->stream, sq); break;
                 }
                 if ((st = prof_end(e))) return st;
                 if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
                 switch (e->nt) {
                     case 1: hipLaunchKernelGGL(kd_split_backward<16>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
                     case 2: hipLaunchKernelGGL(kd_split_backward<32>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
-                    case 3: hipLaunchKernelGGL(kd_split_backward<48>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
-                    default: hipLaunchKernelGGL(kd_split_backward<64>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
+                    case 3: hipLaunchKernelGGL(kd_split_backward_lds<48>, lds_grid, dim3(256), split_lds_bytes(48, 1), e->stream, sq); break;
+                    default: hipLaunchKernelGGL(kd_split_backward_lds<64>, lds_grid, dim3(256), split_lds_bytes(64, 1), e->stream, sq); break;
                 }
                 hipLaunchKernelGGL(kd_split_broadcast, dim3(2048), dim3(256), 0, e->stream, sq, (long long)e->n_chains, fe ? 1 : 0);
                 if ((st = prof_end(e))) return st;
