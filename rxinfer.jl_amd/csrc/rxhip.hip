@@ -2979,21 +2979,20 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                     hipLaunchKernelGGL(kd_split_save, dim3(256), dim3(256), 0, e->stream, sq, (long long)e->n_chains);
                     e->split_ready = true;
                 }
-                const int gpw = 64 / e->dpad;
-                const unsigned nblk_units = (unsigned)(((long long)e->wg_chains * e->S + gpw - 1) / gpw);
                 if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
-                const dim3 lds_grid((unsigned)((e->wg_chains + 3) / 4), (unsigned)e->S);  // four chains of one segment per workgroup
+                const long long per_wg = 4 * (64 / e->dpad);  // chains of one segment per workgroup
+                const dim3 lds_grid((unsigned)((e->wg_chains + per_wg - 1) / per_wg), (unsigned)e->S);
                 switch (e->nt) {
-                    case 1: hipLaunchKernelGGL(kd_split_forward<16>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
-                    case 2: hipLaunchKernelGGL(kd_split_forward<32>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
+                    case 1: hipLaunchKernelGGL(kd_split_forward_lds<16>, lds_grid, dim3(256), split_lds_bytes(16, 2), e->stream, sq); break;
+                    case 2: hipLaunchKernelGGL(kd_split_forward_lds<32>, lds_grid, dim3(256), split_lds_bytes(32, 2), e->stream, sq); break;
                     case 3: hipLaunchKernelGGL(kd_split_forward_lds<48>, lds_grid, dim3(256), split_lds_bytes(48, 2), e->stream, sq); break;
                     default: hipLaunchKernelGGL(kd_split_forward_lds<64>, lds_grid, dim3(256), split_lds_bytes(64, 2), e->stream, sq); break;
                 }
                 if ((st = prof_end(e))) return st;
                 if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
                 switch (e->nt) {
-                    case 1: hipLaunchKernelGGL(kd_split_backward<16>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
-                    case 2: hipLaunchKernelGGL(kd_split_backward<32>, dim3(nblk_units), dim3(64), 0, e->stream, sq); break;
+                    case 1: hipLaunchKernelGGL(kd_split_backward_lds<16>, lds_grid, dim3(256), split_lds_bytes(16, 1), e->stream, sq); break;
+                    case 2: hipLaunchKernelGGL(kd_split_backward_lds<32>, lds_grid, dim3(256), split_lds_bytes(32, 1), e->stream, sq); break;
                     case 3: hipLaunchKernelGGL(kd_split_backward_lds<48>, lds_grid, dim3(256), split_lds_bytes(48, 1), e->stream, sq); break;
                     default: hipLaunchKernelGGL(kd_split_backward_lds<64>, lds_grid, dim3(256), split_lds_bytes(64, 1), e->stream, sq); break;
                 }
