@@ -180,6 +180,26 @@ def extra_c3(device):
             "create_set_data_first_run_ms": create_ms}
 
 
+def extra_mid(device):
+    """Not BASELINE configs: batches of one model at mid-size state dimensions on the MFMA path (model pass once per engine,
+    data pass per sweep — DESIGN §6b), 1 BP sweep + free energy per step."""
+    out = {}
+    for d, dy, C, T in ((8, 4, 1024, 1000), (64, 64, 64, 1000)):
+        m = workloads.random_model(d, dy, seed=d)
+        y = workloads.generate_batch(m, T, 8, seed0=1)
+        y = np.tile(y, (1, C // 8, 1))
+        t0 = time.perf_counter()
+        eng = rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=T, n_chains=C, device=device)
+        eng.set_data(y)
+        eng.run(1, True)
+        first = (time.perf_counter() - t0) * 1e3
+        ms, kt = timed_sweeps(eng, 10, 2)
+        eng.close()
+        out[f"d{d}_chains{C}_T{T}"] = {"ms_per_step": ms, "steps_per_s": T * C / (ms * 1e-3), "kernels_ms_avg": kt,
+                                       "create_set_data_first_run_ms": first}
+    return out
+
+
 def extra_c4(device):
     """BASELINE config 4 on one GPU: 4096 HGF series × T = 2000, 10 VMP iterations per observation, GH-31."""
     S, T, iters = 4096, 2000, 10
@@ -411,7 +431,7 @@ def main():
         extra = {}
         for name, fn in (("per_chain_models", lambda: extra_per_chain_models(mdl, T, C, y, local_rank)), ("c1", lambda: extra_c1(local_rank, not args.no_cpu_baseline)),
                          ("c2_missing", lambda: extra_missing(mdl, T, C, y, local_rank)), ("c3", lambda: extra_c3(local_rank)),
-                         ("c4", lambda: extra_c4(local_rank)), ("c5", lambda: extra_c5(local_rank))):
+                         ("c4", lambda: extra_c4(local_rank)), ("c5", lambda: extra_c5(local_rank)), ("mid_sizes", lambda: extra_mid(local_rank))):
             try:
                 extra[name] = fn()
             except Exception as e:  # noqa: BLE001 — an extra line must never cost the headline line
