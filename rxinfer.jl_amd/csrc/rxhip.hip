@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <mutex>
+#include <set>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -519,6 +520,19 @@ struct DevGuardLite {
     }
     ~DevGuardLite() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
 };
+
+// The dynamic-LDS ceiling of a kernel is a per-device function attribute: set once per (kernel group, device), never per process
+// (a host that drives several GPUs from one process would otherwise launch with the default 64 KB on every device but the first).
+template <class F>
+static void once_per_device(int group, int device, F set) {
+    static std::mutex m;
+    static std::set<std::pair<int, int>> done;
+    std::lock_guard<std::mutex> g(m);
+    if (done.insert({group, device}).second) {
+        set();
+        (void)hipGetLastError();
+    }
+}
 
 // ---- per-model device tables of the MFMA path, shared between engines ---------------------------------------------
 // Constants, per-offset aggregation maps, boundary-scan maps and the boundary inverses depend on the model and the
@@ -1798,12 +1812,10 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     }
     if (e->gseq) {  // no tables: the user-level constants, the priors, the outputs
         e->S = 0; e->L = 1; e->Llast = 1;
-        static std::once_flag lds_once;
-        std::call_once(lds_once, [] {
+        once_per_device(0, e->device, [] {
             (void)hipFuncSetAttribute((const void*)k_gseq_forward, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             (void)hipFuncSetAttribute((const void*)k_gseq_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
         });
-        (void)hipGetLastError();
         const size_t CU = (size_t)e->n_chains, Du = (size_t)e->d;
         ArenaPlan ap;
         ap.upload(&e->d_user, e->h_user.data(), sizeof(double) * e->h_user.size());
@@ -1978,13 +1990,11 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             e->split = e->n_models == 1 && e->S > 0 && (sp_env ? std::atoi(sp_env) != 0 : e->wg_chains >= 4);
         }
         if (e->split) {
-            static std::once_flag split_once;
-            std::call_once(split_once, [] {
+            once_per_device(1, e->device, [] {
                 for (const void* f : {(const void*)kd_split_forward_lds<48>, (const void*)kd_split_forward_lds<64>, (const void*)kd_split_backward_lds<48>,
                                       (const void*)kd_split_backward_lds<64>})
                     (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
             });
-            (void)hipGetLastError();
             ap.plain(&e->d_dtab, sizeof(double) * T * 3 * D * D);
             ap.plain(&e->d_vlast, sizeof(double) * D * D);
             ap.plain(&e->d_vstab, sizeof(double) * T * Du * Du);
@@ -2841,9 +2851,7 @@ rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, d
     sp.step_model = e->d_step_model; sp.cx = e->d_cx; sp.cy = e->d_mu ? e->d_cy_raw : nullptr; sp.off_chain = e->off_chain ? 1 : 0;
     sp.mean = e->d_stream + o_m; sp.cov = e->d_stream + o_c; sp.fe = e->d_stream + o_f; sp.status = e->d_status;
     if (e->dense) {  // any d, dy ≤ 64: one workgroup per chain on the user-level constants (gseq_kernels.hpp)
-        static std::once_flag lds_once;
-        std::call_once(lds_once, [] { (void)hipFuncSetAttribute((const void*)k_gseq_stream_step, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
-        (void)hipGetLastError();
+        once_per_device(2, e->device, [] { (void)hipFuncSetAttribute((const void*)k_gseq_stream_step, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
         GseqStreamParams gs{};
         gs.n_chains = sp.n_chains; gs.k = sp.k; gs.d = e->d; gs.dy = e->dy; gs.ptt = sp.ptt; gs.first = sp.first; gs.y = sp.y; gs.state = sp.state;
         gs.user = e->d_user; gs.prior = e->d_prior; gs.chain_model = sp.chain_model; gs.step_model = sp.step_model; gs.cx = sp.cx; gs.cy = sp.cy;
@@ -3244,10 +3252,8 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
     SET_DEVICE(e);
     const size_t rows = (size_t)e->Tout() * e->n_chains, dy = (size_t)e->dy;
     if (e->dense) {  // any d, dy ≤ 64: observation-space form, one workgroup per (chain, time index)
-        static std::once_flag lds_once;
         // 133 KB of dynamic LDS at d = dy = 64 (the kernel also holds a few bytes of static LDS: not the full 160 KB)
-        std::call_once(lds_once, [] { (void)hipFuncSetAttribute((const void*)k_predict_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
-        (void)hipGetLastError();
+        once_per_device(3, e->device, [] { (void)hipFuncSetAttribute((const void*)k_predict_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
         double* tmp = nullptr;
         HIPCHK(e, hipMalloc(&tmp, sizeof(double) * rows * (dy + dy * dy)));
         GenericParams gp{};
