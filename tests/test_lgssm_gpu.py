@@ -278,3 +278,26 @@ def test_one_round_trip_inference_equals_the_plain_sequence():
             m4, c4, f4 = eng.infer(y, free_energy=True, filtering=True)
         assert np.array_equal(m4, fm) and np.array_equal(c4, fc) and np.array_equal(f4, ff)
         assert np.array_equal(m1, m2) and np.array_equal(c1, c2) and np.array_equal(f1, f2) and np.array_equal(m3, m2)
+
+
+def test_model_tables_timing_entry_point(monkeypatch):
+    """rxhip_get_model_tables_ms: device time of what an engine computes once because it depends on the model only — positive for
+    a shared-model batch on the one-pass schedule, zero for an engine without such tables; the sweep results do not depend on
+    when it is asked."""
+    mdl = workloads.random_model(3, 2, seed=8)
+    args = (mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    y = workloads.generate_batch(mdl, 300, 64, seed0=2)
+    monkeypatch.setenv("RXHIP_ONE_PASS", "1")
+    with rxhip.LGSSMEngine(*args, T=300, n_chains=64) as eng:
+        ms = eng.model_tables_ms()
+        assert 0.0 < ms < 1e3
+        eng.set_data(y)
+        eng.run(1, True)
+        m1, fe1 = eng.marginals()[0].copy(), eng.free_energy()[-1]
+        assert eng.model_tables_ms() == ms      # the events of creation, not of the sweep
+    monkeypatch.setenv("RXHIP_ONE_PASS", "0")
+    with rxhip.LGSSMEngine(*args, T=300, n_chains=64) as eng:
+        assert eng.model_tables_ms() == 0.0
+        eng.set_data(y)
+        eng.run(1, True)
+        assert rel(eng.marginals()[0], m1) < 1e-9 and abs(eng.free_energy()[-1] - fe1) < 1e-9 * abs(fe1)
