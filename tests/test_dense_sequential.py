@@ -111,6 +111,29 @@ def test_kernel_source_on_the_host_with_one_model_per_chain(emu):
         assert nll[c] == pytest.approx(onll, rel=1e-11)
 
 
+@pytest.mark.parametrize("T,ptt", [(1, False), (1, True), (5, True)])
+def test_kernel_source_on_the_host_edge_cases(emu, T, ptt):
+    """A single time index, and a chain that never observes anything (the posterior is the prior pushed through the
+    transitions, the evidence is 1)."""
+    rng = np.random.default_rng(40 + T)
+    d, dy, C = 6, 4, 2
+    mdl = _models(rng, d, dy, 1)
+    one = tuple(x[0] for x in mdl)
+    y = _simulate(rng, mdl, np.zeros(T, dtype=np.int32), C, ptt)
+    y[1] = np.nan                                       # chain 1 observes nothing
+    mean, cov, nll = _emu_run(emu, mdl, y, ptt)
+    for c in range(C):
+        om, oc, onll = rxo.lgssm_kalman_rts(*one, y[c], prior_through_transition=ptt)
+        assert np.allclose(mean[c], om, rtol=1e-10, atol=1e-12) and np.allclose(cov[c], oc, rtol=1e-10, atol=1e-12)
+        assert nll[c] == pytest.approx(onll, rel=1e-11, abs=1e-13)
+    assert nll[1] == 0.0
+    m, V = one[4], one[5]
+    for t in range(T):
+        if t or ptt:
+            m, V = one[0] @ m, one[0] @ V @ one[0].T + one[2]
+        assert np.allclose(mean[1, t], m, rtol=1e-12) and np.allclose(cov[1, t], V, rtol=1e-12)
+
+
 def test_stream_step_source_on_the_host_matches_the_filtering_oracle(emu):
     """k_gseq_stream_step (rxhip_filter_step at d > 4) one observation at a time, with per-step constants, known inputs and
     missing observations, against the oracle's smoother of the observations seen so far (its last belief is the filtered one)."""
