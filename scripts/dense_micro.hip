@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(256) t_step(const double* X, const double* Y, 
 int main() {
     std::vector<double> h(D * D);
     for (int i = 0; i < D; ++i) for (int j = 0; j < D; ++j) h[i * D + j] = (i == j ? 70.0 : 0.0) + 1.0 / (1 + i + j);
-    double *M, *out; hipMalloc(&M, D * D * 8); hipMalloc(&out, 256ull * D * D * 8 + 1024);
+    double *M, *out; hipMalloc(&M, D * D * 8); hipMalloc(&out, 1024ull * D * D * 8 + 1024);
     hipMemcpy(M, h.data(), D * D * 8, hipMemcpyHostToDevice);
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     const size_t lds = 150 * 1024;
@@ -77,6 +77,9 @@ int main() {
         printf("%-34s %8.3f ms total  %8.2f us per op\n", name, ms, ms * 1e3 / REP);
     };
     run("gj_inverse 64x64", [&] { hipLaunchKernelGGL(t_gj, dim3(256), dim3(256), lds, 0, M, out); });
+    // two / four workgroups per CU (registers allow two wavefronts per SIMD): what the sweep kernels see with two segments per CU
+    run("gj_inverse 64x64, 512 workgroups", [&] { hipLaunchKernelGGL(t_gj, dim3(512), dim3(256), 16 * 1024, 0, M, out); });
+    run("gj_inverse 64x64, 1024 workgroups", [&] { hipLaunchKernelGGL(t_gj, dim3(1024), dim3(256), 16 * 1024, 0, M, out); });
 #define MM(mode, name) hipFuncSetAttribute((const void*)t_mm<mode>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
     run(name, [&] { hipLaunchKernelGGL(t_mm<mode>, dim3(256), dim3(256), lds, 0, M, M, out); });
     MM(0, "mm LDS x LDS"); MM(1, "mm global X x LDS"); MM(2, "mm LDS x global Y'"); MM(3, "mm LDS' x LDS");
