@@ -355,7 +355,8 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
  * MvNormalMeanCovariance(out = x[t], μ = A x[t-1], Σ = P) between observed states, t = 2 … T, in (out, μ) order:
  * mean (T-1)*n_chains*2d doubles = [m(x[t]); A m(x[t-1])], cov …*2d*2d = [[V(x[t]), (A X)′], [A X, A V(x[t-1]) A′]] with
  * X = Cov(x[t-1], x[t] | y) (either may be NULL), in `layout` ([T-1][chain][·] or [chain][T-1][·]).
- * node_type: RXHIP_NODE_MVNORMAL_MEAN_COV.  After rxhip_run of a state-space engine; d, dy ≤ 4. */
+ * node_type: RXHIP_NODE_MVNORMAL_MEAN_COV.  After rxhip_run of a state-space engine; any d, dy ≤ 64 (d, dy ≤ 4: from the sweep's own
+ * records; above: the sequential kernels recompute the sweep into scratch arrays with Cov(x[t], x[t+1] | y) kept — a getter, not a hot path). */
 rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double* mean, double* cov, int32_t layout);
 
 /* device views of the same results, layout [T][chain][d] and [T][chain][d][d]; valid until the

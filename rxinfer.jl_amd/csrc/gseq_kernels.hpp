@@ -36,6 +36,8 @@ struct GseqParams {
     const int* step_model;   // model of a time index (transition INTO x[t], observation of y[t]), or null
     double* fe_part;         // [chain]  log p(y) of the chain (the reduction kernels negate and scale)
     int* status;
+    double* cross;           // null, or [T−1][chain][d][d]: Cov(x[t], x[t+1] | y) = G_t V_s(t+1), kept by the backward kernel for the
+                             // node-local joints (k_joint_generic)
 };
 __device__ __forceinline__ size_t gseq_model_index(const GseqParams& p, long long chain, long long t) {
     return p.step_model ? (size_t)p.step_model[t] : p.chain_model ? (size_t)p.chain_model[chain] : 0;
@@ -400,6 +402,7 @@ __global__ void __launch_bounds__(256, 4) k_gseq_backward(GseqParams p) {
             mf[i] = s;                                                                    // m_s(t): thread i owns entry i
         }
         __syncthreads();
+        if (p.cross) RXHIP_FOR_2D(md, d, d, i, j) p.cross[row * d * d + i * d + j] = X0[i * ld + j];
         tile_gemm(X1, ld, d, d, d, X0, ld, 1, X3, 1, ld, 1.0, false, tid, nt);           // (G V_s⁺) G′
         tile_gemm(X1, ld, d, d, d, X3, ld, 1, X2, ld, 1, -1.0, true, tid, nt);           // − G (A V_f): same tile owner, no barrier
         __syncthreads();
@@ -416,6 +419,68 @@ __global__ void __launch_bounds__(256, 4) k_gseq_backward(GseqParams p) {
         __syncthreads();
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// Node-local joint marginal of every transition node MvNormalMeanCovariance(out = x[k+1], μ = A x[k] (+ c[k+1]), Σ = P) at any
+// d ≤ 64 (predict_kernels.hpp k_joint is the d ≤ 4 form):
+//     q(out, μ) = N([m_s(k+1); A m_s(k) + c], [[V_s(k+1), (A X)′], [A X, A V_s(k) A′]]),   X = Cov(x[k], x[k+1] | y) = `cross`.
+// One workgroup per (node, chain); A, X and V_s(k) are staged in LDS, the two products run on the register tiles above.
+struct JointParams {
+    long long T, n_chains;
+    int d, dy;
+    const double* mean;      // [T][chain][d]   posteriors of the last smoothing run
+    const double* cov;       // [T][chain][d][d]
+    const double* cross;     // [T−1][chain][d][d]
+    const double* user;
+    const int* chain_model;
+    const int* step_model;
+    const double* cx;        // null, or known inputs c[t] ([T][d], or [T][chain][d] when off_chain)
+    int off_chain;
+    double* jmean;           // [T−1][chain][2d]
+    double* jcov;            // [T−1][chain][2d][2d]
+};
+__host__ __device__ inline size_t joint_lds_bytes(int d) { return sizeof(double) * (4 * (size_t)d * (d | 1) + 2 * (size_t)d); }
+__global__ void __launch_bounds__(256, 4) k_joint_generic(JointParams p) {
+    RXHIP_GSEQ_EXTERN_SHARED(sm)
+    const int d = p.d, ld = d | 1, tid = threadIdx.x, nt = blockDim.x;
+    const Map2 md(d, tid, nt);
+    double* LA = sm;                  // A
+    double* LX = LA + d * ld;         // X, then A V_s(k)
+    double* LV = LX + d * ld;         // V_s(k), then A V_s(k) A′
+    double* LT = LV + d * ld;         // A X
+    double* m0 = LT + d * ld;         // m_s(k)
+    const long long g = blockIdx.x, k = g / p.n_chains, c = g - k * p.n_chains;
+    GseqParams q{};
+    q.d = d; q.dy = p.dy; q.user = p.user;
+    const GenericModel M = gseq_model(q, p.step_model ? (size_t)p.step_model[k + 1] : p.chain_model ? (size_t)p.chain_model[c] : 0);
+    const long long r0 = k * p.n_chains + c, r1 = (k + 1) * p.n_chains + c;
+    RXHIP_FOR_2D(md, d, d, i, j) {
+        LA[i * ld + j] = M.A[i * d + j];
+        LX[i * ld + j] = p.cross[r0 * d * d + i * d + j];
+        LV[i * ld + j] = p.cov[r0 * d * d + i * d + j];
+    }
+    for (int i = tid; i < d; i += nt) m0[i] = p.mean[r0 * d + i];
+    __syncthreads();
+    tile_gemm(LT, ld, d, d, d, LA, ld, 1, LX, ld, 1, 1.0, false, tid, nt);               // A X
+    __syncthreads();
+    tile_gemm(LX, ld, d, d, d, LA, ld, 1, LV, ld, 1, 1.0, false, tid, nt);               // A V_s(k)
+    __syncthreads();
+    tile_gemm(LV, ld, d, d, d, LX, ld, 1, LA, 1, ld, 1.0, false, tid, nt);               // (A V_s(k)) A′
+    __syncthreads();
+    double* jm = p.jmean + g * 2 * d;
+    double* jc = p.jcov + g * 4 * d * d;
+    for (int i = tid; i < d; i += nt) {
+        double s = p.cx ? p.cx[((k + 1) * (p.off_chain ? p.n_chains : 1) + (p.off_chain ? c : 0)) * d + i] : 0.0;
+        for (int j = 0; j < d; ++j) s += LA[i * ld + j] * m0[j];
+        jm[i] = p.mean[r1 * d + i];
+        jm[d + i] = s;
+    }
+    RXHIP_FOR_2D(md, d, d, i, j) {
+        jc[(size_t)i * 2 * d + j] = p.cov[r1 * d * d + i * d + j];                        // (out, out) = V_s(k+1)
+        jc[(size_t)i * 2 * d + d + j] = LT[j * ld + i];                                   // (out, μ) = (A X)′
+        jc[(size_t)(d + i) * 2 * d + j] = LT[i * ld + j];                                 // (μ, out) = A X
+        jc[(size_t)(d + i) * 2 * d + d + j] = 0.5 * (LV[i * ld + j] + LV[j * ld + i]);    // (μ, μ) = A V_s(k) A′
+    }
 }
 
 }  // namespace rxhip

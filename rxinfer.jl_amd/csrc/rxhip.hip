@@ -3295,13 +3295,50 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
     if (node_type != RXHIP_NODE_MVNORMAL_MEAN_COV || e->kind != 0)
         return fail(e, RXHIP_ERR_BADARG, "get_node_marginals: node-local joints exist for the transition nodes of a state-space engine");
     if (!e->ran || e->last_filter) return fail(e, RXHIP_ERR_STATE, "get_node_marginals: needs a smoothing run (rxhip_run) first");
-    if (e->dense || !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "node-local joints have a device schedule for d, dy ≤ 4 only");
+    if (!e->dense && !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "node-local joints: no device schedule for this shape");
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME) return fail(e, RXHIP_ERR_BADARG, "get_node_marginals: unknown layout %d", layout);
     if (e->T < 2) return RXHIP_OK;  // a single time step has no transition node between observed states
     SET_DEVICE(e);
     const size_t rows = (size_t)(e->T - 1) * e->n_chains, d2 = 2 * (size_t)e->d;
     double* tmp = nullptr;
     HIPCHK(e, hipMalloc(&tmp, sizeof(double) * rows * (d2 + d2 * d2)));
+    if (e->dense) {
+        // any d ≤ 64: Cov(x[t], x[t+1] | y) = G_t V_s(t+1) is what the joints need beyond the posteriors, and no schedule of the
+        // MFMA path keeps it.  The sequential kernels recompute the sweep into scratch arrays with that product kept
+        // (gseq_kernels.hpp: one workgroup per chain) — a getter, not a hot path; the engine's own posteriors stay as they are.
+        const size_t C = (size_t)e->n_chains, T = (size_t)e->T, d = (size_t)e->d;
+        const size_t nm = T * C * d, nc = T * C * d * d, nx = (T - 1) * C * d * d;
+        double* scr = nullptr;
+        if (hipMalloc(&scr, sizeof(double) * (nm + nc + nx)) != hipSuccess) {
+            (void)hipFree(tmp);
+            return fail(e, RXHIP_ERR_HIP, "get_node_marginals: hipMalloc of %zu bytes of scratch failed", sizeof(double) * (nm + nc + nx));
+        }
+        once_per_device(0, e->device, [] {
+            (void)hipFuncSetAttribute((const void*)k_gseq_forward, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_gseq_backward, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
+        });
+        once_per_device(4, e->device, [] { (void)hipFuncSetAttribute((const void*)k_joint_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
+        GseqParams gq{};
+        gq.T = e->T; gq.n_chains = e->n_chains; gq.d = e->d; gq.dy = e->dy; gq.ptt = e->ptt; gq.fe = 0; gq.y = e->d_y;
+        gq.mean = scr; gq.cov = scr + nm; gq.cross = scr + nm + nc; gq.user = e->d_user; gq.prior = e->d_prior;
+        gq.chain_model = e->d_chain_model; gq.step_model = e->d_step_model; gq.fe_part = nullptr; gq.status = e->d_status;
+        const size_t lds = gseq_lds_bytes(e->d, e->dy);
+        hipLaunchKernelGGL(k_gseq_forward, dim3((unsigned)e->n_chains), dim3(256), lds, e->stream, gq);
+        hipLaunchKernelGGL(k_gseq_backward, dim3((unsigned)e->n_chains), dim3(256), lds, e->stream, gq);
+        JointParams jp{};
+        jp.T = e->T; jp.n_chains = e->n_chains; jp.d = e->d; jp.dy = e->dy; jp.mean = e->d_mean; jp.cov = e->d_cov; jp.cross = gq.cross;
+        jp.user = e->d_user; jp.chain_model = e->d_chain_model; jp.step_model = e->d_step_model; jp.cx = e->d_cx; jp.off_chain = e->off_chain ? 1 : 0;
+        jp.jmean = tmp; jp.jcov = tmp + rows * d2;
+        hipLaunchKernelGGL(k_joint_generic, dim3((unsigned)rows), dim3(256), joint_lds_bytes(e->d), e->stream, jp);
+        rxhip_status st = RXHIP_OK;
+        if (hipGetLastError() != hipSuccess) st = fail(e, RXHIP_ERR_HIP, "joint-marginal kernel launch failed");
+        if (!st) st = rxhip_sync(e);
+        if (!st && mean) st = copy_out(e, jp.jmean, mean, (int)d2, layout, e->T - 1);
+        if (!st && cov) st = copy_out(e, jp.jcov, cov, (int)(d2 * d2), layout, e->T - 1);
+        (void)hipFree(scr);
+        (void)hipFree(tmp);
+        return st;
+    }
     PredictParams pp{};
     pp.T = e->T; pp.H = 0; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
     pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.status = e->d_status;

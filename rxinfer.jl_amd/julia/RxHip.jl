@@ -168,7 +168,7 @@ function set_inputs!(e::Engine, flat::Vector{Float64})
 end
 
 """`get_node_local_marginals` of the transition nodes `x[t] ~ MvNormal(μ = A * x[t-1], Σ = P)`, t = 2 … T: the joint q(out, μ) in
-(out, μ) order — mean 2d × (T-1) × chains, cov 2d × 2d × (T-1) × chains (`rxhip_get_node_marginals`; d, dy ≤ 4)."""
+(out, μ) order — mean 2d × (T-1) × chains, cov 2d × 2d × (T-1) × chains (`rxhip_get_node_marginals`; any d, dy ≤ 64)."""
 function node_marginals(e::Engine)
     d2, n = 2 * e.d, e.T - 1
     mean = Array{Float64}(undef, d2, n, e.n_chains)

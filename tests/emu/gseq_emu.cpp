@@ -72,3 +72,31 @@ extern "C" int gseq_emu_stream(long long T, long long n_chains, int d, int dy, i
     }
     return status;
 }
+
+// rxhip_get_node_marginals at d > 4 on the host: forward + backward with the cross-covariances kept, then k_joint_generic
+extern "C" int gseq_emu_joints(long long T, long long n_chains, int d, int dy, int ptt, const double* user, const double* prior,
+                               const int* step_model, const double* y, double* jmean, double* jcov) {
+    using namespace rxhip;
+    std::vector<double> mean((size_t)T * n_chains * d), cov((size_t)T * n_chains * d * d), cross((size_t)(T > 1 ? T - 1 : 1) * n_chains * d * d),
+        logev((size_t)n_chains);
+    GseqParams p{};
+    p.T = T; p.n_chains = n_chains; p.d = d; p.dy = dy; p.ptt = ptt; p.fe = 0; p.y = y; p.mean = mean.data(); p.cov = cov.data(); p.user = user;
+    p.prior = prior; p.step_model = step_model; p.fe_part = logev.data(); p.cross = cross.data();
+    int status = 0;
+    p.status = &status;
+    std::vector<double> lds((gseq_lds_bytes(d, dy) > joint_lds_bytes(d) ? gseq_lds_bytes(d, dy) : joint_lds_bytes(d)) / sizeof(double) + 8);
+    sm = lds.data();
+    for (long long c = 0; c < n_chains; ++c) {
+        blockIdx.x = (unsigned)c;
+        k_gseq_forward(p);
+        k_gseq_backward(p);
+    }
+    JointParams j{};
+    j.T = T; j.n_chains = n_chains; j.d = d; j.dy = dy; j.mean = mean.data(); j.cov = cov.data(); j.cross = cross.data(); j.user = user;
+    j.step_model = step_model; j.jmean = jmean; j.jcov = jcov;
+    for (long long g = 0; g < (T - 1) * n_chains; ++g) {
+        blockIdx.x = (unsigned)g;
+        k_joint_generic(j);
+    }
+    return status;
+}

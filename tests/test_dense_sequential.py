@@ -134,6 +134,28 @@ def test_kernel_source_on_the_host_edge_cases(emu, T, ptt):
         assert np.allclose(mean[1, t], m, rtol=1e-12) and np.allclose(cov[1, t], V, rtol=1e-12)
 
 
+@pytest.mark.parametrize("d,dy,ptt", [(5, 5, False), (9, 9, True), (7, 7, False), (16, 16, True)])   # the oracle's reference schedule needs a square, full-rank B
+def test_joint_kernel_source_on_the_host_matches_the_oracle(emu, d, dy, ptt):
+    """rxhip_get_node_marginals at d > 4: the backward kernel keeps Cov(x[t], x[t+1] | y), k_joint_generic assembles q(out, μ) of
+    every transition node — against the joints the oracle forms inside its Bethe sum."""
+    rng = np.random.default_rng(7 * d + dy)
+    T, C = 9, 2
+    mdl = _models(rng, d, dy, 1)
+    one = tuple(x[0] for x in mdl)
+    y = _simulate(rng, mdl, np.zeros(T, dtype=np.int32), C, ptt)
+    A, B, P, Q, m0, V0 = (np.ascontiguousarray(x, dtype=np.float64) for x in mdl)
+    user = np.concatenate([A[0].ravel(), P[0].ravel(), B[0].ravel(), Q[0].ravel(), np.linalg.inv(Q[0]).ravel()])
+    prior = np.concatenate([m0[0].ravel(), V0[0].ravel()])
+    yt = np.ascontiguousarray(np.transpose(y, (1, 0, 2)))
+    jm, jc = np.empty((T - 1, C, 2 * d)), np.empty((T - 1, C, 2 * d, 2 * d))
+    dp = lambda a: a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+    st = emu.gseq_emu_joints(ctypes.c_longlong(T), ctypes.c_longlong(C), d, dy, int(ptt), dp(user), dp(prior), None, dp(yt), dp(jm), dp(jc))
+    assert st == 0
+    for c in range(C):
+        om, oc = rxo.lgssm_joints(*one, y[c], prior_through_transition=ptt)
+        assert np.allclose(jm[:, c], om, rtol=1e-9, atol=1e-11) and np.allclose(jc[:, c], oc, rtol=1e-8, atol=1e-11)
+
+
 def test_stream_step_source_on_the_host_matches_the_filtering_oracle(emu):
     """k_gseq_stream_step (rxhip_filter_step at d > 4) one observation at a time, with per-step constants, known inputs and
     missing observations, against the oracle's smoother of the observations seen so far (its last belief is the filtered one)."""
@@ -308,3 +330,35 @@ def test_filter_step_at_any_dimension(d, dy, C, masked):
     for c in range(C):
         _, _, onll = rxo.lgssm_kalman_rts(*one, y[c], prior_through_transition=True)
         assert nll[c] == pytest.approx(onll, rel=1e-8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,ptt,C,T,masked", [(5, False, 3, 20, False), (8, True, 16, 30, False), (16, False, 4, 25, True), (64, True, 2, 10, False)])
+def test_node_local_joints_at_any_dimension(d, ptt, C, T, masked):
+    """rxhip_get_node_marginals on the MFMA-path engines (time-parallel, shared-model split, sequential): q(x[t+1], A x[t]) of every
+    transition node against the joints the oracle forms inside its Bethe sum (square, full-rank B: what its reference schedule needs),
+    and — with missing observations — against brute-force conditioning of the whole chain."""
+    import rxhip
+    from test_node_marginals import _full_posterior
+    rng = np.random.default_rng(5 * d + T)
+    mdl = _models(rng, d, d, 1)
+    one = tuple(x[0] for x in mdl)
+    y = _simulate(rng, mdl, np.zeros(T, dtype=np.int32), C, ptt)
+    with rxhip.LGSSMEngine(*one, T=T, n_chains=C, prior_through_transition=ptt, allow_missing=masked) as eng:
+        eng.set_data(y, layout="chain_time")
+        eng.run(free_energy=True)
+        mean, cov = eng.marginals(layout="chain_time")
+        jm, jc = eng.node_marginals(layout="chain_time")
+        mean2, cov2 = eng.marginals(layout="chain_time")
+    assert np.array_equal(mean, mean2) and np.array_equal(cov, cov2)     # the getter leaves the posteriors alone
+    assert jm.shape == (C, T - 1, 2 * d) and jc.shape == (C, T - 1, 2 * d, 2 * d)
+    for c in range(C):
+        om, oc = rxo.lgssm_joints(*one, y[c], prior_through_transition=ptt)
+        assert np.allclose(jm[c], om, rtol=1e-6, atol=1e-9) and np.allclose(jc[c], oc, rtol=1e-6, atol=1e-9)
+        assert np.allclose(jc[c][:, :d, :d], cov[c, 1:], rtol=1e-9, atol=1e-12)   # the (out, out) block is the posterior of x[t+1]
+    if d <= 8:   # independent of the oracle's schedule: blocks of the full posterior of the chain
+        pm, pV = _full_posterior(mdl, y[0], ptt)
+        A = one[0]
+        for k in (0, T // 2, T - 2):
+            X = pV[k * d:(k + 1) * d, (k + 1) * d:(k + 2) * d]
+            assert np.allclose(jc[0, k][d:, :d], A @ X, rtol=1e-6, atol=1e-9)
