@@ -487,6 +487,277 @@ __device__ __forceinline__ bool gj_inverse(Acc<NT>& a, double* rowbuf, double* /
     return ok;
 }
 
+// ---- SPD inverse, blocked: 16×16 panels (round 3) ---------------------------------------------------------------------
+// The rank-4 sweep above pays, per 64×64 inverse, 16 workgroup barriers and 16 redundant 4×4 adjugates in all 256 threads
+// (≈3 150 VALU instructions per wave against 64 MFMAs: the dependent chain publish → barrier → adjugate → MFMA bounds the
+// forward step, not either pipe).  blk_inverse sweeps one 16×16 PANEL per workgroup barrier:
+//   block step k (pivot block row k = wave k's registers):
+//     wave k      publishes its tile row R = A[k, :] as it sits in its registers ([tile][reg][lane]: conflict-free, contiguous),
+//                 inverts the diagonal tile D = A[k, k] INSIDE THE WAVE (diag_inverse16: four rank-4 rounds through 512 bytes of
+//                 wave-private LDS, no workgroup barrier; one column of the 4×4 pivot inverse per lane by Cramer's rule on
+//                 rotated columns — ≈45 flops per lane and round instead of ≈130), publishes −D⁻¹                 [barrier]
+//     wave k      A[k, t] ← D⁻¹ R_t straight from its own registers (no LDS read), A[k, k] ← 2I − D⁻¹
+//     wave w ≠ k  Z̃ = −D⁻¹ R_w (4 MFMAs); trailing tiles A[w, t] += Z̃' R_t (4 MFMAs each); column tile A[w, k] ← R_w' D⁻¹
+//                 (the same two operands swapped — no cancellation against the old tile)
+//   The accumulator layout of v_mfma_f64_16x16x4_f64 (lane (j, q), register r ↔ row q + 4r, column j) IS the B-operand layout
+//   of a k-step that runs over rows {q + 4r : q} in register order, and — for the transposed factor — the A-operand layout:
+//   Z̃ leaves the matrix pipe in exactly the registers the trailing products read it from, and R / D⁻¹ are read back from LDS
+//   at [reg][lane], the address they were written to.  No transposition, no bank conflict, 4 barriers per 64×64 inverse.
+// Accuracy: the rank-4 rounds inside a diagonal tile use the modified-operand form of Sweep4 (pivot rows and columns come out
+// of the same MFMA as the trailing update through ±1 entries), whose error is ε·|D|² relative — harmless for |D| = O(1), not
+// for precisions of 10⁶.  The matrix is therefore equilibrated first, EXACTLY: a_ij ← a_ij·2^(h_i + h_j), h_i = −⌊exponent(a_ii)/2⌋
+// (powers of two: no rounding), so every diagonal entry — and with it every entry of every Schur complement — is below 2; the
+// result is scaled back the same way.  scripts/sim_blk_inverse.py models every lane, register and LDS slot of this routine
+// on the CPU (12 decades between diagonal entries: 1.5e-14 element-wise).
+// LDS: blk_scratch_doubles(NT) doubles (21 KB at NT = 4), double-buffered over block steps.
+__host__ __device__ constexpr int blk_half_doubles(int NT) { return (4 * NT + 4) * 64 + 8; }
+__host__ __device__ constexpr int blk_scratch_doubles(int NT) { return 2 * blk_half_doubles(NT) + 16 * NT; }
+
+// wave-local LDS exchange point: LDS instructions of one wavefront complete in issue order; this only keeps the compiler from
+// moving the reads above the writes
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront", "local");
+}
+
+// One rank-4 round of the in-wave inverse of a 16×16 tile t[r] ↔ D[q + 4r][j] (lane = 16q + j).  Pivot rows K_u = Q + 4u sit in the
+// 16 lanes with q == Q.  sb: 64 doubles, [column j][u].
+template <int Q>
+__device__ __forceinline__ void diag_round(double (&t)[4], double* sb, int j, int q, const double (&eu)[4], double euq, bool& bad, double& detprod) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    if (q == Q) {
+        reinterpret_cast<double2*>(sb + 4 * j)[0] = make_double2(t[0], t[1]);
+        reinterpret_cast<double2*>(sb + 4 * j)[1] = make_double2(t[2], t[3]);
+    }
+    wave_lds_fence();
+    double ri[4];
+    {
+        const double2 x0 = reinterpret_cast<const double2*>(sb + 4 * j)[0], x1 = reinterpret_cast<const double2*>(sb + 4 * j)[1];
+        ri[0] = x0.x; ri[1] = x0.y; ri[2] = x1.x; ri[3] = x1.y;
+    }
+    double yb = sb[4 * j + q];
+    // pivot block D4[u][c] = R[u][Q + 4c], columns rotated so that this lane group's own column c = q comes first (the address
+    // is uniform over the 16 lanes of a group: broadcast reads)
+    double col[4][4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const double* src = sb + 4 * (Q + 4 * ((q + m) & 3));
+        const double2 x0 = reinterpret_cast<const double2*>(src)[0], x1 = reinterpret_cast<const double2*>(src)[1];
+        col[m][0] = x0.x; col[m][1] = x0.y; col[m][2] = x1.x; col[m][3] = x1.y;
+    }
+    wave_lds_fence();  // the next round's publish must not overtake these reads
+    // R̃ = R − E_K: the ±1 entries that make pivot rows, pivot columns and the pivot block fall out of the one MFMA below
+    const double fQ = (j & 3) == Q ? 1.0 : 0.0;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ri[u] = __builtin_fma(-fQ, eu[u], ri[u]);
+    yb = __builtin_fma(-fQ, euq, yb);
+    const double(&a)[4] = col[0];
+    const double(&b)[4] = col[1];
+    const double(&c)[4] = col[2];
+    const double(&d)[4] = col[3];
+    const double m01 = c[0] * d[1] - c[1] * d[0], m02 = c[0] * d[2] - c[2] * d[0], m03 = c[0] * d[3] - c[3] * d[0];
+    const double m12 = c[1] * d[2] - c[2] * d[1], m13 = c[1] * d[3] - c[3] * d[1], m23 = c[2] * d[3] - c[3] * d[2];
+    const double cof0 = (b[1] * m23 - b[2] * m13) + b[3] * m12;
+    const double cof1 = (b[2] * m03 - b[0] * m23) - b[3] * m02;
+    const double cof2 = (b[0] * m13 - b[1] * m03) + b[3] * m01;
+    const double cof3 = (b[1] * m02 - b[0] * m12) - b[2] * m01;
+    const double det = (a[0] * cof0 + a[1] * cof1) + (a[2] * cof2 + a[3] * cof3);   // ± det D4 (sign of the rotation; q = 0: +)
+    const double num = (ri[0] * cof0 + ri[1] * cof1) + (ri[2] * cof2 + ri[3] * cof3);
+    // Cramer: component q of the solution of D4 x = −r̃_j; the rotation's sign is common to numerator and denominator
+    double rc = __builtin_amdgcn_rcp(det);
+    double e = __builtin_fma(-det, rc, 1.0);
+    rc = __builtin_fma(rc, e, rc);
+    e = __builtin_fma(-det, rc, 1.0);
+    rc = __builtin_fma(rc, e, rc);
+    const double xa = -num * rc;
+    // positive definiteness of the pivot block: nested trailing principal minors, in the lanes that see the natural column order
+    const bool good = (d[3] > 0.0) & (m23 > 0.0) & (cof0 > 0.0) & (det > 0.0);   // bitwise: no short-circuit branches
+    bad = bad | ((q == 0) & !good);
+    detprod *= det;  // meaningful in the lanes with q == 0
+    v4d acc = {t[0], t[1], t[2], t[3]};
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa, yb, acc, 0, 0, 0);
+    t[0] = acc[0]; t[1] = acc[1]; t[2] = acc[2]; t[3] = acc[3];
+}
+// t ← D⁻¹ (in place, accumulator layout); detprod = det D in the lanes with q == 0.  Wave-private scratch sb (64 doubles).
+__device__ __forceinline__ void diag_inverse16(double (&t)[4], double* sb, int lane, bool& bad, double& detprod) {
+    const int j = lane & 15, q = lane >> 4, ju = j >> 2;
+    const double eu[4] = {ju == 0 ? 1.0 : 0.0, ju == 1 ? 1.0 : 0.0, ju == 2 ? 1.0 : 0.0, ju == 3 ? 1.0 : 0.0};
+    const double euq = ju == q ? 1.0 : 0.0;
+    detprod = 1.0;
+    diag_round<0>(t, sb, j, q, eu, euq, bad, detprod);
+    diag_round<1>(t, sb, j, q, eu, euq, bad, detprod);
+    diag_round<2>(t, sb, j, q, eu, euq, bad, detprod);
+    diag_round<3>(t, sb, j, q, eu, euq, bad, detprod);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = (j == q + 4 * r ? 2.0 : 0.0) - t[r];
+}
+
+struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+// `prefetch` is called once, before the last block step: loads the caller needs right after the inverse travel under it
+// The equilibration exponents of a matrix, from its diagonal tile `dt` (tile (w, w) in accumulator layout): written by the 16
+// lanes that hold a diagonal element.  blk_inverse does this itself (PUB) — or the caller does, where it has the tile in
+// registers anyway and a workgroup barrier to share (kd_forward_info: the barrier in front of the symmetrisation).
+template <int NT>
+__device__ __forceinline__ void blk_publish_exponents(const double (&dt)[4], double* scratch, int w, int lane) {
+    int* sc = reinterpret_cast<int*>(scratch + 2 * blk_half_doubles(NT));
+    const int j = lane & 15, q = lane >> 4;
+    double dv = 1.0;
+    bool own = false;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+        if (j == q + 4 * r) { dv = dt[r]; own = true; }
+    if (own) {
+        const bool pos = dv > 0.0 && is_finite(dv);
+        const int h = pos ? -(__builtin_amdgcn_frexp_exp(dv) >> 1) : 0x40000000;
+        sc[16 * w + j] = h;
+        sc[16 * NT + 16 * w + 4 * (j & 3) + (j >> 2)] = h;
+    }
+}
+// FINAL = false: no barrier at the end — the caller must pass a workgroup barrier before anything else writes to `scratch`
+// PUB = false: the exponents are in the scratch already (blk_publish_exponents + a workgroup barrier by the caller)
+template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true>
+__device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_, int lane_, LogProd& lp, PF prefetch = PF()) {
+    typedef double v4d __attribute__((ext_vector_type(4)));
+    constexpr int HALF = blk_half_doubles(NT);
+    // the wave index as a scalar (uniform branches below); the lane index laundered, so that the lane constants and LDS addresses
+    // derived from it are recomputed per call instead of being hoisted out of the caller's time loop into (spilled) registers
+    const int w = __builtin_amdgcn_readfirstlane(w_);
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));
+    const int j = lane & 15, q = lane >> 4;
+    int* sc = reinterpret_cast<int*>(scratch + 2 * HALF);  // [2][16 NT]: exponents in natural order | permuted (row q + 4r at 4q + r)
+    bool bad = false;
+    // ---- exact equilibration by powers of two ----
+    if (PUB) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t == w) blk_publish_exponents<NT>(a.v[t], scratch, w, lane);
+        lds_barrier();
+    }
+    int hr[4], hc[NT];
+    {
+        const int4 x = *reinterpret_cast<const int4*>(sc + 16 * NT + 16 * w + 4 * q);
+        hr[0] = x.x; hr[1] = x.y; hr[2] = x.z; hr[3] = x.w;
+        int hsum = 0;
+        bool inval = false;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            hc[t] = sc[16 * t + j];
+            inval = inval || hc[t] == 0x40000000;
+            hc[t] = hc[t] == 0x40000000 ? 0 : hc[t];
+            hsum += hc[t];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hr[r] = hr[r] == 0x40000000 ? 0 : hr[r];
+        bad = __any(inval);  // every wave sees all 16 NT exponents: uniform over the workgroup
+        if (w == 0) {        // Σ h over the whole diagonal: det A = det A_s · 2^(−2 Σ h)
+            hsum += __shfl_xor(hsum, 1);
+            hsum += __shfl_xor(hsum, 2);
+            hsum += __shfl_xor(hsum, 4);
+            hsum += __shfl_xor(hsum, 8);
+            if (lane == 0) lp.expo -= 2 * (long long)hsum;
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) a.v[t][r] = __builtin_ldexp(a.v[t][r], hr[r] + hc[t]);
+    }
+    // ---- block steps ----
+#pragma unroll
+    for (int k = 0; k < NT; ++k) {
+        double* hb = scratch + (k & 1) * HALF;  // R [NT][4][64] | −D⁻¹ [4][64] (first the wave-private scratch of the tile inverse) | det, flag
+        double* nd = hb + NT * 256;
+        double di[4];
+        if (k == NT - 1) prefetch();
+        if (w == k) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) hb[(t * 4 + r) * 64 + lane] = a.v[t][r];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) di[r] = a.v[k][r];
+            double detp;
+            bool badk = false;
+            diag_inverse16(di, nd, lane, badk, detp);
+            badk = __any(badk);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nd[r * 64 + lane] = -di[r];
+            if (lane == 0) {
+                nd[256] = detp;
+                nd[257] = badk ? 1.0 : 0.0;
+            }
+        }
+        lds_barrier();
+        if (nd[257] != 0.0) bad = true;
+        if (w == 0 && lane == 0) lp.mul(nd[256]);
+        if (w == k) {
+            // own tile row from registers: A[k, t] ← D⁻¹ R_t;  pivot block ← −D⁻¹
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t == k) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) a.v[t][r] = -di[r];
+                } else {
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(di[r], a.v[t][r], acc, 0, 0, 0);
+                    a.v[t][0] = acc[0]; a.v[t][1] = acc[1]; a.v[t][2] = acc[2]; a.v[t][3] = acc[3];
+                }
+            }
+        } else {
+            double ndr[4], rw[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ndr[r] = nd[r * 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) rw[r] = hb[(w * 4 + r) * 64 + lane];
+            v4d z = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r) z = __builtin_amdgcn_mfma_f64_16x16x4f64(ndr[r], rw[r], z, 0, 0, 0);  // Z̃ = −D⁻¹ R_w
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                if (t == k) {  // column tile: (D⁻¹ R_w)' = R_w' D⁻¹
+                    v4d acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(rw[r], -ndr[r], acc, 0, 0, 0);
+                    a.v[t][0] = acc[0]; a.v[t][1] = acc[1]; a.v[t][2] = acc[2]; a.v[t][3] = acc[3];
+                } else {
+                    double rt[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rt[r] = hb[(t * 4 + r) * 64 + lane];
+                    v4d acc = {a.v[t][0], a.v[t][1], a.v[t][2], a.v[t][3]};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(z[r], rt[r], acc, 0, 0, 0);
+                    a.v[t][0] = acc[0]; a.v[t][1] = acc[1]; a.v[t][2] = acc[2]; a.v[t][3] = acc[3];
+                }
+            }
+        }
+    }
+    // the array holds −A_s⁻¹: negate, scale back
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) a.v[t][r] = __builtin_ldexp(-a.v[t][r], hr[r] + hc[t]);
+    if (FINAL) lds_barrier();  // the scratch (exponent table, last half) may be reused by the caller
+    return !bad;
+}
+// the SPD inverse the sweep kernels call: RXHIP_INV_BLOCKED selects the panel form
+#ifndef RXHIP_INV_BLOCKED
+#define RXHIP_INV_BLOCKED 1
+#endif
+#ifndef RXHIP_KF_RELOAD
+#define RXHIP_KF_RELOAD 2
+#endif
+template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true>
+__device__ __forceinline__ bool spd_inverse(Acc<NT>& a, double* scratch, int w, int lane, LogProd& lp, PF prefetch = PF()) {
+#if RXHIP_INV_BLOCKED
+    return blk_inverse<NT, PF, FINAL, PUB>(a, scratch, w, lane, lp, prefetch);
+#else
+    prefetch();
+    return gj_inverse<NT>(a, scratch, scratch, w, lane, lp);
+#endif
+}
+
 // ---- vectors in LDS ------------------------------------------------------------------------------
 // out[i] = s0·add[i] + Σ_k M[i][k] x[k]   (M: n×m row-major ld; thread i < n does row i)
 __device__ __forceinline__ void matvec_lds(double* out, const double* M, int ld, int n, int m, const double* x,
@@ -583,21 +854,30 @@ __device__ __forceinline__ void block_dot3(const double* a0, const double* b0, i
 }
 
 // ------------------------------------------------------------------------------------------------
-// LDS carve (dynamic): 4 matrices + vectors
+// LDS carve (dynamic): matrices + vectors + the scratch of the SPD inverse
 template <int NT>
 struct DenseLds {
     using C = DenseCfg<NT>;
     static constexpr int NVEC = 12;
-    static constexpr size_t bytes(int dmax) {
-        return sizeof(double) * ((size_t)4 * C::MAT + (size_t)NVEC * dmax + 8 * C::D + 3 * C::THREADS);
+    // scratch of spd_inverse: the panel buffers of blk_inverse, or the pivot-row buffers of gj_inverse
+    static constexpr int SCR = RXHIP_INV_BLOCKED ? blk_scratch_doubles(NT) : 8 * C::D;
+    // kernels that keep two LDS matrices (two workgroups per CU at d = 64) lend the inverse a matrix that is dead while it runs
+    static constexpr bool ALIAS = RXHIP_INV_BLOCKED && C::MAT >= blk_scratch_doubles(NT);
+    static constexpr int SCR2 = ALIAS ? 8 * C::D : (SCR > 8 * C::D ? SCR : 8 * C::D);   // what those kernels carve besides
+    static constexpr size_t bytes(int dmax) {   // scan kernels (vectors only), kd_prepare_bnd (scratch only)
+        return sizeof(double) * ((size_t)NVEC * dmax + (SCR > 8 * C::D ? SCR : 8 * C::D) + 3 * C::THREADS);
     }
-    // kd_forward_info: 2 matrices, ξ_f | u | 4 partial-sum rows, the pivot-row buffers
+    // kd_forward (filtering runs): 3 matrices, 5 vectors, the scratch, 2 × 4 partial-sum rows
+    static constexpr size_t fwd_bytes(int dmax) {
+        return sizeof(double) * ((size_t)3 * C::MAT + (size_t)13 * dmax + (SCR > 8 * C::D ? SCR : 8 * C::D));
+    }
+    // kd_forward_info: 2 matrices, ξ_f | u | 4 partial-sum rows, the scratch
     static constexpr size_t fwd_info_bytes(int dmax) {
-        return sizeof(double) * ((size_t)2 * C::MAT + (size_t)10 * dmax + 8 * C::D);
+        return sizeof(double) * ((size_t)2 * C::MAT + (size_t)10 * dmax + SCR2);
     }
-    // kd_backward_info: 2 matrices, m_s | C ξ_f, the pivot-row buffers / matvec partials
+    // kd_backward_info: 2 matrices, m_s | C ξ_f, the scratch / matvec partials
     static constexpr size_t bwd_info_bytes(int dmax) {
-        return sizeof(double) * ((size_t)2 * C::MAT + (size_t)2 * dmax + 8 * C::D);
+        return sizeof(double) * ((size_t)2 * C::MAT + (size_t)2 * dmax + SCR2);
     }
     // kd_agg_finish: 6 vectors, the map (B'Q⁻¹)' and a tile of 16 observations
     static constexpr size_t agg_bytes(int dy) {
@@ -938,13 +1218,13 @@ __global__ void __launch_bounds__(64 * NT) kd_prepare_bnd(DenseParams p) {
     LogProd lpd;
     Acc<NT> a;
     acc_load<NT>(a, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
-    ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;
+    ok = spd_inverse<NT>(a, rowbuf, w, lane, lpd) && ok;
     acc_store<NT>(a, p.bnd + ((size_t)seg * 2 + 0) * MM, D, w, lane);
     if (seg + 1 < p.S) {
         acc_load<NT>(a, p.scanm + ((size_t)(seg + 1) * 6 + 2) * MM, D, w, lane);
-        ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;
+        ok = spd_inverse<NT>(a, rowbuf, w, lane, lpd) && ok;
         acc_add_mat<NT>(a, p.scanm + ((size_t)seg * 6 + 5) * MM, D, w, lane, 1.0);
-        ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpd) && ok;
+        ok = spd_inverse<NT>(a, rowbuf, w, lane, lpd) && ok;
         acc_store<NT>(a, p.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
@@ -980,8 +1260,8 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     double* xf = mp + dm;
     double* yv = xf + dm;
     double* qy = yv + dm;
-    double* rowbuf = qy + dm;   // 8·D doubles (two buffers of four pivot rows)
-    double* red = rowbuf + 8 * D;  // [4][dm] partial sums
+    double* rowbuf = qy + dm;   // scratch of the SPD inverse
+    double* red = rowbuf + (DenseLds<NT>::SCR > 8 * D ? DenseLds<NT>::SCR : 8 * D);  // [4][dm] partial sums
     double* red2 = red + 4 * dm;   // [4][dm]
     const long long seg = blockIdx.x, chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
@@ -1087,14 +1367,14 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
         if (FE && tid < dy) qy[tid] = (red2[tid] + red2[dm + tid]) + (red2[2 * dm + tid] + red2[3 * dm + tid]);
         mm_a(lam, M1, std::true_type{});
         // weightedmean_precision of the forward message: Λp = Vp⁻¹
-        ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
+        ok = spd_inverse<NT>(lam, rowbuf, w, lane, lp) && ok;
         acc_store<NT>(lam, M2, LD, w, lane);
         lds_barrier();
         // product with the `*`_B(:in) message: Λf = Λp + B'Q⁻¹B, ξf = Λp mp + G y   (partials; combined after the inverse)
         part_lds(red, M2, mp);
         acc_add_mat<NT>(lam, cst + c.oLOBS, D, w, lane, 1.0);
         // mean_cov of the product: Vf = Λf⁻¹, mf = Vf ξf
-        ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
+        ok = spd_inverse<NT>(lam, rowbuf, w, lane, lp) && ok;
         double sx = 0.0, xfr = 0.0;
         if (tid < D) {
             sx = (red[tid] + red[dm + tid]) + (red[2 * dm + tid] + red[3 * dm + tid]);  // Λp mp
@@ -1157,14 +1437,16 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     // Two LDS matrices only (75 KB at d = 64): TWO workgroups share a CU, so that one's publish → barrier → cofactor → MFMA
     // latency chain runs under the other's (the kernel holds 255 registers: two waves per SIMD fit).  The constant
     // PLW = P⁻¹ + B'Q⁻¹B + A'P⁻¹A is re-read from L2 into dead registers a whole contraction before its use.
-    double* S0 = smem;          // C_t
-    double* S1 = S0 + C::MAT;   // −G_t, then M_{t+1} for the symmetrisation
+    double* S0 = smem;          // scratch of the inverse, then −G_t
+    double* S1 = S0 + C::MAT;   // C_t, then M_{t+1} for the symmetrisation
     double* vec = S1 + C::MAT;
     double* xi = vec;           // ξ_f
     double* u = xi + dm;
     double* xpp = u + dm;       // [4][D] partial sums of ξ_p
     double* cpp = xpp + 4 * dm; // [4][D] partial sums of C_t ξ_f(t) (handed to the backward kernel in the record)
-    double* rowbuf = cpp + 4 * dm;  // 8·D doubles
+    // scratch of the SPD inverse: S0 is dead while it runs (−G_{t−1}: every reader is behind the barrier that precedes the
+    // store of M), so at d ≥ 48 the panel buffers live there and two workgroups still share a CU
+    double* rowbuf = DenseLds<NT>::ALIAS ? S0 : cpp + 4 * dm;
     const long long seg = blockIdx.x, chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
@@ -1178,14 +1460,26 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     bool ok = true;
     LogProd lp;
     Acc<NT> lam, a;
-    // K = P⁻¹A is the A operand of both contractions of a step: its fragments stay in registers for the whole segment
+    // K = P⁻¹A is the A operand of both contractions of a step.  Its fragments (16 doubles per thread at d = 64) are re-read from
+    // L2 after every inverse (KF_RELOAD): held across the panel inverse they pushed the kernel over 256 registers, and every
+    // scratch reload is a VMEM wait that also drains the record stores in flight.  The address is laundered per step so that
+    // the loads are not hoisted out of the loop again.
+    constexpr bool KF_RELOAD = RXHIP_KF_RELOAD && NT >= 3;
     double kf[D / 4];
-    {
-        const double* K = cst + c.oK;
-        const int i = 16 * w + (lane & 15), kq = lane >> 4;
+    auto load_kf = [&]() {
+        const double* K = cst + c.oK + (16 * w + (lane & 15)) * D + (lane >> 4);
+        if (KF_RELOAD) asm volatile("" : "+v"(K));
 #pragma unroll
-        for (int kk = 0; kk < D / 4; ++kk) kf[kk] = K[i * D + 4 * kk + kq];
-    }
+        for (int kk = 0; kk < D / 4; ++kk) kf[kk] = K[4 * kk];
+    };
+    if (!KF_RELOAD) load_kf();
+    // symmetric contraction M_{t+1} = PLW − K G: slots of this wave (tile (w, (w + sl) mod NT), sl < nsw)
+    constexpr int NS = NT / 2 + 1;
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    const int nsw = (NT % 2 == 0 && NT > 1 && ws >= NT / 2) ? NS - 1 : NS;
+    auto slot_tile = [&](int sl) { const int t = ws + sl; return t >= NT ? t - NT : t; };
+    // the equilibration exponents of the next inverse are published where M is stored (one barrier less per step)
+    constexpr bool PREPUB = RXHIP_INV_BLOCKED != 0;
     auto mm_k = [&](Acc<NT>& cacc, const double* Y) {  // cacc += K Y   (Y in LDS, leading dimension LD)
         const int jl = lane & 15, kq = lane >> 4;
         d4 acc[NT];
@@ -1207,11 +1501,16 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     };
     // belief at the segment start in information form: Λ_f = V(b_s)⁻¹ (data-independent: host table), ξ_f = Λ_f m(b_s)
     acc_load<NT>(lam, M.bnd + ((size_t)seg * 2 + 0) * MM, D, w, lane);
-    acc_store<NT>(lam, S0, LD, w, lane);
+    acc_store<NT>(lam, S1, LD, w, lane);
     if (tid < D) u[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
     lds_barrier();
-    matvec_lds(xi, S0, LD, D, D, u, nullptr, 0.0, tid);
+    matvec_lds(xi, S1, LD, D, D, u, nullptr, 0.0, tid);
     acc_add_mat<NT>(lam, cst + c.oW, D, w, lane, 1.0);  // lam carries M_t = Λ_f(t−1) + A'P⁻¹A from here on
+    if (PREPUB) {  // equilibration exponents of the first inverse (later ones: where M is stored)
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+            if (t == ws) blk_publish_exponents<NT>(lam.v[t], rowbuf, ws, lane);
+    }
     // B'Q⁻¹ y_t comes from the aggregation kernel (record of t, second header slot), fetched one step ahead
     double gyn = (tid < D && len > 0) ? p.filt[(chain * p.T + t0) * C::REC + D + tid] : 0.0;
     lds_barrier();
@@ -1223,46 +1522,98 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
             rec[tid] = xi[tid];  // ξ_f(t − 1)
             gyn = p.filt[(chain * p.T + (i + 1 < len ? t + 1 : t)) * C::REC + D + tid];
         }
-        // C = (Λ_f + A'P⁻¹A)⁻¹
-        ok = gj_inverse<NT>(lam, rowbuf, rowbuf, w, lane, lp) && ok;
+        // C = (Λ_f + A'P⁻¹A)⁻¹.  The inverse's scratch is S0 (or its own carve): the next writer of S0 is the store of −G below,
+        // behind a workgroup barrier, so the inverse ends without one.
+#ifndef RXHIP_TEST_NOINV
+        if (KF_RELOAD && RXHIP_KF_RELOAD == 1) ok = spd_inverse<NT, decltype(load_kf), false, !PREPUB>(lam, rowbuf, w, lane, lp, load_kf) && ok;
+        else ok = spd_inverse<NT, NoPrefetch, false, !PREPUB>(lam, rowbuf, w, lane, lp) && ok;
+#endif
+        if (KF_RELOAD && RXHIP_KF_RELOAD == 2) load_kf();
         acc_store_full<NT>(lam, rec + C::HDR, w, lane);
-        acc_store<NT>(lam, S0, LD, w, lane);
-        acc_load<NT>(lam, cst + c.oPLW, D, w, lane);  // lam is dead until M_{t+1} below: the L2 latency hides under G' = K C
+        acc_store<NT>(lam, S1, LD, w, lane);   // every reader of S1 (the symmetrisation) is behind the inverse's barriers
+        int ln = lane;
+        asm volatile("" : "+v"(ln));   // addresses below are recomputed per step, not hoisted into (spilled) registers
+        const int lq = ln >> 4, lj = ln & 15;
+        // PLW tiles of this wave's share of M_{t+1} (below): the L2 latency hides under G' = K C
+        d4 macc[NS];
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const double* src = cst + c.oPLW + (size_t)(16 * ws + lq) * D + 16 * slot_tile(sl) + lj;
+            macc[sl] = (d4){src[0], src[4 * D], src[8 * D], src[12 * D]};
+        }
         lds_barrier();
         // G' = K C
         acc_zero<NT>(a);
-        mm_k(a, S0);
+        mm_k(a, S1);
         acc_store_full<NT>(a, rec + C::HDR + D * D, w, lane);
 #pragma unroll
         for (int q = 0; q < NT; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) a.v[q][r] = -a.v[q][r];
-        acc_store_T<NT>(a, S1, LD, w, lane);  // S1 = −G
+        acc_store_T<NT>(a, S0, LD, w, lane);  // S0 = −G
         lds_barrier();
-        // ξ_p = K C ξ_f = G' ξ_f: column sums of S1, a quarter of the range per thread group;
-        // M_{t+1} = Λ_f(t) + A'P⁻¹A = PLW − K G
+        // ξ_p = K C ξ_f = G' ξ_f: column sums of S0, a quarter of the range per thread group
         {
             double s0 = 0.0, s1 = 0.0, c0 = 0.0, c1 = 0.0;
             const int k0 = grp * (D / 4);
 #pragma unroll
             for (int k = 0; k < D / 4; k += 2) {
-                s0 += S1[(k0 + k) * LD + gi] * xi[k0 + k];
-                s1 += S1[(k0 + k + 1) * LD + gi] * xi[k0 + k + 1];
-                c0 += S0[(k0 + k) * LD + gi] * xi[k0 + k];          // C is symmetric: column sums are conflict-free
-                c1 += S0[(k0 + k + 1) * LD + gi] * xi[k0 + k + 1];
+                s0 += S0[(k0 + k) * LD + gi] * xi[k0 + k];
+                s1 += S0[(k0 + k + 1) * LD + gi] * xi[k0 + k + 1];
+                c0 += S1[(k0 + k) * LD + gi] * xi[k0 + k];          // C is symmetric: column sums are conflict-free
+                c1 += S1[(k0 + k + 1) * LD + gi] * xi[k0 + k + 1];
             }
             xpp[grp * D + gi] = s0 + s1;
             cpp[grp * D + gi] = c0 + c1;
         }
-        mm_k(lam, S1);
+        // M_{t+1} = Λ_f(t) + A'P⁻¹A = PLW − K G is symmetric: every unordered pair of tile indices is computed ONCE, by the wave
+        // that owns the pair (tile (w, t) with (t − w) mod NT ≤ NT/2 — 3, 3, 2, 2 tiles per wave at d = 64 instead of 4), and the
+        // mirror image is read back transposed below: 48 instead of 64 MFMAs on the critical wave, exact symmetry for free
+        // (only the diagonal tiles still average with their own transpose).
+        if (nsw == NS) {
+#pragma unroll
+            for (int kk = 0; kk < D / 4; ++kk)
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl)
+                    macc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(kf[kk], S0[(4 * kk + lq) * LD + 16 * slot_tile(sl) + lj], macc[sl], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < D / 4; ++kk)
+#pragma unroll
+                for (int sl = 0; sl < NS - 1; ++sl)
+                    macc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(kf[kk], S0[(4 * kk + lq) * LD + 16 * slot_tile(sl) + lj], macc[sl], 0, 0, 0);
+        }
         lds_barrier();
         if (tid < D) {
             rec[2 * D + tid] = (cpp[tid] + cpp[D + tid]) + (cpp[2 * D + tid] + cpp[3 * D + tid]);      // C_{t−1} ξ_f(t−1)
             xi[tid] = gyc - ((xpp[tid] + xpp[D + tid]) + (xpp[2 * D + tid] + xpp[3 * D + tid]));       // ξ_f(t)
         }
-        acc_store<NT>(lam, S1, LD, w, lane);       // G is no longer needed: S1 carries M for the symmetrisation
+        // C is no longer needed: S1 carries the computed tiles of M; the exponents of its diagonal (equilibration of the next
+        // inverse) share the barrier
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl)
+            if (sl < nsw) {
+                double* dst = S1 + (16 * ws + lq) * LD + 16 * slot_tile(sl) + lj;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[4 * r * LD] = macc[sl][r];
+            }
+        if (PREPUB) {
+            const double dtile[4] = {macc[0][0], macc[0][1], macc[0][2], macc[0][3]};
+            blk_publish_exponents<NT>(dtile, rowbuf, ws, ln);
+        }
         lds_barrier();
-        acc_symmetrise<NT>(lam, S1, LD, w, lane);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            int dist = t - ws;
+            dist = dist < 0 ? dist + NT : dist;
+            const bool owned = dist < NS - 1 || (dist == NS - 1 && dist < nsw);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * ws + lq + 4 * r, col = 16 * t + lj;
+                const double v = S1[owned ? row * LD + col : col * LD + row];
+                lam.v[t][r] = (t == ws) ? 0.5 * (v + S1[col * LD + row]) : v;
+            }
+        }
     }
     acc_add_mat<NT>(lam, cst + c.oW, D, w, lane, -1.0);
     acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);  // Λ_f at the segment end
@@ -1291,7 +1642,8 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
     double* vec = MG + C::MAT;
     double* ms = vec;           // m_s(t+1), then m_s(t)
     double* xf = ms + dm;       // boundary: ξ_f + ξβ; in the loop: C_t ξ_f(t)
-    double* rowbuf = xf + dm;   // 8·D doubles: pivot rows of the last segment's inverse, then the matvec partials
+    double* rowbuf = xf + dm;   // the matvec partials (and, where no matrix can be lent, the scratch of the last segment's inverse)
+    double* invbuf = DenseLds<NT>::ALIAS ? MG : rowbuf;  // MG is not in use before the first commit()
     const long long seg = blockIdx.x, chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);  // this chain's model tables
     const DenseCst c = DenseCst::make(D, dy);
@@ -1314,7 +1666,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
             lds_barrier();
             acc_load<NT>(a, MV, LD, w, lane);
             lds_barrier();  // every wave has its rows in registers before MV is overwritten below
-            ok = gj_inverse<NT>(a, rowbuf, rowbuf, w, lane, lpe) && ok;
+            ok = spd_inverse<NT>(a, invbuf, w, lane, lpe) && ok;
             if (p.vlast && chain == 0) acc_store<NT>(a, p.vlast, D, w, lane);
         } else
             acc_load<NT>(a, M.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);

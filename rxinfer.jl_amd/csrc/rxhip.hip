@@ -1057,8 +1057,9 @@ struct DenseLaunch {
     static void forward(const DenseParams& p, bool fe, hipStream_t s) {
         slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
             dim3 g(q.S, nc);
-            if (fe) hipLaunchKernelGGL((kd_forward<NT, true>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
-            else hipLaunchKernelGGL((kd_forward<NT, false>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
+            const size_t lds = DenseLds<NT>::fwd_bytes(((q.d > q.dy ? q.d : q.dy) + 1) & ~1);
+            if (fe) hipLaunchKernelGGL((kd_forward<NT, true>), g, dim3(64 * NT), lds, s, q);
+            else hipLaunchKernelGGL((kd_forward<NT, false>), g, dim3(64 * NT), lds, s, q);
         });
     }
     // information-form smoother (one inverse per step; free energy at the smoothed means)

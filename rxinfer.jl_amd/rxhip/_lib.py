@@ -4,7 +4,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.normpath(os.path.join(_HERE, "..", "csrc", "librxhip.so"))
+# RXHIP_LIB: another build of the SAME library (A/B measurements of kernel variants, scripts/ab_variants.sh); never a fallback
+LIB_PATH = os.environ.get("RXHIP_LIB") or os.path.normpath(os.path.join(_HERE, "..", "csrc", "librxhip.so"))
 
 c_double_p = ctypes.POINTER(ctypes.c_double)
 c_int32_p = ctypes.POINTER(ctypes.c_int32)
