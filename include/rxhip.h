@@ -118,8 +118,10 @@ typedef struct {
 rxhip_status rxhip_lgssm_set_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset);
 /* Known inputs that are DATA of every chain — `x[t] ~ MvNormal(μ = A * x[t-1] + B_u * u[t], Σ = P)` with `u` a data variable: the
  * host passes c = B_u u per chain, (T + horizon)·n_chains·d doubles in `layout` ([t][chain][d] or [chain][t][d]); obs_offset
- * likewise with dy; either may be NULL (= zeros).  The engine runs μ[t] = A μ[t-1] + c[t] per chain on the device and shifts data
- * and means per chain from then on.  Same precondition as rxhip_lgssm_set_offsets. */
+ * likewise with dy.  Either may be NULL = keep the offsets the engine was CREATED with, replicated over the chains (a model with
+ * data inputs on the transitions and a constant observation offset passes NULL for the latter); zeros if it was created without.
+ * The engine runs μ[t] = A μ[t-1] + c[t] per chain on the device and shifts data and means per chain from then on.  Same
+ * precondition as rxhip_lgssm_set_offsets. */
 rxhip_status rxhip_lgssm_set_chain_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset, int32_t layout);
 
 /* replaces: create_model(...) + postprocess_plugin (src/inference/batch.jl:252,

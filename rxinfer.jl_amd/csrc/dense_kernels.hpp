@@ -32,7 +32,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct DenseCst {
     int d, dy;
     long long oA, oP, oLOBS, oG, oQI, oHF, oC0, oX1, oS1, oLD1, oC1, oK1, oVF1, oAT, oGT, oHFT, oK1T, oPI, oK, oKT, oW, oV1I, oM1,
-        oBT, oFEC, oPLW, size;
+        oBT, oFEC, oPLW, oLPX, oLQX, size;
     __host__ __device__ static DenseCst make(int d, int dy) {
         DenseCst c;
         c.d = d;
@@ -66,6 +66,10 @@ struct DenseCst {
         c.oBT = o; o += (long long)d * dy;   // B'   [d][dy]
         c.oFEC = o; o += 1;                  // ½[log|V1| + (T−1) log|P| + T(dy log 2π + log|Q|)]
         c.oPLW = o; o += (long long)d * d;   // P⁻¹ + B'Q⁻¹B + A'P⁻¹A (symmetric): M_{t+1} = PLW − K G_t
+        // whitening maps of the free-energy residuals (kd_fe_resid_mfma): with P = L_P L_P', Q = L_Q L_Q'
+        //   r_x'P⁻¹r_x = |L_P⁻¹ x̂_{t+1} − (L_P⁻¹A) x̂_t|²,   r_y'Q⁻¹r_y = |L_Q⁻¹ y_t − (L_Q⁻¹B) x̂_t|²
+        c.oLPX = o; o += (long long)d * 2 * d;                                           // [d][2d]  L_P⁻¹ | −L_P⁻¹A
+        c.oLQX = o; o += (long long)(((dy + 15) / 16) * 16) * (((dy + 3) & ~3) + d);     // [dy↑16][dy↑4 + d]  L_Q⁻¹ | −L_Q⁻¹B
         c.size = (o + 7) / 8 * 8;
         return c;
     }
@@ -1886,6 +1890,141 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
     if (tid == 0) {
         const double tot = ((red[0] + red[1]) + red[2]) + red[3], sec = ((red[4] + red[5]) + red[6]) + red[7];
         dense_fe_write(p, slot0 + blockIdx.x, chain, 0.0, tot - sec, sec);
+    }
+}
+
+// The same residual forms on the matrix cores (round 3).  With the whitening maps of DenseCst (oLPX, oLQX) every term is the
+// squared norm of ONE map applied to stacked means,  ρ_x(t) = [L_P⁻¹ | −L_P⁻¹A]·[x̂_{t+1}; x̂_t],  ρ_y(t) = [L_Q⁻¹ | −L_Q⁻¹B]·[y_t; x̂_t],
+// i.e. two GEMMs with the time steps as columns: a 16-step tile is the B operand (lane (j, kq) reads component 4kk + kq of
+// step j straight from the posterior means — L2), the map is the A operand (staged in LDS once per workgroup, leading
+// dimension K + 2: conflict-free), and the accumulator (rows = components, columns = steps) is squared and summed in place.
+// No intermediate vector, no LDS exchange between the two stages of r'P⁻¹r: d = 64: 0.060 -> 0.0xx ms, and the d = 8 × 1024
+// batch no longer spends a third of its sweep here.  Same grid, same slots and the same step blocks as kd_fe_resid.
+template <int NT>
+inline size_t fe_resid_mfma_lds_bytes(int dy) {
+    constexpr int D = 16 * NT;
+    const int dyr = (dy + 15) / 16 * 16, ky = ((dy + 3) & ~3) + D;
+    return sizeof(double) * ((size_t)D * (2 * D + 2) + (size_t)dyr * (ky + 2) + 16);
+}
+template <int NT>
+__global__ void __launch_bounds__(256) kd_fe_resid_mfma(DenseParams p, int slot0) {
+    constexpr int D = 16 * NT, KX = 2 * D, LDX = KX + 2;
+    constexpr int RT = NT >= 3 ? 4 : NT, PT = 4 / RT;   // waves that share a time tile (one row tile each) · time tiles in flight
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    const int dy = p.dy, dy4 = (dy + 3) & ~3, nty = (dy + 15) / 16, dyr = 16 * nty, KY = dy4 + D, LDY = KY + 2;
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6, j = lane & 15, kq = lane >> 4;
+    double* MX = smem;                      // [D][LDX]
+    double* MY = MX + (size_t)D * LDX;      // [dyr][LDY]
+    double* red = MY + (size_t)dyr * LDY;   // [8]
+    const long long chain = blockIdx.y + p.chain0;
+    const DenseModel M = dense_model(p, chain);
+    const DenseCst c = DenseCst::make(D, dy);
+    const int STEPS = fe_resid_steps(D, dy), NTT = STEPS / 16;
+    const long long t00 = (long long)blockIdx.x * STEPS;
+    {   // stage the two maps (eight loads in flight per thread)
+        const double* sx = M.cst + c.oLPX;
+        for (int k0 = tid; k0 < D * KX; k0 += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (k0 + u * 256 < D * KX) ? sx[k0 + u * 256] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * 256;
+                if (k < D * KX) MX[(k / KX) * LDX + (k % KX)] = v[u];
+            }
+        }
+        const double* sy = M.cst + c.oLQX;
+        for (int k0 = tid; k0 < dyr * KY; k0 += 8 * 256) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = (k0 + u * 256 < dyr * KY) ? sy[k0 + u * 256] : 0.0;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int k = k0 + u * 256;
+                if (k < dyr * KY) MY[(k / KY) * LDY + (k % KY)] = v[u];
+            }
+        }
+    }
+    double s0 = 0.0, s1 = 0.0;   // first / second chain of a packed pair (unpacked: everything in s0)
+    const bool pk = p.pack == 2;
+    if (t00 == 0 && g == 0) {  // prior of the first state: (x̂_1 − m1)'V1⁻¹(x̂_1 − m1), one row per lane (constant map read from L2 once per chain)
+        const double* V1I = M.cst + c.oV1I;
+        const double* m1 = M.cst + c.oM1;
+        if (lane < D) {
+            double u = 0.0;
+            for (int k = 0; k < D; k += 16) {
+                double v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] = V1I[(size_t)(k + r) * D + lane];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) u += v[r] * (dense_load_mean(p, 0, chain, k + r) - m1[k + r]);
+            }
+            const double e = (dense_load_mean(p, 0, chain, lane) - m1[lane]) * u;
+            if (pk && lane >= p.d_sub) s1 += e;
+            else s0 += e;
+        }
+    }
+    __syncthreads();
+    const int rg = g % RT, tp = g / RT;
+    for (int tt = tp; tt < NTT; tt += PT) {
+        const long long t = t00 + 16 * tt + j;   // this lane's time step (B-operand column)
+        if (t00 + 16 * tt >= p.T) break;          // uniform over the wave
+        const bool vy = t < p.T, vx = t + 1 < p.T;
+        double xn[D / 4], xc[D / 4], yv[16];
+#pragma unroll
+        for (int kk = 0; kk < D / 4; ++kk) {
+            xn[kk] = vx ? dense_load_mean(p, t + 1, chain, 4 * kk + kq) : 0.0;
+            xc[kk] = vy ? dense_load_mean(p, t, chain, 4 * kk + kq) : 0.0;
+        }
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = 4 * kk + kq;
+            yv[kk] = (vy && k < dy) ? p.y[(t * p.n_chains + chain) * dy + k] : 0.0;
+        }
+        typedef double v4d __attribute__((ext_vector_type(4)));
+        for (int rt = rg; rt < NT; rt += RT) {   // ρ_x, row tile rt
+            const double* a = MX + (size_t)(16 * rt + j) * LDX + kq;
+            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};   // two independent chains on the matrix pipe
+#pragma unroll
+            for (int kk = 0; kk < D / 4; ++kk) {
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * kk], xn[kk], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[D + 4 * kk], vx ? xc[kk] : 0.0, acc2, 0, 0, 0);
+            }
+            acc += acc2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double e = acc[r] * acc[r];
+                if (pk && 16 * rt + kq + 4 * r >= p.d_sub) s1 += e;
+                else s0 += e;
+            }
+        }
+        for (int rt = rg; rt < nty; rt += RT) {  // ρ_y, row tile rt
+            const double* a = MY + (size_t)(16 * rt + j) * LDY + kq;
+            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int kk = 0; kk < 16; ++kk)
+                if (4 * kk < dy4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * kk], yv[kk], acc, 0, 0, 0);
+#pragma unroll
+            for (int kk = 0; kk < D / 4; ++kk) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[dy4 + 4 * kk], xc[kk], acc2, 0, 0, 0);
+            acc += acc2;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const double e = acc[r] * acc[r];
+                if (pk && 16 * rt + kq + 4 * r >= p.dy_sub) s1 += e;
+                else s0 += e;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s0 += __shfl_down(s0, off);
+        s1 += __shfl_down(s1, off);
+    }
+    if (lane == 0) { red[g] = s0; red[4 + g] = s1; }
+    __syncthreads();
+    if (tid == 0) {
+        const double first = ((red[0] + red[1]) + red[2]) + red[3], sec = ((red[4] + red[5]) + red[6]) + red[7];
+        dense_fe_write(p, slot0 + blockIdx.x, chain, 0.0, first, sec);
     }
 }
 

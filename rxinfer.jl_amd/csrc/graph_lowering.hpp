@@ -4,7 +4,9 @@
 // GraphPPL.postprocess_plugin(::ReactiveMPInferencePlugin, model) (src/model/plugins/reactivemp_inference.jl:272-326):
 // instead of one ReactiveMP object per variable / factor, one pass over the SoA tables.
 #pragma once
+#include <algorithm>
 #include <array>
+#include <cmath>
 #include <map>
 #include <unordered_map>
 #include <cstdint>
@@ -127,6 +129,48 @@ inline bool same_const(const rxhip_graph_desc* g, long long a, long long b) {
 // covariance-parametrised forms (test/inference/prediction_tests.jl:197-213 spells a whole random-walk chain this way): a
 // private copy of the tables gets a new constant variable W⁻¹ per such node and the node type of the covariance form, and the
 // chain lowering below never sees a precision.  Nodes with a random precision (the iid Gaussian×Gamma family) are left alone.
+// Inverse of a constant precision (the covariance the kernels run on): symmetric within rounding or refused — the lowering
+// must not repair an input error by symmetrising afterwards — then through the Cholesky factor (positive definite or refused).
+// 0: ok, 1: not symmetric, 2: not positive definite.
+inline int spd_inverse_checked(int d, const double* W, std::vector<double>& inv) {
+    double amax = 0.0, asym = 0.0;
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j < d; ++j) {
+            amax = std::max(amax, std::fabs(W[(size_t)i * d + j]));
+            asym = std::max(asym, std::fabs(W[(size_t)i * d + j] - W[(size_t)j * d + i]));
+        }
+    if (!(asym <= 1e-12 * amax)) return 1;   // also catches NaN
+    std::vector<double> L((size_t)d * d, 0.0), Li((size_t)d * d, 0.0);
+    for (int j = 0; j < d; ++j) {
+        double s = W[(size_t)j * d + j];
+        for (int k = 0; k < j; ++k) s -= L[(size_t)j * d + k] * L[(size_t)j * d + k];
+        if (!(s > 0.0)) return 2;
+        const double ljj = std::sqrt(s);
+        L[(size_t)j * d + j] = ljj;
+        for (int i = j + 1; i < d; ++i) {
+            double t = 0.5 * (W[(size_t)i * d + j] + W[(size_t)j * d + i]);
+            for (int k = 0; k < j; ++k) t -= L[(size_t)i * d + k] * L[(size_t)j * d + k];
+            L[(size_t)i * d + j] = t / ljj;
+        }
+    }
+    for (int i = 0; i < d; ++i) {   // Li = L⁻¹, row by row
+        Li[(size_t)i * d + i] = 1.0;
+        for (int k = 0; k < i; ++k) {
+            const double l = L[(size_t)i * d + k];
+            for (int j = 0; j <= k; ++j) Li[(size_t)i * d + j] -= l * Li[(size_t)k * d + j];
+        }
+        const double r = 1.0 / L[(size_t)i * d + i];
+        for (int j = 0; j <= i; ++j) Li[(size_t)i * d + j] *= r;
+    }
+    inv.assign((size_t)d * d, 0.0);   // W⁻¹ = Li'Li, symmetric by construction
+    for (int i = 0; i < d; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double t = 0.0;
+            for (int k = i; k < d; ++k) t += Li[(size_t)k * d + i] * Li[(size_t)k * d + j];
+            inv[(size_t)i * d + j] = inv[(size_t)j * d + i] = t;
+        }
+    return 0;
+}
 struct NormalisedGraph {
     rxhip_graph_desc g;
     std::vector<int32_t> var_kind, var_rows, var_cols, factor_type, var_init_family;
@@ -161,21 +205,12 @@ inline rxhip_status normalise_precision_nodes(const rxhip_graph_desc* g0, Normal
         const int d = g0->var_rows[w];
         const double* W;
         if (g0->var_cols[w] != d || !const_value(g0, w, d, d, &W)) return badarg("precision of a Gaussian node is not a square constant");
-        std::vector<double> a(W, W + (size_t)d * d), inv((size_t)d * d, 0.0);
-        for (int i = 0; i < d; ++i) inv[(size_t)i * d + i] = 1.0;
-        for (int k = 0; k < d; ++k) {  // Gauss–Jordan on an SPD block
-            const double pv = a[(size_t)k * d + k];
-            if (!(pv > 0.0)) return badarg("precision of a Gaussian node is not positive definite");
-            for (int j = 0; j < d; ++j) { a[(size_t)k * d + j] /= pv; inv[(size_t)k * d + j] /= pv; }
-            for (int i = 0; i < d; ++i) {
-                if (i == k) continue;
-                const double f2 = a[(size_t)i * d + k];
-                if (f2 == 0.0) continue;
-                for (int j = 0; j < d; ++j) { a[(size_t)i * d + j] -= f2 * a[(size_t)k * d + j]; inv[(size_t)i * d + j] -= f2 * inv[(size_t)k * d + j]; }
-            }
+        std::vector<double> inv;
+        switch (spd_inverse_checked(d, W, inv)) {
+            case 1: return badarg("precision of a Gaussian node is not symmetric");
+            case 2: return badarg("precision of a Gaussian node is not positive definite");
+            default: break;
         }
-        for (int i = 0; i < d; ++i)  // exact symmetry of the covariance the kernels will read
-            for (int j = 0; j < i; ++j) inv[(size_t)i * d + j] = inv[(size_t)j * d + i] = 0.5 * (inv[(size_t)i * d + j] + inv[(size_t)j * d + i]);
         const long long nv = (long long)N.var_kind.size();
         N.var_kind.push_back(RXHIP_VARKIND_CONST);
         N.var_rows.push_back(d);
@@ -775,20 +810,13 @@ inline rxhip_status lower_mvgmm(const rxhip_graph_desc* g, MvGmm& M) {
         M.mu0.assign(mu, mu + d);
         M.S0.assign(S, S + d * d);
         if (g->factor_type[fm] == RXHIP_NODE_MVNORMAL_MEAN_PRECISION) {  // Λ given: the descriptor carries the covariance
-            // Gauss–Jordan on a d ≤ 4 SPD block
-            double a[16], inv[16];
-            for (int i = 0; i < d * d; ++i) { a[i] = S[i]; inv[i] = (i / d == i % d) ? 1.0 : 0.0; }
-            for (int k = 0; k < d; ++k) {
-                const double pv = a[k * d + k];
-                if (!(pv > 0.0)) return badarg("prior precision of the mean is not positive definite");
-                for (int j = 0; j < d; ++j) { a[k * d + j] /= pv; inv[k * d + j] /= pv; }
-                for (int i = 0; i < d; ++i) {
-                    if (i == k) continue;
-                    const double f2 = a[i * d + k];
-                    for (int j = 0; j < d; ++j) { a[i * d + j] -= f2 * a[k * d + j]; inv[i * d + j] -= f2 * inv[k * d + j]; }
-                }
+            std::vector<double> inv;
+            switch (spd_inverse_checked(d, S, inv)) {
+                case 1: return badarg("prior precision of the mean is not symmetric");
+                case 2: return badarg("prior precision of the mean is not positive definite");
+                default: break;
             }
-            M.S0.assign(inv, inv + d * d);
+            M.S0 = inv;
         }
         M.nu0.assign(1, nu);
         M.V0.assign(V, V + d * d);

@@ -343,6 +343,7 @@ struct rxhip_engine {
     double* h_stream = nullptr;   // its pinned host staging block
     double* d_stream = nullptr;   // rxhip_filter_step: belief per chain | staging of y, mean, cov, fe (allocated on first use)
     long long stream_k = 0;
+    bool have_inputs = false;      // engines with data inputs u[t] (du > 0): rxhip_set_data(RXHIP_VAR_U) has been called
     double *d_mu = nullptr, *d_nu = nullptr, *d_cx = nullptr, *d_cy_raw = nullptr;  // known inputs: μ[t] [Tout][d], ν[t] = B μ[t] + d[t] [Tout][dy], c[t], d[t]
     std::vector<double> h_mu, h_nu, h_cx, h_cy, h_offA, h_offB;
     std::vector<double> h_cx_const, h_cy_const;  // the offsets the engine was created with (graph constants), for RXHIP_VAR_U
@@ -658,6 +659,14 @@ static rxhip_status fail(rxhip_engine* e, rxhip_status s, const char* fmt, ...) 
     }
     return s;
 }
+// a temporary device block that is freed on every path out of its scope (early HIPCHK returns included)
+struct DevTmp {
+    void* p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp&) = delete;
+    DevTmp& operator=(const DevTmp&) = delete;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+};
 #define HIPCHK(e, call)                                                                              \
     do {                                                                                             \
         hipError_t _err = (call);                                                                    \
@@ -730,6 +739,35 @@ static bool chol_inv(int n, const double* A, double* out, double* logdet) {
     }
     for (int i = 0; i < n; ++i)
         for (int j = 0; j < i; ++j) out[(size_t)j * n + i] = out[(size_t)i * n + j];
+    return true;
+}
+// Li = L⁻¹ with A = L L' (lower Cholesky factor): x'A⁻¹x = |Li x|² — the whitening maps of the free-energy residuals
+static bool chol_linv(int n, const double* A, double* Li) {
+    std::vector<double> L((size_t)n * n, 0.0);
+    for (int j = 0; j < n; ++j) {
+        double s = A[j * n + j];
+        for (int k = 0; k < j; ++k) s -= L[j * n + k] * L[j * n + k];
+        if (!(s > 0.0)) return false;
+        const double ljj = std::sqrt(s);
+        L[j * n + j] = ljj;
+        for (int i = j + 1; i < n; ++i) {
+            double t = 0.5 * (A[i * n + j] + A[j * n + i]);
+            for (int k = 0; k < j; ++k) t -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = t / ljj;
+        }
+    }
+    std::fill(Li, Li + (size_t)n * n, 0.0);
+    for (int i = 0; i < n; ++i) {
+        double* ri = Li + (size_t)i * n;
+        ri[i] = 1.0;
+        for (int k = 0; k < i; ++k) {
+            const double l = L[i * n + k];
+            const double* rk = Li + (size_t)k * n;
+            for (int j = 0; j <= k; ++j) ri[j] -= l * rk[j];
+        }
+        const double inv = 1.0 / L[i * n + i];
+        for (int j = 0; j <= i; ++j) ri[j] *= inv;
+    }
     return true;
 }
 // C[n×k] = A[n×m] B[m×k]   (row of C accumulated from rows of B: contiguous inner loops)
@@ -1023,7 +1061,8 @@ struct DenseLaunch {
         for (const void* f : {(const void*)kd_agg_finish<NT>, (const void*)kd_scan_local<NT, true>, (const void*)kd_scan_local<NT, false>,
                               (const void*)kd_scan_fix<NT>, (const void*)kd_prepare_bnd<NT>, (const void*)kd_forward<NT, true>, (const void*)kd_forward<NT, false>,
                               (const void*)kd_forward_info<NT, true>, (const void*)kd_forward_info<NT, false>,
-                              (const void*)kd_backward_info<NT, true>, (const void*)kd_backward_info<NT, false>, (const void*)kd_fe_resid})
+                              (const void*)kd_backward_info<NT, true>, (const void*)kd_backward_info<NT, false>, (const void*)kd_fe_resid,
+                              (const void*)kd_fe_resid_mfma<NT>})
             if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
         return hipSuccess;
     }
@@ -1083,11 +1122,19 @@ struct DenseLaunch {
 // free-energy residual terms of an information-form smoothing run: one workgroup per FR_STEPS steps, partial slots 2S…
 static int fe_resid_blocks(long long T, int d, int dy) { const int st = fe_resid_steps(d, dy); return (int)((T + st - 1) / st); }
 static void launch_fe_resid(const DenseParams& p, hipStream_t s) {
+    static const bool valu = std::getenv("RXHIP_FE_RESID_VALU") != nullptr;  // the round-2 form (vector FMAs), kept as a cross-check
     for (long long c0 = 0; c0 < p.n_chains; c0 += 32768) {  // grid.y holds 65 535 blocks
         DenseParams q = p;
         q.chain0 = c0;
         const unsigned nc = (unsigned)(p.n_chains - c0 < 32768 ? p.n_chains - c0 : 32768);
-        hipLaunchKernelGGL(kd_fe_resid, dim3(fe_resid_blocks(p.T, p.d, p.dy), nc), dim3(256), fe_resid_lds_bytes(p.d, p.dy), s, q, 2 * p.S);
+        const dim3 g(fe_resid_blocks(p.T, p.d, p.dy), nc);
+        if (valu) { hipLaunchKernelGGL(kd_fe_resid, g, dim3(256), fe_resid_lds_bytes(p.d, p.dy), s, q, 2 * p.S); continue; }
+        switch (p.d / 16) {
+            case 1: hipLaunchKernelGGL(kd_fe_resid_mfma<1>, g, dim3(256), fe_resid_mfma_lds_bytes<1>(p.dy), s, q, 2 * p.S); break;
+            case 2: hipLaunchKernelGGL(kd_fe_resid_mfma<2>, g, dim3(256), fe_resid_mfma_lds_bytes<2>(p.dy), s, q, 2 * p.S); break;
+            case 3: hipLaunchKernelGGL(kd_fe_resid_mfma<3>, g, dim3(256), fe_resid_mfma_lds_bytes<3>(p.dy), s, q, 2 * p.S); break;
+            default: hipLaunchKernelGGL(kd_fe_resid_mfma<4>, g, dim3(256), fe_resid_mfma_lds_bytes<4>(p.dy), s, q, 2 * p.S); break;
+        }
     }
 }
 #define DENSE_DISPATCH(nt, CALL)                    \
@@ -1187,6 +1234,22 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
         for (int r = 0; r < dy; ++r)
             for (int k = 0; k < d; ++k) cst[c.oBT + (size_t)k * dy + r] = B[(size_t)r * d + k];
         cst[c.oFEC] = 0.5 * (ldV1 + (double)(e->T - 1) * ldP + (double)e->T * (dy * 1.8378770664093454835606594728112 + ldQ));
+        // whitening maps of the residual forms (kd_fe_resid_mfma): [L_P⁻¹ | −L_P⁻¹A], [L_Q⁻¹ | −L_Q⁻¹B] (zero-padded)
+        std::vector<double> LPi(MM), LPiA(MM), LQi((size_t)dy * dy), LQiB((size_t)dy * d);
+        if (!host::chol_linv(d, P, LPi.data())) return fail(e, RXHIP_ERR_NOT_POSDEF, "state noise P is not positive definite");
+        if (!host::chol_linv(dy, Q, LQi.data())) return fail(e, RXHIP_ERR_NOT_POSDEF, "observation noise Q is not positive definite");
+        host::mm(d, d, d, LPi.data(), A, LPiA.data());
+        host::mm(dy, dy, d, LQi.data(), B, LQiB.data());
+        const int dy4 = (dy + 3) & ~3, ky = dy4 + d;
+        for (int i = 0; i < d; ++i)
+            for (int k = 0; k < d; ++k) {
+                cst[c.oLPX + (size_t)i * 2 * d + k] = LPi[(size_t)i * d + k];
+                cst[c.oLPX + (size_t)i * 2 * d + d + k] = -LPiA[(size_t)i * d + k];
+            }
+        for (int i = 0; i < dy; ++i) {
+            for (int k = 0; k < dy; ++k) cst[c.oLQX + (size_t)i * ky + k] = LQi[(size_t)i * dy + k];
+            for (int k = 0; k < d; ++k) cst[c.oLQX + (size_t)i * ky + dy4 + k] = -LQiB[(size_t)i * d + k];
+        }
     }
     for (int i = 0; i < d; ++i) {
         for (int k = 0; k < d; ++k) cst[c.oAT + (size_t)k * d + i] = A[i * d + k];
@@ -1637,20 +1700,31 @@ rxhip_status rxhip_lgssm_set_chain_offsets(rxhip_engine* e, const double* state_
         }
         HIPCHK(e, hipMemcpy(ab, hab.data(), sizeof(double) * hab.size(), hipMemcpyHostToDevice));
     }
-    auto put = [&](double* dst, const double* src, size_t k) -> rxhip_status {  // host [To][C][k] or [C][To][k] -> device [To][C][k]
+    // host [To][C][k] or [C][To][k] -> device [To][C][k].  NULL keeps what the engine was created with: the constant offsets
+    // (graph constants c[t] / d[t]) replicated over the chains — NOT zeros: a model with data inputs on the transitions and a
+    // constant observation offset must keep the latter
+    auto put = [&](double* dst, const double* src, size_t k, const std::vector<double>& created) -> rxhip_status {
         const size_t n = To * C * k;
-        if (!src) { HIPCHK(e, hipMemsetAsync(dst, 0, sizeof(double) * n, e->stream)); return RXHIP_OK; }
-        if (layout == RXHIP_LAYOUT_TIME_CHAIN || C == 1) { HIPCHK(e, hipMemcpy(dst, src, sizeof(double) * n, hipMemcpyHostToDevice)); return RXHIP_OK; }
-        double* tmp = nullptr;
-        HIPCHK(e, hipMalloc(&tmp, sizeof(double) * n));
-        HIPCHK(e, hipMemcpy(tmp, src, sizeof(double) * n, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_transpose_rows, dim3(2048), dim3(256), 0, e->stream, (const double*)tmp, dst, (long long)C, (long long)To, (int)k);
+        std::vector<double> rep;
+        int lay = layout;
+        if (!src) {
+            if (created.size() != To * k) { HIPCHK(e, hipMemsetAsync(dst, 0, sizeof(double) * n, e->stream)); return RXHIP_OK; }
+            rep.resize(n);
+            for (size_t t = 0; t < To; ++t)
+                for (size_t ch = 0; ch < C; ++ch) std::memcpy(&rep[(t * C + ch) * k], &created[t * k], sizeof(double) * k);
+            src = rep.data();
+            lay = RXHIP_LAYOUT_TIME_CHAIN;
+        }
+        if (lay == RXHIP_LAYOUT_TIME_CHAIN || C == 1) { HIPCHK(e, hipMemcpy(dst, src, sizeof(double) * n, hipMemcpyHostToDevice)); return RXHIP_OK; }
+        DevTmp tmp;
+        HIPCHK(e, hipMalloc(&tmp.p, sizeof(double) * n));
+        HIPCHK(e, hipMemcpy(tmp.p, src, sizeof(double) * n, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_transpose_rows, dim3(2048), dim3(256), 0, e->stream, (const double*)tmp.p, dst, (long long)C, (long long)To, (int)k);
         HIPCHK(e, hipStreamSynchronize(e->stream));
-        HIPCHK(e, hipFree(tmp));
         return RXHIP_OK;
     };
-    if (rxhip_status st = put(cx, state_offset, d)) return st;
-    if (rxhip_status st = put(cy, obs_offset, dy)) return st;
+    if (rxhip_status st = put(cx, state_offset, d, e->h_cx_const)) return st;
+    if (rxhip_status st = put(cy, obs_offset, dy, e->h_cy_const)) return st;
     MuParams mp{};
     mp.To = (long long)To; mp.n_chains = e->n_chains; mp.d = e->d; mp.dy = e->dy; mp.ptt = e->ptt; mp.cx = cx; mp.cy = cy; mp.ab = ab;
     mp.step_model = e->d_step_model; mp.mu = mu; mp.nu = nu;
@@ -2714,19 +2788,18 @@ static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t
         HIPCHK(e, hipMemcpyAsync(e->d_y, src, sizeof(double) * need, src_on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
         HIPCHK(e, hipStreamSynchronize(e->stream));
     } else {
-        double* tmp = nullptr;
+        DevTmp tmp_guard;
         const double* dsrc = src;
         if (!src_on_device) {
-            HIPCHK(e, hipMalloc(&tmp, sizeof(double) * need));
-            HIPCHK(e, hipMemcpyAsync(tmp, src, sizeof(double) * need, hipMemcpyHostToDevice, e->stream));
-            dsrc = tmp;
+            HIPCHK(e, hipMalloc(&tmp_guard.p, sizeof(double) * need));
+            HIPCHK(e, hipMemcpyAsync(tmp_guard.p, src, sizeof(double) * need, hipMemcpyHostToDevice, e->stream));
+            dsrc = (const double*)tmp_guard.p;
         }
         // [chain][T][dy] -> [T][chain][dy]
         hipLaunchKernelGGL(k_transpose_rows, dim3(2048), dim3(256), 0, e->stream, dsrc, e->d_y, e->n_chains, e->T,
                            e->dy);
         HIPCHK(e, hipGetLastError());
         HIPCHK(e, hipStreamSynchronize(e->stream));
-        if (tmp) HIPCHK(e, hipFree(tmp));
     }
     if (e->d_nu) {  // known inputs: the sweep sees y − B μ − d
         hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, -1.0, e->off_chain ? 1 : 0);
@@ -2761,7 +2834,9 @@ static rxhip_status ingest_inputs(rxhip_engine* e, const double* u, size_t n, in
         for (size_t t = 0; t < To; ++t)
             for (size_t ch = 0; ch < C; ++ch) std::memcpy(&cy[(t * C + ch) * e->dy], &e->h_cy_const[t * e->dy], sizeof(double) * e->dy);
     }
-    return rxhip_lgssm_set_chain_offsets(e, c.data(), cy.empty() ? nullptr : cy.data(), RXHIP_LAYOUT_TIME_CHAIN);
+    const rxhip_status st = rxhip_lgssm_set_chain_offsets(e, c.data(), cy.empty() ? nullptr : cy.data(), RXHIP_LAYOUT_TIME_CHAIN);
+    if (st == RXHIP_OK) e->have_inputs = true;
+    return st;
 }
 
 rxhip_status rxhip_set_data(rxhip_engine* e, int32_t var_id, const double* host, size_t n, int32_t layout) {
@@ -2836,6 +2911,8 @@ rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, d
     if (!e->dense && !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "filter_step: no device schedule for this shape");
     if ((e->d_step_model || e->d_cx) && e->stream_k >= e->Tout())
         return fail(e, RXHIP_ERR_STATE, "filter_step: the per-step constants / known inputs of this engine end after %lld observations", (long long)e->Tout());
+    if (e->du > 0 && !e->have_inputs)
+        return fail(e, RXHIP_ERR_STATE, "filter_step: this model has data inputs u[t]: call rxhip_set_data(RXHIP_VAR_U) first");
     SET_DEVICE(e);
     const size_t C = (size_t)e->n_chains, d = (size_t)e->d, dy = (size_t)e->dy, ns = e->dense ? d * d : d * (d + 1) / 2;
     const size_t o_y = C * (d + ns), o_m = o_y + C * dy, o_c = o_m + C * d, o_f = o_c + C * d * d, total = o_f + C;
@@ -2864,8 +2941,8 @@ rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, d
     const size_t n_out = (cov || free_energy) ? total - o_m : C * d;  // mean | cov | fe are contiguous
     if (mean || cov || free_energy)
         HIPCHK(e, hipMemcpyAsync(e->h_stream + (o_m - o_y), sp.mean, sizeof(double) * n_out, hipMemcpyDeviceToHost, e->stream));
+    if (rxhip_status st = rxhip_sync(e)) return st;   // a failed step (e.g. NOT_POSDEF) does not advance the per-step constants
     e->stream_k += 1;
-    if (rxhip_status st = rxhip_sync(e)) return st;
     if (mean) std::memcpy(mean, e->h_stream + (o_m - o_y), sizeof(double) * C * d);
     if (cov) std::memcpy(cov, e->h_stream + (o_c - o_y), sizeof(double) * C * d * d);
     if (free_energy) std::memcpy(free_energy, e->h_stream + (o_f - o_y), sizeof(double) * C);
@@ -2893,6 +2970,8 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     }
     if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
     if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
+    // the reference refuses to run while a datavar has no value (batch.jl:387-407): so does an engine whose graph has data inputs
+    if (e->du > 0 && !e->have_inputs) return fail(e, RXHIP_ERR_STATE, "run: this model has data inputs u[t]: call rxhip_set_data(RXHIP_VAR_U) first");
     SET_DEVICE(e);
     if (iterations > e->fe_total_cap) {
         HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -3190,14 +3269,14 @@ static rxhip_status copy_out(rxhip_engine* e, const double* dsrc, double* host, 
         HIPCHK(e, hipMemcpy(host, dsrc, sizeof(double) * n, hipMemcpyDeviceToHost));
         return RXHIP_OK;
     }
-    double* tmp = nullptr;
-    HIPCHK(e, hipMalloc(&tmp, sizeof(double) * n));
+    DevTmp tmp_guard;
+    HIPCHK(e, hipMalloc(&tmp_guard.p, sizeof(double) * n));
+    double* tmp = (double*)tmp_guard.p;
     // [T][chain][k] -> [chain][T][k]
     hipLaunchKernelGGL(k_transpose_rows, dim3(2048), dim3(256), 0, e->stream, dsrc, tmp, rows, e->n_chains, k);
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));
     HIPCHK(e, hipMemcpy(host, tmp, sizeof(double) * n, hipMemcpyDeviceToHost));
-    HIPCHK(e, hipFree(tmp));
     return RXHIP_OK;
 }
 
@@ -3255,8 +3334,9 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
     if (e->dense) {  // any d, dy ≤ 64: observation-space form, one workgroup per (chain, time index)
         // 133 KB of dynamic LDS at d = dy = 64 (the kernel also holds a few bytes of static LDS: not the full 160 KB)
         once_per_device(3, e->device, [] { (void)hipFuncSetAttribute((const void*)k_predict_generic, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024); });
-        double* tmp = nullptr;
-        HIPCHK(e, hipMalloc(&tmp, sizeof(double) * rows * (dy + dy * dy)));
+        DevTmp tmp_guard;
+        HIPCHK(e, hipMalloc(&tmp_guard.p, sizeof(double) * rows * (dy + dy * dy)));
+        double* tmp = (double*)tmp_guard.p;
         GenericParams gp{};
         gp.T = e->T; gp.H = e->H; gp.n_chains = e->n_chains; gp.d = e->d; gp.dy = e->dy; gp.y = e->d_y; gp.mean = e->d_mean; gp.cov = e->d_cov;
         gp.user = e->d_user; gp.chain_model = e->d_chain_model; gp.step_model = e->d_step_model; gp.pmean = tmp; gp.pcov = tmp + rows * dy; gp.status = e->d_status;
@@ -3267,7 +3347,6 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
         if (!st) st = rxhip_sync(e);
         if (!st && mean) st = copy_out(e, gp.pmean, mean, e->dy, layout, e->Tout());
         if (!st && cov) st = copy_out(e, gp.pcov, cov, e->dy * e->dy, layout, e->Tout());
-        (void)hipFree(tmp);
         return st;
     }
     if (!e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "predictions: no schedule for this shape");
@@ -3275,8 +3354,9 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
         HIPCHK(e, hipMalloc(&e->d_bq, sizeof(double) * e->h_bq.size()));
         HIPCHK(e, hipMemcpy(e->d_bq, e->h_bq.data(), sizeof(double) * e->h_bq.size(), hipMemcpyHostToDevice));
     }
-    double* tmp = nullptr;
-    HIPCHK(e, hipMalloc(&tmp, sizeof(double) * rows * (dy + dy * dy)));
+    DevTmp tmp_guard;
+    HIPCHK(e, hipMalloc(&tmp_guard.p, sizeof(double) * rows * (dy + dy * dy)));
+    double* tmp = (double*)tmp_guard.p;
     PredictParams pp{};
     pp.T = e->T; pp.H = e->H; pp.n_chains = e->n_chains; pp.y = e->d_y; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
     pp.bq = e->d_bq; pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.pmean = tmp; pp.pcov = tmp + rows * dy; pp.status = e->d_status;
@@ -3287,7 +3367,6 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
     if (!st) st = rxhip_sync(e);  // also reports a leave-one-out precision that is not positive definite
     if (!st && mean) st = copy_out(e, pp.pmean, mean, e->dy, layout, e->Tout());
     if (!st && cov) st = copy_out(e, pp.pcov, cov, e->dy * e->dy, layout, e->Tout());
-    (void)hipFree(tmp);
     return st;
 }
 
@@ -3301,8 +3380,9 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
     if (e->T < 2) return RXHIP_OK;  // a single time step has no transition node between observed states
     SET_DEVICE(e);
     const size_t rows = (size_t)(e->T - 1) * e->n_chains, d2 = 2 * (size_t)e->d;
-    double* tmp = nullptr;
-    HIPCHK(e, hipMalloc(&tmp, sizeof(double) * rows * (d2 + d2 * d2)));
+    DevTmp tmp_guard;
+    HIPCHK(e, hipMalloc(&tmp_guard.p, sizeof(double) * rows * (d2 + d2 * d2)));
+    double* tmp = (double*)tmp_guard.p;
     if (e->dense) {
         // any d ≤ 64: Cov(x[t], x[t+1] | y) = G_t V_s(t+1) is what the joints need beyond the posteriors, and no schedule of the
         // MFMA path keeps it.  The sequential kernels recompute the sweep into scratch arrays with that product kept
@@ -3311,7 +3391,6 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
         const size_t nm = T * C * d, nc = T * C * d * d, nx = (T - 1) * C * d * d;
         double* scr = nullptr;
         if (hipMalloc(&scr, sizeof(double) * (nm + nc + nx)) != hipSuccess) {
-            (void)hipFree(tmp);
             return fail(e, RXHIP_ERR_HIP, "get_node_marginals: hipMalloc of %zu bytes of scratch failed", sizeof(double) * (nm + nc + nx));
         }
         once_per_device(0, e->device, [] {
@@ -3337,7 +3416,6 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
         if (!st && mean) st = copy_out(e, jp.jmean, mean, (int)d2, layout, e->T - 1);
         if (!st && cov) st = copy_out(e, jp.jcov, cov, (int)(d2 * d2), layout, e->T - 1);
         (void)hipFree(scr);
-        (void)hipFree(tmp);
         return st;
     }
     PredictParams pp{};
@@ -3351,7 +3429,6 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
     if (!st) st = rxhip_sync(e);
     if (!st && mean) st = copy_out(e, pp.jmean, mean, (int)d2, layout, e->T - 1);
     if (!st && cov) st = copy_out(e, pp.jcov, cov, (int)(d2 * d2), layout, e->T - 1);
-    (void)hipFree(tmp);
     return st;
 }
 
@@ -3457,8 +3534,9 @@ rxhip_status rxhip_get_marginals_chains(rxhip_engine* e, int32_t var_id, const i
         if (chains[i] < 0 || chains[i] >= e->n_chains) return fail(e, RXHIP_ERR_BADARG, "get_marginals_chains: chain %lld out of range", (long long)chains[i]);
     SET_DEVICE(e);
     const size_t nm = (size_t)n * e->Tout() * e->d, nc = nm * e->d;
-    char* tmp = nullptr;
-    HIPCHK(e, hipMalloc(&tmp, sizeof(long long) * (size_t)n + sizeof(double) * (nm + nc)));
+    DevTmp tmp_guard;
+    HIPCHK(e, hipMalloc(&tmp_guard.p, sizeof(long long) * (size_t)n + sizeof(double) * (nm + nc)));
+    char* tmp = (char*)tmp_guard.p;
     double* g_mean = (double*)tmp;
     double* g_cov = g_mean + nm;
     long long* d_ch = (long long*)(g_cov + nc);
@@ -3474,7 +3552,6 @@ rxhip_status rxhip_get_marginals_chains(rxhip_engine* e, int32_t var_id, const i
     chk(hipStreamSynchronize(e->stream), "gather");
     if (!st && mean) chk(hipMemcpy(mean, g_mean, sizeof(double) * nm, hipMemcpyDeviceToHost), "copy of means");
     if (!st && cov) chk(hipMemcpy(cov, g_cov, sizeof(double) * nc, hipMemcpyDeviceToHost), "copy of covariances");
-    (void)hipFree(tmp);
     return st;
 }
 
@@ -3518,8 +3595,13 @@ Rccl& rccl() {
         names.push_back("librccl.so.1");
         names.push_back("librccl.so");
         names.push_back("/opt/rocm/lib/librccl.so.1");
+        if (const char* forced = std::getenv("RXHIP_RCCL_LIB")) names.assign(1, forced);  // this copy or none (deployments with their own RCCL; tests)
         for (size_t i = 0; !q->h && i < names.size(); ++i) q->h = dlopen(names[i].c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
-        if (!q->h) { q->err = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?"); return q; }
+        if (!q->h) {
+            const char* de = dlerror();  // ONE call: dlerror() clears the message it returns
+            q->err = std::string("librccl not found: ") + (de ? de : "?");
+            return q;
+        }
         bool all = true;
         auto sym = [&](const char* n) { void* p = dlsym(q->h, n); if (!p) { all = false; q->err = std::string("librccl lacks ") + n; } return p; };
         q->GetUniqueId = (decltype(q->GetUniqueId))sym("ncclGetUniqueId");

@@ -118,26 +118,6 @@ mutable struct GraphTables
                         String[], Float64[], Int32(0), Dict{GraphPPL.NodeLabel, Int64}())
 end
 
-# mirrors rxhip_graph_desc field for field
-struct GraphDescC
-    n_variables::Int64
-    var_kind::Ptr{Int32}
-    var_rows::Ptr{Int32}
-    var_cols::Ptr{Int32}
-    var_const::Ptr{Int64}
-    n_factors::Int64
-    factor_type::Ptr{Int32}
-    factor_iface::Ptr{Int64}
-    const_pool::Ptr{Float64}
-    n_const::Int64
-    n_replicas::Int64
-    factor_iface_ptr::Ptr{Int64}
-    var_init_family::Ptr{Int32}
-    var_init::Ptr{Int64}
-    gh_points::Int32
-    n_observations::Int64
-end
-
 struct UnsupportedGraph <: Exception
     why::String
 end

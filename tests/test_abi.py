@@ -85,3 +85,25 @@ def test_product_does_not_import_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp", ".jl")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "rxoracle" not in txt and "oracle/" not in txt, os.path.join(dp, f)
+
+
+def test_missing_rccl_is_a_status_not_a_crash():
+    """when librccl cannot be opened every rxhip_comm_* entry point returns RXHIP_ERR_RCCL with a message (the loader
+    used to call dlerror() twice and build a std::string from NULL).  RXHIP_RCCL_LIB pins the copy to load; a separate process,
+    because the loader runs once per process."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        f"sys.path.insert(0, {os.path.join(ROOT, 'rxinfer.jl_amd')!r})\n"
+        "from rxhip import _lib\n"
+        "L = _lib.lib()\n"
+        "buf = ctypes.create_string_buffer(128)\n"
+        "st = L.rxhip_comm_unique_id(buf)\n"
+        "L.rxhip_comm_last_error.restype = ctypes.c_char_p\n"
+        "print(st, L.rxhip_comm_last_error().decode())\n")
+    env = dict(os.environ, RXHIP_RCCL_LIB="/nonexistent/librccl.so.1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    st, msg = out.stdout.strip().split(" ", 1)
+    assert int(st) == 8 and "librccl not found" in msg and "nonexistent" in msg   # RXHIP_ERR_RCCL

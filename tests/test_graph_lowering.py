@@ -271,6 +271,20 @@ def test_precision_parametrised_chains_are_the_covariance_form():
     with pytest.raises(rxhip.RxHipError) as ei:
         graph.lower_lgssm(gb.tables()[0])
     assert ei.value.status == _lib.ERR_BADARG and "positive definite" in str(ei.value)
+    # ... and so is one that is not symmetric: the lowering does not repair it by symmetrising the inverse
+    gb, xs, ys = graph.lgssm_graph(4, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    for f, t in enumerate(gb.ftype):
+        if t == _lib.NODE_MVNORMAL_MEAN_COV and np.asarray(gb.const_value(gb.fiface[f][2])).shape == (3, 3):
+            W = np.linalg.inv(np.asarray(gb.const_value(gb.fiface[f][2])))
+            W[0, 1] += 0.05
+            it = list(gb.fiface[f])
+            it[2] = gb.constvar(W)
+            gb.fiface[f] = tuple(it)
+            gb.ftype[f] = _lib.NODE_MVNORMAL_MEAN_PRECISION
+            break
+    with pytest.raises(rxhip.RxHipError) as ei:
+        graph.lower_lgssm(gb.tables()[0])
+    assert ei.value.status == _lib.ERR_BADARG and "not symmetric" in str(ei.value)
 
 
 def test_identity_observation_in_a_vector_chain():

@@ -41,3 +41,40 @@ def julia_fields(name):
 def test_every_mirrored_struct_has_the_header_fields_in_order():
     for cname, jname in PAIRS.items():
         assert julia_fields(jname) == c_fields(cname), (cname, jname)
+
+
+PLUGIN = open(os.path.join(ROOT, "rxinfer.jl_amd", "julia", "HIPInferencePlugin.jl")).read()
+
+
+def test_plugin_holds_no_second_copy_of_a_c_struct():
+    """A C descriptor is mirrored ONCE, in RxHip.jl (checked above).  The plugin once carried a private copy of rxhip_graph_desc
+    that nothing used and that had already lost a field: any struct of the plugin whose fields are pointers is
+    such a copy."""
+    for m in re.finditer(r"(?:mutable\s+)?struct\s+([A-Za-z_0-9]+)[^\n]*\n(.*?)\nend", PLUGIN, re.S):
+        assert "::Ptr{" not in m.group(2), f"struct {m.group(1)} of the plugin mirrors a C struct: keep the mirror in RxHip.jl"
+
+
+def test_node_vocabulary_of_the_plugin_is_the_header_enum():
+    """hip_node(fform) -> (code, name, interfaces) against RXHIP_NODE_* and the interface orders the header documents."""
+    enum = {int(v): k for k, v in re.findall(r"RXHIP_NODE_([A-Z_]+)\s*=\s*(\d+)", HEADER)}
+    codes = {}
+    for code, name, ifaces in re.findall(r"hip_node\(.*?\)\s*=\s*\(Int32\((\d+)\),\s*\"([^\"]+)\",\s*\(([^)]*)\)\)", PLUGIN):
+        codes[int(code)] = (name, [x.strip().lstrip(":") for x in ifaces.split(",") if x.strip()])
+    assert sorted(codes) == sorted(enum), (sorted(codes), sorted(enum))     # every node of the header, no other
+    want = {"MVNORMAL_MEAN_COV": "MvNormalMeanCovariance", "MULTIPLY": "*", "NORMAL_MEAN_VARIANCE": "NormalMeanVariance",
+            "NORMAL_MEAN_PRECISION": "NormalMeanPrecision", "GAMMA_SHAPE_RATE": "GammaShapeRate", "DIRICHLET": "Dirichlet",
+            "BETA": "Beta", "CATEGORICAL": "Categorical", "BERNOULLI": "Bernoulli", "NORMAL_MIXTURE": "NormalMixture", "GCV": "GCV",
+            "WISHART": "Wishart", "ADD": "+", "MVNORMAL_MEAN_PRECISION": "MvNormalMeanPrecision", "GAMMA_SHAPE_SCALE": "GammaShapeScale"}
+    for code, cname in enum.items():
+        assert codes[code][0] == want[cname], (code, cname, codes[code])
+    # interface order: the tuple in the header comment of each enumerator, where it gives one
+    for cname, tup in re.findall(r"RXHIP_NODE_([A-Z_]+)\s*=\s*\d+,?\s*/\*\s*\(([^)]*)\)", HEADER):
+        code = next(k for k, v in enum.items() if v == cname)
+        hdr = [re.sub(r"\[.*?\]", "", x).strip() for x in tup.split(",")]
+        assert codes[code][1] == hdr, (cname, codes[code][1], hdr)
+    # the Python mirror's constants are the same enum
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "rxinfer.jl_amd"))
+    from rxhip import _lib
+    for code, cname in enum.items():
+        assert getattr(_lib, "NODE_" + cname) == code, cname

@@ -286,6 +286,35 @@ def test_infer_mirror_with_control_inputs_as_data():
     assert np.allclose(res.posteriors["x"].mean, om, rtol=1e-6, atol=1e-8) and res.free_energy[-1] == pytest.approx(nll, rel=1e-8)
 
 
+@pytest.mark.gpu
+def test_control_inputs_as_data_keep_a_constant_observation_offset():
+    """`input_matrix` (u as data) together with `obs_offset` — the per-chain inputs must not wipe the constant d[t]
+    (NULL in rxhip_lgssm_set_chain_offsets keeps the offsets of creation).  Checked against the oracle with both offsets and
+    against the same model spelt with the inputs folded into a constant `state_offset`."""
+    import rxhip
+    rng = np.random.default_rng(34)
+    A, B, P, Q = np.array([[1.0, 0.1], [0.0, 1.0]]), np.array([[1.0, 0.0]]), np.eye(2) * 0.01, np.eye(1) * 0.25
+    Bu = np.array([[0.005], [0.1]])
+    T = 60
+    u, y = rng.standard_normal((T, 1)), rng.standard_normal((T, 1))
+    dofs = 1.5 + 0.1 * np.arange(T)[:, None]                      # d[t], (T, dy)
+    spec = rxhip.linear_gaussian_ssm(A, B, P, Q, np.zeros(2), np.eye(2), input_matrix=Bu, obs_offset=dofs)
+    res = rxhip.infer(model=spec, data={"y": y, "u": u}, free_energy=True)
+    om, oc, nll = rxo.lgssm_kalman_rts_affine(A, B, P, Q, np.zeros(2), np.eye(2), y, u @ Bu.T, dofs)
+    assert np.allclose(res.posteriors["x"].mean, om, rtol=1e-6, atol=1e-8)
+    assert res.free_energy[-1] == pytest.approx(nll, rel=1e-8)
+    folded = rxhip.linear_gaussian_ssm(A, B, P, Q, np.zeros(2), np.eye(2), state_offset=u @ Bu.T, obs_offset=dofs)
+    ref = rxhip.infer(model=folded, data={"y": y}, free_energy=True)
+    assert np.allclose(res.posteriors["x"].mean, ref.posteriors["x"].mean, rtol=1e-9, atol=1e-10)
+    assert res.free_energy[-1] == pytest.approx(ref.free_energy[-1], rel=1e-10)
+    # several chains through the same path
+    yc, uc = rng.standard_normal((3, T, 1)), rng.standard_normal((3, T, 1))
+    resc = rxhip.infer(model=spec, data={"y": yc, "u": uc}, free_energy=True)
+    for c in range(3):
+        om, _, nll = rxo.lgssm_kalman_rts_affine(A, B, P, Q, np.zeros(2), np.eye(2), yc[c], uc[c] @ Bu.T, dofs)
+        assert np.allclose(resc.posteriors["x"].mean[c], om, rtol=1e-6, atol=1e-8)
+
+
 def test_data_inputs_in_a_graph_are_recognised():
     """`x[t] ~ MvNormal(μ = A * x[t-1] + B_u * u[t], Σ = P)` with u[t] a data variable: `*`(B_u, u) feeding a `+` without a constant."""
     import rxhip  # noqa: F401
@@ -308,7 +337,7 @@ def test_data_inputs_in_a_graph_are_recognised():
 
 @pytest.mark.gpu
 def test_graph_engine_with_data_inputs():
-    import rxhip  # noqa: F401
+    import rxhip
     from rxhip import graph
     rng = np.random.default_rng(13)
     d, dy, T, du, C = 2, 2, 45, 1, 3
@@ -320,6 +349,10 @@ def test_graph_engine_with_data_inputs():
     eng = graph.create_engine_from_graph(gb.tables(n_replicas=C)[0])
     y, u = rng.standard_normal((C, T, dy)), rng.standard_normal((C, T, du))
     eng.set_data(y, layout="chain_time")
+    # a datavar without a value: the reference refuses to run (batch.jl:387-407), and so does the engine
+    with pytest.raises(rxhip.RxHipError) as ei:
+        eng.run(1, True)
+    assert ei.value.status == rxhip._lib.ERR_STATE and "RXHIP_VAR_U" in str(ei.value)
     eng.set_inputs(u, layout="chain_time")
     eng.run(1, True)
     mean, cov = eng.marginals(layout="chain_time")
