@@ -100,6 +100,11 @@ struct DenseParams {
     // two-level boundary scan (see kd_scan_local / kd_scan_fix): scan steps st = 0 … S−2 in groups of `sg`
     const double* qtab;   // [2][S][d][d]  index q = st + 1: product of the step maps from the start of q's group through st (transposed)
     double* loc;          // [chain][2][S][d]  index q: state after step q − 1 of a scan that starts every group from zero
+    const int* canon;     // [4][S] canonical indices of the boundary maps: a time-invariant model's Riccati recursions converge, and from
+                          // then on the maps of a segment are bit-identical copies of the previous one's (build_dense_tables).  [0][s]: the
+                          // first segment whose prefix maps (scanm 0–2) equal segment s's; [1][s]: suffix maps (3–5); [2][q] / [3][q]: the first q'
+                          // with qtab[dir][q'] == qtab[dir][q].  The scan kernels address maps through it, so a converged stretch of the
+                          // recursion keeps ONE 32 KB map in registers instead of streaming a new copy from HBM every round.  NULL: identity.
     double* bnd;          // [S][2][d][d]  data-independent boundary inverses (kd_prepare_bnd, once per engine): 0: Λ_f(b_s) = V(b_s)⁻¹;  1: V_s(b_{s+1}) = (Λ_f + Λβ)⁻¹ (s < S − 1)
     int sg, ng;           // group size, number of groups
     double* fe_part;      // [slot][user chain]
@@ -118,10 +123,11 @@ struct DenseParams {
 struct DenseModel {
     const double *cst, *tab, *scanm, *qtab;
     double* bnd;
+    const int* canon;
 };
 __device__ __forceinline__ DenseModel dense_model(const DenseParams& p, long long chain) {
     if (p.models) return p.models[p.chain_model[chain]];
-    return DenseModel{p.cst, p.tab, p.scanm, p.qtab, p.bnd};
+    return DenseModel{p.cst, p.tab, p.scanm, p.qtab, p.bnd, p.canon};
 }
 
 // ---- posterior / free-energy output addressing (one chain per workgroup, or the packed pair) -------------------------
@@ -750,7 +756,7 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
 #define RXHIP_INV_BLOCKED 1
 #endif
 #ifndef RXHIP_KF_RELOAD
-#define RXHIP_KF_RELOAD 2
+#define RXHIP_KF_RELOAD 1
 #endif
 template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true>
 __device__ __forceinline__ bool spd_inverse(Acc<NT>& a, double* scratch, int w, int lane, LogProd& lp, PF prefetch = PF()) {
@@ -1054,14 +1060,20 @@ __device__ __forceinline__ void dense_affine_rounds(int nrounds, MapF map_of, WF
     const int part = tid / D, i = tid - part * D, k0 = part * KP;
     if (nrounds <= 0) return;
     double buf[PD][KP], wb[PD];
-    auto fetch = [&](double (&dst)[KP], double& w, int r) {
-        const double* Mt = map_of(r);
+    const double* cur[PD];   // the map each slot holds (uniform over the workgroup): a canonical map that is still there is not fetched again
 #pragma unroll
-        for (int u = 0; u < KP; ++u) dst[u] = Mt[(size_t)(k0 + u) * D + i];
+    for (int q = 0; q < PD; ++q) cur[q] = nullptr;
+    auto fetch = [&](double (&dst)[KP], double& w, const double*& have, int r) {
+        const double* Mt = map_of(r);
+        if (Mt != have) {
+#pragma unroll
+            for (int u = 0; u < KP; ++u) dst[u] = Mt[(size_t)(k0 + u) * D + i];
+            have = Mt;
+        }
         w = tid < D ? w_of(r)[tid] : 0.0;
     };
 #pragma unroll
-    for (int q = 0; q < PD; ++q) fetch(buf[q], wb[q], q < nrounds ? q : nrounds - 1);
+    for (int q = 0; q < PD; ++q) fetch(buf[q], wb[q], cur[q], q < nrounds ? q : nrounds - 1);
     for (int r0 = 0; r0 < nrounds; r0 += PD) {
 #pragma unroll
         for (int q = 0; q < PD; ++q) {
@@ -1074,7 +1086,7 @@ __device__ __forceinline__ void dense_affine_rounds(int nrounds, MapF map_of, WF
                 s1 += buf[q][u + 1] * v0[k0 + u + 1];
             }
             const double wv = wb[q];
-            fetch(buf[q], wb[q], r + PD < nrounds ? r + PD : nrounds - 1);  // unconditional (clamped): keeps the waitcnt bookkeeping exact
+            fetch(buf[q], wb[q], cur[q], r + PD < nrounds ? r + PD : nrounds - 1);  // unconditional (clamped): keeps the waitcnt bookkeeping exact
             red[tid] = s0 + s1;
             lds_barrier();
             if (tid < D) {
@@ -1163,7 +1175,10 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
     auto seg_of = [&](int st) { return dir ? S - 1 - st : st; };
     dense_affine_rounds<NT, true>(
         st1 - st0,
-        [&](int r) { return M.scanm + ((size_t)seg_of(st0 + r) * 6 + (dir ? 3 : 0)) * MM; },
+        [&](int r) {
+            const int sgm = seg_of(st0 + r);
+            return M.scanm + ((size_t)(M.canon ? M.canon[dir * S + sgm] : sgm) * 6 + (dir ? 3 : 0)) * MM;
+        },
         [&](int r) { return p.elem + ((chain * S + seg_of(st0 + r)) * 2 + dir) * D; },
         [&](int r, double x) { loc[(size_t)(st0 + r + 1) * D + tid] = x; }, v0, red, tid);
 }
@@ -1186,19 +1201,20 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_fix(DenseParams p) {
     if (n <= 0) return;
     const double* loc = p.loc + ((chain * 2 + dir) * (size_t)S) * D;
     const double* qt = M.qtab + (size_t)dir * S * MM;
+    const int* qc = M.canon ? M.canon + (2 + dir) * S : nullptr;   // canonical q of every composed map
     if (tid < D) v0[tid] = dir ? 0.0 : p.fstart_m[(chain * S + 0) * D + tid];
     lds_barrier();
     const int sg = p.sg;
     // level 2: state at the start of this group
     dense_affine_rounds<NT, true>(
-        grpj, [&](int r) { return qt + (size_t)((r + 1) * sg) * MM; }, [&](int r) { return loc + (size_t)((r + 1) * sg) * D; },
+        grpj, [&](int r) { const int q = (r + 1) * sg; return qt + (size_t)(qc ? qc[q] : q) * MM; }, [&](int r) { return loc + (size_t)((r + 1) * sg) * D; },
         [&](int, double) {}, v0, red, tid);
     // level 3: the states inside the group
     const int q0 = grpj * sg + 1;
     int q1 = q0 + sg;
     if (q1 > n + 1) q1 = n + 1;
     dense_affine_rounds<NT, false>(
-        q1 - q0, [&](int r) { return qt + (size_t)(q0 + r) * MM; }, [&](int r) { return loc + (size_t)(q0 + r) * D; },
+        q1 - q0, [&](int r) { const int q = q0 + r; return qt + (size_t)(qc ? qc[q] : q) * MM; }, [&](int r) { return loc + (size_t)(q0 + r) * D; },
         [&](int r, double x) {
             const int q = q0 + r;
             if (dir) p.beta_xi[(chain * (S + 1) + (S - q)) * D + tid] = x;

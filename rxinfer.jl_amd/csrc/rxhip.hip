@@ -326,6 +326,7 @@ struct rxhip_engine {
     bool dense = false;
     int nt = 0;
     double *d_scanm = nullptr, *d_fstart_m = nullptr, *d_beta_xi = nullptr, *d_vend = nullptr, *d_qtab = nullptr, *d_loc = nullptr, *d_bnd = nullptr;
+    const int* d_canon = nullptr;  // canonical indices of the boundary maps (DenseParams::canon), inside the shared table block
     int scan_sg = 1, scan_ng = 1;  // two-level boundary scan of the dense path: group size, groups
     int agg_oc = 1, agg_kc = 1;    // dense aggregation product: offsets per K-chunk, K-chunks
     double* d_aggpart = nullptr;   // [chain][agg_kc][S][2·dpad] partial sums of kd_agg_gemm
@@ -547,6 +548,7 @@ struct DenseTables {
     char* block = nullptr;
     size_t bytes = 0;
     double *d_cst = nullptr, *d_tab = nullptr, *d_scanm = nullptr, *d_qtab = nullptr, *d_bnd = nullptr;
+    int* d_canon = nullptr;
     int agg_oc = 1, agg_kc = 1, scan_sg = 1, scan_ng = 1;
     int refs = 0;
     unsigned long long last_use = 0;
@@ -1150,7 +1152,8 @@ static int dense_rec(int nt) { return 3 * 16 * nt + 2 * 256 * nt * nt; }  // Den
 // Per-model tables of the dense path: constants, per-offset gains (K_i, U_i), and the data-independent
 // matrix part of the boundary scan for every segment (see dense_kernels.hpp DenseParams::scanm).
 static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* ds, std::vector<double>& cst,
-                                       std::vector<double>& tab, std::vector<double>& scanm, std::vector<double>& qtab) {
+                                       std::vector<double>& tab, std::vector<double>& scanm, std::vector<double>& qtab,
+                                       std::vector<int>& canon) {
     // ds: the model at KERNEL level (a packed pair is one block-diagonal model of dimension 16, see rxhip_lgssm_create)
     const int d = e->dpad, dy = ds->dy, du = ds->d;
     const size_t MM = (size_t)d * d;
@@ -1348,6 +1351,10 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
     // boundary-scan matrices
     const int S_ = e->S;
     scanm.assign((size_t)(S_ > 0 ? S_ : 1) * 6 * MM, 0.0);
+    // canonical indices (DenseParams::canon): identity until a recursion has converged, then the segment the copies come from
+    canon.assign((size_t)4 * (S_ > 0 ? S_ : 1), 0);
+    for (int q = 0; q < 4; ++q)
+        for (int s = 0; s < S_; ++s) canon[(size_t)q * S_ + s] = s;
     if (S_ > 0) {
         // Both recursions below are Riccati iterations with constant coefficients: after a transient of a few segments the
         // boundary covariance (precision) stops changing, and with it the maps.  Once two consecutive boundaries agree to
@@ -1367,6 +1374,7 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
             double* sm = scanm.data() + (size_t)s * 6 * MM;
             if (conv) {  // maps 0, 1 and V(b_s) of the previous segment
                 std::copy(sm - 6 * MM, sm - 3 * MM, sm);
+                if (s < S_ - 1) canon[s] = canon[s - 1];   // (the last segment has no step map: its slots 0, 1 are never read)
                 continue;
             }
             for (size_t q = 0; q < MM; ++q) sm[2 * MM + q] = Vc[q];
@@ -1396,6 +1404,7 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
             double* sm = scanm.data() + (size_t)s * 6 * MM;
             if (conv) {  // maps 3, 4 and Λβ of the following segment (both full-length segments)
                 std::copy(sm + 9 * MM, sm + 12 * MM, sm + 3 * MM);
+                canon[(size_t)S_ + s] = canon[(size_t)S_ + s + 1];
                 continue;
             }
             for (size_t q = 0; q < MM; ++q) { sm[5 * MM + q] = Lm[q]; tt[q] = g.Ci[q] + Lm[q]; }
@@ -1440,6 +1449,7 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
                 double* qt = qtab.data() + ((size_t)dir * S_ + (st + 1)) * MM;
                 if (grp_same) {
                     std::copy(qt - (size_t)sg * MM, qt - (size_t)sg * MM + MM, qt);
+                    canon[(size_t)(2 + dir) * S_ + (st + 1)] = canon[(size_t)(2 + dir) * S_ + (st + 1 - sg)];
                     qc_stale = true;
                     continue;
                 }
@@ -1568,6 +1578,7 @@ static void free_all(rxhip_engine* e) {
     if (!e->dts.empty()) {  // shared tables: not this engine's to free; nothing may still read them
         if (e->stream) (void)hipStreamSynchronize(e->stream);
         e->d_cst = e->d_tab = e->d_scanm = e->d_qtab = e->d_bnd = nullptr;
+        e->d_canon = nullptr;
         for (DenseTables* dt : e->dts) dense_tables_release(dt);
         e->dts.clear();
     }
@@ -1968,24 +1979,27 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             DenseTables* dt = dense_tables_acquire(key, e->device);
             if (!dt) {
                 std::vector<double> cst, tab, scanm, qtab;
-                st = build_dense_tables(e, &dm, cst, tab, scanm, qtab);
+                std::vector<int> canon;
+                st = build_dense_tables(e, &dm, cst, tab, scanm, qtab, canon);
                 if (st) return st;
                 tr.mark("dense: host tables");
                 dt = new DenseTables;
                 dt->key.swap(key);
                 dt->device = e->device;
                 dt->agg_oc = e->agg_oc; dt->agg_kc = e->agg_kc; dt->scan_sg = e->scan_sg; dt->scan_ng = e->scan_ng;
-                const size_t nb[5] = {cst.size(), tab.size(), scanm.size(), qtab.size(), Sg * 2 * D * D};
-                size_t off[6] = {0};
-                for (int q = 0; q < 5; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * (nb[q] ? nb[q] : 1));
-                dt->bytes = off[5];
-                if (hipMalloc(&dt->block, dt->bytes) != hipSuccess) { delete dt; return fail(e, RXHIP_ERR_HIP, "hipMalloc of %zu bytes (model tables) failed", off[5]); }
+                const size_t nb[6] = {cst.size(), tab.size(), scanm.size(), qtab.size(), Sg * 2 * D * D, (canon.size() + 1) / 2};
+                size_t off[7] = {0};
+                for (int q = 0; q < 6; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * (nb[q] ? nb[q] : 1));
+                dt->bytes = off[6];
+                if (hipMalloc(&dt->block, dt->bytes) != hipSuccess) { delete dt; return fail(e, RXHIP_ERR_HIP, "hipMalloc of %zu bytes (model tables) failed", off[6]); }
                 double** dst[5] = {&dt->d_cst, &dt->d_tab, &dt->d_scanm, &dt->d_qtab, &dt->d_bnd};
                 const std::vector<double>* src[4] = {&cst, &tab, &scanm, &qtab};
                 hipError_t up = hipSuccess;
                 for (int q = 0; q < 5; ++q) *dst[q] = (double*)(dt->block + off[q]);
+                dt->d_canon = (int*)(dt->block + off[5]);
                 for (int q = 0; q < 4 && up == hipSuccess; ++q)
                     up = hipMemcpyAsync(*dst[q], src[q]->data(), sizeof(double) * src[q]->size(), hipMemcpyHostToDevice, e->stream);
+                if (up == hipSuccess) up = hipMemcpyAsync(dt->d_canon, canon.data(), sizeof(int) * canon.size(), hipMemcpyHostToDevice, e->stream);
                 if (up == hipSuccess && e->S > 0) {  // data-independent inverses at the segment boundaries: once per model, on the device
                     DenseParams dp{};
                     dp.S = e->S; dp.d = e->dpad; dp.dy = e->dyk; dp.scanm = dt->d_scanm; dp.bnd = dt->d_bnd; dp.status = nullptr;
@@ -2024,10 +2038,11 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         {
             DenseTables* dt = e->dts[0];
             e->d_cst = dt->d_cst; e->d_tab = dt->d_tab; e->d_scanm = dt->d_scanm; e->d_qtab = dt->d_qtab; e->d_bnd = dt->d_bnd;
+            e->d_canon = dt->d_canon;
         }
         std::vector<DenseModel> hmodels;
         if (e->n_models > 1)
-            for (DenseTables* dt : e->dts) hmodels.push_back(DenseModel{dt->d_cst, dt->d_tab, dt->d_scanm, dt->d_qtab, dt->d_bnd});
+            for (DenseTables* dt : e->dts) hmodels.push_back(DenseModel{dt->d_cst, dt->d_tab, dt->d_scanm, dt->d_qtab, dt->d_bnd, dt->d_canon});
         ArenaPlan ap;
         if (e->n_models > 1) {
             ap.upload(&e->d_models, hmodels.data(), sizeof(DenseModel) * hmodels.size());
@@ -3020,7 +3035,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         dp.pack = e->pack; dp.d_sub = 8; dp.dy_sub = e->dy;
         dp.models = e->n_models > 1 ? e->d_models : nullptr; dp.chain_model = e->d_chain_model;
         dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->d_cst; dp.tab = e->d_tab;
-        dp.bnd = e->d_bnd; dp.qtab = e->d_qtab; dp.loc = e->d_loc; dp.sg = e->scan_sg; dp.ng = e->scan_ng;
+        dp.bnd = e->d_bnd; dp.qtab = e->d_qtab; dp.canon = e->d_canon; dp.loc = e->d_loc; dp.sg = e->scan_sg; dp.ng = e->scan_ng;
         dp.aggpart = e->d_aggpart; dp.agg_oc = e->agg_oc; dp.agg_kc = e->agg_kc; dp.Llast = e->Llast;
         dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;
