@@ -129,6 +129,12 @@ __device__ __forceinline__ DenseModel dense_model(const DenseParams& p, long lon
     if (p.models) return p.models[p.chain_model[chain]];
     return DenseModel{p.cst, p.tab, p.scanm, p.qtab, p.bnd, p.canon};
 }
+// matrix `slot` (0–5) of the boundary-scan tables of segment `seg`, through the canonical index of its direction (tables built
+// on the device hold the maps of a converged recursion once; host-built tables hold copies, and the index is consistent with them)
+__device__ __forceinline__ const double* scan_mat(const DenseModel& M, int S, long long seg, int slot, size_t MM) {
+    const long long cs = M.canon ? M.canon[(slot >= 3 ? S : 0) + seg] : seg;
+    return M.scanm + ((size_t)cs * 6 + slot) * MM;
+}
 
 // ---- posterior / free-energy output addressing (one chain per workgroup, or the packed pair) -------------------------
 // p.n_chains counts what a workgroup owns (a chain, or a pair); the result arrays are indexed by USER chains.
@@ -993,7 +999,7 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_finish(DenseParams p) {
     // the carried vector are formed here, in parallel over segments:  w_s = b_s + M2_s η_s,  w_s' = η_s − N2_s b_s.
     {
         const size_t MM = (size_t)D * D;
-        const double* Mt = M.scanm + ((size_t)seg * 6 + (part < 2 ? 1 : 4)) * MM;  // transposed maps: [k][i]
+        const double* Mt = scan_mat(M, p.S, seg, part < 2 ? 1 : 4, MM);  // transposed maps: [k][i]
         const double* x = part < 2 ? eta : m;
         const int k0 = half * (D / 2);
         double s0 = 0.0, s1 = 0.0;
@@ -1175,10 +1181,7 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
     auto seg_of = [&](int st) { return dir ? S - 1 - st : st; };
     dense_affine_rounds<NT, true>(
         st1 - st0,
-        [&](int r) {
-            const int sgm = seg_of(st0 + r);
-            return M.scanm + ((size_t)(M.canon ? M.canon[dir * S + sgm] : sgm) * 6 + (dir ? 3 : 0)) * MM;
-        },
+        [&](int r) { return scan_mat(M, S, seg_of(st0 + r), dir ? 3 : 0, MM); },
         [&](int r) { return p.elem + ((chain * S + seg_of(st0 + r)) * 2 + dir) * D; },
         [&](int r, double x) { loc[(size_t)(st0 + r + 1) * D + tid] = x; }, v0, red, tid);
 }
@@ -1237,13 +1240,14 @@ __global__ void __launch_bounds__(64 * NT) kd_prepare_bnd(DenseParams p) {
     bool ok = true;
     LogProd lpd;
     Acc<NT> a;
-    acc_load<NT>(a, p.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
+    const DenseModel M{p.cst, p.tab, p.scanm, p.qtab, p.bnd, p.canon};
+    acc_load<NT>(a, scan_mat(M, p.S, seg, 2, MM), D, w, lane);
     ok = spd_inverse<NT>(a, rowbuf, w, lane, lpd) && ok;
     acc_store<NT>(a, p.bnd + ((size_t)seg * 2 + 0) * MM, D, w, lane);
     if (seg + 1 < p.S) {
-        acc_load<NT>(a, p.scanm + ((size_t)(seg + 1) * 6 + 2) * MM, D, w, lane);
+        acc_load<NT>(a, scan_mat(M, p.S, seg + 1, 2, MM), D, w, lane);
         ok = spd_inverse<NT>(a, rowbuf, w, lane, lpd) && ok;
-        acc_add_mat<NT>(a, p.scanm + ((size_t)seg * 6 + 5) * MM, D, w, lane, 1.0);
+        acc_add_mat<NT>(a, scan_mat(M, p.S, seg, 5, MM), D, w, lane, 1.0);
         ok = spd_inverse<NT>(a, rowbuf, w, lane, lpd) && ok;
         acc_store<NT>(a, p.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);
     }
@@ -1340,7 +1344,7 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
     };
     if (tid < D) m[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
     Acc<NT> a, lam;
-    acc_load<NT>(a, M.scanm + ((size_t)seg * 6 + 2) * MM, D, w, lane);
+    acc_load<NT>(a, scan_mat(M, p.S, seg, 2, MM), D, w, lane);
     acc_store<NT>(a, M0, LD, w, lane);
     // y_t and B'Q⁻¹y_t (record of t, second header slot: kd_agg_finish), fetched one step ahead
     double yn = (tid < dy && len > 0) ? p.y[(t0 * p.n_chains + chain) * dy + tid] : 0.0;

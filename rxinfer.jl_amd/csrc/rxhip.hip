@@ -22,6 +22,7 @@
 #include "dense_kernels.hpp"
 #include "gseq_kernels.hpp"
 #include "dense_split_kernels.hpp"
+#include "dense_tab_kernels.hpp"
 #include "gmm_kernels.hpp"
 #include "hgf_kernels.hpp"
 #include "mvgmm_kernels.hpp"
@@ -1149,6 +1150,44 @@ static void launch_fe_resid(const DenseParams& p, hipStream_t s) {
 static int dense_tri(int nt) { return nt * (nt + 1) / 2 * 256; }
 static int dense_rec(int nt) { return 3 * 16 * nt + 2 * 256 * nt * nt; }  // DenseCfg<NT>::REC
 
+// Integer parameters of the MFMA schedule that depend on (L, S) only: K-chunks of the aggregation GEMM, groups of the two-level scan
+static void dense_schedule_ints(rxhip_engine* e) {
+    long long oc = (e->L + 11) / 12;
+    if (oc < 1) oc = 1;
+    e->agg_oc = (int)oc;
+    e->agg_kc = (int)((e->L + oc - 1) / oc);
+    const int n = e->S - 1;
+    int sg = 1;
+    while (sg * sg < n) ++sg;
+    e->scan_sg = sg;
+    e->scan_ng = n > 0 ? (n + sg - 1) / sg : 1;
+}
+
+// The per-model tables built on the device (dense_tab_kernels.hpp): the host pads the model (copies only) and launches six small
+// kernels; nothing is uploaded but 6 d×d matrices.  `blk` is the DenseTables block with its regions already carved.
+template <int NT>
+static hipError_t launch_dense_tab(const TabParams& tp, hipStream_t s) {
+    constexpr int D = 16 * NT;
+    const size_t lds = sizeof(double) * (size_t)(blk_scratch_doubles(NT) + 2 * 64 * NT + 16);
+    const size_t lds_c = lds + sizeof(double) * (size_t)D * (D + 1);
+    hipError_t err;
+    for (const void* f : {(const void*)kt_consts<NT>, (const void*)kt_gains<NT>, (const void*)kt_agg<NT>, (const void*)kt_scan<NT>, (const void*)kt_qtab<NT>})
+        if ((err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return err;
+    hipLaunchKernelGGL((kt_consts<NT>), dim3(1), dim3(64 * NT), lds_c, s, tp);
+    if (tp.S > 0) {
+        hipLaunchKernelGGL((kt_gains<NT>), dim3(1), dim3(64 * NT), lds, s, tp);
+        hipLaunchKernelGGL((kt_agg<NT>), dim3(2), dim3(64 * NT), lds, s, tp);
+        hipLaunchKernelGGL((kt_scan<NT>), dim3(2), dim3(64 * NT), lds, s, tp);
+        hipLaunchKernelGGL(kt_qcanon, dim3(1), dim3(64), 0, s, tp);
+        if (tp.S > 1) hipLaunchKernelGGL((kt_qtab<NT>), dim3((unsigned)tp.ng, 2), dim3(64 * NT), lds, s, tp);
+    }
+    return hipGetLastError();
+}
+static bool dense_tab_on_device(const rxhip_engine* e) {
+    // d ≥ 32: below, the host recursions take well under a millisecond (and a 16×16 model padded into these kernels would not be faster)
+    return e->nt >= 2 && e->dyk <= e->dpad && !std::getenv("RXHIP_HOST_TABLES");
+}
+
 // Per-model tables of the dense path: constants, per-offset gains (K_i, U_i), and the data-independent
 // matrix part of the boundary scan for every segment (see dense_kernels.hpp DenseParams::scanm).
 static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* ds, std::vector<double>& cst,
@@ -1343,11 +1382,8 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
                 for (size_t q = 0; q < MM; ++q) Z[q] = UH[q] + Zn[q];
             }
         }
-        long long oc = (L + 11) / 12;
-        if (oc < 1) oc = 1;
-        e->agg_oc = (int)oc;
-        e->agg_kc = (int)((L + oc - 1) / oc);
     }
+    dense_schedule_ints(e);
     // boundary-scan matrices
     const int S_ = e->S;
     scanm.assign((size_t)(S_ > 0 ? S_ : 1) * 6 * MM, 0.0);
@@ -1427,10 +1463,7 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
     // two-level scan (kd_scan_local / kd_scan_fix): groups of sg ≈ √(S−1) scan steps, composed maps Q_q (transposed)
     {
         const int n = S_ - 1;
-        int sg = 1;
-        while (sg * sg < n) ++sg;
-        e->scan_sg = sg;
-        e->scan_ng = n > 0 ? (n + sg - 1) / sg : 1;
+        const int sg = e->scan_sg;
         qtab.assign((size_t)2 * (S_ > 0 ? S_ : 1) * MM, 0.0);
         std::vector<double> Mp(MM), Qc(MM), Qn(MM);
         for (int dir = 0; dir < 2 && n > 0; ++dir) {
@@ -1978,31 +2011,86 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             }
             DenseTables* dt = dense_tables_acquire(key, e->device);
             if (!dt) {
+                dense_schedule_ints(e);
+                const bool on_dev = dense_tab_on_device(e);
                 std::vector<double> cst, tab, scanm, qtab;
                 std::vector<int> canon;
-                st = build_dense_tables(e, &dm, cst, tab, scanm, qtab, canon);
-                if (st) return st;
-                tr.mark("dense: host tables");
+                const DenseCst cl = DenseCst::make((int)D, e->dyk);
+                const size_t MMd = D * D, dyp4 = (size_t)((e->dyk + 3) & ~3);
+                size_t nb[6];
+                if (on_dev) {
+                    nb[0] = (size_t)cl.size; nb[1] = (size_t)2 * e->L * dyp4 * 2 * D; nb[2] = Sg * 6 * MMd; nb[3] = 2 * Sg * MMd;
+                    nb[4] = Sg * 2 * MMd; nb[5] = (4 * Sg + 1) / 2;
+                } else {
+                    st = build_dense_tables(e, &dm, cst, tab, scanm, qtab, canon);
+                    if (st) return st;
+                    tr.mark("dense: host tables");
+                    nb[0] = cst.size(); nb[1] = tab.size(); nb[2] = scanm.size(); nb[3] = qtab.size(); nb[4] = Sg * 2 * MMd; nb[5] = (canon.size() + 1) / 2;
+                }
                 dt = new DenseTables;
                 dt->key.swap(key);
                 dt->device = e->device;
                 dt->agg_oc = e->agg_oc; dt->agg_kc = e->agg_kc; dt->scan_sg = e->scan_sg; dt->scan_ng = e->scan_ng;
-                const size_t nb[6] = {cst.size(), tab.size(), scanm.size(), qtab.size(), Sg * 2 * D * D, (canon.size() + 1) / 2};
                 size_t off[7] = {0};
                 for (int q = 0; q < 6; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * (nb[q] ? nb[q] : 1));
                 dt->bytes = off[6];
                 if (hipMalloc(&dt->block, dt->bytes) != hipSuccess) { delete dt; return fail(e, RXHIP_ERR_HIP, "hipMalloc of %zu bytes (model tables) failed", off[6]); }
                 double** dst[5] = {&dt->d_cst, &dt->d_tab, &dt->d_scanm, &dt->d_qtab, &dt->d_bnd};
-                const std::vector<double>* src[4] = {&cst, &tab, &scanm, &qtab};
                 hipError_t up = hipSuccess;
                 for (int q = 0; q < 5; ++q) *dst[q] = (double*)(dt->block + off[q]);
                 dt->d_canon = (int*)(dt->block + off[5]);
-                for (int q = 0; q < 4 && up == hipSuccess; ++q)
-                    up = hipMemcpyAsync(*dst[q], src[q]->data(), sizeof(double) * src[q]->size(), hipMemcpyHostToDevice, e->stream);
-                if (up == hipSuccess) up = hipMemcpyAsync(dt->d_canon, canon.data(), sizeof(int) * canon.size(), hipMemcpyHostToDevice, e->stream);
+                DevTmp tab_ws;     // device build: padded inputs | workspace (freed when the tables are done)
+                DevTmp tab_status;
+                if (on_dev) {
+                    // the model padded to d×d (copies only): A | P | V0 | B | Q | m0 — B, Q padded to d rows, Q = I on the padding diagonal
+                    std::vector<double> hin(5 * MMd + D, 0.0);
+                    const int du = dm.d, dyu = dm.dy;
+                    for (int i = 0; i < (int)D; ++i)
+                        for (int j = 0; j < (int)D; ++j) {
+                            const bool in = i < du && j < du;
+                            hin[(size_t)i * D + j] = in ? dm.A[(size_t)i * du + j] : 0.0;
+                            hin[MMd + (size_t)i * D + j] = in ? dm.P[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
+                            hin[2 * MMd + (size_t)i * D + j] = in ? dm.V0[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
+                            hin[3 * MMd + (size_t)i * D + j] = (i < dyu && j < du) ? dm.B[(size_t)i * du + j] : 0.0;
+                            hin[4 * MMd + (size_t)i * D + j] = (i < dyu && j < dyu) ? dm.Q[(size_t)i * dyu + j] : (i == j && i >= dyu ? 1.0 : 0.0);
+                        }
+                    for (int i = 0; i < du; ++i) hin[5 * MMd + i] = dm.m0[i];
+                    const size_t nin = hin.size(), nws = TabWs::doubles((int)D, e->L);
+                    up = hipMalloc(&tab_ws.p, sizeof(double) * (nin + nws));
+                    if (up == hipSuccess) up = hipMalloc(&tab_status.p, sizeof(int));
+                    if (up == hipSuccess) up = hipMemsetAsync(tab_status.p, 0, sizeof(int), e->stream);
+                    if (up == hipSuccess) up = hipMemcpyAsync(tab_ws.p, hin.data(), sizeof(double) * nin, hipMemcpyHostToDevice, e->stream);
+                    if (up == hipSuccess) up = hipMemsetAsync(dt->d_tab, 0, sizeof(double) * nb[1], e->stream);   // the padded k rows of the aggregation maps
+                    if (up == hipSuccess) up = hipMemsetAsync(dt->d_cst, 0, sizeof(double) * nb[0], e->stream);
+                    TabParams tp{};
+                    tp.d = (int)D; tp.dy = e->dyk; tp.ptt = e->ptt; tp.T = e->T; tp.L = e->L; tp.Llast = e->Llast; tp.S = e->S; tp.sg = e->scan_sg; tp.ng = e->scan_ng;
+                    tp.in = (const double*)tab_ws.p; tp.ws = (double*)tab_ws.p + nin; tp.cst = dt->d_cst; tp.tab = dt->d_tab; tp.scanm = dt->d_scanm;
+                    tp.qtab = dt->d_qtab; tp.canon = dt->d_canon; tp.status = (int*)tab_status.p;
+                    if (up == hipSuccess) {
+                        switch (e->nt) {
+                            case 2: up = launch_dense_tab<2>(tp, e->stream); break;
+                            case 3: up = launch_dense_tab<3>(tp, e->stream); break;
+                            default: up = launch_dense_tab<4>(tp, e->stream); break;
+                        }
+                    }
+                    int hst = 0;
+                    if (up == hipSuccess) up = hipMemcpyAsync(&hst, tab_status.p, sizeof(int), hipMemcpyDeviceToHost, e->stream);
+                    if (up == hipSuccess) up = hipStreamSynchronize(e->stream);   // hin dies with this scope; the status decides
+                    if (up == hipSuccess && hst) {
+                        (void)hipFree(dt->block);
+                        delete dt;
+                        return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: a covariance of the model or of its filter recursion is not positive definite", mdl);
+                    }
+                    tr.mark("dense: device tables");
+                } else {
+                    const std::vector<double>* src[4] = {&cst, &tab, &scanm, &qtab};
+                    for (int q = 0; q < 4 && up == hipSuccess; ++q)
+                        up = hipMemcpyAsync(*dst[q], src[q]->data(), sizeof(double) * src[q]->size(), hipMemcpyHostToDevice, e->stream);
+                    if (up == hipSuccess) up = hipMemcpyAsync(dt->d_canon, canon.data(), sizeof(int) * canon.size(), hipMemcpyHostToDevice, e->stream);
+                }
                 if (up == hipSuccess && e->S > 0) {  // data-independent inverses at the segment boundaries: once per model, on the device
                     DenseParams dp{};
-                    dp.S = e->S; dp.d = e->dpad; dp.dy = e->dyk; dp.scanm = dt->d_scanm; dp.bnd = dt->d_bnd; dp.status = nullptr;
+                    dp.S = e->S; dp.d = e->dpad; dp.dy = e->dyk; dp.scanm = dt->d_scanm; dp.bnd = dt->d_bnd; dp.canon = dt->d_canon; dp.status = nullptr;
                     int* d_st = nullptr;
                     up = hipMalloc(&d_st, sizeof(int));
                     if (up == hipSuccess) up = hipMemsetAsync(d_st, 0, sizeof(int), e->stream);
