@@ -556,6 +556,13 @@ rxhip_status rxhip_reset_kernel_times(rxhip_engine* e);
  * such tables.  Waits for those kernels.  The reference has no counterpart: it recomputes these messages for every chain
  * and every call (src/inference/batch.jl:391-430). */
 rxhip_status rxhip_get_model_tables_ms(rxhip_engine* e, double* ms);
+/* Where the host time of the engine's creation went, in milliseconds: ms4[0] host arithmetic on model tables (models of state
+ * dimension < 32; 0 for tables that came from the cache), ms4[1] device kernels that build tables (enqueue — or completion where
+ * their status is needed before the engine exists), ms4[2] uploads (tables, constants; host → device copies + their sync),
+ * ms4[3] device memory (hipMalloc, or the engine pool).  A 23 GB engine is one hipMalloc whose cost depends on the state of
+ * the device's page tables, not on this library: bench.py reports the four next to engine_create_ms.
+ * replaces: the split `create_model` / inference timing of src/callbacks/benchmark.jl:172-207 */
+rxhip_status rxhip_get_create_stages(rxhip_engine* e, double* ms4);
 /* the hipStream_t the engine launches on */
 rxhip_status rxhip_get_stream(rxhip_engine* e, void** stream);
 /* the number of time segments the schedule uses and their length */

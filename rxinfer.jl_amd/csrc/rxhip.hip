@@ -67,14 +67,19 @@ static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) 
 
 // RXHIP_TRACE=1: stage timings of engine creation on stderr (measurement aid, off by default)
 #include <chrono>
+// Stages of an engine's creation (rxhip_get_create_stages): host arithmetic on model tables, device kernels that build tables
+// (host time until they have been enqueued or — where the status is needed — finished), uploads, device memory allocation.
+enum { STAGE_TABLES_HOST = 0, STAGE_TABLES_DEVICE, STAGE_UPLOAD, STAGE_ALLOC, STAGE_COUNT };
 struct StageTrace {
     bool on;
+    double* acc;   // the engine's stage_ms[STAGE_COUNT], or null
     std::chrono::steady_clock::time_point t0;
-    StageTrace() : on(std::getenv("RXHIP_TRACE") != nullptr), t0(std::chrono::steady_clock::now()) {}
-    void mark(const char* what) {
-        if (!on) return;
+    explicit StageTrace(double* acc_ = nullptr) : on(std::getenv("RXHIP_TRACE") != nullptr), acc(acc_), t0(std::chrono::steady_clock::now()) {}
+    void mark(const char* what, int stage = -1) {
         const auto t1 = std::chrono::steady_clock::now();
-        std::fprintf(stderr, "[rxhip] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        if (acc && stage >= 0) acc[stage] += ms;
+        if (on) std::fprintf(stderr, "[rxhip] %-28s %8.3f ms\n", what, ms);
         t0 = t1;
     }
 };
@@ -346,6 +351,7 @@ struct rxhip_engine {
     double* d_stream = nullptr;   // rxhip_filter_step: belief per chain | staging of y, mean, cov, fe (allocated on first use)
     long long stream_k = 0;
     bool have_inputs = false;      // engines with data inputs u[t] (du > 0): rxhip_set_data(RXHIP_VAR_U) has been called
+    double stage_ms[4] = {0.0, 0.0, 0.0, 0.0};  // creation stages (rxhip_get_create_stages): tables host | tables device | upload | alloc
     double *d_mu = nullptr, *d_nu = nullptr, *d_cx = nullptr, *d_cy_raw = nullptr;  // known inputs: μ[t] [Tout][d], ν[t] = B μ[t] + d[t] [Tout][dy], c[t], d[t]
     std::vector<double> h_mu, h_nu, h_cx, h_cy, h_offA, h_offB;
     std::vector<double> h_cx_const, h_cy_const;  // the offsets the engine was created with (graph constants), for RXHIP_VAR_U
@@ -634,9 +640,11 @@ static rxhip_status arena_commit(rxhip_engine* e, ArenaPlan& ap) {
     const size_t up_end = ap.zr.empty() ? (ap.pl.empty() ? off : ap.pl.front().off) : ap.zr.front().off;
     const size_t zr_end = ap.pl.empty() ? off : ap.pl.front().off;
     size_t got = off;
+    StageTrace tr(e->stage_ms);
     e->arena = arena_acquire(e->device, off, &got);
     if (!e->arena && hipMalloc(&e->arena, off) != hipSuccess) { e->arena = nullptr; return fail(e, RXHIP_ERR_HIP, "hipMalloc of %zu bytes failed", off); }
     e->arena_bytes = got;
+    tr.mark("arena (pool or hipMalloc)", STAGE_ALLOC);
     for (auto* grp : {&ap.up, &ap.zr, &ap.pl})
         for (auto& it : *grp) *it.pp = e->arena + it.off;
     if (up_end) {
@@ -648,6 +656,7 @@ static rxhip_status arena_commit(rxhip_engine* e, ArenaPlan& ap) {
     } else if (zr_end > up_end) {
         if (hipMemsetAsync(e->arena + up_end, 0, zr_end - up_end, e->stream) != hipSuccess) return fail(e, RXHIP_ERR_HIP, "memset failed");
     }
+    tr.mark("arena upload + memset", STAGE_UPLOAD);
     return RXHIP_OK;
 }
 
@@ -1959,7 +1968,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         return RXHIP_OK;
     }
     if (dense) {
-        StageTrace tr;
+        StageTrace tr(e->stage_ms);
         hipError_t herr = hipSuccess;
         DENSE_DISPATCH(e->nt, prepare() == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
         if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
@@ -2024,7 +2033,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
                 } else {
                     st = build_dense_tables(e, &dm, cst, tab, scanm, qtab, canon);
                     if (st) return st;
-                    tr.mark("dense: host tables");
+                    tr.mark("dense: host tables", STAGE_TABLES_HOST);
                     nb[0] = cst.size(); nb[1] = tab.size(); nb[2] = scanm.size(); nb[3] = qtab.size(); nb[4] = Sg * 2 * MMd; nb[5] = (canon.size() + 1) / 2;
                 }
                 dt = new DenseTables;
@@ -2081,7 +2090,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
                         delete dt;
                         return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: a covariance of the model or of its filter recursion is not positive definite", mdl);
                     }
-                    tr.mark("dense: device tables");
+                    tr.mark("dense: device tables", STAGE_TABLES_DEVICE);
                 } else {
                     const std::vector<double>* src[4] = {&cst, &tab, &scanm, &qtab};
                     for (int q = 0; q < 4 && up == hipSuccess; ++q)
@@ -2116,10 +2125,10 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
                     return fail(e, RXHIP_ERR_HIP, "upload of the model tables failed: %s", hipGetErrorString(up));
                 }
                 dense_tables_insert(dt);
-                tr.mark("dense: table upload + bnd");
+                tr.mark("dense: table upload + bnd", STAGE_UPLOAD);
             } else {
                 e->agg_oc = dt->agg_oc; e->agg_kc = dt->agg_kc; e->scan_sg = dt->scan_sg; e->scan_ng = dt->scan_ng;
-                tr.mark("dense: tables from cache");
+                tr.mark("dense: tables from cache", STAGE_TABLES_HOST);
             }
             e->dts.push_back(dt);  // released in free_all, whatever happens below
         }
@@ -2179,7 +2188,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             ap.plain(&e->d_fe_const, sizeof(double) * 2 * Sg);
         }
         if ((st = arena_commit(e, ap))) return st;
-        tr.mark("dense: work buffers");
+        tr.mark("dense: work buffers");   // (arena_commit accounts its own stages)
         return RXHIP_OK;
     }
     // per-model tables
@@ -2195,6 +2204,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     const char* op_env = std::getenv("RXHIP_ONE_PASS");
     const bool want_fused = e->uniform && e->S > 0 &&
                             (op_env ? std::atoi(op_env) != 0 : (double)e->n_chains * (double)e->T >= 4194304.0);
+    StageTrace tr(e->stage_ms);
     for (int m = 0; m < e->n_models; ++m) {
         rxhip_status st = build_model_tables(e, m, ds, cst.data() + (size_t)m * vt->cst_size,
                                              tab.data() + (size_t)m * Ltab * vt->tab_size,
@@ -2205,6 +2215,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     e->fused = want_fused && !scan.empty();
     e->fe_const = ft.fe_const;
     e->h_cst0.assign(cst.begin(), cst.begin() + vt->cst_size);
+    tr.mark("lanes: host tables", STAGE_TABLES_HOST);
     const size_t C = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1);
     ArenaPlan ap;
     ap.upload(&e->d_cst, cst.data(), sizeof(double) * cst.size());
@@ -2274,6 +2285,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         // no synchronisation here: the table kernels are ordered before every sweep on the engine's stream, and a covariance
         // that is not positive definite raises the status flag the first run reports (RXHIP_ERR_NOT_POSDEF)
         HIPCHK(e, hipGetLastError());
+        tr.mark("lanes: device tables (enqueued)", STAGE_TABLES_DEVICE);
     }
     return RXHIP_OK;
 }
@@ -3588,6 +3600,11 @@ rxhip_status rxhip_get_kernel_times(rxhip_engine* e, double* ms_avg, uint64_t* l
         if (ms_avg) ms_avg[k] = e->k_n[k] ? e->k_ms[k] / (double)e->k_n[k] : 0.0;
         if (launches) launches[k] = e->k_n[k];
     }
+    return RXHIP_OK;
+}
+rxhip_status rxhip_get_create_stages(rxhip_engine* e, double* ms4) {
+    if (!e || !ms4) return RXHIP_ERR_BADARG;
+    for (int q = 0; q < STAGE_COUNT; ++q) ms4[q] = e->stage_ms[q];
     return RXHIP_OK;
 }
 rxhip_status rxhip_get_model_tables_ms(rxhip_engine* e, double* ms) {

@@ -358,6 +358,13 @@ function model_tables_ms(e::Engine)
     return ms[]
 end
 
+"host milliseconds of the engine's creation by stage: (tables_host, tables_device, upload, alloc) — the split of `create_model` time"
+function create_stages(e::Engine)
+    ms = zeros(Float64, 4)
+    GC.@preserve ms check(e, ccall((:rxhip_get_create_stages, librxhip), Int32, (Ptr{Cvoid}, Ptr{Float64}), e.handle, pointer(ms)))
+    return (tables_host_ms = ms[1], tables_device_ms = ms[2], upload_ms = ms[3], alloc_ms = ms[4])
+end
+
 # ---- generic graph entry: rxhip_graph_desc / rxhip_create (used by HIPInferencePlugin.jl) ----------------------------
 const RXHIP_ERR_UNSUPPORTED = Int32(2)
 

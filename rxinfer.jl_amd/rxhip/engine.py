@@ -279,6 +279,12 @@ class LGSSMEngine:
         self._chk(_lib.lib().rxhip_get_model_tables_ms(self._h, ctypes.byref(ms)))
         return ms.value
 
+    def create_stages(self):
+        """host milliseconds of the engine's creation by stage (rxhip_get_create_stages)"""
+        ms = (ctypes.c_double * 4)()
+        self._chk(_lib.lib().rxhip_get_create_stages(self._h, ms))
+        return {"tables_host_ms": ms[0], "tables_device_ms": ms[1], "upload_ms": ms[2], "alloc_ms": ms[3]}
+
     def schedule(self):
         s, l = ctypes.c_int32(), ctypes.c_int64()
         self._chk(_lib.lib().rxhip_get_schedule(self._h, ctypes.byref(s), ctypes.byref(l)))
