@@ -70,16 +70,24 @@ def cpu_baseline(mdl, y_host, sample_chains):
     return base, fe1
 
 
-def parity_spot(eng, mdl, y_host, chains):
-    """HIP result vs the oracle on the same observations, at the benchmarked size (relative errors, max over the chains)."""
+def parity_spot(eng, mdl, y_host, chains, missing=False):
+    """HIP result vs the oracle on the same observations, at the benchmarked size: relative errors PER TIME STEP — every posterior
+    mean / covariance on the scale of its own step (max |Δ| / max |reference| of that step), maximum over steps and chains.
+    `missing`: the observations carry NaN rows; the checker is then the smoother with skipped updates (the schedule the
+    reference runs for `missing` data, docs/src/manuals/inference/static.md:98-123), itself pinned to brute-force conditioning."""
     rxo = _oracle()
     mean, cov = eng.marginals_of_chains(chains)
     fe = eng.free_energy_per_chain()
     out = {"chains": [int(c) for c in chains], "mean_rel": 0.0, "cov_rel": 0.0, "fe_rel": 0.0}
     for i, c in enumerate(chains):
-        om, oc, ofe, _ = rxo.lgssm_bp(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], y_host[:, c])
-        out["mean_rel"] = max(out["mean_rel"], float(np.max(np.abs(mean[i] - om)) / np.max(np.abs(om))))
-        out["cov_rel"] = max(out["cov_rel"], float(np.max(np.abs(cov[i] - oc)) / np.max(np.abs(oc))))
+        yc = np.ascontiguousarray(y_host[c] if isinstance(y_host, dict) else y_host[:, c])   # {chain: [T][dy]} or [T][chain][dy]
+        if missing:
+            om, oc, ofe = rxo.lgssm_kalman_rts(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], yc)
+        else:
+            om, oc, ofe, _ = rxo.lgssm_bp(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], yc)
+        sd = np.sqrt(np.einsum("tii->ti", oc))   # posterior standard deviations: the scale of a mean error at that step
+        out["mean_rel"] = max(out["mean_rel"], float(np.max(np.abs(mean[i] - om) / sd)))
+        out["cov_rel"] = max(out["cov_rel"], float(np.max(np.abs(cov[i] - oc) / np.max(np.abs(oc), axis=(1, 2), keepdims=True))))
         out["fe_rel"] = max(out["fe_rel"], float(abs(fe[c] - ofe) / abs(ofe)))
     out["ok"] = bool(out["mean_rel"] < 1e-6 and out["cov_rel"] < 1e-6 and out["fe_rel"] < 1e-8)
     return out
@@ -101,7 +109,7 @@ def timed_sweeps(eng, steps, warmup, filter_run=False):
     return dt * 1e3, {k: round(v["ms_avg"], 4) for k, v in eng.kernel_times().items() if v["launches"]}
 
 
-def extra_per_chain_models(mdl, T, C, y_dev, device, steps=3):
+def extra_per_chain_models(mdl, T, C, y_dev, device, y_host=None, steps=3):
     """The same batch with one constant set PER CHAIN (n_models = n_chains): nothing is shared between chains, every chain
     stores and re-reads its full forward message, SURVEY's 416 B/U applies unmodified."""
     tile = lambda a: np.broadcast_to(np.asarray(a, dtype=np.float64), (C,) + np.shape(a)).copy()
@@ -109,6 +117,7 @@ def extra_per_chain_models(mdl, T, C, y_dev, device, steps=3):
                             n_chains=C, chain_model=np.arange(C, dtype=np.int32), device=device)
     eng.set_data_device(y_dev.data_ptr(), y_dev.numel(), keepalive=y_dev)
     ms, kt = timed_sweeps(eng, steps, 1)
+    spot = parity_spot(eng, mdl, y_host, [0, C - 1] if C > 1 else [0]) if y_host is not None else None
     eng.close()
     units = T * C
     b_bwd, b_sweep = 272, 416
@@ -117,7 +126,8 @@ def extra_per_chain_models(mdl, T, C, y_dev, device, steps=3):
             "achieved": b_bwd * units / (k * 1e-3) / 1e9 if k else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": b_bwd * units / (k * 1e-3) / 1e9 / HBM_PEAK_GBS if k else None,
             "sweep_bytes_per_U": b_sweep, "sweep_achieved": b_sweep * units / (ms * 1e-3) / 1e9,
-            "sweep_frac": b_sweep * units / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            "sweep_frac": b_sweep * units / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "rule_calls_per_s": (6 * T - 3) * C / (ms * 1e-3), "parity_spot": spot}
 
 
 def extra_c1(device, with_cpu=True):
@@ -146,7 +156,7 @@ def extra_c1(device, with_cpu=True):
     return out
 
 
-def extra_missing(mdl, T, C, y, device):
+def extra_missing(mdl, T, C, y, device, y_host=None):
     """The C2 batch with 10 % of the observations `missing` (masked, table-free schedule)."""
     yy = y.clone()
     mask = torch.rand((T, C), device=yy.device, generator=torch.Generator(device=yy.device).manual_seed(0)) < 0.1
@@ -154,9 +164,18 @@ def extra_missing(mdl, T, C, y, device):
     eng = rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C, device=device, allow_missing=True)
     eng.set_data_device(yy.data_ptr(), yy.numel(), keepalive=yy)
     ms, kt = timed_sweeps(eng, 5, 2)
+    spot = None
+    if y_host is not None:   # the two checked chains with the SAME mask, on the host
+        chains = [0, C - 1] if C > 1 else [0]
+        cols = {}
+        for c in chains:
+            yc = np.array(y_host[:, c], copy=True)
+            yc[mask[:, c].cpu().numpy()] = np.nan
+            cols[c] = yc
+        spot = parity_spot(eng, mdl, cols, chains, missing=True)
     eng.close()
     return {"workload": f"the headline batch with 10 % of the observations missing (T={T}, {C} chains), 1 BP sweep + free energy",
-            "ms_per_step": ms, "kernels_ms_avg": kt, "steps_per_s": T * C / (ms * 1e-3)}
+            "ms_per_step": ms, "kernels_ms_avg": kt, "steps_per_s": T * C / (ms * 1e-3), "parity_spot": spot}
 
 
 def extra_c3(device):
@@ -164,20 +183,48 @@ def extra_c3(device):
     mdl = workloads.c3_model()
     T, d = 10000, 64
     y = workloads.generate_batch(mdl, T, 1, seed0=6400)
+    # a throwaway engine of ANOTHER d = 64 model first: the first launch of a kernel loads its code object (a property of the
+    # process); the model timed below has never been seen by any engine, so its tables are built, not fetched from the cache
+    with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"] * 1.5, mdl["Q"], mdl["m0"], mdl["V0"], T=400, n_chains=1, device=device) as warm:
+        warm.set_data(y[:400])
+        warm.run(1, True)
     t0 = time.perf_counter()
     eng = rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=1, device=device)
     eng.set_data(y)
     eng.run(1, True)
     create_ms = (time.perf_counter() - t0) * 1e3
+    cstages = eng.create_stages()
     ms, kt = timed_sweeps(eng, 20, 3)
     fms, _ = timed_sweeps(eng, 10, 2, filter_run=True)
     eng.close()
-    ref_flop, exe_flop = 18 * d ** 3 * T, 12 * d ** 3 * T  # SURVEY §8d reference-schedule count | what the kernels execute
+    stages = None
+    # Flop counts.  ref: SURVEY §8d's reference-schedule count (18 d³ per step).  mfma: what the matrix pipe executes, from the
+    # instruction counts of the shipped kernels — v_mfma_f64_16x16x4_f64 = 2048 flop; per time step and workgroup (4 waves):
+    # forward 4·76 (panel inverse: 4·4 tile-inverse rounds, 12 row block, 3·(4 + 16) panel updates) + 4·64 (G' = K C) + 160
+    # (M = PLW − K G, 10 of 16 tiles: symmetric) = 720; backward 2·256 = 512; residual forms of the free energy 256 per 16 steps;
+    # aggregation GEMM [2d × L·dy]·[L·dy × S] ≈ 8 per step — confirmed by SQ_INSTS_VALU_MFMA_F64 (profiles/r03/pmc_c3.txt).  The round-2 kernels
+    # executed 768 + 512 (bench counted 12 d³ = 1536 per step, the counters said 1280).
+    mfma_step = {"kd_forward_info": 720, "kd_backward_info": 512, "kd_fe_resid_mfma": 16, "kd_agg_gemm": 8}
+    mfma_flop = sum(mfma_step.values()) * 2048 * T
+    ref_flop = 18 * d ** 3 * T
+    tf = lambda flop, t_ms: flop / (t_ms * 1e-3) / 1e12
+    fwd_ms, bwd_ms = kt.get("k_forward", 0.0), kt.get("k_backward", 0.0)
+    roof = {"bound": "mfma", "kernel": "kd_forward_info", "flop": mfma_step["kd_forward_info"] * 2048 * T, "ms": fwd_ms,
+            "achieved": tf(mfma_step["kd_forward_info"] * 2048 * T, fwd_ms) if fwd_ms else None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf(mfma_step["kd_forward_info"] * 2048 * T, fwd_ms) / FP64_PEAK_TFLOPS if fwd_ms else None,
+            "mfma_frac": tf(mfma_step["kd_forward_info"] * 2048 * T, fwd_ms) / FP64_PEAK_TFLOPS if fwd_ms else None,
+            "backward": {"kernel": "kd_backward_info", "flop": mfma_step["kd_backward_info"] * 2048 * T, "ms": bwd_ms,
+                         "frac": tf(mfma_step["kd_backward_info"] * 2048 * T, bwd_ms) / FP64_PEAK_TFLOPS if bwd_ms else None},
+            "note": "flop = MFMA instructions of the shipped kernels x 2048 (counters: profiles/r03/pmc_c3.txt); frac = mfma_frac: "
+                    "the kernels execute nothing but MFMA flops worth counting"}
     return {"workload": "LGSSM d=64 dy=64 T=10000, 1 chain, 1 BP sweep + Bethe free energy per step", "ms_per_step": ms,
-            "kernels_ms_avg": kt, "tflops_ref_count": ref_flop / (ms * 1e-3) / 1e12, "tflops_executed": exe_flop / (ms * 1e-3) / 1e12,
-            "peak_tflops_fp64": FP64_PEAK_TFLOPS, "frac": exe_flop / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-            "frac_ref_count": ref_flop / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS, "filter_ms_per_step": fms,
-            "create_set_data_first_run_ms": create_ms}
+            "kernels_ms_avg": kt, "tflops_ref_count": tf(ref_flop, ms), "tflops_executed": tf(mfma_flop, ms),
+            "mfma_flop_per_sweep": mfma_flop, "ref_flop_per_sweep": ref_flop,
+            "peak_tflops_fp64": FP64_PEAK_TFLOPS, "frac": tf(mfma_flop, ms) / FP64_PEAK_TFLOPS,
+            "frac_ref_count": tf(ref_flop, ms) / FP64_PEAK_TFLOPS, "frac_round2_count_12d3": tf(12 * d ** 3 * T, ms) / FP64_PEAK_TFLOPS,
+            "roofline": roof, "filter_ms_per_step": fms,
+            "create_set_data_first_run_ms": create_ms, "create_stages_ms": cstages,
+            "create_note": "a model no engine of the process has seen: tables built on the device (csrc/dense_tab_kernels.hpp)"}
 
 
 def extra_mid(device):
@@ -200,6 +247,22 @@ def extra_mid(device):
     return out
 
 
+VALU_PEAK_WAVE_INSTS = 1024 * 2.4e9 / 4   # wave-instructions / s: 256 CUs × 4 SIMDs, one VALU instruction per wave every 4 cycles at 2.4 GHz
+
+
+def valu_roofline(kernel, key, ms):
+    """Issue-bound kernels (C4, C5): VALU instructions per launch — SQ_INSTS_VALU of the committed PMC pass (profiles/valu_insts.json,
+    scripts/profile_c4c5_pmc.sh) — over the launch time measured here, against the part's VALU issue rate."""
+    try:
+        vj = json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json")))
+        insts, src = float(vj[key]["SQ_INSTS_VALU"]), vj.get("source")
+    except Exception:
+        return {"bound": "valu-issue", "kernel": kernel, "achieved": None, "peak": VALU_PEAK_WAVE_INSTS, "unit": "wave-instructions/s", "frac": None}
+    ach = insts / (ms * 1e-3)
+    return {"bound": "valu-issue", "kernel": kernel, "valu_insts_per_launch": insts, "ms": ms, "achieved": ach, "peak": VALU_PEAK_WAVE_INSTS,
+            "unit": "wave-instructions/s", "frac": ach / VALU_PEAK_WAVE_INSTS, "counter_source": src}
+
+
 def extra_c4(device):
     """BASELINE config 4 on one GPU: 4096 HGF series × T = 2000, 10 VMP iterations per observation, GH-31."""
     S, T, iters = 4096, 2000, 10
@@ -215,9 +278,21 @@ def extra_c4(device):
     ms = (time.perf_counter() - t0) / n * 1e3
     fe = eng.free_energy()
     eng.close()
+    # the 8-GPU shape of BASELINE config 4 (512 series per GPU): a series is a latency chain of 2·10⁴ dependent VMP iterations, so
+    # it strong-scales by capacity, not by latency — the expectation for the scaling run is on record here
+    eng = rxhip.HGFEngine(T, 512, 1.0, 0.0, 0.04, 0.01, device=device)
+    eng.set_data(np.ascontiguousarray(y[:, :512]))
+    eng.run(iters, True)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        eng.run_async(iters, True)
+    eng.sync()
+    ms512 = (time.perf_counter() - t0) / n * 1e3
+    eng.close()
     return {"workload": f"HGF {S} series x T={T}, {iters} VMP iterations per observation, GH-31, with free energy", "ms_per_step": ms,
             "gh_evaluations_per_s": 31 * iters * T * S / (ms * 1e-3), "series_observations_per_s": T * S / (ms * 1e-3),
-            "free_energy_mean_per_series_it10": float(fe[-1] / S)}
+            "free_energy_mean_per_series_it10": float(fe[-1] / S), "roofline": valu_roofline("k_hgf_filter", "c4", ms),
+            "ms_per_step_512_series": ms512}
 
 
 def extra_c5(device):
@@ -235,9 +310,19 @@ def extra_c5(device):
     ms = (time.perf_counter() - t0) / iters * 1e3
     fe = eng.free_energy()
     eng.close()
+    n8 = N // 8   # the 8-GPU shape: 1.25·10⁶ points per GPU
+    eng = rxhip.GMMEngine(n8, mus + 1.5, np.full(K, 1e3), np.full(K, 0.01), np.full(K, 0.01), np.ones(K), mus + 1.5,
+                          np.full(K, 10.0), np.ones(K), np.ones(K), np.ones(K), device=device)
+    eng.set_data(y[:n8])
+    eng.run(2, True)
+    t0 = time.perf_counter()
+    eng.run(iters, True)
+    ms8 = (time.perf_counter() - t0) / iters * 1e3
+    eng.close()
     return {"workload": f"GMM K={K}, N={N}, {iters} VMP iterations (q(z) not materialised: 8 B per point-iteration)", "ms_per_iteration": ms,
             "vmp_iters_per_sec": 1e3 / ms, "point_iterations_per_s": N / (ms * 1e-3), "free_energy_last": float(fe[-1]),
-            "free_energy_monotone": bool(np.all(np.diff(fe) <= 1e-6 * abs(fe[-1])))}
+            "free_energy_monotone": bool(np.all(np.diff(fe) <= 1e-6 * abs(fe[-1]))), "roofline": valu_roofline("k_gmm_pass", "c5", ms),
+            "ms_per_iteration_1p25M_points": ms8}
 
 
 def respawn_under_launcher(n):
@@ -260,7 +345,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--T", type=int, default=100000)
-    ap.add_argument("--chains", type=int, default=1024, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=1024, help="chains per GPU (weak scaling) / of the whole job (strong scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak: --chains per GPU (the driver's scaling run); strong: --chains in total, split over the ranks")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-chains", type=int, default=40)
@@ -295,7 +382,12 @@ def main():
 
     mdl = workloads.c1_model()
     T, C = args.T, args.chains
-    y_host = workloads.generate_batch(mdl, T, C, seed0=42 + rank * C)  # chain c of the JOB: default_rng(42 + c)
+    if args.scaling == "strong":
+        if C % world:
+            sys.exit(f"bench.py --scaling strong: {C} chains do not split over {world} ranks")
+        C //= world
+    # chain c of the JOB: default_rng(42 + c); every rank draws its own shard with its share of the host cores
+    y_host = workloads.generate_batch(mdl, T, C, seed0=42 + rank * C, threads=max(1, min(32, (os.cpu_count() or 1) // world)))
     y = torch.from_numpy(y_host).to(device)
     stream = torch.cuda.Stream(device=device)
     fe_all = torch.zeros(world, dtype=torch.float64, device=device)
@@ -388,11 +480,12 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": sweep_ms,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": args.scaling,
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"LGSSM d=4 dy=4 T={T}, {C} independent chains per GPU (BASELINE config 2), "
+        "config": {"workload": f"LGSSM d=4 dy=4 T={T}, {C} independent chains per GPU (BASELINE config 2"
+                               f"{'' if args.scaling == 'weak' else f': {C * world} chains split over the ranks'}), "
                                "1 BP sweep + Bethe free energy per step; chain c drawn from numpy default_rng(42+c)",
                    "chains_per_gpu": C, "T": T, "segments": sched["segments"], "segment_len": sched["segment_len"],
                    "parallelism": f"chains sharded over {world} GPU(s), RCCL all-gather + ordered sum of the free-energy scalar"},
@@ -412,6 +505,13 @@ def main():
         # model) is built once per engine — `engine_create_ms` is that cost plus the device allocation.  Every sweep reads all
         # observations, recomputes every mean and the free energy, and writes the full posterior (mean + covariance per chain).
         "engine_create_ms": create_ms,
+        # where that went: host arithmetic on tables | device table kernels (enqueue) | uploads | device memory (one hipMalloc of
+        # ≈23 GB here: its cost is the driver's page-table work and varies from box to box — 1 … 500 ms have been seen)
+        "engine_create_stages_ms": eng.create_stages(),
+        # `value` counts the reference's events: 6 rule calls per (chain, step) and sweep.  In a batch that shares ONE model the
+        # covariance half of each of them does not depend on the data and is evaluated once per model (tables above), the mean
+        # half per chain; with nothing shared the same batch runs at roofline_per_chain_models.rule_calls_per_s.
+        "value_note": "reference-equivalent rule calls; shared-model batch: covariance halves evaluated once per model (see roofline_per_chain_models for the nothing-shared figure)",
         # device time of those once-per-engine kernels, and the sweep if they were rebuilt with every sweep
         "model_tables_ms": tables_ms, "ms_per_step_incl_model_tables": sweep_ms + tables_ms,
         "free_energy_rank0": fe_local,
@@ -419,7 +519,7 @@ def main():
     }
     if rank == 0 and not args.no_parity:
         out["parity_spot"] = parity_spot(eng, mdl, y_host, [0, C - 1] if C > 1 else [0])
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:   # N > 1: rank 0 times it on its own shard while the others wait at the teardown
         out["cpu_baseline"], cpu_fe = cpu_baseline(mdl, y_host, min(args.cpu_sample_chains, C))
         out["gpu_over_cpu"] = value / out["cpu_baseline"]["value"]
         gfe = eng.free_energy_per_chain()[:cpu_fe.size]
@@ -429,8 +529,9 @@ def main():
     eng.close()
     if rank == 0 and world == 1 and not args.no_extras:
         extra = {}
-        for name, fn in (("per_chain_models", lambda: extra_per_chain_models(mdl, T, C, y, local_rank)), ("c1", lambda: extra_c1(local_rank, not args.no_cpu_baseline)),
-                         ("c2_missing", lambda: extra_missing(mdl, T, C, y, local_rank)), ("c3", lambda: extra_c3(local_rank)),
+        yh = None if args.no_parity else y_host
+        for name, fn in (("per_chain_models", lambda: extra_per_chain_models(mdl, T, C, y, local_rank, yh)), ("c1", lambda: extra_c1(local_rank, not args.no_cpu_baseline)),
+                         ("c2_missing", lambda: extra_missing(mdl, T, C, y, local_rank, yh)), ("c3", lambda: extra_c3(local_rank)),
                          ("c4", lambda: extra_c4(local_rank)), ("c5", lambda: extra_c5(local_rank)), ("mid_sizes", lambda: extra_mid(local_rank))):
             try:
                 extra[name] = fn()

@@ -20,6 +20,13 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / np.max(np.abs(b)))
 
 
+def step_rel(mean, cov, om, oc):
+    """element-wise in time: every posterior on the scale of ITS OWN step — a mean error in posterior standard deviations, a
+    covariance error relative to the largest entry of that step's covariance (not the max norm over the whole chain)"""
+    sd = np.sqrt(np.einsum("tii->ti", oc))
+    return (float(np.max(np.abs(mean - om) / sd)), float(np.max(np.abs(cov - oc) / np.max(np.abs(oc), axis=(1, 2), keepdims=True))))
+
+
 def test_c2_full_size():
     """C2 exactly as bench.py runs it: d = dy = 4, T = 100 000, 1024 chains (chain c from default_rng(42 + c)), automatic
     schedule (S = 128 segments of 782 steps, two waves per SIMD, table-driven boundary scan with 64-segment LDS chunks).
@@ -45,8 +52,9 @@ def test_c2_full_size():
         om, oc, ofe, _ = ref[i]
         assert rel(mean[i], om) < RTOL_POST, (c, rel(mean[i], om))
         assert rel(cov[i], oc) < RTOL_POST, (c, rel(cov[i], oc))
-        # per-step, not only in the max norm of the whole chain: the covariance of every step on its own scale
-        assert np.max(np.abs(cov[i] - oc) / np.max(np.abs(oc), axis=(1, 2), keepdims=True)) < RTOL_POST
+        # per step, not only in the max norm of the whole chain: every posterior on the scale of its own step
+        em, ec = step_rel(mean[i], cov[i], om, oc)
+        assert em < RTOL_POST and ec < RTOL_POST, (c, em, ec)
         assert abs(fe[c] - ofe) < RTOL_FE * abs(ofe), (c, fe[c], ofe)
     # the batch free energy is the fixed-order sum of the per-chain values
     assert abs(fe_total - np.sum(fe)) < 1e-12 * abs(fe_total)
@@ -57,6 +65,64 @@ def test_c2_full_size():
         eng.run(1, True)
         m2, c2 = eng.marginals_of_chains(chains[:2])
     assert np.array_equal(m2, mean[:2]) and np.array_equal(c2, cov[:2])  # bit-identical from run to run / engine to engine
+
+
+def test_c2_full_size_per_chain_models():
+    """The batch bench.py reports as `roofline_per_chain_models`: the C2 data with one constant set PER CHAIN (n_models = n_chains;
+    every chain its own model — here perturbed per chain, so that nothing can be shared by accident), on the schedule that
+    workload runs on (segment elements computed in the lane, per-chain records).  SURVEY's 416 B/U applies to it unmodified."""
+    mdl = workloads.c1_model()
+    T, C = 100000, 1024
+    y = workloads.generate_batch(mdl, T, C, seed0=42)
+    rng = np.random.default_rng(5)
+    scale = 1.0 + 0.2 * rng.random(C)
+    tile = lambda a: np.broadcast_to(np.asarray(a, dtype=np.float64), (C,) + np.shape(a)).copy()
+    A, B, P, Q, m0, V0 = (tile(mdl[k]) for k in ("A", "B", "P", "Q", "m0", "V0"))
+    P *= scale[:, None, None]
+    Q /= scale[:, None, None]
+    chains = [0, 63, 64, 700, 1023]
+    with rxhip.LGSSMEngine(A, B, P, Q, m0, V0, T=T, n_chains=C, chain_model=np.arange(C, dtype=np.int32)) as eng:
+        sched = eng.schedule()
+        assert sched["segments"] == 128
+        eng.set_data(y)
+        eng.run(1, True)
+        mean, cov = eng.marginals_of_chains(chains)
+        fe = eng.free_energy_per_chain()
+    with ThreadPoolExecutor(8) as ex:
+        ref = list(ex.map(lambda c: rxoracle.lgssm_bp(A[c], B[c], P[c], Q[c], m0[c], V0[c], y[:, c]), chains))
+    for i, c in enumerate(chains):
+        om, oc, ofe, _ = ref[i]
+        em, ec = step_rel(mean[i], cov[i], om, oc)
+        assert em < RTOL_POST and ec < RTOL_POST, (c, em, ec)
+        assert abs(fe[c] - ofe) < RTOL_FE * abs(ofe), (c, fe[c], ofe)
+
+
+def test_c2_full_size_with_missing_observations():
+    """The batch bench.py reports as `extra.c2_missing`: 10 % of the observations of the C2 batch `missing` (NaN), the masked
+    time-parallel schedule at S = 128 segments — boundary scan over elements computed in the lane included.  Checker: the
+    smoother with skipped updates (docs/src/manuals/inference/static.md:98-123; pinned to brute-force conditioning of the joint
+    Gaussian in tests/test_missing_observations.py)."""
+    mdl = workloads.c1_model()
+    T, C = 100000, 1024
+    y = workloads.generate_batch(mdl, T, C, seed0=42)
+    rng = np.random.default_rng(0)
+    gone = rng.random((T, C)) < 0.1
+    gone[5000:5900, 64] = True      # more than a whole segment (782 steps) without a single observation
+    y[gone] = np.nan
+    chains = [0, 64, 511, 1023]
+    with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C, allow_missing=True) as eng:
+        assert eng.schedule()["segments"] == 128
+        eng.set_data(y)
+        eng.run(1, True)
+        mean, cov = eng.marginals_of_chains(chains)
+        fe = eng.free_energy_per_chain()
+    with ThreadPoolExecutor(4) as ex:
+        ref = list(ex.map(lambda c: rxoracle.lgssm_kalman_rts(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], np.ascontiguousarray(y[:, c])), chains))
+    for i, c in enumerate(chains):
+        om, oc, nll = ref[i]
+        em, ec = step_rel(mean[i], cov[i], om, oc)
+        assert em < RTOL_POST and ec < RTOL_POST, (c, em, ec)
+        assert abs(fe[c] - nll) < RTOL_FE * abs(nll), (c, fe[c], nll)
 
 
 def test_c2_full_size_filtering():
