@@ -93,20 +93,28 @@ def parity_spot(eng, mdl, y_host, chains, missing=False):
     return out
 
 
-def timed_sweeps(eng, steps, warmup, filter_run=False):
+def timed_sweeps(eng, steps, warmup, filter_run=False, repeats=2):
+    """`steps` sweeps between two synchronisations, per-kernel HIP-event times alongside.  The EXTRA lines (not the headline
+    region, which is timed once, as the contract says) take the better of `repeats` such measurements: a process that has just
+    released tens of gigabytes of device memory (the engines of the previous lines) occasionally stalls a queue for 50–80 ms
+    once — seen as 3–9 ms "per sweep" in one of several identical runs while the kernel times stayed at their 0.9 ms sum."""
     run = (lambda: eng.run_filter_async(True)) if filter_run else (lambda: eng.run_async(1, True))
     for _ in range(warmup):
         run()
     eng.sync()
-    eng.set_profiling(True)
-    eng.reset_kernel_times()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        run()
-    eng.sync()
-    dt = (time.perf_counter() - t0) / steps
-    eng.set_profiling(False)
-    return dt * 1e3, {k: round(v["ms_avg"], 4) for k, v in eng.kernel_times().items() if v["launches"]}
+    best, kt = None, None
+    for _ in range(max(1, repeats)):
+        eng.set_profiling(True)
+        eng.reset_kernel_times()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        eng.sync()
+        dt = (time.perf_counter() - t0) / steps
+        eng.set_profiling(False)
+        if best is None or dt < best:
+            best, kt = dt, {k: round(v["ms_avg"], 4) for k, v in eng.kernel_times().items() if v["launches"]}
+    return best * 1e3, kt
 
 
 def extra_per_chain_models(mdl, T, C, y_dev, device, y_host=None, steps=3):

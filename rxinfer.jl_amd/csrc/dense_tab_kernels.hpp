@@ -47,6 +47,57 @@ struct TabWs {
     static __host__ __device__ size_t doubles(int d, long long L) { return ((size_t)NSLOT + 3 * (size_t)L) * d * d; }
 };
 
+// The building blocks are NOT inlined: a phase kernel is a chain of a few hundred of them, and inlined the compiler schedules across
+// all of it (512 registers and kilobytes of scratch per lane in the first version — scratch that size also makes the runtime
+// re-provision the queue's scratch space).  One call per product costs nothing next to the product.
+template <int NT, bool TA, bool TB>
+__device__ __attribute__((noinline)) void tab_mm(double* dst, const double* a, const double* b, double alpha, const double* c, double beta, int w, int lane) {
+    constexpr int D = 16 * NT;
+    Acc<NT> acc;
+    acc_zero<NT>(acc);
+    mm_acc<NT, TA, TB>(acc, a, D, b, D, w, lane);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
+            double v = alpha * acc.v[t][r];
+            if (c) v += beta * c[i * D + j];
+            dst[i * D + j] = v;
+        }
+    __syncthreads();
+}
+template <int NT>
+__device__ __attribute__((noinline)) bool tab_inv(double* dst, const double* a, double* lds, double* logdet_out, int w, int lane) {
+    constexpr int D = 16 * NT;
+    Acc<NT> acc;
+    acc_load<NT>(acc, a, D, w, lane);
+    LogProd lp;
+    const bool ok = blk_inverse<NT>(acc, lds, w, lane, lp);
+    acc_store<NT>(acc, dst, D, w, lane);
+    if (w == 0 && lane == 0) lds[blk_scratch_doubles(NT)] = lp.value();
+    __syncthreads();
+    if (logdet_out) *logdet_out = lds[blk_scratch_doubles(NT)];
+    __syncthreads();
+    return ok;
+}
+template <int NT>
+__device__ __attribute__((noinline)) void tab_lin(double* dst, double alpha, const double* a, double beta, const double* b, bool tb, int tid) {
+    constexpr int D = 16 * NT, MM = D * D, NTH = 64 * NT;
+    double v[MM / NTH];
+#pragma unroll
+    for (int u = 0; u < MM / NTH; ++u) {
+        const int k = tid + u * NTH, i = k / D, j = k - i * D;
+        double x = a ? alpha * a[k] : 0.0;
+        if (b) x += beta * (tb ? b[j * D + i] : b[k]);
+        v[u] = x;
+    }
+    __syncthreads();   // a transposed read of dst itself (symmetrisation in place) is complete before anything is written
+#pragma unroll
+    for (int u = 0; u < MM / NTH; ++u) dst[tid + u * NTH] = v[u];
+    __syncthreads();
+}
+
 template <int NT>
 struct TabOps {
     static constexpr int D = 16 * NT, MM = D * D, NTH = 64 * NT;
@@ -56,34 +107,11 @@ struct TabOps {
     // dst = alpha·op(a)·op(b) + beta·c      (c may be null or dst; dst must differ from a and b)
     template <bool TA, bool TB>
     __device__ __forceinline__ void mm(double* dst, const double* a, const double* b, double alpha = 1.0, const double* c = nullptr, double beta = 0.0) const {
-        Acc<NT> acc;
-        acc_zero<NT>(acc);
-        mm_acc<NT, TA, TB>(acc, a, D, b, D, w, lane);
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
-                double v = alpha * acc.v[t][r];
-                if (c) v += beta * c[i * D + j];
-                dst[i * D + j] = v;
-            }
-        sync();
+        tab_mm<NT, TA, TB>(dst, a, b, alpha, c, beta, w, lane);
     }
-    // dst = alpha·a + beta·op(b)   (elementwise; b may be null; dst may alias a, and b when !tb)
+    // dst = alpha·a + beta·op(b)   (elementwise; a, b may be null; dst may alias a, and b)
     __device__ __forceinline__ void lin(double* dst, double alpha, const double* a, double beta = 0.0, const double* b = nullptr, bool tb = false) const {
-        double v[MM / NTH];
-#pragma unroll
-        for (int u = 0; u < MM / NTH; ++u) {
-            const int k = tid + u * NTH, i = k / D, j = k - i * D;
-            double x = a ? alpha * a[k] : 0.0;
-            if (b) x += beta * (tb ? b[j * D + i] : b[k]);
-            v[u] = x;
-        }
-        sync();   // a transposed read of dst itself (symmetrisation in place) is complete before anything is written
-#pragma unroll
-        for (int u = 0; u < MM / NTH; ++u) dst[tid + u * NTH] = v[u];
-        sync();
+        tab_lin<NT>(dst, alpha, a, beta, b, tb, tid);
     }
     __device__ __forceinline__ void sym(double* dst, const double* a) const { lin(dst, 0.5, a, 0.5, a, true); }
     __device__ __forceinline__ void eye(double* dst, double diag) const {
@@ -92,16 +120,7 @@ struct TabOps {
     }
     // dst = a⁻¹ (SPD); *logdet (may be null) receives log det a (valid in every thread); returns false if a is not positive definite
     __device__ __forceinline__ bool inv(double* dst, const double* a, double* logdet) const {
-        Acc<NT> acc;
-        acc_load<NT>(acc, a, D, w, lane);
-        LogProd lp;
-        const bool ok = blk_inverse<NT>(acc, lds, w, lane, lp);
-        acc_store<NT>(acc, dst, D, w, lane);
-        if (tid == 0) lds[blk_scratch_doubles(NT)] = lp.value();
-        sync();
-        if (logdet) *logdet = lds[blk_scratch_doubles(NT)];
-        sync();
-        return ok;
+        return tab_inv<NT>(dst, a, lds, logdet, w, lane);
     }
     // max |a − b| ≤ tol · max |a|   (uniform result)
     __device__ __forceinline__ bool same(const double* a, const double* b, double tol) const {

@@ -3592,6 +3592,14 @@ rxhip_status rxhip_counters(rxhip_engine* e, uint64_t* rule_calls, uint64_t* pro
 rxhip_status rxhip_set_profiling(rxhip_engine* e, int32_t enabled) {
     if (!e) return RXHIP_ERR_BADARG;
     e->profiling = enabled != 0;
+    if (e->profiling) {   // the events a profiled run needs (64 pending pairs at most) exist before it starts: no hipEventCreate inside a timed region
+        SET_DEVICE(e);
+        while (e->pool.size() + 2 * e->pending.size() < 130) {
+            hipEvent_t ev;
+            HIPCHK(e, hipEventCreate(&ev));
+            e->pool.push_back(ev);
+        }
+    }
     return RXHIP_OK;
 }
 rxhip_status rxhip_get_kernel_times(rxhip_engine* e, double* ms_avg, uint64_t* launches) {
