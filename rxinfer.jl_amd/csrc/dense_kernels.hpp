@@ -118,6 +118,11 @@ struct DenseParams {
     const struct DenseModel* models;
     const int* chain_model;
     double* vlast;        // null, or [d][d]: V_s(T−1) of this run (the model pass of dense_split_kernels.hpp keeps it)
+    // `missing` observations, parallel in time (dense_mseg_kernels.hpp): per-chain boundaries and the observation mask
+    int mseg;
+    const double* obs;    // [chain][T]  1: y[t] observed
+    const double* nobs;   // [chain]     number of observed time indices
+    const double* mbnd;   // [chain][S][2][d][d]  Λ_f(b_s) | V_s(b_{s+1})
     long long chain0;     // first workgroup chain of this launch: a grid dimension holds 65 535 blocks, larger batches are launched in slices
 };
 struct DenseModel {
@@ -1524,7 +1529,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
         }
     };
     // belief at the segment start in information form: Λ_f = V(b_s)⁻¹ (data-independent: host table), ξ_f = Λ_f m(b_s)
-    acc_load<NT>(lam, M.bnd + ((size_t)seg * 2 + 0) * MM, D, w, lane);
+    acc_load<NT>(lam, p.mseg ? p.mbnd + (((size_t)chain * p.S + seg) * 2 + 0) * MM : M.bnd + ((size_t)seg * 2 + 0) * MM, D, w, lane);
     acc_store<NT>(lam, S1, LD, w, lane);
     if (tid < D) u[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
     lds_barrier();
@@ -1564,6 +1569,15 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
         for (int sl = 0; sl < NS; ++sl) {
             const double* src = cst + c.oPLW + (size_t)(16 * ws + lq) * D + 16 * slot_tile(sl) + lj;
             macc[sl] = (d4){src[0], src[4 * D], src[8 * D], src[12 * D]};
+        }
+        if (p.mseg && p.obs[chain * p.T + t] == 0.0) {   // y_t missing: no `*`_B(:in) message, Λ_f(t) = Λ_p(t) — B'Q⁻¹B comes off (uniform branch)
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const double* src = cst + c.oLOBS + (size_t)(16 * ws + lq) * D + 16 * slot_tile(sl) + lj;
+                // PLW holds the symmetrised B'Q⁻¹B: take the same symmetric part off
+                const double* srt = cst + c.oLOBS + (size_t)(16 * slot_tile(sl) + lj) * D + 16 * ws + lq;
+                macc[sl] -= (d4){0.5 * (src[0] + srt[0]), 0.5 * (src[4 * D] + srt[4]), 0.5 * (src[8 * D] + srt[8]), 0.5 * (src[12 * D] + srt[12])};
+            }
         }
         lds_barrier();
         // G' = K C
@@ -1693,7 +1707,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
             ok = spd_inverse<NT>(a, invbuf, w, lane, lpe) && ok;
             if (p.vlast && chain == 0) acc_store<NT>(a, p.vlast, D, w, lane);
         } else
-            acc_load<NT>(a, M.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);
+            acc_load<NT>(a, p.mseg ? p.mbnd + (((size_t)chain * p.S + seg) * 2 + 1) * MM : M.bnd + ((size_t)seg * 2 + 1) * MM, D, w, lane);
         acc_store<NT>(a, MV, LD, w, lane);
         lds_barrier();
         matvec_lds(ms, MV, LD, D, D, xf, nullptr, 0.0, tid);
@@ -1755,7 +1769,10 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
     if (FE && tid == 0) {  // the residual quadratic forms are kd_fe_resid's
         double f = 0.0;
         if (seg == p.S - 1) f += lpe.value();        // log|Λ_f(T)|
-        if (seg == 0) f += 2.0 * cst[c.oFEC];
+        if (seg == 0) {
+            f += 2.0 * cst[c.oFEC];
+            if (p.mseg) f -= ((double)p.T - p.nobs[chain]) * cst[c.oC0];   // dy log 2π + log|Q| of the observed time indices only
+        }
         dense_fe_write(p, seg == 0 ? 0 : p.S + seg, chain, f, 0.0, 0.0);
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
@@ -1990,6 +2007,7 @@ __global__ void __launch_bounds__(256) kd_fe_resid_mfma(DenseParams p, int slot0
         const long long t = t00 + 16 * tt + j;   // this lane's time step (B-operand column)
         if (t00 + 16 * tt >= p.T) break;          // uniform over the wave
         const bool vy = t < p.T, vx = t + 1 < p.T;
+        const bool ob = vy && (!p.mseg || p.obs[chain * p.T + t] != 0.0);   // `missing`: no observation node energy at this time index
         double xn[D / 4], xc[D / 4], yv[16];
 #pragma unroll
         for (int kk = 0; kk < D / 4; ++kk) {
@@ -1999,7 +2017,7 @@ __global__ void __launch_bounds__(256) kd_fe_resid_mfma(DenseParams p, int slot0
 #pragma unroll
         for (int kk = 0; kk < 16; ++kk) {
             const int k = 4 * kk + kq;
-            yv[kk] = (vy && k < dy) ? p.y[(t * p.n_chains + chain) * dy + k] : 0.0;
+            yv[kk] = (ob && k < dy) ? p.y[(t * p.n_chains + chain) * dy + k] : 0.0;
         }
         typedef double v4d __attribute__((ext_vector_type(4)));
         for (int rt = rg; rt < NT; rt += RT) {   // ρ_x, row tile rt
@@ -2025,7 +2043,7 @@ __global__ void __launch_bounds__(256) kd_fe_resid_mfma(DenseParams p, int slot0
             for (int kk = 0; kk < 16; ++kk)
                 if (4 * kk < dy4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * kk], yv[kk], acc, 0, 0, 0);
 #pragma unroll
-            for (int kk = 0; kk < D / 4; ++kk) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[dy4 + 4 * kk], xc[kk], acc2, 0, 0, 0);
+            for (int kk = 0; kk < D / 4; ++kk) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[dy4 + 4 * kk], ob ? xc[kk] : 0.0, acc2, 0, 0, 0);
             acc += acc2;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {

@@ -23,6 +23,7 @@
 #include "gseq_kernels.hpp"
 #include "dense_split_kernels.hpp"
 #include "dense_tab_kernels.hpp"
+#include "dense_mseg_kernels.hpp"
 #include "gmm_kernels.hpp"
 #include "hgf_kernels.hpp"
 #include "mvgmm_kernels.hpp"
@@ -368,6 +369,13 @@ struct rxhip_engine {
     bool split = false, split_ready = false;
     double *d_dtab = nullptr, *d_vlast = nullptr, *d_vstab = nullptr, *d_fe_const = nullptr;
     bool gseq = false;        // d > 4 with `missing` observations or per-step constants: sequential schedule (gseq_kernels.hpp)
+    // … and, for `missing` observations under ONE model, the time-parallel schedule of dense_mseg_kernels.hpp for smoothing runs
+    bool mseg = false;
+    int mS = 0;               // its segments / segment length
+    long long mL = 1;
+    char* mseg_block = nullptr;   // one allocation: padded model | constants workspace | cst | obs | nobs | elements | boundaries | records | scratch
+    double *m_in = nullptr, *m_cw = nullptr, *m_cst = nullptr, *m_obs = nullptr, *m_nobs = nullptr, *m_el = nullptr, *m_vec = nullptr,
+           *m_bnd = nullptr, *m_lb = nullptr, *m_ws = nullptr, *m_fe_part = nullptr;
     double* d_prior = nullptr;  // gseq: [n_models][m0 | V0]
     bool masked = false;      // NaN observations are `missing` (rxhip_lgssm_desc.allow_missing): per-chain records, one segment
     int pack = 1;             // 2: pairs of chains share a 16×16 tile as a block-diagonal model (d ≤ 8), see dense_kernels.hpp
@@ -1197,6 +1205,115 @@ static bool dense_tab_on_device(const rxhip_engine* e) {
     return e->nt >= 2 && e->dyk <= e->dpad && !std::getenv("RXHIP_HOST_TABLES");
 }
 
+// ---- `missing` observations on the MFMA path, parallel in time (dense_mseg_kernels.hpp) -------------------------------------
+// Eligible engines: dense, allow_missing, ONE model, no per-step constants, dy ≤ padded d, at least two time steps.  They stay
+// gseq engines for everything else (filtering runs, the step-wise filter, predictions, node-local joints run on the sequential
+// kernels); smoothing runs take the time-parallel schedule unless RXHIP_GSEQ is set (the sequential schedule as the checker).
+static rxhip_status prof_begin(rxhip_engine* e, int k);
+static rxhip_status prof_end(rxhip_engine* e);
+template <int NT>
+static hipError_t mseg_prepare_kernels() {
+    hipError_t err;
+    for (const void* f : {(const void*)km_elements<NT>, (const void*)km_scan<NT>, (const void*)km_bnd<NT>, (const void*)kt_consts<NT>})
+        if ((err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return err;
+    return DenseLaunch<NT>::prepare();
+}
+static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
+    if (!ds->allow_missing || ds->step_model || ds->chain_model || ds->n_models != 1 || e->T < 2 || e->dy > e->dpad || std::getenv("RXHIP_GSEQ"))
+        return RXHIP_OK;
+    const size_t D = (size_t)e->dpad, MM = D * D, C = (size_t)e->n_chains, T = (size_t)e->T;
+    // segments: the element pass costs ≈2 boundary steps per time step, both are sequential chains -> S ≈ √(2T); many chains fill the
+    // machine on their own, and the scratch of the element pass grows with chains × S
+    long long S = (long long)std::ceil(std::sqrt(2.0 * (double)(T - 1)));
+    while (S > 1 && (double)C * (double)S * (MSEG_WS + 9) * MM * 8.0 > 6e9) S = (S + 1) / 2;
+    if (ds->segments > 0) S = ds->segments;
+    if (S > (long long)T - 1) S = (long long)T - 1;
+    if (S < 1) S = 1;
+    long long L = ((long long)T - 1 + S - 1) / S;
+    S = ((long long)T - 1 + L - 1) / L;
+    e->mS = (int)S; e->mL = L;
+    const DenseCst cl = DenseCst::make((int)D, e->dy);
+    const int rec = dense_rec(e->nt), tri = dense_tri(e->nt);
+    const size_t nws = std::max<size_t>((size_t)C * (size_t)S, (size_t)2 * C) * MSEG_WS * MM;
+    const size_t parts[] = {5 * MM + D, TabWs::doubles((int)D, 1), (size_t)cl.size, C * T, C, C * S * 6 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
+                            C * T * (size_t)rec, C * S * (size_t)tri, C * S * D, C * (S + 1) * D,
+                            (2 * (size_t)S + 2 + (size_t)fe_resid_blocks(e->T, e->dpad, e->dy)) * C};
+    size_t off[16] = {0};
+    for (int q = 0; q < 15; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
+    HIPCHK(e, hipMalloc(&e->mseg_block, off[15]));
+    auto at = [&](int q) { return (double*)(e->mseg_block + off[q]); };
+    e->m_in = at(0); e->m_cw = at(1); e->m_cst = at(2); e->m_obs = at(3); e->m_nobs = at(4); e->m_el = at(5); e->m_vec = at(6); e->m_bnd = at(7);
+    e->m_lb = at(8); e->m_ws = at(9); e->d_filt = at(10); e->d_vend = at(11); e->d_fstart_m = at(12); e->d_beta_xi = at(13); e->m_fe_part = at(14);
+    // the model padded to d×d (copies only) and its constant block, built on the device
+    std::vector<double> hin(5 * MM + D, 0.0);
+    const int du = ds->d, dyu = ds->dy;
+    for (int i = 0; i < (int)D; ++i)
+        for (int j = 0; j < (int)D; ++j) {
+            const bool in = i < du && j < du;
+            hin[(size_t)i * D + j] = in ? ds->A[(size_t)i * du + j] : 0.0;
+            hin[MM + (size_t)i * D + j] = in ? ds->P[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
+            hin[2 * MM + (size_t)i * D + j] = in ? ds->V0[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
+            hin[3 * MM + (size_t)i * D + j] = (i < dyu && j < du) ? ds->B[(size_t)i * du + j] : 0.0;
+            hin[4 * MM + (size_t)i * D + j] = (i < dyu && j < dyu) ? ds->Q[(size_t)i * dyu + j] : (i == j && i >= dyu ? 1.0 : 0.0);
+        }
+    for (int i = 0; i < du; ++i) hin[5 * MM + i] = ds->m0[i];
+    HIPCHK(e, hipMemcpyAsync(e->m_in, hin.data(), sizeof(double) * hin.size(), hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->m_cst, 0, sizeof(double) * (size_t)cl.size, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->m_fe_part, 0, sizeof(double) * parts[14], e->stream));
+    HIPCHK(e, hipMemsetAsync(e->d_filt, 0, sizeof(double) * parts[10], e->stream));
+    TabParams tp{};
+    tp.d = (int)D; tp.dy = e->dy; tp.ptt = e->ptt; tp.T = e->T; tp.L = 1; tp.Llast = 1; tp.S = 0; tp.sg = 1; tp.ng = 1;
+    tp.in = e->m_in; tp.ws = e->m_cw; tp.cst = e->m_cst; tp.status = e->d_status;
+    hipError_t herr = hipSuccess;
+    const size_t lds_c = sizeof(double) * (size_t)(blk_scratch_doubles(e->nt) + 2 * 64 * e->nt + 16 + D * (D + 1));
+    switch (e->nt) {
+        case 1: herr = mseg_prepare_kernels<1>(); if (!herr) hipLaunchKernelGGL((kt_consts<1>), dim3(1), dim3(64), lds_c, e->stream, tp); break;
+        case 2: herr = mseg_prepare_kernels<2>(); if (!herr) hipLaunchKernelGGL((kt_consts<2>), dim3(1), dim3(128), lds_c, e->stream, tp); break;
+        case 3: herr = mseg_prepare_kernels<3>(); if (!herr) hipLaunchKernelGGL((kt_consts<3>), dim3(1), dim3(192), lds_c, e->stream, tp); break;
+        default: herr = mseg_prepare_kernels<4>(); if (!herr) hipLaunchKernelGGL((kt_consts<4>), dim3(1), dim3(256), lds_c, e->stream, tp); break;
+    }
+    if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "mseg: kernel preparation failed: %s", hipGetErrorString(herr));
+    HIPCHK(e, hipGetLastError());
+    HIPCHK(e, hipStreamSynchronize(e->stream));   // hin dies here
+    e->mseg = true;
+    return RXHIP_OK;
+}
+template <int NT>
+static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams& dp, bool fe) {
+    const size_t lds = sizeof(double) * (size_t)(blk_scratch_doubles(NT) + 2 * 64 * NT + 8 * 16 * NT + 16);
+    hipStream_t s = e->stream;
+    hipLaunchKernelGGL(km_mask, dim3((unsigned)mp.n_chains), dim3(256), 0, s, mp);
+    hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
+    hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
+    if (mp.S > 1) hipLaunchKernelGGL((km_bnd<NT>), dim3((unsigned)(mp.S - 1), (unsigned)mp.n_chains), dim3(64 * NT), sizeof(double) * blk_scratch_doubles(NT), s, mp);
+    DenseLaunch<NT>::forward_info(dp, fe, s);
+    DenseLaunch<NT>::backward_info(dp, fe, s);
+}
+static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
+    MsegParams mp{};
+    mp.d = e->dpad; mp.dy = e->dy; mp.dy_user = e->dy; mp.ptt = e->ptt; mp.T = e->T; mp.L = e->mL; mp.n_chains = e->n_chains; mp.S = e->mS;
+    mp.y = e->d_y; mp.in = e->m_in; mp.cw = e->m_cw; mp.ws = e->m_ws; mp.obs = e->m_obs; mp.nobs = e->m_nobs; mp.mel = e->m_el; mp.mvec = e->m_vec;
+    mp.mbnd = e->m_bnd; mp.mlb = e->m_lb; mp.fstart_m = e->d_fstart_m; mp.beta_xi = e->d_beta_xi; mp.filt = e->d_filt; mp.rec = dense_rec(e->nt);
+    mp.status = e->d_status;
+    DenseParams dp{};
+    dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->mS; dp.L = e->mL; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy; dp.pack = 1; dp.d_sub = 8; dp.dy_sub = e->dy;
+    dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->m_cst;
+    dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi; dp.fe_part = e->m_fe_part; dp.status = e->d_status;
+    dp.mseg = 1; dp.obs = e->m_obs; dp.nobs = e->m_nobs; dp.mbnd = e->m_bnd;
+    rxhip_status st;
+    if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
+    switch (e->nt) {
+        case 1: mseg_launch<1>(e, mp, dp, fe); break;
+        case 2: mseg_launch<2>(e, mp, dp, fe); break;
+        case 3: mseg_launch<3>(e, mp, dp, fe); break;
+        default: mseg_launch<4>(e, mp, dp, fe); break;
+    }
+    if ((st = prof_end(e))) return st;
+    if (fe) launch_fe_resid(dp, e->stream);
+    return RXHIP_OK;
+}
+
+
 // Per-model tables of the dense path: constants, per-offset gains (K_i, U_i), and the data-independent
 // matrix part of the boundary scan for every segment (see dense_kernels.hpp DenseParams::scanm).
 static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* ds, std::vector<double>& cst,
@@ -1625,6 +1742,7 @@ static void free_all(rxhip_engine* e) {
         e->dts.clear();
     }
     e->d_models = nullptr;  // lives in the arena
+    if (e->mseg_block) e->d_filt = e->d_vend = e->d_fstart_m = e->d_beta_xi = nullptr;  // carved from mseg_block (freed below)
     double** bufs[] = {&e->d_vtab, &e->d_scan, &e->d_filt, &e->d_mean, &e->d_cov, &e->d_cst, &e->d_tab, &e->d_agg, &e->d_elem,
                        &e->d_fstart, &e->d_beta, &e->d_fe_part, &e->d_fe_chain, &e->d_fe_total};
     for (auto b : bufs)
@@ -1642,6 +1760,7 @@ static void free_all(rxhip_engine* e) {
     for (double** b : {&e->d_scanm, &e->d_fstart_m, &e->d_beta_xi, &e->d_vend, &e->d_qtab, &e->d_loc, &e->d_aggpart, &e->d_bnd})
         if (*b) { if (!e->in_arena(*b)) (void)hipFree(*b); *b = nullptr; }
     if (e->d_coll) { (void)hipFree(e->d_coll); e->d_coll = nullptr; }
+    if (e->mseg_block) { (void)hipFree(e->mseg_block); e->mseg_block = nullptr; }
     if (e->d_bq) { (void)hipFree(e->d_bq); e->d_bq = nullptr; }
     if (e->d_stream) { (void)hipFree(e->d_stream); e->d_stream = nullptr; }
     if (e->h_stream) { (void)hipHostFree(e->h_stream); e->h_stream = nullptr; }
@@ -1965,6 +2084,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_mean, sizeof(double) * (size_t)e->Tout() * CU * Du);
         ap.plain(&e->d_cov, sizeof(double) * (size_t)e->Tout() * CU * Du * Du);
         if (rxhip_status st = arena_commit(e, ap)) return st;
+        if (rxhip_status st = mseg_setup(e, ds)) return st;
         return RXHIP_OK;
     }
     if (dense) {
@@ -2267,6 +2387,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->own_y = true;
     }
     if (rxhip_status st = arena_commit(e, ap)) return st;
+    tr.mark("lanes: arena", -1);   // (accounted by arena_commit itself)
     if (e->fused) {  // the per-time-index maps of the one-pass schedule: data-independent, once per engine
         TimeTabParams q{};
         q.T = e->T; q.L = e->L; q.pos = e->d_pos; q.scan = e->d_scan; q.mtab = e->d_mtab; q.ntab = e->d_ntab; q.vtab = e->d_vtab;
@@ -3143,7 +3264,10 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     }
     for (int it = 0; it < iterations; ++it) {
         p.iteration = it;
-        if (e->gseq) {
+        const bool mseg_now = e->gseq && e->mseg && !filter;   // `missing` observations, one model, smoothing: parallel in time
+        if (mseg_now) {
+            if ((st = mseg_run(e, fe))) return st;
+        } else if (e->gseq) {
             GseqParams gq{};
             gq.T = e->T; gq.n_chains = e->n_chains; gq.d = e->d; gq.dy = e->dy; gq.ptt = e->ptt; gq.fe = fe ? 1 : 0; gq.y = e->d_y;
             gq.mean = e->d_mean; gq.cov = e->d_cov; gq.user = e->d_user; gq.prior = e->d_prior; gq.chain_model = e->d_chain_model;
@@ -3249,7 +3373,11 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             if ((st = prof_begin(e, RXHIP_K_FE_REDUCE))) return st;
             const int nb = (int)((e->n_chains + 63) / 64);
             Params pr = p;
-            if (e->dense && !filter && e->S > 0) {
+            if (mseg_now) {   // slots of kd_forward_info / kd_backward_info / kd_fe_resid over the mseg segments
+                pr.fe_part = e->m_fe_part;
+                pr.S = 2 * e->mS - 1 + fe_resid_blocks(e->T, e->dpad, e->dy);
+            }
+            if (e->dense && !e->gseq && !filter && e->S > 0) {
                 // residual quadratic forms at the smoothed means (parallel over all steps), then 2S partial slots of
                 // kd_forward_info / kd_backward_info + kd_fe_resid's
                 launch_fe_resid(dp, e->stream);

@@ -1,0 +1,90 @@
+"""`missing` observations on the MFMA path, parallel in time (csrc/dense_mseg_kernels.hpp): per-(chain, segment) elements and a
+boundary recursion built on the device with the observation mask applied per step, against the sequential schedule it replaces
+for smoothing runs (RXHIP_GSEQ=1: csrc/gseq_kernels.hpp, kept as the checker) and against the oracle — the smoother with skipped
+updates, itself pinned to brute-force conditioning of the joint Gaussian (tests/test_missing_observations.py).
+Reference behaviour: docs/src/manuals/inference/static.md:98-123, test/inference/prediction_tests.jl:197-213."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rxinfer.jl_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(mdl, y, ptt, sequential, monkeypatch, segments=0):
+    import rxhip
+    if sequential:
+        monkeypatch.setenv("RXHIP_GSEQ", "1")
+    else:
+        monkeypatch.delenv("RXHIP_GSEQ", raising=False)
+    T, C = y.shape[0], y.shape[1]
+    with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C, prior_through_transition=ptt,
+                           allow_missing=True, segments=segments) as eng:
+        eng.set_data(y)
+        eng.run(1, True)
+        mean, cov = eng.marginals()
+        fe = eng.free_energy_per_chain()
+        eng.run(2, True)                      # iterations re-push the data: same result
+        assert np.array_equal(eng.marginals()[0], mean)
+        return mean, cov, fe
+
+
+@pytest.mark.parametrize("d,dy,T,C,ptt,segments", [(64, 64, 300, 1, False, 0), (64, 20, 150, 2, True, 5), (33, 7, 200, 3, False, 0), (16, 16, 120, 4, True, 0),
+                                                  (8, 4, 260, 6, False, 0), (5, 3, 40, 3, True, 1), (48, 48, 90, 2, False, 89), (12, 12, 2, 2, False, 0)])
+def test_missing_observations_parallel_in_time(d, dy, T, C, ptt, segments, monkeypatch):
+    import rxoracle as rxo
+    from rxhip import workloads
+    mdl = workloads.random_model(d, dy, seed=300 + d + dy)
+    y = workloads.generate_batch(mdl, T, C, seed0=11)
+    rng = np.random.default_rng(d + T)
+    y[rng.random((T, C)) < 0.15] = np.nan
+    y[0, 0] = np.nan                                   # the first observation of a chain
+    y[-1, C - 1] = np.nan                              # the last one
+    if T > 60:
+        y[20:55, 0] = np.nan                           # whole segments without a single observation
+    y[T // 2, C - 1, 0] = np.nan                       # a partly missing vector counts as missing
+    mp, cp, fp = _run(mdl, y, ptt, False, monkeypatch, segments)
+    ms, cs, fs = _run(mdl, y, ptt, True, monkeypatch)
+    for c in range(C):
+        om, oc, nll = rxo.lgssm_kalman_rts(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], np.ascontiguousarray(y[:, c]), prior_through_transition=ptt)
+        sd = np.sqrt(np.einsum("tii->ti", oc))
+        for name, mean, cov, fe in (("parallel", mp, cp, fp), ("sequential", ms, cs, fs)):
+            em = np.max(np.abs(mean[:, c] - om) / sd)
+            ec = np.max(np.abs(cov[:, c] - oc) / (sd[:, :, None] * sd[:, None, :]))
+            assert em < 1e-6 and ec < 1e-6, (name, c, em, ec)
+            assert fe[c] == pytest.approx(nll, rel=1e-8, abs=1e-9), (name, c)
+
+
+def test_the_rest_of_the_engine_is_unchanged(monkeypatch):
+    """filtering runs, predictions and the step-wise filter of such an engine stay on the sequential kernels"""
+    import rxhip
+    import rxoracle as rxo
+    from rxhip import workloads
+    monkeypatch.delenv("RXHIP_GSEQ", raising=False)
+    mdl = workloads.random_model(24, 6, seed=9)
+    T, C = 60, 2
+    y = workloads.generate_batch(mdl, T, C, seed0=3)
+    y[np.random.default_rng(1).random((T, C)) < 0.2] = np.nan
+    one = (mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    with rxhip.LGSSMEngine(*one, T=T, n_chains=C, allow_missing=True) as eng:
+        eng.set_data(y)
+        eng.run(1, True)
+        mean, cov = eng.marginals()
+        pm, pc = eng.predictions()
+        eng.run_filter(True)
+        fm, fc = eng.marginals()
+    for c in range(C):
+        om, oc, _ = rxo.lgssm_kalman_rts(*one, np.ascontiguousarray(y[:, c]))
+        assert np.allclose(mean[:, c], om, rtol=1e-6, atol=1e-9)
+        t = T // 3
+        yl = y[:, c].copy()
+        yl[t] = np.nan
+        lm, lc, _ = rxo.lgssm_kalman_rts(*one, yl)
+        assert np.allclose(pm[t, c], one[1] @ lm[t], rtol=1e-6, atol=1e-8)
+        qm, qc, _ = rxo.lgssm_kalman_rts(*one, np.ascontiguousarray(y[:t + 1, c]))
+        assert np.allclose(fm[t, c], qm[-1], rtol=1e-6, atol=1e-9) and np.allclose(fc[t, c], qc[-1], rtol=1e-6, atol=1e-9)
