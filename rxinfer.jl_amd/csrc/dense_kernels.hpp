@@ -885,8 +885,8 @@ struct DenseLds {
     // kernels that keep two LDS matrices (two workgroups per CU at d = 64) lend the inverse a matrix that is dead while it runs
     static constexpr bool ALIAS = RXHIP_INV_BLOCKED && C::MAT >= blk_scratch_doubles(NT);
     static constexpr int SCR2 = ALIAS ? 8 * C::D : (SCR > 8 * C::D ? SCR : 8 * C::D);   // what those kernels carve besides
-    static constexpr size_t bytes(int dmax) {   // scan kernels (vectors only), kd_prepare_bnd (scratch only)
-        return sizeof(double) * ((size_t)NVEC * dmax + (SCR > 8 * C::D ? SCR : 8 * C::D) + 3 * C::THREADS);
+    static constexpr size_t bytes(int dmax) {   // scan kernels (vectors + the staging of dense_affine_rounds), kd_prepare_bnd (scratch only)
+        return sizeof(double) * ((size_t)NVEC * dmax + (SCR > 8 * C::D ? SCR : 8 * C::D) + 3 * C::THREADS + 32 + 2 * 32 * C::D + 48);
     }
     // kd_forward (filtering runs): 3 matrices, 5 vectors, the scratch, 2 × 4 partial-sum rows
     static constexpr size_t fwd_bytes(int dmax) {
@@ -1065,48 +1065,83 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_finish(DenseParams p) {
 // One round: y = w + Mt'x with thread group `part` summing a quarter of the k range; the maps of the next PD rounds are kept
 // in flight in registers (a cold 32 KB map read costs ≈2.6 µs; the loads do not depend on x).
 //   CARRY: x <- y after every round (recursion), else x stays (independent applications).
+// Round 3: the additive vectors w of a chunk of rounds are staged in LDS up front and the results leave through LDS at its end
+// (`stage`: 2·SCAN_CHUNK·D doubles) — inside the chain of rounds a global load or store is a VMEM wait per round (and in a
+// converged stretch, where the canonical map stays in registers, the only one): 1.0 -> ≈0.5 µs per round.
+constexpr int SCAN_CHUNK = 32;
+// One workgroup barrier per round: wave w owns rows 16w … 16w + 15 of the product — lane (r = lane & 15, kq = lane >> 4) sums a
+// quarter of the k range of row 16w + r, two shuffles add the four quarters, the 16 lanes with kq = 0 publish x — instead of four
+// thread groups writing partial sums through LDS for wave 0 to combine behind a second barrier.
 template <int NT, bool CARRY, class MapF, class WF, class OutF>
-__device__ __forceinline__ void dense_affine_rounds(int nrounds, MapF map_of, WF w_of, OutF out, double* v0, double* red, int tid) {
+__device__ __forceinline__ void dense_affine_rounds(int nrounds, MapF map_of, WF w_of, OutF out, double* v0, double* v0alt, double* stage, int tid) {
+    // v0 | v0alt: the carried vector, double-buffered (a round reads one copy and publishes into the other: ONE barrier per round);
+    // on return the state is in v0 again
     constexpr int D = 16 * NT, KP = D / 4, PD = 4;
-    const int part = tid / D, i = tid - part * D, k0 = part * KP;
+    const int w = tid >> 6, lane = tid & 63, row = 16 * w + (lane & 15), k0 = (lane >> 4) * KP;
+    const bool pub = lane < 16;
     if (nrounds <= 0) return;
-    double buf[PD][KP], wb[PD];
+    double* wst = stage;                     // [SCAN_CHUNK][D]
+    double* ost = stage + SCAN_CHUNK * D;    // [SCAN_CHUNK][D]
+    // the map of every round of a chunk, resolved up front: map_of() goes through the canonical-index table in global memory, and a
+    // dependent load per round in front of a uniform branch was the whole round time (≈1 µs)
+    const double** mst = reinterpret_cast<const double**>(stage + 2 * SCAN_CHUNK * D);   // [SCAN_CHUNK + PD]
+    double buf[PD][KP];
     const double* cur[PD];   // the map each slot holds (uniform over the workgroup): a canonical map that is still there is not fetched again
 #pragma unroll
     for (int q = 0; q < PD; ++q) cur[q] = nullptr;
-    auto fetch = [&](double (&dst)[KP], double& w, const double*& have, int r) {
-        const double* Mt = map_of(r);
+    auto fetch = [&](double (&dst)[KP], const double*& have, const double* Mt) {
         if (Mt != have) {
 #pragma unroll
-            for (int u = 0; u < KP; ++u) dst[u] = Mt[(size_t)(k0 + u) * D + i];
+            for (int u = 0; u < KP; ++u) dst[u] = Mt[(size_t)(k0 + u) * D + row];
             have = Mt;
         }
-        w = tid < D ? w_of(r)[tid] : 0.0;
     };
-#pragma unroll
-    for (int q = 0; q < PD; ++q) fetch(buf[q], wb[q], cur[q], q < nrounds ? q : nrounds - 1);
-    for (int r0 = 0; r0 < nrounds; r0 += PD) {
-#pragma unroll
-        for (int q = 0; q < PD; ++q) {
-            const int r = r0 + q;
-            if (r >= nrounds) break;
-            double s0 = 0.0, s1 = 0.0;
-#pragma unroll
-            for (int u = 0; u < KP; u += 2) {
-                s0 += buf[q][u] * v0[k0 + u];
-                s1 += buf[q][u + 1] * v0[k0 + u + 1];
-            }
-            const double wv = wb[q];
-            fetch(buf[q], wb[q], cur[q], r + PD < nrounds ? r + PD : nrounds - 1);  // unconditional (clamped): keeps the waitcnt bookkeeping exact
-            red[tid] = s0 + s1;
-            lds_barrier();
-            if (tid < D) {
-                const double x = wv + ((red[tid] + red[D + tid]) + (red[2 * D + tid] + red[3 * D + tid]));
-                if (CARRY) v0[tid] = x;
-                out(r, x);
-            }
-            lds_barrier();
+    for (int c0 = 0; c0 < nrounds; c0 += SCAN_CHUNK) {
+        const int cn = nrounds - c0 < SCAN_CHUNK ? nrounds - c0 : SCAN_CHUNK;
+        if (tid < cn + PD) {   // maps of this chunk and of the PD rounds fetched ahead of the next one (clamped)
+            const int r = c0 + tid < nrounds ? c0 + tid : nrounds - 1;
+            mst[tid] = map_of(r);
         }
+        if (tid < D)
+            for (int rr = 0; rr < cn; ++rr) wst[rr * D + tid] = w_of(c0 + rr)[tid];   // independent loads, all in flight
+        lds_barrier();
+        if (c0 == 0) {
+#pragma unroll
+            for (int q = 0; q < PD; ++q) fetch(buf[q], cur[q], mst[q]);
+        }
+        for (int r0 = c0; r0 < c0 + cn; r0 += PD) {   // SCAN_CHUNK is a multiple of PD: slot q always holds round r0 + q
+#pragma unroll
+            for (int q = 0; q < PD; ++q) {
+                const int r = r0 + q;
+                if (r >= c0 + cn) break;
+                const double* vin = (CARRY && (r & 1)) ? v0alt : v0;
+                double* vout = (r & 1) ? v0 : v0alt;
+                double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                for (int u = 0; u < KP; u += 2) {
+                    s0 += buf[q][u] * vin[k0 + u];
+                    s1 += buf[q][u + 1] * vin[k0 + u + 1];
+                }
+                fetch(buf[q], cur[q], mst[r - c0 + PD]);
+                double sm = s0 + s1;
+                sm += __shfl_xor(sm, 16);
+                sm += __shfl_xor(sm, 32);
+                const double x = wst[(r - c0) * D + row] + sm;
+                if (pub) {
+                    if (CARRY) vout[row] = x;
+                    ost[(r - c0) * D + row] = x;
+                }
+                if (CARRY) lds_barrier();   // the copy this round read is free again only after the NEXT round's barrier: two copies
+            }
+        }
+        lds_barrier();
+        if (tid < D)
+            for (int rr = 0; rr < cn; ++rr) out(c0 + rr, ost[rr * D + tid]);
+        lds_barrier();
+    }
+    if (CARRY && (nrounds & 1)) {   // an odd number of rounds leaves the state in the second copy
+        if (tid < D) v0[tid] = v0alt[tid];
+        lds_barrier();
     }
 }
 
@@ -1188,7 +1223,7 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
         st1 - st0,
         [&](int r) { return scan_mat(M, S, seg_of(st0 + r), dir ? 3 : 0, MM); },
         [&](int r) { return p.elem + ((chain * S + seg_of(st0 + r)) * 2 + dir) * D; },
-        [&](int r, double x) { loc[(size_t)(st0 + r + 1) * D + tid] = x; }, v0, red, tid);
+        [&](int r, double x) { loc[(size_t)(st0 + r + 1) * D + tid] = x; }, v0, v1, red + 3 * 64 * NT + 16, tid);
 }
 
 // levels 2 and 3.  Same grid.  Output: prefix x_q -> fstart_m[q] (filtered mean at the start of segment q);
@@ -1216,7 +1251,7 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_fix(DenseParams p) {
     // level 2: state at the start of this group
     dense_affine_rounds<NT, true>(
         grpj, [&](int r) { const int q = (r + 1) * sg; return qt + (size_t)(qc ? qc[q] : q) * MM; }, [&](int r) { return loc + (size_t)((r + 1) * sg) * D; },
-        [&](int, double) {}, v0, red, tid);
+        [&](int, double) {}, v0, v0 + dm, red + 4 * D + 16, tid);
     // level 3: the states inside the group
     const int q0 = grpj * sg + 1;
     int q1 = q0 + sg;
@@ -1228,7 +1263,7 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_fix(DenseParams p) {
             if (dir) p.beta_xi[(chain * (S + 1) + (S - q)) * D + tid] = x;
             else p.fstart_m[(chain * S + q) * D + tid] = x;
         },
-        v0, red, tid);
+        v0, v0 + dm, red + 4 * D + 16, tid);
 }
 
 // Once per engine: the inverses at the segment boundaries that do not depend on the data —
@@ -1958,28 +1993,26 @@ __global__ void __launch_bounds__(256) kd_fe_resid_mfma(DenseParams p, int slot0
     const DenseCst c = DenseCst::make(D, dy);
     const int STEPS = fe_resid_steps(D, dy), NTT = STEPS / 16;
     const long long t00 = (long long)blockIdx.x * STEPS;
-    {   // stage the two maps (eight loads in flight per thread)
+    {   // stage the two maps: every load of a map in flight at once (D·KX / 256 ≤ 32 per thread), one L2 round trip per map
+        constexpr int NX = D * KX / 256;
         const double* sx = M.cst + c.oLPX;
-        for (int k0 = tid; k0 < D * KX; k0 += 8 * 256) {
-            double v[8];
+        double vx[NX];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (k0 + u * 256 < D * KX) ? sx[k0 + u * 256] : 0.0;
+        for (int u = 0; u < NX; ++u) vx[u] = sx[tid + u * 256];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * 256;
-                if (k < D * KX) MX[(k / KX) * LDX + (k % KX)] = v[u];
-            }
+        for (int u = 0; u < NX; ++u) {
+            const int k = tid + u * 256;
+            MX[(k / KX) * LDX + (k % KX)] = vx[u];
         }
         const double* sy = M.cst + c.oLQX;
-        for (int k0 = tid; k0 < dyr * KY; k0 += 8 * 256) {
-            double v[8];
+        const int ny = dyr * KY;
+        double vyv[32];   // dyr·KY ≤ 64·128
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = (k0 + u * 256 < dyr * KY) ? sy[k0 + u * 256] : 0.0;
+        for (int u = 0; u < 32; ++u) vyv[u] = (tid + u * 256 < ny) ? sy[tid + u * 256] : 0.0;
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int k = k0 + u * 256;
-                if (k < dyr * KY) MY[(k / KY) * LDY + (k % KY)] = v[u];
-            }
+        for (int u = 0; u < 32; ++u) {
+            const int k = tid + u * 256;
+            if (k < ny) MY[(k / KY) * LDY + (k % KY)] = vyv[u];
         }
     }
     double s0 = 0.0, s1 = 0.0;   // first / second chain of a packed pair (unpacked: everything in s0)
