@@ -278,12 +278,13 @@ def extra_c4(device):
     eng = rxhip.HGFEngine(T, S, 1.0, 0.0, 0.04, 0.01, device=device)
     eng.set_data(y)
     eng.run(iters, True)
-    t0 = time.perf_counter()
-    n = 3
-    for _ in range(n):
-        eng.run_async(iters, True)
-    eng.sync()
-    ms = (time.perf_counter() - t0) / n * 1e3
+    n, ms = 3, 1e9
+    for _ in range(2):   # the better of two timings (see timed_sweeps)
+        t0 = time.perf_counter()
+        for _ in range(n):
+            eng.run_async(iters, True)
+        eng.sync()
+        ms = min(ms, (time.perf_counter() - t0) / n * 1e3)
     fe = eng.free_energy()
     eng.close()
     # the 8-GPU shape of BASELINE config 4 (512 series per GPU): a series is a latency chain of 2·10⁴ dependent VMP iterations, so
@@ -291,11 +292,13 @@ def extra_c4(device):
     eng = rxhip.HGFEngine(T, 512, 1.0, 0.0, 0.04, 0.01, device=device)
     eng.set_data(np.ascontiguousarray(y[:, :512]))
     eng.run(iters, True)
-    t0 = time.perf_counter()
-    for _ in range(n):
-        eng.run_async(iters, True)
-    eng.sync()
-    ms512 = (time.perf_counter() - t0) / n * 1e3
+    ms512 = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        for _ in range(n):
+            eng.run_async(iters, True)
+        eng.sync()
+        ms512 = min(ms512, (time.perf_counter() - t0) / n * 1e3)
     eng.close()
     return {"workload": f"HGF {S} series x T={T}, {iters} VMP iterations per observation, GH-31, with free energy", "ms_per_step": ms,
             "gh_evaluations_per_s": 31 * iters * T * S / (ms * 1e-3), "series_observations_per_s": T * S / (ms * 1e-3),
@@ -313,9 +316,11 @@ def extra_c5(device):
                           np.full(K, 10.0), np.ones(K), np.ones(K), np.ones(K), device=device)
     eng.set_data(y)
     eng.run(2, True)
-    t0 = time.perf_counter()
-    eng.run(iters, True)
-    ms = (time.perf_counter() - t0) / iters * 1e3
+    ms = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        eng.run(iters, True)
+        ms = min(ms, (time.perf_counter() - t0) / iters * 1e3)
     fe = eng.free_energy()
     eng.close()
     n8 = N // 8   # the 8-GPU shape: 1.25·10⁶ points per GPU

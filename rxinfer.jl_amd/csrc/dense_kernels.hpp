@@ -134,6 +134,15 @@ __device__ __forceinline__ DenseModel dense_model(const DenseParams& p, long lon
     if (p.models) return p.models[p.chain_model[chain]];
     return DenseModel{p.cst, p.tab, p.scanm, p.qtab, p.bnd, p.canon};
 }
+// Symmetric d×d results (M_{t+1} in the forward kernel, V_s(t) in the backward one, C_t in the records between them) are computed /
+// stored once per unordered pair of tile indices: tile (w, t) belongs to wave w when (t − w) mod NT ≤ NT/2, the even-NT tie
+// (distance NT/2) going to the lower half of the waves — 3, 3, 2, 2 tiles per wave at NT = 4.
+__host__ __device__ inline bool dense_owned_tile(int NT, int w, int t) {
+    int dist = t - w;
+    if (dist < 0) dist += NT;
+    const int NS = NT / 2 + 1, nsw = (NT % 2 == 0 && NT > 1 && w >= NT / 2) ? NS - 1 : NS;
+    return dist < NS - 1 || (dist == NS - 1 && dist < nsw);
+}
 // matrix `slot` (0–5) of the boundary-scan tables of segment `seg`, through the canonical index of its direction (tables built
 // on the device hold the maps of a converged recursion once; host-built tables hold copies, and the index is consistent with them)
 __device__ __forceinline__ const double* scan_mat(const DenseModel& M, int S, long long seg, int slot, size_t MM) {
@@ -1593,7 +1602,17 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
         else ok = spd_inverse<NT, NoPrefetch, false, !PREPUB>(lam, rowbuf, w, lane, lp) && ok;
 #endif
         if (KF_RELOAD && RXHIP_KF_RELOAD == 2) load_kf();
-        acc_store_full<NT>(lam, rec + C::HDR, w, lane);
+        // C_t goes to the record as the backward kernel reads it: the tiles this wave owns in the symmetric pairing (below) — the
+        // accumulator of V_s(t) = C_t + H G' there is computed for the same tiles only (10 of 16 at d = 64)
+#pragma unroll
+        for (int t2 = 0; t2 < NT; ++t2) {
+            int dist = t2 - ws;
+            dist = dist < 0 ? dist + NT : dist;
+            if (dist < NS - 1 || (dist == NS - 1 && dist < nsw)) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) rec[C::HDR + ((w * NT + t2) * 4 + r) * 64 + lane] = lam.v[t2][r];
+            }
+        }
         acc_store<NT>(lam, S1, LD, w, lane);   // every reader of S1 (the symmetrisation) is behind the inverse's barriers
         int ln = lane;
         asm volatile("" : "+v"(ln));   // addresses below are recomputed per step, not hoisted into (spilled) registers
@@ -1754,6 +1773,14 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
     }
     Acc<NT> gN, cc;
     double cxN = 0.0;
+    // V_s(t) = C_t + H G' is symmetric: every unordered pair of tile indices is computed once, by the wave that owns it (the pairing
+    // of kd_forward_info: 3, 3, 2, 2 tiles per wave at d = 64 — 48 instead of 64 MFMAs on the critical wave, and only those tiles
+    // of C_t are read from the record: −19 % of the record traffic of a kernel that moves 3.9 TB/s), written to MV with its mirror
+    // image; every wave then reads its full tile row back for the posterior store.
+    constexpr int NS = NT / 2 + 1;
+    const int ws = __builtin_amdgcn_readfirstlane(w);
+    const int nsw = (NT % 2 == 0 && NT > 1 && ws >= NT / 2) ? NS - 1 : NS;
+    auto slot_tile = [&](int sl) { const int t2 = ws + sl; return t2 >= NT ? t2 - NT : t2; };
     auto prefetch = [&](long long tt) {   // G_tt' and C_tt ξ_f(tt) of the NEXT step travel under the current one
         const double* rec = p.filt + (chain * p.T + tt) * C::REC;
         acc_load_full<NT>(gN, rec + C::HDR + D * D, w, lane);
@@ -1768,10 +1795,26 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
         commit();
     }
     lds_barrier();
+    bool pending = false;       // the posterior of the previous step is still in MV / ms: stored at the top of the next iteration
+    long long tprev = 0;
+    auto flush_posterior = [&]() {
+        acc_load<NT>(cc, MV, LD, w, lane);
+        if (tid < D) dense_store_mean(p, tprev, chain, tid, ms[tid]);
+        dense_store_cov<NT>(p, cc, tprev, chain, w, lane);
+    };
     for (long long t = te - 1; t >= tb; --t) {
         prefetch(t - 1 >= tb ? t - 1 : tb);
-        // C_t: the accumulator of the second contraction; its L2 / HBM latency hides under the first one
-        acc_load_full<NT>(cc, p.filt + (chain * p.T + t) * C::REC + C::HDR, w, lane);
+        // C_t (owned tiles): the accumulators of the second contraction; their L2 / HBM latency hides under the first one
+        d4 vacc[NS];
+        {
+            const double* rec = p.filt + (chain * p.T + t) * C::REC + C::HDR;
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const double* src = rec + ((w * NT + slot_tile(sl)) * 4) * 64 + lane;
+                vacc[sl] = (sl < nsw) ? (d4){src[0], src[64], src[128], src[192]} : (d4){0.0, 0.0, 0.0, 0.0};
+            }
+        }
+        if (pending) flush_posterior();   // V_s(t+1), m_s(t+1): complete in MV / ms since the barrier that closed the last iteration
         // G m_s(t+1): thread group `grp` sums a quarter of the k range down the columns of MG (consecutive threads read
         // consecutive addresses)
         {
@@ -1787,20 +1830,51 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
         // H = G V_s
         acc_zero<NT>(a);
         mm_acc<NT, true, false>(a, MG, LD, MV, LD, w, lane);
-        lds_barrier();  // every wave is through with V_s; the matvec partials are complete
+        lds_barrier();  // every wave is through with V_s (and has its rows of it in registers for the store); the matvec partials are complete
         double mnew = 0.0;
         if (tid < D) mnew = xf[tid] + ((rowbuf[tid] + rowbuf[D + tid]) + (rowbuf[2 * D + tid] + rowbuf[3 * D + tid]));
         acc_store<NT>(a, MV, LD, w, lane);  // this wave's rows of H; only this wave reads them back (LDS is in order per wave)
-        // V_s(t) = C + H G'
-        mm_acc<NT, false, false>(cc, MV, LD, MG, LD, w, lane);
-        if (tid < D) dense_store_mean(p, t, chain, tid, mnew);
-        dense_store_cov<NT>(p, cc, t, chain, w, lane);
+        // V_s(t) = C + H G'  (owned tiles)
+        {
+            const int i = 16 * w + (lane & 15), kq = lane >> 4, jl = lane & 15;
+            if (nsw == NS) {
+#pragma unroll
+                for (int kk = 0; kk < D / 4; ++kk) {
+                    const double av = MV[i * LD + 4 * kk + kq];
+#pragma unroll
+                    for (int sl = 0; sl < NS; ++sl)
+                        vacc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, MG[(4 * kk + kq) * LD + 16 * slot_tile(sl) + jl], vacc[sl], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < D / 4; ++kk) {
+                    const double av = MV[i * LD + 4 * kk + kq];
+#pragma unroll
+                    for (int sl = 0; sl < NS - 1; ++sl)
+                        vacc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, MG[(4 * kk + kq) * LD + 16 * slot_tile(sl) + jl], vacc[sl], 0, 0, 0);
+                }
+            }
+        }
         lds_barrier();  // every wave is through with G' (and with its rows of H)
-        acc_store<NT>(cc, MV, LD, w, lane);
+        // V_s(t) into MV: the owned tiles and their mirror images
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl)
+            if (sl < nsw) {
+                const int ts = slot_tile(sl);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = 16 * ws + (lane >> 4) + 4 * r, col = 16 * ts + (lane & 15);
+                    MV[row * LD + col] = vacc[sl][r];
+                    if (ts != ws) MV[col * LD + row] = vacc[sl][r];
+                }
+            }
         if (tid < D) ms[tid] = mnew;
         commit();
         lds_barrier();
+        pending = true;
+        tprev = t;
     }
+    if (pending) flush_posterior();
     if (FE && tid == 0) {  // the residual quadratic forms are kd_fe_resid's
         double f = 0.0;
         if (seg == p.S - 1) f += lpe.value();        // log|Λ_f(T)|

@@ -45,7 +45,14 @@ __global__ void __launch_bounds__(256) kd_split_tables(SplitParams q) {
         // accumulator order: index ((w·NT + tile)·4 + r)·64 + lane  <->  (row 16w + (lane >> 4) + 4r, col 16·tile + (lane & 15))
         const int lane = e & 63, r = (e >> 6) & 3, wt = e >> 8, w = wt / NT, tile = wt - w * NT;
         const int row = 16 * w + (lane >> 4) + 4 * r, col = 16 * tile + (lane & 15);
-        const double c = rec[e], a = rec[D * D + e];
+        // C_t is symmetric and the record holds the owned tiles only (dense_owned_tile): the others are the mirror images
+        double c;
+        if (dense_owned_tile(NT, w, tile)) c = rec[e];
+        else {
+            const int j = lane & 15, rp = j >> 2, lp = (j & 3) * 16 + (lane >> 4) + 4 * r;   // element (col, row) in tile (tile, w)
+            c = rec[((tile * NT + w) * 4 + rp) * 64 + lp];
+        }
+        const double a = rec[D * D + e];
         tab[row * D + col] = c;
         tab[D * D + col * D + row] = a;       // AT[k = col][i = row] = G′[row][col]
         tab[2 * D * D + row * D + col] = a;   // A[k = row][i = col]  = G′[row][col]

@@ -2164,6 +2164,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
                 for (int q = 0; q < 6; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * (nb[q] ? nb[q] : 1));
                 dt->bytes = off[6];
                 if (hipMalloc(&dt->block, dt->bytes) != hipSuccess) { delete dt; return fail(e, RXHIP_ERR_HIP, "hipMalloc of %zu bytes (model tables) failed", off[6]); }
+                tr.mark("dense: table block (hipMalloc)", STAGE_ALLOC);
                 double** dst[5] = {&dt->d_cst, &dt->d_tab, &dt->d_scanm, &dt->d_qtab, &dt->d_bnd};
                 hipError_t up = hipSuccess;
                 for (int q = 0; q < 5; ++q) *dst[q] = (double*)(dt->block + off[q]);
