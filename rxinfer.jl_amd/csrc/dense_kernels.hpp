@@ -68,6 +68,7 @@ struct DenseCst {
         c.oPLW = o; o += (long long)d * d;   // P⁻¹ + B'Q⁻¹B + A'P⁻¹A (symmetric): M_{t+1} = PLW − K G_t
         // whitening maps of the free-energy residuals (kd_fe_resid_mfma): with P = L_P L_P', Q = L_Q L_Q'
         //   r_x'P⁻¹r_x = |L_P⁻¹ x̂_{t+1} − (L_P⁻¹A) x̂_t|²,   r_y'Q⁻¹r_y = |L_Q⁻¹ y_t − (L_Q⁻¹B) x̂_t|²
+        o = (o + 1) & ~1LL;                                                              // 16-byte loads of both maps
         c.oLPX = o; o += (long long)d * 2 * d;                                           // [d][2d]  L_P⁻¹ | −L_P⁻¹A
         c.oLQX = o; o += (long long)(((dy + 15) / 16) * 16) * (((dy + 3) & ~3) + d);     // [dy↑16][dy↑4 + d]  L_Q⁻¹ | −L_Q⁻¹B
         c.size = (o + 7) / 8 * 8;
@@ -131,8 +132,16 @@ struct DenseModel {
     const int* canon;
 };
 __device__ __forceinline__ DenseModel dense_model(const DenseParams& p, long long chain) {
-    if (p.models) return p.models[p.chain_model[chain]];
-    return DenseModel{p.cst, p.tab, p.scanm, p.qtab, p.bnd, p.canon};
+    // field by field and through an empty asm: returning either struct makes the compiler select between two ADDRESSES — one of them inside the kernel-argument
+    // segment — and read the fields through a vector load of it: a round trip to wherever the kernel arguments live in front of every
+    // dense kernel (the free-energy residual kernel spent 7 of its 17 µs there, the last workgroups 15)
+    DenseModel m{p.cst, p.tab, p.scanm, p.qtab, p.bnd, p.canon};
+    asm volatile("" : "+s"(m.cst), "+s"(m.tab), "+s"(m.scanm), "+s"(m.qtab), "+s"(m.bnd), "+s"(m.canon));   // values now, not loads to be re-addressed
+    if (p.models) {
+        const DenseModel* q = p.models + p.chain_model[chain];
+        m.cst = q->cst; m.tab = q->tab; m.scanm = q->scanm; m.qtab = q->qtab; m.bnd = q->bnd; m.canon = q->canon;
+    }
+    return m;
 }
 // Symmetric d×d results (M_{t+1} in the forward kernel, V_s(t) in the backward one, C_t in the records between them) are computed /
 // stored once per unordered pair of tile indices: tile (w, t) belongs to wave w when (t − w) mod NT ≤ NT/2, the even-NT tie
@@ -165,6 +174,15 @@ __device__ __forceinline__ double dense_load_mean(const DenseParams& p, long lon
         return (j < 16 && i < p.d_out) ? p.mean[((t * p.n_chains + chain) * 2 + sub) * p.d_out + i] : 0.0;
     }
     return j < p.d_out ? p.mean[(t * p.n_chains + chain) * p.d_out + j] : 0.0;
+}
+// the same element without control flow: offset into p.mean (0 when the element does not exist) and whether it exists — for
+// loops that want many such loads in flight (a branch per load makes the compiler wait for each before the next)
+__device__ __forceinline__ long long dense_mean_offset(const DenseParams& p, long long t, long long chain, int j, bool& exists) {
+    const bool pk = p.pack == 2;
+    const int sub = j >> 3, i = pk ? (j & 7) : j;
+    exists = pk ? (j < 16 && i < p.d_out) : (j < p.d_out);
+    const long long row = pk ? (t * p.n_chains + chain) * 2 + sub : t * p.n_chains + chain;
+    return exists ? row * p.d_out + i : 0;
 }
 // one free-energy partial of workgroup-chain `chain`: `indep` does not depend on the data (log-determinants, constants: both
 // chains of a pair share the model, so each owns half of the pair's value), dep0 / dep1 are the data-dependent parts of the
@@ -1899,7 +1917,9 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
 // Small tiles (d, dy ≤ 16 / ≤ 32) would leave three quarters / half of every wavefront idle with one row per lane, so the 64
 // lanes of a wavefront split into G = 4 / 2 lane groups that work on different steps: a pass covers 16·G steps.
 __host__ __device__ inline int fe_resid_groups(int D, int dy) { const int m = D > dy ? D : dy; return m <= 16 ? 4 : m <= 32 ? 2 : 1; }
-__host__ __device__ inline int fe_resid_steps(int D, int dy) { return 48 * fe_resid_groups(D, dy); }  // steps per workgroup (3 passes)
+// steps per workgroup: 3 passes of the VALU form; wide tiles (d or dy > 32) take TWO 16-step tiles per workgroup — a single long chain
+// (T = 10⁴: 313 workgroups) then fills the chip in one round of two workgroups per CU
+__host__ __device__ inline int fe_resid_steps(int D, int dy) { const int g = fe_resid_groups(D, dy); return g == 1 ? 32 : 48 * g; }
 inline size_t fe_resid_lds_bytes(int D, int dy) {
     const size_t pass = 16 * (size_t)fe_resid_groups(D, dy);
     return sizeof(double) * ((size_t)2 * D * D + (size_t)D * dy + (size_t)dy * dy + (2 * pass + 1) * D + pass * dy + 16);
@@ -1908,7 +1928,7 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int D = p.d, dy = p.dy, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
     const int G = fe_resid_groups(D, dy), DL = 64 / G, q = lane / DL, i = lane - q * DL;  // lane group q, row i
-    const int PASS = 16 * G, STEPS = 3 * PASS;
+    const int PASS = 16 * G, STEPS = fe_resid_steps(D, dy);
     const bool pk = p.pack == 2;
     const bool x1 = pk && i >= p.d_sub, y1 = pk && i >= p.dy_sub;  // row i of the state / observation terms belongs to the pair's second chain
     double acc1 = 0.0;
@@ -1939,7 +1959,7 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
     stage(BT, M.cst + c.oBT, D * dy);
     stage(QI, M.cst + c.oQI, dy * dy);
     double acc = 0.0;
-    for (int ps = 0; ps < 3; ++ps) {
+    for (int ps = 0; ps * PASS < STEPS; ++ps) {
         const long long t0 = t00 + (long long)ps * PASS;
         if (t0 >= p.T) break;  // uniform over the workgroup
         for (int k = tid; k < (PASS + 1) * D; k += 256) {
@@ -2041,130 +2061,192 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
 
 // The same residual forms on the matrix cores (round 3).  With the whitening maps of DenseCst (oLPX, oLQX) every term is the
 // squared norm of ONE map applied to stacked means,  ρ_x(t) = [L_P⁻¹ | −L_P⁻¹A]·[x̂_{t+1}; x̂_t],  ρ_y(t) = [L_Q⁻¹ | −L_Q⁻¹B]·[y_t; x̂_t],
-// i.e. two GEMMs with the time steps as columns: a 16-step tile is the B operand (lane (j, kq) reads component 4kk + kq of
-// step j straight from the posterior means — L2), the map is the A operand (staged in LDS once per workgroup, leading
-// dimension K + 2: conflict-free), and the accumulator (rows = components, columns = steps) is squared and summed in place.
-// No intermediate vector, no LDS exchange between the two stages of r'P⁻¹r: d = 64: 0.060 -> 0.0xx ms, and the d = 8 × 1024
-// batch no longer spends a third of its sweep here.  Same grid, same slots and the same step blocks as kd_fe_resid.
+// i.e. two GEMMs with the time steps as columns: the map rows are the A operand, a 16-step tile of means / observations the
+// B operand, and the accumulator (rows = components, columns = steps) is squared and summed in place.  No intermediate
+// vector, no LDS exchange between the two stages of r'P⁻¹r.  Same grid and slots as kd_fe_resid.
 template <int NT>
 inline size_t fe_resid_mfma_lds_bytes(int dy) {
     constexpr int D = 16 * NT;
-    const int dyr = (dy + 15) / 16 * 16, ky = ((dy + 3) & ~3) + D;
-    return sizeof(double) * ((size_t)D * (2 * D + 2) + (size_t)dyr * (ky + 2) + 16);
+    return sizeof(double) * ((size_t)17 * (D + 2) + (size_t)16 * (((dy + 7) & ~7) + 2) + 16 + D + 2);
 }
+// The kernel has 3 % of the sweep's arithmetic and was 5 % of its time (d = 64, T = 10⁴: 44 µs) until time stamps inside it
+// (wall_clock64 at six points of four workgroups) showed where: none of it was arithmetic.
+//   * maps: straight from L2 into registers in the A-operand layout, once per wave (at most two row tiles: 64 doubles per lane at
+//     d = dy = 64), 16 bytes per lane and load with a permuted contraction index (see load_item);
+//   * means / observations of a tile: coalesced loads, ALL issued before the first LDS store, the next tile's issued before this
+//     tile's products (a load -> wait -> store loop was nine round trips per tile);
+//   * B operands: unconditional 16-byte LDS reads in batches (a predicated read per product serialised read -> wait -> product);
+//   * the model pointers: values, not a vector load through the kernel-argument segment (dense_model);
+//   * the prior term: one round trip spread over the four waves at the end, not four round trips of one wave in the first tile.
+// 44 -> 21 µs at d = 64, T = 10⁴ (what is left: 4 µs until the maps are in registers, 2 × 3 µs of products with two workgroups
+// per CU on the same matrix pipes, 2 µs of staging per tile).  17 KB of LDS per workgroup.
 template <int NT>
-__global__ void __launch_bounds__(256) kd_fe_resid_mfma(DenseParams p, int slot0) {
-    constexpr int D = 16 * NT, KX = 2 * D, LDX = KX + 2;
-    constexpr int RT = NT >= 3 ? 4 : NT, PT = 4 / RT;   // waves that share a time tile (one row tile each) · time tiles in flight
+__global__ void __launch_bounds__(256, 2) kd_fe_resid_mfma(DenseParams p, int slot0) {
+    constexpr int D = 16 * NT, KX = 2 * D, LDB = D + 2;
+    typedef double v4d __attribute__((ext_vector_type(4)));
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    const int dy = p.dy, dy4 = (dy + 3) & ~3, nty = (dy + 15) / 16, dyr = 16 * nty, KY = dy4 + D, LDY = KY + 2;
+    const int dy = p.dy, dy4 = (dy + 3) & ~3, dy8 = (dy + 7) & ~7, nty = (dy + 15) / 16, KY = dy4 + D, LDY = dy8 + 2;
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6, j = lane & 15, kq = lane >> 4;
-    double* MX = smem;                      // [D][LDX]
-    double* MY = MX + (size_t)D * LDX;      // [dyr][LDY]
-    double* red = MY + (size_t)dyr * LDY;   // [8]
+    double* xs = smem;                 // [17][LDB]  x̂ of the tile's steps and of the step after it
+    double* ys = xs + 17 * LDB;        // [16][LDY]
+    double* red = ys + 16 * LDY;       // [8]
+    double* dm = red + 8;              // [D]  x̂_1 − m1 (first workgroup of a chain)
+    const int DUMP = (int)(dm + D - xs), DUMPY = (int)(dm + D - ys);   // one slot behind everything: where out-of-tile stores go
     const long long chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);
     const DenseCst c = DenseCst::make(D, dy);
     const int STEPS = fe_resid_steps(D, dy), NTT = STEPS / 16;
     const long long t00 = (long long)blockIdx.x * STEPS;
-    {   // stage the two maps: every load of a map in flight at once (D·KX / 256 ≤ 32 per thread), one L2 round trip per map
-        constexpr int NX = D * KX / 256;
-        const double* sx = M.cst + c.oLPX;
-        double vx[NX];
-#pragma unroll
-        for (int u = 0; u < NX; ++u) vx[u] = sx[tid + u * 256];
-#pragma unroll
-        for (int u = 0; u < NX; ++u) {
-            const int k = tid + u * 256;
-            MX[(k / KX) * LDX + (k % KX)] = vx[u];
-        }
-        const double* sy = M.cst + c.oLQX;
-        const int ny = dyr * KY;
-        double vyv[32];   // dyr·KY ≤ 64·128
-#pragma unroll
-        for (int u = 0; u < 32; ++u) vyv[u] = (tid + u * 256 < ny) ? sy[tid + u * 256] : 0.0;
-#pragma unroll
-        for (int u = 0; u < 32; ++u) {
-            const int k = tid + u * 256;
-            if (k < ny) MY[(k / KY) * LDY + (k % KY)] = vyv[u];
-        }
-    }
     double s0 = 0.0, s1 = 0.0;   // first / second chain of a packed pair (unpacked: everything in s0)
     const bool pk = p.pack == 2;
-    if (t00 == 0 && g == 0) {  // prior of the first state: (x̂_1 − m1)'V1⁻¹(x̂_1 − m1), one row per lane (constant map read from L2 once per chain)
-        const double* V1I = M.cst + c.oV1I;
-        const double* m1 = M.cst + c.oM1;
-        if (lane < D) {
-            double u = 0.0;
-            for (int k = 0; k < D; k += 16) {
-                double v[16];
+    // row-tile items of this wave: item it = g, g + 4 over the list [x-tiles 0 … NT−1 | y-tiles 0 … nty−1] (at most two per wave)
+    const int nitems = NT + nty;
+    const int it0 = g, it1 = g + 4;
+    // A operands of an item: an x item holds [L_P⁻¹ | −L_P⁻¹A] (2·D/4 k-steps), a y item holds L_Q⁻¹ padded to 16 k-steps (zeros
+    // behind dy) followed by −L_Q⁻¹B (D/4 k-steps) — every register index is a compile-time constant.  The contraction index is
+    // PERMUTED so that memory is read in 16-byte pieces: k-steps 2m and 2m + 1 of lane quarter kq are elements 8m + 2kq and
+    // 8m + 2kq + 1 of the row — one 16-byte load per lane and pair of steps, 64 contiguous bytes per row and instruction (half
+    // the cache-line visits of an 8-byte gather: the map loads of the 2 × 4 waves of a CU were 7 of the kernel's 17 µs), and the
+    // B operand of the pair is one 16-byte LDS read of the same two elements.
+    constexpr int KA = (64 + D) / 4 > KX / 4 ? (64 + D) / 4 : KX / 4;   // even
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    double a0[KA], a1[KA];
+    auto load_item = [&](double (&a)[KA], int it) {
+        const bool isx = it < NT, live = it < nitems;
+        const int rt = isx ? it : it - NT, K = isx ? KX : KY;
+        const double* row = (isx ? M.cst + c.oLPX : M.cst + c.oLQX) + (live ? (size_t)(16 * rt + j) * K + 2 * kq : 0);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) v[r] = V1I[(size_t)(k + r) * D + lane];
+        for (int m = 0; m < KA / 2; ++m) {
+            // x item: pairs m < D/8 the first half, the next D/8 the second;  y item: pairs m < 8 the y part (elements below dy4), then the x̂ part
+            const int e = isx ? (m < D / 8 ? 8 * m : D + 8 * (m - D / 8)) : (m < 8 ? 8 * m : dy4 + 8 * (m - 8));
+            const bool ex = live && (isx ? m < D / 4 : (m < 8 ? 8 * m + 2 * kq < dy4 : 8 * (m - 8) < D));
+            v2d v = {0.0, 0.0};
+            if (ex) v = *reinterpret_cast<const v2d*>(row + e);   // (a skipped load, no wait in between)
+            a[2 * m] = v.x;
+            a[2 * m + 1] = v.y;
+        }
+    };
+    load_item(a0, it0);
+    load_item(a1, it1);
+    // The B operands are read unconditionally (a batch of LDS reads ahead of a batch of products; a predicated read per product
+    // serialises read -> wait -> product: 14 µs per tile at d = 64 instead of 2); what must not count — the transition out of the
+    // last step, the observation term of a missing step — is a COLUMN of the product and this lane's own column: masked at the end.
+    auto run_item = [&](const double (&a)[KA], int it, bool vx, bool ob) {
+        if (it >= nitems) return;   // uniform over the wave
+        const bool isx = it < NT;
+        const int rt = isx ? it : it - NT;
+        v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};   // two independent chains on the matrix pipe
+        const double* xr = xs + j * LDB + 2 * kq;
+        if (isx) {   // ρ_x = L_P⁻¹ x̂_{t+1} − (L_P⁻¹A) x̂_t
 #pragma unroll
-                for (int r = 0; r < 16; ++r) u += v[r] * (dense_load_mean(p, 0, chain, k + r) - m1[k + r]);
+            for (int m = 0; m < D / 8; ++m) {
+                const v2d b1 = *reinterpret_cast<const v2d*>(xr + LDB + 8 * m), b0 = *reinterpret_cast<const v2d*>(xr + 8 * m);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * m], b1.x, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[D / 4 + 2 * m], b0.x, acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * m + 1], b1.y, acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[D / 4 + 2 * m + 1], b0.y, acc2, 0, 0, 0);
+                if (m % 2 == 1) __builtin_amdgcn_sched_barrier(0);   // four reads ahead of eight products, not all of them (registers)
             }
-            const double e = (dense_load_mean(p, 0, chain, lane) - m1[lane]) * u;
-            if (pk && lane >= p.d_sub) s1 += e;
+        } else {     // ρ_y = L_Q⁻¹ y_t − (L_Q⁻¹B) x̂_t
+            const double* yr = ys + j * LDY + 2 * kq;
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                if (8 * m < dy4) {   // uniform; the staged row is zero-filled up to dy8, the operand is zero behind dy4
+                    const v2d b = *reinterpret_cast<const v2d*>(yr + 8 * m);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * m], b.x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[2 * m + 1], b.y, acc, 0, 0, 0);
+                }
+#pragma unroll
+            for (int m = 0; m < D / 8; ++m) {
+                const v2d b = *reinterpret_cast<const v2d*>(xr + 8 * m);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[16 + 2 * m], b.x, acc2, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[16 + 2 * m + 1], b.y, acc2, 0, 0, 0);
+                if (m % 4 == 3) __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        acc += acc2;
+        const int sub = isx ? p.d_sub : p.dy_sub;
+        const bool count = isx ? vx : ob;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double e = count ? acc[r] * acc[r] : 0.0;
+            if (pk && 16 * rt + kq + 4 * r >= sub) s1 += e;
             else s0 += e;
         }
+    };
+    // A tile's loads are all issued first and stored to LDS later: a load -> wait -> store loop pays one memory round trip per pass
+    // (nine per tile: 40 µs of a 45 µs kernel at d = 64, whatever the rest of the kernel did), and the NEXT tile's loads are issued
+    // before this tile's products so that they arrive under them.  The existence flags go through an empty asm before they
+    // select (otherwise the compiler moves each load under its flag, and the wait with it); elements past the tile are stored
+    // to a dump slot so that the stores are unconditional too.
+    double xv[NT + 1], yv[4], obv = 1.0, m1v = 0.0;   // 17·D / 256 ≤ NT + 1 passes; dy ≤ 64: at most four
+    int xe[NT + 1], ye[4];
+    auto issue = [&](long long tb) {
+#pragma unroll
+        for (int u = 0; u < NT + 1; ++u) {   // coalesced: consecutive threads, consecutive components of one step
+            const int k = tid + 256 * u, sidx = k / D, comp = k - sidx * D;
+            const long long t = tb + sidx;
+            bool ex;
+            const long long off = dense_mean_offset(p, t < p.T ? t : p.T - 1, chain, comp, ex);
+            xv[u] = p.mean[off];
+            xe[u] = ex && k < 17 * D && t < p.T;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = tid + 256 * u, sidx = k / dy8, comp = k - sidx * dy8;
+            const long long t = tb + sidx;
+            const bool ex = k < 16 * dy8 && t < p.T && comp < dy;
+            yv[u] = p.y[ex ? (t * p.n_chains + chain) * dy + comp : 0];
+            ye[u] = ex;
+        }
+        obv = p.mseg ? p.obs[tb + j < p.T ? chain * p.T + tb + j : 0] : 1.0;   // lane (j, ·): B-operand column j = time step tb + j
+        if (tb == 0) m1v = M.cst[c.oM1 + (tid < D ? tid : 0)];
+    };
+    auto deposit = [&](long long tb) {
+#pragma unroll
+        for (int u = 0; u < NT + 1; ++u) {
+            const int k = tid + 256 * u, sidx = k / D, comp = k - sidx * D;
+            asm volatile("" : "+v"(xe[u]));
+            xv[u] = xe[u] ? xv[u] : 0.0;
+            xs[k < 17 * D ? sidx * LDB + comp : DUMP] = xv[u];
+        }
+        if (tb == 0 && tid < D) dm[tid] = xv[0] - m1v;   // k = tid < D: step 0, component tid
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = tid + 256 * u, sidx = k / dy8, comp = k - sidx * dy8;
+            asm volatile("" : "+v"(ye[u]));
+            ys[k < 16 * dy8 ? sidx * LDY + comp : DUMPY] = ye[u] ? yv[u] : 0.0;
+        }
+    };
+    if (t00 < p.T) issue(t00);
+    for (int tt = 0; tt < NTT; ++tt) {
+        const long long tb = t00 + 16 * tt;
+        if (tb >= p.T) break;   // uniform over the workgroup
+        __syncthreads();        // the previous tile's readers are done
+        deposit(tb);
+        const long long tj = tb + j;
+        const bool vy = tj < p.T, vx = tj + 1 < p.T;
+        const bool ob = vy && obv != 0.0;   // `missing`: no observation node energy at this time index
+        __syncthreads();
+        if (tt + 1 < NTT && tb + 16 < p.T) issue(tb + 16);
+        run_item(a0, it0, vx, ob);
+        run_item(a1, it1, vx, ob);
     }
-    __syncthreads();
-    const int rg = g % RT, tp = g / RT;
-    for (int tt = tp; tt < NTT; tt += PT) {
-        const long long t = t00 + 16 * tt + j;   // this lane's time step (B-operand column)
-        if (t00 + 16 * tt >= p.T) break;          // uniform over the wave
-        const bool vy = t < p.T, vx = t + 1 < p.T;
-        const bool ob = vy && (!p.mseg || p.obs[chain * p.T + t] != 0.0);   // `missing`: no observation node energy at this time index
-        double xn[D / 4], xc[D / 4], yv[16];
+    if (t00 == 0 && lane < D) {   // prior of the first state: (x̂_1 − m1)'V1⁻¹(x̂_1 − m1) = Σ_waves dm_i Σ_{k in the wave's quarter} V1⁻¹[k][i] dm_k
+        const double* V1I = M.cst + c.oV1I + lane;   // row i = lane; every load independent (a uniform address per term would be a
+        double u = 0.0;                              // chain of scalar loads), one round trip for the whole term
 #pragma unroll
-        for (int kk = 0; kk < D / 4; ++kk) {
-            xn[kk] = vx ? dense_load_mean(p, t + 1, chain, 4 * kk + kq) : 0.0;
-            xc[kk] = vy ? dense_load_mean(p, t, chain, 4 * kk + kq) : 0.0;
-        }
-#pragma unroll
-        for (int kk = 0; kk < 16; ++kk) {
-            const int k = 4 * kk + kq;
-            yv[kk] = (ob && k < dy) ? p.y[(t * p.n_chains + chain) * dy + k] : 0.0;
-        }
-        typedef double v4d __attribute__((ext_vector_type(4)));
-        for (int rt = rg; rt < NT; rt += RT) {   // ρ_x, row tile rt
-            const double* a = MX + (size_t)(16 * rt + j) * LDX + kq;
-            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};   // two independent chains on the matrix pipe
-#pragma unroll
-            for (int kk = 0; kk < D / 4; ++kk) {
-                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * kk], xn[kk], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[D + 4 * kk], vx ? xc[kk] : 0.0, acc2, 0, 0, 0);
-            }
-            acc += acc2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double e = acc[r] * acc[r];
-                if (pk && 16 * rt + kq + 4 * r >= p.d_sub) s1 += e;
-                else s0 += e;
-            }
-        }
-        for (int rt = rg; rt < nty; rt += RT) {  // ρ_y, row tile rt
-            const double* a = MY + (size_t)(16 * rt + j) * LDY + kq;
-            v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int kk = 0; kk < 16; ++kk)
-                if (4 * kk < dy4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[4 * kk], yv[kk], acc, 0, 0, 0);
-#pragma unroll
-            for (int kk = 0; kk < D / 4; ++kk) acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[dy4 + 4 * kk], ob ? xc[kk] : 0.0, acc2, 0, 0, 0);
-            acc += acc2;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const double e = acc[r] * acc[r];
-                if (pk && 16 * rt + kq + 4 * r >= p.dy_sub) s1 += e;
-                else s0 += e;
-            }
-        }
+        for (int k = g * (D / 4); k < (g + 1) * (D / 4); ++k) u += V1I[(size_t)k * D] * dm[k];
+        const double e = dm[lane] * u;
+        if (pk && lane >= p.d_sub) s1 += e;
+        else s0 += e;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
         s0 += __shfl_down(s0, off);
         s1 += __shfl_down(s1, off);
     }
+    __syncthreads();
     if (lane == 0) { red[g] = s0; red[4 + g] = s1; }
     __syncthreads();
     if (tid == 0) {
