@@ -131,16 +131,32 @@ struct DenseModel {
     double* bnd;
     const int* canon;
 };
+template <class T>
+__device__ __forceinline__ T* as_global(T* ptr) {   // tells the compiler the address space (global_load instead of flat_load)
+    const unsigned long long v = (unsigned long long)ptr;   // uniform values only: into scalar registers whatever loaded them
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)(((unsigned long long)hi << 32) | lo);
+    asm volatile("" : "+s"(g));   // (without it the two casts cancel before anything can learn from them)
+    return (T*)g;
+}
+template <class T>
+__device__ __forceinline__ T* as_global_v(T* ptr) {   // the same for a pointer in vector registers (e.g. read back from LDS)
+    __attribute__((address_space(1))) T* g = (__attribute__((address_space(1))) T*)ptr;
+    asm volatile("" : "+v"(g));
+    return (T*)g;
+}
 __device__ __forceinline__ DenseModel dense_model(const DenseParams& p, long long chain) {
     // field by field and through an empty asm: returning either struct makes the compiler select between two ADDRESSES — one of them inside the kernel-argument
     // segment — and read the fields through a vector load of it: a round trip to wherever the kernel arguments live in front of every
     // dense kernel (the free-energy residual kernel spent 7 of its 17 µs there, the last workgroups 15)
-    DenseModel m{p.cst, p.tab, p.scanm, p.qtab, p.bnd, p.canon};
-    asm volatile("" : "+s"(m.cst), "+s"(m.tab), "+s"(m.scanm), "+s"(m.qtab), "+s"(m.bnd), "+s"(m.canon));   // values now, not loads to be re-addressed
+    DenseModel m{as_global(p.cst), as_global(p.tab), as_global(p.scanm), as_global(p.qtab), as_global(p.bnd), as_global(p.canon)};   // values now, not loads to be re-addressed
     if (p.models) {
         const DenseModel* q = p.models + p.chain_model[chain];
         m.cst = q->cst; m.tab = q->tab; m.scanm = q->scanm; m.qtab = q->qtab; m.bnd = q->bnd; m.canon = q->canon;
     }
+    // ... and pointers to GLOBAL memory: a pointer of unknown origin is read with flat_load, which counts on the LDS counter too
+    m.cst = as_global(m.cst); m.tab = as_global(m.tab); m.scanm = as_global(m.scanm); m.qtab = as_global(m.qtab);
+    m.bnd = as_global(m.bnd); m.canon = as_global(m.canon);
     return m;
 }
 // Symmetric d×d results (M_{t+1} in the forward kernel, V_s(t) in the backward one, C_t in the records between them) are computed /
@@ -1116,7 +1132,8 @@ __device__ __forceinline__ void dense_affine_rounds(int nrounds, MapF map_of, WF
     const double* cur[PD];   // the map each slot holds (uniform over the workgroup): a canonical map that is still there is not fetched again
 #pragma unroll
     for (int q = 0; q < PD; ++q) cur[q] = nullptr;
-    auto fetch = [&](double (&dst)[KP], const double*& have, const double* Mt) {
+    auto fetch = [&](double (&dst)[KP], const double*& have, const double* Mt0) {
+        const double* Mt = as_global_v(Mt0);   // (through LDS the pointer lost its address space: flat loads count as LDS traffic too)
         if (Mt != have) {
 #pragma unroll
             for (int u = 0; u < KP; ++u) dst[u] = Mt[(size_t)(k0 + u) * D + row];
@@ -1129,8 +1146,19 @@ __device__ __forceinline__ void dense_affine_rounds(int nrounds, MapF map_of, WF
             const int r = c0 + tid < nrounds ? c0 + tid : nrounds - 1;
             mst[tid] = map_of(r);
         }
-        if (tid < D)
-            for (int rr = 0; rr < cn; ++rr) wst[rr * D + tid] = w_of(c0 + rr)[tid];   // independent loads, all in flight
+        {   // the chunk's additive vectors: SCAN_CHUNK·D elements over the 4·D threads, EVERY load issued before the first store (the
+            // round index is clamped, not tested: a test per load makes it load -> wait -> store, one memory round trip per round)
+            constexpr int PER = SCAN_CHUNK / 4;
+            double wv[PER];
+            const int part = tid / D, i = tid - part * D;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) {
+                const int rr = part + 4 * u;
+                wv[u] = w_of(c0 + (rr < cn ? rr : cn - 1))[i];
+            }
+#pragma unroll
+            for (int u = 0; u < PER; ++u) wst[(part + 4 * u) * D + i] = wv[u];
+        }
         lds_barrier();
         if (c0 == 0) {
 #pragma unroll
@@ -1172,7 +1200,7 @@ __device__ __forceinline__ void dense_affine_rounds(int nrounds, MapF map_of, WF
     }
 }
 
-// level 1.  grid (2·ng, chains): blockIdx.x = dir·ng + group;  dir 0 = prefix, 1 = suffix.  Workgroup (0, 0) also performs the
+// level 1.  grid (2·ng + 1, chains): blockIdx.x = dir·ng + group;  dir 0 = prefix, 1 = suffix.  The last workgroup performs the
 // t = 1 update (filtered belief of the first observation, evidence term of filtering runs).
 template <int NT, bool FE>
 __global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
@@ -1191,25 +1219,38 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
     const DenseCst c = DenseCst::make(D, dy);
     const double* cst = M.cst;
     const int S = p.S, n = S - 1;
-    const int dir = blockIdx.x / p.ng, grpj = blockIdx.x - dir * p.ng;
     const size_t MM = (size_t)D * D;
-    if (dir == 0 && grpj == 0) {
-        // filtered belief at t = 1: ξf = V1⁻¹m1 + G y;  mf = c1 + K1 y
+    if (blockIdx.x == gridDim.x - 1) {
+        // The extra workgroup: filtered belief at t = 1: ξf = V1⁻¹m1 + G y;  mf = c1 + K1 y — beside the scans, not in front of the
+        // first group's (its loops over dy were eight memory round trips at the head of the kernel's longest workgroup).  The four
+        // thread groups of D sum a quarter of the k range each.
         if (tid < dy) yv[tid] = p.y[(0 * p.n_chains + chain) * dy + tid];
         lds_barrier();
-        if (tid < D) {
-            double xs = cst[c.oX1 + tid], ms = cst[c.oC1 + tid];
-            for (int k = 0; k < dy; ++k) {
-                xs += cst[c.oGT + (long long)k * D + tid] * yv[k];
-                ms += cst[c.oK1T + (long long)k * D + tid] * yv[k];
+        {
+            double* pst = red + 3 * 64 * NT + 16;   // [3][4][dm] partial sums (the scan's staging area, unused here)
+            const int part = tid / D, i = tid - part * D, kb = (dy + 3) / 4, k0 = part * kb, k1 = k0 + kb < dy ? k0 + kb : dy;
+            double xs = 0.0, ms = 0.0, qs = 0.0;
+#pragma unroll 8
+            for (int k = k0; k < k1; ++k) {
+                xs += cst[c.oGT + (long long)k * D + i] * yv[k];
+                ms += cst[c.oK1T + (long long)k * D + i] * yv[k];
             }
-            v1[tid] = xs;  // ξf
-            v0[tid] = ms;  // mf
-        }
-        if (tid < dy) {
-            double s = 0.0;
-            for (int k = 0; k < dy; ++k) s += cst[c.oQI + (long long)tid * dy + k] * yv[k];
-            v2[tid] = s;  // Q⁻¹ y
+            const bool qsplit = dy <= D;   // rows of Q⁻¹y fit a thread group (else: one thread per row, the whole k range)
+            if (qsplit ? i < dy : tid < dy) {
+                const int r = qsplit ? i : tid, q0 = qsplit ? k0 : 0, q1 = qsplit ? k1 : dy;
+#pragma unroll 8
+                for (int k = q0; k < q1; ++k) qs += cst[c.oQI + (long long)k * dy + r] * yv[k];   // Q⁻¹ is symmetric: column r, coalesced
+            }
+            pst[(0 * 4 + part) * dm + i] = xs;
+            pst[(1 * 4 + part) * dm + i] = ms;
+            if (qsplit) { if (i < dy) pst[(2 * 4 + part) * dm + i] = qs; }
+            else if (tid < dy) { pst[8 * dm + tid] = qs; pst[9 * dm + tid] = 0.0; pst[10 * dm + tid] = 0.0; pst[11 * dm + tid] = 0.0; }
+            lds_barrier();
+            if (tid < D) {
+                v1[tid] = cst[c.oX1 + tid] + ((pst[0 * dm + tid] + pst[1 * dm + tid]) + (pst[2 * dm + tid] + pst[3 * dm + tid]));   // ξf
+                v0[tid] = cst[c.oC1 + tid] + ((pst[4 * dm + tid] + pst[5 * dm + tid]) + (pst[6 * dm + tid] + pst[7 * dm + tid]));   // mf
+            }
+            if (tid < dy) v2[tid] = (pst[8 * dm + tid] + pst[9 * dm + tid]) + (pst[10 * dm + tid] + pst[11 * dm + tid]);             // Q⁻¹ y
         }
         lds_barrier();
         double* rec = p.filt + (chain * p.T + 0) * C::REC;
@@ -1235,8 +1276,9 @@ __global__ void __launch_bounds__(64 * NT) kd_scan_local(DenseParams p) {
                 dense_fe_write(p, 0, chain, cst[c.oC0] + cst[c.oS1] + cst[c.oLD1], (dots[0] - dots[1]) - dep1, dep1);
             }
         }
-        lds_barrier();
+        return;
     }
+    const int dir = blockIdx.x / p.ng, grpj = blockIdx.x - dir * p.ng;
     if (dir == 1 && grpj == 0 && tid < D && S > 0) p.beta_xi[(chain * (S + 1) + S) * D + tid] = 0.0;  // x_0 of the suffix scan
     if (n <= 0) return;
     const int st0 = grpj * p.sg;

@@ -1108,8 +1108,9 @@ struct DenseLaunch {
     static void boundary_scan(const DenseParams& p, bool fe, hipStream_t s) {
         slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
             dim3 g((q.filter ? 1 : 2) * q.ng, nc);  // filtering runs need the prefix direction only
-            if (fe) hipLaunchKernelGGL((kd_scan_local<NT, true>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
-            else hipLaunchKernelGGL((kd_scan_local<NT, false>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
+            dim3 g1(g.x + 1, nc);                   // + the workgroup of the t = 1 update
+            if (fe) hipLaunchKernelGGL((kd_scan_local<NT, true>), g1, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
+            else hipLaunchKernelGGL((kd_scan_local<NT, false>), g1, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
             if (q.S > 1) hipLaunchKernelGGL((kd_scan_fix<NT>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
         });
     }
