@@ -209,10 +209,10 @@ def extra_c3(device):
     # Flop counts.  ref: SURVEY §8d's reference-schedule count (18 d³ per step).  mfma: what the matrix pipe executes, from the
     # instruction counts of the shipped kernels — v_mfma_f64_16x16x4_f64 = 2048 flop; per time step and workgroup (4 waves):
     # forward 4·76 (panel inverse: 4·4 tile-inverse rounds, 12 row block, 3·(4 + 16) panel updates) + 4·64 (G' = K C) + 160
-    # (M = PLW − K G, 10 of 16 tiles: symmetric) = 720; backward 2·256 = 512; residual forms of the free energy 256 per 16 steps;
+    # (M = PLW − K G, 10 of 16 tiles: symmetric) = 720; backward 256 (J' = C K') + 160 (V_s = C + J V_s J', 10 of 16 tiles) = 416; residual forms of the free energy 256 per 16 steps;
     # aggregation GEMM [2d × L·dy]·[L·dy × S] ≈ 8 per step — confirmed by SQ_INSTS_VALU_MFMA_F64 (profiles/r03/pmc_c3.txt).  The round-2 kernels
     # executed 768 + 512 (bench counted 12 d³ = 1536 per step, the counters said 1280).
-    mfma_step = {"kd_forward_info": 720, "kd_backward_info": 512, "kd_fe_resid_mfma": 16, "kd_agg_gemm": 8}
+    mfma_step = {"kd_forward_info": 720, "kd_backward_info": 416, "kd_fe_resid_mfma": 16, "kd_agg_gemm": 8}
     mfma_flop = sum(mfma_step.values()) * 2048 * T
     ref_flop = 18 * d ** 3 * T
     tf = lambda flop, t_ms: flop / (t_ms * 1e-3) / 1e12

@@ -949,6 +949,29 @@ struct DenseLds {
     }
 };
 
+// n doubles into LDS, NB loads per thread in flight: dst[k] = load(k).  Written as a plain loop (load, store, next) the compiler
+// waits for every load before its store — one memory round trip per pass, and staging a 64×64 map with 256 threads is sixteen of
+// them (≈1 µs each out of L2).  The index is clamped instead of tested, and an empty asm between the loads and the stores keeps
+// the compiler from moving each load down to its store.
+template <int NB, int NTHR, class F>
+__device__ __forceinline__ void lds_stage_batched(double* dst, int n, int tid, F load) {
+    for (int k0 = 0; k0 < n; k0 += NB * NTHR) {
+        double v[NB];
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int k = k0 + tid + u * NTHR;
+            v[u] = load(k < n ? k : n - 1);
+        }
+#pragma unroll
+        for (int u = 0; u < NB; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+        for (int u = 0; u < NB; ++u) {
+            const int k = k0 + tid + u * NTHR;
+            if (k < n) dst[k] = v[u];
+        }
+    }
+}
+
 // phase 1 (dense): the element (b_s, η_s) of every segment.  It is linear in the segment's observations with per-offset
 // constant maps (host tables Ψ_i, Θ_i: see build_dense_tables), so instead of a sequential recursion per segment it is ONE
 // product  [2d × L·dy] · [L·dy × S]  on the matrix cores, split over K-chunks of agg_oc offsets for parallelism:
@@ -1035,13 +1058,24 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_finish(DenseParams p) {
     const long long len = b1 - b0;
     const int part = tid / D, i = tid - part * D;
     const int half = part & 1;
-    if (tid < 2 * D) {
+    if (tid < 2 * D) {   // fixed-order sum of the K-chunk partials, every load in flight at once
         double s = 0.0;
-        for (int kc = 0; kc < p.agg_kc; ++kc) s += p.aggpart[(((size_t)chain * p.agg_kc + kc) * p.S + seg) * 2 * D + tid];
+        for (int kc0 = 0; kc0 < p.agg_kc; kc0 += 12) {   // (dense_schedule_ints: at most 12 chunks)
+            double v[12];
+#pragma unroll
+            for (int u = 0; u < 12; ++u) {
+                const int kc = kc0 + u < p.agg_kc ? kc0 + u : p.agg_kc - 1;
+                v[u] = p.aggpart[(((size_t)chain * p.agg_kc + kc) * p.S + seg) * 2 * D + tid];
+            }
+#pragma unroll
+            for (int u = 0; u < 12; ++u) asm volatile("" : "+v"(v[u]));
+#pragma unroll
+            for (int u = 0; u < 12; ++u) s += kc0 + u < p.agg_kc ? v[u] : 0.0;
+        }
         if (tid < D) m[tid] = s;
         else eta[tid - D] = s;
     }
-    for (int q = tid; q < D * dy; q += 64 * NT) GTs[q] = cst[c.oGT + q];
+    lds_stage_batched<16, 64 * NT>(GTs, D * dy, tid, [&](int q) { return cst[c.oGT + q]; });
     lds_barrier();
     // The boundary scan carries v <- w_s + M1_s v (prefix) and ξ <- w_s' + N1_s ξ (suffix); the parts that do not depend on
     // the carried vector are formed here, in parallel over segments:  w_s = b_s + M2_s η_s,  w_s' = η_s − N2_s b_s.
@@ -1074,10 +1108,11 @@ __global__ void __launch_bounds__(64 * NT) kd_agg_finish(DenseParams p) {
     // B'Q⁻¹ y_t for every step of the segment, TS steps per pass: thread (i, part) forms row i for steps part, part + 4, …
     for (long long s0 = 0; s0 < len; s0 += TS) {
         lds_barrier();
-        for (int q = tid; q < TS * dy; q += 64 * NT) {
+        lds_stage_batched<4, 64 * NT>(Ys, TS * dy, tid, [&](int q) {   // (steps past the segment: the last step again; never stored to the record)
             const int st = q / dy, j = q - st * dy;
-            Ys[q] = (s0 + st < len) ? p.y[((b0 + s0 + st) * p.n_chains + chain) * dy + j] : 0.0;
-        }
+            const long long t = b0 + (s0 + st < len ? s0 + st : len - 1);
+            return p.y[(t * p.n_chains + chain) * dy + j];
+        });
         lds_barrier();
         double g[TS / 4];
 #pragma unroll
