@@ -1997,6 +1997,15 @@ __host__ __device__ inline int fe_resid_groups(int D, int dy) { const int m = D 
 // steps per workgroup: 3 passes of the VALU form; wide tiles (d or dy > 32) take TWO 16-step tiles per workgroup — a single long chain
 // (T = 10⁴: 313 workgroups) then fills the chip in one round of two workgroups per CU
 __host__ __device__ inline int fe_resid_steps(int D, int dy) { const int g = fe_resid_groups(D, dy); return g == 1 ? 32 : 48 * g; }
+// tiles of 16 steps per round of kd_fe_resid_mfma: 8 (tile, item) units over its four waves, at most four observation tiles staged
+__host__ __device__ inline int fe_resid_tiles(int D, int dy) {
+    const int nty = (dy + 15) / 16, items = D / 16 + nty;
+    if (D >= 48) return 1;            // (the kernel treats the tile index as a constant there: registers)
+    int t = 8 / items;
+    if (t > 4 / nty) t = 4 / nty;
+    if (t > 2 && D > 16) t = 2;       // steps per workgroup (fe_resid_steps) stay a multiple of the round: 192 = 3·64, 96 = 3·32, 32 = 1·32
+    return t < 1 ? 1 : t;
+}
 inline size_t fe_resid_lds_bytes(int D, int dy) {
     const size_t pass = 16 * (size_t)fe_resid_groups(D, dy);
     return sizeof(double) * ((size_t)2 * D * D + (size_t)D * dy + (size_t)dy * dy + (2 * pass + 1) * D + pass * dy + 16);
@@ -2144,7 +2153,8 @@ __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
 template <int NT>
 inline size_t fe_resid_mfma_lds_bytes(int dy) {
     constexpr int D = 16 * NT;
-    return sizeof(double) * ((size_t)17 * (D + 2) + (size_t)16 * (((dy + 7) & ~7) + 2) + 16 + D + 2);
+    const size_t rs = (size_t)16 * fe_resid_tiles(D, dy);
+    return sizeof(double) * ((rs + 1) * (D + 2) + rs * (((dy + 7) & ~7) + 2) + 16 + D + 2);
 }
 // The kernel has 3 % of the sweep's arithmetic and was 5 % of its time (d = 64, T = 10⁴: 44 µs) until time stamps inside it
 // (wall_clock64 at six points of four workgroups) showed where: none of it was arithmetic.
@@ -2164,21 +2174,24 @@ __global__ void __launch_bounds__(256, 2) kd_fe_resid_mfma(DenseParams p, int sl
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int dy = p.dy, dy4 = (dy + 3) & ~3, dy8 = (dy + 7) & ~7, nty = (dy + 15) / 16, KY = dy4 + D, LDY = dy8 + 2;
     const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6, j = lane & 15, kq = lane >> 4;
-    double* xs = smem;                 // [17][LDB]  x̂ of the tile's steps and of the step after it
-    double* ys = xs + 17 * LDB;        // [16][LDY]
-    double* red = ys + 16 * LDY;       // [8]
+    // row-tile items: [x-tiles 0 … NT−1 | y-tiles 0 … nty−1].  A wave takes at most two (tile, item) units per round, so a round
+    // covers TPB = 8 / items tiles of 16 steps (narrow models: d = 16 has two items — four tiles at once instead of two idle waves)
+    const int nitems = NT + nty, TPB = NT >= 3 ? 1 : fe_resid_tiles(D, dy), nunits = TPB * nitems, RS = 16 * TPB;   // (d ≥ 48: one tile — a constant)
+    double* xs = smem;                 // [RS + 1][LDB]  x̂ of the round's steps and of the step after them
+    double* ys = xs + (RS + 1) * LDB;  // [RS][LDY]
+    double* red = ys + RS * LDY;       // [8]
     double* dm = red + 8;              // [D]  x̂_1 − m1 (first workgroup of a chain)
     const int DUMP = (int)(dm + D - xs), DUMPY = (int)(dm + D - ys);   // one slot behind everything: where out-of-tile stores go
     const long long chain = blockIdx.y + p.chain0;
     const DenseModel M = dense_model(p, chain);
     const DenseCst c = DenseCst::make(D, dy);
-    const int STEPS = fe_resid_steps(D, dy), NTT = STEPS / 16;
+    const int STEPS = fe_resid_steps(D, dy), NTT = STEPS / RS;   // rounds per workgroup
     const long long t00 = (long long)blockIdx.x * STEPS;
     double s0 = 0.0, s1 = 0.0;   // first / second chain of a packed pair (unpacked: everything in s0)
     const bool pk = p.pack == 2;
-    // row-tile items of this wave: item it = g, g + 4 over the list [x-tiles 0 … NT−1 | y-tiles 0 … nty−1] (at most two per wave)
-    const int nitems = NT + nty;
-    const int it0 = g, it1 = g + 4;
+    // units of this wave: g and g + 4 of the round's TPB·items;  unit q = (tile q / items, item q mod items)
+    const int tl0 = NT >= 3 ? 0 : g / nitems, tl1 = NT >= 3 ? 0 : (g + 4) / nitems;
+    const int it0 = g < nunits ? g - tl0 * nitems : nitems, it1 = g + 4 < nunits ? g + 4 - tl1 * nitems : nitems;
     // A operands of an item: an x item holds [L_P⁻¹ | −L_P⁻¹A] (2·D/4 k-steps), a y item holds L_Q⁻¹ padded to 16 k-steps (zeros
     // behind dy) followed by −L_Q⁻¹B (D/4 k-steps) — every register index is a compile-time constant.  The contraction index is
     // PERMUTED so that memory is read in 16-byte pieces: k-steps 2m and 2m + 1 of lane quarter kq are elements 8m + 2kq and
@@ -2208,12 +2221,12 @@ __global__ void __launch_bounds__(256, 2) kd_fe_resid_mfma(DenseParams p, int sl
     // The B operands are read unconditionally (a batch of LDS reads ahead of a batch of products; a predicated read per product
     // serialises read -> wait -> product: 14 µs per tile at d = 64 instead of 2); what must not count — the transition out of the
     // last step, the observation term of a missing step — is a COLUMN of the product and this lane's own column: masked at the end.
-    auto run_item = [&](const double (&a)[KA], int it, bool vx, bool ob) {
+    auto run_item = [&](const double (&a)[KA], int it, int tile, bool vx, bool ob) {
         if (it >= nitems) return;   // uniform over the wave
         const bool isx = it < NT;
         const int rt = isx ? it : it - NT;
         v4d acc = {0.0, 0.0, 0.0, 0.0}, acc2 = {0.0, 0.0, 0.0, 0.0};   // two independent chains on the matrix pipe
-        const double* xr = xs + j * LDB + 2 * kq;
+        const double* xr = xs + (16 * tile + j) * LDB + 2 * kq;
         if (isx) {   // ρ_x = L_P⁻¹ x̂_{t+1} − (L_P⁻¹A) x̂_t
 #pragma unroll
             for (int m = 0; m < D / 8; ++m) {
@@ -2225,7 +2238,7 @@ __global__ void __launch_bounds__(256, 2) kd_fe_resid_mfma(DenseParams p, int sl
                 if (m % 2 == 1) __builtin_amdgcn_sched_barrier(0);   // four reads ahead of eight products, not all of them (registers)
             }
         } else {     // ρ_y = L_Q⁻¹ y_t − (L_Q⁻¹B) x̂_t
-            const double* yr = ys + j * LDY + 2 * kq;
+            const double* yr = ys + (16 * tile + j) * LDY + 2 * kq;
 #pragma unroll
             for (int m = 0; m < 8; ++m)
                 if (8 * m < dy4) {   // uniform; the staged row is zero-filled up to dy8, the operand is zero behind dy4
@@ -2256,58 +2269,61 @@ __global__ void __launch_bounds__(256, 2) kd_fe_resid_mfma(DenseParams p, int sl
     // before this tile's products so that they arrive under them.  The existence flags go through an empty asm before they
     // select (otherwise the compiler moves each load under its flag, and the wait with it); elements past the tile are stored
     // to a dump slot so that the stores are unconditional too.
-    double xv[NT + 1], yv[4], obv = 1.0, m1v = 0.0;   // 17·D / 256 ≤ NT + 1 passes; dy ≤ 64: at most four
-    int xe[NT + 1], ye[4];
+    constexpr int XV = 5;   // (RS + 1)·D / 256 passes at most (TPB·NT ≤ 4);  y: TPB·dy8 / 16 ≤ 4
+    double xv[XV], yv[4], obv0 = 1.0, obv1 = 1.0, m1v = 0.0;
+    int xe[XV], ye[4];
     auto issue = [&](long long tb) {
 #pragma unroll
-        for (int u = 0; u < NT + 1; ++u) {   // coalesced: consecutive threads, consecutive components of one step
+        for (int u = 0; u < XV; ++u) {   // coalesced: consecutive threads, consecutive components of one step
             const int k = tid + 256 * u, sidx = k / D, comp = k - sidx * D;
             const long long t = tb + sidx;
             bool ex;
             const long long off = dense_mean_offset(p, t < p.T ? t : p.T - 1, chain, comp, ex);
             xv[u] = p.mean[off];
-            xe[u] = ex && k < 17 * D && t < p.T;
+            xe[u] = ex && k < (RS + 1) * D && t < p.T;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = tid + 256 * u, sidx = k / dy8, comp = k - sidx * dy8;
             const long long t = tb + sidx;
-            const bool ex = k < 16 * dy8 && t < p.T && comp < dy;
+            const bool ex = k < RS * dy8 && t < p.T && comp < dy;
             yv[u] = p.y[ex ? (t * p.n_chains + chain) * dy + comp : 0];
             ye[u] = ex;
         }
-        obv = p.mseg ? p.obs[tb + j < p.T ? chain * p.T + tb + j : 0] : 1.0;   // lane (j, ·): B-operand column j = time step tb + j
+        // lane (j, ·): B-operand column j of tile tl = time step tb + 16·tl + j
+        obv0 = p.mseg ? p.obs[tb + 16 * tl0 + j < p.T ? chain * p.T + tb + 16 * tl0 + j : 0] : 1.0;
+        obv1 = p.mseg ? p.obs[tb + 16 * tl1 + j < p.T ? chain * p.T + tb + 16 * tl1 + j : 0] : 1.0;
         if (tb == 0) m1v = M.cst[c.oM1 + (tid < D ? tid : 0)];
     };
     auto deposit = [&](long long tb) {
 #pragma unroll
-        for (int u = 0; u < NT + 1; ++u) {
+        for (int u = 0; u < XV; ++u) {
             const int k = tid + 256 * u, sidx = k / D, comp = k - sidx * D;
             asm volatile("" : "+v"(xe[u]));
             xv[u] = xe[u] ? xv[u] : 0.0;
-            xs[k < 17 * D ? sidx * LDB + comp : DUMP] = xv[u];
+            xs[k < (RS + 1) * D ? sidx * LDB + comp : DUMP] = xv[u];
         }
         if (tb == 0 && tid < D) dm[tid] = xv[0] - m1v;   // k = tid < D: step 0, component tid
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int k = tid + 256 * u, sidx = k / dy8, comp = k - sidx * dy8;
             asm volatile("" : "+v"(ye[u]));
-            ys[k < 16 * dy8 ? sidx * LDY + comp : DUMPY] = ye[u] ? yv[u] : 0.0;
+            ys[k < RS * dy8 ? sidx * LDY + comp : DUMPY] = ye[u] ? yv[u] : 0.0;
         }
     };
     if (t00 < p.T) issue(t00);
     for (int tt = 0; tt < NTT; ++tt) {
-        const long long tb = t00 + 16 * tt;
+        const long long tb = t00 + (long long)RS * tt;
         if (tb >= p.T) break;   // uniform over the workgroup
-        __syncthreads();        // the previous tile's readers are done
+        __syncthreads();        // the previous round's readers are done
         deposit(tb);
-        const long long tj = tb + j;
-        const bool vy = tj < p.T, vx = tj + 1 < p.T;
-        const bool ob = vy && obv != 0.0;   // `missing`: no observation node energy at this time index
+        const long long tj0 = tb + 16 * tl0 + j, tj1 = tb + 16 * tl1 + j;
+        const bool vx0 = tj0 + 1 < p.T, vx1 = tj1 + 1 < p.T;
+        const bool ob0 = tj0 < p.T && obv0 != 0.0, ob1 = tj1 < p.T && obv1 != 0.0;   // `missing`: no observation node energy at this time index
         __syncthreads();
-        if (tt + 1 < NTT && tb + 16 < p.T) issue(tb + 16);
-        run_item(a0, it0, vx, ob);
-        run_item(a1, it1, vx, ob);
+        if (tt + 1 < NTT && tb + RS < p.T) issue(tb + RS);
+        run_item(a0, it0, tl0, vx0, ob0);
+        run_item(a1, it1, tl1, vx1, ob1);
     }
     if (t00 == 0 && lane < D) {   // prior of the first state: (x̂_1 − m1)'V1⁻¹(x̂_1 − m1) = Σ_waves dm_i Σ_{k in the wave's quarter} V1⁻¹[k][i] dm_k
         const double* V1I = M.cst + c.oV1I + lane;   // row i = lane; every load independent (a uniform address per term would be a
