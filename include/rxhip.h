@@ -563,6 +563,14 @@ rxhip_status rxhip_get_model_tables_ms(rxhip_engine* e, double* ms);
  * the device's page tables, not on this library: bench.py reports the four next to engine_create_ms.
  * replaces: the split `create_model` / inference timing of src/callbacks/benchmark.jl:172-207 */
 rxhip_status rxhip_get_create_stages(rxhip_engine* e, double* ms4);
+/* Posterior covariances of a batch of chains that share ONE model do not depend on the data: they are one [T][d][d] table per model.
+ * mode 0 (default): every sweep writes them into the posterior array of every chain — what the reference's marginal actors do
+ *   (`src/inference/batch.jl:325-340`: every marginal of every variable, every iteration), and what every BASELINE timing here includes.
+ * mode 1: shared-model batches on the MFMA path (4 < d ≤ 64, one model, ≥ 4 workgroup chains) keep the table and write the per-chain array
+ *   when somebody asks for it (rxhip_get_marginals / _device / _chains, rxhip_lgssm_infer with cov != NULL, predictions, node-local
+ *   joints) — at most once until the next run that rewrites it; means and free energy are unaffected.  Every other engine ignores the
+ *   mode.  (d = 8 × 1024 chains × T = 1000: 0.56 -> 0.40 ms per sweep; the per-chain copies are 30 % of it.) */
+rxhip_status rxhip_set_covariance_mode(rxhip_engine* e, int32_t mode);
 /* the hipStream_t the engine launches on */
 rxhip_status rxhip_get_stream(rxhip_engine* e, void** stream);
 /* the number of time segments the schedule uses and their length */

@@ -71,8 +71,8 @@ __global__ void __launch_bounds__(256) kd_split_save(SplitParams q, long long us
 }
 
 // every sweep: V_s(t) into the posterior array of every chain, the constant free-energy slots into every chain's column
-__global__ void __launch_bounds__(256) kd_split_broadcast(SplitParams q, long long user_chains, int want_fe) {
-    const long long dd = (long long)q.p.d_out * q.p.d_out, row = user_chains * dd, total = q.p.T * row;
+__global__ void __launch_bounds__(256) kd_split_broadcast(SplitParams q, long long user_chains, int want_fe, int want_cov) {
+    const long long dd = (long long)q.p.d_out * q.p.d_out, row = user_chains * dd, total = want_cov ? q.p.T * row : 0;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const long long t = e / row, k = (e - t * row) % dd;
         q.p.cov[e] = q.vstab[t * dd + k];

@@ -367,6 +367,11 @@ struct rxhip_engine {
     int* d_step_model = nullptr;
     // MFMA path, a batch that shares one model: matrices once per engine, vectors per sweep (dense_split_kernels.hpp)
     bool split = false, split_ready = false;
+    // rxhip_set_covariance_mode: 0 = every sweep writes the covariance of every chain; 1 = shared-model batches on the split schedule write
+    // the per-chain array on request (the values do not depend on the data: one [T][d][d] table per model).  cov_pending: the last run left
+    // the array to be materialised; cov_current: the array holds what a materialisation would write
+    int cov_mode = 0;
+    bool cov_pending = false, cov_current = false;
     double *d_dtab = nullptr, *d_vlast = nullptr, *d_vstab = nullptr, *d_fe_const = nullptr;
     bool gseq = false;        // d > 4 with `missing` observations or per-step constants: sequential schedule (gseq_kernels.hpp)
     // … and, for `missing` observations under ONE model, the time-parallel schedule of dense_mseg_kernels.hpp for smoothing runs
@@ -3147,6 +3152,7 @@ rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, d
     if (!e || !y) return RXHIP_ERR_BADARG;
     if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "filter_step: not a state-space engine");
     if (!e->dense && !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "filter_step: no device schedule for this shape");
+    e->cov_current = false; e->cov_pending = false;   // the step-wise filter writes the posterior arrays itself
     if ((e->d_step_model || e->d_cx) && e->stream_k >= e->Tout())
         return fail(e, RXHIP_ERR_STATE, "filter_step: the per-step constants / known inputs of this engine end after %lld observations", (long long)e->Tout());
     if (e->du > 0 && !e->have_inputs)
@@ -3208,6 +3214,9 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     }
     if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
     if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
+    const bool was_cov_current = e->cov_current && !filter;
+    e->cov_current = false;   // any run may rewrite the posterior arrays; the split schedule in mode 1 says otherwise below
+    e->cov_pending = false;
     // the reference refuses to run while a datavar has no value (batch.jl:387-407): so does an engine whose graph has data inputs
     if (e->du > 0 && !e->have_inputs) return fail(e, RXHIP_ERR_STATE, "run: this model has data inputs u[t]: call rxhip_set_data(RXHIP_VAR_U) first");
     SET_DEVICE(e);
@@ -3325,7 +3334,11 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                     case 3: hipLaunchKernelGGL(kd_split_backward_lds<48>, lds_grid, dim3(256), split_lds_bytes(48, 1), e->stream, sq); break;
                     default: hipLaunchKernelGGL(kd_split_backward_lds<64>, lds_grid, dim3(256), split_lds_bytes(64, 1), e->stream, sq); break;
                 }
-                hipLaunchKernelGGL(kd_split_broadcast, dim3(2048), dim3(256), 0, e->stream, sq, (long long)e->n_chains, fe ? 1 : 0);
+                // covariances: every sweep, or (mode 1) when somebody asks for them; the constant free-energy slots every sweep
+                const bool lazy = e->cov_mode == 1 && e->H == 0;
+                if (lazy && was_cov_current) e->cov_current = true;   // nothing in this schedule touches the array
+                else if (lazy) e->cov_pending = true;
+                hipLaunchKernelGGL(kd_split_broadcast, dim3(lazy ? 64 : 2048), dim3(256), 0, e->stream, sq, (long long)e->n_chains, fe ? 1 : 0, lazy ? 0 : 1);
                 if ((st = prof_end(e))) return st;
             } else if (e->S > 0) {
                 if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
@@ -3430,6 +3443,26 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     return RXHIP_OK;
 }
 
+// rxhip_set_covariance_mode(1): the per-chain covariance array of a shared-model batch is written when somebody needs it
+static rxhip_status ensure_cov(rxhip_engine* e) {
+    if (!e || !e->cov_pending) return RXHIP_OK;
+    SET_DEVICE(e);
+    SplitParams sq{};
+    sq.p.T = e->T; sq.p.S = e->S; sq.p.d_out = e->d; sq.p.cov = e->d_cov; sq.p.fe_part = nullptr;
+    sq.vstab = e->d_vstab;
+    hipLaunchKernelGGL(kd_split_broadcast, dim3(2048), dim3(256), 0, e->stream, sq, (long long)e->n_chains, 0, 1);
+    HIPCHK(e, hipGetLastError());
+    e->cov_pending = false;
+    e->cov_current = true;
+    return RXHIP_OK;
+}
+rxhip_status rxhip_set_covariance_mode(rxhip_engine* e, int32_t mode) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (mode != 0 && mode != 1) return fail(e, RXHIP_ERR_BADARG, "set_covariance_mode: mode must be 0 (every sweep) or 1 (on request)");
+    if (rxhip_status st = ensure_cov(e)) return st;
+    e->cov_mode = mode;
+    return RXHIP_OK;
+}
 rxhip_status rxhip_sync(rxhip_engine* e) {
     if (!e) return RXHIP_ERR_BADARG;
     SET_DEVICE(e);
@@ -3481,6 +3514,7 @@ rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32
     e->have_data = true;
     if (rxhip_status st = run_impl(e, filtering ? 1 : iterations, want_fe, filtering != 0)) return st;
     if (mean) HIPCHK(e, hipMemcpyAsync(hm, e->d_mean, sizeof(double) * nm, hipMemcpyDeviceToHost, e->stream));
+    if (cov) { if (rxhip_status stc = ensure_cov(e)) return stc; }
     if (cov) HIPCHK(e, hipMemcpyAsync(hc, e->d_cov, sizeof(double) * nc, hipMemcpyDeviceToHost, e->stream));
     if (fe_per_chain && want_fe) HIPCHK(e, hipMemcpyAsync(hf, e->d_fe_chain, sizeof(double) * C, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(e, hipMemcpyAsync(hs, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
@@ -3502,6 +3536,7 @@ rxhip_status rxhip_get_marginals_device(rxhip_engine* e, int32_t var_id, const d
     if (!e) return RXHIP_ERR_BADARG;
     if (var_id != RXHIP_VAR_X || (e->kind != 0 && e->kind != 3)) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals: no run yet");
+    if (rxhip_status stc = ensure_cov(e)) return stc;   // covariance mode 1: the per-chain array is written now
     if (mean_dev) *mean_dev = e->d_mean;
     if (cov_dev) *cov_dev = e->d_cov;
     return RXHIP_OK;
@@ -3549,6 +3584,7 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
         return fail(e, RXHIP_ERR_BADARG, "get_marginals: unknown layout %d", layout);
     SET_DEVICE(e);
+    if (cov) { if (rxhip_status stc = ensure_cov(e)) return stc; }   // covariance mode 1: the per-chain array is written now
     HIPCHK(e, hipStreamSynchronize(e->stream));
     rxhip_status st;
     // small results (the reference's own benchmark sizes): mean and covariance sit next to each other in the arena, so ONE
@@ -3575,6 +3611,7 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
     if (!e->ran || e->last_filter) return fail(e, RXHIP_ERR_STATE, "get_predictions: needs a smoothing run (rxhip_run) first");
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME) return fail(e, RXHIP_ERR_BADARG, "get_predictions: unknown layout %d", layout);
     SET_DEVICE(e);
+    if (rxhip_status stc = ensure_cov(e)) return stc;
     const size_t rows = (size_t)e->Tout() * e->n_chains, dy = (size_t)e->dy;
     if (e->dense) {  // any d, dy ≤ 64: observation-space form, one workgroup per (chain, time index)
         // 133 KB of dynamic LDS at d = dy = 64 (the kernel also holds a few bytes of static LDS: not the full 160 KB)
@@ -3624,6 +3661,7 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME) return fail(e, RXHIP_ERR_BADARG, "get_node_marginals: unknown layout %d", layout);
     if (e->T < 2) return RXHIP_OK;  // a single time step has no transition node between observed states
     SET_DEVICE(e);
+    if (rxhip_status stc = ensure_cov(e)) return stc;
     const size_t rows = (size_t)(e->T - 1) * e->n_chains, d2 = 2 * (size_t)e->d;
     DevTmp tmp_guard;
     HIPCHK(e, hipMalloc(&tmp_guard.p, sizeof(double) * rows * (d2 + d2 * d2)));
@@ -3791,6 +3829,7 @@ rxhip_status rxhip_get_marginals_chains(rxhip_engine* e, int32_t var_id, const i
     for (int64_t i = 0; i < n; ++i)
         if (chains[i] < 0 || chains[i] >= e->n_chains) return fail(e, RXHIP_ERR_BADARG, "get_marginals_chains: chain %lld out of range", (long long)chains[i]);
     SET_DEVICE(e);
+    if (cov) { if (rxhip_status stc = ensure_cov(e)) return stc; }
     const size_t nm = (size_t)n * e->Tout() * e->d, nc = nm * e->d;
     DevTmp tmp_guard;
     HIPCHK(e, hipMalloc(&tmp_guard.p, sizeof(long long) * (size_t)n + sizeof(double) * (nm + nc)));

@@ -285,6 +285,11 @@ class LGSSMEngine:
         self._chk(_lib.lib().rxhip_get_create_stages(self._h, ms))
         return {"tables_host_ms": ms[0], "tables_device_ms": ms[1], "upload_ms": ms[2], "alloc_ms": ms[3]}
 
+    def set_covariance_mode(self, mode):
+        """0: every sweep writes the covariance of every chain (default); 1: shared-model batches on the MFMA path write the per-chain
+        array when it is asked for (rxhip_set_covariance_mode)"""
+        self._chk(_lib.lib().rxhip_set_covariance_mode(self._h, int(mode)))
+
     def schedule(self):
         s, l = ctypes.c_int32(), ctypes.c_int64()
         self._chk(_lib.lib().rxhip_get_schedule(self._h, ctypes.byref(s), ctypes.byref(l)))
