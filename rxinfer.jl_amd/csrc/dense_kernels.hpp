@@ -32,7 +32,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct DenseCst {
     int d, dy;
     long long oA, oP, oLOBS, oG, oQI, oHF, oC0, oX1, oS1, oLD1, oC1, oK1, oVF1, oAT, oGT, oHFT, oK1T, oPI, oK, oKT, oW, oV1I, oM1,
-        oBT, oFEC, oPLW, oLPX, oLQX, size;
+        oBT, oFEC, oPLW, oPLWM, oLPX, oLQX, size;
     __host__ __device__ static DenseCst make(int d, int dy) {
         DenseCst c;
         c.d = d;
@@ -66,6 +66,7 @@ struct DenseCst {
         c.oBT = o; o += (long long)d * dy;   // B'   [d][dy]
         c.oFEC = o; o += 1;                  // ½[log|V1| + (T−1) log|P| + T(dy log 2π + log|Q|)]
         c.oPLW = o; o += (long long)d * d;   // P⁻¹ + B'Q⁻¹B + A'P⁻¹A (symmetric): M_{t+1} = PLW − K G_t
+        c.oPLWM = o; o += (long long)d * d;  // the same without B'Q⁻¹B: the step after a `missing` observation (masked sweeps)
         // whitening maps of the free-energy residuals (kd_fe_resid_mfma): with P = L_P L_P', Q = L_Q L_Q'
         //   r_x'P⁻¹r_x = |L_P⁻¹ x̂_{t+1} − (L_P⁻¹A) x̂_t|²,   r_y'Q⁻¹r_y = |L_Q⁻¹ y_t − (L_Q⁻¹B) x̂_t|²
         o = (o + 1) & ~1LL;                                                              // 16-byte loads of both maps
@@ -1681,6 +1682,18 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     }
     // B'Q⁻¹ y_t comes from the aggregation kernel (record of t, second header slot), fetched one step ahead
     double gyn = (tid < D && len > 0) ? p.filt[(chain * p.T + t0) * C::REC + D + tid] : 0.0;
+    double obn = (p.mseg && len > 0) ? p.obs[chain * p.T + t0] : 1.0;   // is y_t observed (masked sweeps), one step ahead like gyn
+    d4 plw_r[NT <= 2 ? NS : 1], plwm_r[NT <= 2 ? NS : 1];
+    if constexpr (NT <= 2) {
+        const int lq0 = lane >> 4, lj0 = lane & 15;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl) {
+            const double* s0 = cst + c.oPLW + (size_t)(16 * ws + lq0) * D + 16 * slot_tile(sl) + lj0;
+            const double* s1 = cst + c.oPLWM + (size_t)(16 * ws + lq0) * D + 16 * slot_tile(sl) + lj0;
+            plw_r[sl] = (d4){s0[0], s0[4 * D], s0[8 * D], s0[12 * D]};
+            plwm_r[sl] = (d4){s1[0], s1[4 * D], s1[8 * D], s1[12 * D]};
+        }
+    }
     lds_barrier();
     for (long long i = 0; i < len; ++i) {
         const long long t = t0 + i;
@@ -1713,19 +1726,20 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
         asm volatile("" : "+v"(ln));   // addresses below are recomputed per step, not hoisted into (spilled) registers
         const int lq = ln >> 4, lj = ln & 15;
         // PLW tiles of this wave's share of M_{t+1} (below): the L2 latency hides under G' = K C
+        // y_t missing: no `*`_B(:in) message, Λ_f(t) = Λ_p(t) — the constant without B'Q⁻¹B (a second table, selected by a flag that
+        // was fetched a step ahead: subtracting the tiles here was eight dependent round trips on every missing step)
+        const bool miss = obn == 0.0;
+        if (p.mseg) obn = p.obs[chain * p.T + (i + 1 < len ? t + 1 : t)];
         d4 macc[NS];
+        if constexpr (NT <= 2) {   // narrow models: both constants live in registers (G' = K C is too short to hide an L2 round trip per step)
 #pragma unroll
-        for (int sl = 0; sl < NS; ++sl) {
-            const double* src = cst + c.oPLW + (size_t)(16 * ws + lq) * D + 16 * slot_tile(sl) + lj;
-            macc[sl] = (d4){src[0], src[4 * D], src[8 * D], src[12 * D]};
-        }
-        if (p.mseg && p.obs[chain * p.T + t] == 0.0) {   // y_t missing: no `*`_B(:in) message, Λ_f(t) = Λ_p(t) — B'Q⁻¹B comes off (uniform branch)
+            for (int sl = 0; sl < NS; ++sl) macc[sl] = miss ? plwm_r[sl] : plw_r[sl];
+        } else {
+            const double* plw = cst + (miss ? c.oPLWM : c.oPLW);
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl) {
-                const double* src = cst + c.oLOBS + (size_t)(16 * ws + lq) * D + 16 * slot_tile(sl) + lj;
-                // PLW holds the symmetrised B'Q⁻¹B: take the same symmetric part off
-                const double* srt = cst + c.oLOBS + (size_t)(16 * slot_tile(sl) + lj) * D + 16 * ws + lq;
-                macc[sl] -= (d4){0.5 * (src[0] + srt[0]), 0.5 * (src[4 * D] + srt[4]), 0.5 * (src[8 * D] + srt[8]), 0.5 * (src[12 * D] + srt[12])};
+                const double* src = plw + (size_t)(16 * ws + lq) * D + 16 * slot_tile(sl) + lj;
+                macc[sl] = (d4){src[0], src[4 * D], src[8 * D], src[12 * D]};
             }
         }
         lds_barrier();

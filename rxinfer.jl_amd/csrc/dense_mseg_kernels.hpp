@@ -165,6 +165,22 @@ __global__ void __launch_bounds__(64 * NT) km_elements(MsegParams p) {
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
 
+// One segment per chain (batches with enough chains to fill the machine: mseg_setup): no element is needed, only what km_elements hands
+// to the sweep kernel besides it — B'Q⁻¹y_t of the observed steps, 0 for the missing ones.  One thread per (chain, t ≥ 1, component).
+__global__ void __launch_bounds__(256) km_gy(MsegParams p) {
+    const int D = p.d, dyu = p.dy_user;
+    const long long chain = blockIdx.y, idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long t = 1 + idx / D;
+    const int i = (int)(idx - (t - 1) * D);
+    if (t >= p.T) return;
+    const double* G = p.cw + (size_t)TabWs::G * D * D + (size_t)i * D;
+    const double* yt = p.y + (t * p.n_chains + chain) * dyu;
+    double s = 0.0;
+    if (p.obs[chain * p.T + t] != 0.0)
+        for (int k = 0; k < dyu; ++k) s += G[k] * yt[k];
+    p.filt[(chain * p.T + t) * p.rec + D + i] = s;
+}
+
 // boundary recursion over the segments of one chain: blockIdx.x = 0 prefix, 1 suffix
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p) {

@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(64 * NT) kt_consts(TabParams p) {
             cst[c.oPI + k] = pi;
             cst[c.oW + k] = wc;
             cst[c.oPLW + k] = pi + lo + wc;
+            cst[c.oPLWM + k] = pi + wc;
         }
     }
     o.put(cst + c.oLOBS, D, 1, D, D, W(TabWs::LOBS));

@@ -1232,6 +1232,16 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     // machine on their own, and the scratch of the element pass grows with chains × S
     long long S = (long long)std::ceil(std::sqrt(2.0 * (double)(T - 1)));
     while (S > 1 && (double)C * (double)S * (MSEG_WS + 9) * MM * 8.0 > 6e9) S = (S + 1) / 2;
+    {   // ... unless the chains fill the machine on their own: then ONE segment per chain — the sweep kernels run the whole chain, no
+        // element pass (which costs 6× a sweep step) and no boundary recursion.  Cost model in µs per step / segment and workgroups the
+        // chip holds at once, from profiles/r03/dense_missing_parallel_kernels.txt (d = 64: 106 / 65 / 17, 512; d ≤ 16: 28 / 24 / 5.7, 2048).
+        const double f = (double)(e->nt - 1) / 3.0, c_e = 28.0 + f * 78.0, c_s = 24.0 + f * 41.0, c_f = 5.7 + f * 11.3, conc = e->nt == 1 ? 2048.0 : e->nt == 2 ? 1024.0 : 512.0;
+        auto cost = [&](long long s) {
+            const double steps = std::ceil((double)(T - 1) / (double)s), rounds = std::ceil((double)C * (double)s / conc);
+            return rounds * steps * ((s > 1 ? c_e : 0.0) + c_f) + (s > 1 ? (double)s * c_s * std::ceil(2.0 * (double)C / conc) : 0.0);
+        };
+        if (cost(1) <= cost(S)) S = 1;
+    }
     if (ds->segments > 0) S = ds->segments;
     if (S > (long long)T - 1) S = (long long)T - 1;
     if (S < 1) S = 1;
@@ -1289,7 +1299,8 @@ static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams
     const size_t lds = sizeof(double) * (size_t)(blk_scratch_doubles(NT) + 2 * 64 * NT + 8 * 16 * NT + 16);
     hipStream_t s = e->stream;
     hipLaunchKernelGGL(km_mask, dim3((unsigned)mp.n_chains), dim3(256), 0, s, mp);
-    hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
+    if (mp.S == 1) hipLaunchKernelGGL(km_gy, dim3((unsigned)(((mp.T - 1) * mp.d + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
+    else hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
     hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
     if (mp.S > 1) hipLaunchKernelGGL((km_bnd<NT>), dim3((unsigned)(mp.S - 1), (unsigned)mp.n_chains), dim3(64 * NT), sizeof(double) * blk_scratch_doubles(NT), s, mp);
     DenseLaunch<NT>::forward_info(dp, fe, s);
@@ -1403,6 +1414,8 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
                 cst[c.oPLW + (size_t)i * d + k] = 0.5 * (Pinv[(size_t)i * d + k] + Pinv[(size_t)k * d + i]) +
                                                   0.5 * (Lobs[(size_t)i * d + k] + Lobs[(size_t)k * d + i]) +
                                                   0.5 * (Wc[(size_t)i * d + k] + Wc[(size_t)k * d + i]);
+                cst[c.oPLWM + (size_t)i * d + k] = 0.5 * (Pinv[(size_t)i * d + k] + Pinv[(size_t)k * d + i]) +
+                                                   0.5 * (Wc[(size_t)i * d + k] + Wc[(size_t)k * d + i]);
             }
         for (int i = 0; i < d; ++i) cst[c.oM1 + i] = m1[i];
         for (int r = 0; r < dy; ++r)

@@ -1,9 +1,10 @@
 #!/bin/bash
-# kernel stats of the masked time-parallel schedule
+# kernel stats of the masked time-parallel schedule:  ./scripts/gpu_r03w.sh ["d chains T" ...]
 export TMPDIR=/tmp
 OUT=$PWD/gpurun_out/r03w; mkdir -p "$OUT"; ROOT=$PWD
 cd /tmp
-for cfg in "64 1 2000" "8 1024 1000"; do
+if [ $# -eq 0 ]; then set -- "64 1 2000" "8 1024 1000"; fi
+for cfg in "$@"; do
   tag=$(echo $cfg | tr ' ' '_')
   rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$tag" -o m -- python $ROOT/scripts/prof_mseg.py $cfg > "$OUT/$tag.txt" 2> "$OUT/$tag.err"
   cat "$OUT/$tag.txt"

@@ -7,12 +7,15 @@ import rxhip
 from rxhip import workloads
 
 
-def timed(eng, n=3):
+def timed(eng, n=5):
+    """median of n individually timed sweeps (a process that has just released a large arena sees one-off stalls of 50–80 ms)"""
     eng.run(free_energy=True)
-    t0 = time.perf_counter()
+    ts = []
     for _ in range(n):
+        t0 = time.perf_counter()
         eng.run(free_energy=True)
-    return (time.perf_counter() - t0) / n * 1e3
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return sorted(ts)[len(ts) // 2]
 
 
 for d, C, T in ((8, 1024, 1000), (16, 512, 1000), (32, 256, 500), (64, 256, 200), (64, 1, 2000)):
