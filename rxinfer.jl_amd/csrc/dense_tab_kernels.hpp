@@ -51,8 +51,12 @@ struct TabWs {
 // all of it (512 registers and kilobytes of scratch per lane in the first version — scratch that size also makes the runtime
 // re-provision the queue's scratch space).  One call per product costs nothing next to the product.
 template <int NT, bool TA, bool TB>
-__device__ __attribute__((noinline)) void tab_mm(double* dst, const double* a, const double* b, double alpha, const double* c, double beta, int w, int lane) {
+__device__ __attribute__((noinline)) void tab_mm(double* dst0, const double* a0, const double* b0, double alpha, const double* c0, double beta, int w, int lane) {
     constexpr int D = 16 * NT;
+    // every operand lives in the global workspace: say so (behind a non-inlined call the pointers are of unknown origin, and flat loads
+    // count on the LDS counter as well)
+    double* dst = as_global(dst0);
+    const double *a = as_global(a0), *b = as_global(b0), *c = c0 ? as_global(c0) : nullptr;
     Acc<NT> acc;
     acc_zero<NT>(acc);
     mm_acc<NT, TA, TB>(acc, a, D, b, D, w, lane);
@@ -82,8 +86,10 @@ __device__ __attribute__((noinline)) bool tab_inv(double* dst, const double* a, 
     return ok;
 }
 template <int NT>
-__device__ __attribute__((noinline)) void tab_lin(double* dst, double alpha, const double* a, double beta, const double* b, bool tb, int tid) {
+__device__ __attribute__((noinline)) void tab_lin(double* dst0, double alpha, const double* a0, double beta, const double* b0, bool tb, int tid) {
     constexpr int D = 16 * NT, MM = D * D, NTH = 64 * NT;
+    double* dst = as_global(dst0);
+    const double *a = a0 ? as_global(a0) : nullptr, *b = b0 ? as_global(b0) : nullptr;
     double v[MM / NTH];
 #pragma unroll
     for (int u = 0; u < MM / NTH; ++u) {
