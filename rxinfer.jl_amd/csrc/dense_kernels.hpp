@@ -1673,7 +1673,8 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     acc_store<NT>(lam, S1, LD, w, lane);
     if (tid < D) u[tid] = p.fstart_m[(chain * p.S + seg) * D + tid];
     lds_barrier();
-    matvec_lds(xi, S1, LD, D, D, u, nullptr, 0.0, tid);
+    if (p.mseg == 2) { if (tid < D) xi[tid] = u[tid]; }   // masked sweeps hand over ξ_f(b_s) itself (dense_mseg_kernels.hpp)
+    else matvec_lds(xi, S1, LD, D, D, u, nullptr, 0.0, tid);
     acc_add_mat<NT>(lam, cst + c.oW, D, w, lane, 1.0);  // lam carries M_t = Λ_f(t−1) + A'P⁻¹A from here on
     if (PREPUB) {  // equilibration exponents of the first inverse (later ones: where M is stored)
 #pragma unroll

@@ -35,11 +35,11 @@ struct MsegParams {
     double* ws;             // [chain·S + seg][MSEG_WS] d×d scratch matrices of km_elements; km_scan uses the first 2·chains blocks
     double* obs;            // [chain][T]
     double* nobs;           // [chain]
-    double* mel;            // [chain][S][6][d][d]   Π, C, J, C⁻¹, C⁻¹Π, J + Π'C⁻¹Π
-    double* mvec;           // [chain][S][2][d]      b, η
+    double* mel;            // [chain][S][3][d][d]   Λ, Ψ, Ĵ of the segment (information form, km_elements)
+    double* mvec;           // [chain][S][2][d]      ξ, η̂
     double* mbnd;           // [chain][S][2][d][d]   Λ_f(b_s) | V_s(b_{s+1})
     double* mlb;            // [chain][S][d][d]      Λβ(b_{s+1})
-    double* fstart_m;       // [chain][S][d]
+    double* fstart_m;       // [chain][S][d]         ξ_f(b_s) (the information vector: DenseParams::mseg = 2)
     double* beta_xi;        // [chain][S+1][d]
     double* filt;           // records [chain][T][REC]: slot 1 of the header receives B'Q⁻¹y_t
     int rec;                // REC
@@ -89,77 +89,71 @@ __device__ __forceinline__ double tab_col_dot(const double* M, int i, const doub
     return s0 + s1;
 }
 
+// The element of a segment in INFORMATION form.  Given the state x_b at the segment start, the segment's transitions and observations
+// define a joint Gaussian over (x_b, x_e) with precision [[Ĵ, −Ψ′], [−Ψ, Λ]] and information vector [η̂, ξ] — in the notation of Särkkä &
+// García-Fernández (2021): Λ = C⁻¹, Ψ = C⁻¹Π, Ĵ = J + Π′C⁻¹Π, ξ = C⁻¹b, η̂ = η − Π′C⁻¹b.  Moving the end of the segment one step on is
+// adding the transition factor and eliminating x_t (a Schur complement), then adding the observation's information:
+//     C_t = (Λ + A′P⁻¹A)⁻¹,  Λp = P⁻¹ − K C_t K′ (K = P⁻¹A),  Y = C_t Ψ,  Ψ ← K Y,  Ĵ ← Ĵ − Ψ′Y,  c = C_t ξ,  η̂ ← η̂ + Ψ′c,  ξ ← K c + B′Q⁻¹y,
+//     Λ ← Λp + B′Q⁻¹B   (observed steps only)
+// — the forward step of kd_forward_info plus three products, ONE inverse and five products per step where the covariance form (the
+// first version of this file) needed an inverse and eleven; and the boundary recursions below need exactly (Λ, Ψ, Ĵ, ξ, η̂), nothing else.
+// Out of the known start through the first transition: Λp = P⁻¹, Ψ = K, Ĵ = A′P⁻¹A, ξ = η̂ = 0.
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) km_elements(MsegParams p) {
     constexpr int D = 16 * NT, MM = D * D;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
-    double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;   // m | am | e | eta | yv
-    double *m = vec, *am = vec + D, *ev = vec + 2 * D, *eta = vec + 3 * D, *yv = vec + 4 * D;
+    double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;   // ξ | c | η̂ | y
+    double *xi = vec, *cv = vec + D, *eta = vec + 2 * D, *yv = vec + 3 * D;
     const int tid = o.tid, dyu = p.dy_user;
     const long long seg = blockIdx.x, chain = blockIdx.y;
-    const double *A = p.in, *P = p.in + MM, *B = p.in + 3 * MM, *Q = p.in + 4 * MM;
     auto CW = [&](int slot) { return p.cw + (size_t)slot * MM; };
-    const double *HF = CW(TabWs::HF), *G = CW(TabWs::G);
+    const double *PI = CW(TabWs::PINV), *KC = CW(TabWs::KC), *WC = CW(TabWs::WC), *LO = CW(TabWs::LOBS), *G = CW(TabWs::G);
     double* W = p.ws + ((size_t)chain * p.S + seg) * MSEG_WS * MM;
-    double *V = W, *Pi = W + MM, *J = W + 2 * MM, *Vp = W + 3 * MM, *Si = W + 4 * MM, *K = W + 5 * MM, *U = W + 6 * MM,
-           *HFPi = W + 7 * MM, *T1 = W + 8 * MM, *T2 = W + 9 * MM, *Phi = W + 10 * MM, *T3 = W + 11 * MM;
+    double *Mx = W, *Cx = W + MM, *Gt = W + 2 * MM, *Lp = W + 3 * MM, *Y = W + 4 * MM, *LW = W + 5 * MM;
+    double* g = p.mel + ((size_t)chain * p.S + seg) * 3 * MM;   // Λ | Ψ | Ĵ of this segment (Ψ and Ĵ are updated in place)
+    double *Psi = g + MM, *Jh = g + 2 * MM;
     const long long t0 = seg * p.L;   // boundary b_s: state index of the known start
     long long t1 = t0 + p.L;
     if (t1 > p.T - 1) t1 = p.T - 1;
     bool ok = true;
-    o.eye(V, 0.0);
-    o.eye(J, 0.0);
-    o.eye(Pi, 1.0);
-    if (tid < D) { m[tid] = 0.0; eta[tid] = 0.0; }
-    o.sync();
+    o.lin(LW, 1.0, LO, 1.0, WC);      // B′Q⁻¹B + A′P⁻¹A: what an observed step adds to Λp on the way to the next M
     for (long long t = t0 + 1; t <= t1; ++t) {
         const bool ob = p.obs[chain * p.T + t] != 0.0;   // uniform
         double* rec = p.filt + (chain * p.T + t) * p.rec;
-        o.template mm<false, false>(T1, A, V);
-        o.template mm<false, true>(Vp, T1, A, 1.0, P, 1.0);              // V_p = A V A' + P
-        if (tid < D) am[tid] = tab_row_dot<D>(A, tid, m);               // A m
-        if (ob) {
-            if (tid < D) yv[tid] = tid < dyu ? p.y[(t * p.n_chains + chain) * dyu + tid] : 0.0;
-            o.template mm<false, false>(T1, B, Vp);                      // B V_p  (also a barrier: am, yv are visible)
-            o.template mm<false, true>(T2, T1, B, 1.0, Q, 1.0);          // S = B V_p B' + Q
-            ok = o.inv(Si, T2, nullptr) && ok;
-            o.template mm<true, false>(K, T1, Si);                       // K = V_p B' S⁻¹
-            o.template mm<false, false>(HFPi, HF, Pi);                   // (BA) Π
-            o.template mm<true, false>(U, HFPi, Si);                     // U = ((BA)Π)' S⁻¹
-            o.template mm<false, false>(J, U, HFPi, 1.0, J, 1.0);        // J += U (BA)Π
-            o.template mm<false, false>(T2, K, T1, -1.0, Vp, 1.0);       // V_p − K B V_p
-            o.sym(V, T2);
-            o.template mm<false, false>(Phi, K, HF, -1.0, A, 1.0);       // Φ = A − K (BA)
+        if (tid < D) yv[tid] = (ob && tid < dyu) ? p.y[(t * p.n_chains + chain) * dyu + tid] : 0.0;
+        if (t == t0 + 1) {
+            o.lin(Mx, 1.0, PI, 1.0, ob ? LW : WC);        // M = Λ(t0 + 1) + A′P⁻¹A   (its barriers make yv visible)
+            o.lin(Psi, 1.0, KC);
+            o.lin(Jh, 1.0, WC);
             if (tid < D) {
-                ev[tid] = yv[tid] - tab_row_dot<D>(B, tid, am);          // e = y − B A m   (rows ≥ dy: 0 − 0)
-                rec[D + tid] = tab_row_dot<D>(G, tid, yv);               // B'Q⁻¹y_t for the sweep kernel
+                const double gy = ob ? tab_row_dot<D>(G, tid, yv) : 0.0;
+                xi[tid] = gy;
+                eta[tid] = 0.0;
+                rec[D + tid] = gy;                        // B′Q⁻¹y_t for the sweep kernel
             }
             o.sync();
-            if (tid < D) {
-                eta[tid] += tab_row_dot<D>(U, tid, ev);
-                m[tid] = am[tid] + tab_row_dot<D>(K, tid, ev);
-            }
-            o.template mm<false, false>(T3, Phi, Pi);
-        } else {
-            o.lin(V, 1.0, Vp);                                           // no message from the observation node: filtered = predicted
-            if (tid < D) { m[tid] = am[tid]; rec[D + tid] = 0.0; }
-            o.template mm<false, false>(T3, A, Pi);                      // Φ = A
+            continue;
         }
-        o.lin(Pi, 1.0, T3);
+        ok = o.inv(Cx, Mx, nullptr) && ok;                        // C = (Λ + A′P⁻¹A)⁻¹
+        o.template mm<false, false>(Gt, KC, Cx);                  // K C
+        if (tid < D) cv[tid] = tab_col_dot<D>(Cx, tid, xi);       // c = C ξ   (C is symmetric: coalesced columns)
+        o.template mm<false, false>(Y, Cx, Psi);                  // Y = C Ψ   (its barrier: c is visible)
+        if (tid < D) {
+            const double gy = ob ? tab_row_dot<D>(G, tid, yv) : 0.0;
+            eta[tid] += tab_col_dot<D>(Psi, tid, cv);             // η̂ += Ψ′c   (Ψ of the previous step)
+            xi[tid] = tab_row_dot<D>(KC, tid, cv) + gy;           // ξ = K c + B′Q⁻¹y   (every reader of the old ξ is behind a barrier)
+            rec[D + tid] = gy;
+        }
+        o.template mm<true, false>(Jh, Psi, Y, -1.0, Jh, 1.0);    // Ĵ −= Ψ′Y
+        o.template mm<false, false>(Psi, KC, Y);                  // Ψ = K Y
+        o.template mm<false, true>(Lp, Gt, KC, -1.0, PI, 1.0);    // Λp = P⁻¹ − K C K′
+        o.symadd(Mx, 1.0, Lp, 1.0, ob ? LW : WC);                 // next M = sym(Λp) [+ B′Q⁻¹B] + A′P⁻¹A
     }
-    double* g = p.mel + ((size_t)chain * p.S + seg) * 6 * MM;   // Π, C, J, C⁻¹, X = C⁻¹Π, JJ = J + Π'X
-    o.lin(g, 1.0, Pi);
-    o.lin(g + MM, 1.0, V);
-    o.sym(g + 2 * MM, J);
-    if (t1 > t0) {
-        ok = o.inv(g + 3 * MM, V, nullptr) && ok;
-        o.template mm<false, false>(g + 4 * MM, g + 3 * MM, Pi);
-        o.template mm<true, false>(g + 5 * MM, Pi, g + 4 * MM, 1.0, g + 2 * MM, 1.0);
-    }
+    o.lin(g, 1.0, Mx, -1.0, WC);                                  // Λ at the segment end
     if (tid < D) {
         double* v = p.mvec + ((size_t)chain * p.S + seg) * 2 * D;
-        v[tid] = m[tid];
+        v[tid] = xi[tid];
         v[D + tid] = eta[tid];
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
@@ -181,19 +175,23 @@ __global__ void __launch_bounds__(256) km_gy(MsegParams p) {
     p.filt[(chain * p.T + t) * p.rec + D + i] = s;
 }
 
-// boundary recursion over the segments of one chain: blockIdx.x = 0 prefix, 1 suffix
+// boundary recursion over the segments of one chain: blockIdx.x = 0 prefix, 1 suffix.  Both are the same elimination on the joint of
+// km_elements with the carried information added to one corner:
+//   prefix (filtered belief (Λ_f, ξ_f) at the segment start -> at its end):  T = Λ_f + Ĵ,  Λ_f′ = Λ − Ψ T⁻¹Ψ′,  ξ_f′ = ξ + Ψ T⁻¹(ξ_f + η̂)
+//   suffix (backward message (Λβ, ξβ) at the segment end -> at its start):    T = Λ + Λβ,   Λβ′ = Ĵ − Ψ′T⁻¹Ψ,  ξβ′ = η̂ + Ψ′T⁻¹(ξ + ξβ)
+// — one SPD inverse and two products per segment and direction.
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p) {
     constexpr int D = 16 * NT, MM = D * D;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
     double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
-    double *m = vec, *u = vec + D, *xi = vec + 2 * D, *tv = vec + 3 * D;
+    double *xi = vec, *u = vec + D, *tv = vec + 2 * D;
     const int tid = o.tid, dir = blockIdx.x, S = p.S, dyu = p.dy_user;
     const long long chain = blockIdx.y;
     auto CW = [&](int slot) { return p.cw + (size_t)slot * MM; };
     double* W = p.ws + ((size_t)chain * 2 + dir) * MSEG_WS * MM;   // km_elements is done with the workspace: reuse it
-    double *cur = W, *tt = W + 2 * MM, *Wm = W + 3 * MM, *M1 = W + 4 * MM, *M2 = W + 5 * MM, *nxt = W + 6 * MM;
+    double *cur = W, *tt = W + MM, *Wm = W + 2 * MM, *N1 = W + 3 * MM, *T2 = W + 4 * MM;
     bool ok = true;
     if (dir == 0) {
         // belief at t = 0: prior ⊗ observation message (if y_0 is observed)
@@ -203,35 +201,25 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p) {
             double mm1 = m1v[tid];
             if (p.ptt) mm1 = tab_row_dot<D>(p.in, tid, m1v);           // A m0
             u[tid] = mm1;
-            tv[tid] = tid < dyu ? (ob0 ? p.y[(0 * p.n_chains + chain) * dyu + tid] : 0.0) : 0.0;
+            tv[tid] = (ob0 && tid < dyu) ? p.y[(0 * p.n_chains + chain) * dyu + tid] : 0.0;
         }
-        o.sync();
-        if (ob0) {
-            o.lin(cur, 1.0, CW(TabWs::VF1));
-            if (tid < D) xi[tid] = tab_row_dot<D>(CW(TabWs::V1I), tid, u) + tab_row_dot<D>(CW(TabWs::G), tid, tv);   // V1⁻¹m1 + G y
-            o.sync();
-            if (tid < D) m[tid] = tab_row_dot<D>(CW(TabWs::VF1), tid, xi);
-        } else {
-            o.lin(cur, 1.0, CW(TabWs::V1));
-            if (tid < D) m[tid] = u[tid];
-        }
+        o.lin(cur, 1.0, CW(TabWs::V1I), ob0 ? 1.0 : 0.0, CW(TabWs::LOBS));   // Λ_f(0) = V1⁻¹ [+ B′Q⁻¹B]   (barriers: u, tv visible)
+        if (tid < D) xi[tid] = tab_col_dot<D>(CW(TabWs::V1I), tid, u) + (ob0 ? tab_row_dot<D>(CW(TabWs::G), tid, tv) : 0.0);   // V1⁻¹m1 [+ B′Q⁻¹y]
         o.sync();
         for (int s = 0; s < S; ++s) {
-            if (tid < D) p.fstart_m[((size_t)chain * S + s) * D + tid] = m[tid];
-            double* bn = p.mbnd + ((size_t)chain * S + s) * 2 * MM;
-            ok = o.inv(bn, cur, nullptr) && ok;                           // Λ_f(b_s) = V(b_s)⁻¹
+            if (tid < D) p.fstart_m[((size_t)chain * S + s) * D + tid] = xi[tid];     // ξ_f(b_s)  (DenseParams::mseg = 2: the information vector)
+            o.lin(p.mbnd + ((size_t)chain * S + s) * 2 * MM, 1.0, cur);               // Λ_f(b_s)
             if (s == S - 1) break;
-            const double* g = p.mel + ((size_t)chain * S + s) * 6 * MM;
+            const double* g = p.mel + ((size_t)chain * S + s) * 3 * MM;
             const double* gv = p.mvec + ((size_t)chain * S + s) * 2 * D;
-            o.lin(tt, 1.0, bn, 1.0, g + 2 * MM);                          // V⁻¹ + J
+            o.symadd(tt, 1.0, cur, 1.0, g + 2 * MM);                      // T = Λ_f + Ĵ
             ok = o.inv(Wm, tt, nullptr) && ok;
-            o.template mm<false, false>(M2, g, Wm);                       // M2 = Π W
-            if (tid < D) u[tid] = tab_row_dot<D>(bn, tid, m) + gv[D + tid];   // V⁻¹m + η
-            o.template mm<false, true>(tt, M2, g);                        // M2 Π'   (barrier: u visible)
-            if (tid < D) tv[tid] = tab_row_dot<D>(M2, tid, u) + gv[tid];  // m' = M2 (V⁻¹m + η) + b
-            o.lin(nxt, 0.5, tt, 0.5, tt, true);
-            o.lin(cur, 1.0, nxt, 1.0, g + MM);                            // V' = sym(M2 Π') + C
-            if (tid < D) m[tid] = tv[tid];
+            o.template mm<false, false>(N1, g + MM, Wm);                  // N1 = Ψ T⁻¹
+            if (tid < D) u[tid] = xi[tid] + gv[D + tid];                  // ξ_f + η̂
+            o.template mm<false, true>(T2, N1, g + MM);                   // N1 Ψ′   (its barrier: u is visible)
+            if (tid < D) tv[tid] = gv[tid] + tab_row_dot<D>(N1, tid, u);  // ξ_f′ = ξ + N1 (ξ_f + η̂)
+            o.symadd(cur, -1.0, T2, 1.0, g);                              // Λ_f′ = Λ − sym(N1 Ψ′)
+            if (tid < D) xi[tid] = tv[tid];
             o.sync();
         }
     } else {
@@ -243,16 +231,15 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p) {
             o.lin(p.mlb + ((size_t)chain * S + s) * MM, 1.0, cur);
             if (tid < D) p.beta_xi[((size_t)chain * (S + 1) + s + 1) * D + tid] = xi[tid];
             if (s == 0) break;
-            const double* g = p.mel + ((size_t)chain * S + s) * 6 * MM;   // C⁻¹ = g+3MM, X = g+4MM, JJ = g+5MM
+            const double* g = p.mel + ((size_t)chain * S + s) * 3 * MM;
             const double* gv = p.mvec + ((size_t)chain * S + s) * 2 * D;
-            o.lin(tt, 1.0, g + 3 * MM, 1.0, cur);
-            ok = o.inv(Wm, tt, nullptr) && ok;                            // (C⁻¹ + Λβ)⁻¹
-            o.template mm<true, false>(M1, g + 4 * MM, Wm);               // N1 = X'W
-            o.template mm<false, false>(M2, M1, cur);                     // N2 = N1 Λβ
-            o.template mm<false, false>(tt, M1, g + 4 * MM);              // N1 X
-            if (tid < D) tv[tid] = gv[D + tid] - tab_row_dot<D>(M2, tid, gv) + tab_row_dot<D>(M1, tid, xi);   // η − N2 b + N1 ξβ
-            o.lin(nxt, -0.5, tt, -0.5, tt, true);
-            o.lin(cur, 1.0, nxt, 1.0, g + 5 * MM);                        // JJ − sym(N1 X)
+            o.symadd(tt, 1.0, cur, 1.0, g);                               // T = Λβ + Λ
+            ok = o.inv(Wm, tt, nullptr) && ok;
+            o.template mm<true, false>(N1, g + MM, Wm);                   // N1 = Ψ′T⁻¹
+            if (tid < D) u[tid] = gv[tid] + xi[tid];                      // ξ + ξβ
+            o.template mm<false, false>(T2, N1, g + MM);                  // N1 Ψ   (its barrier: u is visible)
+            if (tid < D) tv[tid] = gv[D + tid] + tab_row_dot<D>(N1, tid, u);   // ξβ′ = η̂ + N1 (ξ + ξβ)
+            o.symadd(cur, -1.0, T2, 1.0, g + 2 * MM);                     // Λβ′ = Ĵ − sym(N1 Ψ)
             if (tid < D) xi[tid] = tv[tid];
             o.sync();
         }

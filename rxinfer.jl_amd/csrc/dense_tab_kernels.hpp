@@ -57,17 +57,49 @@ __device__ __attribute__((noinline)) void tab_mm(double* dst0, const double* a0,
     // count on the LDS counter as well)
     double* dst = as_global(dst0);
     const double *a = as_global(a0), *b = as_global(b0), *c = c0 ? as_global(c0) : nullptr;
-    Acc<NT> acc;
-    acc_zero<NT>(acc);
-    mm_acc<NT, TA, TB>(acc, a, D, b, D, w, lane);
+    // Every operand fragment is loaded BEFORE the first product (the generic mm_acc interleaves them and keeps ≈8 loads in flight:
+    // ten L2 round trips per product), and the contraction index is permuted so that an operand read along k is one 16-byte load for
+    // two k-steps (steps 2m, 2m + 1 of lane quarter kq ↔ k = 8m + 2kq, 8m + 2kq + 1 — both operands use the same map, so the sum is the same).
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    constexpr int KS = D / 4;
+    const int il = lane & 15, kq = lane >> 4, i = 16 * w + il;
+    double av[KS], bv[NT][KS];
+#pragma unroll
+    for (int m = 0; m < KS / 2; ++m) {
+        const int k = 8 * m + 2 * kq;
+        if (TA) { av[2 * m] = a[k * D + i]; av[2 * m + 1] = a[(k + 1) * D + i]; }
+        else { const v2d v = *reinterpret_cast<const v2d*>(a + i * D + k); av[2 * m] = v.x; av[2 * m + 1] = v.y; }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = 16 * t + il;
+            if (TB) { const v2d v = *reinterpret_cast<const v2d*>(b + j * D + k); bv[t][2 * m] = v.x; bv[t][2 * m + 1] = v.y; }
+            else { bv[t][2 * m] = b[k * D + j]; bv[t][2 * m + 1] = b[(k + 1) * D + j]; }
+        }
+    }
+    double cv[NT][4];
+    if (c) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[t][r] = c[acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, t)];
+    }
+#pragma unroll
+    for (int s = 0; s < KS; ++s) asm volatile("" : "+v"(av[s]));   // all of the above is in flight before anything is consumed
+    d4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s = 0; s < KS; ++s)
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s], bv[t][s], acc[t], 0, 0, 0);
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
-            double v = alpha * acc.v[t][r];
-            if (c) v += beta * c[i * D + j];
-            dst[i * D + j] = v;
+            const int ii = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
+            double v = alpha * acc[t][r];
+            if (c) v += beta * cv[t][r];
+            dst[ii * D + j] = v;
         }
     __syncthreads();
 }
@@ -104,6 +136,24 @@ __device__ __attribute__((noinline)) void tab_lin(double* dst0, double alpha, co
     __syncthreads();
 }
 
+// dst = alpha·½(a + a') + gamma·c   (dst may alias a or c)
+template <int NT>
+__device__ __attribute__((noinline)) void tab_symadd(double* dst0, double alpha, const double* a0, double gamma, const double* c0, int tid) {
+    constexpr int D = 16 * NT, MM = D * D, NTH = 64 * NT;
+    double* dst = as_global(dst0);
+    const double *a = as_global(a0), *c = as_global(c0);
+    double v[MM / NTH];
+#pragma unroll
+    for (int u = 0; u < MM / NTH; ++u) {
+        const int k = tid + u * NTH, i = k / D, j = k - i * D;
+        v[u] = alpha * 0.5 * (a[k] + a[j * D + i]) + gamma * c[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < MM / NTH; ++u) dst[tid + u * NTH] = v[u];
+    __syncthreads();
+}
+
 template <int NT>
 struct TabOps {
     static constexpr int D = 16 * NT, MM = D * D, NTH = 64 * NT;
@@ -120,6 +170,9 @@ struct TabOps {
         tab_lin<NT>(dst, alpha, a, beta, b, tb, tid);
     }
     __device__ __forceinline__ void sym(double* dst, const double* a) const { lin(dst, 0.5, a, 0.5, a, true); }
+    __device__ __forceinline__ void symadd(double* dst, double alpha, const double* a, double gamma, const double* c) const {
+        tab_symadd<NT>(dst, alpha, a, gamma, c, tid);
+    }
     __device__ __forceinline__ void eye(double* dst, double diag) const {
         for (int k = tid; k < MM; k += NTH) dst[k] = (k / D == k % D) ? diag : 0.0;
         sync();

@@ -1233,9 +1233,9 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     long long S = (long long)std::ceil(std::sqrt(2.0 * (double)(T - 1)));
     while (S > 1 && (double)C * (double)S * (MSEG_WS + 9) * MM * 8.0 > 6e9) S = (S + 1) / 2;
     {   // ... unless the chains fill the machine on their own: then ONE segment per chain — the sweep kernels run the whole chain, no
-        // element pass (which costs 6× a sweep step) and no boundary recursion.  Cost model in µs per step / segment and workgroups the
-        // chip holds at once, from profiles/r03/dense_missing_parallel_kernels.txt (d = 64: 106 / 65 / 17, 512; d ≤ 16: 28 / 24 / 5.7, 2048).
-        const double f = (double)(e->nt - 1) / 3.0, c_e = 28.0 + f * 78.0, c_s = 24.0 + f * 41.0, c_f = 5.7 + f * 11.3, conc = e->nt == 1 ? 2048.0 : e->nt == 2 ? 1024.0 : 512.0;
+        // element pass (which costs three sweep steps per time step) and no boundary recursion.  Cost model in µs per step / segment and workgroups the
+        // chip holds at once, from profiles/r03/dense_missing_parallel_kernels.txt (d = 64: 54 / 37 / 17, 512; d ≤ 16: ≈15 / 14 / 5.7, 2048).
+        const double f = (double)(e->nt - 1) / 3.0, c_e = 15.0 + f * 39.0, c_s = 14.0 + f * 23.0, c_f = 5.7 + f * 11.3, conc = e->nt == 1 ? 2048.0 : e->nt == 2 ? 1024.0 : 512.0;
         auto cost = [&](long long s) {
             const double steps = std::ceil((double)(T - 1) / (double)s), rounds = std::ceil((double)C * (double)s / conc);
             return rounds * steps * ((s > 1 ? c_e : 0.0) + c_f) + (s > 1 ? (double)s * c_s * std::ceil(2.0 * (double)C / conc) : 0.0);
@@ -1251,7 +1251,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     const DenseCst cl = DenseCst::make((int)D, e->dy);
     const int rec = dense_rec(e->nt), tri = dense_tri(e->nt);
     const size_t nws = std::max<size_t>((size_t)C * (size_t)S, (size_t)2 * C) * MSEG_WS * MM;
-    const size_t parts[] = {5 * MM + D, TabWs::doubles((int)D, 1), (size_t)cl.size, C * T, C, C * S * 6 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
+    const size_t parts[] = {5 * MM + D, TabWs::doubles((int)D, 1), (size_t)cl.size, C * T, C, C * S * 3 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
                             C * T * (size_t)rec, C * S * (size_t)tri, C * S * D, C * (S + 1) * D,
                             (2 * (size_t)S + 2 + (size_t)fe_resid_blocks(e->T, e->dpad, e->dy)) * C};
     size_t off[16] = {0};
@@ -1316,7 +1316,8 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
     dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->mS; dp.L = e->mL; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy; dp.pack = 1; dp.d_sub = 8; dp.dy_sub = e->dy;
     dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->m_cst;
     dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi; dp.fe_part = e->m_fe_part; dp.status = e->d_status;
-    dp.mseg = 1; dp.obs = e->m_obs; dp.nobs = e->m_nobs; dp.mbnd = e->m_bnd;
+    dp.mseg = 2;   // 2: the boundary vector of a segment is the information vector ξ_f(b_s), not the mean
+    dp.obs = e->m_obs; dp.nobs = e->m_nobs; dp.mbnd = e->m_bnd;
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
     switch (e->nt) {
