@@ -1,0 +1,104 @@
+"""The algebra of csrc/dense_mseg_kernels.hpp, restated in numpy and checked on the CPU against the oracle's smoother.
+
+A segment (x_b -> x_e, with its transitions and its observed / missing observations) is carried as the joint information of (x_b, x_e):
+precision [[Ĵ, −Ψ′], [−Ψ, Λ]], vector [η̂, ξ].  One more time step = add the transition factor, eliminate the old end state, add the new
+observation's information (km_elements); the filtered belief travels across a segment by adding it to the x_b corner and eliminating x_b,
+the backward message by adding it to the x_e corner and eliminating x_e (km_scan).  The test builds the elements of a ragged segmentation
+of a chain with missing observations, runs both boundary recursions, and compares
+  * the filtered belief at every boundary with a plain Kalman filter,
+  * (Λ_f + Λβ)⁻¹ and its mean at every boundary with the oracle's smoothed posterior."""
+import numpy as np
+import pytest
+
+
+def _model(d, dy, seed):
+    rng = np.random.default_rng(seed)
+    Qm, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    A = 0.95 * Qm
+    B = rng.standard_normal((dy, d)) / np.sqrt(d)
+    Wp = rng.standard_normal((d, d)) * 0.3
+    P = Wp @ Wp.T + 0.1 * np.eye(d)
+    Wq = rng.standard_normal((dy, dy)) * 0.5
+    Q = Wq @ Wq.T + 0.5 * np.eye(dy)
+    Wv = rng.standard_normal((d, d))
+    return A, B, P, Q, rng.standard_normal(d), Wv @ Wv.T + np.eye(d)
+
+
+def _element(A, B, P, Q, ys):
+    """joint information of (x_b, x_e) for the steps whose observations are `ys` (NaN row = missing): km_elements"""
+    Pi, Qi = np.linalg.inv(P), np.linalg.inv(Q)
+    K, W, Lobs, G = Pi @ A, A.T @ Pi @ A, B.T @ Qi @ B, B.T @ Qi
+    lam = psi = jh = xi = eta = None
+    for y in ys:
+        ob = not np.any(np.isnan(y))
+        if lam is None:                       # out of the known start through the first transition
+            lam_p, psi, jh, xi_p, eta = Pi.copy(), K.copy(), W.copy(), np.zeros(len(A)), np.zeros(len(A))
+        else:
+            C = np.linalg.inv(lam + W)
+            Y, c = C @ psi, C @ xi
+            lam_p = Pi - K @ C @ K.T
+            jh = jh - psi.T @ Y
+            eta = eta + psi.T @ c
+            psi = K @ Y
+            xi_p = K @ c
+        lam = lam_p + (Lobs if ob else 0.0)
+        xi = xi_p + (G @ y if ob else 0.0)
+    return lam, psi, jh, xi, eta
+
+
+@pytest.mark.parametrize("d,dy,T,L,seed", [(3, 2, 41, 7, 1), (6, 6, 30, 4, 2), (5, 1, 26, 25, 3), (4, 3, 12, 1, 4)])
+def test_information_form_elements_and_boundary_recursions(d, dy, T, L, seed):
+    import rxoracle as rxo
+    A, B, P, Q, m0, V0 = _model(d, dy, seed)
+    rng = np.random.default_rng(seed + 10)
+    x = rng.multivariate_normal(m0, V0)
+    y = np.empty((T, dy))
+    for t in range(T):
+        if t:
+            x = A @ x + rng.multivariate_normal(np.zeros(d), P)
+        y[t] = B @ x + rng.multivariate_normal(np.zeros(dy), Q)
+    y[rng.random(T) < 0.25] = np.nan
+    y[0] = np.nan                                        # first observation missing
+    if T > 20:
+        y[8:16] = np.nan                                 # a whole segment (and more) without observations
+    om, oc, _ = rxo.lgssm_kalman_rts(A, B, P, Q, m0, V0, np.ascontiguousarray(y))
+    # plain Kalman filter (covariance form) for the filtered beliefs
+    Qi = np.linalg.inv(Q)
+    mf, Vf = [], []
+    m, V = m0, V0
+    for t in range(T):
+        if t:
+            m, V = A @ m, A @ V @ A.T + P
+        if not np.any(np.isnan(y[t])):
+            S = B @ V @ B.T + Q
+            Kg = V @ B.T @ np.linalg.inv(S)
+            m, V = m + Kg @ (y[t] - B @ m), V - Kg @ B @ V
+        mf.append(m); Vf.append(V)
+    # segments: boundaries b_s = s·L, segment s covers the steps b_s + 1 … min(b_s + L, T − 1)
+    bnd = list(range(0, T - 1, L)) + [T - 1]
+    els = [_element(A, B, P, Q, y[bnd[s] + 1: bnd[s + 1] + 1]) for s in range(len(bnd) - 1)]
+    # prefix: filtered belief at every boundary
+    ob0 = not np.any(np.isnan(y[0]))
+    lam_f = np.linalg.inv(V0) + (B.T @ Qi @ B if ob0 else 0.0)
+    xi_f = np.linalg.inv(V0) @ m0 + (B.T @ Qi @ y[0] if ob0 else 0.0)
+    pre = [(lam_f, xi_f)]
+    for lam, psi, jh, xi, eta in els:
+        Ti = np.linalg.inv(lam_f + jh)
+        lam_f, xi_f = lam - psi @ Ti @ psi.T, xi + psi @ Ti @ (xi_f + eta)
+        pre.append((lam_f, xi_f))
+    for s, (lf, xf) in enumerate(pre):
+        V = np.linalg.inv(lf)
+        assert np.allclose(V, Vf[bnd[s]], rtol=1e-9, atol=1e-11), s
+        assert np.allclose(V @ xf, mf[bnd[s]], rtol=1e-9, atol=1e-11), s
+    # suffix: backward message at every boundary, then the smoothed belief there
+    lam_b, xi_b = np.zeros((d, d)), np.zeros(d)
+    suf = [(lam_b, xi_b)]
+    for lam, psi, jh, xi, eta in reversed(els):
+        Ti = np.linalg.inv(lam + lam_b)
+        lam_b, xi_b = jh - psi.T @ Ti @ psi, eta + psi.T @ Ti @ (xi + xi_b)
+        suf.append((lam_b, xi_b))
+    suf.reverse()
+    for s in range(len(bnd)):
+        Vs = np.linalg.inv(pre[s][0] + suf[s][0])
+        assert np.allclose(Vs, oc[bnd[s]], rtol=1e-8, atol=1e-10), s
+        assert np.allclose(Vs @ (pre[s][1] + suf[s][1]), om[bnd[s]], rtol=1e-8, atol=1e-10), s
