@@ -110,21 +110,22 @@ __global__ void __launch_bounds__(64 * NT) km_elements(MsegParams p) {
     auto CW = [&](int slot) { return p.cw + (size_t)slot * MM; };
     const double *PI = CW(TabWs::PINV), *KC = CW(TabWs::KC), *WC = CW(TabWs::WC), *LO = CW(TabWs::LOBS), *G = CW(TabWs::G);
     double* W = p.ws + ((size_t)chain * p.S + seg) * MSEG_WS * MM;
-    double *Mx = W, *Cx = W + MM, *Gt = W + 2 * MM, *Lp = W + 3 * MM, *Y = W + 4 * MM, *LW = W + 5 * MM;
-    double* g = p.mel + ((size_t)chain * p.S + seg) * 3 * MM;   // Λ | Ψ | Ĵ of this segment (Ψ and Ĵ are updated in place)
-    double *Psi = g + MM, *Jh = g + 2 * MM;
+    double *Cx = W, *Gt = W + MM, *Lp = W + 2 * MM, *Y = W + 3 * MM, *LW = W + 4 * MM, *Ps2 = W + 5 * MM;
+    double* g = p.mel + ((size_t)chain * p.S + seg) * 3 * MM;   // Λ | Ψ | Ĵ of this segment
+    double *Pc = g + MM, *Pn = Ps2, *Jh = g + 2 * MM;           // Ψ alternates between its slot and a scratch matrix (no product overwrites an operand)
     const long long t0 = seg * p.L;   // boundary b_s: state index of the known start
     long long t1 = t0 + p.L;
     if (t1 > p.T - 1) t1 = p.T - 1;
-    bool ok = true;
+    bool ok = true, ob = true;
     o.lin(LW, 1.0, LO, 1.0, WC);      // B′Q⁻¹B + A′P⁻¹A: what an observed step adds to Λp on the way to the next M
+    // the next M = sym(Msrc) + Madd is formed inside the inverse that consumes it (inv_symadd)
+    const double *Msrc = PI, *Madd = WC;
     for (long long t = t0 + 1; t <= t1; ++t) {
-        const bool ob = p.obs[chain * p.T + t] != 0.0;   // uniform
+        ob = p.obs[chain * p.T + t] != 0.0;   // uniform
         double* rec = p.filt + (chain * p.T + t) * p.rec;
         if (tid < D) yv[tid] = (ob && tid < dyu) ? p.y[(t * p.n_chains + chain) * dyu + tid] : 0.0;
         if (t == t0 + 1) {
-            o.lin(Mx, 1.0, PI, 1.0, ob ? LW : WC);        // M = Λ(t0 + 1) + A′P⁻¹A   (its barriers make yv visible)
-            o.lin(Psi, 1.0, KC);
+            o.lin(Pc, 1.0, KC);                           // (its barriers make yv visible)
             o.lin(Jh, 1.0, WC);
             if (tid < D) {
                 const double gy = ob ? tab_row_dot<D>(G, tid, yv) : 0.0;
@@ -133,24 +134,28 @@ __global__ void __launch_bounds__(64 * NT) km_elements(MsegParams p) {
                 rec[D + tid] = gy;                        // B′Q⁻¹y_t for the sweep kernel
             }
             o.sync();
+            Madd = ob ? LW : WC;                          // M = P⁻¹ [+ B′Q⁻¹B] + A′P⁻¹A
             continue;
         }
-        ok = o.inv(Cx, Mx, nullptr) && ok;                        // C = (Λ + A′P⁻¹A)⁻¹
-        o.template mm<false, false>(Gt, KC, Cx);                  // K C
-        if (tid < D) cv[tid] = tab_col_dot<D>(Cx, tid, xi);       // c = C ξ   (C is symmetric: coalesced columns)
-        o.template mm<false, false>(Y, Cx, Psi);                  // Y = C Ψ   (its barrier: c is visible)
+        ok = o.inv_symadd(Cx, 1.0, Msrc, 1.0, Madd) && ok;            // C = (Λ + A′P⁻¹A)⁻¹
+        o.template mm<false, false, false>(Gt, KC, Cx);               // K C            (nobody reads it before the barrier of the next product)
+        if (tid < D) cv[tid] = tab_col_dot<D>(Cx, tid, xi);           // c = C ξ   (C is symmetric: coalesced columns)
+        o.template mm<false, false>(Y, Cx, Pc);                       // Y = C Ψ   (its barrier: c is visible, K C is stored)
         if (tid < D) {
             const double gy = ob ? tab_row_dot<D>(G, tid, yv) : 0.0;
-            eta[tid] += tab_col_dot<D>(Psi, tid, cv);             // η̂ += Ψ′c   (Ψ of the previous step)
-            xi[tid] = tab_row_dot<D>(KC, tid, cv) + gy;           // ξ = K c + B′Q⁻¹y   (every reader of the old ξ is behind a barrier)
+            eta[tid] += tab_col_dot<D>(Pc, tid, cv);                  // η̂ += Ψ′c
+            xi[tid] = tab_row_dot<D>(KC, tid, cv) + gy;               // ξ = K c + B′Q⁻¹y   (every reader of the old ξ is behind a barrier)
             rec[D + tid] = gy;
         }
-        o.template mm<true, false>(Jh, Psi, Y, -1.0, Jh, 1.0);    // Ĵ −= Ψ′Y
-        o.template mm<false, false>(Psi, KC, Y);                  // Ψ = K Y
-        o.template mm<false, true>(Lp, Gt, KC, -1.0, PI, 1.0);    // Λp = P⁻¹ − K C K′
-        o.symadd(Mx, 1.0, Lp, 1.0, ob ? LW : WC);                 // next M = sym(Λp) [+ B′Q⁻¹B] + A′P⁻¹A
+        o.template mm<true, false, false>(Jh, Pc, Y, -1.0, Jh, 1.0);  // Ĵ −= Ψ′Y
+        o.template mm<false, false, false>(Pn, KC, Y);                // Ψ′ = K Y  (into the other copy)
+        o.template mm<false, true>(Lp, Gt, KC, -1.0, PI, 1.0);        // Λp = P⁻¹ − K C K′   (barrier: all three are stored)
+        Msrc = Lp;
+        Madd = ob ? LW : WC;
+        double* sw = Pc; Pc = Pn; Pn = sw;
     }
-    o.lin(g, 1.0, Mx, -1.0, WC);                                  // Λ at the segment end
+    o.symadd(g, 1.0, Msrc, ob ? 1.0 : 0.0, LO);                       // Λ at the segment end = sym(Λp) [+ B′Q⁻¹B]
+    if (Pc != g + MM) o.lin(g + MM, 1.0, Pc);
     if (tid < D) {
         double* v = p.mvec + ((size_t)chain * p.S + seg) * 2 * D;
         v[tid] = xi[tid];
@@ -191,9 +196,11 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p) {
     const long long chain = blockIdx.y;
     auto CW = [&](int slot) { return p.cw + (size_t)slot * MM; };
     double* W = p.ws + ((size_t)chain * 2 + dir) * MSEG_WS * MM;   // km_elements is done with the workspace: reuse it
-    double *cur = W, *tt = W + MM, *Wm = W + 2 * MM, *N1 = W + 3 * MM, *T2 = W + 4 * MM;
+    double *Wm = W, *N1 = W + MM, *T2 = W + 2 * MM;
     bool ok = true;
+    // The carried matrix lives in the array that hands it to the sweep kernels (mbnd / mlb): every step writes the next slot, none copies.
     if (dir == 0) {
+        auto slot = [&](int s) { return p.mbnd + ((size_t)chain * S + s) * 2 * MM; };   // Λ_f(b_s)
         // belief at t = 0: prior ⊗ observation message (if y_0 is observed)
         const bool ob0 = p.obs[chain * p.T] != 0.0;
         const double* m1v = p.in + 5 * MM;   // m0; through the transition when the prior sits on x_0 of the reference's other spelling
@@ -203,43 +210,39 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p) {
             u[tid] = mm1;
             tv[tid] = (ob0 && tid < dyu) ? p.y[(0 * p.n_chains + chain) * dyu + tid] : 0.0;
         }
-        o.lin(cur, 1.0, CW(TabWs::V1I), ob0 ? 1.0 : 0.0, CW(TabWs::LOBS));   // Λ_f(0) = V1⁻¹ [+ B′Q⁻¹B]   (barriers: u, tv visible)
+        o.lin(slot(0), 1.0, CW(TabWs::V1I), ob0 ? 1.0 : 0.0, CW(TabWs::LOBS));   // Λ_f(0) = V1⁻¹ [+ B′Q⁻¹B]   (barriers: u, tv visible)
         if (tid < D) xi[tid] = tab_col_dot<D>(CW(TabWs::V1I), tid, u) + (ob0 ? tab_row_dot<D>(CW(TabWs::G), tid, tv) : 0.0);   // V1⁻¹m1 [+ B′Q⁻¹y]
         o.sync();
         for (int s = 0; s < S; ++s) {
             if (tid < D) p.fstart_m[((size_t)chain * S + s) * D + tid] = xi[tid];     // ξ_f(b_s)  (DenseParams::mseg = 2: the information vector)
-            o.lin(p.mbnd + ((size_t)chain * S + s) * 2 * MM, 1.0, cur);               // Λ_f(b_s)
             if (s == S - 1) break;
             const double* g = p.mel + ((size_t)chain * S + s) * 3 * MM;
             const double* gv = p.mvec + ((size_t)chain * S + s) * 2 * D;
-            o.symadd(tt, 1.0, cur, 1.0, g + 2 * MM);                      // T = Λ_f + Ĵ
-            ok = o.inv(Wm, tt, nullptr) && ok;
+            ok = o.inv_symadd(Wm, 1.0, slot(s), 1.0, g + 2 * MM) && ok;   // T⁻¹, T = Λ_f + Ĵ
             o.template mm<false, false>(N1, g + MM, Wm);                  // N1 = Ψ T⁻¹
             if (tid < D) u[tid] = xi[tid] + gv[D + tid];                  // ξ_f + η̂
             o.template mm<false, true>(T2, N1, g + MM);                   // N1 Ψ′   (its barrier: u is visible)
             if (tid < D) tv[tid] = gv[tid] + tab_row_dot<D>(N1, tid, u);  // ξ_f′ = ξ + N1 (ξ_f + η̂)
-            o.symadd(cur, -1.0, T2, 1.0, g);                              // Λ_f′ = Λ − sym(N1 Ψ′)
+            o.symadd(slot(s + 1), -1.0, T2, 1.0, g);                      // Λ_f′ = Λ − sym(N1 Ψ′)
             if (tid < D) xi[tid] = tv[tid];
             o.sync();
         }
     } else {
-        o.eye(cur, 0.0);   // Λβ(b_S) = 0
+        auto slot = [&](int s) { return p.mlb + ((size_t)chain * S + s) * MM; };   // Λβ at the END boundary of segment s
+        o.eye(slot(S - 1), 0.0);   // Λβ(b_S) = 0
         if (tid < D) xi[tid] = 0.0;
         o.sync();
         for (int s = S - 1; s >= 0; --s) {
-            // message at the END boundary of segment s
-            o.lin(p.mlb + ((size_t)chain * S + s) * MM, 1.0, cur);
             if (tid < D) p.beta_xi[((size_t)chain * (S + 1) + s + 1) * D + tid] = xi[tid];
             if (s == 0) break;
             const double* g = p.mel + ((size_t)chain * S + s) * 3 * MM;
             const double* gv = p.mvec + ((size_t)chain * S + s) * 2 * D;
-            o.symadd(tt, 1.0, cur, 1.0, g);                               // T = Λβ + Λ
-            ok = o.inv(Wm, tt, nullptr) && ok;
+            ok = o.inv_symadd(Wm, 1.0, slot(s), 1.0, g) && ok;            // T⁻¹, T = Λβ + Λ
             o.template mm<true, false>(N1, g + MM, Wm);                   // N1 = Ψ′T⁻¹
             if (tid < D) u[tid] = gv[tid] + xi[tid];                      // ξ + ξβ
             o.template mm<false, false>(T2, N1, g + MM);                  // N1 Ψ   (its barrier: u is visible)
             if (tid < D) tv[tid] = gv[D + tid] + tab_row_dot<D>(N1, tid, u);   // ξβ′ = η̂ + N1 (ξ + ξβ)
-            o.symadd(cur, -1.0, T2, 1.0, g + 2 * MM);                     // Λβ′ = Ĵ − sym(N1 Ψ)
+            o.symadd(slot(s - 1), -1.0, T2, 1.0, g + 2 * MM);             // Λβ′ = Ĵ − sym(N1 Ψ)
             if (tid < D) xi[tid] = tv[tid];
             o.sync();
         }

@@ -50,7 +50,9 @@ struct TabWs {
 // The building blocks are NOT inlined: a phase kernel is a chain of a few hundred of them, and inlined the compiler schedules across
 // all of it (512 registers and kilobytes of scratch per lane in the first version — scratch that size also makes the runtime
 // re-provision the queue's scratch space).  One call per product costs nothing next to the product.
-template <int NT, bool TA, bool TB>
+// SYNC = false: no barrier behind the stores — for a product whose result the NEXT building block does not read (and whose destination
+// nobody is still reading): its stores drain under the next block's loads
+template <int NT, bool TA, bool TB, bool SYNC = true>
 __device__ __attribute__((noinline)) void tab_mm(double* dst0, const double* a0, const double* b0, double alpha, const double* c0, double beta, int w, int lane) {
     constexpr int D = 16 * NT;
     // every operand lives in the global workspace: say so (behind a non-inlined call the pointers are of unknown origin, and flat loads
@@ -101,7 +103,7 @@ __device__ __attribute__((noinline)) void tab_mm(double* dst0, const double* a0,
             if (c) v += beta * cv[t][r];
             dst[ii * D + j] = v;
         }
-    __syncthreads();
+    if (SYNC) __syncthreads();
 }
 template <int NT>
 __device__ __attribute__((noinline)) bool tab_inv(double* dst, const double* a, double* lds, double* logdet_out, int w, int lane) {
@@ -114,6 +116,27 @@ __device__ __attribute__((noinline)) bool tab_inv(double* dst, const double* a, 
     if (w == 0 && lane == 0) lds[blk_scratch_doubles(NT)] = lp.value();
     __syncthreads();
     if (logdet_out) *logdet_out = lds[blk_scratch_doubles(NT)];
+    __syncthreads();
+    return ok;
+}
+// dst = (alpha·½(a + a′) + gamma·c)⁻¹: the symmetrised sum is formed in the accumulator registers on the way in (one building block less
+// in front of every inverse of the masked schedule)
+template <int NT>
+__device__ __attribute__((noinline)) bool tab_inv_symadd(double* dst0, double alpha, const double* a0, double gamma, const double* c0, double* lds, int w, int lane) {
+    constexpr int D = 16 * NT;
+    double* dst = as_global(dst0);
+    const double *a = as_global(a0), *c = as_global(c0);
+    Acc<NT> acc;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
+            acc.v[t][r] = alpha * 0.5 * (a[i * D + j] + a[j * D + i]) + gamma * 0.5 * (c[i * D + j] + c[j * D + i]);
+        }
+    LogProd lp;
+    const bool ok = blk_inverse<NT>(acc, lds, w, lane, lp);
+    acc_store<NT>(acc, dst, D, w, lane);
     __syncthreads();
     return ok;
 }
@@ -161,9 +184,13 @@ struct TabOps {
     double* lds;   // ≥ blk_scratch_doubles(NT) + NTH doubles
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     // dst = alpha·op(a)·op(b) + beta·c      (c may be null or dst; dst must differ from a and b)
-    template <bool TA, bool TB>
+    template <bool TA, bool TB, bool SYNC = true>
     __device__ __forceinline__ void mm(double* dst, const double* a, const double* b, double alpha = 1.0, const double* c = nullptr, double beta = 0.0) const {
-        tab_mm<NT, TA, TB>(dst, a, b, alpha, c, beta, w, lane);
+        tab_mm<NT, TA, TB, SYNC>(dst, a, b, alpha, c, beta, w, lane);
+    }
+    // dst = (alpha·sym(a) + gamma·sym(c))⁻¹
+    __device__ __forceinline__ bool inv_symadd(double* dst, double alpha, const double* a, double gamma, const double* c) const {
+        return tab_inv_symadd<NT>(dst, alpha, a, gamma, c, lds, w, lane);
     }
     // dst = alpha·a + beta·op(b)   (elementwise; a, b may be null; dst may alias a, and b)
     __device__ __forceinline__ void lin(double* dst, double alpha, const double* a, double beta = 0.0, const double* b = nullptr, bool tb = false) const {
