@@ -44,6 +44,10 @@ struct MsegParams {
     double* filt;           // records [chain][T][REC]: slot 1 of the header receives B'Q⁻¹y_t
     int rec;                // REC
     int* status;
+    // two-level boundary recursion (km_group + km_scan levels 2 / 3): groups of sg segments, ng groups; 0: one level over all segments
+    int sg, ng;
+    double* mgrp;           // [chain][ng][3][d][d]  Λ, Ψ, Ĵ of a whole group (km_group)
+    double* mgvec;          // [chain][ng][2][d]     ξ, η̂
 };
 constexpr int MSEG_WS = 14;
 
@@ -180,69 +184,149 @@ __global__ void __launch_bounds__(256) km_gy(MsegParams p) {
     p.filt[(chain * p.T + t) * p.rec + D + i] = s;
 }
 
-// boundary recursion over the segments of one chain: blockIdx.x = 0 prefix, 1 suffix.  Both are the same elimination on the joint of
-// km_elements with the carried information added to one corner:
-//   prefix (filtered belief (Λ_f, ξ_f) at the segment start -> at its end):  T = Λ_f + Ĵ,  Λ_f′ = Λ − Ψ T⁻¹Ψ′,  ξ_f′ = ξ + Ψ T⁻¹(ξ_f + η̂)
-//   suffix (backward message (Λβ, ξβ) at the segment end -> at its start):    T = Λ + Λβ,   Λβ′ = Ĵ − Ψ′T⁻¹Ψ,  ξβ′ = η̂ + Ψ′T⁻¹(ξ + ξβ)
-// — one SPD inverse and two products per segment and direction.
+// Two segments in a row are one segment: stack the joints of (x_a, x_b) and (x_b, x_c) and eliminate x_b —
+//     T = Λ1 + Ĵ2,  Ĵ = Ĵ1 − Ψ1′T⁻¹Ψ1,  Ψ = Ψ2 T⁻¹Ψ1,  Λ = Λ2 − Ψ2 T⁻¹Ψ2′,  η̂ = η̂1 + Ψ1′T⁻¹(ξ1 + η̂2),  ξ = ξ2 + Ψ2 T⁻¹(ξ1 + η̂2)
+// (one inverse, five products).  km_group folds the sg segments of a group into one element, in time order; the boundary recursion then
+// has two levels (km_scan): over the ng group elements, and — all groups in parallel — over the segments of a group from the state at its
+// edge: a sequential depth of 2·sg + ng steps instead of S.
 template <int NT>
-__global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p) {
+__global__ void __launch_bounds__(64 * NT) km_group(MsegParams p) {
+    constexpr int D = 16 * NT, MM = D * D;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
+    double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
+    double *xi = vec, *eta = vec + D, *u = vec + 2 * D;
+    const int tid = o.tid, S = p.S;
+    const long long grp = blockIdx.x, chain = blockIdx.y;
+    const int s0 = (int)grp * p.sg, s1 = s0 + p.sg < S ? s0 + p.sg : S;
+    double* W = p.ws + ((size_t)chain * S + s0) * MSEG_WS * MM;   // the first segment's scratch (km_elements is done with it)
+    double *Ti = W, *Am = W + MM, *Bm = W + 2 * MM, *T2 = W + 3 * MM, *Ps2 = W + 4 * MM;
+    double* G = p.mgrp + ((size_t)chain * p.ng + grp) * 3 * MM;    // Λ | Ψ | Ĵ of the group
+    double *Lc = G, *Pc = G + MM, *Pn = Ps2, *Jc = G + 2 * MM;
+    bool ok = true;
+    {
+        const double* g = p.mel + ((size_t)chain * S + s0) * 3 * MM;
+        const double* gv = p.mvec + ((size_t)chain * S + s0) * 2 * D;
+        o.lin(Lc, 1.0, g);
+        o.lin(Pc, 1.0, g + MM);
+        o.lin(Jc, 1.0, g + 2 * MM);
+        if (tid < D) { xi[tid] = gv[tid]; eta[tid] = gv[D + tid]; }
+        o.sync();
+    }
+    for (int s = s0 + 1; s < s1; ++s) {
+        const double* g = p.mel + ((size_t)chain * S + s) * 3 * MM;     // element 2: Λ2 | Ψ2 | Ĵ2
+        const double* gv = p.mvec + ((size_t)chain * S + s) * 2 * D;
+        ok = o.inv_symadd(Ti, 1.0, Lc, 1.0, g + 2 * MM) && ok;          // T⁻¹, T = Λ1 + Ĵ2
+        if (tid < D) u[tid] = xi[tid] + gv[D + tid];                    // ξ1 + η̂2
+        o.template mm<false, false, false>(Am, Ti, Pc);                 // A = T⁻¹Ψ1
+        o.template mm<false, false>(Bm, g + MM, Ti);                    // B = Ψ2 T⁻¹   (barrier: A is stored, u is visible)
+        if (tid < D) {
+            eta[tid] += tab_col_dot<D>(Am, tid, u);                     // η̂ = η̂1 + A′(ξ1 + η̂2)
+            xi[tid] = gv[tid] + tab_row_dot<D>(Bm, tid, u);             // ξ = ξ2 + B (ξ1 + η̂2)   (u was read from the old ξ before the barrier)
+        }
+        o.template mm<true, false, false>(Jc, Pc, Am, -1.0, Jc, 1.0);   // Ĵ = Ĵ1 − Ψ1′A
+        o.template mm<false, false, false>(Pn, g + MM, Am);             // Ψ = Ψ2 A   (into the other copy)
+        o.template mm<false, true>(T2, Bm, g + MM);                     // B Ψ2′
+        o.symadd(Lc, -1.0, T2, 1.0, g);                                 // Λ = Λ2 − sym(B Ψ2′)
+        double* sw = Pc; Pc = Pn; Pn = sw;
+    }
+    if (Pc != G + MM) o.lin(G + MM, 1.0, Pc);
+    if (tid < D) {
+        double* v = p.mgvec + ((size_t)chain * p.ng + grp) * 2 * D;
+        v[tid] = xi[tid];
+        v[D + tid] = eta[tid];
+    }
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// boundary recursion.  Both directions are the same elimination on a joint with the carried information added to one corner:
+//   prefix (filtered belief (Λ_f, ξ_f) at a segment start -> at its end):  T = Λ_f + Ĵ,  Λ_f′ = Λ − Ψ T⁻¹Ψ′,  ξ_f′ = ξ + Ψ T⁻¹(ξ_f + η̂)
+//   suffix (backward message (Λβ, ξβ) at a segment end -> at its start):    T = Λ + Λβ,   Λβ′ = Ĵ − Ψ′T⁻¹Ψ,  ξβ′ = η̂ + Ψ′T⁻¹(ξ + ξβ)
+// — one SPD inverse and two products per element and direction.  The carried matrix lives in the array that hands it to the sweep kernels
+// (mbnd / mlb): every step writes the next slot, none copies.
+//   level 0: grid (2, chains): every segment of the chain, one after the other (few segments)
+//   level 2: grid (2, chains): over the GROUP elements — the states at the group edges
+//   level 3: grid (2·ng, chains): blockIdx.x = dir·ng + group: the segments inside a group, from the state at its edge
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p, int level) {
     constexpr int D = 16 * NT, MM = D * D;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
     double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
     double *xi = vec, *u = vec + D, *tv = vec + 2 * D;
-    const int tid = o.tid, dir = blockIdx.x, S = p.S, dyu = p.dy_user;
+    const int tid = o.tid, S = p.S, dyu = p.dy_user;
+    const int dir = level == 3 ? (int)blockIdx.x / p.ng : (int)blockIdx.x, grp = level == 3 ? (int)blockIdx.x - dir * p.ng : 0;
     const long long chain = blockIdx.y;
     auto CW = [&](int slot) { return p.cw + (size_t)slot * MM; };
-    double* W = p.ws + ((size_t)chain * 2 + dir) * MSEG_WS * MM;   // km_elements is done with the workspace: reuse it
+    // scratch: slots 8 … 13 of a block nobody else touches now — levels 0 / 2: block (2·chain + dir); level 3: the block of the group's first
+    // segment, three slots per direction (the two directions of a group run side by side)
+    double* W = p.ws + (level == 3 ? ((size_t)chain * S + (size_t)grp * p.sg) * MSEG_WS + 8 + 3 * dir : ((size_t)chain * 2 + dir) * MSEG_WS + 8) * MM;
     double *Wm = W, *N1 = W + MM, *T2 = W + 2 * MM;
     bool ok = true;
-    // The carried matrix lives in the array that hands it to the sweep kernels (mbnd / mlb): every step writes the next slot, none copies.
+    // the run of this workgroup: elements e = 0 … n − 1 in time order, element e ↔ segment (or group) first + e
+    const int first = level == 3 ? grp * p.sg : 0;
+    const int n = level == 3 ? (first + p.sg < S ? p.sg : S - first) : level == 2 ? p.ng : S;
+    const int stride = level == 2 ? p.sg : 1;                     // segments per element
+    auto el = [&](int e) { return level == 2 ? p.mgrp + ((size_t)chain * p.ng + e) * 3 * MM : p.mel + ((size_t)chain * S + first + e) * 3 * MM; };
+    auto elv = [&](int e) { return level == 2 ? p.mgvec + ((size_t)chain * p.ng + e) * 2 * D : p.mvec + ((size_t)chain * S + first + e) * 2 * D; };
+    auto seg_of = [&](int e) { const int sgm = first + e * stride; return sgm < S ? sgm : S; };   // first segment of element e (S: past the end)
     if (dir == 0) {
-        auto slot = [&](int s) { return p.mbnd + ((size_t)chain * S + s) * 2 * MM; };   // Λ_f(b_s)
-        // belief at t = 0: prior ⊗ observation message (if y_0 is observed)
-        const bool ob0 = p.obs[chain * p.T] != 0.0;
-        const double* m1v = p.in + 5 * MM;   // m0; through the transition when the prior sits on x_0 of the reference's other spelling
-        if (tid < D) {
-            double mm1 = m1v[tid];
-            if (p.ptt) mm1 = tab_row_dot<D>(p.in, tid, m1v);           // A m0
-            u[tid] = mm1;
-            tv[tid] = (ob0 && tid < dyu) ? p.y[(0 * p.n_chains + chain) * dyu + tid] : 0.0;
+        // state k = filtered belief at the START of element k: Λ_f -> mbnd[seg_of(k)][0], ξ_f -> fstart_m[seg_of(k)]
+        auto slot = [&](int k) { return p.mbnd + ((size_t)chain * S + seg_of(k)) * 2 * MM; };
+        if (level != 3) {
+            // belief at t = 0: prior ⊗ observation message (if y_0 is observed)
+            const bool ob0 = p.obs[chain * p.T] != 0.0;
+            const double* m1v = p.in + 5 * MM;   // m0; through the transition when the prior sits on x_0 of the reference's other spelling
+            if (tid < D) {
+                double mm1 = m1v[tid];
+                if (p.ptt) mm1 = tab_row_dot<D>(p.in, tid, m1v);           // A m0
+                u[tid] = mm1;
+                tv[tid] = (ob0 && tid < dyu) ? p.y[(0 * p.n_chains + chain) * dyu + tid] : 0.0;
+            }
+            o.lin(slot(0), 1.0, CW(TabWs::V1I), ob0 ? 1.0 : 0.0, CW(TabWs::LOBS));   // Λ_f(0) = V1⁻¹ [+ B′Q⁻¹B]   (barriers: u, tv visible)
+            if (tid < D) xi[tid] = tab_col_dot<D>(CW(TabWs::V1I), tid, u) + (ob0 ? tab_row_dot<D>(CW(TabWs::G), tid, tv) : 0.0);   // V1⁻¹m1 [+ B′Q⁻¹y]
+            o.sync();
+        } else {
+            if (tid < D) xi[tid] = p.fstart_m[((size_t)chain * S + first) * D + tid];   // level 2 left the state at this group's start
+            o.sync();
         }
-        o.lin(slot(0), 1.0, CW(TabWs::V1I), ob0 ? 1.0 : 0.0, CW(TabWs::LOBS));   // Λ_f(0) = V1⁻¹ [+ B′Q⁻¹B]   (barriers: u, tv visible)
-        if (tid < D) xi[tid] = tab_col_dot<D>(CW(TabWs::V1I), tid, u) + (ob0 ? tab_row_dot<D>(CW(TabWs::G), tid, tv) : 0.0);   // V1⁻¹m1 [+ B′Q⁻¹y]
-        o.sync();
-        for (int s = 0; s < S; ++s) {
-            if (tid < D) p.fstart_m[((size_t)chain * S + s) * D + tid] = xi[tid];     // ξ_f(b_s)  (DenseParams::mseg = 2: the information vector)
-            if (s == S - 1) break;
-            const double* g = p.mel + ((size_t)chain * S + s) * 3 * MM;
-            const double* gv = p.mvec + ((size_t)chain * S + s) * 2 * D;
-            ok = o.inv_symadd(Wm, 1.0, slot(s), 1.0, g + 2 * MM) && ok;   // T⁻¹, T = Λ_f + Ĵ
+        for (int k = 0; k < n; ++k) {
+            if (tid < D && (level != 3 || k > 0)) p.fstart_m[((size_t)chain * S + seg_of(k)) * D + tid] = xi[tid];   // ξ_f  (DenseParams::mseg = 2)
+            if (k == n - 1) break;                                        // the state behind the last element is the next run's (or nobody's)
+            const double* g = el(k);
+            const double* gv = elv(k);
+            ok = o.inv_symadd(Wm, 1.0, slot(k), 1.0, g + 2 * MM) && ok;   // T⁻¹, T = Λ_f + Ĵ
             o.template mm<false, false>(N1, g + MM, Wm);                  // N1 = Ψ T⁻¹
             if (tid < D) u[tid] = xi[tid] + gv[D + tid];                  // ξ_f + η̂
             o.template mm<false, true>(T2, N1, g + MM);                   // N1 Ψ′   (its barrier: u is visible)
             if (tid < D) tv[tid] = gv[tid] + tab_row_dot<D>(N1, tid, u);  // ξ_f′ = ξ + N1 (ξ_f + η̂)
-            o.symadd(slot(s + 1), -1.0, T2, 1.0, g);                      // Λ_f′ = Λ − sym(N1 Ψ′)
+            o.symadd(slot(k + 1), -1.0, T2, 1.0, g);                      // Λ_f′ = Λ − sym(N1 Ψ′)
             if (tid < D) xi[tid] = tv[tid];
             o.sync();
         }
     } else {
-        auto slot = [&](int s) { return p.mlb + ((size_t)chain * S + s) * MM; };   // Λβ at the END boundary of segment s
-        o.eye(slot(S - 1), 0.0);   // Λβ(b_S) = 0
-        if (tid < D) xi[tid] = 0.0;
-        o.sync();
-        for (int s = S - 1; s >= 0; --s) {
-            if (tid < D) p.beta_xi[((size_t)chain * (S + 1) + s + 1) * D + tid] = xi[tid];
-            if (s == 0) break;
-            const double* g = p.mel + ((size_t)chain * S + s) * 3 * MM;
-            const double* gv = p.mvec + ((size_t)chain * S + s) * 2 * D;
-            ok = o.inv_symadd(Wm, 1.0, slot(s), 1.0, g) && ok;            // T⁻¹, T = Λβ + Λ
+        // state k = backward message at the END of element k: Λβ -> mlb[last segment of element k], ξβ -> beta_xi[that segment + 1]
+        auto last = [&](int k) { const int e1 = seg_of(k + 1); return e1 - 1; };
+        auto slot = [&](int k) { return p.mlb + ((size_t)chain * S + last(k)) * MM; };
+        if (level != 3 || last(n - 1) == S - 1) {
+            if (level != 3) { o.eye(slot(n - 1), 0.0); }   // Λβ(b_S) = 0   (level 3 finds it there)
+            if (tid < D) xi[tid] = level != 3 ? 0.0 : p.beta_xi[((size_t)chain * (S + 1) + last(n - 1) + 1) * D + tid];
+            o.sync();
+        } else {
+            if (tid < D) xi[tid] = p.beta_xi[((size_t)chain * (S + 1) + last(n - 1) + 1) * D + tid];
+            o.sync();
+        }
+        for (int k = n - 1; k >= 0; --k) {
+            if (tid < D && (level != 3 || k < n - 1)) p.beta_xi[((size_t)chain * (S + 1) + last(k) + 1) * D + tid] = xi[tid];
+            if (k == 0) break;                                            // the message in front of the first element is the previous run's
+            const double* g = el(k);
+            const double* gv = elv(k);
+            ok = o.inv_symadd(Wm, 1.0, slot(k), 1.0, g) && ok;            // T⁻¹, T = Λβ + Λ
             o.template mm<true, false>(N1, g + MM, Wm);                   // N1 = Ψ′T⁻¹
             if (tid < D) u[tid] = gv[tid] + xi[tid];                      // ξ + ξβ
             o.template mm<false, false>(T2, N1, g + MM);                  // N1 Ψ   (its barrier: u is visible)
             if (tid < D) tv[tid] = gv[D + tid] + tab_row_dot<D>(N1, tid, u);   // ξβ′ = η̂ + N1 (ξ + ξβ)
-            o.symadd(slot(s - 1), -1.0, T2, 1.0, g + 2 * MM);             // Λβ′ = Ĵ − sym(N1 Ψ)
+            o.symadd(slot(k - 1), -1.0, T2, 1.0, g + 2 * MM);             // Λβ′ = Ĵ − sym(N1 Ψ)
             if (tid < D) xi[tid] = tv[tid];
             o.sync();
         }

@@ -370,6 +370,8 @@ struct rxhip_engine {
     // rxhip_set_covariance_mode: 0 = every sweep writes the covariance of every chain; 1 = shared-model batches on the split schedule write
     // the per-chain array on request (the values do not depend on the data: one [T][d][d] table per model).  cov_pending: the last run left
     // the array to be materialised; cov_current: the array holds what a materialisation would write
+    int m_sg = 0, m_ng = 0;          // masked schedule: groups of the two-level boundary recursion (0: one level)
+    double *m_grp = nullptr, *m_gvec = nullptr;
     int cov_mode = 0;
     bool cov_pending = false, cov_current = false;
     double *d_dtab = nullptr, *d_vlast = nullptr, *d_vstab = nullptr, *d_fe_const = nullptr;
@@ -1220,7 +1222,7 @@ static rxhip_status prof_end(rxhip_engine* e);
 template <int NT>
 static hipError_t mseg_prepare_kernels() {
     hipError_t err;
-    for (const void* f : {(const void*)km_elements<NT>, (const void*)km_scan<NT>, (const void*)km_bnd<NT>, (const void*)kt_consts<NT>})
+    for (const void* f : {(const void*)km_elements<NT>, (const void*)km_scan<NT>, (const void*)km_group<NT>, (const void*)km_bnd<NT>, (const void*)kt_consts<NT>})
         if ((err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return err;
     return DenseLaunch<NT>::prepare();
 }
@@ -1230,17 +1232,31 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     const size_t D = (size_t)e->dpad, MM = D * D, C = (size_t)e->n_chains, T = (size_t)e->T;
     // segments: the element pass costs ≈2 boundary steps per time step, both are sequential chains -> S ≈ √(2T); many chains fill the
     // machine on their own, and the scratch of the element pass grows with chains × S
-    long long S = (long long)std::ceil(std::sqrt(2.0 * (double)(T - 1)));
-    while (S > 1 && (double)C * (double)S * (MSEG_WS + 9) * MM * 8.0 > 6e9) S = (S + 1) / 2;
-    {   // ... unless the chains fill the machine on their own: then ONE segment per chain — the sweep kernels run the whole chain, no
-        // element pass (which costs three sweep steps per time step) and no boundary recursion.  Cost model in µs per step / segment and workgroups the
-        // chip holds at once, from profiles/r03/dense_missing_parallel_kernels.txt (d = 64: 54 / 37 / 17, 512; d ≤ 16: ≈15 / 14 / 5.7, 2048).
-        const double f = (double)(e->nt - 1) / 3.0, c_e = 15.0 + f * 39.0, c_s = 14.0 + f * 23.0, c_f = 5.7 + f * 11.3, conc = e->nt == 1 ? 2048.0 : e->nt == 2 ? 1024.0 : 512.0;
+    // Segments: a cost model over the sequential depths, in µs per step / element from the measured kernels
+    // (profiles/r03/dense_missing_parallel_kernels.txt; d = 64: element step 50, boundary step 21, group combine 50, sweep step 17–23;
+    // d ≤ 16: ≈15 / 8 / 15 / 5.7) and the workgroups the chip holds at once.  One chain: S ≈ 150 segments at T = 2000 (elements and the
+    // three-level boundary recursion in balance); chains that fill the machine on their own: ONE segment per chain — the sweep kernels run
+    // the whole chain, no element pass (three sweep steps' worth per time step) and no boundary recursion.
+    long long S = 1;
+    {
+        const double f = (double)(e->nt - 1) / 3.0, c_e = 15.0 + f * 35.0, c_s = 8.0 + f * 13.0, c_g = 15.0 + f * 35.0, c_f = 5.7 + f * 14.3;
+        const double conc = e->nt == 1 ? 2048.0 : e->nt == 2 ? 1024.0 : 512.0;
         auto cost = [&](long long s) {
             const double steps = std::ceil((double)(T - 1) / (double)s), rounds = std::ceil((double)C * (double)s / conc);
-            return rounds * steps * ((s > 1 ? c_e : 0.0) + c_f) + (s > 1 ? (double)s * c_s * std::ceil(2.0 * (double)C / conc) : 0.0);
+            double scan = 0.0;
+            if (s >= 16) {
+                const double sg = std::ceil(std::sqrt((double)s)), ng = std::ceil((double)s / sg);
+                scan = (sg * c_g + (ng + 2.0 * sg) * c_s) * std::ceil((double)C * ng / conc);
+            } else if (s > 1)
+                scan = (double)s * c_s * std::ceil(2.0 * (double)C / conc);
+            return rounds * steps * ((s > 1 ? c_e : 0.0) + c_f) + scan;
         };
-        if (cost(1) <= cost(S)) S = 1;
+        double best = 0.7 * cost(1);   // (the interpolated element costs are optimistic between d = 16 and 64: leave one segment only for a clear win)
+        for (long long s = 2; s <= (long long)T - 1; s = std::max(s + 1, (long long)((double)s * 1.15))) {
+            if ((double)C * (double)s * (MSEG_WS + 9) * MM * 8.0 > 6e9) break;   // scratch of the element pass: chains × S blocks
+            const double c = cost(s);
+            if (c < best) { best = c; S = s; }
+        }
     }
     if (ds->segments > 0) S = ds->segments;
     if (S > (long long)T - 1) S = (long long)T - 1;
@@ -1248,18 +1264,28 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     long long L = ((long long)T - 1 + S - 1) / S;
     S = ((long long)T - 1 + L - 1) / L;
     e->mS = (int)S; e->mL = L;
+    // two-level boundary recursion from 16 segments on: groups of ≈√S segments (km_group, km_scan levels 2 / 3)
+    e->m_sg = 0; e->m_ng = 0;
+    if (S >= 16 && !std::getenv("RXHIP_MSEG_ONE_LEVEL")) {
+        int sg = 1;
+        while ((long long)sg * sg < S) ++sg;
+        e->m_sg = sg;
+        e->m_ng = (int)((S + sg - 1) / sg);
+    }
+    const size_t NG = (size_t)(e->m_ng > 0 ? e->m_ng : 1);
     const DenseCst cl = DenseCst::make((int)D, e->dy);
     const int rec = dense_rec(e->nt), tri = dense_tri(e->nt);
     const size_t nws = std::max<size_t>((size_t)C * (size_t)S, (size_t)2 * C) * MSEG_WS * MM;
     const size_t parts[] = {5 * MM + D, TabWs::doubles((int)D, 1), (size_t)cl.size, C * T, C, C * S * 3 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
                             C * T * (size_t)rec, C * S * (size_t)tri, C * S * D, C * (S + 1) * D,
-                            (2 * (size_t)S + 2 + (size_t)fe_resid_blocks(e->T, e->dpad, e->dy)) * C};
-    size_t off[16] = {0};
-    for (int q = 0; q < 15; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
-    HIPCHK(e, hipMalloc(&e->mseg_block, off[15]));
+                            (2 * (size_t)S + 2 + (size_t)fe_resid_blocks(e->T, e->dpad, e->dy)) * C, C * NG * 3 * MM, C * NG * 2 * D};
+    size_t off[18] = {0};
+    for (int q = 0; q < 17; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
+    HIPCHK(e, hipMalloc(&e->mseg_block, off[17]));
     auto at = [&](int q) { return (double*)(e->mseg_block + off[q]); };
     e->m_in = at(0); e->m_cw = at(1); e->m_cst = at(2); e->m_obs = at(3); e->m_nobs = at(4); e->m_el = at(5); e->m_vec = at(6); e->m_bnd = at(7);
     e->m_lb = at(8); e->m_ws = at(9); e->d_filt = at(10); e->d_vend = at(11); e->d_fstart_m = at(12); e->d_beta_xi = at(13); e->m_fe_part = at(14);
+    e->m_grp = at(15); e->m_gvec = at(16);
     // the model padded to d×d (copies only) and its constant block, built on the device
     std::vector<double> hin(5 * MM + D, 0.0);
     const int du = ds->d, dyu = ds->dy;
@@ -1301,7 +1327,12 @@ static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams
     hipLaunchKernelGGL(km_mask, dim3((unsigned)mp.n_chains), dim3(256), 0, s, mp);
     if (mp.S == 1) hipLaunchKernelGGL(km_gy, dim3((unsigned)(((mp.T - 1) * mp.d + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
     else hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
-    hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
+    if (mp.ng > 0) {   // two levels: group elements, the states at the group edges, then every group on its own
+        hipLaunchKernelGGL((km_group<NT>), dim3((unsigned)mp.ng, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
+        hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 2);
+        hipLaunchKernelGGL((km_scan<NT>), dim3(2 * (unsigned)mp.ng, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 3);
+    } else
+        hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 0);
     if (mp.S > 1) hipLaunchKernelGGL((km_bnd<NT>), dim3((unsigned)(mp.S - 1), (unsigned)mp.n_chains), dim3(64 * NT), sizeof(double) * blk_scratch_doubles(NT), s, mp);
     DenseLaunch<NT>::forward_info(dp, fe, s);
     DenseLaunch<NT>::backward_info(dp, fe, s);
@@ -1312,6 +1343,7 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
     mp.y = e->d_y; mp.in = e->m_in; mp.cw = e->m_cw; mp.ws = e->m_ws; mp.obs = e->m_obs; mp.nobs = e->m_nobs; mp.mel = e->m_el; mp.mvec = e->m_vec;
     mp.mbnd = e->m_bnd; mp.mlb = e->m_lb; mp.fstart_m = e->d_fstart_m; mp.beta_xi = e->d_beta_xi; mp.filt = e->d_filt; mp.rec = dense_rec(e->nt);
     mp.status = e->d_status;
+    mp.sg = e->m_sg; mp.ng = e->m_ng; mp.mgrp = e->m_grp; mp.mgvec = e->m_gvec;
     DenseParams dp{};
     dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->mS; dp.L = e->mL; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy; dp.pack = 1; dp.d_sub = 8; dp.dy_sub = e->dy;
     dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->m_cst;
