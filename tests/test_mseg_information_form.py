@@ -102,3 +102,24 @@ def test_information_form_elements_and_boundary_recursions(d, dy, T, L, seed):
         Vs = np.linalg.inv(pre[s][0] + suf[s][0])
         assert np.allclose(Vs, oc[bnd[s]], rtol=1e-8, atol=1e-10), s
         assert np.allclose(Vs @ (pre[s][1] + suf[s][1]), om[bnd[s]], rtol=1e-8, atol=1e-10), s
+
+
+def _compose(e1, e2):
+    """two segments in a row as one: stack the joints of (x_a, x_b) and (x_b, x_c), eliminate x_b (km_group)"""
+    l1, p1, j1, x1, h1 = e1
+    l2, p2, j2, x2, h2 = e2
+    Ti = np.linalg.inv(l1 + j2)
+    u = x1 + h2
+    return l2 - p2 @ Ti @ p2.T, p2 @ Ti @ p1, j1 - p1.T @ Ti @ p1, x2 + p2 @ Ti @ u, h1 + p1.T @ Ti @ u
+
+
+@pytest.mark.parametrize("d,dy,n1,n2,seed", [(4, 2, 5, 3, 1), (7, 7, 1, 9, 2), (3, 1, 6, 1, 3)])
+def test_composition_of_two_elements_is_the_element_of_both(d, dy, n1, n2, seed):
+    A, B, P, Q, _, _ = _model(d, dy, seed)
+    rng = np.random.default_rng(seed)
+    ys = rng.standard_normal((n1 + n2, dy))
+    ys[rng.random(n1 + n2) < 0.3] = np.nan
+    whole = _element(A, B, P, Q, ys)
+    both = _compose(_element(A, B, P, Q, ys[:n1]), _element(A, B, P, Q, ys[n1:]))
+    for a, b in zip(whole, both):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-11)
