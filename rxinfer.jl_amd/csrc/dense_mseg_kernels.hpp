@@ -51,11 +51,12 @@ struct MsegParams {
 };
 constexpr int MSEG_WS = 14;
 
-__global__ void km_mask(MsegParams p) {
+// grid (blocks over time, chains); nobs[chain] must be zero on entry (mseg_launch clears it): exact integer counts, any order
+__global__ void __launch_bounds__(256) km_mask(MsegParams p) {
     __shared__ double red[256];
-    const long long chain = blockIdx.x;
+    const long long chain = blockIdx.y;
     double cnt = 0.0;
-    for (long long t = threadIdx.x; t < p.T; t += blockDim.x) {
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < p.T; t += (long long)gridDim.x * blockDim.x) {
         const double* yt = p.y + (t * p.n_chains + chain) * p.dy_user;
         bool ok = true;
         for (int k = 0; k < p.dy_user; ++k) ok = ok && yt[k] == yt[k];   // NaN = missing
@@ -68,7 +69,7 @@ __global__ void km_mask(MsegParams p) {
         if ((int)threadIdx.x < n) red[threadIdx.x] += red[threadIdx.x + n];
         __syncthreads();
     }
-    if (threadIdx.x == 0) p.nobs[chain] = red[0];
+    if (threadIdx.x == 0 && red[0] != 0.0) atomicAdd(p.nobs + chain, red[0]);   // (sums of small integers: exact in any order)
 }
 
 // out[i] = Σ_k M[i][k] x[k] (+ add[i]); M row-major d×d in global memory, x / out in LDS; thread i < D
@@ -219,14 +220,14 @@ __global__ void __launch_bounds__(64 * NT) km_group(MsegParams p) {
         ok = o.inv_symadd(Ti, 1.0, Lc, 1.0, g + 2 * MM) && ok;          // T⁻¹, T = Λ1 + Ĵ2
         if (tid < D) u[tid] = xi[tid] + gv[D + tid];                    // ξ1 + η̂2
         o.template mm<false, false, false>(Am, Ti, Pc);                 // A = T⁻¹Ψ1
-        o.template mm<false, false>(Bm, g + MM, Ti);                    // B = Ψ2 T⁻¹   (barrier: A is stored, u is visible)
+        o.template mm<false, true>(Bm, Ti, g + MM);                     // B′ = T⁻¹Ψ2′   (barrier: A is stored, u is visible)
         if (tid < D) {
             eta[tid] += tab_col_dot<D>(Am, tid, u);                     // η̂ = η̂1 + A′(ξ1 + η̂2)
-            xi[tid] = gv[tid] + tab_row_dot<D>(Bm, tid, u);             // ξ = ξ2 + B (ξ1 + η̂2)   (u was read from the old ξ before the barrier)
+            xi[tid] = gv[tid] + tab_col_dot<D>(Bm, tid, u);             // ξ = ξ2 + Ψ2 T⁻¹(ξ1 + η̂2)   (u was read from the old ξ before the barrier)
         }
         o.template mm<true, false, false>(Jc, Pc, Am, -1.0, Jc, 1.0);   // Ĵ = Ĵ1 − Ψ1′A
         o.template mm<false, false, false>(Pn, g + MM, Am);             // Ψ = Ψ2 A   (into the other copy)
-        o.template mm<false, true>(T2, Bm, g + MM);                     // B Ψ2′
+        o.template mm<false, false>(T2, g + MM, Bm);                    // Ψ2 T⁻¹Ψ2′
         o.symadd(Lc, -1.0, T2, 1.0, g);                                 // Λ = Λ2 − sym(B Ψ2′)
         double* sw = Pc; Pc = Pn; Pn = sw;
     }
@@ -296,10 +297,10 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p, int level) {
             const double* g = el(k);
             const double* gv = elv(k);
             ok = o.inv_symadd(Wm, 1.0, slot(k), 1.0, g + 2 * MM) && ok;   // T⁻¹, T = Λ_f + Ĵ
-            o.template mm<false, false>(N1, g + MM, Wm);                  // N1 = Ψ T⁻¹
+            o.template mm<false, true>(N1, Wm, g + MM);                   // N1′ = T⁻¹Ψ′   (the transpose: its columns are coalesced for the vector below)
             if (tid < D) u[tid] = xi[tid] + gv[D + tid];                  // ξ_f + η̂
-            o.template mm<false, true>(T2, N1, g + MM);                   // N1 Ψ′   (its barrier: u is visible)
-            if (tid < D) tv[tid] = gv[tid] + tab_row_dot<D>(N1, tid, u);  // ξ_f′ = ξ + N1 (ξ_f + η̂)
+            o.template mm<false, false>(T2, g + MM, N1);                  // Ψ T⁻¹Ψ′   (its barrier: u is visible)
+            if (tid < D) tv[tid] = gv[tid] + tab_col_dot<D>(N1, tid, u);  // ξ_f′ = ξ + Ψ T⁻¹(ξ_f + η̂)
             o.symadd(slot(k + 1), -1.0, T2, 1.0, g);                      // Λ_f′ = Λ − sym(N1 Ψ′)
             if (tid < D) xi[tid] = tv[tid];
             o.sync();
@@ -322,10 +323,10 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p, int level) {
             const double* g = el(k);
             const double* gv = elv(k);
             ok = o.inv_symadd(Wm, 1.0, slot(k), 1.0, g) && ok;            // T⁻¹, T = Λβ + Λ
-            o.template mm<true, false>(N1, g + MM, Wm);                   // N1 = Ψ′T⁻¹
+            o.template mm<false, false>(N1, Wm, g + MM);                  // N1′ = T⁻¹Ψ
             if (tid < D) u[tid] = gv[tid] + xi[tid];                      // ξ + ξβ
-            o.template mm<false, false>(T2, N1, g + MM);                  // N1 Ψ   (its barrier: u is visible)
-            if (tid < D) tv[tid] = gv[D + tid] + tab_row_dot<D>(N1, tid, u);   // ξβ′ = η̂ + N1 (ξ + ξβ)
+            o.template mm<true, false>(T2, g + MM, N1);                   // Ψ′T⁻¹Ψ   (its barrier: u is visible)
+            if (tid < D) tv[tid] = gv[D + tid] + tab_col_dot<D>(N1, tid, u);   // ξβ′ = η̂ + Ψ′T⁻¹(ξ + ξβ)
             o.symadd(slot(k - 1), -1.0, T2, 1.0, g + 2 * MM);             // Λβ′ = Ĵ − sym(N1 Ψ)
             if (tid < D) xi[tid] = tv[tid];
             o.sync();

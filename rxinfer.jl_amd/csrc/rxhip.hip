@@ -1324,7 +1324,8 @@ template <int NT>
 static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams& dp, bool fe) {
     const size_t lds = sizeof(double) * (size_t)(blk_scratch_doubles(NT) + 2 * 64 * NT + 8 * 16 * NT + 16);
     hipStream_t s = e->stream;
-    hipLaunchKernelGGL(km_mask, dim3((unsigned)mp.n_chains), dim3(256), 0, s, mp);
+    (void)hipMemsetAsync(mp.nobs, 0, sizeof(double) * (size_t)mp.n_chains, s);
+    hipLaunchKernelGGL(km_mask, dim3((unsigned)std::min<long long>(64, (mp.T + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
     if (mp.S == 1) hipLaunchKernelGGL(km_gy, dim3((unsigned)(((mp.T - 1) * mp.d + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
     else hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
     if (mp.ng > 0) {   // two levels: group elements, the states at the group edges, then every group on its own
