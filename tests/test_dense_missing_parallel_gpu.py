@@ -88,3 +88,25 @@ def test_the_rest_of_the_engine_is_unchanged(monkeypatch):
         assert np.allclose(pm[t, c], one[1] @ lm[t], rtol=1e-6, atol=1e-8)
         qm, qc, _ = rxo.lgssm_kalman_rts(*one, np.ascontiguousarray(y[:t + 1, c]))
         assert np.allclose(fm[t, c], qm[-1], rtol=1e-6, atol=1e-9) and np.allclose(fc[t, c], qc[-1], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("d,dy,T,C,segments", [(24, 6, 400, 2, 0), (64, 64, 260, 1, 50), (16, 16, 700, 1, 0)])
+def test_two_level_boundary_recursion_equals_one_level(d, dy, T, C, segments, monkeypatch):
+    """from 16 segments on the boundary recursion runs over group elements first (km_group, km_scan levels 2 / 3): the same posteriors and
+    free energy as the plain recursion over all segments (RXHIP_MSEG_ONE_LEVEL), ragged last group included"""
+    from rxhip import workloads
+    mdl = workloads.random_model(d, dy, seed=41 + d)
+    y = workloads.generate_batch(mdl, T, C, seed0=4)
+    y[np.random.default_rng(T).random((T, C)) < 0.2] = np.nan
+    out = []
+    for one_level in (False, True):
+        if one_level:
+            monkeypatch.setenv("RXHIP_MSEG_ONE_LEVEL", "1")
+        else:
+            monkeypatch.delenv("RXHIP_MSEG_ONE_LEVEL", raising=False)
+        out.append(_run(mdl, y, False, False, monkeypatch, segments))
+    (m2, c2, f2), (m1, c1, f1) = out
+    sd = np.sqrt(np.einsum("tcii->tci", c1))
+    assert np.max(np.abs(m2 - m1) / sd) < 1e-8
+    assert np.max(np.abs(c2 - c1) / (sd[..., :, None] * sd[..., None, :])) < 1e-8
+    assert np.allclose(f2, f1, rtol=1e-10, atol=1e-9)
