@@ -110,3 +110,31 @@ def test_two_level_boundary_recursion_equals_one_level(d, dy, T, C, segments, mo
     assert np.max(np.abs(m2 - m1) / sd) < 1e-8
     assert np.max(np.abs(c2 - c1) / (sd[..., :, None] * sd[..., None, :])) < 1e-8
     assert np.allclose(f2, f1, rtol=1e-10, atol=1e-9)
+
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        d = int(rng.choice([5, 8, 13, 16, 24, 32, 40, 48, 64]))
+        dy = int(rng.integers(1, min(d, 64) + 1))
+        T = int(rng.integers(2, 420))
+        C = int(rng.choice([1, 1, 2, 3, 9]))
+        seg = int(rng.choice([0, 0, 0, 1, 2, 17, 33])) if T > 40 else 0
+        yield dict(i=i, d=d, dy=dy, T=T, C=C, segments=min(seg, T - 1), ptt=bool(rng.integers(0, 2)), rate=float(rng.choice([0.05, 0.3, 0.8])))
+
+
+@pytest.mark.parametrize("case", list(_random_cases(12 + int(os.environ.get("RXHIP_STRESS", "0")), 777)),
+                         ids=lambda c: f"{c['i']}-d{c['d']}x{c['dy']}-T{c['T']}-C{c['C']}-s{c['segments']}-{'ptt' if c['ptt'] else 'x1'}-{c['rate']}")
+def test_random_masked_case_against_the_sequential_schedule(case, monkeypatch):
+    """random shapes, segment counts (one level, two levels, one segment per chain) and missing rates up to 80 %: the masked MFMA schedule
+    against the sequential one (itself checked against the oracle above)"""
+    from rxhip import workloads
+    mdl = workloads.random_model(case["d"], case["dy"], seed=900 + case["i"])
+    y = workloads.generate_batch(mdl, case["T"], case["C"], seed0=case["i"])
+    y[np.random.default_rng(case["i"]).random((case["T"], case["C"])) < case["rate"]] = np.nan
+    mp, cp, fp = _run(mdl, y, case["ptt"], False, monkeypatch, case["segments"])
+    ms, cs, fs = _run(mdl, y, case["ptt"], True, monkeypatch)
+    sd = np.sqrt(np.einsum("tcii->tci", cs))
+    assert np.max(np.abs(mp - ms) / sd) < 1e-6
+    assert np.max(np.abs(cp - cs) / (sd[..., :, None] * sd[..., None, :])) < 1e-6
+    assert np.allclose(fp, fs, rtol=1e-8, atol=1e-9)
