@@ -5,21 +5,26 @@
 // and the time index, so none of the per-model tables of the time-parallel schedule survives (dense_kernels.hpp builds its
 // segment boundaries from ONE model and a fully observed chain).  Rounds 1–2 ran these engines sequentially in time
 // (gseq_kernels.hpp: one workgroup per chain — 686 ms for d = 64, T = 2000, against 0.40 ms for the fully observed chain).
-// Here the segment boundaries are built per (chain, segment) ON THE DEVICE, with the mask applied per step:
+// Here the segment boundaries are built per (chain, segment) ON THE DEVICE, with the mask applied per step, in information form:
 //   km_mask      obs[chain][t] = 1 when y[t] of the chain is fully observed (a partly missing vector counts as missing), n_obs per chain
-//   km_elements  one workgroup per (chain, segment): the known-start filter over the segment with the mask — the element (Π, C, J, b, η)
-//                of Särkkä & García-Fernández (2021) and what the backward scan needs of it (C⁻¹, C⁻¹Π, J + Π'C⁻¹Π); B'Q⁻¹y_t of the
-//                observed steps goes into the records for the sweep kernel
-//   km_scan      per chain, two workgroups: prefix — the filtered belief at every segment start (V' = Π(V⁻¹ + J)⁻¹Π' + C, two SPD
-//                inverses per segment); suffix — the backward message (Λβ, ξβ) at every segment end
-//   km_bnd       (V(b_{s+1})⁻¹ + Λβ(b_{s+1}))⁻¹ for every inner boundary (parallel)
-// and the sweep itself is kd_forward_info / kd_backward_info with per-chain boundaries and the observation precision B'Q⁻¹B left
-// out of M_{t+1} at missing steps (DenseParams::mseg).  The free energy is evaluated as on the fully observed path (at the smoothed
-// means), with the observation constants and residuals counted for observed steps only.
-// The matrix products are the non-inlined blocks of dense_tab_kernels.hpp (operands in L2): ≈70 µs per step at d = 64 — a coverage
-// path that is two orders of magnitude faster than the sequential one, not a roofline path: the boundary recursion is sequential
-// over segments (S ≈ √(2T) balances it against the segment length), a tree scan over the elements is the next step.
-// Scope: one model per engine (chain_model / step_model engines keep the sequential schedule), smoothing runs.
+//   km_elements  one workgroup per (chain, segment): the joint information of (state at the segment start, state at its end) that the
+//                segment's transitions and observed steps define — precision [[Ĵ, −Ψ′], [−Ψ, Λ]], vector [η̂, ξ]; one inverse and five
+//                products per step (the step of kd_forward_info plus three products); B′Q⁻¹y_t of the observed steps goes into the
+//                records for the sweep kernel
+//   km_group     (from 16 segments on) the ≈√S segments of a group folded into ONE element: two segments in a row are one segment
+//   km_scan      the boundary recursions — prefix: filtered belief at every segment start; suffix: backward message at every segment
+//                end; one inverse and two products per element and direction; level 2 over the group elements, level 3 inside every
+//                group in parallel (level 0: all segments in one run)
+//   km_bnd       (Λ_f(b_{s+1}) + Λβ(b_{s+1}))⁻¹ for every inner boundary (parallel)
+//   km_gy        one segment per chain (batches that fill the chip on their own): B′Q⁻¹y_t only — no elements, no recursion
+// and the sweep itself is kd_forward_info / kd_backward_info with per-chain boundaries (information vector ξ_f at the segment start:
+// DenseParams::mseg = 2) and the observation precision B′Q⁻¹B left out of M_{t+1} at missing steps (DenseCst::oPLWM).  The free energy
+// is evaluated as on the fully observed path (at the smoothed means), with the observation constants and residuals counted for observed
+// steps only.  mseg_setup (rxhip.hip) picks the number of segments from a cost model over the measured step times.
+// The matrix products are the non-inlined blocks of dense_tab_kernels.hpp (operands in L2): 5–8 µs per call whatever it computes — a
+// coverage path that is two to three orders of magnitude faster than the sequential one (d = 64, T = 2000, one chain: 2.4 ms against
+// 690), not a roofline path.  The algebra is restated in numpy in tests/test_mseg_information_form.py.
+// Scope: one model per engine (chain_model / step_model engines keep the sequential schedule), smoothing runs, dy ≤ padded d.
 #pragma once
 #include "dense_tab_kernels.hpp"
 
