@@ -32,7 +32,7 @@ typedef double d4 __attribute__((ext_vector_type(4)));
 struct DenseCst {
     int d, dy;
     long long oA, oP, oLOBS, oG, oQI, oHF, oC0, oX1, oS1, oLD1, oC1, oK1, oVF1, oAT, oGT, oHFT, oK1T, oPI, oK, oKT, oW, oV1I, oM1,
-        oBT, oFEC, oPLW, oPLWM, oLPX, oLQX, size;
+        oBT, oFEC, oPLW, oPLWM, oLDP, oLPX, oLQX, size;
     __host__ __device__ static DenseCst make(int d, int dy) {
         DenseCst c;
         c.d = d;
@@ -67,6 +67,7 @@ struct DenseCst {
         c.oFEC = o; o += 1;                  // ½[log|V1| + (T−1) log|P| + T(dy log 2π + log|Q|)]
         c.oPLW = o; o += (long long)d * d;   // P⁻¹ + B'Q⁻¹B + A'P⁻¹A (symmetric): M_{t+1} = PLW − K G_t
         c.oPLWM = o; o += (long long)d * d;  // the same without B'Q⁻¹B: the step after a `missing` observation (masked sweeps)
+        c.oLDP = o; o += 2;                  // log|P|, log|V1|: the free-energy constant of a chain with per-step constants is a sum over its steps
         // whitening maps of the free-energy residuals (kd_fe_resid_mfma): with P = L_P L_P', Q = L_Q L_Q'
         //   r_x'P⁻¹r_x = |L_P⁻¹ x̂_{t+1} − (L_P⁻¹A) x̂_t|²,   r_y'Q⁻¹r_y = |L_Q⁻¹ y_t − (L_Q⁻¹B) x̂_t|²
         o = (o + 1) & ~1LL;                                                              // 16-byte loads of both maps
@@ -125,6 +126,12 @@ struct DenseParams {
     const double* obs;    // [chain][T]  1: y[t] observed
     const double* nobs;   // [chain]     number of observed time indices
     const double* mbnd;   // [chain][S][2][d][d]  Λ_f(b_s) | V_s(b_{s+1})
+    // per-step constants on the masked schedule (desc.step_model): time index t runs the constant block cst + step_model[t]·cst_stride;
+    // fe_const[chain] = log|V1| + Σ_t log|P_t| + Σ_{t observed} (dy log 2π + log|Q_t|) (km_feconst); model_sel: the pass of the residual kernel
+    const int* step_model;
+    long long cst_stride;
+    const double* fe_const;
+    int model_sel;
     long long chain0;     // first workgroup chain of this launch: a grid dimension holds 65 535 blocks, larger batches are launched in slices
 };
 struct DenseModel {
@@ -1595,7 +1602,9 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
 //       + ½[(x̂_1−m1)'V1⁻¹(x̂_1−m1) + Σ r_x'P⁻¹r_x + Σ r_y'Q⁻¹r_y]                  (residuals at the smoothed means, backward)
 // Record of time index t: ξ_f(t) | (spare) | C_t (lower tiles) | G_t' (accumulator order).  vend: Λ_f at the segment end.
 // fe_part slots (negated contributions): 0 and S+s: backward of segment 0 / s ≥ 1;  1+s: forward of segment s.
-template <int NT, bool FE>
+// STEPM: per-step constants (masked schedule only) — the constants of the transition INTO step t and of the observation at t come from
+// block step_model[t]: M_t = [P⁻¹ + B′Q⁻¹B]_t + [A′P⁻¹A]_{t+1} − K_t G_{t−1}.  A template flag: the fixed-model kernel keeps its registers.
+template <int NT, bool FE, bool STEPM = false>
 __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  // ≥ 2 waves per SIMD: ≤ 256 registers
     constexpr int D = 16 * NT;
     using C = DenseCfg<NT>;
@@ -1635,13 +1644,15 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     // the loads are not hoisted out of the loop again.
     constexpr bool KF_RELOAD = RXHIP_KF_RELOAD && NT >= 3;
     double kf[D / 4];
+    const double* cst_a = cst;   // STEPM: the block of the step being entered (set at the top of every iteration)
+    auto step_cst = [&](long long t) { return p.cst + (size_t)p.step_model[t < p.T ? t : p.T - 1] * (size_t)p.cst_stride; };
     auto load_kf = [&]() {
-        const double* K = cst + c.oK + (16 * w + (lane & 15)) * D + (lane >> 4);
+        const double* K = (STEPM ? cst_a : cst) + c.oK + (16 * w + (lane & 15)) * D + (lane >> 4);
         if (KF_RELOAD) asm volatile("" : "+v"(K));
 #pragma unroll
         for (int kk = 0; kk < D / 4; ++kk) kf[kk] = K[4 * kk];
     };
-    if (!KF_RELOAD) load_kf();
+    if (!KF_RELOAD && !STEPM) load_kf();
     // symmetric contraction M_{t+1} = PLW − K G: slots of this wave (tile (w, (w + sl) mod NT), sl < nsw)
     constexpr int NS = NT / 2 + 1;
     const int ws = __builtin_amdgcn_readfirstlane(w);
@@ -1675,7 +1686,8 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     lds_barrier();
     if (p.mseg == 2) { if (tid < D) xi[tid] = u[tid]; }   // masked sweeps hand over ξ_f(b_s) itself (dense_mseg_kernels.hpp)
     else matvec_lds(xi, S1, LD, D, D, u, nullptr, 0.0, tid);
-    acc_add_mat<NT>(lam, cst + c.oW, D, w, lane, 1.0);  // lam carries M_t = Λ_f(t−1) + A'P⁻¹A from here on
+    const double* cst_w = STEPM ? step_cst(t0) : cst;     // whose A′P⁻¹A sits in lam at the moment
+    acc_add_mat<NT>(lam, cst_w + c.oW, D, w, lane, 1.0);  // lam carries M_t = Λ_f(t−1) + A'P⁻¹A from here on
     if (PREPUB) {  // equilibration exponents of the first inverse (later ones: where M is stored)
 #pragma unroll
         for (int t = 0; t < NT; ++t)
@@ -1685,7 +1697,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     double gyn = (tid < D && len > 0) ? p.filt[(chain * p.T + t0) * C::REC + D + tid] : 0.0;
     double obn = (p.mseg && len > 0) ? p.obs[chain * p.T + t0] : 1.0;   // is y_t observed (masked sweeps), one step ahead like gyn
     d4 plw_r[NT <= 2 ? NS : 1], plwm_r[NT <= 2 ? NS : 1];
-    if constexpr (NT <= 2) {
+    if constexpr (NT <= 2 && !STEPM) {
         const int lq0 = lane >> 4, lj0 = lane & 15;
 #pragma unroll
         for (int sl = 0; sl < NS; ++sl) {
@@ -1698,6 +1710,10 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
     lds_barrier();
     for (long long i = 0; i < len; ++i) {
         const long long t = t0 + i;
+        if constexpr (STEPM) {
+            cst_a = step_cst(t);
+            if (!KF_RELOAD) load_kf();
+        }
         double* rec = p.filt + (chain * p.T + (t - 1)) * C::REC;
         const double gyc = gyn;
         if (tid < D) {
@@ -1732,7 +1748,17 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
         const bool miss = obn == 0.0;
         if (p.mseg) obn = p.obs[chain * p.T + (i + 1 < len ? t + 1 : t)];
         d4 macc[NS];
-        if constexpr (NT <= 2) {   // narrow models: both constants live in registers (G' = K C is too short to hide an L2 round trip per step)
+        if constexpr (STEPM) {     // [P⁻¹ + B′Q⁻¹B + A′P⁻¹A]_t − [A′P⁻¹A]_t + [A′P⁻¹A]_{t+1}
+            const double* cb = step_cst(t + 1);
+            const double* plw = cst_a + (miss ? c.oPLWM : c.oPLW);
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl) {
+                const size_t o = (size_t)(16 * ws + lq) * D + 16 * slot_tile(sl) + lj;
+                const double *s0 = plw + o, *s1 = cst_a + c.oW + o, *s2 = cb + c.oW + o;
+                macc[sl] = (d4){s0[0] - s1[0] + s2[0], s0[4 * D] - s1[4 * D] + s2[4 * D], s0[8 * D] - s1[8 * D] + s2[8 * D], s0[12 * D] - s1[12 * D] + s2[12 * D]};
+            }
+            cst_w = cb;
+        } else if constexpr (NT <= 2) {   // narrow models: both constants live in registers (G' = K C is too short to hide an L2 round trip per step)
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl) macc[sl] = miss ? plwm_r[sl] : plw_r[sl];
         } else {
@@ -1817,7 +1843,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  
             }
         }
     }
-    acc_add_mat<NT>(lam, cst + c.oW, D, w, lane, -1.0);
+    acc_add_mat<NT>(lam, cst_w + c.oW, D, w, lane, -1.0);
     acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);  // Λ_f at the segment end
     if (seg == p.S - 1 && tid < D) p.filt[(chain * p.T + (t0 + len - 1)) * C::REC + tid] = xi[tid];  // ξ_f(T): no successor writes it
     if (FE && tid == 0) dense_fe_write(p, 1 + seg, chain, lp.value(), 0.0, 0.0);
@@ -1989,8 +2015,11 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
         double f = 0.0;
         if (seg == p.S - 1) f += lpe.value();        // log|Λ_f(T)|
         if (seg == 0) {
-            f += 2.0 * cst[c.oFEC];
-            if (p.mseg) f -= ((double)p.T - p.nobs[chain]) * cst[c.oC0];   // dy log 2π + log|Q| of the observed time indices only
+            if (p.step_model) f += p.fe_const[chain];   // per-step constants: the sum over the chain's steps (km_feconst)
+            else {
+                f += 2.0 * cst[c.oFEC];
+                if (p.mseg) f -= ((double)p.T - p.nobs[chain]) * cst[c.oC0];   // dy log 2π + log|Q| of the observed time indices only
+            }
         }
         dense_fe_write(p, seg == 0 ? 0 : p.S + seg, chain, f, 0.0, 0.0);
     }
@@ -2198,7 +2227,8 @@ __global__ void __launch_bounds__(256, 2) kd_fe_resid_mfma(DenseParams p, int sl
     double* dm = red + 8;              // [D]  x̂_1 − m1 (first workgroup of a chain)
     const int DUMP = (int)(dm + D - xs), DUMPY = (int)(dm + D - ys);   // one slot behind everything: where out-of-tile stores go
     const long long chain = blockIdx.y + p.chain0;
-    const DenseModel M = dense_model(p, chain);
+    DenseModel M = dense_model(p, chain);
+    if (p.step_model) M.cst = p.cst + (size_t)p.model_sel * (size_t)p.cst_stride;   // per-step constants: ONE model per launch, the columns of the others masked
     const DenseCst c = DenseCst::make(D, dy);
     const int STEPS = fe_resid_steps(D, dy), NTT = STEPS / RS;   // rounds per workgroup
     const long long t00 = (long long)blockIdx.x * STEPS;
@@ -2333,14 +2363,20 @@ __global__ void __launch_bounds__(256, 2) kd_fe_resid_mfma(DenseParams p, int sl
         __syncthreads();        // the previous round's readers are done
         deposit(tb);
         const long long tj0 = tb + 16 * tl0 + j, tj1 = tb + 16 * tl1 + j;
-        const bool vx0 = tj0 + 1 < p.T, vx1 = tj1 + 1 < p.T;
-        const bool ob0 = tj0 < p.T && obv0 != 0.0, ob1 = tj1 < p.T && obv1 != 0.0;   // `missing`: no observation node energy at this time index
+        bool vx0 = tj0 + 1 < p.T, vx1 = tj1 + 1 < p.T;
+        bool ob0 = tj0 < p.T && obv0 != 0.0, ob1 = tj1 < p.T && obv1 != 0.0;   // `missing`: no observation node energy at this time index
+        if (p.step_model) {   // the transition into t + 1 belongs to model step_model[t + 1], the observation at t to step_model[t]
+            vx0 = vx0 && p.step_model[tj0 + 1] == p.model_sel;
+            vx1 = vx1 && p.step_model[tj1 + 1] == p.model_sel;
+            ob0 = ob0 && p.step_model[tj0] == p.model_sel;
+            ob1 = ob1 && p.step_model[tj1] == p.model_sel;
+        }
         __syncthreads();
         if (tt + 1 < NTT && tb + RS < p.T) issue(tb + RS);
         run_item(a0, it0, tl0, vx0, ob0);
         run_item(a1, it1, tl1, vx1, ob1);
     }
-    if (t00 == 0 && lane < D) {   // prior of the first state: (x̂_1 − m1)'V1⁻¹(x̂_1 − m1) = Σ_waves dm_i Σ_{k in the wave's quarter} V1⁻¹[k][i] dm_k
+    if (t00 == 0 && lane < D && (!p.step_model || p.step_model[0] == p.model_sel)) {   // prior of the first state: (x̂_1 − m1)'V1⁻¹(x̂_1 − m1) = Σ_waves dm_i Σ_{k in the wave's quarter} V1⁻¹[k][i] dm_k
         const double* V1I = M.cst + c.oV1I + lane;   // row i = lane; every load independent (a uniform address per term would be a
         double u = 0.0;                              // chain of scalar loads), one round trip for the whole term
 #pragma unroll

@@ -53,7 +53,15 @@ struct MsegParams {
     int sg, ng;
     double* mgrp;           // [chain][ng][3][d][d]  Λ, Ψ, Ĵ of a whole group (km_group)
     double* mgvec;          // [chain][ng][2][d]     ξ, η̂
+    // per-step constants (desc.step_model; null: one model): time index t uses block step_model[t] of `in`, `cw` and of the constant
+    // blocks `cst` (strides in doubles); fe_const[chain]: the data-independent part of the free energy, summed over the chain's steps
+    const int* step_model;
+    long long in_stride, cw_stride, cst_stride;
+    const double* cst;
+    double* fe_const;
+    int oC0, oLDP;          // DenseCst offsets of dy log 2π + log|Q| and of log|P|, log|V1|
 };
+__device__ __forceinline__ int mseg_model(const MsegParams& p, long long t) { return p.step_model ? p.step_model[t < p.T ? t : p.T - 1] : 0; }
 constexpr int MSEG_WS = 14;
 
 // grid (blocks over time, chains); nobs[chain] must be zero on entry (mseg_launch clears it): exact integer counts, any order
@@ -117,20 +125,22 @@ __global__ void __launch_bounds__(64 * NT) km_elements(MsegParams p) {
     double *xi = vec, *cv = vec + D, *eta = vec + 2 * D, *yv = vec + 3 * D;
     const int tid = o.tid, dyu = p.dy_user;
     const long long seg = blockIdx.x, chain = blockIdx.y;
-    auto CW = [&](int slot) { return p.cw + (size_t)slot * MM; };
-    const double *PI = CW(TabWs::PINV), *KC = CW(TabWs::KC), *WC = CW(TabWs::WC), *LO = CW(TabWs::LOBS), *G = CW(TabWs::G);
+    auto CW = [&](int m, int slot) { return p.cw + (size_t)m * (size_t)p.cw_stride + (size_t)slot * MM; };   // constants of model m
     double* W = p.ws + ((size_t)chain * p.S + seg) * MSEG_WS * MM;
-    double *Cx = W, *Gt = W + MM, *Lp = W + 2 * MM, *Y = W + 3 * MM, *LW = W + 4 * MM, *Ps2 = W + 5 * MM;
+    double *Cx = W, *Gt = W + MM, *Lp = W + 2 * MM, *Y = W + 3 * MM, *Ps2 = W + 4 * MM;
     double* g = p.mel + ((size_t)chain * p.S + seg) * 3 * MM;   // Λ | Ψ | Ĵ of this segment
     double *Pc = g + MM, *Pn = Ps2, *Jh = g + 2 * MM;           // Ψ alternates between its slot and a scratch matrix (no product overwrites an operand)
     const long long t0 = seg * p.L;   // boundary b_s: state index of the known start
     long long t1 = t0 + p.L;
     if (t1 > p.T - 1) t1 = p.T - 1;
     bool ok = true, ob = true;
-    o.lin(LW, 1.0, LO, 1.0, WC);      // B′Q⁻¹B + A′P⁻¹A: what an observed step adds to Λp on the way to the next M
-    // the next M = sym(Msrc) + Madd is formed inside the inverse that consumes it (inv_symadd)
-    const double *Msrc = PI, *Madd = WC;
+    // Λ(t) = sym(Msrc) [+ B′Q⁻¹B of step t's model]; the M of the next step adds A′P⁻¹A of ITS model — all formed inside the inverse that
+    // consumes them (inv_symadd).  Step t's transition and observation use the constants of model step_model[t] (one model: block 0).
+    const double *Msrc = nullptr, *Mobs = nullptr;
     for (long long t = t0 + 1; t <= t1; ++t) {
+        const int a = mseg_model(p, t);
+        const double *PI = CW(a, TabWs::PINV), *KC = CW(a, TabWs::KC), *WC = CW(a, TabWs::WC), *LO = CW(a, TabWs::LOBS), *G = CW(a, TabWs::G);
+        const bool obp = ob;                  // was the previous step observed
         ob = p.obs[chain * p.T + t] != 0.0;   // uniform
         double* rec = p.filt + (chain * p.T + t) * p.rec;
         if (tid < D) yv[tid] = (ob && tid < dyu) ? p.y[(t * p.n_chains + chain) * dyu + tid] : 0.0;
@@ -144,10 +154,12 @@ __global__ void __launch_bounds__(64 * NT) km_elements(MsegParams p) {
                 rec[D + tid] = gy;                        // B′Q⁻¹y_t for the sweep kernel
             }
             o.sync();
-            Madd = ob ? LW : WC;                          // M = P⁻¹ [+ B′Q⁻¹B] + A′P⁻¹A
+            Msrc = PI;                                    // Λ(t0 + 1) = P⁻¹ [+ B′Q⁻¹B]
+            Mobs = ob ? LO : nullptr;
             continue;
         }
-        ok = o.inv_symadd(Cx, 1.0, Msrc, 1.0, Madd) && ok;            // C = (Λ + A′P⁻¹A)⁻¹
+        (void)obp;
+        ok = o.inv_symadd(Cx, 1.0, Msrc, 1.0, WC, Mobs) && ok;        // C = (Λ(t − 1) + A′P⁻¹A)⁻¹
         o.template mm<false, false, false>(Gt, KC, Cx);               // K C            (nobody reads it before the barrier of the next product)
         if (tid < D) cv[tid] = tab_col_dot<D>(Cx, tid, xi);           // c = C ξ   (C is symmetric: coalesced columns)
         o.template mm<false, false>(Y, Cx, Pc);                       // Y = C Ψ   (its barrier: c is visible, K C is stored)
@@ -161,10 +173,11 @@ __global__ void __launch_bounds__(64 * NT) km_elements(MsegParams p) {
         o.template mm<false, false, false>(Pn, KC, Y);                // Ψ′ = K Y  (into the other copy)
         o.template mm<false, true>(Lp, Gt, KC, -1.0, PI, 1.0);        // Λp = P⁻¹ − K C K′   (barrier: all three are stored)
         Msrc = Lp;
-        Madd = ob ? LW : WC;
+        Mobs = ob ? LO : nullptr;
         double* sw = Pc; Pc = Pn; Pn = sw;
     }
-    o.symadd(g, 1.0, Msrc, ob ? 1.0 : 0.0, LO);                       // Λ at the segment end = sym(Λp) [+ B′Q⁻¹B]
+    if (Mobs) o.symadd(g, 1.0, Msrc, 1.0, Mobs);                      // Λ at the segment end = sym(Λp) [+ B′Q⁻¹B]
+    else o.symadd(g, 1.0, Msrc, 0.0, Msrc);
     if (Pc != g + MM) o.lin(g + MM, 1.0, Pc);
     if (tid < D) {
         double* v = p.mvec + ((size_t)chain * p.S + seg) * 2 * D;
@@ -182,12 +195,32 @@ __global__ void __launch_bounds__(256) km_gy(MsegParams p) {
     const long long t = 1 + idx / D;
     const int i = (int)(idx - (t - 1) * D);
     if (t >= p.T) return;
-    const double* G = p.cw + (size_t)TabWs::G * D * D + (size_t)i * D;
+    const double* G = p.cw + (size_t)mseg_model(p, t) * (size_t)p.cw_stride + (size_t)TabWs::G * D * D + (size_t)i * D;
     const double* yt = p.y + (t * p.n_chains + chain) * dyu;
     double s = 0.0;
     if (p.obs[chain * p.T + t] != 0.0)
         for (int k = 0; k < dyu; ++k) s += G[k] * yt[k];
     p.filt[(chain * p.T + t) * p.rec + D + i] = s;
+}
+
+// per-step constants: what the free energy of a chain owes to constants alone, summed over its steps —
+// log|V1| + Σ_{t ≥ 1} log|P_t| + Σ_{t observed} (dy log 2π + log|Q_t|).  One workgroup per chain, fixed summation order.
+__global__ void __launch_bounds__(256) km_feconst(MsegParams p) {
+    __shared__ double red[256];
+    const long long chain = blockIdx.x;
+    double acc = 0.0;
+    for (long long t = threadIdx.x; t < p.T; t += 256) {
+        const double* cm = p.cst + (size_t)mseg_model(p, t) * (size_t)p.cst_stride;
+        if (t >= 1) acc += cm[p.oLDP];
+        if (p.obs[chain * p.T + t] != 0.0) acc += cm[p.oC0];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int n = 128; n > 0; n >>= 1) {
+        if ((int)threadIdx.x < n) red[threadIdx.x] += red[threadIdx.x + n];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) p.fe_const[chain] = red[0] + (p.cst + (size_t)mseg_model(p, 0) * (size_t)p.cst_stride)[p.oLDP + 1];
 }
 
 // Two segments in a row are one segment: stack the joints of (x_a, x_b) and (x_b, x_c) and eliminate x_b —
@@ -263,7 +296,9 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p, int level) {
     const int tid = o.tid, S = p.S, dyu = p.dy_user;
     const int dir = level == 3 ? (int)blockIdx.x / p.ng : (int)blockIdx.x, grp = level == 3 ? (int)blockIdx.x - dir * p.ng : 0;
     const long long chain = blockIdx.y;
-    auto CW = [&](int slot) { return p.cw + (size_t)slot * MM; };
+    const int m0i = mseg_model(p, 0);   // the prior and the first observation use the constants of step 0's model
+    auto CW = [&](int slot) { return p.cw + (size_t)m0i * (size_t)p.cw_stride + (size_t)slot * MM; };
+    const double* in0 = p.in + (size_t)m0i * (size_t)p.in_stride;
     // scratch: slots 8 … 13 of a block nobody else touches now — levels 0 / 2: block (2·chain + dir); level 3: the block of the group's first
     // segment, three slots per direction (the two directions of a group run side by side)
     double* W = p.ws + (level == 3 ? ((size_t)chain * S + (size_t)grp * p.sg) * MSEG_WS + 8 + 3 * dir : ((size_t)chain * 2 + dir) * MSEG_WS + 8) * MM;
@@ -282,10 +317,10 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p, int level) {
         if (level != 3) {
             // belief at t = 0: prior ⊗ observation message (if y_0 is observed)
             const bool ob0 = p.obs[chain * p.T] != 0.0;
-            const double* m1v = p.in + 5 * MM;   // m0; through the transition when the prior sits on x_0 of the reference's other spelling
+            const double* m1v = in0 + 5 * MM;   // m0; through the transition when the prior sits on x_0 of the reference's other spelling
             if (tid < D) {
                 double mm1 = m1v[tid];
-                if (p.ptt) mm1 = tab_row_dot<D>(p.in, tid, m1v);           // A m0
+                if (p.ptt) mm1 = tab_row_dot<D>(in0, tid, m1v);           // A m0
                 u[tid] = mm1;
                 tv[tid] = (ob0 && tid < dyu) ? p.y[(0 * p.n_chains + chain) * dyu + tid] : 0.0;
             }

@@ -122,17 +122,19 @@ __device__ __attribute__((noinline)) bool tab_inv(double* dst, const double* a, 
 // dst = (alpha·½(a + a′) + gamma·c)⁻¹: the symmetrised sum is formed in the accumulator registers on the way in (one building block less
 // in front of every inverse of the masked schedule)
 template <int NT>
-__device__ __attribute__((noinline)) bool tab_inv_symadd(double* dst0, double alpha, const double* a0, double gamma, const double* c0, double* lds, int w, int lane) {
+__device__ __attribute__((noinline)) bool tab_inv_symadd(double* dst0, double alpha, const double* a0, double gamma, const double* c0, const double* e0, double* lds, int w, int lane) {
     constexpr int D = 16 * NT;
     double* dst = as_global(dst0);
-    const double *a = as_global(a0), *c = as_global(c0);
+    const double *a = as_global(a0), *c = as_global(c0), *e3 = e0 ? as_global(e0) : nullptr;   // optional third term (+ sym(e))
     Acc<NT> acc;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
-            acc.v[t][r] = alpha * 0.5 * (a[i * D + j] + a[j * D + i]) + gamma * 0.5 * (c[i * D + j] + c[j * D + i]);
+            double v = alpha * 0.5 * (a[i * D + j] + a[j * D + i]) + gamma * 0.5 * (c[i * D + j] + c[j * D + i]);
+            if (e3) v += 0.5 * (e3[i * D + j] + e3[j * D + i]);
+            acc.v[t][r] = v;
         }
     LogProd lp;
     const bool ok = blk_inverse<NT>(acc, lds, w, lane, lp);
@@ -189,8 +191,8 @@ struct TabOps {
         tab_mm<NT, TA, TB, SYNC>(dst, a, b, alpha, c, beta, w, lane);
     }
     // dst = (alpha·sym(a) + gamma·sym(c))⁻¹
-    __device__ __forceinline__ bool inv_symadd(double* dst, double alpha, const double* a, double gamma, const double* c) const {
-        return tab_inv_symadd<NT>(dst, alpha, a, gamma, c, lds, w, lane);
+    __device__ __forceinline__ bool inv_symadd(double* dst, double alpha, const double* a, double gamma, const double* c, const double* e = nullptr) const {
+        return tab_inv_symadd<NT>(dst, alpha, a, gamma, c, e, lds, w, lane);
     }
     // dst = alpha·a + beta·op(b)   (elementwise; a, b may be null; dst may alias a, and b)
     __device__ __forceinline__ void lin(double* dst, double alpha, const double* a, double beta = 0.0, const double* b = nullptr, bool tb = false) const {
@@ -334,6 +336,7 @@ __global__ void __launch_bounds__(64 * NT) kt_consts(TabParams p) {
             cst[c.oPLWM + k] = pi + wc;
         }
     }
+    if (tid == 0) { cst[c.oLDP] = ldP; cst[c.oLDP + 1] = ldV1; }
     o.put(cst + c.oLOBS, D, 1, D, D, W(TabWs::LOBS));
     o.put(cst + c.oVF1, D, 1, D, D, W(TabWs::VF1));
     o.put(cst + c.oG, dy, 1, D, dy, W(TabWs::G));

@@ -371,6 +371,9 @@ struct rxhip_engine {
     // the per-chain array on request (the values do not depend on the data: one [T][d][d] table per model).  cov_pending: the last run left
     // the array to be materialised; cov_current: the array holds what a materialisation would write
     int m_sg = 0, m_ng = 0;          // masked schedule: groups of the two-level boundary recursion (0: one level)
+    int m_models = 1;                // masked schedule: constant blocks (per-step constants: desc.n_models, else 1)
+    bool m_stepm = false;            // per-step constants on the masked schedule
+    double* m_feconst = nullptr;
     double *m_grp = nullptr, *m_gvec = nullptr;
     int cov_mode = 0;
     bool cov_pending = false, cov_current = false;
@@ -1088,6 +1091,7 @@ struct DenseLaunch {
         for (const void* f : {(const void*)kd_agg_finish<NT>, (const void*)kd_scan_local<NT, true>, (const void*)kd_scan_local<NT, false>,
                               (const void*)kd_scan_fix<NT>, (const void*)kd_prepare_bnd<NT>, (const void*)kd_forward<NT, true>, (const void*)kd_forward<NT, false>,
                               (const void*)kd_forward_info<NT, true>, (const void*)kd_forward_info<NT, false>,
+                              (const void*)kd_forward_info<NT, true, true>, (const void*)kd_forward_info<NT, false, true>,
                               (const void*)kd_backward_info<NT, true>, (const void*)kd_backward_info<NT, false>, (const void*)kd_fe_resid,
                               (const void*)kd_fe_resid_mfma<NT>})
             if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
@@ -1130,6 +1134,14 @@ struct DenseLaunch {
         });
     }
     // information-form smoother (one inverse per step; free energy at the smoothed means)
+    static void forward_info_stepm(const DenseParams& p, bool fe, hipStream_t s) {   // per-step constants (masked schedule)
+        slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
+            dim3 g(q.S, nc);
+            const size_t lds = DenseLds<NT>::fwd_info_bytes(((q.d > q.dy ? q.d : q.dy) + 1) & ~1);
+            if (fe) hipLaunchKernelGGL((kd_forward_info<NT, true, true>), g, dim3(64 * NT), lds, s, q);
+            else hipLaunchKernelGGL((kd_forward_info<NT, false, true>), g, dim3(64 * NT), lds, s, q);
+        });
+    }
     static void forward_info(const DenseParams& p, bool fe, hipStream_t s, long long chains = -1) {
         const size_t lds = DenseLds<NT>::fwd_info_bytes(((p.d > p.dy ? p.d : p.dy) + 1) & ~1);
         slices(p, chains < 0 ? p.n_chains : chains, [&](const DenseParams& q, unsigned nc) {
@@ -1149,19 +1161,24 @@ struct DenseLaunch {
 };
 // free-energy residual terms of an information-form smoothing run: one workgroup per FR_STEPS steps, partial slots 2S…
 static int fe_resid_blocks(long long T, int d, int dy) { const int st = fe_resid_steps(d, dy); return (int)((T + st - 1) / st); }
-static void launch_fe_resid(const DenseParams& p, hipStream_t s) {
-    static const bool valu = std::getenv("RXHIP_FE_RESID_VALU") != nullptr;  // the round-2 form (vector FMAs), kept as a cross-check
+// passes > 1: per-step constants — one launch per model, each with its own partial slots, the columns of the other models masked
+static void launch_fe_resid(const DenseParams& p, hipStream_t s, int passes = 1) {
+    static const bool valu_env = std::getenv("RXHIP_FE_RESID_VALU") != nullptr;  // the round-2 form (vector FMAs), kept as a cross-check
+    const bool valu = valu_env && !p.step_model;
+    for (int pass = 0; pass < passes; ++pass)
     for (long long c0 = 0; c0 < p.n_chains; c0 += 32768) {  // grid.y holds 65 535 blocks
         DenseParams q = p;
         q.chain0 = c0;
+        q.model_sel = pass;
         const unsigned nc = (unsigned)(p.n_chains - c0 < 32768 ? p.n_chains - c0 : 32768);
         const dim3 g(fe_resid_blocks(p.T, p.d, p.dy), nc);
-        if (valu) { hipLaunchKernelGGL(kd_fe_resid, g, dim3(256), fe_resid_lds_bytes(p.d, p.dy), s, q, 2 * p.S); continue; }
+        const int slot0 = 2 * p.S + pass * (int)g.x;
+        if (valu) { hipLaunchKernelGGL(kd_fe_resid, g, dim3(256), fe_resid_lds_bytes(p.d, p.dy), s, q, slot0); continue; }
         switch (p.d / 16) {
-            case 1: hipLaunchKernelGGL(kd_fe_resid_mfma<1>, g, dim3(256), fe_resid_mfma_lds_bytes<1>(p.dy), s, q, 2 * p.S); break;
-            case 2: hipLaunchKernelGGL(kd_fe_resid_mfma<2>, g, dim3(256), fe_resid_mfma_lds_bytes<2>(p.dy), s, q, 2 * p.S); break;
-            case 3: hipLaunchKernelGGL(kd_fe_resid_mfma<3>, g, dim3(256), fe_resid_mfma_lds_bytes<3>(p.dy), s, q, 2 * p.S); break;
-            default: hipLaunchKernelGGL(kd_fe_resid_mfma<4>, g, dim3(256), fe_resid_mfma_lds_bytes<4>(p.dy), s, q, 2 * p.S); break;
+            case 1: hipLaunchKernelGGL(kd_fe_resid_mfma<1>, g, dim3(256), fe_resid_mfma_lds_bytes<1>(p.dy), s, q, slot0); break;
+            case 2: hipLaunchKernelGGL(kd_fe_resid_mfma<2>, g, dim3(256), fe_resid_mfma_lds_bytes<2>(p.dy), s, q, slot0); break;
+            case 3: hipLaunchKernelGGL(kd_fe_resid_mfma<3>, g, dim3(256), fe_resid_mfma_lds_bytes<3>(p.dy), s, q, slot0); break;
+            default: hipLaunchKernelGGL(kd_fe_resid_mfma<4>, g, dim3(256), fe_resid_mfma_lds_bytes<4>(p.dy), s, q, slot0); break;
         }
     }
 }
@@ -1227,8 +1244,15 @@ static hipError_t mseg_prepare_kernels() {
     return DenseLaunch<NT>::prepare();
 }
 static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
-    if (!ds->allow_missing || ds->step_model || ds->chain_model || ds->n_models != 1 || e->T < 2 || e->dy > e->dpad || std::getenv("RXHIP_GSEQ"))
+    // one model, or per-step constants shared by all chains (desc.step_model: the transition into step t and the observation at t use the
+    // constants of model step_model[t]) — with or without `missing` values; per-chain models keep the sequential schedule
+    const bool stepm = ds->step_model != nullptr && ds->n_models > 1;
+    if (!(ds->allow_missing || stepm) || ds->chain_model || (!stepm && ds->n_models != 1) || e->T < 2 || e->dy > e->dpad || std::getenv("RXHIP_GSEQ") ||
+        (stepm && std::getenv("RXHIP_STEPM_GSEQ")))
         return RXHIP_OK;
+    const size_t NM = stepm ? (size_t)ds->n_models : 1;
+    e->m_models = (int)NM;
+    e->m_stepm = stepm;
     const size_t D = (size_t)e->dpad, MM = D * D, C = (size_t)e->n_chains, T = (size_t)e->T;
     // segments: the element pass costs ≈2 boundary steps per time step, both are sequential chains -> S ≈ √(2T); many chains fill the
     // machine on their own, and the scratch of the element pass grows with chains × S
@@ -1276,43 +1300,57 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     const DenseCst cl = DenseCst::make((int)D, e->dy);
     const int rec = dense_rec(e->nt), tri = dense_tri(e->nt);
     const size_t nws = std::max<size_t>((size_t)C * (size_t)S, (size_t)2 * C) * MSEG_WS * MM;
-    const size_t parts[] = {5 * MM + D, TabWs::doubles((int)D, 1), (size_t)cl.size, C * T, C, C * S * 3 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
+    const size_t parts[] = {NM * (5 * MM + D), NM * TabWs::doubles((int)D, 1), NM * (size_t)cl.size, C * T, C, C * S * 3 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
                             C * T * (size_t)rec, C * S * (size_t)tri, C * S * D, C * (S + 1) * D,
-                            (2 * (size_t)S + 2 + (size_t)fe_resid_blocks(e->T, e->dpad, e->dy)) * C, C * NG * 3 * MM, C * NG * 2 * D};
-    size_t off[18] = {0};
-    for (int q = 0; q < 17; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
-    HIPCHK(e, hipMalloc(&e->mseg_block, off[17]));
+                            (2 * (size_t)S + 2 + NM * (size_t)fe_resid_blocks(e->T, e->dpad, e->dy)) * C, C * NG * 3 * MM, C * NG * 2 * D, C};
+    size_t off[19] = {0};
+    for (int q = 0; q < 18; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
+    HIPCHK(e, hipMalloc(&e->mseg_block, off[18]));
     auto at = [&](int q) { return (double*)(e->mseg_block + off[q]); };
     e->m_in = at(0); e->m_cw = at(1); e->m_cst = at(2); e->m_obs = at(3); e->m_nobs = at(4); e->m_el = at(5); e->m_vec = at(6); e->m_bnd = at(7);
     e->m_lb = at(8); e->m_ws = at(9); e->d_filt = at(10); e->d_vend = at(11); e->d_fstart_m = at(12); e->d_beta_xi = at(13); e->m_fe_part = at(14);
-    e->m_grp = at(15); e->m_gvec = at(16);
-    // the model padded to d×d (copies only) and its constant block, built on the device
-    std::vector<double> hin(5 * MM + D, 0.0);
+    e->m_grp = at(15); e->m_gvec = at(16); e->m_feconst = at(17);
+    // the models padded to d×d (copies only) and their constant blocks, built on the device (one kt_consts launch per model)
+    const size_t IN1 = 5 * MM + D, CW1 = TabWs::doubles((int)D, 1);
+    std::vector<double> hin(NM * IN1, 0.0);
     const int du = ds->d, dyu = ds->dy;
-    for (int i = 0; i < (int)D; ++i)
-        for (int j = 0; j < (int)D; ++j) {
-            const bool in = i < du && j < du;
-            hin[(size_t)i * D + j] = in ? ds->A[(size_t)i * du + j] : 0.0;
-            hin[MM + (size_t)i * D + j] = in ? ds->P[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
-            hin[2 * MM + (size_t)i * D + j] = in ? ds->V0[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
-            hin[3 * MM + (size_t)i * D + j] = (i < dyu && j < du) ? ds->B[(size_t)i * du + j] : 0.0;
-            hin[4 * MM + (size_t)i * D + j] = (i < dyu && j < dyu) ? ds->Q[(size_t)i * dyu + j] : (i == j && i >= dyu ? 1.0 : 0.0);
-        }
-    for (int i = 0; i < du; ++i) hin[5 * MM + i] = ds->m0[i];
+    for (size_t m = 0; m < NM; ++m) {
+        double* h = hin.data() + m * IN1;
+        const double *Am = ds->A + m * (size_t)du * du, *Pm = ds->P + m * (size_t)du * du, *Vm = ds->V0 + m * (size_t)du * du;
+        const double *Bm = ds->B + m * (size_t)dyu * du, *Qm = ds->Q + m * (size_t)dyu * dyu, *m0m = ds->m0 + m * (size_t)du;
+        for (int i = 0; i < (int)D; ++i)
+            for (int j = 0; j < (int)D; ++j) {
+                const bool in = i < du && j < du;
+                h[(size_t)i * D + j] = in ? Am[(size_t)i * du + j] : 0.0;
+                h[MM + (size_t)i * D + j] = in ? Pm[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
+                h[2 * MM + (size_t)i * D + j] = in ? Vm[(size_t)i * du + j] : (i == j ? 1.0 : 0.0);
+                h[3 * MM + (size_t)i * D + j] = (i < dyu && j < du) ? Bm[(size_t)i * du + j] : 0.0;
+                h[4 * MM + (size_t)i * D + j] = (i < dyu && j < dyu) ? Qm[(size_t)i * dyu + j] : (i == j && i >= dyu ? 1.0 : 0.0);
+            }
+        for (int i = 0; i < du; ++i) h[5 * MM + i] = m0m[i];
+    }
     HIPCHK(e, hipMemcpyAsync(e->m_in, hin.data(), sizeof(double) * hin.size(), hipMemcpyHostToDevice, e->stream));
-    HIPCHK(e, hipMemsetAsync(e->m_cst, 0, sizeof(double) * (size_t)cl.size, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->m_cst, 0, sizeof(double) * NM * (size_t)cl.size, e->stream));
     HIPCHK(e, hipMemsetAsync(e->m_fe_part, 0, sizeof(double) * parts[14], e->stream));
     HIPCHK(e, hipMemsetAsync(e->d_filt, 0, sizeof(double) * parts[10], e->stream));
-    TabParams tp{};
-    tp.d = (int)D; tp.dy = e->dy; tp.ptt = e->ptt; tp.T = e->T; tp.L = 1; tp.Llast = 1; tp.S = 0; tp.sg = 1; tp.ng = 1;
-    tp.in = e->m_in; tp.ws = e->m_cw; tp.cst = e->m_cst; tp.status = e->d_status;
     hipError_t herr = hipSuccess;
     const size_t lds_c = sizeof(double) * (size_t)(blk_scratch_doubles(e->nt) + 2 * 64 * e->nt + 16 + D * (D + 1));
     switch (e->nt) {
-        case 1: herr = mseg_prepare_kernels<1>(); if (!herr) hipLaunchKernelGGL((kt_consts<1>), dim3(1), dim3(64), lds_c, e->stream, tp); break;
-        case 2: herr = mseg_prepare_kernels<2>(); if (!herr) hipLaunchKernelGGL((kt_consts<2>), dim3(1), dim3(128), lds_c, e->stream, tp); break;
-        case 3: herr = mseg_prepare_kernels<3>(); if (!herr) hipLaunchKernelGGL((kt_consts<3>), dim3(1), dim3(192), lds_c, e->stream, tp); break;
-        default: herr = mseg_prepare_kernels<4>(); if (!herr) hipLaunchKernelGGL((kt_consts<4>), dim3(1), dim3(256), lds_c, e->stream, tp); break;
+        case 1: herr = mseg_prepare_kernels<1>(); break;
+        case 2: herr = mseg_prepare_kernels<2>(); break;
+        case 3: herr = mseg_prepare_kernels<3>(); break;
+        default: herr = mseg_prepare_kernels<4>(); break;
+    }
+    for (size_t m = 0; m < NM && !herr; ++m) {
+        TabParams tp{};
+        tp.d = (int)D; tp.dy = e->dy; tp.ptt = e->ptt; tp.T = e->T; tp.L = 1; tp.Llast = 1; tp.S = 0; tp.sg = 1; tp.ng = 1;
+        tp.in = e->m_in + m * IN1; tp.ws = e->m_cw + m * CW1; tp.cst = e->m_cst + m * (size_t)cl.size; tp.status = e->d_status;
+        switch (e->nt) {
+            case 1: hipLaunchKernelGGL((kt_consts<1>), dim3(1), dim3(64), lds_c, e->stream, tp); break;
+            case 2: hipLaunchKernelGGL((kt_consts<2>), dim3(1), dim3(128), lds_c, e->stream, tp); break;
+            case 3: hipLaunchKernelGGL((kt_consts<3>), dim3(1), dim3(192), lds_c, e->stream, tp); break;
+            default: hipLaunchKernelGGL((kt_consts<4>), dim3(1), dim3(256), lds_c, e->stream, tp); break;
+        }
     }
     if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "mseg: kernel preparation failed: %s", hipGetErrorString(herr));
     HIPCHK(e, hipGetLastError());
@@ -1335,7 +1373,11 @@ static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams
     } else
         hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 0);
     if (mp.S > 1) hipLaunchKernelGGL((km_bnd<NT>), dim3((unsigned)(mp.S - 1), (unsigned)mp.n_chains), dim3(64 * NT), sizeof(double) * blk_scratch_doubles(NT), s, mp);
-    DenseLaunch<NT>::forward_info(dp, fe, s);
+    if (mp.step_model) {
+        if (fe) hipLaunchKernelGGL(km_feconst, dim3((unsigned)mp.n_chains), dim3(256), 0, s, mp);
+        DenseLaunch<NT>::forward_info_stepm(dp, fe, s);
+    } else
+        DenseLaunch<NT>::forward_info(dp, fe, s);
     DenseLaunch<NT>::backward_info(dp, fe, s);
 }
 static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
@@ -1345,12 +1387,17 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
     mp.mbnd = e->m_bnd; mp.mlb = e->m_lb; mp.fstart_m = e->d_fstart_m; mp.beta_xi = e->d_beta_xi; mp.filt = e->d_filt; mp.rec = dense_rec(e->nt);
     mp.status = e->d_status;
     mp.sg = e->m_sg; mp.ng = e->m_ng; mp.mgrp = e->m_grp; mp.mgvec = e->m_gvec;
+    const DenseCst clm = DenseCst::make(e->dpad, e->dy);
+    mp.step_model = e->m_stepm ? e->d_step_model : nullptr;
+    mp.in_stride = 5LL * e->dpad * e->dpad + e->dpad; mp.cw_stride = (long long)TabWs::doubles(e->dpad, 1); mp.cst_stride = clm.size;
+    mp.cst = e->m_cst; mp.fe_const = e->m_feconst; mp.oC0 = (int)clm.oC0; mp.oLDP = (int)clm.oLDP;
     DenseParams dp{};
     dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->mS; dp.L = e->mL; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy; dp.pack = 1; dp.d_sub = 8; dp.dy_sub = e->dy;
     dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->m_cst;
     dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi; dp.fe_part = e->m_fe_part; dp.status = e->d_status;
     dp.mseg = 2;   // 2: the boundary vector of a segment is the information vector ξ_f(b_s), not the mean
     dp.obs = e->m_obs; dp.nobs = e->m_nobs; dp.mbnd = e->m_bnd;
+    dp.step_model = mp.step_model; dp.cst_stride = clm.size; dp.fe_const = e->m_feconst; dp.model_sel = 0;
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
     switch (e->nt) {
@@ -1360,7 +1407,7 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
         default: mseg_launch<4>(e, mp, dp, fe); break;
     }
     if ((st = prof_end(e))) return st;
-    if (fe) launch_fe_resid(dp, e->stream);
+    if (fe) launch_fe_resid(dp, e->stream, e->m_stepm ? e->m_models : 1);
     return RXHIP_OK;
 }
 
@@ -1455,6 +1502,8 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
         for (int r = 0; r < dy; ++r)
             for (int k = 0; k < d; ++k) cst[c.oBT + (size_t)k * dy + r] = B[(size_t)r * d + k];
         cst[c.oFEC] = 0.5 * (ldV1 + (double)(e->T - 1) * ldP + (double)e->T * (dy * 1.8378770664093454835606594728112 + ldQ));
+        cst[c.oLDP] = ldP;
+        cst[c.oLDP + 1] = ldV1;
         // whitening maps of the residual forms (kd_fe_resid_mfma): [L_P⁻¹ | −L_P⁻¹A], [L_Q⁻¹ | −L_Q⁻¹B] (zero-padded)
         std::vector<double> LPi(MM), LPiA(MM), LQi((size_t)dy * dy), LQiB((size_t)dy * d);
         if (!host::chol_linv(d, P, LPi.data())) return fail(e, RXHIP_ERR_NOT_POSDEF, "state noise P is not positive definite");
@@ -3437,7 +3486,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             Params pr = p;
             if (mseg_now) {   // slots of kd_forward_info / kd_backward_info / kd_fe_resid over the mseg segments
                 pr.fe_part = e->m_fe_part;
-                pr.S = 2 * e->mS - 1 + fe_resid_blocks(e->T, e->dpad, e->dy);
+                pr.S = 2 * e->mS - 1 + (e->m_stepm ? e->m_models : 1) * fe_resid_blocks(e->T, e->dpad, e->dy);
             }
             if (e->dense && !e->gseq && !filter && e->S > 0) {
                 // residual quadratic forms at the smoothed means (parallel over all steps), then 2S partial slots of

@@ -1,0 +1,32 @@
+"""Per-step constants (desc.step_model) at d > 4: the masked MFMA schedule against the sequential one (RXHIP_STEPM_GSEQ=1)."""
+import os, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rxinfer.jl_amd"))
+import numpy as np
+import rxhip
+from rxhip import workloads
+
+
+def med(eng, n=5):
+    eng.run(free_energy=True)
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter(); eng.run(free_energy=True); ts.append((time.perf_counter() - t0) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
+for d, C, T, M in ((64, 1, 2000, 4), (64, 256, 200, 4), (8, 1024, 1000, 4), (16, 1, 5000, 8)):
+    ms = [workloads.random_model(d, d, seed=d + 7 * m) for m in range(M)]
+    mdl = tuple(np.stack([m[k] for m in ms]) for k in ("A", "B", "P", "Q", "m0", "V0"))
+    sm = np.random.default_rng(0).integers(0, M, T).astype(np.int32)
+    y = np.random.default_rng(1).standard_normal((T, C, d))
+    out = []
+    for env in (None, "1"):
+        if env:
+            os.environ["RXHIP_STEPM_GSEQ"] = env
+        else:
+            os.environ.pop("RXHIP_STEPM_GSEQ", None)
+        with rxhip.LGSSMEngine(*mdl, T=T, n_chains=C, step_model=sm) as eng:
+            eng.set_data(y)
+            out.append((med(eng, 5 if env is None else 1), eng.free_energy()[-1]))
+    os.environ.pop("RXHIP_STEPM_GSEQ", None)
+    print(f"d=dy={d} chains={C} T={T} models={M}: masked MFMA schedule {out[0][0]:.2f} ms | sequential {out[1][0]:.2f} ms = {out[1][0] / out[0][0]:.0f}x | FE {out[0][1]:.6f} / {out[1][1]:.6f}", flush=True)

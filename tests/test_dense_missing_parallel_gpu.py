@@ -138,3 +138,47 @@ def test_random_masked_case_against_the_sequential_schedule(case, monkeypatch):
     assert np.max(np.abs(mp - ms) / sd) < 1e-6
     assert np.max(np.abs(cp - cs) / (sd[..., :, None] * sd[..., None, :])) < 1e-6
     assert np.allclose(fp, fs, rtol=1e-8, atol=1e-9)
+
+
+def _step_models(d, dy, M, seed):
+    from rxhip import workloads
+    ms = [workloads.random_model(d, dy, seed=seed + 7 * m) for m in range(M)]
+    return tuple(np.stack([m[k] for m in ms]) for k in ("A", "B", "P", "Q", "m0", "V0"))
+
+
+@pytest.mark.parametrize("d,dy,T,C,M,ptt,rate,segments", [(24, 6, 300, 2, 3, False, 0.15, 0), (64, 64, 120, 1, 2, True, 0.0, 0), (16, 16, 500, 1, 5, False, 0.3, 0),
+                                                            (40, 12, 90, 300, 4, False, 0.1, 0), (8, 8, 64, 3, 64, True, 0.2, 7)])
+def test_per_step_constants_on_the_masked_schedule(d, dy, T, C, M, ptt, rate, segments, monkeypatch):
+    """A[t], P[t], B[t], Q[t] (desc.step_model) at d > 4: the transition into step t and the observation at t use the constants of model
+    step_model[t] — in the segment elements, the sweep kernel (kd_forward_info<…, STEPM>), the residual forms (one pass per model) and the
+    free-energy constant (km_feconst).  Against the oracle and against the sequential schedule (RXHIP_STEPM_GSEQ)."""
+    import rxhip
+    import rxoracle as rxo
+    mdl = _step_models(d, dy, M, seed=500 + d)
+    rng = np.random.default_rng(d + T)
+    sm = rng.integers(0, M, T).astype(np.int32)
+    sm[:3] = [M - 1, 0, M - 1]
+    y = rng.standard_normal((T, C, dy)) * 2.0
+    if rate > 0:
+        y[rng.random((T, C)) < rate] = np.nan
+    out = {}
+    for name, env in (("masked", None), ("sequential", "1")):
+        if env:
+            monkeypatch.setenv("RXHIP_STEPM_GSEQ", env)
+        else:
+            monkeypatch.delenv("RXHIP_STEPM_GSEQ", raising=False)
+        with rxhip.LGSSMEngine(*mdl, T=T, n_chains=C, prior_through_transition=ptt, step_model=sm, allow_missing=rate > 0, segments=segments) as eng:
+            eng.set_data(y)
+            eng.run(1, True)
+            out[name] = eng.marginals() + (eng.free_energy_per_chain(),)
+    mm, cm, fm = out["masked"]
+    ms, cs, fs = out["sequential"]
+    sd = np.sqrt(np.einsum("tcii->tci", cs))
+    assert np.max(np.abs(mm - ms) / sd) < 1e-6
+    assert np.max(np.abs(cm - cs) / (sd[..., :, None] * sd[..., None, :])) < 1e-6
+    assert np.allclose(fm, fs, rtol=1e-8, atol=1e-9)
+    for c in (0, C - 1):
+        om, oc, nll = rxo.lgssm_kalman_rts_affine(*mdl, np.ascontiguousarray(y[:, c]), step_model=sm, prior_through_transition=ptt)
+        sdo = np.sqrt(np.einsum("tii->ti", oc))
+        assert np.max(np.abs(mm[:, c] - om) / sdo) < 1e-6
+        assert fm[c] == pytest.approx(nll, rel=1e-8, abs=1e-9)
