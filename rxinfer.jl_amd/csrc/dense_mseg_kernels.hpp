@@ -24,7 +24,10 @@
 // The matrix products are the non-inlined blocks of dense_tab_kernels.hpp (operands in L2): 5–8 µs per call whatever it computes — a
 // coverage path that is two to three orders of magnitude faster than the sequential one (d = 64, T = 2000, one chain: 2.4 ms against
 // 690), not a roofline path.  The algebra is restated in numpy in tests/test_mseg_information_form.py.
-// Scope: one model per engine (chain_model / step_model engines keep the sequential schedule), smoothing runs, dy ≤ padded d.
+// Per-step constants (desc.step_model): the same kernels with the constant block of model step_model[t] per step (MsegParams::step_model,
+// kd_forward_info<…, STEPM>, one residual pass per model, km_feconst).
+// Scope: one model per engine or per-step constants shared by all chains (chain_model engines keep the sequential schedule), smoothing
+// runs, dy ≤ padded d.
 #pragma once
 #include "dense_tab_kernels.hpp"
 
