@@ -59,12 +59,17 @@ struct MsegParams {
     // per-step constants (desc.step_model; null: one model): time index t uses block step_model[t] of `in`, `cw` and of the constant
     // blocks `cst` (strides in doubles); fe_const[chain]: the data-independent part of the free energy, summed over the chain's steps
     const int* step_model;
+    const int* chain_model; // [chain] one model per chain (exclusive with step_model)
     long long in_stride, cw_stride, cst_stride;
     const double* cst;
     double* fe_const;
     int oC0, oLDP;          // DenseCst offsets of dy log 2π + log|Q| and of log|P|, log|V1|
 };
-__device__ __forceinline__ int mseg_model(const MsegParams& p, long long t) { return p.step_model ? p.step_model[t < p.T ? t : p.T - 1] : 0; }
+// the constant block of (chain, time index): per-step constants shared by all chains, or one model per chain (desc.chain_model), or block 0
+__device__ __forceinline__ int mseg_model(const MsegParams& p, long long chain, long long t) {
+    if (p.step_model) return p.step_model[t < p.T ? t : p.T - 1];
+    return p.chain_model ? p.chain_model[chain] : 0;
+}
 constexpr int MSEG_WS = 14;
 
 // grid (blocks over time, chains); nobs[chain] must be zero on entry (mseg_launch clears it): exact integer counts, any order
@@ -141,7 +146,7 @@ __global__ void __launch_bounds__(64 * NT) km_elements(MsegParams p) {
     // consumes them (inv_symadd).  Step t's transition and observation use the constants of model step_model[t] (one model: block 0).
     const double *Msrc = nullptr, *Mobs = nullptr;
     for (long long t = t0 + 1; t <= t1; ++t) {
-        const int a = mseg_model(p, t);
+        const int a = mseg_model(p, chain, t);
         const double *PI = CW(a, TabWs::PINV), *KC = CW(a, TabWs::KC), *WC = CW(a, TabWs::WC), *LO = CW(a, TabWs::LOBS), *G = CW(a, TabWs::G);
         const bool obp = ob;                  // was the previous step observed
         ob = p.obs[chain * p.T + t] != 0.0;   // uniform
@@ -198,7 +203,7 @@ __global__ void __launch_bounds__(256) km_gy(MsegParams p) {
     const long long t = 1 + idx / D;
     const int i = (int)(idx - (t - 1) * D);
     if (t >= p.T) return;
-    const double* G = p.cw + (size_t)mseg_model(p, t) * (size_t)p.cw_stride + (size_t)TabWs::G * D * D + (size_t)i * D;
+    const double* G = p.cw + (size_t)mseg_model(p, chain, t) * (size_t)p.cw_stride + (size_t)TabWs::G * D * D + (size_t)i * D;
     const double* yt = p.y + (t * p.n_chains + chain) * dyu;
     double s = 0.0;
     if (p.obs[chain * p.T + t] != 0.0)
@@ -213,7 +218,7 @@ __global__ void __launch_bounds__(256) km_feconst(MsegParams p) {
     const long long chain = blockIdx.x;
     double acc = 0.0;
     for (long long t = threadIdx.x; t < p.T; t += 256) {
-        const double* cm = p.cst + (size_t)mseg_model(p, t) * (size_t)p.cst_stride;
+        const double* cm = p.cst + (size_t)mseg_model(p, chain, t) * (size_t)p.cst_stride;
         if (t >= 1) acc += cm[p.oLDP];
         if (p.obs[chain * p.T + t] != 0.0) acc += cm[p.oC0];
     }
@@ -223,7 +228,7 @@ __global__ void __launch_bounds__(256) km_feconst(MsegParams p) {
         if ((int)threadIdx.x < n) red[threadIdx.x] += red[threadIdx.x + n];
         __syncthreads();
     }
-    if (threadIdx.x == 0) p.fe_const[chain] = red[0] + (p.cst + (size_t)mseg_model(p, 0) * (size_t)p.cst_stride)[p.oLDP + 1];
+    if (threadIdx.x == 0) p.fe_const[chain] = red[0] + (p.cst + (size_t)mseg_model(p, chain, 0) * (size_t)p.cst_stride)[p.oLDP + 1];
 }
 
 // Two segments in a row are one segment: stack the joints of (x_a, x_b) and (x_b, x_c) and eliminate x_b —
@@ -299,7 +304,7 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p, int level) {
     const int tid = o.tid, S = p.S, dyu = p.dy_user;
     const int dir = level == 3 ? (int)blockIdx.x / p.ng : (int)blockIdx.x, grp = level == 3 ? (int)blockIdx.x - dir * p.ng : 0;
     const long long chain = blockIdx.y;
-    const int m0i = mseg_model(p, 0);   // the prior and the first observation use the constants of step 0's model
+    const int m0i = mseg_model(p, chain, 0);   // the prior and the first observation use the constants of step 0's model
     auto CW = [&](int slot) { return p.cw + (size_t)m0i * (size_t)p.cw_stride + (size_t)slot * MM; };
     const double* in0 = p.in + (size_t)m0i * (size_t)p.in_stride;
     // scratch: slots 8 … 13 of a block nobody else touches now — levels 0 / 2: block (2·chain + dir); level 3: the block of the group's first

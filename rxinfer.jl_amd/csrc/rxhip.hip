@@ -373,6 +373,8 @@ struct rxhip_engine {
     int m_sg = 0, m_ng = 0;          // masked schedule: groups of the two-level boundary recursion (0: one level)
     int m_models = 1;                // masked schedule: constant blocks (per-step constants: desc.n_models, else 1)
     bool m_stepm = false;            // per-step constants on the masked schedule
+    bool m_chainm = false;           // one model per chain on the masked schedule
+    DenseModel* m_modtab = nullptr;  // [m_models] constant-block pointers for the sweep kernels (one model per chain)
     double* m_feconst = nullptr;
     double *m_grp = nullptr, *m_gvec = nullptr;
     int cov_mode = 0;
@@ -1247,10 +1249,12 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     // one model, or per-step constants shared by all chains (desc.step_model: the transition into step t and the observation at t use the
     // constants of model step_model[t]) — with or without `missing` values; per-chain models keep the sequential schedule
     const bool stepm = ds->step_model != nullptr && ds->n_models > 1;
-    if (!(ds->allow_missing || stepm) || ds->chain_model || (!stepm && ds->n_models != 1) || e->T < 2 || e->dy > e->dpad || std::getenv("RXHIP_GSEQ") ||
-        (stepm && std::getenv("RXHIP_STEPM_GSEQ")))
+    const bool chainm = !stepm && ds->chain_model != nullptr && ds->n_models > 1;   // one model per chain (with `missing` values: else the fully observed MFMA path has them)
+    if (!(ds->allow_missing || stepm) || (ds->chain_model && !chainm) || (!stepm && !chainm && ds->n_models != 1) || e->T < 2 || e->dy > e->dpad ||
+        std::getenv("RXHIP_GSEQ") || ((stepm || chainm) && std::getenv("RXHIP_STEPM_GSEQ")))
         return RXHIP_OK;
-    const size_t NM = stepm ? (size_t)ds->n_models : 1;
+    const size_t NM = (stepm || chainm) ? (size_t)ds->n_models : 1;
+    e->m_chainm = chainm;
     e->m_models = (int)NM;
     e->m_stepm = stepm;
     const size_t D = (size_t)e->dpad, MM = D * D, C = (size_t)e->n_chains, T = (size_t)e->T;
@@ -1302,14 +1306,15 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     const size_t nws = std::max<size_t>((size_t)C * (size_t)S, (size_t)2 * C) * MSEG_WS * MM;
     const size_t parts[] = {NM * (5 * MM + D), NM * TabWs::doubles((int)D, 1), NM * (size_t)cl.size, C * T, C, C * S * 3 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
                             C * T * (size_t)rec, C * S * (size_t)tri, C * S * D, C * (S + 1) * D,
-                            (2 * (size_t)S + 2 + NM * (size_t)fe_resid_blocks(e->T, e->dpad, e->dy)) * C, C * NG * 3 * MM, C * NG * 2 * D, C};
-    size_t off[19] = {0};
-    for (int q = 0; q < 18; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
-    HIPCHK(e, hipMalloc(&e->mseg_block, off[18]));
+                            (2 * (size_t)S + 2 + NM * (size_t)fe_resid_blocks(e->T, e->dpad, e->dy)) * C, C * NG * 3 * MM, C * NG * 2 * D, C,
+                            NM * ((sizeof(DenseModel) + 7) / 8)};
+    size_t off[20] = {0};
+    for (int q = 0; q < 19; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
+    HIPCHK(e, hipMalloc(&e->mseg_block, off[19]));
     auto at = [&](int q) { return (double*)(e->mseg_block + off[q]); };
     e->m_in = at(0); e->m_cw = at(1); e->m_cst = at(2); e->m_obs = at(3); e->m_nobs = at(4); e->m_el = at(5); e->m_vec = at(6); e->m_bnd = at(7);
     e->m_lb = at(8); e->m_ws = at(9); e->d_filt = at(10); e->d_vend = at(11); e->d_fstart_m = at(12); e->d_beta_xi = at(13); e->m_fe_part = at(14);
-    e->m_grp = at(15); e->m_gvec = at(16); e->m_feconst = at(17);
+    e->m_grp = at(15); e->m_gvec = at(16); e->m_feconst = at(17); e->m_modtab = reinterpret_cast<DenseModel*>(at(18));
     // the models padded to d×d (copies only) and their constant blocks, built on the device (one kt_consts launch per model)
     const size_t IN1 = 5 * MM + D, CW1 = TabWs::doubles((int)D, 1);
     std::vector<double> hin(NM * IN1, 0.0);
@@ -1352,6 +1357,9 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
             default: hipLaunchKernelGGL((kt_consts<4>), dim3(1), dim3(256), lds_c, e->stream, tp); break;
         }
     }
+    std::vector<DenseModel> hmod(NM);
+    for (size_t m = 0; m < NM; ++m) hmod[m] = DenseModel{e->m_cst + m * (size_t)cl.size, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (!herr) herr = hipMemcpyAsync(e->m_modtab, hmod.data(), sizeof(DenseModel) * NM, hipMemcpyHostToDevice, e->stream);
     if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "mseg: kernel preparation failed: %s", hipGetErrorString(herr));
     HIPCHK(e, hipGetLastError());
     HIPCHK(e, hipStreamSynchronize(e->stream));   // hin dies here
@@ -1389,6 +1397,7 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
     mp.sg = e->m_sg; mp.ng = e->m_ng; mp.mgrp = e->m_grp; mp.mgvec = e->m_gvec;
     const DenseCst clm = DenseCst::make(e->dpad, e->dy);
     mp.step_model = e->m_stepm ? e->d_step_model : nullptr;
+    mp.chain_model = e->m_chainm ? e->d_chain_model : nullptr;
     mp.in_stride = 5LL * e->dpad * e->dpad + e->dpad; mp.cw_stride = (long long)TabWs::doubles(e->dpad, 1); mp.cst_stride = clm.size;
     mp.cst = e->m_cst; mp.fe_const = e->m_feconst; mp.oC0 = (int)clm.oC0; mp.oLDP = (int)clm.oLDP;
     DenseParams dp{};
@@ -1398,6 +1407,7 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
     dp.mseg = 2;   // 2: the boundary vector of a segment is the information vector ξ_f(b_s), not the mean
     dp.obs = e->m_obs; dp.nobs = e->m_nobs; dp.mbnd = e->m_bnd;
     dp.step_model = mp.step_model; dp.cst_stride = clm.size; dp.fe_const = e->m_feconst; dp.model_sel = 0;
+    if (e->m_chainm) { dp.models = e->m_modtab; dp.chain_model = e->d_chain_model; }   // the sweep kernels' own per-chain lookup (dense_model)
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
     switch (e->nt) {

@@ -182,3 +182,38 @@ def test_per_step_constants_on_the_masked_schedule(d, dy, T, C, M, ptt, rate, se
         sdo = np.sqrt(np.einsum("tii->ti", oc))
         assert np.max(np.abs(mm[:, c] - om) / sdo) < 1e-6
         assert fm[c] == pytest.approx(nll, rel=1e-8, abs=1e-9)
+
+
+@pytest.mark.parametrize("d,dy,T,C,M,segments", [(9, 4, 150, 6, 6, 0), (64, 20, 80, 3, 2, 5), (16, 16, 300, 300, 7, 0)])
+def test_one_model_per_chain_with_missing_observations_on_the_masked_schedule(d, dy, T, C, M, segments, monkeypatch):
+    """desc.chain_model with `missing` values at d > 4: every chain's elements, prior and sweep use ITS model's constant blocks"""
+    import rxhip
+    import rxoracle as rxo
+    mdl = _step_models(d, dy, M, seed=700 + d)
+    rng = np.random.default_rng(d * T)
+    cm = rng.integers(0, M, C).astype(np.int32)
+    cm[0], cm[-1] = M - 1, 0
+    y = rng.standard_normal((T, C, dy)) * 2.0
+    y[rng.random((T, C)) < 0.2] = np.nan
+    out = {}
+    for name, env in (("masked", None), ("sequential", "1")):
+        if env:
+            monkeypatch.setenv("RXHIP_STEPM_GSEQ", env)
+        else:
+            monkeypatch.delenv("RXHIP_STEPM_GSEQ", raising=False)
+        with rxhip.LGSSMEngine(*mdl, T=T, n_chains=C, chain_model=cm, allow_missing=True, segments=segments) as eng:
+            eng.set_data(y)
+            eng.run(1, True)
+            out[name] = eng.marginals() + (eng.free_energy_per_chain(),)
+    mm, cmv, fm = out["masked"]
+    ms, cs, fs = out["sequential"]
+    sd = np.sqrt(np.einsum("tcii->tci", cs))
+    assert np.max(np.abs(mm - ms) / sd) < 1e-6
+    assert np.max(np.abs(cmv - cs) / (sd[..., :, None] * sd[..., None, :])) < 1e-6
+    assert np.allclose(fm, fs, rtol=1e-8, atol=1e-9)
+    for c in (0, C - 1):
+        one = tuple(a[cm[c]] for a in mdl)
+        om, oc, nll = rxo.lgssm_kalman_rts(*one, np.ascontiguousarray(y[:, c]))
+        sdo = np.sqrt(np.einsum("tii->ti", oc))
+        assert np.max(np.abs(mm[:, c] - om) / sdo) < 1e-6
+        assert fm[c] == pytest.approx(nll, rel=1e-8, abs=1e-9)
