@@ -217,3 +217,42 @@ def test_one_model_per_chain_with_missing_observations_on_the_masked_schedule(d,
         sdo = np.sqrt(np.einsum("tii->ti", oc))
         assert np.max(np.abs(mm[:, c] - om) / sdo) < 1e-6
         assert fm[c] == pytest.approx(nll, rel=1e-8, abs=1e-9)
+
+
+def _random_step_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    for i in range(n):
+        d = int(rng.choice([5, 8, 16, 24, 32, 48, 64]))
+        dy = int(rng.integers(1, d + 1))
+        T = int(rng.integers(2, 360))
+        yield dict(i=i, d=d, dy=dy, T=T, C=int(rng.choice([1, 1, 2, 5])), M=int(rng.choice([2, 3, 7, max(2, T // 2)])),
+                   segments=int(rng.choice([0, 0, 1, 3, 19])) if T > 40 else 0, ptt=bool(rng.integers(0, 2)), rate=float(rng.choice([0.0, 0.1, 0.5])))
+
+
+@pytest.mark.parametrize("case", list(_random_step_cases(10 + int(os.environ.get("RXHIP_STRESS", "0")), 4242)),
+                         ids=lambda c: f"{c['i']}-d{c['d']}x{c['dy']}-T{c['T']}-C{c['C']}-M{c['M']}-s{c['segments']}-{'ptt' if c['ptt'] else 'x1'}-{c['rate']}")
+def test_random_per_step_constants_case_against_the_sequential_schedule(case, monkeypatch):
+    import rxhip
+    d, dy, T, C, M = case["d"], case["dy"], case["T"], case["C"], case["M"]
+    mdl = _step_models(d, dy, M, seed=3000 + case["i"])
+    rng = np.random.default_rng(case["i"])
+    sm = rng.integers(0, M, T).astype(np.int32)
+    y = rng.standard_normal((T, C, dy)) * 2.0
+    if case["rate"] > 0:
+        y[rng.random((T, C)) < case["rate"]] = np.nan
+    out = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("RXHIP_STEPM_GSEQ", env)
+        else:
+            monkeypatch.delenv("RXHIP_STEPM_GSEQ", raising=False)
+        with rxhip.LGSSMEngine(*mdl, T=T, n_chains=C, prior_through_transition=case["ptt"], step_model=sm, allow_missing=case["rate"] > 0,
+                               segments=min(case["segments"], T - 1)) as eng:
+            eng.set_data(y)
+            eng.run(1, True)
+            out.append(eng.marginals() + (eng.free_energy_per_chain(),))
+    (mm, cm, fm), (ms, cs, fs) = out
+    sd = np.sqrt(np.einsum("tcii->tci", cs))
+    assert np.max(np.abs(mm - ms) / sd) < 1e-6
+    assert np.max(np.abs(cm - cs) / (sd[..., :, None] * sd[..., None, :])) < 1e-6
+    assert np.allclose(fm, fs, rtol=1e-8, atol=1e-9)
