@@ -1304,7 +1304,9 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     const DenseCst cl = DenseCst::make((int)D, e->dy);
     const int rec = dense_rec(e->nt), tri = dense_tri(e->nt);
     const size_t nws = std::max<size_t>((size_t)C * (size_t)S, (size_t)2 * C) * MSEG_WS * MM;
-    const size_t parts[] = {NM * (5 * MM + D), NM * TabWs::doubles((int)D, 1), NM * (size_t)cl.size, C * T, C, C * S * 3 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
+    static_assert(TabWs::T6 == 15, "kt_consts works in the first 16 workspace slots");
+    const size_t CWN = 16 * MM;   // kt_consts touches the named slots up to TabWs::T6 only: 16 matrices per model (the table builder's workspace has 83)
+    const size_t parts[] = {NM * (5 * MM + D), NM * CWN, NM * (size_t)cl.size, C * T, C, C * S * 3 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
                             C * T * (size_t)rec, C * S * (size_t)tri, C * S * D, C * (S + 1) * D,
                             (2 * (size_t)S + 2 + NM * (size_t)fe_resid_blocks(e->T, e->dpad, e->dy)) * C, C * NG * 3 * MM, C * NG * 2 * D, C,
                             NM * ((sizeof(DenseModel) + 7) / 8)};
@@ -1316,7 +1318,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     e->m_lb = at(8); e->m_ws = at(9); e->d_filt = at(10); e->d_vend = at(11); e->d_fstart_m = at(12); e->d_beta_xi = at(13); e->m_fe_part = at(14);
     e->m_grp = at(15); e->m_gvec = at(16); e->m_feconst = at(17); e->m_modtab = reinterpret_cast<DenseModel*>(at(18));
     // the models padded to d×d (copies only) and their constant blocks, built on the device (one kt_consts launch per model)
-    const size_t IN1 = 5 * MM + D, CW1 = TabWs::doubles((int)D, 1);
+    const size_t IN1 = 5 * MM + D, CW1 = CWN;
     std::vector<double> hin(NM * IN1, 0.0);
     const int du = ds->d, dyu = ds->dy;
     for (size_t m = 0; m < NM; ++m) {
@@ -1398,7 +1400,7 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
     const DenseCst clm = DenseCst::make(e->dpad, e->dy);
     mp.step_model = e->m_stepm ? e->d_step_model : nullptr;
     mp.chain_model = e->m_chainm ? e->d_chain_model : nullptr;
-    mp.in_stride = 5LL * e->dpad * e->dpad + e->dpad; mp.cw_stride = (long long)TabWs::doubles(e->dpad, 1); mp.cst_stride = clm.size;
+    mp.in_stride = 5LL * e->dpad * e->dpad + e->dpad; mp.cw_stride = 16LL * e->dpad * e->dpad; mp.cst_stride = clm.size;
     mp.cst = e->m_cst; mp.fe_const = e->m_feconst; mp.oC0 = (int)clm.oC0; mp.oLDP = (int)clm.oLDP;
     DenseParams dp{};
     dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->mS; dp.L = e->mL; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy; dp.pack = 1; dp.d_sub = 8; dp.dy_sub = e->dy;
