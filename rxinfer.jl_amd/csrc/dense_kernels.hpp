@@ -2399,4 +2399,60 @@ __global__ void __launch_bounds__(256, 2) kd_fe_resid_mfma(DenseParams p, int sl
     }
 }
 
+// Per-step constants with MANY models (a fully time-varying model has one per step): a pass of kd_fe_resid_mfma per model would be a
+// launch per model.  Here every wavefront takes one time step at a time — lane i forms row i of the two whitened residuals with the maps of
+// THAT step's models (rows read along k: uncoalesced, but the work is tiny: 4·d² multiply-adds per step) — 64 steps per workgroup, one
+// partial slot each.  Same terms, same masks as the MFMA form.
+constexpr int FE_STEPS_BLOCK = 64;
+__global__ void __launch_bounds__(256) kd_fe_resid_steps(DenseParams p, int slot0) {
+    __shared__ double xb[4][3][64];
+    __shared__ double red[4];
+    const int D = p.d, dy = p.dy, dy4 = (dy + 3) & ~3, KY = dy4 + D;
+    const int tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
+    const long long chain = blockIdx.y + p.chain0, t00 = (long long)blockIdx.x * FE_STEPS_BLOCK;
+    const DenseCst c = DenseCst::make(D, dy);
+    double* x0 = xb[g][0];
+    double* x1 = xb[g][1];
+    double* yv = xb[g][2];
+    double acc = 0.0;
+    for (int q = g; q < FE_STEPS_BLOCK; q += 4) {
+        const long long t = t00 + q;
+        if (t >= p.T) break;   // uniform over the wavefront
+        const bool hasx = t + 1 < p.T, ob = p.obs[chain * p.T + t] != 0.0;
+        x0[lane] = lane < D ? dense_load_mean(p, t, chain, lane) : 0.0;
+        x1[lane] = (hasx && lane < D) ? dense_load_mean(p, t + 1, chain, lane) : 0.0;
+        yv[lane] = (ob && lane < dy) ? p.y[(t * p.n_chains + chain) * dy + lane] : 0.0;
+        wave_lds_fence();
+        if (hasx && lane < D) {   // ρ_x = L_P⁻¹ x̂_{t+1} − (L_P⁻¹A) x̂_t with the transition INTO t + 1
+            const double* mp = p.cst + (size_t)p.step_model[t + 1] * (size_t)p.cst_stride + c.oLPX + (size_t)lane * 2 * D;
+            double r0 = 0.0, r1 = 0.0;
+#pragma unroll 8
+            for (int k = 0; k < D; k += 2) {
+                r0 += mp[k] * x1[k] + mp[D + k] * x0[k];
+                r1 += mp[k + 1] * x1[k + 1] + mp[D + k + 1] * x0[k + 1];
+            }
+            acc += (r0 + r1) * (r0 + r1);
+        }
+        if (ob && lane < dy) {   // ρ_y = L_Q⁻¹ y_t − (L_Q⁻¹B) x̂_t
+            const double* mq = p.cst + (size_t)p.step_model[t] * (size_t)p.cst_stride + c.oLQX + (size_t)lane * KY;
+            double r = 0.0;
+            for (int k = 0; k < dy; ++k) r += mq[k] * yv[k];
+            for (int k = 0; k < D; ++k) r += mq[dy4 + k] * x0[k];
+            acc += r * r;
+        }
+        if (t == 0 && lane < D) {   // prior of the first state
+            const double* cm = p.cst + (size_t)p.step_model[0] * (size_t)p.cst_stride;
+            double u = 0.0;
+            for (int k = 0; k < D; ++k) u += cm[c.oV1I + (size_t)k * D + lane] * (x0[k] - cm[c.oM1 + k]);
+            acc += (x0[lane] - cm[c.oM1 + lane]) * u;
+        }
+        wave_lds_fence();
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off);
+    if (lane == 0) red[g] = acc;
+    __syncthreads();
+    if (tid == 0) dense_fe_write(p, slot0 + blockIdx.x, chain, 0.0, ((red[0] + red[1]) + red[2]) + red[3], 0.0);
+}
+
 }  // namespace rxhip

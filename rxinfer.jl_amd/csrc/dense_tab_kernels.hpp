@@ -37,6 +37,8 @@ struct TabParams {
     double* qtab;       // [2][S][d][d]
     int* canon;         // [4][S]
     int* status;        // ST_NOT_POSDEF
+    // kt_consts over several models at once (one workgroup per model, blockIdx.x): strides of `in`, `ws`, `cst` in doubles (0: one model)
+    long long in_stride, ws_stride, cst_stride;
 };
 // workspace layout (doubles): NSLOT named d×d matrices, then K_i | U_i | Φ_i for every offset of a segment
 struct TabWs {
@@ -284,10 +286,12 @@ __global__ void __launch_bounds__(64 * NT) kt_consts(TabParams p) {
     TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
     double* Ls = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;   // Cholesky work matrix D×(D+1)
     const int tid = o.tid, dy = p.dy;
-    const double *A = p.in, *P = p.in + MM, *V0 = p.in + 2 * MM, *B = p.in + 3 * MM, *Q = p.in + 4 * MM, *m0 = p.in + 5 * MM;
-    auto W = [&](int slot) { return p.ws + (size_t)slot * MM; };
+    const double* in = p.in + (size_t)blockIdx.x * (size_t)p.in_stride;   // this workgroup's model
+    double* wsb = p.ws + (size_t)blockIdx.x * (size_t)p.ws_stride;
+    const double *A = in, *P = in + MM, *V0 = in + 2 * MM, *B = in + 3 * MM, *Q = in + 4 * MM, *m0 = in + 5 * MM;
+    auto W = [&](int slot) { return wsb + (size_t)slot * MM; };
     const DenseCst c = DenseCst::make(D, dy);
-    double* cst = p.cst;
+    double* cst = p.cst + (size_t)blockIdx.x * (size_t)p.cst_stride;
     bool ok = true;
     double ldQ, ldP, ldV1, ldLf;
     ok = o.inv(W(TabWs::QI), Q, &ldQ) && ok;            // Q⁻¹ (identity on the padding)

@@ -1163,10 +1163,25 @@ struct DenseLaunch {
 };
 // free-energy residual terms of an information-form smoothing run: one workgroup per FR_STEPS steps, partial slots 2S…
 static int fe_resid_blocks(long long T, int d, int dy) { const int st = fe_resid_steps(d, dy); return (int)((T + st - 1) / st); }
+constexpr int FE_RESID_MAX_PASSES = 8;
+static long long mseg_resid_slots(long long T, int d, int dy, bool stepm, int models);
 // passes > 1: per-step constants — one launch per model, each with its own partial slots, the columns of the other models masked
+static long long mseg_resid_slots(long long T, int d, int dy, bool stepm, int models) {   // partial slots the residual kernel(s) write per chain
+    if (stepm && models > FE_RESID_MAX_PASSES) return (T + FE_STEPS_BLOCK - 1) / FE_STEPS_BLOCK;
+    return (long long)(stepm ? models : 1) * fe_resid_blocks(T, d, dy);
+}
 static void launch_fe_resid(const DenseParams& p, hipStream_t s, int passes = 1) {
     static const bool valu_env = std::getenv("RXHIP_FE_RESID_VALU") != nullptr;  // the round-2 form (vector FMAs), kept as a cross-check
     const bool valu = valu_env && !p.step_model;
+    if (p.step_model && passes > FE_RESID_MAX_PASSES) {   // many models: one step per wavefront instead of one launch per model
+        for (long long c0 = 0; c0 < p.n_chains; c0 += 32768) {
+            DenseParams q = p;
+            q.chain0 = c0;
+            const unsigned nc = (unsigned)(p.n_chains - c0 < 32768 ? p.n_chains - c0 : 32768);
+            hipLaunchKernelGGL(kd_fe_resid_steps, dim3((unsigned)((p.T + FE_STEPS_BLOCK - 1) / FE_STEPS_BLOCK), nc), dim3(256), 0, s, q, 2 * p.S);
+        }
+        return;
+    }
     for (int pass = 0; pass < passes; ++pass)
     for (long long c0 = 0; c0 < p.n_chains; c0 += 32768) {  // grid.y holds 65 535 blocks
         DenseParams q = p;
@@ -1348,15 +1363,17 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
         case 3: herr = mseg_prepare_kernels<3>(); break;
         default: herr = mseg_prepare_kernels<4>(); break;
     }
-    for (size_t m = 0; m < NM && !herr; ++m) {
+    if (!herr) {   // one workgroup per model
         TabParams tp{};
         tp.d = (int)D; tp.dy = e->dy; tp.ptt = e->ptt; tp.T = e->T; tp.L = 1; tp.Llast = 1; tp.S = 0; tp.sg = 1; tp.ng = 1;
-        tp.in = e->m_in + m * IN1; tp.ws = e->m_cw + m * CW1; tp.cst = e->m_cst + m * (size_t)cl.size; tp.status = e->d_status;
+        tp.in = e->m_in; tp.ws = e->m_cw; tp.cst = e->m_cst; tp.status = e->d_status;
+        tp.in_stride = (long long)IN1; tp.ws_stride = (long long)CW1; tp.cst_stride = cl.size;
+        const dim3 gm((unsigned)NM);
         switch (e->nt) {
-            case 1: hipLaunchKernelGGL((kt_consts<1>), dim3(1), dim3(64), lds_c, e->stream, tp); break;
-            case 2: hipLaunchKernelGGL((kt_consts<2>), dim3(1), dim3(128), lds_c, e->stream, tp); break;
-            case 3: hipLaunchKernelGGL((kt_consts<3>), dim3(1), dim3(192), lds_c, e->stream, tp); break;
-            default: hipLaunchKernelGGL((kt_consts<4>), dim3(1), dim3(256), lds_c, e->stream, tp); break;
+            case 1: hipLaunchKernelGGL((kt_consts<1>), gm, dim3(64), lds_c, e->stream, tp); break;
+            case 2: hipLaunchKernelGGL((kt_consts<2>), gm, dim3(128), lds_c, e->stream, tp); break;
+            case 3: hipLaunchKernelGGL((kt_consts<3>), gm, dim3(192), lds_c, e->stream, tp); break;
+            default: hipLaunchKernelGGL((kt_consts<4>), gm, dim3(256), lds_c, e->stream, tp); break;
         }
     }
     std::vector<DenseModel> hmod(NM);
@@ -3498,7 +3515,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             Params pr = p;
             if (mseg_now) {   // slots of kd_forward_info / kd_backward_info / kd_fe_resid over the mseg segments
                 pr.fe_part = e->m_fe_part;
-                pr.S = 2 * e->mS - 1 + (e->m_stepm ? e->m_models : 1) * fe_resid_blocks(e->T, e->dpad, e->dy);
+                pr.S = 2 * e->mS - 1 + (int)mseg_resid_slots(e->T, e->dpad, e->dy, e->m_stepm, e->m_models);
             }
             if (e->dense && !e->gseq && !filter && e->S > 0) {
                 // residual quadratic forms at the smoothed means (parallel over all steps), then 2S partial slots of

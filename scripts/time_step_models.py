@@ -14,10 +14,10 @@ def med(eng, n=5):
     return sorted(ts)[len(ts) // 2]
 
 
-for d, C, T, M in ((64, 1, 2000, 4), (64, 256, 200, 4), (8, 1024, 1000, 4), (16, 1, 5000, 8)):
+for d, C, T, M in ((64, 1, 2000, 4), (64, 256, 200, 4), (8, 1024, 1000, 4), (16, 1, 5000, 8), (32, 1, 1000, 1000), (64, 1, 600, 600)):   # the last two: every step its own model
     ms = [workloads.random_model(d, d, seed=d + 7 * m) for m in range(M)]
     mdl = tuple(np.stack([m[k] for m in ms]) for k in ("A", "B", "P", "Q", "m0", "V0"))
-    sm = np.random.default_rng(0).integers(0, M, T).astype(np.int32)
+    sm = np.random.default_rng(0).integers(0, M, T).astype(np.int32) if M < T else np.arange(T, dtype=np.int32)
     y = np.random.default_rng(1).standard_normal((T, C, d))
     out = []
     for env in (None, "1"):
@@ -25,8 +25,10 @@ for d, C, T, M in ((64, 1, 2000, 4), (64, 256, 200, 4), (8, 1024, 1000, 4), (16,
             os.environ["RXHIP_STEPM_GSEQ"] = env
         else:
             os.environ.pop("RXHIP_STEPM_GSEQ", None)
+        t0 = time.perf_counter()
         with rxhip.LGSSMEngine(*mdl, T=T, n_chains=C, step_model=sm) as eng:
+            create_ms = (time.perf_counter() - t0) * 1e3
             eng.set_data(y)
-            out.append((med(eng, 5 if env is None else 1), eng.free_energy()[-1]))
+            out.append((med(eng, 5 if env is None else 1), eng.free_energy()[-1], create_ms))
     os.environ.pop("RXHIP_STEPM_GSEQ", None)
-    print(f"d=dy={d} chains={C} T={T} models={M}: masked MFMA schedule {out[0][0]:.2f} ms | sequential {out[1][0]:.2f} ms = {out[1][0] / out[0][0]:.0f}x | FE {out[0][1]:.6f} / {out[1][1]:.6f}", flush=True)
+    print(f"d=dy={d} chains={C} T={T} models={M}: masked MFMA schedule {out[0][0]:.2f} ms | sequential {out[1][0]:.2f} ms = {out[1][0] / out[0][0]:.0f}x | FE {out[0][1]:.6f} / {out[1][1]:.6f} | engine creation {out[0][2]:.1f} ms", flush=True)
