@@ -256,3 +256,30 @@ def test_random_per_step_constants_case_against_the_sequential_schedule(case, mo
     assert np.max(np.abs(mm - ms) / sd) < 1e-6
     assert np.max(np.abs(cm - cs) / (sd[..., :, None] * sd[..., None, :])) < 1e-6
     assert np.allclose(fm, fs, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("d,dy,T,C,M", [(12, 5, 140, 3, 4), (64, 16, 90, 1, 3)])
+def test_per_step_constants_with_known_inputs_missing_values_and_a_forecast_horizon(d, dy, T, C, M, monkeypatch):
+    """everything at once on the masked schedule: A[t] … Q[t], `+ c[t]` / `+ d[t]` offsets, missing observations, an unobserved tail"""
+    import rxhip
+    import rxoracle as rxo
+    monkeypatch.delenv("RXHIP_STEPM_GSEQ", raising=False)
+    H = 7
+    mdl = _step_models(d, dy, M, seed=80 + d)
+    rng = np.random.default_rng(T + d)
+    sm = rng.integers(0, M, T + H).astype(np.int32)
+    cx, cy = rng.standard_normal((T + H, d)), rng.standard_normal((T + H, dy))
+    y = rng.standard_normal((T, C, dy)) * 2.0
+    y[rng.random((T, C)) < 0.2] = np.nan
+    with rxhip.LGSSMEngine(*mdl, T=T, n_chains=C, step_model=sm, horizon=H, allow_missing=True, state_offset=cx, obs_offset=cy) as eng:
+        eng.set_data(y)
+        eng.run(1, True)
+        mean, cov = eng.marginals()
+        fe = eng.free_energy_per_chain()
+    for c in range(C):
+        yy = np.concatenate([y[:, c], np.full((H, dy), np.nan)])
+        om, oc, nll = rxo.lgssm_kalman_rts_affine(*mdl, np.ascontiguousarray(yy), state_offset=cx, obs_offset=cy, step_model=sm)
+        sd = np.sqrt(np.einsum("tii->ti", oc))
+        assert np.max(np.abs(mean[:, c] - om) / sd) < 1e-6
+        assert np.max(np.abs(cov[:, c] - oc) / (sd[:, :, None] * sd[:, None, :])) < 1e-6
+        assert fe[c] == pytest.approx(nll, rel=1e-8, abs=1e-9)
