@@ -1,6 +1,6 @@
 #!/bin/bash
 set -u
-OUT=$PWD/gpurun_out/r03l; mkdir -p "$OUT"
+OUT=$PWD/gpurun_out/bench_headline; mkdir -p "$OUT"
 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"; tail -3 "$OUT/bench.err"
 python - "$OUT/bench.json" <<'PY'
 import json,sys

@@ -1,7 +1,7 @@
 #!/bin/bash
-# kernel stats of the masked time-parallel schedule:  ./scripts/gpu_r03w.sh ["d chains T" ...]
+# kernel stats of the masked time-parallel schedule:  ./scripts/gpu_masked_kernel_stats.sh ["d chains T" ...]
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/r03w; mkdir -p "$OUT"; ROOT=$PWD
+OUT=$PWD/gpurun_out/masked_stats; mkdir -p "$OUT"; ROOT=$PWD
 cd /tmp
 if [ $# -eq 0 ]; then set -- "64 1 2000" "8 1024 1000"; fi
 for cfg in "$@"; do

@@ -1,7 +1,7 @@
 #!/bin/bash
 # kernel stats of mid-size shared-model batches
 export TMPDIR=/tmp
-OUT=$PWD/gpurun_out/r03x; mkdir -p "$OUT"; ROOT=$PWD
+OUT=$PWD/gpurun_out/mid_stats; mkdir -p "$OUT"; ROOT=$PWD
 cd /tmp
 for cfg in "8 8 1024 1000" "64 64 64 1000"; do
   tag=$(echo $cfg | tr ' ' '_')
