@@ -370,6 +370,7 @@ struct rxhip_engine {
     // rxhip_set_covariance_mode: 0 = every sweep writes the covariance of every chain; 1 = shared-model batches on the split schedule write
     // the per-chain array on request (the values do not depend on the data: one [T][d][d] table per model).  cov_pending: the last run left
     // the array to be materialised; cov_current: the array holds what a materialisation would write
+    int m_dpad = 0, m_nt = 0;        // masked schedule: tile dimension 16·⌈max(d, dy)/16⌉ (the engine's own dpad pads d only)
     int m_sg = 0, m_ng = 0;          // masked schedule: groups of the two-level boundary recursion (0: one level)
     int m_models = 1;                // masked schedule: constant blocks (per-step constants: desc.n_models, else 1)
     bool m_stepm = false;            // per-step constants on the masked schedule
@@ -1265,14 +1266,17 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     // constants of model step_model[t]) — with or without `missing` values; per-chain models keep the sequential schedule
     const bool stepm = ds->step_model != nullptr && ds->n_models > 1;
     const bool chainm = !stepm && ds->chain_model != nullptr && ds->n_models > 1;   // one model per chain (with `missing` values: else the fully observed MFMA path has them)
-    if (!(ds->allow_missing || stepm) || (ds->chain_model && !chainm) || (!stepm && !chainm && ds->n_models != 1) || e->T < 2 || e->dy > e->dpad ||
+    if (!(ds->allow_missing || stepm) || (ds->chain_model && !chainm) || (!stepm && !chainm && ds->n_models != 1) || e->T < 2 ||
         std::getenv("RXHIP_GSEQ") || ((stepm || chainm) && std::getenv("RXHIP_STEPM_GSEQ")))
         return RXHIP_OK;
+    // the masked kernels work on d×d tiles that also hold the observation-space matrices: pad to the larger of d and dy
+    e->m_dpad = 16 * ((std::max(e->d, e->dy) + 15) / 16);
+    e->m_nt = e->m_dpad / 16;
     const size_t NM = (stepm || chainm) ? (size_t)ds->n_models : 1;
     e->m_chainm = chainm;
     e->m_models = (int)NM;
     e->m_stepm = stepm;
-    const size_t D = (size_t)e->dpad, MM = D * D, C = (size_t)e->n_chains, T = (size_t)e->T;
+    const size_t D = (size_t)e->m_dpad, MM = D * D, C = (size_t)e->n_chains, T = (size_t)e->T;
     // segments: the element pass costs ≈2 boundary steps per time step, both are sequential chains -> S ≈ √(2T); many chains fill the
     // machine on their own, and the scratch of the element pass grows with chains × S
     // Segments: a cost model over the sequential depths, in µs per step / element from the measured kernels
@@ -1282,8 +1286,8 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     // the whole chain, no element pass (three sweep steps' worth per time step) and no boundary recursion.
     long long S = 1;
     {
-        const double f = (double)(e->nt - 1) / 3.0, c_e = 15.0 + f * 35.0, c_s = 8.0 + f * 13.0, c_g = 15.0 + f * 35.0, c_f = 5.7 + f * 14.3;
-        const double conc = e->nt == 1 ? 2048.0 : e->nt == 2 ? 1024.0 : 512.0;
+        const double f = (double)(e->m_nt - 1) / 3.0, c_e = 15.0 + f * 35.0, c_s = 8.0 + f * 13.0, c_g = 15.0 + f * 35.0, c_f = 5.7 + f * 14.3;
+        const double conc = e->m_nt == 1 ? 2048.0 : e->m_nt == 2 ? 1024.0 : 512.0;
         auto cost = [&](long long s) {
             const double steps = std::ceil((double)(T - 1) / (double)s), rounds = std::ceil((double)C * (double)s / conc);
             double scan = 0.0;
@@ -1317,13 +1321,13 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     }
     const size_t NG = (size_t)(e->m_ng > 0 ? e->m_ng : 1);
     const DenseCst cl = DenseCst::make((int)D, e->dy);
-    const int rec = dense_rec(e->nt), tri = dense_tri(e->nt);
+    const int rec = dense_rec(e->m_nt), tri = dense_tri(e->m_nt);
     const size_t nws = std::max<size_t>((size_t)C * (size_t)S, (size_t)2 * C) * MSEG_WS * MM;
     static_assert(TabWs::T6 == 15, "kt_consts works in the first 16 workspace slots");
     const size_t CWN = 16 * MM;   // kt_consts touches the named slots up to TabWs::T6 only: 16 matrices per model (the table builder's workspace has 83)
     const size_t parts[] = {NM * (5 * MM + D), NM * CWN, NM * (size_t)cl.size, C * T, C, C * S * 3 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
                             C * T * (size_t)rec, C * S * (size_t)tri, C * S * D, C * (S + 1) * D,
-                            (2 * (size_t)S + 2 + NM * (size_t)fe_resid_blocks(e->T, e->dpad, e->dy)) * C, C * NG * 3 * MM, C * NG * 2 * D, C,
+                            (2 * (size_t)S + 2 + NM * (size_t)fe_resid_blocks(e->T, e->m_dpad, e->dy)) * C, C * NG * 3 * MM, C * NG * 2 * D, C,
                             NM * ((sizeof(DenseModel) + 7) / 8)};
     size_t off[20] = {0};
     for (int q = 0; q < 19; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
@@ -1356,8 +1360,8 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     HIPCHK(e, hipMemsetAsync(e->m_fe_part, 0, sizeof(double) * parts[14], e->stream));
     HIPCHK(e, hipMemsetAsync(e->d_filt, 0, sizeof(double) * parts[10], e->stream));
     hipError_t herr = hipSuccess;
-    const size_t lds_c = sizeof(double) * (size_t)(blk_scratch_doubles(e->nt) + 2 * 64 * e->nt + 16 + D * (D + 1));
-    switch (e->nt) {
+    const size_t lds_c = sizeof(double) * (size_t)(blk_scratch_doubles(e->m_nt) + 2 * 64 * e->m_nt + 16 + D * (D + 1));
+    switch (e->m_nt) {
         case 1: herr = mseg_prepare_kernels<1>(); break;
         case 2: herr = mseg_prepare_kernels<2>(); break;
         case 3: herr = mseg_prepare_kernels<3>(); break;
@@ -1369,7 +1373,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
         tp.in = e->m_in; tp.ws = e->m_cw; tp.cst = e->m_cst; tp.status = e->d_status;
         tp.in_stride = (long long)IN1; tp.ws_stride = (long long)CW1; tp.cst_stride = cl.size;
         const dim3 gm((unsigned)NM);
-        switch (e->nt) {
+        switch (e->m_nt) {
             case 1: hipLaunchKernelGGL((kt_consts<1>), gm, dim3(64), lds_c, e->stream, tp); break;
             case 2: hipLaunchKernelGGL((kt_consts<2>), gm, dim3(128), lds_c, e->stream, tp); break;
             case 3: hipLaunchKernelGGL((kt_consts<3>), gm, dim3(192), lds_c, e->stream, tp); break;
@@ -1409,18 +1413,18 @@ static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams
 }
 static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
     MsegParams mp{};
-    mp.d = e->dpad; mp.dy = e->dy; mp.dy_user = e->dy; mp.ptt = e->ptt; mp.T = e->T; mp.L = e->mL; mp.n_chains = e->n_chains; mp.S = e->mS;
+    mp.d = e->m_dpad; mp.dy = e->dy; mp.dy_user = e->dy; mp.ptt = e->ptt; mp.T = e->T; mp.L = e->mL; mp.n_chains = e->n_chains; mp.S = e->mS;
     mp.y = e->d_y; mp.in = e->m_in; mp.cw = e->m_cw; mp.ws = e->m_ws; mp.obs = e->m_obs; mp.nobs = e->m_nobs; mp.mel = e->m_el; mp.mvec = e->m_vec;
-    mp.mbnd = e->m_bnd; mp.mlb = e->m_lb; mp.fstart_m = e->d_fstart_m; mp.beta_xi = e->d_beta_xi; mp.filt = e->d_filt; mp.rec = dense_rec(e->nt);
+    mp.mbnd = e->m_bnd; mp.mlb = e->m_lb; mp.fstart_m = e->d_fstart_m; mp.beta_xi = e->d_beta_xi; mp.filt = e->d_filt; mp.rec = dense_rec(e->m_nt);
     mp.status = e->d_status;
     mp.sg = e->m_sg; mp.ng = e->m_ng; mp.mgrp = e->m_grp; mp.mgvec = e->m_gvec;
-    const DenseCst clm = DenseCst::make(e->dpad, e->dy);
+    const DenseCst clm = DenseCst::make(e->m_dpad, e->dy);
     mp.step_model = e->m_stepm ? e->d_step_model : nullptr;
     mp.chain_model = e->m_chainm ? e->d_chain_model : nullptr;
-    mp.in_stride = 5LL * e->dpad * e->dpad + e->dpad; mp.cw_stride = 16LL * e->dpad * e->dpad; mp.cst_stride = clm.size;
+    mp.in_stride = 5LL * e->m_dpad * e->m_dpad + e->m_dpad; mp.cw_stride = 16LL * e->m_dpad * e->m_dpad; mp.cst_stride = clm.size;
     mp.cst = e->m_cst; mp.fe_const = e->m_feconst; mp.oC0 = (int)clm.oC0; mp.oLDP = (int)clm.oLDP;
     DenseParams dp{};
-    dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->mS; dp.L = e->mL; dp.d = e->dpad; dp.d_out = e->d; dp.dy = e->dy; dp.pack = 1; dp.d_sub = 8; dp.dy_sub = e->dy;
+    dp.T = e->T; dp.n_chains = e->n_chains; dp.S = e->mS; dp.L = e->mL; dp.d = e->m_dpad; dp.d_out = e->d; dp.dy = e->dy; dp.pack = 1; dp.d_sub = 8; dp.dy_sub = e->dy;
     dp.y = e->d_y; dp.filt = e->d_filt; dp.vend = e->d_vend; dp.mean = e->d_mean; dp.cov = e->d_cov; dp.cst = e->m_cst;
     dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi; dp.fe_part = e->m_fe_part; dp.status = e->d_status;
     dp.mseg = 2;   // 2: the boundary vector of a segment is the information vector ξ_f(b_s), not the mean
@@ -1429,7 +1433,7 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
     if (e->m_chainm) { dp.models = e->m_modtab; dp.chain_model = e->d_chain_model; }   // the sweep kernels' own per-chain lookup (dense_model)
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
-    switch (e->nt) {
+    switch (e->m_nt) {
         case 1: mseg_launch<1>(e, mp, dp, fe); break;
         case 2: mseg_launch<2>(e, mp, dp, fe); break;
         case 3: mseg_launch<3>(e, mp, dp, fe); break;
@@ -3515,7 +3519,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             Params pr = p;
             if (mseg_now) {   // slots of kd_forward_info / kd_backward_info / kd_fe_resid over the mseg segments
                 pr.fe_part = e->m_fe_part;
-                pr.S = 2 * e->mS - 1 + (int)mseg_resid_slots(e->T, e->dpad, e->dy, e->m_stepm, e->m_models);
+                pr.S = 2 * e->mS - 1 + (int)mseg_resid_slots(e->T, e->m_dpad, e->dy, e->m_stepm, e->m_models);
             }
             if (e->dense && !e->gseq && !filter && e->S > 0) {
                 // residual quadratic forms at the smoothed means (parallel over all steps), then 2S partial slots of

@@ -34,7 +34,7 @@ def _run(mdl, y, ptt, sequential, monkeypatch, segments=0):
         return mean, cov, fe
 
 
-@pytest.mark.parametrize("d,dy,T,C,ptt,segments", [(64, 64, 300, 1, False, 0), (64, 20, 150, 2, True, 5), (33, 7, 200, 3, False, 0), (16, 16, 120, 4, True, 0),
+@pytest.mark.parametrize("d,dy,T,C,ptt,segments", [(64, 64, 300, 1, False, 0), (6, 40, 130, 2, False, 0), (20, 33, 70, 1, True, 4), (64, 20, 150, 2, True, 5), (33, 7, 200, 3, False, 0), (16, 16, 120, 4, True, 0),
                                                   (8, 4, 260, 6, False, 0), (5, 3, 40, 3, True, 1), (48, 48, 90, 2, False, 89), (12, 12, 2, 2, False, 0)])
 def test_missing_observations_parallel_in_time(d, dy, T, C, ptt, segments, monkeypatch):
     import rxoracle as rxo
