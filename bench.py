@@ -235,6 +235,43 @@ def extra_c3(device):
             "create_note": "a model no engine of the process has seen: tables built on the device (csrc/dense_tab_kernels.hpp)"}
 
 
+def extra_masked(device):
+    """Not BASELINE configs: `missing` observations and per-step constants at d = 64 on the masked MFMA schedule
+    (csrc/dense_mseg_kernels.hpp) next to the fully observed sweep of the same chain — median of five sweeps each
+    (rounds 1–2 ran these engines sequentially in time: ≈700 ms)."""
+    d, T = 64, 2000
+    m = workloads.random_model(d, d, seed=d)
+    y = workloads.generate_batch(m, T, 1, seed0=1)
+    one = (m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"])
+
+    def med(eng):
+        eng.run(1, True)
+        ts = []
+        for _ in range(5):
+            t0 = time.perf_counter()
+            eng.run(1, True)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return sorted(ts)[2]
+
+    out = {"workload": "LGSSM d=64 dy=64 T=2000, 1 chain, 1 BP sweep + free energy"}
+    with rxhip.LGSSMEngine(*one, T=T, n_chains=1, device=device) as eng:
+        eng.set_data(y)
+        out["fully_observed_ms"] = med(eng)
+    ym = y.copy()
+    ym[np.random.default_rng(0).random((T, 1)) < 0.1] = np.nan
+    with rxhip.LGSSMEngine(*one, T=T, n_chains=1, allow_missing=True, device=device) as eng:
+        eng.set_data(ym)
+        out["missing_10pct_ms"] = med(eng)
+    ms = [workloads.random_model(d, d, seed=d + 7 * k) for k in range(4)]
+    mdl = tuple(np.stack([q[k] for q in ms]) for k in ("A", "B", "P", "Q", "m0", "V0"))
+    sm = np.random.default_rng(0).integers(0, 4, T).astype(np.int32)
+    with rxhip.LGSSMEngine(*mdl, T=T, n_chains=1, step_model=sm, device=device) as eng:
+        eng.set_data(y)
+        out["per_step_constants_4_models_ms"] = med(eng)
+    out["missing_over_observed"] = out["missing_10pct_ms"] / out["fully_observed_ms"]
+    return out
+
+
 def extra_mid(device):
     """Not BASELINE configs: batches of one model at mid-size state dimensions on the MFMA path (model pass once per engine,
     data pass per sweep — DESIGN §6b), 1 BP sweep + free energy per step."""
@@ -555,7 +592,8 @@ def main():
         yh = None if args.no_parity else y_host
         for name, fn in (("per_chain_models", lambda: extra_per_chain_models(mdl, T, C, y, local_rank, yh)), ("c1", lambda: extra_c1(local_rank, not args.no_cpu_baseline)),
                          ("c2_missing", lambda: extra_missing(mdl, T, C, y, local_rank, yh)), ("c3", lambda: extra_c3(local_rank)),
-                         ("c4", lambda: extra_c4(local_rank)), ("c5", lambda: extra_c5(local_rank)), ("mid_sizes", lambda: extra_mid(local_rank))):
+                         ("c4", lambda: extra_c4(local_rank)), ("c5", lambda: extra_c5(local_rank)), ("mid_sizes", lambda: extra_mid(local_rank)),
+                         ("masked_mfma", lambda: extra_masked(local_rank))):
             try:
                 extra[name] = fn()
             except Exception as e:  # noqa: BLE001 — an extra line must never cost the headline line
