@@ -132,6 +132,7 @@ struct DenseParams {
     long long cst_stride;
     const double* fe_const;
     int model_sel;
+    long long oW_off;     // DenseCst::oW (km_filter_out reads the constant block through MsegParams)
     long long chain0;     // first workgroup chain of this launch: a grid dimension holds 65 535 blocks, larger batches are launched in slices
 };
 struct DenseModel {

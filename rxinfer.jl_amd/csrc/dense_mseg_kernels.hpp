@@ -383,6 +383,72 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p, int level) {
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
 
+// Filtering runs (rxhip_run_filter) of masked / per-step engines: the posteriors asked for are q(x_t | y_1..t).  The forward sweep left
+// them in its records in information form — record t holds ξ_f(t) and C_t = (Λ_f(t) + A′P⁻¹A)⁻¹ (the owned tiles), the last step's Λ_f(T−1)
+// is the `vend` of the last segment — so one workgroup per (time index, chain) turns them into moments: Λ_f = C_t⁻¹ − [A′P⁻¹A]_{t+1},
+// V_f = Λ_f⁻¹, m_f = V_f ξ_f.  Two inverses per time index, all in parallel.  (The free energy of such a run is −log p(y) / T: the
+// smoothing pipeline's value, scaled by the reduction.)
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) km_filter_out(MsegParams p, DenseParams q) {
+    constexpr int D = 16 * NT, MM = D * D;
+    using C = DenseCfg<NT>;
+    constexpr int LD = C::LD;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Sm = smem;                  // one matrix
+    double* xi = Sm + C::MAT;           // ξ_f
+    double* red = xi + D;               // [4][D] partial sums
+    double* scr = red + 4 * D;          // scratch of the inverse
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    const long long t = blockIdx.x, chain = blockIdx.y;
+    const double* rec = p.filt + (chain * p.T + t) * p.rec;
+    if (tid < D) xi[tid] = rec[tid];
+    Acc<NT> a;
+    LogProd lp;
+    bool ok = true;
+    if (t == p.T - 1) {   // Λ_f(T − 1): the end of the last segment
+        tri_to_lds<NT>(q.vend + (chain * p.S + (p.S - 1)) * C::TRI, Sm, LD, w, lane);
+        __syncthreads();
+        acc_load<NT>(a, Sm, LD, w, lane);
+        __syncthreads();
+    } else {
+        // C_t: the tiles every wave owns in the symmetric pairing of the sweep kernels, mirrored through LDS
+        constexpr int NS = NT / 2 + 1;
+        const int nsw = (NT % 2 == 0 && NT > 1 && w >= NT / 2) ? NS - 1 : NS;
+#pragma unroll
+        for (int sl = 0; sl < NS; ++sl)
+            if (sl < nsw) {
+                const int t2 = w + sl >= NT ? w + sl - NT : w + sl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const double v = rec[C::HDR + ((w * NT + t2) * 4 + r) * 64 + lane];
+                    const int row = 16 * w + (lane >> 4) + 4 * r, col = 16 * t2 + (lane & 15);
+                    Sm[row * LD + col] = v;
+                    if (t2 != w) Sm[col * LD + row] = v;
+                }
+            }
+        __syncthreads();
+        acc_load<NT>(a, Sm, LD, w, lane);
+        __syncthreads();
+        ok = blk_inverse<NT>(a, scr, w, lane, lp) && ok;                    // M_t = C_t⁻¹
+        const double* cm = p.cst + (size_t)mseg_model(p, chain, t + 1) * (size_t)p.cst_stride;
+        acc_add_mat<NT>(a, cm + q.oW_off, D, w, lane, -1.0);                 // Λ_f(t) = M_t − [A′P⁻¹A]_{t+1}
+    }
+    ok = blk_inverse<NT>(a, scr, w, lane, lp) && ok;                        // V_f = Λ_f⁻¹
+    dense_store_cov<NT>(q, a, t, chain, w, lane);
+    acc_store<NT>(a, Sm, LD, w, lane);
+    __syncthreads();
+    {   // m_f = V_f ξ_f: thread group g sums a quarter of the k range (V_f is symmetric: columns)
+        const int g = tid / D, i = tid - g * D, k0 = g * (D / 4);
+        double sacc = 0.0;
+#pragma unroll
+        for (int k = 0; k < D / 4; ++k) sacc += Sm[(k0 + k) * LD + i] * xi[k0 + k];
+        red[g * D + i] = sacc;
+    }
+    __syncthreads();
+    if (tid < D) dense_store_mean(q, t, chain, tid, (red[tid] + red[D + tid]) + (red[2 * D + tid] + red[3 * D + tid]));
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
 // smoothed covariance at the inner boundaries: V_s(b_{s+1}) = (Λ_f(b_{s+1}) + Λβ(b_{s+1}))⁻¹
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) km_bnd(MsegParams p) {

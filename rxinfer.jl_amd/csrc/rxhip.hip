@@ -1257,7 +1257,8 @@ static rxhip_status prof_end(rxhip_engine* e);
 template <int NT>
 static hipError_t mseg_prepare_kernels() {
     hipError_t err;
-    for (const void* f : {(const void*)km_elements<NT>, (const void*)km_scan<NT>, (const void*)km_group<NT>, (const void*)km_bnd<NT>, (const void*)kt_consts<NT>})
+    for (const void* f : {(const void*)km_elements<NT>, (const void*)km_scan<NT>, (const void*)km_group<NT>, (const void*)km_bnd<NT>, (const void*)km_filter_out<NT>,
+                          (const void*)kt_consts<NT>})
         if ((err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return err;
     return DenseLaunch<NT>::prepare();
 }
@@ -1390,7 +1391,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     return RXHIP_OK;
 }
 template <int NT>
-static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams& dp, bool fe) {
+static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams& dp, bool fe, bool filter) {
     const size_t lds = sizeof(double) * (size_t)(blk_scratch_doubles(NT) + 2 * 64 * NT + 8 * 16 * NT + 16);
     hipStream_t s = e->stream;
     (void)hipMemsetAsync(mp.nobs, 0, sizeof(double) * (size_t)mp.n_chains, s);
@@ -1409,9 +1410,15 @@ static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams
         DenseLaunch<NT>::forward_info_stepm(dp, fe, s);
     } else
         DenseLaunch<NT>::forward_info(dp, fe, s);
-    DenseLaunch<NT>::backward_info(dp, fe, s);
+    if (!filter || fe) DenseLaunch<NT>::backward_info(dp, fe, s);   // a filtering run needs the backward sweep for its free energy only
+
 }
-static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
+template <int NT>
+static void mseg_filter_out(rxhip_engine* e, const MsegParams& mp, const DenseParams& dp) {
+    const size_t ldf = sizeof(double) * (size_t)(DenseCfg<NT>::MAT + 5 * 16 * NT + blk_scratch_doubles(NT) + 16);
+    hipLaunchKernelGGL((km_filter_out<NT>), dim3((unsigned)mp.T, (unsigned)mp.n_chains), dim3(64 * NT), ldf, e->stream, mp, dp);
+}
+static rxhip_status mseg_run(rxhip_engine* e, bool fe, bool filter) {
     MsegParams mp{};
     mp.d = e->m_dpad; mp.dy = e->dy; mp.dy_user = e->dy; mp.ptt = e->ptt; mp.T = e->T; mp.L = e->mL; mp.n_chains = e->n_chains; mp.S = e->mS;
     mp.y = e->d_y; mp.in = e->m_in; mp.cw = e->m_cw; mp.ws = e->m_ws; mp.obs = e->m_obs; mp.nobs = e->m_nobs; mp.mel = e->m_el; mp.mvec = e->m_vec;
@@ -1429,18 +1436,26 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe) {
     dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi; dp.fe_part = e->m_fe_part; dp.status = e->d_status;
     dp.mseg = 2;   // 2: the boundary vector of a segment is the information vector ξ_f(b_s), not the mean
     dp.obs = e->m_obs; dp.nobs = e->m_nobs; dp.mbnd = e->m_bnd;
-    dp.step_model = mp.step_model; dp.cst_stride = clm.size; dp.fe_const = e->m_feconst; dp.model_sel = 0;
+    dp.step_model = mp.step_model; dp.cst_stride = clm.size; dp.fe_const = e->m_feconst; dp.model_sel = 0; dp.oW_off = clm.oW;
     if (e->m_chainm) { dp.models = e->m_modtab; dp.chain_model = e->d_chain_model; }   // the sweep kernels' own per-chain lookup (dense_model)
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
     switch (e->m_nt) {
-        case 1: mseg_launch<1>(e, mp, dp, fe); break;
-        case 2: mseg_launch<2>(e, mp, dp, fe); break;
-        case 3: mseg_launch<3>(e, mp, dp, fe); break;
-        default: mseg_launch<4>(e, mp, dp, fe); break;
+        case 1: mseg_launch<1>(e, mp, dp, fe, filter); break;
+        case 2: mseg_launch<2>(e, mp, dp, fe, filter); break;
+        case 3: mseg_launch<3>(e, mp, dp, fe, filter); break;
+        default: mseg_launch<4>(e, mp, dp, fe, filter); break;
     }
     if ((st = prof_end(e))) return st;
     if (fe) launch_fe_resid(dp, e->stream, e->m_stepm ? e->m_models : 1);
+    if (filter) {   // q(x_t | y_1..t) from the forward records — after the residual forms have read the smoothed means
+        switch (e->m_nt) {
+            case 1: mseg_filter_out<1>(e, mp, dp); break;
+            case 2: mseg_filter_out<2>(e, mp, dp); break;
+            case 3: mseg_filter_out<3>(e, mp, dp); break;
+            default: mseg_filter_out<4>(e, mp, dp); break;
+        }
+    }
     return RXHIP_OK;
 }
 
@@ -3404,9 +3419,11 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     }
     for (int it = 0; it < iterations; ++it) {
         p.iteration = it;
-        const bool mseg_now = e->gseq && e->mseg && !filter;   // `missing` observations, one model, smoothing: parallel in time
+        // `missing` observations / per-step constants at d > 4 on the masked MFMA schedule (smoothing; filtering runs: the same sweep, then the
+        // filtered moments from its records) unless the sequential schedule is asked for as the checker of filtering runs
+        const bool mseg_now = e->gseq && e->mseg && !(filter && std::getenv("RXHIP_FILTER_GSEQ"));
         if (mseg_now) {
-            if ((st = mseg_run(e, fe))) return st;
+            if ((st = mseg_run(e, fe, filter))) return st;
         } else if (e->gseq) {
             GseqParams gq{};
             gq.T = e->T; gq.n_chains = e->n_chains; gq.d = e->d; gq.dy = e->dy; gq.ptt = e->ptt; gq.fe = fe ? 1 : 0; gq.y = e->d_y;

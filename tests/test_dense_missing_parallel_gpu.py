@@ -283,3 +283,38 @@ def test_per_step_constants_with_known_inputs_missing_values_and_a_forecast_hori
         assert np.max(np.abs(mean[:, c] - om) / sd) < 1e-6
         assert np.max(np.abs(cov[:, c] - oc) / (sd[:, :, None] * sd[:, None, :])) < 1e-6
         assert fe[c] == pytest.approx(nll, rel=1e-8, abs=1e-9)
+
+
+@pytest.mark.parametrize("d,dy,T,C,M,rate,segments", [(24, 6, 200, 2, 1, 0.2, 0), (64, 64, 130, 1, 1, 0.1, 0), (16, 16, 300, 300, 1, 0.3, 0), (40, 12, 150, 2, 3, 0.15, 4), (9, 20, 90, 3, 5, 0.0, 0)])
+def test_filtering_runs_on_the_masked_schedule(d, dy, T, C, M, rate, segments, monkeypatch):
+    """rxhip_run_filter of masked / per-step engines: the filtered moments come out of the forward sweep's records (km_filter_out), the free
+    energy is −log p(y) / T — against the sequential schedule (RXHIP_FILTER_GSEQ) and the oracle's filter"""
+    import rxhip
+    import rxoracle as rxo
+    mdl = _step_models(d, dy, M, seed=60 + d)
+    rng = np.random.default_rng(T + d)
+    sm = rng.integers(0, M, T).astype(np.int32) if M > 1 else None
+    y = rng.standard_normal((T, C, dy)) * 2.0
+    if rate > 0:
+        y[rng.random((T, C)) < rate] = np.nan
+    args = mdl if M > 1 else tuple(a[0] for a in mdl)
+    out = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("RXHIP_FILTER_GSEQ", env)
+        else:
+            monkeypatch.delenv("RXHIP_FILTER_GSEQ", raising=False)
+        with rxhip.LGSSMEngine(*args, T=T, n_chains=C, step_model=sm, allow_missing=rate > 0, segments=segments) as eng:
+            eng.set_data(y)
+            eng.run_filter(True)
+            out.append(eng.marginals() + (eng.free_energy_per_chain(),))
+            eng.run(1, True)                       # and a smoothing run afterwards is the smoothing run
+            sm_mean = eng.marginals()[0]
+            eng.run_filter(False)                  # no free energy: forward sweep only
+            assert np.allclose(eng.marginals()[0], out[-1][0], rtol=0, atol=0)
+            assert not np.allclose(sm_mean[: T // 2], out[-1][0][: T // 2])
+    (mm, cm, fm), (ms, cs, fs) = out
+    sd = np.sqrt(np.einsum("tcii->tci", cs))
+    assert np.max(np.abs(mm - ms) / sd) < 1e-6
+    assert np.max(np.abs(cm - cs) / (sd[..., :, None] * sd[..., None, :])) < 1e-6
+    assert np.allclose(fm, fs, rtol=1e-8, atol=1e-9)
