@@ -26,7 +26,8 @@
 // 690), not a roofline path.  The algebra is restated in numpy in tests/test_mseg_information_form.py.
 // Per-step constants (desc.step_model): the same kernels with the constant block of model step_model[t] per step (MsegParams::step_model,
 // kd_forward_info<…, STEPM>, one residual pass per model, km_feconst).
-// Scope: one model per engine, per-step constants shared by all chains, or one model per chain; smoothing runs; the tiles are
+// Scope: one model per engine, per-step constants shared by all chains, or one model per chain; smoothing runs and filtering runs
+// (km_filter_out); the tiles are
 // 16·⌈max(d, dy)/16⌉ wide (MsegParams::d).
 #pragma once
 #include "dense_tab_kernels.hpp"

@@ -32,3 +32,25 @@ for d, C, T, M in ((64, 1, 2000, 4), (64, 256, 200, 4), (8, 1024, 1000, 4), (16,
             out.append((med(eng, 5 if env is None else 1), eng.free_energy()[-1], create_ms))
     os.environ.pop("RXHIP_STEPM_GSEQ", None)
     print(f"d=dy={d} chains={C} T={T} models={M}: masked MFMA schedule {out[0][0]:.2f} ms | sequential {out[1][0]:.2f} ms = {out[1][0] / out[0][0]:.0f}x | FE {out[0][1]:.6f} / {out[1][1]:.6f} | engine creation {out[0][2]:.1f} ms", flush=True)
+
+# filtering runs (rxhip_run_filter) of a masked engine: masked schedule + km_filter_out against the sequential schedule
+for d, C, T in ((64, 1, 2000), (16, 512, 1000)):
+    m = workloads.random_model(d, d, seed=d)
+    y = workloads.generate_batch(m, T, C, seed0=1)
+    y[np.random.default_rng(0).random((T, C)) < 0.1] = np.nan
+    out = []
+    for env in (None, "1"):
+        if env:
+            os.environ["RXHIP_FILTER_GSEQ"] = env
+        else:
+            os.environ.pop("RXHIP_FILTER_GSEQ", None)
+        with rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=T, n_chains=C, allow_missing=True) as eng:
+            eng.set_data(y)
+            eng.run_filter(True)
+            ts = []
+            for _ in range(3 if env is None else 1):
+                t0 = time.perf_counter(); eng.run_filter(True); ts.append((time.perf_counter() - t0) * 1e3)
+            out.append(sorted(ts)[len(ts) // 2])
+    os.environ.pop("RXHIP_FILTER_GSEQ", None)
+    print(f"filtering run, d=dy={d} chains={C} T={T}, 10 % missing: masked MFMA schedule {out[0]:.2f} ms | sequential {out[1]:.2f} ms = {out[1] / out[0]:.0f}x", flush=True)
+

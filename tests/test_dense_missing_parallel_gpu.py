@@ -61,7 +61,7 @@ def test_missing_observations_parallel_in_time(d, dy, T, C, ptt, segments, monke
 
 
 def test_the_rest_of_the_engine_is_unchanged(monkeypatch):
-    """filtering runs, predictions and the step-wise filter of such an engine stay on the sequential kernels"""
+    """filtering runs (masked schedule + km_filter_out), predictions and the step-wise filter (sequential kernels) of such an engine"""
     import rxhip
     import rxoracle as rxo
     from rxhip import workloads
