@@ -2400,6 +2400,35 @@ __global__ void __launch_bounds__(256, 2) kd_fe_resid_mfma(DenseParams p, int sl
     }
 }
 
+// Node-local joints q(x[t], x[t+1] | y) need Cov(x[t], x[t+1] | y) = G_t V_s(t+1) beyond the posteriors (rxhip_get_node_marginals).  After a
+// smoothing run of the information-form sweep the gain is still in the records (G_t′ = K C_t, accumulator order) and V_s(t+1) in the
+// posterior array: one workgroup per (t, chain), one product — instead of re-running the whole chain on the sequential kernels.
+// One chain per tile only (pack = 1).  cross: [T − 1][chain][d_out][d_out].
+template <int NT>
+__global__ void __launch_bounds__(64 * NT) kd_cross_from_records(DenseParams p, double* cross) {
+    constexpr int D = 16 * NT;
+    using C = DenseCfg<NT>;
+    constexpr int LD = C::LD;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* Gt = smem;            // G_t′: [k][i]
+    double* Vs = Gt + C::MAT;     // V_s(t + 1), zero-padded
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, dout = p.d_out;
+    const long long row = blockIdx.x, t = row / p.n_chains, chain = row - t * p.n_chains;
+    Acc<NT> g;
+    acc_load_full<NT>(g, p.filt + (chain * p.T + t) * C::REC + C::HDR + D * D, w, lane);
+    acc_store<NT>(g, Gt, LD, w, lane);
+    const double* vs = p.cov + ((t + 1) * p.n_chains + chain) * (size_t)dout * dout;
+    for (int k = tid; k < D * D; k += 64 * NT) {
+        const int i = k / D, j = k - i * D;
+        Vs[i * LD + j] = (i < dout && j < dout) ? vs[(size_t)i * dout + j] : 0.0;
+    }
+    __syncthreads();
+    Acc<NT> a;
+    acc_zero<NT>(a);
+    mm_acc<NT, true, false>(a, Gt, LD, Vs, LD, w, lane);   // (G_t′)′ V_s(t + 1)
+    acc_store_out<NT>(a, cross + row * (size_t)dout * dout, dout, w, lane);
+}
+
 // Per-step constants with MANY models (a fully time-varying model has one per step): a pass of kd_fe_resid_mfma per model would be a
 // launch per model.  Here every wavefront takes one time step at a time — lane i forms row i of the two whitened residuals with the maps of
 // THAT step's models (rows read along k: uncoalesced, but the work is tiny: 4·d² multiply-adds per step) — 64 steps per workgroup, one

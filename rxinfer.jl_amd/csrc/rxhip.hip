@@ -378,6 +378,7 @@ struct rxhip_engine {
     DenseModel* m_modtab = nullptr;  // [m_models] constant-block pointers for the sweep kernels (one model per chain)
     double* m_feconst = nullptr;
     double *m_grp = nullptr, *m_gvec = nullptr;
+    bool records_hold_gains = false; // the last run was a smoothing sweep of kd_forward_info / kd_backward_info with one chain per tile: d_filt holds G_t′
     int cov_mode = 0;
     bool cov_pending = false, cov_current = false;
     double *d_dtab = nullptr, *d_vlast = nullptr, *d_vstab = nullptr, *d_fe_const = nullptr;
@@ -3296,7 +3297,7 @@ rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, d
     if (!e || !y) return RXHIP_ERR_BADARG;
     if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "filter_step: not a state-space engine");
     if (!e->dense && !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "filter_step: no device schedule for this shape");
-    e->cov_current = false; e->cov_pending = false;   // the step-wise filter writes the posterior arrays itself
+    e->cov_current = false; e->cov_pending = false; e->records_hold_gains = false;   // the step-wise filter writes the posterior arrays itself
     if ((e->d_step_model || e->d_cx) && e->stream_k >= e->Tout())
         return fail(e, RXHIP_ERR_STATE, "filter_step: the per-step constants / known inputs of this engine end after %lld observations", (long long)e->Tout());
     if (e->du > 0 && !e->have_inputs)
@@ -3361,6 +3362,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     const bool was_cov_current = e->cov_current && !filter;
     e->cov_current = false;   // any run may rewrite the posterior arrays; the split schedule in mode 1 says otherwise below
     e->cov_pending = false;
+    e->records_hold_gains = false;
     // the reference refuses to run while a datavar has no value (batch.jl:387-407): so does an engine whose graph has data inputs
     if (e->du > 0 && !e->have_inputs) return fail(e, RXHIP_ERR_STATE, "run: this model has data inputs u[t]: call rxhip_set_data(RXHIP_VAR_U) first");
     SET_DEVICE(e);
@@ -3424,6 +3426,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         const bool mseg_now = e->gseq && e->mseg && !(filter && std::getenv("RXHIP_FILTER_GSEQ"));
         if (mseg_now) {
             if ((st = mseg_run(e, fe, filter))) return st;
+            e->records_hold_gains = !filter;
         } else if (e->gseq) {
             GseqParams gq{};
             gq.T = e->T; gq.n_chains = e->n_chains; gq.d = e->d; gq.dy = e->dy; gq.ptt = e->ptt; gq.fe = fe ? 1 : 0; gq.y = e->d_y;
@@ -3494,6 +3497,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 if (info) {
                     if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
                     DENSE_DISPATCH(e->nt, backward_info(dp, fe, e->stream));
+                    e->records_hold_gains = e->pack == 1;
                     if ((st = prof_end(e))) return st;
                 }
             }
@@ -3831,9 +3835,25 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
         gq.T = e->T; gq.n_chains = e->n_chains; gq.d = e->d; gq.dy = e->dy; gq.ptt = e->ptt; gq.fe = 0; gq.y = e->d_y;
         gq.mean = scr; gq.cov = scr + nm; gq.cross = scr + nm + nc; gq.user = e->d_user; gq.prior = e->d_prior;
         gq.chain_model = e->d_chain_model; gq.step_model = e->d_step_model; gq.fe_part = nullptr; gq.status = e->d_status;
+        // After a sweep of the information-form kernels (one chain per tile, no model / data split) the smoother gains are still in the
+        // records: the cross-covariances are one product per time index.  Otherwise: the sequential re-run.
+        const bool from_records = e->records_hold_gains && !std::getenv("RXHIP_JOINTS_GSEQ");
+        if (from_records) {
+            DenseParams cp{};
+            const int nt = e->mseg ? e->m_nt : e->nt;
+            cp.T = e->T; cp.n_chains = e->n_chains; cp.d = 16 * nt; cp.d_out = e->d; cp.filt = e->d_filt; cp.cov = e->d_cov;
+            const dim3 gr((unsigned)((e->T - 1) * e->n_chains));
+            switch (nt) {
+                case 1: hipLaunchKernelGGL(kd_cross_from_records<1>, gr, dim3(64), sizeof(double) * 2 * DenseCfg<1>::MAT, e->stream, cp, gq.cross); break;
+                case 2: hipLaunchKernelGGL(kd_cross_from_records<2>, gr, dim3(128), sizeof(double) * 2 * DenseCfg<2>::MAT, e->stream, cp, gq.cross); break;
+                case 3: hipLaunchKernelGGL(kd_cross_from_records<3>, gr, dim3(192), sizeof(double) * 2 * DenseCfg<3>::MAT, e->stream, cp, gq.cross); break;
+                default: hipLaunchKernelGGL(kd_cross_from_records<4>, gr, dim3(256), sizeof(double) * 2 * DenseCfg<4>::MAT, e->stream, cp, gq.cross); break;
+            }
+        } else {
         const size_t lds = gseq_lds_bytes(e->d, e->dy);
         hipLaunchKernelGGL(k_gseq_forward, dim3((unsigned)e->n_chains), dim3(256), lds, e->stream, gq);
         hipLaunchKernelGGL(k_gseq_backward, dim3((unsigned)e->n_chains), dim3(256), lds, e->stream, gq);
+        }
         JointParams jp{};
         jp.T = e->T; jp.n_chains = e->n_chains; jp.d = e->d; jp.dy = e->dy; jp.mean = e->d_mean; jp.cov = e->d_cov; jp.cross = gq.cross;
         jp.user = e->d_user; jp.chain_model = e->d_chain_model; jp.step_model = e->d_step_model; jp.cx = e->d_cx; jp.off_chain = e->off_chain ? 1 : 0;

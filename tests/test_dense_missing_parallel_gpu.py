@@ -318,3 +318,31 @@ def test_filtering_runs_on_the_masked_schedule(d, dy, T, C, M, rate, segments, m
     assert np.max(np.abs(mm - ms) / sd) < 1e-6
     assert np.max(np.abs(cm - cs) / (sd[..., :, None] * sd[..., None, :])) < 1e-6
     assert np.allclose(fm, fs, rtol=1e-8, atol=1e-9)
+
+
+@pytest.mark.parametrize("d,dy,T,C,M,rate", [(64, 64, 150, 1, 1, 0.0), (24, 6, 200, 2, 1, 0.2), (40, 12, 120, 2, 3, 0.1), (20, 20, 300, 1, 1, 0.0)])
+def test_node_local_joints_from_the_sweep_records(d, dy, T, C, M, rate, monkeypatch):
+    """q(x[t], x[t+1] | y) of the transition nodes after a sweep of the information-form kernels: Cov(x[t], x[t+1] | y) = G_t V_s(t+1) from
+    the gains the forward sweep left in its records (kd_cross_from_records) against the sequential re-run (RXHIP_JOINTS_GSEQ)"""
+    import rxhip
+    mdl = _step_models(d, dy, M, seed=20 + d)
+    rng = np.random.default_rng(T)
+    sm = rng.integers(0, M, T).astype(np.int32) if M > 1 else None
+    y = rng.standard_normal((T, C, dy)) * 2.0
+    if rate > 0:
+        y[rng.random((T, C)) < rate] = np.nan
+    args = mdl if M > 1 else tuple(a[0] for a in mdl)
+    out = []
+    for env in (None, "1"):
+        if env:
+            monkeypatch.setenv("RXHIP_JOINTS_GSEQ", env)
+        else:
+            monkeypatch.delenv("RXHIP_JOINTS_GSEQ", raising=False)
+        with rxhip.LGSSMEngine(*args, T=T, n_chains=C, step_model=sm, allow_missing=rate > 0) as eng:
+            eng.set_data(y)
+            eng.run(1, True)
+            out.append(eng.node_marginals())
+    (jm, jc), (sm_, sc) = out
+    sd = np.sqrt(np.einsum("tcii->tci", sc))
+    assert np.max(np.abs(jm - sm_) / sd) < 1e-6
+    assert np.max(np.abs(jc - sc) / (sd[..., :, None] * sd[..., None, :])) < 1e-6
