@@ -57,6 +57,10 @@ struct MsegParams {
     int sg, ng;
     double* mgrp;           // [chain][ng][3][d][d]  Λ, Ψ, Ĵ of a whole group (km_group)
     double* mgvec;          // [chain][ng][2][d]     ξ, η̂
+    // log-depth boundary recursion (km_compose + km_apply): hs_rounds > 0 (or S ≤ 2) selects it; two generations of running compositions
+    // per direction — hs [dir][gen parity][chain][S][3][d][d], hsv [dir][gen parity][chain][S][2][d]
+    int hs, hs_rounds;
+    double *hsel, *hsvec;
     // per-step constants (desc.step_model; null: one model): time index t uses block step_model[t] of `in`, `cw` and of the constant
     // blocks `cst` (strides in doubles); fe_const[chain]: the data-independent part of the free energy, summed over the chain's steps
     const int* step_model;
@@ -72,6 +76,10 @@ __device__ __forceinline__ int mseg_model(const MsegParams& p, long long chain, 
     return p.chain_model ? p.chain_model[chain] : 0;
 }
 constexpr int MSEG_WS = 14;
+// LDS of the km kernels (doubles): scratch of the inverse | 2·64·NT | 8 vectors | 16, then — kernels with inlined blocks — the staging
+// matrix of tab_mm_staged
+__host__ __device__ constexpr int mseg_stage_offset(int NT) { return blk_scratch_doubles(NT) + 2 * 64 * NT + 8 * 16 * NT + 16; }
+__host__ __device__ constexpr int mseg_lds_doubles(int NT, bool staged) { return mseg_stage_offset(NT) + (staged ? 16 * NT * tab_stage_ld(NT) : 0); }
 
 // grid (blocks over time, chains); nobs[chain] must be zero on entry (mseg_launch clears it): exact integer counts, any order
 __global__ void __launch_bounds__(256) km_mask(MsegParams p) {
@@ -126,10 +134,10 @@ __device__ __forceinline__ double tab_col_dot(const double* M, int i, const doub
 // first version of this file) needed an inverse and eleven; and the boundary recursions below need exactly (Λ, Ψ, Ĵ, ξ, η̂), nothing else.
 // Out of the known start through the first transition: Λp = P⁻¹, Ψ = K, Ĵ = A′P⁻¹A, ξ = η̂ = 0.
 template <int NT>
-__global__ void __launch_bounds__(64 * NT) km_elements(MsegParams p) {
+__global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
     constexpr int D = 16 * NT, MM = D * D;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
+    TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
     double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;   // ξ | c | η̂ | y
     double *xi = vec, *cv = vec + D, *eta = vec + 2 * D, *yv = vec + 3 * D;
     const int tid = o.tid, dyu = p.dy_user;
@@ -379,6 +387,120 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p, int level) {
             o.symadd(slot(k - 1), -1.0, T2, 1.0, g + 2 * MM);             // Λβ′ = Ĵ − sym(N1 Ψ)
             if (tid < D) xi[tid] = tv[tid];
             o.sync();
+        }
+    }
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// Log-depth boundary recursion (few chains, many segments: the sequential depth of the two-level recursion, 2·√S + √S element steps, is what
+// a single long chain waits for).  Composition of elements is associative, so all prefix compositions P[j] = E_0 ∘ … ∘ E_j and all suffix
+// compositions Q[j] = E_j ∘ … ∘ E_{S−1} come out of ⌈log₂ S⌉ rounds of pairwise compositions (round r: P[j] ← P[j − 2^r] ∘ P[j],
+// Q[j] ← Q[j] ∘ Q[j + 2^r]), 2·S workgroups per round, each the km_group step (one inverse, five products).  An entry at distance i from
+// the origin of its scan takes part in rounds 0 … ⌊log₂ i⌋; generation 0 is the element itself (mel / mvec), generation g ≥ 1 lives in buffer
+// (g − 1) mod 2: a round reads generation r (and the finished generation of its partner) and writes r + 1 into the other buffer, nobody
+// copies.  km_apply then sends the belief at t = 0 through P[s − 1] (filtered belief at the start of segment s) and the empty message
+// through Q[s + 1] (backward message at the end of segment s): one step of km_scan each, all segments in parallel.
+__device__ __forceinline__ int hs_generations(int i) { return i == 0 ? 0 : 32 - __clz(i); }
+__device__ __forceinline__ size_t hs_slot(const MsegParams& p, int dir, int gen, long long chain, int idx) {
+    return ((size_t)(dir * 2 + ((gen - 1) & 1)) * (size_t)p.n_chains + (size_t)chain) * (size_t)p.S + (size_t)idx;
+}
+template <int NT>
+__global__ void __launch_bounds__(64 * NT, 2) km_compose(MsegParams p, int r) {   // ≤ 256 registers: two workgroups per CU at d ≥ 48
+    constexpr int D = 16 * NT, MM = D * D;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
+    double* u = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
+    const int tid = o.tid, S = p.S;
+    const int dir = (int)blockIdx.x / S, j = (int)blockIdx.x - dir * S, h = 1 << r;
+    const long long chain = blockIdx.y;
+    const int i = dir == 0 ? j : S - 1 - j;          // distance from the origin of the scan
+    if (i < h || i == S - 1) return;                 // finished — or the whole chain's composition, which nobody reads
+    const int jp = dir == 0 ? j - h : j + h, gp = hs_generations(i - h) < r ? hs_generations(i - h) : r;
+    auto el = [&](int idx, int gen) { return gen == 0 ? p.mel + ((size_t)chain * S + idx) * 3 * MM : p.hsel + hs_slot(p, dir, gen, chain, idx) * 3 * MM; };
+    auto elv = [&](int idx, int gen) { return gen == 0 ? p.mvec + ((size_t)chain * S + idx) * 2 * D : p.hsvec + hs_slot(p, dir, gen, chain, idx) * 2 * D; };
+    // element 1 comes first in time
+    const double *e1 = dir == 0 ? el(jp, gp) : el(j, r), *e2 = dir == 0 ? el(j, r) : el(jp, gp);
+    const double *v1 = dir == 0 ? elv(jp, gp) : elv(j, r), *v2 = dir == 0 ? elv(j, r) : elv(jp, gp);
+    double* eo = p.hsel + hs_slot(p, dir, r + 1, chain, j) * 3 * MM;
+    double* vo = p.hsvec + hs_slot(p, dir, r + 1, chain, j) * 2 * D;
+    double* W = p.ws + (((size_t)chain * S + j) * MSEG_WS + 4 * dir) * MM;   // km_elements is done with its scratch
+    double *Ti = W, *Am = W + MM, *Bm = W + 2 * MM, *T2 = W + 3 * MM;
+    const bool ok = o.inv_symadd(Ti, 1.0, e1, 1.0, e2 + 2 * MM);             // T⁻¹, T = Λ1 + Ĵ2
+    if (tid < D) u[tid] = v1[tid] + v2[D + tid];                            // ξ1 + η̂2
+    o.template mm<false, false, false>(Am, Ti, e1 + MM);                     // A = T⁻¹Ψ1
+    o.template mm<false, true>(Bm, Ti, e2 + MM);                             // B′ = T⁻¹Ψ2′   (barrier: A is stored, u is visible)
+    if (tid < D) {
+        vo[D + tid] = v1[D + tid] + tab_col_dot<D>(Am, tid, u);             // η̂ = η̂1 + A′(ξ1 + η̂2)
+        vo[tid] = v2[tid] + tab_col_dot<D>(Bm, tid, u);                     // ξ = ξ2 + Ψ2 T⁻¹(ξ1 + η̂2)
+    }
+    o.template mm<true, false, false>(eo + 2 * MM, e1 + MM, Am, -1.0, e1 + 2 * MM, 1.0);   // Ĵ = Ĵ1 − Ψ1′A
+    o.template mm<false, false, false>(eo + MM, e2 + MM, Am);                // Ψ = Ψ2 A
+    o.template mm<false, false>(T2, e2 + MM, Bm);                            // Ψ2 T⁻¹Ψ2′
+    o.symadd(eo, -1.0, T2, 1.0, e2);                                         // Λ = Λ2 − sym(B Ψ2′)
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+template <int NT>
+__global__ void __launch_bounds__(64 * NT, 2) km_apply(MsegParams p) {
+    constexpr int D = 16 * NT, MM = D * D;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
+    double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
+    double *xi = vec, *u = vec + D, *tv = vec + 2 * D;
+    const int tid = o.tid, S = p.S, dyu = p.dy_user;
+    const int dir = (int)blockIdx.x / S, s = (int)blockIdx.x - dir * S;
+    const long long chain = blockIdx.y;
+    double* W = p.ws + (((size_t)chain * S + s) * MSEG_WS + 8 + 3 * dir) * MM;
+    double *Wm = W, *N1 = W + MM, *T2 = W + 2 * MM;
+    bool ok = true;
+    auto fin = [&](int dr, int idx, const double*& g, const double*& gv) {   // the finished composition of entry idx
+        const int gen = hs_generations(dr == 0 ? idx : S - 1 - idx);
+        g = gen == 0 ? p.mel + ((size_t)chain * S + idx) * 3 * MM : p.hsel + hs_slot(p, dr, gen, chain, idx) * 3 * MM;
+        gv = gen == 0 ? p.mvec + ((size_t)chain * S + idx) * 2 * D : p.hsvec + hs_slot(p, dr, gen, chain, idx) * 2 * D;
+    };
+    if (dir == 0) {
+        // belief at t = 0: prior ⊗ observation message (if y_0 is observed) — as km_scan forms it
+        const int m0i = mseg_model(p, chain, 0);
+        auto CW = [&](int slot) { return p.cw + (size_t)m0i * (size_t)p.cw_stride + (size_t)slot * MM; };
+        const double* in0 = p.in + (size_t)m0i * (size_t)p.in_stride;
+        const bool ob0 = p.obs[chain * p.T] != 0.0;
+        const double* m1v = in0 + 5 * MM;
+        if (tid < D) {
+            double mm1 = m1v[tid];
+            if (p.ptt) mm1 = tab_row_dot<D>(in0, tid, m1v);
+            u[tid] = mm1;
+            tv[tid] = (ob0 && tid < dyu) ? p.y[(0 * p.n_chains + chain) * dyu + tid] : 0.0;
+        }
+        o.sync();
+        if (tid < D) xi[tid] = tab_col_dot<D>(CW(TabWs::V1I), tid, u) + (ob0 ? tab_row_dot<D>(CW(TabWs::G), tid, tv) : 0.0);
+        o.sync();
+        double* out = p.mbnd + ((size_t)chain * S + s) * 2 * MM;
+        if (s == 0) {
+            o.lin(out, 1.0, CW(TabWs::V1I), ob0 ? 1.0 : 0.0, CW(TabWs::LOBS));
+            if (tid < D) p.fstart_m[((size_t)chain * S) * D + tid] = xi[tid];
+        } else {
+            const double *g, *gv;
+            fin(0, s - 1, g, gv);
+            ok = o.inv_symadd(Wm, 1.0, CW(TabWs::V1I), 1.0, g + 2 * MM, ob0 ? CW(TabWs::LOBS) : nullptr);   // T⁻¹, T = Λ_f(0) + Ĵ
+            o.template mm<false, true>(N1, Wm, g + MM);                       // N1′ = T⁻¹Ψ′
+            if (tid < D) u[tid] = xi[tid] + gv[D + tid];                      // ξ_f(0) + η̂
+            o.template mm<false, false>(T2, g + MM, N1);                      // Ψ T⁻¹Ψ′   (its barrier: u is visible)
+            if (tid < D) p.fstart_m[((size_t)chain * S + s) * D + tid] = gv[tid] + tab_col_dot<D>(N1, tid, u);
+            o.symadd(out, -1.0, T2, 1.0, g);                                  // Λ_f(b_s) = Λ − sym(N1 Ψ′)
+        }
+    } else {
+        double* out = p.mlb + ((size_t)chain * S + s) * MM;
+        double* xo = p.beta_xi + ((size_t)chain * (S + 1) + s + 1) * D;
+        if (s == S - 1) {
+            o.eye(out, 0.0);                                                  // nothing behind the last step
+            if (tid < D) xo[tid] = 0.0;
+        } else {
+            const double *g, *gv;
+            fin(1, s + 1, g, gv);
+            ok = o.inv_symadd(Wm, 1.0, g, 0.0, g);                            // T⁻¹, T = Λ (+ Λβ = 0)
+            o.template mm<false, false>(N1, Wm, g + MM);                      // N1′ = T⁻¹Ψ
+            o.template mm<true, false>(T2, g + MM, N1);                       // Ψ′T⁻¹Ψ
+            if (tid < D) xo[tid] = gv[D + tid] + tab_col_dot<D>(N1, tid, gv); // ξβ = η̂ + Ψ′T⁻¹ξ
+            o.symadd(out, -1.0, T2, 1.0, g + 2 * MM);                         // Λβ = Ĵ − sym(N1 Ψ)
         }
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);

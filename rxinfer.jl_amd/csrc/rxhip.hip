@@ -378,6 +378,8 @@ struct rxhip_engine {
     DenseModel* m_modtab = nullptr;  // [m_models] constant-block pointers for the sweep kernels (one model per chain)
     double* m_feconst = nullptr;
     double *m_grp = nullptr, *m_gvec = nullptr;
+    int m_hs = 0, m_hs_rounds = 0;   // masked schedule: log-depth boundary recursion (km_compose / km_apply)
+    double *m_hsel = nullptr, *m_hsvec = nullptr;
     bool records_hold_gains = false; // the last run was a smoothing sweep of kd_forward_info / kd_backward_info with one chain per tile: d_filt holds G_t′
     int cov_mode = 0;
     bool cov_pending = false, cov_current = false;
@@ -1258,7 +1260,7 @@ static rxhip_status prof_end(rxhip_engine* e);
 template <int NT>
 static hipError_t mseg_prepare_kernels() {
     hipError_t err;
-    for (const void* f : {(const void*)km_elements<NT>, (const void*)km_scan<NT>, (const void*)km_group<NT>, (const void*)km_bnd<NT>, (const void*)km_filter_out<NT>,
+    for (const void* f : {(const void*)km_elements<NT>, (const void*)km_scan<NT>, (const void*)km_group<NT>, (const void*)km_compose<NT>, (const void*)km_apply<NT>, (const void*)km_bnd<NT>, (const void*)km_filter_out<NT>,
                           (const void*)kt_consts<NT>})
         if ((err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return err;
     return DenseLaunch<NT>::prepare();
@@ -1287,9 +1289,19 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     // three-level boundary recursion in balance); chains that fill the machine on their own: ONE segment per chain — the sweep kernels run
     // the whole chain, no element pass (three sweep steps' worth per time step) and no boundary recursion.
     long long S = 1;
+    // RXHIP_MSEG_SCAN = sequential | log: the boundary recursion as one / two sequential levels, or in ⌈log₂ S⌉ rounds (default: the cheaper one)
+    const char* scan_env = std::getenv("RXHIP_MSEG_SCAN");
+    const int scan_mode = std::getenv("RXHIP_MSEG_ONE_LEVEL") ? 1 : scan_env && !std::strcmp(scan_env, "sequential") ? 1 : scan_env && !std::strcmp(scan_env, "log") ? 2 : 0;
+    auto hs_fits = [&](long long s) { return (double)C * (double)s * (MSEG_WS + 9 + 12) * MM * 8.0 <= 6e9; };   // scratch + elements + four generations
+    auto hs_rounds_of = [](long long s) { int r = 0; while ((1LL << r) <= s - 2) ++r; return r; };
+    const double f = (double)(e->m_nt - 1) / 3.0, c_s = 8.0 + f * 13.0, c_g = 15.0 + f * 35.0;
+    // workgroups in flight: km_elements, km_compose and km_apply carry a register bound of their own (blocks inlined, one operand staged
+    // through LDS: ≤ 256 registers) — 8, 4, 2, 2 workgroups per CU at d = 16 / 32 / 48 / 64, like the sweep kernels; the non-inlined
+    // blocks of km_group / km_scan take 280 – 312 registers at d ≥ 48 (one workgroup per CU; their grids are small)
+    const double conc = e->m_nt == 1 ? 2048.0 : e->m_nt == 2 ? 1024.0 : 512.0;
+    const double conc_c = conc, c_c = 20.0 + f * 50.0;   // a round of compositions with every CU busy: 73 µs at d = 64
     {
-        const double f = (double)(e->m_nt - 1) / 3.0, c_e = 15.0 + f * 35.0, c_s = 8.0 + f * 13.0, c_g = 15.0 + f * 35.0, c_f = 5.7 + f * 14.3;
-        const double conc = e->m_nt == 1 ? 2048.0 : e->m_nt == 2 ? 1024.0 : 512.0;
+        const double c_e = 15.0 + f * 40.0, c_f = 5.7 + f * 21.0;   // element step (55 µs at d = 64 with every CU busy), forward + backward sweep step
         auto cost = [&](long long s) {
             const double steps = std::ceil((double)(T - 1) / (double)s), rounds = std::ceil((double)C * (double)s / conc);
             double scan = 0.0;
@@ -1298,6 +1310,11 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
                 scan = (sg * c_g + (ng + 2.0 * sg) * c_s) * std::ceil((double)C * ng / conc);
             } else if (s > 1)
                 scan = (double)s * c_s * std::ceil(2.0 * (double)C / conc);
+            if (s > 2 && scan_mode != 1 && hs_fits(s)) {   // log-depth: ⌈log₂⌉ rounds of 2·s compositions, one parallel boundary step
+                const double wv = std::ceil(2.0 * (double)C * (double)s / conc_c);
+                const double lg = (double)hs_rounds_of(s) * c_c * wv + 2.5 * c_s * wv;
+                if (lg < scan || scan_mode == 2) scan = lg;
+            }
             return rounds * steps * ((s > 1 ? c_e : 0.0) + c_f) + scan;
         };
         double best = 0.7 * cost(1);   // (the interpolated element costs are optimistic between d = 16 and 64: leave one segment only for a clear win)
@@ -1315,13 +1332,27 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     e->mS = (int)S; e->mL = L;
     // two-level boundary recursion from 16 segments on: groups of ≈√S segments (km_group, km_scan levels 2 / 3)
     e->m_sg = 0; e->m_ng = 0;
-    if (S >= 16 && !std::getenv("RXHIP_MSEG_ONE_LEVEL")) {
+    e->m_hs = 0; e->m_hs_rounds = 0;
+    {   // the boundary recursion of this S: sequential (one level, or two from 16 segments on) or log-depth, by the same cost figures
+        double seq = (double)S * c_s * std::ceil(2.0 * (double)C / conc);
+        if (S >= 16 && !std::getenv("RXHIP_MSEG_ONE_LEVEL")) {
+            const double sg = std::ceil(std::sqrt((double)S)), ng = std::ceil((double)S / sg);
+            seq = (sg * c_g + (ng + 2.0 * sg) * c_s) * std::ceil((double)C * ng / conc);
+        }
+        const double wv = std::ceil(2.0 * (double)C * (double)S / conc_c), lg = (double)hs_rounds_of(S) * c_c * wv + 2.5 * c_s * wv;
+        if (S > 2 && hs_fits(S) && scan_mode != 1 && (lg < seq || scan_mode == 2)) {
+            e->m_hs = 1;
+            e->m_hs_rounds = hs_rounds_of(S);
+        }
+    }
+    if (!e->m_hs && S >= 16 && !std::getenv("RXHIP_MSEG_ONE_LEVEL")) {
         int sg = 1;
         while ((long long)sg * sg < S) ++sg;
         e->m_sg = sg;
         e->m_ng = (int)((S + sg - 1) / sg);
     }
     const size_t NG = (size_t)(e->m_ng > 0 ? e->m_ng : 1);
+    const size_t HS = e->m_hs ? (size_t)C * (size_t)S * 4 : 1;   // entries of the two generations of both scans
     const DenseCst cl = DenseCst::make((int)D, e->dy);
     const int rec = dense_rec(e->m_nt), tri = dense_tri(e->m_nt);
     const size_t nws = std::max<size_t>((size_t)C * (size_t)S, (size_t)2 * C) * MSEG_WS * MM;
@@ -1330,14 +1361,15 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     const size_t parts[] = {NM * (5 * MM + D), NM * CWN, NM * (size_t)cl.size, C * T, C, C * S * 3 * MM, C * S * 2 * D, C * S * 2 * MM, C * S * MM, nws,
                             C * T * (size_t)rec, C * S * (size_t)tri, C * S * D, C * (S + 1) * D,
                             (2 * (size_t)S + 2 + NM * (size_t)fe_resid_blocks(e->T, e->m_dpad, e->dy)) * C, C * NG * 3 * MM, C * NG * 2 * D, C,
-                            NM * ((sizeof(DenseModel) + 7) / 8)};
-    size_t off[20] = {0};
-    for (int q = 0; q < 19; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
-    HIPCHK(e, hipMalloc(&e->mseg_block, off[19]));
+                            NM * ((sizeof(DenseModel) + 7) / 8), HS * 3 * MM, HS * 2 * D};
+    size_t off[22] = {0};
+    for (int q = 0; q < 21; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
+    HIPCHK(e, hipMalloc(&e->mseg_block, off[21]));
     auto at = [&](int q) { return (double*)(e->mseg_block + off[q]); };
     e->m_in = at(0); e->m_cw = at(1); e->m_cst = at(2); e->m_obs = at(3); e->m_nobs = at(4); e->m_el = at(5); e->m_vec = at(6); e->m_bnd = at(7);
     e->m_lb = at(8); e->m_ws = at(9); e->d_filt = at(10); e->d_vend = at(11); e->d_fstart_m = at(12); e->d_beta_xi = at(13); e->m_fe_part = at(14);
     e->m_grp = at(15); e->m_gvec = at(16); e->m_feconst = at(17); e->m_modtab = reinterpret_cast<DenseModel*>(at(18));
+    e->m_hsel = at(19); e->m_hsvec = at(20);
     // the models padded to d×d (copies only) and their constant blocks, built on the device (one kt_consts launch per model)
     const size_t IN1 = 5 * MM + D, CW1 = CWN;
     std::vector<double> hin(NM * IN1, 0.0);
@@ -1393,13 +1425,17 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
 }
 template <int NT>
 static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams& dp, bool fe, bool filter) {
-    const size_t lds = sizeof(double) * (size_t)(blk_scratch_doubles(NT) + 2 * 64 * NT + 8 * 16 * NT + 16);
+    const size_t lds = sizeof(double) * (size_t)mseg_lds_doubles(NT, false), lds_s = sizeof(double) * (size_t)mseg_lds_doubles(NT, true);
     hipStream_t s = e->stream;
     (void)hipMemsetAsync(mp.nobs, 0, sizeof(double) * (size_t)mp.n_chains, s);
     hipLaunchKernelGGL(km_mask, dim3((unsigned)std::min<long long>(64, (mp.T + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
     if (mp.S == 1) hipLaunchKernelGGL(km_gy, dim3((unsigned)(((mp.T - 1) * mp.d + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
-    else hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
-    if (mp.ng > 0) {   // two levels: group elements, the states at the group edges, then every group on its own
+    else hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds_s, s, mp);
+    if (mp.hs) {       // log-depth: all prefix / suffix compositions in ⌈log₂ S⌉ rounds, then every boundary state at once
+        for (int r = 0; r < mp.hs_rounds; ++r)
+            hipLaunchKernelGGL((km_compose<NT>), dim3(2 * (unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds_s, s, mp, r);
+        hipLaunchKernelGGL((km_apply<NT>), dim3(2 * (unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds_s, s, mp);
+    } else if (mp.ng > 0) {   // two levels: group elements, the states at the group edges, then every group on its own
         hipLaunchKernelGGL((km_group<NT>), dim3((unsigned)mp.ng, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
         hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 2);
         hipLaunchKernelGGL((km_scan<NT>), dim3(2 * (unsigned)mp.ng, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 3);
@@ -1426,6 +1462,7 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe, bool filter) {
     mp.mbnd = e->m_bnd; mp.mlb = e->m_lb; mp.fstart_m = e->d_fstart_m; mp.beta_xi = e->d_beta_xi; mp.filt = e->d_filt; mp.rec = dense_rec(e->m_nt);
     mp.status = e->d_status;
     mp.sg = e->m_sg; mp.ng = e->m_ng; mp.mgrp = e->m_grp; mp.mgvec = e->m_gvec;
+    mp.hs = e->m_hs; mp.hs_rounds = e->m_hs_rounds; mp.hsel = e->m_hsel; mp.hsvec = e->m_hsvec;
     const DenseCst clm = DenseCst::make(e->m_dpad, e->dy);
     mp.step_model = e->m_stepm ? e->d_step_model : nullptr;
     mp.chain_model = e->m_chainm ? e->d_chain_model : nullptr;
@@ -3980,8 +4017,8 @@ rxhip_status rxhip_get_schedule(rxhip_engine* e, int32_t* segments, int64_t* seg
         if (segment_len) *segment_len = 256;
         return RXHIP_OK;
     }
-    if (segments) *segments = e->S;
-    if (segment_len) *segment_len = e->L;
+    if (segments) *segments = e->mseg ? e->mS : e->S;          // masked / per-step engines: the schedule of dense_mseg_kernels.hpp
+    if (segment_len) *segment_len = e->mseg ? e->mL : e->L;
     return RXHIP_OK;
 }
 

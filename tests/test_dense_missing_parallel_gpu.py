@@ -99,6 +99,7 @@ def test_two_level_boundary_recursion_equals_one_level(d, dy, T, C, segments, mo
     y = workloads.generate_batch(mdl, T, C, seed0=4)
     y[np.random.default_rng(T).random((T, C)) < 0.2] = np.nan
     out = []
+    monkeypatch.setenv("RXHIP_MSEG_SCAN", "sequential")       # (not the log-depth recursion, which the cost model may prefer)
     for one_level in (False, True):
         if one_level:
             monkeypatch.setenv("RXHIP_MSEG_ONE_LEVEL", "1")
@@ -110,6 +111,28 @@ def test_two_level_boundary_recursion_equals_one_level(d, dy, T, C, segments, mo
     assert np.max(np.abs(m2 - m1) / sd) < 1e-8
     assert np.max(np.abs(c2 - c1) / (sd[..., :, None] * sd[..., None, :])) < 1e-8
     assert np.allclose(f2, f1, rtol=1e-10, atol=1e-9)
+
+
+@pytest.mark.parametrize("d,dy,T,C,segments,ptt", [(24, 6, 400, 2, 0, False), (64, 64, 260, 1, 50, False), (16, 16, 700, 1, 0, True), (8, 3, 90, 3, 3, False),
+                                                      (40, 12, 130, 2, 33, True), (64, 20, 1200, 1, 0, False), (12, 12, 64, 5, 63, False), (32, 32, 50, 1, 4, True)])
+def test_log_depth_boundary_recursion_equals_the_sequential_one(d, dy, T, C, segments, ptt, monkeypatch):
+    """km_compose / km_apply (all prefix and suffix compositions of the segment elements in ⌈log₂ S⌉ rounds, RXHIP_MSEG_SCAN=log) against the
+    plain recursion over all segments (RXHIP_MSEG_ONE_LEVEL): S = 3 … T − 1 segments, powers of two and their neighbours, several chains"""
+    from rxhip import workloads
+    mdl = workloads.random_model(d, dy, seed=61 + d)
+    y = workloads.generate_batch(mdl, T, C, seed0=5)
+    y[np.random.default_rng(T + d).random((T, C)) < 0.2] = np.nan
+    y[0, 0] = np.nan
+    monkeypatch.delenv("RXHIP_MSEG_ONE_LEVEL", raising=False)
+    monkeypatch.setenv("RXHIP_MSEG_SCAN", "log")
+    ml, cl, fl = _run(mdl, y, ptt, False, monkeypatch, segments)
+    monkeypatch.setenv("RXHIP_MSEG_SCAN", "sequential")
+    monkeypatch.setenv("RXHIP_MSEG_ONE_LEVEL", "1")
+    m1, c1, f1 = _run(mdl, y, ptt, False, monkeypatch, segments)
+    sd = np.sqrt(np.einsum("tcii->tci", c1))
+    assert np.max(np.abs(ml - m1) / sd) < 1e-8
+    assert np.max(np.abs(cl - c1) / (sd[..., :, None] * sd[..., None, :])) < 1e-8
+    assert np.allclose(fl, f1, rtol=1e-10, atol=1e-9)
 
 
 def _random_cases(n, seed):

@@ -123,3 +123,60 @@ def test_composition_of_two_elements_is_the_element_of_both(d, dy, n1, n2, seed)
     both = _compose(_element(A, B, P, Q, ys[:n1]), _element(A, B, P, Q, ys[n1:]))
     for a, b in zip(whole, both):
         assert np.allclose(a, b, rtol=1e-9, atol=1e-11)
+
+
+def _generations(i):
+    """rounds an entry at distance i from the origin of its scan takes part in (hs_generations)"""
+    return 0 if i == 0 else int(i).bit_length()
+
+
+@pytest.mark.parametrize("S", [2, 3, 4, 5, 8, 9, 17, 31, 32, 33])
+def test_log_depth_rounds_with_two_buffers_give_every_prefix_and_suffix(S):
+    """km_compose / km_apply: ⌈log₂⌉ rounds of pairwise compositions, generation g ≥ 1 of an entry kept in buffer (g − 1) mod 2 (generation 0:
+    the element itself), the whole chain's composition never formed — every P[j] = E_0 ∘ … ∘ E_j (j ≤ S − 2) and Q[j] = E_j ∘ … ∘ E_{S−1}
+    (j ≥ 1) must come out where km_apply looks for it, and nothing may be read from a slot that the same round writes."""
+    d, dy = 3, 2
+    A, B, P, Q, _, _ = _model(d, dy, S)
+    rng = np.random.default_rng(S)
+    els = []
+    for s in range(S):
+        ys = rng.standard_normal((int(rng.integers(1, 4)), dy))
+        ys[rng.random(len(ys)) < 0.3] = np.nan
+        els.append(_element(A, B, P, Q, ys))
+    rounds = 0
+    while (1 << rounds) <= S - 2:
+        rounds += 1
+    buf = {}                                     # (dir, parity, index) -> element
+
+    def get(dr, idx, gen):
+        return els[idx] if gen == 0 else buf[(dr, (gen - 1) & 1, idx)]
+    for r in range(rounds):
+        h = 1 << r
+        written, read = {}, set()
+        for dr in (0, 1):
+            for j in range(S):
+                i = j if dr == 0 else S - 1 - j
+                if i < h or i == S - 1:
+                    continue
+                jp = j - h if dr == 0 else j + h
+                gp = min(_generations(i - h), r)
+                e_self, e_part = get(dr, j, r), get(dr, jp, gp)
+                if r > 0:
+                    read.add((dr, (r - 1) & 1, j))
+                if gp > 0:
+                    read.add((dr, (gp - 1) & 1, jp))
+                written[(dr, r & 1, j)] = _compose(e_part, e_self) if dr == 0 else _compose(e_self, e_part)
+        assert not (read & set(written)), (S, r)
+        buf.update(written)
+    for j in range(S - 1):                       # prefixes that km_apply reads
+        ref = els[0]
+        for e in els[1:j + 1]:
+            ref = _compose(ref, e)
+        for a, b in zip(get(0, j, _generations(j)), ref):
+            assert np.allclose(a, b, rtol=1e-8, atol=1e-10), (S, j)
+    for j in range(1, S):                        # suffixes
+        ref = els[S - 1]
+        for e in reversed(els[j:S - 1]):
+            ref = _compose(e, ref)
+        for a, b in zip(get(1, j, _generations(S - 1 - j)), ref):
+            assert np.allclose(a, b, rtol=1e-8, atol=1e-10), (S, j)
