@@ -131,7 +131,7 @@ __device__ __forceinline__ double tab_col_dot(const double* M, int i, const doub
 //     C_t = (Λ + A′P⁻¹A)⁻¹,  Λp = P⁻¹ − K C_t K′ (K = P⁻¹A),  Y = C_t Ψ,  Ψ ← K Y,  Ĵ ← Ĵ − Ψ′Y,  c = C_t ξ,  η̂ ← η̂ + Ψ′c,  ξ ← K c + B′Q⁻¹y,
 //     Λ ← Λp + B′Q⁻¹B   (observed steps only)
 // — the forward step of kd_forward_info plus three products, ONE inverse and five products per step where the covariance form (the
-// first version of this file) needed an inverse and eleven; and the boundary recursions below need exactly (Λ, Ψ, Ĵ, ξ, η̂), nothing else.
+// first version of this file) needed an inverse and eleven (products that share an operand run as one block: tab_mm2_staged); and the boundary recursions below need exactly (Λ, Ψ, Ĵ, ξ, η̂), nothing else.
 // Out of the known start through the first transition: Λp = P⁻¹, Ψ = K, Ĵ = A′P⁻¹A, ξ = η̂ = 0.
 template <int NT>
 __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
@@ -177,17 +177,15 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
         }
         (void)obp;
         ok = o.inv_symadd(Cx, 1.0, Msrc, 1.0, WC, Mobs) && ok;        // C = (Λ(t − 1) + A′P⁻¹A)⁻¹
-        o.template mm<false, false, false>(Gt, KC, Cx);               // K C            (nobody reads it before the barrier of the next product)
         if (tid < D) cv[tid] = tab_col_dot<D>(Cx, tid, xi);           // c = C ξ   (C is symmetric: coalesced columns)
-        o.template mm<false, false>(Y, Cx, Pc);                       // Y = C Ψ   (its barrier: c is visible, K C is stored)
+        o.template mm2<false, true, false>(Gt, KC, 1.0, nullptr, 0.0, Y, Pc, Cx);   // K C and Y′ = Ψ′C: C is the shared, staged operand   (barriers: c is visible)
         if (tid < D) {
             const double gy = ob ? tab_row_dot<D>(G, tid, yv) : 0.0;
             eta[tid] += tab_col_dot<D>(Pc, tid, cv);                  // η̂ += Ψ′c
             xi[tid] = tab_row_dot<D>(KC, tid, cv) + gy;               // ξ = K c + B′Q⁻¹y   (every reader of the old ξ is behind a barrier)
             rec[D + tid] = gy;
         }
-        o.template mm<true, false, false>(Jh, Pc, Y, -1.0, Jh, 1.0);  // Ĵ −= Ψ′Y
-        o.template mm<false, false, false>(Pn, KC, Y);                // Ψ′ = K Y  (into the other copy)
+        o.template mm2<true, false, true, false, false>(Jh, Pc, -1.0, Jh, 1.0, Pn, KC, Y);   // Ĵ −= Ψ′Y and Ψ = K Y (into the other copy): Y is the shared operand
         o.template mm<false, true>(Lp, Gt, KC, -1.0, PI, 1.0);        // Λp = P⁻¹ − K C K′   (barrier: all three are stored)
         Msrc = Lp;
         Mobs = ob ? LO : nullptr;
@@ -425,18 +423,14 @@ __global__ void __launch_bounds__(64 * NT, 2) km_compose(MsegParams p, int r) { 
     double* vo = p.hsvec + hs_slot(p, dir, r + 1, chain, j) * 2 * D;
     double* W = p.ws + (((size_t)chain * S + j) * MSEG_WS + 4 * dir) * MM;   // km_elements is done with its scratch
     double *Ti = W, *Am = W + MM, *Bm = W + 2 * MM, *T2 = W + 3 * MM;
+    // (the transposes A′ = Ψ1′T⁻¹ and B = Ψ2 T⁻¹ are what is formed: T⁻¹ is the shared, staged operand of both, and of the two vectors)
     const bool ok = o.inv_symadd(Ti, 1.0, e1, 1.0, e2 + 2 * MM);             // T⁻¹, T = Λ1 + Ĵ2
-    if (tid < D) u[tid] = v1[tid] + v2[D + tid];                            // ξ1 + η̂2
-    o.template mm<false, false, false>(Am, Ti, e1 + MM);                     // A = T⁻¹Ψ1
-    o.template mm<false, true>(Bm, Ti, e2 + MM);                             // B′ = T⁻¹Ψ2′   (barrier: A is stored, u is visible)
-    if (tid < D) {
-        vo[D + tid] = v1[D + tid] + tab_col_dot<D>(Am, tid, u);             // η̂ = η̂1 + A′(ξ1 + η̂2)
-        vo[tid] = v2[tid] + tab_col_dot<D>(Bm, tid, u);                     // ξ = ξ2 + Ψ2 T⁻¹(ξ1 + η̂2)
-    }
-    o.template mm<true, false, false>(eo + 2 * MM, e1 + MM, Am, -1.0, e1 + 2 * MM, 1.0);   // Ĵ = Ĵ1 − Ψ1′A
-    o.template mm<false, false, false>(eo + MM, e2 + MM, Am);                // Ψ = Ψ2 A
-    o.template mm<false, false>(T2, e2 + MM, Bm);                            // Ψ2 T⁻¹Ψ2′
-    o.symadd(eo, -1.0, T2, 1.0, e2);                                         // Λ = Λ2 − sym(B Ψ2′)
+    if (tid < D) u[tid] = v1[tid] + v2[D + tid];                            // ξ1 + η̂2   (visible behind the barriers of the staging)
+    o.template mm2<true, false, false, true>(Am, e1 + MM, 1.0, nullptr, 0.0, Bm, e2 + MM, Ti,   // A′ = Ψ1′T⁻¹, B = Ψ2 T⁻¹
+                                             u, v1 + D, vo + D, v2, vo);     // η̂ = η̂1 + A′(ξ1 + η̂2),  ξ = ξ2 + B(ξ1 + η̂2)
+    o.template mm2<true, false, true, false, false>(eo + 2 * MM, e1 + MM, -1.0, e1 + 2 * MM, 1.0, eo + MM, e2 + MM, Am);   // Ĵ = Ĵ1 − Ψ1′A,  Ψ = Ψ2 A
+    o.template mm<false, true>(T2, e2 + MM, Bm);                             // Ψ2 T⁻¹Ψ2′ = Ψ2 B′
+    o.symadd(eo, -1.0, T2, 1.0, e2);                                         // Λ = Λ2 − sym(Ψ2 B′)
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
 template <int NT>

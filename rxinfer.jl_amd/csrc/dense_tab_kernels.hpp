@@ -118,7 +118,9 @@ __device__ __forceinline__ void tab_mm_staged(double* dst0, const double* a0, co
     typedef double v2d __attribute__((ext_vector_type(2)));
     double* dst = as_global(dst0);
     const double *a = as_global(a0), *b = as_global(b0), *c = c0 ? as_global(c0) : nullptr;
+    asm volatile("" : "+v"(lane));       // inlined in a loop: the index arithmetic below is redone per call, not hoisted into (spilled) registers
     const int il = lane & 15, kq = lane >> 4, i = 16 * w + il, tid = 64 * w + lane;
+    __builtin_amdgcn_sched_barrier(0);   // inlined behind a product without a closing barrier: keep these loads out of its epilogue (registers)
     v2d sb[MM / NTH / 2];
 #pragma unroll
     for (int u = 0; u < MM / NTH / 2; ++u) sb[u] = *reinterpret_cast<const v2d*>(b + 2 * (tid + u * NTH));
@@ -168,6 +170,96 @@ __device__ __forceinline__ void tab_mm_staged(double* dst0, const double* a0, co
             if (c) v += beta * cv[t][r];
             dst[ii * D + j] = v;
         }
+    if (SYNC) __syncthreads();
+}
+// Two products that share the staged operand: dst1 = alpha1·op(a1)·op(b) + beta1·c1, dst2 = op(a2)·op(b) — one staging, one pair of barriers
+// and one pass over the LDS fragments for both.  RD: the epilogue also forms out_k[i] = base_k[i] + Σ_j dst_k[i][j]·u[j] (u in LDS) from the
+// accumulators — a row of 16 lanes holds a row of the tile: four xor-shuffles — for the vectors of the composition, which would otherwise
+// re-read the products from memory.
+template <int NT, bool TA1, bool TA2, bool TB, bool RD = false, bool SYNC = true>
+__device__ __forceinline__ void tab_mm2_staged(double* dst1_, const double* a1_, double alpha1, const double* c1_, double beta1, double* dst2_, const double* a2_,
+                                               const double* b0, double* stage, int w, int lane, const double* u = nullptr, const double* base1 = nullptr,
+                                               double* out1 = nullptr, const double* base2 = nullptr, double* out2 = nullptr) {
+    constexpr int D = 16 * NT, MM = D * D, NTH = 64 * NT, LD = tab_stage_ld(NT), KS = D / 4;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    double *dst1 = as_global(dst1_), *dst2 = as_global(dst2_);
+    const double *a1 = as_global(a1_), *a2 = as_global(a2_), *b = as_global(b0), *c1 = c1_ ? as_global(c1_) : nullptr;
+    asm volatile("" : "+v"(lane));       // inlined in a loop: the index arithmetic below is redone per call, not hoisted into (spilled) registers
+    const int il = lane & 15, kq = lane >> 4, i = 16 * w + il, tid = 64 * w + lane;
+    __builtin_amdgcn_sched_barrier(0);   // inlined behind a product without a closing barrier: keep these loads out of its epilogue (registers)
+    v2d sb[MM / NTH / 2];
+#pragma unroll
+    for (int q = 0; q < MM / NTH / 2; ++q) sb[q] = *reinterpret_cast<const v2d*>(b + 2 * (tid + q * NTH));
+    double av1[KS], av2[KS];
+#pragma unroll
+    for (int m = 0; m < KS / 2; ++m) {
+        const int k = 8 * m + 2 * kq;
+        if (TA1) { av1[2 * m] = a1[k * D + i]; av1[2 * m + 1] = a1[(k + 1) * D + i]; }
+        else { const v2d v = *reinterpret_cast<const v2d*>(a1 + i * D + k); av1[2 * m] = v.x; av1[2 * m + 1] = v.y; }
+        if (TA2) { av2[2 * m] = a2[k * D + i]; av2[2 * m + 1] = a2[(k + 1) * D + i]; }
+        else { const v2d v = *reinterpret_cast<const v2d*>(a2 + i * D + k); av2[2 * m] = v.x; av2[2 * m + 1] = v.y; }
+    }
+    double cv[NT][4];
+    if (c1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[t][r] = c1[acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, t)];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < MM / NTH / 2; ++q) {
+        const int e = 2 * (tid + q * NTH), row = e / D, col = e - row * D;
+        *reinterpret_cast<v2d*>(stage + row * LD + col) = sb[q];
+    }
+    __syncthreads();
+    d4 acc1[NT], acc2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc1[t] = (d4){0.0, 0.0, 0.0, 0.0}; acc2[t] = (d4){0.0, 0.0, 0.0, 0.0}; }
+#pragma unroll
+    for (int m = 0; m < KS / 2; ++m) {
+        const int k = 8 * m + 2 * kq;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = 16 * t + il;
+            double b0v, b1v;
+            if (TB) { const v2d v = *reinterpret_cast<const v2d*>(stage + j * LD + k); b0v = v.x; b1v = v.y; }
+            else { b0v = stage[k * LD + j]; b1v = stage[(k + 1) * LD + j]; }
+            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[2 * m], b0v, acc1[t], 0, 0, 0);
+            acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av2[2 * m], b0v, acc2[t], 0, 0, 0);
+            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[2 * m + 1], b1v, acc1[t], 0, 0, 0);
+            acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av2[2 * m + 1], b1v, acc2[t], 0, 0, 0);
+        }
+    }
+    double rd1[4] = {0.0, 0.0, 0.0, 0.0}, rd2[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const double uj = RD ? u[16 * t + il] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int ii = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
+            double v1 = alpha1 * acc1[t][r];
+            if (c1) v1 += beta1 * cv[t][r];
+            dst1[ii * D + j] = v1;
+            dst2[ii * D + j] = acc2[t][r];
+            if (RD) { rd1[r] += v1 * uj; rd2[r] += acc2[t][r] * uj; }
+        }
+    }
+    if (RD) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int m = 8; m > 0; m >>= 1) {
+                rd1[r] += __shfl_xor(rd1[r], m, 16);
+                rd2[r] += __shfl_xor(rd2[r], m, 16);
+            }
+            if (il == 0) {
+                const int ii = acc_row<NT>(w, lane, r);
+                out1[ii] = base1[ii] + rd1[r];
+                out2[ii] = base2[ii] + rd2[r];
+            }
+        }
+    }
     if (SYNC) __syncthreads();
 }
 template <int NT, bool TA, bool TB, bool SYNC = true>
@@ -269,6 +361,13 @@ struct TabOps {
             else tab_mm_body<NT, TA, TB, SYNC>(dst, a, b, alpha, c, beta, w, lane);
         }
         else tab_mm<NT, TA, TB, SYNC>(dst, a, b, alpha, c, beta, w, lane);
+    }
+    // two products with a shared second operand (tab_mm2_staged; INL kernels with a stage only)
+    template <bool TA1, bool TA2, bool TB, bool RD = false, bool SYNC = true>
+    __device__ __forceinline__ void mm2(double* dst1, const double* a1, double alpha1, const double* c1, double beta1, double* dst2, const double* a2, const double* b,
+                                        const double* u = nullptr, const double* base1 = nullptr, double* out1 = nullptr, const double* base2 = nullptr, double* out2 = nullptr) const {
+        static_assert(INL, "mm2 needs the inlined blocks and a staging matrix");
+        tab_mm2_staged<NT, TA1, TA2, TB, RD, SYNC>(dst1, a1, alpha1, c1, beta1, dst2, a2, b, stage, w, lane, u, base1, out1, base2, out2);
     }
     // dst = (alpha·sym(a) + gamma·sym(c))⁻¹
     __device__ __forceinline__ bool inv_symadd(double* dst, double alpha, const double* a, double gamma, const double* c, const double* e = nullptr) const {
