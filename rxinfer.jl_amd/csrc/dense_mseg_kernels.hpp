@@ -124,6 +124,163 @@ __device__ __forceinline__ double tab_col_dot(const double* M, int i, const doub
     return s0 + s1;
 }
 
+// ---- fused blocks: operands of the short kernels in registers and LDS -----------------------------------------------------------------
+// The composition rounds and the element pass run hundreds of workgroups at once, each with a working set of ≈0.5 MB of d×d matrices:
+// built from the blocks of dense_tab_kernels.hpp (every intermediate through global memory) a round of 450 compositions moved 330 MB in
+// 62 µs — the memory system's rate, not a latency chain.  Here the intermediates stay on the CU: the inverse leaves its result in the
+// accumulators, every product takes its second operand from ONE staging matrix in LDS (written from the accumulators of the block
+// before), first operands are register fragments loaded once, and the symmetrisations read the staging matrix transposed.
+template <int NT, bool TA>
+__device__ __forceinline__ void mfrag_load(double (&av)[4 * NT], const double* a, int w, int lane) {   // A-operand fragments of op(a), rows 16w … 16w + 15
+    constexpr int D = 16 * NT;
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int i = 16 * w + (lane & 15), kq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 2 * NT; ++m) {
+        const int k = 8 * m + 2 * kq;                     // the permuted contraction index of tab_mm_body
+        if (TA) { av[2 * m] = a[k * D + i]; av[2 * m + 1] = a[(k + 1) * D + i]; }
+        else { const v2d v = *reinterpret_cast<const v2d*>(a + i * D + k); av[2 * m] = v.x; av[2 * m + 1] = v.y; }
+    }
+}
+template <int NT>
+__device__ __forceinline__ void macc_to_stage(const d4 (&acc)[NT], double* stage, int w, int lane) {   // accumulator tiles -> row-major staging matrix
+    constexpr int LD = tab_stage_ld(NT);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) stage[acc_row<NT>(w, lane, r) * LD + acc_col<NT>(lane, t)] = acc[t][r];
+}
+// acc_k += op(a_k) · op(B), B staged row-major (TB: its transpose is the operand)
+template <int NT, bool TB, bool TWO>
+__device__ __forceinline__ void mstaged_mma(d4 (&acc1)[NT], d4 (&acc2)[NT], const double (&av1)[4 * NT], const double (&av2)[4 * NT], const double* stage, int lane) {
+    constexpr int LD = tab_stage_ld(NT);
+    typedef double v2d __attribute__((ext_vector_type(2)));
+    const int il = lane & 15, kq = lane >> 4;
+#pragma unroll
+    for (int m = 0; m < 2 * NT; ++m) {
+        const int k = 8 * m + 2 * kq;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int j = 16 * t + il;
+            double b0v, b1v;
+            if (TB) { const v2d v = *reinterpret_cast<const v2d*>(stage + j * LD + k); b0v = v.x; b1v = v.y; }
+            else { b0v = stage[k * LD + j]; b1v = stage[(k + 1) * LD + j]; }
+            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[2 * m], b0v, acc1[t], 0, 0, 0);
+            if (TWO) acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av2[2 * m], b0v, acc2[t], 0, 0, 0);
+            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[2 * m + 1], b1v, acc1[t], 0, 0, 0);
+            if (TWO) acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av2[2 * m + 1], b1v, acc2[t], 0, 0, 0);
+        }
+    }
+}
+template <int NT>
+__device__ __forceinline__ void macc_zero(d4 (&acc)[NT]) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
+}
+// rd[r] = Σ_j acc[row r of this lane][j] · x[j]: the row sums of a product against a vector in LDS, complete in the lanes with (lane & 15) == 0
+template <int NT>
+__device__ __forceinline__ void macc_rowdot(double (&rd)[4], const d4 (&acc)[NT], const double* x, int lane) {
+    const int il = lane & 15;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rd[r] = 0.0;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const double xj = x[16 * t + il];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) rd[r] += acc[t][r] * xj;
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) rd[r] += __shfl_xor(rd[r], m, 16);
+}
+// Two segments in a row as one (the formulas of km_group), fused: reads Λ1, Ĵ2 (twice: symmetrised on the way in), Ψ1, Ψ2, Ĵ1, Λ2 once each,
+// writes Λ, Ψ, Ĵ — 11 matrices of traffic where the block version moved 23.  scr: scratch of the inverse, stage: the staging matrix,
+// u: D doubles of LDS.
+template <int NT>
+__device__ __forceinline__ bool mseg_compose_fused(const double* e1_, const double* e2_, const double* v1, const double* v2, double* eo_, double* vo,
+                                                   double* scr, double* stage, double* u, int w, int lane_) {
+    constexpr int D = 16 * NT, MM = D * D, LD = tab_stage_ld(NT);
+    const double *e1 = as_global(e1_), *e2 = as_global(e2_);
+    double* eo = as_global(eo_);
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));
+    const int tid = 64 * w + lane, il = lane & 15;
+    Acc<NT> T;   // T = Λ1 + Ĵ2, symmetrised
+    {
+        const double *L1 = e1, *J2 = e2 + 2 * MM;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
+                T.v[t][r] = 0.5 * (L1[i * D + j] + L1[j * D + i]) + 0.5 * (J2[i * D + j] + J2[j * D + i]);
+            }
+    }
+    if (tid < D) u[tid] = v1[tid] + v2[D + tid];                      // ξ1 + η̂2
+    LogProd lp;
+    const bool ok = blk_inverse<NT>(T, scr, w, lane, lp);             // T⁻¹ in the accumulators (ends with a barrier: u is visible)
+    double av1[4 * NT], av2[4 * NT];
+    mfrag_load<NT, true>(av1, e1 + MM, w, lane);                      // Ψ1′ and Ψ2: first operands of every product below
+    mfrag_load<NT, false>(av2, e2 + MM, w, lane);
+    d4 a1[NT], a2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a1[t] = (d4){T.v[t][0], T.v[t][1], T.v[t][2], T.v[t][3]};
+    macc_to_stage<NT>(a1, stage, w, lane);
+    __syncthreads();
+    macc_zero<NT>(a1); macc_zero<NT>(a2);
+    mstaged_mma<NT, false, true>(a1, a2, av1, av2, stage, lane);      // A′ = Ψ1′T⁻¹,  B = Ψ2 T⁻¹
+    {
+        double r1[4], r2[4];
+        macc_rowdot<NT>(r1, a1, u, lane);
+        macc_rowdot<NT>(r2, a2, u, lane);
+        if (il == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = acc_row<NT>(w, lane, r);
+                vo[D + i] = v1[D + i] + r1[r];                        // η̂ = η̂1 + A′(ξ1 + η̂2)
+                vo[i] = v2[i] + r2[r];                                // ξ = ξ2 + B(ξ1 + η̂2)
+            }
+        }
+    }
+    double cv[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[t][r] = e1[2 * MM + acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, t)];   // Ĵ1
+    __syncthreads();                                                  // every wave is done with T⁻¹
+    macc_to_stage<NT>(a1, stage, w, lane);                            // A′
+    __syncthreads();
+    d4 jj[NT], pp[NT];
+    macc_zero<NT>(jj); macc_zero<NT>(pp);
+    mstaged_mma<NT, true, true>(jj, pp, av1, av2, stage, lane);       // Ψ1′A,  Ψ2 A
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, t);
+            eo[2 * MM + o] = cv[t][r] - jj[t][r];                     // Ĵ = Ĵ1 − Ψ1′A
+            eo[MM + o] = pp[t][r];                                    // Ψ = Ψ2 A
+            cv[t][r] = e2[o];                                         // Λ2 (for the last block)
+        }
+    __syncthreads();
+    macc_to_stage<NT>(a2, stage, w, lane);                            // B
+    __syncthreads();
+    macc_zero<NT>(jj);
+    mstaged_mma<NT, true, false>(jj, pp, av2, av2, stage, lane);      // Ψ2 B′ = Ψ2 T⁻¹Ψ2′
+    __syncthreads();
+    macc_to_stage<NT>(jj, stage, w, lane);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
+            eo[i * D + j] = cv[t][r] - 0.5 * (jj[t][r] + stage[j * LD + i]);   // Λ = Λ2 − sym(Ψ2 B′)
+        }
+    return ok;
+}
+
 // The element of a segment in INFORMATION form.  Given the state x_b at the segment start, the segment's transitions and observations
 // define a joint Gaussian over (x_b, x_e) with precision [[Ĵ, −Ψ′], [−Ψ, Λ]] and information vector [η̂, ξ] — in the notation of Särkkä &
 // García-Fernández (2021): Λ = C⁻¹, Ψ = C⁻¹Π, Ĵ = J + Π′C⁻¹Π, ξ = C⁻¹b, η̂ = η − Π′C⁻¹b.  Moving the end of the segment one step on is
@@ -135,64 +292,149 @@ __device__ __forceinline__ double tab_col_dot(const double* M, int i, const doub
 // Out of the known start through the first transition: Λp = P⁻¹, Ψ = K, Ĵ = A′P⁻¹A, ξ = η̂ = 0.
 template <int NT>
 __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
-    constexpr int D = 16 * NT, MM = D * D;
+    constexpr int D = 16 * NT, MM = D * D, LD = tab_stage_ld(NT);
     extern __shared__ __attribute__((aligned(16))) double smem[];
     TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
-    double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;   // ξ | c | η̂ | y
-    double *xi = vec, *cv = vec + D, *eta = vec + 2 * D, *yv = vec + 3 * D;
-    const int tid = o.tid, dyu = p.dy_user;
+    double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;   // ξ (two copies) | η̂ | y | B′Q⁻¹y
+    double *xi = vec, *xn = vec + D, *eta = vec + 2 * D, *yv = vec + 3 * D, *gyv = vec + 4 * D;
+    double* stage = smem + mseg_stage_offset(NT);
+    const int tid = o.tid, dyu = p.dy_user, w = o.w;
     const long long seg = blockIdx.x, chain = blockIdx.y;
-    auto CW = [&](int m, int slot) { return p.cw + (size_t)m * (size_t)p.cw_stride + (size_t)slot * MM; };   // constants of model m
+    auto CW = [&](int m, int slot) { return as_global(p.cw + (size_t)m * (size_t)p.cw_stride + (size_t)slot * MM); };   // constants of model m
     double* W = p.ws + ((size_t)chain * p.S + seg) * MSEG_WS * MM;
-    double *Cx = W, *Gt = W + MM, *Lp = W + 2 * MM, *Y = W + 3 * MM, *Ps2 = W + 4 * MM;
-    double* g = p.mel + ((size_t)chain * p.S + seg) * 3 * MM;   // Λ | Ψ | Ĵ of this segment
-    double *Pc = g + MM, *Pn = Ps2, *Jh = g + 2 * MM;           // Ψ alternates between its slot and a scratch matrix (no product overwrites an operand)
+    double* g = as_global(p.mel + ((size_t)chain * p.S + seg) * 3 * MM);   // Λ | Ψ | Ĵ of this segment
+    double *Pc = g + MM, *Pn = as_global(W), *Jh = g + 2 * MM;             // Ψ alternates between its slot and a scratch matrix (a step reads the old one while it writes the new one)
     const long long t0 = seg * p.L;   // boundary b_s: state index of the known start
     long long t1 = t0 + p.L;
     if (t1 > p.T - 1) t1 = p.T - 1;
     bool ok = true, ob = true;
-    // Λ(t) = sym(Msrc) [+ B′Q⁻¹B of step t's model]; the M of the next step adds A′P⁻¹A of ITS model — all formed inside the inverse that
-    // consumes them (inv_symadd).  Step t's transition and observation use the constants of model step_model[t] (one model: block 0).
-    const double *Msrc = nullptr, *Mobs = nullptr;
+    // The running Λp stays in the accumulator registers, symmetrised; Ψ and Ĵ live in global memory (read and written once per step); C, K C,
+    // Y′ = Ψ′C and the unsymmetrised Λp pass through the staging matrix.  Step t's transition and observation use the constants of model
+    // step_model[t] (one model: block 0).
+    double lam[NT][4];
+    const double* LOp = nullptr;   // B′Q⁻¹B of the previous step's model when that step was observed
     for (long long t = t0 + 1; t <= t1; ++t) {
         const int a = mseg_model(p, chain, t);
         const double *PI = CW(a, TabWs::PINV), *KC = CW(a, TabWs::KC), *WC = CW(a, TabWs::WC), *LO = CW(a, TabWs::LOBS), *G = CW(a, TabWs::G);
-        const bool obp = ob;                  // was the previous step observed
         ob = p.obs[chain * p.T + t] != 0.0;   // uniform
         double* rec = p.filt + (chain * p.T + t) * p.rec;
+        int lane = o.lane;
+        asm volatile("" : "+v"(lane));        // (index arithmetic per step, not hoisted into spilled registers)
+        const int il = lane & 15;
         if (tid < D) yv[tid] = (ob && tid < dyu) ? p.y[(t * p.n_chains + chain) * dyu + tid] : 0.0;
-        if (t == t0 + 1) {
-            o.lin(Pc, 1.0, KC);                           // (its barriers make yv visible)
-            o.lin(Jh, 1.0, WC);
-            if (tid < D) {
-                const double gy = ob ? tab_row_dot<D>(G, tid, yv) : 0.0;
-                xi[tid] = gy;
-                eta[tid] = 0.0;
-                rec[D + tid] = gy;                        // B′Q⁻¹y_t for the sweep kernel
-            }
-            o.sync();
-            Msrc = PI;                                    // Λ(t0 + 1) = P⁻¹ [+ B′Q⁻¹B]
-            Mobs = ob ? LO : nullptr;
-            continue;
-        }
-        (void)obp;
-        ok = o.inv_symadd(Cx, 1.0, Msrc, 1.0, WC, Mobs) && ok;        // C = (Λ(t − 1) + A′P⁻¹A)⁻¹
-        if (tid < D) cv[tid] = tab_col_dot<D>(Cx, tid, xi);           // c = C ξ   (C is symmetric: coalesced columns)
-        o.template mm2<false, true, false>(Gt, KC, 1.0, nullptr, 0.0, Y, Pc, Cx);   // K C and Y′ = Ψ′C: C is the shared, staged operand   (barriers: c is visible)
+        __syncthreads();
         if (tid < D) {
             const double gy = ob ? tab_row_dot<D>(G, tid, yv) : 0.0;
-            eta[tid] += tab_col_dot<D>(Pc, tid, cv);                  // η̂ += Ψ′c
-            xi[tid] = tab_row_dot<D>(KC, tid, cv) + gy;               // ξ = K c + B′Q⁻¹y   (every reader of the old ξ is behind a barrier)
-            rec[D + tid] = gy;
+            gyv[tid] = gy;
+            rec[D + tid] = gy;                                    // B′Q⁻¹y_t for the sweep kernel
         }
-        o.template mm2<true, false, true, false, false>(Jh, Pc, -1.0, Jh, 1.0, Pn, KC, Y);   // Ĵ −= Ψ′Y and Ψ = K Y (into the other copy): Y is the shared operand
-        o.template mm<false, true>(Lp, Gt, KC, -1.0, PI, 1.0);        // Λp = P⁻¹ − K C K′   (barrier: all three are stored)
-        Msrc = Lp;
-        Mobs = ob ? LO : nullptr;
-        double* sw = Pc; Pc = Pn; Pn = sw;
+        if (t == t0 + 1) {   // out of the known start through the first transition: Λp = P⁻¹, Ψ = K, Ĵ = A′P⁻¹A, ξ = B′Q⁻¹y, η̂ = 0
+            o.lin(Pc, 1.0, KC);
+            o.lin(Jh, 1.0, WC);
+            if (tid < D) { xi[tid] = gyv[tid]; eta[tid] = 0.0; }
+#pragma unroll
+            for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, tt);
+                    lam[tt][r] = 0.5 * (PI[i * D + j] + PI[j * D + i]);
+                }
+            __syncthreads();
+            LOp = ob ? LO : nullptr;
+            continue;
+        }
+        Acc<NT> T;   // C = (Λ(t − 1) + A′P⁻¹A)⁻¹,  Λ(t − 1) = Λp [+ B′Q⁻¹B]
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, tt);
+                double v = lam[tt][r] + 0.5 * (WC[i * D + j] + WC[j * D + i]);
+                if (LOp) v += 0.5 * (LOp[i * D + j] + LOp[j * D + i]);
+                T.v[tt][r] = v;
+            }
+        LogProd lp;
+        ok = blk_inverse<NT>(T, smem, w, lane, lp) && ok;         // (ends with a barrier: gyv is visible, the staging matrix is free)
+        double avk[4 * NT], avp[4 * NT];
+        mfrag_load<NT, false>(avk, KC, w, lane);                  // K and Ψ′: first operands of the products below
+        mfrag_load<NT, true>(avp, Pc, w, lane);
+        d4 gt[NT], yt[NT];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt) gt[tt] = (d4){T.v[tt][0], T.v[tt][1], T.v[tt][2], T.v[tt][3]};
+        macc_to_stage<NT>(gt, stage, w, lane);
+        __syncthreads();
+        macc_zero<NT>(gt); macc_zero<NT>(yt);
+        mstaged_mma<NT, false, true>(gt, yt, avk, avp, stage, lane);      // K C,  Y′ = Ψ′C
+        {   // ξ = K C ξ + B′Q⁻¹y,  η̂ += Ψ′C ξ: row sums of the two products against the old ξ
+            double r1[4], r2[4];
+            macc_rowdot<NT>(r1, gt, xi, lane);
+            macc_rowdot<NT>(r2, yt, xi, lane);
+            if (il == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int i = acc_row<NT>(w, lane, r);
+                    xn[i] = r1[r] + gyv[i];
+                    eta[i] += r2[r];
+                }
+            }
+        }
+        double cv[NT][4];
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cv[tt][r] = Jh[acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, tt)];
+        __syncthreads();                                                  // every wave is done with C
+        macc_to_stage<NT>(yt, stage, w, lane);
+        __syncthreads();
+        d4 jj[NT], pn[NT];
+        macc_zero<NT>(jj); macc_zero<NT>(pn);
+        mstaged_mma<NT, true, true>(jj, pn, avp, avk, stage, lane);       // Ψ′Y,  K Y
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, tt);
+                Jh[q] = cv[tt][r] - jj[tt][r];                            // Ĵ −= Ψ′Y
+                Pn[q] = pn[tt][r];                                        // Ψ = K Y   (into the other copy)
+                cv[tt][r] = PI[q];
+            }
+        __syncthreads();
+        macc_to_stage<NT>(gt, stage, w, lane);                            // K C
+        __syncthreads();
+        macc_zero<NT>(jj);
+        mstaged_mma<NT, true, false>(jj, pn, avk, avk, stage, lane);      // K (K C)′ = K C K′
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) jj[tt][r] = cv[tt][r] - jj[tt][r];   // Λp = P⁻¹ − K C K′
+        macc_to_stage<NT>(jj, stage, w, lane);
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, tt);
+                lam[tt][r] = 0.5 * (jj[tt][r] + stage[j * LD + i]);
+            }
+        LOp = ob ? LO : nullptr;
+        { double* sw = Pc; Pc = Pn; Pn = sw; }
+        { double* sw = xi; xi = xn; xn = sw; }
+        __syncthreads();                                                  // the staging matrix and yv / gyv are free for the next step
     }
-    if (Mobs) o.symadd(g, 1.0, Msrc, 1.0, Mobs);                      // Λ at the segment end = sym(Λp) [+ B′Q⁻¹B]
-    else o.symadd(g, 1.0, Msrc, 0.0, Msrc);
+    {   // Λ at the segment end = Λp [+ B′Q⁻¹B]
+        const int lane = o.lane;
+#pragma unroll
+        for (int tt = 0; tt < NT; ++tt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, tt);
+                double v = lam[tt][r];
+                if (LOp) v += 0.5 * (LOp[i * D + j] + LOp[j * D + i]);
+                g[i * D + j] = v;
+            }
+    }
+    __syncthreads();
     if (Pc != g + MM) o.lin(g + MM, 1.0, Pc);
     if (tid < D) {
         double* v = p.mvec + ((size_t)chain * p.S + seg) * 2 * D;
@@ -421,16 +663,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_compose(MsegParams p, int r) { 
     const double *v1 = dir == 0 ? elv(jp, gp) : elv(j, r), *v2 = dir == 0 ? elv(j, r) : elv(jp, gp);
     double* eo = p.hsel + hs_slot(p, dir, r + 1, chain, j) * 3 * MM;
     double* vo = p.hsvec + hs_slot(p, dir, r + 1, chain, j) * 2 * D;
-    double* W = p.ws + (((size_t)chain * S + j) * MSEG_WS + 4 * dir) * MM;   // km_elements is done with its scratch
-    double *Ti = W, *Am = W + MM, *Bm = W + 2 * MM, *T2 = W + 3 * MM;
-    // (the transposes A′ = Ψ1′T⁻¹ and B = Ψ2 T⁻¹ are what is formed: T⁻¹ is the shared, staged operand of both, and of the two vectors)
-    const bool ok = o.inv_symadd(Ti, 1.0, e1, 1.0, e2 + 2 * MM);             // T⁻¹, T = Λ1 + Ĵ2
-    if (tid < D) u[tid] = v1[tid] + v2[D + tid];                            // ξ1 + η̂2   (visible behind the barriers of the staging)
-    o.template mm2<true, false, false, true>(Am, e1 + MM, 1.0, nullptr, 0.0, Bm, e2 + MM, Ti,   // A′ = Ψ1′T⁻¹, B = Ψ2 T⁻¹
-                                             u, v1 + D, vo + D, v2, vo);     // η̂ = η̂1 + A′(ξ1 + η̂2),  ξ = ξ2 + B(ξ1 + η̂2)
-    o.template mm2<true, false, true, false, false>(eo + 2 * MM, e1 + MM, -1.0, e1 + 2 * MM, 1.0, eo + MM, e2 + MM, Am);   // Ĵ = Ĵ1 − Ψ1′A,  Ψ = Ψ2 A
-    o.template mm<false, true>(T2, e2 + MM, Bm);                             // Ψ2 T⁻¹Ψ2′ = Ψ2 B′
-    o.symadd(eo, -1.0, T2, 1.0, e2);                                         // Λ = Λ2 − sym(Ψ2 B′)
+    const bool ok = mseg_compose_fused<NT>(e1, e2, v1, v2, eo, vo, smem, smem + mseg_stage_offset(NT), u, o.w, o.lane);
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
 template <int NT>
