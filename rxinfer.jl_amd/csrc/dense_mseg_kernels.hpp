@@ -194,8 +194,8 @@ __device__ __forceinline__ void macc_rowdot(double (&rd)[4], const d4 (&acc)[NT]
 #pragma unroll
         for (int m = 8; m > 0; m >>= 1) rd[r] += __shfl_xor(rd[r], m, 16);
 }
-// Two segments in a row as one (the formulas of km_group), fused: reads Λ1, Ĵ2 (twice: symmetrised on the way in), Ψ1, Ψ2, Ĵ1, Λ2 once each,
-// writes Λ, Ψ, Ĵ — 11 matrices of traffic where the block version moved 23.  scr: scratch of the inverse, stage: the staging matrix,
+// Two segments in a row as one (the formulas of km_group), fused: reads Λ1, Ĵ2, Ψ1, Ψ2, Ĵ1, Λ2 once each, writes Λ, Ψ, Ĵ — 9 matrices of
+// traffic where the block version moved 23.  scr: scratch of the inverse, stage: the staging matrix,
 // u: D doubles of LDS.
 template <int NT>
 __device__ __forceinline__ bool mseg_compose_fused(const double* e1_, const double* e2_, const double* v1, const double* v2, double* eo_, double* vo,
@@ -206,7 +206,10 @@ __device__ __forceinline__ bool mseg_compose_fused(const double* e1_, const doub
     int lane = lane_;
     asm volatile("" : "+v"(lane));
     const int tid = 64 * w + lane, il = lane & 15;
-    Acc<NT> T;   // T = Λ1 + Ĵ2, symmetrised
+    // T = Λ1 + Ĵ2.  Every Λ of this schedule is symmetric by construction (a symmetrised register tile, written once); Ĵ = Ĵ1 − Ψ1′T⁻¹Ψ1 is
+    // symmetric up to the rounding of its products, which ⌈log₂ S⌉ rounds do not amplify (‖T⁻¹Ĵ‖ ≤ 1) — one coalesced read each instead
+    // of a second, transposed (uncoalesced) one for a symmetrisation on the way in
+    Acc<NT> T;
     {
         const double *L1 = e1, *J2 = e2 + 2 * MM;
 #pragma unroll
@@ -214,7 +217,7 @@ __device__ __forceinline__ bool mseg_compose_fused(const double* e1_, const doub
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
-                T.v[t][r] = 0.5 * (L1[i * D + j] + L1[j * D + i]) + 0.5 * (J2[i * D + j] + J2[j * D + i]);
+                T.v[t][r] = L1[i * D + j] + J2[i * D + j];
             }
     }
     if (tid < D) u[tid] = v1[tid] + v2[D + tid];                      // ξ1 + η̂2
@@ -281,6 +284,59 @@ __device__ __forceinline__ bool mseg_compose_fused(const double* e1_, const doub
     return ok;
 }
 
+// One boundary step (the formulas of km_scan), fused: with T⁻¹ in the accumulators (T = carried information + the element's corner),
+//   TA = false (prefix):  N = Ψ T⁻¹,   out_vec = base_vec + N u,  out = Mbase − sym(Ψ N′)      (Λ_f′ = Λ − ΨT⁻¹Ψ′,  ξ_f′ = ξ + ΨT⁻¹(ξ_f + η̂))
+//   TA = true  (suffix):  N = Ψ′T⁻¹,  out_vec = base_vec + N u,  out = Mbase − sym(Ψ′N′)     (Λβ′ = Ĵ − Ψ′T⁻¹Ψ,  ξβ′ = η̂ + Ψ′T⁻¹(ξ + ξβ))
+template <int NT, bool TA>
+__device__ __forceinline__ void mseg_absorb_fused(const Acc<NT>& Ti, const double* psi_, const double* base_vec, const double* u, double* out_vec,
+                                                  const double* Mbase_, double* out_, double* stage, int w, int lane_) {
+    constexpr int D = 16 * NT, LD = tab_stage_ld(NT);
+    const double *psi = as_global(psi_), *Mbase = as_global(Mbase_);
+    double* out = as_global(out_);
+    int lane = lane_;
+    asm volatile("" : "+v"(lane));
+    const int il = lane & 15;
+    double av[4 * NT];
+    mfrag_load<NT, TA>(av, psi, w, lane);
+    d4 n[NT], t2[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) n[t] = (d4){Ti.v[t][0], Ti.v[t][1], Ti.v[t][2], Ti.v[t][3]};
+    macc_to_stage<NT>(n, stage, w, lane);
+    __syncthreads();
+    macc_zero<NT>(n);
+    mstaged_mma<NT, false, false>(n, t2, av, av, stage, lane);        // N = op(Ψ) T⁻¹
+    {
+        double rd[4];
+        macc_rowdot<NT>(rd, n, u, lane);
+        if (il == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = acc_row<NT>(w, lane, r);
+                out_vec[i] = base_vec[i] + rd[r];
+            }
+        }
+    }
+    double cv[NT][4];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cv[t][r] = Mbase[acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, t)];
+    __syncthreads();
+    macc_to_stage<NT>(n, stage, w, lane);
+    __syncthreads();
+    macc_zero<NT>(t2);
+    mstaged_mma<NT, true, false>(t2, n, av, av, stage, lane);         // op(Ψ) N′
+    __syncthreads();
+    macc_to_stage<NT>(t2, stage, w, lane);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
+            out[i * D + j] = cv[t][r] - 0.5 * (t2[t][r] + stage[j * LD + i]);
+        }
+}
 // The element of a segment in INFORMATION form.  Given the state x_b at the segment start, the segment's transitions and observations
 // define a joint Gaussian over (x_b, x_e) with precision [[Ĵ, −Ψ′], [−Ψ, Λ]] and information vector [η̂, ξ] — in the notation of Särkkä &
 // García-Fernández (2021): Λ = C⁻¹, Ψ = C⁻¹Π, Ĵ = J + Π′C⁻¹Π, ξ = C⁻¹b, η̂ = η − Π′C⁻¹b.  Moving the end of the segment one step on is
@@ -315,7 +371,8 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
     const double* LOp = nullptr;   // B′Q⁻¹B of the previous step's model when that step was observed
     for (long long t = t0 + 1; t <= t1; ++t) {
         const int a = mseg_model(p, chain, t);
-        const double *PI = CW(a, TabWs::PINV), *KC = CW(a, TabWs::KC), *WC = CW(a, TabWs::WC), *LO = CW(a, TabWs::LOBS), *G = CW(a, TabWs::G);
+        // (P⁻¹, A′P⁻¹A, B′Q⁻¹B: the exactly symmetric copies kt_consts leaves for this kernel — one coalesced read each)
+        const double *PI = CW(a, TabWs::SPINV), *KC = CW(a, TabWs::KC), *WC = CW(a, TabWs::SWC), *LO = CW(a, TabWs::SLOBS), *G = CW(a, TabWs::G);
         ob = p.obs[chain * p.T + t] != 0.0;   // uniform
         double* rec = p.filt + (chain * p.T + t) * p.rec;
         int lane = o.lane;
@@ -337,7 +394,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, tt);
-                    lam[tt][r] = 0.5 * (PI[i * D + j] + PI[j * D + i]);
+                    lam[tt][r] = PI[i * D + j];
                 }
             __syncthreads();
             LOp = ob ? LO : nullptr;
@@ -349,8 +406,8 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, tt);
-                double v = lam[tt][r] + 0.5 * (WC[i * D + j] + WC[j * D + i]);
-                if (LOp) v += 0.5 * (LOp[i * D + j] + LOp[j * D + i]);
+                double v = lam[tt][r] + WC[i * D + j];
+                if (LOp) v += LOp[i * D + j];
                 T.v[tt][r] = v;
             }
         LogProd lp;
@@ -430,7 +487,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
             for (int r = 0; r < 4; ++r) {
                 const int i = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, tt);
                 double v = lam[tt][r];
-                if (LOp) v += 0.5 * (LOp[i * D + j] + LOp[j * D + i]);
+                if (LOp) v += LOp[i * D + j];
                 g[i * D + j] = v;
             }
     }
@@ -676,8 +733,6 @@ __global__ void __launch_bounds__(64 * NT, 2) km_apply(MsegParams p) {
     const int tid = o.tid, S = p.S, dyu = p.dy_user;
     const int dir = (int)blockIdx.x / S, s = (int)blockIdx.x - dir * S;
     const long long chain = blockIdx.y;
-    double* W = p.ws + (((size_t)chain * S + s) * MSEG_WS + 8 + 3 * dir) * MM;
-    double *Wm = W, *N1 = W + MM, *T2 = W + 2 * MM;
     bool ok = true;
     auto fin = [&](int dr, int idx, const double*& g, const double*& gv) {   // the finished composition of entry idx
         const int gen = hs_generations(dr == 0 ? idx : S - 1 - idx);
@@ -707,12 +762,23 @@ __global__ void __launch_bounds__(64 * NT, 2) km_apply(MsegParams p) {
         } else {
             const double *g, *gv;
             fin(0, s - 1, g, gv);
-            ok = o.inv_symadd(Wm, 1.0, CW(TabWs::V1I), 1.0, g + 2 * MM, ob0 ? CW(TabWs::LOBS) : nullptr);   // T⁻¹, T = Λ_f(0) + Ĵ
-            o.template mm<false, true>(N1, Wm, g + MM);                       // N1′ = T⁻¹Ψ′
-            if (tid < D) u[tid] = xi[tid] + gv[D + tid];                      // ξ_f(0) + η̂
-            o.template mm<false, false>(T2, g + MM, N1);                      // Ψ T⁻¹Ψ′   (its barrier: u is visible)
-            if (tid < D) p.fstart_m[((size_t)chain * S + s) * D + tid] = gv[tid] + tab_col_dot<D>(N1, tid, u);
-            o.symadd(out, -1.0, T2, 1.0, g);                                  // Λ_f(b_s) = Λ − sym(N1 Ψ′)
+            Acc<NT> T;                                                        // T = Λ_f(0) + Ĵ, symmetrised
+            {
+                const double *V1 = as_global(CW(TabWs::V1I)), *LO = as_global(CW(TabWs::LOBS)), *J = as_global(g + 2 * MM);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = acc_row<NT>(o.w, o.lane, r), j = acc_col<NT>(o.lane, t);
+                        double v = 0.5 * (V1[i * D + j] + V1[j * D + i]) + 0.5 * (J[i * D + j] + J[j * D + i]);
+                        if (ob0) v += 0.5 * (LO[i * D + j] + LO[j * D + i]);
+                        T.v[t][r] = v;
+                    }
+            }
+            if (tid < D) u[tid] = xi[tid] + gv[D + tid];                      // ξ_f(0) + η̂   (every reader of the old u is behind a barrier)
+            LogProd lp;
+            ok = blk_inverse<NT>(T, smem, o.w, o.lane, lp);                   // (ends with a barrier: u is visible)
+            mseg_absorb_fused<NT, false>(T, g + MM, gv, u, p.fstart_m + ((size_t)chain * S + s) * D, g, out, smem + mseg_stage_offset(NT), o.w, o.lane);
         }
     } else {
         double* out = p.mlb + ((size_t)chain * S + s) * MM;
@@ -723,11 +789,21 @@ __global__ void __launch_bounds__(64 * NT, 2) km_apply(MsegParams p) {
         } else {
             const double *g, *gv;
             fin(1, s + 1, g, gv);
-            ok = o.inv_symadd(Wm, 1.0, g, 0.0, g);                            // T⁻¹, T = Λ (+ Λβ = 0)
-            o.template mm<false, false>(N1, Wm, g + MM);                      // N1′ = T⁻¹Ψ
-            o.template mm<true, false>(T2, g + MM, N1);                       // Ψ′T⁻¹Ψ
-            if (tid < D) xo[tid] = gv[D + tid] + tab_col_dot<D>(N1, tid, gv); // ξβ = η̂ + Ψ′T⁻¹ξ
-            o.symadd(out, -1.0, T2, 1.0, g + 2 * MM);                         // Λβ = Ĵ − sym(N1 Ψ)
+            Acc<NT> T;                                                        // T = Λ (+ Λβ = 0)
+            {
+                const double* L = as_global(g);
+#pragma unroll
+                for (int t = 0; t < NT; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int i = acc_row<NT>(o.w, o.lane, r), j = acc_col<NT>(o.lane, t);
+                        T.v[t][r] = 0.5 * (L[i * D + j] + L[j * D + i]);
+                    }
+            }
+            if (tid < D) u[tid] = gv[tid];                                    // ξ (+ ξβ = 0)
+            LogProd lp;
+            ok = blk_inverse<NT>(T, smem, o.w, o.lane, lp);
+            mseg_absorb_fused<NT, true>(T, g + MM, gv + D, u, xo, g + 2 * MM, out, smem + mseg_stage_offset(NT), o.w, o.lane);   // ξβ = η̂ + Ψ′T⁻¹ξ,  Λβ = Ĵ − Ψ′T⁻¹Ψ
         }
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);

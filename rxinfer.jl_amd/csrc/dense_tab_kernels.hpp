@@ -43,6 +43,7 @@ struct TabParams {
 // workspace layout (doubles): NSLOT named d×d matrices, then K_i | U_i | Φ_i for every offset of a segment
 struct TabWs {
     enum { QI = 0, PINV, G, LOBS, HF, V1, V1I, VF1, KC, WC, T1, T2, T3, T4, T5, T6, V, PI, J, VP, SI, KK, UU, PHI, HFPI,
+           SPINV = T3, SWC = T4, SLOBS = T5,   // masked schedule (TabParams::S = 0): exactly symmetric copies, written when kt_consts is done with its scratch
            AG0 = 32,   // two element sets of 6 matrices each: Π, C, J, C⁻¹, C⁻¹Π, J + Π'C⁻¹Π
            PER0 = 48,  // per-program scratch of kt_agg (2 programs) and kt_scan (2): 8 matrices each
            NSLOT = 48 + 8 * 4 };
@@ -565,6 +566,12 @@ __global__ void __launch_bounds__(64 * NT) kt_consts(TabParams p) {
         cst[c.oC0] = dy * 1.8378770664093454835606594728112 + ldQ;
         cst[c.oLD1] = ldLf + ldV1;
         cst[c.oFEC] = 0.5 * (ldV1 + (double)(p.T - 1) * ldP + (double)p.T * (dy * 1.8378770664093454835606594728112 + ldQ));
+    }
+    if (p.S == 0) {   // constants of the masked schedule only (dense_mseg_kernels.hpp): its element pass reads P⁻¹, A′P⁻¹A, B′Q⁻¹B symmetrised, once
+        o.sync();
+        o.sym(W(TabWs::SPINV), W(TabWs::PINV));
+        o.sym(W(TabWs::SWC), W(TabWs::WC));
+        o.sym(W(TabWs::SLOBS), W(TabWs::LOBS));
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
