@@ -81,17 +81,26 @@ constexpr int MSEG_WS = 14;
 __host__ __device__ constexpr int mseg_stage_offset(int NT) { return blk_scratch_doubles(NT) + 2 * 64 * NT + 8 * 16 * NT + 16; }
 __host__ __device__ constexpr int mseg_lds_doubles(int NT, bool staged) { return mseg_stage_offset(NT) + (staged ? 16 * NT * tab_stage_ld(NT) : 0); }
 
-// grid (blocks over time, chains); nobs[chain] must be zero on entry (mseg_launch clears it): exact integer counts, any order
+// grid (blocks over time, chains); nobs[chain] must be zero on entry (mseg_launch clears it): exact integer counts, any order.
+// Sixteen lanes share an observation vector (coalesced reads of y), 16 time steps per 256-thread pass.
 __global__ void __launch_bounds__(256) km_mask(MsegParams p) {
     __shared__ double red[256];
     const long long chain = blockIdx.y;
+    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
     double cnt = 0.0;
-    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < p.T; t += (long long)gridDim.x * blockDim.x) {
-        const double* yt = p.y + (t * p.n_chains + chain) * p.dy_user;
-        bool ok = true;
-        for (int k = 0; k < p.dy_user; ++k) ok = ok && yt[k] == yt[k];   // NaN = missing
-        p.obs[chain * p.T + t] = ok ? 1.0 : 0.0;
-        cnt += ok ? 1.0 : 0.0;
+    for (long long t0 = (long long)blockIdx.x * 16; t0 < p.T; t0 += (long long)gridDim.x * 16) {
+        const long long t = t0 + grp;
+        int ok = 1;
+        if (t < p.T) {
+            const double* yt = p.y + (t * p.n_chains + chain) * p.dy_user;
+            for (int k = sub; k < p.dy_user; k += 16) ok &= yt[k] == yt[k] ? 1 : 0;   // NaN = missing
+        }
+#pragma unroll
+        for (int m = 8; m > 0; m >>= 1) ok &= __shfl_xor(ok, m, 16);
+        if (t < p.T && sub == 0) {
+            p.obs[chain * p.T + t] = ok ? 1.0 : 0.0;
+            cnt += ok ? 1.0 : 0.0;
+        }
     }
     red[threadIdx.x] = cnt;
     __syncthreads();

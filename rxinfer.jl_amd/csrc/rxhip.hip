@@ -1299,9 +1299,9 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     // through LDS: ≤ 256 registers) — 8, 4, 2, 2 workgroups per CU at d = 16 / 32 / 48 / 64, like the sweep kernels; the non-inlined
     // blocks of km_group / km_scan take 280 – 312 registers at d ≥ 48 (one workgroup per CU; their grids are small)
     const double conc = e->m_nt == 1 ? 2048.0 : e->m_nt == 2 ? 1024.0 : 512.0;
-    const double conc_c = conc, c_c = 20.0 + f * 50.0;   // a round of compositions with every CU busy: 73 µs at d = 64
+    const double conc_c = conc, c_c = 12.0 + f * 32.0;   // a round of fused compositions with every CU busy: 44 µs at d = 64
     {
-        const double c_e = 15.0 + f * 40.0, c_f = 5.7 + f * 21.0;   // element step (55 µs at d = 64 with every CU busy), forward + backward sweep step
+        const double c_e = 10.0 + f * 22.0, c_f = 5.7 + f * 21.0;   // fused element step (32 µs at d = 64 with every CU busy), forward + backward sweep step
         auto cost = [&](long long s) {
             const double steps = std::ceil((double)(T - 1) / (double)s), rounds = std::ceil((double)C * (double)s / conc);
             double scan = 0.0;
@@ -1312,7 +1312,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
                 scan = (double)s * c_s * std::ceil(2.0 * (double)C / conc);
             if (s > 2 && scan_mode != 1 && hs_fits(s)) {   // log-depth: ⌈log₂⌉ rounds of 2·s compositions, one parallel boundary step
                 const double wv = std::ceil(2.0 * (double)C * (double)s / conc_c);
-                const double lg = (double)hs_rounds_of(s) * c_c * wv + 2.5 * c_s * wv;
+                const double lg = (double)hs_rounds_of(s) * c_c * wv + 1.8 * c_s * wv;
                 if (lg < scan || scan_mode == 2) scan = lg;
             }
             return rounds * steps * ((s > 1 ? c_e : 0.0) + c_f) + scan;
@@ -1339,7 +1339,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
             const double sg = std::ceil(std::sqrt((double)S)), ng = std::ceil((double)S / sg);
             seq = (sg * c_g + (ng + 2.0 * sg) * c_s) * std::ceil((double)C * ng / conc);
         }
-        const double wv = std::ceil(2.0 * (double)C * (double)S / conc_c), lg = (double)hs_rounds_of(S) * c_c * wv + 2.5 * c_s * wv;
+        const double wv = std::ceil(2.0 * (double)C * (double)S / conc_c), lg = (double)hs_rounds_of(S) * c_c * wv + 1.8 * c_s * wv;
         if (S > 2 && hs_fits(S) && scan_mode != 1 && (lg < seq || scan_mode == 2)) {
             e->m_hs = 1;
             e->m_hs_rounds = hs_rounds_of(S);
@@ -1428,7 +1428,7 @@ static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams
     const size_t lds = sizeof(double) * (size_t)mseg_lds_doubles(NT, false), lds_s = sizeof(double) * (size_t)mseg_lds_doubles(NT, true);
     hipStream_t s = e->stream;
     (void)hipMemsetAsync(mp.nobs, 0, sizeof(double) * (size_t)mp.n_chains, s);
-    hipLaunchKernelGGL(km_mask, dim3((unsigned)std::min<long long>(64, (mp.T + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
+    hipLaunchKernelGGL(km_mask, dim3((unsigned)std::min<long long>(mp.n_chains >= 64 ? 16 : 256, (mp.T + 15) / 16), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
     if (mp.S == 1) hipLaunchKernelGGL(km_gy, dim3((unsigned)(((mp.T - 1) * mp.d + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
     else hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds_s, s, mp);
     if (mp.hs) {       // log-depth: all prefix / suffix compositions in ⌈log₂ S⌉ rounds, then every boundary state at once
