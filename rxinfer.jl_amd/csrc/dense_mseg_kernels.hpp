@@ -11,19 +11,26 @@
 //                segment's transitions and observed steps define — precision [[Ĵ, −Ψ′], [−Ψ, Λ]], vector [η̂, ξ]; one inverse and five
 //                products per step (the step of kd_forward_info plus three products); B′Q⁻¹y_t of the observed steps goes into the
 //                records for the sweep kernel
-//   km_group     (from 16 segments on) the ≈√S segments of a group folded into ONE element: two segments in a row are one segment
-//   km_scan      the boundary recursions — prefix: filtered belief at every segment start; suffix: backward message at every segment
-//                end; one inverse and two products per element and direction; level 2 over the group elements, level 3 inside every
-//                group in parallel (level 0: all segments in one run)
+//   km_compose   the boundary recursion in LOG DEPTH: composition of elements is associative, so all prefix compositions E_0 ∘ … ∘ E_j and all
+//                suffix compositions E_j ∘ … ∘ E_{S−1} come out of ⌈log₂ S⌉ rounds of pairwise compositions, 2·S workgroups per round
+//   km_apply     every boundary state at once: the belief at t = 0 through the prefix composition in front of a segment (filtered belief at
+//                its start), the empty message through the suffix composition behind it (backward message at its end)
+//   km_group,    the same states from SEQUENTIAL recursions (few segments, or RXHIP_MSEG_SCAN=sequential — each kind is the other's checker):
+//   km_scan      prefix / suffix steps over the elements, one inverse and two products per element and direction; from 16 segments on in
+//                two levels — km_group folds the ≈√S segments of a group into one element, km_scan level 2 runs over the group elements,
+//                level 3 inside every group in parallel (level 0: all segments in one run)
 //   km_bnd       (Λ_f(b_{s+1}) + Λβ(b_{s+1}))⁻¹ for every inner boundary (parallel)
 //   km_gy        one segment per chain (batches that fill the chip on their own): B′Q⁻¹y_t only — no elements, no recursion
 // and the sweep itself is kd_forward_info / kd_backward_info with per-chain boundaries (information vector ξ_f at the segment start:
 // DenseParams::mseg = 2) and the observation precision B′Q⁻¹B left out of M_{t+1} at missing steps (DenseCst::oPLWM).  The free energy
 // is evaluated as on the fully observed path (at the smoothed means), with the observation constants and residuals counted for observed
-// steps only.  mseg_setup (rxhip.hip) picks the number of segments from a cost model over the measured step times.
-// The matrix products are the non-inlined blocks of dense_tab_kernels.hpp (operands in L2): 5–8 µs per call whatever it computes — a
-// coverage path that is two to three orders of magnitude faster than the sequential one (d = 64, T = 2000, one chain: 2.4 ms against
-// 690), not a roofline path.  The algebra is restated in numpy in tests/test_mseg_information_form.py.
+// steps only.  mseg_setup (rxhip.hip) picks the number of segments and the kind of recursion from a cost model over the measured step times.
+// km_elements, km_compose and km_apply are FUSED (mseg_compose_fused, mseg_absorb_fused and the step of km_elements below): the inverse leaves
+// its result in the accumulators, every product takes its second operand from one staging matrix in LDS and its first from register fragments
+// loaded once, nothing between a kernel's inputs and outputs goes through memory — built from the non-inlined blocks of dense_tab_kernels.hpp
+// (km_group / km_scan still are) a round of 450 compositions moved 330 MB, at the memory system's rate.  d = 64, T = 2000, one chain, 10 %
+// missing: 0.92 ms per sweep (690 on the sequential schedule of rounds 1–2, 2.5 with the sequential recursion on building blocks; the fully
+// observed chain: 0.29).  The algebra and the bookkeeping of the rounds are restated in numpy in tests/test_mseg_information_form.py.
 // Per-step constants (desc.step_model): the same kernels with the constant block of model step_model[t] per step (MsegParams::step_model,
 // kd_forward_info<…, STEPM>, one residual pass per model, km_feconst).
 // Scope: one model per engine, per-step constants shared by all chains, or one model per chain; smoothing runs and filtering runs
