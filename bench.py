@@ -262,6 +262,7 @@ def extra_masked(device):
     with rxhip.LGSSMEngine(*one, T=T, n_chains=1, allow_missing=True, device=device) as eng:
         eng.set_data(ym)
         out["missing_10pct_ms"] = med(eng)
+        out["missing_10pct_schedule"] = eng.schedule()   # segments × segment length of the element pass (log-depth boundary recursion over them)
     ms = [workloads.random_model(d, d, seed=d + 7 * k) for k in range(4)]
     mdl = tuple(np.stack([q[k] for q in ms]) for k in ("A", "B", "P", "Q", "m0", "V0"))
     sm = np.random.default_rng(0).integers(0, 4, T).astype(np.int32)

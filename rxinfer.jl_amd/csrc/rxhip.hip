@@ -1302,8 +1302,10 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     const double conc_c = conc, c_c = 12.0 + f * 32.0;   // a round of fused compositions with every CU busy: 44 µs at d = 64
     {
         const double c_e = 10.0 + f * 22.0, c_f = 5.7 + f * 21.0;   // fused element step (32 µs at d = 64 with every CU busy), forward + backward sweep step
-        auto cost = [&](long long s) {
-            const double steps = std::ceil((double)(T - 1) / (double)s), rounds = std::ceil((double)C * (double)s / conc);
+        auto cost = [&](long long s_asked) {
+            // (the segments that s_asked turns into once the segment length is an integer: ⌈(T − 1) / L⌉ of length L = ⌈(T − 1) / s_asked⌉)
+            const long long Lq = ((long long)T - 1 + s_asked - 1) / s_asked, s = ((long long)T - 1 + Lq - 1) / Lq;
+            const double steps = (double)Lq, rounds = std::ceil((double)C * (double)s / conc);
             double scan = 0.0;
             if (s >= 16) {
                 const double sg = std::ceil(std::sqrt((double)s)), ng = std::ceil((double)s / sg);
