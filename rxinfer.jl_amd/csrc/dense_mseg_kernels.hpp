@@ -68,6 +68,9 @@ struct MsegParams {
     // per direction — hs [dir][gen parity][chain][S][3][d][d], hsv [dir][gen parity][chain][S][2][d]
     int hs, hs_rounds;
     double *hsel, *hsvec;
+    // what the rounds run over: hs_n entries of hs_g segments each (hs_g = 1: the segments themselves; else km_fold composes every group of
+    // hs_g segments into mgrp / mgvec first, and km_inner carries the boundary states from the group edges to the segments inside)
+    int hs_n, hs_g;
     // per-step constants (desc.step_model; null: one model): time index t uses block step_model[t] of `in`, `cw` and of the constant
     // blocks `cst` (strides in doubles); fe_const[chain]: the data-independent part of the free energy, summed over the chain's steps
     const int* step_model;
@@ -715,7 +718,14 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p, int level) {
 // through Q[s + 1] (backward message at the end of segment s): one step of km_scan each, all segments in parallel.
 __device__ __forceinline__ int hs_generations(int i) { return i == 0 ? 0 : 32 - __clz(i); }
 __device__ __forceinline__ size_t hs_slot(const MsegParams& p, int dir, int gen, long long chain, int idx) {
-    return ((size_t)(dir * 2 + ((gen - 1) & 1)) * (size_t)p.n_chains + (size_t)chain) * (size_t)p.S + (size_t)idx;
+    return ((size_t)(dir * 2 + ((gen - 1) & 1)) * (size_t)p.n_chains + (size_t)chain) * (size_t)p.hs_n + (size_t)idx;
+}
+// generation 0 of entry idx: the segment element, or the composition of its group of segments
+__device__ __forceinline__ const double* hs_gen0(const MsegParams& p, long long chain, int idx, int MM) {
+    return p.hs_g > 1 ? p.mgrp + ((size_t)chain * p.hs_n + idx) * 3 * MM : p.mel + ((size_t)chain * p.S + idx) * 3 * MM;
+}
+__device__ __forceinline__ const double* hs_gen0v(const MsegParams& p, long long chain, int idx, int D) {
+    return p.hs_g > 1 ? p.mgvec + ((size_t)chain * p.hs_n + idx) * 2 * D : p.mvec + ((size_t)chain * p.S + idx) * 2 * D;
 }
 template <int NT>
 __global__ void __launch_bounds__(64 * NT, 2) km_compose(MsegParams p, int r) {   // ≤ 256 registers: two workgroups per CU at d ≥ 48
@@ -723,14 +733,14 @@ __global__ void __launch_bounds__(64 * NT, 2) km_compose(MsegParams p, int r) { 
     extern __shared__ __attribute__((aligned(16))) double smem[];
     TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
     double* u = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
-    const int tid = o.tid, S = p.S;
+    const int tid = o.tid, S = p.hs_n;               // entries of the scan
     const int dir = (int)blockIdx.x / S, j = (int)blockIdx.x - dir * S, h = 1 << r;
     const long long chain = blockIdx.y;
     const int i = dir == 0 ? j : S - 1 - j;          // distance from the origin of the scan
     if (i < h || i == S - 1) return;                 // finished — or the whole chain's composition, which nobody reads
     const int jp = dir == 0 ? j - h : j + h, gp = hs_generations(i - h) < r ? hs_generations(i - h) : r;
-    auto el = [&](int idx, int gen) { return gen == 0 ? p.mel + ((size_t)chain * S + idx) * 3 * MM : p.hsel + hs_slot(p, dir, gen, chain, idx) * 3 * MM; };
-    auto elv = [&](int idx, int gen) { return gen == 0 ? p.mvec + ((size_t)chain * S + idx) * 2 * D : p.hsvec + hs_slot(p, dir, gen, chain, idx) * 2 * D; };
+    auto el = [&](int idx, int gen) { return gen == 0 ? hs_gen0(p, chain, idx, MM) : p.hsel + hs_slot(p, dir, gen, chain, idx) * 3 * MM; };
+    auto elv = [&](int idx, int gen) { return gen == 0 ? hs_gen0v(p, chain, idx, D) : p.hsvec + hs_slot(p, dir, gen, chain, idx) * 2 * D; };
     // element 1 comes first in time
     const double *e1 = dir == 0 ? el(jp, gp) : el(j, r), *e2 = dir == 0 ? el(j, r) : el(jp, gp);
     const double *v1 = dir == 0 ? elv(jp, gp) : elv(j, r), *v2 = dir == 0 ? elv(j, r) : elv(jp, gp);
@@ -746,14 +756,15 @@ __global__ void __launch_bounds__(64 * NT, 2) km_apply(MsegParams p) {
     TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
     double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
     double *xi = vec, *u = vec + D, *tv = vec + 2 * D;
-    const int tid = o.tid, S = p.S, dyu = p.dy_user;
+    const int tid = o.tid, S = p.hs_n, dyu = p.dy_user;                      // S: entries of the scan; entry s = segments hs_g·s … (seg0 … seg1)
     const int dir = (int)blockIdx.x / S, s = (int)blockIdx.x - dir * S;
     const long long chain = blockIdx.y;
+    const int seg0 = s * p.hs_g, seg1 = (seg0 + p.hs_g < p.S ? seg0 + p.hs_g : p.S) - 1;
     bool ok = true;
     auto fin = [&](int dr, int idx, const double*& g, const double*& gv) {   // the finished composition of entry idx
         const int gen = hs_generations(dr == 0 ? idx : S - 1 - idx);
-        g = gen == 0 ? p.mel + ((size_t)chain * S + idx) * 3 * MM : p.hsel + hs_slot(p, dr, gen, chain, idx) * 3 * MM;
-        gv = gen == 0 ? p.mvec + ((size_t)chain * S + idx) * 2 * D : p.hsvec + hs_slot(p, dr, gen, chain, idx) * 2 * D;
+        g = gen == 0 ? hs_gen0(p, chain, idx, MM) : p.hsel + hs_slot(p, dr, gen, chain, idx) * 3 * MM;
+        gv = gen == 0 ? hs_gen0v(p, chain, idx, D) : p.hsvec + hs_slot(p, dr, gen, chain, idx) * 2 * D;
     };
     if (dir == 0) {
         // belief at t = 0: prior ⊗ observation message (if y_0 is observed) — as km_scan forms it
@@ -771,10 +782,10 @@ __global__ void __launch_bounds__(64 * NT, 2) km_apply(MsegParams p) {
         o.sync();
         if (tid < D) xi[tid] = tab_col_dot<D>(CW(TabWs::V1I), tid, u) + (ob0 ? tab_row_dot<D>(CW(TabWs::G), tid, tv) : 0.0);
         o.sync();
-        double* out = p.mbnd + ((size_t)chain * S + s) * 2 * MM;
+        double* out = p.mbnd + ((size_t)chain * p.S + seg0) * 2 * MM;
         if (s == 0) {
             o.lin(out, 1.0, CW(TabWs::V1I), ob0 ? 1.0 : 0.0, CW(TabWs::LOBS));
-            if (tid < D) p.fstart_m[((size_t)chain * S) * D + tid] = xi[tid];
+            if (tid < D) p.fstart_m[((size_t)chain * p.S) * D + tid] = xi[tid];
         } else {
             const double *g, *gv;
             fin(0, s - 1, g, gv);
@@ -794,11 +805,11 @@ __global__ void __launch_bounds__(64 * NT, 2) km_apply(MsegParams p) {
             if (tid < D) u[tid] = xi[tid] + gv[D + tid];                      // ξ_f(0) + η̂   (every reader of the old u is behind a barrier)
             LogProd lp;
             ok = blk_inverse<NT>(T, smem, o.w, o.lane, lp);                   // (ends with a barrier: u is visible)
-            mseg_absorb_fused<NT, false>(T, g + MM, gv, u, p.fstart_m + ((size_t)chain * S + s) * D, g, out, smem + mseg_stage_offset(NT), o.w, o.lane);
+            mseg_absorb_fused<NT, false>(T, g + MM, gv, u, p.fstart_m + ((size_t)chain * p.S + seg0) * D, g, out, smem + mseg_stage_offset(NT), o.w, o.lane);
         }
     } else {
-        double* out = p.mlb + ((size_t)chain * S + s) * MM;
-        double* xo = p.beta_xi + ((size_t)chain * (S + 1) + s + 1) * D;
+        double* out = p.mlb + ((size_t)chain * p.S + seg1) * MM;
+        double* xo = p.beta_xi + ((size_t)chain * (p.S + 1) + seg1 + 1) * D;
         if (s == S - 1) {
             o.eye(out, 0.0);                                                  // nothing behind the last step
             if (tid < D) xo[tid] = 0.0;
@@ -820,6 +831,97 @@ __global__ void __launch_bounds__(64 * NT, 2) km_apply(MsegParams p) {
             LogProd lp;
             ok = blk_inverse<NT>(T, smem, o.w, o.lane, lp);
             mseg_absorb_fused<NT, true>(T, g + MM, gv + D, u, xo, g + 2 * MM, out, smem + mseg_stage_offset(NT), o.w, o.lane);   // ξβ = η̂ + Ψ′T⁻¹ξ,  Λβ = Ĵ − Ψ′T⁻¹Ψ
+        }
+    }
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
+// Segments finer than the entries of the scan (hs_g > 1): the element pass and the sweep kernels gain from short segments, the rounds pay per
+// entry.  km_fold composes the hs_g segments of a group into one entry (hs_g − 1 fused compositions in a row, one workgroup per group);
+// km_inner, behind km_apply, carries the filtered belief from the start of a group to the starts of the segments inside it and the backward
+// message from its end to their ends (hs_g − 1 fused boundary steps per direction, all groups at once) — the levels of km_group / km_scan,
+// with the log-depth rounds in the middle.
+template <int NT>
+__global__ void __launch_bounds__(64 * NT, 2) km_fold(MsegParams p) {
+    constexpr int D = 16 * NT, MM = D * D;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
+    double* u = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
+    const int tid = o.tid, S = p.S;
+    const long long grp = blockIdx.x, chain = blockIdx.y;
+    const int s0 = (int)grp * p.hs_g, s1 = s0 + p.hs_g < S ? s0 + p.hs_g : S;
+    double* G = p.mgrp + ((size_t)chain * p.hs_n + grp) * 3 * MM;
+    double* Gv = p.mgvec + ((size_t)chain * p.hs_n + grp) * 2 * D;
+    auto el = [&](int sgm) { return p.mel + ((size_t)chain * S + sgm) * 3 * MM; };
+    auto elv = [&](int sgm) { return p.mvec + ((size_t)chain * S + sgm) * 2 * D; };
+    bool ok = true;
+    if (s1 - s0 == 1) {   // a ragged last group of one segment
+        o.lin(G, 1.0, el(s0));
+        o.lin(G + MM, 1.0, el(s0) + MM);
+        o.lin(G + 2 * MM, 1.0, el(s0) + 2 * MM);
+        if (tid < 2 * D) Gv[tid] = elv(s0)[tid];
+        return;
+    }
+    for (int sgm = s0 + 1; sgm < s1; ++sgm) {
+        // running composition ∘ next segment; from the second step on the running one is read from, and written back to, the group's slot
+        // (every wave has its fragments of Ψ1 and its tiles of Λ1, Ĵ1 in registers before the first output is stored)
+        const double* e1 = sgm == s0 + 1 ? el(s0) : G;
+        const double* v1 = sgm == s0 + 1 ? elv(s0) : Gv;
+        ok = mseg_compose_fused<NT>(e1, el(sgm), v1, elv(sgm), G, Gv, smem, smem + mseg_stage_offset(NT), u, o.w, o.lane) && ok;
+        __syncthreads();
+    }
+    if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
+}
+template <int NT>
+__global__ void __launch_bounds__(64 * NT, 2) km_inner(MsegParams p) {
+    constexpr int D = 16 * NT, MM = D * D;
+    extern __shared__ __attribute__((aligned(16))) double smem[];
+    double* u = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
+    double* stage = smem + mseg_stage_offset(NT);
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, S = p.S;
+    const int dir = (int)blockIdx.x / p.hs_n, grp = (int)blockIdx.x - dir * p.hs_n;
+    const long long chain = blockIdx.y;
+    const int s0 = grp * p.hs_g, s1 = s0 + p.hs_g < S ? s0 + p.hs_g : S;   // segments s0 … s1 − 1
+    bool ok = true;
+    auto load_sum = [&](Acc<NT>& T, const double* a_, const double* b_) {   // T = a + b (both symmetric up to rounding: see mseg_compose_fused)
+        const double *a = as_global(a_), *b = as_global(b_);
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int q = acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, t);
+                T.v[t][r] = a[q] + b[q];
+            }
+    };
+    if (dir == 0) {
+        for (int sgm = s0; sgm + 1 < s1; ++sgm) {   // filtered belief at the start of sgm -> at the start of sgm + 1
+            const double* g = p.mel + ((size_t)chain * S + sgm) * 3 * MM;
+            const double* gv = p.mvec + ((size_t)chain * S + sgm) * 2 * D;
+            const double* lf = p.mbnd + ((size_t)chain * S + sgm) * 2 * MM;
+            const double* xf = p.fstart_m + ((size_t)chain * S + sgm) * D;
+            Acc<NT> T;
+            load_sum(T, lf, g + 2 * MM);                                      // T = Λ_f + Ĵ
+            if (tid < D) u[tid] = xf[tid] + gv[D + tid];                      // ξ_f + η̂
+            LogProd lp;
+            ok = blk_inverse<NT>(T, smem, w, lane, lp) && ok;
+            mseg_absorb_fused<NT, false>(T, g + MM, gv, u, p.fstart_m + ((size_t)chain * S + sgm + 1) * D, g,
+                                         p.mbnd + ((size_t)chain * S + sgm + 1) * 2 * MM, stage, w, lane);
+            __syncthreads();
+        }
+    } else {
+        for (int sgm = s1 - 1; sgm > s0; --sgm) {   // backward message at the end of sgm -> at the end of sgm − 1
+            const double* g = p.mel + ((size_t)chain * S + sgm) * 3 * MM;
+            const double* gv = p.mvec + ((size_t)chain * S + sgm) * 2 * D;
+            const double* lb = p.mlb + ((size_t)chain * S + sgm) * MM;
+            const double* xb = p.beta_xi + ((size_t)chain * (S + 1) + sgm + 1) * D;
+            Acc<NT> T;
+            load_sum(T, g, lb);                                               // T = Λ + Λβ
+            if (tid < D) u[tid] = gv[tid] + xb[tid];                          // ξ + ξβ
+            LogProd lp;
+            ok = blk_inverse<NT>(T, smem, w, lane, lp) && ok;
+            mseg_absorb_fused<NT, true>(T, g + MM, gv + D, u, p.beta_xi + ((size_t)chain * (S + 1) + sgm) * D, g + 2 * MM,
+                                        p.mlb + ((size_t)chain * S + sgm - 1) * MM, stage, w, lane);
+            __syncthreads();
         }
     }
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);

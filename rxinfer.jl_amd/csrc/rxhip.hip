@@ -379,6 +379,7 @@ struct rxhip_engine {
     double* m_feconst = nullptr;
     double *m_grp = nullptr, *m_gvec = nullptr;
     int m_hs = 0, m_hs_rounds = 0;   // masked schedule: log-depth boundary recursion (km_compose / km_apply)
+    int m_hs_n = 0, m_hs_g = 1;      // … over m_hs_n entries of m_hs_g segments each (km_fold / km_inner when m_hs_g > 1)
     double *m_hsel = nullptr, *m_hsvec = nullptr;
     bool records_hold_gains = false; // the last run was a smoothing sweep of kd_forward_info / kd_backward_info with one chain per tile: d_filt holds G_t′
     int cov_mode = 0;
@@ -1260,7 +1261,7 @@ static rxhip_status prof_end(rxhip_engine* e);
 template <int NT>
 static hipError_t mseg_prepare_kernels() {
     hipError_t err;
-    for (const void* f : {(const void*)km_elements<NT>, (const void*)km_scan<NT>, (const void*)km_group<NT>, (const void*)km_compose<NT>, (const void*)km_apply<NT>, (const void*)km_bnd<NT>, (const void*)km_filter_out<NT>,
+    for (const void* f : {(const void*)km_elements<NT>, (const void*)km_scan<NT>, (const void*)km_group<NT>, (const void*)km_compose<NT>, (const void*)km_apply<NT>, (const void*)km_fold<NT>, (const void*)km_inner<NT>, (const void*)km_bnd<NT>, (const void*)km_filter_out<NT>,
                           (const void*)kt_consts<NT>})
         if ((err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return err;
     return DenseLaunch<NT>::prepare();
@@ -1281,13 +1282,11 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     e->m_models = (int)NM;
     e->m_stepm = stepm;
     const size_t D = (size_t)e->m_dpad, MM = D * D, C = (size_t)e->n_chains, T = (size_t)e->T;
-    // segments: the element pass costs ≈2 boundary steps per time step, both are sequential chains -> S ≈ √(2T); many chains fill the
-    // machine on their own, and the scratch of the element pass grows with chains × S
-    // Segments: a cost model over the sequential depths, in µs per step / element from the measured kernels
-    // (profiles/r03/dense_missing_parallel_kernels.txt; d = 64: element step 50, boundary step 21, group combine 50, sweep step 17–23;
-    // d ≤ 16: ≈15 / 8 / 15 / 5.7) and the workgroups the chip holds at once.  One chain: S ≈ 150 segments at T = 2000 (elements and the
-    // three-level boundary recursion in balance); chains that fill the machine on their own: ONE segment per chain — the sweep kernels run
-    // the whole chain, no element pass (three sweep steps' worth per time step) and no boundary recursion.
+    // Segments and the kind of boundary recursion: a cost model over the sequential depths, in µs per step from the measured kernels
+    // (profiles/r03/dense_missing_parallel_kernels.txt; d = 64: fused element step 32, sweep step forward + backward 27, a round of fused
+    // compositions 44, a sequential boundary step 21, a sequential group combine 50; d ≤ 16: 10 / 5.7 / 12 / 8 / 15) and the workgroups
+    // the chip holds at once.  One chain at T = 2000: S = 250 segments of 8 steps, 8 rounds of compositions (log depth); chains that fill
+    // the machine on their own: ONE segment per chain — the sweep kernels run the whole chain, no element pass and no boundary recursion.
     long long S = 1;
     // RXHIP_MSEG_SCAN = sequential | log: the boundary recursion as one / two sequential levels, or in ⌈log₂ S⌉ rounds (default: the cheaper one)
     const char* scan_env = std::getenv("RXHIP_MSEG_SCAN");
@@ -1299,7 +1298,22 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     // through LDS: ≤ 256 registers) — 8, 4, 2, 2 workgroups per CU at d = 16 / 32 / 48 / 64, like the sweep kernels; the non-inlined
     // blocks of km_group / km_scan take 280 – 312 registers at d ≥ 48 (one workgroup per CU; their grids are small)
     const double conc = e->m_nt == 1 ? 2048.0 : e->m_nt == 2 ? 1024.0 : 512.0;
-    const double conc_c = conc, c_c = 12.0 + f * 32.0;   // a round of fused compositions with every CU busy: 44 µs at d = 64
+    const double conc_c = conc, c_c = 8.0 + f * 22.0;    // a round of fused compositions: 30 µs at d = 64 with a CU to itself, 44 µs when workgroups share one
+    // log-depth recursion over ⌈s / g⌉ entries of g segments: km_fold (g − 1 compositions in a row), the rounds, km_apply, km_inner (g − 1 steps)
+    const char* grp_env = std::getenv("RXHIP_MSEG_GROUP");
+    const int grp_forced = grp_env ? std::atoi(grp_env) : 0;
+    auto log_cost = [&](long long s, int g) {
+        const double n = std::ceil((double)s / (double)g), wv = std::ceil(2.0 * (double)C * n / conc_c), wf = std::ceil((double)C * n / conc_c);
+        const double sh2 = 2.0 * (double)C * n > 0.5 * conc_c ? 1.45 : 1.0, sh1 = (double)C * n > 0.5 * conc_c ? 1.45 : 1.0;   // workgroups that share a CU
+        return (double)(g - 1) * (c_c * wf * sh1 + 1.8 * c_s * wv * sh2) + ((double)hs_rounds_of((long long)n) * c_c + 1.8 * c_s) * wv * sh2;
+    };
+    auto log_group = [&](long long s) {   // the group size with the cheapest recursion
+        if (grp_forced > 0) return (int)std::min<long long>(grp_forced, s);
+        int gb = 1;
+        for (int g = 2; g <= 8 && 2 * g <= s; g *= 2)
+            if (log_cost(s, g) < log_cost(s, gb)) gb = g;
+        return gb;
+    };
     {
         const double c_e = 10.0 + f * 22.0, c_f = 5.7 + f * 21.0;   // fused element step (32 µs at d = 64 with every CU busy), forward + backward sweep step
         auto cost = [&](long long s_asked) {
@@ -1312,12 +1326,12 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
                 scan = (sg * c_g + (ng + 2.0 * sg) * c_s) * std::ceil((double)C * ng / conc);
             } else if (s > 1)
                 scan = (double)s * c_s * std::ceil(2.0 * (double)C / conc);
-            if (s > 2 && scan_mode != 1 && hs_fits(s)) {   // log-depth: ⌈log₂⌉ rounds of 2·s compositions, one parallel boundary step
-                const double wv = std::ceil(2.0 * (double)C * (double)s / conc_c);
-                const double lg = (double)hs_rounds_of(s) * c_c * wv + 1.8 * c_s * wv;
+            if (s > 2 && scan_mode != 1 && hs_fits(s)) {   // log-depth: ⌈log₂⌉ rounds of compositions, one parallel boundary step
+                const double lg = log_cost(s, log_group(s));
                 if (lg < scan || scan_mode == 2) scan = lg;
             }
-            return rounds * steps * ((s > 1 ? c_e : 0.0) + c_f) + scan;
+            const double share = e->m_nt >= 3 && (double)C * (double)s > 0.5 * conc ? 1.3 : 1.0;   // d ≥ 48: two workgroups on a CU step 1.3× slower than one (narrower ones: measured neutral)
+            return rounds * steps * share * ((s > 1 ? c_e : 0.0) + c_f) + scan;
         };
         double best = 0.7 * cost(1);   // (the interpolated element costs are optimistic between d = 16 and 64: leave one segment only for a clear win)
         for (long long s = 2; s <= (long long)T - 1; s = std::max(s + 1, (long long)((double)s * 1.15))) {
@@ -1341,10 +1355,14 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
             const double sg = std::ceil(std::sqrt((double)S)), ng = std::ceil((double)S / sg);
             seq = (sg * c_g + (ng + 2.0 * sg) * c_s) * std::ceil((double)C * ng / conc);
         }
-        const double wv = std::ceil(2.0 * (double)C * (double)S / conc_c), lg = (double)hs_rounds_of(S) * c_c * wv + 1.8 * c_s * wv;
+        const int g = S > 2 ? log_group(S) : 1;
+        const double lg = log_cost(S, g);
+        e->m_hs_g = 1; e->m_hs_n = (int)S;
         if (S > 2 && hs_fits(S) && scan_mode != 1 && (lg < seq || scan_mode == 2)) {
             e->m_hs = 1;
-            e->m_hs_rounds = hs_rounds_of(S);
+            e->m_hs_g = g;
+            e->m_hs_n = (int)((S + g - 1) / g);
+            e->m_hs_rounds = hs_rounds_of(e->m_hs_n);
         }
     }
     if (!e->m_hs && S >= 16 && !std::getenv("RXHIP_MSEG_ONE_LEVEL")) {
@@ -1353,8 +1371,8 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
         e->m_sg = sg;
         e->m_ng = (int)((S + sg - 1) / sg);
     }
-    const size_t NG = (size_t)(e->m_ng > 0 ? e->m_ng : 1);
-    const size_t HS = e->m_hs ? (size_t)C * (size_t)S * 4 : 1;   // entries of the two generations of both scans
+    const size_t NG = (size_t)(e->m_hs && e->m_hs_g > 1 ? e->m_hs_n : e->m_ng > 0 ? e->m_ng : 1);   // group elements (km_group, or km_fold)
+    const size_t HS = e->m_hs ? (size_t)C * (size_t)e->m_hs_n * 4 : 1;   // entries of the two generations of both scans
     const DenseCst cl = DenseCst::make((int)D, e->dy);
     const int rec = dense_rec(e->m_nt), tri = dense_tri(e->m_nt);
     const size_t nws = std::max<size_t>((size_t)C * (size_t)S, (size_t)2 * C) * MSEG_WS * MM;
@@ -1434,9 +1452,11 @@ static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams
     if (mp.S == 1) hipLaunchKernelGGL(km_gy, dim3((unsigned)(((mp.T - 1) * mp.d + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
     else hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds_s, s, mp);
     if (mp.hs) {       // log-depth: all prefix / suffix compositions in ⌈log₂ S⌉ rounds, then every boundary state at once
-        for (int r = 0; r < mp.hs_rounds; ++r)
-            hipLaunchKernelGGL((km_compose<NT>), dim3(2 * (unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds_s, s, mp, r);
-        hipLaunchKernelGGL((km_apply<NT>), dim3(2 * (unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds_s, s, mp);
+        const dim3 g1((unsigned)mp.hs_n, (unsigned)mp.n_chains), g2(2 * (unsigned)mp.hs_n, (unsigned)mp.n_chains);
+        if (mp.hs_g > 1) hipLaunchKernelGGL((km_fold<NT>), g1, dim3(64 * NT), lds_s, s, mp);
+        for (int r = 0; r < mp.hs_rounds; ++r) hipLaunchKernelGGL((km_compose<NT>), g2, dim3(64 * NT), lds_s, s, mp, r);
+        hipLaunchKernelGGL((km_apply<NT>), g2, dim3(64 * NT), lds_s, s, mp);
+        if (mp.hs_g > 1) hipLaunchKernelGGL((km_inner<NT>), g2, dim3(64 * NT), lds_s, s, mp);
     } else if (mp.ng > 0) {   // two levels: group elements, the states at the group edges, then every group on its own
         hipLaunchKernelGGL((km_group<NT>), dim3((unsigned)mp.ng, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
         hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 2);
@@ -1464,7 +1484,7 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe, bool filter) {
     mp.mbnd = e->m_bnd; mp.mlb = e->m_lb; mp.fstart_m = e->d_fstart_m; mp.beta_xi = e->d_beta_xi; mp.filt = e->d_filt; mp.rec = dense_rec(e->m_nt);
     mp.status = e->d_status;
     mp.sg = e->m_sg; mp.ng = e->m_ng; mp.mgrp = e->m_grp; mp.mgvec = e->m_gvec;
-    mp.hs = e->m_hs; mp.hs_rounds = e->m_hs_rounds; mp.hsel = e->m_hsel; mp.hsvec = e->m_hsvec;
+    mp.hs = e->m_hs; mp.hs_rounds = e->m_hs_rounds; mp.hsel = e->m_hsel; mp.hsvec = e->m_hsvec; mp.hs_n = e->m_hs_n; mp.hs_g = e->m_hs_g;
     const DenseCst clm = DenseCst::make(e->m_dpad, e->dy);
     mp.step_model = e->m_stepm ? e->d_step_model : nullptr;
     mp.chain_model = e->m_chainm ? e->d_chain_model : nullptr;

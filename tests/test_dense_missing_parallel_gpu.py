@@ -135,6 +135,30 @@ def test_log_depth_boundary_recursion_equals_the_sequential_one(d, dy, T, C, seg
     assert np.allclose(fl, f1, rtol=1e-10, atol=1e-9)
 
 
+@pytest.mark.parametrize("d,dy,T,C,segments,group,ptt", [(64, 64, 260, 1, 50, 2, False), (24, 6, 400, 2, 37, 3, True), (16, 16, 700, 1, 129, 4, False), (8, 3, 90, 3, 9, 4, False),
+                                                            (40, 12, 130, 2, 33, 8, True), (64, 20, 1200, 1, 0, 2, False), (12, 12, 64, 5, 6, 4, False), (32, 32, 50, 1, 4, 2, True)])
+def test_log_depth_recursion_over_groups_of_segments(d, dy, T, C, segments, group, ptt, monkeypatch):
+    """segments finer than the entries of the rounds (RXHIP_MSEG_GROUP: km_fold composes every group first, km_inner carries the boundary
+    states from the group edges inwards): ragged last groups, a last group of one segment, two entries, one entry"""
+    from rxhip import workloads
+    mdl = workloads.random_model(d, dy, seed=71 + d)
+    y = workloads.generate_batch(mdl, T, C, seed0=6)
+    y[np.random.default_rng(T + d).random((T, C)) < 0.2] = np.nan
+    y[-1, 0] = np.nan
+    monkeypatch.delenv("RXHIP_MSEG_ONE_LEVEL", raising=False)
+    monkeypatch.setenv("RXHIP_MSEG_SCAN", "log")
+    monkeypatch.setenv("RXHIP_MSEG_GROUP", str(group))
+    mg, cg, fg = _run(mdl, y, ptt, False, monkeypatch, segments)
+    monkeypatch.delenv("RXHIP_MSEG_GROUP", raising=False)
+    monkeypatch.setenv("RXHIP_MSEG_SCAN", "sequential")
+    monkeypatch.setenv("RXHIP_MSEG_ONE_LEVEL", "1")
+    m1, c1, f1 = _run(mdl, y, ptt, False, monkeypatch, segments)
+    sd = np.sqrt(np.einsum("tcii->tci", c1))
+    assert np.max(np.abs(mg - m1) / sd) < 1e-8
+    assert np.max(np.abs(cg - c1) / (sd[..., :, None] * sd[..., None, :])) < 1e-8
+    assert np.allclose(fg, f1, rtol=1e-10, atol=1e-9)
+
+
 def _random_cases(n, seed):
     rng = np.random.default_rng(seed)
     for i in range(n):

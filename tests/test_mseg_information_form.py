@@ -180,3 +180,65 @@ def test_log_depth_rounds_with_two_buffers_give_every_prefix_and_suffix(S):
             ref = _compose(e, ref)
         for a, b in zip(get(1, j, _generations(S - 1 - j)), ref):
             assert np.allclose(a, b, rtol=1e-8, atol=1e-10), (S, j)
+
+
+@pytest.mark.parametrize("S,g", [(7, 2), (9, 4), (12, 3), (5, 8), (16, 4)])
+def test_groups_of_segments_fold_scan_and_inner_steps(S, g):
+    """km_fold / km_inner around the rounds: fold every group of g segments into one entry, take the boundary states at the group edges from
+    the prefix / suffix compositions of the entries, carry them inwards with one boundary step per segment — the same states as the plain
+    recursions over all segments (ragged last group included)"""
+    d, dy = 3, 2
+    A, B, P, Q, m0, V0 = _model(d, dy, 10 * S + g)
+    rng = np.random.default_rng(S + g)
+    els = []
+    for s in range(S):
+        ys = rng.standard_normal((int(rng.integers(1, 4)), dy))
+        ys[rng.random(len(ys)) < 0.3] = np.nan
+        els.append(_element(A, B, P, Q, ys))
+
+    def fwd(state, e):
+        lam, psi, jh, xi, eta = e
+        Ti = np.linalg.inv(state[0] + jh)
+        return lam - psi @ Ti @ psi.T, xi + psi @ Ti @ (state[1] + eta)
+
+    def bwd(e, state):
+        lam, psi, jh, xi, eta = e
+        Ti = np.linalg.inv(lam + state[0])
+        return jh - psi.T @ Ti @ psi, eta + psi.T @ Ti @ (xi + state[1])
+    b0 = (np.linalg.inv(V0), np.linalg.inv(V0) @ m0)
+    zero = (np.zeros((d, d)), np.zeros(d))
+    pre, suf = [b0], [zero]
+    for e in els:
+        pre.append(fwd(pre[-1], e))
+    for e in reversed(els):
+        suf.append(bwd(e, suf[-1]))
+    suf.reverse()                                  # suf[s]: message at the START of segment s = at the end of segment s − 1
+    n = (S + g - 1) // g
+    ent = []
+    for k in range(n):                             # km_fold
+        run = els[g * k]
+        for e in els[g * k + 1: min(g * k + g, S)]:
+            run = _compose(run, e)
+        ent.append(run)
+    for k in range(n):
+        s0, s1 = g * k, min(g * k + g, S)
+        # km_apply: belief at the start of the group through the prefix composition of the entries in front of it …
+        state = b0
+        if k:
+            P_ = ent[0]
+            for e in ent[1:k]:
+                P_ = _compose(P_, e)
+            state = fwd(b0, P_)
+        # … and km_inner from there
+        for s in range(s0, s1):
+            assert np.allclose(state[0], pre[s][0], rtol=1e-8, atol=1e-10) and np.allclose(state[1], pre[s][1], rtol=1e-8, atol=1e-10), (k, s)
+            state = fwd(state, els[s])
+        state = zero
+        if k < n - 1:
+            Q_ = ent[n - 1]
+            for e in reversed(ent[k + 1: n - 1]):
+                Q_ = _compose(e, Q_)
+            state = bwd(Q_, zero)
+        for s in range(s1 - 1, s0 - 1, -1):        # message at the END of segment s
+            assert np.allclose(state[0], suf[s + 1][0], rtol=1e-8, atol=1e-10) and np.allclose(state[1], suf[s + 1][1], rtol=1e-8, atol=1e-10), (k, s)
+            state = bwd(els[s], state)
