@@ -434,12 +434,19 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if "MASTER_PORT" not in os.environ:
-            s = socket.socket()
-            s.bind(("127.0.0.1", 0))
-            os.environ["MASTER_PORT"] = str(s.getsockname()[1])
-            s.close()
-        dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)  # RCCL on ROCm
+        own_port = "MASTER_PORT" not in os.environ   # (a launcher sets it; a single self-launched rank picks a free one)
+        for attempt in range(5):
+            if own_port:
+                s = socket.socket()
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+                s.close()
+            try:
+                dist.init_process_group("nccl", device_id=device, rank=rank, world_size=world)  # RCCL on ROCm
+                break
+            except RuntimeError:   # the port was taken between the probe and the store's bind (EADDRINUSE): another one
+                if not own_port or attempt == 4:
+                    raise
 
     mdl = workloads.c1_model()
     T, C = args.T, args.chains
