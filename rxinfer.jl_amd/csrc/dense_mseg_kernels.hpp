@@ -15,6 +15,8 @@
 //                suffix compositions E_j ∘ … ∘ E_{S−1} come out of ⌈log₂ S⌉ rounds of pairwise compositions, 2·S workgroups per round
 //   km_apply     every boundary state at once: the belief at t = 0 through the prefix composition in front of a segment (filtered belief at
 //                its start), the empty message through the suffix composition behind it (backward message at its end)
+//   km_fold,     segments finer than the entries of the rounds: km_fold composes groups of g segments into the entries, km_inner carries the
+//   km_inner     boundary states from the group edges to the segments inside (g − 1 steps; all groups at once)
 //   km_group,    the same states from SEQUENTIAL recursions (few segments, or RXHIP_MSEG_SCAN=sequential — each kind is the other's checker):
 //   km_scan      prefix / suffix steps over the elements, one inverse and two products per element and direction; from 16 segments on in
 //                two levels — km_group folds the ≈√S segments of a group into one element, km_scan level 2 runs over the group elements,
@@ -29,7 +31,7 @@
 // its result in the accumulators, every product takes its second operand from one staging matrix in LDS and its first from register fragments
 // loaded once, nothing between a kernel's inputs and outputs goes through memory — built from the non-inlined blocks of dense_tab_kernels.hpp
 // (km_group / km_scan still are) a round of 450 compositions moved 330 MB, at the memory system's rate.  d = 64, T = 2000, one chain, 10 %
-// missing: 0.92 ms per sweep (690 on the sequential schedule of rounds 1–2, 2.5 with the sequential recursion on building blocks; the fully
+// missing: 0.80 ms per sweep (690 on the sequential schedule of rounds 1–2, 2.5 with the sequential recursion on building blocks; the fully
 // observed chain: 0.29).  The algebra and the bookkeeping of the rounds are restated in numpy in tests/test_mseg_information_form.py.
 // Per-step constants (desc.step_model): the same kernels with the constant block of model step_model[t] per step (MsegParams::step_model,
 // kd_forward_info<…, STEPM>, one residual pass per model, km_feconst).
