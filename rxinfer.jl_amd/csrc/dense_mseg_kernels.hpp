@@ -251,7 +251,7 @@ __device__ __forceinline__ bool mseg_compose_fused(const double* e1_, const doub
 #pragma unroll
     for (int t = 0; t < NT; ++t) a1[t] = (d4){T.v[t][0], T.v[t][1], T.v[t][2], T.v[t][3]};
     macc_to_stage<NT>(a1, stage, w, lane);
-    __syncthreads();
+    lds_barrier();
     macc_zero<NT>(a1); macc_zero<NT>(a2);
     mstaged_mma<NT, false, true>(a1, a2, av1, av2, stage, lane);      // A′ = Ψ1′T⁻¹,  B = Ψ2 T⁻¹
     {
@@ -272,9 +272,9 @@ __device__ __forceinline__ bool mseg_compose_fused(const double* e1_, const doub
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cv[t][r] = e1[2 * MM + acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, t)];   // Ĵ1
-    __syncthreads();                                                  // every wave is done with T⁻¹
+    lds_barrier();                                                  // every wave is done with T⁻¹
     macc_to_stage<NT>(a1, stage, w, lane);                            // A′
-    __syncthreads();
+    lds_barrier();
     d4 jj[NT], pp[NT];
     macc_zero<NT>(jj); macc_zero<NT>(pp);
     mstaged_mma<NT, true, true>(jj, pp, av1, av2, stage, lane);       // Ψ1′A,  Ψ2 A
@@ -287,14 +287,14 @@ __device__ __forceinline__ bool mseg_compose_fused(const double* e1_, const doub
             eo[MM + o] = pp[t][r];                                    // Ψ = Ψ2 A
             cv[t][r] = e2[o];                                         // Λ2 (for the last block)
         }
-    __syncthreads();
+    lds_barrier();
     macc_to_stage<NT>(a2, stage, w, lane);                            // B
-    __syncthreads();
+    lds_barrier();
     macc_zero<NT>(jj);
     mstaged_mma<NT, true, false>(jj, pp, av2, av2, stage, lane);      // Ψ2 B′ = Ψ2 T⁻¹Ψ2′
-    __syncthreads();
+    lds_barrier();
     macc_to_stage<NT>(jj, stage, w, lane);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -323,7 +323,7 @@ __device__ __forceinline__ void mseg_absorb_fused(const Acc<NT>& Ti, const doubl
 #pragma unroll
     for (int t = 0; t < NT; ++t) n[t] = (d4){Ti.v[t][0], Ti.v[t][1], Ti.v[t][2], Ti.v[t][3]};
     macc_to_stage<NT>(n, stage, w, lane);
-    __syncthreads();
+    lds_barrier();
     macc_zero<NT>(n);
     mstaged_mma<NT, false, false>(n, t2, av, av, stage, lane);        // N = op(Ψ) T⁻¹
     {
@@ -342,14 +342,14 @@ __device__ __forceinline__ void mseg_absorb_fused(const Acc<NT>& Ti, const doubl
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cv[t][r] = Mbase[acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, t)];
-    __syncthreads();
+    lds_barrier();
     macc_to_stage<NT>(n, stage, w, lane);
-    __syncthreads();
+    lds_barrier();
     macc_zero<NT>(t2);
     mstaged_mma<NT, true, false>(t2, n, av, av, stage, lane);         // op(Ψ) N′
-    __syncthreads();
+    lds_barrier();
     macc_to_stage<NT>(t2, stage, w, lane);
-    __syncthreads();
+    lds_barrier();
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
         asm volatile("" : "+v"(lane));        // (index arithmetic per step, not hoisted into spilled registers)
         const int il = lane & 15;
         if (tid < D) yv[tid] = (ob && tid < dyu) ? p.y[(t * p.n_chains + chain) * dyu + tid] : 0.0;
-        __syncthreads();
+        lds_barrier();
         if (tid < D) {
             const double gy = ob ? tab_row_dot<D>(G, tid, yv) : 0.0;
             gyv[tid] = gy;
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt) gt[tt] = (d4){T.v[tt][0], T.v[tt][1], T.v[tt][2], T.v[tt][3]};
         macc_to_stage<NT>(gt, stage, w, lane);
-        __syncthreads();
+        lds_barrier();
         macc_zero<NT>(gt); macc_zero<NT>(yt);
         mstaged_mma<NT, false, true>(gt, yt, avk, avp, stage, lane);      // K C,  Y′ = Ψ′C
         {   // ξ = K C ξ + B′Q⁻¹y,  η̂ += Ψ′C ξ: row sums of the two products against the old ξ
@@ -461,9 +461,9 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) cv[tt][r] = Jh[acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, tt)];
-        __syncthreads();                                                  // every wave is done with C
+        lds_barrier();                                                  // every wave is done with C
         macc_to_stage<NT>(yt, stage, w, lane);
-        __syncthreads();
+        lds_barrier();
         d4 jj[NT], pn[NT];
         macc_zero<NT>(jj); macc_zero<NT>(pn);
         mstaged_mma<NT, true, true>(jj, pn, avp, avk, stage, lane);       // Ψ′Y,  K Y
@@ -476,18 +476,18 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
                 Pn[q] = pn[tt][r];                                        // Ψ = K Y   (into the other copy)
                 cv[tt][r] = PI[q];
             }
-        __syncthreads();
+        lds_barrier();
         macc_to_stage<NT>(gt, stage, w, lane);                            // K C
-        __syncthreads();
+        lds_barrier();
         macc_zero<NT>(jj);
         mstaged_mma<NT, true, false>(jj, pn, avk, avk, stage, lane);      // K (K C)′ = K C K′
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) jj[tt][r] = cv[tt][r] - jj[tt][r];   // Λp = P⁻¹ − K C K′
         macc_to_stage<NT>(jj, stage, w, lane);
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (int tt = 0; tt < NT; ++tt)
 #pragma unroll
