@@ -263,12 +263,21 @@ def extra_masked(device):
         eng.set_data(ym)
         out["missing_10pct_ms"] = med(eng)
         out["missing_10pct_schedule"] = eng.schedule()   # segments × segment length of the element pass (log-depth boundary recursion over them)
+        out["missing_10pct_parity_spot"] = parity_spot(eng, m, ym, [0], missing=True)   # the timed engine against the oracle, after the timing
     ms = [workloads.random_model(d, d, seed=d + 7 * k) for k in range(4)]
     mdl = tuple(np.stack([q[k] for q in ms]) for k in ("A", "B", "P", "Q", "m0", "V0"))
     sm = np.random.default_rng(0).integers(0, 4, T).astype(np.int32)
     with rxhip.LGSSMEngine(*mdl, T=T, n_chains=1, step_model=sm, device=device) as eng:
         eng.set_data(y)
         out["per_step_constants_4_models_ms"] = med(eng)
+        mean, cov = eng.marginals_of_chains([0])
+        fe = eng.free_energy_per_chain()
+    om, oc, ofe = _oracle().lgssm_kalman_rts_affine(*mdl, np.ascontiguousarray(y[:, 0]), step_model=sm)
+    sd = np.sqrt(np.einsum("tii->ti", oc))
+    spot = {"mean_rel": float(np.max(np.abs(mean[0] - om) / sd)), "fe_rel": float(abs(fe[0] - ofe) / abs(ofe)),
+            "cov_rel": float(np.max(np.abs(cov[0] - oc) / np.max(np.abs(oc), axis=(1, 2), keepdims=True)))}
+    spot["ok"] = bool(spot["mean_rel"] < 1e-6 and spot["cov_rel"] < 1e-6 and spot["fe_rel"] < 1e-8)
+    out["per_step_constants_parity_spot"] = spot
     out["missing_over_observed"] = out["missing_10pct_ms"] / out["fully_observed_ms"]
     return out
 
