@@ -89,7 +89,7 @@ __device__ __forceinline__ int mseg_model(const MsegParams& p, long long chain, 
 }
 constexpr int MSEG_WS = 14;
 // LDS of the km kernels (doubles): scratch of the inverse | 2·64·NT | 8 vectors | 16, then — kernels with inlined blocks — the staging
-// matrix of tab_mm_staged
+// matrix of the fused blocks
 __host__ __device__ constexpr int mseg_stage_offset(int NT) { return blk_scratch_doubles(NT) + 2 * 64 * NT + 8 * 16 * NT + 16; }
 __host__ __device__ constexpr int mseg_lds_doubles(int NT, bool staged) { return mseg_stage_offset(NT) + (staged ? 16 * NT * tab_stage_ld(NT) : 0); }
 
@@ -158,7 +158,7 @@ __device__ __forceinline__ void mfrag_load(double (&av)[4 * NT], const double* a
     const int i = 16 * w + (lane & 15), kq = lane >> 4;
 #pragma unroll
     for (int m = 0; m < 2 * NT; ++m) {
-        const int k = 8 * m + 2 * kq;                     // the permuted contraction index of tab_mm_body
+        const int k = 8 * m + 2 * kq;                     // the permuted contraction index of tab_mm
         if (TA) { av[2 * m] = a[k * D + i]; av[2 * m + 1] = a[(k + 1) * D + i]; }
         else { const v2d v = *reinterpret_cast<const v2d*>(a + i * D + k); av[2 * m] = v.x; av[2 * m + 1] = v.y; }
     }
@@ -365,13 +365,13 @@ __device__ __forceinline__ void mseg_absorb_fused(const Acc<NT>& Ti, const doubl
 //     C_t = (Λ + A′P⁻¹A)⁻¹,  Λp = P⁻¹ − K C_t K′ (K = P⁻¹A),  Y = C_t Ψ,  Ψ ← K Y,  Ĵ ← Ĵ − Ψ′Y,  c = C_t ξ,  η̂ ← η̂ + Ψ′c,  ξ ← K c + B′Q⁻¹y,
 //     Λ ← Λp + B′Q⁻¹B   (observed steps only)
 // — the forward step of kd_forward_info plus three products, ONE inverse and five products per step where the covariance form (the
-// first version of this file) needed an inverse and eleven (products that share an operand run as one block: tab_mm2_staged); and the boundary recursions below need exactly (Λ, Ψ, Ĵ, ξ, η̂), nothing else.
+// first version of this file) needed an inverse and eleven (products that share an operand run as one pass over the staged operand); and the boundary recursions below need exactly (Λ, Ψ, Ĵ, ξ, η̂), nothing else.
 // Out of the known start through the first transition: Λp = P⁻¹, Ψ = K, Ĵ = A′P⁻¹A, ξ = η̂ = 0.
 template <int NT>
 __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
     constexpr int D = 16 * NT, MM = D * D, LD = tab_stage_ld(NT);
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
+    TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
     double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;   // ξ (two copies) | η̂ | y | B′Q⁻¹y
     double *xi = vec, *xn = vec + D, *eta = vec + 2 * D, *yv = vec + 3 * D, *gyv = vec + 4 * D;
     double* stage = smem + mseg_stage_offset(NT);
@@ -733,7 +733,7 @@ template <int NT>
 __global__ void __launch_bounds__(64 * NT, 2) km_compose(MsegParams p, int r) {   // ≤ 256 registers: two workgroups per CU at d ≥ 48
     constexpr int D = 16 * NT, MM = D * D;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
+    TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
     double* u = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
     const int tid = o.tid, S = p.hs_n;               // entries of the scan
     const int dir = (int)blockIdx.x / S, j = (int)blockIdx.x - dir * S, h = 1 << r;
@@ -755,7 +755,7 @@ template <int NT>
 __global__ void __launch_bounds__(64 * NT, 2) km_apply(MsegParams p) {
     constexpr int D = 16 * NT, MM = D * D;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
+    TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
     double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
     double *xi = vec, *u = vec + D, *tv = vec + 2 * D;
     const int tid = o.tid, S = p.hs_n, dyu = p.dy_user;                      // S: entries of the scan; entry s = segments hs_g·s … (seg0 … seg1)
@@ -847,7 +847,7 @@ template <int NT>
 __global__ void __launch_bounds__(64 * NT, 2) km_fold(MsegParams p) {
     constexpr int D = 16 * NT, MM = D * D;
     extern __shared__ __attribute__((aligned(16))) double smem[];
-    TabOps<NT, true> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem, smem + mseg_stage_offset(NT)};
+    TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
     double* u = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
     const int tid = o.tid, S = p.S;
     const long long grp = blockIdx.x, chain = blockIdx.y;

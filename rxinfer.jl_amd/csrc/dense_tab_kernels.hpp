@@ -52,11 +52,13 @@ struct TabWs {
 
 // The building blocks are NOT inlined: a phase kernel is a chain of a few hundred of them, and inlined the compiler schedules across
 // all of it (512 registers and kilobytes of scratch per lane in the first version — scratch that size also makes the runtime
-// re-provision the queue's scratch space).  One call per product costs nothing next to the product.
+// re-provision the queue's scratch space).  One call per product costs nothing next to the product.  (A non-inlined block is compiled
+// without the caller's launch bounds: 280–312 registers at d ≥ 48, one workgroup per CU — kernels that run hundreds of workgroups at once
+// are fused instead: dense_mseg_kernels.hpp.)
 // SYNC = false: no barrier behind the stores — for a product whose result the NEXT building block does not read (and whose destination
 // nobody is still reading): its stores drain under the next block's loads
 template <int NT, bool TA, bool TB, bool SYNC = true>
-__device__ __forceinline__ void tab_mm_body(double* dst0, const double* a0, const double* b0, double alpha, const double* c0, double beta, int w, int lane) {
+__device__ __attribute__((noinline)) void tab_mm(double* dst0, const double* a0, const double* b0, double alpha, const double* c0, double beta, int w, int lane) {
     constexpr int D = 16 * NT;
     // every operand lives in the global workspace: say so (behind a non-inlined call the pointers are of unknown origin, and flat loads
     // count on the LDS counter as well)
@@ -108,165 +110,8 @@ __device__ __forceinline__ void tab_mm_body(double* dst0, const double* a0, cons
         }
     if (SYNC) __syncthreads();
 }
-// The same product with the B operand staged through LDS (`stage`: D × (D + 2) doubles): every wave loads a quarter of it once (the
-// register version above loads all of B in every wave — 128 registers at d = 64, spilled inside an inlined kernel) and reads its
-// fragments from LDS.  Two barriers of its own: every wave is done with the previous staging before the first write, and the writes are
-// complete before the first read.  For the short inlined kernels of dense_mseg_kernels.hpp (TabOps<NT, true> with a stage).
+// leading dimension of the LDS staging matrix of the fused kernels of dense_mseg_kernels.hpp
 constexpr int tab_stage_ld(int NT) { return 16 * NT + 2; }
-template <int NT, bool TA, bool TB, bool SYNC = true>
-__device__ __forceinline__ void tab_mm_staged(double* dst0, const double* a0, const double* b0, double alpha, const double* c0, double beta, double* stage, int w, int lane) {
-    constexpr int D = 16 * NT, MM = D * D, NTH = 64 * NT, LD = tab_stage_ld(NT), KS = D / 4;
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    double* dst = as_global(dst0);
-    const double *a = as_global(a0), *b = as_global(b0), *c = c0 ? as_global(c0) : nullptr;
-    asm volatile("" : "+v"(lane));       // inlined in a loop: the index arithmetic below is redone per call, not hoisted into (spilled) registers
-    const int il = lane & 15, kq = lane >> 4, i = 16 * w + il, tid = 64 * w + lane;
-    __builtin_amdgcn_sched_barrier(0);   // inlined behind a product without a closing barrier: keep these loads out of its epilogue (registers)
-    v2d sb[MM / NTH / 2];
-#pragma unroll
-    for (int u = 0; u < MM / NTH / 2; ++u) sb[u] = *reinterpret_cast<const v2d*>(b + 2 * (tid + u * NTH));
-    double av[KS];
-#pragma unroll
-    for (int m = 0; m < KS / 2; ++m) {
-        const int k = 8 * m + 2 * kq;
-        if (TA) { av[2 * m] = a[k * D + i]; av[2 * m + 1] = a[(k + 1) * D + i]; }
-        else { const v2d v = *reinterpret_cast<const v2d*>(a + i * D + k); av[2 * m] = v.x; av[2 * m + 1] = v.y; }
-    }
-    double cv[NT][4];
-    if (c) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cv[t][r] = c[acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, t)];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < MM / NTH / 2; ++u) {
-        const int e = 2 * (tid + u * NTH), row = e / D, col = e - row * D;
-        *reinterpret_cast<v2d*>(stage + row * LD + col) = sb[u];
-    }
-    __syncthreads();
-    d4 acc[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) acc[t] = (d4){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int m = 0; m < KS / 2; ++m) {
-        const int k = 8 * m + 2 * kq;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int j = 16 * t + il;
-            double b0v, b1v;
-            if (TB) { const v2d v = *reinterpret_cast<const v2d*>(stage + j * LD + k); b0v = v.x; b1v = v.y; }
-            else { b0v = stage[k * LD + j]; b1v = stage[(k + 1) * LD + j]; }
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2 * m], b0v, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[2 * m + 1], b1v, acc[t], 0, 0, 0);
-        }
-    }
-#pragma unroll
-    for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ii = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
-            double v = alpha * acc[t][r];
-            if (c) v += beta * cv[t][r];
-            dst[ii * D + j] = v;
-        }
-    if (SYNC) __syncthreads();
-}
-// Two products that share the staged operand: dst1 = alpha1·op(a1)·op(b) + beta1·c1, dst2 = op(a2)·op(b) — one staging, one pair of barriers
-// and one pass over the LDS fragments for both.  RD: the epilogue also forms out_k[i] = base_k[i] + Σ_j dst_k[i][j]·u[j] (u in LDS) from the
-// accumulators — a row of 16 lanes holds a row of the tile: four xor-shuffles — for the vectors of the composition, which would otherwise
-// re-read the products from memory.
-template <int NT, bool TA1, bool TA2, bool TB, bool RD = false, bool SYNC = true>
-__device__ __forceinline__ void tab_mm2_staged(double* dst1_, const double* a1_, double alpha1, const double* c1_, double beta1, double* dst2_, const double* a2_,
-                                               const double* b0, double* stage, int w, int lane, const double* u = nullptr, const double* base1 = nullptr,
-                                               double* out1 = nullptr, const double* base2 = nullptr, double* out2 = nullptr) {
-    constexpr int D = 16 * NT, MM = D * D, NTH = 64 * NT, LD = tab_stage_ld(NT), KS = D / 4;
-    typedef double v2d __attribute__((ext_vector_type(2)));
-    double *dst1 = as_global(dst1_), *dst2 = as_global(dst2_);
-    const double *a1 = as_global(a1_), *a2 = as_global(a2_), *b = as_global(b0), *c1 = c1_ ? as_global(c1_) : nullptr;
-    asm volatile("" : "+v"(lane));       // inlined in a loop: the index arithmetic below is redone per call, not hoisted into (spilled) registers
-    const int il = lane & 15, kq = lane >> 4, i = 16 * w + il, tid = 64 * w + lane;
-    __builtin_amdgcn_sched_barrier(0);   // inlined behind a product without a closing barrier: keep these loads out of its epilogue (registers)
-    v2d sb[MM / NTH / 2];
-#pragma unroll
-    for (int q = 0; q < MM / NTH / 2; ++q) sb[q] = *reinterpret_cast<const v2d*>(b + 2 * (tid + q * NTH));
-    double av1[KS], av2[KS];
-#pragma unroll
-    for (int m = 0; m < KS / 2; ++m) {
-        const int k = 8 * m + 2 * kq;
-        if (TA1) { av1[2 * m] = a1[k * D + i]; av1[2 * m + 1] = a1[(k + 1) * D + i]; }
-        else { const v2d v = *reinterpret_cast<const v2d*>(a1 + i * D + k); av1[2 * m] = v.x; av1[2 * m + 1] = v.y; }
-        if (TA2) { av2[2 * m] = a2[k * D + i]; av2[2 * m + 1] = a2[(k + 1) * D + i]; }
-        else { const v2d v = *reinterpret_cast<const v2d*>(a2 + i * D + k); av2[2 * m] = v.x; av2[2 * m + 1] = v.y; }
-    }
-    double cv[NT][4];
-    if (c1) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) cv[t][r] = c1[acc_row<NT>(w, lane, r) * D + acc_col<NT>(lane, t)];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < MM / NTH / 2; ++q) {
-        const int e = 2 * (tid + q * NTH), row = e / D, col = e - row * D;
-        *reinterpret_cast<v2d*>(stage + row * LD + col) = sb[q];
-    }
-    __syncthreads();
-    d4 acc1[NT], acc2[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) { acc1[t] = (d4){0.0, 0.0, 0.0, 0.0}; acc2[t] = (d4){0.0, 0.0, 0.0, 0.0}; }
-#pragma unroll
-    for (int m = 0; m < KS / 2; ++m) {
-        const int k = 8 * m + 2 * kq;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int j = 16 * t + il;
-            double b0v, b1v;
-            if (TB) { const v2d v = *reinterpret_cast<const v2d*>(stage + j * LD + k); b0v = v.x; b1v = v.y; }
-            else { b0v = stage[k * LD + j]; b1v = stage[(k + 1) * LD + j]; }
-            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[2 * m], b0v, acc1[t], 0, 0, 0);
-            acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av2[2 * m], b0v, acc2[t], 0, 0, 0);
-            acc1[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[2 * m + 1], b1v, acc1[t], 0, 0, 0);
-            acc2[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av2[2 * m + 1], b1v, acc2[t], 0, 0, 0);
-        }
-    }
-    double rd1[4] = {0.0, 0.0, 0.0, 0.0}, rd2[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const double uj = RD ? u[16 * t + il] : 0.0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int ii = acc_row<NT>(w, lane, r), j = acc_col<NT>(lane, t);
-            double v1 = alpha1 * acc1[t][r];
-            if (c1) v1 += beta1 * cv[t][r];
-            dst1[ii * D + j] = v1;
-            dst2[ii * D + j] = acc2[t][r];
-            if (RD) { rd1[r] += v1 * uj; rd2[r] += acc2[t][r] * uj; }
-        }
-    }
-    if (RD) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int m = 8; m > 0; m >>= 1) {
-                rd1[r] += __shfl_xor(rd1[r], m, 16);
-                rd2[r] += __shfl_xor(rd2[r], m, 16);
-            }
-            if (il == 0) {
-                const int ii = acc_row<NT>(w, lane, r);
-                out1[ii] = base1[ii] + rd1[r];
-                out2[ii] = base2[ii] + rd2[r];
-            }
-        }
-    }
-    if (SYNC) __syncthreads();
-}
-template <int NT, bool TA, bool TB, bool SYNC = true>
-__device__ __attribute__((noinline)) void tab_mm(double* dst0, const double* a0, const double* b0, double alpha, const double* c0, double beta, int w, int lane) {
-    tab_mm_body<NT, TA, TB, SYNC>(dst0, a0, b0, alpha, c0, beta, w, lane);
-}
 template <int NT>
 __device__ __attribute__((noinline)) bool tab_inv(double* dst, const double* a, double* lds, double* logdet_out, int w, int lane) {
     constexpr int D = 16 * NT;
@@ -284,7 +129,7 @@ __device__ __attribute__((noinline)) bool tab_inv(double* dst, const double* a, 
 // dst = (alpha·½(a + a′) + gamma·c)⁻¹: the symmetrised sum is formed in the accumulator registers on the way in (one building block less
 // in front of every inverse of the masked schedule)
 template <int NT>
-__device__ __forceinline__ bool tab_inv_symadd_body(double* dst0, double alpha, const double* a0, double gamma, const double* c0, const double* e0, double* lds, int w, int lane) {
+__device__ __attribute__((noinline)) bool tab_inv_symadd(double* dst0, double alpha, const double* a0, double gamma, const double* c0, const double* e0, double* lds, int w, int lane) {
     constexpr int D = 16 * NT;
     double* dst = as_global(dst0);
     const double *a = as_global(a0), *c = as_global(c0), *e3 = e0 ? as_global(e0) : nullptr;   // optional third term (+ sym(e))
@@ -303,10 +148,6 @@ __device__ __forceinline__ bool tab_inv_symadd_body(double* dst0, double alpha, 
     acc_store<NT>(acc, dst, D, w, lane);
     __syncthreads();
     return ok;
-}
-template <int NT>
-__device__ __attribute__((noinline)) bool tab_inv_symadd(double* dst0, double alpha, const double* a0, double gamma, const double* c0, const double* e0, double* lds, int w, int lane) {
-    return tab_inv_symadd_body<NT>(dst0, alpha, a0, gamma, c0, e0, lds, w, lane);
 }
 template <int NT>
 __device__ __attribute__((noinline)) void tab_lin(double* dst0, double alpha, const double* a0, double beta, const double* b0, bool tb, int tid) {
@@ -345,35 +186,20 @@ __device__ __attribute__((noinline)) void tab_symadd(double* dst0, double alpha,
     __syncthreads();
 }
 
-// INL: the products and the inverse inlined into the calling kernel (short kernels with a register bound of their own: km_compose,
-// km_apply — a non-inlined block is compiled without the caller's launch bounds and takes 280 registers at d = 64)
-template <int NT, bool INL = false>
+template <int NT>
 struct TabOps {
     static constexpr int D = 16 * NT, MM = D * D, NTH = 64 * NT;
     int tid, w, lane;
     double* lds;   // ≥ blk_scratch_doubles(NT) + NTH doubles
-    double* stage = nullptr;   // INL: D × tab_stage_ld(NT) doubles of LDS for the staged product (null: operands in registers)
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     // dst = alpha·op(a)·op(b) + beta·c      (c may be null or dst; dst must differ from a and b)
     template <bool TA, bool TB, bool SYNC = true>
     __device__ __forceinline__ void mm(double* dst, const double* a, const double* b, double alpha = 1.0, const double* c = nullptr, double beta = 0.0) const {
-        if constexpr (INL) {
-            if (stage) tab_mm_staged<NT, TA, TB, SYNC>(dst, a, b, alpha, c, beta, stage, w, lane);
-            else tab_mm_body<NT, TA, TB, SYNC>(dst, a, b, alpha, c, beta, w, lane);
-        }
-        else tab_mm<NT, TA, TB, SYNC>(dst, a, b, alpha, c, beta, w, lane);
-    }
-    // two products with a shared second operand (tab_mm2_staged; INL kernels with a stage only)
-    template <bool TA1, bool TA2, bool TB, bool RD = false, bool SYNC = true>
-    __device__ __forceinline__ void mm2(double* dst1, const double* a1, double alpha1, const double* c1, double beta1, double* dst2, const double* a2, const double* b,
-                                        const double* u = nullptr, const double* base1 = nullptr, double* out1 = nullptr, const double* base2 = nullptr, double* out2 = nullptr) const {
-        static_assert(INL, "mm2 needs the inlined blocks and a staging matrix");
-        tab_mm2_staged<NT, TA1, TA2, TB, RD, SYNC>(dst1, a1, alpha1, c1, beta1, dst2, a2, b, stage, w, lane, u, base1, out1, base2, out2);
+        tab_mm<NT, TA, TB, SYNC>(dst, a, b, alpha, c, beta, w, lane);
     }
     // dst = (alpha·sym(a) + gamma·sym(c))⁻¹
     __device__ __forceinline__ bool inv_symadd(double* dst, double alpha, const double* a, double gamma, const double* c, const double* e = nullptr) const {
-        if constexpr (INL) return tab_inv_symadd_body<NT>(dst, alpha, a, gamma, c, e, lds, w, lane);
-        else return tab_inv_symadd<NT>(dst, alpha, a, gamma, c, e, lds, w, lane);
+        return tab_inv_symadd<NT>(dst, alpha, a, gamma, c, e, lds, w, lane);
     }
     // dst = alpha·a + beta·op(b)   (elementwise; a, b may be null; dst may alias a, and b)
     __device__ __forceinline__ void lin(double* dst, double alpha, const double* a, double beta = 0.0, const double* b = nullptr, bool tb = false) const {
