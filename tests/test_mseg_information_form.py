@@ -242,3 +242,50 @@ def test_groups_of_segments_fold_scan_and_inner_steps(S, g):
         for s in range(s1 - 1, s0 - 1, -1):        # message at the END of segment s
             assert np.allclose(state[0], suf[s + 1][0], rtol=1e-8, atol=1e-10) and np.allclose(state[1], suf[s + 1][1], rtol=1e-8, atol=1e-10), (k, s)
             state = bwd(els[s], state)
+
+
+def _element_fused(A, B, P, Q, ys):
+    """the step as the fused kernel forms it (km_elements): with C in the staging matrix, K C and Y′ = Ψ′C in one pass, the vectors as row
+    sums of those two products against the old ξ, Ĵ −= Ψ′Y and Ψ = K Y from the staged Y′, Λp = P⁻¹ − K (K C)′ symmetrised"""
+    Pi, Qi = np.linalg.inv(P), np.linalg.inv(Q)
+    Pi = 0.5 * (Pi + Pi.T)
+    K, W, Lobs, G = Pi @ A, A.T @ Pi @ A, B.T @ Qi @ B, B.T @ Qi
+    W, Lobs = 0.5 * (W + W.T), 0.5 * (Lobs + Lobs.T)          # the symmetric copies kt_consts leaves
+    lam = None
+    for y in ys:
+        ob = not np.any(np.isnan(y))
+        gy = G @ y if ob else np.zeros(len(A))
+        if lam is None:
+            lam, psi, jh, xi, eta = Pi.copy(), K.copy(), W.copy(), gy, np.zeros(len(A))
+        else:
+            C = np.linalg.inv(lam + W + (Lobs if ob_prev else 0.0))
+            gt, yt = K @ C, psi.T @ C
+            xi, eta = gt @ xi + gy, eta + yt @ xi
+            jh, psi = jh - psi.T @ yt.T, K @ yt.T
+            lp = Pi - K @ gt.T
+            lam = 0.5 * (lp + lp.T)
+        ob_prev = ob
+    return lam + (Lobs if ob_prev else 0.0), psi, jh, xi, eta
+
+
+def _compose_fused(e1, e2):
+    """mseg_compose_fused: A′ = Ψ1′T⁻¹ and B = Ψ2 T⁻¹ from the staged T⁻¹, the vectors as their row sums, then Ψ1′A, Ψ2 A, Ψ2 B′"""
+    l1, p1, j1, x1, h1 = e1
+    l2, p2, j2, x2, h2 = e2
+    Ti = np.linalg.inv(l1 + j2)
+    at, bq, u = p1.T @ Ti, p2 @ Ti, x1 + h2
+    t2 = p2 @ bq.T
+    return l2 - 0.5 * (t2 + t2.T), p2 @ at.T, j1 - p1.T @ at.T, x2 + bq @ u, h1 + at @ u
+
+
+@pytest.mark.parametrize("d,dy,n,seed", [(4, 2, 7, 1), (6, 6, 5, 2), (3, 1, 9, 3)])
+def test_fused_forms_are_the_same_algebra(d, dy, n, seed):
+    A, B, P, Q, _, _ = _model(d, dy, seed)
+    rng = np.random.default_rng(seed)
+    ys = rng.standard_normal((2 * n, dy))
+    ys[rng.random(2 * n) < 0.3] = np.nan
+    for a, b in zip(_element(A, B, P, Q, ys), _element_fused(A, B, P, Q, ys)):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-11)
+    e1, e2 = _element(A, B, P, Q, ys[:n]), _element(A, B, P, Q, ys[n:])
+    for a, b in zip(_compose(e1, e2), _compose_fused(e1, e2)):
+        assert np.allclose(a, b, rtol=1e-9, atol=1e-11)
