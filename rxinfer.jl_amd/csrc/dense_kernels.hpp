@@ -687,6 +687,28 @@ __device__ __forceinline__ void blk_publish_exponents(const double (&dt)[4], dou
         sc[16 * NT + 16 * w + 4 * (j & 3) + (j >> 2)] = h;
     }
 }
+// Sum over the 16 lanes of a DPP row, in every lane of the row: four DPP stages (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror,
+// row_mirror — the reduction of hgf_kernels.hpp) instead of four dependent ds_bpermute round trips with a wait behind each.
+template <int CTRL>
+__device__ __forceinline__ int dpp_row_mov(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xf, 0xf, true); }
+__device__ __forceinline__ int row16_sum(int v) {
+    v += dpp_row_mov<0xB1>(v);
+    v += dpp_row_mov<0x4E>(v);
+    v += dpp_row_mov<0x141>(v);
+    v += dpp_row_mov<0x140>(v);
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_row_mov(double v) {
+    return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ double row16_sum(double v) {
+    v += dpp_row_mov<0xB1>(v);
+    v += dpp_row_mov<0x4E>(v);
+    v += dpp_row_mov<0x141>(v);
+    v += dpp_row_mov<0x140>(v);
+    return v;
+}
 // FINAL = false: no barrier at the end — the caller must pass a workgroup barrier before anything else writes to `scratch`
 // PUB = false: the exponents are in the scratch already (blk_publish_exponents + a workgroup barrier by the caller)
 template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true>
@@ -725,10 +747,7 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
         for (int r = 0; r < 4; ++r) hr[r] = hr[r] == 0x40000000 ? 0 : hr[r];
         bad = __any(inval);  // every wave sees all 16 NT exponents: uniform over the workgroup
         if (w == 0) {        // Σ h over the whole diagonal: det A = det A_s · 2^(−2 Σ h)
-            hsum += __shfl_xor(hsum, 1);
-            hsum += __shfl_xor(hsum, 2);
-            hsum += __shfl_xor(hsum, 4);
-            hsum += __shfl_xor(hsum, 8);
+            hsum = row16_sum(hsum);
             if (lane == 0) lp.expo -= 2 * (long long)hsum;
         }
 #pragma unroll

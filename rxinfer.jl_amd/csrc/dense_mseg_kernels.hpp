@@ -211,9 +211,7 @@ __device__ __forceinline__ void macc_rowdot(double (&rd)[4], const d4 (&acc)[NT]
         for (int r = 0; r < 4; ++r) rd[r] += acc[t][r] * xj;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int m = 8; m > 0; m >>= 1) rd[r] += __shfl_xor(rd[r], m, 16);
+    for (int r = 0; r < 4; ++r) rd[r] = row16_sum(rd[r]);
 }
 // Two segments in a row as one (the formulas of km_group), fused: reads Λ1, Ĵ2, Ψ1, Ψ2, Ĵ1, Λ2 once each, writes Λ, Ψ, Ĵ — 9 matrices of
 // traffic where the block version moved 23.  scr: scratch of the inverse, stage: the staging matrix,
