@@ -2074,7 +2074,7 @@ inline size_t fe_resid_lds_bytes(int D, int dy) {
     const size_t pass = 16 * (size_t)fe_resid_groups(D, dy);
     return sizeof(double) * ((size_t)2 * D * D + (size_t)D * dy + (size_t)dy * dy + (2 * pass + 1) * D + pass * dy + 16);
 }
-__global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
+static __global__ void __launch_bounds__(256) kd_fe_resid(DenseParams p, int slot0) {
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int D = p.d, dy = p.dy, tid = threadIdx.x, lane = tid & 63, g = tid >> 6;
     const int G = fe_resid_groups(D, dy), DL = 64 / G, q = lane / DL, i = lane - q * DL;  // lane group q, row i
@@ -2453,7 +2453,7 @@ __global__ void __launch_bounds__(64 * NT) kd_cross_from_records(DenseParams p, 
 // THAT step's models (rows read along k: uncoalesced, but the work is tiny: 4·d² multiply-adds per step) — 64 steps per workgroup, one
 // partial slot each.  Same terms, same masks as the MFMA form.
 constexpr int FE_STEPS_BLOCK = 64;
-__global__ void __launch_bounds__(256) kd_fe_resid_steps(DenseParams p, int slot0) {
+static __global__ void __launch_bounds__(256) kd_fe_resid_steps(DenseParams p, int slot0) {
     __shared__ double xb[4][3][64];
     __shared__ double red[4];
     const int D = p.d, dy = p.dy, dy4 = (dy + 3) & ~3, KY = dy4 + D;

@@ -95,7 +95,7 @@ __host__ __device__ constexpr int mseg_lds_doubles(int NT, bool staged) { return
 
 // grid (blocks over time, chains); nobs[chain] must be zero on entry (mseg_launch clears it): exact integer counts, any order.
 // Sixteen lanes share an observation vector (coalesced reads of y), 16 time steps per 256-thread pass.
-__global__ void __launch_bounds__(256) km_mask(MsegParams p) {
+static __global__ void __launch_bounds__(256) km_mask(MsegParams p) {
     __shared__ double red[256];
     const long long chain = blockIdx.y;
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
@@ -522,7 +522,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
 
 // One segment per chain (batches with enough chains to fill the machine: mseg_setup): no element is needed, only what km_elements hands
 // to the sweep kernel besides it — B'Q⁻¹y_t of the observed steps, 0 for the missing ones.  One thread per (chain, t ≥ 1, component).
-__global__ void __launch_bounds__(256) km_gy(MsegParams p) {
+static __global__ void __launch_bounds__(256) km_gy(MsegParams p) {
     const int D = p.d, dyu = p.dy_user;
     const long long chain = blockIdx.y, idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long t = 1 + idx / D;
@@ -538,7 +538,7 @@ __global__ void __launch_bounds__(256) km_gy(MsegParams p) {
 
 // per-step constants: what the free energy of a chain owes to constants alone, summed over its steps —
 // log|V1| + Σ_{t ≥ 1} log|P_t| + Σ_{t observed} (dy log 2π + log|Q_t|).  One workgroup per chain, fixed summation order.
-__global__ void __launch_bounds__(256) km_feconst(MsegParams p) {
+static __global__ void __launch_bounds__(256) km_feconst(MsegParams p) {
     __shared__ double red[256];
     const long long chain = blockIdx.x;
     double acc = 0.0;
@@ -934,7 +934,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_inner(MsegParams p) {
 // smoothing pipeline's value, scaled by the reduction.)
 template <int NT>
 __global__ void __launch_bounds__(64 * NT) km_filter_out(MsegParams p, DenseParams q) {
-    constexpr int D = 16 * NT, MM = D * D;
+    constexpr int D = 16 * NT;
     using C = DenseCfg<NT>;
     constexpr int LD = C::LD;
     extern __shared__ __attribute__((aligned(16))) double smem[];

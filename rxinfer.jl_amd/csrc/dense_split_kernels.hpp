@@ -36,7 +36,7 @@ struct SplitParams {
 };
 
 // records of workgroup chain 0 (accumulator order) -> row-major tables; one workgroup per time index
-__global__ void __launch_bounds__(256) kd_split_tables(SplitParams q) {
+static __global__ void __launch_bounds__(256) kd_split_tables(SplitParams q) {
     const int D = q.D, NT = D / 16, tid = threadIdx.x;
     const long long t = blockIdx.x;
     const double* rec = q.p.filt + t * q.rec + 3 * D;   // chain 0: C_t | G_t′, both in accumulator order
@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(256) kd_split_tables(SplitParams q) {
 }
 
 // after the model pass: the posterior covariances and the constant free-energy slots of user chain 0
-__global__ void __launch_bounds__(256) kd_split_save(SplitParams q, long long user_chains) {
+static __global__ void __launch_bounds__(256) kd_split_save(SplitParams q, long long user_chains) {
     const long long dd = (long long)q.p.d_out * q.p.d_out, total = q.p.T * dd;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const long long t = e / dd, k = e - t * dd;
@@ -71,7 +71,7 @@ __global__ void __launch_bounds__(256) kd_split_save(SplitParams q, long long us
 }
 
 // every sweep: V_s(t) into the posterior array of every chain, the constant free-energy slots into every chain's column
-__global__ void __launch_bounds__(256) kd_split_broadcast(SplitParams q, long long user_chains, int want_fe, int want_cov) {
+static __global__ void __launch_bounds__(256) kd_split_broadcast(SplitParams q, long long user_chains, int want_fe, int want_cov) {
     const long long dd = (long long)q.p.d_out * q.p.d_out, row = user_chains * dd, total = want_cov ? q.p.T * row : 0;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
         const long long t = e / row, k = (e - t * row) % dd;

@@ -555,7 +555,7 @@ __global__ void __launch_bounds__(64 * NT) kt_scan(TabParams p) {
 
 // canonical indices of the composed maps: a group whose step maps are, one by one, the canonical maps of the previous group's
 // steps has the previous group's products.  (Sequential integer logic, one thread.)
-__global__ void kt_qcanon(TabParams p) {
+static __global__ void kt_qcanon(TabParams p) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int S = p.S, n = S - 1, sg = p.sg;
     for (int dir = 0; dir < 2; ++dir) {

@@ -1840,7 +1840,7 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
 // both with a fixed summation shape (deterministic run to run: needed for the 1e-8 tolerance).
 // Restates the global sum of src/model/plugins/reactivemp_free_energy.jl:101-123
 // (`sumreduce`, src/helpers.jl:21); NaN/Inf check mirrors src/score/diagnostics.jl:19-51.
-__global__ void __launch_bounds__(256) k_fe_chain(Params p, double* block_part) {
+static __global__ void __launch_bounds__(256) k_fe_chain(Params p, double* block_part) {
     // 64 chains per block; the 4 waves each sum a contiguous quarter of the S+1 partials of
     // their chain (independent loads in flight), combined in fixed order.
     __shared__ double sh[4][64];
@@ -1879,7 +1879,7 @@ __global__ void __launch_bounds__(256) k_fe_chain(Params p, double* block_part) 
 // Few chains (≤ 16): k_fe_chain leaves all but one lane of each wave idle and walks the partials one by one.  Here one
 // workgroup sums the p.S + 1 partials of every chain with all 256 threads (fixed stride and tree shape: deterministic) and
 // finishes with the total — chain and total reduction in a single launch.
-__global__ void __launch_bounds__(256) k_fe_few(Params p) {
+static __global__ void __launch_bounds__(256) k_fe_few(Params p) {
     __shared__ double sh[256];
     const int n = p.S + 1;
     double total = 0.0;
@@ -1904,7 +1904,7 @@ __global__ void __launch_bounds__(256) k_fe_few(Params p) {
         if (bad) atomicOr(p.status, ST_NONFINITE);
     }
 }
-__global__ void __launch_bounds__(256) k_fe_total(Params p, const double* block_part, int nblocks) {
+static __global__ void __launch_bounds__(256) k_fe_total(Params p, const double* block_part, int nblocks) {
     __shared__ double sh[256];
     double local = 0.0;
     for (int b = threadIdx.x; b < nblocks; b += 256) local += block_part[b];

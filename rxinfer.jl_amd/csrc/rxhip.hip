@@ -18,53 +18,19 @@
 #include <string>
 #include <vector>
 
-#include "lgssm_kernels.hpp"
-#include "dense_kernels.hpp"
+#include "launch_tables.hpp"
 #include "gseq_kernels.hpp"
-#include "dense_split_kernels.hpp"
-#include "dense_tab_kernels.hpp"
-#include "dense_mseg_kernels.hpp"
 #include "gmm_kernels.hpp"
 #include "hgf_kernels.hpp"
 #include "mvgmm_kernels.hpp"
 #include "drift_kernels.hpp"
-#include "predict_kernels.hpp"
 #include "generic_kernels.hpp"
 #include "graph_lowering.hpp"
 
 using namespace rxhip;
 
-// ------------------------------------------------------------------------------------------
-// per-(d,dy) dispatch table
-struct LgssmVtbl {
-    int d, dy;
-    int cst_size, tab_size, agg_size;
-    // layout offsets (host table builder writes through these)
-    int oA, oP, oLOBS, oG, oQI, oC0, oM1, oV1, oHF;
-    int tK, tU;
-    int aPI, aC, aJ, aCI, aX, aJJ;
-    int scan_size, sM1, sM2, sVB, sN1, sN2, sLB;
-    int f0_size, fK, fU, fSI, pos_size, pPI, pJ, pC, fs_size, fsA1, fsA2, fsW, mt_row;  // one-pass schedule (k_forward0)
-    void (*forward0)(const Params&, const double*, bool, hipStream_t);
-    void (*time_tables)(const TimeTabParams&, hipStream_t);
-    void (*fe_seg)(const Params&, hipStream_t);
-    int gt_row, se_size;  // SmoothTab / SegEndTab
-    void (*smooth_tables)(const SmoothTabParams&, const double*, hipStream_t);
-    void (*backward_sh)(const Params&, const double*, const double*, hipStream_t);
-    void (*boundary_scan_tab)(const Params&, const double*, bool, hipStream_t);
-    void (*seg_aggregate)(const Params&, const double*, bool, hipStream_t);
-    int ex_size;  // ElemX
-    void (*seg_elements)(const Params&, hipStream_t);
-    void (*boundary_scan)(const Params&, const double*, bool, bool, hipStream_t);
-    void (*forward)(const Params&, const double*, bool, bool, hipStream_t);  // p.filter selects the filtering variant
-    void (*backward)(const Params&, const double*, bool, hipStream_t);
-    void (*forecast)(const PredictParams&, hipStream_t);
-    void (*predict)(const PredictParams&, hipStream_t);
-    void (*joint)(const PredictParams&, hipStream_t);
-    void (*stream_step)(const StreamParams&, hipStream_t);
-};
-
-static inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
+// The kernels templated on a dimension live in translation units of their own (launch_tables.hpp: tu_lgssm.hip per state dimension,
+// tu_dense.hip per MFMA tile count); this file reaches them through LgssmVtbl / DenseVtbl.
 
 // RXHIP_TRACE=1: stage timings of engine creation on stderr (measurement aid, off by default)
 #include <chrono>
@@ -85,145 +51,17 @@ struct StageTrace {
     }
 };
 
-template <int D, int DY>
-struct Launch {
-    using CL = CstLayout<D, DY>;
-    // `hc`: host copy of model 0's constant block, passed by value when all chains share it
-    static CstArg<CL::SIZE> carg(const double* hc) {
-        CstArg<CL::SIZE> a;
-        std::memcpy(a.v, hc, sizeof(double) * CL::SIZE);
-        return a;
-    }
-    static void seg_aggregate(const Params& p, const double* hc, bool uni, hipStream_t s) {
-        const long long total = p.n_chains * (long long)p.S;
-        // shared-model batches only (filtering runs, small smoothing runs); per-chain models compute their elements in the lane
-        if (uni) hipLaunchKernelGGL((k_seg_aggregate<D, DY, true>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
-    }
-    static void seg_elements(const Params& p, hipStream_t s) {
-        hipLaunchKernelGGL((k_seg_elements<D, DY>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
-    }
-    static void boundary_scan(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
-        dim3 grid(nblk(p.n_chains, 64), p.filter ? 1 : 2);  // a filtering run needs the prefix role only
-        if (uni) {
-            if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));
-            else hipLaunchKernelGGL((k_boundary_scan<D, DY, true, false>), grid, dim3(64), 0, s, p, carg(hc));
-        } else {
-            if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, false, true>), grid, dim3(64), 0, s, p, CstArg<1>{});
-            else hipLaunchKernelGGL((k_boundary_scan<D, DY, false, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
-        }
-    }
-    static void boundary_scan_tab(const Params& p, const double* hc, bool fe, hipStream_t s) {
-        dim3 grid(nblk(p.n_chains, 64), p.filter ? 1 : 2);
-        if (fe) hipLaunchKernelGGL((k_boundary_scan_tab<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
-        else hipLaunchKernelGGL((k_boundary_scan_tab<D, DY, false>), grid, dim3(64), 0, s, p, carg(hc));
-    }
-    template <bool FILT>
-    static void forward_t(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
-        const long long total = p.n_chains * (long long)p.S;
-        dim3 grid(nblk(total, 64));
-        if (uni) {
-            if (fe) hipLaunchKernelGGL((k_forward<D, DY, true, true, FILT>), grid, dim3(64), 0, s, p, carg(hc));
-            else hipLaunchKernelGGL((k_forward<D, DY, true, false, FILT>), grid, dim3(64), 0, s, p, carg(hc));
-        } else {
-            if (fe) hipLaunchKernelGGL((k_forward<D, DY, false, true, FILT>), grid, dim3(64), 0, s, p, CstArg<1>{});
-            else hipLaunchKernelGGL((k_forward<D, DY, false, false, FILT>), grid, dim3(64), 0, s, p, CstArg<1>{});
-        }
-    }
-    static void forward(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
-        if (p.filter) forward_t<true>(p, hc, uni, fe, s);
-        else forward_t<false>(p, hc, uni, fe, s);
-    }
-    static void backward(const Params& p, const double* hc, bool uni, hipStream_t s) {
-        const long long total = p.n_chains * (long long)p.S;
-        dim3 grid(nblk(total, 64));
-        if (uni && p.ntab) hipLaunchKernelGGL((k_backward<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));  // one-pass run
-        else if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
-        else hipLaunchKernelGGL((k_backward<D, DY, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
-    }
-    static void forward0(const Params& p, const double* hc, bool fe, hipStream_t s) {
-        const long long total = p.n_chains * (long long)p.S;
-        if (fe) hipLaunchKernelGGL((k_forward0<D, DY, true>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
-        else hipLaunchKernelGGL((k_forward0<D, DY, false>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
-    }
-    static void time_tables(const TimeTabParams& q, hipStream_t s) {
-        hipLaunchKernelGGL((k_time_tables<D>), dim3(nblk(q.T, 64)), dim3(64), 0, s, q);
-    }
-    static void fe_seg(const Params& p, hipStream_t s) {
-        hipLaunchKernelGGL((k_fe_seg<D>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
-    }
-    static void smooth_tables(const SmoothTabParams& q, const double* hc, hipStream_t s) {
-        const long long nblocks = (long long)q.S * smooth_blocks_per_segment(q.L);
-        if (q.T > 1) hipLaunchKernelGGL((k_smooth_tab_steps<D, DY>), dim3(nblk(q.T - 1, 64)), dim3(64), 0, s, q, carg(hc));
-        hipLaunchKernelGGL((k_smooth_tab_compose<D>), dim3(nblk(nblocks, 64)), dim3(64), 0, s, q);
-        hipLaunchKernelGGL((k_smooth_tab_chain<D>), dim3(nblk(q.S, 64)), dim3(64), 0, s, q);
-        hipLaunchKernelGGL((k_smooth_tab_apply<D>), dim3(nblk(nblocks, 64)), dim3(64), 0, s, q);
-    }
-    static void backward_sh(const Params& p, const double* gtab, const double* segend, hipStream_t s) {
-        hipLaunchKernelGGL((k_backward_sh<D>), dim3((unsigned)(p.n_chains / 64 * p.S)), dim3(64), 0, s, p, gtab, segend);
-    }
-    static void forecast(const PredictParams& p, hipStream_t s) {
-        hipLaunchKernelGGL((k_forecast<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
-    }
-    static void predict(const PredictParams& p, hipStream_t s) {
-        const long long total = (p.T + p.H) * p.n_chains;
-        const long long nb = (total + 255) / 256;
-        hipLaunchKernelGGL((k_predict<D, DY>), dim3((unsigned)(nb < 8192 ? nb : 8192)), dim3(256), 0, s, p);
-    }
-    static void joint(const PredictParams& p, hipStream_t s) {
-        const long long nb = ((p.T - 1) * p.n_chains + 255) / 256;
-        hipLaunchKernelGGL((k_joint<D, DY>), dim3((unsigned)(nb < 8192 ? (nb > 0 ? nb : 1) : 8192)), dim3(256), 0, s, p);
-    }
-    static void stream_step(const StreamParams& p, hipStream_t s) {
-        hipLaunchKernelGGL((k_stream_step<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
-    }
-    static LgssmVtbl vtbl() {
-        using TL = TabLayout<D, DY>;
-        using AL = AggLayout<D>;
-        LgssmVtbl v;
-        v.d = D; v.dy = DY;
-        v.cst_size = CL::SIZE; v.tab_size = TL::SIZE; v.agg_size = AL::SIZE;
-        v.oA = CL::A; v.oP = CL::P; v.oLOBS = CL::LOBS; v.oG = CL::G; v.oQI = CL::QI; v.oC0 = CL::C0;
-        v.oM1 = CL::M1; v.oV1 = CL::V1; v.oHF = CL::HF;
-        v.tK = TL::K; v.tU = TL::U;
-        v.aPI = AL::PI; v.aC = AL::C; v.aJ = AL::J; v.aCI = AL::CI; v.aX = AL::X; v.aJJ = AL::JJ;
-        using SL = ScanLayout<D>;
-        v.scan_size = SL::SIZE; v.sM1 = SL::M1; v.sM2 = SL::M2; v.sVB = SL::VB; v.sN1 = SL::N1; v.sN2 = SL::N2; v.sLB = SL::LB;
-        using FL = F0Layout<D, DY>;
-        using PL = PosLayout<D>;
-        using FS = FeSegLayout<D>;
-        v.f0_size = FL::SIZE; v.fK = FL::K; v.fU = FL::U; v.fSI = FL::SI;
-        v.pos_size = PL::SIZE; v.pPI = PL::PI; v.pJ = PL::J; v.pC = PL::C;
-        v.fs_size = FS::SIZE; v.fsA1 = FS::A1; v.fsA2 = FS::A2; v.fsW = FS::W; v.mt_row = TimeTab<D>::MT;
-        v.forward0 = &Launch::forward0;
-        v.time_tables = &Launch::time_tables;
-        v.fe_seg = &Launch::fe_seg;
-        v.gt_row = SmoothTab<D>::SIZE; v.se_size = SegEndTab<D>::SIZE;
-        v.smooth_tables = &Launch::smooth_tables;
-        v.backward_sh = &Launch::backward_sh;
-        v.boundary_scan_tab = &Launch::boundary_scan_tab;
-        v.seg_aggregate = &Launch::seg_aggregate;
-        v.ex_size = ElemX<D>::SIZE;
-        v.seg_elements = &Launch::seg_elements;
-        v.boundary_scan = &Launch::boundary_scan;
-        v.forward = &Launch::forward;
-        v.backward = &Launch::backward;
-        v.forecast = &Launch::forecast;
-        v.predict = &Launch::predict;
-        v.joint = &Launch::joint;
-        v.stream_step = &Launch::stream_step;
-        return v;
-    }
-};
-
 static const std::vector<LgssmVtbl>& vtbls() {
-    static const std::vector<LgssmVtbl> t = {
-        // every state dimension 1..4 with every observation dimension 1..4 (the reference is dimension-generic; d = 5..15
-        // has no schedule yet, d = 16..64 in steps of 16 takes the MFMA path with any dy ≤ 64)
-        Launch<1, 1>::vtbl(), Launch<1, 2>::vtbl(), Launch<1, 3>::vtbl(), Launch<1, 4>::vtbl(),
-        Launch<2, 1>::vtbl(), Launch<2, 2>::vtbl(), Launch<2, 3>::vtbl(), Launch<2, 4>::vtbl(),
-        Launch<3, 1>::vtbl(), Launch<3, 2>::vtbl(), Launch<3, 3>::vtbl(), Launch<3, 4>::vtbl(),
-        Launch<4, 1>::vtbl(), Launch<4, 2>::vtbl(), Launch<4, 3>::vtbl(), Launch<4, 4>::vtbl(),
-    };
+    // every state dimension 1..4 with every observation dimension 1..4 (the reference is dimension-generic; d = 5 … 64 takes the MFMA
+    // path with any dy ≤ 64).  Filling the tables launches nothing: a unit's code object is loaded with its first kernel.
+    static const std::vector<LgssmVtbl> t = [] {
+        std::vector<LgssmVtbl> v(16);
+        lgssm_vtbls_d1(&v[0]);
+        lgssm_vtbls_d2(&v[4]);
+        lgssm_vtbls_d3(&v[8]);
+        lgssm_vtbls_d4(&v[12]);
+        return v;
+    }();
     return t;
 }
 static const LgssmVtbl* find_vtbl(int d, int dy) {
@@ -566,6 +404,18 @@ static void once_per_device(int group, int device, F set) {
         set();
         (void)hipGetLastError();
     }
+}
+// the same for a preparation that can fail (the dynamic-LDS ceilings of a kernel unit): remembered only once it has succeeded
+template <class F>
+static hipError_t once_per_device_checked(int group, int device, F set) {
+    static std::mutex m;
+    static std::set<std::pair<int, int>> done;
+    std::lock_guard<std::mutex> g(m);
+    if (done.count({group, device})) return hipSuccess;
+    const hipError_t err = set();
+    if (err == hipSuccess) done.insert({group, device});
+    else (void)hipGetLastError();
+    return err;
 }
 
 // ---- per-model device tables of the MFMA path, shared between engines ---------------------------------------------
@@ -1087,130 +937,24 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
 static bool dense_supported(int d, int dy) { return d >= 1 && d <= 64 && dy >= 1 && dy <= 64; }
 static int dense_pad(int d) { return (d + 15) / 16 * 16; }
 
-template <int NT>
-struct DenseLaunch {
-    static size_t lds_bytes(int d, int dy) { return DenseLds<NT>::bytes(((d > dy ? d : dy) + 1) & ~1); }
-    // The dynamic-LDS ceiling is a per-FUNCTION attribute shared by every engine of the process: it is raised to the
-    // hardware limit once, never to one engine's need (a later, smaller engine would otherwise lower it under a live one).
-    static hipError_t prepare() {
-        const int bytes = 160 * 1024;
-        hipError_t e;
-        for (const void* f : {(const void*)kd_agg_finish<NT>, (const void*)kd_scan_local<NT, true>, (const void*)kd_scan_local<NT, false>,
-                              (const void*)kd_scan_fix<NT>, (const void*)kd_prepare_bnd<NT>, (const void*)kd_forward<NT, true>, (const void*)kd_forward<NT, false>,
-                              (const void*)kd_forward_info<NT, true>, (const void*)kd_forward_info<NT, false>,
-                              (const void*)kd_forward_info<NT, true, true>, (const void*)kd_forward_info<NT, false, true>,
-                              (const void*)kd_backward_info<NT, true>, (const void*)kd_backward_info<NT, false>, (const void*)kd_fe_resid,
-                              (const void*)kd_fe_resid_mfma<NT>})
-            if ((e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes))) return e;
-        return hipSuccess;
+static const DenseVtbl* dense_vt(int nt) {
+    switch (nt) {
+        case 1: return dense_vtbl_nt1();
+        case 2: return dense_vtbl_nt2();
+        case 3: return dense_vtbl_nt3();
+        default: return dense_vtbl_nt4();
     }
-    // one launch per slice of at most 32 768 workgroup chains (grid.y / grid.z hold 65 535 blocks)
-    template <class F>
-    static void slices(const DenseParams& p, long long chains, F launch) {
-        for (long long c0 = 0; c0 < chains; c0 += 32768) {
-            DenseParams q = p;
-            q.chain0 = p.chain0 + c0;
-            launch(q, (unsigned)(chains - c0 < 32768 ? chains - c0 : 32768));
-        }
-    }
-    static void prepare_bnd(const DenseParams& p, hipStream_t s) {
-        hipLaunchKernelGGL((kd_prepare_bnd<NT>), dim3(p.S), dim3(64 * NT), lds_bytes(p.d, p.dy), s, p);
-    }
-    static void seg_aggregate(const DenseParams& p, hipStream_t s) {
-        const unsigned sb = (unsigned)((p.S - 1 + 15) / 16 + 1);  // blocks of 16 full segments + the last segment on its own
-        slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
-            hipLaunchKernelGGL((kd_agg_gemm<NT>), dim3(sb, (unsigned)q.agg_kc, nc), dim3(64 * NT), 0, s, q);
-            hipLaunchKernelGGL((kd_agg_finish<NT>), dim3(q.S, nc), dim3(64 * NT), DenseLds<NT>::agg_bytes(q.dy), s, q);
-        });
-    }
-    static void boundary_scan(const DenseParams& p, bool fe, hipStream_t s) {
-        slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
-            dim3 g((q.filter ? 1 : 2) * q.ng, nc);  // filtering runs need the prefix direction only
-            dim3 g1(g.x + 1, nc);                   // + the workgroup of the t = 1 update
-            if (fe) hipLaunchKernelGGL((kd_scan_local<NT, true>), g1, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
-            else hipLaunchKernelGGL((kd_scan_local<NT, false>), g1, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
-            if (q.S > 1) hipLaunchKernelGGL((kd_scan_fix<NT>), g, dim3(64 * NT), lds_bytes(q.d, q.dy), s, q);
-        });
-    }
-    static void forward(const DenseParams& p, bool fe, hipStream_t s) {
-        slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
-            dim3 g(q.S, nc);
-            const size_t lds = DenseLds<NT>::fwd_bytes(((q.d > q.dy ? q.d : q.dy) + 1) & ~1);
-            if (fe) hipLaunchKernelGGL((kd_forward<NT, true>), g, dim3(64 * NT), lds, s, q);
-            else hipLaunchKernelGGL((kd_forward<NT, false>), g, dim3(64 * NT), lds, s, q);
-        });
-    }
-    // information-form smoother (one inverse per step; free energy at the smoothed means)
-    static void forward_info_stepm(const DenseParams& p, bool fe, hipStream_t s) {   // per-step constants (masked schedule)
-        slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
-            dim3 g(q.S, nc);
-            const size_t lds = DenseLds<NT>::fwd_info_bytes(((q.d > q.dy ? q.d : q.dy) + 1) & ~1);
-            if (fe) hipLaunchKernelGGL((kd_forward_info<NT, true, true>), g, dim3(64 * NT), lds, s, q);
-            else hipLaunchKernelGGL((kd_forward_info<NT, false, true>), g, dim3(64 * NT), lds, s, q);
-        });
-    }
-    static void forward_info(const DenseParams& p, bool fe, hipStream_t s, long long chains = -1) {
-        const size_t lds = DenseLds<NT>::fwd_info_bytes(((p.d > p.dy ? p.d : p.dy) + 1) & ~1);
-        slices(p, chains < 0 ? p.n_chains : chains, [&](const DenseParams& q, unsigned nc) {
-            dim3 g(q.S, nc);
-            if (fe) hipLaunchKernelGGL((kd_forward_info<NT, true>), g, dim3(64 * NT), lds, s, q);
-            else hipLaunchKernelGGL((kd_forward_info<NT, false>), g, dim3(64 * NT), lds, s, q);
-        });
-    }
-    static void backward_info(const DenseParams& p, bool fe, hipStream_t s, long long chains = -1) {
-        const size_t lds = DenseLds<NT>::bwd_info_bytes(((p.d > p.dy ? p.d : p.dy) + 1) & ~1);
-        slices(p, chains < 0 ? p.n_chains : chains, [&](const DenseParams& q, unsigned nc) {
-            dim3 g(q.S, nc);
-            if (fe) hipLaunchKernelGGL((kd_backward_info<NT, true>), g, dim3(64 * NT), lds, s, q);
-            else hipLaunchKernelGGL((kd_backward_info<NT, false>), g, dim3(64 * NT), lds, s, q);
-        });
-    }
-};
+}
 // free-energy residual terms of an information-form smoothing run: one workgroup per FR_STEPS steps, partial slots 2S…
 static int fe_resid_blocks(long long T, int d, int dy) { const int st = fe_resid_steps(d, dy); return (int)((T + st - 1) / st); }
-constexpr int FE_RESID_MAX_PASSES = 8;
 static long long mseg_resid_slots(long long T, int d, int dy, bool stepm, int models);
 // passes > 1: per-step constants — one launch per model, each with its own partial slots, the columns of the other models masked
 static long long mseg_resid_slots(long long T, int d, int dy, bool stepm, int models) {   // partial slots the residual kernel(s) write per chain
     if (stepm && models > FE_RESID_MAX_PASSES) return (T + FE_STEPS_BLOCK - 1) / FE_STEPS_BLOCK;
     return (long long)(stepm ? models : 1) * fe_resid_blocks(T, d, dy);
 }
-static void launch_fe_resid(const DenseParams& p, hipStream_t s, int passes = 1) {
-    static const bool valu_env = std::getenv("RXHIP_FE_RESID_VALU") != nullptr;  // the round-2 form (vector FMAs), kept as a cross-check
-    const bool valu = valu_env && !p.step_model;
-    if (p.step_model && passes > FE_RESID_MAX_PASSES) {   // many models: one step per wavefront instead of one launch per model
-        for (long long c0 = 0; c0 < p.n_chains; c0 += 32768) {
-            DenseParams q = p;
-            q.chain0 = c0;
-            const unsigned nc = (unsigned)(p.n_chains - c0 < 32768 ? p.n_chains - c0 : 32768);
-            hipLaunchKernelGGL(kd_fe_resid_steps, dim3((unsigned)((p.T + FE_STEPS_BLOCK - 1) / FE_STEPS_BLOCK), nc), dim3(256), 0, s, q, 2 * p.S);
-        }
-        return;
-    }
-    for (int pass = 0; pass < passes; ++pass)
-    for (long long c0 = 0; c0 < p.n_chains; c0 += 32768) {  // grid.y holds 65 535 blocks
-        DenseParams q = p;
-        q.chain0 = c0;
-        q.model_sel = pass;
-        const unsigned nc = (unsigned)(p.n_chains - c0 < 32768 ? p.n_chains - c0 : 32768);
-        const dim3 g(fe_resid_blocks(p.T, p.d, p.dy), nc);
-        const int slot0 = 2 * p.S + pass * (int)g.x;
-        if (valu) { hipLaunchKernelGGL(kd_fe_resid, g, dim3(256), fe_resid_lds_bytes(p.d, p.dy), s, q, slot0); continue; }
-        switch (p.d / 16) {
-            case 1: hipLaunchKernelGGL(kd_fe_resid_mfma<1>, g, dim3(256), fe_resid_mfma_lds_bytes<1>(p.dy), s, q, slot0); break;
-            case 2: hipLaunchKernelGGL(kd_fe_resid_mfma<2>, g, dim3(256), fe_resid_mfma_lds_bytes<2>(p.dy), s, q, slot0); break;
-            case 3: hipLaunchKernelGGL(kd_fe_resid_mfma<3>, g, dim3(256), fe_resid_mfma_lds_bytes<3>(p.dy), s, q, slot0); break;
-            default: hipLaunchKernelGGL(kd_fe_resid_mfma<4>, g, dim3(256), fe_resid_mfma_lds_bytes<4>(p.dy), s, q, slot0); break;
-        }
-    }
-}
-#define DENSE_DISPATCH(nt, CALL)                    \
-    switch (nt) {                                   \
-        case 1: DenseLaunch<1>::CALL; break;        \
-        case 2: DenseLaunch<2>::CALL; break;        \
-        case 3: DenseLaunch<3>::CALL; break;        \
-        default: DenseLaunch<4>::CALL; break;       \
-    }
+static void launch_fe_resid(const DenseParams& p, hipStream_t s, int passes = 1) { dense_vt(p.d / 16)->fe_resid(p, s, passes); }
+#define DENSE_DISPATCH(nt, CALL) dense_vt(nt)->CALL
 static int dense_tri(int nt) { return nt * (nt + 1) / 2 * 256; }
 static int dense_rec(int nt) { return 3 * 16 * nt + 2 * 256 * nt * nt; }  // DenseCfg<NT>::REC
 
@@ -1227,26 +971,6 @@ static void dense_schedule_ints(rxhip_engine* e) {
     e->scan_ng = n > 0 ? (n + sg - 1) / sg : 1;
 }
 
-// The per-model tables built on the device (dense_tab_kernels.hpp): the host pads the model (copies only) and launches six small
-// kernels; nothing is uploaded but 6 d×d matrices.  `blk` is the DenseTables block with its regions already carved.
-template <int NT>
-static hipError_t launch_dense_tab(const TabParams& tp, hipStream_t s) {
-    constexpr int D = 16 * NT;
-    const size_t lds = sizeof(double) * (size_t)(blk_scratch_doubles(NT) + 2 * 64 * NT + 16);
-    const size_t lds_c = lds + sizeof(double) * (size_t)D * (D + 1);
-    hipError_t err;
-    for (const void* f : {(const void*)kt_consts<NT>, (const void*)kt_gains<NT>, (const void*)kt_agg<NT>, (const void*)kt_scan<NT>, (const void*)kt_qtab<NT>})
-        if ((err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return err;
-    hipLaunchKernelGGL((kt_consts<NT>), dim3(1), dim3(64 * NT), lds_c, s, tp);
-    if (tp.S > 0) {
-        hipLaunchKernelGGL((kt_gains<NT>), dim3(1), dim3(64 * NT), lds, s, tp);
-        hipLaunchKernelGGL((kt_agg<NT>), dim3(2), dim3(64 * NT), lds, s, tp);
-        hipLaunchKernelGGL((kt_scan<NT>), dim3(2), dim3(64 * NT), lds, s, tp);
-        hipLaunchKernelGGL(kt_qcanon, dim3(1), dim3(64), 0, s, tp);
-        if (tp.S > 1) hipLaunchKernelGGL((kt_qtab<NT>), dim3((unsigned)tp.ng, 2), dim3(64 * NT), lds, s, tp);
-    }
-    return hipGetLastError();
-}
 static bool dense_tab_on_device(const rxhip_engine* e) {
     // d ≥ 32: below, the host recursions take well under a millisecond (and a 16×16 model padded into these kernels would not be faster)
     return e->nt >= 2 && e->dyk <= e->dpad && !std::getenv("RXHIP_HOST_TABLES");
@@ -1258,14 +982,6 @@ static bool dense_tab_on_device(const rxhip_engine* e) {
 // kernels); smoothing runs take the time-parallel schedule unless RXHIP_GSEQ is set (the sequential schedule as the checker).
 static rxhip_status prof_begin(rxhip_engine* e, int k);
 static rxhip_status prof_end(rxhip_engine* e);
-template <int NT>
-static hipError_t mseg_prepare_kernels() {
-    hipError_t err;
-    for (const void* f : {(const void*)km_elements<NT>, (const void*)km_scan<NT>, (const void*)km_group<NT>, (const void*)km_compose<NT>, (const void*)km_apply<NT>, (const void*)km_fold<NT>, (const void*)km_inner<NT>, (const void*)km_bnd<NT>, (const void*)km_filter_out<NT>,
-                          (const void*)kt_consts<NT>})
-        if ((err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return err;
-    return DenseLaunch<NT>::prepare();
-}
 static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     // one model, or per-step constants shared by all chains (desc.step_model: the transition into step t and the observation at t use the
     // constants of model step_model[t]) — with or without `missing` values; per-chain models keep the sequential schedule
@@ -1415,24 +1131,13 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     HIPCHK(e, hipMemsetAsync(e->d_filt, 0, sizeof(double) * parts[10], e->stream));
     hipError_t herr = hipSuccess;
     const size_t lds_c = sizeof(double) * (size_t)(blk_scratch_doubles(e->m_nt) + 2 * 64 * e->m_nt + 16 + D * (D + 1));
-    switch (e->m_nt) {
-        case 1: herr = mseg_prepare_kernels<1>(); break;
-        case 2: herr = mseg_prepare_kernels<2>(); break;
-        case 3: herr = mseg_prepare_kernels<3>(); break;
-        default: herr = mseg_prepare_kernels<4>(); break;
-    }
+    { const int nt_prep = e->m_nt; herr = once_per_device_checked(120 + nt_prep, e->device, [nt_prep] { return dense_vt(nt_prep)->mseg_prepare(); }); }
     if (!herr) {   // one workgroup per model
         TabParams tp{};
         tp.d = (int)D; tp.dy = e->dy; tp.ptt = e->ptt; tp.T = e->T; tp.L = 1; tp.Llast = 1; tp.S = 0; tp.sg = 1; tp.ng = 1;
         tp.in = e->m_in; tp.ws = e->m_cw; tp.cst = e->m_cst; tp.status = e->d_status;
         tp.in_stride = (long long)IN1; tp.ws_stride = (long long)CW1; tp.cst_stride = cl.size;
-        const dim3 gm((unsigned)NM);
-        switch (e->m_nt) {
-            case 1: hipLaunchKernelGGL((kt_consts<1>), gm, dim3(64), lds_c, e->stream, tp); break;
-            case 2: hipLaunchKernelGGL((kt_consts<2>), gm, dim3(128), lds_c, e->stream, tp); break;
-            case 3: hipLaunchKernelGGL((kt_consts<3>), gm, dim3(192), lds_c, e->stream, tp); break;
-            default: hipLaunchKernelGGL((kt_consts<4>), gm, dim3(256), lds_c, e->stream, tp); break;
-        }
+        dense_vt(e->m_nt)->tab_consts(tp, (unsigned)NM, lds_c, e->stream);
     }
     std::vector<DenseModel> hmod(NM);
     for (size_t m = 0; m < NM; ++m) hmod[m] = DenseModel{e->m_cst + m * (size_t)cl.size, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -1442,40 +1147,6 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     HIPCHK(e, hipStreamSynchronize(e->stream));   // hin dies here
     e->mseg = true;
     return RXHIP_OK;
-}
-template <int NT>
-static void mseg_launch(rxhip_engine* e, const MsegParams& mp, const DenseParams& dp, bool fe, bool filter) {
-    const size_t lds = sizeof(double) * (size_t)mseg_lds_doubles(NT, false), lds_s = sizeof(double) * (size_t)mseg_lds_doubles(NT, true);
-    hipStream_t s = e->stream;
-    (void)hipMemsetAsync(mp.nobs, 0, sizeof(double) * (size_t)mp.n_chains, s);
-    hipLaunchKernelGGL(km_mask, dim3((unsigned)std::min<long long>(mp.n_chains >= 64 ? 16 : 256, (mp.T + 15) / 16), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
-    if (mp.S == 1) hipLaunchKernelGGL(km_gy, dim3((unsigned)(((mp.T - 1) * mp.d + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
-    else hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds_s, s, mp);
-    if (mp.hs) {       // log-depth: all prefix / suffix compositions in ⌈log₂ S⌉ rounds, then every boundary state at once
-        const dim3 g1((unsigned)mp.hs_n, (unsigned)mp.n_chains), g2(2 * (unsigned)mp.hs_n, (unsigned)mp.n_chains);
-        if (mp.hs_g > 1) hipLaunchKernelGGL((km_fold<NT>), g1, dim3(64 * NT), lds_s, s, mp);
-        for (int r = 0; r < mp.hs_rounds; ++r) hipLaunchKernelGGL((km_compose<NT>), g2, dim3(64 * NT), lds_s, s, mp, r);
-        hipLaunchKernelGGL((km_apply<NT>), g2, dim3(64 * NT), lds_s, s, mp);
-        if (mp.hs_g > 1) hipLaunchKernelGGL((km_inner<NT>), g2, dim3(64 * NT), lds_s, s, mp);
-    } else if (mp.ng > 0) {   // two levels: group elements, the states at the group edges, then every group on its own
-        hipLaunchKernelGGL((km_group<NT>), dim3((unsigned)mp.ng, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
-        hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 2);
-        hipLaunchKernelGGL((km_scan<NT>), dim3(2 * (unsigned)mp.ng, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 3);
-    } else
-        hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 0);
-    if (mp.S > 1) hipLaunchKernelGGL((km_bnd<NT>), dim3((unsigned)(mp.S - 1), (unsigned)mp.n_chains), dim3(64 * NT), sizeof(double) * blk_scratch_doubles(NT), s, mp);
-    if (mp.step_model) {
-        if (fe) hipLaunchKernelGGL(km_feconst, dim3((unsigned)mp.n_chains), dim3(256), 0, s, mp);
-        DenseLaunch<NT>::forward_info_stepm(dp, fe, s);
-    } else
-        DenseLaunch<NT>::forward_info(dp, fe, s);
-    if (!filter || fe) DenseLaunch<NT>::backward_info(dp, fe, s);   // a filtering run needs the backward sweep for its free energy only
-
-}
-template <int NT>
-static void mseg_filter_out(rxhip_engine* e, const MsegParams& mp, const DenseParams& dp) {
-    const size_t ldf = sizeof(double) * (size_t)(DenseCfg<NT>::MAT + 5 * 16 * NT + blk_scratch_doubles(NT) + 16);
-    hipLaunchKernelGGL((km_filter_out<NT>), dim3((unsigned)mp.T, (unsigned)mp.n_chains), dim3(64 * NT), ldf, e->stream, mp, dp);
 }
 static rxhip_status mseg_run(rxhip_engine* e, bool fe, bool filter) {
     MsegParams mp{};
@@ -1500,21 +1171,11 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe, bool filter) {
     if (e->m_chainm) { dp.models = e->m_modtab; dp.chain_model = e->d_chain_model; }   // the sweep kernels' own per-chain lookup (dense_model)
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
-    switch (e->m_nt) {
-        case 1: mseg_launch<1>(e, mp, dp, fe, filter); break;
-        case 2: mseg_launch<2>(e, mp, dp, fe, filter); break;
-        case 3: mseg_launch<3>(e, mp, dp, fe, filter); break;
-        default: mseg_launch<4>(e, mp, dp, fe, filter); break;
-    }
+    dense_vt(e->m_nt)->mseg_sweep(mp, dp, fe, filter, e->stream);
     if ((st = prof_end(e))) return st;
     if (fe) launch_fe_resid(dp, e->stream, e->m_stepm ? e->m_models : 1);
     if (filter) {   // q(x_t | y_1..t) from the forward records — after the residual forms have read the smoothed means
-        switch (e->m_nt) {
-            case 1: mseg_filter_out<1>(e, mp, dp); break;
-            case 2: mseg_filter_out<2>(e, mp, dp); break;
-            case 3: mseg_filter_out<3>(e, mp, dp); break;
-            default: mseg_filter_out<4>(e, mp, dp); break;
-        }
+        dense_vt(e->m_nt)->mseg_filter_out(mp, dp, e->stream);
     }
     return RXHIP_OK;
 }
@@ -2300,7 +1961,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     if (dense) {
         StageTrace tr(e->stage_ms);
         hipError_t herr = hipSuccess;
-        DENSE_DISPATCH(e->nt, prepare() == hipSuccess ? (void)0 : (void)(herr = hipErrorInvalidValue));
+        { const int nt_prep = e->nt; herr = once_per_device_checked(100 + nt_prep, e->device, [nt_prep] { return dense_vt(nt_prep)->prepare(); }); }
         if (herr != hipSuccess) return fail(e, RXHIP_ERR_HIP, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
         const size_t C = (size_t)e->wg_chains, CU = (size_t)e->n_chains, T = (size_t)e->T, Sg = (size_t)(e->S > 0 ? e->S : 1),
                      D = (size_t)e->dpad, Du = (size_t)e->d;
@@ -2407,11 +2068,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
                     tp.in = (const double*)tab_ws.p; tp.ws = (double*)tab_ws.p + nin; tp.cst = dt->d_cst; tp.tab = dt->d_tab; tp.scanm = dt->d_scanm;
                     tp.qtab = dt->d_qtab; tp.canon = dt->d_canon; tp.status = (int*)tab_status.p;
                     if (up == hipSuccess) {
-                        switch (e->nt) {
-                            case 2: up = launch_dense_tab<2>(tp, e->stream); break;
-                            case 3: up = launch_dense_tab<3>(tp, e->stream); break;
-                            default: up = launch_dense_tab<4>(tp, e->stream); break;
-                        }
+                        { const int nt_prep = e->nt; up = once_per_device_checked(110 + nt_prep, e->device, [nt_prep] { return dense_vt(nt_prep)->tab_prepare(); }); }
+                        if (up == hipSuccess) up = dense_vt(e->nt)->tab_build(tp, e->stream);
                     }
                     int hst = 0;
                     if (up == hipSuccess) up = hipMemcpyAsync(&hst, tab_status.p, sizeof(int), hipMemcpyDeviceToHost, e->stream);
@@ -2508,11 +2166,8 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             e->split = e->n_models == 1 && e->S > 0 && (sp_env ? std::atoi(sp_env) != 0 : e->wg_chains >= 4);
         }
         if (e->split) {
-            once_per_device(1, e->device, [] {
-                for (const void* f : {(const void*)kd_split_forward_lds<48>, (const void*)kd_split_forward_lds<64>, (const void*)kd_split_backward_lds<48>,
-                                      (const void*)kd_split_backward_lds<64>})
-                    (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 144 * 1024);
-            });
+            const int nt_split = e->nt;
+            once_per_device(16 + nt_split, e->device, [nt_split] { (void)dense_vt(nt_split)->split_prepare(); });
             ap.plain(&e->d_dtab, sizeof(double) * T * 3 * D * D);
             ap.plain(&e->d_vlast, sizeof(double) * D * D);
             ap.plain(&e->d_vstab, sizeof(double) * T * Du * Du);
@@ -3528,20 +3183,10 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
                 const long long per_wg = 4 * (64 / e->dpad);  // chains of one segment per workgroup
                 const dim3 lds_grid((unsigned)((e->wg_chains + per_wg - 1) / per_wg), (unsigned)e->S);
-                switch (e->nt) {
-                    case 1: hipLaunchKernelGGL(kd_split_forward_lds<16>, lds_grid, dim3(256), split_lds_bytes(16, 2), e->stream, sq); break;
-                    case 2: hipLaunchKernelGGL(kd_split_forward_lds<32>, lds_grid, dim3(256), split_lds_bytes(32, 2), e->stream, sq); break;
-                    case 3: hipLaunchKernelGGL(kd_split_forward_lds<48>, lds_grid, dim3(256), split_lds_bytes(48, 2), e->stream, sq); break;
-                    default: hipLaunchKernelGGL(kd_split_forward_lds<64>, lds_grid, dim3(256), split_lds_bytes(64, 2), e->stream, sq); break;
-                }
+                dense_vt(e->nt)->split_forward(sq, lds_grid, e->stream);
                 if ((st = prof_end(e))) return st;
                 if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
-                switch (e->nt) {
-                    case 1: hipLaunchKernelGGL(kd_split_backward_lds<16>, lds_grid, dim3(256), split_lds_bytes(16, 1), e->stream, sq); break;
-                    case 2: hipLaunchKernelGGL(kd_split_backward_lds<32>, lds_grid, dim3(256), split_lds_bytes(32, 1), e->stream, sq); break;
-                    case 3: hipLaunchKernelGGL(kd_split_backward_lds<48>, lds_grid, dim3(256), split_lds_bytes(48, 1), e->stream, sq); break;
-                    default: hipLaunchKernelGGL(kd_split_backward_lds<64>, lds_grid, dim3(256), split_lds_bytes(64, 1), e->stream, sq); break;
-                }
+                dense_vt(e->nt)->split_backward(sq, lds_grid, e->stream);
                 // covariances: every sweep, or (mode 1) when somebody asks for them; the constant free-energy slots every sweep
                 const bool lazy = e->cov_mode == 1 && e->H == 0;
                 if (lazy && was_cov_current) e->cov_current = true;   // nothing in this schedule touches the array
@@ -3550,12 +3195,12 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 if ((st = prof_end(e))) return st;
             } else if (e->S > 0) {
                 if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
-                if (info) { DENSE_DISPATCH(e->nt, forward_info(dp, fe, e->stream)); }
+                if (info) { DENSE_DISPATCH(e->nt, forward_info(dp, fe, e->stream, -1)); }
                 else { DENSE_DISPATCH(e->nt, forward(dp, fe, e->stream)); }
                 if ((st = prof_end(e))) return st;
                 if (info) {
                     if ((st = prof_begin(e, RXHIP_K_BACKWARD))) return st;
-                    DENSE_DISPATCH(e->nt, backward_info(dp, fe, e->stream));
+                    DENSE_DISPATCH(e->nt, backward_info(dp, fe, e->stream, -1));
                     e->records_hold_gains = e->pack == 1;
                     if ((st = prof_end(e))) return st;
                 }
@@ -3902,12 +3547,7 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
             const int nt = e->mseg ? e->m_nt : e->nt;
             cp.T = e->T; cp.n_chains = e->n_chains; cp.d = 16 * nt; cp.d_out = e->d; cp.filt = e->d_filt; cp.cov = e->d_cov;
             const dim3 gr((unsigned)((e->T - 1) * e->n_chains));
-            switch (nt) {
-                case 1: hipLaunchKernelGGL(kd_cross_from_records<1>, gr, dim3(64), sizeof(double) * 2 * DenseCfg<1>::MAT, e->stream, cp, gq.cross); break;
-                case 2: hipLaunchKernelGGL(kd_cross_from_records<2>, gr, dim3(128), sizeof(double) * 2 * DenseCfg<2>::MAT, e->stream, cp, gq.cross); break;
-                case 3: hipLaunchKernelGGL(kd_cross_from_records<3>, gr, dim3(192), sizeof(double) * 2 * DenseCfg<3>::MAT, e->stream, cp, gq.cross); break;
-                default: hipLaunchKernelGGL(kd_cross_from_records<4>, gr, dim3(256), sizeof(double) * 2 * DenseCfg<4>::MAT, e->stream, cp, gq.cross); break;
-            }
+            dense_vt(nt)->cross_from_records(cp, gq.cross, gr, e->stream);
         } else {
         const size_t lds = gseq_lds_bytes(e->d, e->dy);
         hipLaunchKernelGGL(k_gseq_forward, dim3((unsigned)e->n_chains), dim3(256), lds, e->stream, gq);
