@@ -194,10 +194,41 @@ typedef struct {
 static __thread double* g_joint_mean = NULL; /* [T-1][2d]     */
 static __thread double* g_joint_cov = NULL;  /* [T-1][2d][2d] */
 
+/* The message stores of one chain (16 MB + 96 MB at d = 4, T = 10⁵).  rxo_lgssm_bp_batch keeps ONE set per thread for all the chains the
+   thread runs: with a fresh malloc per chain the all-core timing of bench.py's cpu_baseline was page faults and mmap-lock contention
+   (6.7× one core on 256 cores). */
+typedef struct { double *work, *big, *fwdp, *fwdx; } bp_ws;
+static void bp_ws_free(bp_ws* w) {
+    free(w->work); free(w->big); free(w->fwdp); free(w->fwdx);
+    memset(w, 0, sizeof *w);
+}
+static int bp_ws_reserve(bp_ws* w, int d, int dy, int T, int ptt, int want_fe) {
+    const size_t n = (size_t)T + (ptt ? 1 : 0), dm = (size_t)(d > dy ? d : dy), vs = (size_t)d, ms = (size_t)d * d;
+    memset(w, 0, sizeof *w);
+    w->work = (double*)malloc(sizeof(double) * (16 * dm * dm + 64));
+    w->big = (double*)malloc(sizeof(double) * (40 * dm * dm + 64));
+    w->fwdp = (double*)malloc(sizeof(double) * n * (vs + ms));
+    if (want_fe) w->fwdx = (double*)malloc(sizeof(double) * n * (vs + ms) * 6 + sizeof(double) * n);
+    if (!w->work || !w->big || !w->fwdp || (want_fe && !w->fwdx)) { bp_ws_free(w); return RXO_ERR_BADARG; }
+    return RXO_OK;
+}
+static int lgssm_bp_ws(int d, int dy, int T, const double* A, const double* B, const double* P, const double* Q,
+                       const double* m0, const double* V0, int ptt, const double* y, double* post_mean,
+                       double* post_cov, double* free_energy, rxo_counters* counters, bp_ws* ws);
 int rxo_lgssm_bp(int d, int dy, int T, const double* A, const double* B, const double* P, const double* Q,
                  const double* m0, const double* V0, int ptt, const double* y, double* post_mean,
                  double* post_cov, double* free_energy, rxo_counters* counters) {
     if (d <= 0 || dy <= 0 || T <= 0) return RXO_ERR_BADARG;
+    bp_ws ws;
+    int rc = bp_ws_reserve(&ws, d, dy, T, ptt, free_energy != NULL);
+    if (rc) return rc;
+    rc = lgssm_bp_ws(d, dy, T, A, B, P, Q, m0, V0, ptt, y, post_mean, post_cov, free_energy, counters, &ws);
+    bp_ws_free(&ws);
+    return rc;
+}
+static int lgssm_bp_ws(int d, int dy, int T, const double* A, const double* B, const double* P, const double* Q,
+                       const double* m0, const double* V0, int ptt, const double* y, double* post_mean,
+                       double* post_cov, double* free_energy, rxo_counters* counters, bp_ws* ws) {
     const int n = T + (ptt ? 1 : 0); /* number of state variables; state k observes y[k-ptt] */
     const int want_fe = free_energy != NULL;
     const int dm = d > dy ? d : dy;
@@ -207,16 +238,16 @@ int rxo_lgssm_bp(int d, int dy, int T, const double* A, const double* B, const d
     ctx c;
     memset(&c, 0, sizeof c);
     c.count = 1;
-    c.work = (double*)malloc(sizeof(double) * (size_t)(16 * dm * dm + 64));
-    double* big = (double*)malloc(sizeof(double) * (size_t)(40 * dm * dm + 64));
+    c.work = ws->work;
+    double* big = ws->big;
 
     /* stored messages */
-    double* fwdp_x = (double*)malloc(sizeof(double) * n * (vs + ms)); /* (fwd ⊗ obs) as WMP */
+    double* fwdp_x = ws->fwdp; /* (fwd ⊗ obs) as WMP */
     double* fwdp_L = fwdp_x + n * vs;
     double *fwdx_m = NULL, *fwdx_V = NULL, *amsg_m = NULL, *amsg_V = NULL, *tox_x = NULL, *tox_L = NULL,
            *mum_m = NULL, *mum_V = NULL, *bwd_x = NULL, *bwd_L = NULL, *q_m = NULL, *q_V = NULL, *q_ld = NULL;
     if (want_fe) {
-        fwdx_m = (double*)malloc(sizeof(double) * n * (vs + ms) * 6 + sizeof(double) * n);
+        fwdx_m = ws->fwdx;
         fwdx_V = fwdx_m + n * vs;
         amsg_m = fwdx_V + n * ms;
         amsg_V = amsg_m + n * vs;
@@ -229,10 +260,6 @@ int rxo_lgssm_bp(int d, int dy, int T, const double* A, const double* B, const d
         q_m = bwd_L + n * ms;
         q_V = q_m + n * vs;
         q_ld = q_V + n * ms;
-    }
-    if (!c.work || !big || !fwdp_x || (want_fe && !fwdx_m)) {
-        rc = RXO_ERR_BADARG;
-        goto done;
     }
 
     /* scratch vectors / matrices (sized for max(d,dy)) */
@@ -505,11 +532,7 @@ int rxo_lgssm_bp(int d, int dy, int T, const double* A, const double* B, const d
         free(Wq);
     }
 
-done:
-    free(c.work);
-    free(big);
-    free(fwdp_x);
-    free(fwdx_m);
+done:   /* the message stores belong to the caller's workspace */
     return rc;
 }
 
@@ -536,24 +559,38 @@ int rxo_lgssm_bp_batch(int d, int dy, int T, int n_chains, const double* A, cons
     if (n_chains <= 0) return RXO_ERR_BADARG;
     int rc_all = RXO_OK;
     uint64_t rc_rules = 0, rc_prods = 0, rc_margs = 0;
-#ifdef _OPENMP
+    if (d <= 0 || dy <= 0 || T <= 0) return RXO_ERR_BADARG;
     if (nthreads < 1) nthreads = 1;
-#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1) reduction(+ : rc_rules, rc_prods, rc_margs)
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads) reduction(+ : rc_rules, rc_prods, rc_margs)
+#endif
+    {
+    /* one workspace and one set of chain-major staging buffers per thread, reused for every chain the thread runs */
+    bp_ws ws;
+    int rc_ws = bp_ws_reserve(&ws, d, dy, T, ptt, fe != NULL);
+    double* yc = (double*)malloc(sizeof(double) * (size_t)T * dy);
+    double* pm = (double*)malloc(sizeof(double) * (size_t)T * d);
+    double* pc = (double*)malloc(sizeof(double) * (size_t)T * d * d);
+    if (!yc || !pm || !pc) rc_ws = RXO_ERR_BADARG;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
 #endif
     for (int ch = 0; ch < n_chains; ++ch) {
-        double* yc = (double*)malloc(sizeof(double) * (size_t)T * dy);
-        double* pm = (double*)malloc(sizeof(double) * (size_t)T * d);
-        double* pc = (double*)malloc(sizeof(double) * (size_t)T * d * d);
-        for (int t = 0; t < T; ++t)
-            memcpy(yc + (size_t)t * dy, y + ((size_t)t * n_chains + ch) * dy, sizeof(double) * dy);
         rxo_counters cc;
+        memset(&cc, 0, sizeof cc);
         double f = 0.0;
-        int rc = rxo_lgssm_bp(d, dy, T, A, B, P, Q, m0, V0, ptt, yc, pm, pc, fe ? &f : NULL, &cc);
+        int rc = rc_ws;
+        if (!rc) {
+            for (int t = 0; t < T; ++t)
+                memcpy(yc + (size_t)t * dy, y + ((size_t)t * n_chains + ch) * dy, sizeof(double) * dy);
+            rc = lgssm_bp_ws(d, dy, T, A, B, P, Q, m0, V0, ptt, yc, pm, pc, fe ? &f : NULL, &cc, &ws);
+        }
         if (rc) {
 #ifdef _OPENMP
 #pragma omp critical
 #endif
             rc_all = rc;
+            continue;
         }
         for (int t = 0; t < T; ++t) {
             memcpy(post_mean + ((size_t)t * n_chains + ch) * d, pm + (size_t)t * d, sizeof(double) * d);
@@ -563,9 +600,11 @@ int rxo_lgssm_bp_batch(int d, int dy, int T, int n_chains, const double* A, cons
         rc_rules += cc.rule_calls;
         rc_prods += cc.products;
         rc_margs += cc.marginals;
-        free(yc);
-        free(pm);
-        free(pc);
+    }
+    free(yc);
+    free(pm);
+    free(pc);
+    if (!rc_ws) bp_ws_free(&ws);
     }
     if (counters) {
         counters->rule_calls = rc_rules;

@@ -2059,6 +2059,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
                     const size_t nin = hin.size(), nws = TabWs::doubles((int)D, e->L);
                     up = hipMalloc(&tab_ws.p, sizeof(double) * (nin + nws));
                     if (up == hipSuccess) up = hipMalloc(&tab_status.p, sizeof(int));
+                    tr.mark("dense: device tables: workspace hipMalloc", STAGE_TABLES_DEVICE);
                     if (up == hipSuccess) up = hipMemsetAsync(tab_status.p, 0, sizeof(int), e->stream);
                     if (up == hipSuccess) up = hipMemcpyAsync(tab_ws.p, hin.data(), sizeof(double) * nin, hipMemcpyHostToDevice, e->stream);
                     if (up == hipSuccess) up = hipMemsetAsync(dt->d_tab, 0, sizeof(double) * nb[1], e->stream);   // the padded k rows of the aggregation maps
@@ -2069,7 +2070,9 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
                     tp.qtab = dt->d_qtab; tp.canon = dt->d_canon; tp.status = (int*)tab_status.p;
                     if (up == hipSuccess) {
                         { const int nt_prep = e->nt; up = once_per_device_checked(110 + nt_prep, e->device, [nt_prep] { return dense_vt(nt_prep)->tab_prepare(); }); }
+                        tr.mark("dense: device tables: memsets + upload + kernel attributes", STAGE_TABLES_DEVICE);
                         if (up == hipSuccess) up = dense_vt(e->nt)->tab_build(tp, e->stream);
+                        tr.mark("dense: device tables: enqueue", STAGE_TABLES_DEVICE);
                     }
                     int hst = 0;
                     if (up == hipSuccess) up = hipMemcpyAsync(&hst, tab_status.p, sizeof(int), hipMemcpyDeviceToHost, e->stream);

@@ -1,0 +1,126 @@
+"""bench.py's own main() at world size 2 over `gloo`, with a stub engine in place of the HIP engine (no GPU here).
+
+What is under test is the host logic of the bench line that a 1-GPU box never reaches: which chains a rank draws (chain c of the job from
+default_rng(42 + c)), weak / strong sharding of --chains, the free-energy exchange (all-gather + sum in rank order), the max-over-ranks
+timing and the whole-job `value`.  The stub engine computes nothing: its "free energy" is the sum of the observations it was handed, so
+the global value pins both the shard every rank generated and the exchange."""
+import ctypes
+import json
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class StubEngine:
+    """The subset of rxhip.LGSSMEngine that bench.main() drives.  free energy := Σ y of the shard (a checksum of the data it was given)."""
+
+    def __init__(self, A, B, P, Q, m0, V0, T, n_chains, segments=0, device=0, stream=None):
+        self.T, self.C, self.fe, self.runs = int(T), int(n_chains), 0.0, 0
+
+    def close(self):
+        pass
+
+    def model_tables_ms(self):
+        return 0.0
+
+    def set_data_device(self, ptr, n, keepalive=None):
+        assert n == self.T * self.C * 4
+        self._y = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double)), shape=(n,))
+
+    def run_async(self, iterations=1, free_energy=True):
+        self.fe = float(np.sum(self._y))
+        self.runs += 1
+
+    def copy_free_energy_to_device(self, ptr):
+        ctypes.cast(ptr, ctypes.POINTER(ctypes.c_double))[0] = self.fe
+
+    def sync(self):
+        pass
+
+    def set_profiling(self, on):
+        pass
+
+    def reset_kernel_times(self):
+        pass
+
+    def kernel_times(self):
+        return {"k_backward": {"ms_avg": 1.0, "launches": self.runs}}
+
+    def counters(self):
+        return {"rule_calls": (6 * self.T - 3) * self.C}
+
+    def free_energy(self):
+        return np.array([self.fe])
+
+    def schedule(self):
+        return {"segments": 1, "segment_len": self.T}
+
+    def create_stages(self):
+        return {}
+
+
+def _worker(rank, world, port, out_dir, scaling, chains):
+    for p in (ROOT, os.path.join(ROOT, "rxinfer.jl_amd")):
+        sys.path.insert(0, p)
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import contextlib
+    import io
+
+    import bench
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--T", "40", "--chains", str(chains), "--scaling", scaling,
+                    "--no-cpu-baseline", "--no-parity", "--no-extras"], engine_cls=StubEngine, gpu_cls=bench._HostOnly)
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(buf.getvalue())
+
+
+@pytest.mark.parametrize("scaling,chains,per_rank", [("weak", 3, 3), ("strong", 6, 3)])
+def test_bench_main_two_ranks(tmp_path, scaling, chains, per_rank):
+    import torch.multiprocessing as mp
+
+    from rxhip import workloads
+
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), scaling, chains), nprocs=2, join=True)
+    assert (tmp_path / "rank1.txt").read_text() == ""          # rank 0 alone prints
+    lines = (tmp_path / "rank0.txt").read_text().strip().splitlines()
+    assert len(lines) == 1                                      # ONE JSON line
+    out = json.loads(lines[0])
+    T, world = 40, 2
+    assert out["n_gpus"] == world and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == scaling
+    assert out["config"]["chains_per_gpu"] == per_rank and out["timing"] == "single" and out["cpu_baseline"] is None
+    # chain c of the job comes from default_rng(42 + c): rank r owns chains [r·per_rank, (r + 1)·per_rank)
+    mdl = workloads.c1_model()
+    shard = [float(np.sum(workloads.generate_batch(mdl, T, per_rank, seed0=42 + r * per_rank))) for r in range(world)]
+    assert out["free_energy_rank0"] == shard[0]
+    assert out["free_energy_global"] == shard[0] + shard[1]     # all-gather + sum in ascending rank order: bit-identical
+    # whole-job throughput: every rank's rule calls over the slowest rank's time
+    calls = (6 * T - 3) * per_rank * world
+    assert out["value"] == pytest.approx(calls * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"]), rel=1e-12)
+    assert out["vmp_iters_per_sec"] == pytest.approx(1e3 / out["ms_per_step"], rel=1e-12)
+
+
+def test_strong_scaling_needs_divisible_chains():
+    import bench
+
+    os.environ.update({"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "2"})
+    try:
+        with pytest.raises(SystemExit):
+            bench.main(["--gpus", "2", "--chains", "5", "--scaling", "strong", "--T", "8", "--no-cpu-baseline"], engine_cls=StubEngine, gpu_cls=bench._HostOnly)
+    finally:
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            os.environ.pop(k, None)

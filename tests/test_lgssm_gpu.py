@@ -110,7 +110,7 @@ def test_c3_full_size():
     """BASELINE config 3 at its full size (d = dy = 64, T = 10⁴, one chain): 250 segments, two-level boundary scan,
     aggregation as a matrix product — against the oracle's reference schedule over the whole chain (≈30 s of CPU)."""
     mdl = workloads.c3_model()
-    y = workloads.generate_batch(mdl, 10000, 1, seed0=6401)
+    y = workloads.generate_batch(mdl, 10000, 1, seed0=6400)   # BASELINE config 3 as bench.py draws it
     mean, cov, fe, sched = check_against_oracle(mdl, y)
     assert sched["segments"] >= 200
 
