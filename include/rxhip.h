@@ -96,8 +96,12 @@ typedef struct {
                          term; its prediction (rxhip_get_predictions) is the plain predictive.  The covariances then differ
                          per chain and time index: the engine keeps per-chain records and computes the segment elements of
                          the time-parallel schedule in the lane (no per-model tables) at d, dy ≤ 4; larger states (any d, dy ≤ 64)
-                         run the reference's own message order, sequential in time, one workgroup per chain
-                         (csrc/gseq_kernels.hpp).  rxhip_counters keeps reporting the all-observed schedule */
+                         run the masked MFMA schedule, also parallel in time (csrc/dense_mseg_kernels.hpp: per-(chain, segment)
+                         elements in information form, a log-depth boundary recursion over them, then the fully observed sweep
+                         kernels with a mask).  An engine whose per-step records do not fit the device's free memory stays on
+                         the sequential schedule — the reference's own message order, one workgroup per chain
+                         (csrc/gseq_kernels.hpp) — which is also what the step-wise filter and the checker runs use.
+                         rxhip_counters keeps reporting the all-observed schedule */
     const int32_t* step_model; /* NULL, or [T + horizon]: time-varying constants.  step_model[t] names the model (of n_models)
                          whose A, P make the transition INTO x[t] and whose B, Q observe y[t] (`A[t] * x[t-1]`,
                          `MvNormal(μ = …, Σ = P[t])` with per-step constants in the @model loop); the prior (m0, V0) is that of
@@ -118,8 +122,11 @@ typedef struct {
 rxhip_status rxhip_lgssm_set_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset);
 /* Known inputs that are DATA of every chain — `x[t] ~ MvNormal(μ = A * x[t-1] + B_u * u[t], Σ = P)` with `u` a data variable: the
  * host passes c = B_u u per chain, (T + horizon)·n_chains·d doubles in `layout` ([t][chain][d] or [chain][t][d]); obs_offset
- * likewise with dy.  Either may be NULL = keep the offsets the engine was CREATED with, replicated over the chains (a model with
- * data inputs on the transitions and a constant observation offset passes NULL for the latter); zeros if it was created without.
+ * likewise with dy.  Either may be NULL = the offsets the engine was CREATED with (rxhip_lgssm_desc — NOT the latest
+ * rxhip_lgssm_set_offsets values), replicated over the chains (a model with data inputs on the transitions and a constant observation
+ * offset passes NULL for the latter); zeros if it was created without.  On an engine whose graph declares data inputs u[t]
+ * (rxhip_create with a `*`(const, data) node behind a transition) a non-NULL state_offset counts as those inputs having been
+ * supplied, exactly like rxhip_set_data(RXHIP_VAR_U).
  * The engine runs μ[t] = A μ[t-1] + c[t] per chain on the device and shifts data and means per chain from then on.  Same
  * precondition as rxhip_lgssm_set_offsets. */
 rxhip_status rxhip_lgssm_set_chain_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset, int32_t layout);
@@ -358,7 +365,9 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
  * mean (T-1)*n_chains*2d doubles = [m(x[t]); A m(x[t-1])], cov …*2d*2d = [[V(x[t]), (A X)′], [A X, A V(x[t-1]) A′]] with
  * X = Cov(x[t-1], x[t] | y) (either may be NULL), in `layout` ([T-1][chain][·] or [chain][T-1][·]).
  * node_type: RXHIP_NODE_MVNORMAL_MEAN_COV.  After rxhip_run of a state-space engine; any d, dy ≤ 64 (d, dy ≤ 4: from the sweep's own
- * records; above: the sequential kernels recompute the sweep into scratch arrays with Cov(x[t], x[t+1] | y) kept — a getter, not a hot path). */
+ * records; above: Cov(x[t], x[t+1] | y) = G_t V_s(t+1) from the smoother gains the information-form sweep leaves in its records, one product
+ * per time index (kd_cross_from_records); batches on the model / data split and packed pairs re-run the sequential kernels into scratch
+ * arrays instead — a getter, not a hot path). */
 rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double* mean, double* cov, int32_t layout);
 
 /* device views of the same results, layout [T][chain][d] and [T][chain][d][d]; valid until the

@@ -1625,7 +1625,10 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
 // STEPM: per-step constants (masked schedule only) — the constants of the transition INTO step t and of the observation at t come from
 // block step_model[t]: M_t = [P⁻¹ + B′Q⁻¹B]_t + [A′P⁻¹A]_{t+1} − K_t G_{t−1}.  A template flag: the fixed-model kernel keeps its registers.
 template <int NT, bool FE, bool STEPM = false>
-__global__ void __launch_bounds__(64 * NT, 2) kd_forward_info(DenseParams p) {  // ≥ 2 waves per SIMD: ≤ 256 registers
+#ifndef RXHIP_FWD_WAVES
+#define RXHIP_FWD_WAVES 2
+#endif
+__global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(DenseParams p) {  // ≥ 2 waves per SIMD: ≤ 256 registers
     constexpr int D = 16 * NT;
     using C = DenseCfg<NT>;
     constexpr int LD = C::LD;

@@ -46,6 +46,7 @@ namespace rxhip {
 struct MsegParams {
     int d, dy, dy_user, ptt;   // kernel-level dims (d = 16·NT, dy ≤ d); dy_user: length of an observation vector in y
     long long T, L, n_chains;
+    long long chain0;       // first chain of this launch: grid.y holds 65 535 blocks, so a launch covers a slice of at most 32 768 chains
     int S;
     const double* y;        // [T][chain][dy_user]
     const double* in;       // padded model: A | P | V0 | B | Q | m0
@@ -97,7 +98,7 @@ __host__ __device__ constexpr int mseg_lds_doubles(int NT, bool staged) { return
 // Sixteen lanes share an observation vector (coalesced reads of y), 16 time steps per 256-thread pass.
 static __global__ void __launch_bounds__(256) km_mask(MsegParams p) {
     __shared__ double red[256];
-    const long long chain = blockIdx.y;
+    const long long chain = blockIdx.y + p.chain0;
     const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
     double cnt = 0.0;
     for (long long t0 = (long long)blockIdx.x * 16; t0 < p.T; t0 += (long long)gridDim.x * 16) {
@@ -374,7 +375,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
     double *xi = vec, *xn = vec + D, *eta = vec + 2 * D, *yv = vec + 3 * D, *gyv = vec + 4 * D;
     double* stage = smem + mseg_stage_offset(NT);
     const int tid = o.tid, dyu = p.dy_user, w = o.w;
-    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const long long seg = blockIdx.x, chain = blockIdx.y + p.chain0;
     auto CW = [&](int m, int slot) { return as_global(p.cw + (size_t)m * (size_t)p.cw_stride + (size_t)slot * MM); };   // constants of model m
     double* W = p.ws + ((size_t)chain * p.S + seg) * MSEG_WS * MM;
     double* g = as_global(p.mel + ((size_t)chain * p.S + seg) * 3 * MM);   // Λ | Ψ | Ĵ of this segment
@@ -524,7 +525,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_elements(MsegParams p) {
 // to the sweep kernel besides it — B'Q⁻¹y_t of the observed steps, 0 for the missing ones.  One thread per (chain, t ≥ 1, component).
 static __global__ void __launch_bounds__(256) km_gy(MsegParams p) {
     const int D = p.d, dyu = p.dy_user;
-    const long long chain = blockIdx.y, idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long chain = blockIdx.y + p.chain0, idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long t = 1 + idx / D;
     const int i = (int)(idx - (t - 1) * D);
     if (t >= p.T) return;
@@ -540,7 +541,7 @@ static __global__ void __launch_bounds__(256) km_gy(MsegParams p) {
 // log|V1| + Σ_{t ≥ 1} log|P_t| + Σ_{t observed} (dy log 2π + log|Q_t|).  One workgroup per chain, fixed summation order.
 static __global__ void __launch_bounds__(256) km_feconst(MsegParams p) {
     __shared__ double red[256];
-    const long long chain = blockIdx.x;
+    const long long chain = blockIdx.x + p.chain0;
     double acc = 0.0;
     for (long long t = threadIdx.x; t < p.T; t += 256) {
         const double* cm = p.cst + (size_t)mseg_model(p, chain, t) * (size_t)p.cst_stride;
@@ -569,7 +570,7 @@ __global__ void __launch_bounds__(64 * NT) km_group(MsegParams p) {
     double* vec = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
     double *xi = vec, *eta = vec + D, *u = vec + 2 * D;
     const int tid = o.tid, S = p.S;
-    const long long grp = blockIdx.x, chain = blockIdx.y;
+    const long long grp = blockIdx.x, chain = blockIdx.y + p.chain0;
     const int s0 = (int)grp * p.sg, s1 = s0 + p.sg < S ? s0 + p.sg : S;
     double* W = p.ws + ((size_t)chain * S + s0) * MSEG_WS * MM;   // the first segment's scratch (km_elements is done with it)
     double *Ti = W, *Am = W + MM, *Bm = W + 2 * MM, *T2 = W + 3 * MM, *Ps2 = W + 4 * MM;
@@ -628,7 +629,7 @@ __global__ void __launch_bounds__(64 * NT) km_scan(MsegParams p, int level) {
     double *xi = vec, *u = vec + D, *tv = vec + 2 * D;
     const int tid = o.tid, S = p.S, dyu = p.dy_user;
     const int dir = level == 3 ? (int)blockIdx.x / p.ng : (int)blockIdx.x, grp = level == 3 ? (int)blockIdx.x - dir * p.ng : 0;
-    const long long chain = blockIdx.y;
+    const long long chain = blockIdx.y + p.chain0;
     const int m0i = mseg_model(p, chain, 0);   // the prior and the first observation use the constants of step 0's model
     auto CW = [&](int slot) { return p.cw + (size_t)m0i * (size_t)p.cw_stride + (size_t)slot * MM; };
     const double* in0 = p.in + (size_t)m0i * (size_t)p.in_stride;
@@ -735,7 +736,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_compose(MsegParams p, int r) { 
     double* u = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
     const int tid = o.tid, S = p.hs_n;               // entries of the scan
     const int dir = (int)blockIdx.x / S, j = (int)blockIdx.x - dir * S, h = 1 << r;
-    const long long chain = blockIdx.y;
+    const long long chain = blockIdx.y + p.chain0;
     const int i = dir == 0 ? j : S - 1 - j;          // distance from the origin of the scan
     if (i < h || i == S - 1) return;                 // finished — or the whole chain's composition, which nobody reads
     const int jp = dir == 0 ? j - h : j + h, gp = hs_generations(i - h) < r ? hs_generations(i - h) : r;
@@ -758,7 +759,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_apply(MsegParams p) {
     double *xi = vec, *u = vec + D, *tv = vec + 2 * D;
     const int tid = o.tid, S = p.hs_n, dyu = p.dy_user;                      // S: entries of the scan; entry s = segments hs_g·s … (seg0 … seg1)
     const int dir = (int)blockIdx.x / S, s = (int)blockIdx.x - dir * S;
-    const long long chain = blockIdx.y;
+    const long long chain = blockIdx.y + p.chain0;
     const int seg0 = s * p.hs_g, seg1 = (seg0 + p.hs_g < p.S ? seg0 + p.hs_g : p.S) - 1;
     bool ok = true;
     auto fin = [&](int dr, int idx, const double*& g, const double*& gv) {   // the finished composition of entry idx
@@ -848,7 +849,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_fold(MsegParams p) {
     TabOps<NT> o{(int)threadIdx.x, (int)threadIdx.x >> 6, (int)threadIdx.x & 63, smem};
     double* u = smem + blk_scratch_doubles(NT) + 2 * 64 * NT;
     const int tid = o.tid, S = p.S;
-    const long long grp = blockIdx.x, chain = blockIdx.y;
+    const long long grp = blockIdx.x, chain = blockIdx.y + p.chain0;
     const int s0 = (int)grp * p.hs_g, s1 = s0 + p.hs_g < S ? s0 + p.hs_g : S;
     double* G = p.mgrp + ((size_t)chain * p.hs_n + grp) * 3 * MM;
     double* Gv = p.mgvec + ((size_t)chain * p.hs_n + grp) * 2 * D;
@@ -880,7 +881,7 @@ __global__ void __launch_bounds__(64 * NT, 2) km_inner(MsegParams p) {
     double* stage = smem + mseg_stage_offset(NT);
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, S = p.S;
     const int dir = (int)blockIdx.x / p.hs_n, grp = (int)blockIdx.x - dir * p.hs_n;
-    const long long chain = blockIdx.y;
+    const long long chain = blockIdx.y + p.chain0;
     const int s0 = grp * p.hs_g, s1 = s0 + p.hs_g < S ? s0 + p.hs_g : S;   // segments s0 … s1 − 1
     bool ok = true;
     auto load_sum = [&](Acc<NT>& T, const double* a_, const double* b_) {   // T = a + b (both symmetric up to rounding: see mseg_compose_fused)
@@ -943,7 +944,7 @@ __global__ void __launch_bounds__(64 * NT) km_filter_out(MsegParams p, DensePara
     double* red = xi + D;               // [4][D] partial sums
     double* scr = red + 4 * D;          // scratch of the inverse
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const long long t = blockIdx.x, chain = blockIdx.y;
+    const long long t = blockIdx.x, chain = blockIdx.y + p.chain0;
     const double* rec = p.filt + (chain * p.T + t) * p.rec;
     if (tid < D) xi[tid] = rec[tid];
     Acc<NT> a;
@@ -999,7 +1000,7 @@ __global__ void __launch_bounds__(64 * NT) km_bnd(MsegParams p) {
     constexpr int D = 16 * NT, MM = D * D;
     extern __shared__ __attribute__((aligned(16))) double smem[];
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
-    const long long seg = blockIdx.x, chain = blockIdx.y;
+    const long long seg = blockIdx.x, chain = blockIdx.y + p.chain0;
     if (seg + 1 >= p.S) return;
     Acc<NT> a;
     acc_load<NT>(a, p.mbnd + (((size_t)chain * p.S + seg + 1) * 2 + 0) * MM, D, w, lane);

@@ -129,9 +129,11 @@ inline bool same_const(const rxhip_graph_desc* g, long long a, long long b) {
 // covariance-parametrised forms (test/inference/prediction_tests.jl:197-213 spells a whole random-walk chain this way): a
 // private copy of the tables gets a new constant variable W⁻¹ per such node and the node type of the covariance form, and the
 // chain lowering below never sees a precision.  Nodes with a random precision (the iid Gaussian×Gamma family) are left alone.
-// Inverse of a constant precision (the covariance the kernels run on): symmetric within rounding or refused — the lowering
+// Inverse of a constant precision (the covariance the kernels run on): symmetric within ROUND-OFF or refused — the lowering
 // must not repair an input error by symmetrising afterwards — then through the Cholesky factor (positive definite or refused).
-// 0: ok, 1: not symmetric, 2: not positive definite.
+// "Round-off" is scaled to what a host produces: a precision computed as inv(Σ) carries an asymmetry of ≈ eps·cond(Σ)·max|W|, so the
+// bound is 1e-8·max|W| (cond up to ≈ 10⁷; the reference places no symmetry requirement on MvNormalMeanPrecision arguments at all);
+// below it the symmetric part ½(W + W′) is what gets inverted.  0: ok, 1: not symmetric, 2: not positive definite.
 inline int spd_inverse_checked(int d, const double* W, std::vector<double>& inv) {
     double amax = 0.0, asym = 0.0;
     for (int i = 0; i < d; ++i)
@@ -139,7 +141,7 @@ inline int spd_inverse_checked(int d, const double* W, std::vector<double>& inv)
             amax = std::max(amax, std::fabs(W[(size_t)i * d + j]));
             asym = std::max(asym, std::fabs(W[(size_t)i * d + j] - W[(size_t)j * d + i]));
         }
-    if (!(asym <= 1e-12 * amax)) return 1;   // also catches NaN
+    if (!(asym <= 1e-8 * amax)) return 1;   // also catches NaN
     std::vector<double> L((size_t)d * d, 0.0), Li((size_t)d * d, 0.0);
     for (int j = 0; j < d; ++j) {
         double s = W[(size_t)j * d + j];

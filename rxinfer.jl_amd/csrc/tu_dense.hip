@@ -3,6 +3,7 @@
 // (dense_mseg_kernels.hpp), the model / data split of shared-model batches (dense_split_kernels.hpp).
 // Compiled once per tile count: -DRXHIP_TU_NT=1…4; each object carries its own gfx950 code object.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 
 #include "launch_tables.hpp"
@@ -69,8 +70,8 @@ struct DenseLaunchNT {
         });
     }
     // information-form smoother (one inverse per step; free energy at the smoothed means)
-    static void forward_info_stepm(const DenseParams& p, bool fe, hipStream_t s) {   // per-step constants (masked schedule)
-        slices(p, p.n_chains, [&](const DenseParams& q, unsigned nc) {
+    static void forward_info_stepm(const DenseParams& p, bool fe, hipStream_t s, long long chains = -1) {   // per-step constants (masked schedule)
+        slices(p, chains < 0 ? p.n_chains : chains, [&](const DenseParams& q, unsigned nc) {
             dim3 g(q.S, nc);
             const size_t lds = DenseLds<NT>::fwd_info_bytes(((q.d > q.dy ? q.d : q.dy) + 1) & ~1);
             if (fe) hipLaunchKernelGGL((kd_forward_info<NT, true, true>), g, dim3(64 * NT), lds, s, q);
@@ -133,15 +134,40 @@ static hipError_t launch_dense_tab(const TabParams& tp, hipStream_t s) {   // ta
     constexpr int D = 16 * NT;
     const size_t lds = sizeof(double) * (size_t)(blk_scratch_doubles(NT) + 2 * 64 * NT + 16);
     const size_t lds_c = lds + sizeof(double) * (size_t)D * (D + 1);
+    // RXHIP_TRACE=1: device time of every builder kernel (HIP events on the engine's stream; costs a synchronisation — measurement aid)
+    static const bool trace = std::getenv("RXHIP_TRACE") != nullptr;
+    hipEvent_t ev[7];
+    int nev = 0;
+    const char* names[6] = {"kt_consts", "kt_gains", "kt_agg", "kt_scan", "kt_qcanon", "kt_qtab"};
+    auto mark = [&]() {
+        if (trace && hipEventCreate(&ev[nev]) == hipSuccess) { (void)hipEventRecord(ev[nev], s); ++nev; }
+    };
+    mark();
     hipLaunchKernelGGL((kt_consts<NT>), dim3(1), dim3(64 * NT), lds_c, s, tp);
+    mark();
     if (tp.S > 0) {
         hipLaunchKernelGGL((kt_gains<NT>), dim3(1), dim3(64 * NT), lds, s, tp);
+        mark();
         hipLaunchKernelGGL((kt_agg<NT>), dim3(2), dim3(64 * NT), lds, s, tp);
+        mark();
         hipLaunchKernelGGL((kt_scan<NT>), dim3(2), dim3(64 * NT), lds, s, tp);
+        mark();
         hipLaunchKernelGGL(kt_qcanon, dim3(1), dim3(64), 0, s, tp);
+        mark();
         if (tp.S > 1) hipLaunchKernelGGL((kt_qtab<NT>), dim3((unsigned)tp.ng, 2), dim3(64 * NT), lds, s, tp);
+        mark();
     }
-    return hipGetLastError();
+    const hipError_t err = hipGetLastError();
+    if (trace && nev > 1) {
+        (void)hipEventSynchronize(ev[nev - 1]);
+        for (int i = 0; i + 1 < nev; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, ev[i], ev[i + 1]);
+            std::fprintf(stderr, "[rxhip]   device time %-10s %8.3f ms\n", names[i], ms);
+        }
+    }
+    for (int i = 0; i < nev; ++i) (void)hipEventDestroy(ev[i]);
+    return err;
 }
 static void tab_consts(const TabParams& tp, unsigned models, size_t lds, hipStream_t s) {   // one workgroup per model (masked schedule)
     hipLaunchKernelGGL((kt_consts<NT>), dim3(models), dim3(64 * NT), lds, s, tp);
@@ -153,36 +179,51 @@ static hipError_t mseg_prepare_kernels() {
         if ((err = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024))) return err;
     return DenseLaunchNT::prepare();
 }
-static void mseg_launch(const MsegParams& mp, const DenseParams& dp, bool fe, bool filter, hipStream_t s) {
-    const size_t lds = sizeof(double) * (size_t)mseg_lds_doubles(NT, false), lds_s = sizeof(double) * (size_t)mseg_lds_doubles(NT, true);
-    (void)hipMemsetAsync(mp.nobs, 0, sizeof(double) * (size_t)mp.n_chains, s);
-    hipLaunchKernelGGL(km_mask, dim3((unsigned)std::min<long long>(mp.n_chains >= 64 ? 16 : 256, (mp.T + 15) / 16), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
-    if (mp.S == 1) hipLaunchKernelGGL(km_gy, dim3((unsigned)(((mp.T - 1) * mp.d + 255) / 256), (unsigned)mp.n_chains), dim3(256), 0, s, mp);
-    else hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, (unsigned)mp.n_chains), dim3(64 * NT), lds_s, s, mp);
-    if (mp.hs) {       // log-depth: all prefix / suffix compositions in ⌈log₂ S⌉ rounds, then every boundary state at once
-        const dim3 g1((unsigned)mp.hs_n, (unsigned)mp.n_chains), g2(2 * (unsigned)mp.hs_n, (unsigned)mp.n_chains);
-        if (mp.hs_g > 1) hipLaunchKernelGGL((km_fold<NT>), g1, dim3(64 * NT), lds_s, s, mp);
-        for (int r = 0; r < mp.hs_rounds; ++r) hipLaunchKernelGGL((km_compose<NT>), g2, dim3(64 * NT), lds_s, s, mp, r);
-        hipLaunchKernelGGL((km_apply<NT>), g2, dim3(64 * NT), lds_s, s, mp);
-        if (mp.hs_g > 1) hipLaunchKernelGGL((km_inner<NT>), g2, dim3(64 * NT), lds_s, s, mp);
-    } else if (mp.ng > 0) {   // two levels: group elements, the states at the group edges, then every group on its own
-        hipLaunchKernelGGL((km_group<NT>), dim3((unsigned)mp.ng, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp);
-        hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 2);
-        hipLaunchKernelGGL((km_scan<NT>), dim3(2 * (unsigned)mp.ng, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 3);
-    } else
-        hipLaunchKernelGGL((km_scan<NT>), dim3(2, (unsigned)mp.n_chains), dim3(64 * NT), lds, s, mp, 0);
-    if (mp.S > 1) hipLaunchKernelGGL((km_bnd<NT>), dim3((unsigned)(mp.S - 1), (unsigned)mp.n_chains), dim3(64 * NT), sizeof(double) * blk_scratch_doubles(NT), s, mp);
-    if (mp.step_model) {
-        if (fe) hipLaunchKernelGGL(km_feconst, dim3((unsigned)mp.n_chains), dim3(256), 0, s, mp);
-        DenseLaunchNT::forward_info_stepm(dp, fe, s);
-    } else
-        DenseLaunchNT::forward_info(dp, fe, s);
-    if (!filter || fe) DenseLaunchNT::backward_info(dp, fe, s);   // a filtering run needs the backward sweep for its free energy only
-
+// One launch covers at most 32 768 chains (grid.y holds 65 535 blocks; the chains are independent, so a slice runs the whole schedule before
+// the next one starts — the sweep kernels slice themselves the same way, DenseLaunchNT::slices).
+template <class F>
+static void mseg_slices(const MsegParams& mp, const DenseParams& dp, F run) {
+    for (long long c0 = 0; c0 < mp.n_chains; c0 += 32768) {
+        MsegParams m = mp;
+        DenseParams q = dp;
+        m.chain0 = c0;
+        q.chain0 = dp.chain0 + c0;
+        run(m, q, (unsigned)(mp.n_chains - c0 < 32768 ? mp.n_chains - c0 : 32768));
+    }
 }
-static void mseg_filter_out(const MsegParams& mp, const DenseParams& dp, hipStream_t s) {
+static void mseg_launch(const MsegParams& mp_all, const DenseParams& dp_all, bool fe, bool filter, hipStream_t s) {
+    const size_t lds = sizeof(double) * (size_t)mseg_lds_doubles(NT, false), lds_s = sizeof(double) * (size_t)mseg_lds_doubles(NT, true);
+    (void)hipMemsetAsync(mp_all.nobs, 0, sizeof(double) * (size_t)mp_all.n_chains, s);
+    mseg_slices(mp_all, dp_all, [&](const MsegParams& mp, const DenseParams& dp, unsigned nc) {
+        hipLaunchKernelGGL(km_mask, dim3((unsigned)std::min<long long>(nc >= 64 ? 16 : 256, (mp.T + 15) / 16), nc), dim3(256), 0, s, mp);
+        if (mp.S == 1) hipLaunchKernelGGL(km_gy, dim3((unsigned)(((mp.T - 1) * mp.d + 255) / 256), nc), dim3(256), 0, s, mp);
+        else hipLaunchKernelGGL((km_elements<NT>), dim3((unsigned)mp.S, nc), dim3(64 * NT), lds_s, s, mp);
+        if (mp.hs) {       // log-depth: all prefix / suffix compositions in ⌈log₂ S⌉ rounds, then every boundary state at once
+            const dim3 g1((unsigned)mp.hs_n, nc), g2(2 * (unsigned)mp.hs_n, nc);
+            if (mp.hs_g > 1) hipLaunchKernelGGL((km_fold<NT>), g1, dim3(64 * NT), lds_s, s, mp);
+            for (int r = 0; r < mp.hs_rounds; ++r) hipLaunchKernelGGL((km_compose<NT>), g2, dim3(64 * NT), lds_s, s, mp, r);
+            hipLaunchKernelGGL((km_apply<NT>), g2, dim3(64 * NT), lds_s, s, mp);
+            if (mp.hs_g > 1) hipLaunchKernelGGL((km_inner<NT>), g2, dim3(64 * NT), lds_s, s, mp);
+        } else if (mp.ng > 0) {   // two levels: group elements, the states at the group edges, then every group on its own
+            hipLaunchKernelGGL((km_group<NT>), dim3((unsigned)mp.ng, nc), dim3(64 * NT), lds, s, mp);
+            hipLaunchKernelGGL((km_scan<NT>), dim3(2, nc), dim3(64 * NT), lds, s, mp, 2);
+            hipLaunchKernelGGL((km_scan<NT>), dim3(2 * (unsigned)mp.ng, nc), dim3(64 * NT), lds, s, mp, 3);
+        } else
+            hipLaunchKernelGGL((km_scan<NT>), dim3(2, nc), dim3(64 * NT), lds, s, mp, 0);
+        if (mp.S > 1) hipLaunchKernelGGL((km_bnd<NT>), dim3((unsigned)(mp.S - 1), nc), dim3(64 * NT), sizeof(double) * blk_scratch_doubles(NT), s, mp);
+        if (mp.step_model) {
+            if (fe) hipLaunchKernelGGL(km_feconst, dim3(nc), dim3(256), 0, s, mp);   // reads the mask of this slice
+            DenseLaunchNT::forward_info_stepm(dp, fe, s, nc);
+        } else
+            DenseLaunchNT::forward_info(dp, fe, s, nc);
+        if (!filter || fe) DenseLaunchNT::backward_info(dp, fe, s, nc);   // a filtering run needs the backward sweep for its free energy only
+    });
+}
+static void mseg_filter_out(const MsegParams& mp_all, const DenseParams& dp_all, hipStream_t s) {
     const size_t ldf = sizeof(double) * (size_t)(DenseCfg<NT>::MAT + 5 * 16 * NT + blk_scratch_doubles(NT) + 16);
-    hipLaunchKernelGGL((km_filter_out<NT>), dim3((unsigned)mp.T, (unsigned)mp.n_chains), dim3(64 * NT), ldf, s, mp, dp);
+    mseg_slices(mp_all, dp_all, [&](const MsegParams& mp, const DenseParams& dp, unsigned nc) {
+        hipLaunchKernelGGL((km_filter_out<NT>), dim3((unsigned)mp.T, nc), dim3(64 * NT), ldf, s, mp, dp);
+    });
 }
 static hipError_t split_prepare() {
     hipError_t err;

@@ -393,3 +393,59 @@ def test_node_local_joints_from_the_sweep_records(d, dy, T, C, M, rate, monkeypa
     sd = np.sqrt(np.einsum("tcii->tci", sc))
     assert np.max(np.abs(jm - sm_) / sd) < 1e-6
     assert np.max(np.abs(jc - sc) / (sd[..., :, None] * sd[..., None, :])) < 1e-6
+
+
+def test_records_that_do_not_fit_keep_the_sequential_schedule(monkeypatch):
+    """The masked schedule keeps per-step records for every chain (4.5 KB per chain-step at d ≤ 16): an engine whose block does not fit
+    the device stays on the sequential kernels instead of failing at creation.  RXHIP_MSEG_MAX_BYTES caps the block."""
+    import rxhip
+    import rxoracle as rxo
+    from rxhip import workloads
+    d, dy, T, C = 8, 4, 90, 3
+    mdl = workloads.random_model(d, dy, seed=77)
+    y = workloads.generate_batch(mdl, T, C, seed0=3)
+    y[np.random.default_rng(5).random((T, C)) < 0.2] = np.nan
+    monkeypatch.delenv("RXHIP_GSEQ", raising=False)
+    res = {}
+    for cap in (None, "4096"):
+        if cap:
+            monkeypatch.setenv("RXHIP_MSEG_MAX_BYTES", cap)
+        with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C, allow_missing=True) as eng:
+            eng.set_data(y)
+            eng.run(1, True)
+            res[cap] = (*eng.marginals(), eng.free_energy_per_chain(), eng.schedule())
+    assert res[None][3]["segments"] >= 1 and res["4096"][3]["segments"] == 0       # time-parallel / sequential (no segments)
+    for c in range(C):
+        om, oc, nll = rxo.lgssm_kalman_rts(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], np.ascontiguousarray(y[:, c]))
+        sd = np.sqrt(np.einsum("tii->ti", oc))
+        for cap in res:
+            mean, cov, fe, _ = res[cap]
+            assert np.max(np.abs(mean[:, c] - om) / sd) < 1e-6 and np.max(np.abs(cov[:, c] - oc) / (sd[:, :, None] * sd[:, None, :])) < 1e-6, cap
+            assert fe[c] == pytest.approx(nll, rel=1e-8, abs=1e-9), cap
+
+
+def test_more_chains_than_a_grid_dimension_on_the_masked_schedule(monkeypatch):
+    """grid.y holds 65 535 blocks: a masked batch beyond that is launched in slices of 32 768 chains.  70 000 chains of a
+    tiny problem: a handful of them against the oracle, and chains that carry the same data must agree bit for bit across slices."""
+    import rxhip
+    import rxoracle as rxo
+    from rxhip import workloads
+    d, dy, T, C = 6, 3, 5, 70000
+    mdl = workloads.random_model(d, dy, seed=78)
+    base = workloads.generate_batch(mdl, T, 7, seed0=9)
+    base[1, 2] = np.nan
+    base[3, 5] = np.nan
+    y = np.ascontiguousarray(np.tile(base, (1, C // 7, 1)))
+    monkeypatch.delenv("RXHIP_GSEQ", raising=False)
+    with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C, allow_missing=True) as eng:
+        eng.set_data(y)
+        eng.run(1, True)
+        chains = [0, 2, 5, 32767, 32768, 65535, 65536, C - 1]
+        mean, cov = eng.marginals_of_chains(chains)
+        fe = eng.free_energy_per_chain()
+    for i, c in enumerate(chains):
+        om, oc, nll = rxo.lgssm_kalman_rts(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], np.ascontiguousarray(y[:, c]))
+        sd = np.sqrt(np.einsum("tii->ti", oc))
+        assert np.max(np.abs(mean[i] - om) / sd) < 1e-6 and np.max(np.abs(cov[i] - oc) / (sd[:, :, None] * sd[:, None, :])) < 1e-6, c
+        assert fe[c] == pytest.approx(nll, rel=1e-8, abs=1e-9), c
+    assert np.array_equal(fe[:7], fe[C - 7:]) and np.array_equal(fe[32767 - 32767 % 7:32767 - 32767 % 7 + 7], fe[:7])
