@@ -199,13 +199,19 @@ def lgssm_filter(A, B, P, Q, m0, V0, y, prior_through_transition=True, free_ener
     return mean, cov, (float(fe[0]) if free_energy else None), cnt
 
 
-def lgssm_bp_batch(A, B, P, Q, m0, V0, y, prior_through_transition=False, free_energy=True, nthreads=1):
-    """Batch of chains sharing one model.  y: [T][chain][dy].  Returns mean [T,C,d], cov [T,C,d,d], fe[C]|None."""
+def lgssm_bp_batch(A, B, P, Q, m0, V0, y, prior_through_transition=False, free_energy=True, nthreads=1, out=None):
+    """Batch of chains sharing one model.  y: [T][chain][dy].  Returns mean [T,C,d], cov [T,C,d,d], fe[C]|None.
+    out = (mean, cov): result arrays of the caller (bench.py's timed baseline hands over arrays whose pages are already mapped — the
+    first touch of 8 GB of fresh pages by 256 threads of one process would otherwise be most of the measurement)."""
     A, B, P, Q, m0, V0, y = map(_c, (A, B, P, Q, m0, V0, y))
     d, dy = A.shape[0], B.shape[0]
     T, C = y.shape[0], y.shape[1]
-    mean = np.empty((T, C, d))
-    cov = np.empty((T, C, d, d))
+    if out is not None:
+        mean, cov = out
+        assert mean.shape == (T, C, d) and cov.shape == (T, C, d, d) and mean.flags.c_contiguous and cov.flags.c_contiguous
+    else:
+        mean = np.empty((T, C, d))
+        cov = np.empty((T, C, d, d))
     fe = np.empty(C) if free_energy else None
     cnt = Counters()
     rc = lib().rxo_lgssm_bp_batch(d, dy, T, C, _p(A), _p(B), _p(P), _p(Q), _p(m0), _p(V0),

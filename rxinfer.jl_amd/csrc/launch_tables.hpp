@@ -50,6 +50,7 @@ struct LgssmVtbl {
     void (*predict)(const PredictParams&, hipStream_t);
     void (*joint)(const PredictParams&, hipStream_t);
     void (*stream_step)(const StreamParams&, hipStream_t);
+    void (*small_sweep)(const Params&, const double*, bool, hipStream_t);   // the four phases + free energy in ONE launch (k_small_sweep)
 };
 // tu_lgssm.hip, one definition per state dimension: fills out[0..3] (dy = 1…4)
 void lgssm_vtbls_d1(LgssmVtbl* out);

@@ -571,20 +571,26 @@ __device__ __forceinline__ long long seg_len(const Params& p, long long s) {
 //   e_i = y_i − (BA) m_{i−1};  η += U_i e_i;  m_i = A m_{i−1} + K_i e_i       (m_0 = 0)
 // K_i, U_i: per-model gain tables (Kalman gain of the filter started from an exactly known
 // state, and the sensitivity of the innovations to that state).  64 FMAs / step at d = dy = 4.
+// (The phases of the four-phase schedule are written as wave-level bodies — `g`: the (chain, segment) lane of the batch, `lane`: the lane of
+// the wavefront, LDS handed in by the caller — so that k_small_sweep below can run all of them in ONE launch; the kernels proper wrap them.)
+template <int D, int DY>
+struct AggStage {
+    static constexpr int U = 4;                                   // steps per chunk
+    static constexpr int NPC = U * TabLayout<D, DY>::SIZE / 2;    // 16-byte pieces of gain table per chunk
+};
 template <int D, int DY, bool UNI>
-__global__ void __launch_bounds__(64) k_seg_aggregate(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
+__device__ __forceinline__ void seg_aggregate_body(const Params& p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE>& cb, const long long g, const int lane,
+                                                   double2* __restrict__ tbuf_flat) {
     using CL = CstLayout<D, DY>;
     using TL = TabLayout<D, DY>;
-    constexpr int U = 4;                  // steps per chunk
-    constexpr int NPC = U * TL::SIZE / 2; // 16-byte pieces of gain table per chunk
+    constexpr int U = AggStage<D, DY>::U;
+    constexpr int NPC = AggStage<D, DY>::NPC;
     constexpr int PPL = (NPC + 63) / 64;  // pieces per lane
     // The per-offset gains are the same for every lane of the wave (one model): the wave streams
     // them cooperatively global -> registers -> LDS one chunk ahead (double buffered) and reads
     // them back with broadcast ds_reads.  (Scalar loads of the table stall the wave on every
     // step: SMEM returns out of order, so each s_load needs lgkmcnt(0) before first use.)
-    __shared__ double2 tbuf[2][UNI ? NPC : 1];
-    const int lane = threadIdx.x;
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    double2 (*tbuf)[UNI ? NPC : 1] = reinterpret_cast<double2 (*)[UNI ? NPC : 1]>(tbuf_flat);   // [2][NPC], private to the wavefront
     const long long total = p.n_chains * (long long)p.S;
     const bool live = g < total;
     const long long seg = live ? g / p.n_chains : 0;
@@ -684,6 +690,11 @@ __global__ void __launch_bounds__(64) k_seg_aggregate(Params p, const CstArgFor<
             o[(D + a) * p.n_chains] = eta[a];
         }
     }
+}
+template <int D, int DY, bool UNI>
+__global__ void __launch_bounds__(64) k_seg_aggregate(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
+    __shared__ double2 tbuf[2 * (UNI ? AggStage<D, DY>::NPC : 1)];
+    seg_aggregate_body<D, DY, UNI>(p, cb, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, tbuf);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1335,26 +1346,30 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
 // (two 4×4 matvecs per segment and role); matrices come from the per-model ScanLayout table, staged through
 // LDS in chunks of 64 segments (the recursion is latency-bound: a scalar or global load per step would
 // cost more than the arithmetic), and the per-chain element vectors are prefetched one segment ahead.
-template <int D, int DY, bool FE>
-__global__ void __launch_bounds__(64) k_boundary_scan_tab(Params p, const CstArg<CstLayout<D, DY>::SIZE> cb) {
+constexpr int SCAN_TAB_CHUNK = 64;  // segments per LDS chunk
+// one wavefront = 64 chains in one role; `tbl` (SCAN_TAB_CHUNK · ScanLayout::SIZE doubles) is private to it: the staging is ordered by
+// wave-level fences (LDS executes a wave's accesses in order)
+template <int D, int DY, bool FE, int CH = SCAN_TAB_CHUNK>
+__device__ __forceinline__ void boundary_scan_tab_body(const Params& p, const CstArg<CstLayout<D, DY>::SIZE>& cb, const long long chain_raw, const int role,
+                                                       const int lane, double2* __restrict__ tbl) {
     using CL = CstLayout<D, DY>;
     using SL = ScanLayout<D>;
     constexpr int NS = Dim<D>::NS;
-    constexpr int CH = 64;  // segments per LDS chunk
-    __shared__ double2 tbl[CH * SL::SIZE / 2];
-    const int lane = threadIdx.x;
-    const long long chain_raw = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const bool live = chain_raw < p.n_chains;
     const long long chain = live ? chain_raw : 0;
-    const int role = blockIdx.y;
     const CPtr c{cb.v};
     const int S = p.S;
     bool ok = true;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
     auto stage = [&](int s0, int n) {  // segments [s0, s0+n) -> LDS
-        __syncthreads();
+        wave_sync();
         const double2* src = reinterpret_cast<const double2*>(p.scan + (long long)s0 * SL::SIZE);
         for (int q = lane; q < n * SL::SIZE / 2; q += 64) tbl[q] = src[q];
-        __syncthreads();
+        wave_sync();
     };
     auto load_el = [&](int s, double (&b)[D], double (&eta)[D]) {
         const double* el = p.elem + ((long long)s * 2 * D) * p.n_chains + chain;
@@ -1465,6 +1480,11 @@ __global__ void __launch_bounds__(64) k_boundary_scan_tab(Params p, const CstArg
     }
     if (!ok && live) atomicOr(p.status, ST_NOT_POSDEF);
 }
+template <int D, int DY, bool FE>
+__global__ void __launch_bounds__(64) k_boundary_scan_tab(Params p, const CstArg<CstLayout<D, DY>::SIZE> cb) {
+    __shared__ double2 tbl[SCAN_TAB_CHUNK * ScanLayout<D>::SIZE / 2];
+    boundary_scan_tab_body<D, DY, FE>(p, cb, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)blockIdx.y, (int)threadIdx.x, tbl);
+}
 
 // ------------------------------------------------------------------------------------------
 // phase 3: forward sweep inside each segment.  Per step (reference rule names):
@@ -1485,12 +1505,11 @@ template <int D>
 __device__ __forceinline__ void write_marginal_wave(const Params& p, double2* tile, int lane, long long t,
                                                     long long chain0, const double (&m)[D], const Sym<D>& V);
 template <int D, int DY, bool UNI, bool FE, bool FILT = false>
-__global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
+__device__ __forceinline__ void forward_body(const Params& p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE>& cb, const long long g, const int lane,
+                                             double2* __restrict__ tile) {   // tile: the wave's output transpose buffer (FILT), or null
     using CL = CstLayout<D, DY>;
     constexpr bool CAN_TILE = FILT && (D % 2 == 0);
-    __shared__ double2 tile[CAN_TILE ? 64 * (((D + D * D) / 2) | 1) : 1];
-    const bool tiled = CAN_TILE && (p.n_chains % 64 == 0);
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool tiled = CAN_TILE && tile != nullptr && (p.n_chains % 64 == 0);
     const long long total = p.n_chains * (long long)p.S;
     const bool live = g < total;
     const long long seg = live ? g / p.n_chains : 0;
@@ -1561,7 +1580,7 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
         }
         if constexpr (FILT) {
             if constexpr (CAN_TILE) {
-                if (tiled) write_marginal_wave<D>(p, tile, (int)threadIdx.x, t0 + i, chain - threadIdx.x, m, V);
+                if (tiled) write_marginal_wave<D>(p, tile, lane, t0 + i, chain - lane, m, V);
                 else if (live) write_marginal<D>(p, t0 + i, chain, m, V);
             } else if (live)
                 write_marginal<D>(p, t0 + i, chain, m, V);
@@ -1572,6 +1591,12 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
     }
     if (FE && live) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc + lp.value());
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+}
+template <int D, int DY, bool UNI, bool FE, bool FILT = false>
+__global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
+    constexpr bool CAN_TILE = FILT && (D % 2 == 0);
+    __shared__ double2 tile[CAN_TILE ? 64 * (((D + D * D) / 2) | 1) : 1];
+    forward_body<D, DY, UNI, FE, FILT>(p, cb, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, CAN_TILE ? tile : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1651,18 +1676,16 @@ __device__ __forceinline__ void write_marginal_wave(const Params& p, double2* ti
 }
 
 template <int D, int DY, bool UNI, bool FUSED = false>
-__global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
+__device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE>& cb, const long long g, const int lane,
+                                              double2* __restrict__ tile) {   // tile: the wave's output transpose buffer, or null
     static_assert(UNI || !FUSED, "the one-pass schedule exists for shared-model batches only");
     using CL = CstLayout<D, DY>;
     constexpr int NS = Dim<D>::NS;
     constexpr int NP2 = Dim<D>::NP2;
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const long long total = p.n_chains * (long long)p.S;
     // coalesced-store path: every wave holds 64 consecutive chains of ONE segment
     constexpr bool CAN_TILE = (D % 2 == 0);
-    __shared__ double2 tile[CAN_TILE ? 64 * OutTile<CAN_TILE ? D : 2>::STRIDE : 1];
-    const bool tiled = CAN_TILE && (p.n_chains % 64 == 0);
-    const int lane = threadIdx.x;
+    const bool tiled = CAN_TILE && tile != nullptr && (p.n_chains % 64 == 0);
     if (g >= total) return;
     const long long seg = g / p.n_chains;
     const long long chain = g - seg * p.n_chains;
@@ -1834,6 +1857,12 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
     }
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
 }
+template <int D, int DY, bool UNI, bool FUSED = false>
+__global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
+    constexpr bool CAN_TILE = (D % 2 == 0);
+    __shared__ double2 tile[CAN_TILE ? 64 * OutTile<CAN_TILE ? D : 2>::STRIDE : 1];
+    backward_body<D, DY, UNI, FUSED>(p, cb, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, CAN_TILE ? tile : nullptr);
+}
 
 // ------------------------------------------------------------------------------------------
 // Bethe free energy reduction: fe_chain[c] = −Σ_s fe_part[s][c] and the batch total Σ_c fe_chain[c],
@@ -1879,8 +1908,7 @@ static __global__ void __launch_bounds__(256) k_fe_chain(Params p, double* block
 // Few chains (≤ 16): k_fe_chain leaves all but one lane of each wave idle and walks the partials one by one.  Here one
 // workgroup sums the p.S + 1 partials of every chain with all 256 threads (fixed stride and tree shape: deterministic) and
 // finishes with the total — chain and total reduction in a single launch.
-static __global__ void __launch_bounds__(256) k_fe_few(Params p) {
-    __shared__ double sh[256];
+__device__ __forceinline__ void fe_few_body(const Params& p, double* __restrict__ sh) {   // 256 threads, sh[256]
     const int n = p.S + 1;
     double total = 0.0;
     bool bad = false;
@@ -1902,6 +1930,45 @@ static __global__ void __launch_bounds__(256) k_fe_few(Params p) {
     if (threadIdx.x == 0) {
         p.fe_total[p.iteration] = total;
         if (bad) atomicOr(p.status, ST_NONFINITE);
+    }
+}
+static __global__ void __launch_bounds__(256) k_fe_few(Params p) {
+    __shared__ double sh[256];
+    fe_few_body(p, sh);
+}
+
+// ------------------------------------------------------------------------------------------
+// Small problems — a few chains, a short series: BASELINE config 1 and the reference's own benchmark sizes (benchmarks/…ipynb cells 12 / 24,
+// T = 50 … 5000, one chain) — in ONE launch.  The four-phase schedule of such a problem is a latency chain (L steps per phase, S sequential
+// boundary steps) that no kernel boundary shortens; five dependent launches cost more than the arithmetic between them (66 µs per sweep at
+// T = 1000, of which ≈ 25 µs are the gaps).  One workgroup of four wavefronts runs the phases back to back with a workgroup barrier between
+// them; every (chain, segment) pair is one lane, exactly as in the kernels above (same bodies, same arithmetic, bit-identical results):
+//   seg_aggregate_body  all lanes   |  boundary_scan_tab_body  wave 0: prefix role, wave 1: suffix role, lanes = chains
+//   forward_body        all lanes   |  backward_body           all lanes   |  fe_few_body  all 256 threads
+// Needs n_chains · S ≤ 256 and n_chains ≤ 64 (rxhip.hip picks S accordingly), one model, a smoothing run.  LDS: the phases alias one block.
+constexpr int SMALL_SWEEP_THREADS = 256;
+constexpr int SMALL_SWEEP_SCAN_CHUNK = 16;
+template <int D, int DY>
+struct SmallSweepLds {
+    static constexpr int AGG = 4 * 2 * AggStage<D, DY>::NPC;                               // double2 per workgroup: one [2][NPC] block per wave
+    static constexpr int SCAN = 2 * SMALL_SWEEP_SCAN_CHUNK * ScanLayout<D>::SIZE / 2;       // two roles
+    static constexpr int FE = 256 / 2;
+    static constexpr int N = AGG > SCAN ? (AGG > FE ? AGG : FE) : (SCAN > FE ? SCAN : FE);
+};
+template <int D, int DY, bool FE>
+__global__ void __launch_bounds__(SMALL_SWEEP_THREADS) k_small_sweep(Params p, const CstArg<CstLayout<D, DY>::SIZE> cb) {
+    __shared__ double2 lds[SmallSweepLds<D, DY>::N];
+    const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
+    seg_aggregate_body<D, DY, true>(p, cb, tid, lane, lds + w * 2 * AggStage<D, DY>::NPC);
+    __syncthreads();
+    if (w < 2) boundary_scan_tab_body<D, DY, FE, SMALL_SWEEP_SCAN_CHUNK>(p, cb, lane, w, lane, lds + w * (SMALL_SWEEP_SCAN_CHUNK * ScanLayout<D>::SIZE / 2));
+    __syncthreads();
+    forward_body<D, DY, true, FE, false>(p, cb, tid, lane, nullptr);
+    __syncthreads();
+    backward_body<D, DY, true, false>(p, cb, tid, lane, nullptr);
+    if (FE) {
+        __syncthreads();
+        fe_few_body(p, reinterpret_cast<double*>(lds));
     }
 }
 static __global__ void __launch_bounds__(256) k_fe_total(Params p, const double* block_part, int nblocks) {

@@ -1952,6 +1952,20 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             // S* = sqrt(steps · 0.86 / 0.26).  (measured, one chain, d = 2, T = 50 000: 1.18 ms with L = 16, S = 3125.)
             const long long s_lat = (long long)std::ceil(std::sqrt(3.3 * (double)steps));
             if (S_target > s_lat) S_target = s_lat;
+            // a few chains whose lanes fit ONE workgroup run the whole sweep in one launch (k_small_sweep: chains · S ≤ 256, ≤ 64 chains):
+            // take fewer, slightly longer segments for that where it costs at most a few steps of latency
+            const long long cap = e->n_chains <= 64 ? 256 / e->n_chains : 0;
+            if (cap >= 1 && S_target > cap && (steps + cap - 1) / cap <= 32) S_target = cap;
+        }
+        // Batches of one model on the model / data split (below: e->split): the data pass is vectors only, one workgroup per 4·(64/d) chains
+        // of a segment, so the machine fills through MORE segments, and the per-model tables are a recursion over the segment LENGTH
+        // (kt_gains, kt_agg: sequential in L).  Segments of ≈32 steps, at most 128 of them (measured, scripts/time_split_segments.py:
+        // d = 64 × 64 chains × T = 1000: sweep 1.60 -> 1.21 ms and first touch 23 -> 8.5 ms with 32 instead of 8 segments; d = 32 × 256:
+        // 1.25 -> 1.09 ms, 10.6 -> 4.5 ms; d = 8 × 1024: 0.48 -> 0.46 ms).
+        {
+            const char* sp_env = std::getenv("RXHIP_DENSE_SPLIT");
+            const bool split_eligible = dense && !e->gseq && ds->n_models == 1 && (sp_env ? std::atoi(sp_env) != 0 : e->wg_chains >= 4);
+            if (split_eligible && ds->segments <= 0) S_target = std::max(S_target, std::min<long long>(128, (steps + 31) / 32));
         }
         if (S_target < 1) S_target = 1;
         long long L = (steps + S_target - 1) / S_target;
@@ -3161,6 +3175,12 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.fseg = fused ? e->d_fseg : nullptr; p.fe_const = e->fe_const;
     p.fe_scale = filter ? 1.0 / (double)e->T : 1.0;
     const bool fe = want_fe != 0;
+    // k_small_sweep (lgssm_kernels.hpp): the whole four-phase sweep of a small problem in one launch.  Per-kernel profiling keeps the separate
+    // launches (there is nothing to time separately in one kernel); RXHIP_SMALL_SWEEP=0 forces them (the tests compare the two bit for bit).
+    const char* small_env = std::getenv("RXHIP_SMALL_SWEEP");
+    const bool small_off = small_env && std::atoi(small_env) == 0;
+    const bool small_now = !small_off && !e->dense && !fused && !filter && e->uniform && !e->sequential && !e->masked && e->d_scan && e->S > 0 &&
+                           e->n_chains <= 64 && e->n_chains * (long long)e->S <= 256 && !e->profiling;
     rxhip_status st;
     DenseParams dp{};
     if (e->dense && !e->gseq) {
@@ -3250,6 +3270,8 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
             e->vt->forward0(p, e->h_cst0.data(), fe, e->stream);
             if ((st = prof_end(e))) return st;
+        } else if (small_now) {   // a few chains, a short series: aggregate, boundary scan, forward, backward and the free energy in ONE launch
+            e->vt->small_sweep(p, e->h_cst0.data(), fe, e->stream);
         } else if (e->S > 0 && !e->sequential) {
             if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
             e->vt->seg_aggregate(p, e->h_cst0.data(), e->uniform, e->stream);
@@ -3259,13 +3281,13 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             e->vt->seg_elements(p, e->stream);
             if ((st = prof_end(e))) return st;
         }
-        if (!e->dense) {
+        if (!e->dense && !small_now) {
             if ((st = prof_begin(e, RXHIP_K_BOUNDARY_SCAN))) return st;
             if (e->uniform && (e->d_scan || e->S == 0)) e->vt->boundary_scan_tab(p, e->h_cst0.data(), fe, e->stream);
             else e->vt->boundary_scan(p, e->h_cst0.data(), e->uniform, fe, e->stream);
             if ((st = prof_end(e))) return st;
         }
-        if (!e->dense && e->S > 0) {
+        if (!e->dense && e->S > 0 && !small_now) {
             if (!fused) {
                 if ((st = prof_begin(e, RXHIP_K_FORWARD))) return st;
                 e->vt->forward(p, e->h_cst0.data(), e->uniform, fe, e->stream);
@@ -3279,7 +3301,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 if ((st = prof_end(e))) return st;
             }
         }
-        if (fe) {
+        if (fe && !small_now) {
             if ((st = prof_begin(e, RXHIP_K_FE_REDUCE))) return st;
             const int nb = (int)((e->n_chains + 63) / 64);
             Params pr = p;

@@ -101,6 +101,10 @@ struct Launch {
         const long long nb = ((p.T - 1) * p.n_chains + 255) / 256;
         hipLaunchKernelGGL((k_joint<D, DY>), dim3((unsigned)(nb < 8192 ? (nb > 0 ? nb : 1) : 8192)), dim3(256), 0, s, p);
     }
+    static void small_sweep(const Params& p, const double* hc, bool fe, hipStream_t s) {   // n_chains · S ≤ 256, n_chains ≤ 64, one model
+        if (fe) hipLaunchKernelGGL((k_small_sweep<D, DY, true>), dim3(1), dim3(SMALL_SWEEP_THREADS), 0, s, p, carg(hc));
+        else hipLaunchKernelGGL((k_small_sweep<D, DY, false>), dim3(1), dim3(SMALL_SWEEP_THREADS), 0, s, p, carg(hc));
+    }
     static void stream_step(const StreamParams& p, hipStream_t s) {
         hipLaunchKernelGGL((k_stream_step<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
     }
@@ -139,6 +143,7 @@ struct Launch {
         v.predict = &Launch::predict;
         v.joint = &Launch::joint;
         v.stream_step = &Launch::stream_step;
+        v.small_sweep = &Launch::small_sweep;
         return v;
     }
 };

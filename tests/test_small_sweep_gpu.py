@@ -1,0 +1,68 @@
+"""Small problems in one launch (k_small_sweep, csrc/lgssm_kernels.hpp): the four phases of the sweep and the free-energy reduction of a few
+short chains run back to back in one workgroup.  Same bodies as the separate kernels, so the results must be BIT-identical to the five-launch
+schedule (RXHIP_SMALL_SWEEP=0), and both must match the oracle.  Reference shape: benchmarks/Linear Multivariate Gaussian State Space Model
+Benchmark.ipynb cells 12 / 24 (one chain, T = 50 … 5000) and BASELINE config 1 (d = 4, T = 1000)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rxinfer.jl_amd"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(mdl, y, ptt, fused, monkeypatch, fe=True, iterations=1):
+    import rxhip
+    monkeypatch.setenv("RXHIP_SMALL_SWEEP", "1" if fused else "0")
+    T, C = y.shape[0], y.shape[1]
+    with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C, prior_through_transition=ptt) as eng:
+        eng.set_data(y)
+        eng.run(iterations, fe)
+        mean, cov = eng.marginals()
+        return mean, cov, (eng.free_energy_per_chain() if fe else None), (eng.free_energy() if fe else None), eng.schedule()
+
+
+@pytest.mark.parametrize("d,dy,T,C,ptt", [(4, 4, 1000, 1, False), (2, 2, 50, 1, False), (2, 2, 5000, 1, True), (4, 4, 257, 3, False), (3, 2, 400, 8, True),
+                                           (1, 1, 90, 2, False), (4, 1, 130, 5, False), (1, 4, 77, 4, True), (2, 3, 10000, 1, False), (4, 4, 9, 16, False),
+                                           (3, 3, 3, 2, False), (4, 4, 64, 64, True)])
+def test_one_launch_equals_five_and_the_oracle(d, dy, T, C, ptt, monkeypatch):
+    import rxoracle as rxo
+    from rxhip import workloads
+    mdl = workloads.random_model(d, dy, seed=900 + 10 * d + dy) if (d, dy) != (4, 4) else workloads.c1_model()
+    y = workloads.generate_batch(mdl, T, C, seed0=21)
+    m1, c1, f1, t1, sched = _run(mdl, y, ptt, True, monkeypatch, iterations=2)
+    m0, c0, f0, t0, _ = _run(mdl, y, ptt, False, monkeypatch, iterations=2)
+    assert C * sched["segments"] <= 256, sched          # the shape the one-launch schedule takes (rxhip.hip caps S for it at these sizes)
+    assert np.array_equal(m1, m0) and np.array_equal(c1, c0) and np.array_equal(f1, f0) and np.array_equal(t1, t0)
+    for c in range(C):
+        yc = np.ascontiguousarray(y[:, c])
+        if d == dy:    # the reference message schedule (its observation message in moment form needs dy = d), else the smoother it is pinned to
+            om, oc, ofe, _ = rxo.lgssm_bp(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], yc, prior_through_transition=ptt)
+        else:
+            om, oc, ofe = rxo.lgssm_kalman_rts(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], yc, prior_through_transition=ptt)
+        sd = np.sqrt(np.einsum("tii->ti", oc))
+        assert np.max(np.abs(m1[:, c] - om) / sd) < 1e-6 and np.max(np.abs(c1[:, c] - oc) / (sd[:, :, None] * sd[:, None, :])) < 1e-6
+        assert f1[c] == pytest.approx(ofe, rel=1e-8)
+
+
+def test_without_free_energy_and_through_infer(monkeypatch):
+    import rxhip
+    from rxhip import workloads
+    mdl = workloads.c1_model()
+    _, y = workloads.generate_chain(mdl, 1000, 42)
+    yb = y[:, None, :]
+    m1, c1, _, _, _ = _run(mdl, yb, False, True, monkeypatch, fe=False)
+    m0, c0, _, _, _ = _run(mdl, yb, False, False, monkeypatch, fe=False)
+    assert np.array_equal(m1, m0) and np.array_equal(c1, c0)
+    spec = rxhip.linear_gaussian_ssm(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    res = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("RXHIP_SMALL_SWEEP", fused)
+        r = rxhip.infer(model=spec, data={"y": y}, free_energy=True)
+        res[fused] = (r.posteriors["x"].mean, r.posteriors["x"].cov, r.free_energy[-1])
+    assert np.array_equal(res["1"][0], res["0"][0]) and np.array_equal(res["1"][1], res["0"][1]) and res["1"][2] == res["0"][2]
+    assert np.array_equal(res["1"][0], m1[:, 0])
