@@ -134,6 +134,7 @@ struct DenseParams {
     int model_sel;
     long long oW_off;     // DenseCst::oW (km_filter_out reads the constant block through MsegParams)
     long long chain0;     // first workgroup chain of this launch: a grid dimension holds 65 535 blocks, larger batches are launched in slices
+    int wave8;            // masked schedule, one segment per chain, d ≤ 8: the sweep inside one wavefront per chain (dense8_kernels.hpp)
 };
 struct DenseModel {
     const double *cst, *tab, *scanm, *qtab;

@@ -18,6 +18,7 @@
 #include "dense_tab_kernels.hpp"
 #include "dense_mseg_kernels.hpp"
 #include "dense_split_kernels.hpp"
+#include "dense8_kernels.hpp"
 #endif
 
 namespace rxhip {

@@ -1945,7 +1945,8 @@ static __global__ void __launch_bounds__(256) k_fe_few(Params p) {
 // them; every (chain, segment) pair is one lane, exactly as in the kernels above (same bodies, same arithmetic, bit-identical results):
 //   seg_aggregate_body  all lanes   |  boundary_scan_tab_body  wave 0: prefix role, wave 1: suffix role, lanes = chains
 //   forward_body        all lanes   |  backward_body           all lanes   |  fe_few_body  all 256 threads
-// Needs n_chains · S ≤ 256 and n_chains ≤ 64 (rxhip.hip picks S accordingly), one model, a smoothing run.  LDS: the phases alias one block.
+// Needs n_chains · S ≤ 256 and n_chains ≤ 16 (the reduction of k_fe_few; rxhip.hip picks S accordingly), one model, a smoothing run.
+// LDS: the phases alias one block.
 constexpr int SMALL_SWEEP_THREADS = 256;
 constexpr int SMALL_SWEEP_SCAN_CHUNK = 16;
 template <int D, int DY>

@@ -247,6 +247,7 @@ struct rxhip_engine {
     uint64_t rule_calls = 0, products = 0, marginals = 0;
     // profiling
     bool profiling = false;
+    bool m_wave8_last = false;   // the last masked sweep ran on the in-wave d ≤ 8 kernels
     struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
@@ -1050,6 +1051,8 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     };
     {
         const double c_e = 10.0 + f * 22.0, c_f = 5.7 + f * 21.0;   // fused element step (32 µs at d = 64 with every CU busy), forward + backward sweep step
+        const char* w8_env = std::getenv("RXHIP_WAVE8");
+        const bool w8_ok = e->m_nt == 1 && e->d <= 8 && !stepm && !chainm && !(w8_env && std::atoi(w8_env) == 0);
         auto cost = [&](long long s_asked) {
             // (the segments that s_asked turns into once the segment length is an integer: ⌈(T − 1) / L⌉ of length L = ⌈(T − 1) / s_asked⌉)
             const long long Lq = ((long long)T - 1 + s_asked - 1) / s_asked, s = ((long long)T - 1 + Lq - 1) / Lq;
@@ -1065,6 +1068,9 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
                 if (lg < scan || scan_mode == 2) scan = lg;
             }
             const double share = e->m_nt >= 3 && (double)C * (double)s > 0.5 * conc ? 1.3 : 1.0;   // d ≥ 48: two workgroups on a CU step 1.3× slower than one (narrower ones: measured neutral)
+            // one segment per chain at d ≤ 8 runs inside one wavefront per chain (dense8_kernels.hpp): 1.1 + 0.75 µs per step measured with
+            // one wavefront per SIMD (1024 chains), ≈ 1.4 µs per step and 1024 chains beyond that
+            if (s == 1 && w8_ok) return (double)C <= 1024.0 ? steps * 1.85 : ((double)C / 1024.0) * steps * 1.4;
             return rounds * steps * share * ((s > 1 ? c_e : 0.0) + c_f) + scan;
         };
         double best = 0.7 * cost(1);   // (the interpolated element costs are optimistic between d = 16 and 64: leave one segment only for a clear win)
@@ -1211,6 +1217,14 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe, bool filter) {
     dp.obs = e->m_obs; dp.nobs = e->m_nobs; dp.mbnd = e->m_bnd;
     dp.step_model = mp.step_model; dp.cst_stride = clm.size; dp.fe_const = e->m_feconst; dp.model_sel = 0; dp.oW_off = clm.oW;
     if (e->m_chainm) { dp.models = e->m_modtab; dp.chain_model = e->d_chain_model; }   // the sweep kernels' own per-chain lookup (dense_model)
+    // chains that run as ONE segment (they fill the chip on their own) at d ≤ 8: the sweep inside one wavefront per chain
+    // (dense8_kernels.hpp; smoothing runs of one model; RXHIP_WAVE8=0: the MFMA kernels, which stay the checker)
+    {
+        const char* w8 = std::getenv("RXHIP_WAVE8");
+        dp.wave8 = (e->mS == 1 && e->m_nt == 1 && e->d <= 8 && !e->m_stepm && !e->m_chainm && !filter && !(w8 && std::atoi(w8) == 0)) ? 1 : 0;
+        e->m_wave8_last = dp.wave8 != 0;
+        if (dp.wave8) mp.rec = K8_REC;   // km_gy writes B′Q⁻¹y_t into the records the in-wave kernels read
+    }
     rxhip_status st;
     if ((st = prof_begin(e, RXHIP_K_SEG_AGGREGATE))) return st;
     dense_vt(e->m_nt)->mseg_sweep(mp, dp, fe, filter, e->stream);
@@ -1954,7 +1968,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             if (S_target > s_lat) S_target = s_lat;
             // a few chains whose lanes fit ONE workgroup run the whole sweep in one launch (k_small_sweep: chains · S ≤ 256, ≤ 64 chains):
             // take fewer, slightly longer segments for that where it costs at most a few steps of latency
-            const long long cap = e->n_chains <= 64 ? 256 / e->n_chains : 0;
+            const long long cap = e->n_chains <= 16 ? 256 / e->n_chains : 0;
             if (cap >= 1 && S_target > cap && (steps + cap - 1) / cap <= 32) S_target = cap;
         }
         // Batches of one model on the model / data split (below: e->split): the data pass is vectors only, one workgroup per 4·(64/d) chains
@@ -3180,7 +3194,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     const char* small_env = std::getenv("RXHIP_SMALL_SWEEP");
     const bool small_off = small_env && std::atoi(small_env) == 0;
     const bool small_now = !small_off && !e->dense && !fused && !filter && e->uniform && !e->sequential && !e->masked && e->d_scan && e->S > 0 &&
-                           e->n_chains <= 64 && e->n_chains * (long long)e->S <= 256 && !e->profiling;
+                           e->n_chains <= 16 && e->n_chains * (long long)e->S <= 256 && !e->profiling;   // (≤ 16 chains: the free-energy reduction of k_fe_few)
     rxhip_status st;
     DenseParams dp{};
     if (e->dense && !e->gseq) {
@@ -3201,7 +3215,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         const bool mseg_now = e->gseq && e->mseg && !(filter && std::getenv("RXHIP_FILTER_GSEQ"));
         if (mseg_now) {
             if ((st = mseg_run(e, fe, filter))) return st;
-            e->records_hold_gains = !filter;
+            e->records_hold_gains = !filter && !e->m_wave8_last;   // (the in-wave d ≤ 8 sweep keeps records of its own shape)
         } else if (e->gseq) {
             GseqParams gq{};
             gq.T = e->T; gq.n_chains = e->n_chains; gq.d = e->d; gq.dy = e->dy; gq.ptt = e->ptt; gq.fe = fe ? 1 : 0; gq.y = e->d_y;

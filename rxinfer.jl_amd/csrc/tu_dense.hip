@@ -211,6 +211,26 @@ static void mseg_launch(const MsegParams& mp_all, const DenseParams& dp_all, boo
         } else
             hipLaunchKernelGGL((km_scan<NT>), dim3(2, nc), dim3(64 * NT), lds, s, mp, 0);
         if (mp.S > 1) hipLaunchKernelGGL((km_bnd<NT>), dim3((unsigned)(mp.S - 1), nc), dim3(64 * NT), sizeof(double) * blk_scratch_doubles(NT), s, mp);
+        if constexpr (NT == 1) if (dp.wave8) {   // one segment per chain, d ≤ 8, one model: the sweep inside a wavefront (dense8_kernels.hpp)
+            // two chains per wavefront where the chip is oversubscribed anyway (≥ 4 wavefronts per SIMD: 5.9 against 6.2 ms at 4096 chains × T = 1000);
+            // a batch that gives every SIMD at most one wavefront is faster with one chain each (1024 chains: 2.3 against 3.1 ms)
+            const bool two = nc % 2 == 0 && nc >= 4096;
+            const dim3 g8(two ? nc / 2 : nc);
+            if (fe && two) {
+                hipLaunchKernelGGL((k8_forward<true, 2>), g8, dim3(64), 0, s, dp);
+                hipLaunchKernelGGL((k8_backward<true, 2>), g8, dim3(64), 0, s, dp);
+            } else if (fe) {
+                hipLaunchKernelGGL((k8_forward<true, 1>), g8, dim3(64), 0, s, dp);
+                hipLaunchKernelGGL((k8_backward<true, 1>), g8, dim3(64), 0, s, dp);
+            } else if (two) {
+                hipLaunchKernelGGL((k8_forward<false, 2>), g8, dim3(64), 0, s, dp);
+                hipLaunchKernelGGL((k8_backward<false, 2>), g8, dim3(64), 0, s, dp);
+            } else {
+                hipLaunchKernelGGL((k8_forward<false, 1>), g8, dim3(64), 0, s, dp);
+                hipLaunchKernelGGL((k8_backward<false, 1>), g8, dim3(64), 0, s, dp);
+            }
+            return;
+        }
         if (mp.step_model) {
             if (fe) hipLaunchKernelGGL(km_feconst, dim3(nc), dim3(256), 0, s, mp);   // reads the mask of this slice
             DenseLaunchNT::forward_info_stepm(dp, fe, s, nc);
