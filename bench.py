@@ -302,6 +302,53 @@ def extra_c3(device, parity=True):
             "create_note": "a model no engine of the process has seen: tables built on the device (csrc/dense_tab_kernels.hpp)"}
 
 
+def extra_noise_vmp(device, parity=True):
+    """Not a BASELINE config — the first composed graph: the benchmark chain with an unknown observation-noise precision,
+    W ~ Wishart, q(x, W) = q(x) q(W): d = dy = 4, 1024 chains × T = 10⁴, 10 VMP iterations (one BP sweep of every chain + every chain's Wishart
+    update per iteration, all on the device), with the free energy per iteration.  Here a VMP iteration is NOT an idempotent sweep."""
+    mdl = workloads.c1_model()
+    T, C, iters, dy = 10000, 1024, 10, 4
+    y = workloads.generate_batch(mdl, T, C, seed0=4242, threads=min(32, os.cpu_count() or 1))
+    nu0, S0 = dy + 1.0, np.eye(dy)
+    eng = rxhip.LGSSMNoiseEngine(mdl["A"], mdl["B"], mdl["P"], mdl["m0"], mdl["V0"], T, nu0, S0, n_chains=C, device=device)
+    eng.set_data(y)
+    eng.run(iters, True)
+    ms = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter()
+        eng.run_async(iters, True)
+        eng.sync()
+        ms = min(ms, (time.perf_counter() - t0) * 1e3)
+    fe = eng.free_energy()
+    spot = None
+    if parity:
+        chains = [0, C - 1]
+        mean, cov = eng.marginals_of_chains(chains)
+        fec = eng.free_energy_per_chain()
+        nu, V = eng.noise_posterior()
+
+        def check():
+            rxo = _oracle()
+            out = {"chains": chains, "mean_rel": 0.0, "cov_rel": 0.0, "fe_rel": 0.0, "w_rel": 0.0}
+            for i, c in enumerate(chains):
+                om, oc, wh, ofe = rxo.lgssm_noise_vmp(mdl["A"], mdl["B"], mdl["P"], mdl["m0"], mdl["V0"], np.ascontiguousarray(y[:, c]), nu0, S0, nu0, S0, iters)
+                sd = np.sqrt(np.einsum("tii->ti", oc))
+                out["mean_rel"] = max(out["mean_rel"], float(np.max(np.abs(mean[i] - om) / sd)))
+                out["cov_rel"] = max(out["cov_rel"], float(np.max(np.abs(cov[i] - oc) / np.max(np.abs(oc), axis=(1, 2), keepdims=True))))
+                out["fe_rel"] = max(out["fe_rel"], float(abs(fec[c] - ofe[-1]) / abs(ofe[-1])))
+                out["w_rel"] = max(out["w_rel"], float(np.max(np.abs(V[c] - wh[-1, 1:].reshape(dy, dy)) / np.max(np.abs(wh[-1, 1:])))))
+            out["ok"] = bool(out["mean_rel"] < 1e-6 and out["cov_rel"] < 1e-6 and out["fe_rel"] < 1e-8 and out["w_rel"] < 1e-8)
+            return out
+
+        spot = Background(check)
+    eng.close()
+    return {"workload": f"LGSSM d=4 dy=4 T={T}, {C} chains, unknown observation-noise precision W ~ Wishart({nu0:g}, I), q(x, W) = q(x)q(W): {iters} VMP iterations "
+                        "(BP sweep + Wishart update per chain and iteration) with the Bethe free energy per iteration",
+            "ms_per_iteration": ms / iters, "vmp_iters_per_sec": iters / (ms * 1e-3), "rule_calls_per_s": (6 * T - 3) * C * iters / (ms * 1e-3),
+            "free_energy_first_last": [float(fe[0]), float(fe[-1])], "free_energy_monotone": bool(np.all(np.diff(fe) <= 1e-9 * np.abs(fe[:-1]))),
+            "timing": timing_mode(2), "parity_spot": spot}
+
+
 def extra_masked(device):
     """Not BASELINE configs: `missing` observations and per-step constants at d = 64 on the masked MFMA schedule
     (csrc/dense_mseg_kernels.hpp) next to the fully observed sweep of the same chain — median of five sweeps each
@@ -786,7 +833,7 @@ def main(argv=None, engine_cls=None, gpu_cls=_Gpu):
         for name, fn in (("per_chain_models", lambda: extra_per_chain_models(mdl, T, C, y, local_rank, yh)), ("c1", lambda: extra_c1(local_rank, not args.no_cpu_baseline)),
                          ("c2_missing", lambda: extra_missing(mdl, T, C, y, local_rank, yh)), ("c3", lambda: extra_c3(local_rank, par)),
                          ("c4", lambda: extra_c4(local_rank, par)), ("c5", lambda: extra_c5(local_rank, par)), ("mid_sizes", lambda: extra_mid(local_rank)),
-                         ("masked_mfma", lambda: extra_masked(local_rank))):
+                         ("masked_mfma", lambda: extra_masked(local_rank)), ("lgssm_noise_vmp", lambda: extra_noise_vmp(local_rank, par))):
             try:
                 extra[name] = fn()
             except Exception as e:  # noqa: BLE001 — an extra line must never cost the headline line

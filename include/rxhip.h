@@ -135,6 +135,28 @@ rxhip_status rxhip_lgssm_set_chain_offsets(rxhip_engine* e, const double* state_
  * src/model/plugins/reactivemp_inference.jl:272-326) for the LGSSM family */
 rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* desc, rxhip_engine** out);
 
+/* The first COMPOSED graph: the state-space chain above with an UNKNOWN observation-noise precision,
+ *     W ~ Wishart(nu0, S0);   y[t] ~ MvNormal(μ = B * x[t], Λ = W);   q(x[1..T], W) = q(x[1..T]) q(W)      (dy = 1: Gamma(ν/2, 1/(2 S0)))
+ * — the chain of test/models/statespace/mlgssm_test.jl:9-14 with the observation nodes precision-parametrised and the node pair of
+ * test/models/iid/mv_iid_precision_tests.jl:11-15 on W; mean-field factorisation as `@constraints q(x, W) = q(x)q(W)` asks for
+ * (reactivemp_inference.jl:499-501).  replaces: the VMP iteration of src/inference/batch.jl:391-430 over that graph — per iteration ONE
+ * belief-propagation sweep of every chain with its own Q⁻¹ = E[W] (MvNormalMeanPrecision(:μ) with q(Λ)), then the Wishart update of every
+ * chain from the sweep's residual second moments (MvNormalMeanPrecision(:Λ), product with the prior), both on the device; the Bethe free
+ * energy of the iteration's marginals per iteration (csrc/noise_kernels.hpp).  Every chain of the batch is its own graph with its own W.
+ * desc: as for rxhip_lgssm_create with ONE model, d, dy ≤ 4, no horizon / allow_missing / step_model / offsets (RXHIP_ERR_UNSUPPORTED);
+ * desc->Q is ignored (may be NULL).  init_nu, init_V: the `@initialization` marginal q(W) = Wishart(init_nu, init_V).
+ * rxhip_run(iterations, want_fe), rxhip_get_marginals (q(x[t]) of the last iteration), rxhip_get_free_energy (per iteration, summed over
+ * the chains), rxhip_get_free_energy_per_chain (last iteration) as for every engine; rxhip_lgssm_noise_get: q(W) of every chain after the
+ * last iteration — nu [n_chains], V [n_chains][dy][dy] (either may be NULL). */
+typedef struct {
+    double nu0;        /* prior Wishart(nu0, S0) */
+    const double* S0;  /* [dy][dy] */
+    double init_nu;    /* initial marginal q(W) = Wishart(init_nu, init_V) */
+    const double* init_V;
+} rxhip_noise_prior;
+rxhip_status rxhip_lgssm_noise_create(const rxhip_lgssm_desc* desc, const rxhip_noise_prior* prior, rxhip_engine** out);
+rxhip_status rxhip_lgssm_noise_get(rxhip_engine* e, double* nu, double* V);
+
 /* ------------------------------------------------------------------------------------------
  * Generic factor-graph descriptor — the struct-of-arrays dump of a materialised GraphPPL model, i.e. what
  * GraphPPL.postprocess_plugin(::ReactiveMPInferencePlugin, model) iterates over

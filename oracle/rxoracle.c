@@ -1387,6 +1387,97 @@ done:
     return rc;
 }
 
+/* ------------------------------------------------------------------------------------------
+ * A state-space chain whose observation-noise precision is unknown — the first COMPOSED graph: the chain of
+ * test/models/statespace/mlgssm_test.jl:9-14 with the observation nodes in the precision parametrisation and a Wishart prior on it
+ * (the node pair of test/models/iid/mv_iid_precision_tests.jl:11-15):
+ *     x[1] ~ MvNormal(μ = m0, Σ = V0);  x[t] ~ MvNormal(μ = A x[t-1], Σ = P);  W ~ Wishart(ν0, S0);  y[t] ~ MvNormal(μ = B x[t], Λ = W)
+ * with q(x[1..T], W) = q(x[1..T]) q(W) (`@constraints`; the factorisation handling of reactivemp_inference.jl:499-501).  Mean-field VMP:
+ *   q(x)   the MvNormalMeanPrecision(:μ) messages toward B x[t] carry E[W] = νV (ExponentialFamily mean of a Wishart), everything else on
+ *          the chain is sum-product: the smoother of the Gaussian chain with Q = E[W]⁻¹ (rxo_lgssm_kalman_rts, pinned to rxo_lgssm_bp);
+ *   q(W)   MvNormalMeanPrecision(:Λ) sends Wishart(dy + 2, E[(y−Bx)(y−Bx)′]⁻¹) per observation; the product with the prior in natural
+ *          parameters: ν = ν0 + T, V⁻¹ = S0⁻¹ + Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′];
+ *   order  per iteration q(x) with the previous q(W), then q(W) with the new q(x) (the order rxo_mvgmm_vmp assumes for q(m), q(w));
+ *   F      Bethe free energy of the iteration's marginals.  With Ŵ_old = E_old[W] the chain's own terms are the Gaussian model's evidence
+ *          −log p̃(y | Q = Ŵ_old⁻¹) minus the observation nodes' energies in that model; adding the observation nodes' average energies under
+ *          the new q(W) and the Wishart prior node's energy minus H[q(W)] gives
+ *              F = −log p̃(y) + T/2 (log|Ŵ_old| − E_new log|W|) + ½ tr((Ŵ_new − Ŵ_old) Σ_t E[r_t r_t′]) + KL(q_new(W) ‖ p(W)).
+ * In the limit A = I, P → 0, B = I the chain is the iid model with unknown mean: tests/test_oracle.py checks this function against
+ * rxo_mvgmm_vmp (K = 1) there, free energy included.  w_hist: [iterations][1 + dy·dy] = ν | V; fe: [iterations] (nullable).
+ * Test infrastructure: the checker of rxhip_lgssm_noise_create.
+ * ------------------------------------------------------------------------------------------ */
+int rxo_lgssm_noise_vmp(int d, int dy, int T, const double* A, const double* B, const double* P, const double* m0, const double* V0,
+                        int ptt, const double* y, double nu0, const double* S0, double init_nu, const double* init_V, int iterations,
+                        double* post_mean, double* post_cov, double* w_hist, double* fe) {
+    if (d <= 0 || dy <= 0 || T <= 0 || iterations <= 0 || !(nu0 > dy - 1.0) || !(init_nu > dy - 1.0)) return RXO_ERR_BADARG;
+    const double LOG2 = 0.69314718055994530942;
+    const size_t qq = (size_t)dy * dy;
+    double* w = (double*)calloc(8 * qq + 2 * (size_t)dy * d + 4 * (size_t)(dy > d ? dy : d) * (dy > d ? dy : d) + 2 * (size_t)dy, sizeof(double));
+    if (!w) return RXO_ERR_BADARG;
+    double *V = w, *What = V + qq, *Q = What + qq, *S = Q + qq, *S0i = S + qq, *Vn = S0i + qq, *Wn = Vn + qq, *tmp = Wn + qq,
+           *BV = tmp + qq, *r = BV + (size_t)dy * d, *chw = r + 2 * dy;
+    int rc = RXO_OK;
+    double ldS0, nu = init_nu;
+    memcpy(V, init_V, sizeof(double) * qq);
+    if ((rc = cholinv(dy, S0, S0i, &ldS0, chw))) goto done;   /* ldS0 = log|S0| */
+    for (int it = 0; it < iterations; ++it) {
+        double ldW, nll = 0.0;
+        for (size_t i = 0; i < qq; ++i) What[i] = nu * V[i];
+        if ((rc = cholinv(dy, What, Q, &ldW, chw))) goto done;   /* Q = E[W]⁻¹, ldW = log|Ŵ_old| */
+        if ((rc = rxo_lgssm_kalman_rts(d, dy, T, A, B, P, Q, m0, V0, ptt, y, post_mean, post_cov, &nll))) goto done;
+        memset(S, 0, sizeof(double) * qq);
+        for (int t = 0; t < T; ++t) {
+            const double *m = post_mean + (size_t)t * d, *C = post_cov + (size_t)t * d * d;
+            for (int a = 0; a < dy; ++a) {
+                double sm = y[(size_t)t * dy + a];
+                for (int k = 0; k < d; ++k) sm -= B[a * d + k] * m[k];
+                r[a] = sm;
+                for (int k = 0; k < d; ++k) {
+                    double sv = 0.0;
+                    for (int l = 0; l < d; ++l) sv += B[a * d + l] * C[l * d + k];
+                    BV[a * d + k] = sv;
+                }
+            }
+            for (int a = 0; a < dy; ++a)
+                for (int b = 0; b < dy; ++b) {
+                    double sv = r[a] * r[b];
+                    for (int k = 0; k < d; ++k) sv += BV[a * d + k] * B[b * d + k];
+                    S[a * dy + b] += sv;
+                }
+        }
+        for (size_t i = 0; i < qq; ++i) tmp[i] = S0i[i] + 0.5 * (S[i] + S[(i % dy) * dy + i / dy]);
+        double ldVi;
+        if ((rc = cholinv(dy, tmp, Vn, &ldVi, chw))) goto done;   /* V_new, ldVi = log|V_new⁻¹| */
+        const double nun = nu0 + (double)T, ldV = -ldVi;
+        for (size_t i = 0; i < qq; ++i) Wn[i] = nun * Vn[i];
+        if (w_hist) {
+            w_hist[(size_t)it * (1 + qq)] = nun;
+            memcpy(w_hist + (size_t)it * (1 + qq) + 1, Vn, sizeof(double) * qq);
+        }
+        if (fe) {
+            const double Elw = mvdigamma_(0.5 * nun, dy) + dy * LOG2 + ldV;
+            double trdS = 0.0, trS0W = 0.0;
+            for (int a = 0; a < dy; ++a)
+                for (int b = 0; b < dy; ++b) {
+                    trdS += (Wn[a * dy + b] - What[a * dy + b]) * S[b * dy + a];
+                    trS0W += S0i[a * dy + b] * Wn[b * dy + a];
+                }
+            double F = nll + 0.5 * (double)T * (ldW - Elw) + 0.5 * trdS;
+            /* Wishart prior node of W minus H[q(W)] (the lines of rxo_mvgmm_vmp) */
+            F += -(0.5 * (nu0 - dy - 1.0) * Elw - 0.5 * trS0W - 0.5 * nu0 * dy * LOG2 - 0.5 * nu0 * ldS0 - mvlgamma_(0.5 * nu0, dy));
+            F -= 0.5 * (dy + 1.0) * ldV + 0.5 * dy * (dy + 1.0) * LOG2 + mvlgamma_(0.5 * nun, dy) - 0.5 * (nun - dy - 1.0) * mvdigamma_(0.5 * nun, dy) +
+                 0.5 * nun * dy;
+            fe[it] = F;
+            if (!isfinite(F)) { rc = RXO_ERR_NONFINITE_FE; goto done; }
+        }
+        nu = nun;
+        memcpy(V, Vn, sizeof(double) * qq);
+    }
+done:
+    free(w);
+    return rc;
+}
+
 /* ==========================================================================================
  * Hierarchical Gaussian filter (GCV node) — see rxoracle.h for the model, provenance and assumptions.
  * ========================================================================================== */

@@ -162,6 +162,13 @@ int rxo_gmm_accumulate(long long N, int K, const double* y, const double* state,
 int rxo_gmm_update(int K, const double* mu0, const double* v0, const double* a0, const double* b0, const double* alpha0,
                    const double* stats, double* state, double* fe, rxo_counters* counters);
 
+/* LGSSM with an unknown observation-noise precision, W ~ Wishart(nu0, S0), y[t] ~ MvNormal(μ = B x[t], Λ = W), q(x, W) = q(x) q(W):
+ * mean-field VMP, see rxoracle.c.  post_mean [T][d], post_cov [T][d][d] of the last iteration; w_hist [iterations][1 + dy·dy] (ν | V,
+ * nullable); fe [iterations] (nullable).  Checker of rxhip_lgssm_noise_create. */
+int rxo_lgssm_noise_vmp(int d, int dy, int T, const double* A, const double* B, const double* P, const double* m0, const double* V0,
+                        int prior_through_transition, const double* y, double nu0, const double* S0, double init_nu, const double* init_V,
+                        int iterations, double* post_mean, double* post_cov, double* w_hist, double* fe);
+
 /*
  * Multivariate Gaussian mixture, mean-field VMP (test/models/mixtures/gmm_multivariate_tests.jl:6-32):
  *     m[k] ~ MvNormal(mean = mu0[k], cov = S0[k]);  w[k] ~ Wishart(nu0[k], V0[k]);  s ~ Dirichlet(alpha0);

@@ -222,6 +222,24 @@ def lgssm_bp_batch(A, B, P, Q, m0, V0, y, prior_through_transition=False, free_e
     return mean, cov, fe, cnt
 
 
+def lgssm_noise_vmp(A, B, P, m0, V0, y, nu0, S0, init_nu, init_V, iterations, prior_through_transition=False):
+    """LGSSM with unknown observation-noise precision W ~ Wishart(nu0, S0), q(x, W) = q(x) q(W) (rxo_lgssm_noise_vmp), one chain.
+    y: [T][dy].  Returns mean [T,d], cov [T,d,d] (last iteration), w_hist [it, 1 + dy²] (ν | V), fe [it]."""
+    A, B, P, m0, V0, y, S0, init_V = map(_c, (A, B, P, m0, V0, y, S0, init_V))
+    d, dy, T = A.shape[0], B.shape[0], y.shape[0]
+    mean, cov = np.empty((T, d)), np.empty((T, d, d))
+    wh, fe = np.empty((iterations, 1 + dy * dy)), np.empty(iterations)
+    L = lib()
+    L.rxo_lgssm_noise_vmp.restype = ctypes.c_int
+    dp = ctypes.POINTER(ctypes.c_double)
+    L.rxo_lgssm_noise_vmp.argtypes = [ctypes.c_int] * 3 + [dp] * 5 + [ctypes.c_int, dp, ctypes.c_double, dp, ctypes.c_double, dp, ctypes.c_int, dp, dp, dp, dp]
+    rc = L.rxo_lgssm_noise_vmp(d, dy, T, _p(A), _p(B), _p(P), _p(m0), _p(V0), int(prior_through_transition), _p(y), float(nu0), _p(S0),
+                               float(init_nu), _p(init_V), int(iterations), _p(mean), _p(cov), _p(wh), _p(fe))
+    if rc:
+        raise RuntimeError(f"rxo_lgssm_noise_vmp failed with status {rc}")
+    return mean, cov, wh, fe
+
+
 def gmm_vmp(y, mu0, v0, a0, b0, alpha0, init_m_mean, init_m_var, init_p_shape, init_p_rate, init_s_alpha, iterations,
             want_resp=False):
     """Univariate GMM mean-field VMP (see rxoracle.h).  Returns hist [it,5,K], fe [it], resp [N,K]|None, Counters."""

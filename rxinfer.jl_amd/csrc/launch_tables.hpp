@@ -13,6 +13,7 @@
 
 #include "lgssm_kernels.hpp"
 #include "predict_kernels.hpp"
+#include "noise_kernels.hpp"
 #ifndef RXHIP_LAUNCH_LGSSM_ONLY   // tu_lgssm.hip: the d ≤ 4 units do not parse the MFMA headers
 #include "dense_kernels.hpp"
 #include "dense_tab_kernels.hpp"
@@ -52,6 +53,10 @@ struct LgssmVtbl {
     void (*joint)(const PredictParams&, hipStream_t);
     void (*stream_step)(const StreamParams&, hipStream_t);
     void (*small_sweep)(const Params&, const double*, bool, hipStream_t);   // the four phases + free energy in ONE launch (k_small_sweep)
+    // unknown observation-noise precision (noise_kernels.hpp): q(W) ← initial marginal / the Wishart update after a sweep
+    int noise_prior_size;
+    void (*noise_reset)(const NoiseParams&, hipStream_t);
+    void (*noise_update)(const NoiseParams&, hipStream_t);
 };
 // tu_lgssm.hip, one definition per state dimension: fills out[0..3] (dy = 1…4)
 void lgssm_vtbls_d1(LgssmVtbl* out);

@@ -193,7 +193,7 @@ __global__ void __launch_bounds__(256) k_mvg_pass(MvgParams p) {
     for (int q = threadIdx.x; q < NQ; q += 256) p.partial[(size_t)blockIdx.x * NQ + q] = ((sh[0][q] + sh[1][q]) + sh[2][q]) + sh[3][q];
 }
 
-__global__ void __launch_bounds__(256) k_mvg_reduce(MvgParams p, int nq) {
+static __global__ void __launch_bounds__(256) k_mvg_reduce(MvgParams p, int nq) {
     __shared__ double sh[256];
     const int q = blockIdx.x;  // one workgroup per statistic
     double s = 0.0;

@@ -248,6 +248,11 @@ struct rxhip_engine {
     // profiling
     bool profiling = false;
     bool m_wave8_last = false;   // the last masked sweep ran on the in-wave d ≤ 8 kernels
+    // unknown observation-noise precision (rxhip_lgssm_noise_create, noise_kernels.hpp): one block B | prior | state | history
+    bool noise = false;
+    char* noise_block = nullptr;
+    double *n_B = nullptr, *n_prior = nullptr, *n_state = nullptr, *n_hist = nullptr;
+    int n_hist_cap = 0;
     struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
@@ -1688,6 +1693,8 @@ static void free_all(rxhip_engine* e) {
         if (*b) { if (!e->in_arena(*b)) (void)hipFree(*b); *b = nullptr; }
     if (e->d_coll) { (void)hipFree(e->d_coll); e->d_coll = nullptr; }
     if (e->mseg_block) { (void)hipFree(e->mseg_block); e->mseg_block = nullptr; }
+    if (e->noise_block) { (void)hipFree(e->noise_block); e->noise_block = nullptr; }
+    if (e->n_hist) { (void)hipFree(e->n_hist); e->n_hist = nullptr; }
     if (e->d_bq) { (void)hipFree(e->d_bq); e->d_bq = nullptr; }
     if (e->d_stream) { (void)hipFree(e->d_stream); e->d_stream = nullptr; }
     if (e->h_stream) { (void)hipHostFree(e->h_stream); e->h_stream = nullptr; }
@@ -2294,7 +2301,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         }
     }
     ap.zeroed(&e->d_status, sizeof(int));
-    ap.zeroed(&e->d_fe_part, sizeof(double) * (Sg + 1) * C);
+    ap.zeroed(&e->d_fe_part, sizeof(double) * (Sg + 2) * C);   // one slot per segment + the t = 0 update (+ the Wishart slot of a noise engine)
     e->fe_total_cap = 16;
     ap.zeroed(&e->d_fe_total, sizeof(double) * e->fe_total_cap);
     ap.plain(&e->d_fe_blocks, sizeof(double) * ((C + 63) / 64));
@@ -2346,6 +2353,87 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
 
 static rxhip_status prof_begin(rxhip_engine* e, int k);
 static rxhip_status prof_end(rxhip_engine* e);
+
+// A state-space chain whose observation-noise precision is unknown (include/rxhip.h, csrc/noise_kernels.hpp): an engine of the d, dy ≤ 4
+// family with ONE MODEL BLOCK PER CHAIN — every chain carries its own q(W), hence its own observation-side constants, rewritten on the device
+// after every sweep — on the schedule batches with per-chain models take anyway (segment elements computed in the lane).
+rxhip_status rxhip_lgssm_noise_create(const rxhip_lgssm_desc* ds, const rxhip_noise_prior* pr, rxhip_engine** out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    *out = nullptr;
+    if (!ds || !pr || !pr->S0 || !pr->init_V || ds->d <= 0 || ds->dy <= 0 || ds->n_chains <= 0 || !ds->A || !ds->B || !ds->P || !ds->m0 || !ds->V0)
+        return RXHIP_ERR_BADARG;
+    if (!find_vtbl(ds->d, ds->dy) || ds->n_models != 1 || ds->chain_model || ds->step_model || ds->horizon || ds->allow_missing || ds->state_offset ||
+        ds->obs_offset)
+        return RXHIP_ERR_UNSUPPORTED;
+    const size_t C = (size_t)ds->n_chains, d = (size_t)ds->d, dy = (size_t)ds->dy;
+    if (!(pr->nu0 > (double)dy - 1.0) || !(pr->init_nu > (double)dy - 1.0)) return RXHIP_ERR_BADARG;
+    // Q of the first sweep's host-built blocks: E_init[W]⁻¹ (k_noise_reset rewrites the Q-dependent constants at every run start anyway)
+    std::vector<double> W0(dy * dy), Q0(dy * dy), S0i(dy * dy), scratch(dy * dy);
+    for (size_t q = 0; q < dy * dy; ++q) W0[q] = pr->init_nu * pr->init_V[q];
+    double ldS0 = 0.0;
+    if (!host::chol_inv((int)dy, W0.data(), Q0.data(), nullptr) || !host::chol_inv((int)dy, pr->S0, S0i.data(), &ldS0)) return RXHIP_ERR_NOT_POSDEF;
+    auto rep = [&](const double* src, size_t n) {
+        std::vector<double> v(C * n);
+        for (size_t c = 0; c < C; ++c) std::memcpy(&v[c * n], src, sizeof(double) * n);
+        return v;
+    };
+    const std::vector<double> A = rep(ds->A, d * d), B = rep(ds->B, dy * d), P = rep(ds->P, d * d), Q = rep(Q0.data(), dy * dy), m0 = rep(ds->m0, d),
+                              V0 = rep(ds->V0, d * d);
+    std::vector<int32_t> cm(C);
+    for (size_t c = 0; c < C; ++c) cm[c] = (int32_t)c;
+    rxhip_lgssm_desc dd = *ds;
+    dd.n_models = (int32_t)C;
+    dd.A = A.data(); dd.B = B.data(); dd.P = P.data(); dd.Q = Q.data(); dd.m0 = m0.data(); dd.V0 = V0.data(); dd.chain_model = cm.data();
+    // (one chain: a second, unused model block keeps the engine off the shared-model schedule, whose per-position gain tables are built
+    // once from Q on the host)
+    std::vector<double> A2, B2, P2, Q2, m2, V2;
+    if (C == 1) {
+        auto twice = [](const std::vector<double>& v) { std::vector<double> w(v); w.insert(w.end(), v.begin(), v.end()); return w; };
+        A2 = twice(A); B2 = twice(B); P2 = twice(P); Q2 = twice(Q); m2 = twice(m0); V2 = twice(V0);
+        dd.n_models = 2;
+        dd.A = A2.data(); dd.B = B2.data(); dd.P = P2.data(); dd.Q = Q2.data(); dd.m0 = m2.data(); dd.V0 = V2.data();
+    }
+    if (rxhip_status st = rxhip_lgssm_create(&dd, out)) return st;
+    rxhip_engine* e = *out;
+    SET_DEVICE(e);
+    const size_t NPR = (size_t)e->vt->noise_prior_size, NST = C * (1 + dy * dy);
+    size_t off[4] = {0};
+    const size_t parts[3] = {dy * d, NPR, NST};
+    for (int q = 0; q < 3; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
+    HIPCHK(e, hipMalloc(&e->noise_block, off[3]));
+    e->n_B = (double*)(e->noise_block + off[0]); e->n_prior = (double*)(e->noise_block + off[1]); e->n_state = (double*)(e->noise_block + off[2]);
+    PinnedTmp pin(sizeof(double) * (dy * d + NPR));
+    if (!pin.p) return fail(e, RXHIP_ERR_HIP, "hipHostMalloc of the staging block failed");
+    std::memcpy(pin.p, ds->B, sizeof(double) * dy * d);
+    double* hp = pin.p + dy * d;   // ν0 | S0⁻¹ | log|S0| | ν_init | V_init   (NoisePrior<DY>)
+    hp[0] = pr->nu0;
+    std::memcpy(hp + 1, S0i.data(), sizeof(double) * dy * dy);
+    hp[1 + dy * dy] = ldS0;
+    hp[2 + dy * dy] = pr->init_nu;
+    std::memcpy(hp + 3 + dy * dy, pr->init_V, sizeof(double) * dy * dy);
+    HIPCHK(e, hipMemcpyAsync(e->n_B, pin.p, sizeof(double) * dy * d, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemcpyAsync(e->n_prior, hp, sizeof(double) * NPR, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(e, hipMemsetAsync(e->n_state, 0, sizeof(double) * NST, e->stream));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    e->noise = true;
+    return RXHIP_OK;
+}
+
+rxhip_status rxhip_lgssm_noise_get(rxhip_engine* e, double* nu, double* V) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (!e->noise) return fail(e, RXHIP_ERR_BADARG, "noise_get: not an engine with an unknown noise precision");
+    if (!e->ran) return fail(e, RXHIP_ERR_STATE, "noise_get: no run yet");
+    SET_DEVICE(e);
+    const size_t C = (size_t)e->n_chains, q = (size_t)e->dy * e->dy;
+    std::vector<double> st(C * (1 + q));
+    HIPCHK(e, hipStreamSynchronize(e->stream));
+    HIPCHK(e, hipMemcpy(st.data(), e->n_state, sizeof(double) * st.size(), hipMemcpyDeviceToHost));
+    for (size_t c = 0; c < C; ++c) {
+        if (nu) nu[c] = st[c * (1 + q)];
+        if (V) std::memcpy(V + c * q, &st[c * (1 + q) + 1], sizeof(double) * q);
+    }
+    return RXHIP_OK;
+}
 
 rxhip_status rxhip_gmm_create(const rxhip_gmm_desc* ds, rxhip_engine** out) {
     if (!out) return RXHIP_ERR_BADARG;
@@ -3208,6 +3296,21 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;
         dp.filter = p.filter;
     }
+    NoiseParams np{};
+    if (e->noise) {   // a run starts from the @initialization marginal of W (iterations re-push the data: batch.jl:391-430)
+        if (filter) return fail(e, RXHIP_ERR_BADARG, "run_filter: an engine with an unknown noise precision has no streaming twin");
+        np.T = e->T; np.n_chains = e->n_chains; np.S = e->S; np.y = e->d_y; np.mean = e->d_mean; np.cov = e->d_cov; np.B = e->n_B;
+        np.cst = e->d_cst; np.prior = e->n_prior; np.state = e->n_state; np.fe_part = e->d_fe_part; np.status = e->d_status;
+        if (iterations > e->n_hist_cap) {
+            HIPCHK(e, hipStreamSynchronize(e->stream));
+            if (e->n_hist) HIPCHK(e, hipFree(e->n_hist));
+            e->n_hist = nullptr;
+            HIPCHK(e, hipMalloc(&e->n_hist, sizeof(double) * (size_t)iterations * (size_t)e->n_chains * (1 + (size_t)e->dy * e->dy)));
+            e->n_hist_cap = iterations;
+        }
+        np.hist = e->n_hist;
+        e->vt->noise_reset(np, e->stream);
+    }
     for (int it = 0; it < iterations; ++it) {
         p.iteration = it;
         // `missing` observations / per-step constants at d > 4 on the masked MFMA schedule (smoothing; filtering runs: the same sweep, then the
@@ -3315,10 +3418,15 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 if ((st = prof_end(e))) return st;
             }
         }
+        if (e->noise) {   // q(W) of every chain from this sweep's q(x); its free-energy slot; the constants of the next sweep
+            np.iteration = it;
+            e->vt->noise_update(np, e->stream);
+        }
         if (fe && !small_now) {
             if ((st = prof_begin(e, RXHIP_K_FE_REDUCE))) return st;
             const int nb = (int)((e->n_chains + 63) / 64);
             Params pr = p;
+            if (e->noise) pr.S = p.S + 1;   // + the Wishart slot
             if (mseg_now) {   // slots of kd_forward_info / kd_backward_info / kd_fe_resid over the mseg segments
                 pr.fe_part = e->m_fe_part;
                 pr.S = 2 * e->mS - 1 + (int)mseg_resid_slots(e->T, e->m_dpad, e->dy, e->m_stepm, e->m_models);

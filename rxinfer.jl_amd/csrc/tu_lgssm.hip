@@ -105,6 +105,12 @@ struct Launch {
         if (fe) hipLaunchKernelGGL((k_small_sweep<D, DY, true>), dim3(1), dim3(SMALL_SWEEP_THREADS), 0, s, p, carg(hc));
         else hipLaunchKernelGGL((k_small_sweep<D, DY, false>), dim3(1), dim3(SMALL_SWEEP_THREADS), 0, s, p, carg(hc));
     }
+    static void noise_reset(const NoiseParams& p, hipStream_t s) {
+        hipLaunchKernelGGL((k_noise_reset<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
+    }
+    static void noise_update(const NoiseParams& p, hipStream_t s) {
+        hipLaunchKernelGGL((k_noise_update<D, DY>), dim3((unsigned)p.n_chains), dim3(256), 0, s, p);
+    }
     static void stream_step(const StreamParams& p, hipStream_t s) {
         hipLaunchKernelGGL((k_stream_step<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
     }
@@ -144,6 +150,9 @@ struct Launch {
         v.joint = &Launch::joint;
         v.stream_step = &Launch::stream_step;
         v.small_sweep = &Launch::small_sweep;
+        v.noise_prior_size = NoisePrior<DY>::SIZE;
+        v.noise_reset = &Launch::noise_reset;
+        v.noise_update = &Launch::noise_update;
         return v;
     }
 };

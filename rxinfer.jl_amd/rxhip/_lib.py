@@ -99,10 +99,16 @@ class HgfDesc(ctypes.Structure):
         ("n_gh", ctypes.c_int32), ("device", ctypes.c_int32), ("stream", ctypes.c_void_p)]
 
 
+class NoisePrior(ctypes.Structure):   # rxhip_noise_prior
+    _fields_ = [("nu0", ctypes.c_double), ("S0", c_double_p), ("init_nu", ctypes.c_double), ("init_V", c_double_p)]
+
+
 # every symbol include/rxhip.h declares: (name, restype, argtypes)
 _H = ctypes.c_void_p
 SYMBOLS = [
     ("rxhip_lgssm_create", ctypes.c_int32, [ctypes.POINTER(LgssmDesc), ctypes.POINTER(_H)]),
+    ("rxhip_lgssm_noise_create", ctypes.c_int32, [ctypes.POINTER(LgssmDesc), ctypes.POINTER(NoisePrior), ctypes.POINTER(_H)]),
+    ("rxhip_lgssm_noise_get", ctypes.c_int32, [_H, c_double_p, c_double_p]),
     ("rxhip_graph_lower_lgssm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(LgssmLowered)]),
     ("rxhip_graph_lower_gmm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(GmmLowered)]),
     ("rxhip_graph_lower_mvgmm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(MvGmmLowered)]),

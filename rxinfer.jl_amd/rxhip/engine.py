@@ -70,7 +70,7 @@ class LGSSMEngine:
                 self._keep.append(a)
                 setattr(desc, name, _p(a))
         self._h = ctypes.c_void_p()
-        st = L.rxhip_lgssm_create(ctypes.byref(desc), ctypes.byref(self._h))
+        st = self._create(L, desc)
         if st != _lib.OK:
             msg = L.rxhip_last_error(self._h).decode() if self._h else L.rxhip_status_string(st).decode()
             if self._h:
@@ -79,6 +79,9 @@ class LGSSMEngine:
             raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
         self._data_ref = None
         self._iters = 0
+
+    def _create(self, L, desc):
+        return L.rxhip_lgssm_create(ctypes.byref(desc), ctypes.byref(self._h))
 
     # -- plumbing ---------------------------------------------------------------------------
     def _chk(self, st):
@@ -299,6 +302,31 @@ class LGSSMEngine:
         p = ctypes.c_void_p()
         self._chk(_lib.lib().rxhip_get_stream(self._h, ctypes.byref(p)))
         return p.value
+
+
+class LGSSMNoiseEngine(LGSSMEngine):
+    """State-space chains with an UNKNOWN observation-noise precision, `W ~ Wishart(nu0, S0); y[t] ~ MvNormal(μ = B * x[t], Λ = W)` with
+    `q(x, W) = q(x) q(W)` (include/rxhip.h rxhip_lgssm_noise_create): every chain its own W.  run(iterations, free_energy) alternates one
+    belief-propagation sweep of all chains with the Wishart update of all chains, on the device; free_energy() per iteration,
+    noise_posterior() -> (nu [chains], V [chains][dy][dy]) after the last one."""
+
+    def __init__(self, A, B, P, m0, V0, T, nu0, S0, init_nu=None, init_V=None, n_chains=1, prior_through_transition=False, segments=0,
+                 device=-1, stream=None):
+        dy = _c(B).shape[-2]
+        self._pri = _lib.NoisePrior()
+        self._pri_keep = [_c(S0, (dy, dy)), _c(S0 if init_V is None else init_V, (dy, dy))]
+        self._pri.nu0, self._pri.init_nu = float(nu0), float(nu0 if init_nu is None else init_nu)
+        self._pri.S0, self._pri.init_V = _p(self._pri_keep[0]), _p(self._pri_keep[1])
+        super().__init__(A, B, P, np.eye(dy), m0, V0, T, n_chains=n_chains, prior_through_transition=prior_through_transition,
+                         segments=segments, device=device, stream=stream)
+
+    def _create(self, L, desc):
+        return L.rxhip_lgssm_noise_create(ctypes.byref(desc), ctypes.byref(self._pri), ctypes.byref(self._h))
+
+    def noise_posterior(self):
+        nu, V = np.empty(self.n_chains), np.empty((self.n_chains, self.dy, self.dy))
+        self._chk(_lib.lib().rxhip_lgssm_noise_get(self._h, _p(nu), _p(V)))
+        return nu, V
 
 
 class GMMEngine:
