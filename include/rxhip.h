@@ -27,6 +27,30 @@
 extern "C" {
 #endif
 
+/* ------------------------------------------------------------------------------------------
+ * Environment.  The library reads the process environment in three places only:
+ *   RXHIP_TRACE=1        stage timings of engine creation on stderr (measurement aid; no effect on results or schedules)
+ *   RXHIP_RCCL_LIB=path  the librccl.so to open for rxhip_comm_* / rxhip_allreduce_* (default: the one of the HIP runtime in the process)
+ *   RXHIP_TEST_HOOKS=1   enables the schedule switches below.  Without it NONE of them is read: a host's environment cannot change the
+ *                        schedule behind a result.  All of them select between schedules that compute the same posteriors and free energy
+ *                        (the parity tests run both sides); they exist so that one schedule can check another and for A/B timings.
+ *     RXHIP_ONE_PASS=0|1        d, dy <= 4 shared-model batches: force the four-phase / the one-pass table-driven schedule (default: by size)
+ *     RXHIP_ONE_SEGMENT=1       d, dy <= 4 masked / per-step engines: one segment per chain
+ *     RXHIP_BACKWARD_LANES=1    one-pass schedule: the backward sweep of the four-phase schedule instead of the table-driven one
+ *     RXHIP_SMALL_SWEEP=0       few short chains: the five launches of the four-phase schedule instead of k_small_sweep (one launch)
+ *     RXHIP_NO_PACK=1           d <= 8 on the MFMA path: one chain per 16x16 tile instead of two
+ *     RXHIP_DENSE_SPLIT=0|1     MFMA path, one model: without / with the model-data split (default: from four workgroups' worth of chains)
+ *     RXHIP_HOST_TABLES=1       MFMA path: per-model tables by the host builder instead of the device builder (d >= 32)
+ *     RXHIP_FE_RESID_VALU=1     MFMA path: the round-2 residual kernel (vector FMAs) instead of the MFMA one
+ *     RXHIP_GSEQ=1, RXHIP_STEPM_GSEQ=1, RXHIP_FILTER_GSEQ=1, RXHIP_JOINTS_GSEQ=1
+ *                               `missing` / per-step-constant engines at d > 4 (all runs / per-step engines only / filtering runs only /
+ *                               node-local joints only): the sequential schedule (one workgroup per chain, the reference's message order)
+ *                               instead of the time-parallel masked MFMA schedule
+ *     RXHIP_MSEG_SCAN=sequential|log, RXHIP_MSEG_ONE_LEVEL=1, RXHIP_MSEG_GROUP=g
+ *                               masked schedule: kind of the boundary recursion (default: the cheaper one by a cost model)
+ *     RXHIP_MSEG_MAX_BYTES=n    masked schedule: cap on its record block (an engine that exceeds it stays on the sequential schedule)
+ *     RXHIP_WAVE8=0             masked schedule, one segment per chain, d <= 8: the MFMA sweep kernels instead of the in-wave ones
+ * ------------------------------------------------------------------------------------------ */
 typedef struct rxhip_engine rxhip_engine;
 typedef int32_t rxhip_status;
 

@@ -11,6 +11,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "lgssm_kernels.hpp"
 #include "predict_kernels.hpp"
 #include "noise_kernels.hpp"
@@ -65,6 +67,13 @@ void lgssm_vtbls_d3(LgssmVtbl* out);
 void lgssm_vtbls_d4(LgssmVtbl* out);
 
 inline unsigned nblk(long long n, int b) { return (unsigned)((n + b - 1) / b); }
+
+// Schedule switches (include/rxhip.h, "Environment"): every RXHIP_* variable that selects a schedule or a checker path is a TEST HOOK and is read
+// only when RXHIP_TEST_HOOKS=1 is set as well — the environment of a host process cannot change the schedule behind a result by accident.
+inline const char* hook_env(const char* name) {
+    const char* on = std::getenv("RXHIP_TEST_HOOKS");
+    return (on && on[0] == '1' && on[1] == 0) ? std::getenv(name) : nullptr;
+}
 
 #ifndef RXHIP_LAUNCH_LGSSM_ONLY
 // ------------------------------------------------------------------------------------------

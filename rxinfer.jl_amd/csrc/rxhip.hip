@@ -997,7 +997,7 @@ static void dense_schedule_ints(rxhip_engine* e) {
 
 static bool dense_tab_on_device(const rxhip_engine* e) {
     // d ≥ 32: below, the host recursions take well under a millisecond (and a 16×16 model padded into these kernels would not be faster)
-    return e->nt >= 2 && e->dyk <= e->dpad && !std::getenv("RXHIP_HOST_TABLES");
+    return e->nt >= 2 && e->dyk <= e->dpad && !hook_env("RXHIP_HOST_TABLES");
 }
 
 // ---- `missing` observations on the MFMA path, parallel in time (dense_mseg_kernels.hpp) -------------------------------------
@@ -1012,7 +1012,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     const bool stepm = ds->step_model != nullptr && ds->n_models > 1;
     const bool chainm = !stepm && ds->chain_model != nullptr && ds->n_models > 1;   // one model per chain (with `missing` values: else the fully observed MFMA path has them)
     if (!(ds->allow_missing || stepm) || (ds->chain_model && !chainm) || (!stepm && !chainm && ds->n_models != 1) || e->T < 2 ||
-        std::getenv("RXHIP_GSEQ") || ((stepm || chainm) && std::getenv("RXHIP_STEPM_GSEQ")))
+        hook_env("RXHIP_GSEQ") || ((stepm || chainm) && hook_env("RXHIP_STEPM_GSEQ")))
         return RXHIP_OK;
     // the masked kernels work on d×d tiles that also hold the observation-space matrices: pad to the larger of d and dy
     e->m_dpad = 16 * ((std::max(e->d, e->dy) + 15) / 16);
@@ -1029,8 +1029,8 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     // the machine on their own: ONE segment per chain — the sweep kernels run the whole chain, no element pass and no boundary recursion.
     long long S = 1;
     // RXHIP_MSEG_SCAN = sequential | log: the boundary recursion as one / two sequential levels, or in ⌈log₂ S⌉ rounds (default: the cheaper one)
-    const char* scan_env = std::getenv("RXHIP_MSEG_SCAN");
-    const int scan_mode = std::getenv("RXHIP_MSEG_ONE_LEVEL") ? 1 : scan_env && !std::strcmp(scan_env, "sequential") ? 1 : scan_env && !std::strcmp(scan_env, "log") ? 2 : 0;
+    const char* scan_env = hook_env("RXHIP_MSEG_SCAN");
+    const int scan_mode = hook_env("RXHIP_MSEG_ONE_LEVEL") ? 1 : scan_env && !std::strcmp(scan_env, "sequential") ? 1 : scan_env && !std::strcmp(scan_env, "log") ? 2 : 0;
     auto hs_fits = [&](long long s) { return (double)C * (double)s * (MSEG_WS + 9 + 12) * MM * 8.0 <= 6e9; };   // scratch + elements + four generations
     auto hs_rounds_of = [](long long s) { int r = 0; while ((1LL << r) <= s - 2) ++r; return r; };
     const double f = (double)(e->m_nt - 1) / 3.0, c_s = 8.0 + f * 13.0, c_g = 15.0 + f * 35.0;
@@ -1040,7 +1040,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     const double conc = e->m_nt == 1 ? 2048.0 : e->m_nt == 2 ? 1024.0 : 512.0;
     const double conc_c = conc, c_c = 8.0 + f * 22.0;    // a round of fused compositions: 30 µs at d = 64 with a CU to itself, 44 µs when workgroups share one
     // log-depth recursion over ⌈s / g⌉ entries of g segments: km_fold (g − 1 compositions in a row), the rounds, km_apply, km_inner (g − 1 steps)
-    const char* grp_env = std::getenv("RXHIP_MSEG_GROUP");
+    const char* grp_env = hook_env("RXHIP_MSEG_GROUP");
     const int grp_forced = grp_env ? std::atoi(grp_env) : 0;
     auto log_cost = [&](long long s, int g) {
         const double n = std::ceil((double)s / (double)g), wv = std::ceil(2.0 * (double)C * n / conc_c), wf = std::ceil((double)C * n / conc_c);
@@ -1056,7 +1056,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     };
     {
         const double c_e = 10.0 + f * 22.0, c_f = 5.7 + f * 21.0;   // fused element step (32 µs at d = 64 with every CU busy), forward + backward sweep step
-        const char* w8_env = std::getenv("RXHIP_WAVE8");
+        const char* w8_env = hook_env("RXHIP_WAVE8");
         const bool w8_ok = e->m_nt == 1 && e->d <= 8 && !stepm && !chainm && !(w8_env && std::atoi(w8_env) == 0);
         auto cost = [&](long long s_asked) {
             // (the segments that s_asked turns into once the segment length is an integer: ⌈(T − 1) / L⌉ of length L = ⌈(T − 1) / s_asked⌉)
@@ -1096,7 +1096,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     e->m_hs = 0; e->m_hs_rounds = 0;
     {   // the boundary recursion of this S: sequential (one level, or two from 16 segments on) or log-depth, by the same cost figures
         double seq = (double)S * c_s * std::ceil(2.0 * (double)C / conc);
-        if (S >= 16 && !std::getenv("RXHIP_MSEG_ONE_LEVEL")) {
+        if (S >= 16 && !hook_env("RXHIP_MSEG_ONE_LEVEL")) {
             const double sg = std::ceil(std::sqrt((double)S)), ng = std::ceil((double)S / sg);
             seq = (sg * c_g + (ng + 2.0 * sg) * c_s) * std::ceil((double)C * ng / conc);
         }
@@ -1110,7 +1110,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
             e->m_hs_rounds = hs_rounds_of(e->m_hs_n);
         }
     }
-    if (!e->m_hs && S >= 16 && !std::getenv("RXHIP_MSEG_ONE_LEVEL")) {
+    if (!e->m_hs && S >= 16 && !hook_env("RXHIP_MSEG_ONE_LEVEL")) {
         int sg = 1;
         while ((long long)sg * sg < S) ++sg;
         e->m_sg = sg;
@@ -1136,7 +1136,7 @@ static rxhip_status mseg_setup(rxhip_engine* e, const rxhip_lgssm_desc* ds) {
     {
         size_t free_b = 0, total_b = 0;
         bool fits = hipMemGetInfo(&free_b, &total_b) == hipSuccess && (double)off[21] <= 0.9 * (double)free_b;
-        if (const char* cap = std::getenv("RXHIP_MSEG_MAX_BYTES")) fits = fits && off[21] <= std::strtoull(cap, nullptr, 10);
+        if (const char* cap = hook_env("RXHIP_MSEG_MAX_BYTES")) fits = fits && off[21] <= std::strtoull(cap, nullptr, 10);
         if (!fits || hipMalloc(&e->mseg_block, off[21]) != hipSuccess) {
             (void)hipGetLastError();
             e->mseg_block = nullptr;
@@ -1225,7 +1225,7 @@ static rxhip_status mseg_run(rxhip_engine* e, bool fe, bool filter) {
     // chains that run as ONE segment (they fill the chip on their own) at d ≤ 8: the sweep inside one wavefront per chain
     // (dense8_kernels.hpp; smoothing runs of one model; RXHIP_WAVE8=0: the MFMA kernels, which stay the checker)
     {
-        const char* w8 = std::getenv("RXHIP_WAVE8");
+        const char* w8 = hook_env("RXHIP_WAVE8");
         dp.wave8 = (e->mS == 1 && e->m_nt == 1 && e->d <= 8 && !e->m_stepm && !e->m_chainm && !filter && !(w8 && std::atoi(w8) == 0)) ? 1 : 0;
         e->m_wave8_last = dp.wave8 != 0;
         if (dp.wave8) mp.rec = K8_REC;   // km_gy writes B′Q⁻¹y_t into the records the in-wave kernels read
@@ -1932,7 +1932,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     }
     // d ≤ 8: two chains per 16×16 tile (block-diagonal pair) instead of one chain padded to 16 — twice the chains per
     // workgroup for the same MFMA work.  Needs an even batch (the pair is formed from neighbours in memory).
-    e->pack = (dense && !e->gseq && ds->d <= 8 && ds->dy <= 32 && ds->n_chains % 2 == 0 && ds->n_models == 1 && !std::getenv("RXHIP_NO_PACK")) ? 2 : 1;
+    e->pack = (dense && !e->gseq && ds->d <= 8 && ds->dy <= 32 && ds->n_chains % 2 == 0 && ds->n_models == 1 && !hook_env("RXHIP_NO_PACK")) ? 2 : 1;
     e->wg_chains = ds->n_chains / e->pack;
     e->dyk = ds->dy * e->pack;
     if (ds->device >= 0) {
@@ -1964,7 +1964,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         e->L = 1;
         e->Llast = 1;
     } else {
-        long long S_target = (e->sequential && std::getenv("RXHIP_ONE_SEGMENT")) ? 1 : ds->segments > 0 ? ds->segments
+        long long S_target = (e->sequential && hook_env("RXHIP_ONE_SEGMENT")) ? 1 : ds->segments > 0 ? ds->segments
                              : dense ? (256 * dense_wg_per_cu + e->wg_chains - 1) / e->wg_chains
                                      : (131072 + e->n_chains - 1) / e->n_chains;
         if (ds->segments <= 0 && !dense) {
@@ -1984,7 +1984,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         // d = 64 × 64 chains × T = 1000: sweep 1.60 -> 1.21 ms and first touch 23 -> 8.5 ms with 32 instead of 8 segments; d = 32 × 256:
         // 1.25 -> 1.09 ms, 10.6 -> 4.5 ms; d = 8 × 1024: 0.48 -> 0.46 ms).
         {
-            const char* sp_env = std::getenv("RXHIP_DENSE_SPLIT");
+            const char* sp_env = hook_env("RXHIP_DENSE_SPLIT");
             const bool split_eligible = dense && !e->gseq && ds->n_models == 1 && (sp_env ? std::atoi(sp_env) != 0 : e->wg_chains >= 4);
             if (split_eligible && ds->segments <= 0) S_target = std::max(S_target, std::min<long long>(128, (steps + 31) / 32));
         }
@@ -2234,7 +2234,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         // once (model pass on one chain), every sweep is vectors only (d = 8 × 1024 chains × T = 1000: 1.86 -> 0.77 ms;
         // d = 64 × 64 chains: 5.70 -> 1.92 ms).  RXHIP_DENSE_SPLIT=0/1 overrides (tests).
         {
-            const char* sp_env = std::getenv("RXHIP_DENSE_SPLIT");
+            const char* sp_env = hook_env("RXHIP_DENSE_SPLIT");
             e->split = e->n_models == 1 && e->S > 0 && (sp_env ? std::atoi(sp_env) != 0 : e->wg_chains >= 4);
         }
         if (e->split) {
@@ -2259,7 +2259,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     // The one-pass schedule (k_forward0 + table-driven backward sweep) pays where the sweep is bandwidth-bound.  A few chains
     // are a latency chain of L steps either way, and its tables cost 30 µs more at creation (measured, one chain, T = 10⁴:
     // 0.41 against 0.38 ms end to end), so small problems keep the two-pass schedule.  RXHIP_ONE_PASS=0/1 overrides (tests).
-    const char* op_env = std::getenv("RXHIP_ONE_PASS");
+    const char* op_env = hook_env("RXHIP_ONE_PASS");
     const bool want_fused = e->uniform && e->S > 0 &&
                             (op_env ? std::atoi(op_env) != 0 : (double)e->n_chains * (double)e->T >= 4194304.0);
     StageTrace tr(e->stage_ms);
@@ -2294,7 +2294,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.upload(&e->d_fseg, ft.fseg.data(), sizeof(double) * ft.fseg.size());
         ap.plain(&e->d_mtab, sizeof(double) * T * vt->mt_row);
         ap.plain(&e->d_ntab, sizeof(double) * T * vt->mt_row);
-        if (C % 64 == 0 && !std::getenv("RXHIP_BACKWARD_LANES")) {
+        if (C % 64 == 0 && !hook_env("RXHIP_BACKWARD_LANES")) {
             ap.plain(&e->d_gtab, sizeof(double) * T * vt->gt_row);
             ap.plain(&e->d_segend, sizeof(double) * Sg * vt->se_size);
             ap.plain(&e->d_sblk, sizeof(double) * Sg * (size_t)smooth_blocks_per_segment(e->L) * 3 * e->d * e->d);
@@ -3279,7 +3279,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     const bool fe = want_fe != 0;
     // k_small_sweep (lgssm_kernels.hpp): the whole four-phase sweep of a small problem in one launch.  Per-kernel profiling keeps the separate
     // launches (there is nothing to time separately in one kernel); RXHIP_SMALL_SWEEP=0 forces them (the tests compare the two bit for bit).
-    const char* small_env = std::getenv("RXHIP_SMALL_SWEEP");
+    const char* small_env = hook_env("RXHIP_SMALL_SWEEP");
     const bool small_off = small_env && std::atoi(small_env) == 0;
     const bool small_now = !small_off && !e->dense && !fused && !filter && e->uniform && !e->sequential && !e->masked && e->d_scan && e->S > 0 &&
                            e->n_chains <= 16 && e->n_chains * (long long)e->S <= 256 && !e->profiling;   // (≤ 16 chains: the free-energy reduction of k_fe_few)
@@ -3315,7 +3315,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         p.iteration = it;
         // `missing` observations / per-step constants at d > 4 on the masked MFMA schedule (smoothing; filtering runs: the same sweep, then the
         // filtered moments from its records) unless the sequential schedule is asked for as the checker of filtering runs
-        const bool mseg_now = e->gseq && e->mseg && !(filter && std::getenv("RXHIP_FILTER_GSEQ"));
+        const bool mseg_now = e->gseq && e->mseg && !(filter && hook_env("RXHIP_FILTER_GSEQ"));
         if (mseg_now) {
             if ((st = mseg_run(e, fe, filter))) return st;
             e->records_hold_gains = !filter && !e->m_wave8_last;   // (the in-wave d ≤ 8 sweep keeps records of its own shape)
@@ -3726,7 +3726,7 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
         gq.chain_model = e->d_chain_model; gq.step_model = e->d_step_model; gq.fe_part = nullptr; gq.status = e->d_status;
         // After a sweep of the information-form kernels (one chain per tile, no model / data split) the smoother gains are still in the
         // records: the cross-covariances are one product per time index.  Otherwise: the sequential re-run.
-        const bool from_records = e->records_hold_gains && !std::getenv("RXHIP_JOINTS_GSEQ");
+        const bool from_records = e->records_hold_gains && !hook_env("RXHIP_JOINTS_GSEQ");
         if (from_records) {
             DenseParams cp{};
             const int nt = e->mseg ? e->m_nt : e->nt;

@@ -99,7 +99,7 @@ struct DenseLaunchNT {
 static int fe_resid_blocks(long long T, int d, int dy) { const int st = fe_resid_steps(d, dy); return (int)((T + st - 1) / st); }
 // passes > 1: per-step constants — one launch per model, each with its own partial slots, the columns of the other models masked
 static void launch_fe_resid(const DenseParams& p, hipStream_t s, int passes) {
-    static const bool valu_env = std::getenv("RXHIP_FE_RESID_VALU") != nullptr;  // the round-2 form (vector FMAs), kept as a cross-check
+    static const bool valu_env = hook_env("RXHIP_FE_RESID_VALU") != nullptr;  // the round-2 form (vector FMAs), kept as a cross-check
     const bool valu = valu_env && !p.step_model;
     if (p.step_model && passes > FE_RESID_MAX_PASSES) {   // many models: one step per wavefront instead of one launch per model
         for (long long c0 = 0; c0 < p.n_chains; c0 += 32768) {

@@ -1,5 +1,5 @@
 // dense_micro.hip — times the building blocks of the d = 64 path (256 workgroups, 40 repetitions each)
-#include "../rxinfer.jl_amd/csrc/dense_kernels.hpp"
+#include "gj_inverse_legacy.hpp"   // (includes csrc/dense_kernels.hpp)
 #include <cstdio>
 #include <vector>
 using namespace rxhip;

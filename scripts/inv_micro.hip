@@ -3,7 +3,7 @@
 // scaled by 10⁻⁶ / 10⁶, and with twelve decades between the diagonal entries — detection of an indefinite matrix, and timing
 // with one, two and four workgroups per CU.
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -ffp-contract=fast -mllvm -amdgpu-mfma-vgpr-form -o scripts/inv_micro scripts/inv_micro.hip
-#include "../rxinfer.jl_amd/csrc/dense_kernels.hpp"
+#include "gj_inverse_legacy.hpp"   // (includes csrc/dense_kernels.hpp)
 #include <cmath>
 #include <cstdio>
 #include <random>

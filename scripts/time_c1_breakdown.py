@@ -2,6 +2,7 @@
 one-round-trip call (rxhip_lgssm_infer: H2D + sweep + free energy + D2H + one synchronisation), destruction — with the sweep in one launch
 (k_small_sweep) and as five (RXHIP_SMALL_SWEEP=0)."""
 import os, sys, time
+os.environ["RXHIP_TEST_HOOKS"] = "1"   # the schedule switches below are test hooks (include/rxhip.h "Environment")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rxinfer.jl_amd"))
 import numpy as np, rxhip
 from rxhip import workloads

@@ -1,6 +1,7 @@
 """Sweep time of the sequential schedule (csrc/gseq_kernels.hpp: `missing` observations / per-step constants at d > 4)
 next to the time-parallel MFMA schedule on the same fully observed batch."""
 import os, sys, time
+os.environ["RXHIP_TEST_HOOKS"] = "1"   # the schedule switches below are test hooks (include/rxhip.h "Environment")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rxinfer.jl_amd"))
 import numpy as np
 import rxhip

@@ -1,6 +1,7 @@
 """Shared-model batches on the MFMA path: sweep time with the model / data split (dense_split_kernels.hpp) and without
 (RXHIP_DENSE_SPLIT=0), per-kernel averages from the engine's HIP events."""
 import os, sys, time
+os.environ["RXHIP_TEST_HOOKS"] = "1"   # the schedule switches below are test hooks (include/rxhip.h "Environment")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rxinfer.jl_amd"))
 import numpy as np
 import rxhip

@@ -1,6 +1,7 @@
 """Sweep time of the masked (`missing` anywhere) and per-step-constant schedules at batch scale (d = dy = 4, 1024 chains):
 in-lane segment elements (k_seg_elements) against one sequential segment per chain (RXHIP_ONE_SEGMENT=1)."""
 import os
+os.environ["RXHIP_TEST_HOOKS"] = "1"   # the schedule switches below are test hooks (include/rxhip.h "Environment")
 import sys
 import time
 

@@ -1,6 +1,7 @@
 """Masked batches that fill the chip at small state dimensions: sweep + free energy with 10 % missing, in-wave kernels (d ≤ 8) and MFMA kernels,
 next to the fully observed sweep of the same batch."""
 import os, sys, time
+os.environ["RXHIP_TEST_HOOKS"] = "1"   # the schedule switches below are test hooks (include/rxhip.h "Environment")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rxinfer.jl_amd"))
 import numpy as np, rxhip
 from rxhip import workloads

@@ -1,4 +1,6 @@
 """Device time of the once-per-engine table kernels of a shared-model batch (rxhip_get_model_tables_ms)."""
+import os
+os.environ["RXHIP_TEST_HOOKS"] = "1"   # the schedule switches below are test hooks (include/rxhip.h "Environment")
 import sys, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rxinfer.jl_amd"))
 import rxhip

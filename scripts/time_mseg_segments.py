@@ -2,6 +2,7 @@
 recursion (RXHIP_MSEG_SCAN = sequential | log), 10 % of the observations missing:
    python scripts/time_mseg_segments.py d chains T S [S ...]        (S = 0: the cost model's choice)"""
 import os, sys, time
+os.environ["RXHIP_TEST_HOOKS"] = "1"   # the schedule switches below are test hooks (include/rxhip.h "Environment")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rxinfer.jl_amd"))
 import numpy as np
 import rxhip

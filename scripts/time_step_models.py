@@ -1,5 +1,6 @@
 """Per-step constants (desc.step_model) at d > 4: the masked MFMA schedule against the sequential one (RXHIP_STEPM_GSEQ=1)."""
 import os, sys, time
+os.environ["RXHIP_TEST_HOOKS"] = "1"   # the schedule switches below are test hooks (include/rxhip.h "Environment")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "rxinfer.jl_amd"))
 import numpy as np
 import rxhip

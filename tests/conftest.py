@@ -9,6 +9,10 @@ for p in (os.path.join(ROOT, "rxinfer.jl_amd"), os.path.join(ROOT, "oracle"), RO
         sys.path.insert(0, p)
 
 
+# the schedule switches the tests flip (RXHIP_GSEQ, RXHIP_ONE_PASS, … — include/rxhip.h "Environment") are read by the library only with this set
+os.environ["RXHIP_TEST_HOOKS"] = "1"
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: test needs a real MI355X (run with -m gpu on the GPU box)")
 
