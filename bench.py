@@ -301,7 +301,7 @@ def extra_c3(device, parity=True):
     # instruction counts of the shipped kernels — v_mfma_f64_16x16x4_f64 = 2048 flop; per time step and workgroup (4 waves):
     # forward 4·76 (panel inverse: 4·4 tile-inverse rounds, 12 row block, 3·(4 + 16) panel updates) + 4·64 (G' = K C) + 160
     # (M = PLW − K G, 10 of 16 tiles: symmetric) = 720; backward 256 (J' = C K') + 160 (V_s = C + J V_s J', 10 of 16 tiles) = 416; residual forms of the free energy 256 per 16 steps;
-    # aggregation GEMM [2d × L·dy]·[L·dy × S] ≈ 8 per step — confirmed by SQ_INSTS_VALU_MFMA_F64 (profiles/r03/pmc_c3.txt).  The round-2 kernels
+    # aggregation GEMM [2d × L·dy]·[L·dy × S] ≈ 8 per step — confirmed by SQ_INSTS_VALU_MFMA_F64 (profiles/r04/pmc_c3.txt).  The round-2 kernels
     # executed 768 + 512 (bench counted 12 d³ = 1536 per step, the counters said 1280).
     mfma_step = {"kd_forward_info": 720, "kd_backward_info": 416, "kd_fe_resid_mfma": 16, "kd_agg_gemm": 8}
     mfma_flop = sum(mfma_step.values()) * 2048 * T
@@ -314,7 +314,7 @@ def extra_c3(device, parity=True):
             "mfma_frac": tf(mfma_step["kd_forward_info"] * 2048 * T, fwd_ms) / FP64_PEAK_TFLOPS if fwd_ms else None,
             "backward": {"kernel": "kd_backward_info", "flop": mfma_step["kd_backward_info"] * 2048 * T, "ms": bwd_ms,
                          "frac": tf(mfma_step["kd_backward_info"] * 2048 * T, bwd_ms) / FP64_PEAK_TFLOPS if bwd_ms else None},
-            "note": "flop = MFMA instructions of the shipped kernels x 2048 (counters: profiles/r03/pmc_c3.txt); frac = mfma_frac: "
+            "note": "flop = MFMA instructions of the shipped kernels x 2048 (counters: profiles/r04/pmc_c3.txt); frac = mfma_frac: "
                     "the kernels execute nothing but MFMA flops worth counting"}
     return {"workload": "LGSSM d=64 dy=64 T=10000, 1 chain, 1 BP sweep + Bethe free energy per step", "ms_per_step": ms,
             "kernels_ms_avg": kt, "tflops_ref_count": tf(ref_flop, ms), "tflops_executed": tf(mfma_flop, ms),

@@ -9,8 +9,8 @@
 //         sum-product: ONE sweep of the state-space kernels with this chain's constants Q⁻¹ ← E[W]  (each chain its own model block:
 //         B′E[W]B, B′E[W], E[W], dy log 2π − log|E[W]| — written by the kernels below, no host round trip between iterations);
 //   q(W)  MvNormalMeanPrecision(:Λ) sends Wishart(dy + 2, E[(y − Bx)(y − Bx)′]⁻¹) per observation; product with the prior in natural
-//         parameters: ν = ν0 + T, V⁻¹ = S0⁻¹ + Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′]   (k_noise_update: one workgroup per chain reduces
-//         the residual second moments over time in a fixed order, one lane finishes the 4×4 algebra);
+//         parameters: ν = ν0 + T, V⁻¹ = S0⁻¹ + Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′]   (k_noise_moments: an HBM-bound pass over the
+//         posteriors, lane = chain, time slices reduced in a fixed order; k_noise_update: one lane per chain finishes the 4×4 algebra);
 //   F     Bethe free energy of the iteration's marginals = the sweep's −log p̃(y | Q = E_old[W]⁻¹) + T/2 (log|E_old W| − E_new log|W|)
 //         + ½ tr((E_new W − E_old W) Σ_t E[r_t r_t′]) + KL(q_new(W) ‖ p(W)): one extra slot per chain in the sweep's free-energy partials.
 // Order per iteration: q(x) with the previous q(W), then q(W) with the new q(x) (the order the mixture engines assume for q(m), q(w); the CPU
@@ -35,7 +35,10 @@ struct NoiseParams {
     double* fe_part;        // [slot][chain]
     int iteration;
     int* status;
+    double* part;           // [slices][NS][chain]: partial residual second moments of k_noise_moments
+    int slices;             // time slices (fixed per engine: the summation order is the same on every run)
 };
+constexpr int NOISE_MAX_SLICES = 128;
 template <int DY>
 struct NoisePrior {
     static constexpr int NU0 = 0, S0I = 1, LDS0 = 1 + DY * DY, NUI = LDS0 + 1, VI = NUI + 1, SIZE = VI + DY * DY;
@@ -93,25 +96,24 @@ __global__ void __launch_bounds__(64) k_noise_reset(NoiseParams p) {
     noise_write_constants<D, DY>(p.cst + chain * CstLayout<D, DY>::SIZE, p.B, W, log(det));
 }
 
-// after the sweep of an iteration: the Wishart update of every chain, its free-energy slot, the constants of the next sweep
+// after the sweep of an iteration, 1: Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′] per chain.  Lane = chain (the posterior arrays are
+// [t][chain][·]: a wave reads 64 chains' worth of one time index as contiguous runs), workgroup row = time slice: slice s takes
+// t ≡ s (mod slices), its partial sums go to part[s][·][chain].  2 GB of posteriors at d = 4 × 1024 chains × T = 10⁴: an HBM-bound pass.
 template <int D, int DY>
-__global__ void __launch_bounds__(256) k_noise_update(NoiseParams p) {
-    using NP = NoisePrior<DY>;
+__global__ void __launch_bounds__(64) k_noise_moments(NoiseParams p) {
     constexpr int NS = Dim<DY>::NS;
-    __shared__ double red[NS][256];
-    const long long chain = blockIdx.x;
-    const int tid = threadIdx.x;
+    const long long chain = (long long)blockIdx.x * 64 + threadIdx.x;
+    const int slice = blockIdx.y;
+    if (chain >= p.n_chains) return;
     double Bm[DY][D];
 #pragma unroll
     for (int a = 0; a < DY; ++a)
 #pragma unroll
         for (int k = 0; k < D; ++k) Bm[a][k] = p.B[a * D + k];
-    // Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′]: thread `tid` takes t ≡ tid (mod 256), then a fixed tree over the threads — the same sum
-    // on every run
     double acc[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) acc[k] = 0.0;
-    for (long long t = tid; t < p.T; t += 256) {
+    for (long long t = slice; t < p.T; t += p.slices) {
         const double* m = p.mean + (t * p.n_chains + chain) * D;
         const double* C = p.cov + (t * p.n_chains + chain) * D * D;
         const double* yt = p.y + (t * p.n_chains + chain) * DY;
@@ -141,18 +143,26 @@ __global__ void __launch_bounds__(256) k_noise_update(NoiseParams p) {
             }
     }
 #pragma unroll
-    for (int k = 0; k < NS; ++k) red[k][tid] = acc[k];
-    __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
-        if (tid < w)
+    for (int k = 0; k < NS; ++k) p.part[((long long)slice * NS + k) * p.n_chains + chain] = acc[k];
+}
+
+// 2: the Wishart update of every chain (one lane per chain: the slices in ascending order — the same sum on every run), its free-energy
+// slot, the constants of the next sweep
+template <int D, int DY>
+__global__ void __launch_bounds__(64) k_noise_update(NoiseParams p) {
+    using NP = NoisePrior<DY>;
+    constexpr int NS = Dim<DY>::NS;
+    const long long chain = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (chain >= p.n_chains) return;
+    double red0[NS];
 #pragma unroll
-            for (int k = 0; k < NS; ++k) red[k][tid] += red[k][tid + w];
-        __syncthreads();
-    }
-    if (tid != 0) return;
+    for (int k = 0; k < NS; ++k) red0[k] = 0.0;
+    for (int sl = 0; sl < p.slices; ++sl)
+#pragma unroll
+        for (int k = 0; k < NS; ++k) red0[k] += p.part[((long long)sl * NS + k) * p.n_chains + chain];
     Sym<DY> S, Vo, Wo, Vi, Vn, Wn, tmp;
 #pragma unroll
-    for (int k = 0; k < NS; ++k) S.v[k] = red[k][0];
+    for (int k = 0; k < NS; ++k) S.v[k] = red0[k];
     double* st = p.state + chain * (1 + DY * DY);
     const double nuo = st[0], nu0 = p.prior[NP::NU0], nun = nu0 + (double)p.T;
     bool ok = true;

@@ -251,8 +251,8 @@ struct rxhip_engine {
     // unknown observation-noise precision (rxhip_lgssm_noise_create, noise_kernels.hpp): one block B | prior | state | history
     bool noise = false;
     char* noise_block = nullptr;
-    double *n_B = nullptr, *n_prior = nullptr, *n_state = nullptr, *n_hist = nullptr;
-    int n_hist_cap = 0;
+    double *n_B = nullptr, *n_prior = nullptr, *n_state = nullptr, *n_hist = nullptr, *n_part = nullptr;
+    int n_hist_cap = 0, n_slices = 1;
     struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
@@ -2397,11 +2397,19 @@ rxhip_status rxhip_lgssm_noise_create(const rxhip_lgssm_desc* ds, const rxhip_no
     rxhip_engine* e = *out;
     SET_DEVICE(e);
     const size_t NPR = (size_t)e->vt->noise_prior_size, NST = C * (1 + dy * dy);
-    size_t off[4] = {0};
-    const size_t parts[3] = {dy * d, NPR, NST};
-    for (int q = 0; q < 3; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
-    HIPCHK(e, hipMalloc(&e->noise_block, off[3]));
+    // time slices of the residual-moment pass: enough wavefronts to fill the chip (≈ 2048), at least 8 time indices per slice
+    {
+        const long long waves = (long long)((C + 63) / 64);
+        long long sl = (2048 + waves - 1) / waves;
+        sl = std::min<long long>(sl, std::min<long long>(NOISE_MAX_SLICES, std::max<long long>(1, e->T / 8)));
+        e->n_slices = (int)std::max<long long>(1, sl);
+    }
+    size_t off[5] = {0};
+    const size_t parts[4] = {dy * d, NPR, NST, (size_t)e->n_slices * (dy * (dy + 1) / 2) * C};
+    for (int q = 0; q < 4; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
+    HIPCHK(e, hipMalloc(&e->noise_block, off[4]));
     e->n_B = (double*)(e->noise_block + off[0]); e->n_prior = (double*)(e->noise_block + off[1]); e->n_state = (double*)(e->noise_block + off[2]);
+    e->n_part = (double*)(e->noise_block + off[3]);
     PinnedTmp pin(sizeof(double) * (dy * d + NPR));
     if (!pin.p) return fail(e, RXHIP_ERR_HIP, "hipHostMalloc of the staging block failed");
     std::memcpy(pin.p, ds->B, sizeof(double) * dy * d);
@@ -3301,6 +3309,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         if (filter) return fail(e, RXHIP_ERR_BADARG, "run_filter: an engine with an unknown noise precision has no streaming twin");
         np.T = e->T; np.n_chains = e->n_chains; np.S = e->S; np.y = e->d_y; np.mean = e->d_mean; np.cov = e->d_cov; np.B = e->n_B;
         np.cst = e->d_cst; np.prior = e->n_prior; np.state = e->n_state; np.fe_part = e->d_fe_part; np.status = e->d_status;
+        np.part = e->n_part; np.slices = e->n_slices;
         if (iterations > e->n_hist_cap) {
             HIPCHK(e, hipStreamSynchronize(e->stream));
             if (e->n_hist) HIPCHK(e, hipFree(e->n_hist));

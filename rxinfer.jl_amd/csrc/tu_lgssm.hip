@@ -109,7 +109,8 @@ struct Launch {
         hipLaunchKernelGGL((k_noise_reset<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
     }
     static void noise_update(const NoiseParams& p, hipStream_t s) {
-        hipLaunchKernelGGL((k_noise_update<D, DY>), dim3((unsigned)p.n_chains), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((k_noise_moments<D, DY>), dim3(nblk(p.n_chains, 64), (unsigned)p.slices), dim3(64), 0, s, p);
+        hipLaunchKernelGGL((k_noise_update<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
     }
     static void stream_step(const StreamParams& p, hipStream_t s) {
         hipLaunchKernelGGL((k_stream_step<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
