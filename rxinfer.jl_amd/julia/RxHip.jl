@@ -115,6 +115,51 @@ function Engine(A, B, P, Q, m0, V0; T::Integer, n_chains::Integer = 1, prior_thr
     return e
 end
 
+# mirrors rxhip_noise_prior
+struct NoisePrior
+    nu0::Float64
+    S0::Ptr{Float64}
+    init_nu::Float64
+    init_V::Ptr{Float64}
+end
+
+"""
+    NoiseEngine(A, B, P, m0, V0; T, nu0, S0, init_nu = nu0, init_V = S0, n_chains = 1, ...)
+
+The state-space chain with an UNKNOWN observation-noise precision — `W ~ Wishart(nu0, S0); y[t] ~ MvNormal(μ = B * x[t], Λ = W)` under
+`@constraints q(x, W) = q(x)q(W)` (chain: test/models/statespace/mlgssm_test.jl:9-14, node pair: test/models/iid/mv_iid_precision_tests.jl:11-15).
+`run!(e, iterations; free_energy = true)` alternates one BP sweep of every chain with every chain's Wishart update on the device
+(rxhip_lgssm_noise_create, csrc/noise_kernels.hpp); `noise_posterior(e)` returns q(W) of every chain after the last iteration.
+"""
+function NoiseEngine(A, B, P, m0, V0; T::Integer, nu0::Real, S0::AbstractMatrix, init_nu::Real = nu0, init_V::AbstractMatrix = S0,
+                     n_chains::Integer = 1, prior_through_transition::Bool = false, segments::Integer = 0, device::Integer = -1, stream = nothing)
+    d, dy = size(A, 1), size(B, 1)
+    a, b, p, m, v, s0, iv = rowmajor(A), rowmajor(B), rowmajor(P), rowmajor(m0), rowmajor(V0), rowmajor(S0), rowmajor(init_V)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    st = GC.@preserve a b p m v s0 iv begin
+        desc = LgssmDesc(d, dy, T, n_chains, 1, prior_through_transition ? 1 : 0, pointer(a), pointer(b), pointer(p), Ptr{Float64}(C_NULL),
+                         pointer(m), pointer(v), Ptr{Int32}(C_NULL), segments, device, stream_handle(stream), 0, 0, Ptr{Int32}(C_NULL),
+                         Ptr{Float64}(C_NULL), Ptr{Float64}(C_NULL))
+        prior = NoisePrior(nu0, pointer(s0), init_nu, pointer(iv))
+        ccall((:rxhip_lgssm_noise_create, librxhip), Int32, (Ref{LgssmDesc}, Ref{NoisePrior}, Ref{Ptr{Cvoid}}), desc, prior, h)
+    end
+    e = Engine(h[], d, dy, T, n_chains, 0)
+    if st != RXHIP_OK
+        h[] != C_NULL && (try check(e, st) finally ccall((:rxhip_destroy, librxhip), Int32, (Ptr{Cvoid},), h[]) end)
+        throw(RxHipError(st, unsafe_string(ccall((:rxhip_status_string, librxhip), Cstring, (Int32,), st))))
+    end
+    finalizer(destroy!, e)
+    return e
+end
+
+"""q(W) of every chain after the last iteration: (ν [chains], V [dy, dy, chains])."""
+function noise_posterior(e::Engine)
+    nu = Vector{Float64}(undef, e.n_chains)
+    V = Array{Float64}(undef, e.dy, e.dy, e.n_chains)      # symmetric blocks: row- and column-major coincide
+    GC.@preserve nu V check(e, ccall((:rxhip_lgssm_noise_get, librxhip), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}), e.handle, nu, V))
+    return nu, V
+end
+
 function destroy!(e::Engine)
     e.handle == C_NULL && return
     ccall((:rxhip_destroy, librxhip), Int32, (Ptr{Cvoid},), e.handle)
