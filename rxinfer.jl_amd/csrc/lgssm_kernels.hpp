@@ -1947,6 +1947,173 @@ static __global__ void __launch_bounds__(256) k_fe_few(Params p) {
 //   forward_body        all lanes   |  backward_body           all lanes   |  fe_few_body  all 256 threads
 // Needs n_chains · S ≤ 256 and n_chains ≤ 16 (the reduction of k_fe_few; rxhip.hip picks S accordingly), one model, a smoothing run.
 // LDS: the phases alias one block.
+// The boundary recursion of k_small_sweep in LOG depth.  Both recursions of boundary_scan_tab_body are affine in the data-dependent vectors
+// with data-independent matrices (the per-segment table):
+//     prefix  m(b_{s+1}) = M1_s m(b_s) + (b_s + M2_s η_s)            suffix  ξβ(b_s) = N1_s ξβ(b_{s+1}) + (η_s − N2_s b_s),  ξβ(b_S) = 0
+// so the maps (A, c): x ↦ A x + c compose associatively, (A2, c2)∘(A1, c1) = (A2 A1, A2 c1 + c2), and an inclusive Hillis–Steele scan over the
+// S − 1 maps of a chain — lane = (chain, segment), ⌈log₂(S − 1)⌉ rounds of one D×D product and one matrix–vector product per lane, the partner's
+// map through LDS — yields every boundary state at once.  S sequential steps of ≈ 0.6 µs (one wavefront, broadcast table reads) were a third of
+// the sweep of BASELINE config 1 and what kept its segments long (S = 56, L = 18); with the recursion at ≈ 8 × 0.4 µs the schedule takes
+// S ≈ 250, L = 4.  The compositions are NOT the sequential recursion's operations: results agree with it to rounding, not bit for bit.
+// LDS: (D² + D) doubles per lane, [component][lane] (conflict-free): 41 KB at d = 4.
+template <int D>
+struct ScanPar {
+    static constexpr int NE = D * D + D;                         // doubles per map
+    static constexpr int LDS_DOUBLES = NE * 256 + 16 * D;        // the maps + m(b_0) of up to 16 chains
+};
+template <int D, int DY, bool FE>
+__device__ __forceinline__ void boundary_scan_par_body(const Params& p, const CstArg<CstLayout<D, DY>::SIZE>& cb, const int tid, double* __restrict__ lds) {
+    using CL = CstLayout<D, DY>;
+    using SL = ScanLayout<D>;
+    constexpr int NS = Dim<D>::NS, NE = ScanPar<D>::NE;
+    const CPtr c{cb.v};
+    const int S = p.S, C = (int)p.n_chains, n = S - 1;   // n maps per chain and direction
+    const int seg = tid / C, chain = tid - seg * C;
+    const bool live = seg < S;
+    double* x0 = lds + NE * 256;   // [chain][D]: m(b_0)
+    bool ok = true;
+    // the belief after the first observation (t = 0): the prefix recursion starts from its mean
+    if (tid < C) {
+        double mp[D], m[D], yv[DY];
+        Sym<D> Vp, V;
+#pragma unroll
+        for (int i = 0; i < D; ++i) mp[i] = c[CL::M1 + i];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) Vp.v[i] = c[CL::V1 + i];
+        load_y<DY>(p.y, 0, p.n_chains, tid, yv);
+        double quad = 0.0, detprod = 1.0;
+        obs_update<D, DY, FE>(c, mp, Vp, yv, m, V, ok, quad, detprod);
+        store_filt_sh<D>(p, 0, tid, m, V);
+        if (FE) p.fe_part[tid] = -0.5 * (quad + log(detprod));
+        if (p.filter) write_marginal<D>(p, 0, tid, m, V);   // a filtering run: the filtered belief is the marginal
+#pragma unroll
+        for (int i = 0; i < D; ++i) x0[tid * D + i] = m[i];
+    }
+    const int ndir = p.filter ? 1 : 2;   // a filtering run needs the prefix direction only
+    for (int dir = 0; dir < ndir; ++dir) {
+        // this lane's map: prefix index seg (segment seg), suffix index seg ↔ segment S − 1 − seg
+        const int sidx_seg = dir == 0 ? seg : S - 1 - seg;
+        const bool has = live && seg < n;
+        double A[D][D], v[D];
+        if (has) {
+            const double* t = p.scan + (long long)sidx_seg * SL::SIZE;
+            const double* el = p.elem + ((long long)sidx_seg * 2 * D) * p.n_chains + chain;
+            double b[D], eta[D];
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                b[i] = el[i * p.n_chains];
+                eta[i] = el[(D + i) * p.n_chains];
+            }
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                double acc = dir == 0 ? b[i] : eta[i];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    A[i][k] = t[(dir == 0 ? SL::M1 : SL::N1) + i * D + k];
+                    acc += dir == 0 ? t[SL::M2 + i * D + k] * eta[k] : -t[SL::N2 + i * D + k] * b[k];
+                }
+                v[i] = acc;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                v[i] = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) A[i][k] = i == k ? 1.0 : 0.0;
+            }
+        }
+        for (int h = 1; h < n; h <<= 1) {
+            double* cur = lds;
+            __syncthreads();   // the previous round's reads (and the first round: x0, the previous direction's reads) are done
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+#pragma unroll
+                for (int k = 0; k < D; ++k) cur[(i * D + k) * 256 + tid] = A[i][k];
+                cur[(D * D + i) * 256 + tid] = v[i];
+            }
+            __syncthreads();
+            if (has && seg >= h) {   // compose with the map that ends h positions earlier (applied first)
+                const int pl = tid - h * C;
+                double Ap[D][D], vp[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+#pragma unroll
+                    for (int k = 0; k < D; ++k) Ap[i][k] = cur[(i * D + k) * 256 + pl];
+                    vp[i] = cur[(D * D + i) * 256 + pl];
+                }
+                double An[D][D], vn[D];
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double acc = v[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc += A[i][k] * vp[k];
+                    vn[i] = acc;
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        double a2 = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) a2 += A[i][k] * Ap[k][j];
+                        An[i][j] = a2;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    v[i] = vn[i];
+#pragma unroll
+                    for (int j = 0; j < D; ++j) A[i][j] = An[i][j];
+                }
+            }
+        }
+        __syncthreads();
+        if (dir == 0) {
+            // m(b_{seg+1}) = A m(b_0) + v;  the covariances at the boundaries come from the table
+            if (live) {
+                double m[D];
+                if (seg == 0) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) m[i] = x0[chain * D + i];
+                    Sym<D> Vb;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) Vb.v[i] = p.scan[SL::VB + i];
+                    store_soa<D>(p.fstart, 0, p.n_chains, chain, m, Vb);
+                }
+                if (has) {
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double acc = v[i];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc += A[i][k] * x0[chain * D + k];
+                        m[i] = acc;
+                    }
+                    Sym<D> Vb;
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) Vb.v[i] = p.scan[(long long)(seg + 1) * SL::SIZE + SL::VB + i];
+                    store_soa<D>(p.fstart, seg + 1, p.n_chains, chain, m, Vb);
+                }
+            }
+        } else if (live) {
+            // ξβ(b_{S−1−seg}) = v (the recursion starts from ξβ(b_S) = 0);  Λβ(b_s) = table[s − 1].LB
+            if (seg == 0) {
+                double z[D];
+                Sym<D> Z;
+#pragma unroll
+                for (int i = 0; i < D; ++i) z[i] = 0.0;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) Z.v[i] = 0.0;
+                store_soa<D>(p.beta, S, p.n_chains, chain, z, Z);
+            }
+            if (has) {
+                const int sb = S - 1 - seg;   // ≥ 1
+                Sym<D> Lm;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) Lm.v[i] = p.scan[(long long)(sb - 1) * SL::SIZE + SL::LB + i];
+                store_soa<D>(p.beta, sb, p.n_chains, chain, v, Lm);
+            }
+        }
+    }
+    if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+}
+
 constexpr int SMALL_SWEEP_THREADS = 256;
 constexpr int SMALL_SWEEP_SCAN_CHUNK = 16;
 template <int D, int DY>
@@ -1956,20 +2123,30 @@ struct SmallSweepLds {
     static constexpr int FE = 256 / 2;
     static constexpr int N = AGG > SCAN ? (AGG > FE ? AGG : FE) : (SCAN > FE ? SCAN : FE);
 };
-template <int D, int DY, bool FE>
-__global__ void __launch_bounds__(SMALL_SWEEP_THREADS) k_small_sweep(Params p, const CstArg<CstLayout<D, DY>::SIZE> cb) {
-    __shared__ double2 lds[SmallSweepLds<D, DY>::N];
+template <int D, int DY>
+__host__ __device__ constexpr int small_sweep_lds_doubles() {
+    return 2 * SmallSweepLds<D, DY>::N > ScanPar<D>::LDS_DOUBLES ? 2 * SmallSweepLds<D, DY>::N : ScanPar<D>::LDS_DOUBLES;
+}
+// par_scan: the boundary recursion in log depth (boundary_scan_par_body) instead of the sequential one — the host asks for it from 24 segments on.
+// FILT: a filtering run (rxhip_run_filter): prefix direction only, the filtered beliefs are the marginals, no backward phase.
+template <int D, int DY, bool FE, bool FILT>
+__global__ void __launch_bounds__(SMALL_SWEEP_THREADS) k_small_sweep(Params p, const CstArg<CstLayout<D, DY>::SIZE> cb, int par_scan) {
+    extern __shared__ __attribute__((aligned(16))) double small_lds[];
+    double2* lds = reinterpret_cast<double2*>(small_lds);
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63;
     seg_aggregate_body<D, DY, true>(p, cb, tid, lane, lds + w * 2 * AggStage<D, DY>::NPC);
     __syncthreads();
-    if (w < 2) boundary_scan_tab_body<D, DY, FE, SMALL_SWEEP_SCAN_CHUNK>(p, cb, lane, w, lane, lds + w * (SMALL_SWEEP_SCAN_CHUNK * ScanLayout<D>::SIZE / 2));
+    if (par_scan) boundary_scan_par_body<D, DY, FE>(p, cb, tid, small_lds);
+    else if (w < (FILT ? 1 : 2)) boundary_scan_tab_body<D, DY, FE, SMALL_SWEEP_SCAN_CHUNK>(p, cb, lane, w, lane, lds + w * (SMALL_SWEEP_SCAN_CHUNK * ScanLayout<D>::SIZE / 2));
     __syncthreads();
-    forward_body<D, DY, true, FE, false>(p, cb, tid, lane, nullptr);
-    __syncthreads();
-    backward_body<D, DY, true, false>(p, cb, tid, lane, nullptr);
+    forward_body<D, DY, true, FE, FILT>(p, cb, tid, lane, nullptr);
+    if constexpr (!FILT) {
+        __syncthreads();
+        backward_body<D, DY, true, false>(p, cb, tid, lane, nullptr);
+    }
     if (FE) {
         __syncthreads();
-        fe_few_body(p, reinterpret_cast<double*>(lds));
+        fe_few_body(p, small_lds);
     }
 }
 static __global__ void __launch_bounds__(256) k_fe_total(Params p, const double* block_part, int nblocks) {

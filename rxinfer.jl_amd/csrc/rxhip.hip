@@ -248,6 +248,8 @@ struct rxhip_engine {
     // profiling
     bool profiling = false;
     bool m_wave8_last = false;   // the last masked sweep ran on the in-wave d ≤ 8 kernels
+    double* h_stage = nullptr;   // pinned staging block of the creation upload (arena_commit), kept until destruction
+    size_t h_stage_bytes = 0;
     // unknown observation-noise precision (rxhip_lgssm_noise_create, noise_kernels.hpp): one block B | prior | state | history
     bool noise = false;
     char* noise_block = nullptr;
@@ -354,6 +356,7 @@ struct PinnedTmp {
     PinnedTmp(const PinnedTmp&) = delete;
     PinnedTmp& operator=(const PinnedTmp&) = delete;
     ~PinnedTmp() { if (p) pinned_release(p, bytes); }
+    double* detach() { double* q = p; p = nullptr; return q; }   // the caller keeps the block (and returns it to the pool itself)
 };
 static char* arena_acquire(int device, size_t need, size_t* got) {
     ArenaPool& ap = arena_pool();
@@ -551,7 +554,12 @@ static rxhip_status arena_commit(rxhip_engine* e, ArenaPlan& ap) {
         for (auto& it : ap.up) std::memcpy(stage + it.off, it.src, it.bytes);
         if (hipMemcpyAsync(e->arena, stage, up_end, hipMemcpyHostToDevice, e->stream) != hipSuccess) return fail(e, RXHIP_ERR_HIP, "table upload failed");
         if (zr_end > up_end && hipMemsetAsync(e->arena + up_end, 0, zr_end - up_end, e->stream) != hipSuccess) return fail(e, RXHIP_ERR_HIP, "memset failed");
-        if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, RXHIP_ERR_HIP, "table upload failed");  // `stage` dies here
+        if (pageable.empty() && !e->h_stage && e->h_mu.empty()) {   // (engines with known inputs rewrite uploaded regions with blocking copies later)
+            // the pinned block stays with the engine until it is destroyed (behind a stream synchronisation): creation does not wait for the
+            // upload — `infer(...)` of a small problem builds an engine per call, and this wait was a tenth of the call
+            e->h_stage_bytes = pin.bytes;
+            e->h_stage = pin.detach();
+        } else if (hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, RXHIP_ERR_HIP, "table upload failed");  // `stage` dies here
     } else if (zr_end > up_end) {
         if (hipMemsetAsync(e->arena + up_end, 0, zr_end - up_end, e->stream) != hipSuccess) return fail(e, RXHIP_ERR_HIP, "memset failed");
     }
@@ -735,47 +743,73 @@ struct FusedTables { std::vector<double> ftab, pos, fseg; double fe_const = 0.0;
 
 // data-independent part of the boundary scan (see ScanLayout / DenseParams::scanm): per segment the maps that
 // carry the means / weighted means across it, the covariance at its start and the backward precision at its end
-static bool build_scan_matrices(int d, int S, const HostAgg& a0, const HostAgg& aLast, const double* Vf1,
-                                std::vector<std::vector<double>>& M1, std::vector<std::vector<double>>& M2,
-                                std::vector<std::vector<double>>& Vb, std::vector<std::vector<double>>& N1,
-                                std::vector<std::vector<double>>& N2, std::vector<std::vector<double>>& Lb) {
-    const size_t MM = (size_t)d * d;
-    auto z = std::vector<double>(MM, 0.0);
-    M1.assign(S, z); M2.assign(S, z); Vb.assign(S, z); N1.assign(S, z); N2.assign(S, z); Lb.assign(S, z);
-    std::vector<double> Vc(Vf1, Vf1 + MM), Vi(MM), W(MM), tt(MM), m1(MM), m2(MM);
+// Flat tables, [S][d·d] each (one allocation per table: a chain cut into 250 short segments used to pay 1500 small allocations here).
+static bool build_scan_matrices(int d, int S, const HostAgg& a0, const HostAgg& aLast, const double* Vf1, std::vector<double>& M1,
+                                std::vector<double>& M2, std::vector<double>& Vb, std::vector<double>& N1, std::vector<double>& N2,
+                                std::vector<double>& Lb) {
+    const size_t MM = (size_t)d * d, n = (size_t)S * MM;
+    M1.assign(n, 0.0); M2.assign(n, 0.0); Vb.assign(n, 0.0); N1.assign(n, 0.0); N2.assign(n, 0.0); Lb.assign(n, 0.0);
+    std::vector<double> Vc(Vf1, Vf1 + MM), Vi(MM), W(MM), tt(MM), m1(MM), m2(MM), Vprev(MM, 0.0);
+    auto at = [MM](std::vector<double>& t, int s) { return t.data() + (size_t)s * MM; };
+    // Both recursions are Riccati maps of a time-invariant model: once an iterate reproduces its predecessor to rounding (|Δ| ≤ 2⁻⁵⁰ of the largest
+    // entry — an exact fixed point is never reached bit for bit, the last bit keeps flickering) every later segment takes the previous segment's
+    // maps — a chain cut into 250 short segments costs what its first few dozen do.
+    auto same = [MM](const std::vector<double>& x, const std::vector<double>& y) {
+        double amax = 0.0, dmax = 0.0;
+        for (size_t q = 0; q < MM; ++q) { amax = std::max(amax, std::fabs(x[q])); dmax = std::max(dmax, std::fabs(x[q] - y[q])); }
+        return dmax <= 8.9e-16 * amax;
+    };
+    bool conv = false;
     for (int s = 0; s < S; ++s) {
-        Vb[s] = Vc;
+        std::memcpy(at(Vb, s), Vc.data(), sizeof(double) * MM);
         if (s == S - 1) break;
+        if (!conv && s > 0 && same(Vc, Vprev)) conv = true;
+        if (conv) {   // M1, M2 of the previous segment; Vc stays
+            std::memcpy(at(M1, s), at(M1, s - 1), sizeof(double) * MM);
+            std::memcpy(at(M2, s), at(M2, s - 1), sizeof(double) * MM);
+            continue;
+        }
+        Vprev = Vc;
         if (!host::chol_inv(d, Vc.data(), Vi.data(), nullptr)) return false;
         for (size_t q = 0; q < MM; ++q) tt[q] = Vi[q] + a0.J[q];
         if (!host::chol_inv(d, tt.data(), W.data(), nullptr)) return false;
         host::mm(d, d, d, a0.Pi.data(), W.data(), m2.data());
         host::mm(d, d, d, m2.data(), Vi.data(), m1.data());
         host::mmT(d, d, d, m2.data(), a0.Pi.data(), tt.data());
-        M1[s] = m1; M2[s] = m2;
+        std::memcpy(at(M1, s), m1.data(), sizeof(double) * MM);
+        std::memcpy(at(M2, s), m2.data(), sizeof(double) * MM);
         for (int a = 0; a < d; ++a)
             for (int b = 0; b <= a; ++b) {
                 const double v = 0.5 * (tt[a * d + b] + tt[b * d + a]) + a0.C[a * d + b];
                 Vc[a * d + b] = Vc[b * d + a] = v;
             }
     }
-    std::vector<double> Lm(MM, 0.0), n1(MM), n2(MM);
+    std::vector<double> Lm(MM, 0.0), n1(MM), n2(MM), Lprev(MM, 0.0);
+    conv = false;
     for (int s = S - 1; s >= 1; --s) {  // Lb[s] = Λβ(b_{s+1})
         const HostAgg& g = (s == S - 1) ? aLast : a0;
-        Lb[s] = Lm;
+        std::memcpy(at(Lb, s), Lm.data(), sizeof(double) * MM);
+        if (!conv && s < S - 2 && same(Lm, Lprev)) conv = true;   // (from the second full segment on: the last segment has its own element)
+        if (conv) {
+            std::memcpy(at(N1, s), at(N1, s + 1), sizeof(double) * MM);
+            std::memcpy(at(N2, s), at(N2, s + 1), sizeof(double) * MM);
+            continue;
+        }
+        Lprev = Lm;
         for (size_t q = 0; q < MM; ++q) tt[q] = g.Ci[q] + Lm[q];
         if (!host::chol_inv(d, tt.data(), W.data(), nullptr)) return false;
         host::mTm(d, d, d, g.X.data(), W.data(), n1.data());
         host::mm(d, d, d, n1.data(), Lm.data(), n2.data());
         host::mm(d, d, d, n1.data(), g.X.data(), tt.data());
-        N1[s] = n1; N2[s] = n2;
+        std::memcpy(at(N1, s), n1.data(), sizeof(double) * MM);
+        std::memcpy(at(N2, s), n2.data(), sizeof(double) * MM);
         for (int a = 0; a < d; ++a)
             for (int b = 0; b <= a; ++b) {
                 const double v = g.JJ[a * d + b] - 0.5 * (tt[a * d + b] + tt[b * d + a]);
                 Lm[a * d + b] = Lm[b * d + a] = v;
             }
     }
-    if (S > 0) Lb[0] = Lm;
+    if (S > 0) std::memcpy(at(Lb, 0), Lm.data(), sizeof(double) * MM);
     return true;
 }
 
@@ -917,15 +951,16 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
         if (!host::chol_inv(d, V1.data(), V1i.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "prior covariance is not positive definite");
         for (int q = 0; q < d * d; ++q) Lf[q] = V1i[q] + Lobs[q];
         if (!host::chol_inv(d, Lf.data(), Vf1.data(), nullptr)) return fail(e, RXHIP_ERR_NOT_POSDEF, "first filtered precision not positive definite");
-        std::vector<std::vector<double>> M1, M2, Vb, N1, N2, Lb;
+        std::vector<double> M1, M2, Vb, N1, N2, Lb;   // [S][d·d] each
+        const size_t MMs = (size_t)d * d;
         if (!build_scan_matrices(d, e->S, hagg[0], hagg[1], Vf1.data(), M1, M2, Vb, N1, N2, Lb))
             return fail(e, RXHIP_ERR_NOT_POSDEF, "model %d: boundary scan matrix not positive definite", mdl);
         scan_out->assign((size_t)e->S * v.scan_size, 0.0);
         for (int s = 0; s < e->S; ++s) {
             double* t = scan_out->data() + (size_t)s * v.scan_size;
-            for (int q = 0; q < d * d; ++q) { t[v.sM1 + q] = M1[s][q]; t[v.sM2 + q] = M2[s][q]; t[v.sN1 + q] = N1[s][q]; t[v.sN2 + q] = N2[s][q]; }
-            host::pack_sym(d, Vb[s].data(), t + v.sVB);
-            host::pack_sym(d, Lb[s].data(), t + v.sLB);
+            for (int q = 0; q < d * d; ++q) { t[v.sM1 + q] = M1[s * MMs + q]; t[v.sM2 + q] = M2[s * MMs + q]; t[v.sN1 + q] = N1[s * MMs + q]; t[v.sN2 + q] = N2[s * MMs + q]; }
+            host::pack_sym(d, Vb.data() + s * MMs, t + v.sVB);
+            host::pack_sym(d, Lb.data() + s * MMs, t + v.sLB);
         }
         if (fused) {
             // per segment: −2 log p(y_seg | y_before) = [len·dy·log 2π + Σ logdet S⁰_i + logdet(I + V_s J)] + q0
@@ -937,7 +972,7 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
                 const HostAgg& g = (s == e->S - 1) ? hagg[1] : hagg[0];
                 const long long len = (s == e->S - 1) ? e->Llast : L;
                 double ldV = 0.0, ldT = 0.0;
-                if (!host::chol_inv(d, Vb[s].data(), Vi.data(), &ldV)) return fail(e, RXHIP_ERR_NOT_POSDEF, "segment start covariance not positive definite");
+                if (!host::chol_inv(d, Vb.data() + s * MMs, Vi.data(), &ldV)) return fail(e, RXHIP_ERR_NOT_POSDEF, "segment start covariance not positive definite");
                 for (int q = 0; q < d * d; ++q) tt[q] = Vi[q] + g.J[q];
                 if (!host::chol_inv(d, tt.data(), W.data(), &ldT)) return fail(e, RXHIP_ERR_NOT_POSDEF, "segment precision not positive definite");
                 host::mm(d, d, d, W.data(), Vi.data(), A2.data());
@@ -958,6 +993,10 @@ static rxhip_status build_model_tables(rxhip_engine* e, int mdl, const rxhip_lgs
 // dense path (d multiple of 16, ≤ 64): host-side per-model tables and launches
 // any state dimension up to 64: the MFMA path runs on d rounded up to a multiple of 16, the extra dimensions are
 // decoupled padding (A = 0, P = V0 = I, m0 = 0, B = 0: posterior N(0, I), no contribution to the free energy)
+static bool small_sweep_off() {   // RXHIP_SMALL_SWEEP=0 (test hook): the five launches of the four-phase schedule instead of k_small_sweep
+    const char* v = hook_env("RXHIP_SMALL_SWEEP");
+    return v && std::atoi(v) == 0;
+}
 static bool dense_supported(int d, int dy) { return d >= 1 && d <= 64 && dy >= 1 && dy <= 64; }
 static int dense_pad(int d) { return (d + 15) / 16 * 16; }
 
@@ -1707,6 +1746,7 @@ static void free_all(rxhip_engine* e) {
     e->pending.clear();
     e->pool.clear();
     if (e->stream) (void)hipStreamSynchronize(e->stream);  // nothing of this engine may still be running on its buffers
+    if (e->h_stage) { pinned_release(e->h_stage, e->h_stage_bytes); e->h_stage = nullptr; }   // (the creation upload has long finished)
     if (e->own_stream && e->stream) stream_release(e->device, e->stream);
     e->stream = nullptr;
     if (e->arena) arena_release(e->device, e->arena, e->arena_bytes);
@@ -1959,6 +1999,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     // d = 16, 512 chains, T = 1000: 4.27 ms with 2 workgroups per CU, 2.22 ms with 48; d = 32, 128 chains: 4.86 -> 3.02 ms).
     const int dense_wg_per_cu = !dense ? 0 : e->nt == 1 ? 48 : e->nt == 2 ? 8 : 2;
     const long long steps = e->T - 1;  // transitions
+    bool small_short = false;
     if (steps <= 0) {
         e->S = 0;
         e->L = 1;
@@ -1977,6 +2018,12 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             // take fewer, slightly longer segments for that where it costs at most a few steps of latency
             const long long cap = e->n_chains <= 16 ? 256 / e->n_chains : 0;
             if (cap >= 1 && S_target > cap && (steps + cap - 1) / cap <= 32) S_target = cap;
+            // … and with its boundary recursion in log depth (boundary_scan_par_body) the segments of that schedule can be SHORT: as many as
+            // fit the workgroup, down to 3 steps each (measured, scripts/time_small_segments.py)
+            if (cap >= 1 && (steps + cap - 1) / cap <= 32 && e->uniform && !e->masked && ds->step_model == nullptr && !small_sweep_off()) {
+                S_target = std::min<long long>(cap, std::max<long long>(1, steps / 3));
+                small_short = true;
+            }
         }
         // Batches of one model on the model / data split (below: e->split): the data pass is vectors only, one workgroup per 4·(64/d) chains
         // of a segment, so the machine fills through MORE segments, and the per-model tables are a recursion over the segment LENGTH
@@ -1990,7 +2037,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         }
         if (S_target < 1) S_target = 1;
         long long L = (steps + S_target - 1) / S_target;
-        const long long Lmin = ds->segments > 0 ? 1 : 8;
+        const long long Lmin = ds->segments > 0 ? 1 : small_short ? 3 : 8;
         if (L < Lmin) L = Lmin;
         if (L > steps) L = steps;
         e->L = L;
@@ -3287,9 +3334,8 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     const bool fe = want_fe != 0;
     // k_small_sweep (lgssm_kernels.hpp): the whole four-phase sweep of a small problem in one launch.  Per-kernel profiling keeps the separate
     // launches (there is nothing to time separately in one kernel); RXHIP_SMALL_SWEEP=0 forces them (the tests compare the two bit for bit).
-    const char* small_env = hook_env("RXHIP_SMALL_SWEEP");
-    const bool small_off = small_env && std::atoi(small_env) == 0;
-    const bool small_now = !small_off && !e->dense && !fused && !filter && e->uniform && !e->sequential && !e->masked && e->d_scan && e->S > 0 &&
+    const bool small_off = small_sweep_off();
+    const bool small_now = !small_off && !e->dense && !fused && e->uniform && !e->sequential && !e->masked && e->d_scan && e->S > 0 &&
                            e->n_chains <= 16 && e->n_chains * (long long)e->S <= 256 && !e->profiling;   // (≤ 16 chains: the free-energy reduction of k_fe_few)
     rxhip_status st;
     DenseParams dp{};

@@ -101,9 +101,14 @@ struct Launch {
         const long long nb = ((p.T - 1) * p.n_chains + 255) / 256;
         hipLaunchKernelGGL((k_joint<D, DY>), dim3((unsigned)(nb < 8192 ? (nb > 0 ? nb : 1) : 8192)), dim3(256), 0, s, p);
     }
-    static void small_sweep(const Params& p, const double* hc, bool fe, hipStream_t s) {   // n_chains · S ≤ 256, n_chains ≤ 64, one model
-        if (fe) hipLaunchKernelGGL((k_small_sweep<D, DY, true>), dim3(1), dim3(SMALL_SWEEP_THREADS), 0, s, p, carg(hc));
-        else hipLaunchKernelGGL((k_small_sweep<D, DY, false>), dim3(1), dim3(SMALL_SWEEP_THREADS), 0, s, p, carg(hc));
+    static void small_sweep(const Params& p, const double* hc, bool fe, hipStream_t s) {   // n_chains · S ≤ 256, n_chains ≤ 16, one model
+        const size_t lds = sizeof(double) * (size_t)small_sweep_lds_doubles<D, DY>();
+        const int par = p.S >= 24 ? 1 : 0;   // log-depth boundary recursion from 24 segments on (below, ⌈log₂ S⌉ rounds cost what S steps do)
+        if (p.filter) {
+            if (fe) hipLaunchKernelGGL((k_small_sweep<D, DY, true, true>), dim3(1), dim3(SMALL_SWEEP_THREADS), lds, s, p, carg(hc), par);
+            else hipLaunchKernelGGL((k_small_sweep<D, DY, false, true>), dim3(1), dim3(SMALL_SWEEP_THREADS), lds, s, p, carg(hc), par);
+        } else if (fe) hipLaunchKernelGGL((k_small_sweep<D, DY, true, false>), dim3(1), dim3(SMALL_SWEEP_THREADS), lds, s, p, carg(hc), par);
+        else hipLaunchKernelGGL((k_small_sweep<D, DY, false, false>), dim3(1), dim3(SMALL_SWEEP_THREADS), lds, s, p, carg(hc), par);
     }
     static void noise_reset(const NoiseParams& p, hipStream_t s) {
         hipLaunchKernelGGL((k_noise_reset<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
