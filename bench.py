@@ -174,8 +174,18 @@ class Background:
     """A checker that runs on a host thread while the bench goes on (the C oracle releases the GIL): `parity_spot` of the d = 64 chain
     is ≈30 s of one CPU core — outside every timed region, and joined before the JSON line is printed."""
 
+    live = []   # every checker started so far
+
+    @classmethod
+    def quiesce(cls):
+        """Wait for the checkers started so far: the legs that measure HOST-side latency (a first touch, an `infer(...)` call) run on an
+        idle host — under the box's CPU quota (16 CPUs, cgroup) a checker's threads get the timed thread throttled for tens of ms."""
+        for b in cls.live:
+            b.t.join()
+
     def __init__(self, fn):
         self.out = None
+        Background.live.append(self)
 
         def run():
             try:
@@ -218,6 +228,7 @@ def extra_c1(device, with_cpu=True):
     (the cpu_baseline leg of this config: checker and baseline, never the product path)."""
     mdl = workloads.c1_model()
     _, y = workloads.generate_chain(mdl, 1000, 42)
+    Background.quiesce()
     spec = rxhip.linear_gaussian_ssm(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
     rxhip.infer(model=spec, data={"y": y}, free_energy=True, options={"device": device})
     best = 1e9
@@ -265,6 +276,7 @@ def extra_c3(device, parity=True):
     mdl = workloads.c3_model()
     T, d = 10000, 64
     y = workloads.generate_batch(mdl, T, 1, seed0=6400)
+    Background.quiesce()
     # a throwaway engine of ANOTHER d = 64 model first: the first launch of a kernel loads its code object (a property of the
     # process); the model timed below has never been seen by any engine, so its tables are built, not fetched from the cache
     with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"] * 1.5, mdl["Q"], mdl["m0"], mdl["V0"], T=400, n_chains=1, device=device) as warm:
@@ -300,10 +312,11 @@ def extra_c3(device, parity=True):
     # Flop counts.  ref: SURVEY §8d's reference-schedule count (18 d³ per step).  mfma: what the matrix pipe executes, from the
     # instruction counts of the shipped kernels — v_mfma_f64_16x16x4_f64 = 2048 flop; per time step and workgroup (4 waves):
     # forward 4·76 (panel inverse: 4·4 tile-inverse rounds, 12 row block, 3·(4 + 16) panel updates) + 4·64 (G' = K C) + 160
-    # (M = PLW − K G, 10 of 16 tiles: symmetric) = 720; backward 256 (J' = C K') + 160 (V_s = C + J V_s J', 10 of 16 tiles) = 416; residual forms of the free energy 256 per 16 steps;
+    # (M = PLW − K G, 10 of 16 tiles: symmetric) = 720, + 16 where the tile inverses are seeded (4·8 products of a Newton – Schulz step instead of 4·4
+    # rank-4 rounds: every step but a segment's first once the Riccati recursion has converged — 19 of 20 here) = 736; backward 256 (J' = C K') + 160 (V_s = C + J V_s J', 10 of 16 tiles) = 416; residual forms of the free energy 256 per 16 steps;
     # aggregation GEMM [2d × L·dy]·[L·dy × S] ≈ 8 per step — confirmed by SQ_INSTS_VALU_MFMA_F64 (profiles/r04/pmc_c3.txt).  The round-2 kernels
     # executed 768 + 512 (bench counted 12 d³ = 1536 per step, the counters said 1280).
-    mfma_step = {"kd_forward_info": 720, "kd_backward_info": 416, "kd_fe_resid_mfma": 16, "kd_agg_gemm": 8}
+    mfma_step = {"kd_forward_info": 736, "kd_backward_info": 416, "kd_fe_resid_mfma": 16, "kd_agg_gemm": 8}
     mfma_flop = sum(mfma_step.values()) * 2048 * T
     ref_flop = 18 * d ** 3 * T
     tf = lambda flop, t_ms: flop / (t_ms * 1e-3) / 1e12
@@ -425,6 +438,7 @@ def extra_mid(device):
     """Not BASELINE configs: batches of one model at mid-size state dimensions on the MFMA path (model pass once per engine,
     data pass per sweep — DESIGN §6b), 1 BP sweep + free energy per step."""
     out = {}
+    Background.quiesce()
     for d, dy, C, T in ((8, 4, 1024, 1000), (64, 64, 64, 1000)):
         m = workloads.random_model(d, dy, seed=d)
         y = workloads.generate_batch(m, T, 8, seed0=1)

@@ -21,6 +21,7 @@
 // vectors across boundaries.  Inside a segment every step recomputes the full matrix algebra.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "lgssm_kernels.hpp"
 
@@ -578,6 +579,29 @@ __device__ __forceinline__ void diag_inverse16(double (&t)[4], double* sb, int l
 }
 
 struct NoPrefetch { __device__ __forceinline__ void operator()() const {} };
+// Seeding the in-wave tile inverse with the one of the previous TIME step (kd_forward_info, round 4).  Along a chain the pivot tile D_k(t) of
+// block step k differs from D_k(t − 1) by the Riccati recursion's contraction — by rounding once the recursion has converged, which at the
+// segment starts of a long chain is everywhere but in its first segments.  With X₀ = D_k(t − 1)⁻¹ in hand one Newton – Schulz step
+//     W = D X₀,   X₁ = X₀ + X₀′(I − W)
+// is two chains of four MFMAs straight on the accumulator registers (an MFMA whose A operand is a tile in accumulator layout multiplies by the
+// tile's TRANSPOSE, hence X₀′: written this way the antisymmetric part of X₀ cancels instead of doubling — X₀ + X₀′ − X₀′DX₀ is symmetric to
+// rounding whatever X₀ was) in place of four rank-4 rounds with an LDS round trip, a 4×4 Cramer solve and a reciprocal each (≈ 2 300 → 650 cycles,
+// of a wave the other three wait for).  Taken when every |W − I| entry is below 10⁻⁸ (the result is then exact to 10⁻¹⁴; else the exact rounds
+// run and reseed).  The determinant follows from log det D(t) = log det D(t − 1) + tr(W − I) − O(‖W − I‖²): the trace is kept as a per-LANE
+// partial sum, added into a per-lane running total once per step, and reduced over lanes ONCE at the end of the segment.
+struct NoSeed { static constexpr bool ON = false; };
+struct DiagSeed {
+    static constexpr bool ON = true;
+#ifdef RXHIP_TEST_SEEDCOUNT
+    static constexpr int LDS_DOUBLES = 280;
+#else
+    static constexpr int LDS_DOUBLES = 264;   // per wave: the tile [4][64], the determinant at the last exact inversion
+#endif
+    double* x0 = nullptr;
+    bool valid = false;     // wave-uniform: x0 holds the previous step's inverse
+    bool use = false;       // attempt at all (not on masked or per-step-constant sweeps: every step's tile is another matrix)
+    double r = 0.0, a = 0.0;   // lane partials: Σ tr(W − I) since the last exact inversion; Σ over steps of r
+};
 // `prefetch` is called once, before the last block step: loads the caller needs right after the inverse travel under it
 // The equilibration exponents of a matrix, from its diagonal tile `dt` (tile (w, w) in accumulator layout): written by the 16
 // lanes that hold a diagonal element.  blk_inverse does this itself (PUB) — or the caller does, where it has the tile in
@@ -613,6 +637,9 @@ template <int CTRL>
 __device__ __forceinline__ double dpp_row_mov(double v) {
     return __hiloint2double(__builtin_amdgcn_mov_dpp(__double2hiint(v), CTRL, 0xf, 0xf, true), __builtin_amdgcn_mov_dpp(__double2loint(v), CTRL, 0xf, 0xf, true));
 }
+__device__ __forceinline__ double rd_lane(double v, int l) {   // the value of lane l, in every lane
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
 __device__ __forceinline__ double row16_sum(double v) {
     v += dpp_row_mov<0xB1>(v);
     v += dpp_row_mov<0x4E>(v);
@@ -622,8 +649,8 @@ __device__ __forceinline__ double row16_sum(double v) {
 }
 // FINAL = false: no barrier at the end — the caller must pass a workgroup barrier before anything else writes to `scratch`
 // PUB = false: the exponents are in the scratch already (blk_publish_exponents + a workgroup barrier by the caller)
-template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true>
-__device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_, int lane_, LogProd& lp, PF prefetch = PF()) {
+template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true, class SEED = NoSeed>
+__device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_, int lane_, LogProd& lp, PF prefetch = PF(), SEED* seed = nullptr) {
     typedef double v4d __attribute__((ext_vector_type(4)));
     constexpr int HALF = blk_half_doubles(NT);
     // the wave index as a scalar (uniform branches below); the lane index laundered, so that the lane constants and LDS addresses
@@ -666,9 +693,16 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
 #pragma unroll
             for (int r = 0; r < 4; ++r) a.v[t][r] = __builtin_ldexp(a.v[t][r], hr[r] + hc[t]);
     }
+#ifdef RXHIP_TEST_SEEDCOUNT
+    long long tb_ = __builtin_readcyclecounter();
+#define RXHIP_BPH(i) do { if constexpr (SEED::ON) { const long long tn_ = __builtin_readcyclecounter(); if (lane == 0) seed->x0[272 + (i)] += (double)(tn_ - tb_); tb_ = tn_; } } while (0)
+#else
+#define RXHIP_BPH(i) do { } while (0)
+#endif
     // ---- block steps ----
 #pragma unroll
     for (int k = 0; k < NT; ++k) {
+        RXHIP_BPH(k == 0 ? 0 : 3);
         double* hb = scratch + (k & 1) * HALF;  // R [NT][4][64] | −D⁻¹ [4][64] (first the wave-private scratch of the tile inverse) | det, flag
         double* nd = hb + NT * 256;
         double di[4];
@@ -686,7 +720,57 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
             // accumulator registers, X ← X(2I − DX), two chains of four MFMAs instead of four rank-4 rounds, determinant from tr E − ½ tr E².
             // Exact to 10⁻¹³ once X is re-symmetrised every step, and worth nothing: kd_forward_info 0.433 against 0.425 ms; even with the seed
             // forced on every step 0.419.  The diagonal tile is not what the panel steps wait for — DESIGN §6e.)
-            diag_inverse16(di, nd, lane, badk, detp);
+            if constexpr (SEED::ON) {
+                bool done = false;
+#ifdef RXHIP_TEST_SEEDCOUNT
+                const long long tc0 = __builtin_readcyclecounter();
+#endif
+                if (__builtin_expect(seed->valid && seed->use, 1)) {   // (the hot path: the exact rounds below are laid out of line)
+                    double x0[4], e[4];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) x0[r] = seed->x0[r * 64 + lane];
+                    v4d wv = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) wv = __builtin_amdgcn_mfma_f64_16x16x4f64(di[r], x0[r], wv, 0, 0, 0);   // W = D′X₀
+                    bool big = false;
+                    double trp = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const bool dg = j == q + 4 * r;
+                        e[r] = wv[r] - (dg ? 1.0 : 0.0);
+                        big = big | !(__builtin_fabs(e[r]) <= 1e-8);   // (NaN: big)
+                        trp += dg ? e[r] : 0.0;
+                    }
+                    if (__builtin_expect(!__any(big), 1)) {
+                        v4d v = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v = __builtin_amdgcn_mfma_f64_16x16x4f64(x0[r], -e[r], v, 0, 0, 0);   // X₀′(I − W)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) di[r] = x0[r] + v[r];
+                        seed->r += trp;
+                        detp = seed->x0[256];
+                        done = true;
+#ifdef RXHIP_TEST_SEEDCOUNT
+                        seed->x0[257] += 1.0;
+#endif
+                    }
+                }
+                if (__builtin_expect(!done, 0)) {
+                    diag_inverse16(di, nd, lane, badk, detp);
+                    seed->r = 0.0;
+                    seed->valid = true;
+                    if (lane == 0) seed->x0[256] = detp;
+                }
+                seed->a += seed->r;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) seed->x0[r * 64 + lane] = di[r];
+#ifdef RXHIP_TEST_SEEDCOUNT
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (lane == 0) seed->x0[done ? 258 : 259] += (double)(__builtin_readcyclecounter() - tc0);
+#endif
+            } else {
+                diag_inverse16(di, nd, lane, badk, detp);
+            }
             badk = __any(badk);
 #pragma unroll
             for (int r = 0; r < 4; ++r) nd[r * 64 + lane] = -di[r];
@@ -695,7 +779,9 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
                 nd[257] = badk ? 1.0 : 0.0;
             }
         }
+        RXHIP_BPH(1);
         lds_barrier();
+        RXHIP_BPH(2);
         if (nd[257] != 0.0) bad = true;
         if (w == 0 && lane == 0) lp.mul(nd[256]);
         if (w == k) {
@@ -740,11 +826,13 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
             }
         }
     }
+    RXHIP_BPH(3);
     // the array holds −A_s⁻¹: negate, scale back
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) a.v[t][r] = __builtin_ldexp(-a.v[t][r], hr[r] + hc[t]);
+    RXHIP_BPH(4);
     if (FINAL) lds_barrier();  // the scratch (exponent table, last half) may be reused by the caller
     return !bad;
 }
@@ -754,9 +842,9 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
 #define RXHIP_KF_RELOAD 1
 #endif
 
-template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true>
-__device__ __forceinline__ bool spd_inverse(Acc<NT>& a, double* scratch, int w, int lane, LogProd& lp, PF prefetch = PF()) {
-    return blk_inverse<NT, PF, FINAL, PUB>(a, scratch, w, lane, lp, prefetch);
+template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true, class SEED = NoSeed>
+__device__ __forceinline__ bool spd_inverse(Acc<NT>& a, double* scratch, int w, int lane, LogProd& lp, PF prefetch = PF(), SEED* seed = nullptr) {
+    return blk_inverse<NT, PF, FINAL, PUB, SEED>(a, scratch, w, lane, lp, prefetch, seed);
 }
 
 // ---- vectors in LDS ------------------------------------------------------------------------------
@@ -865,6 +953,9 @@ struct DenseLds {
     // kernels that keep two LDS matrices (two workgroups per CU at d = 64) lend the inverse a matrix that is dead while it runs
     static constexpr bool ALIAS = RXHIP_INV_BLOCKED && C::MAT >= blk_scratch_doubles(NT);
     static constexpr int SCR2 = ALIAS ? 8 * C::D : (SCR > 8 * C::D ? SCR : 8 * C::D);   // what those kernels carve besides
+    // kd_forward_info at d ≥ 48 keeps a seed of the tile inverse per wave there (DiagSeed) — 162 304 bytes for two workgroups at d = 64, of 163 840
+    static constexpr bool SEEDED = ALIAS;
+    static constexpr int FWD_TAIL = SEEDED && NT * DiagSeed::LDS_DOUBLES > SCR2 ? NT * DiagSeed::LDS_DOUBLES : SCR2;
     static constexpr size_t bytes(int dmax) {   // scan kernels (vectors + the staging of dense_affine_rounds), kd_prepare_bnd (scratch only)
         return sizeof(double) * ((size_t)NVEC * dmax + (SCR > 8 * C::D ? SCR : 8 * C::D) + 3 * C::THREADS + 32 + 2 * 32 * C::D + 48);
     }
@@ -874,7 +965,7 @@ struct DenseLds {
     }
     // kd_forward_info: 2 matrices, ξ_f | u | 4 partial-sum rows, the scratch
     static constexpr size_t fwd_info_bytes(int dmax) {
-        return sizeof(double) * ((size_t)2 * C::MAT + (size_t)10 * dmax + SCR2);
+        return sizeof(double) * ((size_t)2 * C::MAT + (size_t)10 * dmax + FWD_TAIL);
     }
     // kd_backward_info: 2 matrices, m_s | C ξ_f, the scratch / matvec partials
     static constexpr size_t bwd_info_bytes(int dmax) {
@@ -1533,6 +1624,11 @@ __global__ void __launch_bounds__(64 * NT) kd_forward(DenseParams p) {
 // fe_part slots (negated contributions): 0 and S+s: backward of segment 0 / s ≥ 1;  1+s: forward of segment s.
 // STEPM: per-step constants (masked schedule only) — the constants of the transition INTO step t and of the observation at t come from
 // block step_model[t]: M_t = [P⁻¹ + B′Q⁻¹B]_t + [A′P⁻¹A]_{t+1} − K_t G_{t−1}.  A template flag: the fixed-model kernel keeps its registers.
+#ifdef RXHIP_TEST_SEEDCOUNT   // per-phase cycle counters of kd_forward_info (debug build only), lane 0 of every wave
+#define RXHIP_PH(i) do { if constexpr (SEEDED) { const long long tn_ = __builtin_readcyclecounter(); if (lane == 0) cpp[4 * dm + w * DiagSeed::LDS_DOUBLES + 260 + (i)] += (double)(tn_ - tph_); tph_ = tn_; } } while (0)
+#else
+#define RXHIP_PH(i) do { } while (0)
+#endif
 template <int NT, bool FE, bool STEPM = false>
 #ifndef RXHIP_FWD_WAVES
 #define RXHIP_FWD_WAVES 2
@@ -1570,6 +1666,17 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
     bool ok = true;
     LogProd lp;
     Acc<NT> lam, a;
+    constexpr bool SEEDED = DenseLds<NT>::SEEDED && !STEPM;   // (per-step constants: every step's tile is another matrix)
+    using SeedT = typename std::conditional<SEEDED, DiagSeed, NoSeed>::type;
+    SeedT seed;
+    if constexpr (SEEDED) {
+        seed.x0 = cpp + 4 * dm + w * DiagSeed::LDS_DOUBLES;
+        seed.use = p.mseg == 0;   // (masked sweeps: the same)
+#ifdef RXHIP_TEST_SEEDCOUNT
+        if (lane == 0) for (int q = 257; q < 264; ++q) seed.x0[q] = 0.0;
+        if (lane == 0) for (int q = 0; q < 20; ++q) seed.x0[260 + q] = 0.0;
+#endif
+    }
     // K = P⁻¹A is the A operand of both contractions of a step.  Its fragments (16 doubles per thread at d = 64) are re-read from
     // L2 after every inverse (KF_RELOAD): held across the panel inverse they pushed the kernel over 256 registers, and every
     // scratch reload is a VMEM wait that also drains the record stores in flight.  The address is laundered per step so that
@@ -1640,6 +1747,9 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
         }
     }
     lds_barrier();
+#ifdef RXHIP_TEST_SEEDCOUNT
+    long long tph_ = __builtin_readcyclecounter();
+#endif
     for (long long i = 0; i < len; ++i) {
         const long long t = t0 + i;
         if constexpr (STEPM) {
@@ -1647,6 +1757,7 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
             if (!KF_RELOAD) load_kf();
         }
         double* rec = p.filt + (chain * p.T + (t - 1)) * C::REC;
+        RXHIP_PH(11);
         const double gyc = gyn;
         if (tid < D) {
             rec[tid] = xi[tid];  // ξ_f(t − 1)
@@ -1655,10 +1766,11 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
         // C = (Λ_f + A'P⁻¹A)⁻¹.  The inverse's scratch is S0 (or its own carve): the next writer of S0 is the store of −G below,
         // behind a workgroup barrier, so the inverse ends without one.
 #ifndef RXHIP_TEST_NOINV
-        if (KF_RELOAD && RXHIP_KF_RELOAD == 1) ok = spd_inverse<NT, decltype(load_kf), false, !PREPUB>(lam, rowbuf, w, lane, lp, load_kf) && ok;
-        else ok = spd_inverse<NT, NoPrefetch, false, !PREPUB>(lam, rowbuf, w, lane, lp) && ok;
+        if (KF_RELOAD && RXHIP_KF_RELOAD == 1) ok = spd_inverse<NT, decltype(load_kf), false, !PREPUB, SeedT>(lam, rowbuf, w, lane, lp, load_kf, &seed) && ok;
+        else ok = spd_inverse<NT, NoPrefetch, false, !PREPUB, SeedT>(lam, rowbuf, w, lane, lp, NoPrefetch(), &seed) && ok;
 #endif
         if (KF_RELOAD && RXHIP_KF_RELOAD == 2) load_kf();
+        RXHIP_PH(0);   // the inverse
         // C_t goes to the record as the backward kernel reads it: the tiles this wave owns in the symmetric pairing (below) — the
         // accumulator of V_s(t) = C_t + H G' there is computed for the same tiles only (10 of 16 at d = 64)
 #pragma unroll
@@ -1704,14 +1816,17 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
         lds_barrier();
         // G' = K C
         acc_zero<NT>(a);
+        RXHIP_PH(1);   // record stores of C, C -> S1, PLW loads, barrier
         mm_k(a, S1);
         acc_store_full<NT>(a, rec + C::HDR + D * D, w, lane);
+        RXHIP_PH(2);   // G' = K C + its record stores (issue)
 #pragma unroll
         for (int q = 0; q < NT; ++q)
 #pragma unroll
             for (int r = 0; r < 4; ++r) a.v[q][r] = -a.v[q][r];
         acc_store_T<NT>(a, S0, LD, w, lane);  // S0 = −G
         lds_barrier();
+        RXHIP_PH(3);   // -G -> S0, barrier
         // ξ_p = K C ξ_f = G' ξ_f: column sums of S0, a quarter of the range per thread group
         {
             double s0 = 0.0, s1 = 0.0, c0 = 0.0, c1 = 0.0;
@@ -1726,6 +1841,7 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
             xpp[grp * D + gi] = s0 + s1;
             cpp[grp * D + gi] = c0 + c1;
         }
+        RXHIP_PH(4);   // column sums
         // M_{t+1} = Λ_f(t) + A'P⁻¹A = PLW − K G is symmetric: every unordered pair of tile indices is computed ONCE, by the wave
         // that owns the pair (tile (w, t) with (t − w) mod NT ≤ NT/2 — 3, 3, 2, 2 tiles per wave at d = 64 instead of 4), and the
         // mirror image is read back transposed below: 48 instead of 64 MFMAs on the critical wave, exact symmetry for free
@@ -1744,6 +1860,7 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
                     macc[sl] = __builtin_amdgcn_mfma_f64_16x16x4f64(kf[kk], S0[(4 * kk + lq) * LD + 16 * slot_tile(sl) + lj], macc[sl], 0, 0, 0);
         }
         lds_barrier();
+        RXHIP_PH(5);   // M' contraction, barrier
         if (tid < D) {
             rec[2 * D + tid] = (cpp[tid] + cpp[D + tid]) + (cpp[2 * D + tid] + cpp[3 * D + tid]);      // C_{t−1} ξ_f(t−1)
             xi[tid] = gyc - ((xpp[tid] + xpp[D + tid]) + (xpp[2 * D + tid] + xpp[3 * D + tid]));       // ξ_f(t)
@@ -1762,6 +1879,7 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
             blk_publish_exponents<NT>(dtile, rowbuf, ws, ln);
         }
         lds_barrier();
+        RXHIP_PH(6);   // xi, M' -> S1, exponents, barrier
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             int dist = t - ws;
@@ -1774,11 +1892,31 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
                 lam.v[t][r] = (t == ws) ? 0.5 * (v + S1[col * LD + row]) : v;
             }
         }
+        RXHIP_PH(7);   // symmetrisation reads
     }
     acc_add_mat<NT>(lam, cst_w + c.oW, D, w, lane, -1.0);
     acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);  // Λ_f at the segment end
     if (seg == p.S - 1 && tid < D) p.filt[(chain * p.T + (t0 + len - 1)) * C::REC + tid] = xi[tid];  // ξ_f(T): no successor writes it
-    if (FE && tid == 0) dense_fe_write(p, 1 + seg, chain, lp.value(), 0.0, 0.0);
+    double ldet = 0.0;
+#ifdef RXHIP_TEST_SEEDCOUNT
+    if constexpr (SEEDED) {
+        if (lane == 0 && seg == 100) printf("  wave %d phases (cycles per step): top %.0f | inverse %.0f | C stores+barrier %.0f | G'=KC %.0f | -G store+barrier %.0f | colsums %.0f | M' contraction+barrier %.0f | xi, M' store, barrier %.0f | symmetrise %.0f\n", w,
+            seed.x0[271] / len, seed.x0[260] / len, seed.x0[261] / len, seed.x0[262] / len, seed.x0[263] / len, seed.x0[264] / len, seed.x0[265] / len, seed.x0[266] / len, seed.x0[267] / len);
+        if (lane == 0 && seg == 100) printf("  wave %d inverse (cycles per step): equilibrate %.0f | before the barrier (publish, own tile inverse; else nothing) %.0f | in the barrier %.0f | after it (trailing update) %.0f | scale back %.0f\n", w,
+            seed.x0[272] / len, seed.x0[273] / len, seed.x0[274] / len, seed.x0[275] / len, seed.x0[276] / len);
+        if (lane == 0 && (seg % 50 == 0 || seg == 1 || seg == 2 || seg == 3)) printf("seg %d wave %d: seeded %d of %d steps, %.0f cycles per seeded tile inverse, %.0f per exact one\n", (int)seg, w, (int)seed.x0[257], (int)len, seed.x0[258] / fmax(1.0, seed.x0[257]), seed.x0[259] / fmax(1.0, (double)len - seed.x0[257]));
+    }
+#endif
+    if constexpr (SEEDED && FE) {   // the seeded steps' share of Σ_t log det M_t: lane partials → one number per wave → thread 0
+        double sa = row16_sum(seed.a);
+        sa = (rd_lane(sa, 0) + rd_lane(sa, 16)) + (rd_lane(sa, 32) + rd_lane(sa, 48));
+        lds_barrier();
+        if (lane == 0) xpp[w] = sa;
+        lds_barrier();
+        if (tid == 0)
+            for (int q = 0; q < NT; ++q) ldet += xpp[q];
+    }
+    if (FE && tid == 0) dense_fe_write(p, 1 + seg, chain, lp.value() + ldet, 0.0, 0.0);
     if (!ok && tid == 0) atomicOr(p.status, ST_NOT_POSDEF);
 }
 

@@ -33,7 +33,7 @@ def test_bench_prints_the_contract_line():
     sys.path.insert(0, ROOT)
     import bench
 
-    assert c["all_cores"]["cores"] == bench.host_cores() and c["all_cores"]["value"] > 0  # the cgroup quota, not the visible threads
+    assert c["all_cores"]["cores"] == bench.host_cores()[0] and c["all_cores"]["value"] > 0  # the cgroup quota, not the visible threads
     assert c["free_energy_rel_vs_gpu"] < 1e-8  # both legs ran on the same observations
     ps = d["parity_spot"]
     assert ps["ok"] and ps["mean_rel"] < 1e-6 and ps["cov_rel"] < 1e-6 and ps["fe_rel"] < 1e-8
