@@ -180,6 +180,10 @@ typedef struct {
 } rxhip_noise_prior;
 rxhip_status rxhip_lgssm_noise_create(const rxhip_lgssm_desc* desc, const rxhip_noise_prior* prior, rxhip_engine** out);
 rxhip_status rxhip_lgssm_noise_get(rxhip_engine* e, double* nu, double* V);
+/* on != 0: every later rxhip_run CONTINUES from the q(W) the previous run ended with instead of the `@initialization` marginal (the first run
+ * still starts there) — for drivers that take one VMP iteration per call, as the loop of src/inference/batch.jl:391-430 does: k calls of
+ * rxhip_run(1) then equal one rxhip_run(k), bit for bit.  rxhip_get_free_energy covers the last call's iterations. */
+rxhip_status rxhip_lgssm_noise_continue(rxhip_engine* e, int32_t on);
 
 /* ------------------------------------------------------------------------------------------
  * Generic factor-graph descriptor — the struct-of-arrays dump of a materialised GraphPPL model, i.e. what
@@ -311,6 +315,20 @@ typedef struct {
     int64_t* data_var; /* [N] (nullable) */
 } rxhip_mvgmm_lowered;
 rxhip_status rxhip_graph_lower_mvgmm(const rxhip_graph_desc* g, rxhip_mvgmm_lowered* out);
+
+/* The state-space chain with an unknown observation-noise precision (rxhip_lgssm_noise_create above):
+ *     W ~ Wishart(ν, S)   [dy = 1 also: τ ~ Gamma(shape, rate | scale), lowered as Wishart₁(2·shape, 1/(2·rate))]
+ *     x-chain as for rxhip_graph_lower_lgssm;   y[t] ~ MvNormal(μ = B * x[t], Λ = W)   (`Normal(mean = …, precision = τ)`)
+ * with the `@initialization` marginal q(W) (Wishart, or Gamma for dy = 1).  `chain` is filled as rxhip_graph_lower_lgssm fills it, except
+ * Q (not written: the noise is the unknown).  One model, no offsets / inputs / missing observations, d, dy ≤ 4 — else RXHIP_ERR_UNSUPPORTED. */
+typedef struct {
+    rxhip_lgssm_lowered chain;
+    int64_t precision_var; /* variable id of W */
+    double nu0, init_nu;
+    double* S0;     /* [dy][dy] (nullable) */
+    double* init_V; /* [dy][dy] (nullable) */
+} rxhip_lgssm_noise_lowered;
+rxhip_status rxhip_graph_lower_lgssm_noise(const rxhip_graph_desc* g, rxhip_lgssm_noise_lowered* out);
 
 /* Hierarchical Gaussian filter one-step graph (a11; test/models/statespace/hgf_tests.jl:9-31):
  *     zt_min ~ Normal(data, data); xt_min ~ Normal(data, data); zt ~ Normal(mean = zt_min, var = const);

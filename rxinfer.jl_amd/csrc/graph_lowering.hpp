@@ -571,6 +571,118 @@ inline rxhip_status lower_lgssm(const rxhip_graph_desc* g, Lgssm& L) {
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// The state-space chain with an UNKNOWN observation-noise precision (rxhip_lgssm_noise_create): one Wishart node on a random W —
+// or, for scalar observations, one Gamma node on a random τ (Gamma(a, b) = Wishart₁(ν = 2a, S = 1/(2b))) — and every observation node
+//     y[t] ~ MvNormal(μ = B * x[t], Λ = W)          (`Normal(mean = …, precision = τ)` for dy = 1)
+// precision-parametrised on that ONE variable.  The lowering takes the prior node out, gives the observation nodes a placeholder
+// covariance (the engine never reads desc->Q) and hands the rest to lower_lgssm: what comes back must be a plain chain of one model.
+struct LgssmNoise {
+    Lgssm chain;
+    long long w_var = -1;
+    double nu0 = 0.0, init_nu = 0.0;
+    std::vector<double> S0, init_V;
+};
+inline rxhip_status lower_lgssm_noise(const rxhip_graph_desc* g, LgssmNoise& L) {
+    if (rxhip_status st = check_tables(g)) return st;
+    if (g->factor_iface_ptr) return unsupported("CSR interface tables: not a three-interface Gaussian graph");
+    const long long NV = g->n_variables, NF = g->n_factors;
+    long long fw = -1;
+    bool gamma_form = false;
+    for (long long f = 0; f < NF; ++f) {
+        const int t = g->factor_type[f];
+        if (t == RXHIP_NODE_WISHART || t == RXHIP_NODE_GAMMA_SHAPE_RATE || t == RXHIP_NODE_GAMMA_SHAPE_SCALE) {
+            if (fw >= 0) return unsupported("more than one precision prior in a state-space graph");
+            fw = f;
+            gamma_form = t != RXHIP_NODE_WISHART;
+        }
+    }
+    if (fw < 0) return unsupported("no Wishart / Gamma prior node");
+    const long long w = iface(g, fw, 0);
+    if (g->var_kind[w] != RXHIP_VARKIND_RANDOM) return unsupported("precision prior on a non-random variable");
+    const int dy = g->var_rows[w];
+    if (gamma_form && dy != 1) return badarg("Gamma prior on a precision that is not a scalar");   // (random variables carry their dimension in var_rows only)
+    // the prior's constants
+    L = LgssmNoise();
+    L.w_var = w;
+    if (gamma_form) {
+        double a, b;
+        if (!const_scalar(g, iface(g, fw, 1), &a) || !const_scalar(g, iface(g, fw, 2), &b)) return unsupported("Gamma prior with non-constant parameters");
+        if (g->factor_type[fw] == RXHIP_NODE_GAMMA_SHAPE_SCALE) b = 1.0 / b;
+        if (!(a > 0.0) || !(b > 0.0)) return badarg("Gamma prior parameters must be positive");
+        L.nu0 = 2.0 * a;
+        L.S0.assign(1, 1.0 / (2.0 * b));
+    } else {
+        const double* S;
+        if (!const_scalar(g, iface(g, fw, 1), &L.nu0) || !const_value(g, iface(g, fw, 2), dy, dy, &S)) return unsupported("Wishart prior with non-constant parameters");
+        L.S0.assign(S, S + (size_t)dy * dy);
+    }
+    // the `@initialization` marginal q(W) (the reference refuses to start mean-field VMP without one)
+    const double* q;
+    if (init_params(g, w, RXHIP_INIT_WISHART, 1 + dy * dy, &q)) {
+        L.init_nu = q[0];
+        L.init_V.assign(q + 1, q + 1 + (size_t)dy * dy);
+    } else if (dy == 1 && init_params(g, w, RXHIP_INIT_GAMMA, 2, &q)) {
+        if (!(q[0] > 0.0) || !(q[1] > 0.0)) return badarg("@initialization marginal of the precision must have positive parameters");
+        L.init_nu = 2.0 * q[0];
+        L.init_V.assign(1, 1.0 / (2.0 * q[1]));
+    } else
+        return badarg("mean-field VMP needs an @initialization marginal for the observation precision");
+    // private tables: the prior node removed, the observation nodes in covariance form on a placeholder constant
+    NormalisedGraph N;
+    N.var_kind.assign(g->var_kind, g->var_kind + NV);
+    N.var_rows.assign(g->var_rows, g->var_rows + NV);
+    N.var_cols.assign(g->var_cols, g->var_cols + NV);
+    N.var_const.assign(g->var_const, g->var_const + NV);
+    N.pool.assign(g->const_pool, g->const_pool + g->n_const);
+    if (g->var_init_family) N.var_init_family.assign(g->var_init_family, g->var_init_family + NV);
+    if (g->var_init) N.var_init.assign(g->var_init, g->var_init + NV);
+    const long long placeholder = NV;
+    N.var_kind.push_back(RXHIP_VARKIND_CONST);
+    N.var_rows.push_back(dy);
+    N.var_cols.push_back(dy);
+    N.var_const.push_back((long long)N.pool.size());
+    if (!N.var_init_family.empty()) N.var_init_family.push_back(RXHIP_INIT_NONE);
+    if (!N.var_init.empty()) N.var_init.push_back(-1);
+    for (int i = 0; i < dy; ++i)
+        for (int j = 0; j < dy; ++j) N.pool.push_back(i == j ? 1.0 : 0.0);
+    long long n_obs = 0;
+    for (long long f = 0; f < NF; ++f) {
+        if (f == fw) continue;
+        int t = g->factor_type[f];
+        long long io[3] = {iface(g, f, 0), iface(g, f, 1), iface(g, f, 2)};
+        for (int k = 0; k < 2; ++k)
+            if (io[k] == w) return unsupported("the precision variable is used as something else than a precision");
+        if (io[2] == w) {
+            if ((t != RXHIP_NODE_MVNORMAL_MEAN_PRECISION && t != RXHIP_NODE_NORMAL_MEAN_PRECISION) || g->var_kind[io[0]] != RXHIP_VARKIND_DATA)
+                return unsupported("the random precision must be the Λ of observation nodes only");
+            t = t == RXHIP_NODE_NORMAL_MEAN_PRECISION ? RXHIP_NODE_NORMAL_MEAN_VARIANCE : RXHIP_NODE_MVNORMAL_MEAN_COV;
+            io[2] = placeholder;
+            ++n_obs;
+        }
+        N.factor_type.push_back(t);
+        N.factor_iface.insert(N.factor_iface.end(), io, io + 3);
+    }
+    if (n_obs == 0) return unsupported("precision prior that no observation node uses");
+    N.g = *g;
+    N.g.n_variables = (long long)N.var_kind.size();
+    N.g.n_factors = NF - 1;
+    N.g.var_kind = N.var_kind.data(); N.g.var_rows = N.var_rows.data(); N.g.var_cols = N.var_cols.data(); N.g.var_const = N.var_const.data();
+    N.g.factor_type = N.factor_type.data(); N.g.factor_iface = N.factor_iface.data();
+    N.g.const_pool = N.pool.data(); N.g.n_const = (long long)N.pool.size();
+    N.g.var_init_family = N.var_init_family.empty() ? nullptr : N.var_init_family.data();
+    N.g.var_init = N.var_init.empty() ? nullptr : N.var_init.data();
+    if (rxhip_status st = lower_lgssm(&N.g, L.chain)) return st;
+    const Lgssm& C = L.chain;
+    if (C.T != n_obs) return unsupported("observation nodes with a constant covariance next to the ones with the random precision");
+    if (C.dy != dy) return badarg("the precision's dimension is not the observations'");
+    if (C.n_models != 1 || C.deterministic || !C.cx.empty() || C.du > 0) return unsupported("unknown observation precision: plain chains of one model only");
+    if (C.d > 4 || C.dy > 4) return unsupported("unknown observation precision: d, dy <= 4");
+    if (g->allow_missing) return unsupported("unknown observation precision with missing observations");
+    last_error().clear();
+    return RXHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Mean-field mixture (NormalMixture, K ≤ 16) and its K = 1 form (iid Gaussian with unknown mean and precision)
 struct Gmm {
     long long N = 0;

@@ -252,6 +252,7 @@ struct rxhip_engine {
     size_t h_stage_bytes = 0;
     // unknown observation-noise precision (rxhip_lgssm_noise_create, noise_kernels.hpp): one block B | prior | state | history
     bool noise = false;
+    bool noise_continue = false;   // rxhip_lgssm_noise_continue: runs go on from the current q(W) (iteration-at-a-time drivers)
     char* noise_block = nullptr;
     double *n_B = nullptr, *n_prior = nullptr, *n_state = nullptr, *n_hist = nullptr, *n_part = nullptr;
     int n_hist_cap = 0, n_slices = 1;
@@ -2474,6 +2475,12 @@ rxhip_status rxhip_lgssm_noise_create(const rxhip_lgssm_desc* ds, const rxhip_no
     return RXHIP_OK;
 }
 
+rxhip_status rxhip_lgssm_noise_continue(rxhip_engine* e, int32_t on) {
+    if (!e) return RXHIP_ERR_BADARG;
+    if (!e->noise) return fail(e, RXHIP_ERR_BADARG, "noise_continue: not an engine with an unknown noise precision");
+    e->noise_continue = on != 0;
+    return RXHIP_OK;
+}
 rxhip_status rxhip_lgssm_noise_get(rxhip_engine* e, double* nu, double* V) {
     if (!e) return RXHIP_ERR_BADARG;
     if (!e->noise) return fail(e, RXHIP_ERR_BADARG, "noise_get: not an engine with an unknown noise precision");
@@ -2925,11 +2932,29 @@ static rxhip_status hgf_run_async(rxhip_engine* e, int32_t iterations, int32_t w
 rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_var, double* x_mean, double* x_var,
                                    int32_t layout);
 
+static void fill_lowered(const rxhip_lower::Lgssm& L, rxhip_lgssm_lowered* out, bool with_Q);
 rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowered* out) {
     if (!out) return RXHIP_ERR_BADARG;
     rxhip_lower::Lgssm L;
     rxhip_status st = rxhip_lower::lower_lgssm(g, L);
     if (st) return st;
+    fill_lowered(L, out, true);
+    return RXHIP_OK;
+}
+rxhip_status rxhip_graph_lower_lgssm_noise(const rxhip_graph_desc* g, rxhip_lgssm_noise_lowered* out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    rxhip_lower::LgssmNoise N;
+    rxhip_status st = rxhip_lower::lower_lgssm_noise(g, N);
+    if (st) return st;
+    fill_lowered(N.chain, &out->chain, false);
+    out->precision_var = N.w_var;
+    out->nu0 = N.nu0;
+    out->init_nu = N.init_nu;
+    if (out->S0) std::memcpy(out->S0, N.S0.data(), sizeof(double) * N.S0.size());
+    if (out->init_V) std::memcpy(out->init_V, N.init_V.data(), sizeof(double) * N.init_V.size());
+    return RXHIP_OK;
+}
+static void fill_lowered(const rxhip_lower::Lgssm& L, rxhip_lgssm_lowered* out, bool with_Q) {
     out->d = L.d; out->dy = L.dy; out->T = L.T; out->prior_through_transition = L.ptt;
     out->deterministic = L.deterministic;
     out->n_models = L.n_models;
@@ -2942,10 +2967,9 @@ rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowe
     if (out->step_model) for (long long t = 0; t < L.T; ++t) out->step_model[t] = L.n_models > 1 ? L.step_model[t] : 0;
     if (out->c) std::memcpy(out->c, L.c.data(), L.c.size() * sizeof(double));
     auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
-    cp(out->A, L.A); cp(out->B, L.B); cp(out->P, L.P); cp(out->Q, L.Q); cp(out->m0, L.m0); cp(out->V0, L.V0);
+    cp(out->A, L.A); cp(out->B, L.B); cp(out->P, L.P); if (with_Q) cp(out->Q, L.Q); cp(out->m0, L.m0); cp(out->V0, L.V0);
     if (out->state_var) for (long long t = 0; t < L.T; ++t) out->state_var[t] = L.state_var[t];
     if (out->data_var) for (long long t = 0; t < L.T; ++t) out->data_var[t] = L.data_var[t];
-    return RXHIP_OK;
 }
 const char* rxhip_lowering_error(void) { return rxhip_lower::last_error().c_str(); }
 
@@ -3003,6 +3027,36 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
         d.z0_mean = H.z0m; d.z0_var = H.z0v; d.x0_mean = H.x0m; d.x0_var = H.x0v;
         d.n_gh = H.n_gh; d.device = device; d.stream = stream;
         return rxhip_hgf_create(&d, out);
+    }
+    // a precision prior on top of a state-space chain (no mixture node, a `*` node or a Gaussian transition between random variables):
+    // the chain with unknown observation noise
+    auto noise_chain = [&]() -> bool {
+        if (rxhip_lower::has_node(g, RXHIP_NODE_NORMAL_MIXTURE)) return false;
+        if (!rxhip_lower::has_node(g, RXHIP_NODE_WISHART) && !rxhip_lower::has_node(g, RXHIP_NODE_GAMMA_SHAPE_RATE) && !rxhip_lower::has_node(g, RXHIP_NODE_GAMMA_SHAPE_SCALE)) return false;
+        if (g->factor_iface_ptr) return false;
+        for (long long f = 0; f < g->n_factors; ++f) {
+            const int t = g->factor_type[f];
+            if (t == RXHIP_NODE_MULTIPLY) return true;
+            if ((t == RXHIP_NODE_MVNORMAL_MEAN_COV || t == RXHIP_NODE_NORMAL_MEAN_VARIANCE || t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION) &&
+                g->var_kind[rxhip_lower::iface(g, f, 0)] == RXHIP_VARKIND_RANDOM && g->var_kind[rxhip_lower::iface(g, f, 1)] == RXHIP_VARKIND_RANDOM)
+                return true;
+        }
+        return false;
+    };
+    if (noise_chain()) {
+        rxhip_lower::LgssmNoise N;
+        rxhip_status st = rxhip_lower::lower_lgssm_noise(g, N);
+        if (st) return st;
+        const rxhip_lower::Lgssm& L = N.chain;
+        rxhip_lgssm_desc d;
+        std::memset(&d, 0, sizeof d);
+        d.d = L.d; d.dy = L.dy; d.T = L.T; d.n_chains = g->n_replicas > 0 ? g->n_replicas : 1; d.n_models = 1;
+        d.prior_through_transition = L.ptt;
+        d.A = L.A.data(); d.B = L.B.data(); d.P = L.P.data(); d.Q = nullptr; d.m0 = L.m0.data(); d.V0 = L.V0.data();
+        d.segments = segments; d.device = device; d.stream = stream;
+        rxhip_noise_prior pr;
+        pr.nu0 = N.nu0; pr.S0 = N.S0.data(); pr.init_nu = N.init_nu; pr.init_V = N.init_V.data();
+        return rxhip_lgssm_noise_create(&d, &pr, out);
     }
     if (rxhip_lower::has_node(g, RXHIP_NODE_WISHART)) {
         rxhip_lower::MvGmm M;
@@ -3364,7 +3418,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
             e->n_hist_cap = iterations;
         }
         np.hist = e->n_hist;
-        e->vt->noise_reset(np, e->stream);
+        if (!(e->noise_continue && e->ran)) e->vt->noise_reset(np, e->stream);
     }
     for (int it = 0; it < iterations; ++it) {
         p.iteration = it;

@@ -269,7 +269,7 @@ end
 mutable struct HIPGraphEngine
     engine::RxHip.Engine
     tables::GraphTables
-    family::Symbol                       # :lgssm, :drift, :mixture, :mvmixture, :hgf
+    family::Symbol                       # :lgssm, :lgssm_noise, :drift, :mixture, :mvmixture, :hgf
     data_ids::Vector{Int64}              # data variables in the order rxhip_set_data expects (time order)
     data_slot::Dict{Int64, Int}          # variable id -> position in `staging`
     staging::Vector{Float64}
@@ -374,6 +374,8 @@ function fire!(g::HIPGraphEngine)
     end
     if g.family === :mixture || g.family === :mvmixture
         RxHip.vmp_iteration!(e; free_energy = g.want_free_energy)   # continues from the marginals of the previous iteration
+    elseif g.family === :lgssm_noise
+        RxHip.run!(e; iterations = 1, free_energy = g.want_free_energy)   # one sweep + one Wishart update, from the q(W) of the previous call
     else
         RxHip.run!(e; iterations = 1, free_energy = g.want_free_energy)   # trees: one sweep is the fixed point
     end
@@ -395,11 +397,16 @@ as_marginal(d) = ReactiveMP.Marginal(d, false, false, nothing)
 
 function publish_marginals!(g::HIPGraphEngine)
     e = g.engine
-    if g.family === :lgssm
+    if g.family === :lgssm || g.family === :lgssm_noise
         mean, cov = RxHip.marginals(e)                          # d × T, d × d × T
         for (t, id) in enumerate(g.state_ids)
             haskey(g.marginals, id) || continue
             Rocket.next!(g.marginals[id], as_marginal(ReactiveMP.MvNormalMeanCovariance(mean[:, t, 1], Symmetric(cov[:, :, t, 1]))))
+        end
+        if g.family === :lgssm_noise && haskey(g.marginals, g.component_ids.p[1])
+            ν, V = RxHip.noise_posterior(e)                     # q(W) = Wishart(ν, V); scalar observations with a Gamma prior: Gamma(ν/2, 1/(2V))
+            q = g.component_ids.beta ? ReactiveMP.GammaShapeRate(ν[1] / 2, 1 / (2 * V[1, 1, 1])) : ReactiveMP.Wishart(ν[1], Symmetric(V[:, :, 1]))
+            Rocket.next!(g.marginals[g.component_ids.p[1]], as_marginal(q))
         end
     elseif g.family === :drift
         mean, var = RxHip.marginals(e)
@@ -500,9 +507,12 @@ function GraphPPL.postprocess_plugin(plugin::HIPInferencePlugin, model::GraphPPL
         end
     end
     width = Int(tables.var_rows[lowered.data_ids[1] + 1])
+    # the chain with an unknown noise precision: `p` carries the variable id of W, `beta` whether its prior was spelled as a Gamma
+    comps = lowered.family === :lgssm_noise ? (m = Int64[], p = [lowered.precision_id], s = Int64(-1), beta = lowered.gamma) : component_ids(tables)
+    lowered.family === :lgssm_noise && RxHip.noise_continue!(engine)
     g = HIPGraphEngine(engine, tables, lowered.family, lowered.data_ids, Dict(id => k for (k, id) in enumerate(lowered.data_ids)),
                        zeros(Float64, width * length(lowered.data_ids)), 0, false, marginals, nothing, lowered.state_ids, width,
-                       component_ids(tables),
+                       comps,
                        Dict{Int64, Int}(id => t for (t, id) in enumerate(get(lowered, :input_ids, Int64[])) if id >= 0),
                        zeros(Float64, get(lowered, :du, 0) * length(lowered.data_ids)), get(lowered, :du, 0),
                        Dict{Int64, Any}(), false, getoptions(plugin))

@@ -152,6 +152,11 @@ function NoiseEngine(A, B, P, m0, V0; T::Integer, nu0::Real, S0::AbstractMatrix,
     return e
 end
 
+"""Later `run!` calls continue from the current q(W) instead of the `@initialization` marginal (`rxhip_lgssm_noise_continue`): the plugin takes
+one VMP iteration per `fire!`, as the loop of src/inference/batch.jl:391-430 does."""
+noise_continue!(e::Engine, on::Bool = true) =
+    check(e, ccall((:rxhip_lgssm_noise_continue, librxhip), Int32, (Ptr{Cvoid}, Int32), e.handle, on ? 1 : 0))
+
 """q(W) of every chain after the last iteration: (ν [chains], V [dy, dy, chains])."""
 function noise_posterior(e::Engine)
     nu = Vector{Float64}(undef, e.n_chains)
@@ -461,6 +466,41 @@ mutable struct LgssmLowered
                          0, C_NULL, C_NULL)
 end
 
+# rxhip_lgssm_lowered BY VALUE — the first member of rxhip_lgssm_noise_lowered.  A mutable Julia struct is stored by reference inside another
+# struct; this immutable twin of LgssmLowered (same fields, same order) is stored inline, as C does.
+struct LgssmLoweredFields
+    d::Int32
+    dy::Int32
+    T::Int64
+    prior_through_transition::Int32
+    A::Ptr{Float64}; B::Ptr{Float64}; P::Ptr{Float64}; Q::Ptr{Float64}; m0::Ptr{Float64}; V0::Ptr{Float64}
+    state_var::Ptr{Int64}
+    data_var::Ptr{Int64}
+    deterministic::Int32
+    c::Ptr{Float64}
+    n_models::Int32
+    step_model::Ptr{Int32}
+    has_offsets::Int32
+    state_offset::Ptr{Float64}
+    obs_offset::Ptr{Float64}
+    du::Int32
+    input_matrix::Ptr{Float64}
+    input_var::Ptr{Int64}
+end
+LgssmLoweredFields(; state_var = Ptr{Int64}(C_NULL), data_var = Ptr{Int64}(C_NULL)) =
+    LgssmLoweredFields(0, 0, 0, 0, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, C_NULL, state_var, data_var, 0, C_NULL, 0, C_NULL, 0, C_NULL, C_NULL, 0, C_NULL, C_NULL)
+
+# mirrors rxhip_lgssm_noise_lowered
+mutable struct LgssmNoiseLowered
+    chain::LgssmLoweredFields
+    precision_var::Int64
+    nu0::Float64
+    init_nu::Float64
+    S0::Ptr{Float64}
+    init_V::Ptr{Float64}
+    LgssmNoiseLowered(chain = LgssmLoweredFields()) = new(chain, -1, 0.0, 0.0, C_NULL, C_NULL)
+end
+
 """The engine's stream: `nothing` (engine-owned) or an AMDGPU.jl stream, whose raw `hipStream_t` is handed over so that the
 host's own kernels / copies and the engine's launches are ordered on one queue (AMDGPU.jl only for handles)."""
 stream_handle(::Nothing) = Ptr{Cvoid}(C_NULL)
@@ -509,6 +549,25 @@ function lowered_layout(t)
     has(code) = any(==(Int32(code)), t.factor_type)
     if has(11)
         return (family = :hgf, d = 1, width = 1, data_ids = Int64[findfirst(==(Int32(1)), t.var_kind) - 1], state_ids = Int64[])
+    elseif !has(10) && has(2) && (has(12) || has(5) || has(15))
+        # a precision prior (Wishart; Gamma for scalar observations) on top of a chain with `*` nodes: the state-space chain with an unknown
+        # observation-noise precision (rxhip_graph_lower_lgssm_noise)
+        low = LgssmNoiseLowered()
+        st = with_desc(t, 1, 0) do desc
+            ccall((:rxhip_graph_lower_lgssm_noise, librxhip), Int32, (Ref{GraphDesc}, Ref{LgssmNoiseLowered}), desc, low)
+        end
+        st == RXHIP_OK || throw(RxHipError(st, lowering_error()))
+        T = low.chain.T
+        sv, dv = Vector{Int64}(undef, T), Vector{Int64}(undef, T)
+        GC.@preserve sv dv begin
+            low.chain = LgssmLoweredFields(state_var = pointer(sv), data_var = pointer(dv))
+            st = with_desc(t, 1, 0) do desc
+                ccall((:rxhip_graph_lower_lgssm_noise, librxhip), Int32, (Ref{GraphDesc}, Ref{LgssmNoiseLowered}), desc, low)
+            end
+        end
+        st == RXHIP_OK || throw(RxHipError(st, lowering_error()))
+        return (family = :lgssm_noise, d = Int(low.chain.d), width = Int(low.chain.dy), data_ids = dv, state_ids = sv, precision_id = low.precision_var,
+                gamma = !has(12))
     elseif has(10) || has(4) || (has(14) && has(12))
         ids = Int64[]
         for f in eachindex(t.factor_type)   # the observation nodes' `out` interface, in node order = data order

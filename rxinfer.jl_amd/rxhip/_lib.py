@@ -58,6 +58,11 @@ class LgssmLowered(ctypes.Structure):
                 ("du", ctypes.c_int32), ("input_matrix", c_double_p), ("input_var", c_int64_p)]
 
 
+class LgssmNoiseLowered(ctypes.Structure):
+    _fields_ = [("chain", LgssmLowered), ("precision_var", ctypes.c_int64), ("nu0", ctypes.c_double), ("init_nu", ctypes.c_double),
+                ("S0", c_double_p), ("init_V", c_double_p)]
+
+
 class GmmLowered(ctypes.Structure):
     _fields_ = [("N", ctypes.c_int64), ("K", ctypes.c_int32)] + [(n, c_double_p) for n in (
         "mu0", "v0", "a0", "b0", "alpha0", "init_m_mean", "init_m_var", "init_p_shape", "init_p_rate", "init_s_alpha")] + [
@@ -109,10 +114,12 @@ SYMBOLS = [
     ("rxhip_lgssm_create", ctypes.c_int32, [ctypes.POINTER(LgssmDesc), ctypes.POINTER(_H)]),
     ("rxhip_lgssm_noise_create", ctypes.c_int32, [ctypes.POINTER(LgssmDesc), ctypes.POINTER(NoisePrior), ctypes.POINTER(_H)]),
     ("rxhip_lgssm_noise_get", ctypes.c_int32, [_H, c_double_p, c_double_p]),
+    ("rxhip_lgssm_noise_continue", ctypes.c_int32, [ctypes.c_void_p, ctypes.c_int32]),
     ("rxhip_graph_lower_lgssm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(LgssmLowered)]),
     ("rxhip_graph_lower_gmm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(GmmLowered)]),
     ("rxhip_graph_lower_mvgmm", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(MvGmmLowered)]),
     ("rxhip_graph_lower_hgf", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(HgfLowered)]),
+    ("rxhip_graph_lower_lgssm_noise", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(LgssmNoiseLowered)]),
     ("rxhip_lowering_error", ctypes.c_char_p, []),
     ("rxhip_create", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.POINTER(_H)]),

@@ -37,16 +37,25 @@ class LinearGaussianSSM:
     state_offset: Optional[np.ndarray] = None  # known inputs: x[t] ~ MvNormal(μ = A*x[t-1] + c[t], Σ = P); [d] or [T, d]
     obs_offset: Optional[np.ndarray] = None    # y[t] ~ MvNormal(μ = B*x[t] + d[t], Σ = Q); [dy] or [T, dy]
     input_matrix: Optional[np.ndarray] = None  # B_u of x[t] ~ MvNormal(μ = A*x[t-1] + B_u*u[t], Σ = P), u a data variable
+    noise_precision_prior: Any = None          # Wishart(ν, S): y[t] ~ MvNormal(μ = B*x[t], Λ = W), W ~ Wishart(ν, S), q(x, W) = q(x)q(W); Q is unused
 
 
 def linear_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transition=False, state_offset=None, obs_offset=None,
-                        input_matrix=None):
+                        input_matrix=None, noise_precision_prior=None):
     """`state_offset` / `obs_offset`: known inputs added to the means (`A * x[t-1] + c`, `B * x[t] + d`), one vector or one
-    per time index.  `input_matrix` = B_u: the inputs are DATA, `infer(..., data = {"y": …, "u": …})` with u [T][du] per chain."""
+    per time index.  `input_matrix` = B_u: the inputs are DATA, `infer(..., data = {"y": …, "u": …})` with u [T][du] per chain.
+    `noise_precision_prior = Wishart(ν, S)` (Q = None): the observation noise is UNKNOWN, `y[t] ~ MvNormal(μ = B * x[t], Λ = W)` with
+    `W ~ Wishart(ν, S)` and `@constraints q(x, W) = q(x)q(W)` — `infer(..., iterations = n, initialization = {"W": Wishart(ν, V)})` runs mean-field
+    VMP on the device (d, dy ≤ 4) and returns posteriors["W"] next to posteriors["x"]."""
     f = lambda a: np.asarray(a, dtype=np.float64)
     g = lambda a: None if a is None else f(a)
+    if noise_precision_prior is not None:
+        if Q is not None or state_offset is not None or obs_offset is not None or input_matrix is not None:
+            raise ValueError("an unknown observation precision takes Q = None and no offsets / inputs")
+        Q = np.eye(np.asarray(B).shape[0])
     return LinearGaussianSSM(f(A), f(B), f(P), f(Q), f(prior_mean), f(prior_cov), bool(prior_through_transition),
-                             state_offset=g(state_offset), obs_offset=g(obs_offset), input_matrix=g(input_matrix))
+                             state_offset=g(state_offset), obs_offset=g(obs_offset), input_matrix=g(input_matrix),
+                             noise_precision_prior=noise_precision_prior)
 
 
 def time_varying_gaussian_ssm(A, B, P, Q, prior_mean, prior_cov, prior_through_transition=False):
@@ -380,6 +389,55 @@ def _infer_lgssm_filtering(model, data, free_energy, options, initialization, ca
             eng.close()
 
 
+def _infer_lgssm_noise(model, data, iterations, free_energy, options, initialization, returnvars, catch_exception):
+    """mean-field VMP of the chain with an unknown observation-noise precision (LGSSMNoiseEngine)"""
+    from .engine import LGSSMNoiseEngine
+    options = dict(options or {})
+    unknown = set(options) - _OPTION_KEYS
+    if unknown:
+        raise ValueError(f"Unknown option keys {sorted(unknown)}; available: {sorted(_OPTION_KEYS)}")
+    eng = None
+    try:
+        y = np.asarray(data["y"], dtype=np.float64)
+        single = y.ndim == 2
+        if single:
+            y = y[None]
+        if np.isnan(y).any():
+            raise ValueError("unknown observation precision: missing observations have no device schedule")
+        C, T, dy = y.shape
+        pri = model.noise_precision_prior
+        init = (initialization or {}).get("W")
+        if init is None:   # the reference refuses mean-field VMP without an @initialization marginal
+            raise ValueError("mean-field VMP needs initialization = {\"W\": Wishart(ν, V)}")
+        iters = 1 if iterations is None else int(iterations)
+        eng = LGSSMNoiseEngine(model.A, model.B, model.P, model.prior_mean, model.prior_cov, T, float(pri.nu), np.asarray(pri.S, float).reshape(dy, dy),
+                               float(init.nu), np.asarray(init.S, float).reshape(dy, dy), n_chains=C,
+                               prior_through_transition=model.prior_through_transition, segments=int(options.get("segments", 0)),
+                               device=int(options.get("device", -1)))
+        eng.set_data(y, layout="chain_time")
+        eng.run(iterations=iters, free_energy=free_energy)
+        mean, cov = eng.marginals(layout="chain_time")
+        nu, V = eng.noise_posterior()
+        fe = None
+        if free_energy:
+            fe = eng.free_energy()                      # per iteration, summed over the chains (every chain is its own graph)
+            if single:
+                fe = np.asarray(fe)
+        if single:
+            mean, cov, nu, V = mean[0], cov[0], nu[0], V[0]
+        post = {"x": MvNormalMeanCovariance(mean, cov), "W": Wishart(nu, V)}
+        if returnvars is not None:
+            post = {k: v for k, v in post.items() if k in returnvars}
+        return InferenceResult(post, None, fe, model, None)
+    except Exception as err:
+        if not catch_exception:
+            raise
+        return InferenceResult({}, None, None, model, err)
+    finally:
+        if eng is not None:
+            eng.close()
+
+
 def infer(*, model, data, iterations=None, free_energy=False, options=None, returnvars=None, predictvars=None,
           catch_exception=False, initialization=None, autoupdates=None, keephistory=None, historyvars=None):
     """Static (batch) inference on the device engine; with `autoupdates` (any truthy value: the state-space spec has
@@ -403,6 +461,10 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
         return _infer_drift_chain(model, data, iterations, free_energy, options, catch_exception)
     if not isinstance(model, LinearGaussianSSM):
         raise TypeError("infer: no device schedule for this model type")
+    if model.noise_precision_prior is not None:
+        if autoupdates or predictvars:
+            raise ValueError("unknown observation precision: no streaming twin and no predictions on the device")
+        return _infer_lgssm_noise(model, data, iterations, free_energy, options, initialization, returnvars, catch_exception)
     if autoupdates:
         if iterations not in (None, 1):
             raise ValueError("filtering: the one-step graph is a tree, iterations must be 1")

@@ -323,6 +323,10 @@ class LGSSMNoiseEngine(LGSSMEngine):
     def _create(self, L, desc):
         return L.rxhip_lgssm_noise_create(ctypes.byref(desc), ctypes.byref(self._pri), ctypes.byref(self._h))
 
+    def continue_runs(self, on=True):
+        """later run() calls go on from the current q(W) instead of the initial marginal (rxhip_lgssm_noise_continue)"""
+        self._chk(_lib.lib().rxhip_lgssm_noise_continue(self._h, int(bool(on))))
+
     def noise_posterior(self):
         nu, V = np.empty(self.n_chains), np.empty((self.n_chains, self.dy, self.dy))
         self._chk(_lib.lib().rxhip_lgssm_noise_get(self._h, _p(nu), _p(V)))

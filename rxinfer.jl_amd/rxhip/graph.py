@@ -229,6 +229,85 @@ def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=No
     return gb, xs, ys
 
 
+def lgssm_noise_graph(T, A, B, P, m0, V0, nu0, S0, init=None, prior_through_transition=False, gamma=None):
+    """The chain of `lgssm_graph` with an unknown observation-noise precision: `W ~ Wishart(nu0, S0)` and every observation node
+    `y[t] ~ MvNormal(μ = B * x[t], Λ = W)` (test/models/iid/mv_iid_precision_tests.jl:11-15 spells the node pair).  init = (nu, V): the
+    `@initialization` marginal q(W).  gamma = "rate" | "scale" (dy = 1): `τ ~ Gamma(shape = nu0, rate | scale = S0)` with
+    `y[t] ~ Normal(mean = …, precision = τ)` and init = (shape, rate).  Returns (builder, state vars, data vars, W)."""
+    A, B = np.asarray(A, float), np.asarray(B, float)
+    d, dy = A.shape[0], B.shape[0]
+    gb = GraphBuilder()
+    W = gb.randomvar(dy, name="W")
+    if gamma:
+        gb.node(_lib.NODE_GAMMA_SHAPE_RATE if gamma == "rate" else _lib.NODE_GAMMA_SHAPE_SCALE, W, gb.constvar(float(nu0)), gb.constvar(float(S0)))
+    else:
+        gb.node(_lib.NODE_WISHART, W, gb.constvar(float(nu0)), gb.constvar(np.asarray(S0, float).reshape(dy, dy)))
+    x = gb.randomvar(d)
+    gb.mvnormal_mean_cov(x, gb.constvar(m0), gb.constvar(V0))
+    xs, ys = [], []
+    for t in range(T):
+        if t > 0 or prior_through_transition:
+            a = gb.randomvar(d)
+            gb.multiply(a, gb.constvar(A), x)
+            xn = gb.randomvar(d)
+            gb.mvnormal_mean_cov(xn, a, gb.constvar(P))
+            x = xn
+        b = gb.randomvar(dy)
+        gb.multiply(b, gb.constvar(B), x)
+        y = gb.datavar(dy)
+        gb.node(_lib.NODE_NORMAL_MEAN_PRECISION if gamma else _lib.NODE_MVNORMAL_MEAN_PRECISION, y, b, W)
+        xs.append(x); ys.append(y)
+    if init is not None:
+        if gamma:
+            gb.initialize(W, _lib.INIT_GAMMA, np.asarray(init, float))
+        else:
+            gb.initialize(W, _lib.INIT_WISHART, np.concatenate([[float(init[0])], np.ravel(np.asarray(init[1], float))]))
+    return gb, xs, ys, W
+
+
+def lower_lgssm_noise(g):
+    """Host-only lowering of the chain with an unknown observation-noise precision: dict(d, dy, T, A, B, P, m0, V0, nu0, S0, init_nu, init_V, …)."""
+    L = _lib.lib()
+    out = _lib.LgssmNoiseLowered()
+    st = L.rxhip_graph_lower_lgssm_noise(ctypes.byref(g), ctypes.byref(out))
+    if st != _lib.OK:
+        raise RxHipError(st, L.rxhip_lowering_error().decode())
+    d, dy, T = out.chain.d, out.chain.dy, out.chain.T
+    bufs = dict(A=np.empty((d, d)), B=np.empty((dy, d)), P=np.empty((d, d)), m0=np.empty(d), V0=np.empty((d, d)))
+    for k, v in bufs.items():
+        setattr(out.chain, k, v.ctypes.data_as(_lib.c_double_p))
+    sv, dv = np.empty(T, dtype=np.int64), np.empty(T, dtype=np.int64)
+    out.chain.state_var = sv.ctypes.data_as(_lib.c_int64_p)
+    out.chain.data_var = dv.ctypes.data_as(_lib.c_int64_p)
+    S0, iV = np.empty((dy, dy)), np.empty((dy, dy))
+    out.S0, out.init_V = S0.ctypes.data_as(_lib.c_double_p), iV.ctypes.data_as(_lib.c_double_p)
+    st = L.rxhip_graph_lower_lgssm_noise(ctypes.byref(g), ctypes.byref(out))
+    if st != _lib.OK:
+        raise RxHipError(st, L.rxhip_lowering_error().decode())
+    return dict(d=d, dy=dy, T=T, prior_through_transition=bool(out.chain.prior_through_transition), state_var=sv, data_var=dv,
+                precision_var=int(out.precision_var), nu0=float(out.nu0), S0=S0, init_nu=float(out.init_nu), init_V=iV, **bufs)
+
+
+def create_noise_engine_from_graph(g, segments=0, device=-1, stream=None):
+    """rxhip_create on a chain with an unknown observation-noise precision: an LGSSMNoiseEngine around the new handle."""
+    from .engine import LGSSMNoiseEngine
+
+    low = lower_lgssm_noise(g)
+    L = _lib.lib()
+    h = ctypes.c_void_p()
+    st = L.rxhip_create(ctypes.byref(g), int(segments), int(device), ctypes.c_void_p(stream) if stream else None, ctypes.byref(h))
+    if st != _lib.OK:
+        msg = L.rxhip_lowering_error().decode() or (L.rxhip_last_error(h).decode() if h else "")
+        if h:
+            L.rxhip_destroy(h)
+        raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
+    eng = LGSSMNoiseEngine.__new__(LGSSMNoiseEngine)
+    eng._h, eng.d, eng.dy, eng.T, eng.n_chains, eng.n_models = h, low["d"], low["dy"], low["T"], int(g.n_replicas or 1), 1
+    eng.horizon, eng.du = 0, 0
+    eng._keep, eng._data_ref, eng._iters = [], None, 0
+    return eng
+
+
 def scalar_chain_graph(T, a, b, p, q, m0, v0, prior_through_transition=False, spell="normal", precision=False):
     """Scalar random-walk / AR(1) chains in the spellings RxInfer users write them:
     spell = "normal":  x[t] ~ Normal(mean = x[t-1], var = p), y[t] ~ Normal(mean = x[t], var = q)   (a = b = 1, no `*` nodes)
