@@ -15,7 +15,11 @@
  * a pool of idle engine-owned HIP streams (creation / destruction costs milliseconds on this runtime), up to 4 parked device
  * blocks / 4 GB per process (hipFree ≈0.15 ms for megabytes, tens of ms for a gigabyte), and the read-only per-model tables of
  * the MFMA path, shared by reference count between engines of the same model (≈50 ms of host recursions + a 100 MB upload at
- * d = 64 otherwise).  rxhip_release_cached_memory() returns everything idle to the driver.
+ * d = 64 otherwise), and up to 4 parked small ENGINES: rxhip_destroy of an engine of the d, dy <= 4 family (one model, no masks / per-step
+ * constants / offsets / horizon / caller's stream, T * chains <= 65536, no error ever reported) keeps it, and the next rxhip_lgssm_create
+ * whose descriptor is the same byte for byte (shapes, schedule options, device, every model matrix) returns it reset to the state of a new
+ * engine — an `infer(...)` per call costs a sweep and two copies then, not a construction.  rxhip_release_cached_memory() returns
+ * everything idle to the driver.
  */
 #ifndef RXHIP_H
 #define RXHIP_H
@@ -38,6 +42,7 @@ extern "C" {
  *     RXHIP_ONE_SEGMENT=1       d, dy <= 4 masked / per-step engines: one segment per chain
  *     RXHIP_BACKWARD_LANES=1    one-pass schedule: the backward sweep of the four-phase schedule instead of the table-driven one
  *     RXHIP_SMALL_SWEEP=0       few short chains: the five launches of the four-phase schedule instead of k_small_sweep (one launch)
+ *     RXHIP_ENGINE_POOL=0       rxhip_destroy frees small engines instead of parking them for the next rxhip_lgssm_create of the same descriptor
  *     RXHIP_NO_PACK=1           d <= 8 on the MFMA path: one chain per 16x16 tile instead of two
  *     RXHIP_DENSE_SPLIT=0|1     MFMA path, one model: without / with the model-data split (default: from four workgroups' worth of chains)
  *     RXHIP_HOST_TABLES=1       MFMA path: per-model tables by the host builder instead of the device builder (d >= 32)
@@ -654,7 +659,7 @@ const char* rxhip_status_string(rxhip_status s);
 const char* rxhip_version(void);
 int32_t rxhip_device_count(void); /* number of visible HIP devices (0 if none) */
 rxhip_status rxhip_destroy(rxhip_engine* e);
-/* frees the device blocks parked by destroyed engines (see the note on process-wide state at the top) */
+/* frees the engines, device blocks and pinned blocks parked by destroyed engines (see the note on process-wide state at the top) */
 rxhip_status rxhip_release_cached_memory(void);
 
 #ifdef __cplusplus
