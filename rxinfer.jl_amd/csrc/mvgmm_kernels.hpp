@@ -132,9 +132,13 @@ __global__ void __launch_bounds__(256) k_mvg_pass(MvgParams p) {
 #pragma unroll
         for (int a = 0; a < D; ++a) y[a] = p.y[i * D + a];
         double lg[KT], mx = -1e308;
+        // the derived parameters stay in LDS: the address is laundered per point, else the compiler hoists all KT · DRV loads out of the loop
+        // into registers — next to the KT · STAT accumulators that was 512 registers and 184 bytes of scratch at d = 4, K = 8
+        const double* sd = sdrv;
+        asm volatile("" : "+v"(sd));
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
-            const double* dr = sdrv + k * MD::DRV;  // wave-uniform: broadcast LDS reads
+            const double* dr = sd + k * MD::DRV;  // wave-uniform: broadcast LDS reads
             double dv[D], qf = 0.0;
 #pragma unroll
             for (int a = 0; a < D; ++a) dv[a] = y[a] - dr[1 + MD::NS + a];
