@@ -298,9 +298,13 @@ def extra_c3(device, parity=True):
         warm.run(1, True)
     t0 = time.perf_counter()
     eng = rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=1, device=device)
+    t1 = time.perf_counter()
     eng.set_data(y)
+    t2 = time.perf_counter()
     eng.run(1, True)
-    create_ms = (time.perf_counter() - t0) * 1e3
+    t3 = time.perf_counter()
+    create_ms = (t3 - t0) * 1e3
+    first_split = {"create_ms": (t1 - t0) * 1e3, "set_data_ms": (t2 - t1) * 1e3, "first_run_ms": (t3 - t2) * 1e3}
     cstages = eng.create_stages()
     ms, kt = timed_sweeps(eng, 20, 3)
     spot = parity_spot_deferred(eng, mdl, y, [0]) if parity else None   # the timed engine against the oracle's reference schedule over the whole chain (≈30 s of one host core, on a thread)
@@ -350,7 +354,7 @@ def extra_c3(device, parity=True):
             "frac_ref_count": tf(ref_flop, ms) / FP64_PEAK_TFLOPS, "frac_round2_count_12d3": tf(12 * d ** 3 * T, ms) / FP64_PEAK_TFLOPS,
             "roofline": roof, "filter_ms_per_step": fms, "timing": timing_mode(2), "parity_spot": spot,
             "hoisted_matrices": hoisted,
-            "create_set_data_first_run_ms": create_ms, "create_stages_ms": cstages,
+            "create_set_data_first_run_ms": create_ms, "create_set_data_first_run_split_ms": first_split, "create_stages_ms": cstages,
             "create_note": "a model no engine of the process has seen: tables built on the device (csrc/dense_tab_kernels.hpp)"}
 
 

@@ -1782,7 +1782,9 @@ static bool engine_pool_key(const rxhip_lgssm_desc* ds, std::string& key) {
         ds->horizon != 0 || ds->stream || (long long)ds->T * ds->n_chains > 65536)
         return false;
     auto put = [&](const void* q, size_t n) { key.append((const char*)q, n); };
-    const long long hdr[7] = {ds->d, ds->dy, ds->T, ds->n_chains, ds->prior_through_transition ? 1 : 0, ds->segments, ds->device};
+    int dev = ds->device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return false;   // "the current device" is part of the key as the device it is NOW
+    const long long hdr[7] = {ds->d, ds->dy, ds->T, ds->n_chains, ds->prior_through_transition ? 1 : 0, ds->segments, dev};
     put(hdr, sizeof hdr);
     const size_t d = (size_t)ds->d, dy = (size_t)ds->dy;
     put(ds->A, 8 * d * d); put(ds->B, 8 * dy * d); put(ds->P, 8 * d * d); put(ds->Q, 8 * dy * dy); put(ds->m0, 8 * d); put(ds->V0, 8 * d * d);
