@@ -1219,21 +1219,37 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
 #pragma unroll
                 for (int j = 0; j < D; ++j) oc[i * D + j] = V(i, j);
         }
+        // per-chain models: the element matrices go through registers — the model's table (interior segments always have the full length L:
+        // fetched ONCE, in front of the recursion — re-read per segment it was an L2 round trip on every step of a chain of dependent steps)
+        // or, on the masked / per-step schedules, this (chain, segment)'s own.  The element vectors travel one segment ahead.
+        double al[(!UNI) ? AL::SIZE : 1];
+        if constexpr (!UNI) {
+            if (!p.elemx) {
+#pragma unroll
+                for (int q = 0; q < AL::SIZE; ++q) al[q] = aggm[q];
+            }
+        }
+        double eln[2 * D];
+        {
+            const double* el0 = p.elem + chain;
+#pragma unroll
+            for (int i = 0; i < 2 * D; ++i) eln[i] = S > 1 ? el0[i * p.n_chains] : 0.0;
+        }
         for (int s = 0; s < S; ++s) {
             store_soa<D>(p.fstart, s, p.n_chains, chain, m, V);
             if (s == S - 1) break;
-            // per-chain models: the element matrices go through registers — the model's table (interior segments always
-            // have the full length L) or, on the masked / per-step schedules, this (chain, segment)'s own
-            double al[(!UNI) ? AL::SIZE : 1];
             if constexpr (!UNI) {
                 if (p.elemx) load_elemx<D>(p, s, chain, false, al);
-                else {
-#pragma unroll
-                    for (int q = 0; q < AL::SIZE; ++q) al[q] = aggm[q];
-                }
             }
             const CPtr a{UNI ? aggm : al};
-            const double* el = p.elem + ((long long)s * 2 * D) * p.n_chains + chain;
+            double elc[2 * D];
+#pragma unroll
+            for (int i = 0; i < 2 * D; ++i) elc[i] = eln[i];
+            if (s + 2 < S) {   // (segment S − 1's element is not used by this role)
+                const double* eq = p.elem + ((long long)(s + 1) * 2 * D) * p.n_chains + chain;
+#pragma unroll
+                for (int i = 0; i < 2 * D; ++i) eln[i] = eq[i * p.n_chains];
+            }
             Sym<D> Vi, W, T1;
             double det;
             ok = spd_inv<D>(V, Vi, det) && ok;
@@ -1243,7 +1259,7 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
             double u[D], w[D];
             symv<D>(Vi, m, u);
 #pragma unroll
-            for (int i = 0; i < D; ++i) u[i] += el[(D + i) * p.n_chains];
+            for (int i = 0; i < D; ++i) u[i] += elc[D + i];
             symv<D>(W, u, w);
             // PW = Π W
             double PW[D][D];
@@ -1258,7 +1274,7 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
                 }
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                double sacc = el[i * p.n_chains];
+                double sacc = elc[i];
 #pragma unroll
                 for (int k = 0; k < D; ++k) sacc += a[AL::PI + i * D + k] * w[k];
                 m[i] = sacc;
@@ -1281,23 +1297,33 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
 #pragma unroll
         for (int i = 0; i < NS; ++i) Lm.v[i] = 0.0;
         store_soa<D>(p.beta, S, p.n_chains, chain, xi, Lm);
+        double al[(!UNI) ? AL::SIZE : 1];
+        double eln[2 * D];
+        if (S > 1) {
+            const double* eq = p.elem + ((long long)(S - 1) * 2 * D) * p.n_chains + chain;
+#pragma unroll
+            for (int i = 0; i < 2 * D; ++i) eln[i] = eq[i * p.n_chains];
+        }
         for (int s = S - 1; s >= 1; --s) {
             const double* am = aggm + ((s == S - 1) ? AL::SIZE : 0);
-            double al[(!UNI) ? AL::SIZE : 1];
             if constexpr (!UNI) {
                 if (p.elemx) ok = load_elemx<D>(p, s, chain, true, al) && ok;
-                else {
+                else if (s >= S - 2) {   // the last segment's table, then the interior one: two fetches for the whole recursion
 #pragma unroll
                     for (int q = 0; q < AL::SIZE; ++q) al[q] = am[q];
                 }
             }
             const CPtr a{UNI ? am : al};
-            const double* el = p.elem + ((long long)s * 2 * D) * p.n_chains + chain;
             double b[D], eta[D];
 #pragma unroll
             for (int i = 0; i < D; ++i) {
-                b[i] = el[i * p.n_chains];
-                eta[i] = el[(D + i) * p.n_chains];
+                b[i] = eln[i];
+                eta[i] = eln[D + i];
+            }
+            if (s > 1) {
+                const double* eq = p.elem + ((long long)(s - 1) * 2 * D) * p.n_chains + chain;
+#pragma unroll
+                for (int i = 0; i < 2 * D; ++i) eln[i] = eq[i * p.n_chains];
             }
             Sym<D> T1, W;
             double det;
