@@ -716,10 +716,8 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
             for (int r = 0; r < 4; ++r) di[r] = a.v[k][r];
             double detp;
             bool badk = false;
-            // (Tried in round 4 and NOT kept: seeding this tile's inverse with the one of the previous time step — Newton–Schulz on the
-            // accumulator registers, X ← X(2I − DX), two chains of four MFMAs instead of four rank-4 rounds, determinant from tr E − ½ tr E².
-            // Exact to 10⁻¹³ once X is re-symmetrised every step, and worth nothing: kd_forward_info 0.433 against 0.425 ms; even with the seed
-            // forced on every step 0.419.  The diagonal tile is not what the panel steps wait for — DESIGN §6e.)
+            // (A first attempt at seeding — X ← X(2I − DX) with a re-symmetrisation chain and a wave-wide reduction for the determinant per tile —
+            // cost as much as the rounds it replaced: 0.433 against 0.425 ms.  The form below has neither.  DESIGN §6e.)
             if constexpr (SEED::ON) {
                 bool done = false;
 #ifdef RXHIP_TEST_SEEDCOUNT
