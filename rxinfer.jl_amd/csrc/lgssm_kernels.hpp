@@ -189,6 +189,10 @@ struct Params {
                             // time index (k_seg_elements); null: per-model tables `agg`
     const int* step_model;  // [T] or null: the model of time index t (transition INTO x[t] and observation of y[t]);
                             // one segment, per-chain records (rxhip_lgssm_desc.step_model)
+    // engines with an unknown observation-noise precision (noise_kernels.hpp): the backward sweep accumulates the residual second moments
+    // Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′] of its segment while it holds (m_t, V_t) — part[seg][NS_y][chain]; null otherwise
+    const double* noise_B;  // [DY][D]
+    double* noise_part;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -1701,10 +1705,11 @@ __device__ __forceinline__ void write_marginal_wave(const Params& p, double2* ti
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int D, int DY, bool UNI, bool FUSED = false>
+template <int D, int DY, bool UNI, bool FUSED = false, bool NOISE = false>
 __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE>& cb, const long long g, const int lane,
                                               double2* __restrict__ tile) {   // tile: the wave's output transpose buffer, or null
     static_assert(UNI || !FUSED, "the one-pass schedule exists for shared-model batches only");
+    static_assert(!NOISE || !UNI, "residual moments are accumulated on the per-chain-model sweep");
     using CL = CstLayout<D, DY>;
     constexpr int NS = Dim<D>::NS;
     constexpr int NP2 = Dim<D>::NP2;
@@ -1749,6 +1754,44 @@ __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<U
             }
         }
     };
+    // NOISE: Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′] over the marginals this lane writes (a separate pass over the posteriors was 2 GB
+    // of reads per VMP iteration at d = 4 × 1024 chains × T = 10⁴: here they are in registers)
+    constexpr int NSY = DY * (DY + 1) / 2;
+    double nacc[NOISE ? NSY : 1];
+    if constexpr (NOISE) {
+#pragma unroll
+        for (int k = 0; k < NSY; ++k) nacc[k] = 0.0;
+    }
+    auto noise_add = [&](long long t, const double (&m)[D], const Sym<D>& V) {
+        if constexpr (NOISE) {
+            double yv[DY], r[DY], BV[DY][D];
+            load_y<DY>(p.y, t, p.n_chains, chain, yv);
+            const double* Bm = p.noise_B;   // wave-uniform
+#pragma unroll
+            for (int a = 0; a < DY; ++a) {
+                double sacc = yv[a];
+#pragma unroll
+                for (int k = 0; k < D; ++k) sacc -= Bm[a * D + k] * m[k];
+                r[a] = sacc;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double v = 0.0;
+#pragma unroll
+                    for (int l = 0; l < D; ++l) v += Bm[a * D + l] * V(l, k);
+                    BV[a][k] = v;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < DY; ++a)
+#pragma unroll
+                for (int b = 0; b <= a; ++b) {
+                    double v = r[a] * r[b];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) v += BV[a][k] * Bm[b * D + k];
+                    nacc[sidx(a, b)] += v;
+                }
+        }
+    };
     // smoothed belief at the end boundary: filtered(te) ⊗ β(b_{seg+1})
     double ms[D], mf[D];
     Sym<D> Vs, Vf;
@@ -1785,7 +1828,10 @@ __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<U
         for (int i = 0; i < NS; ++i) Ls.v[i] = Vi.v[i] + Lb.v[i];
         ok = spd_inv<D>(Ls, Vs, det) && ok;
         symv<D>(Vs, u, ms);
-        if (seg == p.S - 1) write_marginal<D>(p, te, chain, ms, Vs);
+        if (seg == p.S - 1) {
+            write_marginal<D>(p, te, chain, ms, Vs);
+            noise_add(te, ms, Vs);
+        }
     }
     double2 rn[UNI ? DimM<D>::MP2 : NP2];
     auto prefetch = [&](long long tt) {
@@ -1880,6 +1926,11 @@ __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<U
             else write_marginal<D>(p, t, chain, ms, Vs);
         } else
             write_marginal<D>(p, t, chain, ms, Vs);
+        noise_add(t, ms, Vs);
+    }
+    if constexpr (NOISE) {
+#pragma unroll
+        for (int k = 0; k < NSY; ++k) p.noise_part[((long long)seg * NSY + k) * p.n_chains + chain] = nacc[k];
     }
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
 }
@@ -1888,6 +1939,13 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
     constexpr bool CAN_TILE = (D % 2 == 0);
     __shared__ double2 tile[CAN_TILE ? 64 * OutTile<CAN_TILE ? D : 2>::STRIDE : 1];
     backward_body<D, DY, UNI, FUSED>(p, cb, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, CAN_TILE ? tile : nullptr);
+}
+// the same sweep of an engine with an unknown observation-noise precision (per-chain constants): + the residual second moments per (segment, chain)
+template <int D, int DY>
+__global__ void __launch_bounds__(64) k_backward_noise(Params p) {
+    constexpr bool CAN_TILE = (D % 2 == 0);
+    __shared__ double2 tile[CAN_TILE ? 64 * OutTile<CAN_TILE ? D : 2>::STRIDE : 1];
+    backward_body<D, DY, false, false, true>(p, CstArg<1>{}, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, CAN_TILE ? tile : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

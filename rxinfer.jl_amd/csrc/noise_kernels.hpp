@@ -9,8 +9,9 @@
 //         sum-product: ONE sweep of the state-space kernels with this chain's constants Q⁻¹ ← E[W]  (each chain its own model block:
 //         B′E[W]B, B′E[W], E[W], dy log 2π − log|E[W]| — written by the kernels below, no host round trip between iterations);
 //   q(W)  MvNormalMeanPrecision(:Λ) sends Wishart(dy + 2, E[(y − Bx)(y − Bx)′]⁻¹) per observation; product with the prior in natural
-//         parameters: ν = ν0 + T, V⁻¹ = S0⁻¹ + Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′]   (k_noise_moments: an HBM-bound pass over the
-//         posteriors, lane = chain, time slices reduced in a fixed order; k_noise_update: one lane per chain finishes the 4×4 algebra);
+//         parameters: ν = ν0 + T, V⁻¹ = S0⁻¹ + Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′]   (accumulated per segment by the backward sweep itself,
+//         k_backward_noise in lgssm_kernels.hpp; engines whose sweep is one segment: k_noise_moments, an HBM-bound pass over the posteriors,
+//         lane = chain, time slices; either way the partials are reduced in a fixed order; k_noise_update: one lane per chain finishes the 4×4 algebra);
 //   F     Bethe free energy of the iteration's marginals = the sweep's −log p̃(y | Q = E_old[W]⁻¹) + T/2 (log|E_old W| − E_new log|W|)
 //         + ½ tr((E_new W − E_old W) Σ_t E[r_t r_t′]) + KL(q_new(W) ‖ p(W)): one extra slot per chain in the sweep's free-energy partials.
 // Order per iteration: q(x) with the previous q(W), then q(W) with the new q(x) (the order the mixture engines assume for q(m), q(w); the CPU
@@ -37,6 +38,7 @@ struct NoiseParams {
     int* status;
     double* part;           // [slices][NS][chain]: partial residual second moments of k_noise_moments
     int slices;             // time slices (fixed per engine: the summation order is the same on every run)
+    int moments_in_sweep;   // the backward sweep left the partial moments per SEGMENT in `part` (slices = segments): k_noise_moments is not launched
 };
 constexpr int NOISE_MAX_SLICES = 128;
 template <int DY>

@@ -2548,7 +2548,7 @@ rxhip_status rxhip_lgssm_noise_create(const rxhip_lgssm_desc* ds, const rxhip_no
         e->n_slices = (int)std::max<long long>(1, sl);
     }
     size_t off[5] = {0};
-    const size_t parts[4] = {dy * d, NPR, NST, (size_t)e->n_slices * (dy * (dy + 1) / 2) * C};
+    const size_t parts[4] = {dy * d, NPR, NST, (size_t)std::max(e->n_slices, e->S) * (dy * (dy + 1) / 2) * C};   // partial moments per time slice, or per segment of the sweep
     for (int q = 0; q < 4; ++q) off[q + 1] = off[q] + ArenaPlan::al(sizeof(double) * parts[q]);
     HIPCHK(e, hipMalloc(&e->noise_block, off[4]));
     e->n_B = (double*)(e->noise_block + off[0]); e->n_prior = (double*)(e->noise_block + off[1]); e->n_state = (double*)(e->noise_block + off[2]);
@@ -3477,6 +3477,10 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.masked = e->masked ? 1 : 0;
     p.step_model = e->d_step_model;
     p.elemx = e->d_elemx;
+    // an unknown observation-noise precision: the backward sweep leaves the residual second moments per (segment, chain) behind
+    const bool noise_in_sweep = e->noise && !e->dense && e->S > 0 && !filter && !hook_env("RXHIP_NOISE_MOMENTS_PASS");
+    p.noise_B = noise_in_sweep ? e->n_B : nullptr;
+    p.noise_part = noise_in_sweep ? e->n_part : nullptr;
     const bool fused = e->fused && !filter;
     p.ftab = fused ? e->d_ftab : nullptr; p.mtab = fused ? e->d_mtab : nullptr; p.ntab = fused ? e->d_ntab : nullptr;
     p.fseg = fused ? e->d_fseg : nullptr; p.fe_const = e->fe_const;
@@ -3505,7 +3509,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         if (filter) return fail(e, RXHIP_ERR_BADARG, "run_filter: an engine with an unknown noise precision has no streaming twin");
         np.T = e->T; np.n_chains = e->n_chains; np.S = e->S; np.y = e->d_y; np.mean = e->d_mean; np.cov = e->d_cov; np.B = e->n_B;
         np.cst = e->d_cst; np.prior = e->n_prior; np.state = e->n_state; np.fe_part = e->d_fe_part; np.status = e->d_status;
-        np.part = e->n_part; np.slices = e->n_slices;
+        np.part = e->n_part; np.slices = noise_in_sweep ? e->S : e->n_slices; np.moments_in_sweep = noise_in_sweep ? 1 : 0;
         if (iterations > e->n_hist_cap) {
             HIPCHK(e, hipStreamSynchronize(e->stream));
             if (e->n_hist) HIPCHK(e, hipFree(e->n_hist));

@@ -66,6 +66,7 @@ struct Launch {
         dim3 grid(nblk(total, 64));
         if (uni && p.ntab) hipLaunchKernelGGL((k_backward<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));  // one-pass run
         else if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
+        else if (p.noise_part) hipLaunchKernelGGL((k_backward_noise<D, DY>), grid, dim3(64), 0, s, p);
         else hipLaunchKernelGGL((k_backward<D, DY, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
     }
     static void forward0(const Params& p, const double* hc, bool fe, hipStream_t s) {
@@ -114,7 +115,7 @@ struct Launch {
         hipLaunchKernelGGL((k_noise_reset<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
     }
     static void noise_update(const NoiseParams& p, hipStream_t s) {
-        hipLaunchKernelGGL((k_noise_moments<D, DY>), dim3(nblk(p.n_chains, 64), (unsigned)p.slices), dim3(64), 0, s, p);
+        if (!p.moments_in_sweep) hipLaunchKernelGGL((k_noise_moments<D, DY>), dim3(nblk(p.n_chains, 64), (unsigned)p.slices), dim3(64), 0, s, p);
         hipLaunchKernelGGL((k_noise_update<D, DY>), dim3(nblk(p.n_chains, 64)), dim3(64), 0, s, p);
     }
     static void stream_step(const StreamParams& p, hipStream_t s) {

@@ -136,3 +136,25 @@ def test_infer_with_an_unknown_observation_precision():
     assert np.allclose(res.free_energy, ofe, rtol=1e-9)
     with pytest.raises(ValueError, match="initialization"):
         rxhip.infer(model=spec, data={"y": y}, iterations=2)
+
+
+def test_moments_inside_the_sweep_equal_the_separate_pass(monkeypatch):
+    """the residual second moments accumulated by the backward sweep (per segment) against the pass over the posteriors (per time slice)"""
+    import rxhip
+    from rxhip import workloads
+    d, dy, T, C, iters = 4, 3, 700, 70, 5
+    mdl = workloads.random_model(d, dy, seed=31)
+    y = workloads.generate_batch(mdl, T, C, seed0=6)
+    out = []
+    for hook in (None, "1"):
+        if hook:
+            monkeypatch.setenv("RXHIP_NOISE_MOMENTS_PASS", hook)
+        else:
+            monkeypatch.delenv("RXHIP_NOISE_MOMENTS_PASS", raising=False)
+        with rxhip.LGSSMNoiseEngine(mdl["A"], mdl["B"], mdl["P"], mdl["m0"], mdl["V0"], T, dy + 1.0, np.eye(dy) * 0.5, dy + 2.0, np.eye(dy) * 0.3, n_chains=C) as eng:
+            eng.set_data(y)
+            eng.run(iters, True)
+            out.append((eng.marginals()[0], eng.free_energy(), eng.noise_posterior()[1], eng.schedule()))
+    (m1, f1, v1, s1), (m2, f2, v2, s2) = out
+    assert s1["segments"] > 1
+    assert np.allclose(m1, m2, rtol=1e-10, atol=1e-12) and np.allclose(f1, f2, rtol=1e-12) and np.allclose(v1, v2, rtol=1e-11)
