@@ -549,7 +549,10 @@ function lowered_layout(t)
     has(code) = any(==(Int32(code)), t.factor_type)
     if has(11)
         return (family = :hgf, d = 1, width = 1, data_ids = Int64[findfirst(==(Int32(1)), t.var_kind) - 1], state_ids = Int64[])
-    elseif !has(10) && has(2) && (has(12) || has(5) || has(15))
+    elseif !has(10) && (has(12) || has(5) || has(15)) && (has(2) || any(eachindex(t.factor_type)) do f   # as rxhip_create decides: a precision prior over a CHAIN
+            io = t.factor_iface[(t.factor_iface_ptr[f] + 1):t.factor_iface_ptr[f + 1]]
+            t.factor_type[f] in (Int32(1), Int32(3), Int32(4), Int32(14)) && length(io) == 3 && t.var_kind[io[1] + 1] == Int32(0) && t.var_kind[io[2] + 1] == Int32(0)
+        end)
         # a precision prior (Wishart; Gamma for scalar observations) on top of a chain with `*` nodes: the state-space chain with an unknown
         # observation-noise precision (rxhip_graph_lower_lgssm_noise)
         low = LgssmNoiseLowered()
