@@ -159,6 +159,7 @@ __global__ void __launch_bounds__(64) k_noise_update(NoiseParams p) {
     double red0[NS];
 #pragma unroll
     for (int k = 0; k < NS; ++k) red0[k] = 0.0;
+#pragma unroll 8   // (same ascending order; the loads of eight slices travel together instead of one round trip per slice)
     for (int sl = 0; sl < p.slices; ++sl)
 #pragma unroll
         for (int k = 0; k < NS; ++k) red0[k] += p.part[((long long)sl * NS + k) * p.n_chains + chain];
