@@ -193,6 +193,7 @@ struct Params {
     // Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′] of its segment while it holds (m_t, V_t) — part[seg][NS_y][chain]; null otherwise
     const double* noise_B;  // [DY][D]
     double* noise_part;
+    int elem_full;          // test hook: k_seg_elements runs the full recursion to the end of every segment (no frozen tail)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -717,7 +718,7 @@ struct ElemX {
     static constexpr int NS = D * (D + 1) / 2;
     static constexpr int PI = 0, J = D * D, C = D * D + NS, SIZE = D * D + 2 * NS;
 };
-template <int D, int DY>
+template <int D, int DY, bool TINV = false>   // TINV: time-invariant models (no masks, no per-step constants) — the variant with the frozen tail
 __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wavefronts per SIMD: the batch is sized for that
     using CL = CstLayout<D, DY>;
     using EX = ElemX<D>;
@@ -746,13 +747,22 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
         for (int k = 0; k < CL::M1; ++k) cr[k] = src[k];
     };
     load_c(p.cst + (long long)cmdl * CL::SIZE);
-    for (long long i = 0; i < len; ++i) {
+    // Time-invariant models (no masks, no per-step constants): the covariance recursion of the known-start filter reaches its fixed point after
+    // the filter's mixing time (≈ 250 of a segment's 782 steps at the BASELINE model) — from there on V, Λp and the gains are CONSTANT, and what
+    // still moves is Π ← F Π (F = V Λp A, the closed loop), b, and the two accumulations that are bilinear in Π (they die out with it).  The loop
+    // below stops where V and J have stopped moving (every lane of the wavefront) and a second kernel runs the frozen recursion over the rest of
+    // the segment: 150 instead of 640 FMAs per step until Π is below 10⁻²⁰, then 36.  Same numbers to rounding (tests/test_converged_elements_gpu.py).
+    constexpr bool tinv = TINV;   // (a kernel of its own: in one kernel the tail's registers cost the masked sweeps 30 % — 148 → 276 B of scratch)
+    double cf1 = 0.0, cf2 = 0.0, cf3 = 0.0;
+    int nsame = 0;
+    long long i = 0;
+    for (; i < len; ++i) {
         const long long t = t0 + i;
-        if (p.step_model) load_c(p.cst + (long long)p.step_model[t] * CL::SIZE);
+        if (!TINV && p.step_model) load_c(p.cst + (long long)p.step_model[t] * CL::SIZE);
         const double* ct = cr;
         double yv[DY];
         load_y<DY>(p.y, t, p.n_chains, chain, yv);
-        const bool miss = p.masked && obs_missing<DY>(yv);
+        const bool miss = !TINV && p.masked && obs_missing<DY>(yv);
         double mp[D], T[D][D], Z[D][D];
         Sym<D> Vp, Lp, Lf, Vn;
         matvec_c<D>(CPtr{ct + CL::A}, b, mp);
@@ -838,7 +848,28 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
             for (int c = 0; c < D; ++c) Pi[a][c] = Pn[a][c];
         }
         V = Vn;
+        if constexpr (tinv) {
+            // fixed point of the covariance recursion: two independent linear functionals of V unchanged to 2 ulp on two steps in a row (an
+            // entrywise comparison would keep the previous V alive through the whole step — 120 more bytes of scratch in a kernel that has none to give)
+            double f1 = 0.0, f2 = 0.0, f3 = 0.0;
+#pragma unroll
+            for (int q = 0; q < NS; ++q) {
+                f1 += V.v[q];
+                f2 += (1.0 + 0.37 * q) * V.v[q];
+                f3 += (1.0 + 0.21 * q) * J.v[q];   // J stops moving later than V (its increments are quadratic in Π): the tail does not touch it
+            }
+            const bool same = fabs(f1 - cf1) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf2) <= 4.5e-16 * fabs(f2) && fabs(f3 - cf3) <= 2.3e-16 * fabs(f3);
+            cf1 = f1;
+            cf2 = f2;
+            cf3 = f3;
+            nsame = same ? nsame + 1 : 0;
+            if (__all(nsame >= 2)) {
+                ++i;
+                break;
+            }
+        }
     }
+    if constexpr (TINV) p.fstart[(seg * Dim<D>::NP) * p.n_chains + chain] = (double)i;   // where the tail kernel takes over (the scan overwrites the slot later)
     double* o = p.elem + (seg * 2 * D) * p.n_chains + chain;
 #pragma unroll
     for (int a = 0; a < D; ++a) {
@@ -854,6 +885,152 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
     for (int q = 0; q < NS; ++q) {
         x[(EX::J + q) * p.n_chains] = J.v[q];
         x[(EX::C + q) * p.n_chains] = V.v[q];
+    }
+    if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
+}
+// The tail of a segment behind the fixed point of its covariance recursion (k_seg_elements<…, TINV = true> stops there and leaves its state in
+// the element arrays and the step index in the first slot of the segment's boundary record): a kernel of its own, because its few registers let
+// many wavefronts hide what is now a chain of dependent loads and short products.
+template <int D, int DY>
+__global__ void __launch_bounds__(64, 2) k_seg_elements_tail(Params p) {
+    using CL = CstLayout<D, DY>;
+    using EX = ElemX<D>;
+    constexpr int NS = Dim<D>::NS;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= p.n_chains * (long long)p.S) return;
+    const long long seg = g / p.n_chains, chain = g - seg * p.n_chains;
+    const long long len = seg_len(p, seg);
+    const long long t0 = seg * p.L + 1;
+    long long i = (long long)p.fstart[(seg * Dim<D>::NP) * p.n_chains + chain];
+    if (i >= len) return;
+    bool ok = true;
+    double cr[CL::M1];
+    {
+        const double* src = p.cst + (long long)model_of<false>(p, chain) * CL::SIZE;
+#pragma unroll
+        for (int k = 0; k < CL::M1; ++k) cr[k] = src[k];
+    }
+    double b[D], eta[D], Pi[D][D];
+    Sym<D> V;
+    double* o = p.elem + (seg * 2 * D) * p.n_chains + chain;
+    double* x = p.elemx + (seg * EX::SIZE) * p.n_chains + chain;
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        b[a] = o[a * p.n_chains];
+        eta[a] = o[(D + a) * p.n_chains];
+#pragma unroll
+        for (int c = 0; c < D; ++c) Pi[a][c] = x[(EX::PI + a * D + c) * p.n_chains];
+    }
+#pragma unroll
+    for (int q = 0; q < NS; ++q) V.v[q] = x[(EX::C + q) * p.n_chains];
+    if (i < len) {   // (wave-uniform: every lane of the wavefront left the full recursion at the same step)
+        const double* ct = cr;
+        double T[D][D], LA[D][D], F[D][D], Gy[D][DY];
+        Sym<D> Vp, Lp, Lf, Vn;
+        double det;
+        predict_cov<D>(CPtr{ct + CL::A}, CPtr{ct + CL::P}, V, T, Vp);
+        ok = spd_inv<D>(Vp, Lp, det) && ok;
+#pragma unroll
+        for (int q = 0; q < NS; ++q) Lf.v[q] = Lp.v[q] + ct[CL::LOBS + q];
+        ok = spd_inv<D>(Lf, Vn, det) && ok;
+#pragma unroll
+        for (int a = 0; a < D; ++a)
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += Lp(a, k) * ct[CL::A + k * D + c];
+                LA[a][c] = acc;   // Λp A
+            }
+#pragma unroll
+        for (int a = 0; a < D; ++a) {
+#pragma unroll
+            for (int c = 0; c < D; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += Vn(a, k) * LA[k][c];
+                F[a][c] = acc;    // V Λp A
+            }
+#pragma unroll
+            for (int c = 0; c < DY; ++c) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += Vn(a, k) * ct[CL::G + k * DY + c];
+                Gy[a][c] = acc;   // V B′Q⁻¹
+            }
+        }
+        bool pilive = true;
+        // the tail is a short dependent chain per step: the observations travel two steps ahead of it
+        double y1[DY], y2[DY];
+        load_y<DY>(p.y, t0 + i, p.n_chains, chain, y1);
+        load_y<DY>(p.y, t0 + (i + 1 < len ? i + 1 : i), p.n_chains, chain, y2);
+        for (; i < len; ++i) {
+            double yv[DY], bn[D];
+#pragma unroll
+            for (int k = 0; k < DY; ++k) {
+                yv[k] = y1[k];
+                y1[k] = y2[k];
+            }
+            load_y<DY>(p.y, t0 + (i + 2 < len ? i + 2 : len - 1), p.n_chains, chain, y2);
+#pragma unroll
+            for (int a = 0; a < D; ++a) {
+                double acc = 0.0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) acc += F[a][k] * b[k];
+#pragma unroll
+                for (int k = 0; k < DY; ++k) acc += Gy[a][k] * yv[k];
+                bn[a] = acc;
+            }
+            if (pilive) {
+                double db[D], w[D];
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    double acc = bn[a];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc -= ct[CL::A + a * D + k] * b[k];
+                    db[a] = acc;
+                }
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int a = 0; a < D; ++a) acc += LA[a][k] * db[a];
+                    w[k] = acc;
+                }
+#pragma unroll
+                for (int c = 0; c < D; ++c) {
+                    double acc = eta[c];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) acc += Pi[k][c] * w[k];
+                    eta[c] = acc;
+                }
+                double Pn[D][D], pmax = 0.0;
+#pragma unroll
+                for (int a = 0; a < D; ++a)
+#pragma unroll
+                    for (int c = 0; c < D; ++c) {
+                        double acc = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) acc += F[a][k] * Pi[k][c];
+                        Pn[a][c] = acc;
+                        pmax = fmax(pmax, fabs(acc));
+                    }
+#pragma unroll
+                for (int a = 0; a < D; ++a)
+#pragma unroll
+                    for (int c = 0; c < D; ++c) Pi[a][c] = Pn[a][c];
+                pilive = __any(pmax > 1e-20);
+            }
+#pragma unroll
+            for (int a = 0; a < D; ++a) b[a] = bn[a];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < D; ++a) {
+        o[a * p.n_chains] = b[a];
+        o[(D + a) * p.n_chains] = eta[a];
+#pragma unroll
+        for (int c = 0; c < D; ++c) x[(EX::PI + a * D + c) * p.n_chains] = Pi[a][c];
     }
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
 }

@@ -3481,6 +3481,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     const bool noise_in_sweep = e->noise && !e->dense && e->S > 0 && !filter && !hook_env("RXHIP_NOISE_MOMENTS_PASS");
     p.noise_B = noise_in_sweep ? e->n_B : nullptr;
     p.noise_part = noise_in_sweep ? e->n_part : nullptr;
+    p.elem_full = hook_env("RXHIP_ELEM_FULL") ? 1 : 0;
     const bool fused = e->fused && !filter;
     p.ftab = fused ? e->d_ftab : nullptr; p.mtab = fused ? e->d_mtab : nullptr; p.ntab = fused ? e->d_ntab : nullptr;
     p.fseg = fused ? e->d_fseg : nullptr; p.fe_const = e->fe_const;

@@ -28,7 +28,10 @@ struct Launch {
         if (uni) hipLaunchKernelGGL((k_seg_aggregate<D, DY, true>), dim3(nblk(total, 64)), dim3(64), 0, s, p, carg(hc));
     }
     static void seg_elements(const Params& p, hipStream_t s) {
-        hipLaunchKernelGGL((k_seg_elements<D, DY>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
+        if (!p.masked && !p.step_model && !p.elem_full && p.L >= 384) {   // (short segments end before the recursion settles: the plain kernel is the faster one there)
+            hipLaunchKernelGGL((k_seg_elements<D, DY, true>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
+            hipLaunchKernelGGL((k_seg_elements_tail<D, DY>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
+        } else hipLaunchKernelGGL((k_seg_elements<D, DY, false>), dim3(nblk(p.n_chains * (long long)p.S, 64)), dim3(64), 0, s, p);
     }
     static void boundary_scan(const Params& p, const double* hc, bool uni, bool fe, hipStream_t s) {
         dim3 grid(nblk(p.n_chains, 64), p.filter ? 1 : 2);  // a filtering run needs the prefix role only
