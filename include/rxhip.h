@@ -42,7 +42,7 @@ extern "C" {
  *     RXHIP_ONE_SEGMENT=1       d, dy <= 4 masked / per-step engines: one segment per chain
  *     RXHIP_BACKWARD_LANES=1    one-pass schedule: the backward sweep of the four-phase schedule instead of the table-driven one
  *     RXHIP_SMALL_SWEEP=0       few short chains: the five launches of the four-phase schedule instead of k_small_sweep (one launch)
- *     RXHIP_ELEM_FULL=1         per-chain models at d, dy <= 4: the segment elements by the full recursion to the end of every segment (no frozen tail)
+ *     RXHIP_ELEM_FULL=1         per-chain models at d, dy <= 4: every recursion of the sweep in full to the end of every segment (no frozen tails, full records)
  *     RXHIP_NOISE_MOMENTS_PASS=1  unknown-noise engines: the residual second moments by a separate pass over the posteriors instead of inside the backward sweep
  *     RXHIP_ENGINE_POOL=0       rxhip_destroy frees small engines instead of parking them for the next rxhip_lgssm_create of the same descriptor
  *     RXHIP_NO_PACK=1           d <= 8 on the MFMA path: one chain per 16x16 tile instead of two

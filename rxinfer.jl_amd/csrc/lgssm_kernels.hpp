@@ -193,6 +193,7 @@ struct Params {
     // Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′] of its segment while it holds (m_t, V_t) — part[seg][NS_y][chain]; null otherwise
     const double* noise_B;  // [DY][D]
     double* noise_part;
+    int tinv_records;       // per-chain, time-invariant models on long segments: k_forward_tinv / k_backward_tinv (mean-only records behind the fixed point)
     int elem_full;          // test hook: k_seg_elements runs the full recursion to the end of every segment (no frozen tail)
 };
 
@@ -490,6 +491,28 @@ __device__ __forceinline__ void store_filt(double* filt, long long t, long long 
     double2* base = reinterpret_cast<double2*>(filt) + ((t * nb64 + (chain >> 6)) * NP2) * 64 + (chain & 63);
 #pragma unroll
     for (int k = 0; k < NP2; ++k) base[k * 64] = make_double2(r[2 * k], r[2 * k + 1]);
+}
+// the rows of a record that hold the mean (MP2 = ⌈D/2⌉ of NP2; odd D: the last of them also carries V[0]) — what the sweeps of a
+// time-invariant per-chain model write and read once the filter covariance has reached its fixed point (TINV variants below)
+template <int D>
+__device__ __forceinline__ void store_filt_mean(double* filt, long long t, long long n_chains, long long chain, const double (&m)[D], const Sym<D>& V) {
+    constexpr int NP2 = Dim<D>::NP2, MP2 = (D + 1) / 2;
+    double r[2 * MP2];
+#pragma unroll
+    for (int i = 0; i < D; ++i) r[i] = m[i];
+    if (D < 2 * MP2) r[D] = V.v[0];
+    const long long nb64 = (n_chains + 63) >> 6;
+    double2* base = reinterpret_cast<double2*>(filt) + ((t * nb64 + (chain >> 6)) * NP2) * 64 + (chain & 63);
+#pragma unroll
+    for (int k = 0; k < MP2; ++k) base[k * 64] = make_double2(r[2 * k], r[2 * k + 1]);
+}
+template <int D>
+__device__ __forceinline__ void load_filt_mean(const double* filt, long long t, long long n_chains, long long chain, double2 (&r)[(D + 1) / 2]) {
+    constexpr int NP2 = Dim<D>::NP2, MP2 = (D + 1) / 2;
+    const long long nb64 = (n_chains + 63) >> 6;
+    const double2* base = reinterpret_cast<const double2*>(filt) + ((t * nb64 + (chain >> 6)) * NP2) * 64 + (chain & 63);
+#pragma unroll
+    for (int k = 0; k < MP2; ++k) r[k] = base[k * 64];
 }
 template <int D>
 __device__ __forceinline__ void load_filt_raw(const double* filt, long long t, long long n_chains,
@@ -1711,9 +1734,10 @@ struct OutTile;
 template <int D>
 __device__ __forceinline__ void write_marginal_wave(const Params& p, double2* tile, int lane, long long t,
                                                     long long chain0, const double (&m)[D], const Sym<D>& V);
-template <int D, int DY, bool UNI, bool FE, bool FILT = false>
+template <int D, int DY, bool UNI, bool FE, bool FILT = false, bool TINV = false>
 __device__ __forceinline__ void forward_body(const Params& p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE>& cb, const long long g, const int lane,
                                              double2* __restrict__ tile) {   // tile: the wave's output transpose buffer (FILT), or null
+    static_assert(!TINV || (!UNI && !FILT), "the frozen tail belongs to smoothing runs of per-chain, time-invariant models");
     using CL = CstLayout<D, DY>;
     constexpr bool CAN_TILE = FILT && (D % 2 == 0);
     const bool tiled = CAN_TILE && tile != nullptr && (p.n_chains % 64 == 0);
@@ -1763,6 +1787,9 @@ __device__ __forceinline__ void forward_body(const Params& p, const CstArgFor<UN
     load_AP(c.p);
     double yv[DY], yn[DY];
     if (len > 0) load_y<DY>(p.y, t0, p.n_chains, chain, yn);
+    double cf1 = 0.0, cf2 = 0.0;      // TINV: the fixed-point test of V_f (as in k_seg_elements)
+    int nsame = 0;
+    long long i_frozen = len;         // first step of the frozen tail
     for (long long i = 0; i < len; ++i) {
 #pragma unroll
         for (int k = 0; k < DY; ++k) yv[k] = yn[k];
@@ -1795,6 +1822,75 @@ __device__ __forceinline__ void forward_body(const Params& p, const CstArgFor<UN
             if (UNI) store_filt_sh<D>(p, t0 + i, chain, m, V);
             else store_filt<D>(p.filt, t0 + i, p.n_chains, chain, m, V);
         }
+        if constexpr (TINV) {
+            // Time-invariant model: V_f stops moving after the filter's mixing time (interior segments start ON the fixed point).  From there on
+            // the records carry the mean only (32 instead of 112 B per step at d = 4, each way) and a step costs no inverse: the loop below.
+            double f1 = 0.0, f2 = 0.0;
+#pragma unroll
+            for (int q = 0; q < Dim<D>::NS; ++q) {
+                f1 += V.v[q];
+                f2 += (1.0 + 0.37 * q) * V.v[q];
+            }
+            const bool same = fabs(f1 - cf1) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf2) <= 4.5e-16 * fabs(f2);
+            cf1 = f1;
+            cf2 = f2;
+            nsame = same ? nsame + 1 : 0;
+            if (__all(nsame >= 2 || !live)) {
+                i_frozen = i + 1;
+                break;
+            }
+        }
+    }
+    if constexpr (TINV) {
+        // first time index whose record carries the mean only (the segment's last record never does) — for the backward sweep, in a slot the scan has left
+        if (live) p.elem[(seg * 2 * D) * p.n_chains + chain] = (double)(t0 + i_frozen);
+        if (i_frozen < len) {   // wave-uniform
+            const CPtr Ac{Ar}, Pc{Pr};
+            double T[D][D];
+            Sym<D> Vp, Lp, Lf;
+            double detp, detl;
+            predict_cov<D>(Ac, Pc, V, T, Vp);
+            ok = spd_inv<D>(Vp, Lp, detp) && ok;
+#pragma unroll
+            for (int q = 0; q < Dim<D>::NS; ++q) Lf.v[q] = Lp.v[q] + oc.lobs[q];
+            ok = spd_inv<D>(Lf, V, detl) && ok;   // V = the fixed point, recomputed from itself
+            const double detc = detl * detp;
+            for (long long i = i_frozen; i < len; ++i) {
+#pragma unroll
+                for (int k = 0; k < DY; ++k) yv[k] = yn[k];
+                if (i + 1 < len) load_y<DY>(p.y, t0 + i + 1, p.n_chains, chain, yn);
+                double mp[D], xp[D], xf[D];
+                matvec_c<D>(Ac, m, mp);
+                symv<D>(Lp, mp, xp);
+#pragma unroll
+                for (int a = 0; a < D; ++a) {
+                    double sacc = xp[a];
+#pragma unroll
+                    for (int k = 0; k < DY; ++k) sacc += oc.g[a * DY + k] * yv[k];
+                    xf[a] = sacc;
+                }
+                symv<D>(V, xf, m);
+                if (FE) {
+                    double q = 0.0, a1 = 0.0, a2 = 0.0;
+#pragma unroll
+                    for (int a = 0; a < DY; ++a) {
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int k = 0; k < DY; ++k) sacc += oc.qi[sidx(a, k)] * yv[k];
+                        q += sacc * yv[a];
+                    }
+#pragma unroll
+                    for (int a = 0; a < D; ++a) {
+                        a1 += xf[a] * m[a];
+                        a2 += xp[a] * mp[a];
+                    }
+                    acc += oc.c0 + q - a1 + a2;
+                    lp.mul(detc);
+                }
+                if (i + 1 < len) store_filt_mean<D>(p.filt, t0 + i, p.n_chains, chain, m, V);
+                else store_filt<D>(p.filt, t0 + i, p.n_chains, chain, m, V);   // the segment's last record is the next segment's (and the end boundary's) full one
+            }
+        }
     }
     if (FE && live) p.fe_part[(seg + 1) * p.n_chains + chain] = -0.5 * (acc + lp.value());
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);
@@ -1804,6 +1900,12 @@ __global__ void __launch_bounds__(64) k_forward(Params p, const CstArgFor<UNI, C
     constexpr bool CAN_TILE = FILT && (D % 2 == 0);
     __shared__ double2 tile[CAN_TILE ? 64 * (((D + D * D) / 2) | 1) : 1];
     forward_body<D, DY, UNI, FE, FILT>(p, cb, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, CAN_TILE ? tile : nullptr);
+}
+// smoothing runs of per-chain, time-invariant models (whole wavefronts of one segment: n_chains a multiple of 64): mean-only records behind the
+// fixed point of V_f
+template <int D, int DY, bool FE>
+__global__ void __launch_bounds__(64) k_forward_tinv(Params p) {   // (capped at 256 registers it spills 900 bytes and takes 5.9 instead of 1.6 ms)
+    forward_body<D, DY, false, FE, false, true>(p, CstArg<1>{}, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, nullptr);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1882,11 +1984,12 @@ __device__ __forceinline__ void write_marginal_wave(const Params& p, double2* ti
     __builtin_amdgcn_wave_barrier();
 }
 
-template <int D, int DY, bool UNI, bool FUSED = false, bool NOISE = false>
+template <int D, int DY, bool UNI, bool FUSED = false, bool NOISE = false, bool TINV = false>
 __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE>& cb, const long long g, const int lane,
                                               double2* __restrict__ tile) {   // tile: the wave's output transpose buffer, or null
     static_assert(UNI || !FUSED, "the one-pass schedule exists for shared-model batches only");
     static_assert(!NOISE || !UNI, "residual moments are accumulated on the per-chain-model sweep");
+    static_assert(!TINV || (!UNI && !NOISE), "mean-only records: per-chain, time-invariant models (k_forward_tinv)");
     using CL = CstLayout<D, DY>;
     constexpr int NS = Dim<D>::NS;
     constexpr int NP2 = Dim<D>::NP2;
@@ -2011,9 +2114,21 @@ __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<U
         }
     }
     double2 rn[UNI ? DimM<D>::MP2 : NP2];
+    // TINV: records tc … te − 1 of this segment carry the mean only (k_forward_tinv) — their covariance is the one of record te, already in Vf
+    long long tc = te + 1;
+    if constexpr (TINV) tc = (long long)p.elem[(seg * 2 * D) * p.n_chains + chain];
     auto prefetch = [&](long long tt) {
         if constexpr (UNI) load_filt_m_sh<D>(p, tt, chain, rn);
-        else load_filt_raw<D>(p.filt, tt, p.n_chains, chain, rn);
+        else if constexpr (TINV) {
+            if (tt >= tc && tt < te) {   // (wave-uniform)
+                const long long nb64 = (p.n_chains + 63) >> 6;
+                const double2* base = reinterpret_cast<const double2*>(p.filt) + ((tt * nb64 + (chain >> 6)) * NP2) * 64 + (chain & 63);
+#pragma unroll
+                for (int k = 0; k < (D + 1) / 2; ++k) rn[k] = base[k * 64];
+            } else
+                load_filt_raw<D>(p.filt, tt, p.n_chains, chain, rn);
+        } else
+            load_filt_raw<D>(p.filt, tt, p.n_chains, chain, rn);
     };
     // per-chain models: transition constants in registers for the whole segment (see k_forward)
     double Ar[UNI ? 1 : D * D], Pr[UNI ? 1 : NS];
@@ -2028,7 +2143,77 @@ __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<U
     load_AP(c.p);
     if (len > 0) prefetch(te - 1);
     if (fused && len > 0) load_N(te - 1);
-    for (long long t = te - 1; t >= tb; --t) {
+    long long tstart = te - 1;
+    if constexpr (TINV) {
+        if (tc < te) {   // (wave-uniform) the mean-only records tc … te − 1: V_f is the one of record te, so Vp, its inverse and the smoother gain are constants
+            const CPtr Ac{Ar}, Pc{Pr};
+            double T[D][D], G[D][D], det;
+            Sym<D> Vp, Lp;
+            predict_cov<D>(Ac, Pc, Vf, T, Vp);
+            ok = spd_inv<D>(Vp, Lp, det) && ok;
+#pragma unroll
+            for (int i = 0; i < D; ++i)
+#pragma unroll
+                for (int j = 0; j < D; ++j) {
+                    double sacc = 0.0;
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sacc += T[k][i] * Lp(k, j);
+                    G[i][j] = sacc;
+                }
+            for (long long t = te - 1; t >= tc; --t) {
+                {
+                    double f[2 * ((D + 1) / 2)];
+#pragma unroll
+                    for (int k = 0; k < (D + 1) / 2; ++k) {
+                        f[2 * k] = rn[k].x;
+                        f[2 * k + 1] = rn[k].y;
+                    }
+#pragma unroll
+                    for (int a = 0; a < D; ++a) mf[a] = f[a];
+                }
+                prefetch(t - 1);   // (tc − 1 > tb: the full record the loop below starts with)
+                double mp[D], dm[D], H[D][D];
+                matvec_c<D>(Ac, mf, mp);
+#pragma unroll
+                for (int i = 0; i < D; ++i) dm[i] = ms[i] - mp[i];
+                Sym<D> Dm;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) Dm.v[i] = Vs.v[i] - Vp.v[i];
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j < D; ++j) {
+                        double sacc = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D; ++k) sacc += G[i][k] * Dm(k, j);
+                        H[i][j] = sacc;
+                    }
+#pragma unroll
+                for (int i = 0; i < D; ++i) {
+                    double sacc = mf[i];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) sacc += G[i][k] * dm[k];
+                    ms[i] = sacc;
+                }
+#pragma unroll
+                for (int i = 0; i < D; ++i)
+#pragma unroll
+                    for (int j = 0; j <= i; ++j) {
+                        double sacc = Vf(i, j);
+#pragma unroll
+                        for (int k = 0; k < D; ++k) sacc += H[i][k] * G[j][k];
+                        Vs(i, j) = sacc;
+                    }
+                if constexpr (CAN_TILE) {
+                    if (tiled) write_marginal_wave<D>(p, tile, lane, t, chain - lane, ms, Vs);
+                    else write_marginal<D>(p, t, chain, ms, Vs);
+                } else
+                    write_marginal<D>(p, t, chain, ms, Vs);
+            }
+            tstart = tc - 1;
+        }
+    }
+    for (long long t = tstart; t >= tb; --t) {
         if constexpr (UNI) {
             unpack_m_sh<D>(rn, mf);
             load_v_sh<D>(p, t, Vf);
@@ -2116,6 +2301,13 @@ __global__ void __launch_bounds__(64) k_backward(Params p, const CstArgFor<UNI, 
     constexpr bool CAN_TILE = (D % 2 == 0);
     __shared__ double2 tile[CAN_TILE ? 64 * OutTile<CAN_TILE ? D : 2>::STRIDE : 1];
     backward_body<D, DY, UNI, FUSED>(p, cb, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, CAN_TILE ? tile : nullptr);
+}
+// the same sweep behind k_forward_tinv: mean-only records where the filter covariance had reached its fixed point
+template <int D, int DY>
+__global__ void __launch_bounds__(64) k_backward_tinv(Params p) {
+    constexpr bool CAN_TILE = (D % 2 == 0);
+    __shared__ double2 tile[CAN_TILE ? 64 * OutTile<CAN_TILE ? D : 2>::STRIDE : 1];
+    backward_body<D, DY, false, false, false, true>(p, CstArg<1>{}, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, CAN_TILE ? tile : nullptr);
 }
 // the same sweep of an engine with an unknown observation-noise precision (per-chain constants): + the residual second moments per (segment, chain)
 template <int D, int DY>

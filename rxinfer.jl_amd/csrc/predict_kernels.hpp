@@ -27,6 +27,8 @@ struct PredictParams {
     // node-local joints (k_joint): the forward message's covariance of every step, as the sweep left it
     const double* filt;   // per-chain records [T][chain/64][NP2][64][2] (per-chain models, masked / per-step schedules) …
     const double* vtab;   // … or [T][NS], one copy for a shared-model batch (then `filt` is null)
+    const double* tinv_tc; // null, or Params::elem after a sweep of k_forward_tinv: first mean-only record of (segment, chain) at [(seg·2D)·chains + chain]
+    long long L;           // … with the segment length of that sweep: the records tc … te − 1 of a segment have the covariance of record te
     double* jmean;        // [T-1][chain][2D]
     double* jcov;         // [T-1][chain][2D][2D]
     const double* mu;     // known inputs (null: none): μ[t] [T+H][D] — the sweep ran on x − μ, y − ν; posteriors are back in x
@@ -171,7 +173,15 @@ __global__ __launch_bounds__(256) void k_joint(PredictParams p) {
         if (p.filt) {
             double2 r[NP2];
             double mf[D];
-            load_filt_raw<D>(p.filt, k, p.n_chains, c, r);
+            long long kr = k;
+            if (p.tinv_tc && k >= 1) {
+                const long long seg = (k - 1) / p.L;
+                long long te = (seg + 1) * p.L;
+                te = te < p.T - 1 ? te : p.T - 1;
+                const long long tc = (long long)p.tinv_tc[(seg * 2 * D) * p.n_chains + c];
+                if (k >= tc && k < te) kr = te;   // a mean-only record: the segment's last record carries its covariance
+            }
+            load_filt_raw<D>(p.filt, kr, p.n_chains, c, r);
             unpack_rec<D>(r, mf, Vf);
         } else {
 #pragma unroll

@@ -251,6 +251,7 @@ struct rxhip_engine {
     double* h_stage = nullptr;   // pinned staging block of the creation upload (arena_commit), kept until destruction
     size_t h_stage_bytes = 0;
     // unknown observation-noise precision (rxhip_lgssm_noise_create, noise_kernels.hpp): one block B | prior | state | history
+    bool records_tinv = false;   // the last smoothing run left mean-only forward records behind the fixed point of V_f (Params::tinv_records)
     bool noise = false;
     bool noise_continue = false;   // rxhip_lgssm_noise_continue: runs go on from the current q(W) (iteration-at-a-time drivers)
     char* noise_block = nullptr;
@@ -1990,6 +1991,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             hit->cov_mode = 0;
             hit->cov_pending = hit->cov_current = false;
             hit->records_hold_gains = false;
+            hit->records_tinv = false;
             hit->stream_k = 0;
             hit->have_inputs = false;
             for (int k = 0; k < RXHIP_K_COUNT; ++k) { hit->k_ms[k] = 0.0; hit->k_n[k] = 0; }
@@ -3482,6 +3484,9 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.noise_B = noise_in_sweep ? e->n_B : nullptr;
     p.noise_part = noise_in_sweep ? e->n_part : nullptr;
     p.elem_full = hook_env("RXHIP_ELEM_FULL") ? 1 : 0;
+    // per-chain, time-invariant models on long segments: mean-only forward records behind the fixed point of V_f (k_forward_tinv / k_backward_tinv)
+    p.tinv_records = (!e->dense && !e->uniform && e->d_elemx && !e->masked && !e->d_step_model && !e->noise && !filter && e->n_chains % 64 == 0 && e->S > 0 &&
+                      e->L >= 384 && !p.elem_full) ? 1 : 0;
     const bool fused = e->fused && !filter;
     p.ftab = fused ? e->d_ftab : nullptr; p.mtab = fused ? e->d_mtab : nullptr; p.ntab = fused ? e->d_ntab : nullptr;
     p.fseg = fused ? e->d_fseg : nullptr; p.fe_const = e->fe_const;
@@ -3675,6 +3680,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     e->last_iterations = iterations;
     e->last_want_fe = fe;
     e->ran = true;
+    e->records_tinv = p.tinv_records != 0 && iterations > 0;
     // reference-equivalent operation counts (6 rule calls, 4 products per step)
     const uint64_t C = (uint64_t)e->n_chains, T = (uint64_t)e->T, I = (uint64_t)iterations;
     e->last_filter = filter;
@@ -3965,6 +3971,7 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
     pp.T = e->T; pp.H = 0; pp.n_chains = e->n_chains; pp.mean = e->d_mean; pp.cov = e->d_cov; pp.cst = e->d_cst;
     pp.chain_model = e->d_chain_model; pp.step_model = e->d_step_model; pp.status = e->d_status;
     pp.filt = e->uniform ? nullptr : e->d_filt; pp.vtab = e->d_vtab;
+    pp.tinv_tc = e->records_tinv ? e->d_elem : nullptr; pp.L = e->L;
     pp.jmean = tmp; pp.jcov = tmp + rows * d2; pp.cx = e->d_cx; pp.off_chain = e->off_chain ? 1 : 0;
     e->vt->joint(pp, e->stream);
     rxhip_status st = RXHIP_OK;

@@ -55,6 +55,9 @@ struct Launch {
         if (uni) {
             if (fe) hipLaunchKernelGGL((k_forward<D, DY, true, true, FILT>), grid, dim3(64), 0, s, p, carg(hc));
             else hipLaunchKernelGGL((k_forward<D, DY, true, false, FILT>), grid, dim3(64), 0, s, p, carg(hc));
+        } else if (!FILT && p.tinv_records) {
+            if (fe) hipLaunchKernelGGL((k_forward_tinv<D, DY, true>), grid, dim3(64), 0, s, p);
+            else hipLaunchKernelGGL((k_forward_tinv<D, DY, false>), grid, dim3(64), 0, s, p);
         } else {
             if (fe) hipLaunchKernelGGL((k_forward<D, DY, false, true, FILT>), grid, dim3(64), 0, s, p, CstArg<1>{});
             else hipLaunchKernelGGL((k_forward<D, DY, false, false, FILT>), grid, dim3(64), 0, s, p, CstArg<1>{});
@@ -70,6 +73,7 @@ struct Launch {
         if (uni && p.ntab) hipLaunchKernelGGL((k_backward<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));  // one-pass run
         else if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
         else if (p.noise_part) hipLaunchKernelGGL((k_backward_noise<D, DY>), grid, dim3(64), 0, s, p);
+        else if (p.tinv_records) hipLaunchKernelGGL((k_backward_tinv<D, DY>), grid, dim3(64), 0, s, p);
         else hipLaunchKernelGGL((k_backward<D, DY, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
     }
     static void forward0(const Params& p, const double* hc, bool fe, hipStream_t s) {

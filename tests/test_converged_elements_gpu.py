@@ -1,6 +1,8 @@
-"""k_seg_elements (per-chain models at d, dy ≤ 4) stops its matrix recursion where the known-start filter's covariance has reached its fixed point and
-runs the frozen recursion over the rest of the segment (lgssm_kernels.hpp).  Against the full recursion (RXHIP_ELEM_FULL=1) and against the oracle,
-with models whose filters settle at very different speeds inside one wavefront, segments shorter and much longer than the settling time."""
+"""Per-chain, time-invariant models at d, dy ≤ 4 on long segments (lgssm_kernels.hpp): k_seg_elements stops its matrix recursion where the known-start
+filter's covariance has reached its fixed point and k_seg_elements_tail runs the frozen recursion; k_forward_tinv writes mean-only records behind the
+fixed point of V_f and k_backward_tinv reads them (the covariance from the segment's last record).  Against the full recursions (RXHIP_ELEM_FULL=1) and
+the oracle, with models whose filters settle at very different speeds inside one wavefront, segments shorter and much longer than the settling time,
+and the node-local joints (which read the forward records) on top."""
 import numpy as np
 import pytest
 
@@ -38,9 +40,11 @@ def test_frozen_tail_against_the_full_recursion_and_the_oracle(d, dy, T, C, segm
                                segments=segments) as eng:
             eng.set_data(y)
             eng.run(1, True)
-            res.append((eng.marginals(), eng.free_energy_per_chain(), eng.schedule()))
-    (m1, c1), f1, sched = res[0]
-    (m2, c2), f2, _ = res[1]
+            res.append((eng.marginals(), eng.free_energy_per_chain(), eng.schedule(), eng.node_marginals() if T <= 4000 else None))
+    (m1, c1), f1, sched, j1 = res[0]
+    (m2, c2), f2, _, j2 = res[1]
+    if j1 is not None:   # the node-local joints read V_f(t) from the forward records: mean-only behind the fixed point, the segment's last record has it
+        assert np.allclose(j1[0], j2[0], rtol=1e-9, atol=1e-11) and np.allclose(j1[1], j2[1], rtol=1e-8, atol=1e-11)
     assert sched["segments"] > 1
     sd = np.sqrt(np.einsum("tcii->tci", c2))
     assert np.max(np.abs(m1 - m2) / sd) < 1e-11 and np.max(np.abs(c1 - c2) / (sd[..., :, None] * sd[..., None, :])) < 1e-11
