@@ -1387,8 +1387,9 @@ __global__ void __launch_bounds__(64) k_fe_seg(Params p) {
 //        m' = Π W (V⁻¹ m + η) + b,  V' = Π W Π' + C
 //   role 1 (suffix): backward message β(b_S) = (0, 0), then
 //        β(b_s): W = (C⁻¹ + Λ)⁻¹,  ξ' = η + X' W (ξ − Λ b),  Λ' = JJ − X' W X
-template <int D, int DY, bool UNI, bool FE>
+template <int D, int DY, bool UNI, bool FE, bool TS = false>   // TS: time-invariant per-chain models — the recursions stop at their fixed points (below)
 __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<UNI, CstLayout<D, DY>::SIZE> cb) {
+    static_assert(!TS || !UNI, "shared-model batches scan vectors only (k_boundary_scan_tab)");
     using CL = CstLayout<D, DY>;
     using AL = AggLayout<D>;
     constexpr int NS = Dim<D>::NS;
@@ -1439,11 +1440,19 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
 #pragma unroll
             for (int i = 0; i < 2 * D; ++i) eln[i] = S > 1 ? el0[i * p.n_chains] : 0.0;
         }
+        // Time-invariant per-chain models (!UNI, no masks, no per-step constants): the interior segments' element MATRICES are identical, so the boundary
+        // covariance V(b_s) is a Riccati recursion over s that reaches its fixed point after a few segments — from there on a segment costs the two
+        // matrix–vector products of the mean, m′ = M1 m + M2 η_s + b_s with M2 = Π W, M1 = M2 V⁻¹, instead of two 4×4 inverses and three products
+        // (the same test as in k_seg_elements; every lane of the wavefront)
+        constexpr bool tinv_scan = TS;   // (an instantiation of its own: masked sweeps keep the plain kernel and its registers)
+        double cf1 = 0.0, cf2 = 0.0, M1[TS ? D : 1][TS ? D : 1], M2[TS ? D : 1][TS ? D : 1];
+        int nsame = 0;
+        bool frozen = false;
         for (int s = 0; s < S; ++s) {
             store_soa<D>(p.fstart, s, p.n_chains, chain, m, V);
             if (s == S - 1) break;
             if constexpr (!UNI) {
-                if (p.elemx) load_elemx<D>(p, s, chain, false, al);
+                if (p.elemx && !frozen) load_elemx<D>(p, s, chain, false, al);
             }
             const CPtr a{UNI ? aggm : al};
             double elc[2 * D];
@@ -1453,6 +1462,21 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
                 const double* eq = p.elem + ((long long)(s + 1) * 2 * D) * p.n_chains + chain;
 #pragma unroll
                 for (int i = 0; i < 2 * D; ++i) eln[i] = eq[i * p.n_chains];
+            }
+            if constexpr (TS) {
+                if (frozen) {   // (wave-uniform)
+                    double mn[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double sacc = elc[i];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) sacc += M1[i][k] * m[k] + M2[i][k] * elc[D + k];
+                        mn[i] = sacc;
+                    }
+#pragma unroll
+                    for (int i = 0; i < D; ++i) m[i] = mn[i];
+                    continue;
+                }
             }
             Sym<D> Vi, W, T1;
             double det;
@@ -1492,6 +1516,33 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
                     for (int k = 0; k < D; ++k) sacc += PW[i][k] * a[AL::PI + j * D + k];
                     V(i, j) = sacc;
                 }
+            if constexpr (TS) {
+                if (tinv_scan) {
+                    double f1 = 0.0, f2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        f1 += V.v[q];
+                        f2 += (1.0 + 0.37 * q) * V.v[q];
+                    }
+                    const bool same = fabs(f1 - cf1) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf2) <= 4.5e-16 * fabs(f2);
+                    cf1 = f1;
+                    cf2 = f2;
+                    nsame = same ? nsame + 1 : 0;
+                    if (__all(nsame >= 2)) {   // M2 = Π W, M1 = Π W V⁻¹ of the step just taken (V in = V out to 2 ulp)
+                        frozen = true;
+#pragma unroll
+                        for (int i = 0; i < D; ++i)
+#pragma unroll
+                            for (int j = 0; j < D; ++j) {
+                                M2[i][j] = PW[i][j];
+                                double sacc = 0.0;
+#pragma unroll
+                                for (int k = 0; k < D; ++k) sacc += PW[i][k] * Vi(k, j);
+                                M1[i][j] = sacc;
+                            }
+                    }
+                }
+            }
         }
     } else {
         double xi[D];
@@ -1508,10 +1559,17 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
 #pragma unroll
             for (int i = 0; i < 2 * D; ++i) eln[i] = eq[i * p.n_chains];
         }
+        // (the same shortcut as in the prefix role: Λ(b_s) reaches its fixed point a few interior segments behind the last one; then
+        //  ξ′ = η_s + N1 ξ − N2 b_s with N1 = X′W, N2 = N1 Λ)
+        constexpr bool tinv_scan = TS;   // (an instantiation of its own: masked sweeps keep the plain kernel and its registers)
+        double cf1 = 0.0, cf2 = 0.0, N1[TS ? D : 1][TS ? D : 1], N2[TS ? D : 1][TS ? D : 1];
+        int nsame = 0;
+        bool frozen = false;
         for (int s = S - 1; s >= 1; --s) {
             const double* am = aggm + ((s == S - 1) ? AL::SIZE : 0);
             if constexpr (!UNI) {
-                if (p.elemx) ok = load_elemx<D>(p, s, chain, true, al) && ok;
+                if (frozen) {
+                } else if (p.elemx) ok = load_elemx<D>(p, s, chain, true, al) && ok;
                 else if (s >= S - 2) {   // the last segment's table, then the interior one: two fetches for the whole recursion
 #pragma unroll
                     for (int q = 0; q < AL::SIZE; ++q) al[q] = am[q];
@@ -1528,6 +1586,22 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
                 const double* eq = p.elem + ((long long)(s - 1) * 2 * D) * p.n_chains + chain;
 #pragma unroll
                 for (int i = 0; i < 2 * D; ++i) eln[i] = eq[i * p.n_chains];
+            }
+            if constexpr (TS) {
+                if (frozen) {   // (wave-uniform)
+                    double xn[D];
+#pragma unroll
+                    for (int i = 0; i < D; ++i) {
+                        double sacc = eta[i];
+#pragma unroll
+                        for (int k = 0; k < D; ++k) sacc += N1[i][k] * xi[k] - N2[i][k] * b[k];
+                        xn[i] = sacc;
+                    }
+#pragma unroll
+                    for (int i = 0; i < D; ++i) xi[i] = xn[i];
+                    store_soa<D>(p.beta, s, p.n_chains, chain, xi, Lm);
+                    continue;
+                }
             }
             Sym<D> T1, W;
             double det;
@@ -1557,6 +1631,7 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
                 for (int k = 0; k < D; ++k) sacc += a[AL::X + k * D + i] * w[k];
                 xi[i] = sacc;
             }
+            Sym<D> Lin = Lm;   // Λ the step started from (N2 below)
 #pragma unroll
             for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -1567,6 +1642,38 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
                     Lm(i, j) = sacc;
                 }
             store_soa<D>(p.beta, s, p.n_chains, chain, xi, Lm);
+            if constexpr (TS) {
+                if (tinv_scan && s < S - 1) {   // (interior elements only: the last segment has its own)
+                    double f1 = 0.0, f2 = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NS; ++q) {
+                        f1 += Lm.v[q];
+                        f2 += (1.0 + 0.37 * q) * Lm.v[q];
+                    }
+                    const bool same = fabs(f1 - cf1) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf2) <= 4.5e-16 * fabs(f2);
+                    cf1 = f1;
+                    cf2 = f2;
+                    nsame = same ? nsame + 1 : 0;
+                    if (__all(nsame >= 2)) {
+                        frozen = true;
+#pragma unroll
+                        for (int i = 0; i < D; ++i)
+#pragma unroll
+                            for (int j = 0; j < D; ++j) {
+                                N1[i][j] = WX[j][i];   // (X′W)[i][j] = (W X)[j][i], W symmetric
+                            }
+#pragma unroll
+                        for (int i = 0; i < D; ++i)
+#pragma unroll
+                            for (int j = 0; j < D; ++j) {
+                                double sacc = 0.0;
+#pragma unroll
+                                for (int k = 0; k < D; ++k) sacc += N1[i][k] * Lin(k, j);
+                                N2[i][j] = sacc;
+                            }
+                    }
+                }
+            }
         }
     }
     if (!ok) atomicOr(p.status, ST_NOT_POSDEF);

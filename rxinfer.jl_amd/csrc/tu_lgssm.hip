@@ -38,6 +38,9 @@ struct Launch {
         if (uni) {
             if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));
             else hipLaunchKernelGGL((k_boundary_scan<D, DY, true, false>), grid, dim3(64), 0, s, p, carg(hc));
+        } else if (!p.masked && !p.step_model && !p.elem_full) {   // time-invariant per-chain models
+            if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, false, true, true>), grid, dim3(64), 0, s, p, CstArg<1>{});
+            else hipLaunchKernelGGL((k_boundary_scan<D, DY, false, false, true>), grid, dim3(64), 0, s, p, CstArg<1>{});
         } else {
             if (fe) hipLaunchKernelGGL((k_boundary_scan<D, DY, false, true>), grid, dim3(64), 0, s, p, CstArg<1>{});
             else hipLaunchKernelGGL((k_boundary_scan<D, DY, false, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
