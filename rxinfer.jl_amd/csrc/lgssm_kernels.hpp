@@ -2096,7 +2096,7 @@ __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<U
                                               double2* __restrict__ tile) {   // tile: the wave's output transpose buffer, or null
     static_assert(UNI || !FUSED, "the one-pass schedule exists for shared-model batches only");
     static_assert(!NOISE || !UNI, "residual moments are accumulated on the per-chain-model sweep");
-    static_assert(!TINV || (!UNI && !NOISE), "mean-only records: per-chain, time-invariant models (k_forward_tinv)");
+    static_assert(!TINV || !UNI, "mean-only records: per-chain, time-invariant models (k_forward_tinv)");
     using CL = CstLayout<D, DY>;
     constexpr int NS = Dim<D>::NS;
     constexpr int NP2 = Dim<D>::NP2;
@@ -2316,6 +2316,7 @@ __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<U
                     else write_marginal<D>(p, t, chain, ms, Vs);
                 } else
                     write_marginal<D>(p, t, chain, ms, Vs);
+                noise_add(t, ms, Vs);
             }
             tstart = tc - 1;
         }
@@ -2417,11 +2418,11 @@ __global__ void __launch_bounds__(64) k_backward_tinv(Params p) {
     backward_body<D, DY, false, false, false, true>(p, CstArg<1>{}, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, CAN_TILE ? tile : nullptr);
 }
 // the same sweep of an engine with an unknown observation-noise precision (per-chain constants): + the residual second moments per (segment, chain)
-template <int D, int DY>
+template <int D, int DY, bool TINV = false>
 __global__ void __launch_bounds__(64) k_backward_noise(Params p) {
     constexpr bool CAN_TILE = (D % 2 == 0);
     __shared__ double2 tile[CAN_TILE ? 64 * OutTile<CAN_TILE ? D : 2>::STRIDE : 1];
-    backward_body<D, DY, false, false, true>(p, CstArg<1>{}, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, CAN_TILE ? tile : nullptr);
+    backward_body<D, DY, false, false, true, TINV>(p, CstArg<1>{}, (long long)blockIdx.x * blockDim.x + threadIdx.x, (int)threadIdx.x, CAN_TILE ? tile : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------

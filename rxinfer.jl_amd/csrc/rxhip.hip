@@ -3485,8 +3485,10 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     p.noise_part = noise_in_sweep ? e->n_part : nullptr;
     p.elem_full = hook_env("RXHIP_ELEM_FULL") ? 1 : 0;
     // per-chain, time-invariant models on long segments: mean-only forward records behind the fixed point of V_f (k_forward_tinv / k_backward_tinv)
-    p.tinv_records = (!e->dense && !e->uniform && e->d_elemx && !e->masked && !e->d_step_model && !e->noise && !filter && e->n_chains % 64 == 0 && e->S > 0 &&
-                      e->L >= 384 && !p.elem_full) ? 1 : 0;
+    // (any segment length: interior segments start ON the fixed point; an unknown-noise engine's models are time-invariant within a sweep, and its
+    //  separate moment pass — the test hook — reads posteriors, not records)
+    p.tinv_records = (!e->dense && !e->uniform && e->d_elemx && !e->masked && !e->d_step_model && !filter && e->n_chains % 64 == 0 && e->S > 0 && !p.elem_full &&
+                      (!e->noise || noise_in_sweep)) ? 1 : 0;
     const bool fused = e->fused && !filter;
     p.ftab = fused ? e->d_ftab : nullptr; p.mtab = fused ? e->d_mtab : nullptr; p.ntab = fused ? e->d_ntab : nullptr;
     p.fseg = fused ? e->d_fseg : nullptr; p.fe_const = e->fe_const;

@@ -75,6 +75,7 @@ struct Launch {
         dim3 grid(nblk(total, 64));
         if (uni && p.ntab) hipLaunchKernelGGL((k_backward<D, DY, true, true>), grid, dim3(64), 0, s, p, carg(hc));  // one-pass run
         else if (uni) hipLaunchKernelGGL((k_backward<D, DY, true>), grid, dim3(64), 0, s, p, carg(hc));
+        else if (p.noise_part && p.tinv_records) hipLaunchKernelGGL((k_backward_noise<D, DY, true>), grid, dim3(64), 0, s, p);
         else if (p.noise_part) hipLaunchKernelGGL((k_backward_noise<D, DY>), grid, dim3(64), 0, s, p);
         else if (p.tinv_records) hipLaunchKernelGGL((k_backward_tinv<D, DY>), grid, dim3(64), 0, s, p);
         else hipLaunchKernelGGL((k_backward<D, DY, false>), grid, dim3(64), 0, s, p, CstArg<1>{});
