@@ -219,7 +219,12 @@ def extra_per_chain_models(mdl, T, C, y_dev, device, y_host=None, steps=3):
             "frac": b_bwd * units / (k * 1e-3) / 1e9 / HBM_PEAK_GBS if k else None,
             "sweep_bytes_per_U": b_sweep, "sweep_achieved": b_sweep * units / (ms * 1e-3) / 1e9,
             "sweep_frac": b_sweep * units / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "rule_calls_per_s": (6 * T - 3) * C / (ms * 1e-3), "parity_spot": spot, "timing": timing_mode(2)}
+            "rule_calls_per_s": (6 * T - 3) * C / (ms * 1e-3), "parity_spot": spot, "timing": timing_mode(2),
+            # SURVEY's algorithmic bytes are charged unmodified (272 B/U for the backward sweep, 416 for the sweep).  Since round 4 a time-invariant chain stops
+            # computing, writing and reading what has reached its fixed point: behind the fixed point of V_f the forward records carry the mean only,
+            # so the backward kernel MOVES ≈ 160 (posterior) + 32 (mean record) B/U and the sweep ≈ 32 + 32 + 32 + 160 + the element pass's 32 — `frac` and
+            # `sweep_frac` are throughput in reference-equivalent bytes (they may exceed what the HBM can do), `moved_frac` is the kernel's own traffic estimate
+            "moved_bytes_per_U_estimate": 192, "moved_frac": 192 * units / (k * 1e-3) / 1e9 / HBM_PEAK_GBS if k else None}
 
 
 def extra_c1(device, with_cpu=True):
