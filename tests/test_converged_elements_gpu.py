@@ -22,7 +22,8 @@ def _models(d, dy, C, seed):
     return out
 
 
-@pytest.mark.parametrize("d,dy,T,C,segments", [(4, 4, 6000, 64, 4), (4, 4, 3000, 70, 0), (3, 2, 5000, 64, 2), (2, 1, 4000, 128, 3), (1, 1, 9000, 64, 2), (4, 2, 900, 64, 30)])
+@pytest.mark.parametrize("d,dy,T,C,segments", [(4, 4, 6000, 64, 4), (4, 4, 3000, 70, 0), (3, 2, 5000, 64, 2), (2, 1, 4000, 128, 3), (1, 1, 9000, 64, 2), (4, 2, 900, 64, 30),
+                                                 (3, 3, 1500, 64, 3), (1, 1, 1200, 128, 2), (3, 1, 2100, 64, 7)])
 def test_frozen_tail_against_the_full_recursion_and_the_oracle(d, dy, T, C, segments, monkeypatch):
     import rxhip
     import rxoracle as rxo
@@ -53,3 +54,31 @@ def test_frozen_tail_against_the_full_recursion_and_the_oracle(d, dy, T, C, segm
         om, oc, nll = rxo.lgssm_kalman_rts(ms[c]["A"], ms[c]["B"], ms[c]["P"], ms[c]["Q"], ms[c]["m0"], ms[c]["V0"], np.ascontiguousarray(y[:, c]))
         s = np.sqrt(np.einsum("tii->ti", oc))
         assert np.max(np.abs(m1[:, c] - om) / s) < 1e-8 and abs(f1[c] - nll) < 1e-9 * abs(nll), c
+
+
+def test_runs_of_every_kind_on_one_engine(monkeypatch):
+    """mean-only records are a property of the LAST smoothing run: filtering runs, repeated iterations and the node-local joints in between"""
+    import rxhip
+    from rxhip import workloads
+    d, dy, T, C = 4, 2, 2400, 64
+    ms = _models(d, dy, C, seed=77)
+    y = np.stack([workloads.generate_batch(ms[c], T, 1, seed0=c)[:, 0] for c in range(C)], axis=1)
+    stack = lambda k: np.stack([m[k] for m in ms])
+    out = []
+    for full in (None, "1"):
+        if full:
+            monkeypatch.setenv("RXHIP_ELEM_FULL", full)
+        else:
+            monkeypatch.delenv("RXHIP_ELEM_FULL", raising=False)
+        with rxhip.LGSSMEngine(stack("A"), stack("B"), stack("P"), stack("Q"), stack("m0"), stack("V0"), T=T, n_chains=C, chain_model=np.arange(C, dtype=np.int32), segments=4) as eng:
+            eng.set_data(y)
+            eng.run(2, True)
+            a = (eng.marginals()[0], eng.free_energy(), eng.node_marginals()[1])
+            eng.run_filter(True)
+            b = (eng.marginals()[0], eng.free_energy_per_chain())
+            eng.run(1, False)
+            c = (eng.marginals()[1], eng.node_marginals()[0])
+            out.append((a, b, c))
+    for x, z in zip(out[0], out[1]):
+        for u, v in zip(x, z):
+            assert np.allclose(u, v, rtol=1e-9, atol=1e-11)
