@@ -344,19 +344,22 @@ def extra_c3(device, parity=True):
     ref_flop = 18 * d ** 3 * T
     tf = lambda flop, t_ms: flop / (t_ms * 1e-3) / 1e12
     fwd_ms, bwd_ms = kt.get("k_forward", 0.0), kt.get("k_backward", 0.0)
-    roof = {"bound": "mfma", "kernel": "kd_forward_info", "flop": mfma_step["kd_forward_info"] * 2048 * T, "ms": fwd_ms,
-            "achieved": tf(mfma_step["kd_forward_info"] * 2048 * T, fwd_ms) if fwd_ms else None, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": tf(mfma_step["kd_forward_info"] * 2048 * T, fwd_ms) / FP64_PEAK_TFLOPS if fwd_ms else None,
-            "mfma_frac": tf(mfma_step["kd_forward_info"] * 2048 * T, fwd_ms) / FP64_PEAK_TFLOPS if fwd_ms else None,
-            "backward": {"kernel": "kd_backward_info", "flop": mfma_step["kd_backward_info"] * 2048 * T, "ms": bwd_ms,
-                         "frac": tf(mfma_step["kd_backward_info"] * 2048 * T, bwd_ms) / FP64_PEAK_TFLOPS if bwd_ms else None},
-            "note": "flop = MFMA instructions of the shipped kernels x 2048 (counters: profiles/r04/pmc_c3.txt); frac = mfma_frac: "
-                    "the kernels execute nothing but MFMA flops worth counting"}
+    # Since round 4 the sweep kernels leave the matrix work of a segment once its matrices repeat (every step's C, G', M and V_s equal the previous
+    # step's to 2 ulp: interior segments after three steps) — the counts above are per FULL step, and most steps of this chain are not full any more.
+    # What the line can state honestly: the reference-equivalent rate (SURVEY's 18 d^3 per step over the sweep time), and the matrix-pipe figure of
+    # the full steps from the counters (profiles/r04/pmc_c3.txt: 0.47 of peak inside the steps that still execute products).  `mfma_frac` is therefore
+    # null; a kernel that finishes sooner by executing fewer products has no business quoting a higher utilisation.
+    roof = {"bound": "mfma", "kernel": "kd_forward_info", "flop": ref_flop, "ms": ms,
+            "achieved": tf(ref_flop, ms), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (reference-equivalent: 18 d^3 per step)",
+            "frac": tf(ref_flop, ms) / FP64_PEAK_TFLOPS, "mfma_frac": None,
+            "full_step_mfma": mfma_step,
+            "note": "frac = reference-schedule flops over the sweep time; executed MFMA work is no longer T x the per-step counts (repeating segments skip it): "
+                    "matrix-pipe utilisation inside full steps 0.47 by the counters, profiles/r04/pmc_c3.txt"}
     return {"workload": "LGSSM d=64 dy=64 T=10000, 1 chain, 1 BP sweep + Bethe free energy per step", "ms_per_step": ms,
-            "kernels_ms_avg": kt, "tflops_ref_count": tf(ref_flop, ms), "tflops_executed": tf(mfma_flop, ms),
-            "mfma_flop_per_sweep": mfma_flop, "ref_flop_per_sweep": ref_flop,
-            "peak_tflops_fp64": FP64_PEAK_TFLOPS, "frac": tf(mfma_flop, ms) / FP64_PEAK_TFLOPS,
-            "frac_ref_count": tf(ref_flop, ms) / FP64_PEAK_TFLOPS, "frac_round2_count_12d3": tf(12 * d ** 3 * T, ms) / FP64_PEAK_TFLOPS,
+            "kernels_ms_avg": kt, "tflops_ref_count": tf(ref_flop, ms), "ref_flop_per_sweep": ref_flop,
+            "mfma_flop_per_sweep_if_every_step_were_full": mfma_flop,
+            "peak_tflops_fp64": FP64_PEAK_TFLOPS, "frac": tf(ref_flop, ms) / FP64_PEAK_TFLOPS,
+            "frac_ref_count": tf(ref_flop, ms) / FP64_PEAK_TFLOPS,
             "roofline": roof, "filter_ms_per_step": fms, "timing": timing_mode(2), "parity_spot": spot,
             "hoisted_matrices": hoisted,
             "create_set_data_first_run_ms": create_ms, "create_set_data_first_run_split_ms": first_split, "create_stages_ms": cstages,

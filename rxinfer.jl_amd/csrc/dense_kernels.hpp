@@ -839,6 +839,9 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
 #ifndef RXHIP_KF_RELOAD
 #define RXHIP_KF_RELOAD 1
 #endif
+#ifndef RXHIP_FWD_FROZEN
+#define RXHIP_FWD_FROZEN 1
+#endif
 
 template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true, class SEED = NoSeed>
 __device__ __forceinline__ bool spd_inverse(Acc<NT>& a, double* scratch, int w, int lane, LogProd& lp, PF prefetch = PF(), SEED* seed = nullptr) {
@@ -953,7 +956,8 @@ struct DenseLds {
     static constexpr int SCR2 = ALIAS ? 8 * C::D : (SCR > 8 * C::D ? SCR : 8 * C::D);   // what those kernels carve besides
     // kd_forward_info at d ≥ 48 keeps a seed of the tile inverse per wave there (DiagSeed) — 162 304 bytes for two workgroups at d = 64, of 163 840
     static constexpr bool SEEDED = ALIAS;
-    static constexpr int FWD_TAIL = SEEDED && NT * DiagSeed::LDS_DOUBLES > SCR2 ? NT * DiagSeed::LDS_DOUBLES : SCR2;
+    static constexpr int FWD_FROZEN = 16;   // kd_forward_info: two functionals of M per wave, the log-determinant state in front of the inverse
+    static constexpr int FWD_TAIL = (SEEDED && NT * DiagSeed::LDS_DOUBLES > SCR2 ? NT * DiagSeed::LDS_DOUBLES : SCR2) + FWD_FROZEN;
     static constexpr size_t bytes(int dmax) {   // scan kernels (vectors + the staging of dense_affine_rounds), kd_prepare_bnd (scratch only)
         return sizeof(double) * ((size_t)NVEC * dmax + (SCR > 8 * C::D ? SCR : 8 * C::D) + 3 * C::THREADS + 32 + 2 * 32 * C::D + 48);
     }
@@ -1748,6 +1752,18 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
 #ifdef RXHIP_TEST_SEEDCOUNT
     long long tph_ = __builtin_readcyclecounter();
 #endif
+    // FROZEN (one set of constants, no masks): once M_{t+1} = M_t to rounding — two linear functionals of its tiles unchanged to 2 ulp on two
+    // steps in a row — every matrix of a step repeats (C, G′, M, the determinants), and the rest of the segment is the loop behind this one:
+    // vectors and record stores only.  Interior segments start on the fixed point (boundary table) and leave after three steps.
+    constexpr bool FROZEN = RXHIP_FWD_FROZEN && SEEDED;
+    // for the backward sweep: the first time index of this segment whose record holds the repeated matrices (default: beyond the segment) — in a
+    // slot of the segment's first record that nothing else touches: tile (1, 0) of C, which no wave owns in the symmetric pairing (NT ≥ 3)
+    constexpr int FZ_SLOT = C::HDR + (NT * 4) * 64;
+    if (FROZEN && tid == 0 && p.mseg == 0 && len > 0) p.filt[(chain * p.T + t0) * C::REC + FZ_SLOT] = (double)(t0 + len);
+    double* fz = cpp + 4 * dm + DenseLds<NT>::FWD_TAIL - DenseLds<NT>::FWD_FROZEN;   // [2·w], [2·w + 1]: this wave's functionals; [8], [9]: lp in front of the inverse
+    double fzp1 = 0.0, fzp2 = 0.0;
+    int fz_same = 0;
+    long long i_frozen = len;
     for (long long i = 0; i < len; ++i) {
         const long long t = t0 + i;
         if constexpr (STEPM) {
@@ -1760,6 +1776,9 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
         if (tid < D) {
             rec[tid] = xi[tid];  // ξ_f(t − 1)
             gyn = p.filt[(chain * p.T + (i + 1 < len ? t + 1 : t)) * C::REC + D + tid];
+        }
+        if constexpr (FROZEN && FE) {
+            if (tid == 0) { fz[8] = lp.mant; fz[9] = (double)lp.expo; }   // the step's determinant factor = what the inverse below multiplies in
         }
         // C = (Λ_f + A'P⁻¹A)⁻¹.  The inverse's scratch is S0 (or its own carve): the next writer of S0 is the store of −G below,
         // behind a workgroup barrier, so the inverse ends without one.
@@ -1876,6 +1895,25 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
             const double dtile[4] = {macc[0][0], macc[0][1], macc[0][2], macc[0][3]};
             blk_publish_exponents<NT>(dtile, rowbuf, ws, ln);
         }
+        if constexpr (FROZEN) {
+            if (p.mseg == 0) {
+                double f1 = 0.0, f2 = 0.0;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl)
+                    if (sl < nsw) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            f1 += macc[sl][r];
+                            f2 += (1.0 + 0.37 * (4 * sl + r) + 0.011 * ln) * macc[sl][r];
+                        }
+                    }
+                f1 = row16_sum(f1);
+                f2 = row16_sum(f2);
+                f1 = (rd_lane(f1, 0) + rd_lane(f1, 16)) + (rd_lane(f1, 32) + rd_lane(f1, 48));
+                f2 = (rd_lane(f2, 0) + rd_lane(f2, 16)) + (rd_lane(f2, 32) + rd_lane(f2, 48));
+                if (ln == 0) { fz[2 * ws] = f1; fz[2 * ws + 1] = f2; }
+            }
+        }
         lds_barrier();
         RXHIP_PH(6);   // xi, M' -> S1, exponents, barrier
 #pragma unroll
@@ -1891,6 +1929,119 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
             }
         }
         RXHIP_PH(7);   // symmetrisation reads
+        if constexpr (FROZEN) {
+            if (p.mseg == 0) {
+                double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    g1 += fz[2 * q];
+                    g2 += fz[2 * q + 1];
+                }
+                const bool same = fabs(g1 - fzp1) <= 4.5e-16 * fabs(g1) && fabs(g2 - fzp2) <= 4.5e-16 * fabs(g2);
+                fzp1 = g1;
+                fzp2 = g2;
+                fz_same = same ? fz_same + 1 : 0;
+                if (fz_same >= 2 && i + 1 < len) {   // (the same numbers in every thread of the workgroup)
+                    i_frozen = i + 1;
+                    break;
+                }
+            }
+        }
+    }
+    if constexpr (FROZEN) {
+        if (i_frozen < len) {
+            // The matrices of step i_frozen − 1, from its record (L2): C in the owned tiles, G′ whole; S1 gets C back, S0 −G (M sits in `lam`)
+            const long long tl = t0 + i_frozen - 1;
+            const double* recl = p.filt + (chain * p.T + (tl - 1)) * C::REC;
+            if (tid == 0) p.filt[(chain * p.T + t0) * C::REC + FZ_SLOT] = (double)(tl - 1);
+            double ct[NS][4], gp[NT][4];
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl)
+                if (sl < nsw) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ct[sl][r] = recl[C::HDR + ((w * NT + slot_tile(sl)) * 4 + r) * 64 + lane];
+                }
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) gp[t2][r] = recl[C::HDR + D * D + ((w * NT + t2) * 4 + r) * 64 + lane];
+            const int lq = lane >> 4, lj = lane & 15;
+            lds_barrier();   // the symmetrisation reads of S1 are done
+#pragma unroll
+            for (int sl = 0; sl < NS; ++sl)
+                if (sl < nsw) {
+                    const int tt = slot_tile(sl);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = 16 * ws + lq + 4 * r, col = 16 * tt + lj;
+                        S1[row * LD + col] = ct[sl][r];
+                        S1[col * LD + row] = ct[sl][r];   // the mirror image (a diagonal tile: its own transpose, the same values to rounding)
+                    }
+                }
+            {   // … and −G again: the exponents of the next inverse were published into S0's lines (the scratch of the inverse lives there)
+                Acc<NT> ng;
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ng.v[t2][r] = -gp[t2][r];
+                acc_store_T<NT>(ng, S0, LD, w, lane);
+            }
+            // the determinant factor of a step, and this wave's share of the seeded traces per step
+            double fm = 1.0;
+            long long fe2 = 0;
+            if constexpr (FE) {
+                if (tid == 0) {
+                    fm = lp.mant / fz[8];
+                    fe2 = lp.expo - (long long)fz[9];
+                }
+            }
+            lds_barrier();
+            for (long long i = i_frozen; i < len; ++i) {
+                const long long t = t0 + i;
+                double* rec = p.filt + (chain * p.T + (t - 1)) * C::REC;
+                const double gyc = gyn;
+                if (tid < D) {
+                    rec[tid] = xi[tid];
+                    gyn = p.filt[(chain * p.T + (i + 1 < len ? t + 1 : t)) * C::REC + D + tid];
+                }
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl)
+                    if (sl < nsw) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rec[C::HDR + ((w * NT + slot_tile(sl)) * 4 + r) * 64 + lane] = ct[sl][r];
+                    }
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) rec[C::HDR + D * D + ((w * NT + t2) * 4 + r) * 64 + lane] = gp[t2][r];
+                {
+                    double s0 = 0.0, s1 = 0.0, c0 = 0.0, c1 = 0.0;
+                    const int k0 = grp * (D / 4);
+#pragma unroll
+                    for (int k = 0; k < D / 4; k += 2) {
+                        s0 += S0[(k0 + k) * LD + gi] * xi[k0 + k];
+                        s1 += S0[(k0 + k + 1) * LD + gi] * xi[k0 + k + 1];
+                        c0 += S1[(k0 + k) * LD + gi] * xi[k0 + k];
+                        c1 += S1[(k0 + k + 1) * LD + gi] * xi[k0 + k + 1];
+                    }
+                    xpp[grp * D + gi] = s0 + s1;
+                    cpp[grp * D + gi] = c0 + c1;
+                }
+                lds_barrier();
+                if (tid < D) {
+                    rec[2 * D + tid] = (cpp[tid] + cpp[D + tid]) + (cpp[2 * D + tid] + cpp[3 * D + tid]);
+                    xi[tid] = gyc - ((xpp[tid] + xpp[D + tid]) + (xpp[2 * D + tid] + xpp[3 * D + tid]));
+                }
+                if constexpr (FE) {
+                    if (tid == 0) {
+                        lp.mul(fm);
+                        lp.expo += fe2;
+                    }
+                    seed.a += seed.r;
+                }
+                lds_barrier();
+            }
+        }
     }
     acc_add_mat<NT>(lam, cst_w + c.oW, D, w, lane, -1.0);
     acc_store_tri<NT>(lam, p.vend + (chain * p.S + seg) * C::TRI, w, lane);  // Λ_f at the segment end
@@ -1902,6 +2053,7 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
             seed.x0[271] / len, seed.x0[260] / len, seed.x0[261] / len, seed.x0[262] / len, seed.x0[263] / len, seed.x0[264] / len, seed.x0[265] / len, seed.x0[266] / len, seed.x0[267] / len);
         if (lane == 0 && seg == 100) printf("  wave %d inverse (cycles per step): equilibrate %.0f | before the barrier (publish, own tile inverse; else nothing) %.0f | in the barrier %.0f | after it (trailing update) %.0f | scale back %.0f\n", w,
             seed.x0[272] / len, seed.x0[273] / len, seed.x0[274] / len, seed.x0[275] / len, seed.x0[276] / len);
+        if (tid == 0 && (seg < 40 || seg % 50 == 0)) printf("seg %d: frozen from step %d of %d\n", (int)seg, (int)i_frozen, (int)len);
         if (lane == 0 && (seg % 50 == 0 || seg == 1 || seg == 2 || seg == 3)) printf("seg %d wave %d: seeded %d of %d steps, %.0f cycles per seeded tile inverse, %.0f per exact one\n", (int)seg, w, (int)seed.x0[257], (int)len, seed.x0[258] / fmax(1.0, seed.x0[257]), seed.x0[259] / fmax(1.0, (double)len - seed.x0[257]));
     }
 #endif
@@ -2006,7 +2158,59 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
         if (tid < D) dense_store_mean(p, tprev, chain, tid, ms[tid]);
         dense_store_cov<NT>(p, cc, tprev, chain, w, lane);
     };
+    // BFROZEN (d ≥ 48, one set of constants, no masks): where the forward sweep found its matrices repeating (records tfz … te − 1 hold the same C and G′)
+    // and V_s has stopped moving as well — two functionals of its tiles unchanged to 2 ulp on two steps in a row — a step is the mean recursion and the
+    // stores: m_s(t) = C ξ_f(t) + G m_s(t+1) against the G′ that sits in MG, V_s(t) = the tile row already in registers.
+    constexpr bool BFROZEN = RXHIP_FWD_FROZEN && DenseLds<NT>::ALIAS;
+    long long tfz = te + 1;
+    if constexpr (BFROZEN) {
+        if (p.mseg == 0 && !p.step_model && len > 0) tfz = (long long)p.filt[(chain * p.T + (tb + 1)) * C::REC + C::HDR + (NT * 4) * 64];   // (kd_forward_info: FZ_SLOT)
+    }
+    double* bz = rowbuf + 4 * D;   // [2·w], [2·w + 1]: this wave's functionals of V_s
+    double bzp1 = 0.0, bzp2 = 0.0;
+    int bz_same = 0;
     for (long long t = te - 1; t >= tb; --t) {
+        if constexpr (BFROZEN) {
+            if (bz_same >= 2 && t >= tfz && t > tb) {   // (workgroup-uniform) a frozen stretch: t … max(tfz, tb + 1)
+                const long long tstop = tfz > tb + 1 ? tfz : tb + 1;
+                // MV holds V_s (complete since the barrier that closed the last step), MG the G′ committed for step t, xf = C ξ_f(t)
+                acc_load<NT>(cc, MV, LD, w, lane);
+                if (pending) {
+                    if (tid < D) dense_store_mean(p, tprev, chain, tid, ms[tid]);
+                    dense_store_cov<NT>(p, cc, tprev, chain, w, lane);
+                    pending = false;
+                }
+                double cxn = 0.0;
+                for (; t >= tstop; --t) {
+                    if (tid < D) cxn = p.filt[(chain * p.T + (t - 1)) * C::REC + 2 * D + tid];   // C ξ_f(t − 1) for the next step
+                    {
+                        const int k0 = grp * (D / 4);
+                        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+                        for (int k = 0; k < D / 4; k += 2) {
+                            s0 += MG[(k0 + k) * LD + gi] * ms[k0 + k];
+                            s1 += MG[(k0 + k + 1) * LD + gi] * ms[k0 + k + 1];
+                        }
+                        rowbuf[grp * D + gi] = s0 + s1;
+                    }
+                    lds_barrier();
+                    if (tid < D) {
+                        const double mnew = xf[tid] + ((rowbuf[tid] + rowbuf[D + tid]) + (rowbuf[2 * D + tid] + rowbuf[3 * D + tid]));
+                        ms[tid] = mnew;
+                        xf[tid] = cxn;
+                        dense_store_mean(p, t, chain, tid, mnew);
+                    }
+                    dense_store_cov<NT>(p, cc, t, chain, w, lane);
+                    lds_barrier();
+                }
+                // back to full steps at t = tstop − 1 (≥ tb): its G′ into MG (xf already holds C ξ_f of that step)
+                bz_same = 0;
+                const double* recn = p.filt + (chain * p.T + t) * C::REC;
+                acc_load_full<NT>(gN, recn + C::HDR + D * D, w, lane);
+                acc_store<NT>(gN, MG, LD, w, lane);
+                lds_barrier();
+            }
+        }
         prefetch(t - 1 >= tb ? t - 1 : tb);
         // C_t (owned tiles): the accumulators of the second contraction; their L2 / HBM latency hides under the first one
         d4 vacc[NS];
@@ -2072,9 +2276,42 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
                     if (ts != ws) MV[col * LD + row] = vacc[sl][r];
                 }
             }
+        if constexpr (BFROZEN) {
+            if (tfz <= te) {
+                double f1 = 0.0, f2 = 0.0;
+#pragma unroll
+                for (int sl = 0; sl < NS; ++sl)
+                    if (sl < nsw) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            f1 += vacc[sl][r];
+                            f2 += (1.0 + 0.37 * (4 * sl + r) + 0.011 * lane) * vacc[sl][r];
+                        }
+                    }
+                f1 = row16_sum(f1);
+                f2 = row16_sum(f2);
+                f1 = (rd_lane(f1, 0) + rd_lane(f1, 16)) + (rd_lane(f1, 32) + rd_lane(f1, 48));
+                f2 = (rd_lane(f2, 0) + rd_lane(f2, 16)) + (rd_lane(f2, 32) + rd_lane(f2, 48));
+                if (lane == 0) { bz[2 * ws] = f1; bz[2 * ws + 1] = f2; }
+            }
+        }
         if (tid < D) ms[tid] = mnew;
         commit();
         lds_barrier();
+        if constexpr (BFROZEN) {
+            if (tfz <= te) {
+                double g1 = 0.0, g2 = 0.0;
+#pragma unroll
+                for (int q = 0; q < NT; ++q) {
+                    g1 += bz[2 * q];
+                    g2 += bz[2 * q + 1];
+                }
+                const bool same = fabs(g1 - bzp1) <= 4.5e-16 * fabs(g1) && fabs(g2 - bzp2) <= 4.5e-16 * fabs(g2);
+                bzp1 = g1;
+                bzp2 = g2;
+                bz_same = same ? bz_same + 1 : 0;
+            }
+        }
         pending = true;
         tprev = t;
     }

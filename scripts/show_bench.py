@@ -9,7 +9,7 @@ r = p["roofline_per_chain_models"]
 print("per-chain models ms", round(r["ms_per_step"], 3), "sweep_frac", round(r["sweep_frac"], 3), "| c2_missing ms", round(e["c2_missing"]["ms_per_step"], 3), e["c2_missing"]["parity_spot"]["ok"])
 c3 = e["c3"]
 print("c1 infer ms", round(e["c1"]["infer_ms"], 4), "(engine built per call:", round(e["c1"].get("infer_ms_engine_built_per_call", 0), 4), ")", "| c3 ms", round(c3["ms_per_step"], 4), c3["kernels_ms_avg"], "first touch", round(c3["create_set_data_first_run_ms"], 2),
-      "mfma_frac", round(c3["roofline"]["mfma_frac"], 4), "frac", round(c3["frac"], 4), "hoisted", round((c3.get("hoisted_matrices") or {}).get("ms_per_step", 0), 4))
+      "frac_ref_count", round(c3["frac_ref_count"], 4), "hoisted", round((c3.get("hoisted_matrices") or {}).get("ms_per_step", 0), 4))
 print("c4 ms", round(e["c4"]["ms_per_step"], 3), e["c4"]["roofline"]["frac"], "| c5 ms/it", round(e["c5"]["ms_per_iteration"], 4), e["c5"]["roofline"]["frac"])
 for k, v in e["mid_sizes"].items():
     print(k, "ms", round(v["ms_per_step"], 4), "first touch", round(v["create_set_data_first_run_ms"], 2), "cov on request", round(v["covariances_on_request"]["ms_per_step"], 4), v["parity_spot"]["ok"])
