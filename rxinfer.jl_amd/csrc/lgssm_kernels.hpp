@@ -282,6 +282,10 @@ struct CPtr {
     const double* p;
     __device__ __forceinline__ double operator[](int i) const { return p[i]; }
 };
+struct LdsLanePtr {  // constants parked in LDS, [k][lane of a 64-thread workgroup]
+    const double* p;
+    __device__ __forceinline__ double operator[](int i) const { return p[i * 64]; }
+};
 // When every chain uses the same model the constant block travels BY VALUE in the kernel
 // argument segment: kernarg reads are scalar loads (s_load_*) that in-loop global stores can
 // never alias, and the values feed v_fma_f64 straight from SGPRs.  (Read through the global
@@ -296,8 +300,8 @@ template <bool UNI, int N>
 using CstArgFor = CstArg<UNI ? N : 1>;
 
 // Vp = A V A' + P ; also returns T = A V (needed by the smoother gain)
-template <int D>
-__device__ __forceinline__ void predict_cov(const CPtr A, const CPtr P, const Sym<D>& V, double (&T)[D][D],
+template <int D, class PT = CPtr>
+__device__ __forceinline__ void predict_cov(const CPtr A, const PT P, const Sym<D>& V, double (&T)[D][D],
                                             Sym<D>& Vp) {
 #pragma unroll
     for (int i = 0; i < D; ++i)
@@ -763,13 +767,38 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
     }
 #pragma unroll
     for (int i = 0; i < NS; ++i) V.v[i] = J.v[i] = 0.0;
-    // the ≈50 constants of a step in registers for the whole segment; per-step constants reload them every step
-    double cr[CL::M1];  // A | P | LOBS | G | QI | C0 (the prefix of the block this kernel reads)
+    // the ≈50 constants of a step stay with the lane for the whole segment (per-step constants reload them every step): A and P in registers; at
+    // D = 4 the 10 + 4·DY doubles of Λ_obs and G — each read once per step — in LDS, [k][lane]: the state of the recursion (44 doubles), the
+    // constants and a step's temporaries do not fit 256 registers at two wavefronts per SIMD, and LDS is the cheaper place to spill to
+    constexpr bool CLDS = D == 4;
+    constexpr int LB = !CLDS ? CL::QI : TINV ? CL::P : CL::LOBS;   // first constant kept in LDS (the time-invariant variant parks P there too)
+    __shared__ double cl[CLDS ? (CL::QI - LB + (TINV ? 3 : 0)) * 64 : 1];
+    double cr[LB];  // A (| P | LOBS | G)
     auto load_c = [&](const double* src) {
 #pragma unroll
-        for (int k = 0; k < CL::M1; ++k) cr[k] = src[k];
+        for (int k = 0; k < LB; ++k) cr[k] = src[k];
+        if constexpr (CLDS) {
+#pragma unroll
+            for (int k = 0; k < CL::QI - LB; ++k) cl[k * 64 + threadIdx.x] = src[LB + k];
+        }
     };
+    auto c_lobs = [&](int q) -> double {
+        if constexpr (CLDS) return cl[(CL::LOBS - LB + q) * 64 + threadIdx.x];
+        else return cr[CL::LOBS + q];
+    };
+    auto c_g = [&](int k) -> double {
+        if constexpr (CLDS) return cl[(CL::G - LB + k) * 64 + threadIdx.x];
+        else return cr[CL::G + k];
+    };
+    const auto c_P = [&]() {
+        if constexpr (CLDS && TINV) return LdsLanePtr{cl + threadIdx.x};
+        else return CPtr{cr + CL::P};
+    }();
     load_c(p.cst + (long long)cmdl * CL::SIZE);
+    if constexpr (CLDS && TINV) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) cl[(CL::QI - LB + k) * 64 + threadIdx.x] = 0.0;
+    }
     // Time-invariant models (no masks, no per-step constants): the covariance recursion of the known-start filter reaches its fixed point after
     // the filter's mixing time (≈ 250 of a segment's 782 steps at the BASELINE model) — from there on V, Λp and the gains are CONSTANT, and what
     // still moves is Π ← F Π (F = V Λp A, the closed loop), b, and the two accumulations that are bilinear in Π (they die out with it).  The loop
@@ -789,7 +818,7 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
         double mp[D], T[D][D], Z[D][D];
         Sym<D> Vp, Lp, Lf, Vn;
         matvec_c<D>(CPtr{ct + CL::A}, b, mp);
-        predict_cov<D>(CPtr{ct + CL::A}, CPtr{ct + CL::P}, V, T, Vp);
+        predict_cov<D>(CPtr{ct + CL::A}, c_P, V, T, Vp);
 #pragma unroll
         for (int a = 0; a < D; ++a)
 #pragma unroll
@@ -803,7 +832,7 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
         ok = spd_inv<D>(Vp, Lp, det) && ok;
         const double wgt = miss ? 0.0 : 1.0;
 #pragma unroll
-        for (int q = 0; q < NS; ++q) Lf.v[q] = Lp.v[q] + wgt * ct[CL::LOBS + q];
+        for (int q = 0; q < NS; ++q) Lf.v[q] = Lp.v[q] + wgt * c_lobs(q);
         ok = spd_inv<D>(Lf, Vn, det) && ok;
         double xf[D], bn[D];
         symv<D>(Lp, mp, xf);
@@ -811,7 +840,7 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
         for (int a = 0; a < D; ++a) {
             double acc = xf[a];
 #pragma unroll
-            for (int k = 0; k < DY; ++k) acc += ct[CL::G + a * DY + k] * (miss ? 0.0 : yv[k]);
+            for (int k = 0; k < DY; ++k) acc += c_g(a * DY + k) * (miss ? 0.0 : yv[k]);
             xf[a] = acc;
         }
         symv<D>(Vn, xf, bn);
@@ -844,26 +873,23 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
             for (int k = 0; k < D; ++k) acc += Y[k][a] * db[k];
             eta[a] = acc;
         }
-        // J += Z′ (Y − Λp Π_i)   (symmetric: lower triangle)
-        double R[D][D];
+        // J += Z′ (Y − Λp Π_i)   (symmetric: lower triangle; one row of R = Y − Λp Π_i at a time — the whole of R does not fit the register file)
 #pragma unroll
-        for (int a = 0; a < D; ++a)
+        for (int k = 0; k < D; ++k) {
+            double Rk[D];
 #pragma unroll
             for (int c = 0; c < D; ++c) {
-                double acc = Y[a][c];
+                double acc = Y[k][c];
 #pragma unroll
-                for (int k = 0; k < D; ++k) acc -= Lp(a, k) * Pn[k][c];
-                R[a][c] = acc;
+                for (int q = 0; q < D; ++q) acc -= Lp(k, q) * Pn[q][c];
+                Rk[c] = acc;
             }
 #pragma unroll
-        for (int a = 0; a < D; ++a)
+            for (int a = 0; a < D; ++a)
 #pragma unroll
-            for (int c = 0; c <= a; ++c) {
-                double acc = J(a, c);
-#pragma unroll
-                for (int k = 0; k < D; ++k) acc += Z[k][a] * R[k][c];
-                J(a, c) = acc;
-            }
+                for (int c = 0; c <= a; ++c) J(a, c) += Z[k][a] * Rk[c];
+            if constexpr (D == 4) __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int a = 0; a < D; ++a) {
             b[a] = bn[a];
@@ -881,10 +907,19 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
                 f2 += (1.0 + 0.37 * q) * V.v[q];
                 f3 += (1.0 + 0.21 * q) * J.v[q];   // J stops moving later than V (its increments are quadratic in Π): the tail does not touch it
             }
-            const bool same = fabs(f1 - cf1) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf2) <= 4.5e-16 * fabs(f2) && fabs(f3 - cf3) <= 2.3e-16 * fabs(f3);
-            cf1 = f1;
-            cf2 = f2;
-            cf3 = f3;
+            bool same;
+            if constexpr (CLDS) {   // the previous step's functionals wait in LDS as well: six registers the step does not have
+                double* cf = cl + (CL::QI - LB) * 64 + threadIdx.x;
+                same = fabs(f1 - cf[0]) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf[64]) <= 4.5e-16 * fabs(f2) && fabs(f3 - cf[128]) <= 2.3e-16 * fabs(f3);
+                cf[0] = f1;
+                cf[64] = f2;
+                cf[128] = f3;
+            } else {
+                same = fabs(f1 - cf1) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf2) <= 4.5e-16 * fabs(f2) && fabs(f3 - cf3) <= 2.3e-16 * fabs(f3);
+                cf1 = f1;
+                cf2 = f2;
+                cf3 = f3;
+            }
             nsame = same ? nsame + 1 : 0;
             if (__all(nsame >= 2)) {
                 ++i;

@@ -8,6 +8,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <mutex>
 #include <set>
@@ -525,16 +526,22 @@ static void dense_tables_release(DenseTables* t) {
 
 // ---- arena planning: register every buffer, then one hipMalloc, one upload of the table block, one memset ----
 struct ArenaPlan {
-    struct Item { void** pp; size_t bytes, off; const void* src; bool zero; };
+    struct Item { void** pp; size_t bytes, off; const void* src; bool zero; bool edge; };
     std::vector<Item> up, zr, pl;  // uploaded tables | zero-initialised | plain
-    template <class T> void upload(T** pp, const void* src, size_t bytes) { up.push_back({(void**)pp, bytes, 0, src, false}); }
-    template <class T> void zeroed(T** pp, size_t bytes) { zr.push_back({(void**)pp, bytes, 0, nullptr, true}); }
-    template <class T> void plain(T** pp, size_t bytes) { pl.push_back({(void**)pp, bytes, 0, nullptr, false}); }
+    template <class T> void upload(T** pp, const void* src, size_t bytes) { up.push_back({(void**)pp, bytes, 0, src, false, false}); }
+    template <class T> void zeroed(T** pp, size_t bytes) { zr.push_back({(void**)pp, bytes, 0, nullptr, true, false}); }
+    template <class T> void plain(T** pp, size_t bytes) { pl.push_back({(void**)pp, bytes, 0, nullptr, false, false}); }
+    // the results of a run next to each other: the LAST zero-initialised item and the FIRST plain items (in the order of the calls) are adjacent
+    // in the arena, so one device-to-host copy serves status word, marginals and free energies (rxhip_lgssm_infer)
+    template <class T> void zeroed_last(T** pp, size_t bytes) { zr.push_back({(void**)pp, bytes, 0, nullptr, true, true}); }
+    template <class T> void plain_first(T** pp, size_t bytes) { pl.push_back({(void**)pp, bytes, 0, nullptr, false, true}); }
     static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 };
 static rxhip_status fail(rxhip_engine* e, rxhip_status s, const char* fmt, ...);
 static rxhip_status arena_commit(rxhip_engine* e, ArenaPlan& ap) {
     size_t off = 0;
+    std::stable_partition(ap.zr.begin(), ap.zr.end(), [](const ArenaPlan::Item& it) { return !it.edge; });
+    std::stable_partition(ap.pl.begin(), ap.pl.end(), [](const ArenaPlan::Item& it) { return it.edge; });
     for (auto* grp : {&ap.up, &ap.zr, &ap.pl})
         for (auto& it : *grp) { it.off = off; off += ArenaPlan::al(it.bytes ? it.bytes : 1); }
     const size_t up_end = ap.zr.empty() ? (ap.pl.empty() ? off : ap.pl.front().off) : ap.zr.front().off;
@@ -2449,7 +2456,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
             ap.plain(&e->d_sblk, sizeof(double) * Sg * (size_t)smooth_blocks_per_segment(e->L) * 3 * e->d * e->d);
         }
     }
-    ap.zeroed(&e->d_status, sizeof(int));
+    ap.zeroed_last(&e->d_status, sizeof(int));   // status | mean | cov | fe_chain: one span (rxhip_lgssm_infer reads it back with one copy)
     ap.zeroed(&e->d_fe_part, sizeof(double) * (Sg + 2) * C);   // one slot per segment + the t = 0 update (+ the Wishart slot of a noise engine)
     e->fe_total_cap = 16;
     ap.zeroed(&e->d_fe_total, sizeof(double) * e->fe_total_cap);
@@ -2460,13 +2467,13 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         ap.plain(&e->d_vtab, sizeof(double) * T * ((size_t)e->d * (e->d + 1) / 2));
     } else
         ap.plain(&e->d_filt, sizeof(double) * T * NP2 * 2 * (((C + 63) / 64) * 64));
-    ap.plain(&e->d_mean, sizeof(double) * (size_t)e->Tout() * C * e->d);
-    ap.plain(&e->d_cov, sizeof(double) * (size_t)e->Tout() * C * e->d * e->d);
+    ap.plain_first(&e->d_mean, sizeof(double) * (size_t)e->Tout() * C * e->d);
+    ap.plain_first(&e->d_cov, sizeof(double) * (size_t)e->Tout() * C * e->d * e->d);
+    ap.plain_first(&e->d_fe_chain, sizeof(double) * C);
     ap.plain(&e->d_elem, sizeof(double) * Sg * 2 * e->d * C);
     if (e->sequential && e->S > 1) ap.plain(&e->d_elemx, sizeof(double) * Sg * vt->ex_size * C);
     ap.plain(&e->d_fstart, sizeof(double) * Sg * NP * C);
     ap.plain(&e->d_beta, sizeof(double) * (Sg + 1) * NP * C);
-    ap.plain(&e->d_fe_chain, sizeof(double) * C);
     // observations of small problems live in the arena too (large ones are allocated on first set_data, or never when
     // the caller hands over a device buffer)
     if (sizeof(double) * T * C * e->dy <= ((size_t)64 << 20)) {
@@ -3752,7 +3759,14 @@ rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32
     if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "infer: not a state-space engine");
     const size_t C = (size_t)e->n_chains, ny = (size_t)e->T * C * e->dy, nm = (size_t)e->Tout() * C * e->d, nc = nm * e->d;
     if (n != ny) return fail(e, RXHIP_ERR_BADARG, "infer: expected %zu doubles, got %zu", ny, n);
-    const size_t total = ny + nm + nc + C + 1;
+    // one staging block: y | the span of the results as it lies in the arena (status word | mean | cov | fe per chain, each 256-byte aligned:
+    // ArenaPlan::zeroed_last / plain_first) or, for engines whose results are not adjacent, the same four pieces one after the other
+    const char* const sp0 = reinterpret_cast<const char*>(e->d_status);
+    const bool span = e->in_arena(e->d_status) && e->in_arena(e->d_mean) && e->in_arena(e->d_cov) && e->in_arena(e->d_fe_chain) &&
+                      reinterpret_cast<const char*>(e->d_mean) == sp0 + 256 &&
+                      reinterpret_cast<const char*>(e->d_cov) == reinterpret_cast<const char*>(e->d_mean) + ArenaPlan::al(sizeof(double) * nm) &&
+                      reinterpret_cast<const char*>(e->d_fe_chain) == reinterpret_cast<const char*>(e->d_cov) + ArenaPlan::al(sizeof(double) * nc);
+    const size_t total = ny + nm + nc + C + 1 + (span ? 4 * 32 : 0);
     // Larger problems gain nothing from fewer round trips and lose on the extra pass through the staging block (measured, d = 2:
     // T = 10⁴, 0.65 MB: 0.345 against 0.362 ms; T = 2.5·10⁴, 1.6 MB: 0.93 against 0.53): they take the plain sequence.
     if (sizeof(double) * total > ((size_t)512 << 10) || !e->d_y || !e->own_y) {
@@ -3763,22 +3777,38 @@ rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32
         return st;
     }
     SET_DEVICE(e);
+    if (e->h_io && e->h_io_bytes < sizeof(double) * total) { pinned_release(e->h_io, e->h_io_bytes); e->h_io = nullptr; }
     if (!e->h_io) {
         e->h_io = pinned_acquire(sizeof(double) * total, &e->h_io_bytes);
         if (!e->h_io) return fail(e, RXHIP_ERR_HIP, "infer: pinned staging allocation failed");
     }
-    double *hy = e->h_io, *hm = hy + ny, *hc = hm + nm, *hf = hc + nc;
-    int* hs = reinterpret_cast<int*>(hf + C);
+    double *hy = e->h_io, *hm, *hc, *hf;
+    int* hs;
+    if (span) {
+        char* hsp = reinterpret_cast<char*>(hy + ny);
+        hs = reinterpret_cast<int*>(hsp);
+        hm = reinterpret_cast<double*>(hsp + 256);
+        hc = reinterpret_cast<double*>(hsp + 256 + ArenaPlan::al(sizeof(double) * nm));
+        hf = reinterpret_cast<double*>(hsp + 256 + ArenaPlan::al(sizeof(double) * nm) + ArenaPlan::al(sizeof(double) * nc));
+    } else {
+        hm = hy + ny; hc = hm + nm; hf = hc + nc;
+        hs = reinterpret_cast<int*>(hf + C);
+    }
     std::memcpy(hy, y, sizeof(double) * ny);
     HIPCHK(e, hipMemcpyAsync(e->d_y, hy, sizeof(double) * ny, hipMemcpyHostToDevice, e->stream));
     if (e->d_nu) hipLaunchKernelGGL(k_shift_rows, dim3(2048), dim3(256), 0, e->stream, e->d_y, (const double*)e->d_nu, e->T, e->n_chains, e->dy, -1.0, e->off_chain ? 1 : 0);
     e->have_data = true;
     if (rxhip_status st = run_impl(e, filtering ? 1 : iterations, want_fe, filtering != 0)) return st;
-    if (mean) HIPCHK(e, hipMemcpyAsync(hm, e->d_mean, sizeof(double) * nm, hipMemcpyDeviceToHost, e->stream));
     if (cov) { if (rxhip_status stc = ensure_cov(e)) return stc; }
-    if (cov) HIPCHK(e, hipMemcpyAsync(hc, e->d_cov, sizeof(double) * nc, hipMemcpyDeviceToHost, e->stream));
-    if (fe_per_chain && want_fe) HIPCHK(e, hipMemcpyAsync(hf, e->d_fe_chain, sizeof(double) * C, hipMemcpyDeviceToHost, e->stream));
-    HIPCHK(e, hipMemcpyAsync(hs, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    if (span) {   // everything the caller reads, in one copy (a copy command costs more than its 160 KB: four of them were a tenth of the call)
+        const size_t bytes = (size_t)(reinterpret_cast<const char*>(e->d_fe_chain + C) - sp0);
+        HIPCHK(e, hipMemcpyAsync(hs, e->d_status, bytes, hipMemcpyDeviceToHost, e->stream));
+    } else {
+        if (mean) HIPCHK(e, hipMemcpyAsync(hm, e->d_mean, sizeof(double) * nm, hipMemcpyDeviceToHost, e->stream));
+        if (cov) HIPCHK(e, hipMemcpyAsync(hc, e->d_cov, sizeof(double) * nc, hipMemcpyDeviceToHost, e->stream));
+        if (fe_per_chain && want_fe) HIPCHK(e, hipMemcpyAsync(hf, e->d_fe_chain, sizeof(double) * C, hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(e, hipMemcpyAsync(hs, e->d_status, sizeof(int), hipMemcpyDeviceToHost, e->stream));
+    }
     HIPCHK(e, hipStreamSynchronize(e->stream));  // the one synchronisation of the call
     if (rxhip_status pst = prof_drain(e, true)) return pst;
     if (*hs) {
