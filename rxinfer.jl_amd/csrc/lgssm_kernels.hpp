@@ -782,18 +782,19 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
             for (int k = 0; k < CL::QI - LB; ++k) cl[k * 64 + threadIdx.x] = src[LB + k];
         }
     };
+    int lo = (int)threadIdx.x;   // the lane's column of the LDS block (laundered once per step: see the loop)
     auto c_lobs = [&](int q) -> double {
-        if constexpr (CLDS) return cl[(CL::LOBS - LB + q) * 64 + threadIdx.x];
+        if constexpr (CLDS) return cl[(CL::LOBS - LB + q) * 64 + lo];
         else return cr[CL::LOBS + q];
     };
     auto c_g = [&](int k) -> double {
-        if constexpr (CLDS) return cl[(CL::G - LB + k) * 64 + threadIdx.x];
+        if constexpr (CLDS) return cl[(CL::G - LB + k) * 64 + lo];
         else return cr[CL::G + k];
     };
-    const auto c_P = [&]() {
-        if constexpr (CLDS && TINV) return LdsLanePtr{cl + threadIdx.x};
+    auto c_P = [&]() {
+        if constexpr (CLDS && LB == CL::P) return LdsLanePtr{cl + lo};
         else return CPtr{cr + CL::P};
-    }();
+    };
     load_c(p.cst + (long long)cmdl * CL::SIZE);
     if constexpr (CLDS && TINV) {
 #pragma unroll
@@ -808,8 +809,11 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
     double cf1 = 0.0, cf2 = 0.0, cf3 = 0.0;
     int nsame = 0;
     long long i = 0;
-    for (; i < len; ++i) {
+    bool go = true;   // TINV: until the fixed point (the step that finds it is counted: the tail starts behind it)
+    for (; i < len && go; ++i) {
         const long long t = t0 + i;
+        // (without this the compiler reads the next step's G out of LDS at the end of this one — and spills it over the back edge)
+        if constexpr (CLDS && TINV) asm volatile("" : "+v"(lo));
         if (!TINV && p.step_model) load_c(p.cst + (long long)p.step_model[t] * CL::SIZE);
         const double* ct = cr;
         double yv[DY];
@@ -818,7 +822,7 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
         double mp[D], T[D][D], Z[D][D];
         Sym<D> Vp, Lp, Lf, Vn;
         matvec_c<D>(CPtr{ct + CL::A}, b, mp);
-        predict_cov<D>(CPtr{ct + CL::A}, c_P, V, T, Vp);
+        predict_cov<D>(CPtr{ct + CL::A}, c_P(), V, T, Vp);
 #pragma unroll
         for (int a = 0; a < D; ++a)
 #pragma unroll
@@ -836,6 +840,8 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
         ok = spd_inv<D>(Lf, Vn, det) && ok;
         double xf[D], bn[D];
         symv<D>(Lp, mp, xf);
+        // (G is read HERE, behind Λp·mp: read at the top of the step with the other constants it waits in scratch for this line)
+        if constexpr (CLDS && TINV) asm volatile("" : "+v"(lo), "+v"(xf[0]));
 #pragma unroll
         for (int a = 0; a < D; ++a) {
             double acc = xf[a];
@@ -909,8 +915,9 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
             }
             bool same;
             if constexpr (CLDS) {   // the previous step's functionals wait in LDS as well: six registers the step does not have
-                double* cf = cl + (CL::QI - LB) * 64 + threadIdx.x;
-                same = fabs(f1 - cf[0]) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf[64]) <= 4.5e-16 * fabs(f2) && fabs(f3 - cf[128]) <= 2.3e-16 * fabs(f3);
+                double* cf = cl + (CL::QI - LB) * 64 + lo;
+                const double g1 = cf[0], g2 = cf[64], g3 = cf[128];   // (no short circuit: three reads, no branches)
+                same = (int)(fabs(f1 - g1) <= 4.5e-16 * fabs(f1)) & (int)(fabs(f2 - g2) <= 4.5e-16 * fabs(f2)) & (int)(fabs(f3 - g3) <= 2.3e-16 * fabs(f3));
                 cf[0] = f1;
                 cf[64] = f2;
                 cf[128] = f3;
@@ -921,20 +928,19 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
                 cf3 = f3;
             }
             nsame = same ? nsame + 1 : 0;
-            if (__all(nsame >= 2)) {
-                ++i;
-                break;
-            }
+            go = !__all(nsame >= 2);
         }
     }
     if constexpr (TINV) p.fstart[(seg * Dim<D>::NP) * p.n_chains + chain] = (double)i;   // where the tail kernel takes over (the scan overwrites the slot later)
     double* o = p.elem + (seg * 2 * D) * p.n_chains + chain;
+    asm volatile("" : "+v"(o));
 #pragma unroll
     for (int a = 0; a < D; ++a) {
         o[a * p.n_chains] = b[a];
         o[(D + a) * p.n_chains] = eta[a];
     }
     double* x = p.elemx + (seg * EX::SIZE) * p.n_chains + chain;
+    asm volatile("" : "+v"(x));   // (the 36 addresses below are formed here, not hoisted above the loop)
 #pragma unroll
     for (int a = 0; a < D; ++a)
 #pragma unroll
@@ -1083,6 +1089,8 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements_tail(Params p) {
             for (int a = 0; a < D; ++a) b[a] = bn[a];
         }
     }
+    // (the addresses are formed again here: kept from the loads above, the 24 of them would sit in 48 registers through the whole loop)
+    asm volatile("" : "+v"(o), "+v"(x));
 #pragma unroll
     for (int a = 0; a < D; ++a) {
         o[a * p.n_chains] = b[a];
