@@ -288,6 +288,23 @@ def test_one_round_trip_inference_equals_the_plain_sequence():
         assert np.array_equal(m1, m2) and np.array_equal(c1, c2) and np.array_equal(f1, f2) and np.array_equal(m3, m2)
 
 
+def test_one_round_trip_inference_on_engines_whose_results_are_not_one_span():
+    """rxhip_lgssm_infer reads status | mean | cov | free energy back with ONE copy where the arena holds them next to each other (d ≤ 4:
+    the test above); the MFMA path's engines keep them apart and take the four copies — same numbers as the plain sequence there too."""
+    for d, dy, T, C in ((8, 3, 60, 2), (20, 5, 40, 1)):
+        mdl = workloads.random_model(d, dy, seed=3 * d)
+        y = workloads.generate_batch(mdl, T, C, seed0=d)
+        with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=C) as eng:
+            m1, c1, f1 = eng.infer(y, free_energy=True)
+            eng.set_data(y)
+            eng.run(1, True)
+            m2, c2 = eng.marginals()
+            f2 = eng.free_energy_per_chain()
+            m3, c3, _ = eng.infer(y, free_energy=False)
+        assert np.array_equal(m1, m2) and np.array_equal(c1, c2) and np.array_equal(f1, f2)
+        assert np.array_equal(m3, m2) and np.array_equal(c3, c2)
+
+
 def test_model_tables_timing_entry_point(monkeypatch):
     """rxhip_get_model_tables_ms: device time of what an engine computes once because it depends on the model only — positive for
     a shared-model batch on the one-pass schedule, zero for an engine without such tables; the sweep results do not depend on
