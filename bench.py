@@ -349,7 +349,7 @@ def extra_c3(device, parity=True):
     tf = lambda flop, t_ms: flop / (t_ms * 1e-3) / 1e12
     fwd_ms, bwd_ms = kt.get("k_forward", 0.0), kt.get("k_backward", 0.0)
     # Since round 4 the sweep kernels leave the matrix work of a segment once its matrices repeat (every step's C, G', M and V_s equal the previous
-    # step's to 2 ulp: interior segments after three steps) — the counts above are per FULL step, and most steps of this chain are not full any more.
+    # step's to 2 ulp: interior segments after two steps) — the counts above are per FULL step, and most steps of this chain are not full any more.
     # What the line can state honestly: the reference-equivalent rate (SURVEY's 18 d^3 per step over the sweep time), and the matrix-pipe figure of
     # the full steps from the counters (profiles/r04/pmc_c3.txt: 0.47 of peak inside the steps that still execute products).  `mfma_frac` is therefore
     # null; a kernel that finishes sooner by executing fewer products has no business quoting a higher utilisation.
@@ -357,7 +357,8 @@ def extra_c3(device, parity=True):
             "achieved": tf(ref_flop, ms), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (reference-equivalent: 18 d^3 per step)",
             "frac": tf(ref_flop, ms) / FP64_PEAK_TFLOPS, "mfma_frac": None,
             "full_step_mfma": mfma_step,
-            "note": "frac = reference-schedule flops over the sweep time; executed MFMA work is no longer T x the per-step counts (repeating segments skip it): "
+            "note": "frac = reference-schedule flops over the sweep time — a rate of WORK DONE FOR THE USER, not a utilisation (it can pass 1: the kernels skip "
+                    "products whose result repeats); executed MFMA work is no longer T x the per-step counts: "
                     "matrix-pipe utilisation inside full steps 0.47 by the counters, profiles/r04/pmc_c3.txt"}
     return {"workload": "LGSSM d=64 dy=64 T=10000, 1 chain, 1 BP sweep + Bethe free energy per step", "ms_per_step": ms,
             "kernels_ms_avg": kt, "tflops_ref_count": tf(ref_flop, ms), "ref_flop_per_sweep": ref_flop,

@@ -842,6 +842,9 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
 #ifndef RXHIP_FWD_FROZEN
 #define RXHIP_FWD_FROZEN 1
 #endif
+#ifndef RXHIP_FZ_CONFIRM
+#define RXHIP_FZ_CONFIRM 1   // consecutive steps on which the functionals of the recursion's matrix must repeat before a segment leaves the matrix work
+#endif
 
 template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true, class SEED = NoSeed>
 __device__ __forceinline__ bool spd_inverse(Acc<NT>& a, double* scratch, int w, int lane, LogProd& lp, PF prefetch = PF(), SEED* seed = nullptr) {
@@ -1941,7 +1944,7 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
                 fzp1 = g1;
                 fzp2 = g2;
                 fz_same = same ? fz_same + 1 : 0;
-                if (fz_same >= 2 && i + 1 < len) {   // (the same numbers in every thread of the workgroup)
+                if (fz_same >= RXHIP_FZ_CONFIRM && i + 1 < len) {   // (the same numbers in every thread of the workgroup)
                     i_frozen = i + 1;
                     break;
                 }
@@ -2171,7 +2174,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
     int bz_same = 0;
     for (long long t = te - 1; t >= tb; --t) {
         if constexpr (BFROZEN) {
-            if (bz_same >= 2 && t >= tfz && t > tb) {   // (workgroup-uniform) a frozen stretch: t … max(tfz, tb + 1)
+            if (bz_same >= RXHIP_FZ_CONFIRM && t >= tfz && t > tb) {   // (workgroup-uniform) a frozen stretch: t … max(tfz, tb + 1)
                 const long long tstop = tfz > tb + 1 ? tfz : tb + 1;
                 // MV holds V_s (complete since the barrier that closed the last step), MG the G′ committed for step t, xf = C ξ_f(t)
                 acc_load<NT>(cc, MV, LD, w, lane);

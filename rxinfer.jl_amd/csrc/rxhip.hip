@@ -2102,11 +2102,12 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
     // kernels are latency-bound, so
     // more resident workgroups pay until the per-segment prologue dominates (measured, scripts/time_mid_dims.py:
     // d = 16, 512 chains, T = 1000: 4.27 ms with 2 workgroups per CU, 2.22 ms with 48; d = 32, 128 chains: 4.86 -> 3.02 ms).
-    // d ≥ 48: two workgroups fit a CU; a time-invariant chain gets three workgroups' worth of segments, because most of them leave the sweep kernels
-    // after a few steps (their matrices repeat: kd_forward_info FROZEN) and the sweep is as long as the segments that do not — measured at C3:
-    // 0.670 ms with 500 segments, 0.612 with 715, 0.626 with 1000 (scripts/gpu_r04_segs.sh)
+    // d ≥ 48: two workgroups fit a CU; a time-invariant chain gets four workgroups' worth of segments, because most of them leave the sweep kernels
+    // after two or three steps (their matrices repeat: kd_forward_info FROZEN) and the sweep is as long as the segments that do not — measured at C3
+    // (scripts/time_c3_clean.py, C3_SEGMENTS): 0.578 ms with 715 segments, 0.553 with 909, 0.547 – 0.557 with 1000, 0.559 with 1111, 0.605 with 1429
+    // (with three repeats required before a segment leaves: 0.670 with 500, 0.612 with 715, 0.626 with 1000)
     const bool dense_frozen = dense && e->nt >= 3 && e->uniform && !e->masked && ds->step_model == nullptr && !e->gseq;
-    const int dense_wg_per_cu = !dense ? 0 : e->nt == 1 ? 48 : e->nt == 2 ? 8 : dense_frozen ? 3 : 2;
+    const int dense_wg_per_cu = !dense ? 0 : e->nt == 1 ? 48 : e->nt == 2 ? 8 : dense_frozen ? 4 : 2;
     const long long steps = e->T - 1;  // transitions
     bool small_short = false;
     if (steps <= 0) {

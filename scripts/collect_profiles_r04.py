@@ -20,7 +20,7 @@ def derive(name):
     return (f"# {name}: {mf:.4g} MFMA per launch = {mf / 1e4:.0f} per time step and workgroup; x 2048 flop / {ns / 1e6:.3f} ms = {tf:.1f} TF/s = {tf / 78.6:.3f} of the fp64 peak "
             f"(under the profiler; bench.py's event time is shorter); SQ_WAIT_ANY {wa / wc:.2f} of the wave cycles; other VALU per MFMA {(valu - mf) / mf:.2f}; "
             f"LDS bank conflicts {lbc / lia:.2f} of the LDS-active cycles")
-hdr = [f"# scripts/profile_r04.sh {tag}: the C3 sweep kernels of the shipped library (d = dy = 64, T = 10^4, one chain; S = 715 x L = 14: three workgroups' worth of segments per CU, two resident) under",
+hdr = [f"# scripts/profile_r04.sh {tag}: the C3 sweep kernels of the shipped library (d = dy = 64, T = 10^4, one chain; S = 1000 x L = 10: four workgroups' worth of segments per CU, two resident) under",
        "# rocprofv3 --pmc (three separate passes) on scripts/prof_driver.py --config c3, averages per dispatch over the timed steps; kd_forward_info with its pivot-tile",
        "# inverses seeded by the previous time step.  SQ_WAVE_CYCLES / SQ_ACTIVE_* / SQ_WAIT_* in units of 4 cycles; SQ_VALU_MFMA_BUSY_CYCLES in cycles (= 64 x SQ_INSTS_VALU_MFMA_F64).",
        "# Round-3 kernel for comparison (the first r04 pass): kd_forward_info 7.199e6 MFMA (720 per step), 3.51e7 VALU instructions of which 5.64e6 FMA_F64 (the Cramer solves of the",
