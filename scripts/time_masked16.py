@@ -9,7 +9,7 @@ m = workloads.random_model(d, dy, seed=d)
 y = np.tile(workloads.generate_batch(m, T, 8, seed0=1), (1, C // 8, 1))
 ym = y.copy(); ym[np.random.default_rng(0).random((T, C)) < 0.1] = np.nan
 args = (m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"])
-for seg in (0, 1, 2, 4, 8):
+for seg in tuple(int(s) for s in os.environ.get("M16_SEGMENTS", "0,1,2,4,8").split(",")):
     with rxhip.LGSSMEngine(*args, T=T, n_chains=C, allow_missing=True, segments=seg) as eng:
         eng.set_data(ym)
         for _ in range(3): eng.run_async(1, True)

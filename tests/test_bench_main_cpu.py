@@ -124,3 +124,38 @@ def test_strong_scaling_needs_divisible_chains():
     finally:
         for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
             os.environ.pop(k, None)
+
+
+def test_timed_sweeps_takes_the_better_repeat_for_time_and_for_every_kernel():
+    """The extra lines of bench.py time `repeats` identical measurements and keep the better one — the sweep time AND, since a stalled queue sits
+    inside one kernel's event pair, every kernel of the instrumented pass (no GPU: an engine stub that plays back scripted kernel times)."""
+    sys.path.insert(0, ROOT)
+    import bench
+
+    class Eng:
+        passes = [{"k_forward": 3.7, "k_backward": 0.23}, {"k_forward": 0.27, "k_backward": 0.25}]
+
+        def __init__(self):
+            self.n, self.prof, self.k = 0, False, -1
+
+        def run_async(self, iterations, fe):
+            self.n += 1
+
+        def sync(self):
+            pass
+
+        def set_profiling(self, on):
+            self.prof = on
+
+        def reset_kernel_times(self):
+            self.k += 1
+
+        def kernel_times(self):
+            out = {name: {"ms_avg": ms, "launches": 5} for name, ms in self.passes[self.k].items()}
+            out["k_unused"] = {"ms_avg": 0.0, "launches": 0}
+            return out
+
+    e = Eng()
+    ms, kt = bench.timed_sweeps(e, steps=5, warmup=2, repeats=2)
+    assert kt == {"k_forward": 0.27, "k_backward": 0.23} and ms >= 0.0
+    assert e.n == 2 + 2 * 5 + 2 * 5 and e.prof is False
