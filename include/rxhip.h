@@ -57,6 +57,25 @@ extern "C" {
  *                               masked schedule: kind of the boundary recursion (default: the cheaper one by a cost model)
  *     RXHIP_MSEG_MAX_BYTES=n    masked schedule: cap on its record block (an engine that exceeds it stays on the sequential schedule)
  *     RXHIP_WAVE8=0             masked schedule, one segment per chain, d <= 8: the MFMA sweep kernels instead of the in-wave ones
+ *     RXHIP_NO_FROZEN=1         MFMA path, time-invariant models at d >= 48: every step of the sweeps in full (no FROZEN / BFROZEN stretches, below)
+ *
+ * Fixed-point exits (time-invariant models only: one set of constants per chain, no `missing`, no per-step constants).  The covariance
+ * recursions of such a chain — forward Riccati, backward smoother — converge geometrically, and the sweeps stop RECOMPUTING a recursion's
+ * matrices once they repeat; the means are always computed step by step.  "Repeat" is decided on the device, per chain or per segment:
+ *   d, dy <= 4 (k_seg_elements, k_boundary_scan, k_forward_tinv): two weighted sums of the matrix's entries, each entry first scaled by the exact
+ *     power of two 2^-floor((e_i + e_j)/2) (e_i: binary exponent of the diagonal entry i, so every scaled entry is O(1) whatever the units of
+ *     the state's components), unchanged to 2 ulp on two consecutive steps in every lane of the wavefront;
+ *   d >= 48 forward (kd_forward_info): in EVERY lane of the workgroup two weighted sums of the lane's 16 entries of the information matrix as
+ *     equilibrated for the inverse (the same power-of-two scaling), unchanged to 2 ulp, and two sums over all tiles, on two consecutive steps;
+ *   d >= 48 backward (kd_backward_info): two sums over the tiles of V_s unchanged to 2 ulp, then V_s(t) against V_s(t+1) entry by entry,
+ *     |dV_ij| <= 1.5e-14 sqrt(V_ii V_jj).
+ * Bound: a per-step change of an entry above ~5e-14 sqrt(M_ii M_jj) keeps the full recursion running (d <= 4 and the forward test: unless the
+ * other entries of the same sum cancel it in both sums — two linear conditions on the direction of a converging iteration); with a contraction
+ * rate rho of the recursion (its closed-loop spectral radius squared) what is frozen is within ~5e-14 / (1 - rho) sqrt(M_ii M_jj) of the fixed
+ * point, entry by entry — 1e-8 of the entry's scale at rho = 1 - 5e-6, a mixing time of 2e5 steps.  Recursions that slow do not repeat to 2 ulp
+ * inside a supported chain length and are simply computed in full.  tests/test_fixed_point_adversarial_gpu.py holds the sweeps to the contract
+ * (1e-6 / 1e-8 against the CPU oracle, 1e-7 against the full recursion) on block models six decades apart with a slowly mixing small block and on
+ * near-unit-root states; RXHIP_ELEM_FULL / RXHIP_NO_FROZEN switch the exits off.
  * ------------------------------------------------------------------------------------------ */
 typedef struct rxhip_engine rxhip_engine;
 typedef int32_t rxhip_status;

@@ -136,6 +136,7 @@ struct DenseParams {
     long long oW_off;     // DenseCst::oW (km_filter_out reads the constant block through MsegParams)
     long long chain0;     // first workgroup chain of this launch: a grid dimension holds 65 535 blocks, larger batches are launched in slices
     int wave8;            // masked schedule, one segment per chain, d ≤ 8: the sweep inside one wavefront per chain (dense8_kernels.hpp)
+    int no_frozen;        // test hook RXHIP_NO_FROZEN=1: kd_forward_info / kd_backward_info take every step in full (no FROZEN / BFROZEN stretches)
 };
 struct DenseModel {
     const double *cst, *tab, *scanm, *qtab;
@@ -843,7 +844,10 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
 #define RXHIP_FWD_FROZEN 1
 #endif
 #ifndef RXHIP_FZ_CONFIRM
-#define RXHIP_FZ_CONFIRM 1   // consecutive steps on which the functionals of the recursion's matrix must repeat before a segment leaves the matrix work
+#define RXHIP_FZ_CONFIRM 2   // consecutive steps on which the tests of the recursion's matrix (below) must pass before a segment leaves the matrix work
+#endif
+#ifndef RXHIP_FZ_TOL
+#define RXHIP_FZ_TOL 1.5e-14 // kd_backward_info, the verification step: |V_s(t) − V_s(t+1)|_ij ≤ TOL · sqrt(V_ii V_jj) (64 ulp on the entry's own scale)
 #endif
 
 template <int NT, class PF = NoPrefetch, bool FINAL = true, bool PUB = true, class SEED = NoSeed>
@@ -1755,16 +1759,24 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
 #ifdef RXHIP_TEST_SEEDCOUNT
     long long tph_ = __builtin_readcyclecounter();
 #endif
-    // FROZEN (one set of constants, no masks): once M_{t+1} = M_t to rounding — two linear functionals of its tiles unchanged to 2 ulp on two
-    // steps in a row — every matrix of a step repeats (C, G′, M, the determinants), and the rest of the segment is the loop behind this one:
-    // vectors and record stores only.  Interior segments start on the fixed point (boundary table) and leave after three steps.
+    // FROZEN (one set of constants, no masks): once M_{t+1} = M_t to rounding every matrix of a step repeats (C, G′, M, the determinants), and the
+    // rest of the segment is the loop behind this one: vectors and record stores only.  Two tests, both on RXHIP_FZ_CONFIRM steps in a row:
+    //  (a) at the top of a step each LANE forms two weighted sums of its 4·NT entries of M_t as the inverse is about to see them — equilibrated by
+    //      the exact powers of two of M's diagonal, M_ij · 2^(h_i + h_j) with |·| ≲ 2 whatever the scales of the state's components — and compares
+    //      them with its own sums of the step before: unchanged to 2 ulp in EVERY lane of the workgroup (256 pairs of functionals over 16 entries
+    //      each: an entry that still moves by more than ≈ 5e-14 · sqrt(M_ii M_jj) per step is seen unless the other 15 entries of its lane cancel
+    //      it in both sums);
+    //  (b) at the end of the step two plain sums over the tiles of M_{t+1} unchanged to 2 ulp (rounds 3–4's only test: it sees what moves the
+    //      largest entries, and nothing else — tests/test_fixed_point_adversarial_gpu.py; kept because it is the later of the two pairs).
+    // At a contraction rate ρ of the recursion a frozen entry is within ≈ 5e-14 / (1 − ρ) · sqrt(M_ii M_jj) of its fixed point (include/rxhip.h
+    // "Fixed-point exits").  Interior segments start on the fixed point (boundary table) and leave after four steps.
     constexpr bool FROZEN = RXHIP_FWD_FROZEN && SEEDED;
     // for the backward sweep: the first time index of this segment whose record holds the repeated matrices (default: beyond the segment) — in a
     // slot of the segment's first record that nothing else touches: tile (1, 0) of C, which no wave owns in the symmetric pairing (NT ≥ 3)
     constexpr int FZ_SLOT = C::HDR + (NT * 4) * 64;
     if (FROZEN && tid == 0 && p.mseg == 0 && len > 0) p.filt[(chain * p.T + t0) * C::REC + FZ_SLOT] = (double)(t0 + len);
     double* fz = cpp + 4 * dm + DenseLds<NT>::FWD_TAIL - DenseLds<NT>::FWD_FROZEN;   // [2·w], [2·w + 1]: this wave's functionals; [8], [9]: lp in front of the inverse
-    double fzp1 = 0.0, fzp2 = 0.0;
+    double fzp1 = 0.0, fzp2 = 0.0, lzp1 = 0.0, lzp2 = 0.0;
     int fz_same = 0;
     long long i_frozen = len;
     for (long long i = 0; i < len; ++i) {
@@ -1782,6 +1794,26 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
         }
         if constexpr (FROZEN && FE) {
             if (tid == 0) { fz[8] = lp.mant; fz[9] = (double)lp.expo; }   // the step's determinant factor = what the inverse below multiplies in
+        }
+        if constexpr (FROZEN) {
+            if (p.mseg == 0) {   // test (a): the exponents of M_t's diagonal were published for the inverse below (natural order | row q + 4r at 4q + r)
+                const int* sc = reinterpret_cast<const int*>(rowbuf + 2 * blk_half_doubles(NT));
+                const int4 hr = *reinterpret_cast<const int4*>(sc + 16 * NT + 16 * ws + 4 * (lane >> 4));
+                double f1 = 0.0, f2 = 0.0;
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) {
+                    const int hc = sc[16 * t2 + (lane & 15)];
+                    const double s0 = __builtin_ldexp(lam.v[t2][0], hr.x + hc), s1 = __builtin_ldexp(lam.v[t2][1], hr.y + hc),
+                                 s2 = __builtin_ldexp(lam.v[t2][2], hr.z + hc), s3 = __builtin_ldexp(lam.v[t2][3], hr.w + hc);
+                    f1 += (s0 + s1) + (s2 + s3);
+                    f2 = fma(fma(fma(fma(f2, 1.37, s0), 1.37, s1), 1.37, s2), 1.37, s3);   // weights 1.37^k: ONE constant in a register, not sixteen
+                }
+                const bool lane_same = fabs(f1 - lzp1) <= 4.5e-16 * fabs(f1) && fabs(f2 - lzp2) <= 4.5e-16 * fabs(f2);
+                lzp1 = f1;
+                lzp2 = f2;
+                const bool wave_same = __all(lane_same) != 0;
+                if (lane == 0) fz[10 + ws] = wave_same ? 1.0 : 0.0;   // read at the end of the step (an invalid exponent gives inf / NaN: never "same")
+            }
         }
         // C = (Λ_f + A'P⁻¹A)⁻¹.  The inverse's scratch is S0 (or its own carve): the next writer of S0 is the store of −G below,
         // behind a workgroup barrier, so the inverse ends without one.
@@ -1940,7 +1972,7 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
                     g1 += fz[2 * q];
                     g2 += fz[2 * q + 1];
                 }
-                const bool same = fabs(g1 - fzp1) <= 4.5e-16 * fabs(g1) && fabs(g2 - fzp2) <= 4.5e-16 * fabs(g2);
+                const bool same = fabs(g1 - fzp1) <= 4.5e-16 * fabs(g1) && fabs(g2 - fzp2) <= 4.5e-16 * fabs(g2) && (fz[10] + fz[11]) + (fz[12] + fz[13]) == (double)NT && !p.no_frozen;
                 fzp1 = g1;
                 fzp2 = g2;
                 fz_same = same ? fz_same + 1 : 0;
@@ -2162,8 +2194,11 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
         dense_store_cov<NT>(p, cc, tprev, chain, w, lane);
     };
     // BFROZEN (d ≥ 48, one set of constants, no masks): where the forward sweep found its matrices repeating (records tfz … te − 1 hold the same C and G′)
-    // and V_s has stopped moving as well — two functionals of its tiles unchanged to 2 ulp on two steps in a row — a step is the mean recursion and the
-    // stores: m_s(t) = C ξ_f(t) + G m_s(t+1) against the G′ that sits in MG, V_s(t) = the tile row already in registers.
+    // and V_s has stopped moving as well, a step is the mean recursion and the stores: m_s(t) = C ξ_f(t) + G m_s(t+1) against the G′ that sits in MG,
+    // V_s(t) = the tile row already in registers.  "Stopped moving" has two stages: two functionals of V_s's tiles unchanged to 2 ulp (every step; a
+    // filter — plain sums see only what moves the largest entries), then on the following step V_s(t) against V_s(t + 1) ENTRY BY ENTRY,
+    // |ΔV_ij| ≤ RXHIP_FZ_TOL · sqrt(V_ii V_jj): the new matrix from MV, the old one from the posterior array, where this very lane stored these entries
+    // at the top of the step.  One failing entry in any wave and the sweep goes on in full steps.
     constexpr bool BFROZEN = RXHIP_FWD_FROZEN && DenseLds<NT>::ALIAS;
     long long tfz = te + 1;
     if constexpr (BFROZEN) {
@@ -2172,9 +2207,11 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
     double* bz = rowbuf + 4 * D;   // [2·w], [2·w + 1]: this wave's functionals of V_s
     double bzp1 = 0.0, bzp2 = 0.0;
     int bz_same = 0;
+    bool bz_verify = false, bz_ok = false;   // (workgroup-uniform) this step ends with the entrywise comparison / it has passed
+    if (p.no_frozen) tfz = te + 1;
     for (long long t = te - 1; t >= tb; --t) {
         if constexpr (BFROZEN) {
-            if (bz_same >= RXHIP_FZ_CONFIRM && t >= tfz && t > tb) {   // (workgroup-uniform) a frozen stretch: t … max(tfz, tb + 1)
+            if (bz_ok && t >= tfz && t > tb) {   // (workgroup-uniform) a frozen stretch: t … max(tfz, tb + 1)
                 const long long tstop = tfz > tb + 1 ? tfz : tb + 1;
                 // MV holds V_s (complete since the barrier that closed the last step), MG the G′ committed for step t, xf = C ξ_f(t)
                 acc_load<NT>(cc, MV, LD, w, lane);
@@ -2208,6 +2245,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
                 }
                 // back to full steps at t = tstop − 1 (≥ tb): its G′ into MG (xf already holds C ξ_f of that step)
                 bz_same = 0;
+                bz_ok = bz_verify = false;
                 const double* recn = p.filt + (chain * p.T + t) * C::REC;
                 acc_load_full<NT>(gN, recn + C::HDR + D * D, w, lane);
                 acc_store<NT>(gN, MG, LD, w, lane);
@@ -2313,6 +2351,31 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
                 bzp1 = g1;
                 bzp2 = g2;
                 bz_same = same ? bz_same + 1 : 0;
+                bz_ok = false;
+                if (bz_verify) {
+                    // MV holds V_s(t) whole (the barrier above); the posterior array holds V_s(t + 1): entry (16w + lane/16 + 4r, 16·t2 + lane%16) was
+                    // stored by this lane (flush_posterior at the top of the step).  Padding dimensions (≥ d_out) are decoupled constants.
+                    const double* vold = p.cov + (tprev * p.n_chains + chain) * ((size_t)p.d_out * p.d_out);
+                    bool bad = false;
+#pragma unroll 1
+                    for (int k = 0; k < 4 * NT; ++k) {   // rolled, no register arrays: once or twice per segment, and the steps have no register to give
+                        const int row = acc_row<NT>(w, lane, k & 3), col = acc_col<NT>(lane, k >> 2);
+                        if (row < p.d_out && col < p.d_out) {
+                            const double sc = sqrt(fabs(MV[row * LD + row] * MV[col * LD + col]));
+                            bad = bad || !(fabs(MV[row * LD + col] - vold[(size_t)row * p.d_out + col]) <= RXHIP_FZ_TOL * sc);
+                        }
+                    }
+                    const bool wave_bad = __any(bad) != 0;
+                    if (lane == 0) bz[8 + ws] = wave_bad ? 1.0 : 0.0;
+                    lds_barrier();
+                    double nbad = 0.0;
+#pragma unroll
+                    for (int q = 0; q < NT; ++q) nbad += bz[8 + q];
+                    bz_verify = false;
+                    bz_ok = same && nbad == 0.0;
+                    if (!bz_ok) bz_same = 0;
+                } else if (bz_same >= RXHIP_FZ_CONFIRM - 1)
+                    bz_verify = true;
             }
         }
         pending = true;

@@ -48,6 +48,21 @@ __device__ __forceinline__ void lds_barrier() {
 // finiteness from the bit pattern (x − x == 0 is not safe under -ffp-contract=fast when x is a product)
 __device__ __forceinline__ bool is_finite(double x) { return (__double2hiint(x) & 0x7ff00000) != 0x7ff00000; }
 
+// the 16-byte posterior stores of the table-driven smoother (written once, never read again by the sweep).  RXHIP_NT_STORES=1 issues them
+// with the non-temporal hint (`global_store_dwordx4 … nt`): an A/B switch — the plain store is what ships, see DESIGN §6f for the measurement
+#ifndef RXHIP_NT_STORES
+#define RXHIP_NT_STORES 0
+#endif
+typedef double rx_d2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void stream_store(double2* p, double a, double b) {
+#if RXHIP_NT_STORES
+    rx_d2v v = {a, b};
+    __builtin_nontemporal_store(v, reinterpret_cast<rx_d2v*>(p));
+#else
+    *p = make_double2(a, b);
+#endif
+}
+
 template <int D>
 struct Dim {
     static constexpr int NS = D * (D + 1) / 2;  // packed symmetric size
@@ -266,6 +281,29 @@ __device__ __forceinline__ bool spd_inv(const Sym<D>& a, Sym<D>& out, double& de
 }
 
 // y = S x  (S symmetric packed)
+// Scale-free linear functionals of a symmetric matrix, for the fixed-point exits of the time-invariant recursions (k_seg_elements<TINV>,
+// k_boundary_scan<TS>, k_forward_tinv).  Every entry is first scaled by an EXACT power of two, S_ij = M_ij · 2^−⌊(e_i + e_j)/2⌋ with e_i the binary
+// exponent of |M_ii| — the entry on the scale of its own row and column, |S_ij| ≤ 2 for a definite matrix — and the functionals are weighted sums
+// of the S_ij.  A test "f unchanged to 2 ulp" then sees a change of ANY entry above ≈ 1e-14 · sqrt(M_ii M_jj), however many decades lie between
+// the state's components (the plain sums of rounds 3–4 saw only what moved the largest entries: tests/test_fixed_point_adversarial_gpu.py).
+// A diagonal entry that crosses a power of two changes its scaled value by a factor of two: the test reads "moved" for that step, never "same".
+// Cost: D exponent extractions and D(D+1)/2 integer adds + ldexp per step.
+template <int D>
+__device__ __forceinline__ void fixpoint_functionals(const Sym<D>& M, double& f1, double& f2) {
+    int e[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) e[i] = __builtin_amdgcn_frexp_exp(fabs(M(i, i)));
+    f1 = 0.0;
+    f2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const double sv = __builtin_amdgcn_ldexp(M.v[sidx(i, j)], -((e[i] + e[j]) >> 1));
+            f1 += sv;
+            f2 += (1.0 + 0.37 * sidx(i, j)) * sv;
+        }
+}
 template <int D>
 __device__ __forceinline__ void symv(const Sym<D>& S, const double (&x)[D], double (&y)[D]) {
 #pragma unroll
@@ -906,13 +944,10 @@ __global__ void __launch_bounds__(64, 2) k_seg_elements(Params p) {  // two wave
         if constexpr (tinv) {
             // fixed point of the covariance recursion: two independent linear functionals of V unchanged to 2 ulp on two steps in a row (an
             // entrywise comparison would keep the previous V alive through the whole step — 120 more bytes of scratch in a kernel that has none to give)
-            double f1 = 0.0, f2 = 0.0, f3 = 0.0;
-#pragma unroll
-            for (int q = 0; q < NS; ++q) {
-                f1 += V.v[q];
-                f2 += (1.0 + 0.37 * q) * V.v[q];
-                f3 += (1.0 + 0.21 * q) * J.v[q];   // J stops moving later than V (its increments are quadratic in Π): the tail does not touch it
-            }
+            double f1, f2, f3, f3b;
+            fixpoint_functionals<D>(V, f1, f2);
+            fixpoint_functionals<D>(J, f3b, f3);   // J stops moving later than V (its increments are quadratic in Π): the tail does not touch it
+            f3 += 0.21 * f3b;
             bool same;
             if constexpr (CLDS) {   // the previous step's functionals wait in LDS as well: six registers the step does not have
                 double* cf = cl + (CL::QI - LB) * 64 + lo;
@@ -1561,12 +1596,8 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
                 }
             if constexpr (TS) {
                 if (tinv_scan) {
-                    double f1 = 0.0, f2 = 0.0;
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) {
-                        f1 += V.v[q];
-                        f2 += (1.0 + 0.37 * q) * V.v[q];
-                    }
+                    double f1, f2;
+                    fixpoint_functionals<D>(V, f1, f2);
                     const bool same = fabs(f1 - cf1) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf2) <= 4.5e-16 * fabs(f2);
                     cf1 = f1;
                     cf2 = f2;
@@ -1687,12 +1718,8 @@ __global__ void __launch_bounds__(64) k_boundary_scan(Params p, const CstArgFor<
             store_soa<D>(p.beta, s, p.n_chains, chain, xi, Lm);
             if constexpr (TS) {
                 if (tinv_scan && s < S - 1) {   // (interior elements only: the last segment has its own)
-                    double f1 = 0.0, f2 = 0.0;
-#pragma unroll
-                    for (int q = 0; q < NS; ++q) {
-                        f1 += Lm.v[q];
-                        f2 += (1.0 + 0.37 * q) * Lm.v[q];
-                    }
+                    double f1, f2;
+                    fixpoint_functionals<D>(Lm, f1, f2);
                     const bool same = fabs(f1 - cf1) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf2) <= 4.5e-16 * fabs(f2);
                     cf1 = f1;
                     cf2 = f2;
@@ -1975,12 +2002,8 @@ __device__ __forceinline__ void forward_body(const Params& p, const CstArgFor<UN
         if constexpr (TINV) {
             // Time-invariant model: V_f stops moving after the filter's mixing time (interior segments start ON the fixed point).  From there on
             // the records carry the mean only (32 instead of 112 B per step at d = 4, each way) and a step costs no inverse: the loop below.
-            double f1 = 0.0, f2 = 0.0;
-#pragma unroll
-            for (int q = 0; q < Dim<D>::NS; ++q) {
-                f1 += V.v[q];
-                f2 += (1.0 + 0.37 * q) * V.v[q];
-            }
+            double f1, f2;
+            fixpoint_functionals<D>(V, f1, f2);
             const bool same = fabs(f1 - cf1) <= 4.5e-16 * fabs(f1) && fabs(f2 - cf2) <= 4.5e-16 * fabs(f2);
             cf1 = f1;
             cf2 = f2;
@@ -3124,12 +3147,12 @@ __global__ void __launch_bounds__(64) k_backward_sh(Params p, const double* __re
 #pragma unroll
         for (int k = 0; k < (NMP + 63) / 64; ++k) {
             const int q = k * 64 + lane;
-            if (q < NMP) om[q] = make_double2(mtile[2 * q], mtile[2 * q + 1]);
+            if (q < NMP) stream_store(om + q, mtile[2 * q], mtile[2 * q + 1]);
         }
 #pragma unroll
         for (int k = 0; k < (NCP + 63) / 64; ++k) {
             const int q = k * 64 + lane;
-            if (q < NCP) oc[q] = make_double2(vs[(2 * q) % (D * D)], vs[(2 * q + 1) % (D * D)]);
+            if (q < NCP) stream_store(oc + q, vs[(2 * q) % (D * D)], vs[(2 * q + 1) % (D * D)]);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

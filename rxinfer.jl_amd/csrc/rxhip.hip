@@ -3523,6 +3523,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;
         dp.filter = p.filter;
+        dp.no_frozen = hook_env("RXHIP_NO_FROZEN") ? 1 : 0;
     }
     NoiseParams np{};
     if (e->noise) {   // a run starts from the @initialization marginal of W (iterations re-push the data: batch.jl:391-430)
