@@ -1,0 +1,388 @@
+"""Generic sum-product / mean-field VMP on an arbitrary acyclic Gaussian factor graph — CPU restatement, TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product (rxinfer.jl_amd/) never does.
+
+What it restates.  The reference materialises ANY GraphPPL model as `factornode(fform, interfaces, factorization)` objects
+(/root/reference/src/model/plugins/reactivemp_inference.jl:490-540), multiplies the inbound messages of every random variable from left to
+right (:365-374, :432-447), forms marginals as the product of all inbound messages (:440-447) and sums the Bethe free energy over node and
+variable terms (src/model/plugins/reactivemp_free_energy.jl:51-126).  The rule bodies live in ReactiveMP.jl ~6.0 / ExponentialFamily.jl 2.1
+(un-vendored; SURVEY.md Appendix A restates them); the ones used here:
+
+  MvNormalMeanCovariance / NormalMeanVariance (out, μ, Σ)   :out  N(mean(m_μ), cov(m_μ) + Σ)         :μ  N(mean(m_out), cov(m_out) + Σ)
+  MvNormalMeanPrecision / NormalMeanPrecision (out, μ, Λ)   the same with Σ = Λ⁻¹ (constant Λ) or Σ = mean(q_Λ)⁻¹ (q(out, μ) q(Λ), mean field)
+        toward Λ:  Wishart(d + 2, E[(out − μ)(out − μ)ᵀ]⁻¹)   (scalar: Gamma(3/2, ½ E[(out − μ)²]))
+  typeof(*) (out, A, in), A constant      :out  N(A m, A V Aᵀ)                    :in  (Aᵀ ξ, Aᵀ Λ A) in weighted-mean / precision form
+  typeof(+) (out, in1, in2)               :out  N(m1 + m2, V1 + V2)               :in1 N(m_out − m2, V_out + V2)   (a constant / data input: V = 0)
+  Wishart (out, ν, S), GammaShapeRate / GammaShapeScale (out, α, β | θ): constant parameters, the prior of a precision variable
+  product of Gaussians: (ξ1 + ξ2, Λ1 + Λ2);  marginal = product of all inbound messages
+  Bethe terms: SURVEY Appendix A.4 as oracle/rxoracle.c lgssm_bp_ws spells them for the state-space graph — stochastic node U − H[q(cluster)],
+  deterministic node −H[q(inputs)], random variable (degree − 1) H[q]; clamped interfaces contribute no entropy.
+
+One deviation, stated: the additive rule applied to a message in weighted-mean / precision form uses Λ' = Λ (Λ + W)⁻¹ W, ξ' = W (Λ + W)⁻¹ ξ
+(W = Σ⁻¹) instead of inverting Λ first — the same message wherever the reference's `mean_cov` exists, and defined for the rank-deficient
+backward messages of an observation map with fewer rows than columns (the reference's cholinv throws there).
+
+Pinning.  tests/test_tree_oracle.py checks this module against (i) brute-force conditioning of the joint Gaussian (marginals, and
+free energy = −log evidence) on random trees, (ii) oracle/rxoracle.c's lgssm_bp / lgssm_noise_vmp on the state-space graphs, which are pinned to
+the reference's golden free energies (tests/test_golden_reference.py), (iii) the RNG-free known answers 3.51551 / 2.26551
+(/root/reference/test/models/models_tests.jl:255,308).
+
+Input: a graph in the exchange format "rxhip-graph-1" (what HIPInferencePlugin.jl's dump_graph writes; a dict) and the data of ONE replica,
+{variable id: vector}."""
+import math
+
+import numpy as np
+from scipy.special import digamma, gammaln
+
+LOG2PI = math.log(2.0 * math.pi)
+
+GAUSS_COV = ("MvNormalMeanCovariance", "NormalMeanVariance")
+GAUSS_PREC = ("MvNormalMeanPrecision", "NormalMeanPrecision")
+PRIORS = ("Wishart", "GammaShapeRate", "GammaShapeScale")
+
+
+def _sym(M):
+    return 0.5 * (M + M.T)
+
+
+class Msg:
+    """A Gaussian message in moment form (m, V) or weighted-mean / precision form (xi, L)."""
+
+    def __init__(self, form, a, B):
+        self.form, self.a, self.B = form, np.asarray(a, float), np.asarray(B, float)
+
+    def mv(self):
+        if self.form == "mv":
+            return self.a, self.B
+        V = np.linalg.inv(self.B)
+        return V @ self.a, _sym(V)
+
+    def wp(self):
+        if self.form == "wp":
+            return self.a, self.B
+        L = np.linalg.inv(self.B)
+        return L @ self.a, _sym(L)
+
+
+def _entropy(V):
+    d = V.shape[0]
+    return 0.5 * (d * (LOG2PI + 1.0) + np.linalg.slogdet(V)[1])
+
+
+def mvdigamma(a, d):
+    return sum(digamma(a - 0.5 * i) for i in range(d))
+
+
+def mvlgamma(a, d):
+    return 0.25 * d * (d - 1) * math.log(math.pi) + sum(gammaln(a - 0.5 * i) for i in range(d))
+
+
+class TreeGraph:
+    def __init__(self, dump):
+        if dump.get("format") != "rxhip-graph-1":
+            raise ValueError("not an rxhip-graph-1 dump")
+        self.vars = dump["variables"]
+        self.factors = [(f["type"], [int(v) for _, v in f["interfaces"]]) for f in dump["factors"]]
+        nv = len(self.vars)
+        self.dim = [int(v["rows"]) for v in self.vars]
+        self.kind = [v["kind"] for v in self.vars]
+        # classify: precision variables are the random `out` of a Wishart / Gamma prior node
+        self.prec_prior = {}
+        for fi, (t, ifs) in enumerate(self.factors):
+            if t in PRIORS:
+                self.prec_prior[ifs[0]] = fi
+        # the output of a deterministic node whose inputs are all clamped (constants, data, such outputs) is clamped itself: `a + b` of two
+        # data variables is a PointMass message in the reference (test/models/models_tests.jl:242-256), not a random variable
+        self.derived = {}
+        changed = True
+        while changed:
+            changed = False
+            for fi, (t, ifs) in enumerate(self.factors):
+                if t in ("*", "+") and ifs[0] not in self.derived and self.kind[ifs[0]] == "random" and \
+                        all(self.kind[x] != "random" or x in self.derived for x in ifs[1:]):
+                    self.derived[ifs[0]] = fi
+                    changed = True
+        self.gauss = [self.kind[v] == "random" and v not in self.prec_prior and v not in self.derived for v in range(nv)]
+        self.nbrs = [[] for _ in range(nv)]   # per variable: (factor, interface) in factor order — the fold order of the product
+        for fi, (t, ifs) in enumerate(self.factors):
+            for k, v in enumerate(ifs):
+                self.nbrs[v].append((fi, k))
+        self._check_supported()
+
+    def _check_supported(self):
+        for t, ifs in self.factors:
+            if t in GAUSS_COV or t in GAUSS_PREC:
+                if self.kind[ifs[2]] != "constant" and not (t in GAUSS_PREC and ifs[2] in self.prec_prior):
+                    raise ValueError(f"{t}: third interface must be a constant (or a Wishart / Gamma variable on a precision node)")
+            elif t == "*":
+                if self.kind[ifs[1]] != "constant":
+                    raise ValueError("`*`: the matrix must be a constant")
+            elif t == "+" or t in PRIORS:
+                pass
+            else:
+                raise ValueError(f"node {t} is not part of the Gaussian tree family")
+
+    def const(self, v):
+        x = np.asarray(self.vars[v]["value"], float)
+        r, c = int(self.vars[v]["rows"]), int(self.vars[v]["cols"])
+        return x.reshape(r, c) if c > 1 else x.reshape(r)
+
+    def init_q(self, v):
+        """the `@initialization` marginal of a precision variable as (nu, V) of a Wishart (a Gamma(a, b) is Wishart_1(2a, 1/(2b)))"""
+        ini = self.vars[v].get("init")
+        if ini is None:
+            raise ValueError("a precision variable needs an @initialization marginal")
+        p = np.asarray(ini["params"], float)
+        d = self.dim[v]
+        if ini["family"] == "gamma":
+            return 2.0 * p[0], np.array([[1.0 / (2.0 * p[1])]])
+        if ini["family"] == "wishart":
+            return float(p[0]), p[1:].reshape(d, d)
+        raise ValueError("unsupported initial marginal for a precision variable")
+
+    def prior_q(self, v):
+        t, ifs = self.factors[self.prec_prior[v]]
+        a, b = self.const(ifs[1]), self.const(ifs[2])
+        if t == "Wishart":
+            return float(a.ravel()[0]), np.asarray(b, float).reshape(self.dim[v], self.dim[v])
+        shape, par = float(a.ravel()[0]), float(np.ravel(b)[0])
+        rate = par if t == "GammaShapeRate" else 1.0 / par
+        return 2.0 * shape, np.array([[1.0 / (2.0 * rate)]])
+
+
+def infer(dump, data, iterations=1, free_energy=True):
+    """Returns dict(mean={var: m}, cov={var: V}, fe=[per iteration], q_prec={var: (nu, V)}, counters=dict(rule_calls, products, marginals))
+    for ONE replica.  `data`: {variable id: vector}; a NaN vector is not supported here (missing observations are the chain engines')."""
+    g = TreeGraph(dump)
+    nv = len(g.vars)
+
+    def value(v):   # clamped value of a data / constant variable, or of a deterministic function of such
+        if g.kind[v] == "constant":
+            return np.atleast_1d(g.const(v)).astype(float)
+        if v in g.derived:
+            t, ifs = g.factors[g.derived[v]]
+            if t == "+":
+                return value(ifs[1]) + value(ifs[2])
+            A = np.atleast_2d(g.const(ifs[1])).astype(float).reshape(g.dim[ifs[0]], g.dim[ifs[2]])
+            return A @ value(ifs[2])
+        return np.atleast_1d(np.asarray(data[v], float))
+
+    qW = {v: g.init_q(v) if g.vars[v].get("init") else g.prior_q(v) for v in g.prec_prior}
+    fe_hist = []
+    out = None
+    for _ in range(max(1, int(iterations))):
+        What = {v: qW[v][0] * qW[v][1] for v in qW}
+        # rule calls as the reference's trace counts them for a run WITHOUT the free energy: the messages the requested marginals pull in — the
+        # marginals of the variables a user can name, i.e. not the anonymous output of a deterministic node (`B * x[t]`).  The remaining messages
+        # (toward such outputs) are formed for the Bethe terms only and are not counted, as in oracle/rxoracle.c.
+        counters = dict(rule_calls=0, products=0, marginals=0, on=True)
+        det_outs = {ifs[0] for t, ifs in g.factors if t in ("*", "+")}
+        f2v, v2f = {}, {}
+
+        def noise_of(fi):
+            t, ifs = g.factors[fi]
+            third = ifs[2]
+            if third in g.prec_prior:
+                W = What[third]
+                return np.linalg.inv(W), W
+            M = np.atleast_2d(g.const(third)).astype(float)
+            if M.shape[0] != M.shape[1]:
+                M = M.reshape(g.dim[ifs[0]], g.dim[ifs[0]])
+            return (M, np.linalg.inv(M)) if t in GAUSS_COV else (np.linalg.inv(M), M)
+
+        def msg_v2f(v, fi, k):
+            key = (v, fi, k)
+            if key not in v2f:
+                ins = [msg_f2v(gf, gk) for gf, gk in g.nbrs[v] if (gf, gk) != (fi, k)]
+                ins = [m for m in ins if m is not None]
+                if not ins:
+                    v2f[key] = None   # an improper (uniform) message: the variable has no other neighbour
+                elif len(ins) == 1:
+                    v2f[key] = ins[0]
+                else:
+                    xi, L = ins[0].wp()
+                    for m in ins[1:]:
+                        x2, L2 = m.wp()
+                        xi, L = xi + x2, L + L2
+                        counters["products"] += counters["on"]
+                    v2f[key] = Msg("wp", xi, L)
+            return v2f[key]
+
+        def wp0(m, d):   # a missing (uniform) message carries no information
+            return (np.zeros(d), np.zeros((d, d))) if m is None else m.wp()
+
+        def additive(m, Sigma, W):
+            if m.form == "mv":
+                return Msg("mv", m.a, m.B + Sigma)
+            G = np.linalg.inv(m.B + W)
+            return Msg("wp", W @ G @ m.a, _sym(m.B @ G @ W))
+
+        def msg_f2v(fi, k):
+            key = (fi, k)
+            if key in f2v:
+                return f2v[key]
+            t, ifs = g.factors[fi]
+            res = None
+            if t in GAUSS_COV or t in GAUSS_PREC:
+                other = ifs[1 - k]
+                Sigma, W = noise_of(fi)
+                if g.gauss[other]:
+                    m = msg_v2f(other, fi, 1 - k)
+                    res = None if m is None else additive(m, Sigma, W)   # an unobserved leaf on the other side: nothing to pass on
+                else:
+                    res = Msg("mv", value(other), Sigma)
+            elif t == "*":
+                A = np.atleast_2d(g.const(ifs[1])).astype(float)
+                if A.shape != (g.dim[ifs[0]], g.dim[ifs[2]]):
+                    A = A.reshape(g.dim[ifs[0]], g.dim[ifs[2]])
+                src = msg_v2f(ifs[2], fi, 2) if k == 0 else msg_v2f(ifs[0], fi, 0)
+                if src is None:
+                    res = None
+                elif k == 0:
+                    m, V = src.mv()
+                    res = Msg("mv", A @ m, _sym(A @ V @ A.T))
+                else:
+                    xi, L = src.wp()
+                    res = Msg("wp", A.T @ xi, _sym(A.T @ L @ A))
+            elif t == "+":
+                o, a, b = ifs
+                if k == 0:
+                    srcs = [msg_v2f(x, fi, kk) if g.gauss[x] else Msg("mv", value(x), np.zeros((g.dim[x], g.dim[x]))) for kk, x in ((1, a), (2, b))]
+                    if any(m is None for m in srcs):
+                        res = None
+                    else:
+                        parts = [m.mv() for m in srcs]
+                        res = Msg("mv", parts[0][0] + parts[1][0], parts[0][1] + parts[1][1])
+                else:
+                    oth, kk = (b, 2) if k == 1 else (a, 1)
+                    mo = msg_v2f(o, fi, 0)
+                    if mo is None or (g.gauss[oth] and msg_v2f(oth, fi, kk) is None):
+                        res = None
+                    elif g.gauss[oth]:
+                        m2, V2 = msg_v2f(oth, fi, kk).mv()
+                        mo_m, mo_V = mo.mv()
+                        res = Msg("mv", mo_m - m2, mo_V + V2)
+                    elif mo.form == "mv":
+                        res = Msg("mv", mo.a - value(oth), mo.B)
+                    else:
+                        res = Msg("wp", mo.a - mo.B @ value(oth), mo.B)
+            else:
+                raise ValueError(t)
+            if res is not None:
+                counters["rule_calls"] += counters["on"]
+            f2v[key] = res
+            return res
+
+        # ---- marginals ----
+        mean, cov, qinfo = {}, {}, {}
+        for v in [v for v in range(nv) if v not in det_outs] + [v for v in range(nv) if v in det_outs]:
+            if not g.gauss[v]:
+                continue
+            counters["on"] = v not in det_outs
+            ins = [m for m in (msg_f2v(fi, k) for fi, k in g.nbrs[v]) if m is not None]
+            if not ins:
+                raise ValueError(f"variable {v} receives no message")
+            xi, L = ins[0].wp()
+            xi, L = xi.copy(), L.copy()
+            for m in ins[1:]:
+                x2, L2 = m.wp()
+                xi, L = xi + x2, L + L2
+            V = _sym(np.linalg.inv(L))
+            mean[v], cov[v] = V @ xi, V
+            qinfo[v] = (xi, L)
+            counters["marginals"] += counters["on"]
+        counters["on"] = False
+
+        # ---- node-local joints of the Gaussian nodes with two random interfaces; residual second moments of every Gaussian node ----
+        def node_moments(fi):
+            """E[(out − μ)(out − μ)ᵀ] and the entropy of the node's Gaussian cluster under the node-local marginal"""
+            t, ifs = g.factors[fi]
+            o, mu = ifs[0], ifs[1]
+            Sigma, W = noise_of(fi)
+            d = g.dim[o]
+            if g.gauss[o] and g.gauss[mu]:
+                xo, Lo = wp0(msg_v2f(o, fi, 0), d)
+                xm, Lm = wp0(msg_v2f(mu, fi, 1), d)
+                Lj = np.block([[Lo + W, -W], [-W, Lm + W]])
+                Vj = _sym(np.linalg.inv(Lj))
+                mj = Vj @ np.concatenate([xo, xm])
+                D = np.hstack([np.eye(d), -np.eye(d)])
+                r = D @ mj
+                return D @ Vj @ D.T + np.outer(r, r), _entropy(Vj), (mj, Vj)
+            if g.gauss[o] or g.gauss[mu]:
+                rv, cv = (o, mu) if g.gauss[o] else (mu, o)
+                r = mean[rv] - value(cv)
+                return cov[rv] + np.outer(r, r), _entropy(cov[rv]), None
+            r = value(o) - value(mu)
+            return np.outer(r, r), 0.0, None
+
+        # ---- q(W) updates (mean field): Wishart(ν0 + n, (S0⁻¹ + Σ E[rrᵀ])⁻¹) ----
+        stats = {v: [0, np.zeros((g.dim[v], g.dim[v]))] for v in qW}
+        moments = {}
+        for fi, (t, ifs) in enumerate(g.factors):
+            if t in GAUSS_COV or t in GAUSS_PREC:
+                moments[fi] = node_moments(fi)
+                if ifs[2] in qW:
+                    stats[ifs[2]][0] += 1
+                    stats[ifs[2]][1] += moments[fi][0]
+        qnew = {}
+        for v in qW:
+            nu0, S0 = g.prior_q(v)
+            Vi = np.linalg.inv(S0) + _sym(stats[v][1])
+            qnew[v] = (nu0 + stats[v][0], _sym(np.linalg.inv(Vi)))
+
+        # ---- Bethe free energy: q(x…) of this sweep, q(W) as just updated ----
+        if free_energy:
+            F = 0.0
+            for fi, (t, ifs) in enumerate(g.factors):
+                if t in GAUSS_COV or t in GAUSS_PREC:
+                    d = g.dim[ifs[0]]
+                    E, H, _ = moments[fi]
+                    third = ifs[2]
+                    if third in qW:
+                        nu, V = qnew[third]
+                        Elogdet = mvdigamma(0.5 * nu, d) + d * math.log(2.0) + np.linalg.slogdet(V)[1]
+                        Wm = nu * V
+                    else:
+                        _, Wm = noise_of(fi)
+                        Elogdet = np.linalg.slogdet(Wm)[1]
+                    F += 0.5 * (d * LOG2PI - Elogdet + np.trace(Wm @ E)) - H
+                elif t in ("*", "+") and fi in g.derived.values():
+                    pass   # all interfaces clamped: the point entropies cancel (CountingReal bookkeeping)
+                elif t == "*":
+                    F += -_entropy(cov[ifs[2]])
+                elif t == "+":
+                    ins = [x for x in ifs[1:] if g.gauss[x]]
+                    if len(ins) == 2:   # joint of the two inputs: q(in1, in2) ∝ m(in1) m(in2) m_out(in1 + in2)
+                        dd = g.dim[ifs[0]]
+                        x1, L1 = wp0(msg_v2f(ifs[1], fi, 1), dd)
+                        x2, L2 = wp0(msg_v2f(ifs[2], fi, 2), dd)
+                        xo, Lo = wp0(msg_v2f(ifs[0], fi, 0), dd)
+                        Lj = np.block([[L1 + Lo, Lo], [Lo, L2 + Lo]])
+                        F += -_entropy(_sym(np.linalg.inv(Lj)))
+                    elif len(ins) == 1:
+                        F += -_entropy(cov[ins[0]])
+                elif t in PRIORS:
+                    v = ifs[0]
+                    d = g.dim[v]
+                    nu0, S0 = g.prior_q(v)
+                    nu, V = qnew[v]
+                    ldV = np.linalg.slogdet(V)[1]
+                    Elw = mvdigamma(0.5 * nu, d) + d * math.log(2.0) + ldV
+                    # average energy of the Wishart prior node under q(W), and −H[q(W)]
+                    U = -(0.5 * (nu0 - d - 1.0) * Elw - 0.5 * np.trace(np.linalg.inv(S0) @ (nu * V)) - 0.5 * nu0 * d * math.log(2.0) -
+                          0.5 * nu0 * np.linalg.slogdet(S0)[1] - mvlgamma(0.5 * nu0, d))
+                    Hq = 0.5 * (d + 1.0) * ldV + 0.5 * d * (d + 1.0) * math.log(2.0) + mvlgamma(0.5 * nu, d) - 0.5 * (nu - d - 1.0) * mvdigamma(0.5 * nu, d) + 0.5 * nu * d
+                    # prior node U − H[q(W)]; each of the n likelihood nodes carries −H[q(W)] for its cluster (W) and the variable term is
+                    # (degree − 1) H[q(W)] = n H[q(W)]: they cancel
+                    F += U - Hq
+            for v in range(nv):
+                if g.gauss[v]:
+                    F += (len(g.nbrs[v]) - 1) * _entropy(cov[v])
+            fe_hist.append(float(F))
+        qW = qnew
+        counters.pop("on")
+        out = dict(mean=mean, cov=cov, joints={fi: m[2] for fi, m in moments.items() if m[2] is not None}, counters=counters)
+    out["fe"] = fe_hist
+    out["q_prec"] = qW
+    return out

@@ -846,6 +846,10 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
 #ifndef RXHIP_FZ_CONFIRM
 #define RXHIP_FZ_CONFIRM 2   // consecutive steps on which the tests of the recursion's matrix (below) must pass before a segment leaves the matrix work
 #endif
+#ifndef RXHIP_FZ_LANE_TOL
+#define RXHIP_FZ_LANE_TOL 7.2e-15   // kd_forward_info, test (a): a lane's sums over its 16 equilibrated entries repeat to 32 ulp (entries that repeat to 1–2 ulp each
+                                    // move such a sum by several ulp: at 2 ulp the test never passed on the BASELINE d = 64 model and no segment froze)
+#endif
 #ifndef RXHIP_FZ_TOL
 #define RXHIP_FZ_TOL 1.5e-14 // kd_backward_info, the verification step: |V_s(t) − V_s(t+1)|_ij ≤ TOL · sqrt(V_ii V_jj) (64 ulp on the entry's own scale)
 #endif
@@ -1763,12 +1767,12 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
     // rest of the segment is the loop behind this one: vectors and record stores only.  Two tests, both on RXHIP_FZ_CONFIRM steps in a row:
     //  (a) at the top of a step each LANE forms two weighted sums of its 4·NT entries of M_t as the inverse is about to see them — equilibrated by
     //      the exact powers of two of M's diagonal, M_ij · 2^(h_i + h_j) with |·| ≲ 2 whatever the scales of the state's components — and compares
-    //      them with its own sums of the step before: unchanged to 2 ulp in EVERY lane of the workgroup (256 pairs of functionals over 16 entries
-    //      each: an entry that still moves by more than ≈ 5e-14 · sqrt(M_ii M_jj) per step is seen unless the other 15 entries of its lane cancel
+    //      them with its own sums of the step before: unchanged to 32 ulp in EVERY lane of the workgroup (256 pairs of functionals over 16 entries
+    //      each: an entry that still moves by more than ≈ 2e-13 · sqrt(M_ii M_jj) per step is seen unless the other 15 entries of its lane cancel
     //      it in both sums);
     //  (b) at the end of the step two plain sums over the tiles of M_{t+1} unchanged to 2 ulp (rounds 3–4's only test: it sees what moves the
     //      largest entries, and nothing else — tests/test_fixed_point_adversarial_gpu.py; kept because it is the later of the two pairs).
-    // At a contraction rate ρ of the recursion a frozen entry is within ≈ 5e-14 / (1 − ρ) · sqrt(M_ii M_jj) of its fixed point (include/rxhip.h
+    // At a contraction rate ρ of the recursion a frozen entry is within ≈ 2e-13 / (1 − ρ) · sqrt(M_ii M_jj) of its fixed point (include/rxhip.h
     // "Fixed-point exits").  Interior segments start on the fixed point (boundary table) and leave after four steps.
     constexpr bool FROZEN = RXHIP_FWD_FROZEN && SEEDED;
     // for the backward sweep: the first time index of this segment whose record holds the repeated matrices (default: beyond the segment) — in a
@@ -1808,7 +1812,7 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
                     f1 += (s0 + s1) + (s2 + s3);
                     f2 = fma(fma(fma(fma(f2, 1.37, s0), 1.37, s1), 1.37, s2), 1.37, s3);   // weights 1.37^k: ONE constant in a register, not sixteen
                 }
-                const bool lane_same = fabs(f1 - lzp1) <= 4.5e-16 * fabs(f1) && fabs(f2 - lzp2) <= 4.5e-16 * fabs(f2);
+                const bool lane_same = fabs(f1 - lzp1) <= RXHIP_FZ_LANE_TOL * fabs(f1) && fabs(f2 - lzp2) <= RXHIP_FZ_LANE_TOL * fabs(f2);
                 lzp1 = f1;
                 lzp2 = f2;
                 const bool wave_same = __all(lane_same) != 0;

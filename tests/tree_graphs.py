@@ -1,0 +1,257 @@
+"""Factor graphs OUTSIDE the pattern-matched families (what `rxhip_create` used to answer with RXHIP_ERR_UNSUPPORTED) for the tests of the
+level-scheduled executor, and a brute-force checker: the joint Gaussian of all random variables conditioned on the data.
+
+Every builder returns (GraphBuilder, data variable ids, dict of named variable lists)."""
+import numpy as np
+
+from rxhip import _lib
+from rxhip.graph import GraphBuilder
+
+
+def _spd(rng, d, scale=1.0):
+    a = rng.standard_normal((d, d))
+    return scale * (a @ a.T / d + 0.5 * np.eye(d))
+
+
+def two_branch_chain(T, d=3, dy1=2, dy2=1, seed=0, precision_spelling=False):
+    """x[t] ~ N(A x[t-1], P) with TWO observation branches per state: y1[t] ~ N(B1 x[t], Q1), y2[t] ~ N(B2 x[t], Q2)
+    (graph_lowering.hpp: "a state with two observation branches")"""
+    rng = np.random.default_rng(seed)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    A = q @ np.diag(rng.uniform(0.5, 0.95, d)) @ q.T
+    B1, B2 = rng.standard_normal((dy1, d)), rng.standard_normal((dy2, d))
+    P, Q1, Q2, V0 = _spd(rng, d, 0.1), _spd(rng, dy1), _spd(rng, dy2, 2.0), _spd(rng, d, 4.0)
+    gb = GraphBuilder()
+    x = gb.randomvar(d)
+    gb.mvnormal_mean_cov(x, gb.constvar(rng.standard_normal(d)), gb.constvar(V0))
+    xs, ys = [], []
+    for t in range(T):
+        if t:
+            a = gb.randomvar(d)
+            gb.multiply(a, gb.constvar(A), x)
+            xn = gb.randomvar(d)
+            if precision_spelling:
+                gb.node(_lib.NODE_MVNORMAL_MEAN_PRECISION, xn, a, gb.constvar(np.linalg.inv(P)))
+            else:
+                gb.mvnormal_mean_cov(xn, a, gb.constvar(P))
+            x = xn
+        for B, Q in ((B1, Q1), (B2, Q2)):
+            b = gb.randomvar(B.shape[0])
+            gb.multiply(b, gb.constvar(B), x)
+            y = gb.datavar(B.shape[0])
+            gb.mvnormal_mean_cov(y, b, gb.constvar(Q))
+            ys.append(y)
+        xs.append(x)
+    return gb, ys, dict(x=xs)
+
+
+def branching_tree(depth=3, fanout=2, d=2, seed=1, observe_leaves_only=False):
+    """A root state with `fanout` children per node down to `depth`: x_child ~ N(A_k x_parent + c_k, P_k); nodes are observed through their own
+    maps, some through `+` with a second random root (u ~ N(m_u, V_u); z = B x + u; y ~ N(z, Q)).  A tree that is not a chain."""
+    rng = np.random.default_rng(seed)
+    gb = GraphBuilder()
+    root = gb.randomvar(d)
+    gb.mvnormal_mean_cov(root, gb.constvar(rng.standard_normal(d)), gb.constvar(_spd(rng, d, 3.0)))
+    xs, ys, us = [root], [], []
+    frontier = [(root, 0)]
+    while frontier:
+        x, lvl = frontier.pop(0)
+        leaf = lvl == depth
+        if leaf or not observe_leaves_only:
+            dy = 1 + (len(ys) % d)
+            b = gb.randomvar(dy)
+            gb.multiply(b, gb.constvar(rng.standard_normal((dy, d))), x)
+            if len(ys) % 3 == 1:   # an additive random disturbance with its own prior
+                u = gb.randomvar(dy)
+                gb.mvnormal_mean_cov(u, gb.constvar(rng.standard_normal(dy)), gb.constvar(_spd(rng, dy, 0.3)))
+                z = gb.randomvar(dy)
+                gb.node(_lib.NODE_ADD, z, b, u)
+                us.append(u)
+                b = z
+            y = gb.datavar(dy)
+            gb.mvnormal_mean_cov(y, b, gb.constvar(_spd(rng, dy, 0.5)))
+            ys.append(y)
+        if not leaf:
+            for k in range(fanout):
+                a = gb.randomvar(d)
+                gb.multiply(a, gb.constvar(0.8 * rng.standard_normal((d, d))), x)
+                w = gb.randomvar(d)
+                gb.node(_lib.NODE_ADD, w, gb.constvar(rng.standard_normal(d)), a) if k % 2 else gb.node(_lib.NODE_ADD, w, a, gb.constvar(rng.standard_normal(d)))
+                c = gb.randomvar(d)
+                gb.mvnormal_mean_cov(c, w, gb.constvar(_spd(rng, d, 0.2)))
+                xs.append(c)
+                frontier.append((c, lvl + 1))
+    return gb, ys, dict(x=xs, u=us)
+
+
+def scalar_tree(n_leaves=5, seed=2):
+    """scalars: m ~ N(0, 10); leaf_k ~ N(mean = a_k m, var = v_k) through `*`; y_k ~ N(mean = leaf_k + c_k, precision = τ_k) — the
+    NormalMeanVariance / NormalMeanPrecision spellings with constant parameters on a star"""
+    rng = np.random.default_rng(seed)
+    gb = GraphBuilder()
+    m = gb.randomvar(1)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, m, gb.constvar(0.3), gb.constvar(10.0))
+    ys, leaves = [], []
+    for k in range(n_leaves):
+        a = gb.randomvar(1)
+        gb.multiply(a, gb.constvar(float(rng.uniform(0.5, 2.0))), m)
+        lf = gb.randomvar(1)
+        gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, lf, a, gb.constvar(float(rng.uniform(0.1, 1.0))))
+        s = gb.randomvar(1)
+        gb.node(_lib.NODE_ADD, s, lf, gb.constvar(float(rng.standard_normal())))
+        y = gb.datavar(1)
+        gb.node(_lib.NODE_NORMAL_MEAN_PRECISION, y, s, gb.constvar(float(rng.uniform(0.5, 3.0))))
+        ys.append(y)
+        leaves.append(lf)
+    return gb, ys, dict(m=[m], leaf=leaves)
+
+
+def chain_with_prediction(T, H, d=2, dy=2, seed=3):
+    """a chain whose last H observation variables are RANDOM (no data): their marginals are the predictions"""
+    rng = np.random.default_rng(seed)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    A, B = q * 0.9, rng.standard_normal((dy, d))
+    P, Q = _spd(rng, d, 0.1), _spd(rng, dy)
+    gb = GraphBuilder()
+    x = gb.randomvar(d)
+    gb.mvnormal_mean_cov(x, gb.constvar(np.zeros(d)), gb.constvar(4.0 * np.eye(d)))
+    xs, ys, preds = [], [], []
+    for t in range(T + H):
+        if t:
+            a = gb.randomvar(d)
+            gb.multiply(a, gb.constvar(A), x)
+            xn = gb.randomvar(d)
+            gb.mvnormal_mean_cov(xn, a, gb.constvar(P))
+            x = xn
+        b = gb.randomvar(dy)
+        gb.multiply(b, gb.constvar(B), x)
+        y = gb.datavar(dy) if t < T else gb.randomvar(dy)
+        gb.mvnormal_mean_cov(y, b, gb.constvar(Q))
+        (ys if t < T else preds).append(y)
+        xs.append(x)
+    return gb, ys, dict(x=xs, pred=preds)
+
+
+def chain_state_noise_precision(T, d=2, dy=2, seed=4, also_obs_noise=False, gamma=False):
+    """x[t] ~ MvNormal(μ = A x[t-1], Λ = W), W ~ Wishart(ν, S) — the UNKNOWN STATE-noise precision (graph_lowering.hpp rejects it); optionally an unknown
+    observation-noise precision R as well.  d = dy = 1 with gamma=True: the Normal / Gamma spelling."""
+    rng = np.random.default_rng(seed)
+    if gamma:
+        d = dy = 1
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    A, B = q * 0.9, (rng.standard_normal((dy, d)) if not gamma else np.array([[1.3]]))
+    Q = _spd(rng, dy)
+    gb = GraphBuilder()
+    W = gb.randomvar(d, name="W")
+    if gamma:
+        gb.node(_lib.NODE_GAMMA_SHAPE_RATE, W, gb.constvar(2.0), gb.constvar(0.5))
+        gb.initialize(W, _lib.INIT_GAMMA, [2.0, 1.0])
+    else:
+        gb.node(_lib.NODE_WISHART, W, gb.constvar(float(d + 2)), gb.constvar(np.eye(d) * 2.0))
+        gb.initialize(W, _lib.INIT_WISHART, np.concatenate([[d + 2.0], np.eye(d).ravel()]))
+    R = None
+    if also_obs_noise:
+        R = gb.randomvar(dy, name="R")
+        gb.node(_lib.NODE_WISHART, R, gb.constvar(float(dy + 1)), gb.constvar(np.eye(dy)))
+        gb.initialize(R, _lib.INIT_WISHART, np.concatenate([[dy + 1.0], np.eye(dy).ravel()]))
+    x = gb.randomvar(d)
+    gb.mvnormal_mean_cov(x, gb.constvar(np.zeros(d)), gb.constvar(4.0 * np.eye(d))) if not gamma else \
+        gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, x, gb.constvar(0.0), gb.constvar(4.0))
+    xs, ys = [], []
+    for t in range(T):
+        if t:
+            a = gb.randomvar(d)
+            gb.multiply(a, gb.constvar(A if not gamma else float(A[0, 0])), x)
+            xn = gb.randomvar(d)
+            gb.node(_lib.NODE_NORMAL_MEAN_PRECISION if gamma else _lib.NODE_MVNORMAL_MEAN_PRECISION, xn, a, W)
+            x = xn
+        b = gb.randomvar(dy)
+        gb.multiply(b, gb.constvar(B if not gamma else float(B[0, 0])), x)
+        y = gb.datavar(dy)
+        if R is not None:
+            gb.node(_lib.NODE_MVNORMAL_MEAN_PRECISION, y, b, R)
+        elif gamma:
+            gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y, b, gb.constvar(float(Q[0, 0])))
+        else:
+            gb.mvnormal_mean_cov(y, b, gb.constvar(Q))
+        xs.append(x); ys.append(y)
+    return gb, ys, dict(x=xs, W=[W] + ([R] if R is not None else []))
+
+
+def random_data(gb, ys, n_replicas, seed=0):
+    """[replica][Σ dims of the data variables] in the order of `ys`"""
+    rng = np.random.default_rng(1000 + seed)
+    return rng.standard_normal((n_replicas, int(sum(gb.rows[v] for v in ys)))) * 1.5
+
+
+def data_dict(gb, ys, row):
+    out, o = {}, 0
+    for v in ys:
+        out[v] = row[o:o + gb.rows[v]]
+        o += gb.rows[v]
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def brute_force(gb, data):
+    """Exact posterior marginals {var: (mean, cov)} and −log evidence of a graph with constant noise parameters: every random variable
+    is written as an affine map of the BASE variables (those no deterministic node defines), the joint density of the base variables is a
+    Gaussian in information form, and conditioning is one dense solve."""
+    nv = len(gb.kind)
+    K_RANDOM, K_DATA, K_CONST = _lib.VARKIND_RANDOM, _lib.VARKIND_DATA, _lib.VARKIND_CONST
+    det_out = {}
+    for t, ifs in zip(gb.ftype, gb.fiface):
+        if t in (_lib.NODE_MULTIPLY, _lib.NODE_ADD):
+            det_out[ifs[0]] = (t, ifs)
+    base = [v for v in range(nv) if gb.kind[v] == K_RANDOM and v not in det_out]
+    off, N = {}, 0
+    for v in base:
+        off[v] = N
+        N += gb.rows[v]
+    aff = {}
+
+    def expr(v):
+        if v in aff:
+            return aff[v]
+        r = gb.rows[v]
+        if gb.kind[v] == K_CONST:
+            e = (np.zeros((r, N)), np.atleast_1d(gb.const_value(v)).astype(float).reshape(r))
+        elif gb.kind[v] == K_DATA:
+            e = (np.zeros((r, N)), np.asarray(data[v], float).reshape(r))
+        elif v in det_out:
+            t, ifs = det_out[v]
+            if t == _lib.NODE_MULTIPLY:
+                A = np.atleast_2d(gb.const_value(ifs[1])).astype(float).reshape(r, gb.rows[ifs[2]])
+                C, c = expr(ifs[2])
+                e = (A @ C, A @ c)
+            else:
+                (C1, c1), (C2, c2) = expr(ifs[1]), expr(ifs[2])
+                e = (C1 + C2, c1 + c2)
+        else:
+            C = np.zeros((r, N))
+            C[:, off[v]:off[v] + r] = np.eye(r)
+            e = (C, np.zeros(r))
+        aff[v] = e
+        return e
+
+    J, h, const = np.zeros((N, N)), np.zeros(N), 0.0
+    for t, ifs in zip(gb.ftype, gb.fiface):
+        if t in (_lib.NODE_MULTIPLY, _lib.NODE_ADD):
+            continue
+        d = gb.rows[ifs[0]]
+        M = np.atleast_2d(gb.const_value(ifs[2])).astype(float).reshape(d, d)
+        W = np.linalg.inv(M) if t in (_lib.NODE_MVNORMAL_MEAN_COV, _lib.NODE_NORMAL_MEAN_VARIANCE) else M
+        (Co, co), (Cm, cm) = expr(ifs[0]), expr(ifs[1])
+        D, e = Co - Cm, co - cm
+        J += D.T @ W @ D
+        h -= D.T @ W @ e
+        const += 0.5 * (d * np.log(2 * np.pi) - np.linalg.slogdet(W)[1] + e @ W @ e)
+    S = np.linalg.inv(J)
+    mu = S @ h
+    nle = const - 0.5 * h @ mu - 0.5 * N * np.log(2 * np.pi) + 0.5 * np.linalg.slogdet(J)[1]
+    post = {}
+    for v in range(nv):
+        if gb.kind[v] == K_RANDOM:
+            C, c = expr(v)
+            post[v] = (C @ mu + c, C @ S @ C.T)
+    return post, float(nle)
