@@ -372,6 +372,67 @@ rxhip_status rxhip_graph_lower_hgf(const rxhip_graph_desc* g, rxhip_hgf_lowered*
  * the node types present; HGF: T = n_observations, series = n_replicas).  segments/device/stream as in rxhip_lgssm_desc. */
 rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out);
 
+/* ------------------------------------------------------------------------------------------
+ * The level-scheduled node-array executor: ANY acyclic Gaussian factor graph (SURVEY §7's design stance: "one kernel over all nodes of the same
+ * (factor type, interface)").  Replaces what `factornode(fform, interfaces, factorization)` + `activate!` build for an arbitrary model
+ * (src/model/plugins/reactivemp_inference.jl:490-540), the message products (:432-447), the marginals (:440-447) and the Bethe sum
+ * (src/model/plugins/reactivemp_free_energy.jl:51-126) for graphs of
+ *     MvNormalMeanCovariance / NormalMeanVariance / MvNormalMeanPrecision / NormalMeanPrecision   (out, μ: random, data or constant;
+ *         third interface: a constant, or — precision nodes — a Wishart / Gamma variable under q(out, μ) q(W));
+ *     typeof(*) with a constant matrix;  typeof(+) (random + random, random + data / constant);
+ *     Wishart / GammaShapeRate / GammaShapeScale priors with constant parameters
+ * whose Gaussian variables form a forest (no cycles; precision variables may touch any number of nodes — the mean-field factorisation cuts those
+ * loops), every dimension ≤ 4.  The host compiles the graph into ops sorted by dependency level (csrc/tree_engine.hip); one kernel
+ * (csrc/tree_kernels.hpp) evaluates (op, replica) items: a launch per level over all nodes of the level, or — deep, narrow graphs — the whole
+ * schedule in one launch with workgroup-resident levels.  Data variables, derived clamped values (`a + b` of two data variables), unobserved
+ * leaves (predictions) are part of the family; `missing` inside the data is not (the chain engines have it).
+ * rxhip_create falls through to this executor for every graph the pattern matcher rejects; rxhip_tree_create asks for it directly (the tests
+ * compare it with the specialised engines on the graphs both can run).
+ * Iterations (VMP): per iteration one sum-product sweep with E[W] of the current q(W), all marginals, then every q(W) update, then the free energy —
+ * the order of rxhip_lgssm_noise_create above.  A run starts from the `@initialization` marginals (default: the priors).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t n_ops, n_levels, n_messages;  /* ops of one iteration, dependency levels, stored messages */
+    int64_t doubles_per_replica;          /* device state per replica */
+    int64_t bytes_per_sweep;              /* algorithmic traffic of one iteration per replica: 8·(d + d(d+1)/2) per message a rule reads or writes */
+    int32_t dmax;                         /* kernel instance: 1, 2 or 4 */
+    int32_t mode;                         /* 0: one launch per level; 1: one launch per iteration (workgroup-resident levels) */
+    int32_t replicas_per_workgroup;       /* mode 1 */
+    int32_t n_precision_vars;
+} rxhip_tree_info;
+rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* stream, rxhip_engine** out);
+/* data of the listed data variables, host [replica][rows of vars[0] | rows of vars[1] | …] (src/inference/batch.jl:405-407 new_observation!) */
+rxhip_status rxhip_tree_set_data(rxhip_engine* e, const int64_t* vars, int64_t n_vars, const double* host);
+/* posteriors of the listed random (Gaussian) variables: mean [var][replica][d], cov [var][replica][d][d], concatenated in list order */
+rxhip_status rxhip_tree_get_marginals(rxhip_engine* e, const int64_t* vars, int64_t n_vars, double* mean, double* cov);
+/* q(W) of a precision variable: nu [replica], V [replica][d][d] (a Gamma(a, b) variable is reported as Wishart_1(2a, 1/(2b))) */
+rxhip_status rxhip_tree_get_precision(rxhip_engine* e, int64_t var, double* nu, double* V);
+rxhip_status rxhip_tree_get_info(rxhip_engine* e, rxhip_tree_info* out);
+/* rxhip_run, rxhip_get_free_energy (sum over the replicas, per iteration), rxhip_get_free_energy_per_chain (per replica, last iteration),
+ * rxhip_counters, rxhip_sync, rxhip_get_stream, rxhip_last_error, rxhip_destroy apply as to every engine. */
+
+/* One rule, evaluated on the device for a batch of inputs — the fine-grained A/B hook of SURVEY §8(b): what
+ * `@rule NodeType(:iface, Marginalisation) (m_… , q_…)` returns for the given inbound message(s) and constants
+ * (test/inference/inference_tests.jl:2049-2066 redirects a node to custom rule code the same way).  Runs the executor's own op on a one-node
+ * schedule: the number a test compares with the reference's rule output. */
+typedef struct {
+    int32_t node_type;      /* RXHIP_NODE_MVNORMAL_MEAN_COV | NORMAL_MEAN_VARIANCE | MVNORMAL_MEAN_PRECISION | NORMAL_MEAN_PRECISION | MULTIPLY | ADD */
+    int32_t iface;          /* the interface the message leaves through, index in the node's interface order (0 = out) */
+    int32_t d_out, d_in;    /* dimension of `out`; of the input of MULTIPLY (A is d_out × d_in), else = d_out */
+    int64_t n;              /* independent evaluations */
+    const double* constant; /* Gaussian nodes: Σ or Λ [d][d]; MULTIPLY: A [d_out][d_in]; ADD: NULL */
+    int32_t in_form;        /* inbound message(s): 0 = (mean, covariance), 1 = (weighted mean, precision) */
+    const double* in_a;     /* [n][d]: Gaussian nodes — the message on the other interface; MULTIPLY — on `in` (iface 0) or `out` (iface 2);
+                               ADD — on in1 (iface 0) or on out (iface 1, 2) */
+    const double* in_B;     /* [n][d][d] */
+    const double* in2_a;    /* ADD: the message on in2 (iface 0) / on the other input (iface 1, 2); else NULL */
+    const double* in2_B;
+    int32_t out_form;       /* form of the result: 0 = (mean, covariance), 1 = (weighted mean, precision) */
+    double* out_a;          /* [n][d'] */
+    double* out_B;          /* [n][d'][d'] */
+} rxhip_rule_call;
+rxhip_status rxhip_rule_eval(const rxhip_rule_call* call, int32_t device);
+
 /* 1 if a device schedule exists for state dimension d and observation dimension dy: every d, dy ≤ 4 has a dedicated
  * one-lane-per-chain schedule; any other d ≤ 64 with dy ≤ 64 runs on the MFMA path (state dimension rounded up to a
  * multiple of 16 with decoupled padding dimensions — exact, but priced as the padded size; d ≤ 8 with an even batch of one

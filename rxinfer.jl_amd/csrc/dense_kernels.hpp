@@ -844,11 +844,13 @@ __device__ __forceinline__ bool blk_inverse(Acc<NT>& a, double* scratch, int w_,
 #define RXHIP_FWD_FROZEN 1
 #endif
 #ifndef RXHIP_FZ_CONFIRM
-#define RXHIP_FZ_CONFIRM 2   // consecutive steps on which the tests of the recursion's matrix (below) must pass before a segment leaves the matrix work
+#define RXHIP_FZ_CONFIRM 1   // consecutive steps on which BOTH tests of the recursion's matrix (below) must pass before a segment leaves the matrix work: one
+                             // such step is two consecutive repeats, M_{t-1} -> M_t by test (a) and M_t -> M_{t+1} by test (b).  (2: measured on the BASELINE d = 64
+                             // chain, 1000 segments of 10 steps that start on the fixed point — 3 full steps per segment instead of 2, k_forward 0.23 -> 0.46 ms)
 #endif
 #ifndef RXHIP_FZ_LANE_TOL
-#define RXHIP_FZ_LANE_TOL 7.2e-15   // kd_forward_info, test (a): a lane's sums over its 16 equilibrated entries repeat to 32 ulp (entries that repeat to 1–2 ulp each
-                                    // move such a sum by several ulp: at 2 ulp the test never passed on the BASELINE d = 64 model and no segment froze)
+#define RXHIP_FZ_LANE_TOL 1.4e-14   // kd_forward_info, test (a): a lane's plain sum over its 16 equilibrated entries (each O(1) at the diagonal) repeats to 16 · 4 ulp of ONE,
+                                    // its 1.37^k-weighted sum to 26 times that (measured on the BASELINE d = 64 model: at 2 ulp of the sums no segment ever froze)
 #endif
 #ifndef RXHIP_FZ_TOL
 #define RXHIP_FZ_TOL 1.5e-14 // kd_backward_info, the verification step: |V_s(t) − V_s(t+1)|_ij ≤ TOL · sqrt(V_ii V_jj) (64 ulp on the entry's own scale)
@@ -1764,16 +1766,18 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
     long long tph_ = __builtin_readcyclecounter();
 #endif
     // FROZEN (one set of constants, no masks): once M_{t+1} = M_t to rounding every matrix of a step repeats (C, G′, M, the determinants), and the
-    // rest of the segment is the loop behind this one: vectors and record stores only.  Two tests, both on RXHIP_FZ_CONFIRM steps in a row:
-    //  (a) at the top of a step each LANE forms two weighted sums of its 4·NT entries of M_t as the inverse is about to see them — equilibrated by
+    // rest of the segment is the loop behind this one: vectors and record stores only.  Two tests, both passed on the same step (RXHIP_FZ_CONFIRM):
+    //  (a) at the end of a step each LANE forms two weighted sums of its 4·NT entries of M_{t+1} as the next inverse is about to see them — equilibrated by
     //      the exact powers of two of M's diagonal, M_ij · 2^(h_i + h_j) with |·| ≲ 2 whatever the scales of the state's components — and compares
-    //      them with its own sums of the step before: unchanged to 32 ulp in EVERY lane of the workgroup (256 pairs of functionals over 16 entries
-    //      each: an entry that still moves by more than ≈ 2e-13 · sqrt(M_ii M_jj) per step is seen unless the other 15 entries of its lane cancel
+    //      them with its own sums of the step before: unchanged to 1.4e-14 (absolute, on that scale) in EVERY lane of the workgroup (256 pairs of functionals
+    //      over 16 entries each: an entry that still moves by more than ≈ 3e-14 · sqrt(M_ii M_jj) per step is seen unless the other 15 entries of its lane cancel
     //      it in both sums);
-    //  (b) at the end of the step two plain sums over the tiles of M_{t+1} unchanged to 2 ulp (rounds 3–4's only test: it sees what moves the
-    //      largest entries, and nothing else — tests/test_fixed_point_adversarial_gpu.py; kept because it is the later of the two pairs).
-    // At a contraction rate ρ of the recursion a frozen entry is within ≈ 2e-13 / (1 − ρ) · sqrt(M_ii M_jj) of its fixed point (include/rxhip.h
-    // "Fixed-point exits").  Interior segments start on the fixed point (boundary table) and leave after four steps.
+    //  (b) two plain sums over the tiles of M_{t+1} unchanged to 2 ulp (rounds 3–4's only test: it sees what moves the largest entries, and nothing
+    //      else — tests/test_fixed_point_adversarial_gpu.py).
+    // (The first comparison of an interior segment is between the boundary table's M and the kernel's first iterate — two different summation orders — and
+    //  usually fails (a); the second one, between two iterates of this loop, passes.)
+    // At a contraction rate ρ of the recursion a frozen entry is within ≈ 3e-14 / (1 − ρ) · sqrt(M_ii M_jj) of its fixed point (include/rxhip.h
+    // "Fixed-point exits").  Interior segments start on the fixed point (boundary table) and leave after two steps.
     constexpr bool FROZEN = RXHIP_FWD_FROZEN && SEEDED;
     // for the backward sweep: the first time index of this segment whose record holds the repeated matrices (default: beyond the segment) — in a
     // slot of the segment's first record that nothing else touches: tile (1, 0) of C, which no wave owns in the symmetric pairing (NT ≥ 3)
@@ -1798,26 +1802,6 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
         }
         if constexpr (FROZEN && FE) {
             if (tid == 0) { fz[8] = lp.mant; fz[9] = (double)lp.expo; }   // the step's determinant factor = what the inverse below multiplies in
-        }
-        if constexpr (FROZEN) {
-            if (p.mseg == 0) {   // test (a): the exponents of M_t's diagonal were published for the inverse below (natural order | row q + 4r at 4q + r)
-                const int* sc = reinterpret_cast<const int*>(rowbuf + 2 * blk_half_doubles(NT));
-                const int4 hr = *reinterpret_cast<const int4*>(sc + 16 * NT + 16 * ws + 4 * (lane >> 4));
-                double f1 = 0.0, f2 = 0.0;
-#pragma unroll
-                for (int t2 = 0; t2 < NT; ++t2) {
-                    const int hc = sc[16 * t2 + (lane & 15)];
-                    const double s0 = __builtin_ldexp(lam.v[t2][0], hr.x + hc), s1 = __builtin_ldexp(lam.v[t2][1], hr.y + hc),
-                                 s2 = __builtin_ldexp(lam.v[t2][2], hr.z + hc), s3 = __builtin_ldexp(lam.v[t2][3], hr.w + hc);
-                    f1 += (s0 + s1) + (s2 + s3);
-                    f2 = fma(fma(fma(fma(f2, 1.37, s0), 1.37, s1), 1.37, s2), 1.37, s3);   // weights 1.37^k: ONE constant in a register, not sixteen
-                }
-                const bool lane_same = fabs(f1 - lzp1) <= RXHIP_FZ_LANE_TOL * fabs(f1) && fabs(f2 - lzp2) <= RXHIP_FZ_LANE_TOL * fabs(f2);
-                lzp1 = f1;
-                lzp2 = f2;
-                const bool wave_same = __all(lane_same) != 0;
-                if (lane == 0) fz[10 + ws] = wave_same ? 1.0 : 0.0;   // read at the end of the step (an invalid exponent gives inf / NaN: never "same")
-            }
         }
         // C = (Λ_f + A'P⁻¹A)⁻¹.  The inverse's scratch is S0 (or its own carve): the next writer of S0 is the store of −G below,
         // behind a workgroup barrier, so the inverse ends without one.
@@ -1968,6 +1952,29 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
             }
         }
         RXHIP_PH(7);   // symmetrisation reads
+        if constexpr (FROZEN) {
+            if (p.mseg == 0) {   // test (a) on M_{t+1} (`lam`, symmetrised): the exponents of its diagonal were published for the next inverse (natural order | row q + 4r at 4q + r)
+                const int* sc = reinterpret_cast<const int*>(rowbuf + 2 * blk_half_doubles(NT));
+                const int4 hr = *reinterpret_cast<const int4*>(sc + 16 * NT + 16 * ws + 4 * (lane >> 4));
+                double f1 = 0.0, f2 = 0.0;
+#pragma unroll
+                for (int t2 = 0; t2 < NT; ++t2) {
+                    const int hc = sc[16 * t2 + (lane & 15)];
+                    const double s0 = __builtin_ldexp(lam.v[t2][0], hr.x + hc), s1 = __builtin_ldexp(lam.v[t2][1], hr.y + hc),
+                                 s2 = __builtin_ldexp(lam.v[t2][2], hr.z + hc), s3 = __builtin_ldexp(lam.v[t2][3], hr.w + hc);
+                    f1 += (s0 + s1) + (s2 + s3);
+                    f2 = fma(fma(fma(fma(f2, 1.37, s0), 1.37, s1), 1.37, s2), 1.37, s3);   // weights 1.37^k: ONE constant in a register, not sixteen
+                }
+                // (absolute bounds: the equilibrated entries live on the scale of a diagonal of order one, and so does their rounding noise — a lane off the
+                //  diagonal sums sixteen entries of either sign to next to nothing, and a bound relative to that sum never passes)
+                const bool lane_same = fabs(f1 - lzp1) <= RXHIP_FZ_LANE_TOL && fabs(f2 - lzp2) <= 26.0 * RXHIP_FZ_LANE_TOL;   // Σ 1.37^k = 26 · 16
+                lzp1 = f1;
+                lzp2 = f2;
+                const bool wave_same = __all(lane_same) != 0;
+                if (lane == 0) fz[10 + ws] = wave_same ? 1.0 : 0.0;   // (an invalid exponent gives inf / NaN: never "same")
+                lds_barrier();
+            }
+        }
         if constexpr (FROZEN) {
             if (p.mseg == 0) {
                 double g1 = 0.0, g2 = 0.0;

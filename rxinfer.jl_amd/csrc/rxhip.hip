@@ -27,6 +27,7 @@
 #include "drift_kernels.hpp"
 #include "generic_kernels.hpp"
 #include "graph_lowering.hpp"
+#include "tree_engine.hpp"
 
 using namespace rxhip;
 
@@ -151,7 +152,8 @@ struct rxhip_engine {
     int* d_status = nullptr;
     double* d_fe_blocks = nullptr;
     // Gaussian-mixture VMP engine (kind == 1)
-    int kind = 0;  // 0: LGSSM, 1: GMM, 2: HGF, 3: noise-free drift chain
+    int kind = 0;  // 0: LGSSM, 1: GMM, 2: HGF, 3: noise-free drift chain, 5: the level-scheduled node-array executor (tree_engine.hip; everything lives behind `tree`)
+    rxhip::tree::Engine* tree = nullptr;
     struct Drift { double m0 = 0, v0 = 1, c = 0, obs_var = 1; } dr;
     struct Hgf {
         rxhip_hgf_desc ds;
@@ -588,6 +590,8 @@ static rxhip_status fail(rxhip_engine* e, rxhip_status s, const char* fmt, ...) 
     }
     return s;
 }
+// entry points of the state-space / mixture engines, called on an engine of the node-array executor
+#define TREE_GUARD(e) do { if ((e) && (e)->tree) return fail((e), RXHIP_ERR_UNSUPPORTED, "%s: not available on an engine of the node-array executor (rxhip_tree_* entry points)", __func__); } while (0)
 // a temporary device block that is freed on every path out of its scope (early HIPCHK returns included)
 struct DevTmp {
     void* p = nullptr;
@@ -740,6 +744,15 @@ static void mTm(int n, int m, int k, const double* A, const double* B, double* C
         }
     }
 }
+// two iterates of a recursion over symmetric positive (semi)definite matrices agree to rounding: every entry on the scale of its own row and column
+static bool spd_same(int n, const double* x, const double* y, double tol) {
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j < n; ++j) {
+            const double sc = std::sqrt(std::fabs(x[(size_t)i * n + i] * x[(size_t)j * n + j]));
+            if (!(std::fabs(x[(size_t)i * n + j] - y[(size_t)i * n + j]) <= tol * sc)) return false;
+        }
+    return true;
+}
 static void pack_sym(int n, const double* A, double* out) {
     for (int i = 0; i < n; ++i)
         for (int j = 0; j <= i; ++j) out[sidx(i, j)] = 0.5 * (A[i * n + j] + A[j * n + i]);
@@ -761,14 +774,11 @@ static bool build_scan_matrices(int d, int S, const HostAgg& a0, const HostAgg& 
     M1.assign(n, 0.0); M2.assign(n, 0.0); Vb.assign(n, 0.0); N1.assign(n, 0.0); N2.assign(n, 0.0); Lb.assign(n, 0.0);
     std::vector<double> Vc(Vf1, Vf1 + MM), Vi(MM), W(MM), tt(MM), m1(MM), m2(MM), Vprev(MM, 0.0);
     auto at = [MM](std::vector<double>& t, int s) { return t.data() + (size_t)s * MM; };
-    // Both recursions are Riccati maps of a time-invariant model: once an iterate reproduces its predecessor to rounding (|Δ| ≤ 2⁻⁵⁰ of the largest
-    // entry — an exact fixed point is never reached bit for bit, the last bit keeps flickering) every later segment takes the previous segment's
-    // maps — a chain cut into 250 short segments costs what its first few dozen do.
-    auto same = [MM](const std::vector<double>& x, const std::vector<double>& y) {
-        double amax = 0.0, dmax = 0.0;
-        for (size_t q = 0; q < MM; ++q) { amax = std::max(amax, std::fabs(x[q])); dmax = std::max(dmax, std::fabs(x[q] - y[q])); }
-        return dmax <= 8.9e-16 * amax;
-    };
+    // Both recursions are Riccati maps of a time-invariant model: once an iterate reproduces its predecessor to rounding every later segment takes
+    // the previous segment's maps — a chain cut into 250 short segments costs what its first few dozen do.  "To rounding" is decided ENTRY BY
+    // ENTRY on each entry's own scale, |Δ_ij| ≤ 1e-13 sqrt(x_ii x_jj) (host::spd_same): relative to the largest entry (rounds 2–4) the test was blind
+    // to a slowly converging block whose units put it decades below another one (tests/test_fixed_point_adversarial_gpu.py).
+    auto same = [d](const std::vector<double>& x, const std::vector<double>& y) { return host::spd_same(d, x.data(), y.data(), 1e-13); };
     bool conv = false;
     for (int s = 0; s < S; ++s) {
         std::memcpy(at(Vb, s), Vc.data(), sizeof(double) * MM);
@@ -1500,17 +1510,10 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
         for (int s = 0; s < S_; ++s) canon[(size_t)q * S_ + s] = s;
     if (S_ > 0) {
         // Both recursions below are Riccati iterations with constant coefficients: after a transient of a few segments the
-        // boundary covariance (precision) stops changing, and with it the maps.  Once two consecutive boundaries agree to
-        // 1e-14 (relative, max norm) the remaining segments reuse the converged maps — the tables of a d = 64, S = 250
-        // engine otherwise cost ≈1.5 GFLOP of host arithmetic per create.
-        auto same = [&](const std::vector<double>& a, const std::vector<double>& b) {
-            double dmax = 0.0, amax = 0.0;
-            for (size_t q = 0; q < MM; ++q) {
-                dmax = std::max(dmax, std::fabs(a[q] - b[q]));
-                amax = std::max(amax, std::fabs(a[q]));
-            }
-            return dmax <= 1e-14 * amax;
-        };
+        // boundary covariance (precision) stops changing, and with it the maps.  Once two consecutive boundaries agree entry by entry,
+        // |Δ_ij| ≤ 1e-13 sqrt(a_ii a_jj) (each entry on its own scale — host::spd_same), the remaining segments reuse the converged
+        // maps — the tables of a d = 64, S = 250 engine otherwise cost ≈1.5 GFLOP of host arithmetic per create.
+        auto same = [&](const std::vector<double>& a, const std::vector<double>& b) { return host::spd_same(d, a.data(), b.data(), 1e-13); };
         std::vector<double> Vc = Vf1, Vi(MM), W(MM), M1(MM), M2(MM), tt(MM), Vprev(MM);
         bool conv = false;
         for (int s = 0; s < S_; ++s) {
@@ -1835,6 +1838,11 @@ rxhip_status rxhip_release_cached_memory(void) {
 
 rxhip_status rxhip_destroy(rxhip_engine* e) {
     if (!e) return RXHIP_OK;
+    if (e->tree) {
+        rxhip::tree::destroy(e->tree);
+        delete e;
+        return RXHIP_OK;
+    }
     if (!e->pool_key.empty() && e->err.empty() && !e->profiling && e->pending.empty() && e->stream && engine_pool_on()) {
         DevGuard dg;
         if (e->device >= 0) (void)dg.set(e->device);
@@ -1885,6 +1893,7 @@ static void offsets_to_shifts(rxhip_engine* e, const double* cx, const double* c
 }
 
 rxhip_status rxhip_lgssm_set_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset) {
+    TREE_GUARD(e);
     if (!e || e->kind != 0) return RXHIP_ERR_BADARG;
     if (!e->d_mu) return fail(e, RXHIP_ERR_STATE, "set_offsets: the engine was created without offsets (pass zero arrays at creation to reserve them)");
     if (e->off_chain) return fail(e, RXHIP_ERR_STATE, "set_offsets: this engine carries per-chain inputs (rxhip_lgssm_set_chain_offsets)");
@@ -1903,6 +1912,7 @@ rxhip_status rxhip_lgssm_set_offsets(rxhip_engine* e, const double* state_offset
 }
 
 rxhip_status rxhip_lgssm_set_chain_offsets(rxhip_engine* e, const double* state_offset, const double* obs_offset, int32_t layout) {
+    TREE_GUARD(e);
     if (!e || e->kind != 0) return RXHIP_ERR_BADARG;
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME) return fail(e, RXHIP_ERR_BADARG, "set_chain_offsets: unknown layout %d", layout);
     if (!e->d_mu) return fail(e, RXHIP_ERR_STATE, "set_chain_offsets: the engine was created without offsets (pass zero arrays at creation to reserve them)");
@@ -2586,12 +2596,14 @@ rxhip_status rxhip_lgssm_noise_create(const rxhip_lgssm_desc* ds, const rxhip_no
 }
 
 rxhip_status rxhip_lgssm_noise_continue(rxhip_engine* e, int32_t on) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (!e->noise) return fail(e, RXHIP_ERR_BADARG, "noise_continue: not an engine with an unknown noise precision");
     e->noise_continue = on != 0;
     return RXHIP_OK;
 }
 rxhip_status rxhip_lgssm_noise_get(rxhip_engine* e, double* nu, double* V) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (!e->noise) return fail(e, RXHIP_ERR_BADARG, "noise_get: not an engine with an unknown noise precision");
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "noise_get: no run yet");
@@ -2741,6 +2753,7 @@ rxhip_status rxhip_mvgmm_create(const rxhip_mvgmm_desc* ds, rxhip_engine** out) 
 }
 
 rxhip_status rxhip_gmm_begin_run(rxhip_engine* e, int32_t iterations) {
+    TREE_GUARD(e);
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (iterations <= 0) return fail(e, RXHIP_ERR_BADARG, "run: iterations must be positive");
     if (!e->have_data) return fail(e, RXHIP_ERR_STATE, "run: no observations (call rxhip_set_data first)");
@@ -2770,6 +2783,7 @@ rxhip_status rxhip_gmm_begin_run(rxhip_engine* e, int32_t iterations) {
     return RXHIP_OK;
 }
 rxhip_status rxhip_gmm_accumulate(rxhip_engine* e) {
+    TREE_GUARD(e);
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (e->g.it >= e->g.iterations) return fail(e, RXHIP_ERR_STATE, "accumulate: no iteration left (call rxhip_gmm_begin_run)");
     SET_DEVICE(e);
@@ -2797,12 +2811,14 @@ rxhip_status rxhip_gmm_accumulate(rxhip_engine* e) {
     return RXHIP_OK;
 }
 rxhip_status rxhip_gmm_statistics_device(rxhip_engine* e, double** stats_dev, int32_t* n) {
+    TREE_GUARD(e);
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (stats_dev) *stats_dev = e->g.d_totals;
     if (n) *n = e->g.nq;
     return RXHIP_OK;
 }
 rxhip_status rxhip_gmm_update(rxhip_engine* e, int32_t want_fe) {
+    TREE_GUARD(e);
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     if (e->g.it >= e->g.iterations) return fail(e, RXHIP_ERR_STATE, "update: no iteration left");
     SET_DEVICE(e);
@@ -2829,6 +2845,7 @@ rxhip_status rxhip_gmm_update(rxhip_engine* e, int32_t want_fe) {
     return RXHIP_OK;
 }
 rxhip_status rxhip_gmm_get_history(rxhip_engine* e, double* hist) {
+    TREE_GUARD(e);
     if (!e || e->kind != 1 || !hist) return RXHIP_ERR_BADARG;
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_history: no run yet");
     SET_DEVICE(e);
@@ -2837,6 +2854,7 @@ rxhip_status rxhip_gmm_get_history(rxhip_engine* e, double* hist) {
     return RXHIP_OK;
 }
 rxhip_status rxhip_gmm_get_responsibilities(rxhip_engine* e, double* resp) {
+    TREE_GUARD(e);
     if (!e || e->kind != 1 || !resp) return RXHIP_ERR_BADARG;
     if (!e->g.materialize) return fail(e, RXHIP_ERR_STATE, "responsibilities were not materialised (desc.materialize_responsibilities)");
     if (!e->ran || e->g.it < e->g.iterations) return fail(e, RXHIP_ERR_STATE, "get_responsibilities: run not finished");
@@ -3120,7 +3138,62 @@ rxhip_status rxhip_graph_lower_hgf(const rxhip_graph_desc* g, rxhip_hgf_lowered*
     return RXHIP_OK;
 }
 
+// the node-array executor behind an rxhip_engine handle (everything lives behind e->tree)
+rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* stream, rxhip_engine** out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    *out = nullptr;
+    rxhip::tree::Engine* t = nullptr;
+    std::string err;
+    const rxhip_status st = rxhip::tree::create(g, device, stream, &t, err);
+    if (st) { rxhip_lower::last_error() = err; return st; }
+    rxhip_engine* e = new rxhip_engine();
+    e->kind = 5;
+    e->tree = t;
+    e->device = rxhip::tree::device_of(t);
+    e->n_chains = g->n_replicas > 0 ? g->n_replicas : 1;
+    *out = e;
+    return RXHIP_OK;
+}
+rxhip_status rxhip_tree_set_data(rxhip_engine* e, const int64_t* vars, int64_t n_vars, const double* host) {
+    if (!e || !e->tree) return e ? fail(e, RXHIP_ERR_BADARG, "rxhip_tree_set_data: not an engine of the node-array executor") : RXHIP_ERR_BADARG;
+    e->err.clear();
+    return rxhip::tree::set_data(e->tree, vars, n_vars, host, e->err);
+}
+rxhip_status rxhip_tree_get_marginals(rxhip_engine* e, const int64_t* vars, int64_t n_vars, double* mean, double* cov) {
+    if (!e || !e->tree) return e ? fail(e, RXHIP_ERR_BADARG, "rxhip_tree_get_marginals: not an engine of the node-array executor") : RXHIP_ERR_BADARG;
+    e->err.clear();
+    return rxhip::tree::get_marginals(e->tree, vars, n_vars, mean, cov, e->err);
+}
+rxhip_status rxhip_tree_get_precision(rxhip_engine* e, int64_t var, double* nu, double* V) {
+    if (!e || !e->tree) return e ? fail(e, RXHIP_ERR_BADARG, "rxhip_tree_get_precision: not an engine of the node-array executor") : RXHIP_ERR_BADARG;
+    e->err.clear();
+    return rxhip::tree::get_precision(e->tree, var, nu, V, e->err);
+}
+rxhip_status rxhip_tree_get_info(rxhip_engine* e, rxhip_tree_info* out) {
+    if (!e || !e->tree || !out) return RXHIP_ERR_BADARG;
+    rxhip::tree::info(e->tree, out);
+    return RXHIP_OK;
+}
+rxhip_status rxhip_rule_eval(const rxhip_rule_call* call, int32_t device) {
+    std::string err;
+    const rxhip_status st = rxhip::tree::rule_eval(call, device, err);
+    if (st) rxhip_lower::last_error() = err;   // (no handle to hang the text on: rxhip_lowering_error() returns it)
+    return st;
+}
+
+static rxhip_status create_pattern_matched(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out);
 rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out) {
+    if (!out) return RXHIP_ERR_BADARG;
+    // the pattern matcher first: its engines are the fast paths of the families they know; every graph it has no schedule for goes to the
+    // level-scheduled node-array executor, and only what THAT rejects (a cycle, a non-Gaussian node it has no rule for) is RXHIP_ERR_UNSUPPORTED
+    rxhip_status st = create_pattern_matched(g, segments, device, stream, out);
+    if (st != RXHIP_ERR_UNSUPPORTED || (out && *out)) return st;
+    const std::string why = rxhip_lower::last_error();
+    st = rxhip_tree_create(g, device, stream, out);
+    if (st == RXHIP_ERR_UNSUPPORTED) rxhip_lower::last_error() = why + " | node-array executor: " + rxhip_lower::last_error();
+    return st;
+}
+static rxhip_status create_pattern_matched(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out) {
     if (!out) return RXHIP_ERR_BADARG;
     *out = nullptr;
     if (rxhip_status st0 = rxhip_lower::check_tables(g)) return st0;
@@ -3318,12 +3391,14 @@ static rxhip_status ingest_inputs(rxhip_engine* e, const double* u, size_t n, in
 }
 
 rxhip_status rxhip_set_data(rxhip_engine* e, int32_t var_id, const double* host, size_t n, int32_t layout) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (var_id == RXHIP_VAR_U) return ingest_inputs(e, host, n, layout);
     if (var_id != RXHIP_VAR_Y) return fail(e, RXHIP_ERR_BADARG, "set_data: variable %d is not a data variable", var_id);
     return ingest(e, host, n, layout, false);
 }
 rxhip_status rxhip_set_data_device(rxhip_engine* e, int32_t var_id, const double* dev, size_t n, int32_t layout) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (var_id != RXHIP_VAR_Y) return fail(e, RXHIP_ERR_BADARG, "set_data: variable %d is not a data variable", var_id);
     return ingest(e, dev, n, layout, true);
@@ -3372,18 +3447,24 @@ static rxhip_status prof_end(rxhip_engine* e) {
 }
 
 static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_fe, bool filter);
-rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) { return run_impl(e, iterations, want_fe, false); }
+rxhip_status rxhip_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
+    if (e && e->tree) return rxhip_run(e, iterations, want_fe);
+    return run_impl(e, iterations, want_fe, false);
+}
 rxhip_status rxhip_run_filter_async(rxhip_engine* e, int32_t want_fe) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "run_filter: not a state-space engine with a streaming twin (the HGF engine is a filter already)");
     return run_impl(e, 1, want_fe, true);
 }
 rxhip_status rxhip_filter_reset(rxhip_engine* e) {
+    TREE_GUARD(e);
     if (!e || e->kind != 0) return RXHIP_ERR_BADARG;
     e->stream_k = 0;
     return RXHIP_OK;
 }
 rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, double* cov, double* free_energy) {
+    TREE_GUARD(e);
     if (!e || !y) return RXHIP_ERR_BADARG;
     if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "filter_step: not a state-space engine");
     if (!e->dense && !e->vt) return fail(e, RXHIP_ERR_UNSUPPORTED, "filter_step: no device schedule for this shape");
@@ -3428,6 +3509,7 @@ rxhip_status rxhip_filter_step(rxhip_engine* e, const double* y, double* mean, d
     return RXHIP_OK;
 }
 rxhip_status rxhip_run_filter(rxhip_engine* e, int32_t want_fe) {
+    TREE_GUARD(e);
     rxhip_status st = rxhip_run_filter_async(e, want_fe);
     if (st) return st;
     return rxhip_sync(e);
@@ -3727,6 +3809,7 @@ static rxhip_status ensure_cov(rxhip_engine* e) {
     return RXHIP_OK;
 }
 rxhip_status rxhip_set_covariance_mode(rxhip_engine* e, int32_t mode) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (mode != 0 && mode != 1) return fail(e, RXHIP_ERR_BADARG, "set_covariance_mode: mode must be 0 (every sweep) or 1 (on request)");
     if (rxhip_status st = ensure_cov(e)) return st;
@@ -3735,6 +3818,7 @@ rxhip_status rxhip_set_covariance_mode(rxhip_engine* e, int32_t mode) {
 }
 rxhip_status rxhip_sync(rxhip_engine* e) {
     if (!e) return RXHIP_ERR_BADARG;
+    if (e->tree) return rxhip::tree::sync(e->tree, e->err);
     SET_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
     if (rxhip_status pst = prof_drain(e, true)) return pst;
@@ -3750,6 +3834,10 @@ rxhip_status rxhip_sync(rxhip_engine* e) {
 }
 
 rxhip_status rxhip_run(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
+    if (e && e->tree) {   // (synchronous: the drivers read the results immediately, src/inference/batch.jl:415)
+        e->err.clear();
+        return rxhip::tree::run(e->tree, iterations, want_fe, e->err);
+    }
     rxhip_status st = rxhip_run_async(e, iterations, want_fe);
     if (st) return st;
     return rxhip_sync(e);
@@ -3757,6 +3845,8 @@ rxhip_status rxhip_run(rxhip_engine* e, int32_t iterations, int32_t want_fe) {
 
 rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32_t iterations, int32_t want_fe, int32_t filtering,
                                double* mean, double* cov, double* fe_per_chain) {
+    TREE_GUARD(e);
+    TREE_GUARD(e);
     if (!e || !y) return RXHIP_ERR_BADARG;
     if (e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "infer: not a state-space engine");
     const size_t C = (size_t)e->n_chains, ny = (size_t)e->T * C * e->dy, nm = (size_t)e->Tout() * C * e->d, nc = nm * e->d;
@@ -3826,6 +3916,8 @@ rxhip_status rxhip_lgssm_infer(rxhip_engine* e, const double* y, size_t n, int32
 
 rxhip_status rxhip_get_marginals_device(rxhip_engine* e, int32_t var_id, const double** mean_dev,
                                         const double** cov_dev) {
+    TREE_GUARD(e);
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (var_id != RXHIP_VAR_X || (e->kind != 0 && e->kind != 3)) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals: no run yet");
@@ -3855,6 +3947,8 @@ static rxhip_status copy_out(rxhip_engine* e, const double* dsrc, double* host, 
 
 rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_var, double* x_mean, double* x_var,
                                    int32_t layout) {
+    TREE_GUARD(e);
+    TREE_GUARD(e);
     if (!e || e->kind != 2) return RXHIP_ERR_BADARG;
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_history: no run yet");
     if (layout != RXHIP_LAYOUT_TIME_CHAIN && layout != RXHIP_LAYOUT_CHAIN_TIME)
@@ -3871,6 +3965,7 @@ rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_va
 }
 
 rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (var_id != RXHIP_VAR_X || (e->kind != 0 && e->kind != 3)) return fail(e, RXHIP_ERR_BADARG, "get_marginals: variable %d is not random", var_id);
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals: no run yet");
@@ -3899,6 +3994,7 @@ rxhip_status rxhip_get_marginals(rxhip_engine* e, int32_t var_id, double* mean, 
 }
 
 rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean, double* cov, int32_t layout) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (var_id != RXHIP_VAR_Y || e->kind != 0) return fail(e, RXHIP_ERR_BADARG, "get_predictions: variable %d is not a data variable of a state-space engine", var_id);
     if (!e->ran || e->last_filter) return fail(e, RXHIP_ERR_STATE, "get_predictions: needs a smoothing run (rxhip_run) first");
@@ -3946,6 +4042,7 @@ rxhip_status rxhip_get_predictions(rxhip_engine* e, int32_t var_id, double* mean
 }
 
 rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double* mean, double* cov, int32_t layout) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (node_type != RXHIP_NODE_MVNORMAL_MEAN_COV || e->kind != 0)
         return fail(e, RXHIP_ERR_BADARG, "get_node_marginals: node-local joints exist for the transition nodes of a state-space engine");
@@ -4022,6 +4119,7 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
 
 rxhip_status rxhip_get_free_energy(rxhip_engine* e, double* per_iteration) {
     if (!e || !per_iteration) return RXHIP_ERR_BADARG;
+    if (e->tree) return rxhip::tree::get_free_energy(e->tree, per_iteration, e->err);
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     SET_DEVICE(e);
     HIPCHK(e, hipStreamSynchronize(e->stream));
@@ -4031,6 +4129,7 @@ rxhip_status rxhip_get_free_energy(rxhip_engine* e, double* per_iteration) {
 }
 rxhip_status rxhip_get_free_energy_per_chain(rxhip_engine* e, double* per_chain) {
     if (!e || !per_chain) return RXHIP_ERR_BADARG;
+    if (e->tree) return rxhip::tree::get_free_energy_per_replica(e->tree, per_chain, e->err);
     if (e->kind == 1) return fail(e, RXHIP_ERR_BADARG, "per-chain free energy is not defined for the mixture engine");
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     SET_DEVICE(e);
@@ -4039,6 +4138,7 @@ rxhip_status rxhip_get_free_energy_per_chain(rxhip_engine* e, double* per_chain)
     return RXHIP_OK;
 }
 rxhip_status rxhip_get_free_energy_device(rxhip_engine* e, double** fe_dev) {
+    TREE_GUARD(e);
     if (!e || !fe_dev) return RXHIP_ERR_BADARG;
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     *fe_dev = (e->kind == 1 ? e->g.d_fe : e->kind == 2 ? e->h.d_fe_total : e->d_fe_total) + (e->last_iterations - 1);
@@ -4046,6 +4146,7 @@ rxhip_status rxhip_get_free_energy_device(rxhip_engine* e, double** fe_dev) {
 }
 
 rxhip_status rxhip_copy_free_energy_to_device(rxhip_engine* e, double* dst_dev) {
+    TREE_GUARD(e);
     if (!e || !dst_dev) return RXHIP_ERR_BADARG;
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     SET_DEVICE(e);
@@ -4056,6 +4157,7 @@ rxhip_status rxhip_copy_free_energy_to_device(rxhip_engine* e, double* dst_dev) 
 
 rxhip_status rxhip_counters(rxhip_engine* e, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals) {
     if (!e) return RXHIP_ERR_BADARG;
+    if (e->tree) { rxhip::tree::counters(e->tree, rule_calls, products, marginals); return RXHIP_OK; }
     if (rule_calls) *rule_calls = e->rule_calls;
     if (products) *products = e->products;
     if (marginals) *marginals = e->marginals;
@@ -4063,6 +4165,7 @@ rxhip_status rxhip_counters(rxhip_engine* e, uint64_t* rule_calls, uint64_t* pro
 }
 
 rxhip_status rxhip_set_profiling(rxhip_engine* e, int32_t enabled) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     e->profiling = enabled != 0;
     if (e->profiling) {   // the events a profiled run needs (64 pending pairs at most) exist before it starts: no hipEventCreate inside a timed region
@@ -4076,6 +4179,7 @@ rxhip_status rxhip_set_profiling(rxhip_engine* e, int32_t enabled) {
     return RXHIP_OK;
 }
 rxhip_status rxhip_get_kernel_times(rxhip_engine* e, double* ms_avg, uint64_t* launches) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     for (int k = 0; k < RXHIP_K_COUNT; ++k) {
         if (ms_avg) ms_avg[k] = e->k_n[k] ? e->k_ms[k] / (double)e->k_n[k] : 0.0;
@@ -4084,11 +4188,13 @@ rxhip_status rxhip_get_kernel_times(rxhip_engine* e, double* ms_avg, uint64_t* l
     return RXHIP_OK;
 }
 rxhip_status rxhip_get_create_stages(rxhip_engine* e, double* ms4) {
+    TREE_GUARD(e);
     if (!e || !ms4) return RXHIP_ERR_BADARG;
     for (int q = 0; q < STAGE_COUNT; ++q) ms4[q] = e->stage_ms[q];
     return RXHIP_OK;
 }
 rxhip_status rxhip_get_model_tables_ms(rxhip_engine* e, double* ms) {
+    TREE_GUARD(e);
     if (!e || !ms) return RXHIP_ERR_BADARG;
     *ms = 0.0;
     if (!e->ev_tab1) return RXHIP_OK;
@@ -4100,6 +4206,7 @@ rxhip_status rxhip_get_model_tables_ms(rxhip_engine* e, double* ms) {
     return RXHIP_OK;
 }
 rxhip_status rxhip_reset_kernel_times(rxhip_engine* e) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     for (int k = 0; k < RXHIP_K_COUNT; ++k) {
         e->k_ms[k] = 0.0;
@@ -4109,10 +4216,12 @@ rxhip_status rxhip_reset_kernel_times(rxhip_engine* e) {
 }
 rxhip_status rxhip_get_stream(rxhip_engine* e, void** stream) {
     if (!e || !stream) return RXHIP_ERR_BADARG;
+    if (e->tree) { *stream = rxhip::tree::stream_of(e->tree); return RXHIP_OK; }
     *stream = (void*)e->stream;
     return RXHIP_OK;
 }
 rxhip_status rxhip_get_schedule(rxhip_engine* e, int32_t* segments, int64_t* segment_len) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (e->kind == 1) {
         if (segments) *segments = e->g.nblocks;
@@ -4127,6 +4236,8 @@ rxhip_status rxhip_get_schedule(rxhip_engine* e, int32_t* segments, int64_t* seg
 
 rxhip_status rxhip_get_marginals_chains(rxhip_engine* e, int32_t var_id, const int64_t* chains, int64_t n, double* mean,
                                         double* cov) {
+    TREE_GUARD(e);
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (var_id != RXHIP_VAR_X || (e->kind != 0 && e->kind != 3)) return fail(e, RXHIP_ERR_BADARG, "get_marginals_chains: variable %d is not random", var_id);
     if (!e->ran) return fail(e, RXHIP_ERR_STATE, "get_marginals_chains: no run yet");
@@ -4291,6 +4402,7 @@ rxhip_status rxhip_comm_destroy(void* comm) {
 }
 
 rxhip_status rxhip_allreduce_free_energy(rxhip_engine* e, void* rccl_comm) {
+    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     double* fe = e->kind == 1 ? e->g.d_fe : e->kind == 2 ? e->h.d_fe_total : e->d_fe_total;
@@ -4298,6 +4410,7 @@ rxhip_status rxhip_allreduce_free_energy(rxhip_engine* e, void* rccl_comm) {
 }
 
 rxhip_status rxhip_gmm_allreduce_statistics(rxhip_engine* e, void* rccl_comm) {
+    TREE_GUARD(e);
     if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
     return ordered_allreduce(e, rccl_comm, e->g.d_totals, e->g.nq, "gmm_allreduce_statistics");
 }

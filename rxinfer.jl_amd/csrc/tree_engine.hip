@@ -1,0 +1,1186 @@
+// tree_engine.hip — host side of the level-scheduled node-array executor (include/rxhip.h "The level-scheduled node-array executor").
+//
+// compile():  rxhip_graph_desc (struct-of-arrays dump of a materialised GraphPPL model)  ->  Program
+//   1. classify the variables: constant, data, precision (random `out` of a Wishart / Gamma prior), derived-clamped (output of a deterministic node
+//      whose inputs are all clamped: a PointMass message in the reference), Gaussian;
+//   2. check the family (node types, constant third interfaces, dimensions) and that the Gaussian variables form a forest (union-find);
+//   3. one message per (factor, Gaussian interface) and direction; structural analysis in dependency order (Kahn): which messages are uniform
+//      (an unobserved leaf sends nothing), which variable → factor messages are aliases (degree 2), the form each message is stored in, its level;
+//   4. ops sorted by level: rules, products, marginals (the sum-product sweep), then the Bethe terms / residual moments, the q(W) updates and the
+//      fixed-order sums of the free energy;
+//   5. slots of the replica-fastest device arrays, the constant pool (matrices, Σ | W | log|W| blocks inverted once on the host, priors).
+// run(): per iteration either one launch per level over all (op, replica) items, or ONE launch in which a workgroup walks all levels for its
+// replicas (deep narrow graphs: a chain is three levels per time step and a launch per level would cost more than the level).
+#include "tree_engine.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+#include <vector>
+
+#include "launch_tables.hpp"   // hook_env
+#include "tree_kernels.hpp"
+
+namespace rxhip {
+namespace tree {
+
+namespace {
+
+struct Fail {
+    rxhip_status st;
+    std::string msg;
+};
+[[noreturn]] void fail(rxhip_status st, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    throw Fail{st, buf};
+}
+
+bool host_chol_inv(int n, const double* A, double* out, double* logdet) {
+    std::vector<double> L((size_t)n * n, 0.0), Li((size_t)n * n, 0.0);
+    double ld = 0.0;
+    for (int j = 0; j < n; ++j) {
+        double s = A[j * n + j];
+        for (int k = 0; k < j; ++k) s -= L[j * n + k] * L[j * n + k];
+        if (!(s > 0.0) || !std::isfinite(s)) return false;
+        L[j * n + j] = std::sqrt(s);
+        ld += std::log(s);
+        for (int i = j + 1; i < n; ++i) {
+            double t = 0.5 * (A[i * n + j] + A[j * n + i]);
+            for (int k = 0; k < j; ++k) t -= L[i * n + k] * L[j * n + k];
+            L[i * n + j] = t / L[j * n + j];
+        }
+    }
+    for (int j = 0; j < n; ++j) {
+        Li[j * n + j] = 1.0 / L[j * n + j];
+        for (int i = j + 1; i < n; ++i) {
+            double t = 0.0;
+            for (int k = j; k < i; ++k) t += L[i * n + k] * Li[k * n + j];
+            Li[i * n + j] = -t / L[i * n + i];
+        }
+    }
+    for (int i = 0; i < n; ++i)
+        for (int j = 0; j <= i; ++j) {
+            double t = 0.0;
+            for (int k = i; k < n; ++k) t += Li[k * n + i] * Li[k * n + j];
+            out[i * n + j] = out[j * n + i] = t;
+        }
+    if (logdet) *logdet = ld;
+    return true;
+}
+double host_digamma(double x) {
+    double r = 0.0;
+    while (x < 6.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    return r + std::log(x) - 0.5 / x - f * (1.0 / 12.0 - f * (1.0 / 120.0 - f * (1.0 / 252.0 - f * (1.0 / 240.0 - f * (1.0 / 132.0)))));
+}
+
+enum VarClass { VC_CONST = 0, VC_DATA = 1, VC_DERIVED = 2, VC_PREC = 3, VC_GAUSS = 4 };
+enum NodeClass { NC_NOISE = 0, NC_MUL = 1, NC_ADD = 2, NC_PRIOR = 3 };
+
+struct Program {
+    int dmax = 1;
+    std::vector<int> ops, aux, lvl_ptr;
+    std::vector<double> cpool;
+    long long msg_doubles = 0, marg_doubles = 0, val_doubles = 0, data_doubles = 0, prec_doubles = 0, term_slots = 0, stat_doubles = 0;
+    int fe_root = -1;
+    int n_ops = 0, n_levels = 0, n_messages = 0;
+    std::vector<int> dim, vclass, marg_off, val_off, prec_off;
+    std::vector<int64_t> data_vars;
+    std::vector<double> prec_init;   // [prec_doubles] initial state (replica-independent)
+    uint64_t rule_calls = 0, products = 0, marginals = 0;
+    long long bytes_per_sweep = 0;
+    int max_width = 0;
+};
+
+struct Compiler {
+    const rxhip_graph_desc* g;
+    Program& P;
+    int64_t nv, nf;
+    std::vector<int64_t> iptr;          // CSR of factor interfaces
+    const int64_t* ifv;
+    std::vector<int> nclass;
+    // edges: (factor, interface) with a Gaussian variable
+    struct Edge { int f, k, v; };
+    std::vector<Edge> edges;
+    std::vector<std::vector<int>> var_edges;      // per variable: its edges in factor order
+    std::vector<std::vector<int>> fac_edges;      // per factor: edge id per interface (−1)
+    // message m: f2v(e) = e, v2f(e) = E + e
+    int E = 0;
+    std::vector<char> null_, needed, form, done;
+    std::vector<int> alias, off, level;
+    std::vector<std::vector<int>> deps, users;
+    std::vector<int> cval_off, cmat_off, noise_off, prior_off;   // constant-pool offsets per variable (−1)
+    struct OpRec { int level; int w[OP_WORDS]; };
+    std::vector<OpRec> recs;
+
+    Compiler(const rxhip_graph_desc* g_, Program& p) : g(g_), P(p) {}
+
+    int64_t iface(int f, int k) const { return ifv[iptr[f] + k]; }
+    int n_iface(int f) const { return (int)(iptr[f + 1] - iptr[f]); }
+    bool clamped(int v) const { return P.vclass[v] == VC_CONST || P.vclass[v] == VC_DATA || P.vclass[v] == VC_DERIVED; }
+    int msz(int d) const { return d + d * (d + 1) / 2; }
+
+    const double* cptr(int v) const { return g->const_pool + g->var_const[v]; }
+    int const_value(int v) {   // vector value of a constant variable in the pool
+        if (cval_off[v] < 0) {
+            cval_off[v] = (int)P.cpool.size();
+            const int n = g->var_rows[v] * g->var_cols[v];
+            P.cpool.insert(P.cpool.end(), cptr(v), cptr(v) + n);
+        }
+        return cval_off[v];
+    }
+    int const_matrix(int v, int rows, int cols) {
+        if ((int64_t)g->var_rows[v] * g->var_cols[v] != (int64_t)rows * cols) fail(RXHIP_ERR_BADARG, "constant %d: %d x %d expected", v, rows, cols);
+        return const_value(v);
+    }
+    int noise_block(int v, int d, bool is_precision) {   // Σ | W | log|W|
+        if (noise_off[v] >= 0) return noise_off[v];
+        if ((int64_t)g->var_rows[v] * g->var_cols[v] != (int64_t)d * d) fail(RXHIP_ERR_BADARG, "noise parameter %d: %d x %d expected", v, d, d);
+        std::vector<double> M(cptr(v), cptr(v) + (size_t)d * d), Mi((size_t)d * d);
+        double amax = 0.0, asym = 0.0;
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j < d; ++j) {
+                amax = std::max(amax, std::fabs(M[i * d + j]));
+                asym = std::max(asym, std::fabs(M[i * d + j] - M[j * d + i]));
+            }
+        if (!(asym <= 1e-12 * amax)) fail(RXHIP_ERR_NOT_POSDEF, "noise parameter %d is not symmetric", v);
+        double ld = 0.0;
+        if (!host_chol_inv(d, M.data(), Mi.data(), &ld)) fail(RXHIP_ERR_NOT_POSDEF, "noise parameter %d is not positive definite", v);
+        noise_off[v] = (int)P.cpool.size();
+        const std::vector<double>&Sg = is_precision ? Mi : M, &W = is_precision ? M : Mi;
+        P.cpool.insert(P.cpool.end(), Sg.begin(), Sg.end());
+        P.cpool.insert(P.cpool.end(), W.begin(), W.end());
+        P.cpool.push_back(is_precision ? ld : -ld);
+        return noise_off[v];
+    }
+
+    void parse() {
+        nv = g->n_variables;
+        nf = g->n_factors;
+        if (nv <= 0 || nf <= 0 || !g->var_kind || !g->var_rows || !g->var_cols || !g->var_const || !g->factor_type || !g->factor_iface)
+            fail(RXHIP_ERR_BADARG, "graph descriptor: missing tables");
+        if (nv > (1ll << 28) || nf > (1ll << 28)) fail(RXHIP_ERR_UNSUPPORTED, "graph too large for the executor's 32-bit tables");
+        iptr.resize(nf + 1);
+        for (int64_t f = 0; f <= nf; ++f) iptr[f] = g->factor_iface_ptr ? g->factor_iface_ptr[f] : 3 * f;
+        ifv = g->factor_iface;
+        P.dim.assign(nv, 0);
+        P.vclass.assign(nv, VC_GAUSS);
+        nclass.assign(nf, -1);
+        for (int64_t v = 0; v < nv; ++v) {
+            P.dim[v] = g->var_rows[v];
+            const int k = g->var_kind[v];
+            if (k == RXHIP_VARKIND_CONST) {
+                P.vclass[v] = VC_CONST;
+                if (g->var_const[v] < 0 || g->var_const[v] + (int64_t)g->var_rows[v] * g->var_cols[v] > g->n_const) fail(RXHIP_ERR_BADARG, "constant %lld: value outside the pool", (long long)v);
+            } else if (k == RXHIP_VARKIND_DATA) P.vclass[v] = VC_DATA;
+            else if (k != RXHIP_VARKIND_RANDOM) fail(RXHIP_ERR_BADARG, "variable %lld: unknown kind %d", (long long)v, k);
+            if (g->var_rows[v] < 1) fail(RXHIP_ERR_BADARG, "variable %lld: no rows", (long long)v);
+        }
+        for (int64_t f = 0; f < nf; ++f) {
+            const int t = g->factor_type[f];
+            for (int k = 0; k < n_iface((int)f); ++k)
+                if (iface((int)f, k) < 0 || iface((int)f, k) >= nv) fail(RXHIP_ERR_BADARG, "factor %lld: interface %d names no variable", (long long)f, k);
+            switch (t) {
+            case RXHIP_NODE_MVNORMAL_MEAN_COV: case RXHIP_NODE_NORMAL_MEAN_VARIANCE: case RXHIP_NODE_MVNORMAL_MEAN_PRECISION: case RXHIP_NODE_NORMAL_MEAN_PRECISION:
+                nclass[f] = NC_NOISE; break;
+            case RXHIP_NODE_MULTIPLY: nclass[f] = NC_MUL; break;
+            case RXHIP_NODE_ADD: nclass[f] = NC_ADD; break;
+            case RXHIP_NODE_WISHART: case RXHIP_NODE_GAMMA_SHAPE_RATE: case RXHIP_NODE_GAMMA_SHAPE_SCALE: nclass[f] = NC_PRIOR; break;
+            default: fail(RXHIP_ERR_UNSUPPORTED, "node type %d is outside the Gaussian tree family of the node-array executor", t);
+            }
+            if (n_iface((int)f) != 3) fail(RXHIP_ERR_BADARG, "factor %lld: three interfaces expected", (long long)f);
+        }
+        // precision variables
+        for (int64_t f = 0; f < nf; ++f)
+            if (nclass[f] == NC_PRIOR) {
+                const int v = (int)iface((int)f, 0);
+                if (g->var_kind[v] != RXHIP_VARKIND_RANDOM) fail(RXHIP_ERR_UNSUPPORTED, "a Wishart / Gamma node with a clamped output has no schedule");
+                if (P.vclass[v] == VC_PREC) fail(RXHIP_ERR_UNSUPPORTED, "precision variable %d has two priors", v);
+                P.vclass[v] = VC_PREC;
+                for (int k = 1; k < 3; ++k)
+                    if (P.vclass[iface((int)f, k)] != VC_CONST) fail(RXHIP_ERR_UNSUPPORTED, "Wishart / Gamma priors need constant parameters");
+            }
+        // derived clamped values
+        bool changed = true;
+        while (changed) {
+            changed = false;
+            for (int64_t f = 0; f < nf; ++f) {
+                if (nclass[f] != NC_MUL && nclass[f] != NC_ADD) continue;
+                const int o = (int)iface((int)f, 0);
+                if (P.vclass[o] != VC_GAUSS) continue;
+                const int a = (int)iface((int)f, 1), b = (int)iface((int)f, 2);
+                if (clamped(a) && clamped(b)) { P.vclass[o] = VC_DERIVED; changed = true; }
+            }
+        }
+    }
+
+    void check_family() {
+        int dmx = 1;
+        for (int64_t f = 0; f < nf; ++f) {
+            const int t = g->factor_type[f], a = (int)iface((int)f, 0), b = (int)iface((int)f, 1), c = (int)iface((int)f, 2);
+            if (nclass[f] == NC_NOISE) {
+                const bool prec_node = t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION;
+                if (P.vclass[a] == VC_PREC || P.vclass[b] == VC_PREC) fail(RXHIP_ERR_UNSUPPORTED, "a precision variable on a Gaussian node's out / mean interface");
+                if (P.dim[a] != P.dim[b]) fail(RXHIP_ERR_BADARG, "factor %lld: out and mean differ in dimension", (long long)f);
+                if (P.vclass[c] == VC_PREC) {
+                    if (!prec_node) fail(RXHIP_ERR_UNSUPPORTED, "a random covariance has no rule here (precision-parametrised nodes only)");
+                    if (P.dim[c] != P.dim[a]) fail(RXHIP_ERR_BADARG, "factor %lld: precision variable of another dimension", (long long)f);
+                } else if (P.vclass[c] != VC_CONST) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: the third interface of a Gaussian node must be a constant or a Wishart / Gamma variable", (long long)f);
+                dmx = std::max(dmx, P.dim[a]);
+            } else if (nclass[f] == NC_MUL) {
+                if (P.vclass[b] != VC_CONST) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: `*` needs a constant matrix", (long long)f);
+                if (P.vclass[a] == VC_PREC || P.vclass[c] == VC_PREC) fail(RXHIP_ERR_UNSUPPORTED, "`*` on a precision variable");
+                if ((int64_t)g->var_rows[b] * g->var_cols[b] != (int64_t)P.dim[a] * P.dim[c]) fail(RXHIP_ERR_BADARG, "factor %lld: matrix is not %d x %d", (long long)f, P.dim[a], P.dim[c]);
+                if (P.vclass[a] == VC_GAUSS && P.vclass[c] != VC_GAUSS) fail(RXHIP_ERR_BADARG, "factor %lld: `*` of a clamped input with a random output", (long long)f);
+                if (clamped(a) && P.vclass[a] != VC_DERIVED) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: `*` with an observed output", (long long)f);
+                dmx = std::max(dmx, std::max(P.dim[a], P.dim[c]));
+            } else if (nclass[f] == NC_ADD) {
+                if (P.dim[a] != P.dim[b] || P.dim[a] != P.dim[c]) fail(RXHIP_ERR_BADARG, "factor %lld: `+` of different dimensions", (long long)f);
+                for (int v : {a, b, c})
+                    if (P.vclass[v] == VC_PREC) fail(RXHIP_ERR_UNSUPPORTED, "`+` on a precision variable");
+                if (clamped(a) && P.vclass[a] != VC_DERIVED) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: `+` with an observed output", (long long)f);
+                dmx = std::max(dmx, P.dim[a]);
+            }
+        }
+        if (dmx > 4) fail(RXHIP_ERR_UNSUPPORTED, "the node-array executor runs dimensions <= 4 (this graph: %d)", dmx);
+        P.dmax = dmx <= 1 ? 1 : dmx <= 2 ? 2 : 4;
+    }
+
+    void build_edges() {
+        var_edges.assign(nv, {});
+        fac_edges.assign(nf, std::vector<int>(3, -1));
+        std::vector<int> uf(nv + nf);
+        std::iota(uf.begin(), uf.end(), 0);
+        auto find = [&](int x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
+        for (int64_t f = 0; f < nf; ++f) {
+            if (nclass[f] == NC_PRIOR) continue;
+            for (int k = 0; k < 3; ++k) {
+                if (k == 1 && nclass[f] == NC_MUL) continue;
+                if (k == 2 && nclass[f] == NC_NOISE) continue;
+                const int v = (int)iface((int)f, k);
+                if (P.vclass[v] != VC_GAUSS) continue;
+                const int ra = find(v), rb = find((int)(nv + f));
+                if (ra == rb) fail(RXHIP_ERR_UNSUPPORTED, "the Gaussian variables do not form a tree (a cycle through variable %d): loopy graphs have no exact schedule", v);
+                uf[ra] = rb;
+                fac_edges[f][k] = (int)edges.size();
+                var_edges[v].push_back((int)edges.size());
+                edges.push_back({(int)f, k, v});
+            }
+        }
+        E = (int)edges.size();
+        if (E == 0) fail(RXHIP_ERR_UNSUPPORTED, "no random Gaussian variable in the graph");
+    }
+
+    // ---- dependencies of every message ----
+    void build_deps() {
+        deps.assign(2 * E, {});
+        for (int e = 0; e < E; ++e) {
+            const Edge& ed = edges[e];
+            const int f = ed.f;
+            auto other = [&](int k) { return fac_edges[f][k]; };
+            if (nclass[f] == NC_NOISE) {
+                if (other(1 - ed.k) >= 0) deps[e].push_back(E + other(1 - ed.k));
+            } else if (nclass[f] == NC_MUL) {
+                const int o = other(ed.k == 0 ? 2 : 0);
+                if (o >= 0) deps[e].push_back(E + o);
+                else if (ed.k == 2) fail(RXHIP_ERR_BADARG, "internal: `*` toward its input without a random output");
+            } else {
+                for (int k = 0; k < 3; ++k)
+                    if (k != ed.k && other(k) >= 0) deps[e].push_back(E + other(k));
+            }
+            for (int e2 : var_edges[ed.v])
+                if (e2 != e) deps[E + e].push_back(e2);
+        }
+        users.assign(2 * E, {});
+        for (int m = 0; m < 2 * E; ++m)
+            for (int dpm : deps[m]) users[dpm].push_back(m);
+    }
+
+    // what the rule that consumes v2f(e) reads it as: 0 moment, 1 precision, 2 either
+    int wanted_form(int e) const {
+        const Edge& ed = edges[e];
+        if (nclass[ed.f] == NC_MUL) return ed.k == 2 ? 0 : 1;   // the message from `in` feeds (:out) in moment form; from `out` feeds (:in) in precision form
+        if (nclass[ed.f] == NC_ADD) {
+            int ng = 0;
+            for (int k = 0; k < 3; ++k) ng += fac_edges[ed.f][k] >= 0;
+            return ng == 3 ? 0 : 2;
+        }
+        return 2;
+    }
+    bool factor_uses_v2f(int f) const {
+        int ng = 0;
+        for (int k = 0; k < 3; ++k) ng += fac_edges[f][k] >= 0;
+        return ng >= 2;
+    }
+
+    void analyse() {
+        const int M = 2 * E;
+        null_.assign(M, 0); needed.assign(M, 0); form.assign(M, 1); done.assign(M, 0);
+        alias.assign(M, -1); off.assign(M, -1); level.assign(M, 0);
+        std::vector<int> indeg(M);
+        std::vector<int> q;
+        for (int m = 0; m < M; ++m) { indeg[m] = (int)deps[m].size(); if (!indeg[m]) q.push_back(m); }
+        size_t head = 0;
+        int processed = 0;
+        while (head < q.size()) {
+            const int m = q[head++];
+            ++processed;
+            if (m >= E) {   // variable -> factor
+                const int e = m - E;
+                std::vector<int> live;
+                for (int dpm : deps[m]) if (!null_[dpm]) live.push_back(dpm);
+                needed[m] = factor_uses_v2f(edges[e].f);
+                if (live.empty()) null_[m] = 1;
+                else if (live.size() == 1) { alias[m] = alias[live[0]] >= 0 ? alias[live[0]] : live[0]; form[m] = form[live[0]]; level[m] = level[live[0]]; }
+                else { form[m] = 1; int lv = 0; for (int x : live) lv = std::max(lv, level[x]); level[m] = lv + 1; }
+            } else {        // factor -> variable
+                const Edge& ed = edges[m];
+                needed[m] = 1;
+                int lv = -1;
+                bool any_null = false;
+                for (int dpm : deps[m]) { any_null = any_null || null_[dpm]; lv = std::max(lv, level[dpm]); }
+                level[m] = lv + 1;
+                if (any_null) null_[m] = 1;
+                else if (nclass[ed.f] == NC_NOISE) {
+                    if (deps[m].empty()) {   // leaf: the form its single consumer wants, precision form otherwise
+                        int wf = 2;
+                        if (var_edges[ed.v].size() == 2) {
+                            const int e2 = var_edges[ed.v][0] == m ? var_edges[ed.v][1] : var_edges[ed.v][0];
+                            wf = wanted_form(e2);
+                        }
+                        form[m] = wf == 0 ? 0 : 1;
+                    } else form[m] = form[deps[m][0]];
+                } else if (nclass[ed.f] == NC_MUL) form[m] = ed.k == 0 ? 0 : 1;
+                else form[m] = deps[m].size() == 2 ? 0 : form[deps[m][0]];
+            }
+            done[m] = 1;
+            for (int u : users[m]) if (--indeg[u] == 0) q.push_back(u);
+        }
+        if (processed != M) fail(RXHIP_ERR_UNSUPPORTED, "internal: the message dependencies of this graph are not acyclic");
+        for (int64_t v = 0; v < nv; ++v)
+            if (P.vclass[v] == VC_GAUSS) {
+                bool any = false;
+                for (int e : var_edges[v]) any = any || !null_[e];
+                if (!any) fail(RXHIP_ERR_BADARG, "random variable %lld receives no message (no prior and no data reach it)", (long long)v);
+            }
+    }
+
+    // ---- emission ----
+    int value_source(int v, int& flag_bit) {   // offset + whether it is a per-replica slot
+        if (P.vclass[v] == VC_CONST) { flag_bit = 0; return const_value(v); }
+        flag_bit = 1;
+        return P.val_off[v];
+    }
+    OpRec& emit(int lvl, int op, int d0) {
+        recs.push_back({});
+        OpRec& r = recs.back();
+        r.level = lvl;
+        std::memset(r.w, 0, sizeof r.w);
+        r.w[W_OP] = op; r.w[W_D0] = d0;
+        r.w[W_IN0] = r.w[W_IN1] = r.w[W_IN2] = r.w[W_OUT] = r.w[W_PREC] = r.w[W_TERM] = -1;
+        return r;
+    }
+    int src_off(int m) const { return off[alias[m] >= 0 ? alias[m] : m]; }
+    void noise_params(OpRec& r, int f, int d) {
+        const int c = (int)iface(f, 2), t = g->factor_type[f];
+        if (P.vclass[c] == VC_PREC) r.w[W_PREC] = P.prec_off[c];
+        else r.w[W_C0] = noise_block(c, d, t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION);
+    }
+
+    void allocate() {
+        P.marg_off.assign(nv, -1); P.val_off.assign(nv, -1); P.prec_off.assign(nv, -1);
+        cval_off.assign(nv, -1); cmat_off.assign(nv, -1); noise_off.assign(nv, -1); prior_off.assign(nv, -1);
+        long long vo = 0;
+        for (int64_t v = 0; v < nv; ++v)
+            if (P.vclass[v] == VC_DATA) { P.val_off[v] = (int)vo; vo += P.dim[v]; P.data_vars.push_back(v); }
+        P.data_doubles = vo;
+        for (int64_t v = 0; v < nv; ++v)
+            if (P.vclass[v] == VC_DERIVED) { P.val_off[v] = (int)vo; vo += P.dim[v]; }
+        P.val_doubles = vo;
+        long long mo = 0, po = 0;
+        for (int64_t v = 0; v < nv; ++v) {
+            if (P.vclass[v] == VC_GAUSS) { P.marg_off[v] = (int)mo; mo += msz(P.dim[v]) + 1; }
+            if (P.vclass[v] == VC_PREC) { const int d = P.dim[v]; P.prec_off[v] = (int)po; po += 2 + d * (d + 1) / 2 + 2 * d * d; }
+        }
+        P.marg_doubles = mo; P.prec_doubles = po;
+        long long so = 0;
+        for (int m = 0; m < 2 * E; ++m)
+            if (!null_[m] && needed[m] && alias[m] < 0) { off[m] = (int)so; so += msz(P.dim[edges[m % E].v]); ++P.n_messages; }
+        for (int m = 0; m < 2 * E; ++m)   // an alias of a message nobody else needed (cannot happen: every f2v is needed)
+            if (alias[m] >= 0 && off[alias[m]] < 0) fail(RXHIP_ERR_BADARG, "internal: alias of an unallocated message");
+        if (so > (1ll << 30) || mo > (1ll << 30) || vo > (1ll << 30)) fail(RXHIP_ERR_UNSUPPORTED, "graph too large for the executor's 32-bit slot offsets");
+        P.msg_doubles = so;
+    }
+
+    void init_precision() {
+        P.prec_init.assign((size_t)P.prec_doubles, 0.0);
+        for (int64_t f = 0; f < nf; ++f) {
+            if (nclass[f] != NC_PRIOR) continue;
+            const int v = (int)iface((int)f, 0), d = P.dim[v], t = g->factor_type[f];
+            const double* a = cptr((int)iface((int)f, 1));
+            const double* b = cptr((int)iface((int)f, 2));
+            double nu0;
+            std::vector<double> S0((size_t)d * d), S0i((size_t)d * d);
+            if (t == RXHIP_NODE_WISHART) {
+                if ((int64_t)g->var_rows[iface((int)f, 2)] * g->var_cols[iface((int)f, 2)] != (int64_t)d * d) fail(RXHIP_ERR_BADARG, "Wishart scale of variable %d is not %d x %d", v, d, d);
+                nu0 = a[0];
+                std::copy(b, b + (size_t)d * d, S0.begin());
+            } else {
+                if (d != 1) fail(RXHIP_ERR_BADARG, "a Gamma prior on a vector variable");
+                const double rate = t == RXHIP_NODE_GAMMA_SHAPE_RATE ? b[0] : 1.0 / b[0];
+                nu0 = 2.0 * a[0];
+                S0[0] = 1.0 / (2.0 * rate);
+            }
+            double ldS0 = 0.0;
+            if (!(nu0 > d - 1.0) || !host_chol_inv(d, S0.data(), S0i.data(), &ldS0)) fail(RXHIP_ERR_NOT_POSDEF, "prior of precision variable %d is not a proper Wishart / Gamma", v);
+            prior_off[v] = (int)P.cpool.size();
+            P.cpool.push_back(nu0);
+            P.cpool.insert(P.cpool.end(), S0i.begin(), S0i.end());
+            P.cpool.push_back(ldS0);
+            // initial marginal: `@initialization`, default the prior
+            double nu = nu0;
+            std::vector<double> V = S0;
+            if (g->var_init_family && g->var_init && g->var_init_family[v] != RXHIP_INIT_NONE && g->var_init[v] >= 0) {
+                const double* q = g->const_pool + g->var_init[v];
+                if (g->var_init_family[v] == RXHIP_INIT_WISHART) { nu = q[0]; std::copy(q + 1, q + 1 + (size_t)d * d, V.begin()); }
+                else if (g->var_init_family[v] == RXHIP_INIT_GAMMA && d == 1) { nu = 2.0 * q[0]; V[0] = 1.0 / (2.0 * q[1]); }
+                else fail(RXHIP_ERR_BADARG, "initial marginal of precision variable %d: Wishart (or Gamma for scalars) expected", v);
+            }
+            std::vector<double> What((size_t)d * d), Whi((size_t)d * d);
+            for (size_t i = 0; i < What.size(); ++i) What[i] = nu * V[i];
+            double ldW = 0.0;
+            if (!(nu > d - 1.0) || !host_chol_inv(d, What.data(), Whi.data(), &ldW)) fail(RXHIP_ERR_NOT_POSDEF, "initial marginal of precision variable %d is not proper", v);
+            double* st = P.prec_init.data() + P.prec_off[v];
+            const int tri = d * (d + 1) / 2;
+            st[0] = nu;
+            for (int i = 0, k = 0; i < d; ++i)
+                for (int j = 0; j <= i; ++j) st[1 + k++] = V[i * d + j];
+            std::copy(What.begin(), What.end(), st + 1 + tri);
+            std::copy(Whi.begin(), Whi.end(), st + 1 + tri + d * d);
+            double el = d * std::log(2.0) + (ldW - d * std::log(nu));
+            for (int i = 0; i < d; ++i) el += host_digamma(0.5 * nu - 0.5 * i);
+            st[1 + tri + 2 * d * d] = el;
+        }
+    }
+
+    void emit_all() {
+        // derived values first (their own dependency order)
+        {
+            std::vector<int> lv(nv, 0);
+            bool changed = true;
+            std::vector<char> emitted(nv, 0);
+            while (changed) {
+                changed = false;
+                for (int64_t f = 0; f < nf; ++f) {
+                    if (nclass[f] != NC_MUL && nclass[f] != NC_ADD) continue;
+                    const int o = (int)iface((int)f, 0);
+                    if (P.vclass[o] != VC_DERIVED || emitted[o]) continue;
+                    const int a = (int)iface((int)f, 1), b = (int)iface((int)f, 2);
+                    auto ready = [&](int v) { return P.vclass[v] != VC_DERIVED || emitted[v]; };
+                    if (nclass[f] == NC_MUL) {
+                        if (!ready(b)) continue;
+                        OpRec& r = emit(lv[b] , OP_DERIVE_MUL, P.dim[o]);
+                        r.w[W_D1] = P.dim[b];
+                        r.w[W_C0] = const_matrix(a, P.dim[o], P.dim[b]);
+                        int bit; r.w[W_VAL] = value_source(b, bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
+                        r.w[W_OUT] = P.val_off[o];
+                        lv[o] = lv[b] + 1;
+                    } else {
+                        if (!ready(a) || !ready(b)) continue;
+                        const int l = std::max(lv[a], lv[b]);
+                        OpRec& r = emit(l, OP_DERIVE_ADD, P.dim[o]);
+                        int bit; r.w[W_VAL] = value_source(a, bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
+                        r.w[W_VAL2] = value_source(b, bit); if (bit) r.w[W_FLAGS] |= F_VAL2_SLOT;
+                        r.w[W_OUT] = P.val_off[o];
+                        lv[o] = l + 1;
+                    }
+                    emitted[o] = 1;
+                    changed = true;
+                }
+            }
+            derived_levels = 0;
+            for (int64_t v = 0; v < nv; ++v) derived_levels = std::max(derived_levels, lv[v]);
+        }
+        const int L0 = derived_levels;   // messages start behind the derived values
+        int maxl = 0;
+        for (int m = 0; m < 2 * E; ++m) {
+            if (null_[m] || !needed[m] || alias[m] >= 0) continue;
+            const Edge& ed = edges[m % E];
+            const int d = P.dim[ed.v], lv = L0 + level[m];
+            maxl = std::max(maxl, lv);
+            if (m >= E) {   // product
+                OpRec& r = emit(lv, OP_PRODUCT, d);
+                r.w[W_OUT] = off[m];
+                r.w[W_LIST] = (int)P.aux.size();
+                int n = 0;
+                for (int dpm : deps[m])
+                    if (!null_[dpm]) { P.aux.push_back(src_off(dpm)); P.aux.push_back(form[dpm]); ++n; P.bytes_per_sweep += 8ll * msz(d); }
+                r.w[W_N] = n;
+                P.bytes_per_sweep += 8ll * msz(d);
+                continue;
+            }
+            const int f = ed.f;
+            if (nclass[f] == NC_NOISE) {
+                const int oe = fac_edges[f][1 - ed.k];
+                if (oe < 0) {
+                    OpRec& r = emit(lv, OP_LEAF, d);
+                    int bit; r.w[W_VAL] = value_source((int)iface(f, 1 - ed.k), bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
+                    if (form[m]) r.w[W_FLAGS] |= F_OUT_WP;
+                    noise_params(r, f, d);
+                    r.w[W_OUT] = off[m];
+                } else {
+                    OpRec& r = emit(lv, OP_NOISE, d);
+                    r.w[W_IN0] = src_off(E + oe);
+                    if (form[E + oe]) r.w[W_FLAGS] |= F_IN0_WP | F_OUT_WP;
+                    noise_params(r, f, d);
+                    r.w[W_OUT] = off[m];
+                    P.bytes_per_sweep += 8ll * msz(d);
+                }
+            } else if (nclass[f] == NC_MUL) {
+                const int dout = P.dim[iface(f, 0)], din = P.dim[iface(f, 2)];
+                OpRec& r = emit(lv, ed.k == 0 ? OP_MUL_OUT : OP_MUL_IN, dout);
+                r.w[W_D1] = din;
+                r.w[W_C0] = const_matrix((int)iface(f, 1), dout, din);
+                const int se = fac_edges[f][ed.k == 0 ? 2 : 0];
+                r.w[W_IN0] = src_off(E + se);
+                if (form[E + se]) r.w[W_FLAGS] |= F_IN0_WP;
+                r.w[W_OUT] = off[m];
+                P.bytes_per_sweep += 8ll * msz(ed.k == 0 ? din : dout);
+            } else {   // `+`
+                std::vector<int> oth;
+                for (int k = 0; k < 3; ++k) if (k != ed.k) oth.push_back(k);
+                const int e0 = fac_edges[f][oth[0]], e1 = fac_edges[f][oth[1]];
+                if (e0 >= 0 && e1 >= 0) {
+                    // out = in1 + in2: (:out) adds the inputs; (:in_k) subtracts the other input from the message toward out
+                    const int first = ed.k == 0 ? e0 : fac_edges[f][0], second = ed.k == 0 ? e1 : (oth[0] == 0 ? e1 : e0);
+                    OpRec& r = emit(lv, ed.k == 0 ? OP_ADD_OUT : OP_ADD_IN, d);
+                    r.w[W_IN0] = src_off(E + first); if (form[E + first]) r.w[W_FLAGS] |= F_IN0_WP;
+                    r.w[W_IN1] = src_off(E + second); if (form[E + second]) r.w[W_FLAGS] |= F_IN1_WP;
+                    r.w[W_OUT] = off[m];
+                    P.bytes_per_sweep += 16ll * msz(d);
+                } else {
+                    const int ge = e0 >= 0 ? e0 : e1, ck = e0 >= 0 ? oth[1] : oth[0];
+                    OpRec& r = emit(lv, OP_SHIFT, d);
+                    r.w[W_IN0] = src_off(E + ge);
+                    if (form[E + ge]) r.w[W_FLAGS] |= F_IN0_WP | F_OUT_WP;
+                    int bit; r.w[W_VAL] = value_source((int)iface(f, ck), bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
+                    if (ed.k != 0) r.w[W_FLAGS] |= F_NEG;   // toward an input: out − constant
+                    r.w[W_OUT] = off[m];
+                    P.bytes_per_sweep += 8ll * msz(d);
+                }
+            }
+            P.bytes_per_sweep += 8ll * msz(d);
+        }
+        // marginals: one level behind the last message
+        const int LM = maxl + 1;
+        for (int64_t v = 0; v < nv; ++v) {
+            if (P.vclass[v] != VC_GAUSS) continue;
+            const int d = P.dim[v];
+            OpRec& r = emit(LM, OP_MARGINAL, d);
+            r.w[W_OUT] = P.marg_off[v];
+            r.w[W_LIST] = (int)P.aux.size();
+            int n = 0;
+            for (int e : var_edges[v])
+                if (!null_[e]) { P.aux.push_back(src_off(e)); P.aux.push_back(form[e]); ++n; P.bytes_per_sweep += 8ll * msz(d); }
+            r.w[W_N] = n;
+            P.bytes_per_sweep += 8ll * (msz(d) + 1);
+        }
+        // Bethe terms and residual moments
+        const int LF = LM + 1;
+        std::vector<int> terms;
+        std::vector<int> ent_coef(nv, 0);
+        std::vector<std::vector<int>> prec_stats(nv);
+        std::vector<int> prec_nodes(nv, 0);
+        long long stat_o = 0;
+        auto new_term = [&]() { terms.push_back((int)P.term_slots); return (int)P.term_slots++; };
+        auto msg_in = [&](OpRec& r, int word, int bit, int m) {
+            if (null_[m]) { r.w[word] = -1; return; }
+            r.w[word] = src_off(m);
+            if (form[m]) r.w[W_FLAGS] |= bit;
+        };
+        for (int64_t v = 0; v < nv; ++v)
+            if (P.vclass[v] == VC_GAUSS) ent_coef[v] = (int)var_edges[v].size() - 1;
+        for (int64_t f = 0; f < nf; ++f) {
+            const int a = (int)iface((int)f, 0), b = (int)iface((int)f, 1), c = (int)iface((int)f, 2);
+            if (nclass[f] == NC_NOISE) {
+                const int d = P.dim[a];
+                const bool ga = P.vclass[a] == VC_GAUSS, gb = P.vclass[b] == VC_GAUSS, rw = P.vclass[c] == VC_PREC;
+                OpRec& r = emit(LF, ga && gb ? OP_FE_NOISE2 : (ga || gb) ? OP_FE_NOISE1 : OP_FE_NOISE0, d);
+                noise_params(r, (int)f, d);
+                if (ga && gb) {
+                    msg_in(r, W_IN0, F_IN0_WP, E + fac_edges[f][0]);
+                    msg_in(r, W_IN1, F_IN1_WP, E + fac_edges[f][1]);
+                } else if (ga || gb) {
+                    r.w[W_IN0] = P.marg_off[ga ? a : b];
+                    int bit; r.w[W_VAL] = value_source(ga ? b : a, bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
+                } else {
+                    int bit; r.w[W_VAL] = value_source(a, bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
+                    r.w[W_VAL2] = value_source(b, bit); if (bit) r.w[W_FLAGS] |= F_VAL2_SLOT;
+                }
+                r.w[W_TERM] = new_term();
+                if (rw) {
+                    r.w[W_FLAGS] |= F_STAT;
+                    r.w[W_C1] = (int)stat_o;
+                    prec_stats[c].push_back((int)stat_o);
+                    stat_o += d * d;
+                }
+            } else if (nclass[f] == NC_MUL) {
+                if (P.vclass[c] == VC_GAUSS && P.vclass[a] == VC_GAUSS) ent_coef[c] -= 1;   // −H[q(in)]
+            } else if (nclass[f] == NC_ADD && P.vclass[a] == VC_GAUSS) {
+                const bool g1 = P.vclass[b] == VC_GAUSS, g2 = P.vclass[c] == VC_GAUSS;
+                if (g1 && g2) {
+                    OpRec& r = emit(LF, OP_FE_ADD2, P.dim[a]);
+                    msg_in(r, W_IN0, F_IN0_WP, E + fac_edges[f][1]);
+                    msg_in(r, W_IN1, F_IN1_WP, E + fac_edges[f][2]);
+                    msg_in(r, W_IN2, F_IN2_WP, E + fac_edges[f][0]);
+                    r.w[W_TERM] = new_term();
+                } else ent_coef[g1 ? b : c] -= 1;
+            }
+        }
+        for (int64_t v = 0; v < nv; ++v)
+            if (P.vclass[v] == VC_GAUSS && ent_coef[v] != 0) {
+                OpRec& r = emit(LF, OP_FE_ENT, P.dim[v]);
+                r.w[W_IN0] = P.marg_off[v];
+                r.w[W_N] = ent_coef[v];
+                r.w[W_TERM] = new_term();
+            }
+        P.stat_doubles = stat_o;
+        // q(W) updates
+        const int LP = LF + 1;
+        for (int64_t v = 0; v < nv; ++v) {
+            if (P.vclass[v] != VC_PREC) continue;
+            OpRec& r = emit(LP, OP_PREC_UPDATE, P.dim[v]);
+            r.w[W_C0] = prior_off[v];
+            r.w[W_PREC] = P.prec_off[v];
+            r.w[W_LIST] = (int)P.aux.size();
+            r.w[W_N] = (int)prec_stats[v].size();
+            for (int s : prec_stats[v]) P.aux.push_back(s);
+            r.w[W_TERM] = new_term();
+        }
+        // fixed-order tree sum of the terms (chunks of 32)
+        int lv = LP + 1;
+        std::vector<int> cur = terms;
+        if (cur.empty()) { cur.push_back((int)P.term_slots++); }
+        while (cur.size() > 1) {
+            std::vector<int> nxt;
+            for (size_t i = 0; i < cur.size(); i += 32) {
+                const size_t n = std::min<size_t>(32, cur.size() - i);
+                OpRec& r = emit(lv, OP_SUM_TERMS, 1);
+                r.w[W_LIST] = (int)P.aux.size();
+                r.w[W_N] = (int)n;
+                for (size_t q = 0; q < n; ++q) P.aux.push_back(cur[i + q]);
+                r.w[W_TERM] = (int)P.term_slots;
+                nxt.push_back((int)P.term_slots++);
+            }
+            cur.swap(nxt);
+            ++lv;
+        }
+        P.fe_root = cur[0];
+        fe_first_level = LF;
+    }
+    int derived_levels = 0, fe_first_level = 0;
+
+    void finish() {
+        std::stable_sort(recs.begin(), recs.end(), [](const OpRec& a, const OpRec& b) { return a.level != b.level ? a.level < b.level : a.w[W_OP] < b.w[W_OP]; });
+        P.n_ops = (int)recs.size();
+        P.ops.resize((size_t)P.n_ops * OP_WORDS);
+        int nl = recs.empty() ? 0 : recs.back().level + 1;
+        P.lvl_ptr.assign(nl + 1, 0);
+        for (int i = 0; i < P.n_ops; ++i) {
+            std::memcpy(&P.ops[(size_t)i * OP_WORDS], recs[i].w, sizeof recs[i].w);
+            P.lvl_ptr[recs[i].level + 1]++;
+        }
+        for (int l = 0; l < nl; ++l) { P.max_width = std::max(P.max_width, P.lvl_ptr[l + 1]); P.lvl_ptr[l + 1] += P.lvl_ptr[l]; }
+        P.n_levels = nl;
+        if (P.aux.empty()) P.aux.push_back(0);
+        if (P.cpool.empty()) P.cpool.push_back(0.0);
+    }
+
+    // rule calls as the reference's trace counts them: what the marginals of the NAMED variables pull in (anonymous outputs of deterministic nodes —
+    // `B * x[t]` — are not requested by a user; the CPU restatements the tests compare with count the same way)
+    void count() {
+        std::vector<char> det_out(nv, 0);
+        for (int64_t f = 0; f < nf; ++f)
+            if (nclass[f] == NC_MUL || nclass[f] == NC_ADD) det_out[iface((int)f, 0)] = 1;
+        std::vector<char> dem(2 * E, 0);
+        std::vector<int> st;
+        for (int64_t v = 0; v < nv; ++v)
+            if (P.vclass[v] == VC_GAUSS && !det_out[v]) {
+                ++P.marginals;
+                for (int e : var_edges[v]) if (!null_[e] && !dem[e]) { dem[e] = 1; st.push_back(e); }
+            }
+        while (!st.empty()) {
+            const int m = st.back(); st.pop_back();
+            for (int dpm : deps[m]) if (!null_[dpm] && !dem[dpm]) { dem[dpm] = 1; st.push_back(dpm); }
+        }
+        for (int m = 0; m < E; ++m) P.rule_calls += dem[m];
+        for (int m = E; m < 2 * E; ++m)
+            if (dem[m] && alias[m] < 0) {
+                int n = 0;
+                for (int dpm : deps[m]) n += !null_[dpm];
+                P.products += n > 1 ? n - 1 : 0;
+            }
+    }
+
+    void compile() {
+        parse();
+        check_family();
+        build_edges();
+        build_deps();
+        analyse();
+        allocate();
+        init_precision();
+        emit_all();
+        finish();
+        count();
+    }
+};
+
+}  // namespace
+
+struct Engine {
+    Program prog;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    long long R = 1, RS = 16;
+    int mode = 0, rb = 16;
+    int *d_ops = nullptr, *d_aux = nullptr, *d_lvl = nullptr, *d_status = nullptr;
+    double *d_cpool = nullptr, *d_msg = nullptr, *d_marg = nullptr, *d_val = nullptr, *d_prec = nullptr, *d_term = nullptr, *d_stat = nullptr, *d_prec_init = nullptr,
+           *d_fe_rep = nullptr, *d_fe_hist = nullptr;
+    int fe_cap = 0;
+    bool have_data = false, ran = false;
+    int last_iterations = 0, last_want_fe = 0;
+    std::vector<char> data_set;
+    uint64_t runs = 0;
+};
+
+namespace {
+struct DevScope {
+    int prev = -1;
+    bool changed = false;
+    explicit DevScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DevScope() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
+};
+#define TCHK(call)                                                                                                   \
+    do {                                                                                                             \
+        hipError_t _e = (call);                                                                                      \
+        if (_e != hipSuccess) { err = std::string(#call) + " failed: " + hipGetErrorString(_e); return RXHIP_ERR_HIP; } \
+    } while (0)
+
+template <class T>
+rxhip_status upload(T** dst, const std::vector<T>& src, std::string& err) {
+    TCHK(hipMalloc(dst, sizeof(T) * std::max<size_t>(1, src.size())));
+    if (!src.empty()) TCHK(hipMemcpy(*dst, src.data(), sizeof(T) * src.size(), hipMemcpyHostToDevice));
+    return RXHIP_OK;
+}
+rxhip_status zalloc(double** dst, long long doubles, std::string& err) {
+    const size_t n = (size_t)std::max<long long>(1, doubles);
+    TCHK(hipMalloc(dst, sizeof(double) * n));
+    TCHK(hipMemset(*dst, 0, sizeof(double) * n));
+    return RXHIP_OK;
+}
+TreeParams params_of(const Engine* e, int want_fe) {
+    TreeParams p{};
+    p.ops = e->d_ops; p.aux = e->d_aux; p.cpool = e->d_cpool; p.msg = e->d_msg; p.marg = e->d_marg; p.val = e->d_val; p.prec = e->d_prec;
+    p.term = e->d_term; p.stat = e->d_stat; p.R = e->R; p.RS = e->RS; p.want_fe = want_fe; p.status = e->d_status;
+    return p;
+}
+template <int N>
+void launch_levels(const Engine* e, const TreeParams& p, int l0, int l1) {
+    if (e->mode == 1) {
+        const unsigned blocks = (unsigned)((e->R + e->rb - 1) / e->rb);
+        hipLaunchKernelGGL(k_tree_levels<N>, dim3(blocks), dim3(256), 0, e->stream, p, e->d_lvl, l0, l1, e->rb);
+    } else {
+        for (int l = l0; l < l1; ++l) {
+            const int o0 = e->prog.lvl_ptr[l], o1 = e->prog.lvl_ptr[l + 1];
+            if (o1 == o0) continue;
+            const long long items = (long long)(o1 - o0) * e->R;
+            const unsigned blocks = (unsigned)std::min<long long>((items + 255) / 256, 1 << 20);
+            hipLaunchKernelGGL(k_tree_ops<N>, dim3(blocks), dim3(256), 0, e->stream, p, o0, o1);
+        }
+    }
+}
+void launch(const Engine* e, const TreeParams& p, int l0, int l1) {
+    switch (e->prog.dmax) {
+    case 1: launch_levels<1>(e, p, l0, l1); break;
+    case 2: launch_levels<2>(e, p, l0, l1); break;
+    default: launch_levels<4>(e, p, l0, l1); break;
+    }
+}
+}  // namespace
+
+rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine** out, std::string& err) {
+    if (!g || !out) { err = "null argument"; return RXHIP_ERR_BADARG; }
+    *out = nullptr;
+    Engine* e = new Engine();
+    try {
+        Compiler c(g, e->prog);
+        c.compile();
+    } catch (const Fail& f) {
+        err = f.msg;
+        delete e;
+        return f.st;
+    } catch (const std::exception& ex) {
+        err = ex.what();
+        delete e;
+        return RXHIP_ERR_BADARG;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { err = "no HIP device visible: the executor has no CPU fallback"; delete e; return RXHIP_ERR_NO_DEVICE; }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    if (device >= ndev) { err = "device ordinal out of range"; delete e; return RXHIP_ERR_BADARG; }
+    e->device = device;
+    DevScope ds(device);
+    e->R = std::max<int64_t>(1, g->n_replicas);
+    e->RS = (e->R + 15) / 16 * 16;
+    const Program& P = e->prog;
+    // schedule: deep graphs walk their levels inside a workgroup (one launch per iteration); wide, shallow ones take a launch per level
+    const double avg_width = (double)P.n_ops / std::max(1, P.n_levels);
+    e->mode = (P.n_levels > 24 && (e->R >= 512 || avg_width * (double)e->R < 16384.0)) ? 1 : 0;
+    if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = std::atoi(m) ? 1 : 0;
+    {
+        long long rb = (e->R / 1024) / 16 * 16;
+        e->rb = (int)std::min<long long>(64, std::max<long long>(16, rb));
+    }
+    auto cleanup = [&](rxhip_status st) { destroy(e); return st; };
+    if (stream) e->stream = (hipStream_t)stream;
+    else {
+        if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { err = "hipStreamCreate failed"; return cleanup(RXHIP_ERR_HIP); }
+        e->own_stream = true;
+    }
+    rxhip_status st;
+    if ((st = upload(&e->d_ops, P.ops, err)) || (st = upload(&e->d_aux, P.aux, err)) || (st = upload(&e->d_lvl, P.lvl_ptr, err)) || (st = upload(&e->d_cpool, P.cpool, err)) ||
+        (st = upload(&e->d_prec_init, P.prec_init, err)) || (st = zalloc(&e->d_msg, P.msg_doubles * e->RS, err)) || (st = zalloc(&e->d_marg, P.marg_doubles * e->RS, err)) ||
+        (st = zalloc(&e->d_val, P.val_doubles * e->RS, err)) || (st = zalloc(&e->d_prec, P.prec_doubles * e->RS, err)) || (st = zalloc(&e->d_term, P.term_slots * e->RS, err)) ||
+        (st = zalloc(&e->d_stat, P.stat_doubles * e->RS, err)) || (st = zalloc(&e->d_fe_rep, e->RS, err)))
+        return cleanup(st);
+    if (hipMalloc(&e->d_status, sizeof(int)) != hipSuccess || hipMemset(e->d_status, 0, sizeof(int)) != hipSuccess) { err = "hipMalloc failed"; return cleanup(RXHIP_ERR_HIP); }
+    e->data_set.assign(P.data_vars.size(), 0);
+    e->have_data = P.data_vars.empty();
+    *out = e;
+    return RXHIP_OK;
+}
+
+void destroy(Engine* e) {
+    if (!e) return;
+    DevScope ds(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (void* q : {(void*)e->d_ops, (void*)e->d_aux, (void*)e->d_lvl, (void*)e->d_status, (void*)e->d_cpool, (void*)e->d_msg, (void*)e->d_marg, (void*)e->d_val, (void*)e->d_prec,
+                    (void*)e->d_term, (void*)e->d_stat, (void*)e->d_prec_init, (void*)e->d_fe_rep, (void*)e->d_fe_hist})
+        if (q) (void)hipFree(q);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+rxhip_status set_data(Engine* e, const int64_t* vars, int64_t n_vars, const double* host, std::string& err) {
+    if (!e || !vars || !host || n_vars <= 0) { err = "set_data: null argument"; return RXHIP_ERR_BADARG; }
+    DevScope ds(e->device);
+    const Program& P = e->prog;
+    long long rows = 0;
+    for (int64_t i = 0; i < n_vars; ++i) {
+        const int64_t v = vars[i];
+        if (v < 0 || v >= (int64_t)P.vclass.size() || P.vclass[v] != VC_DATA) { err = "set_data: variable " + std::to_string(v) + " is not a data variable"; return RXHIP_ERR_BADARG; }
+        rows += P.dim[v];
+    }
+    // device image of the listed slots, replica-fastest; one copy per run of adjacent slots
+    std::vector<double> img;
+    TCHK(hipStreamSynchronize(e->stream));
+    long long col = 0;
+    for (int64_t i = 0; i < n_vars;) {
+        int64_t j = i;
+        long long width = 0;
+        while (j < n_vars && P.val_off[vars[j]] == P.val_off[vars[i]] + width) { width += P.dim[vars[j]]; ++j; }
+        img.assign((size_t)width * e->RS, 0.0);
+        for (long long r = 0; r < e->R; ++r)
+            for (long long k = 0; k < width; ++k) img[(size_t)k * e->RS + r] = host[(size_t)r * rows + col + k];
+        TCHK(hipMemcpy(e->d_val + (size_t)P.val_off[vars[i]] * e->RS, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+        col += width;
+        i = j;
+    }
+    for (int64_t i = 0; i < n_vars; ++i) {
+        const auto it = std::lower_bound(P.data_vars.begin(), P.data_vars.end(), vars[i]);
+        e->data_set[it - P.data_vars.begin()] = 1;
+    }
+    e->have_data = std::all_of(e->data_set.begin(), e->data_set.end(), [](char c) { return c != 0; });
+    return RXHIP_OK;
+}
+
+rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err) {
+    if (!e || iterations < 1) { err = "run: iterations must be positive"; return RXHIP_ERR_BADARG; }
+    if (!e->have_data) { err = "run before every data variable has been set"; return RXHIP_ERR_STATE; }
+    DevScope ds(e->device);
+    const Program& P = e->prog;
+    if (iterations > e->fe_cap) {
+        TCHK(hipStreamSynchronize(e->stream));
+        if (e->d_fe_hist) TCHK(hipFree(e->d_fe_hist));
+        e->d_fe_hist = nullptr;
+        TCHK(hipMalloc(&e->d_fe_hist, sizeof(double) * (size_t)iterations));
+        e->fe_cap = iterations;
+    }
+    TCHK(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
+    // a run starts from the @initialization marginals (iterations re-push the data: src/inference/batch.jl:391-430)
+    if (P.prec_doubles > 0) {
+        std::vector<double> img((size_t)P.prec_doubles * e->RS);
+        for (long long k = 0; k < P.prec_doubles; ++k)
+            for (long long r = 0; r < e->RS; ++r) img[(size_t)k * e->RS + r] = P.prec_init[k];
+        TCHK(hipStreamSynchronize(e->stream));
+        TCHK(hipMemcpy(e->d_prec, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+    }
+    const TreeParams p = params_of(e, want_fe);
+    // without the free energy on a graph without precision variables the sweep ends with the marginals
+    int l_end = P.n_levels;
+    if (!want_fe && P.prec_doubles == 0) {
+        l_end = 0;
+        for (int l = 0; l < P.n_levels; ++l) {
+            bool bp = false;
+            for (int o = P.lvl_ptr[l]; o < P.lvl_ptr[l + 1]; ++o) bp = bp || P.ops[(size_t)o * OP_WORDS + W_OP] <= OP_MARGINAL;
+            if (bp) l_end = l + 1;
+        }
+    }
+    for (int it = 0; it < iterations; ++it) {
+        launch(e, p, 0, l_end);
+        if (want_fe) hipLaunchKernelGGL(k_tree_fe_total, dim3(1), dim3(256), 0, e->stream, e->d_term, (long long)P.fe_root, e->R, e->RS, e->d_fe_rep, e->d_fe_hist + it);
+    }
+    TCHK(hipGetLastError());
+    TCHK(hipStreamSynchronize(e->stream));
+    int status = 0;
+    TCHK(hipMemcpy(&status, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
+    e->ran = true;
+    e->last_iterations = iterations;
+    e->last_want_fe = want_fe;
+    ++e->runs;
+    if (status & 1) { err = "a message or marginal precision was not positive definite"; return RXHIP_ERR_NOT_POSDEF; }
+    if (want_fe) {
+        std::vector<double> h((size_t)iterations);
+        TCHK(hipMemcpy(h.data(), e->d_fe_hist, sizeof(double) * h.size(), hipMemcpyDeviceToHost));
+        for (double v : h)
+            if (!std::isfinite(v)) { err = "free energy is not finite"; return RXHIP_ERR_NONFINITE_FE; }
+    }
+    return RXHIP_OK;
+}
+
+rxhip_status get_marginals(Engine* e, const int64_t* vars, int64_t n_vars, double* mean, double* cov, std::string& err) {
+    if (!e || !vars || n_vars <= 0) { err = "get_marginals: null argument"; return RXHIP_ERR_BADARG; }
+    if (!e->ran) { err = "get_marginals before run"; return RXHIP_ERR_STATE; }
+    DevScope ds(e->device);
+    const Program& P = e->prog;
+    std::vector<double> buf;
+    size_t mo = 0, co = 0;
+    const bool whole = n_vars > 32;
+    if (whole) {
+        buf.resize((size_t)P.marg_doubles * e->RS);
+        TCHK(hipMemcpy(buf.data(), e->d_marg, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    }
+    for (int64_t i = 0; i < n_vars; ++i) {
+        const int64_t v = vars[i];
+        if (v < 0 || v >= (int64_t)P.vclass.size() || P.vclass[v] != VC_GAUSS) { err = "get_marginals: variable " + std::to_string(v) + " is not a random Gaussian variable"; return RXHIP_ERR_BADARG; }
+        const int d = P.dim[v], sz = d + d * (d + 1) / 2;
+        const double* src;
+        if (whole) src = buf.data() + (size_t)P.marg_off[v] * e->RS;
+        else {
+            buf.resize((size_t)sz * e->RS);
+            TCHK(hipMemcpy(buf.data(), e->d_marg + (size_t)P.marg_off[v] * e->RS, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+            src = buf.data();
+        }
+        for (long long r = 0; r < e->R; ++r) {
+            if (mean)
+                for (int k = 0; k < d; ++k) mean[mo + (size_t)r * d + k] = src[(size_t)k * e->RS + r];
+            if (cov)
+                for (int a = 0; a < d; ++a)
+                    for (int b = 0; b <= a; ++b) {
+                        const double x = src[(size_t)(d + a * (a + 1) / 2 + b) * e->RS + r];
+                        cov[co + ((size_t)r * d + a) * d + b] = x;
+                        cov[co + ((size_t)r * d + b) * d + a] = x;
+                    }
+        }
+        mo += (size_t)e->R * d;
+        co += (size_t)e->R * d * d;
+    }
+    return RXHIP_OK;
+}
+
+rxhip_status get_precision(Engine* e, int64_t var, double* nu, double* V, std::string& err) {
+    if (!e) { err = "null engine"; return RXHIP_ERR_BADARG; }
+    if (!e->ran) { err = "get_precision before run"; return RXHIP_ERR_STATE; }
+    const Program& P = e->prog;
+    if (var < 0 || var >= (int64_t)P.vclass.size() || P.vclass[var] != VC_PREC) { err = "not a precision variable"; return RXHIP_ERR_BADARG; }
+    DevScope ds(e->device);
+    const int d = P.dim[var], tri = d * (d + 1) / 2;
+    std::vector<double> buf((size_t)(1 + tri) * e->RS);
+    TCHK(hipMemcpy(buf.data(), e->d_prec + (size_t)P.prec_off[var] * e->RS, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    for (long long r = 0; r < e->R; ++r) {
+        if (nu) nu[r] = buf[r];
+        if (V)
+            for (int a = 0; a < d; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    const double x = buf[(size_t)(1 + a * (a + 1) / 2 + b) * e->RS + r];
+                    V[((size_t)r * d + a) * d + b] = x;
+                    V[((size_t)r * d + b) * d + a] = x;
+                }
+    }
+    return RXHIP_OK;
+}
+
+rxhip_status get_free_energy(Engine* e, double* per_iteration, std::string& err) {
+    if (!e || !per_iteration) { err = "null argument"; return RXHIP_ERR_BADARG; }
+    if (!e->ran || !e->last_want_fe) { err = "no free energy: run with want_free_energy first"; return RXHIP_ERR_STATE; }
+    DevScope ds(e->device);
+    TCHK(hipMemcpy(per_iteration, e->d_fe_hist, sizeof(double) * (size_t)e->last_iterations, hipMemcpyDeviceToHost));
+    return RXHIP_OK;
+}
+rxhip_status get_free_energy_per_replica(Engine* e, double* per_replica, std::string& err) {
+    if (!e || !per_replica) { err = "null argument"; return RXHIP_ERR_BADARG; }
+    if (!e->ran || !e->last_want_fe) { err = "no free energy: run with want_free_energy first"; return RXHIP_ERR_STATE; }
+    DevScope ds(e->device);
+    TCHK(hipMemcpy(per_replica, e->d_fe_rep, sizeof(double) * (size_t)e->R, hipMemcpyDeviceToHost));
+    return RXHIP_OK;
+}
+void counters(Engine* e, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals) {
+    const uint64_t k = (uint64_t)e->R * (uint64_t)std::max(1, e->last_iterations);
+    if (rule_calls) *rule_calls = e->prog.rule_calls * k;
+    if (products) *products = e->prog.products * k;
+    if (marginals) *marginals = e->prog.marginals * k;
+}
+void info(Engine* e, rxhip_tree_info* out) {
+    const Program& P = e->prog;
+    out->n_ops = P.n_ops; out->n_levels = P.n_levels; out->n_messages = P.n_messages;
+    out->doubles_per_replica = P.msg_doubles + P.marg_doubles + P.val_doubles + P.prec_doubles + P.term_slots + P.stat_doubles;
+    out->bytes_per_sweep = P.bytes_per_sweep;
+    out->dmax = P.dmax; out->mode = e->mode; out->replicas_per_workgroup = e->rb;
+    int np = 0;
+    for (int c : P.vclass) np += c == VC_PREC;
+    out->n_precision_vars = np;
+}
+int device_of(Engine* e) { return e->device; }
+void* stream_of(Engine* e) { return (void*)e->stream; }
+rxhip_status sync(Engine* e, std::string& err) {
+    DevScope ds(e->device);
+    TCHK(hipStreamSynchronize(e->stream));
+    return RXHIP_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// one rule on a one-node schedule (include/rxhip.h rxhip_rule_eval)
+rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
+    if (!c || c->n < 1 || !c->in_a || !c->in_B || !c->out_a || !c->out_B) { err = "rule_eval: null argument"; return RXHIP_ERR_BADARG; }
+    const int t = c->node_type;
+    const bool noise = t == RXHIP_NODE_MVNORMAL_MEAN_COV || t == RXHIP_NODE_NORMAL_MEAN_VARIANCE || t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION;
+    if (!noise && t != RXHIP_NODE_MULTIPLY && t != RXHIP_NODE_ADD) { err = "rule_eval: node type without a device rule"; return RXHIP_ERR_UNSUPPORTED; }
+    const int dout = c->d_out, din = t == RXHIP_NODE_MULTIPLY ? c->d_in : c->d_out;
+    if (dout < 1 || din < 1 || dout > 4 || din > 4) { err = "rule_eval: dimensions 1..4"; return RXHIP_ERR_UNSUPPORTED; }
+    if ((noise && (c->iface < 0 || c->iface > 1)) || (t == RXHIP_NODE_MULTIPLY && c->iface != 0 && c->iface != 2) || (t == RXHIP_NODE_ADD && (c->iface < 0 || c->iface > 2))) {
+        err = "rule_eval: no message leaves through that interface"; return RXHIP_ERR_BADARG;
+    }
+    if ((noise || t == RXHIP_NODE_MULTIPLY) && !c->constant) { err = "rule_eval: the node's constant is missing"; return RXHIP_ERR_BADARG; }
+    if (t == RXHIP_NODE_ADD && (!c->in2_a || !c->in2_B)) { err = "rule_eval: `+` needs two inbound messages"; return RXHIP_ERR_BADARG; }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { err = "no HIP device visible"; return RXHIP_ERR_NO_DEVICE; }
+    if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    DevScope ds(device);
+    // the dimension of the inbound message and of the result
+    const int d_in_msg = t == RXHIP_NODE_MULTIPLY ? (c->iface == 0 ? din : dout) : dout;
+    const int d_res = t == RXHIP_NODE_MULTIPLY ? (c->iface == 0 ? dout : din) : dout;
+    const int dmax = std::max(dout, din), N = dmax <= 1 ? 1 : dmax <= 2 ? 2 : 4;
+    auto msz = [](int d) { return d + d * (d + 1) / 2; };
+    const long long R = c->n, RS = (R + 15) / 16 * 16;
+    // slots: in0 | in1 | rule output | converted output (message) ; marginal slot for the moment form
+    const int o_in0 = 0, o_in1 = o_in0 + msz(d_in_msg), o_rule = o_in1 + msz(dout), o_conv = o_rule + msz(d_res);
+    std::vector<double> cpool;
+    std::vector<int> ops, aux;
+    auto op = [&](int code, int d0) { ops.resize(ops.size() + OP_WORDS, 0); int* w = &ops[ops.size() - OP_WORDS]; w[W_OP] = code; w[W_D0] = d0; w[W_IN0] = w[W_IN1] = w[W_IN2] = w[W_OUT] = w[W_PREC] = w[W_TERM] = -1; return w; };
+    int out_wp;   // the form the rule itself leaves its result in
+    if (noise) {
+        std::vector<double> M(c->constant, c->constant + (size_t)dout * dout), Mi((size_t)dout * dout);
+        double ld = 0.0;
+        if (!host_chol_inv(dout, M.data(), Mi.data(), &ld)) { err = "rule_eval: the noise parameter is not positive definite"; return RXHIP_ERR_NOT_POSDEF; }
+        const bool prec = t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION;
+        const std::vector<double>&Sg = prec ? Mi : M, &W = prec ? M : Mi;
+        cpool.insert(cpool.end(), Sg.begin(), Sg.end());
+        cpool.insert(cpool.end(), W.begin(), W.end());
+        cpool.push_back(prec ? ld : -ld);
+        int* w = op(OP_NOISE, dout);
+        w[W_IN0] = o_in0; w[W_OUT] = o_rule; w[W_C0] = 0;
+        if (c->in_form) w[W_FLAGS] |= F_IN0_WP | F_OUT_WP;
+        out_wp = c->in_form;
+    } else if (t == RXHIP_NODE_MULTIPLY) {
+        cpool.assign(c->constant, c->constant + (size_t)dout * din);
+        int* w = op(c->iface == 0 ? OP_MUL_OUT : OP_MUL_IN, dout);
+        w[W_D1] = din; w[W_IN0] = o_in0; w[W_OUT] = o_rule; w[W_C0] = 0;
+        if (c->in_form) w[W_FLAGS] |= F_IN0_WP;
+        out_wp = c->iface == 0 ? 0 : 1;
+    } else {
+        cpool.push_back(0.0);
+        int* w = op(c->iface == 0 ? OP_ADD_OUT : OP_ADD_IN, dout);
+        w[W_IN0] = o_in0; w[W_IN1] = o_in1; w[W_OUT] = o_rule;
+        if (c->in_form) w[W_FLAGS] |= F_IN0_WP | F_IN1_WP;
+        out_wp = 0;
+    }
+    {   // the result in the requested form: a one-message product (precision form) or marginal (mean, covariance)
+        int* w = op(c->out_form ? OP_PRODUCT : OP_MARGINAL, d_res);
+        w[W_OUT] = c->out_form ? o_conv : 0;
+        w[W_LIST] = 0; w[W_N] = 1;
+        aux = {o_rule, out_wp};
+    }
+    const long long msg_d = o_conv + msz(d_res), marg_d = msz(d_res) + 1;
+    std::vector<double> img((size_t)msg_d * RS, 0.0);
+    auto pack = [&](int off, int d, const double* a, const double* B, bool wp) {
+        for (long long r = 0; r < RS; ++r) {
+            const long long rr = r < R ? r : R - 1;   // (padding lanes never run)
+            for (int k = 0; k < d; ++k) img[(size_t)(off + k) * RS + r] = a[(size_t)rr * d + k];
+            for (int i = 0; i < d; ++i)
+                for (int j = 0; j <= i; ++j) img[(size_t)(off + d + i * (i + 1) / 2 + j) * RS + r] = 0.5 * (B[((size_t)rr * d + i) * d + j] + B[((size_t)rr * d + j) * d + i]);
+        }
+        (void)wp;
+    };
+    pack(o_in0, d_in_msg, c->in_a, c->in_B, c->in_form);
+    if (t == RXHIP_NODE_ADD) pack(o_in1, dout, c->in2_a, c->in2_B, c->in_form);
+    int *d_ops = nullptr, *d_aux = nullptr, *d_status = nullptr;
+    double *d_cp = nullptr, *d_msg = nullptr, *d_marg = nullptr;
+    auto freeall = [&]() { for (void* q : {(void*)d_ops, (void*)d_aux, (void*)d_status, (void*)d_cp, (void*)d_msg, (void*)d_marg}) if (q) (void)hipFree(q); };
+    rxhip_status st;
+    if ((st = upload(&d_ops, ops, err)) || (st = upload(&d_aux, aux, err)) || (st = upload(&d_cp, cpool, err)) || (st = upload(&d_msg, img, err)) || (st = zalloc(&d_marg, marg_d * RS, err))) { freeall(); return st; }
+    if (hipMalloc(&d_status, sizeof(int)) != hipSuccess || hipMemset(d_status, 0, sizeof(int)) != hipSuccess) { freeall(); err = "hipMalloc failed"; return RXHIP_ERR_HIP; }
+    TreeParams p{};
+    p.ops = d_ops; p.aux = d_aux; p.cpool = d_cp; p.msg = d_msg; p.marg = d_marg; p.R = R; p.RS = RS; p.status = d_status;
+    const unsigned blocks = (unsigned)std::min<long long>((R + 255) / 256, 1 << 20);
+    for (int o = 0; o < 2; ++o) {
+        if (N == 1) hipLaunchKernelGGL(k_tree_ops<1>, dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
+        else if (N == 2) hipLaunchKernelGGL(k_tree_ops<2>, dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
+        else hipLaunchKernelGGL(k_tree_ops<4>, dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
+    }
+    int status = 0;
+    std::vector<double> res((size_t)(c->out_form ? msg_d : marg_d) * RS);
+    hipError_t he = hipDeviceSynchronize();
+    if (he == hipSuccess) he = hipMemcpy(&status, d_status, sizeof(int), hipMemcpyDeviceToHost);
+    if (he == hipSuccess) he = hipMemcpy(res.data(), c->out_form ? d_msg : d_marg, sizeof(double) * res.size(), hipMemcpyDeviceToHost);
+    freeall();
+    if (he != hipSuccess) { err = std::string("rule_eval: ") + hipGetErrorString(he); return RXHIP_ERR_HIP; }
+    if (status & 1) { err = "rule_eval: a matrix that must be positive definite was not"; return RXHIP_ERR_NOT_POSDEF; }
+    const int ro = c->out_form ? o_conv : 0, d = d_res;
+    for (long long r = 0; r < R; ++r) {
+        for (int k = 0; k < d; ++k) c->out_a[(size_t)r * d + k] = res[(size_t)(ro + k) * RS + r];
+        for (int i = 0; i < d; ++i)
+            for (int j = 0; j <= i; ++j) {
+                const double x = res[(size_t)(ro + d + i * (i + 1) / 2 + j) * RS + r];
+                c->out_B[((size_t)r * d + i) * d + j] = x;
+                c->out_B[((size_t)r * d + j) * d + i] = x;
+            }
+    }
+    return RXHIP_OK;
+}
+
+}  // namespace tree
+}  // namespace rxhip

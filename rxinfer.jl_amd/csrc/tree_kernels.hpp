@@ -1,0 +1,687 @@
+// tree_kernels.hpp — the level-scheduled node-array executor: ONE kernel that evaluates message rules over struct-of-arrays node tables.
+//
+// What it replaces: the reference builds `factornode(fform, interfaces, factorization)` for any graph and fires one @rule body per (node,
+// interface) through reactive streams (src/model/plugins/reactivemp_inference.jl:490-540; products :432-447; Bethe terms
+// reactivemp_free_energy.jl:51-126).  Here the host compiles the graph once (tree_engine.hip) into a list of OPS — one per message, product,
+// marginal, free-energy term — sorted by dependency level, and a work item of this kernel is (op, replica): lane-per-node, replica-fastest
+// storage, so the 64 lanes of a wavefront evaluate the same rule of the same node for 64 replicas with unit-stride loads, or (one replica) 64
+// different nodes of one level.  All state dimensions ≤ DMAX (template: 1, 2, 4) live in registers; runtime dimensions are handled by padding
+// (identity on the diagonal of whatever gets inverted, zeros elsewhere) under fully unrolled loops.
+//
+// Storage (doubles, replica-fastest: element k of slot `off` of replica r at (off + k)·RS + r, RS = replicas rounded up to 16 = a 128-byte line):
+//   message   [d | d(d+1)/2]        moment form (m, V) or weighted-mean / precision form (ξ, Λ); lower triangle, row-major — 8·(d + d(d+1)/2) bytes
+//   marginal  [d | d(d+1)/2 | 1]    mean, covariance, log det covariance
+//   precision [ν | V tri | Ŵ d² | Ŵ⁻¹ d² | E log|W|]    q(W) = Wishart(ν, V) of a mean-field precision variable and what the rules read of it
+//   term / stat: Bethe terms and residual second moments, summed in a fixed order (deterministic to the bit)
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rxhip {
+namespace tree {
+
+enum : int {
+    OP_NOP = 0,
+    OP_DERIVE_MUL = 1,   // clamped value through `A * x`
+    OP_DERIVE_ADD = 2,   // clamped value through `a + b`
+    OP_LEAF = 3,         // Gaussian node, other interface clamped:            N(value, Σ)  |  (W value, W)
+    OP_NOISE = 4,        // Gaussian node toward out / μ, other interface random: the additive rule in the form the inbound message has
+    OP_MUL_OUT = 5,      // typeof(*)(:out):  N(A m, A V Aᵀ)
+    OP_MUL_IN = 6,       // typeof(*)(:in):   (Aᵀ ξ, Aᵀ Λ A)
+    OP_ADD_OUT = 7,      // typeof(+)(:out), two random inputs:  N(m1 + m2, V1 + V2)
+    OP_ADD_IN = 8,       // typeof(+)(:in1 | :in2), the other input random:  N(m_out − m2, V_out + V2)
+    OP_SHIFT = 9,        // typeof(+) with a clamped input: ± the value, in the inbound message's own form
+    OP_PRODUCT = 10,     // product of inbound messages at a variable (outbound variable → factor message)
+    OP_MARGINAL = 11,    // product of ALL inbound messages, as (mean, cov, log det)
+    OP_FE_NOISE2 = 12,   // Bethe term of a Gaussian node with both interfaces random (node-local joint q(out, μ)); residual moments for q(W)
+    OP_FE_NOISE1 = 13,   // … one interface random
+    OP_FE_NOISE0 = 14,   // … both clamped
+    OP_FE_ENT = 15,      // coef · H[q(v)] of a random variable: (degree − 1) minus the deterministic nodes whose only random input it is
+    OP_FE_ADD2 = 16,     // −H[q(in1, in2)] of a `+` node with two random inputs
+    OP_SUM_TERMS = 17,   // fixed-order partial sum of terms
+    OP_PREC_UPDATE = 18  // q(W) ← Wishart(ν0 + n, (S0⁻¹ + Σ E[rrᵀ])⁻¹), its share of the Bethe sum
+};
+constexpr int OP_WORDS = 16;
+// word indices of an op descriptor
+enum : int { W_OP = 0, W_D0, W_D1, W_OUT, W_IN0, W_IN1, W_IN2, W_FLAGS, W_C0, W_C1, W_VAL, W_VAL2, W_PREC, W_TERM, W_N, W_LIST };
+// flags
+enum : int {
+    F_IN0_WP = 1, F_IN1_WP = 2, F_IN2_WP = 4, F_OUT_WP = 8,
+    F_VAL_SLOT = 16,     // W_VAL names a per-replica value slot (data / derived), else the constant pool
+    F_VAL2_SLOT = 32,
+    F_NEG = 64,          // OP_SHIFT: subtract the value
+    F_STAT = 128,        // FE_NOISE*: the node's precision is a random variable — write E[rrᵀ] to the stat slot W_C1
+    F_RAND_IS_MU = 256   // FE_NOISE1: the random interface is μ (r = value − μ)
+};
+
+struct TreeParams {
+    const int* ops;       // [n_ops][OP_WORDS]
+    const int* aux;       // lists: (offset, form) pairs of OP_PRODUCT / OP_MARGINAL, offsets of OP_SUM_TERMS / OP_PREC_UPDATE
+    const double* cpool;  // constants (replica-independent): matrices row-major; noise blocks Σ | W | log|W|; priors ν0 | S0⁻¹ | log|S0|
+    double* msg;
+    double* marg;
+    double* val;          // data and derived values
+    double* prec;
+    double* term;
+    double* stat;
+    long long R, RS;      // replicas; replica stride (R rounded up to 16)
+    int want_fe;
+    int* status;          // bit 0: a matrix that must be positive definite was not
+};
+
+constexpr double T_LOG2PI = 1.8378770664093454836;
+constexpr double T_LOG2 = 0.69314718055994530942;
+
+template <int N>
+__device__ __forceinline__ void ld_vec(const double* b, long long off, int d, long long RS, long long r, double (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = i < d ? b[(off + i) * RS + r] : 0.0;
+}
+template <int N>
+__device__ __forceinline__ void st_vec(double* b, long long off, int d, long long RS, long long r, const double (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+        if (i < d) b[(off + i) * RS + r] = v[i];
+}
+// packed lower triangle -> full symmetric, `pad` on the diagonal beyond d
+template <int N>
+__device__ __forceinline__ void ld_sym(const double* b, long long off, int d, long long RS, long long r, double pad, double (&M)[N][N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            const double x = (i < d) ? b[(off + i * (i + 1) / 2 + j) * RS + r] : (i == j ? pad : 0.0);
+            M[i][j] = x;
+            M[j][i] = x;
+        }
+}
+template <int N>
+__device__ __forceinline__ void st_sym(double* b, long long off, int d, long long RS, long long r, const double (&M)[N][N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j)
+            if (i < d) b[(off + i * (i + 1) / 2 + j) * RS + r] = 0.5 * (M[i][j] + M[j][i]);
+}
+// full d×d per-replica matrix (precision state)
+template <int N>
+__device__ __forceinline__ void ld_full(const double* b, long long off, int d, long long RS, long long r, double pad, double (&M)[N][N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) M[i][j] = (i < d && j < d) ? b[(off + i * d + j) * RS + r] : (i == j ? pad : 0.0);
+}
+template <int N>
+__device__ __forceinline__ void st_full(double* b, long long off, int d, long long RS, long long r, const double (&M)[N][N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (i < d && j < d) b[(off + i * d + j) * RS + r] = M[i][j];
+}
+// constant matrix rows×cols (row-major, the same for every replica), zero padding
+template <int N>
+__device__ __forceinline__ void ld_cmat(const double* c, int rows, int cols, double pad, double (&M)[N][N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) M[i][j] = (i < rows && j < cols) ? c[i * cols + j] : (i == j ? pad : 0.0);
+}
+template <int N>
+__device__ __forceinline__ void ld_cvec(const double* c, int d, double (&v)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = i < d ? c[i] : 0.0;
+}
+
+// inverse and log-determinant of a symmetric positive definite matrix (Cholesky, A = L Lᵀ, A⁻¹ = L⁻ᵀ L⁻¹); false: a pivot ≤ 0 or not finite
+template <int N>
+__device__ __forceinline__ bool spd_inv(const double (&A)[N][N], double (&Ai)[N][N], double& logdet) {
+    double L[N][N], Li[N][N];
+    bool ok = true;
+    double ld = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double s = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+        ok = ok && (s > 0.0) && (s < 1.0e300);
+        const double dj = sqrt(s), rj = 1.0 / dj;
+        ld += log(s);
+        L[j][j] = dj;
+        Li[j][j] = rj;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+            L[i][j] = t * rj;
+        }
+    }
+    // L⁻¹ (lower): Li[i][j] = −(Σ_{k=j}^{i−1} L[i][k] Li[k][j]) / L[i][i]
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = j; k < i; ++k) t += L[i][k] * Li[k][j];
+            Li[i][j] = -t * Li[i][i];
+        }
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j <= i; ++j) {
+            double t = 0.0;
+#pragma unroll
+            for (int k = i; k < N; ++k) t += Li[k][i] * Li[k][j];
+            Ai[i][j] = t;
+            Ai[j][i] = t;
+        }
+    logdet = ld;
+    return ok;
+}
+template <int N>
+__device__ __forceinline__ void matvec(const double (&A)[N][N], const double (&x)[N], double (&y)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) s += A[i][k] * x[k];
+        y[i] = s;
+    }
+}
+template <int N>
+__device__ __forceinline__ void matTvec(const double (&A)[N][N], const double (&x)[N], double (&y)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) s += A[k][i] * x[k];
+        y[i] = s;
+    }
+}
+template <int N>
+__device__ __forceinline__ void matmul(const double (&A)[N][N], const double (&B)[N][N], double (&C)[N][N]) {
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) s += A[i][k] * B[k][j];
+            C[i][j] = s;
+        }
+}
+template <int N>
+__device__ __forceinline__ void matmulT(const double (&A)[N][N], const double (&B)[N][N], double (&C)[N][N]) {   // A Bᵀ
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) s += A[i][k] * B[j][k];
+            C[i][j] = s;
+        }
+}
+template <int N>
+__device__ __forceinline__ void matTmul(const double (&A)[N][N], const double (&B)[N][N], double (&C)[N][N]) {   // Aᵀ B
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) s += A[k][i] * B[k][j];
+            C[i][j] = s;
+        }
+}
+template <int N>
+__device__ __forceinline__ double trace_prod(const double (&A)[N][N], const double (&B)[N][N], int d) {   // tr(A B) over the leading d×d block
+    double s = 0.0;
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (i < d && k < d) s += A[i][k] * B[k][i];
+    return s;
+}
+
+// a message in the form a rule wants: stored (a, B) is converted by one inverse when the forms differ
+template <int N>
+__device__ __forceinline__ bool load_msg(const TreeParams& p, int off, bool stored_wp, bool want_wp, int d, long long r, double (&a)[N], double (&B)[N][N]) {
+    ld_vec<N>(p.msg, off, d, p.RS, r, a);
+    ld_sym<N>(p.msg, off + d, d, p.RS, r, 1.0, B);
+    if (stored_wp == want_wp) return true;
+    double Bi[N][N], t[N], ld;
+    const bool ok = spd_inv<N>(B, Bi, ld);
+    matvec<N>(Bi, a, t);
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        a[i] = t[i];
+#pragma unroll
+        for (int j = 0; j < N; ++j) B[i][j] = Bi[i][j];
+    }
+    return ok;
+}
+template <int N>
+__device__ __forceinline__ void store_msg(const TreeParams& p, int off, int d, long long r, const double (&a)[N], const double (&B)[N][N]) {
+    st_vec<N>(p.msg, off, d, p.RS, r, a);
+    st_sym<N>(p.msg, off + d, d, p.RS, r, B);
+}
+// noise of a Gaussian node: Σ, W = Σ⁻¹ and (E) log|W| — constants (block Σ | W | log|W| at c0) or the state of a precision variable
+template <int N>
+__device__ __forceinline__ void load_noise(const TreeParams& p, const int* w, int d, long long r, bool want_sigma, bool want_w, double (&Sg)[N][N], double (&Wm)[N][N], double& elogdet) {
+    const int ps = w[W_PREC];
+    if (ps >= 0) {
+        const int tri = d * (d + 1) / 2;
+        if (want_w) ld_full<N>(p.prec, ps + 1 + tri, d, p.RS, r, 1.0, Wm);
+        if (want_sigma) ld_full<N>(p.prec, ps + 1 + tri + d * d, d, p.RS, r, 1.0, Sg);
+        elogdet = p.prec[(ps + 1 + tri + 2 * d * d) * p.RS + r];
+    } else {
+        const double* c = p.cpool + w[W_C0];
+        if (want_sigma) ld_cmat<N>(c, d, d, 1.0, Sg);
+        if (want_w) ld_cmat<N>(c + d * d, d, d, 1.0, Wm);
+        elogdet = c[2 * d * d];
+    }
+}
+template <int N>
+__device__ __forceinline__ void load_value(const TreeParams& p, int off, bool slot, int d, long long r, double (&v)[N]) {
+    if (slot) ld_vec<N>(p.val, off, d, p.RS, r, v);
+    else ld_cvec<N>(p.cpool + off, d, v);
+}
+
+__device__ __forceinline__ double t_digamma(double x) {   // x > 0
+    double r = 0.0;
+    while (x < 6.0) { r -= 1.0 / x; x += 1.0; }
+    const double f = 1.0 / (x * x);
+    return r + log(x) - 0.5 / x - f * (1.0 / 12.0 - f * (1.0 / 120.0 - f * (1.0 / 252.0 - f * (1.0 / 240.0 - f * (1.0 / 132.0)))));
+}
+__device__ __forceinline__ double t_mvdigamma(double a, int d) {
+    double s = 0.0;
+    for (int i = 0; i < d; ++i) s += t_digamma(a - 0.5 * i);
+    return s;
+}
+__device__ __forceinline__ double t_mvlgamma(double a, int d) {
+    double s = 0.25 * d * (d - 1) * 1.1447298858494001741;   // log π
+    for (int i = 0; i < d; ++i) s += lgamma(a - 0.5 * i);
+    return s;
+}
+
+// ------------------------------------------------------------------------------------------
+template <int N>
+__device__ __forceinline__ void eval_op(const TreeParams& p, const int* __restrict__ w, long long r) {
+    const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS];
+    bool ok = true;
+    switch (op) {
+    case OP_DERIVE_MUL: {   // val[out] = A (d × d1) val[in]
+        double A[N][N], x[N], y[N];
+        ld_cmat<N>(p.cpool + w[W_C0], d, w[W_D1], 0.0, A);
+        load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, w[W_D1], r, x);
+        matvec<N>(A, x, y);
+        st_vec<N>(p.val, w[W_OUT], d, p.RS, r, y);
+    } break;
+    case OP_DERIVE_ADD: {
+        double x[N], y[N];
+        load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, x);
+        load_value<N>(p, w[W_VAL2], fl & F_VAL2_SLOT, d, r, y);
+#pragma unroll
+        for (int i = 0; i < N; ++i) x[i] += y[i];
+        st_vec<N>(p.val, w[W_OUT], d, p.RS, r, x);
+    } break;
+    case OP_LEAF: {
+        double v[N], Sg[N][N], Wm[N][N], el;
+        load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, v);
+        const bool wp = fl & F_OUT_WP;
+        load_noise<N>(p, w, d, r, !wp, wp, Sg, Wm, el);
+        if (wp) {
+            double xi[N];
+            matvec<N>(Wm, v, xi);
+            store_msg<N>(p, w[W_OUT], d, r, xi, Wm);
+        } else
+            store_msg<N>(p, w[W_OUT], d, r, v, Sg);
+    } break;
+    case OP_NOISE: {
+        double a[N], B[N][N], Sg[N][N], Wm[N][N], el;
+        const bool wp = fl & F_IN0_WP;
+        ok = load_msg<N>(p, w[W_IN0], wp, wp, d, r, a, B);
+        load_noise<N>(p, w, d, r, !wp, wp, Sg, Wm, el);
+        if (!wp) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) B[i][j] += Sg[i][j];
+            store_msg<N>(p, w[W_OUT], d, r, a, B);
+        } else {   // Λ' = Λ (Λ + W)⁻¹ W, ξ' = W (Λ + W)⁻¹ ξ: defined for a rank-deficient Λ, equal to (Λ⁻¹ + Σ)⁻¹ otherwise
+            double G[N][N], Gi[N][N], t[N], xo[N], T1[N][N], Lo[N][N], ld;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) G[i][j] = B[i][j] + Wm[i][j];
+            ok = spd_inv<N>(G, Gi, ld) && ok;
+            matvec<N>(Gi, a, t);
+            matvec<N>(Wm, t, xo);
+            matmul<N>(Gi, Wm, T1);
+            matmul<N>(B, T1, Lo);
+            store_msg<N>(p, w[W_OUT], d, r, xo, Lo);
+        }
+    } break;
+    case OP_MUL_OUT: {   // in: dimension d1 (moment form), out: dimension d
+        double a[N], V[N][N], A[N][N], m[N], T1[N][N], Vo[N][N];
+        ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, false, w[W_D1], r, a, V);
+        ld_cmat<N>(p.cpool + w[W_C0], d, w[W_D1], 0.0, A);
+        matvec<N>(A, a, m);
+        matmul<N>(A, V, T1);
+        matmulT<N>(T1, A, Vo);
+        store_msg<N>(p, w[W_OUT], d, r, m, Vo);
+    } break;
+    case OP_MUL_IN: {    // in: the message toward `out`, dimension d (precision form); out: dimension d1
+        double xi[N], L[N][N], A[N][N], xo[N], T1[N][N], Lo[N][N];
+        ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, true, d, r, xi, L);
+        ld_cmat<N>(p.cpool + w[W_C0], d, w[W_D1], 0.0, A);
+#pragma unroll
+        for (int i = 0; i < N; ++i)   // the padding of Λ beyond d meets zero rows of A
+            if (i >= d) L[i][i] = 0.0;
+        matTvec<N>(A, xi, xo);
+        matTmul<N>(A, L, T1);
+        matmul<N>(T1, A, Lo);
+        store_msg<N>(p, w[W_OUT], w[W_D1], r, xo, Lo);
+    } break;
+    case OP_ADD_OUT:
+    case OP_ADD_IN: {
+        double a0[N], V0[N][N], a1[N], V1[N][N];
+        ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, false, d, r, a0, V0);
+        ok = load_msg<N>(p, w[W_IN1], fl & F_IN1_WP, false, d, r, a1, V1) && ok;
+        const double sg = op == OP_ADD_OUT ? 1.0 : -1.0;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            a0[i] += sg * a1[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) V0[i][j] += V1[i][j];
+        }
+        store_msg<N>(p, w[W_OUT], d, r, a0, V0);
+    } break;
+    case OP_SHIFT: {
+        double a[N], B[N][N], c[N];
+        const bool wp = fl & F_IN0_WP;
+        ok = load_msg<N>(p, w[W_IN0], wp, wp, d, r, a, B);
+        load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, c);
+        const double sg = (fl & F_NEG) ? -1.0 : 1.0;
+        if (wp) {
+            double t[N];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (i >= d) B[i][i] = 0.0;
+            matvec<N>(B, c, t);
+#pragma unroll
+            for (int i = 0; i < N; ++i) a[i] += sg * t[i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) a[i] += sg * c[i];
+        }
+        store_msg<N>(p, w[W_OUT], d, r, a, B);
+    } break;
+    case OP_PRODUCT:
+    case OP_MARGINAL: {
+        double xi[N], L[N][N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            xi[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) L[i][j] = 0.0;
+        }
+        const int n = w[W_N];
+        const int* lst = p.aux + w[W_LIST];
+        for (int q = 0; q < n; ++q) {   // left to right, in factor order (MessagesProductFromLeftToRight)
+            double a[N], B[N][N];
+            ok = load_msg<N>(p, lst[2 * q], lst[2 * q + 1] != 0, true, d, r, a, B) && ok;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                xi[i] += a[i];
+#pragma unroll
+                for (int j = 0; j < N; ++j) L[i][j] += (i < d && j < d) ? B[i][j] : 0.0;
+            }
+        }
+        if (op == OP_PRODUCT) {
+            store_msg<N>(p, w[W_OUT], d, r, xi, L);
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+                if (i >= d) L[i][i] = 1.0;
+            double V[N][N], m[N], ld;
+            ok = spd_inv<N>(L, V, ld) && ok;
+            matvec<N>(V, xi, m);
+            st_vec<N>(p.marg, w[W_OUT], d, p.RS, r, m);
+            st_sym<N>(p.marg, w[W_OUT] + d, d, p.RS, r, V);
+            p.marg[(w[W_OUT] + d + d * (d + 1) / 2) * p.RS + r] = -ld;
+        }
+    } break;
+    case OP_FE_NOISE2: {
+        // joint precision [[Lo + W, −W], [−W, Lm + W]]; with P = Lo + W, S = (Lm + W) − W P⁻¹ W:  log|J| = log|P| + log|S|,
+        // V_μμ = S⁻¹, V_oμ = P⁻¹ W S⁻¹, V_oo = P⁻¹ + P⁻¹ W S⁻¹ W P⁻¹;  r = out − μ
+        double xo[N], Lo[N][N], xm[N], Lm[N][N], Sg[N][N], Wm[N][N], el;
+        if (w[W_IN0] >= 0) ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, true, d, r, xo, Lo);
+        if (w[W_IN1] >= 0) ok = load_msg<N>(p, w[W_IN1], fl & F_IN1_WP, true, d, r, xm, Lm) && ok;
+        load_noise<N>(p, w, d, r, false, true, Sg, Wm, el);
+        double P[N][N], Pi[N][N], S[N][N], Si[N][N], ldP, ldS;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            if (w[W_IN0] < 0) xo[i] = 0.0;
+            if (w[W_IN1] < 0) xm[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const bool in = i < d && j < d;
+                const double lo = (w[W_IN0] >= 0 && in) ? Lo[i][j] : 0.0, lm = (w[W_IN1] >= 0 && in) ? Lm[i][j] : 0.0;
+                P[i][j] = lo + Wm[i][j];
+                S[i][j] = lm + Wm[i][j];
+            }
+        }
+        ok = spd_inv<N>(P, Pi, ldP) && ok;
+        double PW[N][N], T1[N][N];
+        matmul<N>(Pi, Wm, PW);        // P⁻¹ W
+        matTmul<N>(Wm, PW, T1);       // W P⁻¹ W (W symmetric)
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) S[i][j] -= (i < d && j < d) ? T1[i][j] : 0.0;
+        ok = spd_inv<N>(S, Si, ldS) && ok;
+        // means: m_μ = S⁻¹ (ξ_μ + W P⁻¹ ξ_o), m_o = P⁻¹ (ξ_o + W m_μ)
+        double t0[N], t1[N], mm[N], mo[N];
+        matvec<N>(Pi, xo, t0);
+        matvec<N>(Wm, t0, t1);
+#pragma unroll
+        for (int i = 0; i < N; ++i) t1[i] += xm[i];
+        matvec<N>(Si, t1, mm);
+        matvec<N>(Wm, mm, t0);
+#pragma unroll
+        for (int i = 0; i < N; ++i) t0[i] += xo[i];
+        matvec<N>(Pi, t0, mo);
+        // Cov(r) = V_oo − V_oμ − V_μo + V_μμ = P⁻¹ + (P⁻¹W − I) S⁻¹ (P⁻¹W − I)ᵀ
+        double Dm[N][N], T2[N][N], E[N][N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) Dm[i][j] = PW[i][j] - (i == j ? 1.0 : 0.0);
+        matmul<N>(Dm, Si, T2);
+        matmulT<N>(T2, Dm, E);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) E[i][j] += Pi[i][j] + (mo[i] - mm[i]) * (mo[j] - mm[j]);
+        const double H = 0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
+        double term = -H;
+        if (fl & F_STAT) st_full<N>(p.stat, w[W_C1], d, p.RS, r, E);
+        else term += 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
+        p.term[(long long)w[W_TERM] * p.RS + r] = term;
+    } break;
+    case OP_FE_NOISE1:
+    case OP_FE_NOISE0: {
+        double E[N][N], Sg[N][N], Wm[N][N], el, rv[N], H = 0.0;
+        load_noise<N>(p, w, d, r, false, true, Sg, Wm, el);
+        if (op == OP_FE_NOISE1) {
+            double m[N], V[N][N], c[N];
+            ld_vec<N>(p.marg, w[W_IN0], d, p.RS, r, m);
+            ld_sym<N>(p.marg, w[W_IN0] + d, d, p.RS, r, 0.0, V);
+            H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r]);
+            load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, c);
+#pragma unroll
+            for (int i = 0; i < N; ++i) rv[i] = m[i] - c[i];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) E[i][j] = V[i][j] + rv[i] * rv[j];
+        } else {
+            double a[N], b[N];
+            load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, a);
+            load_value<N>(p, w[W_VAL2], fl & F_VAL2_SLOT, d, r, b);
+#pragma unroll
+            for (int i = 0; i < N; ++i) rv[i] = a[i] - b[i];
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) E[i][j] = rv[i] * rv[j];
+        }
+        double term = -H;
+        if (fl & F_STAT) st_full<N>(p.stat, w[W_C1], d, p.RS, r, E);
+        else term += 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
+        p.term[(long long)w[W_TERM] * p.RS + r] = term;
+    } break;
+    case OP_FE_ENT: {
+        const double H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r]);
+        p.term[(long long)w[W_TERM] * p.RS + r] = (double)w[W_N] * H;
+    } break;
+    case OP_FE_ADD2: {   // Lj = [[L1 + Lo, Lo], [Lo, L2 + Lo]]: log|Lj| = log|L1 + Lo| + log|L2 + Lo − Lo (L1 + Lo)⁻¹ Lo|
+        double x[N], L1[N][N], L2[N][N], Lo[N][N];
+        if (w[W_IN0] >= 0) ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, true, d, r, x, L1);
+        if (w[W_IN1] >= 0) ok = load_msg<N>(p, w[W_IN1], fl & F_IN1_WP, true, d, r, x, L2) && ok;
+        if (w[W_IN2] >= 0) ok = load_msg<N>(p, w[W_IN2], fl & F_IN2_WP, true, d, r, x, Lo) && ok;
+        double P[N][N], Pi[N][N], S[N][N], Si[N][N], T1[N][N], T2[N][N], ldP, ldS;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const bool in = i < d && j < d;
+                const double l1 = (w[W_IN0] >= 0 && in) ? L1[i][j] : 0.0, l2 = (w[W_IN1] >= 0 && in) ? L2[i][j] : 0.0, lo = (w[W_IN2] >= 0 && in) ? Lo[i][j] : 0.0;
+                Lo[i][j] = lo;
+                P[i][j] = l1 + lo + ((!in && i == j) ? 1.0 : 0.0);
+                S[i][j] = l2 + lo + ((!in && i == j) ? 1.0 : 0.0);
+            }
+        ok = spd_inv<N>(P, Pi, ldP) && ok;
+        matmul<N>(Pi, Lo, T1);
+        matmul<N>(Lo, T1, T2);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) S[i][j] -= T2[i][j];
+        ok = spd_inv<N>(S, Si, ldS) && ok;
+        p.term[(long long)w[W_TERM] * p.RS + r] = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
+    } break;
+    case OP_SUM_TERMS: {
+        const int n = w[W_N];
+        const int* lst = p.aux + w[W_LIST];
+        double s = 0.0;
+        for (int q = 0; q < n; ++q) s += p.term[(long long)lst[q] * p.RS + r];
+        p.term[(long long)w[W_TERM] * p.RS + r] = s;
+    } break;
+    case OP_PREC_UPDATE: {
+        // prior block at c0: ν0 | S0⁻¹ (d²) | log|S0|;  stats: list of d² slots;  state at W_PREC
+        const double* c = p.cpool + w[W_C0];
+        const double nu0 = c[0], ldS0 = c[1 + d * d];
+        double S0i[N][N], S[N][N];
+        ld_cmat<N>(c + 1, d, d, 1.0, S0i);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) S[i][j] = 0.0;
+        const int n = w[W_N];
+        const int* lst = p.aux + w[W_LIST];
+        for (int q = 0; q < n; ++q) {
+            double E[N][N];
+            ld_full<N>(p.stat, lst[q], d, p.RS, r, 0.0, E);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) S[i][j] += E[i][j];
+        }
+        double Vi[N][N], V[N][N], Ss[N][N], ldVi;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                Ss[i][j] = (i < d && j < d) ? 0.5 * (S[i][j] + S[j][i]) : 0.0;
+                Vi[i][j] = S0i[i][j] + Ss[i][j];
+            }
+        ok = spd_inv<N>(Vi, V, ldVi);
+        const double nu = nu0 + (double)n, ldV = -ldVi;
+        const int ps = w[W_PREC], tri = d * (d + 1) / 2;
+        double What[N][N], Whi[N][N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                What[i][j] = nu * V[i][j];
+                Whi[i][j] = Vi[i][j] / nu;
+            }
+        const double elw = t_mvdigamma(0.5 * nu, d) + d * T_LOG2 + ldV;
+        p.prec[(long long)ps * p.RS + r] = nu;
+        st_sym<N>(p.prec, ps + 1, d, p.RS, r, V);
+        st_full<N>(p.prec, ps + 1 + tri, d, p.RS, r, What);
+        st_full<N>(p.prec, ps + 1 + tri + d * d, d, p.RS, r, Whi);
+        p.prec[(long long)(ps + 1 + tri + 2 * d * d) * p.RS + r] = elw;
+        if (p.want_fe) {
+            // the n likelihood nodes: ½[n d log 2π − n E log|W| + tr(Ŵ Σ E[rrᵀ])]; the prior node U − H[q(W)] (the terms of noise_kernels.hpp, per precision variable)
+            double F = 0.5 * ((double)n * (d * T_LOG2PI - elw) + trace_prod<N>(What, Ss, d));
+            F += -(0.5 * (nu0 - d - 1.0) * elw - 0.5 * trace_prod<N>(S0i, What, d) - 0.5 * nu0 * d * T_LOG2 - 0.5 * nu0 * ldS0 - t_mvlgamma(0.5 * nu0, d));
+            F -= 0.5 * (d + 1.0) * ldV + 0.5 * d * (d + 1.0) * T_LOG2 + t_mvlgamma(0.5 * nu, d) - 0.5 * (nu - d - 1.0) * t_mvdigamma(0.5 * nu, d) + 0.5 * nu * d;
+            p.term[(long long)w[W_TERM] * p.RS + r] = F;
+        }
+    } break;
+    default: break;
+    }
+    if (!ok) atomicOr(p.status, 1);
+}
+
+// one launch per level: items (op, replica) over the grid
+template <int N>
+__global__ void __launch_bounds__(256) k_tree_ops(TreeParams p, int op0, int op1) {
+    const long long total = (long long)(op1 - op0) * p.R;
+    for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
+        const long long o = it / p.R, r = it - o * p.R;
+        eval_op<N>(p, p.ops + (size_t)(op0 + o) * OP_WORDS, r);
+    }
+}
+// the whole schedule in one launch: a workgroup owns `rb` replicas (a multiple of 16: whole 128-byte lines of every slot) and walks the levels with a
+// workgroup barrier between them — for deep, narrow graphs (a chain is three levels per time step) where a launch per level would cost more than the level
+template <int N>
+__global__ void __launch_bounds__(256) k_tree_levels(TreeParams p, const int* __restrict__ lvl_ptr, int l0, int l1, int rb) {
+    const long long r0 = (long long)blockIdx.x * rb;
+    const int nr = (int)((p.R - r0) < rb ? (p.R - r0) : rb);
+    for (int l = l0; l < l1; ++l) {
+        const int o0 = lvl_ptr[l], o1 = lvl_ptr[l + 1];
+        const int total = (o1 - o0) * nr;
+        for (int it = threadIdx.x; it < total; it += blockDim.x) {
+            const int o = it / nr, r = it - o * nr;
+            eval_op<N>(p, p.ops + (size_t)(o0 + o) * OP_WORDS, r0 + r);
+        }
+        __syncthreads();   // (waits for the level's stores: every reader of the next level is in this workgroup)
+    }
+}
+// per-replica free energy = term[root]; total over replicas in a fixed order (one workgroup, pairwise tree over a fixed layout)
+__global__ void __launch_bounds__(256) k_tree_fe_total(const double* __restrict__ term, long long root, long long R, long long RS, double* __restrict__ per_replica, double* __restrict__ total) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (long long r = threadIdx.x; r < R; r += 256) {
+        const double v = term[root * RS + r];
+        if (per_replica) per_replica[r] = v;
+        s += v;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = sh[0];
+}
+
+}  // namespace tree
+}  // namespace rxhip

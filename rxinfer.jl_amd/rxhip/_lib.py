@@ -108,9 +108,27 @@ class NoisePrior(ctypes.Structure):   # rxhip_noise_prior
     _fields_ = [("nu0", ctypes.c_double), ("S0", c_double_p), ("init_nu", ctypes.c_double), ("init_V", c_double_p)]
 
 
+class TreeInfo(ctypes.Structure):   # rxhip_tree_info
+    _fields_ = [("n_ops", ctypes.c_int64), ("n_levels", ctypes.c_int64), ("n_messages", ctypes.c_int64), ("doubles_per_replica", ctypes.c_int64),
+                ("bytes_per_sweep", ctypes.c_int64), ("dmax", ctypes.c_int32), ("mode", ctypes.c_int32), ("replicas_per_workgroup", ctypes.c_int32),
+                ("n_precision_vars", ctypes.c_int32)]
+
+
+class RuleCall(ctypes.Structure):   # rxhip_rule_call
+    _fields_ = [("node_type", ctypes.c_int32), ("iface", ctypes.c_int32), ("d_out", ctypes.c_int32), ("d_in", ctypes.c_int32), ("n", ctypes.c_int64),
+                ("constant", c_double_p), ("in_form", ctypes.c_int32), ("in_a", c_double_p), ("in_B", c_double_p), ("in2_a", c_double_p),
+                ("in2_B", c_double_p), ("out_form", ctypes.c_int32), ("out_a", c_double_p), ("out_B", c_double_p)]
+
+
 # every symbol include/rxhip.h declares: (name, restype, argtypes)
 _H = ctypes.c_void_p
 SYMBOLS = [
+    ("rxhip_tree_create", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.c_int32, ctypes.c_void_p, ctypes.POINTER(_H)]),
+    ("rxhip_tree_set_data", ctypes.c_int32, [_H, c_int64_p, ctypes.c_int64, c_double_p]),
+    ("rxhip_tree_get_marginals", ctypes.c_int32, [_H, c_int64_p, ctypes.c_int64, c_double_p, c_double_p]),
+    ("rxhip_tree_get_precision", ctypes.c_int32, [_H, ctypes.c_int64, c_double_p, c_double_p]),
+    ("rxhip_tree_get_info", ctypes.c_int32, [_H, ctypes.POINTER(TreeInfo)]),
+    ("rxhip_rule_eval", ctypes.c_int32, [ctypes.POINTER(RuleCall), ctypes.c_int32]),
     ("rxhip_lgssm_create", ctypes.c_int32, [ctypes.POINTER(LgssmDesc), ctypes.POINTER(_H)]),
     ("rxhip_lgssm_noise_create", ctypes.c_int32, [ctypes.POINTER(LgssmDesc), ctypes.POINTER(NoisePrior), ctypes.POINTER(_H)]),
     ("rxhip_lgssm_noise_get", ctypes.c_int32, [_H, c_double_p, c_double_p]),

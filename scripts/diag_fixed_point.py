@@ -33,7 +33,7 @@ for pc, C in ((False, 64), (True, 64), (False, 3)):
 d = 4
 rng = np.random.default_rng(12)
 q, _ = np.linalg.qr(rng.standard_normal((d, d)))
-mu = dict(A=(1.0 - 1e-6) * (q @ np.diag([1.0, 0.999, 0.99, 0.9]) @ q.T), B=np.eye(d), P=1e-12 * np.eye(d), Q=np.eye(d), m0=np.zeros(d), V0=4.0 * np.eye(d))
+mu = dict(A=(1.0 - 1e-6) * (q @ np.diag([1.0, 0.999, 0.99, 0.9]) @ q.T), B=np.eye(d), P=1e-8 * np.eye(d), Q=np.eye(d), m0=np.zeros(d), V0=4.0 * np.eye(d))
 yu = np.ascontiguousarray(np.tile(T._generate(mu, 20000, 2, seed=5), (1, 32, 1)))
 for pc in (False, True):
     cases.append((f"unit_root d4 per_chain={pc}", mu, yu, dict(per_chain=pc), (0,)))

@@ -1,0 +1,229 @@
+"""The level-scheduled node-array executor (csrc/tree_engine.hip, tree_kernels.hpp) through the C ABI against oracle/tree_oracle.py — the graphs
+`rxhip_create` used to reject (two observation branches per state, a tree that is not a chain, an unknown STATE-noise precision), the graphs the
+specialised engines run as well (the state-space chain: executor ≡ LGSSMEngine to 1e-12), both launch schedules (one launch per level / workgroup-
+resident levels), several replicas, and the single-rule entry point.
+
+Tolerances: posteriors 1e-6 relative per component on the scale of its posterior standard deviation and free energy 1e-8 (north_star); what is
+measured is 1e-12 or better, asserted at 1e-9."""
+import numpy as np
+import pytest
+
+import tree_graphs as tg
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(gb, ys, R, iterations=1, mode=None, monkeypatch=None, force=True, seed=0):
+    from rxhip.tree import TreeEngine
+    if monkeypatch is not None:
+        (monkeypatch.setenv("RXHIP_TREE_MODE", str(mode)) if mode is not None else monkeypatch.delenv("RXHIP_TREE_MODE", raising=False))
+    data = tg.random_data(gb, ys, R, seed)
+    eng = TreeEngine(gb, n_replicas=R, force_executor=force)
+    eng.set_data(ys, data)
+    eng.run(iterations, True)
+    return eng, data
+
+
+def _check(gb, ys, eng, data, iterations=1, replicas=(0,), tol=1e-9, tol_fe=1e-9, prec_vars=()):
+    import tree_oracle
+    gvars = [v for v in range(len(gb.kind)) if v in eng_gauss(gb)]
+    post = eng.marginals(gvars)
+    fe_rep = eng.free_energy_per_replica()
+    for r in replicas:
+        ref = tree_oracle.infer(gb.to_dump(), tg.data_dict(gb, ys, data[r]), iterations=iterations)
+        for v in gvars:
+            m, V = post[v][0][r], post[v][1][r]
+            sd = np.sqrt(np.diag(ref["cov"][v]))
+            if np.all(sd < 1e-7):
+                continue
+            assert np.max(np.abs(m - ref["mean"][v]) / sd) < tol, (v, r)
+            assert np.max(np.abs(V - ref["cov"][v]) / np.outer(sd, sd)) < tol, (v, r)
+        assert fe_rep[r] == pytest.approx(ref["fe"][-1], rel=tol_fe, abs=1e-9), r
+        for w in prec_vars:
+            nu, V = eng.precision(w)
+            assert nu[r] == pytest.approx(ref["q_prec"][w][0], rel=1e-12)
+            assert np.allclose(V[r], ref["q_prec"][w][1], rtol=1e-9, atol=1e-300)
+    return ref
+
+
+def eng_gauss(gb):
+    """the random Gaussian variables of a builder graph (what tree_oracle classifies as such)"""
+    import tree_oracle
+    g = tree_oracle.TreeGraph(gb.to_dump())
+    return {v for v in range(len(gb.kind)) if g.gauss[v]}
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("builder,kw", [(tg.two_branch_chain, dict(T=12)), (tg.two_branch_chain, dict(T=9, d=2, dy1=2, dy2=2, precision_spelling=True)),
+                                        (tg.two_branch_chain, dict(T=7, d=4, dy1=4, dy2=3)),
+                                        (tg.branching_tree, dict(depth=3, fanout=2, d=1, seed=5)), (tg.branching_tree, dict(depth=2, fanout=3, d=2)),
+                                        (tg.scalar_tree, dict(n_leaves=6)), (tg.chain_with_prediction, dict(T=8, H=3))])
+def test_unsupported_shapes_against_the_oracle(builder, kw, mode, monkeypatch):
+    gb, ys, _ = builder(**kw)
+    R = 5
+    eng, data = _run(gb, ys, R, mode=mode, monkeypatch=monkeypatch)
+    assert eng.info["mode"] == mode
+    finite_fe = not (builder is tg.branching_tree and kw.get("d", 1) > 1)   # (B x with more rows than columns: H[q(Bx)] = −∞, in the reference too)
+    if finite_fe:
+        ref = _check(gb, ys, eng, data, replicas=(0, R - 1))
+        assert eng.counters()["rule_calls"] == ref["counters"]["rule_calls"] * R
+    eng.close()
+
+
+def test_branching_tree_marginals_without_a_free_energy():
+    """a map with more rows than columns makes the Bethe sum −∞ (the entropy of a degenerate image): the sweep itself is exact"""
+    from rxhip.tree import TreeEngine
+    import tree_oracle
+    gb, ys, _ = tg.branching_tree(depth=2, fanout=2, d=2)
+    data = tg.random_data(gb, ys, 3, 1)
+    with TreeEngine(gb, n_replicas=3) as eng:
+        eng.set_data(ys, data)
+        eng.run(1, False)
+        gv = sorted(eng_gauss(gb))
+        post = eng.marginals(gv)
+    bf, _ = tg.brute_force(gb, tg.data_dict(gb, ys, data[2]))
+    for v in gv:
+        sd = np.sqrt(np.diag(bf[v][1]))
+        if np.all(sd < 1e-7):
+            continue
+        ok = sd > 1e-7
+        assert np.max(np.abs(post[v][0][2] - bf[v][0])[ok] / sd[ok]) < 1e-9, v
+
+
+def test_rxhip_create_falls_through_to_the_executor():
+    """the pattern matcher rejects a state with two observation branches (graph_lowering.hpp); rxhip_create now answers with an engine"""
+    import rxhip
+    gb, ys, _ = tg.two_branch_chain(T=6)
+    eng, data = _run(gb, ys, 2, force=False)
+    _check(gb, ys, eng, data, replicas=(1,))
+    eng.close()
+    with pytest.raises(rxhip.RxHipError) as ei:   # a cycle among the Gaussian variables is still unsupported — and says why
+        from rxhip import _lib
+        from rxhip.tree import TreeEngine
+        g2, y2, nm = tg.two_branch_chain(T=3)
+        x0, x2 = nm["x"][0], nm["x"][2]
+        g2.mvnormal_mean_cov(x2, x0, g2.constvar(np.eye(3)))   # closes a loop x0 — x1 — x2 — x0
+        TreeEngine(g2, n_replicas=1, force_executor=False)
+    assert ei.value.status == _lib.ERR_UNSUPPORTED and "cycle" in str(ei.value)
+
+
+@pytest.mark.parametrize("d,dy,T,R,mode", [(4, 4, 60, 70, 1), (3, 3, 40, 3, 0), (2, 2, 300, 1, 1), (1, 1, 25, 130, 0)])
+def test_state_space_chain_equals_the_specialised_engine(d, dy, T, R, mode, monkeypatch):
+    """the LGSSM chain through the generic path against LGSSMEngine (and the oracle)"""
+    import rxhip
+    import rxoracle as rxo
+    from rxhip import workloads
+    from rxhip.graph import lgssm_graph
+    from rxhip.tree import TreeEngine
+    monkeypatch.setenv("RXHIP_TREE_MODE", str(mode))
+    m = workloads.random_model(d, dy, seed=10 * d + dy)
+    y = workloads.generate_batch(m, T, R, seed0=7)                     # [T][R][dy]
+    gb, xs, ys = lgssm_graph(T, m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"])
+    with TreeEngine(gb, n_replicas=R) as eng:
+        eng.set_data(ys, np.ascontiguousarray(np.transpose(y, (1, 0, 2))).reshape(R, T * dy))
+        eng.run(1, True)
+        post = eng.marginals(xs)
+        fe = eng.free_energy_per_replica()
+        cnt = eng.counters()
+    with rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=T, n_chains=R) as ref:
+        ref.set_data(y)
+        ref.run(1, True)
+        mean, cov = ref.marginals()
+        rfe = ref.free_energy_per_chain()
+    tm = np.stack([post[v][0] for v in xs])                            # [T][R][d]
+    tc = np.stack([post[v][1] for v in xs])
+    sd = np.sqrt(np.einsum("trii->tri", cov))
+    assert np.max(np.abs(tm - mean) / sd) < 1e-12 * 50
+    assert np.max(np.abs(tc - cov) / (sd[..., :, None] * sd[..., None, :])) < 1e-12 * 50
+    assert np.max(np.abs(fe - rfe) / np.abs(rfe)) < 1e-12
+    om, oc, ofe, ocnt = rxo.lgssm_bp(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], np.ascontiguousarray(y[:, 0]))
+    assert fe[0] == pytest.approx(ofe, rel=1e-11)
+    assert cnt["rule_calls"] == ocnt.rule_calls * R
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("kw", [dict(T=20, d=2, dy=2), dict(T=15, d=3, dy=2, also_obs_noise=True), dict(T=30, gamma=True)])
+def test_unknown_state_noise_precision_vmp(kw, mode, monkeypatch):
+    """x[t] ~ MvNormal(μ = A x[t-1], Λ = W), W ~ Wishart: every iteration's free energy and the final q(x), q(W) against the oracle"""
+    import tree_oracle
+    gb, ys, named = tg.chain_state_noise_precision(**kw)
+    R, its = 4, 8
+    eng, data = _run(gb, ys, R, iterations=its, mode=mode, monkeypatch=monkeypatch)
+    assert eng.info["n_precision_vars"] == len(named["W"])
+    _check(gb, ys, eng, data, iterations=its, replicas=(0, R - 1), prec_vars=named["W"])
+    fe_it = eng.free_energy()
+    tot = np.zeros(its)
+    for r in range(R):
+        tot += np.array(tree_oracle.infer(gb.to_dump(), tg.data_dict(gb, ys, data[r]), iterations=its)["fe"])
+    assert np.allclose(fe_it, tot, rtol=1e-10)
+    assert np.all(np.diff(fe_it) <= 1e-9 * np.abs(fe_it[:-1]))        # VMP: the free energy does not increase
+    eng.close()
+
+
+def test_observation_noise_vmp_equals_the_specialised_engine():
+    """the composed graph of round 4 (chain + unknown OBSERVATION-noise precision) through the generic path against LGSSMNoiseEngine"""
+    import rxhip
+    from rxhip import workloads
+    from rxhip.graph import lgssm_noise_graph
+    from rxhip.tree import TreeEngine
+    d = dy = 3
+    m = workloads.random_model(d, dy, seed=21)
+    T, R, its = 50, 6, 6
+    y = workloads.generate_batch(m, T, R, seed0=2)
+    S0 = np.eye(dy) * 0.4
+    gb, xs, ys, W = lgssm_noise_graph(T, m["A"], m["B"], m["P"], m["m0"], m["V0"], dy + 2.0, S0, init=(dy + 1.0, np.eye(dy)))
+    with TreeEngine(gb, n_replicas=R) as eng:
+        eng.set_data(ys, np.ascontiguousarray(np.transpose(y, (1, 0, 2))).reshape(R, T * dy))
+        eng.run(its, True)
+        post = eng.marginals(xs)
+        fe = eng.free_energy()
+        nu, V = eng.precision(W)
+    with rxhip.LGSSMNoiseEngine(m["A"], m["B"], m["P"], m["m0"], m["V0"], T=T, n_chains=R, nu0=dy + 2.0, S0=S0, init_nu=dy + 1.0, init_V=np.eye(dy)) as ref:
+        ref.set_data(y)
+        ref.run(its, True)
+        mean, cov = ref.marginals()
+        rfe = ref.free_energy()
+        rnu, rV = ref.noise_posterior()
+    tm = np.stack([post[v][0] for v in xs])
+    sd = np.sqrt(np.einsum("trii->tri", cov))
+    assert np.max(np.abs(tm - mean) / sd) < 1e-10
+    assert np.allclose(fe, rfe, rtol=1e-11)
+    assert np.allclose(nu, rnu) and np.allclose(V, rV, rtol=1e-10)
+
+
+def test_rule_eval_matches_the_rules_as_appendix_a_states_them():
+    from rxhip import _lib
+    from rxhip.tree import rule_eval
+    rng = np.random.default_rng(3)
+    n, d, dy = 37, 3, 2
+
+    def spd(k):
+        a = rng.standard_normal((n, k, k))
+        return a @ np.transpose(a, (0, 2, 1)) / k + 0.5 * np.eye(k)
+    m, V, S = rng.standard_normal((n, d)), spd(d), spd(d)[0]
+    # MvNormalMeanCovariance(:out)(m_μ, q_Σ) = N(mean, cov + Σ)   
+    a, B = rule_eval(_lib.NODE_MVNORMAL_MEAN_COV, 0, S, (m, V))
+    assert np.allclose(a, m, rtol=1e-13) and np.allclose(B, V + S, rtol=1e-13)
+    # the same rule on a weighted-mean / precision message, result asked in moment form
+    L = np.linalg.inv(V)
+    a, B = rule_eval(_lib.NODE_MVNORMAL_MEAN_COV, 1, S, (np.einsum("nij,nj->ni", L, m), L), in_form="wp", out_form="mv")
+    assert np.allclose(a, m, rtol=1e-10) and np.allclose(B, V + S, rtol=1e-10)
+    # precision-parametrised node
+    a, B = rule_eval(_lib.NODE_MVNORMAL_MEAN_PRECISION, 0, np.linalg.inv(S), (m, V))
+    assert np.allclose(B, V + S, rtol=1e-11)
+    # typeof(*)(:out) = N(A m, A V Aᵀ); (:in) = (Aᵀ ξ, Aᵀ Λ A)
+    A = rng.standard_normal((dy, d))
+    a, B = rule_eval(_lib.NODE_MULTIPLY, 0, A, (m, V))
+    assert np.allclose(a, m @ A.T, rtol=1e-13) and np.allclose(B, A @ V @ A.T, rtol=1e-13)
+    xi, Ly = rng.standard_normal((n, dy)), spd(dy)
+    a, B = rule_eval(_lib.NODE_MULTIPLY, 2, A, (xi, Ly), in_form="wp", out_form="wp")
+    assert np.allclose(a, xi @ A, rtol=1e-13) and np.allclose(B, A.T @ Ly @ A, rtol=1e-13)
+    # typeof(+)(:out) and (:in1)
+    m2, V2 = rng.standard_normal((n, d)), spd(d)
+    a, B = rule_eval(_lib.NODE_ADD, 0, None, (m, V), (m2, V2))
+    assert np.allclose(a, m + m2) and np.allclose(B, V + V2)
+    a, B = rule_eval(_lib.NODE_ADD, 1, None, (m, V), (m2, V2))
+    assert np.allclose(a, m - m2) and np.allclose(B, V + V2)
+    # scalars
+    a, B = rule_eval(_lib.NODE_NORMAL_MEAN_VARIANCE, 0, [[2.0]], (m[:, :1], V[:, :1, :1]))
+    assert np.allclose(B, V[:, :1, :1] + 2.0)
