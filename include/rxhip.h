@@ -66,13 +66,14 @@ extern "C" {
  *     power of two 2^-floor((e_i + e_j)/2) (e_i: binary exponent of the diagonal entry i, so every scaled entry is O(1) whatever the units of
  *     the state's components), unchanged to 2 ulp on two consecutive steps in every lane of the wavefront;
  *   d >= 48 forward (kd_forward_info): in EVERY lane of the workgroup two weighted sums of the lane's 16 entries of the information matrix as
- *     equilibrated for the inverse (the same power-of-two scaling), unchanged to 2 ulp, and two sums over all tiles, on two consecutive steps;
+ *     equilibrated for the inverse (the same power-of-two scaling: entries of order one) unchanged to 1.4e-14, and two sums over all tiles to 2 ulp;
  *   d >= 48 backward (kd_backward_info): two sums over the tiles of V_s unchanged to 2 ulp, then V_s(t) against V_s(t+1) entry by entry,
- *     |dV_ij| <= 1.5e-14 sqrt(V_ii V_jj).
- * Bound: a per-step change of an entry above ~5e-14 sqrt(M_ii M_jj) keeps the full recursion running (d <= 4 and the forward test: unless the
+ *     |dV_ij| <= 1.5e-14 sqrt(V_ii V_jj);
+ *   the per-model boundary tables (host and device builders): two consecutive boundary matrices entry by entry, |d_ij| <= 5e-15 sqrt(a_ii a_jj).
+ * Bound: a per-step change of an entry above ~3e-14 sqrt(M_ii M_jj) keeps the full recursion running (d <= 4 and the forward test: unless the
  * other entries of the same sum cancel it in both sums — two linear conditions on the direction of a converging iteration); with a contraction
- * rate rho of the recursion (its closed-loop spectral radius squared) what is frozen is within ~5e-14 / (1 - rho) sqrt(M_ii M_jj) of the fixed
- * point, entry by entry — 1e-8 of the entry's scale at rho = 1 - 5e-6, a mixing time of 2e5 steps.  Recursions that slow do not repeat to 2 ulp
+ * rate rho of the recursion (its closed-loop spectral radius squared) what is frozen is within ~3e-14 / (1 - rho) sqrt(M_ii M_jj) of the fixed
+ * point, entry by entry — 1e-8 of the entry's scale at rho = 1 - 3e-6, a mixing time of 3e5 steps.  Recursions that slow do not repeat that closely
  * inside a supported chain length and are simply computed in full.  tests/test_fixed_point_adversarial_gpu.py holds the sweeps to the contract
  * (1e-6 / 1e-8 against the CPU oracle, 1e-7 against the full recursion) on block models six decades apart with a slowly mixing small block and on
  * near-unit-root states; RXHIP_ELEM_FULL / RXHIP_NO_FROZEN switch the exits off.

@@ -21,6 +21,9 @@
 // layouts (these kernels are latency chains of a few hundred small products, ≈2–3 ms per model at d = 64 — not a roofline path).
 // Restrictions: d ≥ 32 (smaller models are built on the host in well under a millisecond) and dy ≤ d.
 #pragma once
+#ifndef RXHIP_TAB_SAME_TOL
+#define RXHIP_TAB_SAME_TOL 5e-15   // (launch_tables.hpp)
+#endif
 #include "dense_kernels.hpp"
 
 namespace rxhip {
@@ -518,7 +521,7 @@ __global__ void __launch_bounds__(64 * NT) kt_scan(TabParams p) {
             o.lin(sm + MM, 1.0, nullptr, 1.0, M2, true);
             o.lin(nxt, 0.5, tt, 0.5, tt, true);
             o.lin(nxt, 1.0, nxt, 1.0, g + MM);                      // sym(M2 Π') + C
-            conv = o.same(nxt, cur, 1e-13);
+            conv = o.same(nxt, cur, RXHIP_TAB_SAME_TOL);
             o.lin(cur, 1.0, nxt);
         }
     } else {
@@ -543,7 +546,7 @@ __global__ void __launch_bounds__(64 * NT) kt_scan(TabParams p) {
             o.lin(sm + 4 * MM, 1.0, nullptr, 1.0, M2, true);
             o.lin(nxt, -0.5, tt, -0.5, tt, true);
             o.lin(nxt, 1.0, nxt, 1.0, g + 5 * MM);                  // JJ − sym(N1 X)
-            conv = s < S - 1 && o.same(nxt, cur, 1e-13);            // the last segment has its own length: compare full-length steps only
+            conv = s < S - 1 && o.same(nxt, cur, RXHIP_TAB_SAME_TOL);            // the last segment has its own length: compare full-length steps only
             o.lin(cur, 1.0, nxt);
         }
         // segment 0: Λβ(b_1).  Its suffix maps 3, 4 are never read; slot 5 is (kd_prepare_bnd), so segment 0 is always its own canon

@@ -24,6 +24,14 @@
 #include "dense8_kernels.hpp"
 #endif
 
+// convergence of the boundary-table recursions (host builders in rxhip.hip, device builder in dense_tab_kernels.hpp): two consecutive iterates agree
+// entry by entry, |Δ_ij| ≤ TOL · sqrt(a_ii a_jj)
+#ifndef RXHIP_TAB_SAME_TOL
+#define RXHIP_TAB_SAME_TOL 5e-15   // measured on the BASELINE d = 64 chain (1000 segments of 10 steps that start on the table's fixed point): 1e-13 -> sweep 0.82 ms (the
+                                   // segments spend steps converging from a loosely converged boundary), 2e-14 -> 0.65, 5e-15 -> 0.59, 1e-15 -> 0.65 (the recursion never
+                                   // repeats that closely: every boundary its own matrix); round 4's max-norm test: 0.56, blind to badly scaled blocks
+#endif
+
 namespace rxhip {
 
 // ------------------------------------------------------------------------------------------

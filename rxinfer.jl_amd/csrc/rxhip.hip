@@ -776,9 +776,9 @@ static bool build_scan_matrices(int d, int S, const HostAgg& a0, const HostAgg& 
     auto at = [MM](std::vector<double>& t, int s) { return t.data() + (size_t)s * MM; };
     // Both recursions are Riccati maps of a time-invariant model: once an iterate reproduces its predecessor to rounding every later segment takes
     // the previous segment's maps — a chain cut into 250 short segments costs what its first few dozen do.  "To rounding" is decided ENTRY BY
-    // ENTRY on each entry's own scale, |Δ_ij| ≤ 1e-13 sqrt(x_ii x_jj) (host::spd_same): relative to the largest entry (rounds 2–4) the test was blind
+    // ENTRY on each entry's own scale, |Δ_ij| ≤ RXHIP_TAB_SAME_TOL sqrt(x_ii x_jj) (host::spd_same): relative to the largest entry (rounds 2–4) the test was blind
     // to a slowly converging block whose units put it decades below another one (tests/test_fixed_point_adversarial_gpu.py).
-    auto same = [d](const std::vector<double>& x, const std::vector<double>& y) { return host::spd_same(d, x.data(), y.data(), 1e-13); };
+    auto same = [d](const std::vector<double>& x, const std::vector<double>& y) { return host::spd_same(d, x.data(), y.data(), RXHIP_TAB_SAME_TOL); };
     bool conv = false;
     for (int s = 0; s < S; ++s) {
         std::memcpy(at(Vb, s), Vc.data(), sizeof(double) * MM);
@@ -1511,9 +1511,9 @@ static rxhip_status build_dense_tables(rxhip_engine* e, const rxhip_lgssm_desc* 
     if (S_ > 0) {
         // Both recursions below are Riccati iterations with constant coefficients: after a transient of a few segments the
         // boundary covariance (precision) stops changing, and with it the maps.  Once two consecutive boundaries agree entry by entry,
-        // |Δ_ij| ≤ 1e-13 sqrt(a_ii a_jj) (each entry on its own scale — host::spd_same), the remaining segments reuse the converged
+        // |Δ_ij| ≤ RXHIP_TAB_SAME_TOL sqrt(a_ii a_jj) (each entry on its own scale — host::spd_same), the remaining segments reuse the converged
         // maps — the tables of a d = 64, S = 250 engine otherwise cost ≈1.5 GFLOP of host arithmetic per create.
-        auto same = [&](const std::vector<double>& a, const std::vector<double>& b) { return host::spd_same(d, a.data(), b.data(), 1e-13); };
+        auto same = [&](const std::vector<double>& a, const std::vector<double>& b) { return host::spd_same(d, a.data(), b.data(), RXHIP_TAB_SAME_TOL); };
         std::vector<double> Vc = Vf1, Vi(MM), W(MM), M1(MM), M2(MM), tt(MM), Vprev(MM);
         bool conv = false;
         for (int s = 0; s < S_; ++s) {
