@@ -371,6 +371,74 @@ def extra_c3(device, parity=True):
             "create_note": "a model no engine of the process has seen: tables built on the device (csrc/dense_tab_kernels.hpp)"}
 
 
+def extra_node_array(device, parity=True):
+    """Not a BASELINE config — the level-scheduled node-array executor (SURVEY §7's design stance) on a graph OUTSIDE the
+    pattern-matched families: the benchmark chain with TWO observation branches per state (`rxhip_create` used to answer RXHIP_ERR_UNSUPPORTED),
+    d = 4, dy = 2 + 2, T = 256 time steps × 4096 replicas, one sum-product sweep + Bethe free energy per step; and the plain state-space chain
+    of the same size through the executor next to the specialised engine.  Rates: reference-equivalent rule calls (the messages the named
+    marginals pull in) per second; HBM fraction on the algorithmic bytes of the executor's own schedule, 8·(d + d(d+1)/2) per message a rule reads
+    or writes (rxhip_tree_info.bytes_per_sweep)."""
+    from rxhip.graph import lgssm_graph, two_branch_chain_graph
+    from rxhip.tree import TreeEngine
+    mdl = workloads.c1_model()
+    T, R, d = 256, 4096, 4
+    B1, B2 = mdl["B"][:2], mdl["B"][2:]
+    Q1, Q2 = mdl["Q"][:2, :2], mdl["Q"][2:, 2:]
+    y = workloads.generate_batch(mdl, T, R, seed0=777)                   # [T][R][4]: the two branches observe halves of the same y
+    rows = np.ascontiguousarray(np.transpose(y, (1, 0, 2))).reshape(R, T * 4)
+    out = {"workload": f"two observation branches per state (d=4, dy=2+2), T={T}, {R} replicas: 1 sum-product sweep + Bethe free energy on the node-array executor"}
+    for name, build in (("two_branch", lambda: two_branch_chain_graph(T, mdl["A"], B1, B2, mdl["P"], Q1, Q2, mdl["m0"], mdl["V0"])),
+                        ("plain_chain", lambda: lgssm_graph(T, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"]))):
+        t0 = time.perf_counter()
+        gb, xs, ys = build()
+        t1 = time.perf_counter()
+        eng = TreeEngine(gb, n_replicas=R, device=device)
+        t2 = time.perf_counter()
+        eng.set_data(ys, rows)
+        eng.run(1, True)
+        best, dev = 1e9, 1e9
+        for _ in range(5):
+            t = time.perf_counter()
+            eng.run(1, True)
+            best = min(best, time.perf_counter() - t)
+            dev = min(dev, eng.last_iteration_ms())
+        cnt, info = eng.counters(), eng.info
+        line = {"ms_per_step": best * 1e3, "device_ms_per_step": dev, "rule_calls_per_s": cnt["rule_calls"] / (dev * 1e-3),
+                "graph_build_ms": (t1 - t0) * 1e3, "compile_and_allocate_ms": (t2 - t1) * 1e3, "info": info,
+                "roofline": {"bound": "hbm", "achieved": info["bytes_per_sweep"] * R / (dev * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": info["bytes_per_sweep"] * R / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             "bytes": "8·(d + d(d+1)/2) per message read or written by a rule, product or marginal of the schedule (rxhip_tree_info.bytes_per_sweep) × replicas"}}
+        if parity and name == "two_branch":
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import tree_oracle
+            post = eng.marginals(xs)
+            fe = eng.free_energy_per_replica()
+            spot = {"replicas": [0, R - 1], "mean_rel": 0.0, "cov_rel": 0.0, "fe_rel": 0.0}
+            for r in (0, R - 1):
+                data, o = {}, 0
+                for v in ys:
+                    data[v] = rows[r, o:o + gb.rows[v]]
+                    o += gb.rows[v]
+                ref = tree_oracle.infer(gb.to_dump(), data)
+                for v in xs:
+                    sd = np.sqrt(np.diag(ref["cov"][v]))
+                    spot["mean_rel"] = max(spot["mean_rel"], float(np.max(np.abs(post[v][0][r] - ref["mean"][v]) / sd)))
+                    spot["cov_rel"] = max(spot["cov_rel"], float(np.max(np.abs(post[v][1][r] - ref["cov"][v]) / np.outer(sd, sd))))
+                spot["fe_rel"] = max(spot["fe_rel"], float(abs(fe[r] - ref["fe"][0]) / abs(ref["fe"][0])))
+            spot["ok"] = bool(spot["mean_rel"] < 1e-6 and spot["cov_rel"] < 1e-6 and spot["fe_rel"] < 1e-8)
+            line["parity_spot"] = spot
+        eng.close()
+        out[name] = line
+    # the same plain chain on the specialised engine (the fast path the pattern matcher picks)
+    with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=R, device=device) as ref:
+        ref.set_data(y)
+        ref.run(1, True)
+        ms, _ = timed_sweeps(ref, 10, 2)
+    out["plain_chain"]["specialised_engine_ms_per_step"] = ms
+    out["ms_per_step"] = out["two_branch"]["device_ms_per_step"]
+    return out
+
+
 def extra_noise_vmp(device, parity=True):
     """Not a BASELINE config — the first composed graph: the benchmark chain with an unknown observation-noise precision,
     W ~ Wishart, q(x, W) = q(x) q(W): d = dy = 4, 1024 chains × T = 10⁴, 10 VMP iterations (one BP sweep of every chain + every chain's Wishart
@@ -903,7 +971,8 @@ def main(argv=None, engine_cls=None, gpu_cls=_Gpu):
         for name, fn in (("per_chain_models", lambda: extra_per_chain_models(mdl, T, C, y, local_rank, yh)), ("c1", lambda: extra_c1(local_rank, not args.no_cpu_baseline)),
                          ("c2_missing", lambda: extra_missing(mdl, T, C, y, local_rank, yh)), ("c3", lambda: extra_c3(local_rank, par)),
                          ("c4", lambda: extra_c4(local_rank, par)), ("c5", lambda: extra_c5(local_rank, par)), ("mid_sizes", lambda: extra_mid(local_rank)),
-                         ("masked_mfma", lambda: extra_masked(local_rank)), ("lgssm_noise_vmp", lambda: extra_noise_vmp(local_rank, par))):
+                         ("masked_mfma", lambda: extra_masked(local_rank)), ("lgssm_noise_vmp", lambda: extra_noise_vmp(local_rank, par)),
+                         ("node_array", lambda: extra_node_array(local_rank, par))):
             try:
                 extra[name] = fn()
             except Exception as e:  # noqa: BLE001 — an extra line must never cost the headline line

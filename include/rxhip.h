@@ -400,6 +400,7 @@ typedef struct {
     int32_t mode;                         /* 0: one launch per level; 1: one launch per iteration (workgroup-resident levels) */
     int32_t replicas_per_workgroup;       /* mode 1 */
     int32_t n_precision_vars;
+    double last_iteration_ms;             /* device time of the last rxhip_run ÷ its iterations (HIP events around the launches) */
 } rxhip_tree_info;
 rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* stream, rxhip_engine** out);
 /* data of the listed data variables, host [replica][rows of vars[0] | rows of vars[1] | …] (src/inference/batch.jl:405-407 new_observation!) */

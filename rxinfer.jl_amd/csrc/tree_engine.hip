@@ -92,6 +92,7 @@ struct Program {
     std::vector<double> cpool;
     long long msg_doubles = 0, marg_doubles = 0, val_doubles = 0, data_doubles = 0, prec_doubles = 0, term_slots = 0, stat_doubles = 0;
     int fe_root = -1;
+    int fe_level = 0;   // first level of the second phase (Bethe terms, residual moments, q(W) updates, sums)
     int n_ops = 0, n_levels = 0, n_messages = 0;
     std::vector<int> dim, vclass, marg_off, val_off, prec_off;
     std::vector<int64_t> data_vars;
@@ -685,9 +686,9 @@ struct Compiler {
             ++lv;
         }
         P.fe_root = cur[0];
-        fe_first_level = LF;
+        P.fe_level = LF;
     }
-    int derived_levels = 0, fe_first_level = 0;
+    int derived_levels = 0;
 
     void finish() {
         std::stable_sort(recs.begin(), recs.end(), [](const OpRec& a, const OpRec& b) { return a.level != b.level ? a.level < b.level : a.w[W_OP] < b.w[W_OP]; });
@@ -762,6 +763,8 @@ struct Engine {
     int last_iterations = 0, last_want_fe = 0;
     std::vector<char> data_set;
     uint64_t runs = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_iteration_ms = 0.0;
 };
 
 namespace {
@@ -798,20 +801,27 @@ TreeParams params_of(const Engine* e, int want_fe) {
     p.term = e->d_term; p.stat = e->d_stat; p.R = e->R; p.RS = e->RS; p.want_fe = want_fe; p.status = e->d_status;
     return p;
 }
-template <int N>
-void launch_levels(const Engine* e, const TreeParams& p, int l0, int l1) {
+template <int N, int PHASE>
+void launch_phase(const Engine* e, const TreeParams& p, int l0, int l1) {
+    if (l1 <= l0) return;
     if (e->mode == 1) {
         const unsigned blocks = (unsigned)((e->R + e->rb - 1) / e->rb);
-        hipLaunchKernelGGL(k_tree_levels<N>, dim3(blocks), dim3(256), 0, e->stream, p, e->d_lvl, l0, l1, e->rb);
+        hipLaunchKernelGGL((k_tree_levels<N, PHASE>), dim3(blocks), dim3(256), 0, e->stream, p, e->d_lvl, l0, l1, e->rb);
     } else {
         for (int l = l0; l < l1; ++l) {
             const int o0 = e->prog.lvl_ptr[l], o1 = e->prog.lvl_ptr[l + 1];
             if (o1 == o0) continue;
             const long long items = (long long)(o1 - o0) * e->R;
             const unsigned blocks = (unsigned)std::min<long long>((items + 255) / 256, 1 << 20);
-            hipLaunchKernelGGL(k_tree_ops<N>, dim3(blocks), dim3(256), 0, e->stream, p, o0, o1);
+            hipLaunchKernelGGL((k_tree_ops<N, PHASE>), dim3(blocks), dim3(256), 0, e->stream, p, o0, o1);
         }
     }
+}
+template <int N>
+void launch_levels(const Engine* e, const TreeParams& p, int l0, int l1) {   // the sweep, then the second phase
+    const int lf = e->prog.fe_level;
+    launch_phase<N, 0>(e, p, l0, std::min(l1, lf));
+    launch_phase<N, 1>(e, p, std::max(l0, lf), l1);
 }
 void launch(const Engine* e, const TreeParams& p, int l0, int l1) {
     switch (e->prog.dmax) {
@@ -881,6 +891,8 @@ void destroy(Engine* e) {
     for (void* q : {(void*)e->d_ops, (void*)e->d_aux, (void*)e->d_lvl, (void*)e->d_status, (void*)e->d_cpool, (void*)e->d_msg, (void*)e->d_marg, (void*)e->d_val, (void*)e->d_prec,
                     (void*)e->d_term, (void*)e->d_stat, (void*)e->d_prec_init, (void*)e->d_fe_rep, (void*)e->d_fe_hist})
         if (q) (void)hipFree(q);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -941,21 +953,20 @@ rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err) {
     }
     const TreeParams p = params_of(e, want_fe);
     // without the free energy on a graph without precision variables the sweep ends with the marginals
-    int l_end = P.n_levels;
-    if (!want_fe && P.prec_doubles == 0) {
-        l_end = 0;
-        for (int l = 0; l < P.n_levels; ++l) {
-            bool bp = false;
-            for (int o = P.lvl_ptr[l]; o < P.lvl_ptr[l + 1]; ++o) bp = bp || P.ops[(size_t)o * OP_WORDS + W_OP] <= OP_MARGINAL;
-            if (bp) l_end = l + 1;
-        }
-    }
+    const int l_end = (!want_fe && P.prec_doubles == 0) ? P.fe_level : P.n_levels;
+    if (!e->ev0) { TCHK(hipEventCreate(&e->ev0)); TCHK(hipEventCreate(&e->ev1)); }
+    TCHK(hipEventRecord(e->ev0, e->stream));
     for (int it = 0; it < iterations; ++it) {
         launch(e, p, 0, l_end);
         if (want_fe) hipLaunchKernelGGL(k_tree_fe_total, dim3(1), dim3(256), 0, e->stream, e->d_term, (long long)P.fe_root, e->R, e->RS, e->d_fe_rep, e->d_fe_hist + it);
     }
+    TCHK(hipEventRecord(e->ev1, e->stream));
     TCHK(hipGetLastError());
     TCHK(hipStreamSynchronize(e->stream));
+    {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, e->ev0, e->ev1) == hipSuccess) e->last_iteration_ms = (double)ms / iterations;
+    }
     int status = 0;
     TCHK(hipMemcpy(&status, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
     e->ran = true;
@@ -1063,6 +1074,7 @@ void info(Engine* e, rxhip_tree_info* out) {
     int np = 0;
     for (int c : P.vclass) np += c == VC_PREC;
     out->n_precision_vars = np;
+    out->last_iteration_ms = e->last_iteration_ms;
 }
 int device_of(Engine* e) { return e->device; }
 void* stream_of(Engine* e) { return (void*)e->stream; }
@@ -1157,9 +1169,9 @@ rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
     p.ops = d_ops; p.aux = d_aux; p.cpool = d_cp; p.msg = d_msg; p.marg = d_marg; p.R = R; p.RS = RS; p.status = d_status;
     const unsigned blocks = (unsigned)std::min<long long>((R + 255) / 256, 1 << 20);
     for (int o = 0; o < 2; ++o) {
-        if (N == 1) hipLaunchKernelGGL(k_tree_ops<1>, dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
-        else if (N == 2) hipLaunchKernelGGL(k_tree_ops<2>, dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
-        else hipLaunchKernelGGL(k_tree_ops<4>, dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
+        if (N == 1) hipLaunchKernelGGL((k_tree_ops<1, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
+        else if (N == 2) hipLaunchKernelGGL((k_tree_ops<2, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
+        else hipLaunchKernelGGL((k_tree_ops<4, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
     }
     int status = 0;
     std::vector<double> res((size_t)(c->out_form ? msg_d : marg_d) * RS);

@@ -308,8 +308,10 @@ __device__ __forceinline__ double t_mvlgamma(double a, int d) {
 }
 
 // ------------------------------------------------------------------------------------------
+// the sum-product sweep: rules, products, marginals (PHASE 0) — and the Bethe terms, residual moments and q(W) updates (PHASE 1), a kernel of their own:
+// the log-gamma / digamma code and the joint-marginal algebra of the second phase would otherwise set the register budget of every rule
 template <int N>
-__device__ __forceinline__ void eval_op(const TreeParams& p, const int* __restrict__ w, long long r) {
+__device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restrict__ w, long long r) {
     const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS];
     bool ok = true;
     switch (op) {
@@ -455,6 +457,15 @@ __device__ __forceinline__ void eval_op(const TreeParams& p, const int* __restri
             p.marg[(w[W_OUT] + d + d * (d + 1) / 2) * p.RS + r] = -ld;
         }
     } break;
+    default: break;
+    }
+    if (!ok) atomicOr(p.status, 1);
+}
+template <int N>
+__device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restrict__ w, long long r) {
+    const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS];
+    bool ok = true;
+    switch (op) {
     case OP_FE_NOISE2: {
         // joint precision [[Lo + W, −W], [−W, Lm + W]]; with P = Lo + W, S = (Lm + W) − W P⁻¹ W:  log|J| = log|P| + log|S|,
         // V_μμ = S⁻¹, V_oμ = P⁻¹ W S⁻¹, V_oo = P⁻¹ + P⁻¹ W S⁻¹ W P⁻¹;  r = out − μ
@@ -641,17 +652,22 @@ __device__ __forceinline__ void eval_op(const TreeParams& p, const int* __restri
 }
 
 // one launch per level: items (op, replica) over the grid
-template <int N>
+template <int N, int PHASE>
+__device__ __forceinline__ void eval_op(const TreeParams& p, const int* __restrict__ w, long long r) {
+    if (PHASE == 0) eval_bp<N>(p, w, r);
+    else eval_fe<N>(p, w, r);
+}
+template <int N, int PHASE>
 __global__ void __launch_bounds__(256) k_tree_ops(TreeParams p, int op0, int op1) {
     const long long total = (long long)(op1 - op0) * p.R;
     for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
         const long long o = it / p.R, r = it - o * p.R;
-        eval_op<N>(p, p.ops + (size_t)(op0 + o) * OP_WORDS, r);
+        eval_op<N, PHASE>(p, p.ops + (size_t)(op0 + o) * OP_WORDS, r);
     }
 }
 // the whole schedule in one launch: a workgroup owns `rb` replicas (a multiple of 16: whole 128-byte lines of every slot) and walks the levels with a
 // workgroup barrier between them — for deep, narrow graphs (a chain is three levels per time step) where a launch per level would cost more than the level
-template <int N>
+template <int N, int PHASE>
 __global__ void __launch_bounds__(256) k_tree_levels(TreeParams p, const int* __restrict__ lvl_ptr, int l0, int l1, int rb) {
     const long long r0 = (long long)blockIdx.x * rb;
     const int nr = (int)((p.R - r0) < rb ? (p.R - r0) : rb);
@@ -660,7 +676,7 @@ __global__ void __launch_bounds__(256) k_tree_levels(TreeParams p, const int* __
         const int total = (o1 - o0) * nr;
         for (int it = threadIdx.x; it < total; it += blockDim.x) {
             const int o = it / nr, r = it - o * nr;
-            eval_op<N>(p, p.ops + (size_t)(o0 + o) * OP_WORDS, r0 + r);
+            eval_op<N, PHASE>(p, p.ops + (size_t)(o0 + o) * OP_WORDS, r0 + r);
         }
         __syncthreads();   // (waits for the level's stores: every reader of the next level is in this workgroup)
     }

@@ -229,6 +229,33 @@ def lgssm_graph(T, A, B, P, Q, m0, V0, prior_through_transition=False, A_of_t=No
     return gb, xs, ys
 
 
+def two_branch_chain_graph(T, A, B1, B2, P, Q1, Q2, m0, V0):
+    """x[t] ~ MvNormal(A x[t-1], P) with TWO observation branches per state, y1[t] ~ MvNormal(B1 x[t], Q1), y2[t] ~ MvNormal(B2 x[t], Q2) —
+    a graph the state-space pattern matcher rejects (csrc/graph_lowering.hpp) and the node-array executor runs.  Returns (builder, state
+    variables, data variables in time order y1[0], y2[0], y1[1], …)."""
+    gb = GraphBuilder()
+    d = np.asarray(A).shape[0]
+    x = gb.randomvar(d)
+    gb.mvnormal_mean_cov(x, gb.constvar(m0), gb.constvar(V0))
+    xs, ys = [], []
+    for t in range(T):
+        if t:
+            a = gb.randomvar(d)
+            gb.multiply(a, gb.constvar(A), x)
+            xn = gb.randomvar(d)
+            gb.mvnormal_mean_cov(xn, a, gb.constvar(P))
+            x = xn
+        for B, Q in ((B1, Q1), (B2, Q2)):
+            B = np.asarray(B, float)
+            b = gb.randomvar(B.shape[0])
+            gb.multiply(b, gb.constvar(B), x)
+            y = gb.datavar(B.shape[0])
+            gb.mvnormal_mean_cov(y, b, gb.constvar(Q))
+            ys.append(y)
+        xs.append(x)
+    return gb, xs, ys
+
+
 def lgssm_noise_graph(T, A, B, P, m0, V0, nu0, S0, init=None, prior_through_transition=False, gamma=None):
     """The chain of `lgssm_graph` with an unknown observation-noise precision: `W ~ Wishart(nu0, S0)` and every observation node
     `y[t] ~ MvNormal(μ = B * x[t], Λ = W)` (test/models/iid/mv_iid_precision_tests.jl:11-15 spells the node pair).  init = (nu, V): the

@@ -38,8 +38,14 @@ class TreeEngine:
             L.rxhip_destroy(self._h)
             self._h = None
             raise RxHipError(_lib.ERR_BADARG, "the pattern matcher took this graph: not an engine of the node-array executor")
-        self.info = {k: int(getattr(info, k)) for k, _ in _lib.TreeInfo._fields_}
+        self.info = {k: int(getattr(info, k)) for k, _ in _lib.TreeInfo._fields_ if k != "last_iteration_ms"}
         self._iters = 0
+
+    def last_iteration_ms(self):
+        """device time of the last run ÷ its iterations"""
+        info = _lib.TreeInfo()
+        self._chk(_lib.lib().rxhip_tree_get_info(self._h, ctypes.byref(info)))
+        return float(info.last_iteration_ms)
 
     def _chk(self, st):
         if st != _lib.OK:
