@@ -348,22 +348,40 @@ def extra_c3(device, parity=True):
     ref_flop = 18 * d ** 3 * T
     tf = lambda flop, t_ms: flop / (t_ms * 1e-3) / 1e12
     fwd_ms, bwd_ms = kt.get("k_forward", 0.0), kt.get("k_backward", 0.0)
-    # Since round 4 the sweep kernels leave the matrix work of a segment once its matrices repeat (every step's C, G', M and V_s equal the previous
-    # step's to 2 ulp: interior segments after two steps) — the counts above are per FULL step, and most steps of this chain are not full any more.
-    # What the line can state honestly: the reference-equivalent rate (SURVEY's 18 d^3 per step over the sweep time), and the matrix-pipe figure of
-    # the full steps from the counters (profiles/r04/pmc_c3.txt: 0.47 of peak inside the steps that still execute products).  `mfma_frac` is therefore
-    # null; a kernel that finishes sooner by executing fewer products has no business quoting a higher utilisation.
-    roof = {"bound": "mfma", "kernel": "kd_forward_info", "flop": ref_flop, "ms": ms,
-            "achieved": tf(ref_flop, ms), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (reference-equivalent: 18 d^3 per step)",
-            "frac": tf(ref_flop, ms) / FP64_PEAK_TFLOPS, "mfma_frac": None,
-            "full_step_mfma": mfma_step,
-            "note": "frac = reference-schedule flops over the sweep time — a rate of WORK DONE FOR THE USER, not a utilisation (it can pass 1: the kernels skip "
-                    "products whose result repeats); executed MFMA work is no longer T x the per-step counts: "
-                    "matrix-pipe utilisation inside full steps 0.47 by the counters, profiles/r04/pmc_c3.txt"}
+    # Since round 4 the sweep kernels leave the matrix work of a segment once its matrices repeat, so the MFMA work a sweep EXECUTES is no longer
+    # T x the per-step counts above.  The roofline figure of this line is therefore built from what the matrix pipe was measured to execute:
+    # SQ_INSTS_VALU_MFMA_F64 per launch of every sweep kernel (profiles/mfma_insts.json, collected by scripts/profile_r05.sh on this very
+    # workload, guarded by the hash of dense_kernels.hpp: a stale file gives null, never an old number) x 2048 flop / the kernel times of THIS
+    # run.  `frac` = executed MFMA flops of the sweep / sweep time / fp64 peak — a utilisation; the reference-equivalent rate (SURVEY's 18 d^3
+    # per step over the sweep time: work done for the user, which passes 1 when products are skipped) is reported under its own key.
+    executed, stale_mfma = None, None
+    mpath = os.path.join(ROOT, "profiles", "mfma_insts.json")
+    try:
+        mj = json.load(open(mpath))
+        with open(os.path.join(ROOT, "rxinfer.jl_amd", "csrc", "dense_kernels.hpp"), "rb") as f:
+            stale_mfma = mj.get("dense_kernels_sha256") != hashlib.sha256(f.read()).hexdigest()
+        if not stale_mfma:
+            executed = {k: float(v) for k, v in mj["mfma_f64_per_launch"].items()}
+    except (OSError, ValueError, KeyError):
+        pass
+    roof = {"bound": "mfma", "kernel": "kd_forward_info", "ms": ms, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (executed v_mfma_f64_16x16x4_f64 x 2048 flop)",
+            "achieved": None, "frac": None, "per_kernel": None, "full_step_mfma": mfma_step,
+            "reference_equivalent": {"flop": ref_flop, "tflops": tf(ref_flop, ms), "frac_of_peak": tf(ref_flop, ms) / FP64_PEAK_TFLOPS,
+                                     "note": "SURVEY 8d's 18 d^3 per step over the sweep time: a rate of work done for the user, not a utilisation"},
+            "source": "profiles/mfma_insts.json (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64, scripts/profile_r05.sh)" + (" — STALE: dense_kernels.hpp changed since the counters were collected" if stale_mfma else "")}
+    if executed:
+        ex_flop = 2048.0 * sum(executed.values())
+        # kernel names of the profile -> the engine's timing slots (k_forward = kd_forward_info, k_backward = kd_backward_info)
+        per = {}
+        for kn, slot in (("kd_forward_info", "k_forward"), ("kd_backward_info", "k_backward")):
+            if kn in executed and kt.get(slot):
+                per[kn] = {"mfma_insts": executed[kn], "ms": kt[slot], "tflops": tf(2048.0 * executed[kn], kt[slot]), "frac": tf(2048.0 * executed[kn], kt[slot]) / FP64_PEAK_TFLOPS}
+        roof.update({"flop": ex_flop, "achieved": tf(ex_flop, ms), "frac": tf(ex_flop, ms) / FP64_PEAK_TFLOPS, "per_kernel": per,
+                     "note": "executed MFMA flops of ALL sweep kernels over the sweep time; inside full (non-repeating) steps the matrix pipe is busy 0.47 of the time (profiles/r04/pmc_c3.txt)"})
     return {"workload": "LGSSM d=64 dy=64 T=10000, 1 chain, 1 BP sweep + Bethe free energy per step", "ms_per_step": ms,
             "kernels_ms_avg": kt, "tflops_ref_count": tf(ref_flop, ms), "ref_flop_per_sweep": ref_flop,
             "mfma_flop_per_sweep_if_every_step_were_full": mfma_flop,
-            "peak_tflops_fp64": FP64_PEAK_TFLOPS, "frac": tf(ref_flop, ms) / FP64_PEAK_TFLOPS,
+            "peak_tflops_fp64": FP64_PEAK_TFLOPS, "frac": roof["frac"],
             "frac_ref_count": tf(ref_flop, ms) / FP64_PEAK_TFLOPS,
             "roofline": roof, "filter_ms_per_step": fms, "timing": timing_mode(2), "parity_spot": spot,
             "hoisted_matrices": hoisted,
@@ -711,6 +729,93 @@ def respawn_under_launcher(n):
     os.execv(sys.executable, cmd)
 
 
+def sharded_extras(dist, gpu, world, rank, local_rank, hgf_cls=None, gmm_cls=None, shard_cls=None, c4_series=512, c4_T=2000, c5_points=1_250_000, steps4=3, steps5=20):
+    """BASELINE configs 4 and 5 as BASELINE.json DEFINES them — on N GPUs: every rank of an N > 1 run executes its shard and the line carries the
+    whole-job figures (the bodies of scripts/bench_configs.py).  Timing contract of the headline: barrier + synchronise on both
+    sides of exactly K steps, maximum over the ranks.
+      c4: `c4_series` HGF series per GPU × T observations, 10 VMP iterations per observation, GH-31; step = one filtering pass; the exchange is the
+          free energy (10 values): all-gather + sum in rank order, once per step.
+      c5: univariate mixture, K = 16, `c5_points` per GPU; step = ONE VMP iteration = accumulate → all-reduce of the 3K + 1 statistics → update, all
+          three enqueued on one stream (no host wait).  The all-reduce sits on the critical path of every iteration by construction (the update needs
+          the global statistics, the next accumulate the updated marginals): splitting the data in halves only moves which half's reduce is exposed.
+    `*_cls`: test seams (tests/test_bench_main_cpu.py drives this over gloo with stub engines)."""
+    hgf_cls = hgf_cls or rxhip.HGFEngine
+    gmm_cls = gmm_cls or rxhip.GMMEngine
+    if shard_cls is None:
+        from rxhip import distributed as rd
+        shard_cls = rd.DeviceMixtureShard
+    dev = gpu.device
+
+    def timed(step, steps, finish, warmup=2):
+        for _ in range(warmup):
+            step()
+        finish()
+        dist.barrier()
+        gpu.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        finish()
+        gpu.synchronize()
+        dist.barrier()
+        gpu.synchronize()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    out = {}
+    # ---- c4 ----
+    S, T, iters = c4_series, c4_T, 10
+    _, _, y = workloads.generate_hgf_batch(T, S, seed=42 + rank)
+    eng = hgf_cls(T, S, 1.0, 0.0, 0.04, 0.01, device=local_rank)
+    eng.set_data(y)
+    fe_loc = torch.zeros(iters, dtype=torch.float64, device=dev)
+    fe_all = torch.zeros(world * iters, dtype=torch.float64, device=dev)
+    fe_glob = torch.zeros(iters, dtype=torch.float64, device=dev)
+
+    def step4():
+        eng.run_async(iters, True)
+        eng.sync()
+        fe_loc.copy_(torch.as_tensor(np.asarray(eng.free_energy(), dtype=np.float64)).to(dev))
+        dist.all_gather_into_tensor(fe_all, fe_loc)
+        torch.sum(fe_all.view(world, iters), dim=0, out=fe_glob)   # rank order: bit-identical on every rank
+
+    dt = timed(step4, steps4, eng.sync)
+    out["c4"] = {"workload": f"HGF {S} series per GPU x T={T}, 10 VMP iterations per observation, GH-31 (BASELINE config 4), series sharded over {world} GPUs",
+                 "ms_per_step": dt / steps4 * 1e3, "gh_evaluations_per_s": 31 * iters * T * S * world * steps4 / dt, "series_observations_per_s": T * S * world * steps4 / dt,
+                 "exchange": "free energy per iteration: all-gather + sum in rank order, once per filtering pass", "n_gpus": world, "steps": steps4,
+                 "free_energy_mean_per_series_global": (fe_glob.cpu().numpy() / (S * world)).tolist()}
+    eng.close()
+    # ---- c5 ----
+    K, N = 16, c5_points
+    mus = np.arange(1, K + 1) * 10.0 - 80.0
+    rng = np.random.default_rng(12345 + rank)
+    yv = mus[rng.integers(0, K, size=N)] + rng.standard_normal(N)
+    sh = gpu.make_stream()
+    eng = gmm_cls(N, mus + 1.5, np.full(K, 1e3), np.full(K, 0.01), np.full(K, 0.01), np.ones(K), mus + 1.5, np.full(K, 10.0), np.ones(K), np.ones(K), np.ones(K),
+                  device=local_rank, stream=sh)
+    eng.set_data(yv)
+    shard = shard_cls(eng)
+    warm5 = 2
+    with gpu.on_stream():
+        shard.begin(warm5 + steps5)
+
+    def step5():
+        with gpu.on_stream():
+            stats = shard.accumulate()
+            dist.all_reduce(stats)
+            shard.update(True)
+
+    dt = timed(step5, steps5, eng.sync, warmup=warm5)
+    fe = np.asarray(eng.free_energy())
+    out["c5"] = {"workload": f"GMM K=16, {N} points per GPU (BASELINE config 5), points sharded over {world} GPUs", "ms_per_step": dt / steps5 * 1e3,
+                 "vmp_iters_per_sec": steps5 / dt, "point_iterations_per_s": N * world * steps5 / dt, "n_gpus": world, "steps": steps5,
+                 "exchange": "3K + 1 statistics, one all-reduce per VMP iteration, enqueued between accumulate and update on one stream",
+                 "free_energy_last": float(fe[-1]), "free_energy_monotone": bool(np.all(np.diff(fe[warm5:]) <= 1e-6 * abs(fe[-1])))}
+    eng.close()
+    return out
+
+
 class _Gpu:
     """torch's handle on the rank's GPU: device selection, the stream the engine and the collectives share, synchronisation."""
     backend = "nccl"   # RCCL on ROCm
@@ -759,8 +864,8 @@ class _HostOnly:
         pass
 
 
-def main(argv=None, engine_cls=None, gpu_cls=_Gpu):
-    """`engine_cls` / `gpu_cls`: test seams (see _HostOnly); a bench run uses rxhip.LGSSMEngine on the rank's MI355X."""
+def main(argv=None, engine_cls=None, gpu_cls=_Gpu, extra_cls=None):
+    """`engine_cls` / `gpu_cls` / `extra_cls` ({'hgf': …, 'gmm': …, 'shard': …, sizes}): test seams (see _HostOnly); a bench run uses rxhip's engines on the rank's MI355X."""
     engine_cls = engine_cls or rxhip.LGSSMEngine
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -964,6 +1069,13 @@ def main(argv=None, engine_cls=None, gpu_cls=_Gpu):
     elif rank == 0:
         out["cpu_baseline"] = None
     eng.close()
+    if world > 1 and not args.no_extras:   # the configurations BASELINE defines on several GPUs: every rank runs its shard (collectives inside)
+        try:
+            sh = sharded_extras(dist, gpu, world, rank, local_rank, **(extra_cls or {}))
+        except Exception as e:  # noqa: BLE001 — an extra line must never cost the headline line (every rank fails or none: same code, same sizes)
+            sh = {"error": repr(e)}
+        if rank == 0:
+            out["extra"] = sh
     if rank == 0 and world == 1 and not args.no_extras:
         extra = {}
         yh = None if args.no_parity else y_host

@@ -72,6 +72,112 @@ class StubEngine:
         return {}
 
 
+class StubHgf:
+    """free_energy() = a checksum of the series this rank generated, one value per VMP iteration"""
+
+    def __init__(self, T, S, kappa, omega, zv, yv, device=0):
+        self.T, self.S = T, S
+
+    def set_data(self, y):
+        self.sum = float(np.sum(y))
+
+    def run_async(self, iters, fe):
+        self.iters = iters
+
+    def sync(self):
+        pass
+
+    def free_energy(self):
+        return np.arange(1, self.iters + 1) * self.sum
+
+    def close(self):
+        pass
+
+
+class StubGmm:
+    def __init__(self, N, *a, device=0, stream=None):
+        self.N, self.fe = N, []
+
+    def set_data(self, y):
+        self.sum = float(np.sum(y))
+
+    def sync(self):
+        pass
+
+    def free_energy(self):
+        return np.array(self.fe)
+
+    def close(self):
+        pass
+
+
+class StubShard:
+    """accumulate() -> this rank's statistics (here: its data checksum); update() books the all-reduced value as the free energy"""
+
+    def __init__(self, eng):
+        self.e = eng
+
+    def begin(self, n):
+        import torch
+        self.stats = torch.zeros(3, dtype=torch.float64)
+
+    def accumulate(self):
+        self.stats[:] = self.e.sum
+        return self.stats
+
+    def update(self, fe):
+        self.e.fe.append(-float(self.stats[0]) / (1 + len(self.e.fe)))   # decreasing in magnitude -> "monotone" has something to look at
+
+
+def _worker_extras(rank, world, port, out_dir):
+    for p in (ROOT, os.path.join(ROOT, "rxinfer.jl_amd")):
+        sys.path.insert(0, p)
+    os.environ.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    import contextlib
+    import io
+
+    import bench
+
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.main(["--gpus", str(world), "--steps", "2", "--warmup", "1", "--T", "16", "--chains", "2", "--no-cpu-baseline", "--no-parity"],
+                   engine_cls=StubEngine, gpu_cls=bench._HostOnly,
+                   extra_cls=dict(hgf_cls=StubHgf, gmm_cls=StubGmm, shard_cls=StubShard, c4_series=3, c4_T=20, c5_points=50, steps4=2, steps5=4))
+    with open(os.path.join(out_dir, f"rank{rank}.txt"), "w") as f:
+        f.write(buf.getvalue())
+
+
+def test_bench_main_emits_the_sharded_configs_at_world_8(tmp_path):
+    """BASELINE configs 4 and 5 are DEFINED on 8 GPUs: an N > 1 run carries their sharded lines next to the headline"""
+    import torch.multiprocessing as mp
+
+    from rxhip import workloads
+
+    world = 8
+    mp.spawn(_worker_extras, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    lines = (tmp_path / "rank0.txt").read_text().strip().splitlines()
+    assert len(lines) == 1 and all((tmp_path / f"rank{r}.txt").read_text() == "" for r in range(1, world))
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == world and set(out["extra"]) == {"c4", "c5"}, out.get("extra")
+    c4, c5 = out["extra"]["c4"], out["extra"]["c5"]
+    # c4: the global free energy is the rank-ordered sum of what every rank's shard (seed 42 + rank) produced
+    sums = [float(np.sum(workloads.generate_hgf_batch(20, 3, seed=42 + r)[2])) for r in range(world)]
+    tot = 0.0
+    for x in sums:
+        tot += x
+    assert c4["free_energy_mean_per_series_global"][0] == pytest.approx(tot / (3 * world), rel=1e-12) and len(c4["free_energy_mean_per_series_global"]) == 10
+    assert c4["series_observations_per_s"] == pytest.approx(20 * 3 * world / (c4["ms_per_step"] * 1e-3), rel=1e-9)
+    # c5: one all-reduce per iteration made every rank's statistics global
+    K = 16
+    mus = np.arange(1, K + 1) * 10.0 - 80.0
+    tot5 = 0.0
+    for r in range(world):
+        rng = np.random.default_rng(12345 + r)
+        tot5 += float(np.sum(mus[rng.integers(0, K, size=50)] + rng.standard_normal(50)))
+    assert c5["free_energy_last"] == pytest.approx(-tot5 / 6, rel=1e-9)       # the 6th update of the run (2 warm-up + 4 timed)
+    assert c5["point_iterations_per_s"] == pytest.approx(50 * world * c5["vmp_iters_per_sec"], rel=1e-9)
+
+
 def _worker(rank, world, port, out_dir, scaling, chains):
     for p in (ROOT, os.path.join(ROOT, "rxinfer.jl_amd")):
         sys.path.insert(0, p)
