@@ -392,17 +392,19 @@ def extra_c3(device, parity=True):
 def extra_node_array(device, parity=True):
     """Not a BASELINE config — the level-scheduled node-array executor (SURVEY §7's design stance) on a graph OUTSIDE the
     pattern-matched families: the benchmark chain with TWO observation branches per state (`rxhip_create` used to answer RXHIP_ERR_UNSUPPORTED),
-    d = 4, dy = 2 + 2, T = 256 time steps × 4096 replicas, one sum-product sweep + Bethe free energy per step; and the plain state-space chain
+    d = 4, dy = 2 + 2, T = 128 time steps × 65 536 replicas (a lane per replica walks the schedule: the executor's schedule for large batches; the same
+    graph at T = 256 × 4096 replicas — workgroup-resident levels, latency-bound — is in profiles/r05/tree_modes.txt), one sum-product sweep + Bethe free
+    energy per step; and the plain state-space chain
     of the same size through the executor next to the specialised engine.  Rates: reference-equivalent rule calls (the messages the named
     marginals pull in) per second; HBM fraction on the algorithmic bytes of the executor's own schedule, 8·(d + d(d+1)/2) per message a rule reads
     or writes (rxhip_tree_info.bytes_per_sweep)."""
     from rxhip.graph import lgssm_graph, two_branch_chain_graph
     from rxhip.tree import TreeEngine
     mdl = workloads.c1_model()
-    T, R, d = 256, 4096, 4
+    T, R, d = 128, 65536, 4
     B1, B2 = mdl["B"][:2], mdl["B"][2:]
     Q1, Q2 = mdl["Q"][:2, :2], mdl["Q"][2:, 2:]
-    y = workloads.generate_batch(mdl, T, R, seed0=777)                   # [T][R][4]: the two branches observe halves of the same y
+    y = np.random.default_rng(777).standard_normal((T, R, 4)) * 3.0      # [T][R][4]: the two branches observe halves of the same y (timing does not depend on the values)
     rows = np.ascontiguousarray(np.transpose(y, (1, 0, 2))).reshape(R, T * 4)
     out = {"workload": f"two observation branches per state (d=4, dy=2+2), T={T}, {R} replicas: 1 sum-product sweep + Bethe free energy on the node-array executor"}
     for name, build in (("two_branch", lambda: two_branch_chain_graph(T, mdl["A"], B1, B2, mdl["P"], Q1, Q2, mdl["m0"], mdl["V0"])),

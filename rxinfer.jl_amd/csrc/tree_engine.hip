@@ -804,7 +804,10 @@ TreeParams params_of(const Engine* e, int want_fe) {
 template <int N, int PHASE>
 void launch_phase(const Engine* e, const TreeParams& p, int l0, int l1) {
     if (l1 <= l0) return;
-    if (e->mode == 1) {
+    if (e->mode == 2) {
+        const unsigned blocks = (unsigned)((e->R + 63) / 64);
+        hipLaunchKernelGGL((k_tree_walk<N, PHASE>), dim3(blocks), dim3(64), 0, e->stream, p, e->prog.lvl_ptr[l0], e->prog.lvl_ptr[l1]);
+    } else if (e->mode == 1) {
         const unsigned blocks = (unsigned)((e->R + e->rb - 1) / e->rb);
         hipLaunchKernelGGL((k_tree_levels<N, PHASE>), dim3(blocks), dim3(256), 0, e->stream, p, e->d_lvl, l0, l1, e->rb);
     } else {
@@ -860,7 +863,9 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     // schedule: deep graphs walk their levels inside a workgroup (one launch per iteration); wide, shallow ones take a launch per level
     const double avg_width = (double)P.n_ops / std::max(1, P.n_levels);
     e->mode = (P.n_levels > 24 && (e->R >= 512 || avg_width * (double)e->R < 16384.0)) ? 1 : 0;
-    if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = std::atoi(m) ? 1 : 0;
+    // large batches: a lane per replica walks the whole schedule (no barriers; 64 replicas per wavefront, from one wavefront per SIMD on)
+    if (e->R >= 65536) e->mode = 2;
+    if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = std::max(0, std::min(2, std::atoi(m)));
     {
         long long rb = (e->R / 1024) / 16 * 16;
         e->rb = (int)std::min<long long>(64, std::max<long long>(16, rb));

@@ -681,6 +681,14 @@ __global__ void __launch_bounds__(256) k_tree_levels(TreeParams p, const int* __
         __syncthreads();   // (waits for the level's stores: every reader of the next level is in this workgroup)
     }
 }
+// a lane owns a replica and walks the ops of the range in order: no barriers, no cross-lane dependencies, every wavefront evaluates the same op for 64
+// replicas with unit-stride loads — the schedule of LARGE batches (from a few waves per SIMD on it is bound by the messages' HBM traffic, not by latency)
+template <int N, int PHASE>
+__global__ void __launch_bounds__(64) k_tree_walk(TreeParams p, int op0, int op1) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= p.R) return;
+    for (int o = op0; o < op1; ++o) eval_op<N, PHASE>(p, p.ops + (size_t)o * OP_WORDS, r);
+}
 // per-replica free energy = term[root]; total over replicas in a fixed order (one workgroup, pairwise tree over a fixed layout)
 __global__ void __launch_bounds__(256) k_tree_fe_total(const double* __restrict__ term, long long root, long long R, long long RS, double* __restrict__ per_replica, double* __restrict__ total) {
     __shared__ double sh[256];

@@ -15,6 +15,8 @@ from rxhip.tree import TreeEngine  # noqa: E402
 
 T, R = (int(sys.argv[1]) if len(sys.argv) > 1 else 256), (int(sys.argv[2]) if len(sys.argv) > 2 else 4096)
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+if len(sys.argv) > 4:
+    os.environ["RXHIP_TEST_HOOKS"], os.environ["RXHIP_TREE_MODE"] = "1", sys.argv[4]
 mdl = workloads.c1_model()
 gb, xs, ys = two_branch_chain_graph(T, mdl["A"], mdl["B"][:2], mdl["B"][2:], mdl["P"], mdl["Q"][:2, :2], mdl["Q"][2:, 2:], mdl["m0"], mdl["V0"])
 rows = np.random.default_rng(0).standard_normal((R, T * 4)) * 3.0

@@ -53,7 +53,7 @@ def eng_gauss(gb):
     return {v for v in range(len(gb.kind)) if g.gauss[v]}
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("builder,kw", [(tg.two_branch_chain, dict(T=12)), (tg.two_branch_chain, dict(T=9, d=2, dy1=2, dy2=2, precision_spelling=True)),
                                         (tg.two_branch_chain, dict(T=7, d=4, dy1=4, dy2=3)),
                                         (tg.branching_tree, dict(depth=3, fanout=2, d=1, seed=5)), (tg.branching_tree, dict(depth=2, fanout=3, d=2)),
@@ -107,7 +107,7 @@ def test_rxhip_create_falls_through_to_the_executor():
     assert ei.value.status == _lib.ERR_UNSUPPORTED and "cycle" in str(ei.value)
 
 
-@pytest.mark.parametrize("d,dy,T,R,mode", [(4, 4, 60, 70, 1), (3, 3, 40, 3, 0), (2, 2, 300, 1, 1), (1, 1, 25, 130, 0)])
+@pytest.mark.parametrize("d,dy,T,R,mode", [(4, 4, 60, 70, 1), (3, 3, 40, 3, 0), (2, 2, 300, 1, 1), (1, 1, 25, 130, 0), (4, 4, 30, 200, 2)])
 def test_state_space_chain_equals_the_specialised_engine(d, dy, T, R, mode, monkeypatch):
     """the LGSSM chain through the generic path against LGSSMEngine (and the oracle)"""
     import rxhip
@@ -141,7 +141,7 @@ def test_state_space_chain_equals_the_specialised_engine(d, dy, T, R, mode, monk
     assert cnt["rule_calls"] == ocnt.rule_calls * R
 
 
-@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("kw", [dict(T=20, d=2, dy=2), dict(T=15, d=3, dy=2, also_obs_noise=True), dict(T=30, gamma=True)])
 def test_unknown_state_noise_precision_vmp(kw, mode, monkeypatch):
     """x[t] ~ MvNormal(μ = A x[t-1], Λ = W), W ~ Wishart: every iteration's free energy and the final q(x), q(W) against the oracle"""
