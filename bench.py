@@ -91,7 +91,8 @@ def cpu_baseline(mdl, y_host, sample_chains):
     del out
     base = {"value": cnt.rule_calls / dt1, "unit": "rule-calls/s", "cores": 1, "kind": "port",
             "sample": f"chains 0..{sample_chains - 1} x T={T} of the benchmarked batch, 1 BP sweep with free energy, {dt1:.1f} s on 1 of "
-                      f"{ncores} usable host cores (CPU restatement of the reference schedule, not RxInfer)",
+                      f"{ncores} usable host cores (CPU restatement of the reference schedule, not RxInfer); the same restatement on all {ncores} cores "
+                      f"({nthreads} OpenMP threads over chains 0..{n_all - 1}): {cnta.rule_calls / dta:.3e} rule-calls/s",
             "all_cores": {"value": cnta.rule_calls / dta, "unit": "rule-calls/s", "cores": ncores, "threads": nthreads, "cores_note": cores_note,
                           "sample": f"chains 0..{n_all - 1} x T={T}, OpenMP over chains ({nthreads} threads), {dta:.1f} s"}}
     return base, fe1

@@ -269,7 +269,7 @@ end
 mutable struct HIPGraphEngine
     engine::RxHip.Engine
     tables::GraphTables
-    family::Symbol                       # :lgssm, :lgssm_noise, :drift, :mixture, :mvmixture, :hgf
+    family::Symbol                       # :lgssm, :lgssm_noise, :drift, :mixture, :mvmixture, :hgf, :tree (the node-array executor: any acyclic Gaussian graph)
     data_ids::Vector{Int64}              # data variables in the order rxhip_set_data expects (time order)
     data_slot::Dict{Int64, Int}          # variable id -> position in `staging`
     staging::Vector{Float64}
@@ -286,6 +286,7 @@ mutable struct HIPGraphEngine
     predictions::Dict{Int64, Any}        # data variable id -> RecentSubject of its prediction, created on first request
     masked::Bool                         # the engine takes `missing` observations (rebuilt on the first one, see `fire!`)
     options::Any                         # HIPInferenceOptions (segments, device) for that rebuild
+    tree::Any                            # family :tree: RxHip.tree_layout (data offsets, random / precision variable ids), else nothing
 end
 
 """`randomvar` stand-in: a marginal stream the engine pushes into after every sweep."""
@@ -340,6 +341,17 @@ function ReactiveMP.new_observation!(v::HIPDataVariable, value)
         return nothing
     end
     slot = g.data_slot[v.id]
+    if g.family === :tree   # ragged observations: every data variable at its own offset of the staging vector
+        ismissing(value) && error("the node-array executor takes no missing observations; use options = (backend = :reactivemp,)")
+        vals = value isa Real ? (Float64(value),) : value
+        o = g.tree.data_offsets[slot]
+        @inbounds for (k, x) in enumerate(vals)
+            g.staging[o + k] = x
+        end
+        g.received += 1
+        g.received == length(g.data_ids) && fire!(g)
+        return nothing
+    end
     if ismissing(value)   # `missing` = NaN on the device: no message from this observation branch (static.md:98-123)
         g.family === :lgssm || error("the HIP backend takes missing observations in state-space graphs only")
         vals = ntuple(_ -> NaN, g.width)
@@ -367,6 +379,13 @@ function fire!(g::HIPGraphEngine)
         g.masked = true
     end
     e = g.engine
+    if g.family === :tree   # one sweep (+ one update of every q(W)) per call: the loop of batch.jl:391-430 re-pushes the data every iteration
+        RxHip.tree_set_data!(e, g.data_ids, g.staging)
+        RxHip.run!(e; iterations = 1, free_energy = g.want_free_energy)
+        publish_marginals!(g)
+        g.want_free_energy && g.free_energy !== nothing && Rocket.next!(g.free_energy, RxHip.free_energy(e)[end])
+        return nothing
+    end
     isempty(g.input_slot) || RxHip.set_inputs!(e, g.input_staging)
     GC.@preserve g begin
         RxHip.check(e, ccall((:rxhip_set_data, RxHip.librxhip), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Csize_t, Int32),
@@ -397,6 +416,21 @@ as_marginal(d) = ReactiveMP.Marginal(d, false, false, nothing)
 
 function publish_marginals!(g::HIPGraphEngine)
     e = g.engine
+    if g.family === :tree
+        ms, Vs = RxHip.tree_marginals(e, g.tree.state_ids, g.tree.state_dims)
+        for (k, id) in enumerate(g.tree.state_ids)
+            haskey(g.marginals, id) || continue
+            q = (id in g.tree.scalar_ids) ? ReactiveMP.NormalMeanVariance(ms[k][1], Vs[k][1, 1]) :
+                ReactiveMP.MvNormalMeanCovariance(ms[k], Symmetric(Vs[k]))
+            Rocket.next!(g.marginals[id], as_marginal(q))
+        end
+        for id in g.tree.precision_ids
+            haskey(g.marginals, id) || continue
+            ν, V = RxHip.tree_precision(e, id, Int(g.tables.var_rows[id + 1]))
+            Rocket.next!(g.marginals[id], as_marginal(g.tree.gamma[id] ? ReactiveMP.GammaShapeRate(ν / 2, 1 / (2 * V[1, 1])) : ReactiveMP.Wishart(ν, Symmetric(V))))
+        end
+        return nothing
+    end
     if g.family === :lgssm || g.family === :lgssm_noise
         mean, cov = RxHip.marginals(e)                          # d × T, d × d × T
         for (t, id) in enumerate(g.state_ids)
@@ -483,7 +517,8 @@ function GraphPPL.postprocess_plugin(plugin::HIPInferencePlugin, model::GraphPPL
         getoptions(plugin).fallback.warn && @warn "HIP backend: $(err.msg); using ReactiveMP"
         return GraphPPL.postprocess_plugin(ReactiveMPInferencePlugin(getoptions(plugin).fallback), model)
     end
-    lowered = RxHip.lowered_layout(tables)       # family, data / state variable ids in time order, observation width
+    tree = RxHip.tree_info(engine) === nothing ? nothing : RxHip.tree_layout(tables)   # the executor took the graph: its own layout
+    lowered = tree === nothing ? RxHip.lowered_layout(tables) : (family = :tree, data_ids = tree.data_ids, state_ids = tree.state_ids)       # family, data / state variable ids in time order, observation width
     if lowered.family === :hgf
         # one-step graphs driven by `@autoupdates` belong to the streaming driver's event loop (streaming.jl:349-407); the
         # device runs ALL observations in one call, which is reached through RxHip.HgfEngine / RxHip.run_filter!, not here
@@ -508,14 +543,14 @@ function GraphPPL.postprocess_plugin(plugin::HIPInferencePlugin, model::GraphPPL
     end
     width = Int(tables.var_rows[lowered.data_ids[1] + 1])
     # the chain with an unknown noise precision: `p` carries the variable id of W, `beta` whether its prior was spelled as a Gamma
-    comps = lowered.family === :lgssm_noise ? (m = Int64[], p = [lowered.precision_id], s = Int64(-1), beta = lowered.gamma) : component_ids(tables)
+    comps = lowered.family === :tree ? (m = Int64[], p = Int64[], s = Int64(-1), beta = false) : lowered.family === :lgssm_noise ? (m = Int64[], p = [lowered.precision_id], s = Int64(-1), beta = lowered.gamma) : component_ids(tables)
     lowered.family === :lgssm_noise && RxHip.noise_continue!(engine)
     g = HIPGraphEngine(engine, tables, lowered.family, lowered.data_ids, Dict(id => k for (k, id) in enumerate(lowered.data_ids)),
-                       zeros(Float64, width * length(lowered.data_ids)), 0, false, marginals, nothing, lowered.state_ids, width,
+                       zeros(Float64, tree === nothing ? width * length(lowered.data_ids) : tree.data_total), 0, false, marginals, nothing, lowered.state_ids, width,
                        comps,
                        Dict{Int64, Int}(id => t for (t, id) in enumerate(get(lowered, :input_ids, Int64[])) if id >= 0),
                        zeros(Float64, get(lowered, :du, 0) * length(lowered.data_ids)), get(lowered, :du, 0),
-                       Dict{Int64, Any}(), false, getoptions(plugin))
+                       Dict{Int64, Any}(), false, getoptions(plugin), tree)
     gref[] = g
     GraphPPL.setextra!(GraphPPL.getcontext(model), HIPEngineKey, g)   # one handle per model; found again by `score`
     return nothing

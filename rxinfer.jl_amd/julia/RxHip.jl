@@ -537,10 +537,52 @@ function create_from_tables(t; n_replicas::Integer = 1, n_observations::Integer 
         st == RXHIP_ERR_NOT_POSDEF && throw(PosDefException(0))
         throw(RxHipError(st, msg))
     end
+    probe = Engine(h[], 0, 0, 0, n_replicas, 0)
+    if tree_info(probe) !== nothing   # the pattern matcher had no family for this graph: the node-array executor took it (rxhip_tree_* entry points)
+        finalizer(destroy!, probe)
+        return probe
+    end
     lay = lowered_layout(t)
     e = Engine(h[], lay.d, lay.width, length(lay.data_ids), n_replicas, 0)
     finalizer(destroy!, e)
     return e
+end
+
+"""Layout of a graph the node-array executor runs: every data variable (id order) with its offset in the staging vector, every random variable
+that is not a precision variable (the `out` of a Wishart / Gamma node) with its dimension, the precision variables."""
+function tree_layout(t)
+    prec = Set{Int64}()
+    for f in eachindex(t.factor_type)
+        t.factor_type[f] in (Int32(12), Int32(5), Int32(15)) && push!(prec, t.factor_iface[t.factor_iface_ptr[f] + 1])
+    end
+    data = Int64[i - 1 for i in eachindex(t.var_kind) if t.var_kind[i] == Int32(1)]
+    rnd = Int64[i - 1 for i in eachindex(t.var_kind) if t.var_kind[i] == Int32(0) && !((i - 1) in prec)]
+    # univariate variables (their marginals are NormalMeanVariance, not one-dimensional MvNormals): what a Normal(…) node touches, carried through `*` and `+`
+    scal = Set{Int64}()
+    ifs(f) = t.factor_iface[(t.factor_iface_ptr[f] + 1):t.factor_iface_ptr[f + 1]]
+    for f in eachindex(t.factor_type)
+        t.factor_type[f] in (Int32(3), Int32(4)) && union!(scal, ifs(f)[1:2])
+    end
+    grew = true
+    while grew
+        grew = false
+        for f in eachindex(t.factor_type)
+            t.factor_type[f] in (Int32(2), Int32(13)) || continue
+            io = t.factor_type[f] == Int32(2) ? ifs(f)[[1, 3]] : ifs(f)
+            if any(in(scal), io) && !all(in(scal), io) && all(i -> t.var_rows[i + 1] == 1, io)
+                union!(scal, io)
+                grew = true
+            end
+        end
+    end
+    offs, o = Int[], 0
+    for id in data
+        push!(offs, o)
+        o += Int(t.var_rows[id + 1])
+    end
+    return (family = :tree, data_ids = data, data_offsets = offs, data_total = o, state_ids = rnd, state_dims = Int[Int(t.var_rows[id + 1]) for id in rnd],
+            precision_ids = sort!(collect(prec)), scalar_ids = scal, gamma = Dict(id => any(f -> t.factor_type[f] != Int32(12) && t.factor_iface[t.factor_iface_ptr[f] + 1] == id,
+                                                                        eachindex(t.factor_type)) for id in prec))
 end
 
 """Family of the graph and the variable ids (0-based, time order) of its observations / states, from the host-only lowering
@@ -628,6 +670,93 @@ function marginals_of_chains(e::Engine, chains::Vector{Int64})
     GC.@preserve chains mean cov check(e, ccall((:rxhip_get_marginals_chains, librxhip), Int32,
         (Ptr{Cvoid}, Int32, Ptr{Int64}, Int64, Ptr{Float64}, Ptr{Float64}), e.handle, RXHIP_VAR_X, chains, length(chains), mean, cov))
     return mean, cov
+end
+
+# ---- the level-scheduled node-array executor (include/rxhip.h rxhip_tree_*): any acyclic Gaussian graph -----------------------------
+# mirrors rxhip_tree_info
+struct TreeInfo
+    n_ops::Int64
+    n_levels::Int64
+    n_messages::Int64
+    doubles_per_replica::Int64
+    bytes_per_sweep::Int64
+    dmax::Int32
+    mode::Int32
+    replicas_per_workgroup::Int32
+    n_precision_vars::Int32
+    last_iteration_ms::Float64
+end
+# mirrors rxhip_rule_call
+struct RuleCall
+    node_type::Int32
+    iface::Int32
+    d_out::Int32
+    d_in::Int32
+    n::Int64
+    constant::Ptr{Float64}
+    in_form::Int32
+    in_a::Ptr{Float64}
+    in_B::Ptr{Float64}
+    in2_a::Ptr{Float64}
+    in2_B::Ptr{Float64}
+    out_form::Int32
+    out_a::Ptr{Float64}
+    out_B::Ptr{Float64}
+end
+
+"""`rxhip_tree_get_info`, or `nothing` when the handle belongs to one of the pattern-matched families (what `rxhip_create` built
+tells the plugin which set of entry points drives the engine)."""
+function tree_info(e::Engine)
+    info = Ref(TreeInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0))
+    st = ccall((:rxhip_tree_get_info, librxhip), Int32, (Ptr{Cvoid}, Ref{TreeInfo}), e.handle, info)
+    return st == RXHIP_OK ? info[] : nothing
+end
+
+"""Observations of the listed data variables (0-based ids), `flat` = their values side by side, one replica."""
+function tree_set_data!(e::Engine, ids::Vector{Int64}, flat::Vector{Float64})
+    GC.@preserve ids flat check(e, ccall((:rxhip_tree_set_data, librxhip), Int32, (Ptr{Cvoid}, Ptr{Int64}, Int64, Ptr{Float64}),
+                                        e.handle, ids, length(ids), flat))
+end
+
+"""Posteriors of the listed random variables (0-based ids, dimensions `dims`): vectors of means and of covariance matrices (replica 1)."""
+function tree_marginals(e::Engine, ids::Vector{Int64}, dims::Vector{Int})
+    R = e.n_chains
+    mean, cov = Vector{Float64}(undef, R * sum(dims)), Vector{Float64}(undef, R * sum(d -> d * d, dims))
+    GC.@preserve ids mean cov check(e, ccall((:rxhip_tree_get_marginals, librxhip), Int32,
+        (Ptr{Cvoid}, Ptr{Int64}, Int64, Ptr{Float64}, Ptr{Float64}), e.handle, ids, length(ids), mean, cov))
+    ms, Vs, mo, co = Vector{Vector{Float64}}(), Vector{Matrix{Float64}}(), 0, 0
+    for d in dims   # [var][replica][d] / [var][replica][d][d], row-major: replica 1 of every variable
+        push!(ms, mean[(mo + 1):(mo + d)])
+        push!(Vs, collect(transpose(reshape(cov[(co + 1):(co + d * d)], d, d))))
+        mo += R * d
+        co += R * d * d
+    end
+    return ms, Vs
+end
+
+"""q(W) = Wishart(ν, V) of a precision variable (replica 1); a Gamma(a, b) variable comes back as Wishart₁(2a, 1/(2b))."""
+function tree_precision(e::Engine, id::Integer, d::Integer)
+    R = e.n_chains
+    nu, V = Vector{Float64}(undef, R), Vector{Float64}(undef, R * d * d)
+    GC.@preserve nu V check(e, ccall((:rxhip_tree_get_precision, librxhip), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Float64}), e.handle, id, nu, V))
+    return nu[1], collect(transpose(reshape(V[1:(d * d)], d, d)))
+end
+
+"""One message rule on the device (`rxhip_rule_eval`): the A/B hook next to `ReactiveMP.@call_rule`.  `a`: d × n, `B`: d × d × n (column-major
+Julia arrays of symmetric matrices: the C side reads them row-major, the same bytes)."""
+function rule_eval(node_type::Integer, iface::Integer, constant, a::Matrix{Float64}, B::Array{Float64, 3}; a2 = nothing, B2 = nothing,
+                   in_form::Integer = 0, out_form::Integer = 0, d_out::Integer = size(a, 1), d_in::Integer = size(a, 1), device::Integer = -1)
+    n = size(a, 2)
+    dres = node_type == 2 ? (iface == 0 ? d_out : d_in) : d_out
+    oa, oB = Matrix{Float64}(undef, dres, n), Array{Float64, 3}(undef, dres, dres, n)
+    c = constant === nothing ? Float64[] : collect(Float64, transpose(constant))[:]   # row-major for the C side
+    GC.@preserve c a B a2 B2 oa oB begin
+        call = RuleCall(node_type, iface, d_out, d_in, n, isempty(c) ? C_NULL : pointer(c), in_form, pointer(a), pointer(B),
+                        a2 === nothing ? C_NULL : pointer(a2), B2 === nothing ? C_NULL : pointer(B2), out_form, pointer(oa), pointer(oB))
+        st = ccall((:rxhip_rule_eval, librxhip), Int32, (Ref{RuleCall}, Int32), call, device)
+        st == RXHIP_OK || throw(RxHipError(st, lowering_error()))
+    end
+    return oa, oB
 end
 
 # mirrors rxhip_drift_chain_desc

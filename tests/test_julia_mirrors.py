@@ -10,7 +10,8 @@ JULIA = open(os.path.join(ROOT, "rxinfer.jl_amd", "julia", "RxHip.jl")).read()
 PAIRS = {"rxhip_lgssm_desc": "LgssmDesc", "rxhip_graph_desc": "GraphDesc", "rxhip_lgssm_lowered": "LgssmLowered",
          "rxhip_gmm_desc": "GmmDesc", "rxhip_mvgmm_desc": "MvGmmDesc", "rxhip_hgf_desc": "HgfDesc",
          "rxhip_drift_chain_desc": "DriftChainDesc", "rxhip_noise_prior": "NoisePrior",
-         "rxhip_lgssm_noise_lowered": "LgssmNoiseLowered", "rxhip_lgssm_lowered ": "LgssmLoweredFields"}
+         "rxhip_lgssm_noise_lowered": "LgssmNoiseLowered", "rxhip_lgssm_lowered ": "LgssmLoweredFields",
+         "rxhip_tree_info": "TreeInfo", "rxhip_rule_call": "RuleCall"}
 
 
 def c_fields(name):
