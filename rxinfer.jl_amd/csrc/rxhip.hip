@@ -26,8 +26,7 @@
 #include "mvgmm_kernels.hpp"
 #include "drift_kernels.hpp"
 #include "generic_kernels.hpp"
-#include "graph_lowering.hpp"
-#include "tree_engine.hpp"
+#include "engine.hpp"
 
 using namespace rxhip;
 
@@ -107,170 +106,7 @@ __global__ void k_gather_chains(const double* __restrict__ in, double* __restric
         out[g] = in[(t * n_chains + chains[i]) * k + e];
     }
 }
-// out[j] = Σ_r buf[r][j], ranks in ascending order: the cross-GPU sums are bit-identical on every rank and from run to run
-// whatever algorithm the collective library picked for moving the bytes
-__global__ void k_rank_sum(const double* __restrict__ buf, double* __restrict__ out, int nranks, int n) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= n) return;
-    double s = 0.0;
-    for (int r = 0; r < nranks; ++r) s += buf[(size_t)r * n + j];
-    out[j] = s;
-}
 
-// ------------------------------------------------------------------------------------------
-struct rxhip_engine {
-    // one device allocation holds every buffer of a state-space engine (creation / destruction cost two driver calls
-    // instead of ≈40: 2.9 ms -> see DESIGN §6c); pointers inside it are never freed individually
-    char* arena = nullptr;
-    size_t arena_bytes = 0;
-    bool in_arena(const void* q) const { return arena && (const char*)q >= arena && (const char*)q < arena + arena_bytes; }
-    // description
-    int d = 0, dy = 0;
-    int dpad = 0;  // dense path: d rounded up to a multiple of 16 (kernel dimension); == d otherwise
-    long long T = 0, n_chains = 0;
-    long long H = 0;     // time indices without an observation after the T observed ones (rxhip_lgssm_desc.horizon)
-    long long Tout() const { return T + H; }  // rows of the posterior / prediction arrays
-    std::vector<double> h_bq;  // per model B | Q (row-major): the prediction kernel needs them, the sweep does not
-    double* d_bq = nullptr;
-    int n_models = 1;
-    int ptt = 0;
-    int S = 0;
-    long long L = 0, Llast = 0;
-    bool uniform = true;
-    const LgssmVtbl* vt = nullptr;
-    int device = 0;
-    hipStream_t stream = nullptr;
-    bool own_stream = false;
-    // device memory
-    double* d_y = nullptr;
-    bool own_y = false;
-    bool have_data = false;
-    double *d_filt = nullptr, *d_mean = nullptr, *d_cov = nullptr, *d_cst = nullptr, *d_tab = nullptr,
-           *d_vtab = nullptr, *d_scan = nullptr, *d_agg = nullptr, *d_elem = nullptr, *d_fstart = nullptr, *d_beta = nullptr, *d_fe_part = nullptr,
-           *d_fe_chain = nullptr, *d_fe_total = nullptr;
-    int* d_chain_model = nullptr;
-    int* d_status = nullptr;
-    double* d_fe_blocks = nullptr;
-    // Gaussian-mixture VMP engine (kind == 1)
-    int kind = 0;  // 0: LGSSM, 1: GMM, 2: HGF, 3: noise-free drift chain, 5: the level-scheduled node-array executor (tree_engine.hip; everything lives behind `tree`)
-    rxhip::tree::Engine* tree = nullptr;
-    struct Drift { double m0 = 0, v0 = 1, c = 0, obs_var = 1; } dr;
-    struct Hgf {
-        rxhip_hgf_desc ds;
-        double *d_out = nullptr, *d_fe_series = nullptr, *d_gh = nullptr, *d_fe_total = nullptr;
-        int fe_cap = 0;
-    } h;
-    struct Gmm {
-        long long N = 0;
-        int K = 0, KT = 0, materialize = 0, nblocks = 0, it = 0, iterations = 0, hist_cap = 0;
-        int mvd = 0;          // 0: univariate engine; d ≥ 1: multivariate engine (mvgmm_kernels.hpp) of that dimension
-        int nq = 0;           // statistics per iteration (the multi-GPU all-reduce payload)
-        int hist_stride = 0;  // doubles of history per iteration
-        int state_size = 0;   // doubles of the marginal block (d_par / d_init)
-        double *d_resp = nullptr, *d_par = nullptr, *d_drv = nullptr, *d_prior = nullptr, *d_init = nullptr,
-               *d_partial = nullptr, *d_totals = nullptr, *d_hist = nullptr, *d_fe = nullptr;
-    } g;
-    // dense (d = 16·NT) path
-    bool dense = false;
-    int nt = 0;
-    double *d_scanm = nullptr, *d_fstart_m = nullptr, *d_beta_xi = nullptr, *d_vend = nullptr, *d_qtab = nullptr, *d_loc = nullptr, *d_bnd = nullptr;
-    const int* d_canon = nullptr;  // canonical indices of the boundary maps (DenseParams::canon), inside the shared table block
-    int scan_sg = 1, scan_ng = 1;  // two-level boundary scan of the dense path: group size, groups
-    int agg_oc = 1, agg_kc = 1;    // dense aggregation product: offsets per K-chunk, K-chunks
-    double* d_aggpart = nullptr;   // [chain][agg_kc][S][2·dpad] partial sums of kd_agg_gemm
-    // shared-model smoothing in one pass over the observations (k_forward0): tables, see lgssm_kernels.hpp
-    bool fused = false;
-    double *d_ftab = nullptr, *d_mtab = nullptr, *d_ntab = nullptr, *d_pos = nullptr, *d_fseg = nullptr;
-    double fe_const = 0.0;
-    double *d_gtab = nullptr, *d_segend = nullptr, *d_sblk = nullptr;
-    hipEvent_t ev_tab0 = nullptr, ev_tab1 = nullptr;  // around the once-per-engine table kernels (rxhip_get_model_tables_ms)  // table-driven backward sweep (k_backward_sh): batches of a multiple of 64 chains
-    bool sequential = false;  // no per-position tables: missing observations / per-step constants (per-chain records; the segment
-                              // elements are computed in the lane, k_seg_elements, or the chain is ONE segment)
-    double* d_elemx = nullptr;
-    double* h_io = nullptr;       // pinned staging of rxhip_lgssm_infer (pooled)
-    size_t h_io_bytes = 0;
-    double* h_stream = nullptr;   // its pinned host staging block
-    double* d_stream = nullptr;   // rxhip_filter_step: belief per chain | staging of y, mean, cov, fe (allocated on first use)
-    long long stream_k = 0;
-    bool have_inputs = false;      // engines with data inputs u[t] (du > 0): rxhip_set_data(RXHIP_VAR_U) has been called
-    double stage_ms[4] = {0.0, 0.0, 0.0, 0.0};  // creation stages (rxhip_get_create_stages): tables host | tables device | upload | alloc
-    double *d_mu = nullptr, *d_nu = nullptr, *d_cx = nullptr, *d_cy_raw = nullptr;  // known inputs: μ[t] [Tout][d], ν[t] = B μ[t] + d[t] [Tout][dy], c[t], d[t]
-    std::vector<double> h_mu, h_nu, h_cx, h_cy, h_offA, h_offB;
-    std::vector<double> h_cx_const, h_cy_const;  // the offsets the engine was created with (graph constants), for RXHIP_VAR_U
-    std::vector<int> h_offsm;
-    int du = 0;                    // graph engines with data inputs `+ B_u * u[t]`: dimension of u, B_u [d][du], which steps have one
-    std::vector<double> h_Bu;
-    std::vector<char> h_umask;
-    bool off_chain = false;        // the device offset arrays carry a chain axis (rxhip_lgssm_set_chain_offsets)
-    double* d_off_chain = nullptr; // their block: μ | ν | c | d with a chain axis, and A | B of every model
-    std::vector<double> h_user;  // MFMA path: user-level A | P | B | Q | Q⁻¹ of every model (generic_kernels.hpp)
-    double* d_user = nullptr;
-    int* d_step_model = nullptr;
-    // MFMA path, a batch that shares one model: matrices once per engine, vectors per sweep (dense_split_kernels.hpp)
-    bool split = false, split_ready = false;
-    // rxhip_set_covariance_mode: 0 = every sweep writes the covariance of every chain; 1 = shared-model batches on the split schedule write
-    // the per-chain array on request (the values do not depend on the data: one [T][d][d] table per model).  cov_pending: the last run left
-    // the array to be materialised; cov_current: the array holds what a materialisation would write
-    int m_dpad = 0, m_nt = 0;        // masked schedule: tile dimension 16·⌈max(d, dy)/16⌉ (the engine's own dpad pads d only)
-    int m_sg = 0, m_ng = 0;          // masked schedule: groups of the two-level boundary recursion (0: one level)
-    int m_models = 1;                // masked schedule: constant blocks (per-step constants: desc.n_models, else 1)
-    bool m_stepm = false;            // per-step constants on the masked schedule
-    bool m_chainm = false;           // one model per chain on the masked schedule
-    DenseModel* m_modtab = nullptr;  // [m_models] constant-block pointers for the sweep kernels (one model per chain)
-    double* m_feconst = nullptr;
-    double *m_grp = nullptr, *m_gvec = nullptr;
-    int m_hs = 0, m_hs_rounds = 0;   // masked schedule: log-depth boundary recursion (km_compose / km_apply)
-    int m_hs_n = 0, m_hs_g = 1;      // … over m_hs_n entries of m_hs_g segments each (km_fold / km_inner when m_hs_g > 1)
-    double *m_hsel = nullptr, *m_hsvec = nullptr;
-    bool records_hold_gains = false; // the last run was a smoothing sweep of kd_forward_info / kd_backward_info with one chain per tile: d_filt holds G_t′
-    int cov_mode = 0;
-    bool cov_pending = false, cov_current = false;
-    double *d_dtab = nullptr, *d_vlast = nullptr, *d_vstab = nullptr, *d_fe_const = nullptr;
-    bool gseq = false;        // d > 4 with `missing` observations or per-step constants: sequential schedule (gseq_kernels.hpp)
-    // … and, for `missing` observations under ONE model, the time-parallel schedule of dense_mseg_kernels.hpp for smoothing runs
-    bool mseg = false;
-    int mS = 0;               // its segments / segment length
-    long long mL = 1;
-    char* mseg_block = nullptr;   // one allocation: padded model | constants workspace | cst | obs | nobs | elements | boundaries | records | scratch
-    double *m_in = nullptr, *m_cw = nullptr, *m_cst = nullptr, *m_obs = nullptr, *m_nobs = nullptr, *m_el = nullptr, *m_vec = nullptr,
-           *m_bnd = nullptr, *m_lb = nullptr, *m_ws = nullptr, *m_fe_part = nullptr;
-    double* d_prior = nullptr;  // gseq: [n_models][m0 | V0]
-    bool masked = false;      // NaN observations are `missing` (rxhip_lgssm_desc.allow_missing): per-chain records, one segment
-    int pack = 1;             // 2: pairs of chains share a 16×16 tile as a block-diagonal model (d ≤ 8), see dense_kernels.hpp
-    long long wg_chains = 0;  // chains (or pairs) the kernels' grids run over
-    int dyk = 0;              // observation dimension at kernel level (2·dy when packed)
-    std::vector<struct DenseTables*> dts;  // shared per-model device tables of the MFMA path (d_cst, d_tab, … point into model 0's)
-    struct DenseModel* d_models = nullptr;  // [n_models] table pointers on the device (several models per engine)
-    std::vector<double> h_cst0;  // model 0's constant block (kernel argument when all chains share it)
-    int fe_total_cap = 0;
-    // results bookkeeping
-    int last_iterations = 0;
-    bool last_want_fe = false;
-    bool ran = false, last_filter = false;
-    uint64_t rule_calls = 0, products = 0, marginals = 0;
-    // profiling
-    bool profiling = false;
-    bool m_wave8_last = false;   // the last masked sweep ran on the in-wave d ≤ 8 kernels
-    double* h_stage = nullptr;   // pinned staging block of the creation upload (arena_commit), kept until destruction
-    size_t h_stage_bytes = 0;
-    // unknown observation-noise precision (rxhip_lgssm_noise_create, noise_kernels.hpp): one block B | prior | state | history
-    bool records_tinv = false;   // the last smoothing run left mean-only forward records behind the fixed point of V_f (Params::tinv_records)
-    bool noise = false;
-    bool noise_continue = false;   // rxhip_lgssm_noise_continue: runs go on from the current q(W) (iteration-at-a-time drivers)
-    char* noise_block = nullptr;
-    double *n_B = nullptr, *n_prior = nullptr, *n_state = nullptr, *n_hist = nullptr, *n_part = nullptr;
-    int n_hist_cap = 0, n_slices = 1;
-    struct Pending { int k; hipEvent_t a, b; };
-    std::vector<Pending> pending;
-    std::vector<hipEvent_t> pool;
-    double k_ms[RXHIP_K_COUNT] = {};
-    uint64_t k_n[RXHIP_K_COUNT] = {};
-    std::string err = "";
-    std::string pool_key;   // non-empty: this engine may be parked by rxhip_destroy and handed out again by rxhip_lgssm_create (engine pool below)
-    // scratch of the cross-GPU sums (rxhip_allreduce_free_energy / rxhip_gmm_allreduce_statistics): [nranks][n]
-    double* d_coll = nullptr;
-    size_t coll_cap = 0;
-};
 
 
 // ---- idle-stream pool: on this runtime hipStreamCreate costs 1.5–9 ms and hipStreamDestroy ≈1.1 ms, which made
@@ -539,7 +375,6 @@ struct ArenaPlan {
     template <class T> void plain_first(T** pp, size_t bytes) { pl.push_back({(void**)pp, bytes, 0, nullptr, false, true}); }
     static size_t al(size_t x) { return (x + 255) & ~(size_t)255; }
 };
-static rxhip_status fail(rxhip_engine* e, rxhip_status s, const char* fmt, ...);
 static rxhip_status arena_commit(rxhip_engine* e, ArenaPlan& ap) {
     size_t off = 0;
     std::stable_partition(ap.zr.begin(), ap.zr.end(), [](const ArenaPlan::Item& it) { return !it.edge; });
@@ -578,52 +413,6 @@ static rxhip_status arena_commit(rxhip_engine* e, ArenaPlan& ap) {
     tr.mark("arena upload + memset", STAGE_UPLOAD);
     return RXHIP_OK;
 }
-
-static rxhip_status fail(rxhip_engine* e, rxhip_status s, const char* fmt, ...) {
-    if (e) {
-        char buf[512];
-        va_list ap;
-        va_start(ap, fmt);
-        vsnprintf(buf, sizeof buf, fmt, ap);
-        va_end(ap);
-        e->err = buf;
-    }
-    return s;
-}
-// entry points of the state-space / mixture engines, called on an engine of the node-array executor
-#define TREE_GUARD(e) do { if ((e) && (e)->tree) return fail((e), RXHIP_ERR_UNSUPPORTED, "%s: not available on an engine of the node-array executor (rxhip_tree_* entry points)", __func__); } while (0)
-// a temporary device block that is freed on every path out of its scope (early HIPCHK returns included)
-struct DevTmp {
-    void* p = nullptr;
-    DevTmp() = default;
-    DevTmp(const DevTmp&) = delete;
-    DevTmp& operator=(const DevTmp&) = delete;
-    ~DevTmp() { if (p) (void)hipFree(p); }
-};
-#define HIPCHK(e, call)                                                                              \
-    do {                                                                                             \
-        hipError_t _err = (call);                                                                    \
-        if (_err != hipSuccess)                                                                      \
-            return fail((e), RXHIP_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(_err), \
-                        __FILE__, __LINE__);                                                         \
-    } while (0)
-
-
-// Every entry point runs on the engine's device and leaves the CALLER's current device as it found it (a host that drives
-// several GPUs from one thread — torch, the Julia shim — must not be left on another device after a destroy / getter).
-struct DevGuard {
-    int prev = -1;
-    bool changed = false;
-    hipError_t set(int dev) {
-        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-        if (prev == dev) return hipSuccess;
-        hipError_t err = hipSetDevice(dev);
-        changed = err == hipSuccess;
-        return err;
-    }
-    ~DevGuard() { if (changed && prev >= 0) (void)hipSetDevice(prev); }
-};
-#define SET_DEVICE(e) DevGuard _dev_guard; HIPCHK((e), _dev_guard.set((e)->device))
 
 // ------------------------------------------------------------------------------------------
 // host dense helpers for the per-model tables (generic n; off the hot path)
@@ -3060,257 +2849,6 @@ static rxhip_status hgf_run_async(rxhip_engine* e, int32_t iterations, int32_t w
 rxhip_status rxhip_hgf_get_history(rxhip_engine* e, double* z_mean, double* z_var, double* x_mean, double* x_var,
                                    int32_t layout);
 
-static void fill_lowered(const rxhip_lower::Lgssm& L, rxhip_lgssm_lowered* out, bool with_Q);
-rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowered* out) {
-    if (!out) return RXHIP_ERR_BADARG;
-    rxhip_lower::Lgssm L;
-    rxhip_status st = rxhip_lower::lower_lgssm(g, L);
-    if (st) return st;
-    fill_lowered(L, out, true);
-    return RXHIP_OK;
-}
-rxhip_status rxhip_graph_lower_lgssm_noise(const rxhip_graph_desc* g, rxhip_lgssm_noise_lowered* out) {
-    if (!out) return RXHIP_ERR_BADARG;
-    rxhip_lower::LgssmNoise N;
-    rxhip_status st = rxhip_lower::lower_lgssm_noise(g, N);
-    if (st) return st;
-    fill_lowered(N.chain, &out->chain, false);
-    out->precision_var = N.w_var;
-    out->nu0 = N.nu0;
-    out->init_nu = N.init_nu;
-    if (out->S0) std::memcpy(out->S0, N.S0.data(), sizeof(double) * N.S0.size());
-    if (out->init_V) std::memcpy(out->init_V, N.init_V.data(), sizeof(double) * N.init_V.size());
-    return RXHIP_OK;
-}
-static void fill_lowered(const rxhip_lower::Lgssm& L, rxhip_lgssm_lowered* out, bool with_Q) {
-    out->d = L.d; out->dy = L.dy; out->T = L.T; out->prior_through_transition = L.ptt;
-    out->deterministic = L.deterministic;
-    out->n_models = L.n_models;
-    out->has_offsets = L.cx.empty() ? 0 : 1;
-    out->du = L.du;
-    if (out->input_matrix && L.du > 0) std::memcpy(out->input_matrix, L.Bu.data(), sizeof(double) * L.Bu.size());
-    if (out->input_var) for (long long t = 0; t < L.T; ++t) out->input_var[t] = L.du > 0 ? L.input_var[t] : -1;
-    if (out->state_offset) for (size_t q = 0; q < (size_t)L.T * L.d; ++q) out->state_offset[q] = L.cx.empty() ? 0.0 : L.cx[q];
-    if (out->obs_offset) for (size_t q = 0; q < (size_t)L.T * L.dy; ++q) out->obs_offset[q] = L.cy.empty() ? 0.0 : L.cy[q];
-    if (out->step_model) for (long long t = 0; t < L.T; ++t) out->step_model[t] = L.n_models > 1 ? L.step_model[t] : 0;
-    if (out->c) std::memcpy(out->c, L.c.data(), L.c.size() * sizeof(double));
-    auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
-    cp(out->A, L.A); cp(out->B, L.B); cp(out->P, L.P); if (with_Q) cp(out->Q, L.Q); cp(out->m0, L.m0); cp(out->V0, L.V0);
-    if (out->state_var) for (long long t = 0; t < L.T; ++t) out->state_var[t] = L.state_var[t];
-    if (out->data_var) for (long long t = 0; t < L.T; ++t) out->data_var[t] = L.data_var[t];
-}
-const char* rxhip_lowering_error(void) { return rxhip_lower::last_error().c_str(); }
-
-rxhip_status rxhip_graph_lower_gmm(const rxhip_graph_desc* g, rxhip_gmm_lowered* out) {
-    if (!out) return RXHIP_ERR_BADARG;
-    rxhip_lower::Gmm M;
-    rxhip_status st = rxhip_lower::lower_gmm(g, M);
-    if (st) return st;
-    out->N = M.N; out->K = M.K;
-    auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
-    cp(out->mu0, M.mu0); cp(out->v0, M.v0); cp(out->a0, M.a0); cp(out->b0, M.b0); cp(out->alpha0, M.alpha0);
-    cp(out->init_m_mean, M.qm_mean); cp(out->init_m_var, M.qm_var); cp(out->init_p_shape, M.qp_shape);
-    cp(out->init_p_rate, M.qp_rate); cp(out->init_s_alpha, M.qs_alpha);
-    if (out->data_var) for (long long i = 0; i < M.N; ++i) out->data_var[i] = M.data_var[i];
-    return RXHIP_OK;
-}
-rxhip_status rxhip_graph_lower_mvgmm(const rxhip_graph_desc* g, rxhip_mvgmm_lowered* out) {
-    if (!out) return RXHIP_ERR_BADARG;
-    rxhip_lower::MvGmm M;
-    rxhip_status st = rxhip_lower::lower_mvgmm(g, M);
-    if (st) return st;
-    out->N = M.N; out->K = M.K; out->d = M.d;
-    auto cp = [](double* dst, const std::vector<double>& v) { if (dst) std::memcpy(dst, v.data(), v.size() * sizeof(double)); };
-    cp(out->mu0, M.mu0); cp(out->S0, M.S0); cp(out->nu0, M.nu0); cp(out->V0, M.V0); cp(out->alpha0, M.alpha0);
-    cp(out->init_m_mean, M.qm_mean); cp(out->init_m_cov, M.qm_cov); cp(out->init_w_nu, M.qw_nu); cp(out->init_w_V, M.qw_V);
-    cp(out->init_s_alpha, M.qs_alpha);
-    if (out->data_var) for (long long i = 0; i < M.N; ++i) out->data_var[i] = M.data_var[i];
-    return RXHIP_OK;
-}
-rxhip_status rxhip_graph_lower_hgf(const rxhip_graph_desc* g, rxhip_hgf_lowered* out) {
-    if (!out) return RXHIP_ERR_BADARG;
-    rxhip_lower::Hgf H;
-    rxhip_status st = rxhip_lower::lower_hgf(g, H);
-    if (st) return st;
-    out->kappa = H.kappa; out->omega = H.omega; out->z_variance = H.z_variance; out->y_variance = H.y_variance;
-    out->z0_mean = H.z0m; out->z0_var = H.z0v; out->x0_mean = H.x0m; out->x0_var = H.x0v;
-    out->n_gh = H.n_gh; out->zt_var = H.zt; out->xt_var = H.xt; out->y_var = H.y;
-    return RXHIP_OK;
-}
-
-// the node-array executor behind an rxhip_engine handle (everything lives behind e->tree)
-rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* stream, rxhip_engine** out) {
-    if (!out) return RXHIP_ERR_BADARG;
-    *out = nullptr;
-    rxhip::tree::Engine* t = nullptr;
-    std::string err;
-    const rxhip_status st = rxhip::tree::create(g, device, stream, &t, err);
-    if (st) { rxhip_lower::last_error() = err; return st; }
-    rxhip_engine* e = new rxhip_engine();
-    e->kind = 5;
-    e->tree = t;
-    e->device = rxhip::tree::device_of(t);
-    e->n_chains = g->n_replicas > 0 ? g->n_replicas : 1;
-    *out = e;
-    return RXHIP_OK;
-}
-rxhip_status rxhip_tree_set_data(rxhip_engine* e, const int64_t* vars, int64_t n_vars, const double* host) {
-    if (!e || !e->tree) return e ? fail(e, RXHIP_ERR_BADARG, "rxhip_tree_set_data: not an engine of the node-array executor") : RXHIP_ERR_BADARG;
-    e->err.clear();
-    return rxhip::tree::set_data(e->tree, vars, n_vars, host, e->err);
-}
-rxhip_status rxhip_tree_get_marginals(rxhip_engine* e, const int64_t* vars, int64_t n_vars, double* mean, double* cov) {
-    if (!e || !e->tree) return e ? fail(e, RXHIP_ERR_BADARG, "rxhip_tree_get_marginals: not an engine of the node-array executor") : RXHIP_ERR_BADARG;
-    e->err.clear();
-    return rxhip::tree::get_marginals(e->tree, vars, n_vars, mean, cov, e->err);
-}
-rxhip_status rxhip_tree_get_precision(rxhip_engine* e, int64_t var, double* nu, double* V) {
-    if (!e || !e->tree) return e ? fail(e, RXHIP_ERR_BADARG, "rxhip_tree_get_precision: not an engine of the node-array executor") : RXHIP_ERR_BADARG;
-    e->err.clear();
-    return rxhip::tree::get_precision(e->tree, var, nu, V, e->err);
-}
-rxhip_status rxhip_tree_get_info(rxhip_engine* e, rxhip_tree_info* out) {
-    if (!e || !e->tree || !out) return RXHIP_ERR_BADARG;
-    rxhip::tree::info(e->tree, out);
-    return RXHIP_OK;
-}
-rxhip_status rxhip_rule_eval(const rxhip_rule_call* call, int32_t device) {
-    std::string err;
-    const rxhip_status st = rxhip::tree::rule_eval(call, device, err);
-    if (st) rxhip_lower::last_error() = err;   // (no handle to hang the text on: rxhip_lowering_error() returns it)
-    return st;
-}
-
-static rxhip_status create_pattern_matched(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out);
-rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out) {
-    if (!out) return RXHIP_ERR_BADARG;
-    // the pattern matcher first: its engines are the fast paths of the families they know; every graph it has no schedule for goes to the
-    // level-scheduled node-array executor, and only what THAT rejects (a cycle, a non-Gaussian node it has no rule for) is RXHIP_ERR_UNSUPPORTED
-    rxhip_status st = create_pattern_matched(g, segments, device, stream, out);
-    if (st != RXHIP_ERR_UNSUPPORTED || (out && *out)) return st;
-    const std::string why = rxhip_lower::last_error();
-    st = rxhip_tree_create(g, device, stream, out);
-    if (st == RXHIP_ERR_UNSUPPORTED) rxhip_lower::last_error() = why + " | node-array executor: " + rxhip_lower::last_error();
-    return st;
-}
-static rxhip_status create_pattern_matched(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out) {
-    if (!out) return RXHIP_ERR_BADARG;
-    *out = nullptr;
-    if (rxhip_status st0 = rxhip_lower::check_tables(g)) return st0;
-    // family by the node types present (the lowering passes reject everything that is not exactly their graph)
-    if (rxhip_lower::has_node(g, RXHIP_NODE_GCV)) {
-        rxhip_lower::Hgf H;
-        rxhip_status st = rxhip_lower::lower_hgf(g, H);
-        if (st) return st;
-        if (g->n_observations <= 0) { rxhip_lower::last_error() = "streaming graph: n_observations must be positive"; return RXHIP_ERR_BADARG; }
-        rxhip_hgf_desc d;
-        std::memset(&d, 0, sizeof d);
-        d.T = g->n_observations; d.n_series = g->n_replicas > 0 ? g->n_replicas : 1;
-        d.kappa = H.kappa; d.omega = H.omega; d.z_variance = H.z_variance; d.y_variance = H.y_variance;
-        d.z0_mean = H.z0m; d.z0_var = H.z0v; d.x0_mean = H.x0m; d.x0_var = H.x0v;
-        d.n_gh = H.n_gh; d.device = device; d.stream = stream;
-        return rxhip_hgf_create(&d, out);
-    }
-    // a precision prior on top of a state-space chain (no mixture node, a `*` node or a Gaussian transition between random variables):
-    // the chain with unknown observation noise
-    auto noise_chain = [&]() -> bool {
-        if (rxhip_lower::has_node(g, RXHIP_NODE_NORMAL_MIXTURE)) return false;
-        if (!rxhip_lower::has_node(g, RXHIP_NODE_WISHART) && !rxhip_lower::has_node(g, RXHIP_NODE_GAMMA_SHAPE_RATE) && !rxhip_lower::has_node(g, RXHIP_NODE_GAMMA_SHAPE_SCALE)) return false;
-        if (g->factor_iface_ptr) return false;
-        for (long long f = 0; f < g->n_factors; ++f) {
-            const int t = g->factor_type[f];
-            if (t == RXHIP_NODE_MULTIPLY) return true;
-            if ((t == RXHIP_NODE_MVNORMAL_MEAN_COV || t == RXHIP_NODE_NORMAL_MEAN_VARIANCE || t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION) &&
-                g->var_kind[rxhip_lower::iface(g, f, 0)] == RXHIP_VARKIND_RANDOM && g->var_kind[rxhip_lower::iface(g, f, 1)] == RXHIP_VARKIND_RANDOM)
-                return true;
-        }
-        return false;
-    };
-    if (noise_chain()) {
-        rxhip_lower::LgssmNoise N;
-        rxhip_status st = rxhip_lower::lower_lgssm_noise(g, N);
-        if (st) return st;
-        const rxhip_lower::Lgssm& L = N.chain;
-        rxhip_lgssm_desc d;
-        std::memset(&d, 0, sizeof d);
-        d.d = L.d; d.dy = L.dy; d.T = L.T; d.n_chains = g->n_replicas > 0 ? g->n_replicas : 1; d.n_models = 1;
-        d.prior_through_transition = L.ptt;
-        d.A = L.A.data(); d.B = L.B.data(); d.P = L.P.data(); d.Q = nullptr; d.m0 = L.m0.data(); d.V0 = L.V0.data();
-        d.segments = segments; d.device = device; d.stream = stream;
-        rxhip_noise_prior pr;
-        pr.nu0 = N.nu0; pr.S0 = N.S0.data(); pr.init_nu = N.init_nu; pr.init_V = N.init_V.data();
-        return rxhip_lgssm_noise_create(&d, &pr, out);
-    }
-    if (rxhip_lower::has_node(g, RXHIP_NODE_WISHART)) {
-        rxhip_lower::MvGmm M;
-        rxhip_status st = rxhip_lower::lower_mvgmm(g, M);
-        if (st) return st;
-        rxhip_mvgmm_desc d;
-        std::memset(&d, 0, sizeof d);
-        d.N = M.N; d.K = M.K; d.d = M.d;
-        d.mu0 = M.mu0.data(); d.S0 = M.S0.data(); d.nu0 = M.nu0.data(); d.V0 = M.V0.data(); d.alpha0 = M.alpha0.data();
-        d.init_m_mean = M.qm_mean.data(); d.init_m_cov = M.qm_cov.data(); d.init_w_nu = M.qw_nu.data(); d.init_w_V = M.qw_V.data();
-        d.init_s_alpha = M.qs_alpha.data();
-        d.device = device; d.stream = stream;
-        return rxhip_mvgmm_create(&d, out);
-    }
-    // `NormalMeanPrecision` with a RANDOM precision is the iid Gaussian×Gamma model; with constant precisions it is a Gaussian
-    // chain written in precision form (test/inference/prediction_tests.jl:197-213) and belongs to the state-space lowering
-    bool random_precision = false;
-    for (long long f = 0; f < g->n_factors && !random_precision; ++f)
-        random_precision = g->factor_type[f] == RXHIP_NODE_NORMAL_MEAN_PRECISION && rxhip_lower::n_iface(g, f) == 3 &&
-                           g->var_kind[rxhip_lower::iface(g, f, 2)] == RXHIP_VARKIND_RANDOM;
-    if (rxhip_lower::has_node(g, RXHIP_NODE_NORMAL_MIXTURE) || random_precision) {
-        rxhip_lower::Gmm M;
-        rxhip_status st = rxhip_lower::lower_gmm(g, M);
-        if (st) return st;
-        rxhip_gmm_desc d;
-        std::memset(&d, 0, sizeof d);
-        d.N = M.N; d.K = M.K;
-        d.mu0 = M.mu0.data(); d.v0 = M.v0.data(); d.a0 = M.a0.data(); d.b0 = M.b0.data(); d.alpha0 = M.alpha0.data();
-        d.init_m_mean = M.qm_mean.data(); d.init_m_var = M.qm_var.data(); d.init_p_shape = M.qp_shape.data();
-        d.init_p_rate = M.qp_rate.data(); d.init_s_alpha = M.qs_alpha.data();
-        d.device = device; d.stream = stream;
-        return rxhip_gmm_create(&d, out);
-    }
-    rxhip_lower::Lgssm L;
-    rxhip_status st = rxhip_lower::lower_lgssm(g, L);
-    if (st) return st;
-    if (L.deterministic) {
-        rxhip_drift_chain_desc dd;
-        std::memset(&dd, 0, sizeof dd);
-        dd.T = L.T; dd.n_chains = g->n_replicas > 0 ? g->n_replicas : 1;
-        dd.m0 = L.m0[0]; dd.v0 = L.V0[0]; dd.c = L.c[0]; dd.obs_var = L.Q[0];
-        dd.prior_through_transition = L.ptt; dd.device = device; dd.stream = stream;
-        return rxhip_drift_chain_create(&dd, out);
-    }
-    rxhip_lgssm_desc d;
-    std::memset(&d, 0, sizeof d);
-    d.d = L.d; d.dy = L.dy; d.T = L.T; d.n_chains = g->n_replicas > 0 ? g->n_replicas : 1; d.n_models = L.n_models;
-    d.prior_through_transition = L.ptt;
-    std::vector<double> m0s, V0s;
-    if (L.n_models > 1) {  // per-step constants: every model carries the (one) prior of the chain
-        for (int m = 0; m < L.n_models; ++m) {
-            m0s.insert(m0s.end(), L.m0.begin(), L.m0.end());
-            V0s.insert(V0s.end(), L.V0.begin(), L.V0.end());
-        }
-        d.step_model = L.step_model.data();
-    }
-    d.A = L.A.data(); d.B = L.B.data(); d.P = L.P.data(); d.Q = L.Q.data();
-    d.m0 = L.n_models > 1 ? m0s.data() : L.m0.data(); d.V0 = L.n_models > 1 ? V0s.data() : L.V0.data();
-    d.allow_missing = g->allow_missing;
-    if (!L.cx.empty()) { d.state_offset = L.cx.data(); d.obs_offset = L.cy.data(); }
-    d.segments = segments; d.device = device; d.stream = stream;
-    st = rxhip_lgssm_create(&d, out);
-    if (!st && L.du > 0) {  // data inputs: u arrives through rxhip_set_data(RXHIP_VAR_U); its constant part (if any) stays in c
-        (*out)->du = L.du;
-        (*out)->h_Bu = L.Bu;
-        (*out)->h_umask.assign((size_t)L.T, 0);
-        for (long long t = 0; t < L.T; ++t) (*out)->h_umask[(size_t)t] = L.input_var[(size_t)t] >= 0 ? 1 : 0;
-    }
-    return st;
-}
-
 static rxhip_status ingest(rxhip_engine* e, const double* src, size_t n, int32_t layout, bool src_on_device) {
     if (!e) return RXHIP_ERR_BADARG;
     const size_t need = (size_t)e->T * e->n_chains * e->dy;
@@ -4271,148 +3809,4 @@ rxhip_status rxhip_get_marginals_chains(rxhip_engine* e, int32_t var_id, const i
 // ------------------------------------------------------------------------------------------
 // Cross-GPU exchange over RCCL (xGMI).  librccl is opened on first use, not linked: single-GPU hosts never need it, and
 // a process that already carries an RCCL (torch) keeps exactly that one.
-}  // extern "C"
-#include <dlfcn.h>
-#include <rccl/rccl.h>
-namespace {
-struct Rccl {
-    void* h = nullptr;
-    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
-    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-    ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
-    ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
-    const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    std::string err;
-    bool ok = false;
-};
-Rccl& rccl() {
-    static Rccl* r = [] {
-        Rccl* q = new Rccl;
-        // The RCCL to use is the one that belongs to the HIP runtime THIS library runs on: streams and device pointers of
-        // one ROCm installation mean nothing to the libraries of another, and a process may carry two (a pip-installed
-        // torch bundles its own librccl / libhsa-runtime64 next to its libamdhip64).  So: the directory of the loaded
-        // libamdhip64 (dladdr of a HIP entry point) first, then the usual names.  RTLD_DEEPBIND keeps a second RCCL copy in
-        // the process from interposing this one's internal symbols.
-        std::vector<std::string> names;
-        Dl_info di;
-        if (dladdr((const void*)&hipGetDeviceCount, &di) && di.dli_fname) {
-            std::string dir(di.dli_fname);
-            const size_t slash = dir.rfind('/');
-            if (slash != std::string::npos) {
-                dir.resize(slash + 1);
-                names.push_back(dir + "librccl.so.1");
-                names.push_back(dir + "librccl.so");
-            }
-        }
-        names.push_back("librccl.so.1");
-        names.push_back("librccl.so");
-        names.push_back("/opt/rocm/lib/librccl.so.1");
-        if (const char* forced = std::getenv("RXHIP_RCCL_LIB")) names.assign(1, forced);  // this copy or none (deployments with their own RCCL; tests)
-        for (size_t i = 0; !q->h && i < names.size(); ++i) q->h = dlopen(names[i].c_str(), RTLD_NOW | RTLD_LOCAL | RTLD_DEEPBIND);
-        if (!q->h) {
-            const char* de = dlerror();  // ONE call: dlerror() clears the message it returns
-            q->err = std::string("librccl not found: ") + (de ? de : "?");
-            return q;
-        }
-        bool all = true;
-        auto sym = [&](const char* n) { void* p = dlsym(q->h, n); if (!p) { all = false; q->err = std::string("librccl lacks ") + n; } return p; };
-        q->GetUniqueId = (decltype(q->GetUniqueId))sym("ncclGetUniqueId");
-        q->CommInitRank = (decltype(q->CommInitRank))sym("ncclCommInitRank");
-        q->CommDestroy = (decltype(q->CommDestroy))sym("ncclCommDestroy");
-        q->CommCount = (decltype(q->CommCount))sym("ncclCommCount");
-        q->AllGather = (decltype(q->AllGather))sym("ncclAllGather");
-        q->GetErrorString = (decltype(q->GetErrorString))sym("ncclGetErrorString");
-        q->ok = all;
-        return q;
-    }();
-    return *r;
-}
-thread_local std::string g_comm_err;
-// all-gather `n` doubles of every rank into the engine's scratch, then sum in rank order into `inout` (in place)
-rxhip_status ordered_allreduce(rxhip_engine* e, void* comm, double* inout, int n, const char* what) {
-    Rccl& r = rccl();
-    if (!r.ok) return fail(e, RXHIP_ERR_RCCL, "%s: %s", what, r.err.c_str());
-    if (!comm) return fail(e, RXHIP_ERR_BADARG, "%s: null communicator", what);
-    int nranks = 0;
-    ncclResult_t rc = r.CommCount((ncclComm_t)comm, &nranks);
-    if (rc != ncclSuccess) return fail(e, RXHIP_ERR_RCCL, "%s: ncclCommCount: %s", what, r.GetErrorString(rc));
-    if (nranks <= 1) return RXHIP_OK;  // one rank: the local value is the global one, bit for bit
-    SET_DEVICE(e);
-    const size_t need = (size_t)nranks * (size_t)n;
-    if (need > e->coll_cap) {
-        HIPCHK(e, hipStreamSynchronize(e->stream));
-        if (e->d_coll) HIPCHK(e, hipFree(e->d_coll));
-        e->d_coll = nullptr;
-        HIPCHK(e, hipMalloc(&e->d_coll, sizeof(double) * need));
-        e->coll_cap = need;
-    }
-    (void)hipGetLastError();
-    rc = r.AllGather(inout, e->d_coll, (size_t)n, ncclDouble, (ncclComm_t)comm, e->stream);
-    if (rc != ncclSuccess) return fail(e, RXHIP_ERR_RCCL, "%s: ncclAllGather: %s", what, r.GetErrorString(rc));
-    hipLaunchKernelGGL(k_rank_sum, dim3((n + 63) / 64), dim3(64), 0, e->stream, (const double*)e->d_coll, inout, nranks, n);
-    HIPCHK(e, hipGetLastError());
-    return RXHIP_OK;
-}
-}  // namespace
-extern "C" {
-
-const char* rxhip_comm_last_error(void) { return g_comm_err.c_str(); }
-
-rxhip_status rxhip_comm_unique_id(char* id128) {
-    if (!id128) return RXHIP_ERR_BADARG;
-    Rccl& r = rccl();
-    if (!r.ok) { g_comm_err = r.err; return RXHIP_ERR_RCCL; }
-    ncclUniqueId id;
-    static_assert(sizeof(id) == 128, "ncclUniqueId is 128 bytes");
-    ncclResult_t rc = r.GetUniqueId(&id);
-    if (rc != ncclSuccess) { g_comm_err = std::string("ncclGetUniqueId: ") + r.GetErrorString(rc); return RXHIP_ERR_RCCL; }
-    std::memcpy(id128, &id, sizeof id);
-    return RXHIP_OK;
-}
-
-rxhip_status rxhip_comm_init_rank(void** comm, int32_t nranks, const char* id128, int32_t rank, int32_t device) {
-    if (!comm || !id128 || nranks <= 0 || rank < 0 || rank >= nranks) return RXHIP_ERR_BADARG;
-    *comm = nullptr;
-    Rccl& r = rccl();
-    if (!r.ok) { g_comm_err = r.err; return RXHIP_ERR_RCCL; }
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { g_comm_err = "no HIP device"; return RXHIP_ERR_NO_DEVICE; }
-    DevGuard dg;
-    if (device >= 0) {
-        if (device >= ndev || dg.set(device) != hipSuccess) { g_comm_err = "device out of range"; return RXHIP_ERR_BADARG; }
-    }
-    ncclUniqueId id;
-    std::memcpy(&id, id128, sizeof id);
-    ncclComm_t c = nullptr;
-    (void)hipGetLastError();  // RCCL checks hipGetLastError() after its launches: a stale non-sticky error of the host process must not fail it
-    ncclResult_t rc = r.CommInitRank(&c, nranks, id, rank);
-    if (rc != ncclSuccess) { g_comm_err = std::string("ncclCommInitRank: ") + r.GetErrorString(rc); return RXHIP_ERR_RCCL; }
-    *comm = (void*)c;
-    return RXHIP_OK;
-}
-
-rxhip_status rxhip_comm_destroy(void* comm) {
-    if (!comm) return RXHIP_OK;
-    Rccl& r = rccl();
-    if (!r.ok) { g_comm_err = r.err; return RXHIP_ERR_RCCL; }
-    ncclResult_t rc = r.CommDestroy((ncclComm_t)comm);
-    if (rc != ncclSuccess) { g_comm_err = std::string("ncclCommDestroy: ") + r.GetErrorString(rc); return RXHIP_ERR_RCCL; }
-    return RXHIP_OK;
-}
-
-rxhip_status rxhip_allreduce_free_energy(rxhip_engine* e, void* rccl_comm) {
-    TREE_GUARD(e);
-    if (!e) return RXHIP_ERR_BADARG;
-    if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
-    double* fe = e->kind == 1 ? e->g.d_fe : e->kind == 2 ? e->h.d_fe_total : e->d_fe_total;
-    return ordered_allreduce(e, rccl_comm, fe, e->last_iterations, "allreduce_free_energy");
-}
-
-rxhip_status rxhip_gmm_allreduce_statistics(rxhip_engine* e, void* rccl_comm) {
-    TREE_GUARD(e);
-    if (!e || e->kind != 1) return RXHIP_ERR_BADARG;
-    return ordered_allreduce(e, rccl_comm, e->g.d_totals, e->g.nq, "gmm_allreduce_statistics");
-}
-
 }  // extern "C"
