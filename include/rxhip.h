@@ -383,7 +383,7 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  *     typeof(*) with a constant matrix;  typeof(+) (random + random, random + data / constant);
  *     Wishart / GammaShapeRate / GammaShapeScale priors with constant parameters
  * whose Gaussian variables form a forest (no cycles; precision variables may touch any number of nodes — the mean-field factorisation cuts those
- * loops), every dimension ≤ 4.  The host compiles the graph into ops sorted by dependency level (csrc/tree_engine.hip); one kernel
+ * loops), every dimension ≤ 8 (registers hold the 4×4 instance; the 8×8 one spills: it exists so that such graphs run at all).  The host compiles the graph into ops sorted by dependency level (csrc/tree_engine.hip); one kernel
  * (csrc/tree_kernels.hpp) evaluates (op, replica) items: a launch per level over all nodes of the level, or — deep, narrow graphs — the whole
  * schedule in one launch with workgroup-resident levels.  Data variables, derived clamped values (`a + b` of two data variables), unobserved
  * leaves (predictions) are part of the family; `missing` inside the data is not (the chain engines have it).

@@ -208,6 +208,8 @@ struct Params {
     // Σ_t [(y_t − B m_t)(y_t − B m_t)′ + B V_t B′] of its segment while it holds (m_t, V_t) — part[seg][NS_y][chain]; null otherwise
     const double* noise_B;  // [DY][D]
     double* noise_part;
+    int skip_marginals;     // unknown-noise engines, VMP iterations before the last of a run: the sweep leaves its residual moments and free-energy terms,
+                            // not the 160 B/U of posteriors that the next iteration overwrites unread (rxhip_get_marginals returns the LAST iteration's)
     int tinv_records;       // per-chain, time-invariant models on long segments: k_forward_tinv / k_backward_tinv (mean-only records behind the fixed point)
     int elem_full;          // test hook: k_seg_elements runs the full recursion to the end of every segment (no frozen tail)
 };
@@ -2282,7 +2284,7 @@ __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<U
         ok = spd_inv<D>(Ls, Vs, det) && ok;
         symv<D>(Vs, u, ms);
         if (seg == p.S - 1) {
-            write_marginal<D>(p, te, chain, ms, Vs);
+            if (!(NOISE && p.skip_marginals)) write_marginal<D>(p, te, chain, ms, Vs);
             noise_add(te, ms, Vs);
         }
     }
@@ -2377,11 +2379,13 @@ __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<U
                         for (int k = 0; k < D; ++k) sacc += H[i][k] * G[j][k];
                         Vs(i, j) = sacc;
                     }
-                if constexpr (CAN_TILE) {
-                    if (tiled) write_marginal_wave<D>(p, tile, lane, t, chain - lane, ms, Vs);
-                    else write_marginal<D>(p, t, chain, ms, Vs);
-                } else
-                    write_marginal<D>(p, t, chain, ms, Vs);
+                if (!(NOISE && p.skip_marginals)) {   // (wave-uniform)
+                    if constexpr (CAN_TILE) {
+                        if (tiled) write_marginal_wave<D>(p, tile, lane, t, chain - lane, ms, Vs);
+                        else write_marginal<D>(p, t, chain, ms, Vs);
+                    } else
+                        write_marginal<D>(p, t, chain, ms, Vs);
+                }
                 noise_add(t, ms, Vs);
             }
             tstart = tc - 1;
@@ -2457,11 +2461,13 @@ __device__ __forceinline__ void backward_body(const Params& p, const CstArgFor<U
                 for (int k = 0; k < D; ++k) s += H[i][k] * G[j][k];
                 Vs(i, j) = s;
             }
-        if constexpr (CAN_TILE) {
-            if (tiled) write_marginal_wave<D>(p, tile, lane, t, chain - lane, ms, Vs);
-            else write_marginal<D>(p, t, chain, ms, Vs);
-        } else
-            write_marginal<D>(p, t, chain, ms, Vs);
+        if (!(NOISE && p.skip_marginals)) {
+            if constexpr (CAN_TILE) {
+                if (tiled) write_marginal_wave<D>(p, tile, lane, t, chain - lane, ms, Vs);
+                else write_marginal<D>(p, t, chain, ms, Vs);
+            } else
+                write_marginal<D>(p, t, chain, ms, Vs);
+        }
         noise_add(t, ms, Vs);
     }
     if constexpr (NOISE) {

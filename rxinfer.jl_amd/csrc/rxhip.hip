@@ -3163,6 +3163,9 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     }
     for (int it = 0; it < iterations; ++it) {
         p.iteration = it;
+        // an unknown-noise engine writes the posteriors of a run's LAST iteration only (rxhip_get_marginals is defined as that; the moments q(W) needs
+        // are formed inside the sweep): 160 B/U of stores per earlier iteration that nothing ever read
+        p.skip_marginals = (noise_in_sweep && it + 1 < iterations) ? 1 : 0;
         // `missing` observations / per-step constants at d > 4 on the masked MFMA schedule (smoothing; filtering runs: the same sweep, then the
         // filtered moments from its records) unless the sequential schedule is asked for as the checker of filtering runs
         const bool mseg_now = e->gseq && e->mseg && !(filter && hook_env("RXHIP_FILTER_GSEQ"));

@@ -252,8 +252,8 @@ struct Compiler {
                 dmx = std::max(dmx, P.dim[a]);
             }
         }
-        if (dmx > 4) fail(RXHIP_ERR_UNSUPPORTED, "the node-array executor runs dimensions <= 4 (this graph: %d)", dmx);
-        P.dmax = dmx <= 1 ? 1 : dmx <= 2 ? 2 : 4;
+        if (dmx > 8) fail(RXHIP_ERR_UNSUPPORTED, "the node-array executor runs dimensions <= 8 (this graph: %d)", dmx);
+        P.dmax = dmx <= 1 ? 1 : dmx <= 2 ? 2 : dmx <= 4 ? 4 : 8;
     }
 
     void build_edges() {
@@ -830,7 +830,8 @@ void launch(const Engine* e, const TreeParams& p, int l0, int l1) {
     switch (e->prog.dmax) {
     case 1: launch_levels<1>(e, p, l0, l1); break;
     case 2: launch_levels<2>(e, p, l0, l1); break;
-    default: launch_levels<4>(e, p, l0, l1); break;
+    case 4: launch_levels<4>(e, p, l0, l1); break;
+    default: launch_levels<8>(e, p, l0, l1); break;   // (registers for 4x4 blocks: the 8x8 instance spills — it exists so that such graphs run at all)
     }
 }
 }  // namespace
@@ -1097,7 +1098,7 @@ rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
     const bool noise = t == RXHIP_NODE_MVNORMAL_MEAN_COV || t == RXHIP_NODE_NORMAL_MEAN_VARIANCE || t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION;
     if (!noise && t != RXHIP_NODE_MULTIPLY && t != RXHIP_NODE_ADD) { err = "rule_eval: node type without a device rule"; return RXHIP_ERR_UNSUPPORTED; }
     const int dout = c->d_out, din = t == RXHIP_NODE_MULTIPLY ? c->d_in : c->d_out;
-    if (dout < 1 || din < 1 || dout > 4 || din > 4) { err = "rule_eval: dimensions 1..4"; return RXHIP_ERR_UNSUPPORTED; }
+    if (dout < 1 || din < 1 || dout > 8 || din > 8) { err = "rule_eval: dimensions 1..8"; return RXHIP_ERR_UNSUPPORTED; }
     if ((noise && (c->iface < 0 || c->iface > 1)) || (t == RXHIP_NODE_MULTIPLY && c->iface != 0 && c->iface != 2) || (t == RXHIP_NODE_ADD && (c->iface < 0 || c->iface > 2))) {
         err = "rule_eval: no message leaves through that interface"; return RXHIP_ERR_BADARG;
     }
@@ -1110,7 +1111,7 @@ rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
     // the dimension of the inbound message and of the result
     const int d_in_msg = t == RXHIP_NODE_MULTIPLY ? (c->iface == 0 ? din : dout) : dout;
     const int d_res = t == RXHIP_NODE_MULTIPLY ? (c->iface == 0 ? dout : din) : dout;
-    const int dmax = std::max(dout, din), N = dmax <= 1 ? 1 : dmax <= 2 ? 2 : 4;
+    const int dmax = std::max(dout, din), N = dmax <= 1 ? 1 : dmax <= 2 ? 2 : dmax <= 4 ? 4 : 8;
     auto msz = [](int d) { return d + d * (d + 1) / 2; };
     const long long R = c->n, RS = (R + 15) / 16 * 16;
     // slots: in0 | in1 | rule output | converted output (message) ; marginal slot for the moment form
@@ -1176,7 +1177,8 @@ rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
     for (int o = 0; o < 2; ++o) {
         if (N == 1) hipLaunchKernelGGL((k_tree_ops<1, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
         else if (N == 2) hipLaunchKernelGGL((k_tree_ops<2, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
-        else hipLaunchKernelGGL((k_tree_ops<4, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
+        else if (N == 4) hipLaunchKernelGGL((k_tree_ops<4, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
+        else hipLaunchKernelGGL((k_tree_ops<8, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
     }
     int status = 0;
     std::vector<double> res((size_t)(c->out_form ? msg_d : marg_d) * RS);

@@ -55,7 +55,8 @@ def eng_gauss(gb):
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
 @pytest.mark.parametrize("builder,kw", [(tg.two_branch_chain, dict(T=12)), (tg.two_branch_chain, dict(T=9, d=2, dy1=2, dy2=2, precision_spelling=True)),
-                                        (tg.two_branch_chain, dict(T=7, d=4, dy1=4, dy2=3)),
+                                        (tg.two_branch_chain, dict(T=7, d=4, dy1=4, dy2=3)), (tg.two_branch_chain, dict(T=5, d=8, dy1=8, dy2=5)),
+                                        (tg.two_branch_chain, dict(T=6, d=6, dy1=3, dy2=5)),
                                         (tg.branching_tree, dict(depth=3, fanout=2, d=1, seed=5)), (tg.branching_tree, dict(depth=2, fanout=3, d=2)),
                                         (tg.scalar_tree, dict(n_leaves=6)), (tg.chain_with_prediction, dict(T=8, H=3))])
 def test_unsupported_shapes_against_the_oracle(builder, kw, mode, monkeypatch):
@@ -142,7 +143,7 @@ def test_state_space_chain_equals_the_specialised_engine(d, dy, T, R, mode, monk
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2])
-@pytest.mark.parametrize("kw", [dict(T=20, d=2, dy=2), dict(T=15, d=3, dy=2, also_obs_noise=True), dict(T=30, gamma=True)])
+@pytest.mark.parametrize("kw", [dict(T=20, d=2, dy=2), dict(T=15, d=3, dy=2, also_obs_noise=True), dict(T=30, gamma=True), dict(T=8, d=6, dy=5, also_obs_noise=True)])
 def test_unknown_state_noise_precision_vmp(kw, mode, monkeypatch):
     """x[t] ~ MvNormal(μ = A x[t-1], Λ = W), W ~ Wishart: every iteration's free energy and the final q(x), q(W) against the oracle"""
     import tree_oracle
@@ -227,3 +228,10 @@ def test_rule_eval_matches_the_rules_as_appendix_a_states_them():
     # scalars
     a, B = rule_eval(_lib.NODE_NORMAL_MEAN_VARIANCE, 0, [[2.0]], (m[:, :1], V[:, :1, :1]))
     assert np.allclose(B, V[:, :1, :1] + 2.0)
+    # the 8x8 instance
+    m8, V8, A8 = rng.standard_normal((n, 7)), spd(7), rng.standard_normal((5, 7))
+    a, B = rule_eval(_lib.NODE_MULTIPLY, 0, A8, (m8, V8))
+    assert np.allclose(a, m8 @ A8.T, rtol=1e-13) and np.allclose(B, A8 @ V8 @ A8.T, rtol=1e-12)
+    L8 = np.linalg.inv(V8)
+    a, B = rule_eval(_lib.NODE_MVNORMAL_MEAN_COV, 0, spd(7)[0] * 0 + np.eye(7), (np.einsum('nij,nj->ni', L8, m8), L8), in_form='wp', out_form='mv')
+    assert np.allclose(a, m8, rtol=1e-9) and np.allclose(B, V8 + np.eye(7), rtol=1e-9)
