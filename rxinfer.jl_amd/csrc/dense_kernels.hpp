@@ -2050,16 +2050,8 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
                     rec[tid] = xi[tid];
                     gyn = p.filt[(chain * p.T + (i + 1 < len ? t + 1 : t)) * C::REC + D + tid];
                 }
-#pragma unroll
-                for (int sl = 0; sl < NS; ++sl)
-                    if (sl < nsw) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) rec[C::HDR + ((w * NT + slot_tile(sl)) * 4 + r) * 64 + lane] = ct[sl][r];
-                    }
-#pragma unroll
-                for (int t2 = 0; t2 < NT; ++t2)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) rec[C::HDR + D * D + ((w * NT + t2) * 4 + r) * 64 + lane] = gp[t2][r];
+                // (the records of a frozen stretch carry their VECTORS only: C and G′ are the ones of record FZ_SLOT, and every reader — kd_backward_info,
+                //  kd_cross_from_records — goes there for them.  Writing the same 52 KB into every record was what a frozen step cost: 18 of its ≈ 20 µs)
                 {
                     double s0 = 0.0, s1 = 0.0, c0 = 0.0, c1 = 0.0;
                     const int k0 = grp * (D / 4);
@@ -2183,11 +2175,17 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
     const int ws = __builtin_amdgcn_readfirstlane(w);
     const int nsw = (NT % 2 == 0 && NT > 1 && ws >= NT / 2) ? NS - 1 : NS;
     auto slot_tile = [&](int sl) { const int t2 = ws + sl; return t2 >= NT ? t2 - NT : t2; };
+    // the record that carries the MATRICES of time index tt: its own, or — behind the point where the forward sweep found its matrices repeating
+    // (tfz, set below) — the one record of the segment that holds them (kd_forward_info's frozen loop writes vectors only)
+    long long tfz = te + 1;
+    auto mrec = [&](long long tt) { return p.filt + (chain * p.T + (tt > tfz ? tfz : tt)) * C::REC; };
     auto prefetch = [&](long long tt) {   // G_tt' and C_tt ξ_f(tt) of the NEXT step travel under the current one
-        const double* rec = p.filt + (chain * p.T + tt) * C::REC;
-        acc_load_full<NT>(gN, rec + C::HDR + D * D, w, lane);
-        if (tid < D) cxN = rec[2 * D + tid];
+        acc_load_full<NT>(gN, mrec(tt) + C::HDR + D * D, w, lane);
+        if (tid < D) cxN = p.filt[(chain * p.T + tt) * C::REC + 2 * D + tid];
     };
+    if constexpr (RXHIP_FWD_FROZEN && DenseLds<NT>::ALIAS) {
+        if (p.mseg == 0 && !p.step_model && len > 0) tfz = (long long)p.filt[(chain * p.T + (tb + 1)) * C::REC + C::HDR + (NT * 4) * 64];   // (kd_forward_info: FZ_SLOT)
+    }
     auto commit = [&]() {
         acc_store<NT>(gN, MG, LD, w, lane);
         if (tid < D) xf[tid] = cxN;
@@ -2211,19 +2209,15 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
     // |ΔV_ij| ≤ RXHIP_FZ_TOL · sqrt(V_ii V_jj): the new matrix from MV, the old one from the posterior array, where this very lane stored these entries
     // at the top of the step.  One failing entry in any wave and the sweep goes on in full steps.
     constexpr bool BFROZEN = RXHIP_FWD_FROZEN && DenseLds<NT>::ALIAS;
-    long long tfz = te + 1;
-    if constexpr (BFROZEN) {
-        if (p.mseg == 0 && !p.step_model && len > 0) tfz = (long long)p.filt[(chain * p.T + (tb + 1)) * C::REC + C::HDR + (NT * 4) * 64];   // (kd_forward_info: FZ_SLOT)
-    }
     double* bz = rowbuf + 4 * D;   // [2·w], [2·w + 1]: this wave's functionals of V_s
     double bzp1 = 0.0, bzp2 = 0.0;
     int bz_same = 0;
     bool bz_verify = false, bz_ok = false;   // (workgroup-uniform) this step ends with the entrywise comparison / it has passed
-    if (p.no_frozen) tfz = te + 1;
+    const long long tfz_b = p.no_frozen ? te + 1 : tfz;   // where THIS sweep may stop recomputing V_s (test hook: nowhere)
     for (long long t = te - 1; t >= tb; --t) {
         if constexpr (BFROZEN) {
-            if (bz_ok && t >= tfz && t > tb) {   // (workgroup-uniform) a frozen stretch: t … max(tfz, tb + 1)
-                const long long tstop = tfz > tb + 1 ? tfz : tb + 1;
+            if (bz_ok && t >= tfz_b && t > tb) {   // (workgroup-uniform) a frozen stretch: t … max(tfz, tb + 1)
+                const long long tstop = tfz_b > tb + 1 ? tfz_b : tb + 1;
                 // MV holds V_s (complete since the barrier that closed the last step), MG the G′ committed for step t, xf = C ξ_f(t)
                 acc_load<NT>(cc, MV, LD, w, lane);
                 if (pending) {
@@ -2257,8 +2251,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
                 // back to full steps at t = tstop − 1 (≥ tb): its G′ into MG (xf already holds C ξ_f of that step)
                 bz_same = 0;
                 bz_ok = bz_verify = false;
-                const double* recn = p.filt + (chain * p.T + t) * C::REC;
-                acc_load_full<NT>(gN, recn + C::HDR + D * D, w, lane);
+                acc_load_full<NT>(gN, mrec(t) + C::HDR + D * D, w, lane);
                 acc_store<NT>(gN, MG, LD, w, lane);
                 lds_barrier();
             }
@@ -2267,7 +2260,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
         // C_t (owned tiles): the accumulators of the second contraction; their L2 / HBM latency hides under the first one
         d4 vacc[NS];
         {
-            const double* rec = p.filt + (chain * p.T + t) * C::REC + C::HDR;
+            const double* rec = mrec(t) + C::HDR;
 #pragma unroll
             for (int sl = 0; sl < NS; ++sl) {
                 const double* src = rec + ((w * NT + slot_tile(sl)) * 4) * 64 + lane;
@@ -2329,7 +2322,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
                 }
             }
         if constexpr (BFROZEN) {
-            if (tfz <= te) {
+            if (t > tfz_b) {   // (a frozen stretch can only cover steps t − 1 ≥ tfz: below it the tests have nothing to decide)
                 double f1 = 0.0, f2 = 0.0;
 #pragma unroll
                 for (int sl = 0; sl < NS; ++sl)
@@ -2351,7 +2344,7 @@ __global__ void __launch_bounds__(64 * NT, 2) kd_backward_info(DenseParams p) { 
         commit();
         lds_barrier();
         if constexpr (BFROZEN) {
-            if (tfz <= te) {
+            if (t > tfz_b) {   // (a frozen stretch can only cover steps t − 1 ≥ tfz: below it the tests have nothing to decide)
                 double g1 = 0.0, g2 = 0.0;
 #pragma unroll
                 for (int q = 0; q < NT; ++q) {
@@ -2796,7 +2789,15 @@ __global__ void __launch_bounds__(64 * NT) kd_cross_from_records(DenseParams p, 
     const int tid = threadIdx.x, w = tid >> 6, lane = tid & 63, dout = p.d_out;
     const long long row = blockIdx.x, t = row / p.n_chains, chain = row - t * p.n_chains;
     Acc<NT> g;
-    acc_load_full<NT>(g, p.filt + (chain * p.T + t) * C::REC + C::HDR + D * D, w, lane);
+    long long tm = t;   // the record that carries G_t′: its own, or the one record of a frozen stretch that holds the matrices (kd_forward_info: FZ_SLOT)
+    if constexpr (RXHIP_FWD_FROZEN && DenseLds<NT>::ALIAS) {
+        if (p.mseg == 0 && !p.step_model) {
+            const long long tb = (t / p.L) * p.L;
+            const long long tfz = (long long)p.filt[(chain * p.T + (tb + 1)) * C::REC + C::HDR + (NT * 4) * 64];
+            if (t > tfz) tm = tfz;
+        }
+    }
+    acc_load_full<NT>(g, p.filt + (chain * p.T + tm) * C::REC + C::HDR + D * D, w, lane);
     acc_store<NT>(g, Gt, LD, w, lane);
     const double* vs = p.cov + ((t + 1) * p.n_chains + chain) * (size_t)dout * dout;
     for (int k = tid; k < D * D; k += 64 * NT) {

@@ -3623,6 +3623,7 @@ rxhip_status rxhip_get_node_marginals(rxhip_engine* e, int32_t node_type, double
             DenseParams cp{};
             const int nt = e->mseg ? e->m_nt : e->nt;
             cp.T = e->T; cp.n_chains = e->n_chains; cp.d = 16 * nt; cp.d_out = e->d; cp.filt = e->d_filt; cp.cov = e->d_cov;
+            cp.L = e->L > 0 ? e->L : 1; cp.S = e->S; cp.mseg = e->mseg ? 1 : 0; cp.step_model = e->d_step_model;   // (where a frozen stretch's matrices live: kd_forward_info FZ_SLOT)
             const dim3 gr((unsigned)((e->T - 1) * e->n_chains));
             dense_vt(nt)->cross_from_records(cp, gq.cross, gr, e->stream);
         } else {

@@ -8,12 +8,13 @@ import rxhip
 from rxhip import workloads
 import bench
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+SEG = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 mdl = workloads.c3_model()
 y = workloads.generate_batch(mdl, T, 1, seed0=6400)
 import time
 rxhip.lib().rxhip_device_count()
 t0 = time.perf_counter()
-with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=1, device=0) as eng:
+with rxhip.LGSSMEngine(mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"], T=T, n_chains=1, device=0, segments=SEG) as eng:
     eng.set_data(y)
     eng.run(1, True)
     print('create + set_data + first run ms', round((time.perf_counter() - t0) * 1e3, 1))
