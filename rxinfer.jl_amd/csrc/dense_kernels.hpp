@@ -136,6 +136,8 @@ struct DenseParams {
     long long oW_off;     // DenseCst::oW (km_filter_out reads the constant block through MsegParams)
     long long chain0;     // first workgroup chain of this launch: a grid dimension holds 65 535 blocks, larger batches are launched in slices
     int wave8;            // masked schedule, one segment per chain, d ≤ 8: the sweep inside one wavefront per chain (dense8_kernels.hpp)
+    int full_records;     // 1: the records of a frozen stretch carry their (repeated) matrices as well — the model pass of the model / data split, whose table
+                          // kernel (kd_split_tables) reads C_t and G_t′ of EVERY time index
     int no_frozen;        // test hook RXHIP_NO_FROZEN=1: kd_forward_info / kd_backward_info take every step in full (no FROZEN / BFROZEN stretches)
 };
 struct DenseModel {
@@ -2050,8 +2052,20 @@ __global__ void __launch_bounds__(64 * NT, RXHIP_FWD_WAVES) kd_forward_info(Dens
                     rec[tid] = xi[tid];
                     gyn = p.filt[(chain * p.T + (i + 1 < len ? t + 1 : t)) * C::REC + D + tid];
                 }
-                // (the records of a frozen stretch carry their VECTORS only: C and G′ are the ones of record FZ_SLOT, and every reader — kd_backward_info,
-                //  kd_cross_from_records — goes there for them.  Writing the same 52 KB into every record was what a frozen step cost: 18 of its ≈ 20 µs)
+                // (the records of a frozen stretch carry their VECTORS only: C and G′ are the ones of record FZ_SLOT, and every reader of a sweep's records —
+                //  kd_backward_info, kd_cross_from_records — goes there for them; p.full_records: a reader that indexes records by time alone follows)
+                if (p.full_records) {   // (workgroup-uniform)
+#pragma unroll
+                    for (int sl = 0; sl < NS; ++sl)
+                        if (sl < nsw) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) rec[C::HDR + ((w * NT + slot_tile(sl)) * 4 + r) * 64 + lane] = ct[sl][r];
+                        }
+#pragma unroll
+                    for (int t2 = 0; t2 < NT; ++t2)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) rec[C::HDR + D * D + ((w * NT + t2) * 4 + r) * 64 + lane] = gp[t2][r];
+                }
                 {
                     double s0 = 0.0, s1 = 0.0, c0 = 0.0, c1 = 0.0;
                     const int k0 = grp * (D / 4);

@@ -3205,6 +3205,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
                 if (!e->split_ready) {  // the model pass: the full kernels on ONE workgroup chain, their records -> tables
                     DenseParams mp = dp;
                     mp.vlast = e->d_vlast;
+                    mp.full_records = 1;   // kd_split_tables reads the matrices of every time index
                     DENSE_DISPATCH(e->nt, forward_info(mp, true, e->stream, 1));
                     DENSE_DISPATCH(e->nt, backward_info(mp, true, e->stream, 1));
                     hipLaunchKernelGGL(kd_split_tables, dim3((unsigned)e->T), dim3(256), 0, e->stream, sq);
