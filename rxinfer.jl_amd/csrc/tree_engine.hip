@@ -342,7 +342,7 @@ struct Compiler {
                 needed[m] = factor_uses_v2f(edges[e].f);
                 if (live.empty()) null_[m] = 1;
                 else if (live.size() == 1) { alias[m] = alias[live[0]] >= 0 ? alias[live[0]] : live[0]; form[m] = form[live[0]]; level[m] = level[live[0]]; }
-                else { form[m] = 1; int lv = 0; for (int x : live) lv = std::max(lv, level[x]); level[m] = lv + 1; }
+                else { form[m] = 1; int lv = 0; for (int x : live) lv = std::max(lv, level[x]); level[m] = lv + rounds((int)live.size()); }
             } else {        // factor -> variable
                 const Edge& ed = edges[m];
                 needed[m] = 1;
@@ -395,6 +395,32 @@ struct Compiler {
         const int c = (int)iface(f, 2), t = g->factor_type[f];
         if (P.vclass[c] == VC_PREC) r.w[W_PREC] = P.prec_off[c];
         else r.w[W_C0] = noise_block(c, d, t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION);
+    }
+
+    // A product or marginal over MANY inbound messages (a hub variable: the mean of 10^5 iid observations) as a tree of partial products, eight inputs
+    // per op, one level per round — O(n) work in O(log n) levels instead of one lane summing n messages.  Returns the reduced list and the level the
+    // final op may run at.
+    static constexpr int FAN_IN = 8;
+    static int rounds(int n) { int r = 1; while (n > FAN_IN) { n = (n + FAN_IN - 1) / FAN_IN; ++r; } return r; }   // ops in sequence for n inputs
+    std::vector<std::pair<int, int>> reduce_inputs(std::vector<std::pair<int, int>> ins, int d, int& lvl) {
+        while ((int)ins.size() > FAN_IN) {
+            std::vector<std::pair<int, int>> nxt;
+            for (size_t i = 0; i < ins.size(); i += FAN_IN) {
+                const size_t n = std::min<size_t>(FAN_IN, ins.size() - i);
+                if (n == 1) { nxt.push_back(ins[i]); continue; }
+                OpRec& r = emit(lvl, OP_PRODUCT, d);
+                r.w[W_OUT] = (int)P.msg_doubles;
+                P.msg_doubles += msz(d);
+                r.w[W_LIST] = (int)P.aux.size();
+                r.w[W_N] = (int)n;
+                for (size_t q = 0; q < n; ++q) { P.aux.push_back(ins[i + q].first); P.aux.push_back(ins[i + q].second); }
+                P.bytes_per_sweep += 8ll * msz(d) * (long long)(n + 1);
+                nxt.push_back({r.w[W_OUT], 1});
+            }
+            ins.swap(nxt);
+            ++lvl;
+        }
+        return ins;
     }
 
     void allocate() {
@@ -519,13 +545,16 @@ struct Compiler {
             const int d = P.dim[ed.v], lv = L0 + level[m];
             maxl = std::max(maxl, lv);
             if (m >= E) {   // product
-                OpRec& r = emit(lv, OP_PRODUCT, d);
+                std::vector<std::pair<int, int>> ins;
+                for (int dpm : deps[m])
+                    if (!null_[dpm]) ins.push_back({src_off(dpm), (int)form[dpm]});
+                int lvp = lv - rounds((int)ins.size()) + 1;   // a hub: partial products first; `lv` (analyse) is the level of the final op
+                ins = reduce_inputs(ins, d, lvp);
+                OpRec& r = emit(lvp, OP_PRODUCT, d);
                 r.w[W_OUT] = off[m];
                 r.w[W_LIST] = (int)P.aux.size();
-                int n = 0;
-                for (int dpm : deps[m])
-                    if (!null_[dpm]) { P.aux.push_back(src_off(dpm)); P.aux.push_back(form[dpm]); ++n; P.bytes_per_sweep += 8ll * msz(d); }
-                r.w[W_N] = n;
+                r.w[W_N] = (int)ins.size();
+                for (auto& in : ins) { P.aux.push_back(in.first); P.aux.push_back(in.second); P.bytes_per_sweep += 8ll * msz(d); }
                 P.bytes_per_sweep += 8ll * msz(d);
                 continue;
             }
@@ -583,20 +612,25 @@ struct Compiler {
         }
         // marginals: one level behind the last message
         const int LM = maxl + 1;
+        int lm_last = LM;
         for (int64_t v = 0; v < nv; ++v) {
             if (P.vclass[v] != VC_GAUSS) continue;
             const int d = P.dim[v];
-            OpRec& r = emit(LM, OP_MARGINAL, d);
+            std::vector<std::pair<int, int>> ins;
+            for (int e : var_edges[v])
+                if (!null_[e]) ins.push_back({src_off(e), (int)form[e]});
+            int lvm = LM;
+            ins = reduce_inputs(ins, d, lvm);
+            lm_last = std::max(lm_last, lvm);
+            OpRec& r = emit(lvm, OP_MARGINAL, d);
             r.w[W_OUT] = P.marg_off[v];
             r.w[W_LIST] = (int)P.aux.size();
-            int n = 0;
-            for (int e : var_edges[v])
-                if (!null_[e]) { P.aux.push_back(src_off(e)); P.aux.push_back(form[e]); ++n; P.bytes_per_sweep += 8ll * msz(d); }
-            r.w[W_N] = n;
+            r.w[W_N] = (int)ins.size();
+            for (auto& in : ins) { P.aux.push_back(in.first); P.aux.push_back(in.second); P.bytes_per_sweep += 8ll * msz(d); }
             P.bytes_per_sweep += 8ll * (msz(d) + 1);
         }
         // Bethe terms and residual moments
-        const int LF = LM + 1;
+        const int LF = lm_last + 1;
         std::vector<int> terms;
         std::vector<int> ent_coef(nv, 0);
         std::vector<std::vector<int>> prec_stats(nv);

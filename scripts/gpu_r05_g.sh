@@ -2,6 +2,6 @@
 set -u
 OUT=$PWD/gpurun_out/r05_g; mkdir -p "$OUT"
 F='RCCL\|HIP ver\|ROCm\|Hostname\|Librccl\|amdgpu.ids'
-timeout 600 python -m pytest tests/test_noise_vmp_gpu.py tests/test_rccl_gpu.py tests/test_graph_dumps.py tests/test_tree_engine_gpu.py -m gpu -q 2>&1 | grep -v "$F" | tail -5 | tee "$OUT/pytest.txt"
+timeout 600 python -m pytest tests/test_tree_engine_gpu.py -m gpu -q 2>&1 | grep -v "$F" | tail -5 | tee "$OUT/pytest.txt"
 
 

@@ -58,7 +58,8 @@ def eng_gauss(gb):
                                         (tg.two_branch_chain, dict(T=7, d=4, dy1=4, dy2=3)), (tg.two_branch_chain, dict(T=5, d=8, dy1=8, dy2=5)),
                                         (tg.two_branch_chain, dict(T=6, d=6, dy1=3, dy2=5)),
                                         (tg.branching_tree, dict(depth=3, fanout=2, d=1, seed=5)), (tg.branching_tree, dict(depth=2, fanout=3, d=2)),
-                                        (tg.scalar_tree, dict(n_leaves=6)), (tg.chain_with_prediction, dict(T=8, H=3))])
+                                        (tg.scalar_tree, dict(n_leaves=6)), (tg.chain_with_prediction, dict(T=8, H=3)),
+                                        (tg.star, dict(n_leaves=300, d=1)), (tg.star, dict(n_leaves=70, d=3)), (tg.branching_tree, dict(depth=1, fanout=20, d=1, seed=9))])
 def test_unsupported_shapes_against_the_oracle(builder, kw, mode, monkeypatch):
     gb, ys, _ = builder(**kw)
     R = 5

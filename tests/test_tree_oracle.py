@@ -24,7 +24,7 @@ def _check_bruteforce(gb, ys, seed=0, tol=1e-9):
 
 @pytest.mark.parametrize("builder,kw", [(tg.two_branch_chain, dict(T=6)), (tg.two_branch_chain, dict(T=5, d=2, dy1=2, dy2=2, precision_spelling=True)),
                                         (tg.branching_tree, dict(depth=2, fanout=2)), (tg.branching_tree, dict(depth=3, fanout=2, d=3, observe_leaves_only=True)),
-                                        (tg.scalar_tree, dict(n_leaves=4)), (tg.chain_with_prediction, dict(T=5, H=3))])
+                                        (tg.scalar_tree, dict(n_leaves=4)), (tg.chain_with_prediction, dict(T=5, H=3)), (tg.star, dict(n_leaves=40, d=2))])
 def test_marginals_and_free_energy_equal_the_joint_gaussian(builder, kw):
     gb, ys, _ = builder(**kw)
     res, nle = _check_bruteforce(gb, ys)

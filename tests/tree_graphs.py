@@ -106,6 +106,26 @@ def scalar_tree(n_leaves=5, seed=2):
     return gb, ys, dict(m=[m], leaf=leaves)
 
 
+def star(n_leaves=300, d=1, seed=6):
+    """a hub: m ~ N(m0, V0); y_i ~ N(B_i m, Q_i), i = 1 … n — the mean of n observations with constant noise (a variable of degree n + 1: its marginal
+    and every product toward a neighbour are TREES of partial products in the executor)"""
+    rng = np.random.default_rng(seed)
+    gb = GraphBuilder()
+    m = gb.randomvar(d)
+    gb.mvnormal_mean_cov(m, gb.constvar(rng.standard_normal(d)), gb.constvar(_spd(rng, d, 5.0)))
+    ys = []
+    for i in range(n_leaves):
+        if i % 3 == 0:   # a leaf through a map: the hub's message toward `*` is a product of all the others
+            b = gb.randomvar(d)
+            gb.multiply(b, gb.constvar(np.eye(d) + 0.1 * rng.standard_normal((d, d))), m)
+        else:
+            b = m
+        y = gb.datavar(d)
+        gb.mvnormal_mean_cov(y, b, gb.constvar(_spd(rng, d, 1.0 + (i % 5))))
+        ys.append(y)
+    return gb, ys, dict(m=[m])
+
+
 def chain_with_prediction(T, H, d=2, dy=2, seed=3):
     """a chain whose last H observation variables are RANDOM (no data): their marginals are the predictions"""
     rng = np.random.default_rng(seed)
