@@ -19,7 +19,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/c3" -o c3 -- pytho
 C3="python $ROOT/scripts/prof_driver.py --config c3 --steps 3 --warmup 1"
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES --output-format csv -d "$OUT/c3pmc_a" -o a -- $C3 > /dev/null 2> "$OUT/c3pmc_a.err"
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_INSTS_SALU SQ_WAVES --output-format csv -d "$OUT/c3pmc_c" -o c -- $C3 > /dev/null 2> "$OUT/c3pmc_c.err"
-TREE="python $ROOT/scripts/prof_tree.py 256 4096 5"
+TREE="python $ROOT/scripts/prof_tree.py 128 65536 3"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/tree" -o tree -- $TREE > "$OUT/driver_tree.txt" 2> "$OUT/tree.err"
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/tree_fetch" -o fetch -- $TREE > /dev/null 2> "$OUT/tree_fetch.err"
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/tree_write" -o write -- $TREE > /dev/null 2> "$OUT/tree_write.err"
@@ -62,7 +62,7 @@ json.dump(m, open(os.path.join(out, "mfma_insts.json"), "w"), indent=1)
 # the node-array executor: HBM bytes per launch of its kernels
 tk = ("k_tree_levels", "k_tree_ops")
 tf, tw = avg("FETCH_SIZE", "tree_fetch", tk), avg("WRITE_SIZE", "tree_write", tk)
-tt = {"source": f"profiles/{tag}/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scripts/prof_tree.py 256 4096: the bench's node_array workload; per launch, sweep phase + free-energy phase averaged as rocprofv3 names them)",
+tt = {"source": f"profiles/{tag}/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scripts/prof_tree.py 128 65536: the bench's node_array workload; per launch, sweep phase + free-energy phase averaged as rocprofv3 names them)",
       "correction": "as traffic.json (the executor's loads are 8 B/lane unit-stride: the x2 of the guide applies to 16 B/lane streams; both figures given)",
       "tree_kernels_sha256": sha("tree_kernels.hpp")}
 for k in tk:
