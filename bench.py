@@ -429,6 +429,17 @@ def extra_node_array(device, parity=True):
                 "roofline": {"bound": "hbm", "achieved": info["bytes_per_sweep"] * R / (dev * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                              "frac": info["bytes_per_sweep"] * R / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
                              "bytes": "8·(d + d(d+1)/2) per message read or written by a rule, product or marginal of the schedule (rxhip_tree_info.bytes_per_sweep) × replicas"}}
+        if name == "two_branch":   # HBM bytes of the two kernel instances by the PMC counters (profiles/tree_traffic.json, guarded by the hash of tree_kernels.hpp)
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "tree_traffic.json")))
+                with open(os.path.join(ROOT, "rxinfer.jl_amd", "csrc", "tree_kernels.hpp"), "rb") as f:
+                    fresh = tj.get("tree_kernels_sha256") == hashlib.sha256(f.read()).hexdigest()
+                if fresh and tj.get("algorithmic_bytes_per_sweep") == info["bytes_per_sweep"] * R:
+                    line["roofline"]["traffic"] = sum(k["hbm_bytes_per_launch_x2"] for n, k in tj["kernels"].items() if "k_tree_walk" in n)
+                    line["roofline"]["traffic_note"] = "FETCH_SIZE x2 + WRITE_SIZE of both phases per sweep (profiles/tree_traffic.json); x1: " + \
+                        f"{sum(k['hbm_bytes_per_launch_x1'] for n, k in tj['kernels'].items() if 'k_tree_walk' in n):.4g} bytes"
+            except (OSError, ValueError, KeyError):
+                pass
         if parity and name == "two_branch":
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
             import tree_oracle

@@ -60,7 +60,7 @@ m = {"source": f"profiles/{tag}/ (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 …, sc
      "dense_kernels_sha256": sha("dense_kernels.hpp")}
 json.dump(m, open(os.path.join(out, "mfma_insts.json"), "w"), indent=1)
 # the node-array executor: HBM bytes per launch of its kernels
-tk = ("k_tree_levels", "k_tree_ops")
+tk = ("k_tree_walk<4, 0>", "k_tree_walk<4, 1>", "k_tree_levels", "k_tree_ops")
 tf, tw = avg("FETCH_SIZE", "tree_fetch", tk), avg("WRITE_SIZE", "tree_write", tk)
 tt = {"source": f"profiles/{tag}/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scripts/prof_tree.py 128 65536: the bench's node_array workload; per launch, sweep phase + free-energy phase averaged as rocprofv3 names them)",
       "correction": "as traffic.json (the executor's loads are 8 B/lane unit-stride: the x2 of the guide applies to 16 B/lane streams; both figures given)",
