@@ -383,9 +383,11 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  *     typeof(*) with a constant matrix;  typeof(+) (random + random, random + data / constant);
  *     Wishart / GammaShapeRate / GammaShapeScale priors with constant parameters
  * whose Gaussian variables form a forest (no cycles; precision variables may touch any number of nodes — the mean-field factorisation cuts those
- * loops), every dimension ≤ 8 (registers hold the 4×4 instance; the 8×8 one spills: it exists so that such graphs run at all).  The host compiles the graph into ops sorted by dependency level (csrc/tree_engine.hip); one kernel
- * (csrc/tree_kernels.hpp) evaluates (op, replica) items: a launch per level over all nodes of the level, or — deep, narrow graphs — the whole
- * schedule in one launch with workgroup-resident levels.  Data variables, derived clamped values (`a + b` of two data variables), unobserved
+ * loops), every dimension ≤ 64.  The host compiles the graph into ops sorted by dependency level (csrc/tree_engine.hip); one kernel evaluates
+ * (op, replica) items: a launch per level over all nodes of the level, or — deep, narrow graphs — the whole schedule in one launch with workgroup-
+ * resident levels, or — large batches — a lane per replica over the whole schedule.  Dimensions ≤ 8: a LANE per item, matrices in registers
+ * (csrc/tree_kernels.hpp; the 4×4 instance fits, the 8×8 one spills).  Dimensions 9 … 64: a WAVEFRONT per item, matrices staged in LDS
+ * (csrc/tree_wave_kernels.hpp; same op tables and storage; a launch per level, or a wavefront per replica over the whole schedule).  Data variables, derived clamped values (`a + b` of two data variables), unobserved
  * leaves (predictions) are part of the family; `missing` inside the data is not (the chain engines have it).
  * rxhip_create falls through to this executor for every graph the pattern matcher rejects; rxhip_tree_create asks for it directly (the tests
  * compare it with the specialised engines on the graphs both can run).
@@ -396,8 +398,8 @@ typedef struct {
     int64_t n_ops, n_levels, n_messages;  /* ops of one iteration, dependency levels, stored messages */
     int64_t doubles_per_replica;          /* device state per replica */
     int64_t bytes_per_sweep;              /* algorithmic traffic of one iteration per replica: 8·(d + d(d+1)/2) per message a rule reads or writes */
-    int32_t dmax;                         /* kernel instance: 1, 2 or 4 */
-    int32_t mode;                         /* 0: one launch per level; 1: one launch per iteration, workgroup-resident levels; 2: a lane per replica walks the schedule */
+    int32_t dmax;                         /* kernel instance: 1, 2, 4 or 8 (registers); above 8 the graph's largest dimension (LDS-staged kernels) */
+    int32_t mode;                         /* 0: one launch per level; 1: one launch per iteration, workgroup-resident levels (dmax ≤ 8); 2: a lane (dmax ≤ 8) or a wavefront per replica walks the schedule */
     int32_t replicas_per_workgroup;       /* mode 1 */
     int32_t n_precision_vars;
     double last_iteration_ms;             /* device time of the last rxhip_run ÷ its iterations (HIP events around the launches) */

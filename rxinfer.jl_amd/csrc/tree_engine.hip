@@ -25,6 +25,7 @@
 
 #include "launch_tables.hpp"   // hook_env
 #include "tree_kernels.hpp"
+#include "tree_wave_kernels.hpp"
 
 namespace rxhip {
 namespace tree {
@@ -254,8 +255,9 @@ struct Compiler {
                 dmx = std::max(dmx, P.dim[a]);
             }
         }
-        if (dmx > 8) fail(RXHIP_ERR_UNSUPPORTED, "the node-array executor runs dimensions <= 8 (this graph: %d)", dmx);
-        P.dmax = dmx <= 1 ? 1 : dmx <= 2 ? 2 : dmx <= 4 ? 4 : 8;
+        if (dmx > wave::DMAX_WAVE) fail(RXHIP_ERR_UNSUPPORTED, "the node-array executor runs dimensions <= %d (this graph: %d)", wave::DMAX_WAVE, dmx);
+        // <= 8: the register instances (lane per op and replica); above: the graph's own maximum, staged in LDS by a wavefront per op and replica
+        P.dmax = dmx <= 1 ? 1 : dmx <= 2 ? 2 : dmx <= 4 ? 4 : dmx <= 8 ? 8 : dmx;
     }
 
     void build_edges() {
@@ -856,6 +858,30 @@ void launch_phase(const Engine* e, const TreeParams& p, int l0, int l1) {
         }
     }
 }
+// dimensions above 8 (tree_wave_kernels.hpp): a wavefront per (op, replica) and level, or — mode 2 — a wavefront per replica over the whole range
+template <int PHASE>
+void launch_wave_phase(const Engine* e, const TreeParams& p, int l0, int l1) {
+    if (l1 <= l0) return;
+    const int dmax = e->prog.dmax;
+    const size_t lds = wave::lds_bytes(dmax);
+    if (e->mode == 2) {
+        const unsigned blocks = (unsigned)std::min<long long>(e->R, 1 << 20);
+        hipLaunchKernelGGL((wave::k_wave_walk<PHASE>), dim3(blocks), dim3(64), lds, e->stream, p, e->prog.lvl_ptr[l0], e->prog.lvl_ptr[l1], dmax);
+        return;
+    }
+    for (int l = l0; l < l1; ++l) {
+        const int o0 = e->prog.lvl_ptr[l], o1 = e->prog.lvl_ptr[l + 1];
+        if (o1 == o0) continue;
+        const unsigned blocks = (unsigned)std::min<long long>((long long)(o1 - o0) * e->R, 1 << 20);
+        hipLaunchKernelGGL((wave::k_wave_ops<PHASE>), dim3(blocks), dim3(64), lds, e->stream, p, o0, o1, dmax);
+    }
+}
+rxhip_status wave_attributes(int dmax, std::string& err) {   // dynamic LDS above the default 64 KB limit (per device: the attribute lives with the loaded code object)
+    const int bytes = (int)wave::lds_bytes(dmax);
+    for (const void* f : {(const void*)wave::k_wave_ops<0>, (const void*)wave::k_wave_ops<1>, (const void*)wave::k_wave_walk<0>, (const void*)wave::k_wave_walk<1>})
+        TCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(bytes, 64 * 1024)));
+    return RXHIP_OK;
+}
 template <int N>
 void launch_levels(const Engine* e, const TreeParams& p, int l0, int l1) {   // the sweep, then the second phase
     const int lf = e->prog.fe_level;
@@ -863,6 +889,12 @@ void launch_levels(const Engine* e, const TreeParams& p, int l0, int l1) {   // 
     launch_phase<N, 1>(e, p, std::max(l0, lf), l1);
 }
 void launch(const Engine* e, const TreeParams& p, int l0, int l1) {
+    if (e->prog.dmax > 8) {
+        const int lf = e->prog.fe_level;
+        launch_wave_phase<0>(e, p, l0, std::min(l1, lf));
+        launch_wave_phase<1>(e, p, std::max(l0, lf), l1);
+        return;
+    }
     switch (e->prog.dmax) {
     case 1: launch_levels<1>(e, p, l0, l1); break;
     case 2: launch_levels<2>(e, p, l0, l1); break;
@@ -902,7 +934,13 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     e->mode = (P.n_levels > 24 && (e->R >= 512 || avg_width * (double)e->R < 16384.0)) ? 1 : 0;
     // large batches: a lane per replica walks the whole schedule (no barriers; 64 replicas per wavefront, from one wavefront per SIMD on)
     if (e->R >= 65536) e->mode = 2;
+    if (P.dmax > 8) {
+        // wavefront per item: a launch per level while a level has enough items to occupy the device, else one wavefront per replica walks the schedule
+        // (a chain is three levels per step: hundreds of launches of a handful of wavefronts cost more than the walk)
+        e->mode = (avg_width * (double)e->R >= 256.0 && e->R < 4096) ? 0 : 2;
+    }
     if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = std::max(0, std::min(2, std::atoi(m)));
+    if (P.dmax > 8 && e->mode == 1) e->mode = 2;   // (no workgroup-resident schedule for the LDS-staged kernels)
     {
         long long rb = (e->R / 1024) / 16 * 16;
         e->rb = (int)std::min<long long>(64, std::max<long long>(16, rb));
@@ -914,6 +952,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
         e->own_stream = true;
     }
     rxhip_status st;
+    if (P.dmax > 8 && (st = wave_attributes(P.dmax, err))) return cleanup(st);
     if ((st = upload(&e->d_ops, P.ops, err)) || (st = upload(&e->d_aux, P.aux, err)) || (st = upload(&e->d_lvl, P.lvl_ptr, err)) || (st = upload(&e->d_cpool, P.cpool, err)) ||
         (st = upload(&e->d_prec_init, P.prec_init, err)) || (st = zalloc(&e->d_msg, P.msg_doubles * e->RS, err)) || (st = zalloc(&e->d_marg, P.marg_doubles * e->RS, err)) ||
         (st = zalloc(&e->d_val, P.val_doubles * e->RS, err)) || (st = zalloc(&e->d_prec, P.prec_doubles * e->RS, err)) || (st = zalloc(&e->d_term, P.term_slots * e->RS, err)) ||
@@ -1134,7 +1173,7 @@ rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
     const bool noise = t == RXHIP_NODE_MVNORMAL_MEAN_COV || t == RXHIP_NODE_NORMAL_MEAN_VARIANCE || t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION;
     if (!noise && t != RXHIP_NODE_MULTIPLY && t != RXHIP_NODE_ADD) { err = "rule_eval: node type without a device rule"; return RXHIP_ERR_UNSUPPORTED; }
     const int dout = c->d_out, din = t == RXHIP_NODE_MULTIPLY ? c->d_in : c->d_out;
-    if (dout < 1 || din < 1 || dout > 8 || din > 8) { err = "rule_eval: dimensions 1..8"; return RXHIP_ERR_UNSUPPORTED; }
+    if (dout < 1 || din < 1 || dout > wave::DMAX_WAVE || din > wave::DMAX_WAVE) { err = "rule_eval: dimensions 1..64"; return RXHIP_ERR_UNSUPPORTED; }
     if ((noise && (c->iface < 0 || c->iface > 1)) || (t == RXHIP_NODE_MULTIPLY && c->iface != 0 && c->iface != 2) || (t == RXHIP_NODE_ADD && (c->iface < 0 || c->iface > 2))) {
         err = "rule_eval: no message leaves through that interface"; return RXHIP_ERR_BADARG;
     }
@@ -1210,8 +1249,10 @@ rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
     TreeParams p{};
     p.ops = d_ops; p.aux = d_aux; p.cpool = d_cp; p.msg = d_msg; p.marg = d_marg; p.R = R; p.RS = RS; p.status = d_status;
     const unsigned blocks = (unsigned)std::min<long long>((R + 255) / 256, 1 << 20);
+    if (dmax > 8 && (st = wave_attributes(dmax, err))) { freeall(); return st; }
     for (int o = 0; o < 2; ++o) {
-        if (N == 1) hipLaunchKernelGGL((k_tree_ops<1, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
+        if (dmax > 8) hipLaunchKernelGGL((wave::k_wave_ops<0>), dim3((unsigned)std::min<long long>(R, 1 << 20)), dim3(64), wave::lds_bytes(dmax), 0, p, o, o + 1, dmax);
+        else if (N == 1) hipLaunchKernelGGL((k_tree_ops<1, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
         else if (N == 2) hipLaunchKernelGGL((k_tree_ops<2, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
         else if (N == 4) hipLaunchKernelGGL((k_tree_ops<4, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
         else hipLaunchKernelGGL((k_tree_ops<8, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);

@@ -1,0 +1,574 @@
+// tree_wave_kernels.hpp — the node-array executor for dimensions above 8: a WAVEFRONT per (op, replica), matrices staged in LDS.
+//
+// The lane-per-(op, replica) kernels of tree_kernels.hpp keep a rule's matrices in registers, which ends at 8×8 (and spills from 5×5 on).  Here the same op
+// tables (same opcodes, same word layout, same replica-fastest storage: the host side does not know which kernel runs them) are evaluated by one wavefront
+// per work item: a rule's operands are loaded into four d×d LDS tiles (leading dimension dmax + 1: odd, so that a column walk meets 32 different banks) and
+// eight d-vectors, every primitive is a loop of the 64 lanes over the elements of its result, and a wavefront-scope fence orders a primitive's LDS writes
+// before the next one's reads (one wavefront executes its LDS instructions in order; no s_barrier, so that workgroups of several wavefronts would be legal).
+// The inverse is an in-place Gauss–Jordan sweep without pivoting (for a symmetric positive definite matrix the pivots are the Cholesky pivots squared:
+// positive, and their logs sum to the log-determinant); products are 4×4 (2×2 for small results) register tiles per lane with the k loop over LDS rows.
+// LDS per wavefront: (4·dmax·(dmax + 1) + 8·dmax)·8 bytes — 9.7 KB at d = 16, 35 KB at 32, 137 KB at 64 (one wavefront per CU: it runs, it is not fast).
+//
+// RXHIP_HOST_EMUL (tests/ only): the same rule bodies compiled for the host with a "wavefront" of one lane, so that every op can be checked against the
+// register implementation of tree_kernels.hpp without a GPU (tests/test_tree_wave_host.py).  The product never defines it.
+#pragma once
+#include "tree_kernels.hpp"
+
+namespace rxhip {
+namespace tree {
+namespace wave {
+
+constexpr int NBUF = 4, NVEC = 8;
+constexpr int DMAX_WAVE = 64;
+
+#ifdef RXHIP_HOST_EMUL
+constexpr int WL = 1;
+static double wlds[NBUF * DMAX_WAVE * (DMAX_WAVE + 1) + NVEC * DMAX_WAVE];
+__device__ __forceinline__ int w_lane() { return 0; }
+__device__ __forceinline__ void w_sync() {}
+__device__ __forceinline__ double w_sum(double x) { return x; }
+#else
+constexpr int WL = 64;
+extern __shared__ double wlds[];
+__device__ __forceinline__ int w_lane() { return (int)(threadIdx.x & 63); }
+// orders the wavefront's earlier LDS / global accesses before its later ones as seen by its own lanes
+__device__ __forceinline__ void w_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+__device__ __forceinline__ double w_sum(double x) {   // the same value in every lane, summed in a fixed order (butterfly)
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) x += __shfl_xor(x, m, 64);
+    return x;
+}
+#endif
+
+inline size_t lds_bytes(int dmax) { return sizeof(double) * ((size_t)NBUF * dmax * (dmax | 1) + (size_t)NVEC * dmax); }
+
+// the wavefront's workspace: offsets (in doubles) into wlds
+struct Ctx {
+    int lane, LD, dmax, V;
+    __device__ __forceinline__ int M(int k) const { return k * dmax * LD; }
+    __device__ __forceinline__ int v(int k) const { return V + k * dmax; }
+};
+__device__ __forceinline__ Ctx make_ctx(int dmax) {
+    Ctx c;
+    c.lane = w_lane();
+    c.dmax = dmax;
+    c.LD = dmax | 1;
+    c.V = NBUF * dmax * c.LD;
+    return c;
+}
+
+template <class F>
+__device__ __forceinline__ void each(const Ctx& c, int rows, int cols, F f) {
+    for (int e = c.lane; e < rows * cols; e += WL) {
+        const int i = e / cols;
+        f(i, e - i * cols);
+    }
+}
+// (i, j), j <= i, of the e-th element of a packed lower triangle
+__device__ __forceinline__ void tri_index(int e, int& i, int& j) {
+    int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    while ((r + 1) * (r + 2) / 2 <= e) ++r;
+    while (r * (r + 1) / 2 > e) --r;
+    i = r;
+    j = e - r * (r + 1) / 2;
+}
+
+__device__ __forceinline__ void l_vec(const Ctx& c, int v, const double* b, long long off, int d, long long RS, long long r) {
+    for (int i = c.lane; i < d; i += WL) wlds[v + i] = b[(off + i) * RS + r];
+}
+__device__ __forceinline__ void l_cvec(const Ctx& c, int v, const double* cp, int d) {
+    for (int i = c.lane; i < d; i += WL) wlds[v + i] = cp[i];
+}
+__device__ __forceinline__ void s_vec(const Ctx& c, double* b, long long off, int d, long long RS, long long r, int v) {
+    for (int i = c.lane; i < d; i += WL) b[(off + i) * RS + r] = wlds[v + i];
+}
+__device__ __forceinline__ void l_sym(const Ctx& c, int M, const double* b, long long off, int d, long long RS, long long r) {
+    const int LD = c.LD;
+    for (int e = c.lane; e < d * (d + 1) / 2; e += WL) {
+        int i, j;
+        tri_index(e, i, j);
+        const double x = b[(off + e) * RS + r];
+        wlds[M + i * LD + j] = x;
+        wlds[M + j * LD + i] = x;
+    }
+}
+__device__ __forceinline__ void s_sym(const Ctx& c, double* b, long long off, int d, long long RS, long long r, int M) {
+    const int LD = c.LD;
+    for (int e = c.lane; e < d * (d + 1) / 2; e += WL) {
+        int i, j;
+        tri_index(e, i, j);
+        b[(off + e) * RS + r] = 0.5 * (wlds[M + i * LD + j] + wlds[M + j * LD + i]);
+    }
+}
+__device__ __forceinline__ void l_full(const Ctx& c, int M, const double* b, long long off, int d, long long RS, long long r) {
+    const int LD = c.LD;
+    each(c, d, d, [&](int i, int j) { wlds[M + i * LD + j] = b[(off + i * d + j) * RS + r]; });
+}
+__device__ __forceinline__ void s_full(const Ctx& c, double* b, long long off, int d, long long RS, long long r, int M, double scale) {
+    const int LD = c.LD;
+    each(c, d, d, [&](int i, int j) { b[(off + i * d + j) * RS + r] = scale * wlds[M + i * LD + j]; });
+}
+__device__ __forceinline__ void l_cmat(const Ctx& c, int M, const double* cp, int rows, int cols) {
+    const int LD = c.LD;
+    each(c, rows, cols, [&](int i, int j) { wlds[M + i * LD + j] = cp[i * cols + j]; });
+}
+__device__ __forceinline__ void zero_mat(const Ctx& c, int M, int d) {
+    const int LD = c.LD;
+    each(c, d, d, [&](int i, int j) { wlds[M + i * LD + j] = 0.0; });
+}
+// dst += sign · src
+__device__ __forceinline__ void add_mat(const Ctx& c, int dst, int src, int d, double sign) {
+    const int LD = c.LD;
+    each(c, d, d, [&](int i, int j) { wlds[dst + i * LD + j] += sign * wlds[src + i * LD + j]; });
+}
+__device__ __forceinline__ void add_vec(const Ctx& c, int dst, int src, int d, double sign) {
+    for (int i = c.lane; i < d; i += WL) wlds[dst + i] += sign * wlds[src + i];
+}
+
+// in place: A ← A⁻¹ of a symmetric positive definite d×d tile; log|A|; false: a pivot ≤ 0 or not finite.  Scratch: vectors 6 and 7
+__device__ __forceinline__ bool spd_inv(const Ctx& c, int A, int d, double& logdet) {
+    const int LD = c.LD, rk = c.v(6), ck = c.v(7);
+    bool ok = true;
+    double ld = 0.0;
+    for (int k = 0; k < d; ++k) {
+        for (int i = c.lane; i < d; i += WL) {
+            wlds[rk + i] = wlds[A + k * LD + i];
+            wlds[ck + i] = wlds[A + i * LD + k];
+        }
+        w_sync();
+        const double pv = wlds[rk + k];
+        ok = ok && (pv > 0.0) && (pv < 1.0e300);
+        ld += log(pv);
+        const double ip = 1.0 / pv;
+        each(c, d, d, [&](int i, int j) {
+            double x;
+            if (i == k) x = (j == k) ? ip : wlds[rk + j] * ip;
+            else if (j == k) x = -wlds[ck + i] * ip;
+            else x = wlds[A + i * LD + j] - wlds[ck + i] * wlds[rk + j] * ip;
+            wlds[A + i * LD + j] = x;
+        });
+        w_sync();
+    }
+    logdet = ld;
+    return ok;
+}
+// y = op(M) x: element (i, k) of op(M) at M + i·si + k·sk; y must not be x
+__device__ __forceinline__ void matvec(const Ctx& c, int y, int M, int si, int sk, int x, int rows, int cols) {
+    for (int i = c.lane; i < rows; i += WL) {
+        double s = 0.0;
+        for (int k = 0; k < cols; ++k) s += wlds[M + i * si + k * sk] * wlds[x + k];
+        wlds[y + i] = s;
+    }
+    w_sync();
+}
+// C (m×n) = alpha·C + op(A) (m×kk) op(B) (kk×n), alpha ∈ {0, 1} and sign ∈ {+1, −1} on the product; C is neither A nor B
+template <int TM, int TN>
+__device__ __forceinline__ void mm_tiles(const Ctx& c, int C, int A, int sai, int sak, int B, int sbk, int sbj, int m, int kk, int n, bool acc_in, double sign) {
+    const int LD = c.LD, tm = (m + TM - 1) / TM, tn = (n + TN - 1) / TN;
+    for (int t = c.lane; t < tm * tn; t += WL) {
+        const int ti = t / tn, i0 = ti * TM, j0 = (t - ti * tn) * TN;
+        double acc[TM][TN];
+        int ia[TM], jb[TN];
+#pragma unroll
+        for (int a = 0; a < TM; ++a) {
+            ia[a] = A + (i0 + a < m ? i0 + a : m - 1) * sai;
+#pragma unroll
+            for (int b = 0; b < TN; ++b) acc[a][b] = 0.0;
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) jb[b] = B + (j0 + b < n ? j0 + b : n - 1) * sbj;
+        for (int k = 0; k < kk; ++k) {
+            double av[TM], bv[TN];
+#pragma unroll
+            for (int a = 0; a < TM; ++a) av[a] = wlds[ia[a] + k * sak];
+#pragma unroll
+            for (int b = 0; b < TN; ++b) bv[b] = wlds[jb[b] + k * sbk];
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+#pragma unroll
+                for (int b = 0; b < TN; ++b) acc[a][b] = fma(av[a], bv[b], acc[a][b]);
+        }
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+#pragma unroll
+            for (int b = 0; b < TN; ++b)
+                if (i0 + a < m && j0 + b < n) {
+                    const int ix = C + (i0 + a) * LD + j0 + b;
+                    wlds[ix] = acc_in ? wlds[ix] + sign * acc[a][b] : sign * acc[a][b];
+                }
+    }
+    w_sync();
+}
+__device__ __forceinline__ void matmul(const Ctx& c, int C, int A, bool ta, int B, bool tb, int m, int kk, int n, bool acc_in = false, double sign = 1.0) {
+    const int LD = c.LD;
+    const int sai = ta ? 1 : LD, sak = ta ? LD : 1, sbk = tb ? 1 : LD, sbj = tb ? LD : 1;
+    if (m * n > 16 * WL) mm_tiles<4, 4>(c, C, A, sai, sak, B, sbk, sbj, m, kk, n, acc_in, sign);
+    else mm_tiles<2, 2>(c, C, A, sai, sak, B, sbk, sbj, m, kk, n, acc_in, sign);
+}
+// tr(A B) of two d×d tiles
+__device__ __forceinline__ double trace_prod(const Ctx& c, int A, int B, int d) {
+    const int LD = c.LD;
+    double s = 0.0;
+    for (int e = c.lane; e < d * d; e += WL) {
+        const int i = e / d, k = e - i * d;
+        s += wlds[A + i * LD + k] * wlds[B + k * LD + i];
+    }
+    return w_sum(s);
+}
+
+// a message in the form a rule wants, vector → v, matrix → M; a conversion is one inverse (in place) and one product (through vector 5)
+__device__ __forceinline__ bool load_msg(const Ctx& c, const TreeParams& p, int off, bool stored_wp, bool want_wp, int d, long long r, int v, int M) {
+    l_vec(c, v, p.msg, off, d, p.RS, r);
+    l_sym(c, M, p.msg, off + d, d, p.RS, r);
+    w_sync();
+    if (stored_wp == want_wp) return true;
+    double ld;
+    const bool ok = spd_inv(c, M, d, ld);
+    const int t = c.v(5);
+    matvec(c, t, M, c.LD, 1, v, d, d);
+    for (int i = c.lane; i < d; i += WL) wlds[v + i] = wlds[t + i];
+    w_sync();
+    return ok;
+}
+__device__ __forceinline__ void store_msg(const Ctx& c, const TreeParams& p, int off, int d, long long r, int v, int M) {
+    s_vec(c, p.msg, off, d, p.RS, r, v);
+    s_sym(c, p.msg, off + d, d, p.RS, r, M);
+}
+// Σ (want_sigma) or W = Σ⁻¹ of a Gaussian node into M; (E) log|W|
+__device__ __forceinline__ double load_noise(const Ctx& c, const TreeParams& p, const int* w, int d, long long r, bool want_sigma, int M) {
+    const int ps = w[W_PREC];
+    double el;
+    if (ps >= 0) {
+        const int tri = d * (d + 1) / 2;
+        l_full(c, M, p.prec, ps + 1 + tri + (want_sigma ? d * d : 0), d, p.RS, r);
+        el = p.prec[(ps + 1 + tri + 2 * d * d) * p.RS + r];
+    } else {
+        const double* cp = p.cpool + w[W_C0];
+        l_cmat(c, M, cp + (want_sigma ? 0 : d * d), d, d);
+        el = cp[2 * d * d];
+    }
+    w_sync();
+    return el;
+}
+__device__ __forceinline__ void load_value(const Ctx& c, const TreeParams& p, int off, bool slot, int d, long long r, int v) {
+    if (slot) l_vec(c, v, p.val, off, d, p.RS, r);
+    else l_cvec(c, v, p.cpool + off, d);
+    w_sync();
+}
+
+// the sweep (ops up to OP_MARGINAL): the rules of tree_kernels.hpp's eval_bp, op for op
+__device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const int* __restrict__ w, long long r) {
+    const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS], LD = c.LD;
+    const int M0 = c.M(0), M1 = c.M(1), M2 = c.M(2), M3 = c.M(3);
+    const int v0 = c.v(0), v1 = c.v(1), v2 = c.v(2);
+    bool ok = true;
+    switch (op) {
+    case OP_DERIVE_MUL: {
+        const int d1 = w[W_D1];
+        l_cmat(c, M0, p.cpool + w[W_C0], d, d1);
+        load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d1, r, v0);
+        matvec(c, v1, M0, LD, 1, v0, d, d1);
+        s_vec(c, p.val, w[W_OUT], d, p.RS, r, v1);
+    } break;
+    case OP_DERIVE_ADD: {
+        load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v0);
+        load_value(c, p, w[W_VAL2], fl & F_VAL2_SLOT, d, r, v1);
+        add_vec(c, v0, v1, d, 1.0);
+        w_sync();
+        s_vec(c, p.val, w[W_OUT], d, p.RS, r, v0);
+    } break;
+    case OP_LEAF: {
+        load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v0);
+        const bool wp = fl & F_OUT_WP;
+        load_noise(c, p, w, d, r, !wp, M0);
+        if (wp) {
+            matvec(c, v1, M0, LD, 1, v0, d, d);
+            store_msg(c, p, w[W_OUT], d, r, v1, M0);
+        } else
+            store_msg(c, p, w[W_OUT], d, r, v0, M0);
+    } break;
+    case OP_NOISE: {
+        const bool wp = fl & F_IN0_WP;
+        ok = load_msg(c, p, w[W_IN0], wp, wp, d, r, v0, M0);
+        load_noise(c, p, w, d, r, !wp, M1);
+        if (!wp) {
+            add_mat(c, M0, M1, d, 1.0);
+            w_sync();
+            store_msg(c, p, w[W_OUT], d, r, v0, M0);
+        } else {   // Λ' = Λ (Λ + W)⁻¹ W, ξ' = W (Λ + W)⁻¹ ξ
+            each(c, d, d, [&](int i, int j) { wlds[M2 + i * LD + j] = wlds[M0 + i * LD + j] + wlds[M1 + i * LD + j]; });
+            w_sync();
+            double ld;
+            ok = spd_inv(c, M2, d, ld) && ok;
+            matvec(c, v1, M2, LD, 1, v0, d, d);
+            matvec(c, v2, M1, LD, 1, v1, d, d);
+            matmul(c, M3, M2, false, M1, false, d, d, d);   // (Λ + W)⁻¹ W
+            matmul(c, M2, M0, false, M3, false, d, d, d);   // Λ (Λ + W)⁻¹ W
+            store_msg(c, p, w[W_OUT], d, r, v2, M2);
+        }
+    } break;
+    case OP_MUL_OUT: {
+        const int d1 = w[W_D1];
+        ok = load_msg(c, p, w[W_IN0], fl & F_IN0_WP, false, d1, r, v0, M0);
+        l_cmat(c, M1, p.cpool + w[W_C0], d, d1);
+        w_sync();
+        matvec(c, v1, M1, LD, 1, v0, d, d1);
+        matmul(c, M2, M1, false, M0, false, d, d1, d1);   // A V
+        matmul(c, M3, M2, false, M1, true, d, d1, d);     // A V Aᵀ
+        store_msg(c, p, w[W_OUT], d, r, v1, M3);
+    } break;
+    case OP_MUL_IN: {
+        const int d1 = w[W_D1];
+        ok = load_msg(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
+        l_cmat(c, M1, p.cpool + w[W_C0], d, d1);
+        w_sync();
+        matvec(c, v1, M1, 1, LD, v0, d1, d);              // Aᵀ ξ
+        matmul(c, M2, M1, true, M0, false, d1, d, d);     // Aᵀ Λ
+        matmul(c, M3, M2, false, M1, false, d1, d, d1);   // Aᵀ Λ A
+        store_msg(c, p, w[W_OUT], d1, r, v1, M3);
+    } break;
+    case OP_ADD_OUT:
+    case OP_ADD_IN: {
+        ok = load_msg(c, p, w[W_IN0], fl & F_IN0_WP, false, d, r, v0, M0);
+        ok = load_msg(c, p, w[W_IN1], fl & F_IN1_WP, false, d, r, v1, M1) && ok;
+        add_vec(c, v0, v1, d, op == OP_ADD_OUT ? 1.0 : -1.0);
+        add_mat(c, M0, M1, d, 1.0);
+        w_sync();
+        store_msg(c, p, w[W_OUT], d, r, v0, M0);
+    } break;
+    case OP_SHIFT: {
+        const bool wp = fl & F_IN0_WP;
+        ok = load_msg(c, p, w[W_IN0], wp, wp, d, r, v0, M0);
+        load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v1);
+        const double sg = (fl & F_NEG) ? -1.0 : 1.0;
+        if (wp) {
+            matvec(c, v2, M0, LD, 1, v1, d, d);
+            add_vec(c, v0, v2, d, sg);
+        } else
+            add_vec(c, v0, v1, d, sg);
+        w_sync();
+        store_msg(c, p, w[W_OUT], d, r, v0, M0);
+    } break;
+    case OP_PRODUCT:
+    case OP_MARGINAL: {
+        zero_mat(c, M0, d);
+        for (int i = c.lane; i < d; i += WL) wlds[v0 + i] = 0.0;
+        w_sync();
+        const int n = w[W_N];
+        const int* lst = p.aux + w[W_LIST];
+        for (int q = 0; q < n; ++q) {   // left to right, in factor order
+            ok = load_msg(c, p, lst[2 * q], lst[2 * q + 1] != 0, true, d, r, v1, M1) && ok;
+            add_vec(c, v0, v1, d, 1.0);
+            add_mat(c, M0, M1, d, 1.0);
+            w_sync();
+        }
+        if (op == OP_PRODUCT) {
+            store_msg(c, p, w[W_OUT], d, r, v0, M0);
+        } else {
+            double ld;
+            ok = spd_inv(c, M0, d, ld) && ok;
+            matvec(c, v2, M0, LD, 1, v0, d, d);
+            s_vec(c, p.marg, w[W_OUT], d, p.RS, r, v2);
+            s_sym(c, p.marg, w[W_OUT] + d, d, p.RS, r, M0);
+            if (c.lane == 0) p.marg[(w[W_OUT] + d + d * (d + 1) / 2) * p.RS + r] = -ld;
+        }
+    } break;
+    default: break;
+    }
+    if (!ok && c.lane == 0) atomicOr(p.status, 1);
+}
+
+// the second phase: Bethe terms, residual moments, q(W) updates — tree_kernels.hpp's eval_fe, op for op
+__device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const int* __restrict__ w, long long r) {
+    const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS], LD = c.LD;
+    const int M0 = c.M(0), M1 = c.M(1), M2 = c.M(2), M3 = c.M(3);
+    const int v0 = c.v(0), v1 = c.v(1), v2 = c.v(2), v3 = c.v(3), v4 = c.v(4);
+    bool ok = true;
+    switch (op) {
+    case OP_FE_NOISE2: {
+        // P = Λo + W → M0, S = Λμ + W − W P⁻¹ W → M1, W → M2, P⁻¹W → M3 (see eval_fe of tree_kernels.hpp for the algebra)
+        if (w[W_IN0] >= 0) ok = load_msg(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
+        else {
+            zero_mat(c, M0, d);
+            for (int i = c.lane; i < d; i += WL) wlds[v0 + i] = 0.0;
+        }
+        if (w[W_IN1] >= 0) ok = load_msg(c, p, w[W_IN1], fl & F_IN1_WP, true, d, r, v1, M1) && ok;
+        else {
+            zero_mat(c, M1, d);
+            for (int i = c.lane; i < d; i += WL) wlds[v1 + i] = 0.0;
+        }
+        const double el = load_noise(c, p, w, d, r, false, M2);
+        add_mat(c, M0, M2, d, 1.0);
+        add_mat(c, M1, M2, d, 1.0);
+        w_sync();
+        double ldP, ldS;
+        ok = spd_inv(c, M0, d, ldP) && ok;
+        matmul(c, M3, M0, false, M2, false, d, d, d);                // P⁻¹ W
+        matmul(c, M1, M2, true, M3, false, d, d, d, true, -1.0);     // S −= Wᵀ P⁻¹ W
+        ok = spd_inv(c, M1, d, ldS) && ok;
+        // m_μ = S⁻¹ (ξ_μ + W P⁻¹ ξ_o) → v4, m_o = P⁻¹ (ξ_o + W m_μ) → v3
+        matvec(c, v2, M0, LD, 1, v0, d, d);
+        matvec(c, v3, M2, LD, 1, v2, d, d);
+        add_vec(c, v3, v1, d, 1.0);
+        w_sync();
+        matvec(c, v4, M1, LD, 1, v3, d, d);
+        matvec(c, v2, M2, LD, 1, v4, d, d);
+        add_vec(c, v2, v0, d, 1.0);
+        w_sync();
+        matvec(c, v3, M0, LD, 1, v2, d, d);
+        // E[rrᵀ] = P⁻¹ + (P⁻¹W − I) S⁻¹ (P⁻¹W − I)ᵀ + (m_o − m_μ)(m_o − m_μ)ᵀ, into M0
+        for (int i = c.lane; i < d; i += WL) {
+            wlds[M3 + i * LD + i] -= 1.0;
+            wlds[v3 + i] -= wlds[v4 + i];
+        }
+        w_sync();
+        matmul(c, M2, M3, false, M1, false, d, d, d);                // D S⁻¹
+        matmul(c, M0, M2, false, M3, true, d, d, d, true, 1.0);      // P⁻¹ += D S⁻¹ Dᵀ
+        each(c, d, d, [&](int i, int j) { wlds[M0 + i * LD + j] += wlds[v3 + i] * wlds[v3 + j]; });
+        w_sync();
+        double term = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
+        if (fl & F_STAT) s_full(c, p.stat, w[W_C1], d, p.RS, r, M0, 1.0);
+        else {
+            load_noise(c, p, w, d, r, false, M2);
+            term += 0.5 * (d * T_LOG2PI - el + trace_prod(c, M2, M0, d));
+        }
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = term;
+    } break;
+    case OP_FE_NOISE1:
+    case OP_FE_NOISE0: {
+        const double el = load_noise(c, p, w, d, r, false, M1);
+        double H = 0.0;
+        if (op == OP_FE_NOISE1) {
+            l_vec(c, v0, p.marg, w[W_IN0], d, p.RS, r);
+            l_sym(c, M0, p.marg, w[W_IN0] + d, d, p.RS, r);
+            H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r]);
+            load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v1);
+        } else {
+            zero_mat(c, M0, d);
+            load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v0);
+            load_value(c, p, w[W_VAL2], fl & F_VAL2_SLOT, d, r, v1);
+        }
+        add_vec(c, v0, v1, d, -1.0);
+        w_sync();
+        each(c, d, d, [&](int i, int j) { wlds[M0 + i * LD + j] += wlds[v0 + i] * wlds[v0 + j]; });
+        w_sync();
+        double term = -H;
+        if (fl & F_STAT) s_full(c, p.stat, w[W_C1], d, p.RS, r, M0, 1.0);
+        else term += 0.5 * (d * T_LOG2PI - el + trace_prod(c, M1, M0, d));
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = term;
+    } break;
+    case OP_FE_ENT: {
+        const double H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r]);
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = (double)w[W_N] * H;
+    } break;
+    case OP_FE_ADD2: {   // P = Λ1 + Λo → M0, S = Λ2 + Λo − Λo P⁻¹ Λo → M1, Λo → M2
+        if (w[W_IN0] >= 0) ok = load_msg(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
+        else zero_mat(c, M0, d);
+        if (w[W_IN1] >= 0) ok = load_msg(c, p, w[W_IN1], fl & F_IN1_WP, true, d, r, v0, M1) && ok;
+        else zero_mat(c, M1, d);
+        if (w[W_IN2] >= 0) ok = load_msg(c, p, w[W_IN2], fl & F_IN2_WP, true, d, r, v0, M2) && ok;
+        else zero_mat(c, M2, d);
+        w_sync();
+        add_mat(c, M0, M2, d, 1.0);
+        add_mat(c, M1, M2, d, 1.0);
+        w_sync();
+        double ldP, ldS;
+        ok = spd_inv(c, M0, d, ldP) && ok;
+        matmul(c, M3, M0, false, M2, false, d, d, d);
+        matmul(c, M1, M2, false, M3, false, d, d, d, true, -1.0);
+        ok = spd_inv(c, M1, d, ldS) && ok;
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
+    } break;
+    case OP_SUM_TERMS: {
+        if (c.lane == 0) {
+            const int n = w[W_N];
+            const int* lst = p.aux + w[W_LIST];
+            double s = 0.0;
+            for (int q = 0; q < n; ++q) s += p.term[(long long)lst[q] * p.RS + r];
+            p.term[(long long)w[W_TERM] * p.RS + r] = s;
+        }
+    } break;
+    case OP_PREC_UPDATE: {
+        // prior block at c0: ν0 | S0⁻¹ (d²) | log|S0|;  Σ E[rrᵀ] symmetrised → M1, V⁻¹ = S0⁻¹ + that → M2, V → M3
+        const double* cp = p.cpool + w[W_C0];
+        const double nu0 = cp[0], ldS0 = cp[1 + d * d];
+        zero_mat(c, M0, d);
+        w_sync();
+        const int n = w[W_N];
+        const int* lst = p.aux + w[W_LIST];
+        for (int q = 0; q < n; ++q) {
+            const long long so = lst[q];
+            each(c, d, d, [&](int i, int j) { wlds[M0 + i * LD + j] += p.stat[(so + i * d + j) * p.RS + r]; });
+        }
+        w_sync();
+        each(c, d, d, [&](int i, int j) {
+            const double s = 0.5 * (wlds[M0 + i * LD + j] + wlds[M0 + j * LD + i]);
+            wlds[M1 + i * LD + j] = s;
+            const double vi = cp[1 + i * d + j] + s;
+            wlds[M2 + i * LD + j] = vi;
+            wlds[M3 + i * LD + j] = vi;
+        });
+        w_sync();
+        double ldVi;
+        ok = spd_inv(c, M3, d, ldVi);
+        const double nu = nu0 + (double)n, ldV = -ldVi;
+        const int ps = w[W_PREC], tri = d * (d + 1) / 2;
+        const double elw = t_mvdigamma(0.5 * nu, d) + d * T_LOG2 + ldV;
+        if (c.lane == 0) {
+            p.prec[(long long)ps * p.RS + r] = nu;
+            p.prec[(long long)(ps + 1 + tri + 2 * d * d) * p.RS + r] = elw;
+        }
+        s_sym(c, p.prec, ps + 1, d, p.RS, r, M3);
+        s_full(c, p.prec, ps + 1 + tri, d, p.RS, r, M3, nu);
+        s_full(c, p.prec, ps + 1 + tri + d * d, d, p.RS, r, M2, 1.0 / nu);
+        if (p.want_fe) {
+            l_cmat(c, M0, cp + 1, d, d);
+            w_sync();
+            double F = 0.5 * ((double)n * (d * T_LOG2PI - elw) + nu * trace_prod(c, M3, M1, d));
+            F += -(0.5 * (nu0 - d - 1.0) * elw - 0.5 * nu * trace_prod(c, M0, M3, d) - 0.5 * nu0 * d * T_LOG2 - 0.5 * nu0 * ldS0 - t_mvlgamma(0.5 * nu0, d));
+            F -= 0.5 * (d + 1.0) * ldV + 0.5 * d * (d + 1.0) * T_LOG2 + t_mvlgamma(0.5 * nu, d) - 0.5 * (nu - d - 1.0) * t_mvdigamma(0.5 * nu, d) + 0.5 * nu * d;
+            if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = F;
+        }
+    } break;
+    default: break;
+    }
+    if (!ok && c.lane == 0) atomicOr(p.status, 1);
+}
+
+template <int PHASE>
+__device__ __forceinline__ void eval_op(const Ctx& c, const TreeParams& p, const int* __restrict__ w, long long r) {
+    if (PHASE == 0) eval_bp(c, p, w, r);
+    else eval_fe(c, p, w, r);
+}
+
+#ifndef RXHIP_HOST_EMUL
+// one launch per level: a workgroup (one wavefront) per item (op, replica); replica fastest, so that neighbouring workgroups share the 128-byte lines of a slot
+template <int PHASE>
+__global__ void __launch_bounds__(64) k_wave_ops(TreeParams p, int op0, int op1, int dmax) {
+    const Ctx c = make_ctx(dmax);
+    const long long total = (long long)(op1 - op0) * p.R;
+    for (long long it = blockIdx.x; it < total; it += gridDim.x) {
+        const long long o = it / p.R, r = it - o * p.R;
+        eval_op<PHASE>(c, p, p.ops + (size_t)(op0 + o) * OP_WORDS, r);
+        __syncthreads();   // (one wavefront: a fence — the next item reuses the workspace)
+    }
+}
+// a wavefront owns a replica and walks the ops of the range in order (every op's inputs were written by this wavefront or before the launch)
+template <int PHASE>
+__global__ void __launch_bounds__(64) k_wave_walk(TreeParams p, int op0, int op1, int dmax) {
+    const Ctx c = make_ctx(dmax);
+    for (long long r = blockIdx.x; r < p.R; r += gridDim.x)
+        for (int o = op0; o < op1; ++o) {
+            eval_op<PHASE>(c, p, p.ops + (size_t)o * OP_WORDS, r);
+            __syncthreads();   // (a workgroup-scope fence: the op's stores to global memory before the next op's loads by other lanes)
+        }
+}
+#endif
+
+}  // namespace wave
+}  // namespace tree
+}  // namespace rxhip

@@ -1,0 +1,123 @@
+"""The node-array executor at dimensions above 8 (csrc/tree_wave_kernels.hpp: a wavefront per op and replica, matrices staged in LDS) through the C ABI
+against oracle/tree_oracle.py and against the specialised engines — both schedules (a launch per level / a wavefront per replica walks the schedule),
+dimensions 9 … 64, several replicas, VMP over precision variables, the single-rule entry point.
+
+Tolerances as in tests/test_tree_engine_gpu.py: the contract is 1e-6 (posteriors) and 1e-8 (free energy); asserted at 1e-9 / 1e-10 here."""
+import numpy as np
+import pytest
+
+import tree_graphs as tg
+from test_tree_engine_gpu import _check, _run
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("builder,kw,R", [(tg.two_branch_chain, dict(T=5, d=12, dy1=12, dy2=7), 5), (tg.two_branch_chain, dict(T=4, d=16, dy1=9, dy2=16), 70),
+                                          (tg.two_branch_chain, dict(T=3, d=33, dy1=20, dy2=33), 3), (tg.two_branch_chain, dict(T=2, d=64, dy1=64, dy2=30), 2),
+                                          (tg.two_branch_chain, dict(T=4, d=9, dy1=9, dy2=9, precision_spelling=True), 4),
+                                          (tg.chain_with_prediction, dict(T=6, H=2, d=10, dy=10), 3), (tg.star, dict(n_leaves=40, d=9), 3)])
+def test_dimensions_above_8_against_the_oracle(builder, kw, R, mode, monkeypatch):
+    gb, ys, _ = builder(**kw)
+    eng, data = _run(gb, ys, R, mode=mode, monkeypatch=monkeypatch)
+    assert eng.info["mode"] == mode and eng.info["dmax"] == kw["d"]
+    ref = _check(gb, ys, eng, data, replicas=(0, R - 1), tol=1e-9, tol_fe=1e-10)
+    assert eng.counters()["rule_calls"] == ref["counters"]["rule_calls"] * R
+    eng.close()
+
+
+def test_default_schedule_and_workgroup_mode_request(monkeypatch):
+    """without the test hook: a narrow chain of one replica walks; the workgroup-resident schedule (mode 1) does not exist here and maps to the walk"""
+    from rxhip.tree import TreeEngine
+    gb, ys, _ = tg.two_branch_chain(T=4, d=10, dy1=10, dy2=4)
+    monkeypatch.delenv("RXHIP_TREE_MODE", raising=False)
+    with TreeEngine(gb, n_replicas=1) as eng:
+        assert eng.info["mode"] == 2
+    gs, ysn, _ = tg.star(n_leaves=400, d=9)
+    with TreeEngine(gs, n_replicas=8) as eng:
+        assert eng.info["mode"] == 0
+    monkeypatch.setenv("RXHIP_TREE_MODE", "1")
+    with TreeEngine(gb, n_replicas=3) as eng:
+        assert eng.info["mode"] == 2
+
+
+@pytest.mark.parametrize("d,dy,T,R,mode", [(12, 12, 20, 3, 0), (16, 8, 15, 70, 2), (24, 24, 6, 1, 2)])
+def test_state_space_chain_equals_the_specialised_engine(d, dy, T, R, mode, monkeypatch):
+    """the LGSSM chain at d > 8 through the generic path against LGSSMEngine (the MFMA schedule)"""
+    import rxhip
+    from rxhip import workloads
+    from rxhip.graph import lgssm_graph
+    from rxhip.tree import TreeEngine
+    monkeypatch.setenv("RXHIP_TREE_MODE", str(mode))
+    m = workloads.random_model(d, dy, seed=10 * d + dy)
+    y = workloads.generate_batch(m, T, R, seed0=7)                     # [T][R][dy]
+    gb, xs, ys = lgssm_graph(T, m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"])
+    with TreeEngine(gb, n_replicas=R) as eng:
+        eng.set_data(ys, np.ascontiguousarray(np.transpose(y, (1, 0, 2))).reshape(R, T * dy))
+        eng.run(1, True)
+        post = eng.marginals(xs)
+        fe = eng.free_energy_per_replica()
+    with rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=T, n_chains=R) as ref:
+        ref.set_data(y)
+        ref.run(1, True)
+        mean, cov = ref.marginals()
+        rfe = ref.free_energy_per_chain()
+    tm = np.stack([post[v][0] for v in xs])
+    tc = np.stack([post[v][1] for v in xs])
+    sd = np.sqrt(np.einsum("trii->tri", cov))
+    assert np.max(np.abs(tm - mean) / sd) < 1e-9
+    assert np.max(np.abs(tc - cov) / (sd[..., :, None] * sd[..., None, :])) < 1e-9
+    assert np.max(np.abs(fe - rfe) / np.abs(rfe)) < 1e-10
+
+
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("kw", [dict(T=6, d=10, dy=9, also_obs_noise=True), dict(T=5, d=17, dy=17)])
+def test_unknown_state_noise_precision_vmp(kw, mode, monkeypatch):
+    import tree_oracle
+    gb, ys, named = tg.chain_state_noise_precision(**kw)
+    R, its = 3, 5
+    eng, data = _run(gb, ys, R, iterations=its, mode=mode, monkeypatch=monkeypatch)
+    _check(gb, ys, eng, data, iterations=its, replicas=(0, R - 1), prec_vars=named["W"])
+    fe_it = eng.free_energy()
+    tot = np.zeros(its)
+    for r in range(R):
+        tot += np.array(tree_oracle.infer(gb.to_dump(), tg.data_dict(gb, ys, data[r]), iterations=its)["fe"])
+    assert np.allclose(fe_it, tot, rtol=1e-10)
+    eng.close()
+
+
+def test_rule_eval_above_8():
+    from rxhip import _lib
+    from rxhip.tree import rule_eval
+    rng = np.random.default_rng(8)
+    n = 19
+
+    def spd(k):
+        a = rng.standard_normal((n, k, k + 2))
+        return a @ np.transpose(a, (0, 2, 1)) / k + 0.5 * np.eye(k)
+    for d, dy in ((12, 9), (40, 64), (64, 20)):
+        m, V, S = rng.standard_normal((n, d)), spd(d), spd(d)[0]
+        a, B = rule_eval(_lib.NODE_MVNORMAL_MEAN_COV, 0, S, (m, V))
+        assert np.allclose(a, m, rtol=1e-13) and np.allclose(B, V + S, rtol=1e-13)
+        L = np.linalg.inv(V)
+        a, B = rule_eval(_lib.NODE_MVNORMAL_MEAN_COV, 1, S, (np.einsum("nij,nj->ni", L, m), L), in_form="wp", out_form="mv")
+        assert np.allclose(a, m, rtol=1e-8, atol=1e-9) and np.allclose(B, V + S, rtol=1e-8, atol=1e-9)
+        A = rng.standard_normal((dy, d))
+        a, B = rule_eval(_lib.NODE_MULTIPLY, 0, A, (m, V))
+        assert np.allclose(a, m @ A.T, rtol=1e-12, atol=1e-12) and np.allclose(B, A @ V @ A.T, rtol=1e-12, atol=1e-12)
+        xi, Ly = rng.standard_normal((n, dy)), spd(dy)
+        a, B = rule_eval(_lib.NODE_MULTIPLY, 2, A, (xi, Ly), in_form="wp", out_form="wp")
+        assert np.allclose(a, xi @ A, rtol=1e-12, atol=1e-12) and np.allclose(B, A.T @ Ly @ A, rtol=1e-12, atol=1e-12)
+        m2, V2 = rng.standard_normal((n, d)), spd(d)
+        a, B = rule_eval(_lib.NODE_ADD, 1, None, (m, V), (m2, V2))
+        assert np.allclose(a, m - m2) and np.allclose(B, V + V2)
+
+
+def test_dimension_65_is_refused_with_a_reason():
+    import rxhip
+    from rxhip import _lib
+    from rxhip.tree import TreeEngine
+    gb, ys, _ = tg.two_branch_chain(T=2, d=65, dy1=3, dy2=3)
+    with pytest.raises(rxhip.RxHipError) as ei:
+        TreeEngine(gb, n_replicas=1)
+    assert ei.value.status == _lib.ERR_UNSUPPORTED and "64" in str(ei.value)

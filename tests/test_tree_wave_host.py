@@ -1,0 +1,215 @@
+"""The executor's LDS-staged rule bodies (csrc/tree_wave_kernels.hpp, dimensions above 8) against its register rule bodies (csrc/tree_kernels.hpp), op for op.
+
+Both headers are compiled for the HOST by g++ (tests/host_emul/: a stand-in <hip/hip_runtime.h>, a "wavefront" of one lane) and run over the same hand-made
+op tables and random states: what the GPU parity tests established for the register bodies (tests/test_tree_engine_gpu.py against oracle/tree_oracle.py)
+carries over to the wavefront bodies' algebra — buffer reuse, in-place inverse, transposed products, every flag — before a GPU is involved.  What this cannot
+see is a race between lanes; tests/test_tree_engine_gpu.py runs the same graphs at d > 8 on the device.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "rxinfer.jl_amd", "csrc")
+EMUL = os.path.join(ROOT, "tests", "host_emul")
+
+(OP_DERIVE_MUL, OP_DERIVE_ADD, OP_LEAF, OP_NOISE, OP_MUL_OUT, OP_MUL_IN, OP_ADD_OUT, OP_ADD_IN, OP_SHIFT, OP_PRODUCT, OP_MARGINAL, OP_FE_NOISE2, OP_FE_NOISE1,
+ OP_FE_NOISE0, OP_FE_ENT, OP_FE_ADD2, OP_SUM_TERMS, OP_PREC_UPDATE) = range(1, 19)
+W_OP, W_D0, W_D1, W_OUT, W_IN0, W_IN1, W_IN2, W_FLAGS, W_C0, W_C1, W_VAL, W_VAL2, W_PREC, W_TERM, W_N, W_LIST = range(16)
+F_IN0_WP, F_IN1_WP, F_IN2_WP, F_OUT_WP, F_VAL_SLOT, F_VAL2_SLOT, F_NEG, F_STAT, F_RAND_IS_MU = 1, 2, 4, 8, 16, 32, 64, 128, 256
+
+
+@pytest.fixture(scope="module")
+def lib(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("wave_emul") / "wave_diff.so")
+    subprocess.run(["g++", "-O1", "-std=c++17", "-shared", "-fPIC", "-DRXHIP_HOST_EMUL", "-Wno-unknown-pragmas", "-I", EMUL, "-I", CSRC, "-o", so,
+                    os.path.join(EMUL, "wave_diff.cpp")], check=True)
+    L = ctypes.CDLL(so)
+    L.emul_run.restype = ctypes.c_int
+    return L
+
+
+class State:
+    """Slot allocator and storage in the executor's layout: element k of slot `off` of replica r at (off + k) * RS + r."""
+
+    def __init__(self, R, seed):
+        self.R, self.RS = R, (R + 15) // 16 * 16
+        self.rng = np.random.default_rng(seed)
+        self.size = dict(msg=0, marg=0, val=0, prec=0, term=0, stat=0)
+        self.fill = dict(msg=[], marg=[], val=[], prec=[], term=[], stat=[])
+        self.cpool, self.aux, self.ops = [], [], []
+
+    def slot(self, kind, n, values=None):   # values: [R, n]
+        off = self.size[kind]
+        self.size[kind] += n
+        if values is not None:
+            self.fill[kind].append((off, np.asarray(values, float).reshape(self.R, n)))
+        return off
+
+    def const(self, values):
+        off = len(self.cpool)
+        self.cpool.extend(np.asarray(values, float).ravel().tolist())
+        return off
+
+    def spd(self, d, scale=1.0):
+        A = self.rng.standard_normal((self.R, d, d + 2))
+        return scale * (A @ A.transpose(0, 2, 1) / (d + 2) + 0.3 * np.eye(d))
+
+    def message(self, d):   # a slot with a random (vector, SPD matrix) pair: valid in either form
+        v = self.rng.standard_normal((self.R, d))
+        M = self.spd(d)
+        il = np.tril_indices(d)
+        return self.slot("msg", d + d * (d + 1) // 2, np.concatenate([v, M[:, il[0], il[1]]], axis=1))
+
+    def marginal(self, d):
+        v = self.rng.standard_normal((self.R, d))
+        M = self.spd(d)
+        il = np.tril_indices(d)
+        ld = np.linalg.slogdet(M)[1][:, None]
+        return self.slot("marg", d + d * (d + 1) // 2 + 1, np.concatenate([v, M[:, il[0], il[1]], ld], axis=1))
+
+    def noise_const(self, d):
+        S = self.spd(d)[0]
+        W = np.linalg.inv(S)
+        return self.const(np.concatenate([S.ravel(), W.ravel(), [np.linalg.slogdet(W)[1]]]))
+
+    def precision_state(self, d):   # [nu | V tri | What d*d | What^-1 d*d | E log|W|]
+        V = self.spd(d, 0.1)
+        nu = d + 2.0 + self.rng.random((self.R, 1))
+        What = nu[:, :, None] * V
+        il = np.tril_indices(d)
+        el = self.rng.standard_normal((self.R, 1))
+        return self.slot("prec", 2 + d * (d + 1) // 2 + 2 * d * d, np.concatenate([nu, V[:, il[0], il[1]], What.reshape(self.R, -1), np.linalg.inv(What).reshape(self.R, -1), el], axis=1))
+
+    def op(self, code, d, **kw):
+        w = [0] * 16
+        w[W_OP], w[W_D0] = code, d
+        for k in (W_IN0, W_IN1, W_IN2, W_OUT, W_PREC, W_TERM):
+            w[k] = -1
+        for k, v in kw.items():
+            w[globals()["W_" + k.upper()]] = v
+        self.ops.append(w)
+
+    def arrays(self):
+        out = {}
+        for kind, n in self.size.items():
+            a = np.zeros((max(n, 1), self.RS))
+            for off, vals in self.fill[kind]:
+                a[off:off + vals.shape[1], :self.R] = vals.T
+            out[kind] = a
+        return out
+
+
+def run(lib, st, which, n, want_fe=1):
+    arr = st.arrays()
+    ops = np.asarray(st.ops, np.int32).ravel()
+    aux = np.asarray(st.aux + [0], np.int32)
+    cp = np.asarray(st.cpool + [0.0], float)
+    ptr = lambda a, t: a.ctypes.data_as(ctypes.POINTER(t))
+    status = lib.emul_run(which, n, ptr(ops, ctypes.c_int), len(st.ops), ptr(aux, ctypes.c_int), ptr(cp, ctypes.c_double),
+                          *[ptr(arr[k], ctypes.c_double) for k in ("msg", "marg", "val", "prec", "term", "stat")],
+                          ctypes.c_longlong(st.R), ctypes.c_longlong(st.RS), want_fe)
+    return status, arr
+
+
+def build_program(d, d1, seed):
+    """Every opcode with every flag the compiler emits, on independent inputs; (d, d1) the dimensions of a `*` node's out and in."""
+    st = State(R=3, seed=seed)
+    msz = lambda n: n + n * (n + 1) // 2
+    new_msg = lambda n: st.slot("msg", msz(n))
+    rng = st.rng
+    # clamped values: data slots and constants, and the deterministic nodes over them
+    x1 = st.slot("val", d1, rng.standard_normal((st.R, d1)))
+    y0 = st.slot("val", d, rng.standard_normal((st.R, d)))
+    cv = st.const(rng.standard_normal(d))
+    A = st.const(rng.standard_normal((d, d1)))
+    dv = st.slot("val", d)
+    st.op(OP_DERIVE_MUL, d, d1=d1, out=dv, c0=A, val=x1, flags=F_VAL_SLOT)
+    dv2 = st.slot("val", d)
+    st.op(OP_DERIVE_ADD, d, out=dv2, val=dv, val2=cv, flags=F_VAL_SLOT)
+    noise, ps = st.noise_const(d), st.precision_state(d)
+    # leaves
+    for wp in (0, F_OUT_WP):
+        st.op(OP_LEAF, d, out=new_msg(d), val=y0, flags=F_VAL_SLOT | wp, c0=noise)
+        st.op(OP_LEAF, d, out=new_msg(d), val=cv, flags=wp, prec=ps)
+    # the additive rule in both forms, constant noise and a precision variable's
+    for wp in (0, F_IN0_WP | F_OUT_WP):
+        st.op(OP_NOISE, d, in0=st.message(d), out=new_msg(d), flags=wp, c0=noise)
+        st.op(OP_NOISE, d, in0=st.message(d), out=new_msg(d), flags=wp, prec=ps)
+    for wp in (0, F_IN0_WP):
+        st.op(OP_MUL_OUT, d, d1=d1, in0=st.message(d1), out=new_msg(d), c0=A, flags=wp)
+        st.op(OP_MUL_IN, d, d1=d1, in0=st.message(d), out=new_msg(d1), c0=A, flags=wp)
+    for f in (0, F_IN0_WP, F_IN1_WP, F_IN0_WP | F_IN1_WP):
+        st.op(OP_ADD_OUT, d, in0=st.message(d), in1=st.message(d), out=new_msg(d), flags=f)
+        st.op(OP_ADD_IN, d, in0=st.message(d), in1=st.message(d), out=new_msg(d), flags=f)
+    for f in (0, F_IN0_WP, F_NEG, F_IN0_WP | F_NEG):
+        st.op(OP_SHIFT, d, in0=st.message(d), out=new_msg(d), val=y0, flags=f | F_VAL_SLOT)
+        st.op(OP_SHIFT, d, in0=st.message(d), out=new_msg(d), val=cv, flags=f)
+    # products and marginals of three messages in mixed forms
+    for code in (OP_PRODUCT, OP_MARGINAL):
+        lst = len(st.aux)
+        for form in (1, 0, 1):
+            st.aux += [st.message(d), form]
+        st.op(code, d, out=new_msg(d) if code == OP_PRODUCT else st.slot("marg", msz(d) + 1), n=3, list=lst)
+    # second phase
+    terms = []
+    new_term = lambda: terms.append(st.slot("term", 1)) or terms[-1]
+    stats = []
+    for f in (0, F_IN0_WP, F_IN1_WP | F_IN0_WP):
+        st.op(OP_FE_NOISE2, d, in0=st.message(d), in1=st.message(d), flags=f, c0=noise, term=new_term())
+        stats.append(st.slot("stat", d * d))
+        st.op(OP_FE_NOISE2, d, in0=st.message(d), in1=st.message(d), flags=f | F_STAT, prec=ps, c1=stats[-1], term=new_term())
+    st.op(OP_FE_NOISE2, d, in0=-1, in1=st.message(d), flags=F_IN1_WP, c0=noise, term=new_term())
+    st.op(OP_FE_NOISE2, d, in0=st.message(d), in1=-1, flags=0, prec=ps, term=new_term())
+    mg = st.marginal(d)
+    st.op(OP_FE_NOISE1, d, in0=mg, val=y0, flags=F_VAL_SLOT, c0=noise, term=new_term())
+    stats.append(st.slot("stat", d * d))
+    st.op(OP_FE_NOISE1, d, in0=mg, val=cv, flags=F_STAT | F_RAND_IS_MU, prec=ps, c1=stats[-1], term=new_term())
+    st.op(OP_FE_NOISE0, d, val=y0, val2=cv, flags=F_VAL_SLOT, c0=noise, term=new_term())
+    stats.append(st.slot("stat", d * d))
+    st.op(OP_FE_NOISE0, d, val=cv, val2=y0, flags=F_VAL2_SLOT | F_STAT, prec=ps, c1=stats[-1], term=new_term())
+    st.op(OP_FE_ENT, d, in0=mg, n=-2, term=new_term())
+    for f, ins in ((0, (1, 1, 1)), (F_IN0_WP | F_IN2_WP, (1, 1, 1)), (F_IN1_WP, (0, 1, 1)), (F_IN0_WP, (1, 0, 1)), (F_IN0_WP | F_IN1_WP, (1, 1, 0))):
+        slots = [st.message(d) if k else -1 for k in ins]
+        st.op(OP_FE_ADD2, d, in0=slots[0], in1=slots[1], in2=slots[2], flags=f, term=new_term())
+    # q(W) update from the residual moments written above, into a second precision state
+    S0 = st.spd(d, 0.2)[0]
+    prior = st.const(np.concatenate([[d + 1.5], np.linalg.inv(S0).ravel(), [np.linalg.slogdet(S0)[1]]]))
+    ps2 = st.slot("prec", 2 + d * (d + 1) // 2 + 2 * d * d)
+    lst = len(st.aux)
+    st.aux += stats
+    st.op(OP_PREC_UPDATE, d, c0=prior, prec=ps2, n=len(stats), list=lst, term=new_term())
+    lst = len(st.aux)
+    st.aux += terms
+    st.op(OP_SUM_TERMS, d, n=len(terms), list=lst, term=st.slot("term", 1))
+    return st
+
+
+@pytest.mark.parametrize("d,d1", [(3, 2), (2, 3), (8, 5), (12, 9), (9, 16), (20, 20), (32, 24), (33, 40), (64, 48)])
+def test_every_op_matches_the_register_bodies(lib, d, d1):
+    st = build_program(d, d1, seed=100 * d + d1)
+    n = max(d, d1)
+    s0, ref = run(lib, st, 0, n)
+    s1, got = run(lib, st, 1, n)
+    assert s0 == 0 and s1 == 0
+    for kind in ("msg", "marg", "val", "prec", "term", "stat"):
+        a, b = ref[kind][:, :st.R], got[kind][:, :st.R]
+        assert np.all(np.isfinite(a)) and np.all(np.isfinite(b)), kind
+        scale = np.maximum(1.0, np.abs(a))
+        err = np.max(np.abs(a - b) / scale)
+        assert err < 1e-11 * n, (kind, err)
+        assert np.any(a != 0.0) or st.size[kind] == 0, kind
+
+
+def test_a_matrix_that_is_not_positive_definite_is_reported(lib):
+    st = State(R=2, seed=5)
+    d = 12
+    off = st.message(d)
+    st.fill["msg"][-1][1][:, d] = -1.0   # first diagonal entry of the matrix
+    st.op(OP_MARGINAL, d, out=st.slot("marg", d + d * (d + 1) // 2 + 1), n=1, list=0)
+    st.aux += [off, 1]
+    assert run(lib, st, 0, d)[0] == 1
+    assert run(lib, st, 1, d)[0] == 1
