@@ -313,6 +313,11 @@ typedef struct {
  * RXHIP_ERR_UNSUPPORTED if the graph is not such a chain (message via rxhip_lowering_error()). */
 rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowered* out);
 const char* rxhip_lowering_error(void); /* thread-local text of the last lowering failure */
+/* A constant precision / covariance parameter must be symmetric within round-off: max|W − W′| ≤ 1e-8·max|W| (a precision computed as inv(Σ) on the host
+ * carries ≈ eps·cond(Σ)·max|W|), else RXHIP_ERR_BADARG; below the bound the symmetric part ½(W + W′) is what the engines run on.  This returns the largest
+ * max|W − W′| / max|W| the last lowering call of this thread (rxhip_graph_lower_*, rxhip_create, rxhip_tree_create) accepted that way — 0 when every
+ * parameter was exactly symmetric — so that a caller who wants a tighter bound can enforce it. */
+double rxhip_lowering_asymmetry(void);
 
 /* Mean-field mixture (a9/a10): recognises  s ~ Dirichlet|Beta(const); m[k] ~ Normal(mean, var const); p[k] ~ Gamma(shape,
  * rate const); z[i] ~ Categorical|Bernoulli(s); y[i] (data) ~ NormalMixture(switch = z[i], m, p)  in any node order, and

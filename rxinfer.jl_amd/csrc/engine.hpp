@@ -24,7 +24,30 @@ using rxhip::DenseModel;
 using rxhip::LgssmVtbl;
 
 // ------------------------------------------------------------------------------------------
-struct rxhip_engine {
+// What a handle's OWNER changes after creation — data, runs, modes, counters.  One value-initialised sub-object: rxhip_lgssm_create hands a parked engine
+// (engine pool, rxhip.hip) to its next owner by assigning a fresh rxhip_engine_life, so a field added here can never leak from one life to the next.
+// Everything that describes the MODEL and its device tables stays in rxhip_engine proper.
+struct rxhip_engine_life {
+    bool have_data = false;
+    long long stream_k = 0;        // rxhip_filter_step: observations seen
+    bool have_inputs = false;      // engines with data inputs u[t] (du > 0): rxhip_set_data(RXHIP_VAR_U) has been called
+    double stage_ms[4] = {0.0, 0.0, 0.0, 0.0};  // creation stages (rxhip_get_create_stages): tables host | tables device | upload | alloc (zero: nothing was built for this owner)
+    bool records_hold_gains = false; // the last run was a smoothing sweep of kd_forward_info / kd_backward_info with one chain per tile: d_filt holds G_t′
+    bool records_tinv = false;       // the last smoothing run left mean-only forward records behind the fixed point of V_f (Params::tinv_records)
+    bool m_wave8_last = false;       // the last masked sweep ran on the in-wave d ≤ 8 kernels
+    int cov_mode = 0;                // rxhip_set_covariance_mode (see below)
+    bool cov_pending = false, cov_current = false;
+    bool noise_continue = false;     // rxhip_lgssm_noise_continue: runs go on from the current q(W) (iteration-at-a-time drivers)
+    // results bookkeeping
+    int last_iterations = 0;
+    bool last_want_fe = false;
+    bool ran = false, last_filter = false;
+    uint64_t rule_calls = 0, products = 0, marginals = 0;
+    // per-kernel device times (rxhip_set_profiling)
+    double k_ms[RXHIP_K_COUNT] = {};
+    uint64_t k_n[RXHIP_K_COUNT] = {};
+};
+struct rxhip_engine : rxhip_engine_life {
     // one device allocation holds every buffer of a state-space engine (creation / destruction cost two driver calls
     // instead of ≈40: 2.9 ms -> see DESIGN §6c); pointers inside it are never freed individually
     char* arena = nullptr;
@@ -50,7 +73,6 @@ struct rxhip_engine {
     // device memory
     double* d_y = nullptr;
     bool own_y = false;
-    bool have_data = false;
     double *d_filt = nullptr, *d_mean = nullptr, *d_cov = nullptr, *d_cst = nullptr, *d_tab = nullptr,
            *d_vtab = nullptr, *d_scan = nullptr, *d_agg = nullptr, *d_elem = nullptr, *d_fstart = nullptr, *d_beta = nullptr, *d_fe_part = nullptr,
            *d_fe_chain = nullptr, *d_fe_total = nullptr;
@@ -97,9 +119,6 @@ struct rxhip_engine {
     size_t h_io_bytes = 0;
     double* h_stream = nullptr;   // its pinned host staging block
     double* d_stream = nullptr;   // rxhip_filter_step: belief per chain | staging of y, mean, cov, fe (allocated on first use)
-    long long stream_k = 0;
-    bool have_inputs = false;      // engines with data inputs u[t] (du > 0): rxhip_set_data(RXHIP_VAR_U) has been called
-    double stage_ms[4] = {0.0, 0.0, 0.0, 0.0};  // creation stages (rxhip_get_create_stages): tables host | tables device | upload | alloc
     double *d_mu = nullptr, *d_nu = nullptr, *d_cx = nullptr, *d_cy_raw = nullptr;  // known inputs: μ[t] [Tout][d], ν[t] = B μ[t] + d[t] [Tout][dy], c[t], d[t]
     std::vector<double> h_mu, h_nu, h_cx, h_cy, h_offA, h_offB;
     std::vector<double> h_cx_const, h_cy_const;  // the offsets the engine was created with (graph constants), for RXHIP_VAR_U
@@ -128,9 +147,6 @@ struct rxhip_engine {
     int m_hs = 0, m_hs_rounds = 0;   // masked schedule: log-depth boundary recursion (km_compose / km_apply)
     int m_hs_n = 0, m_hs_g = 1;      // … over m_hs_n entries of m_hs_g segments each (km_fold / km_inner when m_hs_g > 1)
     double *m_hsel = nullptr, *m_hsvec = nullptr;
-    bool records_hold_gains = false; // the last run was a smoothing sweep of kd_forward_info / kd_backward_info with one chain per tile: d_filt holds G_t′
-    int cov_mode = 0;
-    bool cov_pending = false, cov_current = false;
     double *d_dtab = nullptr, *d_vlast = nullptr, *d_vstab = nullptr, *d_fe_const = nullptr;
     bool gseq = false;        // d > 4 with `missing` observations or per-step constants: sequential schedule (gseq_kernels.hpp)
     // … and, for `missing` observations under ONE model, the time-parallel schedule of dense_mseg_kernels.hpp for smoothing runs
@@ -149,28 +165,18 @@ struct rxhip_engine {
     struct DenseModel* d_models = nullptr;  // [n_models] table pointers on the device (several models per engine)
     std::vector<double> h_cst0;  // model 0's constant block (kernel argument when all chains share it)
     int fe_total_cap = 0;
-    // results bookkeeping
-    int last_iterations = 0;
-    bool last_want_fe = false;
-    bool ran = false, last_filter = false;
-    uint64_t rule_calls = 0, products = 0, marginals = 0;
     // profiling
     bool profiling = false;
-    bool m_wave8_last = false;   // the last masked sweep ran on the in-wave d ≤ 8 kernels
     double* h_stage = nullptr;   // pinned staging block of the creation upload (arena_commit), kept until destruction
     size_t h_stage_bytes = 0;
     // unknown observation-noise precision (rxhip_lgssm_noise_create, noise_kernels.hpp): one block B | prior | state | history
-    bool records_tinv = false;   // the last smoothing run left mean-only forward records behind the fixed point of V_f (Params::tinv_records)
     bool noise = false;
-    bool noise_continue = false;   // rxhip_lgssm_noise_continue: runs go on from the current q(W) (iteration-at-a-time drivers)
     char* noise_block = nullptr;
     double *n_B = nullptr, *n_prior = nullptr, *n_state = nullptr, *n_hist = nullptr, *n_part = nullptr;
     int n_hist_cap = 0, n_slices = 1;
     struct Pending { int k; hipEvent_t a, b; };
     std::vector<Pending> pending;
     std::vector<hipEvent_t> pool;
-    double k_ms[RXHIP_K_COUNT] = {};
-    uint64_t k_n[RXHIP_K_COUNT] = {};
     std::string err = "";
     std::string pool_key;   // non-empty: this engine may be parked by rxhip_destroy and handed out again by rxhip_lgssm_create (engine pool below)
     // scratch of the cross-GPU sums (rxhip_allreduce_free_energy / rxhip_gmm_allreduce_statistics): [nranks][n]

@@ -14,6 +14,7 @@ extern "C" {
 static void fill_lowered(const rxhip_lower::Lgssm& L, rxhip_lgssm_lowered* out, bool with_Q);
 rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowered* out) {
     if (!out) return RXHIP_ERR_BADARG;
+    rxhip_lower::last_asymmetry() = 0.0;
     rxhip_lower::Lgssm L;
     rxhip_status st = rxhip_lower::lower_lgssm(g, L);
     if (st) return st;
@@ -22,6 +23,7 @@ rxhip_status rxhip_graph_lower_lgssm(const rxhip_graph_desc* g, rxhip_lgssm_lowe
 }
 rxhip_status rxhip_graph_lower_lgssm_noise(const rxhip_graph_desc* g, rxhip_lgssm_noise_lowered* out) {
     if (!out) return RXHIP_ERR_BADARG;
+    rxhip_lower::last_asymmetry() = 0.0;
     rxhip_lower::LgssmNoise N;
     rxhip_status st = rxhip_lower::lower_lgssm_noise(g, N);
     if (st) return st;
@@ -51,6 +53,7 @@ static void fill_lowered(const rxhip_lower::Lgssm& L, rxhip_lgssm_lowered* out, 
     if (out->data_var) for (long long t = 0; t < L.T; ++t) out->data_var[t] = L.data_var[t];
 }
 const char* rxhip_lowering_error(void) { return rxhip_lower::last_error().c_str(); }
+double rxhip_lowering_asymmetry(void) { return rxhip_lower::last_asymmetry(); }
 
 rxhip_status rxhip_graph_lower_gmm(const rxhip_graph_desc* g, rxhip_gmm_lowered* out) {
     if (!out) return RXHIP_ERR_BADARG;
@@ -67,6 +70,7 @@ rxhip_status rxhip_graph_lower_gmm(const rxhip_graph_desc* g, rxhip_gmm_lowered*
 }
 rxhip_status rxhip_graph_lower_mvgmm(const rxhip_graph_desc* g, rxhip_mvgmm_lowered* out) {
     if (!out) return RXHIP_ERR_BADARG;
+    rxhip_lower::last_asymmetry() = 0.0;
     rxhip_lower::MvGmm M;
     rxhip_status st = rxhip_lower::lower_mvgmm(g, M);
     if (st) return st;
@@ -95,6 +99,7 @@ rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* 
     *out = nullptr;
     rxhip::tree::Engine* t = nullptr;
     std::string err;
+    rxhip_lower::last_asymmetry() = 0.0;
     const rxhip_status st = rxhip::tree::create(g, device, stream, &t, err);
     if (st) { rxhip_lower::last_error() = err; return st; }
     rxhip_engine* e = new rxhip_engine();
@@ -147,6 +152,7 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
 static rxhip_status create_pattern_matched(const rxhip_graph_desc* g, int32_t segments, int32_t device, void* stream, rxhip_engine** out) {
     if (!out) return RXHIP_ERR_BADARG;
     *out = nullptr;
+    rxhip_lower::last_asymmetry() = 0.0;
     if (rxhip_status st0 = rxhip_lower::check_tables(g)) return st0;
     // family by the node types present (the lowering passes reject everything that is not exactly their graph)
     if (rxhip_lower::has_node(g, RXHIP_NODE_GCV)) {

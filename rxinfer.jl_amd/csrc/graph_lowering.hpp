@@ -22,6 +22,12 @@ inline std::string& last_error() {
     static thread_local std::string e;
     return e;
 }
+// the largest relative asymmetry max|W − W′| / max|W| among the constant parameters the current lowering call accepted as "symmetric within round-off"
+// and replaced by their symmetric part (spd_inverse_checked below; rxhip_lowering_asymmetry() hands it to the caller); the ABI entry points reset it
+inline double& last_asymmetry() {
+    static thread_local double a = 0.0;
+    return a;
+}
 inline rxhip_status unsupported(const std::string& why) {
     last_error() = why;
     return RXHIP_ERR_UNSUPPORTED;
@@ -133,7 +139,8 @@ inline bool same_const(const rxhip_graph_desc* g, long long a, long long b) {
 // must not repair an input error by symmetrising afterwards — then through the Cholesky factor (positive definite or refused).
 // "Round-off" is scaled to what a host produces: a precision computed as inv(Σ) carries an asymmetry of ≈ eps·cond(Σ)·max|W|, so the
 // bound is 1e-8·max|W| (cond up to ≈ 10⁷; the reference places no symmetry requirement on MvNormalMeanPrecision arguments at all);
-// below it the symmetric part ½(W + W′) is what gets inverted.  0: ok, 1: not symmetric, 2: not positive definite.
+// below it the symmetric part ½(W + W′) is what gets inverted — and the measured asymmetry is kept for rxhip_lowering_asymmetry(), so that a caller who
+// wants the tight bound can have it.  0: ok, 1: not symmetric, 2: not positive definite.
 inline int spd_inverse_checked(int d, const double* W, std::vector<double>& inv) {
     double amax = 0.0, asym = 0.0;
     for (int i = 0; i < d; ++i)
@@ -142,6 +149,7 @@ inline int spd_inverse_checked(int d, const double* W, std::vector<double>& inv)
             asym = std::max(asym, std::fabs(W[(size_t)i * d + j] - W[(size_t)j * d + i]));
         }
     if (!(asym <= 1e-8 * amax)) return 1;   // also catches NaN
+    if (asym > 0.0) last_asymmetry() = std::max(last_asymmetry(), asym / amax);   // accepted and symmetrised: the caller can ask how far
     std::vector<double> L((size_t)d * d, 0.0), Li((size_t)d * d, 0.0);
     for (int j = 0; j < d; ++j) {
         double s = W[(size_t)j * d + j];

@@ -1790,18 +1790,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         }
         if (hit) {
             if (!hit->own_y) hit->d_y = nullptr;   // (a caller's device pointer of the previous life)
-            hit->have_data = false;
-            hit->ran = hit->last_filter = hit->last_want_fe = false;
-            hit->last_iterations = 0;
-            hit->rule_calls = hit->products = hit->marginals = 0;
-            hit->cov_mode = 0;
-            hit->cov_pending = hit->cov_current = false;
-            hit->records_hold_gains = false;
-            hit->records_tinv = false;
-            hit->stream_k = 0;
-            hit->have_inputs = false;
-            for (int k = 0; k < RXHIP_K_COUNT; ++k) { hit->k_ms[k] = 0.0; hit->k_n[k] = 0; }
-            for (double& ms : hit->stage_ms) ms = 0.0;   // nothing was built this time
+            static_cast<rxhip_engine_life&>(*hit) = rxhip_engine_life{};   // every per-owner field at once (engine.hpp)
             *out = hit;
             return RXHIP_OK;
         }

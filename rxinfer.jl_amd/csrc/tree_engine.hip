@@ -23,6 +23,7 @@
 #include <numeric>
 #include <vector>
 
+#include "graph_lowering.hpp"  // last_asymmetry
 #include "launch_tables.hpp"   // hook_env
 #include "tree_kernels.hpp"
 #include "tree_wave_kernels.hpp"
@@ -157,6 +158,7 @@ struct Compiler {
         // (the bound of the state-space lowering, graph_lowering.hpp spd_inverse_checked: a precision computed as inv(Σ) on the host carries eps·cond·max|W|
         //  of asymmetry; below it the symmetric part is what gets factorised)
         if (!(asym <= 1e-8 * amax)) fail(RXHIP_ERR_NOT_POSDEF, "noise parameter %d is not symmetric", v);
+        if (asym > 0.0) rxhip_lower::last_asymmetry() = std::max(rxhip_lower::last_asymmetry(), asym / amax);
         double ld = 0.0;
         if (!host_chol_inv(d, M.data(), Mi.data(), &ld)) fail(RXHIP_ERR_NOT_POSDEF, "noise parameter %d is not positive definite", v);
         noise_off[v] = (int)P.cpool.size();
@@ -935,9 +937,9 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     // large batches: a lane per replica walks the whole schedule (no barriers; 64 replicas per wavefront, from one wavefront per SIMD on)
     if (e->R >= 65536) e->mode = 2;
     if (P.dmax > 8) {
-        // wavefront per item: a launch per level while a level has enough items to occupy the device, else one wavefront per replica walks the schedule
-        // (a chain is three levels per step: hundreds of launches of a handful of wavefronts cost more than the walk)
-        e->mode = (avg_width * (double)e->R >= 256.0 && e->R < 4096) ? 0 : 2;
+        // wavefront per item: a launch per level — a rule at d = 16 is ≈ 17 µs of dependent LDS round trips inside its wavefront, more than a launch, so
+        // the walk (one wavefront per replica, ops in sequence) only pays once the replicas alone fill the device (measured: profiles/r05/tree_wave_modes.txt)
+        e->mode = e->R >= 4096 ? 2 : 0;
     }
     if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = std::max(0, std::min(2, std::atoi(m)));
     if (P.dmax > 8 && e->mode == 1) e->mode = 2;   // (no workgroup-resident schedule for the LDS-staged kernels)

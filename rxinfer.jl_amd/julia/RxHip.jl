@@ -514,6 +514,8 @@ with_desc(f, t, n_replicas::Integer, n_observations::Integer; allow_missing::Boo
 end
 
 lowering_error() = unsafe_string(ccall((:rxhip_lowering_error, librxhip), Cstring, ()))
+"largest relative asymmetry of a constant parameter the last lowering call accepted and symmetrised (include/rxhip.h rxhip_lowering_asymmetry)"
+lowering_asymmetry() = ccall((:rxhip_lowering_asymmetry, librxhip), Cdouble, ())
 
 """
     create_from_tables(tables; n_replicas = 1, n_observations = 0, segments = 0, device = -1, stream = nothing, allow_missing = false)

@@ -139,6 +139,7 @@ SYMBOLS = [
     ("rxhip_graph_lower_hgf", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(HgfLowered)]),
     ("rxhip_graph_lower_lgssm_noise", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(LgssmNoiseLowered)]),
     ("rxhip_lowering_error", ctypes.c_char_p, []),
+    ("rxhip_lowering_asymmetry", ctypes.c_double, []),
     ("rxhip_create", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.POINTER(_H)]),
     ("rxhip_lgssm_supported", ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),

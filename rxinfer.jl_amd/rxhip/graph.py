@@ -387,6 +387,11 @@ def drift_chain_graph(T, m0, v0, c, obs_var, const_first=False):
     return gb, xs, ys
 
 
+def lowering_asymmetry():
+    """max|W − W′| / max|W| of the least symmetric constant parameter the last lowering call of this thread accepted (and symmetrised); 0.0: none."""
+    return float(_lib.lib().rxhip_lowering_asymmetry())
+
+
 def lower_lgssm(g):
     """Host-only lowering (no GPU): returns dict(d, dy, T, prior_through_transition, A, B, P, Q, m0, V0, state_var, data_var)."""
     L = _lib.lib()

@@ -23,8 +23,8 @@ for d, T, R in cases:
             best = 1e9
             for _ in range(3):
                 eng.run(1, True)
-                best = min(best, eng.info["last_iteration_ms"])
+                best = min(best, eng.last_iteration_ms())
             inf = eng.info
             calls = eng.counters()["rule_calls"]
-        print(f"d={d:3d} T={T:3d} R={R:5d} mode={mode}  {best:9.3f} ms/sweep  ops={inf['n_ops']} levels={inf['n_levels']}  {calls / best * 1e-3:10.3e} rule-calls/s  "
+        print(f"d={d:3d} T={T:3d} R={R:5d} mode={mode}  {best:9.3f} ms/sweep  ops={inf['n_ops']} levels={inf['n_levels']}  {calls / best * 1e3:10.3e} rule-calls/s  "
               f"{inf['bytes_per_sweep'] * R / best * 1e-6:8.1f} GB/s", flush=True)

@@ -287,6 +287,35 @@ def test_precision_parametrised_chains_are_the_covariance_form():
     assert ei.value.status == _lib.ERR_BADARG and "not symmetric" in str(ei.value)
 
 
+def test_accepted_asymmetry_of_a_constant_precision_is_reported():
+    """below the round-off bound (1e-8·max|W|) the symmetric part is what gets inverted — and rxhip_lowering_asymmetry() says how far the input was
+    from symmetric, so that a caller can hold a tighter line"""
+    mdl = workloads.random_model(3, 2, seed=4)
+
+    def chain_with_precision(eps):
+        gb, xs, ys = graph.lgssm_graph(4, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+        for f, t in enumerate(gb.ftype):
+            if t == _lib.NODE_MVNORMAL_MEAN_COV and np.asarray(gb.const_value(gb.fiface[f][2])).shape == (3, 3):
+                W = np.linalg.inv(np.asarray(gb.const_value(gb.fiface[f][2])))
+                W = 0.5 * (W + W.T)
+                W[0, 1] += eps * np.max(np.abs(W))
+                it = list(gb.fiface[f])
+                it[2] = gb.constvar(W)
+                gb.fiface[f] = tuple(it)
+                gb.ftype[f] = _lib.NODE_MVNORMAL_MEAN_PRECISION
+                break
+        return gb
+    low0 = graph.lower_lgssm(chain_with_precision(0.0).tables()[0])
+    assert graph.lowering_asymmetry() == 0.0
+    low = graph.lower_lgssm(chain_with_precision(3e-10).tables()[0])
+    assert graph.lowering_asymmetry() == pytest.approx(3e-10, rel=1e-3)
+    assert np.allclose(low["P"], low0["P"], rtol=1e-8) and np.array_equal(low["P"][0], low["P"][0].T)
+    graph.lower_lgssm(chain_with_precision(0.0).tables()[0])
+    assert graph.lowering_asymmetry() == 0.0          # per call, not sticky
+    with pytest.raises(rxhip.RxHipError):
+        graph.lower_lgssm(chain_with_precision(1e-6).tables()[0])
+
+
 def test_identity_observation_in_a_vector_chain():
     """`y[t] ~ MvNormal(μ = x[t], Σ = Q)` without a `*` node: B = I."""
     mdl = workloads.random_model(3, 3, seed=2)
