@@ -26,7 +26,7 @@
 #include "graph_lowering.hpp"  // last_asymmetry
 #include "launch_tables.hpp"   // hook_env
 #include "tree_kernels.hpp"
-#include "tree_wave_kernels.hpp"
+#include "tree_wave.hpp"
 
 namespace rxhip {
 namespace tree {
@@ -835,6 +835,24 @@ rxhip_status zalloc(double** dst, long long doubles, std::string& err) {
     TCHK(hipMemset(*dst, 0, sizeof(double) * n));
     return RXHIP_OK;
 }
+// per-replica free energy = term[root]; total over replicas in a fixed order (one workgroup, pairwise tree over a fixed layout)
+__global__ void __launch_bounds__(256) k_tree_fe_total(const double* __restrict__ term, long long root, long long R, long long RS, double* __restrict__ per_replica, double* __restrict__ total) {
+    __shared__ double sh[256];
+    double s = 0.0;
+    for (long long r = threadIdx.x; r < R; r += 256) {
+        const double v = term[root * RS + r];
+        if (per_replica) per_replica[r] = v;
+        s += v;
+    }
+    sh[threadIdx.x] = s;
+    __syncthreads();
+    for (int h = 128; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = sh[0];
+}
+
 TreeParams params_of(const Engine* e, int want_fe) {
     TreeParams p{};
     p.ops = e->d_ops; p.aux = e->d_aux; p.cpool = e->d_cpool; p.msg = e->d_msg; p.marg = e->d_marg; p.val = e->d_val; p.prec = e->d_prec;
@@ -860,28 +878,24 @@ void launch_phase(const Engine* e, const TreeParams& p, int l0, int l1) {
         }
     }
 }
-// dimensions above 8 (tree_wave_kernels.hpp): a wavefront per (op, replica) and level, or — mode 2 — a wavefront per replica over the whole range
-template <int PHASE>
-void launch_wave_phase(const Engine* e, const TreeParams& p, int l0, int l1) {
+// dimensions above 8 (tree_wave_kernels.hpp, a translation unit per dimension class): a wavefront per (op, replica) and level, or — mode 2 — a wavefront
+// per replica over the whole range
+void launch_wave_phase(const Engine* e, const TreeParams& p, int phase, int l0, int l1) {
     if (l1 <= l0) return;
     const int dmax = e->prog.dmax;
-    const size_t lds = wave::lds_bytes(dmax);
+    const wave::WaveVtbl* vt = wave::wave_vt(dmax);
     if (e->mode == 2) {
-        const unsigned blocks = (unsigned)std::min<long long>(e->R, 1 << 20);
-        hipLaunchKernelGGL((wave::k_wave_walk<PHASE>), dim3(blocks), dim3(64), lds, e->stream, p, e->prog.lvl_ptr[l0], e->prog.lvl_ptr[l1], dmax);
+        vt->walk(phase, p, e->prog.lvl_ptr[l0], e->prog.lvl_ptr[l1], dmax, (unsigned)std::min<long long>(e->R, 1 << 20), e->stream);
         return;
     }
     for (int l = l0; l < l1; ++l) {
         const int o0 = e->prog.lvl_ptr[l], o1 = e->prog.lvl_ptr[l + 1];
         if (o1 == o0) continue;
-        const unsigned blocks = (unsigned)std::min<long long>((long long)(o1 - o0) * e->R, 1 << 20);
-        hipLaunchKernelGGL((wave::k_wave_ops<PHASE>), dim3(blocks), dim3(64), lds, e->stream, p, o0, o1, dmax);
+        vt->ops(phase, p, o0, o1, dmax, (unsigned)std::min<long long>((long long)(o1 - o0) * e->R, 1 << 20), e->stream);
     }
 }
-rxhip_status wave_attributes(int dmax, std::string& err) {   // dynamic LDS above the default 64 KB limit (per device: the attribute lives with the loaded code object)
-    const int bytes = (int)wave::lds_bytes(dmax);
-    for (const void* f : {(const void*)wave::k_wave_ops<0>, (const void*)wave::k_wave_ops<1>, (const void*)wave::k_wave_walk<0>, (const void*)wave::k_wave_walk<1>})
-        TCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, std::max(bytes, 64 * 1024)));
+rxhip_status wave_attributes(int dmax, std::string& err) {
+    TCHK(wave::wave_vt(dmax)->prepare(dmax));
     return RXHIP_OK;
 }
 template <int N>
@@ -893,8 +907,8 @@ void launch_levels(const Engine* e, const TreeParams& p, int l0, int l1) {   // 
 void launch(const Engine* e, const TreeParams& p, int l0, int l1) {
     if (e->prog.dmax > 8) {
         const int lf = e->prog.fe_level;
-        launch_wave_phase<0>(e, p, l0, std::min(l1, lf));
-        launch_wave_phase<1>(e, p, std::max(l0, lf), l1);
+        launch_wave_phase(e, p, 0, l0, std::min(l1, lf));
+        launch_wave_phase(e, p, 1, std::max(l0, lf), l1);
         return;
     }
     switch (e->prog.dmax) {
@@ -1253,7 +1267,7 @@ rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
     const unsigned blocks = (unsigned)std::min<long long>((R + 255) / 256, 1 << 20);
     if (dmax > 8 && (st = wave_attributes(dmax, err))) { freeall(); return st; }
     for (int o = 0; o < 2; ++o) {
-        if (dmax > 8) hipLaunchKernelGGL((wave::k_wave_ops<0>), dim3((unsigned)std::min<long long>(R, 1 << 20)), dim3(64), wave::lds_bytes(dmax), 0, p, o, o + 1, dmax);
+        if (dmax > 8) wave::wave_vt(dmax)->ops(0, p, o, o + 1, dmax, (unsigned)std::min<long long>(R, 1 << 20), nullptr);
         else if (N == 1) hipLaunchKernelGGL((k_tree_ops<1, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
         else if (N == 2) hipLaunchKernelGGL((k_tree_ops<2, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);
         else if (N == 4) hipLaunchKernelGGL((k_tree_ops<4, 0>), dim3(blocks), dim3(256), 0, 0, p, o, o + 1);

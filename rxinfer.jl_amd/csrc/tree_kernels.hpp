@@ -689,23 +689,5 @@ __global__ void __launch_bounds__(64) k_tree_walk(TreeParams p, int op0, int op1
     if (r >= p.R) return;
     for (int o = op0; o < op1; ++o) eval_op<N, PHASE>(p, p.ops + (size_t)o * OP_WORDS, r);
 }
-// per-replica free energy = term[root]; total over replicas in a fixed order (one workgroup, pairwise tree over a fixed layout)
-__global__ void __launch_bounds__(256) k_tree_fe_total(const double* __restrict__ term, long long root, long long R, long long RS, double* __restrict__ per_replica, double* __restrict__ total) {
-    __shared__ double sh[256];
-    double s = 0.0;
-    for (long long r = threadIdx.x; r < R; r += 256) {
-        const double v = term[root * RS + r];
-        if (per_replica) per_replica[r] = v;
-        s += v;
-    }
-    sh[threadIdx.x] = s;
-    __syncthreads();
-    for (int h = 128; h > 0; h >>= 1) {
-        if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = sh[0];
-}
-
 }  // namespace tree
 }  // namespace rxhip

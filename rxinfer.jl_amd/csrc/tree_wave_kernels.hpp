@@ -19,7 +19,9 @@ namespace tree {
 namespace wave {
 
 constexpr int NBUF = 4, NVEC = 8;
+#ifdef RXHIP_HOST_EMUL
 constexpr int DMAX_WAVE = 64;
+#endif
 
 #ifdef RXHIP_HOST_EMUL
 constexpr int WL = 1;
@@ -61,20 +63,28 @@ __device__ __forceinline__ Ctx make_ctx(int dmax) {
     return c;
 }
 
+// f(i, j) for every element of a rows×cols block, element e = i·cols + j on lane e mod 64: ONE integer division per call — the (i, j) of a lane's next
+// element follow from the last by adding (64 div cols, 64 mod cols) with a carry (a division per element was most of the VALU work of an inverse)
 template <class F>
 __device__ __forceinline__ void each(const Ctx& c, int rows, int cols, F f) {
-    for (int e = c.lane; e < rows * cols; e += WL) {
-        const int i = e / cols;
-        f(i, e - i * cols);
+    const int qi = WL / cols, qj = WL - qi * cols;
+    int i = c.lane / cols, j = c.lane - i * cols;
+    while (i < rows) {
+        f(i, j);
+        i += qi;
+        j += qj;
+        if (j >= cols) {
+            j -= cols;
+            ++i;
+        }
     }
 }
-// (i, j), j <= i, of the e-th element of a packed lower triangle
-__device__ __forceinline__ void tri_index(int e, int& i, int& j) {
-    int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-    while ((r + 1) * (r + 2) / 2 <= e) ++r;
-    while (r * (r + 1) / 2 > e) --r;
-    i = r;
-    j = e - r * (r + 1) / 2;
+// f(i, j, e) for every element of a packed lower triangle (j <= i, e = i(i+1)/2 + j): the square's walk above, upper half skipped
+template <class F>
+__device__ __forceinline__ void each_tri(const Ctx& c, int d, F f) {
+    each(c, d, d, [&](int i, int j) {
+        if (j <= i) f(i, j, i * (i + 1) / 2 + j);
+    });
 }
 
 __device__ __forceinline__ void l_vec(const Ctx& c, int v, const double* b, long long off, int d, long long RS, long long r) {
@@ -88,21 +98,15 @@ __device__ __forceinline__ void s_vec(const Ctx& c, double* b, long long off, in
 }
 __device__ __forceinline__ void l_sym(const Ctx& c, int M, const double* b, long long off, int d, long long RS, long long r) {
     const int LD = c.LD;
-    for (int e = c.lane; e < d * (d + 1) / 2; e += WL) {
-        int i, j;
-        tri_index(e, i, j);
+    each_tri(c, d, [&](int i, int j, int e) {
         const double x = b[(off + e) * RS + r];
         wlds[M + i * LD + j] = x;
         wlds[M + j * LD + i] = x;
-    }
+    });
 }
 __device__ __forceinline__ void s_sym(const Ctx& c, double* b, long long off, int d, long long RS, long long r, int M) {
     const int LD = c.LD;
-    for (int e = c.lane; e < d * (d + 1) / 2; e += WL) {
-        int i, j;
-        tri_index(e, i, j);
-        b[(off + e) * RS + r] = 0.5 * (wlds[M + i * LD + j] + wlds[M + j * LD + i]);
-    }
+    each_tri(c, d, [&](int i, int j, int e) { b[(off + e) * RS + r] = 0.5 * (wlds[M + i * LD + j] + wlds[M + j * LD + i]); });
 }
 __device__ __forceinline__ void l_full(const Ctx& c, int M, const double* b, long long off, int d, long long RS, long long r) {
     const int LD = c.LD;
@@ -130,7 +134,7 @@ __device__ __forceinline__ void add_vec(const Ctx& c, int dst, int src, int d, d
 }
 
 // in place: A ← A⁻¹ of a symmetric positive definite d×d tile; log|A|; false: a pivot ≤ 0 or not finite.  Scratch: vectors 6 and 7
-__device__ __forceinline__ bool spd_inv(const Ctx& c, int A, int d, double& logdet) {
+__device__ __forceinline__ bool spd_inv_lds(const Ctx& c, int A, int d, double& logdet) {
     const int LD = c.LD, rk = c.v(6), ck = c.v(7);
     bool ok = true;
     double ld = 0.0;
@@ -155,6 +159,90 @@ __device__ __forceinline__ bool spd_inv(const Ctx& c, int A, int d, double& logd
     }
     logdet = ld;
     return ok;
+}
+#ifndef RXHIP_HOST_EMUL
+// the same sweep with the matrix in REGISTERS: the 64 lanes form an 8×8 grid, lane (bi, bj) holds the B×B block at (bi·B, bj·B) of the matrix padded to
+// 8B with the identity; per pivot the owners publish row k and column k (2·8B doubles of LDS traffic instead of the 3 reads and 1 write per ELEMENT of the
+// sweep above — at d = 32 a wavefront is alone on its SIMD and the inverse was a chain of ≈ 64 dependent LDS instructions per pivot).  d ≤ 8B
+template <int B>
+__device__ __forceinline__ bool spd_inv_blk(const Ctx& c, int A, int d, double& logdet) {
+    const int LD = c.LD, rk = c.v(6), ck = c.v(7);
+    const int bi = c.lane >> 3, bj = c.lane & 7, i0 = bi * B, j0 = bj * B;
+    double a[B][B];
+#pragma unroll
+    for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+            const int i = i0 + p, j = j0 + q;
+            a[p][q] = (i < d && j < d) ? wlds[A + i * LD + j] : (i == j ? 1.0 : 0.0);
+        }
+    bool ok = true;
+    double ld = 0.0;
+    for (int k = 0; k < d; ++k) {
+        const int kb = k / B, kl = k - kb * B;
+        if (bi == kb) {
+#pragma unroll
+            for (int q = 0; q < B; ++q) {
+                double v = a[0][q];
+#pragma unroll
+                for (int p = 1; p < B; ++p) v = (kl == p) ? a[p][q] : v;
+                if (j0 + q < d) wlds[rk + j0 + q] = v;
+            }
+        }
+        if (bj == kb) {
+#pragma unroll
+            for (int p = 0; p < B; ++p) {
+                double v = a[p][0];
+#pragma unroll
+                for (int q = 1; q < B; ++q) v = (kl == q) ? a[p][q] : v;
+                if (i0 + p < d) wlds[ck + i0 + p] = v;
+            }
+        }
+        w_sync();
+        const double pv = wlds[rk + k];
+        ok = ok && (pv > 0.0) && (pv < 1.0e300);
+        ld += log(pv);
+        const double ip = 1.0 / pv;
+        double rr[B], cc[B];
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+            rr[q] = (j0 + q < d) ? wlds[rk + j0 + q] : 0.0;
+            cc[q] = (i0 + q < d) ? wlds[ck + i0 + q] : 0.0;
+        }
+#pragma unroll
+        for (int p = 0; p < B; ++p)
+#pragma unroll
+            for (int q = 0; q < B; ++q) {
+                const int i = i0 + p, j = j0 + q;
+                double x;
+                if (i == k) x = (j == k) ? ip : rr[q] * ip;
+                else if (j == k) x = -cc[p] * ip;
+                else x = a[p][q] - cc[p] * rr[q] * ip;
+                a[p][q] = x;
+            }
+        w_sync();   // (the next pivot's row and column overwrite the scratch vectors)
+    }
+#pragma unroll
+    for (int p = 0; p < B; ++p)
+#pragma unroll
+        for (int q = 0; q < B; ++q)
+            if (i0 + p < d && j0 + q < d) wlds[A + (i0 + p) * LD + j0 + q] = a[p][q];
+    w_sync();
+    logdet = ld;
+    return ok;
+}
+#endif
+// DC: the kernel instance's dimension class (16: dmax ≤ 16, 32: ≤ 32, 64) — one inverse per instance, so that the 2×2 blocks of the small class do not
+// carry the register budget of the 4×4 ones (occupancy: 16 wavefronts per CU fit the LDS at d = 16)
+template <int DC>
+__device__ __forceinline__ bool spd_inv(const Ctx& c, int A, int d, double& logdet) {
+#ifndef RXHIP_HOST_EMUL
+    if (DC <= 16) return spd_inv_blk<2>(c, A, d, logdet);
+    if (DC <= 32) return spd_inv_blk<4>(c, A, d, logdet);
+    return spd_inv_blk<8>(c, A, d, logdet);   // (128 VGPRs of matrix: the one wavefront a CU's LDS holds at this size has the SIMD's 512 to itself)
+#else
+    return spd_inv_lds(c, A, d, logdet);
+#endif
 }
 // y = op(M) x: element (i, k) of op(M) at M + i·si + k·sk; y must not be x
 __device__ __forceinline__ void matvec(const Ctx& c, int y, int M, int si, int sk, int x, int rows, int cols) {
@@ -213,21 +301,19 @@ __device__ __forceinline__ void matmul(const Ctx& c, int C, int A, bool ta, int 
 __device__ __forceinline__ double trace_prod(const Ctx& c, int A, int B, int d) {
     const int LD = c.LD;
     double s = 0.0;
-    for (int e = c.lane; e < d * d; e += WL) {
-        const int i = e / d, k = e - i * d;
-        s += wlds[A + i * LD + k] * wlds[B + k * LD + i];
-    }
+    each(c, d, d, [&](int i, int k) { s += wlds[A + i * LD + k] * wlds[B + k * LD + i]; });
     return w_sum(s);
 }
 
 // a message in the form a rule wants, vector → v, matrix → M; a conversion is one inverse (in place) and one product (through vector 5)
+template <int DC>
 __device__ __forceinline__ bool load_msg(const Ctx& c, const TreeParams& p, int off, bool stored_wp, bool want_wp, int d, long long r, int v, int M) {
     l_vec(c, v, p.msg, off, d, p.RS, r);
     l_sym(c, M, p.msg, off + d, d, p.RS, r);
     w_sync();
     if (stored_wp == want_wp) return true;
     double ld;
-    const bool ok = spd_inv(c, M, d, ld);
+    const bool ok = spd_inv<DC>(c, M, d, ld);
     const int t = c.v(5);
     matvec(c, t, M, c.LD, 1, v, d, d);
     for (int i = c.lane; i < d; i += WL) wlds[v + i] = wlds[t + i];
@@ -261,6 +347,7 @@ __device__ __forceinline__ void load_value(const Ctx& c, const TreeParams& p, in
 }
 
 // the sweep (ops up to OP_MARGINAL): the rules of tree_kernels.hpp's eval_bp, op for op
+template <int DC>
 __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const int* __restrict__ w, long long r) {
     const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS], LD = c.LD;
     const int M0 = c.M(0), M1 = c.M(1), M2 = c.M(2), M3 = c.M(3);
@@ -293,7 +380,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
     } break;
     case OP_NOISE: {
         const bool wp = fl & F_IN0_WP;
-        ok = load_msg(c, p, w[W_IN0], wp, wp, d, r, v0, M0);
+        ok = load_msg<DC>(c, p, w[W_IN0], wp, wp, d, r, v0, M0);
         load_noise(c, p, w, d, r, !wp, M1);
         if (!wp) {
             add_mat(c, M0, M1, d, 1.0);
@@ -303,7 +390,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
             each(c, d, d, [&](int i, int j) { wlds[M2 + i * LD + j] = wlds[M0 + i * LD + j] + wlds[M1 + i * LD + j]; });
             w_sync();
             double ld;
-            ok = spd_inv(c, M2, d, ld) && ok;
+            ok = spd_inv<DC>(c, M2, d, ld) && ok;
             matvec(c, v1, M2, LD, 1, v0, d, d);
             matvec(c, v2, M1, LD, 1, v1, d, d);
             matmul(c, M3, M2, false, M1, false, d, d, d);   // (Λ + W)⁻¹ W
@@ -313,7 +400,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
     } break;
     case OP_MUL_OUT: {
         const int d1 = w[W_D1];
-        ok = load_msg(c, p, w[W_IN0], fl & F_IN0_WP, false, d1, r, v0, M0);
+        ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, false, d1, r, v0, M0);
         l_cmat(c, M1, p.cpool + w[W_C0], d, d1);
         w_sync();
         matvec(c, v1, M1, LD, 1, v0, d, d1);
@@ -323,7 +410,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
     } break;
     case OP_MUL_IN: {
         const int d1 = w[W_D1];
-        ok = load_msg(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
+        ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
         l_cmat(c, M1, p.cpool + w[W_C0], d, d1);
         w_sync();
         matvec(c, v1, M1, 1, LD, v0, d1, d);              // Aᵀ ξ
@@ -333,8 +420,8 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
     } break;
     case OP_ADD_OUT:
     case OP_ADD_IN: {
-        ok = load_msg(c, p, w[W_IN0], fl & F_IN0_WP, false, d, r, v0, M0);
-        ok = load_msg(c, p, w[W_IN1], fl & F_IN1_WP, false, d, r, v1, M1) && ok;
+        ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, false, d, r, v0, M0);
+        ok = load_msg<DC>(c, p, w[W_IN1], fl & F_IN1_WP, false, d, r, v1, M1) && ok;
         add_vec(c, v0, v1, d, op == OP_ADD_OUT ? 1.0 : -1.0);
         add_mat(c, M0, M1, d, 1.0);
         w_sync();
@@ -342,7 +429,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
     } break;
     case OP_SHIFT: {
         const bool wp = fl & F_IN0_WP;
-        ok = load_msg(c, p, w[W_IN0], wp, wp, d, r, v0, M0);
+        ok = load_msg<DC>(c, p, w[W_IN0], wp, wp, d, r, v0, M0);
         load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v1);
         const double sg = (fl & F_NEG) ? -1.0 : 1.0;
         if (wp) {
@@ -361,7 +448,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         const int n = w[W_N];
         const int* lst = p.aux + w[W_LIST];
         for (int q = 0; q < n; ++q) {   // left to right, in factor order
-            ok = load_msg(c, p, lst[2 * q], lst[2 * q + 1] != 0, true, d, r, v1, M1) && ok;
+            ok = load_msg<DC>(c, p, lst[2 * q], lst[2 * q + 1] != 0, true, d, r, v1, M1) && ok;
             add_vec(c, v0, v1, d, 1.0);
             add_mat(c, M0, M1, d, 1.0);
             w_sync();
@@ -370,7 +457,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
             store_msg(c, p, w[W_OUT], d, r, v0, M0);
         } else {
             double ld;
-            ok = spd_inv(c, M0, d, ld) && ok;
+            ok = spd_inv<DC>(c, M0, d, ld) && ok;
             matvec(c, v2, M0, LD, 1, v0, d, d);
             s_vec(c, p.marg, w[W_OUT], d, p.RS, r, v2);
             s_sym(c, p.marg, w[W_OUT] + d, d, p.RS, r, M0);
@@ -383,6 +470,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
 }
 
 // the second phase: Bethe terms, residual moments, q(W) updates — tree_kernels.hpp's eval_fe, op for op
+template <int DC>
 __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const int* __restrict__ w, long long r) {
     const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS], LD = c.LD;
     const int M0 = c.M(0), M1 = c.M(1), M2 = c.M(2), M3 = c.M(3);
@@ -391,12 +479,12 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
     switch (op) {
     case OP_FE_NOISE2: {
         // P = Λo + W → M0, S = Λμ + W − W P⁻¹ W → M1, W → M2, P⁻¹W → M3 (see eval_fe of tree_kernels.hpp for the algebra)
-        if (w[W_IN0] >= 0) ok = load_msg(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
+        if (w[W_IN0] >= 0) ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
         else {
             zero_mat(c, M0, d);
             for (int i = c.lane; i < d; i += WL) wlds[v0 + i] = 0.0;
         }
-        if (w[W_IN1] >= 0) ok = load_msg(c, p, w[W_IN1], fl & F_IN1_WP, true, d, r, v1, M1) && ok;
+        if (w[W_IN1] >= 0) ok = load_msg<DC>(c, p, w[W_IN1], fl & F_IN1_WP, true, d, r, v1, M1) && ok;
         else {
             zero_mat(c, M1, d);
             for (int i = c.lane; i < d; i += WL) wlds[v1 + i] = 0.0;
@@ -406,10 +494,10 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         add_mat(c, M1, M2, d, 1.0);
         w_sync();
         double ldP, ldS;
-        ok = spd_inv(c, M0, d, ldP) && ok;
+        ok = spd_inv<DC>(c, M0, d, ldP) && ok;
         matmul(c, M3, M0, false, M2, false, d, d, d);                // P⁻¹ W
         matmul(c, M1, M2, true, M3, false, d, d, d, true, -1.0);     // S −= Wᵀ P⁻¹ W
-        ok = spd_inv(c, M1, d, ldS) && ok;
+        ok = spd_inv<DC>(c, M1, d, ldS) && ok;
         // m_μ = S⁻¹ (ξ_μ + W P⁻¹ ξ_o) → v4, m_o = P⁻¹ (ξ_o + W m_μ) → v3
         matvec(c, v2, M0, LD, 1, v0, d, d);
         matvec(c, v3, M2, LD, 1, v2, d, d);
@@ -466,21 +554,21 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = (double)w[W_N] * H;
     } break;
     case OP_FE_ADD2: {   // P = Λ1 + Λo → M0, S = Λ2 + Λo − Λo P⁻¹ Λo → M1, Λo → M2
-        if (w[W_IN0] >= 0) ok = load_msg(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
+        if (w[W_IN0] >= 0) ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
         else zero_mat(c, M0, d);
-        if (w[W_IN1] >= 0) ok = load_msg(c, p, w[W_IN1], fl & F_IN1_WP, true, d, r, v0, M1) && ok;
+        if (w[W_IN1] >= 0) ok = load_msg<DC>(c, p, w[W_IN1], fl & F_IN1_WP, true, d, r, v0, M1) && ok;
         else zero_mat(c, M1, d);
-        if (w[W_IN2] >= 0) ok = load_msg(c, p, w[W_IN2], fl & F_IN2_WP, true, d, r, v0, M2) && ok;
+        if (w[W_IN2] >= 0) ok = load_msg<DC>(c, p, w[W_IN2], fl & F_IN2_WP, true, d, r, v0, M2) && ok;
         else zero_mat(c, M2, d);
         w_sync();
         add_mat(c, M0, M2, d, 1.0);
         add_mat(c, M1, M2, d, 1.0);
         w_sync();
         double ldP, ldS;
-        ok = spd_inv(c, M0, d, ldP) && ok;
+        ok = spd_inv<DC>(c, M0, d, ldP) && ok;
         matmul(c, M3, M0, false, M2, false, d, d, d);
         matmul(c, M1, M2, false, M3, false, d, d, d, true, -1.0);
-        ok = spd_inv(c, M1, d, ldS) && ok;
+        ok = spd_inv<DC>(c, M1, d, ldS) && ok;
         if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
     } break;
     case OP_SUM_TERMS: {
@@ -514,7 +602,7 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         });
         w_sync();
         double ldVi;
-        ok = spd_inv(c, M3, d, ldVi);
+        ok = spd_inv<DC>(c, M3, d, ldVi);
         const double nu = nu0 + (double)n, ldV = -ldVi;
         const int ps = w[W_PREC], tri = d * (d + 1) / 2;
         const double elw = t_mvdigamma(0.5 * nu, d) + d * T_LOG2 + ldV;
@@ -539,31 +627,31 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
     if (!ok && c.lane == 0) atomicOr(p.status, 1);
 }
 
-template <int PHASE>
+template <int PHASE, int DC>
 __device__ __forceinline__ void eval_op(const Ctx& c, const TreeParams& p, const int* __restrict__ w, long long r) {
-    if (PHASE == 0) eval_bp(c, p, w, r);
-    else eval_fe(c, p, w, r);
+    if (PHASE == 0) eval_bp<DC>(c, p, w, r);
+    else eval_fe<DC>(c, p, w, r);
 }
 
 #ifndef RXHIP_HOST_EMUL
 // one launch per level: a workgroup (one wavefront) per item (op, replica); replica fastest, so that neighbouring workgroups share the 128-byte lines of a slot
-template <int PHASE>
-__global__ void __launch_bounds__(64) k_wave_ops(TreeParams p, int op0, int op1, int dmax) {
+template <int PHASE, int DC>
+__global__ void __launch_bounds__(64, DC <= 16 ? 2 : 1) k_wave_ops(TreeParams p, int op0, int op1, int dmax) {
     const Ctx c = make_ctx(dmax);
     const long long total = (long long)(op1 - op0) * p.R;
     for (long long it = blockIdx.x; it < total; it += gridDim.x) {
         const long long o = it / p.R, r = it - o * p.R;
-        eval_op<PHASE>(c, p, p.ops + (size_t)(op0 + o) * OP_WORDS, r);
+        eval_op<PHASE, DC>(c, p, p.ops + (size_t)(op0 + o) * OP_WORDS, r);
         __syncthreads();   // (one wavefront: a fence — the next item reuses the workspace)
     }
 }
 // a wavefront owns a replica and walks the ops of the range in order (every op's inputs were written by this wavefront or before the launch)
-template <int PHASE>
-__global__ void __launch_bounds__(64) k_wave_walk(TreeParams p, int op0, int op1, int dmax) {
+template <int PHASE, int DC>
+__global__ void __launch_bounds__(64, DC <= 16 ? 2 : 1) k_wave_walk(TreeParams p, int op0, int op1, int dmax) {
     const Ctx c = make_ctx(dmax);
     for (long long r = blockIdx.x; r < p.R; r += gridDim.x)
         for (int o = op0; o < op1; ++o) {
-            eval_op<PHASE>(c, p, p.ops + (size_t)o * OP_WORDS, r);
+            eval_op<PHASE, DC>(c, p, p.ops + (size_t)o * OP_WORDS, r);
             __syncthreads();   // (a workgroup-scope fence: the op's stores to global memory before the next op's loads by other lanes)
         }
 }

@@ -1,0 +1,43 @@
+// tu_tree_wave.hip — one dimension class of the executor's LDS-staged kernels (tree_wave_kernels.hpp): -DRXHIP_TU_DC=16 | 32 | 64.
+#include "tree_wave.hpp"
+#include "tree_wave_kernels.hpp"
+
+#ifndef RXHIP_TU_DC
+#error "RXHIP_TU_DC: 16, 32 or 64"
+#endif
+
+namespace rxhip {
+namespace tree {
+namespace wave {
+namespace {
+constexpr int DC = RXHIP_TU_DC;
+
+hipError_t prepare(int dmax) {
+    const int bytes = (int)lds_bytes(dmax);
+    if (bytes <= 64 * 1024) return hipSuccess;
+    for (const void* f : {(const void*)k_wave_ops<0, DC>, (const void*)k_wave_ops<1, DC>, (const void*)k_wave_walk<0, DC>, (const void*)k_wave_walk<1, DC>})
+        if (hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes)) return e;
+    return hipSuccess;
+}
+void ops(int phase, const TreeParams& p, int o0, int o1, int dmax, unsigned blocks, hipStream_t stream) {
+    if (phase == 0) hipLaunchKernelGGL((k_wave_ops<0, DC>), dim3(blocks), dim3(64), lds_bytes(dmax), stream, p, o0, o1, dmax);
+    else hipLaunchKernelGGL((k_wave_ops<1, DC>), dim3(blocks), dim3(64), lds_bytes(dmax), stream, p, o0, o1, dmax);
+}
+void walk(int phase, const TreeParams& p, int o0, int o1, int dmax, unsigned blocks, hipStream_t stream) {
+    if (phase == 0) hipLaunchKernelGGL((k_wave_walk<0, DC>), dim3(blocks), dim3(64), lds_bytes(dmax), stream, p, o0, o1, dmax);
+    else hipLaunchKernelGGL((k_wave_walk<1, DC>), dim3(blocks), dim3(64), lds_bytes(dmax), stream, p, o0, o1, dmax);
+}
+const WaveVtbl VT = {prepare, ops, walk};
+}  // namespace
+
+#if RXHIP_TU_DC == 16
+const WaveVtbl* wave_vt16() { return &VT; }
+#elif RXHIP_TU_DC == 32
+const WaveVtbl* wave_vt32() { return &VT; }
+#else
+const WaveVtbl* wave_vt64() { return &VT; }
+#endif
+
+}  // namespace wave
+}  // namespace tree
+}  // namespace rxhip

@@ -19,8 +19,8 @@ static void run_wave(const TreeParams& p, int n_ops, int dmax) {
     for (int o = 0; o < n_ops; ++o) {
         const int* w = p.ops + (size_t)o * OP_WORDS;
         for (long long r = 0; r < p.R; ++r) {
-            if (w[W_OP] <= OP_MARGINAL) wave::eval_bp(c, p, w, r);
-            else wave::eval_fe(c, p, w, r);
+            if (w[W_OP] <= OP_MARGINAL) wave::eval_bp<64>(c, p, w, r);
+            else wave::eval_fe<64>(c, p, w, r);
         }
     }
 }
