@@ -468,6 +468,35 @@ def extra_node_array(device, parity=True):
         ms, _ = timed_sweeps(ref, 10, 2)
     out["plain_chain"]["specialised_engine_ms_per_step"] = ms
     out["ms_per_step"] = out["two_branch"]["device_ms_per_step"]
+    # above d = 8 the rules run on the LDS-staged kernels (a wavefront per op and replica, csrc/tree_wave_kernels.hpp): latency-bound inside the wavefront,
+    # not an HBM roofline — reported as time and rule calls per second, with a parity spot against the generic CPU restatement
+    m16 = workloads.random_model(16, 16, seed=1616)
+    T16, R16 = 64, 256
+    gb, xs, ys = two_branch_chain_graph(T16, m16["A"], m16["B"], m16["B"][:8], m16["P"], m16["Q"], m16["Q"][:8, :8], m16["m0"], m16["V0"])
+    rows16 = np.random.default_rng(778).standard_normal((R16, T16 * 24)) * 2.0
+    with TreeEngine(gb, n_replicas=R16, device=device) as eng:
+        eng.set_data(ys, rows16)
+        eng.run(1, True)
+        dev = 1e9
+        for _ in range(5):
+            eng.run(1, True)
+            dev = min(dev, eng.last_iteration_ms())
+        line = {"workload": f"two observation branches per state (d=16, dy=16+8), T={T16}, {R16} replicas: 1 sweep + Bethe free energy, LDS-staged rule kernels",
+                "device_ms_per_step": dev, "rule_calls_per_s": eng.counters()["rule_calls"] / (dev * 1e-3), "info": eng.info}
+        if parity:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import tree_oracle
+            post, fe = eng.marginals(xs), eng.free_energy_per_replica()
+            r = R16 - 1
+            data, o = {}, 0
+            for v in ys:
+                data[v] = rows16[r, o:o + gb.rows[v]]
+                o += gb.rows[v]
+            ref = tree_oracle.infer(gb.to_dump(), data)
+            em = max(float(np.max(np.abs(post[v][0][r] - ref["mean"][v]) / np.sqrt(np.diag(ref["cov"][v])))) for v in xs)
+            ef = float(abs(fe[r] - ref["fe"][0]) / abs(ref["fe"][0]))
+            line["parity_spot"] = {"replica": r, "mean_rel": em, "fe_rel": ef, "ok": bool(em < 1e-6 and ef < 1e-8)}
+    out["two_branch_d16"] = line
     return out
 
 
