@@ -59,15 +59,23 @@ m = {"source": f"profiles/{tag}/ (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 …, sc
      "mfma_busy_cycles_per_launch": avg("SQ_VALU_MFMA_BUSY_CYCLES", "c3pmc_c", kern, last=3), "busy_cycles_per_launch": avg("SQ_BUSY_CYCLES", "c3pmc_a", kern, last=3),
      "dense_kernels_sha256": sha("dense_kernels.hpp")}
 json.dump(m, open(os.path.join(out, "mfma_insts.json"), "w"), indent=1)
-# the node-array executor: HBM bytes per launch of its kernels
-tk = ("k_tree_walk<4, 0>", "k_tree_walk<4, 1>", "k_tree_levels", "k_tree_ops")
-tf, tw = avg("FETCH_SIZE", "tree_fetch", tk), avg("WRITE_SIZE", "tree_write", tk)
-tt = {"source": f"profiles/{tag}/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, scripts/prof_tree.py 128 65536: the bench's node_array workload; per launch, sweep phase + free-energy phase averaged as rocprofv3 names them)",
-      "correction": "as traffic.json (the executor's loads are 8 B/lane unit-stride: the x2 of the guide applies to 16 B/lane streams; both figures given)",
-      "tree_kernels_sha256": sha("tree_kernels.hpp")}
+# the node-array executor: HBM bytes per launch of its kernel instances (the format bench.py reads: profiles/tree_traffic.json)
+tk = ("k_tree_walk<4, 0>", "k_tree_walk<4, 1>", "k_tree_fe_total")
+tf, tw = avg("FETCH_SIZE", "tree_fetch", tk, last=3), avg("WRITE_SIZE", "tree_write", tk, last=3)
+alg = None
+try:
+    drv = [l for l in open(os.path.join(out, "driver_tree.txt")) if l.startswith("{")][-1]
+    info = eval(drv)   # (the driver prints a Python dict)
+    alg = info["info"]["bytes_per_sweep"] * info["replicas"]
+except Exception:
+    pass
+tt = {"source": f"profiles/{tag}/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, scripts/prof_tree.py 128 65536 3: the bench's node_array workload — two observation branches per state, d = 4, T = 128, 65 536 replicas, lane-per-replica schedule; average of the last 3 launches of each kernel instance)",
+      "correction": "KiB units x1024; FETCH_SIZE as reported and x2 (the guide's gfx950 correction is for 16 B/lane streams; the executor loads 8 B/lane unit-stride): both given",
+      "algorithmic_bytes_per_sweep": alg, "tree_kernels_sha256": sha("tree_kernels.hpp"), "kernels": {}}
 for k in tk:
     if k in tf and k in tw:
-        tt[k] = {"fetch_KiB_units": tf[k], "write_KiB_units": tw[k], "hbm_bytes_per_launch_fetch_x1": tf[k] * 1024 + tw[k] * 1024, "hbm_bytes_per_launch_fetch_x2": tf[k] * 2048 + tw[k] * 1024}
+        tt["kernels"][k] = {"fetch_bytes_x1": tf[k] * 1024, "fetch_bytes_x2": tf[k] * 2048, "write_bytes": tw[k] * 1024,
+                            "hbm_bytes_per_launch_x1": tf[k] * 1024 + tw[k] * 1024, "hbm_bytes_per_launch_x2": tf[k] * 2048 + tw[k] * 1024}
 json.dump(tt, open(os.path.join(out, "tree_traffic.json"), "w"), indent=1)
 print(json.dumps(t, indent=1)); print(json.dumps(m, indent=1)); print(json.dumps(tt, indent=1))
 PY
