@@ -692,7 +692,8 @@ rxhip_status rxhip_comm_init_rank(void** comm, int32_t nranks, const char* id128
 rxhip_status rxhip_comm_destroy(void* comm);
 const char* rxhip_comm_last_error(void);
 /* after rxhip_run[_async](…, want_free_energy = 1): per_iteration free energies of the last run become the sums over all
- * ranks (asynchronous on the engine's stream; rxhip_get_free_energy afterwards returns the global values on every rank) */
+ * ranks (asynchronous on the engine's stream; rxhip_get_free_energy afterwards returns the global values on every rank).  Every engine kind,
+ * the node-array executor included: its replicas shard over the ranks like chains do, and this sum is the path's only exchange. */
 rxhip_status rxhip_allreduce_free_energy(rxhip_engine* e, void* rccl_comm);
 /* between rxhip_gmm_accumulate and rxhip_gmm_update: the statistics buffer becomes the sum over all ranks */
 rxhip_status rxhip_gmm_allreduce_statistics(rxhip_engine* e, void* rccl_comm);

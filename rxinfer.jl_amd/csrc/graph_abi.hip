@@ -106,6 +106,7 @@ rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* 
     e->kind = 5;
     e->tree = t;
     e->device = rxhip::tree::device_of(t);
+    e->stream = (hipStream_t)rxhip::tree::stream_of(t);   // (owned by the executor; the cross-GPU free-energy sum is enqueued on it)
     e->n_chains = g->n_replicas > 0 ? g->n_replicas : 1;
     *out = e;
     return RXHIP_OK;

@@ -148,8 +148,13 @@ rxhip_status rxhip_comm_destroy(void* comm) {
 }
 
 rxhip_status rxhip_allreduce_free_energy(rxhip_engine* e, void* rccl_comm) {
-    TREE_GUARD(e);
     if (!e) return RXHIP_ERR_BADARG;
+    if (e->tree) {   // the node-array executor: replicas shard over ranks with no other exchange (engine.hpp: e->stream / e->device are the executor's)
+        int its = 0;
+        double* fe = rxhip::tree::free_energy_device(e->tree, &its);
+        if (!fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
+        return ordered_allreduce(e, rccl_comm, fe, its, "allreduce_free_energy");
+    }
     if (!e->ran || !e->last_want_fe) return fail(e, RXHIP_ERR_STATE, "free energy was not requested in the last run");
     double* fe = e->kind == 1 ? e->g.d_fe : e->kind == 2 ? e->h.d_fe_total : e->d_fe_total;
     return ordered_allreduce(e, rccl_comm, fe, e->last_iterations, "allreduce_free_energy");

@@ -1628,6 +1628,12 @@ rxhip_status rxhip_release_cached_memory(void) {
 rxhip_status rxhip_destroy(rxhip_engine* e) {
     if (!e) return RXHIP_OK;
     if (e->tree) {
+        if (e->d_coll) {   // scratch of rxhip_allreduce_free_energy
+            DevGuard dg;
+            (void)dg.set(e->device);
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipFree(e->d_coll);
+        }
         rxhip::tree::destroy(e->tree);
         delete e;
         return RXHIP_OK;

@@ -1174,6 +1174,11 @@ void info(Engine* e, rxhip_tree_info* out) {
     out->last_iteration_ms = e->last_iteration_ms;
 }
 int device_of(Engine* e) { return e->device; }
+double* free_energy_device(Engine* e, int* iterations) {
+    const bool have = e->ran && e->last_want_fe;
+    if (iterations) *iterations = have ? e->last_iterations : 0;
+    return have ? e->d_fe_hist : nullptr;
+}
 void* stream_of(Engine* e) { return (void*)e->stream; }
 rxhip_status sync(Engine* e, std::string& err) {
     DevScope ds(e->device);

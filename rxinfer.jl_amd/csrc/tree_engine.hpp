@@ -25,6 +25,9 @@ void info(Engine* e, rxhip_tree_info* out);
 int device_of(Engine* e);
 void* stream_of(Engine* e);
 rxhip_status sync(Engine* e, std::string& err);
+// the per-iteration free energies of the last run where they live on the device (summed over ranks in place by rxhip_allreduce_free_energy); nullptr / 0
+// when the last run did not compute them
+double* free_energy_device(Engine* e, int* iterations);
 rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err);
 
 }  // namespace tree

@@ -41,6 +41,11 @@ class TreeEngine:
         self.info = {k: int(getattr(info, k)) for k, _ in _lib.TreeInfo._fields_ if k != "last_iteration_ms"}
         self._iters = 0
 
+    def allreduce_free_energy(self, comm):
+        """Sum the last run's per-iteration free energies over the ranks of `comm` (rxhip.Communicator), in rank order, in place on the device —
+        replicas shard over GPUs with no other exchange (include/rxhip.h rxhip_allreduce_free_energy)."""
+        self._chk(_lib.lib().rxhip_allreduce_free_energy(self._h, ctypes.c_void_p(int(getattr(comm, "handle", comm) or 0))))
+
     def last_iteration_ms(self):
         """device time of the last run ÷ its iterations"""
         info = _lib.TreeInfo()

@@ -74,3 +74,26 @@ def test_torch_nccl_backend_through_the_bench_exchange_path():
     c = _bench()
     assert a["parity_spot"]["ok"]
     assert a["free_energy_global"] == a["free_energy_rank0"] == b["free_energy_global"] == c["free_energy_rank0"]  # bit-identical
+
+
+def test_c_abi_free_energy_exchange_of_the_node_array_executor():
+    """replicas of an executor engine shard over ranks; the only exchange is the free-energy sum (one rank here: the local values, bit for bit)"""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import tree_graphs as tg
+    from rxhip.tree import TreeEngine
+    gb, ys, _ = tg.two_branch_chain(T=6)
+    data = tg.random_data(gb, ys, 9, 3)
+    with rxhip.Communicator(1, rxhip.Communicator.unique_id(), 0) as comm, TreeEngine(gb, n_replicas=9) as eng:
+        with pytest.raises(rxhip.RxHipError):
+            eng.allreduce_free_energy(comm)       # nothing has run yet
+        eng.set_data(ys, data)
+        eng.run(2, True)
+        fe0 = eng.free_energy()
+        eng.allreduce_free_energy(comm)
+        assert np.array_equal(eng.free_energy(), fe0)
+        eng.run(2, False)
+        with pytest.raises(rxhip.RxHipError):
+            eng.allreduce_free_energy(comm)       # the last run did not compute it
+
