@@ -258,10 +258,16 @@ def infer(dump, data, iterations=1, free_energy=True):
                     mo = msg_v2f(o, fi, 0)
                     if mo is None or (g.gauss[oth] and msg_v2f(oth, fi, kk) is None):
                         res = None
-                    elif g.gauss[oth]:
+                    elif g.gauss[oth] and mo.form == "mv":
                         m2, V2 = msg_v2f(oth, fi, kk).mv()
-                        mo_m, mo_V = mo.mv()
-                        res = Msg("mv", mo_m - m2, mo_V + V2)
+                        res = Msg("mv", mo.a - m2, mo.B + V2)
+                    elif g.gauss[oth]:
+                        # the message from `out` in precision form stays in it: N(m_out − m2, V_out + V2) = (ξ', Λ') with Λ' = Λo (Λo + W2)⁻¹ W2,
+                        # ξ' = W2 (Λo + W2)⁻¹ (ξo + ξ2) − ξ2 — also where Λo is rank-deficient (an observation map with fewer rows than columns behind
+                        # the `+`) and `mean_cov(m_out)`, which the reference's rule calls, does not exist
+                        x2, W2 = msg_v2f(oth, fi, kk).wp()
+                        G = np.linalg.inv(mo.B + W2)
+                        res = Msg("wp", W2 @ G @ (mo.a + x2) - x2, _sym(mo.B @ G @ W2))
                     elif mo.form == "mv":
                         res = Msg("mv", mo.a - value(oth), mo.B)
                     else:

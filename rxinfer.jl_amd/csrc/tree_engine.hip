@@ -367,7 +367,8 @@ struct Compiler {
                         form[m] = wf == 0 ? 0 : 1;
                     } else form[m] = form[deps[m][0]];
                 } else if (nclass[ed.f] == NC_MUL) form[m] = ed.k == 0 ? 0 : 1;
-                else form[m] = deps[m].size() == 2 ? 0 : form[deps[m][0]];
+                else if (deps[m].size() == 2) form[m] = ed.k == 0 ? 0 : form[deps[m][0]];   // `+`: (:out) adds moments; (:in) keeps the form of the message from `out` (deps[m][0])
+                else form[m] = form[deps[m][0]];
             }
             done[m] = 1;
             for (int u : users[m]) if (--indeg[u] == 0) q.push_back(u);
@@ -1240,7 +1241,7 @@ rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
         int* w = op(c->iface == 0 ? OP_ADD_OUT : OP_ADD_IN, dout);
         w[W_IN0] = o_in0; w[W_IN1] = o_in1; w[W_OUT] = o_rule;
         if (c->in_form) w[W_FLAGS] |= F_IN0_WP | F_IN1_WP;
-        out_wp = 0;
+        out_wp = (c->iface != 0 && c->in_form) ? 1 : 0;   // (:in) keeps the form of the message from `out`
     }
     {   // the result in the requested form: a one-message product (precision form) or marginal (mean, covariance)
         int* w = op(c->out_form ? OP_PRODUCT : OP_MARGINAL, d_res);

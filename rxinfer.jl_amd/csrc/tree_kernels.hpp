@@ -28,7 +28,7 @@ enum : int {
     OP_MUL_OUT = 5,      // typeof(*)(:out):  N(A m, A V Aᵀ)
     OP_MUL_IN = 6,       // typeof(*)(:in):   (Aᵀ ξ, Aᵀ Λ A)
     OP_ADD_OUT = 7,      // typeof(+)(:out), two random inputs:  N(m1 + m2, V1 + V2)
-    OP_ADD_IN = 8,       // typeof(+)(:in1 | :in2), the other input random:  N(m_out − m2, V_out + V2)
+    OP_ADD_IN = 8,       // typeof(+)(:in1 | :in2), the other input random:  N(m_out − m2, V_out + V2) — in the form the message from `out` has
     OP_SHIFT = 9,        // typeof(+) with a clamped input: ± the value, in the inbound message's own form
     OP_PRODUCT = 10,     // product of inbound messages at a variable (outbound variable → factor message)
     OP_MARGINAL = 11,    // product of ALL inbound messages, as (mean, cov, log det)
@@ -390,6 +390,30 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
     } break;
     case OP_ADD_OUT:
     case OP_ADD_IN: {
+        if (op == OP_ADD_IN && (fl & F_IN0_WP)) {
+            // the message from `out` in precision form (ξo, Λo), the other input as (ξ2, W2): Λ' = Λo (Λo + W2)⁻¹ W2, ξ' = W2 (Λo + W2)⁻¹ (ξo + ξ2) − ξ2 —
+            // N(m_out − m2, V_out + V2) wherever V_out exists, and defined for a rank-deficient Λo (an observation map with fewer rows than columns
+            // behind the `+`), where the moment form — and the reference's rule — is not
+            double xo[N], Lo[N][N], x2[N], W2[N][N];
+            ok = load_msg<N>(p, w[W_IN0], true, true, d, r, xo, Lo);
+            ok = load_msg<N>(p, w[W_IN1], fl & F_IN1_WP, true, d, r, x2, W2) && ok;
+            double G[N][N], Gi[N][N], t[N], s[N], xn[N], T1[N][N], Ln[N][N], ld;
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                s[i] = xo[i] + x2[i];
+#pragma unroll
+                for (int j = 0; j < N; ++j) G[i][j] = Lo[i][j] + W2[i][j] - ((i >= d && i == j) ? 1.0 : 0.0);   // (both pads are 1 on the diagonal: keep one)
+            }
+            ok = spd_inv<N>(G, Gi, ld) && ok;
+            matvec<N>(Gi, s, t);
+            matvec<N>(W2, t, xn);
+#pragma unroll
+            for (int i = 0; i < N; ++i) xn[i] -= x2[i];
+            matmul<N>(Gi, W2, T1);
+            matmul<N>(Lo, T1, Ln);
+            store_msg<N>(p, w[W_OUT], d, r, xn, Ln);
+            break;
+        }
         double a0[N], V0[N][N], a1[N], V1[N][N];
         ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, false, d, r, a0, V0);
         ok = load_msg<N>(p, w[W_IN1], fl & F_IN1_WP, false, d, r, a1, V1) && ok;

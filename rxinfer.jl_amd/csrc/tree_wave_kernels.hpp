@@ -420,6 +420,22 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
     } break;
     case OP_ADD_OUT:
     case OP_ADD_IN: {
+        if (op == OP_ADD_IN && (fl & F_IN0_WP)) {   // precision form in, precision form out (tree_kernels.hpp): Λ' = Λo (Λo + W2)⁻¹ W2, ξ' = W2 (Λo + W2)⁻¹ (ξo + ξ2) − ξ2
+            ok = load_msg<DC>(c, p, w[W_IN0], true, true, d, r, v0, M0);
+            ok = load_msg<DC>(c, p, w[W_IN1], fl & F_IN1_WP, true, d, r, v1, M1) && ok;
+            each(c, d, d, [&](int i, int j) { wlds[M2 + i * LD + j] = wlds[M0 + i * LD + j] + wlds[M1 + i * LD + j]; });
+            add_vec(c, v0, v1, d, 1.0);
+            w_sync();
+            double ld;
+            ok = spd_inv<DC>(c, M2, d, ld) && ok;
+            matvec(c, v2, M2, LD, 1, v0, d, d);
+            matvec(c, v0, M1, LD, 1, v2, d, d);
+            add_vec(c, v0, v1, d, -1.0);
+            matmul(c, M3, M2, false, M1, false, d, d, d);   // (Λo + W2)⁻¹ W2
+            matmul(c, M2, M0, false, M3, false, d, d, d);   // Λo (Λo + W2)⁻¹ W2
+            store_msg(c, p, w[W_OUT], d, r, v0, M2);
+            break;
+        }
         ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, false, d, r, v0, M0);
         ok = load_msg<DC>(c, p, w[W_IN1], fl & F_IN1_WP, false, d, r, v1, M1) && ok;
         add_vec(c, v0, v1, d, op == OP_ADD_OUT ? 1.0 : -1.0);

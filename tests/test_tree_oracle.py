@@ -104,3 +104,18 @@ def test_state_noise_vmp_free_energy_decreases():
     fe = np.array(res["fe"])
     assert np.all(np.diff(fe) <= 1e-9 * np.abs(fe[:-1])), fe
     assert np.isfinite(fe).all()
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_random_forests_against_brute_force(seed):
+    """random acyclic graphs with constant noise parameters (tests/tree_graphs.py::random_forest): the generic restatement against the joint Gaussian
+    conditioned on the data — every named posterior and the Bethe free energy (= −log evidence on a tree)"""
+    gb, ys, named = tg.random_forest(seed, n_steps=12, dmax=5 if seed % 3 else 12)
+    data = tg.data_dict(gb, ys, tg.random_data(gb, ys, 1, seed)[0])
+    ref = tree_oracle.infer(gb.to_dump(), data)
+    post, nle = tg.brute_force(gb, data)
+    for v in named["x"]:
+        sd = np.sqrt(np.diag(post[v][1]))
+        assert np.max(np.abs(ref["mean"][v] - post[v][0]) / sd) < 1e-8, v
+        assert np.max(np.abs(ref["cov"][v] - post[v][1]) / np.outer(sd, sd)) < 1e-8, v
+    assert ref["fe"][0] == pytest.approx(nle, rel=1e-9, abs=1e-9)

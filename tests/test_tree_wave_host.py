@@ -213,3 +213,49 @@ def test_a_matrix_that_is_not_positive_definite_is_reported(lib):
     st.aux += [off, 1]
     assert run(lib, st, 0, d)[0] == 1
     assert run(lib, st, 1, d)[0] == 1
+
+
+@pytest.mark.parametrize("d,which", [(3, 0), (3, 1), (12, 0), (12, 1)])
+def test_backward_rule_of_plus_in_precision_form(lib, d, which):
+    """typeof(+)(:in) on a precision-form message from `out`: the same Gaussian as the moment-form rule N(m_out − m2, V_out + V2), and finite where the
+    message from `out` is rank-deficient (where it equals the limit of the proper case)"""
+    st = State(R=2, seed=9 + d)
+    rng = st.rng
+    il = np.tril_indices(d)
+    pack = lambda v, M: np.concatenate([v, M[:, il[0], il[1]]], axis=1)
+    mo, Vo, m2, V2 = rng.standard_normal((2, d)), st.spd(d), rng.standard_normal((2, d)), st.spd(d)
+    Lo, W2 = np.linalg.inv(Vo), np.linalg.inv(V2)
+    msz = d + d * (d + 1) // 2
+    a_mv, b_mv = st.slot("msg", msz, pack(mo, Vo)), st.slot("msg", msz, pack(m2, V2))
+    a_wp, b_wp = st.slot("msg", msz, pack(np.einsum("rij,rj->ri", Lo, mo), Lo)), st.slot("msg", msz, pack(np.einsum("rij,rj->ri", W2, m2), W2))
+    # a rank-deficient message from `out`: B' Q⁻¹ B of a map with one row
+    B = rng.standard_normal((1, d))
+    Ld = np.broadcast_to(B.T @ B, (2, d, d)).copy()
+    xd = rng.standard_normal((2, 1)) * B
+    a_def = st.slot("msg", msz, pack(xd, Ld))
+    outs = [st.slot("msg", msz) for _ in range(4)]
+    st.op(OP_ADD_IN, d, in0=a_mv, in1=b_mv, out=outs[0], flags=0)
+    st.op(OP_ADD_IN, d, in0=a_wp, in1=b_wp, out=outs[1], flags=F_IN0_WP | F_IN1_WP)
+    st.op(OP_ADD_IN, d, in0=a_wp, in1=b_mv, out=outs[2], flags=F_IN0_WP)
+    st.op(OP_ADD_IN, d, in0=a_def, in1=b_mv, out=outs[3], flags=F_IN0_WP)
+    status, arr = run(lib, st, which, d)
+    assert status == 0
+
+    def unpack(off):
+        blk = arr["msg"][off:off + msz, :2].T
+        M = np.zeros((2, d, d))
+        M[:, il[0], il[1]] = blk[:, d:]
+        M = M + np.transpose(np.tril(M, -1), (0, 2, 1))
+        return blk[:, :d], M
+    m_ref, V_ref = unpack(outs[0])
+    assert np.allclose(m_ref, mo - m2, rtol=1e-13) and np.allclose(V_ref, Vo + V2, rtol=1e-13)
+    for o in outs[1:3]:
+        xi, L = unpack(o)
+        V = np.linalg.inv(L)
+        assert np.allclose(V, V_ref, rtol=1e-9, atol=1e-11) and np.allclose(np.einsum("rij,rj->ri", V, xi), m_ref, rtol=1e-9, atol=1e-10)
+    # rank-deficient: against the closed form evaluated in numpy, and rank 1 as it must be (Λ' = Λo (Λo + W2)⁻¹ W2)
+    xi, L = unpack(outs[3])
+    G = np.linalg.inv(Ld + W2)
+    x2 = np.einsum("rij,rj->ri", W2, m2)
+    assert np.allclose(L, Ld @ G @ W2, rtol=1e-10, atol=1e-12) and np.allclose(xi, np.einsum("rij,rj->ri", W2 @ G, xd + x2) - x2, rtol=1e-10, atol=1e-11)
+    assert np.all(np.linalg.matrix_rank(L, tol=1e-9) == 1)

@@ -198,6 +198,96 @@ def chain_state_noise_precision(T, d=2, dy=2, seed=4, also_obs_noise=False, gamm
     return gb, ys, dict(x=xs, W=[W] + ([R] if R is not None else []))
 
 
+def random_forest(seed, n_steps=14, dmax=4, precision_vars=False, det_chains=True):
+    """A random acyclic graph of the executor's family, grown one factor group at a time from a root state: noise children (covariance or precision
+    spelling, constant or — `precision_vars` — a Wishart / Gamma variable shared by several nodes), children through `*` (rows ≤ columns: the Bethe sum
+    stays finite), through `+` with a constant or with a second random root, chains of deterministic nodes (`B (A x) + c`), observations direct or
+    through maps, a root whose mean is the sum of two data variables (a derived clamped value), unobserved leaves.  Returns (builder, data variables,
+    dict(x = named Gaussian variables, W = precision variables))."""
+    rng = np.random.default_rng(50_000 + seed)
+    gb = GraphBuilder()
+    dims = [d for d in (1, 2, 3, 4, 5, 8, 12, 20) if d <= dmax] or [1]
+    named, ys, precs = [], [], {}
+
+    def noise_node(out, mu, d):
+        """out ~ N(mu, ·): constant covariance, constant precision, or a shared precision variable of dimension d"""
+        k = rng.integers(0, 4 if precision_vars else 2)
+        if k == 0:
+            gb.mvnormal_mean_cov(out, mu, gb.constvar(_spd(rng, d, rng.uniform(0.2, 2.0)))) if d > 1 else \
+                gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, out, mu, gb.constvar(float(rng.uniform(0.2, 2.0))))
+        elif k == 1:
+            gb.node(_lib.NODE_MVNORMAL_MEAN_PRECISION, out, mu, gb.constvar(np.linalg.inv(_spd(rng, d, rng.uniform(0.2, 2.0))))) if d > 1 else \
+                gb.node(_lib.NODE_NORMAL_MEAN_PRECISION, out, mu, gb.constvar(float(rng.uniform(0.5, 3.0))))
+        else:
+            if d not in precs:
+                W = gb.randomvar(d, name=f"W{d}")
+                if d == 1 and rng.integers(0, 2):
+                    gb.node(_lib.NODE_GAMMA_SHAPE_RATE, W, gb.constvar(2.0), gb.constvar(0.5))
+                    gb.initialize(W, _lib.INIT_GAMMA, [2.0, 1.0])
+                else:
+                    gb.node(_lib.NODE_WISHART, W, gb.constvar(float(d + 2)), gb.constvar(np.eye(d) * 2.0))
+                    gb.initialize(W, _lib.INIT_WISHART, np.concatenate([[d + 2.0], np.eye(d).ravel()]))
+                precs[d] = W
+            gb.node(_lib.NODE_MVNORMAL_MEAN_PRECISION if d > 1 else _lib.NODE_NORMAL_MEAN_PRECISION, out, mu, precs[d])
+
+    def new_root(d):
+        x = gb.randomvar(d)
+        if rng.integers(0, 5) == 0:   # the mean is `a + b` of two data variables (test/models/models_tests.jl:242-256)
+            a, b, s = gb.datavar(d), gb.datavar(d), gb.randomvar(d)
+            gb.node(_lib.NODE_ADD, s, a, b)
+            ys.extend([a, b])
+            noise_node(x, s, d)
+        else:
+            gb.mvnormal_mean_cov(x, gb.constvar(rng.standard_normal(d)), gb.constvar(_spd(rng, d, 3.0)))
+        named.append(x)
+        return x
+
+    def through_map(x, rows=None):
+        d = gb.rows[x]
+        r = rows if rows is not None else int(rng.integers(1, d + 1))
+        a = gb.randomvar(r)
+        gb.multiply(a, gb.constvar(rng.standard_normal((r, d)) if (r, d) != (1, 1) else float(rng.uniform(0.5, 2.0))), x)
+        return a
+
+    def deterministic(x):
+        """x, or x through a short chain of deterministic nodes; returns the variable a noise node may take as its mean"""
+        k = rng.integers(0, 6)
+        if k == 0:
+            return x
+        a = through_map(x) if k in (1, 2, 5) else x
+        d = gb.rows[a]
+        if k in (2, 3):      # + constant (either order)
+            w = gb.randomvar(d)
+            c = gb.constvar(rng.standard_normal(d))
+            gb.node(_lib.NODE_ADD, w, a, c) if rng.integers(0, 2) else gb.node(_lib.NODE_ADD, w, c, a)
+            a = w
+        elif k == 4:         # + a second random root
+            u = gb.randomvar(d)
+            gb.mvnormal_mean_cov(u, gb.constvar(rng.standard_normal(d)), gb.constvar(_spd(rng, d, 0.5)))
+            named.append(u)
+            w = gb.randomvar(d)
+            gb.node(_lib.NODE_ADD, w, a, u) if rng.integers(0, 2) else gb.node(_lib.NODE_ADD, w, u, a)
+            a = w
+        elif k == 5 and det_chains:   # B (A x)
+            a = through_map(a)
+        return a
+
+    new_root(int(rng.choice(dims)))
+    for _ in range(n_steps):
+        x = named[int(rng.integers(0, len(named)))]
+        mean = deterministic(x)
+        d = gb.rows[mean]
+        if rng.integers(0, 2):   # an observation
+            y = gb.datavar(d)
+            noise_node(y, mean, d)
+            ys.append(y)
+        else:                    # a child state (possibly never observed: a prediction)
+            c = gb.randomvar(d)
+            noise_node(c, mean, d)
+            named.append(c)
+    return gb, ys, dict(x=named, W=list(precs.values()))
+
+
 def random_data(gb, ys, n_replicas, seed=0):
     """[replica][Σ dims of the data variables] in the order of `ys`"""
     rng = np.random.default_rng(1000 + seed)
