@@ -396,6 +396,10 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  * leaves (predictions) are part of the family; `missing` inside the data is not (the chain engines have it).
  * rxhip_create falls through to this executor for every graph the pattern matcher rejects; rxhip_tree_create asks for it directly (the tests
  * compare it with the specialised engines on the graphs both can run).
+ * Message forms: a rule keeps the form its inbound message has wherever the algebra allows — the additive rule and the backward rule of `+` (two random
+ * inputs) on a weighted-mean / precision message are Λ' = Λ (Λ + W)⁻¹ W, ξ' = W (Λ + W)⁻¹ (ξ + ξ2) − ξ2 (W: the noise precision, or the other input's,
+ * ξ2 its weighted mean, 0 for noise): the messages of the reference's rules wherever those exist, and defined for the rank-deficient backward message of an
+ * observation map with fewer rows than columns (where `mean_cov` of the reference throws).
  * Iterations (VMP): per iteration one sum-product sweep with E[W] of the current q(W), all marginals, then every q(W) update, then the free energy —
  * the order of rxhip_lgssm_noise_create above.  A run starts from the `@initialization` marginals (default: the priors).
  * ------------------------------------------------------------------------------------------ */

@@ -20,7 +20,12 @@ variable terms (src/model/plugins/reactivemp_free_energy.jl:51-126).  The rule b
 
 One deviation, stated: the additive rule applied to a message in weighted-mean / precision form uses Λ' = Λ (Λ + W)⁻¹ W, ξ' = W (Λ + W)⁻¹ ξ
 (W = Σ⁻¹) instead of inverting Λ first — the same message wherever the reference's `mean_cov` exists, and defined for the rank-deficient
-backward messages of an observation map with fewer rows than columns (the reference's cholinv throws there).
+backward messages of an observation map with fewer rows than columns (the reference's cholinv throws there).  The backward rule of `+` with two
+random inputs is the same rule with the other input as the noise: a precision-form message from `out` gives Λ' = Λo (Λo + W2)⁻¹ W2,
+ξ' = W2 (Λo + W2)⁻¹ (ξo + ξ2) − ξ2 (= N(m_out − m2, V_out + V2) wherever V_out exists): `y ~ N(b'(x + u), q)` with a row vector b is inside the family.
+
+Pinning of the generic machinery on RANDOM graphs: tests/tree_graphs.py::random_forest grows acyclic graphs out of every construct above;
+tests/test_tree_oracle.py::test_random_forests_against_brute_force holds this module to the conditioned joint Gaussian on 24 of them.
 
 Pinning.  tests/test_tree_oracle.py checks this module against (i) brute-force conditioning of the joint Gaussian (marginals, and
 free energy = −log evidence) on random trees, (ii) oracle/rxoracle.c's lgssm_bp / lgssm_noise_vmp on the state-space graphs, which are pinned to
