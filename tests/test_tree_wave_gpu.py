@@ -121,3 +121,16 @@ def test_dimension_65_is_refused_with_a_reason():
     with pytest.raises(rxhip.RxHipError) as ei:
         TreeEngine(gb, n_replicas=1)
     assert ei.value.status == _lib.ERR_UNSUPPORTED and "64" in str(ei.value)
+
+
+@pytest.mark.parametrize("seed,dmax,mode", [(100, 33, 0), (101, 48, 2), (102, 64, 0), (103, 64, 2), (104, 33, 2), (105, 48, 0)])
+def test_random_forests_at_large_dimensions(seed, dmax, mode, monkeypatch):
+    """tests/tree_graphs.py::random_forest with dimensions up to 64 (odd seeds: shared precision variables, 2 VMP iterations) against the oracle"""
+    prec = seed % 2 == 1
+    its = 2 if prec else 1
+    gb, ys, named = tg.random_forest(seed, n_steps=8, dmax=dmax, precision_vars=prec)
+    R = 2
+    eng, data = _run(gb, ys, R, iterations=its, mode=mode, monkeypatch=monkeypatch, seed=seed)
+    assert eng.info["mode"] == mode
+    _check(gb, ys, eng, data, iterations=its, replicas=(0, R - 1), prec_vars=named["W"], tol=1e-8, tol_fe=1e-9)
+    eng.close()

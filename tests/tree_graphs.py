@@ -206,7 +206,7 @@ def random_forest(seed, n_steps=14, dmax=4, precision_vars=False, det_chains=Tru
     dict(x = named Gaussian variables, W = precision variables))."""
     rng = np.random.default_rng(50_000 + seed)
     gb = GraphBuilder()
-    dims = [d for d in (1, 2, 3, 4, 5, 8, 12, 20) if d <= dmax] or [1]
+    dims = [d for d in (1, 2, 3, 4, 5, 8, 12, 20, 33, 48, 64) if d <= dmax] or [1]
     named, ys, precs = [], [], {}
 
     def noise_node(out, mu, d):
