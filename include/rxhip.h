@@ -76,7 +76,8 @@ extern "C" {
  * point, entry by entry — 1e-8 of the entry's scale at rho = 1 - 3e-6, a mixing time of 3e5 steps.  Recursions that slow do not repeat that closely
  * inside a supported chain length and are simply computed in full.  tests/test_fixed_point_adversarial_gpu.py holds the sweeps to the contract
  * (1e-6 / 1e-8 against the CPU oracle, 1e-7 against the full recursion) on block models six decades apart with a slowly mixing small block and on
- * near-unit-root states; RXHIP_ELEM_FULL / RXHIP_NO_FROZEN switch the exits off.
+ * near-unit-root states; rxhip_set_fixed_point_exits(engine, 0) switches the exits of an engine's sweeps off (RXHIP_ELEM_FULL / RXHIP_NO_FROZEN: the same for
+ * every engine of a process, test hooks).
  * ------------------------------------------------------------------------------------------ */
 typedef struct rxhip_engine rxhip_engine;
 typedef int32_t rxhip_status;
@@ -745,6 +746,11 @@ rxhip_status rxhip_get_create_stages(rxhip_engine* e, double* ms4);
  *   joints) — at most once until the next run that rewrites it; means and free energy are unaffected.  Every other engine ignores the
  *   mode.  (d = 8 × 1024 chains × T = 1000: 0.56 -> 0.40 ms per sweep; the per-chain copies are 30 % of it.) */
 rxhip_status rxhip_set_covariance_mode(rxhip_engine* e, int32_t mode);
+/* The fixed-point exits of the sweeps ("Fixed-point exits" at the top of this file) per engine.  enabled = 0: every recursion of every later sweep of this
+ * engine runs in full to the end of every segment — no frozen stretches on the MFMA path, no mean-only records / early exits of the per-chain d, dy ≤ 4
+ * kernels (what RXHIP_NO_FROZEN / RXHIP_ELEM_FULL do under the test hooks, as an API a host can rely on); 1: the default.  The model tables an engine was
+ * created with (built once per model, shared between engines) keep their own convergence tests.  State-space engines; others: RXHIP_ERR_UNSUPPORTED. */
+rxhip_status rxhip_set_fixed_point_exits(rxhip_engine* e, int32_t enabled);
 /* the hipStream_t the engine launches on */
 rxhip_status rxhip_get_stream(rxhip_engine* e, void** stream);
 /* the number of time segments the schedule uses and their length */

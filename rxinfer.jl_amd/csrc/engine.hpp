@@ -38,6 +38,7 @@ struct rxhip_engine_life {
     int cov_mode = 0;                // rxhip_set_covariance_mode (see below)
     bool cov_pending = false, cov_current = false;
     bool noise_continue = false;     // rxhip_lgssm_noise_continue: runs go on from the current q(W) (iteration-at-a-time drivers)
+    bool full_recursions = false;    // rxhip_set_fixed_point_exits(e, 0): every recursion of a sweep in full (no frozen stretches, full records)
     // results bookkeeping
     int last_iterations = 0;
     bool last_want_fe = false;

@@ -3110,7 +3110,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
     const bool noise_in_sweep = e->noise && !e->dense && e->S > 0 && !filter && !hook_env("RXHIP_NOISE_MOMENTS_PASS");
     p.noise_B = noise_in_sweep ? e->n_B : nullptr;
     p.noise_part = noise_in_sweep ? e->n_part : nullptr;
-    p.elem_full = hook_env("RXHIP_ELEM_FULL") ? 1 : 0;
+    p.elem_full = (e->full_recursions || hook_env("RXHIP_ELEM_FULL")) ? 1 : 0;
     // per-chain, time-invariant models on long segments: mean-only forward records behind the fixed point of V_f (k_forward_tinv / k_backward_tinv)
     // (any segment length: interior segments start ON the fixed point; an unknown-noise engine's models are time-invariant within a sweep, and its
     //  separate moment pass — the test hook — reads posteriors, not records)
@@ -3138,7 +3138,7 @@ static rxhip_status run_impl(rxhip_engine* e, int32_t iterations, int32_t want_f
         dp.scanm = e->d_scanm; dp.elem = e->d_elem; dp.fstart_m = e->d_fstart_m; dp.beta_xi = e->d_beta_xi;
         dp.fe_part = e->d_fe_part; dp.status = e->d_status;
         dp.filter = p.filter;
-        dp.no_frozen = hook_env("RXHIP_NO_FROZEN") ? 1 : 0;
+        dp.no_frozen = (e->full_recursions || hook_env("RXHIP_NO_FROZEN")) ? 1 : 0;
     }
     NoiseParams np{};
     if (e->noise) {   // a run starts from the @initialization marginal of W (iterations re-push the data: batch.jl:391-430)
@@ -3351,6 +3351,13 @@ rxhip_status rxhip_set_covariance_mode(rxhip_engine* e, int32_t mode) {
     if (mode != 0 && mode != 1) return fail(e, RXHIP_ERR_BADARG, "set_covariance_mode: mode must be 0 (every sweep) or 1 (on request)");
     if (rxhip_status st = ensure_cov(e)) return st;
     e->cov_mode = mode;
+    return RXHIP_OK;
+}
+rxhip_status rxhip_set_fixed_point_exits(rxhip_engine* e, int32_t enabled) {
+    TREE_GUARD(e);   // (the executor has no such exits: every rule of its schedule is evaluated)
+    if (!e) return RXHIP_ERR_BADARG;
+    if (enabled != 0 && enabled != 1) return fail(e, RXHIP_ERR_BADARG, "set_fixed_point_exits: 0 (every recursion in full) or 1 (default)");
+    e->full_recursions = enabled == 0;
     return RXHIP_OK;
 }
 rxhip_status rxhip_sync(rxhip_engine* e) {

@@ -415,6 +415,10 @@ function create_stages(e::Engine)
     return (tables_host_ms = ms[1], tables_device_ms = ms[2], upload_ms = ms[3], alloc_ms = ms[4])
 end
 
+"false: every recursion of the engine's later sweeps in full — no frozen stretches, no early exits (include/rxhip.h rxhip_set_fixed_point_exits)"
+set_fixed_point_exits!(e::Engine, enabled::Bool) =
+    check(e, ccall((:rxhip_set_fixed_point_exits, librxhip), Int32, (Ptr{Cvoid}, Int32), e.handle, Int32(enabled ? 1 : 0)))
+
 "0: every sweep writes the covariance of every chain (default); 1: shared-model batches on the MFMA path write the per-chain array on request"
 set_covariance_mode!(e::Engine, mode::Integer) =
     check(e, ccall((:rxhip_set_covariance_mode, librxhip), Int32, (Ptr{Cvoid}, Int32), e.handle, Int32(mode)))

@@ -190,6 +190,7 @@ SYMBOLS = [
     ("rxhip_get_model_tables_ms", ctypes.c_int32, [_H, c_double_p]),
     ("rxhip_get_create_stages", ctypes.c_int32, [_H, c_double_p]),
     ("rxhip_set_covariance_mode", ctypes.c_int32, [_H, ctypes.c_int32]),
+    ("rxhip_set_fixed_point_exits", ctypes.c_int32, [_H, ctypes.c_int32]),
     ("rxhip_reset_kernel_times", ctypes.c_int32, [_H]),
     ("rxhip_get_stream", ctypes.c_int32, [_H, ctypes.POINTER(ctypes.c_void_p)]),
     ("rxhip_get_schedule", ctypes.c_int32, [_H, c_int32_p, ctypes.POINTER(ctypes.c_int64)]),

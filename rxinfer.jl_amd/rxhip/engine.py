@@ -288,6 +288,10 @@ class LGSSMEngine:
         self._chk(_lib.lib().rxhip_get_create_stages(self._h, ms))
         return {"tables_host_ms": ms[0], "tables_device_ms": ms[1], "upload_ms": ms[2], "alloc_ms": ms[3]}
 
+    def set_fixed_point_exits(self, enabled):
+        """False: every recursion of this engine's later sweeps runs in full — no frozen stretches, no early exits (rxhip_set_fixed_point_exits)"""
+        self._chk(_lib.lib().rxhip_set_fixed_point_exits(self._h, 1 if enabled else 0))
+
     def set_covariance_mode(self, mode):
         """0: every sweep writes the covariance of every chain (default); 1: shared-model batches on the MFMA path write the per-chain
         array when it is asked for (rxhip_set_covariance_mode)"""

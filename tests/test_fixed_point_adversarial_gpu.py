@@ -138,3 +138,41 @@ def test_identity_like_transition_small_noise_mfma(d, monkeypatch):
     sd = np.sqrt(np.einsum("tcii->tci", cov_f))
     assert np.max(np.abs(mean - mean_f) / sd) < 1e-7, sched
     assert np.max(np.abs(cov - cov_f) / (sd[..., :, None] * sd[..., None, :])) < 1e-7, sched
+
+
+@pytest.mark.parametrize("d,per_chain", [(64, False), (4, True)])
+def test_the_exits_can_be_switched_off_per_engine(d, per_chain, monkeypatch):
+    """rxhip_set_fixed_point_exits(engine, 0) is the test hooks' RXHIP_NO_FROZEN / RXHIP_ELEM_FULL as an API: bit-identical results, and back on again"""
+    import rxhip
+    from rxhip import workloads
+    m = workloads.random_model(d, d, seed=5 + d)
+    T, C = (600, 1) if d == 64 else (4000, 64)
+    y = workloads.generate_batch(m, T, C, seed0=3)
+    hook = _run(m, y, monkeypatch, full=True, per_chain=per_chain)
+    for k in ("RXHIP_ELEM_FULL", "RXHIP_NO_FROZEN"):
+        monkeypatch.delenv(k, raising=False)
+    if per_chain:
+        mm = {k: np.repeat(np.asarray(v)[None], C, 0) for k, v in m.items()}
+        kw = dict(chain_model=np.arange(C, dtype=np.int32))
+    else:
+        mm, kw = m, {}
+    with rxhip.LGSSMEngine(mm["A"], mm["B"], mm["P"], mm["Q"], mm["m0"], mm["V0"], T=T, n_chains=C, **kw) as eng:
+        eng.set_data(y)
+        eng.run(1, True)
+        on = (eng.marginals(), eng.free_energy_per_chain())
+        eng.set_fixed_point_exits(False)
+        eng.run(1, True)
+        off = (eng.marginals(), eng.free_energy_per_chain())
+        eng.set_fixed_point_exits(True)
+        eng.run(1, True)
+        again = (eng.marginals(), eng.free_energy_per_chain())
+    assert np.array_equal(off[0][0], hook[0]) and np.array_equal(off[0][1], hook[1]) and np.array_equal(off[1], hook[2])
+    assert np.array_equal(again[0][0], on[0][0]) and np.array_equal(again[0][1], on[0][1]) and np.array_equal(again[1], on[1])
+    sd = np.sqrt(np.einsum("tcii->tci", off[0][1]))
+    assert np.max(np.abs(on[0][0] - off[0][0]) / sd) < 1e-7
+    with pytest.raises(rxhip.RxHipError):
+        eng2 = rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=8, n_chains=1)
+        try:
+            eng2._chk(rxhip._lib.lib().rxhip_set_fixed_point_exits(eng2._h, 7))
+        finally:
+            eng2.close()
