@@ -134,3 +134,67 @@ def test_random_forests_at_large_dimensions(seed, dmax, mode, monkeypatch):
     assert eng.info["mode"] == mode
     _check(gb, ys, eng, data, iterations=its, replicas=(0, R - 1), prec_vars=named["W"], tol=1e-8, tol_fe=1e-9)
     eng.close()
+
+
+@pytest.mark.parametrize("seed", range(48))
+def test_rule_eval_random_calls(seed):
+    """rxhip_rule_eval with random node types, interfaces, dimensions (1 … 64: register and LDS-staged kernels) and message forms on both sides,
+    against the rules of SURVEY Appendix A.2 evaluated in numpy"""
+    from rxhip import _lib
+    from rxhip.tree import rule_eval
+    rng = np.random.default_rng(9000 + seed)
+    n = int(rng.integers(1, 40))
+    d = int(rng.choice([1, 2, 3, 4, 5, 8, 9, 16, 20, 33, 64]))
+
+    def spd(k, s=1.0):
+        a = rng.standard_normal((n, k, k + 2))
+        return s * (a @ np.transpose(a, (0, 2, 1)) / (k + 2) + 0.4 * np.eye(k))
+
+    def give(m, V, form):     # a Gaussian (m, V) as the arrays of the requested message form
+        if form == "mv":
+            return m, V
+        L = np.linalg.inv(V)
+        return np.einsum("nij,nj->ni", L, m), L
+
+    def take(a, B, form):     # … and back to (m, V)
+        if form == "mv":
+            return a, B
+        V = np.linalg.inv(B)
+        return np.einsum("nij,nj->ni", V, a), V
+    kind = seed % 4
+    in_form, out_form = ("mv", "wp")[int(rng.integers(0, 2))], ("mv", "wp")[int(rng.integers(0, 2))]
+    m, V = rng.standard_normal((n, d)), spd(d)
+    if kind == 0:      # Gaussian node, covariance or precision parametrised, scalar spellings at d = 1
+        S = spd(d)[0]
+        prec = bool(rng.integers(0, 2))
+        t = {(False, False): _lib.NODE_MVNORMAL_MEAN_COV, (True, False): _lib.NODE_MVNORMAL_MEAN_PRECISION,
+             (False, True): _lib.NODE_NORMAL_MEAN_VARIANCE, (True, True): _lib.NODE_NORMAL_MEAN_PRECISION}[(prec, d == 1 and bool(rng.integers(0, 2)))]
+        a, B = rule_eval(t, int(rng.integers(0, 2)), np.linalg.inv(S) if prec else S, give(m, V, in_form), in_form=in_form, out_form=out_form)
+        rm, rV = m, V + S
+    elif kind == 1:    # typeof(*)(:out): rows <= columns so that either form of the result exists
+        r = int(rng.integers(1, d + 1))
+        A = rng.standard_normal((r, d))
+        a, B = rule_eval(_lib.NODE_MULTIPLY, 0, A, give(m, V, in_form), in_form=in_form, out_form=out_form)
+        rm, rV = m @ A.T, A @ V @ A.T
+    elif kind == 2:    # typeof(*)(:in): the message from `out` has the rows' dimension; the result is a precision of rank <= rows
+        r = int(rng.integers(1, d + 1))
+        A = rng.standard_normal((r, d))
+        my, Vy = rng.standard_normal((n, r)), spd(r)
+        out_form = "wp" if r < d else out_form
+        a, B = rule_eval(_lib.NODE_MULTIPLY, 2, A, give(my, Vy, in_form), in_form=in_form, out_form=out_form)
+        Ly = np.linalg.inv(Vy)
+        xi, L = np.einsum("ij,nik,nk->nj", A, Ly, my), np.einsum("ij,nik,kl->njl", A, Ly, A)
+        if out_form == "wp":
+            scale = np.max(np.abs(L))
+            assert np.allclose(a, xi, rtol=1e-8, atol=1e-9 * scale) and np.allclose(B, L, rtol=1e-8, atol=1e-9 * scale)
+            return
+        rV = np.linalg.inv(L)
+        rm = np.einsum("nij,nj->ni", rV, xi)
+    else:              # typeof(+): (:out), (:in1), (:in2)
+        iface = int(rng.integers(0, 3))
+        m2, V2 = rng.standard_normal((n, d)), spd(d)
+        a, B = rule_eval(_lib.NODE_ADD, iface, None, give(m, V, in_form), give(m2, V2, in_form), in_form=in_form, out_form=out_form)
+        rm, rV = (m + m2, V + V2) if iface == 0 else (m - m2, V + V2)
+    gm, gV = take(a, B, out_form)
+    sd = np.sqrt(np.einsum("nii->ni", rV))
+    assert np.max(np.abs(gm - rm) / sd) < 1e-7 and np.max(np.abs(gV - rV) / (sd[:, :, None] * sd[:, None, :])) < 1e-7
