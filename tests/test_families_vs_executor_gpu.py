@@ -79,3 +79,49 @@ def test_chain_families_agree_with_the_executor(seed):
     assert np.max(np.abs(tm - mean) / sd) < 1e-9
     assert np.max(np.abs(tc - cov) / (sd[..., :, None] * sd[..., None, :])) < 1e-9
     assert np.max(np.abs(tfe - fe) / np.abs(fe)) < 1e-10
+
+
+def test_iid_gaussian_with_unknown_mean_and_precision_agrees_at_the_fixed_point():
+    """`iid_gaussians_params` (m ~ Normal, p ~ Gamma, y[i] ~ Normal(m, p⁻¹), q(m)q(p)) and `mv_iid_wishart`: the mixture engine at K = 1 against the
+    executor (a hub of N leaves, one precision variable shared by N nodes).  The two schedules order the updates of an iteration differently, so what must
+    agree is the fixed point: q(m), E[p] and the free energy after 80 iterations."""
+    from rxhip import _lib, graph
+    from rxhip.tree import TreeEngine
+    rng = np.random.default_rng(31)
+    # scalar
+    N = 120
+    y = 0.75 + 3.0 * rng.standard_normal(N)
+    gb, ys = graph.iid_normal_graph(N, 4.0, 8.0, 4.0, 0.125, init=dict(m=(0.0, 1.0), p=(1.0, 1.0)))
+    with graph.create_vmp_engine_from_graph(gb.tables()[0]) as eng:
+        eng.set_data(y)
+        eng.run(80, True)
+        h, fe = eng.history()[-1], eng.free_energy()[-1]
+    with TreeEngine(gb, n_replicas=1) as te:
+        te.set_data(ys, y.reshape(1, N))
+        te.run(80, True)
+        m, p = [v for v in range(len(gb.kind)) if gb.kind[v] == _lib.VARKIND_RANDOM][:2]   # the two random variables, in creation order: m, p
+        post = te.marginals([m])
+        nu, V = te.precision(p)
+        tfe = te.free_energy()[-1]
+    assert post[m][0][0, 0] == pytest.approx(h[0, 0], rel=1e-9) and post[m][1][0, 0, 0] == pytest.approx(h[1, 0], rel=1e-9)
+    assert nu[0] * V[0, 0, 0] == pytest.approx(h[2, 0] / h[3, 0], rel=1e-9)      # E[p] = shape / rate
+    assert tfe == pytest.approx(fe, rel=1e-9)
+    # multivariate
+    d, N = 3, 200
+    Lm = rng.standard_normal((d, d))
+    yv = rng.multivariate_normal(rng.random(d), Lm @ Lm.T + 0.3 * np.eye(d), size=N)
+    gb, ys = graph.mv_iid_graph(N, np.zeros(d), 100.0 * np.eye(d), d + 1.0, np.eye(d), init=dict(m=(np.zeros(d), np.eye(d)), w=(float(d + 1), np.eye(d))))
+    with graph.create_vmp_engine_from_graph(gb.tables()[0]) as eng:
+        eng.set_data(yv)
+        eng.run(80, True)
+        h, fe = eng.history(), eng.free_energy()[-1]
+    with TreeEngine(gb, n_replicas=1) as te:
+        te.set_data(ys, yv.reshape(1, N * d))
+        te.run(80, True)
+        m, p = [v for v in range(len(gb.kind)) if gb.kind[v] == _lib.VARKIND_RANDOM][:2]
+        post = te.marginals([m])
+        nu, V = te.precision(p)
+        tfe = te.free_energy()[-1]
+    assert np.allclose(post[m][0][0], h["mean"][-1, 0], rtol=1e-8, atol=1e-10)
+    assert np.allclose(nu[0] * V[0], h["nu"][-1, 0] * h["V"][-1, 0], rtol=1e-8)
+    assert tfe == pytest.approx(fe, rel=1e-9)
