@@ -389,7 +389,8 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  *     typeof(*) with a constant matrix;  typeof(+) (random + random, random + data / constant);
  *     Wishart / GammaShapeRate / GammaShapeScale priors with constant parameters
  * whose Gaussian variables form a forest (no cycles; precision variables may touch any number of nodes — the mean-field factorisation cuts those
- * loops), every dimension ≤ 64.  The host compiles the graph into ops sorted by dependency level (csrc/tree_engine.hip); one kernel evaluates
+ * loops; no Gaussian variable at all is a forest too: `P ~ Wishart; y[i] ~ MvNormal(μ = m, Λ = P)` with a known mean,
+ * test/models/iid/mv_iid_precision_known_mean_tests.jl), every dimension ≤ 64.  The host compiles the graph into ops sorted by dependency level (csrc/tree_engine.hip); one kernel evaluates
  * (op, replica) items: a launch per level over all nodes of the level, or — deep, narrow graphs — the whole schedule in one launch with workgroup-
  * resident levels, or — large batches — a lane per replica over the whole schedule.  Dimensions ≤ 8: a LANE per item, matrices in registers
  * (csrc/tree_kernels.hpp; the 4×4 instance fits, the 8×8 one spills).  Dimensions 9 … 64: a WAVEFRONT per item, matrices staged in LDS

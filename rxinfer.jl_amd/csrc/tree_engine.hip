@@ -284,7 +284,11 @@ struct Compiler {
             }
         }
         E = (int)edges.size();
-        if (E == 0) fail(RXHIP_ERR_UNSUPPORTED, "no random Gaussian variable in the graph");
+        bool any_prec = false;
+        for (int64_t v = 0; v < nv; ++v) any_prec = any_prec || P.vclass[v] == VC_PREC;
+        // (no Gaussian variable but a precision variable: `y[i] ~ MvNormal(μ = m, Λ = P)` with a KNOWN mean, test/models/iid/mv_iid_precision_known_mean_tests.jl —
+        //  no message at all, the schedule is the nodes' residual moments, the q(W) updates and the Bethe sum)
+        if (E == 0 && !any_prec) fail(RXHIP_ERR_UNSUPPORTED, "no random variable of the Gaussian / Wishart / Gamma family in the graph");
     }
 
     // ---- dependencies of every message ----

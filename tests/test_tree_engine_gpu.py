@@ -257,3 +257,33 @@ def test_random_forests_against_the_oracle(seed, monkeypatch):
     fe_it = eng.free_energy()
     assert np.all(np.isfinite(fe_it)) and np.all(np.diff(fe_it) <= 1e-9 * np.abs(fe_it[:-1]))
     eng.close()
+
+
+@pytest.mark.parametrize("kw,R", [(dict(n=1500, d=2), 1), (dict(n=60, d=3), 5), (dict(n=40, d=1, gamma=True), 3), (dict(n=30, d=12), 2)])
+def test_known_mean_precision_model_is_the_conjugate_closed_form(kw, R):
+    """`mv_iid_wishart_known_mean` (test/models/iid/mv_iid_precision_known_mean_tests.jl): a graph WITHOUT a Gaussian random variable — the schedule is the nodes'
+    residual moments, one q(P) update and the Bethe sum.  Against the conjugate closed form (tests/tree_graphs.py::known_mean_closed_form): q(P), the free
+    energy = −log evidence, and — the reference's own assertion — the same free energy at every iteration; E[P] near the generating precision as the
+    reference asserts it (atol 0.07 at n = 1500)."""
+    from rxhip.tree import TreeEngine
+    gb, ys, named = tg.known_mean_precision(**kw)
+    n, d = len(ys), gb.rows[ys[0]]
+    rng = np.random.default_rng(123)
+    L = rng.standard_normal((d, d)) + 2.0 * np.eye(d)
+    C = L @ L.T / d
+    y = rng.multivariate_normal(named["m"], C, size=(R, n))             # [R][n][d]
+    with TreeEngine(gb, n_replicas=R) as eng:
+        eng.set_data(ys, y.reshape(R, n * d))
+        eng.run(10, True)
+        nu, V = eng.precision(named["W"][0])
+        fe_it = eng.free_energy()
+        fe_rep = eng.free_energy_per_replica()
+    tot = 0.0
+    for r in range(R):
+        rn, rV, nle = tg.known_mean_closed_form(y[r], named["m"], *named["prior"])
+        assert nu[r] == pytest.approx(rn, rel=1e-14) and np.allclose(V[r], rV, rtol=1e-9)
+        assert fe_rep[r] == pytest.approx(nle, rel=1e-10)
+        tot += nle
+    assert np.allclose(fe_it, tot, rtol=1e-10) and np.max(np.abs(fe_it - fe_it[0])) <= 1e-11 * abs(fe_it[0])
+    if kw["n"] == 1500:
+        assert np.allclose(nu[0] * V[0], np.linalg.inv(C), atol=0.07 * np.max(np.abs(np.linalg.inv(C))))

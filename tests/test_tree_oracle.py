@@ -119,3 +119,17 @@ def test_random_forests_against_brute_force(seed):
         assert np.max(np.abs(ref["mean"][v] - post[v][0]) / sd) < 1e-8, v
         assert np.max(np.abs(ref["cov"][v] - post[v][1]) / np.outer(sd, sd)) < 1e-8, v
     assert ref["fe"][0] == pytest.approx(nle, rel=1e-9, abs=1e-9)
+
+
+@pytest.mark.parametrize("kw", [dict(n=40, d=2), dict(n=25, d=3), dict(n=30, d=1, gamma=True)])
+def test_known_mean_precision_model_is_the_conjugate_closed_form(kw):
+    """test/models/iid/mv_iid_precision_known_mean_tests.jl: no Gaussian random variable at all — q(P) is the conjugate Wishart after one iteration and the free
+    energy is −log evidence at EVERY iteration (the reference asserts `all(==(first(fe)), fe)`); both in closed form, no RNG of the reference needed"""
+    gb, ys, named = tg.known_mean_precision(**kw)
+    d = gb.rows[ys[0]]
+    y = np.random.default_rng(3).standard_normal((len(ys), d)) * 1.7 + named["m"]
+    ref = tree_oracle.infer(gb.to_dump(), {v: y[i] for i, v in enumerate(ys)}, iterations=4)
+    nu, V, nle = tg.known_mean_closed_form(y, named["m"], *named["prior"])
+    qn, qV = ref["q_prec"][named["W"][0]]
+    assert qn == pytest.approx(nu, rel=1e-14) and np.allclose(qV, V, rtol=1e-11)
+    assert np.allclose(ref["fe"], nle, rtol=1e-12)

@@ -198,6 +198,42 @@ def chain_state_noise_precision(T, d=2, dy=2, seed=4, also_obs_noise=False, gamm
     return gb, ys, dict(x=xs, W=[W] + ([R] if R is not None else []))
 
 
+def known_mean_precision(n, d, seed=7, gamma=False):
+    """`mv_iid_wishart_known_mean` (test/models/iid/mv_iid_precision_known_mean_tests.jl:11-16): P ~ Wishart(d + 1, I); y[i] ~ MvNormal(μ = m, Λ = P) with a
+    CONSTANT mean — a graph without a single Gaussian random variable.  gamma: the scalar spelling τ ~ Gamma(2, 0.5), y[i] ~ Normal(mean = m, precision = τ).
+    Returns (builder, data variables, dict(W=[P], m=mean, prior=(ν0, S0)))."""
+    rng = np.random.default_rng(seed)
+    if gamma:
+        d = 1
+    gb = GraphBuilder()
+    W = gb.randomvar(d, name="P")
+    if gamma:
+        gb.node(_lib.NODE_GAMMA_SHAPE_RATE, W, gb.constvar(2.0), gb.constvar(0.5))
+        prior = (4.0, np.array([[1.0]]))          # Gamma(a, b) = Wishart_1(2a, 1/(2b))
+    else:
+        gb.node(_lib.NODE_WISHART, W, gb.constvar(float(d + 1)), gb.constvar(np.eye(d)))
+        prior = (float(d + 1), np.eye(d))
+    m = rng.random(d)
+    mc = gb.constvar(m if d > 1 else float(m[0]))
+    ys = []
+    for _ in range(n):
+        y = gb.datavar(d)
+        gb.node(_lib.NODE_NORMAL_MEAN_PRECISION if gamma else _lib.NODE_MVNORMAL_MEAN_PRECISION, y, mc, W)
+        ys.append(y)
+    return gb, ys, dict(W=[W], m=m, prior=prior)
+
+
+def known_mean_closed_form(y, m, nu0, S0):
+    """the conjugate answer of that model: q(P) = Wishart(ν0 + n, (S0⁻¹ + Σ (y − m)(y − m)')⁻¹) after ONE update, and the Bethe free energy = −log evidence
+    = ½ n d log 2π − log Z(ν_n, V_n) + log Z(ν0, S0) with log Z(ν, V) = ½ ν d log 2 + ½ ν log|V| + log Γ_d(ν / 2) — at every iteration"""
+    from scipy.special import multigammaln
+    n, d = y.shape
+    r = y - m
+    Vn = np.linalg.inv(np.linalg.inv(S0) + r.T @ r)
+    logz = lambda nu, V: 0.5 * nu * d * np.log(2.0) + 0.5 * nu * np.linalg.slogdet(V)[1] + multigammaln(0.5 * nu, d)
+    return nu0 + n, Vn, 0.5 * n * d * np.log(2.0 * np.pi) - (logz(nu0 + n, Vn) - logz(nu0, S0))
+
+
 def random_forest(seed, n_steps=14, dmax=4, precision_vars=False, det_chains=True):
     """A random acyclic graph of the executor's family, grown one factor group at a time from a root state: noise children (covariance or precision
     spelling, constant or — `precision_vars` — a Wishart / Gamma variable shared by several nodes), children through `*` (rows ≤ columns: the Bethe sum
