@@ -858,6 +858,45 @@ __global__ void __launch_bounds__(256) k_tree_fe_total(const double* __restrict_
     if (threadIdx.x == 0) *total = sh[0];
 }
 
+// host layout <-> replica-fastest device layout, on the device (at 65 536 replicas the host loops these replace ran for seconds)
+// data: dst[(k)·RS + r] = src[r·rows + col + k] for k < width — a 32×32 LDS tile so that both sides move whole lines
+__global__ void __launch_bounds__(256) k_tree_scatter(double* __restrict__ dst, const double* __restrict__ src, long long R, long long RS, long long rows, long long col, long long width) {
+    __shared__ double tile[32][33];
+    const long long r0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 × 8
+    for (int j = ty; j < 32; j += 8) {
+        const long long r = r0 + j, k = k0 + tx;
+        tile[j][tx] = (r < R && k < width) ? src[r * rows + col + k] : 0.0;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const long long k = k0 + j, r = r0 + tx;
+        if (k < width && r < R) dst[k * RS + r] = tile[tx][j];
+    }
+}
+struct GatherVar { int off, d; long long mo, co; };
+// marginals of the listed variables into [variable][replica][d] / [variable][replica][d][d] (the arrays rxhip_tree_get_marginals fills)
+__global__ void __launch_bounds__(256) k_tree_gather(const double* __restrict__ marg, const GatherVar* __restrict__ vars, int n_vars, long long R, long long RS,
+                                                     double* __restrict__ mean, double* __restrict__ cov) {
+    const long long rblocks = (R + 255) / 256;
+    for (long long it = blockIdx.x; it < (long long)n_vars * rblocks; it += gridDim.x) {
+        const int vi = (int)(it / rblocks);
+        const long long r = (it - (long long)vi * rblocks) * 256 + threadIdx.x;
+        if (r >= R) continue;
+        const GatherVar g = vars[vi];
+        const int d = g.d;
+        if (mean)
+            for (int k = 0; k < d; ++k) mean[g.mo + r * d + k] = marg[(long long)(g.off + k) * RS + r];
+        if (cov)
+            for (int a = 0; a < d; ++a)
+                for (int b = 0; b <= a; ++b) {
+                    const double x = marg[(long long)(g.off + d + a * (a + 1) / 2 + b) * RS + r];
+                    cov[g.co + (r * d + a) * d + b] = x;
+                    cov[g.co + (r * d + b) * d + a] = x;
+                }
+    }
+}
+
 TreeParams params_of(const Engine* e, int want_fe) {
     TreeParams p{};
     p.ops = e->d_ops; p.aux = e->d_aux; p.cpool = e->d_cpool; p.msg = e->d_msg; p.marg = e->d_marg; p.val = e->d_val; p.prec = e->d_prec;
@@ -1009,21 +1048,30 @@ rxhip_status set_data(Engine* e, const int64_t* vars, int64_t n_vars, const doub
         if (v < 0 || v >= (int64_t)P.vclass.size() || P.vclass[v] != VC_DATA) { err = "set_data: variable " + std::to_string(v) + " is not a data variable"; return RXHIP_ERR_BADARG; }
         rows += P.dim[v];
     }
-    // device image of the listed slots, replica-fastest; one copy per run of adjacent slots
-    std::vector<double> img;
+    // the host rows go up as they are ([replica][Σ dims], in blocks of at most 256 MB) and are scattered into the replica-fastest slots on the device:
+    // one kernel per run of adjacent slots
     TCHK(hipStreamSynchronize(e->stream));
-    long long col = 0;
-    for (int64_t i = 0; i < n_vars;) {
-        int64_t j = i;
-        long long width = 0;
-        while (j < n_vars && P.val_off[vars[j]] == P.val_off[vars[i]] + width) { width += P.dim[vars[j]]; ++j; }
-        img.assign((size_t)width * e->RS, 0.0);
-        for (long long r = 0; r < e->R; ++r)
-            for (long long k = 0; k < width; ++k) img[(size_t)k * e->RS + r] = host[(size_t)r * rows + col + k];
-        TCHK(hipMemcpy(e->d_val + (size_t)P.val_off[vars[i]] * e->RS, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
-        col += width;
-        i = j;
+    const long long blk = std::max<long long>(1, std::min<long long>(e->R, ((256ll << 20) / 8) / std::max<long long>(1, rows)));
+    double* d_tmp = nullptr;
+    TCHK(hipMalloc(&d_tmp, sizeof(double) * (size_t)blk * (size_t)rows));
+    rxhip_status st_sc = RXHIP_OK;
+    for (long long r0 = 0; r0 < e->R && !st_sc; r0 += blk) {
+        const long long nr = std::min(blk, e->R - r0);
+        if (hipMemcpy(d_tmp, host + (size_t)r0 * rows, sizeof(double) * (size_t)nr * rows, hipMemcpyHostToDevice) != hipSuccess) { st_sc = RXHIP_ERR_HIP; break; }
+        long long col = 0;
+        for (int64_t i = 0; i < n_vars;) {
+            int64_t j = i;
+            long long width = 0;
+            while (j < n_vars && P.val_off[vars[j]] == P.val_off[vars[i]] + width) { width += P.dim[vars[j]]; ++j; }
+            const dim3 grid((unsigned)((nr + 31) / 32), (unsigned)((width + 31) / 32));
+            hipLaunchKernelGGL(k_tree_scatter, grid, dim3(256), 0, e->stream, e->d_val + (size_t)P.val_off[vars[i]] * e->RS + r0, (const double*)d_tmp, nr, e->RS, rows, col, width);
+            col += width;
+            i = j;
+        }
+        if (hipGetLastError() != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess) st_sc = RXHIP_ERR_HIP;
     }
+    (void)hipFree(d_tmp);
+    if (st_sc) { err = "set_data: copying the data to the device failed"; return st_sc; }
     for (int64_t i = 0; i < n_vars; ++i) {
         const auto it = std::lower_bound(P.data_vars.begin(), P.data_vars.end(), vars[i]);
         e->data_set[it - P.data_vars.begin()] = 1;
@@ -1090,37 +1138,46 @@ rxhip_status get_marginals(Engine* e, const int64_t* vars, int64_t n_vars, doubl
     if (!e->ran) { err = "get_marginals before run"; return RXHIP_ERR_STATE; }
     DevScope ds(e->device);
     const Program& P = e->prog;
-    std::vector<double> buf;
-    size_t mo = 0, co = 0;
-    const bool whole = n_vars > 32;
-    if (whole) {
-        buf.resize((size_t)P.marg_doubles * e->RS);
-        TCHK(hipMemcpy(buf.data(), e->d_marg, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
-    }
+    // gathered on the device into the caller's layout, chunks of variables of at most 256 MB of results, one copy per chunk and array
+    std::vector<GatherVar> gv((size_t)n_vars);
     for (int64_t i = 0; i < n_vars; ++i) {
         const int64_t v = vars[i];
         if (v < 0 || v >= (int64_t)P.vclass.size() || P.vclass[v] != VC_GAUSS) { err = "get_marginals: variable " + std::to_string(v) + " is not a random Gaussian variable"; return RXHIP_ERR_BADARG; }
-        const int d = P.dim[v], sz = d + d * (d + 1) / 2;
-        const double* src;
-        if (whole) src = buf.data() + (size_t)P.marg_off[v] * e->RS;
-        else {
-            buf.resize((size_t)sz * e->RS);
-            TCHK(hipMemcpy(buf.data(), e->d_marg + (size_t)P.marg_off[v] * e->RS, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
-            src = buf.data();
+        gv[i].off = P.marg_off[v];
+        gv[i].d = P.dim[v];
+    }
+    TCHK(hipStreamSynchronize(e->stream));
+    const size_t cap = (256u << 20) / 8;   // doubles per chunk and array
+    size_t mo = 0, co = 0;
+    for (int64_t i0 = 0; i0 < n_vars;) {
+        int64_t i1 = i0;
+        size_t nm = 0, nc = 0;
+        while (i1 < n_vars) {
+            const size_t d = (size_t)gv[i1].d, am = (size_t)e->R * d, ac = am * d;
+            if (i1 > i0 && (nm + am > cap || nc + ac > cap)) break;
+            gv[i1].mo = (long long)nm; gv[i1].co = (long long)nc;
+            nm += am; nc += ac; ++i1;
         }
-        for (long long r = 0; r < e->R; ++r) {
-            if (mean)
-                for (int k = 0; k < d; ++k) mean[mo + (size_t)r * d + k] = src[(size_t)k * e->RS + r];
-            if (cov)
-                for (int a = 0; a < d; ++a)
-                    for (int b = 0; b <= a; ++b) {
-                        const double x = src[(size_t)(d + a * (a + 1) / 2 + b) * e->RS + r];
-                        cov[co + ((size_t)r * d + a) * d + b] = x;
-                        cov[co + ((size_t)r * d + b) * d + a] = x;
-                    }
+        GatherVar* d_gv = nullptr;
+        double *d_m = nullptr, *d_c = nullptr;
+        auto freeall = [&]() { for (void* q : {(void*)d_gv, (void*)d_m, (void*)d_c}) if (q) (void)hipFree(q); };
+        hipError_t he = hipMalloc(&d_gv, sizeof(GatherVar) * (size_t)(i1 - i0));
+        if (he == hipSuccess) he = hipMemcpy(d_gv, gv.data() + i0, sizeof(GatherVar) * (size_t)(i1 - i0), hipMemcpyHostToDevice);
+        if (he == hipSuccess && mean) he = hipMalloc(&d_m, sizeof(double) * nm);
+        if (he == hipSuccess && cov) he = hipMalloc(&d_c, sizeof(double) * nc);
+        if (he == hipSuccess) {
+            const long long items = (long long)(i1 - i0) * ((e->R + 255) / 256);
+            hipLaunchKernelGGL(k_tree_gather, dim3((unsigned)std::min<long long>(items, 1 << 20)), dim3(256), 0, e->stream, (const double*)e->d_marg, (const GatherVar*)d_gv, (int)(i1 - i0),
+                               e->R, e->RS, d_m, d_c);
+            he = hipGetLastError();
         }
-        mo += (size_t)e->R * d;
-        co += (size_t)e->R * d * d;
+        if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
+        if (he == hipSuccess && mean) he = hipMemcpy(mean + mo, d_m, sizeof(double) * nm, hipMemcpyDeviceToHost);
+        if (he == hipSuccess && cov) he = hipMemcpy(cov + co, d_c, sizeof(double) * nc, hipMemcpyDeviceToHost);
+        freeall();
+        if (he != hipSuccess) { err = std::string("get_marginals: ") + hipGetErrorString(he); return RXHIP_ERR_HIP; }
+        mo += nm; co += nc;
+        i0 = i1;
     }
     return RXHIP_OK;
 }
