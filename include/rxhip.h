@@ -395,7 +395,8 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  * resident levels, or — large batches — a lane per replica over the whole schedule.  Dimensions ≤ 8: a LANE per item, matrices in registers
  * (csrc/tree_kernels.hpp; the 4×4 instance fits, the 8×8 one spills).  Dimensions 9 … 64: a WAVEFRONT per item, matrices staged in LDS
  * (csrc/tree_wave_kernels.hpp; same op tables and storage; a launch per level, or a wavefront per replica over the whole schedule).  Data variables, derived clamped values (`a + b` of two data variables), unobserved
- * leaves (predictions) are part of the family; `missing` inside the data is not (the chain engines have it).
+ * leaves (predictions) are part of the family; `missing` inside the data is not (the chain engines have it): rxhip_tree_set_data refuses NaN / Inf
+ * with RXHIP_ERR_BADARG.
  * rxhip_create falls through to this executor for every graph the pattern matcher rejects; rxhip_tree_create asks for it directly (the tests
  * compare it with the specialised engines on the graphs both can run).
  * Message forms: a rule keeps the form its inbound message has wherever the algebra allows — the additive rule and the backward rule of `+` (two random

@@ -860,7 +860,8 @@ __global__ void __launch_bounds__(256) k_tree_fe_total(const double* __restrict_
 
 // host layout <-> replica-fastest device layout, on the device (at 65 536 replicas the host loops these replace ran for seconds)
 // data: dst[(k)·RS + r] = src[r·rows + col + k] for k < width — a 32×32 LDS tile so that both sides move whole lines
-__global__ void __launch_bounds__(256) k_tree_scatter(double* __restrict__ dst, const double* __restrict__ src, long long R, long long RS, long long rows, long long col, long long width) {
+__global__ void __launch_bounds__(256) k_tree_scatter(double* __restrict__ dst, const double* __restrict__ src, long long R, long long RS, long long rows, long long col, long long width,
+                                                      int* __restrict__ status) {
     __shared__ double tile[32][33];
     const long long r0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 × 8
@@ -871,7 +872,11 @@ __global__ void __launch_bounds__(256) k_tree_scatter(double* __restrict__ dst, 
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const long long k = k0 + j, r = r0 + tx;
-        if (k < width && r < R) dst[k * RS + r] = tile[tx][j];
+        if (k < width && r < R) {
+            const double x = tile[tx][j];
+            dst[k * RS + r] = x;
+            if (!(fabs(x) <= 1.79769313486231570815e308)) atomicOr(status, 2);   // NaN (`missing`) or ±Inf in the data: this executor has no rule for it
+        }
     }
 }
 struct GatherVar { int off, d; long long mo, co; };
@@ -1064,7 +1069,7 @@ rxhip_status set_data(Engine* e, const int64_t* vars, int64_t n_vars, const doub
             long long width = 0;
             while (j < n_vars && P.val_off[vars[j]] == P.val_off[vars[i]] + width) { width += P.dim[vars[j]]; ++j; }
             const dim3 grid((unsigned)((nr + 31) / 32), (unsigned)((width + 31) / 32));
-            hipLaunchKernelGGL(k_tree_scatter, grid, dim3(256), 0, e->stream, e->d_val + (size_t)P.val_off[vars[i]] * e->RS + r0, (const double*)d_tmp, nr, e->RS, rows, col, width);
+            hipLaunchKernelGGL(k_tree_scatter, grid, dim3(256), 0, e->stream, e->d_val + (size_t)P.val_off[vars[i]] * e->RS + r0, (const double*)d_tmp, nr, e->RS, rows, col, width, e->d_status);
             col += width;
             i = j;
         }
@@ -1072,6 +1077,15 @@ rxhip_status set_data(Engine* e, const int64_t* vars, int64_t n_vars, const doub
     }
     (void)hipFree(d_tmp);
     if (st_sc) { err = "set_data: copying the data to the device failed"; return st_sc; }
+    {
+        int flag = 0;
+        TCHK(hipMemcpy(&flag, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
+        if (flag & 2) {
+            TCHK(hipMemset(e->d_status, 0, sizeof(int)));
+            err = "set_data: the data hold NaN or Inf — `missing` observations are outside the node-array executor's family (the state-space engines take them: desc.allow_missing)";
+            return RXHIP_ERR_BADARG;
+        }
+    }
     for (int64_t i = 0; i < n_vars; ++i) {
         const auto it = std::lower_bound(P.data_vars.begin(), P.data_vars.end(), vars[i]);
         e->data_set[it - P.data_vars.begin()] = 1;

@@ -287,3 +287,21 @@ def test_known_mean_precision_model_is_the_conjugate_closed_form(kw, R):
     assert np.allclose(fe_it, tot, rtol=1e-10) and np.max(np.abs(fe_it - fe_it[0])) <= 1e-11 * abs(fe_it[0])
     if kw["n"] == 1500:
         assert np.allclose(nu[0] * V[0], np.linalg.inv(C), atol=0.07 * np.max(np.abs(np.linalg.inv(C))))
+
+
+def test_nan_in_the_data_is_refused_by_name():
+    """`missing` observations are outside the executor's family: a NaN in the data is an error at set_data, not a NaN posterior later"""
+    import rxhip
+    from rxhip import _lib
+    from rxhip.tree import TreeEngine
+    gb, ys, _ = tg.two_branch_chain(T=4)
+    data = tg.random_data(gb, ys, 3, 0)
+    with TreeEngine(gb, n_replicas=3) as eng:
+        bad = data.copy()
+        bad[2, 5] = np.nan
+        with pytest.raises(rxhip.RxHipError) as ei:
+            eng.set_data(ys, bad)
+        assert ei.value.status == _lib.ERR_BADARG and "missing" in str(ei.value)
+        eng.set_data(ys, data)          # the engine is still usable
+        eng.run(1, True)
+        assert np.all(np.isfinite(eng.free_energy_per_replica()))
