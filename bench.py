@@ -920,7 +920,8 @@ def main(argv=None, engine_cls=None, gpu_cls=_Gpu, extra_cls=None):
                     help="weak: --chains per GPU (the driver's scaling run); strong: --chains in total, split over the ranks")
     ap.add_argument("--segments", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-chains", type=int, default=40)
+    ap.add_argument("--cpu-sample-chains", type=int, default=96,
+                    help="chains of the benchmarked batch the single-core CPU restatement is timed on (96: about 12 s of one host core)")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-chain-model variant and the C3/C4/C5 lines")
     ap.add_argument("--no-parity", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
