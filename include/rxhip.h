@@ -417,6 +417,11 @@ typedef struct {
     double last_iteration_ms;             /* device time of the last rxhip_run ÷ its iterations (HIP events around the launches) */
 } rxhip_tree_info;
 rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* stream, rxhip_engine** out);
+/* The graph compiler alone — host only, no device: would rxhip_tree_create take this graph, and with what schedule?  Fills the static fields of `out`
+ * (mode = −1: chosen with the batch) and the reference-equivalent counts of ONE replica and iteration (what after_message_rule_call / the products / the
+ * marginals would count: src/inference/batch.jl:495-496); failures as rxhip_tree_create (text: rxhip_lowering_error()).  The plugin can ask before it builds
+ * an engine; the CPU tests hold these counts to the oracle's. */
+rxhip_status rxhip_tree_plan(const rxhip_graph_desc* g, rxhip_tree_info* out, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals);
 /* data of the listed data variables, host [replica][rows of vars[0] | rows of vars[1] | …] (src/inference/batch.jl:405-407 new_observation!) */
 rxhip_status rxhip_tree_set_data(rxhip_engine* e, const int64_t* vars, int64_t n_vars, const double* host);
 /* posteriors of the listed random (Gaussian) variables: mean [var][replica][d], cov [var][replica][d][d], concatenated in list order */

@@ -111,6 +111,13 @@ rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* 
     *out = e;
     return RXHIP_OK;
 }
+rxhip_status rxhip_tree_plan(const rxhip_graph_desc* g, rxhip_tree_info* out, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals) {
+    std::string err;
+    rxhip_lower::last_asymmetry() = 0.0;
+    const rxhip_status st = rxhip::tree::plan(g, out, rule_calls, products, marginals, err);
+    if (st) rxhip_lower::last_error() = err;
+    return st;
+}
 rxhip_status rxhip_tree_set_data(rxhip_engine* e, const int64_t* vars, int64_t n_vars, const double* host) {
     if (!e || !e->tree) return e ? fail(e, RXHIP_ERR_BADARG, "rxhip_tree_set_data: not an engine of the node-array executor") : RXHIP_ERR_BADARG;
     e->err.clear();

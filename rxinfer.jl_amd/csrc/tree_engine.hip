@@ -1030,6 +1030,27 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     return RXHIP_OK;
 }
 
+rxhip_status plan(const rxhip_graph_desc* g, rxhip_tree_info* out, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals, std::string& err) {
+    if (!g || !out) { err = "null argument"; return RXHIP_ERR_BADARG; }
+    Engine e;
+    try {
+        Compiler c(g, e.prog);
+        c.compile();
+    } catch (const Fail& f) {
+        err = f.msg;
+        return f.st;
+    } catch (const std::exception& ex) {
+        err = ex.what();
+        return RXHIP_ERR_BADARG;
+    }
+    e.mode = -1;   // (the schedule is chosen with the batch, at creation)
+    info(&e, out);
+    if (rule_calls) *rule_calls = e.prog.rule_calls;
+    if (products) *products = e.prog.products;
+    if (marginals) *marginals = e.prog.marginals;
+    return RXHIP_OK;
+}
+
 void destroy(Engine* e) {
     if (!e) return;
     DevScope ds(e->device);

@@ -29,6 +29,8 @@ rxhip_status sync(Engine* e, std::string& err);
 // when the last run did not compute them
 double* free_energy_device(Engine* e, int* iterations);
 rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err);
+// the graph compiler alone (host, no device): the schedule's static figures and the reference-equivalent counts of ONE replica and iteration
+rxhip_status plan(const rxhip_graph_desc* g, rxhip_tree_info* out, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals, std::string& err);
 
 }  // namespace tree
 }  // namespace rxhip

@@ -518,6 +518,15 @@ with_desc(f, t, n_replicas::Integer, n_observations::Integer; allow_missing::Boo
 end
 
 lowering_error() = unsafe_string(ccall((:rxhip_lowering_error, librxhip), Cstring, ()))
+"the graph compiler alone (host only): would the node-array executor take this graph, and with what schedule? (include/rxhip.h rxhip_tree_plan)"
+function tree_plan(g::Ref{GraphDesc})
+    info = Ref(TreeInfo())
+    rc, pr, mg = Ref{UInt64}(0), Ref{UInt64}(0), Ref{UInt64}(0)
+    st = ccall((:rxhip_tree_plan, librxhip), Int32, (Ptr{GraphDesc}, Ptr{TreeInfo}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}), g, info, rc, pr, mg)
+    st == 0 || error("rxhip_tree_plan: status $st: $(lowering_error())")
+    return (info = info[], rule_calls = rc[], products = pr[], marginals = mg[])
+end
+
 "largest relative asymmetry of a constant parameter the last lowering call accepted and symmetrised (include/rxhip.h rxhip_lowering_asymmetry)"
 lowering_asymmetry() = ccall((:rxhip_lowering_asymmetry, librxhip), Cdouble, ())
 

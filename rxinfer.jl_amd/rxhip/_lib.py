@@ -140,6 +140,8 @@ SYMBOLS = [
     ("rxhip_graph_lower_lgssm_noise", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(LgssmNoiseLowered)]),
     ("rxhip_lowering_error", ctypes.c_char_p, []),
     ("rxhip_lowering_asymmetry", ctypes.c_double, []),
+    ("rxhip_tree_plan", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.POINTER(TreeInfo), ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                         ctypes.POINTER(ctypes.c_uint64)]),
     ("rxhip_create", ctypes.c_int32, [ctypes.POINTER(GraphDesc), ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p,
                                       ctypes.POINTER(_H)]),
     ("rxhip_lgssm_supported", ctypes.c_int32, [ctypes.c_int32, ctypes.c_int32]),

@@ -124,6 +124,21 @@ class TreeEngine:
         return dict(rule_calls=r.value, products=p.value, marginals=m.value)
 
 
+def plan(gb, n_replicas=1):
+    """The graph compiler alone (rxhip_tree_plan; host only, no GPU needed): dict of the schedule's static figures plus the reference-equivalent counts of one
+    replica and iteration (rule_calls, products, marginals).  Raises RxHipError exactly where TreeEngine(gb) would refuse the graph."""
+    g, keep = gb.tables(n_replicas=n_replicas)
+    info = _lib.TreeInfo()
+    rc, pr, mg = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
+    L = _lib.lib()
+    st = L.rxhip_tree_plan(ctypes.byref(g), ctypes.byref(info), ctypes.byref(rc), ctypes.byref(pr), ctypes.byref(mg))
+    if st != _lib.OK:
+        raise RxHipError(st, L.rxhip_lowering_error().decode() or L.rxhip_status_string(st).decode())
+    out = {k: int(getattr(info, k)) for k, _ in _lib.TreeInfo._fields_ if k != "last_iteration_ms"}
+    out.update(rule_calls=rc.value, products=pr.value, marginals=mg.value)
+    return out
+
+
 def rule_eval(node_type, iface, constant, msg, msg2=None, in_form="mv", out_form="mv", d_out=None, device=-1):
     """One message rule on the device for a batch (rxhip_rule_eval): msg = (a [n][d], B [n][d][d]) in `in_form` ('mv': mean / covariance, 'wp':
     weighted mean / precision).  Returns (a', B') in `out_form`."""
