@@ -401,6 +401,98 @@ function counters(e::Engine)
     return (rule_calls = r[], products = p[], marginals = m[])
 end
 
+# ---- the rest of the C ABI as thin wrappers: asynchronous runs, device-pointer hand-over (AMDGPU.jl arrays stay on the device), profiling, housekeeping ----
+
+"per-chain (per-replica) free energy of the last iteration (`rxhip_get_free_energy_per_chain`)"
+function free_energy_per_chain(e::Engine)
+    fe = Vector{Float64}(undef, e.n_chains)
+    GC.@preserve fe check(e, ccall((:rxhip_get_free_energy_per_chain, librxhip), Int32, (Ptr{Cvoid}, Ptr{Float64}), e.handle, fe))
+    return fe
+end
+
+"enqueue a run on the engine's stream and return (`rxhip_run_async`); `sync!` or any getter waits for it"
+function run_async!(e::Engine; iterations::Integer = 1, free_energy::Bool = true)
+    check(e, ccall((:rxhip_run_async, librxhip), Int32, (Ptr{Cvoid}, Int32, Int32), e.handle, Int32(iterations), Int32(free_energy ? 1 : 0)))
+    e.iterations = iterations
+    return e
+end
+"the streaming twin, enqueued (`rxhip_run_filter_async`)"
+run_filter_async!(e::Engine; free_energy::Bool = true) =
+    (check(e, ccall((:rxhip_run_filter_async, librxhip), Int32, (Ptr{Cvoid}, Int32), e.handle, Int32(free_energy ? 1 : 0))); e.iterations = 1; e)
+
+"observations that already live on the device (`rxhip_set_data_device`): `ptr` a device pointer to `n` doubles in `layout`; the caller keeps the buffer alive"
+set_data_device!(e::Engine, ptr::Ptr{Float64}, n::Integer; var_id::Integer = 0, layout::Integer = RXHIP_LAYOUT_TIME_CHAIN) =
+    check(e, ccall((:rxhip_set_data_device, librxhip), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Csize_t, Int32), e.handle, Int32(var_id), ptr, Csize_t(n), Int32(layout)))
+
+"device views of the posteriors, layout [T][chain][d] / [T][chain][d][d], valid until the next run (`rxhip_get_marginals_device`)"
+function marginals_device(e::Engine; var_id::Integer = 1)
+    m, c = Ref{Ptr{Float64}}(C_NULL), Ref{Ptr{Float64}}(C_NULL)
+    check(e, ccall((:rxhip_get_marginals_device, librxhip), Int32, (Ptr{Cvoid}, Int32, Ref{Ptr{Float64}}, Ref{Ptr{Float64}}), e.handle, Int32(var_id), m, c))
+    return m[], c[]
+end
+
+"device pointer to the per-iteration free energies of the last run (`rxhip_get_free_energy_device`)"
+function free_energy_device(e::Engine)
+    q = Ref{Ptr{Float64}}(C_NULL)
+    check(e, ccall((:rxhip_get_free_energy_device, librxhip), Int32, (Ptr{Cvoid}, Ref{Ptr{Float64}}), e.handle, q))
+    return q[]
+end
+"the last iteration's free energy into a caller's device buffer, on the engine's stream (`rxhip_copy_free_energy_to_device`)"
+copy_free_energy_to_device!(e::Engine, dst::Ptr{Float64}) =
+    check(e, ccall((:rxhip_copy_free_energy_to_device, librxhip), Int32, (Ptr{Cvoid}, Ptr{Float64}), e.handle, dst))
+
+"the hipStream_t the engine launches on (`rxhip_get_stream`)"
+function stream(e::Engine)
+    q = Ref{Ptr{Cvoid}}(C_NULL)
+    check(e, ccall((:rxhip_get_stream, librxhip), Int32, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}), e.handle, q))
+    return q[]
+end
+
+"(segments, segment length) of the time-parallel schedule (`rxhip_get_schedule`)"
+function schedule(e::Engine)
+    s, l = Ref{Int32}(0), Ref{Int64}(0)
+    check(e, ccall((:rxhip_get_schedule, librxhip), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int64}), e.handle, s, l))
+    return (segments = Int(s[]), segment_len = Int(l[]))
+end
+
+const RXHIP_K_COUNT = 10   # include/rxhip.h rxhip_kernel_id
+"per-kernel device times (`RxInferBenchmarkCallbacks`, src/callbacks/benchmark.jl:99-155): `set_profiling!`, then runs, then `kernel_times`"
+set_profiling!(e::Engine, on::Bool) = check(e, ccall((:rxhip_set_profiling, librxhip), Int32, (Ptr{Cvoid}, Int32), e.handle, Int32(on ? 1 : 0)))
+reset_kernel_times!(e::Engine) = check(e, ccall((:rxhip_reset_kernel_times, librxhip), Int32, (Ptr{Cvoid},), e.handle))
+function kernel_times(e::Engine)
+    ms, n = Vector{Float64}(undef, RXHIP_K_COUNT), Vector{UInt64}(undef, RXHIP_K_COUNT)
+    GC.@preserve ms n check(e, ccall((:rxhip_get_kernel_times, librxhip), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{UInt64}), e.handle, ms, n))
+    return (ms_avg = ms, launches = n)
+end
+
+"per-chain known inputs c[t], d[t] of a batch (`rxhip_lgssm_set_chain_offsets`): d × T × chains and dy × T × chains (either may be `nothing`)"
+function set_chain_offsets!(e::Engine, state_offset, obs_offset)
+    so = state_offset === nothing ? Float64[] : vec(Array{Float64}(state_offset))
+    oo = obs_offset === nothing ? Float64[] : vec(Array{Float64}(obs_offset))
+    GC.@preserve so oo check(e, ccall((:rxhip_lgssm_set_chain_offsets, librxhip), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32), e.handle,
+                                       isempty(so) ? Ptr{Float64}(C_NULL) : pointer(so), isempty(oo) ? Ptr{Float64}(C_NULL) : pointer(oo), RXHIP_LAYOUT_CHAIN_TIME))
+end
+
+"responsibilities q(z[i] = k) of the mixture engine after a run, K × N (`rxhip_gmm_get_responsibilities`)"
+function gmm_responsibilities(e::Engine, K::Integer, N::Integer)
+    r = Array{Float64}(undef, K, N)
+    GC.@preserve r check(e, ccall((:rxhip_gmm_get_responsibilities, librxhip), Int32, (Ptr{Cvoid}, Ptr{Float64}), e.handle, r))
+    return r
+end
+"device pointer and length of the mixture's statistics buffer between `accumulate` and `update` (`rxhip_gmm_statistics_device`)"
+function gmm_statistics_device(e::Engine)
+    q, n = Ref{Ptr{Float64}}(C_NULL), Ref{Int32}(0)
+    check(e, ccall((:rxhip_gmm_statistics_device, librxhip), Int32, (Ptr{Cvoid}, Ref{Ptr{Float64}}, Ref{Int32}), e.handle, q, n))
+    return q[], Int(n[])
+end
+
+version() = unsafe_string(ccall((:rxhip_version, librxhip), Cstring, ()))
+device_count() = Int(ccall((:rxhip_device_count, librxhip), Int32, ()))
+"1 if a device schedule exists for state dimension d and observation dimension dy (`rxhip_lgssm_supported`)"
+lgssm_supported(d::Integer, dy::Integer) = ccall((:rxhip_lgssm_supported, librxhip), Int32, (Int32, Int32), Int32(d), Int32(dy)) != 0
+"hand the library's parked engines, arenas and pinned blocks back to the runtime (`rxhip_release_cached_memory`; INTEGRATION.md: lifetime of the pools)"
+release_cached_memory() = ccall((:rxhip_release_cached_memory, librxhip), Int32, ()) == 0
+
 "device time (ms) of the kernels that ran once at creation because their results depend on the model only"
 function model_tables_ms(e::Engine)
     ms = Ref{Float64}(0.0)
@@ -518,6 +610,14 @@ with_desc(f, t, n_replicas::Integer, n_observations::Integer; allow_missing::Boo
 end
 
 lowering_error() = unsafe_string(ccall((:rxhip_lowering_error, librxhip), Cstring, ()))
+"the node-array executor asked for directly (`rxhip_tree_create`; `create_from_tables` reaches it through `rxhip_create` for graphs no family matches)"
+function tree_create(g::Ref{GraphDesc}; device::Integer = -1, stream = C_NULL)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    st = ccall((:rxhip_tree_create, librxhip), Int32, (Ptr{GraphDesc}, Int32, Ptr{Cvoid}, Ref{Ptr{Cvoid}}), g, Int32(device), stream, h)
+    st == 0 || error("rxhip_tree_create: status $st: $(lowering_error())")
+    return h[]
+end
+
 "the graph compiler alone (host only): would the node-array executor take this graph, and with what schedule? (include/rxhip.h rxhip_tree_plan)"
 function tree_plan(g::Ref{GraphDesc})
     info = Ref(TreeInfo())
