@@ -620,9 +620,9 @@ end
 
 "the graph compiler alone (host only): would the node-array executor take this graph, and with what schedule? (include/rxhip.h rxhip_tree_plan)"
 function tree_plan(g::Ref{GraphDesc})
-    info = Ref(TreeInfo())
+    info = Ref(TreeInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0))
     rc, pr, mg = Ref{UInt64}(0), Ref{UInt64}(0), Ref{UInt64}(0)
-    st = ccall((:rxhip_tree_plan, librxhip), Int32, (Ptr{GraphDesc}, Ptr{TreeInfo}, Ptr{UInt64}, Ptr{UInt64}, Ptr{UInt64}), g, info, rc, pr, mg)
+    st = ccall((:rxhip_tree_plan, librxhip), Int32, (Ptr{GraphDesc}, Ref{TreeInfo}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}), g, info, rc, pr, mg)
     st == 0 || error("rxhip_tree_plan: status $st: $(lowering_error())")
     return (info = info[], rule_calls = rc[], products = pr[], marginals = mg[])
 end
