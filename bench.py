@@ -393,7 +393,7 @@ def extra_c3(device, parity=True):
 def extra_node_array(device, parity=True):
     """Not a BASELINE config — the level-scheduled node-array executor (SURVEY §7's design stance) on a graph OUTSIDE the
     pattern-matched families: the benchmark chain with TWO observation branches per state (`rxhip_create` used to answer RXHIP_ERR_UNSUPPORTED),
-    d = 4, dy = 2 + 2, T = 128 time steps × 65 536 replicas (a lane per replica walks the schedule: the executor's schedule for large batches; the same
+    d = 4, dy = 2 + 2, T = 128 time steps × 65 536 replicas (workgroup-resident levels, 128 replicas per workgroup: the executor's schedule at this batch; the same
     graph at T = 256 × 4096 replicas — workgroup-resident levels, latency-bound — is in profiles/r05/tree_modes.txt), one sum-product sweep + Bethe free
     energy per step; and the plain state-space chain
     of the same size through the executor next to the specialised engine.  Rates: reference-equivalent rule calls (the messages the named
@@ -435,9 +435,9 @@ def extra_node_array(device, parity=True):
                 with open(os.path.join(ROOT, "rxinfer.jl_amd", "csrc", "tree_kernels.hpp"), "rb") as f:
                     fresh = tj.get("tree_kernels_sha256") == hashlib.sha256(f.read()).hexdigest()
                 if fresh and tj.get("algorithmic_bytes_per_sweep") == info["bytes_per_sweep"] * R:
-                    line["roofline"]["traffic"] = sum(k["hbm_bytes_per_launch_x2"] for n, k in tj["kernels"].items() if "k_tree_walk" in n)
+                    line["roofline"]["traffic"] = sum(k["hbm_bytes_per_launch_x2"] for n, k in tj["kernels"].items() if "k_tree_" in n and "fe_total" not in n)
                     line["roofline"]["traffic_note"] = "FETCH_SIZE x2 + WRITE_SIZE of both phases per sweep (profiles/tree_traffic.json); x1: " + \
-                        f"{sum(k['hbm_bytes_per_launch_x1'] for n, k in tj['kernels'].items() if 'k_tree_walk' in n):.4g} bytes"
+                        f"{sum(k['hbm_bytes_per_launch_x1'] for n, k in tj['kernels'].items() if 'k_tree_' in n and 'fe_total' not in n):.4g} bytes"
             except (OSError, ValueError, KeyError):
                 pass
         if parity and name == "two_branch":

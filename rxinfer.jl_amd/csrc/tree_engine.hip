@@ -799,7 +799,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     long long R = 1, RS = 16;
-    int mode = 0, rb = 16;
+    int mode = 0, mode_fe = 0, rb = 16;   // schedule of the sweep phase / of the Bethe phase (tree_kernels.hpp: 0 a launch per level, 1 resident levels, 2 walk)
     int *d_ops = nullptr, *d_aux = nullptr, *d_lvl = nullptr, *d_status = nullptr;
     double *d_cpool = nullptr, *d_msg = nullptr, *d_marg = nullptr, *d_val = nullptr, *d_prec = nullptr, *d_term = nullptr, *d_stat = nullptr, *d_prec_init = nullptr,
            *d_fe_rep = nullptr, *d_fe_hist = nullptr;
@@ -911,10 +911,11 @@ TreeParams params_of(const Engine* e, int want_fe) {
 template <int N, int PHASE>
 void launch_phase(const Engine* e, const TreeParams& p, int l0, int l1) {
     if (l1 <= l0) return;
-    if (e->mode == 2) {
+    const int mode = PHASE == 0 ? e->mode : e->mode_fe;
+    if (mode == 2) {
         const unsigned blocks = (unsigned)((e->R + 63) / 64);
         hipLaunchKernelGGL((k_tree_walk<N, PHASE>), dim3(blocks), dim3(64), 0, e->stream, p, e->prog.lvl_ptr[l0], e->prog.lvl_ptr[l1]);
-    } else if (e->mode == 1) {
+    } else if (mode == 1) {
         const unsigned blocks = (unsigned)((e->R + e->rb - 1) / e->rb);
         hipLaunchKernelGGL((k_tree_levels<N, PHASE>), dim3(blocks), dim3(256), 0, e->stream, p, e->d_lvl, l0, l1, e->rb);
     } else {
@@ -997,18 +998,26 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     // schedule: deep graphs walk their levels inside a workgroup (one launch per iteration); wide, shallow ones take a launch per level
     const double avg_width = (double)P.n_ops / std::max(1, P.n_levels);
     e->mode = (P.n_levels > 24 && (e->R >= 512 || avg_width * (double)e->R < 16384.0)) ? 1 : 0;
-    // large batches: a lane per replica walks the whole schedule (no barriers; 64 replicas per wavefront, from one wavefront per SIMD on)
-    if (e->R >= 65536) e->mode = 2;
+    // very large batches: a lane per replica walks the whole schedule (no barriers; 64 replicas per wavefront) — from two wavefronts per SIMD on it passes the
+    // workgroup-resident schedule (131 072 replicas × T = 128: 19.6 against 20.3 ms; at 65 536 the resident schedule wins, 10.65 against 11.67: profiles/r05/tree_modes.txt)
+    if (e->R >= 131072) e->mode = 2;
+    // the Bethe phase is one wide level of independent terms and a short sum tree: there the walk is ahead from 65 536 replicas on (2.05 against 2.69 ms), the
+    // sweep only from 131 072 (scripts/time_tree_phases.py)
+    e->mode_fe = (e->mode == 1 && e->R >= 65536) ? 2 : e->mode;
     if (P.dmax > 8) {
         // wavefront per item: a launch per level — a rule at d = 16 is ≈ 17 µs of dependent LDS round trips inside its wavefront, more than a launch, so
         // the walk (one wavefront per replica, ops in sequence) only pays once the replicas alone fill the device (measured: profiles/r05/tree_wave_modes.txt)
         e->mode = e->R >= 4096 ? 2 : 0;
     }
-    if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = std::max(0, std::min(2, std::atoi(m)));
-    if (P.dmax > 8 && e->mode == 1) e->mode = 2;   // (no workgroup-resident schedule for the LDS-staged kernels)
+    if (P.dmax > 8) e->mode_fe = e->mode;
+    if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = e->mode_fe = std::max(0, std::min(2, std::atoi(m)));
+    if (P.dmax > 8 && e->mode == 1) e->mode = e->mode_fe = 2;   // (no workgroup-resident schedule for the LDS-staged kernels)
     {
-        long long rb = (e->R / 1024) / 16 * 16;
-        e->rb = (int)std::min<long long>(64, std::max<long long>(16, rb));
+        // replicas per workgroup of the resident schedule: about 512 workgroups (two per CU) — measured optimum at every batch from 4 096 to 65 536 replicas
+        // (16 384: rb 16 → 32: 5.79 → 3.93 ms; 32 768: 32 → 64: 7.47 → 6.00; 65 536: 64 → 128: 11.38 → 10.65; 4 096: 16 stays)
+        long long rb = (e->R / 512) / 16 * 16;
+        e->rb = (int)std::min<long long>(128, std::max<long long>(16, rb));
+        if (const char* q = hook_env("RXHIP_TREE_RB")) e->rb = std::max(16, std::min(256, std::atoi(q) / 16 * 16));
     }
     auto cleanup = [&](rxhip_status st) { destroy(e); return st; };
     if (stream) e->stream = (hipStream_t)stream;

@@ -60,7 +60,7 @@ m = {"source": f"profiles/{tag}/ (rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 …, sc
      "dense_kernels_sha256": sha("dense_kernels.hpp")}
 json.dump(m, open(os.path.join(out, "mfma_insts.json"), "w"), indent=1)
 # the node-array executor: HBM bytes per launch of its kernel instances (the format bench.py reads: profiles/tree_traffic.json)
-tk = ("k_tree_walk<4, 0>", "k_tree_walk<4, 1>", "k_tree_fe_total")
+tk = ("k_tree_levels<4, 0>", "k_tree_levels<4, 1>", "k_tree_walk<4, 0>", "k_tree_walk<4, 1>", "k_tree_fe_total")   # (whichever schedule the engine picked for the batch)
 tf, tw = avg("FETCH_SIZE", "tree_fetch", tk, last=3), avg("WRITE_SIZE", "tree_write", tk, last=3)
 alg = None
 try:
@@ -69,7 +69,7 @@ try:
     alg = info["info"]["bytes_per_sweep"] * info["replicas"]
 except Exception:
     pass
-tt = {"source": f"profiles/{tag}/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, scripts/prof_tree.py 128 65536 3: the bench's node_array workload — two observation branches per state, d = 4, T = 128, 65 536 replicas, lane-per-replica schedule; average of the last 3 launches of each kernel instance)",
+tt = {"source": f"profiles/{tag}/ (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, scripts/prof_tree.py 128 65536 3: the bench's node_array workload — two observation branches per state, d = 4, T = 128, 65 536 replicas, the schedule the engine picks for that batch; average of the last 3 launches of each kernel instance)",
       "correction": "KiB units x1024; FETCH_SIZE as reported and x2 (the guide's gfx950 correction is for 16 B/lane streams; the executor loads 8 B/lane unit-stride): both given",
       "algorithmic_bytes_per_sweep": alg, "tree_kernels_sha256": sha("tree_kernels.hpp"), "kernels": {}}
 for k in tk:
