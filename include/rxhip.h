@@ -411,7 +411,8 @@ typedef struct {
     int64_t doubles_per_replica;          /* device state per replica */
     int64_t bytes_per_sweep;              /* algorithmic traffic of one iteration per replica: 8·(d + d(d+1)/2) per message a rule reads or writes */
     int32_t dmax;                         /* kernel instance: 1, 2, 4 or 8 (registers); above 8 the graph's largest dimension (LDS-staged kernels) */
-    int32_t mode;                         /* 0: one launch per level; 1: one launch per iteration, workgroup-resident levels (dmax ≤ 8); 2: a lane (dmax ≤ 8) or a wavefront per replica walks the schedule */
+    int32_t mode;                         /* schedule of the sweep phase — 0: one launch per level; 1: one launch per phase, workgroup-resident levels (dmax ≤ 8); 2: a lane (dmax ≤ 8)
+                                             or a wavefront per replica walks the schedule.  (The Bethe / q(W) phase may take the walk while the sweep is still on 1: from 65 536 replicas.) */
     int32_t replicas_per_workgroup;       /* mode 1 */
     int32_t n_precision_vars;
     double last_iteration_ms;             /* device time of the last rxhip_run ÷ its iterations (HIP events around the launches) */
