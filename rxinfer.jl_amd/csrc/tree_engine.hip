@@ -998,6 +998,20 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     // schedule: deep graphs walk their levels inside a workgroup (one launch per iteration); wide, shallow ones take a launch per level
     const double avg_width = (double)P.n_ops / std::max(1, P.n_levels);
     e->mode = (P.n_levels > 24 && (e->R >= 512 || avg_width * (double)e->R < 16384.0)) ? 1 : 0;
+    if (e->R < 8192 && P.n_levels > 1) {
+        // below the batches that fill the device: a cost model per level, from the widths of THIS schedule — resident levels pay a barrier and
+        // ⌈width · 16 / 256⌉ rule evaluations per thread in a workgroup of 16 replicas, a launch per level pays the launch and ⌈width · R / (256 · 1024)⌉
+        // (measured: 1.0 µs per barrier, 3.6 µs per launch, 2.5 µs per dependent rule evaluation; a tree of depth 7 with 87 ops per level at 16 … 4 096
+        //  replicas is 2 – 3 × faster launched per level, a chain with 8 ops per level 1.4 × faster resident: profiles/r05/tree_small_batches.txt)
+        double c0 = 0.0, c1 = 0.0;
+        for (int l = 0; l < P.n_levels; ++l) {
+            const double w = (double)(P.lvl_ptr[l + 1] - P.lvl_ptr[l]);
+            if (w <= 0.0) continue;
+            c1 += 1.0 + std::ceil(w * (double)std::min<long long>(16, e->R) / 256.0) * 2.5;
+            c0 += 3.6 + std::ceil(w * (double)e->R / (256.0 * 1024.0)) * 2.5;
+        }
+        e->mode = c1 < c0 ? 1 : 0;
+    }
     // very large batches: a lane per replica walks the whole schedule (no barriers; 64 replicas per wavefront) — from two wavefronts per SIMD on it passes the
     // workgroup-resident schedule (131 072 replicas × T = 128: 19.6 against 20.3 ms; at 65 536 the resident schedule wins, 10.65 against 11.67: profiles/r05/tree_modes.txt)
     if (e->R >= 131072) e->mode = 2;
