@@ -333,7 +333,99 @@ struct Compiler {
         return ng >= 2;
     }
 
+    // ---- hubs: a variable of degree n > HUB_MIN whose neighbours each need their own product of the n − 1 other messages ----
+    // Reduced one by one that is O(n²) partial products (a star of 3 000 leaves: 440 000 ops).  Instead the inbound messages sit at the leaves of ONE
+    // FAN_IN-ary tree of partial products (positions = the variable's edge order; a node's product is built once, when first asked for), and the product that
+    // leaves out position j is the product of the SIBLINGS along j's path to the root: ≤ (FAN_IN − 1)·height inputs.  O(n) ops for all n products; the
+    // marginal is the product of the top nodes.  (Products in precision form are sums: the fold order changes the rounding, not the result.)
+    static constexpr int HUB_MIN = 16;
+    struct Hub {
+        int height = 0;                                   // node heights 0 (leaves = edges) … height − 1 (children of the root)
+        std::vector<std::vector<int>> lvl;                // [height][node]: −2 not yet known, −1 empty, else the level of the node's product
+        std::vector<std::vector<std::pair<int, int>>> slot;   // [height][node]: (offset, form) once emitted; offset −2 not yet, −1 empty
+        std::vector<int> pos_of_edge;                     // edge id → position (sparse: by edge id − first edge … kept as a map below)
+    };
+    std::vector<int> hub_of;                              // per variable: index into hubs, −1
+    std::vector<Hub> hubs;
+    std::vector<int> edge_pos;                            // per edge: its position among its variable's edges
+    bool is_hub(int v) const { return hub_of[v] >= 0; }
+    void build_hubs() {
+        hub_of.assign(nv, -1);
+        edge_pos.assign(E, 0);
+        for (int64_t v = 0; v < nv; ++v) {
+            const int n = (int)var_edges[v].size();
+            for (int i = 0; i < n; ++i) edge_pos[var_edges[v][i]] = i;
+            if (n <= HUB_MIN) continue;
+            Hub h;
+            int width = n;
+            while (width > 1) {
+                h.lvl.push_back(std::vector<int>((size_t)width, -2));
+                h.slot.push_back(std::vector<std::pair<int, int>>((size_t)width, {-2, 0}));
+                width = (width + FAN_IN - 1) / FAN_IN;
+                ++h.height;
+            }
+            hub_of[v] = (int)hubs.size();
+            hubs.push_back(std::move(h));
+        }
+    }
+    // level of the product of node (k, idx) of variable v's tree (−1: no live message below it); every live leaf below it has been analysed
+    int hub_node_level(int v, int k, int idx) {
+        Hub& h = hubs[hub_of[v]];
+        int& memo = h.lvl[k][idx];
+        if (memo != -2) return memo;
+        if (k == 0) {
+            const int e = var_edges[v][idx];
+            return memo = (null_[e] ? -1 : level[e]);
+        }
+        int cnt = 0, mx = -1;
+        const int nchild = (int)h.lvl[k - 1].size();
+        for (int c = idx * FAN_IN; c < std::min(nchild, (idx + 1) * FAN_IN); ++c) {
+            const int l = hub_node_level(v, k - 1, c);
+            if (l >= 0) { ++cnt; mx = std::max(mx, l); }
+        }
+        return memo = (cnt == 0 ? -1 : cnt == 1 ? mx : mx + 1);
+    }
+    // the siblings along position j's path: (height, node) pairs
+    template <class F>
+    void hub_siblings(int v, int j, F f) {
+        const Hub& h = hubs[hub_of[v]];
+        int idx = j;
+        for (int k = 0; k < h.height; ++k) {
+            const int parent = idx / FAN_IN, nk = (int)h.lvl[k].size();
+            for (int c = parent * FAN_IN; c < std::min(nk, (parent + 1) * FAN_IN); ++c)
+                if (c != idx) f(k, c);
+            idx = parent;
+        }
+    }
+    // (offset, form) of node (k, idx)'s product, emitting it (and what it needs) on first use; offset −1: empty
+    std::pair<int, int> hub_node_slot(int v, int k, int idx, int L0) {
+        Hub& h = hubs[hub_of[v]];
+        std::pair<int, int>& memo = h.slot[k][idx];
+        if (memo.first != -2) return memo;
+        if (k == 0) {
+            const int e = var_edges[v][idx];
+            return memo = (null_[e] ? std::pair<int, int>{-1, 0} : std::pair<int, int>{src_off(e), (int)form[e]});
+        }
+        std::vector<std::pair<int, int>> ins;
+        const int nchild = (int)h.lvl[k - 1].size(), d = P.dim[v];
+        for (int c = idx * FAN_IN; c < std::min(nchild, (idx + 1) * FAN_IN); ++c) {
+            const auto sl = hub_node_slot(v, k - 1, c, L0);
+            if (sl.first >= 0) ins.push_back(sl);
+        }
+        if (ins.empty()) return memo = {-1, 0};
+        if (ins.size() == 1) return memo = ins[0];
+        OpRec& r = emit(L0 + hub_node_level(v, k, idx), OP_PRODUCT, d);
+        r.w[W_OUT] = (int)P.msg_doubles;
+        P.msg_doubles += msz(d);
+        r.w[W_LIST] = (int)P.aux.size();
+        r.w[W_N] = (int)ins.size();
+        for (auto& in : ins) { P.aux.push_back(in.first); P.aux.push_back(in.second); }
+        P.bytes_per_sweep += 8ll * msz(d) * (long long)(ins.size() + 1);
+        return memo = {r.w[W_OUT], 1};
+    }
+
     void analyse() {
+        build_hubs();
         const int M = 2 * E;
         null_.assign(M, 0); needed.assign(M, 0); form.assign(M, 1); done.assign(M, 0);
         alias.assign(M, -1); off.assign(M, -1); level.assign(M, 0);
@@ -352,7 +444,15 @@ struct Compiler {
                 needed[m] = factor_uses_v2f(edges[e].f);
                 if (live.empty()) null_[m] = 1;
                 else if (live.size() == 1) { alias[m] = alias[live[0]] >= 0 ? alias[live[0]] : live[0]; form[m] = form[live[0]]; level[m] = level[live[0]]; }
-                else { form[m] = 1; int lv = 0; for (int x : live) lv = std::max(lv, level[x]); level[m] = lv + rounds((int)live.size()); }
+                else if (is_hub(edges[e].v)) {   // the product of the siblings along this edge's path through the variable's tree (above)
+                    form[m] = 1;
+                    int cnt = 0, lv = 0;
+                    hub_siblings(edges[e].v, edge_pos[e], [&](int k, int c) {
+                        const int l = hub_node_level(edges[e].v, k, c);
+                        if (l >= 0) { ++cnt; lv = std::max(lv, l); }
+                    });
+                    level[m] = lv + rounds(std::max(cnt, 1));
+                } else { form[m] = 1; int lv = 0; for (int x : live) lv = std::max(lv, level[x]); level[m] = lv + rounds((int)live.size()); }
             } else {        // factor -> variable
                 const Edge& ed = edges[m];
                 needed[m] = 1;
@@ -557,8 +657,14 @@ struct Compiler {
             maxl = std::max(maxl, lv);
             if (m >= E) {   // product
                 std::vector<std::pair<int, int>> ins;
-                for (int dpm : deps[m])
-                    if (!null_[dpm]) ins.push_back({src_off(dpm), (int)form[dpm]});
+                if (is_hub(ed.v)) {
+                    hub_siblings(ed.v, edge_pos[m - E], [&](int k, int c) {
+                        const auto sl = hub_node_slot(ed.v, k, c, L0);
+                        if (sl.first >= 0) ins.push_back(sl);
+                    });
+                } else
+                    for (int dpm : deps[m])
+                        if (!null_[dpm]) ins.push_back({src_off(dpm), (int)form[dpm]});
                 int lvp = lv - rounds((int)ins.size()) + 1;   // a hub: partial products first; `lv` (analyse) is the level of the final op
                 ins = reduce_inputs(ins, d, lvp);
                 OpRec& r = emit(lvp, OP_PRODUCT, d);
@@ -628,9 +734,18 @@ struct Compiler {
             if (P.vclass[v] != VC_GAUSS) continue;
             const int d = P.dim[v];
             std::vector<std::pair<int, int>> ins;
-            for (int e : var_edges[v])
-                if (!null_[e]) ins.push_back({src_off(e), (int)form[e]});
-            int lvm = LM;
+            int hub_lv = 0;
+            if (is_hub((int)v)) {   // the top nodes of the variable's tree (their products exist already wherever a neighbour needed them)
+                const Hub& h = hubs[hub_of[v]];
+                const int top = h.height - 1;
+                for (int c = 0; c < (int)h.lvl[top].size(); ++c) {
+                    const auto sl = hub_node_slot((int)v, top, c, L0);
+                    if (sl.first >= 0) { ins.push_back(sl); hub_lv = std::max(hub_lv, L0 + hub_node_level((int)v, top, c) + 1); }
+                }
+            } else
+                for (int e : var_edges[v])
+                    if (!null_[e]) ins.push_back({src_off(e), (int)form[e]});
+            int lvm = std::max(LM, hub_lv);   // (a hub nobody takes a product from builds its tree for the marginal alone: behind the last node)
             ins = reduce_inputs(ins, d, lvm);
             lm_last = std::max(lm_last, lvm);
             OpRec& r = emit(lvm, OP_MARGINAL, d);

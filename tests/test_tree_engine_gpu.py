@@ -305,3 +305,15 @@ def test_nan_in_the_data_is_refused_by_name():
         eng.set_data(ys, data)          # the engine is still usable
         eng.run(1, True)
         assert np.all(np.isfinite(eng.free_energy_per_replica()))
+
+
+def test_a_hub_of_a_thousand_leaves():
+    """shared partial-product trees at a variable of degree 1 001 (every third leaf behind a map: 334 products of 1 000 messages each from ONE tree)"""
+    gb, ys, named = tg.star(n_leaves=1000, d=2)
+    R = 2
+    eng, data = _run(gb, ys, R)
+    assert eng.info["n_ops"] < 12 * 1000
+    ref = _check(gb, ys, eng, data, replicas=(R - 1,))
+    assert eng.counters()["rule_calls"] == ref["counters"]["rule_calls"] * R
+    eng.close()
+

@@ -73,3 +73,15 @@ def test_what_the_compiler_refuses():
     with pytest.raises(rxhip.RxHipError) as ei:
         plan(gb)
     assert ei.value.status == _lib.ERR_NOT_POSDEF
+
+
+def test_a_hub_costs_a_linear_number_of_ops():
+    """a star whose every third leaf sits behind a map needs n / 3 products of n − 1 messages each: shared partial-product trees keep the schedule linear in n
+    (one by one it was 440 000 ops at n = 3 000)"""
+    sizes = {}
+    for n in (300, 3000):
+        gb, ys, _ = tg.star(n_leaves=n, d=2)
+        p = plan(gb)
+        sizes[n] = p["n_ops"]
+        assert p["rule_calls"] == _oracle_counts(gb, ys)["rule_calls"]
+    assert sizes[3000] < 12 * 3000 and sizes[3000] < 11 * sizes[300]
