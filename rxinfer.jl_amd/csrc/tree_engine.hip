@@ -914,7 +914,7 @@ struct Engine {
     hipStream_t stream = nullptr;
     bool own_stream = false;
     long long R = 1, RS = 16;
-    int mode = 0, mode_fe = 0, rb = 16;   // schedule of the sweep phase / of the Bethe phase (tree_kernels.hpp: 0 a launch per level, 1 resident levels, 2 walk)
+    int mode = 0, mode_fe = 0, rb = 16, rb_fe = 16, wg = 256;   // schedule of the sweep phase / of the Bethe phase (tree_kernels.hpp: 0 a launch per level, 1 resident levels, 2 walk)
     int *d_ops = nullptr, *d_aux = nullptr, *d_lvl = nullptr, *d_status = nullptr;
     double *d_cpool = nullptr, *d_msg = nullptr, *d_marg = nullptr, *d_val = nullptr, *d_prec = nullptr, *d_term = nullptr, *d_stat = nullptr, *d_prec_init = nullptr,
            *d_fe_rep = nullptr, *d_fe_hist = nullptr;
@@ -1031,8 +1031,9 @@ void launch_phase(const Engine* e, const TreeParams& p, int l0, int l1) {
         const unsigned blocks = (unsigned)((e->R + 63) / 64);
         hipLaunchKernelGGL((k_tree_walk<N, PHASE>), dim3(blocks), dim3(64), 0, e->stream, p, e->prog.lvl_ptr[l0], e->prog.lvl_ptr[l1]);
     } else if (mode == 1) {
-        const unsigned blocks = (unsigned)((e->R + e->rb - 1) / e->rb);
-        hipLaunchKernelGGL((k_tree_levels<N, PHASE>), dim3(blocks), dim3(256), 0, e->stream, p, e->d_lvl, l0, l1, e->rb);
+        const int rb = PHASE == 0 ? e->rb : e->rb_fe, wg = PHASE == 0 ? e->wg : 256;   // (the Bethe phase's instance is built for 256 threads: at 512 it spills)
+        const unsigned blocks = (unsigned)((e->R + rb - 1) / rb);
+        hipLaunchKernelGGL((k_tree_levels<N, PHASE>), dim3(blocks), dim3(wg), 0, e->stream, p, e->d_lvl, l0, l1, rb);
     } else {
         for (int l = l0; l < l1; ++l) {
             const int o0 = e->prog.lvl_ptr[l], o1 = e->prog.lvl_ptr[l + 1];
@@ -1122,7 +1123,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
         for (int l = 0; l < P.n_levels; ++l) {
             const double w = (double)(P.lvl_ptr[l + 1] - P.lvl_ptr[l]);
             if (w <= 0.0) continue;
-            c1 += 1.0 + std::ceil(w * (double)std::min<long long>(16, e->R) / 256.0) * 2.5;
+            c1 += 1.0 + std::ceil(w * (double)std::min<long long>(16, e->R) / ((e->R >= 4096 && P.dmax <= 4) ? 512.0 : 256.0)) * 2.5;
             c0 += 3.6 + std::ceil(w * (double)e->R / (256.0 * 1024.0)) * 2.5;
         }
         e->mode = c1 < c0 ? 1 : 0;
@@ -1142,11 +1143,15 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = e->mode_fe = std::max(0, std::min(2, std::atoi(m)));
     if (P.dmax > 8 && e->mode == 1) e->mode = e->mode_fe = 2;   // (no workgroup-resident schedule for the LDS-staged kernels)
     {
-        // replicas per workgroup of the resident schedule: about 512 workgroups (two per CU) — measured optimum at every batch from 4 096 to 65 536 replicas
-        // (16 384: rb 16 → 32: 5.79 → 3.93 ms; 32 768: 32 → 64: 7.47 → 6.00; 65 536: 64 → 128: 11.38 → 10.65; 4 096: 16 stays)
-        long long rb = (e->R / 512) / 16 * 16;
-        e->rb = (int)std::min<long long>(128, std::max<long long>(16, rb));
-        if (const char* q = hook_env("RXHIP_TREE_RB")) e->rb = std::max(16, std::min(256, std::atoi(q) / 16 * 16));
+        // Workgroups of the resident schedule.  Sweep phase, from 4 096 replicas: 512 threads owning R / 256 replicas (≤ 256) — one workgroup of eight wavefronts
+        // per CU; below, and for the Bethe phase: 256 threads owning R / 512 replicas (≤ 128).  Measured optimum at every batch from 4 096 to 65 536 replicas
+        // (profiles/r05/tree_modes.txt: 16 384 replicas 5.79 → 3.19 ms, 32 768: 7.47 → 5.1, 65 536: 11.7 → 9.2).
+        e->wg = (e->R >= 4096 && P.dmax <= 4) ? 512 : 256;
+        long long rb = (e->R / (e->wg == 512 ? 256 : 512)) / 16 * 16;
+        e->rb = (int)std::min<long long>(e->wg == 512 ? 256 : 128, std::max<long long>(16, rb));
+        e->rb_fe = (int)std::min<long long>(128, std::max<long long>(16, (e->R / 512) / 16 * 16));
+        if (const char* q = hook_env("RXHIP_TREE_RB")) e->rb = e->rb_fe = std::max(16, std::min(256, std::atoi(q) / 16 * 16));
+        if (const char* q = hook_env("RXHIP_TREE_WG")) e->wg = std::atoi(q) >= 512 ? 512 : 256;
     }
     auto cleanup = [&](rxhip_status st) { destroy(e); return st; };
     if (stream) e->stream = (hipStream_t)stream;

@@ -689,10 +689,11 @@ __global__ void __launch_bounds__(256) k_tree_ops(TreeParams p, int op0, int op1
         eval_op<N, PHASE>(p, p.ops + (size_t)(op0 + o) * OP_WORDS, r);
     }
 }
+// (sweep phase at N ≤ 4: up to 512 threads — eight wavefronts share a CU's level barriers; the Bethe phase and the 8×8 instance need the registers of 256)
 // the whole schedule in one launch: a workgroup owns `rb` replicas (a multiple of 16: whole 128-byte lines of every slot) and walks the levels with a
 // workgroup barrier between them — for deep, narrow graphs (a chain is three levels per time step) where a launch per level would cost more than the level
 template <int N, int PHASE>
-__global__ void __launch_bounds__(256) k_tree_levels(TreeParams p, const int* __restrict__ lvl_ptr, int l0, int l1, int rb) {
+__global__ void __launch_bounds__((PHASE == 0 && N <= 4) ? 512 : 256) k_tree_levels(TreeParams p, const int* __restrict__ lvl_ptr, int l0, int l1, int rb) {
     const long long r0 = (long long)blockIdx.x * rb;
     const int nr = (int)((p.R - r0) < rb ? (p.R - r0) : rb);
     for (int l = l0; l < l1; ++l) {
