@@ -294,7 +294,7 @@ __device__ __forceinline__ void mm_tiles(const Ctx& c, int C, int A, int sai, in
 __device__ __forceinline__ void matmul(const Ctx& c, int C, int A, bool ta, int B, bool tb, int m, int kk, int n, bool acc_in = false, double sign = 1.0) {
     const int LD = c.LD;
     const int sai = ta ? 1 : LD, sak = ta ? LD : 1, sbk = tb ? 1 : LD, sbj = tb ? LD : 1;
-    if (m * n > 16 * WL) mm_tiles<4, 4>(c, C, A, sai, sak, B, sbk, sbj, m, kk, n, acc_in, sign);
+    if (m * n >= 8 * WL) mm_tiles<4, 4>(c, C, A, sai, sak, B, sbk, sbj, m, kk, n, acc_in, sign);
     else mm_tiles<2, 2>(c, C, A, sai, sak, B, sbk, sbj, m, kk, n, acc_in, sign);
 }
 // tr(A B) of two d×d tiles
