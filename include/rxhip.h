@@ -58,6 +58,10 @@ extern "C" {
  *     RXHIP_MSEG_MAX_BYTES=n    masked schedule: cap on its record block (an engine that exceeds it stays on the sequential schedule)
  *     RXHIP_WAVE8=0             masked schedule, one segment per chain, d <= 8: the MFMA sweep kernels instead of the in-wave ones
  *     RXHIP_NO_FROZEN=1         MFMA path, time-invariant models at d >= 48: every step of the sweeps in full (no FROZEN / BFROZEN stretches, below)
+ *     RXHIP_TREE_MODE=0|1|2     node-array executor: a launch per level / workgroup-resident levels / a lane (a wavefront above d = 8) per replica walks the
+ *                               schedule, for both phases (default: by batch and graph shape, per phase)
+ *     RXHIP_TREE_RB=n, RXHIP_TREE_WG=256|512
+ *                               node-array executor, workgroup-resident levels: replicas per workgroup (multiple of 16) and threads per workgroup of the sweep phase
  *
  * Fixed-point exits (time-invariant models only: one set of constants per chain, no `missing`, no per-step constants).  The covariance
  * recursions of such a chain — forward Riccati, backward smoother — converge geometrically, and the sweeps stop RECOMPUTING a recursion's

@@ -1151,7 +1151,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
         e->rb = (int)std::min<long long>(e->wg == 512 ? 256 : 128, std::max<long long>(16, rb));
         e->rb_fe = (int)std::min<long long>(128, std::max<long long>(16, (e->R / 512) / 16 * 16));
         if (const char* q = hook_env("RXHIP_TREE_RB")) e->rb = e->rb_fe = std::max(16, std::min(256, std::atoi(q) / 16 * 16));
-        if (const char* q = hook_env("RXHIP_TREE_WG")) e->wg = std::atoi(q) >= 512 ? 512 : 256;
+        if (const char* q = hook_env("RXHIP_TREE_WG")) e->wg = (std::atoi(q) >= 512 && P.dmax <= 4) ? 512 : 256;   // (the 8×8 instance is built for 256 threads)
     }
     auto cleanup = [&](rxhip_status st) { destroy(e); return st; };
     if (stream) e->stream = (hipStream_t)stream;
