@@ -283,6 +283,18 @@ typedef struct {
     int64_t n_observations;          /* streaming (one-step) graphs: observations that will be pushed per replica */
     int32_t allow_missing;           /* state-space graphs: some data variable holds `missing` (the data is known when the model
                                         is created, src/inference/batch.jl:252) — as rxhip_lgssm_desc.allow_missing */
+    /* The factorisation of q around every node — what the stock plugin hands to `factornode(fform, interfaces, factorization)` as
+     * GraphPPL.VariationalConstraintsFactorizationIndicesKey (src/model/plugins/reactivemp_inference.jl:499-506): NULL, or one cluster id per entry
+     * of factor_iface (same indexing, [n_factors][3] or CSR): interfaces of ONE node with equal ids share a factor of q — the reference's
+     * ((1, 2), (3,)) on (out, μ, Σ) is 0, 0, 1.  Ids are local to their node; ids of clamped (data / constant) interfaces are ignored.
+     * Every schedule implements ONE factorisation per node type:
+     *   Gaussian nodes — q(out, μ) joint, a random third interface (precision) in a factor of its own;  `*`, `+` — all random interfaces joint;
+     *   GCV — q(y, x) q(z);  NormalMixture, Categorical, Bernoulli and the priors — mean-field (every random interface its own factor);
+     * the node-array executor ALSO runs Gaussian nodes under q(out) q(μ) (mean-field between the two Gaussian interfaces: `MeanField()` on a chain).
+     * A table that asks a node for anything else is RXHIP_ERR_UNSUPPORTED with the node named (→ stock plugin) from every lowering pass, rxhip_create,
+     * rxhip_tree_create and rxhip_tree_plan — never silently the other variational family's posterior.  NULL = the factorisation above (joint Gaussian
+     * interfaces), which is what GraphPPL's default constraints (BetheFactorization) produce for the BP families. */
+    const int32_t* factor_cluster;
 } rxhip_graph_desc;
 
 /* result of the lowering pass for the LGSSM family; matrices are written into caller buffers of the sizes below

@@ -60,7 +60,80 @@ inline long long iface(const rxhip_graph_desc* g, long long f, int k) {
 inline int n_iface(const rxhip_graph_desc* g, long long f) {
     return g->factor_iface_ptr ? (int)(g->factor_iface_ptr[f + 1] - g->factor_iface_ptr[f]) : 3;
 }
+inline const char* node_name(int type) {
+    switch (type) {
+    case RXHIP_NODE_MVNORMAL_MEAN_COV: return "MvNormalMeanCovariance";
+    case RXHIP_NODE_MULTIPLY: return "*";
+    case RXHIP_NODE_NORMAL_MEAN_VARIANCE: return "NormalMeanVariance";
+    case RXHIP_NODE_NORMAL_MEAN_PRECISION: return "NormalMeanPrecision";
+    case RXHIP_NODE_GAMMA_SHAPE_RATE: return "GammaShapeRate";
+    case RXHIP_NODE_DIRICHLET: return "Dirichlet";
+    case RXHIP_NODE_BETA: return "Beta";
+    case RXHIP_NODE_CATEGORICAL: return "Categorical";
+    case RXHIP_NODE_BERNOULLI: return "Bernoulli";
+    case RXHIP_NODE_NORMAL_MIXTURE: return "NormalMixture";
+    case RXHIP_NODE_GCV: return "GCV";
+    case RXHIP_NODE_WISHART: return "Wishart";
+    case RXHIP_NODE_ADD: return "+";
+    case RXHIP_NODE_MVNORMAL_MEAN_PRECISION: return "MvNormalMeanPrecision";
+    case RXHIP_NODE_GAMMA_SHAPE_SCALE: return "GammaShapeScale";
+    default: return "?";
+    }
+}
+// The factorisation of q around every node (rxhip_graph_desc.factor_cluster = the reference's VariationalConstraintsFactorizationIndicesKey,
+// src/model/plugins/reactivemp_inference.jl:499-506) against the ONE factorisation per node type the schedules implement (include/rxhip.h).
+// `gaussian_meanfield` (the node-array executor only): receives, per factor, 1 where a Gaussian node is asked for q(out) q(μ) — without it such a node
+// is refused like every other mismatch, with the node named.  Call after the interface tables have been validated.
+inline rxhip_status check_factorisation(const rxhip_graph_desc* g, std::vector<char>* gaussian_meanfield = nullptr) {
+    if (gaussian_meanfield) gaussian_meanfield->assign((size_t)g->n_factors, 0);
+    if (!g->factor_cluster) return RXHIP_OK;
+    for (long long f = 0; f < g->n_factors; ++f) {
+        const int n = n_iface(g, f), t = g->factor_type[f];
+        const long long base = g->factor_iface_ptr ? g->factor_iface_ptr[f] : 3 * f;
+        auto rnd = [&](int k) { return g->var_kind[iface(g, f, k)] == RXHIP_VARKIND_RANDOM; };
+        auto cl = [&](int k) { return g->factor_cluster[base + k]; };
+        auto refuse = [&](const char* asked, const char* have) {
+            return unsupported("factor " + std::to_string(f) + " (" + node_name(t) + "): the model's constraints ask for " + asked + ", the device schedule of this node implements " +
+                               have + " (rxhip_graph_desc.factor_cluster)");
+        };
+        // which pairs of random interfaces the schedule keeps in one factor of q
+        auto joint = [&](int a, int b) -> bool {
+            switch (t) {
+            case RXHIP_NODE_MVNORMAL_MEAN_COV: case RXHIP_NODE_NORMAL_MEAN_VARIANCE: case RXHIP_NODE_MVNORMAL_MEAN_PRECISION: case RXHIP_NODE_NORMAL_MEAN_PRECISION:
+                return a < 2 && b < 2;
+            case RXHIP_NODE_MULTIPLY: case RXHIP_NODE_ADD: return true;
+            case RXHIP_NODE_GCV: return a < 2 && b < 2;
+            default: return false;
+            }
+        };
+        const bool gauss = t == RXHIP_NODE_MVNORMAL_MEAN_COV || t == RXHIP_NODE_NORMAL_MEAN_VARIANCE || t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION;
+        for (int a = 0; a < n; ++a) {
+            if (!rnd(a)) continue;
+            for (int b = a + 1; b < n; ++b) {
+                if (!rnd(b) || iface(g, f, a) == iface(g, f, b)) continue;
+                const bool same = cl(a) == cl(b), want = joint(a, b);
+                if (same == want) continue;
+                if (gauss && a == 0 && b == 1 && !same) {   // q(out) q(μ)
+                    if (!gaussian_meanfield) return refuse("q(out) q(μ) (mean-field between the Gaussian interfaces)", "the structured q(out, μ); only the node-array executor runs the mean-field form");
+                    (*gaussian_meanfield)[(size_t)f] = 1;
+                    continue;
+                }
+                if (gauss) return refuse("a joint factor of q over a Gaussian interface and the precision", "q(out, μ) q(precision)");
+                if (t == RXHIP_NODE_MULTIPLY || t == RXHIP_NODE_ADD) return refuse("a factorised q around a deterministic node", "the joint over its random interfaces");
+                if (t == RXHIP_NODE_GCV) return refuse(same ? "a joint factor with the volatility input z" : "q(y) q(x)", "q(y, x) q(z)");
+                return refuse("a structured factor of q", "the mean-field factorisation (every random interface its own factor)");
+            }
+        }
+    }
+    return RXHIP_OK;
+}
+inline rxhip_status check_tables_only(const rxhip_graph_desc* g);
+// tables, then the factorisation every pattern-matched family assumes (a Gaussian node under q(out) q(μ) is the executor's: refused here)
 inline rxhip_status check_tables(const rxhip_graph_desc* g) {
+    if (rxhip_status st = check_tables_only(g)) return st;
+    return check_factorisation(g);
+}
+inline rxhip_status check_tables_only(const rxhip_graph_desc* g) {
     if (!g || g->n_variables <= 0 || g->n_factors <= 0 || !g->var_kind || !g->var_rows || !g->var_cols || !g->var_const ||
         !g->factor_type || !g->factor_iface || (g->n_const > 0 && !g->const_pool))
         return badarg("graph descriptor has null tables");

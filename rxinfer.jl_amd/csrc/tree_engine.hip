@@ -205,6 +205,9 @@ struct Compiler {
             }
             if (n_iface((int)f) != 3) fail(RXHIP_ERR_BADARG, "factor %lld: three interfaces expected", (long long)f);
         }
+        // the factorisation the model's constraints ask of every node against the one this schedule implements (q(out, μ) q(W) on Gaussian nodes, joint
+        // deterministic nodes): a mismatch is refused with the node named — never answered with the other variational family's posterior
+        if (rxhip_lower::check_factorisation(g, nullptr)) fail(RXHIP_ERR_UNSUPPORTED, "%s", rxhip_lower::last_error().c_str());
         // precision variables
         for (int64_t f = 0; f < nf; ++f)
             if (nclass[f] == NC_PRIOR) {

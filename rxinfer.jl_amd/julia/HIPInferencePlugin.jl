@@ -111,11 +111,12 @@ mutable struct GraphTables
     factor_iface_ptr::Vector{Int64}       # CSR offsets, 0-based
     factor_iface::Vector{Int64}           # variable ids, 0-based
     factor_iface_names::Vector{String}
+    factor_cluster::Vector{Int32}         # per entry of factor_iface: the cluster of q the interface belongs to WITHIN its node (0-based)
     const_pool::Vector{Float64}
     gh_points::Int32
     id_of::Dict{GraphPPL.NodeLabel, Int64}
     GraphTables() = new(Int32[], Int32[], Int32[], Int64[], Int32[], Int64[], String[], Any[], Int32[], String[], Int64[0], Int64[],
-                        String[], Float64[], Int32(0), Dict{GraphPPL.NodeLabel, Int64}())
+                        String[], Int32[], Float64[], Int32(0), Dict{GraphPPL.NodeLabel, Int64}())
 end
 
 struct UnsupportedGraph <: Exception
@@ -173,15 +174,26 @@ function build_tables(model::GraphPPL.Model)
         code, name, order = spec
         # (interface name, index within an indexed interface such as m[k] of NormalMixture) -> variable id
         found = Dict{Tuple{Symbol, Int}, Int64}()
-        for (vlabel, edge, _) in GraphPPL.neighbors(props)
+        # the factorisation of q around this node, exactly what the stock plugin hands to `factornode(fform, interfaces, factorization)`
+        # (reactivemp_inference.jl:499-506): a tuple of clusters of NEIGHBOUR indices, ((1, 2), (3,)) = q(out, μ) q(Σ)
+        factorization = GraphPPL.getextra(nodedata, GraphPPL.VariationalConstraintsFactorizationIndicesKey)
+        cluster_of_neighbour = Dict{Int, Int32}()
+        for (c, cluster) in enumerate(factorization), n in cluster
+            cluster_of_neighbour[Int(n)] = Int32(c - 1)
+        end
+        cluster_of = Dict{Tuple{Symbol, Int}, Int32}()
+        for (n, (vlabel, edge, _)) in enumerate(GraphPPL.neighbors(props))
             k = something(edge.index, 1)
             found[(GraphPPL.getname(edge), k)] = t.id_of[vlabel]
+            haskey(cluster_of_neighbour, n) || throw(UnsupportedGraph("node $(name): interface $(GraphPPL.getname(edge)) is in no factorisation cluster"))
+            cluster_of[(GraphPPL.getname(edge), k)] = cluster_of_neighbour[n]
         end
         for iname in order
             k = 1
             haskey(found, (iname, 1)) || throw(UnsupportedGraph("node $(name) without interface $(iname)"))
             while haskey(found, (iname, k))     # m[1..K], p[1..K] of NormalMixture are K consecutive entries
                 push!(t.factor_iface, found[(iname, k)])
+                push!(t.factor_cluster, cluster_of[(iname, k)])
                 push!(t.factor_iface_names, k == 1 && !haskey(found, (iname, 2)) ? string(iname) : string(iname, "[", k, "]"))
                 k += 1
             end
@@ -194,8 +206,8 @@ function build_tables(model::GraphPPL.Model)
         elseif meta !== nothing
             throw(UnsupportedGraph("@meta on node $(name)"))   # user meta redirects rule dispatch (inference_tests.jl:2049-2066)
         end
-        # mean-field is the only factorisation the VMP families have a schedule for; BP graphs carry full clusters
-        # (VariationalConstraintsFactorizationIndicesKey is what the stock plugin hands to `factornode`, :499-501)
+        # (the clusters go into rxhip_graph_desc.factor_cluster; every lowering pass and the executor's compiler hold them against the one
+        #  factorisation per node type their schedule implements and answer a mismatch with RXHIP_ERR_UNSUPPORTED -> UnsupportedGraph -> stock plugin)
     end
     fix_shapes!(t)
     return t
@@ -260,7 +272,8 @@ function dump_graph(io::IO, t::GraphTables; n_replicas::Integer = 1, n_observati
         f > 1 && print(io, ",")
         lo, hi = t.factor_iface_ptr[f] + 1, t.factor_iface_ptr[f + 1]
         print(io, "{\"type\":\"", esc(t.factor_name[f]), "\",\"interfaces\":[",
-              join(("[\"" * esc(t.factor_iface_names[k]) * "\"," * string(t.factor_iface[k]) * "]" for k in lo:hi), ","), "]}")
+              join(("[\"" * esc(t.factor_iface_names[k]) * "\"," * string(t.factor_iface[k]) * "]" for k in lo:hi), ","), "],\"clusters\":[",
+              join((string(t.factor_cluster[k]) for k in lo:hi), ","), "]}")
     end
     print(io, "]}")
 end

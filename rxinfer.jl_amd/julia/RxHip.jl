@@ -537,6 +537,7 @@ struct GraphDesc
     gh_points::Int32
     n_observations::Int64
     allow_missing::Int32
+    factor_cluster::Ptr{Int32}
 end
 
 # mirrors rxhip_lgssm_lowered
@@ -606,7 +607,7 @@ with_desc(f, t, n_replicas::Integer, n_observations::Integer; allow_missing::Boo
     f(GraphDesc(length(t.var_kind), pointer(t.var_kind), pointer(t.var_rows), pointer(t.var_cols), pointer(t.var_const),
                 length(t.factor_type), pointer(t.factor_type), pointer(t.factor_iface), pointer(t.const_pool), length(t.const_pool),
                 n_replicas, pointer(t.factor_iface_ptr), pointer(t.var_init_family), pointer(t.var_init), t.gh_points, n_observations,
-                allow_missing ? 1 : 0))
+                allow_missing ? 1 : 0, pointer(t.factor_cluster)))
 end
 
 lowering_error() = unsafe_string(ccall((:rxhip_lowering_error, librxhip), Cstring, ()))

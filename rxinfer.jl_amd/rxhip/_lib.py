@@ -46,7 +46,9 @@ class GraphDesc(ctypes.Structure):
                 ("n_replicas", ctypes.c_int64),
                 # optional extensions (zero = 3-interface Gaussian graphs)
                 ("factor_iface_ptr", c_int64_p), ("var_init_family", c_int32_p), ("var_init", c_int64_p),
-                ("gh_points", ctypes.c_int32), ("n_observations", ctypes.c_int64), ("allow_missing", ctypes.c_int32)]
+                ("gh_points", ctypes.c_int32), ("n_observations", ctypes.c_int64), ("allow_missing", ctypes.c_int32),
+                # the factorisation of q around every node (VariationalConstraintsFactorizationIndicesKey): NULL or one cluster id per factor_iface entry
+                ("factor_cluster", c_int32_p)]
 
 
 class LgssmLowered(ctypes.Structure):

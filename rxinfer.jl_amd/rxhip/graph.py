@@ -39,6 +39,7 @@ class GraphBuilder:
     def __init__(self):
         self.kind, self.rows, self.cols, self.coff = [], [], [], []
         self.ftype, self.fiface = [], []
+        self.fcluster = {}   # factor index -> cluster id per interface (the node's VariationalConstraintsFactorizationIndicesKey); absent: the schedule's own
         self.pool = []
         self._n = 0
         self.init_family, self.init_off = {}, {}
@@ -92,6 +93,8 @@ class GraphBuilder:
             labels = list(order[:2]) + [f"{order[2]}[{k + 1}]" for k in range((len(ifs) - 2) // 2)] + \
                 [f"{order[3]}[{k + 1}]" for k in range((len(ifs) - 2) // 2)] if name == "NormalMixture" else list(order)
             factors.append({"type": name, "interfaces": [[l, int(v)] for l, v in zip(labels, ifs)]})
+            if self.fcluster:
+                factors[-1]["clusters"] = [int(c) for c in self.clusters_of(len(factors) - 1)]
         return {"format": "rxhip-graph-1", "n_replicas": int(n_replicas), "n_observations": int(n_observations),
                 "gh_points": int(self.gh_points), "variables": variables, "factors": factors}
 
@@ -119,7 +122,7 @@ class GraphBuilder:
         for f in dump["factors"]:
             if f["type"] not in codes:
                 raise RxHipError(_lib.ERR_UNSUPPORTED, f"node {f['type']} has no device schedule")
-            gb.node(codes[f["type"]], *[int(i) for _, i in f["interfaces"]])
+            gb.node(codes[f["type"]], *[int(i) for _, i in f["interfaces"]], clusters=f.get("clusters"))
         gb.gh_points = int(dump.get("gh_points", 0))
         gb.n_replicas, gb.n_observations = int(dump.get("n_replicas", 1)), int(dump.get("n_observations", 0))
         return gb
@@ -128,9 +131,70 @@ class GraphBuilder:
         """out ~ MvNormal(μ = mu, Σ = sigma)  ->  MvNormalMeanCovariance (src/model/graphppl.jl:372-376)"""
         self.ftype.append(_lib.NODE_MVNORMAL_MEAN_COV); self.fiface.append((out, mu, sigma))
 
-    def node(self, ntype, *ifaces):
-        """generic factor node: interfaces in the node's declared order"""
+    def node(self, ntype, *ifaces, clusters=None):
+        """generic factor node: interfaces in the node's declared order; clusters: one id per interface — the factorisation of q around the node
+        (GraphPPL.VariationalConstraintsFactorizationIndicesKey, reactivemp_inference.jl:499-506; ((1, 2), (3,)) is 0, 0, 1)"""
         self.ftype.append(ntype); self.fiface.append(tuple(ifaces))
+        if clusters is not None:
+            self.set_clusters(len(self.ftype) - 1, clusters)
+
+    @staticmethod
+    def default_clusters(ntype, n):
+        """the factorisation the device schedules implement per node type (include/rxhip.h rxhip_graph_desc.factor_cluster) — what GraphPPL's default
+        constraints give the BP families and what the reference tests' @constraints give the VMP ones"""
+        if ntype in (_lib.NODE_MVNORMAL_MEAN_COV, _lib.NODE_NORMAL_MEAN_VARIANCE, _lib.NODE_MVNORMAL_MEAN_PRECISION, _lib.NODE_NORMAL_MEAN_PRECISION):
+            return (0, 0, 1)
+        if ntype in (_lib.NODE_MULTIPLY, _lib.NODE_ADD):
+            return (0,) * n
+        if ntype == _lib.NODE_GCV:
+            return (0, 0) + tuple(range(1, n - 1))
+        return tuple(range(n))
+
+    def set_clusters(self, f, clusters):
+        if len(clusters) != len(self.fiface[f]):
+            raise ValueError("one cluster id per interface")
+        self.fcluster[f] = tuple(int(c) for c in clusters)
+
+    def clusters_of(self, f):
+        return self.fcluster.get(f, self.default_clusters(self.ftype[f], len(self.fiface[f])))
+
+    def _grouped(self, f, joint):
+        """cluster ids as GraphPPL materialises them: clamped (data / constant) interfaces each a cluster of their own, random interfaces joined where
+        `joint(k, l)`; clusters numbered by their first interface"""
+        ifs = self.fiface[f]
+        ids, nxt = [-1] * len(ifs), 0
+        for k in range(len(ifs)):
+            if ids[k] >= 0:
+                continue
+            ids[k] = nxt
+            if self.kind[ifs[k]] == _lib.VARKIND_RANDOM:
+                for l in range(k + 1, len(ifs)):
+                    if ids[l] < 0 and self.kind[ifs[l]] == _lib.VARKIND_RANDOM and joint(k, l):
+                        ids[l] = nxt
+            nxt += 1
+        return tuple(ids)
+
+    def bethe(self):
+        """GraphPPL's default constraints: all random interfaces of a node in one factor of q (the BP families)"""
+        for f in range(len(self.ftype)):
+            self.fcluster[f] = self._grouped(f, lambda k, l: True)
+        return self
+
+    def gaussian_joint(self):
+        """`q(x, W) = q(x)q(W)`: the Gaussian interfaces of a node joint, a random precision interface a factor of its own — the constraints a model with
+        Wishart / Gamma precisions needs (under the default the reference has no rule for the joint q(out, μ, W))"""
+        gauss = (_lib.NODE_MVNORMAL_MEAN_COV, _lib.NODE_NORMAL_MEAN_VARIANCE, _lib.NODE_MVNORMAL_MEAN_PRECISION, _lib.NODE_NORMAL_MEAN_PRECISION)
+        for f, t in enumerate(self.ftype):
+            self.fcluster[f] = self._grouped(f, (lambda k, l: k < 2 and l < 2) if t in gauss else (lambda k, l: True))
+        return self
+
+    def mean_field(self):
+        """`constraints = MeanField()`: every interface of every stochastic node a factor of its own; deterministic nodes (`*`, `+`) keep the joint
+        over their random interfaces, as GraphPPL materialises it"""
+        for f, t in enumerate(self.ftype):
+            det = t in (_lib.NODE_MULTIPLY, _lib.NODE_ADD)
+            self.fcluster[f] = self._grouped(f, lambda k, l: det)
+        return self
 
     def initialize(self, var, family, params):
         """`@initialization q(var) = …` (InitMarExtraKey, src/model/plugins/initialization_plugin.jl:201-202)"""
@@ -151,6 +215,7 @@ class GraphBuilder:
         wide = any(len(t) != 3 for t in ifaces)
         fi = np.asarray([v for t in ifaces for v in t], dtype=np.int64)
         ptr = np.concatenate([[0], np.cumsum([len(t) for t in ifaces])]).astype(np.int64)
+        fc = np.asarray([c for i in order for c in self.clusters_of(int(i))], dtype=np.int32) if self.fcluster else None
         nv = len(self.kind)
         fam = np.zeros(nv, dtype=np.int32)
         ioff = np.full(nv, -1, dtype=np.int64)
@@ -179,6 +244,9 @@ class GraphBuilder:
         g.gh_points = int(self.gh_points)
         g.n_observations = int(n_observations)
         g.allow_missing = int(bool(allow_missing))
+        if fc is not None:
+            arrs["fc"] = np.ascontiguousarray(fc)
+            g.factor_cluster = arrs["fc"].ctypes.data_as(_lib.c_int32_p)
         g._keep = arrs  # the descriptor points into these arrays
         return g, arrs
 

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Writes tests/golden/graph_dumps/*.json.gz: the factor graphs GraphPPL builds for the reference's test models, in the
 exchange format the Julia plugin's `dump_graph` emits (rxinfer.jl_amd/julia/HIPInferencePlugin.jl, "rxhip-graph-1") and
-`rxhip.graph.GraphBuilder.from_dump` reads.  No Julia exists in the build image, so the dumps are written BY HAND from the
+`rxhip.graph.GraphBuilder.from_dump` reads — including each node's factorisation clusters ("clusters": one id per interface, the
+node's VariationalConstraintsFactorizationIndicesKey as the model's @constraints materialise it).  No Julia exists in the build image, so the dumps are written BY HAND from the
 `@model` bodies, statement by statement (variables in creation order, one constant variable per use of a constant, one
 anonymous random variable per `A * x` call — docs/src/manuals/model-specification.md:70,217-240):
 
@@ -50,7 +51,7 @@ def mlgssm():
         y = gb.datavar(2, f"y[{i + 1}]")
         gb.node(_lib.NODE_MVNORMAL_MEAN_COV, y, b, gb.constvar(P, "constvar"))
         x_prev = x
-    write("mlgssm", gb)
+    write("mlgssm", gb.bethe())   # no @constraints: GraphPPL's default — the random interfaces of a node share one factor of q
 
 
 def ulgssm():
@@ -64,7 +65,7 @@ def ulgssm():
         y = gb.datavar(1, f"y[{i + 1}]")
         gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y, x, gb.constvar(float(g["obs_var"]), "constvar"))
         x_prev = x
-    write("ulgssm", gb)
+    write("ulgssm", gb.bethe())
 
 
 def gmm_univariate():
@@ -89,7 +90,7 @@ def gmm_univariate():
     for k, mean in enumerate((-2.0, 2.0)):
         gb.initialize(m[k], _lib.INIT_NORMAL, (mean, 1e3))
         gb.initialize(p[k], _lib.INIT_GAMMA, (1.0, 1e-12))
-    write("gmm_univariate", gb)
+    write("gmm_univariate", gb.mean_field())   # gmm_univariate_tests.jl:63-72: MeanField() (and its spelled-out twin)
 
 
 def gmm_multivariate():
@@ -114,7 +115,7 @@ def gmm_multivariate():
         gb.initialize(m[k], _lib.INIT_MVNORMAL, np.concatenate([g["init_mean"][k], np.ravel(g["prior_cov"])]))
         gb.initialize(w[k], _lib.INIT_WISHART, np.concatenate([[float(g["wishart_nu"])], np.ravel(g["wishart_scale"])]))
     gb.initialize(s, _lib.INIT_DIRICHLET, np.ones(K))
-    write("gmm_multivariate", gb)
+    write("gmm_multivariate", gb.mean_field())   # gmm_multivariate_tests.jl:72-76
 
 
 def hgf_step():
@@ -133,6 +134,9 @@ def hgf_step():
     gb.initialize(zt, _lib.INIT_NORMAL, (0.0, 5.0))   # :51-54
     gb.initialize(xt, _lib.INIT_NORMAL, (0.0, 5.0))
     gb.gh_points = 31                                  # GCVMetadata(GaussHermiteCubature(31)), :37-40
+    gb.bethe()
+    gcv = gb.ftype.index(_lib.NODE_GCV)
+    gb.set_clusters(gcv, (0, 0, 1, 2, 3))              # :33-35  q(xt, zt, xt_min) = q(xt, xt_min)q(zt)
     write("hgf_step", gb, n_observations=int(g["y"].size))
 
 

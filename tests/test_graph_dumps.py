@@ -35,7 +35,7 @@ def test_dumps_are_reproducible_from_the_committed_generator(tmp_path):
 def test_dump_format_and_node_vocabulary():
     d = json.load(gzip.open(os.path.join(DUMPS, "mlgssm.json.gz"), "rt"))
     assert d["format"] == "rxhip-graph-1" and len(d["factors"]) == 1 + 4 * 1000 and len(d["variables"]) == 3 + 8 * 1000
-    assert d["factors"][1] == {"type": "*", "interfaces": [["out", 3], ["A", 4], ["in", 0]]}
+    assert d["factors"][1] == {"type": "*", "interfaces": [["out", 3], ["A", 4], ["in", 0]], "clusters": [0, 1, 0]}   # ((1, 3), (2,)): the constant on its own
     assert [i[0] for i in d["factors"][2]["interfaces"]] == ["out", "μ", "Σ"] and d["variables"][0]["name"] == "x_prior"
     names = {v[0] for v in graph.NODE_VOCABULARY.values()}
     for f in os.listdir(DUMPS):
