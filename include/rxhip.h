@@ -441,11 +441,17 @@ rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* 
 rxhip_status rxhip_tree_plan(const rxhip_graph_desc* g, rxhip_tree_info* out, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals);
 /* data of the listed data variables, host [replica][rows of vars[0] | rows of vars[1] | …] (src/inference/batch.jl:405-407 new_observation!) */
 rxhip_status rxhip_tree_set_data(rxhip_engine* e, const int64_t* vars, int64_t n_vars, const double* host);
-/* posteriors of the listed random (Gaussian) variables: mean [var][replica][d], cov [var][replica][d][d], concatenated in list order */
+/* posteriors of the listed random (Gaussian) variables: mean [var][replica][d], cov [var][replica][d][d], concatenated in list order.  A random
+ * variable of the model that the compiler found clamped (the output of `a + b` of two data variables) and a data variable are reported as point
+ * masses: mean = the value, zero covariance. */
 rxhip_status rxhip_tree_get_marginals(rxhip_engine* e, const int64_t* vars, int64_t n_vars, double* mean, double* cov);
 /* q(W) of a precision variable: nu [replica], V [replica][d][d] (a Gamma(a, b) variable is reported as Wishart_1(2a, 1/(2b))) */
 rxhip_status rxhip_tree_get_precision(rxhip_engine* e, int64_t var, double* nu, double* V);
 rxhip_status rxhip_tree_get_info(rxhip_engine* e, rxhip_tree_info* out);
+/* on != 0: every later rxhip_run CONTINUES from the q(W) the previous run ended with instead of the `@initialization` marginals (the first run still
+ * starts there) — for drivers that take one VMP iteration per call, as the loop of src/inference/batch.jl:391-430 does (the plugin's `fire!`):
+ * k calls of rxhip_run(1) then equal one rxhip_run(k), bit for bit.  The twin of rxhip_lgssm_noise_continue. */
+rxhip_status rxhip_tree_continue(rxhip_engine* e, int32_t on);
 /* rxhip_run, rxhip_get_free_energy (sum over the replicas, per iteration), rxhip_get_free_energy_per_chain (per replica, last iteration),
  * rxhip_counters, rxhip_sync, rxhip_get_stream, rxhip_last_error, rxhip_destroy apply as to every engine. */
 

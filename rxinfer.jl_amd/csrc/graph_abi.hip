@@ -138,6 +138,11 @@ rxhip_status rxhip_tree_get_info(rxhip_engine* e, rxhip_tree_info* out) {
     rxhip::tree::info(e->tree, out);
     return RXHIP_OK;
 }
+rxhip_status rxhip_tree_continue(rxhip_engine* e, int32_t on) {
+    if (!e || !e->tree) return e ? fail(e, RXHIP_ERR_BADARG, "rxhip_tree_continue: not an engine of the node-array executor") : RXHIP_ERR_BADARG;
+    rxhip::tree::set_continue(e->tree, on != 0);
+    return RXHIP_OK;
+}
 rxhip_status rxhip_rule_eval(const rxhip_rule_call* call, int32_t device) {
     std::string err;
     const rxhip_status st = rxhip::tree::rule_eval(call, device, err);

@@ -121,7 +121,7 @@ struct Compiler {
     std::vector<char> null_, needed, form, done;
     std::vector<int> alias, off, level;
     std::vector<std::vector<int>> deps, users;
-    std::vector<int> cval_off, cmat_off, noise_off, prior_off;   // constant-pool offsets per variable (−1)
+    std::vector<int> cval_off, cmat_off, noise_off_cov, noise_off_prec, prior_off;   // constant-pool offsets per variable (−1)
     struct OpRec { int level; int w[OP_WORDS]; };
     std::vector<OpRec> recs;
 
@@ -145,7 +145,8 @@ struct Compiler {
         if ((int64_t)g->var_rows[v] * g->var_cols[v] != (int64_t)rows * cols) fail(RXHIP_ERR_BADARG, "constant %d: %d x %d expected", v, rows, cols);
         return const_value(v);
     }
-    int noise_block(int v, int d, bool is_precision) {   // Σ | W | log|W|
+    int noise_block(int v, int d, bool is_precision) {   // Σ | W | log|W|; memoised per (constant, parametrisation): a constant that one node reads as a covariance and another as a precision gets two blocks
+        std::vector<int>& noise_off = is_precision ? noise_off_prec : noise_off_cov;
         if (noise_off[v] >= 0) return noise_off[v];
         if ((int64_t)g->var_rows[v] * g->var_cols[v] != (int64_t)d * d) fail(RXHIP_ERR_BADARG, "noise parameter %d: %d x %d expected", v, d, d);
         std::vector<double> M(cptr(v), cptr(v) + (size_t)d * d), Mi((size_t)d * d);
@@ -539,7 +540,7 @@ struct Compiler {
 
     void allocate() {
         P.marg_off.assign(nv, -1); P.val_off.assign(nv, -1); P.prec_off.assign(nv, -1);
-        cval_off.assign(nv, -1); cmat_off.assign(nv, -1); noise_off.assign(nv, -1); prior_off.assign(nv, -1);
+        cval_off.assign(nv, -1); cmat_off.assign(nv, -1); noise_off_cov.assign(nv, -1); noise_off_prec.assign(nv, -1); prior_off.assign(nv, -1);
         long long vo = 0;
         for (int64_t v = 0; v < nv; ++v)
             if (P.vclass[v] == VC_DATA) { P.val_off[v] = (int)vo; vo += P.dim[v]; P.data_vars.push_back(v); }
@@ -923,6 +924,7 @@ struct Engine {
            *d_fe_rep = nullptr, *d_fe_hist = nullptr;
     int fe_cap = 0;
     bool have_data = false, ran = false;
+    bool cont = false;   // rxhip_tree_continue: later runs go on from the q(W) the previous run ended with
     int last_iterations = 0, last_want_fe = 0;
     std::vector<char> data_set;
     uint64_t runs = 0;
@@ -976,6 +978,12 @@ __global__ void __launch_bounds__(256) k_tree_fe_total(const double* __restrict_
     if (threadIdx.x == 0) *total = sh[0];
 }
 
+// state[k][r] = init[k] for every replica: a run starts from the `@initialization` marginals
+__global__ void __launch_bounds__(256) k_tree_broadcast(double* __restrict__ dst, const double* __restrict__ init, long long n, long long RS) {
+    const long long total = n * RS;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) dst[i] = init[i / RS];
+}
+
 // host layout <-> replica-fastest device layout, on the device (at 65 536 replicas the host loops these replace ran for seconds)
 // data: dst[(k)·RS + r] = src[r·rows + col + k] for k < width — a 32×32 LDS tile so that both sides move whole lines
 __global__ void __launch_bounds__(256) k_tree_scatter(double* __restrict__ dst, const double* __restrict__ src, long long R, long long RS, long long rows, long long col, long long width,
@@ -997,9 +1005,9 @@ __global__ void __launch_bounds__(256) k_tree_scatter(double* __restrict__ dst, 
         }
     }
 }
-struct GatherVar { int off, d; long long mo, co; };
+struct GatherVar { int off, d; long long mo, co; int clamped; };   // clamped: a data / derived value — reported as a point mass (mean = the value, zero covariance)
 // marginals of the listed variables into [variable][replica][d] / [variable][replica][d][d] (the arrays rxhip_tree_get_marginals fills)
-__global__ void __launch_bounds__(256) k_tree_gather(const double* __restrict__ marg, const GatherVar* __restrict__ vars, int n_vars, long long R, long long RS,
+__global__ void __launch_bounds__(256) k_tree_gather(const double* __restrict__ marg, const double* __restrict__ val, const GatherVar* __restrict__ vars, int n_vars, long long R, long long RS,
                                                      double* __restrict__ mean, double* __restrict__ cov) {
     const long long rblocks = (R + 255) / 256;
     for (long long it = blockIdx.x; it < (long long)n_vars * rblocks; it += gridDim.x) {
@@ -1008,6 +1016,13 @@ __global__ void __launch_bounds__(256) k_tree_gather(const double* __restrict__ 
         if (r >= R) continue;
         const GatherVar g = vars[vi];
         const int d = g.d;
+        if (g.clamped) {
+            if (mean)
+                for (int k = 0; k < d; ++k) mean[g.mo + r * d + k] = val[(long long)(g.off + k) * RS + r];
+            if (cov)
+                for (int k = 0; k < d * d; ++k) cov[g.co + r * d * d + k] = 0.0;
+            continue;
+        }
         if (mean)
             for (int k = 0; k < d; ++k) mean[g.mo + r * d + k] = marg[(long long)(g.off + k) * RS + r];
         if (cov)
@@ -1275,12 +1290,11 @@ rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err) {
     }
     TCHK(hipMemsetAsync(e->d_status, 0, sizeof(int), e->stream));
     // a run starts from the @initialization marginals (iterations re-push the data: src/inference/batch.jl:391-430)
-    if (P.prec_doubles > 0) {
-        std::vector<double> img((size_t)P.prec_doubles * e->RS);
-        for (long long k = 0; k < P.prec_doubles; ++k)
-            for (long long r = 0; r < e->RS; ++r) img[(size_t)k * e->RS + r] = P.prec_init[k];
-        TCHK(hipStreamSynchronize(e->stream));
-        TCHK(hipMemcpy(e->d_prec, img.data(), sizeof(double) * img.size(), hipMemcpyHostToDevice));
+    // — unless the caller drives the loop one iteration per call (rxhip_tree_continue): then only the first run does
+    if (P.prec_doubles > 0 && !(e->cont && e->ran)) {
+        const long long total = P.prec_doubles * e->RS;
+        hipLaunchKernelGGL(k_tree_broadcast, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, e->stream, e->d_prec, (const double*)e->d_prec_init,
+                           (long long)P.prec_doubles, e->RS);
     }
     const TreeParams p = params_of(e, want_fe);
     // without the free energy on a graph without precision variables the sweep ends with the marginals
@@ -1323,9 +1337,12 @@ rxhip_status get_marginals(Engine* e, const int64_t* vars, int64_t n_vars, doubl
     std::vector<GatherVar> gv((size_t)n_vars);
     for (int64_t i = 0; i < n_vars; ++i) {
         const int64_t v = vars[i];
-        if (v < 0 || v >= (int64_t)P.vclass.size() || P.vclass[v] != VC_GAUSS) { err = "get_marginals: variable " + std::to_string(v) + " is not a random Gaussian variable"; return RXHIP_ERR_BADARG; }
-        gv[i].off = P.marg_off[v];
+        // (a derived clamped value — `a + b` of two data variables, a random variable of the MODEL — is a point mass, as the reference publishes it; so is a data variable)
+        const bool cl = v >= 0 && v < (int64_t)P.vclass.size() && (P.vclass[v] == VC_DERIVED || P.vclass[v] == VC_DATA);
+        if (v < 0 || v >= (int64_t)P.vclass.size() || (P.vclass[v] != VC_GAUSS && !cl)) { err = "get_marginals: variable " + std::to_string(v) + " is not a random Gaussian variable"; return RXHIP_ERR_BADARG; }
+        gv[i].off = cl ? P.val_off[v] : P.marg_off[v];
         gv[i].d = P.dim[v];
+        gv[i].clamped = cl ? 1 : 0;
     }
     TCHK(hipStreamSynchronize(e->stream));
     const size_t cap = (256u << 20) / 8;   // doubles per chunk and array
@@ -1348,7 +1365,7 @@ rxhip_status get_marginals(Engine* e, const int64_t* vars, int64_t n_vars, doubl
         if (he == hipSuccess && cov) he = hipMalloc(&d_c, sizeof(double) * nc);
         if (he == hipSuccess) {
             const long long items = (long long)(i1 - i0) * ((e->R + 255) / 256);
-            hipLaunchKernelGGL(k_tree_gather, dim3((unsigned)std::min<long long>(items, 1 << 20)), dim3(256), 0, e->stream, (const double*)e->d_marg, (const GatherVar*)d_gv, (int)(i1 - i0),
+            hipLaunchKernelGGL(k_tree_gather, dim3((unsigned)std::min<long long>(items, 1 << 20)), dim3(256), 0, e->stream, (const double*)e->d_marg, (const double*)e->d_val, (const GatherVar*)d_gv, (int)(i1 - i0),
                                e->R, e->RS, d_m, d_c);
             he = hipGetLastError();
         }
@@ -1405,6 +1422,7 @@ void counters(Engine* e, uint64_t* rule_calls, uint64_t* products, uint64_t* mar
     if (products) *products = e->prog.products * k;
     if (marginals) *marginals = e->prog.marginals * k;
 }
+void set_continue(Engine* e, bool on) { e->cont = on; }
 void info(Engine* e, rxhip_tree_info* out) {
     const Program& P = e->prog;
     out->n_ops = P.n_ops; out->n_levels = P.n_levels; out->n_messages = P.n_messages;
@@ -1446,6 +1464,7 @@ rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) { err = "no HIP device visible"; return RXHIP_ERR_NO_DEVICE; }
     if (device < 0 && hipGetDevice(&device) != hipSuccess) device = 0;
+    if (device >= ndev) { err = "rule_eval: device ordinal out of range"; return RXHIP_ERR_BADARG; }
     DevScope ds(device);
     // the dimension of the inbound message and of the result
     const int d_in_msg = t == RXHIP_NODE_MULTIPLY ? (c->iface == 0 ? din : dout) : dout;

@@ -22,6 +22,8 @@ rxhip_status get_free_energy(Engine* e, double* per_iteration, std::string& err)
 rxhip_status get_free_energy_per_replica(Engine* e, double* per_replica, std::string& err);
 void counters(Engine* e, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals);
 void info(Engine* e, rxhip_tree_info* out);
+// on: every later run() continues from the q(W) the previous run ended with (rxhip_tree_continue)
+void set_continue(Engine* e, bool on);
 int device_of(Engine* e);
 void* stream_of(Engine* e);
 rxhip_status sync(Engine* e, std::string& err);

@@ -558,6 +558,7 @@ function GraphPPL.postprocess_plugin(plugin::HIPInferencePlugin, model::GraphPPL
     # the chain with an unknown noise precision: `p` carries the variable id of W, `beta` whether its prior was spelled as a Gamma
     comps = lowered.family === :tree ? (m = Int64[], p = Int64[], s = Int64(-1), beta = false) : lowered.family === :lgssm_noise ? (m = Int64[], p = [lowered.precision_id], s = Int64(-1), beta = lowered.gamma) : component_ids(tables)
     lowered.family === :lgssm_noise && RxHip.noise_continue!(engine)
+    lowered.family === :tree && RxHip.tree_continue!(engine)   # one VMP iteration per `fire!`: go on from the current q(W), not from @initialization
     g = HIPGraphEngine(engine, tables, lowered.family, lowered.data_ids, Dict(id => k for (k, id) in enumerate(lowered.data_ids)),
                        zeros(Float64, tree === nothing ? width * length(lowered.data_ids) : tree.data_total), 0, false, marginals, nothing, lowered.state_ids, width,
                        comps,

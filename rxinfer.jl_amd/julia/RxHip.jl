@@ -157,6 +157,11 @@ one VMP iteration per `fire!`, as the loop of src/inference/batch.jl:391-430 doe
 noise_continue!(e::Engine, on::Bool = true) =
     check(e, ccall((:rxhip_lgssm_noise_continue, librxhip), Int32, (Ptr{Cvoid}, Int32), e.handle, on ? 1 : 0))
 
+"""The same for an engine of the node-array executor (`rxhip_tree_continue`): without it every `run!(e; iterations = 1)` of the plugin's `fire!` would
+restart from the `@initialization` q(W) and `infer(iterations = N)` would return the iteration-1 posterior N times."""
+tree_continue!(e::Engine, on::Bool = true) =
+    check(e, ccall((:rxhip_tree_continue, librxhip), Int32, (Ptr{Cvoid}, Int32), e.handle, on ? 1 : 0))
+
 """q(W) of every chain after the last iteration: (ν [chains], V [dy, dy, chains])."""
 function noise_posterior(e::Engine)
     nu = Vector{Float64}(undef, e.n_chains)

@@ -52,6 +52,11 @@ class TreeEngine:
         self._chk(_lib.lib().rxhip_tree_get_info(self._h, ctypes.byref(info)))
         return float(info.last_iteration_ms)
 
+    def continue_runs(self, on=True):
+        """later run() calls go on from the q(W) the previous run ended with instead of the `@initialization` marginals (rxhip_tree_continue): k calls of
+        run(1) then equal one run(k) — how a driver that takes one VMP iteration per call (batch.jl:391-430) uses the engine"""
+        self._chk(_lib.lib().rxhip_tree_continue(self._h, int(bool(on))))
+
     def _chk(self, st):
         if st != _lib.OK:
             raise RxHipError(st, _lib.lib().rxhip_last_error(self._h).decode())

@@ -317,3 +317,85 @@ def test_a_hub_of_a_thousand_leaves():
     assert eng.counters()["rule_calls"] == ref["counters"]["rule_calls"] * R
     eng.close()
 
+
+
+@pytest.mark.parametrize("kw", [dict(T=6, d=2, dy=2, also_obs_noise=True), dict(T=5, d=1, dy=1, gamma=True)])
+def test_n_runs_of_one_iteration_equal_one_run_of_n(kw):
+    """The plugin's `fire!` takes ONE VMP iteration per call (the loop of src/inference/batch.jl:391-430 re-pushes the data each time).  Without
+    rxhip_tree_continue every call restarted from the `@initialization` q(W): infer(iterations = N) returned the iteration-1 posterior N times and a
+    constant free-energy trace.  With it k calls of run(1) are one run(k), bit for bit; without it the first iteration repeats."""
+    from rxhip.tree import TreeEngine
+    gb, ys, nm = tg.chain_state_noise_precision(**kw)
+    R, N = 3, 4
+    data = tg.random_data(gb, ys, R, 5)
+    gv = sorted(eng_gauss(gb))
+    with TreeEngine(gb, n_replicas=R) as one:
+        one.set_data(ys, data)
+        one.run(N, True)
+        fe_n, post_n, qw_n = one.free_energy(), one.marginals(gv), [one.precision(w) for w in nm["W"]]
+    with TreeEngine(gb, n_replicas=R) as eng:
+        eng.continue_runs(True)
+        fes = []
+        for _ in range(N):
+            eng.set_data(ys, data)   # (the driver re-pushes the data every iteration)
+            eng.run(1, True)
+            fes.append(eng.free_energy()[-1])
+        post, qw = eng.marginals(gv), [eng.precision(w) for w in nm["W"]]
+        assert np.array_equal(np.asarray(fes), np.asarray(fe_n))
+        for v in gv:
+            assert np.array_equal(post[v][0], post_n[v][0]) and np.array_equal(post[v][1], post_n[v][1])
+        for a, b in zip(qw, qw_n):
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+        assert fes[-1] < fes[0] - 1e-6                      # the trace moves
+        eng.continue_runs(False)                             # … and off again: a run restarts from the @initialization marginals
+        eng.run(1, True)
+        assert eng.free_energy()[-1] == fe_n[0]
+
+
+def test_one_constant_read_as_a_covariance_and_as_a_precision():
+    """GraphBuilder.constvar reuse: ONE constant variable is the Σ of a MeanCovariance node and the Λ of a MeanPrecision node.  The compiler's memo of the
+    Σ | W | log|W| block was keyed on the variable alone and handed the second node the first one's block with Σ and W swapped."""
+    from rxhip import _lib
+    from rxhip.graph import GraphBuilder
+    from rxhip.tree import TreeEngine
+    import tree_oracle
+    rng = np.random.default_rng(2)
+    M = tg._spd(rng, 2, 0.7)
+    gb = GraphBuilder()
+    c = gb.constvar(M)
+    x = gb.randomvar(2)
+    gb.mvnormal_mean_cov(x, gb.constvar(np.zeros(2)), gb.constvar(3.0 * np.eye(2)))
+    y1, y2 = gb.datavar(2), gb.datavar(2)
+    gb.node(_lib.NODE_MVNORMAL_MEAN_COV, y1, x, c)          # Σ = M
+    gb.node(_lib.NODE_MVNORMAL_MEAN_PRECISION, y2, x, c)    # Λ = M
+    ys = [y1, y2]
+    data = tg.random_data(gb, ys, 2, 0)
+    with TreeEngine(gb, n_replicas=2) as eng:
+        eng.set_data(ys, data)
+        eng.run(1, True)
+        _check(gb, ys, eng, data, replicas=(0, 1))
+    bf, lev = tg.brute_force(gb, tg.data_dict(gb, ys, data[1]))
+    ref = tree_oracle.infer(gb.to_dump(), tg.data_dict(gb, ys, data[1]))
+    assert np.allclose(ref["mean"][x], bf[x][0], rtol=1e-12) and ref["fe"][-1] == pytest.approx(-lev, rel=1e-12)
+
+
+def test_a_derived_clamped_variable_is_published_as_a_point_mass():
+    """`x ~ N(a + b, 1)` with a, b data (test/models/models_tests.jl:242-256): the anonymous output of `a + b` is a random variable of the MODEL that the
+    compiler finds clamped.  The plugin's layout lists it among the variables to publish; rxhip_tree_get_marginals used to answer RXHIP_ERR_BADARG and the
+    first `fire!` threw.  It is a point mass: mean = the value, zero covariance."""
+    from rxhip import _lib
+    from rxhip.graph import GraphBuilder
+    from rxhip.tree import TreeEngine
+    gb = GraphBuilder()
+    a, b, y = gb.datavar(1), gb.datavar(1), gb.datavar(1)
+    s, x = gb.randomvar(1), gb.randomvar(1)
+    gb.node(_lib.NODE_ADD, s, a, b)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, x, s, gb.constvar(1.0))
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y, x, gb.constvar(1.0))
+    with TreeEngine(gb, n_replicas=2) as eng:
+        eng.set_data([a, b, y], np.array([[2.0, 1.0, 0.0], [0.5, -1.5, 4.0]]))
+        eng.run(1, True)
+        post = eng.marginals([s, x, y])
+        assert np.allclose(post[s][0][:, 0], [3.0, -1.0]) and np.all(post[s][1] == 0.0)
+        assert np.allclose(post[y][0][:, 0], [0.0, 4.0]) and np.all(post[y][1] == 0.0)
+        assert post[x][0][0, 0] == pytest.approx(1.5) and eng.free_energy_per_replica()[0] == pytest.approx(3.51551, abs=1e-5)   # models_tests.jl:255
