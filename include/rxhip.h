@@ -425,13 +425,19 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
 typedef struct {
     int64_t n_ops, n_levels, n_messages;  /* ops of one iteration, dependency levels, stored messages */
     int64_t doubles_per_replica;          /* device state per replica */
-    int64_t bytes_per_sweep;              /* algorithmic traffic of one iteration per replica: 8·(d + d(d+1)/2) per message a rule reads or writes */
+    int64_t bytes_per_sweep;              /* message traffic of one iteration per replica in the engine's schedule: 8·(d + d(d+1)/2) per message a rule reads from or writes to HBM */
     int32_t dmax;                         /* kernel instance: 1, 2, 4 or 8 (registers); above 8 the graph's largest dimension (LDS-staged kernels) */
     int32_t mode;                         /* schedule of the sweep phase — 0: one launch per level; 1: one launch per phase, workgroup-resident levels (dmax ≤ 8); 2: a lane (dmax ≤ 8)
-                                             or a wavefront per replica walks the schedule.  (The Bethe / q(W) phase may take the walk while the sweep is still on 1: from 65 536 replicas.) */
+                                             or a wavefront per replica walks the schedule; 3 (dmax ≤ 4, from 16 384 replicas): strands — a lane per (strand, replica) walks a path of
+                                             dependent ops with the message in registers, one launch per strand level; bytes_per_sweep then counts what THAT schedule moves.
+                                             (The Bethe / q(W) phase keeps 1 or 2.) */
     int32_t replicas_per_workgroup;       /* mode 1 */
     int32_t n_precision_vars;
     double last_iteration_ms;             /* device time of the last rxhip_run ÷ its iterations (HIP events around the launches) */
+    int64_t io_bytes_per_sweep;           /* the floor of ANY schedule, per replica: the data in, the posteriors (mean, packed covariance, log-determinant) of the named variables out */
+    int64_t n_strands, n_strand_levels;   /* mode 3: the sweep cut into strands of dependent ops (a lane walks a strand, messages handed over in registers), their dependency levels */
+    int32_t longest_strand;               /* ops of the longest strand */
+    int64_t strand_bytes_per_sweep;       /* bytes_per_sweep of the strand schedule, whichever mode runs */
 } rxhip_tree_info;
 rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* stream, rxhip_engine** out);
 /* The graph compiler alone — host only, no device: would rxhip_tree_create take this graph, and with what schedule?  Fills the static fields of `out`

