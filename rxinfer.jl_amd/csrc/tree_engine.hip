@@ -109,6 +109,8 @@ struct Program {
     long long io_bytes = 0;                     // what has to move whatever the schedule: the data in, the posteriors of the named variables out
     int longest_strand = 0;
     bool fe_heavy = false;   // the second phase holds OP_FE_ADD2 or OP_PREC_UPDATE ops (else the light kernel instance runs it)
+    int n_push = 0, push_levels = 0;   // marginals formed as images (OP_MARG_PUSH): the first level of the second phase, run on demand when a sweep ran without it
+    std::vector<char> is_push;         // per variable
 };
 
 struct Compiler {
@@ -741,8 +743,22 @@ struct Compiler {
         // marginals: one level behind the last message
         const int LM = maxl + 1;
         int lm_last = LM;
+        // (register kernels) the output of `A * x` with x random: its marginal is the image of x's (OP_MARG_PUSH, second phase) — no product of the
+        // messages on its two edges in the sweep; one level only (the input's own marginal comes from messages)
+        push_from.assign(nv, -1);
+        push_fac.assign(nv, -1);
+        if (P.dmax <= 8)
+            for (int64_t f = 0; f < nf; ++f) {
+                if (nclass[f] != NC_MUL) continue;
+                const int o = (int)iface((int)f, 0), in = (int)iface((int)f, 2);
+                if (P.vclass[o] == VC_GAUSS && P.vclass[in] == VC_GAUSS) { push_from[o] = in; push_fac[o] = (int)f; }
+            }
+        for (int64_t v = 0; v < nv; ++v)
+            if (push_from[v] >= 0 && push_from[push_from[v]] >= 0) push_from[v] = -2;   // the input is an image itself: this one takes the message route
+        for (int64_t v = 0; v < nv; ++v)
+            if (push_from[v] == -2) push_from[v] = -1;
         for (int64_t v = 0; v < nv; ++v) {
-            if (P.vclass[v] != VC_GAUSS) continue;
+            if (P.vclass[v] != VC_GAUSS || push_from[v] >= 0) continue;
             const int d = P.dim[v];
             std::vector<std::pair<int, int>> ins;
             int hub_lv = 0;
@@ -766,8 +782,22 @@ struct Compiler {
             for (auto& in : ins) { P.aux.push_back(in.first); P.aux.push_back(in.second); P.bytes_per_sweep += 8ll * msz(d); }
             P.bytes_per_sweep += 8ll * (msz(d) + 1);
         }
-        // Bethe terms and residual moments
-        const int LF = lm_last + 1;
+        // second phase: first the marginals that are images of other marginals, then the Bethe terms and residual moments
+        const int LPUSH = lm_last + 1;
+        bool any_push = false;
+        for (int64_t v = 0; v < nv; ++v) {
+            if (P.vclass[v] != VC_GAUSS || push_from[v] < 0) continue;
+            const int f = push_fac[v], u = push_from[v];
+            OpRec& r = emit(LPUSH, OP_MARG_PUSH, P.dim[v]);
+            r.w[W_D1] = P.dim[u];
+            r.w[W_C0] = const_matrix((int)iface(f, 1), P.dim[v], P.dim[u]);
+            r.w[W_IN0] = P.marg_off[u];
+            r.w[W_OUT] = P.marg_off[v];
+            any_push = true;
+        }
+        P.n_push = 0;
+        for (int64_t v = 0; v < nv; ++v) P.n_push += push_from[v] >= 0;
+        const int LF = LPUSH + (any_push ? 1 : 0);
         std::vector<int> terms;
         std::vector<int> ent_coef(nv, 0);
         std::vector<std::vector<int>> prec_stats(nv);
@@ -866,11 +896,81 @@ struct Compiler {
             ++lv;
         }
         P.fe_root = cur[0];
-        P.fe_level = LF;
+        P.fe_level = LPUSH;
+        P.push_levels = any_push ? 1 : 0;
     }
     int derived_levels = 0;
+    std::vector<int> push_from, push_fac;   // per variable: the variable whose marginal it is the image of (−1), through which `*` node
+
+    // the messages an op reads: (kind 0: descriptor word idx | kind 1: list entry idx, offset, dimension)
+    struct In { int kind, idx, off, d; };
+    static bool produces_msg(int op) { return op == OP_LEAF || op == OP_NOISE || op == OP_MUL_OUT || op == OP_MUL_IN || op == OP_ADD_OUT || op == OP_ADD_IN || op == OP_SHIFT || op == OP_PRODUCT; }
+    std::vector<In> op_inputs(const int* w) const {
+        std::vector<In> v;
+        switch (w[W_OP]) {
+        case OP_NOISE: case OP_SHIFT: case OP_MUL_IN: v.push_back({0, W_IN0, w[W_IN0], w[W_D0]}); break;
+        case OP_MUL_OUT: v.push_back({0, W_IN0, w[W_IN0], w[W_D1]}); break;
+        case OP_ADD_OUT: case OP_ADD_IN: v.push_back({0, W_IN0, w[W_IN0], w[W_D0]}); v.push_back({0, W_IN1, w[W_IN1], w[W_D0]}); break;
+        case OP_PRODUCT: case OP_MARGINAL:
+            for (int q = 0; q < w[W_N]; ++q) v.push_back({1, q, P.aux[(size_t)w[W_LIST] + 2 * q], w[W_D0]});
+            break;
+        case OP_FE_NOISE2M:
+            if (w[W_IN0] >= 0) v.push_back({0, W_IN0, w[W_IN0], w[W_D0]});
+            break;
+        case OP_FE_NOISE2: case OP_FE_ADD2:
+            for (int k : {W_IN0, W_IN1, W_IN2})
+                if ((k != W_IN2 || w[W_OP] == OP_FE_ADD2) && w[k] >= 0) v.push_back({0, k, w[k], w[W_D0]});
+            break;
+        default: break;
+        }
+        return v;
+    }
+    // messages nobody reads (since the marginals of `A * x` outputs stopped being products of messages: the message toward such an output when the node behind
+    // it is observed, the product that fed it): their ops go, and then whatever only they were reading
+    void eliminate_dead_messages() {
+        std::unordered_map<int, int> prod;
+        std::vector<int> readers(recs.size(), 0);
+        std::vector<char> dead(recs.size(), 0);
+        for (size_t i = 0; i < recs.size(); ++i)
+            if (produces_msg(recs[i].w[W_OP])) prod[recs[i].w[W_OUT]] = (int)i;
+        for (size_t i = 0; i < recs.size(); ++i)
+            for (const In& in : op_inputs(recs[i].w)) {
+                auto it = prod.find(in.off);
+                if (it != prod.end()) ++readers[it->second];
+            }
+        std::vector<int> work;
+        for (size_t i = 0; i < recs.size(); ++i)
+            if (produces_msg(recs[i].w[W_OP]) && readers[i] == 0) work.push_back((int)i);
+        while (!work.empty()) {
+            const int i = work.back();
+            work.pop_back();
+            if (dead[i]) continue;
+            dead[i] = 1;
+            for (const In& in : op_inputs(recs[i].w)) {
+                auto it = prod.find(in.off);
+                if (it != prod.end() && --readers[it->second] == 0) work.push_back(it->second);
+            }
+        }
+        std::vector<OpRec> keep;
+        keep.reserve(recs.size());
+        for (size_t i = 0; i < recs.size(); ++i)
+            if (!dead[i]) keep.push_back(recs[i]);
+        recs.swap(keep);
+    }
 
     void finish() {
+        eliminate_dead_messages();
+        // the sweep's message traffic when every message goes through HBM: 8·(d + d(d+1)/2) per message read or written, + the log-determinant slot of a marginal
+        P.bytes_per_sweep = 0;
+        P.n_messages = 0;
+        for (const OpRec& r : recs) {
+            if (r.level >= P.fe_level) continue;
+            for (const In& in : op_inputs(r.w)) P.bytes_per_sweep += 8ll * msz(in.d);
+            if (produces_msg(r.w[W_OP])) { P.bytes_per_sweep += 8ll * msz(r.w[W_OP] == OP_MUL_IN ? r.w[W_D1] : r.w[W_D0]); ++P.n_messages; }
+            else if (r.w[W_OP] == OP_MARGINAL) P.bytes_per_sweep += 8ll * msz(r.w[W_D0]) + 8;
+        }
+        P.is_push.assign(nv, 0);
+        for (int64_t v = 0; v < nv; ++v) P.is_push[v] = push_from[v] >= 0;
         std::stable_sort(recs.begin(), recs.end(), [](const OpRec& a, const OpRec& b) { return a.level != b.level ? a.level < b.level : a.w[W_OP] < b.w[W_OP]; });
         P.n_ops = (int)recs.size();
         for (const OpRec& r : recs) P.fe_heavy = P.fe_heavy || r.w[W_OP] == OP_FE_ADD2 || r.w[W_OP] == OP_PREC_UPDATE;
@@ -922,32 +1022,10 @@ struct Compiler {
     void build_strands() {
         const int n_sweep = P.lvl_ptr[std::min(P.fe_level, P.n_levels)];
         auto W = [&](int i) { return &P.ops[(size_t)i * OP_WORDS]; };
-        auto produces_msg = [](int op) { return op == OP_LEAF || op == OP_NOISE || op == OP_MUL_OUT || op == OP_MUL_IN || op == OP_ADD_OUT || op == OP_ADD_IN || op == OP_SHIFT || op == OP_PRODUCT; };
         std::unordered_map<int, int> prod;
         for (int i = 0; i < n_sweep; ++i)
             if (produces_msg(W(i)[W_OP])) prod[W(i)[W_OUT]] = i;
-        struct In { int kind, idx, off, d; };   // kind 0: descriptor word idx; 1: list entry idx
-        auto inputs = [&](int i) {
-            std::vector<In> v;
-            const int* w = W(i);
-            switch (w[W_OP]) {
-            case OP_NOISE: case OP_SHIFT: case OP_MUL_IN: v.push_back({0, W_IN0, w[W_IN0], w[W_D0]}); break;
-            case OP_MUL_OUT: v.push_back({0, W_IN0, w[W_IN0], w[W_D1]}); break;
-            case OP_ADD_OUT: case OP_ADD_IN: v.push_back({0, W_IN0, w[W_IN0], w[W_D0]}); v.push_back({0, W_IN1, w[W_IN1], w[W_D0]}); break;
-            case OP_PRODUCT: case OP_MARGINAL:
-                for (int q = 0; q < w[W_N]; ++q) v.push_back({1, q, P.aux[(size_t)w[W_LIST] + 2 * q], w[W_D0]});
-                break;
-            case OP_FE_NOISE2M:
-                if (w[W_IN0] >= 0) v.push_back({0, W_IN0, w[W_IN0], w[W_D0]});
-                break;
-            case OP_FE_NOISE2: case OP_FE_ADD2:
-                for (int k : {W_IN0, W_IN1, W_IN2})
-                    if ((k != W_IN2 || w[W_OP] == OP_FE_ADD2) && w[k] >= 0) v.push_back({0, k, w[k], w[W_D0]});
-                break;
-            default: break;
-            }
-            return v;
-        };
+        auto inputs = [&](int i) { return op_inputs(W(i)); };
         std::vector<int> readers(P.n_ops, 0), oplevel(P.n_ops, 0);
         for (int l = 0; l < P.n_levels; ++l)
             for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1]; ++i) oplevel[i] = l;
@@ -1074,6 +1152,7 @@ struct Engine {
     int fe_cap = 0;
     bool have_data = false, ran = false;
     bool cont = false;   // rxhip_tree_continue: later runs go on from the q(W) the previous run ended with
+    bool push_done = false;   // the image marginals (OP_MARG_PUSH, first level of the second phase) are those of the last sweep
     int last_iterations = 0, last_want_fe = 0;
     std::vector<char> data_set;
     uint64_t runs = 0;
@@ -1318,10 +1397,13 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     }
     if (P.dmax > 8) e->mode_fe = e->mode;
     // the strand schedule (register hand-over along dependent ops, wide levels at full occupancy): from the batches at which two long strands fill the device
-    if (P.dmax <= 4 && e->R >= 16384) { e->mode = 3; e->mode_fe = e->R >= 65536 ? 2 : 1; }
+    if (P.dmax <= 4 && e->R >= 4096) e->mode = 3;
+    // the second phase is one wide level of independent terms and a short sum tree: a launch per level up to 65 536 replicas (0.09 against 1.0 ms for the
+    // walk at 4 096, 1.20 against 1.34 at 65 536), the walk above (2.04 against 2.44 at 131 072): profiles/r06/tree_strands.txt
+    if (e->mode == 3 || (e->mode == 1 && e->R >= 4096)) e->mode_fe = e->R >= 131072 ? 2 : 0;
     if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = e->mode_fe = std::max(0, std::min(3, std::atoi(m)));
     if (e->mode == 3 && P.dmax > 4) e->mode = 2;                  // (the strand kernel carries a message in registers: instances 1, 2, 4)
-    if (e->mode_fe == 3) e->mode_fe = e->R >= 65536 ? 2 : 1;     // (the Bethe phase is one wide level of independent terms: no strands to speak of)
+    if (e->mode_fe == 3) e->mode_fe = e->R >= 131072 ? 2 : 0;    // (the Bethe phase is one wide level of independent terms: no strands to speak of)
     if (const char* m = hook_env("RXHIP_TREE_MODE_FE")) e->mode_fe = std::max(0, std::min(2, std::atoi(m)));
     if (P.dmax > 8 && e->mode == 1) e->mode = e->mode_fe = 2;   // (no workgroup-resident schedule for the LDS-staged kernels)
     if (P.dmax > 8 && e->mode_fe == 1) e->mode_fe = 2;
@@ -1481,6 +1563,7 @@ rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err) {
     int status = 0;
     TCHK(hipMemcpy(&status, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
     e->ran = true;
+    e->push_done = l_end > P.fe_level;
     e->last_iterations = iterations;
     e->last_want_fe = want_fe;
     ++e->runs;
@@ -1509,6 +1592,16 @@ rxhip_status get_marginals(Engine* e, const int64_t* vars, int64_t n_vars, doubl
         gv[i].off = cl ? P.val_off[v] : P.marg_off[v];
         gv[i].d = P.dim[v];
         gv[i].clamped = cl ? 1 : 0;
+    }
+    // a marginal that is the image of another one (the output of `A * x`) is formed in the second phase; a sweep that ran without it forms them now
+    if (!e->push_done && P.push_levels > 0) {
+        bool want = false;
+        for (int64_t i = 0; i < n_vars; ++i) want = want || P.is_push[vars[i]];
+        if (want) {
+            launch(e, params_of(e, 0), P.fe_level, P.fe_level + P.push_levels);
+            TCHK(hipGetLastError());
+            e->push_done = true;
+        }
     }
     TCHK(hipStreamSynchronize(e->stream));
     const size_t cap = (256u << 20) / 8;   // doubles per chunk and array

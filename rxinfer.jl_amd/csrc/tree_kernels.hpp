@@ -39,7 +39,8 @@ enum : int {
     OP_FE_ADD2 = 16,     // −H[q(in1, in2)] of a `+` node with two random inputs
     OP_SUM_TERMS = 17,   // fixed-order partial sum of terms
     OP_PREC_UPDATE = 18, // q(W) ← Wishart(ν0 + n, (S0⁻¹ + Σ E[rrᵀ])⁻¹), its share of the Bethe sum
-    OP_FE_NOISE2M = 19   // OP_FE_NOISE2 from ONE inbound message and the two variables' marginals (register kernels): one inverse instead of three
+    OP_FE_NOISE2M = 19,  // OP_FE_NOISE2 from ONE inbound message and the two variables' marginals (register kernels): one inverse instead of three
+    OP_MARG_PUSH = 20    // marginal of the output of `A * x` as the image of x's marginal: (A m, A V Aᵀ, log|A V Aᵀ|) — second phase, register kernels
 };
 constexpr int OP_WORDS = 16;
 // word indices of an op descriptor
@@ -582,6 +583,26 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         p.term[(long long)w[W_TERM] * p.RS + r] = term;
     } break;
 #endif
+    case OP_MARG_PUSH: {
+        // q(out) of a deterministic node out = A·in IS the image of q(in) (exact on a tree): no product of the two messages on out's edges, so those
+        // messages need not exist for the marginal's sake (the compiler drops the ones nobody else reads).  Only the Bethe terms and a caller who asks for
+        // this (anonymous) variable read it: second phase.  A V Aᵀ singular (more rows than columns): log-determinant −∞, as the message route's entropy.
+        double m[N], V[N][N], A[N][N], mo[N], T1[N][N], Vo[N][N], Vi[N][N], ld;
+        const int din = w[W_D1];
+        ld_vec<N>(p.marg, w[W_IN0], din, p.RS, r, m);
+        ld_sym<N>(p.marg, w[W_IN0] + din, din, p.RS, r, 0.0, V);
+        ld_cmat<N>(p.cpool + w[W_C0], d, din, 0.0, A);
+        matvec<N>(A, m, mo);
+        matmul<N>(A, V, T1);
+        matmulT<N>(T1, A, Vo);
+        st_vec<N>(p.marg, w[W_OUT], d, p.RS, r, mo);
+        st_sym<N>(p.marg, w[W_OUT] + d, d, p.RS, r, Vo);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (i >= d) Vo[i][i] = 1.0;
+        const bool pd = spd_inv<N>(Vo, Vi, ld);
+        p.marg[(long long)(w[W_OUT] + d + d * (d + 1) / 2) * p.RS + r] = pd ? ld : -__builtin_huge_val();
+    } break;
     case OP_FE_NOISE2M: {
         // The same joint q(a, b) of the node's two Gaussian interfaces, from what the sweep has already computed: with P = L_a + W (L_a: the message the
         // variable on side a sends to the node) the Schur complement S = L_b + W − W P⁻¹ W is the MARGINAL precision of b, so S⁻¹ = V_b and log|S| = −log|V_b| are

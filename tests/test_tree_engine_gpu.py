@@ -144,9 +144,15 @@ def test_state_space_chain_equals_the_specialised_engine(d, dy, T, R, mode, monk
     assert np.max(np.abs(tm - mean) / sd) < 1e-12 * 50
     assert np.max(np.abs(tc - cov) / (sd[..., :, None] * sd[..., None, :])) < 1e-12 * 50
     assert np.max(np.abs(fe - rfe) / np.abs(rfe)) < 1e-12
-    om, oc, ofe, ocnt = rxo.lgssm_bp(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], np.ascontiguousarray(y[:, 0]))
-    assert fe[0] == pytest.approx(ofe, rel=1e-11)
-    assert cnt["rule_calls"] == ocnt.rule_calls * R
+    if dy >= d:
+        om, oc, ofe, ocnt = rxo.lgssm_bp(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], np.ascontiguousarray(y[:, 0]))
+        assert fe[0] == pytest.approx(ofe, rel=1e-11)
+        assert cnt["rule_calls"] == ocnt.rule_calls * R
+    else:   # fewer observed dimensions than states: the reference schedule's `cholinv` of the rank-deficient backward message has no answer (lgssm_bp restates
+        #     THAT schedule: status 3 at d = 3, a pivot of rounding noise at d = 2) — the Kalman / RTS restatement is the checker there
+        km, kc, nll = rxo.lgssm_kalman_rts(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], np.ascontiguousarray(y[:, 0]))
+        assert fe[0] == pytest.approx(nll, rel=1e-11) and np.max(np.abs(tm[:, 0] - km) / sd[:, 0]) < 1e-10
+        assert cnt["rule_calls"] == (6 * T - 3) * R
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
