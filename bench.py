@@ -424,17 +424,21 @@ def extra_node_array(device, parity=True):
             best = min(best, time.perf_counter() - t)
             dev = min(dev, eng.last_iteration_ms())
         cnt, info = eng.counters(), eng.info
+        moved = (info["bytes_per_sweep"] + info["fe_bytes_per_sweep"]) * R       # what this schedule moves through HBM per iteration: the sweep's messages + the second phase
         line = {"ms_per_step": best * 1e3, "device_ms_per_step": dev, "rule_calls_per_s": cnt["rule_calls"] / (dev * 1e-3),
                 "graph_build_ms": (t1 - t0) * 1e3, "compile_and_allocate_ms": (t2 - t1) * 1e3, "info": info,
-                "roofline": {"bound": "hbm", "achieved": info["bytes_per_sweep"] * R / (dev * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                             "frac": info["bytes_per_sweep"] * R / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
-                             "bytes": "8·(d + d(d+1)/2) per message read or written by a rule, product or marginal of the schedule (rxhip_tree_info.bytes_per_sweep) × replicas"}}
+                "roofline": {"bound": "hbm", "achieved": moved / (dev * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": moved / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                             # the floor of ANY schedule on this graph: the data in, the posteriors of the named variables out (rxhip_tree_info.io_bytes_per_sweep)
+                             "io_frac": info["io_bytes_per_sweep"] * R / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS, "moved_over_io": moved / (info["io_bytes_per_sweep"] * R),
+                             "bytes": "messages a rule, product or marginal of the schedule reads from / writes to HBM (register hand-overs along a strand left out) + what the Bethe "
+                                      "phase reads and writes (rxhip_tree_info.bytes_per_sweep + fe_bytes_per_sweep) × replicas"}}
         if name == "two_branch":   # HBM bytes of the two kernel instances by the PMC counters (profiles/tree_traffic.json, guarded by the hash of tree_kernels.hpp)
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "tree_traffic.json")))
                 with open(os.path.join(ROOT, "rxinfer.jl_amd", "csrc", "tree_kernels.hpp"), "rb") as f:
                     fresh = tj.get("tree_kernels_sha256") == hashlib.sha256(f.read()).hexdigest()
-                if fresh and tj.get("algorithmic_bytes_per_sweep") == info["bytes_per_sweep"] * R:
+                if fresh and tj.get("algorithmic_bytes_per_sweep") == moved:
                     line["roofline"]["traffic"] = sum(k["hbm_bytes_per_launch_x2"] for n, k in tj["kernels"].items() if "k_tree_" in n and "fe_total" not in n)
                     line["roofline"]["traffic_note"] = "FETCH_SIZE x2 + WRITE_SIZE of both phases per sweep (profiles/tree_traffic.json); x1: " + \
                         f"{sum(k['hbm_bytes_per_launch_x1'] for n, k in tj['kernels'].items() if 'k_tree_' in n and 'fe_total' not in n):.4g} bytes"
@@ -750,6 +754,129 @@ def extra_c5(device, parity=True):
             "ms_per_iteration_1p25M_points": ms8, "timing": timing_mode(2), "parity_spot": spot}
 
 
+def _sig(x, n=6):
+    """floats to n significant digits (the line is for reading; the detail file keeps everything)"""
+    if isinstance(x, bool) or not isinstance(x, float):
+        return x
+    if x != x or x in (float("inf"), float("-inf")) or x == 0.0:
+        return x
+    return float(f"{x:.{n}g}")
+
+
+def _slim(o, n=6):
+    if isinstance(o, dict):   # (free energies and the headline value keep every digit: they are results, the rest are measurements)
+        return {k: (v if ("free_energy" in k or k == "value") else _slim(v, n)) for k, v in o.items()}
+    if isinstance(o, (list, tuple)):
+        return [_slim(v, n) for v in o]
+    return _sig(o, n)
+
+
+def _spot(sp):
+    """a parity spot as [ok, largest relative error of the posteriors, of the free energy]"""
+    if not isinstance(sp, dict):
+        return None
+    errs = [sp.get(k) for k in ("mean_rel", "cov_rel", "post_rel") if sp.get(k) is not None]
+    return [bool(sp.get("ok")), max(errs) if errs else None, sp.get("fe_rel")]
+
+
+def compact_line(out):
+    """The ONE line rank 0 prints, below 8 KB (the driver keeps the parsed fixed keys and an 8 KB tail: a 15 KB line lost most extras): the
+    contract's fields, the dominant kernel's roofline with a scalar summary [ms, roofline fraction, parity ok] of EVERY configuration under
+    roofline.per_config, the CPU baseline, and per configuration the few rates that name it.  Workload texts, kernel breakdowns, notes, counter sources:
+    the detail file (--detail, default bench_detail.json) and DESIGN.md §6."""
+    pick = lambda d, keys: {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+    line = pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"))
+    line["vs_baseline"] = out.get("vs_baseline")
+    line["config"] = pick(out["config"], ("workload", "chains_per_gpu", "T", "segments", "segment_len", "parallelism"))
+    line.update(pick(out, ("vmp_iters_per_sec", "timing", "engine_create_ms", "model_tables_ms", "free_energy_rank0", "free_energy_global", "gpu_over_cpu")))
+    r = out["roofline"]
+    line["roofline"] = pick(r, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_frac", "traffic_stale", "algorithmic_bytes_per_U",
+                                "algorithmic_bytes_per_launch", "kernel_ms_avg", "sweep_frac"))
+    line["roofline"]["traffic"] = r.get("traffic")
+    line["kernels_ms_avg"] = out.get("kernels_ms_avg")
+    if "parity_spot" in out:
+        line["parity_spot"] = out["parity_spot"]
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = pick(cb, ("value", "unit", "cores", "kind", "free_energy_rel_vs_gpu"))
+        c["sample"] = cb.get("sample", "").split(" (")[0][:160]
+        if isinstance(cb.get("all_cores"), dict):
+            c["all_cores"] = pick(cb["all_cores"], ("value", "cores", "threads"))
+        line["cpu_baseline"] = c
+    else:
+        line["cpu_baseline"] = cb
+    per, ex = {}, {}
+
+    def add(name, ms, frac, spot, bound=None, **more):
+        per[name] = [ms, frac, None if spot is None else bool(spot[0])]
+        e = {"ms": ms}
+        if bound:
+            e["bound"] = bound
+        if frac is not None:
+            e["frac"] = frac
+        if spot is not None:
+            e["parity"] = spot
+        e.update({k: v for k, v in more.items() if v is not None})
+        ex[name] = e
+
+    pc = out.get("roofline_per_chain_models")
+    if isinstance(pc, dict) and "error" not in pc:
+        add("per_chain_models", pc.get("ms_per_step"), pc.get("frac"), _spot(pc.get("parity_spot")), "hbm", sweep_frac=pc.get("sweep_frac"), moved_frac=pc.get("moved_frac"),
+            rule_calls_per_s=pc.get("rule_calls_per_s"))
+    extra = out.get("extra") or {}
+    g = lambda d, *ks: (g(d.get(ks[0]), *ks[1:]) if len(ks) > 1 else d.get(ks[0])) if isinstance(d, dict) else None
+    for name, v in extra.items():
+        if not isinstance(v, dict):
+            continue
+        if "error" in v:
+            ex[name] = {"error": str(v["error"])[:200]}
+            per[name] = [None, None, False]
+            continue
+        if name == "c1":
+            add(name, v.get("infer_ms"), None, None, rule_calls_per_s=v.get("rule_calls_per_s"), engine_built_per_call_ms=v.get("infer_ms_engine_built_per_call"),
+                cpu_ms=g(v, "cpu_baseline", "ms"), cpu_mean_rel=g(v, "cpu_baseline", "mean_rel_vs_gpu"), cpu_fe_rel=g(v, "cpu_baseline", "free_energy_rel_vs_gpu"))
+        elif name == "c2_missing":
+            add(name, v.get("ms_per_step"), None, _spot(v.get("parity_spot")), steps_per_s=v.get("steps_per_s"), k_forward_ms=g(v, "kernels_ms_avg", "k_forward"),
+                k_backward_ms=g(v, "kernels_ms_avg", "k_backward"))
+        elif name == "c3":
+            rf = v.get("roofline") or {}
+            add(name, v.get("ms_per_step"), rf.get("frac"), _spot(v.get("parity_spot")), "mfma", achieved_tflops=rf.get("achieved"), peak_tflops=rf.get("peak"),
+                fwd_frac=g(rf, "per_kernel", "kd_forward_info", "frac"), bwd_frac=g(rf, "per_kernel", "kd_backward_info", "frac"), ref_count_tflops=v.get("tflops_ref_count"),
+                filter_ms=v.get("filter_ms_per_step"), hoisted_ms=g(v, "hoisted_matrices", "ms_per_step"), kernels_ms=v.get("kernels_ms_avg"))
+        elif name in ("c4", "c5"):
+            rf = v.get("roofline") or {}
+            add(name, v.get("ms_per_step", v.get("ms_per_iteration")), rf.get("frac"), _spot(v.get("parity_spot")), rf.get("bound"),
+                gh_evaluations_per_s=v.get("gh_evaluations_per_s"), point_iterations_per_s=v.get("point_iterations_per_s"), vmp_iters_per_sec=v.get("vmp_iters_per_sec"),
+                per_gpu_shape_ms=v.get("ms_per_step_512_series", v.get("ms_per_iteration_1p25M_points")), fe_monotone=v.get("free_energy_monotone"),
+                n_gpus=v.get("n_gpus"), free_energy_last=v.get("free_energy_last"), series_observations_per_s=v.get("series_observations_per_s"),
+                free_energy_mean_per_series_global=v.get("free_energy_mean_per_series_global"))
+        elif name == "mid_sizes":
+            for k2, w in v.items():
+                add(k2, w.get("ms_per_step"), None, _spot(w.get("parity_spot")), on_request_ms=g(w, "covariances_on_request", "ms_per_step"))
+        elif name == "masked_mfma":
+            add("d64_T2000_observed", v.get("fully_observed_ms"), None, None)
+            add("d64_T2000_missing10", v.get("missing_10pct_ms"), None, _spot(v.get("missing_10pct_parity_spot")))
+            add("d64_T2000_4_step_models", v.get("per_step_constants_4_models_ms"), None, _spot(v.get("per_step_constants_parity_spot")))
+        elif name == "lgssm_noise_vmp":
+            add(name, v.get("ms_per_iteration"), None, _spot(v.get("parity_spot")), rule_calls_per_s=v.get("rule_calls_per_s"), fe_monotone=v.get("free_energy_monotone"))
+        elif name == "node_array":
+            for k2, w in v.items():
+                if not isinstance(w, dict):
+                    continue
+                rf = w.get("roofline") or {}
+                i = w.get("info") or {}
+                add("executor_" + k2, w.get("device_ms_per_step"), rf.get("frac"), _spot(w.get("parity_spot")), rf.get("bound"), rule_calls_per_s=w.get("rule_calls_per_s"),
+                    io_frac=rf.get("io_frac"), traffic=rf.get("traffic"), mode=i.get("mode"), dmax=i.get("dmax"), bytes_per_sweep=i.get("bytes_per_sweep"),
+                    io_bytes_per_sweep=i.get("io_bytes_per_sweep"), specialised_engine_ms=w.get("specialised_engine_ms_per_step"), mfma_frac=rf.get("mfma_frac"))
+        else:
+            ms = v.get("ms_per_step", v.get("ms_per_iteration"))
+            add(name, ms, g(v, "roofline", "frac"), _spot(v.get("parity_spot")), **{k: w for k, w in v.items() if isinstance(w, (int, float, bool)) and k not in ("ms_per_step",)})
+    line["roofline"]["per_config"] = per   # [ms, roofline fraction (null: a time, not a roofline), parity ok] per configuration
+    if ex:
+        line["extra"] = ex
+    return _slim(line)
+
+
 def _join_background(o):
     if isinstance(o, Background):
         return o.result()
@@ -843,17 +970,22 @@ def sharded_extras(dist, gpu, world, rank, local_rank, hgf_cls=None, gmm_cls=Non
     with gpu.on_stream():
         shard.begin(warm5 + steps5)
 
+    from rxhip import distributed as rdist
+    gathered = [None]
+
     def step5():
         with gpu.on_stream():
             stats = shard.accumulate()
-            dist.all_reduce(stats)
+            # all-gather + ONE local reduction over the rank axis, in place: the same data through the same kernel on every rank — bit-identical on every
+            # rank and from run to run whatever ring or tree RCCL picks (an all-reduce's summation order is the backend's)
+            gathered[0] = rdist.allgather_ordered_sum_(stats, dist, gathered[0])
             shard.update(True)
 
     dt = timed(step5, steps5, eng.sync, warmup=warm5)
     fe = np.asarray(eng.free_energy())
     out["c5"] = {"workload": f"GMM K=16, {N} points per GPU (BASELINE config 5), points sharded over {world} GPUs", "ms_per_step": dt / steps5 * 1e3,
                  "vmp_iters_per_sec": steps5 / dt, "point_iterations_per_s": N * world * steps5 / dt, "n_gpus": world, "steps": steps5,
-                 "exchange": "3K + 1 statistics, one all-reduce per VMP iteration, enqueued between accumulate and update on one stream",
+                 "exchange": "3K + 1 statistics per VMP iteration: all-gather + one reduction over the rank axis (bit-identical on every rank), enqueued between accumulate and update on one stream",
                  "free_energy_last": float(fe[-1]), "free_energy_monotone": bool(np.all(np.diff(fe[warm5:]) <= 1e-6 * abs(fe[-1])))}
     eng.close()
     return out
@@ -924,6 +1056,8 @@ def main(argv=None, engine_cls=None, gpu_cls=_Gpu, extra_cls=None):
                     help="chains of the benchmarked batch the single-core CPU restatement is timed on (96: about 12 s of one host core)")
     ap.add_argument("--no-extras", action="store_true", help="skip the per-chain-model variant and the C3/C4/C5 lines")
     ap.add_argument("--no-parity", action="store_true")
+    ap.add_argument("--detail", default=os.path.join(ROOT, "bench_detail.json"),
+                    help="file that receives the full record (the printed line is its compact form, below 8 KB); '' = none")
     ap.add_argument("--force-dist", action="store_true",
                     help="create the RCCL process group and run the free-energy exchange even with one rank (exercises the N > 1 code path on a 1-GPU box)")
     args = ap.parse_args(argv)
@@ -1136,7 +1270,15 @@ def main(argv=None, engine_cls=None, gpu_cls=_Gpu, extra_cls=None):
         out["roofline_per_chain_models"] = extra.pop("per_chain_models")
         out["extra"] = _join_background(extra)   # the checkers still running on host threads
     if rank == 0:
-        print(json.dumps(out))
+        line = compact_line(out)
+        if args.detail:   # everything measured, with the workload texts, kernel breakdowns, notes and counter sources
+            try:
+                with open(args.detail, "w") as f:
+                    json.dump(out, f, indent=1)
+                line["detail"] = os.path.relpath(args.detail, ROOT) if os.path.isabs(args.detail) else args.detail
+            except OSError:
+                pass
+        print(json.dumps(line, separators=(",", ":")))
     if dist is not None:
         dist.destroy_process_group()
 

@@ -438,6 +438,7 @@ typedef struct {
     int64_t n_strands, n_strand_levels;   /* mode 3: the sweep cut into strands of dependent ops (a lane walks a strand, messages handed over in registers), their dependency levels */
     int32_t longest_strand;               /* ops of the longest strand */
     int64_t strand_bytes_per_sweep;       /* bytes_per_sweep of the strand schedule, whichever mode runs */
+    int64_t fe_bytes_per_sweep;           /* what the second phase (Bethe terms, q(W) updates, the sum) reads and writes per replica: messages, marginals, data values, terms, statistics */
 } rxhip_tree_info;
 rxhip_status rxhip_tree_create(const rxhip_graph_desc* g, int32_t device, void* stream, rxhip_engine** out);
 /* The graph compiler alone — host only, no device: would rxhip_tree_create take this graph, and with what schedule?  Fills the static fields of `out`

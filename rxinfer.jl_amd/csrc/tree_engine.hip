@@ -107,9 +107,10 @@ struct Program {
     std::vector<int> sops, strands, slvl_ptr;   // [n_sweep_ops][OP_WORDS]; [n_strands][2] = (first op, ops); strands of level l: slvl_ptr[l] … slvl_ptr[l + 1]
     long long bytes_per_sweep_strands = 0;      // message bytes this schedule moves through HBM (register hand-overs left out)
     long long io_bytes = 0;                     // what has to move whatever the schedule: the data in, the posteriors of the named variables out
+    long long fe_bytes = 0;                     // the second phase's reads and writes per replica
     int longest_strand = 0;
     bool fe_heavy = false;   // the second phase holds OP_FE_ADD2 or OP_PREC_UPDATE ops (else the light kernel instance runs it)
-    int n_push = 0, push_levels = 0;   // marginals formed as images (OP_MARG_PUSH): the first level of the second phase, run on demand when a sweep ran without it
+    int n_push = 0, lazy_level = -1;   // marginals stored as images of other marginals (OP_MARG_PUSH): a level of their own behind everything a run executes, launched on demand
     std::vector<char> is_push;         // per variable
 };
 
@@ -782,23 +783,21 @@ struct Compiler {
             for (auto& in : ins) { P.aux.push_back(in.first); P.aux.push_back(in.second); P.bytes_per_sweep += 8ll * msz(d); }
             P.bytes_per_sweep += 8ll * (msz(d) + 1);
         }
-        // second phase: first the marginals that are images of other marginals, then the Bethe terms and residual moments
-        const int LPUSH = lm_last + 1;
-        bool any_push = false;
-        for (int64_t v = 0; v < nv; ++v) {
-            if (P.vclass[v] != VC_GAUSS || push_from[v] < 0) continue;
-            const int f = push_fac[v], u = push_from[v];
-            OpRec& r = emit(LPUSH, OP_MARG_PUSH, P.dim[v]);
-            r.w[W_D1] = P.dim[u];
-            r.w[W_C0] = const_matrix((int)iface(f, 1), P.dim[v], P.dim[u]);
-            r.w[W_IN0] = P.marg_off[u];
-            r.w[W_OUT] = P.marg_off[v];
-            any_push = true;
-        }
-        P.n_push = 0;
-        for (int64_t v = 0; v < nv; ++v) P.n_push += push_from[v] >= 0;
-        const int LF = LPUSH + (any_push ? 1 : 0);
+        // second phase: the Bethe terms and residual moments.  A term that needs the marginal of an image variable (push_from) reads the marginal it is the image
+        // of and forms (A m, A V Aᵀ, log|A V Aᵀ|) on the fly (F_PUSH_*), and books that variable's own entropy term while it has the log-determinant (F_FOLD_ENT)
+        const int LF = lm_last + 1;
         std::vector<int> terms;
+        std::vector<std::pair<size_t, int>> fold;   // (op record, variable): ops that have log|V| of an image variable at hand
+        auto marg_of = [&](OpRec& r, int v, int word, int bit, int word_a, int word_du) {
+            if (push_from[v] >= 0) {
+                const int u = push_from[v];
+                r.w[word] = P.marg_off[u];
+                r.w[W_FLAGS] |= bit;
+                r.w[word_a] = const_matrix((int)iface(push_fac[v], 1), P.dim[v], P.dim[u]);
+                r.w[word_du] = P.dim[u];
+            } else
+                r.w[word] = P.marg_off[v];
+        };
         std::vector<int> ent_coef(nv, 0);
         std::vector<std::vector<int>> prec_stats(nv);
         std::vector<int> prec_nodes(nv, 0);
@@ -825,13 +824,17 @@ struct Compiler {
                     const bool use1 = !null_[m1] && form[m1] && (null_[m0] || !form[m0]);
                     r.w[W_OP] = OP_FE_NOISE2M;
                     msg_in(r, W_IN0, F_IN0_WP, use1 ? m1 : m0);
-                    r.w[W_VAL] = P.marg_off[use1 ? b : a];
-                    r.w[W_VAL2] = P.marg_off[use1 ? a : b];
+                    marg_of(r, use1 ? b : a, W_VAL, F_PUSH_A, W_IN1, W_LIST);
+                    marg_of(r, use1 ? a : b, W_VAL2, F_PUSH_B, W_IN2, W_N);
+                    r.w[W_OUT] = 0;
+                    if (push_from[use1 ? a : b] >= 0) fold.push_back({recs.size() - 1, use1 ? a : b});
                 } else if (ga && gb) {
                     msg_in(r, W_IN0, F_IN0_WP, E + fac_edges[f][0]);
                     msg_in(r, W_IN1, F_IN1_WP, E + fac_edges[f][1]);
                 } else if (ga || gb) {
-                    r.w[W_IN0] = P.marg_off[ga ? a : b];
+                    marg_of(r, ga ? a : b, W_IN0, F_PUSH_A, W_IN1, W_D1);
+                    r.w[W_OUT] = 0;
+                    if (push_from[ga ? a : b] >= 0) fold.push_back({recs.size() - 1, ga ? a : b});
                     int bit; r.w[W_VAL] = value_source(ga ? b : a, bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
                 } else {
                     int bit; r.w[W_VAL] = value_source(a, bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
@@ -857,10 +860,23 @@ struct Compiler {
                 } else ent_coef[g1 ? b : c] -= 1;
             }
         }
+        for (auto& fo : fold)   // the entropy term of an image variable goes to the first op that computes its log-determinant anyway
+            if (ent_coef[fo.second] != 0) {
+                recs[fo.first].w[W_FLAGS] |= F_FOLD_ENT;
+                recs[fo.first].w[W_OUT] = ent_coef[fo.second];
+                ent_coef[fo.second] = 0;
+            }
         for (int64_t v = 0; v < nv; ++v)
             if (P.vclass[v] == VC_GAUSS && ent_coef[v] != 0) {
                 OpRec& r = emit(LF, OP_FE_ENT, P.dim[v]);
-                r.w[W_IN0] = P.marg_off[v];
+                if (push_from[v] >= 0) {
+                    const int u = push_from[v];
+                    r.w[W_IN0] = P.marg_off[u];
+                    r.w[W_FLAGS] |= F_PUSH_A;
+                    r.w[W_C0] = const_matrix((int)iface(push_fac[v], 1), P.dim[v], P.dim[u]);
+                    r.w[W_D1] = P.dim[u];
+                } else
+                    r.w[W_IN0] = P.marg_off[v];
                 r.w[W_N] = ent_coef[v];
                 r.w[W_TERM] = new_term();
             }
@@ -896,8 +912,21 @@ struct Compiler {
             ++lv;
         }
         P.fe_root = cur[0];
-        P.fe_level = LPUSH;
-        P.push_levels = any_push ? 1 : 0;
+        P.fe_level = LF;
+        // the stored marginals of the image variables: nobody on the device reads them — formed when a caller asks (rxhip_tree_get_marginals), one level behind
+        // everything a run executes
+        P.n_push = 0;
+        for (int64_t v = 0; v < nv; ++v) {
+            if (P.vclass[v] != VC_GAUSS || push_from[v] < 0) continue;
+            const int f = push_fac[v], u = push_from[v];
+            OpRec& r = emit(lv, OP_MARG_PUSH, P.dim[v]);
+            r.w[W_D1] = P.dim[u];
+            r.w[W_C0] = const_matrix((int)iface(f, 1), P.dim[v], P.dim[u]);
+            r.w[W_IN0] = P.marg_off[u];
+            r.w[W_OUT] = P.marg_off[v];
+            ++P.n_push;
+        }
+        P.lazy_level = P.n_push ? lv : -1;
     }
     int derived_levels = 0;
     std::vector<int> push_from, push_fac;   // per variable: the variable whose marginal it is the image of (−1), through which `*` node
@@ -968,6 +997,30 @@ struct Compiler {
             for (const In& in : op_inputs(r.w)) P.bytes_per_sweep += 8ll * msz(in.d);
             if (produces_msg(r.w[W_OP])) { P.bytes_per_sweep += 8ll * msz(r.w[W_OP] == OP_MUL_IN ? r.w[W_D1] : r.w[W_D0]); ++P.n_messages; }
             else if (r.w[W_OP] == OP_MARGINAL) P.bytes_per_sweep += 8ll * msz(r.w[W_D0]) + 8;
+        }
+        // the second phase: a message per FE_NOISE2 / FE_ADD2 input, a marginal (mean, packed covariance, log-determinant) or a mean per marginal read, data
+        // values, the statistics of the q(W) updates, one double per term written or summed
+        P.fe_bytes = 0;
+        for (const OpRec& r : recs) {
+            if (r.level < P.fe_level || r.w[W_OP] == OP_MARG_PUSH) continue;
+            const int* w = r.w;
+            const int d = w[W_D0];
+            for (const In& in : op_inputs(w)) P.fe_bytes += 8ll * msz(in.d);
+            switch (w[W_OP]) {
+            case OP_FE_NOISE2M:
+                P.fe_bytes += 8ll * ((w[W_FLAGS] & F_PUSH_A) ? w[W_LIST] : d) + 8ll * (msz((w[W_FLAGS] & F_PUSH_B) ? w[W_N] : d) + 1) + 8;
+                break;
+            case OP_FE_NOISE1:
+                P.fe_bytes += 8ll * (msz((w[W_FLAGS] & F_PUSH_A) ? w[W_D1] : d) + 1) + ((w[W_FLAGS] & F_VAL_SLOT) ? 8ll * d : 0) + 8;
+                break;
+            case OP_FE_NOISE0: P.fe_bytes += ((w[W_FLAGS] & F_VAL_SLOT) ? 8ll * d : 0) + ((w[W_FLAGS] & F_VAL2_SLOT) ? 8ll * d : 0) + 8; break;
+            case OP_FE_ENT: P.fe_bytes += ((w[W_FLAGS] & F_PUSH_A) ? 8ll * (msz(w[W_D1]) + 1) : 8) + 8; break;
+            case OP_FE_NOISE2: case OP_FE_ADD2: P.fe_bytes += 8; break;
+            case OP_SUM_TERMS: P.fe_bytes += 8ll * w[W_N] + 8; break;
+            case OP_PREC_UPDATE: P.fe_bytes += 8ll * d * d * w[W_N] + 8ll * (2 + d * (d + 1) / 2 + 2 * d * d) + 8; break;
+            default: break;
+            }
+            if (w[W_FLAGS] & F_STAT) P.fe_bytes += 8ll * d * d;
         }
         P.is_push.assign(nv, 0);
         for (int64_t v = 0; v < nv; ++v) P.is_push[v] = push_from[v] >= 0;
@@ -1546,7 +1599,7 @@ rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err) {
     }
     const TreeParams p = params_of(e, want_fe);
     // without the free energy on a graph without precision variables the sweep ends with the marginals
-    const int l_end = (!want_fe && P.prec_doubles == 0) ? P.fe_level : P.n_levels;
+    const int l_end = (!want_fe && P.prec_doubles == 0) ? P.fe_level : (P.lazy_level >= 0 ? P.lazy_level : P.n_levels);
     if (!e->ev0) { TCHK(hipEventCreate(&e->ev0)); TCHK(hipEventCreate(&e->ev1)); }
     TCHK(hipEventRecord(e->ev0, e->stream));
     for (int it = 0; it < iterations; ++it) {
@@ -1563,7 +1616,7 @@ rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err) {
     int status = 0;
     TCHK(hipMemcpy(&status, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
     e->ran = true;
-    e->push_done = l_end > P.fe_level;
+    e->push_done = false;
     e->last_iterations = iterations;
     e->last_want_fe = want_fe;
     ++e->runs;
@@ -1594,11 +1647,11 @@ rxhip_status get_marginals(Engine* e, const int64_t* vars, int64_t n_vars, doubl
         gv[i].clamped = cl ? 1 : 0;
     }
     // a marginal that is the image of another one (the output of `A * x`) is formed in the second phase; a sweep that ran without it forms them now
-    if (!e->push_done && P.push_levels > 0) {
+    if (!e->push_done && P.lazy_level >= 0) {
         bool want = false;
         for (int64_t i = 0; i < n_vars; ++i) want = want || P.is_push[vars[i]];
         if (want) {
-            launch(e, params_of(e, 0), P.fe_level, P.fe_level + P.push_levels);
+            launch(e, params_of(e, 0), P.lazy_level, P.lazy_level + 1);
             TCHK(hipGetLastError());
             e->push_done = true;
         }
@@ -1692,6 +1745,7 @@ void info(Engine* e, rxhip_tree_info* out) {
     out->n_strand_levels = (int64_t)P.slvl_ptr.size() - 1;
     out->longest_strand = P.longest_strand;
     out->strand_bytes_per_sweep = P.bytes_per_sweep_strands;
+    out->fe_bytes_per_sweep = P.fe_bytes;
     out->dmax = P.dmax; out->mode = e->mode; out->replicas_per_workgroup = e->rb;
     int np = 0;
     for (int c : P.vclass) np += c == VC_PREC;

@@ -53,7 +53,10 @@ enum : int {
     F_NEG = 64,          // OP_SHIFT: subtract the value
     F_STAT = 128,        // FE_NOISE*: the node's precision is a random variable — write E[rrᵀ] to the stat slot W_C1
     F_RAND_IS_MU = 256,  // FE_NOISE1: the random interface is μ (r = value − μ)
-    F_NO_STORE = 512     // strand schedule: the only reader of this op's message is the next op of the strand (it takes it from registers)
+    F_NO_STORE = 512,    // strand schedule: the only reader of this op's message is the next op of the strand (it takes it from registers)
+    F_PUSH_A = 1024,     // Bethe terms: the marginal named by W_VAL (FE_NOISE2M side a) / W_IN0 (FE_NOISE1, FE_ENT) is the IMAGE of the stored one under a constant matrix
+    F_PUSH_B = 2048,     // … the marginal named by W_VAL2 (FE_NOISE2M side b)
+    F_FOLD_ENT = 4096    // FE_NOISE2M / FE_NOISE1: W_OUT · H[q(v)] of the variable whose log|V| the op has at hand (side b / the random interface) is part of this term
 };
 // strand schedule: an input offset that names the message the previous op of the lane's strand left in registers
 constexpr int OFF_REG = -2;
@@ -319,6 +322,61 @@ template <int N>
 __device__ __forceinline__ void load_value(const TreeParams& p, int off, bool slot, int d, long long r, double (&v)[N]) {
     if (slot) ld_vec<N>(p.val, off, d, p.RS, r, v);
     else ld_cvec<N>(p.cpool + off, d, v);
+}
+
+// log-determinant of a symmetric positive definite matrix (Cholesky pivots); false: a pivot ≤ 0
+template <int N>
+__device__ __forceinline__ bool spd_logdet(const double (&A)[N][N], double& logdet) {
+    double L[N][N];
+    bool ok = true;
+    double ld = 0.0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        double s = A[j][j];
+#pragma unroll
+        for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
+        ok = ok && (s > 0.0) && (s < 1.0e300);
+        const double rj = 1.0 / sqrt(s);
+        ld += log(s);
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            double t = A[i][j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= L[i][k] * L[j][k];
+            L[i][j] = t * rj;
+        }
+    }
+    logdet = ld;
+    return ok;
+}
+// A marginal as the Bethe terms read it: (mean, covariance, log|V|) of the slot `off` — or, `push`, of the image of that marginal under the constant d × du
+// matrix at cpool + aoff: the output of `A * x` has the marginal (A m, A V Aᵀ) of x's (exact on a tree), so the marginals of such (anonymous) variables are
+// never stored for the free energy's sake; a singular image (more rows than columns) has log|V| = −∞, as the entropy of the message route.
+template <int N>
+__device__ __forceinline__ void load_marginal(const TreeParams& p, int off, bool push, int aoff, int du, int d, long long r, bool want_cov, double (&m)[N], double (&V)[N][N], double& ldV) {
+    if (!push) {
+        ld_vec<N>(p.marg, off, d, p.RS, r, m);
+        if (want_cov) {
+            ld_sym<N>(p.marg, off + d, d, p.RS, r, 0.0, V);
+            ldV = p.marg[(long long)(off + d + d * (d + 1) / 2) * p.RS + r];
+        }
+        return;
+    }
+    double mu[N], A[N][N];
+    ld_vec<N>(p.marg, off, du, p.RS, r, mu);
+    ld_cmat<N>(p.cpool + aoff, d, du, 0.0, A);
+    matvec<N>(A, mu, m);
+    if (!want_cov) return;
+    double Vu[N][N], T1[N][N], Vp[N][N], ld;
+    ld_sym<N>(p.marg, off + du, du, p.RS, r, 0.0, Vu);
+    matmul<N>(A, Vu, T1);
+    matmulT<N>(T1, A, V);
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = 0; j < N; ++j) Vp[i][j] = (i < d && j < d) ? 0.5 * (V[i][j] + V[j][i]) : (i == j ? 1.0 : 0.0);
+    const bool pd = spd_logdet<N>(Vp, ld);
+    ldV = pd ? ld : -__builtin_huge_val();
 }
 
 __device__ __forceinline__ double t_digamma(double x) {   // x > 0
@@ -618,11 +676,9 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
 #pragma unroll
             for (int j = 0; j < N; ++j) P[i][j] = ((w[W_IN0] >= 0 && i < d && j < d) ? La[i][j] : 0.0) + Wm[i][j];
         ok = spd_inv<N>(P, Pi, ldP) && ok;
-        double ma[N], mb[N], Vb[N][N];
-        ld_vec<N>(p.marg, w[W_VAL], d, p.RS, r, ma);
-        ld_vec<N>(p.marg, w[W_VAL2], d, p.RS, r, mb);
-        ld_sym<N>(p.marg, w[W_VAL2] + d, d, p.RS, r, 0.0, Vb);
-        const double ldVb = p.marg[(long long)(w[W_VAL2] + d + d * (d + 1) / 2) * p.RS + r];
+        double ma[N], mb[N], Vb[N][N], ldVb, unused;
+        load_marginal<N>(p, w[W_VAL], fl & F_PUSH_A, w[W_IN1], w[W_LIST], d, r, false, ma, Vb, unused);
+        load_marginal<N>(p, w[W_VAL2], fl & F_PUSH_B, w[W_IN2], w[W_N], d, r, true, mb, Vb, ldVb);
         double Dm[N][N], T2[N][N], E[N][N];
         matmul<N>(Pi, Wm, Dm);
 #pragma unroll
@@ -635,6 +691,7 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
             for (int j = 0; j < N; ++j) E[i][j] += Pi[i][j] + (ma[i] - mb[i]) * (ma[j] - mb[j]);
         const double H = 0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP - ldVb));
         double term = -H;
+        if (fl & F_FOLD_ENT) term += (double)w[W_OUT] * 0.5 * (d * (T_LOG2PI + 1.0) + ldVb);   // the side-b variable's own Bethe entropy term, folded in (its log|V| is at hand)
         if (fl & F_STAT) st_full<N>(p.stat, w[W_C1], d, p.RS, r, E);
         else term += 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
         p.term[(long long)w[W_TERM] * p.RS + r] = term;
@@ -644,10 +701,10 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         double E[N][N], Sg[N][N], Wm[N][N], el, rv[N], H = 0.0;
         load_noise<N>(p, w, d, r, false, true, Sg, Wm, el);
         if (op == OP_FE_NOISE1) {
-            double m[N], V[N][N], c[N];
-            ld_vec<N>(p.marg, w[W_IN0], d, p.RS, r, m);
-            ld_sym<N>(p.marg, w[W_IN0] + d, d, p.RS, r, 0.0, V);
-            H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r]);
+            double m[N], V[N][N], c[N], ldV;
+            load_marginal<N>(p, w[W_IN0], fl & F_PUSH_A, w[W_IN1], w[W_D1], d, r, true, m, V, ldV);
+            H = 0.5 * (d * (T_LOG2PI + 1.0) + ldV);
+            if (fl & F_FOLD_ENT) H *= (double)(1 - w[W_OUT]);   // (−H of the node + coef·H of the variable, folded: −(1 − coef)·H below)
             load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, c);
 #pragma unroll
             for (int i = 0; i < N; ++i) rv[i] = m[i] - c[i];
@@ -672,8 +729,13 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         p.term[(long long)w[W_TERM] * p.RS + r] = term;
     } break;
     case OP_FE_ENT: {
-        const double H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r]);
-        p.term[(long long)w[W_TERM] * p.RS + r] = (double)w[W_N] * H;
+        double ldV;
+        if (fl & F_PUSH_A) {
+            double m[N], V[N][N];
+            load_marginal<N>(p, w[W_IN0], true, w[W_C0], w[W_D1], d, r, true, m, V, ldV);
+        } else
+            ldV = p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r];
+        p.term[(long long)w[W_TERM] * p.RS + r] = (double)w[W_N] * 0.5 * (d * (T_LOG2PI + 1.0) + ldV);
     } break;
     case OP_FE_ADD2: if (!LIGHT) {   // Lj = [[L1 + Lo, Lo], [Lo, L2 + Lo]]: log|Lj| = log|L1 + Lo| + log|L2 + Lo − Lo (L1 + Lo)⁻¹ Lo|
         double x[N], L1[N][N], L2[N][N], Lo[N][N];

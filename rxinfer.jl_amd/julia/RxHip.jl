@@ -626,7 +626,7 @@ end
 
 "the graph compiler alone (host only): would the node-array executor take this graph, and with what schedule? (include/rxhip.h rxhip_tree_plan)"
 function tree_plan(g::Ref{GraphDesc})
-    info = Ref(TreeInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0))
+    info = Ref(TreeInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0))
     rc, pr, mg = Ref{UInt64}(0), Ref{UInt64}(0), Ref{UInt64}(0)
     st = ccall((:rxhip_tree_plan, librxhip), Int32, (Ptr{GraphDesc}, Ref{TreeInfo}, Ref{UInt64}, Ref{UInt64}, Ref{UInt64}), g, info, rc, pr, mg)
     st == 0 || error("rxhip_tree_plan: status $st: $(lowering_error())")
@@ -811,6 +811,7 @@ struct TreeInfo
     n_strand_levels::Int64
     longest_strand::Int32
     strand_bytes_per_sweep::Int64
+    fe_bytes_per_sweep::Int64
 end
 # mirrors rxhip_rule_call
 struct RuleCall
@@ -833,7 +834,7 @@ end
 """`rxhip_tree_get_info`, or `nothing` when the handle belongs to one of the pattern-matched families (what `rxhip_create` built
 tells the plugin which set of entry points drives the engine)."""
 function tree_info(e::Engine)
-    info = Ref(TreeInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0))
+    info = Ref(TreeInfo(0, 0, 0, 0, 0, 0, 0, 0, 0, 0.0, 0, 0, 0, 0, 0, 0))
     st = ccall((:rxhip_tree_get_info, librxhip), Int32, (Ptr{Cvoid}, Ref{TreeInfo}), e.handle, info)
     return st == RXHIP_OK ? info[] : nothing
 end

@@ -42,6 +42,22 @@ def allreduce_free_energy(fe_local, dist=None, device=None):
     return t.cpu().numpy()
 
 
+def allgather_ordered_sum_(t, dist, scratch=None):
+    """In place: t ← Σ over ranks of t, as an all-gather into [world][n] followed by ONE local reduction over the rank axis.  Every rank reduces the same
+    bytes with the same kernel, so the result is bit-identical on every rank and from run to run, whatever ring or tree the backend would pick for an
+    all-reduce (whose summation order is the backend's) — what the 1e-8 run-to-run free-energy tolerance needs.  Returns the scratch
+    buffer for reuse (allocate once, outside a timed region)."""
+    import torch
+
+    world = dist.get_world_size()
+    flat = t.view(-1)
+    if scratch is None or scratch.numel() != world * flat.numel() or scratch.device != t.device:
+        scratch = torch.empty(world * flat.numel(), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(scratch, flat)
+    torch.sum(scratch.view(world, -1), dim=0, out=flat)
+    return scratch
+
+
 def gather_per_chain(values_local, n_chains, dist=None):
     """All-gather a per-chain array ([local_chains, ...]) into chain order (used by tests / result
     assembly; not on the timed path)."""
@@ -107,15 +123,16 @@ class DeviceMixtureShard:
 def sharded_mixture_vmp(shard, iterations, want_fe=True, dist=None):
     """VMP for a mixture whose points are sharded over ranks (C5): per iteration every rank accumulates the
     responsibility-weighted statistics of its points (3K+1 numbers: Σπ, Σπy, Σπy² per component and Σ H[q(z_i)]),
-    ONE all-reduce(sum) makes them global, and every rank applies the identical update — so all ranks hold the same
+    ONE exchange (all-gather + a local reduction over the rank axis: bit-identical everywhere) makes them global, and every rank applies the identical update — so all ranks hold the same
     q(m), q(p), q(s) and the same (global) free energy without any further exchange.
     Reference semantics: the messages toward m[k], p[k], s are products over ALL points
     (src/model/plugins/reactivemp_inference.jl:365-374); the sum over shards is that product in the natural
     parameters.  `shard`: begin(iterations) / accumulate() -> tensor aliasing the statistics / update(want_fe)."""
     shard.begin(iterations)
     multi = dist is not None and dist.is_initialized() and dist.get_world_size() > 1
+    scratch = None
     for _ in range(iterations):
         stats = shard.accumulate()
         if multi:
-            dist.all_reduce(stats, op=dist.ReduceOp.SUM)
+            scratch = allgather_ordered_sum_(stats, dist, scratch)
         shard.update(want_fe)

@@ -166,7 +166,7 @@ def test_bench_main_emits_the_sharded_configs_at_world_8(tmp_path):
     for x in sums:
         tot += x
     assert c4["free_energy_mean_per_series_global"][0] == pytest.approx(tot / (3 * world), rel=1e-12) and len(c4["free_energy_mean_per_series_global"]) == 10
-    assert c4["series_observations_per_s"] == pytest.approx(20 * 3 * world / (c4["ms_per_step"] * 1e-3), rel=1e-9)
+    assert c4["series_observations_per_s"] == pytest.approx(20 * 3 * world / (c4["ms"] * 1e-3), rel=1e-4)   # (the printed line rounds measurements to 6 digits)
     # c5: one all-reduce per iteration made every rank's statistics global
     K = 16
     mus = np.arange(1, K + 1) * 10.0 - 80.0
@@ -175,7 +175,9 @@ def test_bench_main_emits_the_sharded_configs_at_world_8(tmp_path):
         rng = np.random.default_rng(12345 + r)
         tot5 += float(np.sum(mus[rng.integers(0, K, size=50)] + rng.standard_normal(50)))
     assert c5["free_energy_last"] == pytest.approx(-tot5 / 6, rel=1e-9)       # the 6th update of the run (2 warm-up + 4 timed)
-    assert c5["point_iterations_per_s"] == pytest.approx(50 * world * c5["vmp_iters_per_sec"], rel=1e-9)
+    assert c5["point_iterations_per_s"] == pytest.approx(50 * world * c5["vmp_iters_per_sec"], rel=1e-4)
+    # the line is the compact form of the record: below the 8 KB the driver keeps, every configuration in roofline.per_config as [ms, roofline fraction, parity ok]
+    assert len(lines[0]) < 8192 and set(out["roofline"]["per_config"]) == {"c4", "c5"} and out["roofline"]["per_config"]["c4"][0] == c4["ms"]
 
 
 def _worker(rank, world, port, out_dir, scaling, chains):
@@ -216,8 +218,8 @@ def test_bench_main_two_ranks(tmp_path, scaling, chains, per_rank):
     assert out["free_energy_global"] == shard[0] + shard[1]     # all-gather + sum in ascending rank order: bit-identical
     # whole-job throughput: every rank's rule calls over the slowest rank's time
     calls = (6 * T - 3) * per_rank * world
-    assert out["value"] == pytest.approx(calls * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"]), rel=1e-12)
-    assert out["vmp_iters_per_sec"] == pytest.approx(1e3 / out["ms_per_step"], rel=1e-12)
+    assert out["value"] == pytest.approx(calls * out["steps"] / (out["ms_per_step"] * 1e-3 * out["steps"]), rel=1e-4)   # (ms_per_step is printed with 6 digits)
+    assert out["vmp_iters_per_sec"] == pytest.approx(1e3 / out["ms_per_step"], rel=1e-4)
 
 
 def test_strong_scaling_needs_divisible_chains():

@@ -156,3 +156,44 @@ def test_two_rank_sharded_mixture(tmp_path):
     # (the Gamma rate is a difference of sums, S2 − 2 m S1 + m² S0: its rounding is amplified ≈ 10³×)
     assert np.max(np.abs(r0["hist"].reshape(hist.shape) - hist) / np.abs(hist)) < 1e-9
     assert np.all(np.diff(fe) < 1e-9)
+
+
+def _ordered_sum_worker(rank, world, port, out_dir):
+    sys.path.insert(0, os.path.join(ROOT, "rxinfer.jl_amd"))
+    import torch
+    import torch.distributed as dist
+
+    from rxhip import distributed as rd
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    # contributions whose sum depends on the order of the additions (1e16 + 1 − 1e16 …): 3K + 1 = 49 statistics as C5 exchanges them
+    rng = np.random.default_rng(100 + rank)
+    mine = rng.standard_normal(49) * 10.0 ** rng.integers(-8, 17, 49)
+    runs, scratch = [], None
+    for _ in range(3):
+        t = torch.from_numpy(mine.copy())
+        scratch = rd.allgather_ordered_sum_(t, dist, scratch)
+        runs.append(t.numpy().copy())
+    np.savez(os.path.join(out_dir, f"sum{rank}.npz"), runs=np.array(runs), mine=mine)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_the_mixture_statistics_exchange_is_bit_identical_on_every_rank_and_every_run(tmp_path):
+    """C5's one exchange (3K + 1 statistics per VMP iteration) is an all-gather + one local reduction over the rank axis — the same bytes through the same
+    kernel on every rank — instead of an all-reduce, whose summation order is the backend's (ring or tree, chosen per message size and topology): every
+    rank of a world-8 run holds the same bits, run after run (the 1e-8 run-to-run free-energy tolerance), and they are the reduction of the
+    rank-ordered contributions."""
+    import torch
+    import torch.multiprocessing as mp
+
+    world = 8
+    mp.spawn(_ordered_sum_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(tmp_path / f"sum{r}.npz") for r in range(world)]
+    want = torch.sum(torch.from_numpy(np.stack([r["mine"] for r in res])), dim=0).numpy()
+    for r in res:
+        assert all(np.array_equal(run, want) for run in r["runs"])
+    exact = np.array([float(sum(map(lambda v: __import__("fractions").Fraction(float(v)), col))) for col in np.stack([r["mine"] for r in res]).T])
+    assert np.max(np.abs(want - exact) / np.maximum(np.abs(exact), 1e-300)) < 1e-6   # (a sum, not something else: cancellation bounds the accuracy, the bits are what is pinned)
