@@ -1201,10 +1201,11 @@ struct Engine {
     int mode = 0, mode_fe = 0, rb = 16, rb_fe = 16, wg = 256;   // schedule of the sweep phase / of the Bethe phase (tree_kernels.hpp: 0 a launch per level, 1 resident levels, 2 walk)
     int *d_ops = nullptr, *d_aux = nullptr, *d_lvl = nullptr, *d_status = nullptr, *d_sops = nullptr, *d_strands = nullptr;
     double *d_cpool = nullptr, *d_msg = nullptr, *d_marg = nullptr, *d_val = nullptr, *d_prec = nullptr, *d_term = nullptr, *d_stat = nullptr, *d_prec_init = nullptr,
-           *d_fe_rep = nullptr, *d_fe_hist = nullptr;
+           *d_fe_rep = nullptr, *d_fe_hist = nullptr, *d_fe_part = nullptr;
     int fe_cap = 0;
     bool have_data = false, ran = false;
     bool cont = false;   // rxhip_tree_continue: later runs go on from the q(W) the previous run ended with
+    bool elem_fast = false;   // dimensions above 8: a replica's slots contiguous (TreeParams es = 1), so that a wavefront's loads of a message coalesce
     bool push_done = false;   // the image marginals (OP_MARG_PUSH, first level of the second phase) are those of the last sweep
     int last_iterations = 0, last_want_fe = 0;
     std::vector<char> data_set;
@@ -1241,12 +1242,16 @@ rxhip_status zalloc(double** dst, long long doubles, std::string& err) {
     TCHK(hipMemset(*dst, 0, sizeof(double) * n));
     return RXHIP_OK;
 }
-// per-replica free energy = term[root]; total over replicas in a fixed order (one workgroup, pairwise tree over a fixed layout)
-__global__ void __launch_bounds__(256) k_tree_fe_total(const double* __restrict__ term, long long root, long long R, long long RS, double* __restrict__ per_replica, double* __restrict__ total) {
+// per-replica free energy = term[root]; total over replicas in a fixed order: workgroup b sums replicas [b·FE_CHUNK, (b + 1)·FE_CHUNK) (fixed stride per thread,
+// pairwise tree over a fixed layout) into partial[b]; the last stage (one workgroup) sums the partials the same way — deterministic to the bit, and not one
+// workgroup crawling over 65 536 values (87 µs of a 4.6 ms iteration)
+constexpr int FE_CHUNK = 4096;
+__global__ void __launch_bounds__(256) k_tree_fe_total(const double* __restrict__ src, long long stride, long long n, double* __restrict__ per_replica, double* __restrict__ out) {
     __shared__ double sh[256];
+    const long long lo = (long long)blockIdx.x * FE_CHUNK, hi = lo + FE_CHUNK < n ? lo + FE_CHUNK : n;
     double s = 0.0;
-    for (long long r = threadIdx.x; r < R; r += 256) {
-        const double v = term[root * RS + r];
+    for (long long r = lo + threadIdx.x; r < hi; r += 256) {
+        const double v = src[r * stride];
         if (per_replica) per_replica[r] = v;
         s += v;
     }
@@ -1256,19 +1261,19 @@ __global__ void __launch_bounds__(256) k_tree_fe_total(const double* __restrict_
         if ((int)threadIdx.x < h) sh[threadIdx.x] += sh[threadIdx.x + h];
         __syncthreads();
     }
-    if (threadIdx.x == 0) *total = sh[0];
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
 }
 
 // state[k][r] = init[k] for every replica: a run starts from the `@initialization` marginals
-__global__ void __launch_bounds__(256) k_tree_broadcast(double* __restrict__ dst, const double* __restrict__ init, long long n, long long RS) {
+__global__ void __launch_bounds__(256) k_tree_broadcast(double* __restrict__ dst, const double* __restrict__ init, long long n, long long RS, int elem_fast) {
     const long long total = n * RS;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) dst[i] = init[i / RS];
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) dst[i] = init[elem_fast ? i % n : i / RS];
 }
 
 // host layout <-> replica-fastest device layout, on the device (at 65 536 replicas the host loops these replace ran for seconds)
 // data: dst[(k)·RS + r] = src[r·rows + col + k] for k < width — a 32×32 LDS tile so that both sides move whole lines
-__global__ void __launch_bounds__(256) k_tree_scatter(double* __restrict__ dst, const double* __restrict__ src, long long R, long long RS, long long rows, long long col, long long width,
-                                                      int* __restrict__ status) {
+__global__ void __launch_bounds__(256) k_tree_scatter(double* __restrict__ dst, const double* __restrict__ src, long long R, long long es, long long rs, long long rows, long long col,
+                                                      long long width, int* __restrict__ status) {
     __shared__ double tile[32][33];
     const long long r0 = (long long)blockIdx.x * 32, k0 = (long long)blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 × 8
@@ -1281,15 +1286,15 @@ __global__ void __launch_bounds__(256) k_tree_scatter(double* __restrict__ dst, 
         const long long k = k0 + j, r = r0 + tx;
         if (k < width && r < R) {
             const double x = tile[tx][j];
-            dst[k * RS + r] = x;
+            dst[k * es + r * rs] = x;
             if (!(fabs(x) <= 1.79769313486231570815e308)) atomicOr(status, 2);   // NaN (`missing`) or ±Inf in the data: this executor has no rule for it
         }
     }
 }
 struct GatherVar { int off, d; long long mo, co; int clamped; };   // clamped: a data / derived value — reported as a point mass (mean = the value, zero covariance)
 // marginals of the listed variables into [variable][replica][d] / [variable][replica][d][d] (the arrays rxhip_tree_get_marginals fills)
-__global__ void __launch_bounds__(256) k_tree_gather(const double* __restrict__ marg, const double* __restrict__ val, const GatherVar* __restrict__ vars, int n_vars, long long R, long long RS,
-                                                     double* __restrict__ mean, double* __restrict__ cov) {
+__global__ void __launch_bounds__(256) k_tree_gather(const double* __restrict__ marg, const double* __restrict__ val, const GatherVar* __restrict__ vars, int n_vars, long long R, long long es,
+                                                     long long rs_marg, long long rs_val, double* __restrict__ mean, double* __restrict__ cov) {
     const long long rblocks = (R + 255) / 256;
     for (long long it = blockIdx.x; it < (long long)n_vars * rblocks; it += gridDim.x) {
         const int vi = (int)(it / rblocks);
@@ -1299,17 +1304,17 @@ __global__ void __launch_bounds__(256) k_tree_gather(const double* __restrict__ 
         const int d = g.d;
         if (g.clamped) {
             if (mean)
-                for (int k = 0; k < d; ++k) mean[g.mo + r * d + k] = val[(long long)(g.off + k) * RS + r];
+                for (int k = 0; k < d; ++k) mean[g.mo + r * d + k] = val[(long long)(g.off + k) * es + r * rs_val];
             if (cov)
                 for (int k = 0; k < d * d; ++k) cov[g.co + r * d * d + k] = 0.0;
             continue;
         }
         if (mean)
-            for (int k = 0; k < d; ++k) mean[g.mo + r * d + k] = marg[(long long)(g.off + k) * RS + r];
+            for (int k = 0; k < d; ++k) mean[g.mo + r * d + k] = marg[(long long)(g.off + k) * es + r * rs_marg];
         if (cov)
             for (int a = 0; a < d; ++a)
                 for (int b = 0; b <= a; ++b) {
-                    const double x = marg[(long long)(g.off + d + a * (a + 1) / 2 + b) * RS + r];
+                    const double x = marg[(long long)(g.off + d + a * (a + 1) / 2 + b) * es + r * rs_marg];
                     cov[g.co + (r * d + a) * d + b] = x;
                     cov[g.co + (r * d + b) * d + a] = x;
                 }
@@ -1320,6 +1325,10 @@ TreeParams params_of(const Engine* e, int want_fe) {
     TreeParams p{};
     p.ops = e->d_ops; p.aux = e->d_aux; p.cpool = e->d_cpool; p.msg = e->d_msg; p.marg = e->d_marg; p.val = e->d_val; p.prec = e->d_prec;
     p.term = e->d_term; p.stat = e->d_stat; p.R = e->R; p.RS = e->RS; p.want_fe = want_fe; p.status = e->d_status;
+    const Program& P = e->prog;
+    p.es = e->elem_fast ? 1 : e->RS;
+    p.rs_msg = e->elem_fast ? P.msg_doubles : 1; p.rs_marg = e->elem_fast ? P.marg_doubles : 1; p.rs_val = e->elem_fast ? P.val_doubles : 1;
+    p.rs_prec = e->elem_fast ? P.prec_doubles : 1; p.rs_term = e->elem_fast ? P.term_slots : 1; p.rs_stat = e->elem_fast ? P.stat_doubles : 1;
     return p;
 }
 template <int N, int PHASE>
@@ -1418,8 +1427,10 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     e->device = device;
     DevScope ds(device);
     e->R = std::max<int64_t>(1, g->n_replicas);
+    if (e->R > (long long)FE_CHUNK * FE_CHUNK) { err = "more than 16 777 216 replicas in one engine"; delete e; return RXHIP_ERR_UNSUPPORTED; }   // (two-stage free-energy sum)
     e->RS = (e->R + 15) / 16 * 16;
     const Program& P = e->prog;
+    e->elem_fast = P.dmax > 8;
     // schedule: deep graphs walk their levels inside a workgroup (one launch per iteration); wide, shallow ones take a launch per level
     const double avg_width = (double)P.n_ops / std::max(1, P.n_levels);
     e->mode = (P.n_levels > 24 && (e->R >= 512 || avg_width * (double)e->R < 16384.0)) ? 1 : 0;
@@ -1483,7 +1494,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     if ((st = upload(&e->d_ops, P.ops, err)) || (st = upload(&e->d_aux, P.aux, err)) || (st = upload(&e->d_lvl, P.lvl_ptr, err)) || (st = upload(&e->d_cpool, P.cpool, err)) ||
         (st = upload(&e->d_prec_init, P.prec_init, err)) || (st = zalloc(&e->d_msg, P.msg_doubles * e->RS, err)) || (st = zalloc(&e->d_marg, P.marg_doubles * e->RS, err)) ||
         (st = zalloc(&e->d_val, P.val_doubles * e->RS, err)) || (st = zalloc(&e->d_prec, P.prec_doubles * e->RS, err)) || (st = zalloc(&e->d_term, P.term_slots * e->RS, err)) ||
-        (st = zalloc(&e->d_stat, P.stat_doubles * e->RS, err)) || (st = zalloc(&e->d_fe_rep, e->RS, err)))
+        (st = zalloc(&e->d_stat, P.stat_doubles * e->RS, err)) || (st = zalloc(&e->d_fe_rep, e->RS, err)) || (st = zalloc(&e->d_fe_part, (e->R + FE_CHUNK - 1) / FE_CHUNK, err)))
         return cleanup(st);
     if (hipMalloc(&e->d_status, sizeof(int)) != hipSuccess || hipMemset(e->d_status, 0, sizeof(int)) != hipSuccess) { err = "hipMalloc failed"; return cleanup(RXHIP_ERR_HIP); }
     e->data_set.assign(P.data_vars.size(), 0);
@@ -1518,7 +1529,7 @@ void destroy(Engine* e) {
     DevScope ds(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void* q : {(void*)e->d_sops, (void*)e->d_strands, (void*)e->d_ops, (void*)e->d_aux, (void*)e->d_lvl, (void*)e->d_status, (void*)e->d_cpool, (void*)e->d_msg, (void*)e->d_marg, (void*)e->d_val, (void*)e->d_prec,
-                    (void*)e->d_term, (void*)e->d_stat, (void*)e->d_prec_init, (void*)e->d_fe_rep, (void*)e->d_fe_hist})
+                    (void*)e->d_term, (void*)e->d_stat, (void*)e->d_prec_init, (void*)e->d_fe_rep, (void*)e->d_fe_hist, (void*)e->d_fe_part})
         if (q) (void)hipFree(q);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -1552,7 +1563,8 @@ rxhip_status set_data(Engine* e, const int64_t* vars, int64_t n_vars, const doub
             long long width = 0;
             while (j < n_vars && P.val_off[vars[j]] == P.val_off[vars[i]] + width) { width += P.dim[vars[j]]; ++j; }
             const dim3 grid((unsigned)((nr + 31) / 32), (unsigned)((width + 31) / 32));
-            hipLaunchKernelGGL(k_tree_scatter, grid, dim3(256), 0, e->stream, e->d_val + (size_t)P.val_off[vars[i]] * e->RS + r0, (const double*)d_tmp, nr, e->RS, rows, col, width, e->d_status);
+            const long long es = e->elem_fast ? 1 : e->RS, rs = e->elem_fast ? P.val_doubles : 1;
+            hipLaunchKernelGGL(k_tree_scatter, grid, dim3(256), 0, e->stream, e->d_val + (size_t)P.val_off[vars[i]] * es + (size_t)r0 * rs, (const double*)d_tmp, nr, es, rs, rows, col, width, e->d_status);
             col += width;
             i = j;
         }
@@ -1595,7 +1607,7 @@ rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err) {
     if (P.prec_doubles > 0 && !(e->cont && e->ran)) {
         const long long total = P.prec_doubles * e->RS;
         hipLaunchKernelGGL(k_tree_broadcast, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, e->stream, e->d_prec, (const double*)e->d_prec_init,
-                           (long long)P.prec_doubles, e->RS);
+                           (long long)P.prec_doubles, e->RS, e->elem_fast ? 1 : 0);
     }
     const TreeParams p = params_of(e, want_fe);
     // without the free energy on a graph without precision variables the sweep ends with the marginals
@@ -1604,7 +1616,17 @@ rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err) {
     TCHK(hipEventRecord(e->ev0, e->stream));
     for (int it = 0; it < iterations; ++it) {
         launch(e, p, 0, l_end);
-        if (want_fe) hipLaunchKernelGGL(k_tree_fe_total, dim3(1), dim3(256), 0, e->stream, e->d_term, (long long)P.fe_root, e->R, e->RS, e->d_fe_rep, e->d_fe_hist + it);
+        if (want_fe) {   // Σ over replicas of term[root]: chunks of FE_CHUNK into partials, the partials (≤ FE_CHUNK of them: up to 16.7 M replicas) into the iteration's slot
+            const unsigned nb = (unsigned)((e->R + FE_CHUNK - 1) / FE_CHUNK);
+            const double* root = e->d_term + (size_t)P.fe_root * (e->elem_fast ? 1 : e->RS);
+            const long long stride = e->elem_fast ? P.term_slots : 1;
+            if (nb == 1)
+                hipLaunchKernelGGL(k_tree_fe_total, dim3(1), dim3(256), 0, e->stream, root, stride, e->R, e->d_fe_rep, e->d_fe_hist + it);
+            else {
+                hipLaunchKernelGGL(k_tree_fe_total, dim3(nb), dim3(256), 0, e->stream, root, stride, e->R, e->d_fe_rep, e->d_fe_part);
+                hipLaunchKernelGGL(k_tree_fe_total, dim3(1), dim3(256), 0, e->stream, (const double*)e->d_fe_part, 1ll, (long long)nb, (double*)nullptr, e->d_fe_hist + it);
+            }
+        }
     }
     TCHK(hipEventRecord(e->ev1, e->stream));
     TCHK(hipGetLastError());
@@ -1678,7 +1700,7 @@ rxhip_status get_marginals(Engine* e, const int64_t* vars, int64_t n_vars, doubl
         if (he == hipSuccess) {
             const long long items = (long long)(i1 - i0) * ((e->R + 255) / 256);
             hipLaunchKernelGGL(k_tree_gather, dim3((unsigned)std::min<long long>(items, 1 << 20)), dim3(256), 0, e->stream, (const double*)e->d_marg, (const double*)e->d_val, (const GatherVar*)d_gv, (int)(i1 - i0),
-                               e->R, e->RS, d_m, d_c);
+                               e->R, e->elem_fast ? 1ll : e->RS, e->elem_fast ? (long long)P.marg_doubles : 1ll, e->elem_fast ? (long long)P.val_doubles : 1ll, d_m, d_c);
             he = hipGetLastError();
         }
         if (he == hipSuccess) he = hipStreamSynchronize(e->stream);
@@ -1700,13 +1722,20 @@ rxhip_status get_precision(Engine* e, int64_t var, double* nu, double* V, std::s
     DevScope ds(e->device);
     const int d = P.dim[var], tri = d * (d + 1) / 2;
     std::vector<double> buf((size_t)(1 + tri) * e->RS);
-    TCHK(hipMemcpy(buf.data(), e->d_prec + (size_t)P.prec_off[var] * e->RS, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
+    TCHK(hipStreamSynchronize(e->stream));
+    long long bes = e->RS, brs = 1;   // the copy's layout: element k of replica r at buf[k·bes + r·brs]
+    if (e->elem_fast) {   // a replica's slots are contiguous: the (1 + tri) doubles of this variable out of every replica's block
+        bes = 1; brs = 1 + tri;
+        TCHK(hipMemcpy2D(buf.data(), sizeof(double) * (1 + tri), e->d_prec + P.prec_off[var], sizeof(double) * (size_t)P.prec_doubles, sizeof(double) * (1 + tri), (size_t)e->R,
+                         hipMemcpyDeviceToHost));
+    } else
+        TCHK(hipMemcpy(buf.data(), e->d_prec + (size_t)P.prec_off[var] * e->RS, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));
     for (long long r = 0; r < e->R; ++r) {
-        if (nu) nu[r] = buf[r];
+        if (nu) nu[r] = buf[(size_t)r * brs];
         if (V)
             for (int a = 0; a < d; ++a)
                 for (int b = 0; b <= a; ++b) {
-                    const double x = buf[(size_t)(1 + a * (a + 1) / 2 + b) * e->RS + r];
+                    const double x = buf[(size_t)(1 + a * (a + 1) / 2 + b) * bes + (size_t)r * brs];
                     V[((size_t)r * d + a) * d + b] = x;
                     V[((size_t)r * d + b) * d + a] = x;
                 }
@@ -1849,6 +1878,7 @@ rxhip_status rule_eval(const rxhip_rule_call* c, int device, std::string& err) {
     if (hipMalloc(&d_status, sizeof(int)) != hipSuccess || hipMemset(d_status, 0, sizeof(int)) != hipSuccess) { freeall(); err = "hipMalloc failed"; return RXHIP_ERR_HIP; }
     TreeParams p{};
     p.ops = d_ops; p.aux = d_aux; p.cpool = d_cp; p.msg = d_msg; p.marg = d_marg; p.R = R; p.RS = RS; p.status = d_status;
+    p.es = RS; p.rs_msg = p.rs_marg = p.rs_val = p.rs_prec = p.rs_term = p.rs_stat = 1;   // (packed replica-fastest below, for either kernel family)
     const unsigned blocks = (unsigned)std::min<long long>((R + 255) / 256, 1 << 20);
     if (dmax > 8 && (st = wave_attributes(dmax, err))) { freeall(); return st; }
     for (int o = 0; o < 2; ++o) {

@@ -76,6 +76,10 @@ struct TreeParams {
     double* term;
     double* stat;
     long long R, RS;      // replicas; replica stride (R rounded up to 16)
+    // layout of the per-replica arrays as the LDS-staged kernels (tree_wave_kernels.hpp) address them: element k of slot `off` of replica r at
+    // (off + k)·es + r·rs_<array>.  Replica-fastest (the register kernels of this file, hard-wired): es = RS, rs = 1.  Element-fastest (engines with a
+    // dimension above 8): es = 1, rs = the array's doubles per replica.
+    long long es, rs_msg, rs_marg, rs_val, rs_prec, rs_term, rs_stat;
     int want_fe;
     int* status;          // bit 0: a matrix that must be positive definite was not
 };
@@ -835,8 +839,16 @@ __device__ __forceinline__ void eval_op(const TreeParams& p, const int* __restri
     else if (PHASE == 1) eval_fe<N, false>(p, w, r);
     else eval_fe<N, true>(p, w, r);
 }
+#ifndef RXHIP_FE_WAVES
+#define RXHIP_FE_WAVES 3      // wavefronts per SIMD the light Bethe-phase instance is compiled for (168 VGPRs; measured at 65 536 replicas: 2 → 1.19 / 1.64 ms for the
+                              // plain / two-branch chain, 3 → 1.12 / 1.49, 4 → 1.74 / 2.09 with 220 bytes of scratch; the strand kernel at 3: 2.35 → 2.78 ms, it spills:
+                              // profiles/r06/tree_occupancy.txt.  A/B: make variants/… EXTRA=-DRXHIP_FE_WAVES=…)
+#endif
+#ifndef RXHIP_STRAND_WAVES
+#define RXHIP_STRAND_WAVES 2  // … the strand kernel
+#endif
 template <int N, int PHASE>
-__global__ void __launch_bounds__(256) k_tree_ops(TreeParams p, int op0, int op1) {
+__global__ void __launch_bounds__(256, (PHASE == 2 && N == 4) ? RXHIP_FE_WAVES : 1) k_tree_ops(TreeParams p, int op0, int op1) {
     const long long total = (long long)(op1 - op0) * p.R;
     for (long long it = (long long)blockIdx.x * blockDim.x + threadIdx.x; it < total; it += (long long)gridDim.x * blockDim.x) {
         const long long o = it / p.R, r = it - o * p.R;
@@ -866,7 +878,7 @@ __global__ void __launch_bounds__((PHASE == 0 && N <= 4) ? 512 : 256) k_tree_lev
 // (a marginal, a product elsewhere, the Bethe phase) reads it.  A chain: 2T + 1 leaf strands, then the forward and the backward recursion side by side,
 // then the marginals — three launches, the wide levels at full occupancy, the two recursions without a barrier or a dependent load between their ops.
 template <int N>
-__global__ void __launch_bounds__(64) k_tree_strands(TreeParams p, const int* __restrict__ sops, const int* __restrict__ strands, int s0, int s1) {
+__global__ void __launch_bounds__(64, N == 4 ? RXHIP_STRAND_WAVES : 1) k_tree_strands(TreeParams p, const int* __restrict__ sops, const int* __restrict__ strands, int s0, int s1) {
     const long long nrb = (p.R + 63) / 64, total = (long long)(s1 - s0) * nrb;
     for (long long b = blockIdx.x; b < total; b += gridDim.x) {
         const long long s = b / nrb, r = (b - s * nrb) * 64 + threadIdx.x;

@@ -6,7 +6,8 @@
 // eight d-vectors, every primitive is a loop of the 64 lanes over the elements of its result, and a wavefront-scope fence orders a primitive's LDS writes
 // before the next one's reads (one wavefront executes its LDS instructions in order; no s_barrier, so that workgroups of several wavefronts would be legal).
 // The inverse is an in-place Gauss–Jordan sweep without pivoting (for a symmetric positive definite matrix the pivots are the Cholesky pivots squared:
-// positive, and their logs sum to the log-determinant); products are 4×4 (2×2 for small results) register tiles per lane with the k loop over LDS rows.
+// positive, and their logs sum to the log-determinant); products run on the matrix cores, one v_mfma_f64_16x16x4_f64 per 16×16 tile of the result and four
+// columns of the left operand, operands read from the LDS tiles (mm_mfma; the 4×4 register tiles of mm_tiles are what the host emulation compiles).
 // LDS per wavefront: (4·dmax·(dmax + 1) + 8·dmax)·8 bytes — 9.7 KB at d = 16, 35 KB at 32, 137 KB at 64 (one wavefront per CU: it runs, it is not fast).
 //
 // RXHIP_HOST_EMUL (tests/ only): the same rule bodies compiled for the host with a "wavefront" of one lane, so that every op can be checked against the
@@ -291,11 +292,61 @@ __device__ __forceinline__ void mm_tiles(const Ctx& c, int C, int A, int sai, in
     }
     w_sync();
 }
+#ifndef RXHIP_HOST_EMUL
+// The same product on the matrix cores: one v_mfma_f64_16x16x4_f64 per (16×16 tile of C, 4 columns of op(A)) — lane l feeds op(A)[i0 + (l & 15)][k0 + (l >> 4)]
+// and op(B)[k0 + (l >> 4)][j0 + (l & 15)] and holds C[i0 + (l >> 4) + 4r][j0 + (l & 15)], r = 0 … 3 (the layouts of dense_kernels.hpp).  A tile row of C at a
+// time: the A operand of a k-step is read once from LDS for all NTJ column tiles (2 LDS reads per MFMA at NTJ = 1, 1.25 at 4, against 8 reads per 16 FMAs of
+// the 4×4 register tiles above).  Elements beyond m / kk / n read as zero, whatever the LDS tile holds there.
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+template <int NTJ>
+__device__ __forceinline__ void mm_mfma(const Ctx& c, int C, int A, int sai, int sak, int B, int sbk, int sbj, int m, int kk, int n, bool acc_in, double sign) {
+    const int LD = c.LD, il = c.lane & 15, q = c.lane >> 4;
+    for (int i0 = 0; i0 < m; i0 += 16) {
+        mfma_d4 acc[NTJ];
+#pragma unroll
+        for (int t = 0; t < NTJ; ++t) acc[t] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
+        const int i = i0 + il;
+        const int ia = A + (i < m ? i : m - 1) * sai;
+        for (int k0 = 0; k0 < kk; k0 += 4) {
+            const int k = k0 + q;
+            const bool kv = k < kk;
+            const int kc = kv ? k : kk - 1;
+            const double av = wlds[ia + kc * sak];
+            const double a = (kv && i < m) ? av : 0.0;
+#pragma unroll
+            for (int t = 0; t < NTJ; ++t) {
+                if (16 * t < n) {   // (wavefront-uniform)
+                    const int j = 16 * t + il;
+                    const double bv = wlds[B + kc * sbk + (j < n ? j : n - 1) * sbj];
+                    const double b = (kv && j < n) ? bv : 0.0;
+                    acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[t], 0, 0, 0);
+                }
+            }
+        }
+#pragma unroll
+        for (int t = 0; t < NTJ; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int ii = i0 + q + 4 * r, j = 16 * t + il;
+                if (ii < m && j < n) {
+                    const int ix = C + ii * LD + j;
+                    wlds[ix] = acc_in ? wlds[ix] + sign * acc[t][r] : sign * acc[t][r];
+                }
+            }
+    }
+    w_sync();
+}
+#endif
+template <int DC = 64>
 __device__ __forceinline__ void matmul(const Ctx& c, int C, int A, bool ta, int B, bool tb, int m, int kk, int n, bool acc_in = false, double sign = 1.0) {
     const int LD = c.LD;
     const int sai = ta ? 1 : LD, sak = ta ? LD : 1, sbk = tb ? 1 : LD, sbj = tb ? LD : 1;
+#ifndef RXHIP_HOST_EMUL
+    mm_mfma<(DC + 15) / 16>(c, C, A, sai, sak, B, sbk, sbj, m, kk, n, acc_in, sign);
+#else
     if (m * n >= 8 * WL) mm_tiles<4, 4>(c, C, A, sai, sak, B, sbk, sbj, m, kk, n, acc_in, sign);
     else mm_tiles<2, 2>(c, C, A, sai, sak, B, sbk, sbj, m, kk, n, acc_in, sign);
+#endif
 }
 // tr(A B) of two d×d tiles
 __device__ __forceinline__ double trace_prod(const Ctx& c, int A, int B, int d) {
@@ -308,8 +359,8 @@ __device__ __forceinline__ double trace_prod(const Ctx& c, int A, int B, int d) 
 // a message in the form a rule wants, vector → v, matrix → M; a conversion is one inverse (in place) and one product (through vector 5)
 template <int DC>
 __device__ __forceinline__ bool load_msg(const Ctx& c, const TreeParams& p, int off, bool stored_wp, bool want_wp, int d, long long r, int v, int M) {
-    l_vec(c, v, p.msg, off, d, p.RS, r);
-    l_sym(c, M, p.msg, off + d, d, p.RS, r);
+    l_vec(c, v, p.msg, off, d, p.es, r * p.rs_msg);
+    l_sym(c, M, p.msg, off + d, d, p.es, r * p.rs_msg);
     w_sync();
     if (stored_wp == want_wp) return true;
     double ld;
@@ -321,8 +372,8 @@ __device__ __forceinline__ bool load_msg(const Ctx& c, const TreeParams& p, int 
     return ok;
 }
 __device__ __forceinline__ void store_msg(const Ctx& c, const TreeParams& p, int off, int d, long long r, int v, int M) {
-    s_vec(c, p.msg, off, d, p.RS, r, v);
-    s_sym(c, p.msg, off + d, d, p.RS, r, M);
+    s_vec(c, p.msg, off, d, p.es, r * p.rs_msg, v);
+    s_sym(c, p.msg, off + d, d, p.es, r * p.rs_msg, M);
 }
 // Σ (want_sigma) or W = Σ⁻¹ of a Gaussian node into M; (E) log|W|
 __device__ __forceinline__ double load_noise(const Ctx& c, const TreeParams& p, const int* w, int d, long long r, bool want_sigma, int M) {
@@ -330,8 +381,8 @@ __device__ __forceinline__ double load_noise(const Ctx& c, const TreeParams& p, 
     double el;
     if (ps >= 0) {
         const int tri = d * (d + 1) / 2;
-        l_full(c, M, p.prec, ps + 1 + tri + (want_sigma ? d * d : 0), d, p.RS, r);
-        el = p.prec[(ps + 1 + tri + 2 * d * d) * p.RS + r];
+        l_full(c, M, p.prec, ps + 1 + tri + (want_sigma ? d * d : 0), d, p.es, r * p.rs_prec);
+        el = p.prec[(ps + 1 + tri + 2 * d * d) * p.es + r * p.rs_prec];
     } else {
         const double* cp = p.cpool + w[W_C0];
         l_cmat(c, M, cp + (want_sigma ? 0 : d * d), d, d);
@@ -341,7 +392,7 @@ __device__ __forceinline__ double load_noise(const Ctx& c, const TreeParams& p, 
     return el;
 }
 __device__ __forceinline__ void load_value(const Ctx& c, const TreeParams& p, int off, bool slot, int d, long long r, int v) {
-    if (slot) l_vec(c, v, p.val, off, d, p.RS, r);
+    if (slot) l_vec(c, v, p.val, off, d, p.es, r * p.rs_val);
     else l_cvec(c, v, p.cpool + off, d);
     w_sync();
 }
@@ -359,14 +410,14 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         l_cmat(c, M0, p.cpool + w[W_C0], d, d1);
         load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d1, r, v0);
         matvec(c, v1, M0, LD, 1, v0, d, d1);
-        s_vec(c, p.val, w[W_OUT], d, p.RS, r, v1);
+        s_vec(c, p.val, w[W_OUT], d, p.es, r * p.rs_val, v1);
     } break;
     case OP_DERIVE_ADD: {
         load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v0);
         load_value(c, p, w[W_VAL2], fl & F_VAL2_SLOT, d, r, v1);
         add_vec(c, v0, v1, d, 1.0);
         w_sync();
-        s_vec(c, p.val, w[W_OUT], d, p.RS, r, v0);
+        s_vec(c, p.val, w[W_OUT], d, p.es, r * p.rs_val, v0);
     } break;
     case OP_LEAF: {
         load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v0);
@@ -393,8 +444,8 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
             ok = spd_inv<DC>(c, M2, d, ld) && ok;
             matvec(c, v1, M2, LD, 1, v0, d, d);
             matvec(c, v2, M1, LD, 1, v1, d, d);
-            matmul(c, M3, M2, false, M1, false, d, d, d);   // (Λ + W)⁻¹ W
-            matmul(c, M2, M0, false, M3, false, d, d, d);   // Λ (Λ + W)⁻¹ W
+            matmul<DC>(c, M3, M2, false, M1, false, d, d, d);   // (Λ + W)⁻¹ W
+            matmul<DC>(c, M2, M0, false, M3, false, d, d, d);   // Λ (Λ + W)⁻¹ W
             store_msg(c, p, w[W_OUT], d, r, v2, M2);
         }
     } break;
@@ -404,8 +455,8 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         l_cmat(c, M1, p.cpool + w[W_C0], d, d1);
         w_sync();
         matvec(c, v1, M1, LD, 1, v0, d, d1);
-        matmul(c, M2, M1, false, M0, false, d, d1, d1);   // A V
-        matmul(c, M3, M2, false, M1, true, d, d1, d);     // A V Aᵀ
+        matmul<DC>(c, M2, M1, false, M0, false, d, d1, d1);   // A V
+        matmul<DC>(c, M3, M2, false, M1, true, d, d1, d);     // A V Aᵀ
         store_msg(c, p, w[W_OUT], d, r, v1, M3);
     } break;
     case OP_MUL_IN: {
@@ -414,8 +465,8 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         l_cmat(c, M1, p.cpool + w[W_C0], d, d1);
         w_sync();
         matvec(c, v1, M1, 1, LD, v0, d1, d);              // Aᵀ ξ
-        matmul(c, M2, M1, true, M0, false, d1, d, d);     // Aᵀ Λ
-        matmul(c, M3, M2, false, M1, false, d1, d, d1);   // Aᵀ Λ A
+        matmul<DC>(c, M2, M1, true, M0, false, d1, d, d);     // Aᵀ Λ
+        matmul<DC>(c, M3, M2, false, M1, false, d1, d, d1);   // Aᵀ Λ A
         store_msg(c, p, w[W_OUT], d1, r, v1, M3);
     } break;
     case OP_ADD_OUT:
@@ -431,8 +482,8 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
             matvec(c, v2, M2, LD, 1, v0, d, d);
             matvec(c, v0, M1, LD, 1, v2, d, d);
             add_vec(c, v0, v1, d, -1.0);
-            matmul(c, M3, M2, false, M1, false, d, d, d);   // (Λo + W2)⁻¹ W2
-            matmul(c, M2, M0, false, M3, false, d, d, d);   // Λo (Λo + W2)⁻¹ W2
+            matmul<DC>(c, M3, M2, false, M1, false, d, d, d);   // (Λo + W2)⁻¹ W2
+            matmul<DC>(c, M2, M0, false, M3, false, d, d, d);   // Λo (Λo + W2)⁻¹ W2
             store_msg(c, p, w[W_OUT], d, r, v0, M2);
             break;
         }
@@ -475,9 +526,9 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
             double ld;
             ok = spd_inv<DC>(c, M0, d, ld) && ok;
             matvec(c, v2, M0, LD, 1, v0, d, d);
-            s_vec(c, p.marg, w[W_OUT], d, p.RS, r, v2);
-            s_sym(c, p.marg, w[W_OUT] + d, d, p.RS, r, M0);
-            if (c.lane == 0) p.marg[(w[W_OUT] + d + d * (d + 1) / 2) * p.RS + r] = -ld;
+            s_vec(c, p.marg, w[W_OUT], d, p.es, r * p.rs_marg, v2);
+            s_sym(c, p.marg, w[W_OUT] + d, d, p.es, r * p.rs_marg, M0);
+            if (c.lane == 0) p.marg[(w[W_OUT] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg] = -ld;
         }
     } break;
     default: break;
@@ -511,8 +562,8 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         w_sync();
         double ldP, ldS;
         ok = spd_inv<DC>(c, M0, d, ldP) && ok;
-        matmul(c, M3, M0, false, M2, false, d, d, d);                // P⁻¹ W
-        matmul(c, M1, M2, true, M3, false, d, d, d, true, -1.0);     // S −= Wᵀ P⁻¹ W
+        matmul<DC>(c, M3, M0, false, M2, false, d, d, d);                // P⁻¹ W
+        matmul<DC>(c, M1, M2, true, M3, false, d, d, d, true, -1.0);     // S −= Wᵀ P⁻¹ W
         ok = spd_inv<DC>(c, M1, d, ldS) && ok;
         // m_μ = S⁻¹ (ξ_μ + W P⁻¹ ξ_o) → v4, m_o = P⁻¹ (ξ_o + W m_μ) → v3
         matvec(c, v2, M0, LD, 1, v0, d, d);
@@ -530,26 +581,26 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
             wlds[v3 + i] -= wlds[v4 + i];
         }
         w_sync();
-        matmul(c, M2, M3, false, M1, false, d, d, d);                // D S⁻¹
-        matmul(c, M0, M2, false, M3, true, d, d, d, true, 1.0);      // P⁻¹ += D S⁻¹ Dᵀ
+        matmul<DC>(c, M2, M3, false, M1, false, d, d, d);                // D S⁻¹
+        matmul<DC>(c, M0, M2, false, M3, true, d, d, d, true, 1.0);      // P⁻¹ += D S⁻¹ Dᵀ
         each(c, d, d, [&](int i, int j) { wlds[M0 + i * LD + j] += wlds[v3 + i] * wlds[v3 + j]; });
         w_sync();
         double term = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
-        if (fl & F_STAT) s_full(c, p.stat, w[W_C1], d, p.RS, r, M0, 1.0);
+        if (fl & F_STAT) s_full(c, p.stat, w[W_C1], d, p.es, r * p.rs_stat, M0, 1.0);
         else {
             load_noise(c, p, w, d, r, false, M2);
             term += 0.5 * (d * T_LOG2PI - el + trace_prod(c, M2, M0, d));
         }
-        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = term;
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = term;
     } break;
     case OP_FE_NOISE1:
     case OP_FE_NOISE0: {
         const double el = load_noise(c, p, w, d, r, false, M1);
         double H = 0.0;
         if (op == OP_FE_NOISE1) {
-            l_vec(c, v0, p.marg, w[W_IN0], d, p.RS, r);
-            l_sym(c, M0, p.marg, w[W_IN0] + d, d, p.RS, r);
-            H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r]);
+            l_vec(c, v0, p.marg, w[W_IN0], d, p.es, r * p.rs_marg);
+            l_sym(c, M0, p.marg, w[W_IN0] + d, d, p.es, r * p.rs_marg);
+            H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg]);
             load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v1);
         } else {
             zero_mat(c, M0, d);
@@ -561,13 +612,13 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         each(c, d, d, [&](int i, int j) { wlds[M0 + i * LD + j] += wlds[v0 + i] * wlds[v0 + j]; });
         w_sync();
         double term = -H;
-        if (fl & F_STAT) s_full(c, p.stat, w[W_C1], d, p.RS, r, M0, 1.0);
+        if (fl & F_STAT) s_full(c, p.stat, w[W_C1], d, p.es, r * p.rs_stat, M0, 1.0);
         else term += 0.5 * (d * T_LOG2PI - el + trace_prod(c, M1, M0, d));
-        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = term;
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = term;
     } break;
     case OP_FE_ENT: {
-        const double H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r]);
-        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = (double)w[W_N] * H;
+        const double H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg]);
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = (double)w[W_N] * H;
     } break;
     case OP_FE_ADD2: {   // P = Λ1 + Λo → M0, S = Λ2 + Λo − Λo P⁻¹ Λo → M1, Λo → M2
         if (w[W_IN0] >= 0) ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
@@ -582,18 +633,18 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         w_sync();
         double ldP, ldS;
         ok = spd_inv<DC>(c, M0, d, ldP) && ok;
-        matmul(c, M3, M0, false, M2, false, d, d, d);
-        matmul(c, M1, M2, false, M3, false, d, d, d, true, -1.0);
+        matmul<DC>(c, M3, M0, false, M2, false, d, d, d);
+        matmul<DC>(c, M1, M2, false, M3, false, d, d, d, true, -1.0);
         ok = spd_inv<DC>(c, M1, d, ldS) && ok;
-        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
     } break;
     case OP_SUM_TERMS: {
         if (c.lane == 0) {
             const int n = w[W_N];
             const int* lst = p.aux + w[W_LIST];
             double s = 0.0;
-            for (int q = 0; q < n; ++q) s += p.term[(long long)lst[q] * p.RS + r];
-            p.term[(long long)w[W_TERM] * p.RS + r] = s;
+            for (int q = 0; q < n; ++q) s += p.term[(long long)lst[q] * p.es + r * p.rs_term];
+            p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = s;
         }
     } break;
     case OP_PREC_UPDATE: {
@@ -606,7 +657,7 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         const int* lst = p.aux + w[W_LIST];
         for (int q = 0; q < n; ++q) {
             const long long so = lst[q];
-            each(c, d, d, [&](int i, int j) { wlds[M0 + i * LD + j] += p.stat[(so + i * d + j) * p.RS + r]; });
+            each(c, d, d, [&](int i, int j) { wlds[M0 + i * LD + j] += p.stat[(so + i * d + j) * p.es + r * p.rs_stat]; });
         }
         w_sync();
         each(c, d, d, [&](int i, int j) {
@@ -623,19 +674,19 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         const int ps = w[W_PREC], tri = d * (d + 1) / 2;
         const double elw = t_mvdigamma(0.5 * nu, d) + d * T_LOG2 + ldV;
         if (c.lane == 0) {
-            p.prec[(long long)ps * p.RS + r] = nu;
-            p.prec[(long long)(ps + 1 + tri + 2 * d * d) * p.RS + r] = elw;
+            p.prec[(long long)ps * p.es + r * p.rs_prec] = nu;
+            p.prec[(long long)(ps + 1 + tri + 2 * d * d) * p.es + r * p.rs_prec] = elw;
         }
-        s_sym(c, p.prec, ps + 1, d, p.RS, r, M3);
-        s_full(c, p.prec, ps + 1 + tri, d, p.RS, r, M3, nu);
-        s_full(c, p.prec, ps + 1 + tri + d * d, d, p.RS, r, M2, 1.0 / nu);
+        s_sym(c, p.prec, ps + 1, d, p.es, r * p.rs_prec, M3);
+        s_full(c, p.prec, ps + 1 + tri, d, p.es, r * p.rs_prec, M3, nu);
+        s_full(c, p.prec, ps + 1 + tri + d * d, d, p.es, r * p.rs_prec, M2, 1.0 / nu);
         if (p.want_fe) {
             l_cmat(c, M0, cp + 1, d, d);
             w_sync();
             double F = 0.5 * ((double)n * (d * T_LOG2PI - elw) + nu * trace_prod(c, M3, M1, d));
             F += -(0.5 * (nu0 - d - 1.0) * elw - 0.5 * nu * trace_prod(c, M0, M3, d) - 0.5 * nu0 * d * T_LOG2 - 0.5 * nu0 * ldS0 - t_mvlgamma(0.5 * nu0, d));
             F -= 0.5 * (d + 1.0) * ldV + 0.5 * d * (d + 1.0) * T_LOG2 + t_mvlgamma(0.5 * nu, d) - 0.5 * (nu - d - 1.0) * t_mvdigamma(0.5 * nu, d) + 0.5 * nu * d;
-            if (c.lane == 0) p.term[(long long)w[W_TERM] * p.RS + r] = F;
+            if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = F;
         }
     } break;
     default: break;
@@ -650,7 +701,10 @@ __device__ __forceinline__ void eval_op(const Ctx& c, const TreeParams& p, const
 }
 
 #ifndef RXHIP_HOST_EMUL
-// one launch per level: a workgroup (one wavefront) per item (op, replica); replica fastest, so that neighbouring workgroups share the 128-byte lines of a slot
+// one launch per level: a workgroup (one wavefront) per item (op, replica).  Storage: element k of slot `off` of replica r at (off + k)·es + r·rs_<array>
+// (TreeParams): the engines of this kernel store a replica's slots CONTIGUOUSLY (es = 1, rs = the array's doubles per replica), so that the 64 lanes of the
+// wavefront that loads a message read 64 consecutive doubles — with the replica-fastest layout of the register kernels (es = RS, rs = 1; still what
+// rxhip_rule_eval's one-node schedules use) every lane touched a 128-byte line of its own and 15/16 of the HBM traffic was other replicas' data
 template <int PHASE, int DC>
 __global__ void __launch_bounds__(64, DC <= 16 ? 2 : 1) k_wave_ops(TreeParams p, int op0, int op1, int dmax) {
     const Ctx c = make_ctx(dmax);

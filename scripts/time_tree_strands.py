@@ -16,10 +16,11 @@ T = 128
 graphs = {"plain": lgssm_graph(T, mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"]),
           "two_branch": two_branch_chain_graph(T, mdl["A"], mdl["B"][:2], mdl["B"][2:], mdl["P"], mdl["Q"][:2, :2], mdl["Q"][2:, 2:], mdl["m0"], mdl["V0"])}
 Rs = [int(x) for x in (sys.argv[1].split(",") if len(sys.argv) > 1 else "4096,16384,65536,131072".split(","))]
+SWEEP_MODES = [int(x) for x in (sys.argv[2].split(",") if len(sys.argv) > 2 else "1,2,3".split(","))]
 for name, (gb, xs, ys) in graphs.items():
     for R in Rs:
         rows = np.random.default_rng(0).standard_normal((R, T * 4)) * 3.0
-        for mode in (1, 2, 3):
+        for mode in SWEEP_MODES:
             for mode_fe in (0, 1, 2):
                 if mode != 3 and mode_fe != 2:
                     continue

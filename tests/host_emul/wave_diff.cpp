@@ -31,6 +31,7 @@ extern "C" int emul_run(int which, int n, const int* ops, int n_ops, const int* 
     TreeParams p{};
     p.ops = ops; p.aux = aux; p.cpool = cpool; p.msg = msg; p.marg = marg; p.val = val; p.prec = prec; p.term = term; p.stat = stat;
     p.R = R; p.RS = RS; p.want_fe = want_fe; p.status = &status;
+    p.es = RS; p.rs_msg = p.rs_marg = p.rs_val = p.rs_prec = p.rs_term = p.rs_stat = 1;   // the replica-fastest layout both bodies can read
     if (which == 1) run_wave(p, n_ops, n);
     else if (n <= 8) run_lane<8>(p, n_ops);
     else if (n <= 16) run_lane<16>(p, n_ops);
