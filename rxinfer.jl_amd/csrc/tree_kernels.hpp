@@ -148,20 +148,33 @@ __device__ __forceinline__ void ld_cvec(const double* c, int d, double (&v)[N]) 
     for (int i = 0; i < N; ++i) v[i] = i < d ? c[i] : 0.0;
 }
 
-// inverse and log-determinant of a symmetric positive definite matrix (Cholesky, A = L Lᵀ, A⁻¹ = L⁻ᵀ L⁻¹); false: a pivot ≤ 0 or not finite
+// inverse and log-determinant of a symmetric positive definite matrix (Cholesky, A = L Lᵀ, A⁻¹ = L⁻ᵀ L⁻¹); false: a pivot ≤ 0 or not finite.
+// One reciprocal square root per pivot (1 / √s; √s = s · that) instead of a square root and a division, and ONE logarithm per call: the pivots' mantissas are
+// multiplied (each in [½, 1): no under- or overflow for N ≤ 8 … 64 factors would need rescaling, N ≤ 8 here) and their binary exponents added —
+// log|A| = log(Π mantissas) + ln 2 · Σ exponents.  (Four square roots, four divisions and four logarithms were ≈ 1000 of the ≈ 1600 cycles of a 4×4 call.)
 template <int N>
 __device__ __forceinline__ bool spd_inv(const double (&A)[N][N], double (&Ai)[N][N], double& logdet) {
     double L[N][N], Li[N][N];
     bool ok = true;
-    double ld = 0.0;
+    double mant = 1.0;
+    int expo = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double s = A[j][j];
 #pragma unroll
         for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
         ok = ok && (s > 0.0) && (s < 1.0e300);
-        const double dj = sqrt(s), rj = 1.0 / dj;
-        ld += log(s);
+#ifdef RXHIP_HOST_EMUL
+        const double rj = 1.0 / sqrt(s);
+        int ex;
+        mant *= frexp(s, &ex);
+        expo += ex;
+#else
+        const double rj = rsqrt(s);
+        mant *= __builtin_amdgcn_frexp_mant(s);
+        expo += __builtin_amdgcn_frexp_exp(s);
+#endif
+        const double dj = s * rj;
         L[j][j] = dj;
         Li[j][j] = rj;
 #pragma unroll
@@ -172,6 +185,7 @@ __device__ __forceinline__ bool spd_inv(const double (&A)[N][N], double (&Ai)[N]
             L[i][j] = t * rj;
         }
     }
+    const double ld = log(mant) + 0.69314718055994530942 * (double)expo;
     // L⁻¹ (lower): Li[i][j] = −(Σ_{k=j}^{i−1} L[i][k] Li[k][j]) / L[i][i]
 #pragma unroll
     for (int j = 0; j < N; ++j)
@@ -333,15 +347,24 @@ template <int N>
 __device__ __forceinline__ bool spd_logdet(const double (&A)[N][N], double& logdet) {
     double L[N][N];
     bool ok = true;
-    double ld = 0.0;
+    double mant = 1.0;
+    int expo = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         double s = A[j][j];
 #pragma unroll
         for (int k = 0; k < j; ++k) s -= L[j][k] * L[j][k];
         ok = ok && (s > 0.0) && (s < 1.0e300);
+#ifdef RXHIP_HOST_EMUL
         const double rj = 1.0 / sqrt(s);
-        ld += log(s);
+        int ex;
+        mant *= frexp(s, &ex);
+        expo += ex;
+#else
+        const double rj = rsqrt(s);
+        mant *= __builtin_amdgcn_frexp_mant(s);
+        expo += __builtin_amdgcn_frexp_exp(s);
+#endif
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
             double t = A[i][j];
@@ -350,7 +373,7 @@ __device__ __forceinline__ bool spd_logdet(const double (&A)[N][N], double& logd
             L[i][j] = t * rj;
         }
     }
-    logdet = ld;
+    logdet = log(mant) + 0.69314718055994530942 * (double)expo;
     return ok;
 }
 // A marginal as the Bethe terms read it: (mean, covariance, log|V|) of the slot `off` — or, `push`, of the image of that marginal under the constant d × du

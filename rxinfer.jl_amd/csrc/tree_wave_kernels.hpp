@@ -29,31 +29,56 @@ constexpr int WL = 1;
 static double wlds[NBUF * DMAX_WAVE * (DMAX_WAVE + 1) + NVEC * DMAX_WAVE];
 __device__ __forceinline__ int w_lane() { return 0; }
 __device__ __forceinline__ void w_sync() {}
-__device__ __forceinline__ double w_sum(double x) { return x; }
+__device__ __forceinline__ double w_sum(double x, int) { return x; }
 #else
-constexpr int WL = 64;
+// NW wavefronts work on one item (a workgroup of 64·NW threads): one up to 16×16 — the LDS then holds 16 items per CU and a wavefront each keeps the SIMDs
+// busy — four above: at d = 64 the LDS holds ONE item per CU, and a single wavefront walking 4096-element tiles 64 elements at a time with an LDS round trip
+// per step left three SIMDs idle and the fourth waiting (≈ 100 µs per rule).  Element loops stride by the workgroup, a product's tile rows and the
+// inverse's tile rows go one to a wavefront.
+#ifdef RXHIP_TU_DC
+constexpr int NW = RXHIP_TU_DC > 32 ? 4 : RXHIP_TU_DC > 16 ? 2 : 1;
+#else
+constexpr int NW = 1;
+#endif
+constexpr int WL = 64 * NW;
 extern __shared__ double wlds[];
-__device__ __forceinline__ int w_lane() { return (int)(threadIdx.x & 63); }
-// orders the wavefront's earlier LDS / global accesses before its later ones as seen by its own lanes
+__device__ __forceinline__ int w_lane() { return (int)threadIdx.x; }
+// orders the work item's earlier LDS / global accesses before its later ones as seen by all of its lanes (one wavefront: a fence; several: a barrier)
 __device__ __forceinline__ void w_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (NW == 1) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else
+        __syncthreads();
 }
-__device__ __forceinline__ double w_sum(double x) {   // the same value in every lane, summed in a fixed order (butterfly)
+__device__ __forceinline__ double w_sum(double x, int scratch) {   // the same value in every lane, summed in a fixed order (butterfly, then the wavefronts in order)
 #pragma unroll
     for (int m = 32; m > 0; m >>= 1) x += __shfl_xor(x, m, 64);
-    return x;
+    if (NW == 1) return x;
+    if ((threadIdx.x & 63) == 0) wlds[scratch + (threadIdx.x >> 6)] = x;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) s += wlds[scratch + w];
+    __syncthreads();
+    return s;
 }
 #endif
 
-inline size_t lds_bytes(int dmax) { return sizeof(double) * ((size_t)NBUF * dmax * (dmax | 1) + (size_t)NVEC * dmax); }
+// (+ above 16: the two panels of the blocked inverse — 4 pivot rows of 16·NT + 1 and 16·NT rows of 5, NT = tiles per side of the dimension class)
+inline int wave_nt(int dmax) { return dmax <= 16 ? 1 : dmax <= 32 ? 2 : 4; }
+inline size_t lds_bytes(int dmax) {
+    const size_t nt = (size_t)wave_nt(dmax);
+    return sizeof(double) * ((size_t)NBUF * dmax * (dmax | 1) + (size_t)NVEC * dmax + 4 * (16 * nt + 1) + 16 * nt * 5);
+}
 
 // the wavefront's workspace: offsets (in doubles) into wlds
 struct Ctx {
     int lane, LD, dmax, V;
     __device__ __forceinline__ int M(int k) const { return k * dmax * LD; }
     __device__ __forceinline__ int v(int k) const { return V + k * dmax; }
+    __device__ __forceinline__ int S1() const { return V + NVEC * dmax; }             // blocked inverse: the pivot block's 4 rows (stride 16·NT + 1), then its 4 columns (stride 5)
 };
 __device__ __forceinline__ Ctx make_ctx(int dmax) {
     Ctx c;
@@ -97,29 +122,88 @@ __device__ __forceinline__ void l_cvec(const Ctx& c, int v, const double* cp, in
 __device__ __forceinline__ void s_vec(const Ctx& c, double* b, long long off, int d, long long RS, long long r, int v) {
     for (int i = c.lane; i < d; i += WL) b[(off + i) * RS + r] = wlds[v + i];
 }
+#ifndef RXHIP_HOST_EMUL
+// n elements, element e on lane e mod WL: ALL of a lane's loads first — independent, in flight together — then what is done with them.  (A loop that
+// loads one element and stores it to LDS waits for the memory system once per iteration: at d = 64 a message was 9 … 33 dependent HBM round trips.)
+template <int CH, class L, class S>
+__device__ __forceinline__ void batch(const Ctx& c, int n, L load, S sink) {
+    double x[CH];
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int e = c.lane + k * WL;
+        x[k] = e < n ? load(e) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < CH; ++k) {
+        const int e = c.lane + k * WL;
+        if (e < n) sink(e, x[k]);
+    }
+}
+__device__ __forceinline__ void tri_ij(int e, int& i, int& j) {   // packed lower triangle: e = i(i+1)/2 + j, j ≤ i
+    i = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+    while (i * (i + 1) / 2 > e) --i;
+    while ((i + 1) * (i + 2) / 2 <= e) ++i;
+    j = e - i * (i + 1) / 2;
+}
+#endif
+template <int DC>
 __device__ __forceinline__ void l_sym(const Ctx& c, int M, const double* b, long long off, int d, long long RS, long long r) {
     const int LD = c.LD;
+#ifndef RXHIP_HOST_EMUL
+    batch<(DC * (DC + 1) / 2 + WL - 1) / WL>(c, d * (d + 1) / 2, [&](int e) { return b[(off + e) * RS + r]; }, [&](int e, double x) {
+        int i, j;
+        tri_ij(e, i, j);
+        wlds[M + i * LD + j] = x;
+        wlds[M + j * LD + i] = x;
+    });
+#else
     each_tri(c, d, [&](int i, int j, int e) {
         const double x = b[(off + e) * RS + r];
         wlds[M + i * LD + j] = x;
         wlds[M + j * LD + i] = x;
     });
+#endif
 }
+template <int DC>
 __device__ __forceinline__ void s_sym(const Ctx& c, double* b, long long off, int d, long long RS, long long r, int M) {
     const int LD = c.LD;
+#ifndef RXHIP_HOST_EMUL
+    batch<(DC * (DC + 1) / 2 + WL - 1) / WL>(c, d * (d + 1) / 2, [&](int e) {
+        int i, j;
+        tri_ij(e, i, j);
+        return 0.5 * (wlds[M + i * LD + j] + wlds[M + j * LD + i]);
+    }, [&](int e, double x) { b[(off + e) * RS + r] = x; });
+#else
     each_tri(c, d, [&](int i, int j, int e) { b[(off + e) * RS + r] = 0.5 * (wlds[M + i * LD + j] + wlds[M + j * LD + i]); });
+#endif
 }
+template <int DC>
 __device__ __forceinline__ void l_full(const Ctx& c, int M, const double* b, long long off, int d, long long RS, long long r) {
     const int LD = c.LD;
+#ifndef RXHIP_HOST_EMUL
+    batch<(DC * DC + WL - 1) / WL>(c, d * d, [&](int e) { return b[(off + e) * RS + r]; }, [&](int e, double x) {
+        const int i = e / d;
+        wlds[M + i * LD + e - i * d] = x;
+    });
+#else
     each(c, d, d, [&](int i, int j) { wlds[M + i * LD + j] = b[(off + i * d + j) * RS + r]; });
+#endif
 }
 __device__ __forceinline__ void s_full(const Ctx& c, double* b, long long off, int d, long long RS, long long r, int M, double scale) {
     const int LD = c.LD;
     each(c, d, d, [&](int i, int j) { b[(off + i * d + j) * RS + r] = scale * wlds[M + i * LD + j]; });
 }
+template <int DC>
 __device__ __forceinline__ void l_cmat(const Ctx& c, int M, const double* cp, int rows, int cols) {
     const int LD = c.LD;
+#ifndef RXHIP_HOST_EMUL
+    batch<(DC * DC + WL - 1) / WL>(c, rows * cols, [&](int e) { return cp[e]; }, [&](int e, double x) {
+        const int i = e / cols;
+        wlds[M + i * LD + e - i * cols] = x;
+    });
+#else
     each(c, rows, cols, [&](int i, int j) { wlds[M + i * LD + j] = cp[i * cols + j]; });
+#endif
 }
 __device__ __forceinline__ void zero_mat(const Ctx& c, int M, int d) {
     const int LD = c.LD;
@@ -233,14 +317,17 @@ __device__ __forceinline__ bool spd_inv_blk(const Ctx& c, int A, int d, double& 
     return ok;
 }
 #endif
+#ifndef RXHIP_HOST_EMUL
+template <int DC>
+__device__ __forceinline__ bool spd_inv_blocked(const Ctx& c, int A, int d, double& logdet);   // (below, behind the matrix-core product it is made of)
+#endif
 // DC: the kernel instance's dimension class (16: dmax ≤ 16, 32: ≤ 32, 64) — one inverse per instance, so that the 2×2 blocks of the small class do not
 // carry the register budget of the 4×4 ones (occupancy: 16 wavefronts per CU fit the LDS at d = 16)
 template <int DC>
 __device__ __forceinline__ bool spd_inv(const Ctx& c, int A, int d, double& logdet) {
 #ifndef RXHIP_HOST_EMUL
-    if (DC <= 16) return spd_inv_blk<2>(c, A, d, logdet);
-    if (DC <= 32) return spd_inv_blk<4>(c, A, d, logdet);
-    return spd_inv_blk<8>(c, A, d, logdet);   // (128 VGPRs of matrix: the one wavefront a CU's LDS holds at this size has the SIMD's 512 to itself)
+    if (DC <= 16) return spd_inv_blk<2>(c, A, d, logdet);   // (one wavefront; the blocked sweep at this size — four blocks of one MFMA — measured no faster: 31.3 against 33.2 ms)
+    return spd_inv_blocked<DC>(c, A, d, logdet);
 #else
     return spd_inv_lds(c, A, d, logdet);
 #endif
@@ -298,10 +385,12 @@ __device__ __forceinline__ void mm_tiles(const Ctx& c, int C, int A, int sai, in
 // time: the A operand of a k-step is read once from LDS for all NTJ column tiles (2 LDS reads per MFMA at NTJ = 1, 1.25 at 4, against 8 reads per 16 FMAs of
 // the 4×4 register tiles above).  Elements beyond m / kk / n read as zero, whatever the LDS tile holds there.
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+// ldc: row stride of C (default: the tiles'); skip ≥ 0: the tile row and the tile column of that index are left alone (the blocked inverse's rank-16 update)
 template <int NTJ>
-__device__ __forceinline__ void mm_mfma(const Ctx& c, int C, int A, int sai, int sak, int B, int sbk, int sbj, int m, int kk, int n, bool acc_in, double sign) {
-    const int LD = c.LD, il = c.lane & 15, q = c.lane >> 4;
-    for (int i0 = 0; i0 < m; i0 += 16) {
+__device__ __forceinline__ void mm_mfma(const Ctx& c, int C, int A, int sai, int sak, int B, int sbk, int sbj, int m, int kk, int n, bool acc_in, double sign, int ldc = 0, int skip = -1) {
+    const int LD = ldc ? ldc : c.LD, wv = c.lane >> 6, il = c.lane & 15, q = (c.lane >> 4) & 3;
+    for (int i0 = 16 * wv; i0 < m; i0 += 16 * NW) {   // a tile row to a wavefront
+        if (i0 == 16 * skip) continue;
         mfma_d4 acc[NTJ];
 #pragma unroll
         for (int t = 0; t < NTJ; ++t) acc[t] = (mfma_d4){0.0, 0.0, 0.0, 0.0};
@@ -315,7 +404,7 @@ __device__ __forceinline__ void mm_mfma(const Ctx& c, int C, int A, int sai, int
             const double a = (kv && i < m) ? av : 0.0;
 #pragma unroll
             for (int t = 0; t < NTJ; ++t) {
-                if (16 * t < n) {   // (wavefront-uniform)
+                if (16 * t < n && t != skip) {   // (wavefront-uniform)
                     const int j = 16 * t + il;
                     const double bv = wlds[B + kc * sbk + (j < n ? j : n - 1) * sbj];
                     const double b = (kv && j < n) ? bv : 0.0;
@@ -328,13 +417,132 @@ __device__ __forceinline__ void mm_mfma(const Ctx& c, int C, int A, int sai, int
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int ii = i0 + q + 4 * r, j = 16 * t + il;
-                if (ii < m && j < n) {
+                if (ii < m && j < n && t != skip) {
                     const int ix = C + ii * LD + j;
                     wlds[ix] = acc_in ? wlds[ix] + sign * acc[t][r] : sign * acc[t][r];
                 }
             }
     }
     w_sync();
+}
+#endif
+#ifndef RXHIP_HOST_EMUL
+// The inverse above 16: the same sweep, FOUR pivots at a time, with the matrix in REGISTERS in the accumulator layout of v_mfma_f64_16x16x4_f64 (NT × NT tiles,
+// lane l holds rows (l >> 4) + 4r, column l & 15 of every tile; identity beyond d) — a block of four pivots is a rank-4 update of every tile: ONE matrix-core
+// instruction per tile.  Per block K = {k0 … k0 + 3}: the owners publish the block's four rows and four columns (LDS), every lane inverts the 4×4 pivot block
+// P = A_KK⁻¹ (register Cholesky of tree_kernels.hpp: its pivots are Cholesky pivots of the Schur complement — positive, their logs add up to log|A|), forms the
+// operands it feeds — the old column panel A_IK and the new row panel R = P A_K: — and then
+//     A_IJ −= A_IK R_J  (MFMA, all tiles),   A_K: ← R,   A_:K ← −A_:K P,   A_KK ← P
+// in registers.  Four pivots per block keep the accuracy of the scalar sweep (sixteen lose two to four digits at condition numbers 1e6 … 1e11: measured on
+// the host, scripts/sim_blk_inverse.py); d = 64: 16 blocks × 16 MFMA where the scalar sweep was 64 pivots of ≈ 700 VALU instructions and two LDS round trips.
+template <int DC>
+__device__ __forceinline__ bool spd_inv_blocked(const Ctx& c, int A, int d, double& logdet) {
+    constexpr int NT = (DC + 15) / 16, SL = 16 * NT + 1, NTR = (NT + NW - 1) / NW;   // NTR: tile rows a wavefront holds (tile row ti = wv + NW·tl)
+    const int LD = c.LD, wv = c.lane >> 6, il = c.lane & 15, q = (c.lane >> 4) & 3, S1 = c.S1(), S2 = S1 + 4 * SL;
+    mfma_d4 a[NTR][NT];
+#pragma unroll
+    for (int tl = 0; tl < NTR; ++tl)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * (wv + NW * tl) + q + 4 * r, j = 16 * tj + il;
+                a[tl][tj][r] = (i < d && j < d) ? wlds[A + i * LD + j] : (i == j ? 1.0 : 0.0);
+            }
+    bool ok = true;
+    double ld = 0.0;
+    auto sel4 = [](double x0, double x1, double x2, double x3, int k) { return k == 0 ? x0 : k == 1 ? x1 : k == 2 ? x2 : x3; };
+    for (int k0 = 0; k0 < d; k0 += 4) {   // (a last block that reaches beyond d sweeps identity rows: pivots 1, nothing coupled)
+        const int tK = k0 >> 4, m = (k0 & 15) >> 2;
+        // the block's rows k0 + q (lane (q, il) of the wavefront that holds tile row tK has them in register m) and columns k0 + (il & 3) (lanes with il >> 2 == m)
+#pragma unroll
+        for (int tl = 0; tl < NTR; ++tl) {
+            const int ti = wv + NW * tl;
+            if (ti == tK) {
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) wlds[S1 + q * SL + 16 * tj + il] = sel4(a[tl][tj][0], a[tl][tj][1], a[tl][tj][2], a[tl][tj][3], m);
+            }
+            if ((il >> 2) == m && ti < NT) {
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+                    if (tj == tK) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) wlds[S2 + (16 * ti + q + 4 * r) * 5 + (il & 3)] = a[tl][tj][r];
+                    }
+            }
+        }
+        w_sync();
+        double Pk[4][4], Pi[4][4], l4;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+#pragma unroll
+            for (int y = 0; y < 4; ++y) Pk[x][y] = wlds[S1 + x * SL + k0 + y];
+        ok = tree::spd_inv<4>(Pk, Pi, l4) && ok;
+        ld += l4;
+        // operands: the OLD column panel for this lane's (row il of its tile row, pivot q), negated; the NEW row panel R[q][·] for its (column il of the tile column, pivot q)
+        double Pq[4], bop[NT];   // Pq: row q of P
+#pragma unroll
+        for (int y = 0; y < 4; ++y) Pq[y] = sel4(Pi[0][y], Pi[1][y], Pi[2][y], Pi[3][y], q);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            double s0 = 0.0;
+#pragma unroll
+            for (int y = 0; y < 4; ++y) s0 += Pq[y] * wlds[S1 + y * SL + 16 * t + il];
+            bop[t] = s0;
+        }
+        const int y = il & 3;
+        double Py[4];   // column y of P
+#pragma unroll
+        for (int cc = 0; cc < 4; ++cc) Py[cc] = sel4(Pi[cc][0], Pi[cc][1], Pi[cc][2], Pi[cc][3], y);
+#pragma unroll
+        for (int tl = 0; tl < NTR; ++tl) {
+            const int ti = wv + NW * tl;
+            if (16 * ti >= d || ti >= NT) continue;   // (wavefront-uniform)
+            const double aop = -wlds[S2 + (16 * ti + il) * 5 + q];
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj)
+                if (16 * tj < d) a[tl][tj] = __builtin_amdgcn_mfma_f64_16x16x4f64(aop, bop[tj], a[tl][tj], 0, 0, 0);
+            // the block's own rows (row k0 + q of this lane ← R[q][16 tj + il]), then its columns and the corner
+            if (ti == tK) {
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj) {
+                    const double v = bop[tj];
+                    if (m == 0) a[tl][tj][0] = v; else if (m == 1) a[tl][tj][1] = v; else if (m == 2) a[tl][tj][2] = v; else a[tl][tj][3] = v;
+                }
+            }
+            if ((il >> 2) == m) {
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+                    if (tj == tK) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const int i = 16 * ti + q + 4 * r;
+                            double v;
+                            if (i >= k0 && i < k0 + 4) v = sel4(Py[0], Py[1], Py[2], Py[3], i - k0);   // the corner: P[i − k0][y]
+                            else {                                                                  // −Σ_c A_old[i][k0 + c] P[c][y]
+                                v = 0.0;
+#pragma unroll
+                                for (int cc = 0; cc < 4; ++cc) v -= wlds[S2 + i * 5 + cc] * Py[cc];
+                            }
+                            a[tl][tj][r] = v;
+                        }
+                    }
+            }
+        }
+        w_sync();   // (the next block's panels overwrite the scratch)
+    }
+#pragma unroll
+    for (int tl = 0; tl < NTR; ++tl)
+#pragma unroll
+        for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int i = 16 * (wv + NW * tl) + q + 4 * r, j = 16 * tj + il;
+                if (i < d && j < d) wlds[A + i * LD + j] = a[tl][tj][r];
+            }
+    w_sync();
+    logdet = ld;
+    return ok;
 }
 #endif
 template <int DC = 64>
@@ -353,14 +561,14 @@ __device__ __forceinline__ double trace_prod(const Ctx& c, int A, int B, int d) 
     const int LD = c.LD;
     double s = 0.0;
     each(c, d, d, [&](int i, int k) { s += wlds[A + i * LD + k] * wlds[B + k * LD + i]; });
-    return w_sum(s);
+    return w_sum(s, c.v(7));
 }
 
 // a message in the form a rule wants, vector → v, matrix → M; a conversion is one inverse (in place) and one product (through vector 5)
 template <int DC>
 __device__ __forceinline__ bool load_msg(const Ctx& c, const TreeParams& p, int off, bool stored_wp, bool want_wp, int d, long long r, int v, int M) {
     l_vec(c, v, p.msg, off, d, p.es, r * p.rs_msg);
-    l_sym(c, M, p.msg, off + d, d, p.es, r * p.rs_msg);
+    l_sym<DC>(c, M, p.msg, off + d, d, p.es, r * p.rs_msg);
     w_sync();
     if (stored_wp == want_wp) return true;
     double ld;
@@ -371,21 +579,23 @@ __device__ __forceinline__ bool load_msg(const Ctx& c, const TreeParams& p, int 
     w_sync();
     return ok;
 }
+template <int DC>
 __device__ __forceinline__ void store_msg(const Ctx& c, const TreeParams& p, int off, int d, long long r, int v, int M) {
     s_vec(c, p.msg, off, d, p.es, r * p.rs_msg, v);
-    s_sym(c, p.msg, off + d, d, p.es, r * p.rs_msg, M);
+    s_sym<DC>(c, p.msg, off + d, d, p.es, r * p.rs_msg, M);
 }
 // Σ (want_sigma) or W = Σ⁻¹ of a Gaussian node into M; (E) log|W|
+template <int DC>
 __device__ __forceinline__ double load_noise(const Ctx& c, const TreeParams& p, const int* w, int d, long long r, bool want_sigma, int M) {
     const int ps = w[W_PREC];
     double el;
     if (ps >= 0) {
         const int tri = d * (d + 1) / 2;
-        l_full(c, M, p.prec, ps + 1 + tri + (want_sigma ? d * d : 0), d, p.es, r * p.rs_prec);
+        l_full<DC>(c, M, p.prec, ps + 1 + tri + (want_sigma ? d * d : 0), d, p.es, r * p.rs_prec);
         el = p.prec[(ps + 1 + tri + 2 * d * d) * p.es + r * p.rs_prec];
     } else {
         const double* cp = p.cpool + w[W_C0];
-        l_cmat(c, M, cp + (want_sigma ? 0 : d * d), d, d);
+        l_cmat<DC>(c, M, cp + (want_sigma ? 0 : d * d), d, d);
         el = cp[2 * d * d];
     }
     w_sync();
@@ -407,7 +617,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
     switch (op) {
     case OP_DERIVE_MUL: {
         const int d1 = w[W_D1];
-        l_cmat(c, M0, p.cpool + w[W_C0], d, d1);
+        l_cmat<DC>(c, M0, p.cpool + w[W_C0], d, d1);
         load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d1, r, v0);
         matvec(c, v1, M0, LD, 1, v0, d, d1);
         s_vec(c, p.val, w[W_OUT], d, p.es, r * p.rs_val, v1);
@@ -422,21 +632,21 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
     case OP_LEAF: {
         load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v0);
         const bool wp = fl & F_OUT_WP;
-        load_noise(c, p, w, d, r, !wp, M0);
+        load_noise<DC>(c, p, w, d, r, !wp, M0);
         if (wp) {
             matvec(c, v1, M0, LD, 1, v0, d, d);
-            store_msg(c, p, w[W_OUT], d, r, v1, M0);
+            store_msg<DC>(c, p, w[W_OUT], d, r, v1, M0);
         } else
-            store_msg(c, p, w[W_OUT], d, r, v0, M0);
+            store_msg<DC>(c, p, w[W_OUT], d, r, v0, M0);
     } break;
     case OP_NOISE: {
         const bool wp = fl & F_IN0_WP;
         ok = load_msg<DC>(c, p, w[W_IN0], wp, wp, d, r, v0, M0);
-        load_noise(c, p, w, d, r, !wp, M1);
+        load_noise<DC>(c, p, w, d, r, !wp, M1);
         if (!wp) {
             add_mat(c, M0, M1, d, 1.0);
             w_sync();
-            store_msg(c, p, w[W_OUT], d, r, v0, M0);
+            store_msg<DC>(c, p, w[W_OUT], d, r, v0, M0);
         } else {   // Λ' = Λ (Λ + W)⁻¹ W, ξ' = W (Λ + W)⁻¹ ξ
             each(c, d, d, [&](int i, int j) { wlds[M2 + i * LD + j] = wlds[M0 + i * LD + j] + wlds[M1 + i * LD + j]; });
             w_sync();
@@ -446,28 +656,28 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
             matvec(c, v2, M1, LD, 1, v1, d, d);
             matmul<DC>(c, M3, M2, false, M1, false, d, d, d);   // (Λ + W)⁻¹ W
             matmul<DC>(c, M2, M0, false, M3, false, d, d, d);   // Λ (Λ + W)⁻¹ W
-            store_msg(c, p, w[W_OUT], d, r, v2, M2);
+            store_msg<DC>(c, p, w[W_OUT], d, r, v2, M2);
         }
     } break;
     case OP_MUL_OUT: {
         const int d1 = w[W_D1];
         ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, false, d1, r, v0, M0);
-        l_cmat(c, M1, p.cpool + w[W_C0], d, d1);
+        l_cmat<DC>(c, M1, p.cpool + w[W_C0], d, d1);
         w_sync();
         matvec(c, v1, M1, LD, 1, v0, d, d1);
         matmul<DC>(c, M2, M1, false, M0, false, d, d1, d1);   // A V
         matmul<DC>(c, M3, M2, false, M1, true, d, d1, d);     // A V Aᵀ
-        store_msg(c, p, w[W_OUT], d, r, v1, M3);
+        store_msg<DC>(c, p, w[W_OUT], d, r, v1, M3);
     } break;
     case OP_MUL_IN: {
         const int d1 = w[W_D1];
         ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
-        l_cmat(c, M1, p.cpool + w[W_C0], d, d1);
+        l_cmat<DC>(c, M1, p.cpool + w[W_C0], d, d1);
         w_sync();
         matvec(c, v1, M1, 1, LD, v0, d1, d);              // Aᵀ ξ
         matmul<DC>(c, M2, M1, true, M0, false, d1, d, d);     // Aᵀ Λ
         matmul<DC>(c, M3, M2, false, M1, false, d1, d, d1);   // Aᵀ Λ A
-        store_msg(c, p, w[W_OUT], d1, r, v1, M3);
+        store_msg<DC>(c, p, w[W_OUT], d1, r, v1, M3);
     } break;
     case OP_ADD_OUT:
     case OP_ADD_IN: {
@@ -484,7 +694,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
             add_vec(c, v0, v1, d, -1.0);
             matmul<DC>(c, M3, M2, false, M1, false, d, d, d);   // (Λo + W2)⁻¹ W2
             matmul<DC>(c, M2, M0, false, M3, false, d, d, d);   // Λo (Λo + W2)⁻¹ W2
-            store_msg(c, p, w[W_OUT], d, r, v0, M2);
+            store_msg<DC>(c, p, w[W_OUT], d, r, v0, M2);
             break;
         }
         ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, false, d, r, v0, M0);
@@ -492,7 +702,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         add_vec(c, v0, v1, d, op == OP_ADD_OUT ? 1.0 : -1.0);
         add_mat(c, M0, M1, d, 1.0);
         w_sync();
-        store_msg(c, p, w[W_OUT], d, r, v0, M0);
+        store_msg<DC>(c, p, w[W_OUT], d, r, v0, M0);
     } break;
     case OP_SHIFT: {
         const bool wp = fl & F_IN0_WP;
@@ -505,7 +715,7 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         } else
             add_vec(c, v0, v1, d, sg);
         w_sync();
-        store_msg(c, p, w[W_OUT], d, r, v0, M0);
+        store_msg<DC>(c, p, w[W_OUT], d, r, v0, M0);
     } break;
     case OP_PRODUCT:
     case OP_MARGINAL: {
@@ -521,13 +731,13 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
             w_sync();
         }
         if (op == OP_PRODUCT) {
-            store_msg(c, p, w[W_OUT], d, r, v0, M0);
+            store_msg<DC>(c, p, w[W_OUT], d, r, v0, M0);
         } else {
             double ld;
             ok = spd_inv<DC>(c, M0, d, ld) && ok;
             matvec(c, v2, M0, LD, 1, v0, d, d);
             s_vec(c, p.marg, w[W_OUT], d, p.es, r * p.rs_marg, v2);
-            s_sym(c, p.marg, w[W_OUT] + d, d, p.es, r * p.rs_marg, M0);
+            s_sym<DC>(c, p.marg, w[W_OUT] + d, d, p.es, r * p.rs_marg, M0);
             if (c.lane == 0) p.marg[(w[W_OUT] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg] = -ld;
         }
     } break;
@@ -556,7 +766,7 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
             zero_mat(c, M1, d);
             for (int i = c.lane; i < d; i += WL) wlds[v1 + i] = 0.0;
         }
-        const double el = load_noise(c, p, w, d, r, false, M2);
+        const double el = load_noise<DC>(c, p, w, d, r, false, M2);
         add_mat(c, M0, M2, d, 1.0);
         add_mat(c, M1, M2, d, 1.0);
         w_sync();
@@ -588,18 +798,18 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         double term = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
         if (fl & F_STAT) s_full(c, p.stat, w[W_C1], d, p.es, r * p.rs_stat, M0, 1.0);
         else {
-            load_noise(c, p, w, d, r, false, M2);
+            load_noise<DC>(c, p, w, d, r, false, M2);
             term += 0.5 * (d * T_LOG2PI - el + trace_prod(c, M2, M0, d));
         }
         if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = term;
     } break;
     case OP_FE_NOISE1:
     case OP_FE_NOISE0: {
-        const double el = load_noise(c, p, w, d, r, false, M1);
+        const double el = load_noise<DC>(c, p, w, d, r, false, M1);
         double H = 0.0;
         if (op == OP_FE_NOISE1) {
             l_vec(c, v0, p.marg, w[W_IN0], d, p.es, r * p.rs_marg);
-            l_sym(c, M0, p.marg, w[W_IN0] + d, d, p.es, r * p.rs_marg);
+            l_sym<DC>(c, M0, p.marg, w[W_IN0] + d, d, p.es, r * p.rs_marg);
             H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg]);
             load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v1);
         } else {
@@ -677,11 +887,11 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
             p.prec[(long long)ps * p.es + r * p.rs_prec] = nu;
             p.prec[(long long)(ps + 1 + tri + 2 * d * d) * p.es + r * p.rs_prec] = elw;
         }
-        s_sym(c, p.prec, ps + 1, d, p.es, r * p.rs_prec, M3);
+        s_sym<DC>(c, p.prec, ps + 1, d, p.es, r * p.rs_prec, M3);
         s_full(c, p.prec, ps + 1 + tri, d, p.es, r * p.rs_prec, M3, nu);
         s_full(c, p.prec, ps + 1 + tri + d * d, d, p.es, r * p.rs_prec, M2, 1.0 / nu);
         if (p.want_fe) {
-            l_cmat(c, M0, cp + 1, d, d);
+            l_cmat<DC>(c, M0, cp + 1, d, d);
             w_sync();
             double F = 0.5 * ((double)n * (d * T_LOG2PI - elw) + nu * trace_prod(c, M3, M1, d));
             F += -(0.5 * (nu0 - d - 1.0) * elw - 0.5 * nu * trace_prod(c, M0, M3, d) - 0.5 * nu0 * d * T_LOG2 - 0.5 * nu0 * ldS0 - t_mvlgamma(0.5 * nu0, d));
@@ -706,7 +916,7 @@ __device__ __forceinline__ void eval_op(const Ctx& c, const TreeParams& p, const
 // wavefront that loads a message read 64 consecutive doubles — with the replica-fastest layout of the register kernels (es = RS, rs = 1; still what
 // rxhip_rule_eval's one-node schedules use) every lane touched a 128-byte line of its own and 15/16 of the HBM traffic was other replicas' data
 template <int PHASE, int DC>
-__global__ void __launch_bounds__(64, DC <= 16 ? 2 : 1) k_wave_ops(TreeParams p, int op0, int op1, int dmax) {
+__global__ void __launch_bounds__(WL, DC <= 16 ? 2 : 1) k_wave_ops(TreeParams p, int op0, int op1, int dmax) {
     const Ctx c = make_ctx(dmax);
     const long long total = (long long)(op1 - op0) * p.R;
     for (long long it = blockIdx.x; it < total; it += gridDim.x) {
@@ -717,7 +927,7 @@ __global__ void __launch_bounds__(64, DC <= 16 ? 2 : 1) k_wave_ops(TreeParams p,
 }
 // a wavefront owns a replica and walks the ops of the range in order (every op's inputs were written by this wavefront or before the launch)
 template <int PHASE, int DC>
-__global__ void __launch_bounds__(64, DC <= 16 ? 2 : 1) k_wave_walk(TreeParams p, int op0, int op1, int dmax) {
+__global__ void __launch_bounds__(WL, DC <= 16 ? 2 : 1) k_wave_walk(TreeParams p, int op0, int op1, int dmax) {
     const Ctx c = make_ctx(dmax);
     for (long long r = blockIdx.x; r < p.R; r += gridDim.x)
         for (int o = op0; o < op1; ++o) {

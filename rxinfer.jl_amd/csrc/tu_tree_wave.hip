@@ -20,12 +20,12 @@ hipError_t prepare(int dmax) {
     return hipSuccess;
 }
 void ops(int phase, const TreeParams& p, int o0, int o1, int dmax, unsigned blocks, hipStream_t stream) {
-    if (phase == 0) hipLaunchKernelGGL((k_wave_ops<0, DC>), dim3(blocks), dim3(64), lds_bytes(dmax), stream, p, o0, o1, dmax);
-    else hipLaunchKernelGGL((k_wave_ops<1, DC>), dim3(blocks), dim3(64), lds_bytes(dmax), stream, p, o0, o1, dmax);
+    if (phase == 0) hipLaunchKernelGGL((k_wave_ops<0, DC>), dim3(blocks), dim3(WL), lds_bytes(dmax), stream, p, o0, o1, dmax);
+    else hipLaunchKernelGGL((k_wave_ops<1, DC>), dim3(blocks), dim3(WL), lds_bytes(dmax), stream, p, o0, o1, dmax);
 }
 void walk(int phase, const TreeParams& p, int o0, int o1, int dmax, unsigned blocks, hipStream_t stream) {
-    if (phase == 0) hipLaunchKernelGGL((k_wave_walk<0, DC>), dim3(blocks), dim3(64), lds_bytes(dmax), stream, p, o0, o1, dmax);
-    else hipLaunchKernelGGL((k_wave_walk<1, DC>), dim3(blocks), dim3(64), lds_bytes(dmax), stream, p, o0, o1, dmax);
+    if (phase == 0) hipLaunchKernelGGL((k_wave_walk<0, DC>), dim3(blocks), dim3(WL), lds_bytes(dmax), stream, p, o0, o1, dmax);
+    else hipLaunchKernelGGL((k_wave_walk<1, DC>), dim3(blocks), dim3(WL), lds_bytes(dmax), stream, p, o0, o1, dmax);
 }
 const WaveVtbl VT = {prepare, ops, walk};
 }  // namespace
