@@ -863,9 +863,9 @@ __device__ __forceinline__ void eval_op(const TreeParams& p, const int* __restri
     else eval_fe<N, true>(p, w, r);
 }
 #ifndef RXHIP_FE_WAVES
-#define RXHIP_FE_WAVES 3      // wavefronts per SIMD the light Bethe-phase instance is compiled for (168 VGPRs; measured at 65 536 replicas: 2 → 1.19 / 1.64 ms for the
-                              // plain / two-branch chain, 3 → 1.12 / 1.49, 4 → 1.74 / 2.09 with 220 bytes of scratch; the strand kernel at 3: 2.35 → 2.78 ms, it spills:
-                              // profiles/r06/tree_occupancy.txt.  A/B: make variants/… EXTRA=-DRXHIP_FE_WAVES=…)
+#define RXHIP_FE_WAVES 2      // wavefronts per SIMD the light Bethe-phase instance is compiled for.  Measured at 65 536 replicas (plain / two-branch chain, Bethe phase):
+                              // 2 → 1.12 / 1.44 ms, 3 → 1.31 / 1.71 (96 bytes of scratch), 4 → 1.74 / 2.09 (220 bytes); the strand kernel at 3 spills too
+                              // (2.35 → 2.78 ms): profiles/r06/tree_occupancy.txt.  A/B: make variants/… EXTRA=-DRXHIP_FE_WAVES=…
 #endif
 #ifndef RXHIP_STRAND_WAVES
 #define RXHIP_STRAND_WAVES 2  // … the strand kernel
