@@ -88,6 +88,7 @@ class TreeGraph:
             raise ValueError("not an rxhip-graph-1 dump")
         self.vars = dump["variables"]
         self.factors = [(f["type"], [int(v) for _, v in f["interfaces"]]) for f in dump["factors"]]
+        self.clusters = [f.get("clusters") for f in dump["factors"]]   # the node's factorisation of q (VariationalConstraintsFactorizationIndicesKey), None: the default
         nv = len(self.vars)
         self.dim = [int(v["rows"]) for v in self.vars]
         self.kind = [v["kind"] for v in self.vars]
@@ -112,7 +113,25 @@ class TreeGraph:
         for fi, (t, ifs) in enumerate(self.factors):
             for k, v in enumerate(ifs):
                 self.nbrs[v].append((fi, k))
+        # Gaussian nodes the constraints run under q(out) q(μ): mean field between the two Gaussian interfaces
+        self.mf = [t in GAUSS_COV + GAUSS_PREC and cl is not None and self.gauss[ifs[0]] and self.gauss[ifs[1]] and cl[0] != cl[1]
+                   for (t, ifs), cl in zip(self.factors, self.clusters)]
         self._check_supported()
+
+    def init_gauss(self, v):
+        """the `@initialization` marginal of a Gaussian variable as (mean, covariance)"""
+        ini = self.vars[v].get("init")
+        d = self.dim[v]
+        if ini is not None and ini["family"] in ("normal", "mvnormal"):
+            p = np.asarray(ini["params"], float)
+            return p[:d].copy(), p[d:d + d * d].reshape(d, d).copy()
+        # the anonymous output of `A * x` cannot be named in an @initialization block: the image of its input's initial marginal
+        for t, ifs in self.factors:
+            if t == "*" and ifs[0] == v and self.vars[ifs[2]].get("init") is not None:
+                m, V = self.init_gauss(ifs[2])
+                A = np.atleast_2d(self.const(ifs[1])).astype(float).reshape(d, self.dim[ifs[2]])
+                return A @ m, A @ V @ A.T
+        raise ValueError(f"variable {v} sits on a mean-field Gaussian node and has no Normal / MvNormal @initialization marginal")
 
     def _check_supported(self):
         for t, ifs in self.factors:
@@ -173,6 +192,16 @@ def infer(dump, data, iterations=1, free_energy=True):
         return np.atleast_1d(np.asarray(data[v], float))
 
     qW = {v: g.init_q(v) if g.vars[v].get("init") else g.prior_q(v) for v in g.prec_prior}
+    # Mean field between the Gaussian interfaces of a node (q(out) q(μ)): the rule toward one interface reads the MARGINAL of the other —
+    # MvNormalMeanCovariance(:out)(q_μ, q_Σ) = N(mean(q_μ), Σ), (:μ) alike — so the marginals of those variables are state, started from the @initialization
+    # marginals.  Update order (ASSUMED — the reference's reactive order is not reproducible without it): every rule of an iteration reads the marginals
+    # of the PREVIOUS iteration, then all marginals are replaced.  The fixed point does not depend on the order: tests/test_tree_oracle.py holds it to the
+    # closed form of Gaussian mean field (exact means, blocks of the joint precision).
+    qx = {}
+    for fi, (t, ifs) in enumerate(g.factors):
+        if g.mf[fi]:
+            for v in ifs[:2]:
+                qx[v] = g.init_gauss(v)
     fe_hist = []
     out = None
     for _ in range(max(1, int(iterations))):
@@ -231,7 +260,9 @@ def infer(dump, data, iterations=1, free_energy=True):
             if t in GAUSS_COV or t in GAUSS_PREC:
                 other = ifs[1 - k]
                 Sigma, W = noise_of(fi)
-                if g.gauss[other]:
+                if g.mf[fi]:
+                    res = Msg("mv", qx[other][0], Sigma)
+                elif g.gauss[other]:
                     m = msg_v2f(other, fi, 1 - k)
                     res = None if m is None else additive(m, Sigma, W)   # an unobserved leaf on the other side: nothing to pass on
                 else:
@@ -289,7 +320,7 @@ def infer(dump, data, iterations=1, free_energy=True):
         for v in [v for v in range(nv) if v not in det_outs] + [v for v in range(nv) if v in det_outs]:
             if not g.gauss[v]:
                 continue
-            counters["on"] = v not in det_outs
+            counters["on"] = v not in det_outs or v in qx   # (a mean-field rule reads this marginal: it is computed whoever asks)
             ins = [m for m in (msg_f2v(fi, k) for fi, k in g.nbrs[v]) if m is not None]
             if not ins:
                 raise ValueError(f"variable {v} receives no message")
@@ -301,7 +332,7 @@ def infer(dump, data, iterations=1, free_energy=True):
             V = _sym(np.linalg.inv(L))
             mean[v], cov[v] = V @ xi, V
             qinfo[v] = (xi, L)
-            counters["marginals"] += counters["on"]
+            counters["marginals"] += counters["on"] and v not in det_outs
         counters["on"] = False
 
         # ---- node-local joints of the Gaussian nodes with two random interfaces; residual second moments of every Gaussian node ----
@@ -311,6 +342,9 @@ def infer(dump, data, iterations=1, free_energy=True):
             o, mu = ifs[0], ifs[1]
             Sigma, W = noise_of(fi)
             d = g.dim[o]
+            if g.mf[fi]:   # E[rrᵀ] under q(out) q(μ); the node's share of the entropies: both clusters
+                r = mean[o] - mean[mu]
+                return cov[o] + cov[mu] + np.outer(r, r), _entropy(cov[o]) + _entropy(cov[mu]), None
             if g.gauss[o] and g.gauss[mu]:
                 xo, Lo = wp0(msg_v2f(o, fi, 0), d)
                 xm, Lm = wp0(msg_v2f(mu, fi, 1), d)
@@ -392,6 +426,7 @@ def infer(dump, data, iterations=1, free_energy=True):
                     F += (len(g.nbrs[v]) - 1) * _entropy(cov[v])
             fe_hist.append(float(F))
         qW = qnew
+        qx = {v: (mean[v].copy(), cov[v].copy()) for v in qx}
         counters.pop("on")
         out = dict(mean=mean, cov=cov, joints={fi: m[2] for fi, m in moments.items() if m[2] is not None}, counters=counters)
     out["fe"] = fe_hist

@@ -109,6 +109,8 @@ struct Program {
     long long io_bytes = 0;                     // what has to move whatever the schedule: the data in, the posteriors of the named variables out
     long long fe_bytes = 0;                     // the second phase's reads and writes per replica
     int longest_strand = 0;
+    bool has_mf = false;                // some Gaussian node runs under q(out) q(μ): the marginals of its interfaces are STATE (start: the @initialization marginals)
+    std::vector<double> marg_init;      // [marg_doubles] when has_mf
     bool fe_heavy = false;   // the second phase holds OP_FE_ADD2 or OP_PREC_UPDATE ops (else the light kernel instance runs it)
     int n_push = 0, lazy_level = -1;   // marginals stored as images of other marginals (OP_MARG_PUSH): a level of their own behind everything a run executes, launched on demand
     std::vector<char> is_push;         // per variable
@@ -121,6 +123,7 @@ struct Compiler {
     std::vector<int64_t> iptr;          // CSR of factor interfaces
     const int64_t* ifv;
     std::vector<int> nclass;
+    std::vector<char> mf;   // per factor: a Gaussian node the model's constraints run under q(out) q(μ) — mean field between its two Gaussian interfaces
     // edges: (factor, interface) with a Gaussian variable
     struct Edge { int f, k, v; };
     std::vector<Edge> edges;
@@ -218,7 +221,7 @@ struct Compiler {
         }
         // the factorisation the model's constraints ask of every node against the one this schedule implements (q(out, μ) q(W) on Gaussian nodes, joint
         // deterministic nodes): a mismatch is refused with the node named — never answered with the other variational family's posterior
-        if (rxhip_lower::check_factorisation(g, nullptr)) fail(RXHIP_ERR_UNSUPPORTED, "%s", rxhip_lower::last_error().c_str());
+        if (rxhip_lower::check_factorisation(g, &mf)) fail(RXHIP_ERR_UNSUPPORTED, "%s", rxhip_lower::last_error().c_str());
         // precision variables
         for (int64_t f = 0; f < nf; ++f)
             if (nclass[f] == NC_PRIOR) {
@@ -272,6 +275,14 @@ struct Compiler {
             }
         }
         if (dmx > wave::DMAX_WAVE) fail(RXHIP_ERR_UNSUPPORTED, "the node-array executor runs dimensions <= %d (this graph: %d)", wave::DMAX_WAVE, dmx);
+        // q(out) q(μ) means something only where both interfaces are random Gaussian variables (a clamped one is a cluster of its own anyway)
+        for (int64_t f = 0; f < nf; ++f) {
+            mf[f] = mf[f] && nclass[f] == NC_NOISE && P.vclass[iface((int)f, 0)] == VC_GAUSS && P.vclass[iface((int)f, 1)] == VC_GAUSS;
+            P.has_mf = P.has_mf || mf[f];
+            if (mf[f] && dmx > 8)
+                fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: mean field between the Gaussian interfaces of a node (q(out) q(μ)) runs on the register kernels only: dimensions <= 8 (this graph: %d)",
+                     (long long)f, dmx);
+        }
         // <= 8: the register instances (lane per op and replica); above: the graph's own maximum, staged in LDS by a wavefront per op and replica
         P.dmax = dmx <= 1 ? 1 : dmx <= 2 ? 2 : dmx <= 4 ? 4 : dmx <= 8 ? 8 : dmx;
     }
@@ -279,7 +290,7 @@ struct Compiler {
     void build_edges() {
         var_edges.assign(nv, {});
         fac_edges.assign(nf, std::vector<int>(3, -1));
-        std::vector<int> uf(nv + nf);
+        std::vector<int> uf(nv + 2 * nf);   // (a node under q(out) q(μ) is two leaf factors as far as cycles go: its interfaces do not exchange messages)
         std::iota(uf.begin(), uf.end(), 0);
         auto find = [&](int x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
         for (int64_t f = 0; f < nf; ++f) {
@@ -289,7 +300,7 @@ struct Compiler {
                 if (k == 2 && nclass[f] == NC_NOISE) continue;
                 const int v = (int)iface((int)f, k);
                 if (P.vclass[v] != VC_GAUSS) continue;
-                const int ra = find(v), rb = find((int)(nv + f));
+                const int ra = find(v), rb = find((int)(nv + f + ((mf[f] && k == 1) ? nf : 0)));
                 if (ra == rb) fail(RXHIP_ERR_UNSUPPORTED, "the Gaussian variables do not form a tree (a cycle through variable %d): loopy graphs have no exact schedule", v);
                 uf[ra] = rb;
                 fac_edges[f][k] = (int)edges.size();
@@ -313,7 +324,7 @@ struct Compiler {
             const int f = ed.f;
             auto other = [&](int k) { return fac_edges[f][k]; };
             if (nclass[f] == NC_NOISE) {
-                if (other(1 - ed.k) >= 0) deps[e].push_back(E + other(1 - ed.k));
+                if (!mf[f] && other(1 - ed.k) >= 0) deps[e].push_back(E + other(1 - ed.k));   // (mean field: the rule reads the other interface's MARGINAL, not its message)
             } else if (nclass[f] == NC_MUL) {
                 const int o = other(ed.k == 0 ? 2 : 0);
                 if (o >= 0) deps[e].push_back(E + o);
@@ -342,6 +353,7 @@ struct Compiler {
         return 2;
     }
     bool factor_uses_v2f(int f) const {
+        if (mf[f]) return false;
         int ng = 0;
         for (int k = 0; k < 3; ++k) ng += fac_edges[f][k] >= 0;
         return ng >= 2;
@@ -624,6 +636,57 @@ struct Compiler {
         }
     }
 
+    // the @initialization marginals of the Gaussian variables a mean-field node reads (InitMarExtraKey, src/model/plugins/initialization_plugin.jl:201-202): the
+    // reference refuses to run such a model without them too
+    void init_marginals() {
+        if (!P.has_mf) return;
+        P.marg_init.assign((size_t)P.marg_doubles, 0.0);
+        std::vector<char> need(nv, 0);
+        for (int64_t f = 0; f < nf; ++f)
+            if (mf[f]) need[iface((int)f, 0)] = need[iface((int)f, 1)] = 1;
+        for (int64_t v = 0; v < nv; ++v) {
+            if (!need[v]) continue;
+            const int d = P.dim[v];
+            auto family = [&](int64_t x) { return (g->var_init_family && g->var_init && g->var_init[x] >= 0) ? g->var_init_family[x] : (int)RXHIP_INIT_NONE; };
+            auto has_init = [&](int64_t x) { return family(x) == RXHIP_INIT_MVNORMAL || (family(x) == RXHIP_INIT_NORMAL && P.dim[x] == 1); };
+            std::vector<double> m((size_t)d), V((size_t)d * d), Vi((size_t)d * d);
+            if (has_init(v)) {
+                const double* q = g->const_pool + g->var_init[v];
+                std::copy(q, q + d, m.begin());
+                std::copy(q + d, q + d + (size_t)d * d, V.begin());
+            } else {
+                // the anonymous output of `A * x` cannot be named in an @initialization block: it starts as the image (A m, A V Aᵀ) of its input's initial marginal
+                int64_t fm = -1;
+                for (int64_t f = 0; f < nf && fm < 0; ++f)
+                    if (nclass[f] == NC_MUL && iface((int)f, 0) == v && has_init(iface((int)f, 2))) fm = f;
+                if (fm < 0)
+                    fail(RXHIP_ERR_BADARG, "variable %lld sits on a Gaussian node under q(out) q(μ) and has no @initialization marginal (Normal / MvNormal): the first iteration has nothing to read",
+                         (long long)v);
+                const int64_t u = iface((int)fm, 2);
+                const int du = P.dim[u];
+                const double *A = cptr((int)iface((int)fm, 1)), *q = g->const_pool + g->var_init[u];
+                for (int i = 0; i < d; ++i) {
+                    double sm = 0.0;
+                    for (int k = 0; k < du; ++k) sm += A[i * du + k] * q[k];
+                    m[i] = sm;
+                    for (int j = 0; j < d; ++j) {
+                        double sv = 0.0;
+                        for (int k = 0; k < du; ++k)
+                            for (int l = 0; l < du; ++l) sv += A[i * du + k] * q[du + k * du + l] * A[j * du + l];
+                        V[(size_t)i * d + j] = sv;
+                    }
+                }
+            }
+            double ld = 0.0;
+            if (!host_chol_inv(d, V.data(), Vi.data(), &ld)) fail(RXHIP_ERR_NOT_POSDEF, "initial marginal of variable %lld is not a proper Gaussian", (long long)v);
+            double* st = P.marg_init.data() + P.marg_off[v];
+            std::copy(m.begin(), m.end(), st);
+            for (int i = 0, k = 0; i < d; ++i)
+                for (int j = 0; j <= i; ++j) st[d + k++] = 0.5 * (V[i * d + j] + V[j * d + i]);
+            st[d + d * (d + 1) / 2] = ld;
+        }
+    }
+
     void emit_all() {
         // derived values first (their own dependency order)
         {
@@ -692,9 +755,10 @@ struct Compiler {
             const int f = ed.f;
             if (nclass[f] == NC_NOISE) {
                 const int oe = fac_edges[f][1 - ed.k];
-                if (oe < 0) {
+                if (oe < 0 || mf[f]) {
                     OpRec& r = emit(lv, OP_LEAF, d);
-                    int bit; r.w[W_VAL] = value_source((int)iface(f, 1 - ed.k), bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
+                    if (mf[f]) { r.w[W_VAL] = P.marg_off[iface(f, 1 - ed.k)]; r.w[W_FLAGS] |= F_VAL_MARG; }   // N(E[other interface], Σ): the mean of last iteration's marginal
+                    else { int bit; r.w[W_VAL] = value_source((int)iface(f, 1 - ed.k), bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT; }
                     if (form[m]) r.w[W_FLAGS] |= F_OUT_WP;
                     noise_params(r, f, d);
                     r.w[W_OUT] = off[m];
@@ -754,6 +818,8 @@ struct Compiler {
                 const int o = (int)iface((int)f, 0), in = (int)iface((int)f, 2);
                 if (P.vclass[o] == VC_GAUSS && P.vclass[in] == VC_GAUSS) { push_from[o] = in; push_fac[o] = (int)f; }
             }
+        for (int64_t f = 0; f < nf; ++f)   // (a mean-field rule reads the STORED marginal of its other interface every iteration: such a variable keeps the message route)
+            if (mf[f]) push_from[iface((int)f, 0)] = push_from[iface((int)f, 1)] = -1;
         for (int64_t v = 0; v < nv; ++v)
             if (push_from[v] >= 0 && push_from[push_from[v]] >= 0) push_from[v] = -2;   // the input is an image itself: this one takes the message route
         for (int64_t v = 0; v < nv; ++v)
@@ -817,7 +883,13 @@ struct Compiler {
                 const bool ga = P.vclass[a] == VC_GAUSS, gb = P.vclass[b] == VC_GAUSS, rw = P.vclass[c] == VC_PREC;
                 OpRec& r = emit(LF, ga && gb ? OP_FE_NOISE2 : (ga || gb) ? OP_FE_NOISE1 : OP_FE_NOISE0, d);
                 noise_params(r, (int)f, d);
-                if (ga && gb && P.dmax <= 8) {
+                if (mf[f]) {   // q(out) q(μ): the average energy from the two marginals; the clusters' entropies go with the variables' terms
+                    r.w[W_OP] = OP_FE_NOISE_MF;
+                    r.w[W_VAL] = P.marg_off[a];
+                    r.w[W_VAL2] = P.marg_off[b];
+                    ent_coef[a] -= 1;
+                    ent_coef[b] -= 1;
+                } else if (ga && gb && P.dmax <= 8) {
                     // register kernels: the joint from ONE inbound message and the two marginals (tree_kernels.hpp OP_FE_NOISE2M); side a = the interface
                     // whose message to the node is stored in precision form (no conversion), the out side when both are
                     const int m0 = E + fac_edges[f][0], m1 = E + fac_edges[f][1];
@@ -1013,6 +1085,7 @@ struct Compiler {
             case OP_FE_NOISE1:
                 P.fe_bytes += 8ll * (msz((w[W_FLAGS] & F_PUSH_A) ? w[W_D1] : d) + 1) + ((w[W_FLAGS] & F_VAL_SLOT) ? 8ll * d : 0) + 8;
                 break;
+            case OP_FE_NOISE_MF: P.fe_bytes += 16ll * (msz(d) + 1) + 8; break;
             case OP_FE_NOISE0: P.fe_bytes += ((w[W_FLAGS] & F_VAL_SLOT) ? 8ll * d : 0) + ((w[W_FLAGS] & F_VAL2_SLOT) ? 8ll * d : 0) + 8; break;
             case OP_FE_ENT: P.fe_bytes += ((w[W_FLAGS] & F_PUSH_A) ? 8ll * (msz(w[W_D1]) + 1) : 8) + 8; break;
             case OP_FE_NOISE2: case OP_FE_ADD2: P.fe_bytes += 8; break;
@@ -1048,9 +1121,12 @@ struct Compiler {
             if (nclass[f] == NC_MUL || nclass[f] == NC_ADD) det_out[iface((int)f, 0)] = 1;
         std::vector<char> dem(2 * E, 0);
         std::vector<int> st;
+        std::vector<char> mf_read(nv, 0);   // a mean-field rule reads the marginal of its other interface: that marginal is computed whoever asks, anonymous or not
+        for (int64_t f = 0; f < nf; ++f)
+            if (mf[f]) mf_read[iface((int)f, 0)] = mf_read[iface((int)f, 1)] = 1;
         for (int64_t v = 0; v < nv; ++v)
-            if (P.vclass[v] == VC_GAUSS && !det_out[v]) {
-                ++P.marginals;
+            if (P.vclass[v] == VC_GAUSS && (!det_out[v] || mf_read[v])) {
+                if (!det_out[v]) ++P.marginals;
                 for (int e : var_edges[v]) if (!null_[e] && !dem[e]) { dem[e] = 1; st.push_back(e); }
             }
         while (!st.empty()) {
@@ -1183,6 +1259,7 @@ struct Compiler {
         analyse();
         allocate();
         init_precision();
+        init_marginals();
         emit_all();
         finish();
         count();
@@ -1200,7 +1277,7 @@ struct Engine {
     long long R = 1, RS = 16;
     int mode = 0, mode_fe = 0, rb = 16, rb_fe = 16, wg = 256;   // schedule of the sweep phase / of the Bethe phase (tree_kernels.hpp: 0 a launch per level, 1 resident levels, 2 walk)
     int *d_ops = nullptr, *d_aux = nullptr, *d_lvl = nullptr, *d_status = nullptr, *d_sops = nullptr, *d_strands = nullptr;
-    double *d_cpool = nullptr, *d_msg = nullptr, *d_marg = nullptr, *d_val = nullptr, *d_prec = nullptr, *d_term = nullptr, *d_stat = nullptr, *d_prec_init = nullptr,
+    double *d_cpool = nullptr, *d_msg = nullptr, *d_marg = nullptr, *d_val = nullptr, *d_prec = nullptr, *d_term = nullptr, *d_stat = nullptr, *d_prec_init = nullptr, *d_marg_init = nullptr,
            *d_fe_rep = nullptr, *d_fe_hist = nullptr, *d_fe_part = nullptr;
     int fe_cap = 0;
     bool have_data = false, ran = false;
@@ -1492,7 +1569,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     if (P.dmax > 8 && (st = wave_attributes(P.dmax, err))) return cleanup(st);
     if ((st = upload(&e->d_sops, P.sops, err)) || (st = upload(&e->d_strands, P.strands, err))) return cleanup(st);
     if ((st = upload(&e->d_ops, P.ops, err)) || (st = upload(&e->d_aux, P.aux, err)) || (st = upload(&e->d_lvl, P.lvl_ptr, err)) || (st = upload(&e->d_cpool, P.cpool, err)) ||
-        (st = upload(&e->d_prec_init, P.prec_init, err)) || (st = zalloc(&e->d_msg, P.msg_doubles * e->RS, err)) || (st = zalloc(&e->d_marg, P.marg_doubles * e->RS, err)) ||
+        (st = upload(&e->d_prec_init, P.prec_init, err)) || (st = upload(&e->d_marg_init, P.marg_init, err)) || (st = zalloc(&e->d_msg, P.msg_doubles * e->RS, err)) || (st = zalloc(&e->d_marg, P.marg_doubles * e->RS, err)) ||
         (st = zalloc(&e->d_val, P.val_doubles * e->RS, err)) || (st = zalloc(&e->d_prec, P.prec_doubles * e->RS, err)) || (st = zalloc(&e->d_term, P.term_slots * e->RS, err)) ||
         (st = zalloc(&e->d_stat, P.stat_doubles * e->RS, err)) || (st = zalloc(&e->d_fe_rep, e->RS, err)) || (st = zalloc(&e->d_fe_part, (e->R + FE_CHUNK - 1) / FE_CHUNK, err)))
         return cleanup(st);
@@ -1529,7 +1606,7 @@ void destroy(Engine* e) {
     DevScope ds(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     for (void* q : {(void*)e->d_sops, (void*)e->d_strands, (void*)e->d_ops, (void*)e->d_aux, (void*)e->d_lvl, (void*)e->d_status, (void*)e->d_cpool, (void*)e->d_msg, (void*)e->d_marg, (void*)e->d_val, (void*)e->d_prec,
-                    (void*)e->d_term, (void*)e->d_stat, (void*)e->d_prec_init, (void*)e->d_fe_rep, (void*)e->d_fe_hist, (void*)e->d_fe_part})
+                    (void*)e->d_term, (void*)e->d_stat, (void*)e->d_prec_init, (void*)e->d_marg_init, (void*)e->d_fe_rep, (void*)e->d_fe_hist, (void*)e->d_fe_part})
         if (q) (void)hipFree(q);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -1608,6 +1685,11 @@ rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err) {
         const long long total = P.prec_doubles * e->RS;
         hipLaunchKernelGGL(k_tree_broadcast, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, e->stream, e->d_prec, (const double*)e->d_prec_init,
                            (long long)P.prec_doubles, e->RS, e->elem_fast ? 1 : 0);
+    }
+    if (P.has_mf && !(e->cont && e->ran)) {   // the marginals the mean-field rules read in the first iteration
+        const long long total = P.marg_doubles * e->RS;
+        hipLaunchKernelGGL(k_tree_broadcast, dim3((unsigned)std::min<long long>((total + 255) / 256, 4096)), dim3(256), 0, e->stream, e->d_marg, (const double*)e->d_marg_init,
+                           (long long)P.marg_doubles, e->RS, e->elem_fast ? 1 : 0);
     }
     const TreeParams p = params_of(e, want_fe);
     // without the free energy on a graph without precision variables the sweep ends with the marginals

@@ -40,7 +40,8 @@ enum : int {
     OP_SUM_TERMS = 17,   // fixed-order partial sum of terms
     OP_PREC_UPDATE = 18, // q(W) ← Wishart(ν0 + n, (S0⁻¹ + Σ E[rrᵀ])⁻¹), its share of the Bethe sum
     OP_FE_NOISE2M = 19,  // OP_FE_NOISE2 from ONE inbound message and the two variables' marginals (register kernels): one inverse instead of three
-    OP_MARG_PUSH = 20    // marginal of the output of `A * x` as the image of x's marginal: (A m, A V Aᵀ, log|A V Aᵀ|) — second phase, register kernels
+    OP_MARG_PUSH = 20,   // marginal of the output of `A * x` as the image of x's marginal: (A m, A V Aᵀ, log|A V Aᵀ|) — second phase, register kernels
+    OP_FE_NOISE_MF = 21  // average energy of a Gaussian node under q(out) q(μ) (mean field between its Gaussian interfaces): E[rrᵀ] = V_out + V_μ + (m_out − m_μ)(…)ᵀ
 };
 constexpr int OP_WORDS = 16;
 // word indices of an op descriptor
@@ -56,7 +57,8 @@ enum : int {
     F_NO_STORE = 512,    // strand schedule: the only reader of this op's message is the next op of the strand (it takes it from registers)
     F_PUSH_A = 1024,     // Bethe terms: the marginal named by W_VAL (FE_NOISE2M side a) / W_IN0 (FE_NOISE1, FE_ENT) is the IMAGE of the stored one under a constant matrix
     F_PUSH_B = 2048,     // … the marginal named by W_VAL2 (FE_NOISE2M side b)
-    F_FOLD_ENT = 4096    // FE_NOISE2M / FE_NOISE1: W_OUT · H[q(v)] of the variable whose log|V| the op has at hand (side b / the random interface) is part of this term
+    F_FOLD_ENT = 4096,   // FE_NOISE2M / FE_NOISE1: W_OUT · H[q(v)] of the variable whose log|V| the op has at hand (side b / the random interface) is part of this term
+    F_VAL_MARG = 8192    // OP_LEAF: the value is the MEAN of the marginal slot W_VAL — the rule of a Gaussian node under q(out) q(μ): N(E[μ], Σ) toward out, N(E[out], Σ) toward μ
 };
 // strand schedule: an input offset that names the message the previous op of the lane's strand left in registers
 constexpr int OFF_REG = -2;
@@ -448,7 +450,8 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
     } break;
     case OP_LEAF: {
         double v[N], Sg[N][N], Wm[N][N], el;
-        load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, v);
+        if (fl & F_VAL_MARG) ld_vec<N>(p.marg, w[W_VAL], d, p.RS, r, v);   // (the marginal of the PREVIOUS iteration: every marginal op of the sweep comes after every leaf)
+        else load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, v);
         const bool wp = fl & F_OUT_WP;
         load_noise<N>(p, w, d, r, !wp, wp, Sg, Wm, el);
         if (wp) {
@@ -721,6 +724,23 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         if (fl & F_FOLD_ENT) term += (double)w[W_OUT] * 0.5 * (d * (T_LOG2PI + 1.0) + ldVb);   // the side-b variable's own Bethe entropy term, folded in (its log|V| is at hand)
         if (fl & F_STAT) st_full<N>(p.stat, w[W_C1], d, p.RS, r, E);
         else term += 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
+        p.term[(long long)w[W_TERM] * p.RS + r] = term;
+    } break;
+    case OP_FE_NOISE_MF: {
+        // @average_energy of the Gaussian node with both marginals (docs/src/manuals/inference/create-node.md:200-232 for the macro surface): U = ½[d log 2π −
+        // (E) log|W| + tr(W E[(out − μ)(out − μ)ᵀ])], E[rrᵀ] = V_out + V_μ + (m_out − m_μ)(m_out − m_μ)ᵀ; the clusters' entropies −H[q(out)] − H[q(μ)] are booked
+        // with the variables' own terms (OP_FE_ENT coefficients).  Random precision: E[rrᵀ] goes to the statistics of q(W).
+        double Sg[N][N], Wm[N][N], el, ma[N], mb[N], Va[N][N], Vb[N][N], E[N][N], u0, u1;
+        load_noise<N>(p, w, d, r, false, true, Sg, Wm, el);
+        load_marginal<N>(p, w[W_VAL], false, 0, 0, d, r, true, ma, Va, u0);
+        load_marginal<N>(p, w[W_VAL2], false, 0, 0, d, r, true, mb, Vb, u1);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) E[i][j] = Va[i][j] + Vb[i][j] + (ma[i] - mb[i]) * (ma[j] - mb[j]);
+        double term = 0.0;
+        if (fl & F_STAT) st_full<N>(p.stat, w[W_C1], d, p.RS, r, E);
+        else term = 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
         p.term[(long long)w[W_TERM] * p.RS + r] = term;
     } break;
     case OP_FE_NOISE1:

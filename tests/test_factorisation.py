@@ -80,6 +80,17 @@ def test_a_mean_field_chain_is_not_answered_with_the_structured_posterior():
     # the deterministic nodes of a MeanField() model keep their joint: only the Gaussian transitions are named
     first = int(msg.split("factor ")[1].split(" ")[0])
     assert gb.ftype[first] == _lib.NODE_MVNORMAL_MEAN_COV and gb.kind[gb.fiface[first][0]] == gb.kind[gb.fiface[first][1]] == _lib.VARKIND_RANDOM
+    # the executor's compiler: the mean-field rules need the @initialization marginals of the variables they read (the reference refuses too) …
+    with pytest.raises(rxhip.RxHipError) as ei:
+        plan(gb)
+    assert ei.value.status == _lib.ERR_BADARG and "@initialization" in str(ei.value)
+    # … and with them the graph compiles: every transition node is two leaf rules (6T − 3 rule calls still: one per message), no message crosses it
+    gb, ys, named = tg.mean_field_chain(T=6, d=2, dy=2)
+    p_mf, p_bp = plan(gb), plan(tg.mean_field_chain(T=6, d=2, dy=2)[0].bethe())
+    assert p_mf["rule_calls"] == p_bp["rule_calls"] == 6 * 6 - 3 and p_mf["n_levels"] < p_bp["n_levels"]
+    # above 8 dimensions the rules run on the LDS-staged kernels, which do not have the mean-field leaf: refused by name
+    gb, _, _ = tg.mean_field_chain(T=3, d=9, dy=9)
+    refused(lambda: plan(gb), "q(out) q(μ)", "dimensions <= 8")
 
 
 def test_every_family_checks_its_own_factorisation():

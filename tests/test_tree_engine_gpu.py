@@ -443,3 +443,46 @@ def test_strand_schedule_equals_the_walk_on_random_forests(seed, monkeypatch):
     assert np.allclose(res[3][1], res[2][1], rtol=1e-12, atol=1e-10)
     for a, b in zip(res[3][2], res[2][2]):
         assert np.allclose(a[0], b[0], rtol=1e-13) and np.allclose(a[1], b[1], rtol=1e-10)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("kw", [dict(T=7, d=2, dy=2), dict(T=5, d=3, dy=2, branches=2), dict(T=9, d=1, dy=1), dict(T=6, d=4, dy=3, partial=True), dict(T=4, d=6, dy=5)])
+def test_mean_field_between_gaussian_interfaces(kw, mode, monkeypatch):
+    """`constraints = MeanField()` on a Gaussian chain through the boundary's factorisation table (rxhip_graph_desc.factor_cluster): q(out) q(μ) around the
+    transition nodes.  Every iteration's posteriors and free energy against the extended oracle (which is held to the closed-form fixed point on the CPU,
+    tests/test_tree_oracle.py), in every schedule; k runs of one iteration in continue mode are one run of k; rxhip_create takes the graph (the state-space
+    lowering refuses it by name and the executor answers)."""
+    import tree_oracle
+    from rxhip.tree import TreeEngine
+    gb, ys, named = tg.mean_field_chain(**kw)
+    R, its = 3, 6
+    monkeypatch.setenv("RXHIP_TREE_MODE", str(mode))
+    data = tg.random_data(gb, ys, R, 2)
+    gv = sorted(eng_gauss(gb))
+    with TreeEngine(gb, n_replicas=R, force_executor=False) as eng:
+        eng.set_data(ys, data)
+        for it in (1, its):
+            eng.run(it, True)
+            post, fe = eng.marginals(gv), eng.free_energy_per_replica()
+            ref = tree_oracle.infer(gb.to_dump(), tg.data_dict(gb, ys, data[R - 1]), iterations=it)
+            for v in gv:
+                sd = np.sqrt(np.diag(ref["cov"][v]))
+                if np.all(sd < 1e-7):
+                    continue
+                assert np.max(np.abs(post[v][0][R - 1] - ref["mean"][v]) / sd) < 1e-9, (it, v)
+                assert np.max(np.abs(post[v][1][R - 1] - ref["cov"][v]) / np.outer(sd, sd)) < 1e-9, (it, v)
+            assert fe[R - 1] == pytest.approx(ref["fe"][-1], rel=1e-10), it
+        fe_n = eng.free_energy()
+        assert eng.counters()["rule_calls"] == ref["counters"]["rule_calls"] * R * its
+        eng.continue_runs(True)
+        eng.run(1, True)                      # (the first run of a continued sequence starts from the @initialization marginals …)
+        trace = [eng.free_energy()[-1]]
+        for _ in range(its - 1):
+            eng.set_data(ys, data)
+            eng.run(1, True)                  # (… the later ones from where the last one stopped)
+            trace.append(eng.free_energy()[-1])
+        assert np.array_equal(np.asarray(trace), fe_n)
+    # the structured posterior is something else: the boundary hole this closes returned it silently
+    exact = tree_oracle.infer(gb.bethe().to_dump(), tg.data_dict(gb, ys, data[R - 1]))
+    x_last = named["x"][-2]
+    assert np.max(np.abs(exact["cov"][x_last] - ref["cov"][x_last])) > 1e-3 * np.max(np.abs(exact["cov"][x_last]))

@@ -133,3 +133,29 @@ def test_known_mean_precision_model_is_the_conjugate_closed_form(kw):
     qn, qV = ref["q_prec"][named["W"][0]]
     assert qn == pytest.approx(nu, rel=1e-14) and np.allclose(qV, V, rtol=1e-11)
     assert np.allclose(ref["fe"], nle, rtol=1e-12)
+
+
+@pytest.mark.parametrize("kw", [dict(T=5, d=2, dy=2), dict(T=4, d=3, dy=2, branches=2), dict(T=6, d=1, dy=1), dict(T=6, d=2, dy=1, partial=True)])
+def test_mean_field_between_gaussian_interfaces_converges_to_the_closed_form(kw):
+    """`constraints = MeanField()` on a Gaussian chain: q(out) q(μ) around every Gaussian node (factor_cluster of the graph tables = the reference's
+    VariationalConstraintsFactorizationIndicesKey).  The rules read marginals — MvNormalMeanCovariance(:out)(q_μ, q_Σ) = N(mean(q_μ), Σ) — so the posterior
+    is a fixed point of iterations; its closed form is known without any schedule: the exact posterior means and, per cluster of variables that still share a
+    factor of q, the inverse of the cluster's block of the joint precision; the free energy there is E_q[−log p] − Σ H[q_c].  (Mixed graphs too: `partial`.)"""
+    gb, ys, named = tg.mean_field_chain(**kw)
+    data = tg.data_dict(gb, ys, tg.random_data(gb, ys, 1, 3)[0])
+    out = tree_oracle.infer(gb.to_dump(), data, iterations=1500 if kw.get("partial") else 400)   # (the simultaneous update converges linearly: the dy < d mixed chain is the slow one)
+    post, fe = tg.mean_field_fixed_point(gb, data)
+    for v in named["x"]:
+        sd = np.sqrt(np.diag(post[v][1]))
+        assert np.max(np.abs(out["mean"][v] - post[v][0]) / sd) < 1e-9, v
+        assert np.allclose(out["cov"][v], post[v][1], rtol=1e-9, atol=1e-12)
+    assert out["fe"][-1] == pytest.approx(fe, rel=1e-10)
+    # the bound tightens along the iterations (late: monotone) and stays above the evidence of the structured (exact) posterior
+    exact = tree_oracle.infer(gb.bethe().to_dump(), data)["fe"][-1]
+    assert out["fe"][-1] > exact and np.all(np.diff(out["fe"][50:]) <= 1e-9 * abs(fe))
+    # a missing @initialization is an error, as in the reference
+    gb2, ys2, _ = tg.mean_field_chain(**kw)
+    gb2.init_family.clear()
+    gb2.init_off.clear()
+    with pytest.raises(ValueError):
+        tree_oracle.infer(gb2.to_dump(), data, iterations=2)

@@ -401,3 +401,133 @@ def brute_force(gb, data):
             C, c = expr(v)
             post[v] = (C @ mu + c, C @ S @ C.T)
     return post, float(nle)
+
+
+def mean_field_chain(T, d=2, dy=2, seed=8, branches=1, partial=False):
+    """The benchmark chain under `constraints = MeanField()`: every Gaussian node q(out) q(μ) (the deterministic `*` nodes keep their joint, as GraphPPL materialises
+    it), `@initialization q(x) = MvNormal(0, 4 I)` for every state; the anonymous `A * x[t-1]` starts as the image of its input's initial marginal.  `branches`:
+    observation branches per state; `partial`: only every other transition is mean-field (a graph that mixes structured and factorised nodes).
+    Returns (builder, data variables, dict(x=states))."""
+    rng = np.random.default_rng(seed)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    A = 0.9 * q
+    gb = GraphBuilder()
+    x = gb.randomvar(d, name="x[1]")
+    gb.mvnormal_mean_cov(x, gb.constvar(np.zeros(d)), gb.constvar(4.0 * np.eye(d)))
+    xs, ys = [x], []
+    for t in range(T):
+        if t:
+            a = gb.randomvar(d)
+            gb.multiply(a, gb.constvar(A), x)
+            xn = gb.randomvar(d, name=f"x[{t + 1}]")
+            gb.mvnormal_mean_cov(xn, a, gb.constvar(_spd(rng, d, 0.3)))
+            x = xn
+            xs.append(x)
+        for _ in range(branches):
+            b = gb.randomvar(dy)
+            gb.multiply(b, gb.constvar(rng.standard_normal((dy, d))), x)
+            y = gb.datavar(dy)
+            gb.mvnormal_mean_cov(y, b, gb.constvar(_spd(rng, dy)))
+            ys.append(y)
+    gb.mean_field()
+    if partial:   # every other transition back to the structured q(out, μ)
+        n = 0
+        for f, t in enumerate(gb.ftype):
+            o, mu = gb.fiface[f][0], gb.fiface[f][1]
+            if t == _lib.NODE_MVNORMAL_MEAN_COV and gb.kind[o] == gb.kind[mu] == _lib.VARKIND_RANDOM:
+                n += 1
+                if n % 2 == 0:
+                    gb.set_clusters(f, (0, 0, 1))
+    for v in xs:
+        gb.initialize(v, _lib.INIT_MVNORMAL if d > 1 else _lib.INIT_NORMAL, np.concatenate([np.zeros(d), (4.0 * np.eye(d)).ravel()]))
+    return gb, ys, dict(x=xs)
+
+
+def mean_field_fixed_point(gb, data):
+    """The fixed point of Gaussian mean field, in closed form: with the joint density of the BASE variables (those no deterministic node defines) in information
+    form (J, h), the base variables fall into clusters — two of them share one when a node that is NOT under q(out) q(μ) touches both — and the optimum is
+    q_c = N(μ_c, (J_cc)⁻¹) with μ the EXACT posterior mean.  Returns ({var: (mean, cov)} for every random variable, the variational free energy
+    E_q[−log p(x, y)] − Σ_c H[q_c])."""
+    nv = len(gb.kind)
+    K_RANDOM, K_CONST = _lib.VARKIND_RANDOM, _lib.VARKIND_CONST
+    det_out = {ifs[0]: (t, ifs) for t, ifs in zip(gb.ftype, gb.fiface) if t in (_lib.NODE_MULTIPLY, _lib.NODE_ADD)}
+    base = [v for v in range(nv) if gb.kind[v] == K_RANDOM and v not in det_out]
+    off, N = {}, 0
+    for v in base:
+        off[v] = N
+        N += gb.rows[v]
+    aff = {}
+
+    def expr(v):
+        if v in aff:
+            return aff[v]
+        r = gb.rows[v]
+        if gb.kind[v] == K_CONST:
+            e = (np.zeros((r, N)), np.atleast_1d(gb.const_value(v)).astype(float).reshape(r))
+        elif gb.kind[v] != K_RANDOM:
+            e = (np.zeros((r, N)), np.asarray(data[v], float).reshape(r))
+        elif v in det_out:
+            t, ifs = det_out[v]
+            if t == _lib.NODE_MULTIPLY:
+                A = np.atleast_2d(gb.const_value(ifs[1])).astype(float).reshape(r, gb.rows[ifs[2]])
+                C, c = expr(ifs[2])
+                e = (A @ C, A @ c)
+            else:
+                (C1, c1), (C2, c2) = expr(ifs[1]), expr(ifs[2])
+                e = (C1 + C2, c1 + c2)
+        else:
+            C = np.zeros((r, N))
+            C[:, off[v]:off[v] + r] = np.eye(r)
+            e = (C, np.zeros(r))
+        aff[v] = e
+        return e
+
+    def support(v):   # base variables a random variable is a function of
+        C, _ = expr(v)
+        return {b for b in base if np.any(C[:, off[b]:off[b] + gb.rows[b]] != 0.0)}
+
+    parent = {b: b for b in base}
+
+    def find(x):
+        while parent[x] != x:
+            parent[x] = parent[parent[x]]
+            x = parent[x]
+        return x
+
+    J, h, const = np.zeros((N, N)), np.zeros(N), 0.0
+    for f, (t, ifs) in enumerate(zip(gb.ftype, gb.fiface)):
+        if t in (_lib.NODE_MULTIPLY, _lib.NODE_ADD):
+            continue
+        d = gb.rows[ifs[0]]
+        M = np.atleast_2d(gb.const_value(ifs[2])).astype(float).reshape(d, d)
+        W = np.linalg.inv(M) if t in (_lib.NODE_MVNORMAL_MEAN_COV, _lib.NODE_NORMAL_MEAN_VARIANCE) else M
+        (Co, co), (Cm, cm) = expr(ifs[0]), expr(ifs[1])
+        D, e = Co - Cm, co - cm
+        J += D.T @ W @ D
+        h -= D.T @ W @ e
+        const += 0.5 * (d * np.log(2 * np.pi) - np.linalg.slogdet(W)[1] + e @ W @ e)
+        cl = gb.clusters_of(f)
+        sides = [support(ifs[0]) if gb.kind[ifs[0]] == K_RANDOM else set(), support(ifs[1]) if gb.kind[ifs[1]] == K_RANDOM else set()]
+        groups = [sides[0] | sides[1]] if cl[0] == cl[1] else sides   # q(out, μ) joins everything the node touches; q(out) q(μ) each side on its own
+        for grp in groups:
+            grp = sorted(grp)
+            for b in grp[1:]:
+                parent[find(b)] = find(grp[0])
+    mu = np.linalg.solve(J, h)
+    Sq = np.zeros((N, N))
+    ent = 0.0
+    comps = {}
+    for b in base:
+        comps.setdefault(find(b), []).append(b)
+    for members in comps.values():
+        idx = np.concatenate([np.arange(off[b], off[b] + gb.rows[b]) for b in members])
+        S = np.linalg.inv(J[np.ix_(idx, idx)])
+        Sq[np.ix_(idx, idx)] = S
+        ent += 0.5 * (len(idx) * (1.0 + np.log(2 * np.pi)) + np.linalg.slogdet(S)[1])
+    energy = const + 0.5 * (mu @ J @ mu + np.trace(J @ Sq)) - h @ mu
+    post = {}
+    for v in range(nv):
+        if gb.kind[v] == K_RANDOM:
+            C, c = expr(v)
+            post[v] = (C @ mu + c, C @ Sq @ C.T)
+    return post, float(energy - ent)
