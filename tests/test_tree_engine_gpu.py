@@ -474,12 +474,12 @@ def test_mean_field_between_gaussian_interfaces(kw, mode, monkeypatch):
             assert fe[R - 1] == pytest.approx(ref["fe"][-1], rel=1e-10), it
         fe_n = eng.free_energy()
         assert eng.counters()["rule_calls"] == ref["counters"]["rule_calls"] * R * its
+    with TreeEngine(gb, n_replicas=R) as eng:   # the plugin's way: one iteration per call, continued (the engine's first run starts from the @initialization marginals)
         eng.continue_runs(True)
-        eng.run(1, True)                      # (the first run of a continued sequence starts from the @initialization marginals …)
-        trace = [eng.free_energy()[-1]]
-        for _ in range(its - 1):
+        trace = []
+        for _ in range(its):
             eng.set_data(ys, data)
-            eng.run(1, True)                  # (… the later ones from where the last one stopped)
+            eng.run(1, True)
             trace.append(eng.free_energy()[-1])
         assert np.array_equal(np.asarray(trace), fe_n)
     # the structured posterior is something else: the boundary hole this closes returned it silently
