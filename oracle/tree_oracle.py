@@ -176,7 +176,7 @@ class TreeGraph:
 
 def infer(dump, data, iterations=1, free_energy=True):
     """Returns dict(mean={var: m}, cov={var: V}, fe=[per iteration], q_prec={var: (nu, V)}, counters=dict(rule_calls, products, marginals))
-    for ONE replica.  `data`: {variable id: vector}; a NaN vector is not supported here (missing observations are the chain engines')."""
+    for ONE replica.  `data`: {variable id: vector}; a vector holding NaN is a `missing` observation: its node sends nothing and its Bethe terms cancel."""
     g = TreeGraph(dump)
     nv = len(g.vars)
 
@@ -265,8 +265,8 @@ def infer(dump, data, iterations=1, free_energy=True):
                 elif g.gauss[other]:
                     m = msg_v2f(other, fi, 1 - k)
                     res = None if m is None else additive(m, Sigma, W)   # an unobserved leaf on the other side: nothing to pass on
-                else:
-                    res = Msg("mv", value(other), Sigma)
+                else:   # a `missing` observation (NaN) sends nothing
+                    res = None if np.any(np.isnan(value(other))) else Msg("mv", value(other), Sigma)
             elif t == "*":
                 A = np.atleast_2d(g.const(ifs[1])).astype(float)
                 if A.shape != (g.dim[ifs[0]], g.dim[ifs[2]]):
@@ -357,8 +357,12 @@ def infer(dump, data, iterations=1, free_energy=True):
             if g.gauss[o] or g.gauss[mu]:
                 rv, cv = (o, mu) if g.gauss[o] else (mu, o)
                 r = mean[rv] - value(cv)
+                if np.any(np.isnan(r)):   # `missing`: the clamped side becomes a predicted variable — U − H[q(y, x)] + 0·H[q(y)] = −H[q(x)]
+                    return None, _entropy(cov[rv]), None
                 return cov[rv] + np.outer(r, r), _entropy(cov[rv]), None
             r = value(o) - value(mu)
+            if np.any(np.isnan(r)):
+                return None, 0.0, None
             return np.outer(r, r), 0.0, None
 
         # ---- q(W) updates (mean field): Wishart(ν0 + n, (S0⁻¹ + Σ E[rrᵀ])⁻¹) ----
@@ -368,6 +372,8 @@ def infer(dump, data, iterations=1, free_energy=True):
             if t in GAUSS_COV or t in GAUSS_PREC:
                 moments[fi] = node_moments(fi)
                 if ifs[2] in qW:
+                    if moments[fi][0] is None:
+                        raise ValueError("`missing` observations under a random precision are not part of the family")
                     stats[ifs[2]][0] += 1
                     stats[ifs[2]][1] += moments[fi][0]
         qnew = {}
@@ -383,6 +389,9 @@ def infer(dump, data, iterations=1, free_energy=True):
                 if t in GAUSS_COV or t in GAUSS_PREC:
                     d = g.dim[ifs[0]]
                     E, H, _ = moments[fi]
+                    if E is None:
+                        F += -H
+                        continue
                     third = ifs[2]
                     if third in qW:
                         nu, V = qnew[third]

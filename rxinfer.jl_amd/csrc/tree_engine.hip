@@ -490,7 +490,9 @@ struct Compiler {
                 else if (nclass[ed.f] == NC_NOISE) {
                     if (deps[m].empty()) {   // leaf: the form its single consumer wants, precision form otherwise
                         int wf = 2;
-                        if (var_edges[ed.v].size() == 2) {
+                        const int ov = (int)iface(ed.f, 1 - ed.k);
+                        const bool may_miss = g->allow_missing && !mf[ed.f] && (P.vclass[ov] == VC_DATA || P.vclass[ov] == VC_DERIVED);
+                        if (var_edges[ed.v].size() == 2 && !may_miss) {   // (a `missing` observation is the zero of the precision form: such leaves stay in it)
                             const int e2 = var_edges[ed.v][0] == m ? var_edges[ed.v][1] : var_edges[ed.v][0];
                             wf = wanted_form(e2);
                         }
@@ -758,7 +760,14 @@ struct Compiler {
                 if (oe < 0 || mf[f]) {
                     OpRec& r = emit(lv, OP_LEAF, d);
                     if (mf[f]) { r.w[W_VAL] = P.marg_off[iface(f, 1 - ed.k)]; r.w[W_FLAGS] |= F_VAL_MARG; }   // N(E[other interface], Σ): the mean of last iteration's marginal
-                    else { int bit; r.w[W_VAL] = value_source((int)iface(f, 1 - ed.k), bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT; }
+                    else {
+                        int bit; r.w[W_VAL] = value_source((int)iface(f, 1 - ed.k), bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
+                        if (g->allow_missing && P.vclass[iface(f, 1 - ed.k)] != VC_CONST) {
+                            if (P.vclass[iface(f, 2)] == VC_PREC)
+                                fail(RXHIP_ERR_UNSUPPORTED, "factor %d: `missing` observations under a random precision (the count of the q(W) update would depend on the data)", f);
+                            r.w[W_FLAGS] |= F_MAY_MISS;
+                        }
+                    }
                     if (form[m]) r.w[W_FLAGS] |= F_OUT_WP;
                     noise_params(r, f, d);
                     r.w[W_OUT] = off[m];
@@ -904,11 +913,13 @@ struct Compiler {
                     msg_in(r, W_IN0, F_IN0_WP, E + fac_edges[f][0]);
                     msg_in(r, W_IN1, F_IN1_WP, E + fac_edges[f][1]);
                 } else if (ga || gb) {
+                    if (g->allow_missing && P.vclass[ga ? b : a] != VC_CONST) r.w[W_FLAGS] |= F_MAY_MISS;
                     marg_of(r, ga ? a : b, W_IN0, F_PUSH_A, W_IN1, W_D1);
                     r.w[W_OUT] = 0;
                     if (push_from[ga ? a : b] >= 0) fold.push_back({recs.size() - 1, ga ? a : b});
                     int bit; r.w[W_VAL] = value_source(ga ? b : a, bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
                 } else {
+                    if (g->allow_missing && (P.vclass[a] != VC_CONST || P.vclass[b] != VC_CONST)) r.w[W_FLAGS] |= F_MAY_MISS;
                     int bit; r.w[W_VAL] = value_source(a, bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
                     r.w[W_VAL2] = value_source(b, bit); if (bit) r.w[W_FLAGS] |= F_VAL2_SLOT;
                 }
@@ -1282,6 +1293,7 @@ struct Engine {
     int fe_cap = 0;
     bool have_data = false, ran = false;
     bool cont = false;   // rxhip_tree_continue: later runs go on from the q(W) the previous run ended with
+    bool allow_missing = false;   // created with rxhip_graph_desc.allow_missing: NaN in the data is `missing`
     bool elem_fast = false;   // dimensions above 8: a replica's slots contiguous (TreeParams es = 1), so that a wavefront's loads of a message coalesce
     bool push_done = false;   // the image marginals (OP_MARG_PUSH, first level of the second phase) are those of the last sweep
     int last_iterations = 0, last_want_fe = 0;
@@ -1508,6 +1520,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     e->RS = (e->R + 15) / 16 * 16;
     const Program& P = e->prog;
     e->elem_fast = P.dmax > 8;
+    e->allow_missing = g->allow_missing != 0;
     // schedule: deep graphs walk their levels inside a workgroup (one launch per iteration); wide, shallow ones take a launch per level
     const double avg_width = (double)P.n_ops / std::max(1, P.n_levels);
     e->mode = (P.n_levels > 24 && (e->R >= 512 || avg_width * (double)e->R < 16384.0)) ? 1 : 0;
@@ -1652,9 +1665,10 @@ rxhip_status set_data(Engine* e, const int64_t* vars, int64_t n_vars, const doub
     {
         int flag = 0;
         TCHK(hipMemcpy(&flag, e->d_status, sizeof(int), hipMemcpyDeviceToHost));
-        if (flag & 2) {
+        if ((flag & 2) && e->allow_missing) TCHK(hipMemset(e->d_status, 0, sizeof(int)));   // (NaN = `missing`: the leaves and Bethe terms of this engine look for it)
+        else if (flag & 2) {
             TCHK(hipMemset(e->d_status, 0, sizeof(int)));
-            err = "set_data: the data hold NaN or Inf — `missing` observations are outside the node-array executor's family (the state-space engines take them: desc.allow_missing)";
+            err = "set_data: the data hold NaN or Inf — `missing` observations need an engine created with rxhip_graph_desc.allow_missing (the schedule keeps the data leaves in precision form then)";
             return RXHIP_ERR_BADARG;
         }
     }

@@ -58,6 +58,7 @@ enum : int {
     F_PUSH_A = 1024,     // Bethe terms: the marginal named by W_VAL (FE_NOISE2M side a) / W_IN0 (FE_NOISE1, FE_ENT) is the IMAGE of the stored one under a constant matrix
     F_PUSH_B = 2048,     // … the marginal named by W_VAL2 (FE_NOISE2M side b)
     F_FOLD_ENT = 4096,   // FE_NOISE2M / FE_NOISE1: W_OUT · H[q(v)] of the variable whose log|V| the op has at hand (side b / the random interface) is part of this term
+    F_MAY_MISS = 16384,  // OP_LEAF / FE_NOISE1 / FE_NOISE0 on a DATA value of a graph created with allow_missing: NaN (`missing`) → no message / no energy term
     F_VAL_MARG = 8192    // OP_LEAF: the value is the MEAN of the marginal slot W_VAL — the rule of a Gaussian node under q(out) q(μ): N(E[μ], Σ) toward out, N(E[out], Σ) toward μ
 };
 // strand schedule: an input offset that names the message the previous op of the lane's strand left in registers
@@ -457,6 +458,19 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
         if (wp) {
             double xi[N];
             matvec<N>(Wm, v, xi);
+            if (fl & F_MAY_MISS) {   // a `missing` observation sends nothing: the zero of the precision form (the compiler keeps such leaves in it)
+                bool miss = false;
+#pragma unroll
+                for (int i = 0; i < N; ++i) miss = miss || (i < d && v[i] != v[i]);
+                if (miss) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) {
+                        xi[i] = 0.0;
+#pragma unroll
+                        for (int j = 0; j < N; ++j) Wm[i][j] = 0.0;
+                    }
+                }
+            }
             store_msg<N, STRAND>(p, w[W_OUT], d, r, xi, Wm, fl, reg);
         } else
             store_msg<N, STRAND>(p, w[W_OUT], d, r, v, Sg, fl, reg);
@@ -771,8 +785,13 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
                 for (int j = 0; j < N; ++j) E[i][j] = rv[i] * rv[j];
         }
         double term = -H;
+        bool miss = false;   // a `missing` observation: the node's energy and the entropy of the predicted value cancel — what is left is −H of the random interface
+        if (fl & F_MAY_MISS) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) miss = miss || (i < d && rv[i] != rv[i]);
+        }
         if (fl & F_STAT) st_full<N>(p.stat, w[W_C1], d, p.RS, r, E);
-        else term += 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
+        else if (!miss) term += 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
         p.term[(long long)w[W_TERM] * p.RS + r] = term;
     } break;
     case OP_FE_ENT: {

@@ -635,6 +635,16 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         load_noise<DC>(c, p, w, d, r, !wp, M0);
         if (wp) {
             matvec(c, v1, M0, LD, 1, v0, d, d);
+            if (fl & F_MAY_MISS) {   // a `missing` observation (NaN) sends nothing: the zero of the precision form
+                bool miss = false;
+                for (int i = 0; i < d; ++i) miss = miss || (wlds[v0 + i] != wlds[v0 + i]);
+                if (miss) {
+                    w_sync();
+                    zero_mat(c, M0, d);
+                    for (int i = c.lane; i < d; i += WL) wlds[v1 + i] = 0.0;
+                    w_sync();
+                }
+            }
             store_msg<DC>(c, p, w[W_OUT], d, r, v1, M0);
         } else
             store_msg<DC>(c, p, w[W_OUT], d, r, v0, M0);
@@ -819,11 +829,15 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         }
         add_vec(c, v0, v1, d, -1.0);
         w_sync();
+        bool miss = false;   // a `missing` observation: energy and the predicted value's entropy cancel, −H of the random interface stays
+        if (fl & F_MAY_MISS)
+            for (int i = 0; i < d; ++i) miss = miss || (wlds[v0 + i] != wlds[v0 + i]);
         each(c, d, d, [&](int i, int j) { wlds[M0 + i * LD + j] += wlds[v0 + i] * wlds[v0 + j]; });
         w_sync();
         double term = -H;
         if (fl & F_STAT) s_full(c, p.stat, w[W_C1], d, p.es, r * p.rs_stat, M0, 1.0);
-        else term += 0.5 * (d * T_LOG2PI - el + trace_prod(c, M1, M0, d));
+        else if (!miss) term += 0.5 * (d * T_LOG2PI - el + trace_prod(c, M1, M0, d));
+        else (void)trace_prod(c, M1, M0, d);   // (every lane of the item runs the reduction's barriers)
         if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = term;
     } break;
     case OP_FE_ENT: {

@@ -16,10 +16,11 @@ def _c(a):
 class TreeEngine:
     """One compiled graph × n_replicas independent copies (different data, same constants)."""
 
-    def __init__(self, gb, n_replicas=1, device=-1, stream=None, force_executor=True):
-        """gb: GraphBuilder.  force_executor=False goes through rxhip_create (pattern matcher first; raises if a specialised engine took the graph)."""
+    def __init__(self, gb, n_replicas=1, device=-1, stream=None, force_executor=True, allow_missing=False):
+        """gb: GraphBuilder.  force_executor=False goes through rxhip_create (pattern matcher first; raises if a specialised engine took the graph).
+        allow_missing: NaN in the data is a `missing` observation (rxhip_graph_desc.allow_missing): its node sends nothing, its Bethe terms cancel."""
         L = _lib.lib()
-        g, keep = gb.tables(n_replicas=n_replicas)
+        g, keep = gb.tables(n_replicas=n_replicas, allow_missing=allow_missing)
         self._keep = (g, keep)
         self._h = ctypes.c_void_p()
         if force_executor:

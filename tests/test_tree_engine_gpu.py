@@ -302,7 +302,7 @@ def test_known_mean_precision_model_is_the_conjugate_closed_form(kw, R):
 
 
 def test_nan_in_the_data_is_refused_by_name():
-    """`missing` observations are outside the executor's family: a NaN in the data is an error at set_data, not a NaN posterior later"""
+    """an engine that was not created for `missing` observations (rxhip_graph_desc.allow_missing) refuses a NaN in the data at set_data — not a NaN posterior later"""
     import rxhip
     from rxhip import _lib
     from rxhip.tree import TreeEngine
@@ -486,3 +486,34 @@ def test_mean_field_between_gaussian_interfaces(kw, mode, monkeypatch):
     exact = tree_oracle.infer(gb.bethe().to_dump(), tg.data_dict(gb, ys, data[R - 1]))
     x_last = named["x"][-2]
     assert np.max(np.abs(exact["cov"][x_last] - ref["cov"][x_last])) > 1e-3 * np.max(np.abs(exact["cov"][x_last]))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+@pytest.mark.parametrize("builder,kw", [(tg.two_branch_chain, dict(T=9)), (tg.two_branch_chain, dict(T=6, d=4, dy1=4, dy2=3)), (tg.scalar_tree, dict(n_leaves=6)),
+                                        (tg.two_branch_chain, dict(T=5, d=8, dy1=8, dy2=5)), (tg.two_branch_chain, dict(T=4, d=12, dy1=12, dy2=7)),
+                                        (tg.chain_with_prediction, dict(T=8, H=2))])
+def test_missing_observations_anywhere_in_the_data(builder, kw, mode, monkeypatch):
+    """`missing` inside the data of ANY graph of the family (rxhip_graph_desc.allow_missing; the reference: `data = (y = [1.0, missing, 3.0],)`,
+    test/inference/prediction_tests.jl:197-213 on a chain): a NaN observation sends no message and its node's Bethe terms cancel — a different pattern in every
+    replica, in every schedule.  Checked against the oracle, which is checked against brute-force conditioning with those observations dropped
+    (tests/test_tree_oracle.py)."""
+    from rxhip.tree import TreeEngine
+    import tree_oracle
+    gb, ys, _ = builder(**kw)
+    dmx = max(gb.rows[v] for v in range(len(gb.kind)) if gb.kind[v] != 2)
+    if dmx > 8 and mode in (1, 3):
+        pytest.skip("the LDS-staged kernels have the launch-per-level and the walk schedule")
+    R = 4
+    data = tg.random_data(gb, ys, R, 3)
+    rng = np.random.default_rng(5)
+    o = 0
+    for v in ys:                                      # whole observations missing, ≈ 30 %, never the same in two replicas; replica 0 keeps everything
+        for r in range(1, R):
+            if rng.random() < 0.3:
+                data[r, o:o + gb.rows[v]] = np.nan
+        o += gb.rows[v]
+    monkeypatch.setenv("RXHIP_TREE_MODE", str(mode))
+    with TreeEngine(gb, n_replicas=R, allow_missing=True) as eng:
+        eng.set_data(ys, data)
+        eng.run(1, True)
+        _check(gb, ys, eng, data, replicas=(0, 1, R - 1))

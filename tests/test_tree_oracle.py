@@ -159,3 +159,26 @@ def test_mean_field_between_gaussian_interfaces_converges_to_the_closed_form(kw)
     gb2.init_off.clear()
     with pytest.raises(ValueError):
         tree_oracle.infer(gb2.to_dump(), data, iterations=2)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_missing_observations_are_dropped_observations(seed):
+    """a `missing` (NaN) observation sends no message and contributes nothing to the free energy: posterior and −log evidence equal those of brute-force
+    conditioning on the remaining observations (the joint Gaussian with the missing nodes removed)"""
+    gb, ys, nm = tg.two_branch_chain(T=7, d=3, dy1=2, dy2=1, seed=seed)
+    data = tg.data_dict(gb, ys, tg.random_data(gb, ys, 1, seed)[0])
+    rng = np.random.default_rng(seed)
+    gone = [v for v in ys if rng.random() < 0.35] or [ys[1]]
+    with_nan = {v: (np.full_like(x, np.nan) if v in gone else x) for v, x in data.items()}
+    out = tree_oracle.infer(gb.to_dump(), with_nan)
+    # the same model without those observation nodes
+    from rxhip.graph import GraphBuilder
+    keep = [f for f, ifs in enumerate(gb.fiface) if ifs[0] not in gone]
+    gb2 = GraphBuilder.from_dump(gb.to_dump())
+    gb2.ftype = [gb.ftype[f] for f in keep]
+    gb2.fiface = [gb.fiface[f] for f in keep]
+    bf, nle = tg.brute_force(gb2, data)
+    for v in nm["x"]:
+        sd = np.sqrt(np.diag(bf[v][1]))
+        assert np.max(np.abs(out["mean"][v] - bf[v][0]) / sd) < 1e-9 and np.allclose(out["cov"][v], bf[v][1], rtol=1e-9, atol=1e-12)
+    assert out["fe"][-1] == pytest.approx(nle, rel=1e-10)
