@@ -281,8 +281,9 @@ typedef struct {
     const int64_t* var_init;         /* [n_variables] offset of its parameters in const_pool (−1: none) */
     int32_t gh_points;               /* GCVMetadata(GaussHermiteCubature(n)) of the GCV nodes; 0 = 31 */
     int64_t n_observations;          /* streaming (one-step) graphs: observations that will be pushed per replica */
-    int32_t allow_missing;           /* state-space graphs: some data variable holds `missing` (the data is known when the model
-                                        is created, src/inference/batch.jl:252) — as rxhip_lgssm_desc.allow_missing */
+    int32_t allow_missing;           /* some data variable holds `missing` (the data is known when the model is created,
+                                        src/inference/batch.jl:252): state-space graphs — as rxhip_lgssm_desc.allow_missing (the masked schedule);
+                                        graphs of the node-array executor — the data leaves stay in precision form, where NaN is the zero message */
     /* The factorisation of q around every node — what the stock plugin hands to `factornode(fform, interfaces, factorization)` as
      * GraphPPL.VariationalConstraintsFactorizationIndicesKey (src/model/plugins/reactivemp_inference.jl:499-506): NULL, or one cluster id per entry
      * of factor_iface (same indexing, [n_factors][3] or CSR): interfaces of ONE node with equal ids share a factor of q — the reference's
@@ -406,13 +407,22 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  *     Wishart / GammaShapeRate / GammaShapeScale priors with constant parameters
  * whose Gaussian variables form a forest (no cycles; precision variables may touch any number of nodes — the mean-field factorisation cuts those
  * loops; no Gaussian variable at all is a forest too: `P ~ Wishart; y[i] ~ MvNormal(μ = m, Λ = P)` with a known mean,
- * test/models/iid/mv_iid_precision_known_mean_tests.jl), every dimension ≤ 64.  The host compiles the graph into ops sorted by dependency level (csrc/tree_engine.hip); one kernel evaluates
- * (op, replica) items: a launch per level over all nodes of the level, or — deep, narrow graphs — the whole schedule in one launch with workgroup-
- * resident levels, or — large batches — a lane per replica over the whole schedule.  Dimensions ≤ 8: a LANE per item, matrices in registers
- * (csrc/tree_kernels.hpp; the 4×4 instance fits, the 8×8 one spills).  Dimensions 9 … 64: a WAVEFRONT per item, matrices staged in LDS
- * (csrc/tree_wave_kernels.hpp; same op tables and storage; a launch per level, or a wavefront per replica over the whole schedule).  Data variables, derived clamped values (`a + b` of two data variables), unobserved
- * leaves (predictions) are part of the family; `missing` inside the data is not (the chain engines have it): rxhip_tree_set_data refuses NaN / Inf
- * with RXHIP_ERR_BADARG.
+ * test/models/iid/mv_iid_precision_known_mean_tests.jl), every dimension ≤ 64.  Factorisation (rxhip_graph_desc.factor_cluster): a Gaussian node under
+ * q(out, μ) — structured, the default — or, dimensions ≤ 8, under q(out) q(μ) (`constraints = MeanField()`): its rules then read MARGINALS,
+ * MvNormalMeanCovariance(:out)(q_μ, q_Σ) = N(mean(q_μ), Σ), the node cuts the graph (cycles through it are fine), the marginals of its two variables are state
+ * that starts from their `@initialization` marginals (RXHIP_INIT_NORMAL / MVNORMAL; an anonymous `A * x` output starts as the image of x's; none:
+ * RXHIP_ERR_BADARG), every rule of an iteration reads the marginals of the previous one, and the free energy books the average energy with both marginals.
+ * The host compiles the graph into ops sorted by dependency level (csrc/tree_engine.hip); kernels evaluate (op, replica) items.
+ * Dimensions ≤ 8: a LANE per item, matrices in registers (csrc/tree_kernels.hpp), replica-fastest storage; schedules — a launch per level, workgroup-resident
+ * levels, a lane per replica over the whole schedule, and (dimensions ≤ 4: the default) STRANDS: the sweep cut into paths of dependent ops
+ * that a lane walks with the message in registers, a message going to HBM only when somebody outside its strand reads it.  Marginals of `A * x` outputs are
+ * images of x's marginal: the Bethe terms form them on the fly, they are stored when a caller asks.
+ * Dimensions 9 … 64: a WORK ITEM of 1 / 2 / 4 wavefronts (≤ 16 / ≤ 32 / ≤ 64) per (op, replica), matrices staged in LDS, a replica's slots contiguous in HBM
+ * (csrc/tree_wave_kernels.hpp): products on v_mfma_f64_16x16x4_f64, the inverse a 4-pivot block sweep on the matrix cores with the matrix in accumulator
+ * registers; a launch per level, or an item per replica over the whole schedule.
+ * Data variables, derived clamped values (`a + b` of two data variables), unobserved leaves (predictions) are part of the family; so is `missing` anywhere in
+ * the data when the engine is created with rxhip_graph_desc.allow_missing (a NaN observation sends no message, its node's Bethe terms cancel; not under a
+ * random precision: RXHIP_ERR_UNSUPPORTED) — without it rxhip_tree_set_data refuses NaN / Inf with RXHIP_ERR_BADARG.
  * rxhip_create falls through to this executor for every graph the pattern matcher rejects; rxhip_tree_create asks for it directly (the tests
  * compare it with the specialised engines on the graphs both can run).
  * Message forms: a rule keeps the form its inbound message has wherever the algebra allows — the additive rule and the backward rule of `+` (two random
@@ -428,7 +438,7 @@ typedef struct {
     int64_t bytes_per_sweep;              /* message traffic of one iteration per replica in the engine's schedule: 8·(d + d(d+1)/2) per message a rule reads from or writes to HBM */
     int32_t dmax;                         /* kernel instance: 1, 2, 4 or 8 (registers); above 8 the graph's largest dimension (LDS-staged kernels) */
     int32_t mode;                         /* schedule of the sweep phase — 0: one launch per level; 1: one launch per phase, workgroup-resident levels (dmax ≤ 8); 2: a lane (dmax ≤ 8)
-                                             or a wavefront per replica walks the schedule; 3 (dmax ≤ 4, from 16 384 replicas): strands — a lane per (strand, replica) walks a path of
+                                             or a wavefront per replica walks the schedule; 3 (dmax ≤ 4: the default): strands — a lane per (strand, replica) walks a path of
                                              dependent ops with the message in registers, one launch per strand level; bytes_per_sweep then counts what THAT schedule moves.
                                              (The Bethe / q(W) phase keeps 1 or 2.) */
     int32_t replicas_per_workgroup;       /* mode 1 */

@@ -1551,10 +1551,13 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     }
     if (P.dmax > 8) e->mode_fe = e->mode;
     // the strand schedule (register hand-over along dependent ops, wide levels at full occupancy): from the batches at which two long strands fill the device
-    if (P.dmax <= 4 && e->R >= 4096) e->mode = 3;
+    // (at every batch: a T = 128 chain of ONE replica is 0.60 ms in strands — its two recursions are two lanes walking 382 dependent ops — against 1.9 ms for
+    //  workgroup-resident levels and ≈ 1.5 ms for 390 launches; 256 replicas 0.63 against 1.86; 65 536: 2.3 against 3.9: profiles/r06/tree_strands.txt)
+    if (P.dmax <= 4) e->mode = 3;
     // the second phase is one wide level of independent terms and a short sum tree: a launch per level up to 65 536 replicas (0.09 against 1.0 ms for the
     // walk at 4 096, 1.20 against 1.34 at 65 536), the walk above (2.04 against 2.44 at 131 072): profiles/r06/tree_strands.txt
     if (e->mode == 3 || (e->mode == 1 && e->R >= 4096)) e->mode_fe = e->R >= 131072 ? 2 : 0;
+    if (e->mode == 3 && P.dmax > 4) e->mode = 1;
     if (const char* m = hook_env("RXHIP_TREE_MODE")) e->mode = e->mode_fe = std::max(0, std::min(3, std::atoi(m)));
     if (e->mode == 3 && P.dmax > 4) e->mode = 2;                  // (the strand kernel carries a message in registers: instances 1, 2, 4)
     if (e->mode_fe == 3) e->mode_fe = e->R >= 131072 ? 2 : 0;    // (the Bethe phase is one wide level of independent terms: no strands to speak of)

@@ -384,11 +384,13 @@ end
 """One iteration of the loop at batch.jl:391-430: push the staged data, run ONE sweep / VMP iteration, publish."""
 function fire!(g::HIPGraphEngine)
     g.received = 0
-    if !g.masked && g.family === :lgssm && any(isnan, g.staging)
-        # the first `missing` observation: the time-parallel tables assume every step observed — rebuild the engine with the
-        # masked schedule (rxhip_lgssm_desc.allow_missing).  RXHIP_ERR_UNSUPPORTED (d or dy > 4) surfaces as the error it is.
+    if !g.masked && (g.family === :lgssm || g.family === :tree) && any(isnan, g.staging)
+        # the first `missing` observation: the time-parallel tables assume every step observed (state-space family) and the executor keeps its data leaves in
+        # the form their reader wants (tree family) — rebuild the engine with rxhip_graph_desc.allow_missing: the masked schedule / data leaves in precision
+        # form, where a NaN is the zero message.  RXHIP_ERR_UNSUPPORTED surfaces as the error it is.
         RxHip.destroy!(g.engine)
         g.engine = RxHip.create_from_tables(g.tables; segments = g.options.segments, device = g.options.device, allow_missing = true)
+        g.family === :tree && RxHip.tree_continue!(g.engine)
         g.masked = true
     end
     e = g.engine
