@@ -433,16 +433,15 @@ def extra_node_array(device, parity=True):
                              "io_frac": info["io_bytes_per_sweep"] * R / (dev * 1e-3) / 1e9 / HBM_PEAK_GBS, "moved_over_io": moved / (info["io_bytes_per_sweep"] * R),
                              "bytes": "messages a rule, product or marginal of the schedule reads from / writes to HBM (register hand-overs along a strand left out) + what the Bethe "
                                       "phase reads and writes (rxhip_tree_info.bytes_per_sweep + fe_bytes_per_sweep) × replicas"}}
-        if name == "two_branch":   # HBM bytes of the two kernel instances by the PMC counters (profiles/tree_traffic.json, guarded by the hash of tree_kernels.hpp)
+        if name == "two_branch":   # HBM bytes of an iteration's launches by the PMC counters (profiles/tree_traffic.json, guarded by the hash of tree_kernels.hpp)
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", "tree_traffic.json")))
                 with open(os.path.join(ROOT, "rxinfer.jl_amd", "csrc", "tree_kernels.hpp"), "rb") as f:
                     fresh = tj.get("tree_kernels_sha256") == hashlib.sha256(f.read()).hexdigest()
-                if fresh and tj.get("algorithmic_bytes_per_sweep") == moved:
-                    line["roofline"]["traffic"] = sum(k["hbm_bytes_per_launch_x2"] for n, k in tj["kernels"].items() if "k_tree_" in n and "fe_total" not in n)
-                    line["roofline"]["traffic_note"] = "FETCH_SIZE x2 + WRITE_SIZE of both phases per sweep (profiles/tree_traffic.json); x1: " + \
-                        f"{sum(k['hbm_bytes_per_launch_x1'] for n, k in tj['kernels'].items() if 'k_tree_' in n and 'fe_total' not in n):.4g} bytes"
-            except (OSError, ValueError, KeyError):
+                if fresh and tj.get("moved_bytes_per_sweep") == moved and tj.get("hbm_bytes_per_iteration"):
+                    line["roofline"]["traffic"] = tj["hbm_bytes_per_iteration"]
+                    line["roofline"]["traffic_note"] = f"FETCH_SIZE x {tj.get('fetch_factor_8B_per_lane'):.3g} (calibrated for 8 B/lane unit-stride loads, scripts/fetch_calib.hip) + WRITE_SIZE over all launches of an iteration"
+            except (OSError, ValueError, KeyError, TypeError):
                 pass
         if parity and name == "two_branch":
             sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -472,35 +471,49 @@ def extra_node_array(device, parity=True):
         ms, _ = timed_sweeps(ref, 10, 2)
     out["plain_chain"]["specialised_engine_ms_per_step"] = ms
     out["ms_per_step"] = out["two_branch"]["device_ms_per_step"]
-    # above d = 8 the rules run on the LDS-staged kernels (a wavefront per op and replica, csrc/tree_wave_kernels.hpp): latency-bound inside the wavefront,
-    # not an HBM roofline — reported as time and rule calls per second, with a parity spot against the generic CPU restatement
-    m16 = workloads.random_model(16, 16, seed=1616)
-    T16, R16 = 64, 256
-    gb, xs, ys = two_branch_chain_graph(T16, m16["A"], m16["B"], m16["B"][:8], m16["P"], m16["Q"], m16["Q"][:8, :8], m16["m0"], m16["V0"])
-    rows16 = np.random.default_rng(778).standard_normal((R16, T16 * 24)) * 2.0
-    with TreeEngine(gb, n_replicas=R16, device=device) as eng:
-        eng.set_data(ys, rows16)
-        eng.run(1, True)
-        dev = 1e9
-        for _ in range(5):
+    # above d = 8 the rules run on the LDS-staged kernels (work items of 1 / 2 / 4 wavefronts per op and replica, products and the inverse on the fp64 matrix
+    # cores, csrc/tree_wave_kernels.hpp): time, rule calls per second, a parity spot against the generic CPU restatement — and, for the d = 64 workload the
+    # PMC pass was taken on, the executed v_mfma_f64_16x16x4_f64 instructions over the time against the fp64 MFMA peak (profiles/tree_mfma.json, hash-guarded)
+    for dd, T_, R_ in ((16, 64, 256), (32, 32, 2048), (64, 16, 256)):
+        mm = workloads.random_model(dd, dd, seed=100 * dd + dd)
+        h = dd // 2
+        gb, xs, ys = two_branch_chain_graph(T_, mm["A"], mm["B"], mm["B"][:h], mm["P"], mm["Q"], mm["Q"][:h, :h], mm["m0"], mm["V0"])
+        rows_ = np.random.default_rng(778).standard_normal((R_, T_ * (dd + h))) * 2.0
+        with TreeEngine(gb, n_replicas=R_, device=device) as eng:
+            eng.set_data(ys, rows_)
             eng.run(1, True)
-            dev = min(dev, eng.last_iteration_ms())
-        line = {"workload": f"two observation branches per state (d=16, dy=16+8), T={T16}, {R16} replicas: 1 sweep + Bethe free energy, LDS-staged rule kernels",
-                "device_ms_per_step": dev, "rule_calls_per_s": eng.counters()["rule_calls"] / (dev * 1e-3), "info": eng.info}
-        if parity:
-            sys.path.insert(0, os.path.join(ROOT, "oracle"))
-            import tree_oracle
-            post, fe = eng.marginals(xs), eng.free_energy_per_replica()
-            r = R16 - 1
-            data, o = {}, 0
-            for v in ys:
-                data[v] = rows16[r, o:o + gb.rows[v]]
-                o += gb.rows[v]
-            ref = tree_oracle.infer(gb.to_dump(), data)
-            em = max(float(np.max(np.abs(post[v][0][r] - ref["mean"][v]) / np.sqrt(np.diag(ref["cov"][v])))) for v in xs)
-            ef = float(abs(fe[r] - ref["fe"][0]) / abs(ref["fe"][0]))
-            line["parity_spot"] = {"replica": r, "mean_rel": em, "fe_rel": ef, "ok": bool(em < 1e-6 and ef < 1e-8)}
-    out["two_branch_d16"] = line
+            dev = 1e9
+            for _ in range(3):
+                eng.run(1, True)
+                dev = min(dev, eng.last_iteration_ms())
+            line = {"workload": f"two observation branches per state (d={dd}, dy={dd}+{h}), T={T_}, {R_} replicas: 1 sweep + Bethe free energy, LDS-staged rule kernels",
+                    "device_ms_per_step": dev, "rule_calls_per_s": eng.counters()["rule_calls"] / (dev * 1e-3), "info": eng.info}
+            if dd == 64:
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "tree_mfma.json")))
+                    with open(os.path.join(ROOT, "rxinfer.jl_amd", "csrc", "tree_wave_kernels.hpp"), "rb") as f:
+                        fresh = tj.get("tree_wave_kernels_sha256") == hashlib.sha256(f.read()).hexdigest()
+                    if fresh and tj.get("workload") == {"d": dd, "T": T_, "replicas": R_} and tj.get("mfma_f64_per_iteration"):
+                        tf = tj["mfma_f64_per_iteration"] * tj["flop_per_instruction"] / (dev * 1e-3) / 1e12
+                        line["roofline"] = {"bound": "mfma", "achieved": tf, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s (executed v_mfma_f64_16x16x4_f64 x 2048 flop)",
+                                            "frac": tf / FP64_PEAK_TFLOPS, "mfma_frac": tf / FP64_PEAK_TFLOPS, "mfma_insts_per_iteration": tj["mfma_f64_per_iteration"],
+                                            "source": tj.get("source")}
+                except (OSError, ValueError, KeyError):
+                    pass
+            if parity:
+                sys.path.insert(0, os.path.join(ROOT, "oracle"))
+                import tree_oracle
+                post, fe = eng.marginals(xs), eng.free_energy_per_replica()
+                r = R_ - 1
+                data, o = {}, 0
+                for v in ys:
+                    data[v] = rows_[r, o:o + gb.rows[v]]
+                    o += gb.rows[v]
+                ref = tree_oracle.infer(gb.to_dump(), data)
+                em = max(float(np.max(np.abs(post[v][0][r] - ref["mean"][v]) / np.sqrt(np.diag(ref["cov"][v])))) for v in xs)
+                ef = float(abs(fe[r] - ref["fe"][0]) / abs(ref["fe"][0]))
+                line["parity_spot"] = {"replica": r, "mean_rel": em, "fe_rel": ef, "ok": bool(em < 1e-6 and ef < 1e-8)}
+        out[f"two_branch_d{dd}"] = line
     return out
 
 
@@ -643,11 +656,16 @@ def valu_roofline(kernel, key, ms):
     try:
         vj = json.load(open(os.path.join(ROOT, "profiles", "valu_insts.json")))
         insts, src = float(vj[key]["SQ_INSTS_VALU"]), vj.get("source")
+        # the counters were collected from the kernels of ONE source state: its hash is recorded with them and compared here (absent in files older than round 6)
+        hdr = {"c4": "hgf_kernels.hpp", "c5": "gmm_kernels.hpp"}[key]
+        want = vj.get(hdr.replace(".hpp", "_sha256"))
+        with open(os.path.join(ROOT, "rxinfer.jl_amd", "csrc", hdr), "rb") as f:
+            stale = None if want is None else want != hashlib.sha256(f.read()).hexdigest()
     except Exception:
         return {"bound": "valu-issue", "kernel": kernel, "achieved": None, "peak": VALU_PEAK_WAVE_INSTS, "unit": "wave-instructions/s", "frac": None}
     ach = insts / (ms * 1e-3)
     return {"bound": "valu-issue", "kernel": kernel, "valu_insts_per_launch": insts, "ms": ms, "achieved": ach, "peak": VALU_PEAK_WAVE_INSTS,
-            "unit": "wave-instructions/s", "frac": ach / VALU_PEAK_WAVE_INSTS, "counter_source": src}
+            "unit": "wave-instructions/s", "frac": ach / VALU_PEAK_WAVE_INSTS, "counter_source": src, "counter_stale": stale}
 
 
 def extra_c4(device, parity=True):

@@ -231,3 +231,13 @@ struct DevGuard {
 };
 #define SET_DEVICE(e) DevGuard _dev_guard; HIPCHK((e), _dev_guard.set((e)->device))
 
+// what the translation units of the engines share with the runtime in rxhip.hip: an idle stream of the device (pooled: creating one costs milliseconds on this
+// runtime), the HIP-event pair around a kernel of an engine that is being profiled, the HGF engine's run (vmp_engines.hip) as rxhip_run dispatches to it
+namespace rxhip {
+hipError_t stream_acquire(int device, hipStream_t* out);
+rxhip_status prof_begin(rxhip_engine* e, int k);
+rxhip_status prof_end(rxhip_engine* e);
+rxhip_status hgf_run_async(rxhip_engine* e, int32_t iterations, int32_t want_fe);
+bool host_chol_inv(int n, const double* A, double* out, double* logdet);   // host Cholesky inverse + log-determinant of an SPD matrix (rxhip.hip host::chol_inv)
+}  // namespace rxhip
+
