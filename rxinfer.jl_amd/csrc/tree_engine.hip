@@ -1547,7 +1547,9 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     if (P.dmax > 8) {
         // wavefront per item: a launch per level — a rule at d = 16 is ≈ 17 µs of dependent LDS round trips inside its wavefront, more than a launch, so
         // the walk (one wavefront per replica, ops in sequence) only pays once the replicas alone fill the device (measured: profiles/r05/tree_wave_modes.txt)
-        e->mode = e->R >= 4096 ? 2 : 0;
+        // (round 6, items of 1 / 2 / 4 wavefronts: up to 16 a launch per level stays ahead at every batch — 28.3 against 35.3 ms at 4 096 replicas; above, the walk from
+        //  2 048 replicas — d = 32: 33.8 against 37.1 ms; profiles/r06/tree_wave_modes.txt)
+        e->mode = (P.dmax > 16 && e->R >= 2048) ? 2 : 0;
     }
     if (P.dmax > 8) e->mode_fe = e->mode;
     // the strand schedule (register hand-over along dependent ops, wide levels at full occupancy): from the batches at which two long strands fill the device

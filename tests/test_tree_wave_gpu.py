@@ -35,7 +35,10 @@ def test_default_schedule_and_workgroup_mode_request(monkeypatch):
     with TreeEngine(gb, n_replicas=1) as eng:
         assert eng.info["mode"] == 0
     with TreeEngine(gb, n_replicas=4096) as eng:
-        assert eng.info["mode"] == 2
+        assert eng.info["mode"] == 0          # (up to d = 16 a launch per level stays ahead at every batch)
+    gb32, _, _ = tg.two_branch_chain(T=2, d=20, dy1=20, dy2=4)
+    with TreeEngine(gb32, n_replicas=2048) as eng:
+        assert eng.info["mode"] == 2          # above: a work item per replica walks the schedule once the replicas fill the device
     monkeypatch.setenv("RXHIP_TREE_MODE", "1")
     with TreeEngine(gb, n_replicas=3) as eng:
         assert eng.info["mode"] == 2
