@@ -19,7 +19,8 @@
  * constants / offsets / horizon / caller's stream, T * chains <= 65536, no error ever reported) keeps it, and the next rxhip_lgssm_create
  * whose descriptor is the same byte for byte (shapes, schedule options, device, every model matrix) returns it reset to the state of a new
  * engine — an `infer(...)` per call costs a sweep and two copies then, not a construction.  rxhip_release_cached_memory() returns
- * everything idle to the driver.
+ * everything idle to the driver, and rxhip_set_caching(0) switches ALL of it off for the process: nothing is parked, nothing is shared between
+ * handles — "handles are independent; no global state" (threading) to the letter, at the price of the driver calls above per engine.
  */
 #ifndef RXHIP_H
 #define RXHIP_H
@@ -810,6 +811,10 @@ int32_t rxhip_device_count(void); /* number of visible HIP devices (0 if none) *
 rxhip_status rxhip_destroy(rxhip_engine* e);
 /* frees the engines, device blocks and pinned blocks parked by destroyed engines (see the note on process-wide state at the top) */
 rxhip_status rxhip_release_cached_memory(void);
+/* enabled = 0: no process-wide caching at all from now on — idle streams, device blocks, pinned blocks, per-model tables and parked engines are released now
+ * and nothing is parked or shared again (a destroyed engine frees everything it owns, engines of the same model build their own tables); 1 (the default)
+ * restores the pools.  Callable at any time from any thread; handles that are alive keep what they hold until they are destroyed. */
+rxhip_status rxhip_set_caching(int32_t enabled);
 
 #ifdef __cplusplus
 }

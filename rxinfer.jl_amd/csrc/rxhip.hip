@@ -109,6 +109,11 @@ __global__ void k_gather_chains(const double* __restrict__ in, double* __restric
 // ---- idle-stream pool: on this runtime hipStreamCreate costs 1.5–9 ms and hipStreamDestroy ≈1.1 ms, which made
 // engine construction + destruction ≈2.9 ms whatever the problem size.  Engine-owned streams are therefore recycled
 // per device (drained before they are parked).  This is the library's only process-wide state; it is mutex-protected.
+// rxhip_set_caching(0): a host that wants the ABI's "no global state" to the letter — nothing is parked, nothing is shared between handles, every pool below
+// is bypassed (and emptied at the switch); the default (1) keeps them: they are what makes an engine-per-`infer(...)` host cheap.
+#include <atomic>
+static std::atomic<int> g_caching{1};
+static bool caching_on() { return g_caching.load(std::memory_order_relaxed) != 0; }
 struct StreamPool {
     std::mutex m;
     std::vector<std::pair<int, hipStream_t>> idle;
@@ -118,7 +123,7 @@ static StreamPool& stream_pool() {
     return *p;
 }
 hipError_t rxhip::stream_acquire(int device, hipStream_t* out) {
-    {
+    if (caching_on()) {
         StreamPool& sp = stream_pool();
         std::lock_guard<std::mutex> g(sp.m);
         for (size_t i = 0; i < sp.idle.size(); ++i)
@@ -155,7 +160,7 @@ static PinnedPool& pinned_pool() {
     return *p;
 }
 static double* pinned_acquire(size_t need, size_t* got) {
-    {
+    if (caching_on()) {
         PinnedPool& pp = pinned_pool();
         std::lock_guard<std::mutex> g(pp.m);
         size_t best = pp.idle.size();   // the smallest block that fits (a 16 MB observation block is not spent on a status word)
@@ -175,7 +180,7 @@ static double* pinned_acquire(size_t need, size_t* got) {
     return p;
 }
 static void pinned_release(double* p, size_t bytes) {
-    {
+    if (caching_on()) {
         PinnedPool& pp = pinned_pool();
         std::lock_guard<std::mutex> g(pp.m);
         if (pp.idle.size() < 6) {
@@ -198,6 +203,7 @@ struct PinnedTmp {
     double* detach() { double* q = p; p = nullptr; return q; }   // the caller keeps the block (and returns it to the pool itself)
 };
 static char* arena_acquire(int device, size_t need, size_t* got) {
+    if (!caching_on()) return nullptr;
     ArenaPool& ap = arena_pool();
     std::lock_guard<std::mutex> g(ap.m);
     for (size_t i = 0; i < ap.idle.size(); ++i)
@@ -211,7 +217,7 @@ static char* arena_acquire(int device, size_t need, size_t* got) {
     return nullptr;
 }
 static void arena_release(int device, char* p, size_t bytes) {
-    if (bytes > ((size_t)2 << 30)) {
+    if (bytes > ((size_t)2 << 30) || !caching_on()) {
         (void)hipFree(p);
         return;
     }
@@ -232,7 +238,7 @@ static void arena_release(int device, char* p, size_t bytes) {
 static void stream_release(int device, hipStream_t s) {
     (void)hipStreamSynchronize(s);
     StreamPool& sp = stream_pool();
-    {
+    if (caching_on()) {
         std::lock_guard<std::mutex> g(sp.m);
         if (sp.idle.size() < 32) {
             sp.idle.emplace_back(device, s);
@@ -306,6 +312,7 @@ static DenseTablesPool& dense_tables_pool() {
     return *p;
 }
 static DenseTables* dense_tables_acquire(const std::vector<unsigned char>& key, int device) {
+    if (!caching_on()) return nullptr;   // (every engine builds its own tables; they are freed with it: dense_tables_release)
     DenseTablesPool& tp = dense_tables_pool();
     std::lock_guard<std::mutex> g(tp.m);
     for (DenseTables* t : tp.all)
@@ -356,7 +363,8 @@ static void dense_tables_release(DenseTables* t) {
         std::lock_guard<std::mutex> g(tp.m);
         t->refs--;
     }
-    dense_tables_trim(4, (size_t)1 << 30);
+    if (caching_on()) dense_tables_trim(4, (size_t)1 << 30);
+    else dense_tables_trim(0, 0);
 }
 
 // ---- arena planning: register every buffer, then one hipMalloc, one upload of the table block, one memset ----
@@ -1499,6 +1507,7 @@ static EnginePool& engine_pool() {
     return *p;
 }
 static bool engine_pool_on() {
+    if (!caching_on()) return false;
     const char* v = hook_env("RXHIP_ENGINE_POOL");
     return !(v && std::atoi(v) == 0);
 }
@@ -1533,6 +1542,11 @@ static void engine_pool_flush() {
     for (rxhip_engine* e : old) { free_all(e); delete e; }
 }
 
+rxhip_status rxhip_set_caching(int32_t enabled) {
+    g_caching.store(enabled ? 1 : 0, std::memory_order_relaxed);
+    if (!enabled) return rxhip_release_cached_memory();   // what is idle goes now; what live handles hold goes with them
+    return RXHIP_OK;
+}
 rxhip_status rxhip_release_cached_memory(void) {
     engine_pool_flush();
     dense_tables_trim(0, 0);

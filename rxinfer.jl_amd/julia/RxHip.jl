@@ -497,6 +497,8 @@ device_count() = Int(ccall((:rxhip_device_count, librxhip), Int32, ()))
 lgssm_supported(d::Integer, dy::Integer) = ccall((:rxhip_lgssm_supported, librxhip), Int32, (Int32, Int32), Int32(d), Int32(dy)) != 0
 "hand the library's parked engines, arenas and pinned blocks back to the runtime (`rxhip_release_cached_memory`; INTEGRATION.md: lifetime of the pools)"
 release_cached_memory() = ccall((:rxhip_release_cached_memory, librxhip), Int32, ()) == 0
+"switch the library's process-wide pools off (`false`: nothing parked, nothing shared between handles) or back on (`rxhip_set_caching`)"
+set_caching!(on::Bool) = ccall((:rxhip_set_caching, librxhip), Int32, (Int32,), on ? 1 : 0) == 0
 
 "device time (ms) of the kernels that ran once at creation because their results depend on the model only"
 function model_tables_ms(e::Engine)

@@ -69,3 +69,38 @@ def test_other_descriptors_do_not_hit_and_errors_do_not_park():
         got = _run(e, y)
     for a, b in zip(base, got):
         assert np.array_equal(a, b)
+
+
+def test_caching_off_means_no_process_wide_state():
+    """rxhip_set_caching(0): the ABI's "handles are independent, no global state" (threading) to the letter — a destroyed engine is not parked, an
+    engine of a model another live engine has is built from scratch (its own tables), and the results are the same bits; rxhip_set_caching(1) restores the pools."""
+    import rxhip
+    from rxhip import workloads
+    L = rxhip._lib.lib()
+    m4 = workloads.random_model(4, 4, seed=31)
+    m24 = workloads.random_model(24, 6, seed=32)
+    y4, y24 = workloads.generate_batch(m4, 500, 1, seed0=1), workloads.generate_batch(m24, 200, 1, seed0=2)
+    mk4 = lambda: rxhip.LGSSMEngine(m4["A"], m4["B"], m4["P"], m4["Q"], m4["m0"], m4["V0"], T=500, n_chains=1)
+    mk24 = lambda: rxhip.LGSSMEngine(m24["A"], m24["B"], m24["P"], m24["Q"], m24["m0"], m24["V0"], T=200, n_chains=1)
+    with mk4() as e:
+        want4 = _run(e, y4)
+    with mk24() as e:
+        want24 = _run(e, y24)
+    try:
+        assert L.rxhip_set_caching(0) == 0
+        for _ in range(2):
+            with mk4() as e:
+                assert sum(e.create_stages().values()) > 0.0           # built every time: nothing was parked
+                got4 = _run(e, y4)
+        with mk24() as a, mk24() as b:                                 # two live engines of one model on the MFMA path: each with tables of its own
+            assert sum(a.create_stages().values()) > 0.0 and sum(b.create_stages().values()) > 0.0
+            assert b.create_stages()["tables_device_ms"] + b.create_stages()["tables_host_ms"] > 0.0
+            got24 = _run(b, y24)
+    finally:
+        assert L.rxhip_set_caching(1) == 0
+    for a, b in zip(want4 + want24, got4 + got24):
+        assert np.array_equal(a, b)
+    with mk4() as e:
+        pass
+    with mk4() as e:
+        assert sum(e.create_stages().values()) == 0.0                  # the pools are back
