@@ -413,17 +413,17 @@ def test_a_derived_clamped_variable_is_published_as_a_point_mass():
         assert post[x][0][0, 0] == pytest.approx(1.5) and eng.free_energy_per_replica()[0] == pytest.approx(3.51551, abs=1e-5)   # models_tests.jl:255
 
 
-@pytest.mark.parametrize("seed", range(12))
-def test_strand_schedule_equals_the_walk_on_random_forests(seed, monkeypatch):
+@pytest.mark.parametrize("seed,R", [(s, 70) for s in range(12)] + [(20, 30000), (21, 30000), (22, 50000)])
+def test_strand_schedule_equals_the_walk_on_random_forests(seed, R, monkeypatch):
     """mode 3 (strands: a lane per (strand, replica), messages handed to the next op in registers, stores of messages nobody else reads suppressed) against mode 2
-    (a lane per replica over the whole op list, every message through HBM) on random forests with dimensions ≤ 4, 70 replicas (two wavefronts, one partial):
+    (a lane per replica over the whole op list, every message through HBM) on random forests with dimensions ≤ 4, 70 replicas (two wavefronts, one partial) and
+    tens of thousands:
     the same rule bodies in another order — posteriors, q(W) and free energies to 1e-12"""
     from rxhip.tree import TreeEngine
     prec = seed % 3 == 1
     its = 2 if prec else 1
     gb, ys, named = tg.random_forest(100 + seed, n_steps=18, dmax=(4, 3, 2, 1)[seed % 4], precision_vars=prec)
-    R = 70
-    data = tg.random_data(gb, ys, R, seed)
+    data = tg.random_data(gb, ys, R, seed)   # (the large batches: hundreds of workgroups per strand level in flight — an ordering mistake between strands would show as a race)
     gv = sorted(eng_gauss(gb))
     res = {}
     for mode in (2, 3):
