@@ -292,7 +292,7 @@ typedef struct {
      * Every schedule implements ONE factorisation per node type:
      *   Gaussian nodes — q(out, μ) joint, a random third interface (precision) in a factor of its own;  `*`, `+` — all random interfaces joint;
      *   GCV — q(y, x) q(z);  NormalMixture, Categorical, Bernoulli and the priors — mean-field (every random interface its own factor);
-     * the node-array executor ALSO runs Gaussian nodes under q(out) q(μ) (mean-field between the two Gaussian interfaces: `MeanField()` on a chain).
+     * the node-array executor ALSO runs Gaussian nodes under q(out) q(μ) (mean-field between the two Gaussian interfaces: `MeanField()` on a chain; any dimension ≤ 64).
      * A table that asks a node for anything else is RXHIP_ERR_UNSUPPORTED with the node named (→ stock plugin) from every lowering pass, rxhip_create,
      * rxhip_tree_create and rxhip_tree_plan — never silently the other variational family's posterior.  NULL = the factorisation above (joint Gaussian
      * interfaces), which is what GraphPPL's default constraints (BetheFactorization) produce for the BP families. */
@@ -409,7 +409,7 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  * whose Gaussian variables form a forest (no cycles; precision variables may touch any number of nodes — the mean-field factorisation cuts those
  * loops; no Gaussian variable at all is a forest too: `P ~ Wishart; y[i] ~ MvNormal(μ = m, Λ = P)` with a known mean,
  * test/models/iid/mv_iid_precision_known_mean_tests.jl), every dimension ≤ 64.  Factorisation (rxhip_graph_desc.factor_cluster): a Gaussian node under
- * q(out, μ) — structured, the default — or, dimensions ≤ 8, under q(out) q(μ) (`constraints = MeanField()`): its rules then read MARGINALS,
+ * q(out, μ) — structured, the default — or under q(out) q(μ) (`constraints = MeanField()`): its rules then read MARGINALS,
  * MvNormalMeanCovariance(:out)(q_μ, q_Σ) = N(mean(q_μ), Σ), the node cuts the graph (cycles through it are fine), the marginals of its two variables are state
  * that starts from their `@initialization` marginals (RXHIP_INIT_NORMAL / MVNORMAL; an anonymous `A * x` output starts as the image of x's; none:
  * RXHIP_ERR_BADARG), every rule of an iteration reads the marginals of the previous one, and the free energy books the average energy with both marginals.

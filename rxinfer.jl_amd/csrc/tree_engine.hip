@@ -279,9 +279,7 @@ struct Compiler {
         for (int64_t f = 0; f < nf; ++f) {
             mf[f] = mf[f] && nclass[f] == NC_NOISE && P.vclass[iface((int)f, 0)] == VC_GAUSS && P.vclass[iface((int)f, 1)] == VC_GAUSS;
             P.has_mf = P.has_mf || mf[f];
-            if (mf[f] && dmx > 8)
-                fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: mean field between the Gaussian interfaces of a node (q(out) q(μ)) runs on the register kernels only: dimensions <= 8 (this graph: %d)",
-                     (long long)f, dmx);
+
         }
         // <= 8: the register instances (lane per op and replica); above: the graph's own maximum, staged in LDS by a wavefront per op and replica
         P.dmax = dmx <= 1 ? 1 : dmx <= 2 ? 2 : dmx <= 4 ? 4 : dmx <= 8 ? 8 : dmx;
@@ -817,12 +815,11 @@ struct Compiler {
         // marginals: one level behind the last message
         const int LM = maxl + 1;
         int lm_last = LM;
-        // (register kernels) the output of `A * x` with x random: its marginal is the image of x's (OP_MARG_PUSH, second phase) — no product of the
+        // the output of `A * x` with x random: its marginal is the image of x's (OP_MARG_PUSH, on demand) — no product of the
         // messages on its two edges in the sweep; one level only (the input's own marginal comes from messages)
         push_from.assign(nv, -1);
         push_fac.assign(nv, -1);
-        if (P.dmax <= 8)
-            for (int64_t f = 0; f < nf; ++f) {
+        for (int64_t f = 0; f < nf; ++f) {
                 if (nclass[f] != NC_MUL) continue;
                 const int o = (int)iface((int)f, 0), in = (int)iface((int)f, 2);
                 if (P.vclass[o] == VC_GAUSS && P.vclass[in] == VC_GAUSS) { push_from[o] = in; push_fac[o] = (int)f; }
@@ -898,8 +895,8 @@ struct Compiler {
                     r.w[W_VAL2] = P.marg_off[b];
                     ent_coef[a] -= 1;
                     ent_coef[b] -= 1;
-                } else if (ga && gb && P.dmax <= 8) {
-                    // register kernels: the joint from ONE inbound message and the two marginals (tree_kernels.hpp OP_FE_NOISE2M); side a = the interface
+                } else if (ga && gb) {
+                    // the joint from ONE inbound message and the two marginals (tree_kernels.hpp / tree_wave_kernels.hpp OP_FE_NOISE2M); side a = the interface
                     // whose message to the node is stored in precision form (no conversion), the out side when both are
                     const int m0 = E + fac_edges[f][0], m1 = E + fac_edges[f][1];
                     const bool use1 = !null_[m1] && form[m1] && (null_[m0] || !form[m0]);
@@ -909,9 +906,6 @@ struct Compiler {
                     marg_of(r, use1 ? a : b, W_VAL2, F_PUSH_B, W_IN2, W_N);
                     r.w[W_OUT] = 0;
                     if (push_from[use1 ? a : b] >= 0) fold.push_back({recs.size() - 1, use1 ? a : b});
-                } else if (ga && gb) {
-                    msg_in(r, W_IN0, F_IN0_WP, E + fac_edges[f][0]);
-                    msg_in(r, W_IN1, F_IN1_WP, E + fac_edges[f][1]);
                 } else if (ga || gb) {
                     if (g->allow_missing && P.vclass[ga ? b : a] != VC_CONST) r.w[W_FLAGS] |= F_MAY_MISS;
                     marg_of(r, ga ? a : b, W_IN0, F_PUSH_A, W_IN1, W_D1);

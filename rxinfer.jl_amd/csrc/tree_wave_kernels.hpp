@@ -611,6 +611,39 @@ __device__ __forceinline__ void load_value(const Ctx& c, const TreeParams& p, in
     w_sync();
 }
 
+// A marginal as the second phase reads it — mean → vector vm, covariance → tile MV (want_cov), log|V| returned — of the marginal slot `off`, or (push) of the
+// IMAGE of that marginal under the constant d × du matrix at cpool + aoff: the output of `A * x` has the marginal (A m, A V Aᵀ) of x's, so the sweep never forms
+// the marginals of such (anonymous) variables from messages (tree_kernels.hpp load_marginal, op for op).  Scratch: vector vt; tiles TA, TB, TC (all four tiles of
+// the item when an image's covariance is wanted: callers form images first).  A singular image: log|V| = −∞.
+template <int DC>
+__device__ __forceinline__ double load_marginal(const Ctx& c, const TreeParams& p, int off, bool push, int aoff, int du, int d, long long r, bool want_cov, int vm, int vt, int MV,
+                                                int TA, int TB, int TC) {
+    const int LD = c.LD;
+    if (!push) {
+        l_vec(c, vm, p.marg, off, d, p.es, r * p.rs_marg);
+        double ldV = 0.0;
+        if (want_cov) {
+            l_sym<DC>(c, MV, p.marg, off + d, d, p.es, r * p.rs_marg);
+            ldV = p.marg[(long long)(off + d + d * (d + 1) / 2) * p.es + r * p.rs_marg];
+        }
+        w_sync();
+        return ldV;
+    }
+    l_vec(c, vt, p.marg, off, du, p.es, r * p.rs_marg);
+    l_cmat<DC>(c, TA, p.cpool + aoff, d, du);
+    if (want_cov) l_sym<DC>(c, TB, p.marg, off + du, du, p.es, r * p.rs_marg);
+    w_sync();
+    matvec(c, vm, TA, LD, 1, vt, d, du);
+    if (!want_cov) return 0.0;
+    matmul<DC>(c, TC, TA, false, TB, false, d, du, du);   // A V
+    matmul<DC>(c, MV, TC, false, TA, true, d, du, d);     // A V Aᵀ
+    each(c, d, d, [&](int i, int j) { wlds[TB + i * LD + j] = 0.5 * (wlds[MV + i * LD + j] + wlds[MV + j * LD + i]); });
+    w_sync();
+    double ld;
+    const bool pd = spd_inv<DC>(c, TB, d, ld);
+    return pd ? ld : -__builtin_huge_val();    // (the sweep inverts a copy of V; its pivots' logs are log|V|)
+}
+
 // the sweep (ops up to OP_MARGINAL): the rules of tree_kernels.hpp's eval_bp, op for op
 template <int DC>
 __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const int* __restrict__ w, long long r) {
@@ -634,7 +667,11 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         s_vec(c, p.val, w[W_OUT], d, p.es, r * p.rs_val, v0);
     } break;
     case OP_LEAF: {
-        load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v0);
+        if (fl & F_VAL_MARG) {   // a Gaussian node under q(out) q(μ): the value is the MEAN of the other interface's marginal (of the previous iteration)
+            l_vec(c, v0, p.marg, w[W_VAL], d, p.es, r * p.rs_marg);
+            w_sync();
+        } else
+            load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v0);
         const bool wp = fl & F_OUT_WP;
         load_noise<DC>(c, p, w, d, r, !wp, M0);
         if (wp) {
@@ -817,20 +854,72 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         }
         if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = term;
     } break;
+    case OP_MARG_PUSH: {   // the stored marginal of an `A * x` output, formed when a caller asks for it
+        const double ldV = load_marginal<DC>(c, p, w[W_IN0], true, w[W_C0], w[W_D1], d, r, true, v0, v1, M0, M1, M2, M3);
+        s_vec(c, p.marg, w[W_OUT], d, p.es, r * p.rs_marg, v0);
+        s_sym<DC>(c, p.marg, w[W_OUT] + d, d, p.es, r * p.rs_marg, M0);
+        if (c.lane == 0) p.marg[(long long)(w[W_OUT] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg] = ldV;
+    } break;
+    case OP_FE_NOISE2M: {
+        // tree_kernels.hpp OP_FE_NOISE2M, op for op: the joint of a Gaussian node's two interfaces from ONE inbound message (side a) and the two marginals —
+        // P = L_a + W, log|J| = log|P| − log|V_b|, Cov(a − b) = P⁻¹ + (P⁻¹W − I) V_b (P⁻¹W − I)ᵀ.  V_b → M2 first (an image needs every tile), then P⁻¹ → M0,
+        // D = P⁻¹W − I → M3, D V_b → M1, E → M0.
+        const double ldVb = load_marginal<DC>(c, p, w[W_VAL2], fl & F_PUSH_B, w[W_IN2], w[W_N], d, r, true, v2, v4, M2, M0, M1, M3);   // m_b → v2
+        (void)load_marginal<DC>(c, p, w[W_VAL], fl & F_PUSH_A, w[W_IN1], w[W_LIST], d, r, false, v1, v4, M0, M0, M1, M3);             // m_a → v1
+        if (w[W_IN0] >= 0) ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
+        else zero_mat(c, M0, d);
+        const double el = load_noise<DC>(c, p, w, d, r, false, M1);
+        add_mat(c, M0, M1, d, 1.0);
+        w_sync();
+        double ldP;
+        ok = spd_inv<DC>(c, M0, d, ldP) && ok;
+        matmul<DC>(c, M3, M0, false, M1, false, d, d, d);                // P⁻¹ W
+        for (int i = c.lane; i < d; i += WL) {
+            wlds[M3 + i * LD + i] -= 1.0;
+            wlds[v1 + i] -= wlds[v2 + i];
+        }
+        w_sync();
+        matmul<DC>(c, M1, M3, false, M2, false, d, d, d);                // D V_b
+        matmul<DC>(c, M0, M1, false, M3, true, d, d, d, true, 1.0);      // P⁻¹ += D V_b Dᵀ
+        each(c, d, d, [&](int i, int j) { wlds[M0 + i * LD + j] += wlds[v1 + i] * wlds[v1 + j]; });
+        w_sync();
+        double term = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP - ldVb));
+        if (fl & F_FOLD_ENT) term += (double)w[W_OUT] * 0.5 * (d * (T_LOG2PI + 1.0) + ldVb);
+        if (fl & F_STAT) s_full(c, p.stat, w[W_C1], d, p.es, r * p.rs_stat, M0, 1.0);
+        else {
+            load_noise<DC>(c, p, w, d, r, false, M2);
+            term += 0.5 * (d * T_LOG2PI - el + trace_prod(c, M2, M0, d));
+        }
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = term;
+    } break;
+    case OP_FE_NOISE_MF: {   // a Gaussian node under q(out) q(μ): E[rrᵀ] = V_out + V_μ + (m_out − m_μ)(m_out − m_μ)ᵀ; the entropies go with the variables' terms
+        (void)load_marginal<DC>(c, p, w[W_VAL], false, 0, 0, d, r, true, v0, v4, M0, M1, M2, M3);
+        (void)load_marginal<DC>(c, p, w[W_VAL2], false, 0, 0, d, r, true, v1, v4, M2, M1, M1, M3);
+        const double el = load_noise<DC>(c, p, w, d, r, false, M1);
+        add_vec(c, v0, v1, d, -1.0);
+        add_mat(c, M0, M2, d, 1.0);
+        w_sync();
+        each(c, d, d, [&](int i, int j) { wlds[M0 + i * LD + j] += wlds[v0 + i] * wlds[v0 + j]; });
+        w_sync();
+        double term = 0.0;
+        if (fl & F_STAT) s_full(c, p.stat, w[W_C1], d, p.es, r * p.rs_stat, M0, 1.0);
+        else term = 0.5 * (d * T_LOG2PI - el + trace_prod(c, M1, M0, d));
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = term;
+    } break;
     case OP_FE_NOISE1:
     case OP_FE_NOISE0: {
-        const double el = load_noise<DC>(c, p, w, d, r, false, M1);
         double H = 0.0;
-        if (op == OP_FE_NOISE1) {
-            l_vec(c, v0, p.marg, w[W_IN0], d, p.es, r * p.rs_marg);
-            l_sym<DC>(c, M0, p.marg, w[W_IN0] + d, d, p.es, r * p.rs_marg);
-            H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg]);
+        if (op == OP_FE_NOISE1) {   // (the marginal first: an image of another marginal needs every tile)
+            const double ldV = load_marginal<DC>(c, p, w[W_IN0], fl & F_PUSH_A, w[W_IN1], w[W_D1], d, r, true, v0, v4, M0, M1, M2, M3);
+            H = 0.5 * (d * (T_LOG2PI + 1.0) + ldV);
+            if (fl & F_FOLD_ENT) H *= (double)(1 - w[W_OUT]);
             load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v1);
         } else {
             zero_mat(c, M0, d);
             load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v0);
             load_value(c, p, w[W_VAL2], fl & F_VAL2_SLOT, d, r, v1);
         }
+        const double el = load_noise<DC>(c, p, w, d, r, false, M1);
         add_vec(c, v0, v1, d, -1.0);
         w_sync();
         bool miss = false;   // a `missing` observation: energy and the predicted value's entropy cancel, −H of the random interface stays
@@ -845,8 +934,10 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = term;
     } break;
     case OP_FE_ENT: {
-        const double H = 0.5 * (d * (T_LOG2PI + 1.0) + p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg]);
-        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = (double)w[W_N] * H;
+        double ldV;
+        if (fl & F_PUSH_A) ldV = load_marginal<DC>(c, p, w[W_IN0], true, w[W_C0], w[W_D1], d, r, true, v0, v4, M0, M1, M2, M3);
+        else ldV = p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg];
+        if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = (double)w[W_N] * 0.5 * (d * (T_LOG2PI + 1.0) + ldV);
     } break;
     case OP_FE_ADD2: {   // P = Λ1 + Λo → M0, S = Λ2 + Λo − Λo P⁻¹ Λo → M1, Λo → M2
         if (w[W_IN0] >= 0) ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);

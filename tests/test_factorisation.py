@@ -88,9 +88,9 @@ def test_a_mean_field_chain_is_not_answered_with_the_structured_posterior():
     gb, ys, named = tg.mean_field_chain(T=6, d=2, dy=2)
     p_mf, p_bp = plan(gb), plan(tg.mean_field_chain(T=6, d=2, dy=2)[0].bethe())
     assert p_mf["rule_calls"] == p_bp["rule_calls"] == 6 * 6 - 3 and p_mf["n_levels"] < p_bp["n_levels"]
-    # above 8 dimensions the rules run on the LDS-staged kernels, which do not have the mean-field leaf: refused by name
+    # above 8 dimensions the same ops run on the LDS-staged kernels
     gb, _, _ = tg.mean_field_chain(T=3, d=9, dy=9)
-    refused(lambda: plan(gb), "q(out) q(μ)", "dimensions <= 8")
+    assert plan(gb)["dmax"] == 9 and plan(gb)["rule_calls"] == 6 * 3 - 3
 
 
 def test_every_family_checks_its_own_factorisation():

@@ -446,7 +446,8 @@ def test_strand_schedule_equals_the_walk_on_random_forests(seed, R, monkeypatch)
 
 
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
-@pytest.mark.parametrize("kw", [dict(T=7, d=2, dy=2), dict(T=5, d=3, dy=2, branches=2), dict(T=9, d=1, dy=1), dict(T=6, d=4, dy=3, partial=True), dict(T=4, d=6, dy=5)])
+@pytest.mark.parametrize("kw", [dict(T=7, d=2, dy=2), dict(T=5, d=3, dy=2, branches=2), dict(T=9, d=1, dy=1), dict(T=6, d=4, dy=3, partial=True), dict(T=4, d=6, dy=5),
+                                dict(T=4, d=11, dy=9, partial=True), dict(T=3, d=20, dy=20)])
 def test_mean_field_between_gaussian_interfaces(kw, mode, monkeypatch):
     """`constraints = MeanField()` on a Gaussian chain through the boundary's factorisation table (rxhip_graph_desc.factor_cluster): q(out) q(μ) around the
     transition nodes.  Every iteration's posteriors and free energy against the extended oracle (which is held to the closed-form fixed point on the CPU,
@@ -455,6 +456,8 @@ def test_mean_field_between_gaussian_interfaces(kw, mode, monkeypatch):
     import tree_oracle
     from rxhip.tree import TreeEngine
     gb, ys, named = tg.mean_field_chain(**kw)
+    if kw["d"] > 8 and mode in (1, 3):
+        pytest.skip("the LDS-staged kernels have the launch-per-level and the walk schedule")
     R, its = 3, 6
     monkeypatch.setenv("RXHIP_TREE_MODE", str(mode))
     data = tg.random_data(gb, ys, R, 2)

@@ -18,8 +18,10 @@ EMUL = os.path.join(ROOT, "tests", "host_emul")
 
 (OP_DERIVE_MUL, OP_DERIVE_ADD, OP_LEAF, OP_NOISE, OP_MUL_OUT, OP_MUL_IN, OP_ADD_OUT, OP_ADD_IN, OP_SHIFT, OP_PRODUCT, OP_MARGINAL, OP_FE_NOISE2, OP_FE_NOISE1,
  OP_FE_NOISE0, OP_FE_ENT, OP_FE_ADD2, OP_SUM_TERMS, OP_PREC_UPDATE) = range(1, 19)
+OP_FE_NOISE2M, OP_MARG_PUSH, OP_FE_NOISE_MF = 19, 20, 21
 W_OP, W_D0, W_D1, W_OUT, W_IN0, W_IN1, W_IN2, W_FLAGS, W_C0, W_C1, W_VAL, W_VAL2, W_PREC, W_TERM, W_N, W_LIST = range(16)
 F_IN0_WP, F_IN1_WP, F_IN2_WP, F_OUT_WP, F_VAL_SLOT, F_VAL2_SLOT, F_NEG, F_STAT, F_RAND_IS_MU = 1, 2, 4, 8, 16, 32, 64, 128, 256
+F_PUSH_A, F_PUSH_B, F_FOLD_ENT, F_VAL_MARG = 1024, 2048, 4096, 8192
 
 
 @pytest.fixture(scope="module")
@@ -172,6 +174,25 @@ def build_program(d, d1, seed):
     stats.append(st.slot("stat", d * d))
     st.op(OP_FE_NOISE0, d, val=cv, val2=y0, flags=F_VAL2_SLOT | F_STAT, prec=ps, c1=stats[-1], term=new_term())
     st.op(OP_FE_ENT, d, in0=mg, n=-2, term=new_term())
+    # round 6: the one-message joint term with stored and with image marginals (the marginal of `A * x` as the image of x's), entropy folded in; the stored
+    # marginal of an image; the image in the one-interface term and in the entropy term; a Gaussian node under q(out) q(μ) — its leaf rule and average energy
+    mg2, mgs = st.marginal(d), st.marginal(d)   # (images through a SQUARE map: with more rows than columns the image is singular and its log-determinant −∞ by design)
+    A2 = st.const(rng.standard_normal((d, d)))
+    for f in (0, F_IN0_WP):
+        st.op(OP_FE_NOISE2M, d, in0=st.message(d), val=mg, val2=mg2, flags=f, c0=noise, term=new_term(), out=0)
+        st.op(OP_FE_NOISE2M, d, in0=st.message(d), val=mg2, val2=mgs, in2=A2, n=d, flags=f | F_PUSH_B | F_FOLD_ENT, out=1, c0=noise, term=new_term())
+        st.op(OP_FE_NOISE2M, d, in0=st.message(d), val=mgs, in1=A2, list=d, val2=mg, flags=f | F_PUSH_A, c0=noise, term=new_term(), out=0)
+        stats.append(st.slot("stat", d * d))
+        st.op(OP_FE_NOISE2M, d, in0=st.message(d), val=mg, val2=mgs, in2=A2, n=d, flags=f | F_PUSH_B | F_STAT, prec=ps, c1=stats[-1], term=new_term(), out=0)
+    st.op(OP_FE_NOISE2M, d, in0=-1, val=mg, val2=mg2, flags=0, c0=noise, term=new_term(), out=0)
+    st.op(OP_MARG_PUSH, d, d1=d, in0=mgs, c0=A2, out=st.slot("marg", msz(d) + 1))
+    st.op(OP_FE_NOISE1, d, d1=d, in0=mgs, in1=A2, val=y0, flags=F_VAL_SLOT | F_PUSH_A | F_FOLD_ENT, out=2, c0=noise, term=new_term())
+    st.op(OP_FE_ENT, d, d1=d, in0=mgs, c0=A2, n=3, flags=F_PUSH_A, term=new_term())
+    st.op(OP_FE_NOISE_MF, d, val=mg, val2=mg2, c0=noise, term=new_term())
+    stats.append(st.slot("stat", d * d))
+    st.op(OP_FE_NOISE_MF, d, val=mg2, val2=mg, flags=F_STAT, prec=ps, c1=stats[-1], term=new_term())
+    for wp in (0, F_OUT_WP):
+        st.op(OP_LEAF, d, out=new_msg(d), val=mg, flags=F_VAL_MARG | wp, c0=noise)
     for f, ins in ((0, (1, 1, 1)), (F_IN0_WP | F_IN2_WP, (1, 1, 1)), (F_IN1_WP, (0, 1, 1)), (F_IN0_WP, (1, 0, 1)), (F_IN0_WP | F_IN1_WP, (1, 1, 0))):
         slots = [st.message(d) if k else -1 for k in ins]
         st.op(OP_FE_ADD2, d, in0=slots[0], in1=slots[1], in2=slots[2], flags=f, term=new_term())
