@@ -79,6 +79,27 @@ bool host_chol_inv(int n, const double* A, double* out, double* logdet) {
     if (logdet) *logdet = ld;
     return true;
 }
+// log|det A| of a square matrix (LU with partial pivoting); false: singular to working precision
+bool host_logabsdet(int n, const double* A, double* out) {
+    std::vector<double> M(A, A + (size_t)n * n);
+    double ld = 0.0;
+    for (int k = 0; k < n; ++k) {
+        int piv = k;
+        for (int i = k + 1; i < n; ++i)
+            if (std::fabs(M[(size_t)i * n + k]) > std::fabs(M[(size_t)piv * n + k])) piv = i;
+        const double p = M[(size_t)piv * n + k];
+        if (!(std::fabs(p) > 0.0) || !std::isfinite(p)) return false;
+        if (piv != k)
+            for (int j = 0; j < n; ++j) std::swap(M[(size_t)k * n + j], M[(size_t)piv * n + j]);
+        ld += std::log(std::fabs(p));
+        for (int i = k + 1; i < n; ++i) {
+            const double f = M[(size_t)i * n + k] / p;
+            for (int j = k; j < n; ++j) M[(size_t)i * n + j] -= f * M[(size_t)k * n + j];
+        }
+    }
+    *out = ld;
+    return true;
+}
 double host_digamma(double x) {
     double r = 0.0;
     while (x < 6.0) { r -= 1.0 / x; x += 1.0; }
@@ -495,7 +516,12 @@ struct Compiler {
                             wf = wanted_form(e2);
                         }
                         form[m] = wf == 0 ? 0 : 1;
-                    } else form[m] = form[deps[m][0]];
+                    } else {
+                        // a moment-form sum into a variable with three or more edges: every reader is a product or the marginal, each of which would invert
+                        // it for itself — the op stores the precision form instead (one inverse where there were two or three)
+                        form[m] = form[deps[m][0]];
+                        if (!form[m] && var_edges[ed.v].size() >= 3 && !is_hub(ed.v)) form[m] = 1;
+                    }
                 } else if (nclass[ed.f] == NC_MUL) form[m] = ed.k == 0 ? 0 : 1;
                 else if (deps[m].size() == 2) form[m] = ed.k == 0 ? 0 : form[deps[m][0]];   // `+`: (:out) adds moments; (:in) keeps the form of the message from `out` (deps[m][0])
                 else form[m] = form[deps[m][0]];
@@ -772,7 +798,8 @@ struct Compiler {
                 } else {
                     OpRec& r = emit(lv, OP_NOISE, d);
                     r.w[W_IN0] = src_off(E + oe);
-                    if (form[E + oe]) r.w[W_FLAGS] |= F_IN0_WP | F_OUT_WP;
+                    if (form[E + oe]) r.w[W_FLAGS] |= F_IN0_WP;
+                    if (form[m]) r.w[W_FLAGS] |= F_OUT_WP;
                     noise_params(r, f, d);
                     r.w[W_OUT] = off[m];
                     P.bytes_per_sweep += 8ll * msz(d);
@@ -860,13 +887,16 @@ struct Compiler {
         const int LF = lm_last + 1;
         std::vector<int> terms;
         std::vector<std::pair<size_t, int>> fold;   // (op record, variable): ops that have log|V| of an image variable at hand
-        auto marg_of = [&](OpRec& r, int v, int word, int bit, int word_a, int word_du) {
+        // word_ld (−1: none): where the op finds 2·log|det A| of a SQUARE map — log|A V Aᵀ| = log|V| + 2 log|det A|, so the image's log-determinant costs an
+        // addition instead of a Cholesky sweep (at d = 64: an inverse's worth of work per Bethe term)
+        auto marg_of = [&](OpRec& r, int v, int word, int bit, int word_a, int word_du, int word_ld) {
             if (push_from[v] >= 0) {
                 const int u = push_from[v];
                 r.w[word] = P.marg_off[u];
                 r.w[W_FLAGS] |= bit;
                 r.w[word_a] = const_matrix((int)iface(push_fac[v], 1), P.dim[v], P.dim[u]);
                 r.w[word_du] = P.dim[u];
+                if (word_ld >= 0) r.w[word_ld] = push_logdet(v);
             } else
                 r.w[word] = P.marg_off[v];
         };
@@ -902,13 +932,13 @@ struct Compiler {
                     const bool use1 = !null_[m1] && form[m1] && (null_[m0] || !form[m0]);
                     r.w[W_OP] = OP_FE_NOISE2M;
                     msg_in(r, W_IN0, F_IN0_WP, use1 ? m1 : m0);
-                    marg_of(r, use1 ? b : a, W_VAL, F_PUSH_A, W_IN1, W_LIST);
-                    marg_of(r, use1 ? a : b, W_VAL2, F_PUSH_B, W_IN2, W_N);
+                    marg_of(r, use1 ? b : a, W_VAL, F_PUSH_A, W_IN1, W_LIST, -1);
+                    marg_of(r, use1 ? a : b, W_VAL2, F_PUSH_B, W_IN2, W_N, W_D1);
                     r.w[W_OUT] = 0;
                     if (push_from[use1 ? a : b] >= 0) fold.push_back({recs.size() - 1, use1 ? a : b});
                 } else if (ga || gb) {
                     if (g->allow_missing && P.vclass[ga ? b : a] != VC_CONST) r.w[W_FLAGS] |= F_MAY_MISS;
-                    marg_of(r, ga ? a : b, W_IN0, F_PUSH_A, W_IN1, W_D1);
+                    marg_of(r, ga ? a : b, W_IN0, F_PUSH_A, W_IN1, W_D1, W_IN2);
                     r.w[W_OUT] = 0;
                     if (push_from[ga ? a : b] >= 0) fold.push_back({recs.size() - 1, ga ? a : b});
                     int bit; r.w[W_VAL] = value_source(ga ? b : a, bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT;
@@ -952,6 +982,7 @@ struct Compiler {
                     r.w[W_FLAGS] |= F_PUSH_A;
                     r.w[W_C0] = const_matrix((int)iface(push_fac[v], 1), P.dim[v], P.dim[u]);
                     r.w[W_D1] = P.dim[u];
+                    r.w[W_IN1] = push_logdet(v);
                 } else
                     r.w[W_IN0] = P.marg_off[v];
                 r.w[W_N] = ent_coef[v];
@@ -1001,12 +1032,26 @@ struct Compiler {
             r.w[W_C0] = const_matrix((int)iface(f, 1), P.dim[v], P.dim[u]);
             r.w[W_IN0] = P.marg_off[u];
             r.w[W_OUT] = P.marg_off[v];
+            r.w[W_IN1] = push_logdet((int)v);
             ++P.n_push;
         }
         P.lazy_level = P.n_push ? lv : -1;
     }
     int derived_levels = 0;
     std::vector<int> push_from, push_fac;   // per variable: the variable whose marginal it is the image of (−1), through which `*` node
+    std::vector<int> push_ld;               // per variable: constant-pool offset of 2·log|det A| of a square, nonsingular map (−1: none; −2: not asked yet)
+    int push_logdet(int v) {
+        if (push_ld.empty()) push_ld.assign(nv, -2);
+        if (push_ld[v] != -2) return push_ld[v];
+        const int u = push_from[v], a = (int)iface(push_fac[v], 1);
+        double ld;
+        if (P.dim[v] == P.dim[u] && host_logabsdet(P.dim[v], cptr(a), &ld)) {
+            push_ld[v] = (int)P.cpool.size();
+            P.cpool.push_back(2.0 * ld);
+        } else
+            push_ld[v] = -1;
+        return push_ld[v];
+    }
 
     // the messages an op reads: (kind 0: descriptor word idx | kind 1: list entry idx, offset, dimension)
     struct In { int kind, idx, off, d; };

@@ -382,8 +382,10 @@ __device__ __forceinline__ bool spd_logdet(const double (&A)[N][N], double& logd
 // A marginal as the Bethe terms read it: (mean, covariance, log|V|) of the slot `off` — or, `push`, of the image of that marginal under the constant d × du
 // matrix at cpool + aoff: the output of `A * x` has the marginal (A m, A V Aᵀ) of x's (exact on a tree), so the marginals of such (anonymous) variables are
 // never stored for the free energy's sake; a singular image (more rows than columns) has log|V| = −∞, as the entropy of the message route.
+// ldoff ≥ 0: cpool[ldoff] = 2·log|det A| of a square map — log|A V Aᵀ| = log|V| + that, no Cholesky
 template <int N>
-__device__ __forceinline__ void load_marginal(const TreeParams& p, int off, bool push, int aoff, int du, int d, long long r, bool want_cov, double (&m)[N], double (&V)[N][N], double& ldV) {
+__device__ __forceinline__ void load_marginal(const TreeParams& p, int off, bool push, int aoff, int du, int d, long long r, bool want_cov, double (&m)[N], double (&V)[N][N], double& ldV,
+                                              int ldoff = -1) {
     if (!push) {
         ld_vec<N>(p.marg, off, d, p.RS, r, m);
         if (want_cov) {
@@ -401,6 +403,10 @@ __device__ __forceinline__ void load_marginal(const TreeParams& p, int off, bool
     ld_sym<N>(p.marg, off + du, du, p.RS, r, 0.0, Vu);
     matmul<N>(A, Vu, T1);
     matmulT<N>(T1, A, V);
+    if (ldoff >= 0) {
+        ldV = p.marg[(long long)(off + du + du * (du + 1) / 2) * p.RS + r] + p.cpool[ldoff];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -485,7 +491,13 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
             for (int i = 0; i < N; ++i)
 #pragma unroll
                 for (int j = 0; j < N; ++j) B[i][j] += Sg[i][j];
-            store_msg<N, STRAND>(p, w[W_OUT], d, r, a, B, fl, reg);
+            if (fl & F_OUT_WP) {   // every reader multiplies or marginalises in precision form: converted once here instead of once per reader
+                double Bi[N][N], t[N], ld;
+                ok = spd_inv<N>(B, Bi, ld) && ok;
+                matvec<N>(Bi, a, t);
+                store_msg<N, STRAND>(p, w[W_OUT], d, r, t, Bi, fl, reg);
+            } else
+                store_msg<N, STRAND>(p, w[W_OUT], d, r, a, B, fl, reg);
         } else {   // Λ' = Λ (Λ + W)⁻¹ W, ξ' = W (Λ + W)⁻¹ ξ: defined for a rank-deficient Λ, equal to (Λ⁻¹ + Σ)⁻¹ otherwise
             double G[N][N], Gi[N][N], t[N], xo[N], T1[N][N], Lo[N][N], ld;
 #pragma unroll
@@ -699,6 +711,10 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         matmulT<N>(T1, A, Vo);
         st_vec<N>(p.marg, w[W_OUT], d, p.RS, r, mo);
         st_sym<N>(p.marg, w[W_OUT] + d, d, p.RS, r, Vo);
+        if (w[W_IN1] >= 0) {   // a square map: log|A V Aᵀ| = log|V| + 2 log|det A|
+            p.marg[(long long)(w[W_OUT] + d + d * (d + 1) / 2) * p.RS + r] = p.marg[(long long)(w[W_IN0] + din + din * (din + 1) / 2) * p.RS + r] + p.cpool[w[W_IN1]];
+            break;
+        }
 #pragma unroll
         for (int i = 0; i < N; ++i)
             if (i >= d) Vo[i][i] = 1.0;
@@ -722,7 +738,7 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         ok = spd_inv<N>(P, Pi, ldP) && ok;
         double ma[N], mb[N], Vb[N][N], ldVb, unused;
         load_marginal<N>(p, w[W_VAL], fl & F_PUSH_A, w[W_IN1], w[W_LIST], d, r, false, ma, Vb, unused);
-        load_marginal<N>(p, w[W_VAL2], fl & F_PUSH_B, w[W_IN2], w[W_N], d, r, true, mb, Vb, ldVb);
+        load_marginal<N>(p, w[W_VAL2], fl & F_PUSH_B, w[W_IN2], w[W_N], d, r, true, mb, Vb, ldVb, (fl & F_PUSH_B) ? w[W_D1] : -1);
         double Dm[N][N], T2[N][N], E[N][N];
         matmul<N>(Pi, Wm, Dm);
 #pragma unroll
@@ -763,7 +779,7 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         load_noise<N>(p, w, d, r, false, true, Sg, Wm, el);
         if (op == OP_FE_NOISE1) {
             double m[N], V[N][N], c[N], ldV;
-            load_marginal<N>(p, w[W_IN0], fl & F_PUSH_A, w[W_IN1], w[W_D1], d, r, true, m, V, ldV);
+            load_marginal<N>(p, w[W_IN0], fl & F_PUSH_A, w[W_IN1], w[W_D1], d, r, true, m, V, ldV, (fl & F_PUSH_A) ? w[W_IN2] : -1);
             H = 0.5 * (d * (T_LOG2PI + 1.0) + ldV);
             if (fl & F_FOLD_ENT) H *= (double)(1 - w[W_OUT]);   // (−H of the node + coef·H of the variable, folded: −(1 − coef)·H below)
             load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, c);
@@ -798,7 +814,7 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         double ldV;
         if (fl & F_PUSH_A) {
             double m[N], V[N][N];
-            load_marginal<N>(p, w[W_IN0], true, w[W_C0], w[W_D1], d, r, true, m, V, ldV);
+            load_marginal<N>(p, w[W_IN0], true, w[W_C0], w[W_D1], d, r, true, m, V, ldV, w[W_IN1]);
         } else
             ldV = p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.RS + r];
         p.term[(long long)w[W_TERM] * p.RS + r] = (double)w[W_N] * 0.5 * (d * (T_LOG2PI + 1.0) + ldV);

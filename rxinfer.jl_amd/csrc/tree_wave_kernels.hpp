@@ -617,7 +617,7 @@ __device__ __forceinline__ void load_value(const Ctx& c, const TreeParams& p, in
 // the item when an image's covariance is wanted: callers form images first).  A singular image: log|V| = −∞.
 template <int DC>
 __device__ __forceinline__ double load_marginal(const Ctx& c, const TreeParams& p, int off, bool push, int aoff, int du, int d, long long r, bool want_cov, int vm, int vt, int MV,
-                                                int TA, int TB, int TC) {
+                                                int TA, int TB, int TC, int ldoff = -1) {
     const int LD = c.LD;
     if (!push) {
         l_vec(c, vm, p.marg, off, d, p.es, r * p.rs_marg);
@@ -637,6 +637,8 @@ __device__ __forceinline__ double load_marginal(const Ctx& c, const TreeParams& 
     if (!want_cov) return 0.0;
     matmul<DC>(c, TC, TA, false, TB, false, d, du, du);   // A V
     matmul<DC>(c, MV, TC, false, TA, true, d, du, d);     // A V Aᵀ
+    if (ldoff >= 0)   // a square map: log|A V Aᵀ| = log|V| + 2 log|det A| (the constant from the host) — no sweep
+        return p.marg[(long long)(off + du + du * (du + 1) / 2) * p.es + r * p.rs_marg] + p.cpool[ldoff];
     each(c, d, d, [&](int i, int j) { wlds[TB + i * LD + j] = 0.5 * (wlds[MV + i * LD + j] + wlds[MV + j * LD + i]); });
     w_sync();
     double ld;
@@ -697,7 +699,13 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         if (!wp) {
             add_mat(c, M0, M1, d, 1.0);
             w_sync();
-            store_msg<DC>(c, p, w[W_OUT], d, r, v0, M0);
+            if (fl & F_OUT_WP) {   // converted once for all its readers (tree_kernels.hpp)
+                double ld;
+                ok = spd_inv<DC>(c, M0, d, ld) && ok;
+                matvec(c, v1, M0, LD, 1, v0, d, d);
+                store_msg<DC>(c, p, w[W_OUT], d, r, v1, M0);
+            } else
+                store_msg<DC>(c, p, w[W_OUT], d, r, v0, M0);
         } else {   // Λ' = Λ (Λ + W)⁻¹ W, ξ' = W (Λ + W)⁻¹ ξ
             each(c, d, d, [&](int i, int j) { wlds[M2 + i * LD + j] = wlds[M0 + i * LD + j] + wlds[M1 + i * LD + j]; });
             w_sync();
@@ -855,7 +863,7 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = term;
     } break;
     case OP_MARG_PUSH: {   // the stored marginal of an `A * x` output, formed when a caller asks for it
-        const double ldV = load_marginal<DC>(c, p, w[W_IN0], true, w[W_C0], w[W_D1], d, r, true, v0, v1, M0, M1, M2, M3);
+        const double ldV = load_marginal<DC>(c, p, w[W_IN0], true, w[W_C0], w[W_D1], d, r, true, v0, v1, M0, M1, M2, M3, w[W_IN1]);
         s_vec(c, p.marg, w[W_OUT], d, p.es, r * p.rs_marg, v0);
         s_sym<DC>(c, p.marg, w[W_OUT] + d, d, p.es, r * p.rs_marg, M0);
         if (c.lane == 0) p.marg[(long long)(w[W_OUT] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg] = ldV;
@@ -864,7 +872,7 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
         // tree_kernels.hpp OP_FE_NOISE2M, op for op: the joint of a Gaussian node's two interfaces from ONE inbound message (side a) and the two marginals —
         // P = L_a + W, log|J| = log|P| − log|V_b|, Cov(a − b) = P⁻¹ + (P⁻¹W − I) V_b (P⁻¹W − I)ᵀ.  V_b → M2 first (an image needs every tile), then P⁻¹ → M0,
         // D = P⁻¹W − I → M3, D V_b → M1, E → M0.
-        const double ldVb = load_marginal<DC>(c, p, w[W_VAL2], fl & F_PUSH_B, w[W_IN2], w[W_N], d, r, true, v2, v4, M2, M0, M1, M3);   // m_b → v2
+        const double ldVb = load_marginal<DC>(c, p, w[W_VAL2], fl & F_PUSH_B, w[W_IN2], w[W_N], d, r, true, v2, v4, M2, M0, M1, M3, (fl & F_PUSH_B) ? w[W_D1] : -1);   // m_b → v2
         (void)load_marginal<DC>(c, p, w[W_VAL], fl & F_PUSH_A, w[W_IN1], w[W_LIST], d, r, false, v1, v4, M0, M0, M1, M3);             // m_a → v1
         if (w[W_IN0] >= 0) ok = load_msg<DC>(c, p, w[W_IN0], fl & F_IN0_WP, true, d, r, v0, M0);
         else zero_mat(c, M0, d);
@@ -910,7 +918,7 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
     case OP_FE_NOISE0: {
         double H = 0.0;
         if (op == OP_FE_NOISE1) {   // (the marginal first: an image of another marginal needs every tile)
-            const double ldV = load_marginal<DC>(c, p, w[W_IN0], fl & F_PUSH_A, w[W_IN1], w[W_D1], d, r, true, v0, v4, M0, M1, M2, M3);
+            const double ldV = load_marginal<DC>(c, p, w[W_IN0], fl & F_PUSH_A, w[W_IN1], w[W_D1], d, r, true, v0, v4, M0, M1, M2, M3, (fl & F_PUSH_A) ? w[W_IN2] : -1);
             H = 0.5 * (d * (T_LOG2PI + 1.0) + ldV);
             if (fl & F_FOLD_ENT) H *= (double)(1 - w[W_OUT]);
             load_value(c, p, w[W_VAL], fl & F_VAL_SLOT, d, r, v1);
@@ -935,7 +943,7 @@ __device__ __forceinline__ void eval_fe(const Ctx& c, const TreeParams& p, const
     } break;
     case OP_FE_ENT: {
         double ldV;
-        if (fl & F_PUSH_A) ldV = load_marginal<DC>(c, p, w[W_IN0], true, w[W_C0], w[W_D1], d, r, true, v0, v4, M0, M1, M2, M3);
+        if (fl & F_PUSH_A) ldV = load_marginal<DC>(c, p, w[W_IN0], true, w[W_C0], w[W_D1], d, r, true, v0, v4, M0, M1, M2, M3, w[W_IN1]);
         else ldV = p.marg[(w[W_IN0] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg];
         if (c.lane == 0) p.term[(long long)w[W_TERM] * p.es + r * p.rs_term] = (double)w[W_N] * 0.5 * (d * (T_LOG2PI + 1.0) + ldV);
     } break;

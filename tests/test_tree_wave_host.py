@@ -138,7 +138,7 @@ def build_program(d, d1, seed):
         st.op(OP_LEAF, d, out=new_msg(d), val=y0, flags=F_VAL_SLOT | wp, c0=noise)
         st.op(OP_LEAF, d, out=new_msg(d), val=cv, flags=wp, prec=ps)
     # the additive rule in both forms, constant noise and a precision variable's
-    for wp in (0, F_IN0_WP | F_OUT_WP):
+    for wp in (0, F_IN0_WP | F_OUT_WP, F_OUT_WP):   # (moments in, precision form out: the conversion done once at the producer)
         st.op(OP_NOISE, d, in0=st.message(d), out=new_msg(d), flags=wp, c0=noise)
         st.op(OP_NOISE, d, in0=st.message(d), out=new_msg(d), flags=wp, prec=ps)
     for wp in (0, F_IN0_WP):
@@ -177,17 +177,27 @@ def build_program(d, d1, seed):
     # round 6: the one-message joint term with stored and with image marginals (the marginal of `A * x` as the image of x's), entropy folded in; the stored
     # marginal of an image; the image in the one-interface term and in the entropy term; a Gaussian node under q(out) q(μ) — its leaf rule and average energy
     mg2, mgs = st.marginal(d), st.marginal(d)   # (images through a SQUARE map: with more rows than columns the image is singular and its log-determinant −∞ by design)
-    A2 = st.const(rng.standard_normal((d, d)))
+    A2m = rng.standard_normal((d, d))
+    A2 = st.const(A2m)
+    pairs = []   # (term computed with a Cholesky of the image, the same term with log|A V A'| = log|V| + 2 log|det A| from the constant pool)
+    for ld in (-1, st.const(np.array([2.0 * np.linalg.slogdet(A2m)[1]]))):
+        these = []
+        term = lambda: these.append(new_term()) or these[-1]
+        msgs = [st.message(d) for _ in range(2)] if ld < 0 else msgs
+        for f, m in zip((0, F_IN0_WP), msgs):
+            st.op(OP_FE_NOISE2M, d, d1=ld, in0=m, val=mg2, val2=mgs, in2=A2, n=d, flags=f | F_PUSH_B | F_FOLD_ENT, out=1, c0=noise, term=term())
+            st.op(OP_FE_NOISE2M, d, d1=-1, in0=m, val=mgs, in1=A2, list=d, val2=mg, flags=f | F_PUSH_A, c0=noise, term=new_term(), out=0)
+            stats.append(st.slot("stat", d * d))
+            st.op(OP_FE_NOISE2M, d, d1=ld, in0=m, val=mg, val2=mgs, in2=A2, n=d, flags=f | F_PUSH_B | F_STAT, prec=ps, c1=stats[-1], term=term(), out=0)
+        st.op(OP_MARG_PUSH, d, d1=d, in0=mgs, in1=ld, c0=A2, out=st.slot("marg", msz(d) + 1))
+        these.append(("marg", st.ops[-1][W_OUT] + msz(d)))
+        st.op(OP_FE_NOISE1, d, d1=d, in0=mgs, in1=A2, in2=ld, val=y0, flags=F_VAL_SLOT | F_PUSH_A | F_FOLD_ENT, out=2, c0=noise, term=term())
+        st.op(OP_FE_ENT, d, d1=d, in0=mgs, in1=ld, c0=A2, n=3, flags=F_PUSH_A, term=term())
+        pairs.append(these)
+    st.same = list(zip(*pairs))
     for f in (0, F_IN0_WP):
         st.op(OP_FE_NOISE2M, d, in0=st.message(d), val=mg, val2=mg2, flags=f, c0=noise, term=new_term(), out=0)
-        st.op(OP_FE_NOISE2M, d, in0=st.message(d), val=mg2, val2=mgs, in2=A2, n=d, flags=f | F_PUSH_B | F_FOLD_ENT, out=1, c0=noise, term=new_term())
-        st.op(OP_FE_NOISE2M, d, in0=st.message(d), val=mgs, in1=A2, list=d, val2=mg, flags=f | F_PUSH_A, c0=noise, term=new_term(), out=0)
-        stats.append(st.slot("stat", d * d))
-        st.op(OP_FE_NOISE2M, d, in0=st.message(d), val=mg, val2=mgs, in2=A2, n=d, flags=f | F_PUSH_B | F_STAT, prec=ps, c1=stats[-1], term=new_term(), out=0)
     st.op(OP_FE_NOISE2M, d, in0=-1, val=mg, val2=mg2, flags=0, c0=noise, term=new_term(), out=0)
-    st.op(OP_MARG_PUSH, d, d1=d, in0=mgs, c0=A2, out=st.slot("marg", msz(d) + 1))
-    st.op(OP_FE_NOISE1, d, d1=d, in0=mgs, in1=A2, val=y0, flags=F_VAL_SLOT | F_PUSH_A | F_FOLD_ENT, out=2, c0=noise, term=new_term())
-    st.op(OP_FE_ENT, d, d1=d, in0=mgs, c0=A2, n=3, flags=F_PUSH_A, term=new_term())
     st.op(OP_FE_NOISE_MF, d, val=mg, val2=mg2, c0=noise, term=new_term())
     stats.append(st.slot("stat", d * d))
     st.op(OP_FE_NOISE_MF, d, val=mg2, val2=mg, flags=F_STAT, prec=ps, c1=stats[-1], term=new_term())
@@ -223,6 +233,13 @@ def test_every_op_matches_the_register_bodies(lib, d, d1):
         err = np.max(np.abs(a - b) / scale)
         assert err < 1e-11 * n, (kind, err)
         assert np.any(a != 0.0) or st.size[kind] == 0, kind
+    # a square map's image: the log-determinant by addition gives the term the Cholesky of the image gives
+    for which in (ref, got):
+        for a, b in st.same:
+            ka, oa = a if isinstance(a, tuple) else ("term", a)
+            kb, ob = b if isinstance(b, tuple) else ("term", b)
+            va, vb = which[ka][oa, :st.R], which[kb][ob, :st.R]
+            assert np.allclose(va, vb, rtol=1e-10, atol=1e-10 * n), (a, b, va, vb)
 
 
 def test_a_matrix_that_is_not_positive_definite_is_reported(lib):
