@@ -1616,6 +1616,16 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
         if (const char* q = hook_env("RXHIP_TREE_RB")) e->rb = e->rb_fe = std::max(16, std::min(256, std::atoi(q) / 16 * 16));
         if (const char* q = hook_env("RXHIP_TREE_WG")) e->wg = (std::atoi(q) >= 512 && P.dmax <= 4) ? 512 : 256;   // (the 8×8 instance is built for 256 threads)
     }
+    if (const char* path = hook_env("RXHIP_TREE_DUMP")) {   // (test hook) the schedule, a line per level: the opcodes of its ops — read next to a kernel trace of mode 0
+        if (FILE* fp = std::fopen(path, "w")) {
+            for (int l = 0; l < P.n_levels; ++l) {
+                std::fprintf(fp, "%d%s", l, l >= P.fe_level ? " fe" : "");
+                for (int i = P.lvl_ptr[l]; i < P.lvl_ptr[l + 1]; ++i) std::fprintf(fp, " %d:%d", P.ops[(size_t)i * OP_WORDS + W_OP], P.ops[(size_t)i * OP_WORDS + W_FLAGS]);
+                std::fprintf(fp, "\n");
+            }
+            std::fclose(fp);
+        }
+    }
     auto cleanup = [&](rxhip_status st) { destroy(e); return st; };
     if (stream) e->stream = (hipStream_t)stream;
     else {
