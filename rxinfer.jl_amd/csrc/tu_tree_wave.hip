@@ -1,10 +1,36 @@
-// tu_tree_wave.hip — one dimension class of the executor's LDS-staged kernels (tree_wave_kernels.hpp): -DRXHIP_TU_DC=16 | 32 | 64.
+// tu_tree_wave.hip — one dimension class of the executor's wavefront-per-item kernels: -DRXHIP_TU_DC=16 | 32 | 64 (register tiles: tree_tile_kernels.hpp; LDS-staged:
+// tree_wave_kernels.hpp).
 #include "tree_wave.hpp"
-#include "tree_wave_kernels.hpp"
 
 #ifndef RXHIP_TU_DC
 #error "RXHIP_TU_DC: 16, 32 or 64"
 #endif
+#ifndef RXHIP_TILE_MAX
+#define RXHIP_TILE_MAX 16   // dimension classes up to this one run the register-tile kernels (tree_tile_kernels.hpp), the ones above the LDS-staged kernels
+#endif
+
+#if RXHIP_TU_DC <= RXHIP_TILE_MAX
+#include "tree_tile_kernels.hpp"
+namespace rxhip {
+namespace tree {
+namespace wave {
+namespace {
+constexpr int NT = RXHIP_TU_DC / 16;
+using namespace rxhip::tree::tile;
+
+hipError_t prepare(int) { return hipSuccess; }
+void ops(int phase, const TreeParams& p, int o0, int o1, int, unsigned blocks, hipStream_t stream) {
+    if (phase == 0) hipLaunchKernelGGL((k_tile_ops<0, NT>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+    else hipLaunchKernelGGL((k_tile_ops<1, NT>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+}
+void walk(int phase, const TreeParams& p, int o0, int o1, int, unsigned blocks, hipStream_t stream) {
+    if (phase == 0) hipLaunchKernelGGL((k_tile_walk<0, NT>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+    else hipLaunchKernelGGL((k_tile_walk<1, NT>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+}
+const WaveVtbl VT = {prepare, ops, walk};
+}  // namespace
+#else
+#include "tree_wave_kernels.hpp"
 
 namespace rxhip {
 namespace tree {
@@ -29,6 +55,7 @@ void walk(int phase, const TreeParams& p, int o0, int o1, int dmax, unsigned blo
 }
 const WaveVtbl VT = {prepare, ops, walk};
 }  // namespace
+#endif
 
 #if RXHIP_TU_DC == 16
 const WaveVtbl* wave_vt16() { return &VT; }
