@@ -892,7 +892,11 @@ def compact_line(out):
     line["roofline"]["per_config"] = per   # [ms, roofline fraction (null: a time, not a roofline), parity ok] per configuration
     if ex:
         line["extra"] = ex
-    return _slim(line)
+    slim = _slim(line)
+    for k in ("achieved", "peak", "frac"):   # (the dominant kernel's roofline keeps its digits: frac = achieved / peak exactly)
+        if k in line["roofline"]:
+            slim["roofline"][k] = line["roofline"][k]
+    return slim
 
 
 def _join_background(o):

@@ -437,7 +437,7 @@ typedef struct {
     int64_t n_ops, n_levels, n_messages;  /* ops of one iteration, dependency levels, stored messages */
     int64_t doubles_per_replica;          /* device state per replica */
     int64_t bytes_per_sweep;              /* message traffic of one iteration per replica in the engine's schedule: 8·(d + d(d+1)/2) per message a rule reads from or writes to HBM */
-    int32_t dmax;                         /* kernel instance: 1, 2, 4 or 8 (registers); above 8 the graph's largest dimension (LDS-staged kernels) */
+    int32_t dmax;                         /* kernel instance: 1, 2, 4 or 8 (a lane per item); above 8 the graph's largest dimension (a wavefront or workgroup per item: `kernels`) */
     int32_t mode;                         /* schedule of the sweep phase — 0: one launch per level; 1: one launch per phase, workgroup-resident levels (dmax ≤ 8); 2: a lane (dmax ≤ 8)
                                              or a wavefront per replica walks the schedule; 3 (dmax ≤ 4: the default): strands — a lane per (strand, replica) walks a path of
                                              dependent ops with the message in registers, one launch per strand level; bytes_per_sweep then counts what THAT schedule moves.
@@ -448,6 +448,9 @@ typedef struct {
     int64_t io_bytes_per_sweep;           /* the floor of ANY schedule, per replica: the data in, the posteriors (mean, packed covariance, log-determinant) of the named variables out */
     int64_t n_strands, n_strand_levels;   /* mode 3: the sweep cut into strands of dependent ops (a lane walks a strand, messages handed over in registers), their dependency levels */
     int32_t longest_strand;               /* ops of the longest strand */
+    int32_t kernels;                      /* which kernels run this engine — 0: a lane per (op, replica), matrices in the lane's registers (dmax ≤ 8; from 5 on only above
+                                             1 024 replicas); 1: a wavefront per (op, replica), matrices in registers in the matrix cores' accumulator layout (5 … 32);
+                                             2: a workgroup of four wavefronts per (op, replica), matrices staged in LDS (33 … 64); −1 from rxhip_tree_plan (chosen with the batch) */
     int64_t strand_bytes_per_sweep;       /* bytes_per_sweep of the strand schedule, whichever mode runs */
     int64_t fe_bytes_per_sweep;           /* what the second phase (Bethe terms, q(W) updates, the sum) reads and writes per replica: messages, marginals, data values, terms, statistics */
 } rxhip_tree_info;

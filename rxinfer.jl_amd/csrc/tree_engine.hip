@@ -1333,7 +1333,8 @@ struct Engine {
     bool have_data = false, ran = false;
     bool cont = false;   // rxhip_tree_continue: later runs go on from the q(W) the previous run ended with
     bool allow_missing = false;   // created with rxhip_graph_desc.allow_missing: NaN in the data is `missing`
-    bool elem_fast = false;   // dimensions above 8: a replica's slots contiguous (TreeParams es = 1), so that a wavefront's loads of a message coalesce
+    bool tiled = false;       // the wavefront-per-item kernels run this engine (dimensions above 8; 5 … 8: see create)
+    bool elem_fast = false;   // … and with them: a replica's slots contiguous (TreeParams es = 1), so that a wavefront's loads of a message coalesce
     bool push_done = false;   // the image marginals (OP_MARG_PUSH, first level of the second phase) are those of the last sweep
     int last_iterations = 0, last_want_fe = 0;
     std::vector<char> data_set;
@@ -1517,7 +1518,7 @@ void launch_levels(const Engine* e, const TreeParams& p, int l0, int l1) {   // 
     else launch_phase<N, 1>(e, p, std::max(l0, lf), l1);
 }
 void launch(const Engine* e, const TreeParams& p, int l0, int l1) {
-    if (e->prog.dmax > 8) {
+    if (e->tiled) {
         const int lf = e->prog.fe_level;
         launch_wave_phase(e, p, 0, l0, std::min(l1, lf));
         launch_wave_phase(e, p, 1, std::max(l0, lf), l1);
@@ -1558,7 +1559,12 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     if (e->R > (long long)FE_CHUNK * FE_CHUNK) { err = "more than 16 777 216 replicas in one engine"; delete e; return RXHIP_ERR_UNSUPPORTED; }   // (two-stage free-energy sum)
     e->RS = (e->R + 15) / 16 * 16;
     const Program& P = e->prog;
-    e->elem_fast = P.dmax > 8;
+    // Dimensions 5 … 8: the lane-per-item instance holds 8×8 blocks in one lane's registers (it spills, and a batch of 256 replicas is four wavefronts); a wavefront
+    // per item on register tiles is 2 – 3 × faster up to ≈ 1 000 replicas (d = 8, T = 64, two branches: one replica 2.5 → 0.9 ms, 256: 3.1 → 1.2), the lanes win
+    // once the replicas fill the device (4 096: 3.4 against 5.4 ms; 65 536: 16 against 83): profiles/r06/tree_tile.txt
+    e->tiled = P.dmax > 8 || (P.dmax > 4 && e->R <= 1024);
+    if (const char* t = hook_env("RXHIP_TREE_TILE")) e->tiled = P.dmax > 8 || (P.dmax > 4 && std::atoi(t) != 0);
+    e->elem_fast = e->tiled;
     e->allow_missing = g->allow_missing != 0;
     // schedule: deep graphs walk their levels inside a workgroup (one launch per iteration); wide, shallow ones take a launch per level
     const double avg_width = (double)P.n_ops / std::max(1, P.n_levels);
@@ -1583,14 +1589,17 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     // the Bethe phase is one wide level of independent terms and a short sum tree: there the walk is ahead from 65 536 replicas on (2.05 against 2.69 ms), the
     // sweep only from 131 072 (scripts/time_tree_phases.py)
     e->mode_fe = (e->mode == 1 && e->R >= 65536) ? 2 : e->mode;
-    if (P.dmax > 8) {
+    if (e->tiled) {
         // wavefront per item: a launch per level — a rule at d = 16 is ≈ 17 µs of dependent LDS round trips inside its wavefront, more than a launch, so
         // the walk (one wavefront per replica, ops in sequence) only pays once the replicas alone fill the device (measured: profiles/r05/tree_wave_modes.txt)
         // (round 6, items of 1 / 2 / 4 wavefronts: up to 16 a launch per level stays ahead at every batch — 28.3 against 35.3 ms at 4 096 replicas; above, the walk from
         //  2 048 replicas — d = 32: 33.8 against 37.1 ms; profiles/r06/tree_wave_modes.txt)
-        e->mode = (P.dmax > 16 && e->R >= 2048) ? 2 : 0;
+        // (register tiles up to 32 — tree_tile_kernels.hpp: d = 16: 1.5 against 2.9 ms at 256 replicas, 8.5 against 7.0 at 4 096; d = 32: 2.1 against 4.1 at 256, 10.8 against 9.7 at
+        //  2 048; the LDS-staged class above: 7.9 against 7.3 at 256 — a workgroup per CU already)
+        //  (crossover: d = 16: 2 048 replicas — 4.55 against 4.45 ms; d = 32: 1 024 — 5.8 against 4.9: profiles/r06/tree_tile.txt)
+        e->mode = (e->R >= (P.dmax > 32 ? 256 : P.dmax > 16 ? 1024 : 2048)) ? 2 : 0;
     }
-    if (P.dmax > 8) e->mode_fe = e->mode;
+    if (e->tiled) e->mode_fe = e->mode;
     // the strand schedule (register hand-over along dependent ops, wide levels at full occupancy): from the batches at which two long strands fill the device
     // (at every batch: a T = 128 chain of ONE replica is 0.60 ms in strands — its two recursions are two lanes walking 382 dependent ops — against 1.9 ms for
     //  workgroup-resident levels and ≈ 1.5 ms for 390 launches; 256 replicas 0.63 against 1.86; 65 536: 2.3 against 3.9: profiles/r06/tree_strands.txt)
@@ -1603,8 +1612,8 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     if (e->mode == 3 && P.dmax > 4) e->mode = 2;                  // (the strand kernel carries a message in registers: instances 1, 2, 4)
     if (e->mode_fe == 3) e->mode_fe = e->R >= 131072 ? 2 : 0;    // (the Bethe phase is one wide level of independent terms: no strands to speak of)
     if (const char* m = hook_env("RXHIP_TREE_MODE_FE")) e->mode_fe = std::max(0, std::min(2, std::atoi(m)));
-    if (P.dmax > 8 && e->mode == 1) e->mode = e->mode_fe = 2;   // (no workgroup-resident schedule for the LDS-staged kernels)
-    if (P.dmax > 8 && e->mode_fe == 1) e->mode_fe = 2;
+    if (e->tiled && e->mode == 1) e->mode = e->mode_fe = 2;   // (no workgroup-resident schedule for the LDS-staged kernels)
+    if (e->tiled && e->mode_fe == 1) e->mode_fe = 2;
     {
         // Workgroups of the resident schedule.  Sweep phase, from 4 096 replicas: 512 threads owning R / 256 replicas (≤ 256) — one workgroup of eight wavefronts
         // per CU; below, and for the Bethe phase: 256 threads owning R / 512 replicas (≤ 128).  Measured optimum at every batch from 4 096 to 65 536 replicas
@@ -1633,7 +1642,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
         e->own_stream = true;
     }
     rxhip_status st;
-    if (P.dmax > 8 && (st = wave_attributes(P.dmax, err))) return cleanup(st);
+    if (e->tiled && (st = wave_attributes(P.dmax, err))) return cleanup(st);
     if ((st = upload(&e->d_sops, P.sops, err)) || (st = upload(&e->d_strands, P.strands, err))) return cleanup(st);
     if ((st = upload(&e->d_ops, P.ops, err)) || (st = upload(&e->d_aux, P.aux, err)) || (st = upload(&e->d_lvl, P.lvl_ptr, err)) || (st = upload(&e->d_cpool, P.cpool, err)) ||
         (st = upload(&e->d_prec_init, P.prec_init, err)) || (st = upload(&e->d_marg_init, P.marg_init, err)) || (st = zalloc(&e->d_msg, P.msg_doubles * e->RS, err)) || (st = zalloc(&e->d_marg, P.marg_doubles * e->RS, err)) ||
@@ -1923,6 +1932,7 @@ void info(Engine* e, rxhip_tree_info* out) {
     out->n_strands = (int64_t)(P.strands.size() / 2);
     out->n_strand_levels = (int64_t)P.slvl_ptr.size() - 1;
     out->longest_strand = P.longest_strand;
+    out->kernels = e->mode < 0 ? -1 : !e->tiled ? 0 : P.dmax <= 32 ? 1 : 2;
     out->strand_bytes_per_sweep = P.bytes_per_sweep_strands;
     out->fe_bytes_per_sweep = P.fe_bytes;
     out->dmax = P.dmax; out->mode = e->mode; out->replicas_per_workgroup = e->rb;

@@ -6,7 +6,7 @@
 #error "RXHIP_TU_DC: 16, 32 or 64"
 #endif
 #ifndef RXHIP_TILE_MAX
-#define RXHIP_TILE_MAX 16   // dimension classes up to this one run the register-tile kernels (tree_tile_kernels.hpp), the ones above the LDS-staged kernels
+#define RXHIP_TILE_MAX 32   // dimension classes up to this one run the register-tile kernels (tree_tile_kernels.hpp), the ones above the LDS-staged kernels
 #endif
 
 #if RXHIP_TU_DC <= RXHIP_TILE_MAX

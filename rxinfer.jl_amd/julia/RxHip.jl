@@ -812,6 +812,7 @@ struct TreeInfo
     n_strands::Int64
     n_strand_levels::Int64
     longest_strand::Int32
+    kernels::Int32
     strand_bytes_per_sweep::Int64
     fe_bytes_per_sweep::Int64
 end

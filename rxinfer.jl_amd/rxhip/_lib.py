@@ -114,7 +114,7 @@ class TreeInfo(ctypes.Structure):   # rxhip_tree_info
     _fields_ = [("n_ops", ctypes.c_int64), ("n_levels", ctypes.c_int64), ("n_messages", ctypes.c_int64), ("doubles_per_replica", ctypes.c_int64),
                 ("bytes_per_sweep", ctypes.c_int64), ("dmax", ctypes.c_int32), ("mode", ctypes.c_int32), ("replicas_per_workgroup", ctypes.c_int32),
                 ("n_precision_vars", ctypes.c_int32), ("last_iteration_ms", ctypes.c_double), ("io_bytes_per_sweep", ctypes.c_int64),
-                ("n_strands", ctypes.c_int64), ("n_strand_levels", ctypes.c_int64), ("longest_strand", ctypes.c_int32), ("strand_bytes_per_sweep", ctypes.c_int64), ("fe_bytes_per_sweep", ctypes.c_int64)]
+                ("n_strands", ctypes.c_int64), ("n_strand_levels", ctypes.c_int64), ("longest_strand", ctypes.c_int32), ("kernels", ctypes.c_int32), ("strand_bytes_per_sweep", ctypes.c_int64), ("fe_bytes_per_sweep", ctypes.c_int64)]
 
 
 class RuleCall(ctypes.Structure):   # rxhip_rule_call

@@ -53,9 +53,12 @@ def eng_gauss(gb):
     return {v for v in range(len(gb.kind)) if g.gauss[v]}
 
 
-def _mode_run(mode, gb):
-    """the schedule an engine reports for a requested one: strands (3) exist for the register instances up to 4×4, above the walk takes over"""
+def _mode_run(mode, gb, eng=None):
+    """the schedule an engine reports for a requested one: strands (3) exist for the lane-per-item instances up to 4×4, above the walk takes over; the
+    wavefront-per-item kernels (info.kernels != 0: dimensions 5 … 8 up to 1 024 replicas, and everything above 8) have no workgroup-resident schedule (1)"""
     dmx = max(gb.rows[v] for v in range(len(gb.kind)) if gb.kind[v] != 2)
+    if eng is not None and eng.info["kernels"] != 0 and mode in (1, 3):
+        return 2
     return 2 if (mode == 3 and dmx > 4) else mode
 
 
@@ -70,7 +73,7 @@ def test_unsupported_shapes_against_the_oracle(builder, kw, mode, monkeypatch):
     gb, ys, _ = builder(**kw)
     R = 5
     eng, data = _run(gb, ys, R, mode=mode, monkeypatch=monkeypatch)
-    assert eng.info["mode"] == _mode_run(mode, gb)
+    assert eng.info["mode"] == _mode_run(mode, gb, eng)
     finite_fe = not (builder is tg.branching_tree and kw.get("d", 1) > 1)   # (B x with more rows than columns: H[q(Bx)] = −∞, in the reference too)
     if finite_fe:
         ref = _check(gb, ys, eng, data, replicas=(0, R - 1))
@@ -263,7 +266,7 @@ def test_random_forests_against_the_oracle(seed, monkeypatch):
     mode = (seed // 5) % 4 if dmax <= 8 else (0, 2)[(seed // 5) % 2]
     R = 3
     eng, data = _run(gb, ys, R, iterations=its, mode=mode, monkeypatch=monkeypatch, seed=seed)
-    assert eng.info["mode"] == _mode_run(mode, gb)
+    assert eng.info["mode"] == _mode_run(mode, gb, eng)
     ref = _check(gb, ys, eng, data, iterations=its, replicas=(0, R - 1), prec_vars=named["W"])
     assert eng.counters()["rule_calls"] == ref["counters"]["rule_calls"] * R * its
     fe_it = eng.free_energy()

@@ -1,4 +1,5 @@
-"""The node-array executor at dimensions above 8 (csrc/tree_wave_kernels.hpp: a wavefront per op and replica, matrices staged in LDS) through the C ABI
+"""The node-array executor on its wavefront-per-item kernels (csrc/tree_tile_kernels.hpp: register tiles, dimensions 5 … 32; csrc/tree_wave_kernels.hpp:
+LDS-staged, 33 … 64) through the C ABI
 against oracle/tree_oracle.py and against the specialised engines — both schedules (a launch per level / a wavefront per replica walks the schedule),
 dimensions 9 … 64, several replicas, VMP over precision variables, the single-rule entry point.
 
@@ -28,20 +29,55 @@ def test_dimensions_above_8_against_the_oracle(builder, kw, R, mode, monkeypatch
 
 def test_default_schedule_and_workgroup_mode_request(monkeypatch):
     """without the test hook: a launch per level until the replicas alone fill the device; the workgroup-resident schedule (mode 1) does not exist for
-    these kernels and maps to the walk"""
+    these kernels and maps to the walk.  info.kernels: 1 = register tiles (a wavefront per item, 5 … 32), 2 = LDS-staged (33 … 64), 0 = a lane per item"""
     from rxhip.tree import TreeEngine
     gb, ys, _ = tg.two_branch_chain(T=2, d=10, dy1=10, dy2=4)
     monkeypatch.delenv("RXHIP_TREE_MODE", raising=False)
+    monkeypatch.delenv("RXHIP_TREE_TILE", raising=False)
     with TreeEngine(gb, n_replicas=1) as eng:
+        assert eng.info["mode"] == 0 and eng.info["kernels"] == 1
+    with TreeEngine(gb, n_replicas=1024) as eng:
         assert eng.info["mode"] == 0
-    with TreeEngine(gb, n_replicas=4096) as eng:
-        assert eng.info["mode"] == 0          # (up to d = 16 a launch per level stays ahead at every batch)
+    with TreeEngine(gb, n_replicas=2048) as eng:
+        assert eng.info["mode"] == 2          # a wavefront per replica walks the schedule once the replicas fill the device (d ≤ 16: from 2 048)
     gb32, _, _ = tg.two_branch_chain(T=2, d=20, dy1=20, dy2=4)
-    with TreeEngine(gb32, n_replicas=2048) as eng:
-        assert eng.info["mode"] == 2          # above: a work item per replica walks the schedule once the replicas fill the device
+    with TreeEngine(gb32, n_replicas=512) as eng:
+        assert eng.info["mode"] == 0 and eng.info["kernels"] == 1
+    with TreeEngine(gb32, n_replicas=1024) as eng:
+        assert eng.info["mode"] == 2          # (17 … 32: from 1 024)
+    gb64, _, _ = tg.two_branch_chain(T=2, d=40, dy1=40, dy2=4)
+    with TreeEngine(gb64, n_replicas=8) as eng:
+        assert eng.info["mode"] == 0 and eng.info["kernels"] == 2
+    with TreeEngine(gb64, n_replicas=256) as eng:
+        assert eng.info["mode"] == 2          # (a workgroup per item: 256 of them are one per CU)
     monkeypatch.setenv("RXHIP_TREE_MODE", "1")
     with TreeEngine(gb, n_replicas=3) as eng:
         assert eng.info["mode"] == 2
+    # dimensions 5 … 8: register tiles up to 1 024 replicas, a lane per item above
+    monkeypatch.delenv("RXHIP_TREE_MODE", raising=False)
+    gb6, _, _ = tg.two_branch_chain(T=2, d=6, dy1=6, dy2=4)
+    with TreeEngine(gb6, n_replicas=1024) as eng:
+        assert eng.info["kernels"] == 1 and eng.info["mode"] == 0 and eng.info["dmax"] == 6
+    with TreeEngine(gb6, n_replicas=1025) as eng:
+        assert eng.info["kernels"] == 0 and eng.info["dmax"] == 8
+    gb4, _, _ = tg.two_branch_chain(T=2, d=4, dy1=4, dy2=4)
+    with TreeEngine(gb4, n_replicas=1) as eng:
+        assert eng.info["kernels"] == 0 and eng.info["mode"] == 3
+
+
+@pytest.mark.parametrize("tile", [0, 1])
+@pytest.mark.parametrize("mode", [0, 2])
+@pytest.mark.parametrize("builder,kw,R", [(tg.two_branch_chain, dict(T=5, d=8, dy1=8, dy2=5), 5), (tg.two_branch_chain, dict(T=6, d=6, dy1=3, dy2=5), 70),
+                                          (tg.two_branch_chain, dict(T=4, d=5, dy1=5, dy2=5, precision_spelling=True), 3), (tg.star, dict(n_leaves=40, d=7), 3)])
+def test_dimensions_5_to_8_on_either_kernel_family(builder, kw, R, mode, tile, monkeypatch):
+    """both kernel families on the same graphs against the oracle, whichever the batch would pick"""
+    monkeypatch.setenv("RXHIP_TREE_TILE", str(tile))
+    gb, ys, _ = builder(**kw)
+    eng, data = _run(gb, ys, R, mode=mode, monkeypatch=monkeypatch)
+    assert eng.info["mode"] == mode and eng.info["kernels"] == tile
+    ref = _check(gb, ys, eng, data, replicas=(0, R - 1), tol=1e-9, tol_fe=1e-10)
+    assert eng.counters()["rule_calls"] == ref["counters"]["rule_calls"] * R
+    eng.close()
 
 
 @pytest.mark.parametrize("d,dy,T,R,mode", [(12, 12, 20, 3, 0), (16, 8, 15, 70, 2), (24, 24, 6, 1, 2)])
