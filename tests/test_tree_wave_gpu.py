@@ -57,7 +57,7 @@ def test_default_schedule_and_workgroup_mode_request(monkeypatch):
     monkeypatch.delenv("RXHIP_TREE_MODE", raising=False)
     gb6, _, _ = tg.two_branch_chain(T=2, d=6, dy1=6, dy2=4)
     with TreeEngine(gb6, n_replicas=1024) as eng:
-        assert eng.info["kernels"] == 1 and eng.info["mode"] == 0 and eng.info["dmax"] == 6
+        assert eng.info["kernels"] == 1 and eng.info["mode"] == 0 and eng.info["dmax"] == 8   # (dmax: the instance class — 1, 2, 4, 8 — up to 8)
     with TreeEngine(gb6, n_replicas=1025) as eng:
         assert eng.info["kernels"] == 0 and eng.info["dmax"] == 8
     gb4, _, _ = tg.two_branch_chain(T=2, d=4, dy1=4, dy2=4)
