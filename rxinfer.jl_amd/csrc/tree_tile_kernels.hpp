@@ -41,11 +41,12 @@ template <int NT>
 struct VecK {  // k[t][r] = v[16 t + q + 4 r]
     double k[NT][4];
 };
-// what a lane knows about itself: its place in the tile and, per element it holds, the packed-triangle index e = hi (hi + 1) / 2 + lo with hi in the upper half
+// what a lane knows about itself: its place in the tile and, per element it holds, the BYTE offset 8·e of the packed-triangle element e = hi (hi + 1) / 2 + lo
+// (hi < d  ⇔  e < d (d + 1) / 2: the offset alone says whether the element exists)
 template <int NT>
 struct Lane {
     int q, il;
-    int pk[NT][NT][4];   // e | hi << 16   (hi = max(i, j) < 32, e < 528)
+    unsigned e8[NT][NT][4];
 };
 template <int NT>
 __device__ __forceinline__ Lane<NT> make_lane() {
@@ -60,9 +61,20 @@ __device__ __forceinline__ Lane<NT> make_lane() {
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * ti + L.q + 4 * r, j = 16 * tj + L.il;
                 const int hi = i > j ? i : j, lo = i > j ? j : i;
-                L.pk[ti][tj][r] = (hi * (hi + 1) / 2 + lo) | (hi << 16);
+                L.e8[ti][tj][r] = 8u * (unsigned)(hi * (hi + 1) / 2 + lo);
             }
     return L;
+}
+// element at byte offset off8 of a slot: ES1 (the engines' element-fastest storage, and the constant pool) — scalar base + 32-bit lane offset, no address
+// arithmetic; else element stride es (rxhip_rule_eval's replica-fastest one-node schedules)
+template <bool ES1>
+__device__ __forceinline__ double ldg(const double* b, long long es, unsigned off8) {
+    return ES1 ? *(const double*)((const char*)b + off8) : b[(long long)(off8 >> 3) * es];
+}
+template <bool ES1>
+__device__ __forceinline__ void stg(double* b, long long es, unsigned off8, double x) {
+    if (ES1) *(double*)((char*)b + off8) = x;
+    else b[(long long)(off8 >> 3) * es] = x;
 }
 
 // LDS: the row a pivot publishes, in natural order (R[j]) and with the row index of the register layout contiguous (R[16 t + q + 4 r] at 16 t + 4 q + r)
@@ -87,38 +99,41 @@ __device__ __forceinline__ double wave_sum(double x) {   // the same value in ev
 }
 
 // ---- memory --------------------------------------------------------------------------------------------------------------------------------------------
-// `b` points at element 0 of the slot for this replica; element e at b[e · es]
-template <int NT>
+// `b` points at element 0 of the slot for this replica
+template <int NT, bool ES1>
 __device__ __forceinline__ void load_sym(const Lane<NT>& L, const double* b, long long es, int d, Mat<NT>& m) {
-    const int last = d * (d + 1) / 2 - 1;
+    const unsigned n8 = 4u * (unsigned)(d * (d + 1));
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
         for (int tj = 0; tj < NT; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int e = L.pk[ti][tj][r] & 0xffff, hi = L.pk[ti][tj][r] >> 16;
-                const double x = b[(long long)(e < last ? e : last) * es];
-                m.t[ti][tj][r] = hi < d ? x : 0.0;
+                const unsigned e8 = L.e8[ti][tj][r];
+                const double x = ldg<ES1>(b, es, e8 < n8 ? e8 : n8 - 8u);
+                m.t[ti][tj][r] = e8 < n8 ? x : 0.0;
             }
 }
 // the lower triangle (j ≤ i): the stored message is symmetric by construction
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ void store_sym(const Lane<NT>& L, double* b, long long es, int d, const Mat<NT>& m) {
+    const unsigned n8 = 4u * (unsigned)(d * (d + 1));
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
         for (int tj = 0; tj <= ti; ++tj)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int i = 16 * ti + L.q + 4 * r, j = 16 * tj + L.il;
-                if (j <= i && i < d) b[(long long)(L.pk[ti][tj][r] & 0xffff) * es] = m.t[ti][tj][r];
+                const bool low = tj < ti || L.il <= L.q + 4 * r;
+                if (low && L.e8[ti][tj][r] < n8) stg<ES1>(b, es, L.e8[ti][tj][r], m.t[ti][tj][r]);
             }
 }
-// element (i, j), i < rows, j < cols, at b[(i · si + j · sj) · es]: a row-major rows × cols matrix with (si, sj) = (cols, 1), its transpose with (1, rows-of-the-source … )
-template <int NT>
+// element (i, j), i < rows, j < cols, at element i · si + j · sj of the slot: a row-major rows × cols matrix with (si, sj) = (cols, 1); the transpose of a
+// row-major n × rows matrix with (1, rows)
+template <int NT, bool ES1>
 __device__ __forceinline__ void load_mat(const Lane<NT>& L, const double* b, long long es, int rows, int cols, int si, int sj, Mat<NT>& m) {
-    const int last = (rows - 1) * si + (cols - 1) * sj;
+    const unsigned last = 8u * (unsigned)((rows - 1) * si + (cols - 1) * sj);
+    const unsigned qs = 8u * (unsigned)__mul24(L.q, si), js = 8u * (unsigned)__mul24(L.il, sj);
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
@@ -127,12 +142,12 @@ __device__ __forceinline__ void load_mat(const Lane<NT>& L, const double* b, lon
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * ti + L.q + 4 * r, j = 16 * tj + L.il;
                 const bool in = i < rows && j < cols;
-                const int e = in ? i * si + j * sj : last;
-                const double x = b[(long long)e * es];
+                const unsigned e8 = qs + js + 8u * (unsigned)((16 * ti + 4 * r) * si + 16 * tj * sj);
+                const double x = ldg<ES1>(b, es, in ? e8 : last);
                 m.t[ti][tj][r] = in ? x : 0.0;
             }
 }
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ void store_full(const Lane<NT>& L, double* b, long long es, int d, const Mat<NT>& m, double scale) {
 #pragma unroll
     for (int ti = 0; ti < NT; ++ti)
@@ -141,35 +156,35 @@ __device__ __forceinline__ void store_full(const Lane<NT>& L, double* b, long lo
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int i = 16 * ti + L.q + 4 * r, j = 16 * tj + L.il;
-                if (i < d && j < d) b[(long long)(i * d + j) * es] = scale * m.t[ti][tj][r];
+                if (i < d && j < d) stg<ES1>(b, es, 8u * (unsigned)(i * d + j), scale * m.t[ti][tj][r]);
             }
 }
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ void load_vec(const Lane<NT>& L, const double* b, long long es, int d, Vec<NT>& v) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int i = 16 * t + L.il;
-        const double x = b[(long long)(i < d ? i : d - 1) * es];
+        const double x = ldg<ES1>(b, es, 8u * (unsigned)(i < d ? i : d - 1));
         v.x[t] = i < d ? x : 0.0;
     }
 }
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ void load_veck(const Lane<NT>& L, const double* b, long long es, int d, VecK<NT>& v) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int i = 16 * t + L.q + 4 * r;
-            const double x = b[(long long)(i < d ? i : d - 1) * es];
+            const double x = ldg<ES1>(b, es, 8u * (unsigned)(i < d ? i : d - 1));
             v.k[t][r] = i < d ? x : 0.0;
         }
 }
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ void store_vec(const Lane<NT>& L, double* b, long long es, int d, const Vec<NT>& v) {
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
         const int i = 16 * t + L.il;
-        if (L.q == 0 && i < d) b[(long long)i * es] = v.x[t];
+        if (L.q == 0 && i < d) stg<ES1>(b, es, 8u * (unsigned)i, v.x[t]);
     }
 }
 
@@ -299,7 +314,8 @@ __device__ __noinline__ Inverse<NT> spd_inv_call(int q, int il, Scratch<NT>* sp,
             for (int kq = 0; kq < 4; ++kq) {
                 const int kc = 4 * kr + kq, k = 16 * tk + kc;   // the pivot: row (q = kq, register kr) of tile row tk, column il = kc of tile column tk
                 if (k >= d) break;
-                const double pv = lane_read(a.t[tk][tk][kr], 16 * kq + kc);
+                const int plo = __builtin_amdgcn_readlane(__double2loint(a.t[tk][tk][kr]), 16 * kq + kc), phi = __builtin_amdgcn_readlane(__double2hiint(a.t[tk][tk][kr]), 16 * kq + kc);
+                const double pv = __hiloint2double(phi, plo);   // (wavefront-uniform: in scalar registers)
                 if (L.q == kq) {
 #pragma unroll
                     for (int tj = 0; tj < NT; ++tj) {
@@ -317,23 +333,32 @@ __device__ __noinline__ Inverse<NT> spd_inv_call(int q, int il, Scratch<NT>* sp,
                     for (int r = 0; r < 4; ++r) C[t][r] = s.perm[16 * t + 4 * L.q + r];
                 }
                 w_fence();
-                ok = ok && (pv > 0.0) && (pv < 1.0e300);
-                mant *= __builtin_amdgcn_frexp_mant(pv);
-                expo += __builtin_amdgcn_frexp_exp(pv);
+                // sign and exponent of the pivot on the scalar unit: positive, normal, below 2^996 (≈ 1e300); mantissa in [½, 1) for the running product
+                const unsigned se = (unsigned)phi >> 20;
+                ok = ok && (se - 1u < 2018u);
+                expo += (int)se - 1022;
+                mant *= __hiloint2double((phi & (int)0x800fffff) | 0x3fe00000, plo);
                 double ip = __builtin_amdgcn_rcp(pv);   // v_rcp_f64 + two Newton steps
                 ip = fma(fma(-pv, ip, 1.0), ip, ip);
                 ip = fma(fma(-pv, ip, 1.0), ip, ip);
                 const bool colk = L.il == kc;
 #pragma unroll
                 for (int tj = 0; tj < NT; ++tj) {
-                    // lanes of column k (tile column tk): a ← 0 − C · (−1/p) = a_ik / p; everywhere else a −= C · (R / p)
-                    const bool ck = colk && tj == tk;
-                    const double tt = ck ? -ip : R[tj] * ip;
+                    const double t = R[tj] * ip;
 #pragma unroll
                     for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) a.t[ti][tj][r] = fma(-C[ti][r], tt, ck ? 0.0 : a.t[ti][tj][r]);
-                    if (L.q == kq) a.t[tk][tj][kr] = tt;   // row k: R / p, the corner −1/p
+                        for (int r = 0; r < 4; ++r) a.t[ti][tj][r] = fma(-C[ti][r], t, a.t[ti][tj][r]);
+                    double tt = t;
+                    if (tj == tk && colk) {   // the four lanes of column k: a_ik / p, the corner −1/p (a branch, not eight selects in every lane)
+                        __asm__ volatile("" ::: "memory");
+#pragma unroll
+                        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) a.t[ti][tj][r] = C[ti][r] * ip;
+                        tt = -ip;
+                    }
+                    if (L.q == kq) a.t[tk][tj][kr] = tt;   // row k: R / p
                 }
             }
 #pragma unroll
@@ -373,41 +398,41 @@ template <int NT>
 __device__ __forceinline__ int tiles(int d) { return NT == 1 ? 1 : (d + 15) >> 4; }
 
 // a message in the form a rule wants: a conversion is one inverse and one matrix-vector product
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ bool load_msg(const Env<NT>& E, int off, bool stored_wp, bool want_wp, int d, Vec<NT>& v, Mat<NT>& M) {
     const double* b = E.msg(off);
-    load_vec<NT>(E.L, b, E.p.es, d, v);
-    load_sym<NT>(E.L, b + (long long)d * E.p.es, E.p.es, d, M);
+    load_vec<NT, ES1>(E.L, b, E.p.es, d, v);
+    load_sym<NT, ES1>(E.L, b + (long long)d * E.p.es, E.p.es, d, M);
     if (stored_wp == want_wp) return true;
     double ld;
     const bool ok = spd_inv<NT>(E.L, E.s, M, d, ld);
     v = matvec_t<NT>(M, to_k<NT>(E.L, v));
     return ok;
 }
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ void store_msg(const Env<NT>& E, int off, int d, const Vec<NT>& v, const Mat<NT>& M) {
     double* b = E.msg_w(off);
-    store_vec<NT>(E.L, b, E.p.es, d, v);
-    store_sym<NT>(E.L, b + (long long)d * E.p.es, E.p.es, d, M);
+    store_vec<NT, ES1>(E.L, b, E.p.es, d, v);
+    store_sym<NT, ES1>(E.L, b + (long long)d * E.p.es, E.p.es, d, M);
 }
 // Σ (want_sigma) or W = Σ⁻¹ of a Gaussian node; (E) log|W|
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ double load_noise(const Env<NT>& E, const int* w, int d, bool want_sigma, Mat<NT>& M) {
     const int ps = w[W_PREC];
     if (ps >= 0) {
         const int tri = d * (d + 1) / 2;
         const double* b = E.prec(ps);
-        load_mat<NT>(E.L, b + (long long)(1 + tri + (want_sigma ? d * d : 0)) * E.p.es, E.p.es, d, d, d, 1, M);
+        load_mat<NT, ES1>(E.L, b + (long long)(1 + tri + (want_sigma ? d * d : 0)) * E.p.es, E.p.es, d, d, d, 1, M);
         return b[(long long)(1 + tri + 2 * d * d) * E.p.es];
     }
     const double* cp = E.p.cpool + w[W_C0];
-    load_mat<NT>(E.L, cp + (want_sigma ? 0 : d * d), 1, d, d, d, 1, M);
+    load_mat<NT, true>(E.L, cp + (want_sigma ? 0 : d * d), 1, d, d, d, 1, M);
     return cp[2 * d * d];
 }
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ void load_value(const Env<NT>& E, int off, bool slot, int d, Vec<NT>& v) {
-    if (slot) load_vec<NT>(E.L, E.val(off), E.p.es, d, v);
-    else load_vec<NT>(E.L, E.p.cpool + off, 1, d, v);
+    if (slot) load_vec<NT, ES1>(E.L, E.val(off), E.p.es, d, v);
+    else load_vec<NT, true>(E.L, E.p.cpool + off, 1, d, v);
 }
 template <int NT>
 __device__ __forceinline__ bool any_nan(const Vec<NT>& v) {
@@ -419,24 +444,24 @@ __device__ __forceinline__ bool any_nan(const Vec<NT>& v) {
 
 // A marginal as the second phase reads it (tree_wave_kernels.hpp load_marginal): mean, covariance (want_cov), log|V| — of the slot `off`, or (push) of its IMAGE
 // under the constant d × du matrix at cpool + aoff: (A m, A V Aᵀ); ldoff ≥ 0: a square map, log|A V Aᵀ| = log|V| + cpool[ldoff]
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ double load_marginal(const Env<NT>& E, int off, bool push, int aoff, int du, int d, bool want_cov, Vec<NT>& m, Mat<NT>& V, int ldoff = -1) {
     const double* b = E.marg(off);
     const long long es = E.p.es;
     if (!push) {
-        load_vec<NT>(E.L, b, es, d, m);
+        load_vec<NT, ES1>(E.L, b, es, d, m);
         if (!want_cov) return 0.0;
-        load_sym<NT>(E.L, b + (long long)d * es, es, d, V);
+        load_sym<NT, ES1>(E.L, b + (long long)d * es, es, d, V);
         return b[(long long)(d + d * (d + 1) / 2) * es];
     }
     Mat<NT> at;   // Aᵀ (du × d): element (i, j) = A[j][i] at j · du + i
-    load_mat<NT>(E.L, E.p.cpool + aoff, 1, du, d, 1, du, at);
+    load_mat<NT, true>(E.L, E.p.cpool + aoff, 1, du, d, 1, du, at);
     VecK<NT> mu;
-    load_veck<NT>(E.L, b, es, du, mu);
+    load_veck<NT, ES1>(E.L, b, es, du, mu);
     m = matvec_t<NT>(at, mu);
     if (!want_cov) return 0.0;
     Mat<NT> Vu, Y;
-    load_sym<NT>(E.L, b + (long long)du * es, es, du, Vu);
+    load_sym<NT, ES1>(E.L, b + (long long)du * es, es, du, Vu);
     const int n16 = tiles<NT>(d > du ? d : du);
     mul<NT>(Y, Vu, at, n16);    // V Aᵀ
     mul<NT>(V, at, Y, n16);     // A (V Aᵀ)
@@ -448,7 +473,7 @@ __device__ __forceinline__ double load_marginal(const Env<NT>& E, int off, bool 
 }
 
 // the sweep (ops up to OP_MARGINAL): tree_wave_kernels.hpp eval_bp, op for op
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict__ w) {
     const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS];
     const Lane<NT>& L = E.L;
@@ -458,42 +483,42 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
     case OP_DERIVE_MUL: {
         const int d1 = w[W_D1];
         Mat<NT> at;
-        load_mat<NT>(L, E.p.cpool + w[W_C0], 1, d1, d, 1, d1, at);
+        load_mat<NT, true>(L, E.p.cpool + w[W_C0], 1, d1, d, 1, d1, at);
         VecK<NT> x;
-        if (fl & F_VAL_SLOT) load_veck<NT>(L, E.val(w[W_VAL]), es, d1, x);
-        else load_veck<NT>(L, E.p.cpool + w[W_VAL], 1, d1, x);
-        store_vec<NT>(L, E.val(w[W_OUT]), es, d, matvec_t<NT>(at, x));
+        if (fl & F_VAL_SLOT) load_veck<NT, ES1>(L, E.val(w[W_VAL]), es, d1, x);
+        else load_veck<NT, true>(L, E.p.cpool + w[W_VAL], 1, d1, x);
+        store_vec<NT, ES1>(L, E.val(w[W_OUT]), es, d, matvec_t<NT>(at, x));
     } break;
     case OP_DERIVE_ADD: {
         Vec<NT> a, b;
-        load_value<NT>(E, w[W_VAL], fl & F_VAL_SLOT, d, a);
-        load_value<NT>(E, w[W_VAL2], fl & F_VAL2_SLOT, d, b);
+        load_value<NT, ES1>(E, w[W_VAL], fl & F_VAL_SLOT, d, a);
+        load_value<NT, ES1>(E, w[W_VAL2], fl & F_VAL2_SLOT, d, b);
         axpy<NT>(a, 1.0, b);
-        store_vec<NT>(L, E.val(w[W_OUT]), es, d, a);
+        store_vec<NT, ES1>(L, E.val(w[W_OUT]), es, d, a);
     } break;
     case OP_LEAF: {
         Vec<NT> v;
-        if (fl & F_VAL_MARG) load_vec<NT>(L, E.marg(w[W_VAL]), es, d, v);   // q(out) q(μ): the MEAN of the other interface's marginal (of the previous iteration)
-        else load_value<NT>(E, w[W_VAL], fl & F_VAL_SLOT, d, v);
+        if (fl & F_VAL_MARG) load_vec<NT, ES1>(L, E.marg(w[W_VAL]), es, d, v);   // q(out) q(μ): the MEAN of the other interface's marginal (of the previous iteration)
+        else load_value<NT, ES1>(E, w[W_VAL], fl & F_VAL_SLOT, d, v);
         const bool wp = fl & F_OUT_WP;
         Mat<NT> M;
-        load_noise<NT>(E, w, d, !wp, M);
+        load_noise<NT, ES1>(E, w, d, !wp, M);
         if (wp) {
             Vec<NT> y = matvec_t<NT>(M, to_k<NT>(L, v));
             if ((fl & F_MAY_MISS) && any_nan<NT>(v)) {   // a `missing` observation sends nothing: the zero of the precision form
                 zero<NT>(M);
                 zero<NT>(y);
             }
-            store_msg<NT>(E, w[W_OUT], d, y, M);
+            store_msg<NT, ES1>(E, w[W_OUT], d, y, M);
         } else
-            store_msg<NT>(E, w[W_OUT], d, v, M);
+            store_msg<NT, ES1>(E, w[W_OUT], d, v, M);
     } break;
     case OP_NOISE: {
         const bool wp = fl & F_IN0_WP;
         Vec<NT> v;
         Mat<NT> M, N;
-        ok = load_msg<NT>(E, w[W_IN0], wp, wp, d, v, M);
-        load_noise<NT>(E, w, d, !wp, N);
+        ok = load_msg<NT, ES1>(E, w[W_IN0], wp, wp, d, v, M);
+        load_noise<NT, ES1>(E, w, d, !wp, N);
         if (!wp) {
             axpy<NT>(M, 1.0, N);
             if (fl & F_OUT_WP) {   // converted once for all its readers
@@ -501,7 +526,7 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
                 ok = spd_inv<NT>(L, E.s, M, d, ld) && ok;
                 v = matvec_t<NT>(M, to_k<NT>(L, v));
             }
-            store_msg<NT>(E, w[W_OUT], d, v, M);
+            store_msg<NT, ES1>(E, w[W_OUT], d, v, M);
         } else {   // Λ' = Λ (Λ + W)⁻¹ W, ξ' = W (Λ + W)⁻¹ ξ
             Mat<NT> G = M;
             axpy<NT>(G, 1.0, N);
@@ -513,40 +538,40 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
             const int n16 = tiles<NT>(d);
             mul<NT>(T1, G, N, n16);    // (Λ + W)⁻¹ W
             mul<NT>(Lo, M, T1, n16);   // Λ (Λ + W)⁻¹ W
-            store_msg<NT>(E, w[W_OUT], d, xo, Lo);
+            store_msg<NT, ES1>(E, w[W_OUT], d, xo, Lo);
         }
     } break;
     case OP_MUL_OUT: {   // N(A m, A V Aᵀ): in dimension d1, out dimension d
         const int d1 = w[W_D1];
         Vec<NT> v;
         Mat<NT> V, at, Y, Vo;
-        ok = load_msg<NT>(E, w[W_IN0], fl & F_IN0_WP, false, d1, v, V);
-        load_mat<NT>(L, E.p.cpool + w[W_C0], 1, d1, d, 1, d1, at);   // Aᵀ
+        ok = load_msg<NT, ES1>(E, w[W_IN0], fl & F_IN0_WP, false, d1, v, V);
+        load_mat<NT, true>(L, E.p.cpool + w[W_C0], 1, d1, d, 1, d1, at);   // Aᵀ
         const Vec<NT> m = matvec_t<NT>(at, to_k<NT>(L, v));
         const int n16 = tiles<NT>(d > d1 ? d : d1);
         mul<NT>(Y, V, at, n16);     // V Aᵀ
         mul<NT>(Vo, at, Y, n16);    // A (V Aᵀ)
-        store_msg<NT>(E, w[W_OUT], d, m, Vo);
+        store_msg<NT, ES1>(E, w[W_OUT], d, m, Vo);
     } break;
     case OP_MUL_IN: {    // (Aᵀ ξ, Aᵀ Λ A): in dimension d (the message toward `out`), out dimension d1
         const int d1 = w[W_D1];
         Vec<NT> v;
         Mat<NT> Lm, a, Y, Lo;
-        ok = load_msg<NT>(E, w[W_IN0], fl & F_IN0_WP, true, d, v, Lm);
-        load_mat<NT>(L, E.p.cpool + w[W_C0], 1, d, d1, d1, 1, a);   // A
+        ok = load_msg<NT, ES1>(E, w[W_IN0], fl & F_IN0_WP, true, d, v, Lm);
+        load_mat<NT, true>(L, E.p.cpool + w[W_C0], 1, d, d1, d1, 1, a);   // A
         const Vec<NT> xo = matvec_t<NT>(a, to_k<NT>(L, v));
         const int n16 = tiles<NT>(d > d1 ? d : d1);
         mul<NT>(Y, Lm, a, n16);     // Λ A
         mul<NT>(Lo, a, Y, n16);     // Aᵀ (Λ A)
-        store_msg<NT>(E, w[W_OUT], d1, xo, Lo);
+        store_msg<NT, ES1>(E, w[W_OUT], d1, xo, Lo);
     } break;
     case OP_ADD_OUT:
     case OP_ADD_IN: {
         Vec<NT> v0, v1;
         Mat<NT> M0, M1;
         if (op == OP_ADD_IN && (fl & F_IN0_WP)) {   // Λ' = Λo (Λo + W2)⁻¹ W2, ξ' = W2 (Λo + W2)⁻¹ (ξo + ξ2) − ξ2
-            ok = load_msg<NT>(E, w[W_IN0], true, true, d, v0, M0);
-            ok = load_msg<NT>(E, w[W_IN1], fl & F_IN1_WP, true, d, v1, M1) && ok;
+            ok = load_msg<NT, ES1>(E, w[W_IN0], true, true, d, v0, M0);
+            ok = load_msg<NT, ES1>(E, w[W_IN1], fl & F_IN1_WP, true, d, v1, M1) && ok;
             Mat<NT> G = M0;
             axpy<NT>(G, 1.0, M1);
             axpy<NT>(v0, 1.0, v1);
@@ -559,25 +584,25 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
             const int n16 = tiles<NT>(d);
             mul<NT>(T1, G, M1, n16);
             mul<NT>(Lo, M0, T1, n16);
-            store_msg<NT>(E, w[W_OUT], d, xo, Lo);
+            store_msg<NT, ES1>(E, w[W_OUT], d, xo, Lo);
             break;
         }
-        ok = load_msg<NT>(E, w[W_IN0], fl & F_IN0_WP, false, d, v0, M0);
-        ok = load_msg<NT>(E, w[W_IN1], fl & F_IN1_WP, false, d, v1, M1) && ok;
+        ok = load_msg<NT, ES1>(E, w[W_IN0], fl & F_IN0_WP, false, d, v0, M0);
+        ok = load_msg<NT, ES1>(E, w[W_IN1], fl & F_IN1_WP, false, d, v1, M1) && ok;
         axpy<NT>(v0, op == OP_ADD_OUT ? 1.0 : -1.0, v1);
         axpy<NT>(M0, 1.0, M1);
-        store_msg<NT>(E, w[W_OUT], d, v0, M0);
+        store_msg<NT, ES1>(E, w[W_OUT], d, v0, M0);
     } break;
     case OP_SHIFT: {
         const bool wp = fl & F_IN0_WP;
         Vec<NT> v, x;
         Mat<NT> M;
-        ok = load_msg<NT>(E, w[W_IN0], wp, wp, d, v, M);
-        load_value<NT>(E, w[W_VAL], fl & F_VAL_SLOT, d, x);
+        ok = load_msg<NT, ES1>(E, w[W_IN0], wp, wp, d, v, M);
+        load_value<NT, ES1>(E, w[W_VAL], fl & F_VAL_SLOT, d, x);
         const double sg = (fl & F_NEG) ? -1.0 : 1.0;
         if (wp) axpy<NT>(v, sg, matvec_t<NT>(M, to_k<NT>(L, x)));
         else axpy<NT>(v, sg, x);
-        store_msg<NT>(E, w[W_OUT], d, v, M);
+        store_msg<NT, ES1>(E, w[W_OUT], d, v, M);
     } break;
     case OP_PRODUCT:
     case OP_MARGINAL: {
@@ -588,18 +613,18 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
         const int n = w[W_N];
         const int* lst = E.p.aux + w[W_LIST];
         for (int q = 0; q < n; ++q) {   // left to right, in factor order
-            ok = load_msg<NT>(E, lst[2 * q], lst[2 * q + 1] != 0, true, d, v1, M1) && ok;
+            ok = load_msg<NT, ES1>(E, lst[2 * q], lst[2 * q + 1] != 0, true, d, v1, M1) && ok;
             axpy<NT>(v0, 1.0, v1);
             axpy<NT>(M0, 1.0, M1);
         }
-        if (op == OP_PRODUCT) store_msg<NT>(E, w[W_OUT], d, v0, M0);
+        if (op == OP_PRODUCT) store_msg<NT, ES1>(E, w[W_OUT], d, v0, M0);
         else {
             double ld;
             ok = spd_inv<NT>(L, E.s, M0, d, ld) && ok;
             const Vec<NT> m = matvec_t<NT>(M0, to_k<NT>(L, v0));
             double* b = E.marg(w[W_OUT]);
-            store_vec<NT>(L, b, es, d, m);
-            store_sym<NT>(L, b + (long long)d * es, es, d, M0);
+            store_vec<NT, ES1>(L, b, es, d, m);
+            store_sym<NT, ES1>(L, b + (long long)d * es, es, d, M0);
             if (threadIdx.x == 0) b[(long long)(d + d * (d + 1) / 2) * es] = -ld;
         }
     } break;
@@ -609,7 +634,7 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
 }
 
 // the second phase: Bethe terms, residual moments, q(W) updates — tree_wave_kernels.hpp eval_fe, op for op
-template <int NT>
+template <int NT, bool ES1>
 __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict__ w) {
     const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS];
     const Lane<NT>& L = E.L;
@@ -620,10 +645,10 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
     case OP_MARG_PUSH: {   // the stored marginal of an `A * x` output, formed when a caller asks for it
         Vec<NT> m;
         Mat<NT> V;
-        const double ldV = load_marginal<NT>(E, w[W_IN0], true, w[W_C0], w[W_D1], d, true, m, V, w[W_IN1]);
+        const double ldV = load_marginal<NT, ES1>(E, w[W_IN0], true, w[W_C0], w[W_D1], d, true, m, V, w[W_IN1]);
         double* b = E.marg(w[W_OUT]);
-        store_vec<NT>(L, b, es, d, m);
-        store_sym<NT>(L, b + (long long)d * es, es, d, V);
+        store_vec<NT, ES1>(L, b, es, d, m);
+        store_sym<NT, ES1>(L, b + (long long)d * es, es, d, V);
         if (threadIdx.x == 0) b[(long long)(d + d * (d + 1) / 2) * es] = ldV;
     } break;
     case OP_FE_NOISE2M: {
@@ -631,11 +656,11 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
         // Cov(a − b) = P⁻¹ + D V_b Dᵀ with D = P⁻¹ W − I — formed from Dᵀ = W P⁻¹ − I alone: D (V_b Dᵀ)
         Vec<NT> mb, ma, v0;
         Mat<NT> Vb, P, W, Dt, Y, dummy;
-        const double ldVb = load_marginal<NT>(E, w[W_VAL2], fl & F_PUSH_B, w[W_IN2], w[W_N], d, true, mb, Vb, (fl & F_PUSH_B) ? w[W_D1] : -1);
-        (void)load_marginal<NT>(E, w[W_VAL], fl & F_PUSH_A, w[W_IN1], w[W_LIST], d, false, ma, dummy);
-        if (w[W_IN0] >= 0) ok = load_msg<NT>(E, w[W_IN0], fl & F_IN0_WP, true, d, v0, P);
+        const double ldVb = load_marginal<NT, ES1>(E, w[W_VAL2], fl & F_PUSH_B, w[W_IN2], w[W_N], d, true, mb, Vb, (fl & F_PUSH_B) ? w[W_D1] : -1);
+        (void)load_marginal<NT, ES1>(E, w[W_VAL], fl & F_PUSH_A, w[W_IN1], w[W_LIST], d, false, ma, dummy);
+        if (w[W_IN0] >= 0) ok = load_msg<NT, ES1>(E, w[W_IN0], fl & F_IN0_WP, true, d, v0, P);
         else zero<NT>(P);
-        const double el = load_noise<NT>(E, w, d, false, W);
+        const double el = load_noise<NT, ES1>(E, w, d, false, W);
         axpy<NT>(P, 1.0, W);
         double ldP;
         ok = spd_inv<NT>(L, E.s, P, d, ldP) && ok;
@@ -647,21 +672,21 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
         add_outer<NT>(P, to_k<NT>(L, ma), ma);
         double term = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP - ldVb));
         if (fl & F_FOLD_ENT) term += (double)w[W_OUT] * 0.5 * (d * (T_LOG2PI + 1.0) + ldVb);
-        if (fl & F_STAT) store_full<NT>(L, E.stat(w[W_C1]), es, d, P, 1.0);
+        if (fl & F_STAT) store_full<NT, ES1>(L, E.stat(w[W_C1]), es, d, P, 1.0);
         else term += 0.5 * (d * T_LOG2PI - el + dot<NT>(W, P));
         if (threadIdx.x == 0) *E.term(w[W_TERM]) = term;
     } break;
     case OP_FE_NOISE_MF: {   // a Gaussian node under q(out) q(μ): E[rrᵀ] = V_out + V_μ + (m_out − m_μ)(m_out − m_μ)ᵀ
         Vec<NT> m0, m1;
         Mat<NT> V0, V1, W;
-        (void)load_marginal<NT>(E, w[W_VAL], false, 0, 0, d, true, m0, V0);
-        (void)load_marginal<NT>(E, w[W_VAL2], false, 0, 0, d, true, m1, V1);
-        const double el = load_noise<NT>(E, w, d, false, W);
+        (void)load_marginal<NT, ES1>(E, w[W_VAL], false, 0, 0, d, true, m0, V0);
+        (void)load_marginal<NT, ES1>(E, w[W_VAL2], false, 0, 0, d, true, m1, V1);
+        const double el = load_noise<NT, ES1>(E, w, d, false, W);
         axpy<NT>(m0, -1.0, m1);
         axpy<NT>(V0, 1.0, V1);
         add_outer<NT>(V0, to_k<NT>(L, m0), m0);
         double term = 0.0;
-        if (fl & F_STAT) store_full<NT>(L, E.stat(w[W_C1]), es, d, V0, 1.0);
+        if (fl & F_STAT) store_full<NT, ES1>(L, E.stat(w[W_C1]), es, d, V0, 1.0);
         else term = 0.5 * (d * T_LOG2PI - el + dot<NT>(W, V0));
         if (threadIdx.x == 0) *E.term(w[W_TERM]) = term;
     } break;
@@ -671,21 +696,21 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
         Vec<NT> v0, v1;
         Mat<NT> V, W;
         if (op == OP_FE_NOISE1) {
-            const double ldV = load_marginal<NT>(E, w[W_IN0], fl & F_PUSH_A, w[W_IN1], w[W_D1], d, true, v0, V, (fl & F_PUSH_A) ? w[W_IN2] : -1);
+            const double ldV = load_marginal<NT, ES1>(E, w[W_IN0], fl & F_PUSH_A, w[W_IN1], w[W_D1], d, true, v0, V, (fl & F_PUSH_A) ? w[W_IN2] : -1);
             H = 0.5 * (d * (T_LOG2PI + 1.0) + ldV);
             if (fl & F_FOLD_ENT) H *= (double)(1 - w[W_OUT]);
-            load_value<NT>(E, w[W_VAL], fl & F_VAL_SLOT, d, v1);
+            load_value<NT, ES1>(E, w[W_VAL], fl & F_VAL_SLOT, d, v1);
         } else {
             zero<NT>(V);
-            load_value<NT>(E, w[W_VAL], fl & F_VAL_SLOT, d, v0);
-            load_value<NT>(E, w[W_VAL2], fl & F_VAL2_SLOT, d, v1);
+            load_value<NT, ES1>(E, w[W_VAL], fl & F_VAL_SLOT, d, v0);
+            load_value<NT, ES1>(E, w[W_VAL2], fl & F_VAL2_SLOT, d, v1);
         }
-        const double el = load_noise<NT>(E, w, d, false, W);
+        const double el = load_noise<NT, ES1>(E, w, d, false, W);
         axpy<NT>(v0, -1.0, v1);
         const bool miss = (fl & F_MAY_MISS) && any_nan<NT>(v0);   // a `missing` observation: energy and the predicted value's entropy cancel, −H stays
         add_outer<NT>(V, to_k<NT>(L, v0), v0);
         double term = -H;
-        if (fl & F_STAT) store_full<NT>(L, E.stat(w[W_C1]), es, d, V, 1.0);
+        if (fl & F_STAT) store_full<NT, ES1>(L, E.stat(w[W_C1]), es, d, V, 1.0);
         else {
             const double tr = dot<NT>(W, V);
             if (!miss) term += 0.5 * (d * T_LOG2PI - el + tr);
@@ -697,7 +722,7 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
         if (fl & F_PUSH_A) {
             Vec<NT> m;
             Mat<NT> V;
-            ldV = load_marginal<NT>(E, w[W_IN0], true, w[W_C0], w[W_D1], d, true, m, V, w[W_IN1]);
+            ldV = load_marginal<NT, ES1>(E, w[W_IN0], true, w[W_C0], w[W_D1], d, true, m, V, w[W_IN1]);
         } else
             ldV = E.marg(w[W_IN0])[(long long)(d + d * (d + 1) / 2) * es];
         if (threadIdx.x == 0) *E.term(w[W_TERM]) = (double)w[W_N] * 0.5 * (d * (T_LOG2PI + 1.0) + ldV);
@@ -705,11 +730,11 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
     case OP_FE_ADD2: {   // P = Λ1 + Λo, S = Λ2 + Λo − Λo P⁻¹ Λo
         Vec<NT> v;
         Mat<NT> P, S, Lo, T;
-        if (w[W_IN0] >= 0) ok = load_msg<NT>(E, w[W_IN0], fl & F_IN0_WP, true, d, v, P);
+        if (w[W_IN0] >= 0) ok = load_msg<NT, ES1>(E, w[W_IN0], fl & F_IN0_WP, true, d, v, P);
         else zero<NT>(P);
-        if (w[W_IN1] >= 0) ok = load_msg<NT>(E, w[W_IN1], fl & F_IN1_WP, true, d, v, S) && ok;
+        if (w[W_IN1] >= 0) ok = load_msg<NT, ES1>(E, w[W_IN1], fl & F_IN1_WP, true, d, v, S) && ok;
         else zero<NT>(S);
-        if (w[W_IN2] >= 0) ok = load_msg<NT>(E, w[W_IN2], fl & F_IN2_WP, true, d, v, Lo) && ok;
+        if (w[W_IN2] >= 0) ok = load_msg<NT, ES1>(E, w[W_IN2], fl & F_IN2_WP, true, d, v, Lo) && ok;
         else zero<NT>(Lo);
         axpy<NT>(P, 1.0, Lo);
         axpy<NT>(S, 1.0, Lo);
@@ -740,8 +765,8 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
         const int* lst = E.p.aux + w[W_LIST];
         for (int q = 0; q < n; ++q) {
             Mat<NT> a, b;
-            load_mat<NT>(L, E.stat(lst[q]), es, d, d, d, 1, a);
-            load_mat<NT>(L, E.stat(lst[q]), es, d, d, 1, d, b);
+            load_mat<NT, ES1>(L, E.stat(lst[q]), es, d, d, d, 1, a);
+            load_mat<NT, ES1>(L, E.stat(lst[q]), es, d, d, 1, d, b);
             axpy<NT>(S, 1.0, a);
             axpy<NT>(St, 1.0, b);
         }
@@ -749,7 +774,7 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
         for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
             for (int tj = 0; tj < NT; ++tj) S.t[ti][tj] = 0.5 * (S.t[ti][tj] + St.t[ti][tj]);
-        load_mat<NT>(L, cp + 1, 1, d, d, d, 1, S0i);
+        load_mat<NT, true>(L, cp + 1, 1, d, d, d, 1, S0i);
         Vi = S0i;
         axpy<NT>(Vi, 1.0, S);
         V = Vi;
@@ -763,9 +788,9 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
             pb[0] = nu;
             pb[(long long)(1 + tri + 2 * d * d) * es] = elw;
         }
-        store_sym<NT>(L, pb + es, es, d, V);
-        store_full<NT>(L, pb + (long long)(1 + tri) * es, es, d, V, nu);
-        store_full<NT>(L, pb + (long long)(1 + tri + d * d) * es, es, d, Vi, 1.0 / nu);
+        store_sym<NT, ES1>(L, pb + es, es, d, V);
+        store_full<NT, ES1>(L, pb + (long long)(1 + tri) * es, es, d, V, nu);
+        store_full<NT, ES1>(L, pb + (long long)(1 + tri + d * d) * es, es, d, Vi, 1.0 / nu);
         if (E.p.want_fe) {
             double F = 0.5 * ((double)n * (d * T_LOG2PI - elw) + nu * dot<NT>(V, S));
             F += -(0.5 * (nu0 - d - 1.0) * elw - 0.5 * nu * dot<NT>(S0i, V) - 0.5 * nu0 * d * T_LOG2 - 0.5 * nu0 * ldS0 - t_mvlgamma(0.5 * nu0, d));
@@ -780,7 +805,7 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
 
 // One launch per level: a wavefront (a workgroup of 64) per item (op, replica).  Storage as TreeParams says: element k of slot `off` of replica r at
 // (off + k)·es + r·rs_<array> — the engines above d = 8 store a replica's slots contiguously (es = 1), rxhip_rule_eval's one-node schedules replica-fastest.
-template <int PHASE, int NT>
+template <int PHASE, int NT, bool ES1>
 __global__ void __launch_bounds__(64) k_tile_ops(TreeParams p, int op0, int op1) {
     __shared__ Scratch<NT> scratch;
     const Lane<NT> L = make_lane<NT>();
@@ -789,12 +814,12 @@ __global__ void __launch_bounds__(64) k_tile_ops(TreeParams p, int op0, int op1)
         const long long o = it / p.R;
         const Env<NT> E{L, scratch, p, it - o * p.R};
         const int* w = p.ops + (size_t)(op0 + o) * OP_WORDS;
-        if (PHASE == 0) eval_bp<NT>(E, w);
-        else eval_fe<NT>(E, w);
+        if (PHASE == 0) eval_bp<NT, ES1>(E, w);
+        else eval_fe<NT, ES1>(E, w);
     }
 }
 // a wavefront owns a replica and walks the ops of the range in order (every op's inputs were written by this wavefront or before the launch)
-template <int PHASE, int NT>
+template <int PHASE, int NT, bool ES1>
 __global__ void __launch_bounds__(64) k_tile_walk(TreeParams p, int op0, int op1) {
     __shared__ Scratch<NT> scratch;
     const Lane<NT> L = make_lane<NT>();
@@ -802,8 +827,8 @@ __global__ void __launch_bounds__(64) k_tile_walk(TreeParams p, int op0, int op1
         const Env<NT> E{L, scratch, p, r};
         for (int o = op0; o < op1; ++o) {
             const int* w = p.ops + (size_t)o * OP_WORDS;
-            if (PHASE == 0) eval_bp<NT>(E, w);
-            else eval_fe<NT>(E, w);
+            if (PHASE == 0) eval_bp<NT, ES1>(E, w);
+            else eval_fe<NT, ES1>(E, w);
             __syncthreads();   // (one wavefront: a workgroup-scope fence — this op's stores before the next op's loads by other lanes)
         }
     }

@@ -19,13 +19,17 @@ constexpr int NT = RXHIP_TU_DC / 16;
 using namespace rxhip::tree::tile;
 
 hipError_t prepare(int) { return hipSuccess; }
+// (es = 1: the engines' element-fastest storage — scalar base + lane offset addressing; rxhip_rule_eval's one-node schedules are replica-fastest)
 void ops(int phase, const TreeParams& p, int o0, int o1, int, unsigned blocks, hipStream_t stream) {
-    if (phase == 0) hipLaunchKernelGGL((k_tile_ops<0, NT>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
-    else hipLaunchKernelGGL((k_tile_ops<1, NT>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+    if (p.es == 1) {
+        if (phase == 0) hipLaunchKernelGGL((k_tile_ops<0, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+        else hipLaunchKernelGGL((k_tile_ops<1, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+    } else
+        hipLaunchKernelGGL((k_tile_ops<0, NT, false>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);   // (the sweep's rules only)
 }
 void walk(int phase, const TreeParams& p, int o0, int o1, int, unsigned blocks, hipStream_t stream) {
-    if (phase == 0) hipLaunchKernelGGL((k_tile_walk<0, NT>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
-    else hipLaunchKernelGGL((k_tile_walk<1, NT>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+    if (phase == 0) hipLaunchKernelGGL((k_tile_walk<0, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+    else hipLaunchKernelGGL((k_tile_walk<1, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
 }
 const WaveVtbl VT = {prepare, ops, walk};
 }  // namespace

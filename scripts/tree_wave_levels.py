@@ -26,7 +26,7 @@ levels = [l for l in levels if l and not all(o == 20 for o, _ in l)]   # (the le
 rows = []
 for f in sorted(glob.glob(os.path.join(sys.argv[1], "**", "*kernel_trace.csv"), recursive=True)):
     for r in csv.DictReader(open(f)):
-        if "k_wave_ops" in r.get("Kernel_Name", ""):
+        if "k_wave_ops" in r.get("Kernel_Name", "") or "k_tile_ops" in r.get("Kernel_Name", ""):
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
 rows.sort()
 n = len(levels)
@@ -54,7 +54,7 @@ if len(sys.argv) > 3:
     per = {}
     for f in sorted(glob.glob(os.path.join(sys.argv[1], "**", "*counter_collection.csv"), recursive=True)):
         for r in csv.DictReader(open(f)):
-            if "k_wave_ops" in r.get("Kernel_Name", ""):
+            if "k_wave_ops" in r.get("Kernel_Name", "") or "k_tile_ops" in r.get("Kernel_Name", ""):
                 per.setdefault(r["Counter_Name"], {}).setdefault(int(r["Dispatch_Id"]), 0.0)
                 per[r["Counter_Name"]][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
     fits = {}
