@@ -468,6 +468,9 @@ rxhip_status rxhip_tree_set_data(rxhip_engine* e, const int64_t* vars, int64_t n
 rxhip_status rxhip_tree_get_marginals(rxhip_engine* e, const int64_t* vars, int64_t n_vars, double* mean, double* cov);
 /* q(W) of a precision variable: nu [replica], V [replica][d][d] (a Gamma(a, b) variable is reported as Wishart_1(2a, 1/(2b))) */
 rxhip_status rxhip_tree_get_precision(rxhip_engine* e, int64_t var, double* nu, double* V);
+/* the discrete side of a NormalMixture layer: for the switch z[i] of a mixture node its responsibilities q(z[i] = k), for the probability vector s of
+ * `z ~ Categorical(s)` the concentrations of q(s) = Dirichlet(α) — out [replica][K]; *n_components (nullable) receives K.  Any other variable: RXHIP_ERR_BADARG. */
+rxhip_status rxhip_tree_get_discrete(rxhip_engine* e, int64_t var, double* out, int32_t* n_components);
 rxhip_status rxhip_tree_get_info(rxhip_engine* e, rxhip_tree_info* out);
 /* on != 0: every later rxhip_run CONTINUES from the q(W) the previous run ended with instead of the `@initialization` marginals (the first run still
  * starts there) — for drivers that take one VMP iteration per call, as the loop of src/inference/batch.jl:391-430 does (the plugin's `fire!`):

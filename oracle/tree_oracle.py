@@ -15,6 +15,12 @@ variable terms (src/model/plugins/reactivemp_free_energy.jl:51-126).  The rule b
   typeof(+) (out, in1, in2)               :out  N(m1 + m2, V1 + V2)               :in1 N(m_out − m2, V_out + V2)   (a constant / data input: V = 0)
   Wishart (out, ν, S), GammaShapeRate / GammaShapeScale (out, α, β | θ): constant parameters, the prior of a precision variable
   product of Gaussians: (ξ1 + ξ2, Λ1 + Λ2);  marginal = product of all inbound messages
+  NormalMixture (out, switch, m[1..K], p[1..K]) under MeanField() with  switch ~ Categorical(s),  s ~ Dirichlet(a) | constant  (round 6; the rules of
+        oracle/rxoracle.c rxo_mvgmm_vmp, node by node instead of summed over the data set): the node's log-factor is Σ_k z_k log N(out | m_k, p_k⁻¹), so under
+        mean field it acts on (out, m_k, p_k) as K Gaussian precision nodes each WEIGHTED by π_k = q(z = k) — toward m_k: (π_k E[p_k] E[out], π_k E[p_k]),
+        toward out: the same with E[m_k], toward p_k: ν += π_k, V⁻¹ += π_k E[(out − m_k)(out − m_k)ᵀ], energy Σ_k π_k U_k — and toward the switch:
+        q(z = k) ∝ exp(E log s_k − U_k), U_k = ½[d log 2π − E log|p_k| + tr(E[p_k] E[(out − m_k)(out − m_k)ᵀ])];  q(s) = Dirichlet(a + Σ_i π_i).
+        Schedule per iteration (rxo_mvgmm_vmp): q(z) from the previous marginals, then the Gaussian sweep and q(s) with the new π, then q(p) with the new q(m).
   Bethe terms: SURVEY Appendix A.4 as oracle/rxoracle.c lgssm_bp_ws spells them for the state-space graph — stochastic node U − H[q(cluster)],
   deterministic node −H[q(inputs)], random variable (degree − 1) H[q]; clamped interfaces contribute no entropy.
 
@@ -44,6 +50,7 @@ LOG2PI = math.log(2.0 * math.pi)
 GAUSS_COV = ("MvNormalMeanCovariance", "NormalMeanVariance")
 GAUSS_PREC = ("MvNormalMeanPrecision", "NormalMeanPrecision")
 PRIORS = ("Wishart", "GammaShapeRate", "GammaShapeScale")
+SKIP = ("NormalMixture", "Categorical", "Dirichlet")   # no Gaussian message of their own: the mixture node acts through its K weighted virtual nodes
 
 
 def _sym(M):
@@ -90,6 +97,29 @@ class TreeGraph:
         self.factors = [(f["type"], [int(v) for _, v in f["interfaces"]]) for f in dump["factors"]]
         self.clusters = [f.get("clusters") for f in dump["factors"]]   # the node's factorisation of q (VariationalConstraintsFactorizationIndicesKey), None: the default
         nv = len(self.vars)
+        # NormalMixture under mean field = K weighted Gaussian precision nodes (out, m_k, p_k) appended behind the real factors; the mixture node itself, the
+        # Categorical and the Dirichlet nodes carry no Gaussian message (types in SKIP)
+        self.weight, self.mixtures, self.cat, self.dir = {}, [], {}, {}
+        for fi, (t, ifs) in enumerate(list(self.factors)):
+            if t == "NormalMixture":
+                K = (len(ifs) - 2) // 2
+                if len(ifs) != 2 + 2 * K or K < 1:
+                    raise ValueError("NormalMixture: (out, switch, m[1..K], p[1..K]) expected")
+                cl = self.clusters[fi]
+                rnd = [k for k, v in enumerate(ifs) if self.vars[v]["kind"] == "random"]
+                if cl is not None and len({cl[k] for k in rnd}) != len(rnd):
+                    raise ValueError("NormalMixture: only the mean-field factorisation has rules")
+                vf = []
+                for k in range(K):
+                    self.weight[len(self.factors)] = (ifs[1], k)
+                    vf.append(len(self.factors))
+                    self.factors.append(("MvNormalMeanPrecision", [ifs[0], ifs[2 + k], ifs[2 + K + k]]))
+                    self.clusters.append([0, 1, 2])
+                self.mixtures.append(dict(node=fi, out=ifs[0], z=ifs[1], m=ifs[2:2 + K], p=ifs[2 + K:], virtual=vf))
+            elif t == "Categorical":
+                self.cat[ifs[0]] = ifs[1]
+            elif t == "Dirichlet":
+                self.dir[ifs[0]] = ifs[1]
         self.dim = [int(v["rows"]) for v in self.vars]
         self.kind = [v["kind"] for v in self.vars]
         # classify: precision variables are the random `out` of a Wishart / Gamma prior node
@@ -108,9 +138,11 @@ class TreeGraph:
                         all(self.kind[x] != "random" or x in self.derived for x in ifs[1:]):
                     self.derived[ifs[0]] = fi
                     changed = True
-        self.gauss = [self.kind[v] == "random" and v not in self.prec_prior and v not in self.derived for v in range(nv)]
+        self.gauss = [self.kind[v] == "random" and v not in self.prec_prior and v not in self.derived and v not in self.cat and v not in self.dir for v in range(nv)]
         self.nbrs = [[] for _ in range(nv)]   # per variable: (factor, interface) in factor order — the fold order of the product
         for fi, (t, ifs) in enumerate(self.factors):
+            if t in SKIP:
+                continue
             for k, v in enumerate(ifs):
                 self.nbrs[v].append((fi, k))
         # Gaussian nodes the constraints run under q(out) q(μ): mean field between the two Gaussian interfaces
@@ -143,6 +175,23 @@ class TreeGraph:
                     raise ValueError("`*`: the matrix must be a constant")
             elif t == "+" or t in PRIORS:
                 pass
+            elif t == "NormalMixture":
+                z = ifs[1]
+                if z not in self.cat or self.kind[z] != "random":
+                    raise ValueError("NormalMixture: the switch must be a random variable with a Categorical prior")
+                K = (len(ifs) - 2) // 2
+                for k in ifs[2:2 + K]:
+                    if self.kind[k] != "random":
+                        raise ValueError("NormalMixture: the means must be random variables")
+                for k in ifs[2 + K:]:
+                    if self.kind[k] == "random" and k not in self.prec_prior:
+                        raise ValueError("NormalMixture: a random precision needs a Wishart / Gamma prior")
+            elif t == "Categorical":
+                if self.kind[ifs[1]] == "random" and ifs[1] not in self.dir:
+                    raise ValueError("Categorical: a random probability vector needs a Dirichlet prior")
+            elif t == "Dirichlet":
+                if self.kind[ifs[1]] != "constant":
+                    raise ValueError("Dirichlet: constant concentration expected")
             else:
                 raise ValueError(f"node {t} is not part of the Gaussian tree family")
 
@@ -202,10 +251,43 @@ def infer(dump, data, iterations=1, free_energy=True):
         if g.mf[fi]:
             for v in ifs[:2]:
                 qx[v] = g.init_gauss(v)
+    # mixtures: the switch's rule reads the marginals of the means (and of a random `out`), q(p) and q(s) of the previous iteration
+    for mx in g.mixtures:
+        for v in list(mx["m"]) + [mx["out"]]:
+            if g.gauss[v] and v not in qx:
+                qx[v] = g.init_gauss(v)
+    qs = {}
+    for sv in g.dir:
+        ini = g.vars[sv].get("init")
+        qs[sv] = np.asarray(ini["params"] if ini is not None and ini["family"] == "dirichlet" else np.ravel(g.const(g.dir[sv])), float).copy()
+
+    def elog_s(sv, alphas):   # E log s of a Dirichlet variable, log p of a constant probability vector
+        if g.kind[sv] == "constant":
+            return np.log(np.ravel(g.const(sv)).astype(float))
+        return digamma(alphas[sv]) - digamma(np.sum(alphas[sv]))
     fe_hist = []
     out = None
     for _ in range(max(1, int(iterations))):
         What = {v: qW[v][0] * qW[v][1] for v in qW}
+        # q(z) of every mixture node from the marginals of the previous iteration
+        pi = {}
+        for mx in g.mixtures:
+            o, z = mx["out"], mx["z"]
+            d = g.dim[o]
+            yo, Co = (qx[o][0], qx[o][1]) if g.gauss[o] else (value(o), np.zeros((d, d)))
+            els = elog_s(g.cat[z], qs)
+            lg = np.empty(len(mx["m"]))
+            for k, (mk, pk) in enumerate(zip(mx["m"], mx["p"])):
+                if pk in qW:
+                    nu, V = qW[pk]
+                    elw, Wk = mvdigamma(0.5 * nu, d) + d * math.log(2.0) + np.linalg.slogdet(V)[1], What[pk]
+                else:
+                    Wk = np.atleast_2d(g.const(pk)).astype(float).reshape(d, d)
+                    elw = np.linalg.slogdet(Wk)[1]
+                r = yo - qx[mk][0]
+                lg[k] = els[k] - 0.5 * (d * LOG2PI - elw + np.trace(Wk @ (np.outer(r, r) + qx[mk][1] + Co)))
+            w = np.exp(lg - np.max(lg))
+            pi[z] = w / np.sum(w)
         # rule calls as the reference's trace counts them for a run WITHOUT the free energy: the messages the requested marginals pull in — the
         # marginals of the variables a user can name, i.e. not the anonymous output of a deterministic node (`B * x[t]`).  The remaining messages
         # (toward such outputs) are formed for the Bethe terms only and are not counted, as in oracle/rxoracle.c.
@@ -260,7 +342,11 @@ def infer(dump, data, iterations=1, free_energy=True):
             if t in GAUSS_COV or t in GAUSS_PREC:
                 other = ifs[1 - k]
                 Sigma, W = noise_of(fi)
-                if g.mf[fi]:
+                if fi in g.weight:   # a component of a mixture node: the Gaussian node's message with its log-potential weighted by q(z = k)
+                    wk = pi[g.weight[fi][0]][g.weight[fi][1]]
+                    src = qx[other][0] if g.gauss[other] else value(other)
+                    res = Msg("wp", wk * (W @ src), wk * W)
+                elif g.mf[fi]:
                     res = Msg("mv", qx[other][0], Sigma)
                 elif g.gauss[other]:
                     m = msg_v2f(other, fi, 1 - k)
@@ -374,8 +460,10 @@ def infer(dump, data, iterations=1, free_energy=True):
                 if ifs[2] in qW:
                     if moments[fi][0] is None:
                         raise ValueError("`missing` observations under a random precision are not part of the family")
-                    stats[ifs[2]][0] += 1
-                    stats[ifs[2]][1] += moments[fi][0]
+                    wk = pi[g.weight[fi][0]][g.weight[fi][1]] if fi in g.weight else 1.0
+                    stats[ifs[2]][0] += wk
+                    stats[ifs[2]][1] += wk * moments[fi][0]
+        qs_new = {sv: np.ravel(g.const(g.dir[sv])).astype(float) + sum(pi[z] for z in pi if g.cat[z] == sv) for sv in qs}
         qnew = {}
         for v in qW:
             nu0, S0 = g.prior_q(v)
@@ -400,7 +488,8 @@ def infer(dump, data, iterations=1, free_energy=True):
                     else:
                         _, Wm = noise_of(fi)
                         Elogdet = np.linalg.slogdet(Wm)[1]
-                    F += 0.5 * (d * LOG2PI - Elogdet + np.trace(Wm @ E)) - H
+                    wk = pi[g.weight[fi][0]][g.weight[fi][1]] if fi in g.weight else 1.0
+                    F += wk * 0.5 * (d * LOG2PI - Elogdet + np.trace(Wm @ E)) - H
                 elif t in ("*", "+") and fi in g.derived.values():
                     pass   # all interfaces clamped: the point entropies cancel (CountingReal bookkeeping)
                 elif t == "*":
@@ -433,11 +522,24 @@ def infer(dump, data, iterations=1, free_energy=True):
             for v in range(nv):
                 if g.gauss[v]:
                     F += (len(g.nbrs[v]) - 1) * _entropy(cov[v])
+            # Categorical nodes: −Σ_k π_k E log s_k with the new q(s); −H[q(z)] (node terms −2H, variable term +H); Dirichlet prior node U − H[q(s)]
+            for z, w in pi.items():
+                F += -float(np.dot(w, elog_s(g.cat[z], qs_new))) + float(np.sum(w[w > 0.0] * np.log(w[w > 0.0])))
+            for sv, al in qs_new.items():
+                a0 = np.ravel(g.const(g.dir[sv])).astype(float)
+                els = digamma(al) - digamma(np.sum(al))
+                logB = lambda a: float(np.sum(gammaln(a)) - gammaln(np.sum(a)))
+                U = logB(a0) - float(np.dot(a0 - 1.0, els))
+                Hs = logB(al) + (np.sum(al) - len(al)) * float(digamma(np.sum(al))) - float(np.dot(al - 1.0, digamma(al)))
+                F += U - Hs
             fe_hist.append(float(F))
         qW = qnew
+        qs = qs_new
         qx = {v: (mean[v].copy(), cov[v].copy()) for v in qx}
         counters.pop("on")
         out = dict(mean=mean, cov=cov, joints={fi: m[2] for fi, m in moments.items() if m[2] is not None}, counters=counters)
     out["fe"] = fe_hist
     out["q_prec"] = qW
+    out["q_dir"] = qs
+    out["q_cat"] = pi
     return out

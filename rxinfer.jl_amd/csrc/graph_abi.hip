@@ -133,6 +133,11 @@ rxhip_status rxhip_tree_get_precision(rxhip_engine* e, int64_t var, double* nu, 
     e->err.clear();
     return rxhip::tree::get_precision(e->tree, var, nu, V, e->err);
 }
+rxhip_status rxhip_tree_get_discrete(rxhip_engine* e, int64_t var, double* out, int32_t* n_components) {
+    if (!e || !e->tree) return e ? fail(e, RXHIP_ERR_BADARG, "rxhip_tree_get_discrete: not an engine of the node-array executor") : RXHIP_ERR_BADARG;
+    e->err.clear();
+    return rxhip::tree::get_discrete(e->tree, var, out, n_components, e->err);
+}
 rxhip_status rxhip_tree_get_info(rxhip_engine* e, rxhip_tree_info* out) {
     if (!e || !e->tree || !out) return RXHIP_ERR_BADARG;
     rxhip::tree::info(e->tree, out);

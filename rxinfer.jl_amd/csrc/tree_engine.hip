@@ -107,8 +107,8 @@ double host_digamma(double x) {
     return r + std::log(x) - 0.5 / x - f * (1.0 / 12.0 - f * (1.0 / 120.0 - f * (1.0 / 252.0 - f * (1.0 / 240.0 - f * (1.0 / 132.0)))));
 }
 
-enum VarClass { VC_CONST = 0, VC_DATA = 1, VC_DERIVED = 2, VC_PREC = 3, VC_GAUSS = 4 };
-enum NodeClass { NC_NOISE = 0, NC_MUL = 1, NC_ADD = 2, NC_PRIOR = 3 };
+enum VarClass { VC_CONST = 0, VC_DATA = 1, VC_DERIVED = 2, VC_PREC = 3, VC_GAUSS = 4, VC_CAT = 5, VC_DIR = 6 };   // (CAT: the switch of a mixture node; DIR: its probability vector)
+enum NodeClass { NC_NOISE = 0, NC_MUL = 1, NC_ADD = 2, NC_PRIOR = 3, NC_SKIP = 4 };   // (SKIP: NormalMixture / Categorical / Dirichlet — they act through virtual nodes and state ops)
 
 struct Program {
     int dmax = 1;
@@ -119,6 +119,7 @@ struct Program {
     int fe_level = 0;   // first level of the second phase (Bethe terms, residual moments, q(W) updates, sums)
     int n_ops = 0, n_levels = 0, n_messages = 0;
     std::vector<int> dim, vclass, marg_off, val_off, prec_off;
+    std::vector<int> discrete_k;   // per variable: components of a switch / probability vector (else 0)
     std::vector<int64_t> data_vars;
     std::vector<double> prec_init;   // [prec_doubles] initial state (replica-independent)
     uint64_t rule_calls = 0, products = 0, marginals = 0;
@@ -130,6 +131,7 @@ struct Program {
     long long io_bytes = 0;                     // what has to move whatever the schedule: the data in, the posteriors of the named variables out
     long long fe_bytes = 0;                     // the second phase's reads and writes per replica
     int longest_strand = 0;
+    bool has_mix = false;               // NormalMixture nodes: q(z), q(s) live in the precision-state array; lane-per-item kernels only (dimensions ≤ 8)
     bool has_mf = false;                // some Gaussian node runs under q(out) q(μ): the marginals of its interfaces are STATE (start: the @initialization marginals)
     std::vector<double> marg_init;      // [marg_doubles] when has_mf
     bool fe_heavy = false;   // the second phase holds OP_FE_ADD2 or OP_PREC_UPDATE ops (else the light kernel instance runs it)
@@ -145,6 +147,19 @@ struct Compiler {
     const int64_t* ifv;
     std::vector<int> nclass;
     std::vector<char> mf;   // per factor: a Gaussian node the model's constraints run under q(out) q(μ) — mean field between its two Gaussian interfaces
+    // NormalMixture (out, switch, m[1..K], p[1..K]) under MeanField(): the node's log-factor is Σ_k z_k log N(out | m_k, p_k⁻¹), so toward (out, m_k, p_k) it acts as K
+    // Gaussian precision nodes each WEIGHTED by π_k = q(z = k).  The compiler appends those K virtual three-interface nodes behind the real factors (everything
+    // downstream — leaf rules, Bethe terms, residual moments, entropy bookkeeping — sees ordinary Gaussian nodes carrying a weight) and adds two state ops: q(z) of
+    // every switch before the sweep (OP_CAT_UPDATE, from the marginals of the previous iteration) and q(s) with the switches' terms behind it (OP_DIR_UPDATE).
+    // Schedule and arithmetic: the mixture engine's (vmp_engines.hip: q(z) from the previous marginals, then the Gaussian sweep and q(s), then q(p) with the
+    // new q(m)), node by node instead of summed over the data set; tests/test_tree_mixture_gpu.py holds the two together.
+    std::vector<int64_t> xifv;          // interfaces of the real factors, then of the virtual ones
+    std::vector<int> xtype;             // node types alike
+    std::vector<int> wz, wk;            // per factor: the switch variable and component that weight it (−1)
+    struct Mix { int node, out, z, K; std::vector<int> m, p; };
+    std::vector<Mix> mixes;
+    std::vector<int> cat_s, dir_a, catK;   // per variable: a switch's probability-vector variable; a Dirichlet variable's concentration constant; components
+    int ftype(int f) const { return xtype[f]; }
     // edges: (factor, interface) with a Gaussian variable
     struct Edge { int f, k, v; };
     std::vector<Edge> edges;
@@ -204,6 +219,74 @@ struct Compiler {
         return noise_off[v];
     }
 
+    void expand_mixtures() {
+        wz.assign((size_t)nf, -1); wk.assign((size_t)nf, -1);
+        cat_s.assign((size_t)nv, -1); dir_a.assign((size_t)nv, -1); catK.assign((size_t)nv, 0);
+        const int64_t nf0 = nf;
+        bool any = false;
+        for (int64_t f = 0; f < nf0; ++f) any = any || xtype[f] == RXHIP_NODE_NORMAL_MIXTURE;
+        if (!any) return;
+        xifv.assign(g->factor_iface, g->factor_iface + iptr[nf0]);
+        for (int64_t f = 0; f < nf0; ++f) {
+            if (xtype[f] != RXHIP_NODE_NORMAL_MIXTURE) continue;
+            const int n = n_iface((int)f), K = (n - 2) / 2;
+            if (K < 1 || n != 2 + 2 * K) fail(RXHIP_ERR_BADARG, "factor %lld (NormalMixture): interfaces (out, switch, m[1..K], p[1..K]) expected", (long long)f);
+            Mix mx{(int)f, (int)iface((int)f, 0), (int)iface((int)f, 1), K, {}, {}};
+            const int d = g->var_rows[mx.out];
+            for (int k = 0; k < K; ++k) {
+                mx.m.push_back((int)iface((int)f, 2 + k));
+                mx.p.push_back((int)iface((int)f, 2 + K + k));
+                xtype.push_back(d == 1 ? RXHIP_NODE_NORMAL_MEAN_PRECISION : RXHIP_NODE_MVNORMAL_MEAN_PRECISION);
+                xifv.push_back(mx.out); xifv.push_back(mx.m[k]); xifv.push_back(mx.p[k]);
+                iptr.push_back((int64_t)xifv.size());
+                wz.push_back(mx.z); wk.push_back(k);
+            }
+            mixes.push_back(std::move(mx));
+        }
+        nf = (int64_t)xtype.size();
+        ifv = xifv.data();
+        P.has_mix = true;
+    }
+    void classify_mixtures() {
+        for (int64_t f = 0; f < nf; ++f) {
+            const int t = ftype((int)f);
+            if (t == RXHIP_NODE_CATEGORICAL) {
+                if (n_iface((int)f) != 2) fail(RXHIP_ERR_BADARG, "factor %lld (Categorical): interfaces (out, p) expected", (long long)f);
+                const int z = (int)iface((int)f, 0), sv = (int)iface((int)f, 1);
+                if (g->var_kind[z] != RXHIP_VARKIND_RANDOM || cat_s[z] >= 0) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld (Categorical): the output must be a random variable with this one prior", (long long)f);
+                cat_s[z] = sv;
+                P.vclass[z] = VC_CAT;
+            } else if (t == RXHIP_NODE_DIRICHLET) {
+                if (n_iface((int)f) != 2) fail(RXHIP_ERR_BADARG, "factor %lld (Dirichlet): interfaces (out, a) expected", (long long)f);
+                const int sv = (int)iface((int)f, 0), a = (int)iface((int)f, 1);
+                if (g->var_kind[sv] != RXHIP_VARKIND_RANDOM || dir_a[sv] >= 0 || P.vclass[a] != VC_CONST)
+                    fail(RXHIP_ERR_UNSUPPORTED, "factor %lld (Dirichlet): a random output with this one prior and a constant concentration expected", (long long)f);
+                dir_a[sv] = a;
+                P.vclass[sv] = VC_DIR;
+                catK[sv] = g->var_rows[a] * g->var_cols[a];
+                for (int k = 0; k < catK[sv]; ++k)
+                    if (!(cptr(a)[k] > 0.0)) fail(RXHIP_ERR_BADARG, "factor %lld (Dirichlet): concentrations must be positive", (long long)f);
+            }
+        }
+        for (const Mix& mx : mixes) {
+            if (P.vclass[mx.z] != VC_CAT) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (NormalMixture): the switch must be a random variable with a Categorical prior", mx.node);
+            if (catK[mx.z] != 0) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (NormalMixture): its switch drives another mixture node as well", mx.node);
+            catK[mx.z] = mx.K;
+            const int sv = cat_s[mx.z];
+            if (P.vclass[sv] == VC_DIR) {
+                if (catK[sv] != mx.K) fail(RXHIP_ERR_BADARG, "factor %d (NormalMixture): %d components, a probability vector of %d", mx.node, mx.K, catK[sv]);
+            } else if (P.vclass[sv] == VC_CONST) {
+                if (g->var_rows[sv] * g->var_cols[sv] != mx.K) fail(RXHIP_ERR_BADARG, "factor %d (NormalMixture): %d components, a probability vector of another length", mx.node, mx.K);
+                for (int k = 0; k < mx.K; ++k)
+                    if (!(cptr(sv)[k] > 0.0)) fail(RXHIP_ERR_BADARG, "factor %d (NormalMixture): constant switch probabilities must be positive", mx.node);
+            } else
+                fail(RXHIP_ERR_UNSUPPORTED, "factor %d (NormalMixture): the switch's probability vector must be a constant or a Dirichlet variable", mx.node);
+        }
+        P.discrete_k = catK;
+        for (int64_t v = 0; v < nv; ++v)
+            if (P.vclass[v] == VC_CAT && catK[v] == 0) fail(RXHIP_ERR_UNSUPPORTED, "variable %lld: a Categorical variable that is not the switch of a NormalMixture node has no schedule here", (long long)v);
+    }
+
     void parse() {
         nv = g->n_variables;
         nf = g->n_factors;
@@ -213,6 +296,12 @@ struct Compiler {
         iptr.resize(nf + 1);
         for (int64_t f = 0; f <= nf; ++f) iptr[f] = g->factor_iface_ptr ? g->factor_iface_ptr[f] : 3 * f;
         ifv = g->factor_iface;
+        if (iptr[0] != 0) fail(RXHIP_ERR_BADARG, "factor_iface_ptr must start at 0");
+        xtype.assign(g->factor_type, g->factor_type + nf);
+        for (int64_t f = 0; f < nf; ++f)
+            for (int k = 0; k < n_iface((int)f); ++k)
+                if (iface((int)f, k) < 0 || iface((int)f, k) >= nv) fail(RXHIP_ERR_BADARG, "factor %lld: interface %d names no variable", (long long)f, k);
+        expand_mixtures();
         P.dim.assign(nv, 0);
         P.vclass.assign(nv, VC_GAUSS);
         nclass.assign(nf, -1);
@@ -227,9 +316,8 @@ struct Compiler {
             if (g->var_rows[v] < 1) fail(RXHIP_ERR_BADARG, "variable %lld: no rows", (long long)v);
         }
         for (int64_t f = 0; f < nf; ++f) {
-            const int t = g->factor_type[f];
-            for (int k = 0; k < n_iface((int)f); ++k)
-                if (iface((int)f, k) < 0 || iface((int)f, k) >= nv) fail(RXHIP_ERR_BADARG, "factor %lld: interface %d names no variable", (long long)f, k);
+            const int t = ftype((int)f);
+            if (t == RXHIP_NODE_NORMAL_MIXTURE || t == RXHIP_NODE_CATEGORICAL || t == RXHIP_NODE_DIRICHLET) { nclass[f] = NC_SKIP; continue; }
             switch (t) {
             case RXHIP_NODE_MVNORMAL_MEAN_COV: case RXHIP_NODE_NORMAL_MEAN_VARIANCE: case RXHIP_NODE_MVNORMAL_MEAN_PRECISION: case RXHIP_NODE_NORMAL_MEAN_PRECISION:
                 nclass[f] = NC_NOISE; break;
@@ -243,6 +331,8 @@ struct Compiler {
         // the factorisation the model's constraints ask of every node against the one this schedule implements (q(out, μ) q(W) on Gaussian nodes, joint
         // deterministic nodes): a mismatch is refused with the node named — never answered with the other variational family's posterior
         if (rxhip_lower::check_factorisation(g, &mf)) fail(RXHIP_ERR_UNSUPPORTED, "%s", rxhip_lower::last_error().c_str());
+        mf.resize((size_t)nf, 1);   // (the components of a mixture node: mean field between `out` and the mean wherever both are random)
+        classify_mixtures();
         // precision variables
         for (int64_t f = 0; f < nf; ++f)
             if (nclass[f] == NC_PRIOR) {
@@ -270,7 +360,7 @@ struct Compiler {
     void check_family() {
         int dmx = 1;
         for (int64_t f = 0; f < nf; ++f) {
-            const int t = g->factor_type[f], a = (int)iface((int)f, 0), b = (int)iface((int)f, 1), c = (int)iface((int)f, 2);
+            const int t = ftype((int)f), a = (int)iface((int)f, 0), b = (int)iface((int)f, 1), c = (int)iface((int)f, 2);
             if (nclass[f] == NC_NOISE) {
                 const bool prec_node = t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION;
                 if (P.vclass[a] == VC_PREC || P.vclass[b] == VC_PREC) fail(RXHIP_ERR_UNSUPPORTED, "a precision variable on a Gaussian node's out / mean interface");
@@ -300,20 +390,28 @@ struct Compiler {
         for (int64_t f = 0; f < nf; ++f) {
             mf[f] = mf[f] && nclass[f] == NC_NOISE && P.vclass[iface((int)f, 0)] == VC_GAUSS && P.vclass[iface((int)f, 1)] == VC_GAUSS;
             P.has_mf = P.has_mf || mf[f];
-
         }
+        if (P.has_mix && dmx > 8) fail(RXHIP_ERR_UNSUPPORTED, "NormalMixture nodes run on the lane-per-item kernels: dimensions <= 8 (this graph: %d)", dmx);
+        P.has_mf = P.has_mf || P.has_mix;   // (the switch's rule reads the marginals of the means of the previous iteration: marginals are state)
         // <= 8: the register instances (lane per op and replica); above: the graph's own maximum, staged in LDS by a wavefront per op and replica
         P.dmax = dmx <= 1 ? 1 : dmx <= 2 ? 2 : dmx <= 4 ? 4 : dmx <= 8 ? 8 : dmx;
     }
 
     void build_edges() {
+        for (const Mix& mx : mixes) {
+            for (int k = 0; k < mx.K; ++k) {
+                if (P.vclass[mx.m[k]] == VC_PREC || P.vclass[mx.m[k]] == VC_CAT || P.vclass[mx.m[k]] == VC_DIR) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (NormalMixture): m[%d] is not a Gaussian variable", mx.node, k + 1);
+                if (P.dim[mx.m[k]] != P.dim[mx.out] || P.dim[mx.p[k]] != P.dim[mx.out]) fail(RXHIP_ERR_BADARG, "factor %d (NormalMixture): component %d differs in dimension from `out`", mx.node, k + 1);
+            }
+            if (P.vclass[mx.out] == VC_PREC || P.vclass[mx.out] == VC_CAT || P.vclass[mx.out] == VC_DIR) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (NormalMixture): `out` is not a Gaussian variable or a value", mx.node);
+        }
         var_edges.assign(nv, {});
         fac_edges.assign(nf, std::vector<int>(3, -1));
         std::vector<int> uf(nv + 2 * nf);   // (a node under q(out) q(μ) is two leaf factors as far as cycles go: its interfaces do not exchange messages)
         std::iota(uf.begin(), uf.end(), 0);
         auto find = [&](int x) { while (uf[x] != x) { uf[x] = uf[uf[x]]; x = uf[x]; } return x; };
         for (int64_t f = 0; f < nf; ++f) {
-            if (nclass[f] == NC_PRIOR) continue;
+            if (nclass[f] == NC_PRIOR || nclass[f] == NC_SKIP) continue;
             for (int k = 0; k < 3; ++k) {
                 if (k == 1 && nclass[f] == NC_MUL) continue;
                 if (k == 2 && nclass[f] == NC_NOISE) continue;
@@ -515,7 +613,7 @@ struct Compiler {
                             const int e2 = var_edges[ed.v][0] == m ? var_edges[ed.v][1] : var_edges[ed.v][0];
                             wf = wanted_form(e2);
                         }
-                        form[m] = wf == 0 ? 0 : 1;
+                        form[m] = (wf == 0 && wz[ed.f] < 0) ? 0 : 1;   // (a weighted leaf — a mixture component — stays in precision form: weight 0 is the zero message)
                     } else {
                         // a moment-form sum into a variable with three or more edges: every reader is a product or the marginal, each of which would invert
                         // it for itself — the op stores the precision form instead (one inverse where there were two or three)
@@ -555,7 +653,7 @@ struct Compiler {
     }
     int src_off(int m) const { return off[alias[m] >= 0 ? alias[m] : m]; }
     void noise_params(OpRec& r, int f, int d) {
-        const int c = (int)iface(f, 2), t = g->factor_type[f];
+        const int c = (int)iface(f, 2), t = ftype(f);
         if (P.vclass[c] == VC_PREC) r.w[W_PREC] = P.prec_off[c];
         else r.w[W_C0] = noise_block(c, d, t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION);
     }
@@ -600,6 +698,8 @@ struct Compiler {
         for (int64_t v = 0; v < nv; ++v) {
             if (P.vclass[v] == VC_GAUSS) { P.marg_off[v] = (int)mo; mo += msz(P.dim[v]) + 1; }
             if (P.vclass[v] == VC_PREC) { const int d = P.dim[v]; P.prec_off[v] = (int)po; po += 2 + d * (d + 1) / 2 + 2 * d * d; }
+            if (P.vclass[v] == VC_CAT) { P.prec_off[v] = (int)po; po += catK[v]; }          // q(z): π[K]
+            if (P.vclass[v] == VC_DIR) { P.prec_off[v] = (int)po; po += 2 * catK[v]; }      // q(s): α[K] | E log s[K]
         }
         P.marg_doubles = mo; P.prec_doubles = po;
         long long so = 0;
@@ -613,9 +713,22 @@ struct Compiler {
 
     void init_precision() {
         P.prec_init.assign((size_t)P.prec_doubles, 0.0);
+        for (int64_t v = 0; v < nv; ++v) {
+            double* st = P.prec_init.data() + (P.prec_off[v] >= 0 ? P.prec_off[v] : 0);
+            const int K = catK[v];
+            if (P.vclass[v] == VC_CAT)
+                for (int k = 0; k < K; ++k) st[k] = 1.0 / K;
+            if (P.vclass[v] == VC_DIR) {   // `@initialization` q(s), default the prior
+                const double* a = cptr(dir_a[v]);
+                if (g->var_init_family && g->var_init && g->var_init_family[v] == RXHIP_INIT_DIRICHLET && g->var_init[v] >= 0) a = g->const_pool + g->var_init[v];
+                double sum = 0.0;
+                for (int k = 0; k < K; ++k) { if (!(a[k] > 0.0)) fail(RXHIP_ERR_BADARG, "initial marginal of variable %lld: positive concentrations expected", (long long)v); sum += a[k]; }
+                for (int k = 0; k < K; ++k) { st[k] = a[k]; st[K + k] = host_digamma(a[k]) - host_digamma(sum); }
+            }
+        }
         for (int64_t f = 0; f < nf; ++f) {
             if (nclass[f] != NC_PRIOR) continue;
-            const int v = (int)iface((int)f, 0), d = P.dim[v], t = g->factor_type[f];
+            const int v = (int)iface((int)f, 0), d = P.dim[v], t = ftype((int)f);
             const double* a = cptr((int)iface((int)f, 1));
             const double* b = cptr((int)iface((int)f, 2));
             double nu0;
@@ -670,6 +783,10 @@ struct Compiler {
         std::vector<char> need(nv, 0);
         for (int64_t f = 0; f < nf; ++f)
             if (mf[f]) need[iface((int)f, 0)] = need[iface((int)f, 1)] = 1;
+        for (const Mix& mx : mixes) {
+            for (int mk : mx.m) need[mk] = need[mk] || P.vclass[mk] == VC_GAUSS;
+            need[mx.out] = need[mx.out] || P.vclass[mx.out] == VC_GAUSS;
+        }
         for (int64_t v = 0; v < nv; ++v) {
             if (!need[v]) continue;
             const int d = P.dim[v];
@@ -751,6 +868,25 @@ struct Compiler {
             derived_levels = 0;
             for (int64_t v = 0; v < nv; ++v) derived_levels = std::max(derived_levels, lv[v]);
         }
+        // q(z) of every mixture node, from the marginals q(m), q(p), q(s) (and q(out)) of the PREVIOUS iteration: a level of its own in front of the messages
+        for (const Mix& mx : mixes) {
+            const int d = P.dim[mx.out];
+            OpRec& r = emit(derived_levels, OP_CAT_UPDATE, d);
+            r.w[W_N] = mx.K;
+            r.w[W_OUT] = P.prec_off[mx.z];
+            if (P.vclass[mx.out] == VC_GAUSS) { r.w[W_VAL] = P.marg_off[mx.out]; r.w[W_FLAGS] |= F_VAL_MARG; }
+            else { int bit; r.w[W_VAL] = value_source(mx.out, bit); if (bit) r.w[W_FLAGS] |= F_VAL_SLOT; }
+            const int sv = cat_s[mx.z];
+            if (P.vclass[sv] == VC_DIR) r.w[W_IN0] = P.prec_off[sv];
+            else r.w[W_C0] = log_probabilities(sv, mx.K);
+            r.w[W_LIST] = (int)P.aux.size();
+            for (int k = 0; k < mx.K; ++k) {   // per component: where the mean's marginal (or constant value) and the precision's state (or constant block) are
+                const int mk = mx.m[k], pk = mx.p[k];
+                P.aux.push_back(P.vclass[mk] == VC_GAUSS ? P.marg_off[mk] : -1 - const_value(mk));
+                P.aux.push_back(P.vclass[pk] == VC_PREC ? P.prec_off[pk] : -1 - noise_block(pk, d, true));
+            }
+        }
+        if (!mixes.empty()) ++derived_levels;
         const int L0 = derived_levels;   // messages start behind the derived values
         int maxl = 0;
         for (int m = 0; m < 2 * E; ++m) {
@@ -794,6 +930,7 @@ struct Compiler {
                     }
                     if (form[m]) r.w[W_FLAGS] |= F_OUT_WP;
                     noise_params(r, f, d);
+                    weigh(r, f);
                     r.w[W_OUT] = off[m];
                 } else {
                     OpRec& r = emit(lv, OP_NOISE, d);
@@ -853,6 +990,10 @@ struct Compiler {
             }
         for (int64_t f = 0; f < nf; ++f)   // (a mean-field rule reads the STORED marginal of its other interface every iteration: such a variable keeps the message route)
             if (mf[f]) push_from[iface((int)f, 0)] = push_from[iface((int)f, 1)] = -1;
+        for (const Mix& mx : mixes) {   // (so does the switch's rule)
+            for (int mk : mx.m) push_from[mk] = -1;
+            push_from[mx.out] = -1;
+        }
         for (int64_t v = 0; v < nv; ++v)
             if (push_from[v] >= 0 && push_from[push_from[v]] >= 0) push_from[v] = -2;   // the input is an image itself: this one takes the message route
         for (int64_t v = 0; v < nv; ++v)
@@ -901,7 +1042,7 @@ struct Compiler {
                 r.w[word] = P.marg_off[v];
         };
         std::vector<int> ent_coef(nv, 0);
-        std::vector<std::vector<int>> prec_stats(nv);
+        std::vector<std::vector<int>> prec_stats(nv), prec_weight(nv);
         std::vector<int> prec_nodes(nv, 0);
         long long stat_o = 0;
         auto new_term = [&]() { terms.push_back((int)P.term_slots); return (int)P.term_slots++; };
@@ -948,10 +1089,12 @@ struct Compiler {
                     r.w[W_VAL2] = value_source(b, bit); if (bit) r.w[W_FLAGS] |= F_VAL2_SLOT;
                 }
                 r.w[W_TERM] = new_term();
+                weigh(r, (int)f);
                 if (rw) {
                     r.w[W_FLAGS] |= F_STAT;
                     r.w[W_C1] = (int)stat_o;
                     prec_stats[c].push_back((int)stat_o);
+                    prec_weight[c].push_back(wz[f] >= 0 ? P.prec_off[wz[f]] + wk[f] : -1);
                     stat_o += d * d;
                 }
             } else if (nclass[f] == NC_MUL) {
@@ -998,8 +1141,37 @@ struct Compiler {
             r.w[W_PREC] = P.prec_off[v];
             r.w[W_LIST] = (int)P.aux.size();
             r.w[W_N] = (int)prec_stats[v].size();
-            for (int s : prec_stats[v]) P.aux.push_back(s);
+            bool weighted = false;
+            for (int wo : prec_weight[v]) weighted = weighted || wo >= 0;
+            if (weighted) r.w[W_FLAGS] |= F_WEIGHT;   // the list holds (moments, weight | −1) pairs: ν = ν0 + Σ π, V⁻¹ = S0⁻¹ + Σ π E[rrᵀ] (the moments arrive weighted)
+            for (size_t q = 0; q < prec_stats[v].size(); ++q) {
+                P.aux.push_back(prec_stats[v][q]);
+                if (weighted) P.aux.push_back(prec_weight[v][q]);
+            }
             r.w[W_TERM] = new_term();
+        }
+        // q(s) of every probability vector with its switches' terms: −Σ_i Σ_k π_ik E log s_k (new q(s)), −Σ_i H[q(z_i)], the Dirichlet prior node U − H[q(s)];
+        // switches with a CONSTANT probability vector: one op per vector with the first two terms
+        {
+            std::vector<int> owners;
+            for (const Mix& mx : mixes)
+                if (std::find(owners.begin(), owners.end(), cat_s[mx.z]) == owners.end()) owners.push_back(cat_s[mx.z]);
+            for (int sv : owners) {
+                int K = 0, cnt = 0;
+                const int lst = (int)P.aux.size();
+                for (const Mix& mx : mixes)
+                    if (cat_s[mx.z] == sv) { P.aux.push_back(P.prec_off[mx.z]); K = mx.K; ++cnt; }
+                OpRec& r = emit(LP, OP_DIR_UPDATE, 1);
+                r.w[W_N] = K;
+                r.w[W_LIST] = lst;
+                r.w[W_VAL2] = cnt;
+                if (P.vclass[sv] == VC_DIR) {
+                    r.w[W_PREC] = P.prec_off[sv];
+                    r.w[W_C0] = const_value(dir_a[sv]);
+                } else
+                    r.w[W_C0] = log_probabilities(sv, K);
+                r.w[W_TERM] = new_term();
+            }
         }
         // fixed-order tree sum of the terms (chunks of 32)
         int lv = LP + 1;
@@ -1038,6 +1210,20 @@ struct Compiler {
         P.lazy_level = P.n_push ? lv : -1;
     }
     int derived_levels = 0;
+    std::vector<int> logp_off;   // per constant probability vector: constant-pool offset of its logarithms (−1)
+    int log_probabilities(int v, int K) {
+        if (logp_off.empty()) logp_off.assign(nv, -1);
+        if (logp_off[v] < 0) {
+            logp_off[v] = (int)P.cpool.size();
+            for (int k = 0; k < K; ++k) P.cpool.push_back(std::log(cptr(v)[k]));
+        }
+        return logp_off[v];
+    }
+    void weigh(OpRec& r, int f) {   // a component of a mixture node: the op scales its message / energy / residual moments by π_k = q(z = k)
+        if (wz[f] < 0) return;
+        r.w[W_FLAGS] |= F_WEIGHT;
+        r.w[W_LIST] = P.prec_off[wz[f]] + wk[f];
+    }
     std::vector<int> push_from, push_fac;   // per variable: the variable whose marginal it is the image of (−1), through which `*` node
     std::vector<int> push_ld;               // per variable: constant-pool offset of 2·log|det A| of a square, nonsingular map (−1: none; −2: not asked yet)
     int push_logdet(int v) {
@@ -1149,7 +1335,7 @@ struct Compiler {
         for (int64_t v = 0; v < nv; ++v) P.is_push[v] = push_from[v] >= 0;
         std::stable_sort(recs.begin(), recs.end(), [](const OpRec& a, const OpRec& b) { return a.level != b.level ? a.level < b.level : a.w[W_OP] < b.w[W_OP]; });
         P.n_ops = (int)recs.size();
-        for (const OpRec& r : recs) P.fe_heavy = P.fe_heavy || r.w[W_OP] == OP_FE_ADD2 || r.w[W_OP] == OP_PREC_UPDATE;
+        for (const OpRec& r : recs) P.fe_heavy = P.fe_heavy || r.w[W_OP] == OP_FE_ADD2 || r.w[W_OP] == OP_PREC_UPDATE || r.w[W_OP] == OP_DIR_UPDATE;
         P.ops.resize((size_t)P.n_ops * OP_WORDS);
         int nl = recs.empty() ? 0 : recs.back().level + 1;
         P.lvl_ptr.assign(nl + 1, 0);
@@ -1244,7 +1430,7 @@ struct Compiler {
                 reg_kind[i] = ins[best_k].kind;
                 reg_idx[i] = ins[best_k].idx;
             } else {
-                int lv = (op == OP_DERIVE_MUL || op == OP_DERIVE_ADD) ? oplevel[i] : L0;
+                int lv = (op == OP_DERIVE_MUL || op == OP_DERIVE_ADD || op == OP_CAT_UPDATE) ? oplevel[i] : L0;
                 for (const In& in : ins) lv = std::max(lv, slevel[strand_of[prod[in.off]]] + 1);
                 strand_of[i] = (int)members.size();
                 members.push_back({i});
@@ -1564,6 +1750,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     // once the replicas fill the device (4 096: 3.4 against 5.4 ms; 65 536: 16 against 83): profiles/r06/tree_tile.txt
     e->tiled = P.dmax > 8 || (P.dmax > 4 && e->R <= 1024);
     if (const char* t = hook_env("RXHIP_TREE_TILE")) e->tiled = P.dmax > 8 || (P.dmax > 4 && std::atoi(t) != 0);
+    if (P.has_mix) e->tiled = false;   // (the mixture ops exist in the lane-per-item kernels only; the compiler refused dimensions above 8)
     e->elem_fast = e->tiled;
     e->allow_missing = g->allow_missing != 0;
     // schedule: deep graphs walk their levels inside a workgroup (one launch per iteration); wide, shallow ones take a launch per level
@@ -1899,6 +2086,24 @@ rxhip_status get_precision(Engine* e, int64_t var, double* nu, double* V, std::s
                     V[((size_t)r * d + b) * d + a] = x;
                 }
     }
+    return RXHIP_OK;
+}
+
+// q(z) of a mixture node's switch (K probabilities) or the concentrations of q(s) of a probability vector: [replica][K]
+rxhip_status get_discrete(Engine* e, int64_t var, double* out, int32_t* n_components, std::string& err) {
+    if (!e) { err = "null engine"; return RXHIP_ERR_BADARG; }
+    if (!e->ran) { err = "get_discrete before run"; return RXHIP_ERR_STATE; }
+    const Program& P = e->prog;
+    if (var < 0 || var >= (int64_t)P.vclass.size() || (P.vclass[var] != VC_CAT && P.vclass[var] != VC_DIR)) { err = "not the switch of a mixture node or its probability vector"; return RXHIP_ERR_BADARG; }
+    const int K = P.discrete_k[var];
+    if (n_components) *n_components = K;
+    if (!out) return RXHIP_OK;
+    DevScope ds(e->device);
+    std::vector<double> buf((size_t)K * e->RS);
+    TCHK(hipStreamSynchronize(e->stream));
+    TCHK(hipMemcpy(buf.data(), e->d_prec + (size_t)P.prec_off[var] * e->RS, sizeof(double) * buf.size(), hipMemcpyDeviceToHost));   // (mixture graphs: lane-per-item kernels, replica-fastest storage)
+    for (long long r = 0; r < e->R; ++r)
+        for (int k = 0; k < K; ++k) out[(size_t)r * K + k] = buf[(size_t)k * e->RS + r];
     return RXHIP_OK;
 }
 

@@ -18,6 +18,7 @@ rxhip_status set_data(Engine* e, const int64_t* vars, int64_t n_vars, const doub
 rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err);
 rxhip_status get_marginals(Engine* e, const int64_t* vars, int64_t n_vars, double* mean, double* cov, std::string& err);
 rxhip_status get_precision(Engine* e, int64_t var, double* nu, double* V, std::string& err);
+rxhip_status get_discrete(Engine* e, int64_t var, double* out, int32_t* n_components, std::string& err);
 rxhip_status get_free_energy(Engine* e, double* per_iteration, std::string& err);
 rxhip_status get_free_energy_per_replica(Engine* e, double* per_replica, std::string& err);
 void counters(Engine* e, uint64_t* rule_calls, uint64_t* products, uint64_t* marginals);

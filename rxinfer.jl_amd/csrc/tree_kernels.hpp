@@ -41,6 +41,9 @@ enum : int {
     OP_PREC_UPDATE = 18, // q(W) ← Wishart(ν0 + n, (S0⁻¹ + Σ E[rrᵀ])⁻¹), its share of the Bethe sum
     OP_FE_NOISE2M = 19,  // OP_FE_NOISE2 from ONE inbound message and the two variables' marginals (register kernels): one inverse instead of three
     OP_MARG_PUSH = 20,   // marginal of the output of `A * x` as the image of x's marginal: (A m, A V Aᵀ, log|A V Aᵀ|) — second phase, register kernels
+    OP_CAT_UPDATE = 22,  // q(z) of a NormalMixture node's switch: π_k ∝ exp(E log s_k − ½[d log 2π − E log|p_k| + tr(E[p_k] E[(out − m_k)(out − m_k)ᵀ])]) from the marginals of the
+                         // previous iteration (lane-per-item kernels; the node itself is K weighted Gaussian nodes: F_WEIGHT)
+    OP_DIR_UPDATE = 23,  // q(s) = Dirichlet(a + Σ_i π_i) of a probability vector with the terms of its switches: −Σ π E log s, −H[q(z)], the prior node U − H[q(s)]
     OP_FE_NOISE_MF = 21  // average energy of a Gaussian node under q(out) q(μ) (mean field between its Gaussian interfaces): E[rrᵀ] = V_out + V_μ + (m_out − m_μ)(…)ᵀ
 };
 constexpr int OP_WORDS = 16;
@@ -59,6 +62,8 @@ enum : int {
     F_PUSH_B = 2048,     // … the marginal named by W_VAL2 (FE_NOISE2M side b)
     F_FOLD_ENT = 4096,   // FE_NOISE2M / FE_NOISE1: W_OUT · H[q(v)] of the variable whose log|V| the op has at hand (side b / the random interface) is part of this term
     F_MAY_MISS = 16384,  // OP_LEAF / FE_NOISE1 / FE_NOISE0 on a DATA value of a graph created with allow_missing: NaN (`missing`) → no message / no energy term
+    F_WEIGHT = 32768,    // OP_LEAF / FE_NOISE0 / FE_NOISE1 / FE_NOISE_MF: a component of a mixture node — message, energy and residual moments × π_k, the double at p.prec[W_LIST];
+                         // OP_PREC_UPDATE: the list holds (moments, weight | −1) pairs, ν = ν0 + Σ weights
     F_VAL_MARG = 8192    // OP_LEAF: the value is the MEAN of the marginal slot W_VAL — the rule of a Gaussian node under q(out) q(μ): N(E[μ], Σ) toward out, N(E[out], Σ) toward μ
 };
 // strand schedule: an input offset that names the message the previous op of the lane's strand left in registers
@@ -455,6 +460,58 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
         for (int i = 0; i < N; ++i) x[i] += y[i];
         st_vec<N>(p.val, w[W_OUT], d, p.RS, r, x);
     } break;
+    case OP_CAT_UPDATE: {   // q(z): W_OUT π[K] (precision-state array), W_VAL `out` (value, or F_VAL_MARG: its marginal), W_IN0 q(s) state α | E log s (−1: log p at W_C0),
+                            // list: per component (marginal of m_k | −1 − constant value, state of p_k | −1 − constant noise block)
+        const int K = w[W_N];
+        const int* lst = p.aux + w[W_LIST];
+        double y[N], Cy[N][N], u0;
+        if (fl & F_VAL_MARG) load_marginal<N>(p, w[W_VAL], false, 0, 0, d, r, true, y, Cy, u0);
+        else {
+            load_value<N>(p, w[W_VAL], fl & F_VAL_SLOT, d, r, y);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) Cy[i][j] = 0.0;
+        }
+        double mx = -__builtin_huge_val();
+        for (int k = 0; k < K; ++k) {
+            double m[N], C[N][N], Wm[N][N], elw;
+            const int mo = lst[2 * k], po = lst[2 * k + 1];
+            if (mo >= 0) load_marginal<N>(p, mo, false, 0, 0, d, r, true, m, C, u0);
+            else {
+                load_value<N>(p, -1 - mo, false, d, r, m);
+#pragma unroll
+                for (int i = 0; i < N; ++i)
+#pragma unroll
+                    for (int j = 0; j < N; ++j) C[i][j] = 0.0;
+            }
+            if (po >= 0) {
+                ld_full<N>(p.prec, po + 1 + d * (d + 1) / 2, d, p.RS, r, 0.0, Wm);
+                elw = p.prec[(long long)(po + 1 + d * (d + 1) / 2 + 2 * d * d) * p.RS + r];
+            } else {
+                const double* c = p.cpool + (-1 - po);
+                ld_cmat<N>(c + d * d, d, d, 0.0, Wm);
+                elw = c[2 * d * d];
+            }
+            double q = 0.0;
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) q += (i < d && j < d) ? Wm[i][j] * ((y[i] - m[i]) * (y[j] - m[j]) + C[i][j] + Cy[i][j]) : 0.0;
+            const double els = w[W_IN0] >= 0 ? p.prec[(long long)(w[W_IN0] + K + k) * p.RS + r] : p.cpool[w[W_C0] + k];
+            const double lg = els - 0.5 * (d * T_LOG2PI - elw + q);
+            p.prec[(long long)(w[W_OUT] + k) * p.RS + r] = lg;
+            mx = lg > mx ? lg : mx;
+        }
+        double Z = 0.0;
+        for (int k = 0; k < K; ++k) {
+            const double e = exp(p.prec[(long long)(w[W_OUT] + k) * p.RS + r] - mx);
+            p.prec[(long long)(w[W_OUT] + k) * p.RS + r] = e;
+            Z += e;
+        }
+        for (int k = 0; k < K; ++k) p.prec[(long long)(w[W_OUT] + k) * p.RS + r] /= Z;
+        ok = Z > 0.0 && Z < 1.0e300;
+    } break;
     case OP_LEAF: {
         double v[N], Sg[N][N], Wm[N][N], el;
         if (fl & F_VAL_MARG) ld_vec<N>(p.marg, w[W_VAL], d, p.RS, r, v);   // (the marginal of the PREVIOUS iteration: every marginal op of the sweep comes after every leaf)
@@ -464,6 +521,15 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
         if (wp) {
             double xi[N];
             matvec<N>(Wm, v, xi);
+            if (fl & F_WEIGHT) {   // a mixture component: (π E[W] v, π E[W])
+                const double wt = p.prec[(long long)w[W_LIST] * p.RS + r];
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    xi[i] *= wt;
+#pragma unroll
+                    for (int j = 0; j < N; ++j) Wm[i][j] *= wt;
+                }
+            }
             if (fl & F_MAY_MISS) {   // a `missing` observation sends nothing: the zero of the precision form (the compiler keeps such leaves in it)
                 bool miss = false;
 #pragma unroll
@@ -769,8 +835,15 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
 #pragma unroll
             for (int j = 0; j < N; ++j) E[i][j] = Va[i][j] + Vb[i][j] + (ma[i] - mb[i]) * (ma[j] - mb[j]);
         double term = 0.0;
+        const double wt = (!LIGHT && (fl & F_WEIGHT)) ? p.prec[(long long)w[W_LIST] * p.RS + r] : 1.0;   // (a mixture component)
+        if (!LIGHT && (fl & F_WEIGHT) && (fl & F_STAT)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) E[i][j] *= wt;
+        }
         if (fl & F_STAT) st_full<N>(p.stat, w[W_C1], d, p.RS, r, E);
-        else term = 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
+        else term = wt * 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
         p.term[(long long)w[W_TERM] * p.RS + r] = term;
     } break;
     case OP_FE_NOISE1:
@@ -806,8 +879,15 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
 #pragma unroll
             for (int i = 0; i < N; ++i) miss = miss || (i < d && rv[i] != rv[i]);
         }
+        const double wt = (!LIGHT && (fl & F_WEIGHT)) ? p.prec[(long long)w[W_LIST] * p.RS + r] : 1.0;   // (a mixture component: energy and moments × π_k, the entropy as it is)
+        if (!LIGHT && (fl & F_WEIGHT) && (fl & F_STAT)) {
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) E[i][j] *= wt;
+        }
         if (fl & F_STAT) st_full<N>(p.stat, w[W_C1], d, p.RS, r, E);
-        else if (!miss) term += 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
+        else if (!miss) term += wt * 0.5 * (d * T_LOG2PI - el + trace_prod<N>(Wm, E, d));
         p.term[(long long)w[W_TERM] * p.RS + r] = term;
     } break;
     case OP_FE_ENT: {
@@ -845,6 +925,47 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         ok = spd_inv<N>(S, Si, ldS) && ok;
         p.term[(long long)w[W_TERM] * p.RS + r] = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
     } break;
+    case OP_DIR_UPDATE: if (!LIGHT) {   // W_N K, list: the π slots of W_VAL2 switches; W_PREC the state α | E log s with the prior's concentrations at W_C0 (−1: constant log p at W_C0)
+        const int K = w[W_N], nz = w[W_VAL2], ps = w[W_PREC];
+        const int* lst = p.aux + w[W_LIST];
+        double F = 0.0;
+        for (int i = 0; i < nz; ++i)   // −H[q(z_i)]
+            for (int k = 0; k < K; ++k) {
+                const double pk = p.prec[(long long)(lst[i] + k) * p.RS + r];
+                F += pk > 0.0 ? pk * log(pk) : 0.0;
+            }
+        const double* c = p.cpool + w[W_C0];
+        if (ps < 0) {
+            for (int k = 0; k < K; ++k) {
+                double sk = 0.0;
+                for (int i = 0; i < nz; ++i) sk += p.prec[(long long)(lst[i] + k) * p.RS + r];
+                F -= sk * c[k];
+            }
+        } else {
+            double asum = 0.0, a0sum = 0.0;
+            for (int k = 0; k < K; ++k) {
+                double sk = 0.0;
+                for (int i = 0; i < nz; ++i) sk += p.prec[(long long)(lst[i] + k) * p.RS + r];
+                const double al = c[k] + sk;
+                p.prec[(long long)(ps + k) * p.RS + r] = al;
+                asum += al;
+                a0sum += c[k];
+            }
+            const double dsum = t_digamma(asum);
+            double lB = -lgamma(asum), lB0 = -lgamma(a0sum), Us = 0.0, Hs = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const double al = p.prec[(long long)(ps + k) * p.RS + r], dg = t_digamma(al), els = dg - dsum;
+                p.prec[(long long)(ps + K + k) * p.RS + r] = els;
+                F -= (al - c[k]) * els;          // −Σ_i π_ik E log s_k
+                lB += lgamma(al);
+                lB0 += lgamma(c[k]);
+                Us += (c[k] - 1.0) * els;
+                Hs += (al - 1.0) * dg;
+            }
+            F += (lB0 - Us) - (lB + (asum - K) * dsum - Hs);
+        }
+        if (p.want_fe) p.term[(long long)w[W_TERM] * p.RS + r] = F;
+    } break;
     case OP_SUM_TERMS: {
         const int n = w[W_N];
         const int* lst = p.aux + w[W_LIST];
@@ -864,9 +985,12 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
             for (int j = 0; j < N; ++j) S[i][j] = 0.0;
         const int n = w[W_N];
         const int* lst = p.aux + w[W_LIST];
+        const int stride = (fl & F_WEIGHT) ? 2 : 1;
+        double cnt = 0.0;   // the nodes this precision hangs on: one each, a mixture component π_k (its moments arrive weighted)
         for (int q = 0; q < n; ++q) {
             double E[N][N];
-            ld_full<N>(p.stat, lst[q], d, p.RS, r, 0.0, E);
+            ld_full<N>(p.stat, lst[stride * q], d, p.RS, r, 0.0, E);
+            cnt += (stride == 2 && lst[2 * q + 1] >= 0) ? p.prec[(long long)lst[2 * q + 1] * p.RS + r] : 1.0;
 #pragma unroll
             for (int i = 0; i < N; ++i)
 #pragma unroll
@@ -881,7 +1005,7 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
                 Vi[i][j] = S0i[i][j] + Ss[i][j];
             }
         ok = spd_inv<N>(Vi, V, ldVi);
-        const double nu = nu0 + (double)n, ldV = -ldVi;
+        const double nu = nu0 + cnt, ldV = -ldVi;
         const int ps = w[W_PREC], tri = d * (d + 1) / 2;
         double What[N][N], Whi[N][N];
 #pragma unroll
@@ -899,7 +1023,7 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         p.prec[(long long)(ps + 1 + tri + 2 * d * d) * p.RS + r] = elw;
         if (p.want_fe) {
             // the n likelihood nodes: ½[n d log 2π − n E log|W| + tr(Ŵ Σ E[rrᵀ])]; the prior node U − H[q(W)] (the terms of noise_kernels.hpp, per precision variable)
-            double F = 0.5 * ((double)n * (d * T_LOG2PI - elw) + trace_prod<N>(What, Ss, d));
+            double F = 0.5 * (cnt * (d * T_LOG2PI - elw) + trace_prod<N>(What, Ss, d));
             F += -(0.5 * (nu0 - d - 1.0) * elw - 0.5 * trace_prod<N>(S0i, What, d) - 0.5 * nu0 * d * T_LOG2 - 0.5 * nu0 * ldS0 - t_mvlgamma(0.5 * nu0, d));
             F -= 0.5 * (d + 1.0) * ldV + 0.5 * d * (d + 1.0) * T_LOG2 + t_mvlgamma(0.5 * nu, d) - 0.5 * (nu - d - 1.0) * t_mvdigamma(0.5 * nu, d) + 0.5 * nu * d;
             p.term[(long long)w[W_TERM] * p.RS + r] = F;

@@ -872,6 +872,15 @@ function tree_precision(e::Engine, id::Integer, d::Integer)
     return nu[1], collect(transpose(reshape(V[1:(d * d)], d, d)))
 end
 
+"""q(z = k) of a mixture node's switch, or the concentrations of q(s) of its probability vector (replica 1)."""
+function tree_discrete(e::Engine, id::Integer)
+    K = Ref{Int32}(0)
+    check(e, ccall((:rxhip_tree_get_discrete, librxhip), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Int32}), e.handle, id, C_NULL, K))
+    out = Vector{Float64}(undef, e.n_chains * K[])
+    GC.@preserve out check(e, ccall((:rxhip_tree_get_discrete, librxhip), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}, Ptr{Int32}), e.handle, id, out, C_NULL))
+    return out[1:K[]]
+end
+
 """One message rule on the device (`rxhip_rule_eval`): the A/B hook next to `ReactiveMP.@call_rule`.  `a`: d × n, `B`: d × d × n (column-major
 Julia arrays of symmetric matrices: the C side reads them row-major, the same bytes)."""
 function rule_eval(node_type::Integer, iface::Integer, constant, a::Matrix{Float64}, B::Array{Float64, 3}; a2 = nothing, B2 = nothing,

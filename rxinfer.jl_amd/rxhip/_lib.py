@@ -130,6 +130,7 @@ SYMBOLS = [
     ("rxhip_tree_set_data", ctypes.c_int32, [_H, c_int64_p, ctypes.c_int64, c_double_p]),
     ("rxhip_tree_get_marginals", ctypes.c_int32, [_H, c_int64_p, ctypes.c_int64, c_double_p, c_double_p]),
     ("rxhip_tree_get_precision", ctypes.c_int32, [_H, ctypes.c_int64, c_double_p, c_double_p]),
+    ("rxhip_tree_get_discrete", ctypes.c_int32, [_H, ctypes.c_int64, c_double_p, ctypes.POINTER(ctypes.c_int32)]),
     ("rxhip_tree_get_info", ctypes.c_int32, [_H, ctypes.POINTER(TreeInfo)]),
     ("rxhip_tree_continue", ctypes.c_int32, [_H, ctypes.c_int32]),
     ("rxhip_rule_eval", ctypes.c_int32, [ctypes.POINTER(RuleCall), ctypes.c_int32]),

@@ -113,6 +113,14 @@ class TreeEngine:
         self._chk(_lib.lib().rxhip_tree_get_precision(self._h, int(variable), nu.ctypes.data_as(c_double_p), V.ctypes.data_as(c_double_p)))
         return nu, V
 
+    def discrete(self, variable):
+        """q(z = k) of a mixture node's switch, or the concentrations of q(s) = Dirichlet(α) of its probability vector: [replica][K]"""
+        K = ctypes.c_int32(0)
+        self._chk(_lib.lib().rxhip_tree_get_discrete(self._h, int(variable), None, ctypes.byref(K)))
+        out = np.empty((self.n_replicas, K.value))
+        self._chk(_lib.lib().rxhip_tree_get_discrete(self._h, int(variable), out.ctypes.data_as(c_double_p), None))
+        return out
+
     def free_energy(self):
         """per iteration, summed over the replicas"""
         fe = np.empty(max(self._iters, 1))

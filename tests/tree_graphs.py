@@ -531,3 +531,61 @@ def mean_field_fixed_point(gb, data):
             C, c = expr(v)
             post[v] = (C @ mu + c, C @ Sq @ C.T)
     return post, float(energy - ent)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def mixture_on_tree(N=10, K=2, d=2, seed=11, latent_out=False, const_switch=False, shared_parent=True, const_precision=False):
+    """A mixture layer hanging off a Gaussian tree (test/models/mixtures/gmm_multivariate_tests.jl:6-32 is the flat case):
+         μ0 ~ MvNormal;  m[k] ~ MvNormal(mean = A_k * μ0, cov = S_k)   (shared_parent; else m[k] ~ MvNormal(const, S_k))
+         w[k] ~ Wishart | Gamma (d = 1) | a constant precision;  s ~ Dirichlet | a constant probability vector;  z[i] ~ Categorical(s)
+         x[i] ~ NormalMixture(switch = z[i], m = m, p = w);  latent_out: y[i] ~ MvNormal(mean = B * x[i], cov = Q), else x[i] IS the data
+       with the mixture nodes under mean field (the only factorisation with rules there; the builder's default), the Gaussian nodes of the tree structured.
+       @initialization marginals on m, w, s (and x)."""
+    rng = np.random.default_rng(seed)
+    gb = GraphBuilder()
+    cent = 4.0 * rng.standard_normal((K, d))
+    if shared_parent:
+        mu0 = gb.randomvar(d)
+        gb.node(_lib.NODE_MVNORMAL_MEAN_COV, mu0, gb.constvar(rng.standard_normal(d)), gb.constvar(_spd(rng, d, 2.0)))
+    s = gb.constvar(rng.dirichlet(3.0 * np.ones(K))) if const_switch else gb.randomvar(K)
+    if not const_switch:
+        gb.node(_lib.NODE_DIRICHLET, s, gb.constvar(1.0 + rng.random(K)))
+        gb.initialize(s, _lib.INIT_DIRICHLET, 1.0 + rng.random(K))
+    m, w = [], []
+    for k in range(K):
+        mk = gb.randomvar(d)
+        if shared_parent:
+            ak = gb.randomvar(d)
+            gb.node(_lib.NODE_MULTIPLY, ak, gb.constvar(np.eye(d) + 0.3 * rng.standard_normal((d, d))), mu0)
+            gb.node(_lib.NODE_MVNORMAL_MEAN_COV, mk, ak, gb.constvar(_spd(rng, d, 9.0)))
+        else:
+            gb.node(_lib.NODE_MVNORMAL_MEAN_COV, mk, gb.constvar(cent[k]), gb.constvar(_spd(rng, d, 9.0)))
+        gb.initialize(mk, _lib.INIT_MVNORMAL if d > 1 else _lib.INIT_NORMAL, np.concatenate([cent[k], np.ravel(_spd(rng, d, 4.0))]))
+        if const_precision:
+            wk = gb.constvar(_spd(rng, d, 1.5))
+        else:
+            wk = gb.randomvar(d)
+            if d == 1:
+                gb.node(_lib.NODE_GAMMA_SHAPE_RATE, wk, gb.constvar(2.0 + rng.random()), gb.constvar(1.0 + rng.random()))
+                gb.initialize(wk, _lib.INIT_GAMMA, (2.0 + rng.random(), 1.0 + rng.random()))
+            else:
+                gb.node(_lib.NODE_WISHART, wk, gb.constvar(d + 1.0 + rng.random()), gb.constvar(_spd(rng, d, 0.3)))
+                gb.initialize(wk, _lib.INIT_WISHART, np.concatenate([[d + 1.5], np.ravel(_spd(rng, d, 0.4))]))
+        m.append(mk); w.append(wk)
+    ys, xs, zs = [], [], []
+    dy = max(1, d - 1) if latent_out else d
+    for _ in range(N):
+        z = gb.randomvar(1)
+        gb.node(_lib.NODE_CATEGORICAL, z, s)
+        if latent_out:
+            x, bx, y = gb.randomvar(d), gb.randomvar(dy), gb.datavar(dy)
+            gb.node(_lib.NODE_NORMAL_MIXTURE, x, z, *m, *w)
+            gb.node(_lib.NODE_MULTIPLY, bx, gb.constvar(rng.standard_normal((dy, d))), x)
+            gb.node(_lib.NODE_MVNORMAL_MEAN_COV, y, bx, gb.constvar(_spd(rng, dy, 0.5)))
+            gb.initialize(x, _lib.INIT_MVNORMAL if d > 1 else _lib.INIT_NORMAL, np.concatenate([rng.standard_normal(d), np.ravel(_spd(rng, d, 3.0))]))
+            xs.append(x)
+        else:
+            y = gb.datavar(d)
+            gb.node(_lib.NODE_NORMAL_MIXTURE, y, z, *m, *w)
+        ys.append(y); zs.append(z)
+    return gb, ys, dict(m=m, W=[] if const_precision else w, x=xs, z=zs, s=s)
