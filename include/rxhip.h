@@ -405,7 +405,11 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  *     MvNormalMeanCovariance / NormalMeanVariance / MvNormalMeanPrecision / NormalMeanPrecision   (out, μ: random, data or constant;
  *         third interface: a constant, or — precision nodes — a Wishart / Gamma variable under q(out, μ) q(W));
  *     typeof(*) with a constant matrix;  typeof(+) (random + random, random + data / constant);
- *     Wishart / GammaShapeRate / GammaShapeScale priors with constant parameters
+ *     Wishart / GammaShapeRate / GammaShapeScale priors with constant parameters;
+ *     NormalMixture (out, switch, m[1..K], p[1..K]) under mean field with  switch ~ Categorical(s),  s ~ Dirichlet(a) | a constant  (round 6; dimensions ≤ 8):
+ *         `out` data or a Gaussian variable, the means Gaussian variables of the forest, the precisions Wishart / Gamma variables or constants.  The node acts on
+ *         (out, m[k], p[k]) as K Gaussian precision nodes weighted by q(switch = k); q(switch) is formed from the marginals of the previous iteration before
+ *         the sweep, q(s) behind it (the schedule of the mixture engines; `@initialization` marginals on m, p, s — and `out` — as in the reference)
  * whose Gaussian variables form a forest (no cycles; precision variables may touch any number of nodes — the mean-field factorisation cuts those
  * loops; no Gaussian variable at all is a forest too: `P ~ Wishart; y[i] ~ MvNormal(μ = m, Λ = P)` with a known mean,
  * test/models/iid/mv_iid_precision_known_mean_tests.jl), every dimension ≤ 64.  Factorisation (rxhip_graph_desc.factor_cluster): a Gaussian node under
@@ -418,9 +422,10 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  * levels, a lane per replica over the whole schedule, and (dimensions ≤ 4: the default) STRANDS: the sweep cut into paths of dependent ops
  * that a lane walks with the message in registers, a message going to HBM only when somebody outside its strand reads it.  Marginals of `A * x` outputs are
  * images of x's marginal: the Bethe terms form them on the fly, they are stored when a caller asks.
- * Dimensions 9 … 64: a WORK ITEM of 1 / 2 / 4 wavefronts (≤ 16 / ≤ 32 / ≤ 64) per (op, replica), matrices staged in LDS, a replica's slots contiguous in HBM
- * (csrc/tree_wave_kernels.hpp): products on v_mfma_f64_16x16x4_f64, the inverse a 4-pivot block sweep on the matrix cores with the matrix in accumulator
- * registers; a launch per level, or an item per replica over the whole schedule.
+ * Dimensions 9 … 32 (and 5 … 8 up to 1 024 replicas): a WAVEFRONT per (op, replica), matrices in registers in the accumulator layout of v_mfma_f64_16x16x4_f64
+ * (csrc/tree_tile_kernels.hpp: products straight from registers, the inverse a symmetric sweep), a replica's slots contiguous in HBM; 33 … 64: a workgroup of
+ * four wavefronts per (op, replica), matrices staged in LDS (csrc/tree_wave_kernels.hpp: products on the matrix cores, the inverse a 4-pivot block sweep with
+ * the matrix in accumulator registers); a launch per level, or an item per replica over the whole schedule (rxhip_tree_info.kernels / .mode).
  * Data variables, derived clamped values (`a + b` of two data variables), unobserved leaves (predictions) are part of the family; so is `missing` anywhere in
  * the data when the engine is created with rxhip_graph_desc.allow_missing (a NaN observation sends no message, its node's Bethe terms cancel; not under a
  * random precision: RXHIP_ERR_UNSUPPORTED) — without it rxhip_tree_set_data refuses NaN / Inf with RXHIP_ERR_BADARG.
