@@ -406,7 +406,8 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  *         third interface: a constant, or — precision nodes — a Wishart / Gamma variable under q(out, μ) q(W));
  *     typeof(*) with a constant matrix;  typeof(+) (random + random, random + data / constant);
  *     Wishart / GammaShapeRate / GammaShapeScale priors with constant parameters;
- *     NormalMixture (out, switch, m[1..K], p[1..K]) under mean field with  switch ~ Categorical(s),  s ~ Dirichlet(a) | a constant  (round 6; dimensions ≤ 8):
+ *     NormalMixture (out, switch, m[1..K], p[1..K]) under mean field with  switch ~ Categorical(s),  s ~ Dirichlet(a) | a constant — or, K = 2, switch ~ Bernoulli(s),
+ *         s ~ Beta(a, b)  (round 6; dimensions ≤ 8):
  *         `out` data or a Gaussian variable, the means Gaussian variables of the forest, the precisions Wishart / Gamma variables or constants.  The node acts on
  *         (out, m[k], p[k]) as K Gaussian precision nodes weighted by q(switch = k); q(switch) is formed from the marginals of the previous iteration before
  *         the sweep, q(s) behind it (the schedule of the mixture engines; `@initialization` marginals on m, p, s — and `out` — as in the reference)

@@ -50,7 +50,7 @@ LOG2PI = math.log(2.0 * math.pi)
 GAUSS_COV = ("MvNormalMeanCovariance", "NormalMeanVariance")
 GAUSS_PREC = ("MvNormalMeanPrecision", "NormalMeanPrecision")
 PRIORS = ("Wishart", "GammaShapeRate", "GammaShapeScale")
-SKIP = ("NormalMixture", "Categorical", "Dirichlet")   # no Gaussian message of their own: the mixture node acts through its K weighted virtual nodes
+SKIP = ("NormalMixture", "Categorical", "Dirichlet", "Bernoulli", "Beta")   # no Gaussian message of their own: the mixture node acts through its K weighted virtual nodes
 
 
 def _sym(M):
@@ -116,10 +116,12 @@ class TreeGraph:
                     self.factors.append(("MvNormalMeanPrecision", [ifs[0], ifs[2 + k], ifs[2 + K + k]]))
                     self.clusters.append([0, 1, 2])
                 self.mixtures.append(dict(node=fi, out=ifs[0], z=ifs[1], m=ifs[2:2 + K], p=ifs[2 + K:], virtual=vf))
-            elif t == "Categorical":
+            elif t in ("Categorical", "Bernoulli"):   # Bernoulli(s): the two-component spelling, z = true the FIRST component
                 self.cat[ifs[0]] = ifs[1]
             elif t == "Dirichlet":
                 self.dir[ifs[0]] = ifs[1]
+            elif t == "Beta":                          # Beta(a, b) on the probability of the first component = Dirichlet([a, b])
+                self.dir[ifs[0]] = (ifs[1], ifs[2])
         self.dim = [int(v["rows"]) for v in self.vars]
         self.kind = [v["kind"] for v in self.vars]
         # classify: precision variables are the random `out` of a Wishart / Gamma prior node
@@ -186,14 +188,23 @@ class TreeGraph:
                 for k in ifs[2 + K:]:
                     if self.kind[k] == "random" and k not in self.prec_prior:
                         raise ValueError("NormalMixture: a random precision needs a Wishart / Gamma prior")
-            elif t == "Categorical":
+            elif t in ("Categorical", "Bernoulli"):
                 if self.kind[ifs[1]] == "random" and ifs[1] not in self.dir:
                     raise ValueError("Categorical: a random probability vector needs a Dirichlet prior")
-            elif t == "Dirichlet":
-                if self.kind[ifs[1]] != "constant":
-                    raise ValueError("Dirichlet: constant concentration expected")
+                if not self.mixtures:
+                    raise ValueError(f"node {t} is not part of the Gaussian tree family")
+            elif t in ("Dirichlet", "Beta"):
+                if any(self.kind[x] != "constant" for x in ifs[1:]):
+                    raise ValueError("Dirichlet / Beta: constant parameters expected")
+                if not self.mixtures:
+                    raise ValueError(f"node {t} is not part of the Gaussian tree family")
             else:
                 raise ValueError(f"node {t} is not part of the Gaussian tree family")
+
+    def alpha0(self, sv):
+        """prior concentrations of a Dirichlet / Beta variable"""
+        a = self.dir[sv]
+        return np.array([float(np.ravel(self.const(x))[0]) for x in a]) if isinstance(a, tuple) else np.ravel(self.const(a)).astype(float)
 
     def const(self, v):
         x = np.asarray(self.vars[v]["value"], float)
@@ -259,7 +270,7 @@ def infer(dump, data, iterations=1, free_energy=True):
     qs = {}
     for sv in g.dir:
         ini = g.vars[sv].get("init")
-        qs[sv] = np.asarray(ini["params"] if ini is not None and ini["family"] == "dirichlet" else np.ravel(g.const(g.dir[sv])), float).copy()
+        qs[sv] = np.asarray(ini["params"] if ini is not None and ini["family"] == "dirichlet" else g.alpha0(sv), float).copy()
 
     def elog_s(sv, alphas):   # E log s of a Dirichlet variable, log p of a constant probability vector
         if g.kind[sv] == "constant":
@@ -463,7 +474,7 @@ def infer(dump, data, iterations=1, free_energy=True):
                     wk = pi[g.weight[fi][0]][g.weight[fi][1]] if fi in g.weight else 1.0
                     stats[ifs[2]][0] += wk
                     stats[ifs[2]][1] += wk * moments[fi][0]
-        qs_new = {sv: np.ravel(g.const(g.dir[sv])).astype(float) + sum(pi[z] for z in pi if g.cat[z] == sv) for sv in qs}
+        qs_new = {sv: g.alpha0(sv).astype(float) + sum(pi[z] for z in pi if g.cat[z] == sv) for sv in qs}
         qnew = {}
         for v in qW:
             nu0, S0 = g.prior_q(v)
@@ -526,7 +537,7 @@ def infer(dump, data, iterations=1, free_energy=True):
             for z, w in pi.items():
                 F += -float(np.dot(w, elog_s(g.cat[z], qs_new))) + float(np.sum(w[w > 0.0] * np.log(w[w > 0.0])))
             for sv, al in qs_new.items():
-                a0 = np.ravel(g.const(g.dir[sv])).astype(float)
+                a0 = g.alpha0(sv).astype(float)
                 els = digamma(al) - digamma(np.sum(al))
                 logB = lambda a: float(np.sum(gammaln(a)) - gammaln(np.sum(a)))
                 U = logB(a0) - float(np.dot(a0 - 1.0, els))

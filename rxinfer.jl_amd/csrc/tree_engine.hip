@@ -158,7 +158,18 @@ struct Compiler {
     std::vector<int> wz, wk;            // per factor: the switch variable and component that weight it (−1)
     struct Mix { int node, out, z, K; std::vector<int> m, p; };
     std::vector<Mix> mixes;
-    std::vector<int> cat_s, dir_a, catK;   // per variable: a switch's probability-vector variable; a Dirichlet variable's concentration constant; components
+    std::vector<int> cat_s, dir_a, catK;   // per variable: a switch's probability-vector variable; a Dirichlet variable's concentration constant (≤ −2: Beta, alpha_pool); components
+    std::vector<double> alpha_pool;
+    std::vector<int> alpha_off_;           // per Dirichlet / Beta variable: constant-pool offset of its prior's concentrations (−1)
+    const double* alpha0(int sv) const { return dir_a[sv] <= -2 ? alpha_pool.data() + (-2 - dir_a[sv]) : cptr(dir_a[sv]); }
+    int alpha_off(int sv) {
+        if (alpha_off_.empty()) alpha_off_.assign(nv, -1);
+        if (alpha_off_[sv] < 0) {
+            alpha_off_[sv] = (int)P.cpool.size();
+            P.cpool.insert(P.cpool.end(), alpha0(sv), alpha0(sv) + catK[sv]);
+        }
+        return alpha_off_[sv];
+    }
     int ftype(int f) const { return xtype[f]; }
     // edges: (factor, interface) with a Gaussian variable
     struct Edge { int f, k, v; };
@@ -250,7 +261,7 @@ struct Compiler {
     void classify_mixtures() {
         for (int64_t f = 0; f < nf; ++f) {
             const int t = ftype((int)f);
-            if (t == RXHIP_NODE_CATEGORICAL) {
+            if (t == RXHIP_NODE_CATEGORICAL || (t == RXHIP_NODE_BERNOULLI && P.has_mix)) {   // (Bernoulli(s): the two-component spelling, z = true the FIRST component)
                 if (n_iface((int)f) != 2) fail(RXHIP_ERR_BADARG, "factor %lld (Categorical): interfaces (out, p) expected", (long long)f);
                 const int z = (int)iface((int)f, 0), sv = (int)iface((int)f, 1);
                 if (g->var_kind[z] != RXHIP_VARKIND_RANDOM || cat_s[z] >= 0) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld (Categorical): the output must be a random variable with this one prior", (long long)f);
@@ -259,13 +270,24 @@ struct Compiler {
             } else if (t == RXHIP_NODE_DIRICHLET) {
                 if (n_iface((int)f) != 2) fail(RXHIP_ERR_BADARG, "factor %lld (Dirichlet): interfaces (out, a) expected", (long long)f);
                 const int sv = (int)iface((int)f, 0), a = (int)iface((int)f, 1);
-                if (g->var_kind[sv] != RXHIP_VARKIND_RANDOM || dir_a[sv] >= 0 || P.vclass[a] != VC_CONST)
+                if (g->var_kind[sv] != RXHIP_VARKIND_RANDOM || dir_a[sv] != -1 || P.vclass[a] != VC_CONST)
                     fail(RXHIP_ERR_UNSUPPORTED, "factor %lld (Dirichlet): a random output with this one prior and a constant concentration expected", (long long)f);
                 dir_a[sv] = a;
                 P.vclass[sv] = VC_DIR;
                 catK[sv] = g->var_rows[a] * g->var_cols[a];
                 for (int k = 0; k < catK[sv]; ++k)
                     if (!(cptr(a)[k] > 0.0)) fail(RXHIP_ERR_BADARG, "factor %lld (Dirichlet): concentrations must be positive", (long long)f);
+            } else if (t == RXHIP_NODE_BETA && P.has_mix) {   // Beta(a, b) on the probability of the first component = Dirichlet([a, b])
+                if (n_iface((int)f) != 3) fail(RXHIP_ERR_BADARG, "factor %lld (Beta): interfaces (out, a, b) expected", (long long)f);
+                const int sv = (int)iface((int)f, 0), a = (int)iface((int)f, 1), b = (int)iface((int)f, 2);
+                if (g->var_kind[sv] != RXHIP_VARKIND_RANDOM || dir_a[sv] != -1 || P.vclass[a] != VC_CONST || P.vclass[b] != VC_CONST || !(cptr(a)[0] > 0.0) || !(cptr(b)[0] > 0.0))
+                    fail(RXHIP_ERR_UNSUPPORTED, "factor %lld (Beta): a random output with this one prior and positive constant parameters expected", (long long)f);
+                dir_a[sv] = (int)alpha_pool.size();
+                alpha_pool.push_back(cptr(a)[0]);
+                alpha_pool.push_back(cptr(b)[0]);
+                dir_a[sv] = -2 - dir_a[sv];   // (≤ −2: an entry of alpha_pool, not a constant variable)
+                P.vclass[sv] = VC_DIR;
+                catK[sv] = 2;
             }
         }
         for (const Mix& mx : mixes) {
@@ -317,7 +339,7 @@ struct Compiler {
         }
         for (int64_t f = 0; f < nf; ++f) {
             const int t = ftype((int)f);
-            if (t == RXHIP_NODE_NORMAL_MIXTURE || t == RXHIP_NODE_CATEGORICAL || t == RXHIP_NODE_DIRICHLET) { nclass[f] = NC_SKIP; continue; }
+            if (t == RXHIP_NODE_NORMAL_MIXTURE || t == RXHIP_NODE_CATEGORICAL || t == RXHIP_NODE_DIRICHLET || ((t == RXHIP_NODE_BERNOULLI || t == RXHIP_NODE_BETA) && P.has_mix)) { nclass[f] = NC_SKIP; continue; }
             switch (t) {
             case RXHIP_NODE_MVNORMAL_MEAN_COV: case RXHIP_NODE_NORMAL_MEAN_VARIANCE: case RXHIP_NODE_MVNORMAL_MEAN_PRECISION: case RXHIP_NODE_NORMAL_MEAN_PRECISION:
                 nclass[f] = NC_NOISE; break;
@@ -719,7 +741,7 @@ struct Compiler {
             if (P.vclass[v] == VC_CAT)
                 for (int k = 0; k < K; ++k) st[k] = 1.0 / K;
             if (P.vclass[v] == VC_DIR) {   // `@initialization` q(s), default the prior
-                const double* a = cptr(dir_a[v]);
+                const double* a = alpha0((int)v);
                 if (g->var_init_family && g->var_init && g->var_init_family[v] == RXHIP_INIT_DIRICHLET && g->var_init[v] >= 0) a = g->const_pool + g->var_init[v];
                 double sum = 0.0;
                 for (int k = 0; k < K; ++k) { if (!(a[k] > 0.0)) fail(RXHIP_ERR_BADARG, "initial marginal of variable %lld: positive concentrations expected", (long long)v); sum += a[k]; }
@@ -1167,7 +1189,7 @@ struct Compiler {
                 r.w[W_VAL2] = cnt;
                 if (P.vclass[sv] == VC_DIR) {
                     r.w[W_PREC] = P.prec_off[sv];
-                    r.w[W_C0] = const_value(dir_a[sv]);
+                    r.w[W_C0] = alpha_off(sv);
                 } else
                     r.w[W_C0] = log_probabilities(sv, K);
                 r.w[W_TERM] = new_term();

@@ -74,7 +74,7 @@ def test_what_the_compiler_refuses():
     # dimensions above 8: the mixture ops live in the lane-per-item kernels
     gb, _, _ = tg.mixture_on_tree(N=2, K=2, d=9)
     _refused(gb, _lib.ERR_UNSUPPORTED, "NormalMixture", "8")
-    # a switch without a Categorical prior; a Bernoulli switch (the pattern-matched univariate family has it)
+    # a switch without a Categorical prior; a Bernoulli switch on a one-component node
     gb = graph.GraphBuilder()
     m, w, z, y = gb.randomvar(1), gb.randomvar(1), gb.randomvar(1), gb.datavar(1)
     gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, m, gb.constvar(0.0), gb.constvar(1.0))
@@ -84,7 +84,7 @@ def test_what_the_compiler_refuses():
     s = gb.randomvar(1)
     gb.node(_lib.NODE_BETA, s, gb.constvar(1.0), gb.constvar(1.0))
     gb.node(_lib.NODE_BERNOULLI, z, s)
-    _refused(gb, _lib.ERR_UNSUPPORTED)
+    _refused(gb, _lib.ERR_BADARG, "components")   # a Bernoulli switch is the two-component spelling: this node has one
     # components of another dimension than `out`
     gb, ys, named = tg.mixture_on_tree(N=2, K=2, d=2)
     bad = graph.GraphBuilder.from_dump(gb.to_dump())
@@ -92,3 +92,25 @@ def test_what_the_compiler_refuses():
     y3 = bad.datavar(3)
     bad.fiface[f] = (y3,) + tuple(bad.fiface[f][1:])
     _refused(bad, _lib.ERR_BADARG, "dimension")
+
+
+def _univariate_reference_model(n=60, seed=12345):
+    """test/models/mixtures/gmm_univariate_tests.jl:7-20 with its priors and @initialization (Beta / Bernoulli spelling of the two-component switch)"""
+    rng = np.random.default_rng(seed)
+    z = rng.choice(2, size=n, p=[1 / 3, 2 / 3])
+    y = np.array([-10.0, 10.0])[z] + rng.standard_normal(n) / np.sqrt(np.array([3.777, 0.333])[z])
+    priors = ([-2.0, 2.0], [1e3, 1e3], [0.01, 0.01], [0.01, 0.01], [1.0, 1.0])
+    init = ([-2.0, 2.0], [1e3, 1e3], [1.0, 1.0], [1e-12, 1e-12], [1.0, 1.0])
+    gb, ys = graph.mixture_graph(n, *priors, init=dict(m=(init[0], init[1]), p=(init[2], init[3]), s=init[4]), bernoulli=True)
+    return y, priors, init, gb, ys
+
+
+def test_univariate_reference_model_in_the_bernoulli_spelling():
+    y, priors, init, gb, ys = _univariate_reference_model()
+    iters = 8
+    hist, fe, resp, _ = rxoracle.gmm_vmp(y, *priors, *init, iters, want_resp=True)
+    ref = tree_oracle.infer(gb.to_dump(), {ys[i]: y[i:i + 1] for i in range(y.size)}, iterations=iters)
+    assert np.max(np.abs((np.asarray(ref["fe"]) - fe) / fe)) < 1e-11
+    g = tree_oracle.TreeGraph(gb.to_dump())
+    assert np.allclose(np.stack([ref["q_cat"][m["z"]] for m in g.mixtures]), resp, atol=1e-11)
+    assert plan(gb)["rule_calls"] == ref["counters"]["rule_calls"]

@@ -98,3 +98,22 @@ def test_responsibilities_and_concentrations_are_readable():
         import rxhip
         with pytest.raises(rxhip.RxHipError):
             eng.discrete(named["m"][0])
+
+
+def test_univariate_reference_model_equals_the_specialised_engine():
+    """test/models/mixtures/gmm_univariate_tests.jl:7-20 (Beta / Bernoulli switch, Gamma precisions) through the executor and through GMMEngine"""
+    import rxhip
+    import tree_oracle
+    from rxhip.tree import TreeEngine
+    from test_tree_mixture_cpu import _univariate_reference_model
+    y, priors, init, gb, ys = _univariate_reference_model(n=150)
+    iters = 10
+    with rxhip.GMMEngine(y.size, *priors, *init) as ref:
+        ref.set_data(y)
+        ref.run(iters, True)
+        fe = ref.free_energy()
+    with TreeEngine(gb, n_replicas=1) as eng:
+        eng.set_data(ys, y[None, :])
+        eng.run(iters, True)
+        assert np.allclose(eng.free_energy(), fe, rtol=1e-10)
+        assert np.all(np.diff(eng.free_energy()) < 1e-6 * abs(fe[-1]))   # gmm_univariate_tests.jl: the free energy does not increase
