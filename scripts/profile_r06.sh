@@ -7,6 +7,7 @@
 #   5. the node-array executor, d = 4 (bench's node_array workload): kernel trace, FETCH_SIZE / WRITE_SIZE,
 #      with the calibration of FETCH_SIZE for 8 B/lane unit-stride loads (scripts/fetch_calib.hip)              -> kernel_stats_tree.csv, tree_traffic.json, fetch_calibration.txt
 #   6. the executor at d = 64 (work items of four wavefronts, MFMA products and inverse): kernel stats, MFMA instructions  -> kernel_stats_tree64.csv, tree_mfma.json
+#   7. the executor's register-tile kernels at d = 16 / 32: kernel stats                                       -> kernel_stats_tree16.csv, kernel_stats_tree32.csv
 set -u
 TAG=${1:-r06}
 OUT=$PWD/gpurun_out/prof_$TAG
@@ -36,6 +37,11 @@ rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/calib_write" -o write --
 T64="python $ROOT/scripts/prof_tree_wave.py 64 16 256 3"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/tree64" -o tree64 -- $T64 > "$OUT/driver_tree64.txt" 2> "$OUT/tree64.err"
 rocprofv3 --pmc SQ_INSTS_VALU_MFMA_F64 SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_LDS --output-format csv -d "$OUT/tree64_pmc" -o t -- $T64 > /dev/null 2> "$OUT/tree64_pmc.err"
+# 7. the register-tile kernels at the sizes of the executor's bench lines: kernel stats (d = 16 x 4096 and d = 32 x 2048 replicas, the walk)
+for cfg in "16 64 4096" "32 32 2048"; do
+  set -- $cfg
+  rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/tree$1" -o tree$1 -- python $ROOT/scripts/prof_tree_wave.py $1 $2 $3 3 > "$OUT/driver_tree$1.txt" 2> "$OUT/tree$1.err"
+done
 cd "$ROOT"
 python3 scripts/summarize_prof.py "$OUT" > "$OUT/summary.txt" 2>&1
 python3 - "$OUT" "$TAG" <<'PY'
@@ -141,7 +147,7 @@ for x in (t, m, v, cal, tt, tm):
 PY
 cat "$OUT/summary.txt" | cut -c1-400
 cat "$OUT/driver_tree.txt" "$OUT/driver_tree64.txt" "$OUT/driver_c3.txt" | grep -v 'RCCL\|HIP ver\|ROCm\|Hostname\|Librccl'
-for d in bench c3 tree tree64; do f=$(find "$OUT/$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_$d.csv"; done
+for d in bench c3 tree tree64 tree16 tree32; do f=$(find "$OUT/$d" -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$OUT/kernel_stats_$d.csv"; done
 python3 scripts/trace_tree_launches.py "$OUT/tree" 8 > "$OUT/tree_strand_levels.txt" 2>&1
 find "$OUT" -name "*.csv" -size +4M -delete
 find "$OUT" -name "*_agent_info.csv" -delete

@@ -15,7 +15,7 @@ def find(pattern):
 
 def short(name):
     name = name.split("(")[0]
-    for k in ("k_tree_strands", "k_wave_ops", "k_wave_walk", "k_calib_read8", "k_calib_read16", "k_calib_write8", "k_calib_slots8", "k_tree_walk", "k_tree_levels", "k_tree_ops", "k_tree_fe_total", "kd_agg_gemm", "k8_forward", "k8_backward", "k_noise_update", "k_noise_reset", "k_small_sweep", "k_seg_elements", "km_gy", "km_compose", "km_elements", "km_apply", "km_fold", "km_inner", "km_bnd", "km_mask", "km_group", "km_scan", "kd_fe_resid_mfma", "k_gmm_pass", "k_gmm_reduce", "k_gmm_update", "k_gmm_init", "k_hgf_filter", "k_hgf_fe", "kd_seg_aggregate", "kd_scan_local", "kd_scan_fix", "kd_forward_info", "kd_backward_info", "kd_fe_resid", "kd_forward", "k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce", "k_fe_chain", "k_fe_total",
+    for k in ("k_tree_strands", "k_tile_ops", "k_tile_walk", "k_wave_ops", "k_wave_walk", "k_calib_read8", "k_calib_read16", "k_calib_write8", "k_calib_slots8", "k_tree_walk", "k_tree_levels", "k_tree_ops", "k_tree_fe_total", "kd_agg_gemm", "k8_forward", "k8_backward", "k_noise_update", "k_noise_reset", "k_small_sweep", "k_seg_elements", "km_gy", "km_compose", "km_elements", "km_apply", "km_fold", "km_inner", "km_bnd", "km_mask", "km_group", "km_scan", "kd_fe_resid_mfma", "k_gmm_pass", "k_gmm_reduce", "k_gmm_update", "k_gmm_init", "k_hgf_filter", "k_hgf_fe", "kd_seg_aggregate", "kd_scan_local", "kd_scan_fix", "kd_forward_info", "kd_backward_info", "kd_fe_resid", "kd_forward", "k_seg_aggregate", "k_boundary_scan", "k_forward", "k_backward", "k_fe_reduce", "k_fe_chain", "k_fe_total",
               "k_transpose_rows"):
         if k in name:
             return k
