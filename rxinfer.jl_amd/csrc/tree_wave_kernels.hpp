@@ -1,4 +1,6 @@
-// tree_wave_kernels.hpp — the node-array executor for dimensions above 8: a WAVEFRONT per (op, replica), matrices staged in LDS.
+// tree_wave_kernels.hpp — the node-array executor for dimensions 33 … 64: a WORKGROUP of four wavefronts per (op, replica), matrices staged in LDS.
+// (Round 5 wrote it for everything above 8, one wavefront per item; since round 6 dimensions up to 32 run on the register tiles of tree_tile_kernels.hpp — the
+// items here turned out instruction-issue bound — and the 16 / 32 instances of this file are what the host emulation compiles, tests/test_tree_wave_host.py.)
 //
 // The lane-per-(op, replica) kernels of tree_kernels.hpp keep a rule's matrices in registers, which ends at 8×8 (and spills from 5×5 on).  Here the same op
 // tables (same opcodes, same word layout, same replica-fastest storage: the host side does not know which kernel runs them) are evaluated by one wavefront

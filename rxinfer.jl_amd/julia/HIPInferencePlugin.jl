@@ -444,6 +444,17 @@ function publish_marginals!(g::HIPGraphEngine)
             ν, V = RxHip.tree_precision(e, id, Int(g.tables.var_rows[id + 1]))
             Rocket.next!(g.marginals[id], as_marginal(g.tree.gamma[id] ? ReactiveMP.GammaShapeRate(ν / 2, 1 / (2 * V[1, 1])) : ReactiveMP.Wishart(ν, Symmetric(V))))
         end
+        # a mixture layer's discrete side: q(z) of every switch, q(s) of every probability vector (the Bernoulli / Beta spelling: the FIRST component is `true`)
+        for id in g.tree.switch_ids
+            haskey(g.marginals, id) || continue
+            p = RxHip.tree_discrete(e, id)
+            Rocket.next!(g.marginals[id], as_marginal((id in g.tree.bernoulli) ? ReactiveMP.Bernoulli(p[1]) : ReactiveMP.Categorical(p)))
+        end
+        for id in g.tree.probability_ids
+            haskey(g.marginals, id) || continue
+            a = RxHip.tree_discrete(e, id)
+            Rocket.next!(g.marginals[id], as_marginal((id in g.tree.bernoulli) ? ReactiveMP.Beta(a[1], a[2]) : ReactiveMP.Dirichlet(a)))
+        end
         return nothing
     end
     if g.family === :lgssm || g.family === :lgssm_noise

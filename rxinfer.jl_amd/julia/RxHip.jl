@@ -678,8 +678,15 @@ function tree_layout(t)
     for f in eachindex(t.factor_type)
         t.factor_type[f] in (Int32(12), Int32(5), Int32(15)) && push!(prec, t.factor_iface[t.factor_iface_ptr[f] + 1])
     end
+    # the discrete side of a mixture layer: switches (out of Categorical / Bernoulli) and their probability vectors (out of Dirichlet / Beta) — read with
+    # rxhip_tree_get_discrete, not as Gaussian marginals
+    switch, probs = Set{Int64}(), Set{Int64}()
+    for f in eachindex(t.factor_type)
+        t.factor_type[f] in (Int32(8), Int32(9)) && push!(switch, t.factor_iface[t.factor_iface_ptr[f] + 1])
+        t.factor_type[f] in (Int32(6), Int32(7)) && push!(probs, t.factor_iface[t.factor_iface_ptr[f] + 1])
+    end
     data = Int64[i - 1 for i in eachindex(t.var_kind) if t.var_kind[i] == Int32(1)]
-    rnd = Int64[i - 1 for i in eachindex(t.var_kind) if t.var_kind[i] == Int32(0) && !((i - 1) in prec)]
+    rnd = Int64[i - 1 for i in eachindex(t.var_kind) if t.var_kind[i] == Int32(0) && !((i - 1) in prec) && !((i - 1) in switch) && !((i - 1) in probs)]
     # univariate variables (their marginals are NormalMeanVariance, not one-dimensional MvNormals): what a Normal(…) node touches, carried through `*` and `+`
     scal = Set{Int64}()
     ifs(f) = t.factor_iface[(t.factor_iface_ptr[f] + 1):t.factor_iface_ptr[f + 1]]
@@ -704,7 +711,8 @@ function tree_layout(t)
         o += Int(t.var_rows[id + 1])
     end
     return (family = :tree, data_ids = data, data_offsets = offs, data_total = o, state_ids = rnd, state_dims = Int[Int(t.var_rows[id + 1]) for id in rnd],
-            precision_ids = sort!(collect(prec)), scalar_ids = scal, gamma = Dict(id => any(f -> t.factor_type[f] != Int32(12) && t.factor_iface[t.factor_iface_ptr[f] + 1] == id,
+            precision_ids = sort!(collect(prec)), scalar_ids = scal, switch_ids = sort!(collect(switch)), probability_ids = sort!(collect(probs)),
+            bernoulli = Set{Int64}(t.factor_iface[t.factor_iface_ptr[f] + 1] for f in eachindex(t.factor_type) if t.factor_type[f] in (Int32(9), Int32(7))), gamma = Dict(id => any(f -> t.factor_type[f] != Int32(12) && t.factor_iface[t.factor_iface_ptr[f] + 1] == id,
                                                                         eachindex(t.factor_type)) for id in prec))
 end
 
