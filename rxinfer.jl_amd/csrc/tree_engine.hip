@@ -1704,14 +1704,27 @@ void launch_wave_phase(const Engine* e, const TreeParams& p, int phase, int l0, 
     if (l1 <= l0) return;
     const int dmax = e->prog.dmax;
     const wave::WaveVtbl* vt = wave::wave_vt(dmax);
-    if (e->mode == 2) {
+    if ((phase == 0 ? e->mode : e->mode_fe) == 2) {
         vt->walk(phase, p, e->prog.lvl_ptr[l0], e->prog.lvl_ptr[l1], dmax, (unsigned)std::min<long long>(e->R, 1 << 20), e->stream);
         return;
     }
+    // the second phase on the register tiles: a level's ops are sorted by opcode — the ones without joint-marginal algebra or a q(W) update (the terms of observation
+    // nodes, entropies, sums: most of a chain's second phase) go to the light kernel instance (phase code 2: half the registers, twice the wavefronts per SIMD)
+    auto light = [](int op) { return op == OP_FE_NOISE0 || op == OP_FE_NOISE1 || op == OP_FE_ENT || op == OP_FE_NOISE_MF || op == OP_SUM_TERMS || op == OP_MARG_PUSH; };
     for (int l = l0; l < l1; ++l) {
         const int o0 = e->prog.lvl_ptr[l], o1 = e->prog.lvl_ptr[l + 1];
         if (o1 == o0) continue;
-        vt->ops(phase, p, o0, o1, dmax, (unsigned)std::min<long long>((long long)(o1 - o0) * e->R, 1 << 20), e->stream);
+        if (phase == 0 || dmax > 32) {
+            vt->ops(phase, p, o0, o1, dmax, (unsigned)std::min<long long>((long long)(o1 - o0) * e->R, 1 << 20), e->stream);
+            continue;
+        }
+        for (int a = o0; a < o1;) {
+            const bool la = light(e->prog.ops[(size_t)a * OP_WORDS + W_OP]);
+            int b = a + 1;
+            while (b < o1 && light(e->prog.ops[(size_t)b * OP_WORDS + W_OP]) == la) ++b;
+            vt->ops(la ? 2 : 1, p, a, b, dmax, (unsigned)std::min<long long>((long long)(b - a) * e->R, 1 << 20), e->stream);
+            a = b;
+        }
     }
 }
 rxhip_status wave_attributes(int dmax, std::string& err) {
@@ -1808,7 +1821,9 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
         //  (crossover: d = 16: 2 048 replicas — 4.55 against 4.45 ms; d = 32: 1 024 — 5.8 against 4.9: profiles/r06/tree_tile.txt)
         e->mode = (e->R >= (P.dmax > 32 ? 256 : P.dmax > 16 ? 1024 : 2048)) ? 2 : 0;
     }
-    if (e->tiled) e->mode_fe = e->mode;
+    // the second phase on the register tiles: a launch per level with the light instance for the ops without joint-marginal algebra (launch_wave_phase) — one wide level of
+    // independent terms — beats the walk at every batch (d = 16 × 4 096: 7.2 → 6.4 ms, d = 32 × 2 048: 8.2 → 6.8; profiles/r06/tree_wave_modes.txt); the LDS-staged class keeps the sweep's
+    if (e->tiled) e->mode_fe = P.dmax <= 32 ? 0 : e->mode;
     // the strand schedule (register hand-over along dependent ops, wide levels at full occupancy): from the batches at which two long strands fill the device
     // (at every batch: a T = 128 chain of ONE replica is 0.60 ms in strands — its two recursions are two lanes walking 382 dependent ops — against 1.9 ms for
     //  workgroup-resident levels and ≈ 1.5 ms for 390 launches; 256 replicas 0.63 against 1.86; 65 536: 2.3 against 3.9: profiles/r06/tree_strands.txt)

@@ -23,7 +23,8 @@ hipError_t prepare(int) { return hipSuccess; }
 void ops(int phase, const TreeParams& p, int o0, int o1, int, unsigned blocks, hipStream_t stream) {
     if (p.es == 1) {
         if (phase == 0) hipLaunchKernelGGL((k_tile_ops<0, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
-        else hipLaunchKernelGGL((k_tile_ops<1, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+        else if (phase == 1) hipLaunchKernelGGL((k_tile_ops<1, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
+        else hipLaunchKernelGGL((k_tile_ops<2, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);   // (2: the second phase's light opcodes)
     } else
         hipLaunchKernelGGL((k_tile_ops<0, NT, false>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);   // (the sweep's rules only)
 }
@@ -50,6 +51,7 @@ hipError_t prepare(int dmax) {
     return hipSuccess;
 }
 void ops(int phase, const TreeParams& p, int o0, int o1, int dmax, unsigned blocks, hipStream_t stream) {
+    if (phase == 2) phase = 1;   // (one second-phase instance here)
     if (phase == 0) hipLaunchKernelGGL((k_wave_ops<0, DC>), dim3(blocks), dim3(WL), lds_bytes(dmax), stream, p, o0, o1, dmax);
     else hipLaunchKernelGGL((k_wave_ops<1, DC>), dim3(blocks), dim3(WL), lds_bytes(dmax), stream, p, o0, o1, dmax);
 }

@@ -175,6 +175,22 @@ def test_random_forests_at_large_dimensions(seed, dmax, mode, monkeypatch):
     eng.close()
 
 
+@pytest.mark.parametrize("seed,dmax,mode", [(200 + i, dm, i % 2 * 2) for i, dm in enumerate((9, 12, 16, 16, 17, 20, 24, 24, 29, 32, 32, 32, 6, 7, 8, 5))])
+def test_random_forests_on_the_register_tiles(seed, dmax, mode, monkeypatch):
+    """random forests at the dimensions of the register-tile kernels (one tile: 9 … 16 and, forced, 5 … 8; four tiles: 17 … 32) — every construct of the family,
+    odd seeds with shared precision variables and two VMP iterations — against the oracle, in both schedules"""
+    prec = seed % 2 == 1
+    its = 2 if prec else 1
+    gb, ys, named = tg.random_forest(seed, n_steps=8, dmax=dmax, precision_vars=prec, dim_set=(1, 3, 5, 6, 7, 8, 9, 12, 15, 16, 17, 20, 24, 29, 31, 32))
+    if dmax <= 8:
+        monkeypatch.setenv("RXHIP_TREE_TILE", "1")
+    R = 3
+    eng, data = _run(gb, ys, R, iterations=its, mode=mode, monkeypatch=monkeypatch, seed=seed)
+    assert eng.info["mode"] == mode and eng.info["kernels"] == (1 if eng.info["dmax"] > 4 else 0)   # (a forest's largest dimension is drawn: some stay at 4 and below)
+    _check(gb, ys, eng, data, iterations=its, replicas=(0, R - 1), prec_vars=named["W"], tol=1e-8, tol_fe=1e-9)
+    eng.close()
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_rule_eval_random_calls(seed):
     """rxhip_rule_eval with random node types, interfaces, dimensions (1 … 64: register and LDS-staged kernels) and message forms on both sides,

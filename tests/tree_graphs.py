@@ -234,7 +234,7 @@ def known_mean_closed_form(y, m, nu0, S0):
     return nu0 + n, Vn, 0.5 * n * d * np.log(2.0 * np.pi) - (logz(nu0 + n, Vn) - logz(nu0, S0))
 
 
-def random_forest(seed, n_steps=14, dmax=4, precision_vars=False, det_chains=True):
+def random_forest(seed, n_steps=14, dmax=4, precision_vars=False, det_chains=True, dim_set=(1, 2, 3, 4, 5, 8, 12, 20, 33, 48, 64)):
     """A random acyclic graph of the executor's family, grown one factor group at a time from a root state: noise children (covariance or precision
     spelling, constant or — `precision_vars` — a Wishart / Gamma variable shared by several nodes), children through `*` (rows ≤ columns: the Bethe sum
     stays finite), through `+` with a constant or with a second random root, chains of deterministic nodes (`B (A x) + c`), observations direct or
@@ -242,7 +242,7 @@ def random_forest(seed, n_steps=14, dmax=4, precision_vars=False, det_chains=Tru
     dict(x = named Gaussian variables, W = precision variables))."""
     rng = np.random.default_rng(50_000 + seed)
     gb = GraphBuilder()
-    dims = [d for d in (1, 2, 3, 4, 5, 8, 12, 20, 33, 48, 64) if d <= dmax] or [1]
+    dims = [d for d in dim_set if d <= dmax] or [1]
     named, ys, precs = [], [], {}
 
     def noise_node(out, mu, d):
