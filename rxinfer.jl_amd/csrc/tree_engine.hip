@@ -1541,6 +1541,11 @@ struct Engine {
     bool have_data = false, ran = false;
     bool cont = false;   // rxhip_tree_continue: later runs go on from the q(W) the previous run ended with
     bool allow_missing = false;   // created with rxhip_graph_desc.allow_missing: NaN in the data is `missing`
+    // the launch-per-level schedule as a HIP graph: an iteration's launches (hundreds of short kernels at small batches — 5 µs each, most of it the launch) are captured
+    // once per (free energy wanted, last level) and replayed with ONE hipGraphLaunch per iteration
+    bool use_graph = false;
+    hipGraphExec_t gexec[2] = {nullptr, nullptr};
+    int g_lend[2] = {-1, -1};
     bool tiled = false;       // the wavefront-per-item kernels run this engine (dimensions above 8; 5 … 8: see create)
     bool elem_fast = false;   // … and with them: a replica's slots contiguous (TreeParams es = 1), so that a wavefront's loads of a message coalesce
     bool push_done = false;   // the image marginals (OP_MARG_PUSH, first level of the second phase) are those of the last sweep
@@ -1838,6 +1843,8 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     if (const char* m = hook_env("RXHIP_TREE_MODE_FE")) e->mode_fe = std::max(0, std::min(2, std::atoi(m)));
     if (e->tiled && e->mode == 1) e->mode = e->mode_fe = 2;   // (no workgroup-resident schedule for the LDS-staged kernels)
     if (e->tiled && e->mode_fe == 1) e->mode_fe = 2;
+    e->use_graph = e->mode == 0 && P.n_levels > 8;
+    if (const char* q = hook_env("RXHIP_TREE_GRAPH")) e->use_graph = e->use_graph && std::atoi(q) != 0;
     {
         // Workgroups of the resident schedule.  Sweep phase, from 4 096 replicas: 512 threads owning R / 256 replicas (≤ 256) — one workgroup of eight wavefronts
         // per CU; below, and for the Bethe phase: 256 threads owning R / 512 replicas (≤ 128).  Measured optimum at every batch from 4 096 to 65 536 replicas
@@ -1908,6 +1915,7 @@ void destroy(Engine* e) {
     for (void* q : {(void*)e->d_sops, (void*)e->d_strands, (void*)e->d_ops, (void*)e->d_aux, (void*)e->d_lvl, (void*)e->d_status, (void*)e->d_cpool, (void*)e->d_msg, (void*)e->d_marg, (void*)e->d_val, (void*)e->d_prec,
                     (void*)e->d_term, (void*)e->d_stat, (void*)e->d_prec_init, (void*)e->d_marg_init, (void*)e->d_fe_rep, (void*)e->d_fe_hist, (void*)e->d_fe_part})
         if (q) (void)hipFree(q);
+    for (hipGraphExec_t x : e->gexec) if (x) (void)hipGraphExecDestroy(x);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1996,9 +2004,27 @@ rxhip_status run(Engine* e, int iterations, int want_fe, std::string& err) {
     // without the free energy on a graph without precision variables the sweep ends with the marginals
     const int l_end = (!want_fe && P.prec_doubles == 0) ? P.fe_level : (P.lazy_level >= 0 ? P.lazy_level : P.n_levels);
     if (!e->ev0) { TCHK(hipEventCreate(&e->ev0)); TCHK(hipEventCreate(&e->ev1)); }
+    hipGraphExec_t gx = nullptr;
+    if (e->use_graph) {
+        const int wf = want_fe ? 1 : 0;
+        if (e->gexec[wf] && e->g_lend[wf] != l_end) { (void)hipGraphExecDestroy(e->gexec[wf]); e->gexec[wf] = nullptr; }
+        if (!e->gexec[wf]) {
+            hipGraph_t gr = nullptr;
+            if (hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                launch(e, p, 0, l_end);
+                if (hipStreamEndCapture(e->stream, &gr) == hipSuccess && gr && hipGraphInstantiate(&e->gexec[wf], gr, nullptr, nullptr, 0) == hipSuccess) e->g_lend[wf] = l_end;
+                else e->gexec[wf] = nullptr;
+                if (gr) (void)hipGraphDestroy(gr);
+            }
+            (void)hipGetLastError();
+            if (!e->gexec[wf]) e->use_graph = false;   // (the direct launches below are the same kernels: nothing is lost but the launch overhead)
+        }
+        gx = e->gexec[wf];
+    }
     TCHK(hipEventRecord(e->ev0, e->stream));
     for (int it = 0; it < iterations; ++it) {
-        launch(e, p, 0, l_end);
+        if (gx) TCHK(hipGraphLaunch(gx, e->stream));
+        else launch(e, p, 0, l_end);
         if (want_fe) {   // Σ over replicas of term[root]: chunks of FE_CHUNK into partials, the partials (≤ FE_CHUNK of them: up to 16.7 M replicas) into the iteration's slot
             const unsigned nb = (unsigned)((e->R + FE_CHUNK - 1) / FE_CHUNK);
             const double* root = e->d_term + (size_t)P.fe_root * (e->elem_fast ? 1 : e->RS);
