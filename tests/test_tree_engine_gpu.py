@@ -497,6 +497,7 @@ def test_mean_field_between_gaussian_interfaces(kw, mode, monkeypatch):
 @pytest.mark.parametrize("mode", [0, 1, 2, 3])
 @pytest.mark.parametrize("builder,kw", [(tg.two_branch_chain, dict(T=9)), (tg.two_branch_chain, dict(T=6, d=4, dy1=4, dy2=3)), (tg.scalar_tree, dict(n_leaves=6)),
                                         (tg.two_branch_chain, dict(T=5, d=8, dy1=8, dy2=5)), (tg.two_branch_chain, dict(T=4, d=12, dy1=12, dy2=7)),
+                                        (tg.two_branch_chain, dict(T=3, d=20, dy1=20, dy2=9)), (tg.two_branch_chain, dict(T=2, d=36, dy1=36, dy2=10)),
                                         (tg.chain_with_prediction, dict(T=8, H=2))])
 def test_missing_observations_anywhere_in_the_data(builder, kw, mode, monkeypatch):
     """`missing` inside the data of ANY graph of the family (rxhip_graph_desc.allow_missing; the reference: `data = (y = [1.0, missing, 3.0],)`,

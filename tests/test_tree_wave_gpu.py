@@ -191,6 +191,19 @@ def test_random_forests_on_the_register_tiles(seed, dmax, mode, monkeypatch):
     eng.close()
 
 
+def test_a_batch_whose_message_array_passes_four_gigabytes():
+    """64-bit addressing on the register tiles: 100 000 replicas × ≈ 90 KB of state each — the last replica's slots lie beyond 2³² bytes"""
+    from rxhip.tree import TreeEngine
+    gb, ys, _ = tg.two_branch_chain(T=8, d=12, dy1=12, dy2=7)
+    R = 100000
+    data = tg.random_data(gb, ys, R, 9)
+    with TreeEngine(gb, n_replicas=R) as eng:
+        assert eng.info["kernels"] == 1 and eng.info["doubles_per_replica"] * 8 * R > 2 ** 32
+        eng.set_data(ys, data)
+        eng.run(1, True)
+        _check(gb, ys, eng, data, replicas=(0, R // 2, R - 1), tol=1e-9, tol_fe=1e-10)
+
+
 @pytest.mark.parametrize("seed", range(48))
 def test_rule_eval_random_calls(seed):
     """rxhip_rule_eval with random node types, interfaces, dimensions (1 … 64: register and LDS-staged kernels) and message forms on both sides,
