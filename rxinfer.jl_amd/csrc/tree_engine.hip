@@ -1723,11 +1723,12 @@ void launch_wave_phase(const Engine* e, const TreeParams& p, int phase, int l0, 
             vt->ops(phase, p, o0, o1, dmax, (unsigned)std::min<long long>((long long)(o1 - o0) * e->R, 1 << 20), e->stream);
             continue;
         }
+        auto cls = [&](int i) { const int op = e->prog.ops[(size_t)i * OP_WORDS + W_OP]; return light(op) ? 2 : op == OP_FE_NOISE2M ? 3 : 1; };   // (3: the joint term alone)
         for (int a = o0; a < o1;) {
-            const bool la = light(e->prog.ops[(size_t)a * OP_WORDS + W_OP]);
+            const int ca = cls(a);
             int b = a + 1;
-            while (b < o1 && light(e->prog.ops[(size_t)b * OP_WORDS + W_OP]) == la) ++b;
-            vt->ops(la ? 2 : 1, p, a, b, dmax, (unsigned)std::min<long long>((long long)(b - a) * e->R, 1 << 20), e->stream);
+            while (b < o1 && cls(b) == ca) ++b;
+            vt->ops(ca, p, a, b, dmax, (unsigned)std::min<long long>((long long)(b - a) * e->R, 1 << 20), e->stream);
             a = b;
         }
     }

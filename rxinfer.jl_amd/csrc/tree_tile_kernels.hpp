@@ -636,7 +636,7 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
 // the second phase: Bethe terms, residual moments, q(W) updates — tree_wave_kernels.hpp eval_fe, op for op
 // HEAVY = false: the instance without the joint-marginal algebra (OP_FE_NOISE2M, OP_FE_ADD2) and the q(W) update — the terms of a chain's observation nodes, the
 // entropies, the sums: half the registers, twice the wavefronts per SIMD (the host launches a level's ops by opcode class: tree_engine.hip launch_wave_phase)
-template <int NT, bool ES1, bool HEAVY = true>
+template <int NT, bool ES1, int HEAVY = 1>   // 1: every op; 0: the light ops; 2: OP_FE_NOISE2M alone (the joint term of a chain's transitions: its own register budget)
 __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict__ w) {
     const int op = w[W_OP], d = w[W_D0], fl = w[W_FLAGS];
     const Lane<NT>& L = E.L;
@@ -729,7 +729,7 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
             ldV = E.marg(w[W_IN0])[(long long)(d + d * (d + 1) / 2) * es];
         if (threadIdx.x == 0) *E.term(w[W_TERM]) = (double)w[W_N] * 0.5 * (d * (T_LOG2PI + 1.0) + ldV);
     } break;
-    case OP_FE_ADD2: if (HEAVY) {   // P = Λ1 + Λo, S = Λ2 + Λo − Λo P⁻¹ Λo
+    case OP_FE_ADD2: if (HEAVY == 1) {   // P = Λ1 + Λo, S = Λ2 + Λo − Λo P⁻¹ Λo
         Vec<NT> v;
         Mat<NT> P, S, Lo, T;
         if (w[W_IN0] >= 0) ok = load_msg<NT, ES1>(E, w[W_IN0], fl & F_IN0_WP, true, d, v, P);
@@ -756,7 +756,7 @@ __device__ __forceinline__ void eval_fe(const Env<NT>& E, const int* __restrict_
             *E.term(w[W_TERM]) = s;
         }
     } break;
-    case OP_PREC_UPDATE: if (HEAVY) {
+    case OP_PREC_UPDATE: if (HEAVY == 1) {
         // prior block at c0: ν0 | S0⁻¹ (d²) | log|S0|;  S = Σ E[rrᵀ] symmetrised, V⁻¹ = S0⁻¹ + S, V
         const double* cp = E.p.cpool + w[W_C0];
         const double nu0 = cp[0], ldS0 = cp[1 + d * d];
@@ -817,8 +817,9 @@ __global__ void __launch_bounds__(64) k_tile_ops(TreeParams p, int op0, int op1)
         const Env<NT> E{L, scratch, p, it - o * p.R};
         const int* w = p.ops + (size_t)(op0 + o) * OP_WORDS;
         if (PHASE == 0) eval_bp<NT, ES1>(E, w);
-        else if (PHASE == 1) eval_fe<NT, ES1, true>(E, w);
-        else eval_fe<NT, ES1, false>(E, w);
+        else if (PHASE == 1) eval_fe<NT, ES1, 1>(E, w);
+        else if (PHASE == 2) eval_fe<NT, ES1, 0>(E, w);
+        else eval_fe<NT, ES1, 2>(E, w);
     }
 }
 // a wavefront owns a replica and walks the ops of the range in order (every op's inputs were written by this wavefront or before the launch)

@@ -24,7 +24,8 @@ void ops(int phase, const TreeParams& p, int o0, int o1, int, unsigned blocks, h
     if (p.es == 1) {
         if (phase == 0) hipLaunchKernelGGL((k_tile_ops<0, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
         else if (phase == 1) hipLaunchKernelGGL((k_tile_ops<1, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);
-        else hipLaunchKernelGGL((k_tile_ops<2, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);   // (2: the second phase's light opcodes)
+        else if (phase == 2) hipLaunchKernelGGL((k_tile_ops<2, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);   // (2: the second phase's light opcodes)
+        else hipLaunchKernelGGL((k_tile_ops<3, NT, true>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);                    // (3: OP_FE_NOISE2M alone)
     } else
         hipLaunchKernelGGL((k_tile_ops<0, NT, false>), dim3(blocks), dim3(64), 0, stream, p, o0, o1);   // (the sweep's rules only)
 }
@@ -51,7 +52,7 @@ hipError_t prepare(int dmax) {
     return hipSuccess;
 }
 void ops(int phase, const TreeParams& p, int o0, int o1, int dmax, unsigned blocks, hipStream_t stream) {
-    if (phase == 2) phase = 1;   // (one second-phase instance here)
+    if (phase >= 2) phase = 1;   // (one second-phase instance here)
     if (phase == 0) hipLaunchKernelGGL((k_wave_ops<0, DC>), dim3(blocks), dim3(WL), lds_bytes(dmax), stream, p, o0, o1, dmax);
     else hipLaunchKernelGGL((k_wave_ops<1, DC>), dim3(blocks), dim3(WL), lds_bytes(dmax), stream, p, o0, o1, dmax);
 }
