@@ -170,8 +170,9 @@ class TreeGraph:
     def _check_supported(self):
         for t, ifs in self.factors:
             if t in GAUSS_COV or t in GAUSS_PREC:
-                if self.kind[ifs[2]] != "constant" and not (t in GAUSS_PREC and ifs[2] in self.prec_prior):
-                    raise ValueError(f"{t}: third interface must be a constant (or a Wishart / Gamma variable on a precision node)")
+                scalar_data = self.kind[ifs[2]] == "data" and self.dim[ifs[0]] == 1
+                if self.kind[ifs[2]] != "constant" and not scalar_data and not (t in GAUSS_PREC and ifs[2] in self.prec_prior):
+                    raise ValueError(f"{t}: third interface must be a constant (or a Wishart / Gamma variable on a precision node; scalar nodes: a data variable)")
             elif t == "*":
                 if self.kind[ifs[1]] != "constant":
                     raise ValueError("`*`: the matrix must be a constant")
@@ -312,7 +313,7 @@ def infer(dump, data, iterations=1, free_energy=True):
             if third in g.prec_prior:
                 W = What[third]
                 return np.linalg.inv(W), W
-            M = np.atleast_2d(g.const(third)).astype(float)
+            M = np.atleast_2d(g.const(third) if g.kind[third] == "constant" else value(third)).astype(float)   # (a data-valued scalar variance: @autoupdates)
             if M.shape[0] != M.shape[1]:
                 M = M.reshape(g.dim[ifs[0]], g.dim[ifs[0]])
             return (M, np.linalg.inv(M)) if t in GAUSS_COV else (np.linalg.inv(M), M)

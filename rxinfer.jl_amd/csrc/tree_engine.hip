@@ -131,6 +131,7 @@ struct Program {
     long long io_bytes = 0;                     // what has to move whatever the schedule: the data in, the posteriors of the named variables out
     long long fe_bytes = 0;                     // the second phase's reads and writes per replica
     int longest_strand = 0;
+    bool has_valnoise = false;          // scalar Gaussian nodes with a data-valued variance / precision: lane-per-item kernels only
     bool has_mix = false;               // NormalMixture nodes: q(z), q(s) live in the precision-state array; lane-per-item kernels only (dimensions ≤ 8)
     bool has_mf = false;                // some Gaussian node runs under q(out) q(μ): the marginals of its interfaces are STATE (start: the @initialization marginals)
     std::vector<double> marg_init;      // [marg_doubles] when has_mf
@@ -390,7 +391,9 @@ struct Compiler {
                 if (P.vclass[c] == VC_PREC) {
                     if (!prec_node) fail(RXHIP_ERR_UNSUPPORTED, "a random covariance has no rule here (precision-parametrised nodes only)");
                     if (P.dim[c] != P.dim[a]) fail(RXHIP_ERR_BADARG, "factor %lld: precision variable of another dimension", (long long)f);
-                } else if (P.vclass[c] != VC_CONST) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: the third interface of a Gaussian node must be a constant or a Wishart / Gamma variable", (long long)f);
+                } else if (P.vclass[c] == VC_DATA && P.dim[a] == 1 && g->var_rows[c] * g->var_cols[c] == 1) {
+                    P.has_valnoise = true;   // a scalar node whose variance / precision arrives with the data (`Normal(mean = m_prev, var = v_prev)` of @autoupdates)
+                } else if (P.vclass[c] != VC_CONST) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: the third interface of a Gaussian node must be a constant, a Wishart / Gamma variable or (scalar nodes) a data variable", (long long)f);
                 dmx = std::max(dmx, P.dim[a]);
             } else if (nclass[f] == NC_MUL) {
                 if (P.vclass[b] != VC_CONST) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: `*` needs a constant matrix", (long long)f);
@@ -414,6 +417,7 @@ struct Compiler {
             P.has_mf = P.has_mf || mf[f];
         }
         if (P.has_mix && dmx > 8) fail(RXHIP_ERR_UNSUPPORTED, "NormalMixture nodes run on the lane-per-item kernels: dimensions <= 8 (this graph: %d)", dmx);
+        if (P.has_valnoise && dmx > 8) fail(RXHIP_ERR_UNSUPPORTED, "data-valued variances run on the lane-per-item kernels: dimensions <= 8 (this graph: %d)", dmx);
         P.has_mf = P.has_mf || P.has_mix;   // (the switch's rule reads the marginals of the means of the previous iteration: marginals are state)
         // <= 8: the register instances (lane per op and replica); above: the graph's own maximum, staged in LDS by a wavefront per op and replica
         P.dmax = dmx <= 1 ? 1 : dmx <= 2 ? 2 : dmx <= 4 ? 4 : dmx <= 8 ? 8 : dmx;
@@ -677,7 +681,10 @@ struct Compiler {
     void noise_params(OpRec& r, int f, int d) {
         const int c = (int)iface(f, 2), t = ftype(f);
         if (P.vclass[c] == VC_PREC) r.w[W_PREC] = P.prec_off[c];
-        else r.w[W_C0] = noise_block(c, d, t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION);
+        else if (P.vclass[c] == VC_DATA) {
+            r.w[W_C0] = P.val_off[c];
+            r.w[W_FLAGS] |= F_NOISE_VAL | ((t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION) ? F_NOISE_VAL_PREC : 0);
+        } else r.w[W_C0] = noise_block(c, d, t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION);
     }
 
     // A product or marginal over MANY inbound messages (a hub variable: the mean of 10^5 iid observations) as a tree of partial products, eight inputs
@@ -1791,7 +1798,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     // once the replicas fill the device (4 096: 3.4 against 5.4 ms; 65 536: 16 against 83): profiles/r06/tree_tile.txt
     e->tiled = P.dmax > 8 || (P.dmax > 4 && e->R <= 1024);
     if (const char* t = hook_env("RXHIP_TREE_TILE")) e->tiled = P.dmax > 8 || (P.dmax > 4 && std::atoi(t) != 0);
-    if (P.has_mix) e->tiled = false;   // (the mixture ops exist in the lane-per-item kernels only; the compiler refused dimensions above 8)
+    if (P.has_mix || P.has_valnoise) e->tiled = false;   // (the mixture ops exist in the lane-per-item kernels only; the compiler refused dimensions above 8)
     e->elem_fast = e->tiled;
     e->allow_missing = g->allow_missing != 0;
     // schedule: deep graphs walk their levels inside a workgroup (one launch per iteration); wide, shallow ones take a launch per level

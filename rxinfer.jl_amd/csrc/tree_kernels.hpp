@@ -64,6 +64,9 @@ enum : int {
     F_MAY_MISS = 16384,  // OP_LEAF / FE_NOISE1 / FE_NOISE0 on a DATA value of a graph created with allow_missing: NaN (`missing`) → no message / no energy term
     F_WEIGHT = 32768,    // OP_LEAF / FE_NOISE0 / FE_NOISE1 / FE_NOISE_MF: a component of a mixture node — message, energy and residual moments × π_k, the double at p.prec[W_LIST];
                          // OP_PREC_UPDATE: the list holds (moments, weight | −1) pairs, ν = ν0 + Σ weights
+    F_NOISE_VAL = 131072,      // a SCALAR Gaussian node whose variance (F_NOISE_VAL_PREC: precision) is a DATA variable — `x ~ Normal(mean = m_prev, var = v_prev)` of a streaming
+                               // model's @autoupdates: the value slot W_C0 instead of a constant block (lane-per-item kernels)
+    F_NOISE_VAL_PREC = 262144,
     F_VAL_MARG = 8192    // OP_LEAF: the value is the MEAN of the marginal slot W_VAL — the rule of a Gaussian node under q(out) q(μ): N(E[μ], Σ) toward out, N(E[out], Σ) toward μ
 };
 // strand schedule: an input offset that names the message the previous op of the lane's strand left in registers
@@ -332,6 +335,21 @@ __device__ __forceinline__ void store_msg(const TreeParams& p, int off, int d, l
 template <int N>
 __device__ __forceinline__ void load_noise(const TreeParams& p, const int* w, int d, long long r, bool want_sigma, bool want_w, double (&Sg)[N][N], double (&Wm)[N][N], double& elogdet) {
     const int ps = w[W_PREC];
+    if (w[W_FLAGS] & F_NOISE_VAL) {   // d = 1: the variance / precision of this replica from its value slot
+        const double x = p.val[(long long)w[W_C0] * p.RS + r], xi = 1.0 / x;
+        const bool isp = w[W_FLAGS] & F_NOISE_VAL_PREC;
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                Sg[i][j] = i == j ? 1.0 : 0.0;
+                Wm[i][j] = i == j ? 1.0 : 0.0;
+            }
+        Sg[0][0] = isp ? xi : x;
+        Wm[0][0] = isp ? x : xi;
+        elogdet = log(Wm[0][0]);
+        return;
+    }
     if (ps >= 0) {
         const int tri = d * (d + 1) / 2;
         if (want_w) ld_full<N>(p.prec, ps + 1 + tri, d, p.RS, r, 1.0, Wm);
