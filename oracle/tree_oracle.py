@@ -21,6 +21,11 @@ variable terms (src/model/plugins/reactivemp_free_energy.jl:51-126).  The rule b
         toward out: the same with E[m_k], toward p_k: ν += π_k, V⁻¹ += π_k E[(out − m_k)(out − m_k)ᵀ], energy Σ_k π_k U_k — and toward the switch:
         q(z = k) ∝ exp(E log s_k − U_k), U_k = ½[d log 2π − E log|p_k| + tr(E[p_k] E[(out − m_k)(out − m_k)ᵀ])];  q(s) = Dirichlet(a + Σ_i π_i).
         Schedule per iteration (rxo_mvgmm_vmp): q(z) from the previous marginals, then the Gaussian sweep and q(s) with the new π, then q(p) with the new q(m).
+  GCV (y, x, z, κ, ω), κ and ω constants, under q(y, x) q(z) (test/models/statespace/hgf_tests.jl:28-35; the rules of oracle/rxoracle.c rxo_hgf_filter): toward
+        (y, x) the node IS a scalar Gaussian precision node with γ = exp(−(κ z + ω)): E[γ] = exp(−ω − κ m_z + κ² v_z / 2), E[log γ] = −(κ m_z + ω) from q(z) of the
+        previous iteration.  Toward z it sends ExponentialLinearQuadratic(a = κ, b = ψ e^{−ω}, c = −κ), ψ = E[(y − x)²] under the node-local joint; q(z) is its product
+        with the Gaussian message from the rest of the graph, moment-matched by Gauss–Hermite cubature against that message; every OTHER neighbour of z sees the
+        message through its Gaussian moments (cubature of pdf(z)·exp(z²/2) against N(0, 1)) — the reference's treatment, reproduced to the golden by rxo_hgf_filter.
   Bethe terms: SURVEY Appendix A.4 as oracle/rxoracle.c lgssm_bp_ws spells them for the state-space graph — stochastic node U − H[q(cluster)],
   deterministic node −H[q(inputs)], random variable (degree − 1) H[q]; clamped interfaces contribute no entropy.
 
@@ -50,7 +55,7 @@ LOG2PI = math.log(2.0 * math.pi)
 GAUSS_COV = ("MvNormalMeanCovariance", "NormalMeanVariance")
 GAUSS_PREC = ("MvNormalMeanPrecision", "NormalMeanPrecision")
 PRIORS = ("Wishart", "GammaShapeRate", "GammaShapeScale")
-SKIP = ("NormalMixture", "Categorical", "Dirichlet", "Bernoulli", "Beta")   # no Gaussian message of their own: the mixture node acts through its K weighted virtual nodes
+SKIP = ("NormalMixture", "Categorical", "Dirichlet", "Bernoulli", "Beta", "GCV")   # no Gaussian message of their own: the mixture node acts through its K weighted virtual nodes
 
 
 def _sym(M):
@@ -99,7 +104,8 @@ class TreeGraph:
         nv = len(self.vars)
         # NormalMixture under mean field = K weighted Gaussian precision nodes (out, m_k, p_k) appended behind the real factors; the mixture node itself, the
         # Categorical and the Dirichlet nodes carry no Gaussian message (types in SKIP)
-        self.weight, self.mixtures, self.cat, self.dir = {}, [], {}, {}
+        self.weight, self.mixtures, self.cat, self.dir, self.gcv = {}, [], {}, {}, []
+        self.gh_points = int(dump.get("gh_points") or 31)
         for fi, (t, ifs) in enumerate(list(self.factors)):
             if t == "NormalMixture":
                 K = (len(ifs) - 2) // 2
@@ -116,12 +122,28 @@ class TreeGraph:
                     self.factors.append(("MvNormalMeanPrecision", [ifs[0], ifs[2 + k], ifs[2 + K + k]]))
                     self.clusters.append([0, 1, 2])
                 self.mixtures.append(dict(node=fi, out=ifs[0], z=ifs[1], m=ifs[2:2 + K], p=ifs[2 + K:], virtual=vf))
+            elif t == "GCV":
+                if len(ifs) != 5 or any(int(self.vars[v]["rows"]) != 1 for v in ifs[:3]) or any(self.vars[v]["kind"] != "constant" for v in ifs[3:]):
+                    raise ValueError("GCV: scalar (y, x, z) and constant (κ, ω) expected")
+                cl = self.clusters[fi]
+                if cl is not None and (cl[0] != cl[1] or cl[2] == cl[0]):
+                    raise ValueError("GCV: only q(y, x) q(z) has rules")
+                gam = len(self.vars)   # the node's precision γ(z): a virtual variable, neither random nor clamped
+                self.vars = list(self.vars) + [dict(name=f"gcv_gamma_{fi}", kind="gcvprec", rows=1, cols=1)]
+                fa, fz = len(self.factors), len(self.factors) + 1
+                self.factors.append(("NormalMeanPrecision", [ifs[0], ifs[1], gam]))
+                self.clusters.append([0, 0, 1])
+                self.factors.append(("GCVZ", [ifs[2]]))
+                self.clusters.append([0])
+                self.gcv.append(dict(node=fi, y=ifs[0], x=ifs[1], z=ifs[2], kappa=float(np.ravel(self.vars[ifs[3]]["value"])[0]), omega=float(np.ravel(self.vars[ifs[4]]["value"])[0]),
+                                     fa=fa, fz=fz, gamma=gam))
             elif t in ("Categorical", "Bernoulli"):   # Bernoulli(s): the two-component spelling, z = true the FIRST component
                 self.cat[ifs[0]] = ifs[1]
             elif t == "Dirichlet":
                 self.dir[ifs[0]] = ifs[1]
             elif t == "Beta":                          # Beta(a, b) on the probability of the first component = Dirichlet([a, b])
                 self.dir[ifs[0]] = (ifs[1], ifs[2])
+        nv = len(self.vars)
         self.dim = [int(v["rows"]) for v in self.vars]
         self.kind = [v["kind"] for v in self.vars]
         # classify: precision variables are the random `out` of a Wishart / Gamma prior node
@@ -170,13 +192,15 @@ class TreeGraph:
     def _check_supported(self):
         for t, ifs in self.factors:
             if t in GAUSS_COV or t in GAUSS_PREC:
-                scalar_data = self.kind[ifs[2]] == "data" and self.dim[ifs[0]] == 1
+                scalar_data = self.kind[ifs[2]] in ("data", "gcvprec") and self.dim[ifs[0]] == 1
                 if self.kind[ifs[2]] != "constant" and not scalar_data and not (t in GAUSS_PREC and ifs[2] in self.prec_prior):
                     raise ValueError(f"{t}: third interface must be a constant (or a Wishart / Gamma variable on a precision node; scalar nodes: a data variable)")
             elif t == "*":
                 if self.kind[ifs[1]] != "constant":
                     raise ValueError("`*`: the matrix must be a constant")
-            elif t == "+" or t in PRIORS:
+            elif t == "+" or t in PRIORS or t == "GCVZ":
+                pass
+            elif t == "GCV":
                 pass
             elif t == "NormalMixture":
                 z = ifs[1]
@@ -273,6 +297,16 @@ def infer(dump, data, iterations=1, free_energy=True):
         ini = g.vars[sv].get("init")
         qs[sv] = np.asarray(ini["params"] if ini is not None and ini["family"] == "dirichlet" else g.alpha0(sv), float).copy()
 
+    # GCV nodes: the state of γ(z) = exp(−(κ z + ω)) under q(z): (E γ, E log γ), started from the `@initialization` marginal of z
+    def gamma_of(gc, m, v):
+        return math.exp(-gc["omega"] - gc["kappa"] * m + 0.5 * gc["kappa"] ** 2 * v), -(gc["kappa"] * m + gc["omega"])
+    gstate = {}
+    for gc in g.gcv:
+        m0, V0 = g.init_gauss(gc["z"])
+        gstate[gc["gamma"]] = gamma_of(gc, float(m0[0]), float(V0[0, 0]))
+    gh_x, gh_w = np.polynomial.hermite.hermgauss(g.gh_points)
+    gh_w = gh_w / math.sqrt(math.pi)
+
     def elog_s(sv, alphas):   # E log s of a Dirichlet variable, log p of a constant probability vector
         if g.kind[sv] == "constant":
             return np.log(np.ravel(g.const(sv)).astype(float))
@@ -306,6 +340,7 @@ def infer(dump, data, iterations=1, free_energy=True):
         counters = dict(rule_calls=0, products=0, marginals=0, on=True)
         det_outs = {ifs[0] for t, ifs in g.factors if t in ("*", "+")}
         f2v, v2f = {}, {}
+        gcv_elq = {}
 
         def noise_of(fi):
             t, ifs = g.factors[fi]
@@ -313,6 +348,9 @@ def infer(dump, data, iterations=1, free_energy=True):
             if third in g.prec_prior:
                 W = What[third]
                 return np.linalg.inv(W), W
+            if g.kind[third] == "gcvprec":
+                W = np.array([[gstate[third][0]]])
+                return 1.0 / W, W
             M = np.atleast_2d(g.const(third) if g.kind[third] == "constant" else value(third)).astype(float)   # (a data-valued scalar variance: @autoupdates)
             if M.shape[0] != M.shape[1]:
                 M = M.reshape(g.dim[ifs[0]], g.dim[ifs[0]])
@@ -365,6 +403,23 @@ def infer(dump, data, iterations=1, free_energy=True):
                     res = None if m is None else additive(m, Sigma, W)   # an unobserved leaf on the other side: nothing to pass on
                 else:   # a `missing` observation (NaN) sends nothing
                     res = None if np.any(np.isnan(value(other))) else Msg("mv", value(other), Sigma)
+            elif t == "GCVZ":
+                gc = next(c for c in g.gcv if c["fz"] == fi)
+                xy, Ly = wp0(msg_v2f(gc["y"], gc["fa"], 0), 1)
+                xx, Lx = wp0(msg_v2f(gc["x"], gc["fa"], 1), 1)
+                gam = gstate[gc["gamma"]][0]
+                l11, l22 = float(Ly[0, 0]) + gam, float(Lx[0, 0]) + gam
+                det = l11 * l22 - gam * gam
+                v11, v22, v12 = l22 / det, l11 / det, gam / det
+                m1, m2 = v11 * xy[0] + v12 * xx[0], v12 * xy[0] + v22 * xx[0]
+                psi = (m1 - m2) ** 2 + v11 + v22 - 2.0 * v12
+                a_, b_, c_ = gc["kappa"], psi * math.exp(-gc["omega"]), -gc["kappa"]
+                gcv_elq[gc["z"]] = (a_, b_, c_, fi)
+                epts = math.sqrt(2.0) * gh_x                                # what the neighbours of z see: the message's own Gaussian moments (no other message enters)
+                ecs = gh_w * np.exp(-0.5 * (a_ * epts + b_ * np.exp(c_ * epts)) + 0.5 * epts * epts)
+                em = float(np.sum(epts * ecs) / np.sum(ecs))
+                ev = float(np.sum(ecs * (epts - em) ** 2) / np.sum(ecs))
+                res = Msg("mv", [em], [[ev]])
             elif t == "*":
                 A = np.atleast_2d(g.const(ifs[1])).astype(float)
                 if A.shape != (g.dim[ifs[0]], g.dim[ifs[2]]):
@@ -429,6 +484,16 @@ def infer(dump, data, iterations=1, free_energy=True):
                 xi, L = xi + x2, L + L2
             V = _sym(np.linalg.inv(L))
             mean[v], cov[v] = V @ xi, V
+            if v in gcv_elq:   # the volatility input of a GCV node: the ELQ message times the product of ALL other messages, moment-matched by cubature against that product
+                a_, b_, c_, fz = gcv_elq[v]
+                fwd = msg_v2f(v, fz, 0)
+                if fwd is None:
+                    raise ValueError("GCV: z receives no Gaussian message to moment-match against")
+                zm, fzv = (float(np.ravel(a)[0]) for a in fwd.mv())
+                pts = zm + math.sqrt(2.0 * fzv) * gh_x
+                cs = gh_w * np.exp(-0.5 * (a_ * pts + b_ * np.exp(c_ * pts)))
+                qm = float(np.sum(pts * cs) / np.sum(cs))
+                mean[v], cov[v] = np.array([qm]), np.array([[float(np.sum(cs * (pts - qm) ** 2) / np.sum(cs))]])
             qinfo[v] = (xi, L)
             counters["marginals"] += counters["on"] and v not in det_outs
         counters["on"] = False
@@ -475,6 +540,7 @@ def infer(dump, data, iterations=1, free_energy=True):
                     wk = pi[g.weight[fi][0]][g.weight[fi][1]] if fi in g.weight else 1.0
                     stats[ifs[2]][0] += wk
                     stats[ifs[2]][1] += wk * moments[fi][0]
+        gnew = {gc["gamma"]: gamma_of(gc, float(mean[gc["z"]][0]), float(cov[gc["z"]][0, 0])) for gc in g.gcv}
         qs_new = {sv: g.alpha0(sv).astype(float) + sum(pi[z] for z in pi if g.cat[z] == sv) for sv in qs}
         qnew = {}
         for v in qW:
@@ -497,6 +563,8 @@ def infer(dump, data, iterations=1, free_energy=True):
                         nu, V = qnew[third]
                         Elogdet = mvdigamma(0.5 * nu, d) + d * math.log(2.0) + np.linalg.slogdet(V)[1]
                         Wm = nu * V
+                    elif g.kind[third] == "gcvprec":   # the GCV average energy with the NEW q(z)
+                        Wm, Elogdet = np.array([[gnew[third][0]]]), gnew[third][1]
                     else:
                         _, Wm = noise_of(fi)
                         Elogdet = np.linalg.slogdet(Wm)[1]
@@ -534,6 +602,8 @@ def infer(dump, data, iterations=1, free_energy=True):
             for v in range(nv):
                 if g.gauss[v]:
                     F += (len(g.nbrs[v]) - 1) * _entropy(cov[v])
+            for gc in g.gcv:   # the node's second cluster: −H[q(z)]
+                F += -_entropy(cov[gc["z"]])
             # Categorical nodes: −Σ_k π_k E log s_k with the new q(s); −H[q(z)] (node terms −2H, variable term +H); Dirichlet prior node U − H[q(s)]
             for z, w in pi.items():
                 F += -float(np.dot(w, elog_s(g.cat[z], qs_new))) + float(np.sum(w[w > 0.0] * np.log(w[w > 0.0])))
@@ -546,6 +616,7 @@ def infer(dump, data, iterations=1, free_energy=True):
                 F += U - Hs
             fe_hist.append(float(F))
         qW = qnew
+        gstate = gnew
         qs = qs_new
         qx = {v: (mean[v].copy(), cov[v].copy()) for v in qx}
         counters.pop("on")

@@ -108,7 +108,7 @@ double host_digamma(double x) {
 }
 
 enum VarClass { VC_CONST = 0, VC_DATA = 1, VC_DERIVED = 2, VC_PREC = 3, VC_GAUSS = 4, VC_CAT = 5, VC_DIR = 6 };   // (CAT: the switch of a mixture node; DIR: its probability vector)
-enum NodeClass { NC_NOISE = 0, NC_MUL = 1, NC_ADD = 2, NC_PRIOR = 3, NC_SKIP = 4 };   // (SKIP: NormalMixture / Categorical / Dirichlet — they act through virtual nodes and state ops)
+enum NodeClass { NC_NOISE = 0, NC_MUL = 1, NC_ADD = 2, NC_PRIOR = 3, NC_SKIP = 4, NC_GCVZ = 5 };   // (GCVZ: the z side of a GCV node)   // (SKIP: NormalMixture / Categorical / Dirichlet — they act through virtual nodes and state ops)
 
 struct Program {
     int dmax = 1;
@@ -131,6 +131,7 @@ struct Program {
     long long io_bytes = 0;                     // what has to move whatever the schedule: the data in, the posteriors of the named variables out
     long long fe_bytes = 0;                     // the second phase's reads and writes per replica
     int longest_strand = 0;
+    bool has_gcv = false;               // GCV nodes: lane-per-item kernels only
     bool has_valnoise = false;          // scalar Gaussian nodes with a data-valued variance / precision: lane-per-item kernels only
     bool has_mix = false;               // NormalMixture nodes: q(z), q(s) live in the precision-state array; lane-per-item kernels only (dimensions ≤ 8)
     bool has_mf = false;                // some Gaussian node runs under q(out) q(μ): the marginals of its interfaces are STATE (start: the @initialization marginals)
@@ -157,6 +158,13 @@ struct Compiler {
     std::vector<int64_t> xifv;          // interfaces of the real factors, then of the virtual ones
     std::vector<int> xtype;             // node types alike
     std::vector<int> wz, wk;            // per factor: the switch variable and component that weight it (−1)
+    // GCV(y, x, z, κ, ω) under q(y, x) q(z), κ and ω constants (test/models/statespace/hgf_tests.jl:28-35): toward (y, x) a scalar Gaussian precision node whose precision
+    // γ(z) = exp(−(κ z + ω)) lives in a STATE slot (E γ, E log γ of the previous iteration's q(z)) — virtual node `fa` — and toward z a message op of its own — virtual
+    // node `fz` (tree_kernels.hpp OP_GCV_Z): the joint of (y, x), ψ, the cubature-matched q(z) and the Gaussian moments of the ELQ message for z's other neighbours
+    struct Gcv { int node, y, x, z, kv, ov, fa, fz, state, stat; };
+    std::vector<Gcv> gcvs;
+    std::vector<int> gcv_of;            // per factor: index into gcvs for its two virtual nodes (−1)
+    std::vector<char> gcv_z;            // per variable: the volatility input of a GCV node
     struct Mix { int node, out, z, K; std::vector<int> m, p; };
     std::vector<Mix> mixes;
     std::vector<int> cat_s, dir_a, catK;   // per variable: a switch's probability-vector variable; a Dirichlet variable's concentration constant (≤ −2: Beta, alpha_pool); components
@@ -235,10 +243,32 @@ struct Compiler {
         wz.assign((size_t)nf, -1); wk.assign((size_t)nf, -1);
         cat_s.assign((size_t)nv, -1); dir_a.assign((size_t)nv, -1); catK.assign((size_t)nv, 0);
         const int64_t nf0 = nf;
+        gcv_of.assign((size_t)nf, -1);
+        gcv_z.assign((size_t)nv, 0);
         bool any = false;
-        for (int64_t f = 0; f < nf0; ++f) any = any || xtype[f] == RXHIP_NODE_NORMAL_MIXTURE;
+        for (int64_t f = 0; f < nf0; ++f) any = any || xtype[f] == RXHIP_NODE_NORMAL_MIXTURE || xtype[f] == RXHIP_NODE_GCV;
         if (!any) return;
         xifv.assign(g->factor_iface, g->factor_iface + iptr[nf0]);
+        for (int64_t f = 0; f < nf0; ++f) {
+            if (xtype[f] != RXHIP_NODE_GCV) continue;
+            if (n_iface((int)f) != 5) fail(RXHIP_ERR_BADARG, "factor %lld (GCV): interfaces (y, x, z, κ, ω) expected", (long long)f);
+            Gcv gc{(int)f, (int)iface((int)f, 0), (int)iface((int)f, 1), (int)iface((int)f, 2), (int)iface((int)f, 3), (int)iface((int)f, 4), 0, 0, -1, -1};
+            for (int v : {gc.y, gc.x, gc.z, gc.kv, gc.ov})
+                if (g->var_rows[v] != 1 || g->var_cols[v] != 1) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld (GCV): scalar interfaces expected", (long long)f);
+            if (gcv_z[gc.z]) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld (GCV): its volatility input drives another GCV node as well", (long long)f);
+            gcv_z[gc.z] = 1;
+            gc.fa = (int)xtype.size();
+            xtype.push_back(RXHIP_NODE_NORMAL_MEAN_PRECISION);
+            xifv.push_back(gc.y); xifv.push_back(gc.x); xifv.push_back(gc.z);
+            iptr.push_back((int64_t)xifv.size());
+            gc.fz = (int)xtype.size();
+            xtype.push_back(RXHIP_NODE_GCV);
+            xifv.push_back(gc.z); xifv.push_back(gc.y); xifv.push_back(gc.x);
+            iptr.push_back((int64_t)xifv.size());
+            for (int k = 0; k < 2; ++k) { wz.push_back(-1); wk.push_back(-1); gcv_of.push_back((int)gcvs.size()); }
+            gcvs.push_back(gc);
+            P.has_gcv = true;
+        }
         for (int64_t f = 0; f < nf0; ++f) {
             if (xtype[f] != RXHIP_NODE_NORMAL_MIXTURE) continue;
             const int n = n_iface((int)f), K = (n - 2) / 2;
@@ -251,13 +281,13 @@ struct Compiler {
                 xtype.push_back(d == 1 ? RXHIP_NODE_NORMAL_MEAN_PRECISION : RXHIP_NODE_MVNORMAL_MEAN_PRECISION);
                 xifv.push_back(mx.out); xifv.push_back(mx.m[k]); xifv.push_back(mx.p[k]);
                 iptr.push_back((int64_t)xifv.size());
-                wz.push_back(mx.z); wk.push_back(k);
+                wz.push_back(mx.z); wk.push_back(k); gcv_of.push_back(-1);
             }
             mixes.push_back(std::move(mx));
         }
         nf = (int64_t)xtype.size();
         ifv = xifv.data();
-        P.has_mix = true;
+        P.has_mix = !mixes.empty();
     }
     void classify_mixtures() {
         for (int64_t f = 0; f < nf; ++f) {
@@ -341,6 +371,7 @@ struct Compiler {
         for (int64_t f = 0; f < nf; ++f) {
             const int t = ftype((int)f);
             if (t == RXHIP_NODE_NORMAL_MIXTURE || t == RXHIP_NODE_CATEGORICAL || t == RXHIP_NODE_DIRICHLET || ((t == RXHIP_NODE_BERNOULLI || t == RXHIP_NODE_BETA) && P.has_mix)) { nclass[f] = NC_SKIP; continue; }
+            if (t == RXHIP_NODE_GCV) { nclass[f] = gcv_of[f] >= 0 ? NC_GCVZ : NC_SKIP; continue; }   // (the node itself; its z side)
             switch (t) {
             case RXHIP_NODE_MVNORMAL_MEAN_COV: case RXHIP_NODE_NORMAL_MEAN_VARIANCE: case RXHIP_NODE_MVNORMAL_MEAN_PRECISION: case RXHIP_NODE_NORMAL_MEAN_PRECISION:
                 nclass[f] = NC_NOISE; break;
@@ -355,6 +386,7 @@ struct Compiler {
         // deterministic nodes): a mismatch is refused with the node named — never answered with the other variational family's posterior
         if (rxhip_lower::check_factorisation(g, &mf)) fail(RXHIP_ERR_UNSUPPORTED, "%s", rxhip_lower::last_error().c_str());
         mf.resize((size_t)nf, 1);   // (the components of a mixture node: mean field between `out` and the mean wherever both are random)
+        for (const Gcv& gc : gcvs) mf[gc.fa] = 0;   // (q(y, x): structured)
         classify_mixtures();
         // precision variables
         for (int64_t f = 0; f < nf; ++f)
@@ -388,7 +420,9 @@ struct Compiler {
                 const bool prec_node = t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION;
                 if (P.vclass[a] == VC_PREC || P.vclass[b] == VC_PREC) fail(RXHIP_ERR_UNSUPPORTED, "a precision variable on a Gaussian node's out / mean interface");
                 if (P.dim[a] != P.dim[b]) fail(RXHIP_ERR_BADARG, "factor %lld: out and mean differ in dimension", (long long)f);
-                if (P.vclass[c] == VC_PREC) {
+                if (gcv_of[f] >= 0) {
+                    // γ(z) of a GCV node: a state slot, not a variable
+                } else if (P.vclass[c] == VC_PREC) {
                     if (!prec_node) fail(RXHIP_ERR_UNSUPPORTED, "a random covariance has no rule here (precision-parametrised nodes only)");
                     if (P.dim[c] != P.dim[a]) fail(RXHIP_ERR_BADARG, "factor %lld: precision variable of another dimension", (long long)f);
                 } else if (P.vclass[c] == VC_DATA && P.dim[a] == 1 && g->var_rows[c] * g->var_cols[c] == 1) {
@@ -417,6 +451,12 @@ struct Compiler {
             P.has_mf = P.has_mf || mf[f];
         }
         if (P.has_mix && dmx > 8) fail(RXHIP_ERR_UNSUPPORTED, "NormalMixture nodes run on the lane-per-item kernels: dimensions <= 8 (this graph: %d)", dmx);
+        if (P.has_gcv && dmx > 8) fail(RXHIP_ERR_UNSUPPORTED, "GCV nodes run on the lane-per-item kernels: dimensions <= 8 (this graph: %d)", dmx);
+        for (const Gcv& gc : gcvs) {
+            if (P.vclass[gc.kv] != VC_CONST || P.vclass[gc.ov] != VC_CONST) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (GCV): κ and ω must be constants", gc.node);
+            for (int v : {gc.y, gc.x, gc.z})
+                if (P.vclass[v] != VC_GAUSS) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (GCV): y, x and z must be random Gaussian variables", gc.node);
+        }
         if (P.has_valnoise && dmx > 8) fail(RXHIP_ERR_UNSUPPORTED, "data-valued variances run on the lane-per-item kernels: dimensions <= 8 (this graph: %d)", dmx);
         P.has_mf = P.has_mf || P.has_mix;   // (the switch's rule reads the marginals of the means of the previous iteration: marginals are state)
         // <= 8: the register instances (lane per op and replica); above: the graph's own maximum, staged in LDS by a wavefront per op and replica
@@ -441,6 +481,7 @@ struct Compiler {
             for (int k = 0; k < 3; ++k) {
                 if (k == 1 && nclass[f] == NC_MUL) continue;
                 if (k == 2 && nclass[f] == NC_NOISE) continue;
+                if (k != 0 && nclass[f] == NC_GCVZ) continue;
                 const int v = (int)iface((int)f, k);
                 if (P.vclass[v] != VC_GAUSS) continue;
                 const int ra = find(v), rb = find((int)(nv + f + ((mf[f] && k == 1) ? nf : 0)));
@@ -466,7 +507,13 @@ struct Compiler {
             const Edge& ed = edges[e];
             const int f = ed.f;
             auto other = [&](int k) { return fac_edges[f][k]; };
-            if (nclass[f] == NC_NOISE) {
+            if (nclass[f] == NC_GCVZ) {   // the joint of (y, x) from their messages into the node, and the Gaussian message into z the product is matched against
+                const Gcv& gc = gcvs[gcv_of[f]];
+                for (int k = 0; k < 2; ++k) {
+                    if (fac_edges[gc.fa][k] < 0) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (GCV): y and x must be random variables", gc.node);
+                    deps[e].push_back(E + fac_edges[gc.fa][k]);
+                }
+            } else if (nclass[f] == NC_NOISE) {
                 if (!mf[f] && other(1 - ed.k) >= 0) deps[e].push_back(E + other(1 - ed.k));   // (mean field: the rule reads the other interface's MARGINAL, not its message)
             } else if (nclass[f] == NC_MUL) {
                 const int o = other(ed.k == 0 ? 2 : 0);
@@ -496,6 +543,7 @@ struct Compiler {
         return 2;
     }
     bool factor_uses_v2f(int f) const {
+        if (nclass[f] == NC_GCVZ) return true;
         if (mf[f]) return false;
         int ng = 0;
         for (int k = 0; k < 3; ++k) ng += fac_edges[f][k] >= 0;
@@ -646,7 +694,8 @@ struct Compiler {
                         form[m] = form[deps[m][0]];
                         if (!form[m] && var_edges[ed.v].size() >= 3 && !is_hub(ed.v)) form[m] = 1;
                     }
-                } else if (nclass[ed.f] == NC_MUL) form[m] = ed.k == 0 ? 0 : 1;
+                } else if (nclass[ed.f] == NC_GCVZ) form[m] = 0;   // (the ELQ message's Gaussian moments)
+                else if (nclass[ed.f] == NC_MUL) form[m] = ed.k == 0 ? 0 : 1;
                 else if (deps[m].size() == 2) form[m] = ed.k == 0 ? 0 : form[deps[m][0]];   // `+`: (:out) adds moments; (:in) keeps the form of the message from `out` (deps[m][0])
                 else form[m] = form[deps[m][0]];
             }
@@ -660,6 +709,14 @@ struct Compiler {
                 for (int e : var_edges[v]) any = any || !null_[e];
                 if (!any) fail(RXHIP_ERR_BADARG, "random variable %lld receives no message (no prior and no data reach it)", (long long)v);
             }
+        for (const Gcv& gc : gcvs) {
+            if (null_[fac_edges[gc.fz][0]]) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (GCV): y, x and z each need a proper message from the rest of the graph", gc.node);
+            for (int e2 : var_edges[gc.z]) {   // z's other neighbours see the ELQ message through its Gaussian moments: structured Gaussian nodes only
+                const int f2 = edges[e2].f;
+                if (f2 != gc.fz && !(nclass[f2] == NC_NOISE && !mf[f2]))
+                    fail(RXHIP_ERR_UNSUPPORTED, "factor %d (GCV): its volatility input (variable %d) may only touch structured Gaussian nodes besides", gc.node, gc.z);
+            }
+        }
     }
 
     // ---- emission ----
@@ -680,7 +737,8 @@ struct Compiler {
     int src_off(int m) const { return off[alias[m] >= 0 ? alias[m] : m]; }
     void noise_params(OpRec& r, int f, int d) {
         const int c = (int)iface(f, 2), t = ftype(f);
-        if (P.vclass[c] == VC_PREC) r.w[W_PREC] = P.prec_off[c];
+        if (gcv_of[f] >= 0) r.w[W_PREC] = gcvs[gcv_of[f]].state;
+        else if (P.vclass[c] == VC_PREC) r.w[W_PREC] = P.prec_off[c];
         else if (P.vclass[c] == VC_DATA) {
             r.w[W_C0] = P.val_off[c];
             r.w[W_FLAGS] |= F_NOISE_VAL | ((t == RXHIP_NODE_MVNORMAL_MEAN_PRECISION || t == RXHIP_NODE_NORMAL_MEAN_PRECISION) ? F_NOISE_VAL_PREC : 0);
@@ -730,6 +788,7 @@ struct Compiler {
             if (P.vclass[v] == VC_CAT) { P.prec_off[v] = (int)po; po += catK[v]; }          // q(z): π[K]
             if (P.vclass[v] == VC_DIR) { P.prec_off[v] = (int)po; po += 2 * catK[v]; }      // q(s): α[K] | E log s[K]
         }
+        for (size_t i = 0; i < gcvs.size(); ++i) { gcvs[i].state = (int)po; po += 5; gcvs[i].stat = (int)i; }   // (ψ: the first residual-moment slots)   // γ(z): [· | · | E γ | 1 / E γ | E log γ] — the layout of a scalar precision variable's state
         P.marg_doubles = mo; P.prec_doubles = po;
         long long so = 0;
         for (int m = 0; m < 2 * E; ++m)
@@ -742,6 +801,17 @@ struct Compiler {
 
     void init_precision() {
         P.prec_init.assign((size_t)P.prec_doubles, 0.0);
+        for (const Gcv& gc : gcvs) {   // γ(z) under the `@initialization` marginal of z (hgf_tests.jl:47-50)
+            if (!(g->var_init_family && g->var_init && g->var_init_family[gc.z] == RXHIP_INIT_NORMAL && g->var_init[gc.z] >= 0))
+                fail(RXHIP_ERR_BADARG, "factor %d (GCV): its volatility input (variable %d) needs a Normal @initialization marginal", gc.node, gc.z);
+            const double* q = g->const_pool + g->var_init[gc.z];
+            const double kappa = cptr(gc.kv)[0], omega = cptr(gc.ov)[0];
+            if (!(q[1] > 0.0)) fail(RXHIP_ERR_BADARG, "factor %d (GCV): initial marginal of variable %d is not a proper Gaussian", gc.node, gc.z);
+            double* st = P.prec_init.data() + gc.state;
+            st[2] = std::exp(-omega - kappa * q[0] + 0.5 * kappa * kappa * q[1]);
+            st[3] = 1.0 / st[2];
+            st[4] = -(kappa * q[0] + omega);
+        }
         for (int64_t v = 0; v < nv; ++v) {
             double* st = P.prec_init.data() + (P.prec_off[v] >= 0 ? P.prec_off[v] : 0);
             const int K = catK[v];
@@ -944,6 +1014,19 @@ struct Compiler {
                 continue;
             }
             const int f = ed.f;
+            if (nclass[f] == NC_GCVZ) {
+                const Gcv& gc = gcvs[gcv_of[f]];
+                OpRec& r = emit(lv, OP_GCV_Z, 1);
+                const int my = E + fac_edges[gc.fa][0], mx = E + fac_edges[gc.fa][1];
+                r.w[W_IN0] = src_off(my); if (form[my]) r.w[W_FLAGS] |= F_IN0_WP;
+                r.w[W_IN1] = src_off(mx); if (form[mx]) r.w[W_FLAGS] |= F_IN1_WP;
+                r.w[W_PREC] = gc.state;
+                r.w[W_C0] = gcv_constants(gc);
+                r.w[W_C1] = gc.stat;
+                r.w[W_OUT] = off[m];
+                P.bytes_per_sweep += 8ll * 4 * msz(1);
+                continue;
+            }
             if (nclass[f] == NC_NOISE) {
                 const int oe = fac_edges[f][1 - ed.k];
                 if (oe < 0 || mf[f]) {
@@ -1029,6 +1112,20 @@ struct Compiler {
             if (push_from[v] == -2) push_from[v] = -1;
         for (int64_t v = 0; v < nv; ++v) {
             if (P.vclass[v] != VC_GAUSS || push_from[v] >= 0) continue;
+            if (gcv_z[v]) {   // the volatility input of a GCV node: the ELQ message times the product of all other messages, by cubature
+                const Gcv* gc = nullptr;
+                for (const Gcv& c2 : gcvs) if (c2.z == (int)v) gc = &c2;
+                const int mz = E + fac_edges[gc->fz][0];
+                if (null_[mz]) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (GCV): its volatility input receives no Gaussian message to match the product against", gc->node);
+                OpRec& r = emit(LM, OP_GCV_ZMARG, 1);
+                r.w[W_IN0] = src_off(mz); if (form[mz]) r.w[W_FLAGS] |= F_IN0_WP;
+                r.w[W_IN1] = off[fac_edges[gc->fz][0]];   // (not loaded: names the op whose ψ this one reads, so that every schedule orders the two)
+                r.w[W_C0] = gcv_constants(*gc);
+                r.w[W_C1] = gc->stat;
+                r.w[W_OUT] = P.marg_off[v];
+                lm_last = std::max(lm_last, LM);
+                continue;
+            }
             const int d = P.dim[v];
             std::vector<std::pair<int, int>> ins;
             int hub_lv = 0;
@@ -1073,7 +1170,7 @@ struct Compiler {
         std::vector<int> ent_coef(nv, 0);
         std::vector<std::vector<int>> prec_stats(nv), prec_weight(nv);
         std::vector<int> prec_nodes(nv, 0);
-        long long stat_o = 0;
+        long long stat_o = (long long)gcvs.size();   // (ψ of every GCV node first: allocate())
         auto new_term = [&]() { terms.push_back((int)P.term_slots); return (int)P.term_slots++; };
         auto msg_in = [&](OpRec& r, int word, int bit, int m) {
             if (null_[m]) { r.w[word] = -1; return; }
@@ -1086,7 +1183,7 @@ struct Compiler {
             const int a = (int)iface((int)f, 0), b = (int)iface((int)f, 1), c = (int)iface((int)f, 2);
             if (nclass[f] == NC_NOISE) {
                 const int d = P.dim[a];
-                const bool ga = P.vclass[a] == VC_GAUSS, gb = P.vclass[b] == VC_GAUSS, rw = P.vclass[c] == VC_PREC;
+                const bool ga = P.vclass[a] == VC_GAUSS, gb = P.vclass[b] == VC_GAUSS, rw = P.vclass[c] == VC_PREC || gcv_of[f] >= 0;
                 OpRec& r = emit(LF, ga && gb ? OP_FE_NOISE2 : (ga || gb) ? OP_FE_NOISE1 : OP_FE_NOISE0, d);
                 noise_params(r, (int)f, d);
                 if (mf[f]) {   // q(out) q(μ): the average energy from the two marginals; the clusters' entropies go with the variables' terms
@@ -1099,11 +1196,21 @@ struct Compiler {
                     // the joint from ONE inbound message and the two marginals (tree_kernels.hpp / tree_wave_kernels.hpp OP_FE_NOISE2M); side a = the interface
                     // whose message to the node is stored in precision form (no conversion), the out side when both are
                     const int m0 = E + fac_edges[f][0], m1 = E + fac_edges[f][1];
-                    const bool use1 = !null_[m1] && form[m1] && (null_[m0] || !form[m0]);
+                    bool use1 = !null_[m1] && form[m1] && (null_[m0] || !form[m0]);
+                    if (gcv_z[a] || gcv_z[b]) {   // the marginal of a GCV node's volatility input is not the product of its Gaussian messages: it takes side a, mean from the joint
+                        use1 = gcv_z[b] && !gcv_z[a];
+                        if (null_[use1 ? m1 : m0]) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: no message from the volatility input", (long long)f);
+                        r.w[W_FLAGS] |= F_JOINT_MEAN;
+                        if (gcv_z[a] && gcv_z[b]) {   // a transition between two volatility states: side b from its message as well
+                            if (null_[m1]) fail(RXHIP_ERR_UNSUPPORTED, "factor %lld: no message from the volatility input", (long long)f);
+                            r.w[W_FLAGS] |= F_JOINT_B;
+                        }
+                    }
                     r.w[W_OP] = OP_FE_NOISE2M;
                     msg_in(r, W_IN0, F_IN0_WP, use1 ? m1 : m0);
                     marg_of(r, use1 ? b : a, W_VAL, F_PUSH_A, W_IN1, W_LIST, -1);
                     marg_of(r, use1 ? a : b, W_VAL2, F_PUSH_B, W_IN2, W_N, W_D1);
+                    if (r.w[W_FLAGS] & F_JOINT_B) msg_in(r, W_IN1, F_IN1_WP, m1);   // (side a is interface 0 here; neither side is an image)
                     r.w[W_OUT] = 0;
                     if (push_from[use1 ? a : b] >= 0) fold.push_back({recs.size() - 1, use1 ? a : b});
                 } else if (ga || gb) {
@@ -1122,8 +1229,11 @@ struct Compiler {
                 if (rw) {
                     r.w[W_FLAGS] |= F_STAT;
                     r.w[W_C1] = (int)stat_o;
-                    prec_stats[c].push_back((int)stat_o);
-                    prec_weight[c].push_back(wz[f] >= 0 ? P.prec_off[wz[f]] + wk[f] : -1);
+                    if (gcv_of[f] >= 0) { r.w[W_C1] = gcvs[gcv_of[f]].stat; stat_o -= d * d; }   // (its own slot, shared with the sweep's message op)
+                    else {
+                        prec_stats[c].push_back((int)stat_o);
+                        prec_weight[c].push_back(wz[f] >= 0 ? P.prec_off[wz[f]] + wk[f] : -1);
+                    }
                     stat_o += d * d;
                 }
             } else if (nclass[f] == NC_MUL) {
@@ -1139,6 +1249,7 @@ struct Compiler {
                 } else ent_coef[g1 ? b : c] -= 1;
             }
         }
+        for (const Gcv& gc : gcvs) ent_coef[gc.z] -= 1;   // the node's second cluster: −H[q(z)]
         for (auto& fo : fold)   // the entropy term of an image variable goes to the first op that computes its log-determinant anyway
             if (ent_coef[fo.second] != 0) {
                 recs[fo.first].w[W_FLAGS] |= F_FOLD_ENT;
@@ -1177,6 +1288,14 @@ struct Compiler {
                 P.aux.push_back(prec_stats[v][q]);
                 if (weighted) P.aux.push_back(prec_weight[v][q]);
             }
+            r.w[W_TERM] = new_term();
+        }
+        for (const Gcv& gc : gcvs) {   // γ(z) under the new q(z), the GCV average energy
+            OpRec& r = emit(LP, OP_GCV_PREC, 1);
+            r.w[W_PREC] = gc.state;
+            r.w[W_C0] = gcv_constants(gc);
+            r.w[W_IN0] = P.marg_off[gc.z];
+            r.w[W_C1] = gc.stat;
             r.w[W_TERM] = new_term();
         }
         // q(s) of every probability vector with its switches' terms: −Σ_i Σ_k π_ik E log s_k (new q(s)), −Σ_i H[q(z_i)], the Dirichlet prior node U − H[q(s)];
@@ -1248,6 +1367,49 @@ struct Compiler {
         }
         return logp_off[v];
     }
+    std::vector<int> gcv_coff;
+    int gcv_constants(const Gcv& gc) {
+        const int gi = (int)(&gc - gcvs.data());
+        if (gcv_coff.empty()) gcv_coff.assign(gcvs.size(), -1);
+        if (gcv_coff[gi] >= 0) return gcv_coff[gi];
+        int n = g->gh_points > 0 ? (int)g->gh_points : 31;
+        if (n > 64) fail(RXHIP_ERR_UNSUPPORTED, "Gauss–Hermite cubature with more than 64 points");
+        // Gauss–Hermite nodes and weights: Newton iteration on the orthonormal recurrence (as the HGF engine's table, csrc/rxhip.hip)
+        std::vector<double> x((size_t)n), w((size_t)n);
+        const double PIM4 = 0.7511255444649425;
+        const int m = (n + 1) / 2;
+        double z = 0.0, pp = 0.0;
+        for (int i = 0; i < m; ++i) {
+            if (i == 0) z = std::sqrt((double)(2 * n + 1)) - 1.85575 * std::pow((double)(2 * n + 1), -0.16667);
+            else if (i == 1) z -= 1.14 * std::pow((double)n, 0.426) / z;
+            else if (i == 2) z = 1.86 * z - 0.86 * x[0];
+            else if (i == 3) z = 1.91 * z - 0.91 * x[1];
+            else z = 2.0 * z - x[(size_t)i - 2];
+            for (int its = 0; its < 100; ++its) {
+                double p1 = PIM4, p2 = 0.0;
+                for (int j = 0; j < n; ++j) {
+                    const double p3 = p2;
+                    p2 = p1;
+                    p1 = z * std::sqrt(2.0 / (j + 1)) * p2 - std::sqrt((double)j / (j + 1)) * p3;
+                }
+                pp = std::sqrt(2.0 * n) * p2;
+                const double z1 = z;
+                z = z1 - p1 / pp;
+                if (std::fabs(z - z1) <= 1e-15 * (1.0 + std::fabs(z))) break;
+            }
+            x[(size_t)i] = z;
+            x[(size_t)(n - 1 - i)] = -z;
+            w[(size_t)i] = 2.0 / (pp * pp);
+            w[(size_t)(n - 1 - i)] = w[(size_t)i];
+        }
+        gcv_coff[gi] = (int)P.cpool.size();
+        P.cpool.push_back(cptr(gc.kv)[0]);
+        P.cpool.push_back(cptr(gc.ov)[0]);
+        P.cpool.push_back((double)n);
+        P.cpool.insert(P.cpool.end(), x.begin(), x.end());
+        for (double wi : w) P.cpool.push_back(wi / 1.7724538509055160273);
+        return gcv_coff[gi];
+    }
     void weigh(OpRec& r, int f) {   // a component of a mixture node: the op scales its message / energy / residual moments by π_k = q(z = k)
         if (wz[f] < 0) return;
         r.w[W_FLAGS] |= F_WEIGHT;
@@ -1270,18 +1432,21 @@ struct Compiler {
 
     // the messages an op reads: (kind 0: descriptor word idx | kind 1: list entry idx, offset, dimension)
     struct In { int kind, idx, off, d; };
-    static bool produces_msg(int op) { return op == OP_LEAF || op == OP_NOISE || op == OP_MUL_OUT || op == OP_MUL_IN || op == OP_ADD_OUT || op == OP_ADD_IN || op == OP_SHIFT || op == OP_PRODUCT; }
+    static bool produces_msg(int op) { return op == OP_LEAF || op == OP_NOISE || op == OP_MUL_OUT || op == OP_MUL_IN || op == OP_ADD_OUT || op == OP_ADD_IN || op == OP_SHIFT || op == OP_PRODUCT || op == OP_GCV_Z; }
     std::vector<In> op_inputs(const int* w) const {
         std::vector<In> v;
         switch (w[W_OP]) {
         case OP_NOISE: case OP_SHIFT: case OP_MUL_IN: v.push_back({0, W_IN0, w[W_IN0], w[W_D0]}); break;
         case OP_MUL_OUT: v.push_back({0, W_IN0, w[W_IN0], w[W_D1]}); break;
+        case OP_GCV_Z: for (int k : {W_IN0, W_IN1}) v.push_back({0, k, w[k], 1}); break;
+        case OP_GCV_ZMARG: v.push_back({0, W_IN0, w[W_IN0], 1}); v.push_back({0, W_IN1, w[W_IN1], 1}); break;
         case OP_ADD_OUT: case OP_ADD_IN: v.push_back({0, W_IN0, w[W_IN0], w[W_D0]}); v.push_back({0, W_IN1, w[W_IN1], w[W_D0]}); break;
         case OP_PRODUCT: case OP_MARGINAL:
             for (int q = 0; q < w[W_N]; ++q) v.push_back({1, q, P.aux[(size_t)w[W_LIST] + 2 * q], w[W_D0]});
             break;
         case OP_FE_NOISE2M:
             if (w[W_IN0] >= 0) v.push_back({0, W_IN0, w[W_IN0], w[W_D0]});
+            if ((w[W_FLAGS] & F_JOINT_B) && w[W_IN1] >= 0) v.push_back({0, W_IN1, w[W_IN1], w[W_D0]});
             break;
         case OP_FE_NOISE2: case OP_FE_ADD2:
             for (int k : {W_IN0, W_IN1, W_IN2})
@@ -1364,7 +1529,7 @@ struct Compiler {
         for (int64_t v = 0; v < nv; ++v) P.is_push[v] = push_from[v] >= 0;
         std::stable_sort(recs.begin(), recs.end(), [](const OpRec& a, const OpRec& b) { return a.level != b.level ? a.level < b.level : a.w[W_OP] < b.w[W_OP]; });
         P.n_ops = (int)recs.size();
-        for (const OpRec& r : recs) P.fe_heavy = P.fe_heavy || r.w[W_OP] == OP_FE_ADD2 || r.w[W_OP] == OP_PREC_UPDATE || r.w[W_OP] == OP_DIR_UPDATE;
+        for (const OpRec& r : recs) P.fe_heavy = P.fe_heavy || r.w[W_OP] == OP_FE_ADD2 || r.w[W_OP] == OP_PREC_UPDATE || r.w[W_OP] == OP_DIR_UPDATE || r.w[W_OP] == OP_GCV_PREC;
         P.ops.resize((size_t)P.n_ops * OP_WORDS);
         int nl = recs.empty() ? 0 : recs.back().level + 1;
         P.lvl_ptr.assign(nl + 1, 0);
@@ -1394,6 +1559,10 @@ struct Compiler {
                 if (!det_out[v]) ++P.marginals;
                 for (int e : var_edges[v]) if (!null_[e] && !dem[e]) { dem[e] = 1; st.push_back(e); }
             }
+        for (const Gcv& gc : gcvs) {   // q(z) of a GCV node's volatility input is matched against the product of all its other messages
+            const int m = E + fac_edges[gc.fz][0];
+            if (!null_[m] && !dem[m]) { dem[m] = 1; st.push_back(m); }
+        }
         while (!st.empty()) {
             const int m = st.back(); st.pop_back();
             for (int dpm : deps[m]) if (!null_[dpm] && !dem[dpm]) { dem[dpm] = 1; st.push_back(dpm); }
@@ -1798,7 +1967,7 @@ rxhip_status create(const rxhip_graph_desc* g, int device, void* stream, Engine*
     // once the replicas fill the device (4 096: 3.4 against 5.4 ms; 65 536: 16 against 83): profiles/r06/tree_tile.txt
     e->tiled = P.dmax > 8 || (P.dmax > 4 && e->R <= 1024);
     if (const char* t = hook_env("RXHIP_TREE_TILE")) e->tiled = P.dmax > 8 || (P.dmax > 4 && std::atoi(t) != 0);
-    if (P.has_mix || P.has_valnoise) e->tiled = false;   // (the mixture ops exist in the lane-per-item kernels only; the compiler refused dimensions above 8)
+    if (P.has_mix || P.has_valnoise || P.has_gcv) e->tiled = false;   // (the mixture ops exist in the lane-per-item kernels only; the compiler refused dimensions above 8)
     e->elem_fast = e->tiled;
     e->allow_missing = g->allow_missing != 0;
     // schedule: deep graphs walk their levels inside a workgroup (one launch per iteration); wide, shallow ones take a launch per level

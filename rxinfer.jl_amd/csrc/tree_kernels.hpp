@@ -44,6 +44,10 @@ enum : int {
     OP_CAT_UPDATE = 22,  // q(z) of a NormalMixture node's switch: π_k ∝ exp(E log s_k − ½[d log 2π − E log|p_k| + tr(E[p_k] E[(out − m_k)(out − m_k)ᵀ])]) from the marginals of the
                          // previous iteration (lane-per-item kernels; the node itself is K weighted Gaussian nodes: F_WEIGHT)
     OP_DIR_UPDATE = 23,  // q(s) = Dirichlet(a + Σ_i π_i) of a probability vector with the terms of its switches: −Σ π E log s, −H[q(z)], the prior node U − H[q(s)]
+    OP_GCV_Z = 24,       // GCV(y, x, z, κ, ω) toward z (scalars; q(y, x) q(z)): from the messages y → node, x → node and E[γ] the node-local joint and ψ = E[(y − x)²] (→ the slot W_C1); the
+                         // message z and its neighbours see = the Gaussian moments of ExponentialLinearQuadratic(κ, ψ e^{−ω}, −κ) (cubature against N(0, 1)) → W_OUT.  Constants at W_C0: κ | ω | n | nodes | weights/√π
+    OP_GCV_ZMARG = 26,   // … q(z): that ELQ times the product of all OTHER messages into z (W_IN0), moment-matched by cubature against the product; ψ from the slot OP_GCV_Z left it in
+    OP_GCV_PREC = 25,    // the node's precision γ(z) = exp(−(κ z + ω)) under the new q(z): E γ, 1 / E γ, E log γ into the state slot W_PREC; the GCV average energy ½[log 2π − E log γ + E γ ψ]
     OP_FE_NOISE_MF = 21  // average energy of a Gaussian node under q(out) q(μ) (mean field between its Gaussian interfaces): E[rrᵀ] = V_out + V_μ + (m_out − m_μ)(…)ᵀ
 };
 constexpr int OP_WORDS = 16;
@@ -64,6 +68,10 @@ enum : int {
     F_MAY_MISS = 16384,  // OP_LEAF / FE_NOISE1 / FE_NOISE0 on a DATA value of a graph created with allow_missing: NaN (`missing`) → no message / no energy term
     F_WEIGHT = 32768,    // OP_LEAF / FE_NOISE0 / FE_NOISE1 / FE_NOISE_MF: a component of a mixture node — message, energy and residual moments × π_k, the double at p.prec[W_LIST];
                          // OP_PREC_UPDATE: the list holds (moments, weight | −1) pairs, ν = ν0 + Σ weights
+    F_JOINT_MEAN = 65536,      // OP_FE_NOISE2M: the mean of side a from the node-local joint, P⁻¹(ξ_a + W m_b), not from the variable's marginal — side a is the volatility input of a
+                               // GCV node, whose marginal is a cubature-matched product and not the product of the Gaussian messages the joint is made of
+    F_JOINT_B = 524288,        // … and side b's moments as well (both interfaces are such inputs: a transition between two volatility states): W_IN1 names b's message,
+                               // S = Λ_b + W − W P⁻¹ W, V_b = S⁻¹, m_b = V_b (ξ_b + W P⁻¹ ξ_a)
     F_NOISE_VAL = 131072,      // a SCALAR Gaussian node whose variance (F_NOISE_VAL_PREC: precision) is a DATA variable — `x ~ Normal(mean = m_prev, var = v_prev)` of a streaming
                                // model's @autoupdates: the value slot W_C0 instead of a constant block (lane-per-item kernels)
     F_NOISE_VAL_PREC = 262144,
@@ -478,6 +486,71 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
         for (int i = 0; i < N; ++i) x[i] += y[i];
         st_vec<N>(p.val, w[W_OUT], d, p.RS, r, x);
     } break;
+    case OP_GCV_Z: {
+        double ay[N], By[N][N], ax[N], Bx[N][N];
+        ok = load_msg<N, STRAND>(p, w[W_IN0], fl & F_IN0_WP, true, 1, r, ay, By, reg);
+        ok = load_msg<N, STRAND>(p, w[W_IN1], fl & F_IN1_WP, true, 1, r, ax, Bx, reg) && ok;
+        const double* c = p.cpool + w[W_C0];
+        const double kappa = c[0], A = exp(-c[1]);
+        const int n = (int)c[2];
+        const double *gx = c + 3, *gw = c + 3 + n;
+        const double gam = p.prec[(long long)(w[W_PREC] + 2) * p.RS + r];
+        // @marginalrule GCV(:y_x): joint precision [[Λy + γ, −γ], [−γ, Λx + γ]]
+        const double l11 = By[0][0] + gam, l22 = Bx[0][0] + gam, det = l11 * l22 - gam * gam;
+        ok = ok && det > 0.0;
+        const double v11 = l22 / det, v22 = l11 / det, v12 = gam / det;
+        const double m1 = v11 * ay[0] + v12 * ax[0], m2 = v12 * ay[0] + v22 * ax[0];
+        const double psi = (m1 - m2) * (m1 - m2) + v11 + v22 - 2.0 * v12, b = psi * A;
+        p.stat[(long long)w[W_C1] * p.RS + r] = psi;   // (OP_GCV_ZMARG and OP_GCV_PREC read it; the node's joint term writes the same number again)
+        double en = 0.0, em = 0.0, ev = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double ep = 1.4142135623730951 * gx[i], ec = gw[i] * exp(-0.5 * (kappa * ep + b * exp(-kappa * ep)) + 0.5 * ep * ep);
+            em += ep * ec;
+            en += ec;
+        }
+        em /= en;
+        for (int i = 0; i < n; ++i) {
+            const double ep = 1.4142135623730951 * gx[i], ec = gw[i] * exp(-0.5 * (kappa * ep + b * exp(-kappa * ep)) + 0.5 * ep * ep);
+            ev += ec * (ep - em) * (ep - em);
+        }
+        ev /= en;
+        ok = ok && ev > 0.0 && ev < 1.0e300;
+        double mo[N], Vo[N][N];
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            mo[i] = 0.0;
+#pragma unroll
+            for (int j = 0; j < N; ++j) Vo[i][j] = i == j ? 1.0 : 0.0;
+        }
+        mo[0] = em;
+        Vo[0][0] = ev;
+        store_msg<N, STRAND>(p, w[W_OUT], 1, r, mo, Vo, fl, reg);
+    } break;
+    case OP_GCV_ZMARG: {   // q(z) ∝ ELQ(z) · (the product of all OTHER messages into z, W_IN0): first two moments by cubature against that product
+        double az[N], Bz[N][N];
+        ok = load_msg<N, STRAND>(p, w[W_IN0], fl & F_IN0_WP, false, 1, r, az, Bz, reg);
+        const double* c = p.cpool + w[W_C0];
+        const double kappa = c[0], b = p.stat[(long long)w[W_C1] * p.RS + r] * exp(-c[1]);
+        const int n = (int)c[2];
+        const double *gx = c + 3, *gw = c + 3 + n;
+        const double zm = az[0], sc = sqrt(2.0 * Bz[0][0]);
+        double nrm = 0.0, mean = 0.0, var = 0.0;
+        for (int i = 0; i < n; ++i) {
+            const double pt = zm + sc * gx[i], cv = gw[i] * exp(-0.5 * (kappa * pt + b * exp(-kappa * pt)));
+            mean += pt * cv;
+            nrm += cv;
+        }
+        mean /= nrm;
+        for (int i = 0; i < n; ++i) {
+            const double pt = zm + sc * gx[i], cv = gw[i] * exp(-0.5 * (kappa * pt + b * exp(-kappa * pt)));
+            var += cv * (pt - mean) * (pt - mean);
+        }
+        var /= nrm;
+        ok = ok && var > 0.0 && var < 1.0e300;
+        p.marg[(long long)w[W_OUT] * p.RS + r] = mean;
+        p.marg[(long long)(w[W_OUT] + 1) * p.RS + r] = var;
+        p.marg[(long long)(w[W_OUT] + 2) * p.RS + r] = log(var);
+    } break;
     case OP_CAT_UPDATE: {   // q(z): W_OUT π[K] (precision-state array), W_VAL `out` (value, or F_VAL_MARG: its marginal), W_IN0 q(s) state α | E log s (−1: log p at W_C0),
                             // list: per component (marginal of m_k | −1 − constant value, state of p_k | −1 − constant noise block)
         const int K = w[W_N];
@@ -823,6 +896,36 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
         double ma[N], mb[N], Vb[N][N], ldVb, unused;
         load_marginal<N>(p, w[W_VAL], fl & F_PUSH_A, w[W_IN1], w[W_LIST], d, r, false, ma, Vb, unused);
         load_marginal<N>(p, w[W_VAL2], fl & F_PUSH_B, w[W_IN2], w[W_N], d, r, true, mb, Vb, ldVb, (fl & F_PUSH_B) ? w[W_D1] : -1);
+        if (fl & F_JOINT_B) {
+            double xb[N], Lb[N][N], T1[N][N], T3[N][N], S[N][N], Si[N][N], t[N], u[N], ldS;
+            ok = load_msg<N>(p, w[W_IN1], fl & F_IN1_WP, true, d, r, xb, Lb) && ok;
+            matmul<N>(Pi, Wm, T1);
+            matmul<N>(Wm, T1, T3);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) S[i][j] = (i < d && j < d) ? Lb[i][j] + Wm[i][j] - T3[i][j] : (i == j ? 1.0 : 0.0);
+            ok = spd_inv<N>(S, Si, ldS) && ok;
+            matvec<N>(Pi, xa, t);
+            matvec<N>(Wm, t, u);
+#pragma unroll
+            for (int i = 0; i < N; ++i) u[i] = (i < d) ? u[i] + xb[i] : 0.0;
+            matvec<N>(Si, u, mb);
+#pragma unroll
+            for (int i = 0; i < N; ++i)
+#pragma unroll
+                for (int j = 0; j < N; ++j) Vb[i][j] = Si[i][j];
+            ldVb = -ldS;
+        }
+        if (fl & F_JOINT_MEAN) {
+            double t[N], u[N];
+            matvec<N>(Wm, mb, t);
+#pragma unroll
+            for (int i = 0; i < N; ++i) t[i] = (i < d) ? t[i] + ((w[W_IN0] >= 0) ? xa[i] : 0.0) : 0.0;
+            matvec<N>(Pi, t, u);
+#pragma unroll
+            for (int i = 0; i < N; ++i) ma[i] = u[i];
+        }
         double Dm[N][N], T2[N][N], E[N][N];
         matmul<N>(Pi, Wm, Dm);
 #pragma unroll
@@ -942,6 +1045,16 @@ __device__ __forceinline__ void eval_fe(const TreeParams& p, const int* __restri
             for (int j = 0; j < N; ++j) S[i][j] -= T2[i][j];
         ok = spd_inv<N>(S, Si, ldS) && ok;
         p.term[(long long)w[W_TERM] * p.RS + r] = -0.5 * (2.0 * d * (T_LOG2PI + 1.0) - (ldP + ldS));
+    } break;
+    case OP_GCV_PREC: if (!LIGHT) {   // W_IN0: the marginal slot of z; W_C1: ψ (the residual moment the node's joint term left); W_C0: κ | ω
+        const double* c = p.cpool + w[W_C0];
+        const double m = p.marg[(long long)w[W_IN0] * p.RS + r], v = p.marg[(long long)(w[W_IN0] + 1) * p.RS + r], psi = p.stat[(long long)w[W_C1] * p.RS + r];
+        const double eg = exp(-c[1] - c[0] * m + 0.5 * c[0] * c[0] * v), elg = -(c[0] * m + c[1]);
+        const int ps = w[W_PREC];
+        p.prec[(long long)(ps + 2) * p.RS + r] = eg;
+        p.prec[(long long)(ps + 3) * p.RS + r] = 1.0 / eg;
+        p.prec[(long long)(ps + 4) * p.RS + r] = elg;
+        p.term[(long long)w[W_TERM] * p.RS + r] = 0.5 * (T_LOG2PI - elg + eg * psi);
     } break;
     case OP_DIR_UPDATE: if (!LIGHT) {   // W_N K, list: the π slots of W_VAL2 switches; W_PREC the state α | E log s with the prior's concentrations at W_C0 (−1: constant log p at W_C0)
         const int K = w[W_N], nz = w[W_VAL2], ps = w[W_PREC];

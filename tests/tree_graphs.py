@@ -589,3 +589,25 @@ def mixture_on_tree(N=10, K=2, d=2, seed=11, latent_out=False, const_switch=Fals
             gb.node(_lib.NODE_NORMAL_MIXTURE, y, z, *m, *w)
         ys.append(y); zs.append(z)
     return gb, ys, dict(m=m, W=[] if const_precision else w, x=xs, z=zs, s=s)
+
+
+def volatility_chain(T=5, seed=13, kappa=0.8, omega=-0.5):
+    """A hierarchical Gaussian filter unrolled in time (test/models/statespace/hgf_tests.jl:9-31 is one step of it): a volatility chain z[t] ~ N(z[t−1], σz²) on
+    top of a value chain x[t] ~ GCV(x[t−1], z[t], κ, ω) observed through y[t] ~ N(x[t], σy²); q(x[t], x[t−1]) q(z[t]) at the GCV nodes, `@initialization` on every z[t]."""
+    rng = np.random.default_rng(seed)
+    gb = GraphBuilder()
+    z, x = gb.randomvar(1), gb.randomvar(1)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, z, gb.constvar(0.2), gb.constvar(1.5))
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, x, gb.constvar(-0.3), gb.constvar(2.0))
+    kv, ov = gb.constvar(kappa), gb.constvar(omega)
+    ys, zs, xs = [], [], []
+    for t in range(T):
+        zn, xn, y = gb.randomvar(1), gb.randomvar(1), gb.datavar(1)
+        gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, zn, z, gb.constvar(0.1 + 0.1 * rng.random()))
+        gb.node(_lib.NODE_GCV, xn, x, zn, kv, ov)
+        gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y, xn, gb.constvar(0.05 + 0.1 * rng.random()))
+        gb.initialize(zn, _lib.INIT_NORMAL, (0.1 * rng.standard_normal(), 1.0 + rng.random()))
+        z, x = zn, xn
+        ys.append(y); zs.append(zn); xs.append(xn)
+    gb.gh_points = 31
+    return gb, ys, dict(z=zs, x=xs)
