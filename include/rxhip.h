@@ -411,6 +411,11 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  *         `out` data or a Gaussian variable, the means Gaussian variables of the forest, the precisions Wishart / Gamma variables or constants.  The node acts on
  *         (out, m[k], p[k]) as K Gaussian precision nodes weighted by q(switch = k); q(switch) is formed from the marginals of the previous iteration before
  *         the sweep, q(s) behind it (the schedule of the mixture engines; `@initialization` marginals on m, p, s — and `out` — as in the reference)
+ *     GCV (y, x, z, κ, ω) under q(y, x) q(z), κ and ω constants, everything scalar (round 6; test/models/statespace/hgf_tests.jl:28-35): toward (y, x) a Gaussian node
+ *         whose precision exp(−(κ z + ω)) is taken under q(z) of the previous iteration (`@initialization` on z required); toward z the ExponentialLinearQuadratic
+ *         message — q(z) is its product with all other messages into z, moment-matched by Gauss–Hermite cubature (rxhip_graph_desc.gh_points, default 31) against
+ *         that product, and z's neighbours (structured Gaussian nodes only) see the message through its Gaussian moments, as the reference does;
+ *     scalar Gaussian nodes whose variance / precision is a DATA variable (`x ~ Normal(mean = m_prev, var = v_prev)` of a model driven by @autoupdates)
  * whose Gaussian variables form a forest (no cycles; precision variables may touch any number of nodes — the mean-field factorisation cuts those
  * loops; no Gaussian variable at all is a forest too: `P ~ Wishart; y[i] ~ MvNormal(μ = m, Λ = P)` with a known mean,
  * test/models/iid/mv_iid_precision_known_mean_tests.jl), every dimension ≤ 64.  Factorisation (rxhip_graph_desc.factor_cluster): a Gaussian node under

@@ -86,3 +86,28 @@ def test_a_volatility_layer_on_top_of_a_gaussian_chain(mode, monkeypatch):
             eng.set_data(ys, data)
             eng.run(its, True)
             _check(gb, ys, eng, data, iterations=its, replicas=(0, R - 1), tol=1e-9, tol_fe=1e-9)
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_data_valued_variances_and_precisions(mode, monkeypatch):
+    """scalar Gaussian nodes whose variance (`Normal(mean = m_prev, var = v_prev)`) or precision arrives with the data — the prior nodes of an @autoupdates model —
+    a different value in every replica"""
+    from rxhip import _lib, graph
+    from rxhip.tree import TreeEngine
+    gb = graph.GraphBuilder()
+    xp, x, w = gb.randomvar(1), gb.randomvar(1), gb.randomvar(1)
+    m, v, y, tau, y2 = gb.datavar(1), gb.datavar(1), gb.datavar(1), gb.datavar(1), gb.datavar(1)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, xp, m, v)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, x, xp, gb.constvar(0.3))
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y, x, gb.constvar(0.5))
+    gb.node(_lib.NODE_NORMAL_MEAN_PRECISION, w, x, tau)
+    gb.node(_lib.NODE_NORMAL_MEAN_VARIANCE, y2, w, gb.constvar(0.2))
+    ys = [m, v, y, tau, y2]
+    R = 6
+    rng = np.random.default_rng(1)
+    data = np.stack([[rng.normal(), 0.5 + rng.random(), rng.normal(), 0.5 + 2.0 * rng.random(), rng.normal()] for _ in range(R)])
+    monkeypatch.setenv("RXHIP_TREE_MODE", str(mode))
+    with TreeEngine(gb, n_replicas=R) as eng:
+        eng.set_data(ys, data)
+        eng.run(1, True)
+        _check(gb, ys, eng, data, replicas=(0, 3, R - 1), tol=1e-10, tol_fe=1e-10)
