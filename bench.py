@@ -557,6 +557,41 @@ def extra_node_array(device, parity=True):
         out["mixture_layer"] = line
     except Exception as e:   # (an extra: never the headline's problem)
         out["mixture_layer"] = {"error": repr(e)[:300]}
+    # GCV as an executor op: the reference's HGF step graph (test/models/statespace/hgf_tests.jl:9-31: data-valued prior means and variances, GCV under q(y, x) q(z), 31-point
+    # cubature) as an ONLINE filter — 4096 independent series, one observation per call, rxhip_tree_continue keeps the node's precision state, the posteriors are fed back
+    # as the next priors ON THE HOST (that round trip is in the wall time, not in the device time); 5 VMP iterations per observation; series 0 against the restatement
+    try:
+        from rxhip.graph import hgf_step_graph
+        kap, om, zv_, yv_, its, Th, Rh = 1.0, 0.0, 0.04, 0.01, 5, 20, 4096
+        yh = np.cumsum(np.random.default_rng(780).standard_normal((Th, Rh)), axis=0) * 0.3
+        gb, names = hgf_step_graph(kap, om, zv_, yv_, q_zt=(0.0, 5.0), q_xt=(0.0, 5.0), n_gh=31)
+        dvars = [v for v in range(len(gb.kind)) if gb.kind[v] == 1]
+        qz = np.tile([0.0, 5.0], (Rh, 1))
+        qx = np.tile([0.0, 5.0], (Rh, 1))
+        dev_ms, t0 = [], time.perf_counter()
+        with TreeEngine(gb, n_replicas=Rh, device=device) as eng:
+            eng.continue_runs(True)
+            for t in range(Th):
+                eng.set_data(dvars, np.column_stack([qz[:, 0], qz[:, 1], qx[:, 0], qx[:, 1], yh[t]]))
+                eng.run(its, True)
+                dev_ms.append(eng.last_iteration_ms() * its)
+                post = eng.marginals([names["zt"], names["xt"]])
+                qz = np.column_stack([post[names["zt"]][0][:, 0], post[names["zt"]][1][:, 0, 0]])
+                qx = np.column_stack([post[names["xt"]][0][:, 0], post[names["xt"]][1][:, 0, 0]])
+            info = eng.info
+        wall = (time.perf_counter() - t0) / Th
+        line = {"workload": f"GCV as an executor op: the HGF step graph as an online filter, {Rh} series, {its} VMP iterations per observation, {Th} observations",
+                "device_ms_per_step": float(np.median(dev_ms)), "wall_ms_per_observation": wall * 1e3, "observations_per_s": Rh / (float(np.median(dev_ms)) * 1e-3), "info": info}
+        if parity:
+            sys.path.insert(0, os.path.join(ROOT, "oracle"))
+            import rxoracle
+            zm, zvv, xm, xvv, _, _ = rxoracle.hgf_filter(np.ascontiguousarray(yh[:, 0]), kap, om, zv_, yv_, vmp_iters=its, n_gh=31)
+            em = max(abs(qz[0, 0] - zm[-1]) / np.sqrt(zvv[-1]), abs(qx[0, 0] - xm[-1]) / np.sqrt(xvv[-1]))
+            ev = max(abs(qz[0, 1] - zvv[-1]) / zvv[-1], abs(qx[0, 1] - xvv[-1]) / xvv[-1])
+            line["parity_spot"] = {"series": 0, "mean_rel": float(em), "cov_rel": float(ev), "ok": bool(em < 1e-6 and ev < 1e-6)}
+        out["hgf_online_filter"] = line
+    except Exception as e:
+        out["hgf_online_filter"] = {"error": repr(e)[:300]}
     return out
 
 
@@ -929,7 +964,7 @@ def compact_line(out):
                 add("executor_" + k2, w.get("device_ms_per_step"), rf.get("frac"), _spot(w.get("parity_spot")), rf.get("bound"), rule_calls_per_s=w.get("rule_calls_per_s"),
                     io_frac=rf.get("io_frac"), traffic=rf.get("traffic"), mode=i.get("mode"), dmax=i.get("dmax"), bytes_per_sweep=i.get("bytes_per_sweep"),
                     io_bytes_per_sweep=i.get("io_bytes_per_sweep"), specialised_engine_ms=w.get("specialised_engine_ms_per_step"), mfma_frac=rf.get("mfma_frac"),
-                    kernels=i.get("kernels"), points_per_s=w.get("points_per_s"))
+                    kernels=i.get("kernels"), points_per_s=w.get("points_per_s"), observations_per_s=w.get("observations_per_s"))
         else:
             ms = v.get("ms_per_step", v.get("ms_per_iteration"))
             add(name, ms, g(v, "roofline", "frac"), _spot(v.get("parity_spot")), **{k: w for k, w in v.items() if isinstance(w, (int, float, bool)) and k not in ("ms_per_step",)})
