@@ -349,7 +349,6 @@ struct Compiler {
         iptr.resize(nf + 1);
         for (int64_t f = 0; f <= nf; ++f) iptr[f] = g->factor_iface_ptr ? g->factor_iface_ptr[f] : 3 * f;
         ifv = g->factor_iface;
-        if (iptr[0] != 0) fail(RXHIP_ERR_BADARG, "factor_iface_ptr must start at 0");
         xtype.assign(g->factor_type, g->factor_type + nf);
         for (int64_t f = 0; f < nf; ++f)
             for (int k = 0; k < n_iface((int)f); ++k)

@@ -111,3 +111,15 @@ def test_data_valued_variances_and_precisions(mode, monkeypatch):
         eng.set_data(ys, data)
         eng.run(1, True)
         _check(gb, ys, eng, data, replicas=(0, 3, R - 1), tol=1e-10, tol_fe=1e-10)
+
+
+def test_rxhip_create_hands_generic_gcv_and_mixture_graphs_to_the_executor():
+    """the pattern matcher takes the flat HGF filter and the flat mixture models; a volatility chain unrolled in time and a mixture whose means share a Gaussian parent
+    reach the executor through the same rxhip_create"""
+    from rxhip.tree import TreeEngine
+    for gb, ys, its in ((tg.volatility_chain(T=4)[:2] + (2,)), (tg.mixture_on_tree(N=6, K=2, d=2)[:2] + (2,))):
+        data = tg.random_data(gb, ys, 2, 4)
+        with TreeEngine(gb, n_replicas=2, force_executor=False) as eng:
+            eng.set_data(ys, data)
+            eng.run(its, True)
+            _check(gb, ys, eng, data, iterations=its, replicas=(1,), tol=1e-9, tol_fe=1e-9)
