@@ -321,6 +321,7 @@ struct Compiler {
                 catK[sv] = 2;
             }
         }
+        if (!mixes.empty() && g->allow_missing) fail(RXHIP_ERR_UNSUPPORTED, "`missing` observations in a graph with NormalMixture nodes have no schedule here (allow_missing)");
         for (const Mix& mx : mixes) {
             if (P.vclass[mx.z] != VC_CAT) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (NormalMixture): the switch must be a random variable with a Categorical prior", mx.node);
             if (catK[mx.z] != 0) fail(RXHIP_ERR_UNSUPPORTED, "factor %d (NormalMixture): its switch drives another mixture node as well", mx.node);

@@ -138,10 +138,10 @@ class TreeEngine:
         return dict(rule_calls=r.value, products=p.value, marginals=m.value)
 
 
-def plan(gb, n_replicas=1):
+def plan(gb, n_replicas=1, allow_missing=False):
     """The graph compiler alone (rxhip_tree_plan; host only, no GPU needed): dict of the schedule's static figures plus the reference-equivalent counts of one
     replica and iteration (rule_calls, products, marginals).  Raises RxHipError exactly where TreeEngine(gb) would refuse the graph."""
-    g, keep = gb.tables(n_replicas=n_replicas)
+    g, keep = gb.tables(n_replicas=n_replicas, allow_missing=allow_missing)
     info = _lib.TreeInfo()
     rc, pr, mg = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64()
     L = _lib.lib()

@@ -85,6 +85,11 @@ def test_what_the_compiler_refuses():
     gb.node(_lib.NODE_BETA, s, gb.constvar(1.0), gb.constvar(1.0))
     gb.node(_lib.NODE_BERNOULLI, z, s)
     _refused(gb, _lib.ERR_BADARG, "components")   # a Bernoulli switch is the two-component spelling: this node has one
+    # `missing` observations under a mixture node
+    gb, ys, named = tg.mixture_on_tree(N=3, K=2, d=2)
+    with pytest.raises(rxhip.RxHipError) as ei:
+        plan(gb, allow_missing=True)
+    assert ei.value.status == _lib.ERR_UNSUPPORTED and "missing" in str(ei.value)
     # components of another dimension than `out`
     gb, ys, named = tg.mixture_on_tree(N=2, K=2, d=2)
     bad = graph.GraphBuilder.from_dump(gb.to_dump())
