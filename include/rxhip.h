@@ -423,7 +423,7 @@ rxhip_status rxhip_create(const rxhip_graph_desc* g, int32_t segments, int32_t d
  * MvNormalMeanCovariance(:out)(q_μ, q_Σ) = N(mean(q_μ), Σ), the node cuts the graph (cycles through it are fine), the marginals of its two variables are state
  * that starts from their `@initialization` marginals (RXHIP_INIT_NORMAL / MVNORMAL; an anonymous `A * x` output starts as the image of x's; none:
  * RXHIP_ERR_BADARG), every rule of an iteration reads the marginals of the previous one, and the free energy books the average energy with both marginals.
- * The host compiles the graph into ops sorted by dependency level (csrc/tree_engine.hip); kernels evaluate (op, replica) items.
+ * The host compiles the graph into ops sorted by dependency level (csrc/tree_compiler.hpp; the engine: csrc/tree_engine.hip); kernels evaluate (op, replica) items.
  * Dimensions ≤ 8: a LANE per item, matrices in registers (csrc/tree_kernels.hpp), replica-fastest storage; schedules — a launch per level, workgroup-resident
  * levels, a lane per replica over the whole schedule, and (dimensions ≤ 4: the default) STRANDS: the sweep cut into paths of dependent ops
  * that a lane walks with the message in registers, a message going to HBM only when somebody outside its strand reads it.  Marginals of `A * x` outputs are
