@@ -106,3 +106,49 @@ def test_hgf_dump_reproduces_the_reference_golden():
         eng.set_data(g["y"][:, None])
         eng.run(10, True)
         assert abs(eng.free_energy()[-1] - float(g["fe_reference_it10"])) < 1e-4   # hgf_tests.jl:118 asserts 0.01
+
+
+@pytest.mark.gpu
+def test_reference_mixture_dump_through_the_generic_executor_reproduces_the_golden():
+    """the multivariate mixture model as GraphPPL builds it (500 NormalMixture + 500 Categorical nodes, Dirichlet, Wishart and MvNormal priors) through rxhip_tree_create — a
+    node per data point on the node-array executor — on the reference's own data: the golden free energy of gmm_multivariate_tests.jl:141, and the mixture engine's"""
+    from rxhip.tree import TreeEngine
+    g = np.load(os.path.join(GOLD, "mvgmm_stablerng43.npz"))
+    gb = load("gmm_multivariate")
+    its = int(g["iterations"])
+    ys = [v for v in range(len(gb.kind)) if gb.kind[v] == 1]
+    with TreeEngine(gb, n_replicas=1) as eng:
+        eng.set_data(ys, np.asarray(g["y"], float).reshape(1, -1))
+        eng.run(its, True)
+        fe = eng.free_energy()
+    assert abs(fe[-1] - float(g["fe_reference_it25"])) < float(g["fe_atol"])
+    with graph.create_vmp_engine_from_graph(gb.tables()[0]) as ref:
+        ref.set_data(g["y"])
+        ref.run(its, True)
+        assert np.max(np.abs(fe - ref.free_energy()) / np.abs(fe)) < 1e-9   # every iteration
+
+
+@pytest.mark.gpu
+def test_reference_hgf_dump_through_the_generic_executor_reproduces_the_golden():
+    """the HGF one-step graph as GraphPPL builds it (GCV under q(y, x) q(z), priors whose mean and variance are data, @initialization, 31-point cubature) through
+    rxhip_tree_create as the streaming driver runs it — an observation per call, rxhip_tree_continue, the posteriors fed back by the @autoupdates — on the reference's own
+    series: the golden free energy of hgf_tests.jl:113-118 (the reference asserts it to 0.01)"""
+    from rxhip.tree import TreeEngine
+    g = np.load(os.path.join(GOLD, "hgf_stablerng42.npz"))
+    gb = load("hgf_step")
+    y = np.asarray(g["y"], float).ravel()
+    dv = [v for v in range(len(gb.kind)) if gb.kind[v] == 1]      # z_prev_mean, z_prev_var, x_prev_mean, x_prev_var, y (creation order)
+    d = gb.to_dump()
+    zt = next(i for i, v in enumerate(d["variables"]) if v.get("name") == "zt")
+    xt = next(i for i, v in enumerate(d["variables"]) if v.get("name") == "xt")
+    qz, qx, fes = (0.0, 5.0), (0.0, 5.0), []
+    with TreeEngine(gb, n_replicas=1) as eng:
+        eng.continue_runs(True)
+        for t in range(y.size):
+            eng.set_data(dv, np.array([[qz[0], qz[1], qx[0], qx[1], y[t]]]))
+            eng.run(10, True)
+            post = eng.marginals([zt, xt])
+            qz = (float(post[zt][0][0, 0]), float(post[zt][1][0, 0, 0]))
+            qx = (float(post[xt][0][0, 0]), float(post[xt][1][0, 0, 0]))
+            fes.append(eng.free_energy()[-1])
+    assert abs(np.mean(fes) - float(g["fe_reference_it10"])) < 1e-4
