@@ -152,3 +152,22 @@ def test_reference_hgf_dump_through_the_generic_executor_reproduces_the_golden()
             qx = (float(post[xt][0][0, 0]), float(post[xt][1][0, 0, 0]))
             fes.append(eng.free_energy()[-1])
     assert abs(np.mean(fes) - float(g["fe_reference_it10"])) < 1e-4
+
+
+@pytest.mark.gpu
+def test_reference_univariate_mixture_dump_through_the_generic_executor():
+    """gmm_univariate_tests.jl:7-26 as GraphPPL builds it (Beta / Bernoulli switch, Gamma precisions, NormalMeanVariance priors) through rxhip_tree_create against the
+    restatement the mixture engine is held to"""
+    from rxhip.tree import TreeEngine
+    rng = np.random.default_rng(5)
+    z = rng.random(150) < 1 / 3
+    y = np.where(z, -10 + rng.standard_normal(150) / np.sqrt(3.777), 10 + rng.standard_normal(150) / np.sqrt(0.333))
+    gb = load("gmm_univariate")
+    ys = [v for v in range(len(gb.kind)) if gb.kind[v] == 1]
+    with TreeEngine(gb, n_replicas=1) as eng:
+        eng.set_data(ys, y[None, :])
+        eng.run(10, True)
+        fe = eng.free_energy()
+    _, ofe, _, _ = rxoracle.gmm_vmp(y, [-2.0, 2.0], [1e3, 1e3], [0.01, 0.01], [0.01, 0.01], [1.0, 1.0], [-2.0, 2.0], [1e3, 1e3],
+                                    [1.0, 1.0], [1e-12, 1e-12], [1.0, 1.0], 10)
+    assert np.max(np.abs(fe - ofe) / np.abs(ofe)) < 1e-8
