@@ -62,6 +62,22 @@ def _sym(M):
     return 0.5 * (M + M.T)
 
 
+class ImproperMessage(ValueError):
+    """A rule asked for the other form of a message whose matrix is singular (a rank-deficient precision wanted as a covariance: the reference's `mean_cov` of a
+    MvNormalWeightedMeanPrecision throws a PosDefException there).  numpy.linalg.inv returns numbers of size 1e16 for such a matrix more often than it raises;
+    the check is the residual of the computed inverse."""
+
+
+def _inverse(B):
+    try:
+        X = np.linalg.inv(B)
+    except np.linalg.LinAlgError as e:
+        raise ImproperMessage(str(e))
+    if not np.all(np.isfinite(X)) or np.max(np.abs(B @ X - np.eye(B.shape[0]))) > 1e-3:
+        raise ImproperMessage("a message's matrix is singular to working precision")
+    return X
+
+
 class Msg:
     """A Gaussian message in moment form (m, V) or weighted-mean / precision form (xi, L)."""
 
@@ -71,13 +87,13 @@ class Msg:
     def mv(self):
         if self.form == "mv":
             return self.a, self.B
-        V = np.linalg.inv(self.B)
+        V = _inverse(self.B)
         return V @ self.a, _sym(V)
 
     def wp(self):
         if self.form == "wp":
             return self.a, self.B
-        L = np.linalg.inv(self.B)
+        L = _inverse(self.B)
         return L @ self.a, _sym(L)
 
 
@@ -469,7 +485,7 @@ def infer(dump, data, iterations=1, free_energy=True):
             return res
 
         # ---- marginals ----
-        mean, cov, qinfo = {}, {}, {}
+        mean, cov = {}, {}
         for v in [v for v in range(nv) if v not in det_outs] + [v for v in range(nv) if v in det_outs]:
             if not g.gauss[v]:
                 continue
@@ -477,13 +493,16 @@ def infer(dump, data, iterations=1, free_energy=True):
             ins = [m for m in (msg_f2v(fi, k) for fi, k in g.nbrs[v]) if m is not None]
             if not ins:
                 raise ValueError(f"variable {v} receives no message")
-            xi, L = ins[0].wp()
-            xi, L = xi.copy(), L.copy()
-            for m in ins[1:]:
-                x2, L2 = m.wp()
-                xi, L = xi + x2, L + L2
-            V = _sym(np.linalg.inv(L))
-            mean[v], cov[v] = V @ xi, V
+            if len(ins) == 1:   # one message: the marginal is that message as it stands (no round trip of a covariance through its inverse)
+                mean[v], cov[v] = (np.array(a, float) for a in ins[0].mv())
+            else:
+                xi, L = ins[0].wp()
+                xi, L = xi.copy(), L.copy()
+                for m in ins[1:]:
+                    x2, L2 = m.wp()
+                    xi, L = xi + x2, L + L2
+                V = _sym(_inverse(L))
+                mean[v], cov[v] = V @ xi, V
             if v in gcv_elq:   # the volatility input of a GCV node: the ELQ message times the product of ALL other messages, moment-matched by cubature against that product
                 a_, b_, c_, fz = gcv_elq[v]
                 fwd = msg_v2f(v, fz, 0)
@@ -494,7 +513,6 @@ def infer(dump, data, iterations=1, free_energy=True):
                 cs = gh_w * np.exp(-0.5 * (a_ * pts + b_ * np.exp(c_ * pts)))
                 qm = float(np.sum(pts * cs) / np.sum(cs))
                 mean[v], cov[v] = np.array([qm]), np.array([[float(np.sum(cs * (pts - qm) ** 2) / np.sum(cs))]])
-            qinfo[v] = (xi, L)
             counters["marginals"] += counters["on"] and v not in det_outs
         counters["on"] = False
 

@@ -104,6 +104,7 @@ struct TreeParams {
 };
 
 constexpr double T_LOG2PI = 1.8378770664093454836;
+constexpr double T_ABSENT_VARIANCE = 1.0e200;   // the moment form of "no message" (load_msg)
 constexpr double T_LOG2 = 0.69314718055994530942;
 
 template <int N>
@@ -310,6 +311,22 @@ __device__ __forceinline__ bool load_msg(const TreeParams& p, int off, bool stor
         ld_sym<N>(p.msg, off + d, d, p.RS, r, 1.0, B);
     }
     if (stored_wp == want_wp) return true;
+    if (stored_wp) {
+        // The ZERO of the precision form — a `missing` observation, through whatever maps and shifts it went — has no moment form.  A rule that wants moments
+        // (`*`(:out), `+`(:out)) gets a covariance so wide that what it passes on is nothing to fifteen digits beyond the exponent (the oracle drops the message).
+        bool zero = true;
+#pragma unroll
+        for (int i = 0; i < N; ++i) zero = zero && (i >= d || B[i][i] == 0.0);
+        if (zero) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                a[i] = 0.0;
+#pragma unroll
+                for (int j = 0; j < N; ++j) B[i][j] = i == j ? (i < d ? T_ABSENT_VARIANCE : 1.0) : 0.0;
+            }
+            return true;
+        }
+    }
     double Bi[N][N], t[N], ld;
     const bool ok = spd_inv<N>(B, Bi, ld);
     matvec<N>(Bi, a, t);
@@ -759,9 +776,12 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
         }
         const int n = w[W_N];
         const int* lst = p.aux + w[W_LIST];
+        // a marginal of ONE message in moment form IS the message: taken through the precision and back, the two inversions would square the condition
+        // number in the error (the unobserved end of a `*` / `+` chain); the inversion below then only supplies log|V|
+        const bool single = op == OP_MARGINAL && n == 1 && lst[1] == 0;
         for (int q = 0; q < n; ++q) {   // left to right, in factor order (MessagesProductFromLeftToRight)
             double a[N], B[N][N];
-            ok = load_msg<N, STRAND>(p, lst[2 * q], lst[2 * q + 1] != 0, true, d, r, a, B, reg) && ok;
+            ok = load_msg<N, STRAND>(p, lst[2 * q], lst[2 * q + 1] != 0, !single, d, r, a, B, reg) && ok;
 #pragma unroll
             for (int i = 0; i < N; ++i) {
                 xi[i] += a[i];
@@ -778,6 +798,10 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
             double V[N][N], m[N], ld;
             ok = spd_inv<N>(L, V, ld) && ok;
             matvec<N>(V, xi, m);
+            if (single) {
+                load_msg<N, STRAND>(p, lst[0], false, false, d, r, m, V, reg);
+                ld = -ld;
+            }
             st_vec<N>(p.marg, w[W_OUT], d, p.RS, r, m);
             st_sym<N>(p.marg, w[W_OUT] + d, d, p.RS, r, V);
             p.marg[(w[W_OUT] + d + d * (d + 1) / 2) * p.RS + r] = -ld;

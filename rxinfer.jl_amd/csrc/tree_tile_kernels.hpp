@@ -404,6 +404,19 @@ __device__ __forceinline__ bool load_msg(const Env<NT>& E, int off, bool stored_
     load_vec<NT, ES1>(E.L, b, E.p.es, d, v);
     load_sym<NT, ES1>(E.L, b + (long long)d * E.p.es, E.p.es, d, M);
     if (stored_wp == want_wp) return true;
+    if (stored_wp) {   // the zero of the precision form (a `missing` observation) wanted as moments: tree_kernels.hpp load_msg
+        bool nz = false;
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) nz = nz || ((E.L.q + 4 * r == E.L.il) && M.t[ti][ti][r] != 0.0);
+        if (!__any(nz)) {
+            zero<NT>(v);
+            zero<NT>(M);
+            add_diag<NT>(E.L, M, T_ABSENT_VARIANCE, d);
+            return true;
+        }
+    }
     double ld;
     const bool ok = spd_inv<NT>(E.L, E.s, M, d, ld);
     v = matvec_t<NT>(M, to_k<NT>(E.L, v));
@@ -612,8 +625,9 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
         zero<NT>(v0);
         const int n = w[W_N];
         const int* lst = E.p.aux + w[W_LIST];
+        const bool single = op == OP_MARGINAL && n == 1 && lst[1] == 0;   // (tree_kernels.hpp: the marginal of one moment-form message is the message)
         for (int q = 0; q < n; ++q) {   // left to right, in factor order
-            ok = load_msg<NT, ES1>(E, lst[2 * q], lst[2 * q + 1] != 0, true, d, v1, M1) && ok;
+            ok = load_msg<NT, ES1>(E, lst[2 * q], lst[2 * q + 1] != 0, !single, d, v1, M1) && ok;
             axpy<NT>(v0, 1.0, v1);
             axpy<NT>(M0, 1.0, M1);
         }
@@ -621,7 +635,11 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
         else {
             double ld;
             ok = spd_inv<NT>(L, E.s, M0, d, ld) && ok;
-            const Vec<NT> m = matvec_t<NT>(M0, to_k<NT>(L, v0));
+            Vec<NT> m = matvec_t<NT>(M0, to_k<NT>(L, v0));
+            if (single) {
+                load_msg<NT, ES1>(E, lst[0], false, false, d, m, M0);
+                ld = -ld;
+            }
             double* b = E.marg(w[W_OUT]);
             store_vec<NT, ES1>(L, b, es, d, m);
             store_sym<NT, ES1>(L, b + (long long)d * es, es, d, M0);

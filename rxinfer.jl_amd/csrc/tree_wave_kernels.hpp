@@ -220,6 +220,21 @@ __device__ __forceinline__ void add_vec(const Ctx& c, int dst, int src, int d, d
     for (int i = c.lane; i < d; i += WL) wlds[dst + i] += sign * wlds[src + i];
 }
 
+// The sweeps below treat rows and columns differently (row k ← +a_k·/p, column k ← −a_·k/p), so the computed inverse X is symmetric only up to rounding — and the
+// SKEW part of its error is of size cond·ε with no structure.  A reader that takes one triangle of X turns that skew part into a symmetric perturbation, and a
+// second inversion of (X + Λ) multiplies it by the condition number again: 7e-6 sd at cond 8e6, d = 48, where the mean (X + Xᵀ)/2 gives 4e-10 — as the
+// symmetric sweeps of the other two kernel families and LAPACK do (found by scripts/fuzz_executor.py, seed 3902; the model: scripts/sim_sweep_symmetry.py).
+__device__ __forceinline__ void symmetrise(const Ctx& c, int A, int d) {
+    const int LD = c.LD;
+    each(c, d, d, [&](int i, int j) {
+        if (i < j) {
+            const double m = 0.5 * (wlds[A + i * LD + j] + wlds[A + j * LD + i]);
+            wlds[A + i * LD + j] = m;
+            wlds[A + j * LD + i] = m;
+        }
+    });
+    w_sync();
+}
 // in place: A ← A⁻¹ of a symmetric positive definite d×d tile; log|A|; false: a pivot ≤ 0 or not finite.  Scratch: vectors 6 and 7
 __device__ __forceinline__ bool spd_inv_lds(const Ctx& c, int A, int d, double& logdet) {
     const int LD = c.LD, rk = c.v(6), ck = c.v(7);
@@ -244,6 +259,7 @@ __device__ __forceinline__ bool spd_inv_lds(const Ctx& c, int A, int d, double& 
         });
         w_sync();
     }
+    symmetrise(c, A, d);
     logdet = ld;
     return ok;
 }
@@ -319,6 +335,7 @@ __device__ __forceinline__ bool spd_inv_blk(const Ctx& c, int A, int d, double& 
         for (int q = 0; q < B; ++q)
             if (i0 + p < d && j0 + q < d) wlds[A + (i0 + p) * LD + j0 + q] = a[p][q];
     w_sync();
+    symmetrise(c, A, d);
     logdet = log(mant) + 0.69314718055994530942 * (double)expo;
     return ok;
 }
@@ -547,6 +564,7 @@ __device__ __forceinline__ bool spd_inv_blocked(const Ctx& c, int A, int d, doub
                 if (i < d && j < d) wlds[A + i * LD + j] = a[tl][tj][r];
             }
     w_sync();
+    symmetrise(c, A, d);
     logdet = ld;
     return ok;
 }
@@ -577,6 +595,18 @@ __device__ __forceinline__ bool load_msg(const Ctx& c, const TreeParams& p, int 
     l_sym<DC>(c, M, p.msg, off + d, d, p.es, r * p.rs_msg);
     w_sync();
     if (stored_wp == want_wp) return true;
+    if (stored_wp) {   // the zero of the precision form (a `missing` observation) wanted as moments: tree_kernels.hpp load_msg
+        double nz = 0.0;
+        for (int i = c.lane; i < d; i += WL) nz += wlds[M + i * c.LD + i] != 0.0 ? 1.0 : 0.0;
+        if (w_sum(nz, c.v(7)) == 0.0) {
+            for (int i = c.lane; i < d; i += WL) {
+                wlds[v + i] = 0.0;
+                wlds[M + i * c.LD + i] = T_ABSENT_VARIANCE;
+            }
+            w_sync();
+            return true;
+        }
+    }
     double ld;
     const bool ok = spd_inv<DC>(c, M, d, ld);
     const int t = c.v(5);
@@ -785,8 +815,9 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         w_sync();
         const int n = w[W_N];
         const int* lst = p.aux + w[W_LIST];
+        const bool single = op == OP_MARGINAL && n == 1 && lst[1] == 0;   // (tree_kernels.hpp: the marginal of one moment-form message is the message)
         for (int q = 0; q < n; ++q) {   // left to right, in factor order
-            ok = load_msg<DC>(c, p, lst[2 * q], lst[2 * q + 1] != 0, true, d, r, v1, M1) && ok;
+            ok = load_msg<DC>(c, p, lst[2 * q], lst[2 * q + 1] != 0, !single, d, r, v1, M1) && ok;
             add_vec(c, v0, v1, d, 1.0);
             add_mat(c, M0, M1, d, 1.0);
             w_sync();
@@ -796,7 +827,12 @@ __device__ __forceinline__ void eval_bp(const Ctx& c, const TreeParams& p, const
         } else {
             double ld;
             ok = spd_inv<DC>(c, M0, d, ld) && ok;
-            matvec(c, v2, M0, LD, 1, v0, d, d);
+            if (single) {
+                w_sync();
+                load_msg<DC>(c, p, lst[0], false, false, d, r, v2, M0);
+                ld = -ld;
+            } else
+                matvec(c, v2, M0, LD, 1, v0, d, d);
             s_vec(c, p.marg, w[W_OUT], d, p.es, r * p.rs_marg, v2);
             s_sym<DC>(c, p.marg, w[W_OUT] + d, d, p.es, r * p.rs_marg, M0);
             if (c.lane == 0) p.marg[(w[W_OUT] + d + d * (d + 1) / 2) * p.es + r * p.rs_marg] = -ld;

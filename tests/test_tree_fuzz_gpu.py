@@ -1,0 +1,62 @@
+"""Replays of the randomized differential campaign (scripts/fuzz_executor.py; tests/fuzz_cases.py holds the case generator): the seeds that found defects in
+round 6, and a short run of fresh ones on every suite run.
+
+  1301, 2084  a `missing` observation behind `*`(:out) / `+`(:out): the zero of the precision form reached a rule that works on moments and was inverted
+              (NOT_POSDEF where the reference drops the message) — now the moment form of "no information" (T_ABSENT_VARIANCE, csrc/tree_kernels.hpp load_msg)
+  3902        the unobserved end of a `*` / `+` chain at d = 48: the marginal of its ONE moment-form message went through the precision and back, and the two
+              sweep inverses squared the condition number of A V Aᵀ in the error (7e-6 sd against the oracle's 4e-10) — now the message itself"""
+import numpy as np
+import pytest
+
+import tree_graphs as tg
+from fuzz_cases import run_case
+
+pytestmark = pytest.mark.gpu
+
+
+def _replay(seed, monkeypatch):
+    monkeypatch.setenv("RXHIP_TEST_HOOKS", "1")
+    monkeypatch.setenv("RXHIP_TREE_MODE", "0")   # (registered with monkeypatch so that what run_case sets is undone)
+    monkeypatch.setenv("RXHIP_TREE_TILE", "0")
+    return run_case(seed)
+
+
+@pytest.mark.parametrize("seed", [1301, 2084, 3902])
+def test_seeds_that_found_defects(seed, monkeypatch):
+    assert _replay(seed, monkeypatch) is None
+
+
+@pytest.mark.parametrize("first", [7000, 7040, 7080])
+def test_forty_fresh_cases(first, monkeypatch):
+    findings = [f for f in (_replay(s, monkeypatch) for s in range(first, first + 40)) if f]
+    assert not findings, findings
+
+
+@pytest.mark.parametrize("d", [4, 12, 24, 48, 64])
+def test_unobserved_end_of_a_deterministic_chain_is_the_forward_message(d, monkeypatch):
+    """x ~ N(m, V), y ~ N(x, Σ) observed, s = A x + c with a square random A, leaf ~ N(s, W⁻¹) never observed: q(s) is the one message that reaches s — exact to
+    the conditioning of ONE pass over A V Aᵀ, not two inversions of it.  Against brute-force conditioning of the joint Gaussian."""
+    from rxhip import _lib
+    from rxhip.tree import TreeEngine
+    rng = np.random.default_rng(d)
+    gb = tg.GraphBuilder()
+    x = gb.randomvar(d)
+    gb.mvnormal_mean_cov(x, gb.constvar(rng.standard_normal(d)), gb.constvar(tg._spd(rng, d, 3.0)))
+    y = gb.datavar(d)
+    gb.mvnormal_mean_cov(y, x, gb.constvar(tg._spd(rng, d, 1.0)))
+    a, s, leaf = gb.randomvar(d), gb.randomvar(d), gb.randomvar(d)
+    gb.multiply(a, gb.constvar(rng.standard_normal((d, d))), x)
+    gb.node(_lib.NODE_ADD, s, a, gb.constvar(rng.standard_normal(d)))
+    gb.node(_lib.NODE_MVNORMAL_MEAN_PRECISION, leaf, s, gb.constvar(np.linalg.inv(tg._spd(rng, d, 1.0))))
+    data = tg.random_data(gb, [y], 2, d)
+    monkeypatch.delenv("RXHIP_TREE_MODE", raising=False)
+    monkeypatch.delenv("RXHIP_TREE_TILE", raising=False)
+    with TreeEngine(gb, n_replicas=2) as eng:
+        eng.set_data([y], data)
+        eng.run(1, True)
+        post = eng.marginals([x, s, leaf])
+    bf, _ = tg.brute_force(gb, tg.data_dict(gb, [y], data[1]))
+    for v in (x, s, leaf):
+        sd = np.sqrt(np.diag(bf[v][1]))
+        assert np.max(np.abs(post[v][0][1] - bf[v][0]) / sd) < 1e-9
+        assert np.max(np.abs(post[v][1][1] - bf[v][1]) / np.outer(sd, sd)) < 1e-9

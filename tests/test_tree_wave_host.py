@@ -156,6 +156,13 @@ def build_program(d, d1, seed):
         for form in (1, 0, 1):
             st.aux += [st.message(d), form]
         st.op(code, d, out=new_msg(d) if code == OP_PRODUCT else st.slot("marg", msz(d) + 1), n=3, list=lst)
+    # the marginal of ONE message: in moment form it is the message itself (no round trip through the precision), in precision form one inverse
+    st.single = []
+    for form in (0, 1):
+        lst = len(st.aux)
+        st.aux += [st.message(d), form]
+        st.op(OP_MARGINAL, d, out=st.slot("marg", msz(d) + 1), n=1, list=lst)
+        st.single.append((st.aux[lst], st.ops[-1][W_OUT], form))
     # second phase
     terms = []
     new_term = lambda: terms.append(st.slot("term", 1)) or terms[-1]
@@ -233,6 +240,19 @@ def test_every_op_matches_the_register_bodies(lib, d, d1):
         err = np.max(np.abs(a - b) / scale)
         assert err < 1e-11 * n, (kind, err)
         assert np.any(a != 0.0) or st.size[kind] == 0, kind
+    # the marginal of one moment-form message is that message, bit for bit; its last word the log-determinant of the covariance
+    msz = lambda k: k + k * (k + 1) // 2
+    for which in (ref, got):
+        for src, out, form in st.single:
+            m, g = which["msg"][src:src + msz(d), :st.R], which["marg"][out:out + msz(d) + 1, :st.R]
+            if form == 0:
+                assert np.array_equal(m, g[:-1])
+            for r in range(st.R):
+                M = np.zeros((d, d))
+                M[np.tril_indices(d)] = (g if form == 0 else m)[d:msz(d), r]
+                M = M + M.T - np.diag(np.diag(M))
+                ld = np.linalg.slogdet(M)[1]
+                assert abs(g[-1, r] - (ld if form == 0 else -ld)) < 1e-9 * n
     # a square map's image: the log-determinant by addition gives the term the Cholesky of the image gives
     for which in (ref, got):
         for a, b in st.same:
