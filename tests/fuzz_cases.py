@@ -9,6 +9,7 @@ import tree_graphs as tg
 import tree_oracle
 from rxhip.tree import TreeEngine
 
+STATS = dict(compared=0, refused=0)
 DIMS = (1, 2, 3, 4, 5, 6, 7, 8, 9, 11, 12, 15, 16, 17, 20, 24, 31, 32, 33, 40, 48, 64)
 
 
@@ -72,20 +73,35 @@ def run_case(seed, detail=False):
                         sb = np.sqrt(np.diag(bf[v][1]))
                         line += f"; vs brute force: executor {np.max(np.abs(post[v][0][r] - bf[v][0]) / sb):.2e} / {np.max(np.abs(post[v][1][r] - bf[v][1]) / np.outer(sb, sb)):.2e}, oracle {np.max(np.abs(ref['mean'][v] - bf[v][0]) / sb):.2e} / {np.max(np.abs(ref['cov'][v] - bf[v][1]) / np.outer(sb, sb)):.2e}; cond {np.linalg.cond(bf[v][1]):.1e}"
                     print(line)
+            # The bar: 1e-7 sd / 1e-8 — loosened where the ORACLE is the limit: it forms every marginal by two inversions, so the image of a state under a nearly
+            # singular map (condition c) carries c·ε there, while the executor pushes the state's marginal through the map (seed 34357: condition 3e9, oracle 3e-7 from
+            # brute-force conditioning, executor 8e-16); its entropy terms lose the same digits (seeds 14828, 32341)
+            # Where the graph allows (no precision variables, nothing missing) brute-force conditioning of the joint Gaussian is a second reference without that
+            # limit: a variable passes if the executor agrees with EITHER at the plain bar.
+            conds = {v: float(np.linalg.cond(ref["cov"][v])) for v in gv}
+            dense = None if prec_vars or miss or kind != "forest" else tg.brute_force(gb, tg.data_dict(gb, ys, data[r]))[0]
             for v in gv:
                 sd = np.sqrt(np.diag(ref["cov"][v]))
                 if np.all(sd < 1e-7):
                     continue
-                worst = max(worst, float(np.max(np.abs(post[v][0][r] - ref["mean"][v]) / sd)), float(np.max(np.abs(post[v][1][r] - ref["cov"][v]) / np.outer(sd, sd))))
+                e = max(float(np.max(np.abs(post[v][0][r] - ref["mean"][v]) / sd)), float(np.max(np.abs(post[v][1][r] - ref["cov"][v]) / np.outer(sd, sd))))
+                if dense is not None and v in dense:
+                    sb = np.sqrt(np.diag(dense[v][1]))
+                    e = min(e, max(float(np.max(np.abs(post[v][0][r] - dense[v][0]) / sb)), float(np.max(np.abs(post[v][1][r] - dense[v][1]) / np.outer(sb, sb)))))
+                else:
+                    e /= max(1.0, 2e-8 * conds[v])
+                worst = max(worst, e)
             ef = abs(fe[r] - ref["fe"][-1]) / max(1.0, abs(ref["fe"][-1])) if np.isfinite(ref["fe"][-1]) else 0.0
+            ef /= max(1.0, 1e-7 * max(conds.values()))
             for w in prec_vars:
                 nu, V = eng.precision(w)
                 worst = max(worst, abs(nu[r] - ref["q_prec"][w][0]) / ref["q_prec"][w][0], float(np.max(np.abs(V[r] - ref["q_prec"][w][1])) / np.max(np.abs(ref["q_prec"][w][1]))))
             if not (worst < 1e-7 and ef < 1e-8):
-                return f"FAIL {tag}: posterior err {worst:.2e}, fe rel {ef:.2e} (kernels {eng.info['kernels']}, dmax {eng.info['dmax']})"
+                return f"FAIL {tag}: posterior err {worst:.2e}, fe rel {ef:.2e}, condition-scaled where the oracle is the only reference (kernels {eng.info['kernels']}, dmax {eng.info['dmax']}, largest condition {max(conds.values()):.1e})"
     except Exception as e:   # a refusal by name is fine; anything else is a finding
         msg = str(e)
         if "status 2" in msg or "UNSUPPORTED" in msg:
+            STATS["refused"] += 1
             return None
         if "not positive definite" in msg and miss:   # the dropped observations left a variable without information: improper in the oracle as well?
             try:
@@ -98,4 +114,101 @@ def run_case(seed, detail=False):
             if improper:
                 return None
         return f"ERROR {tag}: {msg[:200]}"
+    STATS["compared"] += 1
+    return None
+
+
+def _spd(rng, d, s=1.0):
+    a = rng.standard_normal((d, d))
+    return s * (a @ a.T / d + 0.5 * np.eye(d))
+
+
+def run_chain_case(seed):
+    """One random linear Gaussian state-space chain (tests/test_families_vs_executor_gpu.py's construction at random sizes: state dimension 1 … 64, 2 … 400
+    steps, 1 … 70 chains, per-step constants, known and data inputs, `missing` observations) through the pattern-matched engine `rxhip_create` picks and through the
+    node-array executor — two implementations that share no kernel.  None if they agree (1e-7 sd, free energy 1e-8) or the lowering refuses by name."""
+    from rxhip import graph
+    rng = np.random.default_rng(seed)
+    d = int(rng.choice([1, 2, 3, 4, 4, 4, 5, 6, 8, 8, 9, 12, 16, 17, 24, 32, 33, 48, 64]))
+    dy = int(rng.integers(1, d + 1)) if rng.random() < 0.7 else d
+    tmax = 400 if d <= 8 else 100 if d <= 32 else 40
+    T = int(np.exp(rng.uniform(np.log(2), np.log(tmax))))
+    C = int(rng.choice([1, 2, 3, 17, 70])) if d <= 16 else int(rng.choice([1, 2, 5]))
+    ptt = bool(rng.integers(0, 2))
+    per_step = rng.random() < 0.3
+    nm = 3
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    As = [q @ np.diag(rng.uniform(0.4, 0.95, d)) @ q.T * rng.uniform(0.8, 1.0) for _ in range(nm)]
+    Bs = [rng.standard_normal((dy, d)) for _ in range(nm)]
+    Ps = [_spd(rng, d, 0.2) for _ in range(nm)]
+    Qs = [_spd(rng, dy, 1.0) for _ in range(nm)]
+    m0, V0 = rng.standard_normal(d), _spd(rng, d, 3.0)
+    pick = rng.integers(0, nm, size=T + 1)
+    kw = {}
+    if per_step:
+        kw.update(A_of_t=lambda t: As[pick[t]], P_of_t=lambda t: Ps[pick[t]], B_of_t=lambda t: Bs[pick[t]], Q_of_t=lambda t: Qs[pick[t]])
+    if rng.random() < 0.3:
+        cx = rng.standard_normal((T + 1, d))
+        kw.update(c_of_t=lambda t: cx[t], const_first=bool(rng.integers(0, 2)))
+    if rng.random() < 0.3:
+        cy = rng.standard_normal((T + 1, dy))
+        kw.update(d_of_t=lambda t: cy[t])
+    du, k = 0, rng.random()
+    if k < 0.15:
+        du = int(rng.integers(1, 3))
+        kw.update(Bu=rng.standard_normal((d, du)), du=du)
+    elif k < 0.3:
+        du = d
+        kw.update(du=d)
+    pmiss = float(rng.choice([0.0, 0.0, 0.1, 0.4]))
+    out = graph.lgssm_graph(T, As[0], Bs[0], Ps[0], Qs[0], m0, V0, prior_through_transition=ptt, **kw)
+    gb, xs, ys = out[0], out[1], out[2]
+    us = out[3] if du else []
+    y = rng.standard_normal((C, T, dy)) * 2.0
+    if pmiss:
+        y[rng.random((C, T)) < pmiss] = np.nan
+    u = rng.standard_normal((C, len(us), du)) if du else None
+    mode = int(rng.integers(0, 4))
+    os.environ["RXHIP_TREE_MODE"] = str(mode)
+    os.environ.pop("RXHIP_TREE_TILE", None)
+    tag = f"chain seed {seed}: d={d} dy={dy} T={T} C={C} ptt={ptt} per_step={per_step} c={'c_of_t' in kw} d={'d_of_t' in kw} du={du} missing={pmiss} executor mode={mode}"
+    try:
+        eng = graph.create_engine_from_graph(gb.tables(n_replicas=C, allow_missing=pmiss > 0)[0])
+    except Exception as e:
+        if "status 2" in str(e) or "UNSUPPORTED" in str(e):
+            STATS["refused"] += 1
+            return None
+        return f"ERROR {tag}: create: {str(e)[:200]}"
+    try:
+        eng.set_data(y, layout="chain_time")
+        if du:
+            un = np.zeros((C, T, du))
+            un[:, T - len(us):] = u
+            eng.set_inputs(un, layout="chain_time")
+        eng.run(1, True)
+        mean, cov = eng.marginals(layout="chain_time")
+        fe = eng.free_energy_per_chain()
+    except Exception as e:
+        return f"ERROR {tag}: engine: {str(e)[:200]}"
+    finally:
+        eng.close()
+    try:
+        with TreeEngine(gb, n_replicas=C, allow_missing=pmiss > 0) as te:
+            te.set_data(ys, y.reshape(C, T * dy))
+            if du:
+                te.set_data(us, u.reshape(C, len(us) * du))
+            te.run(1, True)
+            post = te.marginals(xs)
+            tfe = te.free_energy_per_replica()
+    except Exception as e:
+        return f"ERROR {tag}: executor: {str(e)[:200]}"
+    tm = np.stack([post[v][0] for v in xs], axis=1)      # [C][T][d]
+    tc = np.stack([post[v][1] for v in xs], axis=1)
+    sd = np.sqrt(np.einsum("ctii->cti", cov))
+    em = float(np.max(np.abs(tm - mean) / sd))
+    ec = float(np.max(np.abs(tc - cov) / (sd[..., :, None] * sd[..., None, :])))
+    ef = float(np.max(np.abs(tfe - fe) / np.maximum(1.0, np.abs(fe))))
+    if not (em < 1e-7 and ec < 1e-7 and ef < 1e-8):
+        return f"FAIL {tag}: mean {em:.2e} cov {ec:.2e} fe {ef:.2e}"
+    STATS["compared"] += 1
     return None
