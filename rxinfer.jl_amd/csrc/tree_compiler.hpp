@@ -1134,6 +1134,7 @@ struct Compiler {
             lm_last = std::max(lm_last, lvm);
             OpRec& r = emit(lvm, OP_MARGINAL, d);
             r.w[W_OUT] = P.marg_off[v];
+            if (g->allow_missing) r.w[W_FLAGS] |= F_MAY_MISS;   // (the op looks for the case "one moment-form message, the others the zero of the precision form")
             r.w[W_LIST] = (int)P.aux.size();
             r.w[W_N] = (int)ins.size();
             for (auto& in : ins) { P.aux.push_back(in.first); P.aux.push_back(in.second); P.bytes_per_sweep += 8ll * msz(d); }

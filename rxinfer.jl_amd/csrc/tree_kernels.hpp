@@ -65,7 +65,7 @@ enum : int {
     F_PUSH_A = 1024,     // Bethe terms: the marginal named by W_VAL (FE_NOISE2M side a) / W_IN0 (FE_NOISE1, FE_ENT) is the IMAGE of the stored one under a constant matrix
     F_PUSH_B = 2048,     // … the marginal named by W_VAL2 (FE_NOISE2M side b)
     F_FOLD_ENT = 4096,   // FE_NOISE2M / FE_NOISE1: W_OUT · H[q(v)] of the variable whose log|V| the op has at hand (side b / the random interface) is part of this term
-    F_MAY_MISS = 16384,  // OP_LEAF / FE_NOISE1 / FE_NOISE0 on a DATA value of a graph created with allow_missing: NaN (`missing`) → no message / no energy term
+    F_MAY_MISS = 16384,  // OP_LEAF / FE_NOISE1 / FE_NOISE0 on a DATA value of a graph created with allow_missing: NaN (`missing`) → no message / no energy term; OP_MARGINAL of such a graph
     F_WEIGHT = 32768,    // OP_LEAF / FE_NOISE0 / FE_NOISE1 / FE_NOISE_MF: a component of a mixture node — message, energy and residual moments × π_k, the double at p.prec[W_LIST];
                          // OP_PREC_UPDATE: the list holds (moments, weight | −1) pairs, ν = ν0 + Σ weights
     F_JOINT_MEAN = 65536,      // OP_FE_NOISE2M: the mean of side a from the node-local joint, P⁻¹(ξ_a + W m_b), not from the variable's marginal — side a is the volatility input of a
@@ -778,8 +778,26 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
         const int* lst = p.aux + w[W_LIST];
         // a marginal of ONE message in moment form IS the message: taken through the precision and back, the two inversions would square the condition
         // number in the error (the unobserved end of a `*` / `+` chain); the inversion below then only supplies log|V|
-        const bool single = op == OP_MARGINAL && n == 1 && lst[1] == 0;
+        bool single = op == OP_MARGINAL && n == 1 && lst[1] == 0;
+        int at = 0;
+        if (op == OP_MARGINAL && (fl & F_MAY_MISS) && !single) {   // … and so is the marginal of one moment-form message and `missing` observations (zeros of the precision form)
+            int n_mv = 0;
+            bool info = false;
+            for (int q = 0; q < n; ++q) {
+                if (lst[2 * q + 1] == 0) {
+                    ++n_mv;
+                    at = q;
+                    continue;
+                }
+                double a[N], B[N][N];
+                load_msg<N, STRAND>(p, lst[2 * q], true, true, d, r, a, B, reg);
+#pragma unroll
+                for (int i = 0; i < N; ++i) info = info || (i < d && B[i][i] != 0.0);
+            }
+            single = n_mv == 1 && !info;
+        }
         for (int q = 0; q < n; ++q) {   // left to right, in factor order (MessagesProductFromLeftToRight)
+            if (single && q != at) continue;
             double a[N], B[N][N];
             ok = load_msg<N, STRAND>(p, lst[2 * q], lst[2 * q + 1] != 0, !single, d, r, a, B, reg) && ok;
 #pragma unroll
@@ -799,7 +817,7 @@ __device__ __forceinline__ void eval_bp(const TreeParams& p, const int* __restri
             ok = spd_inv<N>(L, V, ld) && ok;
             matvec<N>(V, xi, m);
             if (single) {
-                load_msg<N, STRAND>(p, lst[0], false, false, d, r, m, V, reg);
+                load_msg<N, STRAND>(p, lst[2 * at], false, false, d, r, m, V, reg);
                 ld = -ld;
             }
             st_vec<N>(p.marg, w[W_OUT], d, p.RS, r, m);

@@ -625,8 +625,24 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
         zero<NT>(v0);
         const int n = w[W_N];
         const int* lst = E.p.aux + w[W_LIST];
-        const bool single = op == OP_MARGINAL && n == 1 && lst[1] == 0;   // (tree_kernels.hpp: the marginal of one moment-form message is the message)
+        bool single = op == OP_MARGINAL && n == 1 && lst[1] == 0;   // (tree_kernels.hpp: the marginal of one moment-form message is the message)
+        int at = 0;
+        if (op == OP_MARGINAL && (fl & F_MAY_MISS) && !single) {   // (… and of one moment-form message next to `missing` observations)
+            int n_mv = 0;
+            bool info = false;
+            for (int q = 0; q < n; ++q) {
+                if (lst[2 * q + 1] == 0) {
+                    ++n_mv;
+                    at = q;
+                    continue;
+                }
+                const double* b = E.msg(lst[2 * q]);
+                for (int i = threadIdx.x; i < d; i += 64) info = info || b[(long long)(d + i * (i + 1) / 2 + i) * es] != 0.0;
+            }
+            single = n_mv == 1 && !__any(info);
+        }
         for (int q = 0; q < n; ++q) {   // left to right, in factor order
+            if (single && q != at) continue;
             ok = load_msg<NT, ES1>(E, lst[2 * q], lst[2 * q + 1] != 0, !single, d, v1, M1) && ok;
             axpy<NT>(v0, 1.0, v1);
             axpy<NT>(M0, 1.0, M1);
@@ -637,7 +653,7 @@ __device__ __forceinline__ void eval_bp(const Env<NT>& E, const int* __restrict_
             ok = spd_inv<NT>(L, E.s, M0, d, ld) && ok;
             Vec<NT> m = matvec_t<NT>(M0, to_k<NT>(L, v0));
             if (single) {
-                load_msg<NT, ES1>(E, lst[0], false, false, d, m, M0);
+                load_msg<NT, ES1>(E, lst[2 * at], false, false, d, m, M0);
                 ld = -ld;
             }
             double* b = E.marg(w[W_OUT]);

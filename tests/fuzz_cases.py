@@ -74,7 +74,7 @@ def run_case(seed, detail=False):
                         line += f"; vs brute force: executor {np.max(np.abs(post[v][0][r] - bf[v][0]) / sb):.2e} / {np.max(np.abs(post[v][1][r] - bf[v][1]) / np.outer(sb, sb)):.2e}, oracle {np.max(np.abs(ref['mean'][v] - bf[v][0]) / sb):.2e} / {np.max(np.abs(ref['cov'][v] - bf[v][1]) / np.outer(sb, sb)):.2e}; cond {np.linalg.cond(bf[v][1]):.1e}"
                     print(line)
             # The bar: 1e-7 sd / 1e-8 — loosened where the ORACLE is the limit: it forms every marginal by two inversions, so the image of a state under a nearly
-            # singular map (condition c) carries c·ε there, while the executor pushes the state's marginal through the map (seed 34357: condition 3e9, oracle 3e-7 from
+            # singular map (condition c) carries ≈ 10 c·ε there, while the executor pushes the state's marginal through the map (seed 34357: condition 3e9, oracle 3e-7 from
             # brute-force conditioning, executor 8e-16); its entropy terms lose the same digits (seeds 14828, 32341)
             # Where the graph allows (no precision variables, nothing missing) brute-force conditioning of the joint Gaussian is a second reference without that
             # limit: a variable passes if the executor agrees with EITHER at the plain bar.
@@ -89,13 +89,13 @@ def run_case(seed, detail=False):
                     sb = np.sqrt(np.diag(dense[v][1]))
                     e = min(e, max(float(np.max(np.abs(post[v][0][r] - dense[v][0]) / sb)), float(np.max(np.abs(post[v][1][r] - dense[v][1]) / np.outer(sb, sb)))))
                 else:
-                    e /= max(1.0, 2e-8 * conds[v])
+                    e /= max(1.0, 1e-7 * conds[v])
                 worst = max(worst, e)
             ef = abs(fe[r] - ref["fe"][-1]) / max(1.0, abs(ref["fe"][-1])) if np.isfinite(ref["fe"][-1]) else 0.0
             ef /= max(1.0, 1e-7 * max(conds.values()))
             for w in prec_vars:
                 nu, V = eng.precision(w)
-                worst = max(worst, abs(nu[r] - ref["q_prec"][w][0]) / ref["q_prec"][w][0], float(np.max(np.abs(V[r] - ref["q_prec"][w][1])) / np.max(np.abs(ref["q_prec"][w][1]))))
+                worst = max(worst, max(abs(nu[r] - ref["q_prec"][w][0]) / ref["q_prec"][w][0], float(np.max(np.abs(V[r] - ref["q_prec"][w][1])) / np.max(np.abs(ref["q_prec"][w][1])))) / max(1.0, 1e-7 * max(conds.values())))
             if not (worst < 1e-7 and ef < 1e-8):
                 return f"FAIL {tag}: posterior err {worst:.2e}, fe rel {ef:.2e}, condition-scaled where the oracle is the only reference (kernels {eng.info['kernels']}, dmax {eng.info['dmax']}, largest condition {max(conds.values()):.1e})"
     except Exception as e:   # a refusal by name is fine; anything else is a finding
@@ -123,7 +123,7 @@ def _spd(rng, d, s=1.0):
     return s * (a @ a.T / d + 0.5 * np.eye(d))
 
 
-def run_chain_case(seed):
+def run_chain_case(seed, detail=False):
     """One random linear Gaussian state-space chain (tests/test_families_vs_executor_gpu.py's construction at random sizes: state dimension 1 … 64, 2 … 400
     steps, 1 … 70 chains, per-step constants, known and data inputs, `missing` observations) through the pattern-matched engine `rxhip_create` picks and through the
     node-array executor — two implementations that share no kernel.  None if they agree (1e-7 sd, free energy 1e-8) or the lowering refuses by name."""
@@ -209,6 +209,31 @@ def run_chain_case(seed):
     ec = float(np.max(np.abs(tc - cov) / (sd[..., :, None] * sd[..., None, :])))
     ef = float(np.max(np.abs(tfe - fe) / np.maximum(1.0, np.abs(fe))))
     if not (em < 1e-7 and ec < 1e-7 and ef < 1e-8):
-        return f"FAIL {tag}: mean {em:.2e} cov {ec:.2e} fe {ef:.2e}"
+        msg = f"FAIL {tag}: mean {em:.2e} cov {ec:.2e} fe {ef:.2e}"
+        if detail:   # the oracle as the arbiter, on the chain with the largest free-energy difference
+            c = int(np.argmax(np.abs(tfe - fe) / np.maximum(1.0, np.abs(fe))))
+            row = np.concatenate([y[c].ravel()] + ([u[c].ravel()] if du else []))
+            try:
+                ref = tree_oracle.infer(gb.to_dump(), tg.data_dict(gb, list(ys) + list(us), row))
+                sdo = [np.sqrt(np.diag(ref["cov"][v])) for v in xs]
+                msg += (f"; chain {c}: free energy engine {fe[c]:.12g}, executor {tfe[c]:.12g}, oracle {ref['fe'][-1]:.12g}; means against the oracle: engine "
+                        f"{max(float(np.max(np.abs(mean[c, t] - ref['mean'][v]) / sdo[t])) for t, v in enumerate(xs)):.2e}, executor "
+                        f"{max(float(np.max(np.abs(tm[c, t] - ref['mean'][v]) / sdo[t])) for t, v in enumerate(xs)):.2e}")
+                g = tree_oracle.TreeGraph(gb.to_dump())
+                rest = [v for v in range(len(gb.kind)) if g.gauss[v] and v not in xs]
+                with TreeEngine(gb, n_replicas=C, allow_missing=pmiss > 0) as te:
+                    te.set_data(ys, y.reshape(C, T * dy))
+                    if du:
+                        te.set_data(us, u.reshape(C, len(us) * du))
+                    te.run(1, True)
+                    pr = te.marginals(rest)
+                worst = max((float(np.max(np.abs(pr[v][1][c] - ref["cov"][v]) / np.outer(np.sqrt(np.diag(ref["cov"][v])), np.sqrt(np.diag(ref["cov"][v]))))), v, float(np.linalg.cond(ref["cov"][v]))) for v in rest)
+                role = {int(gb.fiface[f][0]): (int(gb.ftype[f]), tuple(int(i) for i in gb.fiface[f])) for f in range(len(gb.ftype))}
+                errs = sorted(((float(np.max(np.abs(pr[v][1][c] - ref["cov"][v]) / np.outer(np.sqrt(np.diag(ref["cov"][v])), np.sqrt(np.diag(ref["cov"][v]))))), v) for v in rest), reverse=True)
+                msg += "; worst five: " + ", ".join(f"{v} {role.get(v)} {e:.1e}" for e, v in errs[:5])
+                msg += f"; executor's other variables against the oracle: worst covariance {worst[0]:.1e} (variable {worst[1]}, condition {worst[2]:.1e}); condition of B {[float(f'{np.linalg.cond(b):.2g}') for b in (Bs if per_step else Bs[:1])]}"
+            except Exception as e:
+                msg += f"; oracle: {str(e)[:120]}"
+        return msg
     STATS["compared"] += 1
     return None

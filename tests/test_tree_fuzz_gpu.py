@@ -4,7 +4,14 @@ round 6, and a short run of fresh ones on every suite run.
   1301, 2084  a `missing` observation behind `*`(:out) / `+`(:out): the zero of the precision form reached a rule that works on moments and was inverted
               (NOT_POSDEF where the reference drops the message) — now the moment form of "no information" (T_ABSENT_VARIANCE, csrc/tree_kernels.hpp load_msg)
   3902        the unobserved end of a `*` / `+` chain at d = 48: the marginal of its ONE moment-form message went through the precision and back, and the two
-              sweep inverses squared the condition number of A V Aᵀ in the error (7e-6 sd against the oracle's 4e-10) — now the message itself"""
+              sweep inverses squared the condition number of A V Aᵀ in the error (7e-6 sd against the oracle's 4e-10) — now the message itself; and the
+              LDS-staged kernels read one triangle of an inverse whose sweep is not symmetric — now the mean of the two
+
+Chain cases (the pattern-matched state-space engines against the executor on the same descriptor, run_chain_case):
+  101839, 119783  `y ~ N(B x + c, Q)` behind a square B of condition 3e5 / 2e4 at d = 48 / 33: the four-pivot MFMA sweep of the LDS-staged kernels lost q(B x + c)
+              (0.3 sd; free energy 1e-3) where the one-pivot sweep is exact to 1e-10 — now guarded by the largest variance inflation a_kk (A⁻¹)_kk, redone one pivot
+              at a time above 1e3 (csrc/tree_wave_kernels.hpp spd_inv_blocked)
+  101987      the same B with `missing` observations: the marginal of one moment-form message next to zeros of the precision form is that message"""
 import numpy as np
 import pytest
 
@@ -24,6 +31,23 @@ def _replay(seed, monkeypatch):
 @pytest.mark.parametrize("seed", [1301, 2084, 3902])
 def test_seeds_that_found_defects(seed, monkeypatch):
     assert _replay(seed, monkeypatch) is None
+
+
+@pytest.mark.parametrize("seed", [101839, 101987, 119783])
+def test_chain_seeds_that_found_defects(seed, monkeypatch):
+    monkeypatch.setenv("RXHIP_TREE_MODE", "0")
+    monkeypatch.setenv("RXHIP_TREE_TILE", "0")
+    from fuzz_cases import run_chain_case
+    assert run_chain_case(seed) is None
+
+
+@pytest.mark.parametrize("first", [9000, 9060])
+def test_sixty_fresh_chain_cases(first, monkeypatch):
+    monkeypatch.setenv("RXHIP_TREE_MODE", "0")
+    monkeypatch.setenv("RXHIP_TREE_TILE", "0")
+    from fuzz_cases import run_chain_case
+    findings = [f for f in (run_chain_case(s) for s in range(first, first + 60)) if f]
+    assert not findings, findings
 
 
 @pytest.mark.parametrize("first", [7000, 7040, 7080])

@@ -22,6 +22,7 @@ OP_FE_NOISE2M, OP_MARG_PUSH, OP_FE_NOISE_MF = 19, 20, 21
 W_OP, W_D0, W_D1, W_OUT, W_IN0, W_IN1, W_IN2, W_FLAGS, W_C0, W_C1, W_VAL, W_VAL2, W_PREC, W_TERM, W_N, W_LIST = range(16)
 F_IN0_WP, F_IN1_WP, F_IN2_WP, F_OUT_WP, F_VAL_SLOT, F_VAL2_SLOT, F_NEG, F_STAT, F_RAND_IS_MU = 1, 2, 4, 8, 16, 32, 64, 128, 256
 F_PUSH_A, F_PUSH_B, F_FOLD_ENT, F_VAL_MARG = 1024, 2048, 4096, 8192
+F_MAY_MISS = 16384
 
 
 @pytest.fixture(scope="module")
@@ -163,6 +164,16 @@ def build_program(d, d1, seed):
         st.aux += [st.message(d), form]
         st.op(OP_MARGINAL, d, out=st.slot("marg", msz(d) + 1), n=1, list=lst)
         st.single.append((st.aux[lst], st.ops[-1][W_OUT], form))
+    # … and next to `missing` observations (zeros of the precision form) in a graph created with allow_missing: still the one moment-form message
+    zero = st.message(d)
+    st.fill["msg"][-1][1][:] = 0.0
+    lst = len(st.aux)
+    st.aux += [zero, 1, st.message(d), 0, zero, 1]
+    st.op(OP_MARGINAL, d, out=st.slot("marg", msz(d) + 1), n=3, list=lst, flags=F_MAY_MISS)
+    st.single.append((st.aux[lst + 2], st.ops[-1][W_OUT], 0))
+    lst = len(st.aux)
+    st.aux += [zero, 1, st.message(d), 0, st.message(d), 1]   # (not the case: a precision-form message with content)
+    st.op(OP_MARGINAL, d, out=st.slot("marg", msz(d) + 1), n=3, list=lst, flags=F_MAY_MISS)
     # second phase
     terms = []
     new_term = lambda: terms.append(st.slot("term", 1)) or terms[-1]
