@@ -24,6 +24,8 @@
 #include "drift_kernels.hpp"
 #include "generic_kernels.hpp"
 #include "engine.hpp"
+#include "graph_lowering.hpp"   // (rxhip_lower::last_error: the thread-local text behind rxhip_lowering_error, for refusals that return no handle)
+#include "model_envelope.hpp"
 
 using namespace rxhip;
 
@@ -1708,6 +1710,14 @@ rxhip_status rxhip_lgssm_set_chain_offsets(rxhip_engine* e, const double* state_
     return rxhip_sync(e);
 }
 
+static std::atomic<int>& conditioning_guard() {
+    static std::atomic<int> on{1};
+    return on;
+}
+rxhip_status rxhip_set_conditioning_guard(int32_t enabled) {
+    conditioning_guard().store(enabled ? 1 : 0);
+    return RXHIP_OK;
+}
 rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) {
     if (!out) return RXHIP_ERR_BADARG;
     *out = nullptr;
@@ -1725,6 +1735,25 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         if (ds->chain_model || ds->horizon < 0) return RXHIP_ERR_BADARG;
         for (long long t = 0; t < ds->T + ds->horizon; ++t)
             if (ds->step_model[t] < 0 || ds->step_model[t] >= ds->n_models) return RXHIP_ERR_BADARG;
+    }
+    if (dense && conditioning_guard().load()) {   // the information-form schedules of d > 4 are validated inside an envelope of model conditioning (model_envelope.hpp)
+        const size_t dd = (size_t)ds->d * ds->d, bd = (size_t)ds->dy * ds->d, qq = (size_t)ds->dy * ds->dy;
+        const double limit = ds->d <= 16 ? envelope::ENVELOPE_ONE_TILE : envelope::ENVELOPE_TILES;
+        for (int m = 0; m < ds->n_models; ++m) {
+            // (per-step models: every model against the prior of the chain; a model that is never the first sees V0 only through this bound)
+            const double k = envelope::kappa(ds->d, ds->dy, ds->A + m * dd, ds->B + m * bd, ds->P + m * dd, ds->Q + m * qq, ds->V0 + (ds->step_model ? 0 : m * dd),
+                                             ds->prior_through_transition != 0);
+            if (std::isfinite(k) && k > limit) {
+                char buf[400];
+                std::snprintf(buf, sizeof buf,
+                              "model %d: conditioning kappa = %.3g of its filtered precisions is beyond %.0e, the envelope the information-form chain schedules of d = %d are "
+                              "validated for (csrc/model_envelope.hpp); the node-array executor holds such models (rxhip_create hands the graph to it; rxhip_set_conditioning_guard(0) "
+                              "switches this check off)",
+                              m, k, limit, ds->d);
+                rxhip_lower::last_error() = buf;
+                return RXHIP_ERR_UNSUPPORTED;
+            }
+        }
     }
     std::string pkey;
     if (engine_pool_key(ds, pkey)) {   // a parked engine of exactly this descriptor: as good as new (engine pool above)

@@ -499,6 +499,8 @@ lgssm_supported(d::Integer, dy::Integer) = ccall((:rxhip_lgssm_supported, librxh
 release_cached_memory() = ccall((:rxhip_release_cached_memory, librxhip), Int32, ()) == 0
 "switch the library's process-wide pools off (`false`: nothing parked, nothing shared between handles) or back on (`rxhip_set_caching`)"
 set_caching!(on::Bool) = ccall((:rxhip_set_caching, librxhip), Int32, (Int32,), on ? 1 : 0) == 0
+"the conditioning envelope of the information-form chain engines (d > 4): `false` switches the check at creation off (`rxhip_set_conditioning_guard`; include/rxhip.h)"
+set_conditioning_guard!(on::Bool) = ccall((:rxhip_set_conditioning_guard, librxhip), Int32, (Int32,), on ? 1 : 0) == 0
 
 "device time (ms) of the kernels that ran once at creation because their results depend on the model only"
 function model_tables_ms(e::Engine)

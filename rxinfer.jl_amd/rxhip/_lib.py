@@ -159,6 +159,7 @@ SYMBOLS = [
     ("rxhip_sync", ctypes.c_int32, [_H]),
     ("rxhip_release_cached_memory", ctypes.c_int32, []),
     ("rxhip_set_caching", ctypes.c_int32, [ctypes.c_int32]),
+    ("rxhip_set_conditioning_guard", ctypes.c_int32, [ctypes.c_int32]),
     ("rxhip_get_marginals", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_int32]),
     ("rxhip_get_predictions", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_int32]),
     ("rxhip_get_node_marginals", ctypes.c_int32, [_H, ctypes.c_int32, c_double_p, c_double_p, ctypes.c_int32]),

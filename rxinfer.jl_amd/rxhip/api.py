@@ -11,6 +11,8 @@ from typing import Any, Optional
 
 import numpy as np
 
+from . import _lib
+from ._lib import RxHipError
 from .engine import DriftChainEngine, GMMEngine, HGFEngine, LGSSMEngine, MvGMMEngine
 
 
@@ -438,6 +440,29 @@ def _infer_lgssm_noise(model, data, iterations, free_energy, options, initializa
             eng.close()
 
 
+def _smooth_on_executor(model, y, iters, free_energy, allow_missing, device):
+    """y [chain][T][dy] through the node-array executor on the graph GraphPPL would build for the model (graph.lgssm_graph): mean [chain][T][d], cov, fe [chain][iters] | None"""
+    from . import graph
+    from .tree import TreeEngine
+    C, T, dy = y.shape
+    so, oo = model.state_offset, model.obs_offset
+    kw = {}
+    if so is not None:
+        so = np.broadcast_to(np.asarray(so, float), (T, model.A.shape[-1]))
+        kw["c_of_t"] = lambda t: so[t]
+    if oo is not None:
+        oo = np.broadcast_to(np.asarray(oo, float), (T, dy))
+        kw["d_of_t"] = lambda t: oo[t]
+    gb, xs, ys = graph.lgssm_graph(T, model.A, model.B, model.P, model.Q, model.prior_mean, model.prior_cov,
+                                   prior_through_transition=model.prior_through_transition, **kw)[:3]
+    with TreeEngine(gb, n_replicas=C, allow_missing=allow_missing, device=device) as te:
+        te.set_data(ys, np.ascontiguousarray(y.reshape(C, T * dy)))
+        te.run(1, bool(free_energy))
+        post = te.marginals(xs)
+        fe = np.repeat(te.free_energy_per_replica()[:, None], iters, axis=1) if free_energy else None
+    return np.stack([post[v][0] for v in xs], axis=1), np.stack([post[v][1] for v in xs], axis=1), fe
+
+
 def infer(*, model, data, iterations=None, free_energy=False, options=None, returnvars=None, predictvars=None,
           catch_exception=False, initialization=None, autoupdates=None, keephistory=None, historyvars=None):
     """Static (batch) inference on the device engine; with `autoupdates` (any truthy value: the state-space spec has
@@ -503,12 +528,25 @@ def infer(*, model, data, iterations=None, free_energy=False, options=None, retu
                 raise ValueError(f"time-varying model has {step_model.shape[0]} steps, the data {T + horizon}")
             M = model.A.shape[0]
             m0, V0 = np.broadcast_to(m0, (M,) + m0.shape[-1:]), np.broadcast_to(V0, (M,) + V0.shape[-2:])
-        eng = LGSSMEngine(model.A, model.B, model.P, model.Q, m0, V0, T=T, n_chains=C,
-                          prior_through_transition=model.prior_through_transition, horizon=horizon,
-                          allow_missing=allow_missing, step_model=step_model,
-                          state_offset=(model.state_offset if model.input_matrix is None else np.zeros(model.A.shape[-1])),
-                          obs_offset=model.obs_offset,
-                          segments=int(options.get("segments", 0)), device=int(options.get("device", -1)))
+        try:
+            eng = LGSSMEngine(model.A, model.B, model.P, model.Q, m0, V0, T=T, n_chains=C,
+                              prior_through_transition=model.prior_through_transition, horizon=horizon,
+                              allow_missing=allow_missing, step_model=step_model,
+                              state_offset=(model.state_offset if model.input_matrix is None else np.zeros(model.A.shape[-1])),
+                              obs_offset=model.obs_offset,
+                              segments=int(options.get("segments", 0)), device=int(options.get("device", -1)))
+        except RxHipError as err:
+            # a model beyond the conditioning envelope of the information-form chain engines (include/rxhip.h rxhip_set_conditioning_guard): the same graph on the
+            # node-array executor, as rxhip_create does for a host that hands over the graph — plain smoothing only (the executor has no forecast / prediction entry)
+            if err.status != _lib.ERR_UNSUPPORTED or "kappa" not in str(err) or horizon or predictvars or step_model is not None or model.input_matrix is not None:
+                raise
+            mean, cov, fe = _smooth_on_executor(model, y, iters, free_energy, allow_missing, int(options.get("device", -1)))
+            if single:
+                mean, cov, fe = mean[0], cov[0], (fe[0] if fe is not None else None)
+            post = {"x": MvNormalMeanCovariance(mean, cov)}
+            if returnvars is not None:
+                post = {k: v for k, v in post.items() if k in returnvars}
+            return InferenceResult(post, None, fe, model, None)
         if model.input_matrix is not None:   # control inputs as data: c[t] = B_u u[t] (+ the constant part) for every chain
             if "u" not in data:
                 raise ValueError("this model has data inputs: data must provide `u`")

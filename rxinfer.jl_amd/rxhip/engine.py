@@ -72,7 +72,7 @@ class LGSSMEngine:
         self._h = ctypes.c_void_p()
         st = self._create(L, desc)
         if st != _lib.OK:
-            msg = L.rxhip_last_error(self._h).decode() if self._h else L.rxhip_status_string(st).decode()
+            msg = L.rxhip_last_error(self._h).decode() if self._h else (L.rxhip_lowering_error().decode() if st == _lib.ERR_UNSUPPORTED else "") or L.rxhip_status_string(st).decode()
             if self._h:
                 L.rxhip_destroy(self._h)
                 self._h = None

@@ -504,6 +504,11 @@ def create_engine_from_graph(g, segments=0, device=-1, stream=None):
         if h:
             L.rxhip_destroy(h)
         raise RxHipError(st, msg or L.rxhip_status_string(st).decode())
+    info = _lib.TreeInfo()
+    if L.rxhip_tree_get_info(h, ctypes.byref(info)) == _lib.OK:   # rxhip_create handed the graph to the node-array executor (e.g. a chain beyond the conditioning
+        why = L.rxhip_lowering_error().decode()                   # envelope of the information-form engines): that handle answers to rxhip_tree_*, not to this wrapper
+        L.rxhip_destroy(h)
+        raise RxHipError(_lib.ERR_UNSUPPORTED, "no pattern-matched engine took this graph (rxhip.tree.TreeEngine(gb, force_executor=False) runs it on the executor)" + (": " + why if why else ""))
     low = lower_lgssm(g)
     if low["deterministic"]:
         from .engine import DriftChainEngine

@@ -245,3 +245,69 @@ def run_chain_case(seed, detail=False):
         return msg
     STATS["compared"] += 1
     return None
+
+
+def run_engine_case(seed):
+    """One random case for the state-space engines' own entry points (`LGSSMEngine`: the path the headline benchmark runs): dimensions 1 … 64, 1 … 600 steps, 1 … 130
+    chains, a random number of segments for the parallel-in-time sweep (or the library's choice), either prior placement, `missing` rows, noise scales over four decades
+    — smoothing against the oracle's Kalman / RTS restatement (rxo_lgssm_kalman_rts: posteriors, −log evidence), filtering against rxo_lgssm_filter, `filter_step`
+    against `run_filter`, on up to three chains of the batch.  None or the finding."""
+    import rxhip
+    import rxoracle
+    from rxhip import workloads
+    rng = np.random.default_rng(seed)
+    small = rng.random() < 0.6
+    d = int(rng.choice([1, 2, 3, 4])) if small else int(rng.choice([5, 6, 8, 9, 12, 16, 17, 24, 32, 33, 48, 64]))
+    dy = int(rng.integers(1, d + 1)) if rng.random() < 0.6 else d
+    tmax = 600 if d <= 4 else 150 if d <= 16 else 50
+    T = int(np.exp(rng.uniform(0.0, np.log(tmax))))
+    C = int(rng.choice([1, 2, 3, 64, 70, 128, 130])) if d <= 4 else int(rng.choice([1, 2, 3, 5, 9]))
+    segments = 0 if rng.random() < 0.4 else int(rng.integers(1, T + 1))
+    ptt = bool(rng.integers(0, 2))
+    pmiss = float(rng.choice([0.0, 0.0, 0.1, 0.5]))
+    mdl = workloads.random_model(d, dy, seed, stable=float(rng.uniform(0.3, 0.99)))
+    mdl["P"] = mdl["P"] * 10.0 ** rng.uniform(-2, 1)
+    mdl["Q"] = mdl["Q"] * 10.0 ** rng.uniform(-2, 1)
+    mdl["V0"] = mdl["V0"] * 10.0 ** rng.uniform(-1, 3)
+    y = workloads.generate_batch(mdl, T, C, seed0=seed, threads=1)
+    if pmiss:
+        y[rng.random((T, C)) < pmiss] = np.nan
+    tag = f"engine seed {seed}: d={d} dy={dy} T={T} C={C} segments={segments} ptt={ptt} missing={pmiss}"
+    args = (mdl["A"], mdl["B"], mdl["P"], mdl["Q"], mdl["m0"], mdl["V0"])
+    chains = sorted(set(int(c) for c in rng.integers(0, C, size=3)))
+    try:
+        with rxhip.LGSSMEngine(*args, T=T, n_chains=C, prior_through_transition=ptt, segments=segments, allow_missing=pmiss > 0) as eng:
+            eng.set_data(y)
+            eng.run(1, True)
+            mean, cov = eng.marginals()
+            fe = eng.free_energy_per_chain()
+            filt = None
+            if not pmiss:
+                eng.run_filter(free_energy=True)
+                fm, fc = eng.marginals()
+                ffe = eng.free_energy_per_chain()
+                filt = (fm, fc, ffe)
+    except Exception as e:
+        if "status 2" in str(e) or "UNSUPPORTED" in str(e):
+            STATS["refused"] += 1
+            return None
+        return f"ERROR {tag}: {str(e)[:200]}"
+    worst = 0.0
+    for c in chains:
+        om, oc, onll = rxoracle.lgssm_kalman_rts(*args, y[:, c], prior_through_transition=ptt)
+        sd = np.sqrt(np.einsum("tii->ti", oc))
+        e = max(float(np.max(np.abs(mean[:, c] - om) / sd)), float(np.max(np.abs(cov[:, c] - oc) / (sd[:, :, None] * sd[:, None, :]))))
+        ef = abs(fe[c] - onll) / max(1.0, abs(onll))
+        if not (e < 1e-6 and ef < 1e-8):   # (the contract's bars: the models' noise scales span four decades)
+            return f"FAIL {tag}: chain {c} smoothing: posterior {e:.2e} sd, free energy {ef:.2e} ({fe[c]:.12g} vs {onll:.12g})"
+        worst = max(worst, e)
+        if filt is not None:
+            fm, fc, ffe = filt
+            om, oc, ofe, _ = rxoracle.lgssm_filter(*args, y[:, c], ptt)
+            sd = np.sqrt(np.einsum("tii->ti", oc))
+            e = max(float(np.max(np.abs(fm[:, c] - om) / sd)), float(np.max(np.abs(fc[:, c] - oc) / (sd[:, :, None] * sd[:, None, :]))))
+            ef = abs(ffe[c] - ofe) / max(1.0, abs(ofe))
+            if not (e < 1e-6 and ef < 1e-8):
+                return f"FAIL {tag}: chain {c} filtering: posterior {e:.2e} sd, free energy {ef:.2e} ({ffe[c]:.12g} vs {ofe:.12g})"
+    STATS["compared"] += 1
+    return None

@@ -50,6 +50,21 @@ def test_sixty_fresh_chain_cases(first, monkeypatch):
     assert not findings, findings
 
 
+@pytest.mark.parametrize("seed", [2592, 2851, 2881, 2962, 21574])
+def test_engine_seeds_that_found_the_conditioning_defect(seed):
+    """run_engine_case: models on which the information-form MFMA path was wrong by 0.04 … 2.7 sd (smoothing; 2962, 21574: filtering) — refused at creation now
+    (csrc/model_envelope.hpp), which the case counts as a refusal by name"""
+    from fuzz_cases import run_engine_case
+    assert run_engine_case(seed) is None
+
+
+@pytest.mark.parametrize("first", [11000, 11100])
+def test_a_hundred_fresh_engine_cases(first):
+    from fuzz_cases import run_engine_case
+    findings = [f for f in (run_engine_case(s) for s in range(first, first + 100)) if f]
+    assert not findings, findings
+
+
 @pytest.mark.parametrize("first", [7000, 7040, 7080])
 def test_forty_fresh_cases(first, monkeypatch):
     findings = [f for f in (_replay(s, monkeypatch) for s in range(first, first + 40)) if f]
