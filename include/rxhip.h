@@ -838,7 +838,9 @@ rxhip_status rxhip_set_caching(int32_t enabled);
  * handle (text: rxhip_lowering_error()), and rxhip_create runs the same graph on the node-array executor instead, which holds 1e-10 on such models
  * (csrc/model_envelope.hpp; measured: scripts/calib_dense_envelope.py, profiles/r06/dense_envelope.txt — up to 19 posterior standard deviations wrong at
  * kappa = 3e5 without the check).  enabled = 0 switches the check off for the process (a host that knows its models, measurements); 1 (the default) restores it.
- * The reference has no counterpart: its rules run in covariance form one message at a time. */
+ * The reference has no counterpart: its rules run in covariance form one message at a time.  Engines of d <= 4 carry no check (a long chain has no second home);
+ * their measured envelope: filtering within the contract up to kappa = 1e7, smoothing while lambda_max(Q^-1 (B V0p B' + Q)) <= 1e5 and kappa <= 1e6
+ * (profiles/r06/dense_envelope.txt). */
 rxhip_status rxhip_set_conditioning_guard(int32_t enabled);
 
 #ifdef __cplusplus

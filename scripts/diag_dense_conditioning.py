@@ -14,9 +14,9 @@ import rxhip  # noqa: E402
 import rxoracle  # noqa: E402
 from rxhip import workloads  # noqa: E402
 
-T, C = 20, 2
-for d in (8, 16, 32, 64):
-    for dy in (d // 2, d):
+T, C = 200, 2
+for d in (int(a) for a in sys.argv[1:]) if len(sys.argv) > 1 else (8, 16, 32, 64):
+    for dy in (max(1, d // 2), d):
         for v in (1e0, 1e2, 1e4, 1e6, 1e8):
             for q in (1e-2, 1.0):
                 mdl = workloads.random_model(d, dy, seed=d + dy)
