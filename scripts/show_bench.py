@@ -1,10 +1,14 @@
 """One screen of a bench.py JSON line: the headline, every BASELINE config, first-touch times, parity spots."""
 import json, sys
 p = json.load(open(sys.argv[1]))
-e = p["extra"]
+e = p.get("extra") or {}
 cb = p.get("cpu_baseline") or {}
 print("headline ms", round(p["ms_per_step"], 4), "value", f"{p['value']:.4g}", "frac", round(p["roofline"]["frac"], 4), "traffic_stale", p["roofline"].get("traffic_stale"),
       "parity", (p.get("parity_spot") or {}).get("ok"), "cpu 1-core", f"{cb.get('value', 0):.3g}", "all-cores x", round(cb.get("all_cores", {}).get("value", 0) / max(cb.get("value", 1), 1), 1))
+if "roofline_per_chain_models" not in p:   # the compact line bench.py prints (the long form: bench.py --detail <file>): [ms, roofline fraction, parity] per configuration
+    for k, v in (p["roofline"].get("per_config") or {}).items():
+        print(f"  {k:32s} ms {v[0]:9.4f}  frac {v[1]}  parity {v[2]}")
+    sys.exit(0)
 r = p["roofline_per_chain_models"]
 print("per-chain models ms", round(r["ms_per_step"], 3), "sweep_frac", round(r["sweep_frac"], 3), "| c2_missing ms", round(e["c2_missing"]["ms_per_step"], 3), e["c2_missing"]["parity_spot"]["ok"])
 c3 = e["c3"]
