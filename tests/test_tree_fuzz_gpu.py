@@ -65,6 +65,14 @@ def test_a_hundred_fresh_engine_cases(first):
     assert not findings, findings
 
 
+def test_two_hundred_fresh_cases_of_the_variational_engines():
+    """run_vmp_case: univariate / multivariate mixtures and the hierarchical Gaussian filter at random sizes, priors and iteration counts against the oracle's
+    restatements, every iteration (20 000 cases on the GPU without a finding, profiles/r06/fuzz_campaign.txt)"""
+    from fuzz_cases import run_vmp_case
+    findings = [f for f in (run_vmp_case(s) for s in range(50000, 50200)) if f]
+    assert not findings, findings
+
+
 @pytest.mark.parametrize("first", [7000, 7040, 7080])
 def test_forty_fresh_cases(first, monkeypatch):
     findings = [f for f in (_replay(s, monkeypatch) for s in range(first, first + 40)) if f]
