@@ -65,6 +65,14 @@ def test_a_hundred_fresh_engine_cases(first):
     assert not findings, findings
 
 
+def test_two_hundred_fresh_cases_of_the_engine_options():
+    """run_option_case: known inputs per engine and per chain, per-step constants, forecast horizons with predictions, node-local joints, per-chain models, the step-wise
+    filter, rxhip_lgssm_infer, the unknown-noise chain — against the oracle's restatements and, for partly observed states, a covariance-form numpy smoother"""
+    from fuzz_cases import run_option_case
+    findings = [f for f in (run_option_case(s) for s in range(60000, 60200)) if f]
+    assert not findings, findings
+
+
 def test_two_hundred_fresh_cases_of_the_variational_engines():
     """run_vmp_case: univariate / multivariate mixtures and the hierarchical Gaussian filter at random sizes, priors and iteration counts against the oracle's
     restatements, every iteration (20 000 cases on the GPU without a finding, profiles/r06/fuzz_campaign.txt)"""
