@@ -834,7 +834,7 @@ rxhip_status rxhip_release_cached_memory(void);
 rxhip_status rxhip_set_caching(int32_t enabled);
 /* The state-space engines of d > 4 carry filtered PRECISIONS (information form, parallel in time) and are validated inside an envelope of model conditioning:
  * kappa = max(cond(V0p^-1 + B'Q^-1 B), cond((1 - rho^2) P^-1 + B'Q^-1 B)), rho the spectral radius of A, V0p the prior of the first observed state, cond of the matrix scaled to unit diagonal (units of the state do not count) — a vague prior or a slowly
- * forgetting transition in directions the observations do not see.  Beyond 1e4 (d <= 16) / 1.5e3 (d > 16) rxhip_lgssm_create returns RXHIP_ERR_UNSUPPORTED with NO
+ * forgetting transition in directions the observations do not see.  Beyond 2e3 (d <= 16) / 1e3 (d > 16) rxhip_lgssm_create returns RXHIP_ERR_UNSUPPORTED with NO
  * handle (text: rxhip_lowering_error()), and rxhip_create runs the same graph on the node-array executor instead, which holds 1e-10 on such models
  * (csrc/model_envelope.hpp; measured: scripts/calib_dense_envelope.py, profiles/r06/dense_envelope.txt — up to 19 posterior standard deviations wrong at
  * kappa = 3e5 without the check).  enabled = 0 switches the check off for the process (a host that knows its models, measurements); 1 (the default) restores it.

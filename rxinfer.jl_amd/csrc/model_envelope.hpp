@@ -7,7 +7,8 @@
 // (the first filtered precision; the filtered precision a long chain drifts to where nothing is observed: P / (1 − ρ²) is what the transition lets the
 // variance grow to) separates the models on which posteriors stay within 1e-6 sd / free energies within 1e-8 from those on which they do not:
 // smoothing above one 16×16 tile (d > 16): every failure has κ > 10⁴ (up to 19 sd wrong at κ = 3·10⁵); at d ≤ 16: κ > 3·10⁵; filtering (rxhip_run_filter) is the
-// more delicate of the two: its failures start at κ ≈ 2·10³ (d > 16) and 3·10⁴ (d ≤ 16).  The limits below leave a factor of 1.5 … 3 to the lowest failure seen;
+// more delicate of the two, most of all for a barely observed state (dy = 1 … 3): its failures start at κ = 1.75·10³ (d > 16; 4·10⁻⁵ sd) and 2.4·10³ (d ≤ 16; 7·10⁻⁷ sd,
+// 0.08 sd at 7·10³ — the error grows by 30× per step inside the first segment and is gone behind its end).  The limits below sit under the lowest failure seen;
 // the benchmark models sit at κ = 1.6 (C3) and the random models of the test suite at κ ≤ 700.
 // rxhip_lgssm_create refuses beyond ENVELOPE_* with RXHIP_ERR_UNSUPPORTED and no handle — which rxhip_create (the graph entry point) answers by handing the same
 // graph to the node-array executor, whose symmetric one-pivot sweeps hold 1e-10 on these models — unless rxhip_set_conditioning_guard(0) was called.
@@ -18,8 +19,8 @@
 namespace rxhip {
 namespace envelope {
 
-constexpr double ENVELOPE_ONE_TILE = 1.0e4;   // d ≤ 16
-constexpr double ENVELOPE_TILES = 1.5e3;      // d > 16
+constexpr double ENVELOPE_ONE_TILE = 2.0e3;   // d ≤ 16
+constexpr double ENVELOPE_TILES = 1.0e3;      // d > 16
 
 // lower Cholesky factor in place (row-major n×n; the upper triangle is left alone); false: not positive definite
 inline bool cholesky(std::vector<double>& a, int n) {

