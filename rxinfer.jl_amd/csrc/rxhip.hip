@@ -1741,7 +1741,7 @@ rxhip_status rxhip_lgssm_create(const rxhip_lgssm_desc* ds, rxhip_engine** out) 
         const double limit = ds->d <= 16 ? envelope::ENVELOPE_ONE_TILE : envelope::ENVELOPE_TILES;
         for (int m = 0; m < ds->n_models; ++m) {
             // (per-step models: every model against the prior of the chain; a model that is never the first sees V0 only through this bound)
-            const double k = envelope::kappa(ds->d, ds->dy, ds->A + m * dd, ds->B + m * bd, ds->P + m * dd, ds->Q + m * qq, ds->V0 + (ds->step_model ? 0 : m * dd),
+            const double k = envelope::kappa(ds->d, ds->dy, ds->A + m * dd, ds->B + m * bd, ds->P + m * dd, ds->Q + m * qq, ds->V0 + (ds->step_model ? (size_t)ds->step_model[0] * dd : m * dd),
                                              ds->prior_through_transition != 0);
             if (std::isfinite(k) && k > limit) {
                 char buf[400];
