@@ -20,5 +20,5 @@ for seed in range(s0, s0 + n):
     if finding:
         bad += 1
         print(finding, flush=True)
-print(f"{n} cases from seed {s0}: {bad} failures ({STATS['compared']} compared, {STATS['refused']} refused by name, the rest improper)")
+print(f"{n} cases from seed {s0}: {bad} failures ({STATS['compared']} compared, {STATS['refused']} refused by name{', of them ' + str(STATS['detour']) + ' verified on the executor detour' if STATS.get('detour') else ''}, the rest improper)")
 sys.exit(1 if bad else 0)
